@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.json from the REFERENCE's own compiled objects.
+
+Run in the build container (needs /root/reference):  python tests/golden/make_golden.py
+Each entry is sha1(output buffers) of one checkasm-style case of tests/cases_*.py
+executed through oracle/_ref/libref.so, i.e. produced by the reference C code
+itself.  The oracle (and through it the MI355X backend) must reproduce them.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import providers  # noqa: E402
+
+
+def digest(results):
+    return {k: hashlib.sha1(v).hexdigest()[:20] for k, v in results.items()}
+
+
+def main():
+    ref = providers.ref()
+    assert ref is not None, "needs /root/reference"
+    import cases_h264
+    out = {"seed": 0x264, "cases": digest(cases_h264.run_all(ref, 0x264))}
+    with open(os.path.join(HERE, "h264dsp_ref_sha1.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("h264dsp:", len(out["cases"]), "cases")
+    try:
+        import cases_hevc
+        out = {"seed": 0x265, "cases": digest(cases_hevc.run_all(ref, 0x265))}
+        with open(os.path.join(HERE, "hevcdsp_ref_sha1.json"), "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+        print("hevcdsp:", len(out["cases"]), "cases")
+    except ImportError:
+        pass
+    # struct layout of the pointer tables as the reference headers define them
+    import ctypes as C
+    buf = C.create_string_buffer(8192)
+    ref.lib.ref_layout.restype = C.c_int
+    n = ref.lib.ref_layout(buf, 8192)
+    layout = dict(line.split("=") for line in buf.raw[:n].decode().split("\n") if line)
+    with open(os.path.join(HERE, "abi_layout_ref.json"), "w") as f:
+        json.dump({k: int(v) for k, v in layout.items()}, f, indent=0, sort_keys=True)
+    print("layout:", len(layout), "entries")
+
+
+if __name__ == "__main__":
+    main()
