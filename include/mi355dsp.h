@@ -1,0 +1,54 @@
+/*
+ * mi355dsp.h — C ABI of libmi355dsp.so, the MI355X (gfx950) backend for libav's
+ * H.264 / HEVC DSP pointer tables and libswscale's inner loops.
+ *
+ * Plain C: pointers and sizes only.  Two tiers behind one library:
+ *
+ *  Tier 1 — `ff_<table>_init_mi355x()`: per-architecture init hooks in the style of
+ *    the reference's ff_h264dsp_init_x86() (libavcodec/x86/h264dsp_init.c), called
+ *    right after the C defaults are filled (libavcodec/h264dsp.c:139-142 is where the
+ *    reference calls its arch hooks).  They overwrite the table entries this backend
+ *    implements with functions of IDENTICAL signature and semantics that run the
+ *    work on the GPU synchronously (host pointers in, host pointers out).  This is
+ *    the function-pointer surface the reference's decoder already calls; it is the
+ *    parity surface, not the fast path (one launch per call).
+ *
+ *  Tier 2 — `mi355_h264_*` batched frame reconstruction on device-resident data
+ *    (declared in mi355_h264_frame.h): the throughput path.
+ *
+ * There is NO CPU fallback: every entry point aborts with a message if no gfx950
+ * device was initialised with mi355_init().
+ */
+#ifndef MI355DSP_H
+#define MI355DSP_H
+
+#include "mi355_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Select and initialise GPU `device` (0-based).  0 on success, <0 if there is no such
+ * device or it is not gfx950. */
+int mi355_init(int device);
+int mi355_device_cus(void);
+
+/* replaces ff_h264dsp_init_{x86,arm,...}   libavcodec/h264dsp.h:119-128, call site h264dsp.c:139-142 */
+void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int chroma_format_idc);
+/* replaces ff_h264qpel_init_{x86,...}      libavcodec/h264qpel.h:34-37, call site h264qpel.c:102-109 */
+void ff_h264qpel_init_mi355x(H264QpelContext *c, int bit_depth);
+/* replaces ff_h264chroma_init_{x86,...}    libavcodec/h264chroma.h:36-39, call site h264chroma.c:47-54 */
+void ff_h264chroma_init_mi355x(H264ChromaContext *c, int bit_depth);
+/* replaces ff_h264_pred_init_{x86,...}     libavcodec/h264pred.h:116-121, call site h264pred.c:573-578 */
+void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc);
+/* replaces ff_videodsp_init_{x86,...}      libavcodec/videodsp.h:68-72, call site videodsp.c:42-49 */
+void ff_videodsp_init_mi355x(VideoDSPContext *ctx, int bpc);
+/* replaces ff_hevc_dsp_init_{x86,arm}      libavcodec/hevcdsp.h:118-119, call site hevcdsp.c:248-253 */
+void ff_hevc_dsp_init_mi355x(HEVCDSPContext *c, const int bit_depth);
+/* replaces the tail of ff_hevc_pred_init   libavcodec/hevcpred.c:37-73 (no arch hook exists in the reference) */
+void ff_hevc_pred_init_mi355x(HEVCPredContext *hpc, int bit_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DSP_H */

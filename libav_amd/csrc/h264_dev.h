@@ -1,0 +1,531 @@
+/*
+ * h264_dev.h — wave-cooperative H.264 reconstruction / deblocking building blocks.
+ *
+ * Execution model used by every kernel in this library: ONE 64-lane wavefront per
+ * workgroup, one macroblock (or one DSP call) per wavefront, all staging in that
+ * wave's own LDS.  `__syncthreads()` therefore only orders this wave's LDS
+ * traffic (with __launch_bounds__(64) the compiler drops the s_barrier).  Every
+ * function here must be called by all 64 lanes with wave-uniform arguments unless
+ * it is marked "per lane".
+ *
+ * Arithmetic follows SURVEY.md §8(a) rows a1-a10 (reference file:line quoted at
+ * each function); results are bit-exact with the reference C path.
+ */
+#ifndef MI355_H264_DEV_H
+#define MI355_H264_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mi355 {
+
+__device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+/* A picture plane in HBM; reads outside [0,w)x[0,h) replicate the border, which is
+ * exactly what the reference's emulated_edge_mc produces (videodsp_template.c:24-96,
+ * callers h264_mb.c:239-314). */
+struct PlaneRef {
+    const uint8_t *base;
+    int stride, w, h;
+};
+__device__ __forceinline__ int px_clamped(const PlaneRef &p, int x, int y)
+{
+    x = clip3(x, 0, p.w - 1);
+    y = clip3(y, 0, p.h - 1);
+    return p.base[(size_t)y * p.stride + x];
+}
+
+/* ---- per-wave LDS scratch -------------------------------------------------- */
+constexpr int WIN_PITCH = 24;           /* 21 columns used */
+struct McScratch {
+    uint8_t win[21 * WIN_PITCH];        /* staged reference window, up to 21x21 */
+    int16_t tmp[21 * 16];               /* unclipped horizontal 6-tap sums for the centre position */
+};
+
+/* ---- a5: quarter-pel luma MC (h264qpel_template.c:77-531) -------------------
+ * Block bw x bh whose integer-sample origin in the reference plane is (ix,iy),
+ * fraction (mx,my) in quarter samples.  Result goes to pred[(py+y)*ppitch + px+x]
+ * (LDS), either stored (avg=0) or rounded-averaged with what is there (avg=1:
+ * the reference's avg_ tables / second list of a bi-predicted block). */
+__device__ inline void mc_luma(McScratch &s, const PlaneRef &ref, int ix, int iy, int mx, int my,
+                               int bw, int bh, uint8_t *pred, int ppitch, int px, int py, int avg)
+{
+    const int lane = lane_id();
+    const int ww = bw + 5, wh = bh + 5;
+    for (int i = lane; i < ww * wh; i += 64) {
+        int y = i / ww, x = i - y * ww;
+        s.win[y * WIN_PITCH + x] = (uint8_t)px_clamped(ref, ix - 2 + x, iy - 2 + y);
+    }
+    __syncthreads();
+    const bool use_j = (mx == 2 && my != 0) || (my == 2 && mx != 0);
+    const bool use_b = mx != 0 && my != 2;
+    const bool use_h = my != 0 && mx != 2;
+    const bool use_g = (mx == 0 || my == 0) && ((mx | my) != 2);
+    const int bdy = my == 3, hdx = mx == 3;
+    const int gdx = (my == 0 && mx == 3), gdy = (mx == 0 && my == 3);
+    const int lw = bw == 16 ? 4 : (bw == 8 ? 3 : (bw == 4 ? 2 : 1));
+    if (use_j) {
+        for (int i = lane; i < wh * bw; i += 64) {
+            int y = i >> lw, x = i & (bw - 1);
+            const uint8_t *r = &s.win[y * WIN_PITCH + x];
+            s.tmp[y * 16 + x] = (int16_t)tap6(r[0], r[1], r[2], r[3], r[4], r[5]);
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < bw * bh; i += 64) {
+        int y = i >> lw, x = i & (bw - 1);
+        const uint8_t *c = &s.win[(y + 2) * WIN_PITCH + x + 2];
+        int sum = 0, n = 0;
+        if (use_g) { sum += c[gdy * WIN_PITCH + gdx]; n++; }
+        if (use_b) {
+            int hs;
+            if (use_j) hs = s.tmp[(y + 2 + bdy) * 16 + x];
+            else { const uint8_t *r = c + bdy * WIN_PITCH; hs = tap6(r[-2], r[-1], r[0], r[1], r[2], r[3]); }
+            sum += clip_u8((hs + 16) >> 5); n++;
+        }
+        if (use_h) {
+            const uint8_t *r = c + hdx;
+            int vs = tap6(r[-2 * WIN_PITCH], r[-WIN_PITCH], r[0], r[WIN_PITCH], r[2 * WIN_PITCH], r[3 * WIN_PITCH]);
+            sum += clip_u8((vs + 16) >> 5); n++;
+        }
+        if (use_j) {
+            const int16_t *t = &s.tmp[y * 16 + x];
+            int js = tap6(t[0], t[16], t[32], t[48], t[64], t[80]);
+            sum += clip_u8((js + 512) >> 10); n++;
+        }
+        int v = n == 2 ? (sum + 1) >> 1 : sum;
+        uint8_t *d = &pred[(py + y) * ppitch + px + x];
+        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+    }
+    __syncthreads();
+}
+
+/* ---- a6: 1/8-pel bilinear chroma MC (h264chroma_template.c:27-173) ---------- */
+__device__ inline void mc_chroma(McScratch &s, const PlaneRef &ref, int cx, int cy, int fx, int fy,
+                                 int bw, int bh, uint8_t *pred, int ppitch, int px, int py, int avg)
+{
+    const int lane = lane_id();
+    const int ww = bw + 1, wh = bh + 1;
+    for (int i = lane; i < ww * wh; i += 64) {
+        int y = i / ww, x = i - y * ww;
+        s.win[y * WIN_PITCH + x] = (uint8_t)px_clamped(ref, cx + x, cy + y);
+    }
+    __syncthreads();
+    const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
+    const int lw = bw == 8 ? 3 : (bw == 4 ? 2 : 1);
+    for (int i = lane; i < bw * bh; i += 64) {
+        int y = i >> lw, x = i & (bw - 1);
+        const uint8_t *c = &s.win[y * WIN_PITCH + x];
+        int v = (A * c[0] + B * c[1] + C * c[WIN_PITCH] + D * c[WIN_PITCH + 1] + 32) >> 6;
+        uint8_t *d = &pred[(py + y) * ppitch + px + x];
+        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+    }
+    __syncthreads();
+}
+
+/* ---- a7: explicit / implicit weighted prediction (h264dsp_template.c:30-98) -- */
+__device__ inline void weight_block(uint8_t *p, int pitch, int bw, int bh, int log2_denom, int w, int o)
+{
+    o = (int)((unsigned)o << log2_denom);
+    if (log2_denom) o += 1 << (log2_denom - 1);
+    for (int i = lane_id(); i < bw * bh; i += 64) {
+        int y = i / bw, x = i - y * bw;
+        uint8_t *d = &p[y * pitch + x];
+        *d = (uint8_t)clip_u8((*d * w + o) >> log2_denom);
+    }
+    __syncthreads();
+}
+__device__ inline void biweight_block(uint8_t *dst, const uint8_t *src, int pitch, int bw, int bh,
+                                      int log2_denom, int wd, int ws, int o)
+{
+    o = (int)((unsigned)((o + 1) | 1) << log2_denom);
+    for (int i = lane_id(); i < bw * bh; i += 64) {
+        int y = i / bw, x = i - y * bw;
+        uint8_t *d = &dst[y * pitch + x];
+        *d = (uint8_t)clip_u8((src[y * pitch + x] * ws + *d * wd + o) >> (log2_denom + 1));
+    }
+    __syncthreads();
+}
+
+/* ---- a1: 4x4 inverse transform, 4 lanes per block (h264idct_template.c:33-67) -
+ * Lane q = lane&3 holds storage row q of the (transposed) coefficient block:
+ * c[i] = block[4q+i].  The vertical butterflies of the first pass run across the
+ * four lanes with two xor-shuffles; intermediates are truncated to int16 exactly
+ * as the reference's in-place int16 block does.  On return lane q holds the four
+ * residuals (already >>6) of destination column `col`, rows 0..3.  Per lane, but
+ * all lanes of the quad must execute it together. */
+__device__ __forceinline__ void idct4_quad(const int c[4], int q, int r[4], int &col)
+{
+    int t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int v = c[i];
+        if (i == 0 && q == 0) v = (int16_t)(v + 32);
+        int p = __shfl_xor(v, 2);
+        int s = q == 0 ? v + p : (q == 2 ? p - v : (q == 1 ? v + (p >> 1) : (p >> 1) - v));
+        int o = __shfl_xor(s, 1);
+        t[i] = (int16_t)((q & 1) ? o - s : s + o);
+    }
+    /* lane q now owns intermediate row k' = {0,3,1,2}[q] == destination column */
+    col = q == 0 ? 0 : (q == 1 ? 3 : (q == 2 ? 1 : 2));
+    int e0 = t[0] + t[2], e1 = t[0] - t[2], e2 = (t[1] >> 1) - t[3], e3 = t[1] + (t[3] >> 1);
+    r[0] = (e0 + e3) >> 6;
+    r[1] = (e1 + e2) >> 6;
+    r[2] = (e1 - e2) >> 6;
+    r[3] = (e0 - e3) >> 6;
+}
+
+/* one 8-point pass (h264idct_template.c:80-108) — per lane */
+__device__ __forceinline__ void idct8_1d(const int in[8], int out[8])
+{
+    int a0 = in[0] + in[4], a2 = in[0] - in[4];
+    int a4 = (in[2] >> 1) - in[6], a6 = (in[6] >> 1) + in[2];
+    int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    int a1 = -in[3] + in[5] - in[7] - (in[7] >> 1);
+    int a3 = in[1] + in[7] - in[3] - (in[3] >> 1);
+    int a5 = -in[1] + in[7] + in[5] + (in[5] >> 1);
+    int a7 = in[3] + in[5] + in[1] + (in[1] >> 1);
+    int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2);
+    int b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    out[0] = b0 + b7; out[7] = b0 - b7;
+    out[1] = b2 + b5; out[6] = b2 - b5;
+    out[2] = b4 + b3; out[5] = b4 - b3;
+    out[3] = b6 + b1; out[4] = b6 - b1;
+}
+
+/* 8x8 inverse transform of one block held in LDS (int16 blk[64], overwritten with the
+ * intermediate); 8 lanes (i = 0..7) per block, `active` lanes only but every lane of the
+ * wave must call (barriers inside).  Lane i ends with the residuals of destination
+ * column i, rows 0..7.  h264idct_template.c:69-141. */
+__device__ inline void idct8_lds(int16_t *blk, int i, bool active, int r[8])
+{
+    int in[8], out[8];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) in[k] = blk[i + 8 * k];
+        if (i == 0) in[0] = (int16_t)(in[0] + 32);
+        idct8_1d(in, out);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) blk[i + 8 * k] = (int16_t)out[k];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) in[k] = blk[8 * i + k];
+        idct8_1d(in, out);
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = out[k] >> 6;
+    }
+}
+
+/* add n residuals down a column of an LDS picture tile, with clipping — per lane */
+__device__ __forceinline__ void add_col(uint8_t *p, int pitch, const int *r, int n)
+{
+    for (int k = 0; k < n; k++) p[k * pitch] = (uint8_t)clip_u8(p[k * pitch] + r[k]);
+}
+
+/* ---- a3: DC transforms (h264idct_template.c:242-324) — per lane, serial ------- */
+/* luma: in[16] raw DC levels (row-major), out[k] goes to the DC slot of luma block
+ * dc_slot_block(k) */
+__device__ inline void luma_dc_dequant(const int in[16], int qmul, int out[16])
+{
+    int t[16];
+    for (int i = 0; i < 4; i++) {
+        int s = in[4 * i] + in[4 * i + 1], d = in[4 * i] - in[4 * i + 1];
+        int e = in[4 * i + 2] - in[4 * i + 3], u = in[4 * i + 2] + in[4 * i + 3];
+        t[4 * i] = s + u; t[4 * i + 1] = s - u; t[4 * i + 2] = d - e; t[4 * i + 3] = d + e;
+    }
+    for (int i = 0; i < 4; i++) {
+        int s = t[i] + t[8 + i], d = t[i] - t[8 + i];
+        int e = t[4 + i] - t[12 + i], u = t[4 + i] + t[12 + i];
+        out[4 * i + 0] = (int16_t)(((s + u) * qmul + 128) >> 8);
+        out[4 * i + 1] = (int16_t)(((d + e) * qmul + 128) >> 8);
+        out[4 * i + 2] = (int16_t)(((d - e) * qmul + 128) >> 8);
+        out[4 * i + 3] = (int16_t)(((s - u) * qmul + 128) >> 8);
+    }
+}
+/* coefficient index (in the 256-entry luma array) that out[k] of luma_dc_dequant lands on:
+ * column offsets {0,2,8,10}*16 for i = k>>2, row offsets {0,1,4,5}*16 for k&3 */
+__device__ __host__ __forceinline__ int luma_dc_slot(int k)
+{
+    const int i = k >> 2, j = k & 3;
+    const int co = i == 0 ? 0 : (i == 1 ? 2 : (i == 2 ? 8 : 10));
+    const int ro = j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 4 : 5));
+    return (co + ro) * 16;
+}
+__device__ inline void chroma_dc_dequant(int &a, int &b, int &c, int &d, int qmul)
+{
+    int s0 = a + b, d0 = a - b, s1 = c + d, d1 = c - d;
+    a = (int16_t)(((s0 + s1) * qmul) >> 7);
+    b = (int16_t)(((d0 + d1) * qmul) >> 7);
+    c = (int16_t)(((s0 - s1) * qmul) >> 7);
+    d = (int16_t)(((d0 - d1) * qmul) >> 7);
+}
+
+/* ---- a8: deblocking, one line across an edge — per lane -----------------------
+ * h264dsp_template.c:104-150 (bS<4), :166-218 (bS==4), :233-270 / :294-318 chroma. */
+__device__ __forceinline__ void lf_luma_line(int &p2, int &p1, int &p0, int &q0, int &q1, int &q2,
+                                             int alpha, int beta, int tc0)
+{
+    if (tc0 < 0) return;
+    if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+    int tc = tc0, np1 = p1, nq1 = q1;
+    if (iabs(p2 - p0) < beta) {
+        if (tc0) np1 = p1 + clip3(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0);
+        tc++;
+    }
+    if (iabs(q2 - q0) < beta) {
+        if (tc0) nq1 = q1 + clip3(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0);
+        tc++;
+    }
+    int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    p1 = np1; q1 = nq1;
+    p0 = clip_u8(p0 + delta);
+    q0 = clip_u8(q0 - delta);
+}
+__device__ __forceinline__ void lf_luma_intra_line(int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3,
+                                                   int alpha, int beta)
+{
+    if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+    const int P0 = p0, P1 = p1, P2 = p2, Q0 = q0, Q1 = q1, Q2 = q2;
+    if (iabs(P0 - Q0) < ((alpha >> 2) + 2)) {
+        if (iabs(P2 - P0) < beta) {
+            p0 = (P2 + 2 * P1 + 2 * P0 + 2 * Q0 + Q1 + 4) >> 3;
+            p1 = (P2 + P1 + P0 + Q0 + 2) >> 2;
+            p2 = (2 * p3 + 3 * P2 + P1 + P0 + Q0 + 4) >> 3;
+        } else {
+            p0 = (2 * P1 + P0 + Q1 + 2) >> 2;
+        }
+        if (iabs(Q2 - Q0) < beta) {
+            q0 = (P1 + 2 * P0 + 2 * Q0 + 2 * Q1 + Q2 + 4) >> 3;
+            q1 = (P0 + Q0 + Q1 + Q2 + 2) >> 2;
+            q2 = (2 * q3 + 3 * Q2 + Q1 + Q0 + P0 + 4) >> 3;
+        } else {
+            q0 = (2 * Q1 + Q0 + P1 + 2) >> 2;
+        }
+    } else {
+        p0 = (2 * P1 + P0 + Q1 + 2) >> 2;
+        q0 = (2 * Q1 + Q0 + P1 + 2) >> 2;
+    }
+}
+/* tc is the value the caller passes in tc0[] (already +1 for chroma, h264_loopfilter.c:126-129) */
+__device__ __forceinline__ void lf_chroma_line(int p1, int &p0, int &q0, int q1, int alpha, int beta, int tc)
+{
+    if (tc <= 0) return;
+    if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+    int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    p0 = clip_u8(p0 + delta);
+    q0 = clip_u8(q0 - delta);
+}
+__device__ __forceinline__ void lf_chroma_intra_line(int p1, int &p0, int &q0, int q1, int alpha, int beta)
+{
+    if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+    const int P0 = p0, Q0 = q0;
+    p0 = (2 * p1 + P0 + q1 + 2) >> 2;
+    q0 = (2 * q1 + Q0 + p1 + 2) >> 2;
+}
+
+/* ---- a10: intra prediction (h264pred_template.c) — per lane ---------------------
+ * Directional modes as functions of the reference vectors T[-1..2N-1] (row above,
+ * T[-1] = corner sample) and L[-1..N-1] (column to the left): the standard's
+ * formulation, valid for N=4 on raw edge samples and for N=8 on the pre-filtered edge.
+ * T and L point at element 0 (element -1 must be addressable). */
+__device__ __forceinline__ int f3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+__device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
+
+__device__ inline int pred_dir_px(int mode, int N, int x, int y, const int16_t *T, const int16_t *L)
+{
+    switch (mode) {
+    case 0: return T[x];
+    case 1: return L[y];
+    case 3: /* diagonal down-left */
+        return (x == N - 1 && y == N - 1) ? (T[2 * N - 2] + 3 * T[2 * N - 1] + 2) >> 2
+                                          : f3(T[x + y], T[x + y + 1], T[x + y + 2]);
+    case 4: /* diagonal down-right */
+        if (x > y) return f3(T[x - y - 2], T[x - y - 1], T[x - y]);
+        if (x < y) return f3(L[y - x - 2], L[y - x - 1], L[y - x]);
+        return f3(T[0], T[-1], L[0]);
+    case 5: { /* vertical-right */
+        int z = 2 * x - y, i = x - (y >> 1);
+        if (z >= 0 && !(z & 1)) return f2(T[i - 1], T[i]);
+        if (z > 0) return f3(T[i - 2], T[i - 1], T[i]);
+        if (z == -1) return f3(L[0], T[-1], T[0]);
+        return f3(L[y - 2 * x - 1], L[y - 2 * x - 2], L[y - 2 * x - 3]);
+    }
+    case 6: { /* horizontal-down */
+        int z = 2 * y - x, i = y - (x >> 1);
+        if (z >= 0 && !(z & 1)) return f2(L[i - 1], L[i]);
+        if (z > 0) return f3(L[i - 2], L[i - 1], L[i]);
+        if (z == -1) return f3(L[0], T[-1], T[0]);
+        return f3(T[x - 2 * y - 1], T[x - 2 * y - 2], T[x - 2 * y - 3]);
+    }
+    case 7: { /* vertical-left */
+        int i = x + (y >> 1);
+        return (y & 1) ? f3(T[i], T[i + 1], T[i + 2]) : f2(T[i], T[i + 1]);
+    }
+    case 8: { /* horizontal-up */
+        int z = x + 2 * y, i = y + (x >> 1);
+        if (z > 2 * N - 3) return L[N - 1];
+        if (z == 2 * N - 3) return (L[N - 2] + 3 * L[N - 1] + 2) >> 2;
+        return (z & 1) ? f3(L[i], L[i + 1], L[i + 2]) : f2(L[i], L[i + 1]);
+    }
+    }
+    return 128;
+}
+
+/* which edges a 4x4 / 8x8 luma mode reads: bit0 top, bit1 left, bit2 corner, bit3 top-right */
+__device__ __host__ __forceinline__ int pred_luma_needs(int mode)
+{
+    switch (mode) {
+    case 0: case 10: return 1;
+    case 1: case 9: case 8: return 2;
+    case 2: return 3;
+    case 3: case 7: return 1 | 8;
+    case 4: case 5: case 6: return 1 | 2 | 4;
+    default: return 0;
+    }
+}
+
+/* DC-family value for an NxN luma block from the (already prepared) vectors */
+__device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int16_t *L)
+{
+    int st = 0, sl = 0;
+    for (int i = 0; i < N; i++) { st += T[i]; sl += L[i]; }
+    const int lg = N == 4 ? 2 : 3;
+    if (mode == 2) return (st + sl + N) >> (lg + 1);
+    if (mode == 9) return (sl + (N >> 1)) >> lg;
+    if (mode == 10) return (st + (N >> 1)) >> lg;
+    return 128;
+}
+
+/* plane prediction parameters (h264pred_template.c:434-481 for N=16, :768-802 for N=8):
+ * pixel(x,y) = clip((a + x*H + y*V) >> 5).  top[-1..N-1], left[-1..N-1]. */
+__device__ inline void pred_plane_params(int N, const int16_t *top, const int16_t *left, int &a, int &H, int &V)
+{
+    const int half = N >> 1;
+    H = 0; V = 0;
+    for (int k = 1; k <= half; k++) {
+        H += k * (top[half - 1 + k] - top[half - 1 - k]);
+        V += k * (left[half - 1 + k] - left[half - 1 - k]);
+    }
+    if (N == 16) { H = (5 * H + 32) >> 6;  V = (5 * V + 32) >> 6; }
+    else         { H = (17 * H + 16) >> 5; V = (17 * V + 16) >> 5; }
+    a = 16 * (left[N - 1] + top[N - 1] + 1) - (half - 1) * (V + H);
+}
+
+
+/* ---- wave-level intra predictor -------------------------------------------------
+ * Raw edge samples are gathered by the caller into s.T / s.L (index 0 = corner
+ * p[-1,-1]; T[1+i] = p[i,-1], L[1+j] = p[-1,j]); unavailable samples may hold
+ * anything, they are never used for a legal (mode, availability) combination.
+ * kind: 0 = 4x4 luma (T[5..8] = the caller's `topright` samples), 1 = 8x8 luma with
+ * the (1,2,1) edge pre-filter (h264pred_template.c:846-874), 2 = 8x8 chroma,
+ * 3 = 16x16 luma.  `mode` is the reference's table slot (h264pred.h:34-88).
+ * Writes the NxN block to out[y*pitch+x] (LDS or global). */
+struct PredScratch {
+    int16_t T[1 + 32];
+    int16_t L[1 + 16];
+    int16_t fT[1 + 16];
+    int16_t fL[1 + 8];
+};
+
+__device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int has_tl, int has_tr,
+                                       uint8_t *out, int pitch)
+{
+    const int lane = lane_id();
+    const int16_t *T = s.T + 1, *L = s.L + 1;
+    if (kind == 0 || kind == 1) {
+        const int N = kind == 0 ? 4 : 8;
+        const int needs = pred_luma_needs(mode);
+        if (kind == 1) {
+            /* pre-filter: lanes 0..15 -> fT[0..15], 16..23 -> fL[0..7], 24 -> corner */
+            int v = 0;
+            if (lane < 16 && (needs & 1)) {
+                int x = lane;
+                if (x == 0)       v = f3(has_tl ? T[-1] : T[0], T[0], T[1]);
+                else if (x < 7)   v = f3(T[x - 1], T[x], T[x + 1]);
+                else if (x == 7)  v = f3(has_tr ? T[8] : T[7], T[7], T[6]);
+                else if (!has_tr) v = T[7];
+                else if (x < 15)  v = f3(T[x - 1], T[x], T[x + 1]);
+                else              v = (T[14] + 3 * T[15] + 2) >> 2;
+                s.fT[1 + x] = (int16_t)v;
+            } else if (lane >= 16 && lane < 24 && (needs & 2)) {
+                int y = lane - 16;
+                if (y == 0)      v = f3(has_tl ? L[-1] : L[0], L[0], L[1]);
+                else if (y < 7)  v = f3(L[y - 1], L[y], L[y + 1]);
+                else             v = (L[6] + 3 * L[7] + 2) >> 2;
+                s.fL[1 + y] = (int16_t)v;
+            } else if (lane == 24 && (needs & 4)) {
+                v = f3(L[0], T[-1], T[0]);
+                s.fT[0] = s.fL[0] = (int16_t)v;
+            }
+            __syncthreads();
+            T = s.fT + 1;
+            L = s.fL + 1;
+        }
+        if (lane < N * N) {
+            int x = lane & (N - 1), y = lane / N;
+            int v;
+            if (mode == 2 || mode >= 9) v = pred_dc_value(mode, N, T, L);
+            else v = pred_dir_px(mode, N, x, y, T, L);
+            out[y * pitch + x] = (uint8_t)v;
+        }
+        __syncthreads();
+        return;
+    }
+    if (kind == 3) { /* 16x16: slots DC=0 HOR=1 VERT=2 PLANE=3 LEFT_DC=4 TOP_DC=5 DC128=6 */
+        int st = 0, sl = 0, a = 0, H = 0, V = 0;
+        if (mode == 0 || mode == 5) for (int i = 0; i < 16; i++) st += T[i];
+        if (mode == 0 || mode == 4) for (int i = 0; i < 16; i++) sl += L[i];
+        if (mode == 3) pred_plane_params(16, T, L, a, H, V);
+        for (int i = lane; i < 256; i += 64) {
+            int x = i & 15, y = i >> 4, v;
+            switch (mode) {
+            case 0: v = (st + sl + 16) >> 5; break;
+            case 1: v = L[y]; break;
+            case 2: v = T[x]; break;
+            case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+            case 4: v = (sl + 8) >> 4; break;
+            case 5: v = (st + 8) >> 4; break;
+            default: v = 128; break;
+            }
+            out[y * pitch + x] = (uint8_t)v;
+        }
+        __syncthreads();
+        return;
+    }
+    /* kind == 2: 8x8 chroma; per-4x4-quadrant DC rules of h264pred_template.c:563-766 */
+    {
+        const int x = lane & 7, y = lane >> 3, qx = x >> 2, qy = y >> 2;
+        int t = 0, l = 0, v, a = 0, H = 0, V = 0;
+        for (int i = 0; i < 4; i++) { t += T[4 * qx + i]; l += L[4 * qy + i]; }
+        if (mode == 3) pred_plane_params(8, T, L, a, H, V);
+        const int dc_full = (qx == qy) ? (t + l + 4) >> 3 : (qx ? (t + 2) >> 2 : (l + 2) >> 2);
+        const int dc_left = (l + 2) >> 2, dc_top = (t + 2) >> 2;
+        switch (mode) {
+        case 0: v = dc_full; break;
+        case 1: v = L[y]; break;
+        case 2: v = T[x]; break;
+        case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+        case 4: v = dc_left; break;
+        case 5: v = dc_top; break;
+        case 6: v = 128; break;
+        case 7: v = (qx == 0 && qy == 0) ? (t + l + 4) >> 3 : dc_top; break;   /* L0T */
+        case 8: v = (qx == 0 && qy == 0) ? dc_top : dc_full; break;              /* 0LT */
+        case 9: v = qy ? 128 : dc_left; break;                                   /* L00 */
+        default: v = qy ? dc_left : 128; break;                                  /* 0L0 */
+        }
+        out[y * pitch + x] = (uint8_t)v;
+        __syncthreads();
+    }
+}
+
+}  // namespace mi355
+#endif

@@ -1,0 +1,79 @@
+/*
+ * mi355_rt.h — host-side runtime shared by the C-ABI entry points.
+ *
+ * Tier-1 (per-call, synchronous, host pointers — the reference's DSP pointer
+ * tables as they are called today): every call packs the sample
+ * window it touches into a pinned staging buffer, does ONE H2D copy, ONE kernel
+ * launch, ONE D2H copy and unpacks the written extent.  Slow by construction
+ * (tens of µs per call); it exists so the reference's own decoder and the
+ * checkasm-style parity tests can run through the HIP kernels unchanged.
+ * Tier-2 (batched, device pointers) lives in h264_frame.hip.
+ */
+#ifndef MI355_RT_H
+#define MI355_RT_H
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define MI355_CHECK(expr)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            std::fprintf(stderr, "mi355dsp: %s failed: %s (%s:%d)\n", #expr,                 \
+                         hipGetErrorString(e_), __FILE__, __LINE__);                         \
+            std::abort(); /* the pointer tables are void: there is no error channel */      \
+        }                                                                                    \
+    } while (0)
+
+namespace mi355 {
+
+/* Thread-local staging arena: the reference calls the tables from frame/slice threads. */
+struct Arena {
+    hipStream_t stream = nullptr;
+    uint8_t *host = nullptr;   /* pinned */
+    uint8_t *dev = nullptr;
+    size_t cap = 0, used = 0;
+
+    void ensure();
+    void reset() { used = 0; }
+    /* reserve n bytes (16-byte aligned) in both images; returns the offset */
+    size_t take(size_t n)
+    {
+        size_t off = (used + 15) & ~(size_t)15;
+        if (off + n > cap) { std::fprintf(stderr, "mi355dsp: staging arena overflow\n"); std::abort(); }
+        used = off + n;
+        return off;
+    }
+    template <typename T> T *h(size_t off) { return reinterpret_cast<T *>(host + off); }
+    template <typename T> T *d(size_t off) { return reinterpret_cast<T *>(dev + off); }
+    void upload() { MI355_CHECK(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, stream)); }
+    void download()
+    {
+        MI355_CHECK(hipMemcpyAsync(host, dev, used, hipMemcpyDeviceToHost, stream));
+        MI355_CHECK(hipStreamSynchronize(stream));
+    }
+};
+
+Arena &arena();
+
+/* A rectangular window of host samples mirrored in the arena at a fixed pitch. */
+struct Win {
+    size_t off;
+    int pitch, wbytes, rows;
+};
+/* copy rows x wbytes from (src, stride) into the arena; rows outside [0,valid_rows) x
+ * [0,valid_w) are zero-filled (used when the reference contract forbids reading them) */
+Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int rows,
+             int valid_w = -1, int valid_rows = -1);
+/* copy the sub-rectangle (x0,y0,w,h) of the window back to (dst, stride) where dst is the
+ * host address of window sample (x0,y0) */
+void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows);
+
+bool ready();
+
+}  // namespace mi355
+#endif

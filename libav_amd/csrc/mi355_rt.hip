@@ -1,0 +1,85 @@
+/* mi355_rt.hip — runtime: device selection, thread-local staging arenas. */
+#include "mi355_rt.h"
+#include "../../include/mi355dsp.h"
+
+namespace mi355 {
+
+static int g_device = -1;
+
+bool ready() { return g_device >= 0; }
+
+void Arena::ensure()
+{
+    if (dev) return;
+    if (g_device < 0) {
+        std::fprintf(stderr, "mi355dsp: mi355_init() was not called or found no GPU; "
+                             "there is no CPU fallback in this library\n");
+        std::abort();
+    }
+    MI355_CHECK(hipSetDevice(g_device));
+    cap = 1 << 20;
+    MI355_CHECK(hipStreamCreate(&stream));
+    MI355_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap));
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), cap));
+}
+
+Arena &arena()
+{
+    static thread_local Arena a;
+    a.ensure();
+    a.reset();
+    return a;
+}
+
+Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int rows, int valid_w, int valid_rows)
+{
+    Win w;
+    w.wbytes = wbytes;
+    w.rows = rows;
+    w.pitch = (wbytes + 15) & ~15;
+    w.off = a.take((size_t)w.pitch * rows);
+    uint8_t *p = a.h<uint8_t>(w.off);
+    if (valid_w < 0) valid_w = wbytes;
+    if (valid_rows < 0) valid_rows = rows;
+    for (int y = 0; y < rows; y++) {
+        uint8_t *row = p + (size_t)y * w.pitch;
+        if (y < valid_rows) {
+            std::memcpy(row, src + (ptrdiff_t)y * stride, (size_t)valid_w);
+            std::memset(row + valid_w, 0, (size_t)(w.pitch - valid_w));
+        } else {
+            std::memset(row, 0, (size_t)w.pitch);
+        }
+    }
+    return w;
+}
+
+void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows)
+{
+    const uint8_t *p = a.h<uint8_t>(w.off);
+    for (int y = 0; y < rows; y++)
+        std::memcpy(dst + (ptrdiff_t)y * stride, p + (size_t)(y0 + y) * w.pitch + x0, (size_t)wbytes);
+}
+
+}  // namespace mi355
+
+extern "C" int mi355_init(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -2;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "mi355dsp: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return -3;
+    }
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    mi355::g_device = device;
+    return 0;
+}
+
+extern "C" int mi355_device_cus(void)
+{
+    hipDeviceProp_t prop;
+    if (!mi355::ready() || hipGetDeviceProperties(&prop, mi355::g_device) != hipSuccess) return -1;
+    return prop.multiProcessorCount;
+}

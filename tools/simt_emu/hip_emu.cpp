@@ -1,0 +1,184 @@
+/* hip_emu.cpp — fiber scheduler of the SIMT emulator (TEST TOOLING ONLY, see hip_emu.h). */
+#include "hip_emu.h"
+
+#include <cstdio>
+#include <ucontext.h>
+#include <vector>
+
+namespace simt_emu {
+
+enum State { RUN, WAIT_BLOCK, WAIT_WAVE, DONE };
+
+struct Fiber {
+    ucontext_t ctx;
+    Lane lane;
+    State st;
+    int xchg_val;    /* value published for a shuffle / ballot */
+    int xchg_arg;
+    int xchg_res;
+    char *stack;
+};
+
+Lane *cur = nullptr;
+dim3 g_blockIdx, g_blockDim, g_gridDim;
+
+static std::vector<Fiber> fibers;
+static ucontext_t sched_ctx;
+static Fiber *cur_fiber = nullptr;
+static const std::function<void()> *cur_body = nullptr;
+static const size_t STACK = 256 * 1024;
+
+static void trampoline()
+{
+    (*cur_body)();
+    cur_fiber->st = DONE;
+    swapcontext(&cur_fiber->ctx, &sched_ctx);
+}
+
+static void yield_as(State s)
+{
+    Fiber *f = cur_fiber;
+    f->st = s;
+    swapcontext(&f->ctx, &sched_ctx);
+    /* resumed */
+}
+
+void barrier_block() { yield_as(WAIT_BLOCK); }
+
+/* All live lanes of the wave publish, yield, and are resumed once every live lane of
+ * the wave has published; the resolver (scheduler) fills xchg_res. */
+static int wave_op(int v, int arg, int mode_width)
+{
+    Fiber *f = cur_fiber;
+    f->xchg_val = v;
+    f->xchg_arg = arg;
+    f->xchg_res = mode_width;
+    yield_as(WAIT_WAVE);
+    return f->xchg_res;
+}
+
+int shfl_exchange(int v, int a, int width, int mode) { return wave_op(v, a, (mode << 8) | (width & 0xFF)); }
+unsigned long long ballot(int pred)
+{
+    int lo = wave_op(pred != 0, 0, (4 << 8) | 64);
+    int hi = wave_op(pred != 0, 0, (5 << 8) | 64);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+static void resolve_wave(size_t w0, size_t w1)
+{
+    /* snapshot published values first (results overwrite xchg_res which holds mode) */
+    int vals[64], args[64], modes[64];
+    bool live[64];
+    for (size_t i = w0; i < w1; i++) {
+        Fiber &f = fibers[i];
+        live[i - w0] = f.st == WAIT_WAVE;
+        vals[i - w0] = f.xchg_val;
+        args[i - w0] = f.xchg_arg;
+        modes[i - w0] = f.xchg_res;
+    }
+    for (size_t i = w0; i < w1; i++) {
+        Fiber &f = fibers[i];
+        if (f.st != WAIT_WAVE) continue;
+        int lane = (int)(i - w0);
+        int mode = modes[lane] >> 8, width = modes[lane] & 0xFF;
+        if (width == 0) width = 64;
+        if (mode >= 4) { /* ballot halves */
+            unsigned m = 0;
+            for (int k = 0; k < 32; k++) {
+                int l = k + (mode == 5 ? 32 : 0);
+                if ((size_t)l < w1 - w0 && live[l] && vals[l]) m |= 1u << k;
+            }
+            f.xchg_res = (int)m;
+        } else {
+            int base = lane & ~(width - 1), rel = lane & (width - 1), src;
+            switch (mode) {
+            case 0: src = base + (args[lane] & (width - 1)); break;
+            case 1: src = lane ^ args[lane]; if ((src & ~(width - 1)) != base) src = lane; break;
+            case 2: src = rel - args[lane] >= 0 ? lane - args[lane] : lane; break;
+            default: src = rel + args[lane] < width ? lane + args[lane] : lane; break;
+            }
+            if (src < 0 || (size_t)src >= w1 - w0 || !live[src]) src = lane; /* inactive source: own value */
+            f.xchg_res = vals[src];
+        }
+        f.st = RUN;
+    }
+}
+
+static void run_block(const std::function<void()> &body, unsigned nthreads)
+{
+    cur_body = &body;
+    if (fibers.size() < nthreads) {
+        size_t old = fibers.size();
+        fibers.resize(nthreads);
+        for (size_t i = old; i < nthreads; i++) fibers[i].stack = (char *)std::malloc(STACK);
+    }
+    for (unsigned t = 0; t < nthreads; t++) {
+        Fiber &f = fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK;
+        f.ctx.uc_link = &sched_ctx;
+        makecontext(&f.ctx, trampoline, 0);
+        f.lane.tid = dim3(t % g_blockDim.x, (t / g_blockDim.x) % g_blockDim.y, t / (g_blockDim.x * g_blockDim.y));
+        f.st = RUN;
+    }
+    for (;;) {
+        bool progressed = false;
+        for (unsigned t = 0; t < nthreads; t++) {
+            Fiber &f = fibers[t];
+            if (f.st != RUN) continue;
+            cur_fiber = &f;
+            cur = &f.lane;
+            swapcontext(&sched_ctx, &f.ctx);
+            progressed = true;
+        }
+        /* wave-level rendezvous */
+        for (size_t w0 = 0; w0 < nthreads; w0 += 64) {
+            size_t w1 = w0 + 64 < nthreads ? w0 + 64 : nthreads;
+            bool any = false, all = true;
+            for (size_t i = w0; i < w1; i++) {
+                if (fibers[i].st == WAIT_WAVE) any = true;
+                else if (fibers[i].st != DONE) all = false;
+            }
+            if (any && all) { resolve_wave(w0, w1); progressed = true; }
+        }
+        /* block-level barrier */
+        bool anyb = false, allb = true, alldone = true;
+        for (unsigned t = 0; t < nthreads; t++) {
+            if (fibers[t].st == WAIT_BLOCK) anyb = true;
+            else if (fibers[t].st != DONE) allb = false;
+            if (fibers[t].st != DONE) alldone = false;
+        }
+        if (alldone) break;
+        if (anyb && allb) {
+            for (unsigned t = 0; t < nthreads; t++)
+                if (fibers[t].st == WAIT_BLOCK) fibers[t].st = RUN;
+            progressed = true;
+        }
+        if (!progressed) {
+            std::fprintf(stderr, "simt_emu: deadlock in block (%u,%u,%u): divergent barrier/shuffle "
+                                 "(on a GPU this kernel would hang or read undefined lanes)\n",
+                         g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
+            for (unsigned t = 0; t < nthreads; t++)
+                std::fprintf(stderr, "%d", (int)fibers[t].st);
+            std::fprintf(stderr, "\n");
+            std::abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body)
+{
+    g_gridDim = grid;
+    g_blockDim = block;
+    unsigned nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                g_blockIdx = dim3(bx, by, bz);
+                run_block(body, nthreads);
+            }
+}
+
+}  // namespace simt_emu

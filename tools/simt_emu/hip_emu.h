@@ -1,0 +1,113 @@
+/*
+ * hip_emu.h — a tiny SIMT emulator for DEBUGGING the kernels in libav_amd/csrc on a
+ * machine with no GPU.  TEST TOOLING ONLY: it is never linked into the product
+ * library (libav_amd/libmi355dsp.so is built by hipcc for gfx950 and fails loudly
+ * without a GPU).  `make -C tools/simt_emu emu` compiles the *same* .hip sources
+ * with g++ against this header into tests/_emu/libmi355dsp_emu.so so that the CPU
+ * test-suite (-m "not gpu") can exercise kernel indexing / LDS / shuffle logic
+ * against the oracle before a GPU-minute is spent.
+ *
+ * Model: one workgroup at a time; every work-item is a ucontext fiber; the 64-lane
+ * wavefront is honoured for the shuffle and ballot builtins; __syncthreads() and the shuffles are
+ * cooperative yield points.  A barrier that not every live lane reaches aborts
+ * with a message (that would hang a real GPU).  `__shared__` is `static`
+ * (valid because workgroups run one after another).
+ *
+ * Only the slice of the HIP API our sources use is provided.
+ */
+#ifndef MI355_HIP_EMU_H
+#define MI355_HIP_EMU_H
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace simt_emu {
+struct Lane {
+    dim3 tid;
+};
+extern Lane *cur;
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+void barrier_block();
+int shfl_exchange(int v, int src_lane_rel, int width, int mode); /* mode 0 idx,1 xor,2 up,3 down */
+unsigned long long ballot(int pred);
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+}  // namespace simt_emu
+
+#define threadIdx (simt_emu::cur->tid)
+#define blockIdx (simt_emu::g_blockIdx)
+#define blockDim (simt_emu::g_blockDim)
+#define gridDim (simt_emu::g_gridDim)
+static const int warpSize = 64;
+
+static inline void __syncthreads() { simt_emu::barrier_block(); }
+static inline int __shfl(int v, int lane, int w = 64) { return simt_emu::shfl_exchange(v, lane, w, 0); }
+static inline int __shfl_xor(int v, int m, int w = 64) { return simt_emu::shfl_exchange(v, m, w, 1); }
+static inline int __shfl_up(int v, unsigned d, int w = 64) { return simt_emu::shfl_exchange(v, (int)d, w, 2); }
+static inline int __shfl_down(int v, unsigned d, int w = 64) { return simt_emu::shfl_exchange(v, (int)d, w, 3); }
+static inline unsigned long long __ballot(int p) { return simt_emu::ballot(p); }
+static inline int __any(int p) { return simt_emu::ballot(p) != 0; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+/* ---- host API subset ------------------------------------------------------ */
+typedef int hipError_t;
+typedef struct emu_stream *hipStream_t;
+typedef struct emu_event *hipEvent_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct hipDeviceProp_t {
+    char name[256];
+    char gcnArchName[256];
+    int multiProcessorCount;
+};
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    std::memset(p, 0, sizeof(*p));
+    std::strcpy(p->name, "simt-emu");
+    std::strcpy(p->gcnArchName, "gfx950:emu");
+    p->multiProcessorCount = 4;
+    return hipSuccess;
+}
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)1 << 32; return hipSuccess; }
+
+template <typename K, typename... A>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/, A... args)
+{
+    simt_emu::launch(grid, block, [=]() { kernel(args...); });
+}
+
+#endif /* MI355_HIP_EMU_H */
