@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the H.264 hot path on MI355X (BASELINE.json config 2:
+"H.264 8-bit 1080p: idct_add + qpel MC + deblock on 1xMI355X").
+
+A step = one pass of the hot path (reconstruct + deblock) over a batch of `--frames`
+independent 1080p pictures (= independent streams) per GPU, inputs already
+resident in HBM.  One process per GPU; ranks share nothing on the data path (weak scaling,
+streams shard across ranks); torch.distributed (RCCL) is only the control plane: barrier and
+max/sum of the per-rank counters.
+
+Prints ONE JSON line: metric macroblocks/s (whole job), plus `roofline` for the dominant
+kernel (HIP-event timed) and `cpu_baseline` (the CPU oracle — a scalar port of the
+reference's C path — timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic bytes per macroblock: each input byte read once, each output written once
+B_RECON = 384 + 768 + 128 + 384          # reference samples + coefficients + MB record/mv + unfiltered write
+B_DEBLOCK = 384 + 384 + 64               # unfiltered read + filtered write + side info
+B_FUSED = B_RECON + B_DEBLOCK            # 2432 B/MB: the two-surface pipeline figure
+HBM_PEAK = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64, help="independent 1080p pictures (streams) per GPU per step")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
+                    "they are replicated (own copies in HBM) to fill --frames")
+    ap.add_argument("--mb-width", type=int, default=120)
+    ap.add_argument("--mb-height", type=int, default=68)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import libav_amd
+    import h264_frames as HF
+    lib = libav_amd.load(local_rank)          # raises if the HIP library / GPU is missing: no fallback
+
+    class Prov:                                # the tiny provider interface h264_frames.DeviceFrames expects
+        pass
+    prov = Prov()
+    prov.lib = lib
+
+    mbw, mbh, F = args.mb_width, args.mb_height, args.frames
+    nmb = mbw * mbh
+    G = max(1, min(args.distinct, F))
+    fs = HF.synth_frames_fast(G, mbw, mbh, seed=0x264 + rank, lib=lib)
+    # replicate the G distinct pictures to F pictures (each with its own buffers in HBM)
+    big = HF.FrameSet(F, mbw, mbh, fs.nrefs)
+    for f in range(F):
+        g = f % G
+        big.mb[f] = fs.mb[g]
+        big.mv[:, f] = fs.mv[:, g]
+        big.coef[f] = fs.coef[g]
+        big.slices[f] = fs.slices[g]
+        big.refs[f] = fs.refs[g]
+        big.intra_list[f], big.intra_start[f] = fs.intra_list[g], fs.intra_start[g]
+    big.max_intra_level, big.max_level_width = fs.max_intra_level, fs.max_level_width
+    dev = HF.DeviceFrames(prov, big)
+
+    for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_recon_intra_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_deblock_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
+                          ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = at
+    stream = None   # the null stream: every launch and every event below is on it
+
+    def step(events=None):
+        if events is not None:
+            lib.mi355_event_record(events[0], stream)
+        assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, stream) == 0
+        if events is not None:
+            lib.mi355_event_record(events[1], stream)
+        assert lib.mi355_h264_recon_intra_dev(dev.d_desc, F, big.max_intra_level, big.max_level_width, stream) == 0
+        if events is not None:
+            lib.mi355_event_record(events[2], stream)
+        assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, stream) == 0
+        if events is not None:
+            lib.mi355_event_record(events[3], stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        assert lib.mi355_sync(stream) == 0
+
+    for _ in range(args.warmup):
+        step()
+    evs = [[lib.mi355_event_create() for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    assert lib.mi355_sync(stream) == 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for e in evs) / args.steps
+    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / args.steps
+    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / args.steps
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([float(F * nmb * args.steps)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_mbs = float(cnt.item())
+    else:
+        total_mbs = float(F * nmb * args.steps)
+
+    if rank == 0:
+        value = total_mbs / elapsed
+        n_intra = int(sum(len(x) for x in big.intra_list))
+        n_inter = F * nmb - n_intra
+        ndiag = (mbw - 1) + 2 * (mbh - 1) + 1
+        # dominant kernel = the pass with the largest share of the step
+        passes = {"k_recon_inter": (t_inter, 1, n_inter * B_RECON),
+                  "k_deblock": (t_deblock, ndiag, F * nmb * B_DEBLOCK)}
+        dom = max(passes, key=lambda k: passes[k][0])
+        t_pass, launches, bytes_pass = passes[dom]
+        achieved = bytes_pass / launches / (t_pass / launches * 1e-3)   # algorithmic bytes per launch / avg launch time
+        out = {
+            "metric": "macroblocks_per_s", "value": value, "unit": "macroblocks/s",
+            "frames_per_s": value / nmb, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "H.264 8-bit 4:2:0 1080p (1920x1088 coded), P pictures: qpel MC + idct_add + deblock, "
+                                   "two-surface pipeline, %d independent pictures per GPU per step "
+                                   "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, G),
+                       "frames_per_gpu": F, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
+                       "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
+                       "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world},
+            "pass_ms": {"recon_inter": t_inter, "recon_intra": t_intra, "deblock": t_deblock},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "launches_per_step": launches, "avg_launch_us": t_pass / launches * 1e3,
+                         "algorithmic_bytes_per_launch": bytes_pass / launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fs, args.cpu_seconds)
+        print(json.dumps(out))
+    dev.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fs, seconds):
+    """The CPU oracle (scalar port of the reference C path; oracle/) on this box's host cores, each thread
+    decoding its own picture of the same workload repeatedly for ~`seconds`."""
+    import providers
+    import h264_frames as HF
+    orc = providers.oracle()
+    lib = orc.lib
+    lib.oracle_h264_recon_frame.restype = None
+    lib.oracle_h264_deblock_frame.restype = None
+    ncores = os.cpu_count() or 1
+    nthreads = max(1, min(ncores, 64))
+    recon, dst = fs.planes(), fs.planes()
+    arr, _ = HF.host_frames(fs, recon, dst)
+    # warm the oracle's tables single-threaded, and time one core
+    t0 = time.perf_counter()
+    lib.oracle_h264_recon_frame(C.byref(arr[0]))
+    lib.oracle_h264_deblock_frame(C.byref(arr[0]))
+    one = time.perf_counter() - t0
+    nmb = fs.mb_w * fs.mb_h
+    # per-thread private output surfaces; inputs are shared read-only
+    ctxs = []
+    for t in range(nthreads):
+        r, d = HF.FrameSet.planes(fs), HF.FrameSet.planes(fs)
+        a, _ = HF.host_frames(fs, r, d)
+        ctxs.append((a, r, d))
+    counts = [0] * nthreads
+    stop = time.perf_counter() + seconds
+
+    def work(t):
+        a = ctxs[t][0]
+        g = t % fs.F
+        while time.perf_counter() < stop:
+            lib.oracle_h264_recon_frame(C.byref(a[g]))
+            lib.oracle_h264_deblock_frame(C.byref(a[g]))
+            counts[t] += 1
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    wall = time.perf_counter() - t0
+    return {"value": sum(counts) * nmb / wall, "unit": "macroblocks/s", "cores": nthreads, "kind": "port",
+            "value_1core": nmb / one,
+            "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d threads "
+                      "(reference x86 SIMD not built: no nasm in the image; this is the scalar C oracle)" % (min(nthreads, fs.F), seconds, nthreads)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+/*
+ * mi355_h264_frame.h — Tier-2: batched H.264 macroblock reconstruction + deblocking
+ * on device-resident data (the throughput path; C ABI of libmi355dsp.so).
+ *
+ * What it replaces in the reference: the per-macroblock body of the slice decoder
+ * after entropy decoding —
+ *     ff_h264_hl_decode_mb()   libavcodec/h264_mb.c:798 (hl_decode_mb, h264_mb_template.c:41,
+ *                               8-bit "simple" variant: progressive, 4:2:0, not lossless)
+ *     loop_filter() / ff_h264_filter_mb()   libavcodec/h264_slice.c:2198, h264_loopfilter.c:716
+ * for ALL macroblocks of a batch of independent pictures at once, in the reference's
+ * own "reconstruct the whole picture, then filter it" mode (H264Context.postpone_filter,
+ * h264_slice.c:2344-2345, :2570-2586): pass 1 writes unfiltered samples to `recon`,
+ * pass 2 filters `recon` into `dst`.  The host decoder (entropy decoding, MV prediction,
+ * reference lists) stays the reference's C code and fills the records below from the
+ * state it already holds when it would call ff_h264_hl_decode_mb();
+ * INTEGRATION.md shows that bridge.
+ *
+ * All pointers inside mi355_h264_frame are DEVICE pointers.  Pictures are planar 8-bit
+ * 4:2:0 with byte strides, exactly like the reference's AVFrame planes, so `dst` can be
+ * handed back (or copied out) unchanged.
+ */
+#ifndef MI355_H264_FRAME_H
+#define MI355_H264_FRAME_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mb_type bits: the reference's own encoding (libavcodec/mpegutils.h:51-71,
+ * MB_TYPE_8x8DCT libavcodec/h264dec.h), so cur_pic.mb_type[] can be copied as is. */
+#define MI355_MB_INTRA4x4    0x00000001u  /* with MI355_MB_8x8DCT: Intra 8x8 */
+#define MI355_MB_INTRA16x16  0x00000002u
+#define MI355_MB_INTRA_PCM   0x00000004u
+#define MI355_MB_16x16       0x00000008u
+#define MI355_MB_16x8        0x00000010u
+#define MI355_MB_8x16        0x00000020u
+#define MI355_MB_8x8         0x00000040u
+#define MI355_MB_P0L0        0x00001000u
+#define MI355_MB_P1L0        0x00002000u
+#define MI355_MB_P0L1        0x00004000u
+#define MI355_MB_P1L1        0x00008000u
+#define MI355_MB_8x8DCT      0x01000000u
+#define MI355_MB_INTRA       (MI355_MB_INTRA4x4 | MI355_MB_INTRA16x16 | MI355_MB_INTRA_PCM)
+
+/* mi355_h264_mb.flags */
+#define MI355_MBF_LEFT_EDGE  0x01  /* the left MB edge is filtered (neighbour exists and the slice's
+                                      disable_deblocking_filter_idc allows it: sl->left_type != 0) */
+#define MI355_MBF_TOP_EDGE   0x02  /* same for the top edge (sl->top_type != 0) */
+#define MI355_MBF_NO_DEBLOCK 0x04  /* sl->deblocking_filter == 0 for this MB's slice: copy only */
+
+/* mi355_h264_mb.sub_mb_type[i] (only for MI355_MB_8x8): shape of 8x8 quadrant i */
+#define MI355_SUB_8x8  0
+#define MI355_SUB_8x4  1
+#define MI355_SUB_4x8  2
+#define MI355_SUB_4x4  3
+#define MI355_SUB_L0   0x10  /* quadrant predicted from list 0 */
+#define MI355_SUB_L1   0x20  /* quadrant predicted from list 1 */
+
+/* nnz_mask bit numbers */
+#define MI355_NNZ_LUMA(i)   (i)          /* i = 0..15, the reference's block index (scan8 order) */
+#define MI355_NNZ_CB(j)     (16 + (j))   /* j = 0..3 */
+#define MI355_NNZ_CR(j)     (20 + (j))
+#define MI355_NNZ_LUMA_DC   24           /* non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX]] != 0 */
+#define MI355_NNZ_CB_DC     25
+#define MI355_NNZ_CR_DC     26
+
+/* One macroblock: exactly 64 bytes (offsets in the comments).  Field sources in the reference at the time
+ * ff_h264_hl_decode_mb() runs are given on the right (sl = H264SliceContext). */
+typedef struct mi355_h264_mb {
+    uint32_t mb_type;                    /*  0 h->cur_pic.mb_type[mb_xy] */
+    uint32_t nnz_mask;                   /*  4 MI355_NNZ_*: which blocks carry coefficients; for MI355_MB_8x8DCT
+                                               the four bits of a quadrant are equal (what the loop filter sees
+                                               after fill_filter_caches(), h264_slice.c:2160-2191) */
+    uint16_t cbp;                        /*  8 h->cbp_table[mb_xy] (low 6 bits used) */
+    int8_t   qp;                         /* 10 h->cur_pic.qscale_table[mb_xy] */
+    uint8_t  flags;                      /* 11 MI355_MBF_* */
+    int8_t   slice_alpha_c0_offset;      /* 12 sl->slice_alpha_c0_offset */
+    int8_t   slice_beta_offset;          /* 13 sl->slice_beta_offset */
+    uint8_t  intra16x16_pred_mode;       /* 14 sl->intra16x16_pred_mode (table slot, after availability remap) */
+    uint8_t  chroma_pred_mode;           /* 15 sl->chroma_pred_mode */
+    uint16_t topleft_samples_available;  /* 16 sl->topleft_samples_available */
+    uint16_t topright_samples_available; /* 18 sl->topright_samples_available */
+    uint8_t  sub_mb_type[4];             /* 20 MI355_SUB_*, from sl->sub_mb_type[] */
+    int8_t   ref_idx[2][4];              /* 24 sl->ref_cache[list][scan8[4*i]] per 8x8 quadrant; <0 = unused */
+    uint32_t dc_qmul[3];                 /* 32 pps->dequant4_coeff[{0 | 1,2 intra | 4,5 inter}][qp][0]:
+                                               luma DC (Intra16x16), Cb DC, Cr DC (h264_mb.c:706-708,
+                                               h264_mb_template.c:239-244) */
+    uint8_t  slice_id;                   /* 44 index into mi355_h264_frame.slices */
+    uint8_t  intra_level;                /* 45 0 for inter MBs; for intra MBs 1 + max(level of the intra MBs among
+                                               left, top-left, top, top-right), see mi355_h264_intra_levels() */
+    uint8_t  reserved[2];                /* 46 */
+    int8_t   intra4x4_pred_mode[16];     /* 48 sl->intra4x4_pred_mode_cache[scan8[i]]; Intra 8x8 uses i = 0,4,8,12 */
+} mi355_h264_mb;
+
+/* Coefficients: 384 int16 per macroblock = sl->mb with the chroma planes packed
+ * (luma block i at [16*i], Cb block j at [256+16*j], Cr block j at [320+16*j]),
+ * dequantised and stored transposed exactly as the reference's residual decoder
+ * leaves them.  Two conventions on top:
+ *  - Intra16x16: the 16 luma DC levels of sl->mb_luma_dc[0] are placed in the DC slots
+ *    (index 0 of each 4x4 block): level k goes to coefficient index mi355_luma_dc_slot(k)
+ *    — the position ff_h264_luma_dc_dequant_idct() writes its k-th output to, so the
+ *    device transforms them in place.
+ *  - I_PCM: the 384 raw sample bytes (Y 256, Cb 64, Cr 64) occupy the first 384 bytes.
+ * Blocks whose nnz_mask bit is clear must have all AC coefficients zero. */
+#define MI355_H264_COEFS_PER_MB 384
+static inline int mi355_luma_dc_slot(int k)
+{
+    static const uint8_t col[4] = { 0, 2, 8, 10 }, row[4] = { 0, 1, 4, 5 };
+    return 16 * (col[k >> 2] + row[k & 3]);
+}
+
+/* Motion vectors: int16 (x,y) quarter-sample units per 4x4 block, RASTER order inside
+ * the MB (index = x4 + 4*y4), one array per list: mv[list][mb*16 + blk][2].  Blocks that
+ * do not use a list must hold (0,0) (what mv_cache holds, h264_slice.c:2031-2038). */
+
+#define MI355_H264_MAX_REFS 16   /* per list, progressive pictures */
+#define MI355_H264_MAX_SLOTS 32  /* distinct reference pictures per frame */
+
+/* Per-slice constants (sl->pwt, ref lists, PPS chroma QP tables). */
+typedef struct mi355_h264_slice {
+    uint8_t use_weight;               /* sl->pwt.use_weight: 0 none, 1 explicit, 2 implicit */
+    uint8_t use_weight_chroma;
+    uint8_t luma_log2_weight_denom;
+    uint8_t chroma_log2_weight_denom;
+    uint8_t list_count;               /* sl->list_count */
+    uint8_t reserved[3];
+    uint8_t ref_slot[2][MI355_H264_MAX_REFS];           /* ref_idx -> index into mi355_h264_frame.ref[];
+                                                          also the picture identity the loop filter
+                                                          compares (h->ref2frm, h264_slice.c:1828-1855) */
+    int16_t luma_weight[MI355_H264_MAX_REFS][2][2];      /* [ref][list][{weight,offset}] */
+    int16_t chroma_weight[MI355_H264_MAX_REFS][2][2][2]; /* [ref][list][cb/cr][{weight,offset}] */
+    int16_t implicit_weight[MI355_H264_MAX_REFS][MI355_H264_MAX_REFS]; /* [ref0][ref1], frame MBs */
+    uint8_t chroma_qp_table[2][52];   /* pps->chroma_qp_table[cb/cr][qp] (get_chroma_qp) */
+} mi355_h264_slice;
+
+typedef struct mi355_h264_frame {
+    int32_t mb_width, mb_height;
+    uint8_t *dst[3];                  /* deblocked output picture */
+    int32_t dst_stride[2];            /* luma, chroma */
+    uint8_t *recon[3];                /* unfiltered reconstruction (intra prediction reads it) */
+    int32_t recon_stride[2];
+    const uint8_t *ref[MI355_H264_MAX_SLOTS][3]; /* reference pictures, same strides as dst */
+    const mi355_h264_mb *mb;          /* [mb_width*mb_height], raster */
+    const int16_t *mv[2];             /* see above; mv[1] may be NULL for P pictures */
+    const int16_t *coef;              /* [nmb][384] */
+    const mi355_h264_slice *slices;
+    int32_t nslices;
+    int32_t max_intra_level;          /* max over mb[].intra_level (0: no intra MBs) */
+    /* intra schedule (device arrays; see mi355_h264_intra_schedule): the intra MBs of this
+     * picture sorted by level; level L (1-based) occupies intra_list[start[L-1] .. start[L]) */
+    const uint32_t *intra_list;
+    const int32_t *intra_level_start; /* [max_intra_level + 1] */
+} mi355_h264_frame;
+
+/* Reconstruct and deblock `nframes` independent pictures described by the HOST array
+ * `frames` (its pointers are device pointers).  Work is enqueued on `stream`
+ * (a hipStream_t; NULL = the null stream); the call returns without synchronising.
+ * Returns 0, or <0 on invalid arguments. */
+int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nframes, void *stream);
+
+/* Same, with the descriptor array already resident on the device (`d_frames`), for callers
+ * that keep everything in HBM; geometry limits must then be given explicitly. */
+int mi355_h264_decode_frames_dev(const mi355_h264_frame *d_frames, int nframes,
+                                 int max_mb_width, int max_mb_height, int max_intra_level,
+                                 int max_level_width, void *stream);
+
+/* Individual passes (same argument meaning), exposed for measurement and tests. */
+int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
+int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream);
+int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
+
+/* Host helper (plain CPU bookkeeping, no sample arithmetic): fill mb[].intra_level for one
+ * picture and write the schedule: `list` (capacity mb_width*mb_height) receives the intra MB
+ * indices sorted by level, `level_start` (capacity mb_width + 2*mb_height + 1) the offsets.
+ * Returns the maximum level; *max_level_width receives the largest number of MBs on one level. */
+int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
+                              uint32_t *list, int32_t *level_start, int *max_level_width);
+
+/* Device-memory plumbing for callers that do not link a HIP runtime themselves. */
+void *mi355_malloc(size_t bytes);
+void  mi355_free(void *dptr);
+int   mi355_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int   mi355_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int   mi355_sync(void *stream);
+/* HIP events on the caller's stream (kernel timing without a host sync per kernel) */
+void *mi355_event_create(void);
+void  mi355_event_destroy(void *event);
+int   mi355_event_record(void *event, void *stream);
+float mi355_event_elapsed_ms(void *start, void *end);   /* waits for `end` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_H264_FRAME_H */

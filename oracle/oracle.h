@@ -18,6 +18,12 @@ void oracle_h264chroma_init(H264ChromaContext *c, int bit_depth);               
 void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc); /* h264pred.c:402 */
 void oracle_videodsp_init(VideoDSPContext *c, int bpc);                               /* videodsp.c:35 */
 void oracle_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int size, int mx, int my, int avg);
+void oracle_h264_qpel2(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int size, int mx, int my, int avg);
+void oracle_h264_chroma_mc2(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int h, int x, int y, int w, int avg);
+/* frame level (oracle_h264frame.c): the mi355_h264_frame pointers are HOST pointers here */
+struct mi355_h264_frame;
+void oracle_h264_recon_frame(const struct mi355_h264_frame *f);
+void oracle_h264_deblock_frame(const struct mi355_h264_frame *f);
 #ifdef __cplusplus
 }
 #endif

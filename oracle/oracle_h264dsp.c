@@ -403,7 +403,7 @@ static inline int half_hv(const uint8_t *s, ptrdiff_t st)
 }
 static inline int ravg(int a, int b) { return (a + b + 1) >> 1; }
 
-void oracle_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t st, int size, int mx, int my, int avg)
+void oracle_h264_qpel2(uint8_t *dst, ptrdiff_t dst_st, const uint8_t *src, ptrdiff_t st, int size, int mx, int my, int avg)
 {
     uint8_t out[16 * 16];
     for (int y = 0; y < size; y++)
@@ -433,7 +433,11 @@ void oracle_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t st, int size, 
         }
     for (int y = 0; y < size; y++)
         for (int x = 0; x < size; x++)
-            dst[x + y * st] = avg ? (uint8_t)ravg(dst[x + y * st], out[x + y * 16]) : out[x + y * 16];
+            dst[x + y * dst_st] = avg ? (uint8_t)ravg(dst[x + y * dst_st], out[x + y * 16]) : out[x + y * 16];
+}
+void oracle_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t st, int size, int mx, int my, int avg)
+{
+    oracle_h264_qpel2(dst, st, src, st, size, mx, my, avg);
 }
 
 #define QP1(op, avg, N, mx, my) \
@@ -464,10 +468,10 @@ void oracle_h264qpel_init(H264QpelContext *c, int bit_depth)
 /* identical to the 4-tap formula, but we mirror the read pattern to stay      */
 /* in-bounds on the same inputs.                                               */
 /* ------------------------------------------------------------------------- */
-static void chroma_mc_n(uint8_t *dst, const uint8_t *src, ptrdiff_t st, int h, int x, int y, int w, int avg)
+void oracle_h264_chroma_mc2(uint8_t *dst, ptrdiff_t dst_st, const uint8_t *src, ptrdiff_t st, int h, int x, int y, int w, int avg)
 {
     int A = (8 - x) * (8 - y), B = x * (8 - y), C = (8 - x) * y, D = x * y;
-    for (int j = 0; j < h; j++, dst += st, src += st)
+    for (int j = 0; j < h; j++, dst += dst_st, src += st)
         for (int i = 0; i < w; i++) {
             int v = A * src[i];
             if (B) v += B * src[i + 1];
@@ -478,8 +482,8 @@ static void chroma_mc_n(uint8_t *dst, const uint8_t *src, ptrdiff_t st, int h, i
         }
 }
 #define CFUNCS(W) \
-static void put_chroma##W(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int x, int y) { chroma_mc_n(d, s, st, h, x, y, W, 0); } \
-static void avg_chroma##W(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int x, int y) { chroma_mc_n(d, s, st, h, x, y, W, 1); }
+static void put_chroma##W(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int x, int y) { oracle_h264_chroma_mc2(d, st, s, st, h, x, y, W, 0); } \
+static void avg_chroma##W(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int x, int y) { oracle_h264_chroma_mc2(d, st, s, st, h, x, y, W, 1); }
 CFUNCS(8) CFUNCS(4) CFUNCS(2)
 
 void oracle_h264chroma_init(H264ChromaContext *c, int bit_depth)

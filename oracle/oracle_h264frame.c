@@ -1,0 +1,459 @@
+/*
+ * oracle_h264frame.c — CPU restatement of the reference's per-macroblock
+ * reconstruction and loop-filter drivers, on the Tier-2 record format of
+ * include/mi355_h264_frame.h (HOST pointers).  TEST INFRASTRUCTURE ONLY.
+ *
+ * Reconstruction follows hl_decode_mb() (libavcodec/h264_mb_template.c:41-257, the
+ * SIMPLE 8-bit 4:2:0 variant) with hl_motion (h264_mc_template.c:64-163),
+ * mc_part_std / mc_part_weighted / mc_dir_part (h264_mb.c:204-471),
+ * hl_decode_mb_predict_luma / hl_decode_mb_idct_luma (h264_mb.c:612-795), one
+ * macroblock at a time in raster order into `recon`, calling the DSP tables of
+ * oracle_h264dsp.c / oracle_h264pred.c exactly where the reference calls its own.
+ * Deblocking follows loop_filter() (h264_slice.c:2198) -> ff_h264_filter_mb()
+ * (h264_loopfilter.c:716-847, progressive non-MBAFF frames) with bS from
+ * filter_mb_dir (:472-713) and check_mv (:442-470), in raster order, in place on
+ * `dst` after copying `recon` (the reference's postpone_filter mode,
+ * h264_slice.c:2570-2586).
+ *
+ * Pinned to the reference decoder by tests/golden/h264_stream_*.npz: records
+ * exported from the reference's own decode of a real bitstream, with its output
+ * pictures (tests/golden/make_stream_golden.py).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/mi355_abi.h"
+#include "../include/mi355_h264_frame.h"
+#include "oracle.h"
+
+static H264DSPContext dsp;
+static H264QpelContext qpel;
+static H264ChromaContext chroma;
+static H264PredContext pred;
+static int tables_ready;
+
+static void ensure_tables(void)
+{
+    if (tables_ready) return;
+    oracle_h264dsp_init(&dsp, 8, 1);
+    oracle_h264qpel_init(&qpel, 8);
+    oracle_h264chroma_init(&chroma, 8);
+    oracle_h264_pred_init(&pred, MI355_AV_CODEC_ID_H264, 8, 1);
+    tables_ready = 1;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 1); }  /* block index -> column (h264dec.h scan8) */
+static inline int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >> 3); }
+
+typedef struct Ctx {
+    const mi355_h264_frame *f;
+    int mb_x, mb_y, mb_xy;
+    const mi355_h264_mb *m;
+    const mi355_h264_slice *sl;
+    int16_t coef[16 * 48];       /* sl->mb layout: luma 0.., Cb 256.., Cr 512.. */
+    uint8_t nnzc[15 * 8];
+    uint8_t bipred[3][16 * 16];  /* sl->bipred_scratchpad */
+    uint8_t emu[21 * 32];
+} Ctx;
+
+/* fetch a w x h block at (x,y) of a plane with border replication: what
+ * emulated_edge_mc hands to the MC functions (h264_mb.c:239-314) */
+static void fetch(uint8_t *out, int ostride, const uint8_t *plane, int stride, int pw, int ph, int x, int y, int w, int h)
+{
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++)
+            out[i + j * ostride] = plane[clampi(x + i, 0, pw - 1) + (size_t)clampi(y + j, 0, ph - 1) * stride];
+}
+
+/* mc_dir_part, h264_mb.c:204-318 (chroma_idc == 1, frame MB).  (bx,by) is the partition origin
+ * inside the MB in luma samples, w x h its luma size, n the 4x4 block index whose MV is used. */
+static void mc_dir_part(Ctx *c, int list, int n_raster, int refn, int bx, int by, int w, int h,
+                        uint8_t *dy, int dys, uint8_t *dcb, uint8_t *dcr, int dcs, int avg)
+{
+    const mi355_h264_frame *f = c->f;
+    const int16_t *mv = f->mv[list] + ((size_t)c->mb_xy * 16 + n_raster) * 2;
+    const int slot = c->sl->ref_slot[list][refn];
+    const int pw = 16 * f->mb_width, ph = 16 * f->mb_height;
+    const int mx = mv[0] + (c->mb_x * 16 + bx) * 4;
+    const int my = mv[1] + (c->mb_y * 16 + by) * 4;
+    /* luma: always go through the clamped window — identical to the in-picture read when no
+     * emulation is needed */
+    fetch(c->emu, 32, f->ref[slot][0], f->dst_stride[0], pw, ph, (mx >> 2) - 2, (my >> 2) - 2, w + 5, h + 5);
+    {
+        /* the reference issues square calls (16,8,4 wide) side by side / stacked */
+        int s = w < h ? w : h;
+        for (int oy = 0; oy < h; oy += s)
+            for (int ox = 0; ox < w; ox += s)
+                oracle_h264_qpel2(dy + ox + oy * dys, dys, c->emu + 2 * 32 + 2 + ox + oy * 32, 32, s, mx & 3, my & 3, avg);
+    }
+    for (int p = 1; p < 3; p++) {
+        uint8_t *d = p == 1 ? dcb : dcr;
+        fetch(c->emu, 32, f->ref[slot][p], f->dst_stride[1], pw >> 1, ph >> 1, mx >> 3, my >> 3, (w >> 1) + 1, (h >> 1) + 1);
+        oracle_h264_chroma_mc2(d, dcs, c->emu, 32, h >> 1, mx & 7, my & 7, w >> 1, avg);
+    }
+}
+
+/* mc_part (h264_mc_template.c:44-62) + mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
+static void mc_part(Ctx *c, int n_raster, int quadrant, int bx, int by, int w, int h, int list0, int list1,
+                    uint8_t *dy, uint8_t *dcb, uint8_t *dcr)
+{
+    const mi355_h264_frame *f = c->f;
+    const mi355_h264_slice *sl = c->sl;
+    const int ys = f->recon_stride[0], cs = f->recon_stride[1];
+    uint8_t *py = dy + bx + by * ys, *pcb = dcb + (bx >> 1) + (by >> 1) * cs, *pcr = dcr + (bx >> 1) + (by >> 1) * cs;
+    const int r0 = c->m->ref_idx[0][quadrant], r1 = c->m->ref_idx[1][quadrant];
+    const int weighted = (sl->use_weight == 2 && list0 && list1 && sl->implicit_weight[r0][r1] != 32) || sl->use_weight == 1;
+    const int widx = w == 16 ? 0 : (w == 8 ? 1 : (w == 4 ? 2 : 3)), cwidx = widx + 1;
+    if (!weighted) {
+        int avg = 0;
+        if (list0) { mc_dir_part(c, 0, n_raster, r0, bx, by, w, h, py, ys, pcb, pcr, cs, 0); avg = 1; }
+        if (list1) mc_dir_part(c, 1, n_raster, r1, bx, by, w, h, py, ys, pcb, pcr, cs, avg);
+        return;
+    }
+    if (list0 && list1) {
+        uint8_t *ty = c->bipred[0], *tcb = c->bipred[1], *tcr = c->bipred[2];
+        mc_dir_part(c, 0, n_raster, r0, bx, by, w, h, py, ys, pcb, pcr, cs, 0);
+        mc_dir_part(c, 1, n_raster, r1, bx, by, w, h, ty, 16, tcb, tcr, 16, 0);
+        /* biweight takes one stride for both operands: stage dst rows into a 16-pitch tile */
+        uint8_t dty[16 * 16], dtc[2][16 * 16];
+        for (int j = 0; j < h; j++) memcpy(dty + 16 * j, py + j * ys, (size_t)w);
+        for (int j = 0; j < h / 2; j++) { memcpy(dtc[0] + 16 * j, pcb + j * cs, (size_t)(w / 2)); memcpy(dtc[1] + 16 * j, pcr + j * cs, (size_t)(w / 2)); }
+        if (sl->use_weight == 2) {
+            int w0 = sl->implicit_weight[r0][r1], w1 = 64 - w0;
+            dsp.biweight_h264_pixels_tab[widx](dty, ty, 16, h, 5, w0, w1, 0);
+            dsp.biweight_h264_pixels_tab[cwidx](dtc[0], tcb, 16, h >> 1, 5, w0, w1, 0);
+            dsp.biweight_h264_pixels_tab[cwidx](dtc[1], tcr, 16, h >> 1, 5, w0, w1, 0);
+        } else {
+            dsp.biweight_h264_pixels_tab[widx](dty, ty, 16, h, sl->luma_log2_weight_denom,
+                                               sl->luma_weight[r0][0][0], sl->luma_weight[r1][1][0],
+                                               sl->luma_weight[r0][0][1] + sl->luma_weight[r1][1][1]);
+            for (int p = 0; p < 2; p++)
+                dsp.biweight_h264_pixels_tab[cwidx](dtc[p], p ? tcr : tcb, 16, h >> 1, sl->chroma_log2_weight_denom,
+                                                    sl->chroma_weight[r0][0][p][0], sl->chroma_weight[r1][1][p][0],
+                                                    sl->chroma_weight[r0][0][p][1] + sl->chroma_weight[r1][1][p][1]);
+        }
+        for (int j = 0; j < h; j++) memcpy(py + j * ys, dty + 16 * j, (size_t)w);
+        for (int j = 0; j < h / 2; j++) { memcpy(pcb + j * cs, dtc[0] + 16 * j, (size_t)(w / 2)); memcpy(pcr + j * cs, dtc[1] + 16 * j, (size_t)(w / 2)); }
+    } else {
+        int list = list1 ? 1 : 0, refn = list ? r1 : r0;
+        mc_dir_part(c, list, n_raster, refn, bx, by, w, h, py, ys, pcb, pcr, cs, 0);
+        dsp.weight_h264_pixels_tab[widx](py, ys, h, sl->luma_log2_weight_denom,
+                                         sl->luma_weight[refn][list][0], sl->luma_weight[refn][list][1]);
+        if (sl->use_weight_chroma) {
+            dsp.weight_h264_pixels_tab[cwidx](pcb, cs, h >> 1, sl->chroma_log2_weight_denom,
+                                              sl->chroma_weight[refn][list][0][0], sl->chroma_weight[refn][list][0][1]);
+            dsp.weight_h264_pixels_tab[cwidx](pcr, cs, h >> 1, sl->chroma_log2_weight_denom,
+                                              sl->chroma_weight[refn][list][1][0], sl->chroma_weight[refn][list][1][1]);
+        }
+    }
+}
+
+/* hl_motion, h264_mc_template.c:64-163 */
+static void hl_motion(Ctx *c, uint8_t *dy, uint8_t *dcb, uint8_t *dcr)
+{
+    const uint32_t t = c->m->mb_type;
+#define DIR(part, list) ((t >> (12 + (part) + 2 * (list))) & 1)
+    if (t & MI355_MB_16x16) {
+        mc_part(c, 0, 0, 0, 0, 16, 16, DIR(0, 0), DIR(0, 1), dy, dcb, dcr);
+    } else if (t & MI355_MB_16x8) {
+        mc_part(c, 0, 0, 0, 0, 16, 8, DIR(0, 0), DIR(0, 1), dy, dcb, dcr);
+        mc_part(c, 8, 2, 0, 8, 16, 8, DIR(1, 0), DIR(1, 1), dy, dcb, dcr);
+    } else if (t & MI355_MB_8x16) {
+        mc_part(c, 0, 0, 0, 0, 8, 16, DIR(0, 0), DIR(0, 1), dy, dcb, dcr);
+        mc_part(c, 2, 1, 8, 0, 8, 16, DIR(1, 0), DIR(1, 1), dy, dcb, dcr);
+    } else {
+        for (int i = 0; i < 4; i++) {
+            const int st = c->m->sub_mb_type[i], shape = st & 3;
+            const int l0 = (st & MI355_SUB_L0) != 0, l1 = (st & MI355_SUB_L1) != 0;
+            const int x = (i & 1) * 8, y = (i >> 1) * 8, n = (x >> 2) + 4 * (y >> 2);
+            if (shape == MI355_SUB_8x8) mc_part(c, n, i, x, y, 8, 8, l0, l1, dy, dcb, dcr);
+            else if (shape == MI355_SUB_8x4) {
+                mc_part(c, n, i, x, y, 8, 4, l0, l1, dy, dcb, dcr);
+                mc_part(c, n + 4, i, x, y + 4, 8, 4, l0, l1, dy, dcb, dcr);
+            } else if (shape == MI355_SUB_4x8) {
+                mc_part(c, n, i, x, y, 4, 8, l0, l1, dy, dcb, dcr);
+                mc_part(c, n + 1, i, x + 4, y, 4, 8, l0, l1, dy, dcb, dcr);
+            } else
+                for (int j = 0; j < 4; j++)
+                    mc_part(c, n + (j & 1) + 4 * (j >> 1), i, x + 4 * (j & 1), y + 4 * (j >> 1), 4, 4, l0, l1, dy, dcb, dcr);
+        }
+    }
+#undef DIR
+}
+
+static void block_offsets(int *off, int ys, int cs)
+{
+    for (int i = 0; i < 16; i++) {
+        off[i] = 4 * blk_x4(i) + 4 * blk_y4(i) * ys;
+        off[16 + i] = off[32 + i] = 4 * blk_x4(i) + 4 * blk_y4(i) * cs;
+    }
+}
+
+/* one macroblock of hl_decode_mb (h264_mb_template.c:41-257) */
+static void recon_mb(Ctx *c)
+{
+    const mi355_h264_frame *f = c->f;
+    const mi355_h264_mb *m = c->m;
+    const int ys = f->recon_stride[0], cs = f->recon_stride[1];
+    uint8_t *dy = f->recon[0] + (size_t)c->mb_y * 16 * ys + c->mb_x * 16;
+    uint8_t *dcb = f->recon[1] + (size_t)c->mb_y * 8 * cs + c->mb_x * 8;
+    uint8_t *dcr = f->recon[2] + (size_t)c->mb_y * 8 * cs + c->mb_x * 8;
+    const int16_t *src = f->coef + (size_t)c->mb_xy * MI355_H264_COEFS_PER_MB;
+    const uint32_t t = m->mb_type;
+    int off[48];
+    block_offsets(off, ys, cs);
+
+    if (t & MI355_MB_INTRA_PCM) {   /* h264_mb_template.c:139-153 */
+        const uint8_t *s = (const uint8_t *)src;
+        for (int i = 0; i < 16; i++) memcpy(dy + i * ys, s + 16 * i, 16);
+        for (int i = 0; i < 8; i++) { memcpy(dcb + i * cs, s + 256 + 8 * i, 8); memcpy(dcr + i * cs, s + 320 + 8 * i, 8); }
+        return;
+    }
+    /* sl->mb image + nnz cache */
+    memset(c->coef, 0, sizeof(c->coef));
+    memcpy(c->coef, src, 256 * 2);
+    memcpy(c->coef + 256, src + 256, 64 * 2);
+    memcpy(c->coef + 512, src + 320, 64 * 2);
+    memset(c->nnzc, 0, sizeof(c->nnzc));
+    for (int i = 0; i < 16; i++) c->nnzc[oracle_scan8(i)] = (m->nnz_mask >> i) & 1 ? 2 : 0;
+    for (int j = 0; j < 4; j++) {
+        c->nnzc[oracle_scan8(16 + j)] = (m->nnz_mask >> (16 + j)) & 1 ? 2 : 0;
+        c->nnzc[oracle_scan8(32 + j)] = (m->nnz_mask >> (20 + j)) & 1 ? 2 : 0;
+    }
+
+    if (t & MI355_MB_INTRA) {
+        pred.pred8x8[m->chroma_pred_mode](dcb, cs);
+        pred.pred8x8[m->chroma_pred_mode](dcr, cs);
+        if (t & MI355_MB_INTRA4x4) {      /* hl_decode_mb_predict_luma, h264_mb.c:626-700 */
+            if (t & MI355_MB_8x8DCT) {
+                for (int i = 0; i < 16; i += 4) {
+                    uint8_t *p = dy + off[i];
+                    pred.pred8x8l[m->intra4x4_pred_mode[i]](p, (m->topleft_samples_available << i) & 0x8000,
+                                                            (m->topright_samples_available << i) & 0x4000, ys);
+                    if (c->nnzc[oracle_scan8(i)]) dsp.h264_idct8_add(p, c->coef + i * 16, ys);
+                }
+            } else {
+                for (int i = 0; i < 16; i++) {
+                    uint8_t *p = dy + off[i];
+                    const int dir = m->intra4x4_pred_mode[i];
+                    uint8_t trbuf[4];
+                    const uint8_t *tr = NULL;
+                    if (dir == DIAG_DOWN_LEFT_PRED || dir == VERT_LEFT_PRED) {
+                        if ((m->topright_samples_available << i) & 0x8000) tr = p + 4 - ys;
+                        else { memset(trbuf, p[3 - ys], 4); tr = trbuf; }
+                    }
+                    pred.pred4x4[dir](p, tr, ys);
+                    if (c->nnzc[oracle_scan8(i)]) dsp.h264_idct_add(p, c->coef + i * 16, ys);
+                }
+            }
+        } else {                          /* Intra16x16, h264_mb.c:701-722 */
+            pred.pred16x16[m->intra16x16_pred_mode](dy, ys);
+            if ((m->nnz_mask >> MI355_NNZ_LUMA_DC) & 1) {
+                int16_t dcin[16];
+                for (int k = 0; k < 16; k++) dcin[k] = c->coef[mi355_luma_dc_slot(k)];
+                dsp.h264_luma_dc_dequant_idct(c->coef, dcin, (int)m->dc_qmul[0]);
+            }
+        }
+    } else {
+        hl_motion(c, dy, dcb, dcr);
+    }
+    /* hl_decode_mb_idct_luma, h264_mb.c:726-795 */
+    if (!(t & MI355_MB_INTRA4x4)) {
+        if (t & MI355_MB_INTRA16x16) dsp.h264_idct_add16intra(dy, off, c->coef, ys, c->nnzc);
+        else if (m->cbp & 15) {
+            if (t & MI355_MB_8x8DCT) dsp.h264_idct8_add4(dy, off, c->coef, ys, c->nnzc);
+            else dsp.h264_idct_add16(dy, off, c->coef, ys, c->nnzc);
+        }
+    }
+    if (m->cbp & 0x30) {                  /* h264_mb_template.c:196-247 */
+        uint8_t *dest[2] = { dcb, dcr };
+        if ((m->nnz_mask >> MI355_NNZ_CB_DC) & 1) dsp.h264_chroma_dc_dequant_idct(c->coef + 256, (int)m->dc_qmul[1]);
+        if ((m->nnz_mask >> MI355_NNZ_CR_DC) & 1) dsp.h264_chroma_dc_dequant_idct(c->coef + 512, (int)m->dc_qmul[2]);
+        dsp.h264_idct_add8(dest, off, c->coef, cs, c->nnzc);
+    }
+}
+
+void oracle_h264_recon_frame(const mi355_h264_frame *f)
+{
+    ensure_tables();
+    Ctx *c = (Ctx *)calloc(1, sizeof(Ctx));
+    c->f = f;
+    for (int y = 0; y < f->mb_height; y++)
+        for (int x = 0; x < f->mb_width; x++) {
+            c->mb_x = x; c->mb_y = y; c->mb_xy = x + y * f->mb_width;
+            c->m = &f->mb[c->mb_xy];
+            c->sl = &f->slices[c->m->slice_id];
+            recon_mb(c);
+        }
+    free(c);
+}
+
+/* ------------------------------------------------------------------------- */
+/* loop filter                                                                 */
+/* ------------------------------------------------------------------------- */
+/* Tables 8-16 / 8-17 of the standard, as the reference stores them between two
+ * 52-entry guard bands (h264_loopfilter.c:41-101): index = qp + offset clamps to 0..51 */
+static const uint8_t alpha_tab[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+    32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255 };
+static const uint8_t beta_tab[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+    9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18 };
+static const int8_t tc0_tab[52][3] = {
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},
+    {1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},{2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},
+    {3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},{9,12,18},{10,13,20},
+    {11,15,23},{13,17,25} };
+
+typedef struct MbView {      /* what fill_filter_caches gathers for one MB (h264_slice.c:2056-2196) */
+    const mi355_h264_mb *m;
+    const mi355_h264_slice *sl;
+    const int16_t *mv[2];    /* 16 raster entries x 2 */
+} MbView;
+
+static MbView view(const mi355_h264_frame *f, int mb_xy)
+{
+    MbView v;
+    v.m = &f->mb[mb_xy];
+    v.sl = &f->slices[v.m->slice_id];
+    v.mv[0] = f->mv[0] ? f->mv[0] + (size_t)mb_xy * 32 : NULL;
+    v.mv[1] = f->mv[1] ? f->mv[1] + (size_t)mb_xy * 32 : NULL;
+    return v;
+}
+/* picture identity of the reference used by 4x4 block (x4,y4) of an MB for a list; -1 = none
+ * (ref_cache after the ref2frm mapping, h264_slice.c:2023-2029) */
+static int ref_id(const MbView *v, int list, int x4, int y4)
+{
+    if (v->m->mb_type & MI355_MB_INTRA) return -1;
+    int r = v->m->ref_idx[list][(x4 >> 1) + 2 * (y4 >> 1)];
+    return r < 0 ? -1 : v->sl->ref_slot[list][r];
+}
+static void mv_of(const MbView *v, int list, int x4, int y4, int out[2])
+{
+    if (!v->mv[list] || ref_id(v, list, x4, y4) < 0) { out[0] = out[1] = 0; return; }
+    out[0] = v->mv[list][(x4 + 4 * y4) * 2];
+    out[1] = v->mv[list][(x4 + 4 * y4) * 2 + 1];
+}
+static int mv_far(const int a[2], const int b[2]) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+
+/* check_mv, h264_loopfilter.c:442-470 (mvy_limit 4: frame macroblocks) */
+static int check_mv(const MbView *p, int px, int py, const MbView *q, int qx, int qy, int list_count)
+{
+    int r0p = ref_id(p, 0, px, py), r0q = ref_id(q, 0, qx, qy), mp[2], mq[2];
+    int v = r0p != r0q;
+    if (!v && r0p != -1) { mv_of(p, 0, px, py, mp); mv_of(q, 0, qx, qy, mq); v = mv_far(mp, mq); }
+    if (list_count == 2) {
+        int r1p = ref_id(p, 1, px, py), r1q = ref_id(q, 1, qx, qy), np[2], nq[2];
+        mv_of(p, 1, px, py, np); mv_of(q, 1, qx, qy, nq);
+        if (!v) v = r1p != r1q || mv_far(np, nq);
+        if (v) {
+            if (r0p != r1q || r1p != r0q) return 1;
+            mv_of(p, 0, px, py, mp); mv_of(q, 0, qx, qy, mq);
+            return mv_far(mp, nq) || mv_far(np, mq);
+        }
+    }
+    return v;
+}
+
+/* filter one 16-sample luma edge + the matching chroma edges: filter_mb_edge{v,h,cv,ch},
+ * h264_loopfilter.c:104-236 */
+static void filter_edge(const mi355_h264_mb *m, const int16_t bS[4], int dir, int edge, int intra_ok,
+                        int qp, int qpc0, int qpc1, uint8_t *y, int ys, uint8_t *cb, uint8_t *cr, int cs)
+{
+    const int a = m->slice_alpha_c0_offset, b = m->slice_beta_offset;
+    for (int plane = 0; plane < 3; plane++) {
+        if (plane && (edge & 1)) break;
+        const int q = plane == 0 ? qp : (plane == 1 ? qpc0 : qpc1);
+        const int ia = clampi(q + a, 0, 51), ib = clampi(q + b, 0, 51);
+        const int alpha = alpha_tab[ia], beta = beta_tab[ib];
+        if (!alpha || !beta) continue;
+        uint8_t *pix = plane == 0 ? y + (dir ? 4 * edge * ys : 4 * edge)
+                                  : (plane == 1 ? cb : cr) + (dir ? 2 * edge * cs : 2 * edge);
+        const int st = plane ? cs : ys;
+        if (bS[0] < 4 || !intra_ok) {
+            int8_t tc[4];
+            for (int i = 0; i < 4; i++) tc[i] = (int8_t)((bS[i] ? tc0_tab[ia][bS[i] - 1] : -1) + (plane ? 1 : 0));
+            if (plane == 0) (dir ? dsp.h264_v_loop_filter_luma : dsp.h264_h_loop_filter_luma)(pix, st, alpha, beta, tc);
+            else (dir ? dsp.h264_v_loop_filter_chroma : dsp.h264_h_loop_filter_chroma)(pix, st, alpha, beta, tc);
+        } else {
+            if (plane == 0) (dir ? dsp.h264_v_loop_filter_luma_intra : dsp.h264_h_loop_filter_luma_intra)(pix, st, alpha, beta);
+            else (dir ? dsp.h264_v_loop_filter_chroma_intra : dsp.h264_h_loop_filter_chroma_intra)(pix, st, alpha, beta);
+        }
+    }
+}
+
+/* ff_h264_filter_mb (h264_loopfilter.c:716) for one frame MB */
+static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
+{
+    const int mb_xy = mb_x + mb_y * f->mb_width;
+    MbView cur = view(f, mb_xy);
+    const mi355_h264_mb *m = cur.m;
+    if (m->flags & MI355_MBF_NO_DEBLOCK) return;
+    const int ys = f->dst_stride[0], cs = f->dst_stride[1];
+    uint8_t *y = f->dst[0] + (size_t)mb_y * 16 * ys + mb_x * 16;
+    uint8_t *cb = f->dst[1] + (size_t)mb_y * 8 * cs + mb_x * 8;
+    uint8_t *cr = f->dst[2] + (size_t)mb_y * 8 * cs + mb_x * 8;
+    const int intra = (m->mb_type & MI355_MB_INTRA) != 0;
+    const int dct8 = (m->mb_type & MI355_MB_8x8DCT) != 0;
+    const uint8_t *cq0 = cur.sl->chroma_qp_table[0], *cq1 = cur.sl->chroma_qp_table[1];
+    for (int dir = 0; dir < 2; dir++) {
+        const int have_n = m->flags & (dir ? MI355_MBF_TOP_EDGE : MI355_MBF_LEFT_EDGE);
+        for (int edge = 0; edge < 4; edge++) {
+            int16_t bS[4];
+            int qp, qc0, qc1;
+            if (edge == 0) {
+                if (!have_n) continue;
+                MbView nb = view(f, dir ? mb_xy - f->mb_width : mb_xy - 1);
+                if (intra || (nb.m->mb_type & MI355_MB_INTRA)) {
+                    bS[0] = bS[1] = bS[2] = bS[3] = 4;      /* frame picture, non-interlaced: :528-533 */
+                } else {
+                    for (int i = 0; i < 4; i++) {
+                        int x4 = dir ? i : 0, y4 = dir ? 0 : i;
+                        int nx = dir ? i : 3, ny = dir ? 3 : i;
+                        int nz_c = (m->nnz_mask >> 0) , nz_n = nb.m->nnz_mask;
+                        /* nnz_mask is indexed by block index (scan order): convert raster -> index */
+                        int bi_c = (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1);
+                        int bi_n = (nx & 1) + 2 * (ny & 1) + 4 * (nx >> 1) + 8 * (ny >> 1);
+                        if (((nz_c >> bi_c) | (nz_n >> bi_n)) & 1) bS[i] = 2;
+                        else bS[i] = (int16_t)check_mv(&cur, x4, y4, &nb, nx, ny, cur.sl->list_count);
+                    }
+                }
+                if (!(bS[0] + bS[1] + bS[2] + bS[3])) continue;
+                qp = (m->qp + nb.m->qp + 1) >> 1;
+                qc0 = (cq0[m->qp] + cq0[nb.m->qp] + 1) >> 1;   /* current slice's table for both (:628-629) */
+                qc1 = (cq1[m->qp] + cq1[nb.m->qp] + 1) >> 1;
+            } else {
+                if (dct8 && (edge & 1)) continue;
+                if (intra) bS[0] = bS[1] = bS[2] = bS[3] = 3;
+                else {
+                    for (int i = 0; i < 4; i++) {
+                        int x4 = dir ? i : edge, y4 = dir ? edge : i;
+                        int nx = dir ? i : edge - 1, ny = dir ? edge - 1 : i;
+                        int bi_c = (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1);
+                        int bi_n = (nx & 1) + 2 * (ny & 1) + 4 * (nx >> 1) + 8 * (ny >> 1);
+                        if (((m->nnz_mask >> bi_c) | (m->nnz_mask >> bi_n)) & 1) bS[i] = 2;
+                        else bS[i] = (int16_t)check_mv(&cur, x4, y4, &cur, nx, ny, cur.sl->list_count);
+                    }
+                    if (!(bS[0] + bS[1] + bS[2] + bS[3])) continue;
+                }
+                qp = m->qp; qc0 = cq0[m->qp]; qc1 = cq1[m->qp];
+            }
+            filter_edge(m, bS, dir, edge, edge == 0, qp, qc0, qc1, y, ys, cb, cr, cs);
+        }
+    }
+}
+
+void oracle_h264_deblock_frame(const mi355_h264_frame *f)
+{
+    ensure_tables();
+    for (int p = 0; p < 3; p++) {
+        int rows = (p ? 8 : 16) * f->mb_height, w = (p ? 8 : 16) * f->mb_width;
+        for (int r = 0; r < rows; r++)
+            memcpy(f->dst[p] + (size_t)r * f->dst_stride[p ? 1 : 0], f->recon[p] + (size_t)r * f->recon_stride[p ? 1 : 0], (size_t)w);
+    }
+    for (int y = 0; y < f->mb_height; y++)
+        for (int x = 0; x < f->mb_width; x++)
+            filter_mb(f, x, y);
+}

@@ -1,0 +1,608 @@
+"""Synthetic H.264 macroblock records for the Tier-2 frame path
+and ctypes/numpy mirrors of include/mi355_h264_frame.h.
+
+`synth_frames()` builds well-formed pictures: every field is what the reference's
+slice decoder would hold when it calls ff_h264_hl_decode_mb() (mb_type bits, mv/ref per
+4x4 block with partition replication, dequantised transposed coefficients, nnz masks,
+availability masks and remapped intra modes).  Inputs come from splitmix64 only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from rng import SplitMix64
+
+MB_DT = np.dtype([
+    ("mb_type", "<u4"), ("nnz_mask", "<u4"), ("cbp", "<u2"), ("qp", "i1"), ("flags", "u1"),
+    ("alpha", "i1"), ("beta", "i1"), ("i16mode", "u1"), ("chroma_mode", "u1"),
+    ("topleft", "<u2"), ("topright", "<u2"), ("sub", "u1", 4), ("ref_idx", "i1", (2, 4)),
+    ("dc_qmul", "<u4", 3), ("slice_id", "u1"), ("intra_level", "u1"), ("rsv", "u1", 2),
+    ("i4mode", "i1", 16)])
+assert MB_DT.itemsize == 64
+
+MAX_REFS, MAX_SLOTS = 16, 32
+SLICE_DT = np.dtype([
+    ("use_weight", "u1"), ("use_weight_chroma", "u1"), ("luma_denom", "u1"), ("chroma_denom", "u1"),
+    ("list_count", "u1"), ("rsv", "u1", 3), ("ref_slot", "u1", (2, MAX_REFS)),
+    ("luma_weight", "<i2", (MAX_REFS, 2, 2)), ("chroma_weight", "<i2", (MAX_REFS, 2, 2, 2)),
+    ("implicit_weight", "<i2", (MAX_REFS, MAX_REFS)), ("chroma_qp_table", "u1", (2, 52))])
+assert SLICE_DT.itemsize == 1040
+
+
+class Frame(C.Structure):
+    _fields_ = [("mb_width", C.c_int32), ("mb_height", C.c_int32),
+                ("dst", C.c_void_p * 3), ("dst_stride", C.c_int32 * 2),
+                ("recon", C.c_void_p * 3), ("recon_stride", C.c_int32 * 2),
+                ("ref", (C.c_void_p * 3) * MAX_SLOTS),
+                ("mb", C.c_void_p), ("mv", C.c_void_p * 2), ("coef", C.c_void_p),
+                ("slices", C.c_void_p), ("nslices", C.c_int32), ("max_intra_level", C.c_int32),
+                ("intra_list", C.c_void_p), ("intra_level_start", C.c_void_p)]
+
+
+assert C.sizeof(Frame) == 904
+
+# mb_type bits
+I4, I16, PCM, T16x16, T16x8, T8x16, T8x8 = 1, 2, 4, 8, 16, 32, 64
+P0L0, P1L0, P0L1, P1L1, DCT8 = 0x1000, 0x2000, 0x4000, 0x8000, 0x01000000
+F_LEFT, F_TOP, F_NODB = 1, 2, 4
+ZIGZAG4 = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+# the standard's chroma QP mapping (Table 8-15) for chroma_qp_index_offset = 0
+CHROMA_QP = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]
+DQ0 = [10, 11, 13, 14, 16, 18]
+
+
+def blk_xy(i):
+    return (i & 1) + 2 * ((i >> 2) & 1), ((i >> 1) & 1) + 2 * (i >> 3)
+
+
+def blk_index(x4, y4):
+    return (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1)
+
+
+def luma_dc_slot(k):
+    return 16 * ([0, 2, 8, 10][k >> 2] + [0, 1, 4, 5][k & 3])
+
+
+def dc_qmul(qp):
+    return (DQ0[qp % 6] * 16) << (qp // 6 + 2)
+
+
+class FrameSet:
+    """F independent pictures of identical geometry, host side (numpy)."""
+
+    def __init__(self, nframes, mb_w, mb_h, nrefs):
+        self.F, self.mb_w, self.mb_h, self.nrefs = nframes, mb_w, mb_h, nrefs
+        nmb = mb_w * mb_h
+        self.W, self.H = 16 * mb_w, 16 * mb_h
+        self.mb = np.zeros((nframes, nmb), MB_DT)
+        self.mv = np.zeros((2, nframes, nmb, 16, 2), np.int16)
+        self.coef = np.zeros((nframes, nmb, 384), np.int16)
+        self.slices = np.zeros((nframes, 1), SLICE_DT)
+        self.refs = [[None] * nrefs for _ in range(nframes)]    # [f][slot] -> (Y, Cb, Cr)
+        self.use_l1 = False
+        self.max_intra_level = 0
+        self.max_level_width = 0
+        self.intra_list = [None] * nframes       # per frame: uint32 MB indices sorted by level
+        self.intra_start = [None] * nframes      # per frame: int32 offsets [max_level + 1]
+
+    def planes(self):
+        return [np.zeros((self.F, self.H, self.W), np.uint8), np.zeros((self.F, self.H // 2, self.W // 2), np.uint8),
+                np.zeros((self.F, self.H // 2, self.W // 2), np.uint8)]
+
+
+COEF_B = [24]   # Laplace scale of the AC levels (SURVEY.md §8d uses 24)
+
+
+def _gen_block_coefs(r, n, kind):
+    """n 4x4 blocks -> (coefs[n,16], coded[n]).  §8d: coded w.p. 0.5; DC-only w.p. 0.25 else k~U{1..16}
+    non-zeros at the first k zig-zag positions, Laplace(24) clipped to +-2047."""
+    coded = r.uniform(n) < (0.5 if kind != "dense" else 0.9)
+    dconly = r.uniform(n) < 0.25
+    k = r.randint(1, 16, n)
+    k = np.where(dconly, 1, k)
+    vals = r.laplace_int(COEF_B[0], (n, 16), 2047)
+    vals = np.where(vals == 0, 1, vals)
+    zz = np.array(ZIGZAG4)
+    out = np.zeros((n, 16), np.int16)
+    pos_rank = np.empty(16, np.int64)
+    pos_rank[zz] = np.arange(16)
+    keep = (pos_rank[None, :] < k[:, None]) & coded[:, None]
+    out[keep] = vals[keep].astype(np.int16)
+    return out, coded
+
+
+def _avail_masks(top, left, topleft, topright):
+    tl, tr = 0xFFFF, 0xEEEA
+    if not top:
+        tl, tr = 0xB3FF, 0x26EA
+    if not left:
+        tl &= 0xDF5F
+    if not topleft:
+        tl &= 0x7FFF
+    if not topright:
+        tr &= 0xFBFF
+    return tl, tr
+
+
+def _ref_plane(r, h, w, kind):
+    if kind == "noise":
+        return r.u8((h, w))
+    # smooth: gentle gradient + small noise, so the loop-filter thresholds are actually met
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = r.randint(60, 180)
+    a = base + (xx * r.randint(-3, 3)) // 8 + (yy * r.randint(-3, 3)) // 8 + r.randint(-3, 3, (h, w))
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac=0.0, bframes=False,
+                 weighted=0, dct8_frac=0.0, mv_range=64, offsets=False, pcm_frac=0.0, refs="noise", coef_b=24):
+    """mix: 'p16' (all 16x16), 'mixed' (all partition shapes).  Returns a FrameSet."""
+    fs = FrameSet(nframes, mb_w, mb_h, nrefs)
+    r = SplitMix64(seed)
+    nmb = mb_w * mb_h
+    fs.use_l1 = bframes
+    COEF_B[0] = coef_b
+    for f in range(nframes):
+        for s in range(nrefs):
+            fs.refs[f][s] = (_ref_plane(r, fs.H, fs.W, refs), _ref_plane(r, fs.H // 2, fs.W // 2, refs),
+                             _ref_plane(r, fs.H // 2, fs.W // 2, refs))
+        sl = fs.slices[f, 0]
+        sl["list_count"] = 2 if bframes else 1
+        sl["ref_slot"][0, :nrefs] = np.arange(nrefs)
+        sl["ref_slot"][1, :nrefs] = np.arange(nrefs)[::-1]
+        sl["chroma_qp_table"][0] = CHROMA_QP
+        sl["chroma_qp_table"][1] = CHROMA_QP
+        sl["use_weight"] = weighted
+        if weighted:
+            sl["use_weight_chroma"] = 1
+            sl["luma_denom"], sl["chroma_denom"] = r.randint(0, 7), r.randint(0, 7)
+            sl["luma_weight"] = r.randint(-128, 127, (MAX_REFS, 2, 2))
+            sl["chroma_weight"] = r.randint(-128, 127, (MAX_REFS, 2, 2, 2))
+            iw = r.randint(-64, 128, (MAX_REFS, MAX_REFS))
+            iw[r.randint(0, 1, (MAX_REFS, MAX_REFS)) == 1] = 32
+            sl["implicit_weight"] = iw
+        is_intra = r.uniform(nmb) < intra_frac
+        a_off = 2 * r.randint(-3, 3) if offsets else 0
+        b_off = 2 * r.randint(-3, 3) if offsets else 0
+        for m in range(nmb):
+            mx, my = m % mb_w, m // mb_w
+            rec = fs.mb[f, m]
+            rec["qp"] = qp = r.randint(20, 40)
+            rec["alpha"], rec["beta"] = a_off, b_off
+            rec["flags"] = (F_LEFT if mx else 0) | (F_TOP if my else 0)
+            qpc = CHROMA_QP[qp]
+            intra = bool(is_intra[m])
+            rec["dc_qmul"] = (dc_qmul(qp), dc_qmul(qpc), dc_qmul(qpc))
+            rec["ref_idx"] = -1
+            t = 0
+            use8 = False
+            if intra:
+                top, left = my > 0, mx > 0
+                tl, tr = _avail_masks(top, left, top and left, top and mx + 1 < mb_w)
+                rec["topleft"], rec["topright"] = tl, tr
+                sel = r.uniform()
+                both = top and left
+                c16 = [0, 1, 2, 3] if both else ([1, 4] if left else ([2, 5] if top else [6]))
+                rec["chroma_mode"] = c16[r.randint(0, len(c16) - 1)]
+                if sel < pcm_frac:
+                    t = PCM
+                elif sel < 0.4:
+                    t = I16
+                    rec["i16mode"] = c16[r.randint(0, len(c16) - 1)]
+                else:
+                    t = I4
+                    use8 = r.uniform() < 0.4
+                    if use8:
+                        t |= DCT8
+                    for i in (range(0, 16, 4) if use8 else range(16)):
+                        x4, y4 = blk_xy(i)
+                        btop = top or y4 > 0
+                        bleft = left or x4 > 0
+                        btl = bool((tl << i) & 0x8000)
+                        if btop and bleft:
+                            cand = [0, 1, 2, 3, 7, 8] + ([4, 5, 6] if btl else [])
+                        elif bleft:
+                            cand = [1, 8, 9]
+                        elif btop:
+                            cand = [0, 3, 7, 10]
+                        else:
+                            cand = [11]
+                        rec["i4mode"][i] = cand[r.randint(0, len(cand) - 1)]
+            else:
+                shape = 0 if mix == "p16" else r.randint(0, 3)
+                nl = 2 if bframes else 1
+
+                def pick_dir():
+                    return 1 if not bframes else r.randint(1, 3)     # bit0 L0, bit1 L1
+
+                def set_part(x4, y4, w4, h4, d, quadrants):
+                    for l in range(nl):
+                        if not (d >> l) & 1:
+                            continue
+                        ref = r.randint(0, nrefs - 1)
+                        mv = r.randint(-mv_range, mv_range - 1, 2)
+                        for q in quadrants:
+                            rec["ref_idx"][l][q] = ref
+                        for yy in range(y4, y4 + h4):
+                            for xx in range(x4, x4 + w4):
+                                fs.mv[l, f, m, xx + 4 * yy] = mv
+                if shape == 0:
+                    d = pick_dir()
+                    t = T16x16 | (P0L0 if d & 1 else 0) | (P0L1 if d & 2 else 0)
+                    set_part(0, 0, 4, 4, d, [0, 1, 2, 3])
+                elif shape == 1:
+                    d0, d1 = pick_dir(), pick_dir()
+                    t = T16x8 | (P0L0 if d0 & 1 else 0) | (P0L1 if d0 & 2 else 0) | (P1L0 if d1 & 1 else 0) | (P1L1 if d1 & 2 else 0)
+                    set_part(0, 0, 4, 2, d0, [0, 1])
+                    set_part(0, 2, 4, 2, d1, [2, 3])
+                elif shape == 2:
+                    d0, d1 = pick_dir(), pick_dir()
+                    t = T8x16 | (P0L0 if d0 & 1 else 0) | (P0L1 if d0 & 2 else 0) | (P1L0 if d1 & 1 else 0) | (P1L1 if d1 & 2 else 0)
+                    set_part(0, 0, 2, 4, d0, [0, 2])
+                    set_part(2, 0, 2, 4, d1, [1, 3])
+                else:
+                    t = T8x8
+                    anyl = [0, 0]
+                    for q in range(4):
+                        d = pick_dir()
+                        sub = r.randint(0, 3)
+                        rec["sub"][q] = sub | (0x10 if d & 1 else 0) | (0x20 if d & 2 else 0)
+                        qx, qy = 2 * (q & 1), 2 * (q >> 1)
+                        # all sub-partitions of a quadrant share the reference (one ref_idx per 8x8)
+                        refs = [r.randint(0, nrefs - 1) for _ in range(nl)]
+                        parts = {0: [(0, 0, 2, 2)], 1: [(0, 0, 2, 1), (0, 1, 2, 1)], 2: [(0, 0, 1, 2), (1, 0, 1, 2)],
+                                 3: [(0, 0, 1, 1), (1, 0, 1, 1), (0, 1, 1, 1), (1, 1, 1, 1)]}[sub]
+                        for l in range(nl):
+                            if not (d >> l) & 1:
+                                continue
+                            anyl[l] = 1
+                            rec["ref_idx"][l][q] = refs[l]
+                            for (px, py, pw, ph) in parts:
+                                mv = r.randint(-mv_range, mv_range - 1, 2)
+                                for yy in range(qy + py, qy + py + ph):
+                                    for xx in range(qx + px, qx + px + pw):
+                                        fs.mv[l, f, m, xx + 4 * yy] = mv
+                    t |= (P0L0 | P1L0 if anyl[0] else 0) | (P0L1 | P1L1 if anyl[1] else 0)
+                if shape < 3 or all((rec["sub"][q] & 3) == 0 for q in range(4)):
+                    use8 = r.uniform() < dct8_frac
+                    if use8:
+                        t |= DCT8
+            rec["mb_type"] = t
+            if t & PCM:
+                fs.coef[f, m].view(np.uint8)[:384] = r.u8(384)
+                rec["qp"] = 0
+                rec["cbp"] = 0x2F
+                rec["nnz_mask"] = 0xFFFFFF
+                continue
+            # residual
+            mask = 0
+            cf = fs.coef[f, m]
+            if use8:
+                for q in range(4):
+                    if r.uniform() < 0.5:
+                        blk = np.zeros(64, np.int16)
+                        k = 1 if r.uniform() < 0.25 else r.randint(1, 64)
+                        idx = np.argsort(r.uniform(64) + np.arange(64) * 0.08)[:k]
+                        v = r.laplace_int(24, k, 2047)
+                        blk[idx] = np.where(v == 0, 1, v)
+                        if k == 1:
+                            blk[:] = 0
+                            blk[0] = v[0] if v[0] else 7
+                        cf[q * 64:(q + 1) * 64] = blk
+                        mask |= 0xF << (4 * q)
+            else:
+                blks, coded = _gen_block_coefs(r, 16, "sparse")
+                if t & I16:
+                    blks[:, 0] = 0      # DC travels separately for Intra16x16
+                    coded &= (blks != 0).any(axis=1)
+                cf[:256] = blks.reshape(-1)
+                for i in range(16):
+                    if coded[i]:
+                        mask |= 1 << i
+            if t & I16 and r.uniform() < 0.8:
+                lv = r.laplace_int(40, 16, 2047)
+                for k in range(16):
+                    cf[luma_dc_slot(k)] = lv[k]
+                if lv.any():
+                    mask |= 1 << 24
+            cmode = r.randint(0, 2)
+            if cmode:
+                dcs = r.laplace_int(30, 8, 2047)
+                if cmode == 2:
+                    blks, coded = _gen_block_coefs(r, 8, "sparse")
+                    blks[:, 0] = 0
+                    coded &= (blks != 0).any(axis=1)
+                    cf[256:384] = blks.reshape(-1)
+                    for j in range(8):
+                        if coded[j]:
+                            mask |= 1 << (16 + j)
+                    if not coded.any():
+                        cmode = 1
+                for j in range(8):
+                    cf[256 + 16 * j] = dcs[j]
+                if dcs[:4].any():
+                    mask |= 1 << 25
+                if dcs[4:].any():
+                    mask |= 1 << 26
+                if not dcs.any() and cmode == 1:
+                    cmode = 0
+            cbp = cmode << 4
+            for q in range(4):
+                if (mask >> (4 * q)) & 0xF:
+                    cbp |= 1 << q
+            if t & I16 and (mask & 0xFFFF):
+                cbp |= 15
+            rec["cbp"] = cbp
+            rec["nnz_mask"] = mask
+        fs.max_intra_level = max(fs.max_intra_level, intra_schedule(fs, f))
+    return fs
+
+
+def intra_schedule(fs, f):
+    """python twin of mi355_h264_intra_schedule() (host helper of the C ABI)"""
+    mx = intra_levels(fs.mb[f], fs.mb_w, fs.mb_h)
+    lv = fs.mb[f]["intra_level"].astype(np.int64)
+    order = [np.nonzero(lv == l)[0] for l in range(1, mx + 1)]
+    fs.intra_list[f] = np.concatenate(order).astype(np.uint32) if order else np.zeros(0, np.uint32)
+    fs.intra_start[f] = np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32)
+    if order:
+        fs.max_level_width = max(fs.max_level_width, max(len(o) for o in order))
+    return mx
+
+
+def intra_levels(mb, mb_w, mb_h):
+    mx = 0
+    for y in range(mb_h):
+        for x in range(mb_w):
+            m = mb[x + y * mb_w]
+            if not (m["mb_type"] & 7):
+                m["intra_level"] = 0
+                continue
+            lv = 0
+            for (dx, dy) in ((-1, 0), (-1, -1), (0, -1), (1, -1)):
+                nx, ny = x + dx, y + dy
+                if 0 <= nx < mb_w and 0 <= ny < mb_h:
+                    lv = max(lv, int(mb[nx + ny * mb_w]["intra_level"]))
+            m["intra_level"] = lv + 1
+            mx = max(mx, lv + 1)
+    return mx
+
+
+def host_frames(fs, recon, dst):
+    """ctypes Frame array whose pointers are HOST addresses into fs / recon / dst (for the oracle)."""
+    arr = (Frame * fs.F)()
+    keep = []
+    for f in range(fs.F):
+        fr = arr[f]
+        fr.mb_width, fr.mb_height = fs.mb_w, fs.mb_h
+        for p in range(3):
+            fr.dst[p] = dst[p][f].ctypes.data
+            fr.recon[p] = recon[p][f].ctypes.data
+        fr.dst_stride[0], fr.dst_stride[1] = fs.W, fs.W // 2
+        fr.recon_stride[0], fr.recon_stride[1] = fs.W, fs.W // 2
+        for s in range(fs.nrefs):
+            for p in range(3):
+                fr.ref[s][p] = fs.refs[f][s][p].ctypes.data
+        fr.mb = fs.mb[f].ctypes.data
+        fr.mv[0] = fs.mv[0, f].ctypes.data
+        fr.mv[1] = fs.mv[1, f].ctypes.data if fs.use_l1 else None
+        fr.coef = fs.coef[f].ctypes.data
+        fr.slices = fs.slices[f].ctypes.data
+        fr.nslices = 1
+        fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
+        fr.intra_list = fs.intra_list[f].ctypes.data
+        fr.intra_level_start = fs.intra_start[f].ctypes.data
+    return arr, keep
+
+
+def run_oracle(oracle, fs, deblock=True):
+    """Reference-order reconstruction (+ loop filter) on the CPU oracle; returns (recon, dst) plane lists."""
+    recon, dst = fs.planes(), fs.planes()
+    arr, _ = host_frames(fs, recon, dst)
+    lib = oracle.lib
+    lib.oracle_h264_recon_frame.restype = None
+    lib.oracle_h264_deblock_frame.restype = None
+    for f in range(fs.F):
+        lib.oracle_h264_recon_frame(C.byref(arr[f]))
+        if deblock:
+            lib.oracle_h264_deblock_frame(C.byref(arr[f]))
+    return recon, dst
+
+
+class DeviceFrames:
+    """Uploads a FrameSet through the C ABI's memory helpers and builds device descriptors."""
+
+    def __init__(self, prov, fs):
+        self.lib, self.fs = prov.lib, fs
+        lib = self.lib
+        lib.mi355_malloc.restype = C.c_void_p
+        lib.mi355_malloc.argtypes = [C.c_size_t]
+        lib.mi355_free.argtypes = [C.c_void_p]
+        lib.mi355_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.bufs = []
+        self.mb = self.up(fs.mb)
+        self.mv0 = self.up(fs.mv[0])
+        self.mv1 = self.up(fs.mv[1]) if fs.use_l1 else None
+        self.coef = self.up(fs.coef)
+        self.slices = self.up(fs.slices)
+        ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
+        self.fsz = ysz + 2 * csz
+        self.recon = self.alloc(fs.F * self.fsz)
+        self.dst = self.alloc(fs.F * self.fsz)
+        self.refs = self.alloc(fs.F * fs.nrefs * self.fsz)
+        for f in range(fs.F):
+            for s in range(fs.nrefs):
+                base = self.refs + (f * fs.nrefs + s) * self.fsz
+                y, cb, cr = fs.refs[f][s]
+                self.h2d(base, y)
+                self.h2d(base + ysz, cb)
+                self.h2d(base + ysz + csz, cr)
+        arr = (Frame * fs.F)()
+        nmb = fs.mb_w * fs.mb_h
+        for f in range(fs.F):
+            fr = arr[f]
+            fr.mb_width, fr.mb_height = fs.mb_w, fs.mb_h
+            for kind, base0 in (("dst", self.dst), ("recon", self.recon)):
+                base = base0 + f * self.fsz
+                a = getattr(fr, kind)
+                a[0], a[1], a[2] = base, base + ysz, base + ysz + csz
+            fr.dst_stride[0], fr.dst_stride[1] = fs.W, fs.W // 2
+            fr.recon_stride[0], fr.recon_stride[1] = fs.W, fs.W // 2
+            for s in range(fs.nrefs):
+                base = self.refs + (f * fs.nrefs + s) * self.fsz
+                fr.ref[s][0], fr.ref[s][1], fr.ref[s][2] = base, base + ysz, base + ysz + csz
+            fr.mb = self.mb + f * nmb * 64
+            fr.mv[0] = self.mv0 + f * nmb * 64
+            fr.mv[1] = (self.mv1 + f * nmb * 64) if self.mv1 else None
+            fr.coef = self.coef + f * nmb * 768
+            fr.slices = self.slices + f * SLICE_DT.itemsize
+            fr.nslices = 1
+            fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
+            fr.intra_list = self.up(fs.intra_list[f]) if len(fs.intra_list[f]) else None
+            fr.intra_level_start = self.up(fs.intra_start[f])
+        self.host_desc = arr
+        self.d_desc = self.alloc(C.sizeof(arr))
+        self.lib.mi355_memcpy_h2d(self.d_desc, C.addressof(arr), C.sizeof(arr))
+
+    def alloc(self, n):
+        p = self.lib.mi355_malloc(n)
+        assert p, "device allocation failed"
+        self.bufs.append(p)
+        return p
+
+    def h2d(self, dptr, a):
+        a = np.ascontiguousarray(a)
+        self.lib.mi355_memcpy_h2d(dptr, a.ctypes.data, a.nbytes)
+
+    def up(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.alloc(a.nbytes)
+        self.lib.mi355_memcpy_h2d(p, a.ctypes.data, a.nbytes)
+        return p
+
+    def fetch(self, base):
+        fs = self.fs
+        raw = np.empty(fs.F * self.fsz, np.uint8)
+        self.lib.mi355_memcpy_d2h(raw.ctypes.data, base, raw.nbytes)
+        raw = raw.reshape(fs.F, self.fsz)
+        ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
+        return [raw[:, :ysz].reshape(fs.F, fs.H, fs.W), raw[:, ysz:ysz + csz].reshape(fs.F, fs.H // 2, fs.W // 2),
+                raw[:, ysz + csz:].reshape(fs.F, fs.H // 2, fs.W // 2)]
+
+    def decode(self, stream=None):
+        fs = self.fs
+        fn = self.lib.mi355_h264_decode_frames_dev
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rc = fn(self.d_desc, fs.F, fs.mb_w, fs.mb_h, fs.max_intra_level, fs.max_level_width, stream)
+        assert rc == 0, rc
+        self.lib.mi355_sync.restype = C.c_int
+        assert self.lib.mi355_sync(stream) == 0
+
+    def free(self):
+        for p in self.bufs:
+            self.lib.mi355_free(p)
+        self.bufs = []
+
+
+def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05, mv_range=64, lib=None):
+    """Vectorised generator for the benchmark workload (headline variant):
+    P pictures, one 16x16 partition per inter MB, `intra_frac` Intra16x16 MBs (they force bS 3/4 edges),
+    ref_idx ~ U{0..nrefs-1}, mv ~ U[-mv_range, mv_range) quarter samples, 24 4x4 blocks coded w.p. 0.5.
+    `lib`: a loaded libmi355dsp (its host helper mi355_h264_intra_schedule builds the intra schedule)."""
+    fs = FrameSet(nframes, mb_w, mb_h, nrefs)
+    r = SplitMix64(seed)
+    nmb = mb_w * mb_h
+    N = nframes * nmb
+    for f in range(nframes):
+        for s in range(nrefs):
+            fs.refs[f][s] = (r.u8((fs.H, fs.W)), r.u8((fs.H // 2, fs.W // 2)), r.u8((fs.H // 2, fs.W // 2)))
+    sl = fs.slices[:, 0]
+    sl["list_count"] = 1
+    sl["ref_slot"][:, 0, :nrefs] = np.arange(nrefs)
+    sl["ref_slot"][:, 1, :nrefs] = np.arange(nrefs)
+    sl["chroma_qp_table"][:, 0] = CHROMA_QP
+    sl["chroma_qp_table"][:, 1] = CHROMA_QP
+    mb = fs.mb.reshape(N)
+    mbx = np.tile(np.arange(nmb) % mb_w, nframes)
+    mby = np.tile(np.arange(nmb) // mb_w, nframes)
+    qp = r.randint(20, 40, N)
+    mb["qp"] = qp
+    mb["flags"] = (mbx > 0) * F_LEFT | (mby > 0) * F_TOP
+    qpc = np.array(CHROMA_QP)[qp]
+    dq = np.array(DQ0)
+    mb["dc_qmul"][:, 0] = (dq[qp % 6] * 16) << (qp // 6 + 2)
+    mb["dc_qmul"][:, 1] = mb["dc_qmul"][:, 2] = (dq[qpc % 6] * 16) << (qpc // 6 + 2)
+    intra = r.uniform(N) < intra_frac
+    top, left = mby > 0, mbx > 0
+    # Intra16x16 / chroma modes allowed by availability: both -> {DC,H,V,plane}; left only -> {H,LEFT_DC};
+    # top only -> {V,TOP_DC}; none -> DC_128
+    pick = r.randint(0, 3, (2, N))
+    both = top & left
+    mode = np.where(both, pick, np.where(left, np.where(pick & 1, 1, 4), np.where(top, np.where(pick & 1, 2, 5), 6)))
+    mb["i16mode"] = np.where(intra, mode[0], 0)
+    mb["chroma_mode"] = np.where(intra, mode[1], 0)
+    tl = np.where(top, 0xFFFF, 0xB3FF)
+    tl = np.where(left, tl, tl & 0xDF5F)
+    tl = np.where(top & left, tl, tl & 0x7FFF)
+    tr = np.where(top, 0xEEEA, 0x26EA)
+    tr = np.where(top & (mbx + 1 < mb_w), tr, tr & 0xFBFF)
+    mb["topleft"] = np.where(intra, tl, 0)
+    mb["topright"] = np.where(intra, tr, 0)
+    mb["mb_type"] = np.where(intra, I16, T16x16 | P0L0)
+    ref = r.randint(0, nrefs - 1, N)
+    mb["ref_idx"][:, 0, :] = np.where(intra, -1, ref)[:, None]
+    mb["ref_idx"][:, 1, :] = -1
+    mv = r.randint(-mv_range, mv_range - 1, (N, 2))
+    mv[intra] = 0
+    fs.mv[0].reshape(N, 16, 2)[:] = mv[:, None, :]
+    # residual: 24 blocks per MB
+    blks, coded = _gen_block_coefs(r, N * 24, "sparse")
+    blks = blks.reshape(N, 24, 16)
+    coded = coded.reshape(N, 24)
+    # chroma DC levels travel through the 2x2 transform; Intra16x16 luma DC through the 4x4 one
+    blks[:, 16:, 0] = 0
+    blks[intra, :16, 0] = 0
+    coded &= (blks != 0).any(axis=2)
+    cmode = r.randint(0, 2, N)
+    cdc = r.laplace_int(30, (N, 8), 2047)
+    cdc[cmode == 0] = 0
+    blks[cmode < 2, 16:, :] = 0
+    coded[cmode < 2, 16:] = False
+    blks[:, 16:, 0] = cdc
+    ldc = r.laplace_int(40, (N, 16), 2047)
+    has_ldc = intra & (r.uniform(N) < 0.8)
+    slots = np.array([luma_dc_slot(k) for k in range(16)])
+    cf = fs.coef.reshape(N, 384)
+    cf[:] = blks.reshape(N, 384)
+    ii = np.nonzero(has_ldc)[0]
+    cf[ii[:, None], slots[None, :]] = ldc[ii]
+    mask = (coded.astype(np.uint32) << np.arange(24, dtype=np.uint32)[None, :]).sum(axis=1).astype(np.uint32)
+    mask |= (has_ldc & ldc.any(axis=1)).astype(np.uint32) << 24
+    mask |= cdc[:, :4].any(axis=1).astype(np.uint32) << 25
+    mask |= cdc[:, 4:].any(axis=1).astype(np.uint32) << 26
+    mb["nnz_mask"] = mask
+    chroma_cbp = np.where(coded[:, 16:].any(axis=1), 2, np.where(cdc.any(axis=1), 1, 0))
+    cbp = chroma_cbp << 4
+    for q in range(4):
+        cbp |= ((mask >> (4 * q)) & 0xF != 0).astype(np.int64) << q
+    cbp = np.where(intra & ((mask & 0xFFFF) != 0), cbp | 15, cbp)
+    mb["cbp"] = cbp
+    # intra schedule through the library's host helper when available
+    for f in range(nframes):
+        if lib is not None:
+            lst = np.zeros(nmb, np.uint32)
+            start = np.zeros(mb_w + 2 * mb_h + 2, np.int32)
+            width = C.c_int(0)
+            fn = lib.mi355_h264_intra_schedule
+            fn.restype = C.c_int
+            mx = fn(C.c_void_p(fs.mb[f].ctypes.data), mb_w, mb_h, C.c_void_p(lst.ctypes.data),
+                    C.c_void_p(start.ctypes.data), C.byref(width))
+            fs.intra_list[f] = lst[:start[mx]].copy()
+            fs.intra_start[f] = start[:mx + 1].copy()
+            fs.max_level_width = max(fs.max_level_width, width.value)
+        else:
+            mx = intra_schedule(fs, f)
+        fs.max_intra_level = max(fs.max_intra_level, mx)
+    return fs

@@ -104,6 +104,17 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)1 << 32; return hipSuccess; }
 
+#include <chrono>
+struct emu_event { std::chrono::steady_clock::time_point t; };
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
 template <typename K, typename... A>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/, A... args)
 {
