@@ -68,7 +68,14 @@ def main():
     mbw, mbh, F = args.mb_width, args.mb_height, args.frames
     nmb = mbw * mbh
     G = max(1, min(args.distinct, F))
-    fs = HF.synth_frames_fast(G, mbw, mbh, seed=0x264 + rank, lib=lib)
+    # control plane: rank 0 owns the stream table (world*F streams), every rank takes s % world == rank
+    from libav_amd import shard
+    n_streams = world * F
+    table = shard.make_stream_table(n_streams, 0x264) if rank == 0 else None
+    table = shard.broadcast_stream_table(table, n_streams, "cuda" if world > 1 else "cpu")
+    mine = shard.my_streams(table, rank, world)
+    assert len(mine) == F
+    fs = HF.synth_frames_fast(G, mbw, mbh, seed=mine[0][1], lib=lib)
     # replicate the G distinct pictures to F pictures (each with its own buffers in HBM)
     big = HF.FrameSet(F, mbw, mbh, fs.nrefs)
     for f in range(F):
@@ -124,16 +131,7 @@ def main():
     t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / args.steps
     t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / args.steps
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([float(F * nmb * args.steps)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_mbs = float(cnt.item())
-    else:
-        total_mbs = float(F * nmb * args.steps)
+    elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * args.steps, "cuda" if world > 1 else "cpu")
 
     if rank == 0:
         value = total_mbs / elapsed
