@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="independent 1080p pictures (streams) per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
     ap.add_argument("--mb-width", type=int, default=120)
@@ -76,18 +76,9 @@ def main():
     mine = shard.my_streams(table, rank, world)
     assert len(mine) == F
     fs = HF.synth_frames_fast(G, mbw, mbh, seed=mine[0][1], lib=lib)
-    # replicate the G distinct pictures to F pictures (each with its own buffers in HBM)
-    big = HF.FrameSet(F, mbw, mbh, fs.nrefs)
-    for f in range(F):
-        g = f % G
-        big.mb[f] = fs.mb[g]
-        big.mv[:, f] = fs.mv[:, g]
-        big.coef[f] = fs.coef[g]
-        big.slices[f] = fs.slices[g]
-        big.refs[f] = fs.refs[g]
-        big.intra_list[f], big.intra_start[f] = fs.intra_list[g], fs.intra_start[g]
-    big.max_intra_level, big.max_level_width = fs.max_intra_level, fs.max_level_width
-    dev = HF.DeviceFrames(prov, big)
+    # the G distinct pictures are replicated ON THE DEVICE to F pictures, each with its own buffers in HBM
+    dev = HF.DeviceFrames(prov, fs, replicate=F)
+    big = fs
 
     for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_h264_recon_intra_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -135,7 +126,7 @@ def main():
 
     if rank == 0:
         value = total_mbs / elapsed
-        n_intra = int(sum(len(x) for x in big.intra_list))
+        n_intra = int(sum(len(big.intra_list[f % G]) for f in range(F)))
         n_inter = F * nmb - n_intra
         ndiag = (mbw - 1) + 2 * (mbh - 1) + 1
         # dominant kernel = the pass with the largest share of the step

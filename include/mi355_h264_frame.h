@@ -50,6 +50,7 @@ extern "C" {
                                       disable_deblocking_filter_idc allows it: sl->left_type != 0) */
 #define MI355_MBF_TOP_EDGE   0x02  /* same for the top edge (sl->top_type != 0) */
 #define MI355_MBF_NO_DEBLOCK 0x04  /* sl->deblocking_filter == 0 for this MB's slice: copy only */
+#define MI355_MBF_WEIGHTED   0x08  /* sl->pwt.use_weight != 0: the slice table must be consulted for MC */
 
 /* mi355_h264_mb.sub_mb_type[i] (only for MI355_MB_8x8): shape of 8x8 quadrant i */
 #define MI355_SUB_8x8  0
@@ -91,8 +92,17 @@ typedef struct mi355_h264_mb {
     uint8_t  slice_id;                   /* 44 index into mi355_h264_frame.slices */
     uint8_t  intra_level;                /* 45 0 for inter MBs; for intra MBs 1 + max(level of the intra MBs among
                                                left, top-left, top, top-right), see mi355_h264_intra_levels() */
-    uint8_t  reserved[2];                /* 46 */
-    int8_t   intra4x4_pred_mode[16];     /* 48 sl->intra4x4_pred_mode_cache[scan8[i]]; Intra 8x8 uses i = 0,4,8,12 */
+    uint8_t  qpc[2];                     /* 46 get_chroma_qp(pps, {0,1}, qp): this MB's Cb / Cr QP */
+    union {                              /* 48 */
+        int8_t intra4x4_pred_mode[16];   /*    intra MBs: sl->intra4x4_pred_mode_cache[scan8[i]]; Intra 8x8 uses
+                                               i = 0,4,8,12 */
+        struct {
+            uint8_t ref_pic[2][4];       /*    inter MBs: picture slot (index into mi355_h264_frame.ref[]) of each
+                                               quadrant's reference = slices[slice_id].ref_slot[list][ref_idx],
+                                               0xFF when unused; what the loop filter compares (h->ref2frm) */
+            uint8_t reserved[8];
+        } inter;
+    } u;
 } mi355_h264_mb;
 
 /* Coefficients: 384 int16 per macroblock = sl->mb with the chroma planes packed
@@ -184,6 +194,7 @@ void *mi355_malloc(size_t bytes);
 void  mi355_free(void *dptr);
 int   mi355_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int   mi355_memcpy_d2d(void *dst, const void *src, size_t bytes);
 int   mi355_sync(void *stream);
 /* HIP events on the caller's stream (kernel timing without a host sync per kernel) */
 void *mi355_event_create(void);

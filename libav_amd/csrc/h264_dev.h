@@ -40,27 +40,97 @@ __device__ __forceinline__ int px_clamped(const PlaneRef &p, int x, int y)
 }
 
 /* ---- per-wave LDS scratch -------------------------------------------------- */
-constexpr int WIN_PITCH = 24;           /* 21 columns used */
+constexpr int WY_PITCH = 32;            /* luma window row pitch in bytes (8 dwords): 21 columns + alignment slack */
+constexpr int WC_PITCH = 16;            /* chroma window row pitch (4 dwords): 9 columns + slack */
 struct McScratch {
-    uint8_t win[21 * WIN_PITCH];        /* staged reference window, up to 21x21 */
+    uint32_t winY[21 * (WY_PITCH / 4)]; /* staged luma reference window, up to 21 rows */
+    uint32_t winC[2][9 * (WC_PITCH / 4)];
     int16_t tmp[21 * 16];               /* unclipped horizontal 6-tap sums for the centre position */
+    int shiftY, shiftC;                 /* byte offset of window column 0 inside each staged row */
 };
 
-/* ---- a5: quarter-pel luma MC (h264qpel_template.c:77-531) -------------------
- * Block bw x bh whose integer-sample origin in the reference plane is (ix,iy),
- * fraction (mx,my) in quarter samples.  Result goes to pred[(py+y)*ppitch + px+x]
- * (LDS), either stored (avg=0) or rounded-averaged with what is there (avg=1:
- * the reference's avg_ tables / second list of a bi-predicted block). */
-__device__ inline void mc_luma(McScratch &s, const PlaneRef &ref, int ix, int iy, int mx, int my,
-                               int bw, int bh, uint8_t *pred, int ppitch, int px, int py, int avg)
+/* One window's worth of loads for this lane, issued before anything waits on them.
+ * Fast path (window inside the plane): aligned dword loads, the row is stored as fetched and the
+ * consumer skips `shift` bytes.  Slow path: per-sample clamped reads (== emulated_edge_mc). */
+template <int PITCH, int MAXIT>
+struct WinLoad {
+    uint32_t v[MAXIT];
+    __device__ __forceinline__ void issue(const PlaneRef &ref, int x0, int y0, int ww, int wh, bool inside, int lane)
+    {
+        constexpr int PD = PITCH / 4;
+        if (inside) {
+            const int xa = x0 & ~3, shift = x0 & 3, ndw = (shift + ww + 3) >> 2;
+#pragma unroll
+            for (int k = 0; k < MAXIT; k++) {
+                const int idx = lane + 64 * k, row = idx / PD, dw = idx % PD;
+                v[k] = 0;
+                if (row < wh && dw < ndw)
+                    v[k] = *reinterpret_cast<const uint32_t *>(ref.base + (size_t)(y0 + row) * ref.stride + xa + 4 * dw);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAXIT; k++) {
+                const int idx = lane + 64 * k, row = idx / PD, dw = idx % PD;
+                uint32_t w = 0;
+                if (row < wh && 4 * dw < ww) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) w |= (uint32_t)px_clamped(ref, x0 + 4 * dw + b, y0 + row) << (8 * b);
+                }
+                v[k] = w;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(uint32_t *win, int wh, int lane) const
+    {
+        constexpr int PD = PITCH / 4;
+#pragma unroll
+        for (int k = 0; k < MAXIT; k++) {
+            const int idx = lane + 64 * k;
+            if (idx < wh * PD) win[idx] = v[k];
+        }
+    }
+};
+__device__ __forceinline__ bool win_inside(const PlaneRef &ref, int x0, int y0, int ww, int wh)
+{
+    /* the dword path also needs 4-byte aligned rows */
+    return x0 >= 0 && y0 >= 0 && x0 + ww <= ref.w && y0 + wh <= ref.h &&
+           ((reinterpret_cast<uintptr_t>(ref.base) | (uintptr_t)ref.stride) & 3) == 0;
+}
+
+/* Stage the luma window of a bw x bh block at integer position (ix,iy) [window origin ix-2,iy-2,
+ * (bw+5) x (bh+5)] and, if `cb`/`cr` are given, the (bw/2+1) x (bh/2+1) chroma windows at (cx,cy):
+ * all loads are in flight together, one LDS barrier at the end. */
+__device__ inline void stage_windows(McScratch &s, const PlaneRef *y, int ix, int iy, int bw, int bh,
+                                     const PlaneRef *cb, const PlaneRef *cr, int cx, int cy, int cw, int ch)
 {
     const int lane = lane_id();
-    const int ww = bw + 5, wh = bh + 5;
-    for (int i = lane; i < ww * wh; i += 64) {
-        int y = i / ww, x = i - y * ww;
-        s.win[y * WIN_PITCH + x] = (uint8_t)px_clamped(ref, ix - 2 + x, iy - 2 + y);
+    WinLoad<WY_PITCH, 3> ly;
+    WinLoad<WC_PITCH, 1> lb, lr;
+    bool in_y = false, in_c = false;
+    if (y) {
+        in_y = win_inside(*y, ix - 2, iy - 2, bw + 5, bh + 5);
+        ly.issue(*y, ix - 2, iy - 2, bw + 5, bh + 5, in_y, lane);
     }
+    if (cb) {
+        in_c = win_inside(*cb, cx, cy, cw + 1, ch + 1);
+        lb.issue(*cb, cx, cy, cw + 1, ch + 1, in_c, lane);
+        lr.issue(*cr, cx, cy, cw + 1, ch + 1, in_c, lane);
+    }
+    if (y) { ly.commit(s.winY, bh + 5, lane); s.shiftY = in_y ? ((ix - 2) & 3) : 0; }
+    if (cb) { lb.commit(s.winC[0], ch + 1, lane); lr.commit(s.winC[1], ch + 1, lane); s.shiftC = in_c ? (cx & 3) : 0; }
     __syncthreads();
+}
+
+/* ---- a5: quarter-pel luma MC (h264qpel_template.c:77-531) -------------------
+ * Block bw x bh from the staged window, fraction (mx,my) in quarter samples.  Result goes to
+ * pred[(py+y)*ppitch + px+x] (LDS), either stored (avg=0) or rounded-averaged with what is there
+ * (avg=1: the reference's avg_ tables / second list of a bi-predicted block). */
+__device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int bh,
+                                       uint8_t *pred, int ppitch, int px, int py, int avg)
+{
+    const int lane = lane_id();
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s.winY) + s.shiftY;
+    const int wh = bh + 5;
     const bool use_j = (mx == 2 && my != 0) || (my == 2 && mx != 0);
     const bool use_b = mx != 0 && my != 2;
     const bool use_h = my != 0 && mx != 2;
@@ -71,25 +141,25 @@ __device__ inline void mc_luma(McScratch &s, const PlaneRef &ref, int ix, int iy
     if (use_j) {
         for (int i = lane; i < wh * bw; i += 64) {
             int y = i >> lw, x = i & (bw - 1);
-            const uint8_t *r = &s.win[y * WIN_PITCH + x];
+            const uint8_t *r = &win[y * WY_PITCH + x];
             s.tmp[y * 16 + x] = (int16_t)tap6(r[0], r[1], r[2], r[3], r[4], r[5]);
         }
         __syncthreads();
     }
     for (int i = lane; i < bw * bh; i += 64) {
         int y = i >> lw, x = i & (bw - 1);
-        const uint8_t *c = &s.win[(y + 2) * WIN_PITCH + x + 2];
+        const uint8_t *c = &win[(y + 2) * WY_PITCH + x + 2];
         int sum = 0, n = 0;
-        if (use_g) { sum += c[gdy * WIN_PITCH + gdx]; n++; }
+        if (use_g) { sum += c[gdy * WY_PITCH + gdx]; n++; }
         if (use_b) {
             int hs;
             if (use_j) hs = s.tmp[(y + 2 + bdy) * 16 + x];
-            else { const uint8_t *r = c + bdy * WIN_PITCH; hs = tap6(r[-2], r[-1], r[0], r[1], r[2], r[3]); }
+            else { const uint8_t *r = c + bdy * WY_PITCH; hs = tap6(r[-2], r[-1], r[0], r[1], r[2], r[3]); }
             sum += clip_u8((hs + 16) >> 5); n++;
         }
         if (use_h) {
             const uint8_t *r = c + hdx;
-            int vs = tap6(r[-2 * WIN_PITCH], r[-WIN_PITCH], r[0], r[WIN_PITCH], r[2 * WIN_PITCH], r[3 * WIN_PITCH]);
+            int vs = tap6(r[-2 * WY_PITCH], r[-WY_PITCH], r[0], r[WY_PITCH], r[2 * WY_PITCH], r[3 * WY_PITCH]);
             sum += clip_u8((vs + 16) >> 5); n++;
         }
         if (use_j) {
@@ -105,22 +175,17 @@ __device__ inline void mc_luma(McScratch &s, const PlaneRef &ref, int ix, int iy
 }
 
 /* ---- a6: 1/8-pel bilinear chroma MC (h264chroma_template.c:27-173) ---------- */
-__device__ inline void mc_chroma(McScratch &s, const PlaneRef &ref, int cx, int cy, int fx, int fy,
-                                 int bw, int bh, uint8_t *pred, int ppitch, int px, int py, int avg)
+__device__ inline void mc_chroma_compute(McScratch &s, int plane, int fx, int fy, int bw, int bh,
+                                         uint8_t *pred, int ppitch, int px, int py, int avg)
 {
     const int lane = lane_id();
-    const int ww = bw + 1, wh = bh + 1;
-    for (int i = lane; i < ww * wh; i += 64) {
-        int y = i / ww, x = i - y * ww;
-        s.win[y * WIN_PITCH + x] = (uint8_t)px_clamped(ref, cx + x, cy + y);
-    }
-    __syncthreads();
+    const uint8_t *win = reinterpret_cast<const uint8_t *>(s.winC[plane]) + s.shiftC;
     const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
     const int lw = bw == 8 ? 3 : (bw == 4 ? 2 : 1);
     for (int i = lane; i < bw * bh; i += 64) {
         int y = i >> lw, x = i & (bw - 1);
-        const uint8_t *c = &s.win[y * WIN_PITCH + x];
-        int v = (A * c[0] + B * c[1] + C * c[WIN_PITCH] + D * c[WIN_PITCH + 1] + 32) >> 6;
+        const uint8_t *c = &win[y * WC_PITCH + x];
+        int v = (A * c[0] + B * c[1] + C * c[WC_PITCH] + D * c[WC_PITCH + 1] + 32) >> 6;
         uint8_t *d = &pred[(py + y) * ppitch + px + x];
         *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
     }

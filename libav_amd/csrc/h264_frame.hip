@@ -34,6 +34,7 @@ namespace {
 
 struct MbLds {
     mi355_h264_mb hdr;
+    uint32_t mv[2][16];                      /* (x | y << 16) per 4x4 block, raster order, per list */
     int16_t coef[384];
     uint8_t py[16 * 16], pc[2][8 * 8];       /* prediction -> reconstruction */
     uint8_t qy[16 * 16], qc[2][8 * 8];       /* second prediction for weighted bi-pred */
@@ -44,19 +45,24 @@ __device__ __forceinline__ int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 
 __device__ __forceinline__ int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >> 3); }
 __device__ __forceinline__ int blk_index(int x4, int y4) { return (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1); }
 
-/* record (64 B) and coefficients (768 B) -> LDS, coalesced */
-__device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy)
+/* record (64 B), motion vectors (64 B per list) and coefficients (768 B) -> LDS: every load is
+ * issued before the first wait, so the wave pays one memory round trip for all of them */
+__device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, bool with_coefs)
 {
     const int lane = lane_id();
-    if (lane < 16)
-        reinterpret_cast<uint32_t *>(&s.hdr)[lane] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[lane];
-    __syncthreads();
-}
-__device__ inline void load_coefs(MbLds &s, const mi355_h264_frame &fr, int mb_xy)
-{
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
-    for (int i = lane_id(); i < 192; i += 64) dst[i] = src[i];
+    const uint32_t *hp = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy]);
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    uint32_t hw = 0, mw = 0, c0 = 0, c1 = 0, c2 = 0;
+    if (lane < 16) hw = hp[lane];
+    else if (lane < 32) { if (fr.mv[0]) mw = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + lane - 16]; }
+    else if (lane < 48) { if (fr.mv[1]) mw = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + lane - 32]; }
+    if (with_coefs) { c0 = cp[lane]; c1 = cp[lane + 64]; c2 = cp[lane + 128]; }
+    if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = hw;
+    else if (lane < 48) s.mv[(lane >> 4) - 1][lane & 15] = mw;
+    if (with_coefs) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
+        dst[lane] = c0; dst[lane + 64] = c1; dst[lane + 128] = c2;
+    }
     __syncthreads();
 }
 
@@ -65,16 +71,18 @@ __device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_
                               int mb_xy, int list, int n_raster, int refn, int bx, int by, int w, int h,
                               uint8_t *py, uint8_t *pcb, uint8_t *pcr, int avg)
 {
-    const int16_t *mv = fr.mv[list] + ((size_t)mb_xy * 16 + n_raster) * 2;
-    const int slot = sl.ref_slot[list][refn];
-    const int mx = mv[0] + (mb_x * 16 + bx) * 4;
-    const int my = mv[1] + (mb_y * 16 + by) * 4;
+    (void)sl; (void)refn; (void)mb_xy;
+    const uint32_t mvw = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.mv[list][n_raster]);
+    const int slot = __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.ref_pic[list][(bx >> 3) + 2 * (by >> 3)]);
+    const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
+    const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
     PlaneRef ry{fr.ref[slot][0], fr.dst_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
-    mc_luma(s.mc, ry, mx >> 2, my >> 2, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
     PlaneRef rb{fr.ref[slot][1], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
-    mc_chroma(s.mc, rb, mx >> 3, my >> 3, mx & 7, my & 7, w >> 1, h >> 1, pcb, 8, bx >> 1, by >> 1, avg);
     PlaneRef rr{fr.ref[slot][2], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
-    mc_chroma(s.mc, rr, mx >> 3, my >> 3, mx & 7, my & 7, w >> 1, h >> 1, pcr, 8, bx >> 1, by >> 1, avg);
+    stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
+    mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
+    mc_chroma_compute(s.mc, 0, mx & 7, my & 7, w >> 1, h >> 1, pcb, 8, bx >> 1, by >> 1, avg);
+    mc_chroma_compute(s.mc, 1, mx & 7, my & 7, w >> 1, h >> 1, pcr, 8, bx >> 1, by >> 1, avg);
 }
 
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
@@ -82,7 +90,8 @@ __device__ inline void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355
                                int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
     const int r0 = s.hdr.ref_idx[0][quadrant], r1 = s.hdr.ref_idx[1][quadrant];
-    const bool weighted = (sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1;
+    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) &&
+                          ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
     if (!weighted) {
         int avg = 0;
         if (l0) { mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 0, n_raster, r0, bx, by, w, h, s.py, s.pc[0], s.pc[1], 0); avg = 1; }
@@ -227,16 +236,22 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
 }
 
 /* ------------------------------------------------------------------------- */
+/* Workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Give each XCD one
+ * contiguous run of macroblocks so that horizontally adjacent MBs — which share reference
+ * cache lines and write the same 128-byte lines of `recon` — meet in the same L2. */
+__device__ __forceinline__ int xcd_linear(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
+
 __global__ void __launch_bounds__(64)
-k_recon_inter(const mi355_h264_frame *frames, int max_nmb)
+k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_nmb, int nblocks, int per_xcd)
 {
     __shared__ MbLds s;
-    const int f = blockIdx.x / max_nmb, mb_xy = blockIdx.x - f * max_nmb;
+    const int lin = xcd_linear((int)blockIdx.x, per_xcd);
+    if (lin >= nblocks) return;
+    const int f = lin / max_nmb, mb_xy = lin - f * max_nmb;
     const mi355_h264_frame &fr = frames[f];
     if (mb_xy >= fr.mb_width * fr.mb_height) return;
-    load_mb(s, fr, mb_xy);
+    load_mb(s, fr, mb_xy, true);
     if (s.hdr.mb_type & MI355_MB_INTRA) return;
-    load_coefs(s, fr, mb_xy);
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
@@ -270,8 +285,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     if (k >= count) return;
     const int mb_xy = (int)fr.intra_list[first + k];
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
-    load_mb(s.mb, fr, mb_xy);
-    load_coefs(s.mb, fr, mb_xy);
+    load_mb(s.mb, fr, mb_xy, true);
     const mi355_h264_mb &h = s.mb.hdr;
     const uint32_t t = h.mb_type;
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1];
@@ -325,7 +339,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             if (lane < 17) s.ps.T[lane] = TILE(x0 + lane - 1, y0 - 1);
             if (lane >= 32 && lane < 41) s.ps.L[lane - 32] = TILE(x0 - 1, y0 + lane - 33);
             __syncthreads();
-            intra_pred_wave(s.ps, 1, h.intra4x4_pred_mode[i], (h.topleft_samples_available << i) & 0x8000,
+            intra_pred_wave(s.ps, 1, h.u.intra4x4_pred_mode[i], (h.topleft_samples_available << i) & 0x8000,
                             (h.topright_samples_available << i) & 0x4000, &TILE(x0, y0), TP);
             int r[8];
             idct8_lds(s.mb.coef + i8 * 64, lane & 7, lane < 8, r);
@@ -340,7 +354,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             else if (lane < 9) s.ps.T[lane] = tr_ok ? TILE(x0 + lane - 1, y0 - 1) : TILE(x0 + 3, y0 - 1);
             if (lane >= 32 && lane < 37) s.ps.L[lane - 32] = TILE(x0 - 1, y0 + lane - 33);
             __syncthreads();
-            intra_pred_wave(s.ps, 0, h.intra4x4_pred_mode[i], 0, 0, &TILE(x0, y0), TP);
+            intra_pred_wave(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &TILE(x0, y0), TP);
             const int q = lane & 3;
             int c[4], r[4], col;
 #pragma unroll
@@ -373,58 +387,50 @@ __device__ const uint8_t k_tc0[52][3] = {
     {3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},{9,12,18},{10,13,20},
     {11,15,23},{13,17,25} };
 
+/* motion of one 4x4 block as the loop filter sees it: picture identity per list (-1 = unused, what
+ * ref_cache holds after the ref2frm mapping, h264_slice.c:2023-2029) and the packed mv words */
 struct BlkMotion {
-    int ref[2], mx[2], my[2];
+    int ref[2];
+    uint32_t mv[2];
 };
-/* what fill_filter_caches puts into ref_cache / mv_cache for one 4x4 block (h264_slice.c:1969-2050) */
-__device__ inline BlkMotion load_motion(const mi355_h264_frame &fr, int mb_xy, int x4, int y4)
+__device__ __forceinline__ bool mv_far(uint32_t a, uint32_t b)
 {
-    BlkMotion b;
-    const mi355_h264_mb &m = fr.mb[mb_xy];
-    const mi355_h264_slice &sl = fr.slices[m.slice_id];
-    const bool intra = (m.mb_type & MI355_MB_INTRA) != 0;
-    for (int l = 0; l < 2; l++) {
-        int r = intra ? -1 : m.ref_idx[l][(x4 >> 1) + 2 * (y4 >> 1)];
-        b.ref[l] = r < 0 ? -1 : sl.ref_slot[l][r];
-        if (b.ref[l] >= 0 && fr.mv[l]) {
-            const int16_t *mv = fr.mv[l] + ((size_t)mb_xy * 16 + x4 + 4 * y4) * 2;
-            b.mx[l] = mv[0]; b.my[l] = mv[1];
-        } else {
-            b.mx[l] = b.my[l] = 0;
-        }
-    }
-    return b;
+    return iabs((int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF)) >= 4 || iabs((int16_t)(a >> 16) - (int16_t)(b >> 16)) >= 4;
 }
-__device__ __forceinline__ bool mv_far(int ax, int ay, int bx, int by) { return iabs(ax - bx) >= 4 || iabs(ay - by) >= 4; }
 /* check_mv, h264_loopfilter.c:442-470, frame macroblocks (mvy_limit 4) */
 __device__ inline int check_mv(const BlkMotion &p, const BlkMotion &q, int list_count)
 {
     bool v = p.ref[0] != q.ref[0];
-    if (!v && p.ref[0] != -1) v = mv_far(p.mx[0], p.my[0], q.mx[0], q.my[0]);
+    if (!v && p.ref[0] != -1) v = mv_far(p.mv[0], q.mv[0]);
     if (list_count == 2) {
-        if (!v) v = p.ref[1] != q.ref[1] || mv_far(p.mx[1], p.my[1], q.mx[1], q.my[1]);
+        if (!v) v = p.ref[1] != q.ref[1] || mv_far(p.mv[1], q.mv[1]);
         if (v) {
             if (p.ref[0] != q.ref[1] || p.ref[1] != q.ref[0]) return 1;
-            return mv_far(p.mx[0], p.my[0], q.mx[1], q.my[1]) || mv_far(p.mx[1], p.my[1], q.mx[0], q.my[0]);
+            return mv_far(p.mv[0], q.mv[1]) || mv_far(p.mv[1], q.mv[0]);
         }
     }
     return v;
+}
+__device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, int x4, int y4)
+{
+    if (m.mb_type & MI355_MB_INTRA) return -1;
+    const int r = m.u.inter.ref_pic[list][(x4 >> 1) + 2 * (y4 >> 1)];
+    return r == 0xFF ? -1 : r;
 }
 
 constexpr int DP = 24;   /* luma tile pitch: columns -4..15, rows -4..15 */
 constexpr int DCP = 12;  /* chroma tile pitch: columns -2..7, rows -2..7 */
 struct DeblockLds {
-    mi355_h264_mb hdr;
+    mi355_h264_mb hdr[3];     /* this MB, left neighbour, top neighbour */
     uint8_t y[20 * DP];
     uint8_t c[2][10 * DCP];
     int8_t bs[2][4][4];
-    int8_t qp_n[2];       /* qp of the left / top neighbour */
 };
 #define YT(x, y_) s.y[((y_) + 4) * DP + (x) + 4]
 #define CT(p, x, y_) s.c[p][((y_) + 2) * DCP + (x) + 2]
 
 __global__ void __launch_bounds__(64)
-k_deblock(const mi355_h264_frame *frames, int diag, int max_mb_height)
+k_deblock(const mi355_h264_frame *__restrict__ frames, int diag, int max_mb_height)
 {
     __shared__ DeblockLds s;
     const int lane = lane_id();
@@ -433,103 +439,158 @@ k_deblock(const mi355_h264_frame *frames, int diag, int max_mb_height)
     const int mb_x = diag - 2 * mb_y;
     if (mb_y >= fr.mb_height || mb_x < 0 || mb_x >= fr.mb_width) return;
     const int mb_xy = mb_x + mb_y * fr.mb_width;
-    if (lane < 16)
-        reinterpret_cast<uint32_t *>(&s.hdr)[lane] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[lane];
-    __syncthreads();
-    const mi355_h264_mb &h = s.hdr;
-    const bool filter = !(h.flags & MI355_MBF_NO_DEBLOCK);
-    const bool have_left = filter && (h.flags & MI355_MBF_LEFT_EDGE), have_top = filter && (h.flags & MI355_MBF_TOP_EDGE);
+    const bool has_l = mb_x > 0, has_t = mb_y > 0;
     const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
+    const uint8_t *src = fr.recon[0] + (size_t)mb_y * 16 * rs + mb_x * 16;
+    uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
 
-    /* own samples from `recon`, already-filtered neighbour columns/rows from `dst` */
+    /* ---- phase A: every load this wave needs, issued before the first wait -------------------
+     * records of this MB and of its left / top neighbours; own samples from `recon`; the neighbour
+     * columns / rows (already filtered by earlier diagonals) from `dst`; the motion vectors of the
+     * two 4x4 blocks each (dir, edge, segment) lane compares. */
+    uint32_t hw = 0;
     {
-        const uint8_t *src = fr.recon[0] + (size_t)mb_y * 16 * rs + mb_x * 16;
-        const int row = lane >> 2, seg = lane & 3;
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(src + row * rs + 4 * seg);
-        YT(4 * seg + 0, row) = (uint8_t)v; YT(4 * seg + 1, row) = (uint8_t)(v >> 8);
-        YT(4 * seg + 2, row) = (uint8_t)(v >> 16); YT(4 * seg + 3, row) = (uint8_t)(v >> 24);
-        if (lane < 32) {
-            const int p = lane >> 4, crow = (lane >> 1) & 7, cseg = lane & 1;
-            const uint8_t *cs_ = fr.recon[1 + p] + (size_t)mb_y * 8 * rcs + mb_x * 8;
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(cs_ + crow * rcs + 4 * cseg);
-            CT(p, 4 * cseg + 0, crow) = (uint8_t)w; CT(p, 4 * cseg + 1, crow) = (uint8_t)(w >> 8);
-            CT(p, 4 * cseg + 2, crow) = (uint8_t)(w >> 16); CT(p, 4 * cseg + 3, crow) = (uint8_t)(w >> 24);
-        }
-        const uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
-        if (have_left) {
-            if (lane < 16) {
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(dy + lane * ds - 4);
-                YT(-4, lane) = (uint8_t)w; YT(-3, lane) = (uint8_t)(w >> 8); YT(-2, lane) = (uint8_t)(w >> 16); YT(-1, lane) = (uint8_t)(w >> 24);
-            } else if (lane < 32) {
-                const int p = (lane >> 3) & 1, r = lane & 7;
-                const uint8_t *dc = fr.dst[1 + p] + (size_t)(mb_y * 8 + r) * dcs + mb_x * 8;
-                CT(p, -2, r) = dc[-2]; CT(p, -1, r) = dc[-1];
-            }
-        }
-        if (have_top) {
-            if (lane >= 32 && lane < 48) {
-                const int r = (lane - 32) >> 2, sg = lane & 3;
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(dy + (r - 4) * ds + 4 * sg);
-                YT(4 * sg + 0, r - 4) = (uint8_t)w; YT(4 * sg + 1, r - 4) = (uint8_t)(w >> 8);
-                YT(4 * sg + 2, r - 4) = (uint8_t)(w >> 16); YT(4 * sg + 3, r - 4) = (uint8_t)(w >> 24);
-            } else if (lane >= 48 && lane < 56) {
-                const int p = (lane >> 2) & 1, r = (lane >> 1) & 1, sg = lane & 1;
-                const uint8_t *dc = fr.dst[1 + p] + (size_t)(mb_y * 8 + r - 2) * dcs + mb_x * 8;
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(dc + 4 * sg);
-                CT(p, 4 * sg + 0, r - 2) = (uint8_t)w; CT(p, 4 * sg + 1, r - 2) = (uint8_t)(w >> 8);
-                CT(p, 4 * sg + 2, r - 2) = (uint8_t)(w >> 16); CT(p, 4 * sg + 3, r - 2) = (uint8_t)(w >> 24);
-            }
+        const int which = lane >> 4, w = lane & 15;
+        const int xy = which == 0 ? mb_xy : (which == 1 ? mb_xy - 1 : mb_xy - fr.mb_width);
+        if (which == 0 || (which == 1 && has_l) || (which == 2 && has_t))
+            hw = reinterpret_cast<const uint32_t *>(&fr.mb[xy])[w];
+    }
+    const uint32_t own_y = *reinterpret_cast<const uint32_t *>(src + (lane >> 2) * rs + 4 * (lane & 3));
+    uint32_t own_c = 0, nb_a = 0, nb_b = 0;
+    if (lane < 32) {
+        const int p = lane >> 4, crow = (lane >> 1) & 7, cseg = lane & 1;
+        own_c = *reinterpret_cast<const uint32_t *>(fr.recon[1 + p] + (size_t)(mb_y * 8 + crow) * rcs + mb_x * 8 + 4 * cseg);
+    }
+    if (has_l) {
+        if (lane < 16) nb_a = *reinterpret_cast<const uint32_t *>(dy + lane * ds - 4);
+        else if (lane < 32) {
+            const int p = (lane >> 3) & 1, r = lane & 7;
+            nb_a = *reinterpret_cast<const uint16_t *>(fr.dst[1 + p] + (size_t)(mb_y * 8 + r) * dcs + mb_x * 8 - 2);
         }
     }
-    /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-713 — one (dir, edge, segment) per lane */
+    if (has_t) {
+        if (lane >= 32 && lane < 48) {
+            const int r = (lane - 32) >> 2, sg = lane & 3;
+            nb_b = *reinterpret_cast<const uint32_t *>(dy + (r - 4) * ds + 4 * sg);
+        } else if (lane >= 48 && lane < 56) {
+            const int p = (lane >> 2) & 1, r = (lane >> 1) & 1, sg = lane & 1;
+            nb_b = *reinterpret_cast<const uint32_t *>(fr.dst[1 + p] + (size_t)(mb_y * 8 + r - 2) * dcs + mb_x * 8 + 4 * sg);
+        }
+    }
+    /* bS lanes: (dir, edge, i) -> block p = (x4,y4) of this MB, block q = its neighbour across the edge */
+    const int dir = (lane >> 4) & 1, edge = (lane >> 2) & 3, seg = lane & 3;
+    const int px4 = dir ? seg : edge, py4 = dir ? edge : seg;
+    const bool q_out = edge == 0;                      /* q lives in the neighbouring MB */
+    const int qx4 = dir ? seg : (q_out ? 3 : edge - 1), qy4 = dir ? (q_out ? 3 : edge - 1) : seg;
+    const int q_xy = !q_out ? mb_xy : (dir ? mb_xy - fr.mb_width : mb_xy - 1);
+    const bool q_ok = !q_out || (dir ? has_t : has_l);
+    BlkMotion mp, mq;
+    mp.mv[0] = mp.mv[1] = mq.mv[0] = mq.mv[1] = 0;
+    if (lane < 32) {
+        if (fr.mv[0]) {
+            mp.mv[0] = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + px4 + 4 * py4];
+            if (q_ok) mq.mv[0] = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)q_xy * 16 + qx4 + 4 * qy4];
+        }
+        if (fr.mv[1]) {
+            mp.mv[1] = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + px4 + 4 * py4];
+            if (q_ok) mq.mv[1] = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)q_xy * 16 + qx4 + 4 * qy4];
+        }
+    }
+
+    /* ---- phase B: registers -> LDS ------------------------------------------------------------ */
+    if (lane < 48) reinterpret_cast<uint32_t *>(&s.hdr[lane >> 4])[lane & 15] = hw;
+    {
+        const int row = lane >> 2, sg = lane & 3;
+        YT(4 * sg + 0, row) = (uint8_t)own_y; YT(4 * sg + 1, row) = (uint8_t)(own_y >> 8);
+        YT(4 * sg + 2, row) = (uint8_t)(own_y >> 16); YT(4 * sg + 3, row) = (uint8_t)(own_y >> 24);
+    }
+    if (lane < 32) {
+        const int p = lane >> 4, crow = (lane >> 1) & 7, cseg = lane & 1;
+        CT(p, 4 * cseg + 0, crow) = (uint8_t)own_c; CT(p, 4 * cseg + 1, crow) = (uint8_t)(own_c >> 8);
+        CT(p, 4 * cseg + 2, crow) = (uint8_t)(own_c >> 16); CT(p, 4 * cseg + 3, crow) = (uint8_t)(own_c >> 24);
+    }
+    if (has_l) {
+        if (lane < 16) {
+            YT(-4, lane) = (uint8_t)nb_a; YT(-3, lane) = (uint8_t)(nb_a >> 8); YT(-2, lane) = (uint8_t)(nb_a >> 16); YT(-1, lane) = (uint8_t)(nb_a >> 24);
+        } else if (lane < 32) {
+            const int p = (lane >> 3) & 1, r = lane & 7;
+            CT(p, -2, r) = (uint8_t)nb_a; CT(p, -1, r) = (uint8_t)(nb_a >> 8);
+        }
+    }
+    if (has_t) {
+        if (lane >= 32 && lane < 48) {
+            const int r = (lane - 32) >> 2, sg = lane & 3;
+            YT(4 * sg + 0, r - 4) = (uint8_t)nb_b; YT(4 * sg + 1, r - 4) = (uint8_t)(nb_b >> 8);
+            YT(4 * sg + 2, r - 4) = (uint8_t)(nb_b >> 16); YT(4 * sg + 3, r - 4) = (uint8_t)(nb_b >> 24);
+        } else if (lane >= 48 && lane < 56) {
+            const int p = (lane >> 2) & 1, r = (lane >> 1) & 1, sg = lane & 1;
+            CT(p, 4 * sg + 0, r - 2) = (uint8_t)nb_b; CT(p, 4 * sg + 1, r - 2) = (uint8_t)(nb_b >> 8);
+            CT(p, 4 * sg + 2, r - 2) = (uint8_t)(nb_b >> 16); CT(p, 4 * sg + 3, r - 2) = (uint8_t)(nb_b >> 24);
+        }
+    }
+    __syncthreads();
+
+    const mi355_h264_mb &h = s.hdr[0];
+    const bool filter = !(h.flags & MI355_MBF_NO_DEBLOCK);
+    const bool have_left = filter && (h.flags & MI355_MBF_LEFT_EDGE), have_top = filter && (h.flags & MI355_MBF_TOP_EDGE);
+
+    /* ---- phase C: boundary strengths, filter_mb_dir (h264_loopfilter.c:472-713), one per lane -- */
     if (filter && lane < 32) {
-        const int dir = lane >> 4, edge = (lane >> 2) & 3, i = lane & 3;
         const bool intra = (h.mb_type & MI355_MB_INTRA) != 0;
-        const int list_count = fr.slices[h.slice_id].list_count;
-        const int x4 = dir ? i : edge, y4 = dir ? edge : i;
+        const int list_count = fr.mv[1] ? 2 : 1;     /* sl->list_count == 2 exactly when list-1 vectors exist */
         int bs = 0;
         if (edge == 0) {
             if (dir ? have_top : have_left) {
-                const int n_xy = dir ? mb_xy - fr.mb_width : mb_xy - 1;
-                const mi355_h264_mb &nb = fr.mb[n_xy];
-                if (i == 0) s.qp_n[dir] = nb.qp;
-                const int nx = dir ? i : 3, ny = dir ? 3 : i;
+                const mi355_h264_mb &nb = s.hdr[1 + dir];
                 if (intra || (nb.mb_type & MI355_MB_INTRA)) bs = 4;
-                else if (((h.nnz_mask >> blk_index(x4, y4)) | (nb.nnz_mask >> blk_index(nx, ny))) & 1) bs = 2;
-                else bs = check_mv(load_motion(fr, mb_xy, x4, y4), load_motion(fr, n_xy, nx, ny), list_count);
+                else if (((h.nnz_mask >> blk_index(px4, py4)) | (nb.nnz_mask >> blk_index(qx4, qy4))) & 1) bs = 2;
+                else {
+                    mp.ref[0] = ref_identity(h, 0, px4, py4); mp.ref[1] = ref_identity(h, 1, px4, py4);
+                    mq.ref[0] = ref_identity(nb, 0, qx4, qy4); mq.ref[1] = ref_identity(nb, 1, qx4, qy4);
+                    bs = check_mv(mp, mq, list_count);
+                }
             }
         } else if (!((h.mb_type & MI355_MB_8x8DCT) && (edge & 1))) {
-            const int nx = dir ? i : edge - 1, ny = dir ? edge - 1 : i;
             if (intra) bs = 3;
-            else if (((h.nnz_mask >> blk_index(x4, y4)) | (h.nnz_mask >> blk_index(nx, ny))) & 1) bs = 2;
-            else bs = check_mv(load_motion(fr, mb_xy, x4, y4), load_motion(fr, mb_xy, nx, ny), list_count);
+            else if (((h.nnz_mask >> blk_index(px4, py4)) | (h.nnz_mask >> blk_index(qx4, qy4))) & 1) bs = 2;
+            else {
+                mp.ref[0] = ref_identity(h, 0, px4, py4); mp.ref[1] = ref_identity(h, 1, px4, py4);
+                mq.ref[0] = ref_identity(h, 0, qx4, qy4); mq.ref[1] = ref_identity(h, 1, qx4, qy4);
+                bs = check_mv(mp, mq, list_count);
+            }
         }
-        s.bs[dir][edge][i] = (int8_t)bs;
+        s.bs[dir][edge][seg] = (int8_t)bs;
     }
     __syncthreads();
 
+    /* ---- phase D: the 8 luma + 4 chroma edges, in the reference's order --------------------- */
     if (filter) {
-        const mi355_h264_slice &sl = fr.slices[h.slice_id];
         /* lanes 0..15: luma lines; 16..23: Cb lines; 24..31: Cr lines */
         const int plane = lane < 16 ? 0 : (lane < 24 ? 1 : 2);
         const int line = plane == 0 ? lane : (lane & 7);
-        for (int dir = 0; dir < 2; dir++) {
-            for (int edge = 0; edge < 4; edge++) {
-                if (lane < 32 && !(plane && (edge & 1))) {
-                    const int bs = s.bs[dir][edge][plane ? line >> 1 : line >> 2];
+        for (int d2 = 0; d2 < 2; d2++) {
+            for (int e = 0; e < 4; e++) {
+                if (lane < 32 && !(plane && (e & 1))) {
+                    const int bs = s.bs[d2][e][plane ? line >> 1 : line >> 2];
                     if (bs) {
+                        const mi355_h264_mb &nb = s.hdr[1 + d2];
                         int qp;
-                        if (plane == 0) qp = edge ? h.qp : (h.qp + s.qp_n[dir] + 1) >> 1;
+                        if (plane == 0) qp = e ? h.qp : (h.qp + nb.qp + 1) >> 1;
+                        else if (e) qp = h.qpc[plane - 1];
                         else {
-                            const uint8_t *tab = sl.chroma_qp_table[plane - 1];
-                            qp = edge ? tab[h.qp] : (tab[h.qp] + tab[s.qp_n[dir]] + 1) >> 1;
+                            /* the reference maps the neighbour's QP through the CURRENT slice's table
+                             * (h264_loopfilter.c:628-629); identical to the neighbour's own qpc unless the
+                             * two MBs sit in slices with different PPS chroma offsets */
+                            const int nq = nb.slice_id == h.slice_id ? nb.qpc[plane - 1]
+                                                                     : fr.slices[h.slice_id].chroma_qp_table[plane - 1][nb.qp];
+                            qp = (h.qpc[plane - 1] + nq + 1) >> 1;
                         }
                         const int ia = clip3(qp + h.slice_alpha_c0_offset, 0, 51), ib = clip3(qp + h.slice_beta_offset, 0, 51);
                         const int alpha = k_alpha[ia], beta = k_beta[ib];
                         if (alpha && beta) {
                             if (plane == 0) {
-                                uint8_t *c = dir ? &YT(line, 4 * edge) : &YT(4 * edge, line);
-                                const int xs = dir ? DP : 1;
+                                uint8_t *c = d2 ? &YT(line, 4 * e) : &YT(4 * e, line);
+                                const int xs = d2 ? DP : 1;
                                 int p3 = c[-4 * xs], p2 = c[-3 * xs], p1 = c[-2 * xs], p0 = c[-xs];
                                 int q0 = c[0], q1 = c[xs], q2 = c[2 * xs], q3 = c[3 * xs];
                                 if (bs < 4) lf_luma_line(p2, p1, p0, q0, q1, q2, alpha, beta, k_tc0[ia][bs - 1]);
@@ -537,8 +598,8 @@ k_deblock(const mi355_h264_frame *frames, int diag, int max_mb_height)
                                 c[-3 * xs] = (uint8_t)p2; c[-2 * xs] = (uint8_t)p1; c[-xs] = (uint8_t)p0;
                                 c[0] = (uint8_t)q0; c[xs] = (uint8_t)q1; c[2 * xs] = (uint8_t)q2;
                             } else {
-                                uint8_t *c = dir ? &CT(plane - 1, line, 2 * edge) : &CT(plane - 1, 2 * edge, line);
-                                const int xs = dir ? DCP : 1;
+                                uint8_t *c = d2 ? &CT(plane - 1, line, 2 * e) : &CT(plane - 1, 2 * e, line);
+                                const int xs = d2 ? DCP : 1;
                                 int p1 = c[-2 * xs], p0 = c[-xs], q0 = c[0], q1 = c[xs];
                                 if (bs < 4) lf_chroma_line(p1, p0, q0, q1, alpha, beta, k_tc0[ia][bs - 1] + 1);
                                 else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
@@ -551,10 +612,9 @@ k_deblock(const mi355_h264_frame *frames, int diag, int max_mb_height)
             }
         }
     }
-    /* write back: the MB, plus the neighbour samples its edge-0 filters may have changed */
+    /* ---- phase E: the MB, plus the neighbour samples its edge-0 filters may have changed ------- */
     uint8_t *const dst3[3] = {fr.dst[0], fr.dst[1], fr.dst[2]};
     store_mb(&YT(0, 0), DP, &CT(0, 0, 0), &CT(1, 0, 0), DCP, dst3, fr.dst_stride, mb_x, mb_y);
-    uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
     if (have_left) {
         if (lane < 16) { dy[lane * ds - 3] = YT(-3, lane); dy[lane * ds - 2] = YT(-2, lane); dy[lane * ds - 1] = YT(-1, lane); }
         else if (lane < 32) {
@@ -584,7 +644,9 @@ extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int 
 {
     if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
     const int max_nmb = max_mb_width * max_mb_height;
-    hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(nframes * max_nmb)), dim3(64), 0, (hipStream_t)stream, d_frames, max_nmb);
+    const int nblocks = nframes * max_nmb, per_xcd = (nblocks + 7) / 8;
+    hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
+                       d_frames, max_nmb, nblocks, per_xcd);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -678,6 +740,7 @@ extern "C" void *mi355_malloc(size_t bytes)
 extern "C" void mi355_free(void *p) { if (p) (void)hipFree(p); }
 extern "C" int mi355_memcpy_h2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_memcpy_d2h(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+extern "C" int mi355_memcpy_d2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
 
 extern "C" void *mi355_event_create(void)

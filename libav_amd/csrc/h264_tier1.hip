@@ -35,7 +35,8 @@ k_qpel(const uint8_t *win, int wpitch, uint8_t *dst, int dpitch, int size, int m
         }
     __syncthreads();
     PlaneRef ref{win, wpitch, size + 5, size + 5};
-    mc_luma(s, ref, 2, 2, mx, my, size, size, pred, 16, 0, 0, avg);
+    stage_windows(s, &ref, 2, 2, size, size, nullptr, nullptr, 0, 0, 0, 0);
+    mc_luma_compute(s, mx, my, size, size, pred, 16, 0, 0, avg);
     for (int i = lane; i < size * size; i += 64) {
         int y = i / size, x = i - y * size;
         dst[y * dpitch + x] = pred[y * 16 + x];
@@ -78,7 +79,8 @@ k_chroma(const uint8_t *win, int wpitch, uint8_t *dst, int dpitch, int w, int h,
     /* h can be 16 (4:2:2 callers); the wave handles it in two 8-row halves */
     for (int y0 = 0; y0 < h; y0 += 8) {
         int bh = h - y0 < 8 ? h - y0 : 8;
-        mc_chroma(s, ref, 0, y0, fx, fy, w, bh, pred, 8, 0, y0, avg);
+        stage_windows(s, nullptr, 0, 0, 0, 0, &ref, &ref, 0, y0, w, bh);
+        mc_chroma_compute(s, 0, fx, fy, w, bh, pred, 8, 0, y0, avg);
     }
     for (int i = lane; i < w * h; i += 64) {
         int y = i / w, x = i - y * w;

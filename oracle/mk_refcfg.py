@@ -23,7 +23,7 @@ ARCH_GENERIC_NOT
 HAVE_FAST_64BIT HAVE_FAST_UNALIGNED HAVE_FAST_CLZ HAVE_FAST_CMOV HAVE_LOCAL_ALIGNED
 HAVE_ATTRIBUTE_PACKED HAVE_ATTRIBUTE_MAY_ALIAS HAVE_PRAGMA_DEPRECATED HAVE_INLINE_ASM_LABELS
 HAVE_BUILTIN_VECTOR
-HAVE_ALIGNED_STACK HAVE_ALIGNED_MALLOC HAVE_POSIX_MEMALIGN HAVE_MEMALIGN
+HAVE_ALIGNED_STACK HAVE_POSIX_MEMALIGN HAVE_MEMALIGN
 HAVE_CBRT HAVE_CBRTF HAVE_COPYSIGN HAVE_ERF HAVE_EXP2 HAVE_EXP2F HAVE_EXPF HAVE_HYPOT
 HAVE_ISFINITE HAVE_ISINF HAVE_ISNAN HAVE_LDEXPF HAVE_LLRINT HAVE_LLRINTF HAVE_LOG10F HAVE_LOG2
 HAVE_LOG2F HAVE_LRINT HAVE_LRINTF HAVE_POWF HAVE_RINT HAVE_ROUND HAVE_ROUNDF HAVE_SINF HAVE_TRUNC
@@ -80,6 +80,8 @@ def main():
         for p in PUB:
             o.write("#define AV_HAVE_%s %d\n" % (p, 1 if ("HAVE_" + p) in ONES else 0))
         o.write("#endif\n")
+    with open(os.path.join(OUT, "avversion.h"), "w") as o:      # what avbuild/version.sh would write
+        o.write('#define LIBAV_VERSION "oracle-build"\n')
     print("wrote", OUT, len(toks), "macros")
 
 

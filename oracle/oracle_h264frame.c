@@ -229,14 +229,14 @@ static void recon_mb(Ctx *c)
             if (t & MI355_MB_8x8DCT) {
                 for (int i = 0; i < 16; i += 4) {
                     uint8_t *p = dy + off[i];
-                    pred.pred8x8l[m->intra4x4_pred_mode[i]](p, (m->topleft_samples_available << i) & 0x8000,
+                    pred.pred8x8l[m->u.intra4x4_pred_mode[i]](p, (m->topleft_samples_available << i) & 0x8000,
                                                             (m->topright_samples_available << i) & 0x4000, ys);
                     if (c->nnzc[oracle_scan8(i)]) dsp.h264_idct8_add(p, c->coef + i * 16, ys);
                 }
             } else {
                 for (int i = 0; i < 16; i++) {
                     uint8_t *p = dy + off[i];
-                    const int dir = m->intra4x4_pred_mode[i];
+                    const int dir = m->u.intra4x4_pred_mode[i];
                     uint8_t trbuf[4];
                     const uint8_t *tr = NULL;
                     if (dir == DIAG_DOWN_LEFT_PRED || dir == VERT_LEFT_PRED) {

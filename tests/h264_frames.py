@@ -16,8 +16,8 @@ MB_DT = np.dtype([
     ("mb_type", "<u4"), ("nnz_mask", "<u4"), ("cbp", "<u2"), ("qp", "i1"), ("flags", "u1"),
     ("alpha", "i1"), ("beta", "i1"), ("i16mode", "u1"), ("chroma_mode", "u1"),
     ("topleft", "<u2"), ("topright", "<u2"), ("sub", "u1", 4), ("ref_idx", "i1", (2, 4)),
-    ("dc_qmul", "<u4", 3), ("slice_id", "u1"), ("intra_level", "u1"), ("rsv", "u1", 2),
-    ("i4mode", "i1", 16)])
+    ("dc_qmul", "<u4", 3), ("slice_id", "u1"), ("intra_level", "u1"), ("qpc", "u1", 2),
+    ("i4mode", "i1", 16)])   # i4mode doubles as inter.ref_pic[2][4] (+8 reserved) for inter MBs
 assert MB_DT.itemsize == 64
 
 MAX_REFS, MAX_SLOTS = 16, 32
@@ -44,7 +44,7 @@ assert C.sizeof(Frame) == 904
 # mb_type bits
 I4, I16, PCM, T16x16, T16x8, T8x16, T8x8 = 1, 2, 4, 8, 16, 32, 64
 P0L0, P1L0, P0L1, P1L1, DCT8 = 0x1000, 0x2000, 0x4000, 0x8000, 0x01000000
-F_LEFT, F_TOP, F_NODB = 1, 2, 4
+F_LEFT, F_TOP, F_NODB, F_WEIGHTED = 1, 2, 4, 8
 ZIGZAG4 = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
 # the standard's chroma QP mapping (Table 8-15) for chroma_qp_index_offset = 0
 CHROMA_QP = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]
@@ -169,7 +169,7 @@ def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac
             rec = fs.mb[f, m]
             rec["qp"] = qp = r.randint(20, 40)
             rec["alpha"], rec["beta"] = a_off, b_off
-            rec["flags"] = (F_LEFT if mx else 0) | (F_TOP if my else 0)
+            rec["flags"] = (F_LEFT if mx else 0) | (F_TOP if my else 0) | (F_WEIGHTED if weighted else 0)
             qpc = CHROMA_QP[qp]
             intra = bool(is_intra[m])
             rec["dc_qmul"] = (dc_qmul(qp), dc_qmul(qpc), dc_qmul(qpc))
@@ -268,6 +268,12 @@ def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac
                     if use8:
                         t |= DCT8
             rec["mb_type"] = t
+            rec["qpc"] = (qpc, qpc)
+            if not intra:
+                for l in range(2):
+                    for q in range(4):
+                        ri = int(rec["ref_idx"][l][q])
+                        rec["i4mode"][4 * l + q] = np.uint8(sl["ref_slot"][l][ri]).astype(np.int8) if ri >= 0 else -1
             if t & PCM:
                 fs.coef[f, m].view(np.uint8)[:384] = r.u8(384)
                 rec["qp"] = 0
@@ -388,7 +394,7 @@ def host_frames(fs, recon, dst):
         fr.mv[1] = fs.mv[1, f].ctypes.data if fs.use_l1 else None
         fr.coef = fs.coef[f].ctypes.data
         fr.slices = fs.slices[f].ctypes.data
-        fr.nslices = 1
+        fr.nslices = fs.slices.shape[1]
         fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
         fr.intra_list = fs.intra_list[f].ctypes.data
         fr.intra_level_start = fs.intra_start[f].ctypes.data
@@ -410,9 +416,11 @@ def run_oracle(oracle, fs, deblock=True):
 
 
 class DeviceFrames:
-    """Uploads a FrameSet through the C ABI's memory helpers and builds device descriptors."""
+    """Uploads a FrameSet through the C ABI's memory helpers and builds device descriptors.
+    `replicate` = total number of pictures F >= fs.F: picture f is a device-side copy of picture
+    f % fs.F with its own buffers (bench.py: many independent streams from a few distinct ones)."""
 
-    def __init__(self, prov, fs):
+    def __init__(self, prov, fs, replicate=None):
         self.lib, self.fs = prov.lib, fs
         lib = self.lib
         lib.mi355_malloc.restype = C.c_void_p
@@ -420,27 +428,47 @@ class DeviceFrames:
         lib.mi355_free.argtypes = [C.c_void_p]
         lib.mi355_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mi355_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         self.bufs = []
-        self.mb = self.up(fs.mb)
-        self.mv0 = self.up(fs.mv[0])
-        self.mv1 = self.up(fs.mv[1]) if fs.use_l1 else None
-        self.coef = self.up(fs.coef)
-        self.slices = self.up(fs.slices)
+        G = fs.F
+        F = self.F = replicate or G
+        nmb = fs.mb_w * fs.mb_h
         ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
         self.fsz = ysz + 2 * csz
-        self.recon = self.alloc(fs.F * self.fsz)
-        self.dst = self.alloc(fs.F * self.fsz)
-        self.refs = self.alloc(fs.F * fs.nrefs * self.fsz)
-        for f in range(fs.F):
-            for s in range(fs.nrefs):
-                base = self.refs + (f * fs.nrefs + s) * self.fsz
-                y, cb, cr = fs.refs[f][s]
-                self.h2d(base, y)
-                self.h2d(base + ysz, cb)
-                self.h2d(base + ysz + csz, cr)
-        arr = (Frame * fs.F)()
-        nmb = fs.mb_w * fs.mb_h
-        for f in range(fs.F):
+
+        def up_rep(a, per):
+            """device array of F entries of `per` bytes; first G from the host, rest copied on the device"""
+            a = np.ascontiguousarray(a)
+            assert a.nbytes == G * per
+            p = self.alloc(F * per)
+            lib.mi355_memcpy_h2d(p, a.ctypes.data, a.nbytes)
+            done = G
+            while done < F:            # doubling copies
+                n = min(done, F - done)
+                lib.mi355_memcpy_d2d(p + done * per, p, n * per)
+                done += n
+            return p
+        self.mb = up_rep(fs.mb, nmb * 64)
+        self.mv0 = up_rep(fs.mv[0], nmb * 64)
+        self.mv1 = up_rep(fs.mv[1], nmb * 64) if fs.use_l1 else None
+        self.coef = up_rep(fs.coef, nmb * 768)
+        nsl = fs.slices.shape[1]
+        self.slices = up_rep(fs.slices, nsl * SLICE_DT.itemsize)
+        self.recon = self.alloc(F * self.fsz)
+        self.dst = self.alloc(F * self.fsz)
+        refs_host = np.empty((G, fs.nrefs, self.fsz), np.uint8)
+        for f in range(G):
+            for s_ in range(fs.nrefs):
+                y, cb, cr = fs.refs[f][s_]
+                refs_host[f, s_, :ysz] = y.reshape(-1)
+                refs_host[f, s_, ysz:ysz + csz] = cb.reshape(-1)
+                refs_host[f, s_, ysz + csz:] = cr.reshape(-1)
+        self.refs = up_rep(refs_host, fs.nrefs * self.fsz)
+        ilist = [self.up(fs.intra_list[g]) if len(fs.intra_list[g]) else None for g in range(G)]
+        istart = [self.up(fs.intra_start[g]) for g in range(G)]
+        arr = (Frame * F)()
+        for f in range(F):
+            g = f % G
             fr = arr[f]
             fr.mb_width, fr.mb_height = fs.mb_w, fs.mb_h
             for kind, base0 in (("dst", self.dst), ("recon", self.recon)):
@@ -449,18 +477,18 @@ class DeviceFrames:
                 a[0], a[1], a[2] = base, base + ysz, base + ysz + csz
             fr.dst_stride[0], fr.dst_stride[1] = fs.W, fs.W // 2
             fr.recon_stride[0], fr.recon_stride[1] = fs.W, fs.W // 2
-            for s in range(fs.nrefs):
-                base = self.refs + (f * fs.nrefs + s) * self.fsz
-                fr.ref[s][0], fr.ref[s][1], fr.ref[s][2] = base, base + ysz, base + ysz + csz
+            for s_ in range(fs.nrefs):
+                base = self.refs + (f * fs.nrefs + s_) * self.fsz
+                fr.ref[s_][0], fr.ref[s_][1], fr.ref[s_][2] = base, base + ysz, base + ysz + csz
             fr.mb = self.mb + f * nmb * 64
             fr.mv[0] = self.mv0 + f * nmb * 64
             fr.mv[1] = (self.mv1 + f * nmb * 64) if self.mv1 else None
             fr.coef = self.coef + f * nmb * 768
-            fr.slices = self.slices + f * SLICE_DT.itemsize
-            fr.nslices = 1
-            fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
-            fr.intra_list = self.up(fs.intra_list[f]) if len(fs.intra_list[f]) else None
-            fr.intra_level_start = self.up(fs.intra_start[f])
+            fr.slices = self.slices + f * nsl * SLICE_DT.itemsize
+            fr.nslices = nsl
+            fr.max_intra_level = int(fs.intra_start[g].shape[0]) - 1
+            fr.intra_list = ilist[g]          # read-only: shared between the copies
+            fr.intra_level_start = istart[g]
         self.host_desc = arr
         self.d_desc = self.alloc(C.sizeof(arr))
         self.lib.mi355_memcpy_h2d(self.d_desc, C.addressof(arr), C.sizeof(arr))
@@ -481,21 +509,22 @@ class DeviceFrames:
         self.lib.mi355_memcpy_h2d(p, a.ctypes.data, a.nbytes)
         return p
 
-    def fetch(self, base):
+    def fetch(self, base, first=0, count=None):
         fs = self.fs
-        raw = np.empty(fs.F * self.fsz, np.uint8)
-        self.lib.mi355_memcpy_d2h(raw.ctypes.data, base, raw.nbytes)
-        raw = raw.reshape(fs.F, self.fsz)
+        n = count or self.F
+        raw = np.empty(n * self.fsz, np.uint8)
+        self.lib.mi355_memcpy_d2h(raw.ctypes.data, base + first * self.fsz, raw.nbytes)
+        raw = raw.reshape(n, self.fsz)
         ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
-        return [raw[:, :ysz].reshape(fs.F, fs.H, fs.W), raw[:, ysz:ysz + csz].reshape(fs.F, fs.H // 2, fs.W // 2),
-                raw[:, ysz + csz:].reshape(fs.F, fs.H // 2, fs.W // 2)]
+        return [raw[:, :ysz].reshape(n, fs.H, fs.W), raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, fs.W // 2),
+                raw[:, ysz + csz:].reshape(n, fs.H // 2, fs.W // 2)]
 
     def decode(self, stream=None):
         fs = self.fs
         fn = self.lib.mi355_h264_decode_frames_dev
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        rc = fn(self.d_desc, fs.F, fs.mb_w, fs.mb_h, fs.max_intra_level, fs.max_level_width, stream)
+        rc = fn(self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, fs.max_level_width, stream)
         assert rc == 0, rc
         self.lib.mi355_sync.restype = C.c_int
         assert self.lib.mi355_sync(stream) == 0
@@ -554,6 +583,10 @@ def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05,
     ref = r.randint(0, nrefs - 1, N)
     mb["ref_idx"][:, 0, :] = np.where(intra, -1, ref)[:, None]
     mb["ref_idx"][:, 1, :] = -1
+    mb["qpc"][:, 0] = mb["qpc"][:, 1] = qpc
+    inter_rows = np.nonzero(~intra)[0]
+    mb["i4mode"][inter_rows, 0:4] = ref[inter_rows, None]      # inter.ref_pic[0][q] = ref_slot[0][ref_idx] (identity map)
+    mb["i4mode"][inter_rows, 4:8] = -1
     mv = r.randint(-mv_range, mv_range - 1, (N, 2))
     mv[intra] = 0
     fs.mv[0].reshape(N, 16, 2)[:] = mv[:, None, :]
