@@ -16,7 +16,9 @@ void oracle_h264dsp_init(H264DSPContext *c, int bit_depth, int chroma_format_idc
 void oracle_h264qpel_init(H264QpelContext *c, int bit_depth);                         /* h264qpel.c:37 */
 void oracle_h264chroma_init(H264ChromaContext *c, int bit_depth);                     /* h264chroma.c:39 */
 void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc); /* h264pred.c:402 */
-void oracle_videodsp_init(VideoDSPContext *c, int bpc);                               /* videodsp.c:35 */
+void oracle_videodsp_init(VideoDSPContext *c, int bpc);
+void oracle_hevc_dsp_init(HEVCDSPContext *c, int bit_depth);                         /* hevcdsp.c:136 */
+void oracle_hevc_pred_init(HEVCPredContext *h, int bit_depth);                       /* hevcpred.c:37 */                               /* videodsp.c:35 */
 void oracle_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int size, int mx, int my, int avg);
 void oracle_h264_qpel2(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int size, int mx, int my, int avg);
 void oracle_h264_chroma_mc2(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int h, int x, int y, int w, int avg);
