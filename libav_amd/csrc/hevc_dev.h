@@ -1,0 +1,362 @@
+/*
+ * hevc_dev.h — wave-cooperative HEVC building blocks, bit depth as a
+ * runtime parameter (8, 9, 10): samples are uint8_t or uint16_t, coefficients int16_t.
+ * Same execution model as h264_dev.h: one 64-lane wavefront per workgroup, LDS private to the wave.
+ * Reference: libavcodec/hevcdsp_template.c, hevcpred_template.c (lines quoted per function).
+ */
+#ifndef MI355_HEVC_DEV_H
+#define MI355_HEVC_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "h264_dev.h"   /* clip3, iabs, lane_id */
+
+namespace mi355 {
+
+__device__ __forceinline__ int clip_i16(int v) { return clip3(v, -32768, 32767); }
+__device__ __forceinline__ int clip_px(int v, int bd) { return clip3(v, 0, (1 << bd) - 1); }
+/* sample i of a plane whose element size depends on the bit depth */
+__device__ __forceinline__ int ldpx(const uint8_t *p, int i, int bd) { return bd > 8 ? reinterpret_cast<const uint16_t *>(p)[i] : p[i]; }
+__device__ __forceinline__ void stpx(uint8_t *p, int i, int v, int bd)
+{
+    if (bd > 8) reinterpret_cast<uint16_t *>(p)[i] = (uint16_t)v; else p[i] = (uint8_t)v;
+}
+
+/* ---- inverse DCT matrix: transMatrix[k][n] = c(k) cos((2n+1) k pi/64) in the standard's integers,
+ * generated from the 33 magnitudes of angle index a = (2n+1)k mod 128 ------------------------- */
+__device__ const int8_t k_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                          61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+__device__ __forceinline__ int dct_coef(int k, int n)
+{
+    if (!k) return 64;
+    const int a = ((2 * n + 1) * k) & 127;
+    return a <= 32 ? k_dct_mag[a] : (a <= 64 ? -k_dct_mag[64 - a] : (a <= 96 ? -k_dct_mag[a - 64] : k_dct_mag[128 - a]));
+}
+/* rows of the input a 1-D pass of size H looks at when pruned to `end` (hevcdsp_template.c:140-206) */
+__device__ __forceinline__ bool dct_row_used(int H, int j, int end)
+{
+    if (H == 4) return true;
+    if (j & 1) return j < end;
+    if (H == 32 && ((j >> 1) & 1)) return (j >> 1) < (end >> 1);
+    return true;
+}
+
+struct IdctScratch {
+    int16_t c[32 * 32];
+    int8_t m[32 * 32];     /* m[j*32+n] = transMatrix[j*(32/H)][n] for the current size */
+};
+
+/* In-place 2-D inverse DCT of s.c (HxH, row-major) with the reference's col_limit semantics
+ * (:208-236): first pass down the columns with limit2 shrinking every 4 columns, clip to int16
+ * after (x+64)>>7; second pass along the rows, (x + (1<<(19-bd))) >> (20-bd). */
+template <int H>
+__device__ inline void hevc_idct_wave(IdctScratch &s, int col_limit, int bd)
+{
+    const int lane = lane_id(), step = 32 / H;
+    for (int i = lane; i < H * H; i += 64) s.m[(i / H) * 32 + (i % H)] = (int8_t)dct_coef((i / H) * step, i % H);
+    __syncthreads();
+    const int limit = col_limit < H ? col_limit : H;
+    const int l0 = col_limit + 4 < H ? col_limit + 4 : H;
+    int out[H];
+    if (lane < H) {
+        const int i = lane;
+        const int end = l0 < H ? l0 - 4 * (i > 0 ? (i - 1) >> 2 : 0) : H;
+#pragma unroll
+        for (int n = 0; n < H; n++) out[n] = 0;
+        for (int j = 0; j < H; j++) {
+            if (!dct_row_used(H, j, end)) continue;
+            const int v = s.c[i + H * j];
+#pragma unroll
+            for (int n = 0; n < H; n++) out[n] += s.m[j * 32 + n] * v;
+        }
+#pragma unroll
+        for (int n = 0; n < H; n++) s.c[i + H * n] = (int16_t)clip_i16((out[n] + 64) >> 7);
+    }
+    __syncthreads();
+    if (lane < H) {
+        const int i = lane, shift = 20 - bd, add = 1 << (shift - 1);
+#pragma unroll
+        for (int n = 0; n < H; n++) out[n] = 0;
+        for (int j = 0; j < H; j++) {
+            if (!dct_row_used(H, j, limit)) continue;
+            const int v = s.c[H * i + j];
+#pragma unroll
+            for (int n = 0; n < H; n++) out[n] += s.m[j * 32 + n] * v;
+        }
+#pragma unroll
+        for (int n = 0; n < H; n++) s.c[H * i + n] = (int16_t)clip_i16((out[n] + add) >> shift);
+    }
+    __syncthreads();
+}
+
+/* 4x4 DST-VII for intra luma (:103-136), lanes 0..3 */
+__device__ __forceinline__ void dst4_1d(const int in[4], int out[4])
+{
+    const int c0 = in[0] + in[2], c1 = in[2] + in[3], c2 = in[0] - in[3], c3 = 74 * in[1];
+    out[0] = 29 * c0 + 55 * c1 + c3;
+    out[1] = 55 * c2 - 29 * c1 + c3;
+    out[2] = 74 * (in[0] - in[2] + in[3]);
+    out[3] = 55 * c0 + 29 * c2 - c3;
+}
+__device__ inline void hevc_dst4_wave(int16_t *c, int bd)
+{
+    const int lane = lane_id();
+    int in[4], out[4];
+    if (lane < 4) {
+        for (int k = 0; k < 4; k++) in[k] = c[lane + 4 * k];
+        dst4_1d(in, out);
+        for (int k = 0; k < 4; k++) c[lane + 4 * k] = (int16_t)clip_i16((out[k] + 64) >> 7);
+    }
+    __syncthreads();
+    if (lane < 4) {
+        const int shift = 20 - bd, add = 1 << (shift - 1);
+        for (int k = 0; k < 4; k++) in[k] = c[4 * lane + k];
+        dst4_1d(in, out);
+        for (int k = 0; k < 4; k++) c[4 * lane + k] = (int16_t)clip_i16((out[k] + add) >> shift);
+    }
+    __syncthreads();
+}
+
+/* ---- a14: luma 8-tap / chroma 4-tap MC to the 14-bit intermediate ----------------------------- */
+__device__ const int8_t k_qpel[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                                         { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+__device__ const int8_t k_epel[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+                                         { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+/* src points at sample (0,0) of the block inside a plane/window with `ss` samples per row; dst is
+ * int16 with `ds` elements per row; tmp: (height+7) x 64 int16 scratch (LDS) for the 2-D case.
+ * taps = 8 (qpel, :729-937) or 4 (epel, :939-1089). */
+__device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
+                                    int mx, int my, int bd, int taps, int16_t *tmp)
+{
+    const int lane = lane_id();
+    const int before = taps == 8 ? 3 : 1, extra = taps == 8 ? 7 : 3;
+    const int8_t *fh = taps == 8 ? k_qpel[mx] : k_epel[mx], *fv = taps == 8 ? k_qpel[my] : k_epel[my];
+    if (mx && my) {
+        for (int i = lane; i < (height + extra) * width; i += 64) {
+            const int y = i / width, x = i - y * width;
+            int a = 0;
+            for (int k = 0; k < taps; k++) if (fh[k]) a += fh[k] * ldpx(src, x + k - before + (y - before) * ss, bd);
+            tmp[x + y * 64] = (int16_t)(a >> (bd - 8));
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < height * width; i += 64) {
+        const int y = i / width, x = i - y * width;
+        int a = 0;
+        if (!mx && !my) a = ldpx(src, x + y * ss, bd) << (14 - bd);
+        else if (!my) { for (int k = 0; k < taps; k++) if (fh[k]) a += fh[k] * ldpx(src, x + k - before + y * ss, bd); a >>= bd - 8; }
+        else if (!mx) { for (int k = 0; k < taps; k++) if (fv[k]) a += fv[k] * ldpx(src, x + (y + k - before) * ss, bd); a >>= bd - 8; }
+        else { for (int k = 0; k < taps; k++) a += fv[k] * tmp[x + (y + k) * 64]; a >>= 6; }
+        dst[x + y * ds] = (int16_t)a;
+    }
+    __syncthreads();
+}
+
+/* ---- a15: 14-bit intermediate -> samples (:1091-1242); mode 0 plain, 1 average, 2 weighted,
+ * 3 weighted average ---------------------------------------------------------------------------- */
+struct HevcPredParams {
+    int mode, denom, w0, w1, o0, o1;
+};
+__device__ __forceinline__ int hevc_pred_px(const HevcPredParams &p, int a, int b, int bd)
+{
+    const int shift = 14 - bd;
+    if (p.mode == 0) return clip_px((a + (1 << (shift - 1))) >> shift, bd);
+    if (p.mode == 1) return clip_px((a + b + (1 << shift)) >> (shift + 1), bd);
+    const int log2Wd = p.denom + shift;
+    if (p.mode == 2) {
+        const int ox = p.o0 * (1 << (bd - 8));
+        return clip_px(log2Wd >= 1 ? ((a * p.w0 + (1 << (log2Wd - 1))) >> log2Wd) + ox : a * p.w0 + ox, bd);
+    }
+    const int o0 = p.o0 * (1 << (bd - 8)), o1 = p.o1 * (1 << (bd - 8));
+    return clip_px((a * p.w0 + b * p.w1 + ((o0 + o1 + 1) << log2Wd)) >> (log2Wd + 1), bd);
+}
+
+/* ---- a16: deblocking of one 8-sample edge, lanes 0..7 = the 8 lines (:1264-1392) ----------------
+ * `xs`: sample step across the edge, `ys`: along it.  Decisions use lines 0 and 3 of each 4-line
+ * half, fetched from the neighbouring lanes with shuffles. */
+__device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta, const int *tc_, const uint8_t *no_p_,
+                                         const uint8_t *no_q_, int bd)
+{
+    const int lane = lane_id(), l = lane & 7, j = l >> 2;
+    const bool act = lane < 8;
+    int p[4], q[4];
+    for (int k = 0; k < 4; k++) {
+        p[k] = act ? ldpx(pix, -(k + 1) * xs + l * ys, bd) : 0;
+        q[k] = act ? ldpx(pix, k * xs + l * ys, bd) : 0;
+    }
+    const int dp = iabs(p[2] - 2 * p[1] + p[0]), dq = iabs(q[2] - 2 * q[1] + q[0]);
+    const int sflat = iabs(p[3] - p[0]) + iabs(q[3] - q[0]), sgap = iabs(p[0] - q[0]);
+    /* values of line 0 and line 3 of this lane's half */
+    const int dp0 = __shfl(dp, 4 * j), dp3 = __shfl(dp, 4 * j + 3), dq0 = __shfl(dq, 4 * j), dq3 = __shfl(dq, 4 * j + 3);
+    const int f0 = __shfl(sflat, 4 * j), f3 = __shfl(sflat, 4 * j + 3), g0 = __shfl(sgap, 4 * j), g3 = __shfl(sgap, 4 * j + 3);
+    if (!act) return;
+    beta <<= bd - 8;
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    const int tc = tc_[j] << (bd - 8), no_p = no_p_[j], no_q = no_q_[j];
+    if (d0 + d3 >= beta) return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (f0 < beta_3 && g0 < tc25 && f3 < beta_3 && g3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        const int tc2 = tc << 1;
+        if (!no_p) {
+            stpx(pix, -1 * xs + l * ys, p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2), bd);
+            stpx(pix, -2 * xs + l * ys, p[1] + clip3(((p[2] + p[1] + p[0] + q[0] + 2) >> 2) - p[1], -tc2, tc2), bd);
+            stpx(pix, -3 * xs + l * ys, p[2] + clip3(((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3) - p[2], -tc2, tc2), bd);
+        }
+        if (!no_q) {
+            stpx(pix, 0 * xs + l * ys, q[0] + clip3(((p[1] + 2 * p[0] + 2 * q[0] + 2 * q[1] + q[2] + 4) >> 3) - q[0], -tc2, tc2), bd);
+            stpx(pix, 1 * xs + l * ys, q[1] + clip3(((p[0] + q[0] + q[1] + q[2] + 2) >> 2) - q[1], -tc2, tc2), bd);
+            stpx(pix, 2 * xs + l * ys, q[2] + clip3(((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3) - q[2], -tc2, tc2), bd);
+        }
+    } else {
+        const int tc_2 = tc >> 1, thr = (beta + (beta >> 1)) >> 3;
+        const int nd_p = dp0 + dp3 < thr ? 2 : 1, nd_q = dq0 + dq3 < thr ? 2 : 1;
+        int delta0 = (9 * (q[0] - p[0]) - 3 * (q[1] - p[1]) + 8) >> 4;
+        if (iabs(delta0) >= 10 * tc) return;
+        delta0 = clip3(delta0, -tc, tc);
+        if (!no_p) stpx(pix, -1 * xs + l * ys, clip_px(p[0] + delta0, bd), bd);
+        if (!no_q) stpx(pix, l * ys, clip_px(q[0] - delta0, bd), bd);
+        if (!no_p && nd_p > 1) stpx(pix, -2 * xs + l * ys, clip_px(p[1] + clip3((((p[2] + p[0] + 1) >> 1) - p[1] + delta0) >> 1, -tc_2, tc_2), bd), bd);
+        if (!no_q && nd_q > 1) stpx(pix, xs + l * ys, clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd), bd);
+    }
+}
+__device__ inline void hevc_lf_chroma_wave(uint8_t *pix, int xs, int ys, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd)
+{
+    const int lane = lane_id();
+    if (lane >= 8) return;
+    const int l = lane, j = l >> 2, tc = tc_[j] << (bd - 8);
+    if (tc <= 0) return;
+    const int p1 = ldpx(pix, -2 * xs + l * ys, bd), p0 = ldpx(pix, -xs + l * ys, bd);
+    const int q0 = ldpx(pix, l * ys, bd), q1 = ldpx(pix, xs + l * ys, bd);
+    const int delta0 = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+    if (!no_p_[j]) stpx(pix, -xs + l * ys, clip_px(p0 + delta0, bd), bd);
+    if (!no_q_[j]) stpx(pix, l * ys, clip_px(q0 - delta0, bd), bd);
+}
+
+/* ---- a17: SAO (:270-718).  The region a (class, borders) pair owns is decided by the caller's
+ * geometry helper; every sample of it is independent. ----------------------------------------- */
+struct SaoJob {
+    int width, height;            /* as passed by the reference caller */
+    int c_idx, cls, bd, edge;     /* edge: 0 band, 1 edge */
+    int borders[4];
+    int vert_edge, horiz_edge, diag_edge;
+    int eo_class, band_position;
+    int offset_val[5];
+};
+/* src/dst point at the caller's (0,0) sample; `dt`/`st` = samples per row of dst/src */
+__device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, int st, const SaoJob &j)
+{
+    const int chroma = j.c_idx != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, bd = j.bd, cls = j.cls;
+    int x0 = 0, y0 = 0, w = j.width, h = j.height;
+    if (cls & 1) { y0 = -ch; h = ch; } else if (!j.borders[3]) h -= ch;
+    if (cls & 2) { x0 = -cw; w = cw; } else if (!j.borders[2]) w -= cw;
+    const int w0 = w, h0 = h;
+    if (!j.edge) {
+        const int shift = bd - 5;
+        for (int i = lane_id(); i < w * h; i += 64) {
+            const int y = i / w, x = i - y * w, o = (y0 + y) * st + x0 + x;
+            const int v = ldpx(src, o, bd), k = ((v >> shift) - j.band_position) & 31;
+            stpx(dst, (y0 + y) * dt + x0 + x, clip_px(v + (k < 4 ? j.offset_val[k + 1] : 0), bd), bd);
+        }
+        return;
+    }
+    const int eo = j.eo_class;
+    int init_x = 0, init_y = 0;
+    const bool colpre = !(cls & 2) && eo != 1, rowpre = !(cls & 1) && eo != 0;
+    if (colpre) { if (j.borders[0]) init_x = 1; if (j.borders[2]) w--; }
+    if (rowpre) { if (j.borders[1]) init_y = 1; if (j.borders[3]) h--; }
+    const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
+    const int dx1 = -dx0, dy1 = -dy0;
+    /* restore rules: each class owns one corner of the CTB */
+    const int ex = (cls & 2) ? w - 1 : 0, ey = (cls & 1) ? h - 1 : 0;
+    const int diag_class = (cls == 0 || cls == 3) ? 2 : 3;
+    int save;
+    if (cls == 0) save = !j.diag_edge && eo == 2 && !j.borders[0] && !j.borders[1];
+    else if (cls == 1) save = !j.diag_edge && eo == 3 && !j.borders[0];
+    else if (cls == 2) save = !j.diag_edge && eo == 3 && !j.borders[1];
+    else save = !j.diag_edge && eo == 2;
+    const int ya = init_y + ((cls & 1) ? 0 : save), yb = h - ((cls & 1) ? save : 0);
+    const int xa = init_x + ((cls & 2) ? 0 : save), xb = w - ((cls & 2) ? save : 0);
+    for (int i = lane_id(); i < w0 * h0; i += 64) {
+        const int y = i / w0, x = i - y * w0, o = (y0 + y) * st + x0 + x;
+        const int c = ldpx(src, o, bd);
+        int v;
+        const bool in_main = x >= init_x && x < w && y >= init_y && y < h;
+        if (in_main) {
+            const int a = ldpx(src, o + dx0 + dy0 * st, bd), b = ldpx(src, o + dx1 + dy1 * st, bd);
+            const int d = (c > a) - (c < a) + (c > b) - (c < b);          /* -2..2 */
+            const int idx = d == 0 ? 0 : (d == -2 ? 1 : (d == -1 ? 2 : (d == 1 ? 3 : 4)));
+            v = clip_px(c + j.offset_val[idx], bd);
+        } else {
+            v = clip_px(c + j.offset_val[0], bd);   /* picture-border column / row */
+        }
+        if (j.vert_edge && eo != 1 && x == ex && y >= ya && y < yb) v = c;
+        if (j.horiz_edge && eo != 0 && y == ey && x >= xa && x < xb) v = c;
+        if (j.diag_edge && eo == diag_class && x == ex && y == ey) v = c;
+        stpx(dst, (y0 + y) * dt + x0 + x, v, bd);
+    }
+}
+
+/* ---- a18: pure intra predictors (hevcpred_template.c:349-516); top/left point at element 0 and
+ * element -1 is addressable; `st` = samples per row of the destination ------------------------- */
+__device__ const int8_t k_intra_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                              -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+__device__ const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+
+struct HevcPredScratch {
+    int16_t top[1 + 65], left[1 + 65];   /* [0] = element -1 */
+    int16_t ref[32 + 65];                /* ref[32 + k] = extended main reference k */
+};
+/* kind 0 planar, 1 dc, 2 angular */
+__device__ inline void hevc_pred_wave(HevcPredScratch &s, uint8_t *dst, int st, int log2, int kind, int c_idx, int mode, int bd)
+{
+    const int lane = lane_id(), size = 1 << log2;
+    const int16_t *top = s.top + 1, *left = s.left + 1;
+    if (kind == 0) {
+        for (int i = lane; i < size * size; i += 64) {
+            const int y = i >> log2, x = i & (size - 1);
+            stpx(dst, x + y * st, ((size - 1 - x) * left[y] + (x + 1) * top[size] + (size - 1 - y) * top[x] + (y + 1) * left[size] + size) >> (log2 + 1), bd);
+        }
+        return;
+    }
+    if (kind == 1) {
+        int dc = size;
+        for (int i = 0; i < size; i++) dc += left[i] + top[i];
+        dc >>= log2 + 1;
+        const bool smooth = c_idx == 0 && size < 32;
+        for (int i = lane; i < size * size; i += 64) {
+            const int y = i >> log2, x = i & (size - 1);
+            int v = dc;
+            if (smooth) {
+                if (x == 0 && y == 0) v = (left[0] + 2 * dc + top[0] + 2) >> 2;
+                else if (y == 0) v = (top[x] + 3 * dc + 2) >> 2;
+                else if (x == 0) v = (left[y] + 3 * dc + 2) >> 2;
+            }
+            stpx(dst, x + y * st, v, bd);
+        }
+        return;
+    }
+    const int angle = k_intra_angle[mode - 2], last = (size * angle) >> 5;
+    const bool vertical = mode >= 18;
+    const int16_t *main_e = vertical ? top : left, *side_e = vertical ? left : top;
+    int16_t *ref = s.ref + 32;
+    for (int k = lane; k <= (angle < 0 ? size : 2 * size); k += 64) ref[k] = main_e[k - 1];
+    if (angle < 0 && last < -1)
+        for (int k = last + lane; k <= -1; k += 64) ref[k] = side_e[-1 + ((k * k_inv_angle[mode - 11] + 128) >> 8)];
+    __syncthreads();
+    const bool edge_fix = c_idx == 0 && size < 32 && (mode == 26 || mode == 10);
+    for (int i = lane; i < size * size; i += 64) {
+        const int a = i >> log2, b = i & (size - 1);         /* a: along the minor axis */
+        const int idx = ((a + 1) * angle) >> 5, fact = ((a + 1) * angle) & 31;
+        int v = fact ? ((32 - fact) * ref[b + idx + 1] + fact * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
+        const int x = vertical ? b : a, y = vertical ? a : b;
+        if (edge_fix) {
+            if (mode == 26 && x == 0) v = clip_px(top[0] + ((left[y] - left[-1]) >> 1), bd);
+            if (mode == 10 && y == 0) v = clip_px(left[0] + ((top[x] - top[-1]) >> 1), bd);
+        }
+        stpx(dst, x + y * st, v, bd);
+    }
+}
+
+}  // namespace mi355
+#endif
