@@ -1,0 +1,477 @@
+/*
+ * sws.hip — the libswscale part of the path for yuv420p -> rgb24:
+ *   k_sws_generic   the generic scaler of swscale() (libswscale/swscale.c:343-722) for whole pictures,
+ *                   fused per output tile: horizontal 8->15 bit FIR of the source lines the tile needs
+ *                   (hScale8To15_c :133-147) into LDS, vertical FIR + yuv->rgb LUT
+ *                   (yuv2rgb24_{1,2,X}_c output.c:937-1110) from LDS, RGB rows staged in LDS and
+ *                   written as dwords.  No int16 intermediate ever goes to HBM.
+ *   k_sws_c24       the unscaled converter yuv2rgb_c_24_rgb (yuv2rgb.c:335-363).
+ *   k_sws_line_*    the individual inner loops for the Tier-1 entry points.
+ * Filter banks and LUTs are inputs (built by the reference's init code, see include/mi355_sws.h).
+ * Execution model: 256-thread workgroups (4 waves) sharing one LDS tile; integer only, no MFMA.
+ */
+#include "mi355_rt.h"
+#include "../../include/mi355_sws.h"
+#include "../../include/mi355dsp.h"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int TW = 128;      /* output samples per tile row */
+constexpr int MAXTH = 16;    /* output rows per tile (upper bound) */
+constexpr int MAXL = 48;     /* source luma lines a tile may need */
+constexpr int MAXC = 24;     /* source chroma lines a tile may need */
+constexpr int NT = 256;
+
+struct SwsDev {
+    int srcW, srcH, dstW, dstH, chrSrcW, chrSrcH, chrDstW, special;
+    int hls, hcs, vls, vcs;                 /* filter sizes */
+    const int16_t *hLumC, *hChrC, *vLumC, *vChrC;
+    const int32_t *hLumP, *hChrP, *vLumP, *vChrP;
+    int th;                                 /* output rows per tile chosen at create time */
+    mi355_sws_luts luts;
+};
+
+struct LutLds {
+    uint8_t y[1024];
+    int16_t rV[256], gU[256], gV[256], bU[256];
+};
+__device__ __forceinline__ void lut_load(LutLds &s, const mi355_sws_luts *g, int tid, int nt)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s);
+    for (int i = tid; i < (int)(sizeof(LutLds) / 4); i += nt) dst[i] = src[i];
+}
+__device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+/* yuv2rgb_write, rgb24 branch (output.c:853-866) */
+__device__ __forceinline__ void write_pair(const LutLds &t, uint8_t *dest, int Y1, int Y2, int U, int V)
+{
+    const int r = t.rV[V], g = t.gU[U] + t.gV[V], b = t.bU[U];
+    dest[0] = t.y[r + Y1]; dest[1] = t.y[g + Y1]; dest[2] = t.y[b + Y1];
+    dest[3] = t.y[r + Y2]; dest[4] = t.y[g + Y2]; dest[5] = t.y[b + Y2];
+}
+
+/* one output pair of the three packed templates; rows are addressed through accessors so the same
+ * code serves LDS tiles (whole pictures) and packed global rows (Tier-1 line calls) */
+template <typename Rows>
+__device__ __forceinline__ void rgb_pair(const LutLds &t, uint8_t *dest, const Rows &R, int i, int mode, const int16_t *lumF, int ls,
+                                         const int16_t *chrF, int cs, int yalpha, int uvalpha)
+{
+    int Y1, Y2, U, V;
+    if (mode == 1) {          /* yuv2rgb_1_c_template output.c:1043-1110 */
+        Y1 = clip_u8(R.lum(0, 2 * i) >> 7); Y2 = clip_u8(R.lum(0, 2 * i + 1) >> 7);
+        if (uvalpha < 2048) { U = clip_u8(R.cu(0, i) >> 7); V = clip_u8(R.cv(0, i) >> 7); }
+        else { U = clip_u8((R.cu(0, i) + R.cu(1, i)) >> 8); V = clip_u8((R.cv(0, i) + R.cv(1, i)) >> 8); }
+    } else if (mode == 2) {   /* yuv2rgb_2_c_template :998-1041 */
+        const int ya1 = 4096 - yalpha, ua1 = 4096 - uvalpha;
+        Y1 = clip_u8((R.lum(0, 2 * i) * ya1 + R.lum(1, 2 * i) * yalpha) >> 19);
+        Y2 = clip_u8((R.lum(0, 2 * i + 1) * ya1 + R.lum(1, 2 * i + 1) * yalpha) >> 19);
+        U = clip_u8((R.cu(0, i) * ua1 + R.cu(1, i) * uvalpha) >> 19);
+        V = clip_u8((R.cv(0, i) * ua1 + R.cv(1, i) * uvalpha) >> 19);
+    } else {                  /* yuv2rgb_X_c_template :937-996: clipped only if a value has bit 8 set */
+        Y1 = Y2 = U = V = 1 << 18;
+        for (int j = 0; j < ls; j++) { const int f = lumF[j]; Y1 += R.lum(j, 2 * i) * f; Y2 += R.lum(j, 2 * i + 1) * f; }
+        for (int j = 0; j < cs; j++) { const int f = chrF[j]; U += R.cu(j, i) * f; V += R.cv(j, i) * f; }
+        Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+        if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
+    }
+    write_pair(t, dest, Y1, Y2, U, V);
+}
+__device__ __forceinline__ int packed_mode(int ls, int cs) { return (ls == 1 && cs <= 2) ? 1 : ((ls == 2 && cs == 2) ? 2 : 0); }  /* swscale.c:658-682 */
+
+/* hScale8To15_c swscale.c:133-147 for one output sample */
+__device__ __forceinline__ int hscale_one(const uint8_t *src, const int16_t *f, int pos, int fs)
+{
+    int val = 0;
+    for (int j = 0; j < fs; j++) val += (int)src[pos + j] * f[j];
+    val >>= 7;
+    return val < 32767 ? val : 32767;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+struct TileRows {
+    const int16_t (*lumT)[TW];
+    const int16_t (*cuT)[TW / 2];
+    const int16_t (*cvT)[TW / 2];
+    int lfirst, llo, lmax, cfirst, clo, cmax;   /* first tap line, first staged line, last picture line */
+    __device__ __forceinline__ int lum(int j, int x) const { return lumT[clampi(lfirst + j, 0, lmax) - llo][x]; }
+    __device__ __forceinline__ int cu(int j, int x) const { return cuT[clampi(cfirst + j, 0, cmax) - clo][x]; }
+    __device__ __forceinline__ int cv(int j, int x) const { return cvT[clampi(cfirst + j, 0, cmax) - clo][x]; }
+};
+
+__global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi355_sws_frame *frames)
+{
+    __shared__ int16_t s_lum[MAXL][TW];
+    __shared__ int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
+    __shared__ LutLds s_lut;
+    __shared__ uint8_t s_out[MAXTH][TW * 3];
+    const SwsDev &c = *cp;
+    const mi355_sws_frame fr = frames[blockIdx.z];
+    const int tid = threadIdx.x, th = c.th;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * th, y1 = imin(y0 + th, c.dstH) - 1;
+    const int ls = c.vls, cs = c.vcs;
+    /* source lines this tile needs (swscale.c:459-468 for the first tap, :571-616 for the clamping) */
+    const int lfirst0 = imax(1 - ls, c.vLumP[y0]), lfirst1 = imax(1 - ls, c.vLumP[y1]);
+    const int cfirst0 = imax(1 - cs, c.vChrP[y0]), cfirst1 = imax(1 - cs, c.vChrP[y1]);
+    const int llo = clampi(lfirst0, 0, c.srcH - 1), lhi = clampi(lfirst1 + ls - 1, 0, c.srcH - 1);
+    const int clo = clampi(cfirst0, 0, c.chrSrcH - 1), chi = clampi(cfirst1 + cs - 1, 0, c.chrSrcH - 1);
+    lut_load(s_lut, &c.luts, tid, NT);
+    /* horizontal pass, luma: thread -> one column, loops over the lines */
+    {
+        const int x = tid & (TW - 1), gx = x0 + x;
+        if (gx < c.dstW) {
+            const int pos = c.hLumP[gx];
+            const int16_t *f = c.hLumC + (size_t)gx * c.hls;
+            for (int l = llo + (tid >> 7); l <= lhi; l += NT / TW)
+                s_lum[l - llo][x] = (int16_t)hscale_one(fr.src[0] + (size_t)l * fr.src_stride[0], f, pos, c.hls);
+        } else {
+            /* the phantom partner of the last sample of an odd-width picture: the reference reads the
+             * zero-initialised tail of its line buffer (utils.c:1241-1262) */
+            for (int l = llo + (tid >> 7); l <= lhi; l += NT / TW) s_lum[l - llo][x] = 0;
+        }
+    }
+    /* chroma: 64 columns x 2 planes */
+    {
+        const int x = tid & (TW / 2 - 1), plane = (tid >> 6) & 1, gx = (x0 >> 1) + x;
+        if (gx < c.chrDstW) {
+            const int pos = c.hChrP[gx];
+            const int16_t *f = c.hChrC + (size_t)gx * c.hcs;
+            const uint8_t *sp = fr.src[1 + plane];
+            const int st = fr.src_stride[1 + plane];
+            int16_t (*dstp)[TW / 2] = plane ? s_cv : s_cu;
+            for (int l = clo + (tid >> 7); l <= chi; l += NT / TW)
+                dstp[l - clo][x] = (int16_t)hscale_one(sp + (size_t)l * st, f, pos, c.hcs);
+        }
+    }
+    __syncthreads();
+    /* vertical pass + LUT */
+    const int mode = packed_mode(ls, cs);
+    const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
+    for (int p = tid; p < th * (TW / 2); p += NT) {
+        const int row = p >> 6, i = p & 63, gy = y0 + row;
+        if (gy > y1 || i >= npairs) continue;
+        TileRows R{ s_lum, s_cu, s_cv, imax(1 - ls, c.vLumP[gy]), llo, c.srcH - 1, imax(1 - cs, c.vChrP[gy]), clo, c.chrSrcH - 1 };
+        int ya = 0, ua = 0;
+        if (mode == 1) ua = cs == 1 ? 0 : c.vChrC[2 * gy + 1];
+        else if (mode == 2) { ya = c.vLumC[2 * gy + 1]; ua = c.vChrC[2 * gy + 1]; }
+        rgb_pair(s_lut, &s_out[row][i * 6], R, i, mode, c.vLumC + (size_t)gy * ls, ls, c.vChrC + (size_t)gy * cs, cs, ya, ua);
+    }
+    __syncthreads();
+    /* rows out: only samples below dstW (for odd dstW the reference also writes the phantom partner of
+     * the last sample from uninitialised ring-buffer data; that sample is not reproduced) */
+    const int nbytes = imin(TW, c.dstW - x0) * 3;
+    for (int row = 0; row <= y1 - y0; row++) {
+        uint8_t *d = fr.dst + (size_t)(y0 + row) * fr.dst_stride + (size_t)x0 * 3;
+        if (((uintptr_t)d & 3) == 0 && (nbytes & 3) == 0) {
+            for (int k = tid; k < nbytes / 4; k += NT) reinterpret_cast<uint32_t *>(d)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
+        } else {
+            for (int k = tid; k < nbytes; k += NT) d[k] = s_out[row][k];
+        }
+    }
+}
+
+/* yuv2rgb_c_24_rgb (yuv2rgb.c:335-363): a block converts a 256 x 16 sample tile, each thread a
+ * 2x2 quad per step — one (U,V) pair serves both lines (LOADCHROMA :67-72, nearest chroma) */
+constexpr int C24_ROWS = 16;
+__global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int dstW, int sliceH, int sliceY, const mi355_sws_frame *frames)
+{
+    __shared__ LutLds s_lut;
+    const int tid = threadIdx.x;
+    const mi355_sws_frame fr = frames[blockIdx.z];
+    lut_load(s_lut, luts, tid, NT);
+    __syncthreads();
+    const int x = blockIdx.x * 256 + (tid & 127) * 2;    /* first sample of the pair */
+    if ((x >> 1) >= (dstW >> 1)) return;   /* pairs i < dstW >> 1 (8 + 4 + 2 sample groups, yuv2rgb.c:129-171) */
+    for (int r = (tid >> 7); r < C24_ROWS / 2; r += 2) {
+        const int y = blockIdx.y * C24_ROWS + 2 * r;
+        if (y >= sliceH) break;
+        const uint8_t *py1 = fr.src[0] + (size_t)y * fr.src_stride[0] + x, *py2 = py1 + fr.src_stride[0];
+        const int U = fr.src[1][(size_t)(y >> 1) * fr.src_stride[1] + (x >> 1)], V = fr.src[2][(size_t)(y >> 1) * fr.src_stride[2] + (x >> 1)];
+        uint8_t *d1 = fr.dst + (size_t)(y + sliceY) * fr.dst_stride + (size_t)x * 3, *d2 = d1 + fr.dst_stride;
+        write_pair(s_lut, d1, py1[0], py1[1], U, V);
+        write_pair(s_lut, d2, py2[0], py2[1], U, V);
+    }
+}
+
+/* ---- Tier-1 line kernels ---------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(NT) k_sws_line_hscale(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs)
+{
+    for (int i = threadIdx.x; i < dstW; i += NT) dst[i] = (int16_t)hscale_one(src, filter + (size_t)i * fs, pos[i], fs);
+}
+/* yuv2planeX_8_c output.c:242-255 (fs >= 1 rows at `pitch` elements) / yuv2plane1_8_c :257-266 (fs == 0) */
+__global__ void __launch_bounds__(NT) k_sws_line_plane(const int16_t *filter, int fs, const int16_t *rows, int pitch, uint8_t *dest, int dstW,
+                                                       const uint8_t *dither, int offset)
+{
+    for (int i = threadIdx.x; i < dstW; i += NT) {
+        if (fs == 0) { dest[i] = (uint8_t)clip_u8((rows[i] + dither[(i + offset) & 7]) >> 7); continue; }
+        int val = dither[(i + offset) & 7] << 12;
+        for (int j = 0; j < fs; j++) val += rows[(size_t)j * pitch + i] * filter[j];
+        dest[i] = (uint8_t)clip_u8(val >> 19);
+    }
+}
+struct PackedRows {
+    const int16_t *l, *u, *v;
+    int pitch;
+    __device__ __forceinline__ int lum(int j, int x) const { return l[(size_t)j * pitch + x]; }
+    __device__ __forceinline__ int cu(int j, int x) const { return u[(size_t)j * pitch + x]; }
+    __device__ __forceinline__ int cv(int j, int x) const { return v[(size_t)j * pitch + x]; }
+};
+__global__ void __launch_bounds__(NT) k_sws_line_rgb(const mi355_sws_luts *luts, int mode, const int16_t *lumF, const int16_t *l, int ls,
+                                                     const int16_t *chrF, const int16_t *u, const int16_t *v, int cs, int pitch, uint8_t *dest,
+                                                     int dstW, int yalpha, int uvalpha)
+{
+    __shared__ LutLds s_lut;
+    lut_load(s_lut, luts, threadIdx.x, NT);
+    __syncthreads();
+    PackedRows R{ l, u, v, pitch };
+    for (int i = threadIdx.x; i < ((dstW + 1) >> 1); i += NT) rgb_pair(s_lut, dest + (size_t)i * 6, R, i, mode, lumF, ls, chrF, cs, yalpha, uvalpha);
+}
+
+}  // namespace
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+struct mi355_sws_ctx {
+    SwsDev h;
+    SwsDev *d = nullptr;
+    void *banks[8] = {};
+    /* Tier-1 picture staging */
+    uint8_t *d_src[3] = {}, *d_dst = nullptr;
+    mi355_sws_frame *d_frame = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+template <typename T> static const T *upload_bank(mi355_sws_ctx *c, int slot, const T *host, size_t n)
+{
+    if (!n || !host) return nullptr;
+    void *p;
+    MI355_CHECK(hipMalloc(&p, n * sizeof(T)));
+    MI355_CHECK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    c->banks[slot] = p;
+    return static_cast<const T *>(p);
+}
+
+/* rows per tile: the largest power of two <= MAXTH for which no tile needs more source lines than the
+ * LDS tile holds; 0 if even single rows do not fit (filters larger than the tile: not supported) */
+static int choose_rows(const mi355_sws_desc *d)
+{
+    for (int th = MAXTH; th >= 1; th >>= 1) {
+        bool ok = true;
+        for (int y0 = 0; y0 < d->dstH && ok; y0 += th) {
+            const int y1 = (y0 + th < d->dstH ? y0 + th : d->dstH) - 1;
+            auto span = [&](const mi355_sws_filter &f, int srcH) {
+                int lo = f.pos[y0] > 1 - f.size ? f.pos[y0] : 1 - f.size, hi = (f.pos[y1] > 1 - f.size ? f.pos[y1] : 1 - f.size) + f.size - 1;
+                for (int y = y0; y < y1; y++) if (f.pos[y + 1] < f.pos[y]) return 1 << 30;   /* not monotonic */
+                lo = lo < 0 ? 0 : (lo > srcH - 1 ? srcH - 1 : lo);
+                hi = hi < 0 ? 0 : (hi > srcH - 1 ? srcH - 1 : hi);
+                return hi - lo + 1;
+            };
+            ok = span(d->vLum, d->srcH) <= MAXL && span(d->vChr, d->chrSrcH) <= MAXC;
+        }
+        if (ok) return th;
+    }
+    return 0;
+}
+
+extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
+{
+    if (!ready()) { std::fprintf(stderr, "mi355dsp: mi355_sws_create without mi355_init(); no CPU fallback\n"); std::abort(); }
+    mi355_sws_ctx *c = new mi355_sws_ctx;
+    SwsDev &h = c->h;
+    h.srcW = desc->srcW; h.srcH = desc->srcH; h.dstW = desc->dstW; h.dstH = desc->dstH;
+    h.chrSrcW = desc->chrSrcW; h.chrSrcH = desc->chrSrcH; h.chrDstW = desc->chrDstW; h.special = desc->unscaled_special;
+    h.hls = desc->hLum.size; h.hcs = desc->hChr.size; h.vls = desc->vLum.size; h.vcs = desc->vChr.size;
+    h.luts = desc->luts;
+    h.th = 0;
+    h.hLumC = h.hChrC = h.vLumC = h.vChrC = nullptr;
+    h.hLumP = h.hChrP = h.vLumP = h.vChrP = nullptr;
+    if (!h.special) {
+        if (desc->hLum.n != h.dstW || desc->hChr.n != h.chrDstW || desc->vLum.n != h.dstH || desc->vChr.n != h.dstH ||
+            h.hls < 1 || h.hcs < 1 || h.vls < 1 || h.vcs < 1 || !(h.th = choose_rows(desc))) {
+            std::fprintf(stderr, "mi355dsp: mi355_sws_create: filter banks do not fit this backend (sizes %d/%d/%d/%d)\n", h.hls, h.hcs, h.vls, h.vcs);
+            delete c;
+            return nullptr;
+        }
+        h.hLumC = upload_bank(c, 0, desc->hLum.coef, (size_t)h.dstW * h.hls);    h.hLumP = upload_bank(c, 1, desc->hLum.pos, (size_t)h.dstW);
+        h.hChrC = upload_bank(c, 2, desc->hChr.coef, (size_t)h.chrDstW * h.hcs); h.hChrP = upload_bank(c, 3, desc->hChr.pos, (size_t)h.chrDstW);
+        h.vLumC = upload_bank(c, 4, desc->vLum.coef, (size_t)h.dstH * h.vls);    h.vLumP = upload_bank(c, 5, desc->vLum.pos, (size_t)h.dstH);
+        h.vChrC = upload_bank(c, 6, desc->vChr.coef, (size_t)h.dstH * h.vcs);    h.vChrP = upload_bank(c, 7, desc->vChr.pos, (size_t)h.dstH);
+    }
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d), sizeof(SwsDev)));
+    MI355_CHECK(hipMemcpy(c->d, &h, sizeof(SwsDev), hipMemcpyHostToDevice));
+    MI355_CHECK(hipStreamCreate(&c->stream));
+    return c;
+}
+
+extern "C" void mi355_sws_destroy(mi355_sws_ctx *c)
+{
+    if (!c) return;
+    for (void *p : c->banks) if (p) MI355_CHECK(hipFree(p));
+    for (uint8_t *p : c->d_src) if (p) MI355_CHECK(hipFree(p));
+    if (c->d_dst) MI355_CHECK(hipFree(c->d_dst));
+    if (c->d_frame) MI355_CHECK(hipFree(c->d_frame));
+    if (c->d) MI355_CHECK(hipFree(c->d));
+    if (c->stream) MI355_CHECK(hipStreamDestroy(c->stream));
+    delete c;
+}
+
+extern "C" void mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_frame *d_frames, int nframes, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const SwsDev &h = c->h;
+    if (h.special) {
+        hipLaunchKernelGGL(k_sws_c24, dim3((h.dstW + 255) / 256, (h.srcH + C24_ROWS - 1) / C24_ROWS, nframes), dim3(NT), 0, s,
+                           &c->d->luts, h.dstW, h.srcH, 0, d_frames);
+    } else {
+        hipLaunchKernelGGL(k_sws_generic, dim3((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes), dim3(NT), 0, s, c->d, d_frames);
+    }
+    MI355_CHECK(hipGetLastError());
+}
+
+/* copy a host plane into a tightly pitched device plane */
+static void plane_h2d(uint8_t *d, int dpitch, const uint8_t *h, int hstride, int wbytes, int rows, hipStream_t s)
+{
+    MI355_CHECK(hipMemcpy2DAsync(d, dpitch, h, hstride, wbytes, rows, hipMemcpyHostToDevice, s));
+}
+
+extern "C" int mi355_sws_scale(mi355_sws_ctx *c, const uint8_t *const src[3], const int src_stride[3], uint8_t *dst, int dst_stride)
+{
+    const SwsDev &h = c->h;
+    const int cw = h.chrSrcW, ch = h.chrSrcH;
+    const int pw[3] = { (h.srcW + 15) & ~15, (cw + 15) & ~15, (cw + 15) & ~15 }, ph[3] = { h.srcH, ch, ch };
+    const int dpitch = (h.dstW * 3 + 15) & ~15;
+    if (!c->d_dst) {
+        for (int p = 0; p < 3; p++) MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_src[p]), (size_t)pw[p] * ph[p] + 64));
+        MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_dst), (size_t)dpitch * (h.dstH + 1)));
+        MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_frame), sizeof(mi355_sws_frame)));
+        mi355_sws_frame f;
+        for (int p = 0; p < 3; p++) { f.src[p] = c->d_src[p]; f.src_stride[p] = pw[p]; }
+        f.dst = c->d_dst; f.dst_stride = dpitch;
+        MI355_CHECK(hipMemcpy(c->d_frame, &f, sizeof(f), hipMemcpyHostToDevice));
+    }
+    const int w[3] = { h.srcW, cw, cw };
+    for (int p = 0; p < 3; p++) plane_h2d(c->d_src[p], pw[p], src[p], src_stride[p], w[p], ph[p], c->stream);
+    mi355_sws_scale_frames_dev(c, c->d_frame, 1, c->stream);
+    /* only the samples the converter writes go back: the caller's padding stays untouched */
+    const int out_w = h.special ? (h.dstW & ~1) * 3 : h.dstW * 3;
+    MI355_CHECK(hipMemcpy2DAsync(dst, dst_stride, c->d_dst, dpitch, out_w, h.dstH, hipMemcpyDeviceToHost, c->stream));
+    MI355_CHECK(hipStreamSynchronize(c->stream));
+    return h.special ? h.srcH : h.dstH;
+}
+
+/* ---- Tier-1 line entry points ------------------------------------------------------------------------------ */
+#define LAUNCH_LINE(kernel, a, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(NT), 0, (a).stream, __VA_ARGS__)
+
+extern "C" void mi355_sws_hscale8to15(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize)
+{
+    Arena &a = arena();
+    int last = 0;
+    for (int i = 0; i < dstW; i++) if (filterPos[i] > last) last = filterPos[i];
+    const size_t nsrc = (size_t)last + filterSize;
+    const size_t o_src = a.take(nsrc), o_f = a.take((size_t)dstW * filterSize * 2), o_p = a.take((size_t)dstW * 4), o_d = a.take((size_t)dstW * 2);
+    std::memcpy(a.h<uint8_t>(o_src), src, nsrc);
+    std::memcpy(a.h<int16_t>(o_f), filter, (size_t)dstW * filterSize * 2);
+    std::memcpy(a.h<int32_t>(o_p), filterPos, (size_t)dstW * 4);
+    a.upload();
+    LAUNCH_LINE(k_sws_line_hscale, a, a.d<int16_t>(o_d), dstW, a.d<const uint8_t>(o_src), a.d<const int16_t>(o_f), a.d<const int32_t>(o_p), filterSize);
+    a.download();
+    std::memcpy(dst, a.h<int16_t>(o_d), (size_t)dstW * 2);
+}
+
+static size_t pack_rows(Arena &a, const int16_t **rows, int n, int elems, int pitch)
+{
+    const size_t o = a.take((size_t)(n > 0 ? n : 1) * pitch * 2);
+    for (int j = 0; j < n; j++) std::memcpy(a.h<int16_t>(o) + (size_t)j * pitch, rows[j], (size_t)elems * 2);
+    return o;
+}
+
+static void plane_line(const int16_t *filter, int fs, const int16_t **rows, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    Arena &a = arena();
+    const int n = fs ? fs : 1, pitch = (dstW + 7) & ~7;
+    const size_t o_r = pack_rows(a, rows, n, dstW, pitch), o_f = a.take((size_t)n * 2), o_di = a.take(8), o_d = a.take((size_t)dstW);
+    if (fs) std::memcpy(a.h<int16_t>(o_f), filter, (size_t)fs * 2);
+    std::memcpy(a.h<uint8_t>(o_di), dither, 8);
+    a.upload();
+    LAUNCH_LINE(k_sws_line_plane, a, a.d<const int16_t>(o_f), fs, a.d<const int16_t>(o_r), pitch, a.d<uint8_t>(o_d), dstW, a.d<const uint8_t>(o_di), offset);
+    a.download();
+    std::memcpy(dest, a.h<uint8_t>(o_d), (size_t)dstW);
+}
+extern "C" void mi355_sws_yuv2planeX_8(const int16_t *filter, int filterSize, const int16_t **src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    plane_line(filter, filterSize, src, dest, dstW, dither, offset);
+}
+extern "C" void mi355_sws_yuv2plane1_8(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    plane_line(nullptr, 0, &src, dest, dstW, dither, offset);
+}
+
+static void rgb_line(const mi355_sws_luts *luts, int mode, const int16_t *lumF, const int16_t **l, int ls, const int16_t *chrF,
+                     const int16_t **u, const int16_t **v, int cs, uint8_t *dest, int dstW, int yalpha, int uvalpha)
+{
+    Arena &a = arena();
+    const int npair = (dstW + 1) >> 1, pitch = (2 * npair + 7) & ~7;
+    const size_t o_t = a.take(sizeof(mi355_sws_luts));
+    std::memcpy(a.h<uint8_t>(o_t), luts, sizeof(mi355_sws_luts));
+    const size_t o_l = pack_rows(a, l, ls, 2 * npair, pitch), o_u = pack_rows(a, u, cs, npair, pitch), o_v = pack_rows(a, v, cs, npair, pitch);
+    const size_t o_lf = a.take((size_t)ls * 2 + 2), o_cf = a.take((size_t)cs * 2 + 2), o_d = a.take((size_t)npair * 6);
+    if (lumF) std::memcpy(a.h<int16_t>(o_lf), lumF, (size_t)ls * 2);
+    if (chrF) std::memcpy(a.h<int16_t>(o_cf), chrF, (size_t)cs * 2);
+    a.upload();
+    LAUNCH_LINE(k_sws_line_rgb, a, a.d<const mi355_sws_luts>(o_t), mode, a.d<const int16_t>(o_lf), a.d<const int16_t>(o_l), ls, a.d<const int16_t>(o_cf),
+                a.d<const int16_t>(o_u), a.d<const int16_t>(o_v), cs, pitch, a.d<uint8_t>(o_d), dstW, yalpha, uvalpha);
+    a.download();
+    std::memcpy(dest, a.h<uint8_t>(o_d), (size_t)npair * 6);   /* like the reference: whole pairs, also for odd dstW */
+}
+extern "C" void mi355_sws_yuv2rgb24_X(const mi355_sws_luts *luts, const int16_t *lumFilter, const int16_t **lumSrc, int lumFilterSize,
+                                      const int16_t *chrFilter, const int16_t **chrUSrc, const int16_t **chrVSrc, int chrFilterSize,
+                                      uint8_t *dest, int dstW)
+{
+    rgb_line(luts, 0, lumFilter, lumSrc, lumFilterSize, chrFilter, chrUSrc, chrVSrc, chrFilterSize, dest, dstW, 0, 0);
+}
+extern "C" void mi355_sws_yuv2rgb24_2(const mi355_sws_luts *luts, const int16_t *buf[2], const int16_t *ubuf[2], const int16_t *vbuf[2],
+                                      uint8_t *dest, int dstW, int yalpha, int uvalpha)
+{
+    rgb_line(luts, 2, nullptr, buf, 2, nullptr, ubuf, vbuf, 2, dest, dstW, yalpha, uvalpha);
+}
+extern "C" void mi355_sws_yuv2rgb24_1(const mi355_sws_luts *luts, const int16_t *buf0, const int16_t *ubuf[2], const int16_t *vbuf[2],
+                                      uint8_t *dest, int dstW, int uvalpha)
+{
+    /* ubuf[1]/vbuf[1] are only looked at when uvalpha >= 2048 (output.c:1052, :1079) */
+    const int cs = uvalpha < 2048 ? 1 : 2;
+    rgb_line(luts, 1, nullptr, &buf0, 1, nullptr, ubuf, vbuf, cs, dest, dstW, 0, uvalpha);
+}
+
+extern "C" int mi355_sws_yuv2rgb_c_24_rgb(const mi355_sws_luts *luts, int dstW, const uint8_t *const src[3], const int srcStride[3],
+                                          int srcSliceY, int srcSliceH, uint8_t *dst, int dstStride)
+{
+    if (!ready()) { std::fprintf(stderr, "mi355dsp: mi355_sws_yuv2rgb_c_24_rgb without mi355_init(); no CPU fallback\n"); std::abort(); }
+    /* a slice may be a whole picture: device buffers per call instead of the staging arena */
+    const int rows = srcSliceH, cw = dstW >> 1, crow = (rows + 1) >> 1;   /* even slices, as the reference's callers guarantee */
+    const int pw[3] = { (dstW + 15) & ~15, (cw + 15) & ~15, (cw + 15) & ~15 }, ph[3] = { rows, crow, crow }, w[3] = { dstW & ~1, cw, cw };
+    const int dpitch = (dstW * 3 + 15) & ~15;
+    hipStream_t s = arena().stream;
+    mi355_sws_frame f, *d_f;
+    uint8_t *d_l, *d_dst;
+    for (int p = 0; p < 3; p++) {
+        uint8_t *d;
+        MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&d), (size_t)pw[p] * (ph[p] + 1) + 64));
+        plane_h2d(d, pw[p], src[p], srcStride[p], w[p], ph[p], s);
+        f.src[p] = d; f.src_stride[p] = pw[p];
+    }
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&d_dst), (size_t)dpitch * (rows + 1)));
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&d_f), sizeof(f)));
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&d_l), sizeof(mi355_sws_luts)));
+    f.dst = d_dst; f.dst_stride = dpitch;
+    MI355_CHECK(hipMemcpyAsync(d_f, &f, sizeof(f), hipMemcpyHostToDevice, s));
+    MI355_CHECK(hipMemcpyAsync(d_l, luts, sizeof(mi355_sws_luts), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sws_c24, dim3((dstW + 255) / 256, (rows + C24_ROWS - 1) / C24_ROWS, 1), dim3(NT), 0, s,
+                       reinterpret_cast<const mi355_sws_luts *>(d_l), dstW, rows, 0, d_f);
+    MI355_CHECK(hipMemcpy2DAsync(dst + (ptrdiff_t)srcSliceY * dstStride, dstStride, d_dst, dpitch, (dstW & ~1) * 3, rows, hipMemcpyDeviceToHost, s));
+    MI355_CHECK(hipStreamSynchronize(s));
+    for (int p = 0; p < 3; p++) MI355_CHECK(hipFree(const_cast<uint8_t *>(f.src[p])));
+    MI355_CHECK(hipFree(d_dst)); MI355_CHECK(hipFree(d_f)); MI355_CHECK(hipFree(d_l));
+    return srcSliceH;
+}

@@ -256,3 +256,70 @@ def fate_chain_md5(ref, rgb):
     assert lib.sws_scale(c, src, ss, 0, h, dst, ds) == h
     lib.sws_freeContext(c)
     return hashlib.md5(b"".join(o.tobytes() for o in out)).hexdigest()
+
+
+# ---- Tier 2: a batch of pictures resident in device memory -----------------------------------------
+class DeviceBatch:
+    """nframes pictures (the first `len(pictures)` distinct, the rest device-side copies) + output
+    surfaces + the device array of mi355_sws_frame, through the C ABI's memory helpers."""
+
+    def __init__(self, lib, ctx, pictures, nframes, src_pad=0, dst_pad=0):
+        self.lib, self.ctx, self.n = lib, ctx, nframes
+        lib.mi355_malloc.restype = C.c_void_p
+        lib.mi355_malloc.argtypes = [C.c_size_t]
+        lib.mi355_free.argtypes = [C.c_void_p]
+        for f in ("mi355_memcpy_h2d", "mi355_memcpy_d2h", "mi355_memcpy_d2d"):
+            getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mi355_sws_create.restype = C.c_void_p
+        d = ctx.desc
+        self.bufs = []
+        G = len(pictures)
+        self.strides = [pictures[0][p].shape[1] for p in range(3)]
+        self.psz = [pictures[0][p].size for p in range(3)]
+        self.src = []
+        for p in range(3):
+            base = self.alloc(nframes * self.psz[p] + 64)
+            host = np.ascontiguousarray(np.stack([pic[p] for pic in pictures]))
+            lib.mi355_memcpy_h2d(base, host.ctypes.data, host.nbytes)
+            done = G
+            while done < nframes:
+                k = min(done, nframes - done)
+                lib.mi355_memcpy_d2d(base + done * self.psz[p], base, k * self.psz[p])
+                done += k
+            self.src.append(base)
+        self.dst_stride = (d.dstW * 3 + dst_pad + 3) & ~3
+        self.dsz = self.dst_stride * d.dstH
+        self.dst = self.alloc(nframes * self.dsz + 64)
+        arr = (SwsFrame * nframes)()
+        for f in range(nframes):
+            for p in range(3):
+                arr[f].src[p] = self.src[p] + f * self.psz[p]
+                arr[f].src_stride[p] = self.strides[p]
+            arr[f].dst = self.dst + f * self.dsz
+            arr[f].dst_stride = self.dst_stride
+        self.d_frames = self.alloc(C.sizeof(arr))
+        lib.mi355_memcpy_h2d(self.d_frames, C.addressof(arr), C.sizeof(arr))
+        self.handle = lib.mi355_sws_create(C.byref(d))
+        assert self.handle
+
+    def alloc(self, n):
+        p = self.lib.mi355_malloc(n)
+        assert p
+        self.bufs.append(p)
+        return p
+
+    def run(self, stream=None):
+        self.lib.mi355_sws_scale_frames_dev(C.c_void_p(self.handle), C.c_void_p(self.d_frames), self.n, C.c_void_p(stream))
+
+    def fetch(self, f):
+        d = self.ctx.desc
+        out = np.empty((d.dstH, self.dst_stride), np.uint8)
+        self.lib.mi355_sync(None)
+        self.lib.mi355_memcpy_d2h(out.ctypes.data, self.dst + f * self.dsz, out.nbytes)
+        return out[:, :d.dstW * 3]
+
+    def close(self):
+        self.lib.mi355_sws_destroy(C.c_void_p(self.handle))
+        for p in self.bufs:
+            self.lib.mi355_free(p)
+        self.bufs = []

@@ -96,6 +96,10 @@ static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { retur
 static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) {
+    for (size_t y = 0; y < h; y++) std::memcpy((char *)d + y * dp, (const char *)s + y * sp, w);
+    return hipSuccess;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
