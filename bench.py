@@ -128,10 +128,10 @@ def main():
         value = total_mbs / elapsed
         n_intra = int(sum(len(big.intra_list[f % G]) for f in range(F)))
         n_inter = F * nmb - n_intra
-        ndiag = (mbw - 1) + 2 * (mbh - 1) + 1
+        nbands = (mbh + 3) // 4            # k_deblock: one launch per band of four MB rows
         # dominant kernel = the pass with the largest share of the step
         passes = {"k_recon_inter": (t_inter, 1, n_inter * B_RECON),
-                  "k_deblock": (t_deblock, ndiag, F * nmb * B_DEBLOCK)}
+                  "k_deblock": (t_deblock, nbands, F * nmb * B_DEBLOCK)}
         dom = max(passes, key=lambda k: passes[k][0])
         t_pass, launches, bytes_pass = passes[dom]
         achieved = bytes_pass / launches / (t_pass / launches * 1e-3)   # algorithmic bytes per launch / avg launch time

@@ -25,6 +25,23 @@ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+/* Ordering point for a workgroup that is exactly one wavefront.  __syncthreads() is a workgroup-scope
+ * release/acquire: it drains every outstanding global load and store (s_waitcnt vmcnt(0)), which
+ * serialises prefetches with the work they were meant to overlap.  A single wave executes its LDS and
+ * its vector-memory instructions in issue order, so wavefront-scope fences (no instructions, compiler
+ * ordering only) are sufficient; data dependences still get their own precise waits.
+ * The SIMT emulator runs lanes as fibers and needs a real rendezvous. */
+#ifdef MI355_HIP_EMU_H
+#define MI355_WAVE_SYNC() __syncthreads()
+#else
+#define MI355_WAVE_SYNC()                                        \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#endif
+
 /* A picture plane in HBM; reads outside [0,w)x[0,h) replicate the border, which is
  * exactly what the reference's emulated_edge_mc produces (videodsp_template.c:24-96,
  * callers h264_mb.c:239-314). */

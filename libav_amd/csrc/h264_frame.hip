@@ -418,222 +418,243 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
     return r == 0xFF ? -1 : r;
 }
 
-constexpr int DP = 24;   /* luma tile pitch: columns -4..15, rows -4..15 */
-constexpr int DCP = 12;  /* chroma tile pitch: columns -2..7, rows -2..7 */
+/* One wavefront deblocks a band of four macroblock rows of one picture, walking left to right:
+ * lanes 16g..16g+15 own row 4*band+g and at step t work on macroblock x = t - 2g, so the
+ * reference's raster dependencies (left, top, top-right: h264_slice.c:2198) are met by lock-step
+ * execution inside the wave — no flags, no per-diagonal launches.  A lane holds one luma ROW (4 samples
+ * of the left neighbour carried over from the previous step + 16) and one chroma row in registers for
+ * the vertical edges; the tile then turns through LDS and the lane holds one COLUMN for the
+ * horizontal edges.  Consecutive steps read and write consecutive 16-byte pieces of the same cache
+ * lines, and everything that does not depend on the previous step is fetched one step ahead. */
 struct DeblockLds {
-    mi355_h264_mb hdr[3];     /* this MB, left neighbour, top neighbour */
-    uint8_t y[20 * DP];
-    uint8_t c[2][10 * DCP];
-    int8_t bs[2][4][4];
+    mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
+    uint32_t mv[4][2][2][16];     /* [t&1][list]: this MB's vectors; the other parity is the left neighbour */
+    uint32_t mvt[4][2][4];        /* [list]: bottom row of the top neighbour */
+    uint8_t y[4][20][16];         /* rows -4..15 of the MB's 16 columns */
+    uint8_t c[4][2][10][8];       /* rows -2..7 */
+    uint8_t bs[4][2][4][4];       /* [dir][segment][edge]: the 4 edges of a line are one dword */
 };
-#define YT(x, y_) s.y[((y_) + 4) * DP + (x) + 4]
-#define CT(p, x, y_) s.c[p][((y_) + 2) * DCP + (x) + 2]
 
-__global__ void __launch_bounds__(64)
-k_deblock(const mi355_h264_frame *__restrict__ frames, int diag, int max_mb_height)
+struct EdgeParm {
+    int alpha, beta, ia;
+};
+__device__ __forceinline__ EdgeParm edge_parm(int qp, const mi355_h264_mb &h)
 {
-    __shared__ DeblockLds s;
-    const int lane = lane_id();
-    const int f = blockIdx.x / max_mb_height, mb_y = blockIdx.x - f * max_mb_height;
-    const mi355_h264_frame &fr = frames[f];
-    const int mb_x = diag - 2 * mb_y;
-    if (mb_y >= fr.mb_height || mb_x < 0 || mb_x >= fr.mb_width) return;
-    const int mb_xy = mb_x + mb_y * fr.mb_width;
-    const bool has_l = mb_x > 0, has_t = mb_y > 0;
-    const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
-    const uint8_t *src = fr.recon[0] + (size_t)mb_y * 16 * rs + mb_x * 16;
-    uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
-
-    /* ---- phase A: every load this wave needs, issued before the first wait -------------------
-     * records of this MB and of its left / top neighbours; own samples from `recon`; the neighbour
-     * columns / rows (already filtered by earlier diagonals) from `dst`; the motion vectors of the
-     * two 4x4 blocks each (dir, edge, segment) lane compares. */
-    uint32_t hw = 0;
-    {
-        const int which = lane >> 4, w = lane & 15;
-        const int xy = which == 0 ? mb_xy : (which == 1 ? mb_xy - 1 : mb_xy - fr.mb_width);
-        if (which == 0 || (which == 1 && has_l) || (which == 2 && has_t))
-            hw = reinterpret_cast<const uint32_t *>(&fr.mb[xy])[w];
-    }
-    const uint32_t own_y = *reinterpret_cast<const uint32_t *>(src + (lane >> 2) * rs + 4 * (lane & 3));
-    uint32_t own_c = 0, nb_a = 0, nb_b = 0;
-    if (lane < 32) {
-        const int p = lane >> 4, crow = (lane >> 1) & 7, cseg = lane & 1;
-        own_c = *reinterpret_cast<const uint32_t *>(fr.recon[1 + p] + (size_t)(mb_y * 8 + crow) * rcs + mb_x * 8 + 4 * cseg);
-    }
-    if (has_l) {
-        if (lane < 16) nb_a = *reinterpret_cast<const uint32_t *>(dy + lane * ds - 4);
-        else if (lane < 32) {
-            const int p = (lane >> 3) & 1, r = lane & 7;
-            nb_a = *reinterpret_cast<const uint16_t *>(fr.dst[1 + p] + (size_t)(mb_y * 8 + r) * dcs + mb_x * 8 - 2);
-        }
-    }
-    if (has_t) {
-        if (lane >= 32 && lane < 48) {
-            const int r = (lane - 32) >> 2, sg = lane & 3;
-            nb_b = *reinterpret_cast<const uint32_t *>(dy + (r - 4) * ds + 4 * sg);
-        } else if (lane >= 48 && lane < 56) {
-            const int p = (lane >> 2) & 1, r = (lane >> 1) & 1, sg = lane & 1;
-            nb_b = *reinterpret_cast<const uint32_t *>(fr.dst[1 + p] + (size_t)(mb_y * 8 + r - 2) * dcs + mb_x * 8 + 4 * sg);
-        }
-    }
-    /* bS lanes: (dir, edge, i) -> block p = (x4,y4) of this MB, block q = its neighbour across the edge */
-    const int dir = (lane >> 4) & 1, edge = (lane >> 2) & 3, seg = lane & 3;
+    const int ia = clip3(qp + h.slice_alpha_c0_offset, 0, 51), ib = clip3(qp + h.slice_beta_offset, 0, 51);
+    return EdgeParm{ k_alpha[ia], k_beta[ib], ia };
+}
+/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
+__device__ __forceinline__ void luma_edge(int *v, int bs, const EdgeParm &e)
+{
+    if (!bs || !e.alpha || !e.beta) return;
+    if (bs < 4) lf_luma_line(v[1], v[2], v[3], v[4], v[5], v[6], e.alpha, e.beta, k_tc0[e.ia][bs - 1]);
+    else lf_luma_intra_line(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], e.alpha, e.beta);
+}
+/* v[0..3] = p1 p0 q0 q1 */
+__device__ __forceinline__ void chroma_edge(int *v, int bs, const EdgeParm &e)
+{
+    if (!bs || !e.alpha || !e.beta) return;
+    if (bs < 4) lf_chroma_line(v[0], v[1], v[2], v[3], e.alpha, e.beta, k_tc0[e.ia][bs - 1] + 1);
+    else lf_chroma_intra_line(v[0], v[1], v[2], v[3], e.alpha, e.beta);
+}
+/* chroma QP of the neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
+__device__ __forceinline__ int nb_qpc(const mi355_h264_frame &fr, const mi355_h264_mb &h, const mi355_h264_mb &nb, int p)
+{
+    return nb.slice_id == h.slice_id ? nb.qpc[p] : fr.slices[h.slice_id].chroma_qp_table[p][nb.qp];
+}
+/* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713 (frame macroblocks).  mv[list]: this
+ * MB's 16 vectors; qout[list]: the vector of the block across the MB edge (used when edge == 0) */
+__device__ inline int bs_one(const mi355_h264_mb &h, const mi355_h264_mb &nb, bool have_nb, int dir, int edge, int seg,
+                             const uint32_t (*mv)[16], uint32_t qout0, uint32_t qout1, int list_count)
+{
     const int px4 = dir ? seg : edge, py4 = dir ? edge : seg;
-    const bool q_out = edge == 0;                      /* q lives in the neighbouring MB */
-    const int qx4 = dir ? seg : (q_out ? 3 : edge - 1), qy4 = dir ? (q_out ? 3 : edge - 1) : seg;
-    const int q_xy = !q_out ? mb_xy : (dir ? mb_xy - fr.mb_width : mb_xy - 1);
-    const bool q_ok = !q_out || (dir ? has_t : has_l);
     BlkMotion mp, mq;
-    mp.mv[0] = mp.mv[1] = mq.mv[0] = mq.mv[1] = 0;
-    if (lane < 32) {
-        if (fr.mv[0]) {
-            mp.mv[0] = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + px4 + 4 * py4];
-            if (q_ok) mq.mv[0] = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)q_xy * 16 + qx4 + 4 * qy4];
+    if (edge == 0) {
+        if (!have_nb) return 0;
+        const int qx4 = dir ? seg : 3, qy4 = dir ? 3 : seg;
+        if ((h.mb_type | nb.mb_type) & MI355_MB_INTRA) return 4;
+        if (((h.nnz_mask >> blk_index(px4, py4)) | (nb.nnz_mask >> blk_index(qx4, qy4))) & 1) return 2;
+        for (int l = 0; l < 2; l++) {
+            mp.ref[l] = ref_identity(h, l, px4, py4); mq.ref[l] = ref_identity(nb, l, qx4, qy4);
+            mp.mv[l] = mv[l][px4 + 4 * py4];
         }
-        if (fr.mv[1]) {
-            mp.mv[1] = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + px4 + 4 * py4];
-            if (q_ok) mq.mv[1] = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)q_xy * 16 + qx4 + 4 * qy4];
-        }
+        mq.mv[0] = qout0; mq.mv[1] = qout1;
+        return check_mv(mp, mq, list_count);
     }
+    if ((h.mb_type & MI355_MB_8x8DCT) && (edge & 1)) return 0;
+    if (h.mb_type & MI355_MB_INTRA) return 3;
+    const int qx4 = dir ? seg : edge - 1, qy4 = dir ? edge - 1 : seg;
+    if (((h.nnz_mask >> blk_index(px4, py4)) | (h.nnz_mask >> blk_index(qx4, qy4))) & 1) return 2;
+    for (int l = 0; l < 2; l++) {
+        mp.ref[l] = ref_identity(h, l, px4, py4); mq.ref[l] = ref_identity(h, l, qx4, qy4);
+        mp.mv[l] = mv[l][px4 + 4 * py4]; mq.mv[l] = mv[l][qx4 + 4 * qy4];
+    }
+    return check_mv(mp, mq, list_count);
+}
+__device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
+__device__ __forceinline__ void unpack4(uint32_t w, int *v) { v[0] = w & 0xFF; v[1] = (w >> 8) & 0xFF; v[2] = (w >> 16) & 0xFF; v[3] = w >> 24; }
 
-    /* ---- phase B: registers -> LDS ------------------------------------------------------------ */
-    if (lane < 48) reinterpret_cast<uint32_t *>(&s.hdr[lane >> 4])[lane & 15] = hw;
-    {
-        const int row = lane >> 2, sg = lane & 3;
-        YT(4 * sg + 0, row) = (uint8_t)own_y; YT(4 * sg + 1, row) = (uint8_t)(own_y >> 8);
-        YT(4 * sg + 2, row) = (uint8_t)(own_y >> 16); YT(4 * sg + 3, row) = (uint8_t)(own_y >> 24);
-    }
-    if (lane < 32) {
-        const int p = lane >> 4, crow = (lane >> 1) & 7, cseg = lane & 1;
-        CT(p, 4 * cseg + 0, crow) = (uint8_t)own_c; CT(p, 4 * cseg + 1, crow) = (uint8_t)(own_c >> 8);
-        CT(p, 4 * cseg + 2, crow) = (uint8_t)(own_c >> 16); CT(p, 4 * cseg + 3, crow) = (uint8_t)(own_c >> 24);
-    }
-    if (has_l) {
-        if (lane < 16) {
-            YT(-4, lane) = (uint8_t)nb_a; YT(-3, lane) = (uint8_t)(nb_a >> 8); YT(-2, lane) = (uint8_t)(nb_a >> 16); YT(-1, lane) = (uint8_t)(nb_a >> 24);
-        } else if (lane < 32) {
-            const int p = (lane >> 3) & 1, r = lane & 7;
-            CT(p, -2, r) = (uint8_t)nb_a; CT(p, -1, r) = (uint8_t)(nb_a >> 8);
-        }
-    }
-    if (has_t) {
-        if (lane >= 32 && lane < 48) {
-            const int r = (lane - 32) >> 2, sg = lane & 3;
-            YT(4 * sg + 0, r - 4) = (uint8_t)nb_b; YT(4 * sg + 1, r - 4) = (uint8_t)(nb_b >> 8);
-            YT(4 * sg + 2, r - 4) = (uint8_t)(nb_b >> 16); YT(4 * sg + 3, r - 4) = (uint8_t)(nb_b >> 24);
-        } else if (lane >= 48 && lane < 56) {
-            const int p = (lane >> 2) & 1, r = (lane >> 1) & 1, sg = lane & 1;
-            CT(p, 4 * sg + 0, r - 2) = (uint8_t)nb_b; CT(p, 4 * sg + 1, r - 2) = (uint8_t)(nb_b >> 8);
-            CT(p, 4 * sg + 2, r - 2) = (uint8_t)(nb_b >> 16); CT(p, 4 * sg + 3, r - 2) = (uint8_t)(nb_b >> 24);
-        }
-    }
-    __syncthreads();
-
-    const mi355_h264_mb &h = s.hdr[0];
-    const bool filter = !(h.flags & MI355_MBF_NO_DEBLOCK);
-    const bool have_left = filter && (h.flags & MI355_MBF_LEFT_EDGE), have_top = filter && (h.flags & MI355_MBF_TOP_EDGE);
-
-    /* ---- phase C: boundary strengths, filter_mb_dir (h264_loopfilter.c:472-713), one per lane -- */
-    if (filter && lane < 32) {
-        const bool intra = (h.mb_type & MI355_MB_INTRA) != 0;
-        const int list_count = fr.mv[1] ? 2 : 1;     /* sl->list_count == 2 exactly when list-1 vectors exist */
-        int bs = 0;
-        if (edge == 0) {
-            if (dir ? have_top : have_left) {
-                const mi355_h264_mb &nb = s.hdr[1 + dir];
-                if (intra || (nb.mb_type & MI355_MB_INTRA)) bs = 4;
-                else if (((h.nnz_mask >> blk_index(px4, py4)) | (nb.nnz_mask >> blk_index(qx4, qy4))) & 1) bs = 2;
-                else {
-                    mp.ref[0] = ref_identity(h, 0, px4, py4); mp.ref[1] = ref_identity(h, 1, px4, py4);
-                    mq.ref[0] = ref_identity(nb, 0, qx4, qy4); mq.ref[1] = ref_identity(nb, 1, qx4, qy4);
-                    bs = check_mv(mp, mq, list_count);
-                }
-            }
-        } else if (!((h.mb_type & MI355_MB_8x8DCT) && (edge & 1))) {
-            if (intra) bs = 3;
-            else if (((h.nnz_mask >> blk_index(px4, py4)) | (h.nnz_mask >> blk_index(qx4, qy4))) & 1) bs = 2;
-            else {
-                mp.ref[0] = ref_identity(h, 0, px4, py4); mp.ref[1] = ref_identity(h, 1, px4, py4);
-                mq.ref[0] = ref_identity(h, 0, qx4, qy4); mq.ref[1] = ref_identity(h, 1, qx4, qy4);
-                bs = check_mv(mp, mq, list_count);
-            }
-        }
-        s.bs[dir][edge][seg] = (int8_t)bs;
-    }
-    __syncthreads();
-
-    /* ---- phase D: the 8 luma + 4 chroma edges, in the reference's order --------------------- */
-    if (filter) {
-        /* lanes 0..15: luma lines; 16..23: Cb lines; 24..31: Cr lines */
-        const int plane = lane < 16 ? 0 : (lane < 24 ? 1 : 2);
-        const int line = plane == 0 ? lane : (lane & 7);
-        for (int d2 = 0; d2 < 2; d2++) {
-            for (int e = 0; e < 4; e++) {
-                if (lane < 32 && !(plane && (e & 1))) {
-                    const int bs = s.bs[d2][e][plane ? line >> 1 : line >> 2];
-                    if (bs) {
-                        const mi355_h264_mb &nb = s.hdr[1 + d2];
-                        int qp;
-                        if (plane == 0) qp = e ? h.qp : (h.qp + nb.qp + 1) >> 1;
-                        else if (e) qp = h.qpc[plane - 1];
-                        else {
-                            /* the reference maps the neighbour's QP through the CURRENT slice's table
-                             * (h264_loopfilter.c:628-629); identical to the neighbour's own qpc unless the
-                             * two MBs sit in slices with different PPS chroma offsets */
-                            const int nq = nb.slice_id == h.slice_id ? nb.qpc[plane - 1]
-                                                                     : fr.slices[h.slice_id].chroma_qp_table[plane - 1][nb.qp];
-                            qp = (h.qpc[plane - 1] + nq + 1) >> 1;
-                        }
-                        const int ia = clip3(qp + h.slice_alpha_c0_offset, 0, 51), ib = clip3(qp + h.slice_beta_offset, 0, 51);
-                        const int alpha = k_alpha[ia], beta = k_beta[ib];
-                        if (alpha && beta) {
-                            if (plane == 0) {
-                                uint8_t *c = d2 ? &YT(line, 4 * e) : &YT(4 * e, line);
-                                const int xs = d2 ? DP : 1;
-                                int p3 = c[-4 * xs], p2 = c[-3 * xs], p1 = c[-2 * xs], p0 = c[-xs];
-                                int q0 = c[0], q1 = c[xs], q2 = c[2 * xs], q3 = c[3 * xs];
-                                if (bs < 4) lf_luma_line(p2, p1, p0, q0, q1, q2, alpha, beta, k_tc0[ia][bs - 1]);
-                                else lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
-                                c[-3 * xs] = (uint8_t)p2; c[-2 * xs] = (uint8_t)p1; c[-xs] = (uint8_t)p0;
-                                c[0] = (uint8_t)q0; c[xs] = (uint8_t)q1; c[2 * xs] = (uint8_t)q2;
-                            } else {
-                                uint8_t *c = d2 ? &CT(plane - 1, line, 2 * e) : &CT(plane - 1, 2 * e, line);
-                                const int xs = d2 ? DCP : 1;
-                                int p1 = c[-2 * xs], p0 = c[-xs], q0 = c[0], q1 = c[xs];
-                                if (bs < 4) lf_chroma_line(p1, p0, q0, q1, alpha, beta, k_tc0[ia][bs - 1] + 1);
-                                else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
-                                c[-xs] = (uint8_t)p0; c[0] = (uint8_t)q0;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
-    /* ---- phase E: the MB, plus the neighbour samples its edge-0 filters may have changed ------- */
-    uint8_t *const dst3[3] = {fr.dst[0], fr.dst[1], fr.dst[2]};
-    store_mb(&YT(0, 0), DP, &CT(0, 0, 0), &CT(1, 0, 0), DCP, dst3, fr.dst_stride, mb_x, mb_y);
-    if (have_left) {
-        if (lane < 16) { dy[lane * ds - 3] = YT(-3, lane); dy[lane * ds - 2] = YT(-2, lane); dy[lane * ds - 1] = YT(-1, lane); }
-        else if (lane < 32) {
-            const int p = (lane >> 3) & 1, r = lane & 7;
-            fr.dst[1 + p][(size_t)(mb_y * 8 + r) * dcs + mb_x * 8 - 1] = CT(p, -1, r);
-        }
-    }
-    if (have_top) {
-        if (lane >= 32 && lane < 48) {
-            const int x = lane - 32;
-            dy[-3 * ds + x] = YT(x, -3); dy[-2 * ds + x] = YT(x, -2); dy[-ds + x] = YT(x, -1);
-        } else if (lane >= 48) {
-            const int p = (lane >> 3) & 1, x = lane & 7;
-            fr.dst[1 + p][(size_t)(mb_y * 8 - 1) * dcs + mb_x * 8 + x] = CT(p, x, -1);
-        }
+/* what a lane fetches for one macroblock ahead of time: nothing here is written by the filter */
+struct DeblockPre {
+    uint32_t hw, hw_top, y[4], c[2], mv[2], mvt[2];
+};
+__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const mi355_h264_frame &fr, bool row_ok, int mb_x, int mb_y, int l, int cp, int cr)
+{
+    p.hw = p.hw_top = p.y[0] = p.y[1] = p.y[2] = p.y[3] = p.c[0] = p.c[1] = p.mv[0] = p.mv[1] = p.mvt[0] = p.mvt[1] = 0;
+    if (!row_ok || mb_x < 0 || mb_x >= fr.mb_width) return;
+    const int mb_xy = mb_x + mb_y * fr.mb_width;
+    p.hw = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[l];
+    if (mb_y > 0) p.hw_top = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy - fr.mb_width])[l];
+    const uint32_t *sy = reinterpret_cast<const uint32_t *>(fr.recon[0] + (size_t)(mb_y * 16 + l) * fr.recon_stride[0] + mb_x * 16);
+    p.y[0] = sy[0]; p.y[1] = sy[1]; p.y[2] = sy[2]; p.y[3] = sy[3];
+    const uint32_t *sc = reinterpret_cast<const uint32_t *>(fr.recon[1 + cp] + (size_t)(mb_y * 8 + cr) * fr.recon_stride[1] + mb_x * 8);
+    p.c[0] = sc[0]; p.c[1] = sc[1];
+    for (int li = 0; li < 2; li++) {
+        const uint32_t *mvp = reinterpret_cast<const uint32_t *>(fr.mv[li]);
+        if (!mvp) continue;
+        p.mv[li] = mvp[(size_t)mb_xy * 16 + l];
+        if (l < 4 && mb_y > 0) p.mvt[li] = mvp[(size_t)(mb_xy - fr.mb_width) * 16 + 12 + l];
     }
 }
-#undef YT
-#undef CT
+
+__global__ void __launch_bounds__(64)
+k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
+{
+    __shared__ DeblockLds s;
+    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+    const mi355_h264_frame &fr = frames[blockIdx.x];
+    const int mb_y = 4 * band + g, W = fr.mb_width;
+    const bool row_ok = mb_y < fr.mb_height;
+    const int ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
+    const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
+    const int list_count = fr.mv[1] ? 2 : 1;                 /* sl->list_count == 2 exactly when list-1 vectors exist */
+    const int nsteps = W + 6;
+    const bool has_t = row_ok && mb_y > 0;
+
+    DeblockPre pre;
+    deblock_prefetch(pre, fr, row_ok, -2 * g, mb_y, l, cp, cr);
+    uint32_t left_y = 0, left_c = 0;                         /* columns 12..15 / 6..7 of the previous MB, final */
+    for (int t = 0; t < nsteps; t++) {
+        const int mb_x = t - 2 * g, par = t & 1;
+        const bool valid = row_ok && mb_x >= 0 && mb_x < W;
+        const bool has_l = valid && mb_x > 0;
+        const DeblockPre cur = pre;
+        uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
+        uint8_t *dc = fr.dst[1 + cp] + (size_t)mb_y * 8 * dcs + mb_x * 8;
+        /* ---- phase A: next step's static data; this step's rows above (written one step ago at the
+         * latest, by this wave: visible after the barrier that ended that step) ------------------- */
+        deblock_prefetch(pre, fr, row_ok, mb_x + 1, mb_y, l, cp, cr);
+        uint32_t top_y = 0, top_c = 0;
+        if (valid && has_t) {
+            top_y = *reinterpret_cast<const uint32_t *>(dy + ((l >> 2) - 4) * ds + 4 * (l & 3));
+            if (l < 8) top_c = *reinterpret_cast<const uint32_t *>(fr.dst[1 + (l >> 2)] + (size_t)(mb_y * 8 + ((l >> 1) & 1) - 2) * dcs + mb_x * 8 + 4 * (l & 1));
+        }
+        /* ---- phase B: records and vectors -> LDS ------------------------------------------------- */
+        reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
+        reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
+        s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
+        if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
+        MI355_WAVE_SYNC();
+
+        const mi355_h264_mb &h = s.hdr[g][par], &hl = s.hdr[g][par ^ 1], &ht = s.hdr[g][2];
+        const bool filter = valid && !(h.flags & MI355_MBF_NO_DEBLOCK);
+        const bool have_left = filter && has_l && (h.flags & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags & MI355_MBF_TOP_EDGE);
+
+        /* ---- phase C: boundary strengths: lane (edge = l >> 2, segment = l & 3), both directions --- */
+        {
+            const int edge = l >> 2, seg = l & 3;
+            int b0 = 0, b1 = 0;
+            if (filter) {
+                b0 = bs_one(h, hl, have_left, 0, edge, seg, s.mv[g][par], s.mv[g][par ^ 1][0][3 + 4 * seg], s.mv[g][par ^ 1][1][3 + 4 * seg], list_count);
+                b1 = bs_one(h, ht, have_top, 1, edge, seg, s.mv[g][par], s.mvt[g][0][seg], s.mvt[g][1][seg], list_count);
+            }
+            s.bs[g][0][seg][edge] = (uint8_t)b0;
+            s.bs[g][1][seg][edge] = (uint8_t)b1;
+        }
+        MI355_WAVE_SYNC();
+
+        /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers ------- */
+        {
+            int px[20];
+            unpack4(left_y, px);
+#pragma unroll
+            for (int k = 0; k < 4; k++) unpack4(cur.y[k], px + 4 + 4 * k);
+            const uint32_t bsw = *reinterpret_cast<const uint32_t *>(s.bs[g][0][l >> 2]);
+            if (bsw) {
+                const EdgeParm e0 = edge_parm((h.qp + hl.qp + 1) >> 1, h), ei = edge_parm(h.qp, h);
+                luma_edge(px + 0, bsw & 0xFF, e0);
+#pragma unroll
+                for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw >> (8 * e)) & 0xFF, ei);
+            }
+            uint32_t *row = reinterpret_cast<uint32_t *>(s.y[g][4 + l]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) row[k] = pack4(px + 4 + 4 * k);
+            if (have_left) *reinterpret_cast<uint32_t *>(dy + l * ds - 4) = pack4(px);
+
+            int cx[10];
+            cx[0] = left_c & 0xFF; cx[1] = (left_c >> 8) & 0xFF;
+            unpack4(cur.c[0], cx + 2); unpack4(cur.c[1], cx + 6);
+            const uint32_t bsc = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]);
+            if (bsc & 0x00FF00FF) {
+                chroma_edge(cx + 0, bsc & 0xFF, edge_parm((h.qpc[cp] + nb_qpc(fr, h, hl, cp) + 1) >> 1, h));
+                chroma_edge(cx + 4, (bsc >> 16) & 0xFF, edge_parm(h.qpc[cp], h));
+            }
+            uint32_t *crow = reinterpret_cast<uint32_t *>(s.c[g][cp][2 + cr]);
+            crow[0] = pack4(cx + 2); crow[1] = pack4(cx + 6);
+            if (have_left) *reinterpret_cast<uint16_t *>(dc + cr * dcs - 2) = (uint16_t)(cx[0] | (cx[1] << 8));
+            /* the rows above, fetched in phase A */
+            *reinterpret_cast<uint32_t *>(&s.y[g][l >> 2][4 * (l & 3)]) = top_y;
+            if (l < 8) *reinterpret_cast<uint32_t *>(&s.c[g][l >> 2][(l >> 1) & 1][4 * (l & 1)]) = top_c;
+        }
+        MI355_WAVE_SYNC();
+        /* ---- phase D1: horizontal edges, one luma column + one chroma column per lane ------------- */
+        {
+            const uint32_t bsw = *reinterpret_cast<const uint32_t *>(s.bs[g][1][l >> 2]);
+            if (bsw) {
+                int py[20];
+#pragma unroll
+                for (int k = 0; k < 20; k++) py[k] = s.y[g][k][l];
+                const EdgeParm e0 = edge_parm((h.qp + ht.qp + 1) >> 1, h), ei = edge_parm(h.qp, h);
+                luma_edge(py + 0, bsw & 0xFF, e0);
+#pragma unroll
+                for (int e = 1; e < 4; e++) luma_edge(py + 4 * e, (bsw >> (8 * e)) & 0xFF, ei);
+#pragma unroll
+                for (int k = 1; k < 19; k++) s.y[g][k][l] = (uint8_t)py[k];
+            }
+            const uint32_t bsc = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
+            if (bsc & 0x00FF00FF) {
+                int cy[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) cy[k] = s.c[g][cp][k][cr];
+                chroma_edge(cy + 0, bsc & 0xFF, edge_parm((h.qpc[cp] + nb_qpc(fr, h, ht, cp) + 1) >> 1, h));
+                chroma_edge(cy + 4, (bsc >> 16) & 0xFF, edge_parm(h.qpc[cp], h));
+#pragma unroll
+                for (int k = 1; k < 9; k++) s.c[g][cp][k][cr] = (uint8_t)cy[k];
+            }
+        }
+        MI355_WAVE_SYNC();
+        /* ---- phase E: the MB, the rows above that its top edge may have changed; carry the right-most
+         * columns to the next step --------------------------------------------------------------- */
+        {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(s.y[g][4 + l]);
+            const uint32_t *crow = reinterpret_cast<const uint32_t *>(s.c[g][cp][2 + cr]);
+            const uint32_t r3 = row[3], c1 = crow[1];
+            if (valid) {
+                uint32_t *o = reinterpret_cast<uint32_t *>(dy + l * ds);
+                o[0] = row[0]; o[1] = row[1]; o[2] = row[2]; o[3] = r3;
+                uint32_t *oc = reinterpret_cast<uint32_t *>(dc + cr * dcs);
+                oc[0] = crow[0]; oc[1] = c1;
+                if (have_top) {
+                    if (l < 12) *reinterpret_cast<uint32_t *>(dy + ((l >> 2) - 3) * ds + 4 * (l & 3)) = *reinterpret_cast<const uint32_t *>(&s.y[g][1 + (l >> 2)][4 * (l & 3)]);
+                    else *reinterpret_cast<uint32_t *>(fr.dst[1 + ((l >> 1) & 1)] + (size_t)(mb_y * 8 - 1) * dcs + mb_x * 8 + 4 * (l & 1)) =
+                             *reinterpret_cast<const uint32_t *>(&s.c[g][(l >> 1) & 1][1][4 * (l & 1)]);
+                }
+            }
+            left_y = r3; left_c = c1 >> 16;
+        }
+        MI355_WAVE_SYNC();   /* stores of this step are visible to the wave's next step; LDS may be reused */
+    }
+}
 
 }  // namespace
 
@@ -663,10 +684,10 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
     if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
-    const int ndiag = (max_mb_width - 1) + 2 * (max_mb_height - 1) + 1;
-    for (int d = 0; d < ndiag; d++)
-        hipLaunchKernelGGL(k_deblock, dim3((unsigned)(nframes * max_mb_height)), dim3(64), 0, (hipStream_t)stream,
-                           d_frames, d, max_mb_height);
+    (void)max_mb_width;
+    /* bands of four MB rows, top to bottom: band b reads the rows band b-1 finished */
+    for (int band = 0; band * 4 < max_mb_height; band++)
+        hipLaunchKernelGGL(k_deblock, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, d_frames, band);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
