@@ -433,63 +433,115 @@ struct DeblockLds {
     uint8_t y[4][20][16];         /* rows -4..15 of the MB's 16 columns */
     uint8_t c[4][2][10][8];       /* rows -2..7 */
     uint8_t bs[4][2][4][4];       /* [dir][segment][edge]: the 4 edges of a line are one dword */
+    /* alpha / beta / tc0 tables: a copy in LDS turns the dependent per-edge lookups (qp -> index ->
+     * alpha, beta -> tc0[bS]) from global-memory gathers into LDS reads */
+    uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
 };
 
-struct EdgeParm {
-    int alpha, beta, ia;
+/* The fields of a record the filter looks at, pulled out of LDS in three wide reads so that nothing
+ * below waits on memory again */
+struct MbInfo {
+    uint32_t type, nnz, w2, w3, w11, ref0, ref1;
+    __device__ __forceinline__ int qp() const { return (int8_t)((w2 >> 16) & 0xFF); }
+    __device__ __forceinline__ int flags() const { return (int)(w2 >> 24); }
+    __device__ __forceinline__ int alpha_off() const { return (int8_t)(w3 & 0xFF); }
+    __device__ __forceinline__ int beta_off() const { return (int8_t)((w3 >> 8) & 0xFF); }
+    __device__ __forceinline__ int slice_id() const { return (int)(w11 & 0xFF); }
+    __device__ __forceinline__ int qpc(int p) const { return (int)((w11 >> (16 + 8 * p)) & 0xFF); }
+    __device__ __forceinline__ bool intra() const { return (type & MI355_MB_INTRA) != 0; }
+    /* picture identity of quadrant i8 as ref_cache holds it after ref2frm (h264_slice.c:2023-2029) */
+    __device__ __forceinline__ int ref_id(int list, int i8) const
+    {
+        const int r = (int)(((list ? ref1 : ref0) >> (8 * i8)) & 0xFF);
+        return (intra() || r == 0xFF) ? -1 : r;
+    }
 };
-__device__ __forceinline__ EdgeParm edge_parm(int qp, const mi355_h264_mb &h)
+__device__ __forceinline__ MbInfo mb_info(const mi355_h264_mb &m)
 {
-    const int ia = clip3(qp + h.slice_alpha_c0_offset, 0, 51), ib = clip3(qp + h.slice_beta_offset, 0, 51);
-    return EdgeParm{ k_alpha[ia], k_beta[ib], ia };
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&m);
+    return MbInfo{ w[0], w[1], w[2], w[3], w[11], w[12], w[13] };
 }
-/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
-__device__ __forceinline__ void luma_edge(int *v, int bs, const EdgeParm &e)
+
+/* check_mv (h264_loopfilter.c:442-470, frame macroblocks, mvy_limit 4) without branches */
+__device__ __forceinline__ int check_mv_flat(const int rp[2], const int rq[2], const uint32_t mp[2], const uint32_t mq[2], int list_count)
 {
-    if (!bs || !e.alpha || !e.beta) return;
-    if (bs < 4) lf_luma_line(v[1], v[2], v[3], v[4], v[5], v[6], e.alpha, e.beta, k_tc0[e.ia][bs - 1]);
-    else lf_luma_intra_line(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], e.alpha, e.beta);
+    bool v = rp[0] != rq[0] || (rp[0] != -1 && mv_far(mp[0], mq[0]));
+    if (list_count == 2) {
+        v = v || rp[1] != rq[1] || mv_far(mp[1], mq[1]);
+        const bool cross = rp[0] != rq[1] || rp[1] != rq[0] || mv_far(mp[0], mq[1]) || mv_far(mp[1], mq[0]);
+        v = v && cross;
+    }
+    return v;
 }
-/* v[0..3] = p1 p0 q0 q1 */
-__device__ __forceinline__ void chroma_edge(int *v, int bs, const EdgeParm &e)
-{
-    if (!bs || !e.alpha || !e.beta) return;
-    if (bs < 4) lf_chroma_line(v[0], v[1], v[2], v[3], e.alpha, e.beta, k_tc0[e.ia][bs - 1] + 1);
-    else lf_chroma_intra_line(v[0], v[1], v[2], v[3], e.alpha, e.beta);
-}
-/* chroma QP of the neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
-__device__ __forceinline__ int nb_qpc(const mi355_h264_frame &fr, const mi355_h264_mb &h, const mi355_h264_mb &nb, int p)
-{
-    return nb.slice_id == h.slice_id ? nb.qpc[p] : fr.slices[h.slice_id].chroma_qp_table[p][nb.qp];
-}
-/* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713 (frame macroblocks).  mv[list]: this
- * MB's 16 vectors; qout[list]: the vector of the block across the MB edge (used when edge == 0) */
-__device__ inline int bs_one(const mi355_h264_mb &h, const mi355_h264_mb &nb, bool have_nb, int dir, int edge, int seg,
-                             const uint32_t (*mv)[16], uint32_t qout0, uint32_t qout1, int list_count)
+/* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713: every operand is already in a register.
+ * mp/mq: vectors of the block on this side / across the edge; q*: the macroblock across the edge (the
+ * neighbour for edge 0, this one otherwise) */
+__device__ __forceinline__ int bs_flat(const MbInfo &h, const MbInfo &nb, bool have_nb, int dir, int edge, int seg,
+                                       const uint32_t mp[2], const uint32_t mq[2], int list_count)
 {
     const int px4 = dir ? seg : edge, py4 = dir ? edge : seg;
-    BlkMotion mp, mq;
-    if (edge == 0) {
-        if (!have_nb) return 0;
-        const int qx4 = dir ? seg : 3, qy4 = dir ? 3 : seg;
-        if ((h.mb_type | nb.mb_type) & MI355_MB_INTRA) return 4;
-        if (((h.nnz_mask >> blk_index(px4, py4)) | (nb.nnz_mask >> blk_index(qx4, qy4))) & 1) return 2;
-        for (int l = 0; l < 2; l++) {
-            mp.ref[l] = ref_identity(h, l, px4, py4); mq.ref[l] = ref_identity(nb, l, qx4, qy4);
-            mp.mv[l] = mv[l][px4 + 4 * py4];
+    const bool outer = edge == 0;
+    const int qx4 = dir ? seg : (outer ? 3 : edge - 1), qy4 = dir ? (outer ? 3 : edge - 1) : seg;
+    const uint32_t q_type = outer ? nb.type : h.type, q_nnz = outer ? nb.nnz : h.nnz;
+    const MbInfo q{ q_type, q_nnz, 0, 0, 0, outer ? nb.ref0 : h.ref0, outer ? nb.ref1 : h.ref1 };
+    const int pi8 = (px4 >> 1) + 2 * (py4 >> 1), qi8 = (qx4 >> 1) + 2 * (qy4 >> 1);
+    const int rp[2] = { h.ref_id(0, pi8), h.ref_id(1, pi8) }, rq[2] = { q.ref_id(0, qi8), q.ref_id(1, qi8) };
+    const bool any_intra = ((h.type | q_type) & MI355_MB_INTRA) != 0;
+    const bool coded = (((h.nnz >> blk_index(px4, py4)) | (q_nnz >> blk_index(qx4, qy4))) & 1) != 0;
+    int bs = any_intra ? (outer ? 4 : 3) : (coded ? 2 : check_mv_flat(rp, rq, mp, mq, list_count));
+    if (outer ? !have_nb : ((h.type & MI355_MB_8x8DCT) && (edge & 1))) bs = 0;
+    return bs;
+}
+
+/* alpha, beta, tc0 of one edge of one line (tables 8-16/8-17 through LDS) */
+struct EdgeParm {
+    int alpha, beta, tc0;
+};
+__device__ __forceinline__ EdgeParm edge_parm(const DeblockLds &s, int qp, const MbInfo &h, int bs)
+{
+    const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
+    return EdgeParm{ s.t_alpha[ia], s.t_beta[ib], s.t_tc0[ia][(bs - 1) & 3] };
+}
+/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3.  bS 1..3: h264_loop_filter_luma (h264dsp_template.c:104-150) as
+ * selects; bS 4 (h264_loop_filter_luma_intra :165-210) only where a lane of the wave has it */
+__device__ __forceinline__ void luma_edge(int *v, int bs, const EdgeParm &e, bool wave_has_intra)
+{
+    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    const bool f = bs != 0 && iabs(p0 - q0) < e.alpha && iabs(p1 - p0) < e.beta && iabs(q1 - q0) < e.beta;
+    const bool ap = iabs(p2 - p0) < e.beta, aq = iabs(q2 - q0) < e.beta;
+    const int avg = (p0 + q0 + 1) >> 1, tc0 = e.tc0, tc = tc0 + ap + aq;
+    const int np1 = p1 + clip3(((p2 + avg) >> 1) - p1, -tc0, tc0), nq1 = q1 + clip3(((q2 + avg) >> 1) - q1, -tc0, tc0);
+    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const bool fn = f && bs < 4;
+    v[2] = fn && ap ? np1 : p1;
+    v[5] = fn && aq ? nq1 : q1;
+    v[3] = fn ? clip_u8(p0 + delta) : p0;
+    v[4] = fn ? clip_u8(q0 - delta) : q0;
+    if (wave_has_intra) {
+        const bool fi = f && bs == 4, strong = iabs(p0 - q0) < ((e.alpha >> 2) + 2);
+        const bool sp = strong && ap, sq = strong && aq;
+        const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        if (fi) {
+            v[3] = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : wp0;
+            v[2] = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
+            v[1] = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
+            v[4] = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : wq0;
+            v[5] = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+            v[6] = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
         }
-        mq.mv[0] = qout0; mq.mv[1] = qout1;
-        return check_mv(mp, mq, list_count);
     }
-    if ((h.mb_type & MI355_MB_8x8DCT) && (edge & 1)) return 0;
-    if (h.mb_type & MI355_MB_INTRA) return 3;
-    const int qx4 = dir ? seg : edge - 1, qy4 = dir ? edge - 1 : seg;
-    if (((h.nnz_mask >> blk_index(px4, py4)) | (h.nnz_mask >> blk_index(qx4, qy4))) & 1) return 2;
-    for (int l = 0; l < 2; l++) {
-        mp.ref[l] = ref_identity(h, l, px4, py4); mq.ref[l] = ref_identity(h, l, qx4, qy4);
-        mp.mv[l] = mv[l][px4 + 4 * py4]; mq.mv[l] = mv[l][qx4 + 4 * qy4];
-    }
-    return check_mv(mp, mq, list_count);
+}
+/* v[0..3] = p1 p0 q0 q1: h264_loop_filter_chroma / _intra (h264dsp_template.c:212-265), tc = tc0 + 1 */
+__device__ __forceinline__ void chroma_edge(int *v, int bs, const EdgeParm &e)
+{
+    const int p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
+    const bool f = bs != 0 && iabs(p0 - q0) < e.alpha && iabs(p1 - p0) < e.beta && iabs(q1 - q0) < e.beta;
+    const int tc = e.tc0 + 1;
+    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const int np0 = bs == 4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip_u8(p0 + delta);
+    const int nq0 = bs == 4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip_u8(q0 - delta);
+    v[1] = f ? np0 : p0;
+    v[2] = f ? nq0 : q0;
 }
 __device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
 __device__ __forceinline__ void unpack4(uint32_t w, int *v) { v[0] = w & 0xFF; v[1] = (w >> 8) & 0xFF; v[2] = (w >> 16) & 0xFF; v[3] = w >> 24; }
@@ -498,24 +550,46 @@ __device__ __forceinline__ void unpack4(uint32_t w, int *v) { v[0] = w & 0xFF; v
 struct DeblockPre {
     uint32_t hw, hw_top, y[4], c[2], mv[2], mvt[2];
 };
-__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const mi355_h264_frame &fr, bool row_ok, int mb_x, int mb_y, int l, int cp, int cr)
+/* per-lane addresses of macroblock x = -2g of the lane's row; every step adds one macroblock */
+struct DeblockPtr {
+    const uint8_t *ry, *rc;              /* this lane's luma / chroma row in `recon` */
+    uint8_t *dy, *dc;                    /* the same rows in `dst` */
+    uint8_t *ty, *tc;                    /* the dword of the rows above this lane loads (luma -4.., chroma -2..) */
+    const uint32_t *rec;                 /* dword l of the record */
+    const uint32_t *mv[2];               /* vector l of the MB, per list (null when the list is absent) */
+    ptrdiff_t rec_top, mv_top;           /* distance (in dwords) to the top neighbour's record / bottom-row vector */
+    __device__ __forceinline__ void advance()
+    {
+        ry += 16; rc += 8; dy += 16; dc += 8; ty += 16; tc += 8; rec += 16;
+        if (mv[0]) mv[0] += 16;
+        if (mv[1]) mv[1] += 16;
+    }
+};
+__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr &a, bool ok, bool has_t, int l, bool al16)
 {
     p.hw = p.hw_top = p.y[0] = p.y[1] = p.y[2] = p.y[3] = p.c[0] = p.c[1] = p.mv[0] = p.mv[1] = p.mvt[0] = p.mvt[1] = 0;
-    if (!row_ok || mb_x < 0 || mb_x >= fr.mb_width) return;
-    const int mb_xy = mb_x + mb_y * fr.mb_width;
-    p.hw = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[l];
-    if (mb_y > 0) p.hw_top = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy - fr.mb_width])[l];
-    const uint32_t *sy = reinterpret_cast<const uint32_t *>(fr.recon[0] + (size_t)(mb_y * 16 + l) * fr.recon_stride[0] + mb_x * 16);
-    p.y[0] = sy[0]; p.y[1] = sy[1]; p.y[2] = sy[2]; p.y[3] = sy[3];
-    const uint32_t *sc = reinterpret_cast<const uint32_t *>(fr.recon[1 + cp] + (size_t)(mb_y * 8 + cr) * fr.recon_stride[1] + mb_x * 8);
-    p.c[0] = sc[0]; p.c[1] = sc[1];
+    if (!ok) return;
+    p.hw = a.rec[0];
+    if (has_t) p.hw_top = a.rec[a.rec_top];
+    /* one 16-byte / 8-byte access per row where alignment allows */
+    if (al16) { const uint4 v = *reinterpret_cast<const uint4 *>(a.ry); p.y[0] = v.x; p.y[1] = v.y; p.y[2] = v.z; p.y[3] = v.w; }
+    else { const uint32_t *w = reinterpret_cast<const uint32_t *>(a.ry); p.y[0] = w[0]; p.y[1] = w[1]; p.y[2] = w[2]; p.y[3] = w[3]; }
+    if (al16) { const uint2 v = *reinterpret_cast<const uint2 *>(a.rc); p.c[0] = v.x; p.c[1] = v.y; }
+    else { const uint32_t *w = reinterpret_cast<const uint32_t *>(a.rc); p.c[0] = w[0]; p.c[1] = w[1]; }
+#pragma unroll
     for (int li = 0; li < 2; li++) {
-        const uint32_t *mvp = reinterpret_cast<const uint32_t *>(fr.mv[li]);
-        if (!mvp) continue;
-        p.mv[li] = mvp[(size_t)mb_xy * 16 + l];
-        if (l < 4 && mb_y > 0) p.mvt[li] = mvp[(size_t)(mb_xy - fr.mb_width) * 16 + 12 + l];
+        if (!a.mv[li]) continue;
+        p.mv[li] = a.mv[li][0];
+        if (l < 4 && has_t) p.mvt[li] = a.mv[li][a.mv_top];
     }
 }
+
+#ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of block 0 */
+__device__ unsigned long long g_prof[16];
+#define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && lane == 0) g_prof[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define PROF_MARK(i) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(64)
 k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
@@ -525,53 +599,106 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     const mi355_h264_frame &fr = frames[blockIdx.x];
     const int mb_y = 4 * band + g, W = fr.mb_width;
     const bool row_ok = mb_y < fr.mb_height;
-    const int ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
+    const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
     const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
     const int list_count = fr.mv[1] ? 2 : 1;                 /* sl->list_count == 2 exactly when list-1 vectors exist */
     const int nsteps = W + 6;
     const bool has_t = row_ok && mb_y > 0;
-
+    /* 16-byte rows (luma) / 8-byte rows (chroma) can move as one access when pointers and strides allow */
+    const bool al16 = ((reinterpret_cast<uintptr_t>(fr.recon[0]) | reinterpret_cast<uintptr_t>(fr.dst[0]) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fr.recon[1]) | reinterpret_cast<uintptr_t>(fr.recon[2]) | reinterpret_cast<uintptr_t>(fr.dst[1]) |
+                        reinterpret_cast<uintptr_t>(fr.dst[2]) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
+    if (lane < 52) {
+        s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
+        s.t_tc0[lane][0] = k_tc0[lane][0]; s.t_tc0[lane][1] = k_tc0[lane][1]; s.t_tc0[lane][2] = k_tc0[lane][2]; s.t_tc0[lane][3] = 0;
+    }
+    DeblockPtr a;
+    {
+        const ptrdiff_t x0 = -2 * g;                         /* macroblock column of step 0 (may be negative: never dereferenced then) */
+        const ptrdiff_t yy = row_ok ? mb_y : 0;
+        a.ry = fr.recon[0] + (yy * 16 + l) * rs + x0 * 16;
+        a.rc = fr.recon[1 + cp] + (yy * 8 + cr) * rcs + x0 * 8;
+        a.dy = fr.dst[0] + (yy * 16 + l) * ds + x0 * 16;
+        a.dc = fr.dst[1 + cp] + (yy * 8 + cr) * dcs + x0 * 8;
+        a.ty = fr.dst[0] + (yy * 16 + (l >> 2) - 4) * ds + x0 * 16 + 4 * (l & 3);
+        a.tc = fr.dst[1 + ((l >> 2) & 1)] + (yy * 8 + ((l >> 1) & 1) - 2) * dcs + x0 * 8 + 4 * (l & 1);
+        const ptrdiff_t xy0 = yy * W + x0;
+        a.rec = reinterpret_cast<const uint32_t *>(fr.mb) + xy0 * 16 + l;
+        a.rec_top = -(ptrdiff_t)W * 16;
+        for (int li = 0; li < 2; li++) a.mv[li] = fr.mv[li] ? reinterpret_cast<const uint32_t *>(fr.mv[li]) + xy0 * 16 + l : nullptr;
+        a.mv_top = -(ptrdiff_t)W * 16 + 12;
+    }
     DeblockPre pre;
-    deblock_prefetch(pre, fr, row_ok, -2 * g, mb_y, l, cp, cr);
+    deblock_prefetch(pre, a, row_ok && g == 0, has_t, l, al16);
     uint32_t left_y = 0, left_c = 0;                         /* columns 12..15 / 6..7 of the previous MB, final */
+#ifdef MI355_PROF
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < nsteps; t++) {
+        PROF_MARK(7);
         const int mb_x = t - 2 * g, par = t & 1;
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
         const bool has_l = valid && mb_x > 0;
         const DeblockPre cur = pre;
-        uint8_t *dy = fr.dst[0] + (size_t)mb_y * 16 * ds + mb_x * 16;
-        uint8_t *dc = fr.dst[1 + cp] + (size_t)mb_y * 8 * dcs + mb_x * 8;
-        /* ---- phase A: next step's static data; this step's rows above (written one step ago at the
-         * latest, by this wave: visible after the barrier that ended that step) ------------------- */
-        deblock_prefetch(pre, fr, row_ok, mb_x + 1, mb_y, l, cp, cr);
+        const DeblockPtr at = a;                             /* addresses of this step's macroblock */
+        /* ---- phase A: this step's rows above (written one step ago at the latest, by this wave), then the
+         * next step's static data (vmcnt retires in order: the older request is the one waited for first) */
         uint32_t top_y = 0, top_c = 0;
         if (valid && has_t) {
-            top_y = *reinterpret_cast<const uint32_t *>(dy + ((l >> 2) - 4) * ds + 4 * (l & 3));
-            if (l < 8) top_c = *reinterpret_cast<const uint32_t *>(fr.dst[1 + (l >> 2)] + (size_t)(mb_y * 8 + ((l >> 1) & 1) - 2) * dcs + mb_x * 8 + 4 * (l & 1));
+            top_y = *reinterpret_cast<const uint32_t *>(at.ty);
+            if (l < 8) top_c = *reinterpret_cast<const uint32_t *>(at.tc);
         }
+        a.advance();
+        deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l, al16);
         /* ---- phase B: records and vectors -> LDS ------------------------------------------------- */
         reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
         reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
         s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
         if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
         MI355_WAVE_SYNC();
+        PROF_MARK(0);
 
-        const mi355_h264_mb &h = s.hdr[g][par], &hl = s.hdr[g][par ^ 1], &ht = s.hdr[g][2];
-        const bool filter = valid && !(h.flags & MI355_MBF_NO_DEBLOCK);
-        const bool have_left = filter && has_l && (h.flags & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags & MI355_MBF_TOP_EDGE);
-
-        /* ---- phase C: boundary strengths: lane (edge = l >> 2, segment = l & 3), both directions --- */
+        /* ---- phase C: boundary strengths: lane (edge = l >> 2, segment = l & 3), both directions.  All LDS
+         * reads are issued together; the arithmetic after them has no branches. ------------------- */
+        const MbInfo h = mb_info(s.hdr[g][par]), hl = mb_info(s.hdr[g][par ^ 1]), ht = mb_info(s.hdr[g][2]);
+        const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
+        const bool have_left = filter && has_l && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
         {
-            const int edge = l >> 2, seg = l & 3;
-            int b0 = 0, b1 = 0;
-            if (filter) {
-                b0 = bs_one(h, hl, have_left, 0, edge, seg, s.mv[g][par], s.mv[g][par ^ 1][0][3 + 4 * seg], s.mv[g][par ^ 1][1][3 + 4 * seg], list_count);
-                b1 = bs_one(h, ht, have_top, 1, edge, seg, s.mv[g][par], s.mvt[g][0][seg], s.mvt[g][1][seg], list_count);
+            const int edge = l >> 2, seg = l & 3, em1 = edge ? edge - 1 : 0;
+            uint32_t mp0[2], mq0[2], mp1[2], mq1[2];
+#pragma unroll
+            for (int li = 0; li < 2; li++) {
+                const uint32_t *own = s.mv[g][par][li];
+                const uint32_t in0 = own[em1 + 4 * seg], in1 = own[seg + 4 * em1];
+                const uint32_t out0 = s.mv[g][par ^ 1][li][3 + 4 * seg], out1 = s.mvt[g][li][seg];
+                mp0[li] = own[edge + 4 * seg]; mp1[li] = own[seg + 4 * edge];
+                mq0[li] = edge ? in0 : out0;   mq1[li] = edge ? in1 : out1;
             }
+            const int b0 = filter ? bs_flat(h, hl, have_left, 0, edge, seg, mp0, mq0, list_count) : 0;
+            const int b1 = filter ? bs_flat(h, ht, have_top, 1, edge, seg, mp1, mq1, list_count) : 0;
             s.bs[g][0][seg][edge] = (uint8_t)b0;
             s.bs[g][1][seg][edge] = (uint8_t)b1;
         }
         MI355_WAVE_SYNC();
+        PROF_MARK(1);
+        /* all strengths and all table look-ups of both directions, two LDS round trips in total */
+        const uint32_t bsw0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][l >> 2]), bsw1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][l >> 2]);
+        const uint32_t bsc0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]), bsc1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
+        const int qpc_h = h.qpc(cp);
+        /* chroma QP of a neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
+        const int qpc_l = hl.slice_id() == h.slice_id() ? hl.qpc(cp) : (have_left ? fr.slices[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0);
+        const int qpc_t = ht.slice_id() == h.slice_id() ? ht.qpc(cp) : (have_top ? fr.slices[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0);
+        EdgeParm ev[4], eh[4], cv[2], ch[2];
+        ev[0] = edge_parm(s, (h.qp() + hl.qp() + 1) >> 1, h, bsw0 & 0xFF);
+        eh[0] = edge_parm(s, (h.qp() + ht.qp() + 1) >> 1, h, bsw1 & 0xFF);
+#pragma unroll
+        for (int e = 1; e < 4; e++) {
+            ev[e] = edge_parm(s, h.qp(), h, (bsw0 >> (8 * e)) & 0xFF);
+            eh[e] = edge_parm(s, h.qp(), h, (bsw1 >> (8 * e)) & 0xFF);
+        }
+        cv[0] = edge_parm(s, (qpc_h + qpc_l + 1) >> 1, h, bsc0 & 0xFF); cv[1] = edge_parm(s, qpc_h, h, (bsc0 >> 16) & 0xFF);
+        ch[0] = edge_parm(s, (qpc_h + qpc_t + 1) >> 1, h, bsc1 & 0xFF); ch[1] = edge_parm(s, qpc_h, h, (bsc1 >> 16) & 0xFF);
+        const bool intra_v = __any(((bsw0 & 0xFF) == 4)) != 0, intra_h = __any(((bsw1 & 0xFF) == 4)) != 0;
 
         /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers ------- */
         {
@@ -579,79 +706,79 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             unpack4(left_y, px);
 #pragma unroll
             for (int k = 0; k < 4; k++) unpack4(cur.y[k], px + 4 + 4 * k);
-            const uint32_t bsw = *reinterpret_cast<const uint32_t *>(s.bs[g][0][l >> 2]);
-            if (bsw) {
-                const EdgeParm e0 = edge_parm((h.qp + hl.qp + 1) >> 1, h), ei = edge_parm(h.qp, h);
-                luma_edge(px + 0, bsw & 0xFF, e0);
+            luma_edge(px, bsw0 & 0xFF, ev[0], intra_v);
 #pragma unroll
-                for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw >> (8 * e)) & 0xFF, ei);
-            }
+            for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw0 >> (8 * e)) & 0xFF, ev[e], false);   /* inner edges: bS <= 3 */
             uint32_t *row = reinterpret_cast<uint32_t *>(s.y[g][4 + l]);
 #pragma unroll
             for (int k = 0; k < 4; k++) row[k] = pack4(px + 4 + 4 * k);
-            if (have_left) *reinterpret_cast<uint32_t *>(dy + l * ds - 4) = pack4(px);
+            if (have_left) *reinterpret_cast<uint32_t *>(at.dy - 4) = pack4(px);
 
             int cx[10];
             cx[0] = left_c & 0xFF; cx[1] = (left_c >> 8) & 0xFF;
             unpack4(cur.c[0], cx + 2); unpack4(cur.c[1], cx + 6);
-            const uint32_t bsc = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]);
-            if (bsc & 0x00FF00FF) {
-                chroma_edge(cx + 0, bsc & 0xFF, edge_parm((h.qpc[cp] + nb_qpc(fr, h, hl, cp) + 1) >> 1, h));
-                chroma_edge(cx + 4, (bsc >> 16) & 0xFF, edge_parm(h.qpc[cp], h));
-            }
+            chroma_edge(cx + 0, bsc0 & 0xFF, cv[0]);
+            chroma_edge(cx + 4, (bsc0 >> 16) & 0xFF, cv[1]);
             uint32_t *crow = reinterpret_cast<uint32_t *>(s.c[g][cp][2 + cr]);
             crow[0] = pack4(cx + 2); crow[1] = pack4(cx + 6);
-            if (have_left) *reinterpret_cast<uint16_t *>(dc + cr * dcs - 2) = (uint16_t)(cx[0] | (cx[1] << 8));
+            if (have_left) *reinterpret_cast<uint16_t *>(at.dc - 2) = (uint16_t)(cx[0] | (cx[1] << 8));
+            PROF_MARK(2);
             /* the rows above, fetched in phase A */
             *reinterpret_cast<uint32_t *>(&s.y[g][l >> 2][4 * (l & 3)]) = top_y;
             if (l < 8) *reinterpret_cast<uint32_t *>(&s.c[g][l >> 2][(l >> 1) & 1][4 * (l & 1)]) = top_c;
         }
         MI355_WAVE_SYNC();
+        PROF_MARK(3);
         /* ---- phase D1: horizontal edges, one luma column + one chroma column per lane ------------- */
         {
-            const uint32_t bsw = *reinterpret_cast<const uint32_t *>(s.bs[g][1][l >> 2]);
-            if (bsw) {
-                int py[20];
+            int py[20], cy[10];
 #pragma unroll
-                for (int k = 0; k < 20; k++) py[k] = s.y[g][k][l];
-                const EdgeParm e0 = edge_parm((h.qp + ht.qp + 1) >> 1, h), ei = edge_parm(h.qp, h);
-                luma_edge(py + 0, bsw & 0xFF, e0);
+            for (int k = 0; k < 20; k++) py[k] = s.y[g][k][l];
 #pragma unroll
-                for (int e = 1; e < 4; e++) luma_edge(py + 4 * e, (bsw >> (8 * e)) & 0xFF, ei);
+            for (int k = 0; k < 10; k++) cy[k] = s.c[g][cp][k][cr];
+            luma_edge(py, bsw1 & 0xFF, eh[0], intra_h);
+#pragma unroll
+            for (int e = 1; e < 4; e++) luma_edge(py + 4 * e, (bsw1 >> (8 * e)) & 0xFF, eh[e], false);
+            chroma_edge(cy + 0, bsc1 & 0xFF, ch[0]);
+            chroma_edge(cy + 4, (bsc1 >> 16) & 0xFF, ch[1]);
+            if (bsw1) {
 #pragma unroll
                 for (int k = 1; k < 19; k++) s.y[g][k][l] = (uint8_t)py[k];
             }
-            const uint32_t bsc = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
-            if (bsc & 0x00FF00FF) {
-                int cy[10];
-#pragma unroll
-                for (int k = 0; k < 10; k++) cy[k] = s.c[g][cp][k][cr];
-                chroma_edge(cy + 0, bsc & 0xFF, edge_parm((h.qpc[cp] + nb_qpc(fr, h, ht, cp) + 1) >> 1, h));
-                chroma_edge(cy + 4, (bsc >> 16) & 0xFF, edge_parm(h.qpc[cp], h));
+            if (bsc1 & 0x00FF00FF) {
 #pragma unroll
                 for (int k = 1; k < 9; k++) s.c[g][cp][k][cr] = (uint8_t)cy[k];
             }
         }
         MI355_WAVE_SYNC();
+        PROF_MARK(4);
         /* ---- phase E: the MB, the rows above that its top edge may have changed; carry the right-most
          * columns to the next step --------------------------------------------------------------- */
         {
             const uint32_t *row = reinterpret_cast<const uint32_t *>(s.y[g][4 + l]);
             const uint32_t *crow = reinterpret_cast<const uint32_t *>(s.c[g][cp][2 + cr]);
-            const uint32_t r3 = row[3], c1 = crow[1];
+            const uint32_t r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], c0 = crow[0], c1 = crow[1];
+            const uint32_t tyw = *reinterpret_cast<const uint32_t *>(&s.y[g][1 + (l >> 2) % 3][4 * (l & 3)]);
+            const uint32_t tcw = *reinterpret_cast<const uint32_t *>(&s.c[g][(l >> 1) & 1][1][4 * (l & 1)]);
             if (valid) {
-                uint32_t *o = reinterpret_cast<uint32_t *>(dy + l * ds);
-                o[0] = row[0]; o[1] = row[1]; o[2] = row[2]; o[3] = r3;
-                uint32_t *oc = reinterpret_cast<uint32_t *>(dc + cr * dcs);
-                oc[0] = crow[0]; oc[1] = c1;
+                if (al16) {
+                    *reinterpret_cast<uint4 *>(at.dy) = make_uint4(r0, r1, r2, r3);
+                    *reinterpret_cast<uint2 *>(at.dc) = make_uint2(c0, c1);
+                } else {
+                    uint32_t *o = reinterpret_cast<uint32_t *>(at.dy);
+                    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+                    uint32_t *oc = reinterpret_cast<uint32_t *>(at.dc);
+                    oc[0] = c0; oc[1] = c1;
+                }
                 if (have_top) {
-                    if (l < 12) *reinterpret_cast<uint32_t *>(dy + ((l >> 2) - 3) * ds + 4 * (l & 3)) = *reinterpret_cast<const uint32_t *>(&s.y[g][1 + (l >> 2)][4 * (l & 3)]);
-                    else *reinterpret_cast<uint32_t *>(fr.dst[1 + ((l >> 1) & 1)] + (size_t)(mb_y * 8 - 1) * dcs + mb_x * 8 + 4 * (l & 1)) =
-                             *reinterpret_cast<const uint32_t *>(&s.c[g][(l >> 1) & 1][1][4 * (l & 1)]);
+                    /* luma rows -3..-1 are one row below the ones lanes 0..11 loaded; chroma row -1 */
+                    if (l < 12) *reinterpret_cast<uint32_t *>(at.ty + ds) = tyw;
+                    else *reinterpret_cast<uint32_t *>(fr.dst[1 + ((l >> 1) & 1)] + (size_t)(mb_y * 8 - 1) * dcs + mb_x * 8 + 4 * (l & 1)) = tcw;
                 }
             }
             left_y = r3; left_c = c1 >> 16;
         }
+        PROF_MARK(5);
         MI355_WAVE_SYNC();   /* stores of this step are visible to the wave's next step; LDS may be reused */
     }
 }
@@ -680,6 +807,16 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
                            d_frames, level, max_level_width);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+#ifdef MI355_PROF
+extern "C" void mi355_debug_prof(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = {};
+    MI355_CHECK(hipDeviceSynchronize());
+    MI355_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(z)));
+    if (reset) MI355_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)));
+}
+#endif
 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
