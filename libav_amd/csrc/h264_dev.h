@@ -57,96 +57,111 @@ __device__ __forceinline__ int px_clamped(const PlaneRef &p, int x, int y)
 }
 
 /* ---- per-wave LDS scratch -------------------------------------------------- */
-constexpr int WY_PITCH = 32;            /* luma window row pitch in bytes (8 dwords): 21 columns + alignment slack */
-constexpr int WC_PITCH = 16;            /* chroma window row pitch (4 dwords): 9 columns + slack */
+/* Reference windows are staged ALIGNED TO THE BLOCK: luma window byte b of row r is picture sample
+ * (ix - 4 + b, iy - 2 + r), so block column 0 sits on a dword boundary and every 4-sample segment
+ * of the block reads whole dwords; chroma window byte b of row r is sample (cx + b, cy + r). */
+constexpr int WY_DW = 6;                /* luma window row: 24 bytes = columns -4..19 of the block */
+constexpr int WC_DW = 3;                /* chroma window row: 12 bytes = columns 0..11 */
 struct McScratch {
-    uint32_t winY[21 * (WY_PITCH / 4)]; /* staged luma reference window, up to 21 rows */
-    uint32_t winC[2][9 * (WC_PITCH / 4)];
+    uint32_t winY[21 * WY_DW];          /* up to 21 rows (16 + 5) */
+    uint32_t winC[2][9 * WC_DW];
     int16_t tmp[21 * 16];               /* unclipped horizontal 6-tap sums for the centre position */
-    int shiftY, shiftC;                 /* byte offset of window column 0 inside each staged row */
 };
 
-/* One window's worth of loads for this lane, issued before anything waits on them.
- * Fast path (window inside the plane): aligned dword loads, the row is stored as fetched and the
- * consumer skips `shift` bytes.  Slow path: per-sample clamped reads (== emulated_edge_mc). */
-template <int PITCH, int MAXIT>
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t mi355_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (s & 3))); }
+#else
+__device__ __forceinline__ uint32_t mi355_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
+#endif
+
+/* One window's worth of loads for this lane, issued before anything waits on them.  The window starts
+ * at picture column x0 (any alignment) and is `ndw` dwords wide, `wh` rows high.
+ * Fast path (every dword the realignment touches lies inside the plane, rows 4-byte aligned): two
+ * aligned dword loads + v_alignbyte.  Slow path: per-sample clamped reads (== emulated_edge_mc,
+ * videodsp_template.c:24-96). */
+template <int MAXIT>
 struct WinLoad {
-    uint32_t v[MAXIT];
-    __device__ __forceinline__ void issue(const PlaneRef &ref, int x0, int y0, int ww, int wh, bool inside, int lane)
+    uint32_t lo[MAXIT], hi[MAXIT];
+    uint32_t shift;
+    __device__ __forceinline__ void issue(const PlaneRef &ref, int x0, int y0, int ndw, int wh, bool inside, int lane)
     {
-        constexpr int PD = PITCH / 4;
-        if (inside) {
-            const int xa = x0 & ~3, shift = x0 & 3, ndw = (shift + ww + 3) >> 2;
-#pragma unroll
-            for (int k = 0; k < MAXIT; k++) {
-                const int idx = lane + 64 * k, row = idx / PD, dw = idx % PD;
-                v[k] = 0;
-                if (row < wh && dw < ndw)
-                    v[k] = *reinterpret_cast<const uint32_t *>(ref.base + (size_t)(y0 + row) * ref.stride + xa + 4 * dw);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < MAXIT; k++) {
-                const int idx = lane + 64 * k, row = idx / PD, dw = idx % PD;
-                uint32_t w = 0;
-                if (row < wh && 4 * dw < ww) {
-#pragma unroll
-                    for (int b = 0; b < 4; b++) w |= (uint32_t)px_clamped(ref, x0 + 4 * dw + b, y0 + row) << (8 * b);
-                }
-                v[k] = w;
-            }
-        }
-    }
-    __device__ __forceinline__ void commit(uint32_t *win, int wh, int lane) const
-    {
-        constexpr int PD = PITCH / 4;
+        shift = (uint32_t)x0 & 3;
+        const int xa = x0 & ~3;
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
-            const int idx = lane + 64 * k;
-            if (idx < wh * PD) win[idx] = v[k];
+            const int idx = lane + 64 * k, row = idx / ndw, dw = idx - row * ndw;
+            lo[k] = hi[k] = 0;
+            if (row >= wh) continue;
+            if (inside) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(ref.base + (size_t)(y0 + row) * ref.stride + xa + 4 * dw);
+                lo[k] = p[0];
+                hi[k] = p[1];
+            } else {
+                uint32_t w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) w |= (uint32_t)px_clamped(ref, x0 + 4 * dw + b, y0 + row) << (8 * b);
+                lo[k] = w;
+            }
+        }
+        if (!inside) shift = 0;
+    }
+    __device__ __forceinline__ void commit(uint32_t *win, int pitch_dw, int ndw, int wh, int lane) const
+    {
+#pragma unroll
+        for (int k = 0; k < MAXIT; k++) {
+            const int idx = lane + 64 * k, row = idx / ndw, dw = idx - row * ndw;
+            if (row < wh) win[row * pitch_dw + dw] = mi355_alignbyte(hi[k], lo[k], shift);
         }
     }
 };
-__device__ __forceinline__ bool win_inside(const PlaneRef &ref, int x0, int y0, int ww, int wh)
+__device__ __forceinline__ bool win_inside(const PlaneRef &ref, int x0, int y0, int ndw, int wh)
 {
-    /* the dword path also needs 4-byte aligned rows */
-    return x0 >= 0 && y0 >= 0 && x0 + ww <= ref.w && y0 + wh <= ref.h &&
+    const int xa = x0 & ~3;
+    return xa >= 0 && y0 >= 0 && xa + 4 * (ndw + 1) <= ref.w && y0 + wh <= ref.h &&
            ((reinterpret_cast<uintptr_t>(ref.base) | (uintptr_t)ref.stride) & 3) == 0;
 }
+__device__ __forceinline__ int luma_win_dw(int bw) { return (4 + bw + 3 + 3) >> 2; }      /* columns -4..bw+2 */
+__device__ __forceinline__ int chroma_win_dw(int cw) { return (cw + 1 + 3) >> 2; }          /* columns 0..cw */
 
-/* Stage the luma window of a bw x bh block at integer position (ix,iy) [window origin ix-2,iy-2,
- * (bw+5) x (bh+5)] and, if `cb`/`cr` are given, the (bw/2+1) x (bh/2+1) chroma windows at (cx,cy):
- * all loads are in flight together, one LDS barrier at the end. */
+/* Stage the luma window of a bw x bh block at integer position (ix,iy) and, if `cb`/`cr` are given, the
+ * chroma windows of the cw x ch block at (cx,cy): all loads are in flight together, one LDS barrier
+ * at the end. */
 __device__ inline void stage_windows(McScratch &s, const PlaneRef *y, int ix, int iy, int bw, int bh,
                                      const PlaneRef *cb, const PlaneRef *cr, int cx, int cy, int cw, int ch)
 {
     const int lane = lane_id();
-    WinLoad<WY_PITCH, 3> ly;
-    WinLoad<WC_PITCH, 1> lb, lr;
-    bool in_y = false, in_c = false;
-    if (y) {
-        in_y = win_inside(*y, ix - 2, iy - 2, bw + 5, bh + 5);
-        ly.issue(*y, ix - 2, iy - 2, bw + 5, bh + 5, in_y, lane);
-    }
+    WinLoad<2> ly;
+    WinLoad<1> lb, lr;
+    const int ydw = luma_win_dw(bw), cdw = chroma_win_dw(cw);
+    if (y) ly.issue(*y, ix - 4, iy - 2, ydw, bh + 5, win_inside(*y, ix - 4, iy - 2, ydw, bh + 5), lane);
     if (cb) {
-        in_c = win_inside(*cb, cx, cy, cw + 1, ch + 1);
-        lb.issue(*cb, cx, cy, cw + 1, ch + 1, in_c, lane);
-        lr.issue(*cr, cx, cy, cw + 1, ch + 1, in_c, lane);
+        const bool in_c = win_inside(*cb, cx, cy, cdw, ch + 1);
+        lb.issue(*cb, cx, cy, cdw, ch + 1, in_c, lane);
+        lr.issue(*cr, cx, cy, cdw, ch + 1, in_c, lane);
     }
-    if (y) { ly.commit(s.winY, bh + 5, lane); s.shiftY = in_y ? ((ix - 2) & 3) : 0; }
-    if (cb) { lb.commit(s.winC[0], ch + 1, lane); lr.commit(s.winC[1], ch + 1, lane); s.shiftC = in_c ? (cx & 3) : 0; }
+    if (y) ly.commit(s.winY, WY_DW, ydw, bh + 5, lane);
+    if (cb) { lb.commit(s.winC[0], WC_DW, cdw, ch + 1, lane); lr.commit(s.winC[1], WC_DW, cdw, ch + 1, lane); }
     __syncthreads();
 }
 
+__device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int *v)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (a >> (8 * k)) & 0xFF; v[4 + k] = (b >> (8 * k)) & 0xFF; v[8 + k] = (c >> (8 * k)) & 0xFF; }
+}
+/* rounded average of four packed samples: (a + b + 1) >> 1 per byte */
+__device__ __forceinline__ uint32_t rnd_avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu); }
+
 /* ---- a5: quarter-pel luma MC (h264qpel_template.c:77-531) -------------------
- * Block bw x bh from the staged window, fraction (mx,my) in quarter samples.  Result goes to
- * pred[(py+y)*ppitch + px+x] (LDS), either stored (avg=0) or rounded-averaged with what is there
- * (avg=1: the reference's avg_ tables / second list of a bi-predicted block). */
+ * Block bw x bh from the staged window, fraction (mx,my) in quarter samples.  A lane produces one
+ * 4-sample row segment (whole dwords in, one dword out).  Result goes to pred[(py+y)*ppitch + px+x]
+ * (LDS), either stored (avg=0) or rounded-averaged with what is there (avg=1: the reference's avg_
+ * tables / second list of a bi-predicted block).  Every position is the (rounded average of the)
+ * integer sample G, the horizontal half sample b, the vertical half sample h and the centre j. */
 __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int bh,
                                        uint8_t *pred, int ppitch, int px, int py, int avg)
 {
     const int lane = lane_id();
-    const uint8_t *win = reinterpret_cast<const uint8_t *>(s.winY) + s.shiftY;
     const int wh = bh + 5;
     const bool use_j = (mx == 2 && my != 0) || (my == 2 && mx != 0);
     const bool use_b = mx != 0 && my != 2;
@@ -154,57 +169,106 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
     const bool use_g = (mx == 0 || my == 0) && ((mx | my) != 2);
     const int bdy = my == 3, hdx = mx == 3;
     const int gdx = (my == 0 && mx == 3), gdy = (mx == 0 && my == 3);
-    const int lw = bw == 16 ? 4 : (bw == 8 ? 3 : (bw == 4 ? 2 : 1));
+    const int nseg = bw >= 4 ? bw >> 2 : 1, lseg = nseg == 4 ? 2 : (nseg == 2 ? 1 : 0);
     if (use_j) {
-        for (int i = lane; i < wh * bw; i += 64) {
-            int y = i >> lw, x = i & (bw - 1);
-            const uint8_t *r = &win[y * WY_PITCH + x];
-            s.tmp[y * 16 + x] = (int16_t)tap6(r[0], r[1], r[2], r[3], r[4], r[5]);
+        /* unclipped horizontal sums of all bh+5 rows, 4 per lane */
+        for (int i = lane; i < wh * nseg; i += 64) {
+            const int r = i >> lseg, sx = i & (nseg - 1);
+            const uint32_t *w = &s.winY[r * WY_DW + sx];
+            int v[12];
+            bytes12(w[0], w[1], w[2], v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) s.tmp[r * 16 + 4 * sx + k] = (int16_t)tap6(v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], v[k + 7]);
         }
         __syncthreads();
     }
-    for (int i = lane; i < bw * bh; i += 64) {
-        int y = i >> lw, x = i & (bw - 1);
-        const uint8_t *c = &win[(y + 2) * WY_PITCH + x + 2];
-        int sum = 0, n = 0;
-        if (use_g) { sum += c[gdy * WY_PITCH + gdx]; n++; }
+    for (int i = lane; i < bh * nseg; i += 64) {
+        const int y = i >> lseg, sx = i & (nseg - 1);
+        int sum[4] = { 0, 0, 0, 0 };
+        if (use_g) {
+            const uint32_t *w = &s.winY[(y + 2 + gdy) * WY_DW + sx + 1];
+            const uint32_t g = gdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += (g >> (8 * k)) & 0xFF;
+        }
         if (use_b) {
-            int hs;
-            if (use_j) hs = s.tmp[(y + 2 + bdy) * 16 + x];
-            else { const uint8_t *r = c + bdy * WY_PITCH; hs = tap6(r[-2], r[-1], r[0], r[1], r[2], r[3]); }
-            sum += clip_u8((hs + 16) >> 5); n++;
+            if (use_j) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum[k] += clip_u8((s.tmp[(y + 2 + bdy) * 16 + 4 * sx + k] + 16) >> 5);
+            } else {
+                const uint32_t *w = &s.winY[(y + 2 + bdy) * WY_DW + sx];
+                int v[12];
+                bytes12(w[0], w[1], w[2], v);
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum[k] += clip_u8((tap6(v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], v[k + 7]) + 16) >> 5);
+            }
         }
         if (use_h) {
-            const uint8_t *r = c + hdx;
-            int vs = tap6(r[-2 * WY_PITCH], r[-WY_PITCH], r[0], r[WY_PITCH], r[2 * WY_PITCH], r[3 * WY_PITCH]);
-            sum += clip_u8((vs + 16) >> 5); n++;
+            uint32_t c[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const uint32_t *w = &s.winY[(y + r) * WY_DW + sx + 1];
+                c[r] = hdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sh = 8 * k;
+                sum[k] += clip_u8((tap6((c[0] >> sh) & 0xFF, (c[1] >> sh) & 0xFF, (c[2] >> sh) & 0xFF, (c[3] >> sh) & 0xFF,
+                                        (c[4] >> sh) & 0xFF, (c[5] >> sh) & 0xFF) + 16) >> 5);
+            }
         }
         if (use_j) {
-            const int16_t *t = &s.tmp[y * 16 + x];
-            int js = tap6(t[0], t[16], t[32], t[48], t[64], t[80]);
-            sum += clip_u8((js + 512) >> 10); n++;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int16_t *t = &s.tmp[y * 16 + 4 * sx + k];
+                sum[k] += clip_u8((tap6(t[0], t[16], t[32], t[48], t[64], t[80]) + 512) >> 10);
+            }
         }
-        int v = n == 2 ? (sum + 1) >> 1 : sum;
-        uint8_t *d = &pred[(py + y) * ppitch + px + x];
-        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+        const int two = (int)use_g + (int)use_b + (int)use_h + (int)use_j == 2;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)(two ? (sum[k] + 1) >> 1 : sum[k]) << (8 * k);
+        uint8_t *d = &pred[(py + y) * ppitch + px + 4 * sx];
+        if (bw >= 4) {
+            uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+            *dw = avg ? rnd_avg4(*dw, v) : v;
+        } else {                      /* 2-sample blocks (h264qpel 2x2 tables) */
+            uint16_t *d2 = reinterpret_cast<uint16_t *>(d);
+            *d2 = (uint16_t)(avg ? rnd_avg4(*d2, v) : v);
+        }
     }
     __syncthreads();
 }
 
-/* ---- a6: 1/8-pel bilinear chroma MC (h264chroma_template.c:27-173) ---------- */
-__device__ inline void mc_chroma_compute(McScratch &s, int plane, int fx, int fy, int bw, int bh,
-                                         uint8_t *pred, int ppitch, int px, int py, int avg)
+/* ---- a6: 1/8-pel bilinear chroma MC (h264chroma_template.c:27-173) ----------
+ * `nplanes` planes in one pass (window p -> pred[p]); a lane produces one 4-sample row segment. */
+__device__ inline void mc_chroma_compute(McScratch &s, int nplanes, int fx, int fy, int bw, int bh,
+                                         uint8_t *pred0, uint8_t *pred1, int ppitch, int px, int py, int avg)
 {
     const int lane = lane_id();
-    const uint8_t *win = reinterpret_cast<const uint8_t *>(s.winC[plane]) + s.shiftC;
     const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
-    const int lw = bw == 8 ? 3 : (bw == 4 ? 2 : 1);
-    for (int i = lane; i < bw * bh; i += 64) {
-        int y = i >> lw, x = i & (bw - 1);
-        const uint8_t *c = &win[y * WC_PITCH + x];
-        int v = (A * c[0] + B * c[1] + C * c[WC_PITCH] + D * c[WC_PITCH + 1] + 32) >> 6;
-        uint8_t *d = &pred[(py + y) * ppitch + px + x];
-        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+    const int nseg = bw >= 4 ? bw >> 2 : 1, per_plane = bh * nseg;
+    for (int i = lane; i < per_plane * nplanes; i += 64) {
+        const int plane = i >= per_plane, j = i - plane * per_plane;
+        const int y = nseg == 2 ? j >> 1 : j, sx = nseg == 2 ? j & 1 : 0;
+        const uint32_t *w0 = &s.winC[plane][y * WC_DW + sx], *w1 = w0 + WC_DW;
+        const uint32_t a0 = w0[0], a1 = mi355_alignbyte(w0[1], w0[0], 1), b0 = w1[0], b1 = mi355_alignbyte(w1[1], w1[0], 1);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sh = 8 * k;
+            v |= (uint32_t)((A * (int)((a0 >> sh) & 0xFF) + B * (int)((a1 >> sh) & 0xFF) + C * (int)((b0 >> sh) & 0xFF) + D * (int)((b1 >> sh) & 0xFF) + 32) >> 6) << sh;
+        }
+        uint8_t *d = (plane ? pred1 : pred0) + (py + y) * ppitch + px + 4 * sx;
+        if (bw >= 4) {
+            uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+            *dw = avg ? rnd_avg4(*dw, v) : v;
+        } else if (bw == 2) {
+            uint16_t *d2 = reinterpret_cast<uint16_t *>(d);
+            *d2 = (uint16_t)(avg ? rnd_avg4(*d2, v) : v);
+        } else {
+            *d = (uint8_t)(avg ? rnd_avg4(*d, v & 0xFF) : v);
+        }
     }
     __syncthreads();
 }

@@ -81,12 +81,11 @@ __device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_
     PlaneRef rr{fr.ref[slot][2], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
-    mc_chroma_compute(s.mc, 0, mx & 7, my & 7, w >> 1, h >> 1, pcb, 8, bx >> 1, by >> 1, avg);
-    mc_chroma_compute(s.mc, 1, mx & 7, my & 7, w >> 1, h >> 1, pcr, 8, bx >> 1, by >> 1, avg);
+    mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
 }
 
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
-__device__ inline void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+__device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
                                int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
     const int r0 = s.hdr.ref_idx[0][quadrant], r1 = s.hdr.ref_idx[1][quadrant];
@@ -127,37 +126,34 @@ __device__ inline void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355
     }
 }
 
-/* hl_motion, h264_mc_template.c:64-163 */
+/* hl_motion, h264_mc_template.c:64-163.  The partitions are enumerated by one loop so that mc_part has
+ * a single (inlined) call site. */
 __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y, int mb_xy)
 {
     const uint32_t t = s.hdr.mb_type;
 #define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
-    if (t & MI355_MB_16x16) {
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, DIRF(0, 0), DIRF(0, 1));
-    } else if (t & MI355_MB_16x8) {
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 8, DIRF(0, 0), DIRF(0, 1));
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 8, 2, 0, 8, 16, 8, DIRF(1, 0), DIRF(1, 1));
-    } else if (t & MI355_MB_8x16) {
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 8, 16, DIRF(0, 0), DIRF(0, 1));
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 2, 1, 8, 0, 8, 16, DIRF(1, 0), DIRF(1, 1));
-    } else {
-        for (int i = 0; i < 4; i++) {
+    const int kind = (t & MI355_MB_16x16) ? 0 : ((t & MI355_MB_16x8) ? 1 : ((t & MI355_MB_8x16) ? 2 : 3));
+    const int nparts = kind == 0 ? 1 : (kind == 3 ? 16 : 2);
+    for (int p = 0; p < nparts; p++) {
+        int n, quad, bx, by, w, h, l0, l1;
+        if (kind == 0) { n = 0; quad = 0; bx = 0; by = 0; w = 16; h = 16; l0 = DIRF(0, 0); l1 = DIRF(0, 1); }
+        else if (kind == 1) { n = 8 * p; quad = 2 * p; bx = 0; by = 8 * p; w = 16; h = 8; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
+        else if (kind == 2) { n = 2 * p; quad = p; bx = 8 * p; by = 0; w = 8; h = 16; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
+        else {
+            const int i = p >> 2, j = p & 3;
             const int st = s.hdr.sub_mb_type[i], shape = st & 3;
-            const int l0 = (st & MI355_SUB_L0) != 0, l1 = (st & MI355_SUB_L1) != 0;
-            const int x = (i & 1) * 8, y = (i >> 1) * 8, n = (x >> 2) + 4 * (y >> 2);
-            if (shape == MI355_SUB_8x8) {
-                mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n, i, x, y, 8, 8, l0, l1);
-            } else if (shape == MI355_SUB_8x4) {
-                mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n, i, x, y, 8, 4, l0, l1);
-                mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n + 4, i, x, y + 4, 8, 4, l0, l1);
-            } else if (shape == MI355_SUB_4x8) {
-                mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n, i, x, y, 4, 8, l0, l1);
-                mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n + 1, i, x + 4, y, 4, 8, l0, l1);
-            } else {
-                for (int j = 0; j < 4; j++)
-                    mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n + (j & 1) + 4 * (j >> 1), i, x + 4 * (j & 1), y + 4 * (j >> 1), 4, 4, l0, l1);
-            }
+            const int cnt = shape == MI355_SUB_8x8 ? 1 : (shape == MI355_SUB_4x4 ? 4 : 2);
+            if (j >= cnt) continue;
+            l0 = (st & MI355_SUB_L0) != 0; l1 = (st & MI355_SUB_L1) != 0;
+            const int x = (i & 1) * 8, y = (i >> 1) * 8;
+            quad = i;
+            w = (shape == MI355_SUB_8x8 || shape == MI355_SUB_8x4) ? 8 : 4;
+            h = (shape == MI355_SUB_8x8 || shape == MI355_SUB_4x8) ? 8 : 4;
+            bx = x + (shape == MI355_SUB_4x8 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j & 1) : 0));
+            by = y + (shape == MI355_SUB_8x4 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j >> 1) : 0));
+            n = (bx >> 2) + 4 * (by >> 2);
         }
+        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
 }
@@ -235,6 +231,13 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
     }
 }
 
+#ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of the first blocks */
+__device__ unsigned long long g_prof[16];
+#define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x < 64 && lane_id() == 0) atomicAdd(&g_prof[i], now_ - prof_t); prof_t = now_; } while (0)
+#else
+#define PROF_MARK(i) do { } while (0)
+#endif
+
 /* ------------------------------------------------------------------------- */
 /* Workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Give each XCD one
  * contiguous run of macroblocks so that horizontally adjacent MBs — which share reference
@@ -250,14 +253,22 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_nmb, int nblo
     const int f = lin / max_nmb, mb_xy = lin - f * max_nmb;
     const mi355_h264_frame &fr = frames[f];
     if (mb_xy >= fr.mb_width * fr.mb_height) return;
+#ifdef MI355_PROF
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     load_mb(s, fr, mb_xy, true);
+    PROF_MARK(8);
     if (s.hdr.mb_type & MI355_MB_INTRA) return;
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
+    PROF_MARK(9);
     residual_luma(s, s.py, 16, false);
+    PROF_MARK(10);
     residual_chroma(s, s.pc[0], s.pc[1], 8);
+    PROF_MARK(11);
     store_mb(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
+    PROF_MARK(12);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -584,12 +595,6 @@ __device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr
     }
 }
 
-#ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of block 0 */
-__device__ unsigned long long g_prof[16];
-#define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && lane == 0) g_prof[i] += now_ - prof_t; prof_t = now_; } while (0)
-#else
-#define PROF_MARK(i) do { } while (0)
-#endif
 
 __global__ void __launch_bounds__(64)
 k_deblock(const mi355_h264_frame *__restrict__ frames, int band)

@@ -80,7 +80,7 @@ k_chroma(const uint8_t *win, int wpitch, uint8_t *dst, int dpitch, int w, int h,
     for (int y0 = 0; y0 < h; y0 += 8) {
         int bh = h - y0 < 8 ? h - y0 : 8;
         stage_windows(s, nullptr, 0, 0, 0, 0, &ref, &ref, 0, y0, w, bh);
-        mc_chroma_compute(s, 0, fx, fy, w, bh, pred, 8, 0, y0, avg);
+        mc_chroma_compute(s, 1, fx, fy, w, bh, pred, pred, 8, 0, y0, avg);
     }
     for (int i = lane; i < w * h; i += 64) {
         int y = i / w, x = i - y * w;

@@ -16,14 +16,21 @@ class P: pass
 prov = P(); prov.lib = lib
 fs = HF.synth_frames_fast(4, 120, 68, seed=0x264, lib=lib)
 dev = HF.DeviceFrames(prov, fs, replicate=F)
-lib.mi355_h264_recon_inter_dev(C.c_void_p(dev.d_desc), F, 120, 68, None)
-lib.mi355_h264_recon_intra_dev(C.c_void_p(dev.d_desc), F, fs.max_intra_level, fs.max_level_width, None)
+lib.mi355_debug_prof.argtypes = [C.c_void_p, C.c_int]
 out = (C.c_ulonglong * 16)()
 lib.mi355_debug_prof(out, 1)
 for rep in range(2):
+    lib.mi355_h264_recon_inter_dev(C.c_void_p(dev.d_desc), F, 120, 68, None)
+    lib.mi355_debug_prof(out, 1)
+    tot = sum(out[i] for i in range(8, 13))
+    print("k_recon_inter, first 64 blocks: %.0f clk per MB" % (tot / 64))
+    for i, n in zip(range(8, 13), ["load_mb", "hl_motion (MC)", "residual_luma", "residual_chroma", "store_mb"]):
+        print("  %-20s %8.0f  %5.1f%%" % (n, out[i] / 64, 100.0 * out[i] / tot))
+lib.mi355_h264_recon_intra_dev(C.c_void_p(dev.d_desc), F, fs.max_intra_level, fs.max_level_width, None)
+for rep in range(2):
     lib.mi355_h264_deblock_dev(C.c_void_p(dev.d_desc), F, 120, 68, None)
     lib.mi355_debug_prof(out, 1)
-    steps = 17 * 126
+    steps = 17 * 126 * min(F, 64)
     names = ["A+B: issue loads, hdr/mv->LDS", "C: bS", "D0: vertical edges + rows->LDS", "top rows->LDS", "D1: horizontal edges", "E: stores+carry", "-", "loop top (wait prefetch)"]
     tot = sum(out[i] for i in range(8))
     print("F=%d rep %d: total %.0f clk/step (100 MHz ticks? see below)" % (F, rep, tot / steps))
