@@ -415,6 +415,28 @@ LF_IN(t1_v_lf_luma_intra, 1, 0, 4) LF_IN(t1_h_lf_luma_intra, 1, 1, 4) LF_IN(t1_h
 LF_TC(t1_v_lf_chroma, 2, 0, 2) LF_TC(t1_h_lf_chroma, 2, 1, 2) LF_TC(t1_h_lf_chroma_mbaff, 2, 1, 1)
 LF_IN(t1_v_lf_chroma_intra, 3, 0, 2) LF_IN(t1_h_lf_chroma_intra, 3, 1, 2) LF_IN(t1_h_lf_chroma_mbaff_intra, 3, 1, 1)
 
+/* ---- a4: transform-bypass residual add, h264addpx_template.c:30-72: dst += residual without
+ * clipping (wraps like the reference's pixel type), block cleared afterwards ---------------------- */
+__global__ void __launch_bounds__(64) k_add_pixels(uint8_t *dst, int pitch, const int16_t *blk, int n)
+{
+    for (int i = lane_id(); i < n * n; i += 64) {
+        const int y = i / n, x = i - y * n;
+        dst[y * pitch + x] = (uint8_t)(dst[y * pitch + x] + blk[i]);
+    }
+}
+template <int N> static void add_pixels_clear_shim(uint8_t *dst, int16_t *block, int stride)
+{
+    Arena &a = arena();
+    Win w = win_pack(a, dst, stride, N, N);
+    const size_t b = a.take(N * N * 2);
+    std::memcpy(a.h<int16_t>(b), block, N * N * 2);
+    a.upload();
+    LAUNCH1(k_add_pixels, a, a.d<uint8_t>(w.off), w.pitch, a.d<const int16_t>(b), N);
+    a.download();
+    win_unpack(a, w, dst, stride, 0, 0, N, N);
+    std::memset(block, 0, N * N * 2);
+}
+
 void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int chroma_format_idc)
 {
     /* like an arch hook: only the variants this backend implements are overridden
@@ -440,6 +462,8 @@ void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int ch
     c->h264_idct8_add4 = t1_idct8_add4;
     c->h264_idct_add16intra = t1_idct_add16intra;
     c->h264_luma_dc_dequant_idct = t1_luma_dc_dequant_idct;
+    c->h264_add_pixels4_clear = add_pixels_clear_shim<4>;
+    c->h264_add_pixels8_clear = add_pixels_clear_shim<8>;
     if (chroma_format_idc <= 1) {
         c->h264_h_loop_filter_chroma = t1_h_lf_chroma;
         c->h264_h_loop_filter_chroma_mbaff = t1_h_lf_chroma_mbaff;

@@ -4,7 +4,7 @@ import pytest
 
 import cases_h264
 
-EXPECT_MISSING = {"addpx", "startcode"}   # table slots the backend leaves at the C default
+EXPECT_MISSING = {"startcode"}   # table slots the backend leaves at the C default
 
 
 @pytest.mark.parametrize("group", list(cases_h264.GROUPS))

@@ -12,7 +12,7 @@ import cases_h264
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "h264dsp_ref_sha1.json")
-EXPECT_MISSING = {"addpx", "startcode"}
+EXPECT_MISSING = {"startcode"}
 
 
 @pytest.mark.parametrize("group", list(cases_h264.GROUPS))
