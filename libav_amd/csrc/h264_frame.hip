@@ -432,17 +432,29 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
 /* One wavefront deblocks a band of four macroblock rows of one picture, walking left to right:
  * lanes 16g..16g+15 own row 4*band+g and at step t work on macroblock x = t - 2g, so the
  * reference's raster dependencies (left, top, top-right: h264_slice.c:2198) are met by lock-step
- * execution inside the wave — no flags, no per-diagonal launches.  A lane holds one luma ROW (4 samples
- * of the left neighbour carried over from the previous step + 16) and one chroma row in registers for
- * the vertical edges; the tile then turns through LDS and the lane holds one COLUMN for the
- * horizontal edges.  Consecutive steps read and write consecutive 16-byte pieces of the same cache
- * lines, and everything that does not depend on the previous step is fetched one step ahead. */
+ * execution inside the wave — no flags, no per-diagonal launches.
+ *
+ * Samples move between HBM and LDS in CHUNKS of eight macroblocks per row (128-byte luma / 64-byte
+ * chroma row pieces, adjacent lanes on adjacent addresses): group g's chunk c covers macroblocks
+ * 8c-2g .. 8c-2g+7, so all four groups change chunk at the same step.  A chunk is loaded from `recon`
+ * when its first macroblock comes up, filtered in place in the LDS tile, and written to `dst` one
+ * step after its last macroblock (by then the next macroblock's left edge has patched its last
+ * columns).  Rows above a group's macroblock come from the tile of the group above (same wave, two
+ * steps ahead) or, for the band's first row, from `dst` as the previous band left it; a group does
+ * not write the bottom three rows that the group below will still filter and write itself.
+ * Per-step global traffic is only records and vectors; the L1 sees ~15 sample requests per
+ * macroblock instead of ~130 sixteen-byte ones.
+ *
+ * Inside a step a lane holds one luma ROW (4 samples of the left neighbour + 16) and one chroma row
+ * in registers for the vertical edges; then the tile is read by COLUMN for the horizontal edges. */
+constexpr int DY_PITCH = 144;     /* 128 + 16: rows of a 16-lane b128 access spread over all banks */
+constexpr int DC_PITCH = 72;
 struct DeblockLds {
     mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
     uint32_t mv[4][2][2][16];     /* [t&1][list]: this MB's vectors; the other parity is the left neighbour */
     uint32_t mvt[4][2][4];        /* [list]: bottom row of the top neighbour */
-    uint8_t y[4][20][16];         /* rows -4..15 of the MB's 16 columns */
-    uint8_t c[4][2][10][8];       /* rows -2..7 */
+    uint8_t y[4][2][20][DY_PITCH];      /* [group][chunk parity]: rows -4..15 of eight macroblocks */
+    uint8_t c[4][2][2][10][DC_PITCH];   /* [group][chunk parity][plane]: rows -2..7 */
     uint8_t bs[4][2][4][4];       /* [dir][segment][edge]: the 4 edges of a line are one dword */
     /* alpha / beta / tc0 tables: a copy in LDS turns the dependent per-edge lookups (qp -> index ->
      * alpha, beta -> tc0[bS]) from global-memory gathers into LDS reads */
@@ -557,36 +569,27 @@ __device__ __forceinline__ void chroma_edge(int *v, int bs, const EdgeParm &e)
 __device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
 __device__ __forceinline__ void unpack4(uint32_t w, int *v) { v[0] = w & 0xFF; v[1] = (w >> 8) & 0xFF; v[2] = (w >> 16) & 0xFF; v[3] = w >> 24; }
 
-/* what a lane fetches for one macroblock ahead of time: nothing here is written by the filter */
+/* what a lane fetches for one macroblock ahead of time (records and vectors: never written by the filter) */
 struct DeblockPre {
-    uint32_t hw, hw_top, y[4], c[2], mv[2], mvt[2];
+    uint32_t hw, hw_top, mv[2], mvt[2];
 };
-/* per-lane addresses of macroblock x = -2g of the lane's row; every step adds one macroblock */
 struct DeblockPtr {
-    const uint8_t *ry, *rc;              /* this lane's luma / chroma row in `recon` */
-    uint8_t *dy, *dc;                    /* the same rows in `dst` */
-    uint8_t *ty, *tc;                    /* the dword of the rows above this lane loads (luma -4.., chroma -2..) */
-    const uint32_t *rec;                 /* dword l of the record */
-    const uint32_t *mv[2];               /* vector l of the MB, per list (null when the list is absent) */
+    const uint32_t *rec;                 /* dword l of the record of macroblock x = -2g of the lane's row */
+    const uint32_t *mv[2];               /* vector l of that MB, per list (null when the list is absent) */
     ptrdiff_t rec_top, mv_top;           /* distance (in dwords) to the top neighbour's record / bottom-row vector */
     __device__ __forceinline__ void advance()
     {
-        ry += 16; rc += 8; dy += 16; dc += 8; ty += 16; tc += 8; rec += 16;
+        rec += 16;
         if (mv[0]) mv[0] += 16;
         if (mv[1]) mv[1] += 16;
     }
 };
-__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr &a, bool ok, bool has_t, int l, bool al16)
+__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr &a, bool ok, bool has_t, int l)
 {
-    p.hw = p.hw_top = p.y[0] = p.y[1] = p.y[2] = p.y[3] = p.c[0] = p.c[1] = p.mv[0] = p.mv[1] = p.mvt[0] = p.mvt[1] = 0;
+    p.hw = p.hw_top = p.mv[0] = p.mv[1] = p.mvt[0] = p.mvt[1] = 0;
     if (!ok) return;
     p.hw = a.rec[0];
     if (has_t) p.hw_top = a.rec[a.rec_top];
-    /* one 16-byte / 8-byte access per row where alignment allows */
-    if (al16) { const uint4 v = *reinterpret_cast<const uint4 *>(a.ry); p.y[0] = v.x; p.y[1] = v.y; p.y[2] = v.z; p.y[3] = v.w; }
-    else { const uint32_t *w = reinterpret_cast<const uint32_t *>(a.ry); p.y[0] = w[0]; p.y[1] = w[1]; p.y[2] = w[2]; p.y[3] = w[3]; }
-    if (al16) { const uint2 v = *reinterpret_cast<const uint2 *>(a.rc); p.c[0] = v.x; p.c[1] = v.y; }
-    else { const uint32_t *w = reinterpret_cast<const uint32_t *>(a.rc); p.c[0] = w[0]; p.c[1] = w[1]; }
 #pragma unroll
     for (int li = 0; li < 2; li++) {
         if (!a.mv[li]) continue;
@@ -594,7 +597,31 @@ __device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr
         if (l < 4 && has_t) p.mvt[li] = a.mv[li][a.mv_top];
     }
 }
-
+/* 16 / 8 bytes between a picture row and an LDS tile row */
+__device__ __forceinline__ uint4 ld16(const uint8_t *p, bool al)
+{
+    if (al) return *reinterpret_cast<const uint4 *>(p);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void st16(uint8_t *p, uint4 v, bool al)
+{
+    if (al) { *reinterpret_cast<uint4 *>(p) = v; return; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+__device__ __forceinline__ uint2 ld8(const uint8_t *p, bool al)
+{
+    if (al) return *reinterpret_cast<const uint2 *>(p);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return make_uint2(w[0], w[1]);
+}
+__device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
+{
+    if (al) { *reinterpret_cast<uint2 *>(p) = v; return; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    w[0] = v.x; w[1] = v.y;
+}
 
 __global__ void __launch_bounds__(64)
 k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
@@ -609,10 +636,12 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     const int list_count = fr.mv[1] ? 2 : 1;                 /* sl->list_count == 2 exactly when list-1 vectors exist */
     const int nsteps = W + 6;
     const bool has_t = row_ok && mb_y > 0;
-    /* 16-byte rows (luma) / 8-byte rows (chroma) can move as one access when pointers and strides allow */
-    const bool al16 = ((reinterpret_cast<uintptr_t>(fr.recon[0]) | reinterpret_cast<uintptr_t>(fr.dst[0]) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(fr.recon[1]) | reinterpret_cast<uintptr_t>(fr.recon[2]) | reinterpret_cast<uintptr_t>(fr.dst[1]) |
-                        reinterpret_cast<uintptr_t>(fr.dst[2]) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
+    /* the group below (same wave) filters and writes this row's bottom three luma rows / last chroma row */
+    const bool below = g < 3 && mb_y + 1 < fr.mb_height;
+    /* 16-byte (luma) / 8-byte (chroma) pieces can move as one access when pointers and strides allow */
+    const bool al16 = ((reinterpret_cast<uintptr_t>(fr.recon[0]) | reinterpret_cast<uintptr_t>(fr.dst[0]) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
+    const bool al8 = ((reinterpret_cast<uintptr_t>(fr.recon[1]) | reinterpret_cast<uintptr_t>(fr.recon[2]) | reinterpret_cast<uintptr_t>(fr.dst[1]) |
+                       reinterpret_cast<uintptr_t>(fr.dst[2]) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
     if (lane < 52) {
         s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
         s.t_tc0[lane][0] = k_tc0[lane][0]; s.t_tc0[lane][1] = k_tc0[lane][1]; s.t_tc0[lane][2] = k_tc0[lane][2]; s.t_tc0[lane][3] = 0;
@@ -621,46 +650,106 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     {
         const ptrdiff_t x0 = -2 * g;                         /* macroblock column of step 0 (may be negative: never dereferenced then) */
         const ptrdiff_t yy = row_ok ? mb_y : 0;
-        a.ry = fr.recon[0] + (yy * 16 + l) * rs + x0 * 16;
-        a.rc = fr.recon[1 + cp] + (yy * 8 + cr) * rcs + x0 * 8;
-        a.dy = fr.dst[0] + (yy * 16 + l) * ds + x0 * 16;
-        a.dc = fr.dst[1 + cp] + (yy * 8 + cr) * dcs + x0 * 8;
-        a.ty = fr.dst[0] + (yy * 16 + (l >> 2) - 4) * ds + x0 * 16 + 4 * (l & 3);
-        a.tc = fr.dst[1 + ((l >> 2) & 1)] + (yy * 8 + ((l >> 1) & 1) - 2) * dcs + x0 * 8 + 4 * (l & 1);
         const ptrdiff_t xy0 = yy * W + x0;
         a.rec = reinterpret_cast<const uint32_t *>(fr.mb) + xy0 * 16 + l;
         a.rec_top = -(ptrdiff_t)W * 16;
         for (int li = 0; li < 2; li++) a.mv[li] = fr.mv[li] ? reinterpret_cast<const uint32_t *>(fr.mv[li]) + xy0 * 16 + l : nullptr;
         a.mv_top = -(ptrdiff_t)W * 16 + 12;
     }
+    /* chunk I/O roles of a lane: piece p of a row pair */
+    const int io_p = l & 7, io_r = l >> 3;
+    const uint8_t *const recon_y = fr.recon[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
+    uint8_t *const dst_y = fr.dst[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
+
+    /* load chunk c (macroblocks 8c-2g ..+7) of this group's row into tile parity c & 1 */
+    auto load_chunk = [&](int c) {
+        const int x = 8 * c - 2 * g + io_p, b = c & 1;
+        const bool ok = row_ok && x >= 0 && x < W;
+        uint4 vy[8], ty[2];
+        uint2 vc[8], tc[2];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = 2 * it + io_r;
+            vy[it] = ok ? ld16(recon_y + (ptrdiff_t)row * rs + x * 16, al16) : make_uint4(0, 0, 0, 0);
+            const int plane = it >> 2, crow = 2 * (it & 3) + io_r;
+            vc[it] = ok ? ld8(fr.recon[1 + plane] + (ptrdiff_t)(mb_y * 8 + crow) * rcs + x * 8, al8) : make_uint2(0, 0);
+        }
+        const bool okt = ok && g == 0 && has_t;              /* rows above the band: as the previous band left them */
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            ty[it] = okt ? ld16(dst_y + (ptrdiff_t)(2 * it + io_r - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
+            tc[it] = okt ? ld8(fr.dst[1 + it] + (ptrdiff_t)(mb_y * 8 + io_r - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            *reinterpret_cast<uint4 *>(&s.y[g][b][4 + 2 * it + io_r][16 * io_p]) = vy[it];
+            *reinterpret_cast<uint2 *>(&s.c[g][b][it >> 2][2 + 2 * (it & 3) + io_r][8 * io_p]) = vc[it];
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                *reinterpret_cast<uint4 *>(&s.y[g][b][2 * it + io_r][16 * io_p]) = ty[it];
+                *reinterpret_cast<uint2 *>(&s.c[g][b][it][io_r][8 * io_p]) = tc[it];
+            }
+        }
+    };
+    /* write chunk c back to `dst` */
+    auto flush_chunk = [&](int c) {
+        const int x = 8 * c - 2 * g + io_p, b = c & 1;
+        const bool ok = row_ok && x >= 0 && x < W;
+        const int y_first = has_t ? 1 : 4, y_last = below ? 16 : 19;      /* tile rows: -3.. / 0..  up to 12 / 15 */
+        const int c_first = has_t ? 1 : 2, c_last = below ? 8 : 9;
+#pragma unroll
+        for (int it = 0; it < 10; it++) {
+            const int row = 2 * it + io_r;
+            if (ok && row >= y_first && row <= y_last)
+                st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, *reinterpret_cast<const uint4 *>(&s.y[g][b][row][16 * io_p]), al16);
+        }
+#pragma unroll
+        for (int it = 0; it < 10; it++) {
+            const int plane = it >= 5, row = 2 * (it - 5 * plane) + io_r;
+            if (ok && row >= c_first && row <= c_last)
+                st8(fr.dst[1 + plane] + (ptrdiff_t)(mb_y * 8 + row - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][row][8 * io_p]), al8);
+        }
+    };
+
     DeblockPre pre;
-    deblock_prefetch(pre, a, row_ok && g == 0, has_t, l, al16);
-    uint32_t left_y = 0, left_c = 0;                         /* columns 12..15 / 6..7 of the previous MB, final */
+    deblock_prefetch(pre, a, row_ok && g == 0, has_t, l);
+    int flushed = 0;                                         /* chunks already written back */
 #ifdef MI355_PROF
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     for (int t = 0; t < nsteps; t++) {
         PROF_MARK(7);
         const int mb_x = t - 2 * g, par = t & 1;
+        const int ck = t >> 3, j = t & 7, b = ck & 1;        /* chunk, position in it, tile parity */
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
         const bool has_l = valid && mb_x > 0;
         const DeblockPre cur = pre;
-        const DeblockPtr at = a;                             /* addresses of this step's macroblock */
-        /* ---- phase A: this step's rows above (written one step ago at the latest, by this wave), then the
-         * next step's static data (vmcnt retires in order: the older request is the one waited for first) */
-        uint32_t top_y = 0, top_c = 0;
-        if (valid && has_t) {
-            top_y = *reinterpret_cast<const uint32_t *>(at.ty);
-            if (l < 8) top_c = *reinterpret_cast<const uint32_t *>(at.tc);
+        /* ---- chunk turnover ---------------------------------------------------------------------- */
+        if (j == 1 && ck >= 1) {                             /* the previous chunk got its last left-edge patch in step t-1 */
+            flush_chunk(ck - 1);
+            flushed = ck;
         }
+        if (j == 0) load_chunk(ck);
+        /* ---- phase A: next step's records and vectors ---------------------------------------------- */
         a.advance();
-        deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l, al16);
-        /* ---- phase B: records and vectors -> LDS ------------------------------------------------- */
+        deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l);
+        /* ---- phase B: records and vectors -> LDS; rows above from the group above ------------------ */
         reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
         reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
         s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
         if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
-        MI355_WAVE_SYNC();
+        MI355_WAVE_SYNC();                                   /* also: the chunk load above is visible */
+        if (g > 0 && valid) {
+            /* macroblock x of the row above sits at position (t-2) & 7 of that group's chunk (t-2) >> 3 */
+            const int jb = (t - 2) & 7, bb = ((t - 2) >> 3) & 1;
+            *reinterpret_cast<uint32_t *>(&s.y[g][b][l >> 2][16 * j + 4 * (l & 3)]) =
+                *reinterpret_cast<const uint32_t *>(&s.y[g - 1][bb][16 + (l >> 2)][16 * jb + 4 * (l & 3)]);
+            if (l < 8)
+                *reinterpret_cast<uint32_t *>(&s.c[g][b][l >> 2][(l >> 1) & 1][8 * j + 4 * (l & 1)]) =
+                    *reinterpret_cast<const uint32_t *>(&s.c[g - 1][bb][l >> 2][8 + ((l >> 1) & 1)][8 * jb + 4 * (l & 1)]);
+        }
         PROF_MARK(0);
 
         /* ---- phase C: boundary strengths: lane (edge = l >> 2, segment = l & 3), both directions.  All LDS
@@ -705,42 +794,46 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         ch[0] = edge_parm(s, (qpc_h + qpc_t + 1) >> 1, h, bsc1 & 0xFF); ch[1] = edge_parm(s, qpc_h, h, (bsc1 >> 16) & 0xFF);
         const bool intra_v = __any(((bsw0 & 0xFF) == 4)) != 0, intra_h = __any(((bsw1 & 0xFF) == 4)) != 0;
 
-        /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers ------- */
+        /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers.  The four
+         * samples left of the MB are the previous MB's last columns (previous chunk when j == 0). ----- */
         {
+            uint8_t *rowp = &s.y[g][b][4 + l][16 * j];
+            uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * 7 + 12];
+            const uint4 own = *reinterpret_cast<const uint4 *>(rowp);
+            const uint32_t left_y = *reinterpret_cast<const uint32_t *>(leftp);
             int px[20];
             unpack4(left_y, px);
-#pragma unroll
-            for (int k = 0; k < 4; k++) unpack4(cur.y[k], px + 4 + 4 * k);
+            unpack4(own.x, px + 4); unpack4(own.y, px + 8); unpack4(own.z, px + 12); unpack4(own.w, px + 16);
             luma_edge(px, bsw0 & 0xFF, ev[0], intra_v);
 #pragma unroll
             for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw0 >> (8 * e)) & 0xFF, ev[e], false);   /* inner edges: bS <= 3 */
-            uint32_t *row = reinterpret_cast<uint32_t *>(s.y[g][4 + l]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) row[k] = pack4(px + 4 + 4 * k);
-            if (have_left) *reinterpret_cast<uint32_t *>(at.dy - 4) = pack4(px);
+            if (bsw0) *reinterpret_cast<uint4 *>(rowp) = make_uint4(pack4(px + 4), pack4(px + 8), pack4(px + 12), pack4(px + 16));
+            if (have_left) *reinterpret_cast<uint32_t *>(leftp) = pack4(px);
 
+            uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
+            uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * 7 + 4];
+            const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
+            const uint32_t left_c = *reinterpret_cast<const uint32_t *>(cleftp);      /* columns -4..-1 */
             int cx[10];
-            cx[0] = left_c & 0xFF; cx[1] = (left_c >> 8) & 0xFF;
-            unpack4(cur.c[0], cx + 2); unpack4(cur.c[1], cx + 6);
+            cx[0] = (left_c >> 16) & 0xFF; cx[1] = left_c >> 24;
+            unpack4(cown.x, cx + 2); unpack4(cown.y, cx + 6);
             chroma_edge(cx + 0, bsc0 & 0xFF, cv[0]);
             chroma_edge(cx + 4, (bsc0 >> 16) & 0xFF, cv[1]);
-            uint32_t *crow = reinterpret_cast<uint32_t *>(s.c[g][cp][2 + cr]);
-            crow[0] = pack4(cx + 2); crow[1] = pack4(cx + 6);
-            if (have_left) *reinterpret_cast<uint16_t *>(at.dc - 2) = (uint16_t)(cx[0] | (cx[1] << 8));
-            PROF_MARK(2);
-            /* the rows above, fetched in phase A */
-            *reinterpret_cast<uint32_t *>(&s.y[g][l >> 2][4 * (l & 3)]) = top_y;
-            if (l < 8) *reinterpret_cast<uint32_t *>(&s.c[g][l >> 2][(l >> 1) & 1][4 * (l & 1)]) = top_c;
+            if (bsc0 & 0x00FF00FF) *reinterpret_cast<uint2 *>(crowp) = make_uint2(pack4(cx + 2), pack4(cx + 6));
+            if (have_left) *reinterpret_cast<uint32_t *>(cleftp) = (left_c & 0x0000FFFFu) | ((uint32_t)cx[0] << 16) | ((uint32_t)cx[1] << 24);
         }
+        PROF_MARK(2);
         MI355_WAVE_SYNC();
         PROF_MARK(3);
         /* ---- phase D1: horizontal edges, one luma column + one chroma column per lane ------------- */
         {
             int py[20], cy[10];
+            uint8_t *colp = &s.y[g][b][0][16 * j + l];
+            uint8_t *ccolp = &s.c[g][b][cp][0][8 * j + cr];
 #pragma unroll
-            for (int k = 0; k < 20; k++) py[k] = s.y[g][k][l];
+            for (int k = 0; k < 20; k++) py[k] = colp[k * DY_PITCH];
 #pragma unroll
-            for (int k = 0; k < 10; k++) cy[k] = s.c[g][cp][k][cr];
+            for (int k = 0; k < 10; k++) cy[k] = ccolp[k * DC_PITCH];
             luma_edge(py, bsw1 & 0xFF, eh[0], intra_h);
 #pragma unroll
             for (int e = 1; e < 4; e++) luma_edge(py + 4 * e, (bsw1 >> (8 * e)) & 0xFF, eh[e], false);
@@ -748,44 +841,19 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             chroma_edge(cy + 4, (bsc1 >> 16) & 0xFF, ch[1]);
             if (bsw1) {
 #pragma unroll
-                for (int k = 1; k < 19; k++) s.y[g][k][l] = (uint8_t)py[k];
+                for (int k = 1; k < 19; k++) colp[k * DY_PITCH] = (uint8_t)py[k];
             }
             if (bsc1 & 0x00FF00FF) {
 #pragma unroll
-                for (int k = 1; k < 9; k++) s.c[g][cp][k][cr] = (uint8_t)cy[k];
+                for (int k = 1; k < 9; k++) ccolp[k * DC_PITCH] = (uint8_t)cy[k];
             }
         }
-        MI355_WAVE_SYNC();
         PROF_MARK(4);
-        /* ---- phase E: the MB, the rows above that its top edge may have changed; carry the right-most
-         * columns to the next step --------------------------------------------------------------- */
-        {
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(s.y[g][4 + l]);
-            const uint32_t *crow = reinterpret_cast<const uint32_t *>(s.c[g][cp][2 + cr]);
-            const uint32_t r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], c0 = crow[0], c1 = crow[1];
-            const uint32_t tyw = *reinterpret_cast<const uint32_t *>(&s.y[g][1 + (l >> 2) % 3][4 * (l & 3)]);
-            const uint32_t tcw = *reinterpret_cast<const uint32_t *>(&s.c[g][(l >> 1) & 1][1][4 * (l & 1)]);
-            if (valid) {
-                if (al16) {
-                    *reinterpret_cast<uint4 *>(at.dy) = make_uint4(r0, r1, r2, r3);
-                    *reinterpret_cast<uint2 *>(at.dc) = make_uint2(c0, c1);
-                } else {
-                    uint32_t *o = reinterpret_cast<uint32_t *>(at.dy);
-                    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
-                    uint32_t *oc = reinterpret_cast<uint32_t *>(at.dc);
-                    oc[0] = c0; oc[1] = c1;
-                }
-                if (have_top) {
-                    /* luma rows -3..-1 are one row below the ones lanes 0..11 loaded; chroma row -1 */
-                    if (l < 12) *reinterpret_cast<uint32_t *>(at.ty + ds) = tyw;
-                    else *reinterpret_cast<uint32_t *>(fr.dst[1 + ((l >> 1) & 1)] + (size_t)(mb_y * 8 - 1) * dcs + mb_x * 8 + 4 * (l & 1)) = tcw;
-                }
-            }
-            left_y = r3; left_c = c1 >> 16;
-        }
+        MI355_WAVE_SYNC();   /* the tile is final for this macroblock: the group below and the next step may read it */
         PROF_MARK(5);
-        MI355_WAVE_SYNC();   /* stores of this step are visible to the wave's next step; LDS may be reused */
     }
+    /* chunks still in LDS */
+    for (int c = flushed; c <= (nsteps - 1) >> 3; c++) flush_chunk(c);
 }
 
 }  // namespace
