@@ -434,9 +434,9 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
  * reference's raster dependencies (left, top, top-right: h264_slice.c:2198) are met by lock-step
  * execution inside the wave — no flags, no per-diagonal launches.
  *
- * Samples move between HBM and LDS in CHUNKS of eight macroblocks per row (128-byte luma / 64-byte
+ * Samples move between HBM and LDS in CHUNKS of DCH macroblocks per row (16*DCH-byte luma / 8*DCH-byte
  * chroma row pieces, adjacent lanes on adjacent addresses): group g's chunk c covers macroblocks
- * 8c-2g .. 8c-2g+7, so all four groups change chunk at the same step.  A chunk is loaded from `recon`
+ * DCH*c-2g .. DCH*c-2g+DCH-1, so all four groups change chunk at the same step.  A chunk is loaded from `recon`
  * when its first macroblock comes up, filtered in place in the LDS tile, and written to `dst` one
  * step after its last macroblock (by then the next macroblock's left edge has patched its last
  * columns).  Rows above a group's macroblock come from the tile of the group above (same wave, two
@@ -447,8 +447,10 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
  *
  * Inside a step a lane holds one luma ROW (4 samples of the left neighbour + 16) and one chroma row
  * in registers for the vertical edges; then the tile is read by COLUMN for the horizontal edges. */
-constexpr int DY_PITCH = 144;     /* 128 + 16: rows of a 16-lane b128 access spread over all banks */
-constexpr int DC_PITCH = 72;
+constexpr int DCH_LOG = 3, DCH = 1 << DCH_LOG;    /* macroblocks per chunk */
+constexpr int DY_PITCH = 16 * DCH + 16;           /* + 16: rows of a 16-lane b128 access spread over all banks */
+constexpr int DC_PITCH = 8 * DCH + 8;
+constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
 struct DeblockLds {
     mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
     uint32_t mv[4][2][2][16];     /* [t&1][list]: this MB's vectors; the other parity is the left neighbour */
@@ -520,11 +522,6 @@ __device__ __forceinline__ int bs_flat(const MbInfo &h, const MbInfo &nb, bool h
 struct EdgeParm {
     int alpha, beta, tc0;
 };
-__device__ __forceinline__ EdgeParm edge_parm(const DeblockLds &s, int qp, const MbInfo &h, int bs)
-{
-    const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
-    return EdgeParm{ s.t_alpha[ia], s.t_beta[ib], s.t_tc0[ia][(bs - 1) & 3] };
-}
 /* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3.  bS 1..3: h264_loop_filter_luma (h264dsp_template.c:104-150) as
  * selects; bS 4 (h264_loop_filter_luma_intra :165-210) only where a lane of the wave has it */
 __device__ __forceinline__ void luma_edge(int *v, int bs, const EdgeParm &e, bool wave_has_intra)
@@ -657,59 +654,63 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         a.mv_top = -(ptrdiff_t)W * 16 + 12;
     }
     /* chunk I/O roles of a lane: piece p of a row pair */
-    const int io_p = l & 7, io_r = l >> 3;
+    const int io_p = l & (DCH - 1), io_r = l >> DCH_LOG;
     const uint8_t *const recon_y = fr.recon[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
     uint8_t *const dst_y = fr.dst[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
 
     /* load chunk c (macroblocks 8c-2g ..+7) of this group's row into tile parity c & 1 */
     auto load_chunk = [&](int c) {
-        const int x = 8 * c - 2 * g + io_p, b = c & 1;
+        const int x = DCH * c - 2 * g + io_p, b = c & 1;
         const bool ok = row_ok && x >= 0 && x < W;
-        uint4 vy[8], ty[2];
-        uint2 vc[8], tc[2];
+        constexpr int NY = 16 / DIO_ROWS, NT = (4 + DIO_ROWS - 1) / DIO_ROWS;   /* accesses for 16 rows / for the 4 rows above */
+        uint4 vy[NY], ty[NT];
+        uint2 vc[NY], tc[NT];
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int row = 2 * it + io_r;
+        for (int it = 0; it < NY; it++) {
+            const int row = DIO_ROWS * it + io_r;            /* luma row; as chroma: plane = row >> 3, row & 7 */
             vy[it] = ok ? ld16(recon_y + (ptrdiff_t)row * rs + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            const int plane = it >> 2, crow = 2 * (it & 3) + io_r;
-            vc[it] = ok ? ld8(fr.recon[1 + plane] + (ptrdiff_t)(mb_y * 8 + crow) * rcs + x * 8, al8) : make_uint2(0, 0);
+            vc[it] = ok ? ld8(fr.recon[1 + (row >> 3)] + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
         }
         const bool okt = ok && g == 0 && has_t;              /* rows above the band: as the previous band left them */
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            ty[it] = okt ? ld16(dst_y + (ptrdiff_t)(2 * it + io_r - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            tc[it] = okt ? ld8(fr.dst[1 + it] + (ptrdiff_t)(mb_y * 8 + io_r - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
+        for (int it = 0; it < NT; it++) {
+            const int row = DIO_ROWS * it + io_r;            /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
+            const bool in = okt && row < 4;
+            ty[it] = in ? ld16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
+            tc[it] = in ? ld8(fr.dst[1 + ((row >> 1) & 1)] + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
         }
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            *reinterpret_cast<uint4 *>(&s.y[g][b][4 + 2 * it + io_r][16 * io_p]) = vy[it];
-            *reinterpret_cast<uint2 *>(&s.c[g][b][it >> 2][2 + 2 * (it & 3) + io_r][8 * io_p]) = vc[it];
+        for (int it = 0; it < NY; it++) {
+            const int row = DIO_ROWS * it + io_r;
+            *reinterpret_cast<uint4 *>(&s.y[g][b][4 + row][16 * io_p]) = vy[it];
+            *reinterpret_cast<uint2 *>(&s.c[g][b][row >> 3][2 + (row & 7)][8 * io_p]) = vc[it];
         }
         if (g == 0) {
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
-                *reinterpret_cast<uint4 *>(&s.y[g][b][2 * it + io_r][16 * io_p]) = ty[it];
-                *reinterpret_cast<uint2 *>(&s.c[g][b][it][io_r][8 * io_p]) = tc[it];
+            for (int it = 0; it < NT; it++) {
+                const int row = DIO_ROWS * it + io_r;
+                if (row < 4) {
+                    *reinterpret_cast<uint4 *>(&s.y[g][b][row][16 * io_p]) = ty[it];
+                    *reinterpret_cast<uint2 *>(&s.c[g][b][row >> 1][row & 1][8 * io_p]) = tc[it];
+                }
             }
         }
     };
     /* write chunk c back to `dst` */
     auto flush_chunk = [&](int c) {
-        const int x = 8 * c - 2 * g + io_p, b = c & 1;
+        const int x = DCH * c - 2 * g + io_p, b = c & 1;
         const bool ok = row_ok && x >= 0 && x < W;
         const int y_first = has_t ? 1 : 4, y_last = below ? 16 : 19;      /* tile rows: -3.. / 0..  up to 12 / 15 */
         const int c_first = has_t ? 1 : 2, c_last = below ? 8 : 9;
+        constexpr int NF = 20 / DIO_ROWS;                    /* 20 luma tile rows; 2 x 10 chroma tile rows */
 #pragma unroll
-        for (int it = 0; it < 10; it++) {
-            const int row = 2 * it + io_r;
+        for (int it = 0; it < NF; it++) {
+            const int row = DIO_ROWS * it + io_r;
             if (ok && row >= y_first && row <= y_last)
                 st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, *reinterpret_cast<const uint4 *>(&s.y[g][b][row][16 * io_p]), al16);
-        }
-#pragma unroll
-        for (int it = 0; it < 10; it++) {
-            const int plane = it >= 5, row = 2 * (it - 5 * plane) + io_r;
-            if (ok && row >= c_first && row <= c_last)
-                st8(fr.dst[1 + plane] + (ptrdiff_t)(mb_y * 8 + row - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][row][8 * io_p]), al8);
+            const int plane = row >= 10, crow = row - 10 * plane;
+            if (ok && crow >= c_first && crow <= c_last)
+                st8(fr.dst[1 + plane] + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
         }
     };
 
@@ -722,7 +723,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     for (int t = 0; t < nsteps; t++) {
         PROF_MARK(7);
         const int mb_x = t - 2 * g, par = t & 1;
-        const int ck = t >> 3, j = t & 7, b = ck & 1;        /* chunk, position in it, tile parity */
+        const int ck = t >> DCH_LOG, j = t & (DCH - 1), b = ck & 1;   /* chunk, position in it, tile parity */
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
         const bool has_l = valid && mb_x > 0;
         const DeblockPre cur = pre;
@@ -742,8 +743,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
         MI355_WAVE_SYNC();                                   /* also: the chunk load above is visible */
         if (g > 0 && valid) {
-            /* macroblock x of the row above sits at position (t-2) & 7 of that group's chunk (t-2) >> 3 */
-            const int jb = (t - 2) & 7, bb = ((t - 2) >> 3) & 1;
+            /* macroblock x of the row above sits at position (t-2) % DCH of that group's chunk (t-2) / DCH */
+            const int jb = (t - 2) & (DCH - 1), bb = ((t - 2) >> DCH_LOG) & 1;
             *reinterpret_cast<uint32_t *>(&s.y[g][b][l >> 2][16 * j + 4 * (l & 3)]) =
                 *reinterpret_cast<const uint32_t *>(&s.y[g - 1][bb][16 + (l >> 2)][16 * jb + 4 * (l & 3)]);
             if (l < 8)
@@ -760,8 +761,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         {
             const int edge = l >> 2, seg = l & 3, em1 = edge ? edge - 1 : 0;
             uint32_t mp0[2], mq0[2], mp1[2], mq1[2];
-#pragma unroll
-            for (int li = 0; li < 2; li++) {
+            mp0[1] = mq0[1] = mp1[1] = mq1[1] = 0;
+            for (int li = 0; li < list_count; li++) {
                 const uint32_t *own = s.mv[g][par][li];
                 const uint32_t in0 = own[em1 + 4 * seg], in1 = own[seg + 4 * em1];
                 const uint32_t out0 = s.mv[g][par ^ 1][li][3 + 4 * seg], out1 = s.mvt[g][li][seg];
@@ -783,22 +784,39 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const int qpc_l = hl.slice_id() == h.slice_id() ? hl.qpc(cp) : (have_left ? fr.slices[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0);
         const int qpc_t = ht.slice_id() == h.slice_id() ? ht.qpc(cp) : (have_top ? fr.slices[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0);
         EdgeParm ev[4], eh[4], cv[2], ch[2];
-        ev[0] = edge_parm(s, (h.qp() + hl.qp() + 1) >> 1, h, bsw0 & 0xFF);
-        eh[0] = edge_parm(s, (h.qp() + ht.qp() + 1) >> 1, h, bsw1 & 0xFF);
+        {
+            /* alpha / beta depend on the edge's QP only: six distinct QPs per lane (luma and chroma: inner
+             * edges, left edge, top edge); tc0 also on the line's bS */
+            const int oa = h.alpha_off(), ob = h.beta_off();
+            auto ab = [&](int qp, int &ia, int &alpha, int &beta) {
+                ia = clip3(qp + oa, 0, 51);
+                alpha = s.t_alpha[ia]; beta = s.t_beta[clip3(qp + ob, 0, 51)];
+            };
+            int ia_i, ia_l, ia_t, ic_i, ic_l, ic_t, al_i, al_l, al_t, be_i, be_l, be_t, cal_i, cal_l, cal_t, cbe_i, cbe_l, cbe_t;
+            ab(h.qp(), ia_i, al_i, be_i);
+            ab((h.qp() + hl.qp() + 1) >> 1, ia_l, al_l, be_l);
+            ab((h.qp() + ht.qp() + 1) >> 1, ia_t, al_t, be_t);
+            ab(qpc_h, ic_i, cal_i, cbe_i);
+            ab((qpc_h + qpc_l + 1) >> 1, ic_l, cal_l, cbe_l);
+            ab((qpc_h + qpc_t + 1) >> 1, ic_t, cal_t, cbe_t);
+            auto tc0 = [&](int ia, uint32_t bs) { return (int)s.t_tc0[ia][(bs - 1) & 3]; };
+            ev[0] = EdgeParm{ al_l, be_l, tc0(ia_l, bsw0 & 0xFF) };
+            eh[0] = EdgeParm{ al_t, be_t, tc0(ia_t, bsw1 & 0xFF) };
 #pragma unroll
-        for (int e = 1; e < 4; e++) {
-            ev[e] = edge_parm(s, h.qp(), h, (bsw0 >> (8 * e)) & 0xFF);
-            eh[e] = edge_parm(s, h.qp(), h, (bsw1 >> (8 * e)) & 0xFF);
+            for (int e = 1; e < 4; e++) {
+                ev[e] = EdgeParm{ al_i, be_i, tc0(ia_i, (bsw0 >> (8 * e)) & 0xFF) };
+                eh[e] = EdgeParm{ al_i, be_i, tc0(ia_i, (bsw1 >> (8 * e)) & 0xFF) };
+            }
+            cv[0] = EdgeParm{ cal_l, cbe_l, tc0(ic_l, bsc0 & 0xFF) }; cv[1] = EdgeParm{ cal_i, cbe_i, tc0(ic_i, (bsc0 >> 16) & 0xFF) };
+            ch[0] = EdgeParm{ cal_t, cbe_t, tc0(ic_t, bsc1 & 0xFF) }; ch[1] = EdgeParm{ cal_i, cbe_i, tc0(ic_i, (bsc1 >> 16) & 0xFF) };
         }
-        cv[0] = edge_parm(s, (qpc_h + qpc_l + 1) >> 1, h, bsc0 & 0xFF); cv[1] = edge_parm(s, qpc_h, h, (bsc0 >> 16) & 0xFF);
-        ch[0] = edge_parm(s, (qpc_h + qpc_t + 1) >> 1, h, bsc1 & 0xFF); ch[1] = edge_parm(s, qpc_h, h, (bsc1 >> 16) & 0xFF);
         const bool intra_v = __any(((bsw0 & 0xFF) == 4)) != 0, intra_h = __any(((bsw1 & 0xFF) == 4)) != 0;
 
         /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers.  The four
          * samples left of the MB are the previous MB's last columns (previous chunk when j == 0). ----- */
         {
             uint8_t *rowp = &s.y[g][b][4 + l][16 * j];
-            uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * 7 + 12];
+            uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * (DCH - 1) + 12];
             const uint4 own = *reinterpret_cast<const uint4 *>(rowp);
             const uint32_t left_y = *reinterpret_cast<const uint32_t *>(leftp);
             int px[20];
@@ -811,7 +829,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             if (have_left) *reinterpret_cast<uint32_t *>(leftp) = pack4(px);
 
             uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
-            uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * 7 + 4];
+            uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * (DCH - 1) + 4];
             const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
             const uint32_t left_c = *reinterpret_cast<const uint32_t *>(cleftp);      /* columns -4..-1 */
             int cx[10];
@@ -853,7 +871,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         PROF_MARK(5);
     }
     /* chunks still in LDS */
-    for (int c = flushed; c <= (nsteps - 1) >> 3; c++) flush_chunk(c);
+    for (int c = flushed; c <= (nsteps - 1) >> DCH_LOG; c++) flush_chunk(c);
 }
 
 }  // namespace
