@@ -31,6 +31,18 @@ B_FUSED = B_RECON + B_DEBLOCK            # 2432 B/MB: the two-surface pipeline f
 HBM_PEAK = 8.0e12
 
 
+def measured_traffic(kernel, frames):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            if t.get("frames_per_gpu") == frames and kernel in t.get("kernels", {}):
+                return t["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +164,9 @@ def main():
                          "launches_per_step": launches, "avg_launch_us": t_pass / launches * 1e3,
                          "algorithmic_bytes_per_launch": bytes_pass / launches},
         }
+        # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
+        # (tools/gpu_traffic.sh -> profiles/*hbm_traffic*.json; cannot be collected from inside this process)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, F)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fs, args.cpu_seconds)
         print(json.dumps(out))

@@ -19,6 +19,10 @@ CASES = {
     "one_mb":           dict(nframes=3, mb_w=1, mb_h=1, seed=19, mix="mixed", intra_frac=0.3),
     "one_row":          dict(nframes=1, mb_w=9, mb_h=1, seed=20, mix="mixed", intra_frac=0.3, refs="smooth"),
     "one_col":          dict(nframes=1, mb_w=1, mb_h=7, seed=21, mix="mixed", intra_frac=0.3, refs="smooth"),
+    # several 8-MB chunks and 4-row bands with remainders on both axes, slices switching deblocking off / offsets
+    "wide_mixed":       dict(nframes=2, mb_w=37, mb_h=9, seed=22, mix="mixed", intra_frac=0.15, dct8_frac=0.3, refs="smooth",
+                             coef_b=8, offsets=True),
+    "wide_b":           dict(nframes=1, mb_w=19, mb_h=6, seed=23, mix="mixed", bframes=True, intra_frac=0.1, refs="smooth", coef_b=6),
 }
 
 

@@ -23,3 +23,21 @@ def test_frame_pipeline_gpu_is_deterministic(mi355):
         d.free()
     for p in range(3):
         assert np.array_equal(outs[0][p], outs[1][p])
+
+
+def test_full_size_1080p_batch_matches_oracle(mi355, oracle):
+    """BASELINE.json config 2 at its real size: three 1080p P pictures (the bench generator: 16x16
+    partitions, random quarter-pel vectors over 4 references, ~50 % coded blocks, 5 % Intra16x16),
+    bit-exact against the oracle on every sample of both surfaces."""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x264, lib=mi355.lib)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
+    assert sum(int((a != b).sum()) for a, b in zip(dst_o, recon_o)) > 100000     # the loop filter did real work
