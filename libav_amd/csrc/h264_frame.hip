@@ -447,7 +447,10 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
  *
  * Inside a step a lane holds one luma ROW (4 samples of the left neighbour + 16) and one chroma row
  * in registers for the vertical edges; then the tile is read by COLUMN for the horizontal edges. */
-constexpr int DCH_LOG = 3, DCH = 1 << DCH_LOG;    /* macroblocks per chunk */
+#ifndef MI355_DCH_LOG
+#define MI355_DCH_LOG 2
+#endif
+constexpr int DCH_LOG = MI355_DCH_LOG, DCH = 1 << DCH_LOG;    /* macroblocks per chunk */
 constexpr int DY_PITCH = 16 * DCH + 16;           /* + 16: rows of a 16-lane b128 access spread over all banks */
 constexpr int DC_PITCH = 8 * DCH + 8;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
