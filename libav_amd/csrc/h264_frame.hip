@@ -46,24 +46,40 @@ __device__ __forceinline__ int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >>
 __device__ __forceinline__ int blk_index(int x4, int y4) { return (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1); }
 
 /* record (64 B), motion vectors (64 B per list) and coefficients (768 B) -> LDS: every load is
- * issued before the first wait, so the wave pays one memory round trip for all of them */
-__device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, bool with_coefs)
+ * issued before the first wait, so the wave pays one memory round trip for all of them.  The two
+ * halves can be separated: a strip kernel issues the loads of the next macroblock before it works on
+ * the current one. */
+struct MbLoad {
+    uint32_t hw, mw, c0, c1, c2;
+};
+__device__ __forceinline__ void load_mb_issue(MbLoad &r, const mi355_h264_frame &fr, int mb_xy, bool with_coefs, bool ok)
 {
     const int lane = lane_id();
+    r.hw = r.mw = r.c0 = r.c1 = r.c2 = 0;
+    if (!ok) return;
     const uint32_t *hp = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy]);
     const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-    uint32_t hw = 0, mw = 0, c0 = 0, c1 = 0, c2 = 0;
-    if (lane < 16) hw = hp[lane];
-    else if (lane < 32) { if (fr.mv[0]) mw = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + lane - 16]; }
-    else if (lane < 48) { if (fr.mv[1]) mw = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + lane - 32]; }
-    if (with_coefs) { c0 = cp[lane]; c1 = cp[lane + 64]; c2 = cp[lane + 128]; }
-    if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = hw;
-    else if (lane < 48) s.mv[(lane >> 4) - 1][lane & 15] = mw;
+    if (lane < 16) r.hw = hp[lane];
+    else if (lane < 32) { if (fr.mv[0]) r.mw = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + lane - 16]; }
+    else if (lane < 48) { if (fr.mv[1]) r.mw = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + lane - 32]; }
+    if (with_coefs) { r.c0 = cp[lane]; r.c1 = cp[lane + 64]; r.c2 = cp[lane + 128]; }
+}
+__device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool with_coefs)
+{
+    const int lane = lane_id();
+    if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = r.hw;
+    else if (lane < 48) s.mv[(lane >> 4) - 1][lane & 15] = r.mw;
     if (with_coefs) {
         uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
-        dst[lane] = c0; dst[lane + 64] = c1; dst[lane + 128] = c2;
+        dst[lane] = r.c0; dst[lane + 64] = r.c1; dst[lane + 128] = r.c2;
     }
     __syncthreads();
+}
+__device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, bool with_coefs)
+{
+    MbLoad r;
+    load_mb_issue(r, fr, mb_xy, with_coefs, true);
+    load_mb_commit(s, r, with_coefs);
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */
@@ -179,7 +195,11 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
         for (int i = 0; i < 4; i++) c[i] = s.coef[b * 16 + 4 * q + i];
         const int dc = s.coef[b * 16];
         idct4_quad(c, q, r, col);
-        if (((mask >> b) & 1) || (intra16 && dc))
+        /* a block without the nnz bit but with a DC value (Intra16x16) takes h264_idct_dc_add
+         * (h264idct_template.c:144-156): (dc + 32) >> 6 in int, not the int16 wrap of the full transform */
+        const bool coded = (mask >> b) & 1;
+        if (!coded) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;
+        if (coded || (intra16 && dc))
             add_col(y + (4 * blk_y4(b)) * pitch + 4 * blk_x4(b) + col, pitch, r, 4);
     }
     __syncthreads();
@@ -204,7 +224,9 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
     for (int i = 0; i < 4; i++) c[i] = s.coef[256 + j * 16 + 4 * q + i];
     const int dc = s.coef[256 + j * 16];
     idct4_quad(c, q, r, col);
-    if (lane < 32 && (((mask >> (16 + j)) & 1) || dc)) {
+    const bool coded = (mask >> (16 + j)) & 1;
+    if (!coded) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;       /* DC only: h264_idct_dc_add, no int16 wrap */
+    if (lane < 32 && (coded || dc)) {
         uint8_t *p = (j >> 2) ? cr : cb;
         const int jj = j & 3;
         add_col(p + (4 * (jj >> 1)) * pitch + 4 * (jj & 1) + col, pitch, r, 4);
@@ -244,30 +266,77 @@ __device__ unsigned long long g_prof[16];
  * cache lines and write the same 128-byte lines of `recon` — meet in the same L2. */
 __device__ __forceinline__ int xcd_linear(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
+/* A wave reconstructs a STRIP of four horizontally adjacent macroblocks one after the other and writes
+ * the strip as 64-byte (luma) / 32-byte (chroma) row pieces: a quarter of the store requests of
+ * per-macroblock stores, neighbouring reference windows meet in the same L1, and the record /
+ * coefficient loads of the next macroblock are in flight while the current one is computed. */
+constexpr int STRIP = 4;
+struct StripLds {
+    MbLds mb;
+    uint8_t sy[16][16 * STRIP];
+    uint8_t sc[2][8][8 * STRIP];
+};
+
 __global__ void __launch_bounds__(64)
-k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_nmb, int nblocks, int per_xcd)
+k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_strips, int nblocks, int per_xcd)
 {
-    __shared__ MbLds s;
+    __shared__ StripLds s;
+    const int lane = lane_id();
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
-    const int f = lin / max_nmb, mb_xy = lin - f * max_nmb;
+    const int f = lin / max_strips, strip = lin - f * max_strips;
     const mi355_h264_frame &fr = frames[f];
-    if (mb_xy >= fr.mb_width * fr.mb_height) return;
+    const int W = fr.mb_width, spr = (W + STRIP - 1) / STRIP;            /* strips per row */
+    if (strip >= spr * fr.mb_height) return;
+    const int mb_y = strip / spr, x0 = (strip - mb_y * spr) * STRIP;
+    const int n = W - x0 < STRIP ? W - x0 : STRIP;
 #ifdef MI355_PROF
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
-    load_mb(s, fr, mb_xy, true);
-    PROF_MARK(8);
-    if (s.hdr.mb_type & MI355_MB_INTRA) return;
-    const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
-    const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
-    hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
-    PROF_MARK(9);
-    residual_luma(s, s.py, 16, false);
-    PROF_MARK(10);
-    residual_chroma(s, s.pc[0], s.pc[1], 8);
-    PROF_MARK(11);
-    store_mb(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
+    MbLoad next;
+    load_mb_issue(next, fr, mb_y * W + x0, true, true);
+    uint32_t done = 0;                                                   /* bit k: macroblock k of the strip was reconstructed here */
+    for (int k = 0; k < n; k++) {
+        const int mb_x = x0 + k, mb_xy = mb_y * W + mb_x;
+        load_mb_commit(s.mb, next, true);
+        load_mb_issue(next, fr, mb_xy + 1, true, k + 1 < n);
+        PROF_MARK(8);
+        if (s.mb.hdr.mb_type & MI355_MB_INTRA) { __syncthreads(); continue; }      /* k_recon_intra owns it */
+        const mi355_h264_slice &sl = fr.slices[s.mb.hdr.slice_id];
+        hl_motion(s.mb, fr, sl, mb_x, mb_y, mb_xy);
+        PROF_MARK(9);
+        residual_luma(s.mb, s.mb.py, 16, false);
+        PROF_MARK(10);
+        residual_chroma(s.mb, s.mb.pc[0], s.mb.pc[1], 8);
+        PROF_MARK(11);
+        /* tile -> strip */
+        *reinterpret_cast<uint32_t *>(&s.sy[lane >> 2][16 * k + 4 * (lane & 3)]) = reinterpret_cast<const uint32_t *>(s.mb.py)[lane];
+        if (lane < 32) {
+            const int p = lane >> 4, r = (lane >> 1) & 7, sg = lane & 1;
+            *reinterpret_cast<uint32_t *>(&s.sc[p][r][8 * k + 4 * sg]) = reinterpret_cast<const uint32_t *>(s.mb.pc[p])[lane & 15];
+        }
+        done |= 1u << k;
+        __syncthreads();
+    }
+    /* strip -> picture: lane = (row, 16-byte piece) for luma, (plane, row, 8-byte piece) for chroma */
+    {
+        const int row = lane >> 2, pc = lane & 3;
+        if ((done >> pc) & 1) {
+            uint8_t *d = fr.recon[0] + (size_t)(mb_y * 16 + row) * fr.recon_stride[0] + (x0 + pc) * 16;
+            const uint32_t *v = reinterpret_cast<const uint32_t *>(&s.sy[row][16 * pc]);
+            if (((reinterpret_cast<uintptr_t>(fr.recon[0]) | (uintptr_t)fr.recon_stride[0]) & 15) == 0)
+                *reinterpret_cast<uint4 *>(d) = make_uint4(v[0], v[1], v[2], v[3]);
+            else { uint32_t *o = reinterpret_cast<uint32_t *>(d); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+        }
+        const int p = lane >> 5, crow = (lane >> 2) & 7;
+        if ((done >> pc) & 1) {
+            uint8_t *d = fr.recon[1 + p] + (size_t)(mb_y * 8 + crow) * fr.recon_stride[1] + (x0 + pc) * 8;
+            const uint32_t *v = reinterpret_cast<const uint32_t *>(&s.sc[p][crow][8 * pc]);
+            if (((reinterpret_cast<uintptr_t>(fr.recon[1 + p]) | (uintptr_t)fr.recon_stride[1]) & 7) == 0)
+                *reinterpret_cast<uint2 *>(d) = make_uint2(v[0], v[1]);
+            else { uint32_t *o = reinterpret_cast<uint32_t *>(d); o[0] = v[0]; o[1] = v[1]; }
+        }
+    }
     PROF_MARK(12);
 }
 
@@ -885,10 +954,10 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
     if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
-    const int max_nmb = max_mb_width * max_mb_height;
-    const int nblocks = nframes * max_nmb, per_xcd = (nblocks + 7) / 8;
+    const int max_strips = ((max_mb_width + STRIP - 1) / STRIP) * max_mb_height;
+    const int nblocks = nframes * max_strips, per_xcd = (nblocks + 7) / 8;
     hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
-                       d_frames, max_nmb, nblocks, per_xcd);
+                       d_frames, max_strips, nblocks, per_xcd);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -9,3 +9,22 @@ def test_frame_pipeline_emulated(emu, oracle, name):
     changed = frame_cases.run_case(emu, oracle, name)
     if "smooth" in str(frame_cases.CASES[name]) and frame_cases.CASES[name]["mb_w"] > 1:
         assert changed > 100, "loop filter barely exercised"
+
+
+def test_full_size_1080p_picture_emulated(emu, oracle):
+    """One 1080p picture of the bench workload (BASELINE.json config 2's real size) through the emulated
+    kernels: 8160 macroblocks reach value combinations the small cases do not (this is the case that
+    caught the DC-only transform of Intra16x16 blocks wrapping at int16)."""
+    import numpy as np
+    import h264_frames as HF
+    fs = HF.synth_frames_fast(1, 120, 68, seed=0x264, lib=emu.lib)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(emu, fs)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
