@@ -266,77 +266,32 @@ __device__ unsigned long long g_prof[16];
  * cache lines and write the same 128-byte lines of `recon` — meet in the same L2. */
 __device__ __forceinline__ int xcd_linear(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
-/* A wave reconstructs a STRIP of four horizontally adjacent macroblocks one after the other and writes
- * the strip as 64-byte (luma) / 32-byte (chroma) row pieces: a quarter of the store requests of
- * per-macroblock stores, neighbouring reference windows meet in the same L1, and the record /
- * coefficient loads of the next macroblock are in flight while the current one is computed. */
-constexpr int STRIP = 4;
-struct StripLds {
-    MbLds mb;
-    uint8_t sy[16][16 * STRIP];
-    uint8_t sc[2][8][8 * STRIP];
-};
-
 __global__ void __launch_bounds__(64)
-k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_strips, int nblocks, int per_xcd)
+k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_nmb, int nblocks, int per_xcd)
 {
-    __shared__ StripLds s;
-    const int lane = lane_id();
+    __shared__ MbLds s;
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
-    const int f = lin / max_strips, strip = lin - f * max_strips;
+    const int f = lin / max_nmb, mb_xy = lin - f * max_nmb;
     const mi355_h264_frame &fr = frames[f];
-    const int W = fr.mb_width, spr = (W + STRIP - 1) / STRIP;            /* strips per row */
-    if (strip >= spr * fr.mb_height) return;
-    const int mb_y = strip / spr, x0 = (strip - mb_y * spr) * STRIP;
-    const int n = W - x0 < STRIP ? W - x0 : STRIP;
+    if (mb_xy >= fr.mb_width * fr.mb_height) return;
 #ifdef MI355_PROF
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
-    MbLoad next;
-    load_mb_issue(next, fr, mb_y * W + x0, true, true);
-    uint32_t done = 0;                                                   /* bit k: macroblock k of the strip was reconstructed here */
-    for (int k = 0; k < n; k++) {
-        const int mb_x = x0 + k, mb_xy = mb_y * W + mb_x;
-        load_mb_commit(s.mb, next, true);
-        load_mb_issue(next, fr, mb_xy + 1, true, k + 1 < n);
-        PROF_MARK(8);
-        if (s.mb.hdr.mb_type & MI355_MB_INTRA) { __syncthreads(); continue; }      /* k_recon_intra owns it */
-        const mi355_h264_slice &sl = fr.slices[s.mb.hdr.slice_id];
-        hl_motion(s.mb, fr, sl, mb_x, mb_y, mb_xy);
-        PROF_MARK(9);
-        residual_luma(s.mb, s.mb.py, 16, false);
-        PROF_MARK(10);
-        residual_chroma(s.mb, s.mb.pc[0], s.mb.pc[1], 8);
-        PROF_MARK(11);
-        /* tile -> strip */
-        *reinterpret_cast<uint32_t *>(&s.sy[lane >> 2][16 * k + 4 * (lane & 3)]) = reinterpret_cast<const uint32_t *>(s.mb.py)[lane];
-        if (lane < 32) {
-            const int p = lane >> 4, r = (lane >> 1) & 7, sg = lane & 1;
-            *reinterpret_cast<uint32_t *>(&s.sc[p][r][8 * k + 4 * sg]) = reinterpret_cast<const uint32_t *>(s.mb.pc[p])[lane & 15];
-        }
-        done |= 1u << k;
-        __syncthreads();
-    }
-    /* strip -> picture: lane = (row, 16-byte piece) for luma, (plane, row, 8-byte piece) for chroma */
-    {
-        const int row = lane >> 2, pc = lane & 3;
-        if ((done >> pc) & 1) {
-            uint8_t *d = fr.recon[0] + (size_t)(mb_y * 16 + row) * fr.recon_stride[0] + (x0 + pc) * 16;
-            const uint32_t *v = reinterpret_cast<const uint32_t *>(&s.sy[row][16 * pc]);
-            if (((reinterpret_cast<uintptr_t>(fr.recon[0]) | (uintptr_t)fr.recon_stride[0]) & 15) == 0)
-                *reinterpret_cast<uint4 *>(d) = make_uint4(v[0], v[1], v[2], v[3]);
-            else { uint32_t *o = reinterpret_cast<uint32_t *>(d); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
-        }
-        const int p = lane >> 5, crow = (lane >> 2) & 7;
-        if ((done >> pc) & 1) {
-            uint8_t *d = fr.recon[1 + p] + (size_t)(mb_y * 8 + crow) * fr.recon_stride[1] + (x0 + pc) * 8;
-            const uint32_t *v = reinterpret_cast<const uint32_t *>(&s.sc[p][crow][8 * pc]);
-            if (((reinterpret_cast<uintptr_t>(fr.recon[1 + p]) | (uintptr_t)fr.recon_stride[1]) & 7) == 0)
-                *reinterpret_cast<uint2 *>(d) = make_uint2(v[0], v[1]);
-            else { uint32_t *o = reinterpret_cast<uint32_t *>(d); o[0] = v[0]; o[1] = v[1]; }
-        }
-    }
+    load_mb(s, fr, mb_xy, true);
+    PROF_MARK(8);
+    if (s.hdr.mb_type & MI355_MB_INTRA) return;
+    const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
+    const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
+    hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
+    PROF_MARK(9);
+    residual_luma(s, s.py, 16, false);
+    PROF_MARK(10);
+    residual_chroma(s, s.pc[0], s.pc[1], 8);
+    PROF_MARK(11);
+    /* (a strip variant — four adjacent macroblocks per wave, 64-byte row stores, next macroblock's loads
+     * in flight — measured 7 % slower: the kernel is bound by instruction issue, not by L1 requests) */
+    store_mb(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
     PROF_MARK(12);
 }
 
@@ -954,10 +909,10 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
     if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
-    const int max_strips = ((max_mb_width + STRIP - 1) / STRIP) * max_mb_height;
-    const int nblocks = nframes * max_strips, per_xcd = (nblocks + 7) / 8;
+    const int max_nmb = max_mb_width * max_mb_height;
+    const int nblocks = nframes * max_nmb, per_xcd = (nblocks + 7) / 8;
     hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
-                       d_frames, max_strips, nblocks, per_xcd);
+                       d_frames, max_nmb, nblocks, per_xcd);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -40,4 +40,4 @@ def test_full_size_1080p_batch_matches_oracle(mi355, oracle):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
-    assert sum(int((a != b).sum()) for a, b in zip(dst_o, recon_o)) > 100000     # the loop filter did real work
+    assert sum(int((a != b).sum()) for a, b in zip(dst_o, recon_o)) > 10000      # the loop filter did real work
