@@ -79,6 +79,13 @@ __device__ __forceinline__ uint32_t mi355_alignbyte(uint32_t hi, uint32_t lo, ui
  * Fast path (every dword the realignment touches lies inside the plane, rows 4-byte aligned): two
  * aligned dword loads + v_alignbyte.  Slow path: per-sample clamped reads (== emulated_edge_mc,
  * videodsp_template.c:24-96). */
+/* idx / ndw for the window widths in use (1..6 dwords) and idx < 256 without an integer division */
+__device__ __forceinline__ int div_small(int idx, int ndw)
+{
+    const int m = ndw == 6 ? 10923 : (ndw == 5 ? 13108 : (ndw == 4 ? 16384 : (ndw == 3 ? 21846 : (ndw == 2 ? 32768 : 65536))));
+    return (idx * m) >> 16;
+}
+
 template <int MAXIT>
 struct WinLoad {
     uint32_t lo[MAXIT], hi[MAXIT];
@@ -89,7 +96,7 @@ struct WinLoad {
         const int xa = x0 & ~3;
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
-            const int idx = lane + 64 * k, row = idx / ndw, dw = idx - row * ndw;
+            const int idx = lane + 64 * k, row = div_small(idx, ndw), dw = idx - row * ndw;
             lo[k] = hi[k] = 0;
             if (row >= wh) continue;
             if (inside) {
@@ -109,7 +116,7 @@ struct WinLoad {
     {
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
-            const int idx = lane + 64 * k, row = idx / ndw, dw = idx - row * ndw;
+            const int idx = lane + 64 * k, row = div_small(idx, ndw), dw = idx - row * ndw;
             if (row < wh) win[row * pitch_dw + dw] = mi355_alignbyte(hi[k], lo[k], shift);
         }
     }

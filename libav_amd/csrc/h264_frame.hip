@@ -266,22 +266,27 @@ __device__ unsigned long long g_prof[16];
  * cache lines and write the same 128-byte lines of `recon` — meet in the same L2. */
 __device__ __forceinline__ int xcd_linear(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
+/* n / d for a launch-constant divisor d: the host passes m = ceil(2^40 / d); exact for n < 2^24 */
+__device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
+
 __global__ void __launch_bounds__(64)
-k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_nmb, int nblocks, int per_xcd)
+k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
     __shared__ MbLds s;
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
-    const int f = lin / max_nmb, mb_xy = lin - f * max_nmb;
+    /* lin = (f * max_h + mb_y) * max_w + mb_x */
+    const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
+    const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
     const mi355_h264_frame &fr = frames[f];
-    if (mb_xy >= fr.mb_width * fr.mb_height) return;
+    if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
+    const int mb_xy = mb_y * fr.mb_width + mb_x;
 #ifdef MI355_PROF
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     load_mb(s, fr, mb_xy, true);
     PROF_MARK(8);
     if (s.hdr.mb_type & MI355_MB_INTRA) return;
-    const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
     PROF_MARK(9);
@@ -909,10 +914,18 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
     if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
-    const int max_nmb = max_mb_width * max_mb_height;
-    const int nblocks = nframes * max_nmb, per_xcd = (nblocks + 7) / 8;
-    hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
-                       d_frames, max_nmb, nblocks, per_xcd);
+    /* div_magic is exact below 2^24 work items: larger batches go out as several launches */
+    const int per_frame = max_mb_width * max_mb_height;
+    if (per_frame <= 0 || per_frame >= (1 << 24)) return -3;
+    const int frames_per_launch = ((1 << 24) - 1) / per_frame;
+    const unsigned long long one = 1ull << 40;
+    for (int f0 = 0; f0 < nframes; f0 += frames_per_launch) {
+        const int nf = nframes - f0 < frames_per_launch ? nframes - f0 : frames_per_launch;
+        const int nblocks = nf * per_frame, per_xcd = (nblocks + 7) / 8;
+        hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
+                           d_frames + f0, max_mb_width, max_mb_height, (one + max_mb_width - 1) / max_mb_width,
+                           (one + max_mb_height - 1) / max_mb_height, nblocks, per_xcd);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
