@@ -104,8 +104,8 @@ __device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_
 __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
                                int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
-    const int r0 = s.hdr.ref_idx[0][quadrant], r1 = s.hdr.ref_idx[1][quadrant];
-    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) &&
+    const int r0 = uniform(s.hdr.ref_idx[0][quadrant]), r1 = uniform(s.hdr.ref_idx[1][quadrant]);
+    const bool weighted = (uniform(s.hdr.flags) & MI355_MBF_WEIGHTED) &&
                           ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
     if (!weighted) {
         int avg = 0;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, co
  * a single (inlined) call site. */
 __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y, int mb_xy)
 {
-    const uint32_t t = s.hdr.mb_type;
+    const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
 #define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
     const int kind = (t & MI355_MB_16x16) ? 0 : ((t & MI355_MB_16x8) ? 1 : ((t & MI355_MB_8x16) ? 2 : 3));
     const int nparts = kind == 0 ? 1 : (kind == 3 ? 16 : 2);
@@ -157,7 +157,7 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
         else if (kind == 2) { n = 2 * p; quad = p; bx = 8 * p; by = 0; w = 8; h = 16; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
         else {
             const int i = p >> 2, j = p & 3;
-            const int st = s.hdr.sub_mb_type[i], shape = st & 3;
+            const int st = uniform(s.hdr.sub_mb_type[i]), shape = st & 3;
             const int cnt = shape == MI355_SUB_8x8 ? 1 : (shape == MI355_SUB_4x4 ? 4 : 2);
             if (j >= cnt) continue;
             l0 = (st & MI355_SUB_L0) != 0; l1 = (st & MI355_SUB_L1) != 0;
@@ -180,8 +180,8 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
 __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra16)
 {
     const int lane = lane_id();
-    const uint32_t mask = s.hdr.nnz_mask;
-    if (s.hdr.mb_type & MI355_MB_8x8DCT) {
+    const uint32_t mask = (uint32_t)uniform((int)s.hdr.nnz_mask);
+    if (uniform((int)s.hdr.mb_type) & MI355_MB_8x8DCT) {
         const int b = (lane >> 3) & 3, i = lane & 7;
         const bool active = lane < 32;
         int r[8];
@@ -208,9 +208,9 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
 /* chroma residual: h264_mb_template.c:196-247 */
 __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int pitch)
 {
-    if (!(s.hdr.cbp & 0x30)) return;
+    if (!(uniform(s.hdr.cbp) & 0x30)) return;
     const int lane = lane_id();
-    const uint32_t mask = s.hdr.nnz_mask;
+    const uint32_t mask = (uint32_t)uniform((int)s.hdr.nnz_mask);
     if (lane < 2 && ((mask >> (MI355_NNZ_CB_DC + lane)) & 1)) {
         int16_t *p = s.coef + 256 + 64 * lane;
         int a = p[0], b = p[16], c = p[32], d = p[48];
@@ -286,8 +286,8 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
 #endif
     load_mb(s, fr, mb_xy, true);
     PROF_MARK(8);
-    if (s.hdr.mb_type & MI355_MB_INTRA) return;
-    const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
+    if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
+    const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
     PROF_MARK(9);
     residual_luma(s, s.py, 16, false);
