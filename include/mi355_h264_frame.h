@@ -196,6 +196,11 @@ int   mi355_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2d(void *dst, const void *src, size_t bytes);
 int   mi355_sync(void *stream);
+/* Streams for callers that pipeline half-batches (reconstruction of one against deblocking of the other);
+ * `stream` arguments of every entry point accept these or NULL (the default stream). */
+void *mi355_stream_create(void);
+void  mi355_stream_destroy(void *stream);
+int   mi355_stream_wait_event(void *stream, void *event);
 /* HIP events on the caller's stream (kernel timing without a host sync per kernel) */
 void *mi355_event_create(void);
 void  mi355_event_destroy(void *event);

@@ -82,14 +82,12 @@ __device__ __forceinline__ uint32_t mi355_alignbyte(uint32_t hi, uint32_t lo, ui
  * Fast path (every dword the realignment touches lies inside the plane, rows 4-byte aligned): two
  * aligned dword loads + v_alignbyte.  Slow path: per-sample clamped reads (== emulated_edge_mc,
  * videodsp_template.c:24-96). */
-/* row of window element idx */
-__device__ __forceinline__ int div_small(int idx, int ndw)
-{
-    /* ndw is wave-uniform: the compiler derives one reciprocal per window and keeps it in scalar
-     * registers; a hand-written multiply-shift with a selected constant measured 10 % slower */
-    return idx / ndw;
-}
-
+/* One window's worth of loads for this lane, issued before anything waits on them.  The window starts
+ * at picture column x0 (any alignment) and is `ndw` (<= 8) dwords wide, `wh` rows high.  A row takes 4 or
+ * 8 lanes (some idle) so that (row, dword) of a lane are shifts and masks.
+ * Fast path (every dword the realignment touches lies inside the plane, rows 4-byte aligned): two
+ * aligned dword loads + v_alignbyte.  Slow path: per-sample clamped reads (== emulated_edge_mc,
+ * videodsp_template.c:24-96). */
 template <int MAXIT>
 struct WinLoad {
     uint32_t lo[MAXIT], hi[MAXIT];
@@ -97,14 +95,16 @@ struct WinLoad {
     __device__ __forceinline__ void issue(const PlaneRef &ref, int x0, int y0, int ndw, int wh, bool inside, int lane)
     {
         shift = (uint32_t)x0 & 3;
-        const int xa = x0 & ~3;
+        const int xa = x0 & ~3, sh = ndw > 4 ? 3 : 2, dw = lane & ((1 << sh) - 1), r0 = lane >> sh;
+        const uint8_t *base = ref.base + (ptrdiff_t)(y0 + r0) * ref.stride + xa + 4 * dw;
+        const ptrdiff_t step = (ptrdiff_t)(64 >> sh) * ref.stride;
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
-            const int idx = lane + 64 * k, row = div_small(idx, ndw), dw = idx - row * ndw;
+            const int row = r0 + k * (64 >> sh);
             lo[k] = hi[k] = 0;
-            if (row >= wh) continue;
+            if (row >= wh || dw >= ndw) continue;
             if (inside) {
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(ref.base + (size_t)(y0 + row) * ref.stride + xa + 4 * dw);
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + k * step);
                 lo[k] = p[0];
                 hi[k] = p[1];
             } else {
@@ -118,10 +118,11 @@ struct WinLoad {
     }
     __device__ __forceinline__ void commit(uint32_t *win, int pitch_dw, int ndw, int wh, int lane) const
     {
+        const int sh = ndw > 4 ? 3 : 2, dw = lane & ((1 << sh) - 1), r0 = lane >> sh;
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
-            const int idx = lane + 64 * k, row = div_small(idx, ndw), dw = idx - row * ndw;
-            if (row < wh) win[row * pitch_dw + dw] = mi355_alignbyte(hi[k], lo[k], shift);
+            const int row = r0 + k * (64 >> sh);
+            if (row < wh && dw < ndw) win[row * pitch_dw + dw] = mi355_alignbyte(hi[k], lo[k], shift);
         }
     }
 };
@@ -141,8 +142,8 @@ __device__ inline void stage_windows(McScratch &s, const PlaneRef *y, int ix, in
                                      const PlaneRef *cb, const PlaneRef *cr, int cx, int cy, int cw, int ch)
 {
     const int lane = lane_id();
-    WinLoad<2> ly;
-    WinLoad<1> lb, lr;
+    WinLoad<3> ly;          /* 21 rows x 8 lanes */
+    WinLoad<1> lb, lr;      /* 9 rows x 4 lanes */
     const int ydw = luma_win_dw(bw), cdw = chroma_win_dw(cw);
     if (y) ly.issue(*y, ix - 4, iy - 2, ydw, bh + 5, win_inside(*y, ix - 4, iy - 2, ydw, bh + 5), lane);
     if (cb) {

@@ -95,9 +95,15 @@ __device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_
     PlaneRef ry{fr.ref[slot][0], fr.dst_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
     PlaneRef rb{fr.ref[slot][1], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     PlaneRef rr{fr.ref[slot][2], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
+#ifndef MI355_EXP_NO_STAGE
     stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
+#endif
+#ifndef MI355_EXP_NO_LUMA
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
+#endif
+#ifndef MI355_EXP_NO_CHROMA
     mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
+#endif
 }
 
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
@@ -235,21 +241,23 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
 }
 
 /* tile (LDS) -> picture, 4 bytes per lane */
+__device__ __forceinline__ uint32_t tile_dword(const uint8_t *p)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) return *reinterpret_cast<const uint32_t *>(p);
+    return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+}
 __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb, const uint8_t *cr, int cpitch,
                                 uint8_t *const dst[3], const int32_t stride[2], int mb_x, int mb_y)
 {
     const int lane = lane_id();
     {
         const int row = lane >> 2, seg = lane & 3;
-        const uint8_t *p = y + row * ypitch + 4 * seg;
-        uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
-        *reinterpret_cast<uint32_t *>(dst[0] + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = v;
+        *reinterpret_cast<uint32_t *>(dst[0] + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword(y + row * ypitch + 4 * seg);
     }
     if (lane < 32) {
         const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
-        const uint8_t *p = (plane ? cr : cb) + row * cpitch + 4 * seg;
-        uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
-        *reinterpret_cast<uint32_t *>(dst[1 + plane] + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) = v;
+        *reinterpret_cast<uint32_t *>(dst[1 + plane] + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
+            tile_dword((plane ? cr : cb) + row * cpitch + 4 * seg);
     }
 }
 
@@ -290,10 +298,12 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
     PROF_MARK(9);
+#ifndef MI355_EXP_NO_RESIDUAL
     residual_luma(s, s.py, 16, false);
     PROF_MARK(10);
     residual_chroma(s, s.pc[0], s.pc[1], 8);
     PROF_MARK(11);
+#endif
     /* (a strip variant — four adjacent macroblocks per wave, 64-byte row stores, next macroblock's loads
      * in flight — measured 7 % slower: the kernel is bound by instruction issue, not by L1 requests) */
     store_mb(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
@@ -1031,6 +1041,15 @@ extern "C" int mi355_memcpy_h2d(void *dst, const void *src, size_t bytes) { retu
 extern "C" int mi355_memcpy_d2h(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_memcpy_d2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
+
+extern "C" void *mi355_stream_create(void)
+{
+    hipStream_t st;
+    MI355_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
+extern "C" void mi355_stream_destroy(void *st) { (void)hipStreamDestroy((hipStream_t)st); }
+extern "C" int mi355_stream_wait_event(void *st, void *e) { return hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)e, 0) == hipSuccess ? 0 : -1; }
 
 extern "C" void *mi355_event_create(void)
 {
