@@ -1,0 +1,96 @@
+/*
+ * mi355_hevc_batch.h — Tier 2 for the HEVC rows: the same wave-level code that
+ * sits behind HEVCDSPContext (include/mi355dsp.h), launched over DEVICE-RESIDENT batches of independent
+ * work items — one wavefront per item (eight edge segments per wavefront for the loop filter).
+ *
+ * The reference issues these calls one block at a time from hls_transform_unit / hevc_luma_mv_mpred /
+ * ff_hevc_deblocking_filter / sao_filter_CTB (libavcodec/hevcdec.c, hevc_filter.c); HEVC's in-loop
+ * filters are picture-parallel by construction (all vertical edges, then all horizontal ones; SAO reads
+ * the deblocked picture and writes another), and transform / prediction blocks of a picture do not
+ * depend on each other once the entropy decoder has produced them.  A bridge therefore collects one
+ * job per call site and submits a picture's worth per launch; ordering between dependent stages
+ * (residual after prediction, vertical before horizontal edges, SAO after deblocking) is the caller's
+ * sequence of launches on one stream.  All pointers are device pointers; strides are in BYTES.
+ */
+#ifndef MI355_HEVC_BATCH_H
+#define MI355_HEVC_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a13/a12: one transform unit: c->idct[]/idct_dc[]/transform_4x4_luma/dequant (hevcdsp.h:46-52), then
+ * c->add_residual[] (:45) when `dst` is set (the tail of hls_transform_unit, hevcdec.c:1238-1260) */
+enum { MI355_HEVC_TU_IDCT = 0, MI355_HEVC_TU_IDCT_DC = 1, MI355_HEVC_TU_DST4 = 2, MI355_HEVC_TU_SKIP = 3 };
+typedef struct mi355_hevc_tu_job {
+    int16_t *coeffs;          /* size x size, row-major; rewritten in place when dst == NULL */
+    uint8_t *dst;             /* picture samples of the block, or NULL */
+    int32_t dst_stride;
+    uint8_t log2_size;        /* 2..5 */
+    uint8_t col_limit;        /* as passed to c->idct[] */
+    uint8_t kind;             /* MI355_HEVC_TU_* */
+    uint8_t reserved;
+} mi355_hevc_tu_job;
+int mi355_hevc_residual_batch_dev(const mi355_hevc_tu_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a14: put_hevc_qpel / put_hevc_epel (hevcdsp.h:64-69): width x height samples at `src` (fractions mx,my)
+ * to the 14-bit intermediate */
+typedef struct mi355_hevc_mc_job {
+    const uint8_t *src;       /* sample (0,0) of the block in the reference picture */
+    int16_t *dst;
+    int32_t src_stride, dst_stride;
+    uint8_t width, height;    /* <= 64 */
+    uint8_t mx, my;           /* luma: 0..3, chroma: 0..7 */
+    uint8_t chroma;           /* 0: 8-tap qpel, 1: 4-tap epel */
+    uint8_t reserved[3];
+} mi355_hevc_mc_job;
+int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a15: put_unweighted_pred / _avg / weighted_pred / _avg (hevcdsp.h:71-103) */
+enum { MI355_HEVC_PRED_PUT = 0, MI355_HEVC_PRED_AVG = 1, MI355_HEVC_PRED_W = 2, MI355_HEVC_PRED_W_AVG = 3 };
+typedef struct mi355_hevc_pred_job {
+    uint8_t *dst;
+    const int16_t *src1, *src2;   /* src2 only for the _avg kinds */
+    int32_t dst_stride, src_stride;
+    uint8_t width, height, kind, denom;
+    int16_t w0, w1, o0, o1;
+} mi355_hevc_pred_job;
+int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a16: hevc_{h,v}_loop_filter_{luma,chroma} (hevcdsp.h:104-113): one 8-sample edge segment pair.
+ * Jobs of one launch must not touch the same samples (all vertical edges of a picture, or all
+ * horizontal ones: ff_hevc_deblocking_filter's two passes). */
+typedef struct mi355_hevc_lf_job {
+    uint8_t *pix;             /* first sample on the q side */
+    int32_t stride;
+    int32_t beta;             /* luma only */
+    int32_t tc[2];
+    uint8_t no_p[2], no_q[2];
+    uint8_t horizontal_edge;  /* 1: the edge is horizontal (hevc_h_loop_filter_*) */
+    uint8_t chroma;
+    uint8_t reserved[2];
+} mi355_hevc_lf_job;
+int mi355_hevc_deblock_batch_dev(const mi355_hevc_lf_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a17: sao_band_filter[cls] / sao_edge_filter[cls] (hevcdsp.h:54-62) for one CTB component */
+typedef struct mi355_hevc_sao_job {
+    uint8_t *dst;
+    const uint8_t *src;
+    int32_t stride;           /* both pictures */
+    int32_t width, height;
+    int32_t borders[4];
+    int32_t offset_val[5];
+    uint8_t cls;              /* which of the four table slots: bit 0 = rows above, bit 1 = columns left */
+    uint8_t edge;             /* 0 band, 1 edge */
+    uint8_t c_idx, eo_class, band_position;
+    uint8_t vert_edge, horiz_edge, diag_edge;
+} mi355_hevc_sao_job;
+int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

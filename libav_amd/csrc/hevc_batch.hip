@@ -1,0 +1,162 @@
+/*
+ * hevc_batch.hip — Tier 2 for the HEVC rows: device-resident batches of the HEVCDSPContext operations
+ * (include/mi355_hevc_batch.h).  One wavefront per job (eight edge segments per wavefront in the loop
+ * filter); the arithmetic is the wave-level code of hevc_dev.h that the Tier-1 entry points use, so
+ * parity with the reference carries over (tests/test_hevc_batch_*.py check it again per batch).
+ * Jobs are read with scalar loads (the job index is wave-uniform); samples go HBM <-> LDS/registers
+ * once per job.
+ */
+#include "mi355_rt.h"
+#include "hevc_dev.h"
+#include "../../include/mi355_hevc_batch.h"
+
+using namespace mi355;
+
+namespace {
+
+/* ---- transform units ------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_job *jobs, int n, int bd)
+{
+    __shared__ IdctScratch s;
+    const int lane = lane_id();
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_tu_job j = jobs[blockIdx.x];
+    const int size = 1 << j.log2_size, cnt = size * size;
+    /* coefficients -> LDS, two per lane and access */
+    for (int i = lane; i < cnt / 2; i += 64) reinterpret_cast<uint32_t *>(s.c)[i] = reinterpret_cast<const uint32_t *>(j.coeffs)[i];
+    __syncthreads();
+    if (j.kind == MI355_HEVC_TU_IDCT_DC) {            /* hevcdsp_template.c:238-252 */
+        const int shift = 14 - bd, add = 1 << (shift - 1);
+        const int v = (((s.c[0] + 1) >> 1) + add) >> shift;
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) s.c[i] = (int16_t)v;
+        __syncthreads();
+    } else if (j.kind == MI355_HEVC_TU_SKIP) {        /* :84-98, 4x4 only */
+        const int shift = 13 - bd, off = 1 << (shift - 1);
+        if (lane < 16) s.c[lane] = (int16_t)((s.c[lane] + off) >> shift);
+        __syncthreads();
+    } else if (j.kind == MI355_HEVC_TU_DST4) {
+        hevc_dst4_wave(s.c, bd);
+    } else if (j.log2_size == 2) hevc_idct_wave<4>(s, j.col_limit, bd);
+    else if (j.log2_size == 3) hevc_idct_wave<8>(s, j.col_limit, bd);
+    else if (j.log2_size == 4) hevc_idct_wave<16>(s, j.col_limit, bd);
+    else hevc_idct_wave<32>(s, j.col_limit, bd);
+    if (!j.dst) {
+        for (int i = lane; i < cnt / 2; i += 64) reinterpret_cast<uint32_t *>(j.coeffs)[i] = reinterpret_cast<const uint32_t *>(s.c)[i];
+        return;
+    }
+    /* add_residual (:51-82): two samples per lane */
+    const int half = size >> 1;
+    for (int i = lane; i < cnt / 2; i += 64) {
+        const int y = i / half, x = 2 * (i - y * half);
+        uint8_t *row = j.dst + (size_t)y * j.dst_stride;
+        const int r0 = s.c[y * size + x], r1 = s.c[y * size + x + 1];
+        if (bd > 8) {
+            uint32_t *p = reinterpret_cast<uint32_t *>(row) + (x >> 1);
+            const uint32_t v = *p;
+            *p = (uint32_t)clip_px((int)(v & 0xFFFF) + r0, bd) | ((uint32_t)clip_px((int)(v >> 16) + r1, bd) << 16);
+        } else {
+            uint16_t *p = reinterpret_cast<uint16_t *>(row) + (x >> 1);
+            const uint32_t v = *p;
+            *p = (uint16_t)(clip_px((int)(v & 0xFF) + r0, bd) | (clip_px((int)(v >> 8) + r1, bd) << 8));
+        }
+    }
+}
+
+/* ---- motion compensation ----------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_hevc_mc_batch(const mi355_hevc_mc_job *jobs, int n, int bd)
+{
+    __shared__ int16_t tmp[(64 + 7) * 64];
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_mc_job j = jobs[blockIdx.x];
+    const int px = bd > 8 ? 2 : 1;
+    hevc_mc_wave(j.dst, j.dst_stride / 2, j.src, j.src_stride / px, j.width, j.height, j.mx, j.my, bd, j.chroma ? 4 : 8, tmp);
+}
+
+__global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_job *jobs, int n, int bd)
+{
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_pred_job j = jobs[blockIdx.x];
+    const HevcPredParams p{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
+    const int px = bd > 8 ? 2 : 1, dt = j.dst_stride / px, ss = j.src_stride / 2;
+    const bool two = (j.kind & 1) != 0;
+    for (int i = lane_id(); i < j.width * j.height; i += 64) {
+        const int y = i / j.width, x = i - y * j.width;
+        stpx(j.dst, x + y * dt, hevc_pred_px(p, j.src1[x + y * ss], two ? j.src2[x + y * ss] : 0, bd), bd);
+    }
+}
+
+/* ---- deblocking: eight jobs per wavefront --------------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_hevc_deblock_batch(const mi355_hevc_lf_job *jobs, int n, int bd)
+{
+    __shared__ mi355_hevc_lf_job sj[8];
+    const int lane = lane_id(), slot = lane >> 3;
+    const int first = (int)blockIdx.x * 8;
+    /* 8 jobs x 8 dwords = one coalesced load */
+    if (first + slot < n) reinterpret_cast<uint32_t *>(&sj[slot])[lane & 7] = reinterpret_cast<const uint32_t *>(&jobs[first + slot])[lane & 7];
+    __syncthreads();
+    const bool on = first + slot < n;
+    const mi355_hevc_lf_job &j = sj[slot];
+    const int px = bd > 8 ? 2 : 1, st = on ? j.stride / px : 0;
+    const int xs = on && j.horizontal_edge ? st : 1, ys = on && j.horizontal_edge ? 1 : st;
+    uint8_t *pix = on ? j.pix : nullptr;
+    /* luma and chroma jobs may share a launch: both filters run, each on its own groups */
+    hevc_lf_luma_wave(pix, xs, ys, on ? j.beta : 0, j.tc, j.no_p, j.no_q, bd, true, on && !j.chroma);
+    hevc_lf_chroma_wave(pix, xs, ys, j.tc, j.no_p, j.no_q, bd, true, on && j.chroma);
+}
+
+/* ---- SAO ------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job *jobs, int n, int bd)
+{
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_sao_job j = jobs[blockIdx.x];
+    SaoJob p;
+    p.width = j.width; p.height = j.height; p.c_idx = j.c_idx; p.cls = j.cls; p.bd = bd; p.edge = j.edge;
+    for (int k = 0; k < 4; k++) p.borders[k] = j.borders[k];
+    p.vert_edge = j.vert_edge; p.horiz_edge = j.horiz_edge; p.diag_edge = j.diag_edge;
+    p.eo_class = j.eo_class; p.band_position = j.band_position;
+    for (int k = 0; k < 5; k++) p.offset_val[k] = j.offset_val[k];
+    const int st = j.stride / (bd > 8 ? 2 : 1);
+    hevc_sao_wave(j.dst, st, j.src, st, p);
+}
+
+bool check(int bit_depth, const void *jobs, int n)
+{
+    if (!ready()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
+    return jobs && n > 0 && (bit_depth == 8 || bit_depth == 9 || bit_depth == 10);
+}
+
+}  // namespace
+
+static_assert(sizeof(mi355_hevc_lf_job) == 32, "eight dwords per deblocking job (k_hevc_deblock_batch loads them as such)");
+
+extern "C" int mi355_hevc_residual_batch_dev(const mi355_hevc_tu_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_residual_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_mc_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_pred_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_deblock_batch_dev(const mi355_hevc_lf_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_deblock_batch, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_sao_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -175,11 +175,13 @@ __device__ __forceinline__ int hevc_pred_px(const HevcPredParams &p, int a, int 
 /* ---- a16: deblocking of one 8-sample edge, lanes 0..7 = the 8 lines (:1264-1392) ----------------
  * `xs`: sample step across the edge, `ys`: along it.  Decisions use lines 0 and 3 of each 4-line
  * half, fetched from the neighbouring lanes with shuffles. */
+/* `groups`: false = lanes 0..7 filter one edge (the other lanes idle); true = every group of eight lanes
+ * filters its own edge (per-lane arguments) */
 __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta, const int *tc_, const uint8_t *no_p_,
-                                         const uint8_t *no_q_, int bd)
+                                         const uint8_t *no_q_, int bd, bool groups = false, bool enabled = true)
 {
-    const int lane = lane_id(), l = lane & 7, j = l >> 2;
-    const bool act = lane < 8;
+    const int lane = lane_id(), l = lane & 7, j = l >> 2, g0 = lane & ~7;
+    const bool act = enabled && (groups || lane < 8);
     int p[4], q[4];
     for (int k = 0; k < 4; k++) {
         p[k] = act ? ldpx(pix, -(k + 1) * xs + l * ys, bd) : 0;
@@ -188,15 +190,15 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
     const int dp = iabs(p[2] - 2 * p[1] + p[0]), dq = iabs(q[2] - 2 * q[1] + q[0]);
     const int sflat = iabs(p[3] - p[0]) + iabs(q[3] - q[0]), sgap = iabs(p[0] - q[0]);
     /* values of line 0 and line 3 of this lane's half */
-    const int dp0 = __shfl(dp, 4 * j), dp3 = __shfl(dp, 4 * j + 3), dq0 = __shfl(dq, 4 * j), dq3 = __shfl(dq, 4 * j + 3);
-    const int f0 = __shfl(sflat, 4 * j), f3 = __shfl(sflat, 4 * j + 3), g0 = __shfl(sgap, 4 * j), g3 = __shfl(sgap, 4 * j + 3);
+    const int dp0 = __shfl(dp, g0 + 4 * j), dp3 = __shfl(dp, g0 + 4 * j + 3), dq0 = __shfl(dq, g0 + 4 * j), dq3 = __shfl(dq, g0 + 4 * j + 3);
+    const int f0 = __shfl(sflat, g0 + 4 * j), f3 = __shfl(sflat, g0 + 4 * j + 3), gp0 = __shfl(sgap, g0 + 4 * j), gp3 = __shfl(sgap, g0 + 4 * j + 3);
     if (!act) return;
     beta <<= bd - 8;
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     const int tc = tc_[j] << (bd - 8), no_p = no_p_[j], no_q = no_q_[j];
     if (d0 + d3 >= beta) return;
     const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
-    if (f0 < beta_3 && g0 < tc25 && f3 < beta_3 && g3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+    if (f0 < beta_3 && gp0 < tc25 && f3 < beta_3 && gp3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
         const int tc2 = tc << 1;
         if (!no_p) {
             stpx(pix, -1 * xs + l * ys, p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2), bd);
@@ -220,11 +222,12 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
         if (!no_q && nd_q > 1) stpx(pix, xs + l * ys, clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd), bd);
     }
 }
-__device__ inline void hevc_lf_chroma_wave(uint8_t *pix, int xs, int ys, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd)
+__device__ inline void hevc_lf_chroma_wave(uint8_t *pix, int xs, int ys, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd,
+                                           bool groups = false, bool enabled = true)
 {
     const int lane = lane_id();
-    if (lane >= 8) return;
-    const int l = lane, j = l >> 2, tc = tc_[j] << (bd - 8);
+    if (!enabled || (!groups && lane >= 8)) return;
+    const int l = lane & 7, j = l >> 2, tc = tc_[j] << (bd - 8);
     if (tc <= 0) return;
     const int p1 = ldpx(pix, -2 * xs + l * ys, bd), p0 = ldpx(pix, -xs + l * ys, bd);
     const int q0 = ldpx(pix, l * ys, bd), q1 = ldpx(pix, xs + l * ys, bd);

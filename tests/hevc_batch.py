@@ -1,0 +1,339 @@
+"""Batched (Tier-2) HEVC entry points of include/mi355_hevc_batch.h against the oracle: each check builds a
+picture's worth of independent jobs on non-overlapping cells, runs them in ONE launch on device memory and
+replays the same jobs one by one through the oracle's HEVCDSPContext on a host copy."""
+import ctypes as C
+
+import numpy as np
+
+import abi_ctypes as A
+from cases_hevc import EW, QW, pixels
+from rng import SplitMix64
+
+
+class TuJob(C.Structure):
+    _fields_ = [("coeffs", C.c_void_p), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("log2_size", C.c_uint8),
+                ("col_limit", C.c_uint8), ("kind", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class McJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_stride", C.c_int32), ("dst_stride", C.c_int32),
+                ("width", C.c_uint8), ("height", C.c_uint8), ("mx", C.c_uint8), ("my", C.c_uint8), ("chroma", C.c_uint8),
+                ("reserved", C.c_uint8 * 3)]
+
+
+class PredJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src1", C.c_void_p), ("src2", C.c_void_p), ("dst_stride", C.c_int32), ("src_stride", C.c_int32),
+                ("width", C.c_uint8), ("height", C.c_uint8), ("kind", C.c_uint8), ("denom", C.c_uint8),
+                ("w0", C.c_int16), ("w1", C.c_int16), ("o0", C.c_int16), ("o1", C.c_int16)]
+
+
+class LfJob(C.Structure):
+    _fields_ = [("pix", C.c_void_p), ("stride", C.c_int32), ("beta", C.c_int32), ("tc", C.c_int32 * 2),
+                ("no_p", C.c_uint8 * 2), ("no_q", C.c_uint8 * 2), ("horizontal_edge", C.c_uint8), ("chroma", C.c_uint8),
+                ("reserved", C.c_uint8 * 2)]
+
+
+class SaoJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("borders", C.c_int32 * 4), ("offset_val", C.c_int32 * 5), ("cls", C.c_uint8), ("edge", C.c_uint8),
+                ("c_idx", C.c_uint8), ("eo_class", C.c_uint8), ("band_position", C.c_uint8), ("vert_edge", C.c_uint8),
+                ("horiz_edge", C.c_uint8), ("diag_edge", C.c_uint8)]
+
+
+assert C.sizeof(LfJob) == 32
+
+
+class Dev:
+    """device memory through the C ABI's helpers"""
+
+    def __init__(self, lib):
+        self.lib, self.bufs = lib, []
+        lib.mi355_malloc.restype = C.c_void_p
+        lib.mi355_malloc.argtypes = [C.c_size_t]
+        lib.mi355_free.argtypes = [C.c_void_p]
+        for f in ("mi355_memcpy_h2d", "mi355_memcpy_d2h"):
+            getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+
+    def up(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.lib.mi355_malloc(a.nbytes + 64)
+        assert p
+        self.bufs.append(p)
+        self.lib.mi355_memcpy_h2d(p, a.ctypes.data, a.nbytes)
+        return p
+
+    def up_jobs(self, jobs):
+        arr = (type(jobs[0]) * len(jobs))(*jobs)
+        p = self.lib.mi355_malloc(C.sizeof(arr))
+        self.bufs.append(p)
+        self.lib.mi355_memcpy_h2d(p, C.addressof(arr), C.sizeof(arr))
+        return p
+
+    def down(self, p, like):
+        out = np.empty_like(like)
+        self.lib.mi355_sync(None)
+        self.lib.mi355_memcpy_d2h(out.ctypes.data, p, out.nbytes)
+        return out
+
+    def free(self):
+        for p in self.bufs:
+            self.lib.mi355_free(p)
+        self.bufs = []
+
+
+def _u8p(a, off_bytes=0):
+    return C.cast(a.ctypes.data + off_bytes, A.u8p)
+
+
+def _i16p(a, off_elems=0):
+    return C.cast(a.ctypes.data + 2 * off_elems, A.i16p)
+
+
+def check_residual(prov, oracle, bd, seed, cells=(6, 8)):
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    pic = pixels(r, (cy * 32, cx * 32), bd)
+    stride = pic.strides[0]
+    n = cy * cx
+    coefs = np.zeros((n, 32 * 32), np.int16)
+    meta = []
+    for k in range(n):
+        log2 = r.randint(2, 5)
+        size = 1 << log2
+        kind = [0, 0, 0, 1, 2, 3][r.randint(0, 5)]
+        if kind >= 2:
+            log2, size = 2, 4
+        lim = min(size, [1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 20, 24, 31, 32][r.randint(0, 13)])
+        c = r.laplace_int(300, size * size, 32767).astype(np.int16)
+        if kind == 0 and r.randint(0, 2):
+            m = c.reshape(size, size)
+            m[lim:, :] = 0
+            m[:, lim:] = 0
+        if kind == 1:
+            c[1:] = 0x1111
+        coefs[k, :size * size] = c
+        to_pic = r.randint(0, 3) != 0
+        y0, x0 = (k // cx) * 32 + r.randint(0, (32 - size) // 4) * 4, (k % cx) * 32 + r.randint(0, (32 - size) // 4) * 4
+        meta.append((log2, kind, lim, to_pic, y0, x0))
+    # oracle
+    c_o = oracle.hevcdsp(bd)
+    pic_o, coef_o = pic.copy(), coefs.copy()
+    for k, (log2, kind, lim, to_pic, y0, x0) in enumerate(meta):
+        blk = coef_o[k]
+        i = log2 - 2
+        if kind == 0:
+            c_o.idct[i](_i16p(blk), lim)
+        elif kind == 1:
+            c_o.idct_dc[i](_i16p(blk))
+        elif kind == 2:
+            c_o.transform_4x4_luma(_i16p(blk))
+        else:
+            c_o.dequant(_i16p(blk))
+        if to_pic:
+            c_o.add_residual[i](_u8p(pic_o, y0 * stride + x0 * px), _i16p(blk), stride)
+    # device
+    d = Dev(prov.lib)
+    try:
+        p_pic, p_coef = d.up(pic), d.up(coefs)
+        jobs = [TuJob(p_coef + k * 2048, (p_pic + y0 * stride + x0 * px) if to_pic else None, stride, log2, lim, kind, 0)
+                for k, (log2, kind, lim, to_pic, y0, x0) in enumerate(meta)]
+        assert prov.lib.mi355_hevc_residual_batch_dev(C.c_void_p(d.up_jobs(jobs)), len(jobs), bd, None) == 0
+        pic_g, coef_g = d.down(p_pic, pic), d.down(p_coef, coefs)
+    finally:
+        d.free()
+    assert np.array_equal(pic_g, pic_o), "residual: picture differs (bd %d)" % bd
+    for k, (log2, kind, lim, to_pic, y0, x0) in enumerate(meta):
+        if not to_pic:
+            assert np.array_equal(coef_g[k], coef_o[k]), "residual: coefficients of job %d differ" % k
+    return len(jobs)
+
+
+def check_mc(prov, oracle, bd, seed, n=48):
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    ref = pixels(r, (200, 320), bd)
+    stride = ref.strides[0]
+    out = np.full((n, 64 * 64), 0x2222, np.int16)
+    meta = []
+    for k in range(n):
+        chroma = r.randint(0, 1)
+        wi = r.randint(0, 7)
+        w = (EW if chroma else QW)[wi]
+        h = [4, 8, 12, 16, 24, 32, 64][r.randint(0, 6)]
+        if chroma:
+            h = min(h, 32)
+        mx, my = (r.randint(0, 7), r.randint(0, 7)) if chroma else (r.randint(0, 3), r.randint(0, 3))
+        y0, x0 = r.randint(8, 200 - 8 - h - 8), r.randint(8, 320 - 8 - w - 8)
+        meta.append((chroma, wi, w, h, mx, my, y0, x0))
+    c_o = oracle.hevcdsp(bd)
+    out_o = out.copy()
+    mcbuf = np.zeros((64 + 24) * 64, np.int16)
+    for k, (chroma, wi, w, h, mx, my, y0, x0) in enumerate(meta):
+        tab = c_o.put_hevc_epel if chroma else c_o.put_hevc_qpel
+        tab[int(my != 0)][int(mx != 0)][wi](_i16p(out_o[k]), 128, _u8p(ref, y0 * stride + x0 * px), stride, h, mx, my, _i16p(mcbuf))
+    d = Dev(prov.lib)
+    try:
+        p_ref, p_out = d.up(ref), d.up(out)
+        jobs = [McJob(p_ref + y0 * stride + x0 * px, p_out + k * 8192, stride, 128, w, h, mx, my, chroma)
+                for k, (chroma, wi, w, h, mx, my, y0, x0) in enumerate(meta)]
+        assert prov.lib.mi355_hevc_mc_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
+        out_g = d.down(p_out, out)
+    finally:
+        d.free()
+    assert np.array_equal(out_g, out_o), "mc batch differs (bd %d)" % bd
+    return n
+
+
+def check_pred(prov, oracle, bd, seed, cells=(4, 6)):
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    pic = pixels(r, (cy * 64, cx * 64), bd)
+    stride = pic.strides[0]
+    n = cy * cx
+    s1 = r.randint(-8192, 24575, (n, 64 * 64)).astype(np.int16)
+    s2 = r.randint(-8192, 24575, (n, 64 * 64)).astype(np.int16)
+    meta = []
+    for k in range(n):
+        chroma = r.randint(0, 1)
+        wi = r.randint(0, 7)
+        w = (EW if chroma else QW)[wi]
+        h = [2, 4, 8, 16, 32, 64][r.randint(0, 5)]
+        meta.append((chroma, wi, w, h, r.randint(0, 3), r.randint(0, 7), r.randint(-128, 127), r.randint(-128, 127),
+                     r.randint(-128, 127), r.randint(-128, 127), (k // cx) * 64, (k % cx) * 64))
+    c_o = oracle.hevcdsp(bd)
+    pic_o = pic.copy()
+    for k, (chroma, wi, w, h, kind, denom, w0, w1, o0, o1, y0, x0) in enumerate(meta):
+        dp = _u8p(pic_o, y0 * stride + x0 * px)
+        tabs = ((c_o.put_unweighted_pred_chroma, c_o.put_unweighted_pred_avg_chroma, c_o.weighted_pred_chroma, c_o.weighted_pred_avg_chroma)
+                if chroma else (c_o.put_unweighted_pred, c_o.put_unweighted_pred_avg, c_o.weighted_pred, c_o.weighted_pred_avg))
+        fn = tabs[kind][wi]
+        if kind == 0:
+            fn(dp, stride, _i16p(s1[k]), 128, h)
+        elif kind == 1:
+            fn(dp, stride, _i16p(s1[k]), _i16p(s2[k]), 128, h)
+        elif kind == 2:
+            fn(denom, w0, o0, dp, stride, _i16p(s1[k]), 128, h)
+        else:
+            fn(denom, w0, w1, o0, o1, dp, stride, _i16p(s1[k]), _i16p(s2[k]), 128, h)
+    d = Dev(prov.lib)
+    try:
+        p_pic, p1, p2 = d.up(pic), d.up(s1), d.up(s2)
+        jobs = [PredJob(p_pic + y0 * stride + x0 * px, p1 + k * 8192, p2 + k * 8192, stride, 128, w, h, kind, denom, w0, w1, o0, o1)
+                for k, (chroma, wi, w, h, kind, denom, w0, w1, o0, o1, y0, x0) in enumerate(meta)]
+        assert prov.lib.mi355_hevc_pred_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
+        pic_g = d.down(p_pic, pic)
+    finally:
+        d.free()
+    assert np.array_equal(pic_g, pic_o), "pred batch differs (bd %d)" % bd
+    return n
+
+
+def check_deblock(prov, oracle, bd, seed, cells=(7, 9)):
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    pic = pixels(r, (cy * 16, cx * 16), bd, smooth=True)
+    pic[::5, ::3] = pixels(r, pic[::5, ::3].shape, bd)
+    stride = pic.strides[0]
+    meta = []
+    for k in range(cy * cx):                 # one edge in the middle of each 16x16 cell: nothing overlaps
+        y0, x0 = (k // cx) * 16 + 8, (k % cx) * 16 + 8
+        horiz, chroma = r.randint(0, 1), r.randint(0, 1)
+        step = r.randint(-10 << (bd - 8), 10 << (bd - 8))
+        blk = pic[y0 - 8:y0 + 8, x0 - 8:x0 + 8].astype(np.int64)
+        if horiz:
+            blk[8:, :] += step
+        else:
+            blk[:, 8:] += step
+        pic[y0 - 8:y0 + 8, x0 - 8:x0 + 8] = np.clip(blk, 0, (1 << bd) - 1)
+        # pix = first sample on the q side of an 8-sample edge starting at the cell centre row/column - 4
+        py, pxx = (y0, x0 - 4) if horiz else (y0 - 4, x0)
+        meta.append((horiz, chroma, py, pxx, r.randint(0, 64), [r.randint(0, 24), r.randint(0, 24)],
+                     [int(r.randint(0, 3) == 0), int(r.randint(0, 3) == 0)], [int(r.randint(0, 3) == 0), int(r.randint(0, 3) == 0)]))
+    c_o = oracle.hevcdsp(bd)
+    pic_o = pic.copy()
+    for horiz, chroma, py, pxx, beta, tc, no_p, no_q in meta:
+        tcv = np.array(tc, np.int32)
+        npv, nqv = np.array(no_p, np.uint8), np.array(no_q, np.uint8)
+        pix = _u8p(pic_o, py * stride + pxx * px)
+        tcp = C.cast(tcv.ctypes.data, A.intp)
+        if chroma:
+            (c_o.hevc_h_loop_filter_chroma if horiz else c_o.hevc_v_loop_filter_chroma)(pix, stride, tcp, _u8p(npv), _u8p(nqv))
+        else:
+            (c_o.hevc_h_loop_filter_luma if horiz else c_o.hevc_v_loop_filter_luma)(pix, stride, beta, tcp, _u8p(npv), _u8p(nqv))
+    d = Dev(prov.lib)
+    try:
+        p_pic = d.up(pic)
+        jobs = []
+        for horiz, chroma, py, pxx, beta, tc, no_p, no_q in meta:
+            j = LfJob(p_pic + py * stride + pxx * px, stride, beta)
+            j.tc[0], j.tc[1] = tc
+            j.no_p[0], j.no_p[1] = no_p
+            j.no_q[0], j.no_q[1] = no_q
+            j.horizontal_edge, j.chroma = horiz, chroma
+            jobs.append(j)
+        assert prov.lib.mi355_hevc_deblock_batch_dev(C.c_void_p(d.up_jobs(jobs)), len(jobs), bd, None) == 0
+        pic_g = d.down(p_pic, pic)
+    finally:
+        d.free()
+    assert np.array_equal(pic_g, pic_o), "deblock batch differs (bd %d)" % bd
+    return len(jobs)
+
+
+def check_sao(prov, oracle, bd, seed, cells=(3, 4)):
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    src = pixels(r, (cy * 96, cx * 96), bd, smooth=True)
+    src[::3, ::5] = pixels(r, src[::3, ::5].shape, bd)
+    dst = np.full_like(src, 0x155 if bd > 8 else 0x55)
+    stride = src.strides[0]
+    meta = []
+    for k in range(cy * cx):
+        c_idx = r.randint(0, 2)
+        w = [16, 32, 64][r.randint(0, 2)] >> (1 if c_idx else 0)
+        h = [16, 32, 64][r.randint(0, 2)] >> (1 if c_idx else 0)
+        meta.append(dict(y0=(k // cx) * 96 + 16, x0=(k % cx) * 96 + 16, c_idx=c_idx, w=w, h=h, cls=r.randint(0, 3), edge=r.randint(0, 1),
+                         off=[0] + [r.randint(-7 << (bd - 8), 7 << (bd - 8)) for _ in range(4)], band=r.randint(0, 31), eo=r.randint(0, 3),
+                         borders=[r.randint(0, 1) for _ in range(4)], ve=r.randint(0, 1), he=r.randint(0, 1), de=r.randint(0, 1)))
+    c_o = oracle.hevcdsp(bd)
+    dst_o = dst.copy()
+    for m in meta:
+        sao = A.SAOParams()
+        for i in range(5):
+            sao.offset_val[m["c_idx"]][i] = m["off"][i]
+        sao.band_position[m["c_idx"]] = m["band"]
+        sao.eo_class[m["c_idx"]] = m["eo"]
+        bo = np.array(m["borders"], np.int32)
+        off = m["y0"] * stride + m["x0"] * px
+        if m["edge"]:
+            c_o.sao_edge_filter[m["cls"]](_u8p(dst_o, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp),
+                                          m["w"], m["h"], m["c_idx"], m["ve"], m["he"], m["de"])
+        else:
+            c_o.sao_band_filter[m["cls"]](_u8p(dst_o, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp),
+                                          m["w"], m["h"], m["c_idx"])
+    d = Dev(prov.lib)
+    try:
+        p_src, p_dst = d.up(src), d.up(dst)
+        jobs = []
+        for m in meta:
+            off = m["y0"] * stride + m["x0"] * px
+            j = SaoJob(p_dst + off, p_src + off, stride, m["w"], m["h"])
+            for i in range(4):
+                j.borders[i] = m["borders"][i]
+            for i in range(5):
+                j.offset_val[i] = m["off"][i]
+            j.cls, j.edge, j.c_idx, j.eo_class, j.band_position = m["cls"], m["edge"], m["c_idx"], m["eo"], m["band"]
+            j.vert_edge, j.horiz_edge, j.diag_edge = m["ve"], m["he"], m["de"]
+            jobs.append(j)
+        assert prov.lib.mi355_hevc_sao_batch_dev(C.c_void_p(d.up_jobs(jobs)), len(jobs), bd, None) == 0
+        dst_g = d.down(p_dst, dst)
+    finally:
+        d.free()
+    assert np.array_equal(dst_g, dst_o), "sao batch differs (bd %d)" % bd
+    return len(jobs)
+
+
+CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao}
