@@ -14,43 +14,50 @@ using namespace mi355;
 
 namespace {
 
-/* ---- transform units ------------------------------------------------------------------------------- */
+/* ---- transform units: two per wavefront (a 32-point transform occupies 32 lanes) ---------------------- */
 __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_job *jobs, int n, int bd)
 {
     __shared__ IdctScratch s;
-    const int lane = lane_id();
-    if ((int)blockIdx.x >= n) return;
-    const mi355_hevc_tu_job j = jobs[blockIdx.x];
+    const int lane = lane_id(), half = lane >> 5, hl = lane & 31;
+    const int idx = 2 * (int)blockIdx.x + half;
+    const bool on = idx < n;
+    const mi355_hevc_tu_job j = jobs[on ? idx : 0];
     const int size = 1 << j.log2_size, cnt = size * size;
+    int16_t *c = s.c[half];
     /* coefficients -> LDS, two per lane and access */
-    for (int i = lane; i < cnt / 2; i += 64) reinterpret_cast<uint32_t *>(s.c)[i] = reinterpret_cast<const uint32_t *>(j.coeffs)[i];
+    if (on) for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(c)[i] = reinterpret_cast<const uint32_t *>(j.coeffs)[i];
     __syncthreads();
-    if (j.kind == MI355_HEVC_TU_IDCT_DC) {            /* hevcdsp_template.c:238-252 */
+    /* every lane walks through every kind's barriers; `on && kind` selects who works */
+    {
+        const bool k = on && j.kind == MI355_HEVC_TU_IDCT_DC;      /* hevcdsp_template.c:238-252 */
         const int shift = 14 - bd, add = 1 << (shift - 1);
-        const int v = (((s.c[0] + 1) >> 1) + add) >> shift;
+        const int v = (((c[0] + 1) >> 1) + add) >> shift;
         __syncthreads();
-        for (int i = lane; i < cnt; i += 64) s.c[i] = (int16_t)v;
+        if (k) for (int i = hl; i < cnt; i += 32) c[i] = (int16_t)v;
         __syncthreads();
-    } else if (j.kind == MI355_HEVC_TU_SKIP) {        /* :84-98, 4x4 only */
+    }
+    if (on && j.kind == MI355_HEVC_TU_SKIP) {                      /* :84-98, 4x4 only */
         const int shift = 13 - bd, off = 1 << (shift - 1);
-        if (lane < 16) s.c[lane] = (int16_t)((s.c[lane] + off) >> shift);
-        __syncthreads();
-    } else if (j.kind == MI355_HEVC_TU_DST4) {
-        hevc_dst4_wave(s.c, bd);
-    } else if (j.log2_size == 2) hevc_idct_wave<4>(s, j.col_limit, bd);
-    else if (j.log2_size == 3) hevc_idct_wave<8>(s, j.col_limit, bd);
-    else if (j.log2_size == 4) hevc_idct_wave<16>(s, j.col_limit, bd);
-    else hevc_idct_wave<32>(s, j.col_limit, bd);
+        if (hl < 16) c[hl] = (int16_t)((c[hl] + off) >> shift);
+    }
+    __syncthreads();
+    hevc_dst4_wave(c, bd, hl, on && j.kind == MI355_HEVC_TU_DST4);
+    const bool tr = on && j.kind == MI355_HEVC_TU_IDCT;
+    hevc_idct_half<4>(c, hl, tr && j.log2_size == 2, j.col_limit, bd);
+    hevc_idct_half<8>(c, hl, tr && j.log2_size == 3, j.col_limit, bd);
+    hevc_idct_half<16>(c, hl, tr && j.log2_size == 4, j.col_limit, bd);
+    hevc_idct_half<32>(c, hl, tr && j.log2_size == 5, j.col_limit, bd);
+    if (!on) return;
     if (!j.dst) {
-        for (int i = lane; i < cnt / 2; i += 64) reinterpret_cast<uint32_t *>(j.coeffs)[i] = reinterpret_cast<const uint32_t *>(s.c)[i];
+        for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(j.coeffs)[i] = reinterpret_cast<const uint32_t *>(c)[i];
         return;
     }
     /* add_residual (:51-82): two samples per lane */
-    const int half = size >> 1;
-    for (int i = lane; i < cnt / 2; i += 64) {
-        const int y = i / half, x = 2 * (i - y * half);
+    const int hw = size >> 1;
+    for (int i = hl; i < cnt / 2; i += 32) {
+        const int y = i / hw, x = 2 * (i - y * hw);
         uint8_t *row = j.dst + (size_t)y * j.dst_stride;
-        const int r0 = s.c[y * size + x], r1 = s.c[y * size + x + 1];
+        const int r0 = c[y * size + x], r1 = c[y * size + x + 1];
         if (bd > 8) {
             uint32_t *p = reinterpret_cast<uint32_t *>(row) + (x >> 1);
             const uint32_t v = *p;
@@ -133,7 +140,7 @@ static_assert(sizeof(mi355_hevc_lf_job) == 32, "eight dwords per deblocking job 
 extern "C" int mi355_hevc_residual_batch_dev(const mi355_hevc_tu_job *d_jobs, int n, int bit_depth, void *stream)
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
-    hipLaunchKernelGGL(k_hevc_residual_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    hipLaunchKernelGGL(k_hevc_residual_batch, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, int bit_depth, void *stream)

@@ -23,14 +23,19 @@ __device__ __forceinline__ void stpx(uint8_t *p, int i, int v, int bd)
 }
 
 /* ---- inverse DCT matrix: transMatrix[k][n] = c(k) cos((2n+1) k pi/64) in the standard's integers,
- * generated from the 33 magnitudes of angle index a = (2n+1)k mod 128 ------------------------- */
-__device__ const int8_t k_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-                                          61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
-__device__ __forceinline__ int dct_coef(int k, int n)
+ * generated from the 33 magnitudes of angle index a = (2n+1)k mod 128 — compile-time constants, so the
+ * unrolled transforms below multiply by literals ----------------------------------------------- */
+__host__ __device__ constexpr int dct_mag(int a)
+{
+    constexpr int8_t mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+    return mag[a];
+}
+__host__ __device__ constexpr int dct_coef(int k, int n)
 {
     if (!k) return 64;
     const int a = ((2 * n + 1) * k) & 127;
-    return a <= 32 ? k_dct_mag[a] : (a <= 64 ? -k_dct_mag[64 - a] : (a <= 96 ? -k_dct_mag[a - 64] : k_dct_mag[128 - a]));
+    return a <= 32 ? dct_mag(a) : (a <= 64 ? -dct_mag(64 - a) : (a <= 96 ? -dct_mag(a - 64) : dct_mag(128 - a)));
 }
 /* rows of the input a 1-D pass of size H looks at when pruned to `end` (hevcdsp_template.c:140-206) */
 __device__ __forceinline__ bool dct_row_used(int H, int j, int end)
@@ -41,50 +46,68 @@ __device__ __forceinline__ bool dct_row_used(int H, int j, int end)
     return true;
 }
 
-struct IdctScratch {
-    int16_t c[32 * 32];
-    int8_t m[32 * 32];     /* m[j*32+n] = transMatrix[j*(32/H)][n] for the current size */
+/* One H-point inverse transform in registers, as the even/odd decomposition of the reference's TR_n
+ * macros (hevcdsp_template.c:140-206): out[n] = E[n] + O[n], out[H-1-n] = E[n] - O[n], where O takes the
+ * odd inputs through an (H/2 x H/2) block of the matrix and E is the H/2-point transform of the even
+ * inputs.  Sums are exact integers, so the grouping does not change the result.  `x` holds the H inputs
+ * of THIS size's transform (row j of size H = row j * 32/H of the 32-point matrix); S = 32 / H. */
+template <int H, int S> struct Idct1D {
+    static __device__ __forceinline__ void run(const int *x, int *out)
+    {
+        int xe[H / 2], E[H / 2], O[H / 2];
+#pragma unroll
+        for (int k = 0; k < H / 2; k++) xe[k] = x[2 * k];
+        Idct1D<H / 2, 2 * S>::run(xe, E);
+#pragma unroll
+        for (int n = 0; n < H / 2; n++) {
+            int o = 0;
+#pragma unroll
+            for (int k = 0; k < H / 2; k++) o += dct_coef((2 * k + 1) * S, n) * x[2 * k + 1];
+            O[n] = o;
+        }
+#pragma unroll
+        for (int n = 0; n < H / 2; n++) { out[n] = E[n] + O[n]; out[H - 1 - n] = E[n] - O[n]; }
+    }
+};
+template <int S> struct Idct1D<2, S> {
+    static __device__ __forceinline__ void run(const int *x, int *out)
+    {
+        out[0] = 64 * x[0] + dct_coef(S, 0) * x[1];
+        out[1] = 64 * x[0] + dct_coef(S, 1) * x[1];
+    }
 };
 
-/* In-place 2-D inverse DCT of s.c (HxH, row-major) with the reference's col_limit semantics
- * (:208-236): first pass down the columns with limit2 shrinking every 4 columns, clip to int16
+struct IdctScratch {
+    int16_t c[2][32 * 32];      /* one block per half-wave */
+};
+
+/* In-place 2-D inverse DCT of c (HxH, row-major) by ONE HALF-WAVE (32 lanes; `hl` = lane within the half,
+ * both halves of a wave call this together, each on its own block) with the reference's col_limit
+ * semantics (:208-236): first pass down the columns with limit2 shrinking every 4 columns, clip to int16
  * after (x+64)>>7; second pass along the rows, (x + (1<<(19-bd))) >> (20-bd). */
 template <int H>
-__device__ inline void hevc_idct_wave(IdctScratch &s, int col_limit, int bd)
+__device__ inline void hevc_idct_half(int16_t *c, int hl, bool active, int col_limit, int bd)
 {
-    const int lane = lane_id(), step = 32 / H;
-    for (int i = lane; i < H * H; i += 64) s.m[(i / H) * 32 + (i % H)] = (int8_t)dct_coef((i / H) * step, i % H);
-    __syncthreads();
     const int limit = col_limit < H ? col_limit : H;
     const int l0 = col_limit + 4 < H ? col_limit + 4 : H;
-    int out[H];
-    if (lane < H) {
-        const int i = lane;
+    int in[H], out[H];
+    if (active && hl < H) {
+        const int i = hl;
         const int end = l0 < H ? l0 - 4 * (i > 0 ? (i - 1) >> 2 : 0) : H;
 #pragma unroll
-        for (int n = 0; n < H; n++) out[n] = 0;
-        for (int j = 0; j < H; j++) {
-            if (!dct_row_used(H, j, end)) continue;
-            const int v = s.c[i + H * j];
+        for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, end) ? c[i + H * j] : 0;
+        Idct1D<H, 32 / H>::run(in, out);
 #pragma unroll
-            for (int n = 0; n < H; n++) out[n] += s.m[j * 32 + n] * v;
-        }
-#pragma unroll
-        for (int n = 0; n < H; n++) s.c[i + H * n] = (int16_t)clip_i16((out[n] + 64) >> 7);
+        for (int n = 0; n < H; n++) c[i + H * n] = (int16_t)clip_i16((out[n] + 64) >> 7);
     }
     __syncthreads();
-    if (lane < H) {
-        const int i = lane, shift = 20 - bd, add = 1 << (shift - 1);
+    if (active && hl < H) {
+        const int i = hl, shift = 20 - bd, add = 1 << (shift - 1);
 #pragma unroll
-        for (int n = 0; n < H; n++) out[n] = 0;
-        for (int j = 0; j < H; j++) {
-            if (!dct_row_used(H, j, limit)) continue;
-            const int v = s.c[H * i + j];
+        for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, limit) ? c[H * i + j] : 0;
+        Idct1D<H, 32 / H>::run(in, out);
 #pragma unroll
-            for (int n = 0; n < H; n++) out[n] += s.m[j * 32 + n] * v;
-        }
-#pragma unroll
-        for (int n = 0; n < H; n++) s.c[H * i + n] = (int16_t)clip_i16((out[n] + add) >> shift);
+        for (int n = 0; n < H; n++) c[H * i + n] = (int16_t)clip_i16((out[n] + add) >> shift);
     }
     __syncthreads();
 }
@@ -98,17 +121,16 @@ __device__ __forceinline__ void dst4_1d(const int in[4], int out[4])
     out[2] = 74 * (in[0] - in[2] + in[3]);
     out[3] = 55 * c0 + 29 * c2 - c3;
 }
-__device__ inline void hevc_dst4_wave(int16_t *c, int bd)
+__device__ inline void hevc_dst4_wave(int16_t *c, int bd, int lane, bool active = true)
 {
-    const int lane = lane_id();
     int in[4], out[4];
-    if (lane < 4) {
+    if (active && lane < 4) {
         for (int k = 0; k < 4; k++) in[k] = c[lane + 4 * k];
         dst4_1d(in, out);
         for (int k = 0; k < 4; k++) c[lane + 4 * k] = (int16_t)clip_i16((out[k] + 64) >> 7);
     }
     __syncthreads();
-    if (lane < 4) {
+    if (active && lane < 4) {
         const int shift = 20 - bd, add = 1 << (shift - 1);
         for (int k = 0; k < 4; k++) in[k] = c[4 * lane + k];
         dst4_1d(in, out);

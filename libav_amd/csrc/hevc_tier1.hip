@@ -53,14 +53,15 @@ __global__ void __launch_bounds__(64) k_hevc_transform(int16_t *c, int mode, int
         for (int i = lane; i < n; i += 64) c[i] = (int16_t)v;
         return;
     }
-    for (int i = lane; i < n; i += 64) s.c[i] = c[i];
+    for (int i = lane; i < n; i += 64) s.c[0][i] = c[i];
     __syncthreads();
-    if (mode == 1) hevc_dst4_wave(s.c, bd);
-    else if (size == 4) hevc_idct_wave<4>(s, col_limit, bd);
-    else if (size == 8) hevc_idct_wave<8>(s, col_limit, bd);
-    else if (size == 16) hevc_idct_wave<16>(s, col_limit, bd);
-    else hevc_idct_wave<32>(s, col_limit, bd);
-    for (int i = lane; i < n; i += 64) c[i] = s.c[i];
+    const bool act = lane < 32;           /* one block: the first half-wave works */
+    if (mode == 1) hevc_dst4_wave(s.c[0], bd, lane, act);
+    else if (size == 4) hevc_idct_half<4>(s.c[0], lane & 31, act, col_limit, bd);
+    else if (size == 8) hevc_idct_half<8>(s.c[0], lane & 31, act, col_limit, bd);
+    else if (size == 16) hevc_idct_half<16>(s.c[0], lane & 31, act, col_limit, bd);
+    else hevc_idct_half<32>(s.c[0], lane & 31, act, col_limit, bd);
+    for (int i = lane; i < n; i += 64) c[i] = s.c[0][i];
 }
 static void transform_run(int16_t *coeffs, int mode, int size, int col_limit, int bd)
 {
