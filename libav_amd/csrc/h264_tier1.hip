@@ -565,6 +565,98 @@ template <int M> static void p8l_shim(uint8_t *s, int tl, int tr, ptrdiff_t st) 
 template <int M> static void p8_shim(uint8_t *s, ptrdiff_t st) { pred_shim(s, st, 2, M, 0, 0, nullptr); }
 template <int M> static void p16_shim(uint8_t *s, ptrdiff_t st) { pred_shim(s, st, 3, M, 0, 0, nullptr); }
 
+/* ---- a10, lossless variants: prediction + residual as a running sum (h264pred_template.c:1127-1354) ----
+ * Lane = (block, line); the sum starts at the neighbouring sample (or the (1,2,1)-filtered edge for the
+ * 8x8 `filter_add` slots) and wraps at 8 bits at every step like the reference's pixel type.  Blocks that
+ * feed each other (a block below / right of another one of the same call) run in rounds. */
+struct PredAddJob {
+    int16_t coef[16 * 16];
+    uint8_t bx[16], by[16];          /* block origin inside the window */
+    int32_t n, size, horizontal, filtered, has_tl, has_tr;
+};
+__global__ void __launch_bounds__(64) k_pred_add(uint8_t *win, int pitch, const PredAddJob *job)
+{
+    const int lane = lane_id(), size = job->size, b = lane / size, i = lane - b * size;
+    const bool mine = b < job->n;
+    const int bx = mine ? job->bx[b] : 0, by = mine ? job->by[b] : 0, hz = job->horizontal;
+#define PX(x, y) win[(by + (y)) * pitch + bx + (x)]
+    for (int round = 0; round < 4; round++) {
+        /* blocks whose origin along the prediction direction is `round` blocks from the window's first block */
+        const int along = hz ? bx - 1 : by - 1;      /* the window starts one sample before the first block */
+        if (mine && (job->filtered || (along >> 2) == round) && (!job->filtered || round == 0)) {
+            int v;
+            if (!job->filtered) v = hz ? PX(-1, i) : PX(i, -1);
+            else if (!hz) {      /* PREDICT_8x8_LOAD_TOP :857-862 */
+                const int c = PX(i, -1);
+                const int lft = i == 0 ? (job->has_tl ? PX(-1, -1) : c) : PX(i - 1, -1);
+                const int rgt = i == 7 ? (job->has_tr ? PX(8, -1) : c) : PX(i + 1, -1);
+                v = (lft + 2 * c + rgt + 2) >> 2;
+            } else {             /* PREDICT_8x8_LOAD_LEFT :849-853 */
+                const int c = PX(-1, i);
+                const int up = i == 0 ? (job->has_tl ? PX(-1, -1) : c) : PX(-1, i - 1);
+                v = i == 7 ? (PX(-1, 6) + 3 * c + 2) >> 2 : (up + 2 * c + PX(-1, i + 1) + 2) >> 2;
+            }
+            const int16_t *blk = job->coef + b * size * size;
+            for (int k = 0; k < size; k++) {
+                v = (v + (hz ? blk[i * size + k] : blk[k * size + i])) & 0xFF;
+                if (hz) PX(k, i) = (uint8_t)v; else PX(i, k) = (uint8_t)v;
+            }
+        }
+        __syncthreads();
+    }
+#undef PX
+}
+static void pred_add_run(uint8_t *pix, const int *offs, int nblk, int16_t *block, ptrdiff_t stride, int size, int horizontal,
+                         int filtered, int has_tl, int has_tr)
+{
+    Arena &a = arena();
+    int bx[16], by[16], minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
+    for (int i = 0; i < nblk; i++) {
+        const int off = offs ? offs[i] : 0;
+        const int y = off >= 0 ? (off + (int)stride / 2) / (int)stride : -((-off + (int)stride / 2) / (int)stride);
+        bx[i] = off - y * (int)stride; by[i] = y;
+        if (bx[i] < minx) minx = bx[i];
+        if (by[i] < miny) miny = by[i];
+        if (bx[i] + size > maxx) maxx = bx[i] + size;
+        if (by[i] + size > maxy) maxy = by[i] + size;
+    }
+    /* exactly the samples the reference reads: one line before the blocks along the prediction direction,
+     * and for the filtered 8x8 forms the corner / the sample past the edge only when the flags say so */
+    int x0 = minx, y0 = miny, x1 = maxx;
+    if (horizontal) x0 -= 1; else y0 -= 1;
+    if (filtered && !horizontal) { x0 -= has_tl ? 1 : 0; x1 += has_tr ? 1 : 0; }
+    if (filtered && horizontal) y0 -= has_tl ? 1 : 0;
+    /* the kernel addresses blocks relative to a window that starts one sample before them in both axes */
+    const int wx0 = minx - 1, wy0 = miny - 1;
+    Win w = win_pack(a, nullptr, 0, maxx + 1 - wx0, maxy - wy0, 0, 0);
+    for (int y = y0; y < maxy; y++)
+        std::memcpy(a.h<uint8_t>(w.off) + (size_t)(y - wy0) * w.pitch + (x0 - wx0), pix + y * stride + x0, (size_t)(x1 - x0));
+    const size_t joff = a.take(sizeof(PredAddJob));
+    PredAddJob *job = a.h<PredAddJob>(joff);
+    std::memset(job, 0, sizeof(*job));
+    std::memcpy(job->coef, block, sizeof(int16_t) * (size_t)nblk * size * size);
+    for (int i = 0; i < nblk; i++) { job->bx[i] = (uint8_t)(bx[i] - wx0); job->by[i] = (uint8_t)(by[i] - wy0); }
+    job->n = nblk; job->size = size; job->horizontal = horizontal; job->filtered = filtered; job->has_tl = has_tl; job->has_tr = has_tr;
+    a.upload();
+    LAUNCH1(k_pred_add, a, a.d<uint8_t>(w.off), w.pitch, a.d<const PredAddJob>(joff));
+    a.download();
+    for (int i = 0; i < nblk; i++)
+        win_unpack(a, w, pix + by[i] * stride + bx[i], stride, bx[i] - wx0, by[i] - wy0, size, size);
+    std::memset(block, 0, sizeof(int16_t) * (size_t)nblk * size * size);
+}
+template <int SIZE, int HZ> static void pred_add_shim(uint8_t *pix, int16_t *block, ptrdiff_t stride)
+{
+    pred_add_run(pix, nullptr, 1, block, stride, SIZE, HZ, 0, 0, 0);
+}
+template <int HZ> static void pred8x8l_filter_add_shim(uint8_t *pix, int16_t *block, int tl, int tr, ptrdiff_t stride)
+{
+    pred_add_run(pix, nullptr, 1, block, stride, 8, HZ, 1, tl != 0, tr != 0);
+}
+template <int NBLK, int HZ> static void pred_multi_add_shim(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    pred_add_run(pix, block_offset, NBLK, block, stride, 4, HZ, 0, 0, 0);
+}
+
 void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
 {
     if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264 || chroma_format_idc > 1) return;
@@ -579,6 +671,12 @@ void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_de
     h->pred8x8[8] = p8_shim<8>; h->pred8x8[9] = p8_shim<9>; h->pred8x8[10] = p8_shim<10>;
     h->pred16x16[0] = p16_shim<0>; h->pred16x16[1] = p16_shim<1>; h->pred16x16[2] = p16_shim<2>; h->pred16x16[3] = p16_shim<3>;
     h->pred16x16[4] = p16_shim<4>; h->pred16x16[5] = p16_shim<5>; h->pred16x16[6] = p16_shim<6>;
+    /* lossless (transform bypass) forms: VERT_PRED 0 / HOR_PRED 1; VERT_PRED8x8 2 / HOR_PRED8x8 1 (h264pred.c:551-565) */
+    h->pred4x4_add[0] = pred_add_shim<4, 0>;   h->pred4x4_add[1] = pred_add_shim<4, 1>;
+    h->pred8x8l_add[0] = pred_add_shim<8, 0>;  h->pred8x8l_add[1] = pred_add_shim<8, 1>;
+    h->pred8x8l_filter_add[0] = pred8x8l_filter_add_shim<0>; h->pred8x8l_filter_add[1] = pred8x8l_filter_add_shim<1>;
+    h->pred8x8_add[2] = pred_multi_add_shim<4, 0>;    h->pred8x8_add[1] = pred_multi_add_shim<4, 1>;
+    h->pred16x16_add[2] = pred_multi_add_shim<16, 0>; h->pred16x16_add[1] = pred_multi_add_shim<16, 1>;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
 /* ---- motion compensation ----------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64) k_hevc_mc_batch(const mi355_hevc_mc_job *jobs, int n, int bd)
 {
-    __shared__ int16_t tmp[(64 + 7) * 64];
+    __shared__ HevcMcScratch tmp;
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_mc_job j = jobs[blockIdx.x];
     const int px = bd > 8 ? 2 : 1;

@@ -146,30 +146,44 @@ __device__ const int8_t k_epel[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { 
                                          { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
 /* src points at sample (0,0) of the block inside a plane/window with `ss` samples per row; dst is
- * int16 with `ds` elements per row; tmp: (height+7) x 64 int16 scratch (LDS) for the 2-D case.
- * taps = 8 (qpel, :729-937) or 4 (epel, :939-1089). */
+ * int16 with `ds` elements per row.  taps = 8 (qpel, :729-937) or 4 (epel, :939-1089).  The samples the
+ * taps touch — and only those: a filter that is not applied reads nothing beyond the block, exactly
+ * like the reference's per-direction functions — are staged once in LDS (coalesced row reads), the 2-D
+ * case keeps its first-pass rows there as well. */
+constexpr int HEVC_MC_PITCH = 72;      /* 64 + 7 columns, rounded */
+struct HevcMcScratch {
+    uint16_t win[(64 + 7) * HEVC_MC_PITCH];
+    int16_t tmp[(64 + 7) * 64];
+};
 __device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
-                                    int mx, int my, int bd, int taps, int16_t *tmp)
+                                    int mx, int my, int bd, int taps, HevcMcScratch &s)
 {
     const int lane = lane_id();
     const int before = taps == 8 ? 3 : 1, extra = taps == 8 ? 7 : 3;
     const int8_t *fh = taps == 8 ? k_qpel[mx] : k_epel[mx], *fv = taps == 8 ? k_qpel[my] : k_epel[my];
+    const int bx = mx ? before : 0, by = my ? before : 0;
+    const int cols = width + (mx ? extra : 0), rows = height + (my ? extra : 0);
+    for (int i = lane; i < rows * cols; i += 64) {
+        const int r = i / cols, c = i - r * cols;
+        s.win[r * HEVC_MC_PITCH + c] = (uint16_t)ldpx(src, (c - bx) + (r - by) * ss, bd);
+    }
+    __syncthreads();
     if (mx && my) {
-        for (int i = lane; i < (height + extra) * width; i += 64) {
+        for (int i = lane; i < rows * width; i += 64) {
             const int y = i / width, x = i - y * width;
             int a = 0;
-            for (int k = 0; k < taps; k++) if (fh[k]) a += fh[k] * ldpx(src, x + k - before + (y - before) * ss, bd);
-            tmp[x + y * 64] = (int16_t)(a >> (bd - 8));
+            for (int k = 0; k < taps; k++) a += fh[k] * s.win[y * HEVC_MC_PITCH + x + k];
+            s.tmp[x + y * 64] = (int16_t)(a >> (bd - 8));
         }
         __syncthreads();
     }
     for (int i = lane; i < height * width; i += 64) {
         const int y = i / width, x = i - y * width;
         int a = 0;
-        if (!mx && !my) a = ldpx(src, x + y * ss, bd) << (14 - bd);
-        else if (!my) { for (int k = 0; k < taps; k++) if (fh[k]) a += fh[k] * ldpx(src, x + k - before + y * ss, bd); a >>= bd - 8; }
-        else if (!mx) { for (int k = 0; k < taps; k++) if (fv[k]) a += fv[k] * ldpx(src, x + (y + k - before) * ss, bd); a >>= bd - 8; }
-        else { for (int k = 0; k < taps; k++) a += fv[k] * tmp[x + (y + k) * 64]; a >>= 6; }
+        if (!mx && !my) a = s.win[y * HEVC_MC_PITCH + x] << (14 - bd);
+        else if (!my) { for (int k = 0; k < taps; k++) a += fh[k] * s.win[y * HEVC_MC_PITCH + x + k]; a >>= bd - 8; }
+        else if (!mx) { for (int k = 0; k < taps; k++) a += fv[k] * s.win[(y + k) * HEVC_MC_PITCH + x]; a >>= bd - 8; }
+        else { for (int k = 0; k < taps; k++) a += fv[k] * s.tmp[x + (y + k) * 64]; a >>= 6; }
         dst[x + y * ds] = (int16_t)a;
     }
     __syncthreads();

@@ -142,7 +142,7 @@ static void sao_edge_shim(uint8_t *dst, uint8_t *src, ptrdiff_t stride, SAOParam
 __global__ void __launch_bounds__(64)
 k_hevc_mc(int16_t *dst, int ds, const uint8_t *win, int ss, int ox, int oy, int width, int height, int mx, int my, int bd, int taps)
 {
-    __shared__ int16_t tmp[(64 + 7) * 64];
+    __shared__ HevcMcScratch tmp;
     hevc_mc_wave(dst, ds, win + (ptrdiff_t)(oy * ss + ox) * (bd > 8 ? 2 : 1), ss, width, height, mx, my, bd, taps, tmp);
 }
 /* V, H: which filters this table slot applies ([v][h] index of put_hevc_qpel/epel) */

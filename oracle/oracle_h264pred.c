@@ -11,7 +11,7 @@
  * function of two reference vectors T[-1..2N-1] (row above, T[-1] = corner)
  * and L[-1..N-1] (column to the left), for N = 4 (raw edge samples) and N = 8
  * (edge samples after the low-pass pre-filter).
- * The lossless `*_add` slots (transform bypass) are not restated here.
+ * The lossless `*_add` slots (transform bypass, :1127-1354) are at the end of the file.
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -254,6 +254,61 @@ P8L(0) P8L(1) P8L(2) P8L(3) P8L(4) P8L(5) P8L(6) P8L(7) P8L(8) P8L(9) P8L(10) P8
 P8(0) P8(1) P8(2) P8(3) P8(4) P8(5) P8(6) P8(7) P8(8) P8(9) P8(10)
 P16(0) P16(1) P16(2) P16(3) P16(4) P16(5) P16(6)
 
+/* ---- lossless prediction + residual (h264pred_template.c:1127-1354): a running sum along the prediction
+ * direction that starts at the neighbouring sample and wraps like the reference's `pixel` type at every
+ * step; the coefficient block is cleared ----------------------------------------------------------------- */
+static void run_add(uint8_t *pix, const int16_t *blk, ptrdiff_t stride, int n, int horizontal, const uint8_t *start)
+{
+    for (int i = 0; i < n; i++) {
+        uint8_t v = start[i];
+        for (int k = 0; k < n; k++) {
+            v = (uint8_t)(v + (horizontal ? blk[i * n + k] : blk[k * n + i]));
+            if (horizontal) pix[i * stride + k] = v; else pix[k * stride + i] = v;
+        }
+    }
+}
+static void pred_add(uint8_t *pix, int16_t *blk, ptrdiff_t stride, int n, int horizontal)
+{
+    uint8_t start[8];
+    for (int i = 0; i < n; i++) start[i] = horizontal ? pix[i * stride - 1] : pix[i - stride];
+    run_add(pix, blk, stride, n, horizontal, start);
+    memset(blk, 0, sizeof(*blk) * n * n);
+}
+static void p4_vadd(uint8_t *p, int16_t *b, ptrdiff_t s) { pred_add(p, b, s, 4, 0); }
+static void p4_hadd(uint8_t *p, int16_t *b, ptrdiff_t s) { pred_add(p, b, s, 4, 1); }
+static void p8l_vadd(uint8_t *p, int16_t *b, ptrdiff_t s) { pred_add(p, b, s, 8, 0); }
+static void p8l_hadd(uint8_t *p, int16_t *b, ptrdiff_t s) { pred_add(p, b, s, 8, 1); }
+/* the 8x8 variants that start from the (1,2,1)-filtered edge: PREDICT_8x8_LOAD_TOP :857-862, _LEFT :849-853 */
+static void p8l_vfadd(uint8_t *p, int16_t *b, int has_tl, int has_tr, ptrdiff_t s)
+{
+    uint8_t t[8];
+#define SRC(x, y) p[(x) + (y) * s]
+    t[0] = (uint8_t)(((has_tl ? SRC(-1, -1) : SRC(0, -1)) + 2 * SRC(0, -1) + SRC(1, -1) + 2) >> 2);
+    for (int x = 1; x < 7; x++) t[x] = (uint8_t)((SRC(x - 1, -1) + 2 * SRC(x, -1) + SRC(x + 1, -1) + 2) >> 2);
+    t[7] = (uint8_t)(((has_tr ? SRC(8, -1) : SRC(7, -1)) + 2 * SRC(7, -1) + SRC(6, -1) + 2) >> 2);
+    run_add(p, b, s, 8, 0, t);
+    memset(b, 0, sizeof(*b) * 64);
+}
+static void p8l_hfadd(uint8_t *p, int16_t *b, int has_tl, int has_tr, ptrdiff_t s)
+{
+    uint8_t l[8];
+    (void)has_tr;
+    l[0] = (uint8_t)(((has_tl ? SRC(-1, -1) : SRC(-1, 0)) + 2 * SRC(-1, 0) + SRC(-1, 1) + 2) >> 2);
+    for (int y = 1; y < 7; y++) l[y] = (uint8_t)((SRC(-1, y - 1) + 2 * SRC(-1, y) + SRC(-1, y + 1) + 2) >> 2);
+    l[7] = (uint8_t)((SRC(-1, 6) + 3 * SRC(-1, 7) + 2) >> 2);
+#undef SRC
+    run_add(p, b, s, 8, 1, l);
+    memset(b, 0, sizeof(*b) * 64);
+}
+static void multi_add(uint8_t *pix, const int *off, int16_t *blk, ptrdiff_t s, int nblk, int horizontal)
+{
+    for (int i = 0; i < nblk; i++) pred_add(pix + off[i], blk + i * 16, s, 4, horizontal);
+}
+static void p16_vadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 16, 0); }
+static void p16_hadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 16, 1); }
+static void p8_vadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 4, 0); }
+static void p8_hadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 4, 1); }
+
 /* Fills the H.264 slots (codec_id == AV_CODEC_ID_H264, chroma_format_idc <= 1);
  * leaves every other slot (VP8/RV40/SVQ3 flavours, lossless *_add) untouched. */
 void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
@@ -270,4 +325,10 @@ void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int 
     h->pred8x8[8] = p8_8; h->pred8x8[9] = p8_9; h->pred8x8[10] = p8_10;
     h->pred16x16[0] = p16_0; h->pred16x16[1] = p16_1; h->pred16x16[2] = p16_2; h->pred16x16[3] = p16_3;
     h->pred16x16[4] = p16_4; h->pred16x16[5] = p16_5; h->pred16x16[6] = p16_6;
+    /* VERT_PRED 0 / HOR_PRED 1; VERT_PRED8x8 2 / HOR_PRED8x8 1 (h264pred.h:38-39, :69-70; h264pred.c:551-565) */
+    h->pred4x4_add[0] = p4_vadd; h->pred4x4_add[1] = p4_hadd;
+    h->pred8x8l_add[0] = p8l_vadd; h->pred8x8l_add[1] = p8l_hadd;
+    h->pred8x8l_filter_add[0] = p8l_vfadd; h->pred8x8l_filter_add[1] = p8l_hfadd;
+    h->pred8x8_add[2] = p8_vadd; h->pred8x8_add[1] = p8_hadd;
+    h->pred16x16_add[2] = p16_vadd; h->pred16x16_add[1] = p16_hadd;
 }

@@ -321,6 +321,40 @@ def cases_pred(h, r, out):
             out["pred16x16/%d/%d" % (mode, rep)] = buf.tobytes()
 
 
+def cases_pred_add(h, r, out):
+    """lossless prediction + residual (transform bypass): h264pred_template.c:1127-1354"""
+    stride = 48
+    for name, tab, n in (("pred4x4_add", h.pred4x4_add, 4), ("pred8x8l_add", h.pred8x8l_add, 8)):
+        for d in range(2):
+            for rep in range(3):
+                buf = r.u8((24, stride))
+                blk = r.randint(-255, 255, n * n).astype(np.int16)
+                if not tab[d]:
+                    continue
+                tab[d](p8(buf, 8 * stride + 16), p16(blk), stride)
+                out["%s/%d/%d" % (name, d, rep)] = buf.tobytes() + blk.tobytes()
+    for d in range(2):
+        for rep in range(4):
+            buf = r.u8((24, stride))
+            blk = r.randint(-255, 255, 64).astype(np.int16)
+            if not h.pred8x8l_filter_add[d]:
+                continue
+            h.pred8x8l_filter_add[d](p8(buf, 8 * stride + 16), p16(blk), (rep & 1) * 0x8000, (rep >> 1) * 0x4000, stride)
+            out["pred8x8l_filter_add/%d/%d" % (d, rep)] = buf.tobytes() + blk.tobytes()
+    for name, tab, nblk, w in (("pred8x8_add", h.pred8x8_add, 4, 8), ("pred16x16_add", h.pred16x16_add, 16, 16)):
+        offs = np.array([4 * (i & 1) + 8 * ((i >> 2) & 1) + (4 * ((i >> 1) & 1) + 8 * (i >> 3)) * stride for i in range(16)], np.int32)
+        if nblk == 4:
+            offs = np.array([0, 4, 4 * stride, 4 * stride + 4] + [0] * 12, np.int32)
+        for d in (1, 2):
+            for rep in range(3):
+                buf = r.u8((32, stride))
+                blk = r.randint(-255, 255, 16 * nblk).astype(np.int16)
+                if not tab[d]:
+                    continue
+                tab[d](p8(buf, 8 * stride + 16), C.cast(offs.ctypes.data, A.intp), p16(blk), stride)
+                out["%s/%d/%d" % (name, d, rep)] = buf.tobytes() + blk.tobytes()
+
+
 GROUPS = OrderedDict([
     ("idct", ("h264dsp", cases_idct)),
     ("idct_multi", ("h264dsp", cases_idct_multi)),
@@ -333,6 +367,7 @@ GROUPS = OrderedDict([
     ("chroma", ("h264chroma", cases_chroma)),
     ("videodsp", ("videodsp", cases_videodsp)),
     ("pred", ("h264pred", cases_pred)),
+    ("pred_add", ("h264pred", cases_pred_add)),
 ])
 
 
