@@ -30,6 +30,7 @@ struct SwsDev {
     const int16_t *hLumC, *hChrC, *vLumC, *vChrC;
     const int32_t *hLumP, *hChrP, *vLumP, *vChrP;
     int th;                                 /* output rows per tile chosen at create time */
+    int hstage;                             /* horizontal filter positions never decrease: source spans can be staged in LDS */
     mi355_sws_luts luts;
 };
 
@@ -102,6 +103,128 @@ struct TileRows {
     __device__ __forceinline__ int cv(int j, int x) const { return cvT[clampi(cfirst + j, 0, cmax) - clo][x]; }
 };
 
+/* Horizontal pass of one plane for a tile: COLS output columns starting at gx0, source lines lo..hi, results
+ * to out[line - lo][x].  The source span the columns need ([pos[gx0], pos[last] + fs), monotonic positions)
+ * is staged in LDS SG lines at a time with aligned dword loads — 10 coalesced loads per thread instead of
+ * fs single-byte loads per output sample; spans wider than the stage, unaligned planes and non-monotonic
+ * filters take the direct path. */
+constexpr int SG = 8;                 /* source lines per staging round */
+constexpr int SRC_DW = 76;            /* dwords per staged line: 2:1 with 8 taps needs 128 * 2 + 8 bytes (+2 of slack for zero taps) */
+template <int COLS>
+__device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t *src, int stride, int srcW, const int32_t *posT,
+                                            const int16_t *coefT, int fs, int gx0, int ncols, int lo, int hi,
+                                            uint32_t (*stage)[SRC_DW], int tid, bool zero_tail, bool may_stage)
+{
+    const int x = tid & (COLS - 1), gx = gx0 + x, per = NT / COLS;
+    const bool col_ok = gx < ncols;
+    const int pos = col_ok ? posT[gx] : 0;
+    const int16_t *f = coefT + (size_t)(col_ok ? gx : 0) * fs;
+    const int last = imin(gx0 + COLS, ncols) - 1;
+    const int s0 = posT[gx0], s1 = posT[last] + fs, a0 = s0 & ~3, nd = (s1 - a0 + 3) >> 2;
+    /* the column's filter in registers: the line loops below multiply by them instead of reloading */
+    int cf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cf[j] = (col_ok && j < fs) ? f[j] : 0;
+    const bool staged = may_stage && nd <= SRC_DW - 2 && s1 >= s0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0;
+    if (!staged) {
+        if (col_ok) {
+            for (int l = lo + tid / COLS; l <= hi; l += per) out[l - lo][x] = (int16_t)hscale_one(src + (size_t)l * stride, f, pos, fs);
+        } else if (zero_tail) {
+            for (int l = lo + tid / COLS; l <= hi; l += per) out[l - lo][x] = 0;
+        }
+        return;
+    }
+    for (int base = lo; base <= hi; base += SG) {
+        for (int idx = tid; idx < SG * nd; idx += NT) {
+            const int r = idx / nd, d = idx - r * nd, line = base + r;
+            if (line > hi) continue;
+            const uint8_t *p = src + (size_t)line * stride + a0 + 4 * d;
+            uint32_t w;
+            if (a0 + 4 * d + 4 <= srcW) w = *reinterpret_cast<const uint32_t *>(p);
+            else {
+                w = 0;
+                for (int b = 0; b < 4; b++) if (a0 + 4 * d + b < srcW) w |= (uint32_t)p[b] << (8 * b);
+            }
+            stage[r][d] = w;
+        }
+        __syncthreads();
+        for (int r = tid / COLS; r < SG && base + r <= hi; r += per) {
+            if (col_ok) {
+                const uint8_t *row = reinterpret_cast<const uint8_t *>(stage[r]) + (pos - a0);
+                int val = 0;
+                if (fs <= 2) {
+                    val = (int)row[0] * cf[0] + (int)row[1] * cf[1];               /* taps past fs are zero; the bytes exist (slack) */
+                } else if (fs <= 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) val += (int)row[j] * cf[j];
+                } else if (fs <= 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) val += (int)row[j] * cf[j];
+                } else {
+                    for (int j = 0; j < fs; j++) val += (int)row[j] * f[j];
+                }
+                val >>= 7;
+                out[base + r - lo][x] = (int16_t)(val < 32767 ? val : 32767);
+            } else if (zero_tail) {
+                out[base + r - lo][x] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+/* Vertical pass + LUT for the output rows of a tile with the row's filter taps and source-line indices in
+ * registers: NL / NC = luma / chroma tap counts rounded up to 1, 2, 4 or 8 (taps past the real size carry a
+ * zero coefficient and a valid line index).  A thread owns one output row and every 16th pair of it. */
+template <int NL, int NC>
+__device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut, const int16_t (*s_lum)[TW], const int16_t (*s_cu)[TW / 2],
+                                              const int16_t (*s_cv)[TW / 2], uint8_t (*s_out)[TW * 3], int tid, int y0, int y1, int llo, int clo,
+                                              int npairs, int mode)
+{
+    const int row = tid >> 4, gy = y0 + row;
+    if (gy > y1) return;
+    const int ls = c.vls, cs = c.vcs;
+    const int lfirst = imax(1 - ls, c.vLumP[gy]), cfirst = imax(1 - cs, c.vChrP[gy]);
+    int lf[NL], li[NL], cf[NC], ci[NC];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        lf[j] = j < ls ? c.vLumC[(size_t)gy * ls + j] : 0;
+        li[j] = clampi(lfirst + (j < ls ? j : 0), 0, c.srcH - 1) - llo;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        cf[j] = j < cs ? c.vChrC[(size_t)gy * cs + j] : 0;
+        ci[j] = clampi(cfirst + (j < cs ? j : 0), 0, c.chrSrcH - 1) - clo;
+    }
+    for (int i = tid & 15; i < npairs; i += 16) {
+        int Y1, Y2, U, V;
+        if (mode == 1) {          /* yuv2rgb_1_c_template output.c:1043-1110 (ls == 1, cs <= 2) */
+            const int uvalpha = cs == 1 ? 0 : cf[1];
+            Y1 = clip_u8(s_lum[li[0]][2 * i] >> 7); Y2 = clip_u8(s_lum[li[0]][2 * i + 1] >> 7);
+            if (uvalpha < 2048) { U = clip_u8(s_cu[ci[0]][i] >> 7); V = clip_u8(s_cv[ci[0]][i] >> 7); }
+            else { U = clip_u8((s_cu[ci[0]][i] + s_cu[ci[NC > 1 ? 1 : 0]][i]) >> 8); V = clip_u8((s_cv[ci[0]][i] + s_cv[ci[NC > 1 ? 1 : 0]][i]) >> 8); }
+        } else if (mode == 2) {   /* yuv2rgb_2_c_template :998-1041 (ls == cs == 2) */
+            const int ya = lf[NL > 1 ? 1 : 0], ua = cf[NC > 1 ? 1 : 0], ya1 = 4096 - ya, ua1 = 4096 - ua;
+            Y1 = clip_u8((s_lum[li[0]][2 * i] * ya1 + s_lum[li[NL > 1 ? 1 : 0]][2 * i] * ya) >> 19);
+            Y2 = clip_u8((s_lum[li[0]][2 * i + 1] * ya1 + s_lum[li[NL > 1 ? 1 : 0]][2 * i + 1] * ya) >> 19);
+            U = clip_u8((s_cu[ci[0]][i] * ua1 + s_cu[ci[NC > 1 ? 1 : 0]][i] * ua) >> 19);
+            V = clip_u8((s_cv[ci[0]][i] * ua1 + s_cv[ci[NC > 1 ? 1 : 0]][i] * ua) >> 19);
+        } else {                  /* yuv2rgb_X_c_template :937-996: clipped only if a value has bit 8 set */
+            Y1 = Y2 = U = V = 1 << 18;
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const uint32_t two = *reinterpret_cast<const uint32_t *>(&s_lum[li[j]][2 * i]);
+                Y1 += (int16_t)(two & 0xFFFF) * lf[j]; Y2 += (int16_t)(two >> 16) * lf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NC; j++) { U += s_cu[ci[j]][i] * cf[j]; V += s_cv[ci[j]][i] * cf[j]; }
+            Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+            if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
+        }
+        write_pair(lut, &s_out[row][i * 6], Y1, Y2, U, V);
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi355_sws_frame *frames)
 {
     __shared__ int16_t s_lum[MAXL][TW];
@@ -119,37 +242,28 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     const int llo = clampi(lfirst0, 0, c.srcH - 1), lhi = clampi(lfirst1 + ls - 1, 0, c.srcH - 1);
     const int clo = clampi(cfirst0, 0, c.chrSrcH - 1), chi = clampi(cfirst1 + cs - 1, 0, c.chrSrcH - 1);
     lut_load(s_lut, &c.luts, tid, NT);
-    /* horizontal pass, luma: thread -> one column, loops over the lines */
-    {
-        const int x = tid & (TW - 1), gx = x0 + x;
-        if (gx < c.dstW) {
-            const int pos = c.hLumP[gx];
-            const int16_t *f = c.hLumC + (size_t)gx * c.hls;
-            for (int l = llo + (tid >> 7); l <= lhi; l += NT / TW)
-                s_lum[l - llo][x] = (int16_t)hscale_one(fr.src[0] + (size_t)l * fr.src_stride[0], f, pos, c.hls);
-        } else {
-            /* the phantom partner of the last sample of an odd-width picture: the reference reads the
-             * zero-initialised tail of its line buffer (utils.c:1241-1262) */
-            for (int l = llo + (tid >> 7); l <= lhi; l += NT / TW) s_lum[l - llo][x] = 0;
-        }
-    }
-    /* chroma: 64 columns x 2 planes */
-    {
-        const int x = tid & (TW / 2 - 1), plane = (tid >> 6) & 1, gx = (x0 >> 1) + x;
-        if (gx < c.chrDstW) {
-            const int pos = c.hChrP[gx];
-            const int16_t *f = c.hChrC + (size_t)gx * c.hcs;
-            const uint8_t *sp = fr.src[1 + plane];
-            const int st = fr.src_stride[1 + plane];
-            int16_t (*dstp)[TW / 2] = plane ? s_cv : s_cu;
-            for (int l = clo + (tid >> 7); l <= chi; l += NT / TW)
-                dstp[l - clo][x] = (int16_t)hscale_one(sp + (size_t)l * st, f, pos, c.hcs);
-        }
-    }
+    /* horizontal pass: luma (the phantom partner of the last sample of an odd-width picture reads the
+     * zero-initialised tail of the reference's line buffer, utils.c:1241-1262), then the chroma planes */
+    __shared__ uint32_t s_stage[SG][SRC_DW];
+    hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0);
+    hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
+    hscale_tile<TW / 2>(s_cv, fr.src[2], fr.src_stride[2], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
     __syncthreads();
     /* vertical pass + LUT */
     const int mode = packed_mode(ls, cs);
     const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
+    if (ls <= 8 && cs <= 8) {
+        /* tap counts in registers, rounded up to 1 / 2 / 4 / 8 */
+        const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
+#define MI355_VR(NL, NC) vertical_rows<NL, NC>(c, s_lut, s_lum, s_cu, s_cv, s_out, tid, y0, y1, llo, clo, npairs, mode)
+        switch (bl * 4 + bc) {
+        case 0: MI355_VR(1, 1); break;   case 1: MI355_VR(1, 2); break;   case 2: MI355_VR(1, 4); break;   case 3: MI355_VR(1, 8); break;
+        case 4: MI355_VR(2, 1); break;   case 5: MI355_VR(2, 2); break;   case 6: MI355_VR(2, 4); break;   case 7: MI355_VR(2, 8); break;
+        case 8: MI355_VR(4, 1); break;   case 9: MI355_VR(4, 2); break;   case 10: MI355_VR(4, 4); break;  case 11: MI355_VR(4, 8); break;
+        case 12: MI355_VR(8, 1); break;  case 13: MI355_VR(8, 2); break;  case 14: MI355_VR(8, 4); break;  default: MI355_VR(8, 8); break;
+        }
+#undef MI355_VR
+    } else
     for (int p = tid; p < th * (TW / 2); p += NT) {
         const int row = p >> 6, i = p & 63, gy = y0 + row;
         if (gy > y1 || i >= npairs) continue;
@@ -285,6 +399,9 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
     h.hls = desc->hLum.size; h.hcs = desc->hChr.size; h.vls = desc->vLum.size; h.vcs = desc->vChr.size;
     h.luts = desc->luts;
     h.th = 0;
+    h.hstage = 1;
+    for (int i = 1; i < desc->hLum.n && desc->hLum.pos; i++) if (desc->hLum.pos[i] < desc->hLum.pos[i - 1]) h.hstage = 0;
+    for (int i = 1; i < desc->hChr.n && desc->hChr.pos; i++) if (desc->hChr.pos[i] < desc->hChr.pos[i - 1]) h.hstage = 0;
     h.hLumC = h.hChrC = h.vLumC = h.vChrC = nullptr;
     h.hLumP = h.hChrP = h.vLumP = h.vChrP = nullptr;
     if (!h.special) {

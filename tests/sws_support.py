@@ -46,6 +46,7 @@ CONFIGS = {
     "generic_64x48": (64, 48, 64, 48, 1, 1, 1),             # accurate_rnd: generic path, chroma x2 vertically
     "down2_128x96": (128, 96, 64, 48, 1, 1, 1),             # 2:1 bicubic, 8 taps
     "down_100x76": (100, 76, 64, 48, 1, 1, 1),              # odd ratio
+    "down4_256x192": (256, 192, 64, 48, 1, 1, 1),           # 4:1: more than 8 taps per filter (the generic loops)
     "up2_bilinear": (64, 48, 128, 96, 0, 1, 1),             # 2-tap vertical filters: the _2 template
     "up_bicubic": (64, 48, 96, 80, 1, 1, 1),
     "cif_generic": (352, 288, 352, 288, 1, 1, 1),           # the shape of the FATE pixfmt tests
