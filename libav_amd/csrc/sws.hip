@@ -199,7 +199,7 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
     for (int i = tid & 15; i < npairs; i += 16) {
         int Y1, Y2, U, V;
         if (mode == 1) {          /* yuv2rgb_1_c_template output.c:1043-1110 (ls == 1, cs <= 2) */
-            const int uvalpha = cs == 1 ? 0 : cf[1];
+            const int uvalpha = cs == 1 ? 0 : cf[NC > 1 ? 1 : 0];
             Y1 = clip_u8(s_lum[li[0]][2 * i] >> 7); Y2 = clip_u8(s_lum[li[0]][2 * i + 1] >> 7);
             if (uvalpha < 2048) { U = clip_u8(s_cu[ci[0]][i] >> 7); V = clip_u8(s_cv[ci[0]][i] >> 7); }
             else { U = clip_u8((s_cu[ci[0]][i] + s_cu[ci[NC > 1 ? 1 : 0]][i]) >> 8); V = clip_u8((s_cv[ci[0]][i] + s_cv[ci[NC > 1 ? 1 : 0]][i]) >> 8); }
