@@ -9,7 +9,7 @@
  * SURVEY.md §8(a); each function cites the reference lines it must agree with.
  * 8-bit samples, int16 coefficients (the BIT_DEPTH 8 instantiation).
  * Pinned bit-exact against the reference's own C objects (oracle/_ref, built
- * from /root/reference by oracle/Makefile) in tests/test_oracle_vs_ref.py and
+ * from /root/reference by oracle/Makefile) in tests/test_oracle_h264dsp.py and
  * by the committed golden vectors under tests/golden/.
  */
 #include <stdint.h>
