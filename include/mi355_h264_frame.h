@@ -92,7 +92,9 @@ typedef struct mi355_h264_mb {
     uint8_t  slice_id;                   /* 44 index into mi355_h264_frame.slices */
     uint8_t  intra_level;                /* 45 0 for inter MBs; for intra MBs 1 + max(level of the intra MBs among
                                                left, top-left, top, top-right), see mi355_h264_intra_levels() */
-    uint8_t  qpc[2];                     /* 46 get_chroma_qp(pps, {0,1}, qp): this MB's Cb / Cr QP */
+    uint8_t  qpc[2];                     /* 46 get_chroma_qp(pps, {0,1}, qp): this MB's Cb / Cr QP; MUST equal
+                                               slices[slice_id].chroma_qp_table[p][qp] (I_PCM: qp = 0), the loop filter
+                                               reads it instead of the table */
     union {                              /* 48 */
         int8_t intra4x4_pred_mode[16];   /*    intra MBs: sl->intra4x4_pred_mode_cache[scan8[i]]; Intra 8x8 uses
                                                i = 0,4,8,12 */

@@ -23,6 +23,11 @@ CASES = {
     "wide_mixed":       dict(nframes=2, mb_w=37, mb_h=9, seed=22, mix="mixed", intra_frac=0.15, dct8_frac=0.3, refs="smooth",
                              coef_b=8, offsets=True),
     "wide_b":           dict(nframes=1, mb_w=19, mb_h=6, seed=23, mix="mixed", bframes=True, intra_frac=0.1, refs="smooth", coef_b=6),
+    # ~900 macroblocks each: enough draws to reach the rare value combinations (large coefficients, far vectors)
+    "mid_b_bigcoef":    dict(nframes=1, mb_w=40, mb_h=22, seed=102, mix="mixed", bframes=True, intra_frac=0.15, dct8_frac=0.3, coef_b=200),
+    "mid_b_weighted":   dict(nframes=1, mb_w=40, mb_h=22, seed=103, mix="mixed", bframes=True, weighted=1, intra_frac=0.1, coef_b=100, mv_range=200),
+    "mid_intra_pcm":    dict(nframes=1, mb_w=33, mb_h=19, seed=105, intra_frac=1.0, pcm_frac=0.05, dct8_frac=0.4, coef_b=300),
+    "mid_hugecoef":     dict(nframes=1, mb_w=33, mb_h=19, seed=106, mix="mixed", intra_frac=0.5, dct8_frac=0.4, coef_b=1000),
 }
 
 

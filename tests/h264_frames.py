@@ -276,7 +276,8 @@ def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac
                         rec["i4mode"][4 * l + q] = np.uint8(sl["ref_slot"][l][ri]).astype(np.int8) if ri >= 0 else -1
             if t & PCM:
                 fs.coef[f, m].view(np.uint8)[:384] = r.u8(384)
-                rec["qp"] = 0
+                rec["qp"] = 0                       # qscale_table of an I_PCM MB (h264_cabac.c / h264_cavlc.c)
+                rec["qpc"] = (CHROMA_QP[0], CHROMA_QP[0])   # the record's chroma QPs always follow its qp
                 rec["cbp"] = 0x2F
                 rec["nnz_mask"] = 0xFFFFFF
                 continue
