@@ -145,47 +145,126 @@ __device__ const int8_t k_qpel[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -
 __device__ const int8_t k_epel[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
                                          { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
+/* Two 16-bit x 16-bit products and an accumulate in one instruction (v_dot2_i32_i16): a dword holds two
+ * neighbouring samples, the other operand two neighbouring taps. */
+#ifdef MI355_HIP_EMU_H
+static inline int mi355_dot2(uint32_t a, uint32_t b, int c)
+{
+    return c + (int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int16_t)(a >> 16) * (int16_t)(b >> 16);
+}
+static inline uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
+#else
+typedef short mi355_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mi355_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(mi355_short2, a), __builtin_bit_cast(mi355_short2, b), c, false);
+}
+__device__ __forceinline__ uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+#endif
+
+/* Four consecutive outputs of a 4- or 8-tap FIR along a line of 16-bit values: d[0..5] = the line from the
+ * first output's first tap (dword aligned), t[k] = taps 2k, 2k+1 packed.  Outputs 0 and 2 use the dwords as
+ * they are, 1 and 3 the same dwords shifted by one value. */
+template <int TAPS>
+__device__ __forceinline__ void fir4(const uint32_t *d, const uint32_t *t, int *out)
+{
+    uint32_t e[5];
+#pragma unroll
+    for (int k = 0; k < TAPS / 2 + 1; k++) e[k] = mi355_alignbit16(d[k + 1], d[k]);
+    out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; k++) {
+        out[0] = mi355_dot2(d[k], t[k], out[0]);
+        out[1] = mi355_dot2(e[k], t[k], out[1]);
+        out[2] = mi355_dot2(d[k + 1], t[k], out[2]);
+        out[3] = mi355_dot2(e[k + 1], t[k], out[3]);
+    }
+}
+
 /* src points at sample (0,0) of the block inside a plane/window with `ss` samples per row; dst is
  * int16 with `ds` elements per row.  taps = 8 (qpel, :729-937) or 4 (epel, :939-1089).  The samples the
  * taps touch — and only those: a filter that is not applied reads nothing beyond the block, exactly
- * like the reference's per-direction functions — are staged once in LDS (coalesced row reads), the 2-D
- * case keeps its first-pass rows there as well. */
-constexpr int HEVC_MC_PITCH = 72;      /* 64 + 7 columns, rounded */
+ * like the reference's per-direction functions — are staged once in LDS (coalesced reads).  A lane then
+ * produces four consecutive outputs of a line with dot-product instructions; the vertical filter runs on
+ * a TRANSPOSED copy (the horizontal pass writes its results transposed, a vertical-only block is staged
+ * transposed) so that neighbouring taps are neighbouring values there too. */
+constexpr int HEVC_MC_PITCH = 76;      /* >= 64 + 7 + the 4 values a segment may read past the last tap; even */
 struct HevcMcScratch {
-    uint16_t win[(64 + 7) * HEVC_MC_PITCH];
-    int16_t tmp[(64 + 7) * 64];
+    uint16_t win[(64 + 7) * HEVC_MC_PITCH];      /* [row][col], or [col][row] for vertical-only blocks */
+    int16_t tmp[64 * HEVC_MC_PITCH];             /* [col][row]: first-pass results of the 2-D case */
 };
+template <int TAPS>
+__device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
+                                    int mx, int my, int bd, HevcMcScratch &s)
+{
+    const int lane = lane_id();
+    constexpr int before = TAPS == 8 ? 3 : 1, extra = TAPS - 1;
+    const int8_t *fh = TAPS == 8 ? k_qpel[mx] : k_epel[mx], *fv = TAPS == 8 ? k_qpel[my] : k_epel[my];
+    if (!mx && !my) {
+        for (int i = lane; i < height * width; i += 64) {
+            const int y = i / width, x = i - y * width;
+            dst[x + y * ds] = (int16_t)(ldpx(src, x + y * ss, bd) << (14 - bd));
+        }
+        return;
+    }
+    uint32_t th[TAPS / 2], tv[TAPS / 2];
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; k++) {
+        th[k] = (uint32_t)(uint16_t)(int16_t)fh[2 * k] | ((uint32_t)(uint16_t)(int16_t)fh[2 * k + 1] << 16);
+        tv[k] = (uint32_t)(uint16_t)(int16_t)fv[2 * k] | ((uint32_t)(uint16_t)(int16_t)fv[2 * k + 1] << 16);
+    }
+    const int bx = mx ? before : 0, by = my ? before : 0;
+    const int cols = width + (mx ? extra : 0), rows = height + (my ? extra : 0);
+    const bool transposed = !mx;                          /* vertical only: stage [col][row] */
+    for (int i = lane; i < rows * cols; i += 64) {
+        const int r = i / cols, c = i - r * cols;
+        const uint16_t v = (uint16_t)ldpx(src, (c - bx) + (r - by) * ss, bd);
+        if (transposed) s.win[c * HEVC_MC_PITCH + r] = v; else s.win[r * HEVC_MC_PITCH + c] = v;
+    }
+    __syncthreads();
+    const int wseg = (width + 3) >> 2, hseg = (height + 3) >> 2;
+    if (mx) {
+        /* horizontal pass over `rows` lines, four outputs per lane */
+        for (int i = lane; i < rows * wseg; i += 64) {
+            const int r = i / wseg, x0 = 4 * (i - r * wseg);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
+            uint32_t dd[6];
+#pragma unroll
+            for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
+            int o[4];
+            fir4<TAPS>(dd, th, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int v = o[j] >> (bd - 8);
+                if (x0 + j >= width) continue;
+                if (my) s.tmp[(x0 + j) * HEVC_MC_PITCH + r] = (int16_t)v;
+                else dst[x0 + j + r * ds] = (int16_t)v;
+            }
+        }
+        if (!my) return;
+        __syncthreads();
+    }
+    /* vertical pass along the transposed lines: lane = (column, four output rows) */
+    const int16_t *lines = mx ? s.tmp : reinterpret_cast<const int16_t *>(s.win);
+    const int vshift = mx ? 6 : bd - 8;
+    for (int i = lane; i < width * hseg; i += 64) {
+        const int q = i / width, x = i - q * width, y0 = 4 * q;
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(&lines[x * HEVC_MC_PITCH + y0]);
+        uint32_t dd[6];
+#pragma unroll
+        for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
+        int o[4];
+        fir4<TAPS>(dd, tv, o);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (y0 + j < height) dst[x + (y0 + j) * ds] = (int16_t)(o[j] >> vshift);
+    }
+}
 __device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
                                     int mx, int my, int bd, int taps, HevcMcScratch &s)
 {
-    const int lane = lane_id();
-    const int before = taps == 8 ? 3 : 1, extra = taps == 8 ? 7 : 3;
-    const int8_t *fh = taps == 8 ? k_qpel[mx] : k_epel[mx], *fv = taps == 8 ? k_qpel[my] : k_epel[my];
-    const int bx = mx ? before : 0, by = my ? before : 0;
-    const int cols = width + (mx ? extra : 0), rows = height + (my ? extra : 0);
-    for (int i = lane; i < rows * cols; i += 64) {
-        const int r = i / cols, c = i - r * cols;
-        s.win[r * HEVC_MC_PITCH + c] = (uint16_t)ldpx(src, (c - bx) + (r - by) * ss, bd);
-    }
-    __syncthreads();
-    if (mx && my) {
-        for (int i = lane; i < rows * width; i += 64) {
-            const int y = i / width, x = i - y * width;
-            int a = 0;
-            for (int k = 0; k < taps; k++) a += fh[k] * s.win[y * HEVC_MC_PITCH + x + k];
-            s.tmp[x + y * 64] = (int16_t)(a >> (bd - 8));
-        }
-        __syncthreads();
-    }
-    for (int i = lane; i < height * width; i += 64) {
-        const int y = i / width, x = i - y * width;
-        int a = 0;
-        if (!mx && !my) a = s.win[y * HEVC_MC_PITCH + x] << (14 - bd);
-        else if (!my) { for (int k = 0; k < taps; k++) a += fh[k] * s.win[y * HEVC_MC_PITCH + x + k]; a >>= bd - 8; }
-        else if (!mx) { for (int k = 0; k < taps; k++) a += fv[k] * s.win[(y + k) * HEVC_MC_PITCH + x]; a >>= bd - 8; }
-        else { for (int k = 0; k < taps; k++) a += fv[k] * s.tmp[x + (y + k) * 64]; a >>= 6; }
-        dst[x + y * ds] = (int16_t)a;
-    }
+    if (taps == 8) hevc_mc_taps<8>(dst, ds, src, ss, width, height, mx, my, bd, s);
+    else hevc_mc_taps<4>(dst, ds, src, ss, width, height, mx, my, bd, s);
     __syncthreads();
 }
 
