@@ -24,6 +24,14 @@ __device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+/* exchange inside groups of four lanes as a DPP operand modifier (quad_perm) instead of an LDS-routed shuffle */
+#ifdef MI355_HIP_EMU_H
+static inline int quad_xor1(int v) { return __shfl_xor(v, 1); }
+static inline int quad_xor2(int v) { return __shfl_xor(v, 2); }
+#else
+__device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }   /* quad_perm:[1,0,3,2] */
+__device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }   /* quad_perm:[2,3,0,1] */
+#endif
 /* a value every lane of the wave holds identically (read from this wave's LDS record): telling the
  * compiler moves everything derived from it to the scalar unit */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -323,9 +331,9 @@ __device__ __forceinline__ void idct4_quad(const int c[4], int q, int r[4], int 
     for (int i = 0; i < 4; i++) {
         int v = c[i];
         if (i == 0 && q == 0) v = (int16_t)(v + 32);
-        int p = __shfl_xor(v, 2);
+        int p = quad_xor2(v);
         int s = q == 0 ? v + p : (q == 2 ? p - v : (q == 1 ? v + (p >> 1) : (p >> 1) - v));
-        int o = __shfl_xor(s, 1);
+        int o = quad_xor1(s);
         t[i] = (int16_t)((q & 1) ? o - s : s + o);
     }
     /* lane q now owns intermediate row k' = {0,3,1,2}[q] == destination column */
