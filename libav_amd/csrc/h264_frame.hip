@@ -83,7 +83,7 @@ __device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, 
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */
-__device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+__device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
                               int mb_xy, int list, int n_raster, int refn, int bx, int by, int w, int h,
                               uint8_t *py, uint8_t *pcb, uint8_t *pcr, int avg)
 {
@@ -106,23 +106,27 @@ __device__ inline void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_
 #endif
 }
 
-/* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
+/* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471).  Both lists go
+ * through ONE call site of mc_dir (inlined): a second prediction lands in the q* tiles when the two have to be
+ * blended with weights, on top of the first one (rounded average) otherwise. */
 __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
-                               int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
+                                        int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
     const int r0 = uniform(s.hdr.ref_idx[0][quadrant]), r1 = uniform(s.hdr.ref_idx[1][quadrant]);
     const bool weighted = (uniform(s.hdr.flags) & MI355_MBF_WEIGHTED) &&
                           ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
-    if (!weighted) {
-        int avg = 0;
-        if (l0) { mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 0, n_raster, r0, bx, by, w, h, s.py, s.pc[0], s.pc[1], 0); avg = 1; }
-        if (l1) mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 1, n_raster, r1, bx, by, w, h, s.py, s.pc[0], s.pc[1], avg);
-        return;
+    const bool two = l0 && l1;
+#pragma nounroll
+    for (int list = 0; list < 2; list++) {
+        if (!(list ? l1 : l0)) continue;
+        const bool second = list == 1 && two;
+        const bool to_q = second && weighted;
+        mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, list, n_raster, list ? r1 : r0, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0],
+               to_q ? s.qc[1] : s.pc[1], second && !weighted);
     }
+    if (!weighted) return;
     uint8_t *dy = s.py + by * 16 + bx, *dcb = s.pc[0] + (by >> 1) * 8 + (bx >> 1), *dcr = s.pc[1] + (by >> 1) * 8 + (bx >> 1);
-    if (l0 && l1) {
-        mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 0, n_raster, r0, bx, by, w, h, s.py, s.pc[0], s.pc[1], 0);
-        mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 1, n_raster, r1, bx, by, w, h, s.qy, s.qc[0], s.qc[1], 0);
+    if (two) {
         const uint8_t *ty = s.qy + by * 16 + bx, *tcb = s.qc[0] + (by >> 1) * 8 + (bx >> 1), *tcr = s.qc[1] + (by >> 1) * 8 + (bx >> 1);
         if (sl.use_weight == 2) {
             const int w0 = sl.implicit_weight[r0][r1], w1 = 64 - w0;
@@ -139,7 +143,6 @@ __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, co
         }
     } else {
         const int list = l1 ? 1 : 0, refn = list ? r1 : r0;
-        mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, list, n_raster, refn, bx, by, w, h, s.py, s.pc[0], s.pc[1], 0);
         weight_block(dy, 16, w, h, sl.luma_log2_weight_denom, sl.luma_weight[refn][list][0], sl.luma_weight[refn][list][1]);
         if (sl.use_weight_chroma) {
             weight_block(dcb, 8, w >> 1, h >> 1, sl.chroma_log2_weight_denom, sl.chroma_weight[refn][list][0][0], sl.chroma_weight[refn][list][0][1]);
