@@ -1,0 +1,53 @@
+"""Output-stage chaining: pictures decoded by the batched H.264 path are converted to RGB24 by the
+swscale path without leaving device memory — the deblocked planes of mi355_h264_frame are the mi355_sws_frame
+sources.  Checked against oracle decode + oracle conversion."""
+import ctypes as C
+
+import numpy as np
+
+import h264_frames as HF
+import sws_support as S
+
+
+def run(backend, oracle, nframes=3, mb_w=9, mb_h=6, seed=31):
+    fs = HF.synth_frames(nframes=nframes, mb_w=mb_w, mb_h=mb_h, seed=seed, mix="mixed", intra_frac=0.2, dct8_frac=0.3, refs="smooth", coef_b=8)
+    _, dst_o = HF.run_oracle(oracle, fs)
+    W, H = 16 * mb_w, 16 * mb_h
+    # the unscaled special converter for this picture size, with the LUTs the reference built
+    base = S.load_context("special_64x48")
+    ints = dict(base.ints, srcW=W, srcH=H, dstW=W, dstH=H, chrSrcW=W // 2, chrSrcH=H // 2, chrDstW=W // 2, unscaled_special=1)
+    ctx = S.Context(ints, {k: (np.zeros(0, np.int16), np.zeros(0, np.int32)) for k in S.BANKS}, base.luts)
+    want = [S.oracle_backend(oracle).scale(ctx, [dst_o[0][f], dst_o[1][f], dst_o[2][f]]) for f in range(nframes)]
+
+    lib = backend.lib
+    d = HF.DeviceFrames(backend, fs)
+    lib.mi355_sws_create.restype = C.c_void_p
+    lib.mi355_malloc.restype = C.c_void_p
+    try:
+        d.decode()
+        rgb_stride = W * 3
+        p_rgb = lib.mi355_malloc(C.c_size_t(nframes * rgb_stride * H + 64))
+        frames = (S.SwsFrame * nframes)()
+        for f in range(nframes):
+            fr = d.host_desc[f]
+            for p in range(3):
+                frames[f].src[p] = fr.dst[p]
+                frames[f].src_stride[p] = fr.dst_stride[0] if p == 0 else fr.dst_stride[1]
+            frames[f].dst = p_rgb + f * rgb_stride * H
+            frames[f].dst_stride = rgb_stride
+        p_frames = lib.mi355_malloc(C.c_size_t(C.sizeof(frames)))
+        lib.mi355_memcpy_h2d(C.c_void_p(p_frames), C.addressof(frames), C.c_size_t(C.sizeof(frames)))
+        h = lib.mi355_sws_create(C.byref(ctx.desc))
+        assert h
+        lib.mi355_sws_scale_frames_dev(C.c_void_p(h), C.c_void_p(p_frames), nframes, None)
+        lib.mi355_sync(None)
+        got = np.empty((nframes, H, rgb_stride), np.uint8)
+        lib.mi355_memcpy_d2h(C.c_void_p(got.ctypes.data), C.c_void_p(p_rgb), C.c_size_t(got.nbytes))
+        lib.mi355_sws_destroy(C.c_void_p(h))
+        lib.mi355_free(C.c_void_p(p_rgb))
+        lib.mi355_free(C.c_void_p(p_frames))
+    finally:
+        d.free()
+    for f in range(nframes):
+        assert np.array_equal(got[f], want[f]), "RGB picture %d differs" % f
+    return nframes

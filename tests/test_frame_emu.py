@@ -28,3 +28,8 @@ def test_full_size_1080p_picture_emulated(emu, oracle):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
+
+
+def test_decode_then_convert_on_device_emulated(emu, oracle):
+    import chain_check
+    assert chain_check.run(emu, oracle) == 3

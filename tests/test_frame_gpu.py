@@ -41,3 +41,9 @@ def test_full_size_1080p_batch_matches_oracle(mi355, oracle):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
     assert sum(int((a != b).sum()) for a, b in zip(dst_o, recon_o)) > 10000      # the loop filter did real work
+
+
+def test_decode_then_convert_on_device(mi355, oracle):
+    """H.264 Tier-2 output feeds the swscale kernels without a host round trip"""
+    import chain_check
+    assert chain_check.run(mi355, oracle, nframes=4, mb_w=20, mb_h=12, seed=32) == 4
