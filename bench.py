@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1792, help="independent 1080p pictures (streams) per GPU per step")
+    ap.add_argument("--frames", type=int, default=2048, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
     ap.add_argument("--mb-width", type=int, default=120)

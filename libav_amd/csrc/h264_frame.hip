@@ -493,7 +493,7 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
 #define MI355_DCH_LOG 2
 #endif
 constexpr int DCH_LOG = MI355_DCH_LOG, DCH = 1 << DCH_LOG;    /* macroblocks per chunk */
-constexpr int DY_PITCH = 16 * DCH + 16;           /* + 16: rows of a 16-lane b128 access spread over all banks */
+constexpr int DY_PITCH = 16 * DCH + 8;            /* + 8: the sixteen rows of a 16-lane, 8-byte access fall on 32 different banks */
 constexpr int DC_PITCH = 8 * DCH + 8;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
 struct DeblockLds {
@@ -639,6 +639,17 @@ __device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr
         if (l < 4 && has_t) p.mvt[li] = a.mv[li][a.mv_top];
     }
 }
+/* 16 bytes of an LDS tile row (rows are 8-byte aligned: two 64-bit accesses) */
+__device__ __forceinline__ uint4 lds16(const uint8_t *p)
+{
+    const uint2 a = reinterpret_cast<const uint2 *>(p)[0], b = reinterpret_cast<const uint2 *>(p)[1];
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void lds16(uint8_t *p, uint4 v)
+{
+    reinterpret_cast<uint2 *>(p)[0] = make_uint2(v.x, v.y);
+    reinterpret_cast<uint2 *>(p)[1] = make_uint2(v.z, v.w);
+}
 /* 16 / 8 bytes between a picture row and an LDS tile row */
 __device__ __forceinline__ uint4 ld16(const uint8_t *p, bool al)
 {
@@ -727,7 +738,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 #pragma unroll
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;
-            *reinterpret_cast<uint4 *>(&s.y[g][b][4 + row][16 * io_p]) = vy[it];
+            lds16(&s.y[g][b][4 + row][16 * io_p], vy[it]);
             *reinterpret_cast<uint2 *>(&s.c[g][b][row >> 3][2 + (row & 7)][8 * io_p]) = vc[it];
         }
         if (g == 0) {
@@ -735,7 +746,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             for (int it = 0; it < NT; it++) {
                 const int row = DIO_ROWS * it + io_r;
                 if (row < 4) {
-                    *reinterpret_cast<uint4 *>(&s.y[g][b][row][16 * io_p]) = ty[it];
+                    lds16(&s.y[g][b][row][16 * io_p], ty[it]);
                     *reinterpret_cast<uint2 *>(&s.c[g][b][row >> 1][row & 1][8 * io_p]) = tc[it];
                 }
             }
@@ -752,7 +763,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         for (int it = 0; it < NF; it++) {
             const int row = DIO_ROWS * it + io_r;
             if (ok && row >= y_first && row <= y_last)
-                st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, *reinterpret_cast<const uint4 *>(&s.y[g][b][row][16 * io_p]), al16);
+                st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, lds16(&s.y[g][b][row][16 * io_p]), al16);
             const int plane = row >= 10, crow = row - 10 * plane;
             if (ok && crow >= c_first && crow <= c_last)
                 st8(fr.dst[1 + plane] + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
@@ -862,7 +873,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         {
             uint8_t *rowp = &s.y[g][b][4 + l][16 * j];
             uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * (DCH - 1) + 12];
-            const uint4 own = *reinterpret_cast<const uint4 *>(rowp);
+            const uint4 own = lds16(rowp);
             const uint32_t left_y = *reinterpret_cast<const uint32_t *>(leftp);
             int px[20];
             unpack4(left_y, px);
@@ -870,7 +881,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             luma_edge(px, bsw0 & 0xFF, ev[0], intra_v);
 #pragma unroll
             for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw0 >> (8 * e)) & 0xFF, ev[e], false);   /* inner edges: bS <= 3 */
-            if (bsw0) *reinterpret_cast<uint4 *>(rowp) = make_uint4(pack4(px + 4), pack4(px + 8), pack4(px + 12), pack4(px + 16));
+            if (bsw0) lds16(rowp, make_uint4(pack4(px + 4), pack4(px + 8), pack4(px + 12), pack4(px + 16)));
             if (have_left) *reinterpret_cast<uint32_t *>(leftp) = pack4(px);
 
             uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
