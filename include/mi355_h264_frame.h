@@ -148,6 +148,10 @@ typedef struct mi355_h264_slice {
     uint8_t chroma_qp_table[2][52];   /* pps->chroma_qp_table[cb/cr][qp] (get_chroma_qp) */
 } mi355_h264_slice;
 
+/* Alignment contract of the picture surfaces (what the reference's own frame pool provides: av_frame_get_buffer
+ * aligns planes and line sizes to >= 32 bytes): planes and strides of dst / recon / ref must be multiples of 4
+ * bytes; when luma planes and strides are multiples of 16 and chroma ones of 8 the kernels move whole 16-/8-byte
+ * row pieces (the fast path the benchmark runs).  coef, mv and mb arrays: 4-byte aligned. */
 typedef struct mi355_h264_frame {
     int32_t mb_width, mb_height;
     uint8_t *dst[3];                  /* deblocked output picture */
