@@ -31,10 +31,10 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name):
+def run_case(backend, oracle, name, pad=0):
     fs = HF.synth_frames(**CASES[name])
     recon_o, dst_o = HF.run_oracle(oracle, fs)
-    d = HF.DeviceFrames(backend, fs)
+    d = HF.DeviceFrames(backend, fs, pad=pad)
     try:
         d.decode()
         recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)

@@ -421,8 +421,10 @@ class DeviceFrames:
     `replicate` = total number of pictures F >= fs.F: picture f is a device-side copy of picture
     f % fs.F with its own buffers (bench.py: many independent streams from a few distinct ones)."""
 
-    def __init__(self, prov, fs, replicate=None):
-        self.lib, self.fs = prov.lib, fs
+    def __init__(self, prov, fs, replicate=None, pad=0):
+        """pad: extra bytes per luma row (chroma rows get pad // 2): strides that are multiples of 4 but not of
+        16 / 8 take the kernels' narrow-access paths"""
+        self.lib, self.fs, self.pad = prov.lib, fs, pad
         lib = self.lib
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -434,7 +436,8 @@ class DeviceFrames:
         G = fs.F
         F = self.F = replicate or G
         nmb = fs.mb_w * fs.mb_h
-        ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
+        ys, cs = fs.W + pad, fs.W // 2 + pad // 2            # strides
+        ysz, csz = fs.H * ys, (fs.H // 2) * cs
         self.fsz = ysz + 2 * csz
 
         def up_rep(a, per):
@@ -461,9 +464,9 @@ class DeviceFrames:
         for f in range(G):
             for s_ in range(fs.nrefs):
                 y, cb, cr = fs.refs[f][s_]
-                refs_host[f, s_, :ysz] = y.reshape(-1)
-                refs_host[f, s_, ysz:ysz + csz] = cb.reshape(-1)
-                refs_host[f, s_, ysz + csz:] = cr.reshape(-1)
+                refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :fs.W] = y
+                refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cb
+                refs_host[f, s_, ysz + csz:].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cr
         self.refs = up_rep(refs_host, fs.nrefs * self.fsz)
         ilist = [self.up(fs.intra_list[g]) if len(fs.intra_list[g]) else None for g in range(G)]
         istart = [self.up(fs.intra_start[g]) for g in range(G)]
@@ -476,8 +479,8 @@ class DeviceFrames:
                 base = base0 + f * self.fsz
                 a = getattr(fr, kind)
                 a[0], a[1], a[2] = base, base + ysz, base + ysz + csz
-            fr.dst_stride[0], fr.dst_stride[1] = fs.W, fs.W // 2
-            fr.recon_stride[0], fr.recon_stride[1] = fs.W, fs.W // 2
+            fr.dst_stride[0], fr.dst_stride[1] = ys, cs
+            fr.recon_stride[0], fr.recon_stride[1] = ys, cs
             for s_ in range(fs.nrefs):
                 base = self.refs + (f * fs.nrefs + s_) * self.fsz
                 fr.ref[s_][0], fr.ref[s_][1], fr.ref[s_][2] = base, base + ysz, base + ysz + csz
@@ -516,9 +519,10 @@ class DeviceFrames:
         raw = np.empty(n * self.fsz, np.uint8)
         self.lib.mi355_memcpy_d2h(raw.ctypes.data, base + first * self.fsz, raw.nbytes)
         raw = raw.reshape(n, self.fsz)
-        ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
-        return [raw[:, :ysz].reshape(n, fs.H, fs.W), raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, fs.W // 2),
-                raw[:, ysz + csz:].reshape(n, fs.H // 2, fs.W // 2)]
+        ys, cs = fs.W + self.pad, fs.W // 2 + self.pad // 2
+        ysz, csz = fs.H * ys, (fs.H // 2) * cs
+        return [raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :fs.W], raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2],
+                raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2]]
 
     def decode(self, stream=None):
         fs = self.fs

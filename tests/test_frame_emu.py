@@ -33,3 +33,10 @@ def test_full_size_1080p_picture_emulated(emu, oracle):
 def test_decode_then_convert_on_device_emulated(emu, oracle):
     import chain_check
     assert chain_check.run(emu, oracle) == 3
+
+
+@pytest.mark.parametrize("pad", (8, 24))
+@pytest.mark.parametrize("name", ("mixed_intra", "wide_b", "one_col"))
+def test_frame_pipeline_emulated_unaligned_strides(emu, oracle, name, pad):
+    """strides that are multiples of 8 / 4 only: the dword paths instead of the 16-byte ones"""
+    frame_cases.run_case(emu, oracle, name, pad=pad)

@@ -47,3 +47,9 @@ def test_decode_then_convert_on_device(mi355, oracle):
     """H.264 Tier-2 output feeds the swscale kernels without a host round trip"""
     import chain_check
     assert chain_check.run(mi355, oracle, nframes=4, mb_w=20, mb_h=12, seed=32) == 4
+
+
+@pytest.mark.parametrize("pad", (8, 24))
+@pytest.mark.parametrize("name", ("mixed_intra", "wide_mixed", "mid_b_weighted"))
+def test_frame_pipeline_gpu_unaligned_strides(mi355, oracle, name, pad):
+    frame_cases.run_case(mi355, oracle, name, pad=pad)
