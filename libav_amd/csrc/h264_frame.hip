@@ -302,7 +302,8 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
     PROF_MARK(9);
 #ifndef MI355_EXP_NO_RESIDUAL
-    residual_luma(s, s.py, 16, false);
+    /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
+    if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma(s, s.py, 16, false);
     PROF_MARK(10);
     residual_chroma(s, s.pc[0], s.pc[1], 8);
     PROF_MARK(11);
