@@ -318,31 +318,40 @@ __device__ inline void biweight_block(uint8_t *dst, const uint8_t *src, int pitc
 }
 
 /* ---- a1: 4x4 inverse transform, 4 lanes per block (h264idct_template.c:33-67) -
- * Lane q = lane&3 holds storage row q of the (transposed) coefficient block:
- * c[i] = block[4q+i].  The vertical butterflies of the first pass run across the
- * four lanes with two xor-shuffles; intermediates are truncated to int16 exactly
- * as the reference's in-place int16 block does.  On return lane q holds the four
- * residuals (already >>6) of destination column `col`, rows 0..3.  Per lane, but
- * all lanes of the quad must execute it together. */
-__device__ __forceinline__ void idct4_quad(const int c[4], int q, int r[4], int &col)
+ * Lane j = lane&3 holds storage COLUMN j of the (transposed) coefficient block: c[k] = block[j + 4k].
+ * The reference's first loop (butterflies over k for a fixed position j, intermediates truncated to the
+ * int16 block, block[0] += 32 before it) is then per lane; its second loop (within a storage row, across j)
+ * runs across the four lanes with two quad exchanges.  On return lane j holds the four residuals (already
+ * >> 6) of destination ROW `row` = {0,3,1,2}[j], columns 0..3 — a whole dword of samples to update.
+ * Per lane, but all lanes of the quad must execute it together. */
+__device__ __forceinline__ void idct4_quad(const int c[4], int j, int r[4], int &row)
 {
-    int t[4];
+    const int c0 = j == 0 ? (int16_t)(c[0] + 32) : c[0];
+    const int e0 = c0 + c[2], e1 = c0 - c[2], e2 = (c[1] >> 1) - c[3], e3 = c[1] + (c[3] >> 1);
+    const int b[4] = { (int16_t)(e0 + e3), (int16_t)(e1 + e2), (int16_t)(e1 - e2), (int16_t)(e0 - e3) };
+    const bool odd = j & 1, hi = j >= 2;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int v = c[i];
-        if (i == 0 && q == 0) v = (int16_t)(v + 32);
-        int p = quad_xor2(v);
-        int s = q == 0 ? v + p : (q == 2 ? p - v : (q == 1 ? v + (p >> 1) : (p >> 1) - v));
-        int o = quad_xor1(s);
-        t[i] = (int16_t)((q & 1) ? o - s : s + o);
+    for (int k = 0; k < 4; k++) {
+        const int v = b[k];
+        const int p = quad_xor2(v);
+        const int s = (odd ? p >> 1 : p) + (hi ? -v : v);      /* z0, z3, z1, z2 on lanes 0..3 */
+        const int o = quad_xor1(s);
+        r[k] = (odd ? o - s : o + s) >> 6;
     }
-    /* lane q now owns intermediate row k' = {0,3,1,2}[q] == destination column */
-    col = q == 0 ? 0 : (q == 1 ? 3 : (q == 2 ? 1 : 2));
-    int e0 = t[0] + t[2], e1 = t[0] - t[2], e2 = (t[1] >> 1) - t[3], e3 = t[1] + (t[3] >> 1);
-    r[0] = (e0 + e3) >> 6;
-    r[1] = (e1 + e2) >> 6;
-    r[2] = (e1 - e2) >> 6;
-    r[3] = (e0 - e3) >> 6;
+    row = j == 0 ? 0 : (j == 1 ? 3 : (j == 2 ? 1 : 2));
+}
+/* four residuals onto four neighbouring samples (a dword when the tile row is aligned) */
+__device__ __forceinline__ void add_row4(uint8_t *p, const int *r)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(p);
+        const uint32_t v = *w;
+        *w = (uint32_t)clip_u8((int)(v & 0xFF) + r[0]) | ((uint32_t)clip_u8((int)((v >> 8) & 0xFF) + r[1]) << 8) |
+             ((uint32_t)clip_u8((int)((v >> 16) & 0xFF) + r[2]) << 16) | ((uint32_t)clip_u8((int)(v >> 24) + r[3]) << 24);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = (uint8_t)clip_u8(p[k] + r[k]);
+    }
 }
 
 /* one 8-point pass (h264idct_template.c:80-108) — per lane */

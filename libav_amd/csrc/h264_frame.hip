@@ -199,17 +199,17 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
             add_col(y + (8 * (b >> 1)) * pitch + 8 * (b & 1) + i, pitch, r, 8);
     } else {
         const int b = lane >> 2, q = lane & 3;
-        int c[4], r[4], col;
+        int c[4], r[4], row;
 #pragma unroll
-        for (int i = 0; i < 4; i++) c[i] = s.coef[b * 16 + 4 * q + i];
+        for (int i = 0; i < 4; i++) c[i] = s.coef[b * 16 + q + 4 * i];
         const int dc = s.coef[b * 16];
-        idct4_quad(c, q, r, col);
+        idct4_quad(c, q, r, row);
         /* a block without the nnz bit but with a DC value (Intra16x16) takes h264_idct_dc_add
          * (h264idct_template.c:144-156): (dc + 32) >> 6 in int, not the int16 wrap of the full transform */
         const bool coded = (mask >> b) & 1;
         if (!coded) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;
         if (coded || (intra16 && dc))
-            add_col(y + (4 * blk_y4(b)) * pitch + 4 * blk_x4(b) + col, pitch, r, 4);
+            add_row4(y + (4 * blk_y4(b) + row) * pitch + 4 * blk_x4(b), r);
     }
     __syncthreads();
 }
@@ -228,17 +228,17 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
     }
     __syncthreads();
     const int j = (lane >> 2) & 7, q = lane & 3;
-    int c[4], r[4], col;
+    int c[4], r[4], row;
 #pragma unroll
-    for (int i = 0; i < 4; i++) c[i] = s.coef[256 + j * 16 + 4 * q + i];
+    for (int i = 0; i < 4; i++) c[i] = s.coef[256 + j * 16 + q + 4 * i];
     const int dc = s.coef[256 + j * 16];
-    idct4_quad(c, q, r, col);
+    idct4_quad(c, q, r, row);
     const bool coded = (mask >> (16 + j)) & 1;
     if (!coded) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;       /* DC only: h264_idct_dc_add, no int16 wrap */
     if (lane < 32 && (coded || dc)) {
         uint8_t *p = (j >> 2) ? cr : cb;
         const int jj = j & 3;
-        add_col(p + (4 * (jj >> 1)) * pitch + 4 * (jj & 1) + col, pitch, r, 4);
+        add_row4(p + (4 * (jj >> 1) + row) * pitch + 4 * (jj & 1), r);
     }
     __syncthreads();
 }
@@ -410,11 +410,11 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             __syncthreads();
             intra_pred_wave(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &TILE(x0, y0), TP);
             const int q = lane & 3;
-            int c[4], r[4], col;
+            int c[4], r[4], row;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; k2++) c[k2] = s.mb.coef[i * 16 + 4 * q + k2];
-            idct4_quad(c, q, r, col);
-            if (lane < 4 && ((h.nnz_mask >> i) & 1)) add_col(&TILE(x0 + col, y0), TP, r, 4);
+            for (int k2 = 0; k2 < 4; k2++) c[k2] = s.mb.coef[i * 16 + q + 4 * k2];
+            idct4_quad(c, q, r, row);
+            if (lane < 4 && ((h.nnz_mask >> i) & 1)) add_row4(&TILE(x0, y0 + row), r);
             __syncthreads();
         }
     }

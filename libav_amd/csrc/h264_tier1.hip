@@ -114,16 +114,16 @@ __global__ void __launch_bounds__(64)
 k_idct4(uint8_t *win, int pitch, const Idct4Job *job)
 {
     const int lane = lane_id(), b = lane >> 2, q = lane & 3;
-    int c[4], r[4], col;
-    for (int i = 0; i < 4; i++) c[i] = job->coef[b * 16 + 4 * q + i];
+    int c[4], r[4], row;
+    for (int i = 0; i < 4; i++) c[i] = job->coef[b * 16 + q + 4 * i];
     const int mode = job->mode[b];
-    idct4_quad(c, q, r, col);
+    idct4_quad(c, q, r, row);
     if (mode == 1) { /* h264idct_template.c:144-156 */
         int dc = (job->coef[b * 16] + 32) >> 6;
         r[0] = r[1] = r[2] = r[3] = dc;
     }
     if (mode)
-        add_col(win + job->by[b] * pitch + job->bx[b] + col, pitch, r, 4);
+        add_row4(win + (job->by[b] + row) * pitch + job->bx[b], r);
 }
 
 struct Idct8Job {
