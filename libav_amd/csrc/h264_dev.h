@@ -172,6 +172,54 @@ __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int 
 /* rounded average of four packed samples: (a + b + 1) >> 1 per byte */
 __device__ __forceinline__ uint32_t rnd_avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu); }
 
+/* ---- two 16-bit lanes per register (v_pk_*_i16): the 6-tap sums of 8-bit samples stay within
+ * -2550 .. 10710 and the bilinear chroma sums within 0 .. 16352, so two samples share an instruction */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t pk_make(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
+static inline int pk_lo(uint32_t a) { return (int16_t)(a & 0xFFFF); }
+static inline int pk_hi(uint32_t a) { return (int16_t)(a >> 16); }
+static inline uint32_t pk_add(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
+static inline uint32_t pk_mad(uint32_t a, int k, uint32_t c) { return pk_make(pk_lo(a) * k + pk_lo(c), pk_hi(a) * k + pk_hi(c)); }
+static inline uint32_t pk_ashr(uint32_t a, int n) { return pk_make(pk_lo(a) >> n, pk_hi(a) >> n); }
+static inline uint32_t pk_clip_u8(uint32_t a)
+{
+    const int l = pk_lo(a), h = pk_hi(a);
+    return pk_make(l < 0 ? 0 : (l > 255 ? 255 : l), h < 0 ? 0 : (h > 255 ? 255 : h));
+}
+#else
+typedef short mi355_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mi355_v2s pk_v(uint32_t a) { return __builtin_bit_cast(mi355_v2s, a); }
+__device__ __forceinline__ uint32_t pk_u(mi355_v2s a) { return __builtin_bit_cast(uint32_t, a); }
+__device__ __forceinline__ uint32_t pk_make(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)hi << 16); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_u(pk_v(a) + pk_v(b)); }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, int k, uint32_t c) { return pk_u(pk_v(a) * (mi355_v2s)((short)k) + pk_v(c)); }
+__device__ __forceinline__ uint32_t pk_ashr(uint32_t a, int n) { return pk_u(pk_v(a) >> (mi355_v2s)((short)n)); }
+__device__ __forceinline__ uint32_t pk_clip_u8(uint32_t a)
+{
+    return pk_u(__builtin_elementwise_min(__builtin_elementwise_max(pk_v(a), (mi355_v2s)((short)0)), (mi355_v2s)((short)255)));
+}
+#endif
+constexpr uint32_t PK_M = 0x00FF00FFu;
+/* samples 0,2 and 1,3 of a dword as two packed pairs, and back */
+__device__ __forceinline__ uint32_t pk_even(uint32_t w) { return w & PK_M; }
+__device__ __forceinline__ uint32_t pk_odd(uint32_t w) { return (w >> 8) & PK_M; }
+__device__ __forceinline__ uint32_t pk_bytes(uint32_t e, uint32_t o) { return e | (o << 8); }
+/* (a + f) - 5 (b + e) + 20 (c + d) on pairs */
+__device__ __forceinline__ uint32_t pk_tap6(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+    return pk_mad(pk_add(c, d), 20, pk_mad(pk_add(b, e), -5, pk_add(a, f)));
+}
+/* clip_u8((x + 16) >> 5) on pairs */
+__device__ __forceinline__ uint32_t pk_round5(uint32_t x) { return pk_clip_u8(pk_ashr(pk_add(x, 0x00100010u), 5)); }
+/* raw horizontal 6-tap sums of the four samples whose first taps are bytes 2..5 of (d0,d1,d2): pairs (0,2) and (1,3) */
+__device__ __forceinline__ void pk_htaps(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t &te, uint32_t &to)
+{
+    const uint32_t s2 = mi355_alignbyte(d1, d0, 2), s6 = mi355_alignbyte(d2, d1, 2);
+    const uint32_t e2 = pk_even(s2), o2 = pk_odd(s2), e4 = pk_even(d1), o4 = pk_odd(d1), e6 = pk_even(s6), o6 = pk_odd(s6), e8 = pk_even(d2);
+    te = pk_tap6(e2, o2, e4, o4, e6, o6);
+    to = pk_tap6(o2, e4, o4, e6, o6, e8);
+}
+
 /* ---- a5: quarter-pel luma MC (h264qpel_template.c:77-531) -------------------
  * Block bw x bh from the staged window, fraction (mx,my) in quarter samples.  A lane produces one
  * 4-sample row segment (whole dwords in, one dword out).  Result goes to pred[(py+y)*ppitch + px+x]
@@ -195,59 +243,66 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
         for (int i = lane; i < wh * nseg; i += 64) {
             const int r = i >> lseg, sx = i & (nseg - 1);
             const uint32_t *w = &s.winY[r * WY_DW + sx];
-            int v[12];
-            bytes12(w[0], w[1], w[2], v);
-#pragma unroll
-            for (int k = 0; k < 4; k++) s.tmp[r * 16 + 4 * sx + k] = (int16_t)tap6(v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], v[k + 7]);
+            uint32_t te, to;
+            pk_htaps(w[0], w[1], w[2], te, to);
+            /* pairs (0,2),(1,3) -> four consecutive int16 */
+            uint32_t *t = reinterpret_cast<uint32_t *>(&s.tmp[r * 16 + 4 * sx]);
+            t[0] = (te & 0xFFFFu) | (to << 16);
+            t[1] = (te >> 16) | (to & 0xFFFF0000u);
         }
         __syncthreads();
     }
     for (int i = lane; i < bh * nseg; i += 64) {
         const int y = i >> lseg, sx = i & (nseg - 1);
-        int sum[4] = { 0, 0, 0, 0 };
+        uint32_t se = 0, so = 0;            /* sums of the components, samples (0,2) and (1,3) */
         if (use_g) {
             const uint32_t *w = &s.winY[(y + 2 + gdy) * WY_DW + sx + 1];
             const uint32_t g = gdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
-#pragma unroll
-            for (int k = 0; k < 4; k++) sum[k] += (g >> (8 * k)) & 0xFF;
+            se = pk_even(g); so = pk_odd(g);
         }
         if (use_b) {
+            uint32_t te, to;
             if (use_j) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) sum[k] += clip_u8((s.tmp[(y + 2 + bdy) * 16 + 4 * sx + k] + 16) >> 5);
+                const uint32_t *t = reinterpret_cast<const uint32_t *>(&s.tmp[(y + 2 + bdy) * 16 + 4 * sx]);
+                te = (t[0] & 0xFFFFu) | (t[1] << 16);
+                to = (t[0] >> 16) | (t[1] & 0xFFFF0000u);
             } else {
                 const uint32_t *w = &s.winY[(y + 2 + bdy) * WY_DW + sx];
-                int v[12];
-                bytes12(w[0], w[1], w[2], v);
-#pragma unroll
-                for (int k = 0; k < 4; k++) sum[k] += clip_u8((tap6(v[k + 2], v[k + 3], v[k + 4], v[k + 5], v[k + 6], v[k + 7]) + 16) >> 5);
+                pk_htaps(w[0], w[1], w[2], te, to);
             }
+            se = pk_add(se, pk_round5(te)); so = pk_add(so, pk_round5(to));
         }
         if (use_h) {
-            uint32_t c[6];
+            uint32_t e[6], o[6];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const uint32_t *w = &s.winY[(y + r) * WY_DW + sx + 1];
-                c[r] = hdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
+                const uint32_t c = hdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
+                e[r] = pk_even(c); o[r] = pk_odd(c);
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int sh = 8 * k;
-                sum[k] += clip_u8((tap6((c[0] >> sh) & 0xFF, (c[1] >> sh) & 0xFF, (c[2] >> sh) & 0xFF, (c[3] >> sh) & 0xFF,
-                                        (c[4] >> sh) & 0xFF, (c[5] >> sh) & 0xFF) + 16) >> 5);
-            }
+            se = pk_add(se, pk_round5(pk_tap6(e[0], e[1], e[2], e[3], e[4], e[5])));
+            so = pk_add(so, pk_round5(pk_tap6(o[0], o[1], o[2], o[3], o[4], o[5])));
         }
         if (use_j) {
+            /* second pass over the unclipped first-pass sums: 32-bit arithmetic (sums reach +-430 000) */
+            int jv[4];
+            const uint32_t *t = reinterpret_cast<const uint32_t *>(&s.tmp[y * 16 + 4 * sx]);
+            uint32_t lo[6], hi[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { lo[r] = t[8 * r]; hi[r] = t[8 * r + 1]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int16_t *t = &s.tmp[y * 16 + 4 * sx + k];
-                sum[k] += clip_u8((tap6(t[0], t[16], t[32], t[48], t[64], t[80]) + 512) >> 10);
-            }
-        }
-        const int two = (int)use_g + (int)use_b + (int)use_h + (int)use_j == 2;
-        uint32_t v = 0;
+                int tv[6];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v |= (uint32_t)(two ? (sum[k] + 1) >> 1 : sum[k]) << (8 * k);
+                for (int r = 0; r < 6; r++) { const uint32_t w = k < 2 ? lo[r] : hi[r]; tv[r] = (k & 1) ? (int16_t)(w >> 16) : (int16_t)(w & 0xFFFF); }
+                jv[k] = clip_u8((tap6(tv[0], tv[1], tv[2], tv[3], tv[4], tv[5]) + 512) >> 10);
+            }
+            se = pk_add(se, pk_make(jv[0], jv[2])); so = pk_add(so, pk_make(jv[1], jv[3]));
+        }
+        if ((int)use_g + (int)use_b + (int)use_h + (int)use_j == 2) {
+            se = pk_ashr(pk_add(se, 0x00010001u), 1); so = pk_ashr(pk_add(so, 0x00010001u), 1);
+        }
+        const uint32_t v = pk_bytes(se, so);
         uint8_t *d = &pred[(py + y) * ppitch + px + 4 * sx];
         if (bw >= 4) {
             uint32_t *dw = reinterpret_cast<uint32_t *>(d);
@@ -273,12 +328,10 @@ __device__ inline void mc_chroma_compute(McScratch &s, int nplanes, int fx, int 
         const int y = nseg == 2 ? j >> 1 : j, sx = nseg == 2 ? j & 1 : 0;
         const uint32_t *w0 = &s.winC[plane][y * WC_DW + sx], *w1 = w0 + WC_DW;
         const uint32_t a0 = w0[0], a1 = mi355_alignbyte(w0[1], w0[0], 1), b0 = w1[0], b1 = mi355_alignbyte(w1[1], w1[0], 1);
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sh = 8 * k;
-            v |= (uint32_t)((A * (int)((a0 >> sh) & 0xFF) + B * (int)((a1 >> sh) & 0xFF) + C * (int)((b0 >> sh) & 0xFF) + D * (int)((b1 >> sh) & 0xFF) + 32) >> 6) << sh;
-        }
+        /* (A a + B b + C c + D d + 32) >> 6 on packed pairs: the sums stay below 2^14 */
+        const uint32_t ve = pk_ashr(pk_mad(pk_even(a0), A, pk_mad(pk_even(a1), B, pk_mad(pk_even(b0), C, pk_mad(pk_even(b1), D, 0x00200020u)))), 6);
+        const uint32_t vo = pk_ashr(pk_mad(pk_odd(a0), A, pk_mad(pk_odd(a1), B, pk_mad(pk_odd(b0), C, pk_mad(pk_odd(b1), D, 0x00200020u)))), 6);
+        const uint32_t v = pk_bytes(ve, vo);
         uint8_t *d = (plane ? pred1 : pred0) + (py + y) * ppitch + px + 4 * sx;
         if (bw >= 4) {
             uint32_t *dw = reinterpret_cast<uint32_t *>(d);

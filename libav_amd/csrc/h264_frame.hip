@@ -57,11 +57,11 @@ __device__ __forceinline__ void load_mb_issue(MbLoad &r, const mi355_h264_frame 
     const int lane = lane_id();
     r.hw = r.mw = r.c0 = r.c1 = r.c2 = 0;
     if (!ok) return;
-    const uint32_t *hp = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy]);
-    const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    const uint32_t *hp = reinterpret_cast<const uint32_t *>(&mi355_global(fr.mb)[mb_xy]);
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(mi355_global(fr.coef) + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
     if (lane < 16) r.hw = hp[lane];
-    else if (lane < 32) { if (fr.mv[0]) r.mw = reinterpret_cast<const uint32_t *>(fr.mv[0])[(size_t)mb_xy * 16 + lane - 16]; }
-    else if (lane < 48) { if (fr.mv[1]) r.mw = reinterpret_cast<const uint32_t *>(fr.mv[1])[(size_t)mb_xy * 16 + lane - 32]; }
+    else if (lane < 32) { if (fr.mv[0]) r.mw = reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[0]))[(size_t)mb_xy * 16 + lane - 16]; }
+    else if (lane < 48) { if (fr.mv[1]) r.mw = reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[1]))[(size_t)mb_xy * 16 + lane - 32]; }
     if (with_coefs) { r.c0 = cp[lane]; r.c1 = cp[lane + 64]; r.c2 = cp[lane + 128]; }
 }
 __device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool with_coefs)
@@ -92,9 +92,9 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, con
     const int slot = __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.ref_pic[list][(bx >> 3) + 2 * (by >> 3)]);
     const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
     const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
-    PlaneRef ry{fr.ref[slot][0], fr.dst_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
-    PlaneRef rb{fr.ref[slot][1], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
-    PlaneRef rr{fr.ref[slot][2], fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
+    PlaneRef ry{mi355_global(fr.ref[slot][0]), fr.dst_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
+    PlaneRef rb{mi355_global(fr.ref[slot][1]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
+    PlaneRef rr{mi355_global(fr.ref[slot][2]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
 #ifndef MI355_EXP_NO_STAGE
     stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
 #endif
@@ -255,11 +255,11 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
     const int lane = lane_id();
     {
         const int row = lane >> 2, seg = lane & 3;
-        *reinterpret_cast<uint32_t *>(dst[0] + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword(y + row * ypitch + 4 * seg);
+        *reinterpret_cast<uint32_t *>(mi355_global(dst[0]) + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword(y + row * ypitch + 4 * seg);
     }
     if (lane < 32) {
         const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
-        *reinterpret_cast<uint32_t *>(dst[1 + plane] + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
+        *reinterpret_cast<uint32_t *>(mi355_global_v(dst[1 + plane]) + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
             tile_dword((plane ? cr : cb) + row * cpitch + 4 * seg);
     }
 }
@@ -298,7 +298,7 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     load_mb(s, fr, mb_xy, true);
     PROF_MARK(8);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
-    const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
+    const mi355_h264_slice &sl = mi355_global(fr.slices)[uniform(s.hdr.slice_id)];
     hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
     PROF_MARK(9);
 #ifndef MI355_EXP_NO_RESIDUAL
@@ -335,15 +335,15 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     const int f = blockIdx.x / width, k = blockIdx.x - f * width;
     const mi355_h264_frame &fr = frames[f];
     if (level > fr.max_intra_level) return;
-    const int first = fr.intra_level_start[level - 1], count = fr.intra_level_start[level] - first;
+    const int first = mi355_global(fr.intra_level_start)[level - 1], count = mi355_global(fr.intra_level_start)[level] - first;
     if (k >= count) return;
-    const int mb_xy = (int)fr.intra_list[first + k];
+    const int mb_xy = (int)mi355_global(fr.intra_list)[first + k];
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     load_mb(s.mb, fr, mb_xy, true);
     const mi355_h264_mb &h = s.mb.hdr;
     const uint32_t t = h.mb_type;
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1];
-    uint8_t *const ry = fr.recon[0] + (size_t)mb_y * 16 * ys + mb_x * 16;
+    uint8_t *const ry = mi355_global(fr.recon[0]) + (size_t)mb_y * 16 * ys + mb_x * 16;
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
@@ -358,7 +358,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     }
     if (mb_x > 0 && lane >= 32 && lane < 48) TILE(-1, lane - 32) = ry[(lane - 32) * ys - 1];
     for (int p = 0; p < 2; p++) {
-        const uint8_t *rc = fr.recon[1 + p] + (size_t)mb_y * 8 * cs + mb_x * 8;
+        const uint8_t *rc = mi355_global(fr.recon[1 + p]) + (size_t)mb_y * 8 * cs + mb_x * 8;
         if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0)) s.ctile[p][lane] = rc[lane - 1 - cs];
         if (mb_x > 0 && lane >= 16 && lane < 24) s.ctile[p][(lane - 16 + 1) * CP] = rc[(lane - 16) * cs - 1];
     }
@@ -693,9 +693,9 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     /* the group below (same wave) filters and writes this row's bottom three luma rows / last chroma row */
     const bool below = g < 3 && mb_y + 1 < fr.mb_height;
     /* 16-byte (luma) / 8-byte (chroma) pieces can move as one access when pointers and strides allow */
-    const bool al16 = ((reinterpret_cast<uintptr_t>(fr.recon[0]) | reinterpret_cast<uintptr_t>(fr.dst[0]) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
-    const bool al8 = ((reinterpret_cast<uintptr_t>(fr.recon[1]) | reinterpret_cast<uintptr_t>(fr.recon[2]) | reinterpret_cast<uintptr_t>(fr.dst[1]) |
-                       reinterpret_cast<uintptr_t>(fr.dst[2]) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[0])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[0])) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
+    const bool al8 = ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[1])) | reinterpret_cast<uintptr_t>(mi355_global(fr.recon[2])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[1])) |
+                       reinterpret_cast<uintptr_t>(mi355_global(fr.dst[2])) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
     if (lane < 52) {
         s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
         s.t_tc0[lane][0] = k_tc0[lane][0]; s.t_tc0[lane][1] = k_tc0[lane][1]; s.t_tc0[lane][2] = k_tc0[lane][2]; s.t_tc0[lane][3] = 0;
@@ -705,15 +705,15 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const ptrdiff_t x0 = -2 * g;                         /* macroblock column of step 0 (may be negative: never dereferenced then) */
         const ptrdiff_t yy = row_ok ? mb_y : 0;
         const ptrdiff_t xy0 = yy * W + x0;
-        a.rec = reinterpret_cast<const uint32_t *>(fr.mb) + xy0 * 16 + l;
+        a.rec = reinterpret_cast<const uint32_t *>(mi355_global(fr.mb)) + xy0 * 16 + l;
         a.rec_top = -(ptrdiff_t)W * 16;
-        for (int li = 0; li < 2; li++) a.mv[li] = fr.mv[li] ? reinterpret_cast<const uint32_t *>(fr.mv[li]) + xy0 * 16 + l : nullptr;
+        for (int li = 0; li < 2; li++) a.mv[li] = fr.mv[li] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[li])) + xy0 * 16 + l : nullptr;
         a.mv_top = -(ptrdiff_t)W * 16 + 12;
     }
     /* chunk I/O roles of a lane: piece p of a row pair */
     const int io_p = l & (DCH - 1), io_r = l >> DCH_LOG;
-    const uint8_t *const recon_y = fr.recon[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
-    uint8_t *const dst_y = fr.dst[0] + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
+    const uint8_t *const recon_y = mi355_global(fr.recon[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
+    uint8_t *const dst_y = mi355_global(fr.dst[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
 
     /* load chunk c (macroblocks 8c-2g ..+7) of this group's row into tile parity c & 1 */
     auto load_chunk = [&](int c) {
@@ -726,7 +726,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;            /* luma row; as chroma: plane = row >> 3, row & 7 */
             vy[it] = ok ? ld16(recon_y + (ptrdiff_t)row * rs + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            vc[it] = ok ? ld8(fr.recon[1 + (row >> 3)] + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
+            vc[it] = ok ? ld8(mi355_global_v(fr.recon[1 + (row >> 3)]) + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
         }
         const bool okt = ok && g == 0 && has_t;              /* rows above the band: as the previous band left them */
 #pragma unroll
@@ -734,7 +734,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             const int row = DIO_ROWS * it + io_r;            /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
             const bool in = okt && row < 4;
             ty[it] = in ? ld16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            tc[it] = in ? ld8(fr.dst[1 + ((row >> 1) & 1)] + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
+            tc[it] = in ? ld8(mi355_global_v(fr.dst[1 + ((row >> 1) & 1)]) + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
         }
 #pragma unroll
         for (int it = 0; it < NY; it++) {
@@ -767,7 +767,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                 st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, lds16(&s.y[g][b][row][16 * io_p]), al16);
             const int plane = row >= 10, crow = row - 10 * plane;
             if (ok && crow >= c_first && crow <= c_last)
-                st8(fr.dst[1 + plane] + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
+                st8(mi355_global_v(fr.dst[1 + plane]) + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
         }
     };
 
@@ -838,8 +838,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const uint32_t bsc0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]), bsc1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
         const int qpc_h = h.qpc(cp);
         /* chroma QP of a neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
-        const int qpc_l = hl.slice_id() == h.slice_id() ? hl.qpc(cp) : (have_left ? fr.slices[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0);
-        const int qpc_t = ht.slice_id() == h.slice_id() ? ht.qpc(cp) : (have_top ? fr.slices[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0);
+        const int qpc_l = hl.slice_id() == h.slice_id() ? hl.qpc(cp) : (have_left ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0);
+        const int qpc_t = ht.slice_id() == h.slice_id() ? ht.qpc(cp) : (have_top ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0);
         EdgeParm ev[4], eh[4], cv[2], ch[2];
         {
             /* alpha / beta depend on the edge's QP only: six distinct QPs per lane (luma and chroma: inner

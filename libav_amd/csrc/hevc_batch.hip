@@ -21,7 +21,8 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
     const int lane = lane_id(), half = lane >> 5, hl = lane & 31;
     const int idx = 2 * (int)blockIdx.x + half;
     const bool on = idx < n;
-    const mi355_hevc_tu_job j = jobs[on ? idx : 0];
+    mi355_hevc_tu_job j = jobs[on ? idx : 0];
+    j.coeffs = mi355_global_v(j.coeffs); j.dst = mi355_global_v(j.dst);
     const int size = 1 << j.log2_size, cnt = size * size;
     int16_t *c = s.c[half];
     /* coefficients -> LDS, two per lane and access */
@@ -77,13 +78,14 @@ __global__ void __launch_bounds__(64) k_hevc_mc_batch(const mi355_hevc_mc_job *j
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_mc_job j = jobs[blockIdx.x];
     const int px = bd > 8 ? 2 : 1;
-    hevc_mc_wave(j.dst, j.dst_stride / 2, j.src, j.src_stride / px, j.width, j.height, j.mx, j.my, bd, j.chroma ? 4 : 8, tmp);
+    hevc_mc_wave(mi355_global(j.dst), j.dst_stride / 2, mi355_global(j.src), j.src_stride / px, j.width, j.height, j.mx, j.my, bd, j.chroma ? 4 : 8, tmp);
 }
 
 __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
-    const mi355_hevc_pred_job j = jobs[blockIdx.x];
+    mi355_hevc_pred_job j = jobs[blockIdx.x];
+    j.dst = mi355_global(j.dst); j.src1 = mi355_global(j.src1); j.src2 = mi355_global(j.src2);
     const HevcPredParams p{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
     const int px = bd > 8 ? 2 : 1, dt = j.dst_stride / px, ss = j.src_stride / 2;
     const bool two = (j.kind & 1) != 0;
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_batch(const mi355_hevc_lf_j
     const mi355_hevc_lf_job &j = sj[slot];
     const int px = bd > 8 ? 2 : 1, st = on ? j.stride / px : 0;
     const int xs = on && j.horizontal_edge ? st : 1, ys = on && j.horizontal_edge ? 1 : st;
-    uint8_t *pix = on ? j.pix : nullptr;
+    uint8_t *pix = mi355_global_v(on ? j.pix : nullptr);
     /* luma and chroma jobs may share a launch: both filters run, each on its own groups */
     hevc_lf_luma_wave(pix, xs, ys, on ? j.beta : 0, j.tc, j.no_p, j.no_q, bd, true, on && !j.chroma);
     hevc_lf_chroma_wave(pix, xs, ys, j.tc, j.no_p, j.no_q, bd, true, on && j.chroma);
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
     p.eo_class = j.eo_class; p.band_position = j.band_position;
     for (int k = 0; k < 5; k++) p.offset_val[k] = j.offset_val[k];
     const int st = j.stride / (bd > 8 ? 2 : 1);
-    hevc_sao_wave(j.dst, st, j.src, st, p);
+    hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p);
 }
 
 bool check(int bit_depth, const void *jobs, int n)

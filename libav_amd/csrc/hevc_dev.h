@@ -182,31 +182,91 @@ __device__ __forceinline__ void fir4(const uint32_t *d, const uint32_t *t, int *
 }
 
 /* src points at sample (0,0) of the block inside a plane/window with `ss` samples per row; dst is
- * int16 with `ds` elements per row.  taps = 8 (qpel, :729-937) or 4 (epel, :939-1089).  The samples the
- * taps touch — and only those: a filter that is not applied reads nothing beyond the block, exactly
- * like the reference's per-direction functions — are staged once in LDS (coalesced reads).  A lane then
- * produces four consecutive outputs of a line with dot-product instructions; the vertical filter runs on
- * a TRANSPOSED copy (the horizontal pass writes its results transposed, a vertical-only block is staged
- * transposed) so that neighbouring taps are neighbouring values there too. */
-constexpr int HEVC_MC_PITCH = 76;      /* >= 64 + 7 + the 4 values a segment may read past the last tap; even */
-struct HevcMcScratch {
-    uint16_t win[(64 + 7) * HEVC_MC_PITCH];      /* [row][col], or [col][row] for vertical-only blocks */
-    int16_t tmp[64 * HEVC_MC_PITCH];             /* [col][row]: first-pass results of the 2-D case */
+ * int16 with `ds` elements per row.  taps = 8 (qpel, :729-937) or 4 (epel, :939-1089).  A block is worked
+ * off in tiles of at most 32x32 outputs.  The samples the taps of a tile touch — and only those: a filter
+ * that is not applied reads nothing beyond the block, exactly like the reference's per-direction functions —
+ * are staged once in LDS as 16-bit values, eight bytes per lane and load.  Horizontal pass: a lane produces
+ * four consecutive outputs of a row with dot-product instructions on (sample, sample+1) dwords.  Vertical
+ * pass: a lane owns two neighbouring columns and eight rows; it builds the (row, row+1) dwords of each
+ * column with one byte-permute per pair and feeds the same dot products, so both passes work on the
+ * row-major layout and every result leaves as a dword (two int16) or wider. */
+constexpr int HEVC_MC_TILE = 32;
+constexpr int HEVC_MC_PITCH = 44;      /* values per LDS row: >= 32 + 7 + the 4 values a segment may read past its last tap */
+constexpr int HEVC_MC_ROWS = 40;
+struct __attribute__((aligned(16))) HevcMcScratch {
+    uint16_t win[HEVC_MC_ROWS * HEVC_MC_PITCH];      /* staged samples */
+    int16_t tmp[HEVC_MC_ROWS * HEVC_MC_PITCH];       /* first-pass results of the 2-D case */
 };
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
+static inline uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
+static inline uint32_t mi355_widen_lo(uint32_t w) { return (w & 0xFFu) | ((w & 0xFF00u) << 8); }
+static inline uint32_t mi355_widen_hi(uint32_t w) { return ((w >> 16) & 0xFFu) | ((w >> 8) & 0xFF0000u); }
+#else
+/* v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0C = zero */
+__device__ __forceinline__ uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ uint32_t mi355_widen_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C010C00u); }
+__device__ __forceinline__ uint32_t mi355_widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C030C02u); }
+#endif
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+/* alignment class of the int16 destination: 8, 4 or 2 bytes for every row start */
+__device__ __forceinline__ int hevc_mc_align(const int16_t *dst, int ds)
+{
+    const unsigned a = (unsigned)(uintptr_t)dst | (unsigned)(ds * 2);
+    return (a & 7) == 0 ? 8 : ((a & 3) == 0 ? 4 : 2);
+}
+__device__ __forceinline__ void hevc_mc_st2(int16_t *p, uint32_t v, int amode)
+{
+    if (amode >= 4) *reinterpret_cast<uint32_t *>(p) = v;
+    else { p[0] = (int16_t)(v & 0xFFFF); p[1] = (int16_t)(v >> 16); }
+}
+/* four results (n of them inside the block) */
+__device__ __forceinline__ void hevc_mc_st4(int16_t *p, uint32_t lo, uint32_t hi, int n, int amode)
+{
+    if (n >= 4) {
+        if (amode == 8) *reinterpret_cast<uint2 *>(p) = make_uint2(lo, hi);
+        else { hevc_mc_st2(p, lo, amode); hevc_mc_st2(p + 2, hi, amode); }
+    } else {
+        if (n >= 2) hevc_mc_st2(p, lo, amode); else if (n == 1) p[0] = (int16_t)(lo & 0xFFFF);
+        if (n == 3) p[2] = (int16_t)(hi & 0xFFFF);
+    }
+}
+/* rows x cols samples from `w0` (bytes, `sb` bytes per row) -> s.win as 16-bit values */
+__device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdiff_t sb, int rows, int cols, int bd)
+{
+    const int lane = lane_id(), rowbytes = cols * (bd > 8 ? 2 : 1);
+    if (rowbytes >= 8) {
+        const int K = (rowbytes + 7) >> 3, inv = (65536 + K - 1) / K;      /* i / K for i < 65536 / K */
+        for (int i = lane; i < rows * K; i += 64) {
+            const int r = (i * inv) >> 16, k = i - r * K;
+            /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
+            const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
+            uint64_t v;
+            __builtin_memcpy(&v, w0 + (ptrdiff_t)r * sb + start, 8);
+            v >>= 8 * (want - start);
+            const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+            if (bd > 8) {
+                *reinterpret_cast<uint2 *>(&s.win[r * HEVC_MC_PITCH + 4 * k]) = make_uint2(lo, hi);
+            } else {
+                uint32_t *w = reinterpret_cast<uint32_t *>(&s.win[r * HEVC_MC_PITCH + 8 * k]);
+                w[0] = mi355_widen_lo(lo); w[1] = mi355_widen_hi(lo); w[2] = mi355_widen_lo(hi); w[3] = mi355_widen_hi(hi);
+            }
+        }
+    } else {
+        for (int i = lane; i < rows * cols; i += 64) {
+            const int r = i / cols, c = i - r * cols;
+            s.win[r * HEVC_MC_PITCH + c] = (uint16_t)(bd > 8 ? reinterpret_cast<const uint16_t *>(w0 + (ptrdiff_t)r * sb)[c] : w0[(ptrdiff_t)r * sb + c]);
+        }
+    }
+}
 template <int TAPS>
 __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
                                     int mx, int my, int bd, HevcMcScratch &s)
 {
-    const int lane = lane_id();
+    const int lane = lane_id(), px = bd > 8 ? 2 : 1;
     constexpr int before = TAPS == 8 ? 3 : 1, extra = TAPS - 1;
     const int8_t *fh = TAPS == 8 ? k_qpel[mx] : k_epel[mx], *fv = TAPS == 8 ? k_qpel[my] : k_epel[my];
-    if (!mx && !my) {
-        for (int i = lane; i < height * width; i += 64) {
-            const int y = i / width, x = i - y * width;
-            dst[x + y * ds] = (int16_t)(ldpx(src, x + y * ss, bd) << (14 - bd));
-        }
-        return;
-    }
     uint32_t th[TAPS / 2], tv[TAPS / 2];
 #pragma unroll
     for (int k = 0; k < TAPS / 2; k++) {
@@ -214,50 +274,69 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
         tv[k] = (uint32_t)(uint16_t)(int16_t)fv[2 * k] | ((uint32_t)(uint16_t)(int16_t)fv[2 * k + 1] << 16);
     }
     const int bx = mx ? before : 0, by = my ? before : 0;
-    const int cols = width + (mx ? extra : 0), rows = height + (my ? extra : 0);
-    const bool transposed = !mx;                          /* vertical only: stage [col][row] */
-    for (int i = lane; i < rows * cols; i += 64) {
-        const int r = i / cols, c = i - r * cols;
-        const uint16_t v = (uint16_t)ldpx(src, (c - bx) + (r - by) * ss, bd);
-        if (transposed) s.win[c * HEVC_MC_PITCH + r] = v; else s.win[r * HEVC_MC_PITCH + c] = v;
-    }
-    __syncthreads();
-    const int wseg = (width + 3) >> 2, hseg = (height + 3) >> 2;
-    if (mx) {
-        /* horizontal pass over `rows` lines, four outputs per lane */
-        for (int i = lane; i < rows * wseg; i += 64) {
-            const int r = i / wseg, x0 = 4 * (i - r * wseg);
-            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
-            uint32_t dd[6];
-#pragma unroll
-            for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
-            int o[4];
-            fir4<TAPS>(dd, th, o);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = o[j] >> (bd - 8);
-                if (x0 + j >= width) continue;
-                if (my) s.tmp[(x0 + j) * HEVC_MC_PITCH + r] = (int16_t)v;
-                else dst[x0 + j + r * ds] = (int16_t)v;
+    const int amode = hevc_mc_align(dst, ds);
+    const ptrdiff_t sb = (ptrdiff_t)ss * px;
+    for (int ty = 0; ty < height; ty += HEVC_MC_TILE)
+    for (int tx = 0; tx < width; tx += HEVC_MC_TILE) {
+        const int tw = width - tx < HEVC_MC_TILE ? width - tx : HEVC_MC_TILE, th_ = height - ty < HEVC_MC_TILE ? height - ty : HEVC_MC_TILE;
+        const int rows = th_ + (my ? extra : 0);
+        int16_t *out = dst + (ptrdiff_t)ty * ds + tx;
+        hevc_mc_stage(s, src + (ptrdiff_t)(ty - by) * sb + (ptrdiff_t)(tx - bx) * px, sb, rows, tw + (mx ? extra : 0), bd);
+        __syncthreads();
+        const int wseg = (tw + 3) >> 2, winv = (65536 + wseg - 1) / wseg;
+        if (!mx && !my) {
+            /* put_hevc_*_pixels: sample << (14 - bd); two values per dword shift together (no carry across) */
+            for (int i = lane; i < rows * wseg; i += 64) {
+                const int r = (i * winv) >> 16, x0 = 4 * (i - r * wseg);
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
+                hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, d[0] << (14 - bd), d[1] << (14 - bd), tw - x0, amode);
             }
         }
-        if (!my) return;
+        if (mx) {
+            /* horizontal pass over `rows` lines, four outputs per lane */
+            for (int i = lane; i < rows * wseg; i += 64) {
+                const int r = (i * winv) >> 16, x0 = 4 * (i - r * wseg);
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
+                uint32_t dd[6];
+#pragma unroll
+                for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
+                int o[4];
+                fir4<TAPS>(dd, th, o);
+                const uint32_t lo = pack16(o[0] >> (bd - 8), o[1] >> (bd - 8)), hi = pack16(o[2] >> (bd - 8), o[3] >> (bd - 8));
+                if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_PITCH + x0]) = make_uint2(lo, hi);
+                else hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, lo, hi, tw - x0, amode);
+            }
+            if (my) __syncthreads();
+        }
+        if (my) {
+            /* vertical pass: lane = (column pair, eight output rows) */
+            const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
+            const int vshift = mx ? 6 : bd - 8;
+            const int cp = tw >> 1, cinv = (65536 + cp - 1) / cp, oct = (th_ + 7) >> 3;
+            for (int i = lane; i < cp * oct; i += 64) {
+                const int q = (i * cinv) >> 16, c2 = i - q * cp, y0 = 8 * q;
+                const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
+                int a0[8], a1[8];
+#pragma unroll
+                for (int y = 0; y < 8; y++) a0[y] = a1[y] = 0;
+                uint32_t prev = d[0];
+#pragma unroll
+                for (int r = 0; r < 8 + TAPS - 2; r++) {
+                    const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
+                    const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
+                    prev = cur;
+#pragma unroll
+                    for (int k = 0; k < TAPS / 2; k++) {
+                        const int y = r - 2 * k;
+                        if (y >= 0 && y < 8) { a0[y] = mi355_dot2(p0, tv[k], a0[y]); a1[y] = mi355_dot2(p1, tv[k], a1[y]); }
+                    }
+                }
+#pragma unroll
+                for (int y = 0; y < 8; y++)
+                    if (y0 + y < th_) hevc_mc_st2(out + (ptrdiff_t)(y0 + y) * ds + 2 * c2, pack16(a0[y] >> vshift, a1[y] >> vshift), amode);
+            }
+        }
         __syncthreads();
-    }
-    /* vertical pass along the transposed lines: lane = (column, four output rows) */
-    const int16_t *lines = mx ? s.tmp : reinterpret_cast<const int16_t *>(s.win);
-    const int vshift = mx ? 6 : bd - 8;
-    for (int i = lane; i < width * hseg; i += 64) {
-        const int q = i / width, x = i - q * width, y0 = 4 * q;
-        const uint32_t *d = reinterpret_cast<const uint32_t *>(&lines[x * HEVC_MC_PITCH + y0]);
-        uint32_t dd[6];
-#pragma unroll
-        for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
-        int o[4];
-        fir4<TAPS>(dd, tv, o);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (y0 + j < height) dst[x + (y0 + j) * ds] = (int16_t)(o[j] >> vshift);
     }
 }
 __device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,

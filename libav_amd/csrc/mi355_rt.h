@@ -19,6 +19,36 @@
 #include <cstdlib>
 #include <cstring>
 
+/* A pointer read from a job or picture record has no known address space, and accesses through it become
+ * flat_* instructions, which count against the LDS counter as well as the memory one (every wait for LDS
+ * then also waits for the loads in flight).  A round trip through the global address space, hidden from
+ * the optimiser by an empty asm, turns them into global_* ones.  mi355_global: wave-uniform pointers
+ * (kept in scalar registers), mi355_global_v: per-lane pointers. */
+template <class T> __device__ __forceinline__ T *mi355_global(T *p)
+{
+#if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
+    return p;
+#else
+    /* readfirstlane: a uniform value the compiler could not prove uniform still lands in scalar registers */
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned long long u = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+    auto q = (__attribute__((address_space(1))) T *)u;
+    asm volatile("" : "+s"(q));
+    return (T *)q;
+#endif
+}
+template <class T> __device__ __forceinline__ T *mi355_global_v(T *p)
+{
+#if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
+    return p;
+#else
+    auto q = (__attribute__((address_space(1))) T *)p;
+    asm volatile("" : "+v"(q));
+    return (T *)q;
+#endif
+}
+
 #define MI355_CHECK(expr)                                                                    \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

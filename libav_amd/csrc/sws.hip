@@ -231,8 +231,12 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     __shared__ int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
     __shared__ LutLds s_lut;
     __shared__ uint8_t s_out[MAXTH][TW * 3];
-    const SwsDev &c = *cp;
-    const mi355_sws_frame fr = frames[blockIdx.z];
+    SwsDev c = *cp;                                   /* pointers of the records: global address space (mi355_rt.h) */
+    c.hLumC = mi355_global(c.hLumC); c.hChrC = mi355_global(c.hChrC); c.vLumC = mi355_global(c.vLumC); c.vChrC = mi355_global(c.vChrC);
+    c.hLumP = mi355_global(c.hLumP); c.hChrP = mi355_global(c.hChrP); c.vLumP = mi355_global(c.vLumP); c.vChrP = mi355_global(c.vChrP);
+    mi355_sws_frame fr = frames[blockIdx.z];
+    for (int k = 0; k < 3; k++) fr.src[k] = mi355_global(fr.src[k]);
+    fr.dst = mi355_global(fr.dst);
     const int tid = threadIdx.x, th = c.th;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * th, y1 = imin(y0 + th, c.dstH) - 1;
     const int ls = c.vls, cs = c.vcs;
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     const int cfirst0 = imax(1 - cs, c.vChrP[y0]), cfirst1 = imax(1 - cs, c.vChrP[y1]);
     const int llo = clampi(lfirst0, 0, c.srcH - 1), lhi = clampi(lfirst1 + ls - 1, 0, c.srcH - 1);
     const int clo = clampi(cfirst0, 0, c.chrSrcH - 1), chi = clampi(cfirst1 + cs - 1, 0, c.chrSrcH - 1);
-    lut_load(s_lut, &c.luts, tid, NT);
+    lut_load(s_lut, &cp->luts, tid, NT);
     /* horizontal pass: luma (the phantom partner of the last sample of an odd-width picture reads the
      * zero-initialised tail of the reference's line buffer, utils.c:1241-1262), then the chroma planes */
     __shared__ uint32_t s_stage[SG][SRC_DW];
@@ -294,7 +298,9 @@ __global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int 
 {
     __shared__ LutLds s_lut;
     const int tid = threadIdx.x;
-    const mi355_sws_frame fr = frames[blockIdx.z];
+    mi355_sws_frame fr = frames[blockIdx.z];
+    for (int k = 0; k < 3; k++) fr.src[k] = mi355_global(fr.src[k]);
+    fr.dst = mi355_global(fr.dst);
     lut_load(s_lut, luts, tid, NT);
     __syncthreads();
     const int x = blockIdx.x * 256 + (tid & 127) * 2;    /* first sample of the pair */
