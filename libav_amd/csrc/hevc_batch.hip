@@ -89,6 +89,21 @@ __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_jo
     const HevcPredParams p{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
     const int px = bd > 8 ? 2 : 1, dt = j.dst_stride / px, ss = j.src_stride / 2;
     const bool two = (j.kind & 1) != 0;
+    /* two samples per lane and access when the rows allow it (block widths are even) */
+    const unsigned al = (unsigned)(uintptr_t)j.src1 | (two ? (unsigned)(uintptr_t)j.src2 : 0u) | (unsigned)j.src_stride |
+                        ((unsigned)(uintptr_t)j.dst | (unsigned)j.dst_stride) * (bd > 8 ? 1u : 2u) | ((unsigned)j.width & 1u) * 4u;
+    if ((al & 3) == 0) {
+        const int hw = j.width >> 1, n = hw * j.height, inv = ((1 << 20) + hw - 1) / hw;     /* i / hw, exact for i * (hw - 1) < 2^20 */
+        for (int i = lane_id(); i < n; i += 64) {
+            const int y = (int)(__umul24((unsigned)i, (unsigned)inv) >> 20), x = 2 * (i - y * hw);
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(&j.src1[x + y * ss]);
+            const uint32_t b = two ? *reinterpret_cast<const uint32_t *>(&j.src2[x + y * ss]) : 0u;
+            const int v0 = hevc_pred_px(p, (int16_t)(a & 0xFFFF), (int16_t)(b & 0xFFFF), bd), v1 = hevc_pred_px(p, (int16_t)(a >> 16), (int16_t)(b >> 16), bd);
+            if (bd > 8) *reinterpret_cast<uint32_t *>(j.dst + (size_t)y * j.dst_stride + 2 * x) = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            else *reinterpret_cast<uint16_t *>(j.dst + (size_t)y * j.dst_stride + x) = (uint16_t)(v0 | (v1 << 8));
+        }
+        return;
+    }
     for (int i = lane_id(); i < j.width * j.height; i += 64) {
         const int y = i / j.width, x = i - y * j.width;
         stpx(j.dst, x + y * dt, hevc_pred_px(p, j.src1[x + y * ss], two ? j.src2[x + y * ss] : 0, bd), bd);

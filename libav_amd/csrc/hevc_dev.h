@@ -449,9 +449,9 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
     if (cls & 2) { x0 = -cw; w = cw; } else if (!j.borders[2]) w -= cw;
     const int w0 = w, h0 = h;
     if (!j.edge) {
-        const int shift = bd - 5;
+        const int shift = bd - 5, winv = ((1 << 20) + w - 1) / (w > 0 ? w : 1);     /* i / w: exact for i * (w - 1) < 2^20 */
         for (int i = lane_id(); i < w * h; i += 64) {
-            const int y = i / w, x = i - y * w, o = (y0 + y) * st + x0 + x;
+            const int y = (int)(__umul24((unsigned)i, (unsigned)winv) >> 20), x = i - y * w, o = (y0 + y) * st + x0 + x;
             const int v = ldpx(src, o, bd), k = ((v >> shift) - j.band_position) & 31;
             stpx(dst, (y0 + y) * dt + x0 + x, clip_px(v + (k < 4 ? j.offset_val[k + 1] : 0), bd), bd);
         }
@@ -474,8 +474,9 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
     else save = !j.diag_edge && eo == 2;
     const int ya = init_y + ((cls & 1) ? 0 : save), yb = h - ((cls & 1) ? save : 0);
     const int xa = init_x + ((cls & 2) ? 0 : save), xb = w - ((cls & 2) ? save : 0);
+    const int winv = ((1 << 20) + w0 - 1) / (w0 > 0 ? w0 : 1);                        /* i / w0: exact for i * (w0 - 1) < 2^20 */
     for (int i = lane_id(); i < w0 * h0; i += 64) {
-        const int y = i / w0, x = i - y * w0, o = (y0 + y) * st + x0 + x;
+        const int y = (int)(__umul24((unsigned)i, (unsigned)winv) >> 20), x = i - y * w0, o = (y0 + y) * st + x0 + x;
         const int c = ldpx(src, o, bd);
         int v;
         const bool in_main = x >= init_x && x < w && y >= init_y && y < h;

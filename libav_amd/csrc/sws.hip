@@ -105,11 +105,25 @@ struct TileRows {
 
 /* Horizontal pass of one plane for a tile: COLS output columns starting at gx0, source lines lo..hi, results
  * to out[line - lo][x].  The source span the columns need ([pos[gx0], pos[last] + fs), monotonic positions)
- * is staged in LDS SG lines at a time with aligned dword loads — 10 coalesced loads per thread instead of
- * fs single-byte loads per output sample; spans wider than the stage, unaligned planes and non-monotonic
+ * is staged in LDS SG lines at a time with aligned 16-byte (or dword) loads — a few coalesced loads per thread
+ * instead of fs single-byte loads per output sample; spans wider than the stage, unaligned planes and non-monotonic
  * filters take the direct path. */
-constexpr int SG = 8;                 /* source lines per staging round */
+constexpr int SG = 16;                /* source lines per staging round */
 constexpr int SRC_DW = 76;            /* dwords per staged line: 2:1 with 8 taps needs 128 * 2 + 8 bytes (+2 of slack for zero taps) */
+template <int COLS, int TAPS>
+__device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0, const int *cf, int left)
+{
+    constexpr int per = NT / COLS;
+#pragma unroll
+    for (int k = 0; k < SG / per; k++) {
+        const uint8_t *row = row0 + k * per * (SRC_DW * 4);
+        int val = 0;
+#pragma unroll
+        for (int j = 0; j < TAPS; j++) val += (int)row[j] * cf[j];
+        val >>= 7;
+        if (k * per <= left) out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
+    }
+}
 template <int COLS>
 __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t *src, int stride, int srcW, const int32_t *posT,
                                             const int16_t *coefT, int fs, int gx0, int ncols, int lo, int hi,
@@ -120,7 +134,9 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
     const int pos = col_ok ? posT[gx] : 0;
     const int16_t *f = coefT + (size_t)(col_ok ? gx : 0) * fs;
     const int last = imin(gx0 + COLS, ncols) - 1;
-    const int s0 = posT[gx0], s1 = posT[last] + fs, a0 = s0 & ~3, nd = (s1 - a0 + 3) >> 2;
+    /* 16-byte pieces when the plane allows it, dwords otherwise */
+    const bool al16 = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
+    const int s0 = posT[gx0], s1 = posT[last] + fs, a0 = al16 ? (s0 & ~15) : (s0 & ~3), nd = (s1 - a0 + 3) >> 2;
     /* the column's filter in registers: the line loops below multiply by them instead of reloading */
     int cf[8];
 #pragma unroll
@@ -134,10 +150,28 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         }
         return;
     }
+    /* idx / n as a 24-bit multiply and a shift: exact for idx * (n - 1) < 2^20 (idx < SG * SRC_DW) */
+    const int np = al16 ? (nd + 3) >> 2 : nd, inv = ((1 << 20) + np - 1) / np;
     for (int base = lo; base <= hi; base += SG) {
-        for (int idx = tid; idx < SG * nd; idx += NT) {
-            const int r = idx / nd, d = idx - r * nd, line = base + r;
+        for (int idx = tid; idx < SG * np; idx += NT) {
+            const int r = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), d = idx - r * np, line = base + r;
             if (line > hi) continue;
+            if (al16) {
+                const int off = a0 + 16 * d;
+                const uint8_t *p = src + (size_t)line * stride + off;
+                uint4 w;
+                if (off + 16 <= srcW) w = *reinterpret_cast<const uint4 *>(p);
+                else {
+                    uint32_t q[4];
+                    for (int k = 0; k < 4; k++) {
+                        q[k] = 0;
+                        for (int b = 0; b < 4; b++) if (off + 4 * k + b < srcW) q[k] |= (uint32_t)p[4 * k + b] << (8 * b);
+                    }
+                    w = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+                *reinterpret_cast<uint4 *>(&stage[r][4 * d]) = w;
+                continue;
+            }
             const uint8_t *p = src + (size_t)line * stride + a0 + 4 * d;
             uint32_t w;
             if (a0 + 4 * d + 4 <= srcW) w = *reinterpret_cast<const uint32_t *>(p);
@@ -148,26 +182,29 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
             stage[r][d] = w;
         }
         __syncthreads();
-        for (int r = tid / COLS; r < SG && base + r <= hi; r += per) {
-            if (col_ok) {
-                const uint8_t *row = reinterpret_cast<const uint8_t *>(stage[r]) + (pos - a0);
-                int val = 0;
-                if (fs <= 2) {
-                    val = (int)row[0] * cf[0] + (int)row[1] * cf[1];               /* taps past fs are zero; the bytes exist (slack) */
-                } else if (fs <= 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) val += (int)row[j] * cf[j];
-                } else if (fs <= 8) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) val += (int)row[j] * cf[j];
-                } else {
+        /* the thread's column over the staged lines: fixed trip count, so line and output addresses are
+         * immediate offsets from one base each; tap count rounded up to 1 / 2 / 4 / 8 (taps past fs are zero, the
+         * bytes exist: slack) */
+        const int r0 = tid / COLS;
+        const uint8_t *row0 = reinterpret_cast<const uint8_t *>(stage[r0]) + (pos - a0);
+        int16_t *out0 = &out[base + r0 - lo][x];
+        const int left = hi - base - r0;                     /* lines r0, r0 + per, ... while k * per <= left */
+        if (col_ok) {
+            if (fs == 1) hscale_lines<COLS, 1>(row0, out0, cf, left);
+            else if (fs <= 2) hscale_lines<COLS, 2>(row0, out0, cf, left);
+            else if (fs <= 4) hscale_lines<COLS, 4>(row0, out0, cf, left);
+            else if (fs <= 8) hscale_lines<COLS, 8>(row0, out0, cf, left);
+            else {
+                for (int k = 0; k < SG / per && k * per <= left; k++) {
+                    const uint8_t *row = row0 + k * per * (SRC_DW * 4);
+                    int val = 0;
                     for (int j = 0; j < fs; j++) val += (int)row[j] * f[j];
+                    val >>= 7;
+                    out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
                 }
-                val >>= 7;
-                out[base + r - lo][x] = (int16_t)(val < 32767 ? val : 32767);
-            } else if (zero_tail) {
-                out[base + r - lo][x] = 0;
             }
+        } else if (zero_tail) {
+            for (int k = 0; k < SG / per && k * per <= left; k++) out0[k * per * COLS] = 0;
         }
         __syncthreads();
     }
@@ -230,7 +267,7 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     __shared__ int16_t s_lum[MAXL][TW];
     __shared__ int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
     __shared__ LutLds s_lut;
-    __shared__ uint8_t s_out[MAXTH][TW * 3];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[MAXTH][TW * 3];
     SwsDev c = *cp;                                   /* pointers of the records: global address space (mi355_rt.h) */
     c.hLumC = mi355_global(c.hLumC); c.hChrC = mi355_global(c.hChrC); c.vLumC = mi355_global(c.vLumC); c.vChrC = mi355_global(c.vChrC);
     c.hLumP = mi355_global(c.hLumP); c.hChrP = mi355_global(c.hChrP); c.vLumP = mi355_global(c.vLumP); c.vChrP = mi355_global(c.vChrP);
@@ -248,14 +285,19 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     lut_load(s_lut, &cp->luts, tid, NT);
     /* horizontal pass: luma (the phantom partner of the last sample of an odd-width picture reads the
      * zero-initialised tail of the reference's line buffer, utils.c:1241-1262), then the chroma planes */
-    __shared__ uint32_t s_stage[SG][SRC_DW];
+    /* the staging lines live in the output tile's storage: that is written only after the horizontal pass */
+    static_assert(sizeof(uint32_t) * SG * SRC_DW <= sizeof(s_out), "staging lines must fit into the output tile");
+    uint32_t (*s_stage)[SRC_DW] = reinterpret_cast<uint32_t (*)[SRC_DW]>(&s_out[0][0]);
+#ifndef MI355_SWS_NO_H
     hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0);
     hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
     hscale_tile<TW / 2>(s_cv, fr.src[2], fr.src_stride[2], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
+#endif
     __syncthreads();
     /* vertical pass + LUT */
     const int mode = packed_mode(ls, cs);
     const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
+#ifndef MI355_SWS_NO_V
     if (ls <= 8 && cs <= 8) {
         /* tap counts in registers, rounded up to 1 / 2 / 4 / 8 */
         const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
@@ -277,18 +319,34 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
         else if (mode == 2) { ya = c.vLumC[2 * gy + 1]; ua = c.vChrC[2 * gy + 1]; }
         rgb_pair(s_lut, &s_out[row][i * 6], R, i, mode, c.vLumC + (size_t)gy * ls, ls, c.vChrC + (size_t)gy * cs, cs, ya, ua);
     }
+#endif
     __syncthreads();
     /* rows out: only samples below dstW (for odd dstW the reference also writes the phantom partner of
      * the last sample from uninitialised ring-buffer data; that sample is not reproduced) */
     const int nbytes = imin(TW, c.dstW - x0) * 3;
-    for (int row = 0; row <= y1 - y0; row++) {
-        uint8_t *d = fr.dst + (size_t)(y0 + row) * fr.dst_stride + (size_t)x0 * 3;
-        if (((uintptr_t)d & 3) == 0 && (nbytes & 3) == 0) {
-            for (int k = tid; k < nbytes / 4; k += NT) reinterpret_cast<uint32_t *>(d)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
+#ifndef MI355_SWS_NO_OUT
+    {
+        uint8_t *d0 = fr.dst + (size_t)y0 * fr.dst_stride + (size_t)x0 * 3;
+        const int nrows = y1 - y0 + 1;
+        const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
+        if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
+            const int n = nbytes >> 4, inv = ((1 << 20) + n - 1) / n;
+            for (int idx = tid; idx < nrows * n; idx += NT) {
+                const int row = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), k = idx - row * n;
+                reinterpret_cast<uint4 *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint4 *>(s_out[row])[k];
+            }
+        } else if ((al & 3) == 0) {
+            const int n = nbytes >> 2, inv = ((1 << 20) + n - 1) / n;
+            for (int idx = tid; idx < nrows * n; idx += NT) {
+                const int row = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), k = idx - row * n;
+                reinterpret_cast<uint32_t *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
+            }
         } else {
-            for (int k = tid; k < nbytes; k += NT) d[k] = s_out[row][k];
+            for (int row = 0; row < nrows; row++)
+                for (int k = tid; k < nbytes; k += NT) d0[(size_t)row * fr.dst_stride + k] = s_out[row][k];
         }
     }
+#endif
 }
 
 /* yuv2rgb_c_24_rgb (yuv2rgb.c:335-363): a block converts a 256 x 16 sample tile, each thread a

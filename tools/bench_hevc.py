@@ -104,6 +104,21 @@ def main():
     p_mcs = d.up_jobs(mcs)
     timed("qpel/epel MC to 14 bit", lambda: lib.mi355_hevc_mc_batch_dev(C.c_void_p(p_mcs), n_mc, BD, None), n_mc, (2048 + 2 * 512) / 3 * 2)
 
+    # ---- put_unweighted_pred: the 14-bit intermediates of the PUs -> samples of the reconstruction surface -----------
+    preds = []
+    k = 0
+    for p in range(P):
+        for by in range(H // 32):
+            for bx in range(W // 32):
+                base = p_i16 + k * 3072
+                preds.append(HB.PredJob(p_a + p * ysz + by * 32 * stride + bx * 32 * PX, base, 0, stride, 64, 32, 32, 0, 0, 0, 0, 0, 0))
+                for pl in range(2):
+                    preds.append(HB.PredJob(p_ca + (p * 2 + pl) * csz + by * 16 * (stride // 2) + bx * 16 * PX, base + 2048 + pl * 512, 0,
+                                            stride // 2, 32, 16, 16, 0, 0, 0, 0, 0, 0))
+                k += 1
+    p_preds = d.up_jobs(preds)
+    timed("put_unweighted_pred", lambda: lib.mi355_hevc_pred_batch_dev(C.c_void_p(p_preds), len(preds), BD, None), len(preds), (2048 + 2 * 512) / 3 * 2)
+
     # ---- deblocking: every 8-sample luma edge segment of the 8x8 grid, vertical pass then horizontal pass ------
     def edges(horizontal):
         out = []
@@ -122,6 +137,29 @@ def main():
         p_js = d.up_jobs(js)
         timed(name, lambda p_js=p_js, n=len(js): lib.mi355_hevc_deblock_batch_dev(C.c_void_p(p_js), n, BD, None), len(js), 8 * 8 * PX * 2)
 
+    # chroma edges lie on the 8x8 chroma grid and are filtered only for bS 2 (10 % of them)
+    def chroma_edges(horizontal):
+        out = []
+        for p in range(P):
+            for pl in range(2):
+                for gy in range(H // 16):
+                    for gx in range(W // 16):
+                        if (gy if horizontal else gx) == 0:
+                            continue
+                        for half in range(1):
+                            if rng.random() >= 0.1:
+                                continue
+                            j = HB.LfJob(p_ca + (p * 2 + pl) * csz + gy * 8 * (stride // 2) + gx * 8 * PX, stride // 2, 0)
+                            j.tc[0], j.tc[1] = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+                            j.horizontal_edge = horizontal
+                            j.chroma = 1
+                            out.append(j)
+        return out
+    for horizontal, name in ((0, "deblock chroma, vertical edges (bS 2)"), (1, "deblock chroma, horizontal edges (bS 2)")):
+        js = chroma_edges(horizontal)
+        p_js = d.up_jobs(js)
+        timed(name, lambda p_js=p_js, n=len(js): lib.mi355_hevc_deblock_batch_dev(C.c_void_p(p_js), n, BD, None), len(js), 8 * 4 * PX * 2)
+
     # ---- SAO on every luma CTB (edge class, no picture-border special cases) + both chroma CTBs -------------------
     sao = []
     for p in range(P):
@@ -136,6 +174,30 @@ def main():
     p_sao = d.up_jobs(sao)
     timed("SAO luma CTB (class 0 region)", lambda: lib.mi355_hevc_sao_batch_dev(C.c_void_p(p_sao), len(sao), BD, None), len(sao), 54 * 58 * PX * 2)
 
+    csao = []
+    cs = stride // 2
+    for p in range(P):
+        for pl in range(2):
+            for cy in range(1, H // 64 - 1):
+                for cx in range(1, W // 64 - 1):
+                    o = (p * 2 + pl) * csz + cy * 32 * cs + cx * 32 * PX
+                    j = HB.SaoJob(p_cb + o, p_ca + o, cs, 32, 32)
+                    for i in range(1, 5):
+                        j.offset_val[i] = int(rng.integers(-28, 28))
+                    j.cls, j.edge, j.c_idx, j.eo_class = 0, int(rng.random() < 0.67), 1 + pl, int(rng.integers(0, 4))
+                    j.band_position = int(rng.integers(0, 32))
+                    csao.append(j)
+    p_csao = d.up_jobs(csao)
+    timed("SAO chroma CTBs (class 0 region)", lambda: lib.mi355_hevc_sao_batch_dev(C.c_void_p(p_csao), len(csao), BD, None), len(csao), 26 * 28 * PX * 2)
+
+    # ---- the chain: one launch per stage for the whole batch, summed --------------------------------------------
+    chain_ms = sum(r["ms_per_launch"] for r in results)
+    ctbs = P * (W // 64) * ((H + 63) // 64)
+    chain = {"chain": "config 3: residual + MC + pred + deblock (luma V/H, chroma V/H) + SAO (luma, chroma)", "pictures": P,
+             "ms_per_batch": chain_ms, "pictures_per_s": P / chain_ms * 1e3, "ctb_per_s": ctbs / chain_ms * 1e3,
+             "mb_equivalents_per_s": 16 * ctbs / chain_ms * 1e3, "algorithmic_bytes_per_ctb": 73984,
+             "frac_of_8TBps": ctbs * 73984 / chain_ms / 1e6 / 8000}
+
     # ---- CPU oracle on a sample of the transform stage ---------------------------------------------------------
     orc = providers.oracle().hevcdsp(BD)
     blk = coef[:256].copy()
@@ -145,6 +207,7 @@ def main():
     cpu = 256 / (time.time() - t)
     for r in results:
         print(json.dumps(r))
+    print(json.dumps(chain))
     print(json.dumps({"cpu_oracle_idct32_per_s_1core": cpu}))
     d.free()
 
