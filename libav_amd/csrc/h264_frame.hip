@@ -494,8 +494,11 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
 #define MI355_DCH_LOG 2
 #endif
 constexpr int DCH_LOG = MI355_DCH_LOG, DCH = 1 << DCH_LOG;    /* macroblocks per chunk */
-constexpr int DY_PITCH = 16 * DCH + 8;            /* + 8: the sixteen rows of a 16-lane, 8-byte access fall on 32 different banks */
-constexpr int DC_PITCH = 8 * DCH + 8;
+#ifndef MI355_DPAD
+#define MI355_DPAD 8
+#endif
+constexpr int DY_PITCH = 16 * DCH + MI355_DPAD;   /* + 8: the sixteen rows of a 16-lane, 8-byte access fall on 32 different banks */
+constexpr int DC_PITCH = 8 * DCH + MI355_DPAD;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
 struct DeblockLds {
     mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
@@ -677,6 +680,9 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
     w[0] = v.x; w[1] = v.y;
 }
 
+#ifdef MI355_DEBLOCK_WAVES
+__attribute__((amdgpu_waves_per_eu(MI355_DEBLOCK_WAVES, MI355_DEBLOCK_WAVES)))
+#endif
 __global__ void __launch_bounds__(64)
 k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 {

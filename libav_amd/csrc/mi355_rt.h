@@ -34,7 +34,7 @@ template <class T> __device__ __forceinline__ T *mi355_global(T *p)
     const unsigned long long u = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
     auto q = (__attribute__((address_space(1))) T *)u;
-    asm volatile("" : "+s"(q));
+    asm("" : "+s"(q));
     return (T *)q;
 #endif
 }
@@ -44,7 +44,7 @@ template <class T> __device__ __forceinline__ T *mi355_global_v(T *p)
     return p;
 #else
     auto q = (__attribute__((address_space(1))) T *)p;
-    asm volatile("" : "+v"(q));
+    asm("" : "+v"(q));
     return (T *)q;
 #endif
 }
