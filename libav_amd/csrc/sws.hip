@@ -233,7 +233,11 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
         cf[j] = j < cs ? c.vChrC[(size_t)gy * cs + j] : 0;
         ci[j] = clampi(cfirst + (j < cs ? j : 0), 0, c.chrSrcH - 1) - clo;
     }
-    for (int i = tid & 15; i < npairs; i += 16) {
+    /* fixed trip count: the pairs of a thread are 16 apart, so every LDS address is one base plus an immediate */
+#pragma unroll
+    for (int k = 0; k < TW / 32; k++) {
+        const int i = (tid & 15) + 16 * k;
+        if (i >= npairs) continue;
         int Y1, Y2, U, V;
         if (mode == 1) {          /* yuv2rgb_1_c_template output.c:1043-1110 (ls == 1, cs <= 2) */
             const int uvalpha = cs == 1 ? 0 : cf[NC > 1 ? 1 : 0];
