@@ -655,7 +655,8 @@ __device__ inline void pred_plane_params(int N, const int16_t *top, const int16_
  * anything, they are never used for a legal (mode, availability) combination.
  * kind: 0 = 4x4 luma (T[5..8] = the caller's `topright` samples), 1 = 8x8 luma with
  * the (1,2,1) edge pre-filter (h264pred_template.c:846-874), 2 = 8x8 chroma,
- * 3 = 16x16 luma.  `mode` is the reference's table slot (h264pred.h:34-88).
+ * 3 = 16x16 luma, 4 = 8x16 chroma (4:2:2, the pred8x16_* functions :502-846 that occupy the pred8x8[] slots
+ * when chroma_format_idc == 2).  `mode` is the reference's table slot (h264pred.h:34-88).
  * Writes the NxN block to out[y*pitch+x] (LDS or global). */
 struct PredScratch {
     int16_t T[1 + 32];
@@ -723,6 +724,38 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             case 4: v = (sl + 8) >> 4; break;
             case 5: v = (st + 8) >> 4; break;
             default: v = 128; break;
+            }
+            out[y * pitch + x] = (uint8_t)v;
+        }
+        __syncthreads();
+        return;
+    }
+    if (kind == 4) { /* 8x16 chroma: quadrant DC rules of :590-595 (left), :622-642 (top), :673-720 (both), mad-cow patches :722-766 */
+        int a = 0, H = 0, V = 0;
+        if (mode == 3) {     /* pred8x16_plane :804-846: 4 taps across the top, 8 down the left edge */
+            for (int k = 1; k <= 4; k++) H += k * (T[3 + k] - T[3 - k]);
+            for (int k = 1; k <= 8; k++) V += k * (L[7 + k] - L[7 - k]);
+            H = (17 * H + 16) >> 5; V = (5 * V + 32) >> 6;
+            a = 16 * (L[15] + T[7] + 1) - 7 * V - 3 * H;
+        }
+        for (int i = lane; i < 128; i += 64) {
+            const int x = i & 7, y = i >> 3, qx = x >> 2, qy = y >> 2;
+            int t = 0, l = 0, v;
+            for (int k = 0; k < 4; k++) { t += T[4 * qx + k]; l += L[4 * qy + k]; }
+            const int dc_left = (l + 2) >> 2, dc_top = (t + 2) >> 2;
+            const int dc_full = qy == 0 ? (qx ? dc_top : (t + l + 4) >> 3) : (qx ? (t + l + 4) >> 3 : dc_left);
+            switch (mode) {
+            case 0: v = dc_full; break;
+            case 1: v = L[y]; break;
+            case 2: v = T[x]; break;
+            case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+            case 4: v = dc_left; break;
+            case 5: v = dc_top; break;
+            case 6: v = 128; break;
+            case 7: v = (qx == 0 && qy == 0) ? (t + l + 4) >> 3 : dc_top; break;   /* L0T */
+            case 8: v = (qx == 0 && qy == 0) ? dc_top : dc_full; break;              /* 0LT */
+            case 9: v = qy == 1 ? 128 : dc_left; break;                              /* L00: rows 4..7 only */
+            default: v = qy == 0 ? 128 : dc_left; break;                             /* 0L0 */
             }
             out[y * pitch + x] = (uint8_t)v;
         }

@@ -276,6 +276,21 @@ static void t1_idct_add8(uint8_t **dest, const int *off, int16_t *block, int str
     }
 }
 
+/* ff_h264_idct_add8_422 h264idct_template.c:216-238: the second four blocks of a plane sit at block_offset[i + 4]
+ * and are counted at scan8[i + 4] */
+static void t1_idct_add8_422(uint8_t **dest, const int *off, int16_t *block, int stride, const uint8_t nnzc[15 * 8])
+{
+    for (int j = 1; j < 3; j++) {
+        BlockReq r[8]; int n = 0;
+        for (int i = j * 16; i < j * 16 + 8; i++) {
+            const int k = i < j * 16 + 4 ? i : i + 4;
+            if (nnzc[scan8(k)]) r[n++] = BlockReq{off[k], block + i * 16, 2};
+            else if (block[i * 16]) r[n++] = BlockReq{off[k], block + i * 16, 1};
+        }
+        run_idct4(dest[j - 1], stride, r, n);
+    }
+}
+
 /* DC transforms */
 __global__ void __launch_bounds__(64) k_luma_dc(int16_t *out, const int16_t *in, int qmul)
 {
@@ -315,6 +330,34 @@ static void t1_chroma_dc_dequant_idct(int16_t *block, int qmul)
     LAUNCH1(k_chroma_dc, a, a.d<int16_t>(off), qmul);
     a.download();
     for (int k = 0; k < 4; k++) block[16 * k] = h[k];
+}
+/* ff_h264_chroma422_dc_dequant_idct h264idct_template.c:277-303: 2x4 Hadamard of the eight DC levels
+ * (block[32 * i + 16 * {0,1}]), (x * qmul + 128) >> 8, written back in place */
+__global__ void __launch_bounds__(64) k_chroma422_dc(int16_t *v, int qmul)
+{
+    if (lane_id() == 0) {
+        int t[8];
+        for (int i = 0; i < 4; i++) { t[2 * i] = v[2 * i] + v[2 * i + 1]; t[2 * i + 1] = v[2 * i] - v[2 * i + 1]; }
+        for (int i = 0; i < 2; i++) {
+            const int z0 = t[i] + t[4 + i], z1 = t[i] - t[4 + i], z2 = t[2 + i] - t[6 + i], z3 = t[2 + i] + t[6 + i];
+            v[0 + i] = (int16_t)(((z0 + z3) * qmul + 128) >> 8);
+            v[2 + i] = (int16_t)(((z1 + z2) * qmul + 128) >> 8);
+            v[4 + i] = (int16_t)(((z1 - z2) * qmul + 128) >> 8);
+            v[6 + i] = (int16_t)(((z0 - z3) * qmul + 128) >> 8);
+        }
+    }
+}
+static void t1_chroma422_dc_dequant_idct(int16_t *block, int qmul)
+{
+    Arena &a = arena();
+    size_t off = a.take(16);
+    int16_t *h = a.h<int16_t>(off);
+    for (int i = 0; i < 4; i++) { h[2 * i] = block[32 * i]; h[2 * i + 1] = block[32 * i + 16]; }
+    a.upload();
+    LAUNCH1(k_chroma422_dc, a, a.d<int16_t>(off), qmul);
+    a.download();
+    /* output k of row i lands at block[32 * i + {0, 16}] (x_offset[] = {0, 16}, stride 32) */
+    for (int i = 0; i < 4; i++) { block[32 * i] = h[2 * i]; block[32 * i + 16] = h[2 * i + 1]; }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -414,6 +457,9 @@ LF_TC(t1_v_lf_luma, 0, 0, 4) LF_TC(t1_h_lf_luma, 0, 1, 4) LF_TC(t1_h_lf_luma_mba
 LF_IN(t1_v_lf_luma_intra, 1, 0, 4) LF_IN(t1_h_lf_luma_intra, 1, 1, 4) LF_IN(t1_h_lf_luma_mbaff_intra, 1, 1, 2)
 LF_TC(t1_v_lf_chroma, 2, 0, 2) LF_TC(t1_h_lf_chroma, 2, 1, 2) LF_TC(t1_h_lf_chroma_mbaff, 2, 1, 1)
 LF_IN(t1_v_lf_chroma_intra, 3, 0, 2) LF_IN(t1_h_lf_chroma_intra, 3, 1, 2) LF_IN(t1_h_lf_chroma_mbaff_intra, 3, 1, 1)
+/* 4:2:2: the chroma edge of a macroblock is 16 lines high (h264dsp_template.c:276-283, :321-328) */
+LF_TC(t1_h_lf_chroma422, 2, 1, 4) LF_TC(t1_h_lf_chroma422_mbaff, 2, 1, 2)
+LF_IN(t1_h_lf_chroma422_intra, 3, 1, 4) LF_IN(t1_h_lf_chroma422_mbaff_intra, 3, 1, 2)
 
 /* ---- a4: transform-bypass residual add, h264addpx_template.c:30-72: dst += residual without
  * clipping (wraps like the reference's pixel type), block cleared afterwards ---------------------- */
@@ -440,7 +486,8 @@ template <int N> static void add_pixels_clear_shim(uint8_t *dst, int16_t *block,
 void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int chroma_format_idc)
 {
     /* like an arch hook: only the variants this backend implements are overridden
-     * (8-bit samples, 4:2:0/4:0:0); everything else keeps the C default */
+     * (8-bit samples; 4:0:0, 4:2:0 and 4:2:2 — 4:4:4 chroma goes through the luma entries); everything else keeps
+     * the C default */
     if (bit_depth != 8) return;
     c->weight_h264_pixels_tab[0] = weight_shim<16>;   c->weight_h264_pixels_tab[1] = weight_shim<8>;
     c->weight_h264_pixels_tab[2] = weight_shim<4>;    c->weight_h264_pixels_tab[3] = weight_shim<2>;
@@ -471,6 +518,13 @@ void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int ch
         c->h264_h_loop_filter_chroma_mbaff_intra = t1_h_lf_chroma_mbaff_intra;
         c->h264_idct_add8 = t1_idct_add8;
         c->h264_chroma_dc_dequant_idct = t1_chroma_dc_dequant_idct;
+    } else if (chroma_format_idc == 2) {
+        c->h264_h_loop_filter_chroma = t1_h_lf_chroma422;
+        c->h264_h_loop_filter_chroma_mbaff = t1_h_lf_chroma422_mbaff;
+        c->h264_h_loop_filter_chroma_intra = t1_h_lf_chroma422_intra;
+        c->h264_h_loop_filter_chroma_mbaff_intra = t1_h_lf_chroma422_mbaff_intra;
+        c->h264_idct_add8 = t1_idct_add8_422;
+        c->h264_chroma_dc_dequant_idct = t1_chroma422_dc_dequant_idct;
     }
 }
 
@@ -523,7 +577,8 @@ __global__ void __launch_bounds__(64) k_pred(const PredJob *jp, uint8_t *out, in
 static void pred_shim(uint8_t *src, ptrdiff_t stride, int kind, int mode, int has_tl, int has_tr, const uint8_t *topright)
 {
     Arena &a = arena();
-    const int N = kind == 0 ? 4 : (kind == 3 ? 16 : 8);
+    const int N = kind == 0 ? 4 : (kind == 3 ? 16 : 8);          /* width */
+    const int NH = kind == 4 ? 16 : N;                              /* height: 8x16 for 4:2:2 chroma */
     size_t joff = a.take(sizeof(PredJob));
     PredJob *j = a.h<PredJob>(joff);
     std::memset(j, 0, sizeof(*j));
@@ -547,23 +602,24 @@ static void pred_shim(uint8_t *src, ptrdiff_t stride, int kind, int mode, int ha
         corner = mode == 3;
     }
     if (top) for (int i = 0; i < N; i++) j->T[1 + i] = src[i - stride];
-    if (left) for (int i = 0; i < N; i++) j->L[1 + i] = src[-1 + i * stride];
+    if (left) for (int i = 0; i < NH; i++) j->L[1 + i] = src[-1 + i * stride];
     if (corner) j->T[0] = j->L[0] = src[-1 - stride];
     if (tr) {
         if (kind == 0) for (int i = 0; i < 4; i++) j->T[5 + i] = topright[i];
         else for (int i = 0; i < 8; i++) j->T[9 + i] = src[8 + i - stride];
     }
-    size_t ooff = a.take((size_t)N * 16);
+    size_t ooff = a.take((size_t)NH * 16);
     a.upload();
     LAUNCH1(k_pred, a, a.d<PredJob>(joff), a.d<uint8_t>(ooff), 16);
     a.download();
     const uint8_t *o = a.h<uint8_t>(ooff);
-    for (int y = 0; y < N; y++) std::memcpy(src + y * stride, o + y * 16, (size_t)N);
+    for (int y = 0; y < NH; y++) std::memcpy(src + y * stride, o + y * 16, (size_t)N);
 }
 template <int M> static void p4_shim(uint8_t *s, const uint8_t *tr, ptrdiff_t st) { pred_shim(s, st, 0, M, 0, 1, tr); }
 template <int M> static void p8l_shim(uint8_t *s, int tl, int tr, ptrdiff_t st) { pred_shim(s, st, 1, M, tl != 0, tr != 0, nullptr); }
 template <int M> static void p8_shim(uint8_t *s, ptrdiff_t st) { pred_shim(s, st, 2, M, 0, 0, nullptr); }
 template <int M> static void p16_shim(uint8_t *s, ptrdiff_t st) { pred_shim(s, st, 3, M, 0, 0, nullptr); }
+template <int M> static void p8x16_shim(uint8_t *s, ptrdiff_t st) { pred_shim(s, st, 4, M, 0, 0, nullptr); }
 
 /* ---- a10, lossless variants: prediction + residual as a running sum (h264pred_template.c:1127-1354) ----
  * Lane = (block, line); the sum starts at the neighbouring sample (or the (1,2,1)-filtered edge for the
@@ -656,26 +712,40 @@ template <int NBLK, int HZ> static void pred_multi_add_shim(uint8_t *pix, const 
 {
     pred_add_run(pix, block_offset, NBLK, block, stride, 4, HZ, 0, 0, 0);
 }
+/* pred8x16_{vertical,horizontal}_add :1326-1354: blocks 0..3 at block_offset[0..3], 4..7 at block_offset[8..11] */
+template <int HZ> static void pred8x16_add_shim(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    int offs[8];
+    for (int i = 0; i < 4; i++) { offs[i] = block_offset[i]; offs[4 + i] = block_offset[8 + i]; }
+    pred_add_run(pix, offs, 8, block, stride, 4, HZ, 0, 0, 0);
+}
 
 void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
 {
-    if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264 || chroma_format_idc > 1) return;
+    if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264 || chroma_format_idc > 2) return;
     h->pred4x4[0] = p4_shim<0>; h->pred4x4[1] = p4_shim<1>; h->pred4x4[2] = p4_shim<2>; h->pred4x4[3] = p4_shim<3>;
     h->pred4x4[4] = p4_shim<4>; h->pred4x4[5] = p4_shim<5>; h->pred4x4[6] = p4_shim<6>; h->pred4x4[7] = p4_shim<7>;
     h->pred4x4[8] = p4_shim<8>; h->pred4x4[9] = p4_shim<9>; h->pred4x4[10] = p4_shim<10>; h->pred4x4[11] = p4_shim<11>;
     h->pred8x8l[0] = p8l_shim<0>; h->pred8x8l[1] = p8l_shim<1>; h->pred8x8l[2] = p8l_shim<2>; h->pred8x8l[3] = p8l_shim<3>;
     h->pred8x8l[4] = p8l_shim<4>; h->pred8x8l[5] = p8l_shim<5>; h->pred8x8l[6] = p8l_shim<6>; h->pred8x8l[7] = p8l_shim<7>;
     h->pred8x8l[8] = p8l_shim<8>; h->pred8x8l[9] = p8l_shim<9>; h->pred8x8l[10] = p8l_shim<10>; h->pred8x8l[11] = p8l_shim<11>;
-    h->pred8x8[0] = p8_shim<0>; h->pred8x8[1] = p8_shim<1>; h->pred8x8[2] = p8_shim<2>; h->pred8x8[3] = p8_shim<3>;
-    h->pred8x8[4] = p8_shim<4>; h->pred8x8[5] = p8_shim<5>; h->pred8x8[6] = p8_shim<6>; h->pred8x8[7] = p8_shim<7>;
-    h->pred8x8[8] = p8_shim<8>; h->pred8x8[9] = p8_shim<9>; h->pred8x8[10] = p8_shim<10>;
+    if (chroma_format_idc <= 1) {
+        h->pred8x8[0] = p8_shim<0>; h->pred8x8[1] = p8_shim<1>; h->pred8x8[2] = p8_shim<2>; h->pred8x8[3] = p8_shim<3>;
+        h->pred8x8[4] = p8_shim<4>; h->pred8x8[5] = p8_shim<5>; h->pred8x8[6] = p8_shim<6>; h->pred8x8[7] = p8_shim<7>;
+        h->pred8x8[8] = p8_shim<8>; h->pred8x8[9] = p8_shim<9>; h->pred8x8[10] = p8_shim<10>;
+    } else {   /* 4:2:2: the same slots hold the 8x16 predictors (h264pred.c:470-531) */
+        h->pred8x8[0] = p8x16_shim<0>; h->pred8x8[1] = p8x16_shim<1>; h->pred8x8[2] = p8x16_shim<2>; h->pred8x8[3] = p8x16_shim<3>;
+        h->pred8x8[4] = p8x16_shim<4>; h->pred8x8[5] = p8x16_shim<5>; h->pred8x8[6] = p8x16_shim<6>; h->pred8x8[7] = p8x16_shim<7>;
+        h->pred8x8[8] = p8x16_shim<8>; h->pred8x8[9] = p8x16_shim<9>; h->pred8x8[10] = p8x16_shim<10>;
+    }
     h->pred16x16[0] = p16_shim<0>; h->pred16x16[1] = p16_shim<1>; h->pred16x16[2] = p16_shim<2>; h->pred16x16[3] = p16_shim<3>;
     h->pred16x16[4] = p16_shim<4>; h->pred16x16[5] = p16_shim<5>; h->pred16x16[6] = p16_shim<6>;
     /* lossless (transform bypass) forms: VERT_PRED 0 / HOR_PRED 1; VERT_PRED8x8 2 / HOR_PRED8x8 1 (h264pred.c:551-565) */
     h->pred4x4_add[0] = pred_add_shim<4, 0>;   h->pred4x4_add[1] = pred_add_shim<4, 1>;
     h->pred8x8l_add[0] = pred_add_shim<8, 0>;  h->pred8x8l_add[1] = pred_add_shim<8, 1>;
     h->pred8x8l_filter_add[0] = pred8x8l_filter_add_shim<0>; h->pred8x8l_filter_add[1] = pred8x8l_filter_add_shim<1>;
-    h->pred8x8_add[2] = pred_multi_add_shim<4, 0>;    h->pred8x8_add[1] = pred_multi_add_shim<4, 1>;
+    if (chroma_format_idc <= 1) { h->pred8x8_add[2] = pred_multi_add_shim<4, 0>; h->pred8x8_add[1] = pred_multi_add_shim<4, 1>; }
+    else { h->pred8x8_add[2] = pred8x16_add_shim<0>; h->pred8x8_add[1] = pred8x16_add_shim<1>; }
     h->pred16x16_add[2] = pred_multi_add_shim<16, 0>; h->pred16x16_add[1] = pred_multi_add_shim<16, 1>;
 }
 

@@ -244,10 +244,70 @@ static void pred8x8(uint8_t *src, ptrdiff_t st, int mode)
     }
 }
 
+/* ---- 8x16 chroma (4:2:0's pred8x8[] slots when chroma_format_idc == 2): h264pred_template.c:502-846 ----
+ * Same per-4x4-quadrant DC scheme with four quadrant rows: a quadrant in the first row or the first column uses
+ * what lies next to it, every other one both sums (:673-720).  left_dc is the 8x8 rule on both halves (:590-595),
+ * top_dc the column sums for all sixteen rows (:622-642).  The "mad cow" slots (:722-766) patch the top-left
+ * quadrant or rows 4..7 / 0..3 exactly like their 8x8 forms (the 128 patch is 4 rows high, not 8). */
+static void chroma422_dc_quads(uint8_t *src, ptrdiff_t st, int use_top, int use_left)
+{
+    for (int qy = 0; qy < 4; qy++)
+        for (int qx = 0; qx < 2; qx++) {
+            const int t = use_top ? sum4_top(src, st, qx) : 0, l = use_left ? sum4_left(src, st, qy) : 0;
+            int v;
+            if (use_top && use_left) v = qy == 0 ? (qx ? (t + 2) >> 2 : (t + l + 4) >> 3) : (qx ? (t + l + 4) >> 3 : (l + 2) >> 2);
+            else if (use_left) v = (l + 2) >> 2;
+            else v = (t + 2) >> 2;
+            fill(src + 4 * qx + 4 * qy * st, st, 4, 4, v);
+        }
+}
+static void pred8x16(uint8_t *src, ptrdiff_t st, int mode)
+{
+    int s;
+    switch (mode) {
+    case VERT_PRED8x8:  for (int y = 0; y < 16; y++) memmove(src + y * st, src - st, 8); break;
+    case HOR_PRED8x8:   for (int y = 0; y < 16; y++) memset(src + y * st, src[-1 + y * st], 8); break;
+    case DC_PRED8x8:      chroma422_dc_quads(src, st, 1, 1); break;
+    case LEFT_DC_PRED8x8: chroma422_dc_quads(src, st, 0, 1); break;
+    case TOP_DC_PRED8x8:  chroma422_dc_quads(src, st, 1, 0); break;
+    case DC_128_PRED8x8:  fill(src, st, 8, 16, 128); break;
+    case PLANE_PRED8x8: { /* :804-846 */
+        int H = 0, V = 0;
+        for (int k = 1; k <= 4; k++) H += k * (src[3 + k - st] - src[3 - k - st]);
+        for (int k = 1; k <= 8; k++) V += k * (src[-1 + (7 + k) * st] - src[-1 + (7 - k) * st]);
+        H = (17 * H + 16) >> 5; V = (5 * V + 32) >> 6;
+        const int a = 16 * (src[-1 + 15 * st] + src[7 - st] + 1) - 7 * V - 3 * H;
+        for (int y = 0; y < 16; y++)
+            for (int x = 0; x < 8; x++)
+                src[x + y * st] = (uint8_t)clip_u8((a + x * H + y * V) >> 5);
+        break;
+    }
+    case ALZHEIMER_DC_L0T_PRED8x8:
+        s = sum4_top(src, st, 0) + sum4_left(src, st, 0);
+        chroma422_dc_quads(src, st, 1, 0);
+        fill(src, st, 4, 4, (s + 4) >> 3);
+        break;
+    case ALZHEIMER_DC_0LT_PRED8x8:
+        s = sum4_top(src, st, 0);
+        chroma422_dc_quads(src, st, 1, 1);
+        fill(src, st, 4, 4, (s + 2) >> 2);
+        break;
+    case ALZHEIMER_DC_L00_PRED8x8:
+        chroma422_dc_quads(src, st, 0, 1);
+        fill(src + 4 * st, st, 8, 4, 128);
+        break;
+    case ALZHEIMER_DC_0L0_PRED8x8:
+        chroma422_dc_quads(src, st, 0, 1);
+        fill(src, st, 8, 4, 128);
+        break;
+    }
+}
+
 /* ---- table plumbing ------------------------------------------------------- */
 #define P4(m)  static void p4_##m(uint8_t *s, const uint8_t *tr, ptrdiff_t st) { pred4x4(s, tr, st, m); }
 #define P8L(m) static void p8l_##m(uint8_t *s, int tl, int tr, ptrdiff_t st) { pred8x8l(s, tl, tr, st, m); }
-#define P8(m)  static void p8_##m(uint8_t *s, ptrdiff_t st) { pred8x8(s, st, m); }
+#define P8(m)  static void p8_##m(uint8_t *s, ptrdiff_t st) { pred8x8(s, st, m); } \
+               static void p8x16_##m(uint8_t *s, ptrdiff_t st) { pred8x16(s, st, m); }
 #define P16(m) static void p16_##m(uint8_t *s, ptrdiff_t st) { pred16x16(s, st, m); }
 P4(0) P4(1) P4(2) P4(3) P4(4) P4(5) P4(6) P4(7) P4(8) P4(9) P4(10) P4(11)
 P8L(0) P8L(1) P8L(2) P8L(3) P8L(4) P8L(5) P8L(6) P8L(7) P8L(8) P8L(9) P8L(10) P8L(11)
@@ -308,12 +368,20 @@ static void p16_vadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_
 static void p16_hadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 16, 1); }
 static void p8_vadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 4, 0); }
 static void p8_hadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { multi_add(p, o, b, s, 4, 1); }
+/* pred8x16_*_add :1326-1354: blocks 4..7 use block_offset[8..11] */
+static void p8x16_add(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s, int horizontal)
+{
+    for (int i = 0; i < 4; i++) pred_add(p + o[i], b + i * 16, s, 4, horizontal);
+    for (int i = 4; i < 8; i++) pred_add(p + o[i + 4], b + i * 16, s, 4, horizontal);
+}
+static void p8x16_vadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { p8x16_add(p, o, b, s, 0); }
+static void p8x16_hadd(uint8_t *p, const int *o, int16_t *b, ptrdiff_t s) { p8x16_add(p, o, b, s, 1); }
 
-/* Fills the H.264 slots (codec_id == AV_CODEC_ID_H264, chroma_format_idc <= 1);
- * leaves every other slot (VP8/RV40/SVQ3 flavours, lossless *_add) untouched. */
+/* Fills the H.264 slots (codec_id == AV_CODEC_ID_H264; chroma_format_idc 2 puts the 8x16 forms into the
+ * pred8x8 slots, h264pred.c:470-531, :558-565); leaves every other slot (VP8/RV40/SVQ3 flavours) untouched. */
 void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
 {
-    (void)codec_id; (void)bit_depth; (void)chroma_format_idc;
+    (void)codec_id; (void)bit_depth;
     h->pred4x4[0] = p4_0; h->pred4x4[1] = p4_1; h->pred4x4[2] = p4_2; h->pred4x4[3] = p4_3;
     h->pred4x4[4] = p4_4; h->pred4x4[5] = p4_5; h->pred4x4[6] = p4_6; h->pred4x4[7] = p4_7;
     h->pred4x4[8] = p4_8; h->pred4x4[9] = p4_9; h->pred4x4[10] = p4_10; h->pred4x4[11] = p4_11;
@@ -331,4 +399,10 @@ void oracle_h264_pred_init(H264PredContext *h, int codec_id, int bit_depth, int 
     h->pred8x8l_filter_add[0] = p8l_vfadd; h->pred8x8l_filter_add[1] = p8l_hfadd;
     h->pred8x8_add[2] = p8_vadd; h->pred8x8_add[1] = p8_hadd;
     h->pred16x16_add[2] = p16_vadd; h->pred16x16_add[1] = p16_hadd;
+    if (chroma_format_idc == 2) {
+        h->pred8x8[0] = p8x16_0; h->pred8x8[1] = p8x16_1; h->pred8x8[2] = p8x16_2; h->pred8x8[3] = p8x16_3;
+        h->pred8x8[4] = p8x16_4; h->pred8x8[5] = p8x16_5; h->pred8x8[6] = p8x16_6; h->pred8x8[7] = p8x16_7;
+        h->pred8x8[8] = p8x16_8; h->pred8x8[9] = p8x16_9; h->pred8x8[10] = p8x16_10;
+        h->pred8x8_add[2] = p8x16_vadd; h->pred8x8_add[1] = p8x16_hadd;
+    }
 }

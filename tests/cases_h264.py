@@ -355,6 +355,92 @@ def cases_pred_add(h, r, out):
                 out["%s/%d/%d" % (name, d, rep)] = buf.tobytes() + blk.tobytes()
 
 
+# ------------------------------------------------------------------ 4:2:2 variants (chroma_format_idc == 2)
+def cases_dsp422(c, r, out):
+    """h264_idct_add8 = ff_h264_idct_add8_422, chroma422_dc_dequant_idct, 16-line horizontal chroma edge filters
+    (h264dsp.c:80-84, :88-91, :113-130)"""
+    stride = 48
+    off = _block_offsets(stride)
+    fn = c.h264_idct_add8
+    for rep in range(12):
+        consistent = rep < 8
+        nnzc = np.zeros(15 * 8, np.uint8)
+        blk = np.zeros(16 * 48, np.int16)
+        for j in (1, 2):
+            for i in range(j * 16, j * 16 + 8):
+                k = i if i < j * 16 + 4 else i + 4        # where the block is counted and placed
+                mode = r.randint(0, 3)
+                if mode == 0:
+                    nnz = 0
+                    if r.randint(0, 1):
+                        blk[i * 16] = r.randint(-2047, 2047)
+                elif mode == 1:
+                    nnz = 1
+                    blk[i * 16] = r.randint(-2047, 2047)
+                else:
+                    nnz = r.randint(2, 16)
+                    blk[i * 16: i * 16 + 16] = _coeffs(r, 16, "small")
+                if not consistent:
+                    nnz = r.randint(0, 2)
+                    blk[i * 16: i * 16 + 16] = _coeffs(r, 16, "small") * (r.randint(0, 3) > 0)
+                nnzc[scan8(k)] = nnz
+        planes = [r.u8((24, stride)) for _ in range(2)]
+        if fn:
+            arr = (A.u8p * 2)(p8(planes[0], 4 * stride + 8), p8(planes[1], 4 * stride + 8))
+            fn(arr, pint(off), p16(blk), stride, p8(nnzc))
+            out["422/h264_idct_add8/%d" % rep] = planes[0].tobytes() + planes[1].tobytes() + blk.tobytes()
+    for rep in range(24):
+        qmul = int([16, 64, 208, 1024, 4096, 13 * 512][rep % 6])
+        blk = np.full(128, 0x0777, np.int16)
+        blk[[0, 16, 32, 48, 64, 80, 96, 112]] = _coeffs(r, 8, "small" if rep < 16 else "full")
+        if c.h264_chroma_dc_dequant_idct:
+            c.h264_chroma_dc_dequant_idct(p16(blk), qmul)
+            out["422/chroma_dc/%d" % rep] = blk.tobytes()
+    triples = []
+    a, b, t = 255.0, 18.0, 25.0
+    for _ in range(36):
+        triples.append((int(a), int(b), int(t)))
+        a, b, t = a * 0.9, b * 0.92, t * 0.9
+    stride = 32
+    for name, has_tc in (("h264_h_loop_filter_chroma", 1), ("h264_h_loop_filter_chroma_mbaff", 1),
+                         ("h264_h_loop_filter_chroma_intra", 0), ("h264_h_loop_filter_chroma_mbaff_intra", 0)):
+        fn = getattr(c, name)
+        for k, (al, be, t0) in enumerate(triples):
+            buf = _edge_pixels(r, (32, stride), 1, 8)
+            tc = np.array([r.randint(-1, max(t0, 0)) for _ in range(4)], np.int8)
+            if k % 5 == 0:
+                tc[:] = t0
+            if not fn:
+                continue
+            if has_tc:
+                fn(p8(buf, 8 * stride + 8), stride, al, be, pi8(tc))
+            else:
+                fn(p8(buf, 8 * stride + 8), stride, al, be)
+            out["422/%s/%d" % (name, k)] = buf.tobytes()
+
+
+def cases_pred422(h, r, out):
+    """pred8x8[] = the pred8x16_* functions, pred8x8_add[] = pred8x16_*_add (h264pred.c:470-531, :558-565)"""
+    stride = 48
+    for mode in range(11):
+        fn = h.pred8x8[mode]
+        for rep in range(3):
+            buf = r.u8((32, stride)) if rep else _edge_pixels(r, (32, stride), 0, 4)
+            if not fn:
+                continue
+            fn(p8(buf, 8 * stride + 16), stride)
+            out["422/pred8x8/%d/%d" % (mode, rep)] = buf.tobytes()
+    offs = np.array([4 * (i & 1) + 8 * ((i >> 2) & 1) + (4 * ((i >> 1) & 1) + 8 * (i >> 3)) * stride for i in range(16)], np.int32)
+    for d in (1, 2):
+        for rep in range(3):
+            buf = r.u8((32, stride))
+            blk = r.randint(-255, 255, 16 * 8).astype(np.int16)
+            if not h.pred8x8_add[d]:
+                continue
+            h.pred8x8_add[d](p8(buf, 8 * stride + 16), C.cast(offs.ctypes.data, A.intp), p16(blk), stride)
+            out["422/pred8x8_add/%d/%d" % (d, rep)] = buf.tobytes() + blk.tobytes()
+
+
 GROUPS = OrderedDict([
     ("idct", ("h264dsp", cases_idct)),
     ("idct_multi", ("h264dsp", cases_idct_multi)),
@@ -368,12 +454,14 @@ GROUPS = OrderedDict([
     ("videodsp", ("videodsp", cases_videodsp)),
     ("pred", ("h264pred", cases_pred)),
     ("pred_add", ("h264pred", cases_pred_add)),
+    ("dsp422", ("h264dsp", cases_dsp422, 8, 2)),
+    ("pred422", ("h264pred", cases_pred422, 8, 2)),
 ])
 
 
 def run_group(provider, group, seed=0x264):
-    table, fn = GROUPS[group]
-    ctx = getattr(provider, table)()
+    table, fn, *args = GROUPS[group]
+    ctx = getattr(provider, table)(*args)      # optional (bit_depth, chroma_format_idc)
     out = OrderedDict()
     # the stream depends only on (seed, group), never on which pointers a provider fills
     fn(ctx, SplitMix64(seed * 1000003 + list(GROUPS).index(group)), out)
