@@ -160,7 +160,16 @@ typedef struct VideoDSPContext {
 
 /* ---- HEVCDSPContext (libavcodec/hevcdsp.h:27-114) ------------------------- */
 #ifndef AVCODEC_HEVCDSP_H
-struct GetBitContext;
+/* GetBitContext (libavcodec/get_bits.h:54-61) as the reference's default configuration builds it
+ * (CONFIG_SAFE_BITSTREAM_READER: the fifth field exists and get_bits() clamps the position to it) */
+#ifndef AVCODEC_GET_BITS_H
+typedef struct GetBitContext {
+    const uint8_t *buffer, *buffer_end;
+    int index;
+    int size_in_bits;
+    int size_in_bits_plus8;
+} GetBitContext;
+#endif
 typedef struct SAOParams {
     int offset_abs[3][4];
     int offset_sign[3][4];
@@ -172,7 +181,7 @@ typedef struct SAOParams {
 
 typedef struct HEVCDSPContext {
     void (*put_pcm)(uint8_t *dst, ptrdiff_t stride, int size,
-                    struct GetBitContext *gb, int pcm_bit_depth);
+                    GetBitContext *gb, int pcm_bit_depth);
     void (*add_residual[4])(uint8_t *dst, int16_t *res, ptrdiff_t stride);
     void (*dequant)(int16_t *coeffs);
     void (*transform_4x4_luma)(int16_t *coeffs);

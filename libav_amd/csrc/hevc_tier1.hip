@@ -35,6 +35,37 @@ template <int SIZE, int BD> static void add_residual_shim(uint8_t *dst, int16_t 
     win_unpack(a, w, dst, stride, 0, 0, SIZE * Px<BD>::bytes, SIZE);
 }
 
+/* ---- put_pcm (hevcdsp_template.c:28-41): the raw PCM levels, read from the bitstream with get_bits()
+ * (get_bits.h:228-237, big-endian 32-bit window, position clamped to size_in_bits_plus8), are scaled to the
+ * sample depth.  Walking the bit reader is host bookkeeping; the sample arithmetic and stores run on the device. */
+__global__ void __launch_bounds__(64) k_hevc_put_pcm(uint8_t *dst, int st, const uint16_t *levels, int size, int shift, int bd)
+{
+    for (int i = lane_id(); i < size * size; i += 64) {
+        const int y = i / size, x = i - y * size;
+        stpx(dst, x + y * st, (int)((unsigned)levels[i] << shift) & (bd > 8 ? 0xFFFF : 0xFF), bd);
+    }
+}
+template <int BD> static void put_pcm_shim(uint8_t *dst, ptrdiff_t stride, int size, GetBitContext *gb, int pcm_bit_depth)
+{
+    Arena &a = arena();
+    Win w = win_pack(a, nullptr, 0, size * Px<BD>::bytes, size, 0, 0);
+    size_t l = a.take((size_t)size * size * 2);
+    uint16_t *lv = a.h<uint16_t>(l);
+    unsigned index = (unsigned)gb->index;
+    const unsigned limit = (unsigned)gb->size_in_bits_plus8;
+    for (int i = 0; i < size * size; i++) {
+        const uint8_t *p = gb->buffer + (index >> 3);
+        const uint32_t cache = (((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]) << (index & 7);
+        lv[i] = (uint16_t)(cache >> (32 - pcm_bit_depth));
+        index = index + (unsigned)pcm_bit_depth < limit ? index + (unsigned)pcm_bit_depth : limit;
+    }
+    gb->index = (int)index;
+    a.upload();
+    LAUNCH1(k_hevc_put_pcm, a, a.d<uint8_t>(w.off), w.pitch / Px<BD>::bytes, a.d<const uint16_t>(l), size, BD - pcm_bit_depth, BD);
+    a.download();
+    win_unpack(a, w, dst, stride, 0, 0, size * Px<BD>::bytes, size);
+}
+
 /* mode 0: dequant (hevcdsp_template.c:84-98), 1: DST 4x4 (:103-136), 2: idct_dc (:238-252, size in arg),
  * 3: full idct with col_limit (:208-236) */
 __global__ void __launch_bounds__(64) k_hevc_transform(int16_t *c, int mode, int size, int col_limit, int bd)
@@ -283,6 +314,7 @@ template <int LOG2, int BD> static void angular_shim(uint8_t *s, const uint8_t *
 /* ---- table fill ---------------------------------------------------------------------------------------- */
 template <int BD> static void fill_dsp(HEVCDSPContext *c)
 {
+    c->put_pcm = put_pcm_shim<BD>;
     c->add_residual[0] = add_residual_shim<4, BD>;   c->add_residual[1] = add_residual_shim<8, BD>;
     c->add_residual[2] = add_residual_shim<16, BD>;  c->add_residual[3] = add_residual_shim<32, BD>;
     c->dequant = dequant_shim<BD>;

@@ -481,6 +481,7 @@ ALL_FOR_DEPTH(10)
     c->put_unweighted_pred_chroma[i] = up_##W##_##D; c->put_unweighted_pred_avg_chroma[i] = ua_##W##_##D; \
     c->weighted_pred_chroma[i] = wp_##W##_##D; c->weighted_pred_avg_chroma[i] = wa_##W##_##D;
 #define SET_DEPTH(D) \
+    c->put_pcm = put_pcm_##D; \
     c->add_residual[0] = addres4_##D; c->add_residual[1] = addres8_##D; c->add_residual[2] = addres16_##D; c->add_residual[3] = addres32_##D; \
     c->dequant = dequant_##D; c->transform_4x4_luma = dst4_##D; \
     c->idct[0] = idct4_##D; c->idct[1] = idct8_##D; c->idct[2] = idct16_##D; c->idct[3] = idct32_##D; \
@@ -492,7 +493,24 @@ ALL_FOR_DEPTH(10)
     c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = lfl_h_##D; c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = lfl_v_##D; \
     c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = lfc_h_##D; c->hevc_v_loop_filter_chroma = c->hevc_v_loop_filter_chroma_c = lfc_v_##D;
 
-/* put_pcm (bit reader) is not restated: the slot is left as the caller set it */
+/* put_pcm hevcdsp_template.c:28-41 over get_bits() get_bits.h:228-237 (big-endian reader, safe variant:
+ * index = FFMIN(size_in_bits_plus8, index + n)) */
+static void put_pcm(uint8_t *dst, ptrdiff_t stride, int size, GetBitContext *gb, int pcm_bit_depth, int bd)
+{
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++) {
+            const uint8_t *p = gb->buffer + ((unsigned)gb->index >> 3);
+            const uint32_t cache = (((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]) << (gb->index & 7);
+            const unsigned v = cache >> (32 - pcm_bit_depth);
+            const unsigned next = (unsigned)gb->index + (unsigned)pcm_bit_depth;
+            gb->index = (int)(next < (unsigned)gb->size_in_bits_plus8 ? next : (unsigned)gb->size_in_bits_plus8);
+            if (bd > 8) ((uint16_t *)(dst + y * stride))[x] = (uint16_t)(v << (bd - pcm_bit_depth));
+            else dst[y * stride + x] = (uint8_t)(v << (bd - pcm_bit_depth));
+        }
+}
+static void put_pcm_8(uint8_t *d, ptrdiff_t s, int n, GetBitContext *gb, int pb) { put_pcm(d, s, n, gb, pb, 8); }
+static void put_pcm_9(uint8_t *d, ptrdiff_t s, int n, GetBitContext *gb, int pb) { put_pcm(d, s, n, gb, pb, 9); }
+static void put_pcm_10(uint8_t *d, ptrdiff_t s, int n, GetBitContext *gb, int pb) { put_pcm(d, s, n, gb, pb, 10); }
 void oracle_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
 {
     switch (bit_depth) {

@@ -91,6 +91,11 @@ class VideoDSPContext(C.Structure):
     ]
 
 
+class GetBitContext(C.Structure):   # libavcodec/get_bits.h:54-61 (CONFIG_SAFE_BITSTREAM_READER layout)
+    _fields_ = [("buffer", C.c_void_p), ("buffer_end", C.c_void_p), ("index", C.c_int), ("size_in_bits", C.c_int),
+                ("size_in_bits_plus8", C.c_int)]
+
+
 class SAOParams(C.Structure):
     _fields_ = [("offset_abs", (C.c_int * 4) * 3), ("offset_sign", (C.c_int * 4) * 3),
                 ("band_position", C.c_int * 3), ("eo_class", C.c_int * 3),
@@ -104,11 +109,12 @@ hevc_w_fn = F(None, C.c_uint8, C.c_int16, C.c_int16, u8p, ptrdiff, i16p, ptrdiff
 hevc_wavg_fn = F(None, C.c_uint8, C.c_int16, C.c_int16, C.c_int16, C.c_int16, u8p, ptrdiff, i16p, i16p, ptrdiff, C.c_int)
 hevc_lfl_fn = F(None, u8p, ptrdiff, C.c_int, intp, u8p, u8p)
 hevc_lfc_fn = F(None, u8p, ptrdiff, intp, u8p, u8p)
+hevc_pcm_fn = F(None, u8p, ptrdiff, C.c_int, C.POINTER(GetBitContext), C.c_int)
 
 
 class HEVCDSPContext(C.Structure):
     _fields_ = [
-        ("put_pcm", C.c_void_p),
+        ("put_pcm", hevc_pcm_fn),
         ("add_residual", F(None, u8p, i16p, ptrdiff) * 4),
         ("dequant", F(None, i16p)),
         ("transform_4x4_luma", F(None, i16p)),

@@ -221,10 +221,33 @@ def cases_intra(hp, r, out, bd):
                     out["angular%d/%d" % (size, mode)] = buf.tobytes()
 
 
+def cases_pcm(c, r, out, bd):
+    """put_pcm (hevcdsp_template.c:28-41): coding-block sizes 8..32 luma / 4..16 chroma, every legal PCM depth,
+    starting at an arbitrary bit position; one case runs into the end of the buffer (position clamp)"""
+    px = 2 if bd > 8 else 1
+    for size in (4, 8, 16, 32):
+        for rep in range(3):
+            pcm_bd = [1, bd, r.randint(1, bd)][rep]
+            nbits = size * size * pcm_bd
+            start = r.randint(0, 64)
+            data = r.u8((start + nbits + 7) // 8 + 16)           # 16: the reader's 32-bit window may look past the last level
+            short = rep == 2 and size == 8
+            gb = A.GetBitContext()
+            gb.buffer = data.ctypes.data
+            gb.buffer_end = data.ctypes.data + len(data) - 16
+            gb.index = start
+            gb.size_in_bits = (start + nbits - (5 * pcm_bd if short else 0))
+            gb.size_in_bits_plus8 = gb.size_in_bits + 8
+            dst = pixels(r, (size + 8, size + 16), bd)
+            if c.put_pcm:
+                c.put_pcm(p8(dst, (4 * (size + 16) + 8) * px), (size + 16) * px, size, C.byref(gb), pcm_bd)
+                out["put_pcm%d/%d" % (size, rep)] = dst.tobytes() + np.int32(gb.index).tobytes()
+
+
 GROUPS = OrderedDict([
     ("residual", ("hevcdsp", cases_residual)), ("idct", ("hevcdsp", cases_idct)), ("mc", ("hevcdsp", cases_mc)),
     ("pred", ("hevcdsp", cases_pred)), ("deblock", ("hevcdsp", cases_deblock)), ("sao", ("hevcdsp", cases_sao)),
-    ("intra", ("hevcpred", cases_intra)),
+    ("intra", ("hevcpred", cases_intra)), ("pcm", ("hevcdsp", cases_pcm)),
 ])
 DEPTHS = (8, 10)
 
