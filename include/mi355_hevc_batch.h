@@ -1,5 +1,5 @@
 /*
- * mi355_hevc_batch.h — Tier 2 for the HEVC rows (SURVEY.md §8a a12-a17): the same wave-level code that
+ * mi355_hevc_batch.h — Tier 2 for the HEVC rows (SURVEY.md §8a a12-a18): the same wave-level code that
  * sits behind HEVCDSPContext (include/mi355dsp.h), launched over DEVICE-RESIDENT batches of independent
  * work items — one wavefront per item (eight edge segments per wavefront for the loop filter).
  *
@@ -89,6 +89,24 @@ typedef struct mi355_hevc_sao_job {
     uint8_t vert_edge, horiz_edge, diag_edge;
 } mi355_hevc_sao_job;
 int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a18: pred_planar[] / pred_dc / pred_angular[] (hevcdec.h:399-409, hevcpred_template.c:349-516) for one transform
+ * block.  `top` / `left` point at element 0 of the neighbour arrays the reference's intra_pred() wrapper builds
+ * (hevcpred_template.c:31-334: 2 * size samples each, element -1 = the corner); they live wherever the bridge put
+ * them (typically a per-picture edge buffer filled from the reconstruction).  Jobs of one launch must not depend on
+ * each other's output: the bridge submits one launch per dependency level of the picture's intra blocks (a block
+ * needs its left, top-left, top and top-right neighbours), like mi355_h264_intra_schedule() does for H.264. */
+enum { MI355_HEVC_INTRA_PLANAR = 0, MI355_HEVC_INTRA_DC = 1, MI355_HEVC_INTRA_ANGULAR = 2 };
+typedef struct mi355_hevc_intra_job {
+    uint8_t *dst;             /* sample (0,0) of the block */
+    const uint8_t *top, *left;
+    int32_t stride;           /* of dst, BYTES (the table's own entry points take samples; this header is bytes throughout) */
+    uint8_t log2_size;        /* 2..5 */
+    uint8_t kind;             /* MI355_HEVC_INTRA_* */
+    uint8_t c_idx;            /* 0 luma: DC / angular edge smoothing applies */
+    uint8_t mode;             /* angular: 2..34 */
+} mi355_hevc_intra_job;
+int mi355_hevc_intra_batch_dev(const mi355_hevc_intra_job *d_jobs, int n, int bit_depth, void *stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,20 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
     hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p);
 }
 
+/* ---- intra prediction: one wave per transform block -------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_hevc_intra_batch(const mi355_hevc_intra_job *jobs, int n, int bd)
+{
+    __shared__ HevcPredScratch s;
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_intra_job j = jobs[blockIdx.x];
+    const uint8_t *top = mi355_global(j.top), *left = mi355_global(j.left);
+    const int nedge = 2 * (1 << j.log2_size) + 1, px = bd > 8 ? 2 : 1;
+    /* elements -1 .. 2 * size - 1 of both neighbour arrays -> LDS */
+    for (int i = lane_id(); i < nedge; i += 64) { s.top[i] = (int16_t)ldpx(top - px, i, bd); s.left[i] = (int16_t)ldpx(left - px, i, bd); }
+    __syncthreads();
+    hevc_pred_wave(s, mi355_global(j.dst), j.stride / px, j.log2_size, j.kind, j.c_idx, j.mode, bd);
+}
+
 bool check(int bit_depth, const void *jobs, int n)
 {
     if (!ready()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
@@ -176,6 +190,12 @@ extern "C" int mi355_hevc_deblock_batch_dev(const mi355_hevc_lf_job *d_jobs, int
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_deblock_batch, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_intra_batch_dev(const mi355_hevc_intra_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_intra_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream)

@@ -43,6 +43,11 @@ class SaoJob(C.Structure):
 assert C.sizeof(LfJob) == 32
 
 
+class IntraJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("top", C.c_void_p), ("left", C.c_void_p), ("stride", C.c_int32), ("log2_size", C.c_uint8),
+                ("kind", C.c_uint8), ("c_idx", C.c_uint8), ("mode", C.c_uint8)]
+
+
 class Dev:
     """device memory through the C ABI's helpers"""
 
@@ -336,4 +341,43 @@ def check_sao(prov, oracle, bd, seed, cells=(3, 4)):
     return len(jobs)
 
 
-CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao}
+def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
+    """pred_planar / pred_dc / pred_angular of independent blocks, neighbour arrays in a device edge buffer"""
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    pic = pixels(r, (cy * 32, cx * 32), bd)
+    stride = pic.strides[0]
+    n = cy * cx
+    edges = pixels(r, (n, 2, 72), bd)              # [job][top/left][-1 .. 2*size-1 (+ slack)]
+    meta = []
+    for k in range(n):
+        log2 = r.randint(2, 5)
+        kind = r.randint(0, 2)
+        meta.append((log2, kind, r.randint(0, 2), r.randint(2, 34), (k // cx) * 32, (k % cx) * 32))
+    h_o = oracle.hevcpred(bd)
+    pic_o = pic.copy()
+    for k, (log2, kind, c_idx, mode, y0, x0) in enumerate(meta):
+        dp = _u8p(pic_o, y0 * stride + x0 * px)
+        top, left = _u8p(edges, ((k * 2 + 0) * 72 + 1) * px), _u8p(edges, ((k * 2 + 1) * 72 + 1) * px)
+        if kind == 0:
+            h_o.pred_planar[log2 - 2](dp, top, left, stride // px)
+        elif kind == 1:
+            h_o.pred_dc(dp, top, left, stride // px, log2, c_idx)
+        else:
+            h_o.pred_angular[log2 - 2](dp, top, left, stride // px, c_idx, mode)
+    d = Dev(prov.lib)
+    try:
+        p_pic, p_e = d.up(pic), d.up(edges)
+        jobs = [IntraJob(p_pic + y0 * stride + x0 * px, p_e + ((k * 2 + 0) * 72 + 1) * px, p_e + ((k * 2 + 1) * 72 + 1) * px, stride,
+                         log2, kind, c_idx, mode) for k, (log2, kind, c_idx, mode, y0, x0) in enumerate(meta)]
+        assert prov.lib.mi355_hevc_intra_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
+        pic_g = d.down(p_pic, pic)
+    finally:
+        d.free()
+    assert np.array_equal(pic_g, pic_o), "intra batch differs (bd %d)" % bd
+    return n
+
+
+CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
+          "intra": check_intra}
