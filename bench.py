@@ -184,6 +184,20 @@ def cpu_baseline(fs, seconds):
     lib = orc.lib
     lib.oracle_h264_recon_frame.restype = None
     lib.oracle_h264_deblock_frame.restype = None
+    # With oracle/_ref/libref.so present (the reference's own C files compiled where they lie, by oracle/Makefile; the
+    # built object travels with the tree), the per-macroblock driver calls the reference's compiled functions.
+    kind, what = "port", "the scalar C oracle"
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    if os.path.exists(ref_path):
+        try:
+            ref = C.CDLL(ref_path)
+            fns = [C.cast(getattr(ref, n), C.c_void_p) for n in ("ff_h264dsp_init", "ff_h264qpel_init", "ff_h264chroma_init", "ff_h264_pred_init")]
+            lib.oracle_h264frame_bind_tables.restype = None
+            lib.oracle_h264frame_bind_tables(*fns)
+            kind, what = "reference", "the reference's own C functions (oracle/_ref/libref.so: ff_h264dsp/qpel/chroma/pred_init tables, " \
+                                      "--disable-asm equivalent) called by the restated per-macroblock driver"
+        except (OSError, AttributeError):
+            pass
     ncores = os.cpu_count() or 1
     nthreads = max(1, min(ncores, 64))
     recon, dst = fs.planes(), fs.planes()
@@ -217,10 +231,10 @@ def cpu_baseline(fs, seconds):
     for th in ths:
         th.join()
     wall = time.perf_counter() - t0
-    return {"value": sum(counts) * nmb / wall, "unit": "macroblocks/s", "cores": nthreads, "kind": "port",
+    return {"value": sum(counts) * nmb / wall, "unit": "macroblocks/s", "cores": nthreads, "kind": kind,
             "value_1core": nmb / one,
-            "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d threads "
-                      "(reference x86 SIMD not built: no nasm in the image; this is the scalar C oracle)" % (min(nthreads, fs.F), seconds, nthreads)}
+            "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d threads; %s "
+                      "(reference x86 SIMD not built: no nasm in the image)" % (min(nthreads, fs.F), seconds, nthreads, what)}
 
 
 if __name__ == "__main__":

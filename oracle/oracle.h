@@ -26,6 +26,9 @@ void oracle_h264_chroma_mc2(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *s
 struct mi355_h264_frame;
 void oracle_h264_recon_frame(const struct mi355_h264_frame *f);
 void oracle_h264_deblock_frame(const struct mi355_h264_frame *f);
+/* fill the driver's four tables from other init functions (the reference's, for bench.py's cpu_baseline); NULL = restated */
+void oracle_h264frame_bind_tables(void (*dsp_init)(H264DSPContext *, int, int), void (*qpel_init)(H264QpelContext *, int),
+                                  void (*chroma_init)(H264ChromaContext *, int), void (*pred_init)(H264PredContext *, int, int, int));
 #ifdef __cplusplus
 }
 #endif

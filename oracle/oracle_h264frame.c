@@ -42,6 +42,20 @@ static void ensure_tables(void)
     tables_ready = 1;
 }
 
+/* For bench.py's cpu_baseline of kind "reference": the per-macroblock driver below calls through the four tables,
+ * so filling them with the reference's own ff_*_init (oracle/_ref/libref.so, its C files compiled where they lie)
+ * makes every sample operation of the baseline the reference's compiled code.  NULL = the restated functions. */
+void oracle_h264frame_bind_tables(void (*dsp_init)(H264DSPContext *, int, int), void (*qpel_init)(H264QpelContext *, int),
+                                  void (*chroma_init)(H264ChromaContext *, int), void (*pred_init)(H264PredContext *, int, int, int))
+{
+    tables_ready = 0;
+    ensure_tables();
+    if (dsp_init) dsp_init(&dsp, 8, 1);
+    if (qpel_init) qpel_init(&qpel, 8);
+    if (chroma_init) chroma_init(&chroma, 8);
+    if (pred_init) pred_init(&pred, MI355_AV_CODEC_ID_H264, 8, 1);
+}
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 static inline int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 1); }  /* block index -> column (h264dec.h scan8) */
 static inline int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >> 3); }
