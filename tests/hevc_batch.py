@@ -74,6 +74,12 @@ class Dev:
         self.lib.mi355_memcpy_h2d(p, C.addressof(arr), C.sizeof(arr))
         return p
 
+    def up_struct(self, arr):
+        p = self.lib.mi355_malloc(C.sizeof(arr))
+        self.bufs.append(p)
+        self.lib.mi355_memcpy_h2d(p, C.addressof(arr), C.sizeof(arr))
+        return p
+
     def down(self, p, like):
         out = np.empty_like(like)
         self.lib.mi355_sync(None)

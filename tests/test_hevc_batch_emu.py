@@ -8,3 +8,10 @@ import hevc_batch
 @pytest.mark.parametrize("kind", list(hevc_batch.CHECKS))
 def test_emulated_hevc_batches_match_oracle(emu, oracle, kind, bd):
     assert hevc_batch.CHECKS[kind](emu, oracle, bd, seed=0x265 + bd) > 0
+
+
+@pytest.mark.parametrize("bd", (8, 10))
+def test_emulated_config3_chain_small_picture(emu, oracle, bd):
+    """MC -> pred -> residual -> edges (V, H) -> SAO of one small picture, stage outputs feeding the next stage"""
+    import hevc_config3
+    assert hevc_config3.check(emu, oracle, 256, 192, bd, seed=3) > 0
