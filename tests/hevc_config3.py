@@ -20,10 +20,10 @@ def build(W, H, bd, seed):
     dt = np.uint16 if bd > 8 else np.uint8
     m = dict(W=W, H=H, bd=bd, px=2 if bd > 8 else 1)
     # smooth-ish content so that the deblocking decisions go both ways, plus noise for SAO classes
-    base = r.integers(0, hi + 1, (H // 8 + 1, W // 8 + 1))
-    up = np.kron(base, np.ones((8, 8), np.int64))[:H, :W]
-    m["ref_y"] = np.clip(up + r.integers(-6, 7, (H, W)), 0, hi).astype(dt)
-    m["ref_c"] = np.clip(up[::2, ::2][None] + r.integers(-6, 7, (2, H // 2, W // 2)), 0, hi).astype(dt)
+    base = r.integers(0, hi + 1, (H // 8 + 1, W // 8 + 1), dtype=np.int32)
+    up = np.repeat(np.repeat(base, 8, 0), 8, 1)[:H, :W]
+    m["ref_y"] = np.clip(up + r.integers(-6, 7, (H, W), dtype=np.int32), 0, hi).astype(dt)
+    m["ref_c"] = np.clip(up[::2, ::2][None] + r.integers(-6, 7, (2, H // 2, W // 2), dtype=np.int32), 0, hi).astype(dt)
     m["cur_y"] = r.integers(0, hi + 1, (H, W)).astype(dt)
     m["cur_c"] = r.integers(0, hi + 1, (2, H // 2, W // 2)).astype(dt)
     m["out_y"] = np.full((H, W), 0x155 & hi, dt)
