@@ -259,7 +259,8 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
     }
     if (lane < 32) {
         const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
-        *reinterpret_cast<uint32_t *>(mi355_global_v(dst[1 + plane]) + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
+        uint8_t *const c0 = mi355_global(dst[1]), *const c1 = mi355_global(dst[2]);     /* uniform fetches, per-lane select */
+        *reinterpret_cast<uint32_t *>((plane ? c1 : c0) + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
             tile_dword((plane ? cr : cb) + row * cpitch + 4 * seg);
     }
 }
@@ -500,6 +501,7 @@ constexpr int DCH_LOG = MI355_DCH_LOG, DCH = 1 << DCH_LOG;    /* macroblocks per
 constexpr int DY_PITCH = 16 * DCH + MI355_DPAD;   /* + 8: the sixteen rows of a 16-lane, 8-byte access fall on 32 different banks */
 constexpr int DC_PITCH = 8 * DCH + MI355_DPAD;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
+constexpr int DCH_ISSUE = DCH >= 4 ? 1 : DCH - 1;  /* position in a chunk at which the next chunk's loads are issued */
 struct DeblockLds {
     mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
     uint32_t mv[4][2][2][16];     /* [t&1][list]: this MB's vectors; the other parity is the left neighbour */
@@ -643,6 +645,8 @@ __device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr
         if (l < 4 && has_t) p.mvt[li] = a.mv[li][a.mv_top];
     }
 }
+typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
 /* 16 bytes of an LDS tile row (rows are 8-byte aligned: two 64-bit accesses) */
 __device__ __forceinline__ uint4 lds16(const uint8_t *p)
 {
@@ -651,10 +655,11 @@ __device__ __forceinline__ uint4 lds16(const uint8_t *p)
 }
 __device__ __forceinline__ void lds16(uint8_t *p, uint4 v)
 {
-    reinterpret_cast<uint2 *>(p)[0] = make_uint2(v.x, v.y);
-    reinterpret_cast<uint2 *>(p)[1] = make_uint2(v.z, v.w);
+    reinterpret_cast<mi355_u32x2 *>(p)[0] = mi355_u32x2{ v.x, v.y };
+    reinterpret_cast<mi355_u32x2 *>(p)[1] = mi355_u32x2{ v.z, v.w };
 }
-/* 16 / 8 bytes between a picture row and an LDS tile row */
+/* 16 / 8 bytes between a picture row and an LDS tile row.  The aligned stores go through native vector types:
+ * a HIP uint4 assignment is copied component by component and came out as four dword stores. */
 __device__ __forceinline__ uint4 ld16(const uint8_t *p, bool al)
 {
     if (al) return *reinterpret_cast<const uint4 *>(p);
@@ -663,7 +668,7 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *p, bool al)
 }
 __device__ __forceinline__ void st16(uint8_t *p, uint4 v, bool al)
 {
-    if (al) { *reinterpret_cast<uint4 *>(p) = v; return; }
+    if (al) { *reinterpret_cast<mi355_u32x4 *>(p) = mi355_u32x4{ v.x, v.y, v.z, v.w }; return; }
     uint32_t *w = reinterpret_cast<uint32_t *>(p);
     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
@@ -675,7 +680,7 @@ __device__ __forceinline__ uint2 ld8(const uint8_t *p, bool al)
 }
 __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
 {
-    if (al) { *reinterpret_cast<uint2 *>(p) = v; return; }
+    if (al) { *reinterpret_cast<mi355_u32x2 *>(p) = mi355_u32x2{ v.x, v.y }; return; }
     uint32_t *w = reinterpret_cast<uint32_t *>(p);
     w[0] = v.x; w[1] = v.y;
 }
@@ -718,30 +723,39 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     }
     /* chunk I/O roles of a lane: piece p of a row pair */
     const int io_p = l & (DCH - 1), io_r = l >> DCH_LOG;
+    /* plane pointers once, in scalar registers: a per-lane fetch from the descriptor inside the chunk functions would
+     * put a dependent load (and a wait for everything in flight) in front of every access */
+    const uint8_t *const recon_cb = mi355_global(fr.recon[1]), *const recon_cr = mi355_global(fr.recon[2]);
+    uint8_t *const dst_cb = mi355_global(fr.dst[1]), *const dst_cr = mi355_global(fr.dst[2]);
     const uint8_t *const recon_y = mi355_global(fr.recon[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
     uint8_t *const dst_y = mi355_global(fr.dst[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
 
-    /* load chunk c (macroblocks 8c-2g ..+7) of this group's row into tile parity c & 1 */
-    auto load_chunk = [&](int c) {
-        const int x = DCH * c - 2 * g + io_p, b = c & 1;
+    /* Chunk c (macroblocks DCH*c - 2g .. + DCH-1) of this group's row: the loads are issued a few steps before the
+     * chunk is needed and land in registers (`issue_chunk`); `commit_chunk` moves them into tile parity c & 1 when the
+     * walk reaches the chunk, so the memory latency hides behind the steps in between. */
+    constexpr int NY = 16 / DIO_ROWS, NTOP = (4 + DIO_ROWS - 1) / DIO_ROWS;   /* accesses for 16 rows / for the 4 rows above */
+    uint4 vy[NY], ty[NTOP];
+    uint2 vc[NY], tc[NTOP];
+    auto issue_chunk = [&](int c) {
+        const int x = DCH * c - 2 * g + io_p;
         const bool ok = row_ok && x >= 0 && x < W;
-        constexpr int NY = 16 / DIO_ROWS, NT = (4 + DIO_ROWS - 1) / DIO_ROWS;   /* accesses for 16 rows / for the 4 rows above */
-        uint4 vy[NY], ty[NT];
-        uint2 vc[NY], tc[NT];
 #pragma unroll
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;            /* luma row; as chroma: plane = row >> 3, row & 7 */
             vy[it] = ok ? ld16(recon_y + (ptrdiff_t)row * rs + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            vc[it] = ok ? ld8(mi355_global_v(fr.recon[1 + (row >> 3)]) + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
+            vc[it] = ok ? ld8(((row >> 3) ? recon_cr : recon_cb) + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
         }
         const bool okt = ok && g == 0 && has_t;              /* rows above the band: as the previous band left them */
 #pragma unroll
-        for (int it = 0; it < NT; it++) {
+        for (int it = 0; it < NTOP; it++) {
             const int row = DIO_ROWS * it + io_r;            /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
             const bool in = okt && row < 4;
             ty[it] = in ? ld16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            tc[it] = in ? ld8(mi355_global_v(fr.dst[1 + ((row >> 1) & 1)]) + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
+            tc[it] = in ? ld8((((row >> 1) & 1) ? dst_cr : dst_cb) + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
         }
+    };
+    auto commit_chunk = [&](int c) {
+        const int b = c & 1;
 #pragma unroll
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;
@@ -750,7 +764,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         }
         if (g == 0) {
 #pragma unroll
-            for (int it = 0; it < NT; it++) {
+            for (int it = 0; it < NTOP; it++) {
                 const int row = DIO_ROWS * it + io_r;
                 if (row < 4) {
                     lds16(&s.y[g][b][row][16 * io_p], ty[it]);
@@ -773,10 +787,11 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                 st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, lds16(&s.y[g][b][row][16 * io_p]), al16);
             const int plane = row >= 10, crow = row - 10 * plane;
             if (ok && crow >= c_first && crow <= c_last)
-                st8(mi355_global_v(fr.dst[1 + plane]) + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
+                st8((plane ? dst_cr : dst_cb) + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
         }
     };
 
+    issue_chunk(0);
     DeblockPre pre;
     deblock_prefetch(pre, a, row_ok && g == 0, has_t, l);
     int flushed = 0;                                         /* chunks already written back */
@@ -795,16 +810,20 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             flush_chunk(ck - 1);
             flushed = ck;
         }
-        if (j == 0) load_chunk(ck);
+        if (j == 0) commit_chunk(ck);
+        if (j == DCH_ISSUE) issue_chunk(ck + 1);             /* after the flush above: the stores go first */
+        PROF_MARK(13);
         /* ---- phase A: next step's records and vectors ---------------------------------------------- */
         a.advance();
         deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l);
+        PROF_MARK(14);
         /* ---- phase B: records and vectors -> LDS; rows above from the group above ------------------ */
         reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
         reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
         s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
         if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
         MI355_WAVE_SYNC();                                   /* also: the chunk load above is visible */
+        PROF_MARK(15);
         if (g > 0 && valid) {
             /* macroblock x of the row above sits at position (t-2) % DCH of that group's chunk (t-2) / DCH */
             const int jb = (t - 2) & (DCH - 1), bb = ((t - 2) >> DCH_LOG) & 1;

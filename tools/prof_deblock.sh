@@ -31,8 +31,10 @@ for rep in range(2):
     lib.mi355_h264_deblock_dev(C.c_void_p(dev.d_desc), F, 120, 68, None)
     lib.mi355_debug_prof(out, 1)
     steps = 17 * 126 * min(F, 64)
-    names = ["A+B: issue loads, hdr/mv->LDS", "C: bS", "D0: vertical edges + rows->LDS", "top rows->LDS", "D1: horizontal edges", "E: stores+carry", "-", "loop top (wait prefetch)"]
-    tot = sum(out[i] for i in range(8))
+    names = ["B1: rows from the group above", "C: bS", "D0: vertical edges + rows->LDS", "top rows->LDS", "D1: horizontal edges", "E: stores+carry", "-", "loop top (wait prefetch)"]
+    tot = sum(out[i] for i in range(8)) + sum(out[i] for i in (13, 14, 15))
+    for i, n in ((13, "A0: chunk flush / commit / issue"), (14, "A1: prefetch issue"), (15, "B0: records -> LDS, wave sync")):
+        print("  %-34s %8.0f /step" % (n, out[i] / steps))
     print("F=%d rep %d: total %.0f clk/step (100 MHz ticks? see below)" % (F, rep, tot / steps))
     for i in (7, 0, 1, 2, 3, 4, 5):
         print("  %-34s %8.0f /step  %5.1f%%" % (names[i], out[i] / steps, 100.0 * out[i] / tot))
