@@ -353,9 +353,33 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
 #endif
 }
 
-/* yuv2rgb_c_24_rgb (yuv2rgb.c:335-363): a block converts a 256 x 16 sample tile, each thread a
- * 2x2 quad per step — one (U,V) pair serves both lines (LOADCHROMA :67-72, nearest chroma) */
-constexpr int C24_ROWS = 16;
+constexpr int C24_ROWS = 16, C24_COLS = 512;
+typedef uint32_t sws_u32x2 __attribute__((vector_size(8)));
+/* eight samples of one line: Y bytes in (y0, y1), the four pairs' LUT row offsets in r/g/b -> 24 RGB bytes */
+__device__ __forceinline__ void c24_line(const LutLds &t, uint8_t *d, uint32_t y0, uint32_t y1, const int *r, const int *g, const int *b)
+{
+    uint32_t o[6];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t yy = p < 2 ? y0 : y1;
+        const int Y1 = (yy >> (16 * (p & 1))) & 0xFF, Y2 = (yy >> (16 * (p & 1) + 8)) & 0xFF;
+        const uint32_t r1 = t.y[r[p] + Y1], g1 = t.y[g[p] + Y1], b1 = t.y[b[p] + Y1];
+        const uint32_t r2 = t.y[r[p] + Y2], g2 = t.y[g[p] + Y2], b2 = t.y[b[p] + Y2];
+        /* six bytes per pair: pairs 0,2 start on a dword, pairs 1,3 in the middle of one */
+        if ((p & 1) == 0) {
+            o[3 * (p >> 1)] = r1 | (g1 << 8) | (b1 << 16) | (r2 << 24);
+            o[3 * (p >> 1) + 1] = g2 | (b2 << 8);
+        } else {
+            o[3 * (p >> 1) + 1] |= (r1 << 16) | (g1 << 24);
+            o[3 * (p >> 1) + 2] = b1 | (r2 << 8) | (g2 << 16) | (b2 << 24);
+        }
+    }
+    sws_u32x2 *q = reinterpret_cast<sws_u32x2 *>(d);
+    q[0] = sws_u32x2{ o[0], o[1] }; q[1] = sws_u32x2{ o[2], o[3] }; q[2] = sws_u32x2{ o[4], o[5] };
+}
+/* yuv2rgb_c_24_rgb (yuv2rgb.c:335-363): a block converts a 512 x 16 sample tile; a thread takes eight samples of two
+ * lines per step (8-byte luma loads, 4-byte chroma loads, three 8-byte stores per line) — one (U,V) pair serves both
+ * lines (LOADCHROMA :67-72, nearest chroma).  Unaligned planes and the right edge go pair by pair. */
 __global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int dstW, int sliceH, int sliceY, const mi355_sws_frame *frames)
 {
     __shared__ LutLds s_lut;
@@ -365,16 +389,35 @@ __global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int 
     fr.dst = mi355_global(fr.dst);
     lut_load(s_lut, luts, tid, NT);
     __syncthreads();
-    const int x = blockIdx.x * 256 + (tid & 127) * 2;    /* first sample of the pair */
-    if ((x >> 1) >= (dstW >> 1)) return;   /* pairs i < dstW >> 1 (8 + 4 + 2 sample groups, yuv2rgb.c:129-171) */
-    for (int r = (tid >> 7); r < C24_ROWS / 2; r += 2) {
-        const int y = blockIdx.y * C24_ROWS + 2 * r;
+    const int x = blockIdx.x * C24_COLS + (tid & 63) * 8;   /* first of the thread's eight samples */
+    const int npairs = dstW >> 1;                            /* pairs i < dstW >> 1 (8 + 4 + 2 sample groups, yuv2rgb.c:129-171) */
+    if ((x >> 1) >= npairs) return;
+    const bool wide = (x >> 1) + 4 <= npairs &&
+                      ((reinterpret_cast<uintptr_t>(fr.src[0]) | (uintptr_t)fr.src_stride[0] | reinterpret_cast<uintptr_t>(fr.dst) | (uintptr_t)fr.dst_stride) & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fr.src[1]) | (uintptr_t)fr.src_stride[1] | reinterpret_cast<uintptr_t>(fr.src[2]) | (uintptr_t)fr.src_stride[2]) & 3) == 0;
+    for (int rr = (tid >> 6); rr < C24_ROWS / 2; rr += NT / 64) {
+        const int y = blockIdx.y * C24_ROWS + 2 * rr;
         if (y >= sliceH) break;
         const uint8_t *py1 = fr.src[0] + (size_t)y * fr.src_stride[0] + x, *py2 = py1 + fr.src_stride[0];
-        const int U = fr.src[1][(size_t)(y >> 1) * fr.src_stride[1] + (x >> 1)], V = fr.src[2][(size_t)(y >> 1) * fr.src_stride[2] + (x >> 1)];
+        const uint8_t *pu = fr.src[1] + (size_t)(y >> 1) * fr.src_stride[1] + (x >> 1), *pv = fr.src[2] + (size_t)(y >> 1) * fr.src_stride[2] + (x >> 1);
         uint8_t *d1 = fr.dst + (size_t)(y + sliceY) * fr.dst_stride + (size_t)x * 3, *d2 = d1 + fr.dst_stride;
-        write_pair(s_lut, d1, py1[0], py1[1], U, V);
-        write_pair(s_lut, d2, py2[0], py2[1], U, V);
+        if (wide) {
+            const sws_u32x2 a = *reinterpret_cast<const sws_u32x2 *>(py1), c = *reinterpret_cast<const sws_u32x2 *>(py2);
+            const uint32_t u4 = *reinterpret_cast<const uint32_t *>(pu), v4 = *reinterpret_cast<const uint32_t *>(pv);
+            int r[4], g[4], b[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int U = (u4 >> (8 * p)) & 0xFF, V = (v4 >> (8 * p)) & 0xFF;
+                r[p] = s_lut.rV[V]; g[p] = s_lut.gU[U] + s_lut.gV[V]; b[p] = s_lut.bU[U];
+            }
+            c24_line(s_lut, d1, a[0], a[1], r, g, b);
+            c24_line(s_lut, d2, c[0], c[1], r, g, b);
+        } else {
+            for (int p = 0; p < 4 && (x >> 1) + p < npairs; p++) {
+                write_pair(s_lut, d1 + 6 * p, py1[2 * p], py1[2 * p + 1], pu[p], pv[p]);
+                write_pair(s_lut, d2 + 6 * p, py2[2 * p], py2[2 * p + 1], pu[p], pv[p]);
+            }
+        }
     }
 }
 
@@ -507,7 +550,7 @@ extern "C" void mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fra
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SwsDev &h = c->h;
     if (h.special) {
-        hipLaunchKernelGGL(k_sws_c24, dim3((h.dstW + 255) / 256, (h.srcH + C24_ROWS - 1) / C24_ROWS, nframes), dim3(NT), 0, s,
+        hipLaunchKernelGGL(k_sws_c24, dim3((h.dstW + C24_COLS - 1) / C24_COLS, (h.srcH + C24_ROWS - 1) / C24_ROWS, nframes), dim3(NT), 0, s,
                            &c->d->luts, h.dstW, h.srcH, 0, d_frames);
     } else {
         hipLaunchKernelGGL(k_sws_generic, dim3((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes), dim3(NT), 0, s, c->d, d_frames);
@@ -652,7 +695,7 @@ extern "C" int mi355_sws_yuv2rgb_c_24_rgb(const mi355_sws_luts *luts, int dstW, 
     f.dst = d_dst; f.dst_stride = dpitch;
     MI355_CHECK(hipMemcpyAsync(d_f, &f, sizeof(f), hipMemcpyHostToDevice, s));
     MI355_CHECK(hipMemcpyAsync(d_l, luts, sizeof(mi355_sws_luts), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sws_c24, dim3((dstW + 255) / 256, (rows + C24_ROWS - 1) / C24_ROWS, 1), dim3(NT), 0, s,
+    hipLaunchKernelGGL(k_sws_c24, dim3((dstW + C24_COLS - 1) / C24_COLS, (rows + C24_ROWS - 1) / C24_ROWS, 1), dim3(NT), 0, s,
                        reinterpret_cast<const mi355_sws_luts *>(d_l), dstW, rows, 0, d_f);
     MI355_CHECK(hipMemcpy2DAsync(dst + (ptrdiff_t)srcSliceY * dstStride, dstStride, d_dst, dpitch, (dstW & ~1) * 3, rows, hipMemcpyDeviceToHost, s));
     MI355_CHECK(hipStreamSynchronize(s));
