@@ -394,9 +394,11 @@ __device__ __forceinline__ void idct4_quad(const int c[4], int j, int r[4], int 
     row = j == 0 ? 0 : (j == 1 ? 3 : (j == 2 ? 1 : 2));
 }
 /* four residuals onto four neighbouring samples (a dword when the tile row is aligned) */
+/* ALIGNED: the caller's tile puts every row segment on a dword (no run-time test, no byte path) */
+template <bool ALIGNED = false>
 __device__ __forceinline__ void add_row4(uint8_t *p, const int *r)
 {
-    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+    if (ALIGNED || (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
         uint32_t *w = reinterpret_cast<uint32_t *>(p);
         const uint32_t v = *w;
         *w = (uint32_t)clip_u8((int)(v & 0xFF) + r[0]) | ((uint32_t)clip_u8((int)((v >> 8) & 0xFF) + r[1]) << 8) |

@@ -186,6 +186,7 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
 /* luma residual of a non-Intra4x4/8x8 MB onto a picture tile: hl_decode_mb_idct_luma
  * (h264_mb.c:726-795) with the dc / full / skip choice of h264idct_template.c:174-201 folded
  * into "transform the block iff it carries a coefficient" (identical results) */
+template <bool ALIGNED>   /* ALIGNED: `y` rows start on dwords (the inter kernel's MbLds tiles); the intra tile is offset by its border column */
 __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra16)
 {
     const int lane = lane_id();
@@ -209,12 +210,13 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
         const bool coded = (mask >> b) & 1;
         if (!coded) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;
         if (coded || (intra16 && dc))
-            add_row4(y + (4 * blk_y4(b) + row) * pitch + 4 * blk_x4(b), r);
+            add_row4<ALIGNED>(y + (4 * blk_y4(b) + row) * pitch + 4 * blk_x4(b), r);
     }
     __syncthreads();
 }
 
 /* chroma residual: h264_mb_template.c:196-247 */
+template <bool ALIGNED>
 __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int pitch)
 {
     if (!(uniform(s.hdr.cbp) & 0x30)) return;
@@ -238,30 +240,32 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
     if (lane < 32 && (coded || dc)) {
         uint8_t *p = (j >> 2) ? cr : cb;
         const int jj = j & 3;
-        add_row4(p + (4 * (jj >> 1) + row) * pitch + 4 * (jj & 1), r);
+        add_row4<ALIGNED>(p + (4 * (jj >> 1) + row) * pitch + 4 * (jj & 1), r);
     }
     __syncthreads();
 }
 
 /* tile (LDS) -> picture, 4 bytes per lane */
+template <bool ALIGNED>
 __device__ __forceinline__ uint32_t tile_dword(const uint8_t *p)
 {
-    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) return *reinterpret_cast<const uint32_t *>(p);
+    if (ALIGNED || (reinterpret_cast<uintptr_t>(p) & 3) == 0) return *reinterpret_cast<const uint32_t *>(p);
     return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
 }
+template <bool ALIGNED = false>
 __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb, const uint8_t *cr, int cpitch,
                                 uint8_t *const dst[3], const int32_t stride[2], int mb_x, int mb_y)
 {
     const int lane = lane_id();
     {
         const int row = lane >> 2, seg = lane & 3;
-        *reinterpret_cast<uint32_t *>(mi355_global(dst[0]) + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword(y + row * ypitch + 4 * seg);
+        *reinterpret_cast<uint32_t *>(mi355_global(dst[0]) + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword<ALIGNED>(y + row * ypitch + 4 * seg);
     }
     if (lane < 32) {
         const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
         uint8_t *const c0 = mi355_global(dst[1]), *const c1 = mi355_global(dst[2]);     /* uniform fetches, per-lane select */
         *reinterpret_cast<uint32_t *>((plane ? c1 : c0) + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
-            tile_dword((plane ? cr : cb) + row * cpitch + 4 * seg);
+            tile_dword<ALIGNED>((plane ? cr : cb) + row * cpitch + 4 * seg);
     }
 }
 
@@ -304,14 +308,14 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     PROF_MARK(9);
 #ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
-    if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma(s, s.py, 16, false);
+    if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma<true>(s, s.py, 16, false);
     PROF_MARK(10);
-    residual_chroma(s, s.pc[0], s.pc[1], 8);
+    residual_chroma<true>(s, s.pc[0], s.pc[1], 8);
     PROF_MARK(11);
 #endif
     /* (a strip variant — four adjacent macroblocks per wave, 64-byte row stores, next macroblock's loads
      * in flight — measured 7 % slower: the kernel is bound by instruction issue, not by L1 requests) */
-    store_mb(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
+    store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
     PROF_MARK(12);
 }
 
@@ -387,7 +391,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             }
             __syncthreads();
         }
-        residual_luma(s.mb, &TILE(0, 0), TP, true);
+        residual_luma<false>(s.mb, &TILE(0, 0), TP, true);
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
         for (int i8 = 0; i8 < 4; i8++) {
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
@@ -419,7 +423,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             __syncthreads();
         }
     }
-    residual_chroma(s.mb, &s.ctile[0][CP + 1], &s.ctile[1][CP + 1], CP);
+    residual_chroma<false>(s.mb, &s.ctile[0][CP + 1], &s.ctile[1][CP + 1], CP);
     store_mb(&TILE(0, 0), TP, &s.ctile[0][CP + 1], &s.ctile[1][CP + 1], CP, fr.recon, fr.recon_stride, mb_x, mb_y);
 }
 #undef TILE
