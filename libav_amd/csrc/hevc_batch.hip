@@ -93,9 +93,9 @@ __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_jo
     const unsigned al = (unsigned)(uintptr_t)j.src1 | (two ? (unsigned)(uintptr_t)j.src2 : 0u) | (unsigned)j.src_stride |
                         ((unsigned)(uintptr_t)j.dst | (unsigned)j.dst_stride) * (bd > 8 ? 1u : 2u) | ((unsigned)j.width & 1u) * 4u;
     if ((al & 3) == 0) {
-        const int hw = j.width >> 1, n = hw * j.height, inv = ((1 << 20) + hw - 1) / hw;     /* i / hw, exact for i * (hw - 1) < 2^20 */
+        const int hw = j.width >> 1, n = hw * j.height, inv = mi355_inv20(hw);
         for (int i = lane_id(); i < n; i += 64) {
-            const int y = (int)(__umul24((unsigned)i, (unsigned)inv) >> 20), x = 2 * (i - y * hw);
+            const int y = mi355_div20(i, inv), x = 2 * (i - y * hw);
             const uint32_t a = *reinterpret_cast<const uint32_t *>(&j.src1[x + y * ss]);
             const uint32_t b = two ? *reinterpret_cast<const uint32_t *>(&j.src2[x + y * ss]) : 0u;
             const int v0 = hevc_pred_px(p, (int16_t)(a & 0xFFFF), (int16_t)(b & 0xFFFF), bd), v1 = hevc_pred_px(p, (int16_t)(a >> 16), (int16_t)(b >> 16), bd);

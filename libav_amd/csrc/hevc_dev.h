@@ -237,9 +237,9 @@ __device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdif
 {
     const int lane = lane_id(), rowbytes = cols * (bd > 8 ? 2 : 1);
     if (rowbytes >= 8) {
-        const int K = (rowbytes + 7) >> 3, inv = (65536 + K - 1) / K;      /* i / K for i < 65536 / K */
+        const int K = (rowbytes + 7) >> 3, inv = mi355_inv20(K);
         for (int i = lane; i < rows * K; i += 64) {
-            const int r = (i * inv) >> 16, k = i - r * K;
+            const int r = mi355_div20(i, inv), k = i - r * K;
             /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
             const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
             uint64_t v;
@@ -283,11 +283,11 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
         int16_t *out = dst + (ptrdiff_t)ty * ds + tx;
         hevc_mc_stage(s, src + (ptrdiff_t)(ty - by) * sb + (ptrdiff_t)(tx - bx) * px, sb, rows, tw + (mx ? extra : 0), bd);
         __syncthreads();
-        const int wseg = (tw + 3) >> 2, winv = (65536 + wseg - 1) / wseg;
+        const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
         if (!mx && !my) {
             /* put_hevc_*_pixels: sample << (14 - bd); two values per dword shift together (no carry across) */
             for (int i = lane; i < rows * wseg; i += 64) {
-                const int r = (i * winv) >> 16, x0 = 4 * (i - r * wseg);
+                const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
                 hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, d[0] << (14 - bd), d[1] << (14 - bd), tw - x0, amode);
             }
@@ -295,7 +295,7 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
         if (mx) {
             /* horizontal pass over `rows` lines, four outputs per lane */
             for (int i = lane; i < rows * wseg; i += 64) {
-                const int r = (i * winv) >> 16, x0 = 4 * (i - r * wseg);
+                const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
                 uint32_t dd[6];
 #pragma unroll
@@ -312,9 +312,9 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
             /* vertical pass: lane = (column pair, eight output rows) */
             const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
             const int vshift = mx ? 6 : bd - 8;
-            const int cp = tw >> 1, cinv = (65536 + cp - 1) / cp, oct = (th_ + 7) >> 3;
+            const int cp = tw >> 1, cinv = mi355_inv20(cp), oct = (th_ + 7) >> 3;
             for (int i = lane; i < cp * oct; i += 64) {
-                const int q = (i * cinv) >> 16, c2 = i - q * cp, y0 = 8 * q;
+                const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = 8 * q;
                 const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
                 int a0[8], a1[8];
 #pragma unroll
@@ -449,9 +449,9 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
     if (cls & 2) { x0 = -cw; w = cw; } else if (!j.borders[2]) w -= cw;
     const int w0 = w, h0 = h;
     if (!j.edge) {
-        const int shift = bd - 5, winv = ((1 << 20) + w - 1) / (w > 0 ? w : 1);     /* i / w: exact for i * (w - 1) < 2^20 */
+        const int shift = bd - 5, winv = mi355_inv20(w > 0 ? w : 1);
         for (int i = lane_id(); i < w * h; i += 64) {
-            const int y = (int)(__umul24((unsigned)i, (unsigned)winv) >> 20), x = i - y * w, o = (y0 + y) * st + x0 + x;
+            const int y = mi355_div20(i, winv), x = i - y * w, o = (y0 + y) * st + x0 + x;
             const int v = ldpx(src, o, bd), k = ((v >> shift) - j.band_position) & 31;
             stpx(dst, (y0 + y) * dt + x0 + x, clip_px(v + (k < 4 ? j.offset_val[k + 1] : 0), bd), bd);
         }
@@ -474,9 +474,9 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
     else save = !j.diag_edge && eo == 2;
     const int ya = init_y + ((cls & 1) ? 0 : save), yb = h - ((cls & 1) ? save : 0);
     const int xa = init_x + ((cls & 2) ? 0 : save), xb = w - ((cls & 2) ? save : 0);
-    const int winv = ((1 << 20) + w0 - 1) / (w0 > 0 ? w0 : 1);                        /* i / w0: exact for i * (w0 - 1) < 2^20 */
+    const int winv = mi355_inv20(w0 > 0 ? w0 : 1);
     for (int i = lane_id(); i < w0 * h0; i += 64) {
-        const int y = (int)(__umul24((unsigned)i, (unsigned)winv) >> 20), x = i - y * w0, o = (y0 + y) * st + x0 + x;
+        const int y = mi355_div20(i, winv), x = i - y * w0, o = (y0 + y) * st + x0 + x;
         const int c = ldpx(src, o, bd);
         int v;
         const bool in_main = x >= init_x && x < w && y >= init_y && y < h;

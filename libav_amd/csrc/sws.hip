@@ -151,10 +151,10 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         return;
     }
     /* idx / n as a 24-bit multiply and a shift: exact for idx * (n - 1) < 2^20 (idx < SG * SRC_DW) */
-    const int np = al16 ? (nd + 3) >> 2 : nd, inv = ((1 << 20) + np - 1) / np;
+    const int np = al16 ? (nd + 3) >> 2 : nd, inv = mi355_inv20(np);
     for (int base = lo; base <= hi; base += SG) {
         for (int idx = tid; idx < SG * np; idx += NT) {
-            const int r = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), d = idx - r * np, line = base + r;
+            const int r = mi355_div20(idx, inv), d = idx - r * np, line = base + r;
             if (line > hi) continue;
             if (al16) {
                 const int off = a0 + 16 * d;
@@ -334,15 +334,15 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
         const int nrows = y1 - y0 + 1;
         const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
         if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
-            const int n = nbytes >> 4, inv = ((1 << 20) + n - 1) / n;
+            const int n = nbytes >> 4, inv = mi355_inv20(n);
             for (int idx = tid; idx < nrows * n; idx += NT) {
-                const int row = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), k = idx - row * n;
+                const int row = mi355_div20(idx, inv), k = idx - row * n;
                 reinterpret_cast<uint4 *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint4 *>(s_out[row])[k];
             }
         } else if ((al & 3) == 0) {
-            const int n = nbytes >> 2, inv = ((1 << 20) + n - 1) / n;
+            const int n = nbytes >> 2, inv = mi355_inv20(n);
             for (int idx = tid; idx < nrows * n; idx += NT) {
-                const int row = (int)(__umul24((unsigned)idx, (unsigned)inv) >> 20), k = idx - row * n;
+                const int row = mi355_div20(idx, inv), k = idx - row * n;
                 reinterpret_cast<uint32_t *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
             }
         } else {
