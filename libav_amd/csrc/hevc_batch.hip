@@ -92,6 +92,24 @@ __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_jo
     /* two samples per lane and access when the rows allow it (block widths are even) */
     const unsigned al = (unsigned)(uintptr_t)j.src1 | (two ? (unsigned)(uintptr_t)j.src2 : 0u) | (unsigned)j.src_stride |
                         ((unsigned)(uintptr_t)j.dst | (unsigned)j.dst_stride) * (bd > 8 ? 1u : 2u) | ((unsigned)j.width & 1u) * 4u;
+    const unsigned al8 = al | ((unsigned)(uintptr_t)j.dst | (unsigned)j.dst_stride) * (bd > 8 ? 0u : 2u) | ((unsigned)j.width & 3u) * 2u;
+    if ((al8 & 7) == 0) {      /* four samples per lane: 8-byte loads, one 8- or 4-byte store */
+        const int qw = j.width >> 2, n = qw * j.height, inv = mi355_inv20(qw);
+        typedef uint32_t u32x2 __attribute__((vector_size(8)));
+        for (int i = lane_id(); i < n; i += 64) {
+            const int y = mi355_div20(i, inv), x = 4 * (i - y * qw);
+            const u32x2 a = *reinterpret_cast<const u32x2 *>(&j.src1[x + y * ss]);
+            u32x2 b = { 0u, 0u };
+            if (two) b = *reinterpret_cast<const u32x2 *>(&j.src2[x + y * ss]);
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = hevc_pred_px(p, (int16_t)((a[k >> 1] >> (16 * (k & 1))) & 0xFFFF), (int16_t)((b[k >> 1] >> (16 * (k & 1))) & 0xFFFF), bd);
+            if (bd > 8) *reinterpret_cast<u32x2 *>(j.dst + (size_t)y * j.dst_stride + 2 * x) = u32x2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16) };
+            else *reinterpret_cast<uint32_t *>(j.dst + (size_t)y * j.dst_stride + x) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        }
+        return;
+    }
     if ((al & 3) == 0) {
         const int hw = j.width >> 1, n = hw * j.height, inv = mi355_inv20(hw);
         for (int i = lane_id(); i < n; i += 64) {
@@ -141,7 +159,8 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
     p.eo_class = j.eo_class; p.band_position = j.band_position;
     for (int k = 0; k < 5; k++) p.offset_val[k] = j.offset_val[k];
     const int st = j.stride / (bd > 8 ? 2 : 1);
-    hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p);
+    __shared__ int tbl[32];
+    hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p, tbl);
 }
 
 /* ---- intra prediction: one wave per transform block -------------------------------------------------------- */

@@ -440,14 +440,58 @@ struct SaoJob {
     int eo_class, band_position;
     int offset_val[5];
 };
-/* src/dst point at the caller's (0,0) sample; `dt`/`st` = samples per row of dst/src */
-__device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, int st, const SaoJob &j)
+/* two neighbouring samples at element offset o as one (possibly unaligned) access: low half = sample o */
+__device__ __forceinline__ uint32_t sao_ld2(const uint8_t *p, ptrdiff_t o, int bd)
+{
+    if (bd > 8) { uint32_t v; __builtin_memcpy(&v, p + 2 * o, 4); return v; }
+    uint16_t v; __builtin_memcpy(&v, p + o, 2);
+    return (uint32_t)(v & 0xFF) | ((uint32_t)(v >> 8) << 16);
+}
+__device__ __forceinline__ void sao_st2(uint8_t *p, ptrdiff_t o, int v0, int v1, int bd)
+{
+    if (bd > 8) { const uint32_t v = (uint32_t)v0 | ((uint32_t)v1 << 16); __builtin_memcpy(p + 2 * o, &v, 4); }
+    else { const uint16_t v = (uint16_t)(v0 | (v1 << 8)); __builtin_memcpy(p + o, &v, 2); }
+}
+/* src/dst point at the caller's (0,0) sample; `dt`/`st` = samples per row of dst/src; `tbl`: 32 ints of LDS */
+__device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, int st, const SaoJob &j, int *tbl)
 {
     const int chroma = j.c_idx != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, bd = j.bd, cls = j.cls;
     int x0 = 0, y0 = 0, w = j.width, h = j.height;
     if (cls & 1) { y0 = -ch; h = ch; } else if (!j.borders[3]) h -= ch;
     if (cls & 2) { x0 = -cw; w = cw; } else if (!j.borders[2]) w -= cw;
     const int w0 = w, h0 = h;
+    const int lane = lane_id();
+    /* Fast forms, two samples per lane, offsets from a table in LDS: the band filter always; the edge filter when no
+     * picture border, slice or tile edge touches the region (every sample of it then has both neighbours and none is
+     * restored) — the bulk of a picture. */
+    const bool plain_edge = !(j.borders[0] | j.borders[1] | j.borders[2] | j.borders[3] | j.vert_edge | j.horiz_edge | j.diag_edge);
+    if (w0 > 0 && (w0 & 1) == 0 && (!j.edge || plain_edge)) {
+        if (!j.edge) { if (lane < 32) { const int k = (lane - j.band_position) & 31; tbl[lane] = k < 4 ? j.offset_val[k + 1] : 0; } }
+        else if (lane < 5) tbl[lane] = j.offset_val[lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4)))];   /* edge_idx[] = {1,2,0,3,4} */
+        __syncthreads();
+        const int eo = j.eo_class, hw = w0 >> 1, winv = mi355_inv20(hw), shift = bd - 5;
+        const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
+        const ptrdiff_t da = dx0 + (ptrdiff_t)dy0 * st;
+        for (int i = lane; i < hw * h0; i += 64) {
+            const int y = mi355_div20(i, winv), x = 2 * (i - y * hw);
+            const ptrdiff_t o = (ptrdiff_t)(y0 + y) * st + x0 + x;
+            const uint32_t c2 = sao_ld2(src, o, bd);
+            const int c0 = (int)(c2 & 0xFFFF), c1 = (int)(c2 >> 16);
+            int v0, v1;
+            if (!j.edge) {
+                v0 = c0 + tbl[c0 >> shift]; v1 = c1 + tbl[c1 >> shift];
+            } else {
+                const uint32_t a2 = sao_ld2(src, o + da, bd), b2 = sao_ld2(src, o - da, bd);
+                const int a0 = (int)(a2 & 0xFFFF), a1 = (int)(a2 >> 16), b0 = (int)(b2 & 0xFFFF), b1 = (int)(b2 >> 16);
+                /* sign(c - a) + sign(c - b) + 2 */
+                v0 = c0 + tbl[clip3(c0 - a0, -1, 1) + clip3(c0 - b0, -1, 1) + 2];
+                v1 = c1 + tbl[clip3(c1 - a1, -1, 1) + clip3(c1 - b1, -1, 1) + 2];
+            }
+            sao_st2(dst, (ptrdiff_t)(y0 + y) * dt + x0 + x, clip_px(v0, bd), clip_px(v1, bd), bd);
+        }
+        __syncthreads();
+        return;
+    }
     if (!j.edge) {
         const int shift = bd - 5, winv = mi355_inv20(w > 0 ? w : 1);
         for (int i = lane_id(); i < w * h; i += 64) {

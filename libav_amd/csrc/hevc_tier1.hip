@@ -115,7 +115,8 @@ k_hevc_sao(uint8_t *dbase, int dt, int dox, int doy, const uint8_t *sbase, int s
 {
     const int px = j.bd > 8 ? 2 : 1;
     /* (dox,doy)/(sox,soy): window coordinates of the caller's (0,0) sample */
-    hevc_sao_wave(dbase + (ptrdiff_t)(doy * dt + dox) * px, dt, sbase + (ptrdiff_t)(soy * st + sox) * px, st, j);
+    __shared__ int tbl[32];
+    hevc_sao_wave(dbase + (ptrdiff_t)(doy * dt + dox) * px, dt, sbase + (ptrdiff_t)(soy * st + sox) * px, st, j, tbl);
 }
 template <int CLS, int BD, int EDGE>
 static void sao_run(uint8_t *dst, uint8_t *src, ptrdiff_t stride, SAOParams *sao, int *borders, int width, int height,
