@@ -186,7 +186,7 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
 /* luma residual of a non-Intra4x4/8x8 MB onto a picture tile: hl_decode_mb_idct_luma
  * (h264_mb.c:726-795) with the dc / full / skip choice of h264idct_template.c:174-201 folded
  * into "transform the block iff it carries a coefficient" (identical results) */
-template <bool ALIGNED>   /* ALIGNED: `y` rows start on dwords (the inter kernel's MbLds tiles); the intra tile is offset by its border column */
+template <bool ALIGNED>   /* ALIGNED: every 4-sample row segment of `y` starts on a dword (both frame kernels lay their tiles out that way) */
 __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra16)
 {
     const int lane = lane_id();
@@ -322,15 +322,17 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
 /* ------------------------------------------------------------------------- */
 /* intra                                                                        */
 /* ------------------------------------------------------------------------- */
-constexpr int TP = 28;   /* luma tile pitch: columns -1..23 (8x8 blocks read 16 samples of the row above) */
-constexpr int CP = 12;   /* chroma tile pitch: columns -1..7 */
+constexpr int TP = 32;   /* luma tile pitch: columns -1..23 (8x8 blocks read 16 samples of the row above) */
+constexpr int CP = 16;   /* chroma tile pitch: columns -1..7 */
+constexpr int TO = 4;    /* column 0 sits on a dword (column -1 at TO - 1): residual add and store move whole dwords */
 struct IntraLds {
     MbLds mb;
-    uint8_t tile[17 * TP];
-    uint8_t ctile[2][9 * CP];
+    __attribute__((aligned(16))) uint8_t tile[17 * TP];
+    __attribute__((aligned(16))) uint8_t ctile[2][9 * CP];
     PredScratch ps;
 };
-#define TILE(x, y) s.tile[((y) + 1) * TP + (x) + 1]
+#define TILE(x, y) s.tile[((y) + 1) * TP + (x) + TO]
+#define CTILE(p, x, y) s.ctile[p][((y) + 1) * CP + (x) + TO]
 
 __global__ void __launch_bounds__(64)
 k_recon_intra(const mi355_h264_frame *frames, int level, int width)
@@ -352,7 +354,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
-        store_mb(src, 16, src + 256, src + 320, 8, fr.recon, fr.recon_stride, mb_x, mb_y);
+        store_mb<true>(src, 16, src + 256, src + 320, 8, fr.recon, fr.recon_stride, mb_x, mb_y);
         return;
     }
     /* edge samples of the unfiltered neighbours -> tiles */
@@ -364,17 +366,17 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     if (mb_x > 0 && lane >= 32 && lane < 48) TILE(-1, lane - 32) = ry[(lane - 32) * ys - 1];
     for (int p = 0; p < 2; p++) {
         const uint8_t *rc = mi355_global(fr.recon[1 + p]) + (size_t)mb_y * 8 * cs + mb_x * 8;
-        if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0)) s.ctile[p][lane] = rc[lane - 1 - cs];
-        if (mb_x > 0 && lane >= 16 && lane < 24) s.ctile[p][(lane - 16 + 1) * CP] = rc[(lane - 16) * cs - 1];
+        if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0)) CTILE(p, lane - 1, -1) = rc[lane - 1 - cs];
+        if (mb_x > 0 && lane >= 16 && lane < 24) CTILE(p, -1, lane - 16) = rc[(lane - 16) * cs - 1];
     }
     __syncthreads();
 
     /* chroma prediction: hpc.pred8x8[chroma_pred_mode], h264_mb_template.c:161-164 */
     for (int p = 0; p < 2; p++) {
-        if (lane < 9) s.ps.T[lane] = s.ctile[p][lane];
-        if (lane >= 16 && lane < 25) s.ps.L[lane - 16] = s.ctile[p][(lane - 16) * CP];
+        if (lane < 9) s.ps.T[lane] = CTILE(p, lane - 1, -1);
+        if (lane >= 16 && lane < 25) s.ps.L[lane - 16] = CTILE(p, -1, lane - 17);
         __syncthreads();
-        intra_pred_wave(s.ps, 2, h.chroma_pred_mode, 0, 0, &s.ctile[p][CP + 1], CP);
+        intra_pred_wave(s.ps, 2, h.chroma_pred_mode, 0, 0, &CTILE(p, 0, 0), CP);
     }
 
     if (t & MI355_MB_INTRA16x16) {       /* h264_mb.c:701-722 */
@@ -391,7 +393,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
             }
             __syncthreads();
         }
-        residual_luma<false>(s.mb, &TILE(0, 0), TP, true);
+        residual_luma<true>(s.mb, &TILE(0, 0), TP, true);
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
         for (int i8 = 0; i8 < 4; i8++) {
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
@@ -419,12 +421,12 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
 #pragma unroll
             for (int k2 = 0; k2 < 4; k2++) c[k2] = s.mb.coef[i * 16 + q + 4 * k2];
             idct4_quad(c, q, r, row);
-            if (lane < 4 && ((h.nnz_mask >> i) & 1)) add_row4(&TILE(x0, y0 + row), r);
+            if (lane < 4 && ((h.nnz_mask >> i) & 1)) add_row4<true>(&TILE(x0, y0 + row), r);
             __syncthreads();
         }
     }
-    residual_chroma<false>(s.mb, &s.ctile[0][CP + 1], &s.ctile[1][CP + 1], CP);
-    store_mb(&TILE(0, 0), TP, &s.ctile[0][CP + 1], &s.ctile[1][CP + 1], CP, fr.recon, fr.recon_stride, mb_x, mb_y);
+    residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
+    store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr.recon, fr.recon_stride, mb_x, mb_y);
 }
 #undef TILE
 
