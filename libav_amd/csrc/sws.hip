@@ -79,6 +79,30 @@ __device__ __forceinline__ void rgb_pair(const LutLds &t, uint8_t *dest, const R
     }
     write_pair(t, dest, Y1, Y2, U, V);
 }
+typedef uint32_t sws_u32x2 __attribute__((vector_size(8)));
+typedef uint32_t sws_u32x4 __attribute__((vector_size(16)));
+/* eight neighbouring samples of a line (four pairs sharing a chroma sample each): Y values 0..255 in Y[8], the pairs' LUT
+ * row offsets in r/g/b -> 24 RGB bytes at d (8-byte aligned), three 8-byte stores */
+__device__ __forceinline__ void rgb24_store8(const LutLds &t, uint8_t *d, const int *Y, const int *r, const int *g, const int *b)
+{
+    uint32_t o[6];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int Y1 = Y[2 * p], Y2 = Y[2 * p + 1];
+        const uint32_t r1 = t.y[r[p] + Y1], g1 = t.y[g[p] + Y1], b1 = t.y[b[p] + Y1];
+        const uint32_t r2 = t.y[r[p] + Y2], g2 = t.y[g[p] + Y2], b2 = t.y[b[p] + Y2];
+        /* six bytes per pair: pairs 0,2 start on a dword, pairs 1,3 in the middle of one */
+        if ((p & 1) == 0) {
+            o[3 * (p >> 1)] = r1 | (g1 << 8) | (b1 << 16) | (r2 << 24);
+            o[3 * (p >> 1) + 1] = g2 | (b2 << 8);
+        } else {
+            o[3 * (p >> 1) + 1] |= (r1 << 16) | (g1 << 24);
+            o[3 * (p >> 1) + 2] = b1 | (r2 << 8) | (g2 << 16) | (b2 << 24);
+        }
+    }
+    sws_u32x2 *q = reinterpret_cast<sws_u32x2 *>(d);
+    q[0] = sws_u32x2{ o[0], o[1] }; q[1] = sws_u32x2{ o[2], o[3] }; q[2] = sws_u32x2{ o[4], o[5] };
+}
 __device__ __forceinline__ int packed_mode(int ls, int cs) { return (ls == 1 && cs <= 2) ? 1 : ((ls == 2 && cs == 2) ? 2 : 0); }  /* swscale.c:658-682 */
 
 /* hScale8To15_c swscale.c:133-147 for one output sample */
@@ -216,7 +240,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
 template <int NL, int NC>
 __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut, const int16_t (*s_lum)[TW], const int16_t (*s_cu)[TW / 2],
                                               const int16_t (*s_cv)[TW / 2], uint8_t (*s_out)[TW * 3], int tid, int y0, int y1, int llo, int clo,
-                                              int npairs, int mode)
+                                              int npairs, int mode, uint8_t *wide_dst, int dst_stride)
 {
     const int row = tid >> 4, gy = y0 + row;
     if (gy > y1) return;
@@ -232,6 +256,68 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
     for (int j = 0; j < NC; j++) {
         cf[j] = j < cs ? c.vChrC[(size_t)gy * cs + j] : 0;
         ci[j] = clampi(cfirst + (j < cs ? j : 0), 0, c.chrSrcH - 1) - clo;
+    }
+    if (wide_dst) {
+        /* full tile, 8-byte aligned destination: a thread takes eight neighbouring samples (16 / 8 bytes per LDS read)
+         * and stores its 24 RGB bytes directly */
+        const int grp = tid & 15;
+        int Y[8], U[4], V[4];
+        if (mode == 1) {
+            const int uvalpha = cs == 1 ? 0 : cf[NC > 1 ? 1 : 0];
+            const sws_u32x4 l0 = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[0]][8 * grp]);
+            const sws_u32x2 u0 = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[0]][4 * grp]), v0 = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[0]][4 * grp]);
+            const sws_u32x2 u1 = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[NC > 1 ? 1 : 0]][4 * grp]), v1 = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[NC > 1 ? 1 : 0]][4 * grp]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) Y[k] = clip_u8((int16_t)(l0[k >> 1] >> (16 * (k & 1))) >> 7);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a = (int16_t)(u0[k >> 1] >> (16 * (k & 1))), b = (int16_t)(v0[k >> 1] >> (16 * (k & 1)));
+                const int a1 = (int16_t)(u1[k >> 1] >> (16 * (k & 1))), b1 = (int16_t)(v1[k >> 1] >> (16 * (k & 1)));
+                if (uvalpha < 2048) { U[k] = clip_u8(a >> 7); V[k] = clip_u8(b >> 7); }
+                else { U[k] = clip_u8((a + a1) >> 8); V[k] = clip_u8((b + b1) >> 8); }
+            }
+        } else if (mode == 2) {
+            const int ya = lf[NL > 1 ? 1 : 0], ua = cf[NC > 1 ? 1 : 0], ya1 = 4096 - ya, ua1 = 4096 - ua;
+            const sws_u32x4 l0 = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[0]][8 * grp]), l1 = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[NL > 1 ? 1 : 0]][8 * grp]);
+            const sws_u32x2 u0 = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[0]][4 * grp]), v0 = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[0]][4 * grp]);
+            const sws_u32x2 u1 = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[NC > 1 ? 1 : 0]][4 * grp]), v1 = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[NC > 1 ? 1 : 0]][4 * grp]);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                Y[k] = clip_u8(((int16_t)(l0[k >> 1] >> (16 * (k & 1))) * ya1 + (int16_t)(l1[k >> 1] >> (16 * (k & 1))) * ya) >> 19);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                U[k] = clip_u8(((int16_t)(u0[k >> 1] >> (16 * (k & 1))) * ua1 + (int16_t)(u1[k >> 1] >> (16 * (k & 1))) * ua) >> 19);
+                V[k] = clip_u8(((int16_t)(v0[k >> 1] >> (16 * (k & 1))) * ua1 + (int16_t)(v1[k >> 1] >> (16 * (k & 1))) * ua) >> 19);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) Y[k] = 1 << 18;
+#pragma unroll
+            for (int k = 0; k < 4; k++) U[k] = V[k] = 1 << 18;
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const sws_u32x4 l = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[j]][8 * grp]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) Y[k] += (int16_t)(l[k >> 1] >> (16 * (k & 1))) * lf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                const sws_u32x2 u = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[j]][4 * grp]), v = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[j]][4 * grp]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { U[k] += (int16_t)(u[k >> 1] >> (16 * (k & 1))) * cf[j]; V[k] += (int16_t)(v[k >> 1] >> (16 * (k & 1))) * cf[j]; }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p++) {       /* clipped per pair, only if one of its four values has bit 8 set (output.c:963) */
+                int &Y1 = Y[2 * p], &Y2 = Y[2 * p + 1], &Up = U[p], &Vp = V[p];
+                Y1 >>= 19; Y2 >>= 19; Up >>= 19; Vp >>= 19;
+                if ((Y1 | Y2 | Up | Vp) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); Up = clip_u8(Up); Vp = clip_u8(Vp); }
+            }
+        }
+        int r[4], g[4], b[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) { r[p] = lut.rV[V[p]]; g[p] = lut.gU[U[p]] + lut.gV[V[p]]; b[p] = lut.bU[U[p]]; }
+        rgb24_store8(lut, wide_dst + (size_t)row * dst_stride + 24 * grp, Y, r, g, b);
+        return;
     }
     /* fixed trip count: the pairs of a thread are 16 apart, so every LDS address is one base plus an immediate */
 #pragma unroll
@@ -268,8 +354,8 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
 
 __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi355_sws_frame *frames)
 {
-    __shared__ int16_t s_lum[MAXL][TW];
-    __shared__ int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
+    __shared__ __attribute__((aligned(16))) int16_t s_lum[MAXL][TW];
+    __shared__ __attribute__((aligned(16))) int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
     __shared__ LutLds s_lut;
     __shared__ __attribute__((aligned(16))) uint8_t s_out[MAXTH][TW * 3];
     SwsDev c = *cp;                                   /* pointers of the records: global address space (mi355_rt.h) */
@@ -301,11 +387,15 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     /* vertical pass + LUT */
     const int mode = packed_mode(ls, cs);
     const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
+    /* full tiles with an 8-byte aligned destination leave straight from registers; the others go through s_out */
+    uint8_t *const tile_dst = fr.dst + (size_t)y0 * fr.dst_stride + (size_t)x0 * 3;
+    uint8_t *const wide_dst = (ls <= 8 && cs <= 8 && c.dstW - x0 >= TW && ((reinterpret_cast<uintptr_t>(tile_dst) | (uintptr_t)fr.dst_stride) & 7) == 0)
+                                  ? tile_dst : nullptr;
 #ifndef MI355_SWS_NO_V
     if (ls <= 8 && cs <= 8) {
         /* tap counts in registers, rounded up to 1 / 2 / 4 / 8 */
         const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
-#define MI355_VR(NL, NC) vertical_rows<NL, NC>(c, s_lut, s_lum, s_cu, s_cv, s_out, tid, y0, y1, llo, clo, npairs, mode)
+#define MI355_VR(NL, NC) vertical_rows<NL, NC>(c, s_lut, s_lum, s_cu, s_cv, s_out, tid, y0, y1, llo, clo, npairs, mode, wide_dst, fr.dst_stride)
         switch (bl * 4 + bc) {
         case 0: MI355_VR(1, 1); break;   case 1: MI355_VR(1, 2); break;   case 2: MI355_VR(1, 4); break;   case 3: MI355_VR(1, 8); break;
         case 4: MI355_VR(2, 1); break;   case 5: MI355_VR(2, 2); break;   case 6: MI355_VR(2, 4); break;   case 7: MI355_VR(2, 8); break;
@@ -329,8 +419,8 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
      * the last sample from uninitialised ring-buffer data; that sample is not reproduced) */
     const int nbytes = imin(TW, c.dstW - x0) * 3;
 #ifndef MI355_SWS_NO_OUT
-    {
-        uint8_t *d0 = fr.dst + (size_t)y0 * fr.dst_stride + (size_t)x0 * 3;
+    if (!wide_dst) {
+        uint8_t *d0 = tile_dst;
         const int nrows = y1 - y0 + 1;
         const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
         if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
@@ -354,28 +444,13 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
 }
 
 constexpr int C24_ROWS = 16, C24_COLS = 512;
-typedef uint32_t sws_u32x2 __attribute__((vector_size(8)));
 /* eight samples of one line: Y bytes in (y0, y1), the four pairs' LUT row offsets in r/g/b -> 24 RGB bytes */
 __device__ __forceinline__ void c24_line(const LutLds &t, uint8_t *d, uint32_t y0, uint32_t y1, const int *r, const int *g, const int *b)
 {
-    uint32_t o[6];
+    int Y[8];
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const uint32_t yy = p < 2 ? y0 : y1;
-        const int Y1 = (yy >> (16 * (p & 1))) & 0xFF, Y2 = (yy >> (16 * (p & 1) + 8)) & 0xFF;
-        const uint32_t r1 = t.y[r[p] + Y1], g1 = t.y[g[p] + Y1], b1 = t.y[b[p] + Y1];
-        const uint32_t r2 = t.y[r[p] + Y2], g2 = t.y[g[p] + Y2], b2 = t.y[b[p] + Y2];
-        /* six bytes per pair: pairs 0,2 start on a dword, pairs 1,3 in the middle of one */
-        if ((p & 1) == 0) {
-            o[3 * (p >> 1)] = r1 | (g1 << 8) | (b1 << 16) | (r2 << 24);
-            o[3 * (p >> 1) + 1] = g2 | (b2 << 8);
-        } else {
-            o[3 * (p >> 1) + 1] |= (r1 << 16) | (g1 << 24);
-            o[3 * (p >> 1) + 2] = b1 | (r2 << 8) | (g2 << 16) | (b2 << 24);
-        }
-    }
-    sws_u32x2 *q = reinterpret_cast<sws_u32x2 *>(d);
-    q[0] = sws_u32x2{ o[0], o[1] }; q[1] = sws_u32x2{ o[2], o[3] }; q[2] = sws_u32x2{ o[4], o[5] };
+    for (int k = 0; k < 8; k++) Y[k] = ((k < 4 ? y0 : y1) >> (8 * (k & 3))) & 0xFF;
+    rgb24_store8(t, d, Y, r, g, b);
 }
 /* yuv2rgb_c_24_rgb (yuv2rgb.c:335-363): a block converts a 512 x 16 sample tile; a thread takes eight samples of two
  * lines per step (8-byte luma loads, 4-byte chroma loads, three 8-byte stores per line) — one (U,V) pair serves both
