@@ -60,6 +60,25 @@ typedef struct mi355_hevc_pred_job {
 } mi355_hevc_pred_job;
 int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int n, int bit_depth, void *stream);
 
+/* a14 + a15 fused: what luma_mc / chroma_mc / hevc_luma_mv_mpred's callers do per prediction block (hevcdec.c:1395-1560 and
+ * the put_unweighted_pred / weighted_pred calls that follow each MC call): interpolate the block from one or two reference
+ * pictures and turn the 14-bit result(s) straight into samples.  The intermediate stays in LDS; results are identical to
+ * mi355_hevc_mc_batch_dev followed by mi355_hevc_pred_batch_dev.  `kind`: MI355_HEVC_PRED_PUT / _W use reference 0 only,
+ * _AVG / _W_AVG combine reference 0 (weight w0, offset o0) with reference 1 (w1, o1). */
+typedef struct mi355_hevc_mcpred_job {
+    const uint8_t *src0, *src1;   /* sample (0,0) of the block in each reference picture; src1 unused for the one-reference kinds */
+    uint8_t *dst;
+    int32_t src0_stride, src1_stride, dst_stride;
+    uint8_t width, height;        /* <= 64 */
+    uint8_t chroma;               /* 0: 8-tap qpel (fractions 0..3), 1: 4-tap epel (0..7) */
+    uint8_t kind;                 /* MI355_HEVC_PRED_* */
+    uint8_t mx0, my0, mx1, my1;
+    uint8_t denom;
+    uint8_t reserved[3];
+    int16_t w0, w1, o0, o1;
+} mi355_hevc_mcpred_job;
+int mi355_hevc_mcpred_batch_dev(const mi355_hevc_mcpred_job *d_jobs, int n, int bit_depth, void *stream);
+
 /* a16: hevc_{h,v}_loop_filter_{luma,chroma} (hevcdsp.h:104-113): one 8-sample edge segment pair.
  * Jobs of one launch must not touch the same samples (all vertical edges of a picture, or all
  * horizontal ones: ff_hevc_deblocking_filter's two passes). */

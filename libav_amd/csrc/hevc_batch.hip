@@ -81,6 +81,74 @@ __global__ void __launch_bounds__(64) k_hevc_mc_batch(const mi355_hevc_mc_job *j
     hevc_mc_wave(mi355_global(j.dst), j.dst_stride / 2, mi355_global(j.src), j.src_stride / px, j.width, j.height, j.mx, j.my, bd, j.chroma ? 4 : 8, tmp);
 }
 
+/* ---- MC + prediction fused: the 14-bit intermediate never leaves the CU ------------------------------------------- */
+template <int KIND>
+struct HevcMcToSamples {      /* results (and, for the two-reference kinds, the kept tile of reference 1) -> samples */
+    uint8_t *dst; int stride, bd, amode;                     /* stride in bytes; amode: bytes of guaranteed alignment of a 4-sample segment */
+    HevcPredParams p; const int16_t *other;
+    __device__ __forceinline__ int px(int a, int r, int x) const
+    {
+        HevcPredParams q = p;
+        q.mode = KIND;                                       /* compile-time kind: hevc_pred_px's dispatch folds away */
+        return hevc_pred_px(q, a, (KIND & 1) ? other[r * HEVC_MC_KEEP_PITCH + x] : 0, bd);
+    }
+    __device__ __forceinline__ void put2(int r, int x, uint32_t v) const
+    {
+        const int v0 = px((int16_t)(v & 0xFFFF), r, x), v1 = px((int16_t)(v >> 16), r, x + 1);
+        uint8_t *d = dst + (ptrdiff_t)r * stride;
+        if (bd > 8) {
+            if (amode >= 4) reinterpret_cast<uint32_t *>(d)[x >> 1] = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            else { reinterpret_cast<uint16_t *>(d)[x] = (uint16_t)v0; reinterpret_cast<uint16_t *>(d)[x + 1] = (uint16_t)v1; }
+        } else {
+            if (amode >= 2) reinterpret_cast<uint16_t *>(d)[x >> 1] = (uint16_t)(v0 | (v1 << 8));
+            else { d[x] = (uint8_t)v0; d[x + 1] = (uint8_t)v1; }
+        }
+    }
+    __device__ __forceinline__ void put4(int r, int x0, uint32_t lo, uint32_t hi, int n) const
+    {
+        if (n >= 2) put2(r, x0, lo);
+        else if (n == 1) stpx(dst + (ptrdiff_t)r * stride, x0, px((int16_t)(lo & 0xFFFF), r, x0), bd);
+        if (n >= 4) put2(r, x0 + 2, hi);
+        else if (n == 3) stpx(dst + (ptrdiff_t)r * stride, x0 + 2, px((int16_t)(hi & 0xFFFF), r, x0 + 2), bd);
+    }
+};
+template <int TAPS, int KIND>
+__device__ inline void hevc_mcpred_taps(const mi355_hevc_mcpred_job &j, int bd, HevcMcScratch &s, int16_t *keep)
+{
+    const int px = bd > 8 ? 2 : 1;
+    constexpr int before = TAPS == 8 ? 3 : 1;
+    constexpr bool two = (KIND & 1) != 0;
+    const uint8_t *src0 = mi355_global(j.src0), *src1 = two ? mi355_global(j.src1) : nullptr;
+    uint8_t *dst = mi355_global(j.dst);
+    const unsigned al = (unsigned)(uintptr_t)dst | (unsigned)j.dst_stride;
+    const int amode = bd > 8 ? ((al & 3) == 0 ? 4 : 2) : ((al & 1) == 0 ? 2 : 1);
+    const HevcPredParams pp{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
+    for (int ty = 0; ty < j.height; ty += HEVC_MC_TILE)
+    for (int tx = 0; tx < j.width; tx += HEVC_MC_TILE) {
+        const int tw = j.width - tx < HEVC_MC_TILE ? j.width - tx : HEVC_MC_TILE, th = j.height - ty < HEVC_MC_TILE ? j.height - ty : HEVC_MC_TILE;
+        if (two) {
+            const int bx = j.mx1 ? before : 0, by = j.my1 ? before : 0;
+            hevc_mc_tile<TAPS>(HevcMcToTile{ keep }, src1 + (ptrdiff_t)(ty - by) * j.src1_stride + (ptrdiff_t)(tx - bx) * px, j.src1_stride, tw, th, j.mx1, j.my1, bd, s);
+        }
+        const int bx = j.mx0 ? before : 0, by = j.my0 ? before : 0;
+        const HevcMcToSamples<KIND> sink{ dst + (ptrdiff_t)ty * j.dst_stride + (ptrdiff_t)tx * px, j.dst_stride, bd, amode, pp, two ? keep : nullptr };
+        hevc_mc_tile<TAPS>(sink, src0 + (ptrdiff_t)(ty - by) * j.src0_stride + (ptrdiff_t)(tx - bx) * px, j.src0_stride, tw, th, j.mx0, j.my0, bd, s);
+    }
+}
+__global__ void __launch_bounds__(64) k_hevc_mcpred_batch(const mi355_hevc_mcpred_job *jobs, int n, int bd)
+{
+    __shared__ HevcMcScratch tmp;
+    __shared__ __attribute__((aligned(16))) int16_t keep[HEVC_MC_TILE * HEVC_MC_KEEP_PITCH];
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_mcpred_job j = jobs[blockIdx.x];
+    switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {
+    case 0: hevc_mcpred_taps<8, 0>(j, bd, tmp, keep); break;   case 1: hevc_mcpred_taps<8, 1>(j, bd, tmp, keep); break;
+    case 2: hevc_mcpred_taps<8, 2>(j, bd, tmp, keep); break;   case 3: hevc_mcpred_taps<8, 3>(j, bd, tmp, keep); break;
+    case 4: hevc_mcpred_taps<4, 0>(j, bd, tmp, keep); break;   case 5: hevc_mcpred_taps<4, 1>(j, bd, tmp, keep); break;
+    case 6: hevc_mcpred_taps<4, 2>(j, bd, tmp, keep); break;   default: hevc_mcpred_taps<4, 3>(j, bd, tmp, keep); break;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
@@ -197,6 +265,12 @@ extern "C" int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, i
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_mc_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_mcpred_batch_dev(const mi355_hevc_mcpred_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_mcpred_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int n, int bit_depth, void *stream)

@@ -260,12 +260,30 @@ __device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdif
         }
     }
 }
-template <int TAPS>
-__device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
-                                    int mx, int my, int bd, HevcMcScratch &s)
+/* Where the results of a tile go.  put4: four horizontally adjacent results of row r from column x0 (n of them inside
+ * the tile); put2: two from column x.  Tile-relative coordinates. */
+struct HevcMcToI16 {          /* the reference's destination: int16, `ds` elements per row */
+    int16_t *out; int ds, amode;
+    __device__ __forceinline__ void put4(int r, int x0, uint32_t lo, uint32_t hi, int n) const { hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, lo, hi, n, amode); }
+    __device__ __forceinline__ void put2(int r, int x, uint32_t v) const { hevc_mc_st2(out + (ptrdiff_t)r * ds + x, v, amode); }
+};
+constexpr int HEVC_MC_KEEP_PITCH = 32;
+struct HevcMcToTile {         /* kept in LDS for a second prediction to combine with */
+    int16_t *t;
+    __device__ __forceinline__ void put4(int r, int x0, uint32_t lo, uint32_t hi, int n) const
+    {
+        (void)n;                                             /* the tile has room for whole segments */
+        *reinterpret_cast<uint2 *>(&t[r * HEVC_MC_KEEP_PITCH + x0]) = make_uint2(lo, hi);
+    }
+    __device__ __forceinline__ void put2(int r, int x, uint32_t v) const { *reinterpret_cast<uint32_t *>(&t[r * HEVC_MC_KEEP_PITCH + x]) = v; }
+};
+
+/* one tile of at most 32x32 outputs; w0 = byte address of the first sample the taps touch, sb = bytes per source row */
+template <int TAPS, class Sink>
+__device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff_t sb, int tw, int th_, int mx, int my, int bd, HevcMcScratch &s)
 {
-    const int lane = lane_id(), px = bd > 8 ? 2 : 1;
-    constexpr int before = TAPS == 8 ? 3 : 1, extra = TAPS - 1;
+    const int lane = lane_id();
+    constexpr int extra = TAPS - 1;
     const int8_t *fh = TAPS == 8 ? k_qpel[mx] : k_epel[mx], *fv = TAPS == 8 ? k_qpel[my] : k_epel[my];
     uint32_t th[TAPS / 2], tv[TAPS / 2];
 #pragma unroll
@@ -273,70 +291,78 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
         th[k] = (uint32_t)(uint16_t)(int16_t)fh[2 * k] | ((uint32_t)(uint16_t)(int16_t)fh[2 * k + 1] << 16);
         tv[k] = (uint32_t)(uint16_t)(int16_t)fv[2 * k] | ((uint32_t)(uint16_t)(int16_t)fv[2 * k + 1] << 16);
     }
+    const int rows = th_ + (my ? extra : 0);
+    hevc_mc_stage(s, w0, sb, rows, tw + (mx ? extra : 0), bd);
+    __syncthreads();
+    const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
+    if (!mx && !my) {
+        /* put_hevc_*_pixels: sample << (14 - bd); two values per dword shift together (no carry across) */
+        for (int i = lane; i < rows * wseg; i += 64) {
+            const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
+            sink.put4(r, x0, d[0] << (14 - bd), d[1] << (14 - bd), tw - x0);
+        }
+    }
+    if (mx) {
+        /* horizontal pass over `rows` lines, four outputs per lane */
+        for (int i = lane; i < rows * wseg; i += 64) {
+            const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
+            uint32_t dd[6];
+#pragma unroll
+            for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
+            int o[4];
+            fir4<TAPS>(dd, th, o);
+            const uint32_t lo = pack16(o[0] >> (bd - 8), o[1] >> (bd - 8)), hi = pack16(o[2] >> (bd - 8), o[3] >> (bd - 8));
+            if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_PITCH + x0]) = make_uint2(lo, hi);
+            else sink.put4(r, x0, lo, hi, tw - x0);
+        }
+        if (my) __syncthreads();
+    }
+    if (my) {
+        /* vertical pass: lane = (column pair, eight output rows) */
+        const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
+        const int vshift = mx ? 6 : bd - 8;
+        const int cp = tw >> 1, cinv = mi355_inv20(cp), oct = (th_ + 7) >> 3;
+        for (int i = lane; i < cp * oct; i += 64) {
+            const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = 8 * q;
+            const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
+            int a0[8], a1[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) a0[y] = a1[y] = 0;
+            uint32_t prev = d[0];
+#pragma unroll
+            for (int r = 0; r < 8 + TAPS - 2; r++) {
+                const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
+                const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
+                prev = cur;
+#pragma unroll
+                for (int k = 0; k < TAPS / 2; k++) {
+                    const int y = r - 2 * k;
+                    if (y >= 0 && y < 8) { a0[y] = mi355_dot2(p0, tv[k], a0[y]); a1[y] = mi355_dot2(p1, tv[k], a1[y]); }
+                }
+            }
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                if (y0 + y < th_) sink.put2(y0 + y, 2 * c2, pack16(a0[y] >> vshift, a1[y] >> vshift));
+        }
+    }
+    __syncthreads();
+}
+template <int TAPS>
+__device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
+                                    int mx, int my, int bd, HevcMcScratch &s)
+{
+    const int px = bd > 8 ? 2 : 1;
+    constexpr int before = TAPS == 8 ? 3 : 1;
     const int bx = mx ? before : 0, by = my ? before : 0;
     const int amode = hevc_mc_align(dst, ds);
     const ptrdiff_t sb = (ptrdiff_t)ss * px;
     for (int ty = 0; ty < height; ty += HEVC_MC_TILE)
     for (int tx = 0; tx < width; tx += HEVC_MC_TILE) {
         const int tw = width - tx < HEVC_MC_TILE ? width - tx : HEVC_MC_TILE, th_ = height - ty < HEVC_MC_TILE ? height - ty : HEVC_MC_TILE;
-        const int rows = th_ + (my ? extra : 0);
-        int16_t *out = dst + (ptrdiff_t)ty * ds + tx;
-        hevc_mc_stage(s, src + (ptrdiff_t)(ty - by) * sb + (ptrdiff_t)(tx - bx) * px, sb, rows, tw + (mx ? extra : 0), bd);
-        __syncthreads();
-        const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
-        if (!mx && !my) {
-            /* put_hevc_*_pixels: sample << (14 - bd); two values per dword shift together (no carry across) */
-            for (int i = lane; i < rows * wseg; i += 64) {
-                const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
-                const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
-                hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, d[0] << (14 - bd), d[1] << (14 - bd), tw - x0, amode);
-            }
-        }
-        if (mx) {
-            /* horizontal pass over `rows` lines, four outputs per lane */
-            for (int i = lane; i < rows * wseg; i += 64) {
-                const int r = mi355_div20(i, winv), x0 = 4 * (i - r * wseg);
-                const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[r * HEVC_MC_PITCH + x0]);
-                uint32_t dd[6];
-#pragma unroll
-                for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
-                int o[4];
-                fir4<TAPS>(dd, th, o);
-                const uint32_t lo = pack16(o[0] >> (bd - 8), o[1] >> (bd - 8)), hi = pack16(o[2] >> (bd - 8), o[3] >> (bd - 8));
-                if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_PITCH + x0]) = make_uint2(lo, hi);
-                else hevc_mc_st4(out + (ptrdiff_t)r * ds + x0, lo, hi, tw - x0, amode);
-            }
-            if (my) __syncthreads();
-        }
-        if (my) {
-            /* vertical pass: lane = (column pair, eight output rows) */
-            const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
-            const int vshift = mx ? 6 : bd - 8;
-            const int cp = tw >> 1, cinv = mi355_inv20(cp), oct = (th_ + 7) >> 3;
-            for (int i = lane; i < cp * oct; i += 64) {
-                const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = 8 * q;
-                const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
-                int a0[8], a1[8];
-#pragma unroll
-                for (int y = 0; y < 8; y++) a0[y] = a1[y] = 0;
-                uint32_t prev = d[0];
-#pragma unroll
-                for (int r = 0; r < 8 + TAPS - 2; r++) {
-                    const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
-                    const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
-                    prev = cur;
-#pragma unroll
-                    for (int k = 0; k < TAPS / 2; k++) {
-                        const int y = r - 2 * k;
-                        if (y >= 0 && y < 8) { a0[y] = mi355_dot2(p0, tv[k], a0[y]); a1[y] = mi355_dot2(p1, tv[k], a1[y]); }
-                    }
-                }
-#pragma unroll
-                for (int y = 0; y < 8; y++)
-                    if (y0 + y < th_) hevc_mc_st2(out + (ptrdiff_t)(y0 + y) * ds + 2 * c2, pack16(a0[y] >> vshift, a1[y] >> vshift), amode);
-            }
-        }
-        __syncthreads();
+        const HevcMcToI16 sink{ dst + (ptrdiff_t)ty * ds + tx, ds, amode };
+        hevc_mc_tile<TAPS>(sink, src + (ptrdiff_t)(ty - by) * sb + (ptrdiff_t)(tx - bx) * px, sb, tw, th_, mx, my, bd, s);
     }
 }
 __device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,

@@ -43,6 +43,13 @@ class SaoJob(C.Structure):
 assert C.sizeof(LfJob) == 32
 
 
+class McPredJob(C.Structure):
+    _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("dst", C.c_void_p), ("src0_stride", C.c_int32), ("src1_stride", C.c_int32),
+                ("dst_stride", C.c_int32), ("width", C.c_uint8), ("height", C.c_uint8), ("chroma", C.c_uint8), ("kind", C.c_uint8),
+                ("mx0", C.c_uint8), ("my0", C.c_uint8), ("mx1", C.c_uint8), ("my1", C.c_uint8), ("denom", C.c_uint8),
+                ("reserved", C.c_uint8 * 3), ("w0", C.c_int16), ("w1", C.c_int16), ("o0", C.c_int16), ("o1", C.c_int16)]
+
+
 class IntraJob(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("top", C.c_void_p), ("left", C.c_void_p), ("stride", C.c_int32), ("log2_size", C.c_uint8),
                 ("kind", C.c_uint8), ("c_idx", C.c_uint8), ("mode", C.c_uint8)]
@@ -347,6 +354,63 @@ def check_sao(prov, oracle, bd, seed, cells=(3, 4)):
     return len(jobs)
 
 
+def check_mcpred(prov, oracle, bd, seed, cells=(4, 6)):
+    """fused MC + prediction vs the oracle's put_hevc_qpel/epel followed by its (un)weighted prediction functions"""
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    ref0, ref1 = pixels(r, (200, 320), bd), pixels(r, (200, 320), bd)
+    pic = pixels(r, (cy * 64, cx * 64), bd)
+    rstride, stride = ref0.strides[0], pic.strides[0]
+    n = cy * cx
+    meta = []
+    for k in range(n):
+        chroma = r.randint(0, 1)
+        wi = r.randint(0, 7)
+        w = (EW if chroma else QW)[wi]
+        h = [2, 4, 8, 16, 32, 64][r.randint(0, 5)]
+        fmax = 7 if chroma else 3
+        frac = [r.randint(0, fmax) if r.randint(0, 3) else 0 for _ in range(4)]
+        pos = [(r.randint(8, 200 - 64 - 8), r.randint(8, 320 - 64 - 8)) for _ in range(2)]
+        meta.append((chroma, wi, w, h, r.randint(0, 3), r.randint(0, 7), r.randint(-128, 127), r.randint(-128, 127),
+                     r.randint(-128, 127), r.randint(-128, 127), frac, pos, (k // cx) * 64, (k % cx) * 64))
+    c_o = oracle.hevcdsp(bd)
+    pic_o = pic.copy()
+    mcbuf = np.zeros((64 + 24) * 64, np.int16)
+    t0, t1 = np.zeros(64 * 64, np.int16), np.zeros(64 * 64, np.int16)
+    for chroma, wi, w, h, kind, denom, w0, w1, o0, o1, frac, pos, y0, x0 in meta:
+        tab = c_o.put_hevc_epel if chroma else c_o.put_hevc_qpel
+        for t, ref, (sy, sx), (mx, my) in ((t0, ref0, pos[0], frac[0:2]), (t1, ref1, pos[1], frac[2:4])):
+            tab[int(my != 0)][int(mx != 0)][wi](_i16p(t), 128, _u8p(ref, sy * rstride + sx * px), rstride, h, mx, my, _i16p(mcbuf))
+        dp = _u8p(pic_o, y0 * stride + x0 * px)
+        tabs = ((c_o.put_unweighted_pred_chroma, c_o.put_unweighted_pred_avg_chroma, c_o.weighted_pred_chroma, c_o.weighted_pred_avg_chroma)
+                if chroma else (c_o.put_unweighted_pred, c_o.put_unweighted_pred_avg, c_o.weighted_pred, c_o.weighted_pred_avg))
+        fn = tabs[kind][wi]
+        if kind == 0:
+            fn(dp, stride, _i16p(t0), 128, h)
+        elif kind == 1:
+            fn(dp, stride, _i16p(t0), _i16p(t1), 128, h)
+        elif kind == 2:
+            fn(denom, w0, o0, dp, stride, _i16p(t0), 128, h)
+        else:
+            fn(denom, w0, w1, o0, o1, dp, stride, _i16p(t0), _i16p(t1), 128, h)
+    d = Dev(prov.lib)
+    try:
+        p_pic, p0, p1 = d.up(pic), d.up(ref0), d.up(ref1)
+        jobs = []
+        for chroma, wi, w, h, kind, denom, w0, w1, o0, o1, frac, pos, y0, x0 in meta:
+            j = McPredJob(p0 + pos[0][0] * rstride + pos[0][1] * px, p1 + pos[1][0] * rstride + pos[1][1] * px, p_pic + y0 * stride + x0 * px,
+                          rstride, rstride, stride, w, h, chroma, kind, frac[0], frac[1], frac[2], frac[3], denom)
+            j.w0, j.w1, j.o0, j.o1 = w0, w1, o0, o1
+            jobs.append(j)
+        assert prov.lib.mi355_hevc_mcpred_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
+        pic_g = d.down(p_pic, pic)
+    finally:
+        d.free()
+    assert np.array_equal(pic_g, pic_o), "fused mc + pred batch differs (bd %d)" % bd
+    return n
+
+
 def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
     """pred_planar / pred_dc / pred_angular of independent blocks, neighbour arrays in a device edge buffer"""
     r = SplitMix64(seed)
@@ -386,4 +450,4 @@ def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
 
 
 CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
-          "intra": check_intra}
+          "intra": check_intra, "mcpred": check_mcpred}
