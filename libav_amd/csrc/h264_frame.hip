@@ -313,8 +313,9 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     residual_chroma<true>(s, s.pc[0], s.pc[1], 8);
     PROF_MARK(11);
 #endif
-    /* (a strip variant — four adjacent macroblocks per wave, 64-byte row stores, next macroblock's loads
-     * in flight — measured 7 % slower: the kernel is bound by instruction issue, not by L1 requests) */
+    /* (several macroblocks per wave with the next one's record, vectors and coefficients in flight: two per wave,
+     * unrolled, measured -2.7 %, four +2.7 %, as a real loop +3 % and more — the kernel is bound by instruction issue,
+     * not by the latency of a wave; an earlier strip variant with 64-byte row stores was 7 % slower) */
     store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
     PROF_MARK(12);
 }
