@@ -518,7 +518,7 @@ void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int ch
         c->h264_h_loop_filter_chroma_mbaff_intra = t1_h_lf_chroma_mbaff_intra;
         c->h264_idct_add8 = t1_idct_add8;
         c->h264_chroma_dc_dequant_idct = t1_chroma_dc_dequant_idct;
-    } else if (chroma_format_idc == 2) {
+    } else {   /* 4:2:2, and 4:4:4 like the reference (h264dsp.c:80-130: every idc > 1 gets the 4:2:2 forms; 4:4:4 decoding does not call them) */
         c->h264_h_loop_filter_chroma = t1_h_lf_chroma422;
         c->h264_h_loop_filter_chroma_mbaff = t1_h_lf_chroma422_mbaff;
         c->h264_h_loop_filter_chroma_intra = t1_h_lf_chroma422_intra;
@@ -722,7 +722,7 @@ template <int HZ> static void pred8x16_add_shim(uint8_t *pix, const int *block_o
 
 void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
 {
-    if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264 || chroma_format_idc > 2) return;
+    if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264) return;   /* idc > 1: the 8x16 forms, as h264pred.c:470-565 selects them */
     h->pred4x4[0] = p4_shim<0>; h->pred4x4[1] = p4_shim<1>; h->pred4x4[2] = p4_shim<2>; h->pred4x4[3] = p4_shim<3>;
     h->pred4x4[4] = p4_shim<4>; h->pred4x4[5] = p4_shim<5>; h->pred4x4[6] = p4_shim<6>; h->pred4x4[7] = p4_shim<7>;
     h->pred4x4[8] = p4_shim<8>; h->pred4x4[9] = p4_shim<9>; h->pred4x4[10] = p4_shim<10>; h->pred4x4[11] = p4_shim<11>;

@@ -20,42 +20,45 @@
 #include "libavcodec/videodsp.h"
 #include "../include/mi355dsp.h"      /* the table structs are skipped: the reference's headers came first */
 
+#include "libavutil/pixdesc.h"
+
 extern AVCodec ff_h264_decoder;
 static unsigned long n_hooks;
+static int plain;     /* MI355_TIER1_PLAIN=1: leave the tables as the reference filled them (the comparison run) */
 
 void __real_ff_h264dsp_init(H264DSPContext *c, const int bit_depth, const int chroma_format_idc);
 void __wrap_ff_h264dsp_init(H264DSPContext *c, const int bit_depth, const int chroma_format_idc)
 {
     __real_ff_h264dsp_init(c, bit_depth, chroma_format_idc);
-    ff_h264dsp_init_mi355x(c, bit_depth, chroma_format_idc);
+    if (!plain) ff_h264dsp_init_mi355x(c, bit_depth, chroma_format_idc);
     n_hooks++;
 }
 void __real_ff_h264qpel_init(H264QpelContext *c, int bit_depth);
 void __wrap_ff_h264qpel_init(H264QpelContext *c, int bit_depth)
 {
     __real_ff_h264qpel_init(c, bit_depth);
-    ff_h264qpel_init_mi355x(c, bit_depth);
+    if (!plain) ff_h264qpel_init_mi355x(c, bit_depth);
     n_hooks++;
 }
 void __real_ff_h264chroma_init(H264ChromaContext *c, int bit_depth);
 void __wrap_ff_h264chroma_init(H264ChromaContext *c, int bit_depth)
 {
     __real_ff_h264chroma_init(c, bit_depth);
-    ff_h264chroma_init_mi355x(c, bit_depth);
+    if (!plain) ff_h264chroma_init_mi355x(c, bit_depth);
     n_hooks++;
 }
 void __real_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc);
 void __wrap_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
 {
     __real_ff_h264_pred_init(h, codec_id, bit_depth, chroma_format_idc);
-    ff_h264_pred_init_mi355x(h, codec_id, bit_depth, chroma_format_idc);
+    if (!plain) ff_h264_pred_init_mi355x(h, codec_id, bit_depth, chroma_format_idc);
     n_hooks++;
 }
 void __real_ff_videodsp_init(VideoDSPContext *ctx, int bpc);
 void __wrap_ff_videodsp_init(VideoDSPContext *ctx, int bpc)
 {
     __real_ff_videodsp_init(ctx, bpc);
-    ff_videodsp_init_mi355x(ctx, bpc);
+    if (!plain) ff_videodsp_init_mi355x(ctx, bpc);
     n_hooks++;
 }
 
@@ -64,7 +67,8 @@ static uint32_t get_u32(FILE *f) { uint32_t v = 0; if (fread(&v, 4, 1, f) != 1) 
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: %s in.samples out.yuv\n", argv[0]); return 1; }
-    if (mi355_init(0) != 0) { fprintf(stderr, "mi355_init failed\n"); return 2; }
+    plain = getenv("MI355_TIER1_PLAIN") != NULL;
+    if (!plain && mi355_init(0) != 0) { fprintf(stderr, "mi355_init failed\n"); return 2; }
     FILE *in = fopen(argv[1], "rb"), *out = fopen(argv[2], "wb");
     if (!in || !out) return 1;
     AVCodecContext *c = avcodec_alloc_context3(&ff_h264_decoder);
@@ -90,7 +94,8 @@ int main(int argc, char **argv)
         if (avcodec_send_packet(c, i < n ? &pkt : NULL) < 0) { fprintf(stderr, "send_packet failed\n"); return 7; }
         while (avcodec_receive_frame(c, fr) >= 0) {
             for (int pl = 0; pl < 3; pl++) {
-                const int w = pl ? fr->width / 2 : fr->width, h = pl ? fr->height / 2 : fr->height;
+                const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fr->format);
+                const int w = pl ? fr->width >> d->log2_chroma_w : fr->width, h = pl ? fr->height >> d->log2_chroma_h : fr->height;
                 for (int y = 0; y < h; y++) fwrite(fr->data[pl] + (size_t)y * fr->linesize[pl], 1, w, out);
             }
             shown++;

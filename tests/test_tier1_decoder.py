@@ -41,3 +41,37 @@ def test_reference_decoder_through_tier1_hooks(tmp_path, emu):
         fr = raw[i * fsz:(i + 1) * fsz]
         want = np.concatenate([pics[i][k].reshape(-1) for k in ("y", "cb", "cr")])
         assert np.array_equal(fr, want), "picture %d differs from the reference decoder's" % i
+
+
+CLIP444 = "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/cockatoo.mp4"
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP444)),
+                    reason="needs /root/reference and the sample clip")
+def test_reference_decoder_444_clip_through_tier1_hooks(tmp_path, emu):
+    """High 4:4:4 Predictive 1280x720 (SURVEY.md §8c's second offline clip): the 4:4:4 decode path calls the luma
+    entries for all three planes.  First pictures only (the emulator is slow); hooked vs plain run of the same binary."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mp4_samples
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/h264_tier1_emu"], check=True)
+    avcc, samples = mp4_samples.extract(CLIP444)
+    n = 5
+    src = tmp_path / "s"
+    with open(src, "wb") as f:
+        f.write(struct.pack("<I", len(avcc)) + avcc + struct.pack("<I", n))
+        for s in samples[:n]:
+            f.write(struct.pack("<I", len(s)) + s)
+    exe = os.path.join(ROOT, "oracle", "_ref", "h264_tier1_emu")
+    outs = []
+    for plain in (True, False):
+        out = tmp_path / ("plain.yuv" if plain else "hooked.yuv")
+        env = dict(os.environ)
+        if plain:
+            env["MI355_TIER1_PLAIN"] = "1"
+        else:
+            env.pop("MI355_TIER1_PLAIN", None)
+        r = subprocess.run([exe, str(src), str(out)], capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.fromfile(out, np.uint8))
+    assert outs[0].size == outs[1].size and outs[0].size >= 1280 * 720 * 3, (outs[0].size, outs[1].size)
+    assert np.array_equal(outs[0], outs[1]), "4:4:4 pictures differ: %d samples" % int((outs[0] != outs[1]).sum())
