@@ -34,6 +34,8 @@ typedef struct mi355_hevc_tu_job {
     uint8_t kind;             /* MI355_HEVC_TU_* */
     uint8_t reserved;
 } mi355_hevc_tu_job;
+/* Two consecutive jobs share a wavefront: lists binned by (log2_size, kind, col_limit <= size / 2) run fastest (both
+ * halves then take the same — pruned or full — transform path); any order is correct. */
 int mi355_hevc_residual_batch_dev(const mi355_hevc_tu_job *d_jobs, int n, int bit_depth, void *stream);
 
 /* a14: put_hevc_qpel / put_hevc_epel (hevcdsp.h:64-69): width x height samples at `src` (fractions mx,my)

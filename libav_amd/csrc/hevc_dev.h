@@ -51,25 +51,28 @@ __device__ __forceinline__ bool dct_row_used(int H, int j, int end)
  * odd inputs through an (H/2 x H/2) block of the matrix and E is the H/2-point transform of the even
  * inputs.  Sums are exact integers, so the grouping does not change the result.  `x` holds the H inputs
  * of THIS size's transform (row j of size H = row j * 32/H of the 32-point matrix); S = 32 / H. */
-template <int H, int S> struct Idct1D {
+/* END < H: the pruned form of the reference's TR_32 / TR_16 (`end` argument): the odd-part sums of the 32- and 16-point
+ * levels stop at input END; the 8-point transform of the rows that feed it is always complete, exactly as there. */
+template <int H, int S, int END = H> struct Idct1D {
     static __device__ __forceinline__ void run(const int *x, int *out)
     {
         int xe[H / 2], E[H / 2], O[H / 2];
 #pragma unroll
         for (int k = 0; k < H / 2; k++) xe[k] = x[2 * k];
-        Idct1D<H / 2, 2 * S>::run(xe, E);
+        Idct1D<H / 2, 2 * S, (H / 2 <= 8 ? H / 2 : (END + 1) / 2)>::run(xe, E);
 #pragma unroll
         for (int n = 0; n < H / 2; n++) {
             int o = 0;
 #pragma unroll
-            for (int k = 0; k < H / 2; k++) o += dct_coef((2 * k + 1) * S, n) * x[2 * k + 1];
+            for (int k = 0; k < H / 2; k++)
+                if (2 * k + 1 < END) o += dct_coef((2 * k + 1) * S, n) * x[2 * k + 1];
             O[n] = o;
         }
 #pragma unroll
         for (int n = 0; n < H / 2; n++) { out[n] = E[n] + O[n]; out[H - 1 - n] = E[n] - O[n]; }
     }
 };
-template <int S> struct Idct1D<2, S> {
+template <int S, int END> struct Idct1D<2, S, END> {
     static __device__ __forceinline__ void run(const int *x, int *out)
     {
         out[0] = 64 * x[0] + dct_coef(S, 0) * x[1];
@@ -94,18 +97,31 @@ __device__ inline void hevc_idct_half(int16_t *c, int hl, bool active, int col_l
     if (active && hl < H) {
         const int i = hl;
         const int end = l0 < H ? l0 - 4 * (i > 0 ? (i - 1) >> 2 : 0) : H;
+        /* l0 (>= every lane's `end`) in the lower half: the instantiation without the upper half's inputs and products */
+        if (H >= 16 && l0 <= H / 2) {
 #pragma unroll
-        for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, end) ? c[i + H * j] : 0;
-        Idct1D<H, 32 / H>::run(in, out);
+            for (int j = 0; j < H; j++) in[j] = (j < H / 2 || (j * (32 / H)) % 4 == 0) && dct_row_used(H, j, end) ? c[i + H * j] : 0;
+            Idct1D<H, 32 / H, (H >= 16 ? H / 2 : H)>::run(in, out);
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, end) ? c[i + H * j] : 0;
+            Idct1D<H, 32 / H>::run(in, out);
+        }
 #pragma unroll
         for (int n = 0; n < H; n++) c[i + H * n] = (int16_t)clip_i16((out[n] + 64) >> 7);
     }
     __syncthreads();
     if (active && hl < H) {
         const int i = hl, shift = 20 - bd, add = 1 << (shift - 1);
+        if (H >= 16 && limit <= H / 2) {
 #pragma unroll
-        for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, limit) ? c[H * i + j] : 0;
-        Idct1D<H, 32 / H>::run(in, out);
+            for (int j = 0; j < H; j++) in[j] = (j < H / 2 || (j * (32 / H)) % 4 == 0) && dct_row_used(H, j, limit) ? c[H * i + j] : 0;
+            Idct1D<H, 32 / H, (H >= 16 ? H / 2 : H)>::run(in, out);
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; j++) in[j] = dct_row_used(H, j, limit) ? c[H * i + j] : 0;
+            Idct1D<H, 32 / H>::run(in, out);
+        }
 #pragma unroll
         for (int n = 0; n < H; n++) c[H * i + n] = (int16_t)clip_i16((out[n] + add) >> shift);
     }

@@ -81,6 +81,9 @@ def main():
                                         12 if sparse[k] else 32, 0, 0))
                     k += 1
     assert k == n_tu
+    # two transform units share a wave: a bridge bins its job list by (size, col_limit class) so that both halves take the
+    # same (pruned or full) path; the jobs are independent, their order is the caller's choice
+    tus.sort(key=lambda j: j.col_limit)
     p_tus = d.up_jobs(tus)
     timed("idct32 + add_residual", lambda: lib.mi355_hevc_residual_batch_dev(C.c_void_p(p_tus), n_tu, BD, None), n_tu, 2048 + 2048 + 2048)
 
