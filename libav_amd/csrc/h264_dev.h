@@ -100,33 +100,50 @@ template <int MAXIT>
 struct WinLoad {
     uint32_t lo[MAXIT], hi[MAXIT];
     uint32_t shift;
+    bool whole;              /* loaded by the unpredicated path: commit() may write from every lane */
     __device__ __forceinline__ void issue(const PlaneRef &ref, int x0, int y0, int ndw, int wh, bool inside, int lane)
     {
         shift = (uint32_t)x0 & 3;
         const int xa = x0 & ~3, sh = ndw > 4 ? 3 : 2, dw = lane & ((1 << sh) - 1), r0 = lane >> sh;
-        const uint8_t *base = ref.base + (ptrdiff_t)(y0 + r0) * ref.stride + xa + 4 * dw;
-        const ptrdiff_t step = (ptrdiff_t)(64 >> sh) * ref.stride;
+        whole = inside;
+        if (inside) {
+            /* no lane is switched off: lanes past the window's last row / dword repeat the last one (same address, same
+             * value, same LDS slot in commit()) — a v_min instead of an exec-mask sequence per access */
+            const int dwc = dw < ndw ? dw : ndw - 1;
+            const uint8_t *base = ref.base + (ptrdiff_t)y0 * ref.stride + xa + 4 * dwc;
+#pragma unroll
+            for (int k = 0; k < MAXIT; k++) {
+                const int row = r0 + k * (64 >> sh), rc = row < wh ? row : wh - 1;
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)rc * ref.stride);
+                lo[k] = p[0];
+                hi[k] = p[1];
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
             const int row = r0 + k * (64 >> sh);
             lo[k] = hi[k] = 0;
             if (row >= wh || dw >= ndw) continue;
-            if (inside) {
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + k * step);
-                lo[k] = p[0];
-                hi[k] = p[1];
-            } else {
-                uint32_t w = 0;
+            uint32_t w = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++) w |= (uint32_t)px_clamped(ref, x0 + 4 * dw + b, y0 + row) << (8 * b);
-                lo[k] = w;
-            }
+            for (int b = 0; b < 4; b++) w |= (uint32_t)px_clamped(ref, x0 + 4 * dw + b, y0 + row) << (8 * b);
+            lo[k] = w;
         }
-        if (!inside) shift = 0;
+        shift = 0;
     }
     __device__ __forceinline__ void commit(uint32_t *win, int pitch_dw, int ndw, int wh, int lane) const
     {
         const int sh = ndw > 4 ? 3 : 2, dw = lane & ((1 << sh) - 1), r0 = lane >> sh;
+        if (whole) {
+            const int dwc = dw < ndw ? dw : ndw - 1;
+#pragma unroll
+            for (int k = 0; k < MAXIT; k++) {
+                const int row = r0 + k * (64 >> sh), rc = row < wh ? row : wh - 1;
+                win[rc * pitch_dw + dwc] = mi355_alignbyte(hi[k], lo[k], shift);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < MAXIT; k++) {
             const int row = r0 + k * (64 >> sh);
