@@ -158,11 +158,16 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
     const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
 #define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
     const int kind = (t & MI355_MB_16x16) ? 0 : ((t & MI355_MB_16x8) ? 1 : ((t & MI355_MB_8x16) ? 2 : 3));
-    const int nparts = kind == 0 ? 1 : (kind == 3 ? 16 : 2);
+    if (kind == 0) {
+        /* the common shape gets its own copy of the (inlined) motion code: block size and position are literals there,
+         * so tile loops have one iteration, window sizes are constants and the small-block branches disappear */
+        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, DIRF(0, 0), DIRF(0, 1));
+        return;
+    }
+    const int nparts = kind == 3 ? 16 : 2;
     for (int p = 0; p < nparts; p++) {
         int n, quad, bx, by, w, h, l0, l1;
-        if (kind == 0) { n = 0; quad = 0; bx = 0; by = 0; w = 16; h = 16; l0 = DIRF(0, 0); l1 = DIRF(0, 1); }
-        else if (kind == 1) { n = 8 * p; quad = 2 * p; bx = 0; by = 8 * p; w = 16; h = 8; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
+        if (kind == 1) { n = 8 * p; quad = 2 * p; bx = 0; by = 8 * p; w = 16; h = 8; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
         else if (kind == 2) { n = 2 * p; quad = p; bx = 8 * p; by = 0; w = 8; h = 16; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
         else {
             const int i = p >> 2, j = p & 3;
