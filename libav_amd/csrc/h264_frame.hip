@@ -161,7 +161,15 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
     if (kind == 0) {
         /* the common shape gets its own copy of the (inlined) motion code: block size and position are literals there,
          * so tile loops have one iteration, window sizes are constants and the small-block branches disappear */
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, DIRF(0, 0), DIRF(0, 1));
+        const int l0 = DIRF(0, 0), l1 = DIRF(0, 1);
+#ifndef MI355_NO_P16
+        if (l0 && !l1 && !(uniform(s.hdr.flags) & MI355_MBF_WEIGHTED)) {
+            /* ... and the plain P_16x16 / P_Skip macroblock goes straight to one list-0 prediction written in place */
+            mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
+            return;
+        }
+#endif
+        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
         return;
     }
     const int nparts = kind == 3 ? 16 : 2;
