@@ -826,6 +826,13 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
         const bool has_l = valid && mb_x > 0;
         const DeblockPre cur = pre;
+        /* ---- this step's records and vectors -> LDS, FIRST: the wait for them is a wait for everything in flight (the
+         * loads are predicated, the compiler cannot count them), so it must come before this step issues any load — the
+         * chunk loads and the next step's prefetch below then have a whole step to arrive ------------------------------ */
+        reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
+        reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
+        s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
+        if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
         /* ---- chunk turnover ---------------------------------------------------------------------- */
         if (j == 1 && ck >= 1) {                             /* the previous chunk got its last left-edge patch in step t-1 */
             flush_chunk(ck - 1);
@@ -838,12 +845,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         a.advance();
         deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l);
         PROF_MARK(14);
-        /* ---- phase B: records and vectors -> LDS; rows above from the group above ------------------ */
-        reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
-        reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
-        s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
-        if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
-        MI355_WAVE_SYNC();                                   /* also: the chunk load above is visible */
+        /* ---- phase B: rows above from the group above --------------------------------------------------- */
+        MI355_WAVE_SYNC();                                   /* records, vectors and the chunk committed above are visible */
         PROF_MARK(15);
         if (g > 0 && valid) {
             /* macroblock x of the row above sits at position (t-2) % DCH of that group's chunk (t-2) / DCH */
@@ -884,8 +887,19 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const uint32_t bsc0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]), bsc1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
         const int qpc_h = h.qpc(cp);
         /* chroma QP of a neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
-        const int qpc_l = hl.slice_id() == h.slice_id() ? hl.qpc(cp) : (have_left ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0);
-        const int qpc_t = ht.slice_id() == h.slice_id() ? ht.qpc(cp) : (have_top ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0);
+        /* (the table fetch — neighbour in another slice — is consumed inside its branch: a wait for it after the join would
+         * be a wait for everything in flight, i.e. for the prefetch issued a moment ago, in every step) */
+        int qpc_l = hl.qpc(cp), qpc_t = ht.qpc(cp);
+        if (hl.slice_id() != h.slice_id()) {
+            int v = have_left ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0;
+            MI355_PIN(v);
+            qpc_l = v;
+        }
+        if (ht.slice_id() != h.slice_id()) {
+            int v = have_top ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0;
+            MI355_PIN(v);
+            qpc_t = v;
+        }
         EdgeParm ev[4], eh[4], cv[2], ch[2];
         {
             /* alpha / beta depend on the edge's QP only: six distinct QPs per lane (luma and chroma: inner
