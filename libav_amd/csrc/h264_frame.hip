@@ -52,6 +52,10 @@ __device__ __forceinline__ int blk_index(int x4, int y4) { return (x4 & 1) + 2 *
 struct MbLoad {
     uint32_t hw, mw, c0, c1, c2;
 };
+/* Every lane loads something valid, nothing is predicated: lanes 0..15 the record, 16..31 / 32..47 the list-0 / list-1
+ * vectors (a missing list reads the record instead and is zeroed in commit), the rest repeat the record — with loads
+ * under lane conditions the compiler merged each result with its zero default before issuing the next load, i.e. the wave
+ * paid the record's memory latency and then the coefficients' again. */
 __device__ __forceinline__ void load_mb_issue(MbLoad &r, const mi355_h264_frame &fr, int mb_xy, bool with_coefs, bool ok)
 {
     const int lane = lane_id();
@@ -59,16 +63,18 @@ __device__ __forceinline__ void load_mb_issue(MbLoad &r, const mi355_h264_frame 
     if (!ok) return;
     const uint32_t *hp = reinterpret_cast<const uint32_t *>(&mi355_global(fr.mb)[mb_xy]);
     const uint32_t *cp = reinterpret_cast<const uint32_t *>(mi355_global(fr.coef) + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-    if (lane < 16) r.hw = hp[lane];
-    else if (lane < 32) { if (fr.mv[0]) r.mw = reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[0]))[(size_t)mb_xy * 16 + lane - 16]; }
-    else if (lane < 48) { if (fr.mv[1]) r.mw = reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[1]))[(size_t)mb_xy * 16 + lane - 32]; }
+    const uint32_t *m0 = fr.mv[0] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[0])) + (size_t)mb_xy * 16 : hp;
+    const uint32_t *m1 = fr.mv[1] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[1])) + (size_t)mb_xy * 16 : hp;
+    r.hw = hp[lane & 15];
+    r.mw = (lane & 32 ? m1 : m0)[lane & 15];
     if (with_coefs) { r.c0 = cp[lane]; r.c1 = cp[lane + 64]; r.c2 = cp[lane + 128]; }
+    MI355_ISSUE_FENCE();      /* keep the five loads here: the compiler otherwise sinks each one into the branch of commit() that uses it */
 }
-__device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool with_coefs)
+__device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool with_coefs, bool has0, bool has1)
 {
     const int lane = lane_id();
     if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = r.hw;
-    else if (lane < 48) s.mv[(lane >> 4) - 1][lane & 15] = r.mw;
+    else if (lane < 48) s.mv[(lane >> 4) - 1][lane & 15] = (lane & 32 ? has1 : has0) ? r.mw : 0u;
     if (with_coefs) {
         uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
         dst[lane] = r.c0; dst[lane + 64] = r.c1; dst[lane + 128] = r.c2;
@@ -79,7 +85,7 @@ __device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, 
 {
     MbLoad r;
     load_mb_issue(r, fr, mb_xy, with_coefs, true);
-    load_mb_commit(s, r, with_coefs);
+    load_mb_commit(s, r, with_coefs, fr.mv[0] != nullptr, fr.mv[1] != nullptr);
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */

@@ -63,6 +63,12 @@ __device__ __forceinline__ int mi355_inv20(int n)
 }
 __device__ __forceinline__ int mi355_div20(int i, int inv) { return (int)(__umul24((unsigned)i, (unsigned)inv) >> 20); }
 
+/* compiler-only fence: memory operations are not moved across it (no instruction is emitted, nothing is waited for) */
+#if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
+#define MI355_ISSUE_FENCE() ((void)0)
+#else
+#define MI355_ISSUE_FENCE() asm volatile("" ::: "memory")
+#endif
 /* make a just-loaded value "used" at this point, so that the wait for it is placed here and not at a later join */
 #if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
 #define MI355_PIN(v) ((void)(v))
