@@ -367,29 +367,38 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     if (k >= count) return;
     const int mb_xy = (int)mi355_global(fr.intra_list)[first + k];
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
-    load_mb(s.mb, fr, mb_xy, true);
-    const mi355_h264_mb &h = s.mb.hdr;
-    const uint32_t t = h.mb_type;
+    /* Everything this macroblock reads from memory is requested at once — record, vectors, coefficients and the edge
+     * samples of the unfiltered neighbours (which depend on the position only) — with loads that no lane skips: a lane
+     * without a sample to fetch reads the block's own first sample and drops it.  One memory round trip per wave. */
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1];
     uint8_t *const ry = mi355_global(fr.recon[0]) + (size_t)mb_y * 16 * ys + mb_x * 16;
+    const int pic_w = 16 * fr.mb_width;
+    const bool top_y = mb_y > 0 && lane < 25 && mb_x * 16 + lane - 1 >= 0 && mb_x * 16 + lane - 1 < pic_w;
+    const bool left_y = mb_x > 0 && lane >= 32 && lane < 48;
+    const bool top_c = mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0);
+    const bool left_c = mb_x > 0 && lane >= 16 && lane < 24;
+    const uint8_t *const rcb = mi355_global(fr.recon[1]) + (size_t)mb_y * 8 * cs + mb_x * 8;
+    const uint8_t *const rcr = mi355_global(fr.recon[2]) + (size_t)mb_y * 8 * cs + mb_x * 8;
+    const ptrdiff_t oy = top_y ? (ptrdiff_t)(lane - 1) - ys : (left_y ? (ptrdiff_t)(lane - 32) * ys - 1 : 0);
+    const ptrdiff_t oc = top_c ? (ptrdiff_t)(lane - 1) - cs : (left_c ? (ptrdiff_t)(lane - 16) * cs - 1 : 0);
+    MbLoad ld;
+    load_mb_issue(ld, fr, mb_xy, true, true);
+    const uint8_t e_y = ry[oy], e_cb = rcb[oc], e_cr = rcr[oc];
+    MI355_ISSUE_FENCE();
+    load_mb_commit(s.mb, ld, true, fr.mv[0] != nullptr, fr.mv[1] != nullptr);
+    const mi355_h264_mb &h = s.mb.hdr;
+    const uint32_t t = h.mb_type;
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
         store_mb<true>(src, 16, src + 256, src + 320, 8, fr.recon, fr.recon_stride, mb_x, mb_y);
         return;
     }
-    /* edge samples of the unfiltered neighbours -> tiles */
-    const int pic_w = 16 * fr.mb_width;
-    if (mb_y > 0 && lane < 25) {
-        int x = lane - 1;
-        if (mb_x * 16 + x >= 0 && mb_x * 16 + x < pic_w) TILE(x, -1) = ry[x - ys];
-    }
-    if (mb_x > 0 && lane >= 32 && lane < 48) TILE(-1, lane - 32) = ry[(lane - 32) * ys - 1];
-    for (int p = 0; p < 2; p++) {
-        const uint8_t *rc = mi355_global(fr.recon[1 + p]) + (size_t)mb_y * 8 * cs + mb_x * 8;
-        if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0)) CTILE(p, lane - 1, -1) = rc[lane - 1 - cs];
-        if (mb_x > 0 && lane >= 16 && lane < 24) CTILE(p, -1, lane - 16) = rc[(lane - 16) * cs - 1];
-    }
+    /* edge samples -> tiles */
+    if (top_y) TILE(lane - 1, -1) = e_y;
+    if (left_y) TILE(-1, lane - 32) = e_y;
+    if (top_c) { CTILE(0, lane - 1, -1) = e_cb; CTILE(1, lane - 1, -1) = e_cr; }
+    if (left_c) { CTILE(0, -1, lane - 16) = e_cb; CTILE(1, -1, lane - 16) = e_cr; }
     __syncthreads();
 
     /* chroma prediction: hpc.pred8x8[chroma_pred_mode], h264_mb_template.c:161-164 */
