@@ -253,20 +253,34 @@ __device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdif
 {
     const int lane = lane_id(), rowbytes = cols * (bd > 8 ? 2 : 1);
     if (rowbytes >= 8) {
-        const int K = (rowbytes + 7) >> 3, inv = mi355_inv20(K);
-        for (int i = lane; i < rows * K; i += 64) {
-            const int r = mi355_div20(i, inv), k = i - r * K;
-            /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
-            const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
-            uint64_t v;
-            __builtin_memcpy(&v, w0 + (ptrdiff_t)r * sb + start, 8);
-            v >>= 8 * (want - start);
-            const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-            if (bd > 8) {
-                *reinterpret_cast<uint2 *>(&s.win[r * HEVC_MC_PITCH + 4 * k]) = make_uint2(lo, hi);
-            } else {
-                uint32_t *w = reinterpret_cast<uint32_t *>(&s.win[r * HEVC_MC_PITCH + 8 * k]);
-                w[0] = mi355_widen_lo(lo); w[1] = mi355_widen_hi(lo); w[2] = mi355_widen_lo(hi); w[3] = mi355_widen_hi(hi);
+        const int K = (rowbytes + 7) >> 3, inv = mi355_inv20(K), n = rows * K;
+        /* four pieces per lane and round: all four loads are issued before the first result is touched (a lane past the end
+         * repeats the last piece and drops it) — one memory round trip per 256 pieces instead of one per 64 */
+        constexpr int U = 4;
+        for (int base = 0; base < n; base += 64 * U) {
+            uint64_t v[U];
+            int rr[U], kk[U], sh[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + 64 * u + lane, ic = i < n ? i : n - 1;
+                const int r = mi355_div20(ic, inv), k = ic - r * K;
+                /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
+                const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
+                __builtin_memcpy(&v[u], w0 + (ptrdiff_t)r * sb + start, 8);
+                rr[u] = i < n ? r : -1; kk[u] = k; sh[u] = 8 * (want - start);
+            }
+            MI355_ISSUE_FENCE();
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (rr[u] < 0) continue;
+                const uint64_t w64 = v[u] >> sh[u];
+                const uint32_t lo = (uint32_t)w64, hi = (uint32_t)(w64 >> 32);
+                if (bd > 8) {
+                    *reinterpret_cast<uint2 *>(&s.win[rr[u] * HEVC_MC_PITCH + 4 * kk[u]]) = make_uint2(lo, hi);
+                } else {
+                    uint32_t *w = reinterpret_cast<uint32_t *>(&s.win[rr[u] * HEVC_MC_PITCH + 8 * kk[u]]);
+                    w[0] = mi355_widen_lo(lo); w[1] = mi355_widen_hi(lo); w[2] = mi355_widen_lo(hi); w[3] = mi355_widen_hi(hi);
+                }
             }
         }
     } else {
