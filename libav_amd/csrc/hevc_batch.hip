@@ -164,17 +164,32 @@ __global__ void __launch_bounds__(64) k_hevc_pred_batch(const mi355_hevc_pred_jo
     if ((al8 & 7) == 0) {      /* four samples per lane: 8-byte loads, one 8- or 4-byte store */
         const int qw = j.width >> 2, n = qw * j.height, inv = mi355_inv20(qw);
         typedef uint32_t u32x2 __attribute__((vector_size(8)));
-        for (int i = lane_id(); i < n; i += 64) {
-            const int y = mi355_div20(i, inv), x = 4 * (i - y * qw);
-            const u32x2 a = *reinterpret_cast<const u32x2 *>(&j.src1[x + y * ss]);
-            u32x2 b = { 0u, 0u };
-            if (two) b = *reinterpret_cast<const u32x2 *>(&j.src2[x + y * ss]);
-            int v[4];
+        /* four segments per lane and round, all loads first (the intermediates and the picture cannot alias, but the
+         * compiler does not know) */
+        constexpr int U = 4;
+        for (int base = 0; base < n; base += 64 * U) {
+            u32x2 a[U], b[U];
+            int yy[U], xx[U];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                v[k] = hevc_pred_px(p, (int16_t)((a[k >> 1] >> (16 * (k & 1))) & 0xFFFF), (int16_t)((b[k >> 1] >> (16 * (k & 1))) & 0xFFFF), bd);
-            if (bd > 8) *reinterpret_cast<u32x2 *>(j.dst + (size_t)y * j.dst_stride + 2 * x) = u32x2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16) };
-            else *reinterpret_cast<uint32_t *>(j.dst + (size_t)y * j.dst_stride + x) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            for (int u = 0; u < U; u++) {
+                const int i = base + 64 * u + lane_id(), ic = i < n ? i : n - 1;
+                const int y = mi355_div20(ic, inv), x = 4 * (ic - y * qw);
+                yy[u] = i < n ? y : -1; xx[u] = x;
+                a[u] = *reinterpret_cast<const u32x2 *>(&j.src1[x + y * ss]);
+                b[u] = u32x2{ 0u, 0u };
+                if (two) b[u] = *reinterpret_cast<const u32x2 *>(&j.src2[x + y * ss]);
+            }
+            MI355_ISSUE_FENCE();
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (yy[u] < 0) continue;
+                int v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    v[k] = hevc_pred_px(p, (int16_t)((a[u][k >> 1] >> (16 * (k & 1))) & 0xFFFF), (int16_t)((b[u][k >> 1] >> (16 * (k & 1))) & 0xFFFF), bd);
+                if (bd > 8) *reinterpret_cast<u32x2 *>(j.dst + (size_t)yy[u] * j.dst_stride + 2 * xx[u]) = u32x2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16) };
+                else *reinterpret_cast<uint32_t *>(j.dst + (size_t)yy[u] * j.dst_stride + xx[u]) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            }
         }
         return;
     }
