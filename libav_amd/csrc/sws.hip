@@ -462,27 +462,46 @@ __global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int 
     mi355_sws_frame fr = frames[blockIdx.z];
     for (int k = 0; k < 3; k++) fr.src[k] = mi355_global(fr.src[k]);
     fr.dst = mi355_global(fr.dst);
-    lut_load(s_lut, luts, tid, NT);
-    __syncthreads();
     const int x = blockIdx.x * C24_COLS + (tid & 63) * 8;   /* first of the thread's eight samples */
     const int npairs = dstW >> 1;                            /* pairs i < dstW >> 1 (8 + 4 + 2 sample groups, yuv2rgb.c:129-171) */
-    if ((x >> 1) >= npairs) return;
-    const bool wide = (x >> 1) + 4 <= npairs &&
+    const bool mine = (x >> 1) < npairs;
+    const bool wide = mine && (x >> 1) + 4 <= npairs &&
                       ((reinterpret_cast<uintptr_t>(fr.src[0]) | (uintptr_t)fr.src_stride[0] | reinterpret_cast<uintptr_t>(fr.dst) | (uintptr_t)fr.dst_stride) & 7) == 0 &&
                       ((reinterpret_cast<uintptr_t>(fr.src[1]) | (uintptr_t)fr.src_stride[1] | reinterpret_cast<uintptr_t>(fr.src[2]) | (uintptr_t)fr.src_stride[2]) & 3) == 0;
-    for (int rr = (tid >> 6); rr < C24_ROWS / 2; rr += NT / 64) {
+    /* the samples of both of the thread's line pairs are requested before the LUT copy below: the block pays one memory
+     * round trip, not three (LUT, first pair, second pair) */
+    constexpr int NR = C24_ROWS / 2 / (NT / 64);
+    sws_u32x2 ya[NR], yc[NR];
+    uint32_t u4[NR], v4[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int y = blockIdx.y * C24_ROWS + 2 * ((tid >> 6) + q * (NT / 64));
+        ya[q] = yc[q] = sws_u32x2{ 0u, 0u }; u4[q] = v4[q] = 0;
+        if (wide && y < sliceH) {
+            const uint8_t *py1 = fr.src[0] + (size_t)y * fr.src_stride[0] + x;
+            ya[q] = *reinterpret_cast<const sws_u32x2 *>(py1); yc[q] = *reinterpret_cast<const sws_u32x2 *>(py1 + fr.src_stride[0]);
+            u4[q] = *reinterpret_cast<const uint32_t *>(fr.src[1] + (size_t)(y >> 1) * fr.src_stride[1] + (x >> 1));
+            v4[q] = *reinterpret_cast<const uint32_t *>(fr.src[2] + (size_t)(y >> 1) * fr.src_stride[2] + (x >> 1));
+        }
+    }
+    MI355_ISSUE_FENCE();
+    lut_load(s_lut, luts, tid, NT);
+    __syncthreads();
+    if (!mine) return;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int rr = (tid >> 6) + q * (NT / 64);
         const int y = blockIdx.y * C24_ROWS + 2 * rr;
         if (y >= sliceH) break;
         const uint8_t *py1 = fr.src[0] + (size_t)y * fr.src_stride[0] + x, *py2 = py1 + fr.src_stride[0];
         const uint8_t *pu = fr.src[1] + (size_t)(y >> 1) * fr.src_stride[1] + (x >> 1), *pv = fr.src[2] + (size_t)(y >> 1) * fr.src_stride[2] + (x >> 1);
         uint8_t *d1 = fr.dst + (size_t)(y + sliceY) * fr.dst_stride + (size_t)x * 3, *d2 = d1 + fr.dst_stride;
         if (wide) {
-            const sws_u32x2 a = *reinterpret_cast<const sws_u32x2 *>(py1), c = *reinterpret_cast<const sws_u32x2 *>(py2);
-            const uint32_t u4 = *reinterpret_cast<const uint32_t *>(pu), v4 = *reinterpret_cast<const uint32_t *>(pv);
+            const sws_u32x2 a = ya[q], c = yc[q];
             int r[4], g[4], b[4];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const int U = (u4 >> (8 * p)) & 0xFF, V = (v4 >> (8 * p)) & 0xFF;
+                const int U = (u4[q] >> (8 * p)) & 0xFF, V = (v4[q] >> (8 * p)) & 0xFF;
                 r[p] = s_lut.rV[V]; g[p] = s_lut.gU[U] + s_lut.gV[V]; b[p] = s_lut.bU[U];
             }
             c24_line(s_lut, d1, a[0], a[1], r, g, b);
