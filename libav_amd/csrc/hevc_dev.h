@@ -432,10 +432,27 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
 {
     const int lane = lane_id(), l = lane & 7, j = l >> 2, g0 = lane & ~7;
     const bool act = enabled && (groups || lane < 8);
+    /* across a vertical edge (xs == 1) the eight samples of a line are contiguous: one 16-byte (8-byte for 8-bit samples)
+     * access each way instead of eight loads and up to six stores */
+    const bool row_wise = xs == 1;
     int p[4], q[4];
-    for (int k = 0; k < 4; k++) {
-        p[k] = act ? ldpx(pix, -(k + 1) * xs + l * ys, bd) : 0;
-        q[k] = act ? ldpx(pix, k * xs + l * ys, bd) : 0;
+    if (act && row_wise) {
+        if (bd > 8) {
+            uint32_t w[4];
+            __builtin_memcpy(w, pix + 2 * ((ptrdiff_t)l * ys - 4), 16);
+            p[3] = w[0] & 0xFFFF; p[2] = w[0] >> 16; p[1] = w[1] & 0xFFFF; p[0] = w[1] >> 16;
+            q[0] = w[2] & 0xFFFF; q[1] = w[2] >> 16; q[2] = w[3] & 0xFFFF; q[3] = w[3] >> 16;
+        } else {
+            uint32_t w[2];
+            __builtin_memcpy(w, pix + ((ptrdiff_t)l * ys - 4), 8);
+            p[3] = w[0] & 0xFF; p[2] = (w[0] >> 8) & 0xFF; p[1] = (w[0] >> 16) & 0xFF; p[0] = w[0] >> 24;
+            q[0] = w[1] & 0xFF; q[1] = (w[1] >> 8) & 0xFF; q[2] = (w[1] >> 16) & 0xFF; q[3] = w[1] >> 24;
+        }
+    } else {
+        for (int k = 0; k < 4; k++) {
+            p[k] = act ? ldpx(pix, -(k + 1) * xs + l * ys, bd) : 0;
+            q[k] = act ? ldpx(pix, k * xs + l * ys, bd) : 0;
+        }
     }
     const int dp = iabs(p[2] - 2 * p[1] + p[0]), dq = iabs(q[2] - 2 * q[1] + q[0]);
     const int sflat = iabs(p[3] - p[0]) + iabs(q[3] - q[0]), sgap = iabs(p[0] - q[0]);
@@ -448,17 +465,18 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
     const int tc = tc_[j] << (bd - 8), no_p = no_p_[j], no_q = no_q_[j];
     if (d0 + d3 >= beta) return;
     const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    int np[3] = { p[0], p[1], p[2] }, nq[3] = { q[0], q[1], q[2] };          /* the samples after filtering */
     if (f0 < beta_3 && gp0 < tc25 && f3 < beta_3 && gp3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
         const int tc2 = tc << 1;
         if (!no_p) {
-            stpx(pix, -1 * xs + l * ys, p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2), bd);
-            stpx(pix, -2 * xs + l * ys, p[1] + clip3(((p[2] + p[1] + p[0] + q[0] + 2) >> 2) - p[1], -tc2, tc2), bd);
-            stpx(pix, -3 * xs + l * ys, p[2] + clip3(((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3) - p[2], -tc2, tc2), bd);
+            np[0] = p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2);
+            np[1] = p[1] + clip3(((p[2] + p[1] + p[0] + q[0] + 2) >> 2) - p[1], -tc2, tc2);
+            np[2] = p[2] + clip3(((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3) - p[2], -tc2, tc2);
         }
         if (!no_q) {
-            stpx(pix, 0 * xs + l * ys, q[0] + clip3(((p[1] + 2 * p[0] + 2 * q[0] + 2 * q[1] + q[2] + 4) >> 3) - q[0], -tc2, tc2), bd);
-            stpx(pix, 1 * xs + l * ys, q[1] + clip3(((p[0] + q[0] + q[1] + q[2] + 2) >> 2) - q[1], -tc2, tc2), bd);
-            stpx(pix, 2 * xs + l * ys, q[2] + clip3(((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3) - q[2], -tc2, tc2), bd);
+            nq[0] = q[0] + clip3(((p[1] + 2 * p[0] + 2 * q[0] + 2 * q[1] + q[2] + 4) >> 3) - q[0], -tc2, tc2);
+            nq[1] = q[1] + clip3(((p[0] + q[0] + q[1] + q[2] + 2) >> 2) - q[1], -tc2, tc2);
+            nq[2] = q[2] + clip3(((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3) - q[2], -tc2, tc2);
         }
     } else {
         const int tc_2 = tc >> 1, thr = (beta + (beta >> 1)) >> 3;
@@ -466,10 +484,27 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
         int delta0 = (9 * (q[0] - p[0]) - 3 * (q[1] - p[1]) + 8) >> 4;
         if (iabs(delta0) >= 10 * tc) return;
         delta0 = clip3(delta0, -tc, tc);
-        if (!no_p) stpx(pix, -1 * xs + l * ys, clip_px(p[0] + delta0, bd), bd);
-        if (!no_q) stpx(pix, l * ys, clip_px(q[0] - delta0, bd), bd);
-        if (!no_p && nd_p > 1) stpx(pix, -2 * xs + l * ys, clip_px(p[1] + clip3((((p[2] + p[0] + 1) >> 1) - p[1] + delta0) >> 1, -tc_2, tc_2), bd), bd);
-        if (!no_q && nd_q > 1) stpx(pix, xs + l * ys, clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd), bd);
+        if (!no_p) np[0] = clip_px(p[0] + delta0, bd);
+        if (!no_q) nq[0] = clip_px(q[0] - delta0, bd);
+        if (!no_p && nd_p > 1) np[1] = clip_px(p[1] + clip3((((p[2] + p[0] + 1) >> 1) - p[1] + delta0) >> 1, -tc_2, tc_2), bd);
+        if (!no_q && nd_q > 1) nq[1] = clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd);
+    }
+    if (row_wise) {
+        /* p3 and q3 go back unchanged; no other job of a launch touches this line's eight samples */
+        if (bd > 8) {
+            const uint32_t w[4] = { (uint32_t)p[3] | ((uint32_t)np[2] << 16), (uint32_t)np[1] | ((uint32_t)np[0] << 16),
+                                    (uint32_t)nq[0] | ((uint32_t)nq[1] << 16), (uint32_t)nq[2] | ((uint32_t)q[3] << 16) };
+            __builtin_memcpy(pix + 2 * ((ptrdiff_t)l * ys - 4), w, 16);
+        } else {
+            const uint32_t w[2] = { (uint32_t)p[3] | ((uint32_t)np[2] << 8) | ((uint32_t)np[1] << 16) | ((uint32_t)np[0] << 24),
+                                    (uint32_t)nq[0] | ((uint32_t)nq[1] << 8) | ((uint32_t)nq[2] << 16) | ((uint32_t)q[3] << 24) };
+            __builtin_memcpy(pix + ((ptrdiff_t)l * ys - 4), w, 8);
+        }
+        return;
+    }
+    for (int k = 0; k < 3; k++) {
+        if (np[k] != p[k]) stpx(pix, -(k + 1) * xs + l * ys, np[k], bd);
+        if (nq[k] != q[k]) stpx(pix, k * xs + l * ys, nq[k], bd);
     }
 }
 __device__ inline void hevc_lf_chroma_wave(uint8_t *pix, int xs, int ys, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd,
