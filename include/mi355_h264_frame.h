@@ -90,8 +90,10 @@ typedef struct mi355_h264_mb {
                                                luma DC (Intra16x16), Cb DC, Cr DC (h264_mb.c:706-708,
                                                h264_mb_template.c:239-244) */
     uint8_t  slice_id;                   /* 44 index into mi355_h264_frame.slices */
-    uint8_t  intra_level;                /* 45 0 for inter MBs; for intra MBs 1 + max(level of the intra MBs among
-                                               left, top-left, top, top-right), see mi355_h264_intra_levels() */
+    uint8_t  intra_level;                /* 45 informational, written by mi355_h264_intra_schedule(): 0 for inter MBs;
+                                               for intra MBs 1 + max(level of the intra MBs among left, top-left, top,
+                                               top-right), SATURATED at 255 (an all-intra 2160p picture reaches 508).
+                                               The device never reads it: the schedule is intra_list / intra_level_start */
     uint8_t  qpc[2];                     /* 46 get_chroma_qp(pps, {0,1}, qp): this MB's Cb / Cr QP; MUST equal
                                                slices[slice_id].chroma_qp_table[p][qp] (I_PCM: qp = 0), the loop filter
                                                reads it instead of the table */
@@ -164,7 +166,7 @@ typedef struct mi355_h264_frame {
     const int16_t *coef;              /* [nmb][384] */
     const mi355_h264_slice *slices;
     int32_t nslices;
-    int32_t max_intra_level;          /* max over mb[].intra_level (0: no intra MBs) */
+    int32_t max_intra_level;          /* number of levels = return value of mi355_h264_intra_schedule() (0: no intra MBs) */
     /* intra schedule (device arrays; see mi355_h264_intra_schedule): the intra MBs of this
      * picture sorted by level; level L (1-based) occupies intra_list[start[L-1] .. start[L]) */
     const uint32_t *intra_list;
@@ -188,10 +190,11 @@ int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, in
 int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream);
 int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 
-/* Host helper (plain CPU bookkeeping, no sample arithmetic): fill mb[].intra_level for one
- * picture and write the schedule: `list` (capacity mb_width*mb_height) receives the intra MB
- * indices sorted by level, `level_start` (capacity mb_width + 2*mb_height + 1) the offsets.
- * Returns the maximum level; *max_level_width receives the largest number of MBs on one level. */
+/* Host helper (plain CPU bookkeeping, no sample arithmetic): write the intra schedule of one picture:
+ * `list` (capacity mb_width*mb_height) receives the intra MB indices sorted by level, `level_start`
+ * (capacity mb_width + 2*mb_height + 1) the offsets.  Levels are computed in int (no 8-bit limit: any
+ * picture size).  Returns the maximum level (<0: invalid arguments); *max_level_width receives the
+ * largest number of MBs on one level. */
 int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
                               uint32_t *list, int32_t *level_start, int *max_level_width);
 

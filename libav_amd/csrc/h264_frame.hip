@@ -24,6 +24,7 @@
  * filter_mb_dir + check_mv (h264_loopfilter.c:442-847), fill_filter_caches
  * (h264_slice.c:2056-2196).
  */
+#include <vector>
 #include "mi355_rt.h"
 #include "h264_dev.h"
 #include "../../include/mi355_h264_frame.h"
@@ -1092,30 +1093,40 @@ extern "C" int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nfra
 extern "C" int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
                                          uint32_t *list, int32_t *level_start, int *max_level_width)
 {
-    int maxl = 0;
+    /* Levels are kept in a local int array: an all-intra picture reaches level mb_width + 2 * (mb_height - 1)
+     * (254 at 1920x1088, 508 at 3840x2160), which the record's 8-bit field cannot hold.  The device reads only
+     * `list` / `level_start`; mb[].intra_level receives the level saturated at 255 (informational). */
     const int nmb = mb_width * mb_height;
+    if (!mb || !list || !level_start || nmb <= 0) return -1;
+    std::vector<int32_t> level((size_t)nmb, 0), count;
+    int maxl = 0;
     for (int y = 0; y < mb_height; y++)
         for (int x = 0; x < mb_width; x++) {
-            mi355_h264_mb &m = mb[x + y * mb_width];
+            const int xy = x + y * mb_width;
+            mi355_h264_mb &m = mb[xy];
             if (!(m.mb_type & MI355_MB_INTRA)) { m.intra_level = 0; continue; }
             int lv = 0;
             const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
             for (int k = 0; k < 4; k++) {
-                int nx = x + dx[k], ny = y + dy[k];
-                if (nx >= 0 && nx < mb_width && ny >= 0 && ny < mb_height && mb[nx + ny * mb_width].intra_level > lv)
-                    lv = mb[nx + ny * mb_width].intra_level;
+                const int nx = x + dx[k], ny = y + dy[k];
+                if (nx >= 0 && nx < mb_width && ny >= 0 && ny < mb_height && level[(size_t)(nx + ny * mb_width)] > lv)
+                    lv = level[(size_t)(nx + ny * mb_width)];
             }
-            m.intra_level = (uint8_t)(lv + 1);   /* bounded by mb_width + 2*mb_height - 2 <= 254 for <= 4096x2304 */
+            level[(size_t)xy] = lv + 1;
+            m.intra_level = (uint8_t)(lv + 1 > 255 ? 255 : lv + 1);
             if (lv + 1 > maxl) maxl = lv + 1;
         }
-    int n = 0, width = 0;
+    /* counting sort by level (raster order inside a level) */
+    count.assign((size_t)maxl + 2, 0);
+    for (int i = 0; i < nmb; i++) if (level[(size_t)i]) count[(size_t)level[(size_t)i]]++;
+    int width = 0;
     level_start[0] = 0;
     for (int l = 1; l <= maxl; l++) {
-        for (int i = 0; i < nmb; i++)
-            if (mb[i].intra_level == l) list[n++] = (uint32_t)i;
-        level_start[l] = n;
-        if (level_start[l] - level_start[l - 1] > width) width = level_start[l] - level_start[l - 1];
+        level_start[l] = level_start[l - 1] + count[(size_t)l];
+        if (count[(size_t)l] > width) width = count[(size_t)l];
     }
+    std::vector<int32_t> fill(level_start, level_start + maxl + 1);
+    for (int i = 0; i < nmb; i++) if (level[(size_t)i]) list[fill[(size_t)level[(size_t)i] - 1]++] = (uint32_t)i;
     if (max_level_width) *max_level_width = width;
     return maxl;
 }

@@ -209,6 +209,7 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
         /* intra levels are a pure function of mb_type: recompute them here with the same rule as
          * mi355_h264_intra_schedule() so the fixture is self-contained */
         int maxl = 0;
+        int32_t *level = calloc(nmb, sizeof(*level));   /* int levels: the record's 8-bit field only gets the saturated value */
         for (int y = 0; y < mb_h; y++)
             for (int x = 0; x < mb_w; x++) {
                 mi355_h264_mb *m = &mbs[x + y * mb_w];
@@ -217,11 +218,13 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
                 const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
                 for (int k = 0; k < 4; k++) {
                     int nx = x + dx[k], ny = y + dy[k];
-                    if (nx >= 0 && nx < mb_w && ny >= 0 && ny < mb_h && mbs[nx + ny * mb_w].intra_level > lv) lv = mbs[nx + ny * mb_w].intra_level;
+                    if (nx >= 0 && nx < mb_w && ny >= 0 && ny < mb_h && level[nx + ny * mb_w] > lv) lv = level[nx + ny * mb_w];
                 }
-                m->intra_level = (uint8_t)(lv + 1);
+                level[x + y * mb_w] = lv + 1;
+                m->intra_level = (uint8_t)(lv + 1 > 255 ? 255 : lv + 1);
                 if (lv + 1 > maxl) maxl = lv + 1;
             }
+        free(level);
         (void)lw; (void)list; (void)start;
         const AVFrame *f = h->cur_pic_ptr->f;
         put_u32(0x46523634);     /* "FR64" */

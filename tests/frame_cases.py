@@ -27,6 +27,9 @@ CASES = {
     "mid_b_bigcoef":    dict(nframes=1, mb_w=40, mb_h=22, seed=102, mix="mixed", bframes=True, intra_frac=0.15, dct8_frac=0.3, coef_b=200),
     "mid_b_weighted":   dict(nframes=1, mb_w=40, mb_h=22, seed=103, mix="mixed", bframes=True, weighted=1, intra_frac=0.1, coef_b=100, mv_range=200),
     "mid_intra_pcm":    dict(nframes=1, mb_w=33, mb_h=19, seed=105, intra_frac=1.0, pcm_frac=0.05, dct8_frac=0.4, coef_b=300),
+    # 268 intra dependency levels: more than the record's 8-bit intra_level field can hold (an all-intra picture
+    # above 1080p does this); the schedule must not wrap
+    "tall_all_intra":   dict(nframes=1, mb_w=10, mb_h=130, seed=107, intra_frac=1.0, pcm_frac=0.02, coef_b=10),
     "mid_hugecoef":     dict(nframes=1, mb_w=33, mb_h=19, seed=106, mix="mixed", intra_frac=0.5, dct8_frac=0.4, coef_b=1000),
 }
 

@@ -347,8 +347,8 @@ def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac
 
 def intra_schedule(fs, f):
     """python twin of mi355_h264_intra_schedule() (host helper of the C ABI)"""
-    mx = intra_levels(fs.mb[f], fs.mb_w, fs.mb_h)
-    lv = fs.mb[f]["intra_level"].astype(np.int64)
+    lv = intra_levels(fs.mb[f], fs.mb_w, fs.mb_h)
+    mx = int(lv.max()) if lv.size else 0
     order = [np.nonzero(lv == l)[0] for l in range(1, mx + 1)]
     fs.intra_list[f] = np.concatenate(order).astype(np.uint32) if order else np.zeros(0, np.uint32)
     fs.intra_start[f] = np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32)
@@ -358,21 +358,23 @@ def intra_schedule(fs, f):
 
 
 def intra_levels(mb, mb_w, mb_h):
-    mx = 0
+    """levels in a local int array (an all-intra picture above 1080p exceeds the record's 8-bit field, which only
+    receives the saturated value)"""
+    lv = np.zeros(mb_w * mb_h, np.int64)
+    intra = (mb["mb_type"] & 7) != 0
     for y in range(mb_h):
         for x in range(mb_w):
-            m = mb[x + y * mb_w]
-            if not (m["mb_type"] & 7):
-                m["intra_level"] = 0
+            xy = x + y * mb_w
+            if not intra[xy]:
                 continue
-            lv = 0
+            m = 0
             for (dx, dy) in ((-1, 0), (-1, -1), (0, -1), (1, -1)):
                 nx, ny = x + dx, y + dy
                 if 0 <= nx < mb_w and 0 <= ny < mb_h:
-                    lv = max(lv, int(mb[nx + ny * mb_w]["intra_level"]))
-            m["intra_level"] = lv + 1
-            mx = max(mx, lv + 1)
-    return mx
+                    m = max(m, int(lv[nx + ny * mb_w]))
+            lv[xy] = m + 1
+    mb["intra_level"] = np.minimum(lv, 255)
+    return lv
 
 
 def host_frames(fs, recon, dst):

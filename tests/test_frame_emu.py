@@ -40,3 +40,24 @@ def test_decode_then_convert_on_device_emulated(emu, oracle):
 def test_frame_pipeline_emulated_unaligned_strides(emu, oracle, name, pad):
     """strides that are multiples of 8 / 4 only: the dword paths instead of the 16-byte ones"""
     frame_cases.run_case(emu, oracle, name, pad=pad)
+
+
+def test_intra_schedule_helper_above_255_levels(emu):
+    """mi355_h264_intra_schedule on an all-intra 2560x1440 picture (338 levels): same lists as the python twin, every
+    macroblock listed once, after all four neighbours it predicts from (the 8-bit level field wrapped)."""
+    import numpy as np
+    import h264_frames as HF
+    fs = HF.synth_frames_fast(1, 160, 90, seed=5, intra_frac=1.0, lib=emu.lib)
+    lst, start = fs.intra_list[0].copy(), fs.intra_start[0].copy()
+    assert fs.max_intra_level == 160 + 2 * 89 == len(start) - 1
+    assert sorted(lst.tolist()) == list(range(160 * 90))
+    twin = HF.FrameSet(1, 160, 90, 4)
+    twin.mb[:] = fs.mb
+    assert HF.intra_schedule(twin, 0) == fs.max_intra_level
+    assert np.array_equal(twin.intra_list[0], lst) and np.array_equal(twin.intra_start[0], start)
+    level = np.zeros(160 * 90, np.int64)
+    for l in range(1, len(start)):
+        level[lst[start[l - 1]:start[l]]] = l
+    lv = level.reshape(90, 160)
+    assert (lv[:, 1:] > lv[:, :-1]).all() and (lv[1:, :] > lv[:-1, :]).all() and (lv[1:, :-1] > lv[:-1, 1:]).all()
+    assert fs.mb[0]["intra_level"].max() == 255                      # informational field saturates

@@ -53,3 +53,20 @@ def test_decode_then_convert_on_device(mi355, oracle):
 @pytest.mark.parametrize("name", ("mixed_intra", "wide_mixed", "mid_b_weighted"))
 def test_frame_pipeline_gpu_unaligned_strides(mi355, oracle, name, pad):
     frame_cases.run_case(mi355, oracle, name, pad=pad)
+
+
+def test_all_intra_picture_above_1080p(mi355, oracle):
+    """an all-intra 2560x1440 picture has 338 dependency levels (> 255): every macroblock must still be reconstructed
+    after its neighbours"""
+    fs = HF.synth_frames_fast(1, 160, 90, seed=7, intra_frac=1.0, lib=mi355.lib)
+    assert fs.max_intra_level == 338
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
