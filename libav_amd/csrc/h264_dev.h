@@ -32,6 +32,52 @@ static inline int quad_xor2(int v) { return __shfl_xor(v, 2); }
 __device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }   /* quad_perm:[1,0,3,2] */
 __device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }   /* quad_perm:[2,3,0,1] */
 #endif
+/* ---- single-instruction primitives of the loop filter (device) and their plain-C meaning (emulator) ---------------
+ * absdiff8: |a - b| of two values in 0..255 (v_sad_u16);  med3i: clamp x to [lo, hi], lo <= hi (v_med3_i32);
+ * byte_perm: v_perm_b32 — byte i of the result is byte sel_i of {s1 (0..3), s0 (4..7)}, 0x0C gives 0x00;
+ * quad_bcast<K>: the value lane K of this lane's group of four holds (DPP quad_perm, no LDS);
+ * pk_absdiff_far: true when two packed (x, y) int16 vectors differ by >= 4 in a component (check_mv's
+ * `abs(a - b) >= 4`, h264_loopfilter.c:442-470); the subtraction saturates, so extreme vectors cannot wrap to "near". */
+#ifdef MI355_HIP_EMU_H
+static inline int absdiff8(int a, int b) { return a > b ? a - b : b - a; }
+static inline int med3i(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = (sel >> (8 * i)) & 0xFF;
+        const uint32_t b = c < 8 ? (uint32_t)(src >> (8 * c)) & 0xFF : (c == 0x0C ? 0u : 0xFFu);
+        r |= b << (8 * i);
+    }
+    return r;
+}
+template <int K> static inline int quad_bcast(int v) { return __shfl(v, ((int)(threadIdx.x & 63) & ~3) | K); }
+static inline bool pk_absdiff_far(uint32_t a, uint32_t b)
+{
+    const int dx = (int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF), dy = (int16_t)(a >> 16) - (int16_t)(b >> 16);
+    return (dx < 0 ? -dx : dx) >= 4 || (dy < 0 ? -dy : dy) >= 4;
+}
+#else
+__device__ __forceinline__ int absdiff8(int a, int b) { return (int)__builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, 0u); }
+__device__ __forceinline__ int med3i(int x, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+template <int K> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true); }
+__device__ __forceinline__ bool pk_absdiff_far(uint32_t a, uint32_t b)
+{
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    const v2s d = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b));
+    const v2s n = (v2s)((short)0) - d;
+    const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(d, n));    /* |d| per half, <= 32767 (d = -32768 gives -32768: still >= 4 below) */
+    return (m & 0xFFFCFFFCu) != 0;
+}
+#endif
+
 /* a value every lane of the wave holds identically (read from this wave's LDS record): telling the
  * compiler moves everything derived from it to the scalar unit */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

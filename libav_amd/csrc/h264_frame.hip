@@ -523,11 +523,18 @@ __device__ __forceinline__ int ref_identity(const mi355_h264_mb &m, int list, in
  * columns).  Rows above a group's macroblock come from the tile of the group above (same wave, two
  * steps ahead) or, for the band's first row, from `dst` as the previous band left it; a group does
  * not write the bottom three rows that the group below will still filter and write itself.
- * Per-step global traffic is only records and vectors; the L1 sees ~15 sample requests per
- * macroblock instead of ~130 sixteen-byte ones.
+ *
+ * Side information never passes through LDS: every lane fetches the record fields and the four motion vectors its
+ * boundary-strength role needs straight from memory one step ahead (unpredicated loads from clamped addresses, so the
+ * compiler's wait counts stay exact), computes ONE strength per direction — role (segment = l >> 2, edge = l & 3) —
+ * and the four strengths of a line meet through quad broadcasts (DPP).  alpha / beta / tc0 (tables 8-16 / 8-17 in LDS)
+ * are looked up once per (component, edge kind) by nine lanes of the group and shared through LDS; the per-edge tc0 is a
+ * byte select (v_perm_b32) on the packed strengths.
  *
  * Inside a step a lane holds one luma ROW (4 samples of the left neighbour + 16) and one chroma row
- * in registers for the vertical edges; then the tile is read by COLUMN for the horizontal edges. */
+ * in registers for the vertical edges; then the tile is read by COLUMN for the horizontal edges.  Each edge evaluates
+ * the filterSamplesFlag conditions first and leaves when no line of the wave passes (the reference's own per-line
+ * `continue`, h264dsp_template.c:117-121, taken at wave granularity); results are bit-identical either way. */
 #ifndef MI355_DCH_LOG
 #define MI355_DCH_LOG 2
 #endif
@@ -540,19 +547,16 @@ constexpr int DC_PITCH = 8 * DCH + MI355_DPAD;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
 constexpr int DCH_ISSUE = DCH >= 4 ? 1 : DCH - 1;  /* position in a chunk at which the next chunk's loads are issued */
 struct DeblockLds {
-    mi355_h264_mb hdr[4][3];      /* [t&1] this MB, [(t&1)^1] left neighbour (previous step), [2] top neighbour */
-    uint32_t mv[4][2][2][16];     /* [t&1][list]: this MB's vectors; the other parity is the left neighbour */
-    uint32_t mvt[4][2][4];        /* [list]: bottom row of the top neighbour */
-    uint8_t y[4][2][20][DY_PITCH];      /* [group][chunk parity]: rows -4..15 of eight macroblocks */
+    uint8_t y[4][2][20][DY_PITCH];      /* [group][chunk parity]: rows -4..15 of DCH macroblocks */
     uint8_t c[4][2][2][10][DC_PITCH];   /* [group][chunk parity][plane]: rows -2..7 */
-    uint8_t bs[4][2][4][4];       /* [dir][segment][edge]: the 4 edges of a line are one dword */
-    /* alpha / beta / tc0 tables: a copy in LDS turns the dependent per-edge lookups (qp -> index ->
-     * alpha, beta -> tc0[bS]) from global-memory gathers into LDS reads */
-    uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    /* [group][component * 3 + kind]: component luma / Cb / Cr, kind inner / left / top edge:
+     * word 0 = alpha | beta << 8, word 1 = tc0 by (bS & 3): bytes (0, tc0[bS 1], tc0[bS 2], tc0[bS 3]), chroma + 1 */
+    uint32_t parm[4][9][2];
+    uint8_t t_alpha[52], t_beta[52];
+    uint32_t t_tc0[52];                 /* (0, tc0[0], tc0[1], tc0[2]) per indexA */
 };
 
-/* The fields of a record the filter looks at, pulled out of LDS in three wide reads so that nothing
- * below waits on memory again */
+/* The fields of a record the filter looks at */
 struct MbInfo {
     uint32_t type, nnz, w2, w3, w11, ref0, ref1;
     __device__ __forceinline__ int qp() const { return (int8_t)((w2 >> 16) & 0xFF); }
@@ -561,129 +565,131 @@ struct MbInfo {
     __device__ __forceinline__ int beta_off() const { return (int8_t)((w3 >> 8) & 0xFF); }
     __device__ __forceinline__ int slice_id() const { return (int)(w11 & 0xFF); }
     __device__ __forceinline__ int qpc(int p) const { return (int)((w11 >> (16 + 8 * p)) & 0xFF); }
-    __device__ __forceinline__ bool intra() const { return (type & MI355_MB_INTRA) != 0; }
-    /* picture identity of quadrant i8 as ref_cache holds it after ref2frm (h264_slice.c:2023-2029) */
-    __device__ __forceinline__ int ref_id(int list, int i8) const
-    {
-        const int r = (int)(((list ? ref1 : ref0) >> (8 * i8)) & 0xFF);
-        return (intra() || r == 0xFF) ? -1 : r;
-    }
 };
-__device__ __forceinline__ MbInfo mb_info(const mi355_h264_mb &m)
+typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
+/* words 0-3 and 11-13 of the record at byte offset `off` of `base`: two loads, no predicate */
+__device__ __forceinline__ MbInfo mb_info_load(const uint8_t *base, uint32_t off)
 {
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(&m);
+#ifdef MI355_HIP_EMU_H
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + off);
     return MbInfo{ w[0], w[1], w[2], w[3], w[11], w[12], w[13] };
+#else
+    typedef uint32_t u32x3 __attribute__((vector_size(12)));
+    const mi355_u32x4 a = *reinterpret_cast<const mi355_u32x4 *>(base + off);
+    const u32x3 b = *reinterpret_cast<const u32x3 *>(base + off + 44);
+    return MbInfo{ a[0], a[1], a[2], a[3], b[0], b[1], b[2] };
+#endif
 }
 
-/* check_mv (h264_loopfilter.c:442-470, frame macroblocks, mvy_limit 4) without branches */
-__device__ __forceinline__ int check_mv_flat(const int rp[2], const int rq[2], const uint32_t mp[2], const uint32_t mq[2], int list_count)
+/* check_mv (h264_loopfilter.c:442-470, frame macroblocks, mvy_limit 4) on raw reference bytes (0xFF = unused; the
+ * comparisons are equalities, and intra macroblocks never get here) */
+__device__ __forceinline__ bool check_mv_raw(uint32_t rp0, uint32_t rq0, uint32_t rp1, uint32_t rq1, const uint32_t mp[2], const uint32_t mq[2], bool two_lists)
 {
-    bool v = rp[0] != rq[0] || (rp[0] != -1 && mv_far(mp[0], mq[0]));
-    if (list_count == 2) {
-        v = v || rp[1] != rq[1] || mv_far(mp[1], mq[1]);
-        const bool cross = rp[0] != rq[1] || rp[1] != rq[0] || mv_far(mp[0], mq[1]) || mv_far(mp[1], mq[0]);
+    bool v = rp0 != rq0 || (rp0 != 0xFF && pk_absdiff_far(mp[0], mq[0]));
+    if (two_lists) {
+        v = v || rp1 != rq1 || pk_absdiff_far(mp[1], mq[1]);
+        const bool cross = rp0 != rq1 || rp1 != rq0 || pk_absdiff_far(mp[0], mq[1]) || pk_absdiff_far(mp[1], mq[0]);
         v = v && cross;
     }
     return v;
 }
-/* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713: every operand is already in a register.
- * mp/mq: vectors of the block on this side / across the edge; q*: the macroblock across the edge (the
+/* lane constants of a boundary-strength role in one direction: nnz bits and reference-byte shifts of the block on this
+ * side of the edge (p) and across it (q: in the neighbour macroblock when the edge is the macroblock edge) */
+struct BsRole {
+    uint32_t pbit, qbit, psh, qsh;
+};
+/* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713.  q*: the macroblock across the edge (the
  * neighbour for edge 0, this one otherwise) */
-__device__ __forceinline__ int bs_flat(const MbInfo &h, const MbInfo &nb, bool have_nb, int dir, int edge, int seg,
-                                       const uint32_t mp[2], const uint32_t mq[2], int list_count)
+__device__ __forceinline__ uint32_t bs_role(const MbInfo &h, const MbInfo &nb, bool outer, bool odd, bool enabled, const BsRole &r,
+                                            const uint32_t mp[2], const uint32_t mq[2], bool two_lists)
 {
-    const int px4 = dir ? seg : edge, py4 = dir ? edge : seg;
-    const bool outer = edge == 0;
-    const int qx4 = dir ? seg : (outer ? 3 : edge - 1), qy4 = dir ? (outer ? 3 : edge - 1) : seg;
     const uint32_t q_type = outer ? nb.type : h.type, q_nnz = outer ? nb.nnz : h.nnz;
-    const MbInfo q{ q_type, q_nnz, 0, 0, 0, outer ? nb.ref0 : h.ref0, outer ? nb.ref1 : h.ref1 };
-    const int pi8 = (px4 >> 1) + 2 * (py4 >> 1), qi8 = (qx4 >> 1) + 2 * (qy4 >> 1);
-    const int rp[2] = { h.ref_id(0, pi8), h.ref_id(1, pi8) }, rq[2] = { q.ref_id(0, qi8), q.ref_id(1, qi8) };
+    const uint32_t q_ref0 = outer ? nb.ref0 : h.ref0, q_ref1 = outer ? nb.ref1 : h.ref1;
     const bool any_intra = ((h.type | q_type) & MI355_MB_INTRA) != 0;
-    const bool coded = (((h.nnz >> blk_index(px4, py4)) | (q_nnz >> blk_index(qx4, qy4))) & 1) != 0;
-    int bs = any_intra ? (outer ? 4 : 3) : (coded ? 2 : check_mv_flat(rp, rq, mp, mq, list_count));
-    if (outer ? !have_nb : ((h.type & MI355_MB_8x8DCT) && (edge & 1))) bs = 0;
+    const bool coded = ((h.nnz & r.pbit) | (q_nnz & r.qbit)) != 0;
+    const uint32_t rp0 = (h.ref0 >> r.psh) & 0xFF, rq0 = (q_ref0 >> r.qsh) & 0xFF;
+    const uint32_t rp1 = (h.ref1 >> r.psh) & 0xFF, rq1 = (q_ref1 >> r.qsh) & 0xFF;
+    const uint32_t mvbs = check_mv_raw(rp0, rq0, rp1, rq1, mp, mq, two_lists) ? 1u : 0u;
+    uint32_t bs = any_intra ? (outer ? 4u : 3u) : (coded ? 2u : mvbs);
+    if (!enabled || (!outer && odd && (h.type & MI355_MB_8x8DCT))) bs = 0;
     return bs;
 }
 
-/* alpha, beta, tc0 of one edge of one line (tables 8-16/8-17 through LDS) */
-struct EdgeParm {
-    int alpha, beta, tc0;
-};
-/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3.  bS 1..3: h264_loop_filter_luma (h264dsp_template.c:104-150) as
- * selects; bS 4 (h264_loop_filter_luma_intra :165-210) only where a lane of the wave has it */
-__device__ __forceinline__ void luma_edge(int *v, int bs, const EdgeParm &e, bool wave_has_intra)
+/* Luma edge, one line: p3 p2 p1 p0 | q0 q1 q2 q3.  bS 1..3: h264_loop_filter_luma (h264dsp_template.c:104-150) with the
+ * line's conditions folded into the clipping bounds (tc = 0 leaves a sample as it is); bS 4
+ * (h264_loop_filter_luma_intra :165-210) only where a lane of the wave has it (MAY_INTRA: macroblock edges only).
+ * Returns 0 when no line of the WAVE passes the conditions (nothing changed), else 1, or 2 when the bS 4 filter ran. */
+template <bool MAY_INTRA>
+__device__ __forceinline__ int luma_line(int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3,
+                                         int bs, int alpha, int beta, int tc0)
 {
-    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
-    const bool f = bs != 0 && iabs(p0 - q0) < e.alpha && iabs(p1 - p0) < e.beta && iabs(q1 - q0) < e.beta;
-    const bool ap = iabs(p2 - p0) < e.beta, aq = iabs(q2 - q0) < e.beta;
-    const int avg = (p0 + q0 + 1) >> 1, tc0 = e.tc0, tc = tc0 + ap + aq;
-    const int np1 = p1 + clip3(((p2 + avg) >> 1) - p1, -tc0, tc0), nq1 = q1 + clip3(((q2 + avg) >> 1) - q1, -tc0, tc0);
-    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
+    if (!__any(f)) return 0;
+    const bool ap = absdiff8(p2, p0) < beta, aq = absdiff8(q2, q0) < beta;
     const bool fn = f && bs < 4;
-    v[2] = fn && ap ? np1 : p1;
-    v[5] = fn && aq ? nq1 : q1;
-    v[3] = fn ? clip_u8(p0 + delta) : p0;
-    v[4] = fn ? clip_u8(q0 - delta) : q0;
-    if (wave_has_intra) {
-        const bool fi = f && bs == 4, strong = iabs(p0 - q0) < ((e.alpha >> 2) + 2);
-        const bool sp = strong && ap, sq = strong && aq;
-        const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-        if (fi) {
-            v[3] = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : wp0;
-            v[2] = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
-            v[1] = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
-            v[4] = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : wq0;
-            v[5] = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
-            v[6] = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+    const int avg = (p0 + q0 + 1) >> 1;
+    const int tp = fn && ap ? tc0 : 0, tq = fn && aq ? tc0 : 0, tc = fn ? tc0 + (int)ap + (int)aq : 0;
+    const int np1 = p1 + med3i(((p2 + avg) >> 1) - p1, -tp, tp), nq1 = q1 + med3i(((q2 + avg) >> 1) - q1, -tq, tq);
+    const int delta = med3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const int P0 = p0, P1 = p1, P2 = p2, Q0 = q0, Q1 = q1, Q2 = q2;
+    p1 = np1; q1 = nq1;
+    p0 = clip_u8(P0 + delta);
+    q0 = clip_u8(Q0 - delta);
+    if (MAY_INTRA) {
+        const bool fi = f && bs == 4;
+        if (__any(fi)) {
+            const bool strong = absdiff8(P0, Q0) < ((alpha >> 2) + 2), sp = strong && ap, sq = strong && aq;
+            const int wp0 = (2 * P1 + P0 + Q1 + 2) >> 2, wq0 = (2 * Q1 + Q0 + P1 + 2) >> 2;
+            const int s4 = P0 + Q0 + 4;
+            const int ip0 = sp ? (P2 + 2 * P1 + P0 + Q0 + Q1 + s4) >> 3 : wp0;
+            const int ip1 = sp ? (P2 + P1 + P0 + Q0 + 2) >> 2 : P1;
+            const int ip2 = sp ? (2 * p3 + 3 * P2 + P1 + s4) >> 3 : P2;
+            const int iq0 = sq ? (P1 + P0 + Q0 + 2 * Q1 + Q2 + s4) >> 3 : wq0;
+            const int iq1 = sq ? (P0 + Q0 + Q1 + Q2 + 2) >> 2 : Q1;
+            const int iq2 = sq ? (2 * q3 + 3 * Q2 + Q1 + s4) >> 3 : Q2;
+            p0 = fi ? ip0 : p0; p1 = fi ? ip1 : p1; p2 = fi ? ip2 : p2;
+            q0 = fi ? iq0 : q0; q1 = fi ? iq1 : q1; q2 = fi ? iq2 : q2;
+            return 2;
         }
     }
+    return 1;
 }
-/* v[0..3] = p1 p0 q0 q1: h264_loop_filter_chroma / _intra (h264dsp_template.c:212-265), tc = tc0 + 1 */
-__device__ __forceinline__ void chroma_edge(int *v, int bs, const EdgeParm &e)
+/* Chroma edge, one line: p1 p0 | q0 q1: h264_loop_filter_chroma / _intra (h264dsp_template.c:212-265); `tc1` is the
+ * caller's tc0 + 1 (h264_loopfilter.c:126-129).  Returns whether any line of the wave changed. */
+__device__ __forceinline__ bool chroma_line(int p1, int &p0, int &q0, int q1, int bs, int alpha, int beta, int tc1)
 {
-    const int p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
-    const bool f = bs != 0 && iabs(p0 - q0) < e.alpha && iabs(p1 - p0) < e.beta && iabs(q1 - q0) < e.beta;
-    const int tc = e.tc0 + 1;
-    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-    const int np0 = bs == 4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip_u8(p0 + delta);
-    const int nq0 = bs == 4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip_u8(q0 - delta);
-    v[1] = f ? np0 : p0;
-    v[2] = f ? nq0 : q0;
+    const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
+    if (!__any(f)) return false;
+    const int tc = f && bs < 4 ? tc1 : 0;
+    const int delta = med3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const bool fi = f && bs == 4;
+    const int np0 = fi ? (2 * p1 + p0 + q1 + 2) >> 2 : clip_u8(p0 + delta);
+    const int nq0 = fi ? (2 * q1 + q0 + p1 + 2) >> 2 : clip_u8(q0 - delta);
+    p0 = np0; q0 = nq0;
+    return true;
 }
-__device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
-__device__ __forceinline__ void unpack4(uint32_t w, int *v) { v[0] = w & 0xFF; v[1] = (w >> 8) & 0xFF; v[2] = (w >> 16) & 0xFF; v[3] = w >> 24; }
+/* the same on a row held as dwords: P = samples -4..-1 of the edge, Q = samples 0..3 (memory order) */
+template <bool MAY_INTRA>
+__device__ __forceinline__ bool luma_row_edge(uint32_t &P, uint32_t &Q, int bs, int alpha, int beta, int tc0)
+{
+    int p3 = P & 0xFF, p2 = (P >> 8) & 0xFF, p1 = (P >> 16) & 0xFF, p0 = P >> 24;
+    int q0 = Q & 0xFF, q1 = (Q >> 8) & 0xFF, q2 = (Q >> 16) & 0xFF, q3 = Q >> 24;
+    const int r = luma_line<MAY_INTRA>(p3, p2, p1, p0, q0, q1, q2, q3, bs, alpha, beta, tc0);
+    if (!r) return false;
+    P = (uint32_t)p3 | ((uint32_t)p2 << 8) | ((uint32_t)p1 << 16) | ((uint32_t)p0 << 24);
+    Q = (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | ((uint32_t)q3 << 24);
+    return true;
+}
+__device__ __forceinline__ bool chroma_row_edge(uint32_t &P, uint32_t &Q, int bs, int alpha, int beta, int tc1)
+{
+    int p0 = P >> 24, q0 = Q & 0xFF;
+    if (!chroma_line((P >> 16) & 0xFF, p0, q0, (Q >> 8) & 0xFF, bs, alpha, beta, tc1)) return false;
+    P = (P & 0x00FFFFFFu) | ((uint32_t)p0 << 24);
+    Q = (Q & 0xFFFFFF00u) | (uint32_t)q0;
+    return true;
+}
 
-/* what a lane fetches for one macroblock ahead of time (records and vectors: never written by the filter) */
-struct DeblockPre {
-    uint32_t hw, hw_top, mv[2], mvt[2];
-};
-struct DeblockPtr {
-    const uint32_t *rec;                 /* dword l of the record of macroblock x = -2g of the lane's row */
-    const uint32_t *mv[2];               /* vector l of that MB, per list (null when the list is absent) */
-    ptrdiff_t rec_top, mv_top;           /* distance (in dwords) to the top neighbour's record / bottom-row vector */
-    __device__ __forceinline__ void advance()
-    {
-        rec += 16;
-        if (mv[0]) mv[0] += 16;
-        if (mv[1]) mv[1] += 16;
-    }
-};
-__device__ __forceinline__ void deblock_prefetch(DeblockPre &p, const DeblockPtr &a, bool ok, bool has_t, int l)
-{
-    p.hw = p.hw_top = p.mv[0] = p.mv[1] = p.mvt[0] = p.mvt[1] = 0;
-    if (!ok) return;
-    p.hw = a.rec[0];
-    if (has_t) p.hw_top = a.rec[a.rec_top];
-#pragma unroll
-    for (int li = 0; li < 2; li++) {
-        if (!a.mv[li]) continue;
-        p.mv[li] = a.mv[li][0];
-        if (l < 4 && has_t) p.mvt[li] = a.mv[li][a.mv_top];
-    }
-}
-typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
-typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
 /* 16 bytes of an LDS tile row (rows are 8-byte aligned: two 64-bit accesses) */
 __device__ __forceinline__ uint4 lds16(const uint8_t *p)
 {
@@ -735,7 +741,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     const bool row_ok = mb_y < fr.mb_height;
     const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
     const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
-    const int list_count = fr.mv[1] ? 2 : 1;                 /* sl->list_count == 2 exactly when list-1 vectors exist */
+    const bool two_lists = fr.mv[1] != nullptr;              /* sl->list_count == 2 exactly when list-1 vectors exist */
     const int nsteps = W + 6;
     const bool has_t = row_ok && mb_y > 0;
     /* the group below (same wave) filters and writes this row's bottom three luma rows / last chroma row */
@@ -746,18 +752,45 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                        reinterpret_cast<uintptr_t>(mi355_global(fr.dst[2])) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
     if (lane < 52) {
         s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
-        s.t_tc0[lane][0] = k_tc0[lane][0]; s.t_tc0[lane][1] = k_tc0[lane][1]; s.t_tc0[lane][2] = k_tc0[lane][2]; s.t_tc0[lane][3] = 0;
+        s.t_tc0[lane] = ((uint32_t)k_tc0[lane][0] << 8) | ((uint32_t)k_tc0[lane][1] << 16) | ((uint32_t)k_tc0[lane][2] << 24);
     }
-    DeblockPtr a;
-    {
-        const ptrdiff_t x0 = -2 * g;                         /* macroblock column of step 0 (may be negative: never dereferenced then) */
-        const ptrdiff_t yy = row_ok ? mb_y : 0;
-        const ptrdiff_t xy0 = yy * W + x0;
-        a.rec = reinterpret_cast<const uint32_t *>(mi355_global(fr.mb)) + xy0 * 16 + l;
-        a.rec_top = -(ptrdiff_t)W * 16;
-        for (int li = 0; li < 2; li++) a.mv[li] = fr.mv[li] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[li])) + xy0 * 16 + l : nullptr;
-        a.mv_top = -(ptrdiff_t)W * 16 + 12;
-    }
+    /* ---- boundary-strength role of this lane: segment l >> 2 of edge l & 3, in both directions ---------------- */
+    const int seg = l >> 2, edge = l & 3;
+    const bool outer = edge == 0, odd = (edge & 1) != 0;
+    /* dir 0 (vertical edges): p = block (edge, seg), q = (edge - 1, seg) or the left neighbour's (3, seg);
+     * dir 1 (horizontal):     p = block (seg, edge), q = (seg, edge - 1) or the top neighbour's (seg, 3) */
+    const int qe = outer ? 3 : edge - 1;
+    const BsRole r0{ 1u << blk_index(edge, seg), 1u << blk_index(qe, seg), 8u * ((edge >> 1) + 2 * (seg >> 1)), 8u * ((qe >> 1) + 2 * (seg >> 1)) };
+    const BsRole r1{ 1u << blk_index(seg, edge), 1u << blk_index(seg, qe), 8u * ((seg >> 1) + 2 * (edge >> 1)), 8u * ((seg >> 1) + 2 * (qe >> 1)) };
+    /* vector offsets (bytes) from the macroblock's first vector; the neighbours' are the 16 vectors before / W * 16 before */
+    const int o_p0 = 4 * (edge + 4 * seg), o_q0 = outer ? 4 * (3 + 4 * seg) - 64 : 4 * (edge - 1 + 4 * seg);
+    const int o_p1 = 4 * (seg + 4 * edge), o_q1 = outer ? 4 * (seg + 12) - 64 * W : 4 * (seg + 4 * (edge - 1));
+    const uint8_t *const rec_base = reinterpret_cast<const uint8_t *>(mi355_global(fr.mb));
+    const uint8_t *const mv_base0 = reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[0]));
+    const uint8_t *const mv_base1 = two_lists ? reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[1])) : mv_base0;
+    /* what a lane fetches for one macroblock ahead of time (records and vectors: never written by the filter) */
+    struct Pre {
+        MbInfo h, ht;
+        uint32_t p0[2], q0[2], p1[2], q1[2];
+    };
+    auto prefetch = [&](Pre &p, int x) {
+        const bool ok = row_ok && x >= 0 && x < W;
+        const uint32_t xy = ok ? (uint32_t)(mb_y * W + x) : 0u;
+        const uint32_t roff = xy * 64u, toff = ok && has_t ? roff - 64u * (uint32_t)W : roff;
+        p.h = mb_info_load(rec_base, roff);
+        p.ht = mb_info_load(rec_base, toff);
+        /* clamped addresses: a neighbour that does not exist reads this macroblock's own vector (its strength is masked) */
+        const uint32_t a_p0 = roff + (uint32_t)o_p0, a_p1 = roff + (uint32_t)o_p1;
+        const uint32_t a_q0 = (ok && x > 0) || !outer ? roff + (uint32_t)o_q0 : a_p0;
+        const uint32_t a_q1 = (ok && has_t) || !outer ? roff + (uint32_t)o_q1 : a_p1;
+        p.p0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p0); p.q0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q0);
+        p.p1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p1); p.q1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q1);
+        p.p0[1] = p.q0[1] = p.p1[1] = p.q1[1] = 0;
+        if (two_lists) {
+            p.p0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p0); p.q0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q0);
+            p.p1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p1); p.q1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q1);
+        }
+    };
     /* chunk I/O roles of a lane: piece p of a row pair */
     const int io_p = l & (DCH - 1), io_r = l >> DCH_LOG;
     /* plane pointers once, in scalar registers: a per-lane fetch from the descriptor inside the chunk functions would
@@ -829,26 +862,15 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     };
 
     issue_chunk(0);
-    DeblockPre pre;
-    deblock_prefetch(pre, a, row_ok && g == 0, has_t, l);
+    Pre pre;
+    prefetch(pre, -2 * g);
+    MbInfo hl = pre.h;                                       /* the left neighbour's fields: last step's macroblock */
     int flushed = 0;                                         /* chunks already written back */
-#ifdef MI355_PROF
-    unsigned long long prof_t = __builtin_readcyclecounter();
-#endif
     for (int t = 0; t < nsteps; t++) {
-        PROF_MARK(7);
-        const int mb_x = t - 2 * g, par = t & 1;
+        const int mb_x = t - 2 * g;
         const int ck = t >> DCH_LOG, j = t & (DCH - 1), b = ck & 1;   /* chunk, position in it, tile parity */
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
-        const bool has_l = valid && mb_x > 0;
-        const DeblockPre cur = pre;
-        /* ---- this step's records and vectors -> LDS, FIRST: the wait for them is a wait for everything in flight (the
-         * loads are predicated, the compiler cannot count them), so it must come before this step issues any load — the
-         * chunk loads and the next step's prefetch below then have a whole step to arrive ------------------------------ */
-        reinterpret_cast<uint32_t *>(&s.hdr[g][par])[l] = cur.hw;
-        reinterpret_cast<uint32_t *>(&s.hdr[g][2])[l] = cur.hw_top;
-        s.mv[g][par][0][l] = cur.mv[0]; s.mv[g][par][1][l] = cur.mv[1];
-        if (l < 4) { s.mvt[g][0][l] = cur.mvt[0]; s.mvt[g][1][l] = cur.mvt[1]; }
+        const Pre cur = pre;
         /* ---- chunk turnover ---------------------------------------------------------------------- */
         if (j == 1 && ck >= 1) {                             /* the previous chunk got its last left-edge patch in step t-1 */
             flush_chunk(ck - 1);
@@ -856,14 +878,10 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         }
         if (j == 0) commit_chunk(ck);
         if (j == DCH_ISSUE) issue_chunk(ck + 1);             /* after the flush above: the stores go first */
-        PROF_MARK(13);
-        /* ---- phase A: next step's records and vectors ---------------------------------------------- */
-        a.advance();
-        deblock_prefetch(pre, a, row_ok && mb_x + 1 >= 0 && mb_x + 1 < W, has_t, l);
-        PROF_MARK(14);
-        /* ---- phase B: rows above from the group above --------------------------------------------------- */
-        MI355_WAVE_SYNC();                                   /* records, vectors and the chunk committed above are visible */
-        PROF_MARK(15);
+        /* ---- next step's records and vectors ------------------------------------------------------- */
+        prefetch(pre, mb_x + 1);
+        MI355_WAVE_SYNC();                                   /* the chunk committed above is visible */
+        /* ---- rows above from the group above ------------------------------------------------------- */
         if (g > 0 && valid) {
             /* macroblock x of the row above sits at position (t-2) % DCH of that group's chunk (t-2) / DCH */
             const int jb = (t - 2) & (DCH - 1), bb = ((t - 2) >> DCH_LOG) & 1;
@@ -873,135 +891,113 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                 *reinterpret_cast<uint32_t *>(&s.c[g][b][l >> 2][(l >> 1) & 1][8 * j + 4 * (l & 1)]) =
                     *reinterpret_cast<const uint32_t *>(&s.c[g - 1][bb][l >> 2][8 + ((l >> 1) & 1)][8 * jb + 4 * (l & 1)]);
         }
-        PROF_MARK(0);
-
-        /* ---- phase C: boundary strengths: lane (edge = l >> 2, segment = l & 3), both directions.  All LDS
-         * reads are issued together; the arithmetic after them has no branches. ------------------- */
-        const MbInfo h = mb_info(s.hdr[g][par]), hl = mb_info(s.hdr[g][par ^ 1]), ht = mb_info(s.hdr[g][2]);
+        /* ---- boundary strengths, in registers ------------------------------------------------------- */
+        const MbInfo &h = cur.h, &ht = cur.ht;
         const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
-        const bool have_left = filter && has_l && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
+        const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
+        const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, cur.p0, cur.q0, two_lists);
+        const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, cur.p1, cur.q1, two_lists);
+        /* the four strengths of a line: edge e of this lane's segment sits in lane e of its group of four */
+        const uint32_t bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
+        const uint32_t bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
+        /* a chroma line (row / column cr of plane cp) lies in luma segment cr >> 1 */
+        const int csrc = (lane & ~15) | ((cr >> 1) << 2);
+        const uint32_t bsc0 = (uint32_t)__shfl((int)bsw0, csrc), bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
+        /* ---- alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) ------------ */
         {
-            const int edge = l >> 2, seg = l & 3, em1 = edge ? edge - 1 : 0;
-            uint32_t mp0[2], mq0[2], mp1[2], mq1[2];
-            mp0[1] = mq0[1] = mp1[1] = mq1[1] = 0;
-            for (int li = 0; li < list_count; li++) {
-                const uint32_t *own = s.mv[g][par][li];
-                const uint32_t in0 = own[em1 + 4 * seg], in1 = own[seg + 4 * em1];
-                const uint32_t out0 = s.mv[g][par ^ 1][li][3 + 4 * seg], out1 = s.mvt[g][li][seg];
-                mp0[li] = own[edge + 4 * seg]; mp1[li] = own[seg + 4 * edge];
-                mq0[li] = edge ? in0 : out0;   mq1[li] = edge ? in1 : out1;
+            const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;          /* lanes >= 9 repeat a valid role */
+            const int kindc = kind > 2 ? 2 : kind;
+            const MbInfo &nb = kindc == 1 ? hl : ht;
+            int qa = comp ? h.qpc(comp - 1) : h.qp();
+            int qb = comp ? nb.qpc(comp - 1) : nb.qp();
+            /* chroma QP of a neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629); the table fetch
+             * (neighbour in another slice) is consumed inside its branch */
+            if (comp && kindc && nb.slice_id() != h.slice_id() && (kindc == 1 ? have_left : have_top)) {
+                int v = mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[comp - 1][nb.qp()];
+                MI355_PIN(v);
+                qb = v;
             }
-            const int b0 = filter ? bs_flat(h, hl, have_left, 0, edge, seg, mp0, mq0, list_count) : 0;
-            const int b1 = filter ? bs_flat(h, ht, have_top, 1, edge, seg, mp1, mq1, list_count) : 0;
-            s.bs[g][0][seg][edge] = (uint8_t)b0;
-            s.bs[g][1][seg][edge] = (uint8_t)b1;
+            const int qp = kindc ? (qa + qb + 1) >> 1 : qa;
+            const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
+            const uint32_t w0 = (uint32_t)s.t_alpha[ia] | ((uint32_t)s.t_beta[ib] << 8);
+            const uint32_t w1 = s.t_tc0[ia] + (comp ? 0x01010100u : 0u);
+            if (l < 9) { s.parm[g][l][0] = w0; s.parm[g][l][1] = w1; }
         }
         MI355_WAVE_SYNC();
-        PROF_MARK(1);
-        /* all strengths and all table look-ups of both directions, two LDS round trips in total */
-        const uint32_t bsw0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][l >> 2]), bsw1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][l >> 2]);
-        const uint32_t bsc0 = *reinterpret_cast<const uint32_t *>(s.bs[g][0][cr >> 1]), bsc1 = *reinterpret_cast<const uint32_t *>(s.bs[g][1][cr >> 1]);
-        const int qpc_h = h.qpc(cp);
-        /* chroma QP of a neighbour as the CURRENT slice's table sees it (h264_loopfilter.c:628-629) */
-        /* (the table fetch — neighbour in another slice — is consumed inside its branch: a wait for it after the join would
-         * be a wait for everything in flight, i.e. for the prefetch issued a moment ago, in every step) */
-        int qpc_l = hl.qpc(cp), qpc_t = ht.qpc(cp);
-        if (hl.slice_id() != h.slice_id()) {
-            int v = have_left ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][hl.qp()] : 0;
-            MI355_PIN(v);
-            qpc_l = v;
-        }
-        if (ht.slice_id() != h.slice_id()) {
-            int v = have_top ? mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[cp][ht.qp()] : 0;
-            MI355_PIN(v);
-            qpc_t = v;
-        }
-        EdgeParm ev[4], eh[4], cv[2], ch[2];
-        {
-            /* alpha / beta depend on the edge's QP only: six distinct QPs per lane (luma and chroma: inner
-             * edges, left edge, top edge); tc0 also on the line's bS */
-            const int oa = h.alpha_off(), ob = h.beta_off();
-            auto ab = [&](int qp, int &ia, int &alpha, int &beta) {
-                ia = clip3(qp + oa, 0, 51);
-                alpha = s.t_alpha[ia]; beta = s.t_beta[clip3(qp + ob, 0, 51)];
-            };
-            int ia_i, ia_l, ia_t, ic_i, ic_l, ic_t, al_i, al_l, al_t, be_i, be_l, be_t, cal_i, cal_l, cal_t, cbe_i, cbe_l, cbe_t;
-            ab(h.qp(), ia_i, al_i, be_i);
-            ab((h.qp() + hl.qp() + 1) >> 1, ia_l, al_l, be_l);
-            ab((h.qp() + ht.qp() + 1) >> 1, ia_t, al_t, be_t);
-            ab(qpc_h, ic_i, cal_i, cbe_i);
-            ab((qpc_h + qpc_l + 1) >> 1, ic_l, cal_l, cbe_l);
-            ab((qpc_h + qpc_t + 1) >> 1, ic_t, cal_t, cbe_t);
-            auto tc0 = [&](int ia, uint32_t bs) { return (int)s.t_tc0[ia][(bs - 1) & 3]; };
-            ev[0] = EdgeParm{ al_l, be_l, tc0(ia_l, bsw0 & 0xFF) };
-            eh[0] = EdgeParm{ al_t, be_t, tc0(ia_t, bsw1 & 0xFF) };
-#pragma unroll
-            for (int e = 1; e < 4; e++) {
-                ev[e] = EdgeParm{ al_i, be_i, tc0(ia_i, (bsw0 >> (8 * e)) & 0xFF) };
-                eh[e] = EdgeParm{ al_i, be_i, tc0(ia_i, (bsw1 >> (8 * e)) & 0xFF) };
-            }
-            cv[0] = EdgeParm{ cal_l, cbe_l, tc0(ic_l, bsc0 & 0xFF) }; cv[1] = EdgeParm{ cal_i, cbe_i, tc0(ic_i, (bsc0 >> 16) & 0xFF) };
-            ch[0] = EdgeParm{ cal_t, cbe_t, tc0(ic_t, bsc1 & 0xFF) }; ch[1] = EdgeParm{ cal_i, cbe_i, tc0(ic_i, (bsc1 >> 16) & 0xFF) };
-        }
-        const bool intra_v = __any(((bsw0 & 0xFF) == 4)) != 0, intra_h = __any(((bsw1 & 0xFF) == 4)) != 0;
+        const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * cp];
+        const uint32_t ab_i = pl[0], tr_i = pl[1], ab_l = pl[2], tr_l = pl[3], ab_t = pl[4], tr_t = pl[5];
+        const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_l = pc[2], ctr_l = pc[3], cab_t = pc[4], ctr_t = pc[5];
+        /* tc0 of the four edges of a line at once: byte e = row[bS_e & 3] */
+        const uint32_t tci0 = byte_perm(0, tr_i, bsw0 & 0x03030303u), tcl0 = byte_perm(0, tr_l, bsw0 & 3u);
+        const uint32_t tci1 = byte_perm(0, tr_i, bsw1 & 0x03030303u), tct1 = byte_perm(0, tr_t, bsw1 & 3u);
+        const uint32_t cci0 = byte_perm(0, ctr_i, bsc0 & 0x03030303u), ccl0 = byte_perm(0, ctr_l, bsc0 & 3u);
+        const uint32_t cci1 = byte_perm(0, ctr_i, bsc1 & 0x03030303u), cct1 = byte_perm(0, ctr_t, bsc1 & 3u);
+#define AB_A(w) ((int)((w) & 0xFF))
+#define AB_B(w) ((int)(((w) >> 8) & 0xFF))
+#define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
 
-        /* ---- phase D0: vertical edges, one luma row + one chroma row per lane, in registers.  The four
+        /* ---- vertical edges, one luma row + one chroma row per lane, in registers.  The four
          * samples left of the MB are the previous MB's last columns (previous chunk when j == 0). ----- */
         {
             uint8_t *rowp = &s.y[g][b][4 + l][16 * j];
             uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * (DCH - 1) + 12];
             const uint4 own = lds16(rowp);
-            const uint32_t left_y = *reinterpret_cast<const uint32_t *>(leftp);
-            int px[20];
-            unpack4(left_y, px);
-            unpack4(own.x, px + 4); unpack4(own.y, px + 8); unpack4(own.z, px + 12); unpack4(own.w, px + 16);
-            luma_edge(px, bsw0 & 0xFF, ev[0], intra_v);
-#pragma unroll
-            for (int e = 1; e < 4; e++) luma_edge(px + 4 * e, (bsw0 >> (8 * e)) & 0xFF, ev[e], false);   /* inner edges: bS <= 3 */
-            if (bsw0) lds16(rowp, make_uint4(pack4(px + 4), pack4(px + 8), pack4(px + 12), pack4(px + 16)));
-            if (have_left) *reinterpret_cast<uint32_t *>(leftp) = pack4(px);
+            uint32_t wl = *reinterpret_cast<const uint32_t *>(leftp), w0 = own.x, w1 = own.y, w2 = own.z, w3 = own.w;
+            const bool c0 = luma_row_edge<true>(wl, w0, BYTE(bsw0, 0), AB_A(ab_l), AB_B(ab_l), BYTE(tcl0, 0));
+            const bool c1 = luma_row_edge<false>(w0, w1, BYTE(bsw0, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 1));
+            const bool c2 = luma_row_edge<false>(w1, w2, BYTE(bsw0, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 2));
+            const bool c3 = luma_row_edge<false>(w2, w3, BYTE(bsw0, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 3));
+            if (c0) *reinterpret_cast<uint32_t *>(leftp) = wl;
+            if (c0 || c1 || c2 || c3) lds16(rowp, make_uint4(w0, w1, w2, w3));
 
             uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
             uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * (DCH - 1) + 4];
             const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
-            const uint32_t left_c = *reinterpret_cast<const uint32_t *>(cleftp);      /* columns -4..-1 */
-            int cx[10];
-            cx[0] = (left_c >> 16) & 0xFF; cx[1] = left_c >> 24;
-            unpack4(cown.x, cx + 2); unpack4(cown.y, cx + 6);
-            chroma_edge(cx + 0, bsc0 & 0xFF, cv[0]);
-            chroma_edge(cx + 4, (bsc0 >> 16) & 0xFF, cv[1]);
-            if (bsc0 & 0x00FF00FF) *reinterpret_cast<uint2 *>(crowp) = make_uint2(pack4(cx + 2), pack4(cx + 6));
-            if (have_left) *reinterpret_cast<uint32_t *>(cleftp) = (left_c & 0x0000FFFFu) | ((uint32_t)cx[0] << 16) | ((uint32_t)cx[1] << 24);
+            uint32_t cl = *reinterpret_cast<const uint32_t *>(cleftp), cw0 = cown.x, cw1 = cown.y;      /* columns -4..-1, 0..3, 4..7 */
+            const bool d0 = chroma_row_edge(cl, cw0, BYTE(bsc0, 0), AB_A(cab_l), AB_B(cab_l), BYTE(ccl0, 0));
+            const bool d1 = chroma_row_edge(cw0, cw1, BYTE(bsc0, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci0, 2));
+            if (d0) *reinterpret_cast<uint32_t *>(cleftp) = cl;
+            if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
         }
-        PROF_MARK(2);
         MI355_WAVE_SYNC();
-        PROF_MARK(3);
-        /* ---- phase D1: horizontal edges, one luma column + one chroma column per lane ------------- */
+        /* ---- horizontal edges, one luma column + one chroma column per lane ------------------------------ */
         {
-            int py[20], cy[10];
             uint8_t *colp = &s.y[g][b][0][16 * j + l];
             uint8_t *ccolp = &s.c[g][b][cp][0][8 * j + cr];
-#pragma unroll
-            for (int k = 0; k < 20; k++) py[k] = colp[k * DY_PITCH];
-#pragma unroll
-            for (int k = 0; k < 10; k++) cy[k] = ccolp[k * DC_PITCH];
-            luma_edge(py, bsw1 & 0xFF, eh[0], intra_h);
-#pragma unroll
-            for (int e = 1; e < 4; e++) luma_edge(py + 4 * e, (bsw1 >> (8 * e)) & 0xFF, eh[e], false);
-            chroma_edge(cy + 0, bsc1 & 0xFF, ch[0]);
-            chroma_edge(cy + 4, (bsc1 >> 16) & 0xFF, ch[1]);
-            if (bsw1) {
-#pragma unroll
-                for (int k = 1; k < 19; k++) colp[k * DY_PITCH] = (uint8_t)py[k];
+            int y0 = colp[0 * DY_PITCH], y1 = colp[1 * DY_PITCH], y2 = colp[2 * DY_PITCH], y3 = colp[3 * DY_PITCH];
+            int y4 = colp[4 * DY_PITCH], y5 = colp[5 * DY_PITCH], y6 = colp[6 * DY_PITCH], y7 = colp[7 * DY_PITCH];
+            int y8 = colp[8 * DY_PITCH], y9 = colp[9 * DY_PITCH], y10 = colp[10 * DY_PITCH], y11 = colp[11 * DY_PITCH];
+            int y12 = colp[12 * DY_PITCH], y13 = colp[13 * DY_PITCH], y14 = colp[14 * DY_PITCH], y15 = colp[15 * DY_PITCH];
+            int y16 = colp[16 * DY_PITCH], y17 = colp[17 * DY_PITCH], y18 = colp[18 * DY_PITCH];
+            int u0 = ccolp[0 * DC_PITCH], u1 = ccolp[1 * DC_PITCH], u2 = ccolp[2 * DC_PITCH], u3 = ccolp[3 * DC_PITCH];
+            int u4 = ccolp[4 * DC_PITCH], u5 = ccolp[5 * DC_PITCH], u6 = ccolp[6 * DC_PITCH], u7 = ccolp[7 * DC_PITCH];
+            const int e0 = luma_line<true>(y0, y1, y2, y3, y4, y5, y6, y7, BYTE(bsw1, 0), AB_A(ab_t), AB_B(ab_t), BYTE(tct1, 0));
+            if (e0) {
+                if (e0 == 2) { colp[1 * DY_PITCH] = (uint8_t)y1; colp[6 * DY_PITCH] = (uint8_t)y6; }
+                colp[2 * DY_PITCH] = (uint8_t)y2; colp[3 * DY_PITCH] = (uint8_t)y3; colp[4 * DY_PITCH] = (uint8_t)y4; colp[5 * DY_PITCH] = (uint8_t)y5;
             }
-            if (bsc1 & 0x00FF00FF) {
-#pragma unroll
-                for (int k = 1; k < 9; k++) ccolp[k * DC_PITCH] = (uint8_t)cy[k];
+            if (luma_line<false>(y4, y5, y6, y7, y8, y9, y10, y11, BYTE(bsw1, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 1))) {
+                colp[6 * DY_PITCH] = (uint8_t)y6; colp[7 * DY_PITCH] = (uint8_t)y7; colp[8 * DY_PITCH] = (uint8_t)y8; colp[9 * DY_PITCH] = (uint8_t)y9;
+            }
+            if (luma_line<false>(y8, y9, y10, y11, y12, y13, y14, y15, BYTE(bsw1, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 2))) {
+                colp[10 * DY_PITCH] = (uint8_t)y10; colp[11 * DY_PITCH] = (uint8_t)y11; colp[12 * DY_PITCH] = (uint8_t)y12; colp[13 * DY_PITCH] = (uint8_t)y13;
+            }
+            int y19 = 0;
+            if (luma_line<false>(y12, y13, y14, y15, y16, y17, y18, y19, BYTE(bsw1, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 3))) {
+                colp[14 * DY_PITCH] = (uint8_t)y14; colp[15 * DY_PITCH] = (uint8_t)y15; colp[16 * DY_PITCH] = (uint8_t)y16; colp[17 * DY_PITCH] = (uint8_t)y17;
+            }
+            if (chroma_line(u0, u1, u2, u3, BYTE(bsc1, 0), AB_A(cab_t), AB_B(cab_t), BYTE(cct1, 0))) {
+                ccolp[1 * DC_PITCH] = (uint8_t)u1; ccolp[2 * DC_PITCH] = (uint8_t)u2;
+            }
+            if (chroma_line(u4, u5, u6, u7, BYTE(bsc1, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci1, 2))) {
+                ccolp[5 * DC_PITCH] = (uint8_t)u5; ccolp[6 * DC_PITCH] = (uint8_t)u6;
             }
         }
-        PROF_MARK(4);
+#undef AB_A
+#undef AB_B
+#undef BYTE
         MI355_WAVE_SYNC();   /* the tile is final for this macroblock: the group below and the next step may read it */
-        PROF_MARK(5);
+        hl = h;
     }
     /* chunks still in LDS */
     for (int c = flushed; c <= (nsteps - 1) >> DCH_LOG; c++) flush_chunk(c);
