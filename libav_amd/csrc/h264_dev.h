@@ -78,6 +78,18 @@ __device__ __forceinline__ bool pk_absdiff_far(uint32_t a, uint32_t b)
 }
 #endif
 
+/* a * b + c for operands known to fit 24 bits (v_mad_i32_i24: one instruction, no 32-bit multiply sequence) */
+#ifdef MI355_HIP_EMU_H
+static inline int mad24i(int a, int b, int c) { return a * b + c; }
+#else
+__device__ __forceinline__ int mad24i(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
+
 /* a value every lane of the wave holds identically (read from this wave's LDS record): telling the
  * compiler moves everything derived from it to the scalar unit */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -119,7 +131,7 @@ __device__ __forceinline__ int px_clamped(const PlaneRef &p, int x, int y)
  * of the block reads whole dwords; chroma window byte b of row r is sample (cx + b, cy + r). */
 constexpr int WY_DW = 6;                /* luma window row: 24 bytes = columns -4..19 of the block */
 constexpr int WC_DW = 3;                /* chroma window row: 12 bytes = columns 0..11 */
-struct McScratch {
+struct __attribute__((aligned(8))) McScratch {
     uint32_t winY[21 * WY_DW];          /* up to 21 rows (16 + 5) */
     uint32_t winC[2][9 * WC_DW];
     int16_t tmp[21 * 16];               /* unclipped horizontal 6-tap sums for the centre position */
@@ -227,6 +239,40 @@ __device__ inline void stage_windows(McScratch &s, const PlaneRef *y, int ix, in
     __syncthreads();
 }
 
+/* The same for a whole 16x16 macroblock partition (the common shape) with every size a literal: the 21 x 24-byte luma
+ * window goes out as 63 eight-byte pieces (one round of loads: three dwords per lane, realigned with two
+ * v_alignbyte), the two 9 x 12-byte chroma windows as 36 pieces in a second round, all five loads in flight
+ * before the first LDS write.  Windows that touch the picture border take the clamped generic path. */
+__device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, int iy, const PlaneRef &cb, const PlaneRef &cr, int cx, int cy)
+{
+    const int lane = lane_id();
+    const int x0 = ix - 4, y0 = iy - 2;
+    if (!win_inside(y, x0, y0, WY_DW, 21) || !win_inside(cb, cx, cy, WC_DW, 9)) {
+        stage_windows(s, &y, ix, iy, 16, 16, &cb, &cr, cx, cy, 8, 8);
+        return;
+    }
+    /* luma: lane t -> row t / 3, piece t % 3 (lane 63 repeats the last piece) */
+    const int t = lane < 63 ? lane : 62;
+    const int row = (t * 43) >> 7, piece = t - 3 * row;
+    const uint32_t *ly = reinterpret_cast<const uint32_t *>(y.base + (ptrdiff_t)(y0 + row) * y.stride + (x0 & ~3) + 8 * piece);
+    const uint32_t a0 = ly[0], a1 = ly[1], a2 = ly[2];
+    /* chroma: lane u < 36 -> plane u / 18, row (u % 18) / 2, piece u & 1: piece 0 = bytes 0..7 (source dwords 0..2),
+     * piece 1 = bytes 8..11 (source dwords 2, 3) */
+    const int u = lane < 36 ? lane : 35;
+    const int plane = u >= 18, r2 = u - 18 * plane, crow = r2 >> 1, cpiece = r2 & 1;
+    const uint8_t *cbase = (plane ? cr.base : cb.base) + (ptrdiff_t)(cy + crow) * cb.stride + (cx & ~3);
+    const uint32_t *lc = reinterpret_cast<const uint32_t *>(cbase + 8 * cpiece);
+    const uint32_t c0 = lc[0], c1 = lc[1], c2 = *reinterpret_cast<const uint32_t *>(cbase + 8);
+    const uint32_t shy = (uint32_t)x0 & 3, shc = (uint32_t)cx & 3;
+    typedef uint32_t u32x2 __attribute__((vector_size(8)));
+    *reinterpret_cast<u32x2 *>(&s.winY[row * WY_DW + 2 * piece]) = u32x2{ mi355_alignbyte(a1, a0, shy), mi355_alignbyte(a2, a1, shy) };
+    uint32_t *wc = &s.winC[plane][crow * WC_DW];
+    const uint32_t v0 = mi355_alignbyte(c1, c0, shc), v1 = mi355_alignbyte(c2, c1, shc);
+    if (cpiece) wc[2] = v0;
+    else { wc[0] = v0; wc[1] = v1; }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int *v)
 {
 #pragma unroll
@@ -243,6 +289,9 @@ static inline int pk_lo(uint32_t a) { return (int16_t)(a & 0xFFFF); }
 static inline int pk_hi(uint32_t a) { return (int16_t)(a >> 16); }
 static inline uint32_t pk_add(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
 static inline uint32_t pk_mad(uint32_t a, int k, uint32_t c) { return pk_make(pk_lo(a) * k + pk_lo(c), pk_hi(a) * k + pk_hi(c)); }
+static inline uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) - pk_lo(b), pk_hi(a) - pk_hi(b)); }
+static inline int pk_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+static inline uint32_t pk_adds(uint32_t a, uint32_t b) { return pk_make(pk_sat16(pk_lo(a) + pk_lo(b)), pk_sat16(pk_hi(a) + pk_hi(b))); }
 static inline uint32_t pk_ashr(uint32_t a, int n) { return pk_make(pk_lo(a) >> n, pk_hi(a) >> n); }
 static inline uint32_t pk_clip_u8(uint32_t a)
 {
@@ -256,6 +305,8 @@ __device__ __forceinline__ uint32_t pk_u(mi355_v2s a) { return __builtin_bit_cas
 __device__ __forceinline__ uint32_t pk_make(int lo, int hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)hi << 16); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_u(pk_v(a) + pk_v(b)); }
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, int k, uint32_t c) { return pk_u(pk_v(a) * (mi355_v2s)((short)k) + pk_v(c)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_u(pk_v(a) - pk_v(b)); }
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }   /* saturating */
 __device__ __forceinline__ uint32_t pk_ashr(uint32_t a, int n) { return pk_u(pk_v(a) >> (mi355_v2s)((short)n)); }
 __device__ __forceinline__ uint32_t pk_clip_u8(uint32_t a)
 {
@@ -347,20 +398,22 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
             so = pk_add(so, pk_round5(pk_tap6(o[0], o[1], o[2], o[3], o[4], o[5])));
         }
         if (use_j) {
-            /* second pass over the unclipped first-pass sums: 32-bit arithmetic (sums reach +-430 000) */
-            int jv[4];
+            /* second pass over the unclipped first-pass sums, two samples per instruction.  The sums reach +-430 000, but
+             * (a - 5 b + 20 c + 512) >> 10 == ((((a - b) >> 2) - b + c) >> 2) + c + 32) >> 6 exactly (nested floors), and
+             * with a, b, c (sums of two rows each) in -5100..21420 only the "+ c" of the inner bracket can leave int16
+             * (+-33150): that addition saturates, which moves the bracket only when the final value is already beyond
+             * 0..255 on the same side (c >= 21037 resp. <= -4718 there), so the clipped sample is unchanged. */
             const uint32_t *t = reinterpret_cast<const uint32_t *>(&s.tmp[y * 16 + 4 * sx]);
-            uint32_t lo[6], hi[6];
+            uint32_t jv[2];
 #pragma unroll
-            for (int r = 0; r < 6; r++) { lo[r] = t[8 * r]; hi[r] = t[8 * r + 1]; }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int tv[6];
-#pragma unroll
-                for (int r = 0; r < 6; r++) { const uint32_t w = k < 2 ? lo[r] : hi[r]; tv[r] = (k & 1) ? (int16_t)(w >> 16) : (int16_t)(w & 0xFFFF); }
-                jv[k] = clip_u8((tap6(tv[0], tv[1], tv[2], tv[3], tv[4], tv[5]) + 512) >> 10);
+            for (int hlf = 0; hlf < 2; hlf++) {
+                const uint32_t af = pk_add(t[hlf], t[40 + hlf]), be = pk_add(t[8 + hlf], t[32 + hlf]), cd = pk_add(t[16 + hlf], t[24 + hlf]);
+                const uint32_t t1 = pk_ashr(pk_sub(af, be), 2);
+                const uint32_t t2 = pk_ashr(pk_adds(pk_sub(t1, be), cd), 2);
+                jv[hlf] = pk_clip_u8(pk_ashr(pk_add(pk_add(t2, cd), 0x00200020u), 6));
             }
-            se = pk_add(se, pk_make(jv[0], jv[2])); so = pk_add(so, pk_make(jv[1], jv[3]));
+            /* samples (0,1), (2,3) -> pairs (0,2), (1,3) */
+            se = pk_add(se, byte_perm(jv[1], jv[0], 0x05040100u)); so = pk_add(so, byte_perm(jv[1], jv[0], 0x07060302u));
         }
         if ((int)use_g + (int)use_b + (int)use_h + (int)use_j == 2) {
             se = pk_ashr(pk_add(se, 0x00010001u), 1); so = pk_ashr(pk_add(so, 0x00010001u), 1);
@@ -409,6 +462,28 @@ __device__ inline void mc_chroma_compute(McScratch &s, int nplanes, int fx, int 
     __syncthreads();
 }
 
+/* The 8x8 chroma blocks of a 16x16 partition, both planes at once on all 64 lanes: a lane produces two neighbouring
+ * samples (plane lane >> 5, row (lane >> 2) & 7, columns 2c, 2c + 1 with c = lane & 3) from the three window bytes
+ * 2c .. 2c + 2 of two rows, spread to 16-bit pairs with v_perm_b32.  Same arithmetic as mc_chroma_compute. */
+__device__ inline void mc_chroma16(McScratch &s, int fx, int fy, uint8_t *pred0, uint8_t *pred1, int ppitch, int avg)
+{
+    const int lane = lane_id();
+    const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
+    const int plane = lane >> 5, y = (lane >> 2) & 7, c = lane & 3;
+    const uint32_t *w0 = &s.winC[plane][y * WC_DW + (c >> 1)], *w1 = w0 + WC_DW;
+    const uint32_t sh = 2u * (uint32_t)(c & 1);
+    const uint32_t r0 = mi355_alignbyte(w0[1], w0[0], sh), r1 = mi355_alignbyte(w1[1], w1[0], sh);
+    const uint32_t a0 = byte_perm(0, r0, 0x0C010C00u), a1 = byte_perm(0, r0, 0x0C020C01u);
+    const uint32_t b0 = byte_perm(0, r1, 0x0C010C00u), b1 = byte_perm(0, r1, 0x0C020C01u);
+    /* (A a + B b + C c + D d + 32) >> 6 on packed pairs: the sums stay below 2^14 */
+    const uint32_t v = pk_ashr(pk_mad(a0, A, pk_mad(a1, B, pk_mad(b0, C, pk_mad(b1, D, 0x00200020u)))), 6);
+    uint32_t two = byte_perm(0, v, 0x0C0C0200u);
+    uint16_t *d = reinterpret_cast<uint16_t *>((plane ? pred1 : pred0) + y * ppitch + 2 * c);
+    if (avg) two = rnd_avg4(*d, two);
+    *d = (uint16_t)two;
+    __syncthreads();
+}
+
 /* ---- a7: explicit / implicit weighted prediction (h264dsp_template.c:30-98) -- */
 __device__ inline void weight_block(uint8_t *p, int pitch, int bw, int bh, int log2_denom, int w, int o)
 {
@@ -445,14 +520,16 @@ __device__ __forceinline__ void idct4_quad(const int c[4], int j, int r[4], int 
     const int c0 = j == 0 ? (int16_t)(c[0] + 32) : c[0];
     const int e0 = c0 + c[2], e1 = c0 - c[2], e2 = (c[1] >> 1) - c[3], e3 = c[1] + (c[3] >> 1);
     const int b[4] = { (int16_t)(e0 + e3), (int16_t)(e1 + e2), (int16_t)(e1 - e2), (int16_t)(e0 - e3) };
-    const bool odd = j & 1, hi = j >= 2;
+    /* the cross-lane pass with lane constants instead of selects: lanes 0..3 form z0 = v0 + v2, z3 = v1 + (v3 >> 1),
+     * z1 = v0 - v2, z2 = (v1 >> 1) - v3 from their own value and the one two lanes away (a shift by 0 / 1 and a
+     * multiply-add by +-1; all operands fit 24 bits: int16 inputs, sums below 2^17), then z0 +- z3 / z1 +- z2 with the
+     * neighbour */
+    const int sh = j & 1, sg1 = j >= 2 ? -1 : 1, sg2 = (j & 1) ? -1 : 1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int v = b[k];
-        const int p = quad_xor2(v);
-        const int s = (odd ? p >> 1 : p) + (hi ? -v : v);      /* z0, z3, z1, z2 on lanes 0..3 */
-        const int o = quad_xor1(s);
-        r[k] = (odd ? o - s : o + s) >> 6;
+        const int s = mad24i(v, sg1, quad_xor2(v) >> sh);     /* z0, z3, z1, z2 on lanes 0..3 */
+        r[k] = mad24i(s, sg2, quad_xor1(s)) >> 6;
     }
     row = j == 0 ? 0 : (j == 1 ? 3 : (j == 2 ? 1 : 2));
 }

@@ -39,6 +39,10 @@ struct MbLds {
     int16_t coef[384];
     uint8_t py[16 * 16], pc[2][8 * 8];       /* prediction -> reconstruction */
     uint8_t qy[16 * 16], qc[2][8 * 8];       /* second prediction for weighted bi-pred */
+    uint8_t slot[24];                        /* residual_blocks: the blocks that carry a residual, compacted */
+#ifdef MI355_EXP_LDS_PAD                     /* developer experiment: fewer waves per CU */
+    uint8_t exp_pad[MI355_EXP_LDS_PAD];
+#endif
     McScratch mc;
 };
 
@@ -103,13 +107,15 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, con
     PlaneRef rb{mi355_global(fr.ref[slot][1]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     PlaneRef rr{mi355_global(fr.ref[slot][2]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
 #ifndef MI355_EXP_NO_STAGE
-    stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
+    if (w == 16 && h == 16) stage_windows16(s.mc, ry, mx >> 2, my >> 2, rb, rr, mx >> 3, my >> 3);
+    else stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
 #endif
 #ifndef MI355_EXP_NO_LUMA
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
 #endif
 #ifndef MI355_EXP_NO_CHROMA
-    mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
+    if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, my & 7, pcb, pcr, 8, avg);
+    else mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
 #endif
 }
 
@@ -265,6 +271,53 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
     __syncthreads();
 }
 
+/* Residual of an inter macroblock with 4x4 transforms, luma and chroma in ONE pass over the blocks that carry
+ * anything: a block is listed when its nnz bit is set (full transform, h264idct_template.c:33-67) or, for chroma, when
+ * it has a DC value after ff_h264_chroma_dc_dequant_idct (h264_idct_dc_add :144-156: (dc + 32) >> 6 in int).  With
+ * half of the 24 blocks coded a wave transforms 12 blocks on 48 lanes instead of 16 + 8 block slots in two passes.
+ * Coefficient block b starts at coef[16 * b] and its nnz bit is bit b for luma, Cb and Cr alike.
+ * Same results as residual_luma + residual_chroma (h264_mb.c:726-795, h264_mb_template.c:196-247). */
+template <bool ALIGNED>
+__device__ inline void residual_blocks(MbLds &s)
+{
+    const int lane = lane_id();
+    const uint32_t nnz = (uint32_t)uniform((int)s.hdr.nnz_mask);
+    uint32_t mask = nnz & 0xFFFFu;
+    if (uniform(s.hdr.cbp) & 0x30) {
+        if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
+            int16_t *p = s.coef + 256 + 64 * lane;
+            int a = p[0], b = p[16], c = p[32], d = p[48];
+            chroma_dc_dequant(a, b, c, d, (int)s.hdr.dc_qmul[1 + lane]);
+            p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
+        }
+        __syncthreads();
+        const bool need = lane >= 16 && lane < 24 && (((nnz >> lane) & 1) || s.coef[16 * lane] != 0);
+        mask |= (uint32_t)uniform((int)(uint32_t)__ballot(need));
+    }
+    if (!mask) return;
+    const int n = __popc(mask);
+    if (lane < 24 && ((mask >> lane) & 1)) s.slot[__popc(mask & ((1u << lane) - 1u))] = (uint8_t)lane;
+    __syncthreads();
+    const int k = lane >> 2, q = lane & 3;
+#pragma nounroll
+    for (int base = 0; base < n; base += 16) {
+        const bool act = base + k < n;
+        const int b = s.slot[act ? base + k : 0];
+        int c[4], r[4], row;
+#pragma unroll
+        for (int i = 0; i < 4; i++) c[i] = s.coef[b * 16 + q + 4 * i];
+        const int dc = quad_bcast<0>(c[0]);
+        idct4_quad(c, q, r, row);
+        if (!((nnz >> b) & 1)) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;       /* DC only: h264_idct_dc_add, no int16 wrap */
+        /* destination: luma block b of py (pitch 16) or chroma block (b - 16) & 3 of pc[(b - 16) >> 2] (pitch 8) */
+        const int jj = b & 3;
+        uint8_t *d = b < 16 ? s.py + (4 * blk_y4(b) + row) * 16 + 4 * blk_x4(b)
+                            : s.pc[(b >> 2) & 1] + (4 * (jj >> 1) + row) * 8 + 4 * (jj & 1);
+        if (act) add_row4<ALIGNED>(d, r);
+    }
+    __syncthreads();
+}
+
 /* tile (LDS) -> picture, 4 bytes per lane */
 template <bool ALIGNED>
 __device__ __forceinline__ uint32_t tile_dword(const uint8_t *p)
@@ -328,9 +381,12 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     PROF_MARK(9);
 #ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
-    if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma<true>(s, s.py, 16, false);
-    PROF_MARK(10);
-    residual_chroma<true>(s, s.pc[0], s.pc[1], 8);
+    if (uniform((int)s.hdr.mb_type) & MI355_MB_8x8DCT) {
+        if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma<true>(s, s.py, 16, false);
+        residual_chroma<true>(s, s.pc[0], s.pc[1], 8);
+    } else {
+        residual_blocks<true>(s);
+    }
     PROF_MARK(11);
 #endif
     /* (several macroblocks per wave with the next one's record, vectors and coefficients in flight: two per wave,

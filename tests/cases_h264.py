@@ -219,7 +219,11 @@ def cases_startcode(c, r, out):
     if not c.startcode_find_candidate:
         return
     for rep in range(6):
-        buf = r.randint(1, 255, 300).astype(np.uint8)
+        # the reference scans eight bytes at a time and may look up to 7 bytes past `size` (its callers pad their
+        # buffers with zeros, AV_INPUT_BUFFER_PADDING_SIZE): give it that padding, or the result of a buffer without
+        # a zero byte depends on whatever follows it in memory
+        buf = np.zeros(308, np.uint8)
+        buf[:300] = r.randint(1, 255, 300).astype(np.uint8)
         if rep:
             buf[r.randint(0, 299)] = 0
         out["startcode/%d" % rep] = bytes([c.startcode_find_candidate(p8(buf), 300) & 0xFF])
@@ -242,6 +246,36 @@ def cases_qpel(q, r, out):
                     fn(p8(dst, 4 * stride + (size if size < 16 else 0)), p8(src, 5 * stride + 5), stride)
                     assert (src == keep).all()
                     out["qpel_%s%d/%d/%d" % (tabname, size, pos, rep)] = dst.tobytes()
+
+
+def cases_qpel_extreme(q, r, out):
+    """Adversarial inputs for the centre (hv) positions: sample patterns that drive the unclipped first-pass sums to
+    their extremes (rows of 255 0 255 255 0 255 ... give +10710, their complement -2550), stacked so that the second pass
+    reaches +-475 000 — the values where a 16-bit formulation of the second pass would have to wrap or saturate."""
+    base = np.array([255, 0, 255, 255, 0, 255], np.uint8)
+    hi = np.tile(base, 6)[:32]                  # horizontal sum at the pattern's phase: 10710
+    lo = 255 - hi                               # -2550
+    patterns = {
+        "max": [hi, lo, hi, hi, lo, hi],        # vertical taps (1,-5,20,20,-5,1) all aligned with the signs
+        "min": [lo, hi, lo, lo, hi, lo],
+        "flat255": [np.full(32, 255, np.uint8)] * 6,
+        "checker": [hi, lo] * 3,
+    }
+    for pname, rows in patterns.items():
+        for phase in range(6):
+            src = np.zeros((32, 32), np.uint8)
+            for y in range(32):
+                src[y] = np.roll(rows[(y + phase) % 6], phase)
+            for tabname, tab, sizes in (("put", q.put_h264_qpel_pixels_tab, (0, 1, 2)), ("avg", q.avg_h264_qpel_pixels_tab, (0,))):
+                for si in sizes:
+                    size = 16 >> si
+                    for pos in (6, 9, 10, 11, 14, 5, 7, 13, 15):      # every position that involves the hv plane, + diagonals
+                        fn = tab[si][pos]
+                        if not fn:
+                            continue
+                        dst = r.u8((32, 32))
+                        fn(p8(dst, 4 * 32 + (size if size < 16 else 0)), p8(src, 5 * 32 + 5), 32)
+                        out["qpelx_%s_%s%d/%d/%d" % (pname, tabname, size, pos, phase)] = dst.tobytes()
 
 
 def cases_chroma(ch, r, out):
@@ -456,6 +490,7 @@ GROUPS = OrderedDict([
     ("pred_add", ("h264pred", cases_pred_add)),
     ("dsp422", ("h264dsp", cases_dsp422, 8, 2)),
     ("pred422", ("h264pred", cases_pred422, 8, 2)),
+    ("qpel_extreme", ("h264qpel", cases_qpel_extreme)),
 ])
 
 

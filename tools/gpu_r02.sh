@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 if [ "$MODE" = quick ]; then
-  timeout 600 python -m pytest tests/test_frame_gpu.py tests/test_stream_parity.py -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"
+  timeout 900 python -m pytest tests/test_frame_gpu.py tests/test_stream_parity.py tests/test_tier1_gpu.py -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"
 else
   timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"
 fi

@@ -68,6 +68,7 @@ static inline int __shfl_down(int v, unsigned d, int w = 64) { return simt_emu::
 static inline unsigned long long __ballot(int p) { return simt_emu::ballot(p); }
 static inline int __any(int p) { return simt_emu::ballot(p) != 0; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  /* wave-uniform by contract */
