@@ -3,8 +3,8 @@
  *
  * Execution model used by every kernel in this library: ONE 64-lane wavefront per
  * workgroup, one macroblock (or one DSP call) per wavefront, all staging in that
- * wave's own LDS.  `__syncthreads()` therefore only orders this wave's LDS
- * traffic (with __launch_bounds__(64) the compiler drops the s_barrier).  Every
+ * wave's own LDS.  Ordering points are MI355_WAVE_SYNC() (below): wave scope, no drain of the
+ * loads and stores in flight — a kernel may keep the next macroblock's loads outstanding across them.  Every
  * function here must be called by all 64 lanes with wave-uniform arguments unless
  * it is marked "per lane".
  *
@@ -23,7 +23,13 @@ __device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 25
 __device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
+#ifdef MI355_HIP_EMU_H
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#else
+/* opaque to the optimiser at every call: values derived from the lane number inside a loop are recomputed there (a few
+ * VALU) instead of being hoisted into registers that stay live across the whole loop body */
+__device__ __forceinline__ int lane_id() { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); __builtin_assume(l >= 0 && l < 64); return l; }
+#endif
 /* exchange inside groups of four lanes as a DPP operand modifier (quad_perm) instead of an LDS-routed shuffle */
 #ifdef MI355_HIP_EMU_H
 static inline int quad_xor1(int v) { return __shfl_xor(v, 1); }
@@ -88,6 +94,13 @@ __device__ __forceinline__ int mad24i(int a, int b, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+#endif
+
+/* the value lane `l` (a literal) of the wave holds, as a scalar */
+#ifdef MI355_HIP_EMU_H
+static inline int lane_value(int v, int l) { return __shfl(v, l); }
+#else
+__device__ __forceinline__ int lane_value(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 #endif
 
 /* a value every lane of the wave holds identically (read from this wave's LDS record): telling the
@@ -172,7 +185,7 @@ struct WinLoad {
 #pragma unroll
             for (int k = 0; k < MAXIT; k++) {
                 const int row = r0 + k * (64 >> sh), rc = row < wh ? row : wh - 1;
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)rc * ref.stride);
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + __mul24(rc, ref.stride));
                 lo[k] = p[0];
                 hi[k] = p[1];
             }
@@ -236,41 +249,65 @@ __device__ inline void stage_windows(McScratch &s, const PlaneRef *y, int ix, in
     }
     if (y) ly.commit(s.winY, WY_DW, ydw, bh + 5, lane);
     if (cb) { lb.commit(s.winC[0], WC_DW, cdw, ch + 1, lane); lr.commit(s.winC[1], WC_DW, cdw, ch + 1, lane); }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* The same for a whole 16x16 macroblock partition (the common shape) with every size a literal: the 21 x 24-byte luma
  * window goes out as 63 eight-byte pieces (one round of loads: three dwords per lane, realigned with two
  * v_alignbyte), the two 9 x 12-byte chroma windows as 36 pieces in a second round, all five loads in flight
- * before the first LDS write.  Windows that touch the picture border take the clamped generic path. */
+ * before the first LDS write.  issue() only starts the loads (a caller may keep them in flight across other work:
+ * k_recon_inter requests the next macroblock's windows before it computes the current one), commit() moves them into
+ * the LDS windows.  Only for windows that lie inside the picture (win16_inside); others take the clamped generic path. */
+struct Win16 {
+    uint32_t a0, a1, a2, c0, c1, c2;
+    __device__ __forceinline__ void issue(const uint8_t *yb, const uint8_t *cbb, const uint8_t *crb, int ystride, int cstride, int ix, int iy, int cx, int cy)
+    {
+        const int lane = lane_id();
+        const int x0 = ix - 4, y0 = iy - 2;
+        /* luma: lane t -> row t / 3, piece t % 3 (lane 63 repeats the last piece) */
+        const int t = lane < 63 ? lane : 62;
+        /* offsets in 32 bits through 24-bit multiplies: a 64-bit multiply-add per lane costs four issue slots */
+        const int row = (int)(__umul24((unsigned)t, 43u) >> 7), piece = t - 3 * row;
+        const uint32_t *ly = reinterpret_cast<const uint32_t *>(yb + (uint32_t)(__mul24(y0 + row, ystride) + (x0 & ~3) + 8 * piece));
+        a0 = ly[0]; a1 = ly[1]; a2 = ly[2];
+        /* chroma: lane u < 36 -> plane u / 18, row (u % 18) / 2, piece u & 1: piece 0 = bytes 0..7 (source dwords 0..2),
+         * piece 1 = bytes 8..11 (source dwords 2, 3) */
+        const int u = lane < 36 ? lane : 35;
+        const int plane = u >= 18, r2 = u - 18 * plane, crow = r2 >> 1, cpiece = r2 & 1;
+        const uint8_t *cbase = (plane ? crb : cbb) + (uint32_t)(__mul24(cy + crow, cstride) + (cx & ~3));
+        const uint32_t *lc = reinterpret_cast<const uint32_t *>(cbase + 8 * cpiece);
+        c0 = lc[0]; c1 = lc[1]; c2 = *reinterpret_cast<const uint32_t *>(cbase + 8);
+    }
+    __device__ __forceinline__ void commit(McScratch &s, int ix, int cx) const
+    {
+        const int lane = lane_id();
+        const int t = lane < 63 ? lane : 62;
+        const int row = (int)(__umul24((unsigned)t, 43u) >> 7), piece = t - 3 * row;
+        const int u = lane < 36 ? lane : 35;
+        const int plane = u >= 18, r2 = u - 18 * plane, crow = r2 >> 1, cpiece = r2 & 1;
+        const uint32_t shy = (uint32_t)(ix - 4) & 3, shc = (uint32_t)cx & 3;
+        typedef uint32_t u32x2 __attribute__((vector_size(8)));
+        *reinterpret_cast<u32x2 *>(&s.winY[__umul24((unsigned)row, WY_DW) + 2u * (unsigned)piece]) = u32x2{ mi355_alignbyte(a1, a0, shy), mi355_alignbyte(a2, a1, shy) };
+        uint32_t *wc = &s.winC[plane][__umul24((unsigned)crow, WC_DW)];
+        const uint32_t v0 = mi355_alignbyte(c1, c0, shc), v1 = mi355_alignbyte(c2, c1, shc);
+        if (cpiece) wc[2] = v0;
+        else { wc[0] = v0; wc[1] = v1; }
+    }
+};
+__device__ __forceinline__ bool win16_inside(const PlaneRef &y, int ix, int iy, const PlaneRef &cb, int cx, int cy)
+{
+    return win_inside(y, ix - 4, iy - 2, WY_DW, 21) && win_inside(cb, cx, cy, WC_DW, 9);
+}
 __device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, int iy, const PlaneRef &cb, const PlaneRef &cr, int cx, int cy)
 {
-    const int lane = lane_id();
-    const int x0 = ix - 4, y0 = iy - 2;
-    if (!win_inside(y, x0, y0, WY_DW, 21) || !win_inside(cb, cx, cy, WC_DW, 9)) {
+    if (!win16_inside(y, ix, iy, cb, cx, cy)) {
         stage_windows(s, &y, ix, iy, 16, 16, &cb, &cr, cx, cy, 8, 8);
         return;
     }
-    /* luma: lane t -> row t / 3, piece t % 3 (lane 63 repeats the last piece) */
-    const int t = lane < 63 ? lane : 62;
-    const int row = (t * 43) >> 7, piece = t - 3 * row;
-    const uint32_t *ly = reinterpret_cast<const uint32_t *>(y.base + (ptrdiff_t)(y0 + row) * y.stride + (x0 & ~3) + 8 * piece);
-    const uint32_t a0 = ly[0], a1 = ly[1], a2 = ly[2];
-    /* chroma: lane u < 36 -> plane u / 18, row (u % 18) / 2, piece u & 1: piece 0 = bytes 0..7 (source dwords 0..2),
-     * piece 1 = bytes 8..11 (source dwords 2, 3) */
-    const int u = lane < 36 ? lane : 35;
-    const int plane = u >= 18, r2 = u - 18 * plane, crow = r2 >> 1, cpiece = r2 & 1;
-    const uint8_t *cbase = (plane ? cr.base : cb.base) + (ptrdiff_t)(cy + crow) * cb.stride + (cx & ~3);
-    const uint32_t *lc = reinterpret_cast<const uint32_t *>(cbase + 8 * cpiece);
-    const uint32_t c0 = lc[0], c1 = lc[1], c2 = *reinterpret_cast<const uint32_t *>(cbase + 8);
-    const uint32_t shy = (uint32_t)x0 & 3, shc = (uint32_t)cx & 3;
-    typedef uint32_t u32x2 __attribute__((vector_size(8)));
-    *reinterpret_cast<u32x2 *>(&s.winY[row * WY_DW + 2 * piece]) = u32x2{ mi355_alignbyte(a1, a0, shy), mi355_alignbyte(a2, a1, shy) };
-    uint32_t *wc = &s.winC[plane][crow * WC_DW];
-    const uint32_t v0 = mi355_alignbyte(c1, c0, shc), v1 = mi355_alignbyte(c2, c1, shc);
-    if (cpiece) wc[2] = v0;
-    else { wc[0] = v0; wc[1] = v1; }
-    __syncthreads();
+    Win16 w;
+    w.issue(y.base, cb.base, cr.base, y.stride, cb.stride, ix, iy, cx, cy);
+    w.commit(s, ix, cx);
+    MI355_WAVE_SYNC();
 }
 
 __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int *v)
@@ -356,7 +393,7 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
         /* unclipped horizontal sums of all bh+5 rows, 4 per lane */
         for (int i = lane; i < wh * nseg; i += 64) {
             const int r = i >> lseg, sx = i & (nseg - 1);
-            const uint32_t *w = &s.winY[r * WY_DW + sx];
+            const uint32_t *w = &s.winY[__umul24((unsigned)r, WY_DW) + (unsigned)sx];
             uint32_t te, to;
             pk_htaps(w[0], w[1], w[2], te, to);
             /* pairs (0,2),(1,3) -> four consecutive int16 */
@@ -364,13 +401,13 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
             t[0] = (te & 0xFFFFu) | (to << 16);
             t[1] = (te >> 16) | (to & 0xFFFF0000u);
         }
-        __syncthreads();
+        MI355_WAVE_SYNC();
     }
     for (int i = lane; i < bh * nseg; i += 64) {
         const int y = i >> lseg, sx = i & (nseg - 1);
         uint32_t se = 0, so = 0;            /* sums of the components, samples (0,2) and (1,3) */
         if (use_g) {
-            const uint32_t *w = &s.winY[(y + 2 + gdy) * WY_DW + sx + 1];
+            const uint32_t *w = &s.winY[__umul24((unsigned)(y + 2 + gdy), WY_DW) + (unsigned)sx + 1u];
             const uint32_t g = gdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
             se = pk_even(g); so = pk_odd(g);
         }
@@ -381,7 +418,7 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
                 te = (t[0] & 0xFFFFu) | (t[1] << 16);
                 to = (t[0] >> 16) | (t[1] & 0xFFFF0000u);
             } else {
-                const uint32_t *w = &s.winY[(y + 2 + bdy) * WY_DW + sx];
+                const uint32_t *w = &s.winY[__umul24((unsigned)(y + 2 + bdy), WY_DW) + (unsigned)sx];
                 pk_htaps(w[0], w[1], w[2], te, to);
             }
             se = pk_add(se, pk_round5(te)); so = pk_add(so, pk_round5(to));
@@ -390,7 +427,7 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
             uint32_t e[6], o[6];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                const uint32_t *w = &s.winY[(y + r) * WY_DW + sx + 1];
+                const uint32_t *w = &s.winY[__umul24((unsigned)(y + r), WY_DW) + (unsigned)sx + 1u];
                 const uint32_t c = hdx ? mi355_alignbyte(w[1], w[0], 1) : w[0];
                 e[r] = pk_even(c); o[r] = pk_odd(c);
             }
@@ -428,7 +465,7 @@ __device__ inline void mc_luma_compute(McScratch &s, int mx, int my, int bw, int
             *d2 = (uint16_t)(avg ? rnd_avg4(*d2, v) : v);
         }
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* ---- a6: 1/8-pel bilinear chroma MC (h264chroma_template.c:27-173) ----------
@@ -442,7 +479,7 @@ __device__ inline void mc_chroma_compute(McScratch &s, int nplanes, int fx, int 
     for (int i = lane; i < per_plane * nplanes; i += 64) {
         const int plane = i >= per_plane, j = i - plane * per_plane;
         const int y = nseg == 2 ? j >> 1 : j, sx = nseg == 2 ? j & 1 : 0;
-        const uint32_t *w0 = &s.winC[plane][y * WC_DW + sx], *w1 = w0 + WC_DW;
+        const uint32_t *w0 = &s.winC[plane][__umul24((unsigned)y, WC_DW) + (unsigned)sx], *w1 = w0 + WC_DW;
         const uint32_t a0 = w0[0], a1 = mi355_alignbyte(w0[1], w0[0], 1), b0 = w1[0], b1 = mi355_alignbyte(w1[1], w1[0], 1);
         /* (A a + B b + C c + D d + 32) >> 6 on packed pairs: the sums stay below 2^14 */
         const uint32_t ve = pk_ashr(pk_mad(pk_even(a0), A, pk_mad(pk_even(a1), B, pk_mad(pk_even(b0), C, pk_mad(pk_even(b1), D, 0x00200020u)))), 6);
@@ -459,7 +496,7 @@ __device__ inline void mc_chroma_compute(McScratch &s, int nplanes, int fx, int 
             *d = (uint8_t)(avg ? rnd_avg4(*d, v & 0xFF) : v);
         }
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* The 8x8 chroma blocks of a 16x16 partition, both planes at once on all 64 lanes: a lane produces two neighbouring
@@ -470,7 +507,7 @@ __device__ inline void mc_chroma16(McScratch &s, int fx, int fy, uint8_t *pred0,
     const int lane = lane_id();
     const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
     const int plane = lane >> 5, y = (lane >> 2) & 7, c = lane & 3;
-    const uint32_t *w0 = &s.winC[plane][y * WC_DW + (c >> 1)], *w1 = w0 + WC_DW;
+    const uint32_t *w0 = &s.winC[plane][__umul24((unsigned)y, WC_DW) + (unsigned)(c >> 1)], *w1 = w0 + WC_DW;
     const uint32_t sh = 2u * (uint32_t)(c & 1);
     const uint32_t r0 = mi355_alignbyte(w0[1], w0[0], sh), r1 = mi355_alignbyte(w1[1], w1[0], sh);
     const uint32_t a0 = byte_perm(0, r0, 0x0C010C00u), a1 = byte_perm(0, r0, 0x0C020C01u);
@@ -481,7 +518,7 @@ __device__ inline void mc_chroma16(McScratch &s, int fx, int fy, uint8_t *pred0,
     uint16_t *d = reinterpret_cast<uint16_t *>((plane ? pred1 : pred0) + y * ppitch + 2 * c);
     if (avg) two = rnd_avg4(*d, two);
     *d = (uint16_t)two;
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* ---- a7: explicit / implicit weighted prediction (h264dsp_template.c:30-98) -- */
@@ -494,7 +531,7 @@ __device__ inline void weight_block(uint8_t *p, int pitch, int bw, int bh, int l
         uint8_t *d = &p[y * pitch + x];
         *d = (uint8_t)clip_u8((*d * w + o) >> log2_denom);
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 __device__ inline void biweight_block(uint8_t *dst, const uint8_t *src, int pitch, int bw, int bh,
                                       int log2_denom, int wd, int ws, int o)
@@ -505,7 +542,7 @@ __device__ inline void biweight_block(uint8_t *dst, const uint8_t *src, int pitc
         uint8_t *d = &dst[y * pitch + x];
         *d = (uint8_t)clip_u8((src[y * pitch + x] * ws + *d * wd + o) >> (log2_denom + 1));
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* ---- a1: 4x4 inverse transform, 4 lanes per block (h264idct_template.c:33-67) -
@@ -580,12 +617,12 @@ __device__ inline void idct8_lds(int16_t *blk, int i, bool active, int r[8])
         if (i == 0) in[0] = (int16_t)(in[0] + 32);
         idct8_1d(in, out);
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
     if (active) {
 #pragma unroll
         for (int k = 0; k < 8; k++) blk[i + 8 * k] = (int16_t)out[k];
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
     if (active) {
 #pragma unroll
         for (int k = 0; k < 8; k++) in[k] = blk[8 * i + k];
@@ -837,7 +874,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
                 v = f3(L[0], T[-1], T[0]);
                 s.fT[0] = s.fL[0] = (int16_t)v;
             }
-            __syncthreads();
+            MI355_WAVE_SYNC();
             T = s.fT + 1;
             L = s.fL + 1;
         }
@@ -848,7 +885,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             else v = pred_dir_px(mode, N, x, y, T, L);
             out[y * pitch + x] = (uint8_t)v;
         }
-        __syncthreads();
+        MI355_WAVE_SYNC();
         return;
     }
     if (kind == 3) { /* 16x16: slots DC=0 HOR=1 VERT=2 PLANE=3 LEFT_DC=4 TOP_DC=5 DC128=6 */
@@ -869,7 +906,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             }
             out[y * pitch + x] = (uint8_t)v;
         }
-        __syncthreads();
+        MI355_WAVE_SYNC();
         return;
     }
     if (kind == 4) { /* 8x16 chroma: quadrant DC rules of :590-595 (left), :622-642 (top), :673-720 (both), mad-cow patches :722-766 */
@@ -901,7 +938,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             }
             out[y * pitch + x] = (uint8_t)v;
         }
-        __syncthreads();
+        MI355_WAVE_SYNC();
         return;
     }
     /* kind == 2: 8x8 chroma; per-4x4-quadrant DC rules of h264pred_template.c:563-766 */
@@ -926,7 +963,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
         default: v = qy ? dc_left : 128; break;                                  /* 0L0 */
         }
         out[y * pitch + x] = (uint8_t)v;
-        __syncthreads();
+        MI355_WAVE_SYNC();
     }
 }
 

@@ -50,6 +50,36 @@ __device__ __forceinline__ int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 
 __device__ __forceinline__ int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >> 3); }
 __device__ __forceinline__ int blk_index(int x4, int y4) { return (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1); }
 
+/* The fields of a picture descriptor the reconstruction kernels use, read ONCE into scalar registers at kernel start.
+ * Reading them through the descriptor inside a loop that also stores samples makes every read a fresh (vector) load
+ * that the stores might alias: a dependent memory access in front of each macroblock. */
+struct FrameHot {
+    const mi355_h264_mb *mb;
+    const int16_t *mv[2];
+    const int16_t *coef;
+    const mi355_h264_slice *slices;
+    uint8_t *recon[3];
+    int32_t recon_stride[2], ref_stride[2];
+    int32_t mb_width, mb_height;
+    const mi355_h264_frame *desc;     /* for the reference table when a kernel keeps no copy of it in LDS */
+};
+__device__ __forceinline__ FrameHot frame_hot(const mi355_h264_frame &fr)
+{
+    FrameHot h;
+    h.desc = &fr;
+    h.mb = mi355_global(fr.mb);
+    h.mv[0] = mi355_global(fr.mv[0]); h.mv[1] = mi355_global(fr.mv[1]);
+    h.coef = mi355_global(fr.coef);
+    h.slices = mi355_global(fr.slices);
+    h.recon[0] = mi355_global(fr.recon[0]); h.recon[1] = mi355_global(fr.recon[1]); h.recon[2] = mi355_global(fr.recon[2]);
+    h.recon_stride[0] = uniform(fr.recon_stride[0]); h.recon_stride[1] = uniform(fr.recon_stride[1]);
+    h.ref_stride[0] = uniform(fr.dst_stride[0]); h.ref_stride[1] = uniform(fr.dst_stride[1]);
+    h.mb_width = uniform(fr.mb_width); h.mb_height = uniform(fr.mb_height);
+    return h;
+}
+/* the picture's reference table in LDS: [slot][plane] */
+typedef const uint8_t *const (*RefTable)[3];
+
 /* record (64 B), motion vectors (64 B per list) and coefficients (768 B) -> LDS: every load is
  * issued before the first wait, so the wave pays one memory round trip for all of them.  The two
  * halves can be separated: a strip kernel issues the loads of the next macroblock before it works on
@@ -61,15 +91,15 @@ struct MbLoad {
  * vectors (a missing list reads the record instead and is zeroed in commit), the rest repeat the record — with loads
  * under lane conditions the compiler merged each result with its zero default before issuing the next load, i.e. the wave
  * paid the record's memory latency and then the coefficients' again. */
-__device__ __forceinline__ void load_mb_issue(MbLoad &r, const mi355_h264_frame &fr, int mb_xy, bool with_coefs, bool ok)
+__device__ __forceinline__ void load_mb_issue(MbLoad &r, const FrameHot &fr, int mb_xy, bool with_coefs, bool ok)
 {
     const int lane = lane_id();
     r.hw = r.mw = r.c0 = r.c1 = r.c2 = 0;
     if (!ok) return;
-    const uint32_t *hp = reinterpret_cast<const uint32_t *>(&mi355_global(fr.mb)[mb_xy]);
-    const uint32_t *cp = reinterpret_cast<const uint32_t *>(mi355_global(fr.coef) + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-    const uint32_t *m0 = fr.mv[0] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[0])) + (size_t)mb_xy * 16 : hp;
-    const uint32_t *m1 = fr.mv[1] ? reinterpret_cast<const uint32_t *>(mi355_global(fr.mv[1])) + (size_t)mb_xy * 16 : hp;
+    const uint32_t *hp = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy]);
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    const uint32_t *m0 = fr.mv[0] ? reinterpret_cast<const uint32_t *>(fr.mv[0]) + (size_t)mb_xy * 16 : hp;
+    const uint32_t *m1 = fr.mv[1] ? reinterpret_cast<const uint32_t *>(fr.mv[1]) + (size_t)mb_xy * 16 : hp;
     r.hw = hp[lane & 15];
     r.mw = (lane & 32 ? m1 : m0)[lane & 15];
     if (with_coefs) { r.c0 = cp[lane]; r.c1 = cp[lane + 64]; r.c2 = cp[lane + 128]; }
@@ -84,9 +114,9 @@ __device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool w
         uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
         dst[lane] = r.c0; dst[lane + 64] = r.c1; dst[lane + 128] = r.c2;
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
-__device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, bool with_coefs)
+__device__ inline void load_mb(MbLds &s, const FrameHot &fr, int mb_xy, bool with_coefs)
 {
     MbLoad r;
     load_mb_issue(r, fr, mb_xy, with_coefs, true);
@@ -94,7 +124,7 @@ __device__ inline void load_mb(MbLds &s, const mi355_h264_frame &fr, int mb_xy, 
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */
-__device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+__device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y,
                               int mb_xy, int list, int n_raster, int refn, int bx, int by, int w, int h,
                               uint8_t *py, uint8_t *pcb, uint8_t *pcr, int avg)
 {
@@ -103,9 +133,11 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, con
     const int slot = __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.ref_pic[list][(bx >> 3) + 2 * (by >> 3)]);
     const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
     const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
-    PlaneRef ry{mi355_global(fr.ref[slot][0]), fr.dst_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
-    PlaneRef rb{mi355_global(fr.ref[slot][1]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
-    PlaneRef rr{mi355_global(fr.ref[slot][2]), fr.dst_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
+    (void)refs;
+    const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
+    PlaneRef ry{mi355_global(rp[0]), fr.ref_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
+    PlaneRef rb{mi355_global(rp[1]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
+    PlaneRef rr{mi355_global(rp[2]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
 #ifndef MI355_EXP_NO_STAGE
     if (w == 16 && h == 16) stage_windows16(s.mc, ry, mx >> 2, my >> 2, rb, rr, mx >> 3, my >> 3);
     else stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
@@ -122,7 +154,7 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const mi355_h264_frame &fr, con
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471).  Both lists go
  * through ONE call site of mc_dir (inlined): a second prediction lands in the q* tiles when the two have to be
  * blended with weights, on top of the first one (rounded average) otherwise. */
-__device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+__device__ __forceinline__ void mc_part(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y,
                                         int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
     const int r0 = uniform(s.hdr.ref_idx[0][quadrant]), r1 = uniform(s.hdr.ref_idx[1][quadrant]);
@@ -134,7 +166,7 @@ __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, co
         if (!(list ? l1 : l0)) continue;
         const bool second = list == 1 && two;
         const bool to_q = second && weighted;
-        mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, list, n_raster, list ? r1 : r0, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0],
+        mc_dir(s, fr, refs, sl, mb_x, mb_y, mb_xy, list, n_raster, list ? r1 : r0, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0],
                to_q ? s.qc[1] : s.pc[1], second && !weighted);
     }
     if (!weighted) return;
@@ -166,7 +198,7 @@ __device__ __forceinline__ void mc_part(MbLds &s, const mi355_h264_frame &fr, co
 
 /* hl_motion, h264_mc_template.c:64-163.  The partitions are enumerated by one loop so that mc_part has
  * a single (inlined) call site. */
-__device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y, int mb_xy)
+__device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y, int mb_xy)
 {
     const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
 #define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
@@ -178,11 +210,11 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
 #ifndef MI355_NO_P16
         if (l0 && !l1 && !(uniform(s.hdr.flags) & MI355_MBF_WEIGHTED)) {
             /* ... and the plain P_16x16 / P_Skip macroblock goes straight to one list-0 prediction written in place */
-            mc_dir(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
+            mc_dir(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
             return;
         }
 #endif
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
+        mc_part(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
         return;
     }
     const int nparts = kind == 3 ? 16 : 2;
@@ -204,7 +236,7 @@ __device__ inline void hl_motion(MbLds &s, const mi355_h264_frame &fr, const mi3
             by = y + (shape == MI355_SUB_8x4 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j >> 1) : 0));
             n = (bx >> 2) + 4 * (by >> 2);
         }
-        mc_part(s, fr, sl, mb_x, mb_y, mb_xy, n, quad, bx, by, w, h, l0, l1);
+        mc_part(s, fr, refs, sl, mb_x, mb_y, mb_xy, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
 }
@@ -238,7 +270,7 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
         if (coded || (intra16 && dc))
             add_row4<ALIGNED>(y + (4 * blk_y4(b) + row) * pitch + 4 * blk_x4(b), r);
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* chroma residual: h264_mb_template.c:196-247 */
@@ -254,7 +286,7 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
         chroma_dc_dequant(a, b, c, d, (int)s.hdr.dc_qmul[1 + lane]);
         p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
     const int j = (lane >> 2) & 7, q = lane & 3;
     int c[4], r[4], row;
 #pragma unroll
@@ -268,7 +300,7 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
         const int jj = j & 3;
         add_row4<ALIGNED>(p + (4 * (jj >> 1) + row) * pitch + 4 * (jj & 1), r);
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* Residual of an inter macroblock with 4x4 transforms, luma and chroma in ONE pass over the blocks that carry
@@ -290,14 +322,14 @@ __device__ inline void residual_blocks(MbLds &s)
             chroma_dc_dequant(a, b, c, d, (int)s.hdr.dc_qmul[1 + lane]);
             p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
         }
-        __syncthreads();
+        MI355_WAVE_SYNC();
         const bool need = lane >= 16 && lane < 24 && (((nnz >> lane) & 1) || s.coef[16 * lane] != 0);
         mask |= (uint32_t)uniform((int)(uint32_t)__ballot(need));
     }
     if (!mask) return;
     const int n = __popc(mask);
     if (lane < 24 && ((mask >> lane) & 1)) s.slot[__popc(mask & ((1u << lane) - 1u))] = (uint8_t)lane;
-    __syncthreads();
+    MI355_WAVE_SYNC();
     const int k = lane >> 2, q = lane & 3;
 #pragma nounroll
     for (int base = 0; base < n; base += 16) {
@@ -315,7 +347,7 @@ __device__ inline void residual_blocks(MbLds &s)
                             : s.pc[(b >> 2) & 1] + (4 * (jj >> 1) + row) * 8 + 4 * (jj & 1);
         if (act) add_row4<ALIGNED>(d, r);
     }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 }
 
 /* tile (LDS) -> picture, 4 bytes per lane */
@@ -327,17 +359,16 @@ __device__ __forceinline__ uint32_t tile_dword(const uint8_t *p)
 }
 template <bool ALIGNED = false>
 __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb, const uint8_t *cr, int cpitch,
-                                uint8_t *const dst[3], const int32_t stride[2], int mb_x, int mb_y)
+                                const FrameHot &fr, int mb_x, int mb_y)
 {
     const int lane = lane_id();
     {
         const int row = lane >> 2, seg = lane & 3;
-        *reinterpret_cast<uint32_t *>(mi355_global(dst[0]) + (size_t)(mb_y * 16 + row) * stride[0] + mb_x * 16 + 4 * seg) = tile_dword<ALIGNED>(y + row * ypitch + 4 * seg);
+        *reinterpret_cast<uint32_t *>(fr.recon[0] + (uint32_t)(__mul24(mb_y * 16 + row, fr.recon_stride[0]) + mb_x * 16 + 4 * seg)) = tile_dword<ALIGNED>(y + row * ypitch + 4 * seg);
     }
     if (lane < 32) {
         const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
-        uint8_t *const c0 = mi355_global(dst[1]), *const c1 = mi355_global(dst[2]);     /* uniform fetches, per-lane select */
-        *reinterpret_cast<uint32_t *>((plane ? c1 : c0) + (size_t)(mb_y * 8 + row) * stride[1] + mb_x * 8 + 4 * seg) =
+        *reinterpret_cast<uint32_t *>((plane ? fr.recon[2] : fr.recon[1]) + (uint32_t)(__mul24(mb_y * 8 + row, fr.recon_stride[1]) + mb_x * 8 + 4 * seg)) =
             tile_dword<ALIGNED>((plane ? cr : cb) + row * cpitch + 4 * seg);
     }
 }
@@ -358,6 +389,11 @@ __device__ __forceinline__ int xcd_linear(int b, int per_xcd) { return (b & 7) *
 /* n / d for a launch-constant divisor d: the host passes m = ceil(2^40 / d); exact for n < 2^24 */
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
 
+/* One macroblock per wave.  Measured and not kept (round 2, profiles/r02_experiments.md): a wave walking a run of 4-15
+ * macroblocks with the next macroblock's windows and the one after's record in flight (two register sets, exact
+ * partial waits) was 25-30 % SLOWER although it hid both memory round trips — the kernel is bound by the request rate
+ * of the reference fetch (removing the window loads alone: -30 % time at -8 % VALU), which a deeper pipeline does not
+ * lower, and the loop cost 50 more VALU per macroblock. */
 __global__ void __launch_bounds__(64)
 k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
@@ -367,18 +403,13 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     /* lin = (f * max_h + mb_y) * max_w + mb_x */
     const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
     const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
-    const mi355_h264_frame &fr = frames[f];
+    const FrameHot fr = frame_hot(frames[f]);
     if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
-#ifdef MI355_PROF
-    unsigned long long prof_t = __builtin_readcyclecounter();
-#endif
     load_mb(s, fr, mb_xy, true);
-    PROF_MARK(8);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
-    const mi355_h264_slice &sl = mi355_global(fr.slices)[uniform(s.hdr.slice_id)];
-    hl_motion(s, fr, sl, mb_x, mb_y, mb_xy);
-    PROF_MARK(9);
+    const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
+    hl_motion(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
 #ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
     if (uniform((int)s.hdr.mb_type) & MI355_MB_8x8DCT) {
@@ -387,14 +418,8 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     } else {
         residual_blocks<true>(s);
     }
-    PROF_MARK(11);
 #endif
-    /* (several macroblocks per wave with the next one's record, vectors and coefficients in flight: two per wave,
-     * unrolled, measured -2.7 %, four +2.7 %, as a real loop +3 % and more — the kernel is bound by instruction issue,
-     * not by the latency of a wave; an earlier strip variant with 64-byte row stores was 7 % slower; touching the lines of
-     * the macroblock 8 K - 64 K positions ahead so that later waves start with L2 hits: +6 % time) */
-    store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr.recon, fr.recon_stride, mb_x, mb_y);
-    PROF_MARK(12);
+    store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr, mb_x, mb_y);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -418,24 +443,25 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     __shared__ IntraLds s;
     const int lane = lane_id();
     const int f = blockIdx.x / width, k = blockIdx.x - f * width;
-    const mi355_h264_frame &fr = frames[f];
-    if (level > fr.max_intra_level) return;
-    const int first = mi355_global(fr.intra_level_start)[level - 1], count = mi355_global(fr.intra_level_start)[level] - first;
+    const mi355_h264_frame &frd = frames[f];
+    if (level > frd.max_intra_level) return;
+    const int first = mi355_global(frd.intra_level_start)[level - 1], count = mi355_global(frd.intra_level_start)[level] - first;
     if (k >= count) return;
-    const int mb_xy = (int)mi355_global(fr.intra_list)[first + k];
+    const int mb_xy = (int)mi355_global(frd.intra_list)[first + k];
+    const FrameHot fr = frame_hot(frd);
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     /* Everything this macroblock reads from memory is requested at once — record, vectors, coefficients and the edge
      * samples of the unfiltered neighbours (which depend on the position only) — with loads that no lane skips: a lane
      * without a sample to fetch reads the block's own first sample and drops it.  One memory round trip per wave. */
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1];
-    uint8_t *const ry = mi355_global(fr.recon[0]) + (size_t)mb_y * 16 * ys + mb_x * 16;
+    uint8_t *const ry = fr.recon[0] + (size_t)mb_y * 16 * ys + mb_x * 16;
     const int pic_w = 16 * fr.mb_width;
     const bool top_y = mb_y > 0 && lane < 25 && mb_x * 16 + lane - 1 >= 0 && mb_x * 16 + lane - 1 < pic_w;
     const bool left_y = mb_x > 0 && lane >= 32 && lane < 48;
     const bool top_c = mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0);
     const bool left_c = mb_x > 0 && lane >= 16 && lane < 24;
-    const uint8_t *const rcb = mi355_global(fr.recon[1]) + (size_t)mb_y * 8 * cs + mb_x * 8;
-    const uint8_t *const rcr = mi355_global(fr.recon[2]) + (size_t)mb_y * 8 * cs + mb_x * 8;
+    const uint8_t *const rcb = fr.recon[1] + (size_t)mb_y * 8 * cs + mb_x * 8;
+    const uint8_t *const rcr = fr.recon[2] + (size_t)mb_y * 8 * cs + mb_x * 8;
     const ptrdiff_t oy = top_y ? (ptrdiff_t)(lane - 1) - ys : (left_y ? (ptrdiff_t)(lane - 32) * ys - 1 : 0);
     const ptrdiff_t oc = top_c ? (ptrdiff_t)(lane - 1) - cs : (left_c ? (ptrdiff_t)(lane - 16) * cs - 1 : 0);
     MbLoad ld;
@@ -448,7 +474,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
-        store_mb<true>(src, 16, src + 256, src + 320, 8, fr.recon, fr.recon_stride, mb_x, mb_y);
+        store_mb<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
         return;
     }
     /* edge samples -> tiles */
@@ -513,7 +539,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
         }
     }
     residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
-    store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr.recon, fr.recon_stride, mb_x, mb_y);
+    store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
 }
 #undef TILE
 

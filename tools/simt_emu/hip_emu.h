@@ -61,6 +61,7 @@ static const int warpSize = 64;
 
 static inline void __syncthreads() { simt_emu::barrier_block(); }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 static inline int __shfl(int v, int lane, int w = 64) { return simt_emu::shfl_exchange(v, lane, w, 0); }
 static inline int __shfl_xor(int v, int m, int w = 64) { return simt_emu::shfl_exchange(v, m, w, 1); }
 static inline int __shfl_up(int v, unsigned d, int w = 64) { return simt_emu::shfl_exchange(v, (int)d, w, 2); }
