@@ -23,11 +23,12 @@ __device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 25
 __device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
-#ifdef MI355_HIP_EMU_H
+#if defined(MI355_HIP_EMU_H) || defined(MI355_PLAIN_LANE)
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
-/* opaque to the optimiser at every call: values derived from the lane number inside a loop are recomputed there (a few
- * VALU) instead of being hoisted into registers that stay live across the whole loop body */
+/* Opaque to the optimiser at every call: values derived from the lane number are recomputed in each phase of a kernel
+ * instead of being computed once and kept in registers across all of them.  +26 VALU per macroblock in k_recon_inter,
+ * but 41 instead of 91 VGPRs, i.e. 8 instead of 5 waves per SIMD: 13.75 vs 15.94 ms (profiles/r02_experiments.md). */
 __device__ __forceinline__ int lane_id() { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); __builtin_assume(l >= 0 && l < 64); return l; }
 #endif
 /* exchange inside groups of four lanes as a DPP operand modifier (quad_perm) instead of an LDS-routed shuffle */
@@ -112,9 +113,9 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
  * serialises prefetches with the work they were meant to overlap.  A single wave executes its LDS and
  * its vector-memory instructions in issue order, so wavefront-scope fences (no instructions, compiler
  * ordering only) are sufficient; data dependences still get their own precise waits.
- * The SIMT emulator runs lanes as fibers and needs a real rendezvous. */
+ * The SIMT emulator runs lanes as fibers and needs a real rendezvous (of the wave, like the real thing). */
 #ifdef MI355_HIP_EMU_H
-#define MI355_WAVE_SYNC() __syncthreads()
+#define MI355_WAVE_SYNC() ((void)__shfl(0, 0))   /* a rendezvous of this wave's lanes only (a workgroup may hold several waves) */
 #else
 #define MI355_WAVE_SYNC()                                        \
     do {                                                         \
