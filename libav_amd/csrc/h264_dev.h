@@ -22,6 +22,8 @@ namespace mi355 {
 __device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (a + f) - 5 * (b + e) + 20 * (c + d); }
 #if defined(MI355_HIP_EMU_H) || defined(MI355_PLAIN_LANE)
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -375,7 +375,7 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
 
 #ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of the first blocks */
 __device__ unsigned long long g_prof[16];
-#define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x < 64 && lane_id() == 0) atomicAdd(&g_prof[i], now_ - prof_t); prof_t = now_; } while (0)
+#define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
 #else
 #define PROF_MARK(i) do { } while (0)
 #endif
@@ -650,17 +650,24 @@ struct MbInfo {
 };
 typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
 typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
-/* words 0-3 and 11-13 of the record at byte offset `off` of `base`: two loads, no predicate */
+/* words 0-3 (0-2 for a neighbour, whose slice offsets are not looked at) and 11-13 of the record at byte offset `off` of
+ * `base`: two loads, no predicate.  No loaded word may be dead: the register of a dead word is handed to something else,
+ * and the first write to it then waits for this load (a memory latency per step when that something is set per step). */
+template <bool W3>
 __device__ __forceinline__ MbInfo mb_info_load(const uint8_t *base, uint32_t off)
 {
 #ifdef MI355_HIP_EMU_H
     const uint32_t *w = reinterpret_cast<const uint32_t *>(base + off);
-    return MbInfo{ w[0], w[1], w[2], w[3], w[11], w[12], w[13] };
+    return MbInfo{ w[0], w[1], w[2], W3 ? w[3] : 0u, w[11], w[12], w[13] };
 #else
     typedef uint32_t u32x3 __attribute__((vector_size(12)));
-    const mi355_u32x4 a = *reinterpret_cast<const mi355_u32x4 *>(base + off);
     const u32x3 b = *reinterpret_cast<const u32x3 *>(base + off + 44);
-    return MbInfo{ a[0], a[1], a[2], a[3], b[0], b[1], b[2] };
+    if (W3) {
+        const mi355_u32x4 a = *reinterpret_cast<const mi355_u32x4 *>(base + off);
+        return MbInfo{ a[0], a[1], a[2], a[3], b[0], b[1], b[2] };
+    }
+    const u32x3 a = *reinterpret_cast<const u32x3 *>(base + off);
+    return MbInfo{ a[0], a[1], a[2], 0u, b[0], b[1], b[2] };
 #endif
 }
 
@@ -810,20 +817,15 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
     w[0] = v.x; w[1] = v.y;
 }
 
-#ifdef MI355_DEBLOCK_WAVES
-__attribute__((amdgpu_waves_per_eu(MI355_DEBLOCK_WAVES, MI355_DEBLOCK_WAVES)))
-#endif
-__global__ void __launch_bounds__(64)
-k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
+template <bool TWO_LISTS>     /* list-1 vectors exist (B pictures): a compile-time switch, so that a P picture carries no list-1 state at all */
+__device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_frame &fr, int band)
 {
-    __shared__ DeblockLds s;
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-    const mi355_h264_frame &fr = frames[blockIdx.x];
     const int mb_y = 4 * band + g, W = fr.mb_width;
     const bool row_ok = mb_y < fr.mb_height;
     const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
     const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
-    const bool two_lists = fr.mv[1] != nullptr;              /* sl->list_count == 2 exactly when list-1 vectors exist */
+    constexpr bool two_lists = TWO_LISTS;                    /* sl->list_count == 2 exactly when list-1 vectors exist */
     const int nsteps = W + 6;
     const bool has_t = row_ok && mb_y > 0;
     /* the group below (same wave) filters and writes this row's bottom three luma rows / last chroma row */
@@ -859,15 +861,15 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const bool ok = row_ok && x >= 0 && x < W;
         const uint32_t xy = ok ? (uint32_t)(mb_y * W + x) : 0u;
         const uint32_t roff = xy * 64u, toff = ok && has_t ? roff - 64u * (uint32_t)W : roff;
-        p.h = mb_info_load(rec_base, roff);
-        p.ht = mb_info_load(rec_base, toff);
+        p.h = mb_info_load<true>(rec_base, roff);
+        p.ht = mb_info_load<false>(rec_base, toff);
         /* clamped addresses: a neighbour that does not exist reads this macroblock's own vector (its strength is masked) */
         const uint32_t a_p0 = roff + (uint32_t)o_p0, a_p1 = roff + (uint32_t)o_p1;
         const uint32_t a_q0 = (ok && x > 0) || !outer ? roff + (uint32_t)o_q0 : a_p0;
         const uint32_t a_q1 = (ok && has_t) || !outer ? roff + (uint32_t)o_q1 : a_p1;
         p.p0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p0); p.q0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q0);
         p.p1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p1); p.q1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q1);
-        p.p0[1] = p.q0[1] = p.p1[1] = p.q1[1] = 0;
+        p.p0[1] = p.q0[1] = p.p1[1] = p.q1[1] = 0;           /* constants without list 1 (no register, no write) */
         if (two_lists) {
             p.p0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p0); p.q0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q0);
             p.p1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p1); p.q1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q1);
@@ -888,22 +890,28 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
     constexpr int NY = 16 / DIO_ROWS, NTOP = (4 + DIO_ROWS - 1) / DIO_ROWS;   /* accesses for 16 rows / for the 4 rows above */
     uint4 vy[NY], ty[NTOP];
     uint2 vc[NY], tc[NTOP];
+    /* All loads are unconditional, from clamped positions: a macroblock outside the row reads one that exists (its tile
+     * is never filtered and never written back), and the lanes of groups 1-3 repeat group 0's addresses for the rows
+     * above the band (same cache lines, no extra traffic; only group 0 keeps them).  A predicated load costs a mask
+     * sequence and a zero fill per access and makes the compiler's wait counts inexact. */
+    const int mb_yc = row_ok ? mb_y : fr.mb_height - 1;
+    const uint8_t *const recon_yc = mi355_global(fr.recon[0]) + (ptrdiff_t)mb_yc * 16 * rs;
+    const int top_y0 = 4 * band > 0 ? 4 * band * 16 - 4 : 0, top_c0 = 4 * band > 0 ? 4 * band * 8 - 2 : 0;   /* first row above the band (row 0 when there is none) */
+    const uint8_t *const dst_y0 = mi355_global(fr.dst[0]);
     auto issue_chunk = [&](int c) {
-        const int x = DCH * c - 2 * g + io_p;
-        const bool ok = row_ok && x >= 0 && x < W;
+        const int xr = DCH * c - 2 * g + io_p, x = xr < 0 ? 0 : (xr < W ? xr : W - 1);
+        const int xt0 = DCH * c + io_p, xt = xt0 < W ? xt0 : W - 1;          /* group 0's macroblock */
 #pragma unroll
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;            /* luma row; as chroma: plane = row >> 3, row & 7 */
-            vy[it] = ok ? ld16(recon_y + (ptrdiff_t)row * rs + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            vc[it] = ok ? ld8(((row >> 3) ? recon_cr : recon_cb) + (ptrdiff_t)(mb_y * 8 + (row & 7)) * rcs + x * 8, al8) : make_uint2(0, 0);
+            vy[it] = ld16(recon_yc + (uint32_t)(__mul24(row, rs) + x * 16), al16);
+            vc[it] = ld8(((row >> 3) ? recon_cr : recon_cb) + (uint32_t)(__mul24(mb_yc * 8 + (row & 7), rcs) + x * 8), al8);
         }
-        const bool okt = ok && g == 0 && has_t;              /* rows above the band: as the previous band left them */
 #pragma unroll
         for (int it = 0; it < NTOP; it++) {
-            const int row = DIO_ROWS * it + io_r;            /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
-            const bool in = okt && row < 4;
-            ty[it] = in ? ld16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, al16) : make_uint4(0, 0, 0, 0);
-            tc[it] = in ? ld8((((row >> 1) & 1) ? dst_cr : dst_cb) + (ptrdiff_t)(mb_y * 8 + (row & 1) - 2) * dcs + x * 8, al8) : make_uint2(0, 0);
+            const int row = (DIO_ROWS * it + io_r) & 3;      /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
+            ty[it] = ld16(dst_y0 + (uint32_t)(__mul24(top_y0 + row, ds) + xt * 16), al16);
+            tc[it] = ld8(((row >> 1) ? dst_cr : dst_cb) + (uint32_t)(__mul24(top_c0 + (row & 1), dcs) + xt * 8), al8);
         }
     };
     auto commit_chunk = [&](int c) {
@@ -943,6 +951,9 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         }
     };
 
+#ifdef MI355_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
     issue_chunk(0);
     Pre pre;
     prefetch(pre, -2 * g);
@@ -953,15 +964,22 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         const int ck = t >> DCH_LOG, j = t & (DCH - 1), b = ck & 1;   /* chunk, position in it, tile parity */
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
         const Pre cur = pre;
+        PROF_MARK(0);
         /* ---- chunk turnover ---------------------------------------------------------------------- */
         if (j == 1 && ck >= 1) {                             /* the previous chunk got its last left-edge patch in step t-1 */
             flush_chunk(ck - 1);
             flushed = ck;
         }
+        PROF_MARK(7);
         if (j == 0) commit_chunk(ck);
+        PROF_MARK(6);
         if (j == DCH_ISSUE) issue_chunk(ck + 1);             /* after the flush above: the stores go first */
+        PROF_MARK(5);
         /* ---- next step's records and vectors ------------------------------------------------------- */
+#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 4
         prefetch(pre, mb_x + 1);
+#endif
+        PROF_MARK(1);
         MI355_WAVE_SYNC();                                   /* the chunk committed above is visible */
         /* ---- rows above from the group above ------------------------------------------------------- */
         if (g > 0 && valid) {
@@ -973,6 +991,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                 *reinterpret_cast<uint32_t *>(&s.c[g][b][l >> 2][(l >> 1) & 1][8 * j + 4 * (l & 1)]) =
                     *reinterpret_cast<const uint32_t *>(&s.c[g - 1][bb][l >> 2][8 + ((l >> 1) & 1)][8 * jb + 4 * (l & 1)]);
         }
+        PROF_MARK(2);
+#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 3
         /* ---- boundary strengths, in registers ------------------------------------------------------- */
         const MbInfo &h = cur.h, &ht = cur.ht;
         const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
@@ -985,6 +1005,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
         /* a chroma line (row / column cr of plane cp) lies in luma segment cr >> 1 */
         const int csrc = (lane & ~15) | ((cr >> 1) << 2);
         const uint32_t bsc0 = (uint32_t)__shfl((int)bsw0, csrc), bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
+        PROF_MARK(3);
         /* ---- alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) ------------ */
         {
             const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;          /* lanes >= 9 repeat a valid role */
@@ -1018,6 +1039,8 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 #define AB_B(w) ((int)(((w) >> 8) & 0xFF))
 #define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
 
+        PROF_MARK(4);
+#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 2
         /* ---- vertical edges, one luma row + one chroma row per lane, in registers.  The four
          * samples left of the MB are the previous MB's last columns (previous chunk when j == 0). ----- */
         {
@@ -1025,23 +1048,25 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
             uint8_t *leftp = j ? rowp - 4 : &s.y[g][b ^ 1][4 + l][16 * (DCH - 1) + 12];
             const uint4 own = lds16(rowp);
             uint32_t wl = *reinterpret_cast<const uint32_t *>(leftp), w0 = own.x, w1 = own.y, w2 = own.z, w3 = own.w;
+            uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
+            uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * (DCH - 1) + 4];
+            const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
+            uint32_t cl = *reinterpret_cast<const uint32_t *>(cleftp), cw0 = cown.x, cw1 = cown.y;      /* columns -4..-1, 0..3, 4..7 */
             const bool c0 = luma_row_edge<true>(wl, w0, BYTE(bsw0, 0), AB_A(ab_l), AB_B(ab_l), BYTE(tcl0, 0));
             const bool c1 = luma_row_edge<false>(w0, w1, BYTE(bsw0, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 1));
             const bool c2 = luma_row_edge<false>(w1, w2, BYTE(bsw0, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 2));
             const bool c3 = luma_row_edge<false>(w2, w3, BYTE(bsw0, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 3));
             if (c0) *reinterpret_cast<uint32_t *>(leftp) = wl;
             if (c0 || c1 || c2 || c3) lds16(rowp, make_uint4(w0, w1, w2, w3));
-
-            uint8_t *crowp = &s.c[g][b][cp][2 + cr][8 * j];
-            uint8_t *cleftp = j ? crowp - 4 : &s.c[g][b ^ 1][cp][2 + cr][8 * (DCH - 1) + 4];
-            const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
-            uint32_t cl = *reinterpret_cast<const uint32_t *>(cleftp), cw0 = cown.x, cw1 = cown.y;      /* columns -4..-1, 0..3, 4..7 */
             const bool d0 = chroma_row_edge(cl, cw0, BYTE(bsc0, 0), AB_A(cab_l), AB_B(cab_l), BYTE(ccl0, 0));
             const bool d1 = chroma_row_edge(cw0, cw1, BYTE(bsc0, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci0, 2));
             if (d0) *reinterpret_cast<uint32_t *>(cleftp) = cl;
             if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
         }
+#endif
+        PROF_MARK(5);
         MI355_WAVE_SYNC();
+#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 1
         /* ---- horizontal edges, one luma column + one chroma column per lane ------------------------------ */
         {
             uint8_t *colp = &s.y[g][b][0][16 * j + l];
@@ -1075,14 +1100,33 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
                 ccolp[5 * DC_PITCH] = (uint8_t)u5; ccolp[6 * DC_PITCH] = (uint8_t)u6;
             }
         }
+#endif
 #undef AB_A
 #undef AB_B
 #undef BYTE
+        PROF_MARK(6);
         MI355_WAVE_SYNC();   /* the tile is final for this macroblock: the group below and the next step may read it */
         hl = h;
+#endif
     }
     /* chunks still in LDS */
     for (int c = flushed; c <= (nsteps - 1) >> DCH_LOG; c++) flush_chunk(c);
+#ifdef MI355_PROF
+    PROF_MARK(7);
+    if (blockIdx.x < 64 && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
+}
+
+#ifdef MI355_DEBLOCK_WAVES
+__attribute__((amdgpu_waves_per_eu(MI355_DEBLOCK_WAVES, MI355_DEBLOCK_WAVES)))
+#endif
+__global__ void __launch_bounds__(64)
+k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
+{
+    __shared__ DeblockLds s;
+    const mi355_h264_frame &fr = frames[blockIdx.x];
+    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true>(s, fr, band);
+    else deblock_band<false>(s, fr, band);
 }
 
 }  // namespace
