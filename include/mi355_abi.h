@@ -19,7 +19,7 @@
  * translation unit that already included the reference header (the `--wrap`
  * glue of INTEGRATION.md) uses the reference's definition and this file adds
  * nothing.  tests/test_abi_layout.py checks sizeof/offsetof of every field
- * against a probe compiled from the reference headers (oracle/ref_layout.c).
+ * against a probe compiled from the reference headers (ref_layout() in oracle/ref_glue.c, golden copy tests/golden/abi_layout_ref.json).
  */
 #ifndef MI355_ABI_H
 #define MI355_ABI_H

@@ -171,12 +171,20 @@ typedef struct mi355_h264_frame {
      * picture sorted by level; level L (1-based) occupies intra_list[start[L-1] .. start[L]) */
     const uint32_t *intra_list;
     const int32_t *intra_level_start; /* [max_intra_level + 1] */
+    int32_t max_level_width;          /* largest number of macroblocks on one level (*max_level_width of
+                                         mi355_h264_intra_schedule); 0 = unknown: mi355_h264_decode_frames() then assumes
+                                         the widest level a picture of this size can have */
+    int32_t reserved;
 } mi355_h264_frame;
 
 /* Reconstruct and deblock `nframes` independent pictures described by the HOST array
  * `frames` (its pointers are device pointers).  Work is enqueued on `stream`
- * (a hipStream_t; NULL = the null stream); the call returns without synchronising.
- * Returns 0, or <0 on invalid arguments. */
+ * (a hipStream_t; NULL = the null stream); the call returns without synchronising: the descriptors are copied into a
+ * per-thread pinned buffer before it returns (the caller's array may be reused at once) and travel to a per-thread
+ * device buffer on `stream`; both buffers are allocated once and grow on demand.  A thread that alternates between
+ * streams must not have more than one call's descriptors in flight per stream pair — the second call waits for the
+ * first one's descriptor copy, not for its kernels.
+ * Returns 0; -1 invalid arguments / library not initialised; -2 launch failure; -3 geometry too large; -4 runtime error. */
 int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nframes, void *stream);
 
 /* Same, with the descriptor array already resident on the device (`d_frames`), for callers

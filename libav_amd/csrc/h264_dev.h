@@ -141,6 +141,18 @@ __device__ __forceinline__ int px_clamped(const PlaneRef &p, int x, int y)
     return p.base[(size_t)y * p.stride + x];
 }
 
+/* developer instrumentation (-DMI355_PROF): RPROF(i) adds the shader cycles since the previous mark of this wave to
+ * g_rprof[i]; only waves of the first blocks report (tools/prof_recon.sh) */
+#if defined(MI355_PROF) && !defined(MI355_HIP_EMU_H)
+__device__ unsigned long long g_rprof[16];
+__shared__ unsigned long long rprof_last;
+#define RPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536u) { atomicAdd(&g_rprof[i], now_ - rprof_last); rprof_last = now_; } } while (0)
+#define RPROF_START() do { if ((threadIdx.x & 63) == 0) rprof_last = __builtin_readcyclecounter(); } while (0)
+#else
+#define RPROF(i) do { } while (0)
+#define RPROF_START() do { } while (0)
+#endif
+
 /* ---- per-wave LDS scratch -------------------------------------------------- */
 /* Reference windows are staged ALIGNED TO THE BLOCK: luma window byte b of row r is picture sample
  * (ix - 4 + b, iy - 2 + r), so block column 0 sits on a dword boundary and every 4-sample segment
@@ -309,8 +321,10 @@ __device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, 
     }
     Win16 w;
     w.issue(y.base, cb.base, cr.base, y.stride, cb.stride, ix, iy, cx, cy);
+    RPROF(2);
     w.commit(s, ix, cx);
     MI355_WAVE_SYNC();
+    RPROF(3);
 }
 
 __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int *v)

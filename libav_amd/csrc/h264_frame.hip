@@ -145,6 +145,7 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
 #ifndef MI355_EXP_NO_LUMA
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
 #endif
+    RPROF(4);
 #ifndef MI355_EXP_NO_CHROMA
     if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, my & 7, pcb, pcr, 8, avg);
     else mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
@@ -398,6 +399,7 @@ __global__ void __launch_bounds__(64)
 k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
     __shared__ MbLds s;
+    RPROF_START();
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
     /* lin = (f * max_h + mb_y) * max_w + mb_x */
@@ -406,10 +408,13 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     const FrameHot fr = frame_hot(frames[f]);
     if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
+    RPROF(0);
     load_mb(s, fr, mb_xy, true);
+    RPROF(1);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
     const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
     hl_motion(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
+    RPROF(5);
 #ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
     if (uniform((int)s.hdr.mb_type) & MI355_MB_8x8DCT) {
@@ -419,7 +424,9 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
         residual_blocks<true>(s);
     }
 #endif
+    RPROF(6);
     store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr, mb_x, mb_y);
+    RPROF(7);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1136,7 +1143,7 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 /* ------------------------------------------------------------------------- */
 extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
-    if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
+    if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     /* div_magic is exact below 2^24 work items: larger batches go out as several launches */
     const int per_frame = max_mb_width * max_mb_height;
     if (per_frame <= 0 || per_frame >= (1 << 24)) return -3;
@@ -1154,7 +1161,7 @@ extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int 
 
 extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream)
 {
-    if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
+    if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     if (max_intra_level <= 0 || max_level_width <= 0) return 0;
     for (int level = 1; level <= max_intra_level; level++)
         hipLaunchKernelGGL(k_recon_intra, dim3((unsigned)(nframes * max_level_width)), dim3(64), 0, (hipStream_t)stream,
@@ -1163,6 +1170,13 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
 }
 
 #ifdef MI355_PROF
+extern "C" void mi355_debug_rprof(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = {};
+    MI355_CHECK(hipDeviceSynchronize());
+    MI355_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rprof), sizeof(z)));
+    if (reset) MI355_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_rprof), z, sizeof(z)));
+}
 extern "C" void mi355_debug_prof(unsigned long long *out, int reset)
 {
     unsigned long long z[16] = {};
@@ -1174,7 +1188,7 @@ extern "C" void mi355_debug_prof(unsigned long long *out, int reset)
 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
-    if (!mi355::ready() || !d_frames || nframes <= 0) return -1;
+    if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     (void)max_mb_width;
     /* bands of four MB rows, top to bottom: band b reads the rows band b-1 finished */
     for (int band = 0; band * 4 < max_mb_height; band++)
@@ -1192,24 +1206,46 @@ extern "C" int mi355_h264_decode_frames_dev(const mi355_h264_frame *d_frames, in
     return mi355_h264_deblock_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
 }
 
+/* Descriptors of the host-array entry point travel through a per-thread pinned staging buffer and a per-thread device
+ * buffer, both grow-only: no allocation, no synchronisation and no pageable copy per call.  The event marks the last
+ * copy out of the staging buffer, so that the next call does not overwrite descriptors still being read. */
+namespace {
+struct DescStage {
+    mi355_h264_frame *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t copied = nullptr;
+};
+}
 extern "C" int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nframes, void *stream)
 {
-    if (!mi355::ready() || !frames || nframes <= 0) return -1;
-    int mw = 0, mh = 0, ml = 0;
+    if (!mi355::bind() || !frames || nframes <= 0) return -1;
+    static thread_local DescStage st;
+    int mw = 0, mh = 0, ml = 0, lw = 0;
     for (int i = 0; i < nframes; i++) {
         if (frames[i].mb_width > mw) mw = frames[i].mb_width;
         if (frames[i].mb_height > mh) mh = frames[i].mb_height;
         if (frames[i].max_intra_level > ml) ml = frames[i].max_intra_level;
+        if (frames[i].max_level_width > lw) lw = frames[i].max_level_width;
     }
-    /* descriptors travel through a per-call device buffer; the level width is bounded by the
-     * picture's anti-diagonal only for all-intra pictures, so use the MB count as the safe bound */
-    mi355_h264_frame *d = nullptr;
-    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(*d) * (size_t)nframes));
-    MI355_CHECK(hipMemcpyAsync(d, frames, sizeof(*d) * (size_t)nframes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    int rc = mi355_h264_decode_frames_dev(d, nframes, mw, mh, ml, mw * mh, stream);
-    MI355_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    MI355_CHECK(hipFree(d));
-    return rc;
+    if (!st.copied) MI355_TRY(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming), -4);
+    else MI355_TRY(hipEventSynchronize(st.copied), -4);
+    if ((size_t)nframes > st.cap) {
+        size_t ncap = st.cap ? st.cap : 64;
+        while (ncap < (size_t)nframes) ncap *= 2;
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.dev) { MI355_TRY(hipDeviceSynchronize(), -4); (void)hipFree(st.dev); }     /* kernels of earlier calls may still read it */
+        st.host = st.dev = nullptr; st.cap = 0;
+        MI355_TRY(hipHostMalloc(reinterpret_cast<void **>(&st.host), sizeof(*st.host) * ncap), -4);
+        MI355_TRY(hipMalloc(reinterpret_cast<void **>(&st.dev), sizeof(*st.dev) * ncap), -4);
+        st.cap = ncap;
+    }
+    std::memcpy(st.host, frames, sizeof(*frames) * (size_t)nframes);
+    MI355_TRY(hipMemcpyAsync(st.dev, st.host, sizeof(*frames) * (size_t)nframes, hipMemcpyHostToDevice, (hipStream_t)stream), -4);
+    MI355_TRY(hipEventRecord(st.copied, (hipStream_t)stream), -4);
+    /* a picture whose descriptor does not say how wide its widest intra level is (0) gets the safe bound: every
+     * macroblock of a level (an anti-diagonal cannot hold more than the smaller picture dimension plus one) */
+    if (ml > 0 && lw <= 0) lw = (mw < mh ? mw : mh) + 1;
+    return mi355_h264_decode_frames_dev(st.dev, nframes, mw, mh, ml, lw, stream);
 }
 
 extern "C" int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
@@ -1256,19 +1292,19 @@ extern "C" int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb
 extern "C" void *mi355_malloc(size_t bytes)
 {
     void *p = nullptr;
-    if (!mi355::ready() || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (!mi355::bind() || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     return p;
 }
 extern "C" void mi355_free(void *p) { if (p) (void)hipFree(p); }
-extern "C" int mi355_memcpy_h2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
-extern "C" int mi355_memcpy_d2h(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
-extern "C" int mi355_memcpy_d2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1; }
+extern "C" int mi355_memcpy_h2d(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+extern "C" int mi355_memcpy_d2h(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+extern "C" int mi355_memcpy_d2d(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
 
 extern "C" void *mi355_stream_create(void)
 {
-    hipStream_t st;
-    MI355_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipStream_t st = nullptr;
+    if (!mi355::bind() || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return st;
 }
 extern "C" void mi355_stream_destroy(void *st) { (void)hipStreamDestroy((hipStream_t)st); }
@@ -1276,8 +1312,8 @@ extern "C" int mi355_stream_wait_event(void *st, void *e) { return hipStreamWait
 
 extern "C" void *mi355_event_create(void)
 {
-    hipEvent_t e;
-    MI355_CHECK(hipEventCreate(&e));
+    hipEvent_t e = nullptr;
+    if (!mi355::bind() || hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 extern "C" void mi355_event_destroy(void *e) { (void)hipEventDestroy((hipEvent_t)e); }
@@ -1286,7 +1322,6 @@ extern "C" int mi355_event_record(void *e, void *stream) { return hipEventRecord
 extern "C" float mi355_event_elapsed_ms(void *a, void *b)
 {
     float ms = 0.f;
-    MI355_CHECK(hipEventSynchronize((hipEvent_t)b));
-    MI355_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b));
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess || hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f;
     return ms;
 }

@@ -82,7 +82,17 @@ __device__ __forceinline__ int mi355_div20(int i, int inv) { return (int)(__umul
         if (e_ != hipSuccess) {                                                              \
             std::fprintf(stderr, "mi355dsp: %s failed: %s (%s:%d)\n", #expr,                 \
                          hipGetErrorString(e_), __FILE__, __LINE__);                         \
-            std::abort(); /* the pointer tables are void: there is no error channel */      \
+            std::abort(); /* Tier 1 only: the pointer tables are void, there is no error channel */ \
+        }                                                                                    \
+    } while (0)
+/* Tier 2 (batched entry points: they have return codes): report and hand the failure to the caller */
+#define MI355_TRY(expr, rc)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            std::fprintf(stderr, "mi355dsp: %s failed: %s (%s:%d)\n", #expr,                 \
+                         hipGetErrorString(e_), __FILE__, __LINE__);                         \
+            return rc;                                                                       \
         }                                                                                    \
     } while (0)
 
@@ -101,10 +111,14 @@ struct Arena {
     size_t take(size_t n)
     {
         size_t off = (used + 15) & ~(size_t)15;
-        if (off + n > cap) { std::fprintf(stderr, "mi355dsp: staging arena overflow\n"); std::abort(); }
+        if (off + n > cap) { std::fprintf(stderr, "mi355dsp: staging arena overflow (an entry point did not reserve() its operands)\n"); std::abort(); }
         used = off + n;
         return off;
     }
+    /* make room for `need` bytes of operands BEFORE the first take() of a call (entry points whose operand sizes are not
+     * bounded by the codec: filter banks, picture lines); pointers handed out earlier do not survive a growth */
+    void reserve(size_t need) { if (need + 4096 > cap) grow(need + 4096); }
+    void grow(size_t need);
     template <typename T> T *h(size_t off) { return reinterpret_cast<T *>(host + off); }
     template <typename T> T *d(size_t off) { return reinterpret_cast<T *>(dev + off); }
     void upload() { MI355_CHECK(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, stream)); }
@@ -131,6 +145,9 @@ Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int row
 void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows);
 
 bool ready();
+/* bind the calling thread to the device chosen in mi355_init() (the reference calls the tables and the batch entry points
+ * from frame / slice threads; a thread that never set a device would use device 0); false without a successful init */
+bool bind();
 
 }  // namespace mi355
 #endif

@@ -1,26 +1,51 @@
 /* mi355_rt.hip — runtime: device selection, thread-local staging arenas. */
+#include <atomic>
 #include "mi355_rt.h"
 #include "../../include/mi355dsp.h"
 
 namespace mi355 {
 
-static int g_device = -1;
+static std::atomic<int> g_device{-1};
 
-bool ready() { return g_device >= 0; }
+bool ready() { return g_device.load(std::memory_order_acquire) >= 0; }
+
+bool bind()
+{
+    static thread_local int bound = -1;
+    const int d = g_device.load(std::memory_order_acquire);
+    if (d < 0) return false;
+    if (bound != d) {
+        if (hipSetDevice(d) != hipSuccess) return false;
+        bound = d;
+    }
+    return true;
+}
 
 void Arena::ensure()
 {
     if (dev) return;
-    if (g_device < 0) {
+    if (!bind()) {
         std::fprintf(stderr, "mi355dsp: mi355_init() was not called or found no GPU; "
                              "there is no CPU fallback in this library\n");
         std::abort();
     }
-    MI355_CHECK(hipSetDevice(g_device));
-    cap = 1 << 20;
+    cap = 4 << 20;
     MI355_CHECK(hipStreamCreate(&stream));
     MI355_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap));
     MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), cap));
+}
+
+void Arena::grow(size_t need)
+{
+    size_t ncap = cap;
+    while (ncap < need) ncap *= 2;
+    uint8_t *nh = nullptr, *nd = nullptr;
+    MI355_CHECK(hipHostMalloc(reinterpret_cast<void **>(&nh), ncap));
+    MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&nd), ncap));
+    MI355_CHECK(hipStreamSynchronize(stream));
+    MI355_CHECK(hipHostFree(host));
+    MI355_CHECK(hipFree(dev));
+    host = nh; dev = nd; cap = ncap;
 }
 
 Arena &arena()
@@ -73,13 +98,13 @@ extern "C" int mi355_init(int device)
         return -3;
     }
     if (hipSetDevice(device) != hipSuccess) return -4;
-    mi355::g_device = device;
+    mi355::g_device.store(device, std::memory_order_release);
     return 0;
 }
 
 extern "C" int mi355_device_cus(void)
 {
     hipDeviceProp_t prop;
-    if (!mi355::ready() || hipGetDeviceProperties(&prop, mi355::g_device) != hipSuccess) return -1;
+    if (!mi355::ready() || hipGetDeviceProperties(&prop, mi355::g_device.load()) != hipSuccess) return -1;
     return prop.multiProcessorCount;
 }

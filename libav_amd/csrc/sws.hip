@@ -174,7 +174,8 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         }
         return;
     }
-    /* idx / n as a 24-bit multiply and a shift: exact for idx * (n - 1) < 2^20 (idx < SG * SRC_DW) */
+    /* idx / n as a 24-bit multiply and a shift (mi355_div20: exact for idx * n < 2^19; here idx < SG * n, n <= SRC_DW) */
+    static_assert(SG * SRC_DW * SRC_DW < (1 << 19), "mi355_div20 range");
     const int np = al16 ? (nd + 3) >> 2 : nd, inv = mi355_inv20(np);
     for (int base = lo; base <= hi; base += SG) {
         for (int idx = tid; idx < SG * np; idx += NT) {
@@ -423,6 +424,7 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
         uint8_t *d0 = tile_dst;
         const int nrows = y1 - y0 + 1;
         const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
+        /* mi355_div20 below: idx < nrows * n with nrows <= 16 and n <= TW * 3 / 4 = 96: idx * n < 2^18 */
         if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
             const int n = nbytes >> 4, inv = mi355_inv20(n);
             for (int idx = tid; idx < nrows * n; idx += NT) {
@@ -692,6 +694,7 @@ extern "C" void mi355_sws_hscale8to15(int16_t *dst, int dstW, const uint8_t *src
     int last = 0;
     for (int i = 0; i < dstW; i++) if (filterPos[i] > last) last = filterPos[i];
     const size_t nsrc = (size_t)last + filterSize;
+    a.reserve(nsrc + (size_t)dstW * filterSize * 2 + (size_t)dstW * 6 + 64);
     const size_t o_src = a.take(nsrc), o_f = a.take((size_t)dstW * filterSize * 2), o_p = a.take((size_t)dstW * 4), o_d = a.take((size_t)dstW * 2);
     std::memcpy(a.h<uint8_t>(o_src), src, nsrc);
     std::memcpy(a.h<int16_t>(o_f), filter, (size_t)dstW * filterSize * 2);
@@ -713,6 +716,7 @@ static void plane_line(const int16_t *filter, int fs, const int16_t **rows, uint
 {
     Arena &a = arena();
     const int n = fs ? fs : 1, pitch = (dstW + 7) & ~7;
+    a.reserve((size_t)n * pitch * 2 + (size_t)n * 2 + (size_t)dstW + 128);
     const size_t o_r = pack_rows(a, rows, n, dstW, pitch), o_f = a.take((size_t)n * 2), o_di = a.take(8), o_d = a.take((size_t)dstW);
     if (fs) std::memcpy(a.h<int16_t>(o_f), filter, (size_t)fs * 2);
     std::memcpy(a.h<uint8_t>(o_di), dither, 8);
@@ -735,6 +739,7 @@ static void rgb_line(const mi355_sws_luts *luts, int mode, const int16_t *lumF, 
 {
     Arena &a = arena();
     const int npair = (dstW + 1) >> 1, pitch = (2 * npair + 7) & ~7;
+    a.reserve(sizeof(mi355_sws_luts) + (size_t)(ls + 2 * cs + 3) * pitch * 2 + (size_t)(ls + cs) * 2 + (size_t)npair * 6 + 256);
     const size_t o_t = a.take(sizeof(mi355_sws_luts));
     std::memcpy(a.h<uint8_t>(o_t), luts, sizeof(mi355_sws_luts));
     const size_t o_l = pack_rows(a, l, ls, 2 * npair, pitch), o_u = pack_rows(a, u, cs, npair, pitch), o_v = pack_rows(a, v, cs, npair, pitch);

@@ -36,10 +36,11 @@ class Frame(C.Structure):
                 ("ref", (C.c_void_p * 3) * MAX_SLOTS),
                 ("mb", C.c_void_p), ("mv", C.c_void_p * 2), ("coef", C.c_void_p),
                 ("slices", C.c_void_p), ("nslices", C.c_int32), ("max_intra_level", C.c_int32),
-                ("intra_list", C.c_void_p), ("intra_level_start", C.c_void_p)]
+                ("intra_list", C.c_void_p), ("intra_level_start", C.c_void_p),
+                ("max_level_width", C.c_int32), ("reserved", C.c_int32)]
 
 
-assert C.sizeof(Frame) == 904
+assert C.sizeof(Frame) == 912
 
 # mb_type bits
 I4, I16, PCM, T16x16, T16x8, T8x16, T8x8 = 1, 2, 4, 8, 16, 32, 64
@@ -401,6 +402,7 @@ def host_frames(fs, recon, dst):
         fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
         fr.intra_list = fs.intra_list[f].ctypes.data
         fr.intra_level_start = fs.intra_start[f].ctypes.data
+        fr.max_level_width = fs.max_level_width
     return arr, keep
 
 
@@ -495,6 +497,7 @@ class DeviceFrames:
             fr.max_intra_level = int(fs.intra_start[g].shape[0]) - 1
             fr.intra_list = ilist[g]          # read-only: shared between the copies
             fr.intra_level_start = istart[g]
+            fr.max_level_width = fs.max_level_width
         self.host_desc = arr
         self.d_desc = self.alloc(C.sizeof(arr))
         self.lib.mi355_memcpy_h2d(self.d_desc, C.addressof(arr), C.sizeof(arr))

@@ -122,6 +122,8 @@ static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t
 #include <chrono>
 struct emu_event { std::chrono::steady_clock::time_point t; };
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event; return hipSuccess; }
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
