@@ -9,8 +9,13 @@ streams shard across ranks); torch.distributed (RCCL) is only the control plane:
 max/sum of the per-rank counters.
 
 Prints ONE JSON line: metric macroblocks/s (whole job), plus `roofline` for the dominant
-kernel (HIP-event timed) and `cpu_baseline` (the CPU oracle — a scalar port of the
-reference's C path — timed on the host cores on a bounded sample of the same workload).
+kernel (HIP-event timed), `cpu_baseline` (the reference's own C functions from oracle/_ref/libref.so —
+kind "reference" — or, where that object is missing, the scalar oracle — kind "port" — on ALL hardware threads of
+this box, pinned, on a bounded sample of the same workload) and `extra`: further measured points of the same path
+(64 pictures per step, all-intra pictures, content on which the loop filter fires, swscale config 5, HEVC config 3).
+
+The workload generator is the one tests/test_frame_gpu.py::test_full_size_1080p_batch_matches_oracle checks
+bit-exactly against the oracle at full size; the bench itself does not check outputs.
 """
 import argparse
 import ctypes as C
@@ -55,6 +60,9 @@ def main():
     ap.add_argument("--mb-height", type=int, default=68)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional measured points (rank 0, N=1 only)")
+    ap.add_argument("--queue", action="store_true", help="N>1: ranks pull step-sized batches of streams from the work queue "
+                    "(libav_amd.shard.WorkQueue) instead of the static deal; a rank may then run more or fewer than --steps steps")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,20 +129,35 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    evs = [[lib.mi355_event_create() for _ in range(4)] for _ in range(args.steps)]
+    queue = shard.WorkQueue(world * args.steps, 1) if (args.queue and world > 1) else None
+    evs = []
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
+    if queue is None:
+        for k in range(args.steps):
+            evs.append([lib.mi355_event_create() for _ in range(4)])
+            step(evs[-1])
+    else:
+        # one batch in flight plus one queued: a rank only pulls when its previous-but-one batch has finished
+        while True:
+            if len(evs) >= 2:
+                lib.mi355_event_elapsed_ms(evs[-2][0], evs[-2][3])      # waits for that batch's last event
+            if queue.next() is None:
+                break
+            evs.append([lib.mi355_event_create() for _ in range(4)])
+            step(evs[-1])
     assert lib.mi355_sync(stream) == 0
     barrier()
     elapsed = time.perf_counter() - t0
+    my_steps = len(evs)
 
-    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for e in evs) / args.steps
-    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / args.steps
-    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / args.steps
+    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for e in evs) / max(1, my_steps)
+    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / max(1, my_steps)
+    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / max(1, my_steps)
 
-    elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * args.steps, "cuda" if world > 1 else "cpu")
+    elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * my_steps, "cuda" if world > 1 else "cpu")
+    steps_per_rank = shard.gather_counts(my_steps, "cuda" if world > 1 else "cpu")
+    backend_world = dist.get_world_size() if dist is not None else 1
 
     if rank == 0:
         value = total_mbs / elapsed
@@ -151,13 +174,16 @@ def main():
             "metric": "macroblocks_per_s", "value": value, "unit": "macroblocks/s",
             "frames_per_s": value / nmb, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "rccl_world_size": backend_world, "distribution": "work queue" if queue is not None else "static deal",
+            "steps_per_rank": steps_per_rank,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "H.264 8-bit 4:2:0 1080p (1920x1088 coded), P pictures: qpel MC + idct_add + deblock, "
                                    "two-surface pipeline, %d independent pictures per GPU per step "
                                    "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, G),
                        "frames_per_gpu": F, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
                        "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
-                       "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world},
+                       "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world,
+                       "verified_by": "tests/test_frame_gpu.py::test_full_size_1080p_batch_matches_oracle (same generator, bit-exact)"},
             "pass_ms": {"recon_inter": t_inter, "recon_intra": t_intra, "deblock": t_deblock},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
@@ -169,15 +195,57 @@ def main():
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, F)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fs, args.cpu_seconds)
+        dev.free()
+        dev = None
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_points(lib, prov, mbw, mbh)
         print(json.dumps(out))
-    dev.free()
+    if dev is not None:
+        dev.free()
     if dist is not None:
         dist.destroy_process_group()
 
 
+def extra_points(lib, prov, mbw, mbh):
+    """Further measured points of the same path (each: the three passes back to back, HIP events, 3 steps after 1 warm-up)."""
+    import h264_frames as HF
+    pts = []
+
+    def run(name, fs, F, note):
+        dev = HF.DeviceFrames(prov, fs, replicate=F)
+        try:
+            def once():
+                assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
+                assert lib.mi355_h264_recon_intra_dev(dev.d_desc, F, fs.max_intra_level, fs.max_level_width, None) == 0
+                assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
+            once()
+            e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
+            lib.mi355_event_record(e0, None)
+            for _ in range(3):
+                once()
+            lib.mi355_event_record(e1, None)
+            ms = lib.mi355_event_elapsed_ms(e0, e1) / 3
+        finally:
+            dev.free()
+        v = F * mbw * mbh / (ms * 1e-3)
+        pts.append({"name": name, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F,
+                    "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "note": note})
+
+    base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
+    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (the band launches of k_deblock hold 64 waves)")
+    run("config2_f512", base, 512, "512 pictures per step")
+    intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
+    run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra" % intra.max_intra_level)
+    smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
+    run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
+        "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
+    return pts
+
+
 def cpu_baseline(fs, seconds):
-    """The CPU oracle (scalar port of the reference C path; oracle/) on this box's host cores, each thread
-    decoding its own picture of the same workload repeatedly for ~`seconds`."""
+    """The reference's own C functions (oracle/_ref/libref.so, kind "reference"; the scalar oracle, kind "port", where that
+    object is missing) on every hardware thread of this box, one pinned thread per logical CPU, each decoding its own
+    picture of the same workload repeatedly for ~`seconds`."""
     import providers
     import h264_frames as HF
     orc = providers.oracle()
@@ -198,43 +266,38 @@ def cpu_baseline(fs, seconds):
                                       "--disable-asm equivalent) called by the restated per-macroblock driver"
         except (OSError, AttributeError):
             pass
-    ncores = os.cpu_count() or 1
-    nthreads = max(1, min(ncores, 64))
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    nthreads = max(1, len(cpus))
+    nmb = fs.mb_w * fs.mb_h
+    # one core first (also warms the tables)
     recon, dst = fs.planes(), fs.planes()
     arr, _ = HF.host_frames(fs, recon, dst)
-    # warm the oracle's tables single-threaded, and time one core
     t0 = time.perf_counter()
     lib.oracle_h264_recon_frame(C.byref(arr[0]))
     lib.oracle_h264_deblock_frame(C.byref(arr[0]))
     one = time.perf_counter() - t0
-    nmb = fs.mb_w * fs.mb_h
-    # per-thread private output surfaces; inputs are shared read-only
-    ctxs = []
+    # per-thread private output surfaces; inputs are shared read-only.  The threads are pthreads inside the oracle
+    # library (oracle_h264_bench_threads), pinned one per logical CPU: no interpreter in the timed loop.
+    import numpy as np
+    frames = (HF.Frame * nthreads)()
+    keep = []
     for t in range(nthreads):
-        r, d = HF.FrameSet.planes(fs), HF.FrameSet.planes(fs)
-        a, _ = HF.host_frames(fs, r, d)
-        ctxs.append((a, r, d))
-    counts = [0] * nthreads
-    stop = time.perf_counter() + seconds
-
-    def work(t):
-        a = ctxs[t][0]
-        g = t % fs.F
-        while time.perf_counter() < stop:
-            lib.oracle_h264_recon_frame(C.byref(a[g]))
-            lib.oracle_h264_deblock_frame(C.byref(a[g]))
-            counts[t] += 1
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
-    t0 = time.perf_counter()
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    wall = time.perf_counter() - t0
-    return {"value": sum(counts) * nmb / wall, "unit": "macroblocks/s", "cores": nthreads, "kind": kind,
+        C.memmove(C.byref(frames, t * C.sizeof(HF.Frame)), C.byref(arr[t % fs.F]), C.sizeof(HF.Frame))
+        bufs = [np.zeros((2, fs.H >> (p > 0), fs.W >> (p > 0)), np.uint8) for p in range(3)]      # [recon, dst] per plane
+        keep.append(bufs)
+        for p in range(3):
+            frames[t].recon[p] = bufs[p][0].ctypes.data
+            frames[t].dst[p] = bufs[p][1].ctypes.data
+    cpu_arr = (C.c_int * nthreads)(*cpus)
+    wall = C.c_double(0.0)
+    lib.oracle_h264_bench_threads.restype = C.c_long
+    lib.oracle_h264_bench_threads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
+    n = lib.oracle_h264_bench_threads(C.cast(frames, C.c_void_p), nthreads, C.cast(cpu_arr, C.c_void_p), float(seconds), C.byref(wall))
+    return {"value": n * nmb / wall.value, "unit": "macroblocks/s", "cores": nthreads, "kind": kind,
             "value_1core": nmb / one,
-            "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d threads; %s "
-                      "(reference x86 SIMD not built: no nasm in the image)" % (min(nthreads, fs.F), seconds, nthreads, what)}
+            "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d pinned pthreads (every logical CPU "
+                      "this process may run on); %s (reference x86 SIMD not built: no nasm in the image)"
+                      % (min(nthreads, fs.F), seconds, nthreads, what)}
 
 
 if __name__ == "__main__":

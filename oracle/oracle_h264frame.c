@@ -471,3 +471,59 @@ void oracle_h264_deblock_frame(const mi355_h264_frame *f)
         for (int x = 0; x < f->mb_width; x++)
             filter_mb(f, x, y);
 }
+
+/* ---- CPU baseline driver (bench.py's cpu_baseline leg; SURVEY.md 8d: pthreads, pinned, each thread its own pictures) ----
+ * `nthreads` threads, thread t pinned to cpus[t] (or unpinned when cpus == NULL), each reconstructing and deblocking
+ * its own picture frames[t] repeatedly until `seconds` have passed; returns the total number of pictures decoded and
+ * writes the wall time. */
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+typedef struct {
+    const mi355_h264_frame *f;
+    int cpu;
+    double deadline;
+    long count;
+} BenchArg;
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static void *bench_thread(void *p)
+{
+    BenchArg *a = p;
+    if (a->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    while (now_s() < a->deadline) {
+        oracle_h264_recon_frame(a->f);
+        oracle_h264_deblock_frame(a->f);
+        a->count++;
+    }
+    return NULL;
+}
+long oracle_h264_bench_threads(const mi355_h264_frame *frames, int nthreads, const int *cpus, double seconds, double *wall_s)
+{
+    pthread_t *th = calloc((size_t)nthreads, sizeof(*th));
+    BenchArg *args = calloc((size_t)nthreads, sizeof(*args));
+    ensure_tables();
+    const double t0 = now_s();
+    for (int t = 0; t < nthreads; t++) {
+        args[t] = (BenchArg){ &frames[t], cpus ? cpus[t] : -1, t0 + seconds, 0 };
+        pthread_create(&th[t], NULL, bench_thread, &args[t]);
+    }
+    long total = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        total += args[t].count;
+    }
+    if (wall_s) *wall_s = now_s() - t0;
+    free(th);
+    free(args);
+    return total;
+}

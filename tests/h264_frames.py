@@ -545,18 +545,24 @@ class DeviceFrames:
         self.bufs = []
 
 
-def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05, mv_range=64, lib=None):
+def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05, mv_range=64, lib=None, refs="noise", coef_b=None):
     """Vectorised generator for the benchmark workload (headline variant):
     P pictures, one 16x16 partition per inter MB, `intra_frac` Intra16x16 MBs (they force bS 3/4 edges),
     ref_idx ~ U{0..nrefs-1}, mv ~ U[-mv_range, mv_range) quarter samples, 24 4x4 blocks coded w.p. 0.5.
-    `lib`: a loaded libmi355dsp (its host helper mi355_h264_intra_schedule builds the intra schedule)."""
+    `lib`: a loaded libmi355dsp (its host helper mi355_h264_intra_schedule builds the intra schedule).
+    refs="smooth" / coef_b (Laplace scale of the levels, default 24): content on which the loop filter's conditions hold."""
     fs = FrameSet(nframes, mb_w, mb_h, nrefs)
     r = SplitMix64(seed)
+    COEF_B[0] = 24 if coef_b is None else coef_b
+    dc_scale = COEF_B[0] / 24.0
     nmb = mb_w * mb_h
     N = nframes * nmb
     for f in range(nframes):
         for s in range(nrefs):
-            fs.refs[f][s] = (r.u8((fs.H, fs.W)), r.u8((fs.H // 2, fs.W // 2)), r.u8((fs.H // 2, fs.W // 2)))
+            if refs == "noise":
+                fs.refs[f][s] = (r.u8((fs.H, fs.W)), r.u8((fs.H // 2, fs.W // 2)), r.u8((fs.H // 2, fs.W // 2)))
+            else:
+                fs.refs[f][s] = (_ref_plane(r, fs.H, fs.W, refs), _ref_plane(r, fs.H // 2, fs.W // 2, refs), _ref_plane(r, fs.H // 2, fs.W // 2, refs))
     sl = fs.slices[:, 0]
     sl["list_count"] = 1
     sl["ref_slot"][:, 0, :nrefs] = np.arange(nrefs)
@@ -609,12 +615,12 @@ def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05,
     blks[intra, :16, 0] = 0
     coded &= (blks != 0).any(axis=2)
     cmode = r.randint(0, 2, N)
-    cdc = r.laplace_int(30, (N, 8), 2047)
+    cdc = r.laplace_int(max(1, int(30 * dc_scale)), (N, 8), 2047)
     cdc[cmode == 0] = 0
     blks[cmode < 2, 16:, :] = 0
     coded[cmode < 2, 16:] = False
     blks[:, 16:, 0] = cdc
-    ldc = r.laplace_int(40, (N, 16), 2047)
+    ldc = r.laplace_int(max(1, int(40 * dc_scale)), (N, 16), 2047)
     has_ldc = intra & (r.uniform(N) < 0.8)
     slots = np.array([luma_dc_slot(k) for k in range(16)])
     cf = fs.coef.reshape(N, 384)
