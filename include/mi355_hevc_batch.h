@@ -129,6 +129,40 @@ typedef struct mi355_hevc_intra_job {
 } mi355_hevc_intra_job;
 int mi355_hevc_intra_batch_dev(const mi355_hevc_intra_job *d_jobs, int n, int bit_depth, void *stream);
 
+/* ---- a16, picture level: ff_hevc_hls_filter's deblocking half for a whole picture (deblocking_filter_CTB,
+ * hevc_filter.c:337-505, with its tables tctable / betatable :35-45, chroma_tc :47-72, TC_CALC :332, get_qPy :166,
+ * get_pcm :316) from the frame-level arrays the reference's slice decoder leaves behind — no per-edge work on the host.
+ * All vertical edges of the picture, then all horizontal ones: the reference's per-CTB order (vertical edges of a CTB,
+ * then the horizontal ones eight samples to the left) gives the same picture, because no vertical edge reads a sample a
+ * horizontal edge filtered earlier wrote.  Edge parameters follow the CTB that contains the edge sample
+ * (cur_tc_offset / left_tc_offset, :456-457, :488-490).  All pointers are device pointers. */
+typedef struct mi355_hevc_db_params {   /* DBParams, hevcdec.h:359-362 */
+    int32_t beta_offset, tc_offset;
+} mi355_hevc_db_params;
+typedef struct mi355_hevc_lf_picture {
+    uint8_t *data[3];                  /* s->frame->data: filtered in place */
+    int32_t linesize[3];               /* bytes */
+    int32_t width, height;             /* sps->width / height (luma samples) */
+    int32_t log2_ctb_size;             /* sps->log2_ctb_size */
+    int32_t log2_min_cb_size;          /* sps->log2_min_cb_size, granularity of qp_y_tab */
+    int32_t log2_min_pu_size;          /* sps->log2_min_pu_size, granularity of is_pcm / tab_mvf */
+    int32_t min_cb_width;              /* sps->min_cb_width */
+    int32_t min_pu_width, min_pu_height;
+    int32_t ctb_width;                 /* sps->ctb_width */
+    int32_t bs_width;                  /* s->bs_width = width >> 3 */
+    const uint8_t *vertical_bs;        /* s->vertical_bs [(x >> 3) + (y >> 2) * bs_width] */
+    const uint8_t *horizontal_bs;      /* s->horizontal_bs [(x + y * bs_width) >> 2] */
+    const int8_t *qp_y_tab;            /* s->qp_y_tab */
+    const uint8_t *is_pcm;             /* s->is_pcm (only read when pcmf) */
+    const mi355_hevc_db_params *deblock;   /* s->deblock, one per CTB in raster order */
+    int32_t pcmf;                      /* (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag) || pps->transquant_bypass_enable_flag */
+    int32_t cb_qp_offset, cr_qp_offset;    /* pps->cb_qp_offset / cr_qp_offset */
+} mi355_hevc_lf_picture;
+/* `d_pics`: device array of `npics` descriptors (pictures of independent streams, or of one stream once their
+ * reconstruction is complete).  4:2:0, bit depth 8..10.  Enqueues four launches on `stream` (luma and chroma, vertical
+ * then horizontal) and returns.  max_width / max_height: the largest picture of the batch. */
+int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pics, int npics, int max_width, int max_height, int bit_depth, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,6 +230,123 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_batch(const mi355_hevc_lf_j
     hevc_lf_chroma_wave(pix, xs, ys, j.tc, j.no_p, j.no_q, bd, true, on && j.chroma);
 }
 
+/* ---- deblocking of whole pictures from the frame-level arrays (deblocking_filter_CTB, hevc_filter.c:337-505) ------
+ * One launch per direction.  A group of eight lanes = one 8-sample edge segment (luma) or one 8-chroma-sample segment
+ * (two 8-luma-sample halves); the group derives its own parameters — bS from the reference's arrays, QP average
+ * (get_qPy :166), beta / tc through the tables (:35-45, TC_CALC :332, chroma_tc :47-72) with the offsets of the CTB
+ * that contains the edge sample, pcm / bypass masks (get_pcm :316) — and filters.  Waves are luma or chroma as a
+ * whole.  Segments of one direction never share a sample, so the launch needs no ordering. */
+__device__ const uint8_t k_hevc_tctable[54] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+    5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+__device__ const uint8_t k_hevc_betatable[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28,
+    30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+__device__ const uint8_t k_hevc_qp_c[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+
+struct LfPic {      /* the descriptor with its pointers in the global address space */
+    const mi355_hevc_lf_picture &p;
+    __device__ __forceinline__ int qpy(int x, int y) const
+    {
+        return mi355_global_v(p.qp_y_tab)[(x >> p.log2_min_cb_size) + (y >> p.log2_min_cb_size) * p.min_cb_width];
+    }
+    __device__ __forceinline__ int pcm(int x, int y) const
+    {
+        if (x < 0 || y < 0) return 2;
+        const int xp = x >> p.log2_min_pu_size, yp = y >> p.log2_min_pu_size;
+        if (xp >= p.min_pu_width || yp >= p.min_pu_height) return 2;
+        return mi355_global_v(p.is_pcm)[yp * p.min_pu_width + xp];
+    }
+    __device__ __forceinline__ mi355_hevc_db_params db(int x, int y) const
+    {
+        return mi355_global_v(p.deblock)[(x >> p.log2_ctb_size) + (y >> p.log2_ctb_size) * p.ctb_width];
+    }
+    __device__ __forceinline__ int chroma_tc(int qp_y, int c_idx, int tc_offset) const
+    {
+        const int qp_i = clip3(qp_y + (c_idx == 1 ? p.cb_qp_offset : p.cr_qp_offset), 0, 57);
+        const int qp = qp_i < 30 ? qp_i : (qp_i > 43 ? qp_i - 6 : k_hevc_qp_c[qp_i - 30]);
+        return k_hevc_tctable[clip3(qp + 2 + tc_offset, 0, 53)];
+    }
+};
+__device__ __forceinline__ int hevc_tc_calc(int qp, int bs, int tc_offset)
+{
+    return k_hevc_tctable[clip3(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)];
+}
+
+template <int DIR>      /* 0: vertical edges, 1: horizontal edges */
+__global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_lf_picture *pics, int luma_cols, int luma_rows, int chroma_cols,
+                                                              int chroma_rows, int luma_waves, int waves_per_pic, int bd)
+{
+    const int lane = lane_id(), slot = lane >> 3;
+    const int pic = (int)blockIdx.x / waves_per_pic, w = (int)blockIdx.x - pic * waves_per_pic;
+    const mi355_hevc_lf_picture &p = pics[pic];
+    const LfPic P{ p };
+    const int ps = bd > 8, W = p.width, H = p.height;
+    if (w < luma_waves) {
+        /* ---- luma: segment (gx, gy) of the 8x8 grid */
+        const int seg = w * 8 + slot, gy = seg / luma_cols, gx = seg - gy * luma_cols;
+        const int x = 8 * gx, y = 8 * gy;
+        bool on = gy < luma_rows && x < W && y < H && (DIR ? y >= 8 : x >= 8);
+        int bs0 = 0, bs1 = 0;
+        if (on) {
+            if (DIR) { bs0 = mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2]; bs1 = mi355_global_v(p.horizontal_bs)[(x + 4 + y * p.bs_width) >> 2]; }
+            else { bs0 = mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width]; bs1 = mi355_global_v(p.vertical_bs)[(x >> 3) + ((y + 4) >> 2) * p.bs_width]; }
+            on = (bs0 | bs1) != 0;
+        }
+        int beta = 0, tc[2] = { 0, 0 };
+        uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+        if (on) {
+            const mi355_hevc_db_params d = P.db(x, y);
+            const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
+            beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
+            tc[0] = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
+            tc[1] = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
+            if (p.pcmf) {
+                if (DIR) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 4, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 4, y); }
+                else { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 4); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 4); }
+            }
+        }
+        const int st = p.linesize[0] >> ps;
+        uint8_t *pix = mi355_global_v(p.data[0]) + (on ? (ptrdiff_t)y * p.linesize[0] + ((ptrdiff_t)x << ps) : 0);
+        hevc_lf_luma_wave(pix, DIR ? st : 1, DIR ? 1 : st, beta, tc, no_p, no_q, bd, true, on);
+        return;
+    }
+    /* ---- chroma: plane c, segment on the 16-luma-sample grid; horizontal edges: the reference's pairs start at
+     * x = 8 (mod 16), i.e. at -8 (:469-484), a half outside the picture has bS 0 */
+    const int seg = (w - luma_waves) * 8 + slot, per_plane = chroma_cols * chroma_rows;
+    const int c = seg >= per_plane ? 2 : 1, s2 = seg - (c - 1) * per_plane, gy = s2 / chroma_cols, gx = s2 - gy * chroma_cols;
+    const int x = DIR ? 16 * gx - 8 : 16 * gx, y = 16 * gy;
+    bool on = seg < 2 * per_plane && y < H && (DIR ? (y >= 16 && x < W) : (x >= 16 && x < W));
+    int bs0 = 0, bs1 = 0;
+    if (on) {
+        if (DIR) {
+            bs0 = x < 0 ? 0 : mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2];
+            bs1 = x + 8 >= W ? 0 : mi355_global_v(p.horizontal_bs)[(x + 8 + y * p.bs_width) >> 2];
+        } else {
+            bs0 = mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width];
+            bs1 = mi355_global_v(p.vertical_bs)[(x >> 3) + ((y + 8) >> 2) * p.bs_width];
+        }
+        on = bs0 == 2 || bs1 == 2;
+    }
+    int tc[2] = { 0, 0 };
+    uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+    if (on) {
+        if (DIR) {
+            if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, c, P.db(x, y).tc_offset);
+            if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, c, P.db(x + 8, y).tc_offset);
+            if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 8, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 8, y); }
+        } else {
+            const int tco = P.db(x, y).tc_offset;
+            if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, c, tco);
+            if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, c, tco);
+            if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 8); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 8); }
+        }
+    }
+    const int st = p.linesize[c] >> ps;
+    uint8_t *pix = mi355_global_v(p.data[c]) + (on ? (ptrdiff_t)(y / 2) * p.linesize[c] + (ptrdiff_t)(x / 2) * (1 << ps) : 0);
+    hevc_lf_chroma_wave(pix, DIR ? st : 1, DIR ? 1 : st, tc, no_p, no_q, bd, true, on);
+}
+
 /* ---- SAO ------------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job *jobs, int n, int bd)
 {
@@ -292,6 +409,20 @@ extern "C" int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int 
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_pred_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pics, int npics, int max_width, int max_height, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_pics, npics) || max_width <= 0 || max_height <= 0) return -1;
+    const int lc = (max_width + 7) / 8, lr = (max_height + 7) / 8;
+    for (int dir = 0; dir < 2; dir++) {
+        /* horizontal chroma segments start at x = -8: one more column may be needed */
+        const int cc = dir ? (max_width + 8 + 15) / 16 : (max_width + 15) / 16, cr = (max_height + 15) / 16;
+        const int lw = (lc * lr + 7) / 8, cw = (2 * cc * cr + 7) / 8;
+        const dim3 grid((unsigned)((lw + cw) * npics));
+        if (dir == 0) hipLaunchKernelGGL(k_hevc_deblock_pictures<0>, grid, dim3(64), 0, (hipStream_t)stream, d_pics, lc, lr, cc, cr, lw, lw + cw, bit_depth);
+        else hipLaunchKernelGGL(k_hevc_deblock_pictures<1>, grid, dim3(64), 0, (hipStream_t)stream, d_pics, lc, lr, cc, cr, lw, lw + cw, bit_depth);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_deblock_batch_dev(const mi355_hevc_lf_job *d_jobs, int n, int bit_depth, void *stream)

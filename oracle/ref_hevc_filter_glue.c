@@ -1,0 +1,65 @@
+/* TEST INFRASTRUCTURE (oracle/): drives the REFERENCE's own deblocking_filter_CTB (libavcodec/hevc_filter.c, compiled
+ * where it lies into _ref/libhevcfilterref.so together with hevcdsp.c) on a picture described by this project's
+ * mi355_hevc_lf_picture, with HOST pointers: a zeroed HEVCContext gets exactly the fields hevc_filter.c:337-505 reads,
+ * then ff_hevc_hls_filter() runs for every CTB in raster order (sao_enabled = 0, so it is the deblocking half only).
+ * Pins oracle_hevc_filter.c (tests/test_oracle_hevc_filter.py) and generates tests/golden/hevc_filter_ref_sha1.json. */
+#include <stdlib.h>
+#include <string.h>
+#include "libavutil/mem.h"
+#include "libavutil/frame.h"
+#include "libavcodec/hevcdec.h"
+#include "../include/mi355_hevc_batch.h"
+
+/* three 4-entry tables hevcdsp.c expects from libavcodec/hevcdec.c:45-47 (the decoder itself is not built here; the same
+ * lines ref_glue.c carries for libref.so) */
+const uint8_t ff_hevc_qpel_extra_before[4] = { 0, 3, 3, 3 };
+const uint8_t ff_hevc_qpel_extra_after[4]  = { 0, 4, 4, 4 };
+const uint8_t ff_hevc_qpel_extra[4]        = { 0, 7, 7, 7 };
+/* symbols hevc_filter.c references on paths this driver never takes */
+void ff_thread_report_progress(ThreadFrame *f, int progress, int field) { (void)f; (void)progress; (void)field; }
+RefPicList *ff_hevc_get_ref_list(HEVCContext *s, HEVCFrame *ref, int x0, int y0) { (void)s; (void)x0; (void)y0; return ref->refPicList; }
+
+int ref_hevc_deblock_picture(const mi355_hevc_lf_picture *p, int bit_depth)
+{
+    HEVCContext *s = av_mallocz(sizeof(*s));
+    HEVCSPS *sps = av_mallocz(sizeof(*sps));
+    HEVCPPS *pps = av_mallocz(sizeof(*pps));
+    AVFrame *fr = av_frame_alloc();
+    if (!s || !sps || !pps || !fr) return -1;
+    sps->log2_ctb_size = p->log2_ctb_size;
+    sps->ctb_width = p->ctb_width;
+    sps->width = p->width;
+    sps->height = p->height;
+    sps->pixel_shift = bit_depth > 8;
+    sps->log2_min_cb_size = p->log2_min_cb_size;
+    sps->min_cb_width = p->min_cb_width;
+    sps->log2_min_pu_size = p->log2_min_pu_size;
+    sps->min_pu_width = p->min_pu_width;
+    sps->min_pu_height = p->min_pu_height;
+    sps->sao_enabled = 0;
+    /* pcmf = (pcm_enabled && pcm.loop_filter_disable) || transquant_bypass_enable: any combination with that value */
+    sps->pcm_enabled_flag = 0;
+    pps->transquant_bypass_enable_flag = p->pcmf != 0;
+    pps->cb_qp_offset = p->cb_qp_offset;
+    pps->cr_qp_offset = p->cr_qp_offset;
+    s->ps.sps = sps;
+    s->ps.pps = pps;
+    s->deblock = (DBParams *)p->deblock;           /* same two ints, same order (checked below) */
+    s->vertical_bs = (uint8_t *)p->vertical_bs;
+    s->horizontal_bs = (uint8_t *)p->horizontal_bs;
+    s->bs_width = p->bs_width;
+    s->qp_y_tab = (int8_t *)p->qp_y_tab;
+    s->is_pcm = (uint8_t *)p->is_pcm;
+    for (int i = 0; i < 3; i++) { fr->data[i] = p->data[i]; fr->linesize[i] = p->linesize[i]; }
+    s->frame = fr;
+    ff_hevc_dsp_init(&s->hevcdsp, bit_depth);
+    if (sizeof(DBParams) != sizeof(mi355_hevc_db_params) || offsetof(DBParams, tc_offset) != offsetof(mi355_hevc_db_params, tc_offset)) return -2;
+    const int ctb = 1 << p->log2_ctb_size;
+    for (int y = 0; y < p->height; y += ctb)
+        for (int x = 0; x < p->width; x += ctb)
+            ff_hevc_hls_filter(s, x, y);
+    fr->data[0] = fr->data[1] = fr->data[2] = NULL;
+    av_frame_free(&fr);
+    av_free(pps); av_free(sps); av_free(s);
+    return 0;
+}

@@ -36,6 +36,24 @@ def main():
         print("hevcdsp:", len(out["cases"]), "cases")
     except ImportError:
         pass
+    # picture-level HEVC deblocking driver: the reference's own hevc_filter.c compiled in place
+    import ctypes as C2
+    import subprocess
+    import hevc_filter_cases as HC
+    root = os.path.dirname(os.path.dirname(HERE))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref/libhevcfilterref.so"], check=True)
+    flib = C2.CDLL(os.path.join(root, "oracle", "_ref", "libhevcfilterref.so"))
+    flib.ref_hevc_deblock_picture.restype = C2.c_int
+    cases = {}
+    for name in HC.CASES:
+        planes, _ = HC.run_host(flib.ref_hevc_deblock_picture, name)
+        h = hashlib.sha1()
+        for pl in planes:
+            h.update(pl.tobytes())
+        cases[name] = h.hexdigest()[:20]
+    with open(os.path.join(HERE, "hevc_filter_ref_sha1.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=0, sort_keys=True)
+    print("hevc_filter:", len(cases), "cases")
     # struct layout of the pointer tables as the reference headers define them
     import ctypes as C
     buf = C.create_string_buffer(8192)
