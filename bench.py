@@ -239,7 +239,93 @@ def extra_points(lib, prov, mbw, mbh):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
+    for fn in (hevc_point, sws_points):
+        try:
+            r = fn(lib)
+            pts.extend(r if isinstance(r, list) else [r])
+        except Exception as e:                 # an extra point must not take the headline line down with it
+            pts.append({"name": fn.__name__, "error": repr(e)})
     return pts
+
+
+def hevc_point(lib):
+    """BASELINE config 3 (HEVC 10-bit 2160p) as one back-to-back chain on 64 pictures: tools/hevc_chain.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hevc_chain
+    return hevc_chain.measure(lib, pictures=64, steps=3)
+
+
+def sws_points(lib):
+    """BASELINE config 5 (libswscale yuv420p -> rgb24): 32 device-resident pictures per launch, the reference's own libswscale
+    (oracle/_ref/libswsref.so, C paths) on every logical CPU beside it."""
+    import numpy as np
+    import sws_support as S
+    lib.mi355_event_create.restype = C.c_void_p
+    lib.mi355_event_elapsed_ms.restype = C.c_float
+    out = []
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libswsref.so")
+    ref = C.CDLL(ref_path) if os.path.exists(ref_path) else None
+    if ref is not None:
+        ref.sws_getContext.restype = C.c_void_p
+        ref.sws_getContext.argtypes = [C.c_int] * 7 + [C.c_void_p] * 3
+        ref.sws_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    for name, what in (("hd_special", "1920x1080 unscaled, special converter"), ("hd_generic", "1920x1080 unscaled, accurate_rnd generic path"),
+                       ("uhd_to_hd", "3840x2160 -> 1920x1080 bicubic")):
+        ctx = S.load_context(name)
+        d = ctx.desc
+        pics = [S.picture(name, seed=s) for s in (1, 2)]
+        batch = S.DeviceBatch(lib, ctx, pics, 32)
+        try:
+            for _ in range(2):
+                batch.run()
+            lib.mi355_sync(None)
+            e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
+            lib.mi355_event_record(C.c_void_p(e0), None)
+            for _ in range(10):
+                batch.run()
+            lib.mi355_event_record(C.c_void_p(e1), None)
+            lib.mi355_sync(None)
+            ms = lib.mi355_event_elapsed_ms(C.c_void_p(e0), C.c_void_p(e1)) / 10
+        finally:
+            batch.close()
+        bytes_frame = d.srcW * d.srcH + 2 * d.chrSrcW * d.chrSrcH + d.dstW * d.dstH * 3
+        fps = 32 / (ms * 1e-3)
+        pt = {"name": "config5_sws_" + name, "what": what, "frames_per_launch": 32, "ms_per_launch": ms, "frames_per_s": fps,
+              "algorithmic_bytes_per_frame": bytes_frame, "fraction_of_hbm_roofline": fps * bytes_frame / HBM_PEAK}
+        if ref is not None:
+            sw, sh, dw, dh, bic, acc, bitexact = S.CONFIGS[name]
+            flags = ref.ref_sws_flags_word(bic, acc, bitexact)
+            counts = [0] * len(cpus)
+            stop = time.perf_counter() + 2.0
+
+            def work(t):
+                try:
+                    os.sched_setaffinity(0, {cpus[t]})
+                except (AttributeError, OSError):
+                    pass
+                c = ref.sws_getContext(sw, sh, ref.ref_pix_fmt(0), dw, dh, ref.ref_pix_fmt(1), flags, None, None, None)
+                planes = pics[t % 2]
+                o = np.zeros((dh, dw * 3), np.uint8)
+                src = (C.c_void_p * 4)(*[p.ctypes.data for p in planes], None)
+                strides = (C.c_int * 4)(*[p.strides[0] for p in planes], 0)
+                dst = (C.c_void_p * 4)(o.ctypes.data, None, None, None)
+                dstrides = (C.c_int * 4)(o.strides[0], 0, 0, 0)
+                while time.perf_counter() < stop:
+                    ref.sws_scale(c, src, strides, 0, sh, dst, dstrides)
+                    counts[t] += 1
+                ref.sws_freeContext(C.c_void_p(c))
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(len(cpus))]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            pt["cpu_baseline"] = {"value": sum(counts) / (time.perf_counter() - t0), "unit": "frames/s", "cores": len(cpus), "kind": "reference",
+                                  "sample": "sws_scale of the reference's libswscale (C paths, oracle/_ref/libswsref.so), one context and one picture "
+                                            "per pinned thread, ~2 s"}
+        out.append(pt)
+    return out
 
 
 def cpu_baseline(fs, seconds):
