@@ -213,6 +213,15 @@ int   mi355_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2d(void *dst, const void *src, size_t bytes);
 int   mi355_sync(void *stream);
+/* pinned host memory and asynchronous copies on a stream: what a bridge needs to overlap the host's entropy decoding with
+ * the device's reconstruction (contrib/libav/mi355_h264_bridge.c).  Host buffers of the async copies must come from
+ * mi355_host_alloc(), or the copy is staged and effectively synchronous. */
+void *mi355_host_alloc(size_t bytes);
+void  mi355_host_free(void *p);
+int   mi355_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream);
+int   mi355_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream);
+int   mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream);
+int   mi355_event_sync(void *event);
 /* Streams for callers that pipeline half-batches (reconstruction of one against deblocking of the other);
  * `stream` arguments of every entry point accept these or NULL (the default stream). */
 void *mi355_stream_create(void);

@@ -1299,6 +1299,26 @@ extern "C" void mi355_free(void *p) { if (p) (void)hipFree(p); }
 extern "C" int mi355_memcpy_h2d(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_memcpy_d2h(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_memcpy_d2d(void *dst, const void *src, size_t bytes) { return mi355::bind() && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess ? 0 : -1; }
+extern "C" void *mi355_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!mi355::bind() || hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void mi355_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int mi355_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream)
+{
+    return mi355::bind() && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+extern "C" int mi355_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream)
+{
+    return mi355::bind() && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+extern "C" int mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream)
+{
+    return mi355::bind() && hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+extern "C" int mi355_event_sync(void *event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
 
 extern "C" void *mi355_stream_create(void)
