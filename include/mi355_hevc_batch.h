@@ -163,6 +163,40 @@ typedef struct mi355_hevc_lf_picture {
  * then horizontal) and returns.  max_width / max_height: the largest picture of the batch. */
 int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pics, int npics, int max_width, int max_height, int bit_depth, void *stream);
 
+/* ---- a16, boundary strengths: ff_hevc_deblocking_boundary_strengths (hevc_filter.c:585-725) + boundary_strength
+ * (:507-583) for every 4-sample edge segment of a picture at once, from the motion field and the geometry of the blocks
+ * the reference calls that function for (transform-tree leaves, hevcdec.c:1451, and coding units without residual,
+ * :2095, :2182).  The bridge hands over, per 4x4 luma cell, what the walk knows about the cell's left and top side:
+ *   MI355_HEVC_EDGE_L_BLOCK / _T_BLOCK   the side is the left / top edge of such a block, on the 8x8 grid, and filtered
+ *                                         (boundary_left / boundary_upper true: slice and tile boundaries with filtering
+ *                                         across them switched off are simply not marked)          -> tu_border = 1
+ *   MI355_HEVC_EDGE_L_INNER / _T_INNER   the side lies on the 8x8 grid INSIDE a block whose first prediction unit is
+ *                                         not intra (the "TU internal PU boundaries" loops :629-651, :694-722) -> tu_border = 0
+ * Reference pictures are compared by identity: ref_poc[list][ref_idx] as RefPicList.list[] holds it (one table per call:
+ * pictures whose slices use different lists take one call per group of slices).  Every cell side on the 8x8 grid gets a
+ * value (0 where not marked), so vertical_bs / horizontal_bs need no clearing; layout as in mi355_hevc_lf_picture. */
+enum { MI355_HEVC_EDGE_L_BLOCK = 1, MI355_HEVC_EDGE_T_BLOCK = 2, MI355_HEVC_EDGE_L_INNER = 4, MI355_HEVC_EDGE_T_INNER = 8 };
+typedef struct mi355_hevc_mvfield {     /* MvField, hevcdec.h:326-331: same size and field offsets */
+    int16_t mv[2][2];                   /* [list][x, y] quarter samples */
+    int8_t ref_idx[2];
+    int8_t pred_flag[2];
+    uint8_t is_intra;
+    uint8_t pad[3];
+} mi355_hevc_mvfield;
+typedef struct mi355_hevc_bs_picture {
+    int32_t width, height;              /* luma samples, multiples of 8 */
+    int32_t log2_min_pu_size, log2_min_tb_size;
+    int32_t min_pu_width, min_tb_width;
+    int32_t bs_width;                   /* width >> 3 */
+    int32_t reserved;
+    const mi355_hevc_mvfield *tab_mvf;  /* s->ref->tab_mvf, min-PU granularity */
+    const uint8_t *cbf_luma;            /* s->cbf_luma, min-TB granularity */
+    const uint8_t *edge_flags;          /* MI355_HEVC_EDGE_* per 4x4 luma cell, raster, width / 4 cells per row */
+    int32_t ref_poc[2][16];             /* RefPicList[list].list[ref_idx] */
+    uint8_t *vertical_bs, *horizontal_bs;   /* 2 * bs_width * ((height >> 3) + 1) bytes each */
+} mi355_hevc_bs_picture;
+int mi355_hevc_boundary_strengths_dev(const mi355_hevc_bs_picture *d_pics, int npics, int max_width, int max_height, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -347,6 +347,78 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
     hevc_lf_chroma_wave(pix, DIR ? st : 1, DIR ? 1 : st, tc, no_p, no_q, bd, true, on);
 }
 
+/* ---- boundary strengths of whole pictures: boundary_strength (hevc_filter.c:507-583) for every cell side on the 8x8 grid,
+ * one lane per 4x4 luma cell (see include/mi355_hevc_batch.h for the edge marks) --------------------------------------- */
+struct MvF {
+    int mvx[2], mvy[2], ref[2], pf[2], intra;
+};
+__device__ __forceinline__ MvF mvf_load(const mi355_hevc_mvfield *f)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(f);
+    const uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
+    MvF m;
+    m.mvx[0] = (int16_t)(a & 0xFFFF); m.mvy[0] = (int16_t)(a >> 16);
+    m.mvx[1] = (int16_t)(b & 0xFFFF); m.mvy[1] = (int16_t)(b >> 16);
+    m.ref[0] = (int8_t)(c & 0xFF); m.ref[1] = (int8_t)((c >> 8) & 0xFF);
+    m.pf[0] = (int8_t)((c >> 16) & 0xFF); m.pf[1] = (int8_t)(c >> 24);
+    m.intra = (int)(d & 0xFF);
+    return m;
+}
+__device__ __forceinline__ bool mv_far4(const MvF &a, int la, const MvF &b, int lb)
+{
+    return iabs(a.mvx[la] - b.mvx[lb]) >= 4 || iabs(a.mvy[la] - b.mvy[lb]) >= 4;
+}
+__device__ inline int hevc_bs_pair(const mi355_hevc_bs_picture &p, const MvF &c, int c_cbf, const MvF &n, int n_cbf, bool tu_border)
+{
+    const int mvs = c.pf[0] + c.pf[1];
+    if (tu_border) {
+        if (c.intra || n.intra) return 2;
+        if (c_cbf || n_cbf) return 1;
+    }
+    if (mvs != n.pf[0] + n.pf[1]) return 1;
+    if (mvs == 2) {
+        const int c0 = p.ref_poc[0][c.ref[0] & 15], c1 = p.ref_poc[1][c.ref[1] & 15], n0 = p.ref_poc[0][n.ref[0] & 15], n1 = p.ref_poc[1][n.ref[1] & 15];
+        if (c0 == n0 && c0 == c1 && n0 == n1)
+            return (mv_far4(n, 0, c, 0) || mv_far4(n, 1, c, 1)) && (mv_far4(n, 1, c, 0) || mv_far4(n, 0, c, 1));
+        if (n0 == c0 && n1 == c1) return mv_far4(n, 0, c, 0) || mv_far4(n, 1, c, 1);
+        if (n1 == c0 && n0 == c1) return mv_far4(n, 1, c, 0) || mv_far4(n, 0, c, 1);
+        return 1;
+    }
+    const int lc = c.pf[0] ? 0 : 1, ln = n.pf[0] ? 0 : 1;
+    if (p.ref_poc[lc][c.ref[lc] & 15] != p.ref_poc[ln][n.ref[ln] & 15]) return 1;
+    return mv_far4(c, lc, n, ln);
+}
+__global__ void __launch_bounds__(256) k_hevc_boundary_strengths(const mi355_hevc_bs_picture *pics, int cells_x, int cells_y)
+{
+    const int pic = (int)blockIdx.y;
+    const mi355_hevc_bs_picture &p = pics[pic];
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int cy = i / cells_x, cx = i - cy * cells_x, x = 4 * cx, y = 4 * cy;
+    if (cy >= cells_y || x >= p.width || y >= p.height || (x & y & 4)) return;      /* a cell off both grid lines has no side to rate */
+    const int cw = p.width >> 2;
+    const int fl = mi355_global_v(p.edge_flags)[cy * cw + cx];
+    const mi355_hevc_mvfield *mvf = mi355_global_v(p.tab_mvf);
+    const uint8_t *cbf = mi355_global_v(p.cbf_luma);
+    const MvF c = mvf_load(&mvf[(y >> p.log2_min_pu_size) * p.min_pu_width + (x >> p.log2_min_pu_size)]);
+    const int c_cbf = cbf[(y >> p.log2_min_tb_size) * p.min_tb_width + (x >> p.log2_min_tb_size)];
+    if (!(x & 7)) {
+        int bs = 0;
+        if (x > 0 && (fl & (MI355_HEVC_EDGE_L_BLOCK | MI355_HEVC_EDGE_L_INNER))) {
+            const MvF n = mvf_load(&mvf[(y >> p.log2_min_pu_size) * p.min_pu_width + ((x - 1) >> p.log2_min_pu_size)]);
+            bs = hevc_bs_pair(p, c, c_cbf, n, cbf[(y >> p.log2_min_tb_size) * p.min_tb_width + ((x - 1) >> p.log2_min_tb_size)], (fl & MI355_HEVC_EDGE_L_BLOCK) != 0);
+        }
+        mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width] = (uint8_t)bs;
+    }
+    if (!(y & 7)) {
+        int bs = 0;
+        if (y > 0 && (fl & (MI355_HEVC_EDGE_T_BLOCK | MI355_HEVC_EDGE_T_INNER))) {
+            const MvF n = mvf_load(&mvf[((y - 1) >> p.log2_min_pu_size) * p.min_pu_width + (x >> p.log2_min_pu_size)]);
+            bs = hevc_bs_pair(p, c, c_cbf, n, cbf[((y - 1) >> p.log2_min_tb_size) * p.min_tb_width + (x >> p.log2_min_tb_size)], (fl & MI355_HEVC_EDGE_T_BLOCK) != 0);
+        }
+        mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2] = (uint8_t)bs;
+    }
+}
+
 /* ---- SAO ------------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job *jobs, int n, int bd)
 {
@@ -409,6 +481,13 @@ extern "C" int mi355_hevc_pred_batch_dev(const mi355_hevc_pred_job *d_jobs, int 
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_pred_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_boundary_strengths_dev(const mi355_hevc_bs_picture *d_pics, int npics, int max_width, int max_height, void *stream)
+{
+    if (!ready() || !d_pics || npics <= 0 || max_width <= 0 || max_height <= 0) return -1;
+    const int cx = (max_width + 3) / 4, cy = (max_height + 3) / 4;
+    hipLaunchKernelGGL(k_hevc_boundary_strengths, dim3((unsigned)((cx * cy + 255) / 256), (unsigned)npics), dim3(256), 0, (hipStream_t)stream, d_pics, cx, cy);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pics, int npics, int max_width, int max_height, int bit_depth, void *stream)

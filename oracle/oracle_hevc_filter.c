@@ -11,6 +11,7 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "oracle.h"
 #include "../include/mi355_hevc_batch.h"
 
@@ -121,4 +122,60 @@ void oracle_hevc_deblock_picture(const mi355_hevc_lf_picture *p, int bit_depth)
                 }
                 dsp.hevc_h_loop_filter_chroma(p->data[c] + (ptrdiff_t)(y / 2) * p->linesize[c] + ((x / 2) * (1 << ps)), p->linesize[c], tc, no_p, no_q);
             }
+}
+
+/* ---- boundary strengths: boundary_strength (hevc_filter.c:507-583) per marked 4-sample cell side; see
+ * include/mi355_hevc_batch.h for what the marks mean.  Pinned against ff_hevc_deblocking_boundary_strengths itself,
+ * called for every block of a random tiling (tests/test_oracle_hevc_filter.py). */
+static int far4(const int16_t a[2], const int16_t b[2]) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+static int bs_pair(const mi355_hevc_bs_picture *p, const mi355_hevc_mvfield *c, int c_cbf, const mi355_hevc_mvfield *n, int n_cbf, int tu_border)
+{
+    const int mvs = c->pred_flag[0] + c->pred_flag[1];
+    if (tu_border) {
+        if (c->is_intra || n->is_intra) return 2;
+        if (c_cbf || n_cbf) return 1;
+    }
+    if (mvs != n->pred_flag[0] + n->pred_flag[1]) return 1;
+    if (mvs == 2) {
+        const int c0 = p->ref_poc[0][c->ref_idx[0]], c1 = p->ref_poc[1][c->ref_idx[1]];
+        const int n0 = p->ref_poc[0][n->ref_idx[0]], n1 = p->ref_poc[1][n->ref_idx[1]];
+        if (c0 == n0 && c0 == c1 && n0 == n1)
+            return (far4(n->mv[0], c->mv[0]) || far4(n->mv[1], c->mv[1])) && (far4(n->mv[1], c->mv[0]) || far4(n->mv[0], c->mv[1]));
+        if (n0 == c0 && n1 == c1) return far4(n->mv[0], c->mv[0]) || far4(n->mv[1], c->mv[1]);
+        if (n1 == c0 && n0 == c1) return far4(n->mv[1], c->mv[0]) || far4(n->mv[0], c->mv[1]);
+        return 1;
+    }
+    {   /* one vector each */
+        const int lc = c->pred_flag[0] ? 0 : 1, ln = n->pred_flag[0] ? 0 : 1;
+        if (p->ref_poc[lc][c->ref_idx[lc]] != p->ref_poc[ln][n->ref_idx[ln]]) return 1;
+        return far4(c->mv[lc], n->mv[ln]);
+    }
+}
+void oracle_hevc_boundary_strengths(const mi355_hevc_bs_picture *p)
+{
+    const int cw = p->width >> 2;
+    for (int y = 0; y < p->height; y += 4)
+        for (int x = 0; x < p->width; x += 4) {
+            const int fl = p->edge_flags[(y >> 2) * cw + (x >> 2)];
+            const mi355_hevc_mvfield *c = &p->tab_mvf[(y >> p->log2_min_pu_size) * p->min_pu_width + (x >> p->log2_min_pu_size)];
+            const int c_cbf = p->cbf_luma[(y >> p->log2_min_tb_size) * p->min_tb_width + (x >> p->log2_min_tb_size)];
+            if (!(x & 7)) {
+                int bs = 0;
+                if (x > 0 && (fl & (MI355_HEVC_EDGE_L_BLOCK | MI355_HEVC_EDGE_L_INNER))) {
+                    const mi355_hevc_mvfield *n = &p->tab_mvf[(y >> p->log2_min_pu_size) * p->min_pu_width + ((x - 1) >> p->log2_min_pu_size)];
+                    const int n_cbf = p->cbf_luma[(y >> p->log2_min_tb_size) * p->min_tb_width + ((x - 1) >> p->log2_min_tb_size)];
+                    bs = bs_pair(p, c, c_cbf, n, n_cbf, (fl & MI355_HEVC_EDGE_L_BLOCK) != 0);
+                }
+                p->vertical_bs[(x >> 3) + (y >> 2) * p->bs_width] = (uint8_t)bs;
+            }
+            if (!(y & 7)) {
+                int bs = 0;
+                if (y > 0 && (fl & (MI355_HEVC_EDGE_T_BLOCK | MI355_HEVC_EDGE_T_INNER))) {
+                    const mi355_hevc_mvfield *n = &p->tab_mvf[((y - 1) >> p->log2_min_pu_size) * p->min_pu_width + (x >> p->log2_min_pu_size)];
+                    const int n_cbf = p->cbf_luma[((y - 1) >> p->log2_min_tb_size) * p->min_tb_width + (x >> p->log2_min_tb_size)];
+                    bs = bs_pair(p, c, c_cbf, n, n_cbf, (fl & MI355_HEVC_EDGE_T_BLOCK) != 0);
+                }
+                p->horizontal_bs[(x + y * p->bs_width) >> 2] = (uint8_t)bs;
+            }
+        }
 }

@@ -17,6 +17,7 @@
 #include "libavcodec/h264pred.h"
 #include "libavcodec/videodsp.h"
 #include "libavcodec/hevcdsp.h"
+#include "libavcodec/hevcdec.h"
 
 const uint8_t ff_hevc_qpel_extra_before[4] = { 0, 3, 3, 3 };
 const uint8_t ff_hevc_qpel_extra_after[4]  = { 0, 4, 4, 4 };
@@ -40,6 +41,7 @@ int ref_layout(char *buf, int cap)
     F(HEVCDSPContext, sao_band_filter); F(HEVCDSPContext, put_hevc_qpel); F(HEVCDSPContext, put_hevc_epel);
     F(HEVCDSPContext, put_unweighted_pred); F(HEVCDSPContext, weighted_pred); F(HEVCDSPContext, weighted_pred_avg_chroma);
     F(HEVCDSPContext, hevc_h_loop_filter_luma); F(HEVCDSPContext, hevc_v_loop_filter_chroma_c);
+    Z(HEVCPredContext); F(HEVCPredContext, pred_planar); F(HEVCPredContext, pred_dc); F(HEVCPredContext, pred_angular);
     n += snprintf(buf + n, (size_t)(cap - n), "AV_CODEC_ID_H264=%d\n", (int)AV_CODEC_ID_H264);
     return n;
 }

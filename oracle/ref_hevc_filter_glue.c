@@ -63,3 +63,38 @@ int ref_hevc_deblock_picture(const mi355_hevc_lf_picture *p, int bit_depth)
     av_free(pps); av_free(sps); av_free(s);
     return 0;
 }
+
+/* ---- ff_hevc_deblocking_boundary_strengths itself, called for every block (x0, y0, log2_size) of `blocks` in order, on a
+ * context that holds the picture's motion field, cbf_luma and one RefPicList pair (no slice / tile boundaries:
+ * lc->boundary_flags = 0).  vertical_bs / horizontal_bs must come in zeroed (the function only writes non-zero values). */
+int ref_hevc_boundary_strengths(const mi355_hevc_bs_picture *p, const int32_t *blocks, int nblocks)
+{
+    HEVCContext *s = av_mallocz(sizeof(*s));
+    HEVCSPS *sps = av_mallocz(sizeof(*sps));
+    HEVCPPS *pps = av_mallocz(sizeof(*pps));
+    HEVCFrame *ref = av_mallocz(sizeof(*ref));
+    RefPicList *rpl = av_mallocz(2 * sizeof(*rpl));
+    if (!s || !sps || !pps || !ref || !rpl) return -1;
+    if (sizeof(MvField) != sizeof(mi355_hevc_mvfield) || offsetof(MvField, ref_idx) != offsetof(mi355_hevc_mvfield, ref_idx) ||
+        offsetof(MvField, pred_flag) != offsetof(mi355_hevc_mvfield, pred_flag) || offsetof(MvField, is_intra) != offsetof(mi355_hevc_mvfield, is_intra))
+        return -2;
+    sps->log2_min_pu_size = p->log2_min_pu_size;
+    sps->log2_min_tb_size = p->log2_min_tb_size;
+    sps->min_pu_width = p->min_pu_width;
+    sps->min_tb_width = p->min_tb_width;
+    sps->log2_ctb_size = 6;
+    pps->loop_filter_across_tiles_enabled_flag = 1;
+    s->sh.slice_loop_filter_across_slices_enabled_flag = 1;
+    s->ps.sps = sps; s->ps.pps = pps;
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 16; i++) rpl[l].list[i] = p->ref_poc[l][i];
+    ref->tab_mvf = (MvField *)p->tab_mvf;
+    ref->refPicList = rpl;
+    s->ref = ref;
+    s->cbf_luma = (uint8_t *)p->cbf_luma;
+    s->vertical_bs = p->vertical_bs; s->horizontal_bs = p->horizontal_bs; s->bs_width = p->bs_width;
+    s->HEVClc.boundary_flags = 0;
+    for (int i = 0; i < nblocks; i++) ff_hevc_deblocking_boundary_strengths(s, blocks[3 * i], blocks[3 * i + 1], blocks[3 * i + 2]);
+    av_free(rpl); av_free(ref); av_free(pps); av_free(sps); av_free(s);
+    return 0;
+}

@@ -51,9 +51,14 @@ def main():
         for pl in planes:
             h.update(pl.tobytes())
         cases[name] = h.hexdigest()[:20]
+    import hevc_bs_cases as BC
+    bs_cases = {}
+    for name in BC.CASES:
+        v, h, _ = BC.run_reference(flib, name)
+        bs_cases[name] = hashlib.sha1(v.tobytes() + h.tobytes()).hexdigest()[:20]
     with open(os.path.join(HERE, "hevc_filter_ref_sha1.json"), "w") as f:
-        json.dump({"cases": cases}, f, indent=0, sort_keys=True)
-    print("hevc_filter:", len(cases), "cases")
+        json.dump({"cases": cases, "bs_cases": bs_cases}, f, indent=0, sort_keys=True)
+    print("hevc_filter:", len(cases), "+", len(bs_cases), "cases")
     # struct layout of the pointer tables as the reference headers define them
     import ctypes as C
     buf = C.create_string_buffer(8192)

@@ -19,3 +19,20 @@ def test_deblock_pictures_gpu(mi355, oracle, name):
         for c in range(3):
             assert np.array_equal(want[c], got[c]), "%s: plane %d differs (%d bytes)" % (name, c, int((want[c] != got[c]).sum()))
         assert digest(got) == json.load(open(GOLD))["cases"][name]
+
+
+import hashlib  # noqa: E402
+
+import hevc_bs_cases as BC  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(BC.CASES))
+def test_boundary_strengths_gpu(mi355, oracle, name):
+    ov, oh, _ = BC.run_oracle(oracle.lib, name)
+    res, c = BC.run_device(mi355.lib, name, npics=3)
+    mv, mh = BC.grid_mask(c)
+    for v, h in res:
+        assert np.array_equal(v[mv], ov[mv]) and np.array_equal(h[mh], oh[mh])
+        assert (v[~mv] == 0xEE).all() and (h[~mh] == 0xEE).all()
+        v2, h2 = np.where(mv, v, 0).astype(np.uint8), np.where(mh, h, 0).astype(np.uint8)
+        assert hashlib.sha1(v2.tobytes() + h2.tobytes()).hexdigest()[:20] == json.load(open(GOLD))["bs_cases"][name]

@@ -51,3 +51,24 @@ def test_oracle_driver_matches_golden(oracle, name):
     oracle.lib.oracle_hevc_deblock_picture.restype = None
     got, _ = HC.run_host(oracle.lib.oracle_hevc_deblock_picture, name)
     assert digest(got) == gold["cases"][name]
+
+
+# ---- boundary strengths ---------------------------------------------------------------------------------------------
+import hevc_bs_cases as BC  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(BC.CASES))
+def test_oracle_boundary_strengths_match_reference_function(oracle, name):
+    ref = _ref_lib()
+    rv, rh, c = BC.run_reference(ref, name)
+    ov, oh, _ = BC.run_oracle(oracle.lib, name)
+    assert np.array_equal(rv, ov), "vertical_bs differs at %s" % np.flatnonzero(rv != ov)[:8]
+    assert np.array_equal(rh, oh), "horizontal_bs differs at %s" % np.flatnonzero(rh != oh)[:8]
+    assert len(set(rv.tolist())) == 3 and len(set(rh.tolist())) == 3 or c.w <= 32      # all of 0, 1, 2 occur
+
+
+@pytest.mark.parametrize("name", list(BC.CASES))
+def test_oracle_boundary_strengths_match_golden(oracle, name):
+    gold = json.load(open(GOLD))
+    ov, oh, _ = BC.run_oracle(oracle.lib, name)
+    assert hashlib.sha1(ov.tobytes() + oh.tobytes()).hexdigest()[:20] == gold["bs_cases"][name]
