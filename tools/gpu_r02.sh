@@ -13,14 +13,14 @@ else
   timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"
 fi
 tail -3 $OUT/pytest_gpu.txt
-timeout 300 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 300 python bench.py --no-cpu-baseline --no-extra > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 python3 -c "
 import json; d=json.load(open('$OUT/bench.json')); print('MB/s %.1fM' % (d['value']/1e6), d['pass_ms'])"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/bench_rocprof.json 2> $OUT/stats.err; echo "stats rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 > $OUT/bench_rocprof.json 2> $OUT/stats.err; echo "stats rc=$?"
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   n=$(echo $set | tr ' ' '_')
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$n -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --frames 256 --steps 1 --warmup 0 > $OUT/pmc_$n.log 2>&1; echo "pmc $n rc=$?"
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$n -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --frames 256 --steps 1 --warmup 0 > $OUT/pmc_$n.log 2>&1; echo "pmc $n rc=$?"
 done
 python3 - <<PY
 import csv, glob, collections, json

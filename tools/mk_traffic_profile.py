@@ -11,14 +11,16 @@ t = json.load(open(os.path.join(ROOT, "gpurun_out", tag, "traffic.json")))
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline "
                   "--frames %d --steps 1 --warmup 0" % frames,
        "frames_per_gpu": frames, "unit": "bytes per launch",
-       "note": "raw counter x 1024 (counters are in KiB). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide "
-               "coalesced reads by up to 2x; fetch_bytes_x2 is the upper bound, WRITE_SIZE is uncalibrated but lands "
-               "within a few % of the algorithmic store bytes here",
+       "note": "raw counter x 1024 (counters are in KiB).  Calibration (profiles/r02_calibration.md): FETCH_SIZE counts reads that "
+               "reach the L2 as 128-byte requests at half their size and everything else exactly; WRITE_SIZE is exact.  "
+               "k_recon_inter: the only 128-byte-coalesced stream is the coefficients (768 B per inter macroblock), so "
+               "traffic_bytes = fetch + 0.5 x coefficient bytes + write; k_deblock and k_recon_intra: as reported",
        "kernels": {}}
 for k, v in t.items():
     f, w = v["FETCH_SIZE_per_launch_raw"] * 1024, v["WRITE_SIZE_per_launch_raw"] * 1024
-    out["kernels"][k] = {"launches": v["launches"], "fetch_bytes": f, "fetch_bytes_x2": 2 * f, "write_bytes": w,
-                         "traffic_bytes": f + w, "traffic_bytes_upper": 2 * f + w}
+    corr = 0.5 * 768 * frames * 8160 * 0.95 if k == "k_recon_inter" else 0.0      # coefficient stream, 95 % inter macroblocks
+    out["kernels"][k] = {"launches": v["launches"], "fetch_bytes_reported": f, "fetch_correction_bytes": corr, "write_bytes": w,
+                         "traffic_bytes": f + corr + w}
 path = os.path.join(ROOT, "profiles", "%s_hbm_traffic_f%d.json" % (name, frames))
 json.dump(out, open(path, "w"), indent=1)
 print(path)
