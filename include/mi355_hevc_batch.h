@@ -197,6 +197,42 @@ typedef struct mi355_hevc_bs_picture {
 } mi355_hevc_bs_picture;
 int mi355_hevc_boundary_strengths_dev(const mi355_hevc_bs_picture *d_pics, int npics, int max_width, int max_height, void *stream);
 
+/* ---- a18, wrapper level: HEVCPredContext.intra_pred[log2_size - 2](s, x0, y0, c_idx) (hevcpred_template.c:31-334) for a
+ * list of transform blocks: neighbour availability (the caller's lc->na flags narrowed by the z-scan order test :93-97
+ * and, with constrained_intra_pred, by the motion field's is_intra :105-151), the gather of the 4 * size + 1 neighbour
+ * samples from the picture (:152-170), the constrained-intra substitution (:172-232), the inference of unavailable
+ * samples (:233-270), the [1 2 1] / strong smoothing (:272-318) and the prediction itself (:320-333) — what round 1 left
+ * to the host.  Blocks of one launch must not depend on each other's output (one launch per dependency level of the
+ * picture's intra blocks; a block reads the column left of it from y0 - 1 to y0 + 2 * size - 1 and the row above it
+ * likewise).  All pointers are device pointers. */
+enum { MI355_HEVC_CAND_BOTTOM_LEFT = 1, MI355_HEVC_CAND_LEFT = 2, MI355_HEVC_CAND_UP_LEFT = 4, MI355_HEVC_CAND_UP = 8,
+       MI355_HEVC_CAND_UP_RIGHT = 16 };
+typedef struct mi355_hevc_intra_picture {
+    uint8_t *data[3];                   /* s->frame->data: reconstruction so far, predicted in place */
+    int32_t linesize[3];                /* bytes */
+    int32_t width, height;              /* sps->width / height (luma samples) */
+    int32_t hshift, vshift;             /* sps->hshift[1] / vshift[1] (4:2:0: 1, 1) */
+    int32_t log2_min_pu_size;           /* granularity of tab_mvf */
+    int32_t log2_min_tb_size;           /* granularity of min_tb_addr_zs */
+    int32_t min_pu_width, min_pu_height;
+    int32_t min_tb_width;
+    int32_t constrained_intra_pred;     /* pps->constrained_intra_pred_flag */
+    int32_t strong_intra_smoothing;     /* sps->sps_strong_intra_smoothing_enable_flag */
+    int32_t reserved;
+    const mi355_hevc_mvfield *tab_mvf;  /* s->ref->tab_mvf: only is_intra is read, and only with constrained_intra_pred */
+    const int32_t *min_tb_addr_zs;      /* pps->min_tb_addr_zs [y_tb * min_tb_width + x_tb] */
+} mi355_hevc_intra_picture;
+typedef struct mi355_hevc_intra_block {
+    int32_t pic;                        /* index into the descriptor array */
+    uint16_t x0, y0;                    /* LUMA position of the block, as the reference passes it (chroma too) */
+    uint8_t log2_size;                  /* 2..5, in samples of the plane */
+    uint8_t c_idx;
+    uint8_t mode;                       /* 0 planar, 1 DC, 2..34 angular (lc->tu.cur_intra_pred_mode / lc->pu.intra_pred_mode_c) */
+    uint8_t cand;                       /* MI355_HEVC_CAND_*: lc->na as ff_hevc_set_neighbour_available left it */
+} mi355_hevc_intra_block;
+int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks, int n,
+                                     int bit_depth, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

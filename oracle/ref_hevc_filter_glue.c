@@ -98,3 +98,52 @@ int ref_hevc_boundary_strengths(const mi355_hevc_bs_picture *p, const int32_t *b
     av_free(rpl); av_free(ref); av_free(pps); av_free(sps); av_free(s);
     return 0;
 }
+
+/* ---- HEVCPredContext.intra_pred[] itself (hevcpred_template.c:31-334, via ff_hevc_pred_init), called once per block of
+ * `blocks` in order on a context that holds exactly the fields the wrapper reads: the SPS / PPS geometry, the frame, the
+ * motion field's is_intra, pps->min_tb_addr_zs, lc->na and the two mode fields.  Host pointers. */
+int ref_hevc_intra_pred_blocks(const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks, int n, int bit_depth)
+{
+    HEVCContext *s = av_mallocz(sizeof(*s));
+    HEVCSPS *sps = av_mallocz(sizeof(*sps));
+    HEVCPPS *pps = av_mallocz(sizeof(*pps));
+    HEVCFrame *ref = av_mallocz(sizeof(*ref));
+    AVFrame *fr = av_frame_alloc();
+    if (!s || !sps || !pps || !ref || !fr) return -1;
+    if (sizeof(MvField) != sizeof(mi355_hevc_mvfield) || offsetof(MvField, is_intra) != offsetof(mi355_hevc_mvfield, is_intra) ||
+        sizeof(*pps->min_tb_addr_zs) != sizeof(int32_t))
+        return -2;
+    ff_hevc_pred_init(&s->hpc, bit_depth);
+    s->ps.sps = sps; s->ps.pps = pps; s->ref = ref; s->frame = fr;
+    for (int i = 0; i < n; i++) {
+        const mi355_hevc_intra_picture *p = pics + blocks[i].pic;
+        const mi355_hevc_intra_block *b = blocks + i;
+        sps->width = p->width; sps->height = p->height;
+        sps->pixel_shift = bit_depth > 8;
+        sps->hshift[0] = sps->vshift[0] = 0;
+        sps->hshift[1] = sps->hshift[2] = p->hshift;
+        sps->vshift[1] = sps->vshift[2] = p->vshift;
+        sps->log2_min_pu_size = p->log2_min_pu_size;
+        sps->log2_min_tb_size = p->log2_min_tb_size;
+        sps->min_pu_width = p->min_pu_width; sps->min_pu_height = p->min_pu_height;
+        sps->min_tb_width = p->min_tb_width;
+        sps->sps_strong_intra_smoothing_enable_flag = p->strong_intra_smoothing != 0;
+        pps->constrained_intra_pred_flag = p->constrained_intra_pred != 0;
+        pps->min_tb_addr_zs = (int *)p->min_tb_addr_zs;
+        ref->tab_mvf = (MvField *)p->tab_mvf;
+        for (int c = 0; c < 3; c++) { fr->data[c] = p->data[c]; fr->linesize[c] = p->linesize[c]; }
+        s->HEVClc.na.cand_bottom_left = !!(b->cand & MI355_HEVC_CAND_BOTTOM_LEFT);
+        s->HEVClc.na.cand_left        = !!(b->cand & MI355_HEVC_CAND_LEFT);
+        s->HEVClc.na.cand_up_left     = !!(b->cand & MI355_HEVC_CAND_UP_LEFT);
+        s->HEVClc.na.cand_up          = !!(b->cand & MI355_HEVC_CAND_UP);
+        s->HEVClc.na.cand_up_right    = !!(b->cand & MI355_HEVC_CAND_UP_RIGHT);
+        s->HEVClc.tu.cur_intra_pred_mode = b->mode;
+        s->HEVClc.pu.intra_pred_mode_c = b->mode;
+        s->hpc.intra_pred[b->log2_size - 2](s, b->x0, b->y0, b->c_idx);
+    }
+    fr->data[0] = fr->data[1] = fr->data[2] = NULL;
+    pps->min_tb_addr_zs = NULL;
+    av_frame_free(&fr);
+    av_free(ref); av_free(pps); av_free(sps); av_free(s);
+    return 0;
+}

@@ -59,6 +59,18 @@ def main():
     with open(os.path.join(HERE, "hevc_filter_ref_sha1.json"), "w") as f:
         json.dump({"cases": cases, "bs_cases": bs_cases}, f, indent=0, sort_keys=True)
     print("hevc_filter:", len(cases), "+", len(bs_cases), "cases")
+    # HEVC intra_pred wrapper: the reference's own HEVCPredContext.intra_pred[] (hevcpred_template.c) compiled in place
+    import hevc_intra_cases as IC
+    icases = {}
+    for name in IC.CASES:
+        planes, _ = IC.run_host(flib.ref_hevc_intra_pred_blocks, name)
+        h = hashlib.sha1()
+        for pl in planes:
+            h.update(pl.tobytes())
+        icases[name] = h.hexdigest()[:20]
+    with open(os.path.join(HERE, "hevc_intra_ref_sha1.json"), "w") as f:
+        json.dump(icases, f, indent=0, sort_keys=True)
+    print("hevc_intra:", len(icases), "cases")
     # struct layout of the pointer tables as the reference headers define them
     import ctypes as C
     buf = C.create_string_buffer(8192)
