@@ -449,6 +449,161 @@ __global__ void __launch_bounds__(64) k_hevc_intra_batch(const mi355_hevc_intra_
     hevc_pred_wave(s, mi355_global(j.dst), j.stride / px, j.log2_size, j.kind, j.c_idx, j.mode, bd);
 }
 
+/* ---- intra prediction at wrapper level: intra_pred (hevcpred_template.c:31-334) — availability, gather, constrained-intra
+ * substitution, inference, smoothing, prediction — one wave per transform block.  Lane k owns neighbour k of the left
+ * column and of the top row (at most 64 each; lane 0 also owns the corner).  Everything is lane-parallel except the
+ * constrained-intra substitution (:172-232), a chain of "take the previous sample unless this one is intra" walks that
+ * lane 0 runs over LDS with the is_intra flags fetched beforehand by all lanes: the flag is a rarely used
+ * error-resilience tool and its walk is short (at most 4 * size steps). */
+struct IntraWrapLds {
+    HevcPredScratch pred;                    /* top / left as the prediction reads them; [0] = the corner */
+    uint8_t intra_l[66], intra_t[66];        /* [1 + k]: is_intra of the unit that covers left / top neighbour k */
+};
+static_assert(sizeof(mi355_hevc_intra_picture) == 104 && sizeof(mi355_hevc_intra_block) == 12, "descriptor layout (tests/hevc_intra_cases.py)");
+
+__global__ void __launch_bounds__(64) k_hevc_intra_blocks(const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks, int n_blocks, int bd)
+{
+    __shared__ IntraWrapLds s;
+    if ((int)blockIdx.x >= n_blocks) return;
+    const mi355_hevc_intra_block b = mi355_global_v(blocks)[blockIdx.x];
+    const mi355_hevc_intra_picture p = mi355_global_v(pics)[b.pic];
+    const int lane = lane_id();
+    const int c = b.c_idx, hs = c ? p.hshift : 0, vs = c ? p.vshift : 0;
+    const int log2 = b.log2_size, n = 1 << log2, x0 = b.x0, y0 = b.y0, mode = b.mode;
+    const int nl = n << hs;                                  /* size_in_luma: hshift in both directions (:74) */
+    const int ntb = nl >> p.log2_min_tb_size, px = bd > 8 ? 2 : 1, st = p.linesize[c] / px;
+    uint8_t *org = mi355_global_v(p.data[c]) + ((ptrdiff_t)(y0 >> vs) * p.linesize[c] + (ptrdiff_t)(x0 >> hs) * px);
+    const int32_t *zs = mi355_global_v(p.min_tb_addr_zs);
+    const int xtb = x0 >> p.log2_min_tb_size, ytb = y0 >> p.log2_min_tb_size, here = zs[ytb * p.min_tb_width + xtb];
+    int16_t *L = s.pred.left + 1, *T = s.pred.top + 1;
+
+    /* availability: lc->na, narrowed by decoding order for the two far neighbours (:93-97) */
+    bool a_bl = (b.cand & MI355_HEVC_CAND_BOTTOM_LEFT) && here > zs[(ytb + ntb) * p.min_tb_width + xtb - 1];
+    bool a_l = b.cand & MI355_HEVC_CAND_LEFT, a_ul = b.cand & MI355_HEVC_CAND_UP_LEFT, a_u = b.cand & MI355_HEVC_CAND_UP;
+    bool a_ur = (b.cand & MI355_HEVC_CAND_UP_RIGHT) && here > zs[(ytb - 1) * p.min_tb_width + xtb + ntb];
+    const int n_bl = (imin(y0 + 2 * nl, p.height) - (y0 + nl)) >> vs, n_ur = (imin(x0 + 2 * nl, p.width) - (x0 + nl)) >> hs;
+    const bool cip = p.constrained_intra_pred == 1;
+
+    if (cip) {                                               /* :104-151: a neighbour counts only if a unit of it is intra */
+        const mi355_hevc_mvfield *mvf = mi355_global_v(p.tab_mvf);
+        const int l2pu = p.log2_min_pu_size, pu_mask = (1 << l2pu) - 1, pw = p.min_pu_width, ph = p.min_pu_height;
+        const int npu = imax(nl >> l2pu, 1);
+        const bool on_x = !(x0 & pu_mask), on_y = !(y0 & pu_mask);
+        const int xl = (x0 - 1) >> l2pu, yt = (y0 - 1) >> l2pu;
+        if (a_bl && on_x) { const int y = (y0 + nl) >> l2pu; a_bl = __any(lane < imin(npu, ph - y) && mvf[xl + (y + lane) * pw].is_intra); }
+        if (a_l && on_x)  { const int y = y0 >> l2pu;        a_l  = __any(lane < imin(npu, ph - y) && mvf[xl + (y + lane) * pw].is_intra); }
+        if (a_ul)         a_ul = mvf[xl + yt * pw].is_intra != 0;
+        if (a_u && on_y)  { const int x = x0 >> l2pu;        a_u  = __any(lane < imin(npu, pw - x) && mvf[x + lane + yt * pw].is_intra); }
+        if (a_ur && on_y) { const int x = (x0 + nl) >> l2pu; a_ur = __any(lane < imin(npu, pw - x) && mvf[x + lane + yt * pw].is_intra); }
+        /* per-neighbour flags for the substitution walk; coordinates clamped into the field (a consistent caller never
+         * makes the walk look outside it) */
+        for (int i = lane; i <= 2 * n; i += 64) {
+            const int k = i - 1;
+            const int xs = clip3((x0 - (1 << hs)) >> l2pu, 0, pw - 1), ys = clip3((y0 + k * (1 << vs)) >> l2pu, 0, ph - 1);
+            const int xt = clip3((x0 + k * (1 << hs)) >> l2pu, 0, pw - 1), yu = clip3((y0 - (1 << vs)) >> l2pu, 0, ph - 1);
+            s.intra_l[i] = mvf[xs + ys * pw].is_intra;
+            s.intra_t[i] = mvf[xt + yu * pw].is_intra;
+        }
+    }
+
+    /* gather (:152-170): rows / columns past the picture repeat the last one inside; 128 where constrained intra
+     * prediction leaves a neighbour out */
+    if (lane < 2 * n) {
+        const int dflt = cip ? 128 : 0;
+        int lv = dflt, tv = dflt;
+        if (lane >= n) {
+            if (a_bl) lv = ldpx(org, imin(lane, n + n_bl - 1) * st - 1, bd);
+            if (a_ur) tv = ldpx(org, imin(lane, n + n_ur - 1) - st, bd);
+        } else {
+            if (a_l) lv = ldpx(org, lane * st - 1, bd);
+            if (a_u) tv = ldpx(org, lane - st, bd);
+        }
+        L[lane] = (int16_t)lv; T[lane] = (int16_t)tv;
+        if (lane == 0) L[-1] = T[-1] = (int16_t)(a_ul ? ldpx(org, -st - 1, bd) : 128);
+    }
+    MI355_WAVE_SYNC();
+
+    if (cip && (a_bl || a_l || a_ul || a_u || a_ur)) {       /* :172-232 */
+        if (lane == 0) {
+            const uint8_t *il = s.intra_l + 1, *it = s.intra_t + 1;
+            const int ex = a_ur ? 2 * n : n, ey = a_bl ? 2 * n : n;
+            const int lim_x = x0 + (ex << hs) < p.width ? ex : (p.width - x0) >> hs;
+            const int lim_y = y0 + (ey << vs) < p.height ? ey : (p.height - y0) >> vs;
+            int j = 0;
+            bool from_top = true;                            /* start the walk at the first intra sample of the top row? */
+            if (a_bl || a_l || a_ul) {
+                j = n + (a_bl ? n_bl : 0) - 1;               /* lowest intra sample of the left column, corner included */
+                while (j > -1 && !il[j]) j--;
+                from_top = !il[j];
+            }
+            if (from_top) {
+                const bool ask_corner = (a_bl || a_l || a_ul) || x0 > 0;
+                j = 0;
+                while (j < lim_x && !it[j]) j++;
+                if ((a_bl || a_l || a_ul) || j > 0) {
+                    for (int i = j; i > (ask_corner ? -1 : 0); i--) if (!it[i - 1]) T[i - 1] = T[i];
+                    if (!ask_corner) T[-1] = T[0];
+                }
+                L[-1] = T[-1];
+                j = 0;
+            }
+            if (a_bl || a_l) for (int i = j; i < lim_y; i++) if (!il[i]) L[i] = L[i - 1];
+            if (!a_l) for (int i = 0; i < n; i++) L[i] = L[-1];
+            if (!a_bl) for (int i = n; i < 2 * n; i++) L[i] = L[n - 1];
+            const int stop = (x0 != 0 && y0 == 0) ? 0 : -1;  /* no row above the picture to ask about */
+            for (int i = lim_y - 1; i > stop; i--) if (x0 == 0 || !il[i - 1]) L[i - 1] = L[i];
+            T[-1] = L[-1];
+            if (y0 != 0) for (int i = 0; i < lim_x; i++) if (!it[i]) T[i] = T[i - 1];
+        }
+        MI355_WAVE_SYNC();
+    }
+
+    /* unavailable neighbours take the nearest available sample (:233-270); every step: all lanes read the source, then
+     * the owners write */
+#define FILL_L(from, cnt, v) do { if (lane >= (from) && lane < (from) + (cnt)) L[lane] = (int16_t)(v); } while (0)
+#define FILL_T(from, cnt, v) do { if (lane >= (from) && lane < (from) + (cnt)) T[lane] = (int16_t)(v); } while (0)
+    if (!a_bl) {
+        if (a_l) { const int v = L[n - 1]; MI355_WAVE_SYNC(); FILL_L(n, n, v); }
+        else if (a_ul) { const int v = L[-1]; MI355_WAVE_SYNC(); FILL_L(0, 2 * n, v); a_l = true; }
+        else if (a_u) { const int v = T[0]; MI355_WAVE_SYNC(); if (lane == 0) L[-1] = (int16_t)v; FILL_L(0, 2 * n, v); a_ul = a_l = true; }
+        else if (a_ur) { const int v = T[n]; MI355_WAVE_SYNC(); FILL_T(0, n, v); if (lane == 0) L[-1] = (int16_t)v; FILL_L(0, 2 * n, v); a_u = a_ul = a_l = true; }
+        else { const int v = 1 << (bd - 1); if (lane == 0) L[-1] = (int16_t)v; FILL_T(0, 2 * n, v); FILL_L(0, 2 * n, v); }
+        MI355_WAVE_SYNC();
+    }
+    if (!a_l)  { const int v = L[n];     MI355_WAVE_SYNC(); FILL_L(0, n, v); MI355_WAVE_SYNC(); }
+    if (!a_ul) { const int v = L[0];     MI355_WAVE_SYNC(); if (lane == 0) L[-1] = (int16_t)v; MI355_WAVE_SYNC(); }
+    if (!a_u)  { const int v = L[-1];    MI355_WAVE_SYNC(); FILL_T(0, n, v); MI355_WAVE_SYNC(); }
+    if (!a_ur) { const int v = T[n - 1]; MI355_WAVE_SYNC(); FILL_T(n, n, v); MI355_WAVE_SYNC(); }
+    { const int v = L[-1]; MI355_WAVE_SYNC(); if (lane == 0) T[-1] = (int16_t)v; MI355_WAVE_SYNC(); }
+#undef FILL_L
+#undef FILL_T
+
+    /* smoothing of the neighbours (:272-318) */
+    if (c == 0 && mode != 1 && n != 4) {
+        const int limit = log2 == 3 ? 7 : log2 == 4 ? 1 : 0;
+        if (imin(iabs(mode - 26), iabs(mode - 10)) > limit) {
+            const int corner = L[-1], thr = 1 << (bd - 5);
+            const bool strong = p.strong_intra_smoothing && log2 == 5 && iabs(corner + T[63] - 2 * T[31]) < thr && iabs(corner + L[63] - 2 * L[31]) < thr;
+            int fl = 0, ft = 0, fc = corner;
+            if (lane < 2 * n) {
+                fl = L[lane]; ft = T[lane];
+                if (strong) {
+                    if (lane < 63) { fl = ((63 - lane) * corner + (lane + 1) * L[63] + 32) >> 6; ft = ((63 - lane) * corner + (lane + 1) * T[63] + 32) >> 6; }
+                } else if (lane < 2 * n - 1) {
+                    fl = (L[lane + 1] + 2 * fl + L[lane - 1] + 2) >> 2;
+                    ft = (T[lane + 1] + 2 * ft + T[lane - 1] + 2) >> 2;
+                }
+            }
+            if (!strong) fc = (L[0] + 2 * corner + T[0] + 2) >> 2;
+            MI355_WAVE_SYNC();
+            if (lane < 2 * n) { L[lane] = (int16_t)fl; T[lane] = (int16_t)ft; }
+            if (lane == 0) L[-1] = T[-1] = (int16_t)fc;
+            MI355_WAVE_SYNC();
+        }
+    }
+    hevc_pred_wave(s.pred, org, st, log2, mode == 0 ? 0 : mode == 1 ? 1 : 2, c, mode, bd);
+}
+
 bool check(int bit_depth, const void *jobs, int n)
 {
     if (!ready()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
@@ -514,6 +669,13 @@ extern "C" int mi355_hevc_intra_batch_dev(const mi355_hevc_intra_job *d_jobs, in
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_intra_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks, int n,
+                                                int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_blocks, n) || !d_pics) return -1;
+    hipLaunchKernelGGL(k_hevc_intra_blocks, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_pics, d_blocks, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream)
