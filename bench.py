@@ -36,6 +36,12 @@ B_FUSED = B_RECON + B_DEBLOCK            # 2432 B/MB: the two-surface pipeline f
 HBM_PEAK = 8.0e12
 
 
+def level_widths(fs):
+    """host array for mi355_h264_recon_intra_levels_dev: widest level l over the pictures of the batch"""
+    import ctypes as C
+    return (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+
+
 def measured_traffic(kernel, frames):
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
@@ -101,7 +107,7 @@ def main():
     big = fs
 
     for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-                          ("mi355_h264_recon_intra_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                           ("mi355_h264_deblock_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
                           ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
@@ -115,7 +121,7 @@ def main():
         assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, stream) == 0
         if events is not None:
             lib.mi355_event_record(events[1], stream)
-        assert lib.mi355_h264_recon_intra_dev(dev.d_desc, F, big.max_intra_level, big.max_level_width, stream) == 0
+        assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, big.max_intra_level, level_widths(big), stream) == 0
         if events is not None:
             lib.mi355_event_record(events[2], stream)
         assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, stream) == 0
@@ -216,7 +222,7 @@ def extra_points(lib, prov, mbw, mbh):
         try:
             def once():
                 assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
-                assert lib.mi355_h264_recon_intra_dev(dev.d_desc, F, fs.max_intra_level, fs.max_level_width, None) == 0
+                assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
                 assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
             once()
             e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()

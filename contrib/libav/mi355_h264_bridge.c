@@ -13,7 +13,7 @@
  *   ff_h264_filter_mb / _fast (h264_loopfilter.c:716, :420; called per macroblock from loop_filter, h264_slice.c:2198)
  *       -> nothing: the device derives bS / alpha / beta / tc0 from the records and filters the whole picture.
  *   ff_h264_field_end (h264_picture.c:145; end of every coded picture)
- *       -> staging -> HBM on the stream, mi355_h264_decode_frames_dev(), decoded picture -> the AVFrame the decoder will
+ *       -> staging -> HBM on the stream, mi355_h264_decode_frames_levels_dev(), decoded picture -> the AVFrame the decoder will
  *          output, all enqueued asynchronously; the host waits only when the picture the decoder is about to output is
  *          not finished (always, unless MI355_BRIDGE_LAZY=1, which trusts h->output_frame).
  *
@@ -99,7 +99,8 @@ static int staging_alloc(Bridge *b, Staging *s)
     s->coef = mi355_host_alloc(n * 768);                    s->d_coef = dalloc(n * 768);
     s->slices = mi355_host_alloc(BR_MAX_SLICES * sizeof(*s->slices)); s->d_slices = dalloc(BR_MAX_SLICES * sizeof(*s->slices));
     s->ilist = mi355_host_alloc(n * 4);                     s->d_ilist = dalloc(n * 4);
-    s->istart = mi355_host_alloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 4); s->d_istart = dalloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 4);
+    /* second half of istart: the per-level widths handed to mi355_h264_decode_frames_levels_dev */
+    s->istart = mi355_host_alloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 8); s->d_istart = dalloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 4);
     s->desc = mi355_host_alloc(sizeof(*s->desc));           s->d_desc = dalloc(sizeof(*s->desc));
     s->free_again = mi355_event_create();
     return s->mb && s->d_mb && s->mv[0] && s->d_mv[0] && s->mv[1] && s->d_mv[1] && s->coef && s->d_coef && s->slices && s->d_slices &&
@@ -353,7 +354,9 @@ static int submit_picture(Bridge *b, H264Context *h)
     }
     rc |= mi355_memcpy_h2d_async(s->d_desc, s->desc, sizeof(*s->desc), b->stream);
     if (rc) return -3;
-    if (mi355_h264_decode_frames_dev(s->d_desc, 1, b->mb_w, b->mb_h, maxl, lw, b->stream) != 0) return -4;
+    int32_t *widths = s->istart + (b->mb_w + 2 * b->mb_h + 2);
+    for (int l = 0; l < maxl; l++) widths[l] = s->istart[l + 1] - s->istart[l];
+    if (mi355_h264_decode_frames_levels_dev(s->d_desc, 1, b->mb_w, b->mb_h, maxl, widths, b->stream) != 0) return -4;
     mi355_event_record(s->free_again, b->stream);
     s->in_flight = 1;
     /* the finished picture -> the frame the decoder hands out (coded size; the reference crops on output) */

@@ -193,7 +193,16 @@ int mi355_h264_decode_frames_dev(const mi355_h264_frame *d_frames, int nframes,
                                  int max_mb_width, int max_mb_height, int max_intra_level,
                                  int max_level_width, void *stream);
 
+/* Same, with the intra passes sized level by level: level_widths[l - 1] (HOST array, max_intra_level entries) = the
+ * largest number of macroblocks any picture of the batch has on level l (level_start[l] - level_start[l - 1] as
+ * mi355_h264_intra_schedule wrote them).  With the single bound above every level launches nframes * max_level_width
+ * workgroups, most of which find nothing to do on the sparse later levels (0.5 ms per 2048 pictures of config 2). */
+int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nframes,
+                                        int max_mb_width, int max_mb_height, int max_intra_level,
+                                        const int32_t *level_widths, void *stream);
+
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
+int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream);
 int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);

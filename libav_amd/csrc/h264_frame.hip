@@ -1169,6 +1169,18 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream)
+{
+    if (!mi355::bind() || !d_frames || nframes <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
+    for (int level = 1; level <= max_intra_level; level++) {
+        const int width = level_widths[level - 1];
+        if (width <= 0) continue;
+        if ((long long)nframes * width > 0x7FFFFFFFLL) return -3;
+        hipLaunchKernelGGL(k_recon_intra, dim3((unsigned)(nframes * width)), dim3(64), 0, (hipStream_t)stream, d_frames, level, width);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 #ifdef MI355_PROF
 extern "C" void mi355_debug_rprof(unsigned long long *out, int reset)
 {
@@ -1202,6 +1214,16 @@ extern "C" int mi355_h264_decode_frames_dev(const mi355_h264_frame *d_frames, in
     int rc = mi355_h264_recon_inter_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
     if (rc) return rc;
     rc = mi355_h264_recon_intra_dev(d_frames, nframes, max_intra_level, max_level_width, stream);
+    if (rc) return rc;
+    return mi355_h264_deblock_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
+}
+
+extern "C" int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
+                                                   int max_intra_level, const int32_t *level_widths, void *stream)
+{
+    int rc = mi355_h264_recon_inter_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
+    if (rc) return rc;
+    rc = mi355_h264_recon_intra_levels_dev(d_frames, nframes, max_intra_level, level_widths, stream);
     if (rc) return rc;
     return mi355_h264_deblock_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
 }

@@ -34,12 +34,12 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name, pad=0):
+def run_case(backend, oracle, name, pad=0, per_level=True):
     fs = HF.synth_frames(**CASES[name])
     recon_o, dst_o = HF.run_oracle(oracle, fs)
     d = HF.DeviceFrames(backend, fs, pad=pad)
     try:
-        d.decode()
+        d.decode(per_level=per_level)
         recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
     finally:
         d.free()

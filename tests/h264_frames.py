@@ -355,7 +355,18 @@ def intra_schedule(fs, f):
     fs.intra_start[f] = np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32)
     if order:
         fs.max_level_width = max(fs.max_level_width, max(len(o) for o in order))
+    note_level_widths(fs, [len(o) for o in order])
     return mx
+
+
+def note_level_widths(fs, widths):
+    """fs.level_widths[l - 1] = the largest number of macroblocks any picture has on level l"""
+    cur = getattr(fs, "level_widths", [])
+    n = max(len(cur), len(widths))
+    cur = list(cur) + [0] * (n - len(cur))
+    for i, w in enumerate(widths):
+        cur[i] = max(cur[i], int(w))
+    fs.level_widths = cur
 
 
 def intra_levels(mb, mb_w, mb_h):
@@ -529,12 +540,21 @@ class DeviceFrames:
         return [raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :fs.W], raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2],
                 raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2]]
 
-    def decode(self, stream=None):
+    def decode(self, stream=None, per_level=True):
+        """per_level: intra passes sized by the per-level widths (mi355_h264_decode_frames_levels_dev); otherwise by the
+        single bound max_level_width (mi355_h264_decode_frames_dev)"""
         fs = self.fs
-        fn = self.lib.mi355_h264_decode_frames_dev
-        fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        rc = fn(self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, fs.max_level_width, stream)
+        if per_level:
+            lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+            fn = self.lib.mi355_h264_decode_frames_levels_dev
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            rc = fn(self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, stream)
+        else:
+            fn = self.lib.mi355_h264_decode_frames_dev
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            rc = fn(self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, fs.max_level_width, stream)
         assert rc == 0, rc
         self.lib.mi355_sync.restype = C.c_int
         assert self.lib.mi355_sync(stream) == 0
@@ -651,6 +671,7 @@ def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05,
             fs.intra_list[f] = lst[:start[mx]].copy()
             fs.intra_start[f] = start[:mx + 1].copy()
             fs.max_level_width = max(fs.max_level_width, width.value)
+            note_level_widths(fs, np.diff(start[:mx + 1]).tolist())
         else:
             mx = intra_schedule(fs, f)
         fs.max_intra_level = max(fs.max_intra_level, mx)

@@ -35,6 +35,13 @@ def test_decode_then_convert_on_device_emulated(emu, oracle):
     assert chain_check.run(emu, oracle) == 3
 
 
+@pytest.mark.parametrize("name", ("mixed_intra", "tall_all_intra"))
+def test_frame_pipeline_emulated_single_level_bound(emu, oracle, name):
+    """mi355_h264_decode_frames_dev: every intra level sized by the one bound max_level_width (the other cases go through
+    mi355_h264_decode_frames_levels_dev with per-level widths)"""
+    frame_cases.run_case(emu, oracle, name, per_level=False)
+
+
 @pytest.mark.parametrize("pad", (8, 24))
 @pytest.mark.parametrize("name", ("mixed_intra", "wide_b", "one_col"))
 def test_frame_pipeline_emulated_unaligned_strides(emu, oracle, name, pad):
