@@ -4,7 +4,9 @@
  * bridge state and HIP stream), optionally K times in a row, and reports end-to-end pictures per second.
  *   usage: h264_bridge <in.samples> <out.yuv | -> [threads [loops]]
  *   in.samples: u32 extradata_len, extradata (avcC), u32 n, then n x {u32 len, bytes}   (tests/golden/mp4_samples.py)
- *   MI355_BRIDGE_PLAIN=1: the bridge steps aside at once (the reference's C path: the comparison run).
+ *   MI355_BRIDGE_PLAIN=1: the bridge steps aside at once (the reference's C path: the comparison run);
+ *   MI355_BRIDGE_DIRECT=1: every thread drives its own HIP stream instead of handing pictures to the dispatcher;
+ *   MI355_BRIDGE_LAZY=1: a thread waits for a picture only when the decoder is about to output it.
  * Thread 0 of loop 0 writes the decoded pictures (coded size, planar) to out.yuv.
  */
 #include <pthread.h>
@@ -19,6 +21,7 @@
 extern AVCodec ff_h264_decoder;
 void mi355_h264_bridge_stats(unsigned long *pictures, unsigned long *staging_waits, int *active);
 void mi355_h264_bridge_drain(void);
+void mi355_h264_bridge_batch_stats(unsigned long *batches, unsigned long *pictures);
 
 static uint8_t *file_data;
 static size_t file_size;
@@ -26,6 +29,10 @@ static int loops = 1;
 static const char *out_path;
 
 typedef struct { int id; long shown; unsigned long dev_pictures, waits; int active; int rc; } Arg;
+
+/* the reference's avcodec_open2 / close are serialised by the application when no lock manager is registered
+ * (libavcodec/utils.c: its one-time static table set-up is not re-entrant) */
+static pthread_mutex_t open_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static uint32_t rd32(const uint8_t **p) { uint32_t v; memcpy(&v, *p, 4); *p += 4; return v; }
 
@@ -42,7 +49,10 @@ static void *decode_thread(void *vp)
         memcpy(c->extradata, p, el); p += el;
         c->thread_count = 1;
         c->flags |= AV_CODEC_FLAG_BITEXACT;
-        if (avcodec_open2(c, &ff_h264_decoder, NULL) < 0) { a->rc = 5; return NULL; }
+        pthread_mutex_lock(&open_lock);
+        const int opened = avcodec_open2(c, &ff_h264_decoder, NULL);
+        pthread_mutex_unlock(&open_lock);
+        if (opened < 0) { a->rc = 5; return NULL; }
         const uint32_t n = rd32(&p);
         AVFrame *fr = av_frame_alloc();
         for (uint32_t i = 0; i <= n; i++) {
@@ -70,7 +80,9 @@ static void *decode_thread(void *vp)
             if (i < n) av_packet_unref(&pkt);
         }
         av_frame_free(&fr);
+        pthread_mutex_lock(&open_lock);
         avcodec_free_context(&c);
+        pthread_mutex_unlock(&open_lock);
     }
     mi355_h264_bridge_stats(&a->dev_pictures, &a->waits, &a->active);
     if (out) fclose(out);
@@ -101,7 +113,10 @@ int main(int argc, char **argv)
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    unsigned long batches = 0, batched = 0;
+    mi355_h264_bridge_batch_stats(&batches, &batched);
     printf("{\"threads\": %d, \"loops\": %d, \"pictures_output\": %ld, \"pictures_on_device\": %lu, \"bridges_active\": %d, "
-           "\"staging_waits\": %lu, \"seconds\": %.4f, \"pictures_per_s\": %.1f}\n", nthreads, loops, shown, dev, active, waits, s, (double)shown / s);
+           "\"staging_waits\": %lu, \"launch_sets\": %lu, \"pictures_per_launch_set\": %.2f, \"seconds\": %.4f, \"pictures_per_s\": %.1f}\n",
+           nthreads, loops, shown, dev, active, waits, batches, batches ? (double)batched / (double)batches : 0.0, s, (double)shown / s);
     return rc;
 }

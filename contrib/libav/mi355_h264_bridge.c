@@ -13,17 +13,31 @@
  *   ff_h264_filter_mb / _fast (h264_loopfilter.c:716, :420; called per macroblock from loop_filter, h264_slice.c:2198)
  *       -> nothing: the device derives bS / alpha / beta / tc0 from the records and filters the whole picture.
  *   ff_h264_field_end (h264_picture.c:145; end of every coded picture)
- *       -> staging -> HBM on the stream, mi355_h264_decode_frames_levels_dev(), decoded picture -> the AVFrame the decoder will
- *          output, all enqueued asynchronously; the host waits only when the picture the decoder is about to output is
- *          not finished (always, unless MI355_BRIDGE_LAZY=1, which trusts h->output_frame).
+ *       -> the picture is SUBMITTED: the kernels read the staging block in place (pinned, device-visible memory: no copy
+ *          into HBM first), mi355_h264_decode_frames_levels_dev(), decoded picture -> a pinned buffer, from which the
+ *          decoder thread copies it into the AVFrame the decoder will output.  The host waits only when the picture the
+ *          decoder is about to output is not finished (always, unless MI355_BRIDGE_LAZY=1, which trusts
+ *          h->output_frame), or when it needs the staging set again.
+ *
+ * Two ways to submit:
+ *   batched (default)   N decoder threads = N streams; a picture is handed to ONE dispatcher thread, which owns the only
+ *                       HIP stream: it takes what the decoder threads have queued (at most one picture per stream) and
+ *                       issues, for the whole batch, one descriptor copy, ONE set of kernel launches
+ *                       (mi355_h264_decode_frames_levels_dev over the pictures of all streams) and one launch that
+ *                       writes the finished pictures to the streams' pinned buffers (mi355_copy_batch_dev); two batches
+ *                       in flight.  Decoder threads make no runtime calls after set-up, and the dispatcher makes a fixed
+ *                       number per batch, so the per-picture cost of launches and runtime locks is shared by the streams
+ *                       that are decoding at the same time — the regime the batched kernels are built for.
+ *   direct (MI355_BRIDGE_DIRECT=1)  every decoder thread drives its own HIP stream, one picture per launch set.
  *
  * The decoded picture buffer lives in HBM: one device picture per H264Picture the decoder uses, found again through the
- * reference lists' parent pointers; reference samples never cross PCIe.  Two staging sets alternate, so the host can pack
- * picture n + 1 while the copies and kernels of picture n run.  One bridge state per decoding thread (N decoder threads =
- * N streams = N HIP streams).  Streams outside the Tier-2 scope (MBAFF / field pictures, more than 8 bits, not 4:2:0)
- * and any runtime failure make the bridge step aside for that decoder: the reference's own C path continues.
- * Errors are reported once on stderr; nothing here calls abort().
+ * reference lists' parent pointers; reference samples never cross PCIe.  Two staging sets per stream alternate, so the
+ * host can pack picture n + 1 while the copies and kernels of picture n run.  Streams outside the Tier-2 scope (MBAFF /
+ * field pictures, more than 8 bits, not 4:2:0), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
+ * aside for that decoder: the reference's own C path continues.  Errors are reported once on stderr; nothing here
+ * calls abort().
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,37 +57,60 @@ void __real_ff_h264_filter_mb_fast(const H264Context *h, H264SliceContext *sl, i
 
 #define BR_MAX_PICS 40        /* H264_MAX_PICTURE_COUNT (36) + slack */
 #define BR_MAX_SLICES 64
+#define DISP_MAX_BATCH 256    /* pictures (= streams) per launch set */
+#define DISP_MAX_LEVELS 8192  /* mb_width + 2 * mb_height of the largest picture the dispatcher takes */
+
+struct Bridge;
+struct Staging;
 
 typedef struct DevPic {
     const H264Picture *owner;
-    uint8_t *plane[3];
-    void *done;                 /* event: kernels and the copy into the AVFrame are complete */
-    int pending;
+    uint8_t *plane[3];          /* one allocation, planes back to back */
 } DevPic;
 
-typedef struct Staging {        /* pinned host images and their device mirrors */
-    mi355_h264_mb *mb, *d_mb;
-    int16_t *mv[2], *d_mv[2];
-    int16_t *coef, *d_coef;
-    mi355_h264_slice *slices, *d_slices;
-    uint32_t *ilist, *d_ilist;
-    int32_t *istart, *d_istart;
-    mi355_h264_frame *desc, *d_desc;
-    void *free_again;           /* event: the device no longer reads this set */
+typedef struct Submission {     /* a packed picture on its way through the dispatcher */
+    struct Bridge *b;
+    struct Staging *s;
+    int done, rc;
+    struct Submission *next;
+} Submission;
+
+typedef struct Staging {        /* one pinned, device-visible block (mi355_host_alloc): descriptor, records, vectors, coefficients,
+                                 * slices, intra schedule.  The kernels read them where the decoder thread wrote them: every
+                                 * input byte of a picture is read once, a copy into HBM first would only add a runtime call */
+    uint8_t *host;
+    size_t size;
+    mi355_h264_frame *desc;
+    mi355_h264_mb *mb;
+    int16_t *mv[2];
+    int16_t *coef;
+    mi355_h264_slice *slices;
+    uint32_t *ilist;
+    int32_t *istart;
+    int32_t *widths;            /* host only: macroblocks per intra level */
+    int maxl;
+    uint8_t *out;               /* pinned: the decoded picture as it comes back (device strides, planes back to back) */
+    DevPic *pic;                /* the picture this set was submitted for */
+    uint8_t *frame_data[3];     /* where it goes: the AVFrame the decoder will hand out */
+    int frame_linesize[3];
+    mi355_h264_frame *d_desc;   /* direct mode: the descriptor on the device */
+    void *done;                 /* direct mode: event after the copy into `out` */
+    Submission sub;             /* batched mode */
     int in_flight;
 } Staging;
 
 typedef struct Bridge {
     int state;                  /* 0 new, 1 active, -1 stepped aside */
-    int lazy;
+    int lazy, direct;
     int mb_w, mb_h, nmb;
-    void *stream;
+    void *stream;               /* direct mode */
     Staging st[2];
     int cur;                    /* staging set being packed */
     int open;                   /* a picture is being packed */
     DevPic pics[BR_MAX_PICS];
     uint8_t *recon[3];
     int stride[2];
+    size_t plane_bytes[2];
     /* per picture */
     int nslices, slice_num_of[BR_MAX_SLICES], uses_l1;
     const H264Picture *slot_pic[MI355_H264_MAX_SLOTS];
@@ -90,21 +127,146 @@ static void br_fail(Bridge *b, const char *what)
 }
 
 static void *dalloc(size_t n) { return mi355_malloc(n); }
+static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 static int staging_alloc(Bridge *b, Staging *s)
 {
-    const size_t n = (size_t)b->nmb;
-    s->mb = mi355_host_alloc(n * sizeof(*s->mb));           s->d_mb = dalloc(n * sizeof(*s->mb));
-    for (int l = 0; l < 2; l++) { s->mv[l] = mi355_host_alloc(n * 64); s->d_mv[l] = dalloc(n * 64); }
-    s->coef = mi355_host_alloc(n * 768);                    s->d_coef = dalloc(n * 768);
-    s->slices = mi355_host_alloc(BR_MAX_SLICES * sizeof(*s->slices)); s->d_slices = dalloc(BR_MAX_SLICES * sizeof(*s->slices));
-    s->ilist = mi355_host_alloc(n * 4);                     s->d_ilist = dalloc(n * 4);
-    /* second half of istart: the per-level widths handed to mi355_h264_decode_frames_levels_dev */
-    s->istart = mi355_host_alloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 8); s->d_istart = dalloc((size_t)(b->mb_w + 2 * b->mb_h + 2) * 4);
-    s->desc = mi355_host_alloc(sizeof(*s->desc));           s->d_desc = dalloc(sizeof(*s->desc));
-    s->free_again = mi355_event_create();
-    return s->mb && s->d_mb && s->mv[0] && s->d_mv[0] && s->mv[1] && s->d_mv[1] && s->coef && s->d_coef && s->slices && s->d_slices &&
-           s->ilist && s->d_ilist && s->istart && s->d_istart && s->desc && s->d_desc && s->free_again;
+    const size_t n = (size_t)b->nmb, nlev = (size_t)(b->mb_w + 2 * b->mb_h + 2);
+    size_t o = 0;
+    const size_t o_desc = o;   o = up64(o + sizeof(mi355_h264_frame));
+    const size_t o_mb = o;     o = up64(o + n * sizeof(mi355_h264_mb));
+    const size_t o_mv0 = o;    o = up64(o + n * 64);
+    const size_t o_mv1 = o;    o = up64(o + n * 64);
+    const size_t o_coef = o;   o = up64(o + n * 768);
+    const size_t o_sl = o;     o = up64(o + BR_MAX_SLICES * sizeof(mi355_h264_slice));
+    const size_t o_is = o;     o = up64(o + nlev * 4);
+    const size_t o_il = o;     o = up64(o + n * 4);
+    s->size = o;
+    s->host = mi355_host_alloc(s->size);
+    s->widths = malloc(nlev * 4);
+    s->out = mi355_host_alloc(b->plane_bytes[0] + 2 * b->plane_bytes[1]);
+    if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(sizeof(mi355_h264_frame)); }
+    if (!s->host || !s->widths || !s->out || (b->direct && (!s->done || !s->d_desc))) return 0;
+    s->desc = (mi355_h264_frame *)(s->host + o_desc);
+    s->mb = (mi355_h264_mb *)(s->host + o_mb);
+    s->mv[0] = (int16_t *)(s->host + o_mv0);
+    s->mv[1] = (int16_t *)(s->host + o_mv1);
+    s->coef = (int16_t *)(s->host + o_coef);
+    s->slices = (mi355_h264_slice *)(s->host + o_sl);
+    s->istart = (int32_t *)(s->host + o_is);
+    s->ilist = (uint32_t *)(s->host + o_il);
+    return 1;
+}
+
+/* ---- the dispatcher: one thread, one HIP stream, the pictures of all streams ---------------------------------------- */
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t work, finished;
+    pthread_t thread;
+    int started, broken;
+    Submission *head, *tail;
+    void *stream, *ev[2];
+    mi355_h264_frame *h_desc[2], *d_desc[2];
+    mi355_copy_job *jobs[2];    /* device-visible */
+    Submission *in[2][DISP_MAX_BATCH];
+    int nin[2];
+    int32_t widths[DISP_MAX_LEVELS];
+    unsigned long batches, pictures;
+} disp = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+
+/* one batch: a descriptor copy, the launch set for all its pictures, one launch that brings the finished pictures to the
+ * streams' pinned buffers; nothing waits here */
+static int disp_enqueue(int slot)
+{
+    const int n = disp.nin[slot];
+    int mw = 0, mh = 0, maxl = 0, rc = 0;
+    size_t max_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        const Staging *s = disp.in[slot][i]->s;
+        const Bridge *b = disp.in[slot][i]->b;
+        const size_t bytes = b->plane_bytes[0] + 2 * b->plane_bytes[1];
+        if (b->mb_w > mw) mw = b->mb_w;
+        if (b->mb_h > mh) mh = b->mb_h;
+        for (int l = 0; l < s->maxl; l++)
+            if (l >= maxl || s->widths[l] > disp.widths[l]) disp.widths[l] = s->widths[l];
+        if (s->maxl > maxl) maxl = s->maxl;
+        disp.h_desc[slot][i] = *s->desc;
+        disp.jobs[slot][i].src = s->pic->plane[0]; disp.jobs[slot][i].dst = s->out; disp.jobs[slot][i].bytes = bytes;
+        if (bytes > max_bytes) max_bytes = bytes;
+    }
+    rc |= mi355_memcpy_h2d_async(disp.d_desc[slot], disp.h_desc[slot], (size_t)n * sizeof(mi355_h264_frame), disp.stream);
+    if (!rc && mi355_h264_decode_frames_levels_dev(disp.d_desc[slot], n, mw, mh, maxl, disp.widths, disp.stream) != 0) rc = -1;
+    if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, disp.stream) != 0) rc = -1;
+    rc |= mi355_event_record(disp.ev[slot], disp.stream);
+    return rc;
+}
+
+static void *disp_main(void *arg)
+{
+    (void)arg;
+    int head_slot = 0, inflight = 0, rcs[2] = { 0, 0 };     /* slots head_slot .. head_slot + inflight - 1 (mod 2) are on the device */
+    pthread_mutex_lock(&disp.mu);
+    for (;;) {
+        while (!disp.head && !inflight) pthread_cond_wait(&disp.work, &disp.mu);
+        int took = 0;
+        if (disp.head && inflight < 2) {
+            /* what is queued now, at most one picture per stream (a stream's next picture reads this one's output) */
+            const int slot = (head_slot + inflight) & 1;
+            Submission *keep_head = NULL, *keep_tail = NULL, *c = disp.head;
+            int n = 0;
+            while (c) {
+                Submission *nx = c->next;
+                int later = n >= DISP_MAX_BATCH;
+                for (int i = 0; i < n && !later; i++) later = disp.in[slot][i]->b == c->b;
+                if (later) {
+                    c->next = NULL;
+                    if (keep_tail) keep_tail->next = c; else keep_head = c;
+                    keep_tail = c;
+                } else disp.in[slot][n++] = c;
+                c = nx;
+            }
+            disp.head = keep_head; disp.tail = keep_tail;
+            disp.nin[slot] = n;
+            disp.batches++; disp.pictures += (unsigned long)n;
+            pthread_mutex_unlock(&disp.mu);
+            rcs[slot] = disp_enqueue(slot);
+            pthread_mutex_lock(&disp.mu);
+            inflight++;
+            took = 1;
+        }
+        if (inflight == 2 || (inflight && !took)) {
+            /* the older batch: wait for it, tell its streams */
+            const int slot = head_slot;
+            pthread_mutex_unlock(&disp.mu);
+            const int rc = rcs[slot] | mi355_event_sync(disp.ev[slot]);
+            pthread_mutex_lock(&disp.mu);
+            for (int i = 0; i < disp.nin[slot]; i++) { disp.in[slot][i]->rc = rc; disp.in[slot][i]->done = 1; }
+            pthread_cond_broadcast(&disp.finished);
+            head_slot ^= 1; inflight--;
+        }
+    }
+    return NULL;
+}
+
+static int disp_start(void)
+{
+    pthread_mutex_lock(&disp.mu);
+    if (!disp.started && !disp.broken) {
+        disp.stream = mi355_stream_create();
+        int ok = disp.stream != NULL;
+        for (int k = 0; k < 2 && ok; k++) {
+            disp.ev[k] = mi355_event_create();
+            disp.h_desc[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            disp.d_desc[k] = dalloc(DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            disp.jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
+            ok = disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k];
+        }
+        if (ok && pthread_create(&disp.thread, NULL, disp_main, NULL) == 0) { pthread_detach(disp.thread); disp.started = 1; }
+        else disp.broken = 1;
+    }
+    const int ok = disp.started;
+    pthread_mutex_unlock(&disp.mu);
+    return ok;
 }
 
 static Bridge *bridge_get(const H264Context *h)
@@ -114,6 +276,8 @@ static Bridge *bridge_get(const H264Context *h)
         b = br_tls = calloc(1, sizeof(*b));
         if (!b) return NULL;
         b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL;
+        b->direct = getenv("MI355_BRIDGE_DIRECT") != NULL;
+        if (getenv("MI355_BRIDGE_PLAIN")) b->state = -1;         /* the comparison run: the reference's C path, silently */
     }
     if (b->state) return b;
     if (FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || h->ps.sps->chroma_format_idc != 1 || h->ps.sps->transform_bypass) {
@@ -124,26 +288,36 @@ static Bridge *bridge_get(const H264Context *h)
     if (mi355_init(dev ? atoi(dev) : 0) != 0) { br_fail(b, "no usable MI355X"); return b; }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->stride[0] = (16 * b->mb_w + 63) & ~63; b->stride[1] = b->stride[0] / 2;
-    b->stream = mi355_stream_create();
-    int ok = b->stream != NULL && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
-    for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc((size_t)b->stride[p > 0] * (p ? 8 : 16) * b->mb_h)) != NULL;
-    if (!ok) { br_fail(b, "device or pinned memory allocation failed"); return b; }
+    b->plane_bytes[0] = (size_t)b->stride[0] * 16 * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * 8 * b->mb_h;
+    int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
+    if (ok && b->direct) ok = (b->stream = mi355_stream_create()) != NULL;
+    if (ok && !b->direct) ok = disp_start();
+    ok = ok && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
+    for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[p > 0])) != NULL;
+    if (!ok) { br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
+    b->st[0].sub.b = b->st[1].sub.b = b;
+    b->st[0].sub.s = &b->st[0]; b->st[1].sub.s = &b->st[1];
     b->state = 1;
     return b;
 }
 
-static DevPic *devpic_of(Bridge *b, const H264Picture *p, int create)
+/* the device picture of a decoder picture.  Slots whose owner is not one of THIS decoder context's pictures belong to a
+ * context that was closed (the thread decodes the next stream): they are taken over. */
+static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, int create)
 {
     DevPic *slot = NULL;
     for (int i = 0; i < BR_MAX_PICS; i++) {
         if (b->pics[i].owner == p) return &b->pics[i];
         if (!slot && !b->pics[i].owner) slot = &b->pics[i];
     }
-    if (!create || !slot) return NULL;
+    if (!create) return NULL;
+    for (int i = 0; i < BR_MAX_PICS && !slot; i++)
+        if (b->pics[i].owner < h->DPB || b->pics[i].owner >= h->DPB + H264_MAX_PICTURE_COUNT) slot = &b->pics[i];
+    if (!slot) return NULL;
     if (!slot->plane[0]) {
-        for (int k = 0; k < 3; k++)
-            if (!(slot->plane[k] = dalloc((size_t)b->stride[k > 0] * (k ? 8 : 16) * b->mb_h))) return NULL;
-        if (!(slot->done = mi355_event_create())) return NULL;
+        uint8_t *base = dalloc(b->plane_bytes[0] + 2 * b->plane_bytes[1]);
+        if (!base) return NULL;
+        slot->plane[0] = base; slot->plane[1] = base + b->plane_bytes[0]; slot->plane[2] = slot->plane[1] + b->plane_bytes[1];
     }
     slot->owner = p;
     return slot;
@@ -158,12 +332,39 @@ static int slot_of(Bridge *b, const H264Picture *p)
     return b->nslots++;
 }
 
+/* the picture submitted from this staging set is complete on the device and in `out`: wait for that, then put it where
+ * the decoder will look for it */
+static int finish_set(Bridge *b, Staging *s)
+{
+    if (!s->in_flight) return 0;
+    int rc;
+    if (b->direct) rc = mi355_event_sync(s->done);
+    else {
+        pthread_mutex_lock(&disp.mu);
+        while (!s->sub.done) pthread_cond_wait(&disp.finished, &disp.mu);
+        rc = s->sub.rc;
+        pthread_mutex_unlock(&disp.mu);
+    }
+    s->in_flight = 0;
+    if (rc) return rc;
+    const uint8_t *src = s->out;
+    for (int k = 0; k < 3; k++) {
+        const int w = (k ? 8 : 16) * b->mb_w, hgt = (k ? 8 : 16) * b->mb_h, st = b->stride[k > 0];
+        for (int y = 0; y < hgt; y++) memcpy(s->frame_data[k] + (size_t)y * s->frame_linesize[k], src + (size_t)y * st, (size_t)w);
+        src += b->plane_bytes[k > 0];
+    }
+    return 0;
+}
+
 static void begin_picture(Bridge *b, const H264Context *h)
 {
-    /* the staging set must be free again: the kernels that read its device mirror two pictures ago have finished */
+    /* the staging set must be free again: what was submitted from it two pictures ago has come back */
     b->cur ^= 1;
     Staging *s = &b->st[b->cur];
-    if (s->in_flight) { mi355_event_sync(s->free_again); s->in_flight = 0; b->waits++; }
+    if (s->in_flight) {
+        b->waits++;
+        if (finish_set(b, s) != 0) br_fail(b, "a picture did not come back from the device");
+    }
     memset(s->mb, 0, (size_t)b->nmb * sizeof(*s->mb));
     memset(s->mv[0], 0, (size_t)b->nmb * 64);
     memset(s->mv[1], 0, (size_t)b->nmb * 64);
@@ -323,11 +524,13 @@ void __wrap_ff_h264_filter_mb_fast(const H264Context *h, H264SliceContext *sl, i
 static int submit_picture(Bridge *b, H264Context *h)
 {
     Staging *s = &b->st[b->cur];
-    DevPic *cur = devpic_of(b, h->cur_pic_ptr, 1);
+    DevPic *cur = devpic_of(b, h, h->cur_pic_ptr, 1);
     if (!cur) return -1;
     int lw = 0;
     const int maxl = mi355_h264_intra_schedule(s->mb, b->mb_w, b->mb_h, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;
+    for (int l = 0; l < maxl; l++) s->widths[l] = s->istart[l + 1] - s->istart[l];
+    s->maxl = maxl;
     mi355_h264_frame *f = s->desc;
     memset(f, 0, sizeof(*f));
     f->mb_width = b->mb_w; f->mb_height = b->mb_h;
@@ -335,37 +538,32 @@ static int submit_picture(Bridge *b, H264Context *h)
     f->dst_stride[0] = f->recon_stride[0] = b->stride[0];
     f->dst_stride[1] = f->recon_stride[1] = b->stride[1];
     for (int i = 0; i < b->nslots; i++) {
-        DevPic *r = devpic_of(b, b->slot_pic[i], 0);
+        DevPic *r = devpic_of(b, h, b->slot_pic[i], 0);
         if (!r) return -2;                       /* a reference this bridge never decoded (a stream joined mid-way) */
         for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k];
     }
-    f->mb = s->d_mb; f->mv[0] = s->d_mv[0]; f->mv[1] = b->uses_l1 ? s->d_mv[1] : NULL; f->coef = s->d_coef;
-    f->slices = s->d_slices; f->nslices = b->nslices;
-    f->max_intra_level = maxl; f->intra_list = s->d_ilist; f->intra_level_start = s->d_istart; f->max_level_width = lw;
-    const size_t n = (size_t)b->nmb;
-    int rc = mi355_memcpy_h2d_async(s->d_mb, s->mb, n * sizeof(*s->mb), b->stream);
-    rc |= mi355_memcpy_h2d_async(s->d_mv[0], s->mv[0], n * 64, b->stream);
-    if (b->uses_l1) rc |= mi355_memcpy_h2d_async(s->d_mv[1], s->mv[1], n * 64, b->stream);
-    rc |= mi355_memcpy_h2d_async(s->d_coef, s->coef, n * 768, b->stream);
-    rc |= mi355_memcpy_h2d_async(s->d_slices, s->slices, (size_t)b->nslices * sizeof(*s->slices), b->stream);
-    if (maxl > 0) {
-        rc |= mi355_memcpy_h2d_async(s->d_ilist, s->ilist, (size_t)s->istart[maxl] * 4, b->stream);
-        rc |= mi355_memcpy_h2d_async(s->d_istart, s->istart, (size_t)(maxl + 1) * 4, b->stream);
-    }
-    rc |= mi355_memcpy_h2d_async(s->d_desc, s->desc, sizeof(*s->desc), b->stream);
-    if (rc) return -3;
-    int32_t *widths = s->istart + (b->mb_w + 2 * b->mb_h + 2);
-    for (int l = 0; l < maxl; l++) widths[l] = s->istart[l + 1] - s->istart[l];
-    if (mi355_h264_decode_frames_levels_dev(s->d_desc, 1, b->mb_w, b->mb_h, maxl, widths, b->stream) != 0) return -4;
-    mi355_event_record(s->free_again, b->stream);
-    s->in_flight = 1;
-    /* the finished picture -> the frame the decoder hands out (coded size; the reference crops on output) */
+    /* device-visible host memory: the kernels read the staging block in place */
+    f->mb = s->mb; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef;
+    f->slices = s->slices; f->nslices = b->nslices;
+    f->max_intra_level = maxl; f->intra_list = s->ilist; f->intra_level_start = s->istart; f->max_level_width = lw;
+    s->pic = cur;
+    /* the finished picture goes to the frame the decoder hands out (coded size; the reference crops on output) */
     const AVFrame *fr = h->cur_pic_ptr->f;
-    for (int k = 0; k < 3; k++)
-        if (mi355_memcpy2d_d2h_async(fr->data[k], (size_t)fr->linesize[k], cur->plane[k], (size_t)b->stride[k > 0],
-                                     (size_t)(k ? 8 : 16) * b->mb_w, (size_t)(k ? 8 : 16) * b->mb_h, b->stream)) return -5;
-    mi355_event_record(cur->done, b->stream);
-    cur->pending = 1;
+    for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
+    if (b->direct) {
+        if (mi355_memcpy_h2d_async(s->d_desc, s->desc, sizeof(*s->desc), b->stream)) return -3;
+        if (mi355_h264_decode_frames_levels_dev(s->d_desc, 1, b->mb_w, b->mb_h, maxl, s->widths, b->stream) != 0) return -4;
+        if (mi355_memcpy_d2h_async(s->out, cur->plane[0], b->plane_bytes[0] + 2 * b->plane_bytes[1], b->stream)) return -5;
+        if (mi355_event_record(s->done, b->stream)) return -5;
+    } else {
+        pthread_mutex_lock(&disp.mu);
+        s->sub.done = 0; s->sub.rc = 0; s->sub.next = NULL;
+        if (disp.tail) disp.tail->next = &s->sub; else disp.head = &s->sub;
+        disp.tail = &s->sub;
+        pthread_cond_signal(&disp.work);
+        pthread_mutex_unlock(&disp.mu);
+    }
+    s->in_flight = 1;
     b->pictures++;
     return 0;
 }
@@ -377,19 +575,17 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
         b->open = 0;
         if (submit_picture(b, h) != 0) {
             /* the picture is lost for this path; what was enqueued must drain before the host touches the frames again */
-            mi355_sync(b->stream);
+            finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
             br_fail(b, "submitting a picture to the device failed");
         } else {
             /* wait only for what the decoder is about to hand out: h->output_frame was chosen when the picture started
              * (h264_select_output_frame, h264_slice.c:1173-1290, called from h264_field_start :1528) and shares its buffers
              * with the H264Picture it refers to; without MI355_BRIDGE_LAZY every picture is complete before this returns */
             const uint8_t *out0 = h->output_frame && h->output_frame->buf[0] ? h->output_frame->data[0] : NULL;
-            for (int i = 0; i < BR_MAX_PICS; i++) {
-                DevPic *p = &b->pics[i];
-                if (p->pending && (!b->lazy || (out0 && p->owner && p->owner->f && p->owner->f->data[0] == out0))) {
-                    mi355_event_sync(p->done);
-                    p->pending = 0;
-                }
+            for (int k = 0; k < 2; k++) {
+                Staging *s = &b->st[k];
+                if (s->in_flight && (!b->lazy || (out0 && s->frame_data[0] == out0)))
+                    if (finish_set(b, s) != 0) br_fail(b, "a picture did not come back from the device");
             }
         }
     }
@@ -404,12 +600,18 @@ void mi355_h264_bridge_stats(unsigned long *pictures, unsigned long *staging_wai
     if (staging_waits) *staging_waits = b ? b->waits : 0;
     if (active) *active = b ? b->state : 0;
 }
-/* a decoder thread that ends (or flushes with MI355_BRIDGE_LAZY) calls this: everything enqueued is complete afterwards */
+/* launch sets the dispatcher issued and the pictures they held (process-wide) */
+void mi355_h264_bridge_batch_stats(unsigned long *batches, unsigned long *pictures)
+{
+    pthread_mutex_lock(&disp.mu);
+    if (batches) *batches = disp.batches;
+    if (pictures) *pictures = disp.pictures;
+    pthread_mutex_unlock(&disp.mu);
+}
+/* a decoder thread that ends (or flushes with MI355_BRIDGE_LAZY) calls this: everything it submitted is complete and in
+ * its frames afterwards */
 void mi355_h264_bridge_drain(void)
 {
     Bridge *b = br_tls;
-    if (b && b->state > 0) {
-        mi355_sync(b->stream);
-        for (int i = 0; i < BR_MAX_PICS; i++) b->pics[i].pending = 0;
-    }
+    if (b && b->state > 0) { finish_set(b, &b->st[0]); finish_set(b, &b->st[1]); }
 }

@@ -231,6 +231,17 @@ int   mi355_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *str
 int   mi355_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream);
 int   mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream);
 int   mi355_event_sync(void *event);
+/* Memory from mi355_host_alloc() is DEVICE-VISIBLE at the same address: kernels may read records, vectors and
+ * coefficients where the host wrote them (every input byte of a picture is read once, so nothing is gained by copying it
+ * first), and mi355_copy_batch_dev() may write pictures into it.  `n` independent byte copies in ONE launch (one per
+ * finished picture of a batch instead of one runtime copy call each); src / dst / bytes multiples of 16; `jobs` itself
+ * device-visible.  max_bytes: the largest job. */
+typedef struct mi355_copy_job {
+    const void *src;
+    void *dst;
+    uint64_t bytes;
+} mi355_copy_job;
+int   mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t max_bytes, void *stream);
 /* Streams for callers that pipeline half-batches (reconstruction of one against deblocking of the other);
  * `stream` arguments of every entry point accept these or NULL (the default stream). */
 void *mi355_stream_create(void);

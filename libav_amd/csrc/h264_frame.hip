@@ -1340,6 +1340,28 @@ extern "C" int mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void 
 {
     return mi355::bind() && hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? 0 : -1;
 }
+namespace {
+__global__ void __launch_bounds__(256) k_copy_batch(const mi355_copy_job *jobs, int n)
+{
+    if ((int)blockIdx.y >= n) return;
+    const mi355_copy_job j = mi355_global(jobs)[blockIdx.y];
+    typedef uint32_t u32x4 __attribute__((vector_size(16)));
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(mi355_global(reinterpret_cast<const uint8_t *>(j.src)));
+    u32x4 *dst = reinterpret_cast<u32x4 *>(mi355_global(reinterpret_cast<uint8_t *>(j.dst)));
+    const size_t nvec = (size_t)(j.bytes >> 4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}
+extern "C" int mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t max_bytes, void *stream)
+{
+    if (!mi355::bind() || !jobs || n <= 0) return -1;
+    if (!max_bytes) return 0;
+    const size_t per_block = 256 * 16 * 4;
+    unsigned gx = (unsigned)((max_bytes + per_block - 1) / per_block);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_copy_batch, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 extern "C" int mi355_event_sync(void *event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? 0 : -1; }
 extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
 

@@ -41,17 +41,44 @@ def check_against_golden(raw, n):
 
 
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP)), reason="needs /root/reference and the sample clip")
-@pytest.mark.parametrize("lazy", (False, True))
-def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy):
+@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, True, 1), (True, True, 1), (False, False, 3)))
+def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, threads):
+    """batched submission through the dispatcher thread (default) and direct submission (MI355_BRIDGE_DIRECT), complete
+    at once or lazily; with 3 decoder threads the dispatcher's launch sets hold pictures of several streams"""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
     src, n = samples_file(tmp_path, CLIP)
     out = tmp_path / "o.yuv"
     env = dict(os.environ)
-    env.pop("MI355_BRIDGE_LAZY", None)
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
+        env.pop(k, None)
     if lazy:
         env["MI355_BRIDGE_LAZY"] = "1"
-    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "h264_bridge_emu"), str(src), str(out)], capture_output=True, text=True, timeout=900, env=env)
+    if direct:
+        env["MI355_BRIDGE_DIRECT"] = "1"
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "h264_bridge_emu"), str(src), str(out), str(threads), "1"], capture_output=True, text=True,
+                       timeout=1800, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     stats = json.loads(r.stdout.strip().splitlines()[-1])
-    assert stats["pictures_output"] == n and stats["pictures_on_device"] == n and stats["bridges_active"] == 1, (stats, r.stderr[-500:])
+    assert stats["pictures_output"] == n * threads and stats["pictures_on_device"] == n * threads and stats["bridges_active"] == threads, (stats, r.stderr[-500:])
+    if direct:
+        assert stats["launch_sets"] == 0
+    else:
+        assert stats["launch_sets"] >= n and stats["launch_sets"] * stats["pictures_per_launch_set"] == pytest.approx(n * threads)
+        if threads > 1:
+            assert stats["launch_sets"] < n * threads                   # some launch sets held more than one stream's picture
+    check_against_golden(np.fromfile(out, np.uint8), n)
+
+
+def test_bridge_plain_run_is_the_reference_path(tmp_path):
+    """MI355_BRIDGE_PLAIN=1: the bridge never touches the device and the decoder's own C path produces the golden pictures"""
+    if not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP)):
+        pytest.skip("needs /root/reference and the sample clip")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    src, n = samples_file(tmp_path, CLIP)
+    out = tmp_path / "o.yuv"
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "h264_bridge_emu"), str(src), str(out), "1", "1"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, MI355_BRIDGE_PLAIN="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    stats = json.loads(r.stdout.strip().splitlines()[-1])
+    assert stats["pictures_output"] == n and stats["pictures_on_device"] == 0 and stats["bridges_active"] == 0 and r.stderr.strip() == ""
     check_against_golden(np.fromfile(out, np.uint8), n)

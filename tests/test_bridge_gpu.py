@@ -1,7 +1,7 @@
 """GPU: the reference's H.264 decoder with the Tier-2 bridge (contrib/libav/mi355_h264_bridge.c) bound to the real HIP
 library (oracle/_ref/h264_bridge_gpu, built where /root/reference exists and shipped with the tree):
  * realshort.mp4: every picture equals the unmodified reference decoder's (synchronous and lazy completion, 1 and 4
-   decoder threads = streams);
+   decoder threads = streams, batched through the dispatcher and direct);
  * cockatoo.mp4 (4:4:4: outside the batched path): the bridge steps aside and the reference's C path produces the
    same pictures as the plain run."""
 import json
@@ -22,7 +22,7 @@ def _run(args, env_extra=None, timeout=600):
     if not os.path.exists(EXE):
         pytest.fail("oracle/_ref/h264_bridge_gpu missing: run __graft_entry__.build() where /root/reference exists")
     env = dict(os.environ)
-    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_PLAIN"):
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_DIRECT"):
         env.pop(k, None)
     env.update(env_extra or {})
     r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
@@ -30,14 +30,20 @@ def _run(args, env_extra=None, timeout=600):
     return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
 
 
-@pytest.mark.parametrize("lazy,threads", ((False, 1), (True, 1), (False, 4)))
-def test_bridge_decodes_realshort_on_gpu(tmp_path, mi355, lazy, threads):
+@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, False, 6), (True, False, 6), (False, True, 1), (True, True, 4)))
+def test_bridge_decodes_realshort_on_gpu(tmp_path, mi355, lazy, direct, threads):
     if not os.path.exists(CLIP):
         pytest.skip("sample clip not in this image")
     src, n = samples_file(tmp_path, CLIP)
     out = tmp_path / "o.yuv"
-    stats, err = _run([src, out, threads, 1], {"MI355_BRIDGE_LAZY": "1"} if lazy else None)
-    assert stats["pictures_output"] == n * threads and stats["pictures_on_device"] == n * threads and stats["bridges_active"] == threads, (stats, err[-500:])
+    env = {}
+    if lazy:
+        env["MI355_BRIDGE_LAZY"] = "1"
+    if direct:
+        env["MI355_BRIDGE_DIRECT"] = "1"
+    stats, err = _run([src, out, threads, 2], env)
+    assert stats["pictures_output"] == 2 * n * threads and stats["pictures_on_device"] == 2 * n * threads and stats["bridges_active"] == threads, (stats, err[-500:])
+    assert (stats["launch_sets"] == 0) == direct
     check_against_golden(np.fromfile(out, np.uint8), n)
 
 

@@ -1,6 +1,8 @@
 #!/bin/bash
 # End-to-end throughput of the reference decoder + Tier-2 bridge on realshort.mp4 (GPU box, repo root):
 # N decoder threads = N streams, each decoding the clip `loops` times.  -> gpurun_out/<tag>/bridge.jsonl
+# modes: plain = the reference's C path alone (CPU), batched = pictures of all streams through the dispatcher,
+# direct = one HIP stream and one launch set per decoder thread; "lazy" = wait only for the picture about to be output.
 TAG=${1:-bridge}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
@@ -14,8 +16,10 @@ with open("/tmp/realshort.samples", "wb") as f:
         f.write(struct.pack("<I", len(s)) + s)
 PY
 : > $OUT/bridge.jsonl
-for mode in "" "MI355_BRIDGE_LAZY=1"; do
-  for t in 1 8 32 128; do
-    env $mode oracle/_ref/h264_bridge_gpu /tmp/realshort.samples - $t 20 2>/dev/null | sed "s/^{/{\"mode\": \"${mode:-sync}\", /" | tee -a $OUT/bridge.jsonl
-  done
-done
+run() {  # name, env assignments, threads, loops
+  env $2 timeout 120 oracle/_ref/h264_bridge_gpu /tmp/realshort.samples - $3 $4 2>/dev/null | sed "s/^{/{\"mode\": \"$1\", /" | tee -a $OUT/bridge.jsonl
+}
+for t in 1 32 128 256; do run plain "MI355_BRIDGE_PLAIN=1" $t 20; done
+for t in 1 8 32 128 256; do run batched "X=1" $t 20; done
+for t in 1 32 128 256; do run batched_lazy "MI355_BRIDGE_LAZY=1" $t 20; done
+for t in 1 8 32; do run direct "MI355_BRIDGE_DIRECT=1" $t 20; done
