@@ -1,8 +1,8 @@
 /*
  * ref_sws_glue.c — TEST INFRASTRUCTURE.  Compiled against the reference's own headers (from
  * /root/reference, never copied) into oracle/_ref/libswsref.so together with the reference's
- * libswscale objects.  (1) fills the public descriptor of include/mi355_sws.h from a live
- * SwsContext — the same few lines INTEGRATION.md shows for the in-tree binding; (2) exposes the
+ * libswscale objects and with the product's libswscale binding (contrib/libav/mi355_sws_glue.c).
+ * (1) hands out that binding's descriptor of a live SwsContext; (2) exposes the
  * reference's static inner loops through the pointers the context holds, so the tests can call
  * them one at a time.
  */
@@ -10,26 +10,9 @@
 #include "libswscale/swscale_internal.h"
 #include "mi355_sws.h"
 
-int ref_sws_describe(struct SwsContext *c, mi355_sws_desc *d)
-{
-    if (c->srcFormat != AV_PIX_FMT_YUV420P || c->dstFormat != AV_PIX_FMT_RGB24)
-        return -1;
-    d->srcW = c->srcW; d->srcH = c->srcH; d->dstW = c->dstW; d->dstH = c->dstH;
-    d->chrSrcW = c->chrSrcW; d->chrSrcH = c->chrSrcH; d->chrDstW = c->chrDstW;
-    d->unscaled_special = c->swscale != ff_getSwsFunc(c);
-    d->hLum = (mi355_sws_filter){ c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize, c->dstW };
-    d->hChr = (mi355_sws_filter){ c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize, c->chrDstW };
-    d->vLum = (mi355_sws_filter){ c->vLumFilter, c->vLumFilterPos, c->vLumFilterSize, c->dstH };
-    d->vChr = (mi355_sws_filter){ c->vChrFilter, c->vChrFilterPos, c->vChrFilterSize, c->dstH };
-    memcpy(d->luts.y_table, c->yuvTable, 1024);
-    for (int i = 0; i < 256; i++) {
-        d->luts.rV[i] = c->table_rV[i] - (uint8_t *)c->yuvTable;
-        d->luts.gU[i] = c->table_gU[i] - (uint8_t *)c->yuvTable;
-        d->luts.gV[i] = c->table_gV[i];
-        d->luts.bU[i] = c->table_bU[i] - (uint8_t *)c->yuvTable;
-    }
-    return 0;
-}
+/* the descriptor filler is product code: contrib/libav/mi355_sws_glue.c (compiled into this library from there) */
+int mi355_sws_describe(struct SwsContext *c, mi355_sws_desc *d);
+int ref_sws_describe(struct SwsContext *c, mi355_sws_desc *d) { return mi355_sws_describe(c, d); }
 
 int ref_sws_flags_word(int bicubic, int accurate_rnd, int bitexact)
 {
