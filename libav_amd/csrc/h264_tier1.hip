@@ -54,6 +54,16 @@ static void qpel_shim(uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
     const int y0 = my ? -2 : 0, y1 = my ? SIZE + 3 : SIZE;
     Win w = win_pack(a, nullptr, 0, SIZE + 5, SIZE + 5, 0, 0); /* zero-filled */
     uint8_t *wp = a.h<uint8_t>(w.off);
+    if ((mx & 1) && (my & 1)) {
+        /* the diagonal quarter positions average one horizontally and one vertically filtered half sample
+         * (h264qpel_template.c:429-481: mc11 / mc31 / mc13 / mc33): the reference reads a cross — SIZE rows with the
+         * horizontal apron and SIZE columns with the vertical one — and never the four 2 x 2 / 2 x 3 corners */
+        const int hrow = my == 3, vcol = mx == 3;          /* mc13 / mc33 filter the rows below, mc31 / mc33 the columns to the right */
+        for (int y = hrow; y < hrow + SIZE; y++)
+            std::memcpy(wp + (size_t)(y + 2) * w.pitch, src + y * stride - 2, (size_t)(SIZE + 5));
+        for (int y = -2; y < SIZE + 3; y++)
+            std::memcpy(wp + (size_t)(y + 2) * w.pitch + 2 + vcol, src + y * stride + vcol, (size_t)SIZE);
+    } else
     for (int y = y0; y < y1; y++)
         std::memcpy(wp + (size_t)(y + 2) * w.pitch + (x0 + 2), src + y * stride + x0, (size_t)(x1 - x0));
     Win d = win_pack(a, dst, stride, SIZE, SIZE);
