@@ -695,6 +695,9 @@ __device__ inline void chroma_dc_dequant(int &a, int &b, int &c, int &d, int qmu
 
 /* ---- a8: deblocking, one line across an edge — per lane -----------------------
  * h264dsp_template.c:104-150 (bS<4), :166-218 (bS==4), :233-270 / :294-318 chroma. */
+/* MAXV: the largest sample value (255; (1 << bit_depth) - 1 for the 9 / 10-bit tables, whose callers scale alpha, beta
+ * and tc0 as h264dsp_template.c:110-113 does) */
+template <int MAXV = 255>
 __device__ __forceinline__ void lf_luma_line(int &p2, int &p1, int &p0, int &q0, int &q1, int &q2,
                                              int alpha, int beta, int tc0)
 {
@@ -711,8 +714,8 @@ __device__ __forceinline__ void lf_luma_line(int &p2, int &p1, int &p0, int &q0,
     }
     int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
     p1 = np1; q1 = nq1;
-    p0 = clip_u8(p0 + delta);
-    q0 = clip_u8(q0 - delta);
+    p0 = clip3(p0 + delta, 0, MAXV);
+    q0 = clip3(q0 - delta, 0, MAXV);
 }
 __device__ __forceinline__ void lf_luma_intra_line(int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3,
                                                    int alpha, int beta)
@@ -740,13 +743,14 @@ __device__ __forceinline__ void lf_luma_intra_line(int p3, int &p2, int &p1, int
     }
 }
 /* tc is the value the caller passes in tc0[] (already +1 for chroma, h264_loopfilter.c:126-129) */
+template <int MAXV = 255>
 __device__ __forceinline__ void lf_chroma_line(int p1, int &p0, int &q0, int q1, int alpha, int beta, int tc)
 {
     if (tc <= 0) return;
     if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
     int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-    p0 = clip_u8(p0 + delta);
-    q0 = clip_u8(q0 - delta);
+    p0 = clip3(p0 + delta, 0, MAXV);
+    q0 = clip3(q0 - delta, 0, MAXV);
 }
 __device__ __forceinline__ void lf_chroma_intra_line(int p1, int &p0, int &q0, int q1, int alpha, int beta)
 {
@@ -818,7 +822,7 @@ __device__ __host__ __forceinline__ int pred_luma_needs(int mode)
 }
 
 /* DC-family value for an NxN luma block from the (already prepared) vectors */
-__device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int16_t *L)
+__device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int16_t *L, int mid = 128)
 {
     int st = 0, sl = 0;
     for (int i = 0; i < N; i++) { st += T[i]; sl += L[i]; }
@@ -826,7 +830,7 @@ __device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int
     if (mode == 2) return (st + sl + N) >> (lg + 1);
     if (mode == 9) return (sl + (N >> 1)) >> lg;
     if (mode == 10) return (st + (N >> 1)) >> lg;
-    return 128;
+    return mid;
 }
 
 /* plane prediction parameters (h264pred_template.c:434-481 for N=16, :768-802 for N=8):
@@ -861,9 +865,12 @@ struct PredScratch {
     int16_t fL[1 + 8];
 };
 
+/* PX / BD: sample type and bit depth of the output (uint8_t / 8 for everything but the 9 / 10-bit Tier-1 tables) */
+template <typename PX = uint8_t, int BD = 8>
 __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int has_tl, int has_tr,
-                                       uint8_t *out, int pitch)
+                                       PX *out, int pitch)
 {
+    constexpr int MAXV = (1 << BD) - 1, MID = 1 << (BD - 1);
     const int lane = lane_id();
     const int16_t *T = s.T + 1, *L = s.L + 1;
     if (kind == 0 || kind == 1) {
@@ -898,9 +905,9 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
         if (lane < N * N) {
             int x = lane & (N - 1), y = lane / N;
             int v;
-            if (mode == 2 || mode >= 9) v = pred_dc_value(mode, N, T, L);
+            if (mode == 2 || mode >= 9) v = pred_dc_value(mode, N, T, L, MID);
             else v = pred_dir_px(mode, N, x, y, T, L);
-            out[y * pitch + x] = (uint8_t)v;
+            out[y * pitch + x] = (PX)v;
         }
         MI355_WAVE_SYNC();
         return;
@@ -916,12 +923,12 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             case 0: v = (st + sl + 16) >> 5; break;
             case 1: v = L[y]; break;
             case 2: v = T[x]; break;
-            case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+            case 3: v = clip3((a + x * H + y * V) >> 5, 0, MAXV); break;
             case 4: v = (sl + 8) >> 4; break;
             case 5: v = (st + 8) >> 4; break;
-            default: v = 128; break;
+            default: v = MID; break;
             }
-            out[y * pitch + x] = (uint8_t)v;
+            out[y * pitch + x] = (PX)v;
         }
         MI355_WAVE_SYNC();
         return;
@@ -944,16 +951,16 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
             case 0: v = dc_full; break;
             case 1: v = L[y]; break;
             case 2: v = T[x]; break;
-            case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+            case 3: v = clip3((a + x * H + y * V) >> 5, 0, MAXV); break;
             case 4: v = dc_left; break;
             case 5: v = dc_top; break;
-            case 6: v = 128; break;
+            case 6: v = MID; break;
             case 7: v = (qx == 0 && qy == 0) ? (t + l + 4) >> 3 : dc_top; break;   /* L0T */
             case 8: v = (qx == 0 && qy == 0) ? dc_top : dc_full; break;              /* 0LT */
-            case 9: v = qy == 1 ? 128 : dc_left; break;                              /* L00: rows 4..7 only */
-            default: v = qy == 0 ? 128 : dc_left; break;                             /* 0L0 */
+            case 9: v = qy == 1 ? MID : dc_left; break;                              /* L00: rows 4..7 only */
+            default: v = qy == 0 ? MID : dc_left; break;                             /* 0L0 */
             }
-            out[y * pitch + x] = (uint8_t)v;
+            out[y * pitch + x] = (PX)v;
         }
         MI355_WAVE_SYNC();
         return;
@@ -970,16 +977,16 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
         case 0: v = dc_full; break;
         case 1: v = L[y]; break;
         case 2: v = T[x]; break;
-        case 3: v = clip_u8((a + x * H + y * V) >> 5); break;
+        case 3: v = clip3((a + x * H + y * V) >> 5, 0, MAXV); break;
         case 4: v = dc_left; break;
         case 5: v = dc_top; break;
-        case 6: v = 128; break;
+        case 6: v = MID; break;
         case 7: v = (qx == 0 && qy == 0) ? (t + l + 4) >> 3 : dc_top; break;   /* L0T */
         case 8: v = (qx == 0 && qy == 0) ? dc_top : dc_full; break;              /* 0LT */
-        case 9: v = qy ? 128 : dc_left; break;                                   /* L00 */
-        default: v = qy ? dc_left : 128; break;                                  /* 0L0 */
+        case 9: v = qy ? MID : dc_left; break;                                   /* L00 */
+        default: v = qy ? dc_left : MID; break;                                  /* 0L0 */
         }
-        out[y * pitch + x] = (uint8_t)v;
+        out[y * pitch + x] = (PX)v;
         MI355_WAVE_SYNC();
     }
 }

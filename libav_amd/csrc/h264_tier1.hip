@@ -16,6 +16,15 @@
 
 using namespace mi355;
 
+/* the 9 / 10-bit instantiations live in h264_tier1_hbd.hip */
+namespace mi355 {
+void h264dsp_init_hbd(H264DSPContext *c, int bit_depth, int chroma_format_idc);
+void h264qpel_init_hbd(H264QpelContext *c, int bit_depth);
+void h264chroma_init_hbd(H264ChromaContext *c, int bit_depth);
+void h264pred_init_hbd(H264PredContext *h, int bit_depth, int chroma_format_idc);
+void videodsp_init_hbd(VideoDSPContext *ctx, int bpc);
+}
+
 #define LAUNCH1(kernel, a, ...) \
     hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, (a).stream, __VA_ARGS__)
 
@@ -497,8 +506,8 @@ void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int ch
 {
     /* like an arch hook: only the variants this backend implements are overridden
      * (8-bit samples; 4:0:0, 4:2:0 and 4:2:2 — 4:4:4 chroma goes through the luma entries); everything else keeps
-     * the C default */
-    if (bit_depth != 8) return;
+     * the C default; 9 and 10 bit: h264_tier1_hbd.hip) */
+    if (bit_depth != 8) { h264dsp_init_hbd(c, bit_depth, chroma_format_idc); return; }
     c->weight_h264_pixels_tab[0] = weight_shim<16>;   c->weight_h264_pixels_tab[1] = weight_shim<8>;
     c->weight_h264_pixels_tab[2] = weight_shim<4>;    c->weight_h264_pixels_tab[3] = weight_shim<2>;
     c->biweight_h264_pixels_tab[0] = biweight_shim<16>; c->biweight_h264_pixels_tab[1] = biweight_shim<8>;
@@ -540,7 +549,7 @@ void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int ch
 
 void ff_h264qpel_init_mi355x(H264QpelContext *c, int bit_depth)
 {
-    if (bit_depth != 8) return;
+    if (bit_depth != 8) { h264qpel_init_hbd(c, bit_depth); return; }
 #define QROW(tab, idx, SIZE, AVG) \
     c->tab[idx][0] = qpel_shim<SIZE, 0, AVG>;   c->tab[idx][1] = qpel_shim<SIZE, 1, AVG>;   \
     c->tab[idx][2] = qpel_shim<SIZE, 2, AVG>;   c->tab[idx][3] = qpel_shim<SIZE, 3, AVG>;   \
@@ -559,7 +568,7 @@ void ff_h264qpel_init_mi355x(H264QpelContext *c, int bit_depth)
 
 void ff_h264chroma_init_mi355x(H264ChromaContext *c, int bit_depth)
 {
-    if (bit_depth != 8) return;
+    if (bit_depth != 8) { h264chroma_init_hbd(c, bit_depth); return; }
     c->put_h264_chroma_pixels_tab[0] = chroma_shim<8, 0>; c->put_h264_chroma_pixels_tab[1] = chroma_shim<4, 0>;
     c->put_h264_chroma_pixels_tab[2] = chroma_shim<2, 0>;
     c->avg_h264_chroma_pixels_tab[0] = chroma_shim<8, 1>; c->avg_h264_chroma_pixels_tab[1] = chroma_shim<4, 1>;
@@ -732,7 +741,8 @@ template <int HZ> static void pred8x16_add_shim(uint8_t *pix, const int *block_o
 
 void ff_h264_pred_init_mi355x(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
 {
-    if (bit_depth != 8 || codec_id != MI355_AV_CODEC_ID_H264) return;   /* idc > 1: the 8x16 forms, as h264pred.c:470-565 selects them */
+    if (codec_id != MI355_AV_CODEC_ID_H264) return;
+    if (bit_depth != 8) { h264pred_init_hbd(h, bit_depth, chroma_format_idc); return; }   /* idc > 1: the 8x16 forms, as h264pred.c:470-565 selects them */
     h->pred4x4[0] = p4_shim<0>; h->pred4x4[1] = p4_shim<1>; h->pred4x4[2] = p4_shim<2>; h->pred4x4[3] = p4_shim<3>;
     h->pred4x4[4] = p4_shim<4>; h->pred4x4[5] = p4_shim<5>; h->pred4x4[6] = p4_shim<6>; h->pred4x4[7] = p4_shim<7>;
     h->pred4x4[8] = p4_shim<8>; h->pred4x4[9] = p4_shim<9>; h->pred4x4[10] = p4_shim<10>; h->pred4x4[11] = p4_shim<11>;
@@ -798,7 +808,7 @@ static void t1_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_
 
 void ff_videodsp_init_mi355x(VideoDSPContext *ctx, int bpc)
 {
-    if (bpc > 8) return;
+    if (bpc > 8) { videodsp_init_hbd(ctx, bpc); return; }
     ctx->emulated_edge_mc = t1_emulated_edge_mc;
     /* prefetch stays the C no-op: a host cache hint has no device meaning */
 }

@@ -71,6 +71,12 @@ def main():
     with open(os.path.join(HERE, "hevc_intra_ref_sha1.json"), "w") as f:
         json.dump(icases, f, indent=0, sort_keys=True)
     print("hevc_intra:", len(icases), "cases")
+    # 9 / 10-bit H.264 tables: the reference's BIT_DEPTH 9 / 10 template instantiations (no CPU restatement exists)
+    import cases_h264_hbd as HB
+    hbd = {str(bd): digest(HB.run_all(ref, bd)) for bd in (9, 10)}
+    with open(os.path.join(HERE, "h264dsp_hbd_ref_sha1.json"), "w") as f:
+        json.dump(hbd, f, indent=0, sort_keys=True)
+    print("h264dsp_hbd:", {k: len(v) for k, v in hbd.items()}, "cases")
     # struct layout of the pointer tables as the reference headers define them
     import ctypes as C
     buf = C.create_string_buffer(8192)
