@@ -32,8 +32,16 @@
  *
  * The decoded picture buffer lives in HBM: one device picture per H264Picture the decoder uses, found again through the
  * reference lists' parent pointers; reference samples never cross PCIe.  Two staging sets per stream alternate, so the
- * host can pack picture n + 1 while the copies and kernels of picture n run.  Streams outside the Tier-2 scope (MBAFF /
- * field pictures, more than 8 bits, not 4:2:0), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
+ * host can pack picture n + 1 while the copies and kernels of picture n run.
+ *
+ * 4:4:4 streams (hl_decode_mb_444, h264_mb_template.c:259-345: every plane is decoded like luma — luma interpolation,
+ * luma intra modes, luma transforms, the luma loop filter with the plane's own QP) are submitted as THREE passes per
+ * picture, one per plane: the plane takes the luma role of a descriptor whose chroma planes point at scratch surfaces, with
+ * per-plane records (that plane's coefficient flags, QP and DC multiplier), coefficients and weight tables.  The loop filter
+ * takes its boundary strengths from the LUMA coefficient flags for every plane (filter_mb_dir, h264_loopfilter.c:482-713),
+ * so planes 1 and 2 get a second record array for the filter pass.  No kernel knows about 4:4:4.
+ *
+ * Streams outside the Tier-2 scope (MBAFF / field pictures, more than 8 bits, 4:2:2), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
  * aside for that decoder: the reference's own C path continues.  Errors are reported once on stderr; nothing here
  * calls abort().
  */
@@ -57,7 +65,8 @@ void __real_ff_h264_filter_mb_fast(const H264Context *h, H264SliceContext *sl, i
 
 #define BR_MAX_PICS 40        /* H264_MAX_PICTURE_COUNT (36) + slack */
 #define BR_MAX_SLICES 64
-#define DISP_MAX_BATCH 256    /* pictures (= streams) per launch set */
+#define DISP_MAX_BATCH 256    /* descriptors (pictures of 4:2:0 streams, planes of 4:4:4 ones) per launch set */
+#define BR_MAX_PASSES 3       /* 4:4:4: one pass per plane */
 #define DISP_MAX_LEVELS 8192  /* mb_width + 2 * mb_height of the largest picture the dispatcher takes */
 
 struct Bridge;
@@ -80,11 +89,12 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
                                  * input byte of a picture is read once, a copy into HBM first would only add a runtime call */
     uint8_t *host;
     size_t size;
-    mi355_h264_frame *desc;
-    mi355_h264_mb *mb;
+    mi355_h264_frame *desc;     /* 2 * npass descriptors: [p] reconstruction of pass p, [npass + p] its loop filter */
+    mi355_h264_mb *mb[BR_MAX_PASSES];    /* records the reconstruction of pass p reads */
+    mi355_h264_mb *mbd[BR_MAX_PASSES];   /* records its loop filter reads (4:4:4 planes 1, 2: the luma coefficient flags) */
     int16_t *mv[2];
-    int16_t *coef;
-    mi355_h264_slice *slices;
+    int16_t *coef[BR_MAX_PASSES];
+    mi355_h264_slice *slices[BR_MAX_PASSES];
     uint32_t *ilist;
     int32_t *istart;
     int32_t *widths;            /* host only: macroblocks per intra level */
@@ -93,7 +103,7 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
     DevPic *pic;                /* the picture this set was submitted for */
     uint8_t *frame_data[3];     /* where it goes: the AVFrame the decoder will hand out */
     int frame_linesize[3];
-    mi355_h264_frame *d_desc;   /* direct mode: the descriptor on the device */
+    mi355_h264_frame *d_desc;   /* direct mode: the descriptors on the device */
     void *done;                 /* direct mode: event after the copy into `out` */
     Submission sub;             /* batched mode */
     int in_flight;
@@ -108,9 +118,11 @@ typedef struct Bridge {
     int cur;                    /* staging set being packed */
     int open;                   /* a picture is being packed */
     DevPic pics[BR_MAX_PICS];
-    uint8_t *recon[3];
+    int c444, npass;            /* 4:4:4: three passes (planes) per picture */
+    uint8_t *recon[3];          /* unfiltered reconstruction: Y, Cb, Cr (4:4:4: three full-size planes) */
+    uint8_t *scratch_c[2];      /* 4:4:4: what the passes use as chroma planes (never looked at) */
     int stride[2];
-    size_t plane_bytes[2];
+    size_t plane_bytes[2];      /* luma plane, 4:2:0 chroma plane */
     /* per picture */
     int nslices, slice_num_of[BR_MAX_SLICES], uses_l1;
     const H264Picture *slot_pic[MI355_H264_MAX_SLOTS];
@@ -129,30 +141,41 @@ static void br_fail(Bridge *b, const char *what)
 static void *dalloc(size_t n) { return mi355_malloc(n); }
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
+static size_t picture_bytes(const Bridge *b) { return b->c444 ? 3 * b->plane_bytes[0] : b->plane_bytes[0] + 2 * b->plane_bytes[1]; }
+
 static int staging_alloc(Bridge *b, Staging *s)
 {
     const size_t n = (size_t)b->nmb, nlev = (size_t)(b->mb_w + 2 * b->mb_h + 2);
-    size_t o = 0;
-    const size_t o_desc = o;   o = up64(o + sizeof(mi355_h264_frame));
-    const size_t o_mb = o;     o = up64(o + n * sizeof(mi355_h264_mb));
+    const int np = b->npass;
+    size_t o = 0, o_mb[BR_MAX_PASSES], o_mbd[BR_MAX_PASSES], o_coef[BR_MAX_PASSES], o_sl[BR_MAX_PASSES];
+    const size_t o_desc = o;   o = up64(o + 2 * BR_MAX_PASSES * sizeof(mi355_h264_frame));
+    for (int p = 0; p < np; p++) {
+        o_mb[p] = o;   o = up64(o + n * sizeof(mi355_h264_mb));
+        o_mbd[p] = p ? o : o_mb[0];
+        if (p) o = up64(o + n * sizeof(mi355_h264_mb));
+        o_coef[p] = o; o = up64(o + n * 768);
+        o_sl[p] = o;   o = up64(o + BR_MAX_SLICES * sizeof(mi355_h264_slice));
+    }
     const size_t o_mv0 = o;    o = up64(o + n * 64);
     const size_t o_mv1 = o;    o = up64(o + n * 64);
-    const size_t o_coef = o;   o = up64(o + n * 768);
-    const size_t o_sl = o;     o = up64(o + BR_MAX_SLICES * sizeof(mi355_h264_slice));
     const size_t o_is = o;     o = up64(o + nlev * 4);
     const size_t o_il = o;     o = up64(o + n * 4);
     s->size = o;
     s->host = mi355_host_alloc(s->size);
     s->widths = malloc(nlev * 4);
-    s->out = mi355_host_alloc(b->plane_bytes[0] + 2 * b->plane_bytes[1]);
-    if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(sizeof(mi355_h264_frame)); }
+    s->out = mi355_host_alloc(picture_bytes(b));
+    if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(2 * BR_MAX_PASSES * sizeof(mi355_h264_frame)); }
     if (!s->host || !s->widths || !s->out || (b->direct && (!s->done || !s->d_desc))) return 0;
+    memset(s->host, 0, s->size);
     s->desc = (mi355_h264_frame *)(s->host + o_desc);
-    s->mb = (mi355_h264_mb *)(s->host + o_mb);
+    for (int p = 0; p < np; p++) {
+        s->mb[p] = (mi355_h264_mb *)(s->host + o_mb[p]);
+        s->mbd[p] = (mi355_h264_mb *)(s->host + o_mbd[p]);
+        s->coef[p] = (int16_t *)(s->host + o_coef[p]);
+        s->slices[p] = (mi355_h264_slice *)(s->host + o_sl[p]);
+    }
     s->mv[0] = (int16_t *)(s->host + o_mv0);
     s->mv[1] = (int16_t *)(s->host + o_mv1);
-    s->coef = (int16_t *)(s->host + o_coef);
-    s->slices = (mi355_h264_slice *)(s->host + o_sl);
     s->istart = (int32_t *)(s->host + o_is);
     s->ilist = (uint32_t *)(s->host + o_il);
     return 1;
@@ -174,28 +197,34 @@ static struct {
     unsigned long batches, pictures;
 } disp = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
 
-/* one batch: a descriptor copy, the launch set for all its pictures, one launch that brings the finished pictures to the
- * streams' pinned buffers; nothing waits here */
+/* one batch: a descriptor copy, the launch set for all its pictures (reconstruction from one descriptor array, loop filter
+ * from a second one: they differ for the chroma planes of 4:4:4 pictures), one launch that brings the finished pictures to
+ * the streams' pinned buffers; nothing waits here */
 static int disp_enqueue(int slot)
 {
     const int n = disp.nin[slot];
-    int mw = 0, mh = 0, maxl = 0, rc = 0;
+    int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0;
     size_t max_bytes = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++) nd += disp.in[slot][i]->b->npass;
+    mi355_h264_frame *hr = disp.h_desc[slot], *hd = disp.h_desc[slot] + nd;      /* reconstruction | loop filter */
+    for (int i = 0, k = 0; i < n; i++) {
         const Staging *s = disp.in[slot][i]->s;
         const Bridge *b = disp.in[slot][i]->b;
-        const size_t bytes = b->plane_bytes[0] + 2 * b->plane_bytes[1];
+        const size_t bytes = picture_bytes(b);
         if (b->mb_w > mw) mw = b->mb_w;
         if (b->mb_h > mh) mh = b->mb_h;
         for (int l = 0; l < s->maxl; l++)
             if (l >= maxl || s->widths[l] > disp.widths[l]) disp.widths[l] = s->widths[l];
         if (s->maxl > maxl) maxl = s->maxl;
-        disp.h_desc[slot][i] = *s->desc;
+        for (int p = 0; p < b->npass; p++, k++) { hr[k] = s->desc[p]; hd[k] = s->desc[b->npass + p]; }
         disp.jobs[slot][i].src = s->pic->plane[0]; disp.jobs[slot][i].dst = s->out; disp.jobs[slot][i].bytes = bytes;
         if (bytes > max_bytes) max_bytes = bytes;
     }
-    rc |= mi355_memcpy_h2d_async(disp.d_desc[slot], disp.h_desc[slot], (size_t)n * sizeof(mi355_h264_frame), disp.stream);
-    if (!rc && mi355_h264_decode_frames_levels_dev(disp.d_desc[slot], n, mw, mh, maxl, disp.widths, disp.stream) != 0) rc = -1;
+    mi355_h264_frame *dr = disp.d_desc[slot], *dd = disp.d_desc[slot] + nd;
+    rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), disp.stream);
+    if (!rc && mi355_h264_recon_inter_dev(dr, nd, mw, mh, disp.stream) != 0) rc = -1;
+    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, disp.stream) != 0) rc = -1;
+    if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, disp.stream) != 0) rc = -1;
     if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, disp.stream) != 0) rc = -1;
     rc |= mi355_event_record(disp.ev[slot], disp.stream);
     return rc;
@@ -213,16 +242,16 @@ static void *disp_main(void *arg)
             /* what is queued now, at most one picture per stream (a stream's next picture reads this one's output) */
             const int slot = (head_slot + inflight) & 1;
             Submission *keep_head = NULL, *keep_tail = NULL, *c = disp.head;
-            int n = 0;
+            int n = 0, nd = 0;
             while (c) {
                 Submission *nx = c->next;
-                int later = n >= DISP_MAX_BATCH;
+                int later = nd + c->b->npass > DISP_MAX_BATCH;
                 for (int i = 0; i < n && !later; i++) later = disp.in[slot][i]->b == c->b;
                 if (later) {
                     c->next = NULL;
                     if (keep_tail) keep_tail->next = c; else keep_head = c;
                     keep_tail = c;
-                } else disp.in[slot][n++] = c;
+                } else { disp.in[slot][n++] = c; nd += c->b->npass; }
                 c = nx;
             }
             disp.head = keep_head; disp.tail = keep_tail;
@@ -256,8 +285,8 @@ static int disp_start(void)
         int ok = disp.stream != NULL;
         for (int k = 0; k < 2 && ok; k++) {
             disp.ev[k] = mi355_event_create();
-            disp.h_desc[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_h264_frame));
-            disp.d_desc[k] = dalloc(DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            disp.h_desc[k] = mi355_host_alloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            disp.d_desc[k] = dalloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
             disp.jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
             ok = disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k];
         }
@@ -280,20 +309,24 @@ static Bridge *bridge_get(const H264Context *h)
         if (getenv("MI355_BRIDGE_PLAIN")) b->state = -1;         /* the comparison run: the reference's C path, silently */
     }
     if (b->state) return b;
-    if (FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || h->ps.sps->chroma_format_idc != 1 || h->ps.sps->transform_bypass) {
-        br_fail(b, "stream outside the batched path (needs progressive 8-bit 4:2:0 without transform bypass)");
+    const int idc = h->ps.sps->chroma_format_idc;
+    if (FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
+        h->ps.sps->transform_bypass) {
+        br_fail(b, "stream outside the batched path (needs progressive 8-bit 4:2:0 or 4:4:4 without transform bypass)");
         return b;
     }
     const char *dev = getenv("MI355_DEVICE");
     if (mi355_init(dev ? atoi(dev) : 0) != 0) { br_fail(b, "no usable MI355X"); return b; }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
+    b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
     b->stride[0] = (16 * b->mb_w + 63) & ~63; b->stride[1] = b->stride[0] / 2;
     b->plane_bytes[0] = (size_t)b->stride[0] * 16 * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * 8 * b->mb_h;
     int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
     if (ok && b->direct) ok = (b->stream = mi355_stream_create()) != NULL;
     if (ok && !b->direct) ok = disp_start();
     ok = ok && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
-    for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[p > 0])) != NULL;
+    for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[b->c444 ? 0 : p > 0])) != NULL;
+    for (int p = 0; p < 2 && ok && b->c444; p++) ok = (b->scratch_c[p] = dalloc(b->plane_bytes[1])) != NULL;
     if (!ok) { br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
     b->st[0].sub.b = b->st[1].sub.b = b;
     b->st[0].sub.s = &b->st[0]; b->st[1].sub.s = &b->st[1];
@@ -315,9 +348,10 @@ static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, 
         if (b->pics[i].owner < h->DPB || b->pics[i].owner >= h->DPB + H264_MAX_PICTURE_COUNT) slot = &b->pics[i];
     if (!slot) return NULL;
     if (!slot->plane[0]) {
-        uint8_t *base = dalloc(b->plane_bytes[0] + 2 * b->plane_bytes[1]);
+        uint8_t *base = dalloc(picture_bytes(b));
         if (!base) return NULL;
-        slot->plane[0] = base; slot->plane[1] = base + b->plane_bytes[0]; slot->plane[2] = slot->plane[1] + b->plane_bytes[1];
+        const size_t cb = b->c444 ? b->plane_bytes[0] : b->plane_bytes[1];
+        slot->plane[0] = base; slot->plane[1] = base + b->plane_bytes[0]; slot->plane[2] = slot->plane[1] + cb;
     }
     slot->owner = p;
     return slot;
@@ -349,9 +383,10 @@ static int finish_set(Bridge *b, Staging *s)
     if (rc) return rc;
     const uint8_t *src = s->out;
     for (int k = 0; k < 3; k++) {
-        const int w = (k ? 8 : 16) * b->mb_w, hgt = (k ? 8 : 16) * b->mb_h, st = b->stride[k > 0];
+        const int half = k && !b->c444;
+        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->stride[half];
         for (int y = 0; y < hgt; y++) memcpy(s->frame_data[k] + (size_t)y * s->frame_linesize[k], src + (size_t)y * st, (size_t)w);
-        src += b->plane_bytes[k > 0];
+        src += b->plane_bytes[half];
     }
     return 0;
 }
@@ -365,10 +400,13 @@ static void begin_picture(Bridge *b, const H264Context *h)
         b->waits++;
         if (finish_set(b, s) != 0) br_fail(b, "a picture did not come back from the device");
     }
-    memset(s->mb, 0, (size_t)b->nmb * sizeof(*s->mb));
+    for (int p = 0; p < b->npass; p++) {
+        memset(s->mb[p], 0, (size_t)b->nmb * sizeof(mi355_h264_mb));
+        if (p) memset(s->mbd[p], 0, (size_t)b->nmb * sizeof(mi355_h264_mb));
+        memset(s->slices[p], 0, BR_MAX_SLICES * sizeof(mi355_h264_slice));
+    }
     memset(s->mv[0], 0, (size_t)b->nmb * 64);
     memset(s->mv[1], 0, (size_t)b->nmb * 64);
-    memset(s->slices, 0, BR_MAX_SLICES * sizeof(*s->slices));
     b->nslices = b->nslots = b->uses_l1 = 0;
     b->open = 1;
     (void)h;
@@ -379,7 +417,7 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
     for (int i = 0; i < b->nslices; i++)
         if (b->slice_num_of[i] == sl->slice_num) return i;
     if (b->nslices >= BR_MAX_SLICES) return -1;
-    mi355_h264_slice *s = &b->st[b->cur].slices[b->nslices];
+    mi355_h264_slice *s = &b->st[b->cur].slices[0][b->nslices];
     b->slice_num_of[b->nslices] = sl->slice_num;
     s->use_weight = sl->pwt.use_weight;
     s->use_weight_chroma = sl->pwt.use_weight_chroma;
@@ -402,7 +440,55 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
     }
     for (int t = 0; t < 2; t++)
         for (int q = 0; q < 52; q++) s->chroma_qp_table[t][q] = h->ps.pps->chroma_qp_table[t][q];
+    /* 4:4:4: the plane's own weights in the luma role (mc_part_weighted, h264_mb.c:386-470: chroma_weight_op = luma_weight_op
+     * with sl->pwt.chroma_weight and chroma_log2_weight_denom; tables hold the identity where a flag was not sent) */
+    for (int p = 1; p < b->npass; p++) {
+        mi355_h264_slice *c = &b->st[b->cur].slices[p][b->nslices];
+        *c = *s;
+        c->luma_log2_weight_denom = s->chroma_log2_weight_denom;
+        c->use_weight_chroma = 0;
+        for (int r = 0; r < MI355_H264_MAX_REFS; r++)
+            for (int l = 0; l < 2; l++)
+                for (int k = 0; k < 2; k++) c->luma_weight[r][l][k] = s->chroma_weight[r][l][p - 1][k];
+    }
     return b->nslices++;
+}
+
+/* 4:4:4: the records, coefficients and filter records of planes 1 and 2 (hl_decode_mb_predict_luma / _idct_luma with
+ * p = 1, 2: h264_mb_template.c:323-343; coefficient flags at scan8[16 * p + i], DC levels in sl->mb_luma_dc[p], the DC
+ * multiplier of dequant4_coeff[p] at the plane's QP, h264_mb.c:617-640) */
+static void pack_planes_444(const H264Context *h, H264SliceContext *sl, Staging *st, int idx, int mb_type, int luma_coded)
+{
+    mi355_h264_mb *m0 = &st->mb[0][idx];
+    m0->chroma_pred_mode = 6;                        /* DC_128_PRED8x8: the scratch chroma planes are predicted from nothing */
+    for (int p = 1; p < 3; p++) {
+        mi355_h264_mb *m = &st->mb[p][idx];
+        int16_t *cf = st->coef[p] + (size_t)idx * 384;
+        *m = *m0;
+        m->nnz_mask = 0;
+        m->qp = (int8_t)h->ps.pps->chroma_qp_table[p - 1][m0->qp & 0xff];
+        m->dc_qmul[0] = h->ps.pps->dequant4_coeff[p][sl->chroma_qp[p - 1]][0];
+        memset(cf, 0, 768);
+        if (IS_INTRA_PCM(mb_type)) {
+            memcpy(cf, sl->intra_pcm_ptr + 256 * p, 256);
+            m->nnz_mask = 0xFFFFFF;
+        } else {
+            if (luma_coded) {
+                for (int i = 0; i < 16; i++) {
+                    const int src = IS_8x8DCT(mb_type) ? (i & ~3) : i;
+                    if (sl->non_zero_count_cache[scan8[16 * p + src]]) m->nnz_mask |= 1u << i;
+                }
+                memcpy(cf, sl->mb + 256 * p, 256 * 2);
+            }
+            if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX + p]]) {
+                m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
+                for (int k = 0; k < 16; k++) cf[mi355_luma_dc_slot(k)] = sl->mb_luma_dc[p][k];
+            }
+        }
+        /* the loop filter derives the boundary strengths of every plane from the luma coefficient flags */
+        st->mbd[p][idx] = *m;
+        st->mbd[p][idx].nnz_mask = m0->nnz_mask;
+    }
 }
 
 void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
@@ -413,7 +499,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     Staging *st = &b->st[b->cur];
     const int mb_xy = sl->mb_xy, idx = sl->mb_x + sl->mb_y * b->mb_w;
     const int mb_type = h->cur_pic.mb_type[mb_xy];
-    mi355_h264_mb *m = &st->mb[idx];
+    mi355_h264_mb *m = &st->mb[0][idx];
     const int si = slice_index(b, h, sl);
     if (si < 0) { br_fail(b, "more slices or reference pictures than the batched path holds"); __real_ff_h264_hl_decode_mb(h, sl); return; }
     const int intra = IS_INTRA(mb_type);
@@ -445,12 +531,13 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     m->dc_qmul[2] = h->ps.pps->dequant4_coeff[intra ? 2 : 5][sl->chroma_qp[1]][0];
     memset(m->ref_idx, -1, sizeof(m->ref_idx));
 
-    int16_t *cf = st->coef + (size_t)idx * 384;
+    int16_t *cf = st->coef[0] + (size_t)idx * 384;
     memset(cf, 0, 768);
     if (IS_INTRA_PCM(mb_type)) {
         memcpy(cf, sl->intra_pcm_ptr, 384);
         m->nnz_mask = 0xFFFFFF;
         memset(m->u.intra4x4_pred_mode, 0, 16);
+        if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, 0);
     } else {
         /* coefficient masks: the count caches are only meaningful where cbp says something was coded */
         const int luma_coded = IS_INTRA16x16(mb_type) || (cbp & 15);
@@ -486,7 +573,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 for (int q = 0; q < 4; q++) {
                     const int r = sl->ref_cache[list][scan8[4 * q]];
                     m->ref_idx[list][q] = (int8_t)(r < 0 ? -1 : r);
-                    if (r >= 0) m->u.inter.ref_pic[list][q] = st->slices[si].ref_slot[list][r];
+                    if (r >= 0) m->u.inter.ref_pic[list][q] = st->slices[0][si].ref_slot[list][r];
                 }
                 for (int i = 0; i < 16; i++) {
                     const int x4 = (i & 1) + 2 * ((i >> 2) & 1), y4 = ((i >> 1) & 1) + 2 * (i >> 3);
@@ -504,6 +591,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         }
         /* what the reference's idct_add / dc_dequant functions leave behind (h264idct_template.c:66,:140,:150): the residual
          * decoders rely on finding the block array zeroed */
+        if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, luma_coded);
         if (luma_coded || (cbp & 0x30)) memset(sl->mb, 0, 16 * 48 * sizeof(int16_t));
     }
 }
@@ -527,33 +615,46 @@ static int submit_picture(Bridge *b, H264Context *h)
     DevPic *cur = devpic_of(b, h, h->cur_pic_ptr, 1);
     if (!cur) return -1;
     int lw = 0;
-    const int maxl = mi355_h264_intra_schedule(s->mb, b->mb_w, b->mb_h, s->ilist, s->istart, &lw);
+    const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->mb_h, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;
     for (int l = 0; l < maxl; l++) s->widths[l] = s->istart[l + 1] - s->istart[l];
     s->maxl = maxl;
-    mi355_h264_frame *f = s->desc;
-    memset(f, 0, sizeof(*f));
-    f->mb_width = b->mb_w; f->mb_height = b->mb_h;
-    for (int k = 0; k < 3; k++) { f->dst[k] = cur->plane[k]; f->recon[k] = b->recon[k]; }
-    f->dst_stride[0] = f->recon_stride[0] = b->stride[0];
-    f->dst_stride[1] = f->recon_stride[1] = b->stride[1];
-    for (int i = 0; i < b->nslots; i++) {
-        DevPic *r = devpic_of(b, h, b->slot_pic[i], 0);
-        if (!r) return -2;                       /* a reference this bridge never decoded (a stream joined mid-way) */
-        for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k];
+    const int np = b->npass;
+    for (int p = 0; p < np; p++) {
+        /* pass p: 4:2:0 = the picture; 4:4:4 = plane p in the luma role, scratch surfaces in the chroma roles.  The kernels
+         * read the staging block in place (device-visible host memory) */
+        mi355_h264_frame *f = &s->desc[p];
+        memset(f, 0, sizeof(*f));
+        f->mb_width = b->mb_w; f->mb_height = b->mb_h;
+        f->dst_stride[0] = f->recon_stride[0] = b->stride[0];
+        f->dst_stride[1] = f->recon_stride[1] = b->stride[1];
+        if (b->c444) {
+            f->dst[0] = cur->plane[p]; f->recon[0] = b->recon[p];
+            for (int k = 1; k < 3; k++) f->dst[k] = f->recon[k] = b->scratch_c[k - 1];
+        } else
+            for (int k = 0; k < 3; k++) { f->dst[k] = cur->plane[k]; f->recon[k] = b->recon[k]; }
+        for (int i = 0; i < b->nslots; i++) {
+            DevPic *r = devpic_of(b, h, b->slot_pic[i], 0);
+            if (!r) return -2;                       /* a reference this bridge never decoded (a stream joined mid-way) */
+            if (b->c444) { f->ref[i][0] = r->plane[p]; f->ref[i][1] = b->scratch_c[0]; f->ref[i][2] = b->scratch_c[1]; }
+            else for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k];
+        }
+        f->mb = s->mb[p]; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef[p];
+        f->slices = s->slices[p]; f->nslices = b->nslices;
+        f->max_intra_level = maxl; f->intra_list = s->ilist; f->intra_level_start = s->istart; f->max_level_width = lw;
+        s->desc[np + p] = *f;                        /* the loop filter's view */
+        s->desc[np + p].mb = s->mbd[p];
     }
-    /* device-visible host memory: the kernels read the staging block in place */
-    f->mb = s->mb; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef;
-    f->slices = s->slices; f->nslices = b->nslices;
-    f->max_intra_level = maxl; f->intra_list = s->ilist; f->intra_level_start = s->istart; f->max_level_width = lw;
     s->pic = cur;
     /* the finished picture goes to the frame the decoder hands out (coded size; the reference crops on output) */
     const AVFrame *fr = h->cur_pic_ptr->f;
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
     if (b->direct) {
-        if (mi355_memcpy_h2d_async(s->d_desc, s->desc, sizeof(*s->desc), b->stream)) return -3;
-        if (mi355_h264_decode_frames_levels_dev(s->d_desc, 1, b->mb_w, b->mb_h, maxl, s->widths, b->stream) != 0) return -4;
-        if (mi355_memcpy_d2h_async(s->out, cur->plane[0], b->plane_bytes[0] + 2 * b->plane_bytes[1], b->stream)) return -5;
+        if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
+        if (mi355_h264_recon_inter_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
+            mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
+            mi355_h264_deblock_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->stream) != 0) return -4;
+        if (mi355_memcpy_d2h_async(s->out, cur->plane[0], picture_bytes(b), b->stream)) return -5;
         if (mi355_event_record(s->done, b->stream)) return -5;
     } else {
         pthread_mutex_lock(&disp.mu);

@@ -2,8 +2,8 @@
 library (oracle/_ref/h264_bridge_gpu, built where /root/reference exists and shipped with the tree):
  * realshort.mp4: every picture equals the unmodified reference decoder's (synchronous and lazy completion, 1 and 4
    decoder threads = streams, batched through the dispatcher and direct);
- * cockatoo.mp4 (4:4:4: outside the batched path): the bridge steps aside and the reference's C path produces the
-   same pictures as the plain run."""
+ * cockatoo.mp4 (High 4:4:4 Predictive 720p, P + B pictures, explicit and implicit weighted prediction): all 280 pictures
+   through the device (three plane passes per picture) equal the plain run of the same binary."""
 import json
 import os
 import subprocess
@@ -47,13 +47,26 @@ def test_bridge_decodes_realshort_on_gpu(tmp_path, mi355, lazy, direct, threads)
     check_against_golden(np.fromfile(out, np.uint8), n)
 
 
-def test_bridge_steps_aside_for_444(tmp_path, mi355):
+@pytest.mark.parametrize("mode", ("batched", "lazy", "direct", "threads3"))
+def test_bridge_decodes_444_clip_on_gpu(tmp_path, mi355, mode):
+    """cockatoo.mp4: High 4:4:4 Predictive 1280x720, 280 pictures, CABAC, P pictures with explicit weights and B pictures
+    with implicit weights (weighted_bipred_idc 2), 4 reference frames: every plane goes through the device as its own pass
+    (the plane in the luma role).  Every output picture must equal the plain run of the same binary (MI355_BRIDGE_PLAIN:
+    the reference's own C path)."""
     if not os.path.exists(CLIP444):
         pytest.skip("sample clip not in this image")
-    src, n = samples_file(tmp_path, CLIP444, n=8)
+    n = 280 if mode == "batched" else 60
+    src, n = samples_file(tmp_path, CLIP444, n=n)
     a, b = tmp_path / "a.yuv", tmp_path / "b.yuv"
-    stats, err = _run([src, a, 1, 1])
-    assert stats["bridges_active"] == 0 and stats["pictures_on_device"] == 0 and "outside the batched path" in err
-    # the comparison run: the same binary decoding a second time (the bridge declines again): deterministic output
-    _run([src, b, 1, 1])
-    assert np.array_equal(np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)) and np.fromfile(a, np.uint8).size >= 8 * 1280 * 720 * 3
+    env = {"lazy": {"MI355_BRIDGE_LAZY": "1"}, "direct": {"MI355_BRIDGE_DIRECT": "1"}}.get(mode, {})
+    threads = 3 if mode == "threads3" else 1
+    stats, err = _run([src, a, threads, 1], env)
+    assert stats["bridges_active"] == threads and stats["pictures_on_device"] == n * threads and stats["pictures_output"] == n * threads, (stats, err[-500:])
+    plain, _ = _run([src, b, 1, 1], {"MI355_BRIDGE_PLAIN": "1"})
+    assert plain["pictures_on_device"] == 0 and plain["pictures_output"] == n
+    got, want = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert got.size == want.size == n * 1280 * 720 * 3
+    if not np.array_equal(got, want):
+        fs = 1280 * 720 * 3
+        bad = [i for i in range(n) if not np.array_equal(got[i * fs:(i + 1) * fs], want[i * fs:(i + 1) * fs])]
+        raise AssertionError("pictures differ from the reference decoder's: %s" % bad[:10])
