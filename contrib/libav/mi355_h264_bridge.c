@@ -24,8 +24,9 @@
  *                       HIP stream: it takes what the decoder threads have queued (at most one picture per stream) and
  *                       issues, for the whole batch, one descriptor copy, ONE set of kernel launches
  *                       (mi355_h264_decode_frames_levels_dev over the pictures of all streams) and one launch that
- *                       writes the finished pictures to the streams' pinned buffers (mi355_copy_batch_dev); two batches
- *                       in flight.  Decoder threads make no runtime calls after set-up, and the dispatcher makes a fixed
+ *                       writes the finished pictures to the streams' pinned buffers (mi355_copy_batch_dev); up to four
+ *                       such launch sets in flight, each on its own HIP stream (a small set is a chain of short
+ *                       launches: several chains overlap on the device).  Decoder threads make no runtime calls after set-up, and the dispatcher makes a fixed
  *                       number per batch, so the per-picture cost of launches and runtime locks is shared by the streams
  *                       that are decoding at the same time — the regime the batched kernels are built for.
  *   direct (MI355_BRIDGE_DIRECT=1)  every decoder thread drives its own HIP stream, one picture per launch set.
@@ -81,6 +82,7 @@ typedef struct Submission {     /* a packed picture on its way through the dispa
     struct Bridge *b;
     struct Staging *s;
     int done, rc;
+    unsigned long after;        /* launch set that must finish first (the same decoder's previous picture), 0 = none */
     struct Submission *next;
 } Submission;
 
@@ -128,6 +130,7 @@ typedef struct Bridge {
     const H264Picture *slot_pic[MI355_H264_MAX_SLOTS];
     int nslots;
     unsigned long pictures, waits;
+    unsigned long last_set;     /* launch set (1-based) that holds this decoder's latest picture */
 } Bridge;
 
 static __thread Bridge *br_tls;
@@ -182,35 +185,44 @@ static int staging_alloc(Bridge *b, Staging *s)
 }
 
 /* ---- the dispatcher: one thread, one HIP stream, the pictures of all streams ---------------------------------------- */
+#define DISP_DEPTH 4            /* launch sets in flight, each on its own HIP stream */
 static struct {
     pthread_mutex_t mu;
-    pthread_cond_t work, finished;
-    pthread_t thread;
+    pthread_cond_t work, filled, finished;
+    pthread_t thread, completer;
     int started, broken;
     Submission *head, *tail;
-    void *stream, *ev[2];
-    mi355_h264_frame *h_desc[2], *d_desc[2];
-    mi355_copy_job *jobs[2];    /* device-visible */
-    Submission *in[2][DISP_MAX_BATCH];
-    int nin[2];
+    void *stream[DISP_DEPTH], *ev[DISP_DEPTH];
+    mi355_h264_frame *h_desc[DISP_DEPTH], *d_desc[DISP_DEPTH];
+    mi355_copy_job *jobs[DISP_DEPTH];       /* device-visible */
+    Submission *in[DISP_DEPTH][DISP_MAX_BATCH];
+    int nin[DISP_DEPTH], rcs[DISP_DEPTH];
+    int nbridges, nqueued;                  /* decoders that submit here; pictures waiting in the queue */
+    unsigned long issued, completed;        /* launch sets handed to the device / known complete: set q lives in slot q % DISP_DEPTH */
     int32_t widths[DISP_MAX_LEVELS];
     unsigned long batches, pictures;
-} disp = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+} disp = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
 
-/* one batch: a descriptor copy, the launch set for all its pictures (reconstruction from one descriptor array, loop filter
- * from a second one: they differ for the chroma planes of 4:4:4 pictures), one launch that brings the finished pictures to
- * the streams' pinned buffers; nothing waits here */
+/* one launch set: a descriptor copy, the kernels for all its pictures (reconstruction from one descriptor array, loop
+ * filter from a second one: they differ for the chroma planes of 4:4:4 pictures), one launch that brings the finished
+ * pictures to the streams' pinned buffers; nothing waits here.  The sets of different slots run on different HIP streams:
+ * a small set is a chain of launches that each occupy a few compute units for microseconds, and several such chains
+ * overlap on the device.  A picture whose predecessor of the same decoder is still in flight (MI355_BRIDGE_LAZY) makes
+ * its set wait for that set's event. */
 static int disp_enqueue(int slot)
 {
     const int n = disp.nin[slot];
+    void *st = disp.stream[slot];
     int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0;
     size_t max_bytes = 0;
     for (int i = 0; i < n; i++) nd += disp.in[slot][i]->b->npass;
     mi355_h264_frame *hr = disp.h_desc[slot], *hd = disp.h_desc[slot] + nd;      /* reconstruction | loop filter */
     for (int i = 0, k = 0; i < n; i++) {
-        const Staging *s = disp.in[slot][i]->s;
-        const Bridge *b = disp.in[slot][i]->b;
+        Submission *sub = disp.in[slot][i];
+        const Staging *s = sub->s;
+        const Bridge *b = sub->b;
         const size_t bytes = picture_bytes(b);
+        if (sub->after) rc |= mi355_stream_wait_event(st, disp.ev[(sub->after - 1) % DISP_DEPTH]);
         if (b->mb_w > mw) mw = b->mb_w;
         if (b->mb_h > mh) mh = b->mb_h;
         for (int l = 0; l < s->maxl; l++)
@@ -221,58 +233,77 @@ static int disp_enqueue(int slot)
         if (bytes > max_bytes) max_bytes = bytes;
     }
     mi355_h264_frame *dr = disp.d_desc[slot], *dd = disp.d_desc[slot] + nd;
-    rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), disp.stream);
-    if (!rc && mi355_h264_recon_inter_dev(dr, nd, mw, mh, disp.stream) != 0) rc = -1;
-    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, disp.stream) != 0) rc = -1;
-    if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, disp.stream) != 0) rc = -1;
-    if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, disp.stream) != 0) rc = -1;
-    rc |= mi355_event_record(disp.ev[slot], disp.stream);
+    rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
+    if (!rc && mi355_h264_recon_inter_dev(dr, nd, mw, mh, st) != 0) rc = -1;
+    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, st) != 0) rc = -1;
+    if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, st) != 0) rc = -1;
+    if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, st) != 0) rc = -1;
+    rc |= mi355_event_record(disp.ev[slot], st);
     return rc;
 }
 
+/* takes what the decoder threads have queued into the next free slot and issues it */
 static void *disp_main(void *arg)
 {
     (void)arg;
-    int head_slot = 0, inflight = 0, rcs[2] = { 0, 0 };     /* slots head_slot .. head_slot + inflight - 1 (mod 2) are on the device */
     pthread_mutex_lock(&disp.mu);
     for (;;) {
-        while (!disp.head && !inflight) pthread_cond_wait(&disp.work, &disp.mu);
-        int took = 0;
-        if (disp.head && inflight < 2) {
-            /* what is queued now, at most one picture per stream (a stream's next picture reads this one's output) */
-            const int slot = (head_slot + inflight) & 1;
-            Submission *keep_head = NULL, *keep_tail = NULL, *c = disp.head;
-            int n = 0, nd = 0;
-            while (c) {
-                Submission *nx = c->next;
-                int later = nd + c->b->npass > DISP_MAX_BATCH;
-                for (int i = 0; i < n && !later; i++) later = disp.in[slot][i]->b == c->b;
-                if (later) {
-                    c->next = NULL;
-                    if (keep_tail) keep_tail->next = c; else keep_head = c;
-                    keep_tail = c;
-                } else { disp.in[slot][n++] = c; nd += c->b->npass; }
-                c = nx;
+        /* issue when the device is idle, or when enough pictures wait to make another set worth its launches (a quarter of
+         * the decoders: up to four sets of that size are in flight); a remainder goes out when the sets before it are back */
+        for (;;) {
+            const unsigned long inflight = disp.issued - disp.completed;
+            if (disp.head && (inflight == 0 || (inflight < DISP_DEPTH && 4 * disp.nqueued >= disp.nbridges))) break;
+            pthread_cond_wait(&disp.work, &disp.mu);
+        }
+        /* what is queued now, at most one picture per stream (a stream's next picture reads this one's output) */
+        const int slot = (int)(disp.issued % DISP_DEPTH);
+        Submission *keep_head = NULL, *keep_tail = NULL, *c = disp.head;
+        int n = 0, nd = 0;
+        while (c) {
+            Submission *nx = c->next;
+            int later = nd + c->b->npass > DISP_MAX_BATCH;
+            for (int i = 0; i < n && !later; i++) later = disp.in[slot][i]->b == c->b;
+            if (later) {
+                c->next = NULL;
+                if (keep_tail) keep_tail->next = c; else keep_head = c;
+                keep_tail = c;
+            } else {
+                /* the set that holds this decoder's previous picture, if that has not come back yet */
+                c->after = c->b->last_set > disp.completed ? c->b->last_set : 0;
+                c->b->last_set = disp.issued + 1;
+                disp.in[slot][n++] = c; nd += c->b->npass;
+                disp.nqueued--;
             }
-            disp.head = keep_head; disp.tail = keep_tail;
-            disp.nin[slot] = n;
-            disp.batches++; disp.pictures += (unsigned long)n;
-            pthread_mutex_unlock(&disp.mu);
-            rcs[slot] = disp_enqueue(slot);
-            pthread_mutex_lock(&disp.mu);
-            inflight++;
-            took = 1;
+            c = nx;
         }
-        if (inflight == 2 || (inflight && !took)) {
-            /* the older batch: wait for it, tell its streams */
-            const int slot = head_slot;
-            pthread_mutex_unlock(&disp.mu);
-            const int rc = rcs[slot] | mi355_event_sync(disp.ev[slot]);
-            pthread_mutex_lock(&disp.mu);
-            for (int i = 0; i < disp.nin[slot]; i++) { disp.in[slot][i]->rc = rc; disp.in[slot][i]->done = 1; }
-            pthread_cond_broadcast(&disp.finished);
-            head_slot ^= 1; inflight--;
-        }
+        disp.head = keep_head; disp.tail = keep_tail;
+        disp.nin[slot] = n;
+        disp.batches++; disp.pictures += (unsigned long)n;
+        pthread_mutex_unlock(&disp.mu);
+        const int rc = disp_enqueue(slot);
+        pthread_mutex_lock(&disp.mu);
+        disp.rcs[slot] = rc;
+        disp.issued++;
+        pthread_cond_signal(&disp.filled);
+    }
+    return NULL;
+}
+
+/* waits for the launch sets in the order they were issued and tells their decoder threads */
+static void *disp_complete(void *arg)
+{
+    (void)arg;
+    pthread_mutex_lock(&disp.mu);
+    for (;;) {
+        while (disp.completed == disp.issued) pthread_cond_wait(&disp.filled, &disp.mu);
+        const int slot = (int)(disp.completed % DISP_DEPTH);
+        pthread_mutex_unlock(&disp.mu);
+        const int rc = mi355_event_sync(disp.ev[slot]);
+        pthread_mutex_lock(&disp.mu);
+        for (int i = 0; i < disp.nin[slot]; i++) { disp.in[slot][i]->rc = rc | disp.rcs[slot]; disp.in[slot][i]->done = 1; }
+        disp.completed++;
+        pthread_cond_broadcast(&disp.finished);
+        pthread_cond_signal(&disp.work);
     }
     return NULL;
 }
@@ -281,17 +312,19 @@ static int disp_start(void)
 {
     pthread_mutex_lock(&disp.mu);
     if (!disp.started && !disp.broken) {
-        disp.stream = mi355_stream_create();
-        int ok = disp.stream != NULL;
-        for (int k = 0; k < 2 && ok; k++) {
+        int ok = 1;
+        for (int k = 0; k < DISP_DEPTH && ok; k++) {
+            disp.stream[k] = mi355_stream_create();
             disp.ev[k] = mi355_event_create();
             disp.h_desc[k] = mi355_host_alloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
             disp.d_desc[k] = dalloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
             disp.jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
-            ok = disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k];
+            ok = disp.stream[k] && disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k];
         }
-        if (ok && pthread_create(&disp.thread, NULL, disp_main, NULL) == 0) { pthread_detach(disp.thread); disp.started = 1; }
-        else disp.broken = 1;
+        if (ok && pthread_create(&disp.thread, NULL, disp_main, NULL) == 0 && pthread_create(&disp.completer, NULL, disp_complete, NULL) == 0) {
+            pthread_detach(disp.thread); pthread_detach(disp.completer);
+            disp.started = 1;
+        } else disp.broken = 1;
     }
     const int ok = disp.started;
     pthread_mutex_unlock(&disp.mu);
@@ -328,6 +361,7 @@ static Bridge *bridge_get(const H264Context *h)
     for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[b->c444 ? 0 : p > 0])) != NULL;
     for (int p = 0; p < 2 && ok && b->c444; p++) ok = (b->scratch_c[p] = dalloc(b->plane_bytes[1])) != NULL;
     if (!ok) { br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
+    if (!b->direct) { pthread_mutex_lock(&disp.mu); disp.nbridges++; pthread_mutex_unlock(&disp.mu); }
     b->st[0].sub.b = b->st[1].sub.b = b;
     b->st[0].sub.s = &b->st[0]; b->st[1].sub.s = &b->st[1];
     b->state = 1;
@@ -661,6 +695,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         s->sub.done = 0; s->sub.rc = 0; s->sub.next = NULL;
         if (disp.tail) disp.tail->next = &s->sub; else disp.head = &s->sub;
         disp.tail = &s->sub;
+        disp.nqueued++;
         pthread_cond_signal(&disp.work);
         pthread_mutex_unlock(&disp.mu);
     }
