@@ -379,7 +379,7 @@ static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, 
     }
     if (!create) return NULL;
     for (int i = 0; i < BR_MAX_PICS && !slot; i++)
-        if (b->pics[i].owner < h->DPB || b->pics[i].owner >= h->DPB + H264_MAX_PICTURE_COUNT) slot = &b->pics[i];
+        if ((uintptr_t)b->pics[i].owner < (uintptr_t)h->DPB || (uintptr_t)b->pics[i].owner >= (uintptr_t)(h->DPB + H264_MAX_PICTURE_COUNT)) slot = &b->pics[i];
     if (!slot) return NULL;
     if (!slot->plane[0]) {
         uint8_t *base = dalloc(picture_bytes(b));
