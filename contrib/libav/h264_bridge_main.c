@@ -2,7 +2,9 @@
  * h264_bridge_main.c — a small host around the reference's H.264 decoder + the Tier-2 bridge (mi355_h264_bridge.c):
  * decodes a demuxed elementary stream on N threads (N independent decoder instances = N streams, each with its own
  * bridge state and HIP stream), optionally K times in a row, and reports end-to-end pictures per second.
- *   usage: h264_bridge <in.samples> <out.yuv | -> [threads [loops]]
+ *   usage: h264_bridge <in.samples[,second.samples]> <out.yuv | -> [threads [loops]]
+ *   two inputs: thread t decodes input t % 2 (streams of different sizes and formats meet in the dispatcher's launch
+ *   sets); thread 1 writes its pictures to <out.yuv>.1
  *   in.samples: u32 extradata_len, extradata (avcC), u32 n, then n x {u32 len, bytes}   (tests/golden/mp4_samples.py)
  *   MI355_BRIDGE_PLAIN=1: the bridge steps aside at once (the reference's C path: the comparison run);
  *   MI355_BRIDGE_DIRECT=1: every thread drives its own HIP stream instead of handing pictures to the dispatcher;
@@ -23,8 +25,9 @@ void mi355_h264_bridge_stats(unsigned long *pictures, unsigned long *staging_wai
 void mi355_h264_bridge_drain(void);
 void mi355_h264_bridge_batch_stats(unsigned long *batches, unsigned long *pictures);
 
-static uint8_t *file_data;
-static size_t file_size;
+static uint8_t *file_data[2];
+static size_t file_size[2];
+static int nfiles = 1;
 static int loops = 1;
 static const char *out_path;
 
@@ -39,9 +42,14 @@ static uint32_t rd32(const uint8_t **p) { uint32_t v; memcpy(&v, *p, 4); *p += 4
 static void *decode_thread(void *vp)
 {
     Arg *a = vp;
-    FILE *out = (a->id == 0 && out_path && strcmp(out_path, "-")) ? fopen(out_path, "wb") : NULL;
+    FILE *out = NULL;
+    if (a->id < nfiles && out_path && strcmp(out_path, "-")) {
+        char name[4096];
+        snprintf(name, sizeof(name), a->id ? "%s.%d" : "%s", out_path, a->id);
+        out = fopen(name, "wb");
+    }
     for (int loop = 0; loop < loops; loop++) {
-        const uint8_t *p = file_data;
+        const uint8_t *p = file_data[a->id % nfiles];
         AVCodecContext *c = avcodec_alloc_context3(&ff_h264_decoder);
         const uint32_t el = rd32(&p);
         c->extradata = av_mallocz(el + AV_INPUT_BUFFER_PADDING_SIZE);
@@ -95,12 +103,16 @@ int main(int argc, char **argv)
     const int nthreads = argc > 3 ? atoi(argv[3]) : 1;
     loops = argc > 4 ? atoi(argv[4]) : 1;
     out_path = argv[2];
-    FILE *in = fopen(argv[1], "rb");
-    if (!in) return 1;
-    fseek(in, 0, SEEK_END); file_size = (size_t)ftell(in); fseek(in, 0, SEEK_SET);
-    file_data = malloc(file_size);
-    if (fread(file_data, 1, file_size, in) != file_size) return 4;
-    fclose(in);
+    char *names = strdup(argv[1]), *second = strchr(names, ',');
+    if (second) { *second++ = 0; nfiles = 2; }
+    for (int k = 0; k < nfiles; k++) {
+        FILE *in = fopen(k ? second : names, "rb");
+        if (!in) return 1;
+        fseek(in, 0, SEEK_END); file_size[k] = (size_t)ftell(in); fseek(in, 0, SEEK_SET);
+        file_data[k] = malloc(file_size[k]);
+        if (fread(file_data[k], 1, file_size[k], in) != file_size[k]) return 4;
+        fclose(in);
+    }
     pthread_t *th = calloc((size_t)nthreads, sizeof(*th));
     Arg *args = calloc((size_t)nthreads, sizeof(*args));
     struct timespec t0, t1;

@@ -635,6 +635,15 @@ constexpr int DY_PITCH = 16 * DCH + MI355_DPAD;   /* + 8: the sixteen rows of a 
 constexpr int DC_PITCH = 8 * DCH + MI355_DPAD;
 constexpr int DIO_ROWS = 16 / DCH;                /* rows one 16-lane chunk access covers */
 constexpr int DCH_ISSUE = DCH >= 4 ? 1 : DCH - 1;  /* position in a chunk at which the next chunk's loads are issued */
+/* Small-batch form (k_deblock_bands): waves per workgroup, and by how many steps the wave of band b trails the wave of band
+ * b - 1.  Band b's group 0 requests the rows above its chunk c (macroblocks 4c .. 4c + 3) at its step 4(c - 1) + DCH_ISSUE;
+ * the wave above has them final and written once its group 3 (macroblock x at step x + 6) has filtered macroblock 4c + 4
+ * — whose left edge still changes columns 13..15 of macroblock 4c + 3 — and flushed that chunk (c + 2 of that group, at step
+ * 4(c + 2) + 5 = 4c + 13); the barrier at the end of that step publishes the stores.  So the wave above must be at least
+ * (4c + 14) - (4c - 4 + DCH_ISSUE) = 18 - DCH_ISSUE steps ahead.  The tiles of KW bands share the CU's 160 KB of LDS with
+ * the other workgroups on it: 8 / KW workgroups (pictures) per CU. */
+constexpr int DEBLOCK_LAG = 20;
+static_assert(DCH == 4 && DEBLOCK_LAG >= 18 - DCH_ISSUE, "lag of the small-batch deblocking form");
 struct DeblockLds {
     uint8_t y[4][2][20][DY_PITCH];      /* [group][chunk parity]: rows -4..15 of DCH macroblocks */
     uint8_t c[4][2][2][10][DC_PITCH];   /* [group][chunk parity][plane]: rows -2..7 */
@@ -824,8 +833,13 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
     w[0] = v.x; w[1] = v.y;
 }
 
-template <bool TWO_LISTS>     /* list-1 vectors exist (B pictures): a compile-time switch, so that a P picture carries no list-1 state at all */
-__device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_frame &fr, int band)
+/* KW: waves per workgroup.  1 = a workgroup is one wave and one band (the throughput form: one launch per band, thousands of
+ * pictures per launch).  KW > 1 = the small-batch form: KW waves of a workgroup walk KW consecutive bands of one picture
+ * in the same launch, wave w starting DEBLOCK_LAG steps after wave w - 1, all waves meeting at a workgroup barrier after
+ * every step: a band reads the rows above it (written by the wave above) only after that wave has written them and the
+ * barrier's fence has made them visible — see DEBLOCK_LAG. */
+template <bool TWO_LISTS, int KW>     /* TWO_LISTS: list-1 vectors exist (B pictures): a compile-time switch, so that a P picture carries no list-1 state at all */
+__device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_frame &fr, int band, int wave)
 {
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
     const int mb_y = 4 * band + g, W = fr.mb_width;
@@ -903,7 +917,10 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
      * sequence and a zero fill per access and makes the compiler's wait counts inexact. */
     const int mb_yc = row_ok ? mb_y : fr.mb_height - 1;
     const uint8_t *const recon_yc = mi355_global(fr.recon[0]) + (ptrdiff_t)mb_yc * 16 * rs;
-    const int top_y0 = 4 * band > 0 ? 4 * band * 16 - 4 : 0, top_c0 = 4 * band > 0 ? 4 * band * 8 - 2 : 0;   /* first row above the band (row 0 when there is none) */
+    /* first row above the band (row 0 when there is none).  A band below the picture (a smaller picture in a batch of mixed
+     * sizes, or the tail of a multi-band workgroup) reads where the picture's last band would: in bounds, never used */
+    const int band_c = imin(band, (fr.mb_height - 1) >> 2);
+    const int top_y0 = band_c > 0 ? 4 * band_c * 16 - 4 : 0, top_c0 = band_c > 0 ? 4 * band_c * 8 - 2 : 0;
     const uint8_t *const dst_y0 = mi355_global(fr.dst[0]);
     auto issue_chunk = [&](int c) {
         const int xr = DCH * c - 2 * g + io_p, x = xr < 0 ? 0 : (xr < W ? xr : W - 1);
@@ -961,12 +978,15 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
 #ifdef MI355_PROF
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
 #endif
-    issue_chunk(0);
-    Pre pre;
-    prefetch(pre, -2 * g);
-    MbInfo hl = pre.h;                                       /* the left neighbour's fields: last step's macroblock */
+    Pre pre = {};
+    MbInfo hl = {};                                          /* the left neighbour's fields: last step's macroblock */
     int flushed = 0;                                         /* chunks already written back */
-    for (int t = 0; t < nsteps; t++) {
+    auto start = [&]() __attribute__((always_inline)) {
+        issue_chunk(0);
+        prefetch(pre, -2 * g);
+        hl = pre.h;
+    };
+    auto step = [&](int t) __attribute__((always_inline)) {
         const int mb_x = t - 2 * g;
         const int ck = t >> DCH_LOG, j = t & (DCH - 1), b = ck & 1;   /* chunk, position in it, tile parity */
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
@@ -1115,9 +1135,29 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
         MI355_WAVE_SYNC();   /* the tile is final for this macroblock: the group below and the next step may read it */
         hl = h;
 #endif
-    }
+    };
     /* chunks still in LDS */
-    for (int c = flushed; c <= (nsteps - 1) >> DCH_LOG; c++) flush_chunk(c);
+    auto finish = [&]() __attribute__((always_inline)) {
+        for (int c = flushed; c <= (nsteps - 1) >> DCH_LOG; c++) flush_chunk(c);
+    };
+    if constexpr (KW == 1) {
+        (void)wave;
+        start();
+        for (int t = 0; t < nsteps; t++) step(t);
+        finish();
+    } else {
+        /* every wave runs the same number of global steps and meets the others at the barrier after each one (a wave
+         * whose band lies below the picture only attends).  __syncthreads() = workgroup-scope release + acquire: the
+         * stores a wave issued in this step (flush_chunk) are visible to the waves of this workgroup after it. */
+        const int t0 = DEBLOCK_LAG * wave, t_end = nsteps + DEBLOCK_LAG * (KW - 1);
+        for (int tt = 0; tt < t_end; tt++) {
+            const int t = tt - t0;
+            if (t == 0) start();
+            if (t >= 0 && t < nsteps) step(t);
+            if (t == nsteps - 1) finish();
+            __syncthreads();
+        }
+    }
 #ifdef MI355_PROF
     PROF_MARK(7);
     if (blockIdx.x < 64 && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_prof[i], prof_acc[i]);
@@ -1132,8 +1172,20 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 {
     __shared__ DeblockLds s;
     const mi355_h264_frame &fr = frames[blockIdx.x];
-    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true>(s, fr, band);
-    else deblock_band<false>(s, fr, band);
+    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, 1>(s, fr, band, 0);
+    else deblock_band<false, 1>(s, fr, band, 0);
+}
+
+/* the small-batch form: KW consecutive bands of a picture per workgroup, one wave each (see deblock_band) */
+template <int KW>
+__global__ void __launch_bounds__(64 * KW)
+k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0)
+{
+    __shared__ DeblockLds s[KW];
+    const mi355_h264_frame &fr = frames[blockIdx.x];
+    const int wave = (int)(threadIdx.x >> 6);
+    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, KW>(s[wave], fr, band0 + wave, wave);
+    else deblock_band<false, KW>(s[wave], fr, band0 + wave, wave);
 }
 
 }  // namespace
@@ -1202,9 +1254,42 @@ extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nfra
 {
     if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     (void)max_mb_width;
-    /* bands of four MB rows, top to bottom: band b reads the rows band b-1 finished */
-    for (int band = 0; band * 4 < max_mb_height; band++)
-        hipLaunchKernelGGL(k_deblock, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, d_frames, band);
+    /* bands of four MB rows, top to bottom: band b reads the rows band b-1 finished.  Many pictures: one launch per band, a
+     * wave per picture and band (the launches are full).  Few pictures of some width: the launches would each be a handful
+     * of lone waves walking the whole picture width one after the other — 2 to 6 bands per launch instead, pipelined
+     * inside a workgroup (k_deblock_bands); the form with the fewest sequential steps is chosen. */
+    const int nbands = (max_mb_height + 3) / 4, nsteps = max_mb_width + 6;
+    static const int force = std::getenv("MI355_DEBLOCK_FORM") ? std::atoi(std::getenv("MI355_DEBLOCK_FORM")) : 0;   /* developer override: waves per workgroup */
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    /* sequential steps a form needs: launches x (steps of one walk), times the rounds it takes to get all pictures through the
+     * CUs (8 band tiles fit a CU); a step of the multi-band form is dearer by its barrier (measured: 2.9 against 2.3 us) */
+    int best = 1;
+    double best_cost = 0;
+    const int forms[5] = { 1, 2, 3, 4, 6 };
+    for (int i = 0; i < 5; i++) {
+        const int kw = forms[i];
+        const long resident = (long)cus * (8 / kw);
+        const double rounds = (double)((nframes + resident - 1) / resident);
+        const double cost = rounds * ((nbands + kw - 1) / kw) * (nsteps + DEBLOCK_LAG * (kw - 1)) * (kw > 1 ? 1.25 : 1.0);
+        if (i == 0 || cost < best_cost) { best = kw; best_cost = cost; }
+    }
+    if (force == 1 || force == 2 || force == 3 || force == 4 || force == 6) best = force;
+    hipStream_t st = (hipStream_t)stream;
+    for (int band = 0; band < nbands; band += best) {
+        const dim3 grid((unsigned)nframes);
+        switch (best) {
+        case 2: hipLaunchKernelGGL(k_deblock_bands<2>, grid, dim3(128), 0, st, d_frames, band); break;
+        case 3: hipLaunchKernelGGL(k_deblock_bands<3>, grid, dim3(192), 0, st, d_frames, band); break;
+        case 4: hipLaunchKernelGGL(k_deblock_bands<4>, grid, dim3(256), 0, st, d_frames, band); break;
+        case 6: hipLaunchKernelGGL(k_deblock_bands<6>, grid, dim3(384), 0, st, d_frames, band); break;
+        default: hipLaunchKernelGGL(k_deblock, grid, dim3(64), 0, st, d_frames, band); break;
+        }
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

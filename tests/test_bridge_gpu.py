@@ -70,3 +70,22 @@ def test_bridge_decodes_444_clip_on_gpu(tmp_path, mi355, mode):
         fs = 1280 * 720 * 3
         bad = [i for i in range(n) if not np.array_equal(got[i * fs:(i + 1) * fs], want[i * fs:(i + 1) * fs])]
         raise AssertionError("pictures differ from the reference decoder's: %s" % bad[:10])
+
+
+def test_bridge_mixed_streams_on_gpu(tmp_path, mi355):
+    """two streams of different size and chroma format (320x240 4:2:0 and 1280x720 4:4:4) decoded at the same time by four
+    threads: their pictures meet in the dispatcher's launch sets (mixed geometry in one batch); both outputs must equal
+    the plain runs"""
+    if not (os.path.exists(CLIP) and os.path.exists(CLIP444)):
+        pytest.skip("sample clips not in this image")
+    d1, d2 = tmp_path / "x", tmp_path / "y"
+    d1.mkdir(); d2.mkdir()
+    s1, n1 = samples_file(d1, CLIP)
+    s2, n2 = samples_file(d2, CLIP444, n=36)
+    out = tmp_path / "o.yuv"
+    stats, err = _run(["%s,%s" % (s1, s2), out, 4, 2])
+    assert stats["bridges_active"] == 4 and stats["pictures_on_device"] == 2 * 2 * (n1 + n2), (stats, err[-500:])
+    check_against_golden(np.fromfile(out, np.uint8), n1)
+    ref = tmp_path / "r.yuv"
+    _run([s2, ref, 1, 1], {"MI355_BRIDGE_PLAIN": "1"})
+    assert np.array_equal(np.fromfile(str(out) + ".1", np.uint8), np.fromfile(ref, np.uint8))

@@ -90,6 +90,7 @@ struct hipDeviceProp_t {
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     std::memset(p, 0, sizeof(*p));
     std::strcpy(p->name, "simt-emu");
