@@ -51,3 +51,48 @@ def run_case(backend, oracle, name, pad=0, per_level=True):
 
 def smoke(gpu, oracle):
     assert run_case(gpu, oracle, "mixed_intra") > 0
+
+
+def run_mixed_batch(backend, oracle, names=("mixed_intra", "wide_b", "one_col", "tall_all_intra")):
+    """pictures of DIFFERENT geometry in ONE call (what the bridge's dispatcher produces when streams of different size
+    decode at the same time): the descriptors of several cases are concatenated on the device and go through
+    mi355_h264_decode_frames_levels_dev with the largest width / height and the per-level maxima; every picture must
+    come out as in its own single-geometry run (= the oracle's)."""
+    import ctypes as C
+    sets = [HF.synth_frames(**CASES[n]) for n in names]
+    devs = [HF.DeviceFrames(backend, fs) for fs in sets]
+    lib = backend.lib
+    try:
+        fsz = C.sizeof(devs[0].host_desc) // devs[0].F
+        total = sum(d.F for d in devs)
+        lib.mi355_malloc.restype = C.c_void_p
+        lib.mi355_malloc.argtypes = [C.c_size_t]
+        d_all = lib.mi355_malloc(total * fsz)
+        assert d_all
+        off = 0
+        for d in devs:
+            assert lib.mi355_memcpy_h2d(C.c_void_p(d_all + off), C.c_void_p(C.addressof(d.host_desc)), C.c_size_t(d.F * fsz)) == 0
+            off += d.F * fsz
+        mw, mh = max(fs.mb_w for fs in sets), max(fs.mb_h for fs in sets)
+        ml = max(fs.max_intra_level for fs in sets)
+        widths = [0] * max(1, ml)
+        for fs in sets:
+            for i, w in enumerate(fs.level_widths[:fs.max_intra_level]):
+                widths[i] = max(widths[i], w)
+        lw = (C.c_int32 * len(widths))(*widths)
+        fn = lib.mi355_h264_decode_frames_levels_dev
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        assert fn(d_all, total, mw, mh, ml, lw, None) == 0
+        assert lib.mi355_sync(None) == 0
+        for name, fs, d in zip(names, sets, devs):
+            recon_o, dst_o = HF.run_oracle(oracle, fs)
+            recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+            for p in range(3):
+                assert np.array_equal(recon_o[p], recon_g[p]), "%s: reconstruction differs in plane %d" % (name, p)
+                assert np.array_equal(dst_o[p], dst_g[p]), "%s: deblocked picture differs in plane %d" % (name, p)
+        lib.mi355_free(C.c_void_p(d_all))
+    finally:
+        for d in devs:
+            d.free()
+    return total

@@ -68,3 +68,7 @@ def test_intra_schedule_helper_above_255_levels(emu):
     lv = level.reshape(90, 160)
     assert (lv[:, 1:] > lv[:, :-1]).all() and (lv[1:, :] > lv[:-1, :]).all() and (lv[1:, :-1] > lv[:-1, 1:]).all()
     assert fs.mb[0]["intra_level"].max() == 255                      # informational field saturates
+
+
+def test_mixed_geometry_batch_emulated(emu, oracle):
+    assert frame_cases.run_mixed_batch(emu, oracle) >= 4

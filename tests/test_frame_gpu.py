@@ -70,3 +70,8 @@ def test_all_intra_picture_above_1080p(mi355, oracle):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
+
+
+def test_mixed_geometry_batch_gpu(mi355, oracle):
+    """pictures of different size in one call (largest geometry and per-level maxima passed): each comes out as the oracle's"""
+    assert frame_cases.run_mixed_batch(mi355, oracle) >= 4
