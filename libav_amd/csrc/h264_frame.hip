@@ -440,6 +440,7 @@ struct IntraLds {
     __attribute__((aligned(16))) uint8_t tile[17 * TP];
     __attribute__((aligned(16))) uint8_t ctile[2][9 * CP];
     PredScratch ps;
+    int dc_t[16];                      /* Intra16x16: the luma DC levels between the two butterfly passes */
 };
 #define TILE(x, y) s.tile[((y) + 1) * TP + (x) + TO]
 #define CTILE(p, x, y) s.ctile[p][((y) + 1) * CP + (x) + TO]
@@ -505,11 +506,24 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
         __syncthreads();
         intra_pred_wave(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &TILE(0, 0), TP);
         if ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1) {
-            if (lane == 0) {
-                int in[16], out[16];
-                for (int k2 = 0; k2 < 16; k2++) in[k2] = s.mb.coef[luma_dc_slot(k2)];
-                luma_dc_dequant(in, (int)h.dc_qmul[0], out);
-                for (int k2 = 0; k2 < 16; k2++) s.mb.coef[luma_dc_slot(k2)] = (int16_t)out[k2];
+            /* ff_h264_luma_dc_dequant_idct (h264idct_template.c:242-271) on sixteen lanes: lane 4a + b holds level b of
+             * row a; the row butterflies run inside the quads (DPP), the column butterflies after a turn through LDS, and
+             * lane 4i + j produces output j of column i — the arithmetic of luma_dc_dequant() (h264_dev.h), which one lane
+             * alone needs ~140 instructions for */
+            const int b4 = lane & 3;
+            const int v = s.mb.coef[luma_dc_slot(lane & 15)];
+            const int x1 = quad_xor1(v);
+            const int w = (b4 & 1) ? x1 - v : v + x1;               /* b: 0 s, 1 d, 2 u, 3 e of the row */
+            const int y = quad_xor2(w);
+            const int tv = b4 == 2 ? y - w : (b4 == 1 ? w - y : w + y);   /* s + u, d - e, s - u, d + e */
+            if (lane < 16) s.dc_t[(lane & ~3) | (b4 == 1 ? 2 : (b4 == 2 ? 1 : b4))] = tv;
+            MI355_WAVE_SYNC();
+            if (lane < 16) {
+                const int ci = lane >> 2;
+                const int t0 = s.dc_t[ci], t1 = s.dc_t[4 + ci], t2 = s.dc_t[8 + ci], t3 = s.dc_t[12 + ci];
+                const int ss = t0 + t2, dd = t0 - t2, ee = t1 - t3, uu = t1 + t3;
+                const int r = b4 == 0 ? ss + uu : (b4 == 1 ? dd + ee : (b4 == 2 ? dd - ee : ss - uu));
+                s.mb.coef[luma_dc_slot(lane)] = (int16_t)((r * (int)h.dc_qmul[0] + 128) >> 8);
             }
             __syncthreads();
         }
