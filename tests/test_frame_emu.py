@@ -72,3 +72,8 @@ def test_intra_schedule_helper_above_255_levels(emu):
 
 def test_mixed_geometry_batch_emulated(emu, oracle):
     assert frame_cases.run_mixed_batch(emu, oracle) >= 4
+
+
+def test_copy_batch_emulated(emu):
+    import copy_batch_cases
+    assert copy_batch_cases.run(emu.lib) == 6

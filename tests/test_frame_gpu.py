@@ -75,3 +75,8 @@ def test_all_intra_picture_above_1080p(mi355, oracle):
 def test_mixed_geometry_batch_gpu(mi355, oracle):
     """pictures of different size in one call (largest geometry and per-level maxima passed): each comes out as the oracle's"""
     assert frame_cases.run_mixed_batch(mi355, oracle) >= 4
+
+
+def test_copy_batch_gpu(mi355):
+    import copy_batch_cases
+    assert copy_batch_cases.run(mi355.lib) == 6
