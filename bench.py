@@ -238,8 +238,8 @@ def extra_points(lib, prov, mbw, mbh):
                     "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "note": note})
 
     base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
-    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (the band launches of k_deblock hold 64 waves)")
-    run("config2_f512", base, 512, "512 pictures per step")
+    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (loop filter in its small-batch form: several bands of a picture per workgroup, k_deblock_bands)")
+    run("config2_f512", base, 512, "512 pictures per step (small-batch loop filter form)")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
     run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra" % intra.max_intra_level)
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
