@@ -234,7 +234,7 @@ static int disp_enqueue(int slot)
     }
     mi355_h264_frame *dr = disp.d_desc[slot], *dd = disp.d_desc[slot] + nd;
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
-    if (!rc && mi355_h264_recon_inter_dev(dr, nd, mw, mh, st) != 0) rc = -1;
+    if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, st) != 0) rc = -1;
     if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, st) != 0) rc = -1;
@@ -685,7 +685,7 @@ static int submit_picture(Bridge *b, H264Context *h)
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
     if (b->direct) {
         if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
-        if (mi355_h264_recon_inter_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
+        if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
             mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
             mi355_h264_deblock_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->stream) != 0) return -4;
         if (mi355_memcpy_d2h_async(s->out, cur->plane[0], picture_bytes(b), b->stream)) return -5;

@@ -204,6 +204,10 @@ int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nf
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
 int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
+/* The same pass for descriptors whose `coef` arrays live in device-visible host memory (mi355_host_alloc): an inter
+ * macroblock fetches its coefficient block only when its record's cbp says it has coefficients (a second, dependent round
+ * of loads for those; none for the others) — over PCIe the skipped blocks are what counts.  Same results. */
+int mi355_h264_recon_inter_sparse_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream);
 int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 

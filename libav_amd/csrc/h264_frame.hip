@@ -395,10 +395,14 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
  * partial waits) was 25-30 % SLOWER although it hid both memory round trips — the kernel is bound by the request rate
  * of the reference fetch (removing the window loads alone: -30 % time at -8 % VALU), which a deeper pipeline does not
  * lower, and the loop cost 50 more VALU per macroblock. */
-__global__ void __launch_bounds__(64)
-k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+/* SPARSE: the coefficient array lives in device-visible HOST memory (a bridge's staging block read in place): a macroblock
+ * fetches its 768 bytes only when its record says it has coefficients (cbp), at the price of a second, dependent round of
+ * loads for those that do — in P / B pictures of real streams most macroblocks carry none, and the link is the narrow
+ * place there.  With everything in HBM (the dense form) all five loads of a macroblock go out together. */
+template <bool SPARSE>
+__device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
+                                                 unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
-    __shared__ MbLds s;
     RPROF_START();
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
@@ -409,9 +413,17 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     RPROF(0);
-    load_mb(s, fr, mb_xy, true);
+    load_mb(s, fr, mb_xy, !SPARSE);
     RPROF(1);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
+    if (SPARSE && (uniform((int)s.hdr.cbp) & 0x3F)) {
+        const int lane = lane_id();
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+        const uint32_t c0 = cp[lane], c1 = cp[lane + 64], c2 = cp[lane + 128];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
+        dst[lane] = c0; dst[lane + 64] = c1; dst[lane + 128] = c2;
+        MI355_WAVE_SYNC();
+    }
     const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
     hl_motion(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
     RPROF(5);
@@ -427,6 +439,18 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
     RPROF(6);
     store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr, mb_x, mb_y);
     RPROF(7);
+}
+__global__ void __launch_bounds__(64)
+k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+{
+    __shared__ MbLds s;
+    recon_inter_wave<false>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
+}
+__global__ void __launch_bounds__(64)
+k_recon_inter_sparse(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+{
+    __shared__ MbLds s;
+    recon_inter_wave<true>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1207,7 +1231,7 @@ k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0)
 /* ------------------------------------------------------------------------- */
 /* host entry points                                                            */
 /* ------------------------------------------------------------------------- */
-extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
+static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, bool sparse, void *stream)
 {
     if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     /* div_magic is exact below 2^24 work items: larger batches go out as several launches */
@@ -1218,11 +1242,23 @@ extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int 
     for (int f0 = 0; f0 < nframes; f0 += frames_per_launch) {
         const int nf = nframes - f0 < frames_per_launch ? nframes - f0 : frames_per_launch;
         const int nblocks = nf * per_frame, per_xcd = (nblocks + 7) / 8;
-        hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
-                           d_frames + f0, max_mb_width, max_mb_height, (one + max_mb_width - 1) / max_mb_width,
-                           (one + max_mb_height - 1) / max_mb_height, nblocks, per_xcd);
+        const unsigned long long iw = (one + max_mb_width - 1) / max_mb_width, ih = (one + max_mb_height - 1) / max_mb_height;
+        if (sparse)
+            hipLaunchKernelGGL(k_recon_inter_sparse, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
+                               d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
+        else
+            hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
+                               d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
+{
+    return recon_inter_launch(d_frames, nframes, max_mb_width, max_mb_height, false, stream);
+}
+extern "C" int mi355_h264_recon_inter_sparse_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
+{
+    return recon_inter_launch(d_frames, nframes, max_mb_width, max_mb_height, true, stream);
 }
 
 extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream)

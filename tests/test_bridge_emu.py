@@ -63,7 +63,7 @@ def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, t
     if direct:
         assert stats["launch_sets"] == 0
     else:
-        assert stats["launch_sets"] >= n and stats["launch_sets"] * stats["pictures_per_launch_set"] == pytest.approx(n * threads)
+        assert stats["launch_sets"] >= n and stats["launch_sets"] * stats["pictures_per_launch_set"] == pytest.approx(n * threads, rel=0.01)   # the harness prints two decimals
         if threads > 1:
             assert stats["launch_sets"] < n * threads                   # some launch sets held more than one stream's picture
     check_against_golden(np.fromfile(out, np.uint8), n)
