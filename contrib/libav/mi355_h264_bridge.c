@@ -502,7 +502,7 @@ static void pack_planes_444(const H264Context *h, H264SliceContext *sl, Staging 
         m->nnz_mask = 0;
         m->qp = (int8_t)h->ps.pps->chroma_qp_table[p - 1][m0->qp & 0xff];
         m->dc_qmul[0] = h->ps.pps->dequant4_coeff[p][sl->chroma_qp[p - 1]][0];
-        memset(cf, 0, 768);
+        if (IS_INTRA(mb_type) || luma_coded) memset(cf, 0, 768);
         if (IS_INTRA_PCM(mb_type)) {
             memcpy(cf, sl->intra_pcm_ptr + 256 * p, 256);
             m->nnz_mask = 0xFFFFFF;
@@ -566,7 +566,10 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     memset(m->ref_idx, -1, sizeof(m->ref_idx));
 
     int16_t *cf = st->coef[0] + (size_t)idx * 384;
-    memset(cf, 0, 768);
+    /* an inter macroblock without coefficients (cbp 0) never has its block fetched (mi355_h264_recon_inter_sparse_dev):
+     * no need to clear it either */
+    const int reads_coefs = intra || (cbp & 0x3F);
+    if (reads_coefs) memset(cf, 0, 768);
     if (IS_INTRA_PCM(mb_type)) {
         memcpy(cf, sl->intra_pcm_ptr, 384);
         m->nnz_mask = 0xFFFFFF;
