@@ -34,12 +34,23 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name, pad=0, per_level=True):
+def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False):
     fs = HF.synth_frames(**CASES[name])
+    if sparse:
+        # real P / B pictures: many inter macroblocks carry no residual at all (cbp 0) — about every other one here
+        inter = (fs.mb["mb_type"] & 7) == 0
+        pick = inter & (np.random.default_rng(len(name)).random(inter.shape) < 0.5)
+        fs.mb["cbp"][pick] = 0
+        fs.mb["nnz_mask"][pick] = 0
+        fs.coef[pick] = 0
+        assert pick.any() or not inter.any()
     recon_o, dst_o = HF.run_oracle(oracle, fs)
     d = HF.DeviceFrames(backend, fs, pad=pad)
     try:
-        d.decode(per_level=per_level)
+        if sparse:
+            d.decode_sparse()
+        else:
+            d.decode(per_level=per_level)
         recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
     finally:
         d.free()

@@ -559,6 +559,27 @@ class DeviceFrames:
         self.lib.mi355_sync.restype = C.c_int
         assert self.lib.mi355_sync(stream) == 0
 
+    def decode_sparse(self, poison=True):
+        """the three passes with mi355_h264_recon_inter_sparse_dev: inter macroblocks whose cbp is zero do not fetch their
+        coefficient block — shown by overwriting those blocks on the device with 0x7F7F first"""
+        fs, lib = self.fs, self.lib
+        G = fs.F
+        if poison:
+            coef = fs.coef.copy()
+            inter_empty = ((fs.mb["mb_type"] & 7) == 0) & ((fs.mb["cbp"] & 0x3F) == 0)     # not Intra4x4 / 16x16 / PCM
+            coef[inter_empty] = 0x7F7F
+            nmb = fs.mb_w * fs.mb_h
+            for f in range(self.F):
+                self.h2d(self.coef + f * nmb * 768, coef[f % G])
+        lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+        for name, args in (("mi355_h264_recon_inter_sparse_dev", (fs.mb_w, fs.mb_h)), ("mi355_h264_recon_intra_levels_dev", (fs.max_intra_level, lw)),
+                           ("mi355_h264_deblock_dev", (fs.mb_w, fs.mb_h))):
+            fn = getattr(lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_int] + [C.c_int if isinstance(a, int) else C.c_void_p for a in args] + [C.c_void_p]
+            assert fn(self.d_desc, self.F, *args, None) == 0, name
+        assert lib.mi355_sync(None) == 0
+
     def free(self):
         for p in self.bufs:
             self.lib.mi355_free(p)

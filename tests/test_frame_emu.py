@@ -77,3 +77,9 @@ def test_mixed_geometry_batch_emulated(emu, oracle):
 def test_copy_batch_emulated(emu):
     import copy_batch_cases
     assert copy_batch_cases.run(emu.lib) == 6
+
+
+@pytest.mark.parametrize("name", ("p16_smooth", "mixed_intra", "wide_b", "b_weight_implicit"))
+def test_frame_pipeline_emulated_sparse_coefficients(emu, oracle, name):
+    """mi355_h264_recon_inter_sparse_dev: same pictures, and the coefficient blocks of cbp-0 inter macroblocks are never read"""
+    frame_cases.run_case(emu, oracle, name, sparse=True)

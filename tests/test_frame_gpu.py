@@ -80,3 +80,9 @@ def test_mixed_geometry_batch_gpu(mi355, oracle):
 def test_copy_batch_gpu(mi355):
     import copy_batch_cases
     assert copy_batch_cases.run(mi355.lib) == 6
+
+
+@pytest.mark.parametrize("name", list(frame_cases.CASES))
+def test_frame_pipeline_gpu_sparse_coefficients(mi355, oracle, name):
+    """mi355_h264_recon_inter_sparse_dev: same pictures, and the coefficient blocks of cbp-0 inter macroblocks are never read"""
+    frame_cases.run_case(mi355, oracle, name, sparse=True)
