@@ -31,6 +31,8 @@ struct SwsDev {
     const int32_t *hLumP, *hChrP, *vLumP, *vChrP;
     int th;                                 /* output rows per tile chosen at create time */
     int hstage;                             /* horizontal filter positions never decrease: source spans can be staged in LDS */
+    int hident_l, hident_c;                 /* the horizontal filter of the plane is the identity (one tap of 1 << 14 at position i: an unscaled
+                                             * conversion through the generic path): hScale8To15 is then src << 7 */
     mi355_sws_luts luts;
 };
 
@@ -151,8 +153,34 @@ __device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0,
 template <int COLS>
 __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t *src, int stride, int srcW, const int32_t *posT,
                                             const int16_t *coefT, int fs, int gx0, int ncols, int lo, int hi,
-                                            uint32_t (*stage)[SRC_DW], int tid, bool zero_tail, bool may_stage)
+                                            uint32_t (*stage)[SRC_DW], int tid, bool zero_tail, bool may_stage, bool identity)
 {
+    if (identity) {
+        /* one tap of 1 << 14 at position i: (src * 16384) >> 7 = src << 7 (below the 32767 clamp).  Eight columns per thread:
+         * one 8-byte load (aligned planes, inside the line), one 16-byte LDS write */
+        constexpr int TPL = COLS / 8;                  /* threads per line */
+        const int xg = 8 * (tid % TPL), gxi = gx0 + xg;
+        const bool al8 = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | (uintptr_t)gx0) & 7) == 0;
+        for (int l = lo + tid / TPL; l <= hi; l += NT / TPL) {
+            const uint8_t *p = src + (size_t)l * stride + gxi;
+            uint32_t b0 = 0, b1 = 0;
+            if (al8 && gxi + 8 <= srcW && gxi + 8 <= ncols) { const sws_u32x2 w = *reinterpret_cast<const sws_u32x2 *>(p); b0 = w[0]; b1 = w[1]; }
+            else {
+                for (int k = 0; k < 4; k++) {
+                    if (gxi + k < ncols && gxi + k < srcW) b0 |= (uint32_t)p[k] << (8 * k);
+                    if (gxi + 4 + k < ncols && gxi + 4 + k < srcW) b1 |= (uint32_t)p[4 + k] << (8 * k);
+                }
+            }
+            /* bytes -> int16 << 7, two per dword */
+            sws_u32x4 o;
+            o[0] = ((b0 & 0xFFu) << 7) | ((b0 & 0xFF00u) << 15);
+            o[1] = ((b0 >> 9) & 0x7F80u) | ((b0 >> 1) & 0x7F800000u);
+            o[2] = ((b1 & 0xFFu) << 7) | ((b1 & 0xFF00u) << 15);
+            o[3] = ((b1 >> 9) & 0x7F80u) | ((b1 >> 1) & 0x7F800000u);
+            if (zero_tail || gxi < ncols) *reinterpret_cast<sws_u32x4 *>(&out[l - lo][xg]) = o;
+        }
+        return;
+    }
     const int x = tid & (COLS - 1), gx = gx0 + x, per = NT / COLS;
     const bool col_ok = gx < ncols;
     const int pos = col_ok ? posT[gx] : 0;
@@ -380,9 +408,9 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     static_assert(sizeof(uint32_t) * SG * SRC_DW <= sizeof(s_out), "staging lines must fit into the output tile");
     uint32_t (*s_stage)[SRC_DW] = reinterpret_cast<uint32_t (*)[SRC_DW]>(&s_out[0][0]);
 #ifndef MI355_SWS_NO_H
-    hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0);
-    hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
-    hscale_tile<TW / 2>(s_cv, fr.src[2], fr.src_stride[2], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0);
+    hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0, c.hident_l != 0);
+    hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0, c.hident_c != 0);
+    hscale_tile<TW / 2>(s_cv, fr.src[2], fr.src_stride[2], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0, c.hident_c != 0);
 #endif
     __syncthreads();
     /* vertical pass + LUT */
@@ -609,6 +637,13 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
     h.hstage = 1;
     for (int i = 1; i < desc->hLum.n && desc->hLum.pos; i++) if (desc->hLum.pos[i] < desc->hLum.pos[i - 1]) h.hstage = 0;
     for (int i = 1; i < desc->hChr.n && desc->hChr.pos; i++) if (desc->hChr.pos[i] < desc->hChr.pos[i - 1]) h.hstage = 0;
+    auto identity = [](const mi355_sws_filter &f, int src_w) {
+        if (f.size != 1 || !f.coef || !f.pos || f.n > src_w) return 0;
+        for (int i = 0; i < f.n; i++) if (f.coef[i] != 16384 || f.pos[i] != i) return 0;
+        return 1;
+    };
+    h.hident_l = identity(desc->hLum, h.srcW);
+    h.hident_c = identity(desc->hChr, h.chrSrcW);
     h.hLumC = h.hChrC = h.vLumC = h.vChrC = nullptr;
     h.hLumP = h.hChrP = h.vLumP = h.vChrP = nullptr;
     if (!h.special) {
