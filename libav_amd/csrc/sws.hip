@@ -136,6 +136,47 @@ struct TileRows {
  * filters take the direct path. */
 constexpr int SG = 16;                /* source lines per staging round */
 constexpr int SRC_DW = 76;            /* dwords per staged line: 2:1 with 8 taps needs 128 * 2 + 8 bytes (+2 of slack for zero taps) */
+/* byte funnel shift, byte permute and the two-term 16-bit dot product (v_alignbyte_b32, v_perm_b32, v_dot2_i32_i16); plain C
+ * under the SIMT emulator */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t sws_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (s & 3))); }
+static inline uint32_t sws_pair(uint32_t w, int k) { return ((w >> (16 * k)) & 0xFFu) | (((w >> (16 * k + 8)) & 0xFFu) << 16); }
+static inline int sws_dot2(uint32_t a, uint32_t b, int c) { return c + (int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int16_t)(a >> 16) * (int16_t)(b >> 16); }
+#else
+__device__ __forceinline__ uint32_t sws_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
+/* bytes 2k, 2k + 1 of w as two 16-bit values */
+__device__ __forceinline__ uint32_t sws_pair(uint32_t w, int k) { return __builtin_amdgcn_perm(0u, w, k ? 0x0C030C02u : 0x0C010C00u); }
+typedef short sws_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sws_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(sws_short2, a), __builtin_bit_cast(sws_short2, b), c, false);
+}
+#endif
+/* eight taps: the column's byte offset inside a dword is the same on every staged line, so a line's eight samples are
+ * three aligned dwords funnel-shifted into two, expanded to four 16-bit pairs and multiplied with the coefficient pairs
+ * (3 LDS reads and 10 arithmetic instructions per output instead of 8 byte reads and 8 multiply-adds).  Products and sums
+ * are the same integers (samples 0..255, coefficients 16 bits, |sum| < 2^31). */
+template <int COLS>
+__device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0, const int *cf, int left)
+{
+    constexpr int per = NT / COLS;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row0) & 3);
+    const uint32_t *w0 = reinterpret_cast<const uint32_t *>(row0 - sh);
+    const uint32_t c01 = ((uint32_t)cf[0] & 0xFFFFu) | ((uint32_t)cf[1] << 16), c23 = ((uint32_t)cf[2] & 0xFFFFu) | ((uint32_t)cf[3] << 16);
+    const uint32_t c45 = ((uint32_t)cf[4] & 0xFFFFu) | ((uint32_t)cf[5] << 16), c67 = ((uint32_t)cf[6] & 0xFFFFu) | ((uint32_t)cf[7] << 16);
+#pragma unroll
+    for (int k = 0; k < SG / per; k++) {
+        const uint32_t *w = w0 + k * per * SRC_DW;
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        const uint32_t lo = sws_alignbyte(d1, d0, sh), hi = sws_alignbyte(d2, d1, sh);
+        int val = sws_dot2(sws_pair(lo, 0), c01, 0);
+        val = sws_dot2(sws_pair(lo, 1), c23, val);
+        val = sws_dot2(sws_pair(hi, 0), c45, val);
+        val = sws_dot2(sws_pair(hi, 1), c67, val);
+        val >>= 7;
+        if (k * per <= left) out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
+    }
+}
 template <int COLS, int TAPS>
 __device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0, const int *cf, int left)
 {
@@ -246,7 +287,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
             if (fs == 1) hscale_lines<COLS, 1>(row0, out0, cf, left);
             else if (fs <= 2) hscale_lines<COLS, 2>(row0, out0, cf, left);
             else if (fs <= 4) hscale_lines<COLS, 4>(row0, out0, cf, left);
-            else if (fs <= 8) hscale_lines<COLS, 8>(row0, out0, cf, left);
+            else if (fs <= 8) hscale_lines8<COLS>(row0, out0, cf, left);
             else {
                 for (int k = 0; k < SG / per && k * per <= left; k++) {
                     const uint8_t *row = row0 + k * per * (SRC_DW * 4);
