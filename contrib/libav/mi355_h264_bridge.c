@@ -127,6 +127,7 @@ typedef struct Bridge {
     size_t plane_bytes[2];      /* luma plane, 4:2:0 chroma plane */
     /* per picture */
     int nslices, slice_num_of[BR_MAX_SLICES], uses_l1;
+    int mbs_packed;             /* macroblocks the decoder delivered for the picture being packed */
     const H264Picture *slot_pic[MI355_H264_MAX_SLOTS];
     int nslots;
     unsigned long pictures, waits;
@@ -441,7 +442,7 @@ static void begin_picture(Bridge *b, const H264Context *h)
     }
     memset(s->mv[0], 0, (size_t)b->nmb * 64);
     memset(s->mv[1], 0, (size_t)b->nmb * 64);
-    b->nslices = b->nslots = b->uses_l1 = 0;
+    b->nslices = b->nslots = b->uses_l1 = b->mbs_packed = 0;
     b->open = 1;
     (void)h;
 }
@@ -534,6 +535,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     const int mb_xy = sl->mb_xy, idx = sl->mb_x + sl->mb_y * b->mb_w;
     const int mb_type = h->cur_pic.mb_type[mb_xy];
     mi355_h264_mb *m = &st->mb[0][idx];
+    b->mbs_packed++;
     const int si = slice_index(b, h, sl);
     if (si < 0) { br_fail(b, "more slices or reference pictures than the batched path holds"); __real_ff_h264_hl_decode_mb(h, sl); return; }
     const int intra = IS_INTRA(mb_type);
@@ -712,10 +714,19 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
     Bridge *b = br_tls;
     if (b && b->state > 0 && b->open) {
         b->open = 0;
+        /* a damaged stream: the decoder gave up on a slice and macroblocks are missing.  What was delivered is reconstructed and
+         * brought back (the missing ones hold whatever the device made of empty records, as they hold stale data in the
+         * reference's frame); then this decoder continues on the reference's C path — its error concealment, where built in,
+         * rewrites the frame on the host (ff_er_frame_end below), and the device copy of the picture would no longer be what
+         * later pictures must predict from. */
+        const int incomplete = b->mbs_packed != b->nmb;
         if (submit_picture(b, h) != 0) {
             /* the picture is lost for this path; what was enqueued must drain before the host touches the frames again */
             finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
             br_fail(b, "submitting a picture to the device failed");
+        } else if (incomplete) {
+            finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+            br_fail(b, "incomplete picture (damaged stream)");
         } else {
             /* wait only for what the decoder is about to hand out: h->output_frame was chosen when the picture started
              * (h264_select_output_frame, h264_slice.c:1173-1290, called from h264_field_start :1528) and shares its buffers

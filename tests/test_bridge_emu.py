@@ -82,3 +82,43 @@ def test_bridge_plain_run_is_the_reference_path(tmp_path):
     stats = json.loads(r.stdout.strip().splitlines()[-1])
     assert stats["pictures_output"] == n and stats["pictures_on_device"] == 0 and stats["bridges_active"] == 0 and r.stderr.strip() == ""
     check_against_golden(np.fromfile(out, np.uint8), n)
+
+
+def test_bridge_survives_a_damaged_stream(tmp_path, emu):
+    """a P picture's slice cut to a third of its bytes: whatever the reference's entropy decoder makes of it (with this CABAC
+    clip it reads the padding as skipped macroblocks and completes the picture; a decoder that gives up instead leaves the
+    picture incomplete, which makes the bridge step aside after bringing back what it was given), the bridged run must
+    behave like the plain one: same exit code, same number of pictures, identical pictures before the damage."""
+    if not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP)):
+        pytest.skip("needs /root/reference and the sample clip")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mp4_samples
+    avcc, samples = mp4_samples.extract(CLIP)
+    bad = 9
+    # cut the picture's largest NAL unit (its slice) to a third: the entropy decoder runs out of data in the middle of the picture
+    s, pos, units = samples[bad], 0, []
+    while pos + 4 <= len(s):
+        n = int.from_bytes(s[pos:pos + 4], "big")
+        units.append(s[pos + 4:pos + 4 + n])
+        pos += 4 + n
+    big = max(range(len(units)), key=lambda i: len(units[i]))
+    units[big] = units[big][:max(8, len(units[big]) // 3)]
+    samples[bad] = b"".join(len(u).to_bytes(4, "big") + u for u in units)
+    src = tmp_path / "s"
+    with open(src, "wb") as f:
+        f.write(struct.pack("<I", len(avcc)) + avcc + struct.pack("<I", len(samples)))
+        for x in samples:
+            f.write(struct.pack("<I", len(x)) + x)
+    out, ref = tmp_path / "o.yuv", tmp_path / "r.yuv"
+    exe = os.path.join(ROOT, "oracle", "_ref", "h264_bridge_emu")
+    r = subprocess.run([exe, str(src), str(out), "1", "1"], capture_output=True, text=True, timeout=900)
+    p = subprocess.run([exe, str(src), str(ref), "1", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MI355_BRIDGE_PLAIN="1"))
+    assert r.returncode == p.returncode
+    got, want = np.fromfile(out, np.uint8), np.fromfile(ref, np.uint8)
+    assert got.size == want.size and got.size > 0                                   # same number of pictures as the plain run
+    fs = 320 * 240 * 3 // 2
+    assert np.array_equal(got[:bad * fs], want[:bad * fs])                          # everything before the damage
+    if "incomplete picture" in r.stderr:
+        stats = json.loads(r.stdout.strip().splitlines()[-1])
+        assert stats["bridges_active"] == 0 and stats["pictures_on_device"] >= bad
