@@ -209,6 +209,10 @@ int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, in
  * of loads for those; none for the others) — over PCIe the skipped blocks are what counts.  Same results. */
 int mi355_h264_recon_inter_sparse_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, int max_level_width, void *stream);
+/* The loop filter of the whole batch: bands of four macroblock rows, top to bottom.  The launch shape follows the batch: one
+ * launch per band with a wave per picture when there are enough pictures to fill the device, two to six bands per launch
+ * pipelined inside a workgroup (one wave each) when there are few — same pictures either way (the environment variable
+ * MI355_DEBLOCK_FORM = 1 / 2 / 3 / 4 / 6 pins the number of bands per workgroup: a developer switch). */
 int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 
 /* Host helper (plain CPU bookkeeping, no sample arithmetic): write the intra schedule of one picture:
