@@ -593,10 +593,13 @@ template <bool ALIGNED = false>
 __device__ __forceinline__ void add_row4(uint8_t *p, const int *r)
 {
     if (ALIGNED || (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        /* two 16-bit lanes per register: the residuals are at most 4 * 32768 >> 6 in magnitude (second transform pass on
+         * 16-bit first-pass values; (dc + 32) >> 6 for the DC-only form), sample + residual cannot wrap 16 bits */
         uint32_t *w = reinterpret_cast<uint32_t *>(p);
         const uint32_t v = *w;
-        *w = (uint32_t)clip_u8((int)(v & 0xFF) + r[0]) | ((uint32_t)clip_u8((int)((v >> 8) & 0xFF) + r[1]) << 8) |
-             ((uint32_t)clip_u8((int)((v >> 16) & 0xFF) + r[2]) << 16) | ((uint32_t)clip_u8((int)(v >> 24) + r[3]) << 24);
+        const uint32_t s0 = pk_clip_u8(pk_add(byte_perm(0u, v, 0x0C010C00u), pk_make(r[0], r[1])));
+        const uint32_t s1 = pk_clip_u8(pk_add(byte_perm(0u, v, 0x0C030C02u), pk_make(r[2], r[3])));
+        *w = byte_perm(s1, s0, 0x06040200u);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) p[k] = (uint8_t)clip_u8(p[k] + r[k]);
