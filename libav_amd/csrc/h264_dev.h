@@ -352,6 +352,16 @@ static inline uint32_t pk_clip_u8(uint32_t a)
     const int l = pk_lo(a), h = pk_hi(a);
     return pk_make(l < 0 ? 0 : (l > 255 ? 255 : l), h < 0 ? 0 : (h > 255 ? 255 : h));
 }
+static inline uint32_t pk_ashr_hi1(uint32_t a) { return pk_make(pk_lo(a), pk_hi(a) >> 1); }          /* (lo, hi >> 1) */
+static inline uint32_t pk_mad2(uint32_t a, uint32_t k, uint32_t c) { return pk_make(pk_lo(a) * pk_lo(k) + pk_lo(c), pk_hi(a) * pk_hi(k) + pk_hi(c)); }
+static inline int pk_dot2(uint32_t a, uint32_t b, int c) { return c + pk_lo(a) * pk_lo(b) + pk_hi(a) * pk_hi(b); }      /* v_dot2_i32_i16 */
+static inline int pk_dot2k(uint32_t a, uint32_t k, int c) { return pk_dot2(a, k, c); }
+static inline uint32_t bit_mask(uint32_t v, int bit) { return ((v >> bit) & 1u) ? 0xFFFFFFFFu : 0u; }                            /* v_bfe_i32, width 1 */
+static inline uint32_t pk_sat_u8(uint32_t a)                                                          /* v_sat_pk_u8_i16: clip(lo) | clip(hi) << 8 */
+{
+    const int l = pk_lo(a), h = pk_hi(a);
+    return (uint32_t)(l < 0 ? 0 : (l > 255 ? 255 : l)) | ((uint32_t)(h < 0 ? 0 : (h > 255 ? 255 : h)) << 8);
+}
 #else
 typedef short mi355_v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ mi355_v2s pk_v(uint32_t a) { return __builtin_bit_cast(mi355_v2s, a); }
@@ -366,6 +376,19 @@ __device__ __forceinline__ uint32_t pk_clip_u8(uint32_t a)
 {
     return pk_u(__builtin_elementwise_min(__builtin_elementwise_max(pk_v(a), (mi355_v2s)((short)0)), (mi355_v2s)((short)255)));
 }
+__device__ __forceinline__ uint32_t pk_ashr_hi1(uint32_t a) { return pk_u(pk_v(a) >> mi355_v2s{ 0, 1 }); }
+__device__ __forceinline__ uint32_t pk_mad2(uint32_t a, uint32_t k, uint32_t c) { return pk_u(pk_v(a) * pk_v(k) + pk_v(c)); }
+#ifdef MI355_DOT2_BUILTIN
+__device__ __forceinline__ int pk_dot2(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot2(pk_v(a), pk_v(b), c, false); }
+__device__ __forceinline__ int pk_dot2k(uint32_t a, uint32_t k, int c) { return pk_dot2(a, k, c); }
+#else
+/* the three-address form by name: for the builtin the compiler takes the accumulating two-address form (v_dot2c) and copies
+ * the addend first whenever it is still needed afterwards — a v_mov per product */
+__device__ __forceinline__ int pk_dot2(uint32_t a, uint32_t b, int c) { int d; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ int pk_dot2k(uint32_t a, uint32_t k, int c) { int d; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }   /* k: a wave constant */
+#endif
+__device__ __forceinline__ uint32_t bit_mask(uint32_t v, int bit) { return (uint32_t)__builtin_amdgcn_sbfe((int)v, (uint32_t)bit, 1u); }
+__device__ __forceinline__ uint32_t pk_sat_u8(uint32_t a) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a)); return r; }
 #endif
 constexpr uint32_t PK_M = 0x00FF00FFu;
 /* samples 0,2 and 1,3 of a dword as two packed pairs, and back */

@@ -33,13 +33,15 @@ using namespace mi355;
 
 namespace {
 
+typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
+
 struct MbLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];                      /* (x | y << 16) per 4x4 block, raster order, per list */
     int16_t coef[384];
     uint8_t py[16 * 16], pc[2][8 * 8];       /* prediction -> reconstruction */
     uint8_t qy[16 * 16], qc[2][8 * 8];       /* second prediction for weighted bi-pred */
-    uint8_t slot[24];                        /* residual_blocks: the blocks that carry a residual, compacted */
 #ifdef MI355_EXP_LDS_PAD                     /* developer experiment: fewer waves per CU */
     uint8_t exp_pad[MI355_EXP_LDS_PAD];
 #endif
@@ -304,19 +306,97 @@ __device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int p
     MI355_WAVE_SYNC();
 }
 
-/* Residual of an inter macroblock with 4x4 transforms, luma and chroma in ONE pass over the blocks that carry
- * anything: a block is listed when its nnz bit is set (full transform, h264idct_template.c:33-67) or, for chroma, when
- * it has a DC value after ff_h264_chroma_dc_dequant_idct (h264_idct_dc_add :144-156: (dc + 32) >> 6 in int).  With
- * half of the 24 blocks coded a wave transforms 12 blocks on 48 lanes instead of 16 + 8 block slots in two passes.
- * Coefficient block b starts at coef[16 * b] and its nnz bit is bit b for luma, Cb and Cr alike.
- * Same results as residual_luma + residual_chroma (h264_mb.c:726-795, h264_mb_template.c:196-247). */
-template <bool ALIGNED>
-__device__ inline void residual_blocks(MbLds &s)
+/* Residual of an inter macroblock with 4x4 transforms (h264_mb.c:726-795, h264_mb_template.c:196-247; same results as
+ * residual_luma + residual_chroma above).  Coefficient block b starts at coef[16 * b] and its nnz bit is bit b for luma,
+ * Cb and Cr alike.  A block takes the full transform when its nnz bit is set (h264idct_template.c:33-67) and, for chroma
+ * only, h264_idct_dc_add (:144-156, (dc + 32) >> 6 in int) when the bit is clear but ff_h264_chroma_dc_dequant_idct left
+ * a DC value.
+ *
+ * All 24 blocks at once, two lanes per block, two 16-bit values per register: lane h of block b holds columns 2h, 2h + 1
+ * (coef[16b + 4i + 2h], [.. + 1] for i = 0..3: one dword each).  The first pass runs along i inside the lane and wraps at
+ * 16 bits BY DEFINITION (the reference stores it back into its int16 block), so v_pk_* arithmetic is exact.  The second
+ * pass is int in the reference: the four values of a row — the two halves of this lane's register and of the partner
+ * lane's — meet in v_dot2_i32_i16 (16-bit factors, 32-bit sum) with factors +-1024, which leaves (sum >> 6) in the upper
+ * half of the result (|sum| <= 3.5 * 32768).  A block without anything, and the coefficients other than the DC of a DC-only
+ * chroma block, are masked to zero: the transform of a lone DC is (dc + 32) >> 6 in every position, that of nothing is 0.
+ *
+ * What a lane needs that depends on nothing but its number — tile addresses of its two rows, address of its coefficients,
+ * signs — is a ResidLane: computed from the lane number on the device (resid_lane_compute), read from a table built at
+ * compile time in the emulator build, which checks the two against each other. */
+struct ResidLane {
+    uint32_t off_a, off_b;   /* byte offsets in MbLds of this lane's two destination rows (4 samples each) */
+    uint32_t cw;             /* byte offset in MbLds of coef[16 b + 2 h] */
+    uint32_t dc16;           /* 0xFFFF where the lane's first dword starts with a chroma DC */
+    uint32_t misc;           /* bits 0-7: 32 on lane h = 0 (the rounding constant goes onto element 0); bits 8-9: 1 luma, 2 chroma lane */
+    uint32_t rc;             /* 32 * 1024 on chroma lanes: rounding of the DC-only form, in the second pass's scale */
+    uint32_t ka, kb;         /* factors of this lane's own pair for its two rows */
+};
+struct ResidLaneTable { ResidLane l[64]; };
+constexpr ResidLaneTable make_resid_lanes()
 {
+    ResidLaneTable t{};
+    for (int lane = 0; lane < 64; lane++) {
+        const int b = lane >> 1, h = lane & 1, bc = b < 24 ? b : 23, jj = bc & 3;
+        const bool chroma = bc >= 16;
+        const int x4 = (bc & 1) + 2 * ((bc >> 2) & 1), y4 = ((bc >> 1) & 1) + 2 * (bc >> 3);
+        const int base = chroma ? (int)offsetof(MbLds, pc) + 64 * ((bc >> 2) & 1) + 32 * (jj >> 1) + 4 * (jj & 1) : (int)offsetof(MbLds, py) + 64 * y4 + 4 * x4;
+        const int pitch = chroma ? 8 : 16;
+        ResidLane &e = t.l[lane];
+        e.off_a = (uint32_t)(base + (h ? 1 : 0) * pitch);
+        e.off_b = (uint32_t)(base + (h ? 2 : 3) * pitch);
+        e.cw = (uint32_t)((int)offsetof(MbLds, coef) + (bc * 8 + h) * 4);
+        e.dc16 = b < 24 && chroma && h == 0 ? 0xFFFFu : 0u;
+        e.misc = (h == 0 ? 32u : 0u) | (b >= 24 ? 0u : (chroma ? 0x200u : 0x100u));
+        e.rc = b < 24 && chroma ? 32u * 1024u : 0u;
+        e.ka = h ? 0xFC00FC00u : 0x04000400u;        /* lane 1: -(v2) - (v3);  lane 0: v0 + v1 */
+        e.kb = h ? 0x0400FC00u : 0xFC000400u;        /* lane 1: -(v2) + (v3);  lane 0: v0 - v1 */
+    }
+    return t;
+}
+__device__ const ResidLaneTable k_resid_lanes = make_resid_lanes();
+/* the same values from the lane number (lanes past block 23 get addresses inside MbLds and no `live` bit) */
+__device__ __forceinline__ void resid_lane_compute(ResidLane &r)
+{
+    const uint32_t lane = (uint32_t)lane_id(), h = lane & 1u;
+    const bool chroma = lane >= 32;
+    const uint32_t x = (lane & 2u) * 2u;                                                    /* 4 * (b & 1) */
+    const uint32_t yl = ((lane & 4u) << 4) | (lane & 8u) | ((lane & 16u) << 3);             /* 64 * b1 + 8 * b2 + 128 * b3 */
+    const uint32_t yc = (lane & 12u) << 3;                                                  /* 32 * b1 + 64 * b2 */
+    const uint32_t base = chroma ? (uint32_t)offsetof(MbLds, pc) + yc + x : (uint32_t)offsetof(MbLds, py) + yl + x;
+    const uint32_t pitch = chroma ? 8u : 16u;
+    r.off_a = base + h * pitch;
+    r.off_b = base + (3u - h) * pitch;
+    r.cw = (uint32_t)offsetof(MbLds, coef) + lane * 16u - h * 12u;
+    r.dc16 = (lane & 33u) == 32u ? 0xFFFFu : 0u;
+    r.misc = (h ? 0u : 32u) | (lane < 32 ? 0x100u : (lane < 48 ? 0x200u : 0u));
+    r.rc = chroma ? 32u * 1024u : 0u;
+    r.ka = h ? 0xFC00FC00u : 0x04000400u;
+    r.kb = h ? 0x0400FC00u : 0xFC000400u;
+}
+__device__ __forceinline__ void resid_lane_issue(ResidLane &r)
+{
+#if defined(MI355_HIP_EMU_H)
+    /* the emulator runs the table and checks the arithmetic form (the device build's default) against it */
+    r = k_resid_lanes.l[lane_id()];
+    ResidLane c;
+    resid_lane_compute(c);
+    if (lane_id() < 48 && (c.off_a != r.off_a || c.off_b != r.off_b || c.cw != r.cw || c.dc16 != r.dc16 || c.misc != r.misc || c.rc != r.rc || c.ka != r.ka || c.kb != r.kb)) abort();
+#else
+    /* measured and not kept (profiles/r02_experiments.md): loading the table on the device too (two 16-byte loads per lane,
+     * issued with the record) takes 37 VALU off the macroblock and still costs 4 % of the kernel's time — 2 KB more per
+     * wave through the L1 */
+    (void)r;
+#endif
+}
+template <bool ALIGNED>
+__device__ inline void residual_blocks(MbLds &s, const ResidLane &rl_in)
+{
+    static_assert(ALIGNED, "the tile rows of the frame kernels start on dwords");
     const int lane = lane_id();
     const uint32_t nnz = (uint32_t)uniform((int)s.hdr.nnz_mask);
-    uint32_t mask = nnz & 0xFFFFu;
-    if (uniform(s.hdr.cbp) & 0x30) {
+    const bool has_chroma = (uniform(s.hdr.cbp) & 0x30) != 0;
+    if (!(nnz & 0xFFFFu) && !has_chroma) return;
+    if (has_chroma) {
         if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
             int16_t *p = s.coef + 256 + 64 * lane;
             int a = p[0], b = p[16], c = p[32], d = p[48];
@@ -324,29 +404,46 @@ __device__ inline void residual_blocks(MbLds &s)
             p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
         }
         MI355_WAVE_SYNC();
-        const bool need = lane >= 16 && lane < 24 && (((nnz >> lane) & 1) || s.coef[16 * lane] != 0);
-        mask |= (uint32_t)uniform((int)(uint32_t)__ballot(need));
     }
-    if (!mask) return;
-    const int n = __popc(mask);
-    if (lane < 24 && ((mask >> lane) & 1)) s.slot[__popc(mask & ((1u << lane) - 1u))] = (uint8_t)lane;
-    MI355_WAVE_SYNC();
-    const int k = lane >> 2, q = lane & 3;
-#pragma nounroll
-    for (int base = 0; base < n; base += 16) {
-        const bool act = base + k < n;
-        const int b = s.slot[act ? base + k : 0];
-        int c[4], r[4], row;
+#if defined(MI355_HIP_EMU_H)
+    const ResidLane &rl = rl_in;
+#else
+    ResidLane rl;
+    (void)rl_in;
+    resid_lane_compute(rl);
+#endif
+    /* scalars: the nnz bits that count (lanes past block 23 look at bits 24..31: none), chroma switched off as a whole */
+    const uint32_t nnz24 = nnz & (has_chroma ? 0xFFFFFFu : 0xFFFFu), hc = has_chroma ? 0xFFFFFFFFu : 0u;
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const uint32_t keep = bit_mask(nnz24, lane >> 1);                 /* full transform: all coefficients */
+    const uint32_t keep0 = keep | (rl.dc16 & hc);                     /* a chroma DC stays without the nnz bit */
+    /* + 32 goes onto element 0 in 16 bits for the full transform (block[0] += 1 << 5, :38) but in int for the DC-only form
+     * (:148): there it joins the second pass's sums */
+    const int rnd = (int)(~keep & rl.rc & hc);
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(base + rl.cw);
+    const uint32_t c0 = pk_add(cw[0] & keep0, keep & rl.misc & 0xFFu), c1 = cw[2] & keep, c2 = cw[4] & keep, c3 = cw[6] & keep;
+    /* first pass (:42-52), 16-bit wrap */
+    const uint32_t z0 = pk_add(c0, c2), z1 = pk_sub(c0, c2), z2 = pk_sub(pk_ashr(c1, 1), c3), z3 = pk_add(c1, pk_ashr(c3, 1));
+    const uint32_t w[4] = { pk_add(z0, z3), pk_add(z1, z2), pk_sub(z1, z2), pk_sub(z0, z3) };
+    /* second pass (:54-66) for row i: the lane pair holds (v0, v1 | v2, v3).  With xh = the partner's (lo, hi >> 1):
+     * lane 0 (own = v0, v1; xh = v2, v3 >> 1): rows 0 and 3 = (v0 + v2) +- (v1 + (v3 >> 1));
+     * lane 1 (own = v2, v3; xh = v0, v1 >> 1): rows 1 and 2 = (v0 - v2) +- ((v1 >> 1) - v3) */
+    uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) c[i] = s.coef[b * 16 + q + 4 * i];
-        const int dc = quad_bcast<0>(c[0]);
-        idct4_quad(c, q, r, row);
-        if (!((nnz >> b) & 1)) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;       /* DC only: h264_idct_dc_add, no int16 wrap */
-        /* destination: luma block b of py (pitch 16) or chroma block (b - 16) & 3 of pc[(b - 16) >> 2] (pitch 8) */
-        const int jj = b & 3;
-        uint8_t *d = b < 16 ? s.py + (4 * blk_y4(b) + row) * 16 + 4 * blk_x4(b)
-                            : s.pc[(b >> 2) & 1] + (4 * (jj >> 1) + row) * 8 + 4 * (jj & 1);
-        if (act) add_row4<ALIGNED>(d, r);
+    for (int i = 0; i < 4; i++) {
+        const uint32_t xh = pk_ashr_hi1((uint32_t)quad_xor1((int)w[i]));
+        const int ra = pk_dot2k(xh, 0x04000400u, pk_dot2(w[i], rl.ka, rnd)), rb = pk_dot2k(xh, 0xFC000400u, pk_dot2(w[i], rl.kb, rnd));
+        o[i] = byte_perm((uint32_t)rb, (uint32_t)ra, 0x07060302u);          /* the upper halves: (residual a, residual b) */
+    }
+    if (rl.misc & (has_chroma ? 0x300u : 0x100u)) {
+        uint32_t *pa = reinterpret_cast<uint32_t *>(base + rl.off_a), *pb = reinterpret_cast<uint32_t *>(base + rl.off_b);
+        const uint32_t va = *pa, vb = *pb;
+        /* column i: (sample of row a, sample of row b) + (residual a, residual b), clipped to bytes (a | b << 8) */
+        const uint32_t s0 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C040C00u), o[0])), s1 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C050C01u), o[1]));
+        const uint32_t s2 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C060C02u), o[2])), s3 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C070C03u), o[3]));
+        const uint32_t m01 = byte_perm(s1, s0, 0x05040100u), m23 = byte_perm(s3, s2, 0x05040100u);      /* a0 b0 a1 b1 / a2 b2 a3 b3 */
+        *pa = byte_perm(m23, m01, 0x06040200u);
+        *pb = byte_perm(m23, m01, 0x07050301u);
     }
     MI355_WAVE_SYNC();
 }
@@ -413,6 +510,8 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     RPROF(0);
+    ResidLane rl;
+    resid_lane_issue(rl);            /* lane constants of residual_blocks: in flight with the record */
     load_mb(s, fr, mb_xy, !SPARSE);
     RPROF(1);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
@@ -433,19 +532,27 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
         if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma<true>(s, s.py, 16, false);
         residual_chroma<true>(s, s.pc[0], s.pc[1], 8);
     } else {
-        residual_blocks<true>(s);
+        residual_blocks<true>(s, rl);
     }
 #endif
     RPROF(6);
     store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr, mb_x, mb_y);
     RPROF(7);
 }
+/* Eight waves per SIMD: left alone the compiler takes 106 scalar registers (seven waves).  Capped at 96 it spills more of them
+ * to vector lanes (+45 VALU per macroblock) and the kernel is still 2.5 % faster: it waits on three dependent memory round
+ * trips per macroblock (descriptor, record, reference window), which only more waves in flight hide. */
+#ifndef MI355_RECON_WAVES
+#define MI355_RECON_WAVES 8
+#endif
+__attribute__((amdgpu_waves_per_eu(MI355_RECON_WAVES, MI355_RECON_WAVES)))
 __global__ void __launch_bounds__(64)
 k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
     __shared__ MbLds s;
     recon_inter_wave<false>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
 }
+__attribute__((amdgpu_waves_per_eu(MI355_RECON_WAVES, MI355_RECON_WAVES)))
 __global__ void __launch_bounds__(64)
 k_recon_inter_sparse(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
@@ -680,8 +787,11 @@ constexpr int DCH_ISSUE = DCH >= 4 ? 1 : DCH - 1;  /* position in a chunk at whi
  * 4(c + 2) + 5 = 4c + 13); the barrier at the end of that step publishes the stores.  So the wave above must be at least
  * (4c + 14) - (4c - 4 + DCH_ISSUE) = 18 - DCH_ISSUE steps ahead.  The tiles of KW bands share the CU's 160 KB of LDS with
  * the other workgroups on it: 8 / KW workgroups (pictures) per CU. */
-constexpr int DEBLOCK_LAG = 20;
-static_assert(DCH == 4 && DEBLOCK_LAG >= 18 - DCH_ISSUE, "lag of the small-batch deblocking form");
+/* in general: the last macroblock of the lower band's chunk c lies in chunk c + (DCH + 5) / DCH of the upper wave's group 3 */
+constexpr int DEBLOCK_LAG_MIN = DCH * ((DCH + 5) / DCH + 2) + 2 - DCH_ISSUE;
+constexpr int DEBLOCK_LAG = DEBLOCK_LAG_MIN + (DCH == 4 ? 3 : 1);
+static_assert((DCH == 4 && DEBLOCK_LAG_MIN == 17) || (DCH == 2 && DEBLOCK_LAG_MIN == 11), "lag of the small-batch deblocking form");
+constexpr int DEBLOCK_WAVES_PER_CU = DCH == 4 ? 8 : 12;     /* band tiles (waves) a CU holds: LDS with chunks of four, registers (168) with chunks of two */
 struct DeblockLds {
     uint8_t y[4][2][20][DY_PITCH];      /* [group][chunk parity]: rows -4..15 of DCH macroblocks */
     uint8_t c[4][2][2][10][DC_PITCH];   /* [group][chunk parity][plane]: rows -2..7 */
@@ -702,8 +812,6 @@ struct MbInfo {
     __device__ __forceinline__ int slice_id() const { return (int)(w11 & 0xFF); }
     __device__ __forceinline__ int qpc(int p) const { return (int)((w11 >> (16 + 8 * p)) & 0xFF); }
 };
-typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
-typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
 /* words 0-3 (0-2 for a neighbour, whose slice offsets are not looked at) and 11-13 of the record at byte offset `off` of
  * `base`: two loads, no predicate.  No loaded word may be dead: the register of a dead word is handed to something else,
  * and the first write to it then waits for this load (a memory latency per step when that something is set per step). */
@@ -1001,7 +1109,7 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
         const bool ok = row_ok && x >= 0 && x < W;
         const int y_first = has_t ? 1 : 4, y_last = below ? 16 : 19;      /* tile rows: -3.. / 0..  up to 12 / 15 */
         const int c_first = has_t ? 1 : 2, c_last = below ? 8 : 9;
-        constexpr int NF = 20 / DIO_ROWS;                    /* 20 luma tile rows; 2 x 10 chroma tile rows */
+        constexpr int NF = (20 + DIO_ROWS - 1) / DIO_ROWS;                   /* 20 luma tile rows; 2 x 10 chroma tile rows */
 #pragma unroll
         for (int it = 0; it < NF; it++) {
             const int row = DIO_ROWS * it + io_r;
@@ -1323,7 +1431,7 @@ extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nfra
     const int forms[5] = { 1, 2, 3, 4, 6 };
     for (int i = 0; i < 5; i++) {
         const int kw = forms[i];
-        const long resident = (long)cus * (8 / kw);
+        const long resident = (long)cus * (DEBLOCK_WAVES_PER_CU / kw);
         const double rounds = (double)((nframes + resident - 1) / resident);
         const double cost = rounds * ((nbands + kw - 1) / kw) * (nsteps + DEBLOCK_LAG * (kw - 1)) * (kw > 1 ? 1.25 : 1.0);
         if (i == 0 || cost < best_cost) { best = kw; best_cost = cost; }

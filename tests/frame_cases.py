@@ -30,6 +30,10 @@ CASES = {
     # 268 intra dependency levels: more than the record's 8-bit intra_level field can hold (an all-intra picture
     # above 1080p does this); the schedule must not wrap
     "tall_all_intra":   dict(nframes=1, mb_w=10, mb_h=130, seed=107, intra_frac=1.0, pcm_frac=0.02, coef_b=10),
+    # levels up to +-32767: first-pass values beyond +-8191 (k_recon_inter's 16-bit second pass hands the macroblock to the
+    # int form) and the reference's own int16 wrap of the first pass
+    "mid_wrapcoef":     dict(nframes=1, mb_w=20, mb_h=9, seed=108, mix="mixed", intra_frac=0.2, dct8_frac=0.2, coef_b=6000, coef_clip=32767),
+    "p16_wrapcoef":     dict(nframes=1, mb_w=12, mb_h=5, seed=109, intra_frac=0.1, coef_b=3000, coef_clip=32767),
     "mid_hugecoef":     dict(nframes=1, mb_w=33, mb_h=19, seed=106, mix="mixed", intra_frac=0.5, dct8_frac=0.4, coef_b=1000),
 }
 

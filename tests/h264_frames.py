@@ -92,6 +92,7 @@ class FrameSet:
 
 
 COEF_B = [24]   # Laplace scale of the AC levels (SURVEY.md §8d uses 24)
+COEF_CLIP = [2047]   # magnitude bound of the levels (a case may raise it to reach the transform's 16-bit wrap)
 
 
 def _gen_block_coefs(r, n, kind):
@@ -101,7 +102,7 @@ def _gen_block_coefs(r, n, kind):
     dconly = r.uniform(n) < 0.25
     k = r.randint(1, 16, n)
     k = np.where(dconly, 1, k)
-    vals = r.laplace_int(COEF_B[0], (n, 16), 2047)
+    vals = r.laplace_int(COEF_B[0], (n, 16), COEF_CLIP[0])
     vals = np.where(vals == 0, 1, vals)
     zz = np.array(ZIGZAG4)
     out = np.zeros((n, 16), np.int16)
@@ -136,13 +137,14 @@ def _ref_plane(r, h, w, kind):
 
 
 def synth_frames(nframes, mb_w, mb_h, seed=0x264, nrefs=4, mix="p16", intra_frac=0.0, bframes=False,
-                 weighted=0, dct8_frac=0.0, mv_range=64, offsets=False, pcm_frac=0.0, refs="noise", coef_b=24):
+                 weighted=0, dct8_frac=0.0, mv_range=64, offsets=False, pcm_frac=0.0, refs="noise", coef_b=24, coef_clip=2047):
     """mix: 'p16' (all 16x16), 'mixed' (all partition shapes).  Returns a FrameSet."""
     fs = FrameSet(nframes, mb_w, mb_h, nrefs)
     r = SplitMix64(seed)
     nmb = mb_w * mb_h
     fs.use_l1 = bframes
     COEF_B[0] = coef_b
+    COEF_CLIP[0] = coef_clip
     for f in range(nframes):
         for s in range(nrefs):
             fs.refs[f][s] = (_ref_plane(r, fs.H, fs.W, refs), _ref_plane(r, fs.H // 2, fs.W // 2, refs),
@@ -595,6 +597,7 @@ def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05,
     fs = FrameSet(nframes, mb_w, mb_h, nrefs)
     r = SplitMix64(seed)
     COEF_B[0] = 24 if coef_b is None else coef_b
+    COEF_CLIP[0] = 2047
     dc_scale = COEF_B[0] / 24.0
     nmb = mb_w * mb_h
     N = nframes * nmb
