@@ -36,7 +36,7 @@ namespace {
 typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
 typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
 
-struct MbLds {
+struct __attribute__((aligned(16))) MbLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];                      /* (x | y << 16) per 4x4 block, raster order, per list */
     int16_t coef[384];
@@ -123,6 +123,31 @@ __device__ inline void load_mb(MbLds &s, const FrameHot &fr, int mb_xy, bool wit
     MbLoad r;
     load_mb_issue(r, fr, mb_xy, with_coefs, true);
     load_mb_commit(s, r, with_coefs, fr.mv[0] != nullptr, fr.mv[1] != nullptr);
+}
+
+/* The same 960 bytes as ONE access of 16 bytes per lane: lanes 0-3 the record, 4-7 / 8-11 the list-0 / list-1 vectors (a
+ * missing list reads the record and is zeroed), 12-59 the coefficients, 60-63 repeat lane 59 — and one 16-byte LDS write per
+ * lane, because hdr, mv and coef follow each other in MbLds in that order.  The L1 handles a wave's access four lanes at a
+ * time whatever their width: five dword accesses of 64 lanes are 80 such groups, this is 15 (k_recon_inter's memory
+ * pipeline was busy 60 % of the time, profiles/r02g_pmc3_h264_f2048.json). */
+typedef uint32_t mi355_u32x4u __attribute__((vector_size(16), aligned(4)));
+typedef uint32_t mi355_u32x2u __attribute__((vector_size(8), aligned(4)));
+static_assert(sizeof(mi355_h264_mb) == 64 && offsetof(MbLds, mv) == 64 && offsetof(MbLds, coef) == 192 && MI355_H264_COEFS_PER_MB == 384, "MbLds begins with the 960 bytes load_mb_wide fills");
+__device__ __forceinline__ void load_mb_wide(MbLds &s, const FrameHot &fr, int mb_xy)
+{
+    const int lane = lane_id(), l = lane < 60 ? lane : 59;
+    const uint8_t *hp = reinterpret_cast<const uint8_t *>(&fr.mb[mb_xy]);
+    const uint8_t *cp = reinterpret_cast<const uint8_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    const bool has0 = fr.mv[0] != nullptr, has1 = fr.mv[1] != nullptr;
+    const uint8_t *m0 = has0 ? reinterpret_cast<const uint8_t *>(fr.mv[0]) + (size_t)mb_xy * 64 : hp;
+    const uint8_t *m1 = has1 ? reinterpret_cast<const uint8_t *>(fr.mv[1]) + (size_t)mb_xy * 64 : hp;
+    /* lane l reads 16 bytes at offset 16 * (l - first lane of its part) of its part */
+    const uint8_t *src = l < 4 ? hp + 16 * l : (l < 8 ? m0 + 16 * (l - 4) : (l < 12 ? m1 + 16 * (l - 8) : cp + 16 * (l - 12)));
+    mi355_u32x4u v = *reinterpret_cast<const mi355_u32x4u *>(src);
+    MI355_ISSUE_FENCE();
+    if ((l >= 4 && l < 8 && !has0) || (l >= 8 && l < 12 && !has1)) v = mi355_u32x4u{ 0u, 0u, 0u, 0u };
+    *reinterpret_cast<mi355_u32x4 *>(reinterpret_cast<uint8_t *>(&s) + 16 * l) = mi355_u32x4{ v[0], v[1], v[2], v[3] };
+    MI355_WAVE_SYNC();
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */
@@ -471,6 +496,21 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
     }
 }
 
+/* the inter kernel's tile (py: 16 rows of 16 bytes, then pc: 2 x 8 rows of 8 bytes) -> picture: a row per lane, 16 + 16 lanes */
+__device__ __forceinline__ void store_mb_rows(const MbLds &s, const FrameHot &fr, int mb_x, int mb_y)
+{
+    static_assert(offsetof(MbLds, pc) == offsetof(MbLds, py) + 256, "py and pc are one run of rows");
+    const int lane = lane_id();
+    if (lane < 16) {
+        const mi355_u32x4 v = *reinterpret_cast<const mi355_u32x4 *>(s.py + 16 * lane);
+        *reinterpret_cast<mi355_u32x4u *>(fr.recon[0] + (uint32_t)(__mul24(mb_y * 16 + lane, fr.recon_stride[0]) + mb_x * 16)) = mi355_u32x4u{ v[0], v[1], v[2], v[3] };
+    } else if (lane < 32) {
+        const int plane = (lane >> 3) & 1, row = lane & 7;
+        const mi355_u32x2 v = *reinterpret_cast<const mi355_u32x2 *>(s.py + 256 + 8 * (lane - 16));
+        *reinterpret_cast<mi355_u32x2u *>((plane ? fr.recon[2] : fr.recon[1]) + (uint32_t)(__mul24(mb_y * 8 + row, fr.recon_stride[1]) + mb_x * 8)) = mi355_u32x2u{ v[0], v[1] };
+    }
+}
+
 #ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of the first blocks */
 __device__ unsigned long long g_prof[16];
 #define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
@@ -491,7 +531,9 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
  * macroblocks with the next macroblock's windows and the one after's record in flight (two register sets, exact
  * partial waits) was 25-30 % SLOWER although it hid both memory round trips — the kernel is bound by the request rate
  * of the reference fetch (removing the window loads alone: -30 % time at -8 % VALU), which a deeper pipeline does not
- * lower, and the loop cost 50 more VALU per macroblock. */
+ * lower, and the loop cost 50 more VALU per macroblock.  Nor does a plain loop over 2 / 4 consecutive macroblocks per wave help
+ * (+9 % / +24 % time: the next record's wait also waits for the previous macroblock's stores), nor a prefetch of the record
+ * 1024-5000 macroblocks ahead into the L2 (+5 %). */
 /* SPARSE: the coefficient array lives in device-visible HOST memory (a bridge's staging block read in place): a macroblock
  * fetches its 768 bytes only when its record says it has coefficients (cbp), at the price of a second, dependent round of
  * loads for those that do — in P / B pictures of real streams most macroblocks carry none, and the link is the narrow
@@ -512,7 +554,8 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     RPROF(0);
     ResidLane rl;
     resid_lane_issue(rl);            /* lane constants of residual_blocks: in flight with the record */
-    load_mb(s, fr, mb_xy, !SPARSE);
+    if (SPARSE) load_mb(s, fr, mb_xy, false);
+    else load_mb_wide(s, fr, mb_xy);
     RPROF(1);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
     if (SPARSE && (uniform((int)s.hdr.cbp) & 0x3F)) {
@@ -536,7 +579,7 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     }
 #endif
     RPROF(6);
-    store_mb<true>(s.py, 16, s.pc[0], s.pc[1], 8, fr, mb_x, mb_y);
+    store_mb_rows(s, fr, mb_x, mb_y);
     RPROF(7);
 }
 /* Eight waves per SIMD: left alone the compiler takes 106 scalar registers (seven waves).  Capped at 96 it spills more of them
