@@ -1,0 +1,265 @@
+/* h264_session.hip — whole-frame decoding sessions (include/mi355_h264_session.h): the AVHWAccel-shaped boundary
+ * (start_frame / decode_slice / end_frame, libavcodec/avcodec.h:3062-3086) over the Tier-2 passes.  Host code only: it
+ * uses nothing but the library's public C ABI (mi355_h264_frame.h), so what it does is what any caller of Tier 2 has to do —
+ * surfaces, staging, intra schedule, descriptor, one launch set per picture. */
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include "../../include/mi355_h264_session.h"
+
+namespace {
+
+constexpr int NSETS = 2;                 /* staging sets: one is filled by the host while the other's copy is in flight */
+constexpr size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+struct Layout {                          /* byte offsets inside a staging block (host and device blocks share it) */
+    size_t desc, slices, mb, mv0, mv1, coef, ilist, istart, total;
+};
+
+struct Set {
+    uint8_t *host = nullptr;             /* pinned */
+    uint8_t *dev = nullptr;
+    void *copied = nullptr;              /* event: the block's last host -> device copy has finished */
+    bool used = false;
+};
+
+}  // namespace
+
+struct mi355_h264_session {
+    int mb_w = 0, mb_h = 0, nmb = 0, nsurf = 0, max_slices = 0;
+    int stride[2] = { 0, 0 };
+    size_t plane_off[3] = { 0, 0, 0 }, surf_bytes = 0;
+    uint8_t *surfaces = nullptr;         /* nsurf decoded pictures, then NSETS unfiltered reconstructions */
+    void **surf_done = nullptr;          /* per surface: event after its picture's loop filter */
+    bool *surf_valid = nullptr;
+    Layout lay{};
+    Set set[NSETS];
+    void *stream = nullptr, *copy_stream = nullptr;
+    uint8_t *covered = nullptr;          /* per macroblock of the open picture: some slice delivered it */
+    int32_t *level_widths = nullptr;
+    /* the open picture */
+    bool open = false;
+    int cur = 0, nslices = 0, ncovered = 0;
+    unsigned long frames = 0;
+    mi355_h264_picture_params pp{};
+
+    uint8_t *plane(int surface, int p) const { return surfaces + (size_t)surface * surf_bytes + plane_off[p]; }
+};
+
+extern "C" void mi355_h264_session_close(mi355_h264_session *s)
+{
+    if (!s) return;
+    if (s->stream) mi355_sync(s->stream);
+    if (s->copy_stream) mi355_sync(s->copy_stream);
+    for (int k = 0; k < NSETS; k++) {
+        if (s->set[k].host) mi355_host_free(s->set[k].host);
+        if (s->set[k].dev) mi355_free(s->set[k].dev);
+        if (s->set[k].copied) mi355_event_destroy(s->set[k].copied);
+    }
+    if (s->surf_done)
+        for (int i = 0; i < s->nsurf; i++)
+            if (s->surf_done[i]) mi355_event_destroy(s->surf_done[i]);
+    std::free(s->surf_done);
+    std::free(s->surf_valid);
+    std::free(s->covered);
+    std::free(s->level_widths);
+    if (s->surfaces) mi355_free(s->surfaces);
+    if (s->stream) mi355_stream_destroy(s->stream);
+    if (s->copy_stream) mi355_stream_destroy(s->copy_stream);
+    delete s;
+}
+
+extern "C" int mi355_h264_session_open(mi355_h264_session **out, const mi355_h264_session_params *p)
+{
+    if (!out || !p || p->mb_width <= 0 || p->mb_height <= 0 || p->num_surfaces < 2 || p->num_surfaces > 64 || p->max_slices < 0 || p->max_slices > 255) return -1;
+    if ((long)p->mb_width * p->mb_height >= (1L << 24)) return -1;
+    mi355_h264_session *s = new (std::nothrow) mi355_h264_session;
+    if (!s) return -3;
+    s->mb_w = p->mb_width; s->mb_h = p->mb_height; s->nmb = p->mb_width * p->mb_height;
+    s->nsurf = p->num_surfaces; s->max_slices = p->max_slices ? p->max_slices : 64;
+    /* surfaces: rows of whole 64-byte (luma) / 32-byte (chroma) pieces, the alignment the kernels' 16 / 8-byte paths want */
+    s->stride[0] = (int)up64((size_t)16 * s->mb_w); s->stride[1] = s->stride[0] / 2;
+    const size_t ysz = (size_t)s->stride[0] * 16 * s->mb_h, csz = (size_t)s->stride[1] * 8 * s->mb_h;
+    s->plane_off[0] = 0; s->plane_off[1] = ysz; s->plane_off[2] = ysz + csz; s->surf_bytes = up64(ysz + 2 * csz);
+    Layout &l = s->lay;
+    size_t o = 0;
+    l.desc = o;   o += up64(sizeof(mi355_h264_frame));
+    l.slices = o; o += up64((size_t)s->max_slices * sizeof(mi355_h264_slice));
+    l.mb = o;     o += up64((size_t)s->nmb * sizeof(mi355_h264_mb));
+    l.mv0 = o;    o += up64((size_t)s->nmb * 64);
+    l.mv1 = o;    o += up64((size_t)s->nmb * 64);
+    l.coef = o;   o += up64((size_t)s->nmb * MI355_H264_COEFS_PER_MB * 2);
+    l.ilist = o;  o += up64((size_t)s->nmb * 4);
+    l.istart = o; o += up64((size_t)(s->mb_w + 2 * s->mb_h + 2) * 4);
+    l.total = o;
+    bool ok = true;
+    s->surfaces = static_cast<uint8_t *>(mi355_malloc((size_t)(s->nsurf + NSETS) * s->surf_bytes));
+    ok = ok && s->surfaces;
+    for (int k = 0; k < NSETS && ok; k++) {
+        s->set[k].host = static_cast<uint8_t *>(mi355_host_alloc(l.total));
+        s->set[k].dev = static_cast<uint8_t *>(mi355_malloc(l.total));
+        s->set[k].copied = mi355_event_create();
+        ok = ok && s->set[k].host && s->set[k].dev && s->set[k].copied;
+    }
+    s->stream = mi355_stream_create();
+    s->copy_stream = mi355_stream_create();
+    s->surf_done = static_cast<void **>(std::calloc((size_t)s->nsurf, sizeof(void *)));
+    s->surf_valid = static_cast<bool *>(std::calloc((size_t)s->nsurf, sizeof(bool)));
+    s->covered = static_cast<uint8_t *>(std::calloc((size_t)s->nmb, 1));
+    s->level_widths = static_cast<int32_t *>(std::calloc((size_t)(s->mb_w + 2 * s->mb_h + 2), sizeof(int32_t)));
+    ok = ok && s->stream && s->copy_stream && s->surf_done && s->surf_valid && s->covered && s->level_widths;
+    for (int i = 0; i < s->nsurf && ok; i++) ok = (s->surf_done[i] = mi355_event_create()) != nullptr;
+    if (!ok) { mi355_h264_session_close(s); return -3; }
+    *out = s;
+    return 0;
+}
+
+extern "C" int mi355_h264_start_frame(mi355_h264_session *s, const mi355_h264_picture_params *pp)
+{
+    if (!s || !pp || s->open) return -1;
+    if (pp->surface < 0 || pp->surface >= s->nsurf || pp->nslots < 0 || pp->nslots > MI355_H264_MAX_SLOTS) return -1;
+    for (int i = 0; i < pp->nslots; i++) {
+        const int r = pp->ref_surface[i];
+        if (r < -1 || r >= s->nsurf || r == pp->surface) return -1;
+        if (r >= 0 && !s->surf_valid[r]) return -1;           /* a reference nobody decoded */
+    }
+    s->cur = (int)(s->frames % NSETS);
+    Set &st = s->set[s->cur];
+    if (st.used && mi355_event_sync(st.copied) != 0) return -2;   /* the host block is free once its copy has left */
+    s->pp = *pp;
+    s->nslices = 0; s->ncovered = 0;
+    std::memset(s->covered, 0, (size_t)s->nmb);
+    s->open = true;
+    return 0;
+}
+
+extern "C" int mi355_h264_decode_slice(mi355_h264_session *s, const mi355_h264_slice *hdr, int first_mb, int nmbs, const int32_t *mb_addr,
+                                       const mi355_h264_mb *mb, const int16_t *mv0, const int16_t *mv1, const int16_t *coef)
+{
+    if (!s || !s->open || !hdr || !mb || !mv0 || !coef || nmbs <= 0) return -1;
+    if (s->pp.two_lists && !mv1) return -1;
+    if (s->nslices >= s->max_slices) return -1;
+    if (!mb_addr && (first_mb < 0 || first_mb + nmbs > s->nmb)) return -1;
+    uint8_t *h = s->set[s->cur].host;
+    const Layout &l = s->lay;
+    const int sid = s->nslices;
+    std::memcpy(h + l.slices + (size_t)sid * sizeof(mi355_h264_slice), hdr, sizeof(mi355_h264_slice));
+    mi355_h264_mb *dmb = reinterpret_cast<mi355_h264_mb *>(h + l.mb);
+    if (!mb_addr) {
+        /* a run of consecutive macroblocks: the four arrays are four copies */
+        std::memcpy(dmb + first_mb, mb, (size_t)nmbs * sizeof(mi355_h264_mb));
+        std::memcpy(h + l.mv0 + (size_t)first_mb * 64, mv0, (size_t)nmbs * 64);
+        if (s->pp.two_lists) std::memcpy(h + l.mv1 + (size_t)first_mb * 64, mv1, (size_t)nmbs * 64);
+        std::memcpy(h + l.coef + (size_t)first_mb * MI355_H264_COEFS_PER_MB * 2, coef, (size_t)nmbs * MI355_H264_COEFS_PER_MB * 2);
+    }
+    for (int i = 0; i < nmbs; i++) {
+        const int a = mb_addr ? mb_addr[i] : first_mb + i;
+        if (a < 0 || a >= s->nmb) return -1;
+        if (mb_addr) {
+            dmb[a] = mb[i];
+            std::memcpy(h + l.mv0 + (size_t)a * 64, mv0 + (size_t)i * 32, 64);
+            if (s->pp.two_lists) std::memcpy(h + l.mv1 + (size_t)a * 64, mv1 + (size_t)i * 32, 64);
+            std::memcpy(h + l.coef + (size_t)a * MI355_H264_COEFS_PER_MB * 2, coef + (size_t)i * MI355_H264_COEFS_PER_MB, MI355_H264_COEFS_PER_MB * 2);
+        }
+        dmb[a].slice_id = (uint8_t)sid;
+        if (!s->covered[a]) { s->covered[a] = 1; s->ncovered++; }
+    }
+    s->nslices++;
+    return 0;
+}
+
+extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
+{
+    if (!s || !s->open) return -1;
+    s->open = false;
+    if (s->ncovered != s->nmb || s->nslices == 0) return -4;
+    Set &st = s->set[s->cur];
+    uint8_t *h = st.host, *d = st.dev;
+    const Layout &l = s->lay;
+    int width = 0;
+    int32_t *istart = reinterpret_cast<int32_t *>(h + l.istart);
+    const int levels = mi355_h264_intra_schedule(reinterpret_cast<mi355_h264_mb *>(h + l.mb), s->mb_w, s->mb_h,
+                                                 reinterpret_cast<uint32_t *>(h + l.ilist), istart, &width);
+    if (levels < 0) return -1;
+    for (int k = 0; k < levels; k++) s->level_widths[k] = istart[k + 1] - istart[k];
+    mi355_h264_frame *fr = reinterpret_cast<mi355_h264_frame *>(h + l.desc);
+    std::memset(fr, 0, sizeof(*fr));
+    fr->mb_width = s->mb_w; fr->mb_height = s->mb_h;
+    const int recon = s->nsurf + s->cur;
+    for (int p = 0; p < 3; p++) { fr->dst[p] = s->plane(s->pp.surface, p); fr->recon[p] = s->plane(recon, p); }
+    fr->dst_stride[0] = fr->recon_stride[0] = s->stride[0];
+    fr->dst_stride[1] = fr->recon_stride[1] = s->stride[1];
+    for (int i = 0; i < MI355_H264_MAX_SLOTS; i++) {
+        /* an unused slot points at the first reference (any readable surface: nothing valid names it) */
+        const int r = i < s->pp.nslots && s->pp.ref_surface[i] >= 0 ? s->pp.ref_surface[i] : (s->pp.nslots > 0 && s->pp.ref_surface[0] >= 0 ? s->pp.ref_surface[0] : s->pp.surface);
+        for (int p = 0; p < 3; p++) fr->ref[i][p] = s->plane(r, p);
+    }
+    fr->mb = reinterpret_cast<const mi355_h264_mb *>(d + l.mb);
+    fr->mv[0] = reinterpret_cast<const int16_t *>(d + l.mv0);
+    fr->mv[1] = s->pp.two_lists ? reinterpret_cast<const int16_t *>(d + l.mv1) : nullptr;
+    fr->coef = reinterpret_cast<const int16_t *>(d + l.coef);
+    fr->slices = reinterpret_cast<const mi355_h264_slice *>(d + l.slices);
+    fr->nslices = s->nslices;
+    fr->max_intra_level = levels;
+    fr->intra_list = reinterpret_cast<const uint32_t *>(d + l.ilist);
+    fr->intra_level_start = reinterpret_cast<const int32_t *>(d + l.istart);
+    fr->max_level_width = width;
+    /* one copy for the whole block (P pictures without list 1 still send the unused vector area: it is 6 % of the block) */
+    if (mi355_memcpy_h2d_async(d, h, l.total, s->stream) != 0) return -2;
+    if (mi355_event_record(st.copied, s->stream) != 0) return -2;
+    st.used = true;
+    const int rc = mi355_h264_decode_frames_levels_dev(reinterpret_cast<const mi355_h264_frame *>(d + l.desc), 1, s->mb_w, s->mb_h, levels,
+                                                       s->level_widths, s->stream);
+    if (rc != 0) return rc == -1 ? -1 : -2;
+    if (mi355_event_record(s->surf_done[s->pp.surface], s->stream) != 0) return -2;
+    s->surf_valid[s->pp.surface] = true;
+    s->frames++;
+    return 0;
+}
+
+extern "C" int mi355_h264_surface_wait(mi355_h264_session *s, int surface)
+{
+    if (!s || surface < 0 || surface >= s->nsurf || !s->surf_valid[surface]) return -1;
+    return mi355_event_sync(s->surf_done[surface]) == 0 ? 0 : -2;
+}
+
+extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3])
+{
+    if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf || !s->surf_valid[surface]) return -1;
+    /* on the copy stream, behind the picture's event: later pictures queued on the session's stream are not waited for */
+    if (mi355_stream_wait_event(s->copy_stream, s->surf_done[surface]) != 0) return -2;
+    for (int p = 0; p < 3; p++) {
+        const size_t w = (size_t)(p ? 8 : 16) * s->mb_w, rows = (size_t)(p ? 8 : 16) * s->mb_h;
+        if (!dst[p] || dst_stride[p] < (int)w) return -1;
+        if (mi355_memcpy2d_d2h_async(dst[p], (size_t)dst_stride[p], s->plane(surface, p), (size_t)s->stride[p ? 1 : 0], w, rows, s->copy_stream) != 0) return -2;
+    }
+    return mi355_sync(s->copy_stream) == 0 ? 0 : -2;
+}
+
+extern "C" int mi355_h264_put_frame(mi355_h264_session *s, int surface, const uint8_t *const src[3], const int src_stride[3])
+{
+    if (!s || !src || !src_stride || s->open || surface < 0 || surface >= s->nsurf) return -1;
+    uint8_t *img = static_cast<uint8_t *>(std::malloc(s->surf_bytes));
+    if (!img) return -3;
+    for (int p = 0; p < 3; p++) {
+        const size_t w = (size_t)(p ? 8 : 16) * s->mb_w, rows = (size_t)(p ? 8 : 16) * s->mb_h;
+        if (!src[p] || src_stride[p] < (int)w) { std::free(img); return -1; }
+        for (size_t r = 0; r < rows; r++) std::memcpy(img + s->plane_off[p] + r * (size_t)s->stride[p ? 1 : 0], src[p] + r * (size_t)src_stride[p], w);
+    }
+    /* behind everything queued (pictures that still read the surface's old contents), then wait: `img` goes away */
+    int rc = mi355_sync(s->stream) == 0 && mi355_memcpy_h2d(s->surfaces + (size_t)surface * s->surf_bytes, img, s->surf_bytes) == 0 ? 0 : -2;
+    std::free(img);
+    if (rc == 0) rc = mi355_event_record(s->surf_done[surface], s->stream) == 0 ? 0 : -2;
+    if (rc == 0) s->surf_valid[surface] = true;
+    return rc;
+}
+
+extern "C" const uint8_t *mi355_h264_surface_dev(mi355_h264_session *s, int surface, int plane, int *stride)
+{
+    if (!s || surface < 0 || surface >= s->nsurf || plane < 0 || plane > 2) return nullptr;
+    if (stride) *stride = s->stride[plane ? 1 : 0];
+    return s->plane(surface, plane);
+}
+
+extern "C" void *mi355_h264_session_stream(mi355_h264_session *s) { return s ? s->stream : nullptr; }

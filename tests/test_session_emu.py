@@ -1,0 +1,23 @@
+"""Whole-frame sessions (mi355_h264_session.h) with the product sources under the SIMT emulator."""
+import pytest
+
+import session_cases as SC
+
+
+def test_session_real_stream_in_sequence_emulated(emu):
+    """the first pictures of realshort.mp4 (I, then P pictures each predicted from the surface decoded before)"""
+    assert SC.run_stream(emu, SC.SF_NPZ, 0, 7) == 7
+
+
+def test_session_joined_in_the_middle_pipelined_emulated(emu):
+    """pictures 20..25: the first reference loaded with put_frame, pictures fetched two at a time (end_frame does not wait)"""
+    SC.run_stream(emu, SC.SF_NPZ, 20, 6, nsurf=3, sync_each=False)
+
+
+@pytest.mark.parametrize("name,how", (("b_mixed", "runs"), ("mixed_intra", "addr"), ("wide_b", "split")))
+def test_session_synthetic_pictures_emulated(emu, oracle, name, how):
+    SC.run_synth(emu, oracle, name, how)
+
+
+def test_session_argument_and_state_checks_emulated(emu):
+    SC.run_errors(emu)

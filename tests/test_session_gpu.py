@@ -1,0 +1,27 @@
+"""Whole-frame sessions (mi355_h264_session.h) on the MI355X."""
+import pytest
+
+import frame_cases
+import session_cases as SC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sync_each", (True, False))
+def test_session_real_stream_in_sequence_gpu(mi355, sync_each):
+    """all 36 pictures of realshort.mp4, every picture compared with the reference decoder's"""
+    assert SC.run_stream(mi355, SC.SF_NPZ, 0, None, nsurf=4, sync_each=sync_each) == 36
+
+
+def test_session_joined_in_the_middle_gpu(mi355):
+    SC.run_stream(mi355, SC.SF_NPZ, 17, 12, nsurf=3, sync_each=False)
+
+
+@pytest.mark.parametrize("how", ("runs", "addr", "split"))
+@pytest.mark.parametrize("name", [n for n in frame_cases.CASES if not n.startswith(("tall", "one_"))])
+def test_session_synthetic_pictures_gpu(mi355, oracle, name, how):
+    SC.run_synth(mi355, oracle, name, how)
+
+
+def test_session_argument_and_state_checks_gpu(mi355):
+    SC.run_errors(mi355)
