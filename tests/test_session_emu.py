@@ -21,3 +21,9 @@ def test_session_synthetic_pictures_emulated(emu, oracle, name, how):
 
 def test_session_argument_and_state_checks_emulated(emu):
     SC.run_errors(emu)
+
+
+def test_session_decode_then_convert_on_device_emulated(emu, oracle):
+    """f2 through a session: surfaces of the session are the converter's sources, on the session's stream"""
+    import chain_check
+    assert chain_check.run_session(emu, oracle, first=2, count=2) == 2

@@ -25,3 +25,8 @@ def test_session_synthetic_pictures_gpu(mi355, oracle, name, how):
 
 def test_session_argument_and_state_checks_gpu(mi355):
     SC.run_errors(mi355)
+
+
+def test_session_decode_then_convert_on_device_gpu(mi355, oracle):
+    import chain_check
+    assert chain_check.run_session(mi355, oracle, first=5, count=6) == 6
