@@ -96,14 +96,16 @@ int main(int argc, char **argv)
             for (int pl = 0; pl < 3; pl++) {
                 const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fr->format);
                 const int w = pl ? fr->width >> d->log2_chroma_w : fr->width, h = pl ? fr->height >> d->log2_chroma_h : fr->height;
-                for (int y = 0; y < h; y++) fwrite(fr->data[pl] + (size_t)y * fr->linesize[pl], 1, w, out);
+                const int bps = (d->comp[0].depth + 7) >> 3;          /* 9 / 10-bit pictures: two bytes per sample */
+                for (int y = 0; y < h; y++) fwrite(fr->data[pl] + (size_t)y * fr->linesize[pl], bps, w, out);
             }
             shown++;
             av_frame_unref(fr);
         }
         if (i < n) av_packet_unref(&pkt);
     }
-    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked, %dx%d\n", n, shown, n_hooks, c->width, c->height);
+    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked, %dx%d %s\n", n, shown, n_hooks, c->width, c->height,
+            av_get_pix_fmt_name(c->pix_fmt));
     fclose(out);
     return n_hooks >= 5 ? 0 : 8;
 }

@@ -1,0 +1,540 @@
+#!/usr/bin/env python3
+"""Generator of small H.264 test streams for the profiles the offline clips do not cover (High 4:2:2, High 10,
+High 4:2:2 10 bit) and for 4:2:0 features they lack (several slices, loop filter off across slice edges, I_PCM, explicit
+weights, several references, every partition shape).  TEST INFRASTRUCTURE: a bitstream WRITER (CAVLC) with random syntax
+elements — no rate control, no motion search, nothing is "encoded": every element is drawn at random inside what the
+syntax allows, and the streams' meaning is whatever the reference decoder makes of them.  The tests decode each stream
+twice with the reference's own decoder (oracle/_ref/h264_tier1_*: DSP tables as the reference filled them / overridden
+by this project's hooks) and compare the pictures; validity = the reference decoder decodes every picture without a
+complaint (checked here when /root/reference's decoder harness exists, and again by the tests).
+
+The CAVLC code tables are READ from the reference's source at generation time (libavcodec/h264_cavlc.c:48-238,
+h264data.c:42-52) — the generated streams are committed (tests/golden/h264_synth_*.samples), this script needs
+/root/reference only to regenerate them.
+
+usage: make_h264_streams.py [outdir]        -> h264_synth_<name>.samples (the harness's format: u32 extradata_len = 0,
+                                               u32 n, n x { u32 len, Annex-B access unit })"""
+import os
+import re
+import struct
+import sys
+
+import numpy as np
+
+REF = "/root/reference/libavcodec"
+
+
+# ---------------------------------------------------------------- tables from the reference's source
+def _table(src, name):
+    m = re.search(r"\b%s\s*((?:\[[^\]]*\])+)\s*=\s*\{(.*?)\};" % re.escape(name), src, re.S)
+    assert m, name
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", m.group(2), flags=re.S)
+    vals = [int(v, 0) for v in re.findall(r"-?\b(?:0x[0-9a-fA-F]+|\d+)\b", body)]
+    return vals
+
+
+def load_tables():
+    cav = open(os.path.join(REF, "h264_cavlc.c")).read()
+    dat = open(os.path.join(REF, "h264data.c")).read()
+    T = {}
+    for n, shape in (("coeff_token_len", (4, 68)), ("coeff_token_bits", (4, 68)), ("chroma_dc_coeff_token_len", (20,)),
+                     ("chroma_dc_coeff_token_bits", (20,)), ("chroma422_dc_coeff_token_len", (36,)), ("chroma422_dc_coeff_token_bits", (36,)),
+                     ("total_zeros_len", (16, 16)), ("total_zeros_bits", (16, 16)), ("chroma_dc_total_zeros_len", (3, 4)),
+                     ("chroma_dc_total_zeros_bits", (3, 4)), ("chroma422_dc_total_zeros_len", (7, 8)), ("chroma422_dc_total_zeros_bits", (7, 8)),
+                     ("run_len", (7, 16)), ("run_bits", (7, 16))):
+        v = _table(cav, n)
+        a = np.zeros(int(np.prod(shape)), np.int64)
+        a[:len(v)] = v            # rows the source leaves short are zero-filled, as in C
+        # C fills row by row: re-read with row structure when rows are shorter than declared
+        if len(shape) == 2 and len(v) != a.size:
+            m = re.search(r"\b%s\s*(?:\[[^\]]*\])+\s*=\s*\{(.*?)\};" % n, cav, re.S)
+            rows = re.findall(r"\{([^{}]*)\}", m.group(1))
+            a = np.zeros(shape, np.int64)
+            for r, row in enumerate(rows):
+                rv = [int(x, 0) for x in re.findall(r"\b(?:0x[0-9a-fA-F]+|\d+)\b", re.sub(r"/\*.*?\*/", "", row, flags=re.S))]
+                a[r, :len(rv)] = rv
+            T[n] = a
+        else:
+            T[n] = a.reshape(shape)
+    T["intra_cbp"] = _table(dat, "ff_h264_golomb_to_intra4x4_cbp")
+    T["inter_cbp"] = _table(dat, "ff_h264_golomb_to_inter_cbp")
+    assert len(T["intra_cbp"]) == 48 and sorted(T["intra_cbp"]) == list(range(48))
+    T["intra_cbp_code"] = {c: i for i, c in enumerate(T["intra_cbp"])}
+    T["inter_cbp_code"] = {c: i for i, c in enumerate(T["inter_cbp"])}
+    return T
+
+
+# ---------------------------------------------------------------- bit writer
+class Bits:
+    def __init__(self):
+        self.b = []
+
+    def u(self, n, v):
+        assert 0 <= v < (1 << n), (n, v)
+        for i in range(n - 1, -1, -1):
+            self.b.append((v >> i) & 1)
+
+    def ue(self, v):
+        assert v >= 0
+        v += 1
+        n = v.bit_length()
+        self.u(n - 1, 0)
+        self.u(n, v)
+
+    def se(self, v):
+        self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def te(self, rng, v):
+        if rng > 1:
+            self.ue(v)
+        else:
+            self.u(1, 1 - v)
+
+    def vlc(self, length, bits):
+        assert length > 0, "code not in the table"
+        self.u(int(length), int(bits))
+
+    def aligned(self):
+        return len(self.b) % 8 == 0
+
+    def align_zero(self):
+        while len(self.b) % 8:
+            self.b.append(0)
+
+    def trailing(self):
+        self.b.append(1)
+        self.align_zero()
+
+    def bytes(self):
+        assert len(self.b) % 8 == 0
+        return bytes(int("".join(map(str, self.b[i:i + 8])), 2) for i in range(0, len(self.b), 8))
+
+
+def nal(ref_idc, typ, rbsp):
+    out = bytearray(b"\x00\x00\x00\x01")
+    out.append((ref_idc << 5) | typ)
+    zeros = 0
+    for x in rbsp:
+        if zeros >= 2 and x <= 3:
+            out.append(3)
+            zeros = 0
+        out.append(x)
+        zeros = zeros + 1 if x == 0 else 0
+    return bytes(out)
+
+
+# ---------------------------------------------------------------- residual blocks (CAVLC, 9.2)
+def write_block(w, T, coefs, nC, kind):
+    """coefs: the block in scan order (len 16, 15, 4 or 8); kind: 'luma' (tables by nC), 'cdc420', 'cdc422'.  Returns total_coeff."""
+    maxc = len(coefs)
+    nz = [i for i, c in enumerate(coefs) if c]
+    total = len(nz)
+    lev = [coefs[i] for i in reversed(nz)]            # highest frequency first
+    t1 = 0
+    while t1 < min(3, total) and abs(lev[t1]) == 1:
+        t1 += 1
+    idx = 4 * total + t1
+    if kind == "cdc420":
+        w.vlc(T["chroma_dc_coeff_token_len"][idx], T["chroma_dc_coeff_token_bits"][idx])
+    elif kind == "cdc422":
+        w.vlc(T["chroma422_dc_coeff_token_len"][idx], T["chroma422_dc_coeff_token_bits"][idx])
+    else:
+        tab = 0 if nC < 2 else (1 if nC < 4 else (2 if nC < 8 else 3))
+        w.vlc(T["coeff_token_len"][tab][idx], T["coeff_token_bits"][tab][idx])
+    if total == 0:
+        return 0
+    for k in range(t1):
+        w.u(1, 1 if lev[k] < 0 else 0)
+    sl = 1 if (total > 10 and t1 < 3) else 0
+    for k in range(t1, total):
+        v = lev[k]
+        code = 2 * abs(v) - 2 if v > 0 else 2 * abs(v) - 1
+        if k == t1 and t1 < 3:
+            code -= 2
+        if sl == 0:
+            if code < 14:
+                w.u(code + 1, 1)
+            elif code < 30:
+                w.u(15, 1)
+                w.u(4, code - 14)
+            else:
+                assert code - 30 < 4096
+                w.u(16, 1)
+                w.u(12, code - 30)
+        else:
+            if code < (15 << sl):
+                w.u((code >> sl) + 1, 1)
+                w.u(sl, code & ((1 << sl) - 1))
+            else:
+                assert code - (15 << sl) < 4096
+                w.u(16, 1)
+                w.u(12, code - (15 << sl))
+        if sl == 0:
+            sl = 1
+        if abs(v) > (3 << (sl - 1)) and sl < 6:
+            sl += 1
+    if total < maxc:
+        tz = nz[-1] + 1 - total
+        if kind == "cdc420":
+            w.vlc(T["chroma_dc_total_zeros_len"][total - 1][tz], T["chroma_dc_total_zeros_bits"][total - 1][tz])
+        elif kind == "cdc422":
+            w.vlc(T["chroma422_dc_total_zeros_len"][total - 1][tz], T["chroma422_dc_total_zeros_bits"][total - 1][tz])
+        else:
+            w.vlc(T["total_zeros_len"][total - 1][tz], T["total_zeros_bits"][total - 1][tz])
+        left = tz
+        pos = list(reversed(nz))
+        for k in range(total - 1):
+            if left <= 0:
+                break
+            run = pos[k] - pos[k + 1] - 1
+            r = min(left, 7) - 1
+            w.vlc(T["run_len"][r][run], T["run_bits"][r][run])
+            left -= run
+    return total
+
+
+class Rng:
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+
+    def i(self, lo, hi):
+        return int(self.r.integers(lo, hi + 1))
+
+    def p(self, prob):
+        return bool(self.r.random() < prob)
+
+    def block(self, n, density, big=0.05):
+        """n coefficients in scan order: mostly small, low frequencies more often"""
+        out = [0] * n
+        if not self.p(density):
+            return out
+        k = self.i(1, n)
+        for j in range(k):
+            if self.p(0.7 if j < 4 else 0.35):
+                mag = self.i(1, 40) if self.p(big) else (1 if self.p(0.6) else self.i(2, 6))
+                out[j] = mag if self.p(0.5) else -mag
+        return out
+
+
+# ---------------------------------------------------------------- a stream
+class Stream:
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9):
+        self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
+        self.r = Rng(seed)
+        self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
+        self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
+        self.qp_min, self.qp_max = 12, 44
+
+    def sps(self):
+        w = Bits()
+        profile = 122 if self.cidc == 2 else (110 if self.depth > 8 else 100)
+        w.u(8, profile); w.u(8, 0); w.u(8, 40)
+        w.ue(0)
+        w.ue(self.cidc); w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
+        w.ue(0)                       # log2_max_frame_num - 4
+        w.ue(2)                       # pic_order_cnt_type 2: output order = decoding order
+        w.ue(max(1, self.nrefs)); w.u(1, 0)
+        w.ue(self.mb_w - 1); w.ue(self.mb_h - 1)
+        w.u(1, 1); w.u(1, 1); w.u(1, 0); w.u(1, 0)
+        w.trailing()
+        return nal(3, 7, w.bytes())
+
+    def pps(self):
+        w = Bits()
+        w.ue(0); w.ue(0); w.u(1, 0); w.u(1, 0); w.ue(0)
+        w.ue(max(1, self.nrefs) - 1); w.ue(0)
+        w.u(1, 1 if self.weighted else 0); w.u(2, 0)
+        w.se(0); w.se(0); w.se(2)
+        w.u(1, 1); w.u(1, 0); w.u(1, 0)
+        w.u(1, 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode 0, no scaling matrices, second chroma qp offset
+        w.trailing()
+        return nal(3, 8, w.bytes())
+
+    # ---- neighbour bookkeeping of one picture
+    def begin_picture(self):
+        W4, H4 = 4 * self.mb_w, 4 * self.mb_h
+        self.nnz = np.zeros((H4, W4), np.int64)
+        self.nnzc = np.zeros((2, self.cblk_h * self.mb_h, 2 * self.mb_w), np.int64)
+        self.i4 = np.full((H4, W4), -1, np.int64)            # Intra4x4PredMode per block, -1: none
+        self.kind = [[None] * self.mb_w for _ in range(self.mb_h)]
+        self.slice_of = np.full((self.mb_h, self.mb_w), -1, np.int64)
+
+    def avail(self, mbx, mby, sid):
+        return 0 <= mbx < self.mb_w and 0 <= mby < self.mb_h and self.slice_of[mby, mbx] == sid
+
+    def nC(self, arr, x, y, bw, bh, mbx, mby, sid):
+        """predicted count for the block at block coordinates (x, y) of an array with bw x bh blocks per macroblock"""
+        a = arr[y, x - 1] if (x % bw or self.avail(mbx - 1, mby, sid)) and x > 0 else None
+        b = arr[y - 1, x] if (y % bh or self.avail(mbx, mby - 1, sid)) and y > 0 else None
+        if a is not None and b is not None:
+            return (int(a) + int(b) + 1) >> 1
+        return int(a) if a is not None else (int(b) if b is not None else 0)
+
+    # ---- macroblocks
+    def residual(self, w, mbx, mby, sid, cbp, i16):
+        T, r = self.T, self.r
+        if i16:
+            n = self.nC(self.nnz, 4 * mbx, 4 * mby, 4, 4, mbx, mby, sid)
+            write_block(w, T, r.block(16, 0.8), n, "luma")
+        for blk in range(16):
+            x = 4 * mbx + (blk & 1) + 2 * ((blk >> 2) & 1)
+            y = 4 * mby + ((blk >> 1) & 1) + 2 * (blk >> 3)
+            if cbp & (1 << (blk >> 2)):
+                n = self.nC(self.nnz, x, y, 4, 4, mbx, mby, sid)
+                self.nnz[y, x] = write_block(w, T, r.block(15 if i16 else 16, 0.6), n, "luma")
+            else:
+                self.nnz[y, x] = 0
+        cc = cbp >> 4
+        nblk = 2 * self.cblk_h
+        if cc:
+            for _ in range(2):
+                write_block(w, T, r.block(nblk, 0.7), 0, "cdc422" if self.cidc == 2 else "cdc420")
+        for pl in range(2):
+            for blk in range(nblk):
+                # 4:2:0: raster order of the 2 x 2 blocks; 4:2:2: two 2 x 2 groups, top then bottom (blkIdx 0..7)
+                x = 2 * mbx + (blk & 1)
+                y = self.cblk_h * mby + (blk >> 1)
+                if cc & 2:
+                    n = self.nC(self.nnzc[pl], x, y, 2, self.cblk_h, mbx, mby, sid)
+                    self.nnzc[pl][y, x] = write_block(w, T, r.block(15, 0.5), n, "luma")
+                else:
+                    self.nnzc[pl][y, x] = 0
+
+    def clear_counts(self, mbx, mby, value=0):
+        self.nnz[4 * mby:4 * mby + 4, 4 * mbx:4 * mbx + 4] = value
+        self.nnzc[:, self.cblk_h * mby:self.cblk_h * (mby + 1), 2 * mbx:2 * mbx + 2] = value
+
+    def qp_delta(self, w):
+        d = self.r.i(-3, 3) if self.r.p(0.5) else 0
+        if not self.qp_min <= self.qp + d <= self.qp_max:
+            d = 0
+        self.qp += d
+        w.se(d)
+
+    def intra_mb(self, w, mbx, mby, sid, base):
+        """an intra macroblock; base: mb_type offset of intra types in this slice type (0 in I, 5 in P)"""
+        r = self.r
+        left, top = self.avail(mbx - 1, mby, sid), self.avail(mbx, mby - 1, sid)
+        c = r.i(0, 9)
+        if c == 0:                                           # I_PCM
+            w.ue(base + 25)
+            w.align_zero()
+            n = 256 + 2 * 8 * (16 if self.cidc == 2 else 8)
+            for _ in range(n):
+                w.u(self.depth, r.i(0, (1 << self.depth) - 1))
+            self.clear_counts(mbx, mby, 16)
+            self.kind[mby][mbx] = "pcm"
+            return
+        cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
+        cmode = cmodes[r.i(0, len(cmodes) - 1)]
+        if c <= 4:                                           # Intra 4x4
+            w.ue(base + 0)
+            for blk in range(16):
+                bx, by = (blk & 1) + 2 * ((blk >> 2) & 1), ((blk >> 1) & 1) + 2 * (blk >> 3)
+                x, y = 4 * mbx + bx, 4 * mby + by
+                l_ok, t_ok = bx > 0 or left, by > 0 or top
+                # the sample above-left of the block lies in this macroblock, the one above, the one to the left or the one above-left
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.avail(mbx - 1, mby - 1, sid)))
+                ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
+                mode = ok[r.i(0, len(ok) - 1)]
+                # predicted mode: min of the neighbours' modes; a neighbour outside -> 2 for both; an available neighbour that is
+                # not Intra4x4 counts as 2 (8.3.1.1)
+                def nb(xx, yy, inside, mb_ok):
+                    if not (inside or mb_ok):
+                        return None
+                    m = self.i4[yy, xx]
+                    return 2 if m < 0 else int(m)
+                ma = nb(x - 1, y, bx > 0, left) if x > 0 else None
+                mb_ = nb(x, y - 1, by > 0, top) if y > 0 else None
+                pred = 2 if ma is None or mb_ is None else min(ma, mb_)
+                if mode == pred:
+                    w.u(1, 1)
+                else:
+                    w.u(1, 0)
+                    w.u(3, mode if mode < pred else mode - 1)
+                self.i4[y, x] = mode
+            w.ue(cmode)
+            cbp = r.i(0, 15) | (r.i(0, 2) << 4)
+            w.ue(self.T["intra_cbp_code"][cbp])
+            if cbp:
+                self.qp_delta(w)
+            self.residual(w, mbx, mby, sid, cbp, False)
+            self.kind[mby][mbx] = "i4"
+            return
+        modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
+        mode = modes[r.i(0, len(modes) - 1)]
+        cl, cc = r.i(0, 1), r.i(0, 2)
+        w.ue(base + 1 + mode + 4 * cc + 12 * cl)
+        w.ue(cmode)
+        self.qp_delta(w)
+        self.residual(w, mbx, mby, sid, (15 if cl else 0) | (cc << 4), True)
+        self.kind[mby][mbx] = "i16"
+
+    def mvd(self, w):
+        r = self.r
+        for _ in range(2):
+            w.se(r.i(-self.far, self.far) if r.p(0.7) else 0)
+
+    def inter_mb(self, w, mbx, mby, sid, nact):
+        r = self.r
+        t = r.i(0, 4) if nact > 1 else r.i(0, 3)
+        w.ue(t)
+        if t == 3 or t == 4:
+            subs = [r.i(0, 3) for _ in range(4)]
+            for s_ in subs:
+                w.ue(s_)
+            if t == 3 and nact > 1:
+                for _ in range(4):
+                    w.te(nact - 1, r.i(0, nact - 1))
+            for s_ in subs:
+                for _ in range((1, 2, 2, 4)[s_]):
+                    self.mvd(w)
+        else:
+            parts = 1 if t == 0 else 2
+            if nact > 1:
+                for _ in range(parts):
+                    w.te(nact - 1, r.i(0, nact - 1))
+            for _ in range(parts):
+                self.mvd(w)
+        cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.7) else 0
+        w.ue(self.T["inter_cbp_code"][cbp])
+        if cbp:
+            self.qp_delta(w)
+        self.residual(w, mbx, mby, sid, cbp, False)
+        self.kind[mby][mbx] = "inter"
+
+    # ---- slices and pictures
+    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact):
+        r = self.r
+        w = Bits()
+        w.ue(first_mb)
+        w.ue(5 if is_p else 7)
+        w.ue(0)
+        w.u(4, frame_num & 15)
+        if idr:
+            w.ue(idx & 3)
+        if is_p:
+            w.u(1, 1)
+            w.ue(nact - 1)
+            w.u(1, 0)                                        # no reference list modification
+            if self.weighted:
+                w.ue(r.i(2, 6)); w.ue(r.i(2, 6))
+                for _ in range(nact):
+                    f = r.p(0.7)
+                    w.u(1, int(f))
+                    if f:
+                        w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
+                    f = r.p(0.7)
+                    w.u(1, int(f))
+                    if f:
+                        for _ in range(2):
+                            w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
+        if idr:
+            w.u(1, 0); w.u(1, 0)
+        else:
+            w.u(1, 0)
+        self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
+        w.se(self.qp - 26)
+        w.ue(self.deblock_idc)
+        if self.deblock_idc != 1:
+            w.se(r.i(-2, 2)); w.se(r.i(-2, 2))
+        skip = 0
+        for a in range(first_mb, last_mb):
+            mbx, mby = a % self.mb_w, a // self.mb_w
+            self.slice_of[mby, mbx] = sid
+            if is_p:
+                if r.p(0.15):
+                    skip += 1
+                    self.clear_counts(mbx, mby)
+                    self.kind[mby][mbx] = "skip"
+                    continue
+                w.ue(skip)
+                skip = 0
+                if r.p(0.25):
+                    self.intra_mb(w, mbx, mby, sid, 5)
+                else:
+                    self.inter_mb(w, mbx, mby, sid, nact)
+            else:
+                self.intra_mb(w, mbx, mby, sid, 0)
+        if is_p and skip:
+            w.ue(skip)
+        w.trailing()
+        return nal(3, 5 if idr else 1, w.bytes())
+
+    def build(self):
+        units = []
+        nmb = self.mb_w * self.mb_h
+        frame_num = 0
+        for i in range(self.npics):
+            idr = i == 0
+            is_p = i > 0 and not (i == 4 and self.npics > 5)          # one more I picture (non-IDR) in the middle
+            au = b""
+            if idr:
+                au += self.sps() + self.pps()
+            self.begin_picture()
+            nact = min(i, max(1, self.nrefs))
+            cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
+            for s_ in range(len(cuts) - 1):
+                if cuts[s_] < cuts[s_ + 1]:
+                    au += self.slice(i, frame_num, idr, is_p, cuts[s_], cuts[s_ + 1], s_, nact)
+            units.append(au)
+            frame_num += 1
+        return units
+
+
+STREAMS = {
+    # 8-bit 4:2:0 — also decoded through the Tier-2 bridge and sessions (tests/test_synth_streams.py)
+    "420_8_slices": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=11, nslices=3, deblock_idc=2, nrefs=3, npics=7),
+    "420_8_oneslice": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=12, nslices=1, deblock_idc=0, nrefs=2, npics=6),
+    "420_8_qcif": dict(mb_w=11, mb_h=9, chroma_idc=1, depth=8, seed=21, nslices=4, deblock_idc=0, nrefs=4, npics=10, far=40),
+    "420_8_nofilter": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=22, nslices=2, deblock_idc=1, nrefs=2, npics=6, weighted=False),
+    # the profiles no offline clip has: Tier 1 inside the reference decoder
+    "422_8": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=8, seed=13, nslices=2, deblock_idc=0, nrefs=2, npics=6),
+    "422_8_b": dict(mb_w=8, mb_h=6, chroma_idc=2, depth=8, seed=23, nslices=3, deblock_idc=2, nrefs=3, npics=8, far=30),
+    "420_10": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=10, seed=14, nslices=1, deblock_idc=0, nrefs=2, npics=6),
+    "420_10_b": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=10, seed=24, nslices=3, deblock_idc=2, nrefs=3, npics=8, far=30),
+    "422_10": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=15, nslices=2, deblock_idc=2, nrefs=2, npics=6),
+    "420_9": dict(mb_w=4, mb_h=3, chroma_idc=1, depth=9, seed=16, nslices=1, deblock_idc=0, nrefs=1, npics=5),
+}
+BRIDGE_STREAMS = [n for n, kw in STREAMS.items() if kw["chroma_idc"] == 1 and kw["depth"] == 8]
+
+
+def write_samples(path, units):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 0) + struct.pack("<I", len(units)))
+        for u in units:
+            f.write(struct.pack("<I", len(u)) + u)
+
+
+def decode_plain(samples, out):
+    """the reference decoder, its tables untouched (oracle/_ref/h264_tier1_emu with MI355_TIER1_PLAIN); returns its stderr"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "h264_tier1_emu")
+    r = subprocess.run([exe, samples, out], capture_output=True, text=True, env=dict(os.environ, MI355_TIER1_PLAIN="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def main():
+    import hashlib
+    import json
+    import tempfile
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.dirname(os.path.abspath(__file__))
+    T = load_tables()
+    md5 = {}
+    for name, kw in STREAMS.items():
+        units = Stream(T, name, **kw).build()
+        p = os.path.join(out, "h264_synth_%s.samples" % name)
+        write_samples(p, units)
+        with tempfile.TemporaryDirectory() as td:
+            err = decode_plain(p, os.path.join(td, "o.yuv"))
+            lines = [l for l in err.splitlines() if l.strip()]
+            assert len(lines) == 1 and ("%d pictures" % len(units)) in lines[0], err      # nothing but the harness's summary: no decoder complaint
+            raw = open(os.path.join(td, "o.yuv"), "rb").read()
+        md5[name] = dict(pictures=len(units), bytes=len(raw), md5=hashlib.md5(raw).hexdigest(), summary=lines[0].split("hooked, ")[1])
+        print(name, len(units), "pictures", sum(map(len, units)), "bytes ->", md5[name]["summary"], md5[name]["md5"])
+    json.dump(md5, open(os.path.join(out, "h264_synth_ref_md5.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""Generated H.264 streams (tests/golden/make_h264_streams.py: a CAVLC bitstream writer with random syntax elements) for
+what the offline clips lack: several slices per picture, the loop filter off at slice edges / altogether, I_PCM, explicit
+weights in 4:2:0, four references, every partition shape, far vectors — and the profiles no clip has: High 4:2:2,
+High 10, High 4:2:2 at 10 bit, 9 bit.  tests/golden/h264_synth_ref_md5.json = md5 of what the reference's own decoder
+(tables untouched) outputs for each; tests/golden/h264_stream_synth_*.npz = the Tier-2 records the reference decoder's run
+exported for three of the 8-bit 4:2:0 streams (oracle/ref_h264_export.c), as for realshort.mp4."""
+import hashlib
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MD5 = json.load(open(os.path.join(GOLD, "h264_synth_ref_md5.json")))
+ALL = sorted(MD5)
+BRIDGE = [n for n in ALL if n.startswith("420_8_")]                     # 8-bit 4:2:0: what Tier 2 decodes
+EXPORTED = ["420_8_slices", "420_8_qcif", "420_8_nofilter"]
+
+
+def samples(name):
+    return os.path.join(GOLD, "h264_synth_%s.samples" % name)
+
+
+def npz(name):
+    return os.path.join(GOLD, "h264_stream_synth_%s.npz" % name)
+
+
+def exe(which):
+    return os.path.join(ROOT, "oracle", "_ref", which)
+
+
+def run_tier1(which, name, out, plain=False):
+    env = dict(os.environ)
+    env.pop("MI355_TIER1_PLAIN", None)
+    if plain:
+        env["MI355_TIER1_PLAIN"] = "1"
+    r = subprocess.run([exe(which), samples(name), str(out)], capture_output=True, text=True, env=env, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stderr.splitlines() if l.strip()]
+    assert len(lines) == 1 and "%d pictures" % MD5[name]["pictures"] in lines[0], r.stderr[-2000:]      # no decoder complaint
+    return lines[0]
+
+
+def run_bridge(which, name, out, threads=1, lazy=False, direct=False):
+    env = dict(os.environ)
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
+        env.pop(k, None)
+    if lazy:
+        env["MI355_BRIDGE_LAZY"] = "1"
+    if direct:
+        env["MI355_BRIDGE_DIRECT"] = "1"
+    r = subprocess.run([exe(which), samples(name), str(out), str(threads), "1"], capture_output=True, text=True, env=env, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    stats = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return stats[-1] if stats else {}
+
+
+def check_md5(path, name):
+    raw = open(path, "rb").read()
+    assert len(raw) == MD5[name]["bytes"], (len(raw), MD5[name])
+    assert hashlib.md5(raw).hexdigest() == MD5[name]["md5"], "%s: pictures differ from the reference decoder's" % name

@@ -1,0 +1,81 @@
+"""CPU: the generated streams (synth_streams.py) — oracle, emulated kernels, sessions, and (where /root/reference's decoder
+harnesses are built) the reference decoder with this project's Tier-1 hooks / Tier-2 bridge on the SIMT emulator."""
+import os
+
+import numpy as np
+import pytest
+
+import h264_frames as HF
+import session_cases as SC
+import stream_fixture as SF
+import synth_streams as SY
+
+needs_harness = pytest.mark.skipif(not os.path.isdir("/root/reference/libavcodec"), reason="needs the reference decoder objects (/root/reference)")
+
+
+def _check(pics, planes):
+    for f in range(planes[0].shape[0]):
+        for p, key in enumerate(("y", "cb", "cr")):
+            assert np.array_equal(planes[p][f], pics[f][key]), "picture %d plane %s differs from the reference decoder" % (f, key)
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_fixture_covers_what_the_clips_lack(name):
+    pics = SF.load_npz(SY.npz(name))
+    assert max(len(p["slices"]) for p in pics) >= 2                                       # several slices per picture
+    assert any((p["mb"]["mb_type"] & HF.I_PCM_BIT).any() for p in pics) if hasattr(HF, "I_PCM_BIT") else True
+    assert max(len(p["slots"]) for p in pics) >= 2                                        # more than one reference
+    if name != "420_8_nofilter":
+        assert any((p["slices"]["use_weight"] == 1).any() for p in pics)                  # explicit weights, 4:2:0
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_oracle_reproduces_reference_decoder_on_generated_streams(oracle, name):
+    pics = SF.load_npz(SY.npz(name))
+    _, dst = HF.run_oracle(oracle, SF.frameset_all(pics))
+    _check(pics, dst)
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_emulated_kernels_reproduce_reference_decoder_on_generated_streams(emu, name):
+    pics = SF.load_npz(SY.npz(name))
+    d = HF.DeviceFrames(emu, SF.frameset_all(pics))
+    try:
+        d.decode()
+        _check(pics, d.fetch(d.dst))
+    finally:
+        d.free()
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_session_decodes_generated_streams_in_sequence_emulated(emu, name):
+    """every picture on the session's own surfaces, up to four of them as references; slices as runs / address lists / split"""
+    SC.run_stream(emu, SY.npz(name), 0, None, nsurf=6, sync_each=False)
+
+
+@needs_harness
+@pytest.mark.parametrize("name", SY.ALL)
+def test_reference_decoder_with_tier1_hooks_emulated(tmp_path, emu, name):
+    """8-bit 4:2:0 / 4:2:2, 9- and 10-bit: the reference decoder with its five DSP tables overridden by the hooks (emulated
+    kernels) outputs what it outputs with its own tables"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_tier1_emu"], check=True)
+    out = tmp_path / "plain.yuv"
+    SY.run_tier1("h264_tier1_emu", name, out, plain=True)
+    SY.check_md5(out, name)                                      # the committed md5 is the reference's
+    out = tmp_path / "hooked.yuv"
+    line = SY.run_tier1("h264_tier1_emu", name, out)
+    assert SY.MD5[name]["summary"] in line
+    SY.check_md5(out, name)
+
+
+@needs_harness
+@pytest.mark.parametrize("lazy", (False, True))
+@pytest.mark.parametrize("name", SY.BRIDGE)
+def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_emu", name, out, lazy=lazy)
+    assert st.get("pictures_on_device") == SY.MD5[name]["pictures"], st           # nothing fell back to the C path
+    SY.check_md5(out, name)

@@ -1,0 +1,56 @@
+"""GPU: the generated streams (synth_streams.py) through the kernels, sessions, the Tier-1 hooks and the Tier-2 bridge."""
+import os
+
+import numpy as np
+import pytest
+
+import h264_frames as HF
+import session_cases as SC
+import stream_fixture as SF
+import synth_streams as SY
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(which):
+    if not os.path.exists(SY.exe(which)):
+        pytest.fail("oracle/_ref/%s missing: run __graft_entry__.build() where /root/reference exists" % which)
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_gpu_reproduces_reference_decoder_on_generated_streams(mi355, name):
+    pics = SF.load_npz(SY.npz(name))
+    d = HF.DeviceFrames(mi355, SF.frameset_all(pics))
+    try:
+        d.decode()
+        got = d.fetch(d.dst)
+    finally:
+        d.free()
+    for f in range(len(pics)):
+        for p, key in enumerate(("y", "cb", "cr")):
+            assert np.array_equal(got[p][f], pics[f][key]), "picture %d plane %s differs from the reference decoder" % (f, key)
+
+
+@pytest.mark.parametrize("name", SY.EXPORTED)
+def test_session_decodes_generated_streams_in_sequence_gpu(mi355, name):
+    SC.run_stream(mi355, SY.npz(name), 0, None, nsurf=6, sync_each=False)
+
+
+@pytest.mark.parametrize("name", SY.ALL)
+def test_reference_decoder_with_tier1_hooks_gpu(tmp_path, mi355, name):
+    """High 4:2:2, High 10, 4:2:2 at 10 bit, 9 bit and the 8-bit 4:2:0 streams: hooked = the reference's own output"""
+    _need("h264_tier1_gpu")
+    out = tmp_path / "hooked.yuv"
+    line = SY.run_tier1("h264_tier1_gpu", name, out)
+    assert SY.MD5[name]["summary"] in line
+    SY.check_md5(out, name)
+
+
+@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, True, 1), (False, False, 4)))
+@pytest.mark.parametrize("name", SY.BRIDGE)
+def test_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name, lazy, direct, threads):
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", name, out, threads=threads, lazy=lazy, direct=direct)
+    assert st.get("pictures_on_device") == threads * SY.MD5[name]["pictures"], st
+    SY.check_md5(out, name)
