@@ -218,10 +218,11 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
+        self.bmode = bmode                                   # B pictures: 0 none, 1 implicit weights, 2 explicit weights, 3 plain average
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
 
@@ -232,10 +233,24 @@ class Stream:
         w.ue(0)
         w.ue(self.cidc); w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
         w.ue(0)                       # log2_max_frame_num - 4
-        w.ue(2)                       # pic_order_cnt_type 2: output order = decoding order
+        if self.bmode:
+            w.ue(0); w.ue(2)          # pic_order_cnt_type 0, 6 bits of pic_order_cnt_lsb
+        else:
+            w.ue(2)                   # pic_order_cnt_type 2: output order = decoding order
         w.ue(max(1, self.nrefs)); w.u(1, 0)
         w.ue(self.mb_w - 1); w.ue(self.mb_h - 1)
-        w.u(1, 1); w.u(1, 1); w.u(1, 0); w.u(1, 0)
+        w.u(1, 1); w.u(1, 1); w.u(1, 0)
+        if self.bmode:
+            # VUI with nothing but the bitstream restrictions: one picture of reordering (the decoder need not guess)
+            w.u(1, 1)
+            for _ in range(4):
+                w.u(1, 0)             # aspect ratio, overscan, video signal type, chroma location
+            for _ in range(4):
+                w.u(1, 0)             # timing, NAL HRD, VCL HRD, pic_struct
+            w.u(1, 1)
+            w.u(1, 1); w.ue(0); w.ue(0); w.ue(16); w.ue(16); w.ue(1); w.ue(max(2, self.nrefs))
+        else:
+            w.u(1, 0)
         w.trailing()
         return nal(3, 7, w.bytes())
 
@@ -243,7 +258,7 @@ class Stream:
         w = Bits()
         w.ue(0); w.ue(0); w.u(1, 0); w.u(1, 0); w.ue(0)
         w.ue(max(1, self.nrefs) - 1); w.ue(0)
-        w.u(1, 1 if self.weighted else 0); w.u(2, 0)
+        w.u(1, 1 if self.weighted else 0); w.u(2, (0, 2, 1, 0)[self.bmode])
         w.se(0); w.se(0); w.se(2)
         w.u(1, 1); w.u(1, 0); w.u(1, 0)
         w.u(1, 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode 0, no scaling matrices, second chroma qp offset
@@ -403,16 +418,84 @@ class Stream:
         self.residual(w, mbx, mby, sid, cbp, False)
         self.kind[mby][mbx] = "inter"
 
+    def b_mb(self, w, mbx, mby, sid, nact):
+        """a B macroblock: direct, 16x16 / 16x8 / 8x16 from list 0, list 1 or both, or four sub-macroblocks (Table 7-14, 7-18)"""
+        r = self.r
+        L0, L1, BI = 1, 2, 3
+        t = r.i(0, 22)
+        w.ue(t)
+        if t == 22:
+            subs = [r.i(0, 12) for _ in range(4)]
+            for s_ in subs:
+                w.ue(s_)
+            spred = {0: 0, 1: L0, 2: L1, 3: BI, 4: L0, 5: L0, 6: L1, 7: L1, 8: BI, 9: BI, 10: L0, 11: L1, 12: BI}
+            sparts = {0: 0, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 2, 8: 2, 9: 2, 10: 4, 11: 4, 12: 4}
+            for lst in (L0, L1):
+                if nact > 1:
+                    for s_ in subs:
+                        if spred[s_] & lst:
+                            w.te(nact - 1, r.i(0, nact - 1))
+            for lst in (L0, L1):
+                for s_ in subs:
+                    if spred[s_] & lst:
+                        for _ in range(sparts[s_]):
+                            self.mvd(w)
+        elif t > 0:
+            if t <= 3:
+                preds = [(L0, L1, BI)[t - 1]]
+            else:
+                pair = {4: (L0, L0), 6: (L1, L1), 8: (L0, L1), 10: (L1, L0), 12: (L0, BI), 14: (L1, BI), 16: (BI, L0), 18: (BI, L1), 20: (BI, BI)}
+                preds = list(pair[t & ~1])
+            for lst in (L0, L1):
+                if nact > 1:
+                    for pr in preds:
+                        if pr & lst:
+                            w.te(nact - 1, r.i(0, nact - 1))
+            for lst in (L0, L1):
+                for pr in preds:
+                    if pr & lst:
+                        self.mvd(w)
+        cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.6) else 0
+        w.ue(self.T["inter_cbp_code"][cbp])
+        if cbp:
+            self.qp_delta(w)
+        self.residual(w, mbx, mby, sid, cbp, False)
+        self.kind[mby][mbx] = "inter"
+
     # ---- slices and pictures
-    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact):
+    def weight_table(self, w, n, lists):
+        r = self.r
+        w.ue(r.i(2, 6)); w.ue(r.i(2, 6))
+        for _ in range(lists):
+            for _ in range(n):
+                f = r.p(0.7)
+                w.u(1, int(f))
+                if f:
+                    w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
+                f = r.p(0.7)
+                w.u(1, int(f))
+                if f:
+                    for _ in range(2):
+                        w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
+
+    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact, is_b=False, poc=None, ref_idc=3):
         r = self.r
         w = Bits()
         w.ue(first_mb)
-        w.ue(5 if is_p else 7)
+        w.ue(6 if is_b else (5 if is_p else 7))
         w.ue(0)
         w.u(4, frame_num & 15)
         if idr:
             w.ue(idx & 3)
+        if poc is not None:
+            w.u(6, poc & 63)
+        if is_b:
+            w.u(1, r.i(0, 1))                                # direct_spatial_mv_pred_flag
+            w.u(1, 1)
+            w.ue(nact - 1); w.ue(nact - 1)
+            w.u(1, 0); w.u(1, 0)                             # no reference list modification, either list
+            if self.bmode == 2:
+                self.weight_table(w, nact, 2)
         if is_p:
             w.u(1, 1)
             w.ue(nact - 1)
@@ -431,7 +514,7 @@ class Stream:
                             w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
         if idr:
             w.u(1, 0); w.u(1, 0)
-        else:
+        elif ref_idc:
             w.u(1, 0)
         self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
         w.se(self.qp - 26)
@@ -442,7 +525,7 @@ class Stream:
         for a in range(first_mb, last_mb):
             mbx, mby = a % self.mb_w, a // self.mb_w
             self.slice_of[mby, mbx] = sid
-            if is_p:
+            if is_p or is_b:
                 if r.p(0.15):
                     skip += 1
                     self.clear_counts(mbx, mby)
@@ -450,18 +533,22 @@ class Stream:
                     continue
                 w.ue(skip)
                 skip = 0
-                if r.p(0.25):
-                    self.intra_mb(w, mbx, mby, sid, 5)
+                if r.p(0.25 if is_p else 0.15):
+                    self.intra_mb(w, mbx, mby, sid, 5 if is_p else 23)
+                elif is_b:
+                    self.b_mb(w, mbx, mby, sid, nact)
                 else:
                     self.inter_mb(w, mbx, mby, sid, nact)
             else:
                 self.intra_mb(w, mbx, mby, sid, 0)
-        if is_p and skip:
+        if (is_p or is_b) and skip:
             w.ue(skip)
         w.trailing()
-        return nal(3, 5 if idr else 1, w.bytes())
+        return nal(ref_idc, 5 if idr else 1, w.bytes())
 
     def build(self):
+        if self.bmode:
+            return self.build_b()
         units = []
         nmb = self.mb_w * self.mb_h
         frame_num = 0
@@ -481,12 +568,47 @@ class Stream:
             frame_num += 1
         return units
 
+    def build_b(self):
+        """I0 P4 b2 P8 b6 ... in decoding order (numbers: picture order counts): the B pictures are not references and lie
+        between two of their references"""
+        units = []
+        nmb = self.mb_w * self.mb_h
+        order = [("I", 0)]
+        k = 1
+        while len(order) < self.npics:
+            order.append(("P", 4 * k))
+            if len(order) < self.npics:
+                order.append(("B", 4 * k - 2))
+            k += 1
+        prev_ref_frame_num, nref_pics = -1, 0
+        for i, (kind, poc) in enumerate(order):
+            idr = i == 0
+            is_ref = kind != "B"
+            frame_num = 0 if idr else prev_ref_frame_num + 1
+            au = b""
+            if idr:
+                au += self.sps() + self.pps()
+            self.begin_picture()
+            nact = min(nref_pics, max(1, self.nrefs))
+            cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
+            for s_ in range(len(cuts) - 1):
+                if cuts[s_] < cuts[s_ + 1]:
+                    au += self.slice(i, frame_num, idr, kind == "P", cuts[s_], cuts[s_ + 1], s_, nact, is_b=kind == "B", poc=poc, ref_idc=2 if is_ref else 0)
+            units.append(au)
+            if is_ref:
+                prev_ref_frame_num = frame_num
+                nref_pics += 1
+        return units
+
 
 STREAMS = {
     # 8-bit 4:2:0 — also decoded through the Tier-2 bridge and sessions (tests/test_synth_streams.py)
     "420_8_slices": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=11, nslices=3, deblock_idc=2, nrefs=3, npics=7),
     "420_8_oneslice": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=12, nslices=1, deblock_idc=0, nrefs=2, npics=6),
     "420_8_qcif": dict(mb_w=11, mb_h=9, chroma_idc=1, depth=8, seed=21, nslices=4, deblock_idc=0, nrefs=4, npics=10, far=40),
+    "420_8_b_implicit": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=31, nslices=2, deblock_idc=0, nrefs=3, npics=9, bmode=1, far=20),
+    "420_8_b_explicit": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=32, nslices=1, deblock_idc=0, nrefs=2, npics=7, bmode=2),
+    "420_8_b_average": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=33, nslices=3, deblock_idc=2, nrefs=3, npics=7, bmode=3, weighted=False),
     "420_8_nofilter": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=22, nslices=2, deblock_idc=1, nrefs=2, npics=6, weighted=False),
     # the profiles no offline clip has: Tier 1 inside the reference decoder
     "422_8": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=8, seed=13, nslices=2, deblock_idc=0, nrefs=2, npics=6),
@@ -495,6 +617,8 @@ STREAMS = {
     "420_10_b": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=10, seed=24, nslices=3, deblock_idc=2, nrefs=3, npics=8, far=30),
     "422_10": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=15, nslices=2, deblock_idc=2, nrefs=2, npics=6),
     "420_9": dict(mb_w=4, mb_h=3, chroma_idc=1, depth=9, seed=16, nslices=1, deblock_idc=0, nrefs=1, npics=5),
+    "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
+    "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }
 BRIDGE_STREAMS = [n for n, kw in STREAMS.items() if kw["chroma_idc"] == 1 and kw["depth"] == 8]
 

@@ -33,7 +33,7 @@ def test_gpu_reproduces_reference_decoder_on_generated_streams(mi355, name):
 
 @pytest.mark.parametrize("name", SY.EXPORTED)
 def test_session_decodes_generated_streams_in_sequence_gpu(mi355, name):
-    SC.run_stream(mi355, SY.npz(name), 0, None, nsurf=6, sync_each=False)
+    SC.run_stream(mi355, SY.npz(name), 0, None, nsurf=8, sync_each=False)
 
 
 @pytest.mark.parametrize("name", SY.ALL)
