@@ -80,7 +80,8 @@ static void *decode_thread(void *vp)
                     for (int pl = 0; pl < 3; pl++) {
                         const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fr->format);
                         const int w = pl ? fr->width >> d->log2_chroma_w : fr->width, h = pl ? fr->height >> d->log2_chroma_h : fr->height;
-                        for (int y = 0; y < h; y++) fwrite(fr->data[pl] + (size_t)y * fr->linesize[pl], 1, (size_t)w, out);
+                        const size_t bps = (size_t)(d->comp[0].depth + 7) >> 3;      /* 9 / 10-bit pictures: two bytes per sample */
+                        for (int y = 0; y < h; y++) fwrite(fr->data[pl] + (size_t)y * fr->linesize[pl], bps, (size_t)w, out);
                     }
                 a->shown++;
                 av_frame_unref(fr);

@@ -218,10 +218,11 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
+        self.t8x8 = t8x8                                     # transform_8x8_mode_flag: Intra 8x8 and the 8x8 transform of inter macroblocks
         self.bmode = bmode                                   # B pictures: 0 none, 1 implicit weights, 2 explicit weights, 3 plain average
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
@@ -261,7 +262,7 @@ class Stream:
         w.u(1, 1 if self.weighted else 0); w.u(2, (0, 2, 1, 0)[self.bmode])
         w.se(0); w.se(0); w.se(2)
         w.u(1, 1); w.u(1, 0); w.u(1, 0)
-        w.u(1, 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode 0, no scaling matrices, second chroma qp offset
+        w.u(1, 1 if self.t8x8 else 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode, no scaling matrices, second chroma qp offset
         w.trailing()
         return nal(3, 8, w.bytes())
 
@@ -342,8 +343,37 @@ class Stream:
             return
         cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
         cmode = cmodes[r.i(0, len(cmodes) - 1)]
+        if c <= 4 and self.t8x8 and r.p(0.5):                # Intra 8x8
+            w.ue(base + 0)
+            w.u(1, 1)
+            for b8 in range(4):
+                bx, by = 2 * (b8 & 1), 2 * (b8 >> 1)
+                x, y = 4 * mbx + bx, 4 * mby + by
+                l_ok, t_ok = bx > 0 or left, by > 0 or top
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.avail(mbx - 1, mby - 1, sid)))
+                ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
+                mode = ok[r.i(0, len(ok) - 1)]
+                ma = (2 if self.i4[y, x - 1] < 0 else int(self.i4[y, x - 1])) if (x > 0 and (bx > 0 or left)) else None
+                mb_ = (2 if self.i4[y - 1, x] < 0 else int(self.i4[y - 1, x])) if (y > 0 and (by > 0 or top)) else None
+                pred = 2 if ma is None or mb_ is None else min(ma, mb_)
+                if mode == pred:
+                    w.u(1, 1)
+                else:
+                    w.u(1, 0)
+                    w.u(3, mode if mode < pred else mode - 1)
+                self.i4[y:y + 2, x:x + 2] = mode
+            w.ue(cmode)
+            cbp = r.i(0, 15) | (r.i(0, 2) << 4)
+            w.ue(self.T["intra_cbp_code"][cbp])
+            if cbp:
+                self.qp_delta(w)
+            self.residual(w, mbx, mby, sid, cbp, False)
+            self.kind[mby][mbx] = "i8"
+            return
         if c <= 4:                                           # Intra 4x4
             w.ue(base + 0)
+            if self.t8x8:
+                w.u(1, 0)
             for blk in range(16):
                 bx, by = (blk & 1) + 2 * ((blk >> 2) & 1), ((blk >> 1) & 1) + 2 * (blk >> 3)
                 x, y = 4 * mbx + bx, 4 * mby + by
@@ -394,8 +424,10 @@ class Stream:
         r = self.r
         t = r.i(0, 4) if nact > 1 else r.i(0, 3)
         w.ue(t)
+        small = False
         if t == 3 or t == 4:
             subs = [r.i(0, 3) for _ in range(4)]
+            small = any(subs)
             for s_ in subs:
                 w.ue(s_)
             if t == 3 and nact > 1:
@@ -413,6 +445,8 @@ class Stream:
                 self.mvd(w)
         cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.7) else 0
         w.ue(self.T["inter_cbp_code"][cbp])
+        if self.t8x8 and (cbp & 15) and not small:
+            w.u(1, r.i(0, 1))                                # transform_size_8x8_flag
         if cbp:
             self.qp_delta(w)
         self.residual(w, mbx, mby, sid, cbp, False)
@@ -457,6 +491,8 @@ class Stream:
                         self.mvd(w)
         cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.6) else 0
         w.ue(self.T["inter_cbp_code"][cbp])
+        if self.t8x8 and (cbp & 15) and not (t == 22 and any(s_ > 3 for s_ in subs)):
+            w.u(1, r.i(0, 1))                                # transform_size_8x8_flag (direct_8x8_inference_flag = 1)
         if cbp:
             self.qp_delta(w)
         self.residual(w, mbx, mby, sid, cbp, False)
@@ -609,6 +645,7 @@ STREAMS = {
     "420_8_b_implicit": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=31, nslices=2, deblock_idc=0, nrefs=3, npics=9, bmode=1, far=20),
     "420_8_b_explicit": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=32, nslices=1, deblock_idc=0, nrefs=2, npics=7, bmode=2),
     "420_8_b_average": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=33, nslices=3, deblock_idc=2, nrefs=3, npics=7, bmode=3, weighted=False),
+    "420_8_t8x8": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=41, nslices=3, deblock_idc=0, nrefs=3, npics=9, bmode=1, far=20, t8x8=True),
     "420_8_nofilter": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=22, nslices=2, deblock_idc=1, nrefs=2, npics=6, weighted=False),
     # the profiles no offline clip has: Tier 1 inside the reference decoder
     "422_8": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=8, seed=13, nslices=2, deblock_idc=0, nrefs=2, npics=6),
@@ -617,6 +654,9 @@ STREAMS = {
     "420_10_b": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=10, seed=24, nslices=3, deblock_idc=2, nrefs=3, npics=8, far=30),
     "422_10": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=15, nslices=2, deblock_idc=2, nrefs=2, npics=6),
     "420_9": dict(mb_w=4, mb_h=3, chroma_idc=1, depth=9, seed=16, nslices=1, deblock_idc=0, nrefs=1, npics=5),
+    "422_8_t8x8": dict(mb_w=6, mb_h=5, chroma_idc=2, depth=8, seed=42, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=3, weighted=False, t8x8=True),
+    "420_10_t8x8": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=10, seed=43, nslices=2, deblock_idc=2, nrefs=2, npics=7, bmode=1, t8x8=True),
+    "422_10_t8x8": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=44, nslices=1, deblock_idc=0, nrefs=2, npics=6, t8x8=True),
     "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
     "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }

@@ -82,3 +82,16 @@ def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
     st = SY.run_bridge("h264_bridge_emu", name, out, lazy=lazy)
     assert st.get("pictures_on_device") == SY.MD5[name]["pictures"], st           # nothing fell back to the C path
     SY.check_md5(out, name)
+
+
+@needs_harness
+@pytest.mark.parametrize("name", [n for n in SY.ALL if n not in SY.BRIDGE])
+def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name):
+    """High 4:2:2, 9 / 10 bit: the bridge says so once and the reference's C path decodes the stream — same pictures, nothing on
+    the device"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_emu", name, out)
+    assert st.get("pictures_on_device") == 0 and st.get("pictures_output") == SY.MD5[name]["pictures"], st
+    SY.check_md5(out, name)

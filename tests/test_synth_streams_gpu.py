@@ -46,11 +46,20 @@ def test_reference_decoder_with_tier1_hooks_gpu(tmp_path, mi355, name):
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, True, 1), (False, False, 4)))
+@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 3)))
 @pytest.mark.parametrize("name", SY.BRIDGE)
 def test_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name, lazy, direct, threads):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
     st = SY.run_bridge("h264_bridge_gpu", name, out, threads=threads, lazy=lazy, direct=direct)
     assert st.get("pictures_on_device") == threads * SY.MD5[name]["pictures"], st
+    SY.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", ("422_8_b", "420_10_t8x8"))
+def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name):
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", name, out)
+    assert st.get("pictures_on_device") == 0 and st.get("pictures_output") == SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
