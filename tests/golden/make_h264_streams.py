@@ -59,6 +59,9 @@ def load_tables():
     T["intra_cbp"] = _table(dat, "ff_h264_golomb_to_intra4x4_cbp")
     T["inter_cbp"] = _table(dat, "ff_h264_golomb_to_inter_cbp")
     assert len(T["intra_cbp"]) == 48 and sorted(T["intra_cbp"]) == list(range(48))
+    T["intra_cbp_gray_code"] = {c: i for i, c in enumerate(_table(cav, "golomb_to_intra4x4_cbp_gray"))}
+    T["inter_cbp_gray_code"] = {c: i for i, c in enumerate(_table(cav, "golomb_to_inter_cbp_gray"))}
+    assert len(T["intra_cbp_gray_code"]) == 16 and len(T["inter_cbp_gray_code"]) == 16
     T["intra_cbp_code"] = {c: i for i, c in enumerate(T["intra_cbp"])}
     T["inter_cbp_code"] = {c: i for i, c in enumerate(T["inter_cbp"])}
     return T
@@ -229,10 +232,13 @@ class Stream:
 
     def sps(self):
         w = Bits()
-        profile = 122 if self.cidc == 2 else (110 if self.depth > 8 else 100)
+        profile = 244 if self.cidc == 3 else (122 if self.cidc == 2 else (110 if self.depth > 8 else 100))
         w.u(8, profile); w.u(8, 0); w.u(8, 40)
         w.ue(0)
-        w.ue(self.cidc); w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
+        w.ue(self.cidc)
+        if self.cidc == 3:
+            w.u(1, 0)                 # separate_colour_plane_flag
+        w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
         w.ue(0)                       # log2_max_frame_num - 4
         if self.bmode:
             w.ue(0); w.ue(2)          # pic_order_cnt_type 0, 6 bits of pic_order_cnt_lsb
@@ -270,6 +276,7 @@ class Stream:
     def begin_picture(self):
         W4, H4 = 4 * self.mb_w, 4 * self.mb_h
         self.nnz = np.zeros((H4, W4), np.int64)
+        self.nnz444 = [self.nnz, np.zeros((H4, W4), np.int64), np.zeros((H4, W4), np.int64)]      # 4:4:4: Cb and Cr coded like luma
         self.nnzc = np.zeros((2, self.cblk_h * self.mb_h, 2 * self.mb_w), np.int64)
         self.i4 = np.full((H4, W4), -1, np.int64)            # Intra4x4PredMode per block, -1: none
         self.kind = [[None] * self.mb_w for _ in range(self.mb_h)]
@@ -289,17 +296,21 @@ class Stream:
     # ---- macroblocks
     def residual(self, w, mbx, mby, sid, cbp, i16):
         T, r = self.T, self.r
-        if i16:
-            n = self.nC(self.nnz, 4 * mbx, 4 * mby, 4, 4, mbx, mby, sid)
-            write_block(w, T, r.block(16, 0.8), n, "luma")
-        for blk in range(16):
-            x = 4 * mbx + (blk & 1) + 2 * ((blk >> 2) & 1)
-            y = 4 * mby + ((blk >> 1) & 1) + 2 * (blk >> 3)
-            if cbp & (1 << (blk >> 2)):
-                n = self.nC(self.nnz, x, y, 4, 4, mbx, mby, sid)
-                self.nnz[y, x] = write_block(w, T, r.block(15 if i16 else 16, 0.6), n, "luma")
-            else:
-                self.nnz[y, x] = 0
+        for pl in range(3 if self.cidc == 3 else 1):
+            nnz = self.nnz444[pl]
+            if i16:
+                n = self.nC(nnz, 4 * mbx, 4 * mby, 4, 4, mbx, mby, sid)
+                write_block(w, T, r.block(16, 0.8), n, "luma")
+            for blk in range(16):
+                x = 4 * mbx + (blk & 1) + 2 * ((blk >> 2) & 1)
+                y = 4 * mby + ((blk >> 1) & 1) + 2 * (blk >> 3)
+                if cbp & (1 << (blk >> 2)):
+                    n = self.nC(nnz, x, y, 4, 4, mbx, mby, sid)
+                    nnz[y, x] = write_block(w, T, r.block(15 if i16 else 16, 0.6), n, "luma")
+                else:
+                    nnz[y, x] = 0
+        if self.cidc == 3:
+            return
         cc = cbp >> 4
         nblk = 2 * self.cblk_h
         if cc:
@@ -316,8 +327,31 @@ class Stream:
                 else:
                     self.nnzc[pl][y, x] = 0
 
+    def intra_tail(self, w, cmode):
+        """intra_chroma_pred_mode and coded_block_pattern of an Intra NxN macroblock (4:4:4: no chroma mode, luma bits only)"""
+        r = self.r
+        cbp = r.i(0, 15) | (r.i(0, 2) << 4)
+        if self.cidc == 3:
+            cbp &= 15
+            w.ue(self.T["intra_cbp_gray_code"][cbp])
+        else:
+            w.ue(cmode)
+            w.ue(self.T["intra_cbp_code"][cbp])
+        return cbp
+
+    def inter_cbp(self, w, prob):
+        r = self.r
+        cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(prob) else 0
+        if self.cidc == 3:
+            cbp &= 15
+            w.ue(self.T["inter_cbp_gray_code"][cbp])
+        else:
+            w.ue(self.T["inter_cbp_code"][cbp])
+        return cbp
+
     def clear_counts(self, mbx, mby, value=0):
-        self.nnz[4 * mby:4 * mby + 4, 4 * mbx:4 * mbx + 4] = value
+        for a in self.nnz444:
+            a[4 * mby:4 * mby + 4, 4 * mbx:4 * mbx + 4] = value
         self.nnzc[:, self.cblk_h * mby:self.cblk_h * (mby + 1), 2 * mbx:2 * mbx + 2] = value
 
     def qp_delta(self, w):
@@ -335,7 +369,7 @@ class Stream:
         if c == 0:                                           # I_PCM
             w.ue(base + 25)
             w.align_zero()
-            n = 256 + 2 * 8 * (16 if self.cidc == 2 else 8)
+            n = 768 if self.cidc == 3 else 256 + 2 * 8 * (16 if self.cidc == 2 else 8)
             for _ in range(n):
                 w.u(self.depth, r.i(0, (1 << self.depth) - 1))
             self.clear_counts(mbx, mby, 16)
@@ -362,9 +396,7 @@ class Stream:
                     w.u(1, 0)
                     w.u(3, mode if mode < pred else mode - 1)
                 self.i4[y:y + 2, x:x + 2] = mode
-            w.ue(cmode)
-            cbp = r.i(0, 15) | (r.i(0, 2) << 4)
-            w.ue(self.T["intra_cbp_code"][cbp])
+            cbp = self.intra_tail(w, cmode)
             if cbp:
                 self.qp_delta(w)
             self.residual(w, mbx, mby, sid, cbp, False)
@@ -398,9 +430,7 @@ class Stream:
                     w.u(1, 0)
                     w.u(3, mode if mode < pred else mode - 1)
                 self.i4[y, x] = mode
-            w.ue(cmode)
-            cbp = r.i(0, 15) | (r.i(0, 2) << 4)
-            w.ue(self.T["intra_cbp_code"][cbp])
+            cbp = self.intra_tail(w, cmode)
             if cbp:
                 self.qp_delta(w)
             self.residual(w, mbx, mby, sid, cbp, False)
@@ -409,8 +439,11 @@ class Stream:
         modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
         mode = modes[r.i(0, len(modes) - 1)]
         cl, cc = r.i(0, 1), r.i(0, 2)
+        if self.cidc == 3:
+            cc = 0
         w.ue(base + 1 + mode + 4 * cc + 12 * cl)
-        w.ue(cmode)
+        if self.cidc != 3:
+            w.ue(cmode)
         self.qp_delta(w)
         self.residual(w, mbx, mby, sid, (15 if cl else 0) | (cc << 4), True)
         self.kind[mby][mbx] = "i16"
@@ -443,8 +476,7 @@ class Stream:
                     w.te(nact - 1, r.i(0, nact - 1))
             for _ in range(parts):
                 self.mvd(w)
-        cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.7) else 0
-        w.ue(self.T["inter_cbp_code"][cbp])
+        cbp = self.inter_cbp(w, 0.7)
         if self.t8x8 and (cbp & 15) and not small:
             w.u(1, r.i(0, 1))                                # transform_size_8x8_flag
         if cbp:
@@ -489,8 +521,7 @@ class Stream:
                 for pr in preds:
                     if pr & lst:
                         self.mvd(w)
-        cbp = (r.i(0, 15) | (r.i(0, 2) << 4)) if r.p(0.6) else 0
-        w.ue(self.T["inter_cbp_code"][cbp])
+        cbp = self.inter_cbp(w, 0.6)
         if self.t8x8 and (cbp & 15) and not (t == 22 and any(s_ > 3 for s_ in subs)):
             w.u(1, r.i(0, 1))                                # transform_size_8x8_flag (direct_8x8_inference_flag = 1)
         if cbp:
@@ -657,10 +688,13 @@ STREAMS = {
     "422_8_t8x8": dict(mb_w=6, mb_h=5, chroma_idc=2, depth=8, seed=42, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=3, weighted=False, t8x8=True),
     "420_10_t8x8": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=10, seed=43, nslices=2, deblock_idc=2, nrefs=2, npics=7, bmode=1, t8x8=True),
     "422_10_t8x8": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=44, nslices=1, deblock_idc=0, nrefs=2, npics=6, t8x8=True),
+    "444_8": dict(mb_w=6, mb_h=4, chroma_idc=3, depth=8, seed=51, nslices=3, deblock_idc=2, nrefs=3, npics=7),
+    "444_8_b_t8x8": dict(mb_w=7, mb_h=5, chroma_idc=3, depth=8, seed=52, nslices=2, deblock_idc=0, nrefs=2, npics=9, bmode=1, t8x8=True, far=20),
+    "444_10": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=10, seed=53, nslices=2, deblock_idc=0, nrefs=2, npics=6, bmode=2),
     "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
     "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }
-BRIDGE_STREAMS = [n for n, kw in STREAMS.items() if kw["chroma_idc"] == 1 and kw["depth"] == 8]
+BRIDGE_STREAMS = [n for n, kw in STREAMS.items() if kw["chroma_idc"] in (1, 3) and kw["depth"] == 8]
 
 
 def write_samples(path, units):
