@@ -794,7 +794,7 @@ __device__ __forceinline__ void lf_chroma_intra_line(int p1, int &p0, int &q0, i
 __device__ __forceinline__ int f3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
 __device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
 
-__device__ inline int pred_dir_px(int mode, int N, int x, int y, const int16_t *T, const int16_t *L)
+__device__ inline int pred_dir_px(int mode, int N, int x, int y, const uint16_t *T, const uint16_t *L)
 {
     switch (mode) {
     case 0: return T[x];
@@ -848,7 +848,7 @@ __device__ __host__ __forceinline__ int pred_luma_needs(int mode)
 }
 
 /* DC-family value for an NxN luma block from the (already prepared) vectors */
-__device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int16_t *L, int mid = 128)
+__device__ inline int pred_dc_value(int mode, int N, const uint16_t *T, const uint16_t *L, int mid = 128)
 {
     int st = 0, sl = 0;
     for (int i = 0; i < N; i++) { st += T[i]; sl += L[i]; }
@@ -861,7 +861,7 @@ __device__ inline int pred_dc_value(int mode, int N, const int16_t *T, const int
 
 /* plane prediction parameters (h264pred_template.c:434-481 for N=16, :768-802 for N=8):
  * pixel(x,y) = clip((a + x*H + y*V) >> 5).  top[-1..N-1], left[-1..N-1]. */
-__device__ inline void pred_plane_params(int N, const int16_t *top, const int16_t *left, int &a, int &H, int &V)
+__device__ inline void pred_plane_params(int N, const uint16_t *top, const uint16_t *left, int &a, int &H, int &V)
 {
     const int half = N >> 1;
     H = 0; V = 0;
@@ -885,10 +885,10 @@ __device__ inline void pred_plane_params(int N, const int16_t *top, const int16_
  * when chroma_format_idc == 2).  `mode` is the reference's table slot (h264pred.h:34-88).
  * Writes the NxN block to out[y*pitch+x] (LDS or global). */
 struct PredScratch {
-    int16_t T[1 + 32];
-    int16_t L[1 + 16];
-    int16_t fT[1 + 16];
-    int16_t fL[1 + 8];
+    uint16_t T[1 + 32];            /* unsigned: a 9 / 10-bit plane may hold any 16-bit value (transform bypass does not clip), and the reference sums its samples as unsigned */
+    uint16_t L[1 + 16];
+    uint16_t fT[1 + 16];
+    uint16_t fL[1 + 8];
 };
 
 /* PX / BD: sample type and bit depth of the output (uint8_t / 8 for everything but the 9 / 10-bit Tier-1 tables) */
@@ -898,7 +898,7 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
 {
     constexpr int MAXV = (1 << BD) - 1, MID = 1 << (BD - 1);
     const int lane = lane_id();
-    const int16_t *T = s.T + 1, *L = s.L + 1;
+    const uint16_t *T = s.T + 1, *L = s.L + 1;
     if (kind == 0 || kind == 1) {
         const int N = kind == 0 ? 4 : 8;
         const int needs = pred_luma_needs(mode);

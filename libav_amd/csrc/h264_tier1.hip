@@ -579,7 +579,7 @@ void ff_h264chroma_init_mi355x(H264ChromaContext *c, int bit_depth)
 /* intra prediction                                                            */
 /* ------------------------------------------------------------------------- */
 struct PredJob {
-    int16_t T[1 + 32], L[1 + 16];
+    uint16_t T[1 + 32], L[1 + 16];
     int kind, mode, has_tl, has_tr;
 };
 __global__ void __launch_bounds__(64) k_pred(const PredJob *jp, uint8_t *out, int pitch)

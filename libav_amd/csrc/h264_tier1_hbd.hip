@@ -466,7 +466,7 @@ LF_IN(h_lf_chroma422_intra, 3, 1, 4) LF_IN(h_lf_chroma422_mbaff_intra, 3, 1, 2)
 
 /* ---- intra prediction: h264pred_template.c, the predictors of h264_dev.h on 16-bit samples ----------------------------- */
 struct PredJob {
-    int16_t T[1 + 32], L[1 + 16];
+    uint16_t T[1 + 32], L[1 + 16];
     int kind, mode, has_tl, has_tr;
 };
 template <int BD>

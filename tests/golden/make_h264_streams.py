@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -229,6 +229,9 @@ class Stream:
         self.bmode = bmode                                   # B pictures: 0 none, 1 implicit weights, 2 explicit weights, 3 plain average
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
+        self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
+        if lossless:
+            self.qp_min = self.qp_max = -6 * (depth - 8)
 
     def sps(self):
         w = Bits()
@@ -238,7 +241,7 @@ class Stream:
         w.ue(self.cidc)
         if self.cidc == 3:
             w.u(1, 0)                 # separate_colour_plane_flag
-        w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
+        w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 1 if self.lossless else 0); w.u(1, 0)
         w.ue(0)                       # log2_max_frame_num - 4
         if self.bmode:
             w.ue(0); w.ue(2)          # pic_order_cnt_type 0, 6 bits of pic_order_cnt_lsb
@@ -584,6 +587,8 @@ class Stream:
         elif ref_idc:
             w.u(1, 0)
         self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
+        if self.lossless:
+            self.qp = self.qp_min
         w.se(self.qp - 26)
         w.ue(self.deblock_idc)
         if self.deblock_idc != 1:
@@ -691,6 +696,9 @@ STREAMS = {
     "444_8": dict(mb_w=6, mb_h=4, chroma_idc=3, depth=8, seed=51, nslices=3, deblock_idc=2, nrefs=3, npics=7),
     "444_8_b_t8x8": dict(mb_w=7, mb_h=5, chroma_idc=3, depth=8, seed=52, nslices=2, deblock_idc=0, nrefs=2, npics=9, bmode=1, t8x8=True, far=20),
     "444_10": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=10, seed=53, nslices=2, deblock_idc=0, nrefs=2, npics=6, bmode=2),
+    "420_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=61, nslices=2, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True),
+    "444_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=62, nslices=1, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True, t8x8=True),
+    "422_10_lossless": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=63, nslices=1, deblock_idc=0, nrefs=2, npics=5, weighted=False, lossless=True),
     "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
     "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }
