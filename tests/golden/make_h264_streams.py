@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -229,6 +229,7 @@ class Stream:
         self.bmode = bmode                                   # B pictures: 0 none, 1 implicit weights, 2 explicit weights, 3 plain average
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
+        self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
         if lossless:
             self.qp_min = self.qp_max = -6 * (depth - 8)
@@ -249,7 +250,11 @@ class Stream:
             w.ue(2)                   # pic_order_cnt_type 2: output order = decoding order
         w.ue(max(1, self.nrefs)); w.u(1, 0)
         w.ue(self.mb_w - 1); w.ue(self.mb_h - 1)
-        w.u(1, 1); w.u(1, 1); w.u(1, 0)
+        w.u(1, 1); w.u(1, 1)
+        if self.crop:
+            w.u(1, 1); w.ue(0); w.ue(self.crop[0]); w.ue(0); w.ue(self.crop[1])      # left, right, top, bottom
+        else:
+            w.u(1, 0)
         if self.bmode:
             # VUI with nothing but the bitstream restrictions: one picture of reordering (the decoder need not guess)
             w.u(1, 1)
@@ -270,7 +275,7 @@ class Stream:
         w.ue(max(1, self.nrefs) - 1); w.ue(0)
         w.u(1, 1 if self.weighted else 0); w.u(2, (0, 2, 1, 0)[self.bmode])
         w.se(0); w.se(0); w.se(2)
-        w.u(1, 1); w.u(1, 0); w.u(1, 0)
+        w.u(1, 1); w.u(1, 1 if self.cip else 0); w.u(1, 0)
         w.u(1, 1 if self.t8x8 else 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode, no scaling matrices, second chroma qp offset
         w.trailing()
         return nal(3, 8, w.bytes())
@@ -287,6 +292,12 @@ class Stream:
 
     def avail(self, mbx, mby, sid):
         return 0 <= mbx < self.mb_w and 0 <= mby < self.mb_h and self.slice_of[mby, mbx] == sid
+
+    def iavail(self, mbx, mby, sid):
+        """available for INTRA prediction: with constrained_intra_pred an inter neighbour is not (8.3.1.2, 8.3.3, 8.3.4)"""
+        if not self.avail(mbx, mby, sid):
+            return False
+        return not self.cip or self.kind[mby][mbx] in ("i4", "i8", "i16", "pcm")
 
     def nC(self, arr, x, y, bw, bh, mbx, mby, sid):
         """predicted count for the block at block coordinates (x, y) of an array with bw x bh blocks per macroblock"""
@@ -367,7 +378,7 @@ class Stream:
     def intra_mb(self, w, mbx, mby, sid, base):
         """an intra macroblock; base: mb_type offset of intra types in this slice type (0 in I, 5 in P)"""
         r = self.r
-        left, top = self.avail(mbx - 1, mby, sid), self.avail(mbx, mby - 1, sid)
+        left, top = self.iavail(mbx - 1, mby, sid), self.iavail(mbx, mby - 1, sid)
         c = r.i(0, 9)
         if c == 0:                                           # I_PCM
             w.ue(base + 25)
@@ -378,7 +389,7 @@ class Stream:
             self.clear_counts(mbx, mby, 16)
             self.kind[mby][mbx] = "pcm"
             return
-        cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
+        cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and self.iavail(mbx - 1, mby - 1, sid) else [])
         cmode = cmodes[r.i(0, len(cmodes) - 1)]
         if c <= 4 and self.t8x8 and r.p(0.5):                # Intra 8x8
             w.ue(base + 0)
@@ -387,7 +398,7 @@ class Stream:
                 bx, by = 2 * (b8 & 1), 2 * (b8 >> 1)
                 x, y = 4 * mbx + bx, 4 * mby + by
                 l_ok, t_ok = bx > 0 or left, by > 0 or top
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.avail(mbx - 1, mby - 1, sid)))
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.iavail(mbx - 1, mby - 1, sid)))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
                 ma = (2 if self.i4[y, x - 1] < 0 else int(self.i4[y, x - 1])) if (x > 0 and (bx > 0 or left)) else None
@@ -414,7 +425,7 @@ class Stream:
                 x, y = 4 * mbx + bx, 4 * mby + by
                 l_ok, t_ok = bx > 0 or left, by > 0 or top
                 # the sample above-left of the block lies in this macroblock, the one above, the one to the left or the one above-left
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.avail(mbx - 1, mby - 1, sid)))
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.iavail(mbx - 1, mby - 1, sid)))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
                 # predicted mode: min of the neighbours' modes; a neighbour outside -> 2 for both; an available neighbour that is
@@ -439,7 +450,7 @@ class Stream:
             self.residual(w, mbx, mby, sid, cbp, False)
             self.kind[mby][mbx] = "i4"
             return
-        modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and self.avail(mbx - 1, mby - 1, sid) else [])
+        modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and self.iavail(mbx - 1, mby - 1, sid) else [])
         mode = modes[r.i(0, len(modes) - 1)]
         cl, cc = r.i(0, 1), r.i(0, 2)
         if self.cidc == 3:
@@ -635,7 +646,7 @@ class Stream:
             cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
             for s_ in range(len(cuts) - 1):
                 if cuts[s_] < cuts[s_ + 1]:
-                    au += self.slice(i, frame_num, idr, is_p, cuts[s_], cuts[s_ + 1], s_, nact)
+                    au += self.slice(i, frame_num, idr, is_p and not (self.mixed and self.r.p(0.4)), cuts[s_], cuts[s_ + 1], s_, nact)
             units.append(au)
             frame_num += 1
         return units
@@ -696,6 +707,13 @@ STREAMS = {
     "444_8": dict(mb_w=6, mb_h=4, chroma_idc=3, depth=8, seed=51, nslices=3, deblock_idc=2, nrefs=3, npics=7),
     "444_8_b_t8x8": dict(mb_w=7, mb_h=5, chroma_idc=3, depth=8, seed=52, nslices=2, deblock_idc=0, nrefs=2, npics=9, bmode=1, t8x8=True, far=20),
     "444_10": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=10, seed=53, nslices=2, deblock_idc=0, nrefs=2, npics=6, bmode=2),
+    "420_8_cip_mixed": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=81, nslices=4, deblock_idc=0, nrefs=3, npics=8, cip=True, mixed=True, t8x8=True),
+    "420_8_cip_b": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=82, nslices=2, deblock_idc=2, nrefs=2, npics=7, cip=True, bmode=1),
+    "444_8_cip": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=83, nslices=2, deblock_idc=0, nrefs=2, npics=6, cip=True, mixed=True),
+    "422_10_cip": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=84, nslices=2, deblock_idc=0, nrefs=2, npics=6, cip=True, mixed=True),
+    "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
+    "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
+    "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),
     "420_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=61, nslices=2, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True),
     "444_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=62, nslices=1, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True, t8x8=True),
     "422_10_lossless": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=63, nslices=1, deblock_idc=0, nrefs=2, npics=5, weighted=False, lossless=True),
