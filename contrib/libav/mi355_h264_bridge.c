@@ -58,6 +58,7 @@
 #include "mi355_h264_frame.h"
 
 void __real_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl);
+void __real_ff_h264_flush_change(H264Context *h);
 int __real_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup);
 void __real_ff_h264_filter_mb(const H264Context *h, H264SliceContext *sl, int mb_x, int mb_y, uint8_t *img_y, uint8_t *img_cb,
                               uint8_t *img_cr, unsigned int linesize, unsigned int uvlinesize);
@@ -113,6 +114,7 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
 
 typedef struct Bridge {
     int state;                  /* 0 new, 1 active, -1 stepped aside */
+    int soft;                   /* stepped aside because of the SEQUENCE's format: the next sequence is looked at again */
     int lazy, direct;
     int mb_w, mb_h, nmb;
     void *stream;               /* direct mode */
@@ -332,6 +334,54 @@ static int disp_start(void)
     return ok;
 }
 
+static int finish_set(Bridge *b, Staging *s);
+static void staging_free(Staging *s)
+{
+    if (s->host) mi355_host_free(s->host);
+    free(s->widths);
+    if (s->out) mi355_host_free(s->out);
+    if (s->done) mi355_event_destroy(s->done);
+    if (s->d_desc) mi355_free(s->d_desc);
+    memset(s, 0, sizeof(*s));
+}
+/* give back everything that depends on the picture geometry (what is in flight comes back first): the next sequence sets
+ * the bridge up again */
+static void bridge_release(Bridge *b)
+{
+    if (b->state > 0) {
+        finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+        if (!b->direct) { pthread_mutex_lock(&disp.mu); disp.nbridges--; pthread_mutex_unlock(&disp.mu); }
+    }
+    staging_free(&b->st[0]); staging_free(&b->st[1]);
+    for (int p = 0; p < 3; p++) { if (b->recon[p]) mi355_free(b->recon[p]); b->recon[p] = NULL; }
+    for (int p = 0; p < 2; p++) { if (b->scratch_c[p]) mi355_free(b->scratch_c[p]); b->scratch_c[p] = NULL; }
+    for (int i = 0; i < BR_MAX_PICS; i++) if (b->pics[i].plane[0]) mi355_free(b->pics[i].plane[0]);
+    memset(b->pics, 0, sizeof(b->pics));
+    b->open = 0; b->cur = 0; b->nslots = b->nslices = 0;
+}
+
+/* The decoder starts a (new) sequence: h264_init_ps() calls this when the parameters that size its tables change
+ * (h264_slice.c:973-985; also for the first sequence of a context).  Pictures still in flight belong to the frames it is
+ * about to drop: they come back first.  The bridge keeps its buffers when the new sequence has the geometry it was set up
+ * for, gives them back otherwise (bridge_get sets it up again, or steps aside for a format outside this path — and a
+ * bridge that had stepped aside for that reason looks at the new sequence again). */
+void __wrap_ff_h264_flush_change(H264Context *h)
+{
+    Bridge *b = br_tls;
+    if (b && b->state > 0) {
+        finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+        b->open = 0;
+        const SPS *sps = h->ps.sps;
+        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height == b->mb_h && sps->frame_mbs_only_flag && sps->bit_depth_luma == 8 &&
+                         (sps->chroma_format_idc == 3) == b->c444 && (sps->chroma_format_idc == 1 || sps->chroma_format_idc == 3) &&
+                         !sps->transform_bypass && !sps->residual_color_transform_flag;
+        if (!same) { bridge_release(b); b->state = 0; }
+    } else if (b && b->state < 0 && b->soft) {
+        b->state = 0; b->soft = 0;
+    }
+    __real_ff_h264_flush_change(h);
+}
+
 static Bridge *bridge_get(const H264Context *h)
 {
     Bridge *b = br_tls;
@@ -347,6 +397,7 @@ static Bridge *bridge_get(const H264Context *h)
     if (FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
         h->ps.sps->transform_bypass) {
         br_fail(b, "stream outside the batched path (needs progressive 8-bit 4:2:0 or 4:4:4 without transform bypass)");
+        b->soft = 1;
         return b;
     }
     const char *dev = getenv("MI355_DEVICE");

@@ -711,6 +711,14 @@ STREAMS = {
     "420_8_cip_b": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=82, nslices=2, deblock_idc=2, nrefs=2, npics=7, cip=True, bmode=1),
     "444_8_cip": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=83, nslices=2, deblock_idc=0, nrefs=2, npics=6, cip=True, mixed=True),
     "422_10_cip": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=84, nslices=2, deblock_idc=0, nrefs=2, npics=6, cip=True, mixed=True),
+    # a second sequence with another picture size, bit depth or chroma format follows the first (new SPS + IDR): decoders re-initialise
+    "420_8_resize": [dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=91, nslices=2, deblock_idc=0, nrefs=2, npics=4),
+                     dict(mb_w=4, mb_h=5, chroma_idc=1, depth=8, seed=92, nslices=1, deblock_idc=0, nrefs=2, npics=4, bmode=1),
+                     dict(mb_w=7, mb_h=3, chroma_idc=1, depth=8, seed=93, nslices=2, deblock_idc=2, nrefs=2, npics=3)],
+    "mixed_formats": [dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=94, nslices=1, deblock_idc=0, nrefs=2, npics=3),
+                      dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=95, nslices=1, deblock_idc=0, nrefs=2, npics=3),
+                      dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=96, nslices=2, deblock_idc=0, nrefs=2, npics=3),
+                      dict(mb_w=5, mb_h=3, chroma_idc=1, depth=8, seed=97, nslices=1, deblock_idc=0, nrefs=2, npics=3)],
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),
@@ -720,7 +728,7 @@ STREAMS = {
     "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
     "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }
-BRIDGE_STREAMS = [n for n, kw in STREAMS.items() if kw["chroma_idc"] in (1, 3) and kw["depth"] == 8]
+
 
 
 def write_samples(path, units):
@@ -747,7 +755,7 @@ def main():
     T = load_tables()
     md5 = {}
     for name, kw in STREAMS.items():
-        units = Stream(T, name, **kw).build()
+        units = sum((Stream(T, name, **k).build() for k in kw), []) if isinstance(kw, list) else Stream(T, name, **kw).build()
         p = os.path.join(out, "h264_synth_%s.samples" % name)
         write_samples(p, units)
         with tempfile.TemporaryDirectory() as td:

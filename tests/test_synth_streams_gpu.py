@@ -63,3 +63,12 @@ def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name)
     st = SY.run_bridge("h264_bridge_gpu", name, out)
     assert st.get("pictures_on_device") == 0 and st.get("pictures_output") == SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
+
+
+@pytest.mark.parametrize("lazy", (False, True))
+def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy):
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", "mixed_formats", out, lazy=lazy)
+    assert st.get("pictures_on_device") == 9 and st.get("pictures_output") == 12, st
+    SY.check_md5(out, "mixed_formats")
