@@ -719,6 +719,9 @@ STREAMS = {
                       dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=95, nslices=1, deblock_idc=0, nrefs=2, npics=3),
                       dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=96, nslices=2, deblock_idc=0, nrefs=2, npics=3),
                       dict(mb_w=5, mb_h=3, chroma_idc=1, depth=8, seed=97, nslices=1, deblock_idc=0, nrefs=2, npics=3)],
+    # the reference's own limit is 32 slices per picture (MAX_SLICES, h264dec.h: beyond it the decoder warns and its per-slice
+    # reference tables alias); the bridge holds 64
+    "420_8_slices30": dict(mb_w=10, mb_h=8, chroma_idc=1, depth=8, seed=98, nslices=30, deblock_idc=2, nrefs=2, npics=5, bmode=1),
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),
