@@ -42,7 +42,7 @@ def run_tier1(which, name, out, plain=False):
     return lines[0]
 
 
-def run_bridge(which, name, out, threads=1, lazy=False, direct=False):
+def run_bridge(which, name, out, threads=1, lazy=False, direct=False, loops=1):
     env = dict(os.environ)
     for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
         env.pop(k, None)
@@ -50,7 +50,7 @@ def run_bridge(which, name, out, threads=1, lazy=False, direct=False):
         env["MI355_BRIDGE_LAZY"] = "1"
     if direct:
         env["MI355_BRIDGE_DIRECT"] = "1"
-    r = subprocess.run([exe(which), samples(name), str(out), str(threads), "1"], capture_output=True, text=True, env=env, timeout=1800)
+    r = subprocess.run([exe(which), samples(name), str(out), str(threads), str(loops)], capture_output=True, text=True, env=env, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
     stats = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     return stats[-1] if stats else {}

@@ -109,3 +109,14 @@ def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct):
     st = SY.run_bridge("h264_bridge_emu", "mixed_formats", out, lazy=lazy, direct=direct)
     assert st.get("pictures_on_device") == 9 and st.get("pictures_output") == 12, st
     SY.check_md5(out, "mixed_formats")
+
+
+@needs_harness
+@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 9)))
+def test_bridge_sequence_changes_with_several_decoders_emulated(tmp_path, emu, name, on_device):
+    """four decoder threads, each decoding the stream twice: buffers are given back and set up again while the other decoders'
+    pictures are in the dispatcher's launch sets"""
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_emu", name, out, threads=4, loops=2, lazy=True)
+    assert st.get("pictures_on_device") == 8 * on_device and st.get("pictures_output") == 8 * SY.MD5[name]["pictures"], st
+    SY.check_md5(out, name)

@@ -72,3 +72,12 @@ def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy):
     st = SY.run_bridge("h264_bridge_gpu", "mixed_formats", out, lazy=lazy)
     assert st.get("pictures_on_device") == 9 and st.get("pictures_output") == 12, st
     SY.check_md5(out, "mixed_formats")
+
+
+@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 9)))
+def test_bridge_sequence_changes_with_several_decoders_gpu(tmp_path, mi355, name, on_device):
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", name, out, threads=6, loops=3)
+    assert st.get("pictures_on_device") == 18 * on_device and st.get("pictures_output") == 18 * SY.MD5[name]["pictures"], st
+    SY.check_md5(out, name)
