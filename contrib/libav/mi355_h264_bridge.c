@@ -394,7 +394,9 @@ static Bridge *bridge_get(const H264Context *h)
     }
     if (b->state) return b;
     const int idc = h->ps.sps->chroma_format_idc;
-    if (FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
+    /* a sequence that MAY hold field pictures or field macroblocks (frame_mbs_only_flag 0) is outside the path as a whole: the
+     * choice between a frame and two fields is made per picture (PAFF), and this set-up is not */
+    if (!h->ps.sps->frame_mbs_only_flag || FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
         h->ps.sps->transform_bypass) {
         br_fail(b, "stream outside the batched path (needs progressive 8-bit 4:2:0 or 4:4:4 without transform bypass)");
         b->soft = 1;

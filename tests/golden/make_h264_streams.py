@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -230,6 +230,7 @@ class Stream:
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
+        self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
         if lossless:
             self.qp_min = self.qp_max = -6 * (depth - 8)
@@ -249,8 +250,12 @@ class Stream:
         else:
             w.ue(2)                   # pic_order_cnt_type 2: output order = decoding order
         w.ue(max(1, self.nrefs)); w.u(1, 0)
-        w.ue(self.mb_w - 1); w.ue(self.mb_h - 1)
-        w.u(1, 1); w.u(1, 1)
+        if self.paff:
+            w.ue(self.mb_w - 1); w.ue(self.mb_h // 2 - 1)       # map units: field macroblock rows
+            w.u(1, 0); w.u(1, 0); w.u(1, 1)                      # frame_mbs_only 0, mb_adaptive_frame_field 0, direct_8x8_inference
+        else:
+            w.ue(self.mb_w - 1); w.ue(self.mb_h - 1)
+            w.u(1, 1); w.u(1, 1)
         if self.crop:
             w.u(1, 1); w.ue(0); w.ue(self.crop[0]); w.ue(0); w.ue(self.crop[1])      # left, right, top, bottom
         else:
@@ -559,13 +564,17 @@ class Stream:
                     for _ in range(2):
                         w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
 
-    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact, is_b=False, poc=None, ref_idc=3):
+    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact, is_b=False, poc=None, ref_idc=3, field=None):
         r = self.r
         w = Bits()
         w.ue(first_mb)
         w.ue(6 if is_b else (5 if is_p else 7))
         w.ue(0)
         w.u(4, frame_num & 15)
+        if self.paff:
+            w.u(1, 0 if field is None else 1)
+            if field is not None:
+                w.u(1, field)                                # bottom_field_flag
         if idr:
             w.ue(idx & 3)
         if poc is not None:
@@ -629,7 +638,35 @@ class Stream:
         w.trailing()
         return nal(ref_idc, 5 if idr else 1, w.bytes())
 
+    def build_paff(self):
+        """an IDR frame picture, then every frame as a frame picture or as a top and a bottom field picture (I or P)"""
+        r = self.r
+        units, frame_h, nfr = [], self.mb_h, 0
+        assert frame_h % 2 == 0 and not self.bmode
+        for i in range(self.npics):
+            idr = i == 0
+            au = self.sps() + self.pps() if idr else b""
+            fields = (None,) if (idr or r.p(0.4)) else (0, 1)
+            for fld in fields:
+                self.mb_h = frame_h if fld is None else frame_h // 2
+                nmb = self.mb_w * self.mb_h
+                self.begin_picture()
+                held = min(nfr, max(1, self.nrefs))
+                avail = held if fld is None else 2 * held + (1 if fld == 1 else 0)       # the first field of this frame is a reference of the second
+                is_p = avail > 0 and r.p(0.85)
+                nact = max(1, min(avail, r.i(1, 3)))
+                cuts = [0] + sorted(set(r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
+                for s_ in range(len(cuts) - 1):
+                    if cuts[s_] < cuts[s_ + 1]:
+                        au += self.slice(i, i, idr, is_p, cuts[s_], cuts[s_ + 1], s_, nact, field=fld)
+            units.append(au)
+            nfr += 1
+        self.mb_h = frame_h
+        return units
+
     def build(self):
+        if self.paff:
+            return self.build_paff()
         if self.bmode:
             return self.build_b()
         units = []
@@ -722,6 +759,10 @@ STREAMS = {
     # the reference's own limit is 32 slices per picture (MAX_SLICES, h264dec.h: beyond it the decoder warns and its per-slice
     # reference tables alias); the bridge holds 64
     "420_8_slices30": dict(mb_w=10, mb_h=8, chroma_idc=1, depth=8, seed=98, nslices=30, deblock_idc=2, nrefs=2, npics=5, bmode=1),
+    # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
+    "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
+    "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),
+    "444_8_paff": dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=103, nslices=2, deblock_idc=2, nrefs=2, npics=6, paff=True, cip=True),
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),
