@@ -15,4 +15,4 @@ timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 find $OUT/prof -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/prof -name '*kernel_trace.csv' -exec rm {} \;
 head -6 $OUT/kernel_stats.csv
-bash tools/gpu_traffic.sh ${TAG}_traffic --steps 1 --warmup 0 2>&1 | tail -2
+bash tools/gpu_traffic.sh ${TAG}_traffic --no-extra --steps 1 --warmup 0 2>&1 | tail -2
