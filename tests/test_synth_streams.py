@@ -120,3 +120,38 @@ def test_bridge_sequence_changes_with_several_decoders_emulated(tmp_path, emu, n
     st = SY.run_bridge("h264_bridge_emu", name, out, threads=4, loops=2, lazy=True)
     assert st.get("pictures_on_device") == 8 * on_device and st.get("pictures_output") == 8 * SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
+
+
+@needs_harness
+@pytest.mark.parametrize("seed", range(6))
+def test_bridge_survives_damaged_streams_emulated(tmp_path, emu, seed):
+    """bit errors in slice data: whatever the reference decoder makes of the stream (errors, partial pictures, concealment),
+    the bridge neither crashes nor hangs — it finishes what it has and hands the decoder back to the C path"""
+    import random
+    import struct
+    import subprocess
+    buf = open(SY.samples("420_8_qcif"), "rb").read()
+    p = 4 + struct.unpack_from("<I", buf, 0)[0]
+    n = struct.unpack_from("<I", buf, p)[0]
+    p += 4
+    units = []
+    for _ in range(n):
+        ln = struct.unpack_from("<I", buf, p)[0]
+        units.append(bytearray(buf[p + 4:p + 4 + ln]))
+        p += 4 + ln
+    r = random.Random(seed)
+    for _ in range(r.randint(1, 6)):
+        u = units[r.randint(1, n - 1)]
+        u[r.randint(40, len(u) - 1)] ^= 1 << r.randint(0, 7)
+    src = tmp_path / "d.samples"
+    with open(src, "wb") as f:
+        f.write(struct.pack("<II", 0, n))
+        for u in units:
+            f.write(struct.pack("<I", len(u)) + bytes(u))
+    for lazy in (False, True):
+        env = dict(os.environ)
+        env.pop("MI355_BRIDGE_LAZY", None)
+        if lazy:
+            env["MI355_BRIDGE_LAZY"] = "1"
+        res = subprocess.run([SY.exe("h264_bridge_emu"), str(src), str(tmp_path / "o.yuv"), "1", "1"], capture_output=True, text=True, env=env, timeout=600)
+        assert res.returncode == 0, (res.returncode, res.stderr[-500:])
