@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -230,6 +230,7 @@ class Stream:
         self.cblk_h = 4 if chroma_idc == 2 else 2            # chroma 4x4 blocks per macroblock, vertically
         self.qp_min, self.qp_max = 12, 44
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
+        self.sparse, self.skip = sparse, skip                # scale of the coded-block probabilities, P(skip): 1.0 / 0.15 = dense test content
         self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
         if lossless:
@@ -319,13 +320,13 @@ class Stream:
             nnz = self.nnz444[pl]
             if i16:
                 n = self.nC(nnz, 4 * mbx, 4 * mby, 4, 4, mbx, mby, sid)
-                write_block(w, T, r.block(16, 0.8), n, "luma")
+                write_block(w, T, r.block(16, 0.8 * self.sparse), n, "luma")
             for blk in range(16):
                 x = 4 * mbx + (blk & 1) + 2 * ((blk >> 2) & 1)
                 y = 4 * mby + ((blk >> 1) & 1) + 2 * (blk >> 3)
                 if cbp & (1 << (blk >> 2)):
                     n = self.nC(nnz, x, y, 4, 4, mbx, mby, sid)
-                    nnz[y, x] = write_block(w, T, r.block(15 if i16 else 16, 0.6), n, "luma")
+                    nnz[y, x] = write_block(w, T, r.block(15 if i16 else 16, 0.6 * self.sparse), n, "luma")
                 else:
                     nnz[y, x] = 0
         if self.cidc == 3:
@@ -334,7 +335,7 @@ class Stream:
         nblk = 2 * self.cblk_h
         if cc:
             for _ in range(2):
-                write_block(w, T, r.block(nblk, 0.7), 0, "cdc422" if self.cidc == 2 else "cdc420")
+                write_block(w, T, r.block(nblk, 0.7 * self.sparse), 0, "cdc422" if self.cidc == 2 else "cdc420")
         for pl in range(2):
             for blk in range(nblk):
                 # 4:2:0: raster order of the 2 x 2 blocks; 4:2:2: two 2 x 2 groups, top then bottom (blkIdx 0..7)
@@ -342,7 +343,7 @@ class Stream:
                 y = self.cblk_h * mby + (blk >> 1)
                 if cc & 2:
                     n = self.nC(self.nnzc[pl], x, y, 2, self.cblk_h, mbx, mby, sid)
-                    self.nnzc[pl][y, x] = write_block(w, T, r.block(15, 0.5), n, "luma")
+                    self.nnzc[pl][y, x] = write_block(w, T, r.block(15, 0.5 * self.sparse), n, "luma")
                 else:
                     self.nnzc[pl][y, x] = 0
 
@@ -495,7 +496,7 @@ class Stream:
                     w.te(nact - 1, r.i(0, nact - 1))
             for _ in range(parts):
                 self.mvd(w)
-        cbp = self.inter_cbp(w, 0.7)
+        cbp = self.inter_cbp(w, 0.7 * self.sparse)
         if self.t8x8 and (cbp & 15) and not small:
             w.u(1, r.i(0, 1))                                # transform_size_8x8_flag
         if cbp:
@@ -540,7 +541,7 @@ class Stream:
                 for pr in preds:
                     if pr & lst:
                         self.mvd(w)
-        cbp = self.inter_cbp(w, 0.6)
+        cbp = self.inter_cbp(w, 0.6 * self.sparse)
         if self.t8x8 and (cbp & 15) and not (t == 22 and any(s_ > 3 for s_ in subs)):
             w.u(1, r.i(0, 1))                                # transform_size_8x8_flag (direct_8x8_inference_flag = 1)
         if cbp:
@@ -618,14 +619,14 @@ class Stream:
             mbx, mby = a % self.mb_w, a // self.mb_w
             self.slice_of[mby, mbx] = sid
             if is_p or is_b:
-                if r.p(0.15):
+                if r.p(self.skip):
                     skip += 1
                     self.clear_counts(mbx, mby)
                     self.kind[mby][mbx] = "skip"
                     continue
                 w.ue(skip)
                 skip = 0
-                if r.p(0.25 if is_p else 0.15):
+                if r.p((0.25 if is_p else 0.15) * min(1.0, self.sparse * 2)):
                     self.intra_mb(w, mbx, mby, sid, 5 if is_p else 23)
                 elif is_b:
                     self.b_mb(w, mbx, mby, sid, nact)
