@@ -69,6 +69,19 @@ int mi355_h264_surface_wait(mi355_h264_session *s, int surface);
 /* the session's HIP stream (a hipStream_t): work enqueued on it after end_frame() runs after the picture */
 void *mi355_h264_session_stream(mi355_h264_session *s);
 
+/* ---- groups: the throughput form.  Sessions opened in a group share its HIP stream and do not launch at end_frame(): their
+ * pictures wait until mi355_h264_group_flush() issues ONE launch set for all of them (one descriptor array, one pass of each
+ * Tier-2 kernel over the pictures of all member sessions — picture sizes may differ).  At most one picture per session waits:
+ * the next start_frame() of a session whose picture is still waiting flushes the group first, and so do get_frame(),
+ * surface_wait(), put_frame() and close.  A group and its sessions are used from one thread at a time (hosts that feed from many
+ * threads serialise around it, as contrib/libav/mi355_h264_bridge.c does with its dispatcher).  Close the sessions before
+ * destroying the group. */
+typedef struct mi355_h264_group mi355_h264_group;
+int  mi355_h264_group_create(mi355_h264_group **out);
+void mi355_h264_group_destroy(mi355_h264_group *g);
+int  mi355_h264_session_open_grouped(mi355_h264_session **out, const mi355_h264_session_params *p, mi355_h264_group *g);
+int  mi355_h264_group_flush(mi355_h264_group *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 #include "../../include/mi355_h264_session.h"
 
 namespace {
@@ -26,7 +27,21 @@ struct Set {
 
 }  // namespace
 
+struct mi355_h264_group {
+    void *stream = nullptr;
+    std::vector<mi355_h264_session *> pending;      /* sessions whose latest picture waits for the next flush */
+    mi355_h264_frame *h_desc = nullptr, *d_desc = nullptr;   /* pinned / device: the flush's descriptor array */
+    int cap = 0;
+    void *copied = nullptr;                          /* the last flush's descriptor copy has left h_desc */
+    bool used = false;
+    std::vector<int32_t> widths;
+    int members = 0;
+};
+
 struct mi355_h264_session {
+    mi355_h264_group *group = nullptr;
+    bool pending = false;                 /* grouped: the picture of staging set `cur` has not been launched yet */
+    int pend_levels = 0;
     int mb_w = 0, mb_h = 0, nmb = 0, nsurf = 0, max_slices = 0;
     int stride[2] = { 0, 0 };
     size_t plane_off[3] = { 0, 0, 0 }, surf_bytes = 0;
@@ -50,6 +65,7 @@ struct mi355_h264_session {
 extern "C" void mi355_h264_session_close(mi355_h264_session *s)
 {
     if (!s) return;
+    if (s->group && s->pending) mi355_h264_group_flush(s->group);
     if (s->stream) mi355_sync(s->stream);
     if (s->copy_stream) mi355_sync(s->copy_stream);
     for (int k = 0; k < NSETS; k++) {
@@ -65,12 +81,13 @@ extern "C" void mi355_h264_session_close(mi355_h264_session *s)
     std::free(s->covered);
     std::free(s->level_widths);
     if (s->surfaces) mi355_free(s->surfaces);
-    if (s->stream) mi355_stream_destroy(s->stream);
+    if (s->stream && !s->group) mi355_stream_destroy(s->stream);
     if (s->copy_stream) mi355_stream_destroy(s->copy_stream);
+    if (s->group) s->group->members--;
     delete s;
 }
 
-extern "C" int mi355_h264_session_open(mi355_h264_session **out, const mi355_h264_session_params *p)
+static int session_open_impl(mi355_h264_session **out, const mi355_h264_session_params *p, mi355_h264_group *g)
 {
     if (!out || !p || p->mb_width <= 0 || p->mb_height <= 0 || p->num_surfaces < 2 || p->num_surfaces > 64 || p->max_slices < 0 || p->max_slices > 255) return -1;
     if ((long)p->mb_width * p->mb_height >= (1L << 24)) return -1;
@@ -102,7 +119,8 @@ extern "C" int mi355_h264_session_open(mi355_h264_session **out, const mi355_h26
         s->set[k].copied = mi355_event_create();
         ok = ok && s->set[k].host && s->set[k].dev && s->set[k].copied;
     }
-    s->stream = mi355_stream_create();
+    s->group = g;
+    s->stream = g ? g->stream : mi355_stream_create();
     s->copy_stream = mi355_stream_create();
     s->surf_done = static_cast<void **>(std::calloc((size_t)s->nsurf, sizeof(void *)));
     s->surf_valid = static_cast<bool *>(std::calloc((size_t)s->nsurf, sizeof(bool)));
@@ -110,14 +128,23 @@ extern "C" int mi355_h264_session_open(mi355_h264_session **out, const mi355_h26
     s->level_widths = static_cast<int32_t *>(std::calloc((size_t)(s->mb_w + 2 * s->mb_h + 2), sizeof(int32_t)));
     ok = ok && s->stream && s->copy_stream && s->surf_done && s->surf_valid && s->covered && s->level_widths;
     for (int i = 0; i < s->nsurf && ok; i++) ok = (s->surf_done[i] = mi355_event_create()) != nullptr;
-    if (!ok) { mi355_h264_session_close(s); return -3; }
+    if (!ok) { s->group = nullptr; if (g) s->stream = nullptr; mi355_h264_session_close(s); return -3; }
+    if (g) g->members++;
     *out = s;
     return 0;
+}
+extern "C" int mi355_h264_session_open(mi355_h264_session **out, const mi355_h264_session_params *p) { return session_open_impl(out, p, nullptr); }
+extern "C" int mi355_h264_session_open_grouped(mi355_h264_session **out, const mi355_h264_session_params *p, mi355_h264_group *g)
+{
+    return g ? session_open_impl(out, p, g) : -1;
 }
 
 extern "C" int mi355_h264_start_frame(mi355_h264_session *s, const mi355_h264_picture_params *pp)
 {
     if (!s || !pp || s->open) return -1;
+    /* grouped: this session's previous picture still waits for a launch — it may be a reference of this one, and its staging
+     * set comes up for reuse after the next: everything waiting goes out now */
+    if (s->group && s->pending) { const int rc = mi355_h264_group_flush(s->group); if (rc) return rc; }
     if (pp->surface < 0 || pp->surface >= s->nsurf || pp->nslots < 0 || pp->nslots > MI355_H264_MAX_SLOTS) return -1;
     for (int i = 0; i < pp->nslots; i++) {
         const int r = pp->ref_surface[i];
@@ -205,6 +232,14 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     fr->intra_list = reinterpret_cast<const uint32_t *>(d + l.ilist);
     fr->intra_level_start = reinterpret_cast<const int32_t *>(d + l.istart);
     fr->max_level_width = width;
+    if (s->group) {
+        /* grouped: the picture waits for mi355_h264_group_flush(), which launches it together with the other sessions' */
+        s->pend_levels = levels;
+        s->pending = true;
+        s->group->pending.push_back(s);
+        s->frames++;
+        return 0;
+    }
     /* one copy for the whole block (P pictures without list 1 still send the unused vector area: it is 6 % of the block) */
     if (mi355_memcpy_h2d_async(d, h, l.total, s->stream) != 0) return -2;
     if (mi355_event_record(st.copied, s->stream) != 0) return -2;
@@ -218,15 +253,21 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     return 0;
 }
 
+static int flush_if_pending(mi355_h264_session *s) { return s->group && s->pending ? mi355_h264_group_flush(s->group) : 0; }
+
 extern "C" int mi355_h264_surface_wait(mi355_h264_session *s, int surface)
 {
-    if (!s || surface < 0 || surface >= s->nsurf || !s->surf_valid[surface]) return -1;
+    if (!s || surface < 0 || surface >= s->nsurf) return -1;
+    if (flush_if_pending(s) != 0) return -2;
+    if (!s->surf_valid[surface]) return -1;
     return mi355_event_sync(s->surf_done[surface]) == 0 ? 0 : -2;
 }
 
 extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3])
 {
-    if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf || !s->surf_valid[surface]) return -1;
+    if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf) return -1;
+    if (flush_if_pending(s) != 0) return -2;
+    if (!s->surf_valid[surface]) return -1;
     /* on the copy stream, behind the picture's event: later pictures queued on the session's stream are not waited for */
     if (mi355_stream_wait_event(s->copy_stream, s->surf_done[surface]) != 0) return -2;
     for (int p = 0; p < 3; p++) {
@@ -240,6 +281,7 @@ extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t 
 extern "C" int mi355_h264_put_frame(mi355_h264_session *s, int surface, const uint8_t *const src[3], const int src_stride[3])
 {
     if (!s || !src || !src_stride || s->open || surface < 0 || surface >= s->nsurf) return -1;
+    if (flush_if_pending(s) != 0) return -2;
     uint8_t *img = static_cast<uint8_t *>(std::malloc(s->surf_bytes));
     if (!img) return -3;
     for (int p = 0; p < 3; p++) {
@@ -263,3 +305,74 @@ extern "C" const uint8_t *mi355_h264_surface_dev(mi355_h264_session *s, int surf
 }
 
 extern "C" void *mi355_h264_session_stream(mi355_h264_session *s) { return s ? s->stream : nullptr; }
+
+/* ---- groups: the pictures of many sessions in ONE launch set ------------------------------------------------------- */
+extern "C" int mi355_h264_group_create(mi355_h264_group **out)
+{
+    if (!out) return -1;
+    mi355_h264_group *g = new (std::nothrow) mi355_h264_group;
+    if (!g) return -3;
+    g->stream = mi355_stream_create();
+    g->copied = mi355_event_create();
+    if (!g->stream || !g->copied) { mi355_h264_group_destroy(g); return -3; }
+    *out = g;
+    return 0;
+}
+
+extern "C" void mi355_h264_group_destroy(mi355_h264_group *g)
+{
+    if (!g) return;
+    if (g->stream) mi355_sync(g->stream);
+    if (g->h_desc) mi355_host_free(g->h_desc);
+    if (g->d_desc) mi355_free(g->d_desc);
+    if (g->copied) mi355_event_destroy(g->copied);
+    if (g->stream) mi355_stream_destroy(g->stream);
+    delete g;
+}
+
+extern "C" int mi355_h264_group_flush(mi355_h264_group *g)
+{
+    if (!g) return -1;
+    const int n = (int)g->pending.size();
+    if (!n) return 0;
+    if (n > g->cap) {
+        if (g->used && mi355_event_sync(g->copied) != 0) return -2;
+        if (g->h_desc) mi355_host_free(g->h_desc);
+        if (g->d_desc) { mi355_sync(g->stream); mi355_free(g->d_desc); }
+        g->cap = n + 16;
+        g->h_desc = static_cast<mi355_h264_frame *>(mi355_host_alloc((size_t)g->cap * sizeof(mi355_h264_frame)));
+        g->d_desc = static_cast<mi355_h264_frame *>(mi355_malloc((size_t)g->cap * sizeof(mi355_h264_frame)));
+        g->used = false;
+        if (!g->h_desc || !g->d_desc) { g->cap = 0; return -3; }
+    }
+    if (g->used && mi355_event_sync(g->copied) != 0) return -2;
+    int max_w = 0, max_h = 0, max_l = 0, rc = 0;
+    for (mi355_h264_session *s : g->pending) {
+        max_w = s->mb_w > max_w ? s->mb_w : max_w; max_h = s->mb_h > max_h ? s->mb_h : max_h;
+        max_l = s->pend_levels > max_l ? s->pend_levels : max_l;
+    }
+    g->widths.assign((size_t)max_l + 1, 0);
+    int i = 0;
+    for (mi355_h264_session *s : g->pending) {
+        Set &st = s->set[s->cur];
+        /* the session's records travel in one copy; its descriptor joins the flush's array */
+        if (mi355_memcpy_h2d_async(st.dev, st.host, s->lay.total, g->stream) != 0 || mi355_event_record(st.copied, g->stream) != 0) rc = -2;
+        st.used = true;
+        g->h_desc[i++] = *reinterpret_cast<const mi355_h264_frame *>(st.host + s->lay.desc);
+        for (int l = 0; l < s->pend_levels; l++) if (s->level_widths[l] > g->widths[(size_t)l]) g->widths[(size_t)l] = s->level_widths[l];
+    }
+    if (rc == 0 && (mi355_memcpy_h2d_async(g->d_desc, g->h_desc, (size_t)n * sizeof(mi355_h264_frame), g->stream) != 0 ||
+                    mi355_event_record(g->copied, g->stream) != 0)) rc = -2;
+    g->used = true;
+    if (rc == 0) {
+        const int r = mi355_h264_decode_frames_levels_dev(g->d_desc, n, max_w, max_h, max_l, g->widths.data(), g->stream);
+        if (r != 0) rc = r == -1 ? -1 : -2;
+    }
+    for (mi355_h264_session *s : g->pending) {
+        if (rc == 0 && mi355_event_record(s->surf_done[s->pp.surface], g->stream) == 0) s->surf_valid[s->pp.surface] = true;
+        else if (rc == 0) rc = -2;
+        s->pending = false;
+    }
+    g->pending.clear();
+    return rc;
+}

@@ -30,17 +30,36 @@ def _bind(lib):
     lib.mi355_h264_end_frame.argtypes = [C.c_void_p]
     lib.mi355_h264_get_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.mi355_h264_put_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
-    for f in ("session_open", "start_frame", "decode_slice", "end_frame", "get_frame", "put_frame"):
+    lib.mi355_h264_group_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.mi355_h264_group_destroy.argtypes = [C.c_void_p]
+    lib.mi355_h264_group_destroy.restype = None
+    lib.mi355_h264_group_flush.argtypes = [C.c_void_p]
+    lib.mi355_h264_session_open_grouped.argtypes = [C.POINTER(C.c_void_p), C.POINTER(SessionParams), C.c_void_p]
+    for f in ("session_open", "start_frame", "decode_slice", "end_frame", "get_frame", "put_frame", "group_create", "group_flush", "session_open_grouped"):
         getattr(lib, "mi355_h264_" + f).restype = C.c_int
 
 
+class Group:
+    def __init__(self, lib):
+        _bind(lib)
+        self.lib = lib
+        self.h = C.c_void_p()
+        assert lib.mi355_h264_group_create(C.byref(self.h)) == 0
+
+    def flush(self):
+        return self.lib.mi355_h264_group_flush(self.h)
+
+    def destroy(self):
+        self.lib.mi355_h264_group_destroy(self.h)
+
+
 class Session:
-    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0):
+    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0, group=None):
         _bind(lib)
         self.lib, self.mb_w, self.mb_h = lib, mb_w, mb_h
         self.h = C.c_void_p()
         p = SessionParams(mb_w, mb_h, nsurf, max_slices)
-        rc = lib.mi355_h264_session_open(C.byref(self.h), C.byref(p))
+        rc = lib.mi355_h264_session_open_grouped(C.byref(self.h), C.byref(p), group.h) if group else lib.mi355_h264_session_open(C.byref(self.h), C.byref(p))
         assert rc == 0, rc
 
     def close(self):
@@ -134,6 +153,39 @@ def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True):
     finally:
         ss.close()
     return count
+
+
+def run_group(prov, npzs, nsurf=8, explicit_flush=True):
+    """several streams (different picture sizes), one session each, all in ONE group: picture i of every stream that still has
+    one goes out in the same launch set.  explicit_flush False: nothing calls group_flush — the next start_frame of a session
+    whose picture still waits, and get_frame, flush by themselves."""
+    streams = [SF.load_npz(p) for p in npzs]
+    g = Group(prov.lib)
+    sess = [Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, group=g) for pics in streams]
+    try:
+        for i in range(max(len(p) for p in streams)):
+            live = [(ss, pics) for ss, pics in zip(sess, streams) if i < len(pics)]
+            for ss, pics in live:
+                pc = pics[i]
+                assert all(0 < i - s_ < nsurf for s_ in pc["slots"])
+                assert ss.start(i % nsurf, [s_ % nsurf for s_ in pc["slots"]], pc["use_l1"]) == 0
+                send_picture(ss, pc["mb"], pc["mv0"].reshape(-1, 32), pc["mv1"].reshape(-1, 32) if pc["use_l1"] else None, pc["coef"], pc["slices"],
+                             ("runs", "addr", "split")[i % 3])
+                assert ss.end() == 0
+            if explicit_flush:
+                assert g.flush() == 0
+            if explicit_flush or i % 3 == 2 or i == max(len(p) for p in streams) - 1:
+                lo = i if explicit_flush else max(0, i - 2)
+                for ss, pics in live:
+                    for j in range(lo, i + 1):
+                        got = ss.get(j % nsurf)
+                        for gp, key in zip(got, ("y", "cb", "cr")):
+                            assert np.array_equal(gp, pics[j][key]), "picture %d plane %s differs from the reference decoder" % (j, key)
+    finally:
+        for ss in sess:
+            ss.close()
+        g.destroy()
+    return sum(len(p) for p in streams)
 
 
 def run_synth(prov, oracle, name, how="runs"):

@@ -27,3 +27,12 @@ def test_session_decode_then_convert_on_device_emulated(emu, oracle):
     """f2 through a session: surfaces of the session are the converter's sources, on the session's stream"""
     import chain_check
     assert chain_check.run_session(emu, oracle, first=2, count=2) == 2
+
+
+@pytest.mark.parametrize("explicit_flush", (True, False))
+def test_session_group_one_launch_set_for_several_streams_emulated(emu, explicit_flush):
+    """three generated streams of different picture sizes (slices, I_PCM, B pictures, four references) decoded in step by
+    three sessions of one group: one launch set per step for all of them"""
+    import synth_streams as SY
+    n = SC.run_group(emu, [SY.npz("420_8_slices"), SY.npz("420_8_b_implicit"), SY.npz("420_8_qcif")], explicit_flush=explicit_flush)
+    assert n == 7 + 9 + 10

@@ -30,3 +30,10 @@ def test_session_argument_and_state_checks_gpu(mi355):
 def test_session_decode_then_convert_on_device_gpu(mi355, oracle):
     import chain_check
     assert chain_check.run_session(mi355, oracle, first=5, count=6) == 6
+
+
+@pytest.mark.parametrize("explicit_flush", (True, False))
+def test_session_group_one_launch_set_for_several_streams_gpu(mi355, explicit_flush):
+    import synth_streams as SY
+    names = ("420_8_slices", "420_8_b_implicit", "420_8_qcif", "420_8_t8x8", "420_8_cip_mixed", "420_8_b_average")
+    SC.run_group(mi355, [SY.npz(n) for n in names] + [SC.SF_NPZ], explicit_flush=explicit_flush)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--size", default="1080p")
     ap.add_argument("--sessions", default="1,4,16")
     ap.add_argument("--pictures", type=int, default=64)
+    ap.add_argument("--group", action="store_true", help="all sessions in one group: one launch set per step for all of them")
     a = ap.parse_args()
     prov = providers.mi355()
     if a.size == "realshort":
@@ -35,7 +36,8 @@ def main():
         mb_w, mb_h = 120, 68
         seq = [(fs.mb[f], fs.mv[0, f].reshape(-1, 32), fs.coef[f], fs.slices[f], [f - 1] if f else []) for f in range(4)]
     for S in [int(x) for x in a.sessions.split(",")]:
-        sess = [SC.Session(prov.lib, mb_w, mb_h, 3) for _ in range(S)]
+        grp = SC.Group(prov.lib) if a.group else None
+        sess = [SC.Session(prov.lib, mb_w, mb_h, 3, group=grp) for _ in range(S)]
         try:
             if a.size != "realshort":
                 gray = [np.full((16 * mb_h, 16 * mb_w), 128, np.uint8), np.full((8 * mb_h, 8 * mb_w), 128, np.uint8), np.full((8 * mb_h, 8 * mb_w), 128, np.uint8)]
@@ -51,17 +53,21 @@ def main():
                         assert ss.start(i % 3, r, False) == 0
                         assert ss.slice(sl[:1], 0, mb, mv0, None, coef) == 0
                         assert ss.end() == 0
+                    if grp:
+                        assert grp.flush() == 0
                 for ss in sess:
                     ss.get((n - 1) % 3)
             one_pass(4)
             t0 = time.perf_counter()
             one_pass(a.pictures)
             dt = time.perf_counter() - t0
-            print(json.dumps({"size": a.size, "sessions": S, "pictures": a.pictures * S, "pictures_per_s": round(a.pictures * S / dt, 1),
+            print(json.dumps({"size": a.size, "grouped": bool(a.group), "sessions": S, "pictures": a.pictures * S, "pictures_per_s": round(a.pictures * S / dt, 1),
                               "mb_per_s": round(a.pictures * S * mb_w * mb_h / dt)}), flush=True)
         finally:
             for ss in sess:
                 ss.close()
+            if grp:
+                grp.destroy()
 
 
 if __name__ == "__main__":
