@@ -245,13 +245,62 @@ def extra_points(lib, prov, mbw, mbh):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
-    for fn in (hevc_point, sws_points):
+    for fn in (hevc_point, sws_points, session_points):
         try:
             r = fn(lib)
             pts.extend(r if isinstance(r, list) else [r])
         except Exception as e:                 # an extra point must not take the headline line down with it
             pts.append({"name": fn.__name__, "error": repr(e)})
     return pts
+
+
+def session_points(lib):
+    """Real streams end to end on the device side: the records the REFERENCE decoder's own run
+    exported for realshort.mp4 (36 pictures, 320x240) and for a generated QCIF stream (10 pictures I / P, four slices, four
+    references, I_PCM; tests/golden) through whole-frame sessions in ONE group — picture i of every session in one launch set,
+    every picture predicted from the surfaces the session decoded before, host-to-device copy of each picture's records
+    included; fed by this one Python thread."""
+    import time
+    import session_cases as SC
+    import stream_fixture as SF
+    out = []
+
+    class P:
+        pass
+    prov = P()
+    prov.lib = lib
+    for name, npz, S in (("sessions_group_realshort_x64", SC.SF_NPZ, 64),
+                         ("sessions_group_synth_qcif_x64", os.path.join(ROOT, "tests", "golden", "h264_stream_synth_420_8_qcif.npz"), 64)):
+        pics = SF.load_npz(npz)
+        nsurf = 8
+        grp = SC.Group(lib)
+        sess = [SC.Session(lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, group=grp) for _ in range(S)]
+        try:
+            def one_pass():
+                for i, pc in enumerate(pics):
+                    refs = [s_ % nsurf for s_ in pc["slots"]]
+                    mv0, mv1 = pc["mv0"].reshape(-1, 32), pc["mv1"].reshape(-1, 32) if pc["use_l1"] else None
+                    for ss in sess:
+                        assert ss.start(i % nsurf, refs, pc["use_l1"]) == 0
+                        SC.send_picture(ss, pc["mb"], mv0, mv1, pc["coef"], pc["slices"], "runs")
+                        assert ss.end() == 0
+                    assert grp.flush() == 0
+                for ss in sess:
+                    ss.get((len(pics) - 1) % nsurf)
+            one_pass()
+            t0 = time.perf_counter()
+            one_pass()
+            dt = time.perf_counter() - t0
+            n = S * len(pics)
+            out.append({"name": name, "sessions": S, "pictures": n, "pictures_per_s": n / dt,
+                        "macroblocks_per_s": n * pics[0]["mb_w"] * pics[0]["mb_h"] / dt,
+                        "note": "records exported from the reference decoder's run, decoded in sequence on session surfaces, one launch set per "
+                                "picture index for all sessions (mi355_h264_group_flush); bit-exactness of this path: tests/test_session_gpu.py"})
+        finally:
+            for ss in sess:
+                ss.close()
+            grp.destroy()
+    return out
 
 
 def hevc_point(lib):
