@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -231,6 +231,7 @@ class Stream:
         self.qp_min, self.qp_max = 12, 44
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
         self.sparse, self.skip = sparse, skip                # scale of the coded-block probabilities, P(skip): 1.0 / 0.15 = dense test content
+        self.reorder = reorder                               # reference list modification in every P / B slice (the same picture may appear twice)
         self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
         if lossless:
@@ -550,6 +551,22 @@ class Stream:
         self.kind[mby][mbx] = "inter"
 
     # ---- slices and pictures
+    def list_modification(self, w, frame_num, held):
+        """ref_pic_list_modification of one list: 1..held operations, each moving the short-term frame k frames back (k = 1..held,
+        repeats allowed) to the next index — idc 0 (subtract) only, abs_diff_pic_num_minus1 relative to the running prediction (8.2.4.3.1)"""
+        r = self.r
+        if not (self.reorder and held > 0 and r.p(0.8)):
+            w.u(1, 0)
+            return
+        w.u(1, 1)
+        pred = frame_num & 15
+        for _ in range(r.i(1, held)):
+            target = (frame_num - r.i(1, held)) & 15
+            w.ue(0)
+            w.ue((pred - target - 1) & 15)
+            pred = target
+        w.ue(3)
+
     def weight_table(self, w, n, lists):
         r = self.r
         w.ue(r.i(2, 6)); w.ue(r.i(2, 6))
@@ -584,13 +601,19 @@ class Stream:
             w.u(1, r.i(0, 1))                                # direct_spatial_mv_pred_flag
             w.u(1, 1)
             w.ue(nact - 1); w.ue(nact - 1)
-            w.u(1, 0); w.u(1, 0)                             # no reference list modification, either list
+            if self.reorder:
+                self.list_modification(w, frame_num, nact); self.list_modification(w, frame_num, nact)
+            else:
+                w.u(1, 0); w.u(1, 0)                         # no reference list modification, either list
             if self.bmode == 2:
                 self.weight_table(w, nact, 2)
         if is_p:
             w.u(1, 1)
             w.ue(nact - 1)
-            w.u(1, 0)                                        # no reference list modification
+            if self.reorder:
+                self.list_modification(w, frame_num, nact)
+            else:
+                w.u(1, 0)                                    # no reference list modification
             if self.weighted:
                 w.ue(r.i(2, 6)); w.ue(r.i(2, 6))
                 for _ in range(nact):
@@ -760,6 +783,10 @@ STREAMS = {
     # the reference's own limit is 32 slices per picture (MAX_SLICES, h264dec.h: beyond it the decoder warns and its per-slice
     # reference tables alias); the bridge holds 64
     "420_8_slices30": dict(mb_w=10, mb_h=8, chroma_idc=1, depth=8, seed=98, nslices=30, deblock_idc=2, nrefs=2, npics=5, bmode=1),
+    # reference lists re-ordered per slice, a picture at two indices with different weights
+    "420_8_reorder": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=111, nslices=4, deblock_idc=0, nrefs=4, npics=9, reorder=True),
+    "420_8_reorder_b": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=112, nslices=3, deblock_idc=0, nrefs=3, npics=9, bmode=2, reorder=True),
+    "444_8_reorder_b": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=113, nslices=2, deblock_idc=0, nrefs=3, npics=7, bmode=1, reorder=True),
     # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
     "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
     "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),

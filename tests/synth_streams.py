@@ -15,7 +15,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 MD5 = json.load(open(os.path.join(GOLD, "h264_synth_ref_md5.json")))
 ALL = sorted(MD5)
 BRIDGE = [n for n in ALL if n.startswith(("420_8_", "444_8")) and "lossless" not in n and "paff" not in n]            # 8-bit 4:2:0 and 4:4:4: what Tier 2 decodes
-EXPORTED = ["420_8_slices", "420_8_qcif", "420_8_nofilter", "420_8_b_implicit", "420_8_b_explicit", "420_8_b_average", "420_8_t8x8", "420_8_cip_mixed"]
+EXPORTED = ["420_8_slices", "420_8_qcif", "420_8_nofilter", "420_8_b_implicit", "420_8_b_explicit", "420_8_b_average", "420_8_t8x8", "420_8_cip_mixed", "420_8_reorder_b"]
 
 
 def samples(name):
