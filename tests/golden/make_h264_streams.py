@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False, npps=1, scaling=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -231,6 +231,7 @@ class Stream:
         self.qp_min, self.qp_max = 12, 44
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
         self.sparse, self.skip = sparse, skip                # scale of the coded-block probabilities, P(skip): 1.0 / 0.15 = dense test content
+        self.npps, self.scaling = npps, scaling              # picture parameter sets (chroma QP offsets differ; each slice picks one); scaling lists in them
         self.reorder = reorder                               # reference list modification in every P / B slice (the same picture may appear twice)
         self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
@@ -276,19 +277,40 @@ class Stream:
         w.trailing()
         return nal(3, 7, w.bytes())
 
-    def pps(self):
+    def pps(self, k=0):
         w = Bits()
-        w.ue(0); w.ue(0); w.u(1, 0); w.u(1, 0); w.ue(0)
+        w.ue(k); w.ue(0); w.u(1, 0); w.u(1, 0); w.ue(0)
         w.ue(max(1, self.nrefs) - 1); w.ue(0)
         w.u(1, 1 if self.weighted else 0); w.u(2, (0, 2, 1, 0)[self.bmode])
-        w.se(0); w.se(0); w.se(2)
+        w.se(0); w.se(0); w.se((2, -4, 6, -9)[k & 3])
         w.u(1, 1); w.u(1, 1 if self.cip else 0); w.u(1, 0)
-        w.u(1, 1 if self.t8x8 else 0); w.u(1, 0); w.se(-3)          # transform_8x8_mode, no scaling matrices, second chroma qp offset
+        w.u(1, 1 if self.t8x8 else 0)                        # transform_8x8_mode
+        if self.scaling:
+            # pic_scaling_matrix_present: some lists given (random entries 4..40), the others fall back (7.4.2.2 rules A / B)
+            r = Rng(1000 + 17 * k + self.mb_w)
+            w.u(1, 1)
+            nlists = 6 + ((6 if self.cidc == 3 else 2) if self.t8x8 else 0)
+            for i in range(nlists):
+                present = r.p(0.6)
+                w.u(1, int(present))
+                if present:
+                    last = 8
+                    for _ in range(16 if i < 6 else 64):
+                        nxt = r.i(4, 40)
+                        w.se(nxt - last)
+                        last = nxt
+        else:
+            w.u(1, 0)
+        w.se((-3, 5, 0, -7)[k & 3])                          # second chroma qp offset
         w.trailing()
         return nal(3, 8, w.bytes())
 
+    def param_sets(self):
+        return self.sps() + b"".join(self.pps(k) for k in range(self.npps))
+
     # ---- neighbour bookkeeping of one picture
     def begin_picture(self):
+        self.pic_pps = self.r.i(0, self.npps - 1) if self.npps > 1 else 0
         W4, H4 = 4 * self.mb_w, 4 * self.mb_h
         self.nnz = np.zeros((H4, W4), np.int64)
         self.nnz444 = [self.nnz, np.zeros((H4, W4), np.int64), np.zeros((H4, W4), np.int64)]      # 4:4:4: Cb and Cr coded like luma
@@ -587,7 +609,7 @@ class Stream:
         w = Bits()
         w.ue(first_mb)
         w.ue(6 if is_b else (5 if is_p else 7))
-        w.ue(0)
+        w.ue(self.pic_pps)                                   # every slice of a picture names the same set (the reference insists)
         w.u(4, frame_num & 15)
         if self.paff:
             w.u(1, 0 if field is None else 1)
@@ -669,7 +691,7 @@ class Stream:
         assert frame_h % 2 == 0 and not self.bmode
         for i in range(self.npics):
             idr = i == 0
-            au = self.sps() + self.pps() if idr else b""
+            au = self.param_sets() if idr else b""
             fields = (None,) if (idr or r.p(0.4)) else (0, 1)
             for fld in fields:
                 self.mb_h = frame_h if fld is None else frame_h // 2
@@ -701,7 +723,7 @@ class Stream:
             is_p = i > 0 and not (i == 4 and self.npics > 5)          # one more I picture (non-IDR) in the middle
             au = b""
             if idr:
-                au += self.sps() + self.pps()
+                au += self.param_sets()
             self.begin_picture()
             nact = min(i, max(1, self.nrefs))
             cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
@@ -731,7 +753,7 @@ class Stream:
             frame_num = 0 if idr else prev_ref_frame_num + 1
             au = b""
             if idr:
-                au += self.sps() + self.pps()
+                au += self.param_sets()
             self.begin_picture()
             nact = min(nref_pics, max(1, self.nrefs))
             cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
@@ -787,6 +809,11 @@ STREAMS = {
     "420_8_reorder": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=111, nslices=4, deblock_idc=0, nrefs=4, npics=9, reorder=True),
     "420_8_reorder_b": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=112, nslices=3, deblock_idc=0, nrefs=3, npics=9, bmode=2, reorder=True),
     "444_8_reorder_b": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=113, nslices=2, deblock_idc=0, nrefs=3, npics=7, bmode=1, reorder=True),
+    # several picture parameter sets (chroma QP offsets and scaling lists differ; a picture picks one)
+    "420_8_pps": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=121, nslices=5, deblock_idc=0, nrefs=3, npics=8, npps=4, bmode=1),
+    "420_8_scaling": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=122, nslices=3, deblock_idc=0, nrefs=2, npics=7, npps=3, scaling=True, t8x8=True),
+    "444_8_scaling": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=123, nslices=2, deblock_idc=0, nrefs=2, npics=6, npps=2, scaling=True, t8x8=True, bmode=1),
+    "422_10_scaling": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=124, nslices=2, deblock_idc=0, nrefs=2, npics=6, npps=2, scaling=True, t8x8=True),
     # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
     "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
     "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),
