@@ -77,6 +77,8 @@ struct Staging;
 typedef struct DevPic {
     const H264Picture *owner;
     uint8_t *plane[3];          /* one allocation, planes back to back */
+    int frame_num, poc;         /* what the owner held when this copy was made: the decoder recycles its H264Picture entries, */
+    const uint8_t *data0;       /* and a frame it made up for a frame_num gap can sit where an older picture of ours sat */
 } DevPic;
 
 typedef struct Submission {     /* a packed picture on its way through the dispatcher */
@@ -406,6 +408,9 @@ static Bridge *bridge_get(const H264Context *h)
     if (mi355_init(dev ? atoi(dev) : 0) != 0) { br_fail(b, "no usable MI355X"); return b; }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
+    /* frame_num gaps: the decoder fills a lost frame with a host-side copy of the previous one (h264_slice.c:1425-1452) — every
+     * picture must be complete in its frame before the next one starts */
+    b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL && !h->ps.sps->gaps_in_frame_num_allowed_flag;
     b->stride[0] = (16 * b->mb_w + 63) & ~63; b->stride[1] = b->stride[0] / 2;
     b->plane_bytes[0] = (size_t)b->stride[0] * 16 * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * 8 * b->mb_h;
     int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
@@ -443,6 +448,30 @@ static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, 
     }
     slot->owner = p;
     return slot;
+}
+
+/* A reference this bridge never decoded: a frame the decoder made up for a gap in frame_num (h264_field_start fills it with a
+ * copy of the previous frame, h264_slice.c), or one decoded before the bridge took over.  Its samples are in the host frame:
+ * they go to a new device picture (synchronous copy; nothing on the device uses that picture yet). */
+static DevPic *devpic_upload(Bridge *b, const H264Context *h, const H264Picture *p)
+{
+    if (!p || !p->f || !p->f->data[0]) return NULL;
+    DevPic *r = devpic_of(b, h, p, 1);
+    if (!r) return NULL;
+    uint8_t *tmp = malloc(picture_bytes(b));
+    if (!tmp) { r->owner = NULL; return NULL; }
+    uint8_t *dst = tmp;
+    for (int k = 0; k < 3; k++) {
+        const int half = k && !b->c444;
+        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->stride[half];
+        for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * st, p->f->data[k] + (size_t)y * p->f->linesize[k], (size_t)w);
+        dst += b->plane_bytes[half];
+    }
+    const int rc = mi355_memcpy_h2d(r->plane[0], tmp, picture_bytes(b));
+    free(tmp);
+    if (rc != 0) { r->owner = NULL; return NULL; }
+    r->frame_num = p->frame_num; r->poc = p->poc; r->data0 = p->f->data[0];
+    return r;
 }
 
 static int slot_of(Bridge *b, const H264Picture *p)
@@ -706,6 +735,7 @@ static int submit_picture(Bridge *b, H264Context *h)
     Staging *s = &b->st[b->cur];
     DevPic *cur = devpic_of(b, h, h->cur_pic_ptr, 1);
     if (!cur) return -1;
+    cur->frame_num = h->cur_pic_ptr->frame_num; cur->poc = h->cur_pic_ptr->poc; cur->data0 = h->cur_pic_ptr->f->data[0];
     int lw = 0;
     const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->mb_h, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;
@@ -726,8 +756,10 @@ static int submit_picture(Bridge *b, H264Context *h)
         } else
             for (int k = 0; k < 3; k++) { f->dst[k] = cur->plane[k]; f->recon[k] = b->recon[k]; }
         for (int i = 0; i < b->nslots; i++) {
-            DevPic *r = devpic_of(b, h, b->slot_pic[i], 0);
-            if (!r) return -2;                       /* a reference this bridge never decoded (a stream joined mid-way) */
+            const H264Picture *rp = b->slot_pic[i];
+            DevPic *r = devpic_of(b, h, rp, 0);
+            if (r && (r->frame_num != rp->frame_num || r->poc != rp->poc || r->data0 != rp->f->data[0])) r = NULL;      /* a copy of what that entry held before */
+            if (!r && !(r = devpic_upload(b, h, rp))) return -2;
             if (b->c444) { f->ref[i][0] = r->plane[p]; f->ref[i][1] = b->scratch_c[0]; f->ref[i][2] = b->scratch_c[1]; }
             else for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k];
         }

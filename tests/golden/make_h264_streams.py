@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False, npps=1, scaling=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False, npps=1, scaling=False, gaps=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -232,6 +232,7 @@ class Stream:
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
         self.sparse, self.skip = sparse, skip                # scale of the coded-block probabilities, P(skip): 1.0 / 0.15 = dense test content
         self.npps, self.scaling = npps, scaling              # picture parameter sets (chroma QP offsets differ; each slice picks one); scaling lists in them
+        self.gaps = gaps                                     # gaps_in_frame_num_value_allowed_flag, and some frame_num values are skipped
         self.reorder = reorder                               # reference list modification in every P / B slice (the same picture may appear twice)
         self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
         self.lossless = lossless                             # qpprime_y_zero_transform_bypass_flag and QP'Y = 0 throughout: transform bypass
@@ -252,7 +253,7 @@ class Stream:
             w.ue(0); w.ue(2)          # pic_order_cnt_type 0, 6 bits of pic_order_cnt_lsb
         else:
             w.ue(2)                   # pic_order_cnt_type 2: output order = decoding order
-        w.ue(max(1, self.nrefs)); w.u(1, 0)
+        w.ue(max(1, self.nrefs)); w.u(1, 1 if self.gaps else 0)
         if self.paff:
             w.ue(self.mb_w - 1); w.ue(self.mb_h // 2 - 1)       # map units: field macroblock rows
             w.u(1, 0); w.u(1, 0); w.u(1, 1)                      # frame_mbs_only 0, mb_adaptive_frame_field 0, direct_8x8_inference
@@ -732,6 +733,8 @@ class Stream:
                     au += self.slice(i, frame_num, idr, is_p and not (self.mixed and self.r.p(0.4)), cuts[s_], cuts[s_ + 1], s_, nact)
             units.append(au)
             frame_num += 1
+            if self.gaps and i in (2, 5):
+                frame_num += 1 + (i == 5)                    # one / two frames "lost": the decoder fills the gap with copies of the previous frame
         return units
 
     def build_b(self):
@@ -814,6 +817,8 @@ STREAMS = {
     "420_8_scaling": dict(mb_w=7, mb_h=5, chroma_idc=1, depth=8, seed=122, nslices=3, deblock_idc=0, nrefs=2, npics=7, npps=3, scaling=True, t8x8=True),
     "444_8_scaling": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=123, nslices=2, deblock_idc=0, nrefs=2, npics=6, npps=2, scaling=True, t8x8=True, bmode=1),
     "422_10_scaling": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=124, nslices=2, deblock_idc=0, nrefs=2, npics=6, npps=2, scaling=True, t8x8=True),
+    # frame_num gaps: the decoder inserts frames the bitstream never carried (copies of the previous one) and predicts from them
+    "420_8_gaps": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=131, nslices=2, deblock_idc=0, nrefs=3, npics=9, gaps=True),
     # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
     "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
     "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),
