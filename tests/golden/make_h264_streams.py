@@ -657,8 +657,9 @@ class Stream:
         if self.lossless:
             self.qp = self.qp_min
         w.se(self.qp - 26)
-        w.ue(self.deblock_idc)
-        if self.deblock_idc != 1:
+        idc = self.deblock_idc if self.deblock_idc >= 0 else r.i(0, 2)     # -1: every slice draws its own
+        w.ue(idc)
+        if idc != 1:
             w.se(r.i(-2, 2)); w.se(r.i(-2, 2))
         skip = 0
         for a in range(first_mb, last_mb):
@@ -819,6 +820,13 @@ STREAMS = {
     "422_10_scaling": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=124, nslices=2, deblock_idc=0, nrefs=2, npics=6, npps=2, scaling=True, t8x8=True),
     # frame_num gaps: the decoder inserts frames the bitstream never carried (copies of the previous one) and predicts from them
     "420_8_gaps": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=131, nslices=2, deblock_idc=0, nrefs=3, npics=9, gaps=True),
+    # every slice with its own disable_deblocking_filter_idc; a picture of one macroblock row.  (Pictures ONE MACROBLOCK WIDE are
+    # not used: the reference's own decoder is not self-consistent there — with all vectors zero a P macroblock with 4-wide
+    # partitions does not come out as a copy of its reference, while its DSP functions called one by one are right; this
+    # project's hooks, bridge and oracle agree with each other and with the standard on such streams.)
+    "420_8_idc_per_slice": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=141, nslices=6, deblock_idc=-1, nrefs=2, npics=8, bmode=1),
+    "420_8_9x1": dict(mb_w=9, mb_h=1, chroma_idc=1, depth=8, seed=143, nslices=2, deblock_idc=0, nrefs=2, npics=6, bmode=1),
+    "444_8_2x7": dict(mb_w=2, mb_h=7, chroma_idc=3, depth=8, seed=144, nslices=2, deblock_idc=-1, nrefs=2, npics=6),
     # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
     "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
     "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),
