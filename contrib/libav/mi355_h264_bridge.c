@@ -824,7 +824,13 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
             }
         }
     }
-    return __real_ff_h264_field_end(h, sl, in_setup);
+    /* reference marking runs inside the real function: memory_management_control_operation 5 rewrites the picture's frame_num
+     * and POC (h264_refs.c) — the device copy is labelled with what the picture holds afterwards */
+    DevPic *dp = b && b->state > 0 ? b->st[b->cur].pic : NULL;
+    const H264Picture *hp = h->cur_pic_ptr;
+    const int ret = __real_ff_h264_field_end(h, sl, in_setup);
+    if (dp && hp && dp->owner == hp) { dp->frame_num = hp->frame_num; dp->poc = hp->poc; }
+    return ret;
 }
 
 /* for hosts that want the numbers (the throughput harness prints them) */

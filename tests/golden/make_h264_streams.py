@@ -221,7 +221,7 @@ class Rng:
 
 # ---------------------------------------------------------------- a stream
 class Stream:
-    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False, npps=1, scaling=False, gaps=False):
+    def __init__(self, T, name, mb_w, mb_h, chroma_idc, depth, seed, nslices=1, deblock_idc=0, weighted=True, nrefs=2, npics=6, far=9, bmode=0, t8x8=False, lossless=False, crop=None, mixed=False, cip=False, paff=False, sparse=1.0, skip=0.15, reorder=False, npps=1, scaling=False, gaps=False, mmco=False):
         self.T, self.name, self.mb_w, self.mb_h, self.cidc, self.depth = T, name, mb_w, mb_h, chroma_idc, depth
         self.r = Rng(seed)
         self.nslices, self.deblock_idc, self.weighted, self.nrefs, self.npics, self.far = nslices, deblock_idc, weighted, nrefs, npics, far
@@ -232,6 +232,7 @@ class Stream:
         self.crop, self.mixed, self.cip = crop, mixed, cip   # (right, bottom) cropping in chroma-sample units; I and P slices in one picture; constrained_intra_pred
         self.sparse, self.skip = sparse, skip                # scale of the coded-block probabilities, P(skip): 1.0 / 0.15 = dense test content
         self.npps, self.scaling = npps, scaling              # picture parameter sets (chroma QP offsets differ; each slice picks one); scaling lists in them
+        self.mmco = mmco                                     # adaptive reference marking: a long-term frame (picture 2), memory_management_control_operation 5 (picture 6)
         self.gaps = gaps                                     # gaps_in_frame_num_value_allowed_flag, and some frame_num values are skipped
         self.reorder = reorder                               # reference list modification in every P / B slice (the same picture may appear twice)
         self.paff = paff                                     # frame_mbs_only_flag 0: each frame is coded as a frame picture or as two field pictures
@@ -605,7 +606,7 @@ class Stream:
                     for _ in range(2):
                         w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
 
-    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact, is_b=False, poc=None, ref_idc=3, field=None):
+    def slice(self, idx, frame_num, idr, is_p, first_mb, last_mb, sid, nact, is_b=False, poc=None, ref_idc=3, field=None, marking=None):
         r = self.r
         w = Bits()
         w.ue(first_mb)
@@ -651,6 +652,13 @@ class Stream:
                             w.se(r.i(-20, 90)); w.se(r.i(-12, 12))
         if idr:
             w.u(1, 0); w.u(1, 0)
+        elif ref_idc and marking == "long":
+            w.u(1, 1)
+            w.ue(4); w.ue(1)                                 # one long-term frame index
+            w.ue(3); w.ue(0); w.ue(0)                        # the previous frame becomes long-term frame 0
+            w.ue(0)
+        elif ref_idc and marking == "reset":
+            w.u(1, 1); w.ue(5); w.ue(0)                      # all reference pictures unused; this picture becomes frame_num 0
         elif ref_idc:
             w.u(1, 0)
         self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
@@ -719,7 +727,7 @@ class Stream:
             return self.build_b()
         units = []
         nmb = self.mb_w * self.mb_h
-        frame_num = 0
+        frame_num, held = 0, 0
         for i in range(self.npics):
             idr = i == 0
             is_p = i > 0 and not (i == 4 and self.npics > 5)          # one more I picture (non-IDR) in the middle
@@ -727,13 +735,17 @@ class Stream:
             if idr:
                 au += self.param_sets()
             self.begin_picture()
-            nact = min(i, max(1, self.nrefs))
+            nact = min(i, max(1, self.nrefs)) if not self.mmco else min(held, self.nrefs)
+            marking = ("long" if i == 2 else ("reset" if i == 6 else None)) if self.mmco else None
             cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
             for s_ in range(len(cuts) - 1):
                 if cuts[s_] < cuts[s_ + 1]:
-                    au += self.slice(i, frame_num, idr, is_p and not (self.mixed and self.r.p(0.4)), cuts[s_], cuts[s_ + 1], s_, nact)
+                    au += self.slice(i, frame_num, idr, is_p and not (self.mixed and self.r.p(0.4)), cuts[s_], cuts[s_ + 1], s_, nact, marking=marking)
             units.append(au)
             frame_num += 1
+            held = 1 if marking == "reset" else min(held + 1, max(1, self.nrefs))
+            if marking == "reset":
+                frame_num = 1                                # the picture counts as frame_num 0 from here on
             if self.gaps and i in (2, 5):
                 frame_num += 1 + (i == 5)                    # one / two frames "lost": the decoder fills the gap with copies of the previous frame
         return units
@@ -827,6 +839,8 @@ STREAMS = {
     "420_8_idc_per_slice": dict(mb_w=8, mb_h=6, chroma_idc=1, depth=8, seed=141, nslices=6, deblock_idc=-1, nrefs=2, npics=8, bmode=1),
     "420_8_9x1": dict(mb_w=9, mb_h=1, chroma_idc=1, depth=8, seed=143, nslices=2, deblock_idc=0, nrefs=2, npics=6, bmode=1),
     "444_8_2x7": dict(mb_w=2, mb_h=7, chroma_idc=3, depth=8, seed=144, nslices=2, deblock_idc=-1, nrefs=2, npics=6),
+    # adaptive reference marking: a long-term reference frame, then operation 5 (everything unused, frame_num and POC start over)
+    "420_8_mmco": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=151, nslices=2, deblock_idc=0, nrefs=4, npics=10, mmco=True),
     # interlaced-capable sequences (frame_mbs_only_flag 0): frame pictures and field pairs mixed
     "420_8_paff": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=101, nslices=2, deblock_idc=0, nrefs=2, npics=8, paff=True),
     "422_10_paff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=102, nslices=1, deblock_idc=0, nrefs=2, npics=6, paff=True, t8x8=True),
