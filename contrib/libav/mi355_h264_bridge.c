@@ -133,7 +133,10 @@ typedef struct Bridge {
     int nslices, slice_num_of[BR_MAX_SLICES], uses_l1;
     int mbs_packed;             /* macroblocks the decoder delivered for the picture being packed */
     const H264Picture *slot_pic[MI355_H264_MAX_SLOTS];
+    int slot_par[MI355_H264_MAX_SLOTS];   /* field pictures: the parity of the reference field (0 top, 1 bottom); -1: a frame */
     int nslots;
+    int field, parity;          /* the picture being packed is one field of its frame (PAFF): which */
+    int rows, nmb_pic;          /* its macroblock rows and macroblocks */
     unsigned long pictures, waits;
     unsigned long last_set;     /* launch set (1-based) that holds this decoder's latest picture */
 } Bridge;
@@ -374,7 +377,7 @@ void __wrap_ff_h264_flush_change(H264Context *h)
         finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
         b->open = 0;
         const SPS *sps = h->ps.sps;
-        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height == b->mb_h && sps->frame_mbs_only_flag && sps->bit_depth_luma == 8 &&
+        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == 8 &&
                          (sps->chroma_format_idc == 3) == b->c444 && (sps->chroma_format_idc == 1 || sps->chroma_format_idc == 3) &&
                          !sps->transform_bypass && !sps->residual_color_transform_flag;
         if (!same) { bridge_release(b); b->state = 0; }
@@ -396,11 +399,11 @@ static Bridge *bridge_get(const H264Context *h)
     }
     if (b->state) return b;
     const int idc = h->ps.sps->chroma_format_idc;
-    /* a sequence that MAY hold field pictures or field macroblocks (frame_mbs_only_flag 0) is outside the path as a whole: the
-     * choice between a frame and two fields is made per picture (PAFF), and this set-up is not */
-    if (!h->ps.sps->frame_mbs_only_flag || FRAME_MBAFF(h) || FIELD_PICTURE(h) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
+    /* a sequence that may hold field MACROBLOCKS (mb_adaptive_frame_field_flag) is outside the path as a whole; field PICTURES
+     * (PAFF: the choice between a frame and two fields is made per picture) are inside: begin_picture() looks at each one */
+    if ((!h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff) || FRAME_MBAFF(h) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
         h->ps.sps->transform_bypass) {
-        br_fail(b, "stream outside the batched path (needs progressive 8-bit 4:2:0 or 4:4:4 without transform bypass)");
+        br_fail(b, "stream outside the batched path (needs 8-bit 4:2:0 or 4:4:4 frame or field pictures without MBAFF and transform bypass)");
         b->soft = 1;
         return b;
     }
@@ -474,12 +477,13 @@ static DevPic *devpic_upload(Bridge *b, const H264Context *h, const H264Picture 
     return r;
 }
 
-static int slot_of(Bridge *b, const H264Picture *p)
+static int slot_of(Bridge *b, const H264Picture *p, int par)
 {
     for (int i = 0; i < b->nslots; i++)
-        if (b->slot_pic[i] == p) return i;
+        if (b->slot_pic[i] == p && b->slot_par[i] == par) return i;
     if (b->nslots >= MI355_H264_MAX_SLOTS) return -1;
     b->slot_pic[b->nslots] = p;
+    b->slot_par[b->nslots] = par;
     return b->nslots++;
 }
 
@@ -525,8 +529,11 @@ static void begin_picture(Bridge *b, const H264Context *h)
     memset(s->mv[0], 0, (size_t)b->nmb * 64);
     memset(s->mv[1], 0, (size_t)b->nmb * 64);
     b->nslices = b->nslots = b->uses_l1 = b->mbs_packed = 0;
+    b->field = h->picture_structure != PICT_FRAME;
+    b->parity = h->picture_structure == PICT_BOTTOM_FIELD;
+    b->rows = b->field ? b->mb_h / 2 : b->mb_h;
+    b->nmb_pic = b->mb_w * b->rows;
     b->open = 1;
-    (void)h;
 }
 
 static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *sl)
@@ -541,12 +548,15 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
     s->luma_log2_weight_denom = sl->pwt.luma_log2_weight_denom;
     s->chroma_log2_weight_denom = sl->pwt.chroma_log2_weight_denom;
     s->list_count = sl->list_count;
-    for (unsigned list = 0; list < sl->list_count; list++)
-        for (unsigned i = 0; i < sl->ref_count[list] && i < MI355_H264_MAX_REFS; i++) {
-            const int slot = slot_of(b, sl->ref_list[list][i].parent);
+    for (unsigned list = 0; list < sl->list_count; list++) {
+        if (sl->ref_count[list] > MI355_H264_MAX_REFS) return -1;        /* 17..32 fields per list: more than the slice table holds */
+        for (unsigned i = 0; i < sl->ref_count[list]; i++) {
+            /* a field picture's list entries are fields: (frame, parity) names the reference */
+            const int slot = slot_of(b, sl->ref_list[list][i].parent, b->field ? (sl->ref_list[list][i].reference & 3) - 1 : -1);
             if (slot < 0) return -1;
             s->ref_slot[list][i] = (uint8_t)slot;
         }
+    }
     for (int r = 0; r < MI355_H264_MAX_REFS; r++) {
         for (int l = 0; l < 2; l++)
             for (int k = 0; k < 2; k++) {
@@ -614,7 +624,8 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     if (!b || b->state < 0) { __real_ff_h264_hl_decode_mb(h, sl); return; }
     if (!b->open) begin_picture(b, h);
     Staging *st = &b->st[b->cur];
-    const int mb_xy = sl->mb_xy, idx = sl->mb_x + sl->mb_y * b->mb_w;
+    /* in a field picture sl->mb_y counts FRAME macroblock rows (2 * field row + parity, h264_slice.c:2324-2329, 2456-2460) */
+    const int mb_xy = sl->mb_xy, mb_row = sl->mb_y >> b->field, idx = sl->mb_x + mb_row * b->mb_w;
     const int mb_type = h->cur_pic.mb_type[mb_xy];
     mi355_h264_mb *m = &st->mb[0][idx];
     b->mbs_packed++;
@@ -637,7 +648,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     if (!sl->deblocking_filter) m->flags |= MI355_MBF_NO_DEBLOCK;
     else {
         if (sl->mb_x > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - 1] == sl->slice_num)) m->flags |= MI355_MBF_LEFT_EDGE;
-        if (sl->mb_y > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - h->mb_stride] == sl->slice_num)) m->flags |= MI355_MBF_TOP_EDGE;
+        if (mb_row > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - (h->mb_stride << b->field)] == sl->slice_num)) m->flags |= MI355_MBF_TOP_EDGE;
     }
     if (sl->pwt.use_weight) m->flags |= MI355_MBF_WEIGHTED;
     m->intra16x16_pred_mode = (uint8_t)sl->intra16x16_pred_mode;
@@ -695,6 +706,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                     const int r = sl->ref_cache[list][scan8[4 * q]];
                     m->ref_idx[list][q] = (int8_t)(r < 0 ? -1 : r);
                     if (r >= 0) m->u.inter.ref_pic[list][q] = st->slices[0][si].ref_slot[list][r];
+                    if (r >= 0 && b->field) m->u.inter.chroma_dy[list][q] = (int8_t)(2 * (b->parity - ((sl->ref_list[list][r].reference & 3) - 1)));
                 }
                 for (int i = 0; i < 16; i++) {
                     const int x4 = (i & 1) + 2 * ((i >> 2) & 1), y4 = ((i >> 1) & 1) + 2 * (i >> 3);
@@ -737,7 +749,7 @@ static int submit_picture(Bridge *b, H264Context *h)
     if (!cur) return -1;
     cur->frame_num = h->cur_pic_ptr->frame_num; cur->poc = h->cur_pic_ptr->poc; cur->data0 = h->cur_pic_ptr->f->data[0];
     int lw = 0;
-    const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->mb_h, s->ilist, s->istart, &lw);
+    const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->rows, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;
     for (int l = 0; l < maxl; l++) s->widths[l] = s->istart[l + 1] - s->istart[l];
     s->maxl = maxl;
@@ -747,21 +759,29 @@ static int submit_picture(Bridge *b, H264Context *h)
          * read the staging block in place (device-visible host memory) */
         mi355_h264_frame *f = &s->desc[p];
         memset(f, 0, sizeof(*f));
-        f->mb_width = b->mb_w; f->mb_height = b->mb_h;
-        f->dst_stride[0] = f->recon_stride[0] = b->stride[0];
-        f->dst_stride[1] = f->recon_stride[1] = b->stride[1];
+        /* a field picture: every other line of the frame's planes — first line at the field's parity, strides doubled; its
+         * references are fields addressed the same way (the unfiltered reconstruction is a surface of its own: plain rows) */
+        const int fs = b->field ? 2 : 1;
+        f->mb_width = b->mb_w; f->mb_height = b->rows;
+        f->field_picture = b->field;
+        f->dst_stride[0] = fs * b->stride[0]; f->recon_stride[0] = b->stride[0];
+        f->dst_stride[1] = fs * b->stride[1]; f->recon_stride[1] = b->stride[1];
+        const size_t fo[2] = { b->field && b->parity ? (size_t)b->stride[0] : 0, b->field && b->parity ? (size_t)b->stride[1] : 0 };
         if (b->c444) {
-            f->dst[0] = cur->plane[p]; f->recon[0] = b->recon[p];
+            f->dst[0] = cur->plane[p] + fo[0]; f->recon[0] = b->recon[p];
             for (int k = 1; k < 3; k++) f->dst[k] = f->recon[k] = b->scratch_c[k - 1];
+            f->dst_stride[1] = f->recon_stride[1] = b->stride[1];
         } else
-            for (int k = 0; k < 3; k++) { f->dst[k] = cur->plane[k]; f->recon[k] = b->recon[k]; }
+            for (int k = 0; k < 3; k++) { f->dst[k] = cur->plane[k] + fo[k > 0]; f->recon[k] = b->recon[k]; }
         for (int i = 0; i < b->nslots; i++) {
             const H264Picture *rp = b->slot_pic[i];
             DevPic *r = devpic_of(b, h, rp, 0);
-            if (r && (r->frame_num != rp->frame_num || r->poc != rp->poc || r->data0 != rp->f->data[0])) r = NULL;      /* a copy of what that entry held before */
+            /* a copy of what that entry held before?  (not asked of the frame being decoded: its second field predicts from its first) */
+            if (r && rp != h->cur_pic_ptr && (r->frame_num != rp->frame_num || r->poc != rp->poc || r->data0 != rp->f->data[0])) r = NULL;
             if (!r && !(r = devpic_upload(b, h, rp))) return -2;
-            if (b->c444) { f->ref[i][0] = r->plane[p]; f->ref[i][1] = b->scratch_c[0]; f->ref[i][2] = b->scratch_c[1]; }
-            else for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k];
+            const size_t ro[2] = { b->slot_par[i] > 0 ? (size_t)b->stride[0] : 0, b->slot_par[i] > 0 ? (size_t)b->stride[1] : 0 };
+            if (b->c444) { f->ref[i][0] = r->plane[p] + ro[0]; f->ref[i][1] = b->scratch_c[0]; f->ref[i][2] = b->scratch_c[1]; }
+            else for (int k = 0; k < 3; k++) f->ref[i][k] = r->plane[k] + ro[k > 0];
         }
         f->mb = s->mb[p]; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef[p];
         f->slices = s->slices[p]; f->nslices = b->nslices;
@@ -804,7 +824,7 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
          * reference's frame); then this decoder continues on the reference's C path — its error concealment, where built in,
          * rewrites the frame on the host (ff_er_frame_end below), and the device copy of the picture would no longer be what
          * later pictures must predict from. */
-        const int incomplete = b->mbs_packed != b->nmb;
+        const int incomplete = b->mbs_packed != b->nmb_pic;
         if (submit_picture(b, h) != 0) {
             /* the picture is lost for this path; what was enqueued must drain before the host touches the frames again */
             finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);

@@ -5,7 +5,7 @@
  * What it replaces in the reference: the per-macroblock body of the slice decoder
  * after entropy decoding —
  *     ff_h264_hl_decode_mb()   libavcodec/h264_mb.c:798 (hl_decode_mb, h264_mb_template.c:41,
- *                               8-bit "simple" variant: progressive, 4:2:0, not lossless)
+ *                               8-bit "simple" variant: frame or field pictures without MBAFF, 4:2:0, not lossless)
  *     loop_filter() / ff_h264_filter_mb()   libavcodec/h264_slice.c:2198, h264_loopfilter.c:716
  * for ALL macroblocks of a batch of independent pictures at once, in the reference's
  * own "reconstruct the whole picture, then filter it" mode (H264Context.postpone_filter,
@@ -104,7 +104,9 @@ typedef struct mi355_h264_mb {
             uint8_t ref_pic[2][4];       /*    inter MBs: picture slot (index into mi355_h264_frame.ref[]) of each
                                                quadrant's reference = slices[slice_id].ref_slot[list][ref_idx],
                                                0xFF when unused; what the loop filter compares (h->ref2frm) */
-            uint8_t reserved[8];
+            int8_t  chroma_dy[2][4];     /*    field pictures: what mc_dir_part adds to the chroma vector's y (eighth samples of a chroma
+                                               line) when the reference field has the other parity: 2 * (parity of this field -
+                                               parity of the reference), h264_mb.c:287-291; 0 in frame pictures */
         } inter;
     } u;
 } mi355_h264_mb;
@@ -130,7 +132,7 @@ static inline int mi355_luma_dc_slot(int k)
  * the MB (index = x4 + 4*y4), one array per list: mv[list][mb*16 + blk][2].  Blocks that
  * do not use a list must hold (0,0) (what mv_cache holds, h264_slice.c:2031-2038). */
 
-#define MI355_H264_MAX_REFS 16   /* per list, progressive pictures */
+#define MI355_H264_MAX_REFS 16   /* per list (a field picture with more than 16 fields in a list is outside the path) */
 #define MI355_H264_MAX_SLOTS 32  /* distinct reference pictures per frame */
 
 /* Per-slice constants (sl->pwt, ref lists, PPS chroma QP tables). */
@@ -174,7 +176,11 @@ typedef struct mi355_h264_frame {
     int32_t max_level_width;          /* largest number of macroblocks on one level (*max_level_width of
                                          mi355_h264_intra_schedule); 0 = unknown: mi355_h264_decode_frames() then assumes
                                          the widest level a picture of this size can have */
-    int32_t reserved;
+    int32_t field_picture;            /* 1: the picture is ONE FIELD of a frame (PAFF) — its planes are every other line of the frame's
+                                         (pointers at the field's first line, strides doubled, mb_height = the field's), every reference
+                                         slot is a field addressed the same way; the loop filter then uses the vertical vector limit 2
+                                         (h264_loopfilter.c:723) and strength 3 instead of 4 on horizontal macroblock edges of intra
+                                         macroblocks (:551-556).  0: a frame picture */
 } mi355_h264_frame;
 
 /* Reconstruct and deblock `nframes` independent pictures described by the HOST array

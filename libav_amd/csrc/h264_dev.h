@@ -62,10 +62,10 @@ static inline uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel)
     return r;
 }
 template <int K> static inline int quad_bcast(int v) { return __shfl(v, ((int)(threadIdx.x & 63) & ~3) | K); }
-static inline bool pk_absdiff_far(uint32_t a, uint32_t b)
+static inline bool pk_absdiff_far(uint32_t a, uint32_t b, uint32_t mask = 0xFFFCFFFCu)      /* mask 0xFFFEFFFC: the vertical limit is 2 (field pictures) */
 {
     const int dx = (int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF), dy = (int16_t)(a >> 16) - (int16_t)(b >> 16);
-    return (dx < 0 ? -dx : dx) >= 4 || (dy < 0 ? -dy : dy) >= 4;
+    return (dx < 0 ? -dx : dx) >= 4 || (dy < 0 ? -dy : dy) >= ((mask >> 16) == 0xFFFE ? 2 : 4);
 }
 #else
 __device__ __forceinline__ int absdiff8(int a, int b) { return (int)__builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, 0u); }
@@ -77,13 +77,13 @@ __device__ __forceinline__ int med3i(int x, int lo, int hi)
 }
 __device__ __forceinline__ uint32_t byte_perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 template <int K> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true); }
-__device__ __forceinline__ bool pk_absdiff_far(uint32_t a, uint32_t b)
+__device__ __forceinline__ bool pk_absdiff_far(uint32_t a, uint32_t b, uint32_t mask = 0xFFFCFFFCu)
 {
     typedef short v2s __attribute__((ext_vector_type(2)));
     const v2s d = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b));
     const v2s n = (v2s)((short)0) - d;
     const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(d, n));    /* |d| per half, <= 32767 (d = -32768 gives -32768: still >= 4 below) */
-    return (m & 0xFFFCFFFCu) != 0;
+    return (m & mask) != 0;
 }
 #endif
 

@@ -160,22 +160,24 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
     const int slot = __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.ref_pic[list][(bx >> 3) + 2 * (by >> 3)]);
     const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
     const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
+    /* the chroma vector of a field predicted from a field of the other parity: h264_mb.c:287-291 (0 in frame pictures) */
+    const int myc = my + __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.chroma_dy[list][(bx >> 3) + 2 * (by >> 3)]);
     (void)refs;
     const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
     PlaneRef ry{mi355_global(rp[0]), fr.ref_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
     PlaneRef rb{mi355_global(rp[1]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     PlaneRef rr{mi355_global(rp[2]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
 #ifndef MI355_EXP_NO_STAGE
-    if (w == 16 && h == 16) stage_windows16(s.mc, ry, mx >> 2, my >> 2, rb, rr, mx >> 3, my >> 3);
-    else stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, my >> 3, w >> 1, h >> 1);
+    if (w == 16 && h == 16) stage_windows16(s.mc, ry, mx >> 2, my >> 2, rb, rr, mx >> 3, myc >> 3);
+    else stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, myc >> 3, w >> 1, h >> 1);
 #endif
 #ifndef MI355_EXP_NO_LUMA
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
 #endif
     RPROF(4);
 #ifndef MI355_EXP_NO_CHROMA
-    if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, my & 7, pcb, pcr, 8, avg);
-    else mc_chroma_compute(s.mc, 2, mx & 7, my & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
+    if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, myc & 7, pcb, pcr, 8, avg);
+    else mc_chroma_compute(s.mc, 2, mx & 7, myc & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
 #endif
 }
 
@@ -878,12 +880,12 @@ __device__ __forceinline__ MbInfo mb_info_load(const uint8_t *base, uint32_t off
 
 /* check_mv (h264_loopfilter.c:442-470, frame macroblocks, mvy_limit 4) on raw reference bytes (0xFF = unused; the
  * comparisons are equalities, and intra macroblocks never get here) */
-__device__ __forceinline__ bool check_mv_raw(uint32_t rp0, uint32_t rq0, uint32_t rp1, uint32_t rq1, const uint32_t mp[2], const uint32_t mq[2], bool two_lists)
+__device__ __forceinline__ bool check_mv_raw(uint32_t rp0, uint32_t rq0, uint32_t rp1, uint32_t rq1, const uint32_t mp[2], const uint32_t mq[2], bool two_lists, uint32_t far)
 {
-    bool v = rp0 != rq0 || (rp0 != 0xFF && pk_absdiff_far(mp[0], mq[0]));
+    bool v = rp0 != rq0 || (rp0 != 0xFF && pk_absdiff_far(mp[0], mq[0], far));
     if (two_lists) {
-        v = v || rp1 != rq1 || pk_absdiff_far(mp[1], mq[1]);
-        const bool cross = rp0 != rq1 || rp1 != rq0 || pk_absdiff_far(mp[0], mq[1]) || pk_absdiff_far(mp[1], mq[0]);
+        v = v || rp1 != rq1 || pk_absdiff_far(mp[1], mq[1], far);
+        const bool cross = rp0 != rq1 || rp1 != rq0 || pk_absdiff_far(mp[0], mq[1], far) || pk_absdiff_far(mp[1], mq[0], far);
         v = v && cross;
     }
     return v;
@@ -896,7 +898,7 @@ struct BsRole {
 /* one boundary strength, filter_mb_dir h264_loopfilter.c:472-713.  q*: the macroblock across the edge (the
  * neighbour for edge 0, this one otherwise) */
 __device__ __forceinline__ uint32_t bs_role(const MbInfo &h, const MbInfo &nb, bool outer, bool odd, bool enabled, const BsRole &r,
-                                            const uint32_t mp[2], const uint32_t mq[2], bool two_lists)
+                                            const uint32_t mp[2], const uint32_t mq[2], bool two_lists, uint32_t far, uint32_t intra_edge)
 {
     const uint32_t q_type = outer ? nb.type : h.type, q_nnz = outer ? nb.nnz : h.nnz;
     const uint32_t q_ref0 = outer ? nb.ref0 : h.ref0, q_ref1 = outer ? nb.ref1 : h.ref1;
@@ -904,8 +906,8 @@ __device__ __forceinline__ uint32_t bs_role(const MbInfo &h, const MbInfo &nb, b
     const bool coded = ((h.nnz & r.pbit) | (q_nnz & r.qbit)) != 0;
     const uint32_t rp0 = (h.ref0 >> r.psh) & 0xFF, rq0 = (q_ref0 >> r.qsh) & 0xFF;
     const uint32_t rp1 = (h.ref1 >> r.psh) & 0xFF, rq1 = (q_ref1 >> r.qsh) & 0xFF;
-    const uint32_t mvbs = check_mv_raw(rp0, rq0, rp1, rq1, mp, mq, two_lists) ? 1u : 0u;
-    uint32_t bs = any_intra ? (outer ? 4u : 3u) : (coded ? 2u : mvbs);
+    const uint32_t mvbs = check_mv_raw(rp0, rq0, rp1, rq1, mp, mq, two_lists, far) ? 1u : 0u;
+    uint32_t bs = any_intra ? (outer ? intra_edge : 3u) : (coded ? 2u : mvbs);      /* intra_edge: 4, or 3 on the horizontal macroblock edges of a field picture */
     if (!enabled || (!outer && odd && (h.type & MI355_MB_8x8DCT))) bs = 0;
     return bs;
 }
@@ -1033,6 +1035,9 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
     const int mb_y = 4 * band + g, W = fr.mb_width;
     const bool row_ok = mb_y < fr.mb_height;
+    /* a field picture (PAFF): vertical vector limit 2 instead of 4 (h264_loopfilter.c:723), strength 3 on horizontal intra macroblock edges */
+    const bool field = uniform(fr.field_picture) != 0;
+    const uint32_t mv_far = field ? 0xFFFEFFFCu : 0xFFFCFFFCu;
     const int rs = fr.recon_stride[0], rcs = fr.recon_stride[1], ds = fr.dst_stride[0], dcs = fr.dst_stride[1];
     const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
     constexpr bool two_lists = TWO_LISTS;                    /* sl->list_count == 2 exactly when list-1 vectors exist */
@@ -1213,8 +1218,8 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
         const MbInfo &h = cur.h, &ht = cur.ht;
         const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
         const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
-        const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, cur.p0, cur.q0, two_lists);
-        const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, cur.p1, cur.q1, two_lists);
+        const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, cur.p0, cur.q0, two_lists, mv_far, 4u);
+        const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, cur.p1, cur.q1, two_lists, mv_far, field ? 3u : 4u);
         /* the four strengths of a line: edge e of this lane's segment sits in lane e of its group of four */
         const uint32_t bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
         const uint32_t bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
