@@ -847,6 +847,10 @@ STREAMS = {
     "444_8_paff": dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=103, nslices=2, deblock_idc=2, nrefs=2, npics=6, paff=True, cip=True),
     "420_8_paff_b": dict(mb_w=8, mb_h=8, chroma_idc=1, depth=8, seed=104, nslices=4, deblock_idc=-1, nrefs=4, npics=12, paff=True, cip=True, far=24),
     "420_8_paff_t8x8": dict(mb_w=7, mb_h=6, chroma_idc=1, depth=8, seed=105, nslices=3, deblock_idc=2, nrefs=3, npics=10, paff=True, t8x8=True, npps=3, scaling=True),
+    "paff_and_frames": [dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=106, nslices=2, deblock_idc=0, nrefs=2, npics=5, paff=True),
+                        dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=107, nslices=1, deblock_idc=0, nrefs=2, npics=4, bmode=1),
+                        dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=108, nslices=2, deblock_idc=0, nrefs=2, npics=5, paff=True),
+                        dict(mb_w=5, mb_h=4, chroma_idc=2, depth=8, seed=109, nslices=1, deblock_idc=0, nrefs=2, npics=3, paff=True)],
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),

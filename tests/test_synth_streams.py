@@ -85,7 +85,7 @@ def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
 
 
 @needs_harness
-@pytest.mark.parametrize("name", [n for n in SY.ALL if n not in SY.BRIDGE and n != "mixed_formats"])
+@pytest.mark.parametrize("name", [n for n in SY.ALL if n not in SY.BRIDGE and n not in ("mixed_formats", "paff_and_frames")])
 def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name):
     """High 4:2:2, 9 / 10 bit: the bridge says so once and the reference's C path decodes the stream — same pictures, nothing on
     the device"""
@@ -98,17 +98,19 @@ def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name):
 
 
 @needs_harness
+@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 9, 12), ("paff_and_frames", 19, 17)))
 @pytest.mark.parametrize("lazy,direct", ((False, False), (True, False), (False, True)))
-def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct):
+def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct, name, on_device, frames):
     """a stream whose sequences differ in chroma format and bit depth (8-bit 4:2:0, 10-bit 4:2:2, 8-bit 4:4:4, 8-bit 4:2:0): the
     bridge gives its buffers back at each change (the decoder calls ff_h264_flush_change), steps aside for the sequence outside
-    Tier 2 and comes back for the next one; `420_8_resize` (three picture sizes, all on the device) is among SY.BRIDGE"""
+    Tier 2 and comes back for the next one; `paff_and_frames`: PAFF 4:2:0, progressive with B pictures at the same size (buffers
+    kept), PAFF 4:4:4, PAFF 4:2:2 (steps aside); `420_8_resize` (three picture sizes, all on the device) is among SY.BRIDGE"""
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
     out = tmp_path / "o.yuv"
-    st = SY.run_bridge("h264_bridge_emu", "mixed_formats", out, lazy=lazy, direct=direct)
-    assert st.get("pictures_on_device") == 9 and st.get("pictures_output") == 12, st
-    SY.check_md5(out, "mixed_formats")
+    st = SY.run_bridge("h264_bridge_emu", name, out, lazy=lazy, direct=direct)
+    assert st.get("pictures_on_device") == on_device and st.get("pictures_output") == frames, st
+    SY.check_md5(out, name)
 
 
 @needs_harness

@@ -65,13 +65,14 @@ def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name)
     SY.check_md5(out, name)
 
 
+@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 9, 12), ("paff_and_frames", 19, 17)))
 @pytest.mark.parametrize("lazy", (False, True))
-def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy):
+def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy, name, on_device, frames):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
-    st = SY.run_bridge("h264_bridge_gpu", "mixed_formats", out, lazy=lazy)
-    assert st.get("pictures_on_device") == 9 and st.get("pictures_output") == 12, st
-    SY.check_md5(out, "mixed_formats")
+    st = SY.run_bridge("h264_bridge_gpu", name, out, lazy=lazy)
+    assert st.get("pictures_on_device") == on_device and st.get("pictures_output") == frames, st
+    SY.check_md5(out, name)
 
 
 @pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 9)))
