@@ -330,10 +330,25 @@ class Stream:
             return False
         return not self.cip or self.kind[mby][mbx] in ("i4", "i8", "i16", "pcm")
 
+    def nbrs(self, x, y, bw, bh, mbx, mby, sid):
+        """storage positions (row, column) of the blocks to the left of and above block (x, y) of a grid with bw x bh blocks per
+        macroblock, or None where that neighbour is not available (6.4.11.4; MbaffStream: 6.4.12.2)"""
+        a = (y, x - 1) if (x % bw or self.avail(mbx - 1, mby, sid)) and x > 0 else None
+        b = (y - 1, x) if (y % bh or self.avail(mbx, mby - 1, sid)) and y > 0 else None
+        return a, b
+
+    def intra_avail(self, mbx, mby, sid):
+        """left, top, top-left macroblock usable for intra prediction"""
+        return self.iavail(mbx - 1, mby, sid), self.iavail(mbx, mby - 1, sid), self.iavail(mbx - 1, mby - 1, sid)
+
+    def ref_range(self, nact):
+        return nact
+
     def nC(self, arr, x, y, bw, bh, mbx, mby, sid):
         """predicted count for the block at block coordinates (x, y) of an array with bw x bh blocks per macroblock"""
-        a = arr[y, x - 1] if (x % bw or self.avail(mbx - 1, mby, sid)) and x > 0 else None
-        b = arr[y - 1, x] if (y % bh or self.avail(mbx, mby - 1, sid)) and y > 0 else None
+        pa, pb = self.nbrs(x, y, bw, bh, mbx, mby, sid)
+        a = arr[pa] if pa is not None else None
+        b = arr[pb] if pb is not None else None
         if a is not None and b is not None:
             return (int(a) + int(b) + 1) >> 1
         return int(a) if a is not None else (int(b) if b is not None else 0)
@@ -409,7 +424,7 @@ class Stream:
     def intra_mb(self, w, mbx, mby, sid, base):
         """an intra macroblock; base: mb_type offset of intra types in this slice type (0 in I, 5 in P)"""
         r = self.r
-        left, top = self.iavail(mbx - 1, mby, sid), self.iavail(mbx, mby - 1, sid)
+        left, top, topleft = self.intra_avail(mbx, mby, sid)
         c = r.i(0, 9)
         if c == 0:                                           # I_PCM
             w.ue(base + 25)
@@ -420,7 +435,7 @@ class Stream:
             self.clear_counts(mbx, mby, 16)
             self.kind[mby][mbx] = "pcm"
             return
-        cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and self.iavail(mbx - 1, mby - 1, sid) else [])
+        cmodes = [0] + ([1] if left else []) + ([2] if top else []) + ([3] if left and top and topleft else [])
         cmode = cmodes[r.i(0, len(cmodes) - 1)]
         if c <= 4 and self.t8x8 and r.p(0.5):                # Intra 8x8
             w.ue(base + 0)
@@ -429,11 +444,16 @@ class Stream:
                 bx, by = 2 * (b8 & 1), 2 * (b8 >> 1)
                 x, y = 4 * mbx + bx, 4 * mby + by
                 l_ok, t_ok = bx > 0 or left, by > 0 or top
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.iavail(mbx - 1, mby - 1, sid)))
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else topleft))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
-                ma = (2 if self.i4[y, x - 1] < 0 else int(self.i4[y, x - 1])) if (x > 0 and (bx > 0 or left)) else None
-                mb_ = (2 if self.i4[y - 1, x] < 0 else int(self.i4[y - 1, x])) if (y > 0 and (by > 0 or top)) else None
+                pa, pb = self.nbrs(x, y, 4, 4, mbx, mby, sid)
+                if pa is not None and not (bx > 0 or left):
+                    pa = None
+                if pb is not None and not (by > 0 or top):
+                    pb = None
+                ma = None if pa is None else (2 if self.i4[pa] < 0 else int(self.i4[pa]))
+                mb_ = None if pb is None else (2 if self.i4[pb] < 0 else int(self.i4[pb]))
                 pred = 2 if ma is None or mb_ is None else min(ma, mb_)
                 if mode == pred:
                     w.u(1, 1)
@@ -456,18 +476,18 @@ class Stream:
                 x, y = 4 * mbx + bx, 4 * mby + by
                 l_ok, t_ok = bx > 0 or left, by > 0 or top
                 # the sample above-left of the block lies in this macroblock, the one above, the one to the left or the one above-left
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else self.iavail(mbx - 1, mby - 1, sid)))
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else topleft))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
                 # predicted mode: min of the neighbours' modes; a neighbour outside -> 2 for both; an available neighbour that is
                 # not Intra4x4 counts as 2 (8.3.1.1)
-                def nb(xx, yy, inside, mb_ok):
-                    if not (inside or mb_ok):
-                        return None
-                    m = self.i4[yy, xx]
-                    return 2 if m < 0 else int(m)
-                ma = nb(x - 1, y, bx > 0, left) if x > 0 else None
-                mb_ = nb(x, y - 1, by > 0, top) if y > 0 else None
+                pa, pb = self.nbrs(x, y, 4, 4, mbx, mby, sid)
+                if pa is not None and not (bx > 0 or left):
+                    pa = None                                # constrained intra: an inter neighbour does not count
+                if pb is not None and not (by > 0 or top):
+                    pb = None
+                ma = None if pa is None else (2 if self.i4[pa] < 0 else int(self.i4[pa]))
+                mb_ = None if pb is None else (2 if self.i4[pb] < 0 else int(self.i4[pb]))
                 pred = 2 if ma is None or mb_ is None else min(ma, mb_)
                 if mode == pred:
                     w.u(1, 1)
@@ -481,7 +501,7 @@ class Stream:
             self.residual(w, mbx, mby, sid, cbp, False)
             self.kind[mby][mbx] = "i4"
             return
-        modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and self.iavail(mbx - 1, mby - 1, sid) else [])
+        modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and topleft else [])
         mode = modes[r.i(0, len(modes) - 1)]
         cl, cc = r.i(0, 1), r.i(0, 2)
         if self.cidc == 3:
@@ -501,6 +521,7 @@ class Stream:
     def inter_mb(self, w, mbx, mby, sid, nact):
         r = self.r
         t = r.i(0, 4) if nact > 1 else r.i(0, 3)
+        multi = self.ref_range(nact) > 1
         w.ue(t)
         small = False
         if t == 3 or t == 4:
@@ -508,17 +529,17 @@ class Stream:
             small = any(subs)
             for s_ in subs:
                 w.ue(s_)
-            if t == 3 and nact > 1:
+            if t == 3 and multi:
                 for _ in range(4):
-                    w.te(nact - 1, r.i(0, nact - 1))
+                    w.te(self.ref_range(nact) - 1, r.i(0, self.ref_range(nact) - 1))
             for s_ in subs:
                 for _ in range((1, 2, 2, 4)[s_]):
                     self.mvd(w)
         else:
             parts = 1 if t == 0 else 2
-            if nact > 1:
+            if multi:
                 for _ in range(parts):
-                    w.te(nact - 1, r.i(0, nact - 1))
+                    w.te(self.ref_range(nact) - 1, r.i(0, self.ref_range(nact) - 1))
             for _ in range(parts):
                 self.mvd(w)
         cbp = self.inter_cbp(w, 0.7 * self.sparse)
@@ -783,6 +804,142 @@ class Stream:
         return units
 
 
+class MbaffStream(Stream):
+    """MBAFF frames (mb_adaptive_frame_field_flag): macroblock PAIRS, each coded as two frame or two field macroblocks.  The grids
+    keep one entry per macroblock (row 2 * pair row + position in the pair) in the macroblock's own block order; what changes is
+    WHERE the neighbours A (left) and B (above) of a block are (6.4.12.2, Table 6-4).  No skipped macroblocks (the inference rules
+    for mb_field_decoding_flag stay out of the picture), no modes that need the above-left neighbour macroblock."""
+
+    def sps(self):
+        w = Bits()
+        profile = 244 if self.cidc == 3 else (122 if self.cidc == 2 else (110 if self.depth > 8 else 100))
+        w.u(8, profile); w.u(8, 0); w.u(8, 40)
+        w.ue(0)
+        w.ue(self.cidc)
+        if self.cidc == 3:
+            w.u(1, 0)
+        w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
+        w.ue(0); w.ue(2)
+        w.ue(max(1, self.nrefs)); w.u(1, 0)
+        w.ue(self.mb_w - 1); w.ue(self.mb_h // 2 - 1)
+        w.u(1, 0); w.u(1, 1); w.u(1, 1)                      # frame_mbs_only 0, mb_adaptive_frame_field 1, direct_8x8_inference
+        w.u(1, 0); w.u(1, 0)
+        w.trailing()
+        return nal(3, 7, w.bytes())
+
+    def begin_picture(self):
+        super().begin_picture()
+        self.fld = np.zeros((self.mb_h // 2, self.mb_w), np.int64)       # per pair: coded as field macroblocks
+
+    def pair_ok(self, px, py, sid):
+        return 0 <= px < self.mb_w and 0 <= py < self.mb_h // 2 and self.slice_of[2 * py, px] == sid
+
+    def nbrs(self, x, y, bw, bh, mbx, mby, sid):
+        bx, by = x % bw, y % bh
+        px, py, pos = mbx, mby >> 1, mby & 1
+        cur_field = int(self.fld[py, px])
+        if bx > 0:
+            a = (y, x - 1)
+        elif not self.pair_ok(px - 1, py, sid):
+            a = None
+        else:
+            lf = int(self.fld[py, px - 1])
+            max_h, yn = 4 * bh, 4 * by
+            if not cur_field:
+                if not lf:
+                    nb_pos, ym = pos, yn
+                else:
+                    nb_pos, ym = (0 if yn % 2 == 0 else 1), ((yn + max_h) >> 1 if pos else yn >> 1)
+            else:
+                if not lf:
+                    if yn < max_h // 2:
+                        nb_pos, ym = 0, (yn << 1) + pos
+                    else:
+                        nb_pos, ym = 1, (yn << 1) + pos - max_h
+                else:
+                    nb_pos, ym = pos, yn
+            a = (bh * (2 * py + nb_pos) + (ym >> 2), bw * (px - 1) + bw - 1)
+        if by > 0:
+            b = (y - 1, x)
+        elif not cur_field and pos == 1:
+            b = (bh * (2 * py) + bh - 1, x)                                  # the top macroblock of the same pair
+        elif not self.pair_ok(px, py - 1, sid):
+            b = None
+        else:
+            above_field = int(self.fld[py - 1, px])
+            nb_pos = 0 if (cur_field and pos == 0 and above_field) else 1
+            b = (bh * (2 * (py - 1) + nb_pos) + bh - 1, x)
+        return a, b
+
+    def intra_avail(self, mbx, mby, sid):
+        px, py, pos = mbx, mby >> 1, mby & 1
+        left = self.pair_ok(px - 1, py, sid)
+        top = True if (pos == 1 and not self.fld[py, px]) else self.pair_ok(px, py - 1, sid)
+        return left, top, False
+
+    def ref_range(self, nact):
+        return 2 * nact if self.cur_field else nact
+
+    def slice(self, idx, frame_num, idr, is_p, first_pair, last_pair, sid, nact, **kw):
+        r = self.r
+        w = Bits()
+        w.ue(first_pair)                                     # first_mb_in_slice counts pairs in an MBAFF frame
+        w.ue(5 if is_p else 7)
+        w.ue(0)
+        w.u(4, frame_num & 15)
+        w.u(1, 0)                                            # field_pic_flag
+        if idr:
+            w.ue(idx & 3)
+        if is_p:
+            w.u(1, 1)
+            w.ue(nact - 1)
+            w.u(1, 0)
+            if self.weighted:
+                self.weight_table(w, nact, 1)
+        if idr:
+            w.u(1, 0); w.u(1, 0)
+        else:
+            w.u(1, 0)
+        self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
+        w.se(self.qp - 26)
+        idc = self.deblock_idc if self.deblock_idc >= 0 else r.i(0, 2)
+        w.ue(idc)
+        if idc != 1:
+            w.se(r.i(-2, 2)); w.se(r.i(-2, 2))
+        for p_ in range(first_pair, last_pair):
+            px, py = p_ % self.mb_w, p_ // self.mb_w
+            self.fld[py, px] = self.cur_field = int(r.p(0.5))
+            for pos in (0, 1):
+                mby = 2 * py + pos
+                self.slice_of[mby, px] = sid
+                if is_p:
+                    w.ue(0)                                  # mb_skip_run
+                if pos == 0:
+                    w.u(1, self.cur_field)                   # mb_field_decoding_flag
+                if not is_p or r.p(0.3):
+                    self.intra_mb(w, px, mby, sid, 5 if is_p else 0)
+                else:
+                    self.inter_mb(w, px, mby, sid, nact)
+        w.trailing()
+        return nal(3, 5 if idr else 1, w.bytes())
+
+    def build(self):
+        units = []
+        npairs = self.mb_w * self.mb_h // 2
+        for i in range(self.npics):
+            idr = i == 0
+            is_p = i > 0 and i != 4
+            au = self.param_sets() if idr else b""
+            self.begin_picture()
+            nact = min(i, max(1, self.nrefs))
+            cuts = [0] + sorted(set(self.r.i(1, npairs - 1) for _ in range(self.nslices - 1))) + [npairs]
+            for s_ in range(len(cuts) - 1):
+                if cuts[s_] < cuts[s_ + 1]:
+                    au += self.slice(i, i, idr, is_p, cuts[s_], cuts[s_ + 1], s_, nact)
+            units.append(au)
+        return units
+
+
 STREAMS = {
     # 8-bit 4:2:0 — also decoded through the Tier-2 bridge and sessions (tests/test_synth_streams.py)
     "420_8_slices": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=11, nslices=3, deblock_idc=2, nrefs=3, npics=7),
@@ -851,6 +1008,10 @@ STREAMS = {
                         dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=107, nslices=1, deblock_idc=0, nrefs=2, npics=4, bmode=1),
                         dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=108, nslices=2, deblock_idc=0, nrefs=2, npics=5, paff=True),
                         dict(mb_w=5, mb_h=4, chroma_idc=2, depth=8, seed=109, nslices=1, deblock_idc=0, nrefs=2, npics=3, paff=True)],
+    # MBAFF: macroblock pairs coded as frame or field macroblocks (Tier 1: the *_mbaff loop filters; Tier 2 steps aside)
+    "420_8_mbaff": dict(mb_w=7, mb_h=6, chroma_idc=1, depth=8, seed=161, nslices=2, deblock_idc=0, nrefs=2, npics=7, mbaff=True),
+    "422_10_mbaff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=162, nslices=1, deblock_idc=0, nrefs=2, npics=6, mbaff=True),
+    "444_8_mbaff": dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=163, nslices=2, deblock_idc=-1, nrefs=2, npics=6, mbaff=True),
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),
@@ -887,7 +1048,10 @@ def main():
     T = load_tables()
     md5 = {}
     for name, kw in STREAMS.items():
-        units = sum((Stream(T, name, **k).build() for k in kw), []) if isinstance(kw, list) else Stream(T, name, **kw).build()
+        def make(k):
+            k = dict(k)
+            return (MbaffStream if k.pop("mbaff", False) else Stream)(T, name, **k).build()
+        units = sum((make(k) for k in kw), []) if isinstance(kw, list) else make(kw)
         p = os.path.join(out, "h264_synth_%s.samples" % name)
         write_samples(p, units)
         with tempfile.TemporaryDirectory() as td:

@@ -2,7 +2,7 @@
 what the offline clips lack: several slices per picture, the loop filter off at slice edges / altogether, I_PCM, explicit
 weights in 4:2:0, four references, every partition shape, far vectors — and the profiles no clip has: High 4:2:2,
 High 10, High 4:2:2 at 10 bit, 9 bit, High 4:4:4 Predictive with slices / I_PCM (8 and 10 bit), transform bypass (lossless) in 4:2:0, 4:4:4 and 10-bit 4:2:2; cropped pictures; constrained intra prediction with I and P
-slices in one picture; sequences that change picture size / format; interlaced-capable sequences with field pictures (PAFF: Tier 2 decodes them too).  tests/golden/h264_synth_ref_md5.json = md5 of what the reference's own decoder
+slices in one picture; sequences that change picture size / format; interlaced-capable sequences with field pictures (PAFF: Tier 2 decodes them too) and with macroblock pairs coded as frame / field macroblocks (MBAFF).  tests/golden/h264_synth_ref_md5.json = md5 of what the reference's own decoder
 (tables untouched) outputs for each; tests/golden/h264_stream_synth_*.npz = the Tier-2 records the reference decoder's run
 exported for seven of the 8-bit 4:2:0 streams (four of them with B pictures: implicit weights, explicit weights, plain average; one with the 8x8 transform and Intra 8x8) (oracle/ref_h264_export.c), as for realshort.mp4."""
 import hashlib
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 MD5 = json.load(open(os.path.join(GOLD, "h264_synth_ref_md5.json")))
 ALL = sorted(MD5)
-BRIDGE = [n for n in ALL if n.startswith(("420_8_", "444_8")) and "lossless" not in n]            # 8-bit 4:2:0 and 4:4:4: what Tier 2 decodes
+BRIDGE = [n for n in ALL if n.startswith(("420_8_", "444_8")) and "lossless" not in n and "mbaff" not in n]            # 8-bit 4:2:0 and 4:4:4: what Tier 2 decodes
 # field pictures: the bridge counts pictures (a frame coded as two fields is two), the md5 file counts output frames
 ON_DEVICE = {"420_8_paff": 13, "420_8_paff_b": 19, "420_8_paff_t8x8": 14, "444_8_paff": 8}
 EXPORTED = ["420_8_slices", "420_8_qcif", "420_8_nofilter", "420_8_b_implicit", "420_8_b_explicit", "420_8_b_average", "420_8_t8x8", "420_8_cip_mixed", "420_8_reorder_b"]

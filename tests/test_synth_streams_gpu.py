@@ -56,7 +56,7 @@ def test_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name, lazy, direc
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("name", ("422_8_b", "420_10_t8x8", "444_10", "420_8_lossless", "444_8_lossless", "422_10_paff"))
+@pytest.mark.parametrize("name", ("422_8_b", "420_10_t8x8", "444_10", "420_8_lossless", "444_8_lossless", "422_10_paff", "420_8_mbaff", "444_8_mbaff"))
 def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
