@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-to-end throughput of the reference decoder + Tier-2 bridge on a GENERATED 1080p stream (build/streams/h264_synth_1080p.samples:
-# tests/golden/make_h264_streams.py with mb_w=120, mb_h=68, 10 pictures I/P/B, 4 slices, 8x8 transform, three references, sparse
+# tools/make_1080p_stream.py: mb_w=120, mb_h=68, 10 pictures I/P/B, 4 slices, 8x8 transform, three references, sparse
 # residuals — 109 KB per picture).  GPU box, repo root: tools/bridge_1080p.sh <tag>   -> gpurun_out/<tag>/bridge_1080p.jsonl
 TAG=${1:-bridge1080}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
