@@ -91,6 +91,9 @@ static void mc_dir_part(Ctx *c, int list, int n_raster, int refn, int bx, int by
     const int pw = 16 * f->mb_width, ph = 16 * f->mb_height;
     const int mx = mv[0] + (c->mb_x * 16 + bx) * 4;
     const int my = mv[1] + (c->mb_y * 16 + by) * 4;
+    /* a field picture predicting from a field of the other parity: the chroma vector moves by a quarter of a chroma line
+     * (h264_mb.c:287-291); the record carries 2 * (parity of this field - parity of the reference) per list and quadrant */
+    const int myc = my + (f->field_picture ? f->mb[c->mb_xy].u.inter.chroma_dy[list][(bx >> 3) + 2 * (by >> 3)] : 0);
     /* luma: always go through the clamped window — identical to the in-picture read when no
      * emulation is needed */
     fetch(c->emu, 32, f->ref[slot][0], f->dst_stride[0], pw, ph, (mx >> 2) - 2, (my >> 2) - 2, w + 5, h + 5);
@@ -103,8 +106,8 @@ static void mc_dir_part(Ctx *c, int list, int n_raster, int refn, int bx, int by
     }
     for (int p = 1; p < 3; p++) {
         uint8_t *d = p == 1 ? dcb : dcr;
-        fetch(c->emu, 32, f->ref[slot][p], f->dst_stride[1], pw >> 1, ph >> 1, mx >> 3, my >> 3, (w >> 1) + 1, (h >> 1) + 1);
-        oracle_h264_chroma_mc2(d, dcs, c->emu, 32, h >> 1, mx & 7, my & 7, w >> 1, avg);
+        fetch(c->emu, 32, f->ref[slot][p], f->dst_stride[1], pw >> 1, ph >> 1, mx >> 3, myc >> 3, (w >> 1) + 1, (h >> 1) + 1);
+        oracle_h264_chroma_mc2(d, dcs, c->emu, 32, h >> 1, mx & 7, myc & 7, w >> 1, avg);
     }
 }
 
@@ -350,9 +353,10 @@ static void mv_of(const MbView *v, int list, int x4, int y4, int out[2])
     out[0] = v->mv[list][(x4 + 4 * y4) * 2];
     out[1] = v->mv[list][(x4 + 4 * y4) * 2 + 1];
 }
-static int mv_far(const int a[2], const int b[2]) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+static int mvy_limit = 4;      /* 4 in frame pictures, 2 in field pictures (h264_loopfilter.c:723): set per picture by the loop filter's entry point */
+static int mv_far(const int a[2], const int b[2]) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= mvy_limit; }
 
-/* check_mv, h264_loopfilter.c:442-470 (mvy_limit 4: frame macroblocks) */
+/* check_mv, h264_loopfilter.c:442-470 */
 static int check_mv(const MbView *p, int px, int py, const MbView *q, int qx, int qy, int list_count)
 {
     int r0p = ref_id(p, 0, px, py), r0q = ref_id(q, 0, qx, qy), mp[2], mq[2];
@@ -421,7 +425,8 @@ static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
                 if (!have_n) continue;
                 MbView nb = view(f, dir ? mb_xy - f->mb_width : mb_xy - 1);
                 if (intra || (nb.m->mb_type & MI355_MB_INTRA)) {
-                    bS[0] = bS[1] = bS[2] = bS[3] = 4;      /* frame picture, non-interlaced: :528-533 */
+                    /* :551-556: 4, but 3 on the horizontal macroblock edges of a field picture */
+                    bS[0] = bS[1] = bS[2] = bS[3] = (int16_t)(dir && f->field_picture ? 3 : 4);
                 } else {
                     for (int i = 0; i < 4; i++) {
                         int x4 = dir ? i : 0, y4 = dir ? 0 : i;
@@ -462,6 +467,7 @@ static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
 void oracle_h264_deblock_frame(const mi355_h264_frame *f)
 {
     ensure_tables();
+    mvy_limit = f->field_picture ? 2 : 4;
     for (int p = 0; p < 3; p++) {
         int rows = (p ? 8 : 16) * f->mb_height, w = (p ? 8 : 16) * f->mb_width;
         for (int r = 0; r < rows; r++)
