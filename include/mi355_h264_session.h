@@ -32,7 +32,7 @@ extern "C" {
 typedef struct mi355_h264_session mi355_h264_session;
 
 typedef struct mi355_h264_session_params {
-    int32_t mb_width, mb_height;      /* 8-bit 4:2:0 progressive frame pictures of 16 mb_width x 16 mb_height samples */
+    int32_t mb_width, mb_height;      /* 8-bit 4:2:0 frames of 16 mb_width x 16 mb_height samples, decoded as frame pictures or as field pairs */
     int32_t num_surfaces;             /* decoded picture buffer size + 1 (the picture being decoded); 2 .. 64 */
     int32_t max_slices;               /* per picture; 0 = 64 */
 } mi355_h264_session_params;
@@ -42,6 +42,11 @@ typedef struct mi355_h264_picture_params {
     int32_t nslots;                              /* entries of ref_surface in use */
     int32_t ref_surface[MI355_H264_MAX_SLOTS];   /* reference slot — what mi355_h264_slice.ref_slot[][] and the records name — -> surface */
     int32_t two_lists;                           /* the slices carry list-1 vectors (B picture) */
+    int32_t field;                               /* 0: a frame picture; 1 / 2: the top / bottom FIELD of the frame in `surface` (PAFF; the session's
+                                                    mb_height must be even): the slices' macroblock addresses count the field's macroblocks, the
+                                                    records carry chroma_dy (mi355_h264_frame.h) */
+    int32_t ref_parity[MI355_H264_MAX_SLOTS];    /* field pictures: 0 / 1 = the slot is the top / bottom field of ref_surface[slot] (the second
+                                                    field of a frame may name the first field of its own surface) */
 } mi355_h264_picture_params;
 
 int  mi355_h264_session_open(mi355_h264_session **out, const mi355_h264_session_params *p);

@@ -56,6 +56,7 @@ struct mi355_h264_session {
     /* the open picture */
     bool open = false;
     int cur = 0, nslices = 0, ncovered = 0;
+    int rows = 0, nmb_pic = 0;            /* macroblock rows / macroblocks of the open picture (a field has half the frame's) */
     unsigned long frames = 0;
     mi355_h264_picture_params pp{};
 
@@ -146,15 +147,19 @@ extern "C" int mi355_h264_start_frame(mi355_h264_session *s, const mi355_h264_pi
      * set comes up for reuse after the next: everything waiting goes out now */
     if (s->group && s->pending) { const int rc = mi355_h264_group_flush(s->group); if (rc) return rc; }
     if (pp->surface < 0 || pp->surface >= s->nsurf || pp->nslots < 0 || pp->nslots > MI355_H264_MAX_SLOTS) return -1;
+    if (pp->field < 0 || pp->field > 2 || (pp->field && (s->mb_h & 1))) return -1;
     for (int i = 0; i < pp->nslots; i++) {
         const int r = pp->ref_surface[i];
-        if (r < -1 || r >= s->nsurf || r == pp->surface) return -1;
+        /* a picture does not predict from itself — except a field from the OTHER field of its frame */
+        if (r < -1 || r >= s->nsurf || (r == pp->surface && !(pp->field && pp->ref_parity[i] == 2 - pp->field))) return -1;
         if (r >= 0 && !s->surf_valid[r]) return -1;           /* a reference nobody decoded */
     }
     s->cur = (int)(s->frames % NSETS);
     Set &st = s->set[s->cur];
     if (st.used && mi355_event_sync(st.copied) != 0) return -2;   /* the host block is free once its copy has left */
     s->pp = *pp;
+    s->rows = pp->field ? s->mb_h / 2 : s->mb_h;
+    s->nmb_pic = s->mb_w * s->rows;
     s->nslices = 0; s->ncovered = 0;
     std::memset(s->covered, 0, (size_t)s->nmb);
     s->open = true;
@@ -167,7 +172,7 @@ extern "C" int mi355_h264_decode_slice(mi355_h264_session *s, const mi355_h264_s
     if (!s || !s->open || !hdr || !mb || !mv0 || !coef || nmbs <= 0) return -1;
     if (s->pp.two_lists && !mv1) return -1;
     if (s->nslices >= s->max_slices) return -1;
-    if (!mb_addr && (first_mb < 0 || first_mb + nmbs > s->nmb)) return -1;
+    if (!mb_addr && (first_mb < 0 || first_mb + nmbs > s->nmb_pic)) return -1;
     uint8_t *h = s->set[s->cur].host;
     const Layout &l = s->lay;
     const int sid = s->nslices;
@@ -182,7 +187,7 @@ extern "C" int mi355_h264_decode_slice(mi355_h264_session *s, const mi355_h264_s
     }
     for (int i = 0; i < nmbs; i++) {
         const int a = mb_addr ? mb_addr[i] : first_mb + i;
-        if (a < 0 || a >= s->nmb) return -1;
+        if (a < 0 || a >= s->nmb_pic) return -1;
         if (mb_addr) {
             dmb[a] = mb[i];
             std::memcpy(h + l.mv0 + (size_t)a * 64, mv0 + (size_t)i * 32, 64);
@@ -200,27 +205,32 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
 {
     if (!s || !s->open) return -1;
     s->open = false;
-    if (s->ncovered != s->nmb || s->nslices == 0) return -4;
+    if (s->ncovered != s->nmb_pic || s->nslices == 0) return -4;
     Set &st = s->set[s->cur];
     uint8_t *h = st.host, *d = st.dev;
     const Layout &l = s->lay;
     int width = 0;
     int32_t *istart = reinterpret_cast<int32_t *>(h + l.istart);
-    const int levels = mi355_h264_intra_schedule(reinterpret_cast<mi355_h264_mb *>(h + l.mb), s->mb_w, s->mb_h,
+    const int levels = mi355_h264_intra_schedule(reinterpret_cast<mi355_h264_mb *>(h + l.mb), s->mb_w, s->rows,
                                                  reinterpret_cast<uint32_t *>(h + l.ilist), istart, &width);
     if (levels < 0) return -1;
     for (int k = 0; k < levels; k++) s->level_widths[k] = istart[k + 1] - istart[k];
     mi355_h264_frame *fr = reinterpret_cast<mi355_h264_frame *>(h + l.desc);
     std::memset(fr, 0, sizeof(*fr));
-    fr->mb_width = s->mb_w; fr->mb_height = s->mb_h;
+    /* a field picture: every other line of the surface (first line at the field's parity, strides doubled); its references are
+     * fields addressed the same way; the unfiltered reconstruction surface keeps plain rows */
+    const int fld = s->pp.field, fs = fld ? 2 : 1;
+    fr->mb_width = s->mb_w; fr->mb_height = s->rows;
+    fr->field_picture = fld != 0;
     const int recon = s->nsurf + s->cur;
-    for (int p = 0; p < 3; p++) { fr->dst[p] = s->plane(s->pp.surface, p); fr->recon[p] = s->plane(recon, p); }
-    fr->dst_stride[0] = fr->recon_stride[0] = s->stride[0];
-    fr->dst_stride[1] = fr->recon_stride[1] = s->stride[1];
+    for (int p = 0; p < 3; p++) { fr->dst[p] = s->plane(s->pp.surface, p) + (fld == 2 ? s->stride[p ? 1 : 0] : 0); fr->recon[p] = s->plane(recon, p); }
+    fr->dst_stride[0] = fs * s->stride[0]; fr->recon_stride[0] = s->stride[0];
+    fr->dst_stride[1] = fs * s->stride[1]; fr->recon_stride[1] = s->stride[1];
     for (int i = 0; i < MI355_H264_MAX_SLOTS; i++) {
         /* an unused slot points at the first reference (any readable surface: nothing valid names it) */
         const int r = i < s->pp.nslots && s->pp.ref_surface[i] >= 0 ? s->pp.ref_surface[i] : (s->pp.nslots > 0 && s->pp.ref_surface[0] >= 0 ? s->pp.ref_surface[0] : s->pp.surface);
-        for (int p = 0; p < 3; p++) fr->ref[i][p] = s->plane(r, p);
+        const int rpar = fld && i < s->pp.nslots ? (s->pp.ref_parity[i] != 0) : 0;
+        for (int p = 0; p < 3; p++) fr->ref[i][p] = s->plane(r, p) + (rpar ? s->stride[p ? 1 : 0] : 0);
     }
     fr->mb = reinterpret_cast<const mi355_h264_mb *>(d + l.mb);
     fr->mv[0] = reinterpret_cast<const int16_t *>(d + l.mv0);
@@ -244,7 +254,7 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     if (mi355_memcpy_h2d_async(d, h, l.total, s->stream) != 0) return -2;
     if (mi355_event_record(st.copied, s->stream) != 0) return -2;
     st.used = true;
-    const int rc = mi355_h264_decode_frames_levels_dev(reinterpret_cast<const mi355_h264_frame *>(d + l.desc), 1, s->mb_w, s->mb_h, levels,
+    const int rc = mi355_h264_decode_frames_levels_dev(reinterpret_cast<const mi355_h264_frame *>(d + l.desc), 1, s->mb_w, s->rows, levels,
                                                        s->level_widths, s->stream);
     if (rc != 0) return rc == -1 ? -1 : -2;
     if (mi355_event_record(s->surf_done[s->pp.surface], s->stream) != 0) return -2;

@@ -65,6 +65,22 @@ def _frame(fs, f, par, mb_ptr, mv0, mv1, coef, slices, ilist, istart, dst, recon
     return fr
 
 
+def oracle_picture(fs, f, olib, r):
+    """picture f as a field: inputs and what the oracle makes of them (whole frame planes)"""
+    ys, cs = fs.W, fs.W // 2
+    par, dst0, refs, rpar = _surfaces(fs, f, r)
+    mb = _records(fs, f, par, rpar)
+    il = fs.intra_list[f] if len(fs.intra_list[f]) else np.zeros(1, np.uint32)
+    odst = [a.copy() for a in dst0]
+    orec = [np.zeros((fs.H, ys), np.uint8), np.zeros((fs.H // 2, cs), np.uint8), np.zeros((fs.H // 2, cs), np.uint8)]
+    ofr = _frame(fs, f, par, mb.ctypes.data, fs.mv[0, f].ctypes.data, fs.mv[1, f].ctypes.data if fs.use_l1 else None, fs.coef[f].ctypes.data,
+                 fs.slices[f].ctypes.data, il.ctypes.data, fs.intra_start[f].ctypes.data, [a.ctypes.data for a in odst], [a.ctypes.data for a in orec],
+                 [[a.ctypes.data for a in pl] for pl in refs], rpar, ys, cs)
+    olib.oracle_h264_recon_frame(C.byref(ofr))
+    olib.oracle_h264_deblock_frame(C.byref(ofr))
+    return par, dst0, refs, rpar, mb, il, orec, odst
+
+
 def run(backend, oracle, fs, seed=7):
     lib, olib = backend.lib, oracle.lib
     olib.oracle_h264_recon_frame.restype = None
@@ -81,18 +97,7 @@ def run(backend, oracle, fs, seed=7):
     ys, cs = fs.W, fs.W // 2
     changed = 0
     for f in range(fs.F):
-        par, dst0, refs, rpar = _surfaces(fs, f, r)
-        mb = _records(fs, f, par, rpar)
-        il = fs.intra_list[f] if len(fs.intra_list[f]) else np.zeros(1, np.uint32)
-        # ---- oracle
-        odst = [a.copy() for a in dst0]
-        orec = [np.zeros((fs.H, ys), np.uint8), np.zeros((fs.H // 2, cs), np.uint8), np.zeros((fs.H // 2, cs), np.uint8)]
-        ofr = _frame(fs, f, par, mb.ctypes.data, fs.mv[0, f].ctypes.data, fs.mv[1, f].ctypes.data if fs.use_l1 else None, fs.coef[f].ctypes.data,
-                     fs.slices[f].ctypes.data, il.ctypes.data, fs.intra_start[f].ctypes.data, [a.ctypes.data for a in odst], [a.ctypes.data for a in orec],
-                     [[a.ctypes.data for a in pl] for pl in refs], rpar, ys, cs)
-        olib.oracle_h264_recon_frame(C.byref(ofr))
-        olib.oracle_h264_deblock_frame(C.byref(ofr))
-        # ---- device
+        par, dst0, refs, rpar, mb, il, orec, odst = oracle_picture(fs, f, olib, r)
         allocs = []
 
         def up(a):
@@ -102,7 +107,7 @@ def run(backend, oracle, fs, seed=7):
             allocs.append(p)
             return p
         ddst = [up(a) for a in dst0]
-        drec = [up(a) for a in orec]
+        drec = [up(np.zeros_like(a)) for a in orec]
         dfr = _frame(fs, f, par, up(mb), up(fs.mv[0, f]), up(fs.mv[1, f]) if fs.use_l1 else None, up(fs.coef[f]), up(fs.slices[f]), up(il), up(fs.intra_start[f]),
                      ddst, drec, [[up(a) for a in pl] for pl in refs], rpar, ys, cs)
         d_desc = up(np.frombuffer(bytes(dfr), np.uint8))
@@ -119,3 +124,30 @@ def run(backend, oracle, fs, seed=7):
         for a in allocs:
             lib.mi355_free(a)
     return changed
+
+
+def run_session(backend, oracle, fs, seed=9, how="runs"):
+    """the same through a whole-frame session (mi355_h264_session.h, picture parameter `field`): references and the frame the
+    field goes into are loaded with put_frame, the field is decoded with start_frame / decode_slice / end_frame"""
+    import session_cases as SC
+    olib = oracle.lib
+    olib.oracle_h264_recon_frame.restype = None
+    olib.oracle_h264_deblock_frame.restype = None
+    r = SplitMix64(seed)
+    nref = fs.nrefs
+    ss = SC.Session(backend.lib, fs.mb_w, 2 * fs.mb_h, nref + 1, 8)
+    try:
+        for f in range(fs.F):
+            par, dst0, refs, rpar, mb, il, orec, odst = oracle_picture(fs, f, olib, r)
+            for s_ in range(nref):
+                ss.put(s_, refs[s_])
+            ss.put(nref, dst0)
+            assert ss.start(nref, list(range(nref)), fs.use_l1, field=1 + par, ref_parity=rpar) == 0
+            SC.send_picture(ss, mb, fs.mv[0, f].reshape(-1, 32), fs.mv[1, f].reshape(-1, 32) if fs.use_l1 else None, fs.coef[f], fs.slices[f], how)
+            assert ss.end() == 0
+            got = ss.get(nref)
+            for p in range(3):
+                assert np.array_equal(got[p], odst[p]), "picture %d plane %d differs from the oracle" % (f, p)
+    finally:
+        ss.close()
+    return fs.F

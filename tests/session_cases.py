@@ -18,7 +18,8 @@ class SessionParams(C.Structure):
 
 
 class PictureParams(C.Structure):
-    _fields_ = [("surface", C.c_int32), ("nslots", C.c_int32), ("ref_surface", C.c_int32 * MAX_SLOTS), ("two_lists", C.c_int32)]
+    _fields_ = [("surface", C.c_int32), ("nslots", C.c_int32), ("ref_surface", C.c_int32 * MAX_SLOTS), ("two_lists", C.c_int32),
+                ("field", C.c_int32), ("ref_parity", C.c_int32 * MAX_SLOTS)]
 
 
 def _bind(lib):
@@ -65,11 +66,13 @@ class Session:
     def close(self):
         self.lib.mi355_h264_session_close(self.h)
 
-    def start(self, surface, refs, two_lists):
+    def start(self, surface, refs, two_lists, field=0, ref_parity=()):
         pp = PictureParams()
-        pp.surface, pp.nslots, pp.two_lists = surface, len(refs), int(two_lists)
+        pp.surface, pp.nslots, pp.two_lists, pp.field = surface, len(refs), int(two_lists), field
         for i, r in enumerate(refs):
             pp.ref_surface[i] = r
+        for i, rp in enumerate(ref_parity):
+            pp.ref_parity[i] = rp
         return self.lib.mi355_h264_start_frame(self.h, C.byref(pp))
 
     def slice(self, hdr, first, mb, mv0, mv1, coef, addr=None):

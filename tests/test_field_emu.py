@@ -9,3 +9,10 @@ import h264_frames as HF
 @pytest.mark.parametrize("name", ("mixed_intra", "b_mixed", "wide_b", "p16_smooth"))
 def test_field_pictures_emulated(emu, oracle, name):
     assert field_cases.run(emu, oracle, HF.synth_frames(**frame_cases.CASES[name])) > 1000
+
+
+@pytest.mark.parametrize("name,how", (("b_mixed", "runs"), ("mixed_intra", "split")))
+def test_field_pictures_through_sessions_emulated(emu, oracle, name, how):
+    """picture parameter `field`: the field goes into every other line of its surface, references are (surface, parity)"""
+    fs = HF.synth_frames(**frame_cases.CASES[name])
+    assert field_cases.run_session(emu, oracle, fs, how=how) == fs.F

@@ -11,3 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in frame_cases.CASES if not n.startswith(("tall", "one_", "mid_intra"))])
 def test_field_pictures_gpu(mi355, oracle, name):
     assert field_cases.run(mi355, oracle, HF.synth_frames(**frame_cases.CASES[name])) > 1000
+
+
+@pytest.mark.parametrize("name", ("b_mixed", "mixed_intra", "wide_b", "b_weight_implicit", "mid_b_weighted"))
+def test_field_pictures_through_sessions_gpu(mi355, oracle, name):
+    fs = HF.synth_frames(**frame_cases.CASES[name])
+    assert field_cases.run_session(mi355, oracle, fs) == fs.F
