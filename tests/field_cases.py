@@ -12,13 +12,21 @@ import h264_frames as HF
 from rng import SplitMix64
 
 
-def _surfaces(fs, f, r):
-    """frame surfaces (double height) for picture f: destination (random), references (the FrameSet's pictures on one parity)"""
+def _surfaces(fs, f, r, par=None, dst=None):
+    """frame surfaces (double height) for picture f: destination (random), references (the FrameSet's pictures on one parity).
+    dst given: the field goes into THAT frame, and reference slot 0 is the frame's other field (second field of a frame
+    predicting from the first)"""
     H, W = fs.H, fs.W
-    par = f & 1
-    dst = [r.u8((2 * H, W)), r.u8((H, W // 2)), r.u8((H, W // 2))]
+    par = f & 1 if par is None else par
+    own = dst is not None
+    if not own:
+        dst = [r.u8((2 * H, W)), r.u8((H, W // 2)), r.u8((H, W // 2))]
     refs, rpar = [], []
     for s_ in range(fs.nrefs):
+        if own and s_ == 0:
+            refs.append(dst)
+            rpar.append(1 - par)
+            continue
         rp = (s_ + f) & 1
         planes = []
         for p in range(3):
@@ -65,13 +73,15 @@ def _frame(fs, f, par, mb_ptr, mv0, mv1, coef, slices, ilist, istart, dst, recon
     return fr
 
 
-def oracle_picture(fs, f, olib, r):
+def oracle_picture(fs, f, olib, r, par=None, dst=None):
     """picture f as a field: inputs and what the oracle makes of them (whole frame planes)"""
     ys, cs = fs.W, fs.W // 2
-    par, dst0, refs, rpar = _surfaces(fs, f, r)
+    par, dst0, refs, rpar = _surfaces(fs, f, r, par, dst)
     mb = _records(fs, f, par, rpar)
     il = fs.intra_list[f] if len(fs.intra_list[f]) else np.zeros(1, np.uint32)
-    odst = [a.copy() for a in dst0]
+    odst = dst0 if dst is not None else [a.copy() for a in dst0]       # a frame's second field: decoded in place, next to the first
+    if dst is not None:
+        refs = [odst if pl is dst0 else pl for pl in refs]
     orec = [np.zeros((fs.H, ys), np.uint8), np.zeros((fs.H // 2, cs), np.uint8), np.zeros((fs.H // 2, cs), np.uint8)]
     ofr = _frame(fs, f, par, mb.ctypes.data, fs.mv[0, f].ctypes.data, fs.mv[1, f].ctypes.data if fs.use_l1 else None, fs.coef[f].ctypes.data,
                  fs.slices[f].ctypes.data, il.ctypes.data, fs.intra_start[f].ctypes.data, [a.ctypes.data for a in odst], [a.ctypes.data for a in orec],
@@ -151,3 +161,37 @@ def run_session(backend, oracle, fs, seed=9, how="runs"):
     finally:
         ss.close()
     return fs.F
+
+
+def run_session_pairs(backend, oracle, fs, seed=11):
+    """frames as field PAIRS in one surface: picture 2k is decoded as the top field of surface `nref`, picture 2k + 1 as its
+    bottom field with reference slot 0 = the top field just decoded (same surface, other parity)"""
+    import session_cases as SC
+    olib = oracle.lib
+    olib.oracle_h264_recon_frame.restype = None
+    olib.oracle_h264_deblock_frame.restype = None
+    r = SplitMix64(seed)
+    nref = fs.nrefs
+    ss = SC.Session(backend.lib, fs.mb_w, 2 * fs.mb_h, nref + 1, 8)
+    try:
+        for k in range(fs.F // 2):
+            frame = None
+            for par in (0, 1):
+                f = 2 * k + par
+                _, dst0, refs, rpar, mb, il, orec, odst = oracle_picture(fs, f, olib, r, par=par, dst=frame)
+                for s_ in range(nref):
+                    if not (par == 1 and s_ == 0):
+                        ss.put(s_, refs[s_])
+                if par == 0:
+                    ss.put(nref, dst0)
+                surf = [nref if (par == 1 and s_ == 0) else s_ for s_ in range(nref)]
+                assert ss.start(nref, surf, fs.use_l1, field=1 + par, ref_parity=rpar) == 0
+                SC.send_picture(ss, mb, fs.mv[0, f].reshape(-1, 32), fs.mv[1, f].reshape(-1, 32) if fs.use_l1 else None, fs.coef[f], fs.slices[f], "runs")
+                assert ss.end() == 0
+                frame = odst
+            got = ss.get(nref)
+            for p in range(3):
+                assert np.array_equal(got[p], frame[p]), "frame %d plane %d differs from the oracle" % (k, p)
+    finally:
+        ss.close()
+    return fs.F // 2

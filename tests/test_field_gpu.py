@@ -17,3 +17,9 @@ def test_field_pictures_gpu(mi355, oracle, name):
 def test_field_pictures_through_sessions_gpu(mi355, oracle, name):
     fs = HF.synth_frames(**frame_cases.CASES[name])
     assert field_cases.run_session(mi355, oracle, fs) == fs.F
+
+
+@pytest.mark.parametrize("name", ("b_mixed", "p16_smooth", "mixed_intra"))
+def test_field_pairs_in_one_surface_gpu(mi355, oracle, name):
+    fs = HF.synth_frames(**frame_cases.CASES[name])
+    assert field_cases.run_session_pairs(mi355, oracle, fs) == fs.F // 2
