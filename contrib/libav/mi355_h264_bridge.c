@@ -118,6 +118,7 @@ typedef struct Bridge {
     int state;                  /* 0 new, 1 active, -1 stepped aside */
     int soft;                   /* stepped aside because of the SEQUENCE's format: the next sequence is looked at again */
     int lazy, direct;
+    int null_submit;            /* MI355_BRIDGE_NULL (developer): pictures are packed and dropped — times the host side alone */
     int mb_w, mb_h, nmb;
     void *stream;               /* direct mode */
     Staging st[2];
@@ -395,6 +396,7 @@ static Bridge *bridge_get(const H264Context *h)
         if (!b) return NULL;
         b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL;
         b->direct = getenv("MI355_BRIDGE_DIRECT") != NULL;
+        b->null_submit = getenv("MI355_BRIDGE_NULL") != NULL;
         if (getenv("MI355_BRIDGE_PLAIN")) b->state = -1;         /* the comparison run: the reference's C path, silently */
     }
     if (b->state) return b;
@@ -664,9 +666,9 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     /* an inter macroblock without coefficients (cbp 0) never has its block fetched (mi355_h264_recon_inter_sparse_dev):
      * no need to clear it either */
     const int reads_coefs = intra || (cbp & 0x3F);
-    if (reads_coefs) memset(cf, 0, 768);
     if (IS_INTRA_PCM(mb_type)) {
         memcpy(cf, sl->intra_pcm_ptr, 384);
+        memset(cf + 192, 0, 384);
         m->nnz_mask = 0xFFFFFF;
         memset(m->u.intra4x4_pred_mode, 0, 16);
         if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, 0);
@@ -679,7 +681,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 if (sl->non_zero_count_cache[scan8[src]]) m->nnz_mask |= 1u << i;
             }
             memcpy(cf, sl->mb, 256 * 2);
-        }
+        } else if (reads_coefs) memset(cf, 0, 256 * 2);
         if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX]]) {
             m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
             for (int k = 0; k < 16; k++) cf[mi355_luma_dc_slot(k)] = sl->mb_luma_dc[0][k];
@@ -694,7 +696,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 }
             if (sl->non_zero_count_cache[scan8[CHROMA_DC_BLOCK_INDEX + 0]]) m->nnz_mask |= 1u << MI355_NNZ_CB_DC;
             if (sl->non_zero_count_cache[scan8[CHROMA_DC_BLOCK_INDEX + 1]]) m->nnz_mask |= 1u << MI355_NNZ_CR_DC;
-        }
+        } else if (reads_coefs) memset(cf + 256, 0, 128 * 2);
         if (intra) {
             for (int i = 0; i < 16; i++) m->u.intra4x4_pred_mode[i] = sl->intra4x4_pred_mode_cache[scan8[i]];
         } else {
@@ -725,7 +727,12 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         /* what the reference's idct_add / dc_dequant functions leave behind (h264idct_template.c:66,:140,:150): the residual
          * decoders rely on finding the block array zeroed */
         if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, luma_coded);
-        if (luma_coded || (cbp & 0x30)) memset(sl->mb, 0, 16 * 48 * sizeof(int16_t));
+        if (b->c444) {
+            if (luma_coded || (cbp & 0x30)) memset(sl->mb, 0, 16 * 48 * sizeof(int16_t));
+        } else {
+            if (luma_coded) memset(sl->mb, 0, 256 * 2);
+            if (cbp & 0x30) { memset(sl->mb + 256, 0, 64 * 2); memset(sl->mb + 512, 0, 64 * 2); }
+        }
     }
 }
 
@@ -825,7 +832,9 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
          * rewrites the frame on the host (ff_er_frame_end below), and the device copy of the picture would no longer be what
          * later pictures must predict from. */
         const int incomplete = b->mbs_packed != b->nmb_pic;
-        if (submit_picture(b, h) != 0) {
+        if (b->null_submit) {
+            b->pictures++;
+        } else if (submit_picture(b, h) != 0) {
             /* the picture is lost for this path; what was enqueued must drain before the host touches the frames again */
             finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
             br_fail(b, "submitting a picture to the device failed");
