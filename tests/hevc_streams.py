@@ -1,0 +1,39 @@
+"""Generated HEVC streams (tests/golden/make_hevc_streams.py: a CABAC bitstream writer with random syntax elements; the
+reference tree holds no HEVC sample): I pictures with every transform size 4..32, the three coefficient scans, Intra NxN,
+SAO band / edge with merging, deblocking offsets / off, cu_qp_delta, transform skip, transquant bypass, default scaling
+lists, several slices, CTB sizes 16 / 32 / 64, 8 and 10 bit — and P / B pictures: skip, merge, AMVP with random vector
+differences, all partition shapes (AMP too), one or two lists, explicit weights, constrained intra prediction.
+tests/golden/hevc_streams.json = md5 of what the reference's own decoder (tables untouched) outputs for each."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MD5 = json.load(open(os.path.join(GOLD, "hevc_streams.json")))
+ALL = sorted(MD5)
+
+
+def samples(name):
+    return os.path.join(GOLD, "hevc_synth_%s.samples" % name)
+
+
+def run_tier1(which, name, out, plain=False):
+    """-> number of table entries the hooks replaced; asserts that the decoder raised no complaint"""
+    env = dict(os.environ)
+    env.pop("MI355_TIER1_PLAIN", None)
+    if plain:
+        env["MI355_TIER1_PLAIN"] = "1"
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", which), samples(name), str(out)], capture_output=True, text=True, env=env, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stderr.splitlines() if l.strip()]
+    assert len(lines) == 1 and "%d pictures" % MD5[name]["pictures"] in lines[0], r.stderr[-2000:]
+    return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1))
+
+
+def check_md5(path, name):
+    raw = open(path, "rb").read()
+    assert len(raw) == MD5[name]["bytes"], (len(raw), MD5[name])
+    assert hashlib.md5(raw).hexdigest() == MD5[name]["md5"], "%s: pictures differ from the reference decoder's" % name

@@ -1,0 +1,42 @@
+"""CPU: the REFERENCE's own HEVC decoder with its three DSP tables (hevcdec.c:443-445: HEVCDSPContext, HEVCPredContext,
+VideoDSPContext) overridden through the linker by this project's ff_*_init_mi355x hooks, running the SIMT-emulated build
+of the product sources, decodes the generated streams (hevc_streams.py) to what it decodes with its own tables."""
+import os
+import subprocess
+
+import pytest
+
+import hevc_streams as HS
+
+needs_harness = pytest.mark.skipif(not os.path.isdir("/root/reference/libavcodec"), reason="needs the reference decoder objects (/root/reference)")
+
+
+def test_streams_cover_both_depths_and_inter_pictures():
+    assert {HS.MD5[n]["pix_fmt"] for n in HS.ALL} == {"yuv420p", "yuv420p10le"}
+    assert sum(n.startswith("pb_") for n in HS.ALL) >= 4 and sum(n.startswith("i_") for n in HS.ALL) >= 8
+    for n in HS.ALL:
+        assert os.path.getsize(HS.samples(n)) > 1000
+
+
+@needs_harness
+def test_writer_is_deterministic_and_the_reference_accepts_its_streams(tmp_path):
+    """the committed streams are what the writer writes today (tables re-read from the reference's sources)"""
+    import hashlib
+    import sys
+    sys.path.insert(0, HS.GOLD)
+    import make_hevc_streams as M
+    for name in ("i_8bit", "pb_10bit_weighted"):
+        pkts = M.Hevc(name, **M.STREAMS[name]).build()
+        assert hashlib.md5(b"".join(pkts)).hexdigest() == HS.MD5[name]["stream_md5"]
+
+
+@needs_harness
+@pytest.mark.parametrize("name", HS.ALL)
+def test_reference_hevc_decoder_with_tier1_hooks_emulated(tmp_path, emu, name):
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_tier1_emu"], check=True)
+    out = tmp_path / "plain.yuv"
+    assert HS.run_tier1("hevc_tier1_emu", name, out, plain=True) == 0
+    HS.check_md5(out, name)                                      # the committed md5 is the reference's
+    out = tmp_path / "hooked.yuv"
+    assert HS.run_tier1("hevc_tier1_emu", name, out) >= 150      # the hooks filled the tables (169 entries at this revision)
+    HS.check_md5(out, name)

@@ -1,0 +1,21 @@
+"""GPU (HEVC): the REFERENCE's own HEVC decoder, its three DSP tables overridden through the linker
+by this project's ff_*_init_mi355x hooks and bound to the real HIP library, decodes the generated streams (hevc_streams.py)
+on the MI355X to what the unmodified reference decoder produced (tests/golden/hevc_streams.json).
+oracle/_ref/hevc_tier1_gpu is built where /root/reference exists (oracle/Makefile, __graft_entry__.build()) and travels to
+the GPU box with the tree."""
+import os
+
+import pytest
+
+import hevc_streams as HS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", HS.ALL)
+def test_reference_hevc_decoder_on_gpu(tmp_path, mi355, name):
+    if not os.path.exists(os.path.join(HS.ROOT, "oracle", "_ref", "hevc_tier1_gpu")):
+        pytest.fail("oracle/_ref/hevc_tier1_gpu missing: run __graft_entry__.build() where /root/reference exists")
+    out = tmp_path / "hooked.yuv"
+    assert HS.run_tier1("hevc_tier1_gpu", name, out) >= 150
+    HS.check_md5(out, name)
