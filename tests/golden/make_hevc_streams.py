@@ -185,6 +185,10 @@ class Cabac:
             self.low -= 512
             self.outstanding += 1
 
+    def restart(self):
+        """after pcm_flag (a terminating bin equal to 1, flushed by term()) and the raw samples: 9.3.2.5 initialisation, contexts kept"""
+        self.low, self.range, self.first, self.outstanding = 0, 510, 1, 0
+
     def byps(self, n, v):
         for i in range(n - 1, -1, -1):
             self.byp((v >> i) & 1)
@@ -236,7 +240,7 @@ def scan_tables(log2, scan_idx):
 class Hevc:
     def __init__(self, name, seed, w=96, h=64, bd=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, depth_intra=2,
                  depth_inter=2, sao=1, dbf_off=0, dbf_offsets=(0, 0), strong=1, qp=30, qp_delta=0, tskip=0, bypass=0, slices=1,
-                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0):
+                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0):
         self.__dict__.update(locals())
         self.rng = random.Random(seed)
         self.tables = load_tables()
@@ -271,7 +275,9 @@ class Hevc:
         b.u(1, 1 if self.scaling else 0)
         if self.scaling:
             b.u(1, 0)                                                # default lists
-        b.u(1, self.amp); b.u(1, self.sao); b.u(1, 0)
+        b.u(1, self.amp); b.u(1, self.sao); b.u(1, 1 if self.pcm else 0)
+        if self.pcm:                                                 # PCM samples one / two bits narrower than the pictures': put_pcm shifts
+            b.u(4, self.bd - 2); b.u(4, self.bd - 3); b.ue(0); b.ue(min(self.log2_ctb, 5) - 3); b.u(1, self.pcm_lf_off)
         b.ue(0)                                                      # no short-term sets in the SPS: every slice carries its own
         b.u(1, 0); b.u(1, 0); b.u(1, self.strong); b.u(1, 0); b.u(1, 0)
         b.trailing()
@@ -308,6 +314,8 @@ class Hevc:
         self.ipm = [[1] * n4w for _ in range(n4h)]                 # intra mode (INTRA_DC where not intra)
         self.skipf = [[0] * n4w for _ in range(n4h)]
         nctb = self.cw * self.ch
+        self.poc = poc
+        self.pcm_blocks = getattr(self, "pcm_blocks", [])
         idr = poc == 0 or not self.inter
         self.stype = 2 if idr else (1 if poc % 2 else 0)           # HEVC_SLICE_B 0, P 1, I 2
         self.nrefs = 0 if idr else min(poc, 2)
@@ -495,6 +503,22 @@ class Hevc:
                 nxn = int(r.random() < 0.5) if log2 > self.log2_min_tb else 0
                 c.enc(PART_MODE, 0, 1 - nxn)
                 part = 3 if nxn else 0
+            if part == 0 and self.pcm and 3 <= log2 <= min(self.log2_ctb, 5):
+                pcm = int(r.random() < 0.25)
+                c.term(pcm)
+                if pcm:
+                    b = c.out
+                    while len(b.b) % 8:
+                        b.b.append(0)                                # pcm_alignment_zero_bit
+                    luma = [r.randrange(1 << (self.bd - 1)) for _ in range(size * size)]
+                    for v in luma:
+                        b.u(self.bd - 1, v)
+                    for _ in range(size * size // 2):
+                        b.u(self.bd - 2, r.randrange(1 << (self.bd - 2)))
+                    c.restart()
+                    self.fill(self.ipm, x0, y0, size, 1)
+                    self.pcm_blocks.append((self.poc, x0, y0, size, luma))
+                    return
             self.intra_pu(x0, y0, log2, part == 3)
             self.max_depth = self.depth_intra + (1 if part == 3 else 0)
             self.intra_cu, self.intra_split = 1, part == 3
@@ -915,6 +939,10 @@ STREAMS = {
     "i_ctb64": dict(seed=4, log2_ctb=6, w=136, h=72, depth_intra=3, sao=2),
     "i_qpdelta_tskip": dict(seed=5, qp_delta=1, tskip=1, cb_off=3, cr_off=-4, qp=24),
     "i_bypass_nodbf": dict(seed=6, bypass=1, dbf_off=1, strong=0),
+    "i_bypass_filtered": dict(seed=9, bypass=1, sao=2, qp=34),
+    "i_pcm_unfiltered": dict(seed=10, pcm=1, pcm_lf_off=1, dbf_off=1, sao=0),
+    "i_pcm_lf_off_10bit": dict(seed=15, pcm=1, pcm_lf_off=1, bd=10, sao=2, slices=2),
+    "pb_pcm": dict(seed=16, pcm=1, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4),
     "i_mincb16": dict(seed=7, log2_min_cb=4, log2_min_tb=3, depth_intra=1, w=96, h=96, qp=38, density=0.6),
     "i_scaling_10bit": dict(seed=8, scaling=1, bd=10, slices=3, across=0),
     "pb_8bit": dict(seed=11, inter=1, pictures=5),
@@ -953,7 +981,8 @@ def main():
     for name, kw in STREAMS.items():
         if only and name not in only:
             continue
-        pkts = Hevc(name, **kw).build()
+        kw_obj = Hevc(name, **kw)
+        pkts = kw_obj.build()
         path = os.path.join(OUT, "hevc_synth_%s.samples" % name)
         write_samples(path, pkts)
         rc, err, data = decode(path, exe)
@@ -964,6 +993,17 @@ def main():
         if not ok:
             print("\n".join(msgs[:8]))
             sys.exit(1)
+        h = kw_obj
+        if h.pcm and h.dbf_off and not h.sao:                        # nothing filters: the PCM samples must come out as written
+            import numpy as np
+            bps = 2 if h.bd > 8 else 1
+            fsz = h.w * h.h * 3 // 2
+            pic = np.frombuffer(data, np.uint16 if bps == 2 else np.uint8).reshape(-1, fsz)
+            assert h.pcm_blocks
+            for (poc, x0, y0, size, luma) in h.pcm_blocks:
+                got = pic[poc][:h.w * h.h].reshape(h.h, h.w)[y0:y0 + size, x0:x0 + size]
+                assert (got.reshape(-1) == np.array(luma) * 2).all(), (name, poc, x0, y0)
+            print("   %d PCM blocks decode to the samples written" % len(h.pcm_blocks))
         gold[name] = {"md5": hashlib.md5(data).hexdigest(), "bytes": len(data), "pictures": int(m.group(2)), "width": int(m.group(3)), "height": int(m.group(4)),
                       "pix_fmt": m.group(5), "stream_md5": hashlib.md5(b"".join(pkts)).hexdigest()}
     if not only:
