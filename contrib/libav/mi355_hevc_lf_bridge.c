@@ -1,0 +1,229 @@
+/*
+ * mi355_hevc_lf_bridge.c — the reference's HEVC decoder with its in-loop DEBLOCKING done per PICTURE on the MI355X.
+ *
+ * The reference deblocks CTB by CTB as the slice decoder advances (hls_slice_data -> ff_hevc_hls_filters ->
+ * ff_hevc_hls_filter -> deblocking_filter_CTB, hevcdec.c:2334-2339, hevc_filter.c:728-745).  Linked into the decoder with
+ *     -Wl,--wrap=ff_hevc_hls_filters,--wrap=ff_hevc_hls_filter
+ * this file turns that into one call per picture: the per-CTB calls are dropped, and when the slice decoder reports the
+ * picture's last CTB (hevcdec.c:2337-2339) the frame-level arrays it left behind — vertical_bs / horizontal_bs, qp_y_tab,
+ * is_pcm, the per-CTB DBParams — go to mi355_hevc_deblock_pictures_dev() (include/mi355_hevc_batch.h) exactly as they lie
+ * in HEVCContext, with the unfiltered picture; the filtered picture comes back into s->frame.  Compiled against the
+ * reference's headers (oracle/Makefile, _ref/hevc_lf_emu / _ref/hevc_lf_gpu).
+ *
+ * Sample adaptive offset follows on the device (sequences with sps->sao_enabled): the reference filters a CTB's samples in
+ * up to four pieces, each when the deblocking of the CTBs around it is final (sao_filter_CTB, hevc_filter.c:188-313: the
+ * CTB itself minus the strips its right / lower neighbours will still deblock, plus those strips of its left / upper /
+ * upper-left neighbours, each with the OWNER's parameters).  On a fully deblocked picture the pieces are independent:
+ * this file lists them all (one mi355_hevc_sao_job per piece and component, with the edge flags the reference derives
+ * from slice addresses and slice_loop_filter_across_slices_enabled_flag) and mi355_hevc_sao_batch_dev() runs them in one
+ * launch, reading the deblocked picture and writing the picture the decoder outputs and predicts from (s->sao_frame).
+ *
+ * Scope of this binding: 4:2:0, no tiles, decoders without frame threads (progress is reported once per picture).
+ * Everything else keeps the reference's path — MI355_HEVC_LF_PLAIN=1 keeps it for every picture.
+ * One decoder = one stream of pictures here; a host with many decoders batches pictures of all of them into ONE call
+ * (`npics`), as contrib/libav/mi355_h264_bridge.c does for H.264.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "libavcodec/avcodec.h"
+#include "libavcodec/hevcdec.h"
+#include "mi355_hevc_batch.h"
+#include "mi355dsp.h"             /* mi355_init (the table structs are skipped: the reference's headers came first) */
+#include "mi355_h264_frame.h"      /* the runtime entry points: mi355_malloc / mi355_memcpy_* / mi355_sync */
+
+void __real_ff_hevc_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size);
+void __real_ff_hevc_hls_filter(HEVCContext *s, int x, int y);
+
+static struct {
+    size_t plane_bytes[3], bs_bytes, qp_bytes, pcm_bytes, db_bytes;
+    uint8_t *plane[3], *vbs, *hbs, *qp, *pcm, *db;
+    uint8_t *out[3], *jobs;                /* SAO: the output picture, the job list */
+    size_t out_bytes[3], jobs_bytes;
+    mi355_hevc_sao_job *host_jobs;
+    size_t host_jobs_n;
+    mi355_hevc_lf_picture *desc;
+    void *stream;
+    unsigned long pictures;
+    int plain, failed;
+} lf;
+
+static void fail(const char *what);
+static int active(const HEVCContext *s)
+{
+    static int init;
+    if (!init) {
+        init = 1;
+        lf.plain = getenv("MI355_HEVC_LF_PLAIN") != NULL;
+        if (!lf.plain && mi355_init(getenv("MI355_DEVICE") ? atoi(getenv("MI355_DEVICE")) : 0) != 0) fail("no MI355X");
+    }
+    return !lf.plain && !lf.failed && !s->ps.pps->tiles_enabled_flag && !(s->avctx->active_thread_type & FF_THREAD_FRAME) && s->ps.sps->chroma_format_idc == 1;
+}
+
+static int ensure(uint8_t **p, size_t *have, size_t want)
+{
+    if (*p && *have >= want) return 0;
+    if (*p) mi355_free(*p);
+    *p = mi355_malloc(want);
+    *have = *p ? want : 0;
+    return *p ? 0 : -1;
+}
+
+static void fail(const char *what)
+{
+    fprintf(stderr, "mi355 hevc lf bridge: %s; the reference's path takes over\n", what);
+    lf.failed = 1;
+}
+
+
+/* The pieces of sao_filter_CTB for every CTB of the picture.  Piece k of CTB (cx, cy) belongs to the CTB at
+ * (cx - (k >> 1), cy - (k & 1)) — k = the reference's class number: 0 the CTB itself, 1 the strip of the CTB above,
+ * 2 of the CTB to the left, 3 of the one above-left — and is filtered with that CTB's parameters. */
+static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const src[3], mi355_hevc_sao_job *jobs)
+{
+    const HEVCSPS *sps = s->ps.sps;
+    const int cw = sps->ctb_width, chn = sps->ctb_height;
+    int n = 0;
+    for (int cy = 0; cy < chn; cy++)
+        for (int cx = 0; cx < cw; cx++) {
+            const int here = cy * cw + cx;
+            const int has_l = cx > 0, has_u = cy > 0;
+            /* slice address and "filter across slice edges" of the four CTBs around the CTB's top-left corner */
+            const int a_c = s->tab_slice_address[here], a_l = has_l ? s->tab_slice_address[here - 1] : a_c;
+            const int a_u = has_u ? s->tab_slice_address[here - cw] : a_c, a_ul = has_l && has_u ? s->tab_slice_address[here - cw - 1] : a_c;
+            const int f_c = s->filter_slice_edges[here], f_l = has_l ? s->filter_slice_edges[here - 1] : 1, f_u = has_u ? s->filter_slice_edges[here - cw] : 1;
+            uint8_t vert[4] = { 0 }, horiz[4] = { 0 }, diag[4] = { 0 };
+            if (has_l) vert[0] = vert[2] = !f_c && a_c != a_l;
+            if (has_u) horiz[0] = horiz[1] = !f_c && a_c != a_u;
+            if (has_l && has_u) {
+                vert[1] = vert[3] = !f_u && a_u != a_ul;
+                horiz[2] = horiz[3] = !f_l && a_l != a_ul;
+                diag[0] = diag[3] = !f_c && a_c != a_ul;
+                /* the anti-diagonal joins the left and the upper CTB: the later of the two decides */
+                diag[1] = diag[2] = a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0;
+            }
+            const int borders[4] = { cx == 0, cy == 0, cx == cw - 1, cy == chn - 1 };
+            for (int c = 0; c < 3; c++) {
+                const int sh = c ? 1 : 0;
+                const int size = (1 << sps->log2_ctb_size) >> sh;
+                const int x0 = cx * size, y0 = cy * size;
+                const int w = FFMIN(size, (sps->width >> sh) - x0), h = FFMIN(size, (sps->height >> sh) - y0);
+                const size_t off = (size_t)y0 * s->frame->linesize[c] + ((size_t)x0 << sps->pixel_shift);
+                for (int k = 0; k < 4; k++) {
+                    if (((k & 1) && !has_u) || ((k & 2) && !has_l)) continue;
+                    const SAOParams *p = &s->sao[here - (k & 1) * cw - (k >> 1)];
+                    if (p->type_idx[c] != SAO_BAND && p->type_idx[c] != SAO_EDGE) continue;
+                    mi355_hevc_sao_job *j = &jobs[n++];
+                    memset(j, 0, sizeof(*j));
+                    j->dst = dst[c] + off; j->src = src[c] + off;
+                    j->stride = s->frame->linesize[c];
+                    j->width = w; j->height = h;
+                    for (int e = 0; e < 4; e++) j->borders[e] = borders[e];
+                    for (int e = 0; e < 5; e++) j->offset_val[e] = p->offset_val[c][e];
+                    j->cls = (uint8_t)k;
+                    j->edge = p->type_idx[c] == SAO_EDGE;
+                    j->c_idx = (uint8_t)c; j->eo_class = (uint8_t)p->eo_class[c]; j->band_position = p->band_position[c];
+                    j->vert_edge = vert[k]; j->horiz_edge = horiz[k]; j->diag_edge = diag[k];
+                }
+            }
+        }
+    return n;
+}
+
+static int filter_picture(HEVCContext *s)
+{
+    const HEVCSPS *sps = s->ps.sps;
+    const int h[3] = { sps->height, sps->height >> 1, sps->height >> 1 };
+    size_t sz[3];
+    if (!lf.stream && !(lf.stream = mi355_stream_create())) return -1;
+    for (int i = 0; i < 3; i++) {
+        sz[i] = (size_t)s->frame->linesize[i] * h[i];
+        if (s->frame->linesize[i] <= 0 || ensure(&lf.plane[i], &lf.plane_bytes[i], sz[i])) return -1;
+    }
+    const size_t bs = 2 * (size_t)s->bs_width * (s->bs_height + 1);
+    const size_t qp = (size_t)((sps->width >> sps->log2_min_cb_size) + 1) * ((sps->height >> sps->log2_min_cb_size) + 1);
+    const size_t pcm = (size_t)sps->min_pu_width * sps->min_pu_height;
+    const size_t db = (size_t)sps->ctb_width * sps->ctb_height * sizeof(*s->deblock);
+    size_t have;
+    have = lf.bs_bytes; if (ensure(&lf.vbs, &have, bs)) return -1;
+    if (ensure(&lf.hbs, &lf.bs_bytes, bs)) return -1;
+    if (ensure(&lf.qp, &lf.qp_bytes, qp) || ensure(&lf.pcm, &lf.pcm_bytes, pcm) || ensure(&lf.db, &lf.db_bytes, db)) return -1;
+    if (!lf.desc && !(lf.desc = mi355_malloc(sizeof(*lf.desc)))) return -1;
+
+    mi355_hevc_lf_picture d;
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < 3; i++) { d.data[i] = lf.plane[i]; d.linesize[i] = s->frame->linesize[i]; }
+    d.width = sps->width; d.height = sps->height;
+    d.log2_ctb_size = sps->log2_ctb_size;
+    d.log2_min_cb_size = sps->log2_min_cb_size;
+    d.log2_min_pu_size = sps->log2_min_pu_size;
+    d.min_cb_width = sps->min_cb_width;
+    d.min_pu_width = sps->min_pu_width; d.min_pu_height = sps->min_pu_height;
+    d.ctb_width = sps->ctb_width;
+    d.bs_width = s->bs_width;
+    d.vertical_bs = lf.vbs; d.horizontal_bs = lf.hbs;
+    d.qp_y_tab = (const int8_t *)lf.qp;
+    d.is_pcm = lf.pcm;
+    d.deblock = (const mi355_hevc_db_params *)lf.db;
+    d.pcmf = (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag) || s->ps.pps->transquant_bypass_enable_flag;
+    d.cb_qp_offset = s->ps.pps->cb_qp_offset; d.cr_qp_offset = s->ps.pps->cr_qp_offset;
+
+    int rc = 0;
+    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_h2d(lf.plane[i], s->frame->data[i], sz[i]);
+    rc |= mi355_memcpy_h2d(lf.vbs, s->vertical_bs, bs) | mi355_memcpy_h2d(lf.hbs, s->horizontal_bs, bs);
+    rc |= mi355_memcpy_h2d(lf.qp, s->qp_y_tab, qp) | mi355_memcpy_h2d(lf.pcm, s->is_pcm, pcm) | mi355_memcpy_h2d(lf.db, s->deblock, db);
+    rc |= mi355_memcpy_h2d(lf.desc, &d, sizeof(d));
+    if (rc) return -2;
+    if (mi355_hevc_deblock_pictures_dev(lf.desc, 1, sps->width, sps->height, sps->bit_depth, lf.stream) != 0) return -2;
+    if (!sps->sao_enabled) {
+        if (mi355_sync(lf.stream) != 0) return -2;
+        for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], lf.plane[i], sz[i]);
+        if (rc) return -2;
+        lf.pictures++;
+        return 0;
+    }
+    /* SAO: deblocked picture -> the picture the decoder keeps (copy_CTB of every CTB = the whole picture, then the pieces) */
+    const size_t max_jobs = (size_t)sps->ctb_width * sps->ctb_height * 12;
+    if (lf.host_jobs_n < max_jobs) {
+        free(lf.host_jobs);
+        lf.host_jobs = malloc(max_jobs * sizeof(*lf.host_jobs));
+        lf.host_jobs_n = lf.host_jobs ? max_jobs : 0;
+        if (!lf.host_jobs) return -1;
+    }
+    if (ensure(&lf.jobs, &lf.jobs_bytes, max_jobs * sizeof(*lf.host_jobs))) return -1;
+    for (int i = 0; i < 3; i++) if (ensure(&lf.out[i], &lf.out_bytes[i], sz[i])) return -1;
+    const int n = sao_jobs(s, lf.out, lf.plane, lf.host_jobs);
+    if (mi355_sync(lf.stream) != 0) return -2;
+    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2d(lf.out[i], lf.plane[i], sz[i]);
+    if (n) rc |= mi355_memcpy_h2d(lf.jobs, lf.host_jobs, (size_t)n * sizeof(*lf.host_jobs));
+    if (rc) return -2;
+    if (n && mi355_hevc_sao_batch_dev((const mi355_hevc_sao_job *)lf.jobs, n, sps->bit_depth, lf.stream) != 0) return -2;
+    if (mi355_sync(lf.stream) != 0) return -2;
+    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->sao_frame->data[i], lf.out[i], sz[i]);
+    if (rc) return -2;
+    lf.pictures++;
+    return 0;
+}
+
+void __wrap_ff_hevc_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
+{
+    if (!active(s)) __real_ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb_size);
+    /* else: nothing per CTB — the picture is filtered when its last CTB arrives */
+}
+
+/* called by the slice decoder itself only for the picture's last CTB (hevcdec.c:2337-2339); the per-CTB calls come
+ * through ff_hevc_hls_filters inside hevc_filter.c and never pass here */
+void __wrap_ff_hevc_hls_filter(HEVCContext *s, int x, int y)
+{
+    if (!active(s)) { __real_ff_hevc_hls_filter(s, x, y); return; }
+    if (getenv("MI355_HEVC_LF_TRACE")) fprintf(stderr, "lf: picture poc %d, last CTB at %d, %d (slice from CTB %d)\n", s->poc, x, y, s->sh.slice_ctb_addr_rs);
+    if (filter_picture(s) != 0) {
+        /* nothing of this picture has been filtered yet: the reference's own loop over all CTBs does it */
+        fail("the device pass failed");
+        const int ctb = 1 << s->ps.sps->log2_ctb_size;
+        for (int yy = 0; yy < s->ps.sps->height; yy += ctb)
+            for (int xx = 0; xx < s->ps.sps->width; xx += ctb) __real_ff_hevc_hls_filter(s, xx, yy);
+    }
+}
+
+unsigned long mi355_hevc_lf_bridge_pictures(void) { return lf.pictures; }

@@ -58,6 +58,23 @@ void __wrap_ff_videodsp_init(VideoDSPContext *ctx, int bpc)
     n_hooks++;
 }
 
+/* the writer's streams are open loop: a stream whose arithmetic decoding ran out of step would still decode to SOMETHING.
+ * Counting the coding tree units and the slice ends the decoder sees catches that: a slice that misses its end flag runs
+ * on into the CTUs of the next one (tests/golden/make_hevc_streams.py compares both counts with what it wrote). */
+static unsigned long n_ctus, n_slice_ends;
+int __real_ff_hevc_end_of_slice_flag_decode(HEVCContext *s);
+int __wrap_ff_hevc_end_of_slice_flag_decode(HEVCContext *s)
+{
+    const int r = __real_ff_hevc_end_of_slice_flag_decode(s);
+    n_ctus++;
+    n_slice_ends += r != 0;
+    if (getenv("MI355_HEVC_TRACE_SLICES")) fprintf(stderr, "ctu %lu end_of_slice %d\n", n_ctus, r);
+    return r;
+}
+
+/* present when contrib/libav/mi355_hevc_lf_bridge.c is linked in (_ref/hevc_lf_*): pictures deblocked by the picture-level pass */
+extern unsigned long mi355_hevc_lf_bridge_pictures(void) __attribute__((weak));
+
 static uint32_t get_u32(FILE *f) { uint32_t v = 0; if (fread(&v, 4, 1, f) != 1) exit(4); return v; }
 
 int main(int argc, char **argv)
@@ -100,8 +117,8 @@ int main(int argc, char **argv)
         }
         if (i < n) av_packet_unref(&pkt);
     }
-    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked (%lu entries replaced), %dx%d %s\n", n, shown, n_hooks, n_replaced, c->width, c->height,
-            av_get_pix_fmt_name(c->pix_fmt));
+    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked (%lu entries replaced), %dx%d %s, %lu pictures deblocked per picture, %lu coding tree units in %lu slices\n", n, shown, n_hooks, n_replaced, c->width, c->height,
+            av_get_pix_fmt_name(c->pix_fmt), mi355_hevc_lf_bridge_pictures ? mi355_hevc_lf_bridge_pictures() : 0ul, n_ctus, n_slice_ends);
     fclose(out);
     return n_hooks >= 3 ? 0 : 8;
 }

@@ -275,7 +275,7 @@ class Hevc:
         b.u(1, 1 if self.scaling else 0)
         if self.scaling:
             b.u(1, 0)                                                # default lists
-        b.u(1, self.amp); b.u(1, self.sao); b.u(1, 1 if self.pcm else 0)
+        b.u(1, self.amp); b.u(1, 1 if self.sao else 0); b.u(1, 1 if self.pcm else 0)
         if self.pcm:                                                 # PCM samples one / two bits narrower than the pictures': put_pcm shifts
             b.u(4, self.bd - 2); b.u(4, self.bd - 3); b.ue(0); b.ue(min(self.log2_ctb, 5) - 3); b.u(1, self.pcm_lf_off)
         b.ue(0)                                                      # no short-term sets in the SPS: every slice carries its own
@@ -321,6 +321,8 @@ class Hevc:
         self.nrefs = 0 if idr else min(poc, 2)
         starts = sorted(set([0] + [self.rng.randrange(1, nctb) for _ in range(self.slices - 1)])) if nctb > 1 else [0]
         out = b""
+        self.n_slices = getattr(self, "n_slices", 0) + len(starts)
+        self.n_ctus = getattr(self, "n_ctus", 0) + nctb
         for si, first in enumerate(starts):
             end = starts[si + 1] if si + 1 < len(starts) else nctb
             out += self.slice(poc, idr, first, end, nctb)
@@ -942,6 +944,11 @@ STREAMS = {
     "i_bypass_filtered": dict(seed=9, bypass=1, sao=2, qp=34),
     "i_pcm_unfiltered": dict(seed=10, pcm=1, pcm_lf_off=1, dbf_off=1, sao=0),
     "i_pcm_lf_off_10bit": dict(seed=15, pcm=1, pcm_lf_off=1, bd=10, sao=2, slices=2),
+    # without SAO: what contrib/libav/mi355_hevc_lf_bridge.c deblocks per picture
+    "i_nosao_8bit": dict(seed=21, sao=0, qp_delta=1, dbf_offsets=(1, -2), slices=3, pcm=1, pcm_lf_off=1, bypass=1, cb_off=2, cr_off=-3),
+    "i_nosao_10bit_ctb64": dict(seed=22, sao=0, bd=10, log2_ctb=6, w=136, h=72, depth_intra=3, qp=36),
+    "pb_nosao_8bit": dict(seed=23, sao=0, inter=1, pictures=5, qp_delta=1, qp=34),
+    "pb_nosao_ctb16_10bit": dict(seed=24, sao=0, inter=1, pictures=4, bd=10, log2_ctb=4, log2_max_tb=4, slices=3, w=104, h=56, qp=38),
     "pb_pcm": dict(seed=16, pcm=1, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4),
     "i_mincb16": dict(seed=7, log2_min_cb=4, log2_min_tb=3, depth_intra=1, w=96, h=96, qp=38, density=0.6),
     "i_scaling_10bit": dict(seed=8, scaling=1, bd=10, slices=3, across=0),
@@ -987,8 +994,11 @@ def main():
         write_samples(path, pkts)
         rc, err, data = decode(path, exe)
         msgs = [l for l in err.splitlines() if not l.startswith("tier1:")]
-        m = re.search(r"(\d+) packets, (\d+) pictures.* (\d+)x(\d+) (\w+)", err)
-        ok = rc == 0 and not msgs and m and int(m.group(2)) == kw.get("pictures", 2)
+        m = re.search(r"(\d+) packets, (\d+) pictures.* (\d+)x(\d+) (\w+),", err)
+        # open loop: the decoder must have seen exactly the coding tree units and slice ends that were written
+        cnt = re.search(r"(\d+) coding tree units in (\d+) slices", err)
+        ok = rc == 0 and not msgs and m and int(m.group(2)) == kw.get("pictures", 2) and cnt and \
+            (int(cnt.group(1)), int(cnt.group(2))) == (kw_obj.n_ctus, kw_obj.n_slices)
         print(name, "bytes", sum(map(len, pkts)), "->", err.strip().splitlines()[-1] if err.strip() else rc, "OK" if ok else "REJECTED")
         if not ok:
             print("\n".join(msgs[:8]))
@@ -1005,7 +1015,7 @@ def main():
                 assert (got.reshape(-1) == np.array(luma) * 2).all(), (name, poc, x0, y0)
             print("   %d PCM blocks decode to the samples written" % len(h.pcm_blocks))
         gold[name] = {"md5": hashlib.md5(data).hexdigest(), "bytes": len(data), "pictures": int(m.group(2)), "width": int(m.group(3)), "height": int(m.group(4)),
-                      "pix_fmt": m.group(5), "stream_md5": hashlib.md5(b"".join(pkts)).hexdigest()}
+                      "pix_fmt": m.group(5), "ctus": kw_obj.n_ctus, "slices": kw_obj.n_slices, "stream_md5": hashlib.md5(b"".join(pkts)).hexdigest()}
     if not only:
         json.dump(gold, open(gold_path, "w"), indent=1, sort_keys=True)
         print("wrote", gold_path)

@@ -3,7 +3,8 @@ reference tree holds no HEVC sample): I pictures with every transform size 4..32
 SAO band / edge with merging, deblocking offsets / off, cu_qp_delta, transform skip, transquant bypass, default scaling
 lists, several slices, CTB sizes 16 / 32 / 64, 8 and 10 bit — and P / B pictures: skip, merge, AMVP with random vector
 differences, all partition shapes (AMP too), one or two lists, explicit weights, constrained intra prediction.
-tests/golden/hevc_streams.json = md5 of what the reference's own decoder (tables untouched) outputs for each."""
+tests/golden/hevc_streams.json = md5 of what the reference's own decoder (tables untouched) outputs for each, and the
+number of coding tree units / slices written (the decoder must see exactly those: the streams are open loop)."""
 import hashlib
 import json
 import os
@@ -20,17 +21,22 @@ def samples(name):
     return os.path.join(GOLD, "hevc_synth_%s.samples" % name)
 
 
-def run_tier1(which, name, out, plain=False):
-    """-> number of table entries the hooks replaced; asserts that the decoder raised no complaint"""
+def run_tier1(which, name, out, plain=False, lf_plain=False):
+    """-> (table entries the hooks replaced, pictures filtered by the picture-level pass); asserts that the decoder raised no
+    complaint and saw exactly the coding tree units and slice ends the writer wrote (the arithmetic decoding stayed in step)"""
     env = dict(os.environ)
     env.pop("MI355_TIER1_PLAIN", None)
+    env.pop("MI355_HEVC_LF_PLAIN", None)
     if plain:
         env["MI355_TIER1_PLAIN"] = "1"
+    if lf_plain:
+        env["MI355_HEVC_LF_PLAIN"] = "1"
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", which), samples(name), str(out)], capture_output=True, text=True, env=env, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stderr.splitlines() if l.strip()]
     assert len(lines) == 1 and "%d pictures" % MD5[name]["pictures"] in lines[0], r.stderr[-2000:]
-    return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1))
+    assert "%d coding tree units in %d slices" % (MD5[name]["ctus"], MD5[name]["slices"]) in lines[0], lines[0]
+    return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1)), int(re.search(r"(\d+) pictures deblocked per picture", lines[0]).group(1))
 
 
 def check_md5(path, name):

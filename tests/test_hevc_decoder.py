@@ -13,7 +13,7 @@ needs_harness = pytest.mark.skipif(not os.path.isdir("/root/reference/libavcodec
 
 def test_streams_cover_both_depths_and_inter_pictures():
     assert {HS.MD5[n]["pix_fmt"] for n in HS.ALL} == {"yuv420p", "yuv420p10le"}
-    assert sum(n.startswith("pb_") for n in HS.ALL) >= 4 and sum(n.startswith("i_") for n in HS.ALL) >= 8
+    assert sum(n.startswith("pb_") for n in HS.ALL) >= 6 and sum(n.startswith("i_") for n in HS.ALL) >= 12
     for n in HS.ALL:
         assert os.path.getsize(HS.samples(n)) > 1000
 
@@ -35,8 +35,25 @@ def test_writer_is_deterministic_and_the_reference_accepts_its_streams(tmp_path)
 def test_reference_hevc_decoder_with_tier1_hooks_emulated(tmp_path, emu, name):
     subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_tier1_emu"], check=True)
     out = tmp_path / "plain.yuv"
-    assert HS.run_tier1("hevc_tier1_emu", name, out, plain=True) == 0
+    assert HS.run_tier1("hevc_tier1_emu", name, out, plain=True)[0] == 0
     HS.check_md5(out, name)                                      # the committed md5 is the reference's
     out = tmp_path / "hooked.yuv"
-    assert HS.run_tier1("hevc_tier1_emu", name, out) >= 150      # the hooks filled the tables (169 entries at this revision)
+    assert HS.run_tier1("hevc_tier1_emu", name, out)[0] >= 150   # the hooks filled the tables (169 entries at this revision)
+    HS.check_md5(out, name)
+
+
+@needs_harness
+@pytest.mark.parametrize("name", HS.ALL)
+def test_reference_hevc_decoder_with_picture_level_filters_emulated(tmp_path, emu, name):
+    """contrib/libav/mi355_hevc_lf_bridge.c: deblocking and SAO of every picture in one device pass each, fed with the arrays
+    the reference's slice decoder leaves behind — the whole sequence (P / B pictures predict from the filtered pictures)
+    equals the reference's; with the DSP tables hooked as well, and with the reference's own tables"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_lf_emu"], check=True)
+    for plain in (False, True):
+        out = tmp_path / "lf.yuv"
+        hooks, pictures = HS.run_tier1("hevc_lf_emu", name, out, plain=plain)
+        assert pictures == HS.MD5[name]["pictures"] and (hooks == 0) == plain
+        HS.check_md5(out, name)
+    out = tmp_path / "lf_plain.yuv"
+    assert HS.run_tier1("hevc_lf_emu", name, out, plain=True, lf_plain=True) == (0, 0)
     HS.check_md5(out, name)

@@ -17,5 +17,16 @@ def test_reference_hevc_decoder_on_gpu(tmp_path, mi355, name):
     if not os.path.exists(os.path.join(HS.ROOT, "oracle", "_ref", "hevc_tier1_gpu")):
         pytest.fail("oracle/_ref/hevc_tier1_gpu missing: run __graft_entry__.build() where /root/reference exists")
     out = tmp_path / "hooked.yuv"
-    assert HS.run_tier1("hevc_tier1_gpu", name, out) >= 150
+    assert HS.run_tier1("hevc_tier1_gpu", name, out)[0] >= 150
+    HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", HS.ALL)
+def test_reference_hevc_decoder_with_picture_level_filters_on_gpu(tmp_path, mi355, name):
+    """contrib/libav/mi355_hevc_lf_bridge.c: the reference's tables untouched, deblocking + SAO per picture on the MI355X"""
+    if not os.path.exists(os.path.join(HS.ROOT, "oracle", "_ref", "hevc_lf_gpu")):
+        pytest.fail("oracle/_ref/hevc_lf_gpu missing: run __graft_entry__.build() where /root/reference exists")
+    out = tmp_path / "lf.yuv"
+    hooks, pictures = HS.run_tier1("hevc_lf_gpu", name, out, plain=True)
+    assert hooks == 0 and pictures == HS.MD5[name]["pictures"]
     HS.check_md5(out, name)
