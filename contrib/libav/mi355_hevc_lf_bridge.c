@@ -3,7 +3,7 @@
  *
  * The reference deblocks CTB by CTB as the slice decoder advances (hls_slice_data -> ff_hevc_hls_filters ->
  * ff_hevc_hls_filter -> deblocking_filter_CTB, hevcdec.c:2334-2339, hevc_filter.c:728-745).  Linked into the decoder with
- *     -Wl,--wrap=ff_hevc_hls_filters,--wrap=ff_hevc_hls_filter
+ *     -Wl,--wrap=ff_hevc_hls_filters,--wrap=ff_hevc_hls_filter,--wrap=ff_hevc_deblocking_boundary_strengths
  * this file turns that into one call per picture: the per-CTB calls are dropped, and when the slice decoder reports the
  * picture's last CTB (hevcdec.c:2337-2339) the frame-level arrays it left behind — vertical_bs / horizontal_bs, qp_y_tab,
  * is_pcm, the per-CTB DBParams — go to mi355_hevc_deblock_pictures_dev() (include/mi355_hevc_batch.h) exactly as they lie
@@ -34,6 +34,7 @@
 
 void __real_ff_hevc_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size);
 void __real_ff_hevc_hls_filter(HEVCContext *s, int x, int y);
+void __real_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size);
 
 static struct {
     size_t plane_bytes[3], bs_bytes, qp_bytes, pcm_bytes, db_bytes;
@@ -42,6 +43,14 @@ static struct {
     size_t out_bytes[3], jobs_bytes;
     mi355_hevc_sao_job *host_jobs;
     size_t host_jobs_n;
+    /* boundary strengths on the device: what the walk over the coding tree knows about every 4x4 cell's left / top side */
+    uint8_t *edge_flags, *d_edge, *d_mvf, *d_cbf;
+    size_t edge_cells, d_edge_bytes, d_mvf_bytes, d_cbf_bytes;
+    mi355_hevc_bs_picture *d_bs_desc;
+    const void *bs_ref;                    /* the picture the flags belong to */
+    int bs_lists_set, bs_uniform, bs_slice;
+    int32_t ref_poc[2][16];
+    unsigned long bs_pictures;
     mi355_hevc_lf_picture *desc;
     void *stream;
     unsigned long pictures;
@@ -75,6 +84,97 @@ static void fail(const char *what)
     lf.failed = 1;
 }
 
+
+/* ---- boundary strengths.  The reference derives them block by block while it walks the coding tree
+ * (ff_hevc_deblocking_boundary_strengths, hevc_filter.c:585-725, called for transform-tree leaves, PCM and residual-free
+ * coding units).  Here the walk only MARKS the cell sides it would examine — block edges on the 8x8 grid that are
+ * filtered (slice edges with filtering across them off are left unmarked) and the grid lines inside blocks that are not
+ * intra — and mi355_hevc_boundary_strengths_dev() derives every strength of the picture in one pass from tab_mvf /
+ * cbf_luma as they lie in the decoder.  The device pass compares reference pictures through ONE table per picture: a
+ * picture whose slices use different lists keeps the host's strengths (the reference's function still runs; a binding that
+ * knows its streams may drop it).  MI355_HEVC_BS_HOST=1 keeps the host's strengths for every picture. */
+static void bs_begin(const HEVCContext *s)
+{
+    const size_t cells = (size_t)(s->ps.sps->width >> 2) * (s->ps.sps->height >> 2);
+    if (lf.edge_cells < cells) {
+        free(lf.edge_flags);
+        lf.edge_flags = malloc(cells);
+        lf.edge_cells = lf.edge_flags ? cells : 0;
+    }
+    if (lf.edge_flags) memset(lf.edge_flags, 0, cells);
+    lf.bs_ref = s->ref;
+    lf.bs_lists_set = 0;
+    lf.bs_uniform = lf.edge_flags != NULL && !getenv("MI355_HEVC_BS_HOST");
+    lf.bs_slice = -1;
+    memset(lf.ref_poc, 0, sizeof(lf.ref_poc));
+}
+
+void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
+{
+    __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size);
+    if (!active(s)) return;
+    if (lf.bs_ref != s->ref) bs_begin(s);
+    if (!lf.bs_uniform) return;
+    const HEVCSPS *sps = s->ps.sps;
+    const HEVCLocalContext *lc = &s->HEVClc;
+    if (lf.bs_slice != (int)s->sh.slice_addr) {                     /* a new slice: its lists must be the picture's */
+        lf.bs_slice = (int)s->sh.slice_addr;
+        if (s->sh.slice_type != HEVC_SLICE_I && s->ref->refPicList) {
+            int32_t now[2][16];
+            memset(now, 0, sizeof(now));
+            for (int l = 0; l < 2; l++)
+                for (int i = 0; i < s->ref->refPicList[l].nb_refs && i < 16; i++) now[l][i] = s->ref->refPicList[l].list[i];
+            if (!lf.bs_lists_set) { memcpy(lf.ref_poc, now, sizeof(now)); lf.bs_lists_set = 1; }
+            else if (memcmp(lf.ref_poc, now, sizeof(now))) { lf.bs_uniform = 0; return; }
+        }
+    }
+    const int size = 1 << log2_trafo_size, cw = sps->width >> 2, ctb_mask = (1 << sps->log2_ctb_size) - 1;
+    const int inner = log2_trafo_size > sps->log2_min_pu_size &&
+                      !s->ref->tab_mvf[(y0 >> sps->log2_min_pu_size) * sps->min_pu_width + (x0 >> sps->log2_min_pu_size)].is_intra;
+    /* a slice edge with filtering across it switched off is not an edge (tiles: active() excludes them) */
+    const int top = y0 > 0 && !(y0 & 7) &&
+                    !(!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_UPPER_SLICE) && !(y0 & ctb_mask));
+    const int left = x0 > 0 && !(x0 & 7) &&
+                     !(!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_LEFT_SLICE) && !(x0 & ctb_mask));
+    for (int j = 0; j < size; j += 4)
+        for (int i = 0; i < size; i += 4) {
+            uint8_t f = 0;
+            if (i == 0 && left) f |= MI355_HEVC_EDGE_L_BLOCK;
+            if (j == 0 && top) f |= MI355_HEVC_EDGE_T_BLOCK;
+            if (inner && i && !(i & 7)) f |= MI355_HEVC_EDGE_L_INNER;
+            if (inner && j && !(j & 7)) f |= MI355_HEVC_EDGE_T_INNER;
+            if (f) lf.edge_flags[((y0 + j) >> 2) * cw + ((x0 + i) >> 2)] |= f;
+        }
+}
+
+/* -> 1: vertical_bs / horizontal_bs of the picture were derived on the device (lf.vbs / lf.hbs hold them) */
+static int bs_on_device(HEVCContext *s, size_t bs_bytes)
+{
+    const HEVCSPS *sps = s->ps.sps;
+    if (lf.bs_ref != s->ref || !lf.bs_uniform || (sps->width & 7) || (sps->height & 7)) return 0;
+    const size_t cells = (size_t)(sps->width >> 2) * (sps->height >> 2);
+    const size_t mvf = (size_t)sps->min_pu_width * sps->min_pu_height * sizeof(mi355_hevc_mvfield);
+    const size_t cbf = (size_t)sps->min_tb_width * sps->min_tb_height;
+    if (sizeof(MvField) != sizeof(mi355_hevc_mvfield)) return 0;
+    if (ensure(&lf.d_edge, &lf.d_edge_bytes, cells) || ensure(&lf.d_mvf, &lf.d_mvf_bytes, mvf) || ensure(&lf.d_cbf, &lf.d_cbf_bytes, cbf)) return 0;
+    if (!lf.d_bs_desc && !(lf.d_bs_desc = mi355_malloc(sizeof(*lf.d_bs_desc)))) return 0;
+    mi355_hevc_bs_picture d;
+    memset(&d, 0, sizeof(d));
+    d.width = sps->width; d.height = sps->height;
+    d.log2_min_pu_size = sps->log2_min_pu_size; d.log2_min_tb_size = sps->log2_min_tb_size;
+    d.min_pu_width = sps->min_pu_width; d.min_tb_width = sps->min_tb_width;
+    d.bs_width = s->bs_width;
+    d.tab_mvf = (const mi355_hevc_mvfield *)lf.d_mvf; d.cbf_luma = lf.d_cbf; d.edge_flags = lf.d_edge;
+    memcpy(d.ref_poc, lf.ref_poc, sizeof(d.ref_poc));
+    d.vertical_bs = lf.vbs; d.horizontal_bs = lf.hbs;
+    (void)bs_bytes;
+    int rc = mi355_memcpy_h2d(lf.d_edge, lf.edge_flags, cells) | mi355_memcpy_h2d(lf.d_mvf, s->ref->tab_mvf, mvf) |
+             mi355_memcpy_h2d(lf.d_cbf, s->cbf_luma, cbf) | mi355_memcpy_h2d(lf.d_bs_desc, &d, sizeof(d));
+    if (rc) return 0;
+    if (mi355_hevc_boundary_strengths_dev(lf.d_bs_desc, 1, sps->width, sps->height, lf.stream) != 0) return 0;
+    lf.bs_pictures++;
+    return 1;
+}
 
 /* The pieces of sao_filter_CTB for every CTB of the picture.  Piece k of CTB (cx, cy) belongs to the CTB at
  * (cx - (k >> 1), cy - (k & 1)) — k = the reference's class number: 0 the CTB itself, 1 the strip of the CTB above,
@@ -170,7 +270,8 @@ static int filter_picture(HEVCContext *s)
 
     int rc = 0;
     for (int i = 0; i < 3; i++) rc |= mi355_memcpy_h2d(lf.plane[i], s->frame->data[i], sz[i]);
-    rc |= mi355_memcpy_h2d(lf.vbs, s->vertical_bs, bs) | mi355_memcpy_h2d(lf.hbs, s->horizontal_bs, bs);
+    if (!bs_on_device(s, bs)) rc |= mi355_memcpy_h2d(lf.vbs, s->vertical_bs, bs) | mi355_memcpy_h2d(lf.hbs, s->horizontal_bs, bs);
+    lf.bs_ref = NULL;
     rc |= mi355_memcpy_h2d(lf.qp, s->qp_y_tab, qp) | mi355_memcpy_h2d(lf.pcm, s->is_pcm, pcm) | mi355_memcpy_h2d(lf.db, s->deblock, db);
     rc |= mi355_memcpy_h2d(lf.desc, &d, sizeof(d));
     if (rc) return -2;
@@ -227,3 +328,4 @@ void __wrap_ff_hevc_hls_filter(HEVCContext *s, int x, int y)
 }
 
 unsigned long mi355_hevc_lf_bridge_pictures(void) { return lf.pictures; }
+unsigned long mi355_hevc_lf_bridge_bs_pictures(void) { return lf.bs_pictures; }

@@ -74,6 +74,7 @@ int __wrap_ff_hevc_end_of_slice_flag_decode(HEVCContext *s)
 
 /* present when contrib/libav/mi355_hevc_lf_bridge.c is linked in (_ref/hevc_lf_*): pictures deblocked by the picture-level pass */
 extern unsigned long mi355_hevc_lf_bridge_pictures(void) __attribute__((weak));
+extern unsigned long mi355_hevc_lf_bridge_bs_pictures(void) __attribute__((weak));
 
 static uint32_t get_u32(FILE *f) { uint32_t v = 0; if (fread(&v, 4, 1, f) != 1) exit(4); return v; }
 
@@ -117,8 +118,8 @@ int main(int argc, char **argv)
         }
         if (i < n) av_packet_unref(&pkt);
     }
-    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked (%lu entries replaced), %dx%d %s, %lu pictures deblocked per picture, %lu coding tree units in %lu slices\n", n, shown, n_hooks, n_replaced, c->width, c->height,
-            av_get_pix_fmt_name(c->pix_fmt), mi355_hevc_lf_bridge_pictures ? mi355_hevc_lf_bridge_pictures() : 0ul, n_ctus, n_slice_ends);
+    fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked (%lu entries replaced), %dx%d %s, %lu pictures deblocked per picture (%lu with strengths from the device), %lu coding tree units in %lu slices\n", n, shown, n_hooks, n_replaced, c->width, c->height,
+            av_get_pix_fmt_name(c->pix_fmt), mi355_hevc_lf_bridge_pictures ? mi355_hevc_lf_bridge_pictures() : 0ul, mi355_hevc_lf_bridge_bs_pictures ? mi355_hevc_lf_bridge_bs_pictures() : 0ul, n_ctus, n_slice_ends);
     fclose(out);
     return n_hooks >= 3 ? 0 : 8;
 }

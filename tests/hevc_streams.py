@@ -22,7 +22,8 @@ def samples(name):
 
 
 def run_tier1(which, name, out, plain=False, lf_plain=False):
-    """-> (table entries the hooks replaced, pictures filtered by the picture-level pass); asserts that the decoder raised no
+    """-> (table entries the hooks replaced, pictures filtered by the picture-level pass); asserts that those pictures took
+    their boundary strengths from the device pass too (one reference list set per picture in all streams), that the decoder raised no
     complaint and saw exactly the coding tree units and slice ends the writer wrote (the arithmetic decoding stayed in step)"""
     env = dict(os.environ)
     env.pop("MI355_TIER1_PLAIN", None)
@@ -36,7 +37,9 @@ def run_tier1(which, name, out, plain=False, lf_plain=False):
     lines = [l for l in r.stderr.splitlines() if l.strip()]
     assert len(lines) == 1 and "%d pictures" % MD5[name]["pictures"] in lines[0], r.stderr[-2000:]
     assert "%d coding tree units in %d slices" % (MD5[name]["ctus"], MD5[name]["slices"]) in lines[0], lines[0]
-    return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1)), int(re.search(r"(\d+) pictures deblocked per picture", lines[0]).group(1))
+    lf = re.search(r"(\d+) pictures deblocked per picture \((\d+) with strengths from the device\)", lines[0])
+    assert lf.group(1) == lf.group(2), lines[0]
+    return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1)), int(lf.group(1))
 
 
 def check_md5(path, name):

@@ -45,7 +45,7 @@ def test_reference_hevc_decoder_with_tier1_hooks_emulated(tmp_path, emu, name):
 @needs_harness
 @pytest.mark.parametrize("name", HS.ALL)
 def test_reference_hevc_decoder_with_picture_level_filters_emulated(tmp_path, emu, name):
-    """contrib/libav/mi355_hevc_lf_bridge.c: deblocking and SAO of every picture in one device pass each, fed with the arrays
+    """contrib/libav/mi355_hevc_lf_bridge.c: boundary strengths, deblocking and SAO of every picture in one device pass each, fed with the arrays
     the reference's slice decoder leaves behind — the whole sequence (P / B pictures predict from the filtered pictures)
     equals the reference's; with the DSP tables hooked as well, and with the reference's own tables"""
     subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_lf_emu"], check=True)
