@@ -151,7 +151,8 @@ void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0
 static int bs_on_device(HEVCContext *s, size_t bs_bytes)
 {
     const HEVCSPS *sps = s->ps.sps;
-    if (lf.bs_ref != s->ref || !lf.bs_uniform || (sps->width & 7) || (sps->height & 7)) return 0;
+    if (lf.bs_ref != s->ref) bs_begin(s);                           /* no slice of the picture is deblocked: no edge marked */
+    if (!lf.bs_uniform || (sps->width & 7) || (sps->height & 7)) return 0;
     const size_t cells = (size_t)(sps->width >> 2) * (sps->height >> 2);
     const size_t mvf = (size_t)sps->min_pu_width * sps->min_pu_height * sizeof(mi355_hevc_mvfield);
     const size_t cbf = (size_t)sps->min_tb_width * sps->min_tb_height;
