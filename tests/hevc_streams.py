@@ -21,7 +21,7 @@ def samples(name):
     return os.path.join(GOLD, "hevc_synth_%s.samples" % name)
 
 
-def run_tier1(which, name, out, plain=False, lf_plain=False):
+def run_tier1(which, name, out, plain=False, lf_plain=False, intra_device=False):
     """-> (table entries the hooks replaced, pictures filtered by the picture-level pass); asserts that those pictures took
     their boundary strengths from the device pass too (one reference list set per picture in all streams), that the decoder raised no
     complaint and saw exactly the coding tree units and slice ends the writer wrote (the arithmetic decoding stayed in step)"""
@@ -32,11 +32,16 @@ def run_tier1(which, name, out, plain=False, lf_plain=False):
         env["MI355_TIER1_PLAIN"] = "1"
     if lf_plain:
         env["MI355_HEVC_LF_PLAIN"] = "1"
+    env.pop("MI355_HEVC_INTRA_DEVICE", None)
+    if intra_device:
+        env["MI355_HEVC_INTRA_DEVICE"] = "1"
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", which), samples(name), str(out)], capture_output=True, text=True, env=env, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stderr.splitlines() if l.strip()]
     assert len(lines) == 1 and "%d pictures" % MD5[name]["pictures"] in lines[0], r.stderr[-2000:]
     assert "%d coding tree units in %d slices" % (MD5[name]["ctus"], MD5[name]["slices"]) in lines[0], lines[0]
+    if intra_device:
+        return int(re.search(r"(\d+) intra blocks predicted by the batched wrapper", lines[0]).group(1))
     lf = re.search(r"(\d+) pictures deblocked per picture \((\d+) with strengths from the device\)", lines[0])
     assert lf.group(1) == lf.group(2), lines[0]
     return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1)), int(lf.group(1))

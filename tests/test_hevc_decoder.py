@@ -57,3 +57,15 @@ def test_reference_hevc_decoder_with_picture_level_filters_emulated(tmp_path, em
     out = tmp_path / "lf_plain.yuv"
     assert HS.run_tier1("hevc_lf_emu", name, out, plain=True, lf_plain=True) == (0, 0)
     HS.check_md5(out, name)
+
+
+@needs_harness
+@pytest.mark.parametrize("name", HS.ALL)
+def test_batched_intra_wrapper_inside_the_reference_decoder_emulated(tmp_path, emu, name):
+    """HEVCPredContext.intra_pred[] replaced by mi355_hevc_intra_pred_blocks_dev(), one block per call, on the decoder's own
+    state (picture so far, lc->na, tab_mvf with constrained intra prediction, min_tb_addr_zs): every intra block of every
+    stream — a pin of the batched wrapper, not a binding (oracle/ref_hevc_tier1_main.c)"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_tier1_emu"], check=True)
+    out = tmp_path / "intra.yuv"
+    assert HS.run_tier1("hevc_tier1_emu", name, out, intra_device=True) >= 100
+    HS.check_md5(out, name)

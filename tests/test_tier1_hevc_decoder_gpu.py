@@ -30,3 +30,11 @@ def test_reference_hevc_decoder_with_picture_level_filters_on_gpu(tmp_path, mi35
     hooks, pictures = HS.run_tier1("hevc_lf_gpu", name, out, plain=True)
     assert hooks == 0 and pictures == HS.MD5[name]["pictures"]
     HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", ["i_8bit", "i_10bit", "pb_ctb16_slices_cip"])
+def test_batched_intra_wrapper_inside_the_reference_decoder_on_gpu(tmp_path, mi355, name):
+    """intra_pred[] replaced by mi355_hevc_intra_pred_blocks_dev(), one block per call, on the decoder's own state"""
+    out = tmp_path / "intra.yuv"
+    assert HS.run_tier1("hevc_tier1_gpu", name, out, intra_device=True) >= 100
+    HS.check_md5(out, name)
