@@ -236,7 +236,8 @@ static int filter_picture(HEVCContext *s)
     const HEVCSPS *sps = s->ps.sps;
     const int h[3] = { sps->height, sps->height >> 1, sps->height >> 1 };
     size_t sz[3];
-    if (!lf.stream && !(lf.stream = mi355_stream_create())) return -1;
+    /* lf.stream stays the default stream: the plain copies below run on it too, so copies and passes are ordered by the
+     * stream alone (a binding that overlaps pictures would take pinned staging + its own stream, as the H.264 bridge does) */
     for (int i = 0; i < 3; i++) {
         sz[i] = (size_t)s->frame->linesize[i] * h[i];
         if (s->frame->linesize[i] <= 0 || ensure(&lf.plane[i], &lf.plane_bytes[i], sz[i])) return -1;
