@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-extra", action="store_true", help="skip the additional measured points (rank 0, N=1 only)")
+    ap.add_argument("--layout", choices=("tiled", "linear"), default="tiled", help="surface layout of dst / recon / reference "
+                    "pictures in HBM: macroblock-tiled (the decoded-picture-buffer layout, include/mi355_h264_frame.h) or planes "
+                    "with line strides (AVFrame-like)")
     ap.add_argument("--queue", action="store_true", help="N>1: ranks pull step-sized batches of streams from the work queue "
                     "(libav_amd.shard.WorkQueue) instead of the static deal; a rank may then run more or fewer than --steps steps")
     args = ap.parse_args()
@@ -103,7 +106,8 @@ def main():
     assert len(mine) == F
     fs = HF.synth_frames_fast(G, mbw, mbh, seed=mine[0][1], lib=lib)
     # the G distinct pictures are replicated ON THE DEVICE to F pictures, each with its own buffers in HBM
-    dev = HF.DeviceFrames(prov, fs, replicate=F)
+    tiled = args.layout == "tiled"
+    dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=tiled)
     big = fs
 
     for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -186,6 +190,9 @@ def main():
             "config": {"workload": "H.264 8-bit 4:2:0 1080p (1920x1088 coded), P pictures: qpel MC + idct_add + deblock, "
                                    "two-surface pipeline, %d independent pictures per GPU per step "
                                    "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, G),
+                       "surface_layout": "macroblock-tiled decoded-picture-buffer surfaces (256-byte luma + 128-byte chroma tiles; "
+                                         "a picture is de-tiled only when it leaves HBM: extra point config2_f2048_detile)" if tiled
+                                         else "planes with line strides",
                        "frames_per_gpu": F, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
                        "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
                        "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world,
@@ -204,7 +211,7 @@ def main():
         dev.free()
         dev = None
         if world == 1 and not args.no_extra:
-            out["extra"] = extra_points(lib, prov, mbw, mbh)
+            out["extra"] = extra_points(lib, prov, mbw, mbh, tiled)
         print(json.dumps(out))
     if dev is not None:
         dev.free()
@@ -212,18 +219,22 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_points(lib, prov, mbw, mbh):
+def extra_points(lib, prov, mbw, mbh, tiled=True):
     """Further measured points of the same path (each: the three passes back to back, HIP events, 3 steps after 1 warm-up)."""
     import h264_frames as HF
     pts = []
 
-    def run(name, fs, F, note):
-        dev = HF.DeviceFrames(prov, fs, replicate=F)
+    def run(name, fs, F, note, layout_tiled=tiled, detile=False):
+        dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=layout_tiled)
         try:
+            conv = detile_jobs(lib, dev, fs, F) if detile else None
+
             def once():
                 assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
                 assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
                 assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
+                if conv is not None:
+                    assert lib.mi355_h264_surface_convert_dev(conv, F, mbw, mbh, None) == 0
             once()
             e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
             lib.mi355_event_record(e0, None)
@@ -238,6 +249,12 @@ def extra_points(lib, prov, mbw, mbh):
                     "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "note": note})
 
     base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
+    if tiled:
+        run("config2_f2048_detile", base, 2048, "the headline workload with every finished picture also converted to planes with line strides "
+            "(mi355_h264_surface_convert_dev: what a picture costs when it LEAVES HBM — display, host copy, a consumer that wants lines; "
+            "+384 B read and written per macroblock; references stay tiled)", detile=True)
+    run("config2_f2048_linear" if tiled else "config2_f2048_tiled", base, 2048, "the headline workload on the OTHER surface layout (%s)"
+        % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled)
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (loop filter in its small-batch form: several bands of a picture per workgroup, k_deblock_bands)")
     run("config2_f512", base, 512, "512 pictures per step (small-batch loop filter form)")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
@@ -252,6 +269,29 @@ def extra_points(lib, prov, mbw, mbh):
         except Exception as e:                 # an extra point must not take the headline line down with it
             pts.append({"name": fn.__name__, "error": repr(e)})
     return pts
+
+
+def detile_jobs(lib, dev, fs, F):
+    """device array of F mi355_surface_job: picture f's tiled dst -> its own linear planes"""
+    class Job(C.Structure):
+        _fields_ = [("lin", C.c_void_p * 3), ("tiled", C.c_void_p * 2), ("lin_stride", C.c_int32 * 2), ("tiled_stride", C.c_int32 * 2),
+                    ("mb_width", C.c_int32), ("mb_height", C.c_int32), ("to_tiled", C.c_int32), ("reserved0", C.c_int32)]
+    lib.mi355_h264_surface_convert_dev.restype = C.c_int
+    lib.mi355_h264_surface_convert_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    ysz, csz = fs.H * fs.W, fs.H * fs.W // 4
+    lin = dev.alloc(F * (ysz + 2 * csz))
+    arr = (Job * F)()
+    for f in range(F):
+        j, d = arr[f], dev.host_desc[f]
+        base = lin + f * (ysz + 2 * csz)
+        j.lin[0], j.lin[1], j.lin[2] = base, base + ysz, base + ysz + csz
+        j.tiled[0], j.tiled[1] = d.dst[0], d.dst[1]
+        j.lin_stride[0], j.lin_stride[1] = fs.W, fs.W // 2
+        j.tiled_stride[0], j.tiled_stride[1] = d.dst_stride[0], d.dst_stride[1]
+        j.mb_width, j.mb_height, j.to_tiled = fs.mb_w, fs.mb_h, 0
+    p = dev.alloc(C.sizeof(arr))
+    lib.mi355_memcpy_h2d(p, C.addressof(arr), C.sizeof(arr))
+    return p
 
 
 def session_points(lib):

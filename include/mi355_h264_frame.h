@@ -181,7 +181,47 @@ typedef struct mi355_h264_frame {
                                          slot is a field addressed the same way; the loop filter then uses the vertical vector limit 2
                                          (h264_loopfilter.c:723) and strength 3 instead of 4 on horizontal macroblock edges of intra
                                          macroblocks (:551-556).  0: a frame picture */
+    int32_t surface_layout;           /* MI355_SURFACE_LINEAR (0): dst / recon / ref are planes with byte strides, as above.
+                                         MI355_SURFACE_TILED (1): macroblock-tiled surfaces, the layout a decoded picture buffer
+                                         keeps while it stays in HBM (see below); frame pictures only */
+    int32_t reserved0;
 } mi355_h264_frame;
+
+/* Macroblock-tiled surfaces (surface_layout == MI355_SURFACE_TILED).  What the reference keeps in an AVFrame with a line
+ * stride (h264_mb.c:239-314 fetches a 21 x 21 window as 21 row pieces of 21 different cache lines, h264_mb_template.c:85-91
+ * writes a macroblock as 32 row pieces) is stored here so that the unit every pass moves — a macroblock — is a run of whole
+ * 128-byte lines:
+ *   plane 0 (dst[0] / recon[0] / ref[s][0]): luma.  Macroblock (x, y) occupies the 256 bytes at y * stride[0] + x * 256:
+ *            its 16 rows of 16 samples one after the other.
+ *   plane 1 (dst[1] / recon[1] / ref[s][1]): chroma.  Macroblock (x, y) occupies the 128 bytes at y * stride[1] + x * 128:
+ *            the 8 rows of 8 Cb samples, then the 8 rows of 8 Cr samples.
+ *   plane 2 pointers are not read.
+ * dst_stride / recon_stride = bytes per macroblock ROW of tiles (>= 256 * mb_width / 128 * mb_width, multiples of 128); the
+ * reference surfaces use dst_stride, as in the linear layout.  Surfaces must be 128-byte aligned.
+ * All three kinds of surface of a picture use the same layout; field pictures (field_picture != 0) must be linear.
+ * mi355_h264_surface_convert_dev() moves pictures between the two layouts (upload of a reference decoded elsewhere; a
+ * picture leaving HBM for display or for a consumer that wants lines). */
+#define MI355_SURFACE_LINEAR 0
+#define MI355_SURFACE_TILED  1
+#define MI355_TILE_LUMA_BYTES   256
+#define MI355_TILE_CHROMA_BYTES 128
+
+/* One picture to convert between the layouts.  `lin`: three planes with byte strides lin_stride[0] (luma), [1] (both chroma
+ * planes); `tiled`: the two tiled planes with their macroblock-row strides.  Device pointers, or device-visible host memory
+ * (mi355_host_alloc) on the linear side. */
+typedef struct mi355_surface_job {
+    uint8_t *lin[3];
+    uint8_t *tiled[2];
+    int32_t lin_stride[2];
+    int32_t tiled_stride[2];
+    int32_t mb_width, mb_height;
+    int32_t to_tiled;                 /* 1: lin -> tiled, 0: tiled -> lin */
+    int32_t reserved0;
+} mi355_surface_job;
+/* `n` conversions in ONE launch; `jobs` device-visible; max_mb_width / max_mb_height: the largest picture of the batch.
+ * Linear planes and strides must be multiples of 8 bytes (luma 16 for the widest accesses; 4-byte multiples take a dword
+ * path).  Returns 0, or -1 / -2 / -3 as mi355_h264_decode_frames. */
+int mi355_h264_surface_convert_dev(const mi355_surface_job *jobs, int n, int max_mb_width, int max_mb_height, void *stream);
 
 /* Reconstruct and deblock `nframes` independent pictures described by the HOST array
  * `frames` (its pointers are device pointers).  Work is enqueued on `stream`

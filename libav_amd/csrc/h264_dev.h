@@ -327,6 +327,92 @@ __device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, 
     RPROF(3);
 }
 
+/* ---- reference windows from MACROBLOCK-TILED surfaces (mi355_h264_frame.surface_layout == MI355_SURFACE_TILED) ------------
+ * Luma macroblock (x, y) = 256 bytes at y * ypitch + x * 256 (16 rows of 16), chroma macroblock = 128 bytes at
+ * y * cpitch + x * 128 (8 rows of 8 Cb, then 8 rows of 8 Cr).  The (bh + 5) x (bw + 5) luma window spans at most three tiles
+ * in a row: it is fetched as 16-byte row pieces — lane (piece p, row r) one global_load_dwordx4, four neighbouring lanes
+ * four consecutive rows of one tile = 64 contiguous bytes, the whole window 6-12 cache lines instead of one (or two) per
+ * row — into `raw`, 48 bytes per row starting at picture column xb (a multiple of 16).  Rows clamp to the picture by
+ * clamping the row number of the address (emulated_edge_mc's vertical replication, videodsp_template.c:24-96, for free);
+ * columns are replicated in the second step: raw -> the block-aligned windows of McScratch that the filters read (dword
+ * reads + v_alignbyte when every column the filters use lies inside the picture, per sample with clamped column otherwise).
+ * The two chroma windows the same way: 8-byte pieces, two per row and plane. */
+struct TiledRef {
+    const uint8_t *y, *c;
+    int ypitch, cpitch;          /* bytes per macroblock row of tiles */
+    int mbw, mbh;
+};
+struct __attribute__((aligned(16))) McRaw {
+    uint32_t pre[4];             /* the dword in front of row 0 is read (never used) when the window starts 1-2 columns left of xb */
+    uint8_t y[21 * 48];
+    uint8_t c[2][9 * 16];
+    uint32_t post[4];            /* ... and the dword behind the last row */
+};
+typedef uint32_t mi355_raw_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t mi355_raw_u32x2 __attribute__((vector_size(8)));
+__device__ inline void stage_windows_tiled(McScratch &s, McRaw &raw, const TiledRef &t, int ix, int iy, int bw, int bh,
+                                           int cx, int cy, int cw, int ch)
+{
+    const int lane = lane_id();
+    const int wpix = 16 * t.mbw, hpix = 16 * t.mbh, wc = 8 * t.mbw, hc = 8 * t.mbh;
+    const int rows = bh + 5, crows = ch + 1;
+    /* ---- loads: everything in flight before the first LDS write ---- */
+    const int xb = clip3((ix - 2) & ~15, 0, imax(0, 16 * (t.mbw - 3)));
+    const int L = lane < 63 ? lane : 62;
+    const int p = (int)(__umul24((unsigned)L, 49u) >> 10), r = L - 21 * p;          /* L / 21, L % 21 */
+    const int y = clip3(iy - 2 + imin(r, rows - 1), 0, hpix - 1);
+    const int tx = imin((xb >> 4) + p, t.mbw - 1);
+    const mi355_raw_u32x4 vy = *reinterpret_cast<const mi355_raw_u32x4 *>(t.y + (uint32_t)(__mul24(y >> 4, t.ypitch) + tx * 256 + (y & 15) * 16));
+    const int xc = clip3(cx & ~7, 0, imax(0, 8 * (t.mbw - 2)));
+    const int U = lane < 36 ? lane : 35;
+    const int plane = U >= 18, rem = U - 18 * plane, piece = rem >= 9, crow = rem - 9 * piece;
+    const int yc = clip3(cy + imin(crow, crows - 1), 0, hc - 1);
+    const int txc = imin((xc >> 3) + piece, t.mbw - 1);
+    const mi355_raw_u32x2 vc = *reinterpret_cast<const mi355_raw_u32x2 *>(t.c + (uint32_t)(__mul24(yc >> 3, t.cpitch) + txc * 128 + plane * 64 + (yc & 7) * 8));
+    MI355_ISSUE_FENCE();
+    *reinterpret_cast<mi355_raw_u32x4 *>(raw.y + r * 48 + p * 16) = vy;
+    *reinterpret_cast<mi355_raw_u32x2 *>(raw.c[plane] + crow * 16 + piece * 8) = vc;
+    MI355_WAVE_SYNC();
+    /* ---- raw -> block-aligned windows ---- */
+    {
+        const int ydw = luma_win_dw(bw), n = rows * ydw, inv = mi355_inv20(ydw);
+        const bool inside = ix - 2 >= 0 && ix + bw + 2 <= wpix - 1;
+        const int o0 = ix - 4 - xb;
+        for (int i = lane; i < n; i += 64) {
+            const int row = mi355_div20(i, inv), k = i - row * ydw, o = o0 + 4 * k;
+            uint32_t v;
+            if (inside) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(raw.y + row * 48) + (o >> 2);
+                v = mi355_alignbyte(q[1], q[0], (uint32_t)o & 3u);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= (uint32_t)raw.y[row * 48 + clip3(ix - 4 + 4 * k + b, 0, wpix - 1) - xb] << (8 * b);
+            }
+            s.winY[row * WY_DW + k] = v;
+        }
+    }
+    {
+        const int cdw = chroma_win_dw(cw), per = crows * cdw, n = 2 * per, inv = mi355_inv20(cdw);
+        const bool inside = cx >= 0 && cx + cw <= wc - 1;
+        const int o0 = cx - xc;
+        for (int i = lane; i < n; i += 64) {
+            const int pl = i >= per, j = i - pl * per, row = mi355_div20(j, inv), k = j - row * cdw, o = o0 + 4 * k;
+            uint32_t v;
+            if (inside) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(raw.c[pl] + row * 16) + (o >> 2);
+                v = mi355_alignbyte(q[1], q[0], (uint32_t)o & 3u);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= (uint32_t)raw.c[pl][row * 16 + clip3(cx + 4 * k + b, 0, wc - 1) - xc] << (8 * b);
+            }
+            s.winC[pl][row * WC_DW + k] = v;
+        }
+    }
+    MI355_WAVE_SYNC();
+}
+
 __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int *v)
 {
 #pragma unroll

@@ -46,6 +46,7 @@ struct __attribute__((aligned(16))) MbLds {
     uint8_t exp_pad[MI355_EXP_LDS_PAD];
 #endif
     McScratch mc;
+    McRaw raw;                                /* tiled surfaces: the reference windows as fetched (stage_windows_tiled) */
 };
 
 __device__ __forceinline__ int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 1); }
@@ -65,6 +66,9 @@ struct FrameHot {
     int32_t mb_width, mb_height;
     const mi355_h264_frame *desc;     /* for the reference table when a kernel keeps no copy of it in LDS */
 };
+/* macroblock-tiled surfaces (mi355_h264_frame.h): plane 0 = 256-byte luma tiles, plane 1 = 128-byte chroma tiles (Cb, Cr) */
+__device__ __forceinline__ uint32_t tile_y_off(int mb_x, int mb_y, int stride) { return (uint32_t)(__mul24(mb_y, stride) + mb_x * MI355_TILE_LUMA_BYTES); }
+__device__ __forceinline__ uint32_t tile_c_off(int mb_x, int mb_y, int stride) { return (uint32_t)(__mul24(mb_y, stride) + mb_x * MI355_TILE_CHROMA_BYTES); }
 __device__ __forceinline__ FrameHot frame_hot(const mi355_h264_frame &fr)
 {
     FrameHot h;
@@ -151,6 +155,7 @@ __device__ __forceinline__ void load_mb_wide(MbLds &s, const FrameHot &fr, int m
 }
 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318 */
+template <bool TILED>
 __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y,
                               int mb_xy, int list, int n_raster, int refn, int bx, int by, int w, int h,
                               uint8_t *py, uint8_t *pcb, uint8_t *pcr, int avg)
@@ -164,6 +169,22 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
     const int myc = my + __builtin_amdgcn_readfirstlane((int)s.hdr.u.inter.chroma_dy[list][(bx >> 3) + 2 * (by >> 3)]);
     (void)refs;
     const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
+    if (TILED) {
+        const TiledRef tr{mi355_global(rp[0]), mi355_global(rp[1]), fr.ref_stride[0], fr.ref_stride[1], fr.mb_width, fr.mb_height};
+#ifndef MI355_EXP_NO_STAGE
+        stage_windows_tiled(s.mc, s.raw, tr, mx >> 2, my >> 2, w, h, mx >> 3, myc >> 3, w >> 1, h >> 1);
+#endif
+        RPROF(3);
+#ifndef MI355_EXP_NO_LUMA
+        mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
+#endif
+        RPROF(4);
+#ifndef MI355_EXP_NO_CHROMA
+        if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, myc & 7, pcb, pcr, 8, avg);
+        else mc_chroma_compute(s.mc, 2, mx & 7, myc & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
+#endif
+        return;
+    }
     PlaneRef ry{mi355_global(rp[0]), fr.ref_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
     PlaneRef rb{mi355_global(rp[1]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     PlaneRef rr{mi355_global(rp[2]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
@@ -184,6 +205,7 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471).  Both lists go
  * through ONE call site of mc_dir (inlined): a second prediction lands in the q* tiles when the two have to be
  * blended with weights, on top of the first one (rounded average) otherwise. */
+template <bool TILED>
 __device__ __forceinline__ void mc_part(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y,
                                         int mb_xy, int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
@@ -196,7 +218,7 @@ __device__ __forceinline__ void mc_part(MbLds &s, const FrameHot &fr, RefTable r
         if (!(list ? l1 : l0)) continue;
         const bool second = list == 1 && two;
         const bool to_q = second && weighted;
-        mc_dir(s, fr, refs, sl, mb_x, mb_y, mb_xy, list, n_raster, list ? r1 : r0, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0],
+        mc_dir<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, list, n_raster, list ? r1 : r0, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0],
                to_q ? s.qc[1] : s.pc[1], second && !weighted);
     }
     if (!weighted) return;
@@ -228,6 +250,7 @@ __device__ __forceinline__ void mc_part(MbLds &s, const FrameHot &fr, RefTable r
 
 /* hl_motion, h264_mc_template.c:64-163.  The partitions are enumerated by one loop so that mc_part has
  * a single (inlined) call site. */
+template <bool TILED>
 __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, const mi355_h264_slice &sl, int mb_x, int mb_y, int mb_xy)
 {
     const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
@@ -240,11 +263,11 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
 #ifndef MI355_NO_P16
         if (l0 && !l1 && !(uniform(s.hdr.flags) & MI355_MBF_WEIGHTED)) {
             /* ... and the plain P_16x16 / P_Skip macroblock goes straight to one list-0 prediction written in place */
-            mc_dir(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
+            mc_dir<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
             return;
         }
 #endif
-        mc_part(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
+        mc_part<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
         return;
     }
     const int nparts = kind == 3 ? 16 : 2;
@@ -266,7 +289,7 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
             by = y + (shape == MI355_SUB_8x4 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j >> 1) : 0));
             n = (bx >> 2) + 4 * (by >> 2);
         }
-        mc_part(s, fr, refs, sl, mb_x, mb_y, mb_xy, n, quad, bx, by, w, h, l0, l1);
+        mc_part<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
 }
@@ -513,6 +536,32 @@ __device__ __forceinline__ void store_mb_rows(const MbLds &s, const FrameHot &fr
     }
 }
 
+/* the same tile into a macroblock-tiled surface: py and pc ARE the tile (16 x 16, then 8 x 8 Cb, 8 x 8 Cr): 24 lanes, 16 bytes each,
+ * three whole cache lines */
+__device__ __forceinline__ void store_mb_tiled(const MbLds &s, const FrameHot &fr, int mb_x, int mb_y)
+{
+    static_assert(offsetof(MbLds, pc) == offsetof(MbLds, py) + 256, "py and pc are one run of rows");
+    const int lane = lane_id();
+    if (lane < 24) {
+        const mi355_u32x4 v = *reinterpret_cast<const mi355_u32x4 *>(s.py + 16 * lane);
+        uint8_t *d = lane < 16 ? fr.recon[0] + tile_y_off(mb_x, mb_y, fr.recon_stride[0]) + 16 * lane
+                               : fr.recon[1] + tile_c_off(mb_x, mb_y, fr.recon_stride[1]) + 16 * (lane - 16);
+        *reinterpret_cast<mi355_u32x4 *>(d) = v;
+    }
+}
+/* a tile with pitches (the intra kernel's, or raw I_PCM samples) into a macroblock-tiled surface: a dword per lane, 64 + 32 lanes */
+template <bool ALIGNED = false>
+__device__ inline void store_mb_pitched_tiled(const uint8_t *y, int ypitch, const uint8_t *cb, const uint8_t *cr, int cpitch,
+                                              const FrameHot &fr, int mb_x, int mb_y)
+{
+    const int lane = lane_id();
+    *reinterpret_cast<uint32_t *>(fr.recon[0] + tile_y_off(mb_x, mb_y, fr.recon_stride[0]) + 4 * lane) = tile_dword<ALIGNED>(y + (lane >> 2) * ypitch + 4 * (lane & 3));
+    if (lane < 32) {
+        const int plane = lane >> 4, row = (lane >> 1) & 7, seg = lane & 1;
+        *reinterpret_cast<uint32_t *>(fr.recon[1] + tile_c_off(mb_x, mb_y, fr.recon_stride[1]) + 4 * lane) = tile_dword<ALIGNED>((plane ? cr : cb) + row * cpitch + 4 * seg);
+    }
+}
+
 #ifdef MI355_PROF   /* developer instrumentation (tools/prof_deblock.sh): per-phase shader-clock totals of the first blocks */
 __device__ unsigned long long g_prof[16];
 #define PROF_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
@@ -540,17 +589,10 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
  * fetches its 768 bytes only when its record says it has coefficients (cbp), at the price of a second, dependent round of
  * loads for those that do — in P / B pictures of real streams most macroblocks carry none, and the link is the narrow
  * place there.  With everything in HBM (the dense form) all five loads of a macroblock go out together. */
-template <bool SPARSE>
-__device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
-                                                 unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+template <bool SPARSE, bool TILED>
+__device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame &frd, int mb_x, int mb_y)
 {
-    RPROF_START();
-    const int lin = xcd_linear((int)blockIdx.x, per_xcd);
-    if (lin >= nblocks) return;
-    /* lin = (f * max_h + mb_y) * max_w + mb_x */
-    const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
-    const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
-    const FrameHot fr = frame_hot(frames[f]);
+    const FrameHot fr = frame_hot(frd);
     if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     RPROF(0);
@@ -569,7 +611,7 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
         MI355_WAVE_SYNC();
     }
     const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
-    hl_motion(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
+    hl_motion<TILED>(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
     RPROF(5);
 #ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
@@ -581,8 +623,23 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     }
 #endif
     RPROF(6);
-    store_mb_rows(s, fr, mb_x, mb_y);
+    if (TILED) store_mb_tiled(s, fr, mb_x, mb_y);
+    else store_mb_rows(s, fr, mb_x, mb_y);
     RPROF(7);
+}
+template <bool SPARSE>
+__device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
+                                                 unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+{
+    RPROF_START();
+    const int lin = xcd_linear((int)blockIdx.x, per_xcd);
+    if (lin >= nblocks) return;
+    /* lin = (f * max_h + mb_y) * max_w + mb_x */
+    const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
+    const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+    /* the surface layout is a property of the picture: both forms of the macroblock code live in the kernel, a wave takes one */
+    if (uniform(frames[f].surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
+    else recon_inter_mb<SPARSE, false>(s, frames[f], mb_x, mb_y);
 }
 /* Eight waves per SIMD: left alone the compiler takes 106 scalar registers (seven waves).  Capped at 96 it spills more of them
  * to vector lanes (+45 VALU per macroblock) and the kernel is still 2.5 % faster: it waits on three dependent memory round
@@ -621,17 +678,10 @@ struct IntraLds {
 #define TILE(x, y) s.tile[((y) + 1) * TP + (x) + TO]
 #define CTILE(p, x, y) s.ctile[p][((y) + 1) * CP + (x) + TO]
 
-__global__ void __launch_bounds__(64)
-k_recon_intra(const mi355_h264_frame *frames, int level, int width)
+template <bool TILED>
+__device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_frame &frd, int mb_xy)
 {
-    __shared__ IntraLds s;
     const int lane = lane_id();
-    const int f = blockIdx.x / width, k = blockIdx.x - f * width;
-    const mi355_h264_frame &frd = frames[f];
-    if (level > frd.max_intra_level) return;
-    const int first = mi355_global(frd.intra_level_start)[level - 1], count = mi355_global(frd.intra_level_start)[level] - first;
-    if (k >= count) return;
-    const int mb_xy = (int)mi355_global(frd.intra_list)[first + k];
     const FrameHot fr = frame_hot(frd);
     const int mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width;
     /* Everything this macroblock reads from memory is requested at once — record, vectors, coefficients and the edge
@@ -650,7 +700,19 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     const ptrdiff_t oc = top_c ? (ptrdiff_t)(lane - 1) - cs : (left_c ? (ptrdiff_t)(lane - 16) * cs - 1 : 0);
     MbLoad ld;
     load_mb_issue(ld, fr, mb_xy, true, true);
-    const uint8_t e_y = ry[oy], e_cb = rcb[oc], e_cr = rcr[oc];
+    uint8_t e_y, e_cb, e_cr;
+    if (TILED) {
+        /* the same samples in tiles: the row above = last row of the tiles above (left, own, right), the column to the left = last
+         * column of the left tile; Cb and Cr sit 64 bytes apart in one chroma tile */
+        const int xt = mb_x * 16 + lane - 1, xtc = mb_x * 8 + lane - 1;
+        const uint32_t ty = top_y ? tile_y_off(xt >> 4, mb_y - 1, ys) + 15 * 16 + (xt & 15)
+                                  : (left_y ? tile_y_off(mb_x - 1, mb_y, ys) + (lane - 32) * 16 + 15 : tile_y_off(mb_x, mb_y, ys));
+        const uint32_t tc = top_c ? tile_c_off(xtc >> 3, mb_y - 1, cs) + 7 * 8 + (xtc & 7)
+                                  : (left_c ? tile_c_off(mb_x - 1, mb_y, cs) + (lane - 16) * 8 + 7 : tile_c_off(mb_x, mb_y, cs));
+        e_y = fr.recon[0][ty]; e_cb = fr.recon[1][tc]; e_cr = fr.recon[1][tc + 64];
+    } else {
+        e_y = ry[oy]; e_cb = rcb[oc]; e_cr = rcr[oc];
+    }
     MI355_ISSUE_FENCE();
     load_mb_commit(s.mb, ld, true, fr.mv[0] != nullptr, fr.mv[1] != nullptr);
     const mi355_h264_mb &h = s.mb.hdr;
@@ -658,7 +720,8 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
-        store_mb<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
+        if (TILED) store_mb_pitched_tiled<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
+        else store_mb<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
         return;
     }
     /* edge samples -> tiles */
@@ -736,9 +799,24 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
         }
     }
     residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
-    store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
+    if (TILED) store_mb_pitched_tiled<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
+    else store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
 }
 #undef TILE
+
+__global__ void __launch_bounds__(64)
+k_recon_intra(const mi355_h264_frame *frames, int level, int width)
+{
+    __shared__ IntraLds s;
+    const int f = blockIdx.x / width, k = blockIdx.x - f * width;
+    const mi355_h264_frame &frd = frames[f];
+    if (level > frd.max_intra_level) return;
+    const int first = mi355_global(frd.intra_level_start)[level - 1], count = mi355_global(frd.intra_level_start)[level] - first;
+    if (k >= count) return;
+    const int mb_xy = (int)mi355_global(frd.intra_list)[first + k];
+    if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true>(s, frd, mb_xy);
+    else recon_intra_mb<false>(s, frd, mb_xy);
+}
 
 /* ------------------------------------------------------------------------- */
 /* deblocking                                                                   */
@@ -1029,7 +1107,10 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
  * in the same launch, wave w starting DEBLOCK_LAG steps after wave w - 1, all waves meeting at a workgroup barrier after
  * every step: a band reads the rows above it (written by the wave above) only after that wave has written them and the
  * barrier's fence has made them visible — see DEBLOCK_LAG. */
-template <bool TWO_LISTS, int KW>     /* TWO_LISTS: list-1 vectors exist (B pictures): a compile-time switch, so that a P picture carries no list-1 state at all */
+/* TILED: recon and dst are macroblock-tiled surfaces (mi355_h264_frame.h): a lane's share of a chunk is then four consecutive
+ * rows of ONE macroblock (64 contiguous bytes per four lanes, whole cache lines per macroblock) instead of one row piece of
+ * each of four macroblocks; the LDS tiles and everything between load and store are the same. */
+template <bool TWO_LISTS, int KW, bool TILED>     /* TWO_LISTS: list-1 vectors exist (B pictures): a compile-time switch, so that a P picture carries no list-1 state at all */
 __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_frame &fr, int band, int wave)
 {
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
@@ -1046,8 +1127,8 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
     /* the group below (same wave) filters and writes this row's bottom three luma rows / last chroma row */
     const bool below = g < 3 && mb_y + 1 < fr.mb_height;
     /* 16-byte (luma) / 8-byte (chroma) pieces can move as one access when pointers and strides allow */
-    const bool al16 = ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[0])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[0])) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
-    const bool al8 = ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[1])) | reinterpret_cast<uintptr_t>(mi355_global(fr.recon[2])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[1])) |
+    const bool al16 = TILED || ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[0])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[0])) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
+    const bool al8 = TILED || ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[1])) | reinterpret_cast<uintptr_t>(mi355_global(fr.recon[2])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[1])) |
                        reinterpret_cast<uintptr_t>(mi355_global(fr.dst[2])) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
     if (lane < 52) {
         s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
@@ -1091,12 +1172,11 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
         }
     };
     /* chunk I/O roles of a lane: piece p of a row pair */
-    const int io_p = l & (DCH - 1), io_r = l >> DCH_LOG;
+    const int io_p = TILED ? l >> (4 - DCH_LOG) : l & (DCH - 1), io_r = TILED ? l & (DIO_ROWS - 1) : l >> DCH_LOG;
     /* plane pointers once, in scalar registers: a per-lane fetch from the descriptor inside the chunk functions would
      * put a dependent load (and a wait for everything in flight) in front of every access */
     const uint8_t *const recon_cb = mi355_global(fr.recon[1]), *const recon_cr = mi355_global(fr.recon[2]);
     uint8_t *const dst_cb = mi355_global(fr.dst[1]), *const dst_cr = mi355_global(fr.dst[2]);
-    const uint8_t *const recon_y = mi355_global(fr.recon[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * rs;
     uint8_t *const dst_y = mi355_global(fr.dst[0]) + (ptrdiff_t)(row_ok ? mb_y : 0) * 16 * ds;
 
     /* Chunk c (macroblocks DCH*c - 2g .. + DCH-1) of this group's row: the loads are issued a few steps before the
@@ -1115,19 +1195,32 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
      * sizes, or the tail of a multi-band workgroup) reads where the picture's last band would: in bounds, never used */
     const int band_c = imin(band, (fr.mb_height - 1) >> 2);
     const int top_y0 = band_c > 0 ? 4 * band_c * 16 - 4 : 0, top_c0 = band_c > 0 ? 4 * band_c * 8 - 2 : 0;
-    const uint8_t *const dst_y0 = mi355_global(fr.dst[0]);
+    uint8_t *const dst_y0 = mi355_global(fr.dst[0]);
+    const uint8_t *const recon_y0 = mi355_global(fr.recon[0]);
+    const int top_mb = band_c > 0 ? 4 * band_c - 1 : 0;
     auto issue_chunk = [&](int c) {
         const int xr = DCH * c - 2 * g + io_p, x = xr < 0 ? 0 : (xr < W ? xr : W - 1);
         const int xt0 = DCH * c + io_p, xt = xt0 < W ? xt0 : W - 1;          /* group 0's macroblock */
 #pragma unroll
         for (int it = 0; it < NY; it++) {
             const int row = DIO_ROWS * it + io_r;            /* luma row; as chroma: plane = row >> 3, row & 7 */
+            if (TILED) {
+                vy[it] = ld16(recon_y0 + tile_y_off(x, mb_yc, rs) + 16 * row, true);
+                vc[it] = ld8(recon_cb + tile_c_off(x, mb_yc, rcs) + 8 * row, true);         /* Cb rows 0..7, Cr rows 8..15 of the chroma tile */
+                continue;
+            }
             vy[it] = ld16(recon_yc + (uint32_t)(__mul24(row, rs) + x * 16), al16);
             vc[it] = ld8(((row >> 3) ? recon_cr : recon_cb) + (uint32_t)(__mul24(mb_yc * 8 + (row & 7), rcs) + x * 8), al8);
         }
 #pragma unroll
         for (int it = 0; it < NTOP; it++) {
             const int row = (DIO_ROWS * it + io_r) & 3;      /* 0..3: luma rows -4..-1; chroma: plane = row >> 1, row -2 + (row & 1) */
+            if (TILED) {
+                /* the last four luma rows / last two rows of each chroma plane of the tile above the band (tile 0 when there is none) */
+                ty[it] = ld16(dst_y0 + tile_y_off(xt, top_mb, ds) + 16 * (12 + row), true);
+                tc[it] = ld8(dst_cb + tile_c_off(xt, top_mb, dcs) + 64 * (row >> 1) + 8 * (6 + (row & 1)), true);
+                continue;
+            }
             ty[it] = ld16(dst_y0 + (uint32_t)(__mul24(top_y0 + row, ds) + xt * 16), al16);
             tc[it] = ld8(((row >> 1) ? dst_cr : dst_cb) + (uint32_t)(__mul24(top_c0 + (row & 1), dcs) + xt * 8), al8);
         }
@@ -1161,9 +1254,18 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
 #pragma unroll
         for (int it = 0; it < NF; it++) {
             const int row = DIO_ROWS * it + io_r;
+            const int plane = row >= 10, crow = row - 10 * plane;
+            if (TILED) {
+                /* tile rows -4..-1 (chroma -2, -1) are the last rows of the tile above */
+                if (ok && row >= y_first && row <= y_last)
+                    st16(dst_y0 + (row >= 4 ? tile_y_off(x, mb_y, ds) + 16 * (row - 4) : tile_y_off(x, mb_y - 1, ds) + 16 * (12 + row)), lds16(&s.y[g][b][row][16 * io_p]), true);
+                if (ok && crow >= c_first && crow <= c_last)
+                    st8(dst_cb + (crow >= 2 ? tile_c_off(x, mb_y, dcs) + 8 * (crow - 2) : tile_c_off(x, mb_y - 1, dcs) + 8 * (6 + crow)) + 64 * plane,
+                        *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), true);
+                continue;
+            }
             if (ok && row >= y_first && row <= y_last)
                 st16(dst_y + (ptrdiff_t)(row - 4) * ds + x * 16, lds16(&s.y[g][b][row][16 * io_p]), al16);
-            const int plane = row >= 10, crow = row - 10 * plane;
             if (ok && crow >= c_first && crow <= c_last)
                 st8((plane ? dst_cr : dst_cb) + (ptrdiff_t)(mb_y * 8 + crow - 2) * dcs + x * 8, *reinterpret_cast<const uint2 *>(&s.c[g][b][plane][crow][8 * io_p]), al8);
         }
@@ -1366,8 +1468,13 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 {
     __shared__ DeblockLds s;
     const mi355_h264_frame &fr = frames[blockIdx.x];
-    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, 1>(s, fr, band, 0);
-    else deblock_band<false, 1>(s, fr, band, 0);
+    if (uniform(fr.surface_layout) == MI355_SURFACE_TILED) {
+        if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, 1, true>(s, fr, band, 0);
+        else deblock_band<false, 1, true>(s, fr, band, 0);
+        return;
+    }
+    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, 1, false>(s, fr, band, 0);
+    else deblock_band<false, 1, false>(s, fr, band, 0);
 }
 
 /* the small-batch form: KW consecutive bands of a picture per workgroup, one wave each (see deblock_band) */
@@ -1378,8 +1485,13 @@ k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0)
     __shared__ DeblockLds s[KW];
     const mi355_h264_frame &fr = frames[blockIdx.x];
     const int wave = (int)(threadIdx.x >> 6);
-    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, KW>(s[wave], fr, band0 + wave, wave);
-    else deblock_band<false, KW>(s[wave], fr, band0 + wave, wave);
+    if (uniform(fr.surface_layout) == MI355_SURFACE_TILED) {
+        if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, KW, true>(s[wave], fr, band0 + wave, wave);
+        else deblock_band<false, KW, true>(s[wave], fr, band0 + wave, wave);
+        return;
+    }
+    if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, KW, false>(s[wave], fr, band0 + wave, wave);
+    else deblock_band<false, KW, false>(s[wave], fr, band0 + wave, wave);
 }
 
 }  // namespace
@@ -1539,6 +1651,8 @@ extern "C" int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nfra
         if (frames[i].mb_height > mh) mh = frames[i].mb_height;
         if (frames[i].max_intra_level > ml) ml = frames[i].max_intra_level;
         if (frames[i].max_level_width > lw) lw = frames[i].max_level_width;
+        /* tiled surfaces hold frame pictures only (a field would be every other row of every tile) */
+        if (frames[i].surface_layout != MI355_SURFACE_LINEAR && (frames[i].surface_layout != MI355_SURFACE_TILED || frames[i].field_picture)) return -1;
     }
     if (!st.copied) MI355_TRY(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming), -4);
     else MI355_TRY(hipEventSynchronize(st.copied), -4);
@@ -1651,6 +1765,42 @@ extern "C" int mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t ma
     unsigned gx = (unsigned)((max_bytes + per_block - 1) / per_block);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_copy_batch, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+namespace {
+/* linear planes <-> macroblock tiles: 32 lanes per macroblock (16 luma rows of 16 bytes, 16 chroma rows of 8), eight macroblocks
+ * per workgroup; the tiled side of a macroblock is one run of 256 + 128 bytes */
+__global__ void __launch_bounds__(256) k_surface_convert(const mi355_surface_job *jobs, int n)
+{
+    if ((int)blockIdx.y >= n) return;
+    const mi355_surface_job &j = mi355_global(jobs)[blockIdx.y];
+    const int W = uniform(j.mb_width), H = uniform(j.mb_height);
+    const int mb = (int)blockIdx.x * 8 + (int)(threadIdx.x >> 5), r = (int)threadIdx.x & 31;
+    if (mb >= W * H) return;
+    const int mb_y = mb / W, mb_x = mb - mb_y * W;
+    const bool to_tiled = uniform(j.to_tiled) != 0;
+    if (r < 16) {
+        uint8_t *lin = mi355_global(j.lin[0]) + (size_t)(mb_y * 16 + r) * j.lin_stride[0] + mb_x * 16;
+        uint8_t *til = mi355_global(j.tiled[0]) + (size_t)mb_y * j.tiled_stride[0] + mb_x * MI355_TILE_LUMA_BYTES + 16 * r;
+        const bool al = ((reinterpret_cast<uintptr_t>(j.lin[0]) | (uintptr_t)j.lin_stride[0]) & 15) == 0;
+        if (to_tiled) st16(til, ld16(lin, al), true);
+        else st16(lin, ld16(til, true), al);
+    } else {
+        const int plane = (r - 16) >> 3, row = (r - 16) & 7;
+        uint8_t *lin = mi355_global(j.lin[1 + plane]) + (size_t)(mb_y * 8 + row) * j.lin_stride[1] + mb_x * 8;
+        uint8_t *til = mi355_global(j.tiled[1]) + (size_t)mb_y * j.tiled_stride[1] + mb_x * MI355_TILE_CHROMA_BYTES + 8 * (r - 16);
+        const bool al = ((reinterpret_cast<uintptr_t>(j.lin[1]) | reinterpret_cast<uintptr_t>(j.lin[2]) | (uintptr_t)j.lin_stride[1]) & 7) == 0;
+        if (to_tiled) st8(til, ld8(lin, al), true);
+        else st8(lin, ld8(til, true), al);
+    }
+}
+}
+extern "C" int mi355_h264_surface_convert_dev(const mi355_surface_job *jobs, int n, int max_mb_width, int max_mb_height, void *stream)
+{
+    if (!mi355::bind() || !jobs || n <= 0 || max_mb_width <= 0 || max_mb_height <= 0) return -1;
+    const long long nmb = (long long)max_mb_width * max_mb_height;
+    if (nmb > 0x3FFFFFFF || n > 65535) return -3;
+    hipLaunchKernelGGL(k_surface_convert, dim3((unsigned)((nmb + 7) / 8), (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_event_sync(void *event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? 0 : -1; }

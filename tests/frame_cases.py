@@ -38,7 +38,7 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False):
+def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=False):
     fs = HF.synth_frames(**CASES[name])
     if sparse:
         # real P / B pictures: many inter macroblocks carry no residual at all (cbp 0) — about every other one here
@@ -49,7 +49,7 @@ def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False):
         fs.coef[pick] = 0
         assert pick.any() or not inter.any()
     recon_o, dst_o = HF.run_oracle(oracle, fs)
-    d = HF.DeviceFrames(backend, fs, pad=pad)
+    d = HF.DeviceFrames(backend, fs, pad=pad, tiled=tiled)
     try:
         if sparse:
             d.decode_sparse()
@@ -68,14 +68,14 @@ def smoke(gpu, oracle):
     assert run_case(gpu, oracle, "mixed_intra") > 0
 
 
-def run_mixed_batch(backend, oracle, names=("mixed_intra", "wide_b", "one_col", "tall_all_intra")):
+def run_mixed_batch(backend, oracle, names=("mixed_intra", "wide_b", "one_col", "tall_all_intra"), tiled=()):
     """pictures of DIFFERENT geometry in ONE call (what the bridge's dispatcher produces when streams of different size
     decode at the same time): the descriptors of several cases are concatenated on the device and go through
     mi355_h264_decode_frames_levels_dev with the largest width / height and the per-level maxima; every picture must
     come out as in its own single-geometry run (= the oracle's)."""
     import ctypes as C
     sets = [HF.synth_frames(**CASES[n]) for n in names]
-    devs = [HF.DeviceFrames(backend, fs) for fs in sets]
+    devs = [HF.DeviceFrames(backend, fs, tiled=n in tiled) for n, fs in zip(names, sets)]      # layouts may be mixed in one call
     lib = backend.lib
     try:
         fsz = C.sizeof(devs[0].host_desc) // devs[0].F
@@ -111,3 +111,81 @@ def run_mixed_batch(backend, oracle, names=("mixed_intra", "wide_b", "one_col", 
         for d in devs:
             d.free()
     return total
+
+
+def run_surface_convert(backend, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24, 512), (120, 68, 0, 0))):
+    """mi355_h264_surface_convert_dev against the numpy statement of the tiled layout (HF.tile_planes), both directions, several
+    pictures of different size in one launch; (mb_w, mb_h, linear pad, tile-row pad)"""
+    import ctypes as C
+    lib = backend.lib
+
+    class Job(C.Structure):
+        _fields_ = [("lin", C.c_void_p * 3), ("tiled", C.c_void_p * 2), ("lin_stride", C.c_int32 * 2), ("tiled_stride", C.c_int32 * 2),
+                    ("mb_width", C.c_int32), ("mb_height", C.c_int32), ("to_tiled", C.c_int32), ("reserved0", C.c_int32)]
+    assert C.sizeof(Job) == 72
+    lib.mi355_malloc.restype = C.c_void_p
+    lib.mi355_malloc.argtypes = [C.c_size_t]
+    lib.mi355_free.argtypes = [C.c_void_p]
+    lib.mi355_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    fn = lib.mi355_h264_surface_convert_dev
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(7)
+    bufs, jobs_fwd, jobs_back, meta = [], [], [], []
+
+    def dev(nbytes, init=None):
+        p = lib.mi355_malloc(nbytes)
+        assert p
+        bufs.append(p)
+        if init is not None:
+            init = np.ascontiguousarray(init)
+            assert lib.mi355_memcpy_h2d(p, init.ctypes.data, init.nbytes) == 0
+        return p
+    try:
+        for (mw, mh, lpad, tpad) in cases:
+            W, H = 16 * mw, 16 * mh
+            ys, cs = W + lpad, W // 2 + lpad // 2
+            lin = [np.zeros((H, ys), np.uint8), np.zeros((H // 2, cs), np.uint8), np.zeros((H // 2, cs), np.uint8)]
+            planes = [rng.integers(0, 256, (H, W), dtype=np.uint8), rng.integers(0, 256, (H // 2, W // 2), dtype=np.uint8),
+                      rng.integers(0, 256, (H // 2, W // 2), dtype=np.uint8)]
+            for a, b in zip(lin, planes):
+                a[:, :b.shape[1]] = b
+            d_lin = [dev(a.nbytes, a) for a in lin]
+            tys, tcs = mw * 256 + tpad, mw * 128 + tpad // 2
+            d_t = [dev(mh * tys, np.full(mh * tys, 0xA5, np.uint8)), dev(mh * tcs, np.full(mh * tcs, 0xA5, np.uint8))]
+            d_back = [dev(a.nbytes, np.full(a.shape, 0x5A, np.uint8)) for a in lin]
+            for to_tiled, lins, lst in ((1, d_lin, jobs_fwd), (0, d_back, jobs_back)):
+                j = Job()
+                for k in range(3):
+                    j.lin[k] = lins[k]
+                j.tiled[0], j.tiled[1] = d_t
+                j.lin_stride[0], j.lin_stride[1] = ys, cs
+                j.tiled_stride[0], j.tiled_stride[1] = tys, tcs
+                j.mb_width, j.mb_height, j.to_tiled = mw, mh, to_tiled
+                lst.append(j)
+            meta.append((mw, mh, ys, cs, tys, tcs, planes, d_t, d_back))
+        maxw, maxh = max(c[0] for c in cases), max(c[1] for c in cases)
+        for lst in (jobs_fwd, jobs_back):
+            arr = (Job * len(lst))(*lst)
+            d_jobs = dev(C.sizeof(arr))
+            assert lib.mi355_memcpy_h2d(d_jobs, C.addressof(arr), C.sizeof(arr)) == 0
+            assert fn(d_jobs, len(lst), maxw, maxh, None) == 0
+            assert lib.mi355_sync(None) == 0
+        for (mw, mh, ys, cs, tys, tcs, planes, d_t, d_back) in meta:
+            ty, tc = HF.tile_planes(*planes)
+            got_y, got_c = np.empty(mh * tys, np.uint8), np.empty(mh * tcs, np.uint8)
+            lib.mi355_memcpy_d2h(got_y.ctypes.data, d_t[0], got_y.nbytes)
+            lib.mi355_memcpy_d2h(got_c.ctypes.data, d_t[1], got_c.nbytes)
+            assert np.array_equal(got_y.reshape(mh, tys)[:, :mw * 256].reshape(-1), ty)
+            assert np.array_equal(got_c.reshape(mh, tcs)[:, :mw * 128].reshape(-1), tc)
+            assert (got_y.reshape(mh, tys)[:, mw * 256:] == 0xA5).all()          # padding untouched
+            for k, (st, pl) in enumerate(zip((ys, cs, cs), planes)):
+                back = np.empty((pl.shape[0], st), np.uint8)
+                lib.mi355_memcpy_d2h(back.ctypes.data, d_back[k], back.nbytes)
+                assert np.array_equal(back[:, :pl.shape[1]], pl)
+                assert (back[:, pl.shape[1]:] == 0x5A).all()
+    finally:
+        for p in bufs:
+            lib.mi355_free(p)
+    return len(cases)

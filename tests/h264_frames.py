@@ -37,10 +37,31 @@ class Frame(C.Structure):
                 ("mb", C.c_void_p), ("mv", C.c_void_p * 2), ("coef", C.c_void_p),
                 ("slices", C.c_void_p), ("nslices", C.c_int32), ("max_intra_level", C.c_int32),
                 ("intra_list", C.c_void_p), ("intra_level_start", C.c_void_p),
-                ("max_level_width", C.c_int32), ("reserved", C.c_int32)]
+                ("max_level_width", C.c_int32), ("reserved", C.c_int32),     # reserved = field_picture
+                ("surface_layout", C.c_int32), ("reserved0", C.c_int32)]
 
 
-assert C.sizeof(Frame) == 912
+assert C.sizeof(Frame) == 920
+
+
+def tile_planes(y, cb, cr):
+    """planes (H, W), (H/2, W/2) x 2 -> macroblock-tiled surfaces (include/mi355_h264_frame.h): luma tiles (256 B per
+    macroblock, raster order), chroma tiles (128 B per macroblock: 8 rows of Cb, 8 rows of Cr) as flat uint8 arrays"""
+    h, w = y.shape
+    mh, mw = h // 16, w // 16
+    ty = y.reshape(mh, 16, mw, 16).transpose(0, 2, 1, 3)
+    tc = np.concatenate([cb.reshape(mh, 8, mw, 8).transpose(0, 2, 1, 3), cr.reshape(mh, 8, mw, 8).transpose(0, 2, 1, 3)], axis=2)
+    return np.ascontiguousarray(ty).reshape(-1), np.ascontiguousarray(tc).reshape(-1)
+
+
+def untile_planes(ty, tc, mw, mh):
+    """inverse of tile_planes (leading batch dimensions are kept)"""
+    lead = ty.shape[:-1]
+    y = ty.reshape(lead + (mh, mw, 16, 16)).swapaxes(-3, -2).reshape(lead + (16 * mh, 16 * mw))
+    c = tc.reshape(lead + (mh, mw, 2, 8, 8))
+    cb = c[..., 0, :, :].swapaxes(-3, -2).reshape(lead + (8 * mh, 8 * mw))
+    cr = c[..., 1, :, :].swapaxes(-3, -2).reshape(lead + (8 * mh, 8 * mw))
+    return [y, cb, cr]
 
 # mb_type bits
 I4, I16, PCM, T16x16, T16x8, T8x16, T8x8 = 1, 2, 4, 8, 16, 32, 64
@@ -438,10 +459,12 @@ class DeviceFrames:
     `replicate` = total number of pictures F >= fs.F: picture f is a device-side copy of picture
     f % fs.F with its own buffers (bench.py: many independent streams from a few distinct ones)."""
 
-    def __init__(self, prov, fs, replicate=None, pad=0):
+    def __init__(self, prov, fs, replicate=None, pad=0, tiled=False):
         """pad: extra bytes per luma row (chroma rows get pad // 2): strides that are multiples of 4 but not of
-        16 / 8 take the kernels' narrow-access paths"""
-        self.lib, self.fs, self.pad = prov.lib, fs, pad
+        16 / 8 take the kernels' narrow-access paths.
+        tiled: dst / recon / reference surfaces in the macroblock-tiled layout (pad then = extra bytes per macroblock ROW of
+        luma tiles, a multiple of 256; chroma rows get half)"""
+        self.lib, self.fs, self.pad, self.tiled = prov.lib, fs, pad, tiled
         lib = self.lib
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -455,7 +478,12 @@ class DeviceFrames:
         nmb = fs.mb_w * fs.mb_h
         ys, cs = fs.W + pad, fs.W // 2 + pad // 2            # strides
         ysz, csz = fs.H * ys, (fs.H // 2) * cs
-        self.fsz = ysz + 2 * csz
+        if tiled:
+            assert pad % 256 == 0
+            ys, cs = fs.mb_w * 256 + pad, fs.mb_w * 128 + pad // 2   # bytes per macroblock row of tiles
+            ysz, csz = fs.mb_h * ys, 0                               # plane 1 (both chroma planes) follows plane 0
+            self.tys, self.tcs = ys, cs
+        self.fsz = ysz + 2 * csz if not tiled else ysz + fs.mb_h * cs
 
         def up_rep(a, per):
             """device array of F entries of `per` bytes; first G from the host, rest copied on the device"""
@@ -481,6 +509,11 @@ class DeviceFrames:
         for f in range(G):
             for s_ in range(fs.nrefs):
                 y, cb, cr = fs.refs[f][s_]
+                if tiled:
+                    ty, tc = tile_planes(y, cb, cr)
+                    refs_host[f, s_, :ysz].reshape(fs.mb_h, ys)[:, :fs.mb_w * 256] = ty.reshape(fs.mb_h, -1)
+                    refs_host[f, s_, ysz:].reshape(fs.mb_h, cs)[:, :fs.mb_w * 128] = tc.reshape(fs.mb_h, -1)
+                    continue
                 refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :fs.W] = y
                 refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cb
                 refs_host[f, s_, ysz + csz:].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cr
@@ -511,6 +544,7 @@ class DeviceFrames:
             fr.intra_list = ilist[g]          # read-only: shared between the copies
             fr.intra_level_start = istart[g]
             fr.max_level_width = fs.max_level_width
+            fr.surface_layout = 1 if tiled else 0
         self.host_desc = arr
         self.d_desc = self.alloc(C.sizeof(arr))
         self.lib.mi355_memcpy_h2d(self.d_desc, C.addressof(arr), C.sizeof(arr))
@@ -537,6 +571,11 @@ class DeviceFrames:
         raw = np.empty(n * self.fsz, np.uint8)
         self.lib.mi355_memcpy_d2h(raw.ctypes.data, base + first * self.fsz, raw.nbytes)
         raw = raw.reshape(n, self.fsz)
+        if self.tiled:
+            ysz = fs.mb_h * self.tys
+            ty = raw[:, :ysz].reshape(n, fs.mb_h, self.tys)[:, :, :fs.mb_w * 256].reshape(n, -1)
+            tc = raw[:, ysz:].reshape(n, fs.mb_h, self.tcs)[:, :, :fs.mb_w * 128].reshape(n, -1)
+            return untile_planes(ty, tc, fs.mb_w, fs.mb_h)
         ys, cs = fs.W + self.pad, fs.W // 2 + self.pad // 2
         ysz, csz = fs.H * ys, (fs.H // 2) * cs
         return [raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :fs.W], raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2],

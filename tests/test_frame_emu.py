@@ -83,3 +83,28 @@ def test_copy_batch_emulated(emu):
 def test_frame_pipeline_emulated_sparse_coefficients(emu, oracle, name):
     """mi355_h264_recon_inter_sparse_dev: same pictures, and the coefficient blocks of cbp-0 inter macroblocks are never read"""
     frame_cases.run_case(emu, oracle, name, sparse=True)
+
+
+@pytest.mark.parametrize("name", list(frame_cases.CASES))
+def test_frame_pipeline_emulated_tiled_surfaces(emu, oracle, name):
+    """the same pictures with dst / recon / reference surfaces in the macroblock-tiled layout (mi355_h264_frame.surface_layout)"""
+    frame_cases.run_case(emu, oracle, name, tiled=True)
+
+
+@pytest.mark.parametrize("name", ("mixed_intra", "wide_b"))
+def test_frame_pipeline_emulated_tiled_surfaces_padded_rows(emu, oracle, name):
+    frame_cases.run_case(emu, oracle, name, tiled=True, pad=512)
+
+
+@pytest.mark.parametrize("name", ("p16_smooth", "mixed_intra", "b_weight_implicit"))
+def test_frame_pipeline_emulated_tiled_sparse(emu, oracle, name):
+    frame_cases.run_case(emu, oracle, name, tiled=True, sparse=True)
+
+
+def test_mixed_layout_batch_emulated(emu, oracle):
+    """linear and tiled pictures of different geometry in one call"""
+    assert frame_cases.run_mixed_batch(emu, oracle, tiled=("wide_b", "tall_all_intra")) >= 4
+
+
+def test_surface_convert_emulated(emu):
+    assert frame_cases.run_surface_convert(emu, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24, 512))) == 3

@@ -86,3 +86,44 @@ def test_copy_batch_gpu(mi355):
 def test_frame_pipeline_gpu_sparse_coefficients(mi355, oracle, name):
     """mi355_h264_recon_inter_sparse_dev: same pictures, and the coefficient blocks of cbp-0 inter macroblocks are never read"""
     frame_cases.run_case(mi355, oracle, name, sparse=True)
+
+
+@pytest.mark.parametrize("name", list(frame_cases.CASES))
+def test_frame_pipeline_gpu_tiled_surfaces(mi355, oracle, name):
+    """the same pictures with dst / recon / reference surfaces in the macroblock-tiled layout (mi355_h264_frame.surface_layout)"""
+    frame_cases.run_case(mi355, oracle, name, tiled=True)
+
+
+@pytest.mark.parametrize("name", ("mixed_intra", "wide_b", "mid_b_weighted"))
+def test_frame_pipeline_gpu_tiled_surfaces_padded_rows(mi355, oracle, name):
+    frame_cases.run_case(mi355, oracle, name, tiled=True, pad=512)
+
+
+@pytest.mark.parametrize("name", ("p16_smooth", "mixed_intra", "b_weight_implicit", "mid_b_bigcoef"))
+def test_frame_pipeline_gpu_tiled_sparse(mi355, oracle, name):
+    frame_cases.run_case(mi355, oracle, name, tiled=True, sparse=True)
+
+
+def test_mixed_layout_batch_gpu(mi355, oracle):
+    """linear and tiled pictures of different geometry in one call"""
+    assert frame_cases.run_mixed_batch(mi355, oracle, tiled=("wide_b", "tall_all_intra")) >= 4
+
+
+def test_surface_convert_gpu(mi355):
+    assert frame_cases.run_surface_convert(mi355) == 4
+
+
+def test_full_size_1080p_batch_tiled_matches_oracle(mi355, oracle):
+    """BASELINE.json config 2 at its real size on macroblock-tiled surfaces (what bench.py times by default): three 1080p P
+    pictures of the bench generator, every sample of both surfaces against the oracle"""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x264, lib=mi355.lib)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs, tiled=True)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
