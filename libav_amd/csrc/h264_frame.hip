@@ -1787,7 +1787,7 @@ __global__ void __launch_bounds__(256) k_surface_convert(const mi355_surface_job
         else st16(lin, ld16(til, true), al);
     } else {
         const int plane = (r - 16) >> 3, row = (r - 16) & 7;
-        uint8_t *lin = mi355_global(j.lin[1 + plane]) + (size_t)(mb_y * 8 + row) * j.lin_stride[1] + mb_x * 8;
+        uint8_t *lin = mi355_global_v(plane ? j.lin[2] : j.lin[1]) + (size_t)(mb_y * 8 + row) * j.lin_stride[1] + mb_x * 8;      /* per lane: not mi355_global */
         uint8_t *til = mi355_global(j.tiled[1]) + (size_t)mb_y * j.tiled_stride[1] + mb_x * MI355_TILE_CHROMA_BYTES + 8 * (r - 16);
         const bool al = ((reinterpret_cast<uintptr_t>(j.lin[1]) | reinterpret_cast<uintptr_t>(j.lin[2]) | (uintptr_t)j.lin_stride[1]) & 7) == 0;
         if (to_tiled) st8(til, ld8(lin, al), true);

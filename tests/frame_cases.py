@@ -177,8 +177,10 @@ def run_surface_convert(backend, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24,
             got_y, got_c = np.empty(mh * tys, np.uint8), np.empty(mh * tcs, np.uint8)
             lib.mi355_memcpy_d2h(got_y.ctypes.data, d_t[0], got_y.nbytes)
             lib.mi355_memcpy_d2h(got_c.ctypes.data, d_t[1], got_c.nbytes)
-            assert np.array_equal(got_y.reshape(mh, tys)[:, :mw * 256].reshape(-1), ty)
-            assert np.array_equal(got_c.reshape(mh, tcs)[:, :mw * 128].reshape(-1), tc)
+            gy, gc = got_y.reshape(mh, tys)[:, :mw * 256].reshape(-1), got_c.reshape(mh, tcs)[:, :mw * 128].reshape(-1)
+            assert np.array_equal(gy, ty), "luma tiles differ (%d x %d, strides %d / %d): first at byte %d" % (mw, mh, ys, tys, int(np.argmax(gy != ty)))
+            assert np.array_equal(gc, tc), "chroma tiles differ (%d x %d, strides %d / %d): %d bytes, first at %d: %s" % (
+                mw, mh, cs, tcs, int((gc != tc).sum()), int(np.argmax(gc != tc)), np.flatnonzero(gc != tc)[:24].tolist())
             assert (got_y.reshape(mh, tys)[:, mw * 256:] == 0xA5).all()          # padding untouched
             for k, (st, pl) in enumerate(zip((ys, cs, cs), planes)):
                 back = np.empty((pl.shape[0], st), np.uint8)

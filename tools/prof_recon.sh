@@ -14,7 +14,7 @@ assert lib.mi355_init(0) == 0
 class P: pass
 prov = P(); prov.lib = lib
 fs = HF.synth_frames_fast(4, 120, 68, seed=0x264, lib=lib)
-dev = HF.DeviceFrames(prov, fs, replicate=F)
+dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=os.environ.get("LAYOUT", "tiled") == "tiled")
 lib.mi355_debug_rprof.argtypes = [C.c_void_p, C.c_int]
 out = (C.c_ulonglong * 16)()
 d = C.c_void_p(dev.d_desc)
