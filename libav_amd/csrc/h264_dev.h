@@ -157,13 +157,18 @@ __shared__ unsigned long long rprof_last;
 /* Reference windows are staged ALIGNED TO THE BLOCK: luma window byte b of row r is picture sample
  * (ix - 4 + b, iy - 2 + r), so block column 0 sits on a dword boundary and every 4-sample segment
  * of the block reads whole dwords; chroma window byte b of row r is sample (cx + b, cy + r). */
-constexpr int WY_DW = 6;                /* luma window row: 24 bytes = columns -4..19 of the block */
-constexpr int WC_DW = 3;                /* chroma window row: 12 bytes = columns 0..11 */
+constexpr int WY_DW = 12;               /* luma window row pitch in dwords: the window itself is 6 dwords (24 bytes = columns -4..19 of the
+                                           block); the rest of a row takes the surplus of stage_windows_tiled's whole-piece writes */
+constexpr int WC_DW = 4;                /* chroma window row pitch: the window is 3 dwords (columns 0..11) */
+constexpr int WY_PAD = 10, WC_PAD = 4;  /* dwords in front of row 0 that those writes may reach */
 struct __attribute__((aligned(8))) McScratch {
+    uint32_t padY[WY_PAD];
     uint32_t winY[21 * WY_DW];          /* up to 21 rows (16 + 5) */
-    uint32_t winC[2][9 * WC_DW];
+    uint32_t padC[WC_PAD];
+    uint32_t winC[2][9 * WC_DW + WC_PAD];   /* the tail of plane 0 is the front pad of plane 1 */
     int16_t tmp[21 * 16];               /* unclipped horizontal 6-tap sums for the centre position */
 };
+static_assert(offsetof(McScratch, winY) % 8 == 0 && offsetof(McScratch, winC) % 8 == 0 && (WY_DW % 2) == 0, "8-byte stores into the windows");
 
 #ifdef MI355_HIP_EMU_H
 static inline uint32_t mi355_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (s & 3))); }
@@ -311,7 +316,7 @@ struct Win16 {
 };
 __device__ __forceinline__ bool win16_inside(const PlaneRef &y, int ix, int iy, const PlaneRef &cb, int cx, int cy)
 {
-    return win_inside(y, ix - 4, iy - 2, WY_DW, 21) && win_inside(cb, cx, cy, WC_DW, 9);
+    return win_inside(y, ix - 4, iy - 2, 6, 21) && win_inside(cb, cx, cy, 3, 9);
 }
 __device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, int iy, const PlaneRef &cb, const PlaneRef &cr, int cx, int cy)
 {
@@ -330,82 +335,94 @@ __device__ inline void stage_windows16(McScratch &s, const PlaneRef &y, int ix, 
 /* ---- reference windows from MACROBLOCK-TILED surfaces (mi355_h264_frame.surface_layout == MI355_SURFACE_TILED) ------------
  * Luma macroblock (x, y) = 256 bytes at y * ypitch + x * 256 (16 rows of 16), chroma macroblock = 128 bytes at
  * y * cpitch + x * 128 (8 rows of 8 Cb, then 8 rows of 8 Cr).  The (bh + 5) x (bw + 5) luma window spans at most three tiles
- * in a row: it is fetched as 16-byte row pieces — lane (piece p, row r) one global_load_dwordx4, four neighbouring lanes
- * four consecutive rows of one tile = 64 contiguous bytes, the whole window 6-12 cache lines instead of one (or two) per
- * row — into `raw`, 48 bytes per row starting at picture column xb (a multiple of 16).  Rows clamp to the picture by
- * clamping the row number of the address (emulated_edge_mc's vertical replication, videodsp_template.c:24-96, for free);
- * columns are replicated in the second step: raw -> the block-aligned windows of McScratch that the filters read (dword
- * reads + v_alignbyte when every column the filters use lies inside the picture, per sample with clamped column otherwise).
- * The two chroma windows the same way: 8-byte pieces, two per row and plane. */
+ * in a row: it is fetched as 16-byte row pieces — lane 3 r + p piece p of row r, one global_load_dwordx4 each, the whole
+ * window 6-12 cache lines instead of one (or two) per row.  Rows clamp to the picture by clamping the row number of the
+ * address (emulated_edge_mc's vertical replication, videodsp_template.c:24-96, for free).
+ *
+ * A lane turns its piece straight into the four dwords of the block-aligned window it covers: with o = the window's first
+ * column - the first column fetched (xb, a multiple of 16), byte shift o & 3, the lane funnel-shifts its four dwords and the
+ * first dword of the NEXT piece — the neighbouring lane's, one DPP move — and writes them to window dwords 4 p - (o >> 2) ..
+ * + 3 of its row.  The three lanes of a row write twelve consecutive dwords of which the window is six: rows are 12 dwords
+ * apart (WY_DW) and the surplus lands in the gap behind the previous row's window or in front of the next one's (WY_PAD in
+ * front of row 0).  No second pass, no predication.  The two chroma windows the same way: 8-byte pieces, two per row and
+ * plane (lane 18 plane + 2 row + piece), rows 4 dwords apart.
+ *
+ * A window that reaches over the left or right picture border (columns are replicated there) takes the per-sample path with
+ * clamped coordinates: the macroblocks at the picture's sides whose vectors point outwards. */
 struct TiledRef {
     const uint8_t *y, *c;
     int ypitch, cpitch;          /* bytes per macroblock row of tiles */
     int mbw, mbh;
 };
-struct __attribute__((aligned(16))) McRaw {
-    uint32_t pre[4];             /* the dword in front of row 0 is read (never used) when the window starts 1-2 columns left of xb */
-    uint8_t y[21 * 48];
-    uint8_t c[2][9 * 16];
-    uint32_t post[4];            /* ... and the dword behind the last row */
-};
 typedef uint32_t mi355_raw_u32x4 __attribute__((vector_size(16)));
 typedef uint32_t mi355_raw_u32x2 __attribute__((vector_size(8)));
-__device__ inline void stage_windows_tiled(McScratch &s, McRaw &raw, const TiledRef &t, int ix, int iy, int bw, int bh,
-                                           int cx, int cy, int cw, int ch)
+typedef uint32_t mi355_raw_u32x2a4 __attribute__((vector_size(8), aligned(4)));
+/* the value the next lane holds (lane 63: unspecified) */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t lane_next(uint32_t v) { return (uint32_t)__shfl_down((int)v, 1); }
+#else
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   /* wave_shl:1 */
+#endif
+__device__ inline void stage_windows_tiled(McScratch &s, const TiledRef &t, int ix, int iy, int bw, int bh, int cx, int cy, int cw, int ch)
 {
     const int lane = lane_id();
     const int wpix = 16 * t.mbw, hpix = 16 * t.mbh, wc = 8 * t.mbw, hc = 8 * t.mbh;
     const int rows = bh + 5, crows = ch + 1;
-    /* ---- loads: everything in flight before the first LDS write ---- */
-    const int xb = clip3((ix - 2) & ~15, 0, imax(0, 16 * (t.mbw - 3)));
-    const int L = lane < 63 ? lane : 62;
-    const int p = (int)(__umul24((unsigned)L, 49u) >> 10), r = L - 21 * p;          /* L / 21, L % 21 */
-    const int y = clip3(iy - 2 + imin(r, rows - 1), 0, hpix - 1);
-    const int tx = imin((xb >> 4) + p, t.mbw - 1);
-    const mi355_raw_u32x4 vy = *reinterpret_cast<const mi355_raw_u32x4 *>(t.y + (uint32_t)(__mul24(y >> 4, t.ypitch) + tx * 256 + (y & 15) * 16));
-    const int xc = clip3(cx & ~7, 0, imax(0, 8 * (t.mbw - 2)));
-    const int U = lane < 36 ? lane : 35;
-    const int plane = U >= 18, rem = U - 18 * plane, piece = rem >= 9, crow = rem - 9 * piece;
-    const int yc = clip3(cy + imin(crow, crows - 1), 0, hc - 1);
-    const int txc = imin((xc >> 3) + piece, t.mbw - 1);
-    const mi355_raw_u32x2 vc = *reinterpret_cast<const mi355_raw_u32x2 *>(t.c + (uint32_t)(__mul24(yc >> 3, t.cpitch) + txc * 128 + plane * 64 + (yc & 7) * 8));
-    MI355_ISSUE_FENCE();
-    *reinterpret_cast<mi355_raw_u32x4 *>(raw.y + r * 48 + p * 16) = vy;
-    *reinterpret_cast<mi355_raw_u32x2 *>(raw.c[plane] + crow * 16 + piece * 8) = vc;
-    MI355_WAVE_SYNC();
-    /* ---- raw -> block-aligned windows ---- */
+    if (ix - 4 >= 0 && ix + bw + 2 <= wpix - 1 && cx >= 0 && cx + cw <= wc - 1) {
+        /* ---- loads: everything in flight before the first LDS write ---- */
+        const int xb = imin((ix - 4) & ~15, imax(0, 16 * (t.mbw - 3)));
+        const int o = ix - 4 - xb;                                                     /* 0 .. 37 */
+        const int L = lane < 63 ? lane : 62;
+        const int r = (int)(__umul24((unsigned)L, 43u) >> 7), p = L - 3 * r;          /* L / 3, L % 3 */
+        const int y = clip3(iy - 2 + imin(r, rows - 1), 0, hpix - 1);
+        const int tx = imin((xb >> 4) + p, t.mbw - 1);
+        const mi355_raw_u32x4 vy = *reinterpret_cast<const mi355_raw_u32x4 *>(t.y + (uint32_t)(__mul24(y >> 4, t.ypitch) + tx * 256 + (y & 15) * 16));
+        const int xc = imin(cx & ~7, imax(0, 8 * (t.mbw - 2)));
+        const int oc = cx - xc;                                                        /* 0 .. 13 */
+        const int U = lane < 36 ? lane : 35;
+        const int plane = U >= 18, rem = U - 18 * plane, crow = rem >> 1, piece = rem & 1;
+        const int yc = clip3(cy + imin(crow, crows - 1), 0, hc - 1);
+        const int txc = imin((xc >> 3) + piece, t.mbw - 1);
+        const mi355_raw_u32x2 vc = *reinterpret_cast<const mi355_raw_u32x2 *>(t.c + (uint32_t)(__mul24(yc >> 3, t.cpitch) + txc * 128 + plane * 64 + (yc & 7) * 8));
+        MI355_ISSUE_FENCE();
+        /* ---- piece -> window dwords ---- */
+        const uint32_t sy = (uint32_t)o & 3u, sc = (uint32_t)oc & 3u;
+        const uint32_t ny = lane_next(vy[0]), nc = lane_next(vc[0]);
+        uint32_t *wy = s.winY + (__mul24(r, WY_DW) + 4 * p - (o >> 2));
+        *reinterpret_cast<mi355_raw_u32x2a4 *>(wy) = mi355_raw_u32x2a4{ mi355_alignbyte(vy[1], vy[0], sy), mi355_alignbyte(vy[2], vy[1], sy) };
+        *reinterpret_cast<mi355_raw_u32x2a4 *>(wy + 2) = mi355_raw_u32x2a4{ mi355_alignbyte(vy[3], vy[2], sy), mi355_alignbyte(ny, vy[3], sy) };
+        uint32_t *wcp = s.winC[0] + (__mul24(plane, 9 * WC_DW + WC_PAD) + crow * WC_DW + 2 * piece - (oc >> 2));
+        *reinterpret_cast<mi355_raw_u32x2a4 *>(wcp) = mi355_raw_u32x2a4{ mi355_alignbyte(vc[1], vc[0], sc), mi355_alignbyte(nc, vc[1], sc) };
+        MI355_WAVE_SYNC();
+        return;
+    }
+    /* ---- per sample, coordinates clamped to the picture ---- */
     {
         const int ydw = luma_win_dw(bw), n = rows * ydw, inv = mi355_inv20(ydw);
-        const bool inside = ix - 2 >= 0 && ix + bw + 2 <= wpix - 1;
-        const int o0 = ix - 4 - xb;
         for (int i = lane; i < n; i += 64) {
-            const int row = mi355_div20(i, inv), k = i - row * ydw, o = o0 + 4 * k;
-            uint32_t v;
-            if (inside) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(raw.y + row * 48) + (o >> 2);
-                v = mi355_alignbyte(q[1], q[0], (uint32_t)o & 3u);
-            } else {
-                v = 0;
+            const int row = mi355_div20(i, inv), k = i - row * ydw;
+            const int y = clip3(iy - 2 + row, 0, hpix - 1);
+            const uint8_t *rp = t.y + (uint32_t)(__mul24(y >> 4, t.ypitch) + (y & 15) * 16);
+            uint32_t v = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++) v |= (uint32_t)raw.y[row * 48 + clip3(ix - 4 + 4 * k + b, 0, wpix - 1) - xb] << (8 * b);
+            for (int b = 0; b < 4; b++) {
+                const int x = clip3(ix - 4 + 4 * k + b, 0, wpix - 1);
+                v |= (uint32_t)rp[(x >> 4) * 256 + (x & 15)] << (8 * b);
             }
             s.winY[row * WY_DW + k] = v;
         }
     }
     {
         const int cdw = chroma_win_dw(cw), per = crows * cdw, n = 2 * per, inv = mi355_inv20(cdw);
-        const bool inside = cx >= 0 && cx + cw <= wc - 1;
-        const int o0 = cx - xc;
         for (int i = lane; i < n; i += 64) {
-            const int pl = i >= per, j = i - pl * per, row = mi355_div20(j, inv), k = j - row * cdw, o = o0 + 4 * k;
-            uint32_t v;
-            if (inside) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(raw.c[pl] + row * 16) + (o >> 2);
-                v = mi355_alignbyte(q[1], q[0], (uint32_t)o & 3u);
-            } else {
-                v = 0;
+            const int pl = i >= per, j = i - pl * per, row = mi355_div20(j, inv), k = j - row * cdw;
+            const int y = clip3(cy + row, 0, hc - 1);
+            const uint8_t *rp = t.c + (uint32_t)(__mul24(y >> 3, t.cpitch) + pl * 64 + (y & 7) * 8);
+            uint32_t v = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++) v |= (uint32_t)raw.c[pl][row * 16 + clip3(cx + 4 * k + b, 0, wc - 1) - xc] << (8 * b);
+            for (int b = 0; b < 4; b++) {
+                const int x = clip3(cx + 4 * k + b, 0, wc - 1);
+                v |= (uint32_t)rp[(x >> 3) * 128 + (x & 7)] << (8 * b);
             }
             s.winC[pl][row * WC_DW + k] = v;
         }

@@ -46,7 +46,6 @@ struct __attribute__((aligned(16))) MbLds {
     uint8_t exp_pad[MI355_EXP_LDS_PAD];
 #endif
     McScratch mc;
-    McRaw raw;                                /* tiled surfaces: the reference windows as fetched (stage_windows_tiled) */
 };
 
 __device__ __forceinline__ int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 1); }
@@ -172,7 +171,7 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
     if (TILED) {
         const TiledRef tr{mi355_global(rp[0]), mi355_global(rp[1]), fr.ref_stride[0], fr.ref_stride[1], fr.mb_width, fr.mb_height};
 #ifndef MI355_EXP_NO_STAGE
-        stage_windows_tiled(s.mc, s.raw, tr, mx >> 2, my >> 2, w, h, mx >> 3, myc >> 3, w >> 1, h >> 1);
+        stage_windows_tiled(s.mc, tr, mx >> 2, my >> 2, w, h, mx >> 3, myc >> 3, w >> 1, h >> 1);
 #endif
         RPROF(3);
 #ifndef MI355_EXP_NO_LUMA
