@@ -34,6 +34,16 @@
  * The decoded picture buffer lives in HBM: one device picture per H264Picture the decoder uses, found again through the
  * reference lists' parent pointers; reference samples never cross PCIe.  Two staging sets per stream alternate, so the
  * host can pack picture n + 1 while the copies and kernels of picture n run.
+ * Sequences of frame pictures only (frame_mbs_only_flag, 4:2:0) keep their device pictures MACROBLOCK-TILED
+ * (mi355_h264_frame.h, MI355_SURFACE_TILED: a macroblock is a run of whole cache lines for the reference fetch, the
+ * reconstruction stores and the loop filter); a picture is turned back into lines by the launch that brings it to the
+ * pinned buffer (mi355_h264_surface_convert_dev instead of a plain copy).  MI355_BRIDGE_LINEAR=1, sequences that may hold
+ * field pictures and 4:4:4 keep planes with line strides.
+ *
+ * Threads: ONE decoder context per thread and no threading INSIDE a decoder (avctx->thread_count = 1): the bridge finds
+ * its state per thread and its references per context — with frame threads a reference decoded by another thread would
+ * be read from a host frame that is not complete yet, with slice threads one picture would be packed by several threads.
+ * A decoder opened with either kind of threading is left to the reference's C path.
  *
  * 4:4:4 streams (hl_decode_mb_444, h264_mb_template.c:259-345: every plane is decoded like luma — luma interpolation,
  * luma intra modes, luma transforms, the luma loop filter with the plane's own QP) are submitted as THREE passes per
@@ -76,7 +86,7 @@ struct Staging;
 
 typedef struct DevPic {
     const H264Picture *owner;
-    uint8_t *plane[3];          /* one allocation, planes back to back */
+    uint8_t *plane[3];          /* one allocation, planes back to back (tiled: luma tiles, chroma tiles; [2] unused) */
     int frame_num, poc;         /* what the owner held when this copy was made: the decoder recycles its H264Picture entries, */
     const uint8_t *data0;       /* and a frame it made up for a frame_num gap can sit where an older picture of ours sat */
 } DevPic;
@@ -104,8 +114,10 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
     int32_t *istart;
     int32_t *widths;            /* host only: macroblocks per intra level */
     int maxl;
-    uint8_t *out;               /* pinned: the decoded picture as it comes back (device strides, planes back to back) */
+    uint8_t *out;               /* pinned: the decoded picture as it comes back (planes with line strides, back to back) */
     DevPic *pic;                /* the picture this set was submitted for */
+    int field, parity;          /* it was a field picture: only the lines of its parity go to the frame */
+    mi355_surface_job *cvt;     /* pinned, direct mode with tiled device pictures: the conversion job of the copy-back */
     uint8_t *frame_data[3];     /* where it goes: the AVFrame the decoder will hand out */
     int frame_linesize[3];
     mi355_h264_frame *d_desc;   /* direct mode: the descriptors on the device */
@@ -128,8 +140,11 @@ typedef struct Bridge {
     int c444, npass;            /* 4:4:4: three passes (planes) per picture */
     uint8_t *recon[3];          /* unfiltered reconstruction: Y, Cb, Cr (4:4:4: three full-size planes) */
     uint8_t *scratch_c[2];      /* 4:4:4: what the passes use as chroma planes (never looked at) */
-    int stride[2];
-    size_t plane_bytes[2];      /* luma plane, 4:2:0 chroma plane */
+    int stride[2];              /* device surfaces: bytes per line, or per macroblock row of tiles */
+    size_t plane_bytes[2];      /* device surfaces: luma plane, 4:2:0 chroma plane (tiled: the one plane of Cb + Cr tiles) */
+    int tiled;                  /* device pictures are macroblock-tiled (frame-only 4:2:0 sequences) */
+    int lin_stride[2];          /* the pinned picture buffer `out`: bytes per line */
+    size_t lin_bytes[2];
     /* per picture */
     int nslices, slice_num_of[BR_MAX_SLICES], uses_l1;
     int mbs_packed;             /* macroblocks the decoder delivered for the picture being packed */
@@ -153,7 +168,19 @@ static void br_fail(Bridge *b, const char *what)
 static void *dalloc(size_t n) { return mi355_malloc(n); }
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-static size_t picture_bytes(const Bridge *b) { return b->c444 ? 3 * b->plane_bytes[0] : b->plane_bytes[0] + 2 * b->plane_bytes[1]; }
+static size_t picture_bytes(const Bridge *b) { return b->c444 ? 3 * b->plane_bytes[0] : b->plane_bytes[0] + (b->tiled ? 1 : 2) * b->plane_bytes[1]; }
+static size_t out_bytes(const Bridge *b) { return b->c444 ? 3 * b->lin_bytes[0] : b->lin_bytes[0] + 2 * b->lin_bytes[1]; }
+/* the job that turns device picture `pic` into the lines of the pinned buffer `out` */
+static void convert_job(const Bridge *b, const DevPic *pic, uint8_t *out, mi355_surface_job *j)
+{
+    memset(j, 0, sizeof(*j));
+    j->lin[0] = out; j->lin[1] = out + b->lin_bytes[0]; j->lin[2] = j->lin[1] + b->lin_bytes[1];
+    j->tiled[0] = pic->plane[0]; j->tiled[1] = pic->plane[1];
+    j->lin_stride[0] = b->lin_stride[0]; j->lin_stride[1] = b->lin_stride[1];
+    j->tiled_stride[0] = b->stride[0]; j->tiled_stride[1] = b->stride[1];
+    j->mb_width = b->mb_w; j->mb_height = b->mb_h;
+    j->to_tiled = 0;
+}
 
 static int staging_alloc(Bridge *b, Staging *s)
 {
@@ -175,9 +202,9 @@ static int staging_alloc(Bridge *b, Staging *s)
     s->size = o;
     s->host = mi355_host_alloc(s->size);
     s->widths = malloc(nlev * 4);
-    s->out = mi355_host_alloc(picture_bytes(b));
-    if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(2 * BR_MAX_PASSES * sizeof(mi355_h264_frame)); }
-    if (!s->host || !s->widths || !s->out || (b->direct && (!s->done || !s->d_desc))) return 0;
+    s->out = mi355_host_alloc(out_bytes(b));
+    if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(2 * BR_MAX_PASSES * sizeof(mi355_h264_frame)); s->cvt = mi355_host_alloc(sizeof(mi355_surface_job)); }
+    if (!s->host || !s->widths || !s->out || (b->direct && (!s->done || !s->d_desc || !s->cvt))) return 0;
     memset(s->host, 0, s->size);
     s->desc = (mi355_h264_frame *)(s->host + o_desc);
     for (int p = 0; p < np; p++) {
@@ -203,7 +230,8 @@ static struct {
     Submission *head, *tail;
     void *stream[DISP_DEPTH], *ev[DISP_DEPTH];
     mi355_h264_frame *h_desc[DISP_DEPTH], *d_desc[DISP_DEPTH];
-    mi355_copy_job *jobs[DISP_DEPTH];       /* device-visible */
+    mi355_copy_job *jobs[DISP_DEPTH];       /* device-visible: pictures that come back as they are */
+    mi355_surface_job *cvt[DISP_DEPTH];     /* device-visible: tiled pictures that come back as lines */
     Submission *in[DISP_DEPTH][DISP_MAX_BATCH];
     int nin[DISP_DEPTH], rcs[DISP_DEPTH];
     int nbridges, nqueued;                  /* decoders that submit here; pictures waiting in the queue */
@@ -222,7 +250,7 @@ static int disp_enqueue(int slot)
 {
     const int n = disp.nin[slot];
     void *st = disp.stream[slot];
-    int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0;
+    int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0, ncopy = 0, ncvt = 0, cw = 0, chh = 0;
     size_t max_bytes = 0;
     for (int i = 0; i < n; i++) nd += disp.in[slot][i]->b->npass;
     mi355_h264_frame *hr = disp.h_desc[slot], *hd = disp.h_desc[slot] + nd;      /* reconstruction | loop filter */
@@ -238,15 +266,23 @@ static int disp_enqueue(int slot)
             if (l >= maxl || s->widths[l] > disp.widths[l]) disp.widths[l] = s->widths[l];
         if (s->maxl > maxl) maxl = s->maxl;
         for (int p = 0; p < b->npass; p++, k++) { hr[k] = s->desc[p]; hd[k] = s->desc[b->npass + p]; }
-        disp.jobs[slot][i].src = s->pic->plane[0]; disp.jobs[slot][i].dst = s->out; disp.jobs[slot][i].bytes = bytes;
-        if (bytes > max_bytes) max_bytes = bytes;
+        if (b->tiled) {
+            convert_job(b, s->pic, s->out, &disp.cvt[slot][ncvt++]);
+            if (b->mb_w > cw) cw = b->mb_w;
+            if (b->mb_h > chh) chh = b->mb_h;
+        } else {
+            disp.jobs[slot][ncopy].src = s->pic->plane[0]; disp.jobs[slot][ncopy].dst = s->out; disp.jobs[slot][ncopy].bytes = bytes;
+            ncopy++;
+            if (bytes > max_bytes) max_bytes = bytes;
+        }
     }
     mi355_h264_frame *dr = disp.d_desc[slot], *dd = disp.d_desc[slot] + nd;
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
     if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, st) != 0) rc = -1;
-    if (!rc && mi355_copy_batch_dev(disp.jobs[slot], n, max_bytes, st) != 0) rc = -1;
+    if (!rc && ncopy && mi355_copy_batch_dev(disp.jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
+    if (!rc && ncvt && mi355_h264_surface_convert_dev(disp.cvt[slot], ncvt, cw, chh, st) != 0) rc = -1;
     rc |= mi355_event_record(disp.ev[slot], st);
     return rc;
 }
@@ -328,7 +364,8 @@ static int disp_start(void)
             disp.h_desc[k] = mi355_host_alloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
             disp.d_desc[k] = dalloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
             disp.jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
-            ok = disp.stream[k] && disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k];
+            disp.cvt[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_surface_job));
+            ok = disp.stream[k] && disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k] && disp.cvt[k];
         }
         if (ok && pthread_create(&disp.thread, NULL, disp_main, NULL) == 0 && pthread_create(&disp.completer, NULL, disp_complete, NULL) == 0) {
             pthread_detach(disp.thread); pthread_detach(disp.completer);
@@ -341,6 +378,12 @@ static int disp_start(void)
 }
 
 static int finish_set(Bridge *b, Staging *s);
+/* both sets, the older submission first: the two fields of a frame go to the same AVFrame */
+static int finish_all(Bridge *b)
+{
+    const int r0 = finish_set(b, &b->st[b->cur ^ 1]), r1 = finish_set(b, &b->st[b->cur]);
+    return r0 ? r0 : r1;
+}
 static void staging_free(Staging *s)
 {
     if (s->host) mi355_host_free(s->host);
@@ -348,6 +391,7 @@ static void staging_free(Staging *s)
     if (s->out) mi355_host_free(s->out);
     if (s->done) mi355_event_destroy(s->done);
     if (s->d_desc) mi355_free(s->d_desc);
+    if (s->cvt) mi355_host_free(s->cvt);
     memset(s, 0, sizeof(*s));
 }
 /* give back everything that depends on the picture geometry (what is in flight comes back first): the next sequence sets
@@ -355,7 +399,7 @@ static void staging_free(Staging *s)
 static void bridge_release(Bridge *b)
 {
     if (b->state > 0) {
-        finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+        finish_all(b);
         if (!b->direct) { pthread_mutex_lock(&disp.mu); disp.nbridges--; pthread_mutex_unlock(&disp.mu); }
     }
     staging_free(&b->st[0]); staging_free(&b->st[1]);
@@ -375,12 +419,13 @@ void __wrap_ff_h264_flush_change(H264Context *h)
 {
     Bridge *b = br_tls;
     if (b && b->state > 0) {
-        finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+        finish_all(b);
         b->open = 0;
         const SPS *sps = h->ps.sps;
         const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == 8 &&
                          (sps->chroma_format_idc == 3) == b->c444 && (sps->chroma_format_idc == 1 || sps->chroma_format_idc == 3) &&
-                         !sps->transform_bypass && !sps->residual_color_transform_flag;
+                         !sps->transform_bypass && !sps->residual_color_transform_flag &&
+                         (!b->tiled || sps->frame_mbs_only_flag);        /* tiled device pictures hold frames only */
         if (!same) { bridge_release(b); b->state = 0; }
     } else if (b && b->state < 0 && b->soft) {
         b->state = 0; b->soft = 0;
@@ -409,6 +454,12 @@ static Bridge *bridge_get(const H264Context *h)
         b->soft = 1;
         return b;
     }
+    /* one decoder context per thread, no threads inside it (see the header comment) */
+    if (h->avctx->active_thread_type || h->nb_slice_ctx > 1) {
+        br_fail(b, "decoder opened with frame or slice threads (the bridge needs thread_count = 1 per decoder; run one decoder per stream and thread)");
+        b->soft = 1;
+        return b;
+    }
     const char *dev = getenv("MI355_DEVICE");
     if (mi355_init(dev ? atoi(dev) : 0) != 0) { br_fail(b, "no usable MI355X"); return b; }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
@@ -416,8 +467,16 @@ static Bridge *bridge_get(const H264Context *h)
     /* frame_num gaps: the decoder fills a lost frame with a host-side copy of the previous one (h264_slice.c:1425-1452) — every
      * picture must be complete in its frame before the next one starts */
     b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL && !h->ps.sps->gaps_in_frame_num_allowed_flag;
-    b->stride[0] = (16 * b->mb_w + 63) & ~63; b->stride[1] = b->stride[0] / 2;
-    b->plane_bytes[0] = (size_t)b->stride[0] * 16 * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * 8 * b->mb_h;
+    b->lin_stride[0] = (16 * b->mb_w + 63) & ~63; b->lin_stride[1] = b->lin_stride[0] / 2;
+    b->lin_bytes[0] = (size_t)b->lin_stride[0] * 16 * b->mb_h; b->lin_bytes[1] = (size_t)b->lin_stride[1] * 8 * b->mb_h;
+    b->tiled = h->ps.sps->frame_mbs_only_flag && !b->c444 && !getenv("MI355_BRIDGE_LINEAR");
+    if (b->tiled) {
+        b->stride[0] = MI355_TILE_LUMA_BYTES * b->mb_w; b->stride[1] = MI355_TILE_CHROMA_BYTES * b->mb_w;
+        b->plane_bytes[0] = (size_t)b->stride[0] * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * b->mb_h;
+    } else {
+        b->stride[0] = b->lin_stride[0]; b->stride[1] = b->lin_stride[1];
+        b->plane_bytes[0] = b->lin_bytes[0]; b->plane_bytes[1] = b->lin_bytes[1];
+    }
     int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
     if (ok && b->direct) ok = (b->stream = mi355_stream_create()) != NULL;
     if (ok && !b->direct) ok = disp_start();
@@ -449,7 +508,7 @@ static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, 
         uint8_t *base = dalloc(picture_bytes(b));
         if (!base) return NULL;
         const size_t cb = b->c444 ? b->plane_bytes[0] : b->plane_bytes[1];
-        slot->plane[0] = base; slot->plane[1] = base + b->plane_bytes[0]; slot->plane[2] = slot->plane[1] + cb;
+        slot->plane[0] = base; slot->plane[1] = base + b->plane_bytes[0]; slot->plane[2] = b->tiled ? slot->plane[1] : slot->plane[1] + cb;
     }
     slot->owner = p;
     return slot;
@@ -466,6 +525,17 @@ static DevPic *devpic_upload(Bridge *b, const H264Context *h, const H264Picture 
     uint8_t *tmp = malloc(picture_bytes(b));
     if (!tmp) { r->owner = NULL; return NULL; }
     uint8_t *dst = tmp;
+    if (b->tiled) {
+        /* lines -> macroblock tiles (mi355_h264_frame.h): 16 rows of 16 luma samples, then per macroblock 8 rows of 8 Cb, 8 rows of 8 Cr */
+        for (int my = 0; my < b->mb_h; my++)
+            for (int mx = 0; mx < b->mb_w; mx++) {
+                uint8_t *ty = tmp + (size_t)my * b->stride[0] + (size_t)mx * MI355_TILE_LUMA_BYTES;
+                uint8_t *tc = tmp + b->plane_bytes[0] + (size_t)my * b->stride[1] + (size_t)mx * MI355_TILE_CHROMA_BYTES;
+                for (int y = 0; y < 16; y++) memcpy(ty + 16 * y, p->f->data[0] + (size_t)(16 * my + y) * p->f->linesize[0] + 16 * mx, 16);
+                for (int k = 1; k < 3; k++)
+                    for (int y = 0; y < 8; y++) memcpy(tc + 64 * (k - 1) + 8 * y, p->f->data[k] + (size_t)(8 * my + y) * p->f->linesize[k] + 8 * mx, 8);
+            }
+    } else
     for (int k = 0; k < 3; k++) {
         const int half = k && !b->c444;
         const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->stride[half];
@@ -504,12 +574,14 @@ static int finish_set(Bridge *b, Staging *s)
     }
     s->in_flight = 0;
     if (rc) return rc;
+    /* a field picture brings its own lines only: the frame's other field may have come back (or will come back) from another set */
     const uint8_t *src = s->out;
+    const int y0 = s->field ? s->parity : 0, dy = s->field ? 2 : 1;
     for (int k = 0; k < 3; k++) {
         const int half = k && !b->c444;
-        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->stride[half];
-        for (int y = 0; y < hgt; y++) memcpy(s->frame_data[k] + (size_t)y * s->frame_linesize[k], src + (size_t)y * st, (size_t)w);
-        src += b->plane_bytes[half];
+        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->lin_stride[half];
+        for (int y = y0; y < hgt; y += dy) memcpy(s->frame_data[k] + (size_t)y * s->frame_linesize[k], src + (size_t)y * st, (size_t)w);
+        src += b->lin_bytes[half];
     }
     return 0;
 }
@@ -771,6 +843,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         const int fs = b->field ? 2 : 1;
         f->mb_width = b->mb_w; f->mb_height = b->rows;
         f->field_picture = b->field;
+        f->surface_layout = b->tiled ? MI355_SURFACE_TILED : MI355_SURFACE_LINEAR;
         f->dst_stride[0] = fs * b->stride[0]; f->recon_stride[0] = b->stride[0];
         f->dst_stride[1] = fs * b->stride[1]; f->recon_stride[1] = b->stride[1];
         const size_t fo[2] = { b->field && b->parity ? (size_t)b->stride[0] : 0, b->field && b->parity ? (size_t)b->stride[1] : 0 };
@@ -797,6 +870,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         s->desc[np + p].mb = s->mbd[p];
     }
     s->pic = cur;
+    s->field = b->field; s->parity = b->parity;
     /* the finished picture goes to the frame the decoder hands out (coded size; the reference crops on output) */
     const AVFrame *fr = h->cur_pic_ptr->f;
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
@@ -805,7 +879,10 @@ static int submit_picture(Bridge *b, H264Context *h)
         if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
             mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
             mi355_h264_deblock_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->stream) != 0) return -4;
-        if (mi355_memcpy_d2h_async(s->out, cur->plane[0], picture_bytes(b), b->stream)) return -5;
+        if (b->tiled) {
+            convert_job(b, cur, s->out, s->cvt);
+            if (mi355_h264_surface_convert_dev(s->cvt, 1, b->mb_w, b->mb_h, b->stream) != 0) return -5;
+        } else if (mi355_memcpy_d2h_async(s->out, cur->plane[0], picture_bytes(b), b->stream)) return -5;
         if (mi355_event_record(s->done, b->stream)) return -5;
     } else {
         pthread_mutex_lock(&disp.mu);
@@ -836,10 +913,10 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
             b->pictures++;
         } else if (submit_picture(b, h) != 0) {
             /* the picture is lost for this path; what was enqueued must drain before the host touches the frames again */
-            finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+            finish_all(b);
             br_fail(b, "submitting a picture to the device failed");
         } else if (incomplete) {
-            finish_set(b, &b->st[0]); finish_set(b, &b->st[1]);
+            finish_all(b);
             br_fail(b, "incomplete picture (damaged stream)");
         } else {
             /* wait only for what the decoder is about to hand out: h->output_frame was chosen when the picture started
@@ -847,7 +924,7 @@ int __wrap_ff_h264_field_end(H264Context *h, H264SliceContext *sl, int in_setup)
              * with the H264Picture it refers to; without MI355_BRIDGE_LAZY every picture is complete before this returns */
             const uint8_t *out0 = h->output_frame && h->output_frame->buf[0] ? h->output_frame->data[0] : NULL;
             for (int k = 0; k < 2; k++) {
-                Staging *s = &b->st[k];
+                Staging *s = &b->st[b->cur ^ 1 ^ k];         /* the older submission first */
                 if (s->in_flight && (!b->lazy || (out0 && s->frame_data[0] == out0)))
                     if (finish_set(b, s) != 0) br_fail(b, "a picture did not come back from the device");
             }
@@ -883,5 +960,5 @@ void mi355_h264_bridge_batch_stats(unsigned long *batches, unsigned long *pictur
 void mi355_h264_bridge_drain(void)
 {
     Bridge *b = br_tls;
-    if (b && b->state > 0) { finish_set(b, &b->st[0]); finish_set(b, &b->st[1]); }
+    if (b && b->state > 0) finish_all(b);
 }

@@ -284,6 +284,7 @@ void  mi355_host_free(void *p);
 int   mi355_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream);
 int   mi355_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream);
 int   mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream);
+int   mi355_memcpy2d_d2d_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream);
 int   mi355_event_sync(void *event);
 /* Memory from mi355_host_alloc() is DEVICE-VISIBLE at the same address: kernels may read records, vectors and
  * coefficients where the host wrote them (every input byte of a picture is read once, so nothing is gained by copying it

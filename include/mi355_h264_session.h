@@ -35,6 +35,11 @@ typedef struct mi355_h264_session_params {
     int32_t mb_width, mb_height;      /* 8-bit 4:2:0 frames of 16 mb_width x 16 mb_height samples, decoded as frame pictures or as field pairs */
     int32_t num_surfaces;             /* decoded picture buffer size + 1 (the picture being decoded); 2 .. 64 */
     int32_t max_slices;               /* per picture; 0 = 64 */
+    int32_t surface_layout;           /* MI355_SURFACE_LINEAR (0): the surfaces are planes with line strides.  MI355_SURFACE_TILED (1): the
+                                         decoded picture buffer keeps its pictures macroblock-tiled (mi355_h264_frame.h) — the fast
+                                         layout; frame pictures only (start_frame() with field != 0 fails), get_frame() / put_frame() /
+                                         export_frame_dev() convert on the device */
+    int32_t reserved0;
 } mi355_h264_session_params;
 
 typedef struct mi355_h264_picture_params {
@@ -68,8 +73,14 @@ int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[
  * Synchronous. */
 int mi355_h264_put_frame(mi355_h264_session *s, int surface, const uint8_t *const src[3], const int src_stride[3]);
 /* Device address of a surface's plane (valid while the session lives; contents defined once the picture's event has
- * passed: mi355_h264_surface_wait) and its stride — for consumers on the device. */
+ * passed: mi355_h264_surface_wait) and its stride — for consumers on the device.  A tiled session hands out its tile planes:
+ * plane 0 = luma tiles, plane 1 = chroma tiles (plane 2 = plane 1), stride = bytes per macroblock row of tiles. */
 const uint8_t *mi355_h264_surface_dev(mi355_h264_session *s, int surface, int plane, int *stride);
+/* A surface as planes with line strides in DEVICE memory of the caller (dst planes y, cb, cr; strides multiples of 8, luma
+ * 16 for the widest stores), for a consumer on the device that wants lines (mi355_sws_scale_frames_dev: the f2 chain).
+ * Enqueued on `stream` (a hipStream_t; NULL = the session's stream) behind the picture's event; nothing waits.  One launch:
+ * a tiled session converts, a linear one copies plane by plane. */
+int mi355_h264_export_frame_dev(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3], void *stream);
 int mi355_h264_surface_wait(mi355_h264_session *s, int surface);
 /* the session's HIP stream (a hipStream_t): work enqueued on it after end_frame() runs after the picture */
 void *mi355_h264_session_stream(mi355_h264_session *s);

@@ -1744,6 +1744,10 @@ extern "C" int mi355_memcpy2d_d2h_async(void *dst, size_t dst_pitch, const void 
 {
     return mi355::bind() && hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? 0 : -1;
 }
+extern "C" int mi355_memcpy2d_d2d_async(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream)
+{
+    return mi355::bind() && hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
 namespace {
 __global__ void __launch_bounds__(256) k_copy_batch(const mi355_copy_job *jobs, int n)
 {

@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int NSETS = 2;                 /* staging sets: one is filled by the host while the other's copy is in flight */
+constexpr unsigned NJOBS = 64;           /* conversion jobs in flight per session */
 constexpr size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 struct Layout {                          /* byte offsets inside a staging block (host and device blocks share it) */
@@ -43,7 +44,13 @@ struct mi355_h264_session {
     bool pending = false;                 /* grouped: the picture of staging set `cur` has not been launched yet */
     int pend_levels = 0;
     int mb_w = 0, mb_h = 0, nmb = 0, nsurf = 0, max_slices = 0;
-    int stride[2] = { 0, 0 };
+    int stride[2] = { 0, 0 };             /* bytes per line, or per macroblock row of tiles */
+    bool tiled = false;                   /* surfaces are macroblock-tiled (mi355_h264_frame.h) */
+    int lin_stride[2] = { 0, 0 };         /* tiled sessions: the line strides of `lin` */
+    uint8_t *lin = nullptr;               /* tiled sessions: one picture as planes with line strides (device), between the tiles and the host */
+    size_t lin_off[3] = { 0, 0, 0 }, lin_bytes = 0;
+    mi355_surface_job *jobs = nullptr;    /* tiled sessions: pinned conversion jobs (ring of NJOBS: a job is read when its launch runs) */
+    unsigned njob = 0;
     size_t plane_off[3] = { 0, 0, 0 }, surf_bytes = 0;
     uint8_t *surfaces = nullptr;         /* nsurf decoded pictures, then NSETS unfiltered reconstructions */
     void **surf_done = nullptr;          /* per surface: event after its picture's loop filter */
@@ -82,6 +89,8 @@ extern "C" void mi355_h264_session_close(mi355_h264_session *s)
     std::free(s->covered);
     std::free(s->level_widths);
     if (s->surfaces) mi355_free(s->surfaces);
+    if (s->lin) mi355_free(s->lin);
+    if (s->jobs) mi355_host_free(s->jobs);
     if (s->stream && !s->group) mi355_stream_destroy(s->stream);
     if (s->copy_stream) mi355_stream_destroy(s->copy_stream);
     if (s->group) s->group->members--;
@@ -91,6 +100,7 @@ extern "C" void mi355_h264_session_close(mi355_h264_session *s)
 static int session_open_impl(mi355_h264_session **out, const mi355_h264_session_params *p, mi355_h264_group *g)
 {
     if (!out || !p || p->mb_width <= 0 || p->mb_height <= 0 || p->num_surfaces < 2 || p->num_surfaces > 64 || p->max_slices < 0 || p->max_slices > 255) return -1;
+    if (p->surface_layout != MI355_SURFACE_LINEAR && p->surface_layout != MI355_SURFACE_TILED) return -1;
     if ((long)p->mb_width * p->mb_height >= (1L << 24)) return -1;
     mi355_h264_session *s = new (std::nothrow) mi355_h264_session;
     if (!s) return -3;
@@ -98,8 +108,17 @@ static int session_open_impl(mi355_h264_session **out, const mi355_h264_session_
     s->nsurf = p->num_surfaces; s->max_slices = p->max_slices ? p->max_slices : 64;
     /* surfaces: rows of whole 64-byte (luma) / 32-byte (chroma) pieces, the alignment the kernels' 16 / 8-byte paths want */
     s->stride[0] = (int)up64((size_t)16 * s->mb_w); s->stride[1] = s->stride[0] / 2;
-    const size_t ysz = (size_t)s->stride[0] * 16 * s->mb_h, csz = (size_t)s->stride[1] * 8 * s->mb_h;
+    size_t ysz = (size_t)s->stride[0] * 16 * s->mb_h, csz = (size_t)s->stride[1] * 8 * s->mb_h;
     s->plane_off[0] = 0; s->plane_off[1] = ysz; s->plane_off[2] = ysz + csz; s->surf_bytes = up64(ysz + 2 * csz);
+    s->tiled = p->surface_layout == MI355_SURFACE_TILED;
+    if (s->tiled) {
+        /* the line-stride picture between tiles and host; then the surfaces proper: luma tiles, chroma tiles */
+        s->lin_stride[0] = s->stride[0]; s->lin_stride[1] = s->stride[1];
+        s->lin_off[0] = 0; s->lin_off[1] = ysz; s->lin_off[2] = ysz + csz; s->lin_bytes = s->surf_bytes;
+        s->stride[0] = MI355_TILE_LUMA_BYTES * s->mb_w; s->stride[1] = MI355_TILE_CHROMA_BYTES * s->mb_w;
+        ysz = (size_t)s->stride[0] * s->mb_h; csz = (size_t)s->stride[1] * s->mb_h;
+        s->plane_off[0] = 0; s->plane_off[1] = s->plane_off[2] = ysz; s->surf_bytes = up64(ysz + csz);
+    }
     Layout &l = s->lay;
     size_t o = 0;
     l.desc = o;   o += up64(sizeof(mi355_h264_frame));
@@ -114,6 +133,11 @@ static int session_open_impl(mi355_h264_session **out, const mi355_h264_session_
     bool ok = true;
     s->surfaces = static_cast<uint8_t *>(mi355_malloc((size_t)(s->nsurf + NSETS) * s->surf_bytes));
     ok = ok && s->surfaces;
+    if (s->tiled) {
+        s->lin = static_cast<uint8_t *>(mi355_malloc(s->lin_bytes));
+        s->jobs = static_cast<mi355_surface_job *>(mi355_host_alloc(NJOBS * sizeof(mi355_surface_job)));
+        ok = ok && s->lin && s->jobs;
+    }
     for (int k = 0; k < NSETS && ok; k++) {
         s->set[k].host = static_cast<uint8_t *>(mi355_host_alloc(l.total));
         s->set[k].dev = static_cast<uint8_t *>(mi355_malloc(l.total));
@@ -148,6 +172,7 @@ extern "C" int mi355_h264_start_frame(mi355_h264_session *s, const mi355_h264_pi
     if (s->group && s->pending) { const int rc = mi355_h264_group_flush(s->group); if (rc) return rc; }
     if (pp->surface < 0 || pp->surface >= s->nsurf || pp->nslots < 0 || pp->nslots > MI355_H264_MAX_SLOTS) return -1;
     if (pp->field < 0 || pp->field > 2 || (pp->field && (s->mb_h & 1))) return -1;
+    if (pp->field && s->tiled) return -1;                         /* tiled surfaces hold frame pictures only */
     for (int i = 0; i < pp->nslots; i++) {
         const int r = pp->ref_surface[i];
         /* a picture does not predict from itself — except a field from the OTHER field of its frame */
@@ -222,6 +247,7 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     const int fld = s->pp.field, fs = fld ? 2 : 1;
     fr->mb_width = s->mb_w; fr->mb_height = s->rows;
     fr->field_picture = fld != 0;
+    fr->surface_layout = s->tiled ? MI355_SURFACE_TILED : MI355_SURFACE_LINEAR;
     const int recon = s->nsurf + s->cur;
     for (int p = 0; p < 3; p++) { fr->dst[p] = s->plane(s->pp.surface, p) + (fld == 2 ? s->stride[p ? 1 : 0] : 0); fr->recon[p] = s->plane(recon, p); }
     fr->dst_stride[0] = fs * s->stride[0]; fr->recon_stride[0] = s->stride[0];
@@ -273,6 +299,20 @@ extern "C" int mi355_h264_surface_wait(mi355_h264_session *s, int surface)
     return mi355_event_sync(s->surf_done[surface]) == 0 ? 0 : -2;
 }
 
+/* one conversion between surface `surface` of a tiled session and planes with line strides, on `stream`; the job lives in the
+ * session's pinned ring until the launch has read it */
+static int convert(mi355_h264_session *s, int surface, uint8_t *const lin[3], const int lin_stride[3], int to_tiled, void *stream)
+{
+    mi355_surface_job *j = &s->jobs[s->njob++ % NJOBS];
+    std::memset(j, 0, sizeof(*j));
+    for (int p = 0; p < 3; p++) j->lin[p] = lin[p];
+    j->tiled[0] = s->plane(surface, 0); j->tiled[1] = s->plane(surface, 1);
+    j->lin_stride[0] = lin_stride[0]; j->lin_stride[1] = lin_stride[1];
+    j->tiled_stride[0] = s->stride[0]; j->tiled_stride[1] = s->stride[1];
+    j->mb_width = s->mb_w; j->mb_height = s->mb_h; j->to_tiled = to_tiled;
+    return mi355_h264_surface_convert_dev(j, 1, s->mb_w, s->mb_h, stream);
+}
+
 extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3])
 {
     if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf) return -1;
@@ -280,10 +320,18 @@ extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t 
     if (!s->surf_valid[surface]) return -1;
     /* on the copy stream, behind the picture's event: later pictures queued on the session's stream are not waited for */
     if (mi355_stream_wait_event(s->copy_stream, s->surf_done[surface]) != 0) return -2;
+    if (s->tiled) {
+        /* tiles -> lines on the device (s->lin; the copy stream orders its users), then the lines to the host */
+        uint8_t *const lin[3] = { s->lin + s->lin_off[0], s->lin + s->lin_off[1], s->lin + s->lin_off[2] };
+        const int ls[3] = { s->lin_stride[0], s->lin_stride[1], s->lin_stride[1] };
+        if (convert(s, surface, lin, ls, 0, s->copy_stream) != 0) return -2;
+    }
     for (int p = 0; p < 3; p++) {
         const size_t w = (size_t)(p ? 8 : 16) * s->mb_w, rows = (size_t)(p ? 8 : 16) * s->mb_h;
         if (!dst[p] || dst_stride[p] < (int)w) return -1;
-        if (mi355_memcpy2d_d2h_async(dst[p], (size_t)dst_stride[p], s->plane(surface, p), (size_t)s->stride[p ? 1 : 0], w, rows, s->copy_stream) != 0) return -2;
+        const uint8_t *src = s->tiled ? s->lin + s->lin_off[p] : s->plane(surface, p);
+        const size_t st = (size_t)(s->tiled ? s->lin_stride[p ? 1 : 0] : s->stride[p ? 1 : 0]);
+        if (mi355_memcpy2d_d2h_async(dst[p], (size_t)dst_stride[p], src, st, w, rows, s->copy_stream) != 0) return -2;
     }
     return mi355_sync(s->copy_stream) == 0 ? 0 : -2;
 }
@@ -292,15 +340,25 @@ extern "C" int mi355_h264_put_frame(mi355_h264_session *s, int surface, const ui
 {
     if (!s || !src || !src_stride || s->open || surface < 0 || surface >= s->nsurf) return -1;
     if (flush_if_pending(s) != 0) return -2;
-    uint8_t *img = static_cast<uint8_t *>(std::malloc(s->surf_bytes));
+    const size_t img_bytes = s->tiled ? s->lin_bytes : s->surf_bytes;
+    uint8_t *img = static_cast<uint8_t *>(std::malloc(img_bytes));
     if (!img) return -3;
     for (int p = 0; p < 3; p++) {
         const size_t w = (size_t)(p ? 8 : 16) * s->mb_w, rows = (size_t)(p ? 8 : 16) * s->mb_h;
         if (!src[p] || src_stride[p] < (int)w) { std::free(img); return -1; }
-        for (size_t r = 0; r < rows; r++) std::memcpy(img + s->plane_off[p] + r * (size_t)s->stride[p ? 1 : 0], src[p] + r * (size_t)src_stride[p], w);
+        const size_t off = s->tiled ? s->lin_off[p] : s->plane_off[p], st = (size_t)(s->tiled ? s->lin_stride[p ? 1 : 0] : s->stride[p ? 1 : 0]);
+        for (size_t r = 0; r < rows; r++) std::memcpy(img + off + r * st, src[p] + r * (size_t)src_stride[p], w);
     }
     /* behind everything queued (pictures that still read the surface's old contents), then wait: `img` goes away */
-    int rc = mi355_sync(s->stream) == 0 && mi355_memcpy_h2d(s->surfaces + (size_t)surface * s->surf_bytes, img, s->surf_bytes) == 0 ? 0 : -2;
+    int rc;
+    if (s->tiled) {
+        /* lines -> the session's line picture -> tiles (the copy stream orders the users of s->lin) */
+        uint8_t *const lin[3] = { s->lin + s->lin_off[0], s->lin + s->lin_off[1], s->lin + s->lin_off[2] };
+        const int ls[3] = { s->lin_stride[0], s->lin_stride[1], s->lin_stride[1] };
+        rc = mi355_sync(s->stream) == 0 && mi355_sync(s->copy_stream) == 0 && mi355_memcpy_h2d(s->lin, img, img_bytes) == 0 &&
+             convert(s, surface, lin, ls, 1, s->copy_stream) == 0 && mi355_sync(s->copy_stream) == 0 ? 0 : -2;
+    } else
+        rc = mi355_sync(s->stream) == 0 && mi355_memcpy_h2d(s->surfaces + (size_t)surface * s->surf_bytes, img, s->surf_bytes) == 0 ? 0 : -2;
     std::free(img);
     if (rc == 0) rc = mi355_event_record(s->surf_done[surface], s->stream) == 0 ? 0 : -2;
     if (rc == 0) s->surf_valid[surface] = true;
@@ -312,6 +370,23 @@ extern "C" const uint8_t *mi355_h264_surface_dev(mi355_h264_session *s, int surf
     if (!s || surface < 0 || surface >= s->nsurf || plane < 0 || plane > 2) return nullptr;
     if (stride) *stride = s->stride[plane ? 1 : 0];
     return s->plane(surface, plane);
+}
+
+extern "C" int mi355_h264_export_frame_dev(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3], void *stream)
+{
+    if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf) return -1;
+    if (flush_if_pending(s) != 0) return -2;
+    if (!s->surf_valid[surface]) return -1;
+    for (int p = 0; p < 3; p++)
+        if (!dst[p] || dst_stride[p] < (p ? 8 : 16) * s->mb_w || (p == 2 && dst_stride[2] != dst_stride[1])) return -1;
+    void *st = stream ? stream : s->stream;
+    if (st != s->stream && mi355_stream_wait_event(st, s->surf_done[surface]) != 0) return -2;
+    if (s->tiled) return convert(s, surface, dst, dst_stride, 0, st) == 0 ? 0 : -2;
+    for (int p = 0; p < 3; p++) {
+        const size_t w = (size_t)(p ? 8 : 16) * s->mb_w, rows = (size_t)(p ? 8 : 16) * s->mb_h;
+        if (mi355_memcpy2d_d2d_async(dst[p], (size_t)dst_stride[p], s->plane(surface, p), (size_t)s->stride[p ? 1 : 0], w, rows, st) != 0) return -2;
+    }
+    return 0;
 }
 
 extern "C" void *mi355_h264_session_stream(mi355_h264_session *s) { return s ? s->stream : nullptr; }

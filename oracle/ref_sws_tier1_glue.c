@@ -7,3 +7,5 @@
  */
 unsigned long mi355_sws_glue_calls(void);
 unsigned long ref_sws_tier1_calls(void) { return mi355_sws_glue_calls(); }
+unsigned long mi355_sws_glue_pictures(void);
+unsigned long ref_sws_pictures(void) { return mi355_sws_glue_pictures(); }

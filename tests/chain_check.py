@@ -53,10 +53,11 @@ def run(backend, oracle, nframes=3, mb_w=9, mb_h=6, seed=31):
     return nframes
 
 
-def run_session(backend, oracle, first=3, count=3):
+def run_session(backend, oracle, first=3, count=3, tiled=False):
     """The same chain through a whole-frame session (mi355_h264_session.h): pictures `first` .. of the real stream are decoded
     on the session's surfaces and converted from those surfaces (mi355_h264_surface_dev) by work enqueued on the session's
-    stream right behind end_frame() — nothing waits in between.  Expected: the reference decoder's picture through the
+    stream right behind end_frame() — nothing waits in between.  tiled: the session keeps macroblock-tiled surfaces and the
+    converter reads lines that mi355_h264_export_frame_dev() wrote (one launch per picture, same stream).  Expected: the reference decoder's picture through the
     oracle's conversion."""
     import session_cases as SC
     import stream_fixture as SF
@@ -78,7 +79,12 @@ def run_session(backend, oracle, first=3, count=3):
     lib.mi355_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     nsurf = count + 2
-    ss = SC.Session(lib, mb_w, mb_h, nsurf)
+    ss = SC.Session(lib, mb_w, mb_h, nsurf, tiled=tiled)
+    lib.mi355_h264_export_frame_dev.restype = C.c_int
+    lib.mi355_h264_export_frame_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+    lys, lcs = (W + 63) & ~63, ((W + 63) & ~63) // 2
+    lin_bytes = lys * H + 2 * lcs * (H // 2)
+    p_lin = lib.mi355_malloc(C.c_size_t(count * lin_bytes)) if tiled else None
     rgb_stride = W * 3
     p_rgb = lib.mi355_malloc(C.c_size_t(count * rgb_stride * H + 64))
     p_frames = lib.mi355_malloc(C.c_size_t(C.sizeof(S.SwsFrame) * count))
@@ -96,10 +102,19 @@ def run_session(backend, oracle, first=3, count=3):
             assert ss.start(i % nsurf, [s_ % nsurf for s_ in pc["slots"]], pc["use_l1"]) == 0
             SC.send_picture(ss, pc["mb"], pc["mv0"].reshape(-1, 32), None, pc["coef"], pc["slices"], "runs")
             assert ss.end() == 0
-            for p in range(3):
-                st = C.c_int(0)
-                frames[k].src[p] = lib.mi355_h264_surface_dev(ss.h, i % nsurf, p, C.byref(st))
-                frames[k].src_stride[p] = st.value
+            if tiled:
+                base_ = p_lin + k * lin_bytes
+                planes = (C.c_void_p * 3)(base_, base_ + lys * H, base_ + lys * H + lcs * (H // 2))
+                strides = (C.c_int * 3)(lys, lcs, lcs)
+                assert lib.mi355_h264_export_frame_dev(ss.h, i % nsurf, planes, strides, None) == 0
+                for p in range(3):
+                    frames[k].src[p] = planes[p]
+                    frames[k].src_stride[p] = strides[p]
+            else:
+                for p in range(3):
+                    st = C.c_int(0)
+                    frames[k].src[p] = lib.mi355_h264_surface_dev(ss.h, i % nsurf, p, C.byref(st))
+                    frames[k].src_stride[p] = st.value
             frames[k].dst = p_rgb + k * rgb_stride * H
             frames[k].dst_stride = rgb_stride
         lib.mi355_memcpy_h2d(C.c_void_p(p_frames), C.addressof(frames), C.c_size_t(C.sizeof(frames)))
@@ -111,6 +126,8 @@ def run_session(backend, oracle, first=3, count=3):
         lib.mi355_sws_destroy(C.c_void_p(h))
         lib.mi355_free(C.c_void_p(p_rgb))
         lib.mi355_free(C.c_void_p(p_frames))
+        if p_lin:
+            lib.mi355_free(C.c_void_p(p_lin))
         ss.close()
     ob = S.oracle_backend(oracle)
     for k in range(count):

@@ -14,7 +14,8 @@ MAX_SLOTS = HF.MAX_SLOTS
 
 
 class SessionParams(C.Structure):
-    _fields_ = [("mb_width", C.c_int32), ("mb_height", C.c_int32), ("num_surfaces", C.c_int32), ("max_slices", C.c_int32)]
+    _fields_ = [("mb_width", C.c_int32), ("mb_height", C.c_int32), ("num_surfaces", C.c_int32), ("max_slices", C.c_int32),
+                ("surface_layout", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PictureParams(C.Structure):
@@ -55,11 +56,12 @@ class Group:
 
 
 class Session:
-    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0, group=None):
+    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0, group=None, tiled=False):
+        """tiled: the session keeps its surfaces macroblock-tiled (frame pictures only)"""
         _bind(lib)
         self.lib, self.mb_w, self.mb_h = lib, mb_w, mb_h
         self.h = C.c_void_p()
-        p = SessionParams(mb_w, mb_h, nsurf, max_slices)
+        p = SessionParams(mb_w, mb_h, nsurf, max_slices, 1 if tiled else 0, 0)
         rc = lib.mi355_h264_session_open_grouped(C.byref(self.h), C.byref(p), group.h) if group else lib.mi355_h264_session_open(C.byref(self.h), C.byref(p))
         assert rc == 0, rc
 
@@ -128,10 +130,10 @@ def send_picture(ss, mb, mv0, mv1, coef, slices, how):
             assert rc == 0, rc
 
 
-def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True):
+def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True, tiled=False):
     pics = SF.load_npz(npz)
     count = len(pics) - first if count is None else count
-    ss = Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf)
+    ss = Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, tiled=tiled)
     try:
         if first > 0:      # join the stream in the middle: the references of the first picture come from the fixture
             for s_ in pics[first]["slots"]:
@@ -158,13 +160,13 @@ def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True):
     return count
 
 
-def run_group(prov, npzs, nsurf=8, explicit_flush=True):
+def run_group(prov, npzs, nsurf=8, explicit_flush=True, tiled=()):
     """several streams (different picture sizes), one session each, all in ONE group: picture i of every stream that still has
     one goes out in the same launch set.  explicit_flush False: nothing calls group_flush — the next start_frame of a session
     whose picture still waits, and get_frame, flush by themselves."""
     streams = [SF.load_npz(p) for p in npzs]
     g = Group(prov.lib)
-    sess = [Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, group=g) for pics in streams]
+    sess = [Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, group=g, tiled=k in tiled) for k, pics in enumerate(streams)]
     try:
         for i in range(max(len(p) for p in streams)):
             live = [(ss, pics) for ss, pics in zip(sess, streams) if i < len(pics)]
@@ -191,12 +193,12 @@ def run_group(prov, npzs, nsurf=8, explicit_flush=True):
     return sum(len(p) for p in streams)
 
 
-def run_synth(prov, oracle, name, how="runs"):
+def run_synth(prov, oracle, name, how="runs", tiled=False):
     import frame_cases
     fs = HF.synth_frames(**frame_cases.CASES[name])
     _, want = HF.run_oracle(oracle, fs)
     nref = fs.nrefs
-    ss = Session(prov.lib, fs.mb_w, fs.mb_h, nref + 1, 8)
+    ss = Session(prov.lib, fs.mb_w, fs.mb_h, nref + 1, 8, tiled=tiled)
     try:
         for f in range(fs.F):
             for s_ in range(nref):
@@ -215,6 +217,15 @@ def run_errors(prov):
     """state and argument checks; an incomplete picture is refused at end_frame and the session goes on"""
     pics = SF.load_npz(SF_NPZ)
     pc = pics[0]
+    bad = C.c_void_p()
+    _bind(prov.lib)
+    assert prov.lib.mi355_h264_session_open(C.byref(bad), C.byref(SessionParams(pc["mb_w"], pc["mb_h"], 3, 0, 7, 0))) == -1   # no such layout
+    if pc["mb_h"] % 2 == 0:
+        st = Session(prov.lib, pc["mb_w"], pc["mb_h"], 3, tiled=True)
+        try:
+            assert st.start(0, [], False, field=1) == -1                 # tiled surfaces hold frame pictures only
+        finally:
+            st.close()
     ss = Session(prov.lib, pc["mb_w"], pc["mb_h"], 3)
     try:
         assert ss.end() == -1                                            # no open picture

@@ -41,20 +41,23 @@ def check_against_golden(raw, n):
 
 
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP)), reason="needs /root/reference and the sample clip")
-@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, True, 1), (True, True, 1), (False, False, 3)))
-def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, threads):
+@pytest.mark.parametrize("lazy,direct,threads,linear", ((False, False, 1, False), (True, False, 1, False), (False, True, 1, False), (True, True, 1, False), (False, False, 3, False),
+                                                        (False, False, 1, True), (True, True, 1, True)))
+def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, threads, linear):
     """batched submission through the dispatcher thread (default) and direct submission (MI355_BRIDGE_DIRECT), complete
     at once or lazily; with 3 decoder threads the dispatcher's launch sets hold pictures of several streams"""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
     src, n = samples_file(tmp_path, CLIP)
     out = tmp_path / "o.yuv"
     env = dict(os.environ)
-    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_LINEAR"):
         env.pop(k, None)
     if lazy:
         env["MI355_BRIDGE_LAZY"] = "1"
     if direct:
         env["MI355_BRIDGE_DIRECT"] = "1"
+    if linear:
+        env["MI355_BRIDGE_LINEAR"] = "1"          # device pictures as planes with line strides (the default for this clip: macroblock tiles)
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "h264_bridge_emu"), str(src), str(out), str(threads), "1"], capture_output=True, text=True,
                        timeout=1800, env=env)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -17,25 +17,66 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "sws_ref_sha1.json")
 GENERIC = [k for k in S.SMALL if not k.startswith("special")]
 
 
-@pytest.fixture(scope="module")
-def hooked(emu):
-    if not S.HAVE_REFERENCE:
-        pytest.skip("/root/reference not present")
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/libswsref_tier1.so"], check=True)
-    ref = S.Reference.__new__(S.Reference)
-    ref.lib = lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libswsref_tier1.so"))
+def bind(ref, path):
+    ref.lib = lib = C.CDLL(path)
     lib.sws_getContext.restype = C.c_void_p
     lib.sws_getContext.argtypes = [C.c_int] * 7 + [C.c_void_p] * 3
     lib.sws_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.sws_freeContext.argtypes = [C.c_void_p]
     lib.ref_sws_tier1_calls.restype = C.c_ulong
+    lib.ref_sws_pictures.restype = C.c_ulong
+    return ref
+
+
+@pytest.fixture(scope="module")
+def hooked(emu):
+    if not S.HAVE_REFERENCE:
+        pytest.skip("/root/reference not present")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/libswsref_tier1.so"], check=True)
+    ref = bind(S.Reference.__new__(S.Reference), os.path.join(ROOT, "oracle", "_ref", "libswsref_tier1.so"))
     ref.name = "ref+tier1"
     return ref
 
 
 @pytest.mark.parametrize("name", GENERIC)
-def test_reference_sws_scale_through_tier1_inner_loops(hooked, name):
-    before = hooked.lib.ref_sws_tier1_calls()
+def test_reference_sws_scale_through_tier1_inner_loops(hooked, name, monkeypatch):
+    monkeypatch.setenv("MI355_SWS_LINES", "1")                # the inner-loop form of the binding (read when the context is made)
+    before, pics = hooked.lib.ref_sws_tier1_calls(), hooked.lib.ref_sws_pictures()
     out = hooked.scale(name, S.picture(name), dst_pad=8)
     assert hooked.lib.ref_sws_tier1_calls() > before          # the shims really ran
+    assert hooked.lib.ref_sws_pictures() == pics
+    assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]
+
+
+@pytest.mark.parametrize("name", S.SMALL)
+def test_reference_sws_scale_whole_picture_binding(hooked, name, monkeypatch):
+    """the default form: SwsContext.swscale replaced through both selectors (ff_getSwsFunc, ff_yuv2rgb_get_func_ptr) — the
+    reference's sws_scale() of a whole picture is one pass of the product's fused kernel"""
+    monkeypatch.delenv("MI355_SWS_LINES", raising=False)
+    before, calls = hooked.lib.ref_sws_pictures(), hooked.lib.ref_sws_tier1_calls()
+    out = hooked.scale(name, S.picture(name), dst_pad=8)
+    assert hooked.lib.ref_sws_pictures() == before + 1
+    assert hooked.lib.ref_sws_tier1_calls() == calls
+    assert (out[:, -8:] == 0x5A).all()
+    assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]
+
+
+def test_sliced_calls_keep_the_reference_function(hooked, monkeypatch):
+    """a picture handed over in two slices goes to the function the reference had chosen (same picture as in one piece)"""
+    monkeypatch.delenv("MI355_SWS_LINES", raising=False)
+    name = "generic_64x48"
+    sw, sh, dw, dh = S.CONFIGS[name][:4]
+    planes = S.picture(name)
+    c = hooked.open(name)
+    import numpy as np
+    out = np.full((dh, dw * 3 + 8), 0x5A, np.uint8)
+    strides = (C.c_int * 4)(*[p.strides[0] for p in planes], 0)
+    dst = (C.c_void_p * 4)(out.ctypes.data, None, None, None)
+    dstrides = (C.c_int * 4)(out.strides[0], 0, 0, 0)
+    before, n = hooked.lib.ref_sws_pictures(), 0
+    for y0, hh in ((0, sh // 2), (sh // 2, sh - sh // 2)):
+        src = (C.c_void_p * 4)(planes[0][y0:].ctypes.data, planes[1][y0 // 2:].ctypes.data, planes[2][y0 // 2:].ctypes.data, None)
+        n += hooked.lib.sws_scale(c, src, strides, y0, hh, dst, dstrides)
+    hooked.close(c)
+    assert n == dh and hooked.lib.ref_sws_pictures() == before
     assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]

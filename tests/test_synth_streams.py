@@ -157,3 +157,46 @@ def test_bridge_survives_damaged_streams_emulated(tmp_path, emu, seed):
             env["MI355_BRIDGE_LAZY"] = "1"
         res = subprocess.run([SY.exe("h264_bridge_emu"), str(src), str(tmp_path / "o.yuv"), "1", "1"], capture_output=True, text=True, env=env, timeout=600)
         assert res.returncode == 0, (res.returncode, res.stderr[-500:])
+
+
+def _truncate_samples(src, dst, keep):
+    """the first `keep` packets of a .samples file (u32 extradata size, extradata, u32 count, count x (u32 size, bytes))"""
+    import struct
+    raw = open(src, "rb").read()
+    el, = struct.unpack_from("<I", raw, 0)
+    o = 4 + el
+    n, = struct.unpack_from("<I", raw, o)
+    o += 4
+    head, body, k = raw[:4 + el], b"", min(keep, n)
+    for _ in range(k):
+        ln, = struct.unpack_from("<I", raw, o)
+        body += raw[o:o + 4 + ln]
+        o += 4 + ln
+    open(dst, "wb").write(head + struct.pack("<I", k) + body)
+    return k
+
+
+@needs_harness
+@pytest.mark.parametrize("name", ("444_8_paff", "420_8_paff"))
+def test_bridge_lazy_field_pairs_at_the_end_of_a_stream_emulated(tmp_path, emu, name):
+    """MI355_BRIDGE_LAZY with PAFF: the two fields of a frame can be in flight in either order of staging sets when the stream
+    ends (or is flushed); each brings back its own lines only.  Every truncation of the stream to 2..7 packets — ends in a field
+    pair after an odd and after an even number of pictures — must give what the reference's C path gives."""
+    import hashlib
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    for keep in range(2, 8):
+        src = tmp_path / ("t%d.samples" % keep)
+        _truncate_samples(SY.samples(name), src, keep)
+        md5 = {}
+        for mode, envs in (("plain", {"MI355_BRIDGE_PLAIN": "1"}), ("default", {}), ("lazy", {"MI355_BRIDGE_LAZY": "1"}),
+                           ("lazy_direct", {"MI355_BRIDGE_LAZY": "1", "MI355_BRIDGE_DIRECT": "1"})):
+            env = dict(os.environ)
+            for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
+                env.pop(k, None)
+            env.update(envs)
+            out = tmp_path / ("o_%s_%d.yuv" % (mode, keep))
+            r = subprocess.run([SY.exe("h264_bridge_emu"), str(src), str(out), "1", "1"], capture_output=True, text=True, env=env, timeout=1800)
+            assert r.returncode == 0, r.stderr[-2000:]
+            md5[mode] = hashlib.md5(open(out, "rb").read()).hexdigest()
+        assert len(set(md5.values())) == 1, (name, keep, md5)
