@@ -30,6 +30,13 @@
  *                       number per batch, so the per-picture cost of launches and runtime locks is shared by the streams
  *                       that are decoding at the same time — the regime the batched kernels are built for.
  *   direct (MI355_BRIDGE_DIRECT=1)  every decoder thread drives its own HIP stream, one picture per launch set.
+ *   sessions (MI355_BRIDGE_SESSION=1)  the reference-side caller of the whole-frame façade (include/mi355_h264_session.h, the
+ *                       AVHWAccel-shaped boundary: start_frame / decode_slice / end_frame, libavcodec/avcodec.h:3062-3086,
+ *                       call sites h264_slice.c:1534, h264dec.c:591, h264_picture.c:166): at the end of a picture the bridge
+ *                       names the surfaces (one per H264Picture), hands the picture's slices — the macroblocks it packed,
+ *                       run by run — to mi355_h264_decode_slice(), and takes the result back with mi355_h264_get_frame().
+ *                       The session owns surfaces, staging copies, intra schedule and launches; the bridge only parses.
+ *                       4:2:0 frame and field pictures (4:4:4 is submitted plane by plane, which sessions do not do).
  *
  * The decoded picture buffer lives in HBM: one device picture per H264Picture the decoder uses, found again through the
  * reference lists' parent pointers; reference samples never cross PCIe.  Two staging sets per stream alternate, so the
@@ -66,6 +73,7 @@
 #include "libavcodec/mpegutils.h"
 #include "mi355dsp.h"
 #include "mi355_h264_frame.h"
+#include "mi355_h264_session.h"
 
 void __real_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl);
 void __real_ff_h264_flush_change(H264Context *h);
@@ -130,6 +138,7 @@ typedef struct Bridge {
     int state;                  /* 0 new, 1 active, -1 stepped aside */
     int soft;                   /* stepped aside because of the SEQUENCE's format: the next sequence is looked at again */
     int lazy, direct;
+    mi355_h264_session *sess;   /* MI355_BRIDGE_SESSION: pictures go through a whole-frame session; pics[i] is surface i */
     int null_submit;            /* MI355_BRIDGE_NULL (developer): pictures are packed and dropped — times the host side alone */
     int mb_w, mb_h, nmb;
     void *stream;               /* direct mode */
@@ -405,8 +414,9 @@ static void bridge_release(Bridge *b)
     staging_free(&b->st[0]); staging_free(&b->st[1]);
     for (int p = 0; p < 3; p++) { if (b->recon[p]) mi355_free(b->recon[p]); b->recon[p] = NULL; }
     for (int p = 0; p < 2; p++) { if (b->scratch_c[p]) mi355_free(b->scratch_c[p]); b->scratch_c[p] = NULL; }
-    for (int i = 0; i < BR_MAX_PICS; i++) if (b->pics[i].plane[0]) mi355_free(b->pics[i].plane[0]);
+    for (int i = 0; i < BR_MAX_PICS; i++) if (b->pics[i].plane[0] && !b->sess) mi355_free(b->pics[i].plane[0]);
     memset(b->pics, 0, sizeof(b->pics));
+    if (b->sess) { mi355_h264_session_close(b->sess); b->sess = NULL; }
     b->open = 0; b->cur = 0; b->nslots = b->nslices = 0;
 }
 
@@ -478,7 +488,13 @@ static Bridge *bridge_get(const H264Context *h)
         b->plane_bytes[0] = b->lin_bytes[0]; b->plane_bytes[1] = b->lin_bytes[1];
     }
     int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
-    if (ok && b->direct) ok = (b->stream = mi355_stream_create()) != NULL;
+    if (getenv("MI355_BRIDGE_SESSION") && !b->c444) {
+        /* one surface per H264Picture the decoder may hold; a slice that is not one run of macroblocks goes in run by run */
+        const mi355_h264_session_params sp = { b->mb_w, b->mb_h, BR_MAX_PICS, 255, b->tiled ? MI355_SURFACE_TILED : MI355_SURFACE_LINEAR, 0 };
+        ok = ok && mi355_h264_session_open(&b->sess, &sp) == 0;
+        b->direct = 1; b->lazy = 0;                  /* nothing goes through the dispatcher; every picture is complete at its end */
+    }
+    if (ok && b->direct && !b->sess) ok = (b->stream = mi355_stream_create()) != NULL;
     if (ok && !b->direct) ok = disp_start();
     ok = ok && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
     for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[b->c444 ? 0 : p > 0])) != NULL;
@@ -504,6 +520,7 @@ static DevPic *devpic_of(Bridge *b, const H264Context *h, const H264Picture *p, 
     for (int i = 0; i < BR_MAX_PICS && !slot; i++)
         if ((uintptr_t)b->pics[i].owner < (uintptr_t)h->DPB || (uintptr_t)b->pics[i].owner >= (uintptr_t)(h->DPB + H264_MAX_PICTURE_COUNT)) slot = &b->pics[i];
     if (!slot) return NULL;
+    if (b->sess) slot->plane[0] = (uint8_t *)b->sess;            /* the session owns the surface: pics[i] is surface i */
     if (!slot->plane[0]) {
         uint8_t *base = dalloc(picture_bytes(b));
         if (!base) return NULL;
@@ -522,6 +539,13 @@ static DevPic *devpic_upload(Bridge *b, const H264Context *h, const H264Picture 
     if (!p || !p->f || !p->f->data[0]) return NULL;
     DevPic *r = devpic_of(b, h, p, 1);
     if (!r) return NULL;
+    if (b->sess) {
+        const uint8_t *const src[3] = { p->f->data[0], p->f->data[1], p->f->data[2] };
+        const int st[3] = { p->f->linesize[0], p->f->linesize[1], p->f->linesize[2] };
+        if (mi355_h264_put_frame(b->sess, (int)(r - b->pics), src, st) != 0) { r->owner = NULL; return NULL; }
+        r->frame_num = p->frame_num; r->poc = p->poc; r->data0 = p->f->data[0];
+        return r;
+    }
     uint8_t *tmp = malloc(picture_bytes(b));
     if (!tmp) { r->owner = NULL; return NULL; }
     uint8_t *dst = tmp;
@@ -821,12 +845,49 @@ void __wrap_ff_h264_filter_mb_fast(const H264Context *h, H264SliceContext *sl, i
     __real_ff_h264_filter_mb_fast(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize);
 }
 
+/* MI355_BRIDGE_SESSION: the packed picture through the whole-frame session (the AVHWAccel-shaped calls) */
+static int submit_session(Bridge *b, H264Context *h, Staging *s, DevPic *cur)
+{
+    mi355_h264_picture_params pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.surface = (int)(cur - b->pics);
+    pp.nslots = b->nslots;
+    pp.two_lists = b->uses_l1;
+    pp.field = b->field ? 1 + b->parity : 0;
+    for (int i = 0; i < b->nslots; i++) {
+        const H264Picture *rp = b->slot_pic[i];
+        DevPic *r = devpic_of(b, h, rp, 0);
+        if (r && rp != h->cur_pic_ptr && (r->frame_num != rp->frame_num || r->poc != rp->poc || r->data0 != rp->f->data[0])) r = NULL;
+        if (!r && !(r = devpic_upload(b, h, rp))) return -2;
+        pp.ref_surface[i] = (int)(r - b->pics);
+        pp.ref_parity[i] = b->slot_par[i] > 0;
+    }
+    if (mi355_h264_start_frame(b->sess, &pp) != 0) return -3;                        /* AVHWAccel.start_frame */
+    /* AVHWAccel.decode_slice, once per run of consecutive macroblocks of a slice */
+    for (int first = 0; first < b->nmb_pic; ) {
+        const int si = s->mb[0][first].slice_id;
+        int n = 1;
+        while (first + n < b->nmb_pic && s->mb[0][first + n].slice_id == si) n++;
+        if (mi355_h264_decode_slice(b->sess, &s->slices[0][si], first, n, NULL, s->mb[0] + first, s->mv[0] + (size_t)first * 32,
+                                    b->uses_l1 ? s->mv[1] + (size_t)first * 32 : NULL, s->coef[0] + (size_t)first * 384) != 0) return -4;
+        first += n;
+    }
+    if (mi355_h264_end_frame(b->sess) != 0) return -5;                               /* AVHWAccel.end_frame */
+    const AVFrame *fr = h->cur_pic_ptr->f;
+    uint8_t *const dst[3] = { fr->data[0], fr->data[1], fr->data[2] };
+    const int st[3] = { fr->linesize[0], fr->linesize[1], fr->linesize[2] };
+    if (mi355_h264_get_frame(b->sess, pp.surface, dst, st) != 0) return -6;
+    b->pictures++;
+    return 0;
+}
+
 static int submit_picture(Bridge *b, H264Context *h)
 {
     Staging *s = &b->st[b->cur];
     DevPic *cur = devpic_of(b, h, h->cur_pic_ptr, 1);
     if (!cur) return -1;
     cur->frame_num = h->cur_pic_ptr->frame_num; cur->poc = h->cur_pic_ptr->poc; cur->data0 = h->cur_pic_ptr->f->data[0];
+    if (b->sess) { s->pic = cur; return submit_session(b, h, s, cur); }
     int lw = 0;
     const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->rows, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;

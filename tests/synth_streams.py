@@ -44,10 +44,12 @@ def run_tier1(which, name, out, plain=False):
     return lines[0]
 
 
-def run_bridge(which, name, out, threads=1, lazy=False, direct=False, loops=1):
+def run_bridge(which, name, out, threads=1, lazy=False, direct=False, loops=1, session=False):
     env = dict(os.environ)
-    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN"):
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_SESSION", "MI355_BRIDGE_LINEAR"):
         env.pop(k, None)
+    if session:
+        env["MI355_BRIDGE_SESSION"] = "1"         # pictures through the whole-frame session façade (mi355_h264_session.h)
     if lazy:
         env["MI355_BRIDGE_LAZY"] = "1"
     if direct:

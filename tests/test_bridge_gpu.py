@@ -22,7 +22,7 @@ def _run(args, env_extra=None, timeout=600):
     if not os.path.exists(EXE):
         pytest.fail("oracle/_ref/h264_bridge_gpu missing: run __graft_entry__.build() where /root/reference exists")
     env = dict(os.environ)
-    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_DIRECT"):
+    for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_SESSION", "MI355_BRIDGE_LINEAR"):
         env.pop(k, None)
     env.update(env_extra or {})
     r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
@@ -30,8 +30,12 @@ def _run(args, env_extra=None, timeout=600):
     return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
 
 
-@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, False, 6), (True, False, 6), (False, True, 1), (True, True, 4)))
+@pytest.mark.parametrize("lazy,direct,threads", ((False, False, 1), (True, False, 1), (False, False, 6), (True, False, 6), (False, True, 1), (True, True, 4),
+                                                 (False, "session", 1), (False, "session", 4), (False, "linear", 3)))
 def test_bridge_decodes_realshort_on_gpu(tmp_path, mi355, lazy, direct, threads):
+    """batched / lazy / direct submission; "session": every picture through the whole-frame session façade
+    (MI355_BRIDGE_SESSION: mi355_h264_start_frame / decode_slice / end_frame called by the reference decoder's bridge);
+    "linear": device pictures as planes with line strides instead of macroblock tiles"""
     if not os.path.exists(CLIP):
         pytest.skip("sample clip not in this image")
     src, n = samples_file(tmp_path, CLIP)
@@ -39,8 +43,14 @@ def test_bridge_decodes_realshort_on_gpu(tmp_path, mi355, lazy, direct, threads)
     env = {}
     if lazy:
         env["MI355_BRIDGE_LAZY"] = "1"
-    if direct:
+    if direct == "session":
+        env["MI355_BRIDGE_SESSION"] = "1"
+    elif direct == "linear":
+        env["MI355_BRIDGE_LINEAR"] = "1"
+        direct = False
+    elif direct:
         env["MI355_BRIDGE_DIRECT"] = "1"
+    direct = bool(direct)
     stats, err = _run([src, out, threads, 2], env)
     assert stats["pictures_output"] == 2 * n * threads and stats["pictures_on_device"] == 2 * n * threads and stats["bridges_active"] == threads, (stats, err[-500:])
     assert (stats["launch_sets"] == 0) == direct

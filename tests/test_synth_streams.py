@@ -200,3 +200,16 @@ def test_bridge_lazy_field_pairs_at_the_end_of_a_stream_emulated(tmp_path, emu, 
             assert r.returncode == 0, r.stderr[-2000:]
             md5[mode] = hashlib.md5(open(out, "rb").read()).hexdigest()
         assert len(set(md5.values())) == 1, (name, keep, md5)
+
+
+@needs_harness
+@pytest.mark.parametrize("name", [n for n in SY.BRIDGE if not n.startswith("444")])
+def test_bridge_through_the_session_facade_emulated(tmp_path, emu, name):
+    """MI355_BRIDGE_SESSION: the reference decoder hands every picture to mi355_h264_start_frame / decode_slice / end_frame
+    (the AVHWAccel-shaped façade) and takes it back with get_frame — frame and field pictures, slices, B pictures, weights"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_emu", name, out, session=True)
+    assert st.get("pictures_on_device") == SY.ON_DEVICE.get(name, SY.MD5[name]["pictures"]) and st.get("launch_sets") == 0, st
+    SY.check_md5(out, name)

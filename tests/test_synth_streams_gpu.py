@@ -56,6 +56,17 @@ def test_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name, lazy, direc
     SY.check_md5(out, name)
 
 
+@pytest.mark.parametrize("name", [n for n in SY.BRIDGE if not n.startswith("444")])
+def test_bridge_through_the_session_facade_gpu(tmp_path, mi355, name):
+    """MI355_BRIDGE_SESSION: the reference decoder's pictures through mi355_h264_start_frame / decode_slice / end_frame /
+    get_frame (the façade's reference-side caller), two decoder threads = two sessions"""
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", name, out, threads=2, session=True)
+    assert st.get("pictures_on_device") == 2 * SY.ON_DEVICE.get(name, SY.MD5[name]["pictures"]) and st.get("launch_sets") == 0, st
+    SY.check_md5(out, name)
+
+
 @pytest.mark.parametrize("name", ("422_8_b", "420_10_t8x8", "444_10", "420_8_lossless", "444_8_lossless", "422_10_paff", "420_8_mbaff", "444_8_mbaff"))
 def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name):
     _need("h264_bridge_gpu")
