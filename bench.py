@@ -255,6 +255,11 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             "+384 B read and written per macroblock; references stay tiled)", detile=True)
     run("config2_f2048_linear" if tiled else "config2_f2048_tiled", base, 2048, "the headline workload on the OTHER surface layout (%s)"
         % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled)
+    mixed = HF.synth_frames_fast(4, mbw, mbh, seed=0x2640, lib=lib, partitions="mixed")
+    run("config2_mixed_partitions_f2048", mixed, 2048, "SURVEY 8d's second run of config 2: inter macroblocks are 16x16 / 16x8 / 8x16 / 8x8 (a quarter each), 8x8 "
+        "quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each), one vector per partition, one reference per partition / quadrant: 5.6 prediction blocks "
+        "and reference windows per macroblock on average instead of 1 (the algorithmic bytes stay 2432 per macroblock: the fraction is against the "
+        "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (loop filter in its small-batch form: several bands of a picture per workgroup, k_deblock_bands)")
     run("config2_f512", base, 512, "512 pictures per step (small-batch loop filter form)")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)

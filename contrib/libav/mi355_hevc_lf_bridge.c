@@ -14,8 +14,9 @@
  * up to four pieces, each when the deblocking of the CTBs around it is final (sao_filter_CTB, hevc_filter.c:188-313: the
  * CTB itself minus the strips its right / lower neighbours will still deblock, plus those strips of its left / upper /
  * upper-left neighbours, each with the OWNER's parameters).  On a fully deblocked picture the pieces are independent:
- * this file lists them all (one mi355_hevc_sao_job per piece and component, with the edge flags the reference derives
- * from slice addresses and slice_loop_filter_across_slices_enabled_flag) and mi355_hevc_sao_batch_dev() runs them in one
+ * this file lists them all (one mi355_hevc_sao_ctb_job per CTB component: the copy of the deblocked samples plus its up to four
+ * pieces, with the edge flags the reference derives from slice addresses and slice_loop_filter_across_slices_enabled_flag)
+ * and mi355_hevc_sao_ctbs_dev() runs them in one
  * launch, reading the deblocked picture and writing the picture the decoder outputs and predicts from (s->sao_frame).
  *
  * Scope of this binding: 4:2:0, no tiles, decoders without frame threads (progress is reported once per picture).
@@ -41,7 +42,7 @@ static struct {
     uint8_t *plane[3], *vbs, *hbs, *qp, *pcm, *db;
     uint8_t *out[3], *jobs;                /* SAO: the output picture, the job list */
     size_t out_bytes[3], jobs_bytes;
-    mi355_hevc_sao_job *host_jobs;
+    mi355_hevc_sao_ctb_job *host_jobs;
     size_t host_jobs_n;
     /* boundary strengths on the device: what the walk over the coding tree knows about every 4x4 cell's left / top side */
     uint8_t *edge_flags, *d_edge, *d_mvf, *d_cbf;
@@ -180,7 +181,7 @@ static int bs_on_device(HEVCContext *s, size_t bs_bytes)
 /* The pieces of sao_filter_CTB for every CTB of the picture.  Piece k of CTB (cx, cy) belongs to the CTB at
  * (cx - (k >> 1), cy - (k & 1)) — k = the reference's class number: 0 the CTB itself, 1 the strip of the CTB above,
  * 2 of the CTB to the left, 3 of the one above-left — and is filtered with that CTB's parameters. */
-static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const src[3], mi355_hevc_sao_job *jobs)
+static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const src[3], mi355_hevc_sao_ctb_job *jobs)
 {
     const HEVCSPS *sps = s->ps.sps;
     const int cw = sps->ctb_width, chn = sps->ctb_height;
@@ -203,28 +204,32 @@ static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const 
                 /* the anti-diagonal joins the left and the upper CTB: the later of the two decides */
                 diag[1] = diag[2] = a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0;
             }
-            const int borders[4] = { cx == 0, cy == 0, cx == cw - 1, cy == chn - 1 };
             for (int c = 0; c < 3; c++) {
                 const int sh = c ? 1 : 0;
                 const int size = (1 << sps->log2_ctb_size) >> sh;
                 const int x0 = cx * size, y0 = cy * size;
                 const int w = FFMIN(size, (sps->width >> sh) - x0), h = FFMIN(size, (sps->height >> sh) - y0);
                 const size_t off = (size_t)y0 * s->frame->linesize[c] + ((size_t)x0 << sps->pixel_shift);
-                for (int k = 0; k < 4; k++) {
+                /* one job per CTB component: the copy of the deblocked samples and the pieces, in the reference's order
+                 * (the CTB itself, the strip of the CTB to the left, of the one above, of the one above-left) */
+                mi355_hevc_sao_ctb_job *j = &jobs[n++];
+                memset(j, 0, sizeof(*j));
+                j->dst = dst[c] + off; j->src = src[c] + off;
+                j->stride = s->frame->linesize[c];
+                j->width = w; j->height = h;
+                j->borders[0] = cx == 0; j->borders[1] = cy == 0; j->borders[2] = cx == cw - 1; j->borders[3] = cy == chn - 1;
+                j->c_idx = (uint8_t)c;
+                static const int order[4] = { 0, 2, 1, 3 };
+                for (int i = 0; i < 4; i++) {
+                    const int k = order[i];
                     if (((k & 1) && !has_u) || ((k & 2) && !has_l)) continue;
                     const SAOParams *p = &s->sao[here - (k & 1) * cw - (k >> 1)];
-                    if (p->type_idx[c] != SAO_BAND && p->type_idx[c] != SAO_EDGE) continue;
-                    mi355_hevc_sao_job *j = &jobs[n++];
-                    memset(j, 0, sizeof(*j));
-                    j->dst = dst[c] + off; j->src = src[c] + off;
-                    j->stride = s->frame->linesize[c];
-                    j->width = w; j->height = h;
-                    for (int e = 0; e < 4; e++) j->borders[e] = borders[e];
-                    for (int e = 0; e < 5; e++) j->offset_val[e] = p->offset_val[c][e];
-                    j->cls = (uint8_t)k;
-                    j->edge = p->type_idx[c] == SAO_EDGE;
-                    j->c_idx = (uint8_t)c; j->eo_class = (uint8_t)p->eo_class[c]; j->band_position = p->band_position[c];
-                    j->vert_edge = vert[k]; j->horiz_edge = horiz[k]; j->diag_edge = diag[k];
+                    mi355_hevc_sao_piece *q = &j->piece[j->npieces++];
+                    for (int e = 0; e < 5; e++) q->offset_val[e] = p->offset_val[c][e];
+                    q->cls = (uint8_t)k;
+                    q->type = p->type_idx[c] == SAO_EDGE ? 2 : p->type_idx[c] == SAO_BAND ? 1 : 0;
+                    q->eo_class = (uint8_t)p->eo_class[c]; q->band_position = p->band_position[c];
+                    q->vert_edge = vert[k]; q->horiz_edge = horiz[k]; q->diag_edge = diag[k];
                 }
             }
         }
@@ -285,8 +290,8 @@ static int filter_picture(HEVCContext *s)
         lf.pictures++;
         return 0;
     }
-    /* SAO: deblocked picture -> the picture the decoder keeps (copy_CTB of every CTB = the whole picture, then the pieces) */
-    const size_t max_jobs = (size_t)sps->ctb_width * sps->ctb_height * 12;
+    /* SAO: deblocked picture -> the picture the decoder keeps, one job per CTB component (copy + pieces) */
+    const size_t max_jobs = (size_t)sps->ctb_width * sps->ctb_height * 3;
     if (lf.host_jobs_n < max_jobs) {
         free(lf.host_jobs);
         lf.host_jobs = malloc(max_jobs * sizeof(*lf.host_jobs));
@@ -297,10 +302,9 @@ static int filter_picture(HEVCContext *s)
     for (int i = 0; i < 3; i++) if (ensure(&lf.out[i], &lf.out_bytes[i], sz[i])) return -1;
     const int n = sao_jobs(s, lf.out, lf.plane, lf.host_jobs);
     if (mi355_sync(lf.stream) != 0) return -2;
-    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2d(lf.out[i], lf.plane[i], sz[i]);
     if (n) rc |= mi355_memcpy_h2d(lf.jobs, lf.host_jobs, (size_t)n * sizeof(*lf.host_jobs));
     if (rc) return -2;
-    if (n && mi355_hevc_sao_batch_dev((const mi355_hevc_sao_job *)lf.jobs, n, sps->bit_depth, lf.stream) != 0) return -2;
+    if (n && mi355_hevc_sao_ctbs_dev((const mi355_hevc_sao_ctb_job *)lf.jobs, n, sps->bit_depth, lf.stream) != 0) return -2;
     if (mi355_sync(lf.stream) != 0) return -2;
     for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->sao_frame->data[i], lf.out[i], sz[i]);
     if (rc) return -2;

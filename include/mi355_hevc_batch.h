@@ -111,6 +111,47 @@ typedef struct mi355_hevc_sao_job {
 } mi355_hevc_sao_job;
 int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream);
 
+/* a17, CTB level: everything sao_filter_CTB (hevc_filter.c:188-314) does for one component of one CTB in ONE job — the copy
+ * of the deblocked samples into the output picture and the up to four pieces (the CTB's own region with its parameters,
+ * the strips left / above / above-left with the parameters of the CTBs they belong to), so that a picture's SAO is one
+ * launch that reads the deblocked picture once and writes the output picture once.  dst / src point at the CTB's first
+ * sample; width / height / borders as for mi355_hevc_sao_job.  The job copies the region its pieces partition — the CTB
+ * shifted left by 8 + 2 and up by 4 + 2 luma samples (half for chroma), except at picture borders — then filters the pieces
+ * in the reference's order; the regions of different jobs do not overlap, so the jobs of a picture are independent (the
+ * reference copies the CTB shifted by 8 / 4 and lets the next CTB's piece overwrite two columns / rows of it: same
+ * samples in the end). */
+typedef struct mi355_hevc_sao_piece {
+    int32_t offset_val[5];
+    uint8_t cls;              /* bit 0 = rows above, bit 1 = columns left (the reference's class) */
+    uint8_t type;             /* 0 none (the copy stands), 1 band, 2 edge */
+    uint8_t eo_class, band_position;
+    uint8_t vert_edge, horiz_edge, diag_edge, reserved;
+} mi355_hevc_sao_piece;
+typedef struct mi355_hevc_sao_ctb_job {
+    uint8_t *dst;
+    const uint8_t *src;
+    int32_t stride;           /* both pictures, bytes */
+    int32_t width, height;
+    int32_t borders[4];       /* the CTB lies on the picture's left / top / right / bottom border */
+    uint8_t c_idx, npieces, reserved[2];
+    mi355_hevc_sao_piece piece[4];
+} mi355_hevc_sao_ctb_job;
+int mi355_hevc_sao_ctbs_dev(const mi355_hevc_sao_ctb_job *d_jobs, int n, int bit_depth, void *stream);
+
+/* a11, batched: emulated_edge_mc (videodsp_template.c:24-96; HEVC callers hevcdec.c:1555, 1613-1630) — a block_w x block_h
+ * window at (src_x, src_y) of a w x h plane (`src` = the plane's sample (0, 0)... see below) copied into `dst` with the
+ * picture's border samples replicated.  `src` points at the window's first sample INSIDE OR OUTSIDE the plane, exactly as
+ * the reference passes it (plane origin + src_y * stride + src_x samples).  The prediction jobs of blocks that reach over a
+ * picture border then name `dst` as their source, as the decoder's luma_mc / chroma_mc do. */
+typedef struct mi355_edge_emu_job {
+    uint8_t *dst;
+    const uint8_t *src;
+    int32_t dst_stride, src_stride;   /* bytes */
+    int32_t block_w, block_h;         /* samples */
+    int32_t src_x, src_y, w, h;
+} mi355_edge_emu_job;
+int mi355_edge_emu_batch_dev(const mi355_edge_emu_job *d_jobs, int n, int bit_depth, void *stream);
+
 /* a18: pred_planar[] / pred_dc / pred_angular[] (hevcdec.h:399-409, hevcpred_template.c:349-516) for one transform
  * block.  `top` / `left` point at element 0 of the neighbour arrays the reference's intra_pred() wrapper builds
  * (hevcpred_template.c:31-334: 2 * size samples each, element -1 = the corner); they live wherever the bridge put

@@ -435,6 +435,80 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
     hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p, tbl);
 }
 
+/* one component of one CTB: copy of the region its pieces partition, then the pieces (mi355_hevc_batch.h) */
+__global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
+{
+    if ((int)blockIdx.x >= n) return;
+    const mi355_hevc_sao_ctb_job &j = jobs[blockIdx.x];
+    const int chroma = uniform(j.c_idx) != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, px = bd > 8 ? 2 : 1;
+    const int W = uniform(j.width), H = uniform(j.height), stride = uniform(j.stride);
+    const int b0 = uniform(j.borders[0]), b1 = uniform(j.borders[1]), b2 = uniform(j.borders[2]), b3 = uniform(j.borders[3]);
+    uint8_t *dst = mi355_global(j.dst);
+    const uint8_t *src = mi355_global(j.src);
+    {
+        const int xs = b0 ? 0 : cw, ys = b1 ? 0 : ch;
+        const int cols = xs + (b2 ? W : W - cw), rows = ys + (b3 ? H : H - ch);
+        if (cols > 0 && rows > 0) {
+            /* rows of `cols` samples starting xs samples left of the CTB: dword pieces where pointers, stride and the first byte allow, bytes otherwise */
+            const int nbytes = cols * px;
+            const ptrdiff_t o0 = -(ptrdiff_t)ys * stride - (ptrdiff_t)xs * px;
+            const bool al = (((uintptr_t)dst | (uintptr_t)src | (uintptr_t)stride | (uintptr_t)(xs * px)) & 3) == 0;
+            if (al) {
+                const int ndw = nbytes >> 2, tail = nbytes & 3, per = ndw + (tail ? 1 : 0), inv = mi355_inv20(per > 0 ? per : 1);
+                for (int i = lane_id(); i < per * rows; i += 64) {
+                    const int y = mi355_div20(i, inv), k = i - y * per;
+                    const ptrdiff_t o = o0 + (ptrdiff_t)y * stride + 4 * k;
+                    if (k < ndw) *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+                    else for (int t = 0; t < tail; t++) dst[o + t] = src[o + t];
+                }
+            } else {
+                for (int i = lane_id(); i < nbytes * rows; i += 64) {          /* (the reciprocal division is exact below 2^19 only) */
+                    const int y = i / nbytes, k = i - y * nbytes;
+                    const ptrdiff_t o = o0 + (ptrdiff_t)y * stride + k;
+                    dst[o] = src[o];
+                }
+            }
+        }
+    }
+    __syncthreads();          /* one wave: its stores to a sample land in program order; the pieces below overwrite the copy */
+    __shared__ int tbl[32];
+    const int st = stride / px, np = uniform(j.npieces);
+    for (int k = 0; k < np && k < 4; k++) {
+        const mi355_hevc_sao_piece &q = j.piece[k];
+        if (uniform(q.type) == 0) continue;
+        SaoJob p;
+        p.width = W; p.height = H; p.c_idx = chroma ? 1 : 0; p.cls = uniform(q.cls); p.bd = bd; p.edge = uniform(q.type) == 2;
+        p.borders[0] = b0; p.borders[1] = b1; p.borders[2] = b2; p.borders[3] = b3;
+        p.vert_edge = uniform(q.vert_edge); p.horiz_edge = uniform(q.horiz_edge); p.diag_edge = uniform(q.diag_edge);
+        p.eo_class = uniform(q.eo_class); p.band_position = uniform(q.band_position);
+        for (int e = 0; e < 5; e++) p.offset_val[e] = uniform(q.offset_val[e]);
+        hevc_sao_wave(dst, st, src, st, p, tbl);
+        __syncthreads();
+    }
+}
+
+/* emulated_edge_mc as a batch: one wave per window */
+__global__ void __launch_bounds__(64) k_edge_emu_batch(const mi355_edge_emu_job *jobs, int n, int bd)
+{
+    if ((int)blockIdx.x >= n) return;
+    const mi355_edge_emu_job &j = jobs[blockIdx.x];
+    const int bw = uniform(j.block_w), bh = uniform(j.block_h), sx = uniform(j.src_x), sy = uniform(j.src_y), w = uniform(j.w), h = uniform(j.h);
+    const int ss = uniform(j.src_stride), ds = uniform(j.dst_stride), px = bd > 8 ? 2 : 1;
+    uint8_t *dst = mi355_global(j.dst);
+    /* `src` is the window's first sample (possibly outside the plane): the plane's sample (0, 0) lies sy rows and sx samples before it */
+    const uint8_t *plane = mi355_global(j.src) - (ptrdiff_t)sy * ss - (ptrdiff_t)sx * px;
+    if (bw <= 0 || bh <= 0 || w <= 0 || h <= 0) return;
+    const int inv = mi355_inv20(bw);
+    for (int i = lane_id(); i < bw * bh; i += 64) {
+        const int y = mi355_div20(i, inv), x = i - y * bw;
+        const int cx = clip3(sx + x, 0, w - 1), cy = clip3(sy + y, 0, h - 1);
+        const uint8_t *s = plane + (ptrdiff_t)cy * ss + (ptrdiff_t)cx * px;
+        uint8_t *d = dst + (ptrdiff_t)y * ds + (ptrdiff_t)x * px;
+        if (bd > 8) *reinterpret_cast<uint16_t *>(d) = *reinterpret_cast<const uint16_t *>(s);
+        else *d = *s;
+    }
+}
+
 /* ---- intra prediction: one wave per transform block -------------------------------------------------------- */
 __global__ void __launch_bounds__(64) k_hevc_intra_batch(const mi355_hevc_intra_job *jobs, int n, int bd)
 {
@@ -676,6 +750,18 @@ extern "C" int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *
 {
     if (!check(bit_depth, d_blocks, n) || !d_pics) return -1;
     hipLaunchKernelGGL(k_hevc_intra_blocks, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_pics, d_blocks, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_sao_ctbs_dev(const mi355_hevc_sao_ctb_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_hevc_sao_ctbs, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_edge_emu_batch_dev(const mi355_edge_emu_job *d_jobs, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_jobs, n)) return -1;
+    hipLaunchKernelGGL(k_edge_emu_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream)

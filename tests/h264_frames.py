@@ -627,12 +627,14 @@ class DeviceFrames:
         self.bufs = []
 
 
-def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05, mv_range=64, lib=None, refs="noise", coef_b=None):
+def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05, mv_range=64, lib=None, refs="noise", coef_b=None, partitions="16x16"):
     """Vectorised generator for the benchmark workload (headline variant):
     P pictures, one 16x16 partition per inter MB, `intra_frac` Intra16x16 MBs (they force bS 3/4 edges),
     ref_idx ~ U{0..nrefs-1}, mv ~ U[-mv_range, mv_range) quarter samples, 24 4x4 blocks coded w.p. 0.5.
     `lib`: a loaded libmi355dsp (its host helper mi355_h264_intra_schedule builds the intra schedule).
-    refs="smooth" / coef_b (Laplace scale of the levels, default 24): content on which the loop filter's conditions hold."""
+    refs="smooth" / coef_b (Laplace scale of the levels, default 24): content on which the loop filter's conditions hold.
+    partitions="mixed": SURVEY 8d's second run — each inter macroblock is 16x16, 16x8, 8x16 or 8x8 (a quarter each), the 8x8
+    quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each); one vector per partition, one reference per partition (per quadrant in 8x8)."""
     fs = FrameSet(nframes, mb_w, mb_h, nrefs)
     r = SplitMix64(seed)
     COEF_B[0] = 24 if coef_b is None else coef_b
@@ -689,6 +691,33 @@ def synth_frames_fast(nframes, mb_w, mb_h, seed=0x264, nrefs=4, intra_frac=0.05,
     mv = r.randint(-mv_range, mv_range - 1, (N, 2))
     mv[intra] = 0
     fs.mv[0].reshape(N, 16, 2)[:] = mv[:, None, :]
+    if partitions == "mixed":
+        shape = r.randint(0, 3, N)                     # 0 16x16, 1 16x8, 2 8x16, 3 8x8
+        sub = r.randint(0, 3, (N, 4))                   # per quadrant: MI355_SUB_8x8 / 8x4 / 4x8 / 4x4
+        mv16 = r.randint(-mv_range, mv_range - 1, (N, 16, 2))      # a vector per 4x4 block (raster); partitions take their first block's
+        refq = r.randint(0, nrefs - 1, (N, 4))          # a reference per quadrant
+        b = np.arange(16)
+        bx, by = b & 3, b >> 2
+        quad = (bx >> 1) + 2 * (by >> 1)
+        # the block whose vector a block takes (raster index), per shape
+        src16 = np.zeros(16, np.int64)
+        src168 = np.where(by < 2, 0, 8)
+        src816 = np.where(bx < 2, 0, 2)
+        q0 = (2 * (quad & 1)) + 4 * (2 * (quad >> 1))  # first block of the block's quadrant
+        per_sub = np.stack([q0, q0 + 4 * (by & 1), q0 + (bx & 1), b])          # 8x8, 8x4, 4x8, 4x4
+        src = np.where((shape == 0)[:, None], src16[None, :], np.where((shape == 1)[:, None], src168[None, :], np.where((shape == 2)[:, None], src816[None, :],
+                       per_sub[sub[:, quad], b[None, :]])))
+        mvm = np.take_along_axis(mv16, src[:, :, None].repeat(2, axis=2), axis=1)
+        # references: one per partition (16x8: quadrants 0, 1 | 2, 3; 8x16: 0, 2 | 1, 3), one per quadrant in 8x8
+        rq = np.where((shape == 0)[:, None], refq[:, :1].repeat(4, axis=1), np.where((shape == 1)[:, None], refq[:, [0, 0, 2, 2]],
+                      np.where((shape == 2)[:, None], refq[:, [0, 1, 0, 1]], refq)))
+        inter = ~intra
+        fs.mv[0].reshape(N, 16, 2)[inter] = mvm[inter]
+        mb["ref_idx"][inter, 0, :] = rq[inter]
+        mb["i4mode"][inter, 0:4] = rq[inter]
+        mt = np.array([T16x16 | P0L0, T16x8 | P0L0 | P1L0, T8x16 | P0L0 | P1L0, T8x8 | P0L0 | P1L0], np.uint32)[shape]
+        mb["mb_type"] = np.where(intra, I16, mt)
+        mb["sub"] = np.where(((shape == 3) & inter)[:, None], sub | 0x10, 0)
     # residual: 24 blocks per MB
     blks, coded = _gen_block_coefs(r, N * 24, "sparse")
     blks = blks.reshape(N, 24, 16)

@@ -43,6 +43,24 @@ class SaoJob(C.Structure):
 assert C.sizeof(LfJob) == 32
 
 
+class SaoPiece(C.Structure):
+    _fields_ = [("offset_val", C.c_int32 * 5), ("cls", C.c_uint8), ("type", C.c_uint8), ("eo_class", C.c_uint8), ("band_position", C.c_uint8),
+                ("vert_edge", C.c_uint8), ("horiz_edge", C.c_uint8), ("diag_edge", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class SaoCtbJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("borders", C.c_int32 * 4), ("c_idx", C.c_uint8), ("npieces", C.c_uint8), ("reserved", C.c_uint8 * 2), ("piece", SaoPiece * 4)]
+
+
+class EdgeEmuJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("dst_stride", C.c_int32), ("src_stride", C.c_int32), ("block_w", C.c_int32),
+                ("block_h", C.c_int32), ("src_x", C.c_int32), ("src_y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+assert C.sizeof(SaoPiece) == 28 and C.sizeof(SaoCtbJob) == 160 and C.sizeof(EdgeEmuJob) == 48
+
+
 class McPredJob(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("dst", C.c_void_p), ("src0_stride", C.c_int32), ("src1_stride", C.c_int32),
                 ("dst_stride", C.c_int32), ("width", C.c_uint8), ("height", C.c_uint8), ("chroma", C.c_uint8), ("kind", C.c_uint8),
@@ -354,6 +372,142 @@ def check_sao(prov, oracle, bd, seed, cells=(3, 4)):
     return len(jobs)
 
 
+def sao_ctb_pieces(cx, cy, cw, chn, params, slice_addr, filter_edges):
+    """what sao_filter_CTB (hevc_filter.c:188-314) derives for CTB (cx, cy): [(class, parameters of the owning CTB, vert, horiz, diag)]
+    in the reference's order, and the CTB's picture-border flags"""
+    here = cy * cw + cx
+    has_l, has_u = cx > 0, cy > 0
+    a_c = slice_addr[here]
+    a_l = slice_addr[here - 1] if has_l else a_c
+    a_u = slice_addr[here - cw] if has_u else a_c
+    a_ul = slice_addr[here - cw - 1] if has_l and has_u else a_c
+    f_c = filter_edges[here]
+    f_l = filter_edges[here - 1] if has_l else 1
+    f_u = filter_edges[here - cw] if has_u else 1
+    vert, horiz, diag = [0] * 4, [0] * 4, [0] * 4
+    if has_l:
+        vert[0] = vert[2] = int(not f_c and a_c != a_l)
+    if has_u:
+        horiz[0] = horiz[1] = int(not f_c and a_c != a_u)
+    if has_l and has_u:
+        vert[1] = vert[3] = int(not f_u and a_u != a_ul)
+        horiz[2] = horiz[3] = int(not f_l and a_l != a_ul)
+        diag[0] = diag[3] = int(not f_c and a_c != a_ul)
+        diag[1] = diag[2] = int(not f_l) if a_l > a_u else (int(not f_u) if a_l < a_u else 0)
+    order = [0] + ([2] if has_l else []) + ([1] if has_u else []) + ([3] if has_l and has_u else [])
+    return [(k, params[here - (k & 1) * cw - (k >> 1)], vert[k], horiz[k], diag[k]) for k in order], [int(cx == 0), int(cy == 0), int(cx == cw - 1), int(cy == chn - 1)]
+
+
+def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
+    """mi355_hevc_sao_ctbs_dev (copy + the up to four pieces of a CTB component in one job) on a whole 4:2:0 picture with ragged
+    last CTBs, random parameters (off / band / edge), two slices with and without filtering across their edge — against
+    sao_filter_CTB restated over the oracle's table functions: per CTB in raster order, copy_CTB of the CTB shifted by 8 / 4, then
+    the pieces"""
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    W, H = size
+    ctb = 1 << log2_ctb
+    cw, chn = -(-W // ctb), -(-H // ctb)
+    planes = [pixels(r, (H >> (c > 0), W >> (c > 0)), bd, smooth=True) for c in range(3)]
+    for pl in planes:
+        pl[::3, ::5] = pixels(r, pl[::3, ::5].shape, bd)
+    outs = [np.full_like(pl, 0x155 if bd > 8 else 0x55) for pl in planes]
+    params = []
+    for _ in range(cw * chn):
+        params.append(dict(type=[r.randint(0, 2) for _ in range(3)], off=[[0] + [r.randint(-7 << (bd - 8), 7 << (bd - 8)) for _ in range(4)] for _ in range(3)],
+                           band=[r.randint(0, 31) for _ in range(3)], eo=[r.randint(0, 3) for _ in range(3)]))
+    first2 = r.randint(1, cw * chn - 1)                    # the second slice starts here (raster scan = tile scan)
+    slice_addr = [0 if i < first2 else first2 for i in range(cw * chn)]
+    filter_edges = [1 if i < first2 else r.randint(0, 1) for i in range(cw * chn)]
+    if cw * chn > 2:
+        filter_edges[first2] = 0
+    c_o = oracle.hevcdsp(bd)
+    exp = [o.copy() for o in outs]
+    jobs = []
+    for cy in range(chn):
+        for cx in range(cw):
+            pieces, borders = sao_ctb_pieces(cx, cy, cw, chn, params, slice_addr, filter_edges)
+            bo = np.array(borders, np.int32)
+            for c in range(3):
+                sh = 1 if c else 0
+                size_c = ctb >> sh
+                x0, y0 = cx * size_c, cy * size_c
+                w, h = min(size_c, (W >> sh) - x0), min(size_c, (H >> sh) - y0)
+                src, dst = planes[c], exp[c]
+                stride = src.strides[0]
+                xs, ys = (0 if borders[0] else 8 >> sh), (0 if borders[1] else 4 >> sh)
+                cwid, chgt = (w + xs if borders[2] else w), (h + ys if borders[3] else h)
+                dst[y0 - ys:y0 - ys + chgt, x0 - xs:x0 - xs + cwid] = src[y0 - ys:y0 - ys + chgt, x0 - xs:x0 - xs + cwid]      # copy_CTB
+                off = y0 * stride + x0 * px
+                j = SaoCtbJob(0, 0, stride, w, h)
+                j.c_idx, j.npieces = c, len(pieces)
+                for e in range(4):
+                    j.borders[e] = borders[e]
+                for n, (k, p, ve, he, de) in enumerate(pieces):
+                    q = j.piece[n]
+                    q.cls, q.type, q.eo_class, q.band_position, q.vert_edge, q.horiz_edge, q.diag_edge = k, p["type"][c], p["eo"][c], p["band"][c], ve, he, de
+                    for i in range(5):
+                        q.offset_val[i] = p["off"][c][i]
+                    if p["type"][c] == 0:
+                        continue
+                    sao = A.SAOParams()
+                    for i in range(5):
+                        sao.offset_val[c][i] = p["off"][c][i]
+                    sao.band_position[c], sao.eo_class[c] = p["band"][c], p["eo"][c]
+                    if p["type"][c] == 2:
+                        c_o.sao_edge_filter[k](_u8p(dst, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp), w, h, c, ve, he, de)
+                    else:
+                        c_o.sao_band_filter[k](_u8p(dst, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp), w, h, c)
+                jobs.append((c, off, j))
+    d = Dev(prov.lib)
+    try:
+        p_src, p_dst = [d.up(pl) for pl in planes], [d.up(o) for o in outs]
+        arr = []
+        for c, off, j in jobs:
+            j.dst, j.src = p_dst[c] + off, p_src[c] + off
+            arr.append(j)
+        prov.lib.mi355_hevc_sao_ctbs_dev.restype = C.c_int
+        assert prov.lib.mi355_hevc_sao_ctbs_dev(C.c_void_p(d.up_jobs(arr)), len(arr), bd, None) == 0
+        got = [d.down(p_dst[c], outs[c]) for c in range(3)]
+    finally:
+        d.free()
+    for c in range(3):
+        assert np.array_equal(got[c], exp[c]), "CTB-level SAO differs in plane %d (bd %d)" % (c, bd)
+    return len(jobs)
+
+
+def check_edge_emu(prov, oracle, bd, seed, n=40):
+    """mi355_edge_emu_batch_dev against the definition of emulated_edge_mc (videodsp_template.c:24-96: the window with every
+    coordinate clamped to the plane)"""
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    w, h = 70, 41
+    plane = pixels(r, (h, w + 6), bd)                      # 6 samples of row padding
+    stride = plane.strides[0]
+    meta = []
+    for k in range(n):
+        bw, bh = r.randint(1, 71), r.randint(1, 71)
+        meta.append((bw, bh, r.randint(-bw - 3, w + 3), r.randint(-bh - 3, h + 3)))
+    bufs = np.full((n, 71, 80), 0x155 if bd > 8 else 0x55, plane.dtype)
+    exp = bufs.copy()
+    for k, (bw, bh, sx, sy) in enumerate(meta):
+        ys = np.clip(np.arange(sy, sy + bh), 0, h - 1)
+        xs = np.clip(np.arange(sx, sx + bw), 0, w - 1)
+        exp[k, :bh, :bw] = plane[:, :w][np.ix_(ys, xs)]
+    d = Dev(prov.lib)
+    try:
+        p_pl, p_b = d.up(plane), d.up(bufs)
+        jobs = [EdgeEmuJob(p_b + k * bufs.strides[0], p_pl + sy * stride + sx * px, bufs.strides[1], stride, bw, bh, sx, sy, w, h)
+                for k, (bw, bh, sx, sy) in enumerate(meta)]
+        prov.lib.mi355_edge_emu_batch_dev.restype = C.c_int
+        assert prov.lib.mi355_edge_emu_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
+        got = d.down(p_b, bufs)
+    finally:
+        d.free()
+    assert np.array_equal(got, exp), "edge emulation batch differs (bd %d)" % bd
+    return n
+
+
 def check_mcpred(prov, oracle, bd, seed, cells=(4, 6)):
     """fused MC + prediction vs the oracle's put_hevc_qpel/epel followed by its (un)weighted prediction functions"""
     r = SplitMix64(seed)
@@ -450,4 +604,4 @@ def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
 
 
 CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
-          "intra": check_intra, "mcpred": check_mcpred}
+          "intra": check_intra, "mcpred": check_mcpred, "sao_ctbs": check_sao_ctbs, "edge_emu": check_edge_emu}

@@ -108,3 +108,22 @@ def test_mixed_layout_batch_emulated(emu, oracle):
 
 def test_surface_convert_emulated(emu):
     assert frame_cases.run_surface_convert(emu, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24, 512))) == 3
+
+
+@pytest.mark.parametrize("tiled", (True, False))
+def test_mixed_partition_workload_matches_oracle_emulated(emu, oracle, tiled):
+    """the mixed-partition variant of the bench generator (16x16 / 16x8 / 8x16 / 8x8 with every sub-partition shape) on a
+    small picture whose windows reach over every border"""
+    import numpy as np
+    import h264_frames as HF
+    fs = HF.synth_frames_fast(2, 7, 5, seed=0x2640, lib=emu.lib, partitions="mixed")
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(emu, fs, tiled=tiled)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])

@@ -127,3 +127,20 @@ def test_full_size_1080p_batch_tiled_matches_oracle(mi355, oracle):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
+
+
+@pytest.mark.parametrize("tiled", (True, False))
+def test_full_size_1080p_mixed_partitions_matches_oracle(mi355, oracle, tiled):
+    """SURVEY 8d's second run of config 2 (bench.py's extra point config2_mixed_partitions): 16x16 / 16x8 / 8x16 / 8x8 macroblocks
+    with 8x8 / 8x4 / 4x8 / 4x4 quadrants, one vector per partition — two 1080p pictures, every sample against the oracle"""
+    fs = HF.synth_frames_fast(2, 120, 68, seed=0x2640, lib=mi355.lib, partitions="mixed")
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs, tiled=tiled)
+    try:
+        d.decode()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
