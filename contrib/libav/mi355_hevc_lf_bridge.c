@@ -14,8 +14,8 @@
  * up to four pieces, each when the deblocking of the CTBs around it is final (sao_filter_CTB, hevc_filter.c:188-313: the
  * CTB itself minus the strips its right / lower neighbours will still deblock, plus those strips of its left / upper /
  * upper-left neighbours, each with the OWNER's parameters).  On a fully deblocked picture the pieces are independent:
- * this file lists them all (one mi355_hevc_sao_ctb_job per CTB component: the copy of the deblocked samples plus its up to four
- * pieces, with the edge flags the reference derives from slice addresses and slice_loop_filter_across_slices_enabled_flag)
+ * this file lists them all (one mi355_hevc_sao_ctb_job per CTB component: the up to four calls that filter the CTB's own samples,
+ * with the edge flags the reference derives from slice addresses and slice_loop_filter_across_slices_enabled_flag)
  * and mi355_hevc_sao_ctbs_dev() runs them in one
  * launch, reading the deblocked picture and writing the picture the decoder outputs and predicts from (s->sao_frame).
  *
@@ -186,50 +186,50 @@ static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const 
     const HEVCSPS *sps = s->ps.sps;
     const int cw = sps->ctb_width, chn = sps->ctb_height;
     int n = 0;
-    for (int cy = 0; cy < chn; cy++)
-        for (int cx = 0; cx < cw; cx++) {
-            const int here = cy * cw + cx;
-            const int has_l = cx > 0, has_u = cy > 0;
-            /* slice address and "filter across slice edges" of the four CTBs around the CTB's top-left corner */
-            const int a_c = s->tab_slice_address[here], a_l = has_l ? s->tab_slice_address[here - 1] : a_c;
-            const int a_u = has_u ? s->tab_slice_address[here - cw] : a_c, a_ul = has_l && has_u ? s->tab_slice_address[here - cw - 1] : a_c;
-            const int f_c = s->filter_slice_edges[here], f_l = has_l ? s->filter_slice_edges[here - 1] : 1, f_u = has_u ? s->filter_slice_edges[here - cw] : 1;
-            uint8_t vert[4] = { 0 }, horiz[4] = { 0 }, diag[4] = { 0 };
-            if (has_l) vert[0] = vert[2] = !f_c && a_c != a_l;
-            if (has_u) horiz[0] = horiz[1] = !f_c && a_c != a_u;
-            if (has_l && has_u) {
-                vert[1] = vert[3] = !f_u && a_u != a_ul;
-                horiz[2] = horiz[3] = !f_l && a_l != a_ul;
-                diag[0] = diag[3] = !f_c && a_c != a_ul;
-                /* the anti-diagonal joins the left and the upper CTB: the later of the two decides */
-                diag[1] = diag[2] = a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0;
-            }
+    /* one job per CTB component = the OWNER's samples: what the reference filters with this CTB's parameters while this CTB
+     * (class 0), the CTB to its right (class 2), the CTB below (class 1) and the one below-right (class 3) pass through */
+    for (int oy = 0; oy < chn; oy++)
+        for (int ox = 0; ox < cw; ox++) {
+            const SAOParams *p = &s->sao[oy * cw + ox];
             for (int c = 0; c < 3; c++) {
                 const int sh = c ? 1 : 0;
                 const int size = (1 << sps->log2_ctb_size) >> sh;
-                const int x0 = cx * size, y0 = cy * size;
-                const int w = FFMIN(size, (sps->width >> sh) - x0), h = FFMIN(size, (sps->height >> sh) - y0);
-                const size_t off = (size_t)y0 * s->frame->linesize[c] + ((size_t)x0 << sps->pixel_shift);
-                /* one job per CTB component: the copy of the deblocked samples and the pieces, in the reference's order
-                 * (the CTB itself, the strip of the CTB to the left, of the one above, of the one above-left) */
                 mi355_hevc_sao_ctb_job *j = &jobs[n++];
                 memset(j, 0, sizeof(*j));
+                const size_t off = (size_t)(oy * size) * s->frame->linesize[c] + ((size_t)(ox * size) << sps->pixel_shift);
                 j->dst = dst[c] + off; j->src = src[c] + off;
                 j->stride = s->frame->linesize[c];
-                j->width = w; j->height = h;
-                j->borders[0] = cx == 0; j->borders[1] = cy == 0; j->borders[2] = cx == cw - 1; j->borders[3] = cy == chn - 1;
                 j->c_idx = (uint8_t)c;
-                static const int order[4] = { 0, 2, 1, 3 };
-                for (int i = 0; i < 4; i++) {
-                    const int k = order[i];
-                    if (((k & 1) && !has_u) || ((k & 2) && !has_l)) continue;
-                    const SAOParams *p = &s->sao[here - (k & 1) * cw - (k >> 1)];
+                for (int k = 0; k < 4; k++) {
+                    /* the CTB the reference calls class k for */
+                    const int cx = ox + (k >> 1), cy = oy + (k & 1);
+                    if (cx >= cw || cy >= chn) continue;
+                    const int here = cy * cw + cx;
+                    const int has_l = cx > 0, has_u = cy > 0;
+                    /* slice address and "filter across slice edges" of the four CTBs around that CTB's top-left corner */
+                    const int a_c = s->tab_slice_address[here], a_l = has_l ? s->tab_slice_address[here - 1] : a_c;
+                    const int a_u = has_u ? s->tab_slice_address[here - cw] : a_c, a_ul = has_l && has_u ? s->tab_slice_address[here - cw - 1] : a_c;
+                    const int f_c = s->filter_slice_edges[here], f_l = has_l ? s->filter_slice_edges[here - 1] : 1, f_u = has_u ? s->filter_slice_edges[here - cw] : 1;
+                    uint8_t vert[4] = { 0 }, horiz[4] = { 0 }, diag[4] = { 0 };
+                    if (has_l) vert[0] = vert[2] = !f_c && a_c != a_l;
+                    if (has_u) horiz[0] = horiz[1] = !f_c && a_c != a_u;
+                    if (has_l && has_u) {
+                        vert[1] = vert[3] = !f_u && a_u != a_ul;
+                        horiz[2] = horiz[3] = !f_l && a_l != a_ul;
+                        diag[0] = diag[3] = !f_c && a_c != a_ul;
+                        /* the anti-diagonal joins the left and the upper CTB: the later of the two decides */
+                        diag[1] = diag[2] = a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0;
+                    }
+                    const int x0 = cx * size, y0 = cy * size;
                     mi355_hevc_sao_piece *q = &j->piece[j->npieces++];
                     for (int e = 0; e < 5; e++) q->offset_val[e] = p->offset_val[c][e];
                     q->cls = (uint8_t)k;
                     q->type = p->type_idx[c] == SAO_EDGE ? 2 : p->type_idx[c] == SAO_BAND ? 1 : 0;
                     q->eo_class = (uint8_t)p->eo_class[c]; q->band_position = p->band_position[c];
                     q->vert_edge = vert[k]; q->horiz_edge = horiz[k]; q->diag_edge = diag[k];
+                    q->borders = (uint8_t)((cx == 0) | ((cy == 0) << 1) | ((cx == cw - 1) << 2) | ((cy == chn - 1) << 3));
+                    q->dx = (int16_t)((k >> 1) * size); q->dy = (int16_t)((k & 1) * size);
+                    q->width = (int16_t)FFMIN(size, (sps->width >> sh) - x0); q->height = (int16_t)FFMIN(size, (sps->height >> sh) - y0);
                 }
             }
         }
@@ -290,7 +290,7 @@ static int filter_picture(HEVCContext *s)
         lf.pictures++;
         return 0;
     }
-    /* SAO: deblocked picture -> the picture the decoder keeps, one job per CTB component (copy + pieces) */
+    /* SAO: deblocked picture -> the picture the decoder keeps, one job per CTB component (the pieces that make up its own samples) */
     const size_t max_jobs = (size_t)sps->ctb_width * sps->ctb_height * 3;
     if (lf.host_jobs_n < max_jobs) {
         free(lf.host_jobs);

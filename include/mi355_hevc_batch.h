@@ -111,28 +111,28 @@ typedef struct mi355_hevc_sao_job {
 } mi355_hevc_sao_job;
 int mi355_hevc_sao_batch_dev(const mi355_hevc_sao_job *d_jobs, int n, int bit_depth, void *stream);
 
-/* a17, CTB level: everything sao_filter_CTB (hevc_filter.c:188-314) does for one component of one CTB in ONE job — the copy
- * of the deblocked samples into the output picture and the up to four pieces (the CTB's own region with its parameters,
- * the strips left / above / above-left with the parameters of the CTBs they belong to), so that a picture's SAO is one
- * launch that reads the deblocked picture once and writes the output picture once.  dst / src point at the CTB's first
- * sample; width / height / borders as for mi355_hevc_sao_job.  The job copies the region its pieces partition — the CTB
- * shifted left by 8 + 2 and up by 4 + 2 luma samples (half for chroma), except at picture borders — then filters the pieces
- * in the reference's order; the regions of different jobs do not overlap, so the jobs of a picture are independent (the
- * reference copies the CTB shifted by 8 / 4 and lets the next CTB's piece overwrite two columns / rows of it: same
- * samples in the end). */
+/* a17, CTB level: sample adaptive offset of one component of one CTB's OWN samples in ONE job, so that a picture's SAO is one
+ * launch that reads the deblocked picture once and writes every sample of the output picture once, in whole cache lines.
+ * sao_filter_CTB (hevc_filter.c:188-314) filters a CTB's samples in up to four calls made while four different CTBs pass
+ * through the decoder (the CTB itself: class 0 without its right / bottom strips; the CTB to its right: class 2 = that strip;
+ * the CTB below: class 1; the one below-right: class 3), all with the OWNER's parameters.  A job lists those calls as
+ * `pieces`: each names the CTB the reference makes the call for (first sample relative to the job's, size, picture-border
+ * flags) and carries the flags the reference derives for that CTB and class.  A piece of type 0 (the owner has SAO off) is
+ * copied.  The pieces of all jobs partition the picture: jobs are independent. */
 typedef struct mi355_hevc_sao_piece {
     int32_t offset_val[5];
-    uint8_t cls;              /* bit 0 = rows above, bit 1 = columns left (the reference's class) */
-    uint8_t type;             /* 0 none (the copy stands), 1 band, 2 edge */
+    uint8_t cls;              /* bit 0 = rows above, bit 1 = columns left of the piece's CTB (the reference's class) */
+    uint8_t type;             /* 0 none (copy), 1 band, 2 edge */
     uint8_t eo_class, band_position;
-    uint8_t vert_edge, horiz_edge, diag_edge, reserved;
+    uint8_t vert_edge, horiz_edge, diag_edge;
+    uint8_t borders;          /* bit e: the piece's CTB lies on the picture's left / top / right / bottom border (e = 0..3) */
+    int16_t dx, dy;           /* first sample of the piece's CTB relative to dst / src (0 or the CTB size) */
+    int16_t width, height;    /* of the piece's CTB */
 } mi355_hevc_sao_piece;
 typedef struct mi355_hevc_sao_ctb_job {
-    uint8_t *dst;
+    uint8_t *dst;             /* first sample of the owner CTB */
     const uint8_t *src;
     int32_t stride;           /* both pictures, bytes */
-    int32_t width, height;
-    int32_t borders[4];       /* the CTB lies on the picture's left / top / right / bottom border */
     uint8_t c_idx, npieces, reserved[2];
     mi355_hevc_sao_piece piece[4];
 } mi355_hevc_sao_ctb_job;

@@ -435,50 +435,57 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
     hevc_sao_wave(mi355_global(j.dst), st, mi355_global(j.src), st, p, tbl);
 }
 
-/* one component of one CTB: copy of the region its pieces partition, then the pieces (mi355_hevc_batch.h) */
+/* one component of one CTB (mi355_hevc_batch.h): its up to four pieces, each either filtered (band / edge: the filter functions
+ * write every sample of their region) or, where the owning CTB has SAO off, copied — every sample of the output picture is
+ * written exactly once, by the job whose pieces partition its neighbourhood */
+typedef uint32_t mi355_sao_u32x4a4 __attribute__((vector_size(16), aligned(4)));
+__device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src, int stride, int x0, int y0, int w, int h, int px)
+{
+    if (w <= 0 || h <= 0) return;
+    const int nbytes = w * px;
+    const ptrdiff_t o0 = (ptrdiff_t)y0 * stride + (ptrdiff_t)x0 * px;
+    if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)stride | (uintptr_t)(x0 * px) | (uintptr_t)nbytes) & 3) == 0) {
+        /* rows in 16-byte pieces (dword-aligned vector accesses) and a tail of dwords */
+        const int nv = nbytes >> 4, nt = (nbytes & 15) >> 2, per = nv + nt, inv = mi355_inv20(per);
+        for (int i = lane_id(); i < per * h; i += 64) {
+            const int y = mi355_div20(i, inv), k = i - y * per;
+            const ptrdiff_t o = o0 + (ptrdiff_t)y * stride;
+            if (k < nv) *reinterpret_cast<mi355_sao_u32x4a4 *>(dst + o + 16 * k) = *reinterpret_cast<const mi355_sao_u32x4a4 *>(src + o + 16 * k);
+            else *reinterpret_cast<uint32_t *>(dst + o + 16 * nv + 4 * (k - nv)) = *reinterpret_cast<const uint32_t *>(src + o + 16 * nv + 4 * (k - nv));
+        }
+        return;
+    }
+    for (int i = lane_id(); i < nbytes * h; i += 64) {          /* (the reciprocal division is exact below 2^19 only) */
+        const int y = i / nbytes, k = i - y * nbytes;
+        dst[o0 + (ptrdiff_t)y * stride + k] = src[o0 + (ptrdiff_t)y * stride + k];
+    }
+}
 __global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_sao_ctb_job &j = jobs[blockIdx.x];
     const int chroma = uniform(j.c_idx) != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, px = bd > 8 ? 2 : 1;
-    const int W = uniform(j.width), H = uniform(j.height), stride = uniform(j.stride);
-    const int b0 = uniform(j.borders[0]), b1 = uniform(j.borders[1]), b2 = uniform(j.borders[2]), b3 = uniform(j.borders[3]);
-    uint8_t *dst = mi355_global(j.dst);
-    const uint8_t *src = mi355_global(j.src);
-    {
-        const int xs = b0 ? 0 : cw, ys = b1 ? 0 : ch;
-        const int cols = xs + (b2 ? W : W - cw), rows = ys + (b3 ? H : H - ch);
-        if (cols > 0 && rows > 0) {
-            /* rows of `cols` samples starting xs samples left of the CTB: dword pieces where pointers, stride and the first byte allow, bytes otherwise */
-            const int nbytes = cols * px;
-            const ptrdiff_t o0 = -(ptrdiff_t)ys * stride - (ptrdiff_t)xs * px;
-            const bool al = (((uintptr_t)dst | (uintptr_t)src | (uintptr_t)stride | (uintptr_t)(xs * px)) & 3) == 0;
-            if (al) {
-                const int ndw = nbytes >> 2, tail = nbytes & 3, per = ndw + (tail ? 1 : 0), inv = mi355_inv20(per > 0 ? per : 1);
-                for (int i = lane_id(); i < per * rows; i += 64) {
-                    const int y = mi355_div20(i, inv), k = i - y * per;
-                    const ptrdiff_t o = o0 + (ptrdiff_t)y * stride + 4 * k;
-                    if (k < ndw) *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
-                    else for (int t = 0; t < tail; t++) dst[o + t] = src[o + t];
-                }
-            } else {
-                for (int i = lane_id(); i < nbytes * rows; i += 64) {          /* (the reciprocal division is exact below 2^19 only) */
-                    const int y = i / nbytes, k = i - y * nbytes;
-                    const ptrdiff_t o = o0 + (ptrdiff_t)y * stride + k;
-                    dst[o] = src[o];
-                }
-            }
-        }
-    }
-    __syncthreads();          /* one wave: its stores to a sample land in program order; the pieces below overwrite the copy */
+    const int stride = uniform(j.stride);
+    uint8_t *dst0 = mi355_global(j.dst);
+    const uint8_t *src0 = mi355_global(j.src);
     __shared__ int tbl[32];
     const int st = stride / px, np = uniform(j.npieces);
     for (int k = 0; k < np && k < 4; k++) {
         const mi355_hevc_sao_piece &q = j.piece[k];
-        if (uniform(q.type) == 0) continue;
+        const int cls = uniform(q.cls), type = uniform(q.type), W = uniform(q.width), H = uniform(q.height), bo = uniform(q.borders);
+        const ptrdiff_t off = (ptrdiff_t)uniform(q.dy) * stride + (ptrdiff_t)uniform(q.dx) * px;
+        uint8_t *dst = dst0 + off;
+        const uint8_t *src = src0 + off;
+        if (type == 0) {
+            /* the region hevc_sao_wave would take for this class */
+            const int x0 = (cls & 2) ? -cw : 0, y0 = (cls & 1) ? -ch : 0;
+            const int w = (cls & 2) ? cw : ((bo & 4) ? W : W - cw), h = (cls & 1) ? ch : ((bo & 8) ? H : H - ch);
+            sao_copy_region(dst, src, stride, x0, y0, w, h, px);
+            continue;
+        }
         SaoJob p;
-        p.width = W; p.height = H; p.c_idx = chroma ? 1 : 0; p.cls = uniform(q.cls); p.bd = bd; p.edge = uniform(q.type) == 2;
-        p.borders[0] = b0; p.borders[1] = b1; p.borders[2] = b2; p.borders[3] = b3;
+        p.width = W; p.height = H; p.c_idx = chroma ? 1 : 0; p.cls = cls; p.bd = bd; p.edge = type == 2;
+        p.borders[0] = bo & 1; p.borders[1] = (bo >> 1) & 1; p.borders[2] = (bo >> 2) & 1; p.borders[3] = (bo >> 3) & 1;
         p.vert_edge = uniform(q.vert_edge); p.horiz_edge = uniform(q.horiz_edge); p.diag_edge = uniform(q.diag_edge);
         p.eo_class = uniform(q.eo_class); p.band_position = uniform(q.band_position);
         for (int e = 0; e < 5; e++) p.offset_val[e] = uniform(q.offset_val[e]);

@@ -45,12 +45,13 @@ assert C.sizeof(LfJob) == 32
 
 class SaoPiece(C.Structure):
     _fields_ = [("offset_val", C.c_int32 * 5), ("cls", C.c_uint8), ("type", C.c_uint8), ("eo_class", C.c_uint8), ("band_position", C.c_uint8),
-                ("vert_edge", C.c_uint8), ("horiz_edge", C.c_uint8), ("diag_edge", C.c_uint8), ("reserved", C.c_uint8)]
+                ("vert_edge", C.c_uint8), ("horiz_edge", C.c_uint8), ("diag_edge", C.c_uint8), ("borders", C.c_uint8),
+                ("dx", C.c_int16), ("dy", C.c_int16), ("width", C.c_int16), ("height", C.c_int16)]
 
 
 class SaoCtbJob(C.Structure):
-    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
-                ("borders", C.c_int32 * 4), ("c_idx", C.c_uint8), ("npieces", C.c_uint8), ("reserved", C.c_uint8 * 2), ("piece", SaoPiece * 4)]
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("stride", C.c_int32), ("c_idx", C.c_uint8), ("npieces", C.c_uint8), ("reserved", C.c_uint8 * 2),
+                ("piece", SaoPiece * 4)]
 
 
 class EdgeEmuJob(C.Structure):
@@ -58,7 +59,7 @@ class EdgeEmuJob(C.Structure):
                 ("block_h", C.c_int32), ("src_x", C.c_int32), ("src_y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
-assert C.sizeof(SaoPiece) == 28 and C.sizeof(SaoCtbJob) == 160 and C.sizeof(EdgeEmuJob) == 48
+assert C.sizeof(SaoPiece) == 36 and C.sizeof(SaoCtbJob) == 168 and C.sizeof(EdgeEmuJob) == 48
 
 
 class McPredJob(C.Structure):
@@ -399,7 +400,7 @@ def sao_ctb_pieces(cx, cy, cw, chn, params, slice_addr, filter_edges):
 
 
 def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
-    """mi355_hevc_sao_ctbs_dev (copy + the up to four pieces of a CTB component in one job) on a whole 4:2:0 picture with ragged
+    """mi355_hevc_sao_ctbs_dev (one job per CTB component: the up to four reference calls that make up the CTB's own samples) on a whole 4:2:0 picture with ragged
     last CTBs, random parameters (off / band / edge), two slices with and without filtering across their edge — against
     sao_filter_CTB restated over the oracle's table functions: per CTB in raster order, copy_CTB of the CTB shifted by 8 / 4, then
     the pieces"""
@@ -423,7 +424,7 @@ def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
         filter_edges[first2] = 0
     c_o = oracle.hevcdsp(bd)
     exp = [o.copy() for o in outs]
-    jobs = []
+    owner = {}                                             # (owner CTB, component) -> its pieces as the reference's calls produce them
     for cy in range(chn):
         for cx in range(cw):
             pieces, borders = sao_ctb_pieces(cx, cy, cw, chn, params, slice_addr, filter_edges)
@@ -439,15 +440,9 @@ def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
                 cwid, chgt = (w + xs if borders[2] else w), (h + ys if borders[3] else h)
                 dst[y0 - ys:y0 - ys + chgt, x0 - xs:x0 - xs + cwid] = src[y0 - ys:y0 - ys + chgt, x0 - xs:x0 - xs + cwid]      # copy_CTB
                 off = y0 * stride + x0 * px
-                j = SaoCtbJob(0, 0, stride, w, h)
-                j.c_idx, j.npieces = c, len(pieces)
-                for e in range(4):
-                    j.borders[e] = borders[e]
-                for n, (k, p, ve, he, de) in enumerate(pieces):
-                    q = j.piece[n]
-                    q.cls, q.type, q.eo_class, q.band_position, q.vert_edge, q.horiz_edge, q.diag_edge = k, p["type"][c], p["eo"][c], p["band"][c], ve, he, de
-                    for i in range(5):
-                        q.offset_val[i] = p["off"][c][i]
+                for (k, p, ve, he, de) in pieces:
+                    ox, oy = cx - (k >> 1), cy - (k & 1)
+                    owner.setdefault((oy, ox, c), []).append(dict(cls=k, p=p, ve=ve, he=he, de=de, borders=borders, dx=(k >> 1) * size_c, dy=(k & 1) * size_c, w=w, h=h))
                     if p["type"][c] == 0:
                         continue
                     sao = A.SAOParams()
@@ -458,7 +453,21 @@ def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
                         c_o.sao_edge_filter[k](_u8p(dst, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp), w, h, c, ve, he, de)
                     else:
                         c_o.sao_band_filter[k](_u8p(dst, off), _u8p(src, off), stride, C.byref(sao), C.cast(bo.ctypes.data, A.intp), w, h, c)
-                jobs.append((c, off, j))
+    jobs = []
+    for (oy, ox, c), pcs in sorted(owner.items()):
+        sh = 1 if c else 0
+        size_c = ctb >> sh
+        stride = planes[c].strides[0]
+        j = SaoCtbJob(0, 0, stride)
+        j.c_idx, j.npieces = c, len(pcs)
+        for n, m in enumerate(pcs):
+            q, p = j.piece[n], m["p"]
+            q.cls, q.type, q.eo_class, q.band_position, q.vert_edge, q.horiz_edge, q.diag_edge = m["cls"], p["type"][c], p["eo"][c], p["band"][c], m["ve"], m["he"], m["de"]
+            q.borders = sum(b << e for e, b in enumerate(m["borders"]))
+            q.dx, q.dy, q.width, q.height = m["dx"], m["dy"], m["w"], m["h"]
+            for i in range(5):
+                q.offset_val[i] = p["off"][c][i]
+        jobs.append((c, oy * size_c * stride + ox * size_c * px, j))
     d = Dev(prov.lib)
     try:
         p_src, p_dst = [d.up(pl) for pl in planes], [d.up(o) for o in outs]

@@ -2,8 +2,8 @@
 per CTB four 32x32 luma + two 32x32 chroma transform units (75 % with non-zeros in the top-left 8x8 only), 32x32
 uni-predicted prediction units, deblocking of the whole picture FROM ITS FRAME-LEVEL ARRAYS (bS 1 on every 32x32 TU / PU
 edge, bS 2 on 10 %, QP ~ U{22..37}: beta / tc derived on the device by mi355_hevc_deblock_pictures_dev), SAO of EVERY
-CTB (50 % edge, 25 % band, 25 % off; one job per CTB component = the copy + its up to four pieces with the border classes,
-mi355_hevc_sao_ctbs_dev).  Prediction blocks lie where their vectors put them: those that reach over a picture border go
+CTB (50 % edge, 25 % band, 25 % off; one job per CTB component = the up to four reference calls that make up the CTB's own
+samples, with their border classes: mi355_hevc_sao_ctbs_dev).  Prediction blocks lie where their vectors put them: those that reach over a picture border go
 through mi355_edge_emu_batch_dev first (emulated_edge_mc, as luma_mc / chroma_mc do, hevcdec.c:1555, 1613-1630).  Job arrays are numpy records laid out like the C structs; nothing loops per job.
 Stages are enqueued one after the other on the null stream, each reading what the previous one wrote:
   edge emulation -> scratch;  fused MC + put_unweighted_pred -> recon;  idct32 + add_residual -> recon;  deblock (V then H) in place;
@@ -15,6 +15,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hevc_filter_cases as HFC  # noqa: E402
 
@@ -27,12 +28,11 @@ SAO_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("width", 
                    ("offset_val", "<i4", 5), ("cls", "u1"), ("edge", "u1"), ("c_idx", "u1"), ("eo_class", "u1"), ("band_position", "u1"),
                    ("vert_edge", "u1"), ("horiz_edge", "u1"), ("diag_edge", "u1")])
 PIECE_DT = np.dtype([("offset_val", "<i4", 5), ("cls", "u1"), ("type", "u1"), ("eo_class", "u1"), ("band_position", "u1"), ("vert_edge", "u1"),
-                     ("horiz_edge", "u1"), ("diag_edge", "u1"), ("rsv", "u1")])
-SAOC_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("width", "<i4"), ("height", "<i4"), ("borders", "<i4", 4), ("c_idx", "u1"),
-                    ("npieces", "u1"), ("rsv", "u1", 2), ("piece", PIECE_DT, 4)])
+                     ("horiz_edge", "u1"), ("diag_edge", "u1"), ("borders", "u1"), ("dx", "<i2"), ("dy", "<i2"), ("width", "<i2"), ("height", "<i2")])
+SAOC_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("c_idx", "u1"), ("npieces", "u1"), ("rsv", "u1", 2), ("piece", PIECE_DT, 4)])
 EE_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("dst_stride", "<i4"), ("src_stride", "<i4"), ("block_w", "<i4"), ("block_h", "<i4"),
                   ("src_x", "<i4"), ("src_y", "<i4"), ("w", "<i4"), ("h", "<i4")])
-assert TU_DT.itemsize == 24 and MP_DT.itemsize == 56 and SAO_DT.itemsize == 72 and PIECE_DT.itemsize == 28 and SAOC_DT.itemsize == 160 and EE_DT.itemsize == 48
+assert TU_DT.itemsize == 24 and MP_DT.itemsize == 56 and SAO_DT.itemsize == 72 and PIECE_DT.itemsize == 36 and SAOC_DT.itemsize == 168 and EE_DT.itemsize == 48
 BYTES_PER_CTB = 73984
 
 
@@ -184,8 +184,6 @@ class Chain:
         band = rng.integers(0, 32, (P, 3, ncy, ncx)).astype(np.uint8)
         self.host["sao"] = (typ, offs, eo, band)
         sao = np.zeros((P, 3, ncy, ncx), SAOC_DT)
-        sao["borders"][..., 0], sao["borders"][..., 1] = (cx == 0)[None, None], (cy == 0)[None, None]
-        sao["borders"][..., 2], sao["borders"][..., 3] = (cx == ncx - 1)[None, None], (cy == ncy - 1)[None, None]
         for c in range(3):
             sz_c, st_c = (64, ls) if c == 0 else (32, cs)
             wc, hc = (W, H) if c == 0 else (W // 2, H // 2)
@@ -194,26 +192,26 @@ class Chain:
             dst_b = (self.out_y + pic * ysz) if c == 0 else (self.out_c + (pic * 2 + (c - 1)) * csz)
             sao["src"][:, c], sao["dst"][:, c] = src_b[:, None, None] + o, dst_b[:, None, None] + o
             sao["stride"][:, c] = st_c
-            sao["width"][:, c] = np.minimum(sz_c, wc - cx * sz_c)[None]
-            sao["height"][:, c] = np.minimum(sz_c, hc - cy * sz_c)[None]
             sao["c_idx"][:, c] = c
-        # pieces in the reference's order: the CTB itself (class 0), the CTB to the left (2), above (1), above-left (3)
-        npieces = np.zeros((ncy, ncx), np.int64)
-        for k, dx, dy in ((0, 0, 0), (2, 1, 0), (1, 0, 1), (3, 1, 1)):
-            have = (cx >= dx) & (cy >= dy)
-            own_y, own_x = np.maximum(cy - dy, 0), np.maximum(cx - dx, 0)
-            for i in np.unique(npieces[have]):
-                sel = have & (npieces == i)                               # CTBs whose piece number i is class k
-                yy, xx = np.nonzero(sel)
-                pc = sao["piece"][:, :, yy, xx, int(i)]
-                pc["cls"] = k
-                pc["type"] = typ[:, :, own_y[yy, xx], own_x[yy, xx]]
-                pc["eo_class"] = eo[:, :, own_y[yy, xx], own_x[yy, xx]]
-                pc["band_position"] = band[:, :, own_y[yy, xx], own_x[yy, xx]]
-                pc["offset_val"][..., 1:] = offs[:, :, own_y[yy, xx], own_x[yy, xx]]
-                sao["piece"][:, :, yy, xx, int(i)] = pc
-            npieces = npieces + have
-        sao["npieces"] = npieces[None, None].astype(np.uint8)
+            # the owner's samples = class 0 of the CTB itself, class 2 of the CTB to its right, class 1 of the one below, class 3 of the one
+            # below-right, all with the OWNER's parameters (one slice, no tiles: no unfilterable edges)
+            npieces = np.zeros((ncy, ncx), np.int64)
+            for k in (0, 2, 1, 3):
+                px_, py_ = cx + (k >> 1), cy + (k & 1)                    # the CTB the reference makes this call for
+                have = (px_ < ncx) & (py_ < ncy)
+                for i in np.unique(npieces[have]):
+                    yy, xx = np.nonzero(have & (npieces == i))
+                    pc = sao["piece"][:, c, yy, xx, int(i)]
+                    pc["cls"] = k
+                    pc["type"], pc["eo_class"], pc["band_position"] = typ[:, c, yy, xx], eo[:, c, yy, xx], band[:, c, yy, xx]
+                    pc["offset_val"][..., 1:] = offs[:, c, yy, xx]
+                    qx, qy = px_[yy, xx], py_[yy, xx]
+                    pc["borders"] = ((qx == 0) | ((qy == 0) << 1) | ((qx == ncx - 1) << 2) | ((qy == ncy - 1) << 3))[None]
+                    pc["dx"], pc["dy"] = ((k >> 1) * sz_c), ((k & 1) * sz_c)
+                    pc["width"], pc["height"] = np.minimum(sz_c, wc - qx * sz_c)[None], np.minimum(sz_c, hc - qy * sz_c)[None]
+                    sao["piece"][:, c, yy, xx, int(i)] = pc
+                npieces = npieces + have
+            sao["npieces"][:, c] = npieces[None].astype(np.uint8)
         self.n_sao, self.d_sao = sao.size, self.up(sao)
         self.ctbs = P * ((W + 63) // 64) * ((H + 63) // 64)
         lib.mi355_hevc_deblock_pictures_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -288,7 +286,7 @@ def measure(lib, pictures=64, steps=3, cpu_seconds=6.0):
 if __name__ == "__main__":
     import json
     import libav_amd
-    print(json.dumps(measure(libav_amd.load(0), int(sys.argv[1]) if len(sys.argv) > 1 else 64)))
+    print(json.dumps(measure(libav_amd.load(0), int(sys.argv[1]) if len(sys.argv) > 1 else 64, cpu_seconds=0)))
 
 
 # ---- the same pictures through the reference's own functions (oracle/ref_hevc_chain.c in oracle/_ref/libhevcfilterref.so) --------
