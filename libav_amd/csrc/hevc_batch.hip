@@ -460,6 +460,61 @@ __device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src
         dst[o0 + (ptrdiff_t)y * stride + k] = src[o0 + (ptrdiff_t)y * stride + k];
     }
 }
+/* eight neighbouring samples per lane: whole 16-byte (8-byte at 8 bit) pieces of a row */
+typedef uint32_t mi355_sao_u32x4a2 __attribute__((vector_size(16), aligned(2)));
+typedef uint32_t mi355_sao_u32x2a1 __attribute__((vector_size(8), aligned(1)));
+__device__ __forceinline__ void sao_ld8(const uint8_t *p, bool wide, int v[8])
+{
+    if (wide) {
+        const mi355_sao_u32x4a2 q = *reinterpret_cast<const mi355_sao_u32x4a2 *>(p);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[2 * k] = (int)(q[k] & 0xFFFFu); v[2 * k + 1] = (int)(q[k] >> 16); }
+    } else {
+        const mi355_sao_u32x2a1 q = *reinterpret_cast<const mi355_sao_u32x2a1 *>(p);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (int)((q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+    }
+}
+/* The whole region of an owner CTB in one pass when its pieces differ in nothing that matters: the band filter always (it
+ * knows no borders), the edge filter when no piece touches a picture border or an unfilterable slice / tile edge (every
+ * sample then has both neighbours and none is restored) — same arithmetic as hevc_sao_wave's fast forms (sao_band_filter,
+ * sao_edge_filter: hevcdsp_template.c:270-718), eight samples per lane, rows written in whole aligned pieces. */
+__device__ inline void sao_region_fast(uint8_t *dst, const uint8_t *src, int stride, int W, int H, bool edge, int eo, int band_position,
+                                       const int32_t *offset_val, int bd, int *tbl)
+{
+    const int lane = lane_id();
+    if (!edge) { if (lane < 32) { const int k = (lane - band_position) & 31; tbl[lane] = k < 4 ? offset_val[k + 1] : 0; } }
+    else if (lane < 5) tbl[lane] = offset_val[lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4)))];   /* edge_idx[] = {1,2,0,3,4} */
+    __syncthreads();
+    const bool wide = bd > 8;
+    const int px = wide ? 2 : 1, per = W >> 3, inv = mi355_inv20(per), shift = bd - 5;
+    const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
+    const ptrdiff_t da = (ptrdiff_t)dx0 * px + (ptrdiff_t)dy0 * stride;
+    for (int i = lane; i < per * H; i += 64) {
+        const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
+        const ptrdiff_t o = (ptrdiff_t)y * stride + (ptrdiff_t)x * px;
+        int c[8], v[8];
+        sao_ld8(src + o, wide, c);
+        if (!edge) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[c[k] >> shift], bd);
+        } else {
+            int a[8], b[8];
+            sao_ld8(src + o + da, wide, a);
+            sao_ld8(src + o - da, wide, b);
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[clip3(c[k] - a[k], -1, 1) + clip3(c[k] - b[k], -1, 1) + 2], bd);
+        }
+        if (wide) {
+            *reinterpret_cast<mi355_sao_u32x4a2 *>(dst + o) = mi355_sao_u32x4a2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                                                                               (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16) };
+        } else {
+            *reinterpret_cast<mi355_sao_u32x2a1 *>(dst + o) = mi355_sao_u32x2a1{ (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24),
+                                                                               (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24) };
+        }
+    }
+    __syncthreads();
+}
 __global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
@@ -470,6 +525,24 @@ __global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_j
     const uint8_t *src0 = mi355_global(j.src);
     __shared__ int tbl[32];
     const int st = stride / px, np = uniform(j.npieces);
+    /* piece 0 is the owner's own call (class 0): its size is the region's, its parameters are every piece's */
+    if (np >= 1 && uniform(j.piece[0].cls) == 0 && uniform(j.piece[0].dx) == 0 && uniform(j.piece[0].dy) == 0) {
+        const mi355_hevc_sao_piece &q0 = j.piece[0];
+        const int type = uniform(q0.type), W = uniform(q0.width), H = uniform(q0.height);
+        bool plain = true, same = true;
+        for (int k = 0; k < np && k < 4; k++) {
+            const mi355_hevc_sao_piece &q = j.piece[k];
+            plain = plain && !(uniform(q.borders) | uniform(q.vert_edge) | uniform(q.horiz_edge) | uniform(q.diag_edge));
+            same = same && uniform(q.type) == type;
+        }
+        if (same && type == 0) { sao_copy_region(dst0, src0, stride, 0, 0, W, H, px); return; }
+        if (same && (W & 7) == 0 && (type == 1 || (type == 2 && plain))) {
+            int32_t ov[5];
+            for (int e = 0; e < 5; e++) ov[e] = uniform(q0.offset_val[e]);
+            sao_region_fast(dst0, src0, stride, W, H, type == 2, uniform(q0.eo_class), uniform(q0.band_position), ov, bd, tbl);
+            return;
+        }
+    }
     for (int k = 0; k < np && k < 4; k++) {
         const mi355_hevc_sao_piece &q = j.piece[k];
         const int cls = uniform(q.cls), type = uniform(q.type), W = uniform(q.width), H = uniform(q.height), bo = uniform(q.borders);

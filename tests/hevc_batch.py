@@ -399,7 +399,12 @@ def sao_ctb_pieces(cx, cy, cw, chn, params, slice_addr, filter_edges):
     return [(k, params[here - (k & 1) * cw - (k >> 1)], vert[k], horiz[k], diag[k]) for k in order], [int(cx == 0), int(cy == 0), int(cx == cw - 1), int(cy == chn - 1)]
 
 
-def check_sao_ctbs(prov, oracle, bd, seed, size=(200, 150), log2_ctb=6):
+def check_sao_ctbs(prov, oracle, bd, seed, sizes=((200, 150), (328, 264)), log2_ctb=6):
+    """two pictures: 4 x 3 CTBs (every CTB touches a border or a slice edge somewhere) and 6 x 5 (interior CTBs take the whole-region forms)"""
+    return sum(_check_sao_ctbs(prov, oracle, bd, seed + 7 * i, size, log2_ctb) for i, size in enumerate(sizes))
+
+
+def _check_sao_ctbs(prov, oracle, bd, seed, size, log2_ctb):
     """mi355_hevc_sao_ctbs_dev (one job per CTB component: the up to four reference calls that make up the CTB's own samples) on a whole 4:2:0 picture with ragged
     last CTBs, random parameters (off / band / edge), two slices with and without filtering across their edge — against
     sao_filter_CTB restated over the oracle's table functions: per CTB in raster order, copy_CTB of the CTB shifted by 8 / 4, then
