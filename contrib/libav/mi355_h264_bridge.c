@@ -91,6 +91,7 @@ void __real_ff_h264_filter_mb_fast(const H264Context *h, H264SliceContext *sl, i
 
 struct Bridge;
 struct Staging;
+struct Disp;
 
 typedef struct DevPic {
     const H264Picture *owner;
@@ -138,6 +139,8 @@ typedef struct Bridge {
     int state;                  /* 0 new, 1 active, -1 stepped aside */
     int soft;                   /* stepped aside because of the SEQUENCE's format: the next sequence is looked at again */
     int lazy, direct;
+    int device;                 /* the GPU this decoder was dealt to */
+    struct Disp *disp;          /* ... and its dispatcher (batched mode) */
     mi355_h264_session *sess;   /* MI355_BRIDGE_SESSION: pictures go through a whole-frame session; pics[i] is surface i */
     int null_submit;            /* MI355_BRIDGE_NULL (developer): pictures are packed and dropped — times the host side alone */
     int mb_w, mb_h, nmb;
@@ -231,7 +234,9 @@ static int staging_alloc(Bridge *b, Staging *s)
 
 /* ---- the dispatcher: one thread, one HIP stream, the pictures of all streams ---------------------------------------- */
 #define DISP_DEPTH 4            /* launch sets in flight, each on its own HIP stream */
-static struct {
+#define DISP_MAX_DEVICES 16     /* one dispatcher (thread pair, streams) per GPU of the node that decoders were dealt to */
+typedef struct Disp {
+    int device;
     pthread_mutex_t mu;
     pthread_cond_t work, filled, finished;
     pthread_t thread, completer;
@@ -247,7 +252,10 @@ static struct {
     unsigned long issued, completed;        /* launch sets handed to the device / known complete: set q lives in slot q % DISP_DEPTH */
     int32_t widths[DISP_MAX_LEVELS];
     unsigned long batches, pictures;
-} disp = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+} Disp;
+static Disp disps[DISP_MAX_DEVICES];
+static pthread_mutex_t disps_mu = PTHREAD_MUTEX_INITIALIZER;   /* creation of the dispatchers; each has its own lock afterwards */
+static int disps_ready, bridge_count;
 
 /* one launch set: a descriptor copy, the kernels for all its pictures (reconstruction from one descriptor array, loop
  * filter from a second one: they differ for the chroma planes of 4:4:4 pictures), one launch that brings the finished
@@ -255,90 +263,91 @@ static struct {
  * a small set is a chain of launches that each occupy a few compute units for microseconds, and several such chains
  * overlap on the device.  A picture whose predecessor of the same decoder is still in flight (MI355_BRIDGE_LAZY) makes
  * its set wait for that set's event. */
-static int disp_enqueue(int slot)
+static int disp_enqueue(Disp *D, int slot)
 {
-    const int n = disp.nin[slot];
-    void *st = disp.stream[slot];
+    const int n = D->nin[slot];
+    void *st = D->stream[slot];
     int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0, ncopy = 0, ncvt = 0, cw = 0, chh = 0;
     size_t max_bytes = 0;
-    for (int i = 0; i < n; i++) nd += disp.in[slot][i]->b->npass;
-    mi355_h264_frame *hr = disp.h_desc[slot], *hd = disp.h_desc[slot] + nd;      /* reconstruction | loop filter */
+    for (int i = 0; i < n; i++) nd += D->in[slot][i]->b->npass;
+    mi355_h264_frame *hr = D->h_desc[slot], *hd = D->h_desc[slot] + nd;      /* reconstruction | loop filter */
     for (int i = 0, k = 0; i < n; i++) {
-        Submission *sub = disp.in[slot][i];
+        Submission *sub = D->in[slot][i];
         const Staging *s = sub->s;
         const Bridge *b = sub->b;
         const size_t bytes = picture_bytes(b);
-        if (sub->after) rc |= mi355_stream_wait_event(st, disp.ev[(sub->after - 1) % DISP_DEPTH]);
+        if (sub->after) rc |= mi355_stream_wait_event(st, D->ev[(sub->after - 1) % DISP_DEPTH]);
         if (b->mb_w > mw) mw = b->mb_w;
         if (b->mb_h > mh) mh = b->mb_h;
         for (int l = 0; l < s->maxl; l++)
-            if (l >= maxl || s->widths[l] > disp.widths[l]) disp.widths[l] = s->widths[l];
+            if (l >= maxl || s->widths[l] > D->widths[l]) D->widths[l] = s->widths[l];
         if (s->maxl > maxl) maxl = s->maxl;
         for (int p = 0; p < b->npass; p++, k++) { hr[k] = s->desc[p]; hd[k] = s->desc[b->npass + p]; }
         if (b->tiled) {
-            convert_job(b, s->pic, s->out, &disp.cvt[slot][ncvt++]);
+            convert_job(b, s->pic, s->out, &D->cvt[slot][ncvt++]);
             if (b->mb_w > cw) cw = b->mb_w;
             if (b->mb_h > chh) chh = b->mb_h;
         } else {
-            disp.jobs[slot][ncopy].src = s->pic->plane[0]; disp.jobs[slot][ncopy].dst = s->out; disp.jobs[slot][ncopy].bytes = bytes;
+            D->jobs[slot][ncopy].src = s->pic->plane[0]; D->jobs[slot][ncopy].dst = s->out; D->jobs[slot][ncopy].bytes = bytes;
             ncopy++;
             if (bytes > max_bytes) max_bytes = bytes;
         }
     }
-    mi355_h264_frame *dr = disp.d_desc[slot], *dd = disp.d_desc[slot] + nd;
+    mi355_h264_frame *dr = D->d_desc[slot], *dd = D->d_desc[slot] + nd;
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
     if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
-    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, disp.widths, st) != 0) rc = -1;
+    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, st) != 0) rc = -1;
-    if (!rc && ncopy && mi355_copy_batch_dev(disp.jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
-    if (!rc && ncvt && mi355_h264_surface_convert_dev(disp.cvt[slot], ncvt, cw, chh, st) != 0) rc = -1;
-    rc |= mi355_event_record(disp.ev[slot], st);
+    if (!rc && ncopy && mi355_copy_batch_dev(D->jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
+    if (!rc && ncvt && mi355_h264_surface_convert_dev(D->cvt[slot], ncvt, cw, chh, st) != 0) rc = -1;
+    rc |= mi355_event_record(D->ev[slot], st);
     return rc;
 }
 
 /* takes what the decoder threads have queued into the next free slot and issues it */
 static void *disp_main(void *arg)
 {
-    (void)arg;
-    pthread_mutex_lock(&disp.mu);
+    Disp *D = arg;
+    mi355_set_device(D->device);
+    pthread_mutex_lock(&D->mu);
     for (;;) {
         /* issue when the device is idle, or when enough pictures wait to make another set worth its launches (a quarter of
          * the decoders: up to four sets of that size are in flight); a remainder goes out when the sets before it are back */
         for (;;) {
-            const unsigned long inflight = disp.issued - disp.completed;
-            if (disp.head && (inflight == 0 || (inflight < DISP_DEPTH && 4 * disp.nqueued >= disp.nbridges))) break;
-            pthread_cond_wait(&disp.work, &disp.mu);
+            const unsigned long inflight = D->issued - D->completed;
+            if (D->head && (inflight == 0 || (inflight < DISP_DEPTH && 4 * D->nqueued >= D->nbridges))) break;
+            pthread_cond_wait(&D->work, &D->mu);
         }
         /* what is queued now, at most one picture per stream (a stream's next picture reads this one's output) */
-        const int slot = (int)(disp.issued % DISP_DEPTH);
-        Submission *keep_head = NULL, *keep_tail = NULL, *c = disp.head;
+        const int slot = (int)(D->issued % DISP_DEPTH);
+        Submission *keep_head = NULL, *keep_tail = NULL, *c = D->head;
         int n = 0, nd = 0;
         while (c) {
             Submission *nx = c->next;
             int later = nd + c->b->npass > DISP_MAX_BATCH;
-            for (int i = 0; i < n && !later; i++) later = disp.in[slot][i]->b == c->b;
+            for (int i = 0; i < n && !later; i++) later = D->in[slot][i]->b == c->b;
             if (later) {
                 c->next = NULL;
                 if (keep_tail) keep_tail->next = c; else keep_head = c;
                 keep_tail = c;
             } else {
                 /* the set that holds this decoder's previous picture, if that has not come back yet */
-                c->after = c->b->last_set > disp.completed ? c->b->last_set : 0;
-                c->b->last_set = disp.issued + 1;
-                disp.in[slot][n++] = c; nd += c->b->npass;
-                disp.nqueued--;
+                c->after = c->b->last_set > D->completed ? c->b->last_set : 0;
+                c->b->last_set = D->issued + 1;
+                D->in[slot][n++] = c; nd += c->b->npass;
+                D->nqueued--;
             }
             c = nx;
         }
-        disp.head = keep_head; disp.tail = keep_tail;
-        disp.nin[slot] = n;
-        disp.batches++; disp.pictures += (unsigned long)n;
-        pthread_mutex_unlock(&disp.mu);
-        const int rc = disp_enqueue(slot);
-        pthread_mutex_lock(&disp.mu);
-        disp.rcs[slot] = rc;
-        disp.issued++;
-        pthread_cond_signal(&disp.filled);
+        D->head = keep_head; D->tail = keep_tail;
+        D->nin[slot] = n;
+        D->batches++; D->pictures += (unsigned long)n;
+        pthread_mutex_unlock(&D->mu);
+        const int rc = disp_enqueue(D, slot);
+        pthread_mutex_lock(&D->mu);
+        D->rcs[slot] = rc;
+        D->issued++;
+        pthread_cond_signal(&D->filled);
     }
     return NULL;
 }
@@ -346,44 +355,56 @@ static void *disp_main(void *arg)
 /* waits for the launch sets in the order they were issued and tells their decoder threads */
 static void *disp_complete(void *arg)
 {
-    (void)arg;
-    pthread_mutex_lock(&disp.mu);
+    Disp *D = arg;
+    mi355_set_device(D->device);
+    pthread_mutex_lock(&D->mu);
     for (;;) {
-        while (disp.completed == disp.issued) pthread_cond_wait(&disp.filled, &disp.mu);
-        const int slot = (int)(disp.completed % DISP_DEPTH);
-        pthread_mutex_unlock(&disp.mu);
-        const int rc = mi355_event_sync(disp.ev[slot]);
-        pthread_mutex_lock(&disp.mu);
-        for (int i = 0; i < disp.nin[slot]; i++) { disp.in[slot][i]->rc = rc | disp.rcs[slot]; disp.in[slot][i]->done = 1; }
-        disp.completed++;
-        pthread_cond_broadcast(&disp.finished);
-        pthread_cond_signal(&disp.work);
+        while (D->completed == D->issued) pthread_cond_wait(&D->filled, &D->mu);
+        const int slot = (int)(D->completed % DISP_DEPTH);
+        pthread_mutex_unlock(&D->mu);
+        const int rc = mi355_event_sync(D->ev[slot]);
+        pthread_mutex_lock(&D->mu);
+        for (int i = 0; i < D->nin[slot]; i++) { D->in[slot][i]->rc = rc | D->rcs[slot]; D->in[slot][i]->done = 1; }
+        D->completed++;
+        pthread_cond_broadcast(&D->finished);
+        pthread_cond_signal(&D->work);
     }
     return NULL;
 }
 
-static int disp_start(void)
+/* the dispatcher of `device` (the calling thread is on that device) */
+static Disp *disp_start(int device)
 {
-    pthread_mutex_lock(&disp.mu);
-    if (!disp.started && !disp.broken) {
-        int ok = 1;
-        for (int k = 0; k < DISP_DEPTH && ok; k++) {
-            disp.stream[k] = mi355_stream_create();
-            disp.ev[k] = mi355_event_create();
-            disp.h_desc[k] = mi355_host_alloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
-            disp.d_desc[k] = dalloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
-            disp.jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
-            disp.cvt[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_surface_job));
-            ok = disp.stream[k] && disp.ev[k] && disp.h_desc[k] && disp.d_desc[k] && disp.jobs[k] && disp.cvt[k];
+    if (device < 0 || device >= DISP_MAX_DEVICES) return NULL;
+    Disp *D = &disps[device];
+    pthread_mutex_lock(&disps_mu);
+    if (!disps_ready) {
+        for (int i = 0; i < DISP_MAX_DEVICES; i++) {
+            pthread_mutex_init(&disps[i].mu, NULL);
+            pthread_cond_init(&disps[i].work, NULL); pthread_cond_init(&disps[i].filled, NULL); pthread_cond_init(&disps[i].finished, NULL);
         }
-        if (ok && pthread_create(&disp.thread, NULL, disp_main, NULL) == 0 && pthread_create(&disp.completer, NULL, disp_complete, NULL) == 0) {
-            pthread_detach(disp.thread); pthread_detach(disp.completer);
-            disp.started = 1;
-        } else disp.broken = 1;
+        disps_ready = 1;
     }
-    const int ok = disp.started;
-    pthread_mutex_unlock(&disp.mu);
-    return ok;
+    if (!D->started && !D->broken) {
+        int ok = 1;
+        D->device = device;
+        for (int k = 0; k < DISP_DEPTH && ok; k++) {
+            D->stream[k] = mi355_stream_create();
+            D->ev[k] = mi355_event_create();
+            D->h_desc[k] = mi355_host_alloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            D->d_desc[k] = dalloc(2 * DISP_MAX_BATCH * sizeof(mi355_h264_frame));
+            D->jobs[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_copy_job));
+            D->cvt[k] = mi355_host_alloc(DISP_MAX_BATCH * sizeof(mi355_surface_job));
+            ok = D->stream[k] && D->ev[k] && D->h_desc[k] && D->d_desc[k] && D->jobs[k] && D->cvt[k];
+        }
+        if (ok && pthread_create(&D->thread, NULL, disp_main, D) == 0 && pthread_create(&D->completer, NULL, disp_complete, D) == 0) {
+            pthread_detach(D->thread); pthread_detach(D->completer);
+            D->started = 1;
+        } else D->broken = 1;
+    }
+    const int ok = D->started;
+    pthread_mutex_unlock(&disps_mu);
+    return ok ? D : NULL;
 }
 
 static int finish_set(Bridge *b, Staging *s);
@@ -409,7 +430,7 @@ static void bridge_release(Bridge *b)
 {
     if (b->state > 0) {
         finish_all(b);
-        if (!b->direct) { pthread_mutex_lock(&disp.mu); disp.nbridges--; pthread_mutex_unlock(&disp.mu); }
+        if (!b->direct && b->disp) { pthread_mutex_lock(&b->disp->mu); b->disp->nbridges--; pthread_mutex_unlock(&b->disp->mu); }
     }
     staging_free(&b->st[0]); staging_free(&b->st[1]);
     for (int p = 0; p < 3; p++) { if (b->recon[p]) mi355_free(b->recon[p]); b->recon[p] = NULL; }
@@ -470,8 +491,25 @@ static Bridge *bridge_get(const H264Context *h)
         b->soft = 1;
         return b;
     }
-    const char *dev = getenv("MI355_DEVICE");
-    if (mi355_init(dev ? atoi(dev) : 0) != 0) { br_fail(b, "no usable MI355X"); return b; }
+    /* which GPU: MI355_DEVICE=n names one; MI355_DEVICES=N (or "all") deals the decoders of this process over the first N GPUs of
+     * the node, decoder k -> device k mod N — one host process driving the whole node, each decoder's decoded-picture buffer in its
+     * own GPU's HBM, one dispatcher per GPU, nothing shared between them */
+    {
+        const char *dev = getenv("MI355_DEVICE"), *devs = getenv("MI355_DEVICES");
+        int device = dev ? atoi(dev) : 0;
+        if (!dev && devs) {
+            int n = strcmp(devs, "all") ? atoi(devs) : mi355_device_count();
+            if (n > mi355_device_count()) n = mi355_device_count();
+            if (n > DISP_MAX_DEVICES) n = DISP_MAX_DEVICES;
+            pthread_mutex_lock(&disps_mu);
+            const int k = bridge_count++;
+            pthread_mutex_unlock(&disps_mu);
+            device = n > 0 ? k % n : 0;
+        }
+        if (mi355_get_device() < 0 && mi355_init(device) != 0) { br_fail(b, "no usable MI355X"); return b; }
+        if (mi355_set_device(device) != 0) { br_fail(b, "no usable MI355X"); return b; }      /* this decoder thread works on its GPU from now on */
+        b->device = device;
+    }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
     /* frame_num gaps: the decoder fills a lost frame with a host-side copy of the previous one (h264_slice.c:1425-1452) — every
@@ -495,12 +533,12 @@ static Bridge *bridge_get(const H264Context *h)
         b->direct = 1; b->lazy = 0;                  /* nothing goes through the dispatcher; every picture is complete at its end */
     }
     if (ok && b->direct && !b->sess) ok = (b->stream = mi355_stream_create()) != NULL;
-    if (ok && !b->direct) ok = disp_start();
+    if (ok && !b->direct) ok = (b->disp = disp_start(b->device)) != NULL;
     ok = ok && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
     for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[b->c444 ? 0 : p > 0])) != NULL;
     for (int p = 0; p < 2 && ok && b->c444; p++) ok = (b->scratch_c[p] = dalloc(b->plane_bytes[1])) != NULL;
     if (!ok) { br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
-    if (!b->direct) { pthread_mutex_lock(&disp.mu); disp.nbridges++; pthread_mutex_unlock(&disp.mu); }
+    if (!b->direct) { pthread_mutex_lock(&b->disp->mu); b->disp->nbridges++; pthread_mutex_unlock(&b->disp->mu); }
     b->st[0].sub.b = b->st[1].sub.b = b;
     b->st[0].sub.s = &b->st[0]; b->st[1].sub.s = &b->st[1];
     b->state = 1;
@@ -591,10 +629,11 @@ static int finish_set(Bridge *b, Staging *s)
     int rc;
     if (b->direct) rc = mi355_event_sync(s->done);
     else {
-        pthread_mutex_lock(&disp.mu);
-        while (!s->sub.done) pthread_cond_wait(&disp.finished, &disp.mu);
+        Disp *D = b->disp;
+        pthread_mutex_lock(&D->mu);
+        while (!s->sub.done) pthread_cond_wait(&D->finished, &D->mu);
         rc = s->sub.rc;
-        pthread_mutex_unlock(&disp.mu);
+        pthread_mutex_unlock(&D->mu);
     }
     s->in_flight = 0;
     if (rc) return rc;
@@ -946,13 +985,14 @@ static int submit_picture(Bridge *b, H264Context *h)
         } else if (mi355_memcpy_d2h_async(s->out, cur->plane[0], picture_bytes(b), b->stream)) return -5;
         if (mi355_event_record(s->done, b->stream)) return -5;
     } else {
-        pthread_mutex_lock(&disp.mu);
+        Disp *D = b->disp;
+        pthread_mutex_lock(&D->mu);
         s->sub.done = 0; s->sub.rc = 0; s->sub.next = NULL;
-        if (disp.tail) disp.tail->next = &s->sub; else disp.head = &s->sub;
-        disp.tail = &s->sub;
-        disp.nqueued++;
-        pthread_cond_signal(&disp.work);
-        pthread_mutex_unlock(&disp.mu);
+        if (D->tail) D->tail->next = &s->sub; else D->head = &s->sub;
+        D->tail = &s->sub;
+        D->nqueued++;
+        pthread_cond_signal(&D->work);
+        pthread_mutex_unlock(&D->mu);
     }
     s->in_flight = 1;
     b->pictures++;
@@ -1011,10 +1051,16 @@ void mi355_h264_bridge_stats(unsigned long *pictures, unsigned long *staging_wai
 /* launch sets the dispatcher issued and the pictures they held (process-wide) */
 void mi355_h264_bridge_batch_stats(unsigned long *batches, unsigned long *pictures)
 {
-    pthread_mutex_lock(&disp.mu);
-    if (batches) *batches = disp.batches;
-    if (pictures) *pictures = disp.pictures;
-    pthread_mutex_unlock(&disp.mu);
+    unsigned long nb = 0, np = 0;
+    pthread_mutex_lock(&disps_mu);
+    for (int i = 0; i < DISP_MAX_DEVICES && disps_ready; i++) {
+        pthread_mutex_lock(&disps[i].mu);
+        nb += disps[i].batches; np += disps[i].pictures;
+        pthread_mutex_unlock(&disps[i].mu);
+    }
+    pthread_mutex_unlock(&disps_mu);
+    if (batches) *batches = nb;
+    if (pictures) *pictures = np;
 }
 /* a decoder thread that ends (or flushes with MI355_BRIDGE_LAZY) calls this: everything it submitted is complete and in
  * its frames afterwards */

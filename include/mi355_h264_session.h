@@ -39,7 +39,9 @@ typedef struct mi355_h264_session_params {
                                          decoded picture buffer keeps its pictures macroblock-tiled (mi355_h264_frame.h) — the fast
                                          layout; frame pictures only (start_frame() with field != 0 fails), get_frame() / put_frame() /
                                          export_frame_dev() convert on the device */
-    int32_t reserved0;
+    int32_t device;                   /* 0: the calling thread's device (mi355_set_device(), else mi355_init()'s); n > 0: device n - 1.  A
+                                         session (and everything it owns) lives on one device; its entry points switch the calling thread to
+                                         it for the duration of the call.  Sessions of a group must live on the group's device */
 } mi355_h264_session_params;
 
 typedef struct mi355_h264_picture_params {
@@ -93,7 +95,7 @@ void *mi355_h264_session_stream(mi355_h264_session *s);
  * threads serialise around it, as contrib/libav/mi355_h264_bridge.c does with its dispatcher).  Close the sessions before
  * destroying the group. */
 typedef struct mi355_h264_group mi355_h264_group;
-int  mi355_h264_group_create(mi355_h264_group **out);
+int  mi355_h264_group_create(mi355_h264_group **out);             /* on the calling thread's device */
 void mi355_h264_group_destroy(mi355_h264_group *g);
 int  mi355_h264_session_open_grouped(mi355_h264_session **out, const mi355_h264_session_params *p, mi355_h264_group *g);
 int  mi355_h264_group_flush(mi355_h264_group *g);

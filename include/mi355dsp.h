@@ -32,6 +32,13 @@ extern "C" {
  * device or it is not gfx950. */
 int mi355_init(int device);
 int mi355_device_cus(void);
+/* One host process, several GPUs: mi355_init() names the process default; a thread that calls mi355_set_device(d) works on
+ * device d from then on (allocations, copies, launches, Tier-1 staging), -1 returns it to the default.  Sessions, groups and
+ * swscale contexts remember the device of the thread that created them and switch to it inside their entry points.  0 on
+ * success, <0 as mi355_init(). */
+int mi355_set_device(int device);
+int mi355_get_device(void);
+int mi355_device_count(void);
 
 /* replaces ff_h264dsp_init_{x86,arm,...}   libavcodec/h264dsp.h:119-128, call site h264dsp.c:139-142 */
 void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int chroma_format_idc);

@@ -8,12 +8,22 @@
 #include <new>
 #include <vector>
 #include "../../include/mi355_h264_session.h"
+#include "../../include/mi355dsp.h"
 
 namespace {
 
 constexpr int NSETS = 2;                 /* staging sets: one is filled by the host while the other's copy is in flight */
 constexpr unsigned NJOBS = 64;           /* conversion jobs in flight per session */
 constexpr size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+/* the calling thread works on a context's device for the duration of an entry point (public C ABI only, like the rest of this file) */
+struct OnDevice {
+    int prev;
+    explicit OnDevice(int device) : prev(mi355_get_device()) { if (device >= 0 && device != prev) (void)mi355_set_device(device); else prev = -2; }
+    ~OnDevice() { if (prev != -2) (void)mi355_set_device(prev); }
+    OnDevice(const OnDevice &) = delete;
+    OnDevice &operator=(const OnDevice &) = delete;
+};
 
 struct Layout {                          /* byte offsets inside a staging block (host and device blocks share it) */
     size_t desc, slices, mb, mv0, mv1, coef, ilist, istart, total;
@@ -29,6 +39,7 @@ struct Set {
 }  // namespace
 
 struct mi355_h264_group {
+    int device = -1;
     void *stream = nullptr;
     std::vector<mi355_h264_session *> pending;      /* sessions whose latest picture waits for the next flush */
     mi355_h264_frame *h_desc = nullptr, *d_desc = nullptr;   /* pinned / device: the flush's descriptor array */
@@ -40,6 +51,7 @@ struct mi355_h264_group {
 };
 
 struct mi355_h264_session {
+    int device = -1;
     mi355_h264_group *group = nullptr;
     bool pending = false;                 /* grouped: the picture of staging set `cur` has not been launched yet */
     int pend_levels = 0;
@@ -73,6 +85,7 @@ struct mi355_h264_session {
 extern "C" void mi355_h264_session_close(mi355_h264_session *s)
 {
     if (!s) return;
+    OnDevice on(s->device);
     if (s->group && s->pending) mi355_h264_group_flush(s->group);
     if (s->stream) mi355_sync(s->stream);
     if (s->copy_stream) mi355_sync(s->copy_stream);
@@ -102,8 +115,13 @@ static int session_open_impl(mi355_h264_session **out, const mi355_h264_session_
     if (!out || !p || p->mb_width <= 0 || p->mb_height <= 0 || p->num_surfaces < 2 || p->num_surfaces > 64 || p->max_slices < 0 || p->max_slices > 255) return -1;
     if (p->surface_layout != MI355_SURFACE_LINEAR && p->surface_layout != MI355_SURFACE_TILED) return -1;
     if ((long)p->mb_width * p->mb_height >= (1L << 24)) return -1;
+    if (p->device < 0 || p->device > mi355_device_count()) return -1;
+    const int device = p->device > 0 ? p->device - 1 : mi355_get_device();
+    if (device < 0 || (g && g->device != device)) return -1;      /* no device chosen yet / not the group's */
+    OnDevice on(device);
     mi355_h264_session *s = new (std::nothrow) mi355_h264_session;
     if (!s) return -3;
+    s->device = device;
     s->mb_w = p->mb_width; s->mb_h = p->mb_height; s->nmb = p->mb_width * p->mb_height;
     s->nsurf = p->num_surfaces; s->max_slices = p->max_slices ? p->max_slices : 64;
     /* surfaces: rows of whole 64-byte (luma) / 32-byte (chroma) pieces, the alignment the kernels' 16 / 8-byte paths want */
@@ -167,6 +185,7 @@ extern "C" int mi355_h264_session_open_grouped(mi355_h264_session **out, const m
 extern "C" int mi355_h264_start_frame(mi355_h264_session *s, const mi355_h264_picture_params *pp)
 {
     if (!s || !pp || s->open) return -1;
+    OnDevice on(s->device);
     /* grouped: this session's previous picture still waits for a launch — it may be a reference of this one, and its staging
      * set comes up for reuse after the next: everything waiting goes out now */
     if (s->group && s->pending) { const int rc = mi355_h264_group_flush(s->group); if (rc) return rc; }
@@ -229,6 +248,7 @@ extern "C" int mi355_h264_decode_slice(mi355_h264_session *s, const mi355_h264_s
 extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
 {
     if (!s || !s->open) return -1;
+    OnDevice on(s->device);
     s->open = false;
     if (s->ncovered != s->nmb_pic || s->nslices == 0) return -4;
     Set &st = s->set[s->cur];
@@ -294,6 +314,7 @@ static int flush_if_pending(mi355_h264_session *s) { return s->group && s->pendi
 extern "C" int mi355_h264_surface_wait(mi355_h264_session *s, int surface)
 {
     if (!s || surface < 0 || surface >= s->nsurf) return -1;
+    OnDevice on(s->device);
     if (flush_if_pending(s) != 0) return -2;
     if (!s->surf_valid[surface]) return -1;
     return mi355_event_sync(s->surf_done[surface]) == 0 ? 0 : -2;
@@ -316,6 +337,7 @@ static int convert(mi355_h264_session *s, int surface, uint8_t *const lin[3], co
 extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3])
 {
     if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf) return -1;
+    OnDevice on(s->device);
     if (flush_if_pending(s) != 0) return -2;
     if (!s->surf_valid[surface]) return -1;
     /* on the copy stream, behind the picture's event: later pictures queued on the session's stream are not waited for */
@@ -339,6 +361,8 @@ extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t 
 extern "C" int mi355_h264_put_frame(mi355_h264_session *s, int surface, const uint8_t *const src[3], const int src_stride[3])
 {
     if (!s || !src || !src_stride || s->open || surface < 0 || surface >= s->nsurf) return -1;
+    OnDevice on(s->device);
+
     if (flush_if_pending(s) != 0) return -2;
     const size_t img_bytes = s->tiled ? s->lin_bytes : s->surf_bytes;
     uint8_t *img = static_cast<uint8_t *>(std::malloc(img_bytes));
@@ -375,6 +399,7 @@ extern "C" const uint8_t *mi355_h264_surface_dev(mi355_h264_session *s, int surf
 extern "C" int mi355_h264_export_frame_dev(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3], void *stream)
 {
     if (!s || !dst || !dst_stride || surface < 0 || surface >= s->nsurf) return -1;
+    OnDevice on(s->device);
     if (flush_if_pending(s) != 0) return -2;
     if (!s->surf_valid[surface]) return -1;
     for (int p = 0; p < 3; p++)
@@ -395,8 +420,10 @@ extern "C" void *mi355_h264_session_stream(mi355_h264_session *s) { return s ? s
 extern "C" int mi355_h264_group_create(mi355_h264_group **out)
 {
     if (!out) return -1;
+    if (mi355_get_device() < 0) return -1;
     mi355_h264_group *g = new (std::nothrow) mi355_h264_group;
     if (!g) return -3;
+    g->device = mi355_get_device();
     g->stream = mi355_stream_create();
     g->copied = mi355_event_create();
     if (!g->stream || !g->copied) { mi355_h264_group_destroy(g); return -3; }
@@ -407,6 +434,7 @@ extern "C" int mi355_h264_group_create(mi355_h264_group **out)
 extern "C" void mi355_h264_group_destroy(mi355_h264_group *g)
 {
     if (!g) return;
+    OnDevice on(g->device);
     if (g->stream) mi355_sync(g->stream);
     if (g->h_desc) mi355_host_free(g->h_desc);
     if (g->d_desc) mi355_free(g->d_desc);
@@ -418,6 +446,7 @@ extern "C" void mi355_h264_group_destroy(mi355_h264_group *g)
 extern "C" int mi355_h264_group_flush(mi355_h264_group *g)
 {
     if (!g) return -1;
+    OnDevice on(g->device);
     const int n = (int)g->pending.size();
     if (!n) return 0;
     if (n > g->cap) {

@@ -760,7 +760,8 @@ __global__ void __launch_bounds__(64) k_hevc_intra_blocks(const mi355_hevc_intra
 
 bool check(int bit_depth, const void *jobs, int n)
 {
-    if (!ready()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
+    /* bind(): the calling thread's device (mi355_set_device, else mi355_init's) — not whatever device the thread last used */
+    if (!bind()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
     return jobs && n > 0 && (bit_depth == 8 || bit_depth == 9 || bit_depth == 10);
 }
 

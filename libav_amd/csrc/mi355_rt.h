@@ -104,6 +104,7 @@ struct Arena {
     uint8_t *host = nullptr;   /* pinned */
     uint8_t *dev = nullptr;
     size_t cap = 0, used = 0;
+    int device = -1;           /* the device `dev` and `stream` live on */
 
     void ensure();
     void reset() { used = 0; }
@@ -145,9 +146,18 @@ Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int row
 void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows);
 
 bool ready();
-/* bind the calling thread to the device chosen in mi355_init() (the reference calls the tables and the batch entry points
+int current_device();
+/* bind the calling thread to its device — mi355_set_device() of this thread, else the one chosen in mi355_init() (the reference calls the tables and the batch entry points
  * from frame / slice threads; a thread that never set a device would use device 0); false without a successful init */
 bool bind();
+/* inside a context's entry point: the calling thread works on the context's device until the scope ends */
+struct DeviceScope {
+    int prev;
+    explicit DeviceScope(int device);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 }  // namespace mi355
 #endif

@@ -5,14 +5,33 @@
 
 namespace mi355 {
 
-static std::atomic<int> g_device{-1};
+static std::atomic<int> g_device{-1};     /* the process default: mi355_init() */
+static thread_local int t_device = -1;    /* this thread's own device: mi355_set_device(); -1 = the process default */
+static std::atomic<unsigned> g_checked{0};   /* bit d: device d was found to be a gfx950 */
 
-bool ready() { return g_device.load(std::memory_order_acquire) >= 0; }
+int current_device() { return t_device >= 0 ? t_device : g_device.load(std::memory_order_acquire); }
+bool ready() { return current_device() >= 0; }
+
+/* 0, or mi355_init()'s error codes */
+static int check_device(int device)
+{
+    int n = 0;
+    if (device < 0 || hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return -1;
+    if (device < 32 && (g_checked.load(std::memory_order_acquire) >> device) & 1u) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -2;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "mi355dsp: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return -3;
+    }
+    if (device < 32) g_checked.fetch_or(1u << device, std::memory_order_acq_rel);
+    return 0;
+}
 
 bool bind()
 {
     static thread_local int bound = -1;
-    const int d = g_device.load(std::memory_order_acquire);
+    const int d = current_device();
     if (d < 0) return false;
     if (bound != d) {
         if (hipSetDevice(d) != hipSuccess) return false;
@@ -21,15 +40,30 @@ bool bind()
     return true;
 }
 
+DeviceScope::DeviceScope(int device) : prev(t_device)
+{
+    if (device >= 0) { t_device = device; (void)bind(); }
+}
+DeviceScope::~DeviceScope()
+{
+    if (t_device != prev) { t_device = prev; (void)bind(); }
+}
+
 void Arena::ensure()
 {
-    if (dev) return;
+    if (dev && device == current_device()) return;
+    if (dev) {
+        /* the thread moved to another device (mi355_set_device): its staging follows */
+        { DeviceScope back(device); (void)hipStreamSynchronize(stream); (void)hipHostFree(host); (void)hipFree(dev); (void)hipStreamDestroy(stream); }
+        host = dev = nullptr; stream = nullptr; cap = used = 0;
+    }
     if (!bind()) {
         std::fprintf(stderr, "mi355dsp: mi355_init() was not called or found no GPU; "
                              "there is no CPU fallback in this library\n");
         std::abort();
     }
     cap = 4 << 20;
+    device = current_device();
     MI355_CHECK(hipStreamCreate(&stream));
     MI355_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), cap));
     MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), cap));
@@ -89,22 +123,35 @@ void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, 
 
 extern "C" int mi355_init(int device)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return -1;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -2;
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        std::fprintf(stderr, "mi355dsp: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
-        return -3;
-    }
+    const int rc = mi355::check_device(device);
+    if (rc) return rc;
     if (hipSetDevice(device) != hipSuccess) return -4;
     mi355::g_device.store(device, std::memory_order_release);
     return 0;
 }
 
+/* One host process, several GPUs (the reference's model is one process with a thread per stream, pthread_frame.c:502-541): a
+ * thread chooses ITS device; everything it allocates, copies and launches through this library from then on lives there.
+ * -1 goes back to the process default.  Contexts (sessions, groups, swscale contexts) remember the device they were made on
+ * and switch to it inside their entry points, whichever thread calls. */
+extern "C" int mi355_set_device(int device)
+{
+    if (device < 0) { mi355::t_device = -1; return mi355::bind() ? 0 : -1; }
+    const int rc = mi355::check_device(device);
+    if (rc) return rc;
+    mi355::t_device = device;
+    return mi355::bind() ? 0 : -4;
+}
+extern "C" int mi355_get_device(void) { return mi355::current_device(); }
+extern "C" int mi355_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int mi355_device_cus(void)
 {
     hipDeviceProp_t prop;
-    if (!mi355::ready() || hipGetDeviceProperties(&prop, mi355::g_device.load()) != hipSuccess) return -1;
+    if (!mi355::ready() || hipGetDeviceProperties(&prop, mi355::current_device()) != hipSuccess) return -1;
     return prop.multiProcessorCount;
 }

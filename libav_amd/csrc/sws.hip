@@ -631,6 +631,7 @@ struct mi355_sws_ctx {
     uint8_t *d_src[3] = {}, *d_dst = nullptr;
     mi355_sws_frame *d_frame = nullptr;
     hipStream_t stream = nullptr;
+    int device = -1;            /* the device of the thread that created the context: its entry points switch to it */
 };
 
 template <typename T> static const T *upload_bank(mi355_sws_ctx *c, int slot, const T *host, size_t n)
@@ -667,8 +668,9 @@ static int choose_rows(const mi355_sws_desc *d)
 
 extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
 {
-    if (!ready()) { std::fprintf(stderr, "mi355dsp: mi355_sws_create without mi355_init(); no CPU fallback\n"); std::abort(); }
+    if (!bind()) { std::fprintf(stderr, "mi355dsp: mi355_sws_create without mi355_init(); no CPU fallback\n"); std::abort(); }
     mi355_sws_ctx *c = new mi355_sws_ctx;
+    c->device = current_device();
     SwsDev &h = c->h;
     h.srcW = desc->srcW; h.srcH = desc->srcH; h.dstW = desc->dstW; h.dstH = desc->dstH;
     h.chrSrcW = desc->chrSrcW; h.chrSrcH = desc->chrSrcH; h.chrDstW = desc->chrDstW; h.special = desc->unscaled_special;
@@ -708,6 +710,7 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
 extern "C" void mi355_sws_destroy(mi355_sws_ctx *c)
 {
     if (!c) return;
+    DeviceScope on(c->device);
     for (void *p : c->banks) if (p) MI355_CHECK(hipFree(p));
     for (uint8_t *p : c->d_src) if (p) MI355_CHECK(hipFree(p));
     if (c->d_dst) MI355_CHECK(hipFree(c->d_dst));
@@ -721,6 +724,7 @@ extern "C" void mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fra
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SwsDev &h = c->h;
+    DeviceScope on(c->device);
     if (h.special) {
         hipLaunchKernelGGL(k_sws_c24, dim3((h.dstW + C24_COLS - 1) / C24_COLS, (h.srcH + C24_ROWS - 1) / C24_ROWS, nframes), dim3(NT), 0, s,
                            &c->d->luts, h.dstW, h.srcH, 0, d_frames);
@@ -739,6 +743,7 @@ static void plane_h2d(uint8_t *d, int dpitch, const uint8_t *h, int hstride, int
 extern "C" int mi355_sws_scale(mi355_sws_ctx *c, const uint8_t *const src[3], const int src_stride[3], uint8_t *dst, int dst_stride)
 {
     const SwsDev &h = c->h;
+    DeviceScope on(c->device);
     const int cw = h.chrSrcW, ch = h.chrSrcH;
     const int pw[3] = { (h.srcW + 15) & ~15, (cw + 15) & ~15, (cw + 15) & ~15 }, ph[3] = { h.srcH, ch, ch };
     const int dpitch = (h.dstW * 3 + 15) & ~15;

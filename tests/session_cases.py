@@ -15,7 +15,7 @@ MAX_SLOTS = HF.MAX_SLOTS
 
 class SessionParams(C.Structure):
     _fields_ = [("mb_width", C.c_int32), ("mb_height", C.c_int32), ("num_surfaces", C.c_int32), ("max_slices", C.c_int32),
-                ("surface_layout", C.c_int32), ("reserved0", C.c_int32)]
+                ("surface_layout", C.c_int32), ("device", C.c_int32)]
 
 
 class PictureParams(C.Structure):
@@ -56,12 +56,12 @@ class Group:
 
 
 class Session:
-    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0, group=None, tiled=False):
-        """tiled: the session keeps its surfaces macroblock-tiled (frame pictures only)"""
+    def __init__(self, lib, mb_w, mb_h, nsurf, max_slices=0, group=None, tiled=False, device=0):
+        """tiled: the session keeps its surfaces macroblock-tiled (frame pictures only); device: 0 = the calling thread's, n = device n - 1"""
         _bind(lib)
         self.lib, self.mb_w, self.mb_h = lib, mb_w, mb_h
         self.h = C.c_void_p()
-        p = SessionParams(mb_w, mb_h, nsurf, max_slices, 1 if tiled else 0, 0)
+        p = SessionParams(mb_w, mb_h, nsurf, max_slices, 1 if tiled else 0, device)
         rc = lib.mi355_h264_session_open_grouped(C.byref(self.h), C.byref(p), group.h) if group else lib.mi355_h264_session_open(C.byref(self.h), C.byref(p))
         assert rc == 0, rc
 
@@ -130,10 +130,10 @@ def send_picture(ss, mb, mv0, mv1, coef, slices, how):
             assert rc == 0, rc
 
 
-def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True, tiled=False):
+def run_stream(prov, npz, first=0, count=None, nsurf=3, sync_each=True, tiled=False, device=0):
     pics = SF.load_npz(npz)
     count = len(pics) - first if count is None else count
-    ss = Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, tiled=tiled)
+    ss = Session(prov.lib, pics[0]["mb_w"], pics[0]["mb_h"], nsurf, tiled=tiled, device=device)
     try:
         if first > 0:      # join the stream in the middle: the references of the first picture come from the fixture
             for s_ in pics[first]["slots"]:

@@ -42,7 +42,7 @@ def check_against_golden(raw, n):
 
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/libavcodec") and os.path.exists(CLIP)), reason="needs /root/reference and the sample clip")
 @pytest.mark.parametrize("lazy,direct,threads,linear", ((False, False, 1, False), (True, False, 1, False), (False, True, 1, False), (True, True, 1, False), (False, False, 3, False),
-                                                        (False, False, 1, True), (True, True, 1, True), (False, False, 1, "session")))
+                                                        (False, False, 1, True), (True, True, 1, True), (False, False, 1, "session"), (False, False, 1, "device1")))
 def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, threads, linear):
     """batched submission through the dispatcher thread (default) and direct submission (MI355_BRIDGE_DIRECT), complete
     at once or lazily; with 3 decoder threads the dispatcher's launch sets hold pictures of several streams"""
@@ -52,6 +52,9 @@ def test_bridge_decodes_realshort_on_the_emulator(tmp_path, emu, lazy, direct, t
     env = dict(os.environ)
     for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_LINEAR", "MI355_BRIDGE_SESSION"):
         env.pop(k, None)
+    if linear == "device1":                       # the second of two (emulated) GPUs: the decoder thread, its dispatcher and its pictures live there
+        env["MI355_EMU_DEVICES"], env["MI355_DEVICE"] = "2", "1"
+        linear = False
     if linear == "session":                       # the whole-frame session façade as the submission path
         env["MI355_BRIDGE_SESSION"] = "1"
         linear, direct = False, True

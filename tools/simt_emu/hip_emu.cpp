@@ -168,8 +168,19 @@ static void run_block(const std::function<void()> &body, unsigned nthreads)
     }
 }
 
+static long g_launches[16], g_alloc_bytes[16];
+int device_count()
+{
+    const char *e = std::getenv("MI355_EMU_DEVICES");
+    const int n = e ? std::atoi(e) : 1;
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+int &current_device() { static thread_local int d = 0; return d; }
+void note_alloc(size_t n) { g_alloc_bytes[current_device() & 15] += (long)n; }
+
 void launch(dim3 grid, dim3 block, const std::function<void()> &body)
 {
+    g_launches[current_device() & 15]++;
     g_gridDim = grid;
     g_blockDim = block;
     unsigned nthreads = block.x * block.y * block.z;
@@ -182,3 +193,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
 }
 
 }  // namespace simt_emu
+
+extern "C" void simt_emu_device_stats(int device, long out[2])
+{
+    out[0] = simt_emu::g_launches[device & 15];
+    out[1] = simt_emu::g_alloc_bytes[device & 15];
+}

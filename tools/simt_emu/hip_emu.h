@@ -88,9 +88,12 @@ struct hipDeviceProp_t {
     int multiProcessorCount;
 };
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+/* MI355_EMU_DEVICES=N: N make-believe devices (one address space); per device the emulator counts launches and allocated bytes
+ * (simt_emu_device_stats), so a test can see WHERE a context's work went */
+namespace simt_emu { int device_count(); int &current_device(); void note_alloc(size_t n); }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = simt_emu::device_count(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= simt_emu::device_count()) return hipErrorUnknown; simt_emu::current_device() = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = simt_emu::current_device(); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     std::memset(p, 0, sizeof(*p));
     std::strcpy(p->name, "simt-emu");
@@ -98,7 +101,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->multiProcessorCount = 4;
     return hipSuccess;
 }
-static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); simt_emu::note_alloc(n); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
