@@ -267,7 +267,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
-    for fn in (hevc_point, sws_points, session_points):
+    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points):
         try:
             r = fn(lib)
             pts.extend(r if isinstance(r, list) else [r])
@@ -345,6 +345,33 @@ def session_points(lib):
             for ss in sess:
                 ss.close()
             grp.destroy()
+    return out
+
+
+def hevc_bridge_points(lib):
+    """The reference's own HEVC decoder with the Tier-2 bridge (contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c: every
+    prediction block, transform unit and intra block of a picture recorded and run on the device level by level, in-loop filters on the
+    same device picture, references in HBM) on two generated streams, and the SAME binary with everything forwarded to the reference's
+    C functions beside it (oracle/_ref/hevc_bridge_gpu, built where /root/reference exists).  One decoder, one picture per launch set,
+    pictures of 96x64..128x128 samples: this is the launch-bound end of the path, reported as measured."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "hevc_bridge_gpu")
+    out = []
+    if not os.path.exists(exe):
+        return out
+    for name in ("pb_ctb64_depth0", "i_ctb64"):
+        src = os.path.join(ROOT, "tests", "golden", "hevc_synth_%s.samples" % name)
+        pt = {"name": "hevc_bridge_" + name}
+        for key, env in (("bridge", {}), ("reference_c_decoder", {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
+            e = dict(os.environ)
+            for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN"):
+                e.pop(k, None)
+            e.update(env)
+            r = subprocess.run([exe, src, "-", "20"], capture_output=True, text=True, env=e, timeout=600)
+            st = json.loads(r.stdout.strip().splitlines()[-1])
+            pt[key] = {k: st[k] for k in ("pictures_output", "pictures_reconstructed_on_device", "reconstruction_launches", "dependency_levels", "pictures_per_s")}
+        pt["note"] = "20 passes over the stream in one process; bit-exactness of this path: tests/test_hevc_bridge_gpu.py (all 20 generated streams)"
+        out.append(pt)
     return out
 
 

@@ -1,0 +1,634 @@
+/*
+ * mi355_hevc_bridge.c — the HEVC Tier-2 bridge: PRODUCT glue that lives beside the reference's HEVC decoder and turns it into
+ * host = parsing and entropy decoding only, MI355X = everything the per-block DSP did.  With contrib/libav/mi355_hevc_lf_bridge.c
+ * (the in-loop filters of a whole picture on the device) it keeps a picture in HBM from its first predicted sample to the
+ * sample-adaptive-offset output the next pictures predict from.
+ *
+ * The decoder's reconstruction is static code (hls_prediction_unit hevcdec.c:1695, luma_mc / chroma_mc :1528 / :1582,
+ * hls_transform_unit / hls_residual_coding :1263 / :902, intra_prediction through hls_transform_unit :1270-1285, hls_pcm_sample
+ * :1461) that reaches the samples ONLY through three pointer tables: HEVCDSPContext (hevcdsp.h:41-114), HEVCPredContext.intra_pred
+ * (hevcdec.h:399-409) and VideoDSPContext.emulated_edge_mc (videodsp.h:52).  Linked with
+ *     -Wl,--wrap=ff_hevc_dsp_init,--wrap=ff_hevc_pred_init,--wrap=ff_videodsp_init,--wrap=ff_hevc_frame_rps
+ * (plus the filter bridge's wraps) this file fills those entries with functions that RECORD what the decoder asked for instead
+ * of doing it:
+ *     emulated_edge_mc                      -> a window job (mi355_edge_emu_batch_dev) whose output a prediction job will name
+ *     put_hevc_qpel / put_hevc_epel         -> remembered under the intermediate buffer they were to fill
+ *     put_unweighted_pred[_avg] / weighted_pred[_avg] (+ _chroma)
+ *                                           -> one fused prediction job (mi355_hevc_mcpred_batch_dev) from the remembered call(s)
+ *     idct / idct_dc / transform_4x4_luma / dequant, then add_residual
+ *                                           -> one transform-unit job (mi355_hevc_residual_batch_dev) with a copy of the coefficients
+ *     put_pcm                               -> a transform-unit job of kind PCM (the samples, read from the bitstream on the host)
+ *     intra_pred[]                          -> an intra block (mi355_hevc_intra_pred_blocks_dev) with lc->na and the mode as they are now
+ * Every job gets a dependency LEVEL from a map of which level last wrote each 4x4 (chroma 2x2) cell: a prediction block goes one
+ * level above whatever wrote its area, a residual above its prediction, an intra block above the neighbours it reads.  When the
+ * slice decoder reports the picture's last CTB, the filter bridge calls mi355_hevc_recon_finish(): the jobs go out level by level
+ * (inter pictures: two or three levels; intra pictures: as deep as their prediction chains), then boundary strengths, deblocking
+ * and SAO run on the same device picture, and the finished picture is copied to the host frame the decoder outputs.  Reference
+ * samples never cross PCIe: the decoded picture buffer lives in HBM, one device surface per host frame buffer (found again by
+ * the plane a source pointer falls into); a reference this bridge did not decode (a frame the decoder made up for a missing
+ * reference) is uploaded once.
+ *
+ * Scope: what the filter bridge takes (4:2:0, no tiles, no frame threads), 8 / 9 / 10 bit, one decoder per thread.  A picture
+ * outside it is reconstructed by the reference's own functions (the entries forward to the tables the reference filled) and
+ * its surface is uploaded when a later picture needs it.  MI355_HEVC_RECON_PLAIN=1 forwards everything.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "libavcodec/avcodec.h"
+#include "libavcodec/hevcdec.h"
+#include "libavcodec/videodsp.h"
+#include "mi355_hevc_batch.h"
+#include "mi355dsp.h"
+#include "mi355_h264_frame.h"      /* the runtime entry points: mi355_malloc / mi355_memcpy_* / mi355_sync */
+
+void __real_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth);
+void __real_ff_hevc_pred_init(HEVCPredContext *c, int bit_depth);
+void __real_ff_videodsp_init(VideoDSPContext *c, int bpc);
+int __real_ff_hevc_frame_rps(HEVCContext *s);
+
+#define MAX_SURF 48
+typedef struct Surface {
+    const uint8_t *host[3];            /* the host frame's planes: the key */
+    int linesize[3], rows[3];
+    uint8_t *dev;                      /* one allocation, planes back to back */
+    size_t off[3], bytes;
+    int valid, poc;                    /* the device copy holds the picture with this POC */
+    unsigned long used;                /* picture counter at last use (recycling) */
+} Surface;
+typedef struct Loc { int surf; size_t off; } Loc;          /* surf >= 0: byte `off` of that surface's allocation; -2: of the window scratch */
+
+typedef struct EmuRec { Loc src; size_t dst_off; int src_stride, bw, bh, sx, sy, w, h; } EmuRec;
+typedef struct McRec {
+    Loc src[2], dst;
+    int sstride[2], dstride, w, h, chroma, kind, mx[2], my[2], denom, wt[2], of[2], level;
+} McRec;
+typedef struct TuRec { Loc dst; size_t coef_off; int dstride, log2, col_limit, kind, level; } TuRec;
+typedef struct IntraRec { mi355_hevc_intra_block b; int level; } IntraRec;
+typedef struct Pending { const int16_t *tmp; Loc src; int sstride, w, h, mx, my, chroma, live; } Pending;
+
+static __thread struct Recon {
+    int init, plain, failed;
+    HEVCContext *s;
+    int on;                             /* the open picture is reconstructed on the device */
+    int bd, px;
+    HEVCDSPContext orig_dsp;
+    HEVCPredContext orig_pred;
+    VideoDSPContext orig_vdsp;
+    Surface surf[MAX_SURF];
+    int cur;                            /* surface of s->frame */
+    unsigned long pictures, on_device, uploads, launches, levels_total;
+    /* what the open picture recorded */
+    EmuRec *emu; int nemu, cemu; size_t emu_bytes;
+    McRec *mc; int nmc, cmc;
+    TuRec *tu; int ntu, ctu;
+    int16_t *coef; size_t ncoef, ccoef;
+    IntraRec *intra; int nintra, cintra;
+    uint16_t *lvl[3]; int lw[3], lh[3], lshift[3]; size_t lcells[3];
+    int max_level;
+    Pending pend[8];
+    struct { const uint8_t *buf; size_t dst_off; int stride, rows; } last_emu;
+    int transform_kind, transform_col_limit; const int16_t *transform_coeffs;
+    /* device staging */
+    uint8_t *d_stage; size_t d_stage_bytes; uint8_t *h_stage; size_t h_stage_bytes;
+    uint8_t *d_emu; size_t d_emu_bytes;
+    uint8_t *d_mvf, *d_zs; size_t d_mvf_bytes, d_zs_bytes;
+} R;
+
+static void recon_fail(const char *what)
+{
+    if (!R.failed) fprintf(stderr, "mi355 hevc bridge: %s; later pictures are reconstructed by the reference's functions\n", what);
+    R.failed = 1;
+}
+static int grow(void **p, int *cap, int need, size_t elem)
+{
+    if (need <= *cap) return 0;
+    int n = *cap ? *cap : 256;
+    while (n < need) n *= 2;
+    void *q = realloc(*p, (size_t)n * elem);
+    if (!q) return -1;
+    *p = q; *cap = n;
+    return 0;
+}
+static int dev_ensure(uint8_t **p, size_t *have, size_t want)
+{
+    if (*p && *have >= want) return 0;
+    if (*p) mi355_free(*p);
+    *p = mi355_malloc(want + 64);
+    *have = *p ? want : 0;
+    return *p ? 0 : -1;
+}
+
+/* ---- surfaces ---------------------------------------------------------------------------------------------------------- */
+static Surface *surface_of_frame(const HEVCContext *s, const AVFrame *f, int create)
+{
+    Surface *free_slot = NULL, *oldest = NULL;
+    for (int i = 0; i < MAX_SURF; i++) {
+        Surface *u = &R.surf[i];
+        if (u->host[0] == f->data[0] && u->host[0]) {
+            /* the same buffer with another geometry (a new sequence): start over */
+            if (u->linesize[0] != f->linesize[0] || u->rows[0] != s->ps.sps->height) { u->valid = 0; u->host[0] = NULL; free_slot = free_slot ? free_slot : u; continue; }
+            return u;
+        }
+        if (!u->host[0]) { if (!free_slot) free_slot = u; }
+        else if (!oldest || u->used < oldest->used) oldest = u;
+    }
+    if (!create) return NULL;
+    Surface *u = free_slot ? free_slot : oldest;
+    if (!u) return NULL;
+    const int rows[3] = { s->ps.sps->height, s->ps.sps->height >> s->ps.sps->vshift[1], s->ps.sps->height >> s->ps.sps->vshift[2] };
+    size_t off = 0;
+    for (int i = 0; i < 3; i++) {
+        u->host[i] = f->data[i]; u->linesize[i] = f->linesize[i]; u->rows[i] = rows[i];
+        u->off[i] = off;
+        off += ((size_t)f->linesize[i] * rows[i] + 255) & ~(size_t)255;
+    }
+    if (!u->dev || u->bytes < off) {
+        if (u->dev) mi355_free(u->dev);
+        u->dev = mi355_malloc(off + 256);
+        u->bytes = u->dev ? off : 0;
+        if (!u->dev) { u->host[0] = NULL; return NULL; }
+    }
+    u->valid = 0;
+    u->used = R.pictures;
+    return u;
+}
+/* the surface and byte offset of a pointer into some frame's plane (a frame of the decoded picture buffer this bridge has not
+ * seen yet gets its surface now) */
+static int locate(const HEVCContext *s, const uint8_t *p, Loc *out)
+{
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < MAX_SURF; i++) {
+            const Surface *u = &R.surf[i];
+            if (!u->host[0]) continue;
+            for (int k = 0; k < 3; k++)
+                if (p >= u->host[k] && p < u->host[k] + (size_t)u->linesize[k] * u->rows[k]) {
+                    out->surf = i; out->off = u->off[k] + (size_t)(p - u->host[k]);
+                    R.surf[i].used = R.pictures;
+                    return 0;
+                }
+        }
+        if (pass) break;
+        /* not a frame we know: one of the decoder's frames we have not met (made up for a missing reference, or decoded before the bridge took over) */
+        int found = 0;
+        for (int i = 0; i < FF_ARRAY_ELEMS(s->DPB) && !found; i++) {
+            const AVFrame *f = s->DPB[i].frame;
+            if (!f || !f->data[0]) continue;
+            for (int k = 0; k < 3 && !found; k++) {
+                const int rows = k ? s->ps.sps->height >> s->ps.sps->vshift[k] : s->ps.sps->height;
+                if (p >= f->data[k] && p < f->data[k] + (size_t)f->linesize[k] * rows) found = surface_of_frame(s, f, 1) != NULL;
+            }
+        }
+        if (!found) return -1;
+    }
+    return -1;
+}
+
+/* ---- levels ------------------------------------------------------------------------------------------------------------ */
+static int plane_of(const Surface *u, size_t off) { return off >= u->off[2] ? 2 : (off >= u->off[1] ? 1 : 0); }
+/* cells of plane k covered by the rectangle (x, y, w, h) in samples of that plane, clipped to the plane */
+static int level_max(int k, int x, int y, int w, int h)
+{
+    const int sh = R.lshift[k];
+    int x0 = x >> sh, y0 = y >> sh, x1 = (x + w - 1) >> sh, y1 = (y + h - 1) >> sh, m = 0;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 >= R.lw[k]) x1 = R.lw[k] - 1;
+    if (y1 >= R.lh[k]) y1 = R.lh[k] - 1;
+    for (int yy = y0; yy <= y1; yy++) {
+        const uint16_t *row = R.lvl[k] + (size_t)yy * R.lw[k];
+        for (int xx = x0; xx <= x1; xx++) if (row[xx] > m) m = row[xx];
+    }
+    return m;
+}
+static void level_set(int k, int x, int y, int w, int h, int level)
+{
+    const int sh = R.lshift[k];
+    int x0 = x >> sh, y0 = y >> sh, x1 = (x + w - 1) >> sh, y1 = (y + h - 1) >> sh;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 >= R.lw[k]) x1 = R.lw[k] - 1;
+    if (y1 >= R.lh[k]) y1 = R.lh[k] - 1;
+    for (int yy = y0; yy <= y1; yy++) {
+        uint16_t *row = R.lvl[k] + (size_t)yy * R.lw[k];
+        for (int xx = x0; xx <= x1; xx++) row[xx] = (uint16_t)level;
+    }
+    if (level > R.max_level) R.max_level = level;
+}
+/* plane and position (samples) of a destination pointer inside the open picture's frame */
+static int dst_position(const uint8_t *dst, int *k, int *x, int *y, Loc *loc)
+{
+    const Surface *u = &R.surf[R.cur];
+    for (int i = 0; i < 3; i++)
+        if (dst >= u->host[i] && dst < u->host[i] + (size_t)u->linesize[i] * u->rows[i]) {
+            const size_t o = (size_t)(dst - u->host[i]);
+            *k = i; *y = (int)(o / (size_t)u->linesize[i]); *x = (int)(o % (size_t)u->linesize[i]) / R.px;
+            loc->surf = R.cur; loc->off = u->off[i] + o;
+            return 0;
+        }
+    return -1;
+}
+
+/* ---- the recording entries --------------------------------------------------------------------------------------------- */
+static const uint8_t k_w_luma[8] = { 4, 8, 12, 16, 24, 32, 48, 64 }, k_w_chroma[8] = { 2, 4, 6, 8, 12, 16, 24, 32 };
+
+static void rec_emu(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize, ptrdiff_t src_linesize, int bw, int bh, int sx, int sy, int w, int h)
+{
+    if (!R.on) { R.orig_vdsp.emulated_edge_mc(buf, src, buf_linesize, src_linesize, bw, bh, sx, sy, w, h); return; }
+    if (grow((void **)&R.emu, &R.cemu, R.nemu + 1, sizeof(*R.emu))) { recon_fail("out of memory"); return; }
+    EmuRec *e = &R.emu[R.nemu];
+    /* the plane's first sample lies sy rows and sx samples before the window's */
+    const uint8_t *origin = src - (ptrdiff_t)sy * src_linesize - (ptrdiff_t)sx * R.px;
+    Loc o;
+    if (locate(R.s, origin, &o)) { recon_fail("a reference picture the bridge cannot place"); return; }
+    /* kept relative to the plane's first sample: the window itself may start outside the plane */
+    e->src = o; e->src_stride = (int)src_linesize; e->bw = bw; e->bh = bh; e->sx = sx; e->sy = sy; e->w = w; e->h = h;
+    e->dst_off = R.emu_bytes;
+    R.emu_bytes += ((size_t)buf_linesize * bh + 63) & ~(size_t)63;
+    R.last_emu.buf = buf; R.last_emu.dst_off = e->dst_off; R.last_emu.stride = (int)buf_linesize; R.last_emu.rows = bh;
+    R.nemu++;
+}
+
+static void rec_mc(int16_t *tmp, uint8_t *src, ptrdiff_t ss, int w, int h, int mx, int my, int chroma, void (*orig)(int16_t *, ptrdiff_t, uint8_t *, ptrdiff_t, int, int, int, int16_t *),
+                   ptrdiff_t ds, int16_t *mcbuffer)
+{
+    if (!R.on) { orig(tmp, ds, src, ss, h, mx, my, mcbuffer); return; }
+    Pending *p = NULL;
+    for (int i = 0; i < 8; i++) if (R.pend[i].live && R.pend[i].tmp == tmp) p = &R.pend[i];
+    for (int i = 0; i < 8 && !p; i++) if (!R.pend[i].live) p = &R.pend[i];
+    if (!p) p = &R.pend[0];
+    p->tmp = tmp; p->sstride = (int)ss; p->w = w; p->h = h; p->mx = mx; p->my = my; p->chroma = chroma; p->live = 1;
+    if (R.last_emu.buf && src >= R.last_emu.buf && src < R.last_emu.buf + (size_t)R.last_emu.stride * R.last_emu.rows) {
+        p->src.surf = -2; p->src.off = R.last_emu.dst_off + (size_t)(src - R.last_emu.buf);
+    } else if (locate(R.s, src, &p->src)) { recon_fail("a reference picture the bridge cannot place"); p->live = 0; }
+}
+#define MC_FN(name, tab, chroma, i) \
+    static void name##_##i(int16_t *dst, ptrdiff_t ds, uint8_t *src, ptrdiff_t ss, int height, int mx, int my, int16_t *mcbuffer) \
+    { rec_mc(dst, src, ss, tab[i], height, mx, my, chroma, R.orig_dsp.put_hevc_##name[!!my][!!mx][i], ds, mcbuffer); }
+#define MC_FNS(name, tab, chroma) MC_FN(name, tab, chroma, 0) MC_FN(name, tab, chroma, 1) MC_FN(name, tab, chroma, 2) MC_FN(name, tab, chroma, 3) \
+                                   MC_FN(name, tab, chroma, 4) MC_FN(name, tab, chroma, 5) MC_FN(name, tab, chroma, 6) MC_FN(name, tab, chroma, 7)
+MC_FNS(qpel, k_w_luma, 0)
+MC_FNS(epel, k_w_chroma, 1)
+
+static Pending *pending_of(const int16_t *tmp)
+{
+    for (int i = 0; i < 8; i++) if (R.pend[i].live && R.pend[i].tmp == tmp) return &R.pend[i];
+    return NULL;
+}
+/* one prediction block: `kind` MI355_HEVC_PRED_*, sources = the remembered MC calls that filled src1 (and src2) */
+static void rec_pred(uint8_t *dst, ptrdiff_t dstride, const int16_t *src1, const int16_t *src2, int w, int h, int kind, int denom, int w0, int w1, int o0, int o1)
+{
+    Pending *a = pending_of(src1), *b = src2 ? pending_of(src2) : NULL;
+    int k, x, y;
+    Loc dl;
+    if (!a || (src2 && !b) || dst_position(dst, &k, &x, &y, &dl)) { recon_fail("a prediction call the bridge cannot match with its interpolation"); return; }
+    if (grow((void **)&R.mc, &R.cmc, R.nmc + 1, sizeof(*R.mc))) { recon_fail("out of memory"); return; }
+    McRec *m = &R.mc[R.nmc++];
+    memset(m, 0, sizeof(*m));
+    m->src[0] = a->src; m->sstride[0] = a->sstride; m->mx[0] = a->mx; m->my[0] = a->my;
+    if (b) { m->src[1] = b->src; m->sstride[1] = b->sstride; m->mx[1] = b->mx; m->my[1] = b->my; }
+    m->dst = dl; m->dstride = (int)dstride; m->w = w; m->h = h; m->chroma = a->chroma; m->kind = kind;
+    m->denom = denom; m->wt[0] = w0; m->wt[1] = w1; m->of[0] = o0; m->of[1] = o1;
+    m->level = level_max(k, x, y, w, h) + 1;
+    level_set(k, x, y, w, h, m->level);
+    a->live = 0;                       /* an intermediate is consumed once: its slot is free for the next interpolation */
+    if (b) b->live = 0;
+}
+#define PRED_FNS_I(i) \
+    static void up_##i(uint8_t *d, ptrdiff_t ds, int16_t *s1, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.put_unweighted_pred[i](d, ds, s1, ss, h); return; } rec_pred(d, ds, s1, NULL, k_w_luma[i], h, MI355_HEVC_PRED_PUT, 0, 0, 0, 0, 0); } \
+    static void upc_##i(uint8_t *d, ptrdiff_t ds, int16_t *s1, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.put_unweighted_pred_chroma[i](d, ds, s1, ss, h); return; } rec_pred(d, ds, s1, NULL, k_w_chroma[i], h, MI355_HEVC_PRED_PUT, 0, 0, 0, 0, 0); } \
+    static void upa_##i(uint8_t *d, ptrdiff_t ds, int16_t *s1, int16_t *s2, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.put_unweighted_pred_avg[i](d, ds, s1, s2, ss, h); return; } rec_pred(d, ds, s1, s2, k_w_luma[i], h, MI355_HEVC_PRED_AVG, 0, 0, 0, 0, 0); } \
+    static void upac_##i(uint8_t *d, ptrdiff_t ds, int16_t *s1, int16_t *s2, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.put_unweighted_pred_avg_chroma[i](d, ds, s1, s2, ss, h); return; } rec_pred(d, ds, s1, s2, k_w_chroma[i], h, MI355_HEVC_PRED_AVG, 0, 0, 0, 0, 0); } \
+    static void wp_##i(uint8_t dn, int16_t w, int16_t o, uint8_t *d, ptrdiff_t ds, int16_t *s1, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.weighted_pred[i](dn, w, o, d, ds, s1, ss, h); return; } rec_pred(d, ds, s1, NULL, k_w_luma[i], h, MI355_HEVC_PRED_W, dn, w, 0, o, 0); } \
+    static void wpc_##i(uint8_t dn, int16_t w, int16_t o, uint8_t *d, ptrdiff_t ds, int16_t *s1, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.weighted_pred_chroma[i](dn, w, o, d, ds, s1, ss, h); return; } rec_pred(d, ds, s1, NULL, k_w_chroma[i], h, MI355_HEVC_PRED_W, dn, w, 0, o, 0); } \
+    static void wpa_##i(uint8_t dn, int16_t w0, int16_t w1, int16_t o0, int16_t o1, uint8_t *d, ptrdiff_t ds, int16_t *s1, int16_t *s2, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.weighted_pred_avg[i](dn, w0, w1, o0, o1, d, ds, s1, s2, ss, h); return; } rec_pred(d, ds, s1, s2, k_w_luma[i], h, MI355_HEVC_PRED_W_AVG, dn, w0, w1, o0, o1); } \
+    static void wpac_##i(uint8_t dn, int16_t w0, int16_t w1, int16_t o0, int16_t o1, uint8_t *d, ptrdiff_t ds, int16_t *s1, int16_t *s2, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.weighted_pred_avg_chroma[i](dn, w0, w1, o0, o1, d, ds, s1, s2, ss, h); return; } rec_pred(d, ds, s1, s2, k_w_chroma[i], h, MI355_HEVC_PRED_W_AVG, dn, w0, w1, o0, o1); }
+PRED_FNS_I(0) PRED_FNS_I(1) PRED_FNS_I(2) PRED_FNS_I(3) PRED_FNS_I(4) PRED_FNS_I(5) PRED_FNS_I(6) PRED_FNS_I(7)
+
+/* the transform that precedes add_residual (hls_residual_coding, hevcdec.c:1236-1260): remembered until the add arrives */
+static void note_transform(const int16_t *coeffs, int kind, int col_limit) { R.transform_coeffs = coeffs; R.transform_kind = kind; R.transform_col_limit = col_limit; }
+static void rec_dequant(int16_t *c) { if (!R.on) { R.orig_dsp.dequant(c); return; } note_transform(c, MI355_HEVC_TU_SKIP, 0); }
+static void rec_dst4(int16_t *c) { if (!R.on) { R.orig_dsp.transform_4x4_luma(c); return; } note_transform(c, MI355_HEVC_TU_DST4, 0); }
+#define IDCT_FNS(i) \
+    static void idct_##i(int16_t *c, int col_limit) { if (!R.on) { R.orig_dsp.idct[i](c, col_limit); return; } note_transform(c, MI355_HEVC_TU_IDCT, col_limit); } \
+    static void idct_dc_##i(int16_t *c) { if (!R.on) { R.orig_dsp.idct_dc[i](c); return; } note_transform(c, MI355_HEVC_TU_IDCT_DC, 0); }
+IDCT_FNS(0) IDCT_FNS(1) IDCT_FNS(2) IDCT_FNS(3)
+
+static void rec_tu(uint8_t *dst, const int16_t *samples, ptrdiff_t stride, int log2, int kind, int col_limit)
+{
+    int k, x, y;
+    Loc dl;
+    const int size = 1 << log2, n = size * size;
+    if (dst_position(dst, &k, &x, &y, &dl)) { recon_fail("a residual outside the picture"); return; }
+    if (grow((void **)&R.tu, &R.ctu, R.ntu + 1, sizeof(*R.tu))) { recon_fail("out of memory"); return; }
+    if (R.ncoef + (size_t)n > R.ccoef) {
+        size_t c = R.ccoef ? R.ccoef : (1u << 16);
+        while (c < R.ncoef + (size_t)n) c *= 2;
+        int16_t *q = realloc(R.coef, c * sizeof(int16_t));
+        if (!q) { recon_fail("out of memory"); return; }
+        R.coef = q; R.ccoef = c;
+    }
+    TuRec *t = &R.tu[R.ntu++];
+    t->dst = dl; t->dstride = (int)stride; t->log2 = log2; t->kind = kind; t->col_limit = col_limit;
+    t->coef_off = R.ncoef;
+    memcpy(R.coef + R.ncoef, samples, (size_t)n * sizeof(int16_t));
+    R.ncoef += (size_t)n;
+    t->level = level_max(k, x, y, size, size) + 1;
+    level_set(k, x, y, size, size, t->level);
+}
+#define ADD_FN(i) \
+    static void add_res_##i(uint8_t *dst, int16_t *res, ptrdiff_t stride) \
+    { \
+        if (!R.on) { R.orig_dsp.add_residual[i](dst, res, stride); return; } \
+        const int have = R.transform_coeffs == res; \
+        rec_tu(dst, res, stride, i + 2, have ? R.transform_kind : MI355_HEVC_TU_BYPASS, have ? R.transform_col_limit : 0); \
+        R.transform_coeffs = NULL; \
+    }
+ADD_FN(0) ADD_FN(1) ADD_FN(2) ADD_FN(3)
+
+/* pcm_sample: the samples come from the bitstream — read by the reference's own function into a block of their own, then a job */
+static void rec_pcm(uint8_t *dst, ptrdiff_t stride, int size, GetBitContext *gb, int pcm_bit_depth)
+{
+    if (!R.on) { R.orig_dsp.put_pcm(dst, stride, size, gb, pcm_bit_depth); return; }
+    uint8_t blk[32 * 32 * 2];
+    int16_t smp[32 * 32];
+    int log2 = 2;
+    while ((1 << log2) < size) log2++;
+    if (size > 32 || (1 << log2) != size) { recon_fail("a PCM block size the bridge does not take"); return; }
+    R.orig_dsp.put_pcm(blk, (ptrdiff_t)size * R.px, size, gb, pcm_bit_depth);
+    for (int i = 0; i < size * size; i++) smp[i] = R.px == 2 ? (int16_t)((const uint16_t *)blk)[i] : (int16_t)blk[i];
+    rec_tu(dst, smp, stride, log2, MI355_HEVC_TU_PCM, 0);
+}
+
+static void rec_intra(HEVCContext *s, int x0, int y0, int c_idx, int log2)
+{
+    if (!R.on) { R.orig_pred.intra_pred[log2 - 2](s, x0, y0, c_idx); return; }
+    const HEVCLocalContext *lc = &s->HEVClc;
+    if (grow((void **)&R.intra, &R.cintra, R.nintra + 1, sizeof(*R.intra))) { recon_fail("out of memory"); return; }
+    IntraRec *r = &R.intra[R.nintra++];
+    memset(r, 0, sizeof(*r));
+    r->b.pic = 0;
+    r->b.x0 = (uint16_t)x0; r->b.y0 = (uint16_t)y0; r->b.log2_size = (uint8_t)log2; r->b.c_idx = (uint8_t)c_idx;
+    r->b.mode = (uint8_t)(c_idx ? lc->pu.intra_pred_mode_c : lc->tu.cur_intra_pred_mode);
+    r->b.cand = (uint8_t)((lc->na.cand_bottom_left ? MI355_HEVC_CAND_BOTTOM_LEFT : 0) | (lc->na.cand_left ? MI355_HEVC_CAND_LEFT : 0) |
+                          (lc->na.cand_up_left ? MI355_HEVC_CAND_UP_LEFT : 0) | (lc->na.cand_up ? MI355_HEVC_CAND_UP : 0) |
+                          (lc->na.cand_up_right ? MI355_HEVC_CAND_UP_RIGHT : 0));
+    /* the block in its plane, the neighbours it may read: one row above (from the corner, 2 size + 1 samples), one column left */
+    const int size = 1 << log2, x = x0 >> (c_idx ? s->ps.sps->hshift[c_idx] : 0), y = y0 >> (c_idx ? s->ps.sps->vshift[c_idx] : 0);
+    int m = level_max(c_idx, x, y, size, size);
+    const int a = level_max(c_idx, x - 1, y - 1, 2 * size + 1, 1), b = level_max(c_idx, x - 1, y, 1, 2 * size);
+    if (a > m) m = a;
+    if (b > m) m = b;
+    r->level = m + 1;
+    level_set(c_idx, x, y, size, size, r->level);
+}
+static void intra_2(HEVCContext *s, int x0, int y0, int c) { rec_intra(s, x0, y0, c, 2); }
+static void intra_3(HEVCContext *s, int x0, int y0, int c) { rec_intra(s, x0, y0, c, 3); }
+static void intra_4(HEVCContext *s, int x0, int y0, int c) { rec_intra(s, x0, y0, c, 4); }
+static void intra_5(HEVCContext *s, int x0, int y0, int c) { rec_intra(s, x0, y0, c, 5); }
+
+/* ---- table wraps ------------------------------------------------------------------------------------------------------- */
+static void first_use(void)
+{
+    if (R.init) return;
+    R.init = 1;
+    R.plain = getenv("MI355_HEVC_RECON_PLAIN") != NULL;
+}
+void __wrap_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
+{
+    __real_ff_hevc_dsp_init(c, bit_depth);
+    first_use();
+    R.orig_dsp = *c;
+    R.bd = bit_depth; R.px = bit_depth > 8 ? 2 : 1;
+    if (R.plain) return;
+#define SET8(field, fn) do { c->field[0] = fn##_0; c->field[1] = fn##_1; c->field[2] = fn##_2; c->field[3] = fn##_3; c->field[4] = fn##_4; c->field[5] = fn##_5; c->field[6] = fn##_6; c->field[7] = fn##_7; } while (0)
+    for (int v = 0; v < 2; v++)
+        for (int h = 0; h < 2; h++) { SET8(put_hevc_qpel[v][h], qpel); SET8(put_hevc_epel[v][h], epel); }
+    SET8(put_unweighted_pred, up); SET8(put_unweighted_pred_chroma, upc); SET8(put_unweighted_pred_avg, upa); SET8(put_unweighted_pred_avg_chroma, upac);
+    SET8(weighted_pred, wp); SET8(weighted_pred_chroma, wpc); SET8(weighted_pred_avg, wpa); SET8(weighted_pred_avg_chroma, wpac);
+#undef SET8
+    c->idct[0] = idct_0; c->idct[1] = idct_1; c->idct[2] = idct_2; c->idct[3] = idct_3;
+    c->idct_dc[0] = idct_dc_0; c->idct_dc[1] = idct_dc_1; c->idct_dc[2] = idct_dc_2; c->idct_dc[3] = idct_dc_3;
+    c->add_residual[0] = add_res_0; c->add_residual[1] = add_res_1; c->add_residual[2] = add_res_2; c->add_residual[3] = add_res_3;
+    c->dequant = rec_dequant; c->transform_4x4_luma = rec_dst4; c->put_pcm = rec_pcm;
+}
+void __wrap_ff_hevc_pred_init(HEVCPredContext *c, int bit_depth)
+{
+    __real_ff_hevc_pred_init(c, bit_depth);
+    first_use();
+    R.orig_pred = *c;
+    if (R.plain) return;
+    c->intra_pred[0] = intra_2; c->intra_pred[1] = intra_3; c->intra_pred[2] = intra_4; c->intra_pred[3] = intra_5;
+}
+void __wrap_ff_videodsp_init(VideoDSPContext *c, int bpc)
+{
+    __real_ff_videodsp_init(c, bpc);
+    first_use();
+    R.orig_vdsp = *c;
+    if (R.plain) return;
+    c->emulated_edge_mc = rec_emu;
+}
+
+/* the filter bridge's test of a picture it takes (mi355_hevc_lf_bridge.c): the two must agree picture by picture */
+int mi355_hevc_lf_bridge_active(const HEVCContext *s) __attribute__((weak));
+
+/* a picture starts: hevc_frame_start calls ff_hevc_frame_rps right after ff_hevc_set_new_ref (hevcdec.c:2452-2457) */
+int __wrap_ff_hevc_frame_rps(HEVCContext *s)
+{
+    const int ret = __real_ff_hevc_frame_rps(s);
+    first_use();
+    R.s = s;
+    R.on = 0;
+    R.pictures++;
+    if (ret < 0 || R.plain || R.failed || !s->frame || !s->frame->data[0]) return ret;
+    if (!mi355_hevc_lf_bridge_active || !mi355_hevc_lf_bridge_active(s)) return ret;
+    const HEVCSPS *sps = s->ps.sps;
+    Surface *u = surface_of_frame(s, s->frame, 1);
+    if (!u) { recon_fail("no device memory for a picture"); return ret; }
+    R.cur = (int)(u - R.surf);
+    u->valid = 0;
+    /* level maps: luma cells of 4x4, chroma cells of 2x2 samples */
+    for (int k = 0; k < 3; k++) {
+        R.lshift[k] = k ? 1 : 2;
+        R.lw[k] = ((sps->width >> (k ? sps->hshift[k] : 0)) + (1 << R.lshift[k]) - 1) >> R.lshift[k];
+        R.lh[k] = ((sps->height >> (k ? sps->vshift[k] : 0)) + (1 << R.lshift[k]) - 1) >> R.lshift[k];
+        const size_t cells = (size_t)R.lw[k] * R.lh[k];
+        if (R.lcells[k] < cells) {
+            free(R.lvl[k]);
+            R.lvl[k] = malloc(cells * sizeof(uint16_t));
+            R.lcells[k] = R.lvl[k] ? cells : 0;
+            if (!R.lvl[k]) { recon_fail("out of memory"); return ret; }
+        }
+        memset(R.lvl[k], 0, cells * sizeof(uint16_t));
+    }
+    R.nemu = R.nmc = R.ntu = R.nintra = 0;
+    R.ncoef = 0; R.emu_bytes = 0; R.max_level = 0;
+    memset(R.pend, 0, sizeof(R.pend));
+    memset(&R.last_emu, 0, sizeof(R.last_emu));
+    R.transform_coeffs = NULL;
+    R.on = 1;
+    return ret;
+}
+
+/* ---- the picture goes out ----------------------------------------------------------------------------------------------- */
+static uint8_t *resolve(const Loc *l) { return l->surf == -2 ? R.d_emu + l->off : R.surf[l->surf].dev + l->off; }
+static int upload_surface(const HEVCContext *s, Surface *u)
+{
+    /* the host frame holds the picture (reconstructed by the reference's functions, or made up by the decoder) */
+    for (int k = 0; k < 3; k++)
+        if (mi355_memcpy_h2d(u->dev + u->off[k], u->host[k], (size_t)u->linesize[k] * u->rows[k]) != 0) return -1;
+    (void)s;
+    u->valid = 1;
+    R.uploads++;
+    return 0;
+}
+/* is the device copy of surface `i` the picture the decoder's frame holds now? */
+static int surface_current(const HEVCContext *s, const Surface *u)
+{
+    if (!u->valid) return 0;
+    for (int i = 0; i < FF_ARRAY_ELEMS(s->DPB); i++) {
+        const HEVCFrame *f = &s->DPB[i];
+        if (f->frame && f->frame->data[0] == u->host[0]) return f->poc == u->poc;
+    }
+    return 1;      /* the work frame of sequences with SAO (s->tmp_frame) is nobody's reference */
+}
+
+/* Called by the filter bridge when the slice decoder reports the picture's last CTB.  Returns 0 when this picture was not
+ * recorded (the filter bridge then uploads the host frame as it always did), 1 when the unfiltered reconstruction now lies in
+ * cur[] (device planes of s->frame) and the finished picture must go to fin[] (device planes of the frame later pictures
+ * predict from: s->sao_frame with SAO, else the same), < 0 on failure. */
+int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
+{
+    if (!R.on || R.s != s) return 0;
+    R.on = 0;
+    if (R.failed) return -1;
+    const HEVCSPS *sps = s->ps.sps;
+    Surface *uc = &R.surf[R.cur];
+    /* references: whatever the recorded jobs name must hold the decoder's current picture */
+    for (int i = 0; i < R.nmc + R.nemu; i++) {
+        const Loc *ls[2]; int nl = 0;
+        if (i < R.nmc) { ls[nl++] = &R.mc[i].src[0]; if (R.mc[i].kind & 1) ls[nl++] = &R.mc[i].src[1]; }
+        else ls[nl++] = &R.emu[i - R.nmc].src;
+        for (int q = 0; q < nl; q++) {
+            if (ls[q]->surf < 0) continue;
+            Surface *u = &R.surf[ls[q]->surf];
+            if (u == uc) return -1;                              /* a picture cannot predict from itself */
+            if (!surface_current(s, u) && upload_surface(s, u)) return -1;
+        }
+    }
+    /* staging: jobs of every kind sorted by level, coefficients, the intra descriptor */
+    const size_t mvf_bytes = (size_t)sps->min_pu_width * sps->min_pu_height * sizeof(MvField);
+    const size_t zs_bytes = (size_t)sps->min_tb_width * sps->min_tb_height * sizeof(int);
+    size_t o = 0;
+    const size_t o_emu = o;   o += ((size_t)R.nemu * sizeof(mi355_edge_emu_job) + 63) & ~(size_t)63;
+    const size_t o_mc = o;    o += ((size_t)R.nmc * sizeof(mi355_hevc_mcpred_job) + 63) & ~(size_t)63;
+    const size_t o_tu = o;    o += ((size_t)R.ntu * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
+    const size_t o_in = o;    o += ((size_t)R.nintra * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
+    const size_t o_desc = o;  o += (sizeof(mi355_hevc_intra_picture) + 63) & ~(size_t)63;
+    const size_t o_coef = o;  o += (R.ncoef * sizeof(int16_t) + 63) & ~(size_t)63;
+    if (R.h_stage_bytes < o) {
+        free(R.h_stage);
+        R.h_stage = malloc(o);
+        R.h_stage_bytes = R.h_stage ? o : 0;
+        if (!R.h_stage) return -1;
+    }
+    if (dev_ensure(&R.d_stage, &R.d_stage_bytes, o) || dev_ensure(&R.d_emu, &R.d_emu_bytes, R.emu_bytes + 64)) return -1;
+    if (R.nintra && (dev_ensure(&R.d_mvf, &R.d_mvf_bytes, mvf_bytes) || dev_ensure(&R.d_zs, &R.d_zs_bytes, zs_bytes))) return -1;
+    const int L = R.max_level;
+    /* counting sort by level of the three job kinds */
+    int *start = calloc((size_t)(L + 2) * 3, sizeof(int));
+    if (!start) return -1;
+    int *smc = start, *stu = start + (L + 2), *sin = start + 2 * (L + 2);
+    for (int i = 0; i < R.nmc; i++) smc[R.mc[i].level + 1]++;
+    for (int i = 0; i < R.ntu; i++) stu[R.tu[i].level + 1]++;
+    for (int i = 0; i < R.nintra; i++) sin[R.intra[i].level + 1]++;
+    for (int l = 1; l <= L + 1; l++) { smc[l] += smc[l - 1]; stu[l] += stu[l - 1]; sin[l] += sin[l - 1]; }
+    mi355_edge_emu_job *je = (mi355_edge_emu_job *)(R.h_stage + o_emu);
+    mi355_hevc_mcpred_job *jm = (mi355_hevc_mcpred_job *)(R.h_stage + o_mc);
+    mi355_hevc_tu_job *jt = (mi355_hevc_tu_job *)(R.h_stage + o_tu);
+    mi355_hevc_intra_block *ji = (mi355_hevc_intra_block *)(R.h_stage + o_in);
+    for (int i = 0; i < R.nemu; i++) {
+        const EmuRec *e = &R.emu[i];
+        mi355_edge_emu_job *j = &je[i];
+        memset(j, 0, sizeof(*j));
+        j->dst = R.d_emu + e->dst_off;
+        /* the job's `src` is the window's first sample: the plane's first sample + sy rows + sx samples */
+        j->src = resolve(&e->src) + (ptrdiff_t)e->sy * e->src_stride + (ptrdiff_t)e->sx * R.px;
+        j->dst_stride = EDGE_EMU_BUFFER_STRIDE * R.px; j->src_stride = e->src_stride;
+        j->block_w = e->bw; j->block_h = e->bh; j->src_x = e->sx; j->src_y = e->sy; j->w = e->w; j->h = e->h;
+    }
+    {
+        int *fill = malloc((size_t)(L + 2) * sizeof(int));
+        if (!fill) { free(start); return -1; }
+        memcpy(fill, smc, (size_t)(L + 2) * sizeof(int));
+        for (int i = 0; i < R.nmc; i++) {
+            const McRec *m = &R.mc[i];
+            mi355_hevc_mcpred_job *j = &jm[fill[m->level]++];
+            memset(j, 0, sizeof(*j));
+            j->src0 = resolve(&m->src[0]); j->src0_stride = m->sstride[0];
+            if (m->kind & 1) { j->src1 = resolve(&m->src[1]); j->src1_stride = m->sstride[1]; }
+            j->dst = resolve(&m->dst); j->dst_stride = m->dstride;
+            j->width = (uint8_t)m->w; j->height = (uint8_t)m->h; j->chroma = (uint8_t)m->chroma; j->kind = (uint8_t)m->kind;
+            j->mx0 = (uint8_t)m->mx[0]; j->my0 = (uint8_t)m->my[0]; j->mx1 = (uint8_t)m->mx[1]; j->my1 = (uint8_t)m->my[1];
+            j->denom = (uint8_t)m->denom; j->w0 = (int16_t)m->wt[0]; j->w1 = (int16_t)m->wt[1]; j->o0 = (int16_t)m->of[0]; j->o1 = (int16_t)m->of[1];
+        }
+        memcpy(fill, stu, (size_t)(L + 2) * sizeof(int));
+        for (int i = 0; i < R.ntu; i++) {
+            const TuRec *t = &R.tu[i];
+            mi355_hevc_tu_job *j = &jt[fill[t->level]++];
+            memset(j, 0, sizeof(*j));
+            j->coeffs = (int16_t *)(R.d_stage + o_coef) + t->coef_off;
+            j->dst = resolve(&t->dst); j->dst_stride = t->dstride;
+            j->log2_size = (uint8_t)t->log2; j->col_limit = (uint8_t)t->col_limit; j->kind = (uint8_t)t->kind;
+        }
+        memcpy(fill, sin, (size_t)(L + 2) * sizeof(int));
+        for (int i = 0; i < R.nintra; i++) ji[fill[R.intra[i].level]++] = R.intra[i].b;
+        free(fill);
+    }
+    mi355_hevc_intra_picture *d = (mi355_hevc_intra_picture *)(R.h_stage + o_desc);
+    memset(d, 0, sizeof(*d));
+    for (int k = 0; k < 3; k++) { d->data[k] = uc->dev + uc->off[k]; d->linesize[k] = uc->linesize[k]; }
+    d->width = sps->width; d->height = sps->height; d->hshift = sps->hshift[1]; d->vshift = sps->vshift[1];
+    d->log2_min_pu_size = sps->log2_min_pu_size; d->log2_min_tb_size = sps->log2_min_tb_size;
+    d->min_pu_width = sps->min_pu_width; d->min_pu_height = sps->min_pu_height; d->min_tb_width = sps->min_tb_width;
+    d->constrained_intra_pred = s->ps.pps->constrained_intra_pred_flag;
+    d->strong_intra_smoothing = sps->sps_strong_intra_smoothing_enable_flag;
+    d->tab_mvf = (const mi355_hevc_mvfield *)R.d_mvf; d->min_tb_addr_zs = (const int32_t *)R.d_zs;
+    memcpy(R.h_stage + o_coef, R.coef, R.ncoef * sizeof(int16_t));
+    int rc = mi355_memcpy_h2d(R.d_stage, R.h_stage, o);
+    if (R.nintra) rc |= mi355_memcpy_h2d(R.d_mvf, s->ref->tab_mvf, mvf_bytes) | mi355_memcpy_h2d(R.d_zs, s->ps.pps->min_tb_addr_zs, zs_bytes);
+    if (rc) { free(start); return -1; }
+    /* windows first (they read reference pictures only), then level by level: the three kinds of one level touch disjoint samples */
+    if (R.nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(R.d_stage + o_emu), R.nemu, R.bd, NULL) != 0) rc = -1;
+    for (int l = 1; l <= L && !rc; l++) {
+        const int nm = smc[l + 1] - smc[l], nt = stu[l + 1] - stu[l], ni = sin[l + 1] - sin[l];
+        if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(R.d_stage + o_mc) + smc[l], nm, R.bd, NULL) != 0) rc = -1;
+        if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(R.d_stage + o_tu) + stu[l], nt, R.bd, NULL) != 0) rc = -1;
+        if (ni && mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
+        R.launches += (nm != 0) + (nt != 0) + (ni != 0);
+    }
+    free(start);
+    if (rc) return -1;
+    R.levels_total += (unsigned long)L;
+    /* where the finished picture goes */
+    Surface *uf = uc;
+    if (sps->sao_enabled) {
+        uf = surface_of_frame(s, s->sao_frame, 1);
+        if (!uf) return -1;
+    }
+    for (int k = 0; k < 3; k++) { cur[k] = uc->dev + uc->off[k]; fin[k] = uf->dev + uf->off[k]; }
+    uf->valid = 1; uf->poc = s->poc;         /* true once the filter bridge's passes (queued behind these launches) have run */
+    if (uf != uc) uc->valid = 0;
+    R.on_device++;
+    return 1;
+}
+
+/* for hosts that want the numbers */
+void mi355_hevc_bridge_stats(unsigned long *pictures, unsigned long *on_device, unsigned long *uploads, unsigned long *launches, unsigned long *levels)
+{
+    if (pictures) *pictures = R.pictures;
+    if (on_device) *on_device = R.on_device;
+    if (uploads) *uploads = R.uploads;
+    if (launches) *launches = R.launches;
+    if (levels) *levels = R.levels_total;
+}

@@ -79,6 +79,12 @@ static int ensure(uint8_t **p, size_t *have, size_t want)
     return *p ? 0 : -1;
 }
 
+/* the reconstruction bridge (contrib/libav/mi355_hevc_bridge.c, when linked in) asks per picture: the two must agree */
+int mi355_hevc_lf_bridge_active(const HEVCContext *s) { return active(s); }
+/* ... and hands over the picture it reconstructed on the device: 1 = cur[] holds the unfiltered picture (device planes), the
+ * finished one goes to fin[]; 0 = not its picture (the host frame is uploaded, as without it); < 0 = failed */
+int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3]) __attribute__((weak));
+
 static void fail(const char *what)
 {
     fprintf(stderr, "mi355 hevc lf bridge: %s; the reference's path takes over\n", what);
@@ -243,9 +249,15 @@ static int filter_picture(HEVCContext *s)
     size_t sz[3];
     /* lf.stream stays the default stream: the plain copies below run on it too, so copies and passes are ordered by the
      * stream alone (a binding that overlaps pictures would take pinned staging + its own stream, as the H.264 bridge does) */
+    uint8_t *plane[3], *out[3], *rcur[3], *rfin[3];
+    const int on_dev = mi355_hevc_recon_finish ? mi355_hevc_recon_finish(s, rcur, rfin) : 0;
+    if (on_dev < 0) return -3;                                   /* the picture exists nowhere: see __wrap_ff_hevc_hls_filter */
     for (int i = 0; i < 3; i++) {
         sz[i] = (size_t)s->frame->linesize[i] * h[i];
-        if (s->frame->linesize[i] <= 0 || ensure(&lf.plane[i], &lf.plane_bytes[i], sz[i])) return -1;
+        if (s->frame->linesize[i] <= 0) return -1;
+        if (on_dev) { plane[i] = rcur[i]; continue; }
+        if (ensure(&lf.plane[i], &lf.plane_bytes[i], sz[i])) return -1;
+        plane[i] = lf.plane[i];
     }
     const size_t bs = 2 * (size_t)s->bs_width * (s->bs_height + 1);
     const size_t qp = (size_t)((sps->width >> sps->log2_min_cb_size) + 1) * ((sps->height >> sps->log2_min_cb_size) + 1);
@@ -259,7 +271,7 @@ static int filter_picture(HEVCContext *s)
 
     mi355_hevc_lf_picture d;
     memset(&d, 0, sizeof(d));
-    for (int i = 0; i < 3; i++) { d.data[i] = lf.plane[i]; d.linesize[i] = s->frame->linesize[i]; }
+    for (int i = 0; i < 3; i++) { d.data[i] = plane[i]; d.linesize[i] = s->frame->linesize[i]; }
     d.width = sps->width; d.height = sps->height;
     d.log2_ctb_size = sps->log2_ctb_size;
     d.log2_min_cb_size = sps->log2_min_cb_size;
@@ -276,7 +288,7 @@ static int filter_picture(HEVCContext *s)
     d.cb_qp_offset = s->ps.pps->cb_qp_offset; d.cr_qp_offset = s->ps.pps->cr_qp_offset;
 
     int rc = 0;
-    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_h2d(lf.plane[i], s->frame->data[i], sz[i]);
+    for (int i = 0; i < 3 && !on_dev; i++) rc |= mi355_memcpy_h2d(plane[i], s->frame->data[i], sz[i]);
     if (!bs_on_device(s, bs)) rc |= mi355_memcpy_h2d(lf.vbs, s->vertical_bs, bs) | mi355_memcpy_h2d(lf.hbs, s->horizontal_bs, bs);
     lf.bs_ref = NULL;
     rc |= mi355_memcpy_h2d(lf.qp, s->qp_y_tab, qp) | mi355_memcpy_h2d(lf.pcm, s->is_pcm, pcm) | mi355_memcpy_h2d(lf.db, s->deblock, db);
@@ -285,7 +297,7 @@ static int filter_picture(HEVCContext *s)
     if (mi355_hevc_deblock_pictures_dev(lf.desc, 1, sps->width, sps->height, sps->bit_depth, lf.stream) != 0) return -2;
     if (!sps->sao_enabled) {
         if (mi355_sync(lf.stream) != 0) return -2;
-        for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], lf.plane[i], sz[i]);
+        for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], plane[i], sz[i]);
         if (rc) return -2;
         lf.pictures++;
         return 0;
@@ -299,14 +311,55 @@ static int filter_picture(HEVCContext *s)
         if (!lf.host_jobs) return -1;
     }
     if (ensure(&lf.jobs, &lf.jobs_bytes, max_jobs * sizeof(*lf.host_jobs))) return -1;
-    for (int i = 0; i < 3; i++) if (ensure(&lf.out[i], &lf.out_bytes[i], sz[i])) return -1;
-    const int n = sao_jobs(s, lf.out, lf.plane, lf.host_jobs);
+    for (int i = 0; i < 3; i++) {
+        if (on_dev) { out[i] = rfin[i]; continue; }
+        if (ensure(&lf.out[i], &lf.out_bytes[i], sz[i])) return -1;
+        out[i] = lf.out[i];
+    }
+    const int n = sao_jobs(s, out, plane, lf.host_jobs);
     if (mi355_sync(lf.stream) != 0) return -2;
     if (n) rc |= mi355_memcpy_h2d(lf.jobs, lf.host_jobs, (size_t)n * sizeof(*lf.host_jobs));
     if (rc) return -2;
     if (n && mi355_hevc_sao_ctbs_dev((const mi355_hevc_sao_ctb_job *)lf.jobs, n, sps->bit_depth, lf.stream) != 0) return -2;
+    /* cu_transquant_bypass / pcm_loop_filter_disabled blocks keep their deblocked samples: the decoder copies them from s->frame into
+     * s->sao_frame on the host afterwards (restore_tqb_pixels, hevcdec.c:2343-2370, called :2596-2600).  A picture reconstructed on the
+     * device has them only there: the same copy for the device picture (window jobs: plain block copies), and the deblocked picture goes
+     * to the host's s->frame too, for the decoder's own copy */
+    const int restore = on_dev && (s->ps.pps->transquant_bypass_enable_flag || (sps->pcm.loop_filter_disable_flag && sps->pcm_enabled_flag));
+    if (restore) {
+        const int mps = 1 << sps->log2_min_pu_size;
+        size_t nj = 0;
+        for (size_t i = 0; i < pcm; i++) nj += s->is_pcm[i] != 0;
+        if (nj) {
+            mi355_edge_emu_job *hj = malloc(3 * nj * sizeof(*hj));
+            uint8_t *dj = mi355_malloc(3 * nj * sizeof(*hj));
+            if (!hj || !dj) { free(hj); if (dj) mi355_free(dj); return -1; }
+            size_t k = 0;
+            for (int y = 0; y < sps->min_pu_height; y++)
+                for (int x = 0; x < sps->min_pu_width; x++) {
+                    if (!s->is_pcm[y * sps->min_pu_width + x]) continue;
+                    for (int c = 0; c < 3; c++) {
+                        const int hs = sps->hshift[c], vs = sps->vshift[c];
+                        const size_t off = (size_t)((y * mps) >> vs) * s->frame->linesize[c] + ((size_t)((x * mps) >> hs) << sps->pixel_shift);
+                        mi355_edge_emu_job *j = &hj[k++];
+                        memset(j, 0, sizeof(*j));
+                        j->dst = out[c] + off; j->src = plane[c] + off;
+                        j->dst_stride = j->src_stride = s->frame->linesize[c];
+                        /* the reference copies `min_pu_size >> hshift` BYTES per row (hevcdec.c:2357-2363): half the block's samples above 8 bit */
+                        j->block_w = (mps >> hs) >> sps->pixel_shift; j->block_h = mps >> vs;
+                        j->src_x = (x * mps) >> hs; j->src_y = (y * mps) >> vs; j->w = sps->width >> hs; j->h = sps->height >> vs;
+                    }
+                }
+            rc = mi355_memcpy_h2d(dj, hj, k * sizeof(*hj));
+            if (!rc && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)dj, (int)k, sps->bit_depth, lf.stream) != 0) rc = -1;
+            rc |= mi355_sync(lf.stream);
+            free(hj); mi355_free(dj);
+            if (rc) return -2;
+        }
+    }
     if (mi355_sync(lf.stream) != 0) return -2;
-    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->sao_frame->data[i], lf.out[i], sz[i]);
+    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->sao_frame->data[i], out[i], sz[i]);
+    if (restore) for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], plane[i], sz[i]);
     if (rc) return -2;
     lf.pictures++;
     return 0;
@@ -324,7 +377,9 @@ void __wrap_ff_hevc_hls_filter(HEVCContext *s, int x, int y)
 {
     if (!active(s)) { __real_ff_hevc_hls_filter(s, x, y); return; }
     if (getenv("MI355_HEVC_LF_TRACE")) fprintf(stderr, "lf: picture poc %d, last CTB at %d, %d (slice from CTB %d)\n", s->poc, x, y, s->sh.slice_ctb_addr_rs);
-    if (filter_picture(s) != 0) {
+    const int frc = filter_picture(s);
+    if (frc == -3) { fail("the device reconstruction of a picture failed: that picture is lost"); return; }
+    if (frc != 0) {
         /* nothing of this picture has been filtered yet: the reference's own loop over all CTBs does it */
         fail("the device pass failed");
         const int ctb = 1 << s->ps.sps->log2_ctb_size;

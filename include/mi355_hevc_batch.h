@@ -24,7 +24,9 @@ extern "C" {
 
 /* a13/a12: one transform unit: c->idct[]/idct_dc[]/transform_4x4_luma/dequant (hevcdsp.h:46-52), then
  * c->add_residual[] (:45) when `dst` is set (the tail of hls_transform_unit, hevcdec.c:1238-1260) */
-enum { MI355_HEVC_TU_IDCT = 0, MI355_HEVC_TU_IDCT_DC = 1, MI355_HEVC_TU_DST4 = 2, MI355_HEVC_TU_SKIP = 3 };
+enum { MI355_HEVC_TU_IDCT = 0, MI355_HEVC_TU_IDCT_DC = 1, MI355_HEVC_TU_DST4 = 2, MI355_HEVC_TU_SKIP = 3,
+       MI355_HEVC_TU_BYPASS = 4,      /* cu_transquant_bypass: the coefficients ARE the residual (hls_residual_coding, hevcdec.c:1236-1260) */
+       MI355_HEVC_TU_PCM = 5 };       /* pcm_sample: `coeffs` holds the samples themselves (put_pcm, hevcdsp_template.c:28-41): stored, not added */
 typedef struct mi355_hevc_tu_job {
     int16_t *coeffs;          /* size x size, row-major; rewritten in place when dst == NULL */
     uint8_t *dst;             /* picture samples of the block, or NULL */

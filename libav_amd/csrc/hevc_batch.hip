@@ -53,19 +53,20 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
         for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(j.coeffs)[i] = reinterpret_cast<const uint32_t *>(c)[i];
         return;
     }
-    /* add_residual (:51-82): two samples per lane */
+    /* add_residual (:51-82): two samples per lane; PCM blocks store their samples instead */
     const int hw = size >> 1;
+    const uint32_t keep = j.kind == MI355_HEVC_TU_PCM ? 0u : 0xFFFFFFFFu;
     for (int i = hl; i < cnt / 2; i += 32) {
         const int y = i / hw, x = 2 * (i - y * hw);
         uint8_t *row = j.dst + (size_t)y * j.dst_stride;
         const int r0 = c[y * size + x], r1 = c[y * size + x + 1];
         if (bd > 8) {
             uint32_t *p = reinterpret_cast<uint32_t *>(row) + (x >> 1);
-            const uint32_t v = *p;
+            const uint32_t v = *p & keep;
             *p = (uint32_t)clip_px((int)(v & 0xFFFF) + r0, bd) | ((uint32_t)clip_px((int)(v >> 16) + r1, bd) << 16);
         } else {
             uint16_t *p = reinterpret_cast<uint16_t *>(row) + (x >> 1);
-            const uint32_t v = *p;
+            const uint32_t v = *p & keep;
             *p = (uint16_t)(clip_px((int)(v & 0xFF) + r0, bd) | (clip_px((int)(v >> 8) + r1, bd) << 8));
         }
     }

@@ -1,0 +1,34 @@
+"""CPU (emulated kernels), where /root/reference exists: the HEVC Tier-2 bridge — the reference's own HEVC decoder with every
+prediction block, transform unit, intra block and PCM block RECORDED through its three pointer tables and run on the (emulated)
+device level by level, the in-loop filters of the picture on the same device picture, references in device memory
+(contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c; VERDICT r2 "what's missing" 1).  Every generated stream — I / P / B,
+all transform sizes and scans, Intra NxN, PCM, transform skip, transquant bypass with the filters on, SAO with merging, slices,
+AMP, merge / AMVP, explicit weights, constrained intra prediction, 8 and 10 bit — must come out as from the unmodified decoder."""
+import os
+import subprocess
+
+import pytest
+
+import hevc_streams as HS
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/libavcodec"), reason="needs the reference decoder objects (/root/reference)")
+
+
+@pytest.mark.parametrize("name", HS.ALL)
+def test_hevc_bridge_decodes_generated_streams_emulated(tmp_path, emu, name):
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_emu", name, out)
+    n = HS.MD5[name]["pictures"]
+    assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n and st["pictures_filtered_on_device"] == n, st
+    assert st["reference_uploads"] == 0, st                               # references never crossed the link
+    HS.check_md5(out, name)
+
+
+def test_hevc_bridge_plain_run_is_the_reference_path(tmp_path, emu):
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    name = HS.ALL[0]
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_emu", name, out, plain=True)
+    assert st["pictures_reconstructed_on_device"] == 0 and st["pictures_filtered_on_device"] == 0
+    HS.check_md5(out, name)

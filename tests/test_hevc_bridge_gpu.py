@@ -1,0 +1,31 @@
+"""GPU: the HEVC Tier-2 bridge (contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c) inside the reference's own HEVC decoder
+bound to the real library (oracle/_ref/hevc_bridge_gpu, built HERE by __graft_entry__.build(); /root/reference is not read on the
+GPU box): every generated stream reconstructed and filtered on the MI355X, references in HBM, output identical to the unmodified
+decoder's (tests/golden/hevc_streams.json)."""
+import os
+
+import pytest
+
+import hevc_streams as HS
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(HS.ROOT, "oracle", "_ref", "hevc_bridge_gpu")
+
+
+@pytest.mark.parametrize("name", HS.ALL)
+def test_hevc_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name):
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/hevc_bridge_gpu missing: __graft_entry__.build() makes it where /root/reference exists")
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_gpu", name, out)
+    n = HS.MD5[name]["pictures"]
+    assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n and st["pictures_filtered_on_device"] == n, st
+    assert st["reference_uploads"] == 0, st
+    HS.check_md5(out, name)
+
+
+def test_hevc_bridge_plain_run_gpu(tmp_path, mi355):
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_gpu", "pb_8bit", out, plain=True)
+    assert st["pictures_reconstructed_on_device"] == 0 and st["pictures_filtered_on_device"] == 0
+    HS.check_md5(out, "pb_8bit")
