@@ -53,7 +53,7 @@ typedef struct Surface {
     int linesize[3], rows[3];
     uint8_t *dev;                      /* one allocation, planes back to back */
     size_t off[3], bytes;
-    int valid, poc;                    /* the device copy holds the picture with this POC */
+    int valid, poc, seq;               /* the device copy holds the picture with this POC of this sequence (HEVCFrame.sequence) */
     unsigned long used;                /* picture counter at last use (recycling) */
 } Surface;
 typedef struct Loc { int surf; size_t off; } Loc;          /* surf >= 0: byte `off` of that surface's allocation; -2: of the window scratch */
@@ -126,8 +126,10 @@ static Surface *surface_of_frame(const HEVCContext *s, const AVFrame *f, int cre
     for (int i = 0; i < MAX_SURF; i++) {
         Surface *u = &R.surf[i];
         if (u->host[0] == f->data[0] && u->host[0]) {
-            /* the same buffer with another geometry (a new sequence): start over */
-            if (u->linesize[0] != f->linesize[0] || u->rows[0] != s->ps.sps->height) { u->valid = 0; u->host[0] = NULL; free_slot = free_slot ? free_slot : u; continue; }
+            /* the same first plane with other planes or another geometry (the buffer pool hands planes out one by one; a new sequence, a new
+             * decoder): not the frame this surface mirrors — start over */
+            if (u->host[1] != f->data[1] || u->host[2] != f->data[2] || u->linesize[0] != f->linesize[0] || u->linesize[1] != f->linesize[1] ||
+                u->rows[0] != s->ps.sps->height) { u->valid = 0; u->host[0] = NULL; free_slot = free_slot ? free_slot : u; continue; }
             return u;
         }
         if (!u->host[0]) { if (!free_slot) free_slot = u; }
@@ -437,6 +439,8 @@ int __wrap_ff_hevc_frame_rps(HEVCContext *s)
 {
     const int ret = __real_ff_hevc_frame_rps(s);
     first_use();
+    if (R.s != s)                       /* another decoder on this thread: nothing on the device is its picture */
+        for (int i = 0; i < MAX_SURF; i++) R.surf[i].valid = 0;
     R.s = s;
     R.on = 0;
     R.pictures++;
@@ -488,7 +492,7 @@ static int surface_current(const HEVCContext *s, const Surface *u)
     if (!u->valid) return 0;
     for (int i = 0; i < FF_ARRAY_ELEMS(s->DPB); i++) {
         const HEVCFrame *f = &s->DPB[i];
-        if (f->frame && f->frame->data[0] == u->host[0]) return f->poc == u->poc;
+        if (f->frame && f->frame->data[0] == u->host[0]) return f->poc == u->poc && f->sequence == u->seq;
     }
     return 1;      /* the work frame of sequences with SAO (s->tmp_frame) is nobody's reference */
 }
@@ -617,7 +621,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
         if (!uf) return -1;
     }
     for (int k = 0; k < 3; k++) { cur[k] = uc->dev + uc->off[k]; fin[k] = uf->dev + uf->off[k]; }
-    uf->valid = 1; uf->poc = s->poc;         /* true once the filter bridge's passes (queued behind these launches) have run */
+    uf->valid = 1; uf->poc = s->poc; uf->seq = s->seq_decode;         /* true once the filter bridge's passes (queued behind these launches) have run */
     if (uf != uc) uc->valid = 0;
     R.on_device++;
     return 1;
