@@ -37,7 +37,8 @@ void __real_ff_hevc_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_si
 void __real_ff_hevc_hls_filter(HEVCContext *s, int x, int y);
 void __real_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size);
 
-static struct {
+/* one decoder per thread (as the reconstruction bridge): the state is the thread's */
+static __thread struct {
     size_t plane_bytes[3], bs_bytes, qp_bytes, pcm_bytes, db_bytes;
     uint8_t *plane[3], *vbs, *hbs, *qp, *pcm, *db;
     uint8_t *out[3], *jobs;                /* SAO: the output picture, the job list */
@@ -61,7 +62,7 @@ static struct {
 static void fail(const char *what);
 static int active(const HEVCContext *s)
 {
-    static int init;
+    static __thread int init;
     if (!init) {
         init = 1;
         lf.plain = getenv("MI355_HEVC_LF_PLAIN") != NULL;

@@ -24,6 +24,7 @@
  * filter_mb_dir + check_mv (h264_loopfilter.c:442-847), fill_filter_caches
  * (h264_slice.c:2056-2196).
  */
+#include <cstdlib>
 #include <vector>
 #include "mi355_rt.h"
 #include "h264_dev.h"
@@ -728,20 +729,20 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
     if (left_y) TILE(-1, lane - 32) = e_y;
     if (top_c) { CTILE(0, lane - 1, -1) = e_cb; CTILE(1, lane - 1, -1) = e_cr; }
     if (left_c) { CTILE(0, -1, lane - 16) = e_cb; CTILE(1, -1, lane - 16) = e_cr; }
-    __syncthreads();
+    MI355_WAVE_SYNC();
 
     /* chroma prediction: hpc.pred8x8[chroma_pred_mode], h264_mb_template.c:161-164 */
     for (int p = 0; p < 2; p++) {
         if (lane < 9) s.ps.T[lane] = CTILE(p, lane - 1, -1);
         if (lane >= 16 && lane < 25) s.ps.L[lane - 16] = CTILE(p, -1, lane - 17);
-        __syncthreads();
+        MI355_WAVE_SYNC();
         intra_pred_wave(s.ps, 2, h.chroma_pred_mode, 0, 0, &CTILE(p, 0, 0), CP);
     }
 
     if (t & MI355_MB_INTRA16x16) {       /* h264_mb.c:701-722 */
         if (lane < 17) s.ps.T[lane] = TILE(lane - 1, -1);
         if (lane >= 32 && lane < 49) s.ps.L[lane - 32] = TILE(-1, lane - 33);
-        __syncthreads();
+        MI355_WAVE_SYNC();
         intra_pred_wave(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &TILE(0, 0), TP);
         if ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1) {
             /* ff_h264_luma_dc_dequant_idct (h264idct_template.c:242-271) on sixteen lanes: lane 4a + b holds level b of
@@ -763,7 +764,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
                 const int r = b4 == 0 ? ss + uu : (b4 == 1 ? dd + ee : (b4 == 2 ? dd - ee : ss - uu));
                 s.mb.coef[luma_dc_slot(lane)] = (int16_t)((r * (int)h.dc_qmul[0] + 128) >> 8);
             }
-            __syncthreads();
+            MI355_WAVE_SYNC();
         }
         residual_luma<true>(s.mb, &TILE(0, 0), TP, true);
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
@@ -771,13 +772,13 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
             if (lane < 17) s.ps.T[lane] = TILE(x0 + lane - 1, y0 - 1);
             if (lane >= 32 && lane < 41) s.ps.L[lane - 32] = TILE(x0 - 1, y0 + lane - 33);
-            __syncthreads();
+            MI355_WAVE_SYNC();
             intra_pred_wave(s.ps, 1, h.u.intra4x4_pred_mode[i], (h.topleft_samples_available << i) & 0x8000,
                             (h.topright_samples_available << i) & 0x4000, &TILE(x0, y0), TP);
             int r[8];
             idct8_lds(s.mb.coef + i8 * 64, lane & 7, lane < 8, r);
             if (lane < 8 && ((h.nnz_mask >> i) & 1)) add_col(&TILE(x0 + lane, y0), TP, r, 8);
-            __syncthreads();
+            MI355_WAVE_SYNC();
         }
     } else {                              /* Intra 4x4: h264_mb.c:657-700 */
         for (int i = 0; i < 16; i++) {
@@ -786,7 +787,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
             if (lane < 5) s.ps.T[lane] = TILE(x0 + lane - 1, y0 - 1);
             else if (lane < 9) s.ps.T[lane] = tr_ok ? TILE(x0 + lane - 1, y0 - 1) : TILE(x0 + 3, y0 - 1);
             if (lane >= 32 && lane < 37) s.ps.L[lane - 32] = TILE(x0 - 1, y0 + lane - 33);
-            __syncthreads();
+            MI355_WAVE_SYNC();
             intra_pred_wave(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &TILE(x0, y0), TP);
             const int q = lane & 3;
             int c[4], r[4], row;
@@ -794,7 +795,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
             for (int k2 = 0; k2 < 4; k2++) c[k2] = s.mb.coef[i * 16 + q + 4 * k2];
             idct4_quad(c, q, r, row);
             if (lane < 4 && ((h.nnz_mask >> i) & 1)) add_row4<true>(&TILE(x0, y0 + row), r);
-            __syncthreads();
+            MI355_WAVE_SYNC();
         }
     }
     residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
@@ -815,6 +816,33 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     const int mb_xy = (int)mi355_global(frd.intra_list)[first + k];
     if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true>(s, frd, mb_xy);
     else recon_intra_mb<false>(s, frd, mb_xy);
+}
+
+/* The same for pictures whose intra macroblocks form long dependency chains (I pictures: width + 2 height levels): ONE launch, a
+ * workgroup of INTRA_WAVES waves per picture walks the picture's levels — wave w takes macroblocks w, w + INTRA_WAVES, ... of a
+ * level, the workgroup meets at a barrier between levels (workgroup-scope release / acquire: the waves of a workgroup share the
+ * CU's L1, so the samples a wave stored are what the others load).  A level costs a barrier instead of a launch. */
+constexpr int INTRA_WAVES = 8;
+__global__ void __launch_bounds__(64 * INTRA_WAVES)
+k_recon_intra_levels(const mi355_h264_frame *frames)
+{
+    __shared__ IntraLds s[INTRA_WAVES];
+    const mi355_h264_frame &frd = frames[blockIdx.x];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int levels = uniform(frd.max_intra_level);
+    const bool tiled = uniform(frd.surface_layout) == MI355_SURFACE_TILED;
+    const int32_t *start = mi355_global(frd.intra_level_start);
+    const uint32_t *list = mi355_global(frd.intra_list);
+    for (int level = 1; level <= levels; level++) {
+        const int first = uniform(start[level - 1]), count = uniform(start[level]) - first;
+        for (int k = wave; k < count; k += INTRA_WAVES) {
+            const int mb_xy = uniform((int)list[first + k]);
+            if (tiled) recon_intra_mb<true>(s[wave], frd, mb_xy);
+            else recon_intra_mb<false>(s[wave], frd, mb_xy);
+            MI355_WAVE_SYNC();      /* the wave's LDS record is reused: every lane is done with this macroblock's before the next one's arrives */
+        }
+        __syncthreads();
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1541,6 +1569,15 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
 extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream)
 {
     if (!mi355::bind() || !d_frames || nframes <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
+    /* long chains (I pictures, intra-heavy pictures): one launch that walks the levels inside a workgroup per picture; short ones
+     * (a few wide levels: P / B pictures with scattered intra macroblocks): a launch per level fills the device better.
+     * MI355_INTRA_PERSISTENT=0 / 1 forces one form (developer switch) */
+    const char *fe = std::getenv("MI355_INTRA_PERSISTENT");
+    const int forced = fe ? (fe[0] == '0' ? 0 : 1) : -1;
+    if (max_intra_level > 0 && (forced == 1 || (forced < 0 && max_intra_level >= 12))) {
+        hipLaunchKernelGGL(k_recon_intra_levels, dim3((unsigned)nframes), dim3(64 * INTRA_WAVES), 0, (hipStream_t)stream, d_frames);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     for (int level = 1; level <= max_intra_level; level++) {
         const int width = level_widths[level - 1];
         if (width <= 0) continue;

@@ -32,6 +32,8 @@ if [ "$CLIP" = cockatoo ]; then
 else
   for t in 1 32 128 256; do run plain "MI355_BRIDGE_PLAIN=1" $t $LOOPS; done
   for t in 1 8 32 128 256; do run batched "X=1" $t $LOOPS; done
+  for t in 32 128; do run batched_linear "MI355_BRIDGE_LINEAR=1" $t $LOOPS; done
+  for t in 1 32; do run sessions "MI355_BRIDGE_SESSION=1" $t $LOOPS; done
   for t in 1 32 128 256; do run batched_lazy "MI355_BRIDGE_LAZY=1" $t $LOOPS; done
   for t in 1 8 32; do run direct "MI355_BRIDGE_DIRECT=1" $t $LOOPS; done
 fi

@@ -2,6 +2,7 @@
 #include "hip_emu.h"
 
 #include <cstdio>
+#include <dlfcn.h>
 #include <ucontext.h>
 #include <vector>
 
@@ -17,6 +18,7 @@ struct Fiber {
     int xchg_arg;
     int xchg_res;
     char *stack;
+    const void *where = nullptr;   /* return address of the pending barrier / wave operation (deadlock report) */
 };
 
 Lane *cur = nullptr;
@@ -43,7 +45,7 @@ static void yield_as(State s)
     /* resumed */
 }
 
-void barrier_block() { yield_as(WAIT_BLOCK); }
+void barrier_block() { cur_fiber->where = __builtin_return_address(0); yield_as(WAIT_BLOCK); }
 
 /* All live lanes of the wave publish, yield, and are resumed once every live lane of
  * the wave has published; the resolver (scheduler) fills xchg_res. */
@@ -57,7 +59,7 @@ static int wave_op(int v, int arg, int mode_width)
     return f->xchg_res;
 }
 
-int shfl_exchange(int v, int a, int width, int mode) { return wave_op(v, a, (mode << 8) | (width & 0xFF)); }
+int shfl_exchange(int v, int a, int width, int mode) { cur_fiber->where = __builtin_return_address(0); return wave_op(v, a, (mode << 8) | (width & 0xFF)); }
 unsigned long long ballot(int pred)
 {
     int lo = wave_op(pred != 0, 0, (4 << 8) | 64);
@@ -163,6 +165,20 @@ static void run_block(const std::function<void()> &body, unsigned nthreads)
             for (unsigned t = 0; t < nthreads; t++)
                 std::fprintf(stderr, "%d", (int)fibers[t].st);
             std::fprintf(stderr, "\n");
+            /* where the stuck lanes wait (addresses inside the library: addr2line -e tests/_emu/libmi355dsp_emu.so <offset>) */
+            {
+                const void *seen[8]; int ns = 0;
+                for (unsigned t = 0; t < nthreads; t++) {
+                    if (fibers[t].st == DONE) continue;
+                    bool dup = false;
+                    for (int k = 0; k < ns; k++) dup = dup || seen[k] == fibers[t].where;
+                    if (dup || ns >= 8) continue;
+                    seen[ns++] = fibers[t].where;
+                    Dl_info di;
+                    if (dladdr(fibers[t].where, &di) && di.dli_fbase)
+                        std::fprintf(stderr, "  lane %u (state %d) waits at %s+0x%lx\n", t, (int)fibers[t].st, di.dli_fname, (unsigned long)((const char *)fibers[t].where - (const char *)di.dli_fbase));
+                }
+            }
             std::abort();
         }
     }
