@@ -818,33 +818,6 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     else recon_intra_mb<false>(s, frd, mb_xy);
 }
 
-/* The same for pictures whose intra macroblocks form long dependency chains (I pictures: width + 2 height levels): ONE launch, a
- * workgroup of INTRA_WAVES waves per picture walks the picture's levels — wave w takes macroblocks w, w + INTRA_WAVES, ... of a
- * level, the workgroup meets at a barrier between levels (workgroup-scope release / acquire: the waves of a workgroup share the
- * CU's L1, so the samples a wave stored are what the others load).  A level costs a barrier instead of a launch. */
-constexpr int INTRA_WAVES = 8;
-__global__ void __launch_bounds__(64 * INTRA_WAVES)
-k_recon_intra_levels(const mi355_h264_frame *frames)
-{
-    __shared__ IntraLds s[INTRA_WAVES];
-    const mi355_h264_frame &frd = frames[blockIdx.x];
-    const int wave = (int)(threadIdx.x >> 6);
-    const int levels = uniform(frd.max_intra_level);
-    const bool tiled = uniform(frd.surface_layout) == MI355_SURFACE_TILED;
-    const int32_t *start = mi355_global(frd.intra_level_start);
-    const uint32_t *list = mi355_global(frd.intra_list);
-    for (int level = 1; level <= levels; level++) {
-        const int first = uniform(start[level - 1]), count = uniform(start[level]) - first;
-        for (int k = wave; k < count; k += INTRA_WAVES) {
-            const int mb_xy = uniform((int)list[first + k]);
-            if (tiled) recon_intra_mb<true>(s[wave], frd, mb_xy);
-            else recon_intra_mb<false>(s[wave], frd, mb_xy);
-            MI355_WAVE_SYNC();      /* the wave's LDS record is reused: every lane is done with this macroblock's before the next one's arrives */
-        }
-        __syncthreads();
-    }
-}
-
 /* ------------------------------------------------------------------------- */
 /* deblocking                                                                   */
 /* ------------------------------------------------------------------------- */
@@ -1569,15 +1542,11 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
 extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream)
 {
     if (!mi355::bind() || !d_frames || nframes <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
-    /* long chains (I pictures, intra-heavy pictures): one launch that walks the levels inside a workgroup per picture; short ones
-     * (a few wide levels: P / B pictures with scattered intra macroblocks): a launch per level fills the device better.
-     * MI355_INTRA_PERSISTENT=0 / 1 forces one form (developer switch) */
-    const char *fe = std::getenv("MI355_INTRA_PERSISTENT");
-    const int forced = fe ? (fe[0] == '0' ? 0 : 1) : -1;
-    if (max_intra_level > 0 && (forced == 1 || (forced < 0 && max_intra_level >= 12))) {
-        hipLaunchKernelGGL(k_recon_intra_levels, dim3((unsigned)nframes), dim3(64 * INTRA_WAVES), 0, (hipStream_t)stream, d_frames);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
+    /* one launch per level.  Measured and not kept (round 3, tools/exp_intra.py): ONE launch with a workgroup of eight waves per
+     * picture walking the picture's levels (a barrier instead of a launch per level) — all-intra 512 pictures 6.2 ms against 5.5,
+     * 64 pictures 5.0 against 1.9, P pictures 1.1 against 0.9: a level of an I picture is up to 60 macroblocks wide, a workgroup
+     * works through it in rounds, and the picture's 254 levels become a serial chain of ~20 us each whatever the batch, while a
+     * launch runs a level of ALL pictures side by side for ~7.5 us */
     for (int level = 1; level <= max_intra_level; level++) {
         const int width = level_widths[level - 1];
         if (width <= 0) continue;
