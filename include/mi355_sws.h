@@ -66,7 +66,7 @@ int mi355_sws_scale(mi355_sws_ctx *ctx, const uint8_t *const src[3], const int s
                     uint8_t *dst, int dst_stride);
 
 /* Tier 2: a batch of pictures resident in HBM, one launch; d_frames is a device array. */
-void mi355_sws_scale_frames_dev(mi355_sws_ctx *ctx, const mi355_sws_frame *d_frames, int nframes, void *stream);
+int mi355_sws_scale_frames_dev(mi355_sws_ctx *ctx, const mi355_sws_frame *d_frames, int nframes, void *stream);   /* 0, -1 bad argument, -2 launch failure */
 
 /* ---- the individual inner loops (Tier 1, host pointers), argument lists of the reference's
  * function-pointer types minus the SwsContext ------------------------------------------------ */

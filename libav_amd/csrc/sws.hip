@@ -720,8 +720,9 @@ extern "C" void mi355_sws_destroy(mi355_sws_ctx *c)
     delete c;
 }
 
-extern "C" void mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_frame *d_frames, int nframes, void *stream)
+extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_frame *d_frames, int nframes, void *stream)
 {
+    if (!c || !d_frames || nframes <= 0) return -1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SwsDev &h = c->h;
     DeviceScope on(c->device);
@@ -731,7 +732,7 @@ extern "C" void mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fra
     } else {
         hipLaunchKernelGGL(k_sws_generic, dim3((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes), dim3(NT), 0, s, c->d, d_frames);
     }
-    MI355_CHECK(hipGetLastError());
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 /* copy a host plane into a tightly pitched device plane */
@@ -758,7 +759,7 @@ extern "C" int mi355_sws_scale(mi355_sws_ctx *c, const uint8_t *const src[3], co
     }
     const int w[3] = { h.srcW, cw, cw };
     for (int p = 0; p < 3; p++) plane_h2d(c->d_src[p], pw[p], src[p], src_stride[p], w[p], ph[p], c->stream);
-    mi355_sws_scale_frames_dev(c, c->d_frame, 1, c->stream);
+    if (mi355_sws_scale_frames_dev(c, c->d_frame, 1, c->stream) != 0) return -2;
     /* only the samples the converter writes go back: the caller's padding stays untouched */
     const int out_w = h.special ? (h.dstW & ~1) * 3 : h.dstW * 3;
     MI355_CHECK(hipMemcpy2DAsync(dst, dst_stride, c->d_dst, dpitch, out_w, h.dstH, hipMemcpyDeviceToHost, c->stream));

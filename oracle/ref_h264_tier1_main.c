@@ -23,52 +23,15 @@
 #include "libavutil/pixdesc.h"
 
 extern AVCodec ff_h264_decoder;
-static unsigned long n_hooks;
-static int plain;     /* MI355_TIER1_PLAIN=1: leave the tables as the reference filled them (the comparison run) */
-
-void __real_ff_h264dsp_init(H264DSPContext *c, const int bit_depth, const int chroma_format_idc);
-void __wrap_ff_h264dsp_init(H264DSPContext *c, const int bit_depth, const int chroma_format_idc)
-{
-    __real_ff_h264dsp_init(c, bit_depth, chroma_format_idc);
-    if (!plain) ff_h264dsp_init_mi355x(c, bit_depth, chroma_format_idc);
-    n_hooks++;
-}
-void __real_ff_h264qpel_init(H264QpelContext *c, int bit_depth);
-void __wrap_ff_h264qpel_init(H264QpelContext *c, int bit_depth)
-{
-    __real_ff_h264qpel_init(c, bit_depth);
-    if (!plain) ff_h264qpel_init_mi355x(c, bit_depth);
-    n_hooks++;
-}
-void __real_ff_h264chroma_init(H264ChromaContext *c, int bit_depth);
-void __wrap_ff_h264chroma_init(H264ChromaContext *c, int bit_depth)
-{
-    __real_ff_h264chroma_init(c, bit_depth);
-    if (!plain) ff_h264chroma_init_mi355x(c, bit_depth);
-    n_hooks++;
-}
-void __real_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc);
-void __wrap_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc)
-{
-    __real_ff_h264_pred_init(h, codec_id, bit_depth, chroma_format_idc);
-    if (!plain) ff_h264_pred_init_mi355x(h, codec_id, bit_depth, chroma_format_idc);
-    n_hooks++;
-}
-void __real_ff_videodsp_init(VideoDSPContext *ctx, int bpc);
-void __wrap_ff_videodsp_init(VideoDSPContext *ctx, int bpc)
-{
-    __real_ff_videodsp_init(ctx, bpc);
-    if (!plain) ff_videodsp_init_mi355x(ctx, bpc);
-    n_hooks++;
-}
+/* the wraps themselves are PRODUCT code: contrib/libav/mi355_wrap.c, compiled into this binary from there */
+void mi355_wrap_stats(unsigned long *tables_hooked, unsigned long *entries_replaced);
 
 static uint32_t get_u32(FILE *f) { uint32_t v = 0; if (fread(&v, 4, 1, f) != 1) exit(4); return v; }
 
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: %s in.samples out.yuv\n", argv[0]); return 1; }
-    plain = getenv("MI355_TIER1_PLAIN") != NULL;
-    if (!plain && mi355_init(0) != 0) { fprintf(stderr, "mi355_init failed\n"); return 2; }
+    if (!getenv("MI355_TIER1_PLAIN") && mi355_init(0) != 0) { fprintf(stderr, "mi355_init failed\n"); return 2; }
     FILE *in = fopen(argv[1], "rb"), *out = fopen(argv[2], "wb");
     if (!in || !out) return 1;
     AVCodecContext *c = avcodec_alloc_context3(&ff_h264_decoder);
@@ -104,6 +67,8 @@ int main(int argc, char **argv)
         }
         if (i < n) av_packet_unref(&pkt);
     }
+    unsigned long n_hooks = 0;
+    mi355_wrap_stats(&n_hooks, NULL);
     fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked, %dx%d %s\n", n, shown, n_hooks, c->width, c->height,
             av_get_pix_fmt_name(c->pix_fmt));
     fclose(out);

@@ -22,25 +22,11 @@
 #include "libavutil/pixdesc.h"
 
 extern AVCodec ff_hevc_decoder;
-static unsigned long n_hooks, n_replaced;
-/* how many pointer-sized entries of a table the hook changed: a hook that silently fills nothing would leave the
- * comparison run comparing the reference with itself */
-static void count_replaced(const void *before, const void *after, size_t bytes)
-{
-    const void *const *a = before, *const *b = after;
-    for (size_t i = 0; i < bytes / sizeof(void *); i++) n_replaced += a[i] != b[i];
-}
+/* the wraps themselves are PRODUCT code: contrib/libav/mi355_wrap.c, compiled into this binary from there (with
+ * -DMI355_WRAP_NO_H264; ff_hevc_pred_init is wrapped HERE because of the pin below and applies the hook the same way) */
+void mi355_wrap_stats(unsigned long *tables_hooked, unsigned long *entries_replaced);
+static unsigned long n_pred_hooks, n_pred_replaced;
 static int plain;     /* MI355_TIER1_PLAIN=1: leave the tables as the reference filled them (the comparison run) */
-
-void __real_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth);
-void __wrap_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
-{
-    __real_ff_hevc_dsp_init(c, bit_depth);
-    HEVCDSPContext was = *c;
-    if (!plain) ff_hevc_dsp_init_mi355x(c, bit_depth);
-    count_replaced(&was, c, sizeof(was));
-    n_hooks++;
-}
 
 /* MI355_HEVC_INTRA_DEVICE=1 (a PIN, not a binding: one launch and two picture copies per block): HEVCPredContext.intra_pred[]
  * — the context-walking wrapper the Tier-1 hook leaves to the reference's C (hevcpred_template.c:31-334) — is replaced by
@@ -107,21 +93,12 @@ void __wrap_ff_hevc_pred_init(HEVCPredContext *c, int bit_depth)
     __real_ff_hevc_pred_init(c, bit_depth);
     HEVCPredContext was = *c;
     if (!plain) ff_hevc_pred_init_mi355x(c, bit_depth);
-    count_replaced(&was, c, sizeof(was));
+    for (size_t i = 0; i < sizeof(was) / sizeof(void *); i++) n_pred_replaced += ((void **)&was)[i] != ((void **)c)[i];
     if (getenv("MI355_HEVC_INTRA_DEVICE")) {
         if (plain && mi355_init(0) != 0) { fprintf(stderr, "mi355_init failed\n"); exit(2); }
         c->intra_pred[0] = intra_dev_2; c->intra_pred[1] = intra_dev_3; c->intra_pred[2] = intra_dev_4; c->intra_pred[3] = intra_dev_5;
     }
-    n_hooks++;
-}
-void __real_ff_videodsp_init(VideoDSPContext *ctx, int bpc);
-void __wrap_ff_videodsp_init(VideoDSPContext *ctx, int bpc)
-{
-    __real_ff_videodsp_init(ctx, bpc);
-    VideoDSPContext was = *ctx;
-    if (!plain) ff_videodsp_init_mi355x(ctx, bpc);
-    count_replaced(&was, ctx, sizeof(was));
-    n_hooks++;
+    n_pred_hooks++;
 }
 
 /* the writer's streams are open loop: a stream whose arithmetic decoding ran out of step would still decode to SOMETHING.
@@ -184,6 +161,9 @@ int main(int argc, char **argv)
         }
         if (i < n) av_packet_unref(&pkt);
     }
+    unsigned long n_hooks = 0, n_replaced = 0;
+    mi355_wrap_stats(&n_hooks, &n_replaced);
+    n_hooks += n_pred_hooks; n_replaced += n_pred_replaced;
     fprintf(stderr, "tier1: %u packets, %d pictures, %lu table initialisations hooked (%lu entries replaced), %dx%d %s, %lu pictures deblocked per picture (%lu with strengths from the device), %lu coding tree units in %lu slices, %lu intra blocks predicted by the batched wrapper\n", n, shown, n_hooks, n_replaced, c->width, c->height,
             av_get_pix_fmt_name(c->pix_fmt), mi355_hevc_lf_bridge_pictures ? mi355_hevc_lf_bridge_pictures() : 0ul, mi355_hevc_lf_bridge_bs_pictures ? mi355_hevc_lf_bridge_bs_pictures() : 0ul, n_ctus, n_slice_ends, n_intra_dev);
     fclose(out);
