@@ -267,9 +267,15 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
             return;
         }
 #endif
+#ifdef MI355_EXP_ONLY_P16
+        return;
+#endif
         mc_part<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
         return;
     }
+#ifdef MI355_EXP_ONLY_P16
+    return;
+#endif
     const int nparts = kind == 3 ? 16 : 2;
     for (int p = 0; p < nparts; p++) {
         int n, quad, bx, by, w, h, l0, l1;
@@ -638,8 +644,12 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
     const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
     /* the surface layout is a property of the picture: both forms of the macroblock code live in the kernel, a wave takes one */
+#ifdef MI355_EXP_ONLY_TILED      /* developer experiment: the instruction listing of one form alone (tools/isa_lines.py) */
+    recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
+#else
     if (uniform(frames[f].surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
     else recon_inter_mb<SPARSE, false>(s, frames[f], mb_x, mb_y);
+#endif
 }
 /* Eight waves per SIMD: left alone the compiler takes 106 scalar registers (seven waves).  Capped at 96 it spills more of them
  * to vector lanes (+45 VALU per macroblock) and the kernel is still 2.5 % faster: it waits on three dependent memory round

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int TW = 128;      /* output samples per tile row */
 constexpr int MAXTH = 16;    /* output rows per tile (upper bound) */
-constexpr int MAXL = 48;     /* source luma lines a tile may need */
+constexpr int MAXL = 48;     /* source luma lines a tile may need (upper bound: the LDS tile is sized per context, sws_plan) */
 constexpr int MAXC = 24;     /* source chroma lines a tile may need */
 constexpr int NT = 256;
 
@@ -30,6 +30,7 @@ struct SwsDev {
     const int16_t *hLumC, *hChrC, *vLumC, *vChrC;
     const int32_t *hLumP, *hChrP, *vLumP, *vChrP;
     int th;                                 /* output rows per tile chosen at create time */
+    int lum_lines, chr_lines;               /* source lines the LDS tile holds (the largest span of a tile of th rows) */
     int hstage;                             /* horizontal filter positions never decrease: source spans can be staged in LDS */
     int hident_l, hident_c;                 /* the horizontal filter of the plane is the identity (one tap of 1 << 14 at position i: an unscaled
                                              * conversion through the generic path): hScale8To15 is then src << 7 */
@@ -44,7 +45,10 @@ __device__ __forceinline__ void lut_load(LutLds &s, const mi355_sws_luts *g, int
 {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
     uint32_t *dst = reinterpret_cast<uint32_t *>(&s);
-    for (int i = tid; i < (int)(sizeof(LutLds) / 4); i += nt) dst[i] = src[i];
+    static_assert(sizeof(LutLds) == 3 * 4 * NT, "three dwords per thread");
+    (void)nt;
+    const uint32_t a = src[tid], b = src[tid + NT], c = src[tid + 2 * NT];      /* in flight together */
+    dst[tid] = a; dst[tid + NT] = b; dst[tid + 2 * NT] = c;
 }
 __device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 /* yuv2rgb_write, rgb24 branch (output.c:853-866) */
@@ -129,13 +133,21 @@ struct TileRows {
     __device__ __forceinline__ int cv(int j, int x) const { return cvT[clampi(cfirst + j, 0, cmax) - clo][x]; }
 };
 
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 /* Horizontal pass of one plane for a tile: COLS output columns starting at gx0, source lines lo..hi, results
  * to out[line - lo][x].  The source span the columns need ([pos[gx0], pos[last] + fs), monotonic positions)
  * is staged in LDS SG lines at a time with aligned 16-byte (or dword) loads — a few coalesced loads per thread
  * instead of fs single-byte loads per output sample; spans wider than the stage, unaligned planes and non-monotonic
  * filters take the direct path. */
-constexpr int SG = 16;                /* source lines per staging round */
+#ifndef MI355_SWS_SG
+#define MI355_SWS_SG 16
+#endif
+constexpr int SG = MI355_SWS_SG;      /* source lines per staging round (a round costs two workgroup barriers) */
 constexpr int SRC_DW = 76;            /* dwords per staged line: 2:1 with 8 taps needs 128 * 2 + 8 bytes (+2 of slack for zero taps) */
+constexpr int STAGE_BYTES = (int)sizeof(uint32_t) * SG * SRC_DW;
+constexpr int OUT_ROWS = STAGE_BYTES / (TW * 3);            /* rows of a narrow tile written per pass (they reuse the staging lines) */
+static_assert(OUT_ROWS >= 8, "the narrow form needs at most two passes over a tile of MAXTH rows");
 /* byte funnel shift, byte permute and the two-term 16-bit dot product (v_alignbyte_b32, v_perm_b32, v_dot2_i32_i16); plain C
  * under the SIMT emulator */
 #ifdef MI355_HIP_EMU_H
@@ -157,38 +169,59 @@ __device__ __forceinline__ int sws_dot2(uint32_t a, uint32_t b, int c)
  * (3 LDS reads and 10 arithmetic instructions per output instead of 8 byte reads and 8 multiply-adds).  Products and sums
  * are the same integers (samples 0..255, coefficients 16 bits, |sum| < 2^31). */
 template <int COLS>
-__device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0, const int *cf, int left)
+__device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0, const uint32_t *cp, int left)
 {
     constexpr int per = NT / COLS;
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row0) & 3);
     const uint32_t *w0 = reinterpret_cast<const uint32_t *>(row0 - sh);
-    const uint32_t c01 = ((uint32_t)cf[0] & 0xFFFFu) | ((uint32_t)cf[1] << 16), c23 = ((uint32_t)cf[2] & 0xFFFFu) | ((uint32_t)cf[3] << 16);
-    const uint32_t c45 = ((uint32_t)cf[4] & 0xFFFFu) | ((uint32_t)cf[5] << 16), c67 = ((uint32_t)cf[6] & 0xFFFFu) | ((uint32_t)cf[7] << 16);
+    const uint32_t c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
+    static_assert(COLS >= 64, "a wave's threads share their first line: `left` is the same on all of them");
+    /* four lines at a time: their twelve LDS reads go out together, then the arithmetic of the four (one read-wait-compute chain
+     * per line leaves the wave waiting for the LDS once per output).  A short last round ends at a branch of the wave between
+     * groups; inside a group only the store is conditional (the staged lines exist, the result rows past `left` may not). */
+    constexpr int G = 4, N = SG / per;
+    static_assert(N % G == 0, "groups of four lines");
 #pragma unroll
-    for (int k = 0; k < SG / per; k++) {
-        const uint32_t *w = w0 + k * per * SRC_DW;
-        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-        const uint32_t lo = sws_alignbyte(d1, d0, sh), hi = sws_alignbyte(d2, d1, sh);
-        int val = sws_dot2(sws_pair(lo, 0), c01, 0);
-        val = sws_dot2(sws_pair(lo, 1), c23, val);
-        val = sws_dot2(sws_pair(hi, 0), c45, val);
-        val = sws_dot2(sws_pair(hi, 1), c67, val);
-        val >>= 7;
-        if (k * per <= left) out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
+    for (int g = 0; g < N; g += G) {
+        if (g * per > left) break;
+        uint32_t d[G][3];
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            const uint32_t *w = w0 + (g + q) * per * SRC_DW;
+            d[q][0] = w[0]; d[q][1] = w[1]; d[q][2] = w[2];
+        }
+        int val[G];
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            const uint32_t lo = sws_alignbyte(d[q][1], d[q][0], sh), hi = sws_alignbyte(d[q][2], d[q][1], sh);
+            int v = sws_dot2(sws_pair(lo, 0), c01, 0);
+            v = sws_dot2(sws_pair(lo, 1), c23, v);
+            v = sws_dot2(sws_pair(hi, 0), c45, v);
+            v = sws_dot2(sws_pair(hi, 1), c67, v);
+            v >>= 7;
+            val[q] = v < 32767 ? v : 32767;
+        }
+#pragma unroll
+        for (int q = 0; q < G; q++)
+            if ((g + q) * per <= left) out0[(g + q) * per * COLS] = (int16_t)val[q];
     }
 }
 template <int COLS, int TAPS>
-__device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0, const int *cf, int left)
+__device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0, const uint32_t *cp, int left)
 {
     constexpr int per = NT / COLS;
+    int cf[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; j++) cf[j] = (int16_t)(cp[j >> 1] >> (16 * (j & 1)));
 #pragma unroll
     for (int k = 0; k < SG / per; k++) {
+        if (k * per > left) break;
         const uint8_t *row = row0 + k * per * (SRC_DW * 4);
         int val = 0;
 #pragma unroll
         for (int j = 0; j < TAPS; j++) val += (int)row[j] * cf[j];
         val >>= 7;
-        if (k * per <= left) out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
+        out0[k * per * COLS] = (int16_t)(val < 32767 ? val : 32767);
     }
 }
 template <int COLS>
@@ -224,16 +257,29 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
     }
     const int x = tid & (COLS - 1), gx = gx0 + x, per = NT / COLS;
     const bool col_ok = gx < ncols;
-    const int pos = col_ok ? posT[gx] : 0;
-    const int16_t *f = coefT + (size_t)(col_ok ? gx : 0) * fs;
+    /* no load below sits under a lane condition (a conditional load is a branch, the load and a wait for it: a memory round
+     * trip per tap): columns past the picture read the last column's entries and do not use them */
+    const int gxc = col_ok ? gx : ncols - 1;
+    const int pos = posT[gxc];
+    const int16_t *f = coefT + (size_t)gxc * fs;
     const int last = imin(gx0 + COLS, ncols) - 1;
     /* 16-byte pieces when the plane allows it, dwords otherwise */
     const bool al16 = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
     const int s0 = posT[gx0], s1 = posT[last] + fs, a0 = al16 ? (s0 & ~15) : (s0 & ~3), nd = (s1 - a0 + 3) >> 2;
-    /* the column's filter in registers: the line loops below multiply by them instead of reloading */
-    int cf[8];
+    /* the column's filter in registers as four pairs of 16-bit taps (taps past fs are zero): the line loops below multiply by
+     * them instead of reloading.  Eight taps: the column's entry of the bank is one aligned 16-byte word (the banks are
+     * hipMalloc'ed by mi355_sws_create) */
+    uint32_t cp[4];
+    if (fs == 8) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(f);
+        cp[0] = w.x; cp[1] = w.y; cp[2] = w.z; cp[3] = w.w;
+    } else {
+        int t[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) cf[j] = (col_ok && j < fs) ? f[j] : 0;
+        for (int j = 0; j < 8; j++) t[j] = f[j < fs ? j : 0];
+#pragma unroll
+        for (int j = 0; j < 4; j++) cp[j] = (2 * j < fs ? (uint32_t)t[2 * j] & 0xFFFFu : 0u) | (2 * j + 1 < fs ? (uint32_t)t[2 * j + 1] << 16 : 0u);
+    }
     const bool staged = may_stage && nd <= SRC_DW - 2 && s1 >= s0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0;
     if (!staged) {
         if (col_ok) {
@@ -246,26 +292,50 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
     /* idx / n as a 24-bit multiply and a shift (mi355_div20: exact for idx * n < 2^19; here idx < SG * n, n <= SRC_DW) */
     static_assert(SG * SRC_DW * SRC_DW < (1 << 19), "mi355_div20 range");
     const int np = al16 ? (nd + 3) >> 2 : nd, inv = mi355_inv20(np);
+    /* 16-byte pieces travel through registers, one round ahead: the loads of round r + 1 are issued before round r's
+     * arithmetic and stored to the staging lines after it (a round's loads would otherwise be waited for at its first
+     * barrier with nothing to do: a third of the kernel's time on a 2:1 reduction).  At most PF pieces per thread and round. */
+    constexpr int PF = (SG * ((SRC_DW + 3) / 4) + NT - 1) / NT;
+    uint4 pre[PF];
+    auto fetch16 = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            /* nothing under a lane condition: a piece past the round's last repeats the last one, a line past the plane's last
+             * needed line repeats that one (the same bytes to the same place, or to a staging line nothing reads) */
+            const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np, line = imin(base + r, hi);
+            /* the aligned 16 bytes lie inside the line's stride (both multiples of 16, off < srcW <= stride): always readable;
+             * bytes at and past srcW (padding) are cleared — no filter tap with a non-zero coefficient reads them, the value
+             * only has to be the same everywhere */
+            const int off = a0 + 16 * d;
+            uint4 w = *reinterpret_cast<const uint4 *>(src + (size_t)line * stride + imin(off, (srcW - 1) & ~15));
+            const int nv = srcW - off;                                  /* valid bytes: >= 16 inside the picture, <= 0 past it */
+            if (nv < 16) {
+                uint32_t q[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int n = nv - 4 * k;
+                    q[k] = n >= 4 ? q[k] : (n <= 0 ? 0u : q[k] & ((1u << (8 * n)) - 1u));
+                }
+                w = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+            pre[j] = w;
+        }
+    };
+#ifndef MI355_SWS_EXP_NOSTAGE     /* developer experiments (tools/exp_sws_sg.sh): the pass without its loads / without its arithmetic */
+    if (al16) fetch16(lo);
+#endif
     for (int base = lo; base <= hi; base += SG) {
+#ifndef MI355_SWS_EXP_NOSTAGE
+        if (al16) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np;
+                *reinterpret_cast<uint4 *>(&stage[r][4 * d]) = pre[j];
+            }
+        } else
         for (int idx = tid; idx < SG * np; idx += NT) {
             const int r = mi355_div20(idx, inv), d = idx - r * np, line = base + r;
             if (line > hi) continue;
-            if (al16) {
-                const int off = a0 + 16 * d;
-                const uint8_t *p = src + (size_t)line * stride + off;
-                uint4 w;
-                if (off + 16 <= srcW) w = *reinterpret_cast<const uint4 *>(p);
-                else {
-                    uint32_t q[4];
-                    for (int k = 0; k < 4; k++) {
-                        q[k] = 0;
-                        for (int b = 0; b < 4; b++) if (off + 4 * k + b < srcW) q[k] |= (uint32_t)p[4 * k + b] << (8 * b);
-                    }
-                    w = make_uint4(q[0], q[1], q[2], q[3]);
-                }
-                *reinterpret_cast<uint4 *>(&stage[r][4 * d]) = w;
-                continue;
-            }
             const uint8_t *p = src + (size_t)line * stride + a0 + 4 * d;
             uint32_t w;
             if (a0 + 4 * d + 4 <= srcW) w = *reinterpret_cast<const uint32_t *>(p);
@@ -275,19 +345,24 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
             }
             stage[r][d] = w;
         }
+#endif
         __syncthreads();
+#ifndef MI355_SWS_EXP_NOSTAGE
+        if (al16 && base + SG <= hi) fetch16(base + SG);
+#endif
         /* the thread's column over the staged lines: fixed trip count, so line and output addresses are
          * immediate offsets from one base each; tap count rounded up to 1 / 2 / 4 / 8 (taps past fs are zero, the
          * bytes exist: slack) */
         const int r0 = tid / COLS;
         const uint8_t *row0 = reinterpret_cast<const uint8_t *>(stage[r0]) + (pos - a0);
         int16_t *out0 = &out[base + r0 - lo][x];
-        const int left = hi - base - r0;                     /* lines r0, r0 + per, ... while k * per <= left */
+        const int left = uniform(hi - base - r0);            /* lines r0, r0 + per, ... while k * per <= left (r0: one value per wave) */
+#ifndef MI355_SWS_EXP_NOLINES
         if (col_ok) {
-            if (fs == 1) hscale_lines<COLS, 1>(row0, out0, cf, left);
-            else if (fs <= 2) hscale_lines<COLS, 2>(row0, out0, cf, left);
-            else if (fs <= 4) hscale_lines<COLS, 4>(row0, out0, cf, left);
-            else if (fs <= 8) hscale_lines8<COLS>(row0, out0, cf, left);
+            if (fs == 1) hscale_lines<COLS, 1>(row0, out0, cp, left);
+            else if (fs <= 2) hscale_lines<COLS, 2>(row0, out0, cp, left);
+            else if (fs <= 4) hscale_lines<COLS, 4>(row0, out0, cp, left);
+            else if (fs <= 8) hscale_lines8<COLS>(row0, out0, cp, left);
             else {
                 for (int k = 0; k < SG / per && k * per <= left; k++) {
                     const uint8_t *row = row0 + k * per * (SRC_DW * 4);
@@ -300,6 +375,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         } else if (zero_tail) {
             for (int k = 0; k < SG / per && k * per <= left; k++) out0[k * per * COLS] = 0;
         }
+#endif
         __syncthreads();
     }
 }
@@ -307,27 +383,33 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
 /* Vertical pass + LUT for the output rows of a tile with the row's filter taps and source-line indices in
  * registers: NL / NC = luma / chroma tap counts rounded up to 1, 2, 4 or 8 (taps past the real size carry a
  * zero coefficient and a valid line index).  A thread owns one output row and every 16th pair of it. */
-template <int NL, int NC>
+template <int NL, int NC, bool WIDE>
 __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut, const int16_t (*s_lum)[TW], const int16_t (*s_cu)[TW / 2],
                                               const int16_t (*s_cv)[TW / 2], uint8_t (*s_out)[TW * 3], int tid, int y0, int y1, int llo, int clo,
-                                              int npairs, int mode, uint8_t *wide_dst, int dst_stride)
+                                              int npairs, int mode, uint8_t *wide_dst, int dst_stride, int out_row0)
 {
+    /* out_row0: first tile row of this pass of the narrow form (s_out holds OUT_ROWS rows at a time) */
     const int row = tid >> 4, gy = y0 + row;
-    if (gy > y1) return;
+    if (gy > y1 || (!WIDE && (row < out_row0 || row >= out_row0 + OUT_ROWS))) return;
     const int ls = c.vls, cs = c.vcs;
     const int lfirst = imax(1 - ls, c.vLumP[gy]), cfirst = imax(1 - cs, c.vChrP[gy]);
+    /* the taps: every load unconditional (a tap past the filter reads tap 0 and becomes zero), so that they are in flight together */
     int lf[NL], li[NL], cf[NC], ci[NC];
 #pragma unroll
+    for (int j = 0; j < NL; j++) lf[j] = c.vLumC[(size_t)gy * ls + (j < ls ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < NC; j++) cf[j] = c.vChrC[(size_t)gy * cs + (j < cs ? j : 0)];
+#pragma unroll
     for (int j = 0; j < NL; j++) {
-        lf[j] = j < ls ? c.vLumC[(size_t)gy * ls + j] : 0;
+        lf[j] = j < ls ? lf[j] : 0;
         li[j] = clampi(lfirst + (j < ls ? j : 0), 0, c.srcH - 1) - llo;
     }
 #pragma unroll
     for (int j = 0; j < NC; j++) {
-        cf[j] = j < cs ? c.vChrC[(size_t)gy * cs + j] : 0;
+        cf[j] = j < cs ? cf[j] : 0;
         ci[j] = clampi(cfirst + (j < cs ? j : 0), 0, c.chrSrcH - 1) - clo;
     }
-    if (wide_dst) {
+    if (WIDE) {
         /* full tile, 8-byte aligned destination: a thread takes eight neighbouring samples (16 / 8 bytes per LDS read)
          * and stores its 24 RGB bytes directly */
         const int grp = tid & 15;
@@ -418,16 +500,104 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
             Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
             if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
         }
-        write_pair(lut, &s_out[row][i * 6], Y1, Y2, U, V);
+        write_pair(lut, &s_out[row - out_row0][i * 6], Y1, Y2, U, V);
     }
 }
 
+/* LDS of a workgroup, sized per context (sws_plan): the horizontal pass's results for the source lines a tile needs, the tables, and one
+ * block shared by the staging lines (horizontal pass) and the output rows of tiles that cannot store from registers (after it). */
+__host__ __device__ constexpr int sws_lds_bytes(int lum_lines, int chr_lines)
+{
+    return lum_lines * TW * 2 + 2 * chr_lines * (TW / 2) * 2 + (int)sizeof(LutLds) + STAGE_BYTES;
+}
+
+/* the sixteen tap-count instances of vertical_rows (taps in registers, rounded up to 1 / 2 / 4 / 8) */
+#define MI355_VR(NL, NC) vertical_rows<NL, NC, MI355_VR_WIDE>(c, s_lut, s_lum, s_cu, s_cv, s_out, tid, y0, y1, llo, clo, npairs, mode, wide_dst, fr.dst_stride, r0)
+#define MI355_VR_ALL \
+    switch (bl * 4 + bc) { \
+    case 0: MI355_VR(1, 1); break;   case 1: MI355_VR(1, 2); break;   case 2: MI355_VR(1, 4); break;   case 3: MI355_VR(1, 8); break; \
+    case 4: MI355_VR(2, 1); break;   case 5: MI355_VR(2, 2); break;   case 6: MI355_VR(2, 4); break;   case 7: MI355_VR(2, 8); break; \
+    case 8: MI355_VR(4, 1); break;   case 9: MI355_VR(4, 2); break;   case 10: MI355_VR(4, 4); break;  case 11: MI355_VR(4, 8); break; \
+    case 12: MI355_VR(8, 1); break;  case 13: MI355_VR(8, 2); break;  case 14: MI355_VR(8, 4); break;  default: MI355_VR(8, 8); break; \
+    }
+
+/* Tiles that cannot store from registers (the picture's right edge, a destination that is not 8-byte aligned, filters of more than
+ * eight taps): the rows go through s_out, OUT_ROWS at a time. */
+__device__ __forceinline__ void vertical_narrow(const SwsDev *cp, const LutLds *lutp, const int16_t (*s_lum)[TW], const int16_t (*s_cu)[TW / 2],
+                                                          const int16_t (*s_cv)[TW / 2], uint8_t (*s_out)[TW * 3], uint8_t *tile_dst, int dst_stride,
+                                                          int x0, int y0, int y1, int llo, int clo)
+{
+    SwsDev c = *cp;
+    c.vLumC = mi355_global(c.vLumC); c.vChrC = mi355_global(c.vChrC); c.vLumP = mi355_global(c.vLumP); c.vChrP = mi355_global(c.vChrP);
+    const LutLds &s_lut = *lutp;
+    const int tid = threadIdx.x, ls = c.vls, cs = c.vcs, mode = packed_mode(ls, cs);
+    const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
+    const int nbytes = imin(TW, c.dstW - x0) * 3, nrows_all = y1 - y0 + 1;
+    const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
+    uint8_t *const wide_dst = nullptr;
+    struct { int dst_stride; } fr{ dst_stride };
+    for (int r0 = 0; r0 < nrows_all; r0 += OUT_ROWS) {
+#ifndef MI355_SWS_NO_V
+        if (ls <= 8 && cs <= 8) {
+#define MI355_VR_WIDE false
+            MI355_VR_ALL
+#undef MI355_VR_WIDE
+        } else
+        for (int p = tid; p < OUT_ROWS * (TW / 2); p += NT) {
+            const int row = r0 + (p >> 6), i = p & 63, gy = y0 + row;
+            if (gy > y1 || i >= npairs) continue;
+            TileRows R{ s_lum, s_cu, s_cv, imax(1 - ls, c.vLumP[gy]), llo, c.srcH - 1, imax(1 - cs, c.vChrP[gy]), clo, c.chrSrcH - 1 };
+            int ya = 0, ua = 0;
+            if (mode == 1) ua = cs == 1 ? 0 : c.vChrC[2 * gy + 1];
+            else if (mode == 2) { ya = c.vLumC[2 * gy + 1]; ua = c.vChrC[2 * gy + 1]; }
+            rgb_pair(s_lut, &s_out[row - r0][i * 6], R, i, mode, c.vLumC + (size_t)gy * ls, ls, c.vChrC + (size_t)gy * cs, cs, ya, ua);
+        }
+#endif
+        __syncthreads();
+        /* rows out: only samples below dstW (for odd dstW the reference also writes the phantom partner of
+         * the last sample from uninitialised ring-buffer data; that sample is not reproduced) */
+#ifndef MI355_SWS_NO_OUT
+        {
+            uint8_t *d0 = tile_dst + (size_t)r0 * fr.dst_stride;
+            const int nrows = imin(OUT_ROWS, nrows_all - r0);
+            const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
+            /* mi355_div20 below: idx < nrows * n with nrows <= 16 and n <= TW * 3 / 4 = 96: idx * n < 2^18 */
+            if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
+                const int n = nbytes >> 4, inv = mi355_inv20(n);
+                for (int idx = tid; idx < nrows * n; idx += NT) {
+                    const int row = mi355_div20(idx, inv), k = idx - row * n;
+                    reinterpret_cast<uint4 *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint4 *>(s_out[row])[k];
+                }
+            } else if ((al & 3) == 0) {
+                const int n = nbytes >> 2, inv = mi355_inv20(n);
+                for (int idx = tid; idx < nrows * n; idx += NT) {
+                    const int row = mi355_div20(idx, inv), k = idx - row * n;
+                    reinterpret_cast<uint32_t *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
+                }
+            } else {
+                for (int row = 0; row < nrows; row++)
+                    for (int k = tid; k < nbytes; k += NT) d0[(size_t)row * fr.dst_stride + k] = s_out[row][k];
+            }
+        }
+#endif
+        __syncthreads();                           /* the next pass overwrites s_out */
+    }
+}
+
+/* LCAP / CCAP: source lines the LDS tile holds — the context's largest tile span picks the instance (sws_launch), and with it how
+ * many workgroups a CU's 160 KB hold (one wave of each per SIMD); WAVES: the waves per SIMD the register allocation then aims at */
+template <int LCAP, int CCAP, int WAVES>
+#ifndef MI355_HIP_EMU_H
+__attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+#endif
 __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi355_sws_frame *frames)
 {
-    __shared__ __attribute__((aligned(16))) int16_t s_lum[MAXL][TW];
-    __shared__ __attribute__((aligned(16))) int16_t s_cu[MAXC][TW / 2], s_cv[MAXC][TW / 2];
+    __shared__ __attribute__((aligned(16))) int16_t s_lum[LCAP][TW];
+    __shared__ __attribute__((aligned(16))) int16_t s_cu[CCAP][TW / 2], s_cv[CCAP][TW / 2];
     __shared__ LutLds s_lut;
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[MAXTH][TW * 3];
+    /* the staging lines of the horizontal pass; the output rows of tiles that cannot store from registers reuse them after it */
+    __shared__ __attribute__((aligned(16))) uint8_t s_io[STAGE_BYTES];
+    uint8_t (*s_out)[TW * 3] = reinterpret_cast<uint8_t (*)[TW * 3]>(s_io);
     SwsDev c = *cp;                                   /* pointers of the records: global address space (mi355_rt.h) */
     c.hLumC = mi355_global(c.hLumC); c.hChrC = mi355_global(c.hChrC); c.vLumC = mi355_global(c.vLumC); c.vChrC = mi355_global(c.vChrC);
     c.hLumP = mi355_global(c.hLumP); c.hChrP = mi355_global(c.hChrP); c.vLumP = mi355_global(c.vLumP); c.vChrP = mi355_global(c.vChrP);
@@ -445,9 +615,7 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     lut_load(s_lut, &cp->luts, tid, NT);
     /* horizontal pass: luma (the phantom partner of the last sample of an odd-width picture reads the
      * zero-initialised tail of the reference's line buffer, utils.c:1241-1262), then the chroma planes */
-    /* the staging lines live in the output tile's storage: that is written only after the horizontal pass */
-    static_assert(sizeof(uint32_t) * SG * SRC_DW <= sizeof(s_out), "staging lines must fit into the output tile");
-    uint32_t (*s_stage)[SRC_DW] = reinterpret_cast<uint32_t (*)[SRC_DW]>(&s_out[0][0]);
+    uint32_t (*s_stage)[SRC_DW] = reinterpret_cast<uint32_t (*)[SRC_DW]>(s_io);
 #ifndef MI355_SWS_NO_H
     hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0, c.hident_l != 0);
     hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0, c.hident_c != 0);
@@ -457,61 +625,24 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     /* vertical pass + LUT */
     const int mode = packed_mode(ls, cs);
     const int npairs = imin(TW, c.dstW - x0 + 1) >> 1;     /* (dstW + 1) >> 1 pairs in the picture */
-    /* full tiles with an 8-byte aligned destination leave straight from registers; the others go through s_out */
+    /* full tiles with an 8-byte aligned destination leave straight from registers; the others go through s_out, OUT_ROWS rows at a time */
     uint8_t *const tile_dst = fr.dst + (size_t)y0 * fr.dst_stride + (size_t)x0 * 3;
     uint8_t *const wide_dst = (ls <= 8 && cs <= 8 && c.dstW - x0 >= TW && ((reinterpret_cast<uintptr_t>(tile_dst) | (uintptr_t)fr.dst_stride) & 7) == 0)
                                   ? tile_dst : nullptr;
+    /* tap counts in registers, rounded up to 1 / 2 / 4 / 8 */
+    const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
 #ifndef MI355_SWS_NO_V
-    if (ls <= 8 && cs <= 8) {
-        /* tap counts in registers, rounded up to 1 / 2 / 4 / 8 */
-        const int bl = ls <= 1 ? 0 : (ls <= 2 ? 1 : (ls <= 4 ? 2 : 3)), bc = cs <= 1 ? 0 : (cs <= 2 ? 1 : (cs <= 4 ? 2 : 3));
-#define MI355_VR(NL, NC) vertical_rows<NL, NC>(c, s_lut, s_lum, s_cu, s_cv, s_out, tid, y0, y1, llo, clo, npairs, mode, wide_dst, fr.dst_stride)
-        switch (bl * 4 + bc) {
-        case 0: MI355_VR(1, 1); break;   case 1: MI355_VR(1, 2); break;   case 2: MI355_VR(1, 4); break;   case 3: MI355_VR(1, 8); break;
-        case 4: MI355_VR(2, 1); break;   case 5: MI355_VR(2, 2); break;   case 6: MI355_VR(2, 4); break;   case 7: MI355_VR(2, 8); break;
-        case 8: MI355_VR(4, 1); break;   case 9: MI355_VR(4, 2); break;   case 10: MI355_VR(4, 4); break;  case 11: MI355_VR(4, 8); break;
-        case 12: MI355_VR(8, 1); break;  case 13: MI355_VR(8, 2); break;  case 14: MI355_VR(8, 4); break;  default: MI355_VR(8, 8); break;
-        }
+    if (wide_dst) {                               /* uniform over the workgroup: every row leaves from registers */
+        const int r0 = 0;
+#define MI355_VR_WIDE true
+        MI355_VR_ALL
+#undef MI355_VR_WIDE
+        return;
+    }
+#endif
+    vertical_narrow(cp, &s_lut, s_lum, s_cu, s_cv, s_out, tile_dst, fr.dst_stride, x0, y0, y1, llo, clo);
+#undef MI355_VR_ALL
 #undef MI355_VR
-    } else
-    for (int p = tid; p < th * (TW / 2); p += NT) {
-        const int row = p >> 6, i = p & 63, gy = y0 + row;
-        if (gy > y1 || i >= npairs) continue;
-        TileRows R{ s_lum, s_cu, s_cv, imax(1 - ls, c.vLumP[gy]), llo, c.srcH - 1, imax(1 - cs, c.vChrP[gy]), clo, c.chrSrcH - 1 };
-        int ya = 0, ua = 0;
-        if (mode == 1) ua = cs == 1 ? 0 : c.vChrC[2 * gy + 1];
-        else if (mode == 2) { ya = c.vLumC[2 * gy + 1]; ua = c.vChrC[2 * gy + 1]; }
-        rgb_pair(s_lut, &s_out[row][i * 6], R, i, mode, c.vLumC + (size_t)gy * ls, ls, c.vChrC + (size_t)gy * cs, cs, ya, ua);
-    }
-#endif
-    __syncthreads();
-    /* rows out: only samples below dstW (for odd dstW the reference also writes the phantom partner of
-     * the last sample from uninitialised ring-buffer data; that sample is not reproduced) */
-    const int nbytes = imin(TW, c.dstW - x0) * 3;
-#ifndef MI355_SWS_NO_OUT
-    if (!wide_dst) {
-        uint8_t *d0 = tile_dst;
-        const int nrows = y1 - y0 + 1;
-        const unsigned al = (unsigned)(uintptr_t)d0 | (unsigned)fr.dst_stride | (unsigned)nbytes;
-        /* mi355_div20 below: idx < nrows * n with nrows <= 16 and n <= TW * 3 / 4 = 96: idx * n < 2^18 */
-        if ((al & 15) == 0) {                     /* 16 bytes per thread and store */
-            const int n = nbytes >> 4, inv = mi355_inv20(n);
-            for (int idx = tid; idx < nrows * n; idx += NT) {
-                const int row = mi355_div20(idx, inv), k = idx - row * n;
-                reinterpret_cast<uint4 *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint4 *>(s_out[row])[k];
-            }
-        } else if ((al & 3) == 0) {
-            const int n = nbytes >> 2, inv = mi355_inv20(n);
-            for (int idx = tid; idx < nrows * n; idx += NT) {
-                const int row = mi355_div20(idx, inv), k = idx - row * n;
-                reinterpret_cast<uint32_t *>(d0 + (size_t)row * fr.dst_stride)[k] = reinterpret_cast<const uint32_t *>(s_out[row])[k];
-            }
-        } else {
-            for (int row = 0; row < nrows; row++)
-                for (int k = tid; k < nbytes; k += NT) d0[(size_t)row * fr.dst_stride + k] = s_out[row][k];
-        }
-    }
-#endif
 }
 
 constexpr int C24_ROWS = 16, C24_COLS = 512;
@@ -645,11 +776,13 @@ template <typename T> static const T *upload_bank(mi355_sws_ctx *c, int slot, co
 }
 
 /* rows per tile: the largest power of two <= MAXTH for which no tile needs more source lines than the
- * LDS tile holds; 0 if even single rows do not fit (filters larger than the tile: not supported) */
-static int choose_rows(const mi355_sws_desc *d)
+ * LDS tile may hold; 0 if even single rows do not fit (filters larger than the tile: not supported).  lines[2]: the largest
+ * luma / chroma span of a tile — what the context's LDS tile is sized for. */
+static int choose_rows(const mi355_sws_desc *d, int lines[2])
 {
     for (int th = MAXTH; th >= 1; th >>= 1) {
         bool ok = true;
+        lines[0] = lines[1] = 1;
         for (int y0 = 0; y0 < d->dstH && ok; y0 += th) {
             const int y1 = (y0 + th < d->dstH ? y0 + th : d->dstH) - 1;
             auto span = [&](const mi355_sws_filter &f, int srcH) {
@@ -659,7 +792,10 @@ static int choose_rows(const mi355_sws_desc *d)
                 hi = hi < 0 ? 0 : (hi > srcH - 1 ? srcH - 1 : hi);
                 return hi - lo + 1;
             };
-            ok = span(d->vLum, d->srcH) <= MAXL && span(d->vChr, d->chrSrcH) <= MAXC;
+            const int sl = span(d->vLum, d->srcH), sc = span(d->vChr, d->chrSrcH);
+            ok = sl <= MAXL && sc <= MAXC;
+            lines[0] = sl > lines[0] ? sl : lines[0];
+            lines[1] = sc > lines[1] ? sc : lines[1];
         }
         if (ok) return th;
     }
@@ -677,6 +813,8 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
     h.hls = desc->hLum.size; h.hcs = desc->hChr.size; h.vls = desc->vLum.size; h.vcs = desc->vChr.size;
     h.luts = desc->luts;
     h.th = 0;
+    h.lum_lines = h.chr_lines = 1;
+    int lines[2] = { 1, 1 };
     h.hstage = 1;
     for (int i = 1; i < desc->hLum.n && desc->hLum.pos; i++) if (desc->hLum.pos[i] < desc->hLum.pos[i - 1]) h.hstage = 0;
     for (int i = 1; i < desc->hChr.n && desc->hChr.pos; i++) if (desc->hChr.pos[i] < desc->hChr.pos[i - 1]) h.hstage = 0;
@@ -691,11 +829,12 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
     h.hLumP = h.hChrP = h.vLumP = h.vChrP = nullptr;
     if (!h.special) {
         if (desc->hLum.n != h.dstW || desc->hChr.n != h.chrDstW || desc->vLum.n != h.dstH || desc->vChr.n != h.dstH ||
-            h.hls < 1 || h.hcs < 1 || h.vls < 1 || h.vcs < 1 || !(h.th = choose_rows(desc))) {
+            h.hls < 1 || h.hcs < 1 || h.vls < 1 || h.vcs < 1 || !(h.th = choose_rows(desc, lines))) {
             std::fprintf(stderr, "mi355dsp: mi355_sws_create: filter banks do not fit this backend (sizes %d/%d/%d/%d)\n", h.hls, h.hcs, h.vls, h.vcs);
             delete c;
             return nullptr;
         }
+        h.lum_lines = lines[0]; h.chr_lines = lines[1];
         h.hLumC = upload_bank(c, 0, desc->hLum.coef, (size_t)h.dstW * h.hls);    h.hLumP = upload_bank(c, 1, desc->hLum.pos, (size_t)h.dstW);
         h.hChrC = upload_bank(c, 2, desc->hChr.coef, (size_t)h.chrDstW * h.hcs); h.hChrP = upload_bank(c, 3, desc->hChr.pos, (size_t)h.chrDstW);
         h.vLumC = upload_bank(c, 4, desc->vLum.coef, (size_t)h.dstH * h.vls);    h.vLumP = upload_bank(c, 5, desc->vLum.pos, (size_t)h.dstH);
@@ -730,7 +869,12 @@ extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fram
         hipLaunchKernelGGL(k_sws_c24, dim3((h.dstW + C24_COLS - 1) / C24_COLS, (h.srcH + C24_ROWS - 1) / C24_ROWS, nframes), dim3(NT), 0, s,
                            &c->d->luts, h.dstW, h.srcH, 0, d_frames);
     } else {
-        hipLaunchKernelGGL(k_sws_generic, dim3((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes), dim3(NT), 0, s, c->d, d_frames);
+        /* a CU's 160 KB of LDS hold `wgs` workgroups, one wave of each per SIMD: the instance whose register budget matches */
+        const dim3 grid((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes);
+        static_assert(160 * 1024 / sws_lds_bytes(28, 16) >= 8 && 160 * 1024 / sws_lds_bytes(40, 20) == 7 && 160 * 1024 / sws_lds_bytes(MAXL, MAXC) == 6, "workgroups per CU of the instances");
+        if (h.lum_lines <= 28 && h.chr_lines <= 16) hipLaunchKernelGGL((k_sws_generic<28, 16, 8>), grid, dim3(NT), 0, s, c->d, d_frames);
+        else if (h.lum_lines <= 40 && h.chr_lines <= 20) hipLaunchKernelGGL((k_sws_generic<40, 20, 7>), grid, dim3(NT), 0, s, c->d, d_frames);
+        else hipLaunchKernelGGL((k_sws_generic<MAXL, MAXC, 6>), grid, dim3(NT), 0, s, c->d, d_frames);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
