@@ -44,3 +44,5 @@ for k, a in res.items():
     print(k, {c: "%.4g" % v for c, v in sorted(a.items())})
 PY
 find $OUT -name '*.csv' -size +1M -delete
+# config-3 / config-5 kernels: times, traffic and instruction counters (own rocprofv3 runs) -> <tag>_k/{hevc_chain,sws}_kernels.json
+cd $GRAFT_REPO_ROOT && bash tools/gpu_r03f.sh ${TAG}_k 2>&1 | tail -30

@@ -45,3 +45,4 @@ PY
 }
 run_set hevc_chain python $GRAFT_REPO_ROOT/tools/hevc_chain.py 64
 
+run_set sws python $GRAFT_REPO_ROOT/tools/bench_sws.py --frames 32 --steps 5
