@@ -431,17 +431,21 @@ __device__ __forceinline__ void resid_lane_compute(ResidLane &r)
 }
 __device__ __forceinline__ void resid_lane_issue(ResidLane &r)
 {
-#if defined(MI355_HIP_EMU_H)
-    /* the emulator runs the table and checks the arithmetic form (the device build's default) against it */
+    /* the table, two 16-byte loads per lane issued with the record.  Round 2 measured this form 4 % SLOWER than computing the
+     * values (37 VALU) — the kernel was waiting for memory then; on tiled surfaces it runs at the VALU's issue rate and the same
+     * change is 2.7 % faster (10.77 -> 10.48 ms, profiles/r03_experiments.md).  A second table for the motion code's lane constants
+     * (23 more VALU for three more loads) no longer moved the time: 10.52 -> 10.51 ms, not kept.
+     * MI355_RESID_LANES_COMPUTED keeps the other form. */
+#if defined(MI355_RESID_LANES_COMPUTED) && !defined(MI355_HIP_EMU_H)
+    (void)r;
+#else
     r = k_resid_lanes.l[lane_id()];
+#endif
+#if defined(MI355_HIP_EMU_H)
+    /* the emulator checks the arithmetic form against the table */
     ResidLane c;
     resid_lane_compute(c);
     if (lane_id() < 48 && (c.off_a != r.off_a || c.off_b != r.off_b || c.cw != r.cw || c.dc16 != r.dc16 || c.misc != r.misc || c.rc != r.rc || c.ka != r.ka || c.kb != r.kb)) abort();
-#else
-    /* measured and not kept (profiles/r02_experiments.md): loading the table on the device too (two 16-byte loads per lane,
-     * issued with the record) takes 37 VALU off the macroblock and still costs 4 % of the kernel's time — 2 KB more per
-     * wave through the L1 */
-    (void)r;
 #endif
 }
 template <bool ALIGNED>
@@ -461,7 +465,7 @@ __device__ inline void residual_blocks(MbLds &s, const ResidLane &rl_in)
         }
         MI355_WAVE_SYNC();
     }
-#if defined(MI355_HIP_EMU_H)
+#if !defined(MI355_RESID_LANES_COMPUTED) || defined(MI355_HIP_EMU_H)
     const ResidLane &rl = rl_in;
 #else
     ResidLane rl;
