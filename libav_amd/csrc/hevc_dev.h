@@ -37,6 +37,36 @@ __host__ __device__ constexpr int dct_coef(int k, int n)
     const int a = ((2 * n + 1) * k) & 127;
     return a <= 32 ? dct_mag(a) : (a <= 64 ? -dct_mag(64 - a) : (a <= 96 ? -dct_mag(a - 64) : dct_mag(128 - a)));
 }
+/* Two 16-bit x 16-bit products and an accumulate in one instruction (v_dot2_i32_i16): a dword holds two
+ * neighbouring samples, the other operand two neighbouring taps. */
+#ifdef MI355_HIP_EMU_H
+static inline int mi355_dot2(uint32_t a, uint32_t b, int c)
+{
+    return c + (int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int16_t)(a >> 16) * (int16_t)(b >> 16);
+}
+static inline uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
+#else
+typedef short mi355_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mi355_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(mi355_short2, a), __builtin_bit_cast(mi355_short2, b), c, false);
+}
+__device__ __forceinline__ uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+#endif
+
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
+static inline uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
+static inline uint32_t mi355_widen_lo(uint32_t w) { return (w & 0xFFu) | ((w & 0xFF00u) << 8); }
+static inline uint32_t mi355_widen_hi(uint32_t w) { return ((w >> 16) & 0xFFu) | ((w >> 8) & 0xFF0000u); }
+#else
+/* v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0C = zero */
+__device__ __forceinline__ uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ uint32_t mi355_widen_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C010C00u); }
+__device__ __forceinline__ uint32_t mi355_widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C030C02u); }
+#endif
+
 /* rows of the input a 1-D pass of size H looks at when pruned to `end` (hevcdsp_template.c:140-206) */
 __device__ __forceinline__ bool dct_row_used(int H, int j, int end)
 {
@@ -60,12 +90,23 @@ template <int H, int S, int END = H> struct Idct1D {
 #pragma unroll
         for (int k = 0; k < H / 2; k++) xe[k] = x[2 * k];
         Idct1D<H / 2, 2 * S, (H / 2 <= 8 ? H / 2 : (END + 1) / 2)>::run(xe, E);
+        /* the odd part two inputs at a time (v_dot2_i32_i16: the inputs are int16 in both passes, the matrix entries fit a byte):
+         * (x[4m+1], x[4m+3]) against the matrix pair of output n.  H = 4 has one such pair, larger sizes H / 4.  END is a
+         * multiple of 4 wherever it prunes (16 or 8 of 32, 8 of 16): whole pairs drop out. */
+        static_assert(H == 4 || END % 4 == 0, "pruning by whole input pairs");
+        uint32_t xo[H / 4];
+#pragma unroll
+        for (int m = 0; m < H / 4; m++) xo[m] = mi355_pair_lo((uint32_t)x[4 * m + 1], (uint32_t)x[4 * m + 3]);
 #pragma unroll
         for (int n = 0; n < H / 2; n++) {
             int o = 0;
 #pragma unroll
-            for (int k = 0; k < H / 2; k++)
-                if (2 * k + 1 < END) o += dct_coef((2 * k + 1) * S, n) * x[2 * k + 1];
+            for (int m = 0; m < H / 4; m++)
+                if (4 * m + 1 < END) {
+                    const uint32_t kk = ((uint32_t)dct_coef((4 * m + 1) * S, n) & 0xFFFFu) |
+                                        ((uint32_t)(4 * m + 3 < END ? dct_coef((4 * m + 3) * S, n) : 0) << 16);
+                    o = mi355_dot2(xo[m], kk, o);
+                }
             O[n] = o;
         }
 #pragma unroll
@@ -161,23 +202,6 @@ __device__ const int8_t k_qpel[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -
 __device__ const int8_t k_epel[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
                                          { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
-/* Two 16-bit x 16-bit products and an accumulate in one instruction (v_dot2_i32_i16): a dword holds two
- * neighbouring samples, the other operand two neighbouring taps. */
-#ifdef MI355_HIP_EMU_H
-static inline int mi355_dot2(uint32_t a, uint32_t b, int c)
-{
-    return c + (int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int16_t)(a >> 16) * (int16_t)(b >> 16);
-}
-static inline uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
-#else
-typedef short mi355_short2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int mi355_dot2(uint32_t a, uint32_t b, int c)
-{
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(mi355_short2, a), __builtin_bit_cast(mi355_short2, b), c, false);
-}
-__device__ __forceinline__ uint32_t mi355_alignbit16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
-#endif
-
 /* Four consecutive outputs of a 4- or 8-tap FIR along a line of 16-bit values: d[0..5] = the line from the
  * first output's first tap (dword aligned), t[k] = taps 2k, 2k+1 packed.  Outputs 0 and 2 use the dwords as
  * they are, 1 and 3 the same dwords shifted by one value. */
@@ -213,18 +237,6 @@ struct __attribute__((aligned(16))) HevcMcScratch {
     uint16_t win[HEVC_MC_ROWS * HEVC_MC_PITCH];      /* staged samples */
     int16_t tmp[HEVC_MC_ROWS * HEVC_MC_PITCH];       /* first-pass results of the 2-D case */
 };
-#ifdef MI355_HIP_EMU_H
-static inline uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
-static inline uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
-static inline uint32_t mi355_widen_lo(uint32_t w) { return (w & 0xFFu) | ((w & 0xFF00u) << 8); }
-static inline uint32_t mi355_widen_hi(uint32_t w) { return ((w >> 16) & 0xFFu) | ((w >> 8) & 0xFF0000u); }
-#else
-/* v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0C = zero */
-__device__ __forceinline__ uint32_t mi355_pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
-__device__ __forceinline__ uint32_t mi355_pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-__device__ __forceinline__ uint32_t mi355_widen_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C010C00u); }
-__device__ __forceinline__ uint32_t mi355_widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C030C02u); }
-#endif
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 /* alignment class of the int16 destination: 8, 4 or 2 bytes for every row start */
 __device__ __forceinline__ int hevc_mc_align(const int16_t *dst, int ds)
