@@ -455,6 +455,11 @@ static inline uint32_t pk_clip_u8(uint32_t a)
     const int l = pk_lo(a), h = pk_hi(a);
     return pk_make(l < 0 ? 0 : (l > 255 ? 255 : l), h < 0 ? 0 : (h > 255 ? 255 : h));
 }
+static inline uint32_t pk_clip_max(uint32_t a, int maxv)           /* both halves to 0 .. maxv */
+{
+    const int l = pk_lo(a), h = pk_hi(a);
+    return pk_make(l < 0 ? 0 : (l > maxv ? maxv : l), h < 0 ? 0 : (h > maxv ? maxv : h));
+}
 static inline uint32_t pk_ashr_hi1(uint32_t a) { return pk_make(pk_lo(a), pk_hi(a) >> 1); }          /* (lo, hi >> 1) */
 static inline uint32_t pk_mad2(uint32_t a, uint32_t k, uint32_t c) { return pk_make(pk_lo(a) * pk_lo(k) + pk_lo(c), pk_hi(a) * pk_hi(k) + pk_hi(c)); }
 static inline int pk_dot2(uint32_t a, uint32_t b, int c) { return c + pk_lo(a) * pk_lo(b) + pk_hi(a) * pk_hi(b); }      /* v_dot2_i32_i16 */
@@ -478,6 +483,10 @@ __device__ __forceinline__ uint32_t pk_ashr(uint32_t a, int n) { return pk_u(pk_
 __device__ __forceinline__ uint32_t pk_clip_u8(uint32_t a)
 {
     return pk_u(__builtin_elementwise_min(__builtin_elementwise_max(pk_v(a), (mi355_v2s)((short)0)), (mi355_v2s)((short)255)));
+}
+__device__ __forceinline__ uint32_t pk_clip_max(uint32_t a, int maxv)           /* both halves to 0 .. maxv */
+{
+    return pk_u(__builtin_elementwise_min(__builtin_elementwise_max(pk_v(a), (mi355_v2s)((short)0)), (mi355_v2s)((short)maxv)));
 }
 __device__ __forceinline__ uint32_t pk_ashr_hi1(uint32_t a) { return pk_u(pk_v(a) >> mi355_v2s{ 0, 1 }); }
 __device__ __forceinline__ uint32_t pk_mad2(uint32_t a, uint32_t k, uint32_t c) { return pk_u(pk_v(a) * pk_v(k) + pk_v(c)); }

@@ -53,21 +53,24 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
         for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(j.coeffs)[i] = reinterpret_cast<const uint32_t *>(c)[i];
         return;
     }
-    /* add_residual (:51-82): two samples per lane; PCM blocks store their samples instead */
-    const int hw = size >> 1;
+    /* add_residual (:51-82): two samples per lane and step, both in one register (the residuals are neighbours in LDS: one
+     * dword; sample + residual saturates at int16 and is clipped to the sample range after — the same value as the reference's
+     * clip of the int sum); PCM blocks store their samples instead.  Sizes are powers of two: rows by shifts. */
+    const int lhw = j.log2_size - 1, hw = 1 << lhw, maxv = (1 << bd) - 1;
     const uint32_t keep = j.kind == MI355_HEVC_TU_PCM ? 0u : 0xFFFFFFFFu;
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(c);
     for (int i = hl; i < cnt / 2; i += 32) {
-        const int y = i / hw, x = 2 * (i - y * hw);
+        const int y = i >> lhw, xp = i & (hw - 1);
         uint8_t *row = j.dst + (size_t)y * j.dst_stride;
-        const int r0 = c[y * size + x], r1 = c[y * size + x + 1];
+        const uint32_t r = cw[i];
         if (bd > 8) {
-            uint32_t *p = reinterpret_cast<uint32_t *>(row) + (x >> 1);
-            const uint32_t v = *p & keep;
-            *p = (uint32_t)clip_px((int)(v & 0xFFFF) + r0, bd) | ((uint32_t)clip_px((int)(v >> 16) + r1, bd) << 16);
+            uint32_t *p = reinterpret_cast<uint32_t *>(row) + xp;
+            *p = pk_clip_max(pk_adds(*p & keep, r), maxv);
         } else {
-            uint16_t *p = reinterpret_cast<uint16_t *>(row) + (x >> 1);
-            const uint32_t v = *p & keep;
-            *p = (uint16_t)(clip_px((int)(v & 0xFF) + r0, bd) | (clip_px((int)(v >> 8) + r1, bd) << 8));
+            uint16_t *p = reinterpret_cast<uint16_t *>(row) + xp;
+            const uint32_t v = mi355_widen_lo((uint32_t)*p & keep);                /* two bytes -> two 16-bit values */
+            const uint32_t o = pk_clip_max(pk_adds(v, r), maxv);
+            *p = (uint16_t)((o & 0xFFu) | ((o >> 8) & 0xFF00u));
         }
     }
 }

@@ -320,6 +320,36 @@ struct HevcMcToTile {         /* kept in LDS for a second prediction to combine 
     __device__ __forceinline__ void put2(int r, int x, uint32_t v) const { *reinterpret_cast<uint32_t *>(&t[r * HEVC_MC_KEEP_PITCH + x]) = v; }
 };
 
+/* vertical pass of a tile from row-major 16-bit lines (HEVC_MC_PITCH values apart): a lane owns the column pair c2 and R output
+ * rows; it builds the (row, row + 1) dwords of each column with one byte-permute per pair and feeds the dot products */
+template <int TAPS, int R, class Sink>
+__device__ __forceinline__ void hevc_mc_vpass(const Sink &sink, const uint32_t *lines, const uint32_t *tv, int cp, int th_, int vshift, int lane)
+{
+    const int cinv = mi355_inv20(cp), groups = (th_ + R - 1) / R;
+    for (int i = lane; i < cp * groups; i += 64) {
+        const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = R * q;
+        const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
+        int a0[R], a1[R];
+#pragma unroll
+        for (int y = 0; y < R; y++) a0[y] = a1[y] = 0;
+        uint32_t prev = d[0];
+#pragma unroll
+        for (int r = 0; r < R + TAPS - 2; r++) {
+            const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
+            const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
+            prev = cur;
+#pragma unroll
+            for (int k = 0; k < TAPS / 2; k++) {
+                const int y = r - 2 * k;
+                if (y >= 0 && y < R) { a0[y] = mi355_dot2(p0, tv[k], a0[y]); a1[y] = mi355_dot2(p1, tv[k], a1[y]); }
+            }
+        }
+#pragma unroll
+        for (int y = 0; y < R; y++)
+            if (y0 + y < th_) sink.put2(y0 + y, 2 * c2, pack16(a0[y] >> vshift, a1[y] >> vshift));
+    }
+}
+
 /* one tile of at most 32x32 outputs; w0 = byte address of the first sample the taps touch, sb = bytes per source row */
 template <int TAPS, class Sink>
 __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff_t sb, int tw, int th_, int mx, int my, int bd, HevcMcScratch &s)
@@ -362,32 +392,15 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
         if (my) __syncthreads();
     }
     if (my) {
-        /* vertical pass: lane = (column pair, eight output rows) */
+        /* vertical pass: lane = (column pair, R output rows).  R = 8 when that fills the wave (a 32x32 tile: 16 pairs x 4 groups);
+         * smaller tiles take 4 or 2 rows per lane — a 16x16 chroma block with R = 8 is 16 busy lanes running the longest
+         * instruction stream (R + TAPS - 1 rows in, R out), with R = 2 it is 64 lanes and a third of the instructions */
         const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
         const int vshift = mx ? 6 : bd - 8;
-        const int cp = tw >> 1, cinv = mi355_inv20(cp), oct = (th_ + 7) >> 3;
-        for (int i = lane; i < cp * oct; i += 64) {
-            const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = 8 * q;
-            const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
-            int a0[8], a1[8];
-#pragma unroll
-            for (int y = 0; y < 8; y++) a0[y] = a1[y] = 0;
-            uint32_t prev = d[0];
-#pragma unroll
-            for (int r = 0; r < 8 + TAPS - 2; r++) {
-                const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
-                const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
-                prev = cur;
-#pragma unroll
-                for (int k = 0; k < TAPS / 2; k++) {
-                    const int y = r - 2 * k;
-                    if (y >= 0 && y < 8) { a0[y] = mi355_dot2(p0, tv[k], a0[y]); a1[y] = mi355_dot2(p1, tv[k], a1[y]); }
-                }
-            }
-#pragma unroll
-            for (int y = 0; y < 8; y++)
-                if (y0 + y < th_) sink.put2(y0 + y, 2 * c2, pack16(a0[y] >> vshift, a1[y] >> vshift));
-        }
+        const int cp = tw >> 1;
+        if (cp * ((th_ + 7) >> 3) > 32) hevc_mc_vpass<TAPS, 8>(sink, lines, tv, cp, th_, vshift, lane);
+        else if (cp * ((th_ + 3) >> 2) > 32) hevc_mc_vpass<TAPS, 4>(sink, lines, tv, cp, th_, vshift, lane);
+        else hevc_mc_vpass<TAPS, 2>(sink, lines, tv, cp, th_, vshift, lane);
     }
     __syncthreads();
 }
