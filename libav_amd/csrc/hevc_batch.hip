@@ -98,8 +98,17 @@ struct HevcMcToSamples {      /* results (and, for the two-reference kinds, the 
     }
     __device__ __forceinline__ void put2(int r, int x, uint32_t v) const
     {
-        const int v0 = px((int16_t)(v & 0xFFFF), r, x), v1 = px((int16_t)(v >> 16), r, x + 1);
         uint8_t *d = dst + (ptrdiff_t)r * stride;
+        if (KIND == 0 && ((bd > 8 && amode >= 4) || (bd <= 8 && amode >= 2))) {
+            /* put_unweighted_pred (hevcdsp_template.c:1092-1113: (a + (1 << (shift - 1))) >> shift, clipped) on the pair: the rounding add saturates at int16,
+             * where the reference's int sum is beyond the sample range on the same side anyway */
+            const int shift = 14 - bd, rnd = 1 << (shift - 1);
+            const uint32_t o = pk_clip_max(pk_ashr(pk_adds(v, (uint32_t)rnd * 0x00010001u), shift), (1 << bd) - 1);
+            if (bd > 8) reinterpret_cast<uint32_t *>(d)[x >> 1] = o;
+            else reinterpret_cast<uint16_t *>(d)[x >> 1] = (uint16_t)((o & 0xFFu) | ((o >> 8) & 0xFF00u));
+            return;
+        }
+        const int v0 = px((int16_t)(v & 0xFFFF), r, x), v1 = px((int16_t)(v >> 16), r, x + 1);
         if (bd > 8) {
             if (amode >= 4) reinterpret_cast<uint32_t *>(d)[x >> 1] = (uint32_t)v0 | ((uint32_t)v1 << 16);
             else { reinterpret_cast<uint16_t *>(d)[x] = (uint16_t)v0; reinterpret_cast<uint16_t *>(d)[x + 1] = (uint16_t)v1; }
