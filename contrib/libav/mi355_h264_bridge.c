@@ -2,7 +2,7 @@
  * mi355_h264_bridge.c — the H.264 Tier-2 bridge: PRODUCT glue that lives beside the reference's decoder.
  *
  * Compiled against the reference's own headers and linked into its decoder with
- *   -Wl,--wrap=ff_h264_hl_decode_mb,--wrap=ff_h264_field_end,--wrap=ff_h264_filter_mb,--wrap=ff_h264_filter_mb_fast
+ *   -Wl,--wrap=ff_h264_hl_decode_mb,--wrap=ff_h264_field_end,--wrap=ff_h264_filter_mb,--wrap=ff_h264_filter_mb_fast,--wrap=ff_h264_flush_change
  * (nothing in the reference tree is modified), it turns the decoder into: host = parsing and entropy decoding only,
  * MI355X = everything the per-macroblock DSP did.
  *
@@ -167,13 +167,25 @@ typedef struct Bridge {
     int rows, nmb_pic;          /* its macroblock rows and macroblocks */
     unsigned long pictures, waits;
     unsigned long last_set;     /* launch set (1-based) that holds this decoder's latest picture */
+    int max_slices;             /* slices of a picture the tables hold (BR_MAX_SLICES) */
+    int releasing;              /* br_fail is giving the buffers back: failures met on the way are only reported */
 } Bridge;
 
 static __thread Bridge *br_tls;
 
+static void bridge_release(Bridge *b);
+/* The decoder leaves the batched path.  A bridge that was set up gives everything back first: pictures in flight come back
+ * into their frames (both sets, MI355_BRIDGE_LAZY or not), the dispatcher stops counting this decoder, pinned and device
+ * buffers are freed.  When this happens in the MIDDLE of a picture (a slice beyond the tables of the path) the macroblocks
+ * packed so far are lost: that picture is damaged, like one the decoder gave up on, and the message says so. */
 static void br_fail(Bridge *b, const char *what)
 {
-    if (b->state >= 0) fprintf(stderr, "mi355 bridge: %s — this decoder continues on the reference's C path\n", what);
+    if (b->releasing) { fprintf(stderr, "mi355 bridge: %s (while giving the buffers back)\n", what); return; }
+    const int was = b->state;
+    if (was >= 0)
+        fprintf(stderr, "mi355 bridge: %s — this decoder continues on the reference's C path%s\n", what,
+                was > 0 && b->open ? " (the picture being decoded is damaged)" : "");
+    if (was > 0) { b->releasing = 1; bridge_release(b); b->releasing = 0; }
     b->state = -1;
 }
 
@@ -464,15 +476,34 @@ void __wrap_ff_h264_flush_change(H264Context *h)
     __real_ff_h264_flush_change(h);
 }
 
+static pthread_key_t br_key;
+static pthread_once_t br_key_once = PTHREAD_ONCE_INIT;
+static void br_thread_exit(void *p)
+{
+    Bridge *b = p;
+    if (!b) return;
+    b->releasing = 1;                 /* failures on the way out are only reported */
+    bridge_release(b);
+    if (br_tls == b) br_tls = NULL;
+    free(b);
+}
+static void br_key_make(void) { pthread_key_create(&br_key, br_thread_exit); }
+
 static Bridge *bridge_get(const H264Context *h)
 {
     Bridge *b = br_tls;
     if (!b) {
         b = br_tls = calloc(1, sizeof(*b));
         if (!b) return NULL;
+        /* a decoder thread that exits gives its pictures, pinned buffers and dispatcher slot back (the key's destructor) */
+        pthread_once(&br_key_once, br_key_make);
+        pthread_setspecific(br_key, b);
         b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL;
         b->direct = getenv("MI355_BRIDGE_DIRECT") != NULL;
         b->null_submit = getenv("MI355_BRIDGE_NULL") != NULL;
+        /* MI355_BRIDGE_MAX_SLICES: a smaller slice table (tests: a picture with more slices than the path holds) */
+        const int ms = getenv("MI355_BRIDGE_MAX_SLICES") ? atoi(getenv("MI355_BRIDGE_MAX_SLICES")) : BR_MAX_SLICES;
+        b->max_slices = ms < 1 ? 1 : (ms > BR_MAX_SLICES ? BR_MAX_SLICES : ms);
         if (getenv("MI355_BRIDGE_PLAIN")) b->state = -1;         /* the comparison run: the reference's C path, silently */
     }
     if (b->state) return b;
@@ -537,7 +568,7 @@ static Bridge *bridge_get(const H264Context *h)
     ok = ok && staging_alloc(b, &b->st[0]) && staging_alloc(b, &b->st[1]);
     for (int p = 0; p < 3 && ok; p++) ok = (b->recon[p] = dalloc(b->plane_bytes[b->c444 ? 0 : p > 0])) != NULL;
     for (int p = 0; p < 2 && ok && b->c444; p++) ok = (b->scratch_c[p] = dalloc(b->plane_bytes[1])) != NULL;
-    if (!ok) { br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
+    if (!ok) { bridge_release(b); br_fail(b, "device, pinned memory or dispatcher set-up failed"); return b; }
     if (!b->direct) { pthread_mutex_lock(&b->disp->mu); b->disp->nbridges++; pthread_mutex_unlock(&b->disp->mu); }
     b->st[0].sub.b = b->st[1].sub.b = b;
     b->st[0].sub.s = &b->st[0]; b->st[1].sub.s = &b->st[1];
@@ -656,7 +687,7 @@ static void begin_picture(Bridge *b, const H264Context *h)
     Staging *s = &b->st[b->cur];
     if (s->in_flight) {
         b->waits++;
-        if (finish_set(b, s) != 0) br_fail(b, "a picture did not come back from the device");
+        if (finish_set(b, s) != 0) { br_fail(b, "a picture did not come back from the device"); return; }     /* the caller looks at b->state */
     }
     for (int p = 0; p < b->npass; p++) {
         memset(s->mb[p], 0, (size_t)b->nmb * sizeof(mi355_h264_mb));
@@ -677,7 +708,7 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
 {
     for (int i = 0; i < b->nslices; i++)
         if (b->slice_num_of[i] == sl->slice_num) return i;
-    if (b->nslices >= BR_MAX_SLICES) return -1;
+    if (b->nslices >= b->max_slices) return -1;
     mi355_h264_slice *s = &b->st[b->cur].slices[0][b->nslices];
     b->slice_num_of[b->nslices] = sl->slice_num;
     s->use_weight = sl->pwt.use_weight;
@@ -760,6 +791,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     Bridge *b = bridge_get(h);
     if (!b || b->state < 0) { __real_ff_h264_hl_decode_mb(h, sl); return; }
     if (!b->open) begin_picture(b, h);
+    if (b->state < 0) { __real_ff_h264_hl_decode_mb(h, sl); return; }
     Staging *st = &b->st[b->cur];
     /* in a field picture sl->mb_y counts FRAME macroblock rows (2 * field row + parity, h264_slice.c:2324-2329, 2456-2460) */
     const int mb_xy = sl->mb_xy, mb_row = sl->mb_y >> b->field, idx = sl->mb_x + mb_row * b->mb_w;

@@ -117,6 +117,21 @@ static void bs_begin(const HEVCContext *s)
     memset(lf.ref_poc, 0, sizeof(lf.ref_poc));
 }
 
+/* a new slice: its reference lists must be the picture's for the device to rate motion edges with one list table */
+static void bs_slice_lists(const HEVCContext *s)
+{
+    if (!lf.bs_uniform || lf.bs_slice == (int)s->sh.slice_addr) return;
+    lf.bs_slice = (int)s->sh.slice_addr;
+    if (s->sh.slice_type != HEVC_SLICE_I && s->ref->refPicList) {
+        int32_t now[2][16];
+        memset(now, 0, sizeof(now));
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < s->ref->refPicList[l].nb_refs && i < 16; i++) now[l][i] = s->ref->refPicList[l].list[i];
+        if (!lf.bs_lists_set) { memcpy(lf.ref_poc, now, sizeof(now)); lf.bs_lists_set = 1; }
+        else if (memcmp(lf.ref_poc, now, sizeof(now))) lf.bs_uniform = 0;
+    }
+}
+
 void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
 {
     __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size);
@@ -125,17 +140,8 @@ void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0
     if (!lf.bs_uniform) return;
     const HEVCSPS *sps = s->ps.sps;
     const HEVCLocalContext *lc = &s->HEVClc;
-    if (lf.bs_slice != (int)s->sh.slice_addr) {                     /* a new slice: its lists must be the picture's */
-        lf.bs_slice = (int)s->sh.slice_addr;
-        if (s->sh.slice_type != HEVC_SLICE_I && s->ref->refPicList) {
-            int32_t now[2][16];
-            memset(now, 0, sizeof(now));
-            for (int l = 0; l < 2; l++)
-                for (int i = 0; i < s->ref->refPicList[l].nb_refs && i < 16; i++) now[l][i] = s->ref->refPicList[l].list[i];
-            if (!lf.bs_lists_set) { memcpy(lf.ref_poc, now, sizeof(now)); lf.bs_lists_set = 1; }
-            else if (memcmp(lf.ref_poc, now, sizeof(now))) { lf.bs_uniform = 0; return; }
-        }
-    }
+    bs_slice_lists(s);
+    if (!lf.bs_uniform) return;
     const int size = 1 << log2_trafo_size, cw = sps->width >> 2, ctb_mask = (1 << sps->log2_ctb_size) - 1;
     const int inner = log2_trafo_size > sps->log2_min_pu_size &&
                       !s->ref->tab_mvf[(y0 >> sps->log2_min_pu_size) * sps->min_pu_width + (x0 >> sps->log2_min_pu_size)].is_intra;
@@ -368,8 +374,13 @@ static int filter_picture(HEVCContext *s)
 
 void __wrap_ff_hevc_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
 {
-    if (!active(s)) __real_ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb_size);
-    /* else: nothing per CTB — the picture is filtered when its last CTB arrives */
+    if (!active(s)) { __real_ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb_size); return; }
+    /* nothing per CTB — the picture is filtered when its last CTB arrives.  One thing is noted here, because every CTB of every
+     * slice passes: a slice with deblocking switched off never calls ff_hevc_deblocking_boundary_strengths (hevcdec.c, hls_transform_tree / hls_coding_unit: called under !disable_deblocking_filter_flag),
+     * so its reference lists would not be compared with the picture's — a deblocked neighbour rating the edge between them on the
+     * device could use the wrong list table.  The lists of such a slice are compared here. */
+    if (lf.bs_ref != s->ref) bs_begin(s);
+    if (s->sh.disable_deblocking_filter_flag) bs_slice_lists(s);
 }
 
 /* called by the slice decoder itself only for the picture's last CTB (hevcdec.c:2337-2339); the per-CTB calls come

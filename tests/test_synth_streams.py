@@ -1,5 +1,6 @@
 """CPU: the generated streams (synth_streams.py) — oracle, emulated kernels, sessions, and (where /root/reference's decoder
 harnesses are built) the reference decoder with this project's Tier-1 hooks / Tier-2 bridge on the SIMT emulator."""
+import json
 import os
 
 import numpy as np
@@ -157,6 +158,29 @@ def test_bridge_survives_damaged_streams_emulated(tmp_path, emu, seed):
             env["MI355_BRIDGE_LAZY"] = "1"
         res = subprocess.run([SY.exe("h264_bridge_emu"), str(src), str(tmp_path / "o.yuv"), "1", "1"], capture_output=True, text=True, env=env, timeout=600)
         assert res.returncode == 0, (res.returncode, res.stderr[-500:])
+
+
+@needs_harness
+@pytest.mark.parametrize("lazy", (False, True))
+def test_bridge_leaves_the_path_in_the_middle_of_a_picture_emulated(tmp_path, emu, lazy):
+    """a picture with more slices than the bridge's tables hold (MI355_BRIDGE_MAX_SLICES=8 on the 30-slice stream): the bridge
+    gives back what is in flight and its buffers, the decoder finishes the stream on the C path — same exit code and number of
+    pictures as the plain run, no hang, and the pictures before the one that overflowed are the reference's"""
+    import subprocess
+    name = "420_8_slices30"
+    env = dict(os.environ, MI355_BRIDGE_MAX_SLICES="8")
+    env.pop("MI355_BRIDGE_LAZY", None)
+    if lazy:
+        env["MI355_BRIDGE_LAZY"] = "1"
+    out, ref = tmp_path / "o.yuv", tmp_path / "r.yuv"
+    res = subprocess.run([SY.exe("h264_bridge_emu"), SY.samples(name), str(out), "1", "1"], capture_output=True, text=True, env=env, timeout=600)
+    plain = subprocess.run([SY.exe("h264_bridge_emu"), SY.samples(name), str(ref), "1", "1"], capture_output=True, text=True,
+                           env=dict(os.environ, MI355_BRIDGE_PLAIN="1"), timeout=600)
+    assert res.returncode == plain.returncode == 0, (res.returncode, res.stderr[-500:])
+    assert "more slices or reference pictures than the batched path holds" in res.stderr
+    st = json.loads(res.stdout.strip().splitlines()[-1])
+    assert st["bridges_active"] == 0 and st["pictures_output"] == SY.MD5[name]["pictures"], st
+    assert os.path.getsize(out) == os.path.getsize(ref)
 
 
 def _truncate_samples(src, dst, keep):
