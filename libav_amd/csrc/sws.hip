@@ -154,10 +154,14 @@ static_assert(OUT_ROWS >= 8, "the narrow form needs at most two passes over a ti
 static inline uint32_t sws_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (s & 3))); }
 static inline uint32_t sws_pair(uint32_t w, int k) { return ((w >> (16 * k)) & 0xFFu) | (((w >> (16 * k + 8)) & 0xFFu) << 16); }
 static inline int sws_dot2(uint32_t a, uint32_t b, int c) { return c + (int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int16_t)(a >> 16) * (int16_t)(b >> 16); }
+static inline uint32_t sws_lo2(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }            /* (a.lo, b.lo) */
+static inline uint32_t sws_hi2(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }        /* (a.hi, b.hi) */
 #else
 __device__ __forceinline__ uint32_t sws_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
 /* bytes 2k, 2k + 1 of w as two 16-bit values */
 __device__ __forceinline__ uint32_t sws_pair(uint32_t w, int k) { return __builtin_amdgcn_perm(0u, w, k ? 0x0C030C02u : 0x0C010C00u); }
+__device__ __forceinline__ uint32_t sws_lo2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }      /* (a.lo, b.lo) */
+__device__ __forceinline__ uint32_t sws_hi2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }      /* (a.hi, b.hi) */
 typedef short sws_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int sws_dot2(uint32_t a, uint32_t b, int c)
 {
@@ -446,17 +450,43 @@ __device__ __forceinline__ void vertical_rows(const SwsDev &c, const LutLds &lut
             for (int k = 0; k < 8; k++) Y[k] = 1 << 18;
 #pragma unroll
             for (int k = 0; k < 4; k++) U[k] = V[k] = 1 << 18;
+            /* two taps at a time: the same sample of two source lines side by side in a dword (one byte-permute) against the
+             * tap pair, v_dot2_i32_i16 — the same integer sum as the reference's per-tap multiply-add (15-bit samples,
+             * 16-bit coefficients, int accumulators) */
+            if (NL >= 2) {
 #pragma unroll
-            for (int j = 0; j < NL; j++) {
-                const sws_u32x4 l = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[j]][8 * grp]);
+                for (int j = 0; j + 1 < NL; j += 2) {
+                    const sws_u32x4 la = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[j]][8 * grp]), lb = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[j + 1]][8 * grp]);
+                    const uint32_t cp = ((uint32_t)lf[j] & 0xFFFFu) | ((uint32_t)lf[j + 1] << 16);
 #pragma unroll
-                for (int k = 0; k < 8; k++) Y[k] += (int16_t)(l[k >> 1] >> (16 * (k & 1))) * lf[j];
+                    for (int q = 0; q < 4; q++) {
+                        Y[2 * q] = sws_dot2(sws_lo2(la[q], lb[q]), cp, Y[2 * q]);
+                        Y[2 * q + 1] = sws_dot2(sws_hi2(la[q], lb[q]), cp, Y[2 * q + 1]);
+                    }
+                }
+            } else {
+                const sws_u32x4 l = *reinterpret_cast<const sws_u32x4 *>(&s_lum[li[0]][8 * grp]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) Y[k] += (int16_t)(l[k >> 1] >> (16 * (k & 1))) * lf[0];
             }
+            if (NC >= 2) {
 #pragma unroll
-            for (int j = 0; j < NC; j++) {
-                const sws_u32x2 u = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[j]][4 * grp]), v = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[j]][4 * grp]);
+                for (int j = 0; j + 1 < NC; j += 2) {
+                    const sws_u32x2 ua = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[j]][4 * grp]), ub = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[j + 1]][4 * grp]);
+                    const sws_u32x2 va = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[j]][4 * grp]), vb = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[j + 1]][4 * grp]);
+                    const uint32_t cp = ((uint32_t)cf[j] & 0xFFFFu) | ((uint32_t)cf[j + 1] << 16);
 #pragma unroll
-                for (int k = 0; k < 4; k++) { U[k] += (int16_t)(u[k >> 1] >> (16 * (k & 1))) * cf[j]; V[k] += (int16_t)(v[k >> 1] >> (16 * (k & 1))) * cf[j]; }
+                    for (int q = 0; q < 2; q++) {
+                        U[2 * q] = sws_dot2(sws_lo2(ua[q], ub[q]), cp, U[2 * q]);
+                        U[2 * q + 1] = sws_dot2(sws_hi2(ua[q], ub[q]), cp, U[2 * q + 1]);
+                        V[2 * q] = sws_dot2(sws_lo2(va[q], vb[q]), cp, V[2 * q]);
+                        V[2 * q + 1] = sws_dot2(sws_hi2(va[q], vb[q]), cp, V[2 * q + 1]);
+                    }
+                }
+            } else {
+                const sws_u32x2 u = *reinterpret_cast<const sws_u32x2 *>(&s_cu[ci[0]][4 * grp]), v = *reinterpret_cast<const sws_u32x2 *>(&s_cv[ci[0]][4 * grp]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { U[k] += (int16_t)(u[k >> 1] >> (16 * (k & 1))) * cf[0]; V[k] += (int16_t)(v[k >> 1] >> (16 * (k & 1))) * cf[0]; }
             }
 #pragma unroll
             for (int p = 0; p < 4; p++) {       /* clipped per pair, only if one of its four values has bit 8 set (output.c:963) */
