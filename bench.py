@@ -352,14 +352,16 @@ def hevc_bridge_points(lib):
     """The reference's own HEVC decoder with the Tier-2 bridge (contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c: every
     prediction block, transform unit and intra block of a picture recorded and run on the device level by level, in-loop filters on the
     same device picture, references in HBM) on two generated streams, and the SAME binary with everything forwarded to the reference's
-    C functions beside it (oracle/_ref/hevc_bridge_gpu, built where /root/reference exists).  One decoder, one picture per launch set,
-    pictures of 96x64..128x128 samples: this is the launch-bound end of the path, reported as measured."""
+    C functions beside it (oracle/_ref/hevc_bridge_gpu, built where /root/reference exists).  One decoder, one picture per launch set:
+    generated 1920x1080 P / B streams (CTB 64) with 2 % and with 30 % intra coding units outside the first picture (a picture's launches
+    follow its dependency levels, and those follow its intra blocks: 4x4 intra blocks everywhere are a wavefront of ~850 levels at 1080p),
+    832x480, and two of the small ones (136x72: the launch-bound end of the path)."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "hevc_bridge_gpu")
     out = []
     if not os.path.exists(exe):
         return out
-    for name in ("pb_ctb64_depth0", "i_ctb64"):
+    for name in ("pb_1080p_few_intra", "pb_1080p_ctb64", "pb_480p_ctb64", "pb_ctb64_depth0", "i_ctb64"):
         src = os.path.join(ROOT, "tests", "golden", "hevc_synth_%s.samples" % name)
         pt = {"name": "hevc_bridge_" + name}
         for key, env in (("bridge", {}), ("reference_c_decoder", {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):

@@ -442,6 +442,18 @@ int __wrap_ff_hevc_frame_rps(HEVCContext *s)
     if (R.s != s)                       /* another decoder on this thread: nothing on the device is its picture */
         for (int i = 0; i < MAX_SURF; i++) R.surf[i].valid = 0;
     R.s = s;
+    /* a surface mirrors a frame the decoder HOLDS (a DPB entry, the picture being decoded, the SAO work frame): anything else is
+     * memory that went back to the buffer pool — or to another decoder at the same address — and must not be matched by address
+     * ranges (locate) or read (upload_surface) any more */
+    for (int i = 0; i < MAX_SURF; i++) {
+        Surface *u = &R.surf[i];
+        if (!u->host[0]) continue;
+        int held = (s->frame && s->frame->data[0] == u->host[0]) || (s->sao_frame && s->sao_frame->data[0] == u->host[0]) ||
+                   (s->tmp_frame && s->tmp_frame->data[0] == u->host[0]);
+        for (int k = 0; k < FF_ARRAY_ELEMS(s->DPB) && !held; k++)
+            held = s->DPB[k].frame && s->DPB[k].frame->data[0] == u->host[0];
+        if (!held) { u->valid = 0; u->host[0] = u->host[1] = u->host[2] = NULL; }
+    }
     R.on = 0;
     R.pictures++;
     if (ret < 0 || R.plain || R.failed || !s->frame || !s->frame->data[0]) return ret;
@@ -539,6 +551,13 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     if (dev_ensure(&R.d_stage, &R.d_stage_bytes, o) || dev_ensure(&R.d_emu, &R.d_emu_bytes, R.emu_bytes + 64)) return -1;
     if (R.nintra && (dev_ensure(&R.d_mvf, &R.d_mvf_bytes, mvf_bytes) || dev_ensure(&R.d_zs, &R.d_zs_bytes, zs_bytes))) return -1;
     const int L = R.max_level;
+    if (getenv("MI355_HEVC_RECON_TRACE")) {
+        int lm = 0, lt = 0, li = 0;
+        for (int i = 0; i < R.nmc; i++) if (R.mc[i].level > lm) lm = R.mc[i].level;
+        for (int i = 0; i < R.ntu; i++) if (R.tu[i].level > lt) lt = R.tu[i].level;
+        for (int i = 0; i < R.nintra; i++) if (R.intra[i].level > li) li = R.intra[i].level;
+        fprintf(stderr, "recon: poc %d: %d prediction blocks (levels <= %d), %d transform units (<= %d), %d intra blocks (<= %d), %d windows\n", s->poc, R.nmc, lm, R.ntu, lt, R.nintra, li, R.nemu);
+    }
     /* counting sort by level of the three job kinds */
     int *start = calloc((size_t)(L + 2) * 3, sizeof(int));
     if (!start) return -1;

@@ -240,7 +240,7 @@ def scan_tables(log2, scan_idx):
 class Hevc:
     def __init__(self, name, seed, w=96, h=64, bd=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, depth_intra=2,
                  depth_inter=2, sao=1, dbf_off=0, dbf_offsets=(0, 0), strong=1, qp=30, qp_delta=0, tskip=0, bypass=0, slices=1,
-                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0):
+                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3):
         self.__dict__.update(locals())
         self.rng = random.Random(seed)
         self.tables = load_tables()
@@ -497,7 +497,7 @@ class Hevc:
             self.fill(self.ipm, x0, y0, size, 1)
             return
         if self.stype != 2:
-            intra = int(r.random() < 0.3)
+            intra = int(r.random() < self.intra_frac)       # share of intra coding units in P / B slices
             c.enc(PRED_MODE, 0, intra)
         part = 0                                                     # 2Nx2N
         if intra:
@@ -956,6 +956,9 @@ STREAMS = {
     "pb_10bit_weighted": dict(seed=12, inter=1, pictures=5, bd=10, weighted=1, w=80, h=72),
     "pb_ctb16_slices_cip": dict(seed=13, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4, slices=3, cip=1, w=104, h=56, amp=0),
     "pb_ctb64_depth0": dict(seed=14, inter=1, pictures=4, log2_ctb=6, w=136, h=72, depth_inter=0, depth_intra=1, weighted=1),
+    "pb_480p_ctb64": dict(seed=31, inter=1, pictures=4, log2_ctb=6, w=832, h=480, depth_inter=1, depth_intra=2, sao=2),
+    "pb_1080p_ctb64": dict(seed=32, inter=1, pictures=5, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2),
+    "pb_1080p_few_intra": dict(seed=33, inter=1, pictures=6, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2, intra_frac=0.02),
 }
 
 

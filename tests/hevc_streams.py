@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 MD5 = json.load(open(os.path.join(GOLD, "hevc_streams.json")))
 ALL = sorted(MD5)
+EMU = [n for n in ALL if not n.startswith("pb_1080p")]        # the SIMT emulator takes half a minute per pass over the 1080p stream: GPU tests only
 
 
 def samples(name):
