@@ -181,8 +181,8 @@ __device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0
     const uint32_t c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
     static_assert(COLS >= 64, "a wave's threads share their first line: `left` is the same on all of them");
     /* four lines at a time: their twelve LDS reads go out together, then the arithmetic of the four (one read-wait-compute chain
-     * per line leaves the wave waiting for the LDS once per output).  A short last round ends at a branch of the wave between
-     * groups; inside a group only the store is conditional (the staged lines exist, the result rows past `left` may not). */
+     * per line leaves the wave waiting for the LDS once per output).  A short last round ends at a branch of the wave, between
+     * groups or inside one (the reads of a group are unconditional: the staged lines exist). */
     constexpr int G = 4, N = SG / per;
     static_assert(N % G == 0, "groups of four lines");
 #pragma unroll
@@ -194,20 +194,17 @@ __device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0
             const uint32_t *w = w0 + (g + q) * per * SRC_DW;
             d[q][0] = w[0]; d[q][1] = w[1]; d[q][2] = w[2];
         }
-        int val[G];
 #pragma unroll
         for (int q = 0; q < G; q++) {
+            if ((g + q) * per > left) break;                 /* of the wave, like the one between groups */
             const uint32_t lo = sws_alignbyte(d[q][1], d[q][0], sh), hi = sws_alignbyte(d[q][2], d[q][1], sh);
             int v = sws_dot2(sws_pair(lo, 0), c01, 0);
             v = sws_dot2(sws_pair(lo, 1), c23, v);
             v = sws_dot2(sws_pair(hi, 0), c45, v);
             v = sws_dot2(sws_pair(hi, 1), c67, v);
             v >>= 7;
-            val[q] = v < 32767 ? v : 32767;
+            out0[(g + q) * per * COLS] = (int16_t)(v < 32767 ? v : 32767);
         }
-#pragma unroll
-        for (int q = 0; q < G; q++)
-            if ((g + q) * per <= left) out0[(g + q) * per * COLS] = (int16_t)val[q];
     }
 }
 template <int COLS, int TAPS>
@@ -301,27 +298,27 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
      * barrier with nothing to do: a third of the kernel's time on a 2:1 reduction).  At most PF pieces per thread and round. */
     constexpr int PF = (SG * ((SRC_DW + 3) / 4) + NT - 1) / NT;
     uint4 pre[PF];
+    /* which piece of a round a thread moves does not change from round to round: its staging row, source column and LDS address are
+     * worked out once per plane.  Nothing sits under a lane condition: a piece past the round's last repeats the last one, a line past
+     * the plane's last needed line repeats that one (the same bytes to the same place, or to a staging line nothing reads). */
+    int p_row[PF], p_col[PF];
+    uint32_t *p_lds[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+        const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np, off = a0 + 16 * d;
+        p_row[j] = r;
+        p_col[j] = imin(off, (srcW - 1) & ~15);
+        p_lds[j] = &stage[r][4 * d];
+    }
     auto fetch16 = [&](int base) {
 #pragma unroll
         for (int j = 0; j < PF; j++) {
-            /* nothing under a lane condition: a piece past the round's last repeats the last one, a line past the plane's last
-             * needed line repeats that one (the same bytes to the same place, or to a staging line nothing reads) */
-            const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np, line = imin(base + r, hi);
-            /* the aligned 16 bytes lie inside the line's stride (both multiples of 16, off < srcW <= stride): always readable;
-             * bytes at and past srcW (padding) are cleared — no filter tap with a non-zero coefficient reads them, the value
-             * only has to be the same everywhere */
-            const int off = a0 + 16 * d;
-            uint4 w = *reinterpret_cast<const uint4 *>(src + (size_t)line * stride + imin(off, (srcW - 1) & ~15));
-            const int nv = srcW - off;                                  /* valid bytes: >= 16 inside the picture, <= 0 past it */
-            if (nv < 16) {
-                uint32_t q[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int n = nv - 4 * k;
-                    q[k] = n >= 4 ? q[k] : (n <= 0 ? 0u : q[k] & ((1u << (8 * n)) - 1u));
-                }
-                w = make_uint4(q[0], q[1], q[2], q[3]);
-            }
+            if (j * NT >= SG * np) break;                    /* a narrow plane's round is fewer pieces than threads: the same for every thread */
+            /* the aligned 16 bytes lie inside the line's stride (both multiples of 16, column < srcW <= stride): always readable.
+             * Bytes at and past srcW (padding) are whatever the plane holds there: no tap with a non-zero coefficient reads them —
+             * mi355_sws_create stages only filter banks whose every position + size stays inside the line, as the reference's
+             * initFilter builds them (utils.c "fix borders") — and a tap past the filter's size multiplies them by zero. */
+            const uint4 w = *reinterpret_cast<const uint4 *>(src + (size_t)imin(base + p_row[j], hi) * stride + p_col[j]);
             pre[j] = w;
         }
     };
@@ -333,8 +330,8 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         if (al16) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
-                const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np;
-                *reinterpret_cast<uint4 *>(&stage[r][4 * d]) = pre[j];
+                if (j * NT >= SG * np) break;
+                *reinterpret_cast<uint4 *>(p_lds[j]) = pre[j];
             }
         } else
         for (int idx = tid; idx < SG * np; idx += NT) {
@@ -848,6 +845,9 @@ extern "C" mi355_sws_ctx *mi355_sws_create(const mi355_sws_desc *desc)
     h.hstage = 1;
     for (int i = 1; i < desc->hLum.n && desc->hLum.pos; i++) if (desc->hLum.pos[i] < desc->hLum.pos[i - 1]) h.hstage = 0;
     for (int i = 1; i < desc->hChr.n && desc->hChr.pos; i++) if (desc->hChr.pos[i] < desc->hChr.pos[i - 1]) h.hstage = 0;
+    /* ... and every tap inside its line (the staged form does not clear what lies past the line's end) */
+    for (int i = 0; i < desc->hLum.n && desc->hLum.pos; i++) if (desc->hLum.pos[i] < 0 || desc->hLum.pos[i] + desc->hLum.size > desc->srcW) h.hstage = 0;
+    for (int i = 0; i < desc->hChr.n && desc->hChr.pos; i++) if (desc->hChr.pos[i] < 0 || desc->hChr.pos[i] + desc->hChr.size > desc->chrSrcW) h.hstage = 0;
     auto identity = [](const mi355_sws_filter &f, int src_w) {
         if (f.size != 1 || !f.coef || !f.pos || f.n > src_w) return 0;
         for (int i = 0; i < f.n; i++) if (f.coef[i] != 16384 || f.pos[i] != i) return 0;
