@@ -146,6 +146,13 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 constexpr int SG = MI355_SWS_SG;      /* source lines per staging round (a round costs two workgroup barriers) */
 constexpr int SRC_DW = 76;            /* dwords per staged line: 2:1 with 8 taps needs 128 * 2 + 8 bytes (+2 of slack for zero taps) */
 constexpr int STAGE_BYTES = (int)sizeof(uint32_t) * SG * SRC_DW;
+/* a chroma tile row is half as wide: its staged lines are about half as long (64 * 2 + 8 bytes + the 15 of a 16-byte aligned start) and a
+ * round holds half as many again in the same storage (the 20 chroma lines of a 2:1 reduction: one round instead of two) */
+template <int COLS> struct StageGeom {
+    static constexpr int PITCH = COLS == TW ? SRC_DW : 40;             /* dwords per staged line: a multiple of four (16-byte LDS stores) */
+    static constexpr int LINES = COLS == TW ? SG : (3 * SG) / 2;       /* staged lines per round */
+    static_assert(PITCH % 4 == 0 && (size_t)PITCH * LINES * sizeof(uint32_t) <= (size_t)STAGE_BYTES, "a round fits the staging storage");
+};
 constexpr int OUT_ROWS = STAGE_BYTES / (TW * 3);            /* rows of a narrow tile written per pass (they reuse the staging lines) */
 static_assert(OUT_ROWS >= 8, "the narrow form needs at most two passes over a tile of MAXTH rows");
 /* byte funnel shift, byte permute and the two-term 16-bit dot product (v_alignbyte_b32, v_perm_b32, v_dot2_i32_i16); plain C
@@ -180,18 +187,18 @@ __device__ __forceinline__ void hscale_lines8(const uint8_t *row0, int16_t *out0
     const uint32_t *w0 = reinterpret_cast<const uint32_t *>(row0 - sh);
     const uint32_t c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
     static_assert(COLS >= 64, "a wave's threads share their first line: `left` is the same on all of them");
-    /* four lines at a time: their twelve LDS reads go out together, then the arithmetic of the four (one read-wait-compute chain
+    /* four (chroma: three) lines at a time: their LDS reads go out together, then the arithmetic of the group (one read-wait-compute chain
      * per line leaves the wave waiting for the LDS once per output).  A short last round ends at a branch of the wave, between
      * groups or inside one (the reads of a group are unconditional: the staged lines exist). */
-    constexpr int G = 4, N = SG / per;
-    static_assert(N % G == 0, "groups of four lines");
+    constexpr int N = StageGeom<COLS>::LINES / per, G = N % 4 == 0 ? 4 : 3, PITCH = StageGeom<COLS>::PITCH;
+    static_assert(StageGeom<COLS>::LINES % per == 0 && N % G == 0, "whole groups of lines");
 #pragma unroll
     for (int g = 0; g < N; g += G) {
         if (g * per > left) break;
         uint32_t d[G][3];
 #pragma unroll
         for (int q = 0; q < G; q++) {
-            const uint32_t *w = w0 + (g + q) * per * SRC_DW;
+            const uint32_t *w = w0 + (g + q) * per * PITCH;
             d[q][0] = w[0]; d[q][1] = w[1]; d[q][2] = w[2];
         }
 #pragma unroll
@@ -215,9 +222,9 @@ __device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0,
 #pragma unroll
     for (int j = 0; j < TAPS; j++) cf[j] = (int16_t)(cp[j >> 1] >> (16 * (j & 1)));
 #pragma unroll
-    for (int k = 0; k < SG / per; k++) {
+    for (int k = 0; k < StageGeom<COLS>::LINES / per; k++) {
         if (k * per > left) break;
-        const uint8_t *row = row0 + k * per * (SRC_DW * 4);
+        const uint8_t *row = row0 + k * per * (StageGeom<COLS>::PITCH * 4);
         int val = 0;
 #pragma unroll
         for (int j = 0; j < TAPS; j++) val += (int)row[j] * cf[j];
@@ -228,8 +235,10 @@ __device__ __forceinline__ void hscale_lines(const uint8_t *row0, int16_t *out0,
 template <int COLS>
 __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t *src, int stride, int srcW, const int32_t *posT,
                                             const int16_t *coefT, int fs, int gx0, int ncols, int lo, int hi,
-                                            uint32_t (*stage)[SRC_DW], int tid, bool zero_tail, bool may_stage, bool identity)
+                                            uint32_t *stage_mem, int tid, bool zero_tail, bool may_stage, bool identity)
 {
+    constexpr int PITCH = StageGeom<COLS>::PITCH, LINES = StageGeom<COLS>::LINES;
+    uint32_t (*stage)[PITCH] = reinterpret_cast<uint32_t (*)[PITCH]>(stage_mem);
     if (identity) {
         /* one tap of 1 << 14 at position i: (src * 16384) >> 7 = src << 7 (below the 32767 clamp).  Eight columns per thread:
          * one 8-byte load (aligned planes, inside the line), one 16-byte LDS write */
@@ -281,7 +290,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
 #pragma unroll
         for (int j = 0; j < 4; j++) cp[j] = (2 * j < fs ? (uint32_t)t[2 * j] & 0xFFFFu : 0u) | (2 * j + 1 < fs ? (uint32_t)t[2 * j + 1] << 16 : 0u);
     }
-    const bool staged = may_stage && nd <= SRC_DW - 2 && s1 >= s0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0;
+    const bool staged = may_stage && nd <= PITCH - 2 && s1 >= s0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3) == 0;
     if (!staged) {
         if (col_ok) {
             for (int l = lo + tid / COLS; l <= hi; l += per) out[l - lo][x] = (int16_t)hscale_one(src + (size_t)l * stride, f, pos, fs);
@@ -290,13 +299,13 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
         }
         return;
     }
-    /* idx / n as a 24-bit multiply and a shift (mi355_div20: exact for idx * n < 2^19; here idx < SG * n, n <= SRC_DW) */
-    static_assert(SG * SRC_DW * SRC_DW < (1 << 19), "mi355_div20 range");
+    /* idx / n as a 24-bit multiply and a shift (mi355_div20: exact for idx * n < 2^19; here idx < LINES * n, n <= PITCH) */
+    static_assert(LINES * PITCH * PITCH < (1 << 19), "mi355_div20 range");
     const int np = al16 ? (nd + 3) >> 2 : nd, inv = mi355_inv20(np);
     /* 16-byte pieces travel through registers, one round ahead: the loads of round r + 1 are issued before round r's
      * arithmetic and stored to the staging lines after it (a round's loads would otherwise be waited for at its first
      * barrier with nothing to do: a third of the kernel's time on a 2:1 reduction).  At most PF pieces per thread and round. */
-    constexpr int PF = (SG * ((SRC_DW + 3) / 4) + NT - 1) / NT;
+    constexpr int PF = (LINES * ((PITCH + 3) / 4) + NT - 1) / NT;
     uint4 pre[PF];
     /* which piece of a round a thread moves does not change from round to round: its staging row, source column and LDS address are
      * worked out once per plane.  Nothing sits under a lane condition: a piece past the round's last repeats the last one, a line past
@@ -305,7 +314,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
     uint32_t *p_lds[PF];
 #pragma unroll
     for (int j = 0; j < PF; j++) {
-        const int idx = imin(tid + j * NT, SG * np - 1), r = mi355_div20(idx, inv), d = idx - r * np, off = a0 + 16 * d;
+        const int idx = imin(tid + j * NT, LINES * np - 1), r = mi355_div20(idx, inv), d = idx - r * np, off = a0 + 16 * d;
         p_row[j] = r;
         p_col[j] = imin(off, (srcW - 1) & ~15);
         p_lds[j] = &stage[r][4 * d];
@@ -313,7 +322,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
     auto fetch16 = [&](int base) {
 #pragma unroll
         for (int j = 0; j < PF; j++) {
-            if (j * NT >= SG * np) break;                    /* a narrow plane's round is fewer pieces than threads: the same for every thread */
+            if (j * NT >= LINES * np) break;                 /* a narrow plane's round is fewer pieces than threads: the same for every thread */
             /* the aligned 16 bytes lie inside the line's stride (both multiples of 16, column < srcW <= stride): always readable.
              * Bytes at and past srcW (padding) are whatever the plane holds there: no tap with a non-zero coefficient reads them —
              * mi355_sws_create stages only filter banks whose every position + size stays inside the line, as the reference's
@@ -325,16 +334,16 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
 #ifndef MI355_SWS_EXP_NOSTAGE     /* developer experiments (tools/exp_sws_sg.sh): the pass without its loads / without its arithmetic */
     if (al16) fetch16(lo);
 #endif
-    for (int base = lo; base <= hi; base += SG) {
+    for (int base = lo; base <= hi; base += LINES) {
 #ifndef MI355_SWS_EXP_NOSTAGE
         if (al16) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
-                if (j * NT >= SG * np) break;
+                if (j * NT >= LINES * np) break;
                 *reinterpret_cast<uint4 *>(p_lds[j]) = pre[j];
             }
         } else
-        for (int idx = tid; idx < SG * np; idx += NT) {
+        for (int idx = tid; idx < LINES * np; idx += NT) {
             const int r = mi355_div20(idx, inv), d = idx - r * np, line = base + r;
             if (line > hi) continue;
             const uint8_t *p = src + (size_t)line * stride + a0 + 4 * d;
@@ -349,7 +358,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
 #endif
         __syncthreads();
 #ifndef MI355_SWS_EXP_NOSTAGE
-        if (al16 && base + SG <= hi) fetch16(base + SG);
+        if (al16 && base + LINES <= hi) fetch16(base + LINES);
 #endif
         /* the thread's column over the staged lines: fixed trip count, so line and output addresses are
          * immediate offsets from one base each; tap count rounded up to 1 / 2 / 4 / 8 (taps past fs are zero, the
@@ -365,8 +374,8 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
             else if (fs <= 4) hscale_lines<COLS, 4>(row0, out0, cp, left);
             else if (fs <= 8) hscale_lines8<COLS>(row0, out0, cp, left);
             else {
-                for (int k = 0; k < SG / per && k * per <= left; k++) {
-                    const uint8_t *row = row0 + k * per * (SRC_DW * 4);
+                for (int k = 0; k < LINES / per && k * per <= left; k++) {
+                    const uint8_t *row = row0 + k * per * (PITCH * 4);
                     int val = 0;
                     for (int j = 0; j < fs; j++) val += (int)row[j] * f[j];
                     val >>= 7;
@@ -374,7 +383,7 @@ __device__ __forceinline__ void hscale_tile(int16_t (*out)[COLS], const uint8_t 
                 }
             }
         } else if (zero_tail) {
-            for (int k = 0; k < SG / per && k * per <= left; k++) out0[k * per * COLS] = 0;
+            for (int k = 0; k < LINES / per && k * per <= left; k++) out0[k * per * COLS] = 0;
         }
 #endif
         __syncthreads();
@@ -642,7 +651,7 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
     lut_load(s_lut, &cp->luts, tid, NT);
     /* horizontal pass: luma (the phantom partner of the last sample of an odd-width picture reads the
      * zero-initialised tail of the reference's line buffer, utils.c:1241-1262), then the chroma planes */
-    uint32_t (*s_stage)[SRC_DW] = reinterpret_cast<uint32_t (*)[SRC_DW]>(s_io);
+    uint32_t *s_stage = reinterpret_cast<uint32_t *>(s_io);
 #ifndef MI355_SWS_NO_H
     hscale_tile<TW>(s_lum, fr.src[0], fr.src_stride[0], c.srcW, c.hLumP, c.hLumC, c.hls, x0, c.dstW, llo, lhi, s_stage, tid, true, c.hstage != 0, c.hident_l != 0);
     hscale_tile<TW / 2>(s_cu, fr.src[1], fr.src_stride[1], c.chrSrcW, c.hChrP, c.hChrC, c.hcs, x0 >> 1, c.chrDstW, clo, chi, s_stage, tid, false, c.hstage != 0, c.hident_c != 0);
