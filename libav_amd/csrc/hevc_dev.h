@@ -260,41 +260,49 @@ __device__ __forceinline__ void hevc_mc_st4(int16_t *p, uint32_t lo, uint32_t hi
         if (n == 3) p[2] = (int16_t)(hi & 0xFFFF);
     }
 }
+/* one round of hevc_mc_stage: U pieces of eight bytes per lane, all U loads issued before the first result is touched (a lane
+ * past the end repeats the last piece and drops it) — one memory round trip per 64 U pieces */
+template <int U>
+__device__ __forceinline__ void hevc_mc_stage_round(HevcMcScratch &s, const uint8_t *w0, ptrdiff_t sb, int base, int n, int K, int inv, int rowbytes, int bd, int lane)
+{
+    uint64_t v[U];
+    int rr[U], kk[U], sh[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int i = base + 64 * u + lane, ic = i < n ? i : n - 1;
+        const int r = mi355_div20(ic, inv), k = ic - r * K;
+        /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
+        const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
+        __builtin_memcpy(&v[u], w0 + (ptrdiff_t)r * sb + start, 8);
+        rr[u] = i < n ? r : -1; kk[u] = k; sh[u] = 8 * (want - start);
+    }
+    MI355_ISSUE_FENCE();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (rr[u] < 0) continue;
+        const uint64_t w64 = v[u] >> sh[u];
+        const uint32_t lo = (uint32_t)w64, hi = (uint32_t)(w64 >> 32);
+        if (bd > 8) {
+            *reinterpret_cast<uint2 *>(&s.win[rr[u] * HEVC_MC_PITCH + 4 * kk[u]]) = make_uint2(lo, hi);
+        } else {
+            uint32_t *w = reinterpret_cast<uint32_t *>(&s.win[rr[u] * HEVC_MC_PITCH + 8 * kk[u]]);
+            w[0] = mi355_widen_lo(lo); w[1] = mi355_widen_hi(lo); w[2] = mi355_widen_lo(hi); w[3] = mi355_widen_hi(hi);
+        }
+    }
+}
 /* rows x cols samples from `w0` (bytes, `sb` bytes per row) -> s.win as 16-bit values */
 __device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdiff_t sb, int rows, int cols, int bd)
 {
     const int lane = lane_id(), rowbytes = cols * (bd > 8 ? 2 : 1);
     if (rowbytes >= 8) {
         const int K = (rowbytes + 7) >> 3, inv = mi355_inv20(K), n = rows * K;
-        /* four pieces per lane and round: all four loads are issued before the first result is touched (a lane past the end
-         * repeats the last piece and drops it) — one memory round trip per 256 pieces instead of one per 64 */
-        constexpr int U = 4;
-        for (int base = 0; base < n; base += 64 * U) {
-            uint64_t v[U];
-            int rr[U], kk[U], sh[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = base + 64 * u + lane, ic = i < n ? i : n - 1;
-                const int r = mi355_div20(ic, inv), k = ic - r * K;
-                /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
-                const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
-                __builtin_memcpy(&v[u], w0 + (ptrdiff_t)r * sb + start, 8);
-                rr[u] = i < n ? r : -1; kk[u] = k; sh[u] = 8 * (want - start);
-            }
-            MI355_ISSUE_FENCE();
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (rr[u] < 0) continue;
-                const uint64_t w64 = v[u] >> sh[u];
-                const uint32_t lo = (uint32_t)w64, hi = (uint32_t)(w64 >> 32);
-                if (bd > 8) {
-                    *reinterpret_cast<uint2 *>(&s.win[rr[u] * HEVC_MC_PITCH + 4 * kk[u]]) = make_uint2(lo, hi);
-                } else {
-                    uint32_t *w = reinterpret_cast<uint32_t *>(&s.win[rr[u] * HEVC_MC_PITCH + 8 * kk[u]]);
-                    w[0] = mi355_widen_lo(lo); w[1] = mi355_widen_hi(lo); w[2] = mi355_widen_lo(hi); w[3] = mi355_widen_hi(hi);
-                }
-            }
-        }
+        /* rounds of four pieces per lane while that many remain, then three, two or one: a 16x16 chroma block's window is 95 pieces,
+         * and every piece slot costs its ~20 instructions whether a lane uses it or not */
+        int base = 0;
+        for (; n - base > 192; base += 256) hevc_mc_stage_round<4>(s, w0, sb, base, n, K, inv, rowbytes, bd, lane);
+        if (n - base > 128) hevc_mc_stage_round<3>(s, w0, sb, base, n, K, inv, rowbytes, bd, lane);
+        else if (n - base > 64) hevc_mc_stage_round<2>(s, w0, sb, base, n, K, inv, rowbytes, bd, lane);
+        else if (n - base > 0) hevc_mc_stage_round<1>(s, w0, sb, base, n, K, inv, rowbytes, bd, lane);
     } else {
         for (int i = lane; i < rows * cols; i += 64) {
             const int r = i / cols, c = i - r * cols;
