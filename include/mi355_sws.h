@@ -47,7 +47,10 @@ typedef struct mi355_sws_desc {
 
 typedef struct mi355_sws_ctx mi355_sws_ctx;   /* descriptor + filter banks resident in HBM */
 
-/* one picture of a batch, device pointers */
+/* one picture of a batch, device pointers.  A source plane whose pointer and stride are multiples of 16 is fetched in aligned 16-byte
+ * pieces: every line must be readable over its whole STRIDE (src_stride[k] bytes, also the last line's — the bytes between the width
+ * and the stride may hold anything; the reference's own buffers are allocated that way, libavutil/frame.c).  Planes with other
+ * pointers or strides are read sample-exactly. */
 typedef struct mi355_sws_frame {
     const uint8_t *src[3];
     int src_stride[3];
