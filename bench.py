@@ -364,15 +364,20 @@ def hevc_bridge_points(lib):
     for name in ("pb_1080p_few_intra", "pb_1080p_ctb64", "pb_480p_ctb64", "pb_ctb64_depth0", "i_ctb64"):
         src = os.path.join(ROOT, "tests", "golden", "hevc_synth_%s.samples" % name)
         pt = {"name": "hevc_bridge_" + name}
-        for key, env in (("bridge", {}), ("reference_c_decoder", {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
+        for key, env in (("bridge", {}), ("bridge_random_access_pictures_on_host", {"MI355_HEVC_BRIDGE_IRAP_ON_HOST": "1"}),
+                         ("reference_c_decoder", {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
+            if key == "bridge_random_access_pictures_on_host" and not name.startswith("pb_1080p"):
+                continue
             e = dict(os.environ)
-            for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN"):
+            for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST"):
                 e.pop(k, None)
             e.update(env)
             r = subprocess.run([exe, src, "-", "20"], capture_output=True, text=True, env=e, timeout=600)
             st = json.loads(r.stdout.strip().splitlines()[-1])
             pt[key] = {k: st[k] for k in ("pictures_output", "pictures_reconstructed_on_device", "reconstruction_launches", "dependency_levels", "pictures_per_s")}
-        pt["note"] = "20 passes over the stream in one process; bit-exactness of this path: tests/test_hevc_bridge_gpu.py (all 20 generated streams)"
+        pt["note"] = ("20 passes over the stream in one process; bit-exactness of this path: tests/test_hevc_bridge_gpu.py (all generated streams); "
+                      "bridge_random_access_pictures_on_host: MI355_HEVC_BRIDGE_IRAP_ON_HOST=1, the all-intra first picture of each pass reconstructed by "
+                      "the reference's functions on the host (filtered on the device, uploaded once)")
         out.append(pt)
     return out
 

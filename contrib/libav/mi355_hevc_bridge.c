@@ -68,7 +68,7 @@ typedef struct IntraRec { mi355_hevc_intra_block b; int level; } IntraRec;
 typedef struct Pending { const int16_t *tmp; Loc src; int sstride, w, h, mx, my, chroma, live; } Pending;
 
 static __thread struct Recon {
-    int init, plain, failed;
+    int init, plain, failed, irap_on_host;
     HEVCContext *s;
     int on;                             /* the open picture is reconstructed on the device */
     int bd, px;
@@ -395,6 +395,11 @@ static void first_use(void)
     if (R.init) return;
     R.init = 1;
     R.plain = getenv("MI355_HEVC_RECON_PLAIN") != NULL;
+    /* a scheduling policy, off by default: random-access pictures (every slice intra) stay with the reference's functions on the host —
+     * intra prediction is a chain of blocks each waiting for its neighbours, nanoseconds apart on a CPU and one launch apart here (a
+     * 1920x1080 picture of 4x4 blocks is ~3700 dependency levels) — and come to the device once, finished, when a later picture
+     * predicts from them (upload_surface); the filter bridge still filters them on the device */
+    R.irap_on_host = getenv("MI355_HEVC_BRIDGE_IRAP_ON_HOST") != NULL;
 }
 void __wrap_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
 {
@@ -458,6 +463,7 @@ int __wrap_ff_hevc_frame_rps(HEVCContext *s)
     R.pictures++;
     if (ret < 0 || R.plain || R.failed || !s->frame || !s->frame->data[0]) return ret;
     if (!mi355_hevc_lf_bridge_active || !mi355_hevc_lf_bridge_active(s)) return ret;
+    if (R.irap_on_host && IS_IRAP(s)) return ret;
     const HEVCSPS *sps = s->ps.sps;
     Surface *u = surface_of_frame(s, s->frame, 1);
     if (!u) { recon_fail("no device memory for a picture"); return ret; }
@@ -493,7 +499,11 @@ static int upload_surface(const HEVCContext *s, Surface *u)
     /* the host frame holds the picture (reconstructed by the reference's functions, or made up by the decoder) */
     for (int k = 0; k < 3; k++)
         if (mi355_memcpy_h2d(u->dev + u->off[k], u->host[k], (size_t)u->linesize[k] * u->rows[k]) != 0) return -1;
-    (void)s;
+    /* it mirrors that frame as the decoder holds it now: later lookups compare the picture's number and sequence */
+    for (int i = 0; i < FF_ARRAY_ELEMS(s->DPB); i++) {
+        const HEVCFrame *f = &s->DPB[i];
+        if (f->frame && f->frame->data[0] == u->host[0]) { u->poc = f->poc; u->seq = f->sequence; }
+    }
     u->valid = 1;
     R.uploads++;
     return 0;
@@ -542,10 +552,10 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     const size_t o_in = o;    o += ((size_t)R.nintra * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
     const size_t o_desc = o;  o += (sizeof(mi355_hevc_intra_picture) + 63) & ~(size_t)63;
     const size_t o_coef = o;  o += (R.ncoef * sizeof(int16_t) + 63) & ~(size_t)63;
-    if (R.h_stage_bytes < o) {
-        free(R.h_stage);
-        R.h_stage = malloc(o);
-        R.h_stage_bytes = R.h_stage ? o : 0;
+    if (R.h_stage_bytes < o) {                      /* pinned: the one copy of a picture's jobs and coefficients runs at the link's rate */
+        if (R.h_stage) mi355_host_free(R.h_stage);
+        R.h_stage = mi355_host_alloc(o + o / 4);
+        R.h_stage_bytes = R.h_stage ? o + o / 4 : 0;
         if (!R.h_stage) return -1;
     }
     if (dev_ensure(&R.d_stage, &R.d_stage_bytes, o) || dev_ensure(&R.d_emu, &R.d_emu_bytes, R.emu_bytes + 64)) return -1;

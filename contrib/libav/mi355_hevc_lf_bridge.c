@@ -51,6 +51,7 @@ static __thread struct {
     mi355_hevc_bs_picture *d_bs_desc;
     const void *bs_ref;                    /* the picture the flags belong to */
     int bs_lists_set, bs_uniform, bs_slice;
+    uint8_t *h_out; size_t h_out_bytes;             /* pinned bounce buffer of the picture coming back */
     int32_t ref_poc[2][16];
     unsigned long bs_pictures;
     mi355_hevc_lf_picture *desc;
@@ -249,6 +250,21 @@ static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const 
     return n;
 }
 
+/* a finished plane comes back through a pinned buffer: the copy over the link runs at the link's rate (into the decoder's pageable
+ * frame it is staged by the runtime in small pieces), the copy into the frame at memory speed */
+static int picture_d2h(uint8_t *dst, const uint8_t *dev, size_t n)
+{
+    if (lf.h_out_bytes < n) {
+        if (lf.h_out) mi355_host_free(lf.h_out);
+        lf.h_out = mi355_host_alloc(n);
+        lf.h_out_bytes = lf.h_out ? n : 0;
+    }
+    if (!lf.h_out) return mi355_memcpy_d2h(dst, dev, n);
+    if (mi355_memcpy_d2h(lf.h_out, dev, n) != 0) return -1;
+    memcpy(dst, lf.h_out, n);
+    return 0;
+}
+
 static int filter_picture(HEVCContext *s)
 {
     const HEVCSPS *sps = s->ps.sps;
@@ -304,7 +320,7 @@ static int filter_picture(HEVCContext *s)
     if (mi355_hevc_deblock_pictures_dev(lf.desc, 1, sps->width, sps->height, sps->bit_depth, lf.stream) != 0) return -2;
     if (!sps->sao_enabled) {
         if (mi355_sync(lf.stream) != 0) return -2;
-        for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], plane[i], sz[i]);
+        for (int i = 0; i < 3; i++) rc |= picture_d2h(s->frame->data[i], plane[i], sz[i]);
         if (rc) return -2;
         lf.pictures++;
         return 0;
@@ -365,8 +381,8 @@ static int filter_picture(HEVCContext *s)
         }
     }
     if (mi355_sync(lf.stream) != 0) return -2;
-    for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->sao_frame->data[i], out[i], sz[i]);
-    if (restore) for (int i = 0; i < 3; i++) rc |= mi355_memcpy_d2h(s->frame->data[i], plane[i], sz[i]);
+    for (int i = 0; i < 3; i++) rc |= picture_d2h(s->sao_frame->data[i], out[i], sz[i]);
+    if (restore) for (int i = 0; i < 3; i++) rc |= picture_d2h(s->frame->data[i], plane[i], sz[i]);
     if (rc) return -2;
     lf.pictures++;
     return 0;

@@ -32,3 +32,17 @@ def test_hevc_bridge_plain_run_is_the_reference_path(tmp_path, emu):
     st = HS.run_bridge("hevc_bridge_emu", name, out, plain=True)
     assert st["pictures_reconstructed_on_device"] == 0 and st["pictures_filtered_on_device"] == 0
     HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", ["pb_8bit", "pb_10bit_weighted", "pb_480p_ctb64"])
+def test_hevc_bridge_random_access_pictures_on_the_host_emulated(tmp_path, emu, name):
+    """MI355_HEVC_BRIDGE_IRAP_ON_HOST=1 (a scheduling policy): the stream's first picture — all intra, a long chain of dependent blocks —
+    is reconstructed by the reference's functions, filtered on the device like every picture, and uploaded ONCE when the next picture
+    predicts from it; everything else as without the policy, the output the reference's"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_emu", name, out, irap_on_host=True)
+    n = HS.MD5[name]["pictures"]
+    assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n - 1 and st["pictures_filtered_on_device"] == n, st
+    assert st["reference_uploads"] == 1, st
+    HS.check_md5(out, name)

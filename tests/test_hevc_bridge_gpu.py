@@ -29,3 +29,15 @@ def test_hevc_bridge_plain_run_gpu(tmp_path, mi355):
     st = HS.run_bridge("hevc_bridge_gpu", "pb_8bit", out, plain=True)
     assert st["pictures_reconstructed_on_device"] == 0 and st["pictures_filtered_on_device"] == 0
     HS.check_md5(out, "pb_8bit")
+
+
+@pytest.mark.parametrize("name", ["pb_8bit", "pb_480p_ctb64", "pb_1080p_few_intra"])
+def test_hevc_bridge_random_access_pictures_on_the_host_gpu(tmp_path, mi355, name):
+    """MI355_HEVC_BRIDGE_IRAP_ON_HOST=1: the all-intra first picture stays with the reference's functions, is filtered on the device and
+    uploaded once when the next picture predicts from it; output identical"""
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_gpu", name, out, irap_on_host=True)
+    n = HS.MD5[name]["pictures"]
+    assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n - 1 and st["pictures_filtered_on_device"] == n, st
+    assert st["reference_uploads"] == 1, st
+    HS.check_md5(out, name)
