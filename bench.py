@@ -242,11 +242,22 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
                 once()
             lib.mi355_event_record(e1, None)
             ms = lib.mi355_event_elapsed_ms(e0, e1) / 3
+            # one more step with an event after every pass: where the step's time goes
+            ev = [lib.mi355_event_create() for _ in range(4)]
+            lib.mi355_event_record(ev[0], None)
+            assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
+            lib.mi355_event_record(ev[1], None)
+            assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
+            lib.mi355_event_record(ev[2], None)
+            assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
+            lib.mi355_event_record(ev[3], None)
+            lib.mi355_sync(None)
+            passes = {k: lib.mi355_event_elapsed_ms(ev[i], ev[i + 1]) for i, k in enumerate(("recon_inter", "recon_intra", "deblock"))}
         finally:
             dev.free()
         v = F * mbw * mbh / (ms * 1e-3)
         pts.append({"name": name, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F,
-                    "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "note": note})
+                    "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "pass_ms": passes, "note": note})
 
     base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
     if tiled:

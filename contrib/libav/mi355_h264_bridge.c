@@ -998,6 +998,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         f->mb = s->mb[p]; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef[p];
         f->slices = s->slices[p]; f->nslices = b->nslices;
         f->max_intra_level = maxl; f->intra_list = s->ilist; f->intra_level_start = s->istart; f->max_level_width = lw;
+        f->flags = maxl > 0 && s->istart[maxl] == b->nmb_pic ? MI355_FRAME_NO_INTER : 0;      /* an I picture: the inter pass has nothing to do */
         s->desc[np + p] = *f;                        /* the loop filter's view */
         s->desc[np + p].mb = s->mbd[p];
     }

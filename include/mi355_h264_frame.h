@@ -184,8 +184,12 @@ typedef struct mi355_h264_frame {
     int32_t surface_layout;           /* MI355_SURFACE_LINEAR (0): dst / recon / ref are planes with byte strides, as above.
                                          MI355_SURFACE_TILED (1): macroblock-tiled surfaces, the layout a decoded picture buffer
                                          keeps while it stays in HBM (see below); frame pictures only */
-    int32_t reserved0;
+    int32_t flags;                    /* MI355_FRAME_NO_INTER (1): the picture holds no inter macroblock (an I picture): a wave of the inter pass
+                                         leaves after reading this word instead of fetching its record and coefficients to find that out
+                                         (960 bytes per macroblock; the launch of the picture's waves itself stays: 0.87 ms per 512 1080p
+                                         pictures either way).  A hint: 0 is always right */
 } mi355_h264_frame;
+#define MI355_FRAME_NO_INTER 1
 
 /* Macroblock-tiled surfaces (surface_layout == MI355_SURFACE_TILED).  What the reference keeps in an AVFrame with a line
  * stride (h264_mb.c:239-314 fetches a 21 x 21 window as 21 row pieces of 21 different cache lines, h264_mb_template.c:85-91

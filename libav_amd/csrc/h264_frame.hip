@@ -603,7 +603,7 @@ template <bool SPARSE, bool TILED>
 __device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame &frd, int mb_x, int mb_y)
 {
     const FrameHot fr = frame_hot(frd);
-    if (mb_x >= fr.mb_width || mb_y >= fr.mb_height) return;
+    if (mb_x >= fr.mb_width || mb_y >= fr.mb_height || (uniform(frd.flags) & MI355_FRAME_NO_INTER)) return;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     RPROF(0);
     ResidLane rl;

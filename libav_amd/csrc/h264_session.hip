@@ -288,6 +288,7 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     fr->intra_list = reinterpret_cast<const uint32_t *>(d + l.ilist);
     fr->intra_level_start = reinterpret_cast<const int32_t *>(d + l.istart);
     fr->max_level_width = width;
+    fr->flags = levels > 0 && istart[levels] == s->nmb_pic ? MI355_FRAME_NO_INTER : 0;      /* an I picture: the inter pass has nothing to do */
     if (s->group) {
         /* grouped: the picture waits for mi355_h264_group_flush(), which launches it together with the other sessions' */
         s->pend_levels = levels;

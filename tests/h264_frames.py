@@ -38,7 +38,7 @@ class Frame(C.Structure):
                 ("slices", C.c_void_p), ("nslices", C.c_int32), ("max_intra_level", C.c_int32),
                 ("intra_list", C.c_void_p), ("intra_level_start", C.c_void_p),
                 ("max_level_width", C.c_int32), ("reserved", C.c_int32),     # reserved = field_picture
-                ("surface_layout", C.c_int32), ("reserved0", C.c_int32)]
+                ("surface_layout", C.c_int32), ("flags", C.c_int32)]
 
 
 assert C.sizeof(Frame) == 920
@@ -437,6 +437,7 @@ def host_frames(fs, recon, dst):
         fr.intra_list = fs.intra_list[f].ctypes.data
         fr.intra_level_start = fs.intra_start[f].ctypes.data
         fr.max_level_width = fs.max_level_width
+        fr.flags = 1 if int(fs.intra_start[f][-1]) == fs.mb_w * fs.mb_h else 0       # MI355_FRAME_NO_INTER: every macroblock is on some intra level
     return arr, keep
 
 
@@ -545,6 +546,7 @@ class DeviceFrames:
             fr.intra_level_start = istart[g]
             fr.max_level_width = fs.max_level_width
             fr.surface_layout = 1 if tiled else 0
+            fr.flags = 1 if int(fs.intra_start[g][-1]) == fs.mb_w * fs.mb_h else 0    # MI355_FRAME_NO_INTER
         self.host_desc = arr
         self.d_desc = self.alloc(C.sizeof(arr))
         self.lib.mi355_memcpy_h2d(self.d_desc, C.addressof(arr), C.sizeof(arr))
