@@ -286,52 +286,39 @@ __device__ __forceinline__ int hevc_tc_calc(int qp, int bs, int tc_offset)
     return k_hevc_tctable[clip3(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)];
 }
 
+/* A wave looks at 64 consecutive segments of the grid (one per lane), keeps those that have something to filter (bS != 0; chroma: bS 2)
+ * and filters them eight at a time, eight lanes per segment: on a picture of 32x32 blocks a quarter of the 8x8 grid's edges carry a
+ * strength, and a wave that took eight consecutive segments as they came ran a quarter full (1.55 M waves per 64 2160p pictures, most
+ * of their lanes idle: the launch rate of the waves bounded the pass). */
 template <int DIR>      /* 0: vertical edges, 1: horizontal edges */
 __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_lf_picture *pics, int luma_cols, int luma_rows, int chroma_cols,
                                                               int chroma_rows, int luma_waves, int waves_per_pic, int bd)
 {
+    __shared__ uint8_t s_act[64];
     const int lane = lane_id(), slot = lane >> 3;
     const int pic = (int)blockIdx.x / waves_per_pic, w = (int)blockIdx.x - pic * waves_per_pic;
     const mi355_hevc_lf_picture &p = pics[pic];
     const LfPic P{ p };
     const int ps = bd > 8, W = p.width, H = p.height;
-    if (w < luma_waves) {
-        /* ---- luma: segment (gx, gy) of the 8x8 grid */
-        const int seg = w * 8 + slot, gy = seg / luma_cols, gx = seg - gy * luma_cols;
-        const int x = 8 * gx, y = 8 * gy;
-        bool on = gy < luma_rows && x < W && y < H && (DIR ? y >= 8 : x >= 8);
-        int bs0 = 0, bs1 = 0;
-        if (on) {
-            if (DIR) { bs0 = mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2]; bs1 = mi355_global_v(p.horizontal_bs)[(x + 4 + y * p.bs_width) >> 2]; }
-            else { bs0 = mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width]; bs1 = mi355_global_v(p.vertical_bs)[(x >> 3) + ((y + 4) >> 2) * p.bs_width]; }
-            on = (bs0 | bs1) != 0;
-        }
-        int beta = 0, tc[2] = { 0, 0 };
-        uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
-        if (on) {
-            const mi355_hevc_db_params d = P.db(x, y);
-            const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
-            beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
-            tc[0] = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
-            tc[1] = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
-            if (p.pcmf) {
-                if (DIR) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 4, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 4, y); }
-                else { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 4); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 4); }
-            }
-        }
-        const int st = p.linesize[0] >> ps;
-        uint8_t *pix = mi355_global_v(p.data[0]) + (on ? (ptrdiff_t)y * p.linesize[0] + ((ptrdiff_t)x << ps) : 0);
-        hevc_lf_luma_wave(pix, DIR ? st : 1, DIR ? 1 : st, beta, tc, no_p, no_q, bd, true, on);
-        return;
-    }
-    /* ---- chroma: plane c, segment on the 16-luma-sample grid; horizontal edges: the reference's pairs start at
-     * x = 8 (mod 16), i.e. at -8 (:469-484), a half outside the picture has bS 0 */
-    const int seg = (w - luma_waves) * 8 + slot, per_plane = chroma_cols * chroma_rows;
-    const int c = seg >= per_plane ? 2 : 1, s2 = seg - (c - 1) * per_plane, gy = s2 / chroma_cols, gx = s2 - gy * chroma_cols;
-    const int x = DIR ? 16 * gx - 8 : 16 * gx, y = 16 * gy;
-    bool on = seg < 2 * per_plane && y < H && (DIR ? (y >= 16 && x < W) : (x >= 16 && x < W));
-    int bs0 = 0, bs1 = 0;
-    if (on) {
+    const bool luma = w < luma_waves;
+    const int per_plane = chroma_cols * chroma_rows;
+    /* strengths of segment `seg` (luma: the 8x8 grid; chroma: plane c on the 16-luma-sample grid; horizontal chroma edges: the reference's
+     * pairs start at x = 8 (mod 16), i.e. at -8 (:469-484), a half outside the picture has bS 0) -> does it filter anything */
+    auto luma_seg = [&](int seg, int &x, int &y, int &bs0, int &bs1) {
+        const int gy = seg / luma_cols, gx = seg - gy * luma_cols;
+        x = 8 * gx; y = 8 * gy;
+        bs0 = bs1 = 0;
+        if (!(gy < luma_rows && x < W && y < H && (DIR ? y >= 8 : x >= 8))) return false;
+        if (DIR) { bs0 = mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2]; bs1 = mi355_global_v(p.horizontal_bs)[(x + 4 + y * p.bs_width) >> 2]; }
+        else { bs0 = mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width]; bs1 = mi355_global_v(p.vertical_bs)[(x >> 3) + ((y + 4) >> 2) * p.bs_width]; }
+        return (bs0 | bs1) != 0;
+    };
+    auto chroma_seg = [&](int seg, int &c, int &x, int &y, int &bs0, int &bs1) {
+        c = seg >= per_plane ? 2 : 1;
+        const int s2 = seg - (c - 1) * per_plane, gy = s2 / chroma_cols, gx = s2 - gy * chroma_cols;
+        x = DIR ? 16 * gx - 8 : 16 * gx; y = 16 * gy;
+        bs0 = bs1 = 0;
+        if (!(seg < 2 * per_plane && y < H && (DIR ? (y >= 16 && x < W) : (x >= 16 && x < W)))) return false;
         if (DIR) {
             bs0 = x < 0 ? 0 : mi355_global_v(p.horizontal_bs)[(x + y * p.bs_width) >> 2];
             bs1 = x + 8 >= W ? 0 : mi355_global_v(p.horizontal_bs)[(x + 8 + y * p.bs_width) >> 2];
@@ -339,25 +326,64 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
             bs0 = mi355_global_v(p.vertical_bs)[(x >> 3) + (y >> 2) * p.bs_width];
             bs1 = mi355_global_v(p.vertical_bs)[(x >> 3) + ((y + 8) >> 2) * p.bs_width];
         }
-        on = bs0 == 2 || bs1 == 2;
+        return bs0 == 2 || bs1 == 2;
+    };
+    /* ---- the wave's 64 candidates, the live ones listed in LDS in lane order */
+    const int seg_base = (luma ? w : w - luma_waves) * 64;
+    bool cand;
+    {
+        int c, x, y, b0, b1;
+        cand = luma ? luma_seg(seg_base + lane, x, y, b0, b1) : chroma_seg(seg_base + lane, c, x, y, b0, b1);
     }
-    int tc[2] = { 0, 0 };
-    uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
-    if (on) {
-        if (DIR) {
-            if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, c, P.db(x, y).tc_offset);
-            if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, c, P.db(x + 8, y).tc_offset);
-            if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 8, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 8, y); }
+    const unsigned long long live = __ballot(cand);
+    const int count = __popcll(live);
+    if (!count) return;
+    if (cand) s_act[__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    __syncthreads();
+    for (int it = 0; it * 8 < count; it++) {
+        const int k = it * 8 + slot;
+        const int seg = seg_base + (k < count ? s_act[k] : s_act[0]);
+        if (luma) {
+            int x, y, bs0, bs1;
+            const bool on = luma_seg(seg, x, y, bs0, bs1) && k < count;
+            int beta = 0, tc[2] = { 0, 0 };
+            uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+            if (on) {
+                const mi355_hevc_db_params d = P.db(x, y);
+                const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
+                beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
+                tc[0] = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
+                tc[1] = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
+                if (p.pcmf) {
+                    if (DIR) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 4, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 4, y); }
+                    else { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 4); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 4); }
+                }
+            }
+            const int st = p.linesize[0] >> ps;
+            uint8_t *pix = mi355_global_v(p.data[0]) + (on ? (ptrdiff_t)y * p.linesize[0] + ((ptrdiff_t)x << ps) : 0);
+            hevc_lf_luma_wave(pix, DIR ? st : 1, DIR ? 1 : st, beta, tc, no_p, no_q, bd, true, on);
         } else {
-            const int tco = P.db(x, y).tc_offset;
-            if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, c, tco);
-            if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, c, tco);
-            if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 8); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 8); }
+            int c, x, y, bs0, bs1;
+            const bool on = chroma_seg(seg, c, x, y, bs0, bs1) && k < count;
+            int tc[2] = { 0, 0 };
+            uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+            if (on) {
+                if (DIR) {
+                    if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, c, P.db(x, y).tc_offset);
+                    if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, c, P.db(x + 8, y).tc_offset);
+                    if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 8, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 8, y); }
+                } else {
+                    const int tco = P.db(x, y).tc_offset;
+                    if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, c, tco);
+                    if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, c, tco);
+                    if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 8); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 8); }
+                }
+            }
+            const int st = p.linesize[c] >> ps;
+            uint8_t *pix = mi355_global_v(p.data[c]) + (on ? (ptrdiff_t)(y / 2) * p.linesize[c] + (ptrdiff_t)(x / 2) * (1 << ps) : 0);
+            hevc_lf_chroma_wave(pix, DIR ? st : 1, DIR ? 1 : st, tc, no_p, no_q, bd, true, on);
         }
     }
-    const int st = p.linesize[c] >> ps;
-    uint8_t *pix = mi355_global_v(p.data[c]) + (on ? (ptrdiff_t)(y / 2) * p.linesize[c] + (ptrdiff_t)(x / 2) * (1 << ps) : 0);
-    hevc_lf_chroma_wave(pix, DIR ? st : 1, DIR ? 1 : st, tc, no_p, no_q, bd, true, on);
 }
 
 /* ---- boundary strengths of whole pictures: boundary_strength (hevc_filter.c:507-583) for every cell side on the 8x8 grid,
@@ -820,7 +846,7 @@ extern "C" int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pi
     for (int dir = 0; dir < 2; dir++) {
         /* horizontal chroma segments start at x = -8: one more column may be needed */
         const int cc = dir ? (max_width + 8 + 15) / 16 : (max_width + 15) / 16, cr = (max_height + 15) / 16;
-        const int lw = (lc * lr + 7) / 8, cw = (2 * cc * cr + 7) / 8;
+        const int lw = (lc * lr + 63) / 64, cw = (2 * cc * cr + 63) / 64;      /* a wave takes 64 candidate segments */
         const dim3 grid((unsigned)((lw + cw) * npics));
         if (dir == 0) hipLaunchKernelGGL(k_hevc_deblock_pictures<0>, grid, dim3(64), 0, (hipStream_t)stream, d_pics, lc, lr, cc, cr, lw, lw + cw, bit_depth);
         else hipLaunchKernelGGL(k_hevc_deblock_pictures<1>, grid, dim3(64), 0, (hipStream_t)stream, d_pics, lc, lr, cc, cr, lw, lw + cw, bit_depth);
