@@ -318,6 +318,11 @@ struct HevcMcToI16 {          /* the reference's destination: int16, `ds` elemen
     __device__ __forceinline__ void put2(int r, int x, uint32_t v) const { hevc_mc_st2(out + (ptrdiff_t)r * ds + x, v, amode); }
 };
 constexpr int HEVC_MC_KEEP_PITCH = 32;
+/* two-reference predictions (k_hevc_mcpred_batch): tiles of HEVC_MC_BI_TILE_H rows use HEVC_MC_BI_ROWS rows of win / tmp; the kept tile of the
+ * first reference sits in tmp behind them */
+constexpr int HEVC_MC_BI_TILE_H = 16, HEVC_MC_BI_ROWS = HEVC_MC_BI_TILE_H + 7;
+static_assert((HEVC_MC_BI_ROWS * HEVC_MC_PITCH) % 4 == 0 && HEVC_MC_BI_ROWS * HEVC_MC_PITCH + HEVC_MC_BI_TILE_H * HEVC_MC_KEEP_PITCH <= HEVC_MC_ROWS * HEVC_MC_PITCH,
+              "the kept tile fits behind the rows of a 16-row tile, 8-byte aligned");
 struct HevcMcToTile {         /* kept in LDS for a second prediction to combine with */
     int16_t *t;
     __device__ __forceinline__ void put4(int r, int x0, uint32_t lo, uint32_t hi, int n) const
