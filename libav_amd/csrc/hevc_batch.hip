@@ -137,7 +137,7 @@ __device__ inline void hevc_mcpred_taps(const mi355_hevc_mcpred_job &j, int bd, 
     const int amode = bd > 8 ? ((al & 3) == 0 ? 4 : 2) : ((al & 1) == 0 ? 2 : 1);
     const HevcPredParams pp{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
     /* two references: tiles of 16 rows, so that windows, first-pass results (23 rows each) and the kept tile share the scratch */
-    constexpr int TH = two ? HEVC_MC_BI_TILE_H : HEVC_MC_TILE;
+    constexpr int TH = two ? HEVC_MC_BI_TILE_H : HEVC_MC_TILE_H;
     for (int ty = 0; ty < j.height; ty += TH)
     for (int tx = 0; tx < j.width; tx += HEVC_MC_TILE) {
         const int tw = j.width - tx < HEVC_MC_TILE ? j.width - tx : HEVC_MC_TILE, th = j.height - ty < TH ? j.height - ty : TH;

@@ -232,7 +232,11 @@ __device__ __forceinline__ void fir4(const uint32_t *d, const uint32_t *t, int *
  * row-major layout and every result leaves as a dword (two int16) or wider. */
 constexpr int HEVC_MC_TILE = 32;
 constexpr int HEVC_MC_PITCH = 44;      /* values per LDS row: >= 32 + 7 + the 4 values a segment may read past its last tap */
-constexpr int HEVC_MC_ROWS = 40;
+#ifndef MI355_HEVC_MC_TILE_H
+#define MI355_HEVC_MC_TILE_H 32
+#endif
+constexpr int HEVC_MC_TILE_H = MI355_HEVC_MC_TILE_H;      /* rows of a tile (32 wide) */
+constexpr int HEVC_MC_ROWS = HEVC_MC_TILE_H + 8;
 struct __attribute__((aligned(16))) HevcMcScratch {
     uint16_t win[HEVC_MC_ROWS * HEVC_MC_PITCH];      /* staged samples */
     int16_t tmp[HEVC_MC_ROWS * HEVC_MC_PITCH];       /* first-pass results of the 2-D case */
@@ -320,7 +324,7 @@ struct HevcMcToI16 {          /* the reference's destination: int16, `ds` elemen
 constexpr int HEVC_MC_KEEP_PITCH = 32;
 /* two-reference predictions (k_hevc_mcpred_batch): tiles of HEVC_MC_BI_TILE_H rows use HEVC_MC_BI_ROWS rows of win / tmp; the kept tile of the
  * first reference sits in tmp behind them */
-constexpr int HEVC_MC_BI_TILE_H = 16, HEVC_MC_BI_ROWS = HEVC_MC_BI_TILE_H + 7;
+constexpr int HEVC_MC_BI_TILE_H = HEVC_MC_TILE_H / 2, HEVC_MC_BI_ROWS = HEVC_MC_BI_TILE_H + 7;
 static_assert((HEVC_MC_BI_ROWS * HEVC_MC_PITCH) % 4 == 0 && HEVC_MC_BI_ROWS * HEVC_MC_PITCH + HEVC_MC_BI_TILE_H * HEVC_MC_KEEP_PITCH <= HEVC_MC_ROWS * HEVC_MC_PITCH,
               "the kept tile fits behind the rows of a 16-row tile, 8-byte aligned");
 struct HevcMcToTile {         /* kept in LDS for a second prediction to combine with */
@@ -426,9 +430,9 @@ __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, in
     const int bx = mx ? before : 0, by = my ? before : 0;
     const int amode = hevc_mc_align(dst, ds);
     const ptrdiff_t sb = (ptrdiff_t)ss * px;
-    for (int ty = 0; ty < height; ty += HEVC_MC_TILE)
+    for (int ty = 0; ty < height; ty += HEVC_MC_TILE_H)
     for (int tx = 0; tx < width; tx += HEVC_MC_TILE) {
-        const int tw = width - tx < HEVC_MC_TILE ? width - tx : HEVC_MC_TILE, th_ = height - ty < HEVC_MC_TILE ? height - ty : HEVC_MC_TILE;
+        const int tw = width - tx < HEVC_MC_TILE ? width - tx : HEVC_MC_TILE, th_ = height - ty < HEVC_MC_TILE_H ? height - ty : HEVC_MC_TILE_H;
         const HevcMcToI16 sink{ dst + (ptrdiff_t)ty * ds + tx, ds, amode };
         hevc_mc_tile<TAPS>(sink, src + (ptrdiff_t)(ty - by) * sb + (ptrdiff_t)(tx - bx) * px, sb, tw, th_, mx, my, bd, s);
     }
