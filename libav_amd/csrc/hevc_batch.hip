@@ -506,6 +506,24 @@ __device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src
 /* eight neighbouring samples per lane: whole 16-byte (8-byte at 8 bit) pieces of a row */
 typedef uint32_t mi355_sao_u32x4a2 __attribute__((vector_size(16), aligned(2)));
 typedef uint32_t mi355_sao_u32x2a1 __attribute__((vector_size(8), aligned(1)));
+struct SaoRaw { uint32_t q[4]; };      /* eight samples as loaded: 16 bytes (above 8 bit) or 8 */
+__device__ __forceinline__ SaoRaw sao_raw(const uint8_t *p, bool wide)
+{
+    SaoRaw r;
+    if (wide) { const mi355_sao_u32x4a2 q = *reinterpret_cast<const mi355_sao_u32x4a2 *>(p); r.q[0] = q[0]; r.q[1] = q[1]; r.q[2] = q[2]; r.q[3] = q[3]; }
+    else { const mi355_sao_u32x2a1 q = *reinterpret_cast<const mi355_sao_u32x2a1 *>(p); r.q[0] = q[0]; r.q[1] = q[1]; r.q[2] = r.q[3] = 0; }
+    return r;
+}
+__device__ __forceinline__ void sao_unpack(const SaoRaw &r, bool wide, int v[8])
+{
+    if (wide) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[2 * k] = (int)(r.q[k] & 0xFFFFu); v[2 * k + 1] = (int)(r.q[k] >> 16); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (int)((r.q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+    }
+}
 __device__ __forceinline__ void sao_ld8(const uint8_t *p, bool wide, int v[8])
 {
     if (wide) {
@@ -533,27 +551,48 @@ __device__ inline void sao_region_fast(uint8_t *dst, const uint8_t *src, int str
     const int px = wide ? 2 : 1, per = W >> 3, inv = mi355_inv20(per), shift = bd - 5;
     const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
     const ptrdiff_t da = (ptrdiff_t)dx0 * px + (ptrdiff_t)dy0 * stride;
-    for (int i = lane; i < per * H; i += 64) {
-        const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
-        const ptrdiff_t o = (ptrdiff_t)y * stride + (ptrdiff_t)x * px;
-        int c[8], v[8];
-        sao_ld8(src + o, wide, c);
-        if (!edge) {
+    /* two steps of a lane at a time: the loads of both (centre and, for the edge filter, its two neighbours) are issued before
+     * the first result is stored — source and destination may be one picture as far as the compiler knows, so a store
+     * ends the loads it will move ahead of it, and a 64x64 region was eight memory round trips one after the other */
+#ifndef MI355_SAO_U
+#define MI355_SAO_U 2
+#endif
+    constexpr int U = MI355_SAO_U;
+    const int n = per * H;
+    for (int i0 = lane; i0 < n; i0 += 64 * U) {
+        SaoRaw rc[U], ra[U], rb[U];
+        ptrdiff_t o[U];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[c[k] >> shift], bd);
-        } else {
-            int a[8], b[8];
-            sao_ld8(src + o + da, wide, a);
-            sao_ld8(src + o - da, wide, b);
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[clip3(c[k] - a[k], -1, 1) + clip3(c[k] - b[k], -1, 1) + 2], bd);
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + 64 * u < n ? i0 + 64 * u : n - 1;       /* a step past the end repeats the last one and stores nothing */
+            const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
+            o[u] = (ptrdiff_t)y * stride + (ptrdiff_t)x * px;
+            rc[u] = sao_raw(src + o[u], wide);
+            if (edge) { ra[u] = sao_raw(src + o[u] + da, wide); rb[u] = sao_raw(src + o[u] - da, wide); }
         }
-        if (wide) {
-            *reinterpret_cast<mi355_sao_u32x4a2 *>(dst + o) = mi355_sao_u32x4a2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
-                                                                               (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16) };
-        } else {
-            *reinterpret_cast<mi355_sao_u32x2a1 *>(dst + o) = mi355_sao_u32x2a1{ (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24),
-                                                                               (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24) };
+        MI355_ISSUE_FENCE();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i0 + 64 * u >= n) continue;
+            int c[8], v[8];
+            sao_unpack(rc[u], wide, c);
+            if (!edge) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[c[k] >> shift], bd);
+            } else {
+                int a[8], b[8];
+                sao_unpack(ra[u], wide, a);
+                sao_unpack(rb[u], wide, b);
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[clip3(c[k] - a[k], -1, 1) + clip3(c[k] - b[k], -1, 1) + 2], bd);
+            }
+            if (wide) {
+                *reinterpret_cast<mi355_sao_u32x4a2 *>(dst + o[u]) = mi355_sao_u32x4a2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                                                                                      (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16) };
+            } else {
+                *reinterpret_cast<mi355_sao_u32x2a1 *>(dst + o[u]) = mi355_sao_u32x2a1{ (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24),
+                                                                                      (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24) };
+            }
         }
     }
     __syncthreads();
