@@ -25,8 +25,14 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
     j.coeffs = mi355_global_v(j.coeffs); j.dst = mi355_global_v(j.dst);
     const int size = 1 << j.log2_size, cnt = size * size;
     int16_t *c = s.c[half];
-    /* coefficients -> LDS, two per lane and access */
-    if (on) for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(c)[i] = reinterpret_cast<const uint32_t *>(j.coeffs)[i];
+    /* coefficients -> LDS: eight per lane and access where the block allows it (16-byte aligned, 8x8 and larger), two otherwise */
+    if (on) {
+        if (cnt >= 64 && (reinterpret_cast<uintptr_t>(j.coeffs) & 15) == 0) {
+            for (int i = hl; i < cnt / 8; i += 32) reinterpret_cast<uint4 *>(c)[i] = reinterpret_cast<const uint4 *>(j.coeffs)[i];
+        } else {
+            for (int i = hl; i < cnt / 2; i += 32) reinterpret_cast<uint32_t *>(c)[i] = reinterpret_cast<const uint32_t *>(j.coeffs)[i];
+        }
+    }
     __syncthreads();
     /* every lane walks through every kind's barriers; `on && kind` selects who works */
     {
@@ -59,6 +65,17 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
     const int lhw = j.log2_size - 1, hw = 1 << lhw, maxv = (1 << bd) - 1;
     const uint32_t keep = j.kind == MI355_HEVC_TU_PCM ? 0u : 0xFFFFFFFFu;
     const uint32_t *cw = reinterpret_cast<const uint32_t *>(c);
+    if (bd > 8 && size >= 8 && ((reinterpret_cast<uintptr_t>(j.dst) | (uintptr_t)j.dst_stride) & 7) == 0) {
+        /* four samples per lane and step (8 bytes each way) */
+        const int lqw = j.log2_size - 2, qw = 1 << lqw;
+        for (int i = hl; i < cnt / 4; i += 32) {
+            const int y = i >> lqw, xq = i & (qw - 1);
+            uint2 *p = reinterpret_cast<uint2 *>(j.dst + (size_t)y * j.dst_stride) + xq;
+            const uint2 v = *p, r = *reinterpret_cast<const uint2 *>(cw + 2 * i);
+            *p = make_uint2(pk_clip_max(pk_adds(v.x & keep, r.x), maxv), pk_clip_max(pk_adds(v.y & keep, r.y), maxv));
+        }
+        return;
+    }
     for (int i = hl; i < cnt / 2; i += 32) {
         const int y = i >> lhw, xp = i & (hw - 1);
         uint8_t *row = j.dst + (size_t)y * j.dst_stride;
@@ -153,9 +170,9 @@ __device__ inline void hevc_mcpred_taps(const mi355_hevc_mcpred_job &j, int bd, 
 __global__ void __launch_bounds__(64) k_hevc_mcpred_batch(const mi355_hevc_mcpred_job *jobs, int n, int bd)
 {
     __shared__ HevcMcScratch tmp;
-    /* the kept tile of a two-reference prediction lives behind the rows a 16-row tile uses of `tmp` (below): 7 KB of LDS per wave
-     * instead of 9, 23 waves per CU instead of 18 — the kernel's time follows its occupancy (1.61 -> 1.37 ms on the one-reference chain) */
-    int16_t *const keep = tmp.tmp + HEVC_MC_BI_ROWS * HEVC_MC_PITCH;
+    /* the kept tile of a two-reference prediction lives behind the rows a 16-row tile uses of `tmp` (below): 6.4 KB of LDS per wave
+     * instead of 9, 25 waves per CU instead of 18 — the kernel's time follows its occupancy (1.61 -> 1.37 ms on the one-reference chain) */
+    int16_t *const keep = tmp.tmp + HEVC_MC_BI_ROWS * HEVC_MC_TPITCH;
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_mcpred_job j = jobs[blockIdx.x];
     switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {

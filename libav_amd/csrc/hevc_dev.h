@@ -121,8 +121,8 @@ template <int S, int END> struct Idct1D<2, S, END> {
     }
 };
 
-struct IdctScratch {
-    int16_t c[2][32 * 32];      /* one block per half-wave */
+struct __attribute__((aligned(16))) IdctScratch {
+    int16_t c[2][32 * 32];      /* one block per half-wave (filled and read back 16 / 8 bytes per lane) */
 };
 
 /* In-place 2-D inverse DCT of c (HxH, row-major) by ONE HALF-WAVE (32 lanes; `hl` = lane within the half,
@@ -232,6 +232,8 @@ __device__ __forceinline__ void fir4(const uint32_t *d, const uint32_t *t, int *
  * row-major layout and every result leaves as a dword (two int16) or wider. */
 constexpr int HEVC_MC_TILE = 32;
 constexpr int HEVC_MC_PITCH = 44;      /* values per LDS row: >= 32 + 7 + the 4 values a segment may read past its last tap */
+constexpr int HEVC_MC_TPITCH = 36;     /* ... of the first pass's results: 32 columns (+ 4: rows start 8 bytes apart, 18 dwords: no two of the vertical
+                                          pass's sixteen column pairs x groups of rows share a bank pattern) — 6.4 KB of scratch per wave instead of 7 */
 #ifndef MI355_HEVC_MC_TILE_H
 #define MI355_HEVC_MC_TILE_H 32
 #endif
@@ -239,7 +241,7 @@ constexpr int HEVC_MC_TILE_H = MI355_HEVC_MC_TILE_H;      /* rows of a tile (32 
 constexpr int HEVC_MC_ROWS = HEVC_MC_TILE_H + 8;
 struct __attribute__((aligned(16))) HevcMcScratch {
     uint16_t win[HEVC_MC_ROWS * HEVC_MC_PITCH];      /* staged samples */
-    int16_t tmp[HEVC_MC_ROWS * HEVC_MC_PITCH];       /* first-pass results of the 2-D case */
+    int16_t tmp[HEVC_MC_ROWS * HEVC_MC_TPITCH];      /* first-pass results of the 2-D case */
 };
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 /* alignment class of the int16 destination: 8, 4 or 2 bytes for every row start */
@@ -325,7 +327,7 @@ constexpr int HEVC_MC_KEEP_PITCH = 32;
 /* two-reference predictions (k_hevc_mcpred_batch): tiles of HEVC_MC_BI_TILE_H rows use HEVC_MC_BI_ROWS rows of win / tmp; the kept tile of the
  * first reference sits in tmp behind them */
 constexpr int HEVC_MC_BI_TILE_H = HEVC_MC_TILE_H / 2, HEVC_MC_BI_ROWS = HEVC_MC_BI_TILE_H + 7;
-static_assert((HEVC_MC_BI_ROWS * HEVC_MC_PITCH) % 4 == 0 && HEVC_MC_BI_ROWS * HEVC_MC_PITCH + HEVC_MC_BI_TILE_H * HEVC_MC_KEEP_PITCH <= HEVC_MC_ROWS * HEVC_MC_PITCH,
+static_assert((HEVC_MC_BI_ROWS * HEVC_MC_TPITCH) % 4 == 0 && HEVC_MC_BI_ROWS * HEVC_MC_TPITCH + HEVC_MC_BI_TILE_H * HEVC_MC_KEEP_PITCH <= HEVC_MC_ROWS * HEVC_MC_TPITCH,
               "the kept tile fits behind the rows of a 16-row tile, 8-byte aligned");
 struct HevcMcToTile {         /* kept in LDS for a second prediction to combine with */
     int16_t *t;
@@ -340,19 +342,19 @@ struct HevcMcToTile {         /* kept in LDS for a second prediction to combine 
 /* vertical pass of a tile from row-major 16-bit lines (HEVC_MC_PITCH values apart): a lane owns the column pair c2 and R output
  * rows; it builds the (row, row + 1) dwords of each column with one byte-permute per pair and feeds the dot products */
 template <int TAPS, int R, class Sink>
-__device__ __forceinline__ void hevc_mc_vpass(const Sink &sink, const uint32_t *lines, const uint32_t *tv, int cp, int th_, int vshift, int lane)
-{
+__device__ __forceinline__ void hevc_mc_vpass(const Sink &sink, const uint32_t *lines, int pitch2, const uint32_t *tv, int cp, int th_, int vshift, int lane)
+{   /* pitch2: dwords per line (HEVC_MC_PITCH / 2 for staged samples, HEVC_MC_TPITCH / 2 for first-pass results) */
     const int cinv = mi355_inv20(cp), groups = (th_ + R - 1) / R;
     for (int i = lane; i < cp * groups; i += 64) {
         const int q = mi355_div20(i, cinv), c2 = i - q * cp, y0 = R * q;
-        const uint32_t *d = lines + y0 * (HEVC_MC_PITCH / 2) + c2;
+        const uint32_t *d = lines + y0 * pitch2 + c2;
         int a0[R], a1[R];
 #pragma unroll
         for (int y = 0; y < R; y++) a0[y] = a1[y] = 0;
         uint32_t prev = d[0];
 #pragma unroll
         for (int r = 0; r < R + TAPS - 2; r++) {
-            const uint32_t cur = d[(r + 1) * (HEVC_MC_PITCH / 2)];
+            const uint32_t cur = d[(r + 1) * pitch2];
             const uint32_t p0 = mi355_pair_lo(prev, cur), p1 = mi355_pair_hi(prev, cur);
             prev = cur;
 #pragma unroll
@@ -403,7 +405,7 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
             int o[4];
             fir4<TAPS>(dd, th, o);
             const uint32_t lo = pack16(o[0] >> (bd - 8), o[1] >> (bd - 8)), hi = pack16(o[2] >> (bd - 8), o[3] >> (bd - 8));
-            if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_PITCH + x0]) = make_uint2(lo, hi);
+            if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_TPITCH + x0]) = make_uint2(lo, hi);
             else sink.put4(r, x0, lo, hi, tw - x0);
         }
         if (my) __syncthreads();
@@ -415,9 +417,10 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
         const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
         const int vshift = mx ? 6 : bd - 8;
         const int cp = tw >> 1;
-        if (cp * ((th_ + 7) >> 3) > 32) hevc_mc_vpass<TAPS, 8>(sink, lines, tv, cp, th_, vshift, lane);
-        else if (cp * ((th_ + 3) >> 2) > 32) hevc_mc_vpass<TAPS, 4>(sink, lines, tv, cp, th_, vshift, lane);
-        else hevc_mc_vpass<TAPS, 2>(sink, lines, tv, cp, th_, vshift, lane);
+        const int pitch2 = (mx ? HEVC_MC_TPITCH : HEVC_MC_PITCH) / 2;
+        if (cp * ((th_ + 7) >> 3) > 32) hevc_mc_vpass<TAPS, 8>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
+        else if (cp * ((th_ + 3) >> 2) > 32) hevc_mc_vpass<TAPS, 4>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
+        else hevc_mc_vpass<TAPS, 2>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
     }
     __syncthreads();
 }
