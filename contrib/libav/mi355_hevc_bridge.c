@@ -62,6 +62,8 @@ typedef struct EmuRec { Loc src; size_t dst_off; int src_stride, bw, bh, sx, sy,
 typedef struct McRec {
     Loc src[2], dst;
     int sstride[2], dstride, w, h, chroma, kind, mx[2], my[2], denom, wt[2], of[2], level;
+    Loc srcb[2], dstb;                 /* chroma == 2: the Cr block of the same prediction unit (one job for both planes) */
+    int k, x, y;                       /* plane and position of the block (pairing the Cr block with its Cb block) */
 } McRec;
 typedef struct TuRec { Loc dst; size_t coef_off; int dstride, log2, col_limit, kind, level; } TuRec;
 typedef struct IntraRec { mi355_hevc_intra_block b; int level; } IntraRec;
@@ -291,10 +293,26 @@ static void rec_pred(uint8_t *dst, ptrdiff_t dstride, const int16_t *src1, const
     if (b) { m->src[1] = b->src; m->sstride[1] = b->sstride; m->mx[1] = b->mx; m->my[1] = b->my; }
     m->dst = dl; m->dstride = (int)dstride; m->w = w; m->h = h; m->chroma = a->chroma; m->kind = kind;
     m->denom = denom; m->wt[0] = w0; m->wt[1] = w1; m->of[0] = o0; m->of[1] = o1;
+    m->k = k; m->x = x; m->y = y;
     m->level = level_max(k, x, y, w, h) + 1;
     level_set(k, x, y, w, h, m->level);
     a->live = 0;                       /* an intermediate is consumed once: its slot is free for the next interpolation */
     if (b) b->live = 0;
+    /* chroma_mc runs Cb, then Cr with the same vector (hevcdec.c:1582-1640, called twice per prediction unit): with unweighted prediction
+     * the two blocks differ in their planes only and become ONE job (mi355_hevc_batch.h, chroma == 2: windows fetched together, every pass
+     * over both planes) on the later of their two levels */
+    if (k == 2 && R.nmc >= 2 && (kind == MI355_HEVC_PRED_PUT || kind == MI355_HEVC_PRED_AVG)) {
+        McRec *c = m - 1;
+        if (c->chroma == 1 && c->k == 1 && c->x == x && c->y == y && c->w == w && c->h == h && c->kind == kind && c->dstride == m->dstride &&
+            c->sstride[0] == m->sstride[0] && c->mx[0] == m->mx[0] && c->my[0] == m->my[0] &&
+            (!b || (c->sstride[1] == m->sstride[1] && c->mx[1] == m->mx[1] && c->my[1] == m->my[1]))) {
+            c->srcb[0] = m->src[0]; c->srcb[1] = m->src[1]; c->dstb = m->dst;
+            c->chroma = 2;
+            if (m->level > c->level) { c->level = m->level; level_set(1, x, y, w, h, c->level); }
+            else if (c->level > m->level) level_set(2, x, y, w, h, c->level);
+            R.nmc--;
+        }
+    }
 }
 #define PRED_FNS_I(i) \
     static void up_##i(uint8_t *d, ptrdiff_t ds, int16_t *s1, ptrdiff_t ss, int h) { if (!R.on) { R.orig_dsp.put_unweighted_pred[i](d, ds, s1, ss, h); return; } rec_pred(d, ds, s1, NULL, k_w_luma[i], h, MI355_HEVC_PRED_PUT, 0, 0, 0, 0, 0); } \
@@ -602,6 +620,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
             if (m->kind & 1) { j->src1 = resolve(&m->src[1]); j->src1_stride = m->sstride[1]; }
             j->dst = resolve(&m->dst); j->dst_stride = m->dstride;
             j->width = (uint8_t)m->w; j->height = (uint8_t)m->h; j->chroma = (uint8_t)m->chroma; j->kind = (uint8_t)m->kind;
+            if (m->chroma == 2) { j->src0_b = resolve(&m->srcb[0]); if (m->kind & 1) j->src1_b = resolve(&m->srcb[1]); j->dst_b = resolve(&m->dstb); }
             j->mx0 = (uint8_t)m->mx[0]; j->my0 = (uint8_t)m->my[0]; j->mx1 = (uint8_t)m->mx[1]; j->my1 = (uint8_t)m->my[1];
             j->denom = (uint8_t)m->denom; j->w0 = (int16_t)m->wt[0]; j->w1 = (int16_t)m->wt[1]; j->o0 = (int16_t)m->of[0]; j->o1 = (int16_t)m->of[1];
         }

@@ -74,12 +74,17 @@ typedef struct mi355_hevc_mcpred_job {
     uint8_t *dst;
     int32_t src0_stride, src1_stride, dst_stride;
     uint8_t width, height;        /* <= 64 */
-    uint8_t chroma;               /* 0: 8-tap qpel (fractions 0..3), 1: 4-tap epel (0..7) */
+    uint8_t chroma;               /* 0: 8-tap qpel (fractions 0..3), 1: 4-tap epel (0..7), 2: 4-tap epel of BOTH chroma planes of the block: the
+                                     second plane (Cr) at src0_b / src1_b / dst_b with the same strides, vector fractions and parameters —
+                                     for the unweighted kinds only (MI355_HEVC_PRED_PUT, _AVG: the weighted ones carry per-plane weights).
+                                     One job instead of two: the windows of both planes are fetched in one round trip and share every pass */
     uint8_t kind;                 /* MI355_HEVC_PRED_* */
     uint8_t mx0, my0, mx1, my1;
     uint8_t denom;
     uint8_t reserved[3];
     int16_t w0, w1, o0, o1;
+    const uint8_t *src0_b, *src1_b;   /* chroma == 2: the second plane */
+    uint8_t *dst_b;
 } mi355_hevc_mcpred_job;
 int mi355_hevc_mcpred_batch_dev(const mi355_hevc_mcpred_job *d_jobs, int n, int bit_depth, void *stream);
 

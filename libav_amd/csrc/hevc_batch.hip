@@ -148,23 +148,42 @@ __device__ inline void hevc_mcpred_taps(const mi355_hevc_mcpred_job &j, int bd, 
     const int px = bd > 8 ? 2 : 1;
     constexpr int before = TAPS == 8 ? 3 : 1;
     constexpr bool two = (KIND & 1) != 0;
+    const bool pair = TAPS == 4 && j.chroma == 2;        /* both chroma planes of the block (unweighted kinds) */
     const uint8_t *src0 = mi355_global(j.src0), *src1 = two ? mi355_global(j.src1) : nullptr;
     uint8_t *dst = mi355_global(j.dst);
-    const unsigned al = (unsigned)(uintptr_t)dst | (unsigned)j.dst_stride;
+    const uint8_t *src0b = pair ? mi355_global(j.src0_b) : nullptr, *src1b = pair && two ? mi355_global(j.src1_b) : nullptr;
+    uint8_t *dstb = pair ? mi355_global(j.dst_b) : nullptr;
+    const unsigned al = (unsigned)(uintptr_t)dst | (unsigned)j.dst_stride | (pair ? (unsigned)(uintptr_t)dstb : 0u);
     const int amode = bd > 8 ? ((al & 3) == 0 ? 4 : 2) : ((al & 1) == 0 ? 2 : 1);
     const HevcPredParams pp{ j.kind, j.denom, j.w0, j.w1, j.o0, j.o1 };
+    if (pair && KIND == 0) {
+        /* one reference: the planes share every pass of a tile (hevc_mc_tile_pair, tiles of HEVC_MC_PAIR_TILE_H rows) */
+        const int bx = j.mx0 ? before : 0, by = j.my0 ? before : 0;
+        for (int ty = 0; ty < j.height; ty += HEVC_MC_PAIR_TILE_H)
+        for (int tx = 0; tx < j.width; tx += HEVC_MC_TILE) {
+            const int tw = j.width - tx < HEVC_MC_TILE ? j.width - tx : HEVC_MC_TILE, th = j.height - ty < HEVC_MC_PAIR_TILE_H ? j.height - ty : HEVC_MC_PAIR_TILE_H;
+            const ptrdiff_t so = (ptrdiff_t)(ty - by) * j.src0_stride + (ptrdiff_t)(tx - bx) * px, dof = (ptrdiff_t)ty * j.dst_stride + (ptrdiff_t)tx * px;
+            const HevcMcToSamples<KIND> sa{ dst + dof, j.dst_stride, bd, amode, pp, nullptr }, sb{ dstb + dof, j.dst_stride, bd, amode, pp, nullptr };
+            hevc_mc_tile_pair(sa, sb, src0 + so, src0b + so, j.src0_stride, tw, th, j.mx0, j.my0, bd, s);
+        }
+        return;
+    }
     /* two references: tiles of 16 rows, so that windows, first-pass results (23 rows each) and the kept tile share the scratch */
     constexpr int TH = two ? HEVC_MC_BI_TILE_H : HEVC_MC_TILE_H;
-    for (int ty = 0; ty < j.height; ty += TH)
-    for (int tx = 0; tx < j.width; tx += HEVC_MC_TILE) {
-        const int tw = j.width - tx < HEVC_MC_TILE ? j.width - tx : HEVC_MC_TILE, th = j.height - ty < TH ? j.height - ty : TH;
-        if (two) {
-            const int bx = j.mx1 ? before : 0, by = j.my1 ? before : 0;
-            hevc_mc_tile<TAPS>(HevcMcToTile{ keep }, src1 + (ptrdiff_t)(ty - by) * j.src1_stride + (ptrdiff_t)(tx - bx) * px, j.src1_stride, tw, th, j.mx1, j.my1, bd, s);
+    for (int plane = 0; plane < (pair ? 2 : 1); plane++) {           /* a pair with two references: plane by plane */
+        const uint8_t *p0 = plane ? src0b : src0, *p1 = plane ? src1b : src1;
+        uint8_t *pd = plane ? dstb : dst;
+        for (int ty = 0; ty < j.height; ty += TH)
+        for (int tx = 0; tx < j.width; tx += HEVC_MC_TILE) {
+            const int tw = j.width - tx < HEVC_MC_TILE ? j.width - tx : HEVC_MC_TILE, th = j.height - ty < TH ? j.height - ty : TH;
+            if (two) {
+                const int bx = j.mx1 ? before : 0, by = j.my1 ? before : 0;
+                hevc_mc_tile<TAPS>(HevcMcToTile{ keep }, p1 + (ptrdiff_t)(ty - by) * j.src1_stride + (ptrdiff_t)(tx - bx) * px, j.src1_stride, tw, th, j.mx1, j.my1, bd, s);
+            }
+            const int bx = j.mx0 ? before : 0, by = j.my0 ? before : 0;
+            const HevcMcToSamples<KIND> sink{ pd + (ptrdiff_t)ty * j.dst_stride + (ptrdiff_t)tx * px, j.dst_stride, bd, amode, pp, two ? keep : nullptr };
+            hevc_mc_tile<TAPS>(sink, p0 + (ptrdiff_t)(ty - by) * j.src0_stride + (ptrdiff_t)(tx - bx) * px, j.src0_stride, tw, th, j.mx0, j.my0, bd, s);
         }
-        const int bx = j.mx0 ? before : 0, by = j.my0 ? before : 0;
-        const HevcMcToSamples<KIND> sink{ dst + (ptrdiff_t)ty * j.dst_stride + (ptrdiff_t)tx * px, j.dst_stride, bd, amode, pp, two ? keep : nullptr };
-        hevc_mc_tile<TAPS>(sink, src0 + (ptrdiff_t)(ty - by) * j.src0_stride + (ptrdiff_t)(tx - bx) * px, j.src0_stride, tw, th, j.mx0, j.my0, bd, s);
     }
 }
 __global__ void __launch_bounds__(64) k_hevc_mcpred_batch(const mi355_hevc_mcpred_job *jobs, int n, int bd)
@@ -175,7 +194,7 @@ __global__ void __launch_bounds__(64) k_hevc_mcpred_batch(const mi355_hevc_mcpre
     int16_t *const keep = tmp.tmp + HEVC_MC_BI_ROWS * HEVC_MC_TPITCH;
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_mcpred_job j = jobs[blockIdx.x];
-    switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {
+    switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {          /* chroma 1 and 2: the 4-tap instances */
     case 0: hevc_mcpred_taps<8, 0>(j, bd, tmp, keep); break;   case 1: hevc_mcpred_taps<8, 1>(j, bd, tmp, keep); break;
     case 2: hevc_mcpred_taps<8, 2>(j, bd, tmp, keep); break;   case 3: hevc_mcpred_taps<8, 3>(j, bd, tmp, keep); break;
     case 4: hevc_mcpred_taps<4, 0>(j, bd, tmp, keep); break;   case 5: hevc_mcpred_taps<4, 1>(j, bd, tmp, keep); break;

@@ -239,6 +239,10 @@ constexpr int HEVC_MC_TPITCH = 36;     /* ... of the first pass's results: 32 co
 #endif
 constexpr int HEVC_MC_TILE_H = MI355_HEVC_MC_TILE_H;      /* rows of a tile (32 wide) */
 constexpr int HEVC_MC_ROWS = HEVC_MC_TILE_H + 8;
+/* both chroma planes of a block in one tile pass (k_hevc_mcpred_batch, chroma == 2): tiles of at most HEVC_MC_PAIR_TILE_H rows, the second
+ * plane's window and first-pass rows HEVC_MC_PAIR_ROW rows below the first's */
+constexpr int HEVC_MC_PAIR_ROW = HEVC_MC_ROWS / 2, HEVC_MC_PAIR_TILE_H = HEVC_MC_PAIR_ROW - 4;
+static_assert(HEVC_MC_PAIR_TILE_H + 3 <= HEVC_MC_PAIR_ROW && 2 * HEVC_MC_PAIR_ROW <= HEVC_MC_ROWS, "two 4-tap windows in the scratch");
 struct __attribute__((aligned(16))) HevcMcScratch {
     uint16_t win[HEVC_MC_ROWS * HEVC_MC_PITCH];      /* staged samples */
     int16_t tmp[HEVC_MC_ROWS * HEVC_MC_TPITCH];      /* first-pass results of the 2-D case */
@@ -268,18 +272,24 @@ __device__ __forceinline__ void hevc_mc_st4(int16_t *p, uint32_t lo, uint32_t hi
 }
 /* one round of hevc_mc_stage: U pieces of eight bytes per lane, all U loads issued before the first result is touched (a lane
  * past the end repeats the last piece and drops it) — one memory round trip per 64 U pieces */
-template <int U>
-__device__ __forceinline__ void hevc_mc_stage_round(HevcMcScratch &s, const uint8_t *w0, ptrdiff_t sb, int base, int n, int K, int inv, int rowbytes, int bd, int lane)
+/* PAIR: rows 0 .. rows_a - 1 come from w0 and land in LDS rows 0 .., rows rows_a .. from w0b and land HEVC_MC_PAIR_ROW rows further down
+ * (the windows of both chroma planes of a block in one set of loads) */
+template <int U, bool PAIR = false>
+__device__ __forceinline__ void hevc_mc_stage_round(HevcMcScratch &s, const uint8_t *w0, ptrdiff_t sb, int base, int n, int K, int inv, int rowbytes, int bd, int lane,
+                                                    const uint8_t *w0b = nullptr, int rows_a = 0)
 {
     uint64_t v[U];
     int rr[U], kk[U], sh[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int i = base + 64 * u + lane, ic = i < n ? i : n - 1;
-        const int r = mi355_div20(ic, inv), k = ic - r * K;
+        int r = mi355_div20(ic, inv);
+        const int k = ic - r * K;
         /* the last piece of a row is fetched so that it ends with the row, then shifted into place */
         const int want = 8 * k, start = want < rowbytes - 8 ? want : rowbytes - 8;
-        __builtin_memcpy(&v[u], w0 + (ptrdiff_t)r * sb + start, 8);
+        const uint8_t *rowp = w0 + (ptrdiff_t)r * sb;
+        if (PAIR && r >= rows_a) { rowp = w0b + (ptrdiff_t)(r - rows_a) * sb; r += HEVC_MC_PAIR_ROW - rows_a; }
+        __builtin_memcpy(&v[u], rowp + start, 8);
         rr[u] = i < n ? r : -1; kk[u] = k; sh[u] = 8 * (want - start);
     }
     MI355_ISSUE_FENCE();
@@ -313,6 +323,28 @@ __device__ inline void hevc_mc_stage(HevcMcScratch &s, const uint8_t *w0, ptrdif
         for (int i = lane; i < rows * cols; i += 64) {
             const int r = i / cols, c = i - r * cols;
             s.win[r * HEVC_MC_PITCH + c] = (uint16_t)(bd > 8 ? reinterpret_cast<const uint16_t *>(w0 + (ptrdiff_t)r * sb)[c] : w0[(ptrdiff_t)r * sb + c]);
+        }
+    }
+}
+/* the windows of two planes (same geometry) in one go; rows of the second plane HEVC_MC_PAIR_ROW rows below the first's */
+__device__ inline void hevc_mc_stage_pair(HevcMcScratch &s, const uint8_t *w0a, const uint8_t *w0b, ptrdiff_t sb, int rows, int cols, int bd)
+{
+    const int lane = lane_id(), rowbytes = cols * (bd > 8 ? 2 : 1);
+    if (rowbytes >= 8) {
+        const int K = (rowbytes + 7) >> 3, inv = mi355_inv20(K), n = 2 * rows * K;
+        int base = 0;
+        for (; n - base > 192; base += 256) hevc_mc_stage_round<4, true>(s, w0a, sb, base, n, K, inv, rowbytes, bd, lane, w0b, rows);
+        if (n - base > 128) hevc_mc_stage_round<3, true>(s, w0a, sb, base, n, K, inv, rowbytes, bd, lane, w0b, rows);
+        else if (n - base > 64) hevc_mc_stage_round<2, true>(s, w0a, sb, base, n, K, inv, rowbytes, bd, lane, w0b, rows);
+        else if (n - base > 0) hevc_mc_stage_round<1, true>(s, w0a, sb, base, n, K, inv, rowbytes, bd, lane, w0b, rows);
+    } else {
+        for (int i = lane; i < 2 * rows * cols; i += 64) {
+            int r = i / cols;
+            const int c = i - r * cols;
+            const uint8_t *w0 = w0a;
+            int lr = r;
+            if (r >= rows) { w0 = w0b; r -= rows; lr = r + HEVC_MC_PAIR_ROW; }
+            s.win[lr * HEVC_MC_PITCH + c] = (uint16_t)(bd > 8 ? reinterpret_cast<const uint16_t *>(w0 + (ptrdiff_t)r * sb)[c] : w0[(ptrdiff_t)r * sb + c]);
         }
     }
 }
@@ -421,6 +453,63 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
         if (cp * ((th_ + 7) >> 3) > 32) hevc_mc_vpass<TAPS, 8>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
         else if (cp * ((th_ + 3) >> 2) > 32) hevc_mc_vpass<TAPS, 4>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
         else hevc_mc_vpass<TAPS, 2>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
+    }
+    __syncthreads();
+}
+/* the same tile of BOTH chroma planes (4-tap filters, one vector): windows staged together, every pass over the rows of both.
+ * sink0 / sink1: where plane 0 / plane 1 results go; w0a / w0b: first sample the taps touch in each plane */
+template <class Sink>
+__device__ inline void hevc_mc_tile_pair(const Sink &sink0, const Sink &sink1, const uint8_t *w0a, const uint8_t *w0b, ptrdiff_t sb, int tw, int th_, int mx, int my, int bd,
+                                         HevcMcScratch &s)
+{
+    constexpr int TAPS = 4, extra = TAPS - 1;
+    const int lane = lane_id();
+    const int8_t *fh = k_epel[mx], *fv = k_epel[my];
+    uint32_t th[TAPS / 2], tv[TAPS / 2];
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; k++) {
+        th[k] = (uint32_t)(uint16_t)(int16_t)fh[2 * k] | ((uint32_t)(uint16_t)(int16_t)fh[2 * k + 1] << 16);
+        tv[k] = (uint32_t)(uint16_t)(int16_t)fv[2 * k] | ((uint32_t)(uint16_t)(int16_t)fv[2 * k + 1] << 16);
+    }
+    const int rows = th_ + (my ? extra : 0);
+    hevc_mc_stage_pair(s, w0a, w0b, sb, rows, tw + (mx ? extra : 0), bd);
+    __syncthreads();
+    const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
+    /* item i of a row-wise pass: row r of plane pl, LDS row lr */
+#define MI355_PAIR_ROW(i) const int r2 = mi355_div20(i, winv), x0 = 4 * (i - r2 * wseg), pl = r2 >= rows, r = r2 - (pl ? rows : 0), lr = r + (pl ? HEVC_MC_PAIR_ROW : 0)
+    if (!mx && !my) {
+        for (int i = lane; i < 2 * rows * wseg; i += 64) {
+            MI355_PAIR_ROW(i);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[lr * HEVC_MC_PITCH + x0]);
+            const uint32_t lo = d[0] << (14 - bd), hi = d[1] << (14 - bd);
+            if (pl) sink1.put4(r, x0, lo, hi, tw - x0); else sink0.put4(r, x0, lo, hi, tw - x0);
+        }
+    }
+    if (mx) {
+        for (int i = lane; i < 2 * rows * wseg; i += 64) {
+            MI355_PAIR_ROW(i);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&s.win[lr * HEVC_MC_PITCH + x0]);
+            uint32_t dd[6];
+#pragma unroll
+            for (int k = 0; k < TAPS / 2 + 2; k++) dd[k] = d[k];
+            int o[4];
+            fir4<TAPS>(dd, th, o);
+            const uint32_t lo = pack16(o[0] >> (bd - 8), o[1] >> (bd - 8)), hi = pack16(o[2] >> (bd - 8), o[3] >> (bd - 8));
+            if (my) *reinterpret_cast<uint2 *>(&s.tmp[lr * HEVC_MC_TPITCH + x0]) = make_uint2(lo, hi);
+            else if (pl) sink1.put4(r, x0, lo, hi, tw - x0);
+            else sink0.put4(r, x0, lo, hi, tw - x0);
+        }
+        if (my) __syncthreads();
+    }
+#undef MI355_PAIR_ROW
+    if (my) {
+        const uint32_t *lines = reinterpret_cast<const uint32_t *>(mx ? reinterpret_cast<const uint16_t *>(s.tmp) : s.win);
+        const int vshift = mx ? 6 : bd - 8, pitch2 = (mx ? HEVC_MC_TPITCH : HEVC_MC_PITCH) / 2;
+        const int cp = tw >> 1;
+        const uint32_t *lines1 = lines + HEVC_MC_PAIR_ROW * pitch2;
+        /* one call per plane, no barrier between them: together they fill the wave (a 16x16 block: 64 + 64 items of two rows) */
+        if (cp * ((th_ + 3) >> 2) > 32) { hevc_mc_vpass<TAPS, 4>(sink0, lines, pitch2, tv, cp, th_, vshift, lane); hevc_mc_vpass<TAPS, 4>(sink1, lines1, pitch2, tv, cp, th_, vshift, lane); }
+        else { hevc_mc_vpass<TAPS, 2>(sink0, lines, pitch2, tv, cp, th_, vshift, lane); hevc_mc_vpass<TAPS, 2>(sink1, lines1, pitch2, tv, cp, th_, vshift, lane); }
     }
     __syncthreads();
 }

@@ -66,7 +66,8 @@ class McPredJob(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("dst", C.c_void_p), ("src0_stride", C.c_int32), ("src1_stride", C.c_int32),
                 ("dst_stride", C.c_int32), ("width", C.c_uint8), ("height", C.c_uint8), ("chroma", C.c_uint8), ("kind", C.c_uint8),
                 ("mx0", C.c_uint8), ("my0", C.c_uint8), ("mx1", C.c_uint8), ("my1", C.c_uint8), ("denom", C.c_uint8),
-                ("reserved", C.c_uint8 * 3), ("w0", C.c_int16), ("w1", C.c_int16), ("o0", C.c_int16), ("o1", C.c_int16)]
+                ("reserved", C.c_uint8 * 3), ("w0", C.c_int16), ("w1", C.c_int16), ("o0", C.c_int16), ("o1", C.c_int16),
+                ("src0_b", C.c_void_p), ("src1_b", C.c_void_p), ("dst_b", C.c_void_p)]       # chroma == 2: the second plane
 
 
 class IntraJob(C.Structure):
@@ -540,7 +541,12 @@ def check_mcpred(prov, oracle, bd, seed, cells=(4, 6)):
         fmax = 7 if chroma else 3
         frac = [r.randint(0, fmax) if r.randint(0, 3) else 0 for _ in range(4)]
         pos = [(r.randint(8, 200 - 64 - 8), r.randint(8, 320 - 64 - 8)) for _ in range(2)]
-        meta.append((chroma, wi, w, h, r.randint(0, 3), r.randint(0, 7), r.randint(-128, 127), r.randint(-128, 127),
+        kind = r.randint(0, 3)
+        # chroma == 2: both chroma planes of a block in one job (unweighted kinds): plane B reads the two references swapped
+        # and writes 32 samples to the right of plane A in the block's 64x64 cell
+        if chroma and kind < 2 and r.randint(0, 1):
+            chroma = 2
+        meta.append((chroma, wi, w, h, kind, r.randint(0, 7), r.randint(-128, 127), r.randint(-128, 127),
                      r.randint(-128, 127), r.randint(-128, 127), frac, pos, (k // cx) * 64, (k % cx) * 64))
     c_o = oracle.hevcdsp(bd)
     pic_o = pic.copy()
@@ -548,20 +554,22 @@ def check_mcpred(prov, oracle, bd, seed, cells=(4, 6)):
     t0, t1 = np.zeros(64 * 64, np.int16), np.zeros(64 * 64, np.int16)
     for chroma, wi, w, h, kind, denom, w0, w1, o0, o1, frac, pos, y0, x0 in meta:
         tab = c_o.put_hevc_epel if chroma else c_o.put_hevc_qpel
-        for t, ref, (sy, sx), (mx, my) in ((t0, ref0, pos[0], frac[0:2]), (t1, ref1, pos[1], frac[2:4])):
-            tab[int(my != 0)][int(mx != 0)][wi](_i16p(t), 128, _u8p(ref, sy * rstride + sx * px), rstride, h, mx, my, _i16p(mcbuf))
-        dp = _u8p(pic_o, y0 * stride + x0 * px)
-        tabs = ((c_o.put_unweighted_pred_chroma, c_o.put_unweighted_pred_avg_chroma, c_o.weighted_pred_chroma, c_o.weighted_pred_avg_chroma)
-                if chroma else (c_o.put_unweighted_pred, c_o.put_unweighted_pred_avg, c_o.weighted_pred, c_o.weighted_pred_avg))
-        fn = tabs[kind][wi]
-        if kind == 0:
-            fn(dp, stride, _i16p(t0), 128, h)
-        elif kind == 1:
-            fn(dp, stride, _i16p(t0), _i16p(t1), 128, h)
-        elif kind == 2:
-            fn(denom, w0, o0, dp, stride, _i16p(t0), 128, h)
-        else:
-            fn(denom, w0, w1, o0, o1, dp, stride, _i16p(t0), _i16p(t1), 128, h)
+        for plane in range(2 if chroma == 2 else 1):
+            ra, rb = (ref1, ref0) if plane else (ref0, ref1)
+            for t, ref, (sy, sx), (mx, my) in ((t0, ra, pos[0], frac[0:2]), (t1, rb, pos[1], frac[2:4])):
+                tab[int(my != 0)][int(mx != 0)][wi](_i16p(t), 128, _u8p(ref, sy * rstride + sx * px), rstride, h, mx, my, _i16p(mcbuf))
+            dp = _u8p(pic_o, y0 * stride + (x0 + 32 * plane) * px)
+            tabs = ((c_o.put_unweighted_pred_chroma, c_o.put_unweighted_pred_avg_chroma, c_o.weighted_pred_chroma, c_o.weighted_pred_avg_chroma)
+                    if chroma else (c_o.put_unweighted_pred, c_o.put_unweighted_pred_avg, c_o.weighted_pred, c_o.weighted_pred_avg))
+            fn = tabs[kind][wi]
+            if kind == 0:
+                fn(dp, stride, _i16p(t0), 128, h)
+            elif kind == 1:
+                fn(dp, stride, _i16p(t0), _i16p(t1), 128, h)
+            elif kind == 2:
+                fn(denom, w0, o0, dp, stride, _i16p(t0), 128, h)
+            else:
+                fn(denom, w0, w1, o0, o1, dp, stride, _i16p(t0), _i16p(t1), 128, h)
     d = Dev(prov.lib)
     try:
         p_pic, p0, p1 = d.up(pic), d.up(ref0), d.up(ref1)
@@ -570,6 +578,9 @@ def check_mcpred(prov, oracle, bd, seed, cells=(4, 6)):
             j = McPredJob(p0 + pos[0][0] * rstride + pos[0][1] * px, p1 + pos[1][0] * rstride + pos[1][1] * px, p_pic + y0 * stride + x0 * px,
                           rstride, rstride, stride, w, h, chroma, kind, frac[0], frac[1], frac[2], frac[3], denom)
             j.w0, j.w1, j.o0, j.o1 = w0, w1, o0, o1
+            if chroma == 2:
+                j.src0_b, j.src1_b = p1 + pos[0][0] * rstride + pos[0][1] * px, p0 + pos[1][0] * rstride + pos[1][1] * px
+                j.dst_b = p_pic + y0 * stride + (x0 + 32) * px
             jobs.append(j)
         assert prov.lib.mi355_hevc_mcpred_batch_dev(C.c_void_p(d.up_jobs(jobs)), n, bd, None) == 0
         pic_g = d.down(p_pic, pic)

@@ -23,7 +23,7 @@ W, H, BD, PX = 3840, 2160, 10, 2
 TU_DT = np.dtype([("coeffs", "<u8"), ("dst", "<u8"), ("dst_stride", "<i4"), ("log2_size", "u1"), ("col_limit", "u1"), ("kind", "u1"), ("rsv", "u1")])
 MP_DT = np.dtype([("src0", "<u8"), ("src1", "<u8"), ("dst", "<u8"), ("s0", "<i4"), ("s1", "<i4"), ("ds", "<i4"), ("width", "u1"), ("height", "u1"),
                   ("chroma", "u1"), ("kind", "u1"), ("mx0", "u1"), ("my0", "u1"), ("mx1", "u1"), ("my1", "u1"), ("denom", "u1"), ("rsv", "u1", 3),
-                  ("w0", "<i2"), ("w1", "<i2"), ("o0", "<i2"), ("o1", "<i2")])
+                  ("w0", "<i2"), ("w1", "<i2"), ("o0", "<i2"), ("o1", "<i2"), ("src0_b", "<u8"), ("src1_b", "<u8"), ("dst_b", "<u8")])
 SAO_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("width", "<i4"), ("height", "<i4"), ("borders", "<i4", 4),
                    ("offset_val", "<i4", 5), ("cls", "u1"), ("edge", "u1"), ("c_idx", "u1"), ("eo_class", "u1"), ("band_position", "u1"),
                    ("vert_edge", "u1"), ("horiz_edge", "u1"), ("diag_edge", "u1")])
@@ -32,7 +32,7 @@ PIECE_DT = np.dtype([("offset_val", "<i4", 5), ("cls", "u1"), ("type", "u1"), ("
 SAOC_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("c_idx", "u1"), ("npieces", "u1"), ("rsv", "u1", 2), ("piece", PIECE_DT, 4)])
 EE_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("dst_stride", "<i4"), ("src_stride", "<i4"), ("block_w", "<i4"), ("block_h", "<i4"),
                   ("src_x", "<i4"), ("src_y", "<i4"), ("w", "<i4"), ("h", "<i4")])
-assert TU_DT.itemsize == 24 and MP_DT.itemsize == 56 and SAO_DT.itemsize == 72 and PIECE_DT.itemsize == 36 and SAOC_DT.itemsize == 168 and EE_DT.itemsize == 48
+assert TU_DT.itemsize == 24 and MP_DT.itemsize == 80 and SAO_DT.itemsize == 72 and PIECE_DT.itemsize == 36 and SAOC_DT.itemsize == 168 and EE_DT.itemsize == 48
 BYTES_PER_CTB = 73984
 
 
@@ -121,6 +121,13 @@ class Chain:
             mp["mx0"][:, :, k], mp["my0"][:, :, k] = mvx & 7, mvy & 7
         ee = np.concatenate(ee) if ee else np.zeros(0, EE_DT)
         self.n_ee, self.d_ee = ee.size, (self.up(ee) if ee.size else 0)
+        # the two chroma blocks of a prediction unit as ONE job (chroma = 2: same vector, strides and — unweighted — parameters; the edge test
+        # of a block is the same in both planes, so both read the picture or both read their windows)
+        assert (mp["s0"][:, :, 1] == mp["s0"][:, :, 2]).all()
+        pairs = mp[:, :, 1].copy()
+        pairs["chroma"] = 2
+        pairs["src0_b"], pairs["dst_b"] = mp["src0"][:, :, 2], mp["dst"][:, :, 2]
+        mp = np.concatenate([mp[:, :, 0].reshape(-1), pairs.reshape(-1)])
         self.n_mp, self.d_mp = mp.size, self.up(mp)
         # ---- transform units: 32x32, all coded; 75 % carry non-zeros in the top-left 8x8 only (col_limit 12)
         ncy, ncx = np.meshgrid(np.arange(H // 64), np.arange(W // 64), indexing="ij")
