@@ -83,6 +83,7 @@ static __thread struct Recon {
     /* what the open picture recorded */
     EmuRec *emu; int nemu, cemu; size_t emu_bytes;
     McRec *mc; int nmc, cmc;
+    int last_loc;                      /* surface the last locate() found */
     TuRec *tu; int ntu, ctu;
     int16_t *coef; size_t ncoef, ccoef;
     IntraRec *intra; int nintra, cintra;
@@ -161,6 +162,17 @@ static Surface *surface_of_frame(const HEVCContext *s, const AVFrame *f, int cre
  * seen yet gets its surface now) */
 static int locate(const HEVCContext *s, const uint8_t *p, Loc *out)
 {
+    /* the surface of the previous call first: a prediction unit's calls name the same reference picture (a dozen thousand calls per picture) */
+    {
+        const Surface *u = &R.surf[R.last_loc];
+        if (u->host[0])
+            for (int k = 0; k < 3; k++)
+                if (p >= u->host[k] && p < u->host[k] + (size_t)u->linesize[k] * u->rows[k]) {
+                    out->surf = R.last_loc; out->off = u->off[k] + (size_t)(p - u->host[k]);
+                    R.surf[R.last_loc].used = R.pictures;
+                    return 0;
+                }
+    }
     for (int pass = 0; pass < 2; pass++) {
         for (int i = 0; i < MAX_SURF; i++) {
             const Surface *u = &R.surf[i];
@@ -169,6 +181,7 @@ static int locate(const HEVCContext *s, const uint8_t *p, Loc *out)
                 if (p >= u->host[k] && p < u->host[k] + (size_t)u->linesize[k] * u->rows[k]) {
                     out->surf = i; out->off = u->off[k] + (size_t)(p - u->host[k]);
                     R.surf[i].used = R.pictures;
+                    R.last_loc = i;
                     return 0;
                 }
         }
