@@ -19,7 +19,8 @@
  * and mi355_hevc_sao_ctbs_dev() runs them in one
  * launch, reading the deblocked picture and writing the picture the decoder outputs and predicts from (s->sao_frame).
  *
- * Scope of this binding: 4:2:0, no tiles, decoders without frame threads (progress is reported once per picture).
+ * Scope of this binding: 4:2:0, decoders without frame threads (progress is reported once per picture); tiles included (the
+ * edge rules of loop_filter_across_tiles_enabled_flag are applied where the edges are marked and where the SAO pieces are listed).
  * Everything else keeps the reference's path — MI355_HEVC_LF_PLAIN=1 keeps it for every picture.
  * One decoder = one stream of pictures here; a host with many decoders batches pictures of all of them into ONE call
  * (`npics`), as contrib/libav/mi355_h264_bridge.c does for H.264.
@@ -69,7 +70,7 @@ static int active(const HEVCContext *s)
         lf.plain = getenv("MI355_HEVC_LF_PLAIN") != NULL;
         if (!lf.plain && mi355_init(getenv("MI355_DEVICE") ? atoi(getenv("MI355_DEVICE")) : 0) != 0) fail("no MI355X");
     }
-    return !lf.plain && !lf.failed && !s->ps.pps->tiles_enabled_flag && !(s->avctx->active_thread_type & FF_THREAD_FRAME) && s->ps.sps->chroma_format_idc == 1;
+    return !lf.plain && !lf.failed && !(s->avctx->active_thread_type & FF_THREAD_FRAME) && s->ps.sps->chroma_format_idc == 1;
 }
 
 static int ensure(uint8_t **p, size_t *have, size_t want)
@@ -146,11 +147,14 @@ void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0
     const int size = 1 << log2_trafo_size, cw = sps->width >> 2, ctb_mask = (1 << sps->log2_ctb_size) - 1;
     const int inner = log2_trafo_size > sps->log2_min_pu_size &&
                       !s->ref->tab_mvf[(y0 >> sps->log2_min_pu_size) * sps->min_pu_width + (x0 >> sps->log2_min_pu_size)].is_intra;
-    /* a slice edge with filtering across it switched off is not an edge (tiles: active() excludes them) */
+    /* a slice or tile edge with filtering across it switched off is not an edge (hevc_filter.c:599-607, :661-669) */
+    const int no_tile = !s->ps.pps->loop_filter_across_tiles_enabled_flag;
     const int top = y0 > 0 && !(y0 & 7) &&
-                    !(!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_UPPER_SLICE) && !(y0 & ctb_mask));
+                    !(((!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_UPPER_SLICE)) ||
+                       (no_tile && (lc->boundary_flags & BOUNDARY_UPPER_TILE))) && !(y0 & ctb_mask));
     const int left = x0 > 0 && !(x0 & 7) &&
-                     !(!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_LEFT_SLICE) && !(x0 & ctb_mask));
+                     !(((!s->sh.slice_loop_filter_across_slices_enabled_flag && (lc->boundary_flags & BOUNDARY_LEFT_SLICE)) ||
+                        (no_tile && (lc->boundary_flags & BOUNDARY_LEFT_TILE))) && !(x0 & ctb_mask));
     for (int j = 0; j < size; j += 4)
         for (int i = 0; i < size; i += 4) {
             uint8_t f = 0;
@@ -199,6 +203,8 @@ static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const 
 {
     const HEVCSPS *sps = s->ps.sps;
     const int cw = sps->ctb_width, chn = sps->ctb_height;
+    const int no_tile = s->ps.pps->tiles_enabled_flag && !s->ps.pps->loop_filter_across_tiles_enabled_flag;
+    const int *tid = s->ps.pps->tile_id, *ts = s->ps.pps->ctb_addr_rs_to_ts;
     int n = 0;
     /* one job per CTB component = the OWNER's samples: what the reference filters with this CTB's parameters while this CTB
      * (class 0), the CTB to its right (class 2), the CTB below (class 1) and the one below-right (class 3) pass through */
@@ -224,15 +230,19 @@ static int sao_jobs(const HEVCContext *s, uint8_t *const dst[3], uint8_t *const 
                     const int a_c = s->tab_slice_address[here], a_l = has_l ? s->tab_slice_address[here - 1] : a_c;
                     const int a_u = has_u ? s->tab_slice_address[here - cw] : a_c, a_ul = has_l && has_u ? s->tab_slice_address[here - cw - 1] : a_c;
                     const int f_c = s->filter_slice_edges[here], f_l = has_l ? s->filter_slice_edges[here - 1] : 1, f_u = has_u ? s->filter_slice_edges[here - cw] : 1;
+                    /* tile edges with filtering across them off (hevc_filter.c:208-266): a tile edge runs through the whole picture,
+                     * so the column / row of THIS CTB decides for the pieces above / to the left too */
+                    const int lt = no_tile && has_l && tid[ts[here]] != tid[ts[here - 1]];
+                    const int ut = no_tile && has_u && tid[ts[here]] != tid[ts[here - cw]];
                     uint8_t vert[4] = { 0 }, horiz[4] = { 0 }, diag[4] = { 0 };
-                    if (has_l) vert[0] = vert[2] = !f_c && a_c != a_l;
-                    if (has_u) horiz[0] = horiz[1] = !f_c && a_c != a_u;
+                    if (has_l) vert[0] = vert[2] = (!f_c && a_c != a_l) || lt;
+                    if (has_u) horiz[0] = horiz[1] = (!f_c && a_c != a_u) || ut;
                     if (has_l && has_u) {
-                        vert[1] = vert[3] = !f_u && a_u != a_ul;
-                        horiz[2] = horiz[3] = !f_l && a_l != a_ul;
-                        diag[0] = diag[3] = !f_c && a_c != a_ul;
+                        vert[1] = vert[3] = (!f_u && a_u != a_ul) || lt;
+                        horiz[2] = horiz[3] = (!f_l && a_l != a_ul) || ut;
+                        diag[0] = diag[3] = (!f_c && a_c != a_ul) || lt || ut;
                         /* the anti-diagonal joins the left and the upper CTB: the later of the two decides */
-                        diag[1] = diag[2] = a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0;
+                        diag[1] = diag[2] = (a_l > a_u ? !f_l : a_l < a_u ? !f_u : 0) || lt || ut;
                     }
                     const int x0 = cx * size, y0 = cy * size;
                     mi355_hevc_sao_piece *q = &j->piece[j->npieces++];

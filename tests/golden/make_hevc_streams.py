@@ -240,7 +240,7 @@ def scan_tables(log2, scan_idx):
 class Hevc:
     def __init__(self, name, seed, w=96, h=64, bd=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, depth_intra=2,
                  depth_inter=2, sao=1, dbf_off=0, dbf_offsets=(0, 0), strong=1, qp=30, qp_delta=0, tskip=0, bypass=0, slices=1,
-                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3):
+                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3, tiles=None, across_tiles=1, tile_sizes=None):
         self.__dict__.update(locals())
         self.rng = random.Random(seed)
         self.tables = load_tables()
@@ -291,7 +291,16 @@ class Hevc:
         if self.qp_delta:
             b.ue(1)                                                  # diff_cu_qp_delta_depth
         b.se(self.cb_off); b.se(self.cr_off); b.u(1, 0)
-        b.u(1, self.weighted); b.u(1, self.weighted); b.u(1, self.bypass); b.u(1, 0); b.u(1, 0)
+        b.u(1, self.weighted); b.u(1, self.weighted); b.u(1, self.bypass); b.u(1, 1 if self.tiles else 0); b.u(1, 0)
+        if self.tiles:                                               # hevc_ps.c: columns, rows, uniform spacing or explicit sizes
+            b.ue(self.tiles[0] - 1); b.ue(self.tiles[1] - 1)
+            b.u(1, 0 if self.tile_sizes else 1)
+            if self.tile_sizes:
+                for v in self.tile_sizes[0][:-1]:
+                    b.ue(v - 1)
+                for v in self.tile_sizes[1][:-1]:
+                    b.ue(v - 1)
+            b.u(1, self.across_tiles)
         b.u(1, self.across)
         ctl = self.dbf_off or any(self.dbf_offsets)
         b.u(1, 1 if ctl else 0)
@@ -319,7 +328,16 @@ class Hevc:
         idr = poc == 0 or not self.inter
         self.stype = 2 if idr else (1 if poc % 2 else 0)           # HEVC_SLICE_B 0, P 1, I 2
         self.nrefs = 0 if idr else min(poc, 2)
+        self.tile_scan()
         starts = sorted(set([0] + [self.rng.randrange(1, nctb) for _ in range(self.slices - 1)])) if nctb > 1 else [0]
+        if self.tiles:
+            # H.265 6.3.1: a slice holds whole tiles, or a tile whole slices — slice starts (positions in tile scan) are a
+            # subset of the tile starts in one picture, a superset in the next
+            tstarts = [t for t in range(nctb) if t == 0 or self.tile_id[self.ts2rs[t]] != self.tile_id[self.ts2rs[t - 1]]]
+            if poc % 2:
+                starts = sorted(set(starts) | set(tstarts))
+            else:
+                starts = sorted(set([0] + self.rng.sample(tstarts[1:], min(self.slices - 1, len(tstarts) - 1))))
         out = b""
         self.n_slices = getattr(self, "n_slices", 0) + len(starts)
         self.n_ctus = getattr(self, "n_ctus", 0) + nctb
@@ -327,6 +345,31 @@ class Hevc:
             end = starts[si + 1] if si + 1 < len(starts) else nctb
             out += self.slice(poc, idr, first, end, nctb)
         return out
+
+    def tile_scan(self):
+        """H.265 6.5.1 (hevc_ps.c setup_pps): coding tree blocks in tile scan, the tile every block lies in"""
+        nctb = self.cw * self.ch
+        if not self.tiles:
+            self.ts2rs, self.tile_id = list(range(nctb)), [0] * nctb
+            return
+        nc, nr = self.tiles
+        if self.tile_sizes:
+            cols, rows = self.tile_sizes
+        else:
+            cols = [(i + 1) * self.cw // nc - i * self.cw // nc for i in range(nc)]
+            rows = [(i + 1) * self.ch // nr - i * self.ch // nr for i in range(nr)]
+        assert sum(cols) == self.cw and sum(rows) == self.ch and min(cols) > 0 and min(rows) > 0
+        self.ts2rs, self.tile_id = [], [0] * nctb
+        y0 = 0
+        for j, th in enumerate(rows):
+            x0 = 0
+            for i, tw in enumerate(cols):
+                for y in range(y0, y0 + th):
+                    for x in range(x0, x0 + tw):
+                        self.ts2rs.append(y * self.cw + x)
+                        self.tile_id[y * self.cw + x] = j * nc + i
+                x0 += tw
+            y0 += th
 
     def slice(self, poc, idr, first, end, nctb):
         r = self.rng
@@ -336,7 +379,7 @@ class Hevc:
             b.u(1, 0)
         b.ue(0)
         if first:
-            b.u((nctb - 1).bit_length(), first)
+            b.u((nctb - 1).bit_length(), self.ts2rs[first])             # slice_segment_address: raster scan
         b.ue(self.stype)
         if not idr:
             b.u(8, poc & 255)
@@ -362,22 +405,67 @@ class Hevc:
         b.se(sqp - 26)
         if self.across and (sao_l or sao_c or not self.dbf_off):
             b.u(1, r.randrange(2))
-        b.align_one()
-        c = Cabac(self.tables, b)
+        d = Bits()                                                   # slice_segment_data(): starts on a byte
+        c = Cabac(self.tables, d)
         c.init_states(2 - self.stype, sqp)
         self.c, self.sao_l, self.sao_c = c, sao_l, sao_c
         self.sao_tab = getattr(self, "sao_tab", {})
-        for addr in range(first, end):
-            self.first_in_slice, self.addr = first, addr
+        first_rs = self.ts2rs[first]
+        subs = []                                                    # byte positions where the tiles after the first begin
+        for ts in range(first, end):
+            addr = self.ts2rs[ts]
+            self.first_in_slice, self.addr = first_rs, addr
             rx, ry = addr % self.cw, addr // self.cw
-            self.left_ok = rx > 0 and addr - first > 0
-            self.up_ok = ry > 0 and addr - first >= self.cw
+            # hls_decode_neighbour (hevcdec.c:2255-2300): in the slice (distance in raster scan, as the decoder has it) and in the tile
+            in_slice = addr - first_rs
+            self.left_ok = rx > 0 and in_slice > 0 and self.tile_id[addr] == self.tile_id[addr - 1]
+            self.up_ok = ry > 0 and in_slice >= self.cw and self.tile_id[addr] == self.tile_id[addr - self.cw]
             self.sao_syntax(rx, ry)
             self.quadtree(rx << self.log2_ctb, ry << self.log2_ctb, self.log2_ctb, 0)
-            c.term(1 if addr == end - 1 else 0)
-        while len(b.b) % 8:
-            b.b.append(0)
-        return nal(19 if idr else 1, b.bytes())
+            c.term(1 if ts == end - 1 else 0)
+            if ts + 1 < end and self.tile_id[self.ts2rs[ts + 1]] != self.tile_id[addr]:
+                c.term(1)                                            # end_of_subset_one_bit, byte_alignment(): the flush's last bit is the one
+                while len(d.b) % 8:
+                    d.b.append(0)
+                subs.append(len(d.b) // 8)
+                c.restart()
+                c.init_states(2 - self.stype, sqp)
+        while len(d.b) % 8:
+            d.b.append(0)
+        data = d.bytes()
+        if not self.tiles:
+            b.align_one()
+            return nal(19 if idr else 1, b.bytes() + data)
+        # entry points (7.4.7.1): sizes of the subsets in bytes of the NAL unit, emulation prevention bytes included — those depend
+        # on the header in front, so: write, count, write again until the sizes stand
+        sizes = [q - p for p, q in zip([0] + subs, subs + [len(data)])]
+        for _ in range(8):
+            hb = Bits()
+            hb.b = list(b.b)
+            hb.ue(len(subs))
+            if subs:
+                hb.ue(31)
+                for v in sizes[:-1]:
+                    hb.u(32, v - 1)
+            hb.align_one()
+            head = hb.bytes()
+            unit = nal(19 if idr else 1, head + data)
+            # position of every payload byte in the escaped unit
+            pos, z, k = [], 0, 6
+            for byte in head + data:
+                if z >= 2 and byte <= 3:
+                    k += 1
+                    z = 0
+                pos.append(k)
+                k += 1
+                z = z + 1 if byte == 0 else 0
+            pos.append(k)
+            bounds = [len(head) + q for q in [0] + subs + [len(data)]]
+            now = [pos[bounds[i + 1]] - pos[bounds[i]] for i in range(len(bounds) - 1)]
+            if now == sizes:
+                return unit
+            sizes = now
+        raise RuntimeError("entry points do not settle")
 
     def pred_weights(self, b):
         r = self.rng
@@ -956,6 +1044,14 @@ STREAMS = {
     "pb_10bit_weighted": dict(seed=12, inter=1, pictures=5, bd=10, weighted=1, w=80, h=72),
     "pb_ctb16_slices_cip": dict(seed=13, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4, slices=3, cip=1, w=104, h=56, amp=0),
     "pb_ctb64_depth0": dict(seed=14, inter=1, pictures=4, log2_ctb=6, w=136, h=72, depth_inter=0, depth_intra=1, weighted=1),
+    # tiles (hevc_ps.c setup_pps, hls_decode_neighbour hevcdec.c:2255-2300, the tile rules of hevc_filter.c): uniform and explicit
+    # grids, filtering across tile edges on and off, slices of whole tiles and tiles of whole slices
+    "i_tiles_2x2": dict(seed=41, tiles=(2, 2), across_tiles=0, log2_ctb=4, log2_max_tb=4, w=104, h=72, sao=2, slices=2),
+    "i_tiles_3x1_10bit": dict(seed=42, tiles=(3, 1), across_tiles=1, bd=10, w=136, h=72, sao=2, qp_delta=1, slices=2),
+    "pb_tiles_2x3_noacross": dict(seed=43, tiles=(2, 3), across_tiles=0, across=0, inter=1, pictures=5, log2_ctb=4, log2_max_tb=4, w=104, h=88,
+                                  sao=2, slices=3, tile_sizes=((5, 2), (1, 3, 2))),
+    "pb_tiles_3x2_nosao_10bit": dict(seed=44, tiles=(3, 2), across_tiles=0, inter=1, pictures=4, bd=10, w=136, h=104, sao=0, slices=2, weighted=1,
+                                     dbf_offsets=(1, -1)),
     "pb_480p_ctb64": dict(seed=31, inter=1, pictures=4, log2_ctb=6, w=832, h=480, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_ctb64": dict(seed=32, inter=1, pictures=5, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_few_intra": dict(seed=33, inter=1, pictures=6, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2, intra_frac=0.02),
@@ -1019,9 +1115,10 @@ def main():
             print("   %d PCM blocks decode to the samples written" % len(h.pcm_blocks))
         gold[name] = {"md5": hashlib.md5(data).hexdigest(), "bytes": len(data), "pictures": int(m.group(2)), "width": int(m.group(3)), "height": int(m.group(4)),
                       "pix_fmt": m.group(5), "ctus": kw_obj.n_ctus, "slices": kw_obj.n_slices, "stream_md5": hashlib.md5(b"".join(pkts)).hexdigest()}
-    if not only:
-        json.dump(gold, open(gold_path, "w"), indent=1, sort_keys=True)
-        print("wrote", gold_path)
+    if only:                                                         # named streams: their entries join the ones on file
+        gold = dict(json.load(open(gold_path)), **gold)
+    json.dump(gold, open(gold_path, "w"), indent=1, sort_keys=True)
+    print("wrote", gold_path)
 
 
 if __name__ == "__main__":
