@@ -240,7 +240,7 @@ def scan_tables(log2, scan_idx):
 class Hevc:
     def __init__(self, name, seed, w=96, h=64, bd=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, depth_intra=2,
                  depth_inter=2, sao=1, dbf_off=0, dbf_offsets=(0, 0), strong=1, qp=30, qp_delta=0, tskip=0, bypass=0, slices=1,
-                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3, tiles=None, across_tiles=1, tile_sizes=None):
+                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3, tiles=None, across_tiles=1, tile_sizes=None, pyramid=0, wpp=0, dep=0):
         self.__dict__.update(locals())
         self.rng = random.Random(seed)
         self.tables = load_tables()
@@ -285,13 +285,13 @@ class Hevc:
 
     def pps(self):
         b = Bits()
-        b.ue(0); b.ue(0); b.u(1, 0); b.u(1, 0); b.u(3, 0); b.u(1, self.sdh); b.u(1, 0)
+        b.ue(0); b.ue(0); b.u(1, self.dep); b.u(1, 0); b.u(3, 0); b.u(1, self.sdh); b.u(1, 0)
         b.ue(1); b.ue(1)                                             # two references by default in both lists
         b.se(0); b.u(1, self.cip); b.u(1, self.tskip); b.u(1, 1 if self.qp_delta else 0)
         if self.qp_delta:
             b.ue(1)                                                  # diff_cu_qp_delta_depth
         b.se(self.cb_off); b.se(self.cr_off); b.u(1, 0)
-        b.u(1, self.weighted); b.u(1, self.weighted); b.u(1, self.bypass); b.u(1, 1 if self.tiles else 0); b.u(1, 0)
+        b.u(1, self.weighted); b.u(1, self.weighted); b.u(1, self.bypass); b.u(1, 1 if self.tiles else 0); b.u(1, self.wpp)
         if self.tiles:                                               # hevc_ps.c: columns, rows, uniform spacing or explicit sizes
             b.ue(self.tiles[0] - 1); b.ue(self.tiles[1] - 1)
             b.u(1, 0 if self.tile_sizes else 1)
@@ -323,11 +323,22 @@ class Hevc:
         self.ipm = [[1] * n4w for _ in range(n4h)]                 # intra mode (INTRA_DC where not intra)
         self.skipf = [[0] * n4w for _ in range(n4h)]
         nctb = self.cw * self.ch
+        self.neg, self.pos = [poc - 1 - i for i in range(min(poc, 2))], []       # the reference picture set: before / after in output order
+        if self.pyramid and poc:
+            # groups of four in decoding order: the anchor (4 after the last), then the middle, then the two between — pictures
+            # leave the decoder in another order than they enter it, and references lie on both sides
+            g, k = divmod(poc - 1, 4)
+            base = 4 * g
+            poc = base + (4, 2, 1, 3)[k]
+            self.neg, self.pos = {4: ([base], []), 2: ([base], [base + 4]), 1: ([base], [base + 2, base + 4]),
+                                  3: ([base + 2, base], [base + 4])}[poc - base]
         self.poc = poc
         self.pcm_blocks = getattr(self, "pcm_blocks", [])
         idr = poc == 0 or not self.inter
         self.stype = 2 if idr else (1 if poc % 2 else 0)           # HEVC_SLICE_B 0, P 1, I 2
-        self.nrefs = 0 if idr else min(poc, 2)
+        if self.pyramid and not idr:
+            self.stype = 1 if poc % 8 == 4 else 0                    # every other anchor a P picture
+        self.nrefs = 0 if idr else len(self.neg) + len(self.pos)
         self.tile_scan()
         starts = sorted(set([0] + [self.rng.randrange(1, nctb) for _ in range(self.slices - 1)])) if nctb > 1 else [0]
         if self.tiles:
@@ -338,12 +349,17 @@ class Hevc:
                 starts = sorted(set(starts) | set(tstarts))
             else:
                 starts = sorted(set([0] + self.rng.sample(tstarts[1:], min(self.slices - 1, len(tstarts) - 1))))
+        if self.wpp:
+            # wavefronts: slices begin with a row here (the reference's decoder takes a row's contexts from the row above whatever
+            # slice that lay in, hevc_cabac.c:397-411; with slices of whole rows that is what 9.3.1 says too)
+            starts = sorted(set([0] + [self.rng.randrange(1, self.ch) * self.cw for _ in range(self.slices - 1)])) if self.ch > 1 else [0]
         out = b""
         self.n_slices = getattr(self, "n_slices", 0) + len(starts)
         self.n_ctus = getattr(self, "n_ctus", 0) + nctb
         for si, first in enumerate(starts):
             end = starts[si + 1] if si + 1 < len(starts) else nctb
-            out += self.slice(poc, idr, first, end, nctb)
+            dependent = int(bool(self.dep and si and self.rng.random() < 0.6))     # a slice segment that continues the slice before it
+            out += self.slice(poc, idr, first, end, nctb, dependent)
         return out
 
     def tile_scan(self):
@@ -371,7 +387,7 @@ class Hevc:
                 x0 += tw
             y0 += th
 
-    def slice(self, poc, idr, first, end, nctb):
+    def slice(self, poc, idr, first, end, nctb, dependent=0):
         r = self.rng
         b = Bits()
         b.u(1, 1 if first == 0 else 0)
@@ -379,14 +395,27 @@ class Hevc:
             b.u(1, 0)
         b.ue(0)
         if first:
+            if self.dep:
+                b.u(1, dependent)
             b.u((nctb - 1).bit_length(), self.ts2rs[first])             # slice_segment_address: raster scan
+        if dependent:
+            # hls_slice_header (hevcdec.c): everything else is the slice's; the contexts go on from the end of the segment before
+            # (ff_hevc_cabac_init: cabac_init_state only for independent segments)
+            return self.slice_data(b, idr, first, end, self.c.state)
+        self.slice_rs = self.ts2rs[first]
         b.ue(self.stype)
         if not idr:
             b.u(8, poc & 255)
             b.u(1, 0)                                                # the slice's own short-term set (hevc_ps.c ff_hevc_decode_short_term_rps)
-            b.ue(self.nrefs); b.ue(0)
-            for _ in range(self.nrefs):
-                b.ue(0); b.u(1, 1)                                   # delta_poc_s0_minus1 0, used
+            b.ue(len(self.neg)); b.ue(len(self.pos))
+            at = poc
+            for v in self.neg:
+                b.ue(at - v - 1); b.u(1, 1)                          # delta_poc_s0_minus1, used
+                at = v
+            at = poc
+            for v in self.pos:
+                b.ue(v - at - 1); b.u(1, 1)                          # delta_poc_s1_minus1, used
+                at = v
         sao_l = sao_c = 0
         if self.sao:
             sao_l, sao_c = r.randrange(2) if self.sao == 1 else 1, r.randrange(2) if self.sao == 1 else 1
@@ -405,13 +434,24 @@ class Hevc:
         b.se(sqp - 26)
         if self.across and (sao_l or sao_c or not self.dbf_off):
             b.u(1, r.randrange(2))
+        self.sqp, self.sao_l, self.sao_c = sqp, sao_l, sao_c
+        return self.slice_data(b, idr, first, end, None)
+
+    def slice_data(self, b, idr, first, end, states):
+        sqp = self.sqp
         d = Bits()                                                   # slice_segment_data(): starts on a byte
         c = Cabac(self.tables, d)
-        c.init_states(2 - self.stype, sqp)
-        self.c, self.sao_l, self.sao_c = c, sao_l, sao_c
+        if states is None or (self.wpp and self.cw == 1) or \
+           (self.tiles and self.tile_id[self.ts2rs[first]] != self.tile_id[self.ts2rs[first - 1]]):
+            c.init_states(2 - self.stype, sqp)                       # also a dependent segment that opens a tile (hevc_cabac.c:381-385)
+        elif self.wpp:
+            c.state = list(self.wpp_saved)                           # a dependent segment at the start of a row: the row above decides
+        else:
+            c.state = list(states)
+        self.c = c
         self.sao_tab = getattr(self, "sao_tab", {})
-        first_rs = self.ts2rs[first]
-        subs = []                                                    # byte positions where the tiles after the first begin
+        first_rs = self.slice_rs                                     # of the SLICE: a dependent segment's neighbours in the segments before it count
+        subs = []                                                    # byte positions where the tiles / rows after the first begin
         for ts in range(first, end):
             addr = self.ts2rs[ts]
             self.first_in_slice, self.addr = first_rs, addr
@@ -422,18 +462,24 @@ class Hevc:
             self.up_ok = ry > 0 and in_slice >= self.cw and self.tile_id[addr] == self.tile_id[addr - self.cw]
             self.sao_syntax(rx, ry)
             self.quadtree(rx << self.log2_ctb, ry << self.log2_ctb, self.log2_ctb, 0)
+            if self.wpp and rx == 1:
+                self.wpp_saved = list(c.state)                       # 9.3.2.2 / ff_hevc_save_states: after the second block of a row
             c.term(1 if ts == end - 1 else 0)
-            if ts + 1 < end and self.tile_id[self.ts2rs[ts + 1]] != self.tile_id[addr]:
+            new_row = self.wpp and ts + 1 < end and self.ts2rs[ts + 1] % self.cw == 0
+            if ts + 1 < end and (new_row or self.tile_id[self.ts2rs[ts + 1]] != self.tile_id[addr]):
                 c.term(1)                                            # end_of_subset_one_bit, byte_alignment(): the flush's last bit is the one
                 while len(d.b) % 8:
                     d.b.append(0)
                 subs.append(len(d.b) // 8)
                 c.restart()
-                c.init_states(2 - self.stype, sqp)
+                if new_row and self.cw > 1:
+                    c.state = list(self.wpp_saved)
+                else:
+                    c.init_states(2 - self.stype, sqp)
         while len(d.b) % 8:
             d.b.append(0)
         data = d.bytes()
-        if not self.tiles:
+        if not (self.tiles or self.wpp):
             b.align_one()
             return nal(19 if idr else 1, b.bytes() + data)
         # entry points (7.4.7.1): sizes of the subsets in bytes of the NAL unit, emulation prevention bytes included — those depend
@@ -1052,6 +1098,15 @@ STREAMS = {
                                   sao=2, slices=3, tile_sizes=((5, 2), (1, 3, 2))),
     "pb_tiles_3x2_nosao_10bit": dict(seed=44, tiles=(3, 2), across_tiles=0, inter=1, pictures=4, bd=10, w=136, h=104, sao=0, slices=2, weighted=1,
                                      dbf_offsets=(1, -1)),
+    # pictures that leave the decoder in another order than they enter it, references before and after (hevc_refs.c: bumping, frame RPS)
+    "pb_pyramid": dict(seed=45, inter=1, pictures=10, pyramid=1, sao=2, w=112, h=80, weighted=1),
+    "pb_pyramid_tiles_10bit": dict(seed=46, inter=1, pictures=7, pyramid=1, bd=10, tiles=(2, 2), across_tiles=0, w=136, h=104, slices=2),
+    # wavefronts (entropy_coding_sync: contexts of a row from the second block of the row above) and dependent slice segments
+    # (tab_slice_address stays the slice's: no slice edge between the segments)
+    "i_wpp": dict(seed=47, wpp=1, slices=2, w=136, h=104, sao=2, across=0),
+    "pb_wpp_dep_10bit": dict(seed=48, wpp=1, dep=1, slices=4, inter=1, pictures=4, bd=10, log2_ctb=4, log2_max_tb=4, w=104, h=88, sao=2, across=0),
+    "pb_dep_slices": dict(seed=49, dep=1, slices=5, inter=1, pictures=4, w=136, h=104, sao=2, across=0, qp_delta=1),
+    "pb_tiles_dep": dict(seed=50, dep=1, slices=3, tiles=(2, 2), across_tiles=0, across=0, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4, w=104, h=88, sao=2),
     "pb_480p_ctb64": dict(seed=31, inter=1, pictures=4, log2_ctb=6, w=832, h=480, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_ctb64": dict(seed=32, inter=1, pictures=5, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_few_intra": dict(seed=33, inter=1, pictures=6, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2, intra_frac=0.02),

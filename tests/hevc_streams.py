@@ -2,8 +2,9 @@
 reference tree holds no HEVC sample): I pictures with every transform size 4..32, the three coefficient scans, Intra NxN,
 SAO band / edge with merging, deblocking offsets / off, cu_qp_delta, transform skip, transquant bypass, default scaling
 lists, several slices, tiles (uniform and explicit grids, filtering across their edges on and off, slices of whole tiles and
-tiles of whole slices), CTB sizes 16 / 32 / 64, 8 and 10 bit — and P / B pictures: skip, merge, AMVP with random vector
-differences, all partition shapes (AMP too), one or two lists, explicit weights, constrained intra prediction.
+tiles of whole slices), wavefronts, dependent slice segments, CTB sizes 16 / 32 / 64, 8 and 10 bit — and P / B pictures: skip, merge, AMVP with random vector
+differences, all partition shapes (AMP too), one or two lists, explicit weights, constrained intra prediction, groups of
+pictures decoded out of output order with references on both sides.
 tests/golden/hevc_streams.json = md5 of what the reference's own decoder (tables untouched) outputs for each, and the
 number of coding tree units / slices written (the decoder must see exactly those: the streams are open loop)."""
 import hashlib
