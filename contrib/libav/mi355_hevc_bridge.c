@@ -28,7 +28,7 @@
  * the plane a source pointer falls into); a reference this bridge did not decode (a frame the decoder made up for a missing
  * reference) is uploaded once.
  *
- * Scope: what the filter bridge takes (4:2:0, no tiles, no frame threads), 8 / 9 / 10 bit, one decoder per thread.  A picture
+ * Scope: what the filter bridge takes (4:2:0, no frame threads; tiles, wavefronts and dependent slice segments included), 8 / 9 / 10 bit, one decoder per thread.  A picture
  * outside it is reconstructed by the reference's own functions (the entries forward to the tables the reference filled) and
  * its surface is uploaded when a later picture needs it.  MI355_HEVC_RECON_PLAIN=1 forwards everything.
  */
