@@ -1107,6 +1107,7 @@ STREAMS = {
     "pb_wpp_dep_10bit": dict(seed=48, wpp=1, dep=1, slices=4, inter=1, pictures=4, bd=10, log2_ctb=4, log2_max_tb=4, w=104, h=88, sao=2, across=0),
     "pb_dep_slices": dict(seed=49, dep=1, slices=5, inter=1, pictures=4, w=136, h=104, sao=2, across=0, qp_delta=1),
     "pb_tiles_dep": dict(seed=50, dep=1, slices=3, tiles=(2, 2), across_tiles=0, across=0, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4, w=104, h=88, sao=2),
+    "pb_9bit": dict(seed=51, bd=9, inter=1, pictures=4, w=112, h=80, sao=2, weighted=1, pcm=1, tskip=1, qp_delta=1),
     "pb_480p_ctb64": dict(seed=31, inter=1, pictures=4, log2_ctb=6, w=832, h=480, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_ctb64": dict(seed=32, inter=1, pictures=5, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_few_intra": dict(seed=33, inter=1, pictures=6, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2, intra_frac=0.02),

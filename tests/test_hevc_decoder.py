@@ -12,7 +12,7 @@ needs_harness = pytest.mark.skipif(not os.path.isdir("/root/reference/libavcodec
 
 
 def test_streams_cover_both_depths_and_inter_pictures():
-    assert {HS.MD5[n]["pix_fmt"] for n in HS.ALL} == {"yuv420p", "yuv420p10le"}
+    assert {HS.MD5[n]["pix_fmt"] for n in HS.ALL} == {"yuv420p", "yuv420p9le", "yuv420p10le"}
     assert sum(n.startswith("pb_") for n in HS.ALL) >= 6 and sum(n.startswith("i_") for n in HS.ALL) >= 12
     for n in HS.ALL:
         assert os.path.getsize(HS.samples(n)) > 1000
