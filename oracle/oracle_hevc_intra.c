@@ -74,7 +74,13 @@ void oracle_hevc_intra_pred_block(const mi355_hevc_intra_picture *p, const mi355
         if (a_u && on_y)  { const int xt = x0 >> l2pu;        a_u  = any_intra_pu(p, xt, yt, 1, imin_(npu, p->min_pu_width - xt)); }
         if (a_ur && on_y) { const int xr = (x0 + nl) >> l2pu; a_ur = any_intra_pu(p, xr, yt, 1, imin_(npu, p->min_pu_width - xr)); }
         fill(L, 128, 2 * NMAX); fill(T, 128, 2 * NMAX);
-        L[-1] = T[-1] = 128;            /* the reference leaves its corner unset here; every path writes it before use */
+        /* The reference's loop above starts at index 0 (:157-160): its corner left[-1] / top[-1] is NOT set here.  Every path writes it
+         * before use — except one: the corner's unit is intra but the corner is not a candidate (cand_up_left 0 because it lies
+         * across a slice or tile edge).  The substitution walks (:187-199, :214-221) ask IS_INTRA, not the candidate flag, leave such
+         * a corner alone and then copy it into the whole left column: the reference predicts from a sample it never wrote (whatever
+         * its stack held; found by tools/hevc_stream_sweep.py, seed 7 case 32: a 16x16 block at a tile edge predicted from 0).
+         * Here the corner starts like every other neighbour the reference initialises: 128. */
+        L[-1] = T[-1] = 128;
     } else {
         fill(Lb, 0, 2 * NMAX + 1); fill(Tb, 0, 2 * NMAX + 1);
     }
