@@ -17,7 +17,9 @@ EXE = os.path.join(ROOT, 'oracle', '_ref', 'h264_bridge_emu')
 bad = 0
 for it in range(N):
     fmt = rng.choice(((1, 8), (1, 8), (1, 8), (3, 8), (2, 8), (1, 10)))
-    kw = dict(mb_w=rng.randrange(2, 12), mb_h=rng.randrange(2, 9), chroma_idc=fmt[0], depth=fmt[1], seed=rng.randrange(1 << 30),
+    # pictures at least three macroblocks wide: with a 16-byte chroma line the reference's two-reference weighted prediction keeps its Cb
+    # and Cr intermediates in overlapping rows (h264_mb.c:407-409: tmp_cr = tmp_cb + 16, rows mb_uvlinesize apart)
+    kw = dict(mb_w=rng.randrange(3, 12), mb_h=rng.randrange(2, 9), chroma_idc=fmt[0], depth=fmt[1], seed=rng.randrange(1 << 30),
               nslices=rng.randrange(1, 6), deblock_idc=rng.choice((-1, 0, 0, 1, 2)), weighted=bool(rng.randrange(2)), nrefs=rng.randrange(1, 5),
               npics=rng.randrange(4, 11), far=rng.choice((9, 20, 40)), bmode=rng.randrange(4), t8x8=bool(rng.randrange(2)),
               cip=bool(rng.randrange(2)), mixed=bool(rng.randrange(2)), paff=rng.random() < 0.3, reorder=rng.random() < 0.3,
@@ -26,6 +28,12 @@ for it in range(N):
     if kw['paff']:
         kw['mb_h'] += kw['mb_h'] & 1                  # field pairs: an even number of macroblock rows
         kw['bmode'] = 0                               # the writer's field pictures are I / P
+        kw['reorder'] = kw['gaps'] = kw['mmco'] = False   # ... with default lists and marking
+        # field pictures with disable_deblocking_filter_idc 2: the reference decides whether an intra macroblock's unfiltered
+        # above-left border is swapped in from slice_table[mb_xy - 1 - mb_stride] (h264_mb.c:525-527) — the row of the OTHER field,
+        # whose entries are whatever an earlier picture left: its output differs from its own idc 0 output on one-slice pictures
+        if kw['deblock_idc'] == 2:
+            kw['deblock_idc'] = 0
     if kw['mmco']:
         kw['nrefs'] = max(kw['nrefs'], 3)
     try:
@@ -62,11 +70,17 @@ for it in range(N):
             if os.path.exists(p): datas += open(p, 'rb').read()
         outs.append((hashlib.md5(datas if plain or threads == 1 else open(out, 'rb').read()).hexdigest(), st[-1] if st else {}, r.stderr.strip()))
     if not ok: bad += 1; continue
+    if outs[0][2]:
+        # the plain decoder complains: a combination the writer does not produce valid streams for (field pairs with list
+        # re-ordering / gaps / marking operations) — nothing to compare against
+        print(it, 'SKIP (the reference decoder rejects the stream: %s)' % outs[0][2].splitlines()[-1][-60:])
+        continue
     same = outs[0][0] == outs[1][0]
     j = outs[1][1]
     in_scope = fmt in ((1, 8), (3, 8))
-    on_dev = j.get('pictures_on_device') == j.get('pictures_output')
-    verdict = 'OK' if same and (on_dev or not in_scope) else 'MISMATCH'
+    # field pictures count one by one on the device, pairs come out as one frame
+    on_dev = j.get('pictures_on_device', 0) >= j.get('pictures_output', -1)
+    verdict = 'OK' if same and (on_dev or not in_scope) else ('MISMATCH' if not same else 'NOT ON DEVICE')
     print(it, verdict, variant, 'on device %s/%s' % (j.get('pictures_on_device'), j.get('pictures_output')),
           {k: v for k, v in kw.items() if k not in ('seed', 'far', 'sparse', 'skip')})
     if verdict != 'OK':
