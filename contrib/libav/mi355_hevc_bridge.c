@@ -65,12 +65,12 @@ typedef struct McRec {
     Loc srcb[2], dstb;                 /* chroma == 2: the Cr block of the same prediction unit (one job for both planes) */
     int k, x, y;                       /* plane and position of the block (pairing the Cr block with its Cb block) */
 } McRec;
-typedef struct TuRec { Loc dst; size_t coef_off; int dstride, log2, col_limit, kind, level; } TuRec;
-typedef struct IntraRec { mi355_hevc_intra_block b; int level; } IntraRec;
+typedef struct TuRec { Loc dst; size_t coef_off; int dstride, log2, col_limit, kind, level, fused; } TuRec;     /* fused: runs in its block's prediction launch */
+typedef struct IntraRec { mi355_hevc_intra_block b; int level, k, x, y, size, tu; } IntraRec;              /* plane position of the block; tu: its transform unit (R.tu index) or -1 */
 typedef struct Pending { const int16_t *tmp; Loc src; int sstride, w, h, mx, my, chroma, live; } Pending;
 
 static __thread struct Recon {
-    int init, plain, failed, irap_on_host;
+    int init, plain, failed, irap_on_host, split_intra;
     HEVCContext *s;
     int on;                             /* the open picture is reconstructed on the device */
     int bd, px;
@@ -366,7 +366,20 @@ static void rec_tu(uint8_t *dst, const int16_t *samples, ptrdiff_t stride, int l
     t->coef_off = R.ncoef;
     memcpy(R.coef + R.ncoef, samples, (size_t)n * sizeof(int16_t));
     R.ncoef += (size_t)n;
-    t->level = level_max(k, x, y, size, size) + 1;
+    t->fused = 0;
+    const int here = level_max(k, x, y, size, size);
+    /* the unit of the intra block predicted just before (hls_transform_unit, hevcdec.c:1002-1030 then :1238-1260: prediction, then the
+     * residual of the same block): it joins the prediction's launch (mi355_hevc_intra_recon_blocks_dev) — one level instead of two */
+    if (!R.split_intra && kind != MI355_HEVC_TU_PCM && R.nintra) {
+        IntraRec *li = &R.intra[R.nintra - 1];
+        if (li->tu < 0 && li->k == k && li->x == x && li->y == y && li->size == size && li->level == here) {
+            li->tu = R.ntu - 1;
+            t->fused = 1;
+            t->level = li->level;
+            return;
+        }
+    }
+    t->level = here + 1;
     level_set(k, x, y, size, size, t->level);
 }
 #define ADD_FN(i) \
@@ -413,6 +426,7 @@ static void rec_intra(HEVCContext *s, int x0, int y0, int c_idx, int log2)
     if (a > m) m = a;
     if (b > m) m = b;
     r->level = m + 1;
+    r->k = c_idx; r->x = x; r->y = y; r->size = size; r->tu = -1;
     level_set(c_idx, x, y, size, size, r->level);
 }
 static void intra_2(HEVCContext *s, int x0, int y0, int c) { rec_intra(s, x0, y0, c, 2); }
@@ -431,6 +445,7 @@ static void first_use(void)
      * 1920x1080 picture of 4x4 blocks is ~3700 dependency levels) — and come to the device once, finished, when a later picture
      * predicts from them (upload_surface); the filter bridge still filters them on the device */
     R.irap_on_host = getenv("MI355_HEVC_BRIDGE_IRAP_ON_HOST") != NULL;
+    R.split_intra = getenv("MI355_HEVC_BRIDGE_SPLIT_INTRA") != NULL;      /* an intra block's prediction and residual as two launches (the form before the fused kernel) */
 }
 void __wrap_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
 {
@@ -581,6 +596,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     const size_t o_mc = o;    o += ((size_t)R.nmc * sizeof(mi355_hevc_mcpred_job) + 63) & ~(size_t)63;
     const size_t o_tu = o;    o += ((size_t)R.ntu * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
     const size_t o_in = o;    o += ((size_t)R.nintra * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
+    const size_t o_fu = o;    o += ((size_t)R.nintra * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;       /* the unit of every intra block (coeffs NULL: none) */
     const size_t o_desc = o;  o += (sizeof(mi355_hevc_intra_picture) + 63) & ~(size_t)63;
     const size_t o_coef = o;  o += (R.ncoef * sizeof(int16_t) + 63) & ~(size_t)63;
     if (R.h_stage_bytes < o) {                      /* pinned: the one copy of a picture's jobs and coefficients runs at the link's rate */
@@ -604,7 +620,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     if (!start) return -1;
     int *smc = start, *stu = start + (L + 2), *sin = start + 2 * (L + 2);
     for (int i = 0; i < R.nmc; i++) smc[R.mc[i].level + 1]++;
-    for (int i = 0; i < R.ntu; i++) stu[R.tu[i].level + 1]++;
+    for (int i = 0; i < R.ntu; i++) if (!R.tu[i].fused) stu[R.tu[i].level + 1]++;
     for (int i = 0; i < R.nintra; i++) sin[R.intra[i].level + 1]++;
     for (int l = 1; l <= L + 1; l++) { smc[l] += smc[l - 1]; stu[l] += stu[l - 1]; sin[l] += sin[l - 1]; }
     mi355_edge_emu_job *je = (mi355_edge_emu_job *)(R.h_stage + o_emu);
@@ -640,6 +656,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
         memcpy(fill, stu, (size_t)(L + 2) * sizeof(int));
         for (int i = 0; i < R.ntu; i++) {
             const TuRec *t = &R.tu[i];
+            if (t->fused) continue;
             mi355_hevc_tu_job *j = &jt[fill[t->level]++];
             memset(j, 0, sizeof(*j));
             j->coeffs = (int16_t *)(R.d_stage + o_coef) + t->coef_off;
@@ -647,7 +664,19 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
             j->log2_size = (uint8_t)t->log2; j->col_limit = (uint8_t)t->col_limit; j->kind = (uint8_t)t->kind;
         }
         memcpy(fill, sin, (size_t)(L + 2) * sizeof(int));
-        for (int i = 0; i < R.nintra; i++) ji[fill[R.intra[i].level]++] = R.intra[i].b;
+        mi355_hevc_tu_job *jf = (mi355_hevc_tu_job *)(R.h_stage + o_fu);
+        for (int i = 0; i < R.nintra; i++) {
+            const int at = fill[R.intra[i].level]++;
+            ji[at] = R.intra[i].b;
+            mi355_hevc_tu_job *j = &jf[at];
+            memset(j, 0, sizeof(*j));
+            if (R.intra[i].tu >= 0) {
+                const TuRec *t = &R.tu[R.intra[i].tu];
+                j->coeffs = (int16_t *)(R.d_stage + o_coef) + t->coef_off;
+                j->dst = resolve(&t->dst); j->dst_stride = t->dstride;
+                j->log2_size = (uint8_t)t->log2; j->col_limit = (uint8_t)t->col_limit; j->kind = (uint8_t)t->kind;
+            }
+        }
         free(fill);
     }
     mi355_hevc_intra_picture *d = (mi355_hevc_intra_picture *)(R.h_stage + o_desc);
@@ -669,7 +698,11 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
         const int nm = smc[l + 1] - smc[l], nt = stu[l + 1] - stu[l], ni = sin[l + 1] - sin[l];
         if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(R.d_stage + o_mc) + smc[l], nm, R.bd, NULL) != 0) rc = -1;
         if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(R.d_stage + o_tu) + stu[l], nt, R.bd, NULL) != 0) rc = -1;
-        if (ni && mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
+        if (ni && !R.split_intra &&
+            mi355_hevc_intra_recon_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l],
+                                              (const mi355_hevc_tu_job *)(R.d_stage + o_fu) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
+        if (ni && R.split_intra &&
+            mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
         R.launches += (nm != 0) + (nt != 0) + (ni != 0);
     }
     free(start);

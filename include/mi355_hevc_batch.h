@@ -280,6 +280,12 @@ typedef struct mi355_hevc_intra_block {
 } mi355_hevc_intra_block;
 int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks, int n,
                                      int bit_depth, void *stream);
+/* The same with each block's residual behind its prediction in ONE launch — an intra transform block as hls_transform_unit runs it
+ * (hevcdec.c:1002-1030 s->hpc.intra_pred[], then :1238-1260 the transform and add_residual of the same block): d_tus[i] is the unit of
+ * d_blocks[i] (`dst` = the block's samples, as for mi355_hevc_residual_batch_dev), `coeffs` NULL for a block that has none.  A caller
+ * that walks dependency levels (contrib/libav/mi355_hevc_bridge.c) issues one launch per level instead of two. */
+int mi355_hevc_intra_recon_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
+                                      const mi355_hevc_tu_job *d_tus, int n, int bit_depth, void *stream);
 
 #ifdef __cplusplus
 }

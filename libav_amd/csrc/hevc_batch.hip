@@ -15,13 +15,9 @@ using namespace mi355;
 namespace {
 
 /* ---- transform units: two per wavefront (a 32-point transform occupies 32 lanes) ---------------------- */
-__global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_job *jobs, int n, int bd)
+/* one transform unit on a half wave (`half`, lanes hl = 0..31); `on`: this half has a unit.  Every lane of the wave walks through every barrier. */
+__device__ __forceinline__ void hevc_residual_run(IdctScratch &s, mi355_hevc_tu_job j, const bool on, const int half, const int hl, const int bd)
 {
-    __shared__ IdctScratch s;
-    const int lane = lane_id(), half = lane >> 5, hl = lane & 31;
-    const int idx = 2 * (int)blockIdx.x + half;
-    const bool on = idx < n;
-    mi355_hevc_tu_job j = jobs[on ? idx : 0];
     j.coeffs = mi355_global_v(j.coeffs); j.dst = mi355_global_v(j.dst);
     const int size = 1 << j.log2_size, cnt = size * size;
     int16_t *c = s.c[half];
@@ -90,6 +86,15 @@ __global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_
             *p = (uint16_t)((o & 0xFFu) | ((o >> 8) & 0xFF00u));
         }
     }
+}
+
+__global__ void __launch_bounds__(64) k_hevc_residual_batch(const mi355_hevc_tu_job *jobs, int n, int bd)
+{
+    __shared__ IdctScratch s;
+    const int lane = lane_id(), half = lane >> 5, hl = lane & 31;
+    const int idx = 2 * (int)blockIdx.x + half;
+    const bool on = idx < n;
+    hevc_residual_run(s, jobs[on ? idx : 0], on, half, hl, bd);
 }
 
 /* ---- motion compensation ----------------------------------------------------------------------------- */
@@ -733,11 +738,8 @@ struct IntraWrapLds {
 };
 static_assert(sizeof(mi355_hevc_intra_picture) == 104 && sizeof(mi355_hevc_intra_block) == 12, "descriptor layout (tests/hevc_intra_cases.py)");
 
-__global__ void __launch_bounds__(64) k_hevc_intra_blocks(const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks, int n_blocks, int bd)
+__device__ __forceinline__ void hevc_intra_block_run(IntraWrapLds &s, const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block b, const int bd)
 {
-    __shared__ IntraWrapLds s;
-    if ((int)blockIdx.x >= n_blocks) return;
-    const mi355_hevc_intra_block b = mi355_global_v(blocks)[blockIdx.x];
     const mi355_hevc_intra_picture p = mi355_global_v(pics)[b.pic];
     const int lane = lane_id();
     const int c = b.c_idx, hs = c ? p.hshift : 0, vs = c ? p.vshift : 0;
@@ -876,6 +878,30 @@ __global__ void __launch_bounds__(64) k_hevc_intra_blocks(const mi355_hevc_intra
     hevc_pred_wave(s.pred, org, st, log2, mode == 0 ? 0 : mode == 1 ? 1 : 2, c, mode, bd);
 }
 
+__global__ void __launch_bounds__(64) k_hevc_intra_blocks(const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks, int n_blocks, int bd)
+{
+    __shared__ IntraWrapLds s;
+    if ((int)blockIdx.x >= n_blocks) return;
+    hevc_intra_block_run(s, pics, mi355_global_v(blocks)[blockIdx.x], bd);
+}
+
+/* An intra transform block as the reference's hls_transform_unit runs it (hevcdec.c:1002-1030, :1238-1260): the prediction of the
+ * block, then its residual on the samples just predicted — one launch per dependency level instead of two.  tus[i] belongs to
+ * blocks[i] (coeffs NULL: a block without residual); the unit runs on the wave's first half. */
+__global__ void __launch_bounds__(64) k_hevc_intra_recon_blocks(const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks,
+                                                                const mi355_hevc_tu_job *tus, int n_blocks, int bd)
+{
+    __shared__ IntraWrapLds s;
+    __shared__ IdctScratch t;
+    if ((int)blockIdx.x >= n_blocks) return;
+    hevc_intra_block_run(s, pics, mi355_global_v(blocks)[blockIdx.x], bd);
+    const mi355_hevc_tu_job j = mi355_global_v(tus)[blockIdx.x];
+    if (!j.coeffs) return;
+    __syncthreads();            /* workgroup-scope release / acquire: the prediction's stores are what the residual's loads of the same samples see */
+    const int lane = lane_id();
+    hevc_residual_run(t, j, lane < 32, lane >> 5, lane & 31, bd);
+}
+
 bool check(int bit_depth, const void *jobs, int n)
 {
     /* bind(): the calling thread's device (mi355_set_device, else mi355_init's) — not whatever device the thread last used */
@@ -891,6 +917,13 @@ extern "C" int mi355_hevc_residual_batch_dev(const mi355_hevc_tu_job *d_jobs, in
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
     hipLaunchKernelGGL(k_hevc_residual_batch, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_intra_recon_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
+                                                 const mi355_hevc_tu_job *d_tus, int n, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_blocks, n) || !d_pics || !d_tus) return -1;
+    hipLaunchKernelGGL(k_hevc_intra_recon_blocks, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_pics, d_blocks, d_tus, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, int bit_depth, void *stream)

@@ -172,8 +172,16 @@ def run_host(fn, name):
     return [p.copy() for p in c.planes], c
 
 
-def run_device(lib, name, npics=1):
-    """the product: everything on the device, one call per launch group covering all pictures"""
+class TuJob(C.Structure):                 # mi355_hevc_tu_job (include/mi355_hevc_batch.h)
+    _fields_ = [("coeffs", C.c_void_p), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("log2_size", C.c_uint8),
+                ("col_limit", C.c_uint8), ("kind", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+def run_device(lib, name, npics=1, residual=None):
+    """the product: everything on the device, one call per launch group covering all pictures.
+    residual: None = predictions only; "split" = every group's predictions, then the transform units of its blocks
+    (mi355_hevc_residual_batch_dev); "fused" = both in one launch per group (mi355_hevc_intra_recon_blocks_dev).  Units: random
+    coefficients, kinds idct / idct_dc / bypass (4x4 luma also dst / skip), about a third of the blocks without one."""
     c = Case(name)
     lib.mi355_malloc.restype = C.c_void_p
     lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -210,8 +218,47 @@ def run_device(lib, name, npics=1):
         spans.append((pos, len(g) * npics))
         pos += len(g) * npics
     d_blocks = up(np.frombuffer(b"".join(chunks), np.uint8))
+    if residual:
+        assert C.sizeof(TuJob) == 24
+        r = SplitMix64(0x7E51D + sum(map(ord, name)))
+        total = sum(cnt for _, cnt in spans)
+        coef = r.randint(-400, 400, (total, 1024)).astype(np.int16)
+        coef[r.uniform(total) < 0.5, 16:] = 0                        # sparse units too
+        d_coef = up(coef)
+        tus = (TuJob * total)()
+        k = 0
+        for g in c.launches:
+            for i in range(npics):
+                for b in g:
+                    x0, y0, l2, c_idx, _, _ = c.blocks[b]
+                    sh = 1 if c_idx else 0
+                    px = 2 if c.bd > 8 else 1
+                    stride = c.planes[c_idx].shape[1]
+                    dst = planes_dev[i][c_idx] + stride + (y0 >> sh) * stride + (x0 >> sh) * px
+                    kinds = [0, 1, 4] + ([2, 3] if l2 == 2 and c_idx == 0 else [])     # MI355_HEVC_TU_IDCT, _IDCT_DC, _BYPASS, _DST4, _SKIP
+                    kind = kinds[int(r.randint(0, len(kinds) - 1))]
+                    has = r.uniform() < 0.7
+                    tus[k] = TuJob(d_coef + k * 2048 if has else None, dst, stride, l2, int(r.randint(1, 1 << l2)), kind, 0)
+                    k += 1
+        d_tus = up(np.frombuffer(bytes(tus), np.uint8))
+        fused = lib.mi355_hevc_intra_recon_blocks_dev
+        fused.restype = C.c_int
+        fused.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        res = lib.mi355_hevc_residual_batch_dev
+        res.restype = C.c_int
+        res.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     for start, cnt in spans:
+        if residual == "fused":
+            assert fused(d_desc, d_blocks + start * C.sizeof(IntraBlock), d_tus + start * 24, cnt, c.bd, None) == 0
+            continue
         assert fn(d_desc, d_blocks + start * C.sizeof(IntraBlock), cnt, c.bd, None) == 0
+        if residual == "split":
+            # the units that exist, packed (the batch entry point takes no empty jobs)
+            live = [tus[j] for j in range(start, start + cnt) if tus[j].coeffs]
+            if live:
+                arr = (TuJob * len(live))(*live)
+                d_live = up(np.frombuffer(bytes(arr), np.uint8))
+                assert res(d_live, len(live), c.bd, None) == 0
     assert lib.mi355_sync(None) == 0
     outs = []
     for i in range(npics):

@@ -46,3 +46,15 @@ def test_hevc_bridge_random_access_pictures_on_the_host_emulated(tmp_path, emu, 
     assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n - 1 and st["pictures_filtered_on_device"] == n, st
     assert st["reference_uploads"] == 1, st
     HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", ["i_ctb64", "pb_tiles_dep", "i_pcm_lf_off_10bit"])
+def test_hevc_bridge_intra_blocks_with_their_residual_in_one_launch_emulated(tmp_path, emu, name):
+    """the default: an intra block's transform unit rides in the launch of its prediction (mi355_hevc_intra_recon_blocks_dev) — fewer
+    dependency levels and launches than MI355_HEVC_BRIDGE_SPLIT_INTRA=1 (the two-launch form), the same pictures"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    fused = HS.run_bridge("hevc_bridge_emu", name, tmp_path / "f.yuv")
+    HS.check_md5(tmp_path / "f.yuv", name)
+    split = HS.run_bridge("hevc_bridge_emu", name, tmp_path / "s.yuv", split_intra=True)
+    HS.check_md5(tmp_path / "s.yuv", name)
+    assert fused["dependency_levels"] < split["dependency_levels"] and fused["reconstruction_launches"] < split["reconstruction_launches"], (fused, split)

@@ -41,3 +41,14 @@ def test_hevc_bridge_random_access_pictures_on_the_host_gpu(tmp_path, mi355, nam
     assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n - 1 and st["pictures_filtered_on_device"] == n, st
     assert st["reference_uploads"] == 1, st
     HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name", ["i_ctb64", "pb_tiles_dep", "pb_1080p_few_intra"])
+def test_hevc_bridge_two_launch_form_of_intra_blocks_gpu(tmp_path, mi355, name):
+    """MI355_HEVC_BRIDGE_SPLIT_INTRA=1: prediction and residual of an intra block as two launches (the default fuses them,
+    mi355_hevc_intra_recon_blocks_dev: the test above) — the same pictures from more dependency levels"""
+    out = tmp_path / "o.yuv"
+    split = HS.run_bridge("hevc_bridge_gpu", name, out, split_intra=True)
+    HS.check_md5(out, name)
+    fused = HS.run_bridge("hevc_bridge_gpu", name, tmp_path / "f.yuv")
+    assert fused["dependency_levels"] < split["dependency_levels"], (fused, split)

@@ -20,3 +20,14 @@ def test_intra_pred_blocks_gpu(mi355, oracle, name):
         for c in range(3):
             assert np.array_equal(want[c], got[c]), "%s: plane %d differs (%d bytes)" % (name, c, int((want[c] != got[c]).sum()))
         assert digest(got) == json.load(open(GOLD))[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(IC.CASES))
+def test_intra_blocks_with_their_residual_in_one_launch_gpu(mi355, name):
+    """prediction + the block's transform unit in one launch (mi355_hevc_intra_recon_blocks_dev) = the two launches it replaces"""
+    split, _ = IC.run_device(mi355.lib, name, npics=2, residual="split")
+    fused, _ = IC.run_device(mi355.lib, name, npics=2, residual="fused")
+    for a, b in zip(split, fused):
+        for c in range(3):
+            assert np.array_equal(a[c], b[c]), "%s: plane %d differs (%d bytes)" % (name, c, int((a[c] != b[c]).sum()))
