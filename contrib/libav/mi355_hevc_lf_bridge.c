@@ -52,6 +52,11 @@ static __thread struct {
     mi355_hevc_bs_picture *d_bs_desc;
     const void *bs_ref;                    /* the picture the flags belong to */
     int bs_lists_set, bs_uniform, bs_slice;
+    /* the calls of ff_hevc_deblocking_boundary_strengths the picture has made so far, not yet passed on (see bs_replay) */
+    struct BsCall { uint16_t x0, y0; uint8_t log2, boundary_flags, across; } *bs_calls;
+    size_t bs_ncalls, bs_ccalls;
+    int bs_deferred;
+    unsigned long bs_calls_dropped;
     uint8_t *h_out; size_t h_out_bytes;             /* pinned bounce buffer of the picture coming back */
     int32_t ref_poc[2][16];
     unsigned long bs_pictures;
@@ -116,11 +121,35 @@ static void bs_begin(const HEVCContext *s)
     lf.bs_lists_set = 0;
     lf.bs_uniform = lf.edge_flags != NULL && !getenv("MI355_HEVC_BS_HOST");
     lf.bs_slice = -1;
+    lf.bs_ncalls = 0;
+    lf.bs_deferred = lf.bs_uniform;
     memset(lf.ref_poc, 0, sizeof(lf.ref_poc));
 }
 
+/* While a picture's strengths are expected from the device, the reference's own function is NOT run (it is a tenth of the decoder's
+ * host time next to the bridge): its calls are noted — position, size, and the three things it reads that change from block to
+ * block (lc->boundary_flags, the slice's filter-across flag, the slice's list through s->ref->refPicList) — and run only if the
+ * picture turns out to need the host's strengths (a slice with other lists than the first).  Everything else the function reads
+ * (tab_mvf, cbf_luma, the per-CTB list table behind ff_hevc_get_ref_list) stays as it is until the picture ends. */
+static void bs_replay(HEVCContext *s)
+{
+    HEVCLocalContext *lc = &s->HEVClc;
+    const int flags = lc->boundary_flags, across = s->sh.slice_loop_filter_across_slices_enabled_flag;
+    RefPicList *const rpl = s->ref->refPicList;
+    for (size_t i = 0; i < lf.bs_ncalls; i++) {
+        const struct BsCall *c = &lf.bs_calls[i];
+        lc->boundary_flags = c->boundary_flags;
+        s->sh.slice_loop_filter_across_slices_enabled_flag = c->across;
+        s->ref->refPicList = ff_hevc_get_ref_list(s, s->ref, c->x0, c->y0);
+        __real_ff_hevc_deblocking_boundary_strengths(s, c->x0, c->y0, c->log2);
+    }
+    lc->boundary_flags = flags; s->sh.slice_loop_filter_across_slices_enabled_flag = across; s->ref->refPicList = rpl;
+    lf.bs_ncalls = 0;
+    lf.bs_deferred = 0;
+}
+
 /* a new slice: its reference lists must be the picture's for the device to rate motion edges with one list table */
-static void bs_slice_lists(const HEVCContext *s)
+static void bs_slice_lists(HEVCContext *s)
 {
     if (!lf.bs_uniform || lf.bs_slice == (int)s->sh.slice_addr) return;
     lf.bs_slice = (int)s->sh.slice_addr;
@@ -130,20 +159,26 @@ static void bs_slice_lists(const HEVCContext *s)
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < s->ref->refPicList[l].nb_refs && i < 16; i++) now[l][i] = s->ref->refPicList[l].list[i];
         if (!lf.bs_lists_set) { memcpy(lf.ref_poc, now, sizeof(now)); lf.bs_lists_set = 1; }
-        else if (memcmp(lf.ref_poc, now, sizeof(now))) lf.bs_uniform = 0;
+        else if (memcmp(lf.ref_poc, now, sizeof(now))) { lf.bs_uniform = 0; if (lf.bs_deferred) bs_replay(s); }
     }
 }
 
 void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
 {
-    __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size);
-    if (!active(s)) return;
+    if (!active(s)) { __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size); return; }
     if (lf.bs_ref != s->ref) bs_begin(s);
-    if (!lf.bs_uniform) return;
+    if (lf.bs_uniform) bs_slice_lists(s);                            /* may find other lists: runs the calls noted so far */
+    if (!lf.bs_uniform) { __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size); return; }
     const HEVCSPS *sps = s->ps.sps;
     const HEVCLocalContext *lc = &s->HEVClc;
-    bs_slice_lists(s);
-    if (!lf.bs_uniform) return;
+    if (lf.bs_ncalls == lf.bs_ccalls) {
+        const size_t c = lf.bs_ccalls ? 2 * lf.bs_ccalls : 4096;
+        struct BsCall *q = realloc(lf.bs_calls, c * sizeof(*q));
+        if (!q) { lf.bs_uniform = 0; bs_replay(s); __real_ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size); return; }
+        lf.bs_calls = q; lf.bs_ccalls = c;
+    }
+    lf.bs_calls[lf.bs_ncalls++] = (struct BsCall){ (uint16_t)x0, (uint16_t)y0, (uint8_t)log2_trafo_size, (uint8_t)lc->boundary_flags,
+                                                   (uint8_t)s->sh.slice_loop_filter_across_slices_enabled_flag };
     const int size = 1 << log2_trafo_size, cw = sps->width >> 2, ctb_mask = (1 << sps->log2_ctb_size) - 1;
     const int inner = log2_trafo_size > sps->log2_min_pu_size &&
                       !s->ref->tab_mvf[(y0 >> sps->log2_min_pu_size) * sps->min_pu_width + (x0 >> sps->log2_min_pu_size)].is_intra;
@@ -167,7 +202,7 @@ void __wrap_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0
 }
 
 /* -> 1: vertical_bs / horizontal_bs of the picture were derived on the device (lf.vbs / lf.hbs hold them) */
-static int bs_on_device(HEVCContext *s, size_t bs_bytes)
+static int bs_on_device_try(HEVCContext *s, size_t bs_bytes)
 {
     const HEVCSPS *sps = s->ps.sps;
     if (lf.bs_ref != s->ref) bs_begin(s);                           /* no slice of the picture is deblocked: no edge marked */
@@ -194,6 +229,14 @@ static int bs_on_device(HEVCContext *s, size_t bs_bytes)
     if (mi355_hevc_boundary_strengths_dev(lf.d_bs_desc, 1, sps->width, sps->height, lf.stream) != 0) return 0;
     lf.bs_pictures++;
     return 1;
+}
+
+static int bs_on_device(HEVCContext *s, size_t bs_bytes)
+{
+    const int done = bs_on_device_try(s, bs_bytes);
+    if (!done && lf.bs_deferred) bs_replay(s);                      /* the host's strengths after all: the calls noted, now */
+    else if (done) lf.bs_calls_dropped += lf.bs_ncalls;
+    return done;
 }
 
 /* The pieces of sao_filter_CTB for every CTB of the picture.  Piece k of CTB (cx, cy) belongs to the CTB at

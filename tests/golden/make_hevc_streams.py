@@ -240,7 +240,7 @@ def scan_tables(log2, scan_idx):
 class Hevc:
     def __init__(self, name, seed, w=96, h=64, bd=8, log2_ctb=5, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, depth_intra=2,
                  depth_inter=2, sao=1, dbf_off=0, dbf_offsets=(0, 0), strong=1, qp=30, qp_delta=0, tskip=0, bypass=0, slices=1,
-                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3, tiles=None, across_tiles=1, tile_sizes=None, pyramid=0, wpp=0, dep=0):
+                 pictures=2, cb_off=0, cr_off=0, amp=1, inter=0, weighted=0, cip=0, density=0.35, scaling=0, across=1, sdh=0, pcm=0, pcm_lf_off=0, intra_frac=0.3, tiles=None, across_tiles=1, tile_sizes=None, pyramid=0, wpp=0, dep=0, vary_refs=0):
         self.__dict__.update(locals())
         self.rng = random.Random(seed)
         self.tables = load_tables()
@@ -422,9 +422,15 @@ class Hevc:
             b.u(1, sao_l); b.u(1, sao_c)
         if not idr:
             b.u(1, 1)                                                # num_ref_idx_active_override
-            b.ue(self.nrefs - 1)
+            if self.vary_refs:
+                # every slice its own number of active references: the slices of a picture then use DIFFERENT lists (what the filter
+                # bridge's one-table-per-picture boundary-strength pass cannot rate: it must fall back to the decoder's strengths)
+                self.nact = r.randrange(1, self.nrefs + 1)
+            else:
+                self.nact = self.nrefs
+            b.ue(self.nact - 1)
             if self.stype == 0:
-                b.ue(self.nrefs - 1)
+                b.ue(self.nact - 1)
                 b.u(1, 0)                                            # mvd_l1_zero_flag
             if self.weighted:
                 self.pred_weights(b)
@@ -519,13 +525,13 @@ class Hevc:
         b.ue(ld)                                                     # luma_log2_weight_denom
         b.se(cd - ld)                                                # delta_chroma_log2_weight_denom
         for _l in range(2 if self.stype == 0 else 1):
-            lf = [r.randrange(2) for _ in range(self.nrefs)]
-            cf = [r.randrange(2) for _ in range(self.nrefs)]
+            lf = [r.randrange(2) for _ in range(self.nact)]
+            cf = [r.randrange(2) for _ in range(self.nact)]
             for f in lf:
                 b.u(1, f)
             for f in cf:
                 b.u(1, f)
-            for i in range(self.nrefs):
+            for i in range(self.nact):
                 if lf[i]:
                     b.se(r.randrange(-20, 21)); b.se(r.randrange(-30, 31))
                 if cf[i]:
@@ -761,9 +767,9 @@ class Hevc:
         for lst in (0, 1):
             if (lst == 0 and idc == 1) or (lst == 1 and idc == 0):
                 continue
-            if self.nrefs > 1:
-                ri = r.randrange(self.nrefs)
-                mx = self.nrefs - 1
+            if self.nact > 1:
+                ri = r.randrange(self.nact)
+                mx = self.nact - 1
                 for k in range(min(mx, 2)):
                     c.enc(REF_L0, k, 1 if ri > k else 0)
                     if ri <= k:
@@ -1108,6 +1114,9 @@ STREAMS = {
     "pb_dep_slices": dict(seed=49, dep=1, slices=5, inter=1, pictures=4, w=136, h=104, sao=2, across=0, qp_delta=1),
     "pb_tiles_dep": dict(seed=50, dep=1, slices=3, tiles=(2, 2), across_tiles=0, across=0, inter=1, pictures=4, log2_ctb=4, log2_max_tb=4, w=104, h=88, sao=2),
     "pb_9bit": dict(seed=51, bd=9, inter=1, pictures=4, w=112, h=80, sao=2, weighted=1, pcm=1, tskip=1, qp_delta=1),
+    # every slice with its own number of active references: the slices of a picture use different lists (the filter bridge must take the
+    # decoder's boundary strengths for such pictures: the calls it had put aside are run then)
+    "pb_slices_own_lists": dict(seed=52, inter=1, pictures=6, slices=4, vary_refs=1, sao=2, w=136, h=104, weighted=1, across=0),
     "pb_480p_ctb64": dict(seed=31, inter=1, pictures=4, log2_ctb=6, w=832, h=480, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_ctb64": dict(seed=32, inter=1, pictures=5, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2),
     "pb_1080p_few_intra": dict(seed=33, inter=1, pictures=6, log2_ctb=6, w=1920, h=1080, depth_inter=1, depth_intra=2, sao=2, intra_frac=0.02),

@@ -17,7 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 MD5 = json.load(open(os.path.join(GOLD, "hevc_streams.json")))
 ALL = sorted(MD5)
-EMU = [n for n in ALL if not n.startswith("pb_1080p")]        # the SIMT emulator takes half a minute per pass over the 1080p stream: GPU tests only
+EMU = [n for n in ALL if not n.startswith("pb_1080p")]
+# pictures whose slices use different reference lists: the filter bridge takes the decoder's own boundary strengths for them (the calls of
+# ff_hevc_deblocking_boundary_strengths it had put aside are run when the second list set shows up)
+MIXED_LISTS = {"pb_slices_own_lists"}        # the SIMT emulator takes half a minute per pass over the 1080p stream: GPU tests only
 
 
 def samples(name):
@@ -46,7 +49,10 @@ def run_tier1(which, name, out, plain=False, lf_plain=False, intra_device=False)
     if intra_device:
         return int(re.search(r"(\d+) intra blocks predicted by the batched wrapper", lines[0]).group(1))
     lf = re.search(r"(\d+) pictures deblocked per picture \((\d+) with strengths from the device\)", lines[0])
-    assert lf.group(1) == lf.group(2), lines[0]
+    if name in MIXED_LISTS and int(lf.group(1)):
+        assert 0 < int(lf.group(2)) < int(lf.group(1)), lines[0]
+    else:
+        assert lf.group(1) == lf.group(2), lines[0]
     return int(re.search(r"\((\d+) entries replaced\)", lines[0]).group(1)), int(lf.group(1))
 
 
