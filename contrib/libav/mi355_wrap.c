@@ -48,6 +48,18 @@ static int hooks_on(void)
     }
     return state > 0;
 }
+/* MI355_TIER1_SKIP=h264dsp,qpel,chroma,pred,videodsp,hevcdsp,hevcpred: leave the named tables to the reference (finding which table a
+ * difference comes from) */
+static int skipped(const char *table)
+{
+    const char *e = getenv("MI355_TIER1_SKIP"), *p = e ? strstr(e, table) : NULL;
+    const size_t n = strlen(table);
+    while (p) {
+        if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return 1;
+        p = strstr(p + 1, table);
+    }
+    return 0;
+}
 static void count(const void *before, const void *after, size_t bytes)
 {
     const void *const *a = before, *const *b = after;
@@ -66,7 +78,7 @@ void __wrap_ff_h264dsp_init(H264DSPContext *c, const int bit_depth, const int ch
 {
     __real_ff_h264dsp_init(c, bit_depth, chroma_format_idc);
     const H264DSPContext was = *c;
-    if (hooks_on()) ff_h264dsp_init_mi355x(c, bit_depth, chroma_format_idc);
+    if (hooks_on() && !skipped("h264dsp")) ff_h264dsp_init_mi355x(c, bit_depth, chroma_format_idc);
     count(&was, c, sizeof(was));
 }
 void __real_ff_h264qpel_init(H264QpelContext *c, int bit_depth);
@@ -74,7 +86,7 @@ void __wrap_ff_h264qpel_init(H264QpelContext *c, int bit_depth)
 {
     __real_ff_h264qpel_init(c, bit_depth);
     const H264QpelContext was = *c;
-    if (hooks_on()) ff_h264qpel_init_mi355x(c, bit_depth);
+    if (hooks_on() && !skipped("qpel")) ff_h264qpel_init_mi355x(c, bit_depth);
     count(&was, c, sizeof(was));
 }
 void __real_ff_h264chroma_init(H264ChromaContext *c, int bit_depth);
@@ -82,7 +94,7 @@ void __wrap_ff_h264chroma_init(H264ChromaContext *c, int bit_depth)
 {
     __real_ff_h264chroma_init(c, bit_depth);
     const H264ChromaContext was = *c;
-    if (hooks_on()) ff_h264chroma_init_mi355x(c, bit_depth);
+    if (hooks_on() && !skipped("chroma")) ff_h264chroma_init_mi355x(c, bit_depth);
     count(&was, c, sizeof(was));
 }
 void __real_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_depth, const int chroma_format_idc);
@@ -90,7 +102,7 @@ void __wrap_ff_h264_pred_init(H264PredContext *h, int codec_id, const int bit_de
 {
     __real_ff_h264_pred_init(h, codec_id, bit_depth, chroma_format_idc);
     const H264PredContext was = *h;
-    if (hooks_on()) ff_h264_pred_init_mi355x(h, codec_id, bit_depth, chroma_format_idc);
+    if (hooks_on() && !skipped("pred")) ff_h264_pred_init_mi355x(h, codec_id, bit_depth, chroma_format_idc);
     count(&was, h, sizeof(was));
 }
 #endif
@@ -101,7 +113,7 @@ void __wrap_ff_videodsp_init(VideoDSPContext *ctx, int bpc)
 {
     __real_ff_videodsp_init(ctx, bpc);
     const VideoDSPContext was = *ctx;
-    if (hooks_on()) ff_videodsp_init_mi355x(ctx, bpc);
+    if (hooks_on() && !skipped("videodsp")) ff_videodsp_init_mi355x(ctx, bpc);
     count(&was, ctx, sizeof(was));
 }
 #endif
@@ -112,7 +124,7 @@ void __wrap_ff_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
 {
     __real_ff_hevc_dsp_init(c, bit_depth);
     const HEVCDSPContext was = *c;
-    if (hooks_on()) ff_hevc_dsp_init_mi355x(c, bit_depth);
+    if (hooks_on() && !skipped("hevcdsp")) ff_hevc_dsp_init_mi355x(c, bit_depth);
     count(&was, c, sizeof(was));
 }
 #ifndef MI355_WRAP_HEVC_NO_PRED
@@ -121,7 +133,7 @@ void __wrap_ff_hevc_pred_init(HEVCPredContext *c, int bit_depth)
 {
     __real_ff_hevc_pred_init(c, bit_depth);
     const HEVCPredContext was = *c;
-    if (hooks_on()) ff_hevc_pred_init_mi355x(c, bit_depth);
+    if (hooks_on() && !skipped("hevcpred")) ff_hevc_pred_init_mi355x(c, bit_depth);
     count(&was, c, sizeof(was));
 }
 #endif
