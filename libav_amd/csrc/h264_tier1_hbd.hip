@@ -35,8 +35,13 @@ k_hbd_qpel(const px *win, int wp, px *dst, int dp, int size, int mx, int my, int
         auto rawh = [&](int xx, int yy) { return tap6(S(xx - 2, yy), S(xx - 1, yy), S(xx, yy), S(xx + 1, yy), S(xx + 2, yy), S(xx + 3, yy)); };
         auto hh = [&](int xx, int yy) { return clip3((rawh(xx, yy) + 16) >> 5, 0, maxv); };
         auto vv = [&](int xx, int yy) { return clip3((tap6(S(xx, yy - 2), S(xx, yy - 1), S(xx, yy), S(xx, yy + 1), S(xx, yy + 2), S(xx, yy + 3)) + 16) >> 5, 0, maxv); };
+        /* the reference keeps the first pass of the 2-D positions in int16_t, biased by `pad` at 10 bit (h264qpel_template.c:119-146):
+         * samples inside the bit depth's range fit, samples outside it (planes of transform-bypass streams, whose residual adds do
+         * not clip) wrap — and so does this */
+        const int pad = maxv > 511 ? -10 * maxv : 0;
+        auto tmph = [&](int xx, int yy) { return (int)(int16_t)(rawh(xx, yy) + pad) - pad; };
         auto hv = [&](int xx, int yy) {
-            return clip3((tap6(rawh(xx, yy - 2), rawh(xx, yy - 1), rawh(xx, yy), rawh(xx, yy + 1), rawh(xx, yy + 2), rawh(xx, yy + 3)) + 512) >> 10, 0, maxv);
+            return clip3((tap6(tmph(xx, yy - 2), tmph(xx, yy - 1), tmph(xx, yy), tmph(xx, yy + 1), tmph(xx, yy + 2), tmph(xx, yy + 3)) + 512) >> 10, 0, maxv);
         };
         int v;
         if (my == 0) v = mx == 0 ? S(x, y) : (mx == 2 ? hh(x, y) : f2(S(x + (mx == 3), y), hh(x, y)));

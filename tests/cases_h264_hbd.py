@@ -227,15 +227,21 @@ def cases_loopfilter(c, r, out, bd, idc=1):
 # ------------------------------------------------------------------ qpel / chroma / videodsp
 def cases_qpel(q, r, out, bd):
     mx = (1 << bd) - 1
+    r2 = SplitMix64(0x0b7 + bd)          # its own stream for the out-of-range repetitions: the cases before them keep their values
     for tabname, tab, nsz in (("put", q.put_h264_qpel_pixels_tab, 4), ("avg", q.avg_h264_qpel_pixels_tab, 3)):
         for si in range(nsz):
             size = 16 >> si
             for pos in range(16):
                 fn = tab[si][pos]
-                for rep in range(3):
+                for rep in range(5):
                     stride = 32
                     if rep == 0:
                         src = pix(r, (32, stride), bd)
+                    elif rep >= 3:
+                        # samples OUTSIDE the bit depth's range (transform-bypass streams leave them in a plane: add_pixels does not
+                        # clip): the reference keeps the first pass of the 2-D positions in int16_t (+ the 10-bit bias) and wraps,
+                        # h264qpel_template.c:119-146.  rep 3: a few times the largest value, rep 4: any 16-bit value
+                        src = r2.randint(0, 4 * mx + 3 if rep == 3 else 65535, (32, stride)).astype(np.uint16)
                     elif rep == 1:
                         src = edge_pixels(r, (32, stride), 1, 11, bd)
                     else:
@@ -244,7 +250,7 @@ def cases_qpel(q, r, out, bd):
                         hi = np.tile(np.array([mx, 0, mx, mx, 0, mx], np.int64), 6)[:32]
                         rows = [hi, mx - hi, hi, hi, mx - hi, hi]
                         src = np.stack([np.roll(rows[(y + pos) % 6], pos % 6) for y in range(32)]).astype(np.uint16)
-                    dst = pix(r, (32, stride), bd)
+                    dst = pix(r if rep < 3 else r2, (32, stride), bd)
                     keep = src.copy()
                     if not fn:
                         continue
