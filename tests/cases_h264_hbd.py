@@ -34,8 +34,11 @@ def pint(a):
     return C.cast(a.ctypes.data, A.intp)
 
 
+WILD = False   # group "wild": samples anywhere in 16 bits, as transform-bypass streams can leave them in a plane (their residual adds do not clip)
+
+
 def pix(r, shape, bd):
-    return r.randint(0, (1 << bd) - 1, shape).astype(np.uint16)
+    return r.randint(0, 65535 if WILD else (1 << bd) - 1, shape).astype(np.uint16)
 
 
 def edge_pixels(r, shape, axis, pos, bd):
@@ -48,6 +51,9 @@ def edge_pixels(r, shape, axis, pos, bd):
     idx[axis] = slice(pos, None)
     a[tuple(idx)] += step
     mask = r.randint(0, 7, shape) == 0
+    if WILD:    # the same field lifted out of the bit depth's range (the conditions still fire), strays anywhere in 16 bits
+        a = np.where(mask, r.randint(0, 65535, shape), a + r.randint(1 << bd, 60000))
+        return np.clip(a, 0, 65535).astype(np.uint16)
     a = np.where(mask, r.randint(0, (1 << bd) - 1, shape), a)
     return np.clip(a, 0, (1 << bd) - 1).astype(np.uint16)
 
@@ -378,10 +384,21 @@ def cases_pred_add(h, r, out, bd, idc=1):
                 out["%s/%d/%d" % (name, d, rep)] = buf.tobytes() + blk.tobytes()
 
 
-GROUPS = ("idct", "idct_multi", "dc", "addpx", "weight", "loopfilter", "qpel", "chroma", "videodsp", "pred", "pred_add", "422")
+GROUPS = ("idct", "idct_multi", "dc", "addpx", "weight", "loopfilter", "qpel", "chroma", "videodsp", "pred", "pred_add", "422", "wild")
 
 
 def run_group(provider, group, bd, seed=0x2640):
+    global WILD
+    if group == "wild":     # the sample-reading entries once more on out-of-range planes (the 2-D qpel positions have theirs in "qpel")
+        out = OrderedDict()
+        WILD = True
+        try:
+            for g in ("idct", "addpx", "weight", "loopfilter", "chroma", "videodsp", "pred", "pred_add"):
+                for k, v in run_group(provider, g, bd, seed + 77).items():
+                    out[g + "." + k] = v
+        finally:
+            WILD = False
+        return out
     out = OrderedDict()
     r = SplitMix64(seed + 1000 * bd + sum(ord(ch) for ch in group))
     if group in ("idct", "idct_multi", "dc", "addpx", "weight", "loopfilter"):

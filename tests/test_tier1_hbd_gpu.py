@@ -11,8 +11,14 @@ from test_tier1_hbd_emu import GOLD
 pytestmark = pytest.mark.gpu
 
 
+# "wild" (every sample-reading entry on planes outside the bit depth's range) was written after the round's GPU minutes were spent: identical to
+# the reference on the emulator, never yet run on hardware -> recorded as x / X by the first GPU run instead of stopping it; drop the mark after that.
+_GROUPS = [pytest.param(g, marks=pytest.mark.xfail(strict=False, reason="first hardware run of the out-of-range cases")) if g == "wild" else g
+           for g in HB.GROUPS]
+
+
 @pytest.mark.parametrize("bd", (9, 10))
-@pytest.mark.parametrize("group", HB.GROUPS)
+@pytest.mark.parametrize("group", _GROUPS)
 def test_hbd_tables_gpu_vs_golden(mi355, bd, group):
     gold = json.load(open(GOLD))[str(bd)]
     got = HB.run_group(mi355, group, bd)
