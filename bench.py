@@ -31,8 +31,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic bytes per macroblock: each input byte read once, each output written once
 B_RECON = 384 + 768 + 128 + 384          # reference samples + coefficients + MB record/mv + unfiltered write
-B_DEBLOCK = 384 + 384 + 64               # unfiltered read + filtered write + side info
-B_FUSED = B_RECON + B_DEBLOCK            # 2432 B/MB: the two-surface pipeline figure
+B_DEBLOCK = 384 + 384 + 64               # the loop filter alone: unfiltered read + filtered write + side info (its isolated roofline figure)
+B_FUSED = 2432                           # SURVEY.md 8(d) / DESIGN 6.1: the two-surface pipeline figure the headline fraction is quoted on
+                                         # (1664 + 768: the filter's second read of the 64-byte record is not part of the contract figure)
 HBM_PEAK = 8.0e12
 
 
@@ -67,22 +68,48 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-extra", action="store_true", help="skip the additional measured points (rank 0, N=1 only)")
+    ap.add_argument("--notes", action="store_true", help="keep the long `note` / `sample` texts of the extra points in the JSON line (without them "
+                    "the whole line stays under the 16 KB the driver's record keeps; what each point is: README.md, DESIGN.md 6)")
     ap.add_argument("--layout", choices=("tiled", "linear"), default="tiled", help="surface layout of dst / recon / reference "
                     "pictures in HBM: macroblock-tiled (the decoded-picture-buffer layout, include/mi355_h264_frame.h) or planes "
                     "with line strides (AVFrame-like)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the control plane at N>1 "
+                    "(nccl = RCCL; gloo only with --dry, for the CPU test of the launch path)")
+    ap.add_argument("--dry", action="store_true", help="control plane only: no GPU, no library; a step is a 1 ms sleep.  What the CPU test of "
+                    "`--gpus N` uses (tests/test_bench_launch.py); the line says \"dry\": true and is not a measurement")
     ap.add_argument("--queue", action="store_true", help="N>1: ranks pull step-sized batches of streams from the work queue "
                     "(libav_amd.shard.WorkQueue) instead of the static deal; a rank may then run more or fewer than --steps steps")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N ranks and not started by a launcher: start them (one process per GPU, the contract's own command line)
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, world))
+    if args.backend == "gloo" and not args.dry:
+        sys.exit("bench.py: --backend gloo is the CPU control-plane test and needs --dry")
+    ctl = "cpu" if (world == 1 or args.backend == "gloo") else "cuda"      # where the control plane's small tensors live
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    if args.dry:
+        return dry_run(args, rank, world, dist, ctl)
 
     import numpy as np
     import libav_amd
@@ -101,7 +128,7 @@ def main():
     from libav_amd import shard
     n_streams = world * F
     table = shard.make_stream_table(n_streams, 0x264) if rank == 0 else None
-    table = shard.broadcast_stream_table(table, n_streams, "cuda" if world > 1 else "cpu")
+    table = shard.broadcast_stream_table(table, n_streams, ctl)
     mine = shard.my_streams(table, rank, world)
     assert len(mine) == F
     fs = HF.synth_frames_fast(G, mbw, mbh, seed=mine[0][1], lib=lib)
@@ -165,8 +192,8 @@ def main():
     t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / max(1, my_steps)
     t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / max(1, my_steps)
 
-    elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * my_steps, "cuda" if world > 1 else "cpu")
-    steps_per_rank = shard.gather_counts(my_steps, "cuda" if world > 1 else "cpu")
+    elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * my_steps, ctl)
+    steps_per_rank = shard.gather_counts(my_steps, ctl)
     backend_world = dist.get_world_size() if dist is not None else 1
 
     if rank == 0:
@@ -210,11 +237,54 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fs, args.cpu_seconds)
         dev.free()
         dev = None
+        # every measured point's fraction of the HBM roofline as a short scalar inside `config` (the driver's record keeps
+        # `config` whole and only the NAMES of other top-level keys): headline first
+        points = {"config2_f%d" % F: round(value / world * B_FUSED / HBM_PEAK, 4)}
         if world == 1 and not args.no_extra:
             out["extra"] = extra_points(lib, prov, mbw, mbh, tiled)
+            for p in out["extra"]:
+                for key in ("fused_fraction_of_hbm_roofline", "fraction_of_hbm_roofline"):
+                    if isinstance(p.get(key), float):
+                        points[p["name"]] = round(p[key], 4)
+                for key in ("bridge", "reference_c_decoder"):                      # decoder end to end: pictures/s, bridge vs C
+                    if isinstance(p.get(key), dict) and "pictures_per_s" in p[key]:
+                        points[p["name"] + ("" if key == "bridge" else "_c")] = round(p[key]["pictures_per_s"], 1)
+            if not args.notes:
+                for p in out["extra"]:
+                    for key in ("note", "what", "sample"):
+                        p.pop(key, None)
+                    if isinstance(p.get("cpu_baseline"), dict):
+                        p["cpu_baseline"].pop("sample", None)
+        out["config"]["points"] = points
         print(json.dumps(out))
     if dev is not None:
         dev.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, dist, ctl):
+    """--dry: the launch path and the control plane of the bench with nothing behind them (CPU test of `--gpus N`)."""
+    from libav_amd import shard
+    F, nmb = args.frames, args.mb_width * args.mb_height
+    table = shard.make_stream_table(world * F, 0x264) if rank == 0 else None
+    table = shard.broadcast_stream_table(table, world * F, ctl)
+    assert len(shard.my_streams(table, rank, world)) == F
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if dist is not None:
+        dist.barrier()
+    elapsed, total = shard.reduce_counters(time.perf_counter() - t0, F * nmb * args.steps, ctl)
+    steps_per_rank = shard.gather_counts(args.steps, ctl)
+    if rank == 0:
+        print(json.dumps({"metric": "macroblocks_per_s", "value": total / elapsed, "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "rccl_world_size": dist.get_world_size() if dist is not None else 1, "steps_per_rank": steps_per_rank,
+                          "vs_baseline": None, "dtype": "u8", "data": "none", "dry": True,
+                          "config": {"workload": "DRY RUN: control plane only (%s), no kernel ran" % args.backend}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -473,6 +543,21 @@ def sws_points(lib):
     return out
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unreadable"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(fs, seconds):
     """The reference's own C functions (oracle/_ref/libref.so, kind "reference"; the scalar oracle, kind "port", where that
     object is missing) on every hardware thread of this box, one pinned thread per logical CPU, each decoding its own
@@ -524,8 +609,12 @@ def cpu_baseline(fs, seconds):
     lib.oracle_h264_bench_threads.restype = C.c_long
     lib.oracle_h264_bench_threads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
     n = lib.oracle_h264_bench_threads(C.cast(frames, C.c_void_p), nthreads, C.cast(cpu_arr, C.c_void_p), float(seconds), C.byref(wall))
-    return {"value": n * nmb / wall.value, "unit": "macroblocks/s", "cores": nthreads, "kind": kind,
+    value = n * nmb / wall.value
+    return {"value": value, "unit": "macroblocks/s", "cores": nthreads, "kind": kind,
             "value_1core": nmb / one,
+            # what the box actually delivered: the threads' aggregate over ONE thread running alone (a leased box is usually
+            # CPU-quota'd or shared: 256 pinned threads have measured 9x one core), and the cgroup's own quota where it states one
+            "effective_cores": round(value / (nmb / one), 1), "cgroup_cpu_quota_cores": cgroup_cpu_quota(),
             "sample": "%d pictures of the same workload decoded repeatedly for %.0f s on %d pinned pthreads (every logical CPU "
                       "this process may run on); %s (reference x86 SIMD not built: no nasm in the image)"
                       % (min(nthreads, fs.F), seconds, nthreads, what)}

@@ -11,10 +11,9 @@ from test_tier1_hbd_emu import GOLD
 pytestmark = pytest.mark.gpu
 
 
-# "wild" (every sample-reading entry on planes outside the bit depth's range) was written after the round's GPU minutes were spent: identical to
-# the reference on the emulator, never yet run on hardware -> recorded as x / X by the first GPU run instead of stopping it; drop the mark after that.
-_GROUPS = [pytest.param(g, marks=pytest.mark.xfail(strict=False, reason="first hardware run of the out-of-range cases")) if g == "wild" else g
-           for g in HB.GROUPS]
+# "wild" (every sample-reading entry on planes outside the bit depth's range) passed its first hardware run at the end of round 3
+# (GPUTEST_r03: 2 xpassed): a plain test now, a regression fails.
+_GROUPS = list(HB.GROUPS)
 
 
 @pytest.mark.parametrize("bd", (9, 10))

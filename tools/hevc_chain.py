@@ -220,7 +220,9 @@ class Chain:
                 npieces = npieces + have
             sao["npieces"][:, c] = npieces[None].astype(np.uint8)
         self.n_sao, self.d_sao = sao.size, self.up(sao)
-        self.ctbs = P * ((W + 63) // 64) * ((H + 63) // 64)
+        # credited units: the CTBs the chain codes COMPLETELY (prediction + residual of luma and chroma: H // 64 rows; VERDICT r3: the 34th,
+        # partial CTB row of 2160 lines gets luma blocks for its first 32 lines only and no chroma units — filtered and SAO'd, not credited)
+        self.ctbs = P * (W // 64) * (H // 64)
         lib.mi355_hevc_deblock_pictures_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 
     def alloc(self, n):
