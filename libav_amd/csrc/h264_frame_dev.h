@@ -1,0 +1,66 @@
+/*
+ * h264_frame_dev.h — small device helpers shared by the Tier-2 frame kernels (h264_frame.hip: reconstruction, surface
+ * conversion; h264_deblock.hip: the loop filter): vector typedefs, macroblock-tile addressing, 16- / 8-byte moves.
+ */
+#ifndef MI355_H264_FRAME_DEV_H
+#define MI355_H264_FRAME_DEV_H
+
+#include "mi355_rt.h"
+#include "h264_dev.h"
+#include "../../include/mi355_h264_frame.h"
+
+namespace mi355 {
+
+typedef uint32_t mi355_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t mi355_u32x2 __attribute__((vector_size(8)));
+typedef uint32_t mi355_u32x4u __attribute__((vector_size(16), aligned(4)));
+typedef uint32_t mi355_u32x2u __attribute__((vector_size(8), aligned(4)));
+
+__device__ __forceinline__ int blk_x4(int i) { return (i & 1) + 2 * ((i >> 2) & 1); }
+__device__ __forceinline__ int blk_y4(int i) { return ((i >> 1) & 1) + 2 * (i >> 3); }
+__device__ __forceinline__ int blk_index(int x4, int y4) { return (x4 & 1) + 2 * (y4 & 1) + 4 * (x4 >> 1) + 8 * (y4 >> 1); }
+
+/* macroblock-tiled surfaces (mi355_h264_frame.h): plane 0 = 256-byte luma tiles, plane 1 = 128-byte chroma tiles (Cb, Cr) */
+__device__ __forceinline__ uint32_t tile_y_off(int mb_x, int mb_y, int stride) { return (uint32_t)(__mul24(mb_y, stride) + mb_x * MI355_TILE_LUMA_BYTES); }
+__device__ __forceinline__ uint32_t tile_c_off(int mb_x, int mb_y, int stride) { return (uint32_t)(__mul24(mb_y, stride) + mb_x * MI355_TILE_CHROMA_BYTES); }
+
+/* 16 bytes of an LDS tile row (rows are 8-byte aligned: two 64-bit accesses) */
+__device__ __forceinline__ uint4 lds16(const uint8_t *p)
+{
+    const uint2 a = reinterpret_cast<const uint2 *>(p)[0], b = reinterpret_cast<const uint2 *>(p)[1];
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void lds16(uint8_t *p, uint4 v)
+{
+    reinterpret_cast<mi355_u32x2 *>(p)[0] = mi355_u32x2{ v.x, v.y };
+    reinterpret_cast<mi355_u32x2 *>(p)[1] = mi355_u32x2{ v.z, v.w };
+}
+/* 16 / 8 bytes between a picture row and an LDS tile row.  The aligned stores go through native vector types:
+ * a HIP uint4 assignment is copied component by component and came out as four dword stores. */
+__device__ __forceinline__ uint4 ld16(const uint8_t *p, bool al)
+{
+    if (al) return *reinterpret_cast<const uint4 *>(p);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void st16(uint8_t *p, uint4 v, bool al)
+{
+    if (al) { *reinterpret_cast<mi355_u32x4 *>(p) = mi355_u32x4{ v.x, v.y, v.z, v.w }; return; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+__device__ __forceinline__ uint2 ld8(const uint8_t *p, bool al)
+{
+    if (al) return *reinterpret_cast<const uint2 *>(p);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return make_uint2(w[0], w[1]);
+}
+__device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
+{
+    if (al) { *reinterpret_cast<mi355_u32x2 *>(p) = mi355_u32x2{ v.x, v.y }; return; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    w[0] = v.x; w[1] = v.y;
+}
+
+}  // namespace mi355
+#endif
