@@ -35,6 +35,7 @@ B_DEBLOCK = 384 + 384 + 64               # the loop filter alone: unfiltered rea
 B_FUSED = 2432                           # SURVEY.md 8(d) / DESIGN 6.1: the two-surface pipeline figure the headline fraction is quoted on
                                          # (1664 + 768: the filter's second read of the 64-byte record is not part of the contract figure)
 HBM_PEAK = 8.0e12
+LAYOUT_MASK = {False: 1, True: 2}        # MI355_LAYOUTS_LINEAR / MI355_LAYOUTS_TILED: the bench knows which layout its pictures have
 
 
 def level_widths(fs):
@@ -139,7 +140,7 @@ def main():
 
     for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-                          ("mi355_h264_deblock_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
                           ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
         getattr(lib, name).restype = res
@@ -155,7 +156,7 @@ def main():
         assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, big.max_intra_level, level_widths(big), stream) == 0
         if events is not None:
             lib.mi355_event_record(events[2], stream)
-        assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, stream) == 0
+        assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[tiled], stream) == 0
         if events is not None:
             lib.mi355_event_record(events[3], stream)
 
@@ -200,10 +201,9 @@ def main():
         value = total_mbs / elapsed
         n_intra = int(sum(len(big.intra_list[f % G]) for f in range(F)))
         n_inter = F * nmb - n_intra
-        nbands = (mbh + 3) // 4            # k_deblock: one launch per band of four MB rows
-        # dominant kernel = the pass with the largest share of the step
+        # dominant kernel = the pass with the largest share of the step (the loop filter is ONE launch for all bands of all pictures since round 4)
         passes = {"k_recon_inter": (t_inter, 1, n_inter * B_RECON),
-                  "k_deblock": (t_deblock, nbands, F * nmb * B_DEBLOCK)}
+                  "k_deblock_tiled" if tiled else "k_deblock_linear": (t_deblock, 1, F * nmb * B_DEBLOCK)}
         dom = max(passes, key=lambda k: passes[k][0])
         t_pass, launches, bytes_pass = passes[dom]
         achieved = bytes_pass / launches / (t_pass / launches * 1e-3)   # algorithmic bytes per launch / avg launch time
@@ -302,7 +302,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             def once():
                 assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
                 assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
-                assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
+                assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
                 if conv is not None:
                     assert lib.mi355_h264_surface_convert_dev(conv, F, mbw, mbh, None) == 0
             once()
@@ -319,7 +319,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             lib.mi355_event_record(ev[1], None)
             assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
             lib.mi355_event_record(ev[2], None)
-            assert lib.mi355_h264_deblock_dev(dev.d_desc, F, mbw, mbh, None) == 0
+            assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
             lib.mi355_event_record(ev[3], None)
             lib.mi355_sync(None)
             passes = {k: lib.mi355_event_elapsed_ms(ev[i], ev[i + 1]) for i, k in enumerate(("recon_inter", "recon_intra", "deblock"))}
@@ -341,8 +341,8 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         "quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each), one vector per partition, one reference per partition / quadrant: 5.6 prediction blocks "
         "and reference windows per macroblock on average instead of 1 (the algorithmic bytes stay 2432 per macroblock: the fraction is against the "
         "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
-    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step (loop filter in its small-batch form: several bands of a picture per workgroup, k_deblock_bands)")
-    run("config2_f512", base, 512, "512 pictures per step (small-batch loop filter form)")
+    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
+    run("config2_f512", base, 512, "512 pictures per step")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
     run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra" % intra.max_intra_level)
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)

@@ -264,6 +264,12 @@ int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int nframes, in
  * pipelined inside a workgroup (one wave each) when there are few — same pictures either way (the environment variable
  * MI355_DEBLOCK_FORM = 1 / 2 / 3 / 4 / 6 pins the number of bands per workgroup: a developer switch). */
 int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
+/* The same for a caller that knows which surface layouts occur in the batch (the descriptors live on the device: the entry point
+ * above cannot look, and launches the loop filter's kernel for each layout — the waves of the kernel whose layout a picture does
+ * not have leave at once, ~1 us per 1000 macroblock-row bands): `layouts` = MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED, or one of them. */
+#define MI355_LAYOUTS_LINEAR 1
+#define MI355_LAYOUTS_TILED  2
+int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int layouts, void *stream);
 
 /* Host helper (plain CPU bookkeeping, no sample arithmetic): write the intra schedule of one picture:
  * `list` (capacity mb_width*mb_height) receives the intra MB indices sorted by level, `level_start`

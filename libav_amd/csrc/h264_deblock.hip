@@ -854,9 +854,9 @@ __device__ __forceinline__ void deblock2_band(Deblock2Lds &s, const mi355_h264_f
     for (int t = 0; t < nsteps; t++) {
         const int mb_x = t - 2 * g, slot = mb_x & (DB2_RING - 1), lslot = (mb_x - 1) & (DB2_RING - 1);
         const bool valid = row_ok && mb_x >= 0 && mb_x < W;
-        const Pre cur = pre;
-        await_above(t + 1);
-        prefetch(pre, mb_x + 1);
+        /* `pre` holds this macroblock's loads; each part is consumed by one phase below, and the next macroblock's loads are issued once the
+         * last part is (after the vertical edges): the two sets of registers are never alive together */
+        const Pre &cur = pre;
         /* group 0: the second line / chroma tile of the macroblock above, into the ring of the band above */
         if (top_band && g == 0) {
             *reinterpret_cast<mi355_u32x2 *>(ay + slot * 256 + 128 + 8 * l) = mi355_u32x2{ cur.ay.x, cur.ay.y };
@@ -919,7 +919,11 @@ __device__ __forceinline__ void deblock2_band(Deblock2Lds &s, const mi355_h264_f
             if (d0) *reinterpret_cast<uint32_t *>(left_c + 8 * l + 4) = cl;
             *reinterpret_cast<mi355_u32x2 *>(own_c + 8 * l) = mi355_u32x2{ cw0, cw1 };
         }
+        hl = cur.h;
         MI355_WAVE_SYNC();
+        /* ---- the next macroblock's loads (behind the band above's progress, where there is one) ------------------------------------ */
+        await_above(t + 1);
+        prefetch(pre, mb_x + 1);
         /* ---- horizontal edges: one luma column + one chroma column per lane; rows -4..-1 (chroma -2, -1) are rows 12..15 (6, 7) of the
          * tile above, read and patched where it lies ------------------------------------------------------------------------- */
         {
@@ -996,7 +1000,6 @@ __device__ __forceinline__ void deblock2_band(Deblock2Lds &s, const mi355_h264_f
             const int done = t - 6 < 0 ? 0 : (t - 6 < W ? t - 6 : W);
             if (lane == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
         }
-        hl = h;
     }
     if (!TILED && hand) {
         /* planes with line strides: the band below waits for all of this one (see the head of this section) */
@@ -1005,24 +1008,390 @@ __device__ __forceinline__ void deblock2_band(Deblock2Lds &s, const mi355_h264_f
     }
 }
 
+
+/* ===================================================================================================================== */
+/* The same form for macroblock-tiled surfaces: tiles arrive by LDS-DMA                                                    */
+/* ===================================================================================================================== */
+/* deblock2_band holds a macroblock's rows in registers from the load to the vertical edges and the next macroblock's in a
+ * second set behind them: 145+ vector registers, three waves per SIMD, 59 % of the VALU's issue slots used (a wave issues one
+ * instruction of any kind per four cycles; a step is ~450 VALU among ~1050 instructions and three LDS round trips).  On tiled
+ * surfaces a macroblock is 256 + 128 contiguous bytes, so the tiles of the four groups' next macroblocks go straight from memory
+ * into the LDS ring (global_load_lds_dwordx4: no register holds a sample in flight), a whole step before they are used:
+ *   - ring[step & 3][group]: a 16-byte piece lands at base + 16 * lane, so the ring is lane-linear and unpadded; the four
+ *     groups' column accesses of the horizontal edges are kept off each other's banks by WHICH piece a lane fetches: row r
+ *     of group g's tile lives at 16 * (r ^ g) (chroma: 16-byte piece k at 16 * (k ^ g));
+ *   - the second tile line + chroma tile of the macroblock above a band arrive the same way (16 lanes, agent scope) into
+ *     above[step & 1], swizzled with 3 (= the group "above group 0");
+ *   - what a step makes final is written out at the START of the next step, right after the wait that begins it, so that wait
+ *     finds stores a whole step old and the progress counter can be published without a drain of its own;
+ *   - lane constants (boundary-strength roles, vector offsets) sit in a 768-byte LDS table and everything else derived from
+ *     the lane number is recomputed per step from an opaque lane id: hoisted out of the loop they cost 40 registers. */
+struct __attribute__((aligned(128))) Deblock3Lds {
+    uint8_t y[4][4][256];
+    uint8_t c[4][4][128];
+    uint8_t above[2][256];
+    uint32_t parm[4][9][2];
+    uint32_t role[16][12];      /* per lane of a group: BsRole r0, BsRole r1, o_p0, o_q0, o_p1, o_q1 */
+    uint8_t t_alpha[52], t_beta[52];
+    uint32_t t_tc0[52];
+};
+static_assert(sizeof(Deblock3Lds) <= 8192, "twenty waves per CU");
+
+/* sixteen bytes per lane from memory straight into LDS at lds_base + 16 * lane (lds_base wave-uniform) */
+#ifdef MI355_HIP_EMU_H
+template <bool AGENT> static inline void lds_dma16(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 16 * (threadIdx.x & 63), src, 16); }
+#else
+template <bool AGENT> __device__ __forceinline__ void lds_dma16(const uint8_t *src, uint8_t *lds_base)
+{
+    typedef __attribute__((address_space(1))) const void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)lds_base, 16, 0, AGENT ? 16 : 0);      /* aux 16 = sc1: served past the vector L1 */
+}
+#endif
+
+template <bool TWO_LISTS>
+__device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_frame &fr, int band, uint32_t *prog)
+{
+    const int W = uniform(fr.mb_width), H = uniform(fr.mb_height);
+    const bool field = uniform(fr.field_picture) != 0;
+    const uint32_t mv_far = field ? 0xFFFEFFFCu : 0xFFFCFFFCu;
+    const int rs = uniform(fr.recon_stride[0]), rcs = uniform(fr.recon_stride[1]), ds = uniform(fr.dst_stride[0]), dcs = uniform(fr.dst_stride[1]);
+    constexpr bool two_lists = TWO_LISTS;
+    const int nsteps = W + 7;
+    const bool hand = 4 * band + 4 < H;                      /* a band follows: group 3's row is handed to it */
+    const bool top_band = band > 0;
+    const int ya = top_band ? 4 * band - 1 : 0;
+    const uint8_t *const rec_base = reinterpret_cast<const uint8_t *>(mi355_global(fr.mb));
+    const uint8_t *const mv_base0 = reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[0]));
+    const uint8_t *const mv_base1 = two_lists ? reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[1])) : mv_base0;
+    const uint8_t *const recon_y0 = mi355_global(fr.recon[0]), *const recon_c0 = mi355_global(fr.recon[1]);
+    uint8_t *const dst_y0 = mi355_global(fr.dst[0]), *const dst_c0 = mi355_global(fr.dst[1]);
+    uint32_t *const prog_above = prog + (top_band ? band - 1 : 0), *const prog_self = prog + band;
+    {
+        const int lane = lane_id(), l = lane & 15;
+        if (lane < 52) {
+            s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
+            s.t_tc0[lane] = ((uint32_t)k_tc0[lane][0] << 8) | ((uint32_t)k_tc0[lane][1] << 16) | ((uint32_t)k_tc0[lane][2] << 24);
+        }
+        if (lane < 16) {
+            /* role of lane l of a group: segment l >> 2 of edge l & 3, in both directions (as deblock_band) */
+            const int seg = l >> 2, edge = l & 3, qe = edge == 0 ? 3 : edge - 1;
+            const bool outer = edge == 0;
+            uint32_t *r = s.role[l];
+            r[0] = 1u << blk_index(edge, seg); r[1] = 1u << blk_index(qe, seg); r[2] = 8u * ((edge >> 1) + 2 * (seg >> 1)); r[3] = 8u * ((qe >> 1) + 2 * (seg >> 1));
+            r[4] = 1u << blk_index(seg, edge); r[5] = 1u << blk_index(seg, qe); r[6] = 8u * ((seg >> 1) + 2 * (edge >> 1)); r[7] = 8u * ((seg >> 1) + 2 * (qe >> 1));
+            r[8] = (uint32_t)(4 * (edge + 4 * seg));
+            r[9] = (uint32_t)(outer ? 4 * (3 + 4 * seg) - 64 : 4 * (edge - 1 + 4 * seg));
+            r[10] = (uint32_t)(4 * (seg + 4 * edge));
+            r[11] = (uint32_t)(outer ? 4 * (seg + 12) - 64 * W : 4 * (seg + 4 * (edge - 1)));
+        }
+    }
+    MI355_WAVE_SYNC();
+
+    struct Pre {
+        MbInfo h, ht;
+        uint32_t p0[2], q0[2], p1[2], q1[2];
+    };
+    /* Per-lane constants of the address arithmetic, computed once: a dozen registers against ~150 instructions per step (the first
+     * version recomputed rows, tile offsets and swizzles from the lane number in every step: 637 VALU per step, the kernel bound by them).
+     * LDS offsets are byte offsets from `s`, without the term of the ring slot; memory offsets are those of step 0, a step adds a tile. */
+    uint8_t *const lds = reinterpret_cast<uint8_t *>(&s);
+    constexpr uint32_t OY = (uint32_t)offsetof(Deblock3Lds, y), OC = (uint32_t)offsetof(Deblock3Lds, c), OA = (uint32_t)offsetof(Deblock3Lds, above);
+    uint32_t k_g2, k_rec, k_topd, k_dy, k_dc, k_gc2, k_da, k_sab, k_sc, k_sd, k_se, k_la, k_lc, k_ld, k_rv, k_cv, k_flags;
+    enum { KF_ROW = 1, KF_TOP = 2, KF_BOTTOM = 4, KF_LO = 8, KF_G0 = 16, KF_ROW0 = 32 };
+    {
+        const int lane = lane_id(), g = lane >> 4, l = lane & 15, ga = (g - 1) & 3;
+        const int mb_y = 4 * band + g, mb_yc = mb_y < H ? mb_y : H - 1;
+        const bool row_ok = mb_y < H, has_t = row_ok && mb_y > 0, bottom = row_ok && (g == 3 || mb_y == H - 1), lo = l < 8;
+        k_flags = (row_ok ? KF_ROW : 0) | (has_t ? KF_TOP : 0) | (bottom ? KF_BOTTOM : 0) | (lo ? KF_LO : 0) | (g == 0 ? KF_G0 : 0) | (mb_yc == 0 ? KF_ROW0 : 0);
+        k_g2 = (uint32_t)(2 * g);
+        k_rec = (uint32_t)(64 * mb_yc * W);
+        k_topd = mb_yc > 0 ? 64u * (uint32_t)W : 0u;
+        k_dy = (uint32_t)(mb_yc * rs + 16 * (l ^ g));
+        {   /* chroma tiles: lanes 0..31, lane -> (group lane >> 3, piece lane & 7) */
+            const int gc = (lane >> 3) & 3, q = lane & 7, yc = 4 * band + gc < H ? 4 * band + gc : H - 1;
+            k_dc = (uint32_t)(yc * rcs + 16 * (q ^ gc));
+            k_gc2 = (uint32_t)(2 * gc);
+        }
+        /* the macroblock above group 0's: lanes 0..7 its second luma line, lanes 8..15 its chroma tile (offsets into dst[0] / dst[1]) */
+        k_da = (lane & 8) ? (uint32_t)(ya * dcs + 16 * ((lane & 7) ^ 3)) : (uint32_t)(ya * ds + 128 + 16 * ((lane & 7) ^ 3));
+        k_sab = lo ? (uint32_t)(mb_y * ds - (2 * g + 1) * 256 + 16 * l) : (uint32_t)((mb_y - 1) * ds - 2 * g * 256 + 16 * l);
+        k_sc = (uint32_t)((mb_y - 1) * dcs - 2 * g * 128 + 8 * l);
+        k_sd = (uint32_t)(mb_y * ds - (2 * g + 1) * 256 + 128 + 8 * l);
+        k_se = (uint32_t)(mb_y * dcs - (2 * g + 1) * 128 + 8 * l);
+        k_rv = (uint32_t)(256 * g + 16 * (l ^ g));                                         /* luma row l of the own tile */
+        k_cv = (uint32_t)(128 * g + 16 * ((l >> 1) ^ g) + 8 * (l & 1));                    /* chroma row (plane l >> 3, row l & 7) of the own tile */
+        k_la = lo ? k_rv : (uint32_t)(g ? 256 * ga + 128 + 16 * ((l - 8) ^ ga) : 16 * ((l - 8) ^ 3));       /* (a): row l of the left tile / (b): row l of the tile above */
+        k_lc = (uint32_t)(g ? 128 * ga + 16 * ((l >> 1) ^ ga) + 8 * (l & 1) : 128 + 16 * ((l >> 1) ^ 3) + 8 * (l & 1));   /* chroma row of the tile above */
+        k_ld = (uint32_t)(256 * g + 16 * ((8 + (l >> 1)) ^ g) + 8 * (l & 1));              /* half (l & 1) of row 8 + (l >> 1) of the own tile */
+    }
+    auto kf = [&](uint32_t bit) { return (k_flags & bit) != 0; };
+    /* records and vectors of group g's macroblock t1 - 2g: into registers */
+    auto prefetch = [&](Pre &p, int t1) {
+        const int l = lane_id() & 15;
+        const bool outer = (l & 3) == 0;
+        const int xc = med3i(t1 - (int)k_g2, 0, W - 1);
+        const uint32_t roff = k_rec + ((uint32_t)xc << 6), toff = roff - k_topd;
+        p.h = mb_info_load<true>(rec_base, roff);
+        p.ht = mb_info_load<false>(rec_base, toff);
+        const mi355_u32x4 o = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][8]);
+        const uint32_t a_p0 = roff + o[0], a_p1 = roff + o[2];
+        const uint32_t a_q0 = xc > 0 || !outer ? roff + o[1] : a_p0;
+        const uint32_t a_q1 = !kf(KF_ROW0) || !outer ? roff + o[3] : a_p1;
+        p.p0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p0); p.q0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q0);
+        p.p1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p1); p.q1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q1);
+        p.p0[1] = p.q0[1] = p.p1[1] = p.q1[1] = 0;
+        if (two_lists) {
+            p.p0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p0); p.q0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q0);
+            p.p1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p1); p.q1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q1);
+        }
+    };
+    /* the tiles of step t1 (group g: macroblock t1 - 2g, clamped into its row) into ring slot t1 & 3; group 0's macroblock above into above[t1 & 1] */
+    auto dma_issue = [&](int t1) {
+        const int lane = lane_id();
+        lds_dma16<false>(recon_y0 + (k_dy + ((uint32_t)med3i(t1 - (int)k_g2, 0, W - 1) << 8)), &s.y[t1 & 3][0][0]);
+        if (lane < 32) lds_dma16<false>(recon_c0 + (k_dc + ((uint32_t)med3i(t1 - (int)k_gc2, 0, W - 1) << 7)), &s.c[t1 & 3][0][0]);
+        if (top_band && lane < 16) {
+            const int xa = t1 < W ? t1 : W - 1;
+            const uint8_t *src = (lane & 8) ? dst_c0 + (k_da + ((uint32_t)xa << 7)) : dst_y0 + (k_da + ((uint32_t)xa << 8));
+            lds_dma16<true>(src, &s.above[t1 & 1][0]);
+        }
+        MI355_ISSUE_FENCE();
+    };
+    uint32_t seen = 0;
+    auto await_above = [&](int x0) {
+        if (!top_band) return;
+        const uint32_t need = (uint32_t)(x0 + 1 < W ? x0 + 1 : W);
+        if (seen >= need) return;
+        for (;;) {
+            seen = (uint32_t)uniform((int)agent_load_u32(mi355_global_v(prog_above)));
+            if (seen >= need) break;
+            wave_nap();
+        }
+        MI355_ISSUE_FENCE();
+    };
+    /* what step ts made final goes out (at the start of step ts + 1): a whole tile line per eight lanes.
+     * lanes 0..7 of a group: rows 0..7 of the previous macroblock of its row (its last columns got macroblock x's left edge);
+     * lanes 8..15: rows 8..15 of the macroblock above (its last rows got macroblock x's top edge), and that one's chroma tile;
+     * a row nobody of this wave works below: the previous macroblock's own second line and chroma tile as well */
+    auto stores = [&](int ts) {
+        const uint32_t u1y = OY + 1024u * (uint32_t)((ts - 1) & 3), u2y = OY + 1024u * (uint32_t)((ts - 2) & 3), ua = OA + 256u * (uint32_t)(ts & 1);
+        const uint32_t u1c = OC + 512u * (uint32_t)((ts - 1) & 3), u2c = OC + 512u * (uint32_t)((ts - 2) & 3);
+        const uint32_t xhi = (uint32_t)ts - k_g2, xlo = xhi - 1u;                        /* macroblock x of this step, and the one before it */
+        const bool in_lo = xlo < (uint32_t)W, in_hi = xhi < (uint32_t)W;
+        const bool lo = kf(KF_LO), g0 = kf(KF_G0);
+        const bool ok = lo ? (kf(KF_ROW) && in_lo) : (kf(KF_TOP) && in_hi);
+        const uint4 v = lds16(lds + (k_la + (lo ? u1y : (g0 ? ua : u2y))));
+        if (ok) st16(dst_y0 + (k_sab + ((uint32_t)ts << 8)), v, true);
+        const uint2 vc = *reinterpret_cast<const uint2 *>(lds + (k_lc + (g0 ? ua : u2c)));
+        if (kf(KF_TOP) && in_hi) st8(dst_c0 + (k_sc + ((uint32_t)ts << 7)), vc, true);
+        const uint2 by = *reinterpret_cast<const uint2 *>(lds + (k_ld + u1y)), bc = *reinterpret_cast<const uint2 *>(lds + (k_cv + u1c));
+        if (kf(KF_BOTTOM) && in_lo) {
+            uint8_t *py = dst_y0 + (k_sd + ((uint32_t)ts << 8)), *pcc = dst_c0 + (k_se + ((uint32_t)ts << 7));
+            if (hand) { agent_store8(py, by, true); agent_store8(pcc, bc, true); }
+            else { st8(py, by, true); st8(pcc, bc, true); }
+        }
+        MI355_WAVE_SYNC();                                   /* every lane has read its pieces: the slots are free for the DMA issued next (program order
+                                                                on the device; a rendezvous of the fibers in the emulator) */
+    };
+
+    Pre pre = {};
+    MbInfo hl = {};
+    await_above(0);
+    dma_issue(0);
+    prefetch(pre, 0);
+    hl = pre.h;
+#pragma nounroll
+    for (int t = 0; t < nsteps; t++) {
+        /* ---- everything requested during the last step is here; what was stored during it is out ---------------------------------- */
+        agent_drain_stores();
+        if (hand && t >= 2 && (t & (DB2_PUB - 1)) == 0) {
+            /* stores(t - 2) were issued in step t - 1: group 3 has macroblocks 0 .. t - 9 of its row out */
+            const int done = t - 8 < 0 ? 0 : (t - 8 < W ? t - 8 : W);
+            if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
+        }
+        MI355_WAVE_SYNC();
+        if (t > 0) stores(t - 1);
+        await_above(t + 1);
+        dma_issue(t + 1);
+        /* ---- boundary strengths ---------------------------------------------------------------------------------------------- */
+        uint32_t bsw0, bsw1, bsc0, bsc1;
+        {
+            const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+            const int mb_y = 4 * band + g, mb_x = t - 2 * g;
+            const bool row_ok = mb_y < H, has_t = row_ok && mb_y > 0, valid = row_ok && mb_x >= 0 && mb_x < W;
+            const bool outer = (l & 3) == 0, odd = (l & 1) != 0;
+            const MbInfo &h = pre.h, &ht = pre.ht;
+            const mi355_u32x4 ra = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][0]), rb = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][4]);
+            const BsRole r0{ ra[0], ra[1], ra[2], ra[3] }, r1{ rb[0], rb[1], rb[2], rb[3] };
+            const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
+            const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
+            const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, pre.p0, pre.q0, two_lists, mv_far, 4u);
+            const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, pre.p1, pre.q1, two_lists, mv_far, field ? 3u : 4u);
+            bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
+            bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
+            const int csrc = (lane & ~15) | (((l & 7) >> 1) << 2);
+            bsc0 = (uint32_t)__shfl((int)bsw0, csrc); bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
+            /* alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) */
+            const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;
+            const int kindc = kind > 2 ? 2 : kind;
+            const MbInfo &nb = kindc == 1 ? hl : ht;
+            int qa = comp ? h.qpc(comp - 1) : h.qp();
+            int qb = comp ? nb.qpc(comp - 1) : nb.qp();
+            if (comp && kindc && nb.slice_id() != h.slice_id() && (kindc == 1 ? have_left : have_top)) {
+                int v = mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[comp - 1][nb.qp()];
+                MI355_PIN(v);
+                qb = v;
+            }
+            const int qp = kindc ? (qa + qb + 1) >> 1 : qa;
+            const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
+            const uint32_t w0 = (uint32_t)s.t_alpha[ia] | ((uint32_t)s.t_beta[ib] << 8);
+            const uint32_t w1 = s.t_tc0[ia] + (comp ? 0x01010100u : 0u);
+            if (l < 9) { s.parm[g][l][0] = w0; s.parm[g][l][1] = w1; }
+            hl = h;
+        }
+        /* the next macroblock's records and vectors: the registers of this one's are free */
+        prefetch(pre, t + 1);
+        MI355_WAVE_SYNC();
+#define AB_A(w) ((int)((w) & 0xFF))
+#define AB_B(w) ((int)(((w) >> 8) & 0xFF))
+#define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
+        /* ---- vertical edges: lane l of a group = luma row l and chroma row (plane l >> 3, row l & 7), from and to the ring ---------------- */
+        {
+            const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+            const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * (l >> 3)];
+            const uint32_t ab_i = pl[0], tr_i = pl[1], ab_l = pl[2], tr_l = pl[3];
+            const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_l = pc[2], ctr_l = pc[3];
+            const uint32_t tci0 = byte_perm(0, tr_i, bsw0 & 0x03030303u), tcl0 = byte_perm(0, tr_l, bsw0 & 3u);
+            const uint32_t cci0 = byte_perm(0, ctr_i, bsc0 & 0x03030303u), ccl0 = byte_perm(0, ctr_l, bsc0 & 3u);
+            uint8_t *rowp = lds + (k_rv + OY + 1024u * (uint32_t)(t & 3)), *leftp = lds + (k_rv + OY + 12u + 1024u * (uint32_t)((t - 1) & 3));
+            uint8_t *crowp = lds + (k_cv + OC + 512u * (uint32_t)(t & 3)), *cleftp = lds + (k_cv + OC + 4u + 512u * (uint32_t)((t - 1) & 3));
+            const uint4 own = lds16(rowp);
+            const uint2 cown = *reinterpret_cast<const uint2 *>(crowp);
+            uint32_t wl = *reinterpret_cast<const uint32_t *>(leftp), w0 = own.x, w1 = own.y, w2 = own.z, w3 = own.w;
+            uint32_t cl = *reinterpret_cast<const uint32_t *>(cleftp), cw0 = cown.x, cw1 = cown.y;
+            const bool c0 = luma_row_edge<true>(wl, w0, BYTE(bsw0, 0), AB_A(ab_l), AB_B(ab_l), BYTE(tcl0, 0));
+            const bool c1 = luma_row_edge<false>(w0, w1, BYTE(bsw0, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 1));
+            const bool c2 = luma_row_edge<false>(w1, w2, BYTE(bsw0, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 2));
+            const bool c3 = luma_row_edge<false>(w2, w3, BYTE(bsw0, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 3));
+            if (c0) *reinterpret_cast<uint32_t *>(leftp) = wl;
+            if (c0 || c1 || c2 || c3) lds16(rowp, make_uint4(w0, w1, w2, w3));
+            const bool d0 = chroma_row_edge(cl, cw0, BYTE(bsc0, 0), AB_A(cab_l), AB_B(cab_l), BYTE(ccl0, 0));
+            const bool d1 = chroma_row_edge(cw0, cw1, BYTE(bsc0, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci0, 2));
+            if (d0) *reinterpret_cast<uint32_t *>(cleftp) = cl;
+            if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
+        }
+        MI355_WAVE_SYNC();
+        /* ---- horizontal edges: lane l of a group = luma column l and chroma column (plane l >> 3, column l & 7); rows -4..-1 (chroma -2, -1)
+         * are rows 12..15 (6, 7) of the tile above — in the ring of the group above, or in above[] — read and patched where they lie -------- */
+        {
+            const int lane = lane_id(), g = lane >> 4, l = lane & 15, ga = (g - 1) & 3, cp = l >> 3, cr = l & 7;
+            const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * cp];
+            const uint32_t ab_i = pl[0], tr_i = pl[1], ab_t = pl[4], tr_t = pl[5];
+            const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_t = pc[4], ctr_t = pc[5];
+            const uint32_t tci1 = byte_perm(0, tr_i, bsw1 & 0x03030303u), tct1 = byte_perm(0, tr_t, bsw1 & 3u);
+            const uint32_t cci1 = byte_perm(0, ctr_i, bsc1 & 0x03030303u), cct1 = byte_perm(0, ctr_t, bsc1 & 3u);
+            uint8_t *const Y = &s.y[t & 3][g][l], *const C = &s.c[t & 3][g][64 * cp + cr];
+            uint8_t *const A = (g ? &s.y[(t - 2) & 3][ga][128] : &s.above[t & 1][0]) + l;          /* row 8 + m at A[16 * (m ^ ga)] */
+            uint8_t *const CA = (g ? &s.c[(t - 2) & 3][ga][0] : &s.above[t & 1][128]) + 64 * cp + cr;
+            /* row r of the own tile at Y[16 * (r ^ g)]: r = 4k + j -> 64k + 16 * (j ^ g) */
+#define YR(r) Y[64 * ((r) >> 2) + 16 * (((r) & 3) ^ g)]
+#define AR(r) A[64 * (((r) - 8) >> 2) + 16 * ((((r) - 8) & 3) ^ ga)]
+#define CR(r) C[16 * (((r) >> 1) ^ g) + 8 * ((r) & 1)]
+#define CAR(r) CA[16 * (((r) >> 1) ^ ga) + 8 * ((r) & 1)]
+            int y0 = AR(12), y1 = AR(13), y2 = AR(14), y3 = AR(15);
+            int y4 = YR(0), y5 = YR(1), y6 = YR(2), y7 = YR(3), y8 = YR(4), y9 = YR(5), y10 = YR(6), y11 = YR(7);
+            int y12 = YR(8), y13 = YR(9), y14 = YR(10), y15 = YR(11), y16 = YR(12), y17 = YR(13), y18 = YR(14);
+            int u0 = CAR(6), u1 = CAR(7), u2 = CR(0), u3 = CR(1), u4 = CR(2), u5 = CR(3), u6 = CR(4), u7 = CR(5);
+            const int e0 = luma_line<true>(y0, y1, y2, y3, y4, y5, y6, y7, BYTE(bsw1, 0), AB_A(ab_t), AB_B(ab_t), BYTE(tct1, 0));
+            if (e0) {
+                if (e0 == 2) { AR(13) = (uint8_t)y1; YR(2) = (uint8_t)y6; }
+                AR(14) = (uint8_t)y2; AR(15) = (uint8_t)y3; YR(0) = (uint8_t)y4; YR(1) = (uint8_t)y5;
+            }
+            if (luma_line<false>(y4, y5, y6, y7, y8, y9, y10, y11, BYTE(bsw1, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 1))) {
+                YR(2) = (uint8_t)y6; YR(3) = (uint8_t)y7; YR(4) = (uint8_t)y8; YR(5) = (uint8_t)y9;
+            }
+            if (luma_line<false>(y8, y9, y10, y11, y12, y13, y14, y15, BYTE(bsw1, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 2))) {
+                YR(6) = (uint8_t)y10; YR(7) = (uint8_t)y11; YR(8) = (uint8_t)y12; YR(9) = (uint8_t)y13;
+            }
+            int y19 = 0;
+            if (luma_line<false>(y12, y13, y14, y15, y16, y17, y18, y19, BYTE(bsw1, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 3))) {
+                YR(10) = (uint8_t)y14; YR(11) = (uint8_t)y15; YR(12) = (uint8_t)y16; YR(13) = (uint8_t)y17;
+            }
+            if (chroma_line(u0, u1, u2, u3, BYTE(bsc1, 0), AB_A(cab_t), AB_B(cab_t), BYTE(cct1, 0))) {
+                CAR(7) = (uint8_t)u1; CR(0) = (uint8_t)u2;
+            }
+            if (chroma_line(u4, u5, u6, u7, BYTE(bsc1, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci1, 2))) {
+                CR(3) = (uint8_t)u5; CR(4) = (uint8_t)u6;
+            }
+#undef YR
+#undef AR
+#undef CR
+#undef CAR
+        }
+#undef AB_A
+#undef AB_B
+#undef BYTE
+    }
+    /* ---- the last step's results, and the closing word to the band below --------------------------------------------------------- */
+    agent_drain_stores();
+    MI355_WAVE_SYNC();
+    stores(nsteps - 1);
+    if (hand) {
+        agent_drain_stores();
+        if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)W);
+    }
+}
+
+/* Band-major tickets: all pictures' band 0, then band 1, ...; a wave's only dependence is the ticket nframes before its own, taken by a
+ * wave that is running or done whatever order the hardware dispatches workgroups in.  Two kernels share the launch geometry and the
+ * progress words and each takes the pictures of ONE surface layout (a picture of the other layout costs its waves a ticket and a look at
+ * the descriptor): the tiled form must not carry the other's registers.  sync[0] / sync[1]: the kernels' ticket counters; sync[16 ...]:
+ * one progress word per picture and band. */
+template <bool TILED>
+__device__ __forceinline__ bool deblock_ticket(const mi355_h264_frame *frames, int nframes, int nbands, uint32_t *sync, int &pic, int &band)
+{
+    uint32_t tk = 0;
+    if (lane_id() == 0) tk = atomicAdd(mi355_global(sync) + (TILED ? 0 : 1), 1u);
+    tk = (uint32_t)lane_value((int)tk, 0);
+    band = (int)(tk / (uint32_t)nframes);
+    pic = (int)(tk - (uint32_t)band * (uint32_t)nframes);
+    if (band >= nbands) return false;
+    const mi355_h264_frame &fr = frames[pic];
+    return 4 * band < uniform(fr.mb_height) && (uniform(fr.surface_layout) == MI355_SURFACE_TILED) == TILED;
+}
+#ifdef MI355_DB3_WAVES
+__attribute__((amdgpu_waves_per_eu(MI355_DB3_WAVES, MI355_DB3_WAVES)))
+#endif
 __global__ void __launch_bounds__(64)
-k_deblock2(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
+k_deblock_tiled(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
+{
+    int pic, band;
+    if (!deblock_ticket<true>(frames, nframes, nbands, sync, pic, band)) return;
+    const mi355_h264_frame &fr = frames[pic];
+    uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
+#ifdef MI355_DEBLOCK_TILED_IN_REGISTERS          /* developer switch: the register form on tiled surfaces (round 4's first version) */
+    __shared__ Deblock2Lds s;
+    if (mi355_global(fr.mv[1]) != nullptr) deblock2_band<true, true>(s, fr, band, prog);
+    else deblock2_band<false, true>(s, fr, band, prog);
+#else
+    __shared__ Deblock3Lds s;
+#ifdef MI355_EXP_DB2_ONLY        /* developer experiment: the instruction listing / register count of one instance alone (P pictures) */
+    deblock3_band<false>(s, fr, band, prog);
+    return;
+#endif
+    if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true>(s, fr, band, prog);
+    else deblock3_band<false>(s, fr, band, prog);
+#endif
+}
+__global__ void __launch_bounds__(64)
+k_deblock_linear(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
 {
     __shared__ Deblock2Lds s;
-    /* band-major tickets: all pictures' band 0, then band 1, ...; a wave's only dependence is the ticket nframes before its own */
-    uint32_t tk = 0;
-    if (lane_id() == 0) tk = atomicAdd(mi355_global(sync), 1u);
-    tk = (uint32_t)lane_value((int)tk, 0);
-    const int band = (int)(tk / (uint32_t)nframes), pic = (int)(tk - (uint32_t)band * (uint32_t)nframes);
-    if (band >= nbands) return;
+    int pic, band;
+    if (!deblock_ticket<false>(frames, nframes, nbands, sync, pic, band)) return;
     const mi355_h264_frame &fr = frames[pic];
-    if (4 * band >= uniform(fr.mb_height)) return;
     uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
-    if (uniform(fr.surface_layout) == MI355_SURFACE_TILED) {
-        if (mi355_global(fr.mv[1]) != nullptr) deblock2_band<true, true>(s, fr, band, prog);
-        else deblock2_band<false, true>(s, fr, band, prog);
-        return;
-    }
     if (mi355_global(fr.mv[1]) != nullptr) deblock2_band<true, false>(s, fr, band, prog);
     else deblock2_band<false, false>(s, fr, band, prog);
 }
@@ -1074,7 +1443,12 @@ uint32_t *sync_words(hipStream_t st, size_t words)
 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
-    if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
+    return mi355_h264_deblock_layouts_dev(d_frames, nframes, max_mb_width, max_mb_height, MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED, stream);
+}
+
+extern "C" int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int layouts, void *stream)
+{
+    if (!mi355::bind() || !d_frames || nframes <= 0 || !(layouts & (MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED))) return -1;
     const int nbands = (max_mb_height + 3) / 4, nsteps = max_mb_width + 6;
     /* MI355_DEBLOCK_FORM (developer switch): unset / 0 = ONE launch for all bands of all pictures (k_deblock2); 1 = a launch per band
      * (k_deblock), 2 / 3 / 4 / 6 = that many bands per workgroup (k_deblock_bands), -1 = the cheaper of those by the estimate below:
@@ -1088,7 +1462,8 @@ extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nfra
         uint32_t *sync = sync_words(st, words);
         if (!sync) return -4;
         MI355_TRY(hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st), -4);
-        hipLaunchKernelGGL(k_deblock2, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
+        if (layouts & MI355_LAYOUTS_TILED) hipLaunchKernelGGL(k_deblock_tiled, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
+        if (layouts & MI355_LAYOUTS_LINEAR) hipLaunchKernelGGL(k_deblock_linear, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     static int cus = 0;

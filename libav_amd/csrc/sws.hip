@@ -919,34 +919,54 @@ extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fram
 }
 
 /* copy a host plane into a tightly pitched device plane */
-static void plane_h2d(uint8_t *d, int dpitch, const uint8_t *h, int hstride, int wbytes, int rows, hipStream_t s)
+static bool plane_h2d(uint8_t *d, int dpitch, const uint8_t *h, int hstride, int wbytes, int rows, hipStream_t s)
 {
-    MI355_CHECK(hipMemcpy2DAsync(d, dpitch, h, hstride, wbytes, rows, hipMemcpyHostToDevice, s));
+    return hipMemcpy2DAsync(d, dpitch, h, hstride, wbytes, rows, hipMemcpyHostToDevice, s) == hipSuccess;
 }
 
 extern "C" int mi355_sws_scale(mi355_sws_ctx *c, const uint8_t *const src[3], const int src_stride[3], uint8_t *dst, int dst_stride)
 {
+    /* Every failure comes back as a negative value and leaves the context usable: the caller (contrib/libav/mi355_sws_glue.c) falls
+     * back to the reference's function for that picture.  Strides must be positive and cover a line: sws_scale() itself also
+     * takes negative ones (bottom-up pictures, vf_vflip) — not this entry point (-1), a 2-D copy has no negative pitch. */
+    if (!c || !src || !src_stride || !dst) return -1;
     const SwsDev &h = c->h;
-    DeviceScope on(c->device);
     const int cw = h.chrSrcW, ch = h.chrSrcH;
+    const int w[3] = { h.srcW, cw, cw };
+    const int out_w = h.special ? (h.dstW & ~1) * 3 : h.dstW * 3;      /* only the samples the converter writes go back: the caller's padding stays untouched */
+    for (int p = 0; p < 3; p++) if (!src[p] || src_stride[p] < w[p]) return -1;
+    if (dst_stride < out_w) return -1;
+    DeviceScope on(c->device);
     const int pw[3] = { (h.srcW + 15) & ~15, (cw + 15) & ~15, (cw + 15) & ~15 }, ph[3] = { h.srcH, ch, ch };
     const int dpitch = (h.dstW * 3 + 15) & ~15;
     if (!c->d_dst) {
-        for (int p = 0; p < 3; p++) MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_src[p]), (size_t)pw[p] * ph[p] + 64));
-        MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_dst), (size_t)dpitch * (h.dstH + 1)));
-        MI355_CHECK(hipMalloc(reinterpret_cast<void **>(&c->d_frame), sizeof(mi355_sws_frame)));
-        mi355_sws_frame f;
-        for (int p = 0; p < 3; p++) { f.src[p] = c->d_src[p]; f.src_stride[p] = pw[p]; }
-        f.dst = c->d_dst; f.dst_stride = dpitch;
-        MI355_CHECK(hipMemcpy(c->d_frame, &f, sizeof(f), hipMemcpyHostToDevice));
+        uint8_t *ns[3] = { nullptr, nullptr, nullptr }, *nd = nullptr;
+        mi355_sws_frame *nf = nullptr;
+        bool ok = true;
+        for (int p = 0; p < 3 && ok; p++) ok = hipMalloc(reinterpret_cast<void **>(&ns[p]), (size_t)pw[p] * ph[p] + 64) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void **>(&nd), (size_t)dpitch * (h.dstH + 1)) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void **>(&nf), sizeof(mi355_sws_frame)) == hipSuccess;
+        if (ok) {
+            mi355_sws_frame f;
+            for (int p = 0; p < 3; p++) { f.src[p] = ns[p]; f.src_stride[p] = pw[p]; }
+            f.dst = nd; f.dst_stride = dpitch;
+            ok = hipMemcpy(nf, &f, sizeof(f), hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (!ok) {
+            for (int p = 0; p < 3; p++) if (ns[p]) (void)hipFree(ns[p]);
+            if (nd) (void)hipFree(nd);
+            if (nf) (void)hipFree(nf);
+            (void)hipGetLastError();
+            return -4;
+        }
+        for (int p = 0; p < 3; p++) c->d_src[p] = ns[p];
+        c->d_dst = nd; c->d_frame = nf;
     }
-    const int w[3] = { h.srcW, cw, cw };
-    for (int p = 0; p < 3; p++) plane_h2d(c->d_src[p], pw[p], src[p], src_stride[p], w[p], ph[p], c->stream);
-    if (mi355_sws_scale_frames_dev(c, c->d_frame, 1, c->stream) != 0) return -2;
-    /* only the samples the converter writes go back: the caller's padding stays untouched */
-    const int out_w = h.special ? (h.dstW & ~1) * 3 : h.dstW * 3;
-    MI355_CHECK(hipMemcpy2DAsync(dst, dst_stride, c->d_dst, dpitch, out_w, h.dstH, hipMemcpyDeviceToHost, c->stream));
-    MI355_CHECK(hipStreamSynchronize(c->stream));
+    for (int p = 0; p < 3; p++)
+        if (!plane_h2d(c->d_src[p], pw[p], src[p], src_stride[p], w[p], ph[p], c->stream)) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->stream); return -4; }
+    if (mi355_sws_scale_frames_dev(c, c->d_frame, 1, c->stream) != 0) { (void)hipStreamSynchronize(c->stream); return -2; }
+    if (hipMemcpy2DAsync(dst, dst_stride, c->d_dst, dpitch, out_w, h.dstH, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->stream); return -4; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -4;
     return h.special ? h.srcH : h.dstH;
 }
 

@@ -144,3 +144,29 @@ def test_full_size_1080p_mixed_partitions_matches_oracle(mi355, oracle, tiled):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
+
+
+@pytest.mark.parametrize("F,tiled", ((640, True), (96, True), (160, False)))
+def test_loop_filter_bands_hand_down_under_load(mi355, oracle, F, tiled):
+    """The single-launch loop filter (k_deblock2) hands rows from band to band THROUGH MEMORY inside one launch (agent-scope
+    write-through stores, progress counters: h264_deblock.hip).  Many 1080p pictures at once — hundreds of bands in flight on
+    every XCD, band pairs on different XCDs — on content where the filter changes most lines, decoded twice with `dst`
+    overwritten in between (a line served stale from a cache would hold the scribble); EVERY picture compared with the oracle's."""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x2264, lib=mi355.lib, refs="smooth", coef_b=4)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs, replicate=F, tiled=tiled)
+    try:
+        d.decode()
+        assert mi355.lib.mi355_memcpy_d2d(d.dst, d.recon, F * d.fsz) == 0        # scribble: the unfiltered pictures
+        d.decode()
+        bad = []
+        for first in range(0, F, 32):
+            n = min(32, F - first)
+            got = d.fetch(d.dst, first, n)
+            for i in range(n):
+                g = (first + i) % fs.F
+                if not all(np.array_equal(dst_o[p][g], got[p][i]) for p in range(3)):
+                    bad.append(first + i)
+        assert not bad, "%d of %d pictures differ from the oracle, first: %s" % (len(bad), F, bad[:8])
+    finally:
+        d.free()
