@@ -138,7 +138,7 @@ def main():
     dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=tiled)
     big = fs
 
-    for name, res, at in (("mi355_h264_recon_inter_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                           ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -150,7 +150,7 @@ def main():
     def step(events=None):
         if events is not None:
             lib.mi355_event_record(events[0], stream)
-        assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, stream) == 0
+        assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[tiled], stream) == 0
         if events is not None:
             lib.mi355_event_record(events[1], stream)
         assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, big.max_intra_level, level_widths(big), stream) == 0
@@ -202,7 +202,7 @@ def main():
         n_intra = int(sum(len(big.intra_list[f % G]) for f in range(F)))
         n_inter = F * nmb - n_intra
         # dominant kernel = the pass with the largest share of the step (the loop filter is ONE launch for all bands of all pictures since round 4)
-        passes = {"k_recon_inter": (t_inter, 1, n_inter * B_RECON),
+        passes = {"k_recon_inter_tiled" if tiled else "k_recon_inter": (t_inter, 1, n_inter * B_RECON),
                   "k_deblock_tiled" if tiled else "k_deblock_linear": (t_deblock, 1, F * nmb * B_DEBLOCK)}
         dom = max(passes, key=lambda k: passes[k][0])
         t_pass, launches, bytes_pass = passes[dom]
@@ -300,7 +300,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             conv = detile_jobs(lib, dev, fs, F) if detile else None
 
             def once():
-                assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
+                assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
                 assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
                 assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
                 if conv is not None:
@@ -315,7 +315,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             # one more step with an event after every pass: where the step's time goes
             ev = [lib.mi355_event_create() for _ in range(4)]
             lib.mi355_event_record(ev[0], None)
-            assert lib.mi355_h264_recon_inter_dev(dev.d_desc, F, mbw, mbh, None) == 0
+            assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
             lib.mi355_event_record(ev[1], None)
             assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
             lib.mi355_event_record(ev[2], None)

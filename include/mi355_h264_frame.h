@@ -207,6 +207,9 @@ typedef struct mi355_h264_frame {
  * picture leaving HBM for display or for a consumer that wants lines). */
 #define MI355_SURFACE_LINEAR 0
 #define MI355_SURFACE_TILED  1
+/* bit mask of the layouts a batch may hold (the *_layouts_dev entry points) */
+#define MI355_LAYOUTS_LINEAR 1
+#define MI355_LAYOUTS_TILED  2
 #define MI355_TILE_LUMA_BYTES   256
 #define MI355_TILE_CHROMA_BYTES 128
 
@@ -254,6 +257,10 @@ int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nf
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
 int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
+/* The same for a caller that knows which surface layouts occur in the batch (MI355_LAYOUTS_*, below): a batch that is tiled throughout runs the
+ * kernel instance that carries the tiled form of the macroblock code alone (fewer registers spilled, half the code); a picture of another layout
+ * in such a launch is left untouched.  Any other mask = mi355_h264_recon_inter_dev. */
+int mi355_h264_recon_inter_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int layouts, void *stream);
 /* The same pass for descriptors whose `coef` arrays live in device-visible host memory (mi355_host_alloc): an inter
  * macroblock fetches its coefficient block only when its record's cbp says it has coefficients (a second, dependent round
  * of loads for those; none for the others) — over PCIe the skipped blocks are what counts.  Same results. */
@@ -267,8 +274,6 @@ int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int ma
 /* The same for a caller that knows which surface layouts occur in the batch (the descriptors live on the device: the entry point
  * above cannot look, and launches the loop filter's kernel for each layout — the waves of the kernel whose layout a picture does
  * not have leave at once, ~1 us per 1000 macroblock-row bands): `layouts` = MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED, or one of them. */
-#define MI355_LAYOUTS_LINEAR 1
-#define MI355_LAYOUTS_TILED  2
 int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int layouts, void *stream);
 
 /* Host helper (plain CPU bookkeeping, no sample arithmetic): write the intra schedule of one picture:

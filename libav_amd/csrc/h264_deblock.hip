@@ -627,11 +627,12 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
 __attribute__((amdgpu_waves_per_eu(MI355_DEBLOCK_WAVES, MI355_DEBLOCK_WAVES)))
 #endif
 __global__ void __launch_bounds__(64)
-k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
+k_deblock(const mi355_h264_frame *__restrict__ frames, int band, int skip_tiled)      /* skip_tiled: k_deblock_tiled takes the tiled pictures of the batch */
 {
     __shared__ DeblockLds s;
     const mi355_h264_frame &fr = frames[blockIdx.x];
     if (uniform(fr.surface_layout) == MI355_SURFACE_TILED) {
+        if (skip_tiled) return;
         if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, 1, true>(s, fr, band, 0);
         else deblock_band<false, 1, true>(s, fr, band, 0);
         return;
@@ -643,12 +644,13 @@ k_deblock(const mi355_h264_frame *__restrict__ frames, int band)
 /* the small-batch form: KW consecutive bands of a picture per workgroup, one wave each (see deblock_band) */
 template <int KW>
 __global__ void __launch_bounds__(64 * KW)
-k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0)
+k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0, int skip_tiled)
 {
     __shared__ DeblockLds s[KW];
     const mi355_h264_frame &fr = frames[blockIdx.x];
     const int wave = (int)(threadIdx.x >> 6);
     if (uniform(fr.surface_layout) == MI355_SURFACE_TILED) {
+        if (skip_tiled) return;
         if (mi355_global(fr.mv[1]) != nullptr) deblock_band<true, KW, true>(s[wave], fr, band0 + wave, wave);
         else deblock_band<false, KW, true>(s[wave], fr, band0 + wave, wave);
         return;
@@ -658,48 +660,11 @@ k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0)
 }
 
 
-/* ===================================================================================================================== */
-/* The loop filter, second form (round 4): every band of every picture in ONE launch                                       */
-/* ===================================================================================================================== */
-/* What stays of the form above: a wave = a band of four macroblock rows of one picture, lanes 16g..16g+15 = row 4 * band + g,
- * group g at macroblock x = t - 2g in step t (the reference's raster dependencies by lock-step execution), boundary strengths
- * by lane role, the edge filters themselves.  What changes:
- *
- *  - the unit that moves is ONE MACROBLOCK per group and step, not a chunk of four: on macroblock-tiled surfaces a macroblock
- *    is two + one whole cache lines whoever reads it, so nothing is gained by gathering four; a lane loads its luma row and
- *    its chroma row of the next macroblock one step ahead into registers and the vertical edges are filtered there before the
- *    rows ever reach LDS.  LDS holds a ring of four macroblocks per group (8.4 KB per wave instead of 18.5) and no chunk
- *    registers are carried (the old form: 209 vector registers, two waves per SIMD);
- *  - the rows above a macroblock are not copied: the horizontal edges read and patch rows 12..15 of the tile in the ring of
- *    the group above, and that tile's SECOND cache line (rows 8..15) and its chroma tile are written to `dst` by the group
- *    BELOW once they are final — every store is a whole 128-byte line of a tile (the old form wrote rows 0..12 and 13..15 of
- *    a tile from two places);
- *  - bands do not wait for launches: all bands of all pictures are workgroups of one launch, taken in band-major order from a
- *    ticket counter (a wave only ever waits for a lower ticket, which is running or done: no dependence on dispatch order),
- *    and band b + 1 follows band b a few macroblocks behind.  Band b hands the second tile lines and chroma tiles of its
- *    last row down through `dst` with agent-scope write-through stores, drains them and publishes how many macroblocks are
- *    out in a progress counter; band b + 1 polls the counter and reads them with agent-scope loads
- *    (/opt/skills/guides/cdna_hip_programming.md section 6, guideline 16, form R1: sc1 payload + drained flag, sc1 loads on
- *    the consumer).  That hand-over is per macroblock only on TILED surfaces, where the lines handed down belong to one
- *    macroblock; on planes with line strides a cache line holds row pieces of eight macroblocks, so band b + 1 waits for
- *    the whole band b there, behind an agent-scope release / acquire pair.
- * With 2048 pictures the launch keeps every SIMD at its register-bound occupancy (the per-band launches were 2048 waves = two
- * per SIMD whatever the kernel needed); with 64 pictures a picture's seventeen bands overlap with a lag of ~11 steps. */
-constexpr int DB2_RING = 4;
-constexpr int DB2_GY = DB2_RING * 256 + 16;      /* bytes per group: + 16 so that the four groups' column accesses fall on different banks */
-constexpr int DB2_GC = DB2_RING * 128 + 16;
+
 #ifndef MI355_DB2_PUB_LOG
-#define MI355_DB2_PUB_LOG 2                      /* a band publishes its progress every 1 << PUB_LOG steps (each publication drains the wave's stores) */
+#define MI355_DB2_PUB_LOG 2                      /* a band publishes its progress every 1 << PUB_LOG steps */
 #endif
 constexpr int DB2_PUB = 1 << MI355_DB2_PUB_LOG;
-struct __attribute__((aligned(16))) Deblock2Lds {
-    uint8_t y[5 * DB2_GY];      /* [0]: tiles of the row above the band (second lines only), [g + 1]: group g; DB2_RING tiles of 16 x 16 each */
-    uint8_t c[5 * DB2_GC];      /* chroma tiles: 8 rows of Cb, 8 rows of Cr */
-    uint32_t parm[4][9][2];     /* as DeblockLds */
-    uint8_t t_alpha[52], t_beta[52];
-    uint32_t t_tc0[52];
-};
-
 /* agent-scope accesses of the band hand-over (plain in the emulator: workgroups run one after the other there) */
 #ifdef MI355_HIP_EMU_H
 static inline uint32_t agent_load_u32(const uint32_t *p) { return *p; }
@@ -709,7 +674,7 @@ static inline void agent_store8(uint8_t *p, uint2 v, bool al8) { st8(p, v, al8);
 static inline void agent_drain_stores() {}
 static inline void agent_release() {}
 static inline void agent_acquire() {}
-static inline void wave_nap() { std::fprintf(stderr, "k_deblock2: a band waits for a band that has not run (emulator: workgroups run in order)\n"); std::abort(); }
+static inline void wave_nap() { std::fprintf(stderr, "k_deblock_tiled: a band waits for a band that has not run (emulator: workgroups run in order)\n"); std::abort(); }
 #else
 __device__ __forceinline__ uint32_t agent_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_store_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -736,296 +701,38 @@ __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMI
 __device__ __forceinline__ void wave_nap() { __builtin_amdgcn_s_sleep(16); }
 #endif
 
-template <bool TWO_LISTS, bool TILED>
-__device__ __forceinline__ void deblock2_band(Deblock2Lds &s, const mi355_h264_frame &fr, int band, uint32_t *prog)
-{
-    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-    const int W = uniform(fr.mb_width), H = uniform(fr.mb_height);
-    const int mb_y = 4 * band + g;
-    const bool row_ok = mb_y < H;
-    const bool field = uniform(fr.field_picture) != 0;
-    const uint32_t mv_far = field ? 0xFFFEFFFCu : 0xFFFCFFFCu;
-    const int rs = uniform(fr.recon_stride[0]), rcs = uniform(fr.recon_stride[1]), ds = uniform(fr.dst_stride[0]), dcs = uniform(fr.dst_stride[1]);
-    const int cp = l >> 3, cr = l & 7;                       /* this lane's chroma plane and row / column */
-    constexpr bool two_lists = TWO_LISTS;
-    const int nsteps = W + 7;                                /* group 3 reaches x = W: the step that writes macroblock W - 1 out */
-    const bool has_t = row_ok && mb_y > 0;
-    /* no group of this wave works below this row: the row's second tile lines and chroma tiles go out from here ... */
-    const bool bottom = row_ok && (g == 3 || mb_y == H - 1);
-    /* ... and when a band follows (wave-uniform; then the row is group 3's) they are handed to it: written through and announced */
-    const bool hand = 4 * band + 4 < H;
-    const bool top_band = band > 0;                          /* the rows above this band are band - 1's hand-down in `dst` */
-    const bool al16 = TILED || ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[0])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[0])) | (uintptr_t)rs | (uintptr_t)ds) & 15) == 0;
-    const bool al8 = TILED || ((reinterpret_cast<uintptr_t>(mi355_global(fr.recon[0])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[0])) | (uintptr_t)rs | (uintptr_t)ds |
-                       reinterpret_cast<uintptr_t>(mi355_global(fr.recon[1])) | reinterpret_cast<uintptr_t>(mi355_global(fr.recon[2])) | reinterpret_cast<uintptr_t>(mi355_global(fr.dst[1])) |
-                       reinterpret_cast<uintptr_t>(mi355_global(fr.dst[2])) | (uintptr_t)rcs | (uintptr_t)dcs) & 7) == 0;
-    if (lane < 52) {
-        s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
-        s.t_tc0[lane] = ((uint32_t)k_tc0[lane][0] << 8) | ((uint32_t)k_tc0[lane][1] << 16) | ((uint32_t)k_tc0[lane][2] << 24);
-    }
-    MI355_WAVE_SYNC();
-    /* ---- boundary-strength role of this lane: segment l >> 2 of edge l & 3, in both directions (as deblock_band) ---------- */
-    const int seg = l >> 2, edge = l & 3;
-    const bool outer = edge == 0, odd = (edge & 1) != 0;
-    const int qe = outer ? 3 : edge - 1;
-    const BsRole r0{ 1u << blk_index(edge, seg), 1u << blk_index(qe, seg), 8u * ((edge >> 1) + 2 * (seg >> 1)), 8u * ((qe >> 1) + 2 * (seg >> 1)) };
-    const BsRole r1{ 1u << blk_index(seg, edge), 1u << blk_index(seg, qe), 8u * ((seg >> 1) + 2 * (edge >> 1)), 8u * ((seg >> 1) + 2 * (qe >> 1)) };
-    const int o_p0 = 4 * (edge + 4 * seg), o_q0 = outer ? 4 * (3 + 4 * seg) - 64 : 4 * (edge - 1 + 4 * seg);
-    const int o_p1 = 4 * (seg + 4 * edge), o_q1 = outer ? 4 * (seg + 12) - 64 * W : 4 * (seg + 4 * (edge - 1));
-    const uint8_t *const rec_base = reinterpret_cast<const uint8_t *>(mi355_global(fr.mb));
-    const uint8_t *const mv_base0 = reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[0]));
-    const uint8_t *const mv_base1 = two_lists ? reinterpret_cast<const uint8_t *>(mi355_global(fr.mv[1])) : mv_base0;
-    const uint8_t *const recon_y0 = mi355_global(fr.recon[0]), *const recon_cb = mi355_global(fr.recon[1]), *const recon_cr = mi355_global(fr.recon[2]);
-    uint8_t *const dst_y0 = mi355_global(fr.dst[0]), *const dst_cb = mi355_global(fr.dst[1]), *const dst_cr = mi355_global(fr.dst[2]);
-    /* a row below the picture (the last band of a picture whose height is no multiple of four, a smaller picture of a mixed batch)
-     * walks the picture's last row: every load in bounds, nothing filtered, nothing stored */
-    const int mb_yc = row_ok ? mb_y : H - 1;
-    const int ya = top_band ? 4 * band - 1 : 0;              /* the macroblock row above the band */
-
-    /* what a lane fetches for one macroblock ahead of time */
-    struct Pre {
-        uint4 ty;                /* its luma row ... */
-        uint2 tc;                /* ... and its chroma row (plane l >> 3, row l & 7) of the macroblock, unfiltered */
-        uint2 ay, ac;            /* its eight bytes of the second tile line (row 8 + (l >> 1), half l & 1) / of the chroma tile of group 0's
-                                    macroblock in the row above the band: every group loads them (same addresses, same lines), group 0 uses them */
-        MbInfo h, ht;
-        uint32_t p0[2], q0[2], p1[2], q1[2];
-    };
-    auto prefetch = [&](Pre &p, int x) {
-        const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
-        const uint32_t xy = (uint32_t)(mb_yc * W + xc);
-        const uint32_t roff = xy * 64u, toff = mb_yc > 0 ? roff - 64u * (uint32_t)W : roff;
-        p.h = mb_info_load<true>(rec_base, roff);
-        p.ht = mb_info_load<false>(rec_base, toff);
-        /* clamped addresses: a neighbour that does not exist reads this macroblock's own vector (its strength is masked) */
-        const uint32_t a_p0 = roff + (uint32_t)o_p0, a_p1 = roff + (uint32_t)o_p1;
-        const uint32_t a_q0 = xc > 0 || !outer ? roff + (uint32_t)o_q0 : a_p0;
-        const uint32_t a_q1 = mb_yc > 0 || !outer ? roff + (uint32_t)o_q1 : a_p1;
-        p.p0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p0); p.q0[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q0);
-        p.p1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_p1); p.q1[0] = *reinterpret_cast<const uint32_t *>(mv_base0 + a_q1);
-        p.p0[1] = p.q0[1] = p.p1[1] = p.q1[1] = 0;
-        if (two_lists) {
-            p.p0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p0); p.q0[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q0);
-            p.p1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_p1); p.q1[1] = *reinterpret_cast<const uint32_t *>(mv_base1 + a_q1);
-        }
-        if (TILED) {
-            p.ty = ld16(recon_y0 + tile_y_off(xc, mb_yc, rs) + 16 * l, true);
-            p.tc = ld8(recon_cb + tile_c_off(xc, mb_yc, rcs) + 8 * l, true);
-        } else {
-            p.ty = ld16(recon_y0 + (uint32_t)(__mul24(16 * mb_yc + l, rs) + 16 * xc), al16);
-            p.tc = ld8((cp ? recon_cr : recon_cb) + (uint32_t)(__mul24(8 * mb_yc + cr, rcs) + 8 * xc), al8);
-        }
-        p.ay = p.ac = make_uint2(0u, 0u);
-        if (top_band) {                                      /* wave-uniform */
-            const int x0 = x + 2 * g, xa = x0 < 0 ? 0 : (x0 < W ? x0 : W - 1);     /* group 0's macroblock of this step */
-            if (TILED) {
-                p.ay = agent_load8(dst_y0 + tile_y_off(xa, ya, ds) + 128 + 8 * l, true);
-                p.ac = agent_load8(dst_cb + tile_c_off(xa, ya, dcs) + 8 * l, true);
-            } else {
-                p.ay = agent_load8(dst_y0 + (uint32_t)(__mul24(16 * ya + 8 + (l >> 1), ds) + 16 * xa + 8 * (l & 1)), al8);
-                p.ac = agent_load8((cp ? dst_cr : dst_cb) + (uint32_t)(__mul24(8 * ya + cr, dcs) + 8 * xa), al8);
-            }
-        }
-    };
-    /* the band above has written (and drained) the macroblocks of its last row up to x0: `seen` = the last value read from its counter */
-    uint32_t seen = 0;
-    uint32_t *const prog_above = prog + (top_band ? band - 1 : 0), *const prog_self = prog + band;
-    auto await_above = [&](int x0) {
-        if (!top_band) return;
-        const uint32_t need = TILED ? (uint32_t)(x0 + 1 < W ? x0 + 1 : W) : (uint32_t)W;
-        if (seen >= need) return;
-        for (;;) {
-            seen = (uint32_t)uniform((int)agent_load_u32(mi355_global_v(prog_above)));
-            if (seen >= need) break;
-            wave_nap();
-        }
-        if (!TILED) agent_acquire();
-        MI355_ISSUE_FENCE();                                 /* the loads of the hand-down stay behind the poll */
-    };
-
-    Pre pre = {};
-    MbInfo hl = {};                                          /* the left neighbour's fields: last step's macroblock */
-    uint8_t *const gy = s.y + (g + 1) * DB2_GY, *const gc = s.c + (g + 1) * DB2_GC;      /* this group's rings */
-    uint8_t *const ay = s.y + g * DB2_GY, *const ac = s.c + g * DB2_GC;                  /* the rings of the row above (group g - 1's, or the band above's) */
-    await_above(0);
-    prefetch(pre, -2 * g);
-    hl = pre.h;
-#pragma nounroll
-    for (int t = 0; t < nsteps; t++) {
-        const int mb_x = t - 2 * g, slot = mb_x & (DB2_RING - 1), lslot = (mb_x - 1) & (DB2_RING - 1);
-        const bool valid = row_ok && mb_x >= 0 && mb_x < W;
-        /* `pre` holds this macroblock's loads; each part is consumed by one phase below, and the next macroblock's loads are issued once the
-         * last part is (after the vertical edges): the two sets of registers are never alive together */
-        const Pre &cur = pre;
-        /* group 0: the second line / chroma tile of the macroblock above, into the ring of the band above */
-        if (top_band && g == 0) {
-            *reinterpret_cast<mi355_u32x2 *>(ay + slot * 256 + 128 + 8 * l) = mi355_u32x2{ cur.ay.x, cur.ay.y };
-            *reinterpret_cast<mi355_u32x2 *>(ac + slot * 128 + 8 * l) = mi355_u32x2{ cur.ac.x, cur.ac.y };
-        }
-        /* ---- boundary strengths, in registers (as deblock_band) ---------------------------------------------- */
-        const MbInfo &h = cur.h, &ht = cur.ht;
-        const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
-        const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
-        const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, cur.p0, cur.q0, two_lists, mv_far, 4u);
-        const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, cur.p1, cur.q1, two_lists, mv_far, field ? 3u : 4u);
-        const uint32_t bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
-        const uint32_t bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
-        const int csrc = (lane & ~15) | ((cr >> 1) << 2);
-        const uint32_t bsc0 = (uint32_t)__shfl((int)bsw0, csrc), bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
-        /* ---- alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) ------------ */
-        {
-            const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;
-            const int kindc = kind > 2 ? 2 : kind;
-            const MbInfo &nb = kindc == 1 ? hl : ht;
-            int qa = comp ? h.qpc(comp - 1) : h.qp();
-            int qb = comp ? nb.qpc(comp - 1) : nb.qp();
-            if (comp && kindc && nb.slice_id() != h.slice_id() && (kindc == 1 ? have_left : have_top)) {
-                int v = mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[comp - 1][nb.qp()];
-                MI355_PIN(v);
-                qb = v;
-            }
-            const int qp = kindc ? (qa + qb + 1) >> 1 : qa;
-            const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
-            const uint32_t w0 = (uint32_t)s.t_alpha[ia] | ((uint32_t)s.t_beta[ib] << 8);
-            const uint32_t w1 = s.t_tc0[ia] + (comp ? 0x01010100u : 0u);
-            if (l < 9) { s.parm[g][l][0] = w0; s.parm[g][l][1] = w1; }
-        }
-        MI355_WAVE_SYNC();
-        const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * cp];
-        const uint32_t ab_i = pl[0], tr_i = pl[1], ab_l = pl[2], tr_l = pl[3], ab_t = pl[4], tr_t = pl[5];
-        const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_l = pc[2], ctr_l = pc[3], cab_t = pc[4], ctr_t = pc[5];
-        const uint32_t tci0 = byte_perm(0, tr_i, bsw0 & 0x03030303u), tcl0 = byte_perm(0, tr_l, bsw0 & 3u);
-        const uint32_t tci1 = byte_perm(0, tr_i, bsw1 & 0x03030303u), tct1 = byte_perm(0, tr_t, bsw1 & 3u);
-        const uint32_t cci0 = byte_perm(0, ctr_i, bsc0 & 0x03030303u), ccl0 = byte_perm(0, ctr_l, bsc0 & 3u);
-        const uint32_t cci1 = byte_perm(0, ctr_i, bsc1 & 0x03030303u), cct1 = byte_perm(0, ctr_t, bsc1 & 3u);
-#define AB_A(w) ((int)((w) & 0xFF))
-#define AB_B(w) ((int)(((w) >> 8) & 0xFF))
-#define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
-        uint8_t *const own_y = gy + slot * 256, *const left_y = gy + lslot * 256, *const own_c = gc + slot * 128, *const left_c = gc + lslot * 128;
-        uint8_t *const abv_y = ay + slot * 256, *const abv_c = ac + slot * 128;
-        /* ---- vertical edges: the lane's luma row and chroma row, in the registers they were loaded into; the four samples to the
-         * left are the last columns of the previous macroblock's row (in the ring, after ITS horizontal edges) ------------------ */
-        {
-            uint32_t wl = *reinterpret_cast<const uint32_t *>(left_y + 16 * l + 12), w0 = cur.ty.x, w1 = cur.ty.y, w2 = cur.ty.z, w3 = cur.ty.w;
-            uint32_t cl = *reinterpret_cast<const uint32_t *>(left_c + 8 * l + 4), cw0 = cur.tc.x, cw1 = cur.tc.y;
-            const bool c0 = luma_row_edge<true>(wl, w0, BYTE(bsw0, 0), AB_A(ab_l), AB_B(ab_l), BYTE(tcl0, 0));
-            luma_row_edge<false>(w0, w1, BYTE(bsw0, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 1));
-            luma_row_edge<false>(w1, w2, BYTE(bsw0, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 2));
-            luma_row_edge<false>(w2, w3, BYTE(bsw0, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci0, 3));
-            if (c0) *reinterpret_cast<uint32_t *>(left_y + 16 * l + 12) = wl;
-            lds16(own_y + 16 * l, make_uint4(w0, w1, w2, w3));
-            const bool d0 = chroma_row_edge(cl, cw0, BYTE(bsc0, 0), AB_A(cab_l), AB_B(cab_l), BYTE(ccl0, 0));
-            chroma_row_edge(cw0, cw1, BYTE(bsc0, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci0, 2));
-            if (d0) *reinterpret_cast<uint32_t *>(left_c + 8 * l + 4) = cl;
-            *reinterpret_cast<mi355_u32x2 *>(own_c + 8 * l) = mi355_u32x2{ cw0, cw1 };
-        }
-        hl = cur.h;
-        MI355_WAVE_SYNC();
-        /* ---- the next macroblock's loads (behind the band above's progress, where there is one) ------------------------------------ */
-        await_above(t + 1);
-        prefetch(pre, mb_x + 1);
-        /* ---- horizontal edges: one luma column + one chroma column per lane; rows -4..-1 (chroma -2, -1) are rows 12..15 (6, 7) of the
-         * tile above, read and patched where it lies ------------------------------------------------------------------------- */
-        {
-            uint8_t *colp = own_y + l, *acolp = abv_y + l;
-            uint8_t *ccolp = own_c + 64 * cp + cr, *accolp = abv_c + 64 * cp + cr;
-            int y0 = acolp[16 * 12], y1 = acolp[16 * 13], y2 = acolp[16 * 14], y3 = acolp[16 * 15];
-            int y4 = colp[16 * 0], y5 = colp[16 * 1], y6 = colp[16 * 2], y7 = colp[16 * 3];
-            int y8 = colp[16 * 4], y9 = colp[16 * 5], y10 = colp[16 * 6], y11 = colp[16 * 7];
-            int y12 = colp[16 * 8], y13 = colp[16 * 9], y14 = colp[16 * 10], y15 = colp[16 * 11];
-            int y16 = colp[16 * 12], y17 = colp[16 * 13], y18 = colp[16 * 14];
-            int u0 = accolp[8 * 6], u1 = accolp[8 * 7], u2 = ccolp[8 * 0], u3 = ccolp[8 * 1];
-            int u4 = ccolp[8 * 2], u5 = ccolp[8 * 3], u6 = ccolp[8 * 4], u7 = ccolp[8 * 5];
-            const int e0 = luma_line<true>(y0, y1, y2, y3, y4, y5, y6, y7, BYTE(bsw1, 0), AB_A(ab_t), AB_B(ab_t), BYTE(tct1, 0));
-            if (e0) {
-                if (e0 == 2) { acolp[16 * 13] = (uint8_t)y1; colp[16 * 2] = (uint8_t)y6; }
-                acolp[16 * 14] = (uint8_t)y2; acolp[16 * 15] = (uint8_t)y3; colp[16 * 0] = (uint8_t)y4; colp[16 * 1] = (uint8_t)y5;
-            }
-            if (luma_line<false>(y4, y5, y6, y7, y8, y9, y10, y11, BYTE(bsw1, 1), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 1))) {
-                colp[16 * 2] = (uint8_t)y6; colp[16 * 3] = (uint8_t)y7; colp[16 * 4] = (uint8_t)y8; colp[16 * 5] = (uint8_t)y9;
-            }
-            if (luma_line<false>(y8, y9, y10, y11, y12, y13, y14, y15, BYTE(bsw1, 2), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 2))) {
-                colp[16 * 6] = (uint8_t)y10; colp[16 * 7] = (uint8_t)y11; colp[16 * 8] = (uint8_t)y12; colp[16 * 9] = (uint8_t)y13;
-            }
-            int y19 = 0;
-            if (luma_line<false>(y12, y13, y14, y15, y16, y17, y18, y19, BYTE(bsw1, 3), AB_A(ab_i), AB_B(ab_i), BYTE(tci1, 3))) {
-                colp[16 * 10] = (uint8_t)y14; colp[16 * 11] = (uint8_t)y15; colp[16 * 12] = (uint8_t)y16; colp[16 * 13] = (uint8_t)y17;
-            }
-            if (chroma_line(u0, u1, u2, u3, BYTE(bsc1, 0), AB_A(cab_t), AB_B(cab_t), BYTE(cct1, 0))) {
-                accolp[8 * 7] = (uint8_t)u1; ccolp[8 * 0] = (uint8_t)u2;
-            }
-            if (chroma_line(u4, u5, u6, u7, BYTE(bsc1, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci1, 2))) {
-                ccolp[8 * 3] = (uint8_t)u5; ccolp[8 * 4] = (uint8_t)u6;
-            }
-        }
-#undef AB_A
-#undef AB_B
-#undef BYTE
-        MI355_WAVE_SYNC();
-        /* ---- what is final goes out, a whole tile line per eight lanes ------------------------------------------------------------
-         * lanes 0..7: rows 0..7 of the previous macroblock of this row (its last columns got this macroblock's left edge);
-         * lanes 8..15: rows 8..15 of the macroblock above (its last rows got this macroblock's top edge), and its chroma tile */
-        {
-            const bool lo = l < 8;
-            const int sx = lo ? mb_x - 1 : mb_x, sy = lo ? mb_y : mb_y - 1;
-            const bool ok = lo ? (row_ok && mb_x >= 1 && mb_x <= W) : (has_t && valid);
-            const uint4 v = lds16((lo ? left_y : abv_y) + 16 * l);
-            if (ok) {
-                if (TILED) st16(dst_y0 + tile_y_off(sx, sy, ds) + 16 * l, v, true);
-                else st16(dst_y0 + (uint32_t)(__mul24(16 * sy + l, ds) + 16 * sx), v, al16);
-            }
-            const uint2 vc = *reinterpret_cast<const uint2 *>(abv_c + 8 * l);
-            if (has_t && valid) {
-                if (TILED) st8(dst_cb + tile_c_off(mb_x, mb_y - 1, dcs) + 8 * l, vc, true);
-                else st8((cp ? dst_cr : dst_cb) + (uint32_t)(__mul24(8 * (mb_y - 1) + cr, dcs) + 8 * mb_x), vc, al8);
-            }
-            /* a row nobody of this wave works below: its own second line and chroma tile as well */
-            const uint2 by = *reinterpret_cast<const uint2 *>(left_y + 128 + 8 * l), bc = *reinterpret_cast<const uint2 *>(left_c + 8 * l);
-            if (bottom && mb_x >= 1 && mb_x <= W) {
-                uint8_t *py, *pcc;
-                if (TILED) {
-                    py = dst_y0 + tile_y_off(mb_x - 1, mb_y, ds) + 128 + 8 * l;
-                    pcc = dst_cb + tile_c_off(mb_x - 1, mb_y, dcs) + 8 * l;
-                } else {
-                    py = dst_y0 + (uint32_t)(__mul24(16 * mb_y + 8 + (l >> 1), ds) + 16 * (mb_x - 1) + 8 * (l & 1));
-                    pcc = (cp ? dst_cr : dst_cb) + (uint32_t)(__mul24(8 * mb_y + cr, dcs) + 8 * (mb_x - 1));
-                }
-                if (hand && TILED) { agent_store8(py, by, true); agent_store8(pcc, bc, true); }
-                else { st8(py, by, al8); st8(pcc, bc, al8); }
-            }
-        }
-        /* ---- the band below may take the macroblocks that are out: group 3 has stored macroblocks 0 .. t - 7 of its row --------- */
-        if (TILED && hand && ((t & (DB2_PUB - 1)) == DB2_PUB - 1 || t == nsteps - 1)) {
-            agent_drain_stores();
-            const int done = t - 6 < 0 ? 0 : (t - 6 < W ? t - 6 : W);
-            if (lane == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
-        }
-    }
-    if (!TILED && hand) {
-        /* planes with line strides: the band below waits for all of this one (see the head of this section) */
-        agent_release();
-        if (lane == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)W);
-    }
-}
-
-
 /* ===================================================================================================================== */
-/* The same form for macroblock-tiled surfaces: tiles arrive by LDS-DMA                                                    */
+/* The loop filter on macroblock-tiled surfaces (round 4): every band of every picture in ONE launch, tiles by LDS-DMA     */
 /* ===================================================================================================================== */
-/* deblock2_band holds a macroblock's rows in registers from the load to the vertical edges and the next macroblock's in a
- * second set behind them: 145+ vector registers, three waves per SIMD, 59 % of the VALU's issue slots used (a wave issues one
- * instruction of any kind per four cycles; a step is ~450 VALU among ~1050 instructions and three LDS round trips).  On tiled
- * surfaces a macroblock is 256 + 128 contiguous bytes, so the tiles of the four groups' next macroblocks go straight from memory
- * into the LDS ring (global_load_lds_dwordx4: no register holds a sample in flight), a whole step before they are used:
- *   - ring[step & 3][group]: a 16-byte piece lands at base + 16 * lane, so the ring is lane-linear and unpadded; the four
- *     groups' column accesses of the horizontal edges are kept off each other's banks by WHICH piece a lane fetches: row r
- *     of group g's tile lives at 16 * (r ^ g) (chroma: 16-byte piece k at 16 * (k ^ g));
- *   - the second tile line + chroma tile of the macroblock above a band arrive the same way (16 lanes, agent scope) into
- *     above[step & 1], swizzled with 3 (= the group "above group 0");
- *   - what a step makes final is written out at the START of the next step, right after the wait that begins it, so that wait
- *     finds stores a whole step old and the progress counter can be published without a drain of its own;
- *   - lane constants (boundary-strength roles, vector offsets) sit in a 768-byte LDS table and everything else derived from
- *     the lane number is recomputed per step from an opaque lane id: hoisted out of the loop they cost 40 registers. */
+/* What stays of deblock_band above: a wave = a band of four macroblock rows of one picture, lanes 16g..16g+15 = row 4 * band + g,
+ * group g at macroblock x = t - 2g in step t (the reference's raster dependencies by lock-step execution), boundary strengths by
+ * lane role, the edge filters themselves.  What changes:
+ *
+ *  - bands do not wait for launches.  All bands of all pictures are workgroups of one launch, taken in band-major order from a
+ *    ticket counter (a wave only ever waits for a lower ticket, which is running or done: no dependence on the order the
+ *    hardware dispatches workgroups in), and band b + 1 follows band b a dozen macroblocks behind: band b hands the second tile
+ *    lines and the chroma tiles of its last row down through `dst` with agent-scope write-through stores and publishes how
+ *    many macroblocks are out in a progress counter; band b + 1 polls the counter and fetches them with agent-scope loads
+ *    (/opt/skills/guides/cdna_hip_programming.md section 6, guideline 16, form R1: sc1 payload, drained, flag; sc1 loads on the
+ *    consumer).  With 2048 pictures the launch keeps every SIMD at its register-bound occupancy (the per-band launches were
+ *    2048 waves = two per SIMD whatever the kernel needed); with 64 pictures a picture's seventeen bands overlap;
+ *  - the unit that moves is ONE MACROBLOCK per group and step: a tile is two + one whole cache lines whoever reads it.  The
+ *    tiles of the four groups' next macroblocks go straight from memory into an LDS ring (global_load_lds_dwordx4: no register
+ *    holds a sample in flight; the first version of this form kept them in registers: 145 of them, three waves per SIMD), a
+ *    whole step before they are used:
+ *      ring[step & 3][group]: a 16-byte piece lands at base + 16 * lane, so the ring is lane-linear and unpadded; the four
+ *      groups' column accesses of the horizontal edges are kept off each other's banks by WHICH piece a lane fetches: row r of
+ *      group g's tile lives at 16 * (r ^ g) (chroma: 16-byte piece k at 16 * (k ^ g));
+ *      the second tile line + chroma tile of the macroblock above a band arrive the same way (16 lanes, agent scope) into
+ *      above[step & 1], swizzled with 3 (= the group "above group 0");
+ *  - the rows above a macroblock are not copied: the horizontal edges read and patch rows 12..15 of the tile in the ring of the
+ *    group above, and that tile's SECOND cache line (rows 8..15) and its chroma tile are written to `dst` by the group BELOW
+ *    once they are final — every store is a whole 128-byte line of a tile;
+ *  - what a step makes final is written out at the START of the next step, right after the wait that begins it: that wait
+ *    finds stores a whole step old, and the progress counter is published behind it without a drain of its own;
+ *  - the boundary-strength roles sit in a 768-byte LDS table, the address arithmetic in a dozen per-lane constants.
+ * The kernel runs at the VALU's issue rate (profiles/r04d_pmc_deblock_tiled_f2048.txt: 555 VALU per step, 84 % of the issue slots
+ * at four waves per SIMD). */
 struct __attribute__((aligned(128))) Deblock3Lds {
     uint8_t y[4][4][256];
     uint8_t c[4][4][128];
@@ -1344,56 +1051,29 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
 }
 
 /* Band-major tickets: all pictures' band 0, then band 1, ...; a wave's only dependence is the ticket nframes before its own, taken by a
- * wave that is running or done whatever order the hardware dispatches workgroups in.  Two kernels share the launch geometry and the
- * progress words and each takes the pictures of ONE surface layout (a picture of the other layout costs its waves a ticket and a look at
- * the descriptor): the tiled form must not carry the other's registers.  sync[0] / sync[1]: the kernels' ticket counters; sync[16 ...]:
- * one progress word per picture and band. */
-template <bool TILED>
-__device__ __forceinline__ bool deblock_ticket(const mi355_h264_frame *frames, int nframes, int nbands, uint32_t *sync, int &pic, int &band)
-{
-    uint32_t tk = 0;
-    if (lane_id() == 0) tk = atomicAdd(mi355_global(sync) + (TILED ? 0 : 1), 1u);
-    tk = (uint32_t)lane_value((int)tk, 0);
-    band = (int)(tk / (uint32_t)nframes);
-    pic = (int)(tk - (uint32_t)band * (uint32_t)nframes);
-    if (band >= nbands) return false;
-    const mi355_h264_frame &fr = frames[pic];
-    return 4 * band < uniform(fr.mb_height) && (uniform(fr.surface_layout) == MI355_SURFACE_TILED) == TILED;
-}
+ * wave that is running or done.  sync[0]: the ticket counter; sync[16 ...]: one progress word per picture and band.  Pictures that
+ * are not tiled are left to k_deblock / k_deblock_bands (their waves take a ticket, look at the descriptor and leave). */
 #ifdef MI355_DB3_WAVES
 __attribute__((amdgpu_waves_per_eu(MI355_DB3_WAVES, MI355_DB3_WAVES)))
 #endif
 __global__ void __launch_bounds__(64)
 k_deblock_tiled(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
 {
-    int pic, band;
-    if (!deblock_ticket<true>(frames, nframes, nbands, sync, pic, band)) return;
-    const mi355_h264_frame &fr = frames[pic];
-    uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
-#ifdef MI355_DEBLOCK_TILED_IN_REGISTERS          /* developer switch: the register form on tiled surfaces (round 4's first version) */
-    __shared__ Deblock2Lds s;
-    if (mi355_global(fr.mv[1]) != nullptr) deblock2_band<true, true>(s, fr, band, prog);
-    else deblock2_band<false, true>(s, fr, band, prog);
-#else
     __shared__ Deblock3Lds s;
+    uint32_t tk = 0;
+    if (lane_id() == 0) tk = atomicAdd(mi355_global(sync), 1u);
+    tk = (uint32_t)lane_value((int)tk, 0);
+    const int band = (int)(tk / (uint32_t)nframes), pic = (int)(tk - (uint32_t)band * (uint32_t)nframes);
+    if (band >= nbands) return;
+    const mi355_h264_frame &fr = frames[pic];
+    if (4 * band >= uniform(fr.mb_height) || uniform(fr.surface_layout) != MI355_SURFACE_TILED) return;
+    uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
 #ifdef MI355_EXP_DB2_ONLY        /* developer experiment: the instruction listing / register count of one instance alone (P pictures) */
     deblock3_band<false>(s, fr, band, prog);
     return;
 #endif
     if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true>(s, fr, band, prog);
     else deblock3_band<false>(s, fr, band, prog);
-#endif
-}
-__global__ void __launch_bounds__(64)
-k_deblock_linear(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
-{
-    __shared__ Deblock2Lds s;
-    int pic, band;
-    if (!deblock_ticket<false>(frames, nframes, nbands, sync, pic, band)) return;
-    const mi355_h264_frame &fr = frames[pic];
-    uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
-    if (mi355_global(fr.mv[1]) != nullptr) deblock2_band<true, false>(s, fr, band, prog);
-    else deblock2_band<false, false>(s, fr, band, prog);
 }
 
 }  // namespace
@@ -1450,21 +1130,22 @@ extern "C" int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, 
 {
     if (!mi355::bind() || !d_frames || nframes <= 0 || !(layouts & (MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED))) return -1;
     const int nbands = (max_mb_height + 3) / 4, nsteps = max_mb_width + 6;
-    /* MI355_DEBLOCK_FORM (developer switch): unset / 0 = ONE launch for all bands of all pictures (k_deblock2); 1 = a launch per band
-     * (k_deblock), 2 / 3 / 4 / 6 = that many bands per workgroup (k_deblock_bands), -1 = the cheaper of those by the estimate below:
-     * the forms of rounds 1-3, kept for comparison */
+    if (nbands <= 0 || max_mb_width <= 0) return -1;
+    /* Tiled pictures: ONE launch for all bands of all pictures (k_deblock_tiled).  Pictures with line strides (field pictures, 4:4:4 plane
+     * passes, callers that keep AVFrame-like planes): the forms of rounds 1-3, whose chunked row pieces suit that layout — a launch per
+     * band, or 2 to 6 bands per workgroup when the pictures are few.  MI355_DEBLOCK_FORM (developer switch) = 1 / 2 / 3 / 4 / 6 pins the
+     * latter's bands per workgroup and sends tiled pictures through it as well (what round 3 measured). */
     static const int force = std::getenv("MI355_DEBLOCK_FORM") ? std::atoi(std::getenv("MI355_DEBLOCK_FORM")) : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (force == 0) {
-        if (nbands <= 0 || max_mb_width <= 0) return -1;
+    const bool tiled_launch = (layouts & MI355_LAYOUTS_TILED) && force == 0;
+    if (tiled_launch) {
         if ((long long)nframes * nbands > 0x7FFFFFFFLL) return -3;
         const size_t words = 16 + (size_t)nframes * (size_t)nbands;
         uint32_t *sync = sync_words(st, words);
         if (!sync) return -4;
         MI355_TRY(hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st), -4);
-        if (layouts & MI355_LAYOUTS_TILED) hipLaunchKernelGGL(k_deblock_tiled, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
-        if (layouts & MI355_LAYOUTS_LINEAR) hipLaunchKernelGGL(k_deblock_linear, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
+        hipLaunchKernelGGL(k_deblock_tiled, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
+        if (!(layouts & MI355_LAYOUTS_LINEAR)) return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     static int cus = 0;
     if (!cus) {
@@ -1485,14 +1166,15 @@ extern "C" int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, 
         if (i == 0 || cost < best_cost) { best = kw; best_cost = cost; }
     }
     if (force == 1 || force == 2 || force == 3 || force == 4 || force == 6) best = force;
+    const int skip = tiled_launch ? 1 : 0;
     for (int band = 0; band < nbands; band += best) {
         const dim3 grid((unsigned)nframes);
         switch (best) {
-        case 2: hipLaunchKernelGGL(k_deblock_bands<2>, grid, dim3(128), 0, st, d_frames, band); break;
-        case 3: hipLaunchKernelGGL(k_deblock_bands<3>, grid, dim3(192), 0, st, d_frames, band); break;
-        case 4: hipLaunchKernelGGL(k_deblock_bands<4>, grid, dim3(256), 0, st, d_frames, band); break;
-        case 6: hipLaunchKernelGGL(k_deblock_bands<6>, grid, dim3(384), 0, st, d_frames, band); break;
-        default: hipLaunchKernelGGL(k_deblock, grid, dim3(64), 0, st, d_frames, band); break;
+        case 2: hipLaunchKernelGGL(k_deblock_bands<2>, grid, dim3(128), 0, st, d_frames, band, skip); break;
+        case 3: hipLaunchKernelGGL(k_deblock_bands<3>, grid, dim3(192), 0, st, d_frames, band, skip); break;
+        case 4: hipLaunchKernelGGL(k_deblock_bands<4>, grid, dim3(256), 0, st, d_frames, band, skip); break;
+        case 6: hipLaunchKernelGGL(k_deblock_bands<6>, grid, dim3(384), 0, st, d_frames, band, skip); break;
+        default: hipLaunchKernelGGL(k_deblock, grid, dim3(64), 0, st, d_frames, band, skip); break;
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

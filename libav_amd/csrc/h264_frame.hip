@@ -618,7 +618,10 @@ __device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame 
     else store_mb_rows(s, fr, mb_x, mb_y);
     RPROF(7);
 }
-template <bool SPARSE>
+/* LAYOUTS: the surface layouts the launch may meet (MI355_LAYOUTS_*).  A picture says which one it has and the general kernel carries both forms of the
+ * macroblock code; a caller that knows its batch is tiled throughout launches the instance that holds the tiled form alone — 61 instead of 139 scalar
+ * registers spilled at eight waves per SIMD (each spill and reload is a VALU instruction), half the code */
+template <bool SPARSE, int LAYOUTS = MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED>
 __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
                                                  unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
@@ -629,12 +632,12 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
     const int row = div_magic(lin, inv_w), mb_x = lin - row * max_w;
     const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
     /* the surface layout is a property of the picture: both forms of the macroblock code live in the kernel, a wave takes one */
-#ifdef MI355_EXP_ONLY_TILED      /* developer experiment: the instruction listing of one form alone (tools/isa_lines.py) */
-    recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
-#else
+    if (LAYOUTS == MI355_LAYOUTS_TILED) {
+        if (uniform(frames[f].surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
+        return;                                              /* a picture of the other layout in a launch that promised none: left alone */
+    }
     if (uniform(frames[f].surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<SPARSE, true>(s, frames[f], mb_x, mb_y);
     else recon_inter_mb<SPARSE, false>(s, frames[f], mb_x, mb_y);
-#endif
 }
 /* Eight waves per SIMD: left alone the compiler takes 106 scalar registers (seven waves).  Capped at 96 it spills more of them
  * to vector lanes (+45 VALU per macroblock) and the kernel is still 2.5 % faster: it waits on three dependent memory round
@@ -648,6 +651,13 @@ k_recon_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
 {
     __shared__ MbLds s;
     recon_inter_wave<false>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
+}
+__attribute__((amdgpu_waves_per_eu(MI355_RECON_WAVES, MI355_RECON_WAVES)))
+__global__ void __launch_bounds__(64)
+k_recon_inter_tiled(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+{
+    __shared__ MbLds s;
+    recon_inter_wave<false, MI355_LAYOUTS_TILED>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
 }
 __attribute__((amdgpu_waves_per_eu(MI355_RECON_WAVES, MI355_RECON_WAVES)))
 __global__ void __launch_bounds__(64)
@@ -818,7 +828,7 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
 /* ------------------------------------------------------------------------- */
 /* host entry points                                                            */
 /* ------------------------------------------------------------------------- */
-static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, bool sparse, void *stream)
+static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, bool sparse, void *stream, int layouts = MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED)
 {
     if (!mi355::bind() || !d_frames || nframes <= 0) return -1;
     /* div_magic is exact below 2^24 work items: larger batches go out as several launches */
@@ -833,6 +843,9 @@ static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int
         if (sparse)
             hipLaunchKernelGGL(k_recon_inter_sparse, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
                                d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
+        else if (layouts == MI355_LAYOUTS_TILED)
+            hipLaunchKernelGGL(k_recon_inter_tiled, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
+                               d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
         else
             hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
                                d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
@@ -842,6 +855,11 @@ static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int
 extern "C" int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
     return recon_inter_launch(d_frames, nframes, max_mb_width, max_mb_height, false, stream);
+}
+extern "C" int mi355_h264_recon_inter_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int layouts, void *stream)
+{
+    if (!(layouts & (MI355_LAYOUTS_LINEAR | MI355_LAYOUTS_TILED))) return -1;
+    return recon_inter_launch(d_frames, nframes, max_mb_width, max_mb_height, false, stream, layouts);
 }
 extern "C" int mi355_h264_recon_inter_sparse_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {

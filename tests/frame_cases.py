@@ -38,7 +38,7 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=False):
+def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=False, by_layout=False):
     fs = HF.synth_frames(**CASES[name])
     if sparse:
         # real P / B pictures: many inter macroblocks carry no residual at all (cbp 0) — about every other one here
@@ -53,6 +53,8 @@ def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=F
     try:
         if sparse:
             d.decode_sparse()
+        elif by_layout:
+            d.decode_by_layout()
         else:
             d.decode(per_level=per_level)
         recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)

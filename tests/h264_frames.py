@@ -602,6 +602,20 @@ class DeviceFrames:
         self.lib.mi355_sync.restype = C.c_int
         assert self.lib.mi355_sync(stream) == 0
 
+    def decode_by_layout(self):
+        """the three passes through the entry points that take the batch's surface layouts (what bench.py, the sessions and the bridge call:
+        mi355_h264_recon_inter_layouts_dev / mi355_h264_deblock_layouts_dev — the kernel instances that carry one layout's code alone)"""
+        fs, lib = self.fs, self.lib
+        mask = 2 if self.tiled else 1
+        lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+        for name, args in (("mi355_h264_recon_inter_layouts_dev", (fs.mb_w, fs.mb_h, mask)), ("mi355_h264_recon_intra_levels_dev", (fs.max_intra_level, lw)),
+                           ("mi355_h264_deblock_layouts_dev", (fs.mb_w, fs.mb_h, mask))):
+            fn = getattr(lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_int] + [C.c_int if isinstance(a, int) else C.c_void_p for a in args] + [C.c_void_p]
+            assert fn(self.d_desc, self.F, *args, None) == 0, name
+        assert lib.mi355_sync(None) == 0
+
     def decode_sparse(self, poison=True):
         """the three passes with mi355_h264_recon_inter_sparse_dev: inter macroblocks whose cbp is zero do not fetch their
         coefficient block — shown by overwriting those blocks on the device with 0x7F7F first"""

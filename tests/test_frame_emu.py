@@ -127,3 +127,10 @@ def test_mixed_partition_workload_matches_oracle_emulated(emu, oracle, tiled):
     for p in range(3):
         assert np.array_equal(recon_o[p], recon_g[p])
         assert np.array_equal(dst_o[p], dst_g[p])
+
+
+@pytest.mark.parametrize("tiled", (True, False))
+@pytest.mark.parametrize("name", list(frame_cases.CASES))
+def test_frame_pipeline_emulated_layout_entry_points(emu, oracle, name, tiled):
+    """mi355_h264_recon_inter_layouts_dev / mi355_h264_deblock_layouts_dev with the batch's one layout named: the single-layout kernel instances"""
+    frame_cases.run_case(emu, oracle, name, tiled=tiled, by_layout=True)

@@ -156,9 +156,9 @@ def test_loop_filter_bands_hand_down_under_load(mi355, oracle, F, tiled):
     recon_o, dst_o = HF.run_oracle(oracle, fs)
     d = HF.DeviceFrames(mi355, fs, replicate=F, tiled=tiled)
     try:
-        d.decode()
+        d.decode_by_layout()
         assert mi355.lib.mi355_memcpy_d2d(d.dst, d.recon, F * d.fsz) == 0        # scribble: the unfiltered pictures
-        d.decode()
+        d.decode_by_layout()
         bad = []
         for first in range(0, F, 32):
             n = min(32, F - first)
@@ -170,3 +170,10 @@ def test_loop_filter_bands_hand_down_under_load(mi355, oracle, F, tiled):
         assert not bad, "%d of %d pictures differ from the oracle, first: %s" % (len(bad), F, bad[:8])
     finally:
         d.free()
+
+
+@pytest.mark.parametrize("tiled", (True, False))
+@pytest.mark.parametrize("name", list(frame_cases.CASES))
+def test_frame_pipeline_gpu_layout_entry_points(mi355, oracle, name, tiled):
+    """mi355_h264_recon_inter_layouts_dev / mi355_h264_deblock_layouts_dev with the batch's one layout named: the single-layout kernel instances"""
+    frame_cases.run_case(mi355, oracle, name, tiled=tiled, by_layout=True)
