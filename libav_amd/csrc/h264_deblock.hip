@@ -661,10 +661,6 @@ k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0, int skip
 
 
 
-#ifndef MI355_DB2_PUB_LOG
-#define MI355_DB2_PUB_LOG 2                      /* a band publishes its progress every 1 << PUB_LOG steps */
-#endif
-constexpr int DB2_PUB = 1 << MI355_DB2_PUB_LOG;
 /* agent-scope accesses of the band hand-over (plain in the emulator: workgroups run one after the other there) */
 #ifdef MI355_HIP_EMU_H
 static inline uint32_t agent_load_u32(const uint32_t *p) { return *p; }
@@ -893,15 +889,26 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
         const uint2 vc = *reinterpret_cast<const uint2 *>(lds + (k_lc + (g0 ? ua : u2c)));
         if (kf(KF_TOP) && in_hi) st8(dst_c0 + (k_sc + ((uint32_t)ts << 7)), vc, true);
         const uint2 by = *reinterpret_cast<const uint2 *>(lds + (k_ld + u1y)), bc = *reinterpret_cast<const uint2 *>(lds + (k_cv + u1c));
-        if (kf(KF_BOTTOM) && in_lo) {
-            uint8_t *py = dst_y0 + (k_sd + ((uint32_t)ts << 8)), *pcc = dst_c0 + (k_se + ((uint32_t)ts << 7));
-            if (hand) { agent_store8(py, by, true); agent_store8(pcc, bc, true); }
-            else { st8(py, by, true); st8(pcc, bc, true); }
+        if (!hand && kf(KF_BOTTOM) && in_lo) {              /* with a band below, group 3's row went out in hand_down(), a step earlier */
+            st8(dst_y0 + (k_sd + ((uint32_t)ts << 8)), by, true);
+            st8(dst_c0 + (k_se + ((uint32_t)ts << 7)), bc, true);
         }
         MI355_WAVE_SYNC();                                   /* every lane has read its pieces: the slots are free for the DMA issued next (program order
                                                                 on the device; a rendezvous of the fibers in the emulator) */
     };
 
+    /* Group 3's row of a band with a band below: the second tile line and the chroma tile of the PREVIOUS macroblock are what that band
+     * waits for, and they are ready as soon as this step's vertical edges have patched its last columns — they leave right then, written
+     * through, and are announced behind the wait that begins the next step (the band below finishes and rewrites them) */
+    auto hand_down = [&](int t) {
+        const uint32_t u1y = OY + 1024u * (uint32_t)((t - 1) & 3), u1c = OC + 512u * (uint32_t)((t - 1) & 3);
+        const uint32_t xlo = (uint32_t)t - k_g2 - 1u;
+        const uint2 by = *reinterpret_cast<const uint2 *>(lds + (k_ld + u1y)), bc = *reinterpret_cast<const uint2 *>(lds + (k_cv + u1c));
+        if (kf(KF_BOTTOM) && xlo < (uint32_t)W) {
+            agent_store8(dst_y0 + (k_sd + ((uint32_t)t << 8)), by, true);
+            agent_store8(dst_c0 + (k_se + ((uint32_t)t << 7)), bc, true);
+        }
+    };
     Pre pre = {};
     MbInfo hl = {};
     await_above(0);
@@ -912,9 +919,9 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
     for (int t = 0; t < nsteps; t++) {
         /* ---- everything requested during the last step is here; what was stored during it is out ---------------------------------- */
         agent_drain_stores();
-        if (hand && t >= 2 && (t & (DB2_PUB - 1)) == 0) {
-            /* stores(t - 2) were issued in step t - 1: group 3 has macroblocks 0 .. t - 9 of its row out */
-            const int done = t - 8 < 0 ? 0 : (t - 8 < W ? t - 8 : W);
+        if (hand && t >= 8) {
+            /* hand_down(t - 1) is out: group 3's macroblocks 0 .. t - 8 */
+            const int done = t - 7 < W ? t - 7 : W;
             if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
         }
         MI355_WAVE_SYNC();
@@ -989,6 +996,7 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
         }
         MI355_WAVE_SYNC();
+        if (hand) hand_down(t);
         /* ---- horizontal edges: lane l of a group = luma column l and chroma column (plane l >> 3, column l & 7); rows -4..-1 (chroma -2, -1)
          * are rows 12..15 (6, 7) of the tile above — in the ring of the group above, or in above[] — read and patched where they lie -------- */
         {
