@@ -33,6 +33,14 @@ using namespace mi355;
 namespace {
 
 
+/* Scratch of the general partition path on tiled surfaces (hl_motion4): the macroblock as sixteen 4x4 blocks, each with its own
+ * vector, reference and block-aligned window */
+struct __attribute__((aligned(16))) Mc4Scratch {
+    uint32_t winY[16][9][3];     /* block b: rows iy - 2 .. iy + 6, byte j = picture column ix - 4 + j (block column 0 on a dword) */
+    uint32_t winC[2][16][3];     /* plane, block: rows cy .. cy + 2, byte j = column cx + j (j = 0..2) */
+    int16_t tmp[16][9][4];       /* unclipped horizontal 6-tap sums of a block's nine rows (centre positions) */
+    uint64_t qref[2][4][2];      /* [list][quadrant]: luma and chroma plane of the quadrant's reference picture */
+};
 struct __attribute__((aligned(16))) MbLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];                      /* (x | y << 16) per 4x4 block, raster order, per list */
@@ -42,7 +50,10 @@ struct __attribute__((aligned(16))) MbLds {
 #ifdef MI355_EXP_LDS_PAD                     /* developer experiment: fewer waves per CU */
     uint8_t exp_pad[MI355_EXP_LDS_PAD];
 #endif
-    McScratch mc;
+    union {
+        McScratch mc;                        /* one partition's windows (the 16x16 path; every path on surfaces with line strides) */
+        Mc4Scratch mc4;                      /* the windows of sixteen 4x4 blocks (the general path on tiled surfaces) */
+    };
 };
 
 
@@ -236,6 +247,270 @@ __device__ __forceinline__ void mc_part(MbLds &s, const FrameHot &fr, RefTable r
     }
 }
 
+/* ---- the general partition path on macroblock-tiled surfaces ---------------------------------------------------------------------
+ * hl_motion's partition loop (below) spends a whole-wave pass of ~230 instructions on every partition whatever its size: a macroblock
+ * of 4x4 sub-partitions is sixteen of them per list (SURVEY 8d's mixed run: 5.6 prediction blocks per macroblock, 36 ms per 2048
+ * pictures against 10.4 for 16x16).  Here every macroblock that is not one 16x16 partition is sixteen 4x4 blocks, FOUR LANES each
+ * (lane 4b + r = row r of block b, raster order), and a lane works with its own block's vector, reference and quarter-sample case:
+ *   - per list, the nine 12-byte window rows of every block are fetched by 144 lane tasks (three rounds): one unaligned 12-byte load
+ *     from the tile holding the row's first byte and, for rows that run over the tile's edge, a second one from the next tile, merged
+ *     by byte masks (v_bfi); chroma: 3 x 3 bytes per block and plane, 96 tasks;
+ *   - the filters are mc_luma_compute's arithmetic (h264qpel_template.c:77-531) with the position flags per lane: every component
+ *     (integer sample, horizontal / vertical half sample, centre) is evaluated where ANY lane needs it and added where THIS lane does;
+ *   - weights per 8x8 quadrant afterwards (mc_part's formulas: one reference per quadrant and list).
+ * Windows that reach over the left or right picture border take per-byte clamped loads (emulated_edge_mc's replication), rows clamp by
+ * their row number.  Same results as the partition loop, which stays for surfaces with line strides. */
+__device__ __forceinline__ void mc4_list(MbLds &s, const FrameHot &fr, int mb_x, int mb_y, int list, uint32_t use, uint32_t to_q, uint32_t avg)
+{
+    /* use / to_q / avg: bit b = block b is predicted from this list / its prediction goes to the q tiles (weighted second list) /
+     * is averaged into what the first list left */
+    Mc4Scratch &m = s.mc4;
+    const int wpix = 16 * fr.mb_width, hpix = 16 * fr.mb_height, wc = wpix >> 1, hc = hpix >> 1;
+    /* ---- luma windows: task i = 9 b + k ---------------------------------------------------------------------------------- */
+#pragma unroll
+    for (int round = 0; round < 3; round++) {
+        const int i = lane_id() + 64 * round;
+        const int ic = i < 144 ? i : 143;
+        const int b = (ic * 57) >> 9, k = ic - 9 * b;
+        const uint32_t mvw = s.mv[list][b];
+        const int x0 = mb_x * 16 + 4 * (b & 3) + ((int)(int16_t)(mvw & 0xFFFF) >> 2) - 4;
+        const int y = clip3(mb_y * 16 + 4 * (b >> 2) + ((int)(int16_t)(mvw >> 16) >> 2) - 2 + k, 0, hpix - 1);
+        const uint8_t *ref = reinterpret_cast<const uint8_t *>(m.qref[list][(b & 2 ? 1 : 0) + (b & 8 ? 2 : 0)][0]);
+        const uint8_t *row = mi355_global_v(ref) + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + (y & 15) * 16);
+        const bool cross = x0 < 0 || x0 + 11 > wpix - 1;
+        const int xs = clip3(x0, 0, wpix - 12), tx = xs >> 4, ox = xs & 15;
+        struct __attribute__((packed)) B12 { uint32_t a, b, c; };
+        B12 va, vb;
+        __builtin_memcpy(&va, row + tx * 256 + ox, 12);
+        /* the part of the row that lies in the next tile: its byte j sits 16 - ox bytes in front of that tile's row */
+        __builtin_memcpy(&vb, row + (ox > 4 ? (tx + 1) * 256 - (16 - ox) : tx * 256 + ox), 12);
+        MI355_ISSUE_FENCE();
+        const int na = 16 - ox;                              /* bytes of the window in the first tile (>= 12: all) */
+        uint32_t w[3] = { va.a, va.b, va.c };
+        const uint32_t wb[3] = { vb.a, vb.b, vb.c };
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int n = na - 4 * d;                        /* bytes of dword d that come from the first tile */
+            const uint32_t keep = n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << (8 * n)) - 1u));
+            w[d] = (w[d] & keep) | (wb[d] & ~keep);
+        }
+        if (__any(cross)) {
+            if (cross) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int x = clip3(x0 + 4 * d + j, 0, wpix - 1);
+                        v |= (uint32_t)row[(x >> 4) * 256 + (x & 15)] << (8 * j);
+                    }
+                    w[d] = v;
+                }
+            }
+        }
+        if (i < 144) { m.winY[b][k][0] = w[0]; m.winY[b][k][1] = w[1]; m.winY[b][k][2] = w[2]; }
+    }
+    /* ---- chroma windows: task i = 48 plane + 3 b + k ------------------------------------------------------------------------- */
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        const int i = lane_id() + 64 * round;
+        const int ic = i < 96 ? i : 95;
+        const int plane = ic >= 48, rem = ic - 48 * plane, b = (rem * 43) >> 7, k = rem - 3 * b;
+        const uint32_t mvw = s.mv[list][b];
+        const int x0 = mb_x * 8 + 2 * (b & 3) + ((int)(int16_t)(mvw & 0xFFFF) >> 3);
+        const int y = clip3(mb_y * 8 + 2 * (b >> 2) + ((int)(int16_t)(mvw >> 16) >> 3) + k, 0, hc - 1);
+        const uint8_t *ref = reinterpret_cast<const uint8_t *>(m.qref[list][(b & 2 ? 1 : 0) + (b & 8 ? 2 : 0)][1]);
+        const uint8_t *row = mi355_global_v(ref) + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + plane * 64 + (y & 7) * 8);
+        const bool cross = x0 < 0 || x0 + 2 > wc - 1;
+        const int xs = clip3(x0, 0, wc - 4), tx = xs >> 3, ox = xs & 7;
+        uint32_t va, vb;
+        __builtin_memcpy(&va, row + tx * 128 + ox, 4);
+        __builtin_memcpy(&vb, row + (ox > 4 ? (tx + 1) * 128 - (8 - ox) : tx * 128 + ox), 4);
+        MI355_ISSUE_FENCE();
+        const int na = 8 - ox;
+        const uint32_t keep = na >= 4 ? 0xFFFFFFFFu : ((1u << (8 * na)) - 1u);
+        /* a window that ends on the picture's last column starts one byte behind the last four-byte load that stays inside the row */
+        uint32_t w = ((va & keep) | (vb & ~keep)) >> (8 * (cross ? 0 : x0 - xs));
+        if (__any(cross)) {
+            if (cross) {
+                w = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int x = clip3(x0 + j, 0, wc - 1);
+                    w |= (uint32_t)row[(x >> 3) * 128 + (x & 7)] << (8 * j);
+                }
+            }
+        }
+        if (i < 96) m.winC[plane][b][k] = w;
+    }
+    MI355_WAVE_SYNC();
+    /* ---- per lane: block b = lane >> 2, row r = lane & 3 -------------------------------------------------------------------------- */
+    const int lane = lane_id(), b = lane >> 2, r = lane & 3;
+    const uint32_t mvw = s.mv[list][b];
+    const int mx = (int)(mvw & 3u), my = (int)((mvw >> 16) & 3u);
+    const bool used = (use >> b) & 1;
+    const bool use_j = used && ((mx == 2 && my != 0) || (my == 2 && mx != 0));
+    const bool use_b = used && mx != 0 && my != 2;
+    const bool use_h = used && my != 0 && mx != 2;
+    const bool use_g = used && (mx == 0 || my == 0) && ((mx | my) != 2);
+    if (__any(use_j)) {
+        /* unclipped horizontal sums of the nine rows of every block that has a centre position: task i = 9 b + k again */
+#pragma unroll
+        for (int round = 0; round < 3; round++) {
+            const int i = lane_id() + 64 * round;
+            const int ic = i < 144 ? i : 143;
+            const int tb = (ic * 57) >> 9, k = ic - 9 * tb;
+            const uint32_t *w = m.winY[tb][k];
+            uint32_t te, to;
+            pk_htaps(w[0], w[1], w[2], te, to);
+            if (i < 144) {
+                uint32_t *t = reinterpret_cast<uint32_t *>(m.tmp[tb][k]);
+                t[0] = (te & 0xFFFFu) | (to << 16);
+                t[1] = (te >> 16) | (to & 0xFFFF0000u);
+            }
+        }
+        MI355_WAVE_SYNC();
+    }
+    uint32_t se = 0, so = 0;                                 /* sums of the components, samples (0,2) and (1,3) */
+    if (__any(use_g)) {
+        const int gdx = (my == 0 && mx == 3), gdy = (mx == 0 && my == 3);
+        const uint32_t *w = m.winY[b][r + 2 + gdy];
+        const uint32_t g = gdx ? mi355_alignbyte(w[2], w[1], 1) : w[1];
+        if (use_g) { se = pk_even(g); so = pk_odd(g); }
+    }
+    if (__any(use_b)) {
+        const int bdy = my == 3;
+        uint32_t te, to;
+        if (use_j) {
+            const uint32_t *t = reinterpret_cast<const uint32_t *>(m.tmp[b][r + 2 + bdy]);
+            te = (t[0] & 0xFFFFu) | (t[1] << 16);
+            to = (t[0] >> 16) | (t[1] & 0xFFFF0000u);
+        } else {
+            const uint32_t *w = m.winY[b][r + 2 + bdy];
+            pk_htaps(w[0], w[1], w[2], te, to);
+        }
+        if (use_b) { se = pk_add(se, pk_round5(te)); so = pk_add(so, pk_round5(to)); }
+    }
+    if (__any(use_h)) {
+        const int hdx = mx == 3;
+        uint32_t e[6], o[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t *w = m.winY[b][r + q];
+            const uint32_t c = hdx ? mi355_alignbyte(w[2], w[1], 1) : w[1];
+            e[q] = pk_even(c); o[q] = pk_odd(c);
+        }
+        const uint32_t he = pk_round5(pk_tap6(e[0], e[1], e[2], e[3], e[4], e[5])), ho = pk_round5(pk_tap6(o[0], o[1], o[2], o[3], o[4], o[5]));
+        if (use_h) { se = pk_add(se, he); so = pk_add(so, ho); }
+    }
+    if (__any(use_j)) {
+        /* second pass over the unclipped sums: mc_luma_compute's staged-shift form (exact, see there) */
+        const uint32_t *t = reinterpret_cast<const uint32_t *>(m.tmp[b][r]);
+        uint32_t jv[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const uint32_t af = pk_add(t[hlf], t[10 + hlf]), be = pk_add(t[2 + hlf], t[8 + hlf]), cd = pk_add(t[4 + hlf], t[6 + hlf]);
+            const uint32_t t1 = pk_ashr(pk_sub(af, be), 2);
+            const uint32_t t2 = pk_ashr(pk_adds(pk_sub(t1, be), cd), 2);
+            jv[hlf] = pk_clip_u8(pk_ashr(pk_add(pk_add(t2, cd), 0x00200020u), 6));
+        }
+        if (use_j) { se = pk_add(se, byte_perm(jv[1], jv[0], 0x05040100u)); so = pk_add(so, byte_perm(jv[1], jv[0], 0x07060302u)); }
+    }
+    if ((int)use_g + (int)use_b + (int)use_h + (int)use_j == 2) {
+        se = pk_ashr(pk_add(se, 0x00010001u), 1); so = pk_ashr(pk_add(so, 0x00010001u), 1);
+    }
+    const bool q_dst = (to_q >> b) & 1, do_avg = (avg >> b) & 1;
+    {
+        const uint32_t v = pk_bytes(se, so);
+        uint32_t *d = reinterpret_cast<uint32_t *>((q_dst ? s.qy : s.py) + (4 * (b >> 2) + r) * 16 + 4 * (b & 3));
+        if (used) *d = do_avg ? rnd_avg4(*d, v) : v;
+    }
+    /* chroma (h264chroma_template.c:27-173): lane (b, r) = plane r >> 1, row r & 1 of the block's 2x2 samples */
+    {
+        const int plane = r >> 1, cy = r & 1;
+        const int fx = (int)(mvw & 7u), fy = (int)((mvw >> 16) & 7u);
+        const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
+        const uint32_t r0 = m.winC[plane][b][cy], r1 = m.winC[plane][b][cy + 1];
+        const uint32_t a0 = byte_perm(0, r0, 0x0C010C00u), a1 = byte_perm(0, r0, 0x0C020C01u);
+        const uint32_t b0 = byte_perm(0, r1, 0x0C010C00u), b1 = byte_perm(0, r1, 0x0C020C01u);
+        const uint32_t v = pk_ashr(pk_mad(a0, A, pk_mad(a1, B, pk_mad(b0, C, pk_mad(b1, D, 0x00200020u)))), 6);
+        uint32_t two = byte_perm(0, v, 0x0C0C0200u);
+        uint16_t *d = reinterpret_cast<uint16_t *>((q_dst ? s.qc[plane] : s.pc[plane]) + (2 * (b >> 2) + cy) * 8 + 2 * (b & 3));
+        if (used) {
+            if (do_avg) two = rnd_avg4(*d, two);
+            *d = (uint16_t)two;
+        }
+    }
+    MI355_WAVE_SYNC();
+}
+
+__device__ inline void hl_motion4(MbLds &s, const FrameHot &fr, const mi355_h264_slice &sl, int mb_x, int mb_y)
+{
+    const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
+    const int kind = (t & MI355_MB_16x8) ? 1 : ((t & MI355_MB_8x16) ? 2 : ((t & MI355_MB_16x16) ? 0 : 3));
+    /* the quadrants' reference planes -> LDS (lane 4 * list + quadrant) */
+    {
+        const int lane = lane_id(), l8 = lane & 7, list = l8 >> 2, q = l8 & 3;
+        const int slot = s.hdr.u.inter.ref_pic[list][q];
+        const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
+        const uint64_t py = (uint64_t)reinterpret_cast<uintptr_t>(rp[0]), pc = (uint64_t)reinterpret_cast<uintptr_t>(rp[1]);
+        MI355_ISSUE_FENCE();
+        if (lane < 8) { s.mc4.qref[list][q][0] = py; s.mc4.qref[list][q][1] = pc; }
+    }
+    /* per quadrant (wave-uniform): which lists, which weights */
+    uint32_t use0 = 0, use1 = 0, wq = 0;
+    const bool slice_w = (uniform(s.hdr.flags) & MI355_MBF_WEIGHTED) != 0;
+    for (int q = 0; q < 4; q++) {
+        int l0, l1;
+        if (kind == 3) { const int st = uniform(s.hdr.sub_mb_type[q]); l0 = (st & MI355_SUB_L0) != 0; l1 = (st & MI355_SUB_L1) != 0; }
+        else {
+            const int part = kind == 0 ? 0 : (kind == 1 ? q >> 1 : q & 1);
+            l0 = (int)((t >> (12 + part)) & 1); l1 = (int)((t >> (14 + part)) & 1);
+        }
+        const uint32_t blocks = 0x33u << (2 * (q & 1) + 8 * (q >> 1));          /* the quadrant's four 4x4 blocks (raster bits) */
+        if (l0) use0 |= blocks;
+        if (l1) use1 |= blocks;
+        const int r0 = uniform(s.hdr.ref_idx[0][q]), r1 = uniform(s.hdr.ref_idx[1][q]);
+        if (slice_w && ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1)) wq |= blocks;
+    }
+    MI355_WAVE_SYNC();
+    if (use0) mc4_list(s, fr, mb_x, mb_y, 0, use0, 0, 0);
+    if (use1) mc4_list(s, fr, mb_x, mb_y, 1, use1, use0 & use1 & wq, use0 & use1 & ~wq);
+    if (!wq) return;
+    /* weights, per quadrant: mc_part_weighted, h264_mb.c:369-471 */
+    for (int q = 0; q < 4; q++) {
+        const uint32_t blocks = 0x33u << (2 * (q & 1) + 8 * (q >> 1));
+        if (!(wq & blocks)) continue;
+        const int bx = 8 * (q & 1), by = 8 * (q >> 1);
+        const bool l0 = (use0 & blocks) != 0, l1 = (use1 & blocks) != 0;
+        const int r0 = uniform(s.hdr.ref_idx[0][q]), r1 = uniform(s.hdr.ref_idx[1][q]);
+        uint8_t *dy = s.py + by * 16 + bx, *dcb = s.pc[0] + (by >> 1) * 8 + (bx >> 1), *dcr = s.pc[1] + (by >> 1) * 8 + (bx >> 1);
+        if (l0 && l1) {
+            const uint8_t *ty = s.qy + by * 16 + bx, *tcb = s.qc[0] + (by >> 1) * 8 + (bx >> 1), *tcr = s.qc[1] + (by >> 1) * 8 + (bx >> 1);
+            if (sl.use_weight == 2) {
+                const int w0 = sl.implicit_weight[r0][r1], w1 = 64 - w0;
+                biweight_block(dy, ty, 16, 8, 8, 5, w0, w1, 0);
+                biweight_block(dcb, tcb, 8, 4, 4, 5, w0, w1, 0);
+                biweight_block(dcr, tcr, 8, 4, 4, 5, w0, w1, 0);
+            } else {
+                biweight_block(dy, ty, 16, 8, 8, sl.luma_log2_weight_denom, sl.luma_weight[r0][0][0], sl.luma_weight[r1][1][0],
+                               sl.luma_weight[r0][0][1] + sl.luma_weight[r1][1][1]);
+                biweight_block(dcb, tcb, 8, 4, 4, sl.chroma_log2_weight_denom, sl.chroma_weight[r0][0][0][0],
+                               sl.chroma_weight[r1][1][0][0], sl.chroma_weight[r0][0][0][1] + sl.chroma_weight[r1][1][0][1]);
+                biweight_block(dcr, tcr, 8, 4, 4, sl.chroma_log2_weight_denom, sl.chroma_weight[r0][0][1][0],
+                               sl.chroma_weight[r1][1][1][0], sl.chroma_weight[r0][0][1][1] + sl.chroma_weight[r1][1][1][1]);
+            }
+        } else {
+            const int list = l1 ? 1 : 0, refn = list ? r1 : r0;
+            weight_block(dy, 16, 8, 8, sl.luma_log2_weight_denom, sl.luma_weight[refn][list][0], sl.luma_weight[refn][list][1]);
+            if (sl.use_weight_chroma) {
+                weight_block(dcb, 8, 4, 4, sl.chroma_log2_weight_denom, sl.chroma_weight[refn][list][0][0], sl.chroma_weight[refn][list][0][1]);
+                weight_block(dcr, 8, 4, 4, sl.chroma_log2_weight_denom, sl.chroma_weight[refn][list][1][0], sl.chroma_weight[refn][list][1][1]);
+            }
+        }
+    }
+}
+
 /* hl_motion, h264_mc_template.c:64-163.  The partitions are enumerated by one loop so that mc_part has
  * a single (inlined) call site. */
 template <bool TILED>
@@ -263,6 +538,9 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
     }
 #ifdef MI355_EXP_ONLY_P16
     return;
+#endif
+#ifndef MI355_NO_MC4
+    if (TILED) { hl_motion4(s, fr, sl, mb_x, mb_y); return; }
 #endif
     const int nparts = kind == 3 ? 16 : 2;
     for (int p = 0; p < nparts; p++) {

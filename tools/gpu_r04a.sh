@@ -7,7 +7,7 @@ TAG=${1:-r04a}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_frame_gpu.py tests/test_field_gpu.py tests/test_session_gpu.py -m gpu -x -q > $OUT/pytest_frames.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_frames.txt
+timeout 900 python -m pytest tests/test_frame_gpu.py tests/test_field_gpu.py tests/test_session_gpu.py tests/test_bridge_gpu.py tests/test_synth_streams_gpu.py -m gpu -x -q > $OUT/pytest_frames.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_frames.txt
 tail -6 $OUT/pytest_frames.txt
 cp libav_amd/libmi355dsp.so /tmp/orig.so
 times() {   # $1 = label
@@ -19,8 +19,8 @@ lib = libav_amd.load(0)
 class P: pass
 prov = P(); prov.lib = lib
 lib.mi355_event_create.restype = C.c_void_p; lib.mi355_event_elapsed_ms.restype = C.c_float
-for content, kw in (("noise", {}), ("smooth", dict(refs="smooth", coef_b=4))):
-    fs = HF.synth_frames_fast(4, 120, 68, seed=0x264 if content == "noise" else 0x2264, lib=lib, **kw)
+for content, kw in (("noise", {}), ("smooth", dict(refs="smooth", coef_b=4)), ("mixed", dict(partitions="mixed"))):
+    fs = HF.synth_frames_fast(4, 120, 68, seed={"noise": 0x264, "smooth": 0x2264, "mixed": 0x2640}[content], lib=lib, **kw)
     lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
     for F in ((2048, 512, 64) if content == "noise" else (2048,)):
         dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=True)
@@ -32,7 +32,7 @@ for content, kw in (("noise", {}), ("smooth", dict(refs="smooth", coef_b=4))):
                 lib.mi355_event_record(C.c_void_p(e0), None); fn(); lib.mi355_event_record(C.c_void_p(e1), None); lib.mi355_sync(None)
                 best = min(best, lib.mi355_event_elapsed_ms(C.c_void_p(e0), C.c_void_p(e1)))
             return best
-        ti = timed(lambda: lib.mi355_h264_recon_inter_dev(d, F, 120, 68, None))
+        ti = timed(lambda: lib.mi355_h264_recon_inter_layouts_dev(d, F, 120, 68, 2, None) if hasattr(lib, 'mi355_h264_recon_inter_layouts_dev') else lib.mi355_h264_recon_inter_dev(d, F, 120, 68, None))
         tx = timed(lambda: lib.mi355_h264_recon_intra_levels_dev(d, F, fs.max_intra_level, lw, None))
         td = timed(lambda: lib.mi355_h264_deblock_layouts_dev(d, F, 120, 68, 2, None) if hasattr(lib, 'mi355_h264_deblock_layouts_dev') else lib.mi355_h264_deblock_dev(d, F, 120, 68, None), 5)
         nmb = F * 8160
