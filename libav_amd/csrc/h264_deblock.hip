@@ -462,9 +462,7 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
         if (j == DCH_ISSUE) issue_chunk(ck + 1);             /* after the flush above: the stores go first */
         PROF_MARK(5);
         /* ---- next step's records and vectors ------------------------------------------------------- */
-#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 4
         prefetch(pre, mb_x + 1);
-#endif
         PROF_MARK(1);
         MI355_WAVE_SYNC();                                   /* the chunk committed above is visible */
         /* ---- rows above from the group above ------------------------------------------------------- */
@@ -478,7 +476,6 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
                     *reinterpret_cast<const uint32_t *>(&s.c[g - 1][bb][l >> 2][8 + ((l >> 1) & 1)][8 * jb + 4 * (l & 1)]);
         }
         PROF_MARK(2);
-#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 3
         /* ---- boundary strengths, in registers ------------------------------------------------------- */
         const MbInfo &h = cur.h, &ht = cur.ht;
         const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
@@ -526,7 +523,6 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
 #define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
 
         PROF_MARK(4);
-#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 2
         /* ---- vertical edges, one luma row + one chroma row per lane, in registers.  The four
          * samples left of the MB are the previous MB's last columns (previous chunk when j == 0). ----- */
         {
@@ -549,10 +545,8 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
             if (d0) *reinterpret_cast<uint32_t *>(cleftp) = cl;
             if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
         }
-#endif
         PROF_MARK(5);
         MI355_WAVE_SYNC();
-#if !defined(MI355_EXP_DBK) || MI355_EXP_DBK < 1
         /* ---- horizontal edges, one luma column + one chroma column per lane ------------------------------ */
         {
             uint8_t *colp = &s.y[g][b][0][16 * j + l];
@@ -586,14 +580,12 @@ __device__ __forceinline__ void deblock_band(DeblockLds &s, const mi355_h264_fra
                 ccolp[5 * DC_PITCH] = (uint8_t)u5; ccolp[6 * DC_PITCH] = (uint8_t)u6;
             }
         }
-#endif
 #undef AB_A
 #undef AB_B
 #undef BYTE
         PROF_MARK(6);
         MI355_WAVE_SYNC();   /* the tile is final for this macroblock: the group below and the next step may read it */
         hl = h;
-#endif
     };
     /* chunks still in LDS */
     auto finish = [&]() __attribute__((always_inline)) {

@@ -33,6 +33,8 @@ using namespace mi355;
 namespace {
 
 
+/* byte offsets of the prediction tiles in MbLds (behind the MbCore part; MbLds is no standard-layout type, offsetof() is not for it) */
+constexpr int MB_PY_OFF = 960, MB_PC_OFF = 960 + 256;
 /* Scratch of the general partition path on tiled surfaces (hl_motion4): the macroblock as sixteen 4x4 blocks, each with its own
  * vector, reference and block-aligned window */
 struct __attribute__((aligned(16))) Mc4Scratch {
@@ -41,15 +43,17 @@ struct __attribute__((aligned(16))) Mc4Scratch {
     int16_t tmp[16][9][4];       /* unclipped horizontal 6-tap sums of a block's nine rows (centre positions) */
     uint64_t qref[2][4][2];      /* [list][quadrant]: luma and chroma plane of the quadrant's reference picture */
 };
-struct __attribute__((aligned(16))) MbLds {
+/* what every kernel keeps of a macroblock: record, vectors, coefficients (the intra kernel's LDS holds this part alone) */
+struct __attribute__((aligned(16))) MbCore {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];                      /* (x | y << 16) per 4x4 block, raster order, per list */
     int16_t coef[384];
+};
+static_assert(sizeof(MbCore) == 960, "record + vectors + coefficients");
+/* ... and the inter kernels' prediction tiles and motion scratch behind it */
+struct __attribute__((aligned(16))) MbLds : MbCore {
     uint8_t py[16 * 16], pc[2][8 * 8];       /* prediction -> reconstruction */
     uint8_t qy[16 * 16], qc[2][8 * 8];       /* second prediction for weighted bi-pred */
-#ifdef MI355_EXP_LDS_PAD                     /* developer experiment: fewer waves per CU */
-    uint8_t exp_pad[MI355_EXP_LDS_PAD];
-#endif
     union {
         McScratch mc;                        /* one partition's windows (the 16x16 path; every path on surfaces with line strides) */
         Mc4Scratch mc4;                      /* the windows of sixteen 4x4 blocks (the general path on tiled surfaces) */
@@ -112,7 +116,7 @@ __device__ __forceinline__ void load_mb_issue(MbLoad &r, const FrameHot &fr, int
     if (with_coefs) { r.c0 = cp[lane]; r.c1 = cp[lane + 64]; r.c2 = cp[lane + 128]; }
     MI355_ISSUE_FENCE();      /* keep the five loads here: the compiler otherwise sinks each one into the branch of commit() that uses it */
 }
-__device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool with_coefs, bool has0, bool has1)
+__device__ __forceinline__ void load_mb_commit(MbCore &s, const MbLoad &r, bool with_coefs, bool has0, bool has1)
 {
     const int lane = lane_id();
     if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = r.hw;
@@ -123,7 +127,7 @@ __device__ __forceinline__ void load_mb_commit(MbLds &s, const MbLoad &r, bool w
     }
     MI355_WAVE_SYNC();
 }
-__device__ inline void load_mb(MbLds &s, const FrameHot &fr, int mb_xy, bool with_coefs)
+__device__ inline void load_mb(MbCore &s, const FrameHot &fr, int mb_xy, bool with_coefs)
 {
     MbLoad r;
     load_mb_issue(r, fr, mb_xy, with_coefs, true);
@@ -135,7 +139,7 @@ __device__ inline void load_mb(MbLds &s, const FrameHot &fr, int mb_xy, bool wit
  * lane, because hdr, mv and coef follow each other in MbLds in that order.  The L1 handles a wave's access four lanes at a
  * time whatever their width: five dword accesses of 64 lanes are 80 such groups, this is 15 (k_recon_inter's memory
  * pipeline was busy 60 % of the time, profiles/r02g_pmc3_h264_f2048.json). */
-static_assert(sizeof(mi355_h264_mb) == 64 && offsetof(MbLds, mv) == 64 && offsetof(MbLds, coef) == 192 && MI355_H264_COEFS_PER_MB == 384, "MbLds begins with the 960 bytes load_mb_wide fills");
+static_assert(sizeof(mi355_h264_mb) == 64 && offsetof(MbCore, mv) == 64 && offsetof(MbCore, coef) == 192 && MI355_H264_COEFS_PER_MB == 384, "MbLds begins with the 960 bytes load_mb_wide fills");
 __device__ __forceinline__ void load_mb_wide(MbLds &s, const FrameHot &fr, int mb_xy)
 {
     const int lane = lane_id(), l = lane < 60 ? lane : 59;
@@ -170,35 +174,23 @@ __device__ __forceinline__ void mc_dir(MbLds &s, const FrameHot &fr, RefTable re
     const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
     if (TILED) {
         const TiledRef tr{mi355_global(rp[0]), mi355_global(rp[1]), fr.ref_stride[0], fr.ref_stride[1], fr.mb_width, fr.mb_height};
-#ifndef MI355_EXP_NO_STAGE
         stage_windows_tiled(s.mc, tr, mx >> 2, my >> 2, w, h, mx >> 3, myc >> 3, w >> 1, h >> 1);
-#endif
         RPROF(3);
-#ifndef MI355_EXP_NO_LUMA
         mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
-#endif
         RPROF(4);
-#ifndef MI355_EXP_NO_CHROMA
         if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, myc & 7, pcb, pcr, 8, avg);
         else mc_chroma_compute(s.mc, 2, mx & 7, myc & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
-#endif
         return;
     }
     PlaneRef ry{mi355_global(rp[0]), fr.ref_stride[0], 16 * fr.mb_width, 16 * fr.mb_height};
     PlaneRef rb{mi355_global(rp[1]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
     PlaneRef rr{mi355_global(rp[2]), fr.ref_stride[1], 8 * fr.mb_width, 8 * fr.mb_height};
-#ifndef MI355_EXP_NO_STAGE
     if (w == 16 && h == 16) stage_windows16(s.mc, ry, mx >> 2, my >> 2, rb, rr, mx >> 3, myc >> 3);
     else stage_windows(s.mc, &ry, mx >> 2, my >> 2, w, h, &rb, &rr, mx >> 3, myc >> 3, w >> 1, h >> 1);
-#endif
-#ifndef MI355_EXP_NO_LUMA
     mc_luma_compute(s.mc, mx & 3, my & 3, w, h, py, 16, bx, by, avg);
-#endif
     RPROF(4);
-#ifndef MI355_EXP_NO_CHROMA
     if (w == 16 && h == 16) mc_chroma16(s.mc, mx & 7, myc & 7, pcb, pcr, 8, avg);
     else mc_chroma_compute(s.mc, 2, mx & 7, myc & 7, w >> 1, h >> 1, pcb, pcr, 8, bx >> 1, by >> 1, avg);
-#endif
 }
 
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471).  Both lists go
@@ -523,25 +515,15 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
         /* the common shape gets its own copy of the (inlined) motion code: block size and position are literals there,
          * so tile loops have one iteration, window sizes are constants and the small-block branches disappear */
         const int l0 = DIRF(0, 0), l1 = DIRF(0, 1);
-#ifndef MI355_NO_P16
         if (l0 && !l1 && !(uniform(s.hdr.flags) & MI355_MBF_WEIGHTED)) {
             /* ... and the plain P_16x16 / P_Skip macroblock goes straight to one list-0 prediction written in place */
             mc_dir<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 0, 16, 16, s.py, s.pc[0], s.pc[1], 0);
             return;
         }
-#endif
-#ifdef MI355_EXP_ONLY_P16
-        return;
-#endif
         mc_part<TILED>(s, fr, refs, sl, mb_x, mb_y, mb_xy, 0, 0, 0, 0, 16, 16, l0, l1);
         return;
     }
-#ifdef MI355_EXP_ONLY_P16
-    return;
-#endif
-#ifndef MI355_NO_MC4
     if (TILED) { hl_motion4(s, fr, sl, mb_x, mb_y); return; }
-#endif
     const int nparts = kind == 3 ? 16 : 2;
     for (int p = 0; p < nparts; p++) {
         int n, quad, bx, by, w, h, l0, l1;
@@ -570,7 +552,7 @@ __device__ inline void hl_motion(MbLds &s, const FrameHot &fr, RefTable refs, co
  * (h264_mb.c:726-795) with the dc / full / skip choice of h264idct_template.c:174-201 folded
  * into "transform the block iff it carries a coefficient" (identical results) */
 template <bool ALIGNED>   /* ALIGNED: every 4-sample row segment of `y` starts on a dword (both frame kernels lay their tiles out that way) */
-__device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra16)
+__device__ inline void residual_luma(MbCore &s, uint8_t *y, int pitch, bool intra16)
 {
     const int lane = lane_id();
     const uint32_t mask = (uint32_t)uniform((int)s.hdr.nnz_mask);
@@ -600,7 +582,7 @@ __device__ inline void residual_luma(MbLds &s, uint8_t *y, int pitch, bool intra
 
 /* chroma residual: h264_mb_template.c:196-247 */
 template <bool ALIGNED>
-__device__ inline void residual_chroma(MbLds &s, uint8_t *cb, uint8_t *cr, int pitch)
+__device__ inline void residual_chroma(MbCore &s, uint8_t *cb, uint8_t *cr, int pitch)
 {
     if (!(uniform(s.hdr.cbp) & 0x30)) return;
     const int lane = lane_id();
@@ -661,12 +643,12 @@ constexpr ResidLaneTable make_resid_lanes()
         const int b = lane >> 1, h = lane & 1, bc = b < 24 ? b : 23, jj = bc & 3;
         const bool chroma = bc >= 16;
         const int x4 = (bc & 1) + 2 * ((bc >> 2) & 1), y4 = ((bc >> 1) & 1) + 2 * (bc >> 3);
-        const int base = chroma ? (int)offsetof(MbLds, pc) + 64 * ((bc >> 2) & 1) + 32 * (jj >> 1) + 4 * (jj & 1) : (int)offsetof(MbLds, py) + 64 * y4 + 4 * x4;
+        const int base = chroma ? (int)MB_PC_OFF + 64 * ((bc >> 2) & 1) + 32 * (jj >> 1) + 4 * (jj & 1) : (int)MB_PY_OFF + 64 * y4 + 4 * x4;
         const int pitch = chroma ? 8 : 16;
         ResidLane &e = t.l[lane];
         e.off_a = (uint32_t)(base + (h ? 1 : 0) * pitch);
         e.off_b = (uint32_t)(base + (h ? 2 : 3) * pitch);
-        e.cw = (uint32_t)((int)offsetof(MbLds, coef) + (bc * 8 + h) * 4);
+        e.cw = (uint32_t)((int)offsetof(MbCore, coef) + (bc * 8 + h) * 4);
         e.dc16 = b < 24 && chroma && h == 0 ? 0xFFFFu : 0u;
         e.misc = (h == 0 ? 32u : 0u) | (b >= 24 ? 0u : (chroma ? 0x200u : 0x100u));
         e.rc = b < 24 && chroma ? 32u * 1024u : 0u;
@@ -684,11 +666,11 @@ __device__ __forceinline__ void resid_lane_compute(ResidLane &r)
     const uint32_t x = (lane & 2u) * 2u;                                                    /* 4 * (b & 1) */
     const uint32_t yl = ((lane & 4u) << 4) | (lane & 8u) | ((lane & 16u) << 3);             /* 64 * b1 + 8 * b2 + 128 * b3 */
     const uint32_t yc = (lane & 12u) << 3;                                                  /* 32 * b1 + 64 * b2 */
-    const uint32_t base = chroma ? (uint32_t)offsetof(MbLds, pc) + yc + x : (uint32_t)offsetof(MbLds, py) + yl + x;
+    const uint32_t base = chroma ? (uint32_t)MB_PC_OFF + yc + x : (uint32_t)MB_PY_OFF + yl + x;
     const uint32_t pitch = chroma ? 8u : 16u;
     r.off_a = base + h * pitch;
     r.off_b = base + (3u - h) * pitch;
-    r.cw = (uint32_t)offsetof(MbLds, coef) + lane * 16u - h * 12u;
+    r.cw = (uint32_t)offsetof(MbCore, coef) + lane * 16u - h * 12u;
     r.dc16 = (lane & 33u) == 32u ? 0xFFFFu : 0u;
     r.misc = (h ? 0u : 32u) | (lane < 32 ? 0x100u : (lane < 48 ? 0x200u : 0u));
     r.rc = chroma ? 32u * 1024u : 0u;
@@ -800,7 +782,7 @@ __device__ inline void store_mb(const uint8_t *y, int ypitch, const uint8_t *cb,
 /* the inter kernel's tile (py: 16 rows of 16 bytes, then pc: 2 x 8 rows of 8 bytes) -> picture: a row per lane, 16 + 16 lanes */
 __device__ __forceinline__ void store_mb_rows(const MbLds &s, const FrameHot &fr, int mb_x, int mb_y)
 {
-    static_assert(offsetof(MbLds, pc) == offsetof(MbLds, py) + 256, "py and pc are one run of rows");
+    static_assert(MB_PC_OFF == MB_PY_OFF + 256, "py and pc are one run of rows");
     const int lane = lane_id();
     if (lane < 16) {
         const mi355_u32x4 v = *reinterpret_cast<const mi355_u32x4 *>(s.py + 16 * lane);
@@ -816,7 +798,7 @@ __device__ __forceinline__ void store_mb_rows(const MbLds &s, const FrameHot &fr
  * three whole cache lines */
 __device__ __forceinline__ void store_mb_tiled(const MbLds &s, const FrameHot &fr, int mb_x, int mb_y)
 {
-    static_assert(offsetof(MbLds, pc) == offsetof(MbLds, py) + 256, "py and pc are one run of rows");
+    static_assert(MB_PC_OFF == MB_PY_OFF + 256, "py and pc are one run of rows");
     const int lane = lane_id();
     if (lane < 24) {
         const mi355_u32x4 v = *reinterpret_cast<const mi355_u32x4 *>(s.py + 16 * lane);
@@ -882,7 +864,6 @@ __device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame 
     const mi355_h264_slice &sl = fr.slices[uniform(s.hdr.slice_id)];
     hl_motion<TILED>(s, fr, nullptr, sl, mb_x, mb_y, mb_xy);
     RPROF(5);
-#ifndef MI355_EXP_NO_RESIDUAL
     /* inter MBs without luma coefficients (cbp & 15 == 0: skip and most of real P/B pictures) have nothing to add */
     if (uniform((int)s.hdr.mb_type) & MI355_MB_8x8DCT) {
         if (uniform((int)s.hdr.nnz_mask) & 0xFFFF) residual_luma<true>(s, s.py, 16, false);
@@ -890,7 +871,6 @@ __device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame 
     } else {
         residual_blocks<true>(s, rl);
     }
-#endif
     RPROF(6);
     if (TILED) store_mb_tiled(s, fr, mb_x, mb_y);
     else store_mb_rows(s, fr, mb_x, mb_y);
@@ -904,6 +884,9 @@ __device__ __forceinline__ void recon_inter_wave(MbLds &s, const mi355_h264_fram
                                                  unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
     RPROF_START();
+#ifdef MI355_HIP_EMU_H
+    if (reinterpret_cast<uint8_t *>(s.py) - reinterpret_cast<uint8_t *>(&s) != MB_PY_OFF || reinterpret_cast<uint8_t *>(s.pc) - reinterpret_cast<uint8_t *>(&s) != MB_PC_OFF) abort();
+#endif
     const int lin = xcd_linear((int)blockIdx.x, per_xcd);
     if (lin >= nblocks) return;
     /* lin = (f * max_h + mb_y) * max_w + mb_x */
@@ -952,7 +935,7 @@ constexpr int TP = 32;   /* luma tile pitch: columns -1..23 (8x8 blocks read 16 
 constexpr int CP = 16;   /* chroma tile pitch: columns -1..7 */
 constexpr int TO = 4;    /* column 0 sits on a dword (column -1 at TO - 1): residual add and store move whole dwords */
 struct IntraLds {
-    MbLds mb;
+    MbCore mb;
     __attribute__((aligned(16))) uint8_t tile[17 * TP];
     __attribute__((aligned(16))) uint8_t ctile[2][9 * CP];
     PredScratch ps;
