@@ -246,9 +246,9 @@ def main():
                 for key in ("fused_fraction_of_hbm_roofline", "fraction_of_hbm_roofline"):
                     if isinstance(p.get(key), float):
                         points[p["name"]] = round(p[key], 4)
-                for key in ("bridge", "reference_c_decoder"):                      # decoder end to end: pictures/s, bridge vs C
+                for key in ("bridge", "hooked", "reference_c_decoder"):            # decoder end to end: pictures/s, bridge (or hooked tables) vs C
                     if isinstance(p.get(key), dict) and "pictures_per_s" in p[key]:
-                        points[p["name"] + ("" if key == "bridge" else "_c")] = round(p[key]["pictures_per_s"], 1)
+                        points[p["name"] + ("_c" if key == "reference_c_decoder" else "")] = round(p[key]["pictures_per_s"], 1)
             if not args.notes:
                 for p in out["extra"]:
                     for key in ("note", "what", "sample"):
@@ -348,7 +348,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
-    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points):
+    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
         try:
             r = fn(lib)
             pts.extend(r if isinstance(r, list) else [r])
@@ -426,6 +426,58 @@ def session_points(lib):
             for ss in sess:
                 ss.close()
             grp.destroy()
+    return out
+
+
+def h264_real_stream_points(lib):
+    """What a REAL bitstream sees: the reference's own H.264 decoder, entropy decoding and all, end to end.
+    (a) Tier 2 through the bridge (contrib/libav/mi355_h264_bridge.c: reconstruction and loop filter of every picture on the device, the
+    decoded-picture buffer in HBM): 64 decoder threads on a generated 1080p I / P / B stream (tests/golden/h264_synth_1080p.samples, 109 KB per
+    picture), the SAME binary with everything left to the reference's C functions beside it, on as many threads — the host's entropy decoding is the
+    wall on both sides, so this aggregate is the honest figure, not the kernels' synthetic rate.
+    (b) Tier 1, the literal per-call boundary `north_star` names (ff_*_init hooks: one synchronous stage / launch / copy-back per DSP call): the hooked
+    decoder on realshort.mp4 beside the plain one.  A FUNCTIONAL pin (every shim called by its real caller), not an accelerator — the figure is here so
+    that nobody takes it for one."""
+    import subprocess
+    import struct
+    import tempfile
+    out = []
+    exe = os.path.join(ROOT, "oracle", "_ref", "h264_bridge_gpu")
+    src = os.path.join(ROOT, "tests", "golden", "h264_synth_1080p.samples")
+    if os.path.exists(exe) and os.path.exists(src):
+        pt = {"name": "h264_bridge_1080p_x64", "what": "reference H.264 decoder + Tier-2 bridge, 64 decoder threads, generated 1080p stream, 3 passes each"}
+        for key, env in (("bridge", {}), ("reference_c_decoder", {"MI355_BRIDGE_PLAIN": "1"})):
+            e = dict(os.environ)
+            e.pop("MI355_BRIDGE_PLAIN", None)
+            e.update(env)
+            r = subprocess.run([exe, src, "-", "64", "3"], capture_output=True, text=True, env=e, timeout=600)
+            st = json.loads(r.stdout.strip().splitlines()[-1])
+            pt[key] = {k: st[k] for k in ("threads", "pictures_output", "pictures_on_device", "pictures_per_launch_set", "pictures_per_s")}
+            pt[key]["macroblocks_per_s"] = st["pictures_per_s"] * 8160
+        out.append(pt)
+    exe1 = os.path.join(ROOT, "oracle", "_ref", "h264_tier1_gpu")
+    clip = "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/realshort.mp4"
+    if os.path.exists(exe1) and os.path.exists(clip):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import mp4_samples
+        avcc, samples = mp4_samples.extract(clip)
+        with tempfile.TemporaryDirectory() as tmp:
+            s_path = os.path.join(tmp, "s")
+            with open(s_path, "wb") as f:
+                f.write(struct.pack("<I", len(avcc)) + avcc + struct.pack("<I", len(samples)))
+                for smp in samples:
+                    f.write(struct.pack("<I", len(smp)) + smp)
+            pt = {"name": "tier1_hooked_decoder_realshort", "what": "FUNCTIONAL BOUNDARY, not an accelerator: the reference decoder with its DSP tables hooked "
+                  "(one synchronous launch per DSP call), 36 pictures of 320x240, process start and device initialisation included"}
+            for key, env in (("hooked", {}), ("reference_c_decoder", {"MI355_TIER1_PLAIN": "1"})):
+                e = dict(os.environ)
+                e.pop("MI355_TIER1_PLAIN", None)
+                e.update(env)
+                t0 = time.perf_counter()
+                r = subprocess.run([exe1, s_path, os.path.join(tmp, "o.yuv")], capture_output=True, text=True, env=e, timeout=900)
+                dt = time.perf_counter() - t0
+                pt[key] = {"pictures": len(samples), "seconds": dt, "pictures_per_s": len(samples) / dt, "rc": r.returncode}
+            out.append(pt)
     return out
 
 

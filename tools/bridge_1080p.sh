@@ -1,10 +1,10 @@
 #!/bin/bash
-# End-to-end throughput of the reference decoder + Tier-2 bridge on a GENERATED 1080p stream (build/streams/h264_synth_1080p.samples:
+# End-to-end throughput of the reference decoder + Tier-2 bridge on a GENERATED 1080p stream (tests/golden/h264_synth_1080p.samples:
 # tools/make_1080p_stream.py: mb_w=120, mb_h=68, 10 pictures I/P/B, 4 slices, 8x8 transform, three references, sparse
 # residuals — 109 KB per picture).  GPU box, repo root: tools/bridge_1080p.sh <tag>   -> gpurun_out/<tag>/bridge_1080p.jsonl
 TAG=${1:-bridge1080}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-S=build/streams/h264_synth_1080p.samples
+S=tests/golden/h264_synth_1080p.samples
 MI355_BRIDGE_PLAIN=1 oracle/_ref/h264_bridge_gpu $S /tmp/plain.yuv 1 1 > /dev/null 2>&1
 oracle/_ref/h264_bridge_gpu $S /tmp/bridge.yuv 1 1 2>&1 | tail -1 | cut -c1-200
 cmp /tmp/plain.yuv /tmp/bridge.yuv && echo "bridge output identical to the reference decoder's ($(md5sum < /tmp/plain.yuv | cut -c1-32))" | tee $OUT/identical.txt

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (needs /root/reference: the CAVLC code tables are read from its source): the generated 1080p 4:2:0 stream
 tools/bridge_1080p.sh decodes — 120 x 68 macroblocks, 10 pictures I / P / B (implicit weights), four slices, 8x8 transform,
-three references, sparse residuals and 45 % skipped macroblocks: 109 KB per picture.  -> build/streams/h264_synth_1080p.samples
-(build/ is not committed; it travels to the GPU box with the tree)."""
+three references, sparse residuals and 45 % skipped macroblocks: 109 KB per picture.  -> tests/golden/h264_synth_1080p.samples (committed)."""
 import os
 import sys
 
@@ -13,7 +12,6 @@ import make_h264_streams as M
 T = M.load_tables()
 kw = dict(mb_w=120, mb_h=68, chroma_idc=1, depth=8, seed=2024, nslices=4, deblock_idc=0, nrefs=3, npics=10, bmode=1, t8x8=True, far=24, sparse=0.35, skip=0.45)
 units = M.Stream(T, "hd", **kw).build()
-out = os.path.join(ROOT, "build", "streams")
-os.makedirs(out, exist_ok=True)
+out = os.path.join(ROOT, "tests", "golden")        # committed (1.1 MB): bench.py's h264_bridge_1080p point and tools/bridge_1080p.sh decode it
 M.write_samples(os.path.join(out, "h264_synth_1080p.samples"), units)
 print(len(units), "pictures", sum(map(len, units)), "bytes")
