@@ -1001,11 +1001,18 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             uint8_t *const Y = &s.y[t & 3][g][l], *const C = &s.c[t & 3][g][64 * cp + cr];
             uint8_t *const A = (g ? &s.y[(t - 2) & 3][ga][128] : &s.above[t & 1][0]) + l;          /* row 8 + m at A[16 * (m ^ ga)] */
             uint8_t *const CA = (g ? &s.c[(t - 2) & 3][ga][0] : &s.above[t & 1][128]) + 64 * cp + cr;
-            /* row r of the own tile at Y[16 * (r ^ g)]: r = 4k + j -> 64k + 16 * (j ^ g) */
-#define YR(r) Y[64 * ((r) >> 2) + 16 * (((r) & 3) ^ g)]
-#define AR(r) A[64 * (((r) - 8) >> 2) + 16 * ((((r) - 8) & 3) ^ ga)]
-#define CR(r) C[16 * (((r) >> 1) ^ g) + 8 * ((r) & 1)]
-#define CAR(r) CA[16 * (((r) >> 1) ^ ga) + 8 * ((r) & 1)]
+            /* row r of the own tile at Y[16 * (r ^ g)]: r = 4k + j -> 64k + 16 * (j ^ g): one base per j (the swizzle is an exclusive or: not an
+             * address offset the instruction could carry), the rest immediate offsets */
+            const int g16 = 16 * g, a16 = 16 * ga;
+            uint8_t *const Y0 = Y + g16, *const Y1 = Y + (g16 ^ 16), *const Y2 = Y + (g16 ^ 32), *const Y3 = Y + (g16 ^ 48);
+            uint8_t *const A0 = A + 64 + a16, *const A1 = A + 64 + (a16 ^ 16), *const A2 = A + 64 + (a16 ^ 32), *const A3 = A + 64 + (a16 ^ 48);
+            uint8_t *const C0 = C + g16, *const C1 = C + (g16 ^ 16), *const C2 = C + (g16 ^ 32), *const CA3 = CA + (a16 ^ 48);
+#define YJ(j) ((j) == 0 ? Y0 : ((j) == 1 ? Y1 : ((j) == 2 ? Y2 : Y3)))
+#define AJ(j) ((j) == 0 ? A0 : ((j) == 1 ? A1 : ((j) == 2 ? A2 : A3)))
+#define YR(r) YJ((r) & 3)[64 * ((r) >> 2)]
+#define AR(r) AJ((r) & 3)[0]
+#define CR(r) (((r) >> 1) == 0 ? C0 : (((r) >> 1) == 1 ? C1 : C2))[8 * ((r) & 1)]
+#define CAR(r) CA3[8 * ((r) & 1)]
             int y0 = AR(12), y1 = AR(13), y2 = AR(14), y3 = AR(15);
             int y4 = YR(0), y5 = YR(1), y6 = YR(2), y7 = YR(3), y8 = YR(4), y9 = YR(5), y10 = YR(6), y11 = YR(7);
             int y12 = YR(8), y13 = YR(9), y14 = YR(10), y15 = YR(11), y16 = YR(12), y17 = YR(13), y18 = YR(14);
@@ -1031,6 +1038,8 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             if (chroma_line(u4, u5, u6, u7, BYTE(bsc1, 2), AB_A(cab_i), AB_B(cab_i), BYTE(cci1, 2))) {
                 CR(3) = (uint8_t)u5; CR(4) = (uint8_t)u6;
             }
+#undef YJ
+#undef AJ
 #undef YR
 #undef AR
 #undef CR

@@ -62,5 +62,7 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
     w[0] = v.x; w[1] = v.y;
 }
 
+/* h264_frame_tiled.hip: launches k_recon_inter_tiled (the tiled-only instance of the inter reconstruction kernel) */
+void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd, hipStream_t stream);
 }  // namespace mi355
 #endif
