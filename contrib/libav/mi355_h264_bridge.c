@@ -279,7 +279,7 @@ static int disp_enqueue(Disp *D, int slot)
 {
     const int n = D->nin[slot];
     void *st = D->stream[slot];
-    int mw = 0, mh = 0, maxl = 0, rc = 0, nd = 0, ncopy = 0, ncvt = 0, cw = 0, chh = 0;
+    int mw = 0, mh = 0, maxl = 0, layouts = 0, rc = 0, nd = 0, ncopy = 0, ncvt = 0, cw = 0, chh = 0;
     size_t max_bytes = 0;
     for (int i = 0; i < n; i++) nd += D->in[slot][i]->b->npass;
     mi355_h264_frame *hr = D->h_desc[slot], *hd = D->h_desc[slot] + nd;      /* reconstruction | loop filter */
@@ -294,6 +294,7 @@ static int disp_enqueue(Disp *D, int slot)
         for (int l = 0; l < s->maxl; l++)
             if (l >= maxl || s->widths[l] > D->widths[l]) D->widths[l] = s->widths[l];
         if (s->maxl > maxl) maxl = s->maxl;
+        layouts |= b->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR;
         for (int p = 0; p < b->npass; p++, k++) { hr[k] = s->desc[p]; hd[k] = s->desc[b->npass + p]; }
         if (b->tiled) {
             convert_job(b, s->pic, s->out, &D->cvt[slot][ncvt++]);
@@ -309,7 +310,7 @@ static int disp_enqueue(Disp *D, int slot)
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
     if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
-    if (!rc && mi355_h264_deblock_dev(dd, nd, mw, mh, st) != 0) rc = -1;
+    if (!rc && mi355_h264_deblock_layouts_dev(dd, nd, mw, mh, layouts, st) != 0) rc = -1;      /* the loop filter's kernel(s) for the layouts this batch holds */
     if (!rc && ncopy && mi355_copy_batch_dev(D->jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
     if (!rc && ncvt && mi355_h264_surface_convert_dev(D->cvt[slot], ncvt, cw, chh, st) != 0) rc = -1;
     rc |= mi355_event_record(D->ev[slot], st);
@@ -1011,7 +1012,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
         if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
             mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
-            mi355_h264_deblock_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->stream) != 0) return -4;
+            mi355_h264_deblock_layouts_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR, b->stream) != 0) return -4;
         if (b->tiled) {
             convert_job(b, cur, s->out, s->cvt);
             if (mi355_h264_surface_convert_dev(s->cvt, 1, b->mb_w, b->mb_h, b->stream) != 0) return -5;

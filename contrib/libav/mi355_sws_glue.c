@@ -136,23 +136,44 @@ typedef struct Bound {
     int special;                  /* ... through ff_yuv2rgb_get_func_ptr */
     mi355_sws_ctx *dev;
     int failed;                   /* the device side does not take this context: the reference's function from now on */
+    int busy;                     /* calls of mi355_sws_scale in flight on `dev` (under bound_mu): the device context is destroyed only at 0 */
+    unsigned long stamp;          /* last use: the slot with the oldest stamp is recycled when the table is full */
     uint8_t y_table[1024];        /* the tables the device context was built from */
     int32_t gv0;
 } Bound;
 static Bound bound[MI355_SWS_SLOTS];
 static pthread_mutex_t bound_mu = PTHREAD_MUTEX_INITIALIZER;
-static unsigned long n_pictures;
+static pthread_cond_t bound_idle = PTHREAD_COND_INITIALIZER;
+static unsigned long n_pictures, n_stamp;
 unsigned long mi355_sws_glue_pictures(void) { return n_pictures; }   /* whole pictures converted on the device so far (diagnostics) */
+int mi355_sws_glue_live_contexts(void)                                /* contexts that hold a device side right now (diagnostics) */
+{
+    int n = 0;
+    pthread_mutex_lock(&bound_mu);
+    for (int i = 0; i < MI355_SWS_SLOTS; i++) n += bound[i].c && bound[i].dev;
+    pthread_mutex_unlock(&bound_mu);
+    return n;
+}
 
+/* under bound_mu: wait until no call runs on the slot's device context, then drop it */
+static void slot_release(Bound *b)
+{
+    while (b->busy) pthread_cond_wait(&bound_idle, &bound_mu);
+    if (b->dev) mi355_sws_destroy(b->dev);
+    memset(b, 0, sizeof(*b));
+}
 static Bound *bound_find(SwsContext *c, int create)
 {
-    Bound *free_slot = NULL;
+    Bound *free_slot = NULL, *oldest = NULL;
     for (int i = 0; i < MI355_SWS_SLOTS; i++) {
         if (bound[i].c == c) return &bound[i];
         if (!free_slot && !bound[i].c) free_slot = &bound[i];
+        if (bound[i].c && !bound[i].busy && (!oldest || bound[i].stamp < oldest->stamp)) oldest = &bound[i];
     }
-    if (create && free_slot) { memset(free_slot, 0, sizeof(*free_slot)); free_slot->c = c; }
-    return create ? free_slot : NULL;
+    if (!create) return NULL;
+    if (!free_slot && oldest) { slot_release(oldest); free_slot = oldest; }     /* table full: the least recently used context loses its device side */
+    if (free_slot) { memset(free_slot, 0, sizeof(*free_slot)); free_slot->c = c; }
+    return free_slot;
 }
 /* a selector runs for this context: sws_init_context() of a new context — possibly at the address of one that was freed */
 static SwsFunc bind(SwsContext *c, SwsFunc real, int special)
@@ -161,9 +182,8 @@ static SwsFunc bind(SwsContext *c, SwsFunc real, int special)
     pthread_mutex_lock(&bound_mu);
     Bound *b = bound_find(c, 1);
     if (b) {
-        if (b->dev) mi355_sws_destroy(b->dev);
-        memset(b, 0, sizeof(*b));
-        b->c = c; b->real = real; b->special = special;
+        slot_release(b);
+        b->c = c; b->real = real; b->special = special; b->stamp = ++n_stamp;
     }
     pthread_mutex_unlock(&bound_mu);
     return b ? mi355_swsfunc_entry : real;
@@ -175,8 +195,11 @@ static int mi355_swsfunc(SwsContext *c, const uint8_t *src[], int srcStride[], i
     Bound *b = bound_find(c, 0);
     SwsFunc real = b ? b->real : NULL;
     mi355_sws_ctx *dev = NULL;
-    if (b && !b->failed && srcSliceY == 0 && srcSliceH == c->srcH) {
-        if (b->dev && (memcmp(b->y_table, c->yuvTable, 1024) || b->gv0 != c->table_gV[0])) { mi355_sws_destroy(b->dev); b->dev = NULL; }
+    /* the device path takes whole pictures with positive strides (a 2-D copy has no negative pitch; sws_scale() itself also takes bottom-up
+     * pictures — vf_vflip makes them — and those go to the reference's function) */
+    if (b && !b->failed && srcSliceY == 0 && srcSliceH == c->srcH &&
+        srcStride[0] > 0 && srcStride[1] > 0 && srcStride[2] > 0 && dstStride[0] > 0) {
+        if (b->dev && !b->busy && (memcmp(b->y_table, c->yuvTable, 1024) || b->gv0 != c->table_gV[0])) { mi355_sws_destroy(b->dev); b->dev = NULL; }
         if (!b->dev) {
             mi355_sws_desc d;
             if (device_ready() && describe(c, &d, b->special) == 0) b->dev = mi355_sws_create(&d);
@@ -184,14 +207,34 @@ static int mi355_swsfunc(SwsContext *c, const uint8_t *src[], int srcStride[], i
             else b->failed = 1;
         }
         dev = b->dev;
+        if (dev) { b->busy++; b->stamp = ++n_stamp; }          /* the context stays until this call is back (a bind() or free for its address waits) */
     }
     pthread_mutex_unlock(&bound_mu);
     if (dev) {
         const int st[3] = { srcStride[0], srcStride[1], srcStride[2] };
         const int n = mi355_sws_scale(dev, src, st, dst[0], dstStride[0]);
+        pthread_mutex_lock(&bound_mu);
+        b->busy--;
+        pthread_cond_broadcast(&bound_idle);
+        pthread_mutex_unlock(&bound_mu);
         if (n > 0) { __sync_fetch_and_add(&n_pictures, 1); return n; }
+        /* a failed copy / launch / allocation: this picture by the reference's function (mi355_sws_scale leaves the context usable) */
     }
     return real ? real(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride) : 0;
+}
+
+/* sws_freeContext: the context's device side goes with it (--wrap=sws_freeContext; without the wrap an entry stays until its address is
+ * bound again or the table recycles it) */
+void __real_sws_freeContext(SwsContext *c);
+void __wrap_sws_freeContext(SwsContext *c)
+{
+    if (c) {
+        pthread_mutex_lock(&bound_mu);
+        Bound *b = bound_find(c, 0);
+        if (b) slot_release(b);
+        pthread_mutex_unlock(&bound_mu);
+    }
+    __real_sws_freeContext(c);
 }
 
 SwsFunc __real_ff_getSwsFunc(SwsContext *c);

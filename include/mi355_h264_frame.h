@@ -254,6 +254,12 @@ int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nf
                                         int max_mb_width, int max_mb_height, int max_intra_level,
                                         const int32_t *level_widths, void *stream);
 
+/* The same for a caller that knows which surface layouts its batch holds (MI355_LAYOUTS_*: sessions, bridges, the bench): the
+ * reconstruction and the loop filter then run the kernel instances of those layouts alone (see the *_layouts_dev passes below). */
+int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_frames, int nframes,
+                                         int max_mb_width, int max_mb_height, int max_intra_level,
+                                         const int32_t *level_widths, int layouts, void *stream);
+
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
 int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);

@@ -37,7 +37,9 @@ int mi355_device_cus(void);
  * swscale contexts remember the device of the thread that created them and switch to it inside their entry points.  0 on
  * success, <0 as mi355_init(). */
 int mi355_set_device(int device);
-int mi355_get_device(void);
+int mi355_get_device(void);            /* the device this thread works on now: its own, or the process default */
+int mi355_get_thread_device(void);     /* the thread's OWN setting: -1 while it follows the process default (what a scope that switches
+                                          devices temporarily must put back with mi355_set_device) */
 int mi355_device_count(void);
 
 /* replaces ff_h264dsp_init_{x86,arm,...}   libavcodec/h264dsp.h:119-128, call site h264dsp.c:139-142 */

@@ -291,6 +291,16 @@ extern "C" int mi355_h264_decode_frames_dev(const mi355_h264_frame *d_frames, in
     return mi355_h264_deblock_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
 }
 
+extern "C" int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
+                                                    int max_intra_level, const int32_t *level_widths, int layouts, void *stream)
+{
+    int rc = mi355_h264_recon_inter_layouts_dev(d_frames, nframes, max_mb_width, max_mb_height, layouts, stream);
+    if (rc) return rc;
+    rc = mi355_h264_recon_intra_levels_dev(d_frames, nframes, max_intra_level, level_widths, stream);
+    if (rc) return rc;
+    return mi355_h264_deblock_layouts_dev(d_frames, nframes, max_mb_width, max_mb_height, layouts, stream);
+}
+
 extern "C" int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
                                                    int max_intra_level, const int32_t *level_widths, void *stream)
 {
@@ -309,12 +319,24 @@ struct DescStage {
     mi355_h264_frame *host = nullptr, *dev = nullptr;
     size_t cap = 0;
     hipEvent_t copied = nullptr;
+    int device = -1;                 /* the device `dev` and `copied` live on: a thread may move between devices (mi355_set_device) */
 };
+/* one staging set per device this thread has used */
+DescStage &desc_stage(int device)
+{
+    static thread_local std::vector<DescStage> sets;
+    for (DescStage &d : sets) if (d.device == device) return d;
+    sets.emplace_back();
+    sets.back().device = device;
+    return sets.back();
+}
 }
 extern "C" int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nframes, void *stream)
 {
     if (!mi355::bind() || !frames || nframes <= 0) return -1;
-    static thread_local DescStage st;
+    /* the calling thread's device decides where the descriptors go: its own buffers and event per device (one set for the
+     * whole thread recorded an event of GPU 0 on a stream of GPU 1 after mi355_set_device) */
+    DescStage &st = desc_stage(mi355::current_device());
     int mw = 0, mh = 0, ml = 0, lw = 0;
     for (int i = 0; i < nframes; i++) {
         if (frames[i].mb_width > mw) mw = frames[i].mb_width;

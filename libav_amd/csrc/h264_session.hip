@@ -18,8 +18,12 @@ constexpr size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 /* the calling thread works on a context's device for the duration of an entry point (public C ABI only, like the rest of this file) */
 struct OnDevice {
-    int prev;
-    explicit OnDevice(int device) : prev(mi355_get_device()) { if (device >= 0 && device != prev) (void)mi355_set_device(device); else prev = -2; }
+    int prev;                            /* the thread's own setting (-1: it follows the process default), or -2: nothing to put back */
+    explicit OnDevice(int device) : prev(mi355_get_thread_device())
+    {
+        if (device >= 0 && device != mi355_get_device()) (void)mi355_set_device(device);
+        else prev = -2;
+    }
     ~OnDevice() { if (prev != -2) (void)mi355_set_device(prev); }
     OnDevice(const OnDevice &) = delete;
     OnDevice &operator=(const OnDevice &) = delete;
@@ -62,6 +66,8 @@ struct mi355_h264_session {
     uint8_t *lin = nullptr;               /* tiled sessions: one picture as planes with line strides (device), between the tiles and the host */
     size_t lin_off[3] = { 0, 0, 0 }, lin_bytes = 0;
     mi355_surface_job *jobs = nullptr;    /* tiled sessions: pinned conversion jobs (ring of NJOBS: a job is read when its launch runs) */
+    void *job_done[NJOBS] = {};           /* per ring slot: event behind the launch that reads it (a slot is reused only after it) */
+    bool job_used[NJOBS] = {};
     unsigned njob = 0;
     size_t plane_off[3] = { 0, 0, 0 }, surf_bytes = 0;
     uint8_t *surfaces = nullptr;         /* nsurf decoded pictures, then NSETS unfiltered reconstructions */
@@ -104,6 +110,7 @@ extern "C" void mi355_h264_session_close(mi355_h264_session *s)
     if (s->surfaces) mi355_free(s->surfaces);
     if (s->lin) mi355_free(s->lin);
     if (s->jobs) mi355_host_free(s->jobs);
+    for (unsigned k = 0; k < NJOBS; k++) if (s->job_done[k]) mi355_event_destroy(s->job_done[k]);
     if (s->stream && !s->group) mi355_stream_destroy(s->stream);
     if (s->copy_stream) mi355_stream_destroy(s->copy_stream);
     if (s->group) s->group->members--;
@@ -301,8 +308,8 @@ extern "C" int mi355_h264_end_frame(mi355_h264_session *s)
     if (mi355_memcpy_h2d_async(d, h, l.total, s->stream) != 0) return -2;
     if (mi355_event_record(st.copied, s->stream) != 0) return -2;
     st.used = true;
-    const int rc = mi355_h264_decode_frames_levels_dev(reinterpret_cast<const mi355_h264_frame *>(d + l.desc), 1, s->mb_w, s->rows, levels,
-                                                       s->level_widths, s->stream);
+    const int rc = mi355_h264_decode_frames_layouts_dev(reinterpret_cast<const mi355_h264_frame *>(d + l.desc), 1, s->mb_w, s->rows, levels,
+                                                        s->level_widths, s->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR, s->stream);
     if (rc != 0) return rc == -1 ? -1 : -2;
     if (mi355_event_record(s->surf_done[s->pp.surface], s->stream) != 0) return -2;
     s->surf_valid[s->pp.surface] = true;
@@ -325,14 +332,20 @@ extern "C" int mi355_h264_surface_wait(mi355_h264_session *s, int surface)
  * session's pinned ring until the launch has read it */
 static int convert(mi355_h264_session *s, int surface, uint8_t *const lin[3], const int lin_stride[3], int to_tiled, void *stream)
 {
-    mi355_surface_job *j = &s->jobs[s->njob++ % NJOBS];
+    const unsigned slot = s->njob++ % NJOBS;
+    /* the launch that read this slot last must have run (more than NJOBS exports queued on a busy stream overwrote jobs not yet read) */
+    if (!s->job_done[slot] && !(s->job_done[slot] = mi355_event_create())) return -4;
+    if (s->job_used[slot] && mi355_event_sync(s->job_done[slot]) != 0) return -4;
+    mi355_surface_job *j = &s->jobs[slot];
     std::memset(j, 0, sizeof(*j));
     for (int p = 0; p < 3; p++) j->lin[p] = lin[p];
     j->tiled[0] = s->plane(surface, 0); j->tiled[1] = s->plane(surface, 1);
     j->lin_stride[0] = lin_stride[0]; j->lin_stride[1] = lin_stride[1];
     j->tiled_stride[0] = s->stride[0]; j->tiled_stride[1] = s->stride[1];
     j->mb_width = s->mb_w; j->mb_height = s->mb_h; j->to_tiled = to_tiled;
-    return mi355_h264_surface_convert_dev(j, 1, s->mb_w, s->mb_h, stream);
+    const int rc = mi355_h264_surface_convert_dev(j, 1, s->mb_w, s->mb_h, stream);
+    if (rc == 0 && mi355_event_record(s->job_done[slot], stream) == 0) s->job_used[slot] = true;
+    return rc;
 }
 
 extern "C" int mi355_h264_get_frame(mi355_h264_session *s, int surface, uint8_t *const dst[3], const int dst_stride[3])
@@ -467,20 +480,21 @@ extern "C" int mi355_h264_group_flush(mi355_h264_group *g)
         max_l = s->pend_levels > max_l ? s->pend_levels : max_l;
     }
     g->widths.assign((size_t)max_l + 1, 0);
-    int i = 0;
+    int i = 0, layouts = 0;
     for (mi355_h264_session *s : g->pending) {
         Set &st = s->set[s->cur];
         /* the session's records travel in one copy; its descriptor joins the flush's array */
         if (mi355_memcpy_h2d_async(st.dev, st.host, s->lay.total, g->stream) != 0 || mi355_event_record(st.copied, g->stream) != 0) rc = -2;
         st.used = true;
         g->h_desc[i++] = *reinterpret_cast<const mi355_h264_frame *>(st.host + s->lay.desc);
+        layouts |= s->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR;
         for (int l = 0; l < s->pend_levels; l++) if (s->level_widths[l] > g->widths[(size_t)l]) g->widths[(size_t)l] = s->level_widths[l];
     }
     if (rc == 0 && (mi355_memcpy_h2d_async(g->d_desc, g->h_desc, (size_t)n * sizeof(mi355_h264_frame), g->stream) != 0 ||
                     mi355_event_record(g->copied, g->stream) != 0)) rc = -2;
     g->used = true;
     if (rc == 0) {
-        const int r = mi355_h264_decode_frames_levels_dev(g->d_desc, n, max_w, max_h, max_l, g->widths.data(), g->stream);
+        const int r = mi355_h264_decode_frames_layouts_dev(g->d_desc, n, max_w, max_h, max_l, g->widths.data(), layouts, g->stream);
         if (r != 0) rc = r == -1 ? -1 : -2;
     }
     for (mi355_h264_session *s : g->pending) {

@@ -143,6 +143,7 @@ extern "C" int mi355_set_device(int device)
     return mi355::bind() ? 0 : -4;
 }
 extern "C" int mi355_get_device(void) { return mi355::current_device(); }
+extern "C" int mi355_get_thread_device(void) { return mi355::t_device; }
 extern "C" int mi355_device_count(void)
 {
     int n = 0;

@@ -80,3 +80,60 @@ def test_sliced_calls_keep_the_reference_function(hooked, monkeypatch):
     hooked.close(c)
     assert n == dh and hooked.lib.ref_sws_pictures() == before
     assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]
+
+
+def test_bottom_up_pictures_go_to_the_reference_function(hooked, monkeypatch):
+    """negative line sizes are legal for sws_scale() (vf_vflip makes them): the whole-picture binding must hand such a call to the function
+    the reference chose instead of a 2-D copy with a negative pitch (that aborted the process)"""
+    import numpy as np
+    monkeypatch.delenv("MI355_SWS_LINES", raising=False)
+    name = "generic_64x48"
+    sw, sh, dw, dh = S.CONFIGS[name][:4]
+    planes = S.picture(name)
+    outs = []
+    for flip in (False, True):
+        c = hooked.open(name)
+        out = np.full((dh, dw * 3), 0x5A, np.uint8)
+        src_planes = [np.ascontiguousarray(p[::-1]) for p in planes] if not flip else planes          # not flipped: an upside-down copy, read top-down
+        if flip:
+            src = (C.c_void_p * 4)(*[p.ctypes.data + (p.shape[0] - 1) * p.strides[0] for p in planes], None)
+            strides = (C.c_int * 4)(*[-p.strides[0] for p in planes], 0)
+        else:
+            src = (C.c_void_p * 4)(*[p.ctypes.data for p in src_planes], None)
+            strides = (C.c_int * 4)(*[p.strides[0] for p in src_planes], 0)
+        dst = (C.c_void_p * 4)(out.ctypes.data, None, None, None)
+        dstrides = (C.c_int * 4)(out.strides[0], 0, 0, 0)
+        before = hooked.lib.ref_sws_pictures()
+        assert hooked.lib.sws_scale(c, src, strides, 0, sh, dst, dstrides) == dh
+        assert hooked.lib.ref_sws_pictures() == before + (0 if flip else 1)       # the bottom-up call stayed with the reference
+        hooked.close(c)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_freed_contexts_give_their_device_side_back(hooked, monkeypatch):
+    """sws_freeContext (wrapped: --wrap=sws_freeContext, what a statically linked caller gets) releases the context's device side; 300 contexts
+    in a row neither leak nor run the table full"""
+    monkeypatch.delenv("MI355_SWS_LINES", raising=False)
+    lib = hooked.lib
+    lib.mi355_sws_glue_live_contexts.restype = C.c_int
+    getattr(lib, "__wrap_sws_freeContext").argtypes = [C.c_void_p]
+    name = "generic_64x48"
+    base = lib.mi355_sws_glue_live_contexts()
+    import numpy as np
+    sw, sh, dw, dh = S.CONFIGS[name][:4]
+    planes = S.picture(name)
+    src = (C.c_void_p * 4)(*[p.ctypes.data for p in planes], None)
+    strides = (C.c_int * 4)(*[p.strides[0] for p in planes], 0)
+    out = np.zeros((dh, dw * 3), np.uint8)
+    dst = (C.c_void_p * 4)(out.ctypes.data, None, None, None)
+    dstrides = (C.c_int * 4)(out.strides[0], 0, 0, 0)
+    for i in range(300):
+        c = hooked.open(name)
+        before = lib.ref_sws_pictures()
+        assert lib.sws_scale(c, src, strides, 0, sh, dst, dstrides) == dh
+        assert lib.ref_sws_pictures() == before + 1 and lib.mi355_sws_glue_live_contexts() == base + 1
+        getattr(lib, "__wrap_sws_freeContext")(C.c_void_p(c))
+        assert lib.mi355_sws_glue_live_contexts() == base
+    out = hooked.scale(name, S.picture(name), dst_pad=8)                          # and the binding still takes pictures afterwards
+    assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]
