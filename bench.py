@@ -497,12 +497,17 @@ def hevc_bridge_points(lib):
     for name in ("pb_1080p_few_intra", "pb_1080p_ctb64", "pb_480p_ctb64", "pb_ctb64_depth0", "i_ctb64"):
         src = os.path.join(ROOT, "tests", "golden", "hevc_synth_%s.samples" % name)
         pt = {"name": "hevc_bridge_" + name}
-        for key, env in (("bridge", {}), ("bridge_random_access_pictures_on_host", {"MI355_HEVC_BRIDGE_IRAP_ON_HOST": "1"}),
+        # "bridge": the product's default policy (pictures below 1.5 M luma samples stay with the C path: MI355_HEVC_BRIDGE_MIN_PIXELS);
+        # "bridge_forced": every picture on the device whatever its size (what round 3 reported as "bridge")
+        for key, env in (("bridge", {}), ("bridge_forced", {"MI355_HEVC_BRIDGE_MIN_PIXELS": "0"}),
+                         ("bridge_random_access_pictures_on_host", {"MI355_HEVC_BRIDGE_IRAP_ON_HOST": "1"}),
                          ("reference_c_decoder", {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
             if key == "bridge_random_access_pictures_on_host" and not name.startswith("pb_1080p"):
                 continue
+            if key == "bridge_forced" and name.startswith("pb_1080p"):
+                continue                                        # the policy takes 1080p anyway
             e = dict(os.environ)
-            for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST"):
+            for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_MIN_PIXELS"):
                 e.pop(k, None)
             e.update(env)
             r = subprocess.run([exe, src, "-", "20"], capture_output=True, text=True, env=e, timeout=600)

@@ -64,6 +64,7 @@ static __thread struct {
     void *stream;
     unsigned long pictures;
     int plain, failed;
+    long min_pixels;                                /* pictures smaller than this stay with the reference's C path (MI355_HEVC_BRIDGE_MIN_PIXELS) */
 } lf;
 
 static void fail(const char *what);
@@ -73,9 +74,15 @@ static int active(const HEVCContext *s)
     if (!init) {
         init = 1;
         lf.plain = getenv("MI355_HEVC_LF_PLAIN") != NULL;
+        /* A scheduling policy: one decoder's picture is a launch set per dependency level, a few tens of microseconds each whatever the picture's
+         * size, while the C functions' time falls with the area — measured (bench.py hevc_bridge_*, one decoder): 1920x1080 39 pictures/s against
+         * 34, 832x480 120 against 172, 136x72 560 against 5400.  Below this many luma samples the bridges step aside (a sequence is all or
+         * nothing: the reference pictures must live where the decoder's path expects them).  0 = always on the device (the tests). */
+        lf.min_pixels = getenv("MI355_HEVC_BRIDGE_MIN_PIXELS") ? atol(getenv("MI355_HEVC_BRIDGE_MIN_PIXELS")) : 1500000L;
         if (!lf.plain && mi355_init(getenv("MI355_DEVICE") ? atoi(getenv("MI355_DEVICE")) : 0) != 0) fail("no MI355X");
     }
-    return !lf.plain && !lf.failed && !(s->avctx->active_thread_type & FF_THREAD_FRAME) && s->ps.sps->chroma_format_idc == 1;
+    return !lf.plain && !lf.failed && !(s->avctx->active_thread_type & FF_THREAD_FRAME) && s->ps.sps->chroma_format_idc == 1 &&
+           (long)s->ps.sps->width * s->ps.sps->height >= lf.min_pixels;
 }
 
 static int ensure(uint8_t **p, size_t *have, size_t want)

@@ -39,6 +39,7 @@ def run_tier1(which, name, out, plain=False, lf_plain=False, intra_device=False)
     if lf_plain:
         env["MI355_HEVC_LF_PLAIN"] = "1"
     env.pop("MI355_HEVC_INTRA_DEVICE", None)
+    env["MI355_HEVC_BRIDGE_MIN_PIXELS"] = "0"           # the generated streams are small: the size policy of the bridges must not send them to the C path
     if intra_device:
         env["MI355_HEVC_INTRA_DEVICE"] = "1"
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", which), samples(name), str(out)], capture_output=True, text=True, env=env, timeout=1800)
@@ -68,6 +69,7 @@ def run_bridge(which, name, out, plain=False, irap_on_host=False, split_intra=Fa
     env = dict(os.environ)
     for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BS_HOST", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_SPLIT_INTRA"):
         env.pop(k, None)
+    env["MI355_HEVC_BRIDGE_MIN_PIXELS"] = "0"           # small streams on the device all the same (default: pictures below 1.5 M samples stay on the host)
     if plain:
         env["MI355_HEVC_RECON_PLAIN"] = env["MI355_HEVC_LF_PLAIN"] = "1"
     if irap_on_host:

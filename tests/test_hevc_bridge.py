@@ -58,3 +58,22 @@ def test_hevc_bridge_intra_blocks_with_their_residual_in_one_launch_emulated(tmp
     split = HS.run_bridge("hevc_bridge_emu", name, tmp_path / "s.yuv", split_intra=True)
     HS.check_md5(tmp_path / "s.yuv", name)
     assert fused["dependency_levels"] < split["dependency_levels"] and fused["reconstruction_launches"] < split["reconstruction_launches"], (fused, split)
+
+
+def test_small_pictures_stay_on_the_host_by_default(emu, tmp_path):
+    """the bridges' size policy (MI355_HEVC_BRIDGE_MIN_PIXELS, default 1.5 M luma samples): a 96x64 stream decoded WITHOUT the tests' override is left to
+    the reference's C path — same pictures, nothing reconstructed on the device — because one decoder's launch set per dependency level costs more than the C
+    functions on small pictures (below 1080p the bridge was a slow-down of up to 27x)"""
+    import subprocess
+    import json
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    name = "pb_8bit"
+    out = tmp_path / "o.yuv"
+    env = dict(os.environ)
+    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_MIN_PIXELS"):
+        env.pop(k, None)
+    r = subprocess.run([os.path.join(HS.ROOT, "oracle", "_ref", "hevc_bridge_emu"), HS.samples(name), str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stderr.strip() == "", r.stderr[-1000:]
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["pictures_output"] > 0 and st["pictures_reconstructed_on_device"] == 0
+    HS.check_md5(out, name)
