@@ -725,12 +725,14 @@ struct __attribute__((aligned(128))) Deblock3Lds {
     uint8_t y[4][4][256];
     uint8_t c[4][4][128];
     uint8_t above[2][256];
-    uint32_t parm[4][9][2];
+    uint32_t parm[2][4][9][2];  /* [step & 1 in the two-wave form, 0 otherwise] */
     uint32_t role[16][12];      /* per lane of a group: BsRole r0, BsRole r1, o_p0, o_q0, o_p1, o_q1 */
     uint8_t t_alpha[52], t_beta[52];
     uint32_t t_tc0[52];
 };
-static_assert(sizeof(Deblock3Lds) <= 8192, "twenty waves per CU");
+/* the two-wave form's mailbox: the strengths of the four edges of this lane's luma / chroma lines, both directions, for the step after this one */
+struct __attribute__((aligned(16))) Deblock3Mail { uint32_t bs[2][64][4]; };
+static_assert(sizeof(Deblock3Lds) <= 8192 + 288, "nineteen or twenty waves per CU");
 
 /* sixteen bytes per lane from memory straight into LDS at lds_base + 16 * lane (lds_base wave-uniform) */
 #ifdef MI355_HIP_EMU_H
@@ -744,9 +746,19 @@ template <bool AGENT> __device__ __forceinline__ void lds_dma16(const uint8_t *s
 }
 #endif
 
-template <bool TWO_LISTS>
-__device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_frame &fr, int band, uint32_t *prog)
+/* NW = 1: the wave does everything (the throughput form).  NW = 2 (few pictures: SIMDs stand idle and a lone wave's step is a serial chain
+ * of ~1100 instructions): the band's workgroup is TWO waves — wave 0 runs only the edge phases of step t, wave 1 meanwhile writes out what
+ * step t - 1 finished, issues the loads of step t + 1 and derives the strengths and parameters of step t + 1, which reach wave 0 through LDS
+ * (`mail`, parm[step & 1]); two workgroup barriers per step (LDS only: the loads in flight stay in flight). */
+#ifdef MI355_HIP_EMU_H
+#define MI355_WG_BARRIER_LDS() __syncthreads()
+#else
+#define MI355_WG_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+template <bool TWO_LISTS, int NW>
+__device__ __forceinline__ void deblock3_band(Deblock3Lds &s, Deblock3Mail *mail, const mi355_h264_frame &fr, int band, uint32_t *prog, int wave)
 {
+    const bool edge_wave = NW == 1 || wave == 0, srv_wave = NW == 1 || wave == 1;
     const int W = uniform(fr.mb_width), H = uniform(fr.mb_height);
     const bool field = uniform(fr.field_picture) != 0;
     const uint32_t mv_far = field ? 0xFFFEFFFCu : 0xFFFCFFFCu;
@@ -762,7 +774,7 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
     const uint8_t *const recon_y0 = mi355_global(fr.recon[0]), *const recon_c0 = mi355_global(fr.recon[1]);
     uint8_t *const dst_y0 = mi355_global(fr.dst[0]), *const dst_c0 = mi355_global(fr.dst[1]);
     uint32_t *const prog_above = prog + (top_band ? band - 1 : 0), *const prog_self = prog + band;
-    {
+    if (NW == 1 || wave == 0) {
         const int lane = lane_id(), l = lane & 15;
         if (lane < 52) {
             s.t_alpha[lane] = k_alpha[lane]; s.t_beta[lane] = k_beta[lane];
@@ -781,7 +793,7 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             r[11] = (uint32_t)(outer ? 4 * (seg + 12) - 64 * W : 4 * (seg + 4 * (edge - 1)));
         }
     }
-    MI355_WAVE_SYNC();
+    if (NW == 1) MI355_WAVE_SYNC(); else MI355_WG_BARRIER_LDS();
 
     struct Pre {
         MbInfo h, ht;
@@ -901,71 +913,53 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             agent_store8(dst_c0 + (k_se + ((uint32_t)t << 7)), bc, true);
         }
     };
-    Pre pre = {};
+    Pre pre = {}, pre_next = {};
     MbInfo hl = {};
-    await_above(0);
-    dma_issue(0);
-    prefetch(pre, 0);
-    hl = pre.h;
-#pragma nounroll
-    for (int t = 0; t < nsteps; t++) {
-        /* ---- everything requested during the last step is here; what was stored during it is out ---------------------------------- */
-        agent_drain_stores();
-        if (hand && t >= 8) {
-            /* hand_down(t - 1) is out: group 3's macroblocks 0 .. t - 8 */
-            const int done = t - 7 < W ? t - 7 : W;
-            if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
-        }
-        MI355_WAVE_SYNC();
-        if (t > 0) stores(t - 1);
-        await_above(t + 1);
-        dma_issue(t + 1);
-        /* ---- boundary strengths ---------------------------------------------------------------------------------------------- */
-        uint32_t bsw0, bsw1, bsc0, bsc1;
-        {
-            const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-            const int mb_y = 4 * band + g, mb_x = t - 2 * g;
-            const bool row_ok = mb_y < H, has_t = row_ok && mb_y > 0, valid = row_ok && mb_x >= 0 && mb_x < W;
-            const bool outer = (l & 3) == 0, odd = (l & 1) != 0;
-            const MbInfo &h = pre.h, &ht = pre.ht;
-            const mi355_u32x4 ra = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][0]), rb = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][4]);
-            const BsRole r0{ ra[0], ra[1], ra[2], ra[3] }, r1{ rb[0], rb[1], rb[2], rb[3] };
-            const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
-            const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
-            const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, pre.p0, pre.q0, two_lists, mv_far, 4u);
-            const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, pre.p1, pre.q1, two_lists, mv_far, field ? 3u : 4u);
-            bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
-            bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
-            const int csrc = (lane & ~15) | (((l & 7) >> 1) << 2);
-            bsc0 = (uint32_t)__shfl((int)bsw0, csrc); bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
-            /* alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) */
-            const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;
-            const int kindc = kind > 2 ? 2 : kind;
-            const MbInfo &nb = kindc == 1 ? hl : ht;
-            int qa = comp ? h.qpc(comp - 1) : h.qp();
-            int qb = comp ? nb.qpc(comp - 1) : nb.qp();
-            if (comp && kindc && nb.slice_id() != h.slice_id() && (kindc == 1 ? have_left : have_top)) {
-                int v = mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[comp - 1][nb.qp()];
-                MI355_PIN(v);
-                qb = v;
-            }
-            const int qp = kindc ? (qa + qb + 1) >> 1 : qa;
-            const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
-            const uint32_t w0 = (uint32_t)s.t_alpha[ia] | ((uint32_t)s.t_beta[ib] << 8);
-            const uint32_t w1 = s.t_tc0[ia] + (comp ? 0x01010100u : 0u);
-            if (l < 9) { s.parm[g][l][0] = w0; s.parm[g][l][1] = w1; }
-            hl = h;
-        }
-        /* the next macroblock's records and vectors: the registers of this one's are free */
-        prefetch(pre, t + 1);
-        MI355_WAVE_SYNC();
 #define AB_A(w) ((int)((w) & 0xFF))
 #define AB_B(w) ((int)(((w) >> 8) & 0xFF))
 #define BYTE(w, e) ((int)(((w) >> (8 * (e))) & 0xFF))
+    /* boundary strengths of step t's macroblocks from `pre` (their records and vectors) and `hl` (the previous macroblock's), packed per line:
+     * byte e of bsw0 / bsw1 = the strength of vertical / horizontal edge e of this lane's luma row / column, bsc0 / bsc1 the same for its chroma
+     * line; alpha / beta / tc0 of the step into parm[pb] */
+    auto strengths = [&](int t, int pb, uint32_t &bsw0, uint32_t &bsw1, uint32_t &bsc0, uint32_t &bsc1) {
+        const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+        const int mb_y = 4 * band + g, mb_x = t - 2 * g;
+        const bool row_ok = mb_y < H, has_t = row_ok && mb_y > 0, valid = row_ok && mb_x >= 0 && mb_x < W;
+        const bool outer = (l & 3) == 0, odd = (l & 1) != 0;
+        const MbInfo &h = pre.h, &ht = pre.ht;
+        const mi355_u32x4 ra = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][0]), rb = *reinterpret_cast<const mi355_u32x4 *>(&s.role[l][4]);
+        const BsRole r0{ ra[0], ra[1], ra[2], ra[3] }, r1{ rb[0], rb[1], rb[2], rb[3] };
+        const bool filter = valid && !(h.flags() & MI355_MBF_NO_DEBLOCK);
+        const bool have_left = filter && mb_x > 0 && (h.flags() & MI355_MBF_LEFT_EDGE), have_top = filter && has_t && (h.flags() & MI355_MBF_TOP_EDGE);
+        const uint32_t b0 = bs_role(h, hl, outer, odd, filter && (!outer || have_left), r0, pre.p0, pre.q0, two_lists, mv_far, 4u);
+        const uint32_t b1 = bs_role(h, ht, outer, odd, filter && (!outer || have_top), r1, pre.p1, pre.q1, two_lists, mv_far, field ? 3u : 4u);
+        bsw0 = (uint32_t)quad_bcast<0>((int)b0) | ((uint32_t)quad_bcast<1>((int)b0) << 8) | ((uint32_t)quad_bcast<2>((int)b0) << 16) | ((uint32_t)quad_bcast<3>((int)b0) << 24);
+        bsw1 = (uint32_t)quad_bcast<0>((int)b1) | ((uint32_t)quad_bcast<1>((int)b1) << 8) | ((uint32_t)quad_bcast<2>((int)b1) << 16) | ((uint32_t)quad_bcast<3>((int)b1) << 24);
+        const int csrc = (lane & ~15) | (((l & 7) >> 1) << 2);
+        bsc0 = (uint32_t)__shfl((int)bsw0, csrc); bsc1 = (uint32_t)__shfl((int)bsw1, csrc);
+        /* alpha / beta / tc0: lane k < 9 of a group looks up (component k / 3, edge kind k % 3) */
+        const int comp = l < 3 ? 0 : (l < 6 ? 1 : 2), kind = l - 3 * comp;
+        const int kindc = kind > 2 ? 2 : kind;
+        const MbInfo &nb = kindc == 1 ? hl : ht;
+        int qa = comp ? h.qpc(comp - 1) : h.qp();
+        int qb = comp ? nb.qpc(comp - 1) : nb.qp();
+        if (comp && kindc && nb.slice_id() != h.slice_id() && (kindc == 1 ? have_left : have_top)) {
+            int v = mi355_global(fr.slices)[h.slice_id()].chroma_qp_table[comp - 1][nb.qp()];
+            MI355_PIN(v);
+            qb = v;
+        }
+        const int qp = kindc ? (qa + qb + 1) >> 1 : qa;
+        const int ia = clip3(qp + h.alpha_off(), 0, 51), ib = clip3(qp + h.beta_off(), 0, 51);
+        const uint32_t w0 = (uint32_t)s.t_alpha[ia] | ((uint32_t)s.t_beta[ib] << 8);
+        const uint32_t w1 = s.t_tc0[ia] + (comp ? 0x01010100u : 0u);
+        if (l < 9) { s.parm[pb][g][l][0] = w0; s.parm[pb][g][l][1] = w1; }
+        hl = h;
+    };
+    auto edges_v = [&](int t, int pb, uint32_t bsw0, uint32_t bsc0) {
         /* ---- vertical edges: lane l of a group = luma row l and chroma row (plane l >> 3, row l & 7), from and to the ring ---------------- */
         {
             const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-            const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * (l >> 3)];
+            const uint32_t *pl = s.parm[pb][g][0], *pc = s.parm[pb][g][3 + 3 * (l >> 3)];
             const uint32_t ab_i = pl[0], tr_i = pl[1], ab_l = pl[2], tr_l = pl[3];
             const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_l = pc[2], ctr_l = pc[3];
             const uint32_t tci0 = byte_perm(0, tr_i, bsw0 & 0x03030303u), tcl0 = byte_perm(0, tr_l, bsw0 & 3u);
@@ -987,13 +981,13 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
             if (d0) *reinterpret_cast<uint32_t *>(cleftp) = cl;
             if (d0 || d1) *reinterpret_cast<mi355_u32x2 *>(crowp) = mi355_u32x2{ cw0, cw1 };
         }
-        MI355_WAVE_SYNC();
-        if (hand) hand_down(t);
+    };
+    auto edges_h = [&](int t, int pb, uint32_t bsw1, uint32_t bsc1) {
         /* ---- horizontal edges: lane l of a group = luma column l and chroma column (plane l >> 3, column l & 7); rows -4..-1 (chroma -2, -1)
          * are rows 12..15 (6, 7) of the tile above — in the ring of the group above, or in above[] — read and patched where they lie -------- */
         {
             const int lane = lane_id(), g = lane >> 4, l = lane & 15, ga = (g - 1) & 3, cp = l >> 3, cr = l & 7;
-            const uint32_t *pl = s.parm[g][0], *pc = s.parm[g][3 + 3 * cp];
+            const uint32_t *pl = s.parm[pb][g][0], *pc = s.parm[pb][g][3 + 3 * cp];
             const uint32_t ab_i = pl[0], tr_i = pl[1], ab_t = pl[4], tr_t = pl[5];
             const uint32_t cab_i = pc[0], ctr_i = pc[1], cab_t = pc[4], ctr_t = pc[5];
             const uint32_t tci1 = byte_perm(0, tr_i, bsw1 & 0x03030303u), tct1 = byte_perm(0, tr_t, bsw1 & 3u);
@@ -1045,14 +1039,96 @@ __device__ __forceinline__ void deblock3_band(Deblock3Lds &s, const mi355_h264_f
 #undef CR
 #undef CAR
         }
+    };
+    if constexpr (NW == 1) {
+        await_above(0);
+        dma_issue(0);
+        prefetch(pre, 0);
+        hl = pre.h;
+#pragma nounroll
+        for (int t = 0; t < nsteps; t++) {
+            /* ---- everything requested during the last step is here; what was stored during it is out ------------------------------ */
+            agent_drain_stores();
+            if (hand && t >= 8) {
+                /* hand_down(t - 1) is out: group 3's macroblocks 0 .. t - 8 */
+                const int done = t - 7 < W ? t - 7 : W;
+                if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
+            }
+            MI355_WAVE_SYNC();
+            if (t > 0) stores(t - 1);
+            await_above(t + 1);
+            dma_issue(t + 1);
+            uint32_t bsw0, bsw1, bsc0, bsc1;
+            strengths(t, 0, bsw0, bsw1, bsc0, bsc1);
+            /* the next macroblock's records and vectors: the registers of this one's are free */
+            prefetch(pre, t + 1);
+            MI355_WAVE_SYNC();
+            edges_v(t, 0, bsw0, bsc0);
+            MI355_WAVE_SYNC();
+            if (hand) hand_down(t);
+            edges_h(t, 0, bsw1, bsc1);
+        }
+        /* ---- the last step's results, and the closing word to the band below ----------------------------------------------------- */
+        agent_drain_stores();
+        MI355_WAVE_SYNC();
+        stores(nsteps - 1);
+    } else {
+        /* wave 1 first: the loads of step 0, the strengths of step 0 into the mailbox, the records of step 1 */
+        if (srv_wave) {
+            await_above(0);
+            dma_issue(0);
+            prefetch(pre, 0);
+            hl = pre.h;
+            uint32_t b[4];
+            strengths(0, 0, b[0], b[1], b[2], b[3]);
+            *reinterpret_cast<mi355_u32x4 *>(mail->bs[0][lane_id()]) = mi355_u32x4{ b[0], b[1], b[2], b[3] };
+            prefetch(pre_next, 1);
+        }
+#pragma nounroll
+        for (int t = 0; t < nsteps; t++) {
+            /* both waves: what this wave stored during the last step is out; wave 1: the tiles of step t have landed, the records of step t + 1 are here */
+            agent_drain_stores();
+            if (edge_wave && hand && t >= 8) {
+                /* the hand-down is the edge wave's (right behind its vertical edges, as in the one-wave form): hand_down(t - 1) is out */
+                const int done = t - 7 < W ? t - 7 : W;
+                if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)done);
+            }
+            MI355_WG_BARRIER_LDS();
+            if (edge_wave) {
+                const mi355_u32x4 b = *reinterpret_cast<const mi355_u32x4 *>(mail->bs[t & 1][lane_id()]);
+                edges_v(t, t & 1, b[0], b[2]);
+                MI355_WAVE_SYNC();
+                if (hand) hand_down(t);
+                edges_h(t, t & 1, b[1], b[3]);
+            } else {
+                /* a second set of record registers: the loads of step t + 2 go out FIRST and have the whole step (this wave has registers to spare;
+                 * issued last, they would be waited for at once by the drain that begins the next step) */
+                pre = pre_next;
+                prefetch(pre_next, t + 2);
+                if (t > 0) stores(t - 1);
+                await_above(t + 1);
+                dma_issue(t + 1);
+                uint32_t b[4];
+                strengths(t + 1, (t + 1) & 1, b[0], b[1], b[2], b[3]);
+                *reinterpret_cast<mi355_u32x4 *>(mail->bs[(t + 1) & 1][lane_id()]) = mi355_u32x4{ b[0], b[1], b[2], b[3] };
+            }
+            MI355_WG_BARRIER_LDS();
+        }
+        if (!srv_wave) {
+            /* the edge wave's last hand-down (macroblock W - 1) and the closing word to the band below */
+            if (hand) {
+                agent_drain_stores();
+                if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)W);
+            }
+            return;
+        }
+        agent_drain_stores();
+        stores(nsteps - 1);
+        return;
+    }
 #undef AB_A
 #undef AB_B
 #undef BYTE
-    }
-    /* ---- the last step's results, and the closing word to the band below --------------------------------------------------------- */
-    agent_drain_stores();
-    MI355_WAVE_SYNC();
-    stores(nsteps - 1);
     if (hand) {
         agent_drain_stores();
         if (lane_id() == 0) agent_store_u32(mi355_global_v(prog_self), (uint32_t)W);
@@ -1078,11 +1154,30 @@ k_deblock_tiled(const mi355_h264_frame *__restrict__ frames, int nframes, int nb
     if (4 * band >= uniform(fr.mb_height) || uniform(fr.surface_layout) != MI355_SURFACE_TILED) return;
     uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
 #ifdef MI355_EXP_DB2_ONLY        /* developer experiment: the instruction listing / register count of one instance alone (P pictures) */
-    deblock3_band<false>(s, fr, band, prog);
+    deblock3_band<false, 1>(s, nullptr, fr, band, prog, 0);
     return;
 #endif
-    if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true>(s, fr, band, prog);
-    else deblock3_band<false>(s, fr, band, prog);
+    if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true, 1>(s, nullptr, fr, band, prog, 0);
+    else deblock3_band<false, 1>(s, nullptr, fr, band, prog, 0);
+}
+/* the same with two waves per band (few pictures): see deblock3_band */
+__global__ void __launch_bounds__(128)
+k_deblock_tiled2(const mi355_h264_frame *__restrict__ frames, int nframes, int nbands, uint32_t *sync)
+{
+    __shared__ Deblock3Lds s;
+    __shared__ Deblock3Mail mail;
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) ticket = atomicAdd(mi355_global(sync), 1u);
+    __syncthreads();
+    const uint32_t tk = (uint32_t)uniform((int)ticket);
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int band = (int)(tk / (uint32_t)nframes), pic = (int)(tk - (uint32_t)band * (uint32_t)nframes);
+    if (band >= nbands) return;
+    const mi355_h264_frame &fr = frames[pic];
+    if (4 * band >= uniform(fr.mb_height) || uniform(fr.surface_layout) != MI355_SURFACE_TILED) return;
+    uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
+    if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true, 2>(s, &mail, fr, band, prog, wave);
+    else deblock3_band<false, 2>(s, &mail, fr, band, prog, wave);
 }
 
 }  // namespace
@@ -1153,7 +1248,17 @@ extern "C" int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, 
         uint32_t *sync = sync_words(st, words);
         if (!sync) return -4;
         MI355_TRY(hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st), -4);
-        hipLaunchKernelGGL(k_deblock_tiled, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
+        /* few bands in all (fewer than two per SIMD): two waves per band, the edge phases beside everything else (MI355_DEBLOCK_WAVES = 1 / 2 pins the form) */
+        static const int pin = std::getenv("MI355_DEBLOCK_WAVES") ? std::atoi(std::getenv("MI355_DEBLOCK_WAVES")) : 0;
+        static int simds = 0;
+        if (!simds) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            simds = 4 * (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        }
+        const bool two = pin == 2 || (pin != 1 && (long long)nframes * nbands < 2LL * simds);
+        if (two) hipLaunchKernelGGL(k_deblock_tiled2, dim3((unsigned)(nframes * nbands)), dim3(128), 0, st, d_frames, nframes, nbands, sync);
+        else hipLaunchKernelGGL(k_deblock_tiled, dim3((unsigned)(nframes * nbands)), dim3(64), 0, st, d_frames, nframes, nbands, sync);
         if (!(layouts & MI355_LAYOUTS_LINEAR)) return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     static int cus = 0;

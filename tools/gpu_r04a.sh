@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round 4, session a: the single-launch loop filter on hardware — parity (frame / field / session suites + the hand-down stress
 # test), then pass times of every library in build/variants for 2048 / 512 / 64 pictures, and the old forms beside them.
-# Usage (repo root, via gpurun): bash tools/gpu_r04a.sh <tag>
+# Usage (repo root, via gpurun): bash tools/gpu_r04a.sh <tag>     (R04_QUICK=1: pass times of the built library and the variants only)
 set -u
 TAG=${1:-r04a}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_frame_gpu.py tests/test_field_gpu.py tests/test_session_gpu.py tests/test_bridge_gpu.py tests/test_synth_streams_gpu.py -m gpu -x -q > $OUT/pytest_frames.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_frames.txt
+[ -n "${R04_QUICK:-}" ] || timeout 900 python -m pytest tests/test_frame_gpu.py tests/test_field_gpu.py tests/test_session_gpu.py tests/test_bridge_gpu.py tests/test_synth_streams_gpu.py -m gpu -x -q > $OUT/pytest_frames.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_frames.txt
 tail -6 $OUT/pytest_frames.txt
 cp libav_amd/libmi355dsp.so /tmp/orig.so
 times() {   # $1 = label
@@ -40,7 +40,7 @@ for content, kw in (("noise", {}), ("smooth", dict(refs="smooth", coef_b=4)), ("
         dev.free()
 PY
 }
-MI355_DEBLOCK_FORM=-1 times old_forms
+[ -n "${R04_QUICK:-}" ] || MI355_DEBLOCK_FORM=-1 times old_forms
 times default
 for so in build/variants/*.so; do
   [ -e "$so" ] || continue
