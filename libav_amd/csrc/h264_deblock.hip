@@ -734,18 +734,6 @@ struct __attribute__((aligned(128))) Deblock3Lds {
 struct __attribute__((aligned(16))) Deblock3Mail { uint32_t bs[2][64][4]; };
 static_assert(sizeof(Deblock3Lds) <= 8192 + 288, "nineteen or twenty waves per CU");
 
-/* sixteen bytes per lane from memory straight into LDS at lds_base + 16 * lane (lds_base wave-uniform) */
-#ifdef MI355_HIP_EMU_H
-template <bool AGENT> static inline void lds_dma16(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 16 * (threadIdx.x & 63), src, 16); }
-#else
-template <bool AGENT> __device__ __forceinline__ void lds_dma16(const uint8_t *src, uint8_t *lds_base)
-{
-    typedef __attribute__((address_space(1))) const void *gptr;
-    typedef __attribute__((address_space(3))) void *lptr;
-    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)lds_base, 16, 0, AGENT ? 16 : 0);      /* aux 16 = sc1: served past the vector L1 */
-}
-#endif
-
 /* NW = 1: the wave does everything (the throughput form).  NW = 2 (few pictures: SIMDs stand idle and a lone wave's step is a serial chain
  * of ~1100 instructions): the band's workgroup is TWO waves — wave 0 runs only the edge phases of step t, wave 1 meanwhile writes out what
  * step t - 1 finished, issues the loads of step t + 1 and derives the strengths and parameters of step t + 1, which reach wave 0 through LDS

@@ -65,4 +65,22 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
 /* h264_frame_tiled.hip: launches k_recon_inter_tiled (the tiled-only instance of the inter reconstruction kernel) */
 void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd, hipStream_t stream);
 }  // namespace mi355
+/* sixteen bytes per lane from memory straight into LDS at lds_base + 16 * lane (lds_base wave-uniform) */
+#ifdef MI355_HIP_EMU_H
+template <bool AGENT> static inline void lds_dma16(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 16 * (threadIdx.x & 63), src, 16); }
+#else
+template <bool AGENT> __device__ __forceinline__ void lds_dma16(const uint8_t *src, uint8_t *lds_base)
+{
+    typedef __attribute__((address_space(1))) const void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)lds_base, 16, 0, AGENT ? 16 : 0);      /* aux 16 = sc1: served past the vector L1 */
+}
+#endif
+/* what a wave puts between its lds_dma16 calls and its first LDS read of their data (memory loads in flight are waited for as well) */
+#ifdef MI355_HIP_EMU_H
+static inline void lds_dma_wait() {}
+#else
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
 #endif

@@ -119,25 +119,26 @@ __device__ inline void load_mb(MbCore &s, const FrameHot &fr, int mb_xy, bool wi
 }
 
 /* The same 960 bytes as ONE access of 16 bytes per lane: lanes 0-3 the record, 4-7 / 8-11 the list-0 / list-1 vectors (a
- * missing list reads the record and is zeroed), 12-59 the coefficients, 60-63 repeat lane 59 — and one 16-byte LDS write per
- * lane, because hdr, mv and coef follow each other in MbLds in that order.  The L1 handles a wave's access four lanes at a
+ * missing list reads sixteen zero bytes), 12-59 the coefficients, 60-63 repeat lane 59 — and one 16-byte LDS write per
+ * lane (done by the memory pipeline itself: lds_dma16), because hdr, mv and coef follow each other in MbLds in that order.  The L1 handles a wave's access four lanes at a
  * time whatever their width: five dword accesses of 64 lanes are 80 such groups, this is 15 (k_recon_inter's memory
  * pipeline was busy 60 % of the time, profiles/r02g_pmc3_h264_f2048.json). */
 static_assert(sizeof(mi355_h264_mb) == 64 && offsetof(MbCore, mv) == 64 && offsetof(MbCore, coef) == 192 && MI355_H264_COEFS_PER_MB == 384, "MbLds begins with the 960 bytes load_mb_wide fills");
+__device__ const uint32_t k_zero16[4] = { 0u, 0u, 0u, 0u };           /* what the lanes of a missing vector list read */
 __device__ __forceinline__ void load_mb_wide(MbLds &s, const FrameHot &fr, int mb_xy)
 {
     const int lane = lane_id(), l = lane < 60 ? lane : 59;
     const uint8_t *hp = reinterpret_cast<const uint8_t *>(&fr.mb[mb_xy]);
     const uint8_t *cp = reinterpret_cast<const uint8_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    const uint8_t *zp = reinterpret_cast<const uint8_t *>(k_zero16);
     const bool has0 = fr.mv[0] != nullptr, has1 = fr.mv[1] != nullptr;
-    const uint8_t *m0 = has0 ? reinterpret_cast<const uint8_t *>(fr.mv[0]) + (size_t)mb_xy * 64 : hp;
-    const uint8_t *m1 = has1 ? reinterpret_cast<const uint8_t *>(fr.mv[1]) + (size_t)mb_xy * 64 : hp;
-    /* lane l reads 16 bytes at offset 16 * (l - first lane of its part) of its part */
-    const uint8_t *src = l < 4 ? hp + 16 * l : (l < 8 ? m0 + 16 * (l - 4) : (l < 12 ? m1 + 16 * (l - 8) : cp + 16 * (l - 12)));
-    mi355_u32x4u v = *reinterpret_cast<const mi355_u32x4u *>(src);
-    MI355_ISSUE_FENCE();
-    if ((l >= 4 && l < 8 && !has0) || (l >= 8 && l < 12 && !has1)) v = mi355_u32x4u{ 0u, 0u, 0u, 0u };
-    *reinterpret_cast<mi355_u32x4 *>(reinterpret_cast<uint8_t *>(&s) + 16 * l) = mi355_u32x4{ v[0], v[1], v[2], v[3] };
+    const uint8_t *m0 = has0 ? reinterpret_cast<const uint8_t *>(fr.mv[0]) + (size_t)mb_xy * 64 + 16 * (l - 4) : zp;
+    const uint8_t *m1 = has1 ? reinterpret_cast<const uint8_t *>(fr.mv[1]) + (size_t)mb_xy * 64 + 16 * (l - 8) : zp;
+    /* lane l reads 16 bytes at offset 16 * (l - first lane of its part) of its part, and the memory pipeline writes them to LDS at 16 * lane:
+     * no register, no LDS write instruction (lanes 60-63 land in s.py, which nothing has written yet: one macroblock per wave) */
+    const uint8_t *src = l < 4 ? hp + 16 * l : (l < 8 ? m0 : (l < 12 ? m1 : cp + 16 * (l - 12)));
+    lds_dma16<false>(src, reinterpret_cast<uint8_t *>(&s));
+    lds_dma_wait();
     MI355_WAVE_SYNC();
 }
 
