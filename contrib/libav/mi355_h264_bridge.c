@@ -59,7 +59,12 @@
  * takes its boundary strengths from the LUMA coefficient flags for every plane (filter_mb_dir, h264_loopfilter.c:482-713),
  * so planes 1 and 2 get a second record array for the filter pass.  No kernel knows about 4:4:4.
  *
- * Streams outside the Tier-2 scope (MBAFF / field pictures, more than 8 bits, 4:2:2), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
+ * High 10 / High 4:2:2 (9 / 10-bit samples, chroma_format_idc 2): the same packing with the reference's own widths — `dctcoef` is
+ * 32 bits wide when sps->bit_depth_luma > 8 (sl->mb holds int32, h264dec.h), chroma has sixteen rows in 4:2:2 — and the pictures go
+ * through mi355_h264_decode_frames_wide_dev (the second kernel set, libav_amd/csrc/h264_frame_wide.hip) on planes with line strides;
+ * a launch set of the dispatcher holds pictures of ONE format.
+ *
+ * Streams outside the Tier-2 scope (MBAFF, transform bypass, more than 10 bits), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
  * aside for that decoder: the reference's own C path continues.  Errors are reported once on stderr; nothing here
  * calls abort().
  */
@@ -150,6 +155,11 @@ typedef struct Bridge {
     int open;                   /* a picture is being packed */
     DevPic pics[BR_MAX_PICS];
     int c444, npass;            /* 4:4:4: three passes (planes) per picture */
+    int wide;                   /* the sequence's format goes through the second kernel set (mi355_h264_decode_frames_wide_dev): more than 8 bits or 4:2:2 */
+    int bit_depth, idc;         /* sps->bit_depth_luma, sps->chroma_format_idc of the sequence the bridge is set up for */
+    int kidc;                   /* the chroma format the kernels see: idc, or 1 for 4:4:4 (planes in the luma role, scratch chroma) */
+    int px, csize;              /* bytes per sample (`pixel`) and per coefficient (`dctcoef`) */
+    int crows, ncoef;           /* chroma rows of a macroblock (8; 16 in 4:2:2), coefficients per macroblock (384; 512 in 4:2:2) */
     uint8_t *recon[3];          /* unfiltered reconstruction: Y, Cb, Cr (4:4:4: three full-size planes) */
     uint8_t *scratch_c[2];      /* 4:4:4: what the passes use as chroma planes (never looked at) */
     int stride[2];              /* device surfaces: bytes per line, or per macroblock row of tiles */
@@ -189,9 +199,12 @@ static void br_fail(Bridge *b, const char *what)
     b->state = -1;
 }
 
+static int fmt_class(const Bridge *b) { return b->wide ? 10 * b->bit_depth + b->kidc : 0; }
 static void *dalloc(size_t n) { return mi355_malloc(n); }
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
+/* pictures of one class share a launch set: 0 = the 8-bit 4:2:0 / 4:4:4 kernels, otherwise 10 * bit depth + the kernels' chroma format */
+static int fmt_class(const struct Bridge *b);
 static size_t picture_bytes(const Bridge *b) { return b->c444 ? 3 * b->plane_bytes[0] : b->plane_bytes[0] + (b->tiled ? 1 : 2) * b->plane_bytes[1]; }
 static size_t out_bytes(const Bridge *b) { return b->c444 ? 3 * b->lin_bytes[0] : b->lin_bytes[0] + 2 * b->lin_bytes[1]; }
 /* the job that turns device picture `pic` into the lines of the pinned buffer `out` */
@@ -216,7 +229,7 @@ static int staging_alloc(Bridge *b, Staging *s)
         o_mb[p] = o;   o = up64(o + n * sizeof(mi355_h264_mb));
         o_mbd[p] = p ? o : o_mb[0];
         if (p) o = up64(o + n * sizeof(mi355_h264_mb));
-        o_coef[p] = o; o = up64(o + n * 768);
+        o_coef[p] = o; o = up64(o + n * (size_t)b->ncoef * b->csize);
         o_sl[p] = o;   o = up64(o + BR_MAX_SLICES * sizeof(mi355_h264_slice));
     }
     const size_t o_mv0 = o;    o = up64(o + n * 64);
@@ -308,9 +321,15 @@ static int disp_enqueue(Disp *D, int slot)
     }
     mi355_h264_frame *dr = D->d_desc[slot], *dd = D->d_desc[slot] + nd;
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
+    const Bridge *b0 = D->in[slot][0]->b;
+    if (b0->wide) {      /* High 10 / High 4:2:2: the second kernel set, reconstruction and loop filter from their descriptor arrays */
+        if (!rc && mi355_h264_decode_frames_wide_dev(dr, nd, mw, mh, maxl, D->widths, b0->bit_depth, b0->kidc, 3, st) != 0) rc = -1;
+        if (!rc && mi355_h264_decode_frames_wide_dev(dd, nd, mw, mh, 0, NULL, b0->bit_depth, b0->kidc, 4, st) != 0) rc = -1;
+    } else {
     if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_layouts_dev(dd, nd, mw, mh, layouts, st) != 0) rc = -1;      /* the loop filter's kernel(s) for the layouts this batch holds */
+    }
     if (!rc && ncopy && mi355_copy_batch_dev(D->jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
     if (!rc && ncvt && mi355_h264_surface_convert_dev(D->cvt[slot], ncvt, cw, chh, st) != 0) rc = -1;
     rc |= mi355_event_record(D->ev[slot], st);
@@ -338,6 +357,7 @@ static void *disp_main(void *arg)
         while (c) {
             Submission *nx = c->next;
             int later = nd + c->b->npass > DISP_MAX_BATCH;
+            if (n && !later) later = fmt_class(D->in[slot][0]->b) != fmt_class(c->b);      /* one kernel set per launch set */
             for (int i = 0; i < n && !later; i++) later = D->in[slot][i]->b == c->b;
             if (later) {
                 c->next = NULL;
@@ -466,8 +486,8 @@ void __wrap_ff_h264_flush_change(H264Context *h)
         finish_all(b);
         b->open = 0;
         const SPS *sps = h->ps.sps;
-        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == 8 &&
-                         (sps->chroma_format_idc == 3) == b->c444 && (sps->chroma_format_idc == 1 || sps->chroma_format_idc == 3) &&
+        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == b->bit_depth &&
+                         sps->chroma_format_idc == b->idc &&
                          !sps->transform_bypass && !sps->residual_color_transform_flag &&
                          (!b->tiled || sps->frame_mbs_only_flag);        /* tiled device pictures hold frames only */
         if (!same) { bridge_release(b); b->state = 0; }
@@ -511,9 +531,9 @@ static Bridge *bridge_get(const H264Context *h)
     const int idc = h->ps.sps->chroma_format_idc;
     /* a sequence that may hold field MACROBLOCKS (mb_adaptive_frame_field_flag) is outside the path as a whole; field PICTURES
      * (PAFF: the choice between a frame and two fields is made per picture) are inside: begin_picture() looks at each one */
-    if ((!h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff) || FRAME_MBAFF(h) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->pixel_shift || (idc != 1 && idc != 3) || h->ps.sps->residual_color_transform_flag ||
-        h->ps.sps->transform_bypass) {
-        br_fail(b, "stream outside the batched path (needs 8-bit 4:2:0 or 4:4:4 frame or field pictures without MBAFF and transform bypass)");
+    if ((!h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff) || FRAME_MBAFF(h) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
+        (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || h->ps.sps->transform_bypass || getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2)) {
+        br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4 frame or field pictures without MBAFF and transform bypass)");
         b->soft = 1;
         return b;
     }
@@ -544,12 +564,16 @@ static Bridge *bridge_get(const H264Context *h)
     }
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
+    b->bit_depth = h->ps.sps->bit_depth_luma; b->idc = idc; b->kidc = idc == 3 ? 1 : idc;
+    b->wide = b->bit_depth > 8 || idc == 2;
+    b->px = b->bit_depth > 8 ? 2 : 1; b->csize = b->bit_depth > 8 ? 4 : 2;
+    b->crows = idc == 2 ? 16 : 8; b->ncoef = idc == 2 ? 512 : 384;
     /* frame_num gaps: the decoder fills a lost frame with a host-side copy of the previous one (h264_slice.c:1425-1452) — every
      * picture must be complete in its frame before the next one starts */
     b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL && !h->ps.sps->gaps_in_frame_num_allowed_flag;
-    b->lin_stride[0] = (16 * b->mb_w + 63) & ~63; b->lin_stride[1] = b->lin_stride[0] / 2;
-    b->lin_bytes[0] = (size_t)b->lin_stride[0] * 16 * b->mb_h; b->lin_bytes[1] = (size_t)b->lin_stride[1] * 8 * b->mb_h;
-    b->tiled = h->ps.sps->frame_mbs_only_flag && !b->c444 && !getenv("MI355_BRIDGE_LINEAR");
+    b->lin_stride[0] = (16 * b->mb_w * b->px + 63) & ~63; b->lin_stride[1] = b->lin_stride[0] / 2;
+    b->lin_bytes[0] = (size_t)b->lin_stride[0] * 16 * b->mb_h; b->lin_bytes[1] = (size_t)b->lin_stride[1] * b->crows * b->mb_h;
+    b->tiled = h->ps.sps->frame_mbs_only_flag && !b->c444 && !b->wide && !getenv("MI355_BRIDGE_LINEAR");
     if (b->tiled) {
         b->stride[0] = MI355_TILE_LUMA_BYTES * b->mb_w; b->stride[1] = MI355_TILE_CHROMA_BYTES * b->mb_w;
         b->plane_bytes[0] = (size_t)b->stride[0] * b->mb_h; b->plane_bytes[1] = (size_t)b->stride[1] * b->mb_h;
@@ -558,7 +582,7 @@ static Bridge *bridge_get(const H264Context *h)
         b->plane_bytes[0] = b->lin_bytes[0]; b->plane_bytes[1] = b->lin_bytes[1];
     }
     int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
-    if (getenv("MI355_BRIDGE_SESSION") && !b->c444) {
+    if (getenv("MI355_BRIDGE_SESSION") && !b->c444 && !b->wide) {
         /* one surface per H264Picture the decoder may hold; a slice that is not one run of macroblocks goes in run by run */
         const mi355_h264_session_params sp = { b->mb_w, b->mb_h, BR_MAX_PICS, 255, b->tiled ? MI355_SURFACE_TILED : MI355_SURFACE_LINEAR, 0 };
         ok = ok && mi355_h264_session_open(&b->sess, &sp) == 0;
@@ -632,7 +656,7 @@ static DevPic *devpic_upload(Bridge *b, const H264Context *h, const H264Picture 
     } else
     for (int k = 0; k < 3; k++) {
         const int half = k && !b->c444;
-        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->stride[half];
+        const int w = (half ? 8 : 16) * b->mb_w * b->px, hgt = (half ? b->crows : 16) * b->mb_h, st = b->stride[half];
         for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * st, p->f->data[k] + (size_t)y * p->f->linesize[k], (size_t)w);
         dst += b->plane_bytes[half];
     }
@@ -674,7 +698,7 @@ static int finish_set(Bridge *b, Staging *s)
     const int y0 = s->field ? s->parity : 0, dy = s->field ? 2 : 1;
     for (int k = 0; k < 3; k++) {
         const int half = k && !b->c444;
-        const int w = (half ? 8 : 16) * b->mb_w, hgt = (half ? 8 : 16) * b->mb_h, st = b->lin_stride[half];
+        const int w = (half ? 8 : 16) * b->mb_w * b->px, hgt = (half ? b->crows : 16) * b->mb_h, st = b->lin_stride[half];
         for (int y = y0; y < hgt; y += dy) memcpy(s->frame_data[k] + (size_t)y * s->frame_linesize[k], src + (size_t)y * st, (size_t)w);
         src += b->lin_bytes[half];
     }
@@ -750,6 +774,21 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
     return b->nslices++;
 }
 
+/* I_PCM samples for the second kernel set, one per coefficient slot: samples `first` .. `first + n - 1` of the macroblock's PCM payload —
+ * bytes at 8 bits, bit_depth-wide big-endian fields otherwise (h264_mb_template.c:99-153) */
+static void pcm_unpack(const Bridge *b, const uint8_t *src, int first, int n, uint8_t *cf)
+{
+    for (int i = 0; i < n; i++) {
+        unsigned v = 0;
+        if (b->bit_depth == 8) v = src[first + i];
+        else {
+            const size_t bit = (size_t)(first + i) * b->bit_depth;
+            for (int k = 0; k < b->bit_depth; k++) v = (v << 1) | ((src[(bit + k) >> 3] >> (7 - ((bit + k) & 7))) & 1);
+        }
+        if (b->csize == 4) ((int32_t *)cf)[i] = (int32_t)v; else ((int16_t *)cf)[i] = (int16_t)v;
+    }
+}
+
 /* 4:4:4: the records, coefficients and filter records of planes 1 and 2 (hl_decode_mb_predict_luma / _idct_luma with
  * p = 1, 2: h264_mb_template.c:323-343; coefficient flags at scan8[16 * p + i], DC levels in sl->mb_luma_dc[p], the DC
  * multiplier of dequant4_coeff[p] at the plane's QP, h264_mb.c:617-640) */
@@ -759,14 +798,17 @@ static void pack_planes_444(const H264Context *h, H264SliceContext *sl, Staging 
     m0->chroma_pred_mode = 6;                        /* DC_128_PRED8x8: the scratch chroma planes are predicted from nothing */
     for (int p = 1; p < 3; p++) {
         mi355_h264_mb *m = &st->mb[p][idx];
-        int16_t *cf = st->coef[p] + (size_t)idx * 384;
+        const Bridge *b = br_tls;
+        const int cs = b->csize;
+        uint8_t *cf = (uint8_t *)st->coef[p] + (size_t)idx * 384 * cs;
         *m = *m0;
         m->nnz_mask = 0;
         m->qp = (int8_t)h->ps.pps->chroma_qp_table[p - 1][m0->qp & 0xff];
         m->dc_qmul[0] = h->ps.pps->dequant4_coeff[p][sl->chroma_qp[p - 1]][0];
-        if (IS_INTRA(mb_type) || luma_coded) memset(cf, 0, 768);
+        if (IS_INTRA(mb_type) || luma_coded) memset(cf, 0, 384 * (size_t)cs);
         if (IS_INTRA_PCM(mb_type)) {
-            memcpy(cf, sl->intra_pcm_ptr + 256 * p, 256);
+            if (b->wide) pcm_unpack(b, sl->intra_pcm_ptr, 256 * p, 256, cf);
+            else memcpy(cf, sl->intra_pcm_ptr + 256 * p, 256);
             m->nnz_mask = 0xFFFFFF;
         } else {
             if (luma_coded) {
@@ -774,11 +816,11 @@ static void pack_planes_444(const H264Context *h, H264SliceContext *sl, Staging 
                     const int src = IS_8x8DCT(mb_type) ? (i & ~3) : i;
                     if (sl->non_zero_count_cache[scan8[16 * p + src]]) m->nnz_mask |= 1u << i;
                 }
-                memcpy(cf, sl->mb + 256 * p, 256 * 2);
+                memcpy(cf, (const uint8_t *)sl->mb + 256 * (size_t)p * cs, 256 * (size_t)cs);
             }
             if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX + p]]) {
                 m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
-                for (int k = 0; k < 16; k++) cf[mi355_luma_dc_slot(k)] = sl->mb_luma_dc[p][k];
+                for (int k = 0; k < 16; k++) memcpy(cf + (size_t)mi355_luma_dc_slot(k) * cs, (const uint8_t *)sl->mb_luma_dc[p] + (size_t)k * cs, (size_t)cs);
             }
         }
         /* the loop filter derives the boundary strengths of every plane from the luma coefficient flags */
@@ -826,17 +868,21 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     m->topleft_samples_available = (uint16_t)sl->topleft_samples_available;
     m->topright_samples_available = (uint16_t)sl->topright_samples_available;
     m->dc_qmul[0] = h->ps.pps->dequant4_coeff[0][sl->qscale][0];
-    m->dc_qmul[1] = h->ps.pps->dequant4_coeff[intra ? 1 : 4][sl->chroma_qp[0]][0];
-    m->dc_qmul[2] = h->ps.pps->dequant4_coeff[intra ? 2 : 5][sl->chroma_qp[1]][0];
+    const int cq3 = b->idc == 2 ? 3 : 0;          /* chroma422_dc_dequant_idct takes the multiplier of QPc + 3 (h264_mb_template.c:232-236) */
+    m->dc_qmul[1] = h->ps.pps->dequant4_coeff[intra ? 1 : 4][sl->chroma_qp[0] + cq3][0];
+    m->dc_qmul[2] = h->ps.pps->dequant4_coeff[intra ? 2 : 5][sl->chroma_qp[1] + cq3][0];
     memset(m->ref_idx, -1, sizeof(m->ref_idx));
 
-    int16_t *cf = st->coef[0] + (size_t)idx * 384;
+    /* `dctcoef` is int32_t when the samples have more than 8 bits: sl->mb, sl->mb_luma_dc and the staging block are addressed in bytes */
+    const size_t cs = (size_t)b->csize, ncc = b->idc == 2 ? 128 : 64;
+    uint8_t *cf = (uint8_t *)st->coef[0] + (size_t)idx * b->ncoef * cs;
+    uint8_t *mbp = (uint8_t *)sl->mb;
     /* an inter macroblock without coefficients (cbp 0) never has its block fetched (mi355_h264_recon_inter_sparse_dev):
      * no need to clear it either */
     const int reads_coefs = intra || (cbp & 0x3F);
     if (IS_INTRA_PCM(mb_type)) {
-        memcpy(cf, sl->intra_pcm_ptr, 384);
-        memset(cf + 192, 0, 384);
+        if (b->wide) pcm_unpack(b, sl->intra_pcm_ptr, 0, b->c444 ? 256 : 256 + 2 * 8 * b->crows, cf);
+        else { memcpy(cf, sl->intra_pcm_ptr, 384); memset(cf + 384, 0, 384); }
         m->nnz_mask = 0xFFFFFF;
         memset(m->u.intra4x4_pred_mode, 0, 16);
         if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, 0);
@@ -848,15 +894,15 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 const int src = IS_8x8DCT(mb_type) ? (i & ~3) : i;
                 if (sl->non_zero_count_cache[scan8[src]]) m->nnz_mask |= 1u << i;
             }
-            memcpy(cf, sl->mb, 256 * 2);
-        } else if (reads_coefs) memset(cf, 0, 256 * 2);
+            memcpy(cf, mbp, 256 * cs);
+        } else if (reads_coefs) memset(cf, 0, 256 * cs);
         if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX]]) {
             m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
-            for (int k = 0; k < 16; k++) cf[mi355_luma_dc_slot(k)] = sl->mb_luma_dc[0][k];
+            for (int k = 0; k < 16; k++) memcpy(cf + (size_t)mi355_luma_dc_slot(k) * cs, (const uint8_t *)sl->mb_luma_dc[0] + k * cs, cs);
         }
         if (cbp & 0x30) {
-            memcpy(cf + 256, sl->mb + 256, 64 * 2);
-            memcpy(cf + 320, sl->mb + 512, 64 * 2);
+            memcpy(cf + 256 * cs, mbp + 256 * cs, ncc * cs);
+            memcpy(cf + (256 + ncc) * cs, mbp + 512 * cs, ncc * cs);
             if (cbp & 0x20)
                 for (int j = 0; j < 4; j++) {
                     if (sl->non_zero_count_cache[scan8[16 + j]]) m->nnz_mask |= 1u << MI355_NNZ_CB(j);
@@ -864,7 +910,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 }
             if (sl->non_zero_count_cache[scan8[CHROMA_DC_BLOCK_INDEX + 0]]) m->nnz_mask |= 1u << MI355_NNZ_CB_DC;
             if (sl->non_zero_count_cache[scan8[CHROMA_DC_BLOCK_INDEX + 1]]) m->nnz_mask |= 1u << MI355_NNZ_CR_DC;
-        } else if (reads_coefs) memset(cf + 256, 0, 128 * 2);
+        } else if (reads_coefs) memset(cf + 256 * cs, 0, 2 * ncc * cs);
         if (intra) {
             for (int i = 0; i < 16; i++) m->u.intra4x4_pred_mode[i] = sl->intra4x4_pred_mode_cache[scan8[i]];
         } else {
@@ -896,10 +942,10 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
          * decoders rely on finding the block array zeroed */
         if (b->c444) pack_planes_444(h, sl, st, idx, mb_type, luma_coded);
         if (b->c444) {
-            if (luma_coded || (cbp & 0x30)) memset(sl->mb, 0, 16 * 48 * sizeof(int16_t));
+            if (luma_coded || (cbp & 0x30)) memset(mbp, 0, 16 * 48 * cs);
         } else {
-            if (luma_coded) memset(sl->mb, 0, 256 * 2);
-            if (cbp & 0x30) { memset(sl->mb + 256, 0, 64 * 2); memset(sl->mb + 512, 0, 64 * 2); }
+            if (luma_coded) memset(mbp, 0, 256 * cs);
+            if (cbp & 0x30) { memset(mbp + 256 * cs, 0, ncc * cs); memset(mbp + 512 * cs, 0, ncc * cs); }
         }
     }
 }
@@ -1010,6 +1056,10 @@ static int submit_picture(Bridge *b, H264Context *h)
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
     if (b->direct) {
         if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
+        if (b->wide) {
+            if (mi355_h264_decode_frames_wide_dev(s->d_desc, np, b->mb_w, b->mb_h, maxl, s->widths, b->bit_depth, b->kidc, 3, b->stream) != 0 ||
+                mi355_h264_decode_frames_wide_dev(s->d_desc + np, np, b->mb_w, b->mb_h, 0, NULL, b->bit_depth, b->kidc, 4, b->stream) != 0) return -4;
+        } else
         if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
             mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
             mi355_h264_deblock_layouts_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR, b->stream) != 0) return -4;

@@ -260,6 +260,24 @@ int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_frames, int n
                                          int max_mb_width, int max_mb_height, int max_intra_level,
                                          const int32_t *level_widths, int layouts, void *stream);
 
+/* The same three passes for the formats outside the 8-bit kernels above: bit_depth 9 / 10 with chroma_format_idc 1 / 2 (High 10,
+ * High 4:2:2 — h264_mb_template.c:27-58 PIXEL_SHIFT, :174-232 CHROMA422) and bit_depth 8 with chroma_format_idc 2.  What changes in
+ * the descriptors of such a batch (every picture of it has the same format):
+ *   - samples of dst / recon / ref are uint16_t when bit_depth > 8 (`pixel`, bit_depth_template.c:49-87); strides stay in bytes;
+ *     surfaces are MI355_SURFACE_LINEAR; with chroma_format_idc 2 the chroma planes have the luma's height;
+ *   - coef holds int32_t when bit_depth > 8 (`dctcoef`), int16_t otherwise: 256 luma + 2 * 64 chroma per macroblock, or 2 * 128 with
+ *     chroma_format_idc 2 (Cb block j at [256 + 16 * j], Cr at [384 + 16 * j], j = 0..7 in the reference's order: sl->mb + 256 /
+ *     + 512, h264idct_template.c:216-238), laid out as MI355_H264_COEFS_PER_MB describes otherwise; an I_PCM macroblock holds its
+ *     samples one per coefficient slot (Y, Cb, Cr) — the host unpacks the bit_depth-wide fields of h264_mb_template.c:108-137;
+ *   - mi355_h264_mb: qp / qpc are the table values (QpBdOffset included, as h->cur_pic.qscale_table holds them); dc_qmul[1..2] with
+ *     chroma_format_idc 2 = dequant4_coeff[..][chroma_qp + 3][0] (h264_mb_template.c:232-236); the nnz_mask bits of chroma BLOCKS
+ *     are not read (a block is transformed iff it holds a coefficient), the DC bits are.
+ * passes: bit 0 inter, bit 1 intra, bit 2 loop filter (7 = everything; the separate bits are for measurement).
+ * Returns 0, -1 (arguments / a format this entry point does not take — 8-bit 4:2:0 has the kernels above), -2, -3 as the others. */
+int mi355_h264_decode_frames_wide_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
+                                      int max_intra_level, const int32_t *level_widths, int bit_depth, int chroma_format_idc,
+                                      int passes, void *stream);
+
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
 int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);

@@ -1,0 +1,741 @@
+/*
+ * h264_frame_wide.hip — Tier-2 for the H.264 formats outside the 8-bit 4:2:0 kernels (h264_frame.hip, h264_deblock.hip):
+ * 9- and 10-bit samples (High 10) and 4:2:2 chroma (High 4:2:2), frame or field pictures without MBAFF and without
+ * transform bypass.  C ABI: mi355_h264_decode_frames_wide_dev (include/mi355_h264_frame.h).
+ *
+ * Reference behaviour restated: hl_decode_mb with PIXEL_SHIFT / CHROMA422 (h264_mb_template.c:27-58, :174-232, :239-257),
+ * mc_dir_part / mc_part_std / mc_part_weighted (h264_mb.c:204-471, the chroma_idc == 2 branches :284-315), hl_motion
+ * (h264_mc_template.c:64-163), hl_decode_mb_predict_luma / _idct_luma (h264_mb.c:612-795), the BIT_DEPTH 9 / 10 templates of
+ * h264idct_template.c:33-310 (chroma422_dc_dequant_idct :275-310, idct_add8_422 :216-238), h264qpel_template.c:77-300,
+ * h264chroma_template.c:28-200, h264dsp_template.c:30-330 (weights, loop-filter lines, the sixteen-line chroma422 edge),
+ * h264pred_template.c (pred8x16_* :502-846), ff_h264_filter_mb / filter_mb_dir / check_mv (h264_loopfilter.c:442-847).
+ *
+ * This is the SECOND kernel set DESIGN.md §8 announces, in its first form: one wave per macroblock, samples widened to 16 bits
+ * and coefficients to 32 bits in LDS whatever the picture holds, the arithmetic per sample as the templates write it (the
+ * device functions the 9 / 10-bit Tier-1 tables already run, h264_tier1_hbd.hip, pinned against the reference's own objects).
+ * Three passes as in the 8-bit set: every inter macroblock in one launch; intra macroblocks level by level
+ * (mi355_h264_intra_schedule); the loop filter as one launch per anti-diagonal d = x + 2y (the reference's raster order only
+ * needs left, top and top-right done).  Surfaces are planes with byte strides (MI355_SURFACE_LINEAR).  No byte packing, no
+ * tiled surfaces, no single-launch loop filter yet: parity first (bench point config2_high10 in bench.py).
+ */
+#include <type_traits>
+#include "h264_frame_dev.h"
+
+using namespace mi355;
+
+namespace {
+
+template <int BD, int CF> struct Fmt {
+    typedef typename std::conditional<(BD > 8), uint16_t, uint8_t>::type PX;      /* `pixel` */
+    typedef typename std::conditional<(BD > 8), int32_t, int16_t>::type COEF;     /* `dctcoef` */
+    static constexpr int CH = CF == 2 ? 16 : 8;          /* chroma rows of a macroblock */
+    static constexpr int NCB = CF == 2 ? 8 : 4;          /* 4x4 blocks of a chroma plane */
+    static constexpr int NCOEF = 256 + 2 * 16 * NCB;     /* coefficients per macroblock: 384 / 512 */
+    static constexpr int MAXV = (1 << BD) - 1;
+};
+
+/* position of chroma block j of a plane in 4-sample units: the reference's block_offset[16 + j] (4:2:0, j = 0..3) and
+ * block_offset[16 + j] / [16 + j + 4] (4:2:2, h264idct_template.c:222-236) */
+__device__ __forceinline__ int cblk_x4(int j) { return j & 1; }
+__device__ __forceinline__ int cblk_y4(int j) { return ((j >> 1) & 1) + 2 * (j >> 2); }
+
+/* ---- inverse transforms on 32-bit LDS copies of the coefficients; stores between the two passes have the width of dctcoef ------ */
+template <typename COEF>
+__device__ inline void wide_idct4(const int32_t *c, int r[16])       /* h264idct_template.c:33-66; r[4 * row + column] */
+{
+    int t[16];
+    for (int i = 0; i < 4; i++) {
+        const int c0 = (COEF)(c[i] + (i == 0 ? 32 : 0));
+        const int z0 = c0 + c[i + 8], z1 = c0 - c[i + 8], z2 = (c[i + 4] >> 1) - c[i + 12], z3 = c[i + 4] + (c[i + 12] >> 1);
+        t[i] = (COEF)(z0 + z3); t[i + 4] = (COEF)(z1 + z2); t[i + 8] = (COEF)(z1 - z2); t[i + 12] = (COEF)(z0 - z3);
+    }
+    for (int i = 0; i < 4; i++) {
+        const int z0 = t[4 * i] + t[4 * i + 2], z1 = t[4 * i] - t[4 * i + 2], z2 = (t[4 * i + 1] >> 1) - t[4 * i + 3], z3 = t[4 * i + 1] + (t[4 * i + 3] >> 1);
+        r[i] = (z0 + z3) >> 6; r[4 + i] = (z1 + z2) >> 6; r[8 + i] = (z1 - z2) >> 6; r[12 + i] = (z0 - z3) >> 6;
+    }
+}
+/* sixteen (or NB) 4x4 blocks at once: lane 4 * b + q adds row q of block b; every lane of the wave calls */
+template <int BD, int CF>
+__device__ inline void wide_add_blocks4(const int32_t *coef, int nblocks, bool chroma, uint16_t *dst, int pitch)
+{
+    typedef Fmt<BD, CF> F;
+    const int lane = lane_id(), b = lane >> 2, q = lane & 3;
+    if (b < nblocks) {
+        int r[16];
+        wide_idct4<typename F::COEF>(coef + 16 * b, r);
+        const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
+        uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
+        for (int k = 0; k < 4; k++) d[k] = (uint16_t)clip3(d[k] + r[4 * q + k], 0, F::MAXV);
+    }
+    MI355_WAVE_SYNC();
+}
+/* the four 8x8 blocks of the luma plane (h264idct_template.c:69-141): lane 8 * b + i transforms column i of block b */
+template <int BD, int CF>
+__device__ inline void wide_add_blocks8(const int32_t *coef, int32_t (*t8)[64], int first, int nblocks, uint16_t *dst, int pitch)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::COEF COEF;
+    const int lane = lane_id(), b = first + (lane >> 3), i = lane & 7;
+    const bool on = (lane >> 3) < nblocks;
+    int in[8], out[8];
+    if (on) {
+        for (int k = 0; k < 8; k++) in[k] = coef[64 * b + i + 8 * k];
+        if (i == 0) in[0] = (COEF)(in[0] + 32);
+        idct8_1d(in, out);
+        for (int k = 0; k < 8; k++) t8[b & 3][i + 8 * k] = (COEF)out[k];
+    }
+    MI355_WAVE_SYNC();
+    if (on) {
+        for (int k = 0; k < 8; k++) in[k] = t8[b & 3][k + 8 * i];
+        idct8_1d(in, out);
+        uint16_t *d = dst + 8 * (b >> 1) * pitch + 8 * (b & 1) + i;
+        for (int k = 0; k < 8; k++) d[k * pitch] = (uint16_t)clip3(d[k * pitch] + (out[k] >> 6), 0, F::MAXV);
+    }
+    MI355_WAVE_SYNC();
+}
+
+/* DC transforms (h264idct_template.c:242-324), one lane each, in place in the DC slots of the LDS coefficient copy */
+template <typename COEF>
+__device__ inline void wide_luma_dc(int32_t *coef, int qmul)
+{
+    int v[16], t[16];
+    for (int k = 0; k < 16; k++) v[k] = coef[luma_dc_slot(k)];
+    for (int i = 0; i < 4; i++) {
+        const int s = v[4 * i] + v[4 * i + 1], d = v[4 * i] - v[4 * i + 1], e = v[4 * i + 2] - v[4 * i + 3], u = v[4 * i + 2] + v[4 * i + 3];
+        t[4 * i] = s + u; t[4 * i + 1] = s - u; t[4 * i + 2] = d - e; t[4 * i + 3] = d + e;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int s = t[i] + t[8 + i], d = t[i] - t[8 + i], e = t[4 + i] - t[12 + i], u = t[4 + i] + t[12 + i];
+        coef[luma_dc_slot(4 * i + 0)] = (COEF)(((s + u) * qmul + 128) >> 8);
+        coef[luma_dc_slot(4 * i + 1)] = (COEF)(((d + e) * qmul + 128) >> 8);
+        coef[luma_dc_slot(4 * i + 2)] = (COEF)(((d - e) * qmul + 128) >> 8);
+        coef[luma_dc_slot(4 * i + 3)] = (COEF)(((s - u) * qmul + 128) >> 8);
+    }
+}
+template <typename COEF, int CF>
+__device__ inline void wide_chroma_dc(int32_t *c, int qmul)       /* c: the plane's first coefficient */
+{
+    if (CF == 2) {                                                 /* chroma422_dc_dequant_idct :275-310 */
+        int v[8], t[8];
+        for (int i = 0; i < 4; i++) { v[2 * i] = c[32 * i]; v[2 * i + 1] = c[32 * i + 16]; }
+        for (int i = 0; i < 4; i++) { t[2 * i] = v[2 * i] + v[2 * i + 1]; t[2 * i + 1] = v[2 * i] - v[2 * i + 1]; }
+        for (int i = 0; i < 2; i++) {
+            const int z0 = t[i] + t[4 + i], z1 = t[i] - t[4 + i], z2 = t[2 + i] - t[6 + i], z3 = t[2 + i] + t[6 + i];
+            v[0 + i] = (COEF)(((z0 + z3) * qmul + 128) >> 8);
+            v[2 + i] = (COEF)(((z1 + z2) * qmul + 128) >> 8);
+            v[4 + i] = (COEF)(((z1 - z2) * qmul + 128) >> 8);
+            v[6 + i] = (COEF)(((z0 - z3) * qmul + 128) >> 8);
+        }
+        for (int i = 0; i < 4; i++) { c[32 * i] = v[2 * i]; c[32 * i + 16] = v[2 * i + 1]; }
+    } else {                                                       /* chroma_dc_dequant_idct :312-324 */
+        const int a = c[0], b = c[16], cc = c[32], d = c[48];
+        const int s0 = a + b, d0 = a - b, s1 = cc + d, d1 = cc - d;
+        c[0] = (COEF)(((s0 + s1) * qmul) >> 7); c[16] = (COEF)(((d0 + d1) * qmul) >> 7);
+        c[32] = (COEF)(((s0 - s1) * qmul) >> 7); c[48] = (COEF)(((d0 - d1) * qmul) >> 7);
+    }
+}
+
+/* The chroma residual of a macroblock (h264_mb_template.c:225-257): DC transforms where the record says DC levels were coded, then
+ * every block through the full transform — idct_add8's choice between idct_add, idct_dc_add and nothing (h264idct_template.c:203-238)
+ * is "transform the block iff it holds a coefficient", and a block of zeros adds zero.  cb / cr: the planes' 8 x CH tiles. */
+template <int BD, int CF>
+__device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &h, uint16_t *cb, uint16_t *cr, int pitch)
+{
+    typedef Fmt<BD, CF> F;
+    if (!(h.cbp & 0x30)) return;
+    const int lane = lane_id();
+    if (lane < 2 && ((h.nnz_mask >> (MI355_NNZ_CB_DC + lane)) & 1))
+        wide_chroma_dc<typename F::COEF, CF>(coef + 256 + 16 * F::NCB * lane, (int)h.dc_qmul[1 + lane]);
+    MI355_WAVE_SYNC();
+    wide_add_blocks4<BD, CF>(coef + 256, F::NCB, true, cb, pitch);
+    wide_add_blocks4<BD, CF>(coef + 256 + 16 * F::NCB, F::NCB, true, cr, pitch);
+}
+
+/* the macroblock's coefficients -> the 32-bit LDS copy */
+template <int BD, int CF>
+__device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr, int mb_xy)
+{
+    typedef Fmt<BD, CF> F;
+    const typename F::COEF *cp = reinterpret_cast<const typename F::COEF *>(fr.coef) + (size_t)mb_xy * F::NCOEF;
+    for (int i = lane_id(); i < F::NCOEF; i += 64) dst[i] = cp[i];
+    MI355_WAVE_SYNC();
+}
+
+template <int BD, int CF>
+__device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, int mb_y, const uint16_t *y, int ypitch, const uint16_t *cb, const uint16_t *cr, int cpitch)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    const int lane = lane_id();
+    for (int i = lane; i < 256; i += 64) {
+        const int r = i >> 4, c = i & 15;
+        reinterpret_cast<PX *>(fr.recon[0] + (size_t)(16 * mb_y + r) * fr.recon_stride[0])[16 * mb_x + c] = (PX)y[r * ypitch + c];
+    }
+    for (int i = lane; i < 8 * F::CH; i += 64) {
+        const int r = i >> 3, c = i & 7;
+        reinterpret_cast<PX *>(fr.recon[1] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1])[8 * mb_x + c] = (PX)cb[r * cpitch + c];
+        reinterpret_cast<PX *>(fr.recon[2] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1])[8 * mb_x + c] = (PX)cr[r * cpitch + c];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* inter                                                                        */
+/* ------------------------------------------------------------------------- */
+constexpr int WP = 21;          /* pitch of the luma window: 16 + 5 */
+constexpr int CWP = 9, CWIN = 160;   /* chroma windows: 9 x 17 per plane, the second plane at CWIN */
+struct WideInterLds {
+    mi355_h264_mb hdr;
+    uint32_t mv[2][16];
+    int32_t coef[512];
+    uint16_t py[256], pc[2][128], qy[256], qc[2][128];
+    uint16_t win[WP * WP + 7];
+    int32_t t8[4][64];
+};
+
+/* one luma sample at quarter position (mx, my): h264qpel_template.c:77-300 as the standard writes it; the first pass of the 2-D
+ * positions is kept in 16 bits around the reference's bias (:119-146), so that samples outside the bit depth's range wrap as they do there */
+__device__ inline int wide_qpel_px(const uint16_t *win, int x, int y, int mx, int my, int maxv)
+{
+#define S(xx, yy) ((int)win[((yy) + 2) * WP + (xx) + 2])
+    auto rawh = [&](int xx, int yy) { return tap6(S(xx - 2, yy), S(xx - 1, yy), S(xx, yy), S(xx + 1, yy), S(xx + 2, yy), S(xx + 3, yy)); };
+    auto hh = [&](int xx, int yy) { return clip3((rawh(xx, yy) + 16) >> 5, 0, maxv); };
+    auto vv = [&](int xx, int yy) { return clip3((tap6(S(xx, yy - 2), S(xx, yy - 1), S(xx, yy), S(xx, yy + 1), S(xx, yy + 2), S(xx, yy + 3)) + 16) >> 5, 0, maxv); };
+    const int pad = maxv > 511 ? -10 * maxv : 0;
+    auto tmph = [&](int xx, int yy) { return (int)(int16_t)(rawh(xx, yy) + pad) - pad; };
+    auto hv = [&](int xx, int yy) {
+        return clip3((tap6(tmph(xx, yy - 2), tmph(xx, yy - 1), tmph(xx, yy), tmph(xx, yy + 1), tmph(xx, yy + 2), tmph(xx, yy + 3)) + 512) >> 10, 0, maxv);
+    };
+    int v;
+    if (my == 0) v = mx == 0 ? S(x, y) : (mx == 2 ? hh(x, y) : f2(S(x + (mx == 3), y), hh(x, y)));
+    else if (mx == 0) v = my == 2 ? vv(x, y) : f2(S(x, y + (my == 3)), vv(x, y));
+    else if (mx == 2 && my == 2) v = hv(x, y);
+    else if (mx == 2) v = f2(hh(x, y + (my == 3)), hv(x, y));
+    else if (my == 2) v = f2(vv(x + (mx == 3), y), hv(x, y));
+    else v = f2(hh(x, y + (my == 3)), vv(x + (mx == 3), y));
+#undef S
+    return v;
+}
+
+/* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318.  Windows are fetched with clamped coordinates, which is
+ * what emulated_edge_mc produces (videodsp_template.c:24-96).  dy / dcb / dcr: the macroblock's 16-pitch luma and 8-pitch chroma tiles */
+template <int BD, int CF>
+__device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, int mb_x, int mb_y, int list, int n_raster, int quadrant,
+                                   int bx, int by, int w, int h, uint16_t *dy, uint16_t *dcb, uint16_t *dcr, int avg)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    const int lane = lane_id();
+    const uint32_t mvw = s.mv[list][n_raster];
+    const int slot = s.hdr.u.inter.ref_pic[list][quadrant];
+    const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
+    const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
+    const uint8_t *const *rp = fr.ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
+    const int W = 16 * fr.mb_width, H = 16 * fr.mb_height;
+    {
+        const int x0 = (mx >> 2) - 2, y0 = (my >> 2) - 2, ww = w + 5, hh = h + 5;
+        for (int i = lane; i < ww * hh; i += 64) {
+            const int r = i / ww, c = i - r * ww;
+            const int xx = clip3(x0 + c, 0, W - 1), yy = clip3(y0 + r, 0, H - 1);
+            s.win[r * WP + c] = reinterpret_cast<const PX *>(rp[0] + (size_t)yy * fr.dst_stride[0])[xx];
+        }
+        MI355_WAVE_SYNC();
+        for (int i = lane; i < w * h; i += 64) {
+            const int y = i / w, x = i - y * w;
+            const int v = wide_qpel_px(s.win, x, y, mx & 3, my & 3, F::MAXV);
+            uint16_t *d = dy + (by + y) * 16 + bx + x;
+            *d = (uint16_t)(avg ? f2(*d, v) : v);
+        }
+        MI355_WAVE_SYNC();
+    }
+    /* chroma: eighth-sample bilinear (h264chroma_template.c:28-200); 4:2:2 keeps the luma's vertical resolution (h264_mb.c:284-315) */
+    const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, cby = CF == 2 ? by : by >> 1;
+    const int myc = CF == 1 ? my + s.hdr.u.inter.chroma_dy[list][quadrant] : my;
+    const int cx = mx >> 3, cy = CF == 2 ? myc >> 2 : myc >> 3, fx = mx & 7, fy = CF == 2 ? (myc << 1) & 7 : myc & 7;
+    const int CWd = 8 * fr.mb_width, CHt = F::CH * fr.mb_height, cww = cw + 1, chh = ch + 1;
+    for (int p = 0; p < 2; p++)
+        for (int i = lane; i < cww * chh; i += 64) {
+            const int r = i / cww, c = i - r * cww;
+            const int xx = clip3(cx + c, 0, CWd - 1), yy = clip3(cy + r, 0, CHt - 1);
+            s.win[p * CWIN + r * CWP + c] = reinterpret_cast<const PX *>(rp[1 + p] + (size_t)yy * fr.dst_stride[1])[xx];
+        }
+    MI355_WAVE_SYNC();
+    const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
+    for (int p = 0; p < 2; p++)
+        for (int i = lane; i < cw * ch; i += 64) {
+            const int y = i / cw, x = i - y * cw;
+            const uint16_t *q = s.win + p * CWIN + y * CWP + x;
+            const int v = (A * q[0] + B * q[1] + C * q[CWP] + D * q[CWP + 1] + 32) >> 6;
+            uint16_t *d = (p ? dcr : dcb) + (cby + y) * 8 + (bx >> 1) + x;
+            *d = (uint16_t)(avg ? f2(*d, v) : v);
+        }
+    MI355_WAVE_SYNC();
+}
+
+/* weighted prediction on a w x h block of an LDS tile: h264dsp_template.c:30-98 */
+template <int BD>
+__device__ inline void wide_weight(uint16_t *p, int pitch, int w, int h, int ld, int wt, int off)
+{
+    int o = (int)((unsigned)off << (ld + (BD - 8)));
+    if (ld) o += 1 << (ld - 1);
+    for (int i = lane_id(); i < w * h; i += 64) {
+        const int y = i / w, x = i - y * w;
+        p[y * pitch + x] = (uint16_t)clip3((p[y * pitch + x] * wt + o) >> ld, 0, (1 << BD) - 1);
+    }
+    MI355_WAVE_SYNC();
+}
+template <int BD>
+__device__ inline void wide_biweight(uint16_t *d, const uint16_t *s, int pitch, int w, int h, int ld, int wd, int ws, int off)
+{
+    const int o = (int)((unsigned)((((int)((unsigned)off << (BD - 8))) + 1) | 1) << ld);
+    for (int i = lane_id(); i < w * h; i += 64) {
+        const int y = i / w, x = i - y * w;
+        d[y * pitch + x] = (uint16_t)clip3((s[y * pitch + x] * ws + d[y * pitch + x] * wd + o) >> (ld + 1), 0, (1 << BD) - 1);
+    }
+    MI355_WAVE_SYNC();
+}
+
+/* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
+template <int BD, int CF>
+__device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+                                    int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
+{
+    const int r0 = s.hdr.ref_idx[0][quadrant], r1 = s.hdr.ref_idx[1][quadrant];
+    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
+    const bool two = l0 && l1;
+    for (int list = 0; list < 2; list++) {
+        if (!(list ? l1 : l0)) continue;
+        const bool second = list == 1 && two, to_q = second && weighted;
+        wide_mc_dir<BD, CF>(s, fr, mb_x, mb_y, list, n_raster, quadrant, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0], to_q ? s.qc[1] : s.pc[1],
+                            second && !weighted);
+    }
+    if (!weighted) return;
+    const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, co = (CF == 2 ? by : by >> 1) * 8 + (bx >> 1);
+    uint16_t *dy = s.py + by * 16 + bx, *dcb = s.pc[0] + co, *dcr = s.pc[1] + co;
+    if (two) {
+        const uint16_t *ty = s.qy + by * 16 + bx, *tcb = s.qc[0] + co, *tcr = s.qc[1] + co;
+        if (sl.use_weight == 2) {
+            const int w0 = sl.implicit_weight[r0][r1], w1 = 64 - w0;
+            wide_biweight<BD>(dy, ty, 16, w, h, 5, w0, w1, 0);
+            wide_biweight<BD>(dcb, tcb, 8, cw, ch, 5, w0, w1, 0);
+            wide_biweight<BD>(dcr, tcr, 8, cw, ch, 5, w0, w1, 0);
+        } else {
+            wide_biweight<BD>(dy, ty, 16, w, h, sl.luma_log2_weight_denom, sl.luma_weight[r0][0][0], sl.luma_weight[r1][1][0],
+                              sl.luma_weight[r0][0][1] + sl.luma_weight[r1][1][1]);
+            wide_biweight<BD>(dcb, tcb, 8, cw, ch, sl.chroma_log2_weight_denom, sl.chroma_weight[r0][0][0][0], sl.chroma_weight[r1][1][0][0],
+                              sl.chroma_weight[r0][0][0][1] + sl.chroma_weight[r1][1][0][1]);
+            wide_biweight<BD>(dcr, tcr, 8, cw, ch, sl.chroma_log2_weight_denom, sl.chroma_weight[r0][0][1][0], sl.chroma_weight[r1][1][1][0],
+                              sl.chroma_weight[r0][0][1][1] + sl.chroma_weight[r1][1][1][1]);
+        }
+    } else {
+        const int list = l1 ? 1 : 0, refn = list ? r1 : r0;
+        wide_weight<BD>(dy, 16, w, h, sl.luma_log2_weight_denom, sl.luma_weight[refn][list][0], sl.luma_weight[refn][list][1]);
+        if (sl.use_weight_chroma) {
+            wide_weight<BD>(dcb, 8, cw, ch, sl.chroma_log2_weight_denom, sl.chroma_weight[refn][list][0][0], sl.chroma_weight[refn][list][0][1]);
+            wide_weight<BD>(dcr, 8, cw, ch, sl.chroma_log2_weight_denom, sl.chroma_weight[refn][list][1][0], sl.chroma_weight[refn][list][1][1]);
+        }
+    }
+}
+
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
+{
+    typedef Fmt<BD, CF> F;
+    __shared__ WideInterLds s;
+    const int per = max_w * max_h, f = (int)blockIdx.x / per, rem = (int)blockIdx.x - f * per, mb_y = rem / max_w, mb_x = rem - mb_y * max_w;
+    const mi355_h264_frame &fr = frames[f];
+    if (mb_x >= fr.mb_width || mb_y >= fr.mb_height || (fr.flags & MI355_FRAME_NO_INTER)) return;
+    const int mb_xy = mb_y * fr.mb_width + mb_x, lane = lane_id();
+    if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[lane];
+    else if (lane < 48) {
+        const int list = (lane >> 4) - 1;
+        s.mv[list][lane & 15] = fr.mv[list] ? reinterpret_cast<const uint32_t *>(fr.mv[list])[(size_t)mb_xy * 16 + (lane & 15)] : 0u;
+    }
+    MI355_WAVE_SYNC();
+    const uint32_t t = s.hdr.mb_type;
+    if (t & MI355_MB_INTRA) return;
+    const bool luma_coded = (s.hdr.cbp & 15) != 0, chroma_coded = (s.hdr.cbp & 0x30) != 0;
+    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy);
+    const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
+
+    /* hl_motion, h264_mc_template.c:64-163 */
+#define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
+    const int kind = (t & MI355_MB_16x16) ? 0 : ((t & MI355_MB_16x8) ? 1 : ((t & MI355_MB_8x16) ? 2 : 3));
+    const int nparts = kind == 0 ? 1 : (kind == 3 ? 16 : 2);
+    for (int p = 0; p < nparts; p++) {
+        int n, quad, bx, by, w, h, l0, l1;
+        if (kind == 0) { n = 0; quad = 0; bx = by = 0; w = h = 16; l0 = DIRF(0, 0); l1 = DIRF(0, 1); }
+        else if (kind == 1) { n = 8 * p; quad = 2 * p; bx = 0; by = 8 * p; w = 16; h = 8; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
+        else if (kind == 2) { n = 2 * p; quad = p; bx = 8 * p; by = 0; w = 8; h = 16; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
+        else {
+            const int i = p >> 2, j = p & 3;
+            const int st = s.hdr.sub_mb_type[i], shape = st & 3;
+            const int cnt = shape == MI355_SUB_8x8 ? 1 : (shape == MI355_SUB_4x4 ? 4 : 2);
+            if (j >= cnt) continue;
+            l0 = (st & MI355_SUB_L0) != 0; l1 = (st & MI355_SUB_L1) != 0;
+            const int x = (i & 1) * 8, y = (i >> 1) * 8;
+            quad = i;
+            w = (shape == MI355_SUB_8x8 || shape == MI355_SUB_8x4) ? 8 : 4;
+            h = (shape == MI355_SUB_8x8 || shape == MI355_SUB_4x8) ? 8 : 4;
+            bx = x + (shape == MI355_SUB_4x8 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j & 1) : 0));
+            by = y + (shape == MI355_SUB_8x4 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j >> 1) : 0));
+            n = (bx >> 2) + 4 * (by >> 2);
+        }
+        wide_mc_part<BD, CF>(s, fr, sl, mb_x, mb_y, n, quad, bx, by, w, h, l0, l1);
+    }
+#undef DIRF
+    /* hl_decode_mb_idct_luma (h264_mb.c:726-795): every block of a macroblock whose cbp says luma was coded goes through the full
+     * transform (idct_add16 / idct8_add4 choose between full, DC-only and nothing per block — same sums, a block of zeros adds zero) */
+    if (luma_coded) {
+        if (t & MI355_MB_8x8DCT) wide_add_blocks8<BD, CF>(s.coef, s.t8, 0, 4, s.py, 16);
+        else wide_add_blocks4<BD, CF>(s.coef, 16, false, s.py, 16);
+    }
+    wide_residual_chroma<BD, CF>(s.coef, s.hdr, s.pc[0], s.pc[1], 8);
+    wide_store_mb<BD, CF>(fr, mb_x, mb_y, s.py, 16, s.pc[0], s.pc[1], 8);
+}
+
+/* ------------------------------------------------------------------------- */
+/* intra                                                                        */
+/* ------------------------------------------------------------------------- */
+constexpr int TPW = 32;   /* luma tile pitch: columns -1..23 at TOW - 1 .. */
+constexpr int CPW = 16;   /* chroma tile pitch: columns -1..7 */
+constexpr int TOW = 4;
+struct WideIntraLds {
+    mi355_h264_mb hdr;
+    int32_t coef[512];
+    uint16_t tile[17 * TPW];
+    uint16_t ctile[2][17 * CPW];
+    PredScratch ps;
+    int32_t t8[4][64];
+};
+#define WTILE(x, y) s.tile[((y) + 1) * TPW + (x) + TOW]
+#define WCTILE(p, x, y) s.ctile[p][((y) + 1) * CPW + (x) + TOW]
+
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_intra(const mi355_h264_frame *frames, int level, int width)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    __shared__ WideIntraLds s;
+    const int f = (int)blockIdx.x / width, k = (int)blockIdx.x - f * width;
+    const mi355_h264_frame &fr = frames[f];
+    if (level > fr.max_intra_level) return;
+    const int first = fr.intra_level_start[level - 1], count = fr.intra_level_start[level] - first;
+    if (k >= count) return;
+    const int mb_xy = (int)fr.intra_list[first + k], mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width, lane = lane_id();
+    if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[lane];
+    wide_load_coefs<BD, CF>(s.coef, fr, mb_xy);
+    const mi355_h264_mb &h = s.hdr;
+    const uint32_t t = h.mb_type;
+    if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:101-153: the samples themselves, one per coefficient slot: Y, Cb, Cr */
+        for (int i = lane; i < 256; i += 64) WTILE(i & 15, i >> 4) = (uint16_t)s.coef[i];
+        for (int i = lane; i < 8 * F::CH; i += 64) { WCTILE(0, i & 7, i >> 3) = (uint16_t)s.coef[256 + i]; WCTILE(1, i & 7, i >> 3) = (uint16_t)s.coef[256 + 8 * F::CH + i]; }
+        MI355_WAVE_SYNC();
+        wide_store_mb<BD, CF>(fr, mb_x, mb_y, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
+        return;
+    }
+    /* the unfiltered edge samples of the neighbours: the row above (columns -1..23), the column to the left */
+    const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], pic_w = 16 * fr.mb_width;
+    if (mb_y > 0 && lane < 25 && mb_x * 16 + lane - 1 >= 0 && mb_x * 16 + lane - 1 < pic_w)
+        WTILE(lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y - 1) * ys)[16 * mb_x + lane - 1];
+    if (mb_x > 0 && lane >= 32 && lane < 48)
+        WTILE(-1, lane - 32) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y + lane - 32) * ys)[16 * mb_x - 1];
+    for (int p = 0; p < 2; p++) {
+        if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0))
+            WCTILE(p, lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y - 1) * cs)[8 * mb_x + lane - 1];
+        if (mb_x > 0 && lane >= 16 && lane < 16 + F::CH)
+            WCTILE(p, -1, lane - 16) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + lane - 16) * cs)[8 * mb_x - 1];
+    }
+    MI355_WAVE_SYNC();
+
+    /* chroma prediction: hpc.pred8x8[chroma_pred_mode] — the pred8x16 functions when chroma_format_idc == 2 (h264pred.c:439-470) */
+    for (int p = 0; p < 2; p++) {
+        if (lane < 9) s.ps.T[lane] = WCTILE(p, lane - 1, -1);
+        if (lane >= 16 && lane < 17 + F::CH) s.ps.L[lane - 16] = WCTILE(p, -1, lane - 17);
+        MI355_WAVE_SYNC();
+        intra_pred_wave<uint16_t, BD>(s.ps, CF == 2 ? 4 : 2, h.chroma_pred_mode, 0, 0, &WCTILE(p, 0, 0), CPW);
+    }
+    if (t & MI355_MB_INTRA16x16) {       /* h264_mb.c:701-722 */
+        if (lane < 17) s.ps.T[lane] = WTILE(lane - 1, -1);
+        if (lane >= 32 && lane < 49) s.ps.L[lane - 32] = WTILE(-1, lane - 33);
+        MI355_WAVE_SYNC();
+        intra_pred_wave<uint16_t, BD>(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &WTILE(0, 0), TPW);
+        if (lane == 0 && ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1)) wide_luma_dc<typename F::COEF>(s.coef, (int)h.dc_qmul[0]);
+        MI355_WAVE_SYNC();
+        wide_add_blocks4<BD, CF>(s.coef, 16, false, &WTILE(0, 0), TPW);      /* idct_add16intra: full, DC-only or nothing per block = the full transform */
+    } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
+        for (int i8 = 0; i8 < 4; i8++) {
+            const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
+            if (lane < 17) s.ps.T[lane] = WTILE(x0 + lane - 1, y0 - 1);
+            if (lane >= 32 && lane < 41) s.ps.L[lane - 32] = WTILE(x0 - 1, y0 + lane - 33);
+            MI355_WAVE_SYNC();
+            intra_pred_wave<uint16_t, BD>(s.ps, 1, h.u.intra4x4_pred_mode[i], (h.topleft_samples_available << i) & 0x8000,
+                                          (h.topright_samples_available << i) & 0x4000, &WTILE(x0, y0), TPW);
+            wide_add_blocks8<BD, CF>(s.coef, s.t8, i8, 1, &WTILE(0, 0), TPW);
+        }
+    } else {                              /* Intra 4x4: h264_mb.c:657-700 */
+        for (int i = 0; i < 16; i++) {
+            const int x0 = 4 * blk_x4(i), y0 = 4 * blk_y4(i);
+            const int tr_ok = (h.topright_samples_available << i) & 0x8000;
+            if (lane < 5) s.ps.T[lane] = WTILE(x0 + lane - 1, y0 - 1);
+            else if (lane < 9) s.ps.T[lane] = tr_ok ? WTILE(x0 + lane - 1, y0 - 1) : WTILE(x0 + 3, y0 - 1);
+            if (lane >= 32 && lane < 37) s.ps.L[lane - 32] = WTILE(x0 - 1, y0 + lane - 33);
+            MI355_WAVE_SYNC();
+            intra_pred_wave<uint16_t, BD>(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &WTILE(x0, y0), TPW);
+            if (lane < 4) {
+                int r[16];
+                wide_idct4<typename F::COEF>(s.coef + 16 * i, r);
+                uint16_t *d = &WTILE(x0, y0 + lane);
+                for (int c = 0; c < 4; c++) d[c] = (uint16_t)clip3(d[c] + r[4 * lane + c], 0, F::MAXV);
+            }
+            MI355_WAVE_SYNC();
+        }
+    }
+    wide_residual_chroma<BD, CF>(s.coef, h, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
+    wide_store_mb<BD, CF>(fr, mb_x, mb_y, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
+}
+#undef WTILE
+#undef WCTILE
+
+/* ------------------------------------------------------------------------- */
+/* loop filter                                                                  */
+/* ------------------------------------------------------------------------- */
+__device__ const uint8_t kw_alpha[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+    32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255 };
+__device__ const uint8_t kw_beta[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+    9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18 };
+__device__ const uint8_t kw_tc0[52][3] = {
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},
+    {1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},{2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},
+    {3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},{9,12,18},{10,13,20},
+    {11,15,23},{13,17,25} };
+
+constexpr int DYP = 20, DCPW = 10;       /* pitches of the filter's luma (-4..15) and chroma (-2..7) tiles */
+struct WideDbLds {
+    mi355_h264_mb m[3];                  /* this macroblock, its left and its top neighbour */
+    int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
+    uint32_t mv[2][25];
+    uint8_t nnz[25];
+    uint8_t bs[2][4][4];
+    uint16_t y[20 * DYP];                /* rows / columns -4..15 */
+    uint16_t c[2][18 * DCPW];            /* rows -2..15, columns -2..7 */
+};
+#define DY(x, yy) s.y[((yy) + 4) * DYP + (x) + 4]
+#define DC(p, x, yy) s.c[p][((yy) + 2) * DCPW + (x) + 2]
+
+__device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
+{
+    return iabs((int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF)) >= 4 || iabs((int16_t)(a >> 16) - (int16_t)(b >> 16)) >= ylim;
+}
+/* check_mv, h264_loopfilter.c:442-470 */
+__device__ inline int wide_check_mv(const WideDbLds &s, int b, int bn, int list_count, int ylim)
+{
+    bool v = s.ref[0][b] != s.ref[0][bn];
+    if (!v && s.ref[0][b] != -1) v = wide_mv_far(s.mv[0][b], s.mv[0][bn], ylim);
+    if (list_count == 2) {
+        if (!v) v = s.ref[1][b] != s.ref[1][bn] || wide_mv_far(s.mv[1][b], s.mv[1][bn], ylim);
+        if (v) {
+            if (s.ref[0][b] != s.ref[1][bn] || s.ref[0][bn] != s.ref[1][b]) return 1;
+            return wide_mv_far(s.mv[0][b], s.mv[1][bn], ylim) || wide_mv_far(s.mv[1][b], s.mv[0][bn], ylim);
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int list, int x4, int y4)
+{
+    if (m.mb_type & MI355_MB_INTRA) return -1;
+    const int r = m.u.inter.ref_pic[list][(x4 >> 1) + 2 * (y4 >> 1)];
+    return r == 0xFF ? -1 : r;
+}
+
+/* one macroblock of anti-diagonal d: ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without MBAFF.
+ * The macroblock's own samples come from `recon`, four columns of the left and four rows of the top neighbour from `dst` (as those
+ * macroblocks' own passes left them); the macroblock, three columns and three rows (one of each in chroma) go back to `dst`. */
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_deblock(const mi355_h264_frame *frames, int d, int max_h)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    __shared__ WideDbLds s;
+    const int f = (int)blockIdx.x / max_h, mb_y = (int)blockIdx.x - f * max_h, mb_x = d - 2 * mb_y, lane = lane_id();
+    const mi355_h264_frame &fr = frames[f];
+    if (mb_y >= fr.mb_height || mb_x < 0 || mb_x >= fr.mb_width) return;
+    const int mb_xy = mb_y * fr.mb_width + mb_x;
+    const bool has_left = mb_x > 0, has_top = mb_y > 0;
+    /* records: this macroblock, left, top */
+    if (lane < 48) {
+        const int which = lane >> 4;
+        const int xy = which == 0 ? mb_xy : (which == 1 ? (has_left ? mb_xy - 1 : mb_xy) : (has_top ? mb_xy - fr.mb_width : mb_xy));
+        reinterpret_cast<uint32_t *>(&s.m[which])[lane & 15] = reinterpret_cast<const uint32_t *>(&fr.mb[xy])[lane & 15];
+    }
+    /* samples */
+    const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], yd = fr.dst_stride[0], cd = fr.dst_stride[1];
+    for (int i = lane; i < 256; i += 64)
+        DY(i & 15, i >> 4) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y + (i >> 4)) * ys)[16 * mb_x + (i & 15)];
+    if (has_left) { const int r = lane >> 2, c = (lane & 3) - 4; DY(c, r) = reinterpret_cast<const PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c]; }
+    if (has_top) { const int r = (lane >> 4) - 4, c = lane & 15; DY(c, r) = reinterpret_cast<const PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c]; }
+    for (int p = 0; p < 2; p++) {
+        for (int i = lane; i < 8 * F::CH; i += 64)
+            DC(p, i & 7, i >> 3) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + (i >> 3)) * cs)[8 * mb_x + (i & 7)];
+        if (has_left && lane < 2 * F::CH) { const int r = lane >> 1, c = (lane & 1) - 2; DC(p, c, r) = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd)[8 * mb_x + c]; }
+        if (has_top && lane < 16) { const int r = (lane >> 3) - 2, c = lane & 7; DC(p, c, r) = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd)[8 * mb_x + c]; }
+    }
+    MI355_WAVE_SYNC();
+    const mi355_h264_mb &m = s.m[0];
+    if (!(m.flags & MI355_MBF_NO_DEBLOCK)) {
+        /* the motion and coefficient flags the strengths are derived from: fill_filter_caches, h264_slice.c:2056-2196 */
+        if (lane < 24) {
+            int which, x4, y4, cx, cy;
+            if (lane < 16) { which = 0; x4 = lane & 3; y4 = lane >> 2; cx = x4; cy = y4; }
+            else if (lane < 20) { which = 1; x4 = 3; y4 = lane - 16; cx = -1; cy = y4; }
+            else { which = 2; x4 = lane - 20; y4 = 3; cx = x4; cy = -1; }
+            const int xy = which == 0 ? mb_xy : (which == 1 ? (has_left ? mb_xy - 1 : mb_xy) : (has_top ? mb_xy - fr.mb_width : mb_xy));
+            const int ci = (cy + 1) * 5 + cx + 1;
+            for (int list = 0; list < 2; list++) {
+                s.ref[list][ci] = wide_ref_identity(s.m[which], list, x4, y4);
+                s.mv[list][ci] = fr.mv[list] ? reinterpret_cast<const uint32_t *>(fr.mv[list])[(size_t)xy * 16 + x4 + 4 * y4] : 0u;
+            }
+            s.nnz[ci] = (uint8_t)((s.m[which].nnz_mask >> blk_index(x4, y4)) & 1);
+        }
+        MI355_WAVE_SYNC();
+        /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane = 16 * dir + 4 * edge + i */
+        if (lane < 32) {
+            const int dir = lane >> 4, edge = (lane >> 2) & 3, i = lane & 3;
+            const uint32_t t = m.mb_type;
+            const int mask_edge = dir == 0 ? ((t >> 3) & 7) == 0 ? 0 : (((t >> 3) & 7) < 4 ? 3 : 1)
+                                           : ((t >> 3) & 7) == 0 ? 0 : (((t >> 3) & 7) == 1 ? 3 : (((t >> 3) & 7) < 4 ? 1 : 3));
+            const int edges = (mask_edge == 3 && !(m.cbp & 15)) ? 1 : 4;
+            const uint32_t par_types = MI355_MB_16x16 | (MI355_MB_8x16 >> dir);
+            const bool mask_par0 = (t & par_types) != 0;
+            const int list_count = fr.slices[m.slice_id].list_count, ylim = fr.field_picture ? 2 : 4;
+            const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
+            const int b = (y + 1) * 5 + x + 1, bn = b - (dir ? 5 : 1);
+            int bs = 0;
+            if (edge == 0) {
+                const mi355_h264_mb &mm = s.m[1 + dir];
+                if (m.flags & (dir ? MI355_MBF_TOP_EDGE : MI355_MBF_LEFT_EDGE)) {
+                    if ((t | mm.mb_type) & MI355_MB_INTRA) bs = (!fr.field_picture || dir == 0) ? 4 : 3;
+                    else if (s.nnz[b] | s.nnz[bn]) bs = 2;
+                    else if (mask_par0 && (mm.mb_type & par_types)) bs = wide_check_mv(s, 6, 6 - (dir ? 5 : 1), list_count, ylim);
+                    else bs = wide_check_mv(s, b, bn, list_count, ylim);
+                }
+            } else if (edge < edges) {
+                const bool deblock_edge = !((t & MI355_MB_8x8DCT) && (edge & 1));
+                if (deblock_edge || (CF == 2 && dir == 1)) {
+                    if (t & MI355_MB_INTRA) bs = 3;
+                    else if (s.nnz[b] | s.nnz[bn]) bs = 2;
+                    else if (edge & mask_edge) bs = 0;
+                    else if (mask_par0) { const int b0 = dir == 0 ? 5 + edge + 1 : (edge + 1) * 5 + 1; bs = wide_check_mv(s, b0, b0 - (dir ? 5 : 1), list_count, ylim); }
+                    else bs = wide_check_mv(s, b, bn, list_count, ylim);
+                }
+            }
+            s.bs[dir][edge][i] = (uint8_t)bs;
+        }
+        MI355_WAVE_SYNC();
+        /* the edges: lanes 0..15 a luma line each, 16..31 Cb, 32..47 Cr */
+        const int qp_bd = 6 * (BD - 8), a_off = m.slice_alpha_c0_offset, b_off = m.slice_beta_offset;
+        const int comp = lane >> 4, line = lane & 15;
+        const bool dct8 = (m.mb_type & MI355_MB_8x8DCT) != 0;
+        for (int dir = 0; dir < 2; dir++)
+            for (int edge = 0; edge < 4; edge++) {
+                if (comp < 3) {
+                    const mi355_h264_mb &mm = s.m[1 + dir];
+                    if (comp == 0) {
+                        const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
+                        const int bs = s.bs[dir][edge][line >> 2];
+                        if (luma_on && bs) {
+                            const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
+                            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+                            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+                            uint16_t *q = dir == 0 ? &DY(4 * edge, line) : &DY(line, 4 * edge);
+                            const int st = dir == 0 ? 1 : DYP;
+                            if (bs < 4) {
+                                int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
+                                lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)));
+                                q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
+                            } else {
+                                int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
+                                lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
+                                q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
+                            }
+                        }
+                    } else {
+                        /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
+                         * at rows 0 and 4 in 4:2:0, all four at rows 0, 4, 8, 12 in 4:2:2 (:679-686) */
+                        const int p = comp - 1;
+                        const bool on = dir == 0 ? !(edge & 1) && line < F::CH : (CF == 2 || !(edge & 1)) && line < 8;
+                        const int bs = dir == 0 ? s.bs[0][edge][CF == 2 ? line >> 2 : line >> 1] : s.bs[1][edge][line >> 1];
+                        if (on && bs) {
+                            const int qp = edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p];
+                            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+                            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+                            uint16_t *q = dir == 0 ? &DC(p, 2 * edge, line) : &DC(p, line, CF == 2 ? 4 * edge : 2 * edge);
+                            const int st = dir == 0 ? 1 : DCPW;
+                            int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
+                            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
+                            else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
+                            q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
+                        }
+                    }
+                }
+                MI355_WAVE_SYNC();
+            }
+    }
+    /* out: the macroblock, and what its left and top edges changed of the neighbours */
+    for (int i = lane; i < 256; i += 64)
+        reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + (i >> 4)) * yd)[16 * mb_x + (i & 15)] = (PX)DY(i & 15, i >> 4);
+    if (has_left && lane < 48) { const int r = lane / 3, c = lane % 3 - 3; reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c] = (PX)DY(c, r); }
+    if (has_top && lane < 48) { const int r = lane / 16 - 3, c = lane & 15; reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c] = (PX)DY(c, r); }
+    for (int p = 0; p < 2; p++) {
+        for (int i = lane; i < 8 * F::CH; i += 64)
+            reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + (i >> 3)) * cd)[8 * mb_x + (i & 7)] = (PX)DC(p, i & 7, i >> 3);
+        if (has_left && lane < F::CH) reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + lane) * cd)[8 * mb_x - 1] = (PX)DC(p, -1, lane);
+        if (has_top && lane < 8) reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd)[8 * mb_x + lane] = (PX)DC(p, lane, -1);
+    }
+}
+#undef DY
+#undef DC
+
+template <int BD, int CF>
+int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, int max_intra_level, const int32_t *level_widths, int passes, hipStream_t st)
+{
+    if (passes & 1) {
+        if ((long long)nframes * mw * mh > 0x7FFFFFFFLL) return -3;
+        hipLaunchKernelGGL((k_wide_inter<BD, CF>), dim3((unsigned)(nframes * mw * mh)), dim3(64), 0, st, d_frames, mw, mh);
+    }
+    if (passes & 2)
+        for (int level = 1; level <= max_intra_level; level++) {
+            const int width = level_widths[level - 1];
+            if (width <= 0) continue;
+            if ((long long)nframes * width > 0x7FFFFFFFLL) return -3;
+            hipLaunchKernelGGL((k_wide_intra<BD, CF>), dim3((unsigned)(nframes * width)), dim3(64), 0, st, d_frames, level, width);
+        }
+    if (passes & 4)
+        for (int d = 0; d <= (mw - 1) + 2 * (mh - 1); d++)
+            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3((unsigned)(nframes * mh)), dim3(64), 0, st, d_frames, d, mh);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+extern "C" int mi355_h264_decode_frames_wide_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
+                                                 int max_intra_level, const int32_t *level_widths, int bit_depth, int chroma_format_idc,
+                                                 int passes, void *stream)
+{
+    if (!mi355::bind() || !d_frames || nframes <= 0 || max_mb_width <= 0 || max_mb_height <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = bit_depth * 10 + chroma_format_idc;
+    switch (key) {
+    case 91:  return wide_launch<9, 1>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
+    case 101: return wide_launch<10, 1>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
+    case 82:  return wide_launch<8, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
+    case 92:  return wide_launch<9, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
+    case 102: return wide_launch<10, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
+    default:  return -1;                 /* 8-bit 4:2:0 has its own kernels (mi355_h264_decode_frames_layouts_dev) */
+    }
+}

@@ -86,26 +86,26 @@ def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
 
 
 @needs_harness
-@pytest.mark.parametrize("name", [n for n in SY.ALL if n not in SY.BRIDGE and n not in ("mixed_formats", "paff_and_frames")])
-def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name):
-    """High 4:2:2, 9 / 10 bit: the bridge says so once and the reference's C path decodes the stream — same pictures, nothing on
-    the device"""
+@pytest.mark.parametrize("name,no_wide", [(n, False) for n in SY.OUTSIDE] + [(n, True) for n in ("422_8_b", "420_10_t8x8", "444_10", "422_10_paff")])
+def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name, no_wide):
+    """MBAFF, transform bypass (and High 4:2:2, 9 / 10 bit when the second kernel set is switched off): the bridge says so once and the
+    reference's C path decodes the stream — same pictures, nothing on the device"""
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
     out = tmp_path / "o.yuv"
-    st = SY.run_bridge("h264_bridge_emu", name, out)
+    st = SY.run_bridge("h264_bridge_emu", name, out, no_wide=no_wide)
     assert st.get("pictures_on_device") == 0 and st.get("pictures_output") == SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
 
 
 @needs_harness
-@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 9, 12), ("paff_and_frames", 19, 17)))
+@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 12, 12), ("paff_and_frames", 23, 17)))
 @pytest.mark.parametrize("lazy,direct", ((False, False), (True, False), (False, True)))
 def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct, name, on_device, frames):
     """a stream whose sequences differ in chroma format and bit depth (8-bit 4:2:0, 10-bit 4:2:2, 8-bit 4:4:4, 8-bit 4:2:0): the
-    bridge gives its buffers back at each change (the decoder calls ff_h264_flush_change), steps aside for the sequence outside
-    Tier 2 and comes back for the next one; `paff_and_frames`: PAFF 4:2:0, progressive with B pictures at the same size (buffers
-    kept), PAFF 4:4:4, PAFF 4:2:2 (steps aside); `420_8_resize` (three picture sizes, all on the device) is among SY.BRIDGE"""
+    bridge gives its buffers back at each change (the decoder calls ff_h264_flush_change) and sets itself up for the next format —
+    the 10-bit 4:2:2 sequence goes through the second kernel set; `paff_and_frames`: PAFF 4:2:0, progressive with B pictures at the
+    same size (buffers kept), PAFF 4:4:4, PAFF 4:2:2; `420_8_resize` (three picture sizes, all on the device) is among SY.BRIDGE"""
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
     out = tmp_path / "o.yuv"
@@ -115,7 +115,7 @@ def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct, n
 
 
 @needs_harness
-@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 9)))
+@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 12)))
 def test_bridge_sequence_changes_with_several_decoders_emulated(tmp_path, emu, name, on_device):
     """four decoder threads, each decoding the stream twice: buffers are given back and set up again while the other decoders'
     pictures are in the dispatcher's launch sets"""
@@ -227,7 +227,7 @@ def test_bridge_lazy_field_pairs_at_the_end_of_a_stream_emulated(tmp_path, emu, 
 
 
 @needs_harness
-@pytest.mark.parametrize("name", [n for n in SY.BRIDGE if not n.startswith("444")])
+@pytest.mark.parametrize("name", [n for n in SY.CLASSIC if not n.startswith("444")])
 def test_bridge_through_the_session_facade_emulated(tmp_path, emu, name):
     """MI355_BRIDGE_SESSION: the reference decoder hands every picture to mi355_h264_start_frame / decode_slice / end_frame
     (the AVHWAccel-shaped façade) and takes it back with get_frame — frame and field pictures, slices, B pictures, weights"""

@@ -56,7 +56,7 @@ def test_bridge_decodes_generated_streams_gpu(tmp_path, mi355, name, lazy, direc
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("name", [n for n in SY.BRIDGE if not n.startswith("444")])
+@pytest.mark.parametrize("name", [n for n in SY.CLASSIC if not n.startswith("444")])
 def test_bridge_through_the_session_facade_gpu(tmp_path, mi355, name):
     """MI355_BRIDGE_SESSION: the reference decoder's pictures through mi355_h264_start_frame / decode_slice / end_frame /
     get_frame (the façade's reference-side caller), two decoder threads = two sessions"""
@@ -67,16 +67,17 @@ def test_bridge_through_the_session_facade_gpu(tmp_path, mi355, name):
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("name", ("422_8_b", "420_10_t8x8", "444_10", "420_8_lossless", "444_8_lossless", "422_10_paff", "420_8_mbaff", "444_8_mbaff"))
-def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name):
+@pytest.mark.parametrize("name,no_wide", (("422_8_b", True), ("420_10_t8x8", True), ("444_10", True), ("420_8_lossless", False), ("444_8_lossless", False), ("422_10_lossless", False),
+                                          ("422_10_paff", True), ("420_8_mbaff", False), ("444_8_mbaff", False), ("422_10_mbaff", False)))
+def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name, no_wide):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
-    st = SY.run_bridge("h264_bridge_gpu", name, out)
+    st = SY.run_bridge("h264_bridge_gpu", name, out, no_wide=no_wide)
     assert st.get("pictures_on_device") == 0 and st.get("pictures_output") == SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 9, 12), ("paff_and_frames", 19, 17)))
+@pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 12, 12), ("paff_and_frames", 23, 17)))
 @pytest.mark.parametrize("lazy", (False, True))
 def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy, name, on_device, frames):
     _need("h264_bridge_gpu")
@@ -86,7 +87,7 @@ def test_bridge_follows_sequence_changes_gpu(tmp_path, mi355, lazy, name, on_dev
     SY.check_md5(out, name)
 
 
-@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 9)))
+@pytest.mark.parametrize("name,on_device", (("420_8_resize", 11), ("mixed_formats", 12)))
 def test_bridge_sequence_changes_with_several_decoders_gpu(tmp_path, mi355, name, on_device):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
