@@ -32,6 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # algorithmic bytes per macroblock: each input byte read once, each output written once
 B_RECON = 384 + 768 + 128 + 384          # reference samples + coefficients + MB record/mv + unfiltered write
 B_DEBLOCK = 384 + 384 + 64               # the loop filter alone: unfiltered read + filtered write + side info (its isolated roofline figure)
+B_FUSED_HIGH10 = 4736                    # the same accounting with 16-bit samples (4 x 384 more) and 32-bit coefficients (768 more)
 B_FUSED = 2432                           # SURVEY.md 8(d) / DESIGN 6.1: the two-surface pipeline figure the headline fraction is quoted on
                                          # (1664 + 768: the filter's second read of the 64-byte record is not part of the contract figure)
 HBM_PEAK = 8.0e12
@@ -141,6 +142,7 @@ def main():
     for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                           ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_decode_frames_wide_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
                           ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
         getattr(lib, name).restype = res
@@ -348,6 +350,34 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
+    # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set
+    try:
+        F10 = 512
+        dev = HF.DeviceFrames(prov, base, replicate=F10, bit_depth=10)
+        try:
+            lw = level_widths(base)
+
+            def wide(passes):
+                assert lib.mi355_h264_decode_frames_wide_dev(dev.d_desc, F10, mbw, mbh, base.max_intra_level, lw, 10, 1, passes, None) == 0
+            wide(7)
+            ev = [lib.mi355_event_create() for _ in range(4)]
+            lib.mi355_event_record(ev[0], None)
+            for i, p in enumerate((1, 2, 4)):
+                wide(p)
+                lib.mi355_event_record(ev[i + 1], None)
+            lib.mi355_sync(None)
+            passes = {k: lib.mi355_event_elapsed_ms(ev[i], ev[i + 1]) for i, k in enumerate(("recon_inter", "recon_intra", "deblock"))}
+            ms = sum(passes.values())
+        finally:
+            dev.free()
+        v = F10 * mbw * mbh / (ms * 1e-3)
+        pts.append({"name": "config2_high10_f%d" % F10, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F10,
+                    "bytes_per_mb_fused": B_FUSED_HIGH10, "fused_fraction_of_hbm_roofline": v * B_FUSED_HIGH10 / HBM_PEAK, "pass_ms": passes,
+                    "note": "config 2 as a High 10 batch: 16-bit samples, 32-bit coefficients (DeviceFrames(bit_depth=10)), planes with line strides, through "
+                            "mi355_h264_decode_frames_wide_dev — the second kernel set in its first, plain form (one wave per macroblock, per-sample arithmetic, "
+                            "one loop-filter launch per anti-diagonal); parity: the generated High 10 / High 4:2:2 streams against the reference decoder"})
+    except Exception as e:
+        pts.append({"name": "config2_high10", "error": repr(e)})
     for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
         try:
             r = fn(lib)

@@ -271,9 +271,11 @@ int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_frames, int n
  *     samples one per coefficient slot (Y, Cb, Cr) — the host unpacks the bit_depth-wide fields of h264_mb_template.c:108-137;
  *   - mi355_h264_mb: qp / qpc are the table values (QpBdOffset included, as h->cur_pic.qscale_table holds them); dc_qmul[1..2] with
  *     chroma_format_idc 2 = dequant4_coeff[..][chroma_qp + 3][0] (h264_mb_template.c:232-236); the nnz_mask bits of chroma BLOCKS
- *     are not read (a block is transformed iff it holds a coefficient), the DC bits are.
+ *     are not read (the kernels look at a block's coefficients: AC present, DC alone, nothing), the DC bits are.
  * passes: bit 0 inter, bit 1 intra, bit 2 loop filter (7 = everything; the separate bits are for measurement).
- * Returns 0, -1 (arguments / a format this entry point does not take — 8-bit 4:2:0 has the kernels above), -2, -3 as the others. */
+ * bit_depth 8 with chroma_format_idc 1 is taken too: the pictures the kernels above decode, through this kernel set (linear surfaces
+ * only; how the two sets are tested against each other and against the oracle).
+ * Returns 0, -1 (arguments / a format outside 8..10 bits, 4:2:0 / 4:2:2), -2, -3 as the others. */
 int mi355_h264_decode_frames_wide_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
                                       int max_intra_level, const int32_t *level_widths, int bit_depth, int chroma_format_idc,
                                       int passes, void *stream);

@@ -54,6 +54,20 @@ __device__ inline void wide_idct4(const int32_t *c, int r[16])       /* h264idct
         r[i] = (z0 + z3) >> 6; r[4 + i] = (z1 + z2) >> 6; r[8 + i] = (z1 - z2) >> 6; r[12 + i] = (z0 - z3) >> 6;
     }
 }
+/* The residual of one 4x4 block as the reference's dispatchers apply it (idct_add16 / idct_add16intra / idct_add8, h264idct_template.c:174-238):
+ * the full transform when the block holds an AC coefficient, the DC-only form (dc + 32) >> 6 when it holds its DC alone — the same
+ * sums except that the DC-only form does not pass through a dctcoef store, which wraps at 16 bits — nothing otherwise.  false: nothing to add */
+template <typename COEF>
+__device__ inline bool wide_block4(const int32_t *c, int r[16])
+{
+    int ac = 0;
+    for (int k = 1; k < 16; k++) ac |= c[k];
+    if (ac) { wide_idct4<COEF>(c, r); return true; }
+    if (!c[0]) return false;
+    const int dc = (c[0] + 32) >> 6;
+    for (int k = 0; k < 16; k++) r[k] = dc;
+    return true;
+}
 /* sixteen (or NB) 4x4 blocks at once: lane 4 * b + q adds row q of block b; every lane of the wave calls */
 template <int BD, int CF>
 __device__ inline void wide_add_blocks4(const int32_t *coef, int nblocks, bool chroma, uint16_t *dst, int pitch)
@@ -62,14 +76,15 @@ __device__ inline void wide_add_blocks4(const int32_t *coef, int nblocks, bool c
     const int lane = lane_id(), b = lane >> 2, q = lane & 3;
     if (b < nblocks) {
         int r[16];
-        wide_idct4<typename F::COEF>(coef + 16 * b, r);
-        const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
-        uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
-        for (int k = 0; k < 4; k++) d[k] = (uint16_t)clip3(d[k] + r[4 * q + k], 0, F::MAXV);
+        if (wide_block4<typename F::COEF>(coef + 16 * b, r)) {
+            const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
+            uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
+            for (int k = 0; k < 4; k++) d[k] = (uint16_t)clip3(d[k] + r[4 * q + k], 0, F::MAXV);
+        }
     }
     MI355_WAVE_SYNC();
 }
-/* the four 8x8 blocks of the luma plane (h264idct_template.c:69-141): lane 8 * b + i transforms column i of block b */
+/* the four 8x8 blocks of the luma plane (h264idct_template.c:69-141, dispatch :189-201): lane 8 * b + i transforms column i of block b */
 template <int BD, int CF>
 __device__ inline void wide_add_blocks8(const int32_t *coef, int32_t (*t8)[64], int first, int nblocks, uint16_t *dst, int pitch)
 {
@@ -78,16 +93,29 @@ __device__ inline void wide_add_blocks8(const int32_t *coef, int32_t (*t8)[64], 
     const int lane = lane_id(), b = first + (lane >> 3), i = lane & 7;
     const bool on = (lane >> 3) < nblocks;
     int in[8], out[8];
+    /* does the block hold an AC coefficient?  every lane looks at its column, the eight answers meet in LDS */
     if (on) {
-        for (int k = 0; k < 8; k++) in[k] = coef[64 * b + i + 8 * k];
+        int ac = 0;
+        for (int k = 0; k < 8; k++) { in[k] = coef[64 * b + i + 8 * k]; if (i | k) ac |= in[k]; }
+        t8[b & 3][i] = ac;
+    }
+    MI355_WAVE_SYNC();
+    int ac = 0;
+    if (on) for (int k = 0; k < 8; k++) ac |= t8[b & 3][k];
+    MI355_WAVE_SYNC();
+    const int dc0 = on ? coef[64 * b] : 0;
+    if (on && ac) {
         if (i == 0) in[0] = (COEF)(in[0] + 32);
         idct8_1d(in, out);
         for (int k = 0; k < 8; k++) t8[b & 3][i + 8 * k] = (COEF)out[k];
     }
     MI355_WAVE_SYNC();
-    if (on) {
-        for (int k = 0; k < 8; k++) in[k] = t8[b & 3][k + 8 * i];
-        idct8_1d(in, out);
+    if (on && (ac || dc0)) {
+        if (ac) {
+            for (int k = 0; k < 8; k++) in[k] = t8[b & 3][k + 8 * i];
+            idct8_1d(in, out);
+        } else
+            for (int k = 0; k < 8; k++) out[k] = dc0 + 32;          /* idct8_dc_add: (dc + 32) >> 6 on every sample */
         uint16_t *d = dst + 8 * (b >> 1) * pitch + 8 * (b & 1) + i;
         for (int k = 0; k < 8; k++) d[k * pitch] = (uint16_t)clip3(d[k * pitch] + (out[k] >> 6), 0, F::MAXV);
     }
@@ -136,8 +164,8 @@ __device__ inline void wide_chroma_dc(int32_t *c, int qmul)       /* c: the plan
 }
 
 /* The chroma residual of a macroblock (h264_mb_template.c:225-257): DC transforms where the record says DC levels were coded, then
- * every block through the full transform — idct_add8's choice between idct_add, idct_dc_add and nothing (h264idct_template.c:203-238)
- * is "transform the block iff it holds a coefficient", and a block of zeros adds zero.  cb / cr: the planes' 8 x CH tiles. */
+ * every block through wide_block4 — idct_add8's choice between idct_add, idct_dc_add and nothing (h264idct_template.c:203-238) read off the
+ * coefficients themselves (a chroma block's count is the count of its AC coefficients).  cb / cr: the planes' 8 x CH tiles. */
 template <int BD, int CF>
 __device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &h, uint16_t *cb, uint16_t *cr, int pitch)
 {
@@ -384,8 +412,8 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         wide_mc_part<BD, CF>(s, fr, sl, mb_x, mb_y, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
-    /* hl_decode_mb_idct_luma (h264_mb.c:726-795): every block of a macroblock whose cbp says luma was coded goes through the full
-     * transform (idct_add16 / idct8_add4 choose between full, DC-only and nothing per block — same sums, a block of zeros adds zero) */
+    /* hl_decode_mb_idct_luma (h264_mb.c:726-795): idct_add16 / idct8_add4 choose between full, DC-only and nothing per block; so does
+     * wide_block4 / wide_add_blocks8, from the coefficients (a block whose count is 1 with a DC level holds nothing else) */
     if (luma_coded) {
         if (t & MI355_MB_8x8DCT) wide_add_blocks8<BD, CF>(s.coef, s.t8, 0, 4, s.py, 16);
         else wide_add_blocks4<BD, CF>(s.coef, 16, false, s.py, 16);
@@ -463,7 +491,7 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
         intra_pred_wave<uint16_t, BD>(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &WTILE(0, 0), TPW);
         if (lane == 0 && ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1)) wide_luma_dc<typename F::COEF>(s.coef, (int)h.dc_qmul[0]);
         MI355_WAVE_SYNC();
-        wide_add_blocks4<BD, CF>(s.coef, 16, false, &WTILE(0, 0), TPW);      /* idct_add16intra: full, DC-only or nothing per block = the full transform */
+        wide_add_blocks4<BD, CF>(s.coef, 16, false, &WTILE(0, 0), TPW);      /* idct_add16intra: full, DC-only or nothing per block */
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
         for (int i8 = 0; i8 < 4; i8++) {
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
@@ -485,9 +513,10 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
             intra_pred_wave<uint16_t, BD>(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &WTILE(x0, y0), TPW);
             if (lane < 4) {
                 int r[16];
-                wide_idct4<typename F::COEF>(s.coef + 16 * i, r);
-                uint16_t *d = &WTILE(x0, y0 + lane);
-                for (int c = 0; c < 4; c++) d[c] = (uint16_t)clip3(d[c] + r[4 * lane + c], 0, F::MAXV);
+                if (wide_block4<typename F::COEF>(s.coef + 16 * i, r)) {
+                    uint16_t *d = &WTILE(x0, y0 + lane);
+                    for (int c = 0; c < 4; c++) d[c] = (uint16_t)clip3(d[c] + r[4 * lane + c], 0, F::MAXV);
+                }
             }
             MI355_WAVE_SYNC();
         }
@@ -731,11 +760,12 @@ extern "C" int mi355_h264_decode_frames_wide_dev(const mi355_h264_frame *d_frame
     hipStream_t st = (hipStream_t)stream;
     const int key = bit_depth * 10 + chroma_format_idc;
     switch (key) {
+    case 81:  return wide_launch<8, 1>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);   /* what the 8-bit kernels decode too: this set against that one (tests) */
     case 91:  return wide_launch<9, 1>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
     case 101: return wide_launch<10, 1>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
     case 82:  return wide_launch<8, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
     case 92:  return wide_launch<9, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
     case 102: return wide_launch<10, 2>(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, passes, st);
-    default:  return -1;                 /* 8-bit 4:2:0 has its own kernels (mi355_h264_decode_frames_layouts_dev) */
+    default:  return -1;
     }
 }

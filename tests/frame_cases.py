@@ -38,7 +38,7 @@ CASES = {
 }
 
 
-def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=False, by_layout=False):
+def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=False, by_layout=False, wide=False):
     fs = HF.synth_frames(**CASES[name])
     if sparse:
         # real P / B pictures: many inter macroblocks carry no residual at all (cbp 0) — about every other one here
@@ -49,12 +49,18 @@ def run_case(backend, oracle, name, pad=0, per_level=True, sparse=False, tiled=F
         fs.coef[pick] = 0
         assert pick.any() or not inter.any()
     recon_o, dst_o = HF.run_oracle(oracle, fs)
+    if wide:
+        # the second kernel set takes an I_PCM macroblock's samples one per coefficient slot (mi355_h264_frame.h), not as 384 bytes
+        pcm = (fs.mb["mb_type"] & 4) != 0
+        fs.coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int16)
     d = HF.DeviceFrames(backend, fs, pad=pad, tiled=tiled)
     try:
         if sparse:
             d.decode_sparse()
         elif by_layout:
             d.decode_by_layout()
+        elif wide:
+            d.decode_wide()                  # the second kernel set (h264_frame_wide.hip) on the pictures the first one decodes
         else:
             d.decode(per_level=per_level)
         recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)

@@ -460,12 +460,19 @@ class DeviceFrames:
     `replicate` = total number of pictures F >= fs.F: picture f is a device-side copy of picture
     f % fs.F with its own buffers (bench.py: many independent streams from a few distinct ones)."""
 
-    def __init__(self, prov, fs, replicate=None, pad=0, tiled=False):
-        """pad: extra bytes per luma row (chroma rows get pad // 2): strides that are multiples of 4 but not of
+    def __init__(self, prov, fs, replicate=None, pad=0, tiled=False, bit_depth=8):
+        """bit_depth 9 / 10: the same pictures as a High 10 batch for mi355_h264_decode_frames_wide_dev — 16-bit samples (the 8-bit reference
+        samples shifted up, the low bits filled from the sample's position), 32-bit coefficients (scaled by the same shift), QPs raised by
+        QpBdOffset; there is no frame-level oracle for these (parity of the wide kernels: the generated High 10 / High 4:2:2 streams
+        against the reference decoder, and decode_wide(8, 1) against the oracle): measurement and determinism only.
+        pad: extra bytes per luma row (chroma rows get pad // 2): strides that are multiples of 4 but not of
         16 / 8 take the kernels' narrow-access paths.
         tiled: dst / recon / reference surfaces in the macroblock-tiled layout (pad then = extra bytes per macroblock ROW of
         luma tiles, a multiple of 256; chroma rows get half)"""
         self.lib, self.fs, self.pad, self.tiled = prov.lib, fs, pad, tiled
+        self.bit_depth, px, sh = bit_depth, (2 if bit_depth > 8 else 1), bit_depth - 8
+        self.px = px
+        assert not (tiled and px == 2)
         lib = self.lib
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -477,7 +484,7 @@ class DeviceFrames:
         G = fs.F
         F = self.F = replicate or G
         nmb = fs.mb_w * fs.mb_h
-        ys, cs = fs.W + pad, fs.W // 2 + pad // 2            # strides
+        ys, cs = px * fs.W + pad, px * fs.W // 2 + pad // 2            # strides
         ysz, csz = fs.H * ys, (fs.H // 2) * cs
         if tiled:
             assert pad % 256 == 0
@@ -498,10 +505,20 @@ class DeviceFrames:
                 lib.mi355_memcpy_d2d(p + done * per, p, n * per)
                 done += n
             return p
-        self.mb = up_rep(fs.mb, nmb * 64)
+        mb = fs.mb
+        coef, cbytes = fs.coef, 768
+        if px == 2:
+            mb = fs.mb.copy()
+            mb["qp"] += 6 * sh
+            mb["qpc"] += 6 * sh
+            coef, cbytes = fs.coef.astype(np.int32) << sh, 1536
+            pcm = (fs.mb["mb_type"] & 4) != 0
+            coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32) << sh
+        self.cbytes = cbytes
+        self.mb = up_rep(mb, nmb * 64)
         self.mv0 = up_rep(fs.mv[0], nmb * 64)
         self.mv1 = up_rep(fs.mv[1], nmb * 64) if fs.use_l1 else None
-        self.coef = up_rep(fs.coef, nmb * 768)
+        self.coef = up_rep(coef, nmb * cbytes)
         nsl = fs.slices.shape[1]
         self.slices = up_rep(fs.slices, nsl * SLICE_DT.itemsize)
         self.recon = self.alloc(F * self.fsz)
@@ -515,9 +532,14 @@ class DeviceFrames:
                     refs_host[f, s_, :ysz].reshape(fs.mb_h, ys)[:, :fs.mb_w * 256] = ty.reshape(fs.mb_h, -1)
                     refs_host[f, s_, ysz:].reshape(fs.mb_h, cs)[:, :fs.mb_w * 128] = tc.reshape(fs.mb_h, -1)
                     continue
-                refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :fs.W] = y
-                refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cb
-                refs_host[f, s_, ysz + csz:].reshape(fs.H // 2, cs)[:, :fs.W // 2] = cr
+                if px == 2:
+                    def wide(a):
+                        lo = (np.arange(a.shape[1], dtype=np.uint16)[None, :] * 3 + np.arange(a.shape[0], dtype=np.uint16)[:, None] * 5) & ((1 << sh) - 1)
+                        return ((a.astype(np.uint16) << sh) | lo).view(np.uint8).reshape(a.shape[0], -1)
+                    y, cb, cr = wide(y), wide(cb), wide(cr)
+                refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :px * fs.W] = y
+                refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :px * fs.W // 2] = cb
+                refs_host[f, s_, ysz + csz:].reshape(fs.H // 2, cs)[:, :px * fs.W // 2] = cr
         self.refs = up_rep(refs_host, fs.nrefs * self.fsz)
         ilist = [self.up(fs.intra_list[g]) if len(fs.intra_list[g]) else None for g in range(G)]
         istart = [self.up(fs.intra_start[g]) for g in range(G)]
@@ -538,7 +560,7 @@ class DeviceFrames:
             fr.mb = self.mb + f * nmb * 64
             fr.mv[0] = self.mv0 + f * nmb * 64
             fr.mv[1] = (self.mv1 + f * nmb * 64) if self.mv1 else None
-            fr.coef = self.coef + f * nmb * 768
+            fr.coef = self.coef + f * nmb * cbytes
             fr.slices = self.slices + f * nsl * SLICE_DT.itemsize
             fr.nslices = nsl
             fr.max_intra_level = int(fs.intra_start[g].shape[0]) - 1
@@ -578,8 +600,13 @@ class DeviceFrames:
             ty = raw[:, :ysz].reshape(n, fs.mb_h, self.tys)[:, :, :fs.mb_w * 256].reshape(n, -1)
             tc = raw[:, ysz:].reshape(n, fs.mb_h, self.tcs)[:, :, :fs.mb_w * 128].reshape(n, -1)
             return untile_planes(ty, tc, fs.mb_w, fs.mb_h)
-        ys, cs = fs.W + self.pad, fs.W // 2 + self.pad // 2
+        px = self.px
+        ys, cs = px * fs.W + self.pad, px * fs.W // 2 + self.pad // 2
         ysz, csz = fs.H * ys, (fs.H // 2) * cs
+        if px == 2:
+            return [np.ascontiguousarray(raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :2 * fs.W]).view(np.uint16),
+                    np.ascontiguousarray(raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W]).view(np.uint16),
+                    np.ascontiguousarray(raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W]).view(np.uint16)]
         return [raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :fs.W], raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2],
                 raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2]]
 
@@ -615,6 +642,20 @@ class DeviceFrames:
             fn.argtypes = [C.c_void_p, C.c_int] + [C.c_int if isinstance(a, int) else C.c_void_p for a in args] + [C.c_void_p]
             assert fn(self.d_desc, self.F, *args, None) == 0, name
         assert lib.mi355_sync(None) == 0
+
+    def decode_wide(self, bit_depth=8, idc=1, passes=7, sync=True):
+        """the three passes of the SECOND kernel set (mi355_h264_decode_frames_wide_dev: High 10 / High 4:2:2, and 8-bit 4:2:0 for this
+        comparison) on linear surfaces"""
+        fs, lib = self.fs, self.lib
+        assert not self.tiled
+        lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+        fn = lib.mi355_h264_decode_frames_wide_dev
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rc = fn(self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, bit_depth, idc, passes, None)
+        assert rc == 0, rc
+        if sync:
+            assert lib.mi355_sync(None) == 0
 
     def decode_sparse(self, poison=True):
         """the three passes with mi355_h264_recon_inter_sparse_dev: inter macroblocks whose cbp is zero do not fetch their

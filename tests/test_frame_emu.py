@@ -1,7 +1,9 @@
 """CPU: Tier-2 kernels under the SIMT emulator (test tooling) vs the oracle, bit-exact."""
+import numpy as np
 import pytest
 
 import frame_cases
+import h264_frames as HF
 
 
 @pytest.mark.parametrize("name", list(frame_cases.CASES))
@@ -134,3 +136,35 @@ def test_mixed_partition_workload_matches_oracle_emulated(emu, oracle, tiled):
 def test_frame_pipeline_emulated_layout_entry_points(emu, oracle, name, tiled):
     """mi355_h264_recon_inter_layouts_dev / mi355_h264_deblock_layouts_dev with the batch's one layout named: the single-layout kernel instances"""
     frame_cases.run_case(emu, oracle, name, tiled=tiled, by_layout=True)
+
+
+@pytest.mark.parametrize("pad", (0, 8))
+@pytest.mark.parametrize("name", [n for n in frame_cases.CASES if n != "tall_all_intra"])
+def test_second_kernel_set_on_8bit_420_pictures_emulated(emu, oracle, name, pad):
+    """mi355_h264_decode_frames_wide_dev (the High 10 / High 4:2:2 kernels, instantiated for 8-bit 4:2:0) against the oracle on the
+    cases of the first kernel set: partitions, weights, intra modes, I_PCM, the 8x8 transform, slices with the filter off"""
+    frame_cases.run_case(emu, oracle, name, pad=pad, wide=True)
+
+
+@pytest.mark.parametrize("name", ("p16_noise", "p16_smooth", "b_weight_explicit"))
+def test_second_kernel_set_10bit_sanity_emulated(emu, oracle, name):
+    """h264_frames.DeviceFrames(bit_depth=10): the 8-bit case scaled to 10 bits (samples and coefficients shifted by two, QPs raised by 12)
+    through mi355_h264_decode_frames_wide_dev(10, 1).  NOT a parity test (parity of the 10-bit kernels: the generated High 10 streams
+    against the reference decoder, tests/test_synth_streams*.py) — it pins that this measurement input decodes to what the 8-bit picture
+    is, four times as large: samples inside 10 bits, nine samples in ten within one 8-bit step of the 8-bit oracle's picture (the rest:
+    DC levels that wrap in the 8-bit path's 16-bit coefficients and do not in 32 bits, filter decisions at a threshold), and two runs
+    agree sample for sample"""
+    fs = HF.synth_frames(**frame_cases.CASES[name])
+    _, dst8 = HF.run_oracle(oracle, fs)
+    runs = []
+    for _ in range(2):
+        d = HF.DeviceFrames(emu, fs, bit_depth=10)
+        try:
+            d.decode_wide(10, 1)
+            runs.append(d.fetch(d.dst))
+        finally:
+            d.free()
+    for p in range(3):
+        assert np.array_equal(runs[0][p], runs[1][p])
+        assert runs[0][p].max() <= 1023
+        assert (np.abs(runs[0][p].astype(np.int32) / 4.0 - dst8[p]) <= 1.0).mean() > 0.9, (name, p)

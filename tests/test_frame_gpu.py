@@ -177,3 +177,44 @@ def test_loop_filter_bands_hand_down_under_load(mi355, oracle, F, tiled):
 def test_frame_pipeline_gpu_layout_entry_points(mi355, oracle, name, tiled):
     """mi355_h264_recon_inter_layouts_dev / mi355_h264_deblock_layouts_dev with the batch's one layout named: the single-layout kernel instances"""
     frame_cases.run_case(mi355, oracle, name, tiled=tiled, by_layout=True)
+
+
+@pytest.mark.parametrize("pad", (0, 8))
+@pytest.mark.parametrize("name", [n for n in frame_cases.CASES if n != "tall_all_intra"])
+def test_second_kernel_set_on_8bit_420_pictures(mi355, oracle, name, pad):
+    """mi355_h264_decode_frames_wide_dev (the High 10 / High 4:2:2 kernels of h264_frame_wide.hip, instantiated for 8-bit 4:2:0) against
+    the oracle on the cases of the first kernel set — the second set's partition walk, weights, intra predictors, transforms, I_PCM and
+    loop filter on hardware (its 16-bit / 4:2:2 instances: the generated streams, tests/test_synth_streams_gpu.py)"""
+    frame_cases.run_case(mi355, oracle, name, pad=pad, wide=True)
+
+
+def test_second_kernel_set_full_size_1080p_matches_oracle(mi355, oracle):
+    """three 1080p P pictures of the bench generator through the second kernel set (8-bit 4:2:0 instance): every sample of both surfaces —
+    376 anti-diagonal launches of the loop filter over 24 480 macroblocks"""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x264, lib=mi355.lib)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs)
+    try:
+        d.decode_wide()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
+
+
+def test_second_kernel_set_10bit_1080p_is_deterministic_and_in_range(mi355):
+    """the bench point's input (DeviceFrames(bit_depth=10): config 2 scaled to 10 bits) through mi355_h264_decode_frames_wide_dev(10, 1):
+    two runs agree sample for sample, samples stay inside 10 bits (parity of the 10-bit kernels: the generated High 10 streams)"""
+    fs = HF.synth_frames_fast(2, 120, 68, seed=0x264, lib=mi355.lib)
+    outs = []
+    for _ in range(2):
+        d = HF.DeviceFrames(mi355, fs, bit_depth=10)
+        try:
+            d.decode_wide(10, 1)
+            outs.append(d.fetch(d.dst))
+        finally:
+            d.free()
+    for p in range(3):
+        assert np.array_equal(outs[0][p], outs[1][p]) and outs[0][p].max() <= 1023 and outs[0][p].std() > 10
