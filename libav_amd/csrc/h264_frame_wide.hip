@@ -34,6 +34,35 @@ template <int BD, int CF> struct Fmt {
     static constexpr int MAXV = (1 << BD) - 1;
 };
 
+/* N samples between a picture row (4-byte aligned address, N * sizeof(PX) a multiple of 4) and 16-bit samples in LDS */
+template <typename PX, int N>
+__device__ __forceinline__ void wide_ld_row(const uint8_t *p, uint16_t *d)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    if (sizeof(PX) == 2) {
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) { const uint32_t v = w[k]; d[2 * k] = (uint16_t)(v & 0xFFFF); d[2 * k + 1] = (uint16_t)(v >> 16); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N / 4; k++) {
+            const uint32_t v = w[k];
+            d[4 * k] = (uint16_t)(v & 0xFF); d[4 * k + 1] = (uint16_t)((v >> 8) & 0xFF); d[4 * k + 2] = (uint16_t)((v >> 16) & 0xFF); d[4 * k + 3] = (uint16_t)(v >> 24);
+        }
+    }
+}
+template <typename PX, int N>
+__device__ __forceinline__ void wide_st_row(uint8_t *p, const uint16_t *d)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    if (sizeof(PX) == 2) {
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) w[k] = (uint32_t)d[2 * k] | ((uint32_t)d[2 * k + 1] << 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N / 4; k++) w[k] = (uint32_t)d[4 * k] | ((uint32_t)d[4 * k + 1] << 8) | ((uint32_t)d[4 * k + 2] << 16) | ((uint32_t)d[4 * k + 3] << 24);
+    }
+}
+
 /* position of chroma block j of a plane in 4-sample units: the reference's block_offset[16 + j] (4:2:0, j = 0..3) and
  * block_offset[16 + j] / [16 + j + 4] (4:2:2, h264idct_template.c:222-236) */
 __device__ __forceinline__ int cblk_x4(int j) { return j & 1; }
@@ -79,7 +108,11 @@ __device__ inline void wide_add_blocks4(const int32_t *coef, int nblocks, bool c
         if (wide_block4<typename F::COEF>(coef + 16 * b, r)) {
             const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
             uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
-            for (int k = 0; k < 4; k++) d[k] = (uint16_t)clip3(d[k] + r[4 * q + k], 0, F::MAXV);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int rk = q == 0 ? r[k] : (q == 1 ? r[4 + k] : (q == 2 ? r[8 + k] : r[12 + k]));      /* row q, without indexing the array by a lane's value */
+                d[k] = (uint16_t)clip3(d[k] + rk, 0, F::MAXV);
+            }
         }
     }
     MI355_WAVE_SYNC();
@@ -194,29 +227,29 @@ __device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, int m
 {
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
+    constexpr int PXB = (int)sizeof(PX);
     const int lane = lane_id();
-    for (int i = lane; i < 256; i += 64) {
-        const int r = i >> 4, c = i & 15;
-        reinterpret_cast<PX *>(fr.recon[0] + (size_t)(16 * mb_y + r) * fr.recon_stride[0])[16 * mb_x + c] = (PX)y[r * ypitch + c];
+    {   /* luma: lane = 4 * row + quarter */
+        const int r = lane >> 2, c = 4 * (lane & 3);
+        wide_st_row<PX, 4>(fr.recon[0] + (size_t)(16 * mb_y + r) * fr.recon_stride[0] + (16 * mb_x + c) * PXB, y + r * ypitch + c);
     }
-    for (int i = lane; i < 8 * F::CH; i += 64) {
-        const int r = i >> 3, c = i & 7;
-        reinterpret_cast<PX *>(fr.recon[1] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1])[8 * mb_x + c] = (PX)cb[r * cpitch + c];
-        reinterpret_cast<PX *>(fr.recon[2] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1])[8 * mb_x + c] = (PX)cr[r * cpitch + c];
+    if (lane < 4 * F::CH) {   /* chroma: lane = (2 * row + half) of Cb, then of Cr */
+        const int p = lane >= 2 * F::CH, k = lane - 2 * F::CH * p, r = k >> 1, c = 4 * (k & 1);
+        wide_st_row<PX, 4>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1] + (8 * mb_x + c) * PXB, (p ? cr : cb) + r * cpitch + c);
     }
 }
 
 /* ------------------------------------------------------------------------- */
 /* inter                                                                        */
 /* ------------------------------------------------------------------------- */
-constexpr int WP = 21;          /* pitch of the luma window: 16 + 5 */
-constexpr int CWP = 9, CWIN = 160;   /* chroma windows: 9 x 17 per plane, the second plane at CWIN */
+constexpr int WP = 24;          /* pitch of the luma window: 16 + 5 columns, fetched as up to three pieces of eight */
+constexpr int CWP = 16, CWIN = 17 * CWP;   /* chroma windows: 9 x 17 per plane (two pieces of eight per row), the second plane at CWIN */
 struct WideInterLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];
     int32_t coef[512];
     uint16_t py[256], pc[2][128], qy[256], qc[2][128];
-    uint16_t win[WP * WP + 7];
+    uint16_t win[2 * CWIN + 8];     /* >= 21 * WP */
     int32_t t8[4][64];
 };
 
@@ -259,8 +292,19 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
     const uint8_t *const *rp = fr.ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
     const int W = 16 * fr.mb_width, H = 16 * fr.mb_height;
+    const int lw = w == 16 ? 4 : (w == 8 ? 3 : 2);            /* log2 of the block's width */
     {
-        const int x0 = (mx >> 2) - 2, y0 = (my >> 2) - 2, ww = w + 5, hh = h + 5;
+        const int x0 = (mx >> 2) - 2, y0 = (my >> 2) - 2, ww = w + 5, hh = h + 5, nc = (ww + 7) >> 3;
+        if (x0 >= 0 && y0 >= 0 && x0 + 8 * nc <= W && y0 + hh <= H) {
+            /* the window lies inside the picture: one piece of eight samples per lane (any alignment), <= 21 rows x 3 pieces */
+            const int r = nc == 3 ? lane / 3 : (nc == 2 ? lane >> 1 : lane), c = lane - r * nc;
+            if (r < hh) {
+                PX v[8];
+                __builtin_memcpy(v, rp[0] + (size_t)(y0 + r) * fr.dst_stride[0] + (size_t)(x0 + 8 * c) * sizeof(PX), sizeof(v));
+#pragma unroll
+                for (int k = 0; k < 8; k++) s.win[r * WP + 8 * c + k] = v[k];
+            }
+        } else
         for (int i = lane; i < ww * hh; i += 64) {
             const int r = i / ww, c = i - r * ww;
             const int xx = clip3(x0 + c, 0, W - 1), yy = clip3(y0 + r, 0, H - 1);
@@ -268,7 +312,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
         }
         MI355_WAVE_SYNC();
         for (int i = lane; i < w * h; i += 64) {
-            const int y = i / w, x = i - y * w;
+            const int y = i >> lw, x = i & (w - 1);
             const int v = wide_qpel_px(s.win, x, y, mx & 3, my & 3, F::MAXV);
             uint16_t *d = dy + (by + y) * 16 + bx + x;
             *d = (uint16_t)(avg ? f2(*d, v) : v);
@@ -279,7 +323,17 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, cby = CF == 2 ? by : by >> 1;
     const int myc = CF == 1 ? my + s.hdr.u.inter.chroma_dy[list][quadrant] : my;
     const int cx = mx >> 3, cy = CF == 2 ? myc >> 2 : myc >> 3, fx = mx & 7, fy = CF == 2 ? (myc << 1) & 7 : myc & 7;
-    const int CWd = 8 * fr.mb_width, CHt = F::CH * fr.mb_height, cww = cw + 1, chh = ch + 1;
+    const int CWd = 8 * fr.mb_width, CHt = F::CH * fr.mb_height, cww = cw + 1, chh = ch + 1, ncc = (cww + 7) >> 3;
+    if (cx >= 0 && cy >= 0 && cx + 8 * ncc <= CWd && cy + chh <= CHt) {
+        const int r = ncc == 2 ? lane >> 1 : lane, c = lane - r * ncc;
+        for (int p = 0; p < 2; p++)
+            if (r < chh) {
+                PX v[8];
+                __builtin_memcpy(v, rp[1 + p] + (size_t)(cy + r) * fr.dst_stride[1] + (size_t)(cx + 8 * c) * sizeof(PX), sizeof(v));
+#pragma unroll
+                for (int k = 0; k < 8; k++) s.win[p * CWIN + r * CWP + 8 * c + k] = v[k];
+            }
+    } else
     for (int p = 0; p < 2; p++)
         for (int i = lane; i < cww * chh; i += 64) {
             const int r = i / cww, c = i - r * cww;
@@ -290,7 +344,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
     for (int p = 0; p < 2; p++)
         for (int i = lane; i < cw * ch; i += 64) {
-            const int y = i / cw, x = i - y * cw;
+            const int y = i >> (lw - 1), x = i & (cw - 1);
             const uint16_t *q = s.win + p * CWIN + y * CWP + x;
             const int v = (A * q[0] + B * q[1] + C * q[CWP] + D * q[CWP + 1] + 32) >> 6;
             uint16_t *d = (p ? dcr : dcb) + (cby + y) * 8 + (bx >> 1) + x;
@@ -305,8 +359,9 @@ __device__ inline void wide_weight(uint16_t *p, int pitch, int w, int h, int ld,
 {
     int o = (int)((unsigned)off << (ld + (BD - 8)));
     if (ld) o += 1 << (ld - 1);
+    const int lw = w == 16 ? 4 : (w == 8 ? 3 : (w == 4 ? 2 : 1));
     for (int i = lane_id(); i < w * h; i += 64) {
-        const int y = i / w, x = i - y * w;
+        const int y = i >> lw, x = i & (w - 1);
         p[y * pitch + x] = (uint16_t)clip3((p[y * pitch + x] * wt + o) >> ld, 0, (1 << BD) - 1);
     }
     MI355_WAVE_SYNC();
@@ -315,8 +370,9 @@ template <int BD>
 __device__ inline void wide_biweight(uint16_t *d, const uint16_t *s, int pitch, int w, int h, int ld, int wd, int ws, int off)
 {
     const int o = (int)((unsigned)((((int)((unsigned)off << (BD - 8))) + 1) | 1) << ld);
+    const int lw = w == 16 ? 4 : (w == 8 ? 3 : (w == 4 ? 2 : 1));
     for (int i = lane_id(); i < w * h; i += 64) {
-        const int y = i / w, x = i - y * w;
+        const int y = i >> lw, x = i & (w - 1);
         d[y * pitch + x] = (uint16_t)clip3((s[y * pitch + x] * ws + d[y * pitch + x] * wd + o) >> (ld + 1), 0, (1 << BD) - 1);
     }
     MI355_WAVE_SYNC();
@@ -515,7 +571,11 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
                 int r[16];
                 if (wide_block4<typename F::COEF>(s.coef + 16 * i, r)) {
                     uint16_t *d = &WTILE(x0, y0 + lane);
-                    for (int c = 0; c < 4; c++) d[c] = (uint16_t)clip3(d[c] + r[4 * lane + c], 0, F::MAXV);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int rc = lane == 0 ? r[c] : (lane == 1 ? r[4 + c] : (lane == 2 ? r[8 + c] : r[12 + c]));
+                        d[c] = (uint16_t)clip3(d[c] + rc, 0, F::MAXV);
+                    }
                 }
             }
             MI355_WAVE_SYNC();
@@ -581,48 +641,60 @@ __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int lis
     return r == 0xFF ? -1 : r;
 }
 
-/* one macroblock of anti-diagonal d: ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without MBAFF.
- * The macroblock's own samples come from `recon`, four columns of the left and four rows of the top neighbour from `dst` (as those
+/* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter macroblock (d - 2 * mb_y, mb_y) of picture 4 * k + g —
+ * ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without MBAFF.  Sixteen lanes are what one macroblock has
+ * to offer (the sixteen lines across a luma edge; 8 + 8 chroma lines); four macroblocks fill the wave, and a lane moves whole rows
+ * (32 bytes of a 10-bit luma row) between memory and the group's LDS tiles.
+ * A macroblock's own samples come from `recon`, four columns of the left and four rows of the top neighbour from `dst` (as those
  * macroblocks' own passes left them); the macroblock, three columns and three rows (one of each in chroma) go back to `dst`. */
 template <int BD, int CF>
 __global__ void __launch_bounds__(64)
-k_wide_deblock(const mi355_h264_frame *frames, int d, int max_h)
+k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
 {
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
-    __shared__ WideDbLds s;
-    const int f = (int)blockIdx.x / max_h, mb_y = (int)blockIdx.x - f * max_h, mb_x = d - 2 * mb_y, lane = lane_id();
-    const mi355_h264_frame &fr = frames[f];
-    if (mb_y >= fr.mb_height || mb_x < 0 || mb_x >= fr.mb_width) return;
+    constexpr int PXB = (int)sizeof(PX);
+    __shared__ WideDbLds sh[4];
+    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+    WideDbLds &s = sh[g];
+    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, mb_x = d - 2 * mb_y;
+    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
+    const bool ok = f < nframes && mb_y < fr.mb_height && mb_x >= 0 && mb_x < fr.mb_width;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     const bool has_left = mb_x > 0, has_top = mb_y > 0;
-    /* records: this macroblock, left, top */
-    if (lane < 48) {
-        const int which = lane >> 4;
-        const int xy = which == 0 ? mb_xy : (which == 1 ? (has_left ? mb_xy - 1 : mb_xy) : (has_top ? mb_xy - fr.mb_width : mb_xy));
-        reinterpret_cast<uint32_t *>(&s.m[which])[lane & 15] = reinterpret_cast<const uint32_t *>(&fr.mb[xy])[lane & 15];
-    }
-    /* samples */
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], yd = fr.dst_stride[0], cd = fr.dst_stride[1];
-    for (int i = lane; i < 256; i += 64)
-        DY(i & 15, i >> 4) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y + (i >> 4)) * ys)[16 * mb_x + (i & 15)];
-    if (has_left) { const int r = lane >> 2, c = (lane & 3) - 4; DY(c, r) = reinterpret_cast<const PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c]; }
-    if (has_top) { const int r = (lane >> 4) - 4, c = lane & 15; DY(c, r) = reinterpret_cast<const PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c]; }
-    for (int p = 0; p < 2; p++) {
-        for (int i = lane; i < 8 * F::CH; i += 64)
-            DC(p, i & 7, i >> 3) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + (i >> 3)) * cs)[8 * mb_x + (i & 7)];
-        if (has_left && lane < 2 * F::CH) { const int r = lane >> 1, c = (lane & 1) - 2; DC(p, c, r) = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd)[8 * mb_x + c]; }
-        if (has_top && lane < 16) { const int r = (lane >> 3) - 2, c = lane & 7; DC(p, c, r) = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd)[8 * mb_x + c]; }
+    if (ok) {
+        /* records: this macroblock, left, top; one dword of each per lane */
+        const int xl = has_left ? mb_xy - 1 : mb_xy, xt = has_top ? mb_xy - fr.mb_width : mb_xy;
+        reinterpret_cast<uint32_t *>(&s.m[0])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[l];
+        reinterpret_cast<uint32_t *>(&s.m[1])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xl])[l];
+        reinterpret_cast<uint32_t *>(&s.m[2])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xt])[l];
+        /* samples: lane l brings row l of the macroblock, its four left neighbours, a quarter row of the four rows above */
+        wide_ld_row<PX, 16>(fr.recon[0] + (size_t)(16 * mb_y + l) * ys + 16 * mb_x * PXB, &DY(0, l));
+        if (has_left) wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
+        if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
+        for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
+            const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
+            wide_ld_row<PX, 8>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + r) * cs + 8 * mb_x * PXB, &DC(p, 0, r));
+            if (has_left) {
+                const PX *q = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd) + 8 * mb_x;
+                DC(p, -2, r) = q[-2]; DC(p, -1, r) = q[-1];
+            }
+        }
+        if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_ld_row<PX, 4>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x + c) * PXB, &DC(p, c, r)); }
     }
     MI355_WAVE_SYNC();
     const mi355_h264_mb &m = s.m[0];
-    if (!(m.flags & MI355_MBF_NO_DEBLOCK)) {
-        /* the motion and coefficient flags the strengths are derived from: fill_filter_caches, h264_slice.c:2056-2196 */
-        if (lane < 24) {
+    const bool filter = ok && !(m.flags & MI355_MBF_NO_DEBLOCK);
+    if (filter) {
+        /* the motion and coefficient flags the strengths are derived from (fill_filter_caches, h264_slice.c:2056-2196): lane l its own
+         * 4x4 block, lanes 0..3 / 4..7 also a block of the left neighbour's last column / the top neighbour's last row */
+        for (int k = 0; k < 2; k++) {
+            if (k && l >= 8) break;
             int which, x4, y4, cx, cy;
-            if (lane < 16) { which = 0; x4 = lane & 3; y4 = lane >> 2; cx = x4; cy = y4; }
-            else if (lane < 20) { which = 1; x4 = 3; y4 = lane - 16; cx = -1; cy = y4; }
-            else { which = 2; x4 = lane - 20; y4 = 3; cx = x4; cy = -1; }
+            if (!k) { which = 0; x4 = l & 3; y4 = l >> 2; cx = x4; cy = y4; }
+            else if (l < 4) { which = 1; x4 = 3; y4 = l; cx = -1; cy = y4; }
+            else { which = 2; x4 = l - 4; y4 = 3; cx = x4; cy = -1; }
             const int xy = which == 0 ? mb_xy : (which == 1 ? (has_left ? mb_xy - 1 : mb_xy) : (has_top ? mb_xy - fr.mb_width : mb_xy));
             const int ci = (cy + 1) * 5 + cx + 1;
             for (int list = 0; list < 2; list++) {
@@ -631,17 +703,18 @@ k_wide_deblock(const mi355_h264_frame *frames, int d, int max_h)
             }
             s.nnz[ci] = (uint8_t)((s.m[which].nnz_mask >> blk_index(x4, y4)) & 1);
         }
-        MI355_WAVE_SYNC();
-        /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane = 16 * dir + 4 * edge + i */
-        if (lane < 32) {
-            const int dir = lane >> 4, edge = (lane >> 2) & 3, i = lane & 3;
-            const uint32_t t = m.mb_type;
-            const int mask_edge = dir == 0 ? ((t >> 3) & 7) == 0 ? 0 : (((t >> 3) & 7) < 4 ? 3 : 1)
-                                           : ((t >> 3) & 7) == 0 ? 0 : (((t >> 3) & 7) == 1 ? 3 : (((t >> 3) & 7) < 4 ? 1 : 3));
+    }
+    MI355_WAVE_SYNC();
+    if (filter) {
+        /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane l = 4 * edge + i, both directions */
+        const uint32_t t = m.mb_type;
+        const int edge = l >> 2, i = l & 3, tk = (t >> 3) & 7;
+        const int list_count = fr.slices[m.slice_id].list_count, ylim = fr.field_picture ? 2 : 4;
+        for (int dir = 0; dir < 2; dir++) {
+            const int mask_edge = dir == 0 ? (tk == 0 ? 0 : (tk < 4 ? 3 : 1)) : (tk == 0 ? 0 : (tk == 1 ? 3 : (tk < 4 ? 1 : 3)));
             const int edges = (mask_edge == 3 && !(m.cbp & 15)) ? 1 : 4;
             const uint32_t par_types = MI355_MB_16x16 | (MI355_MB_8x16 >> dir);
             const bool mask_par0 = (t & par_types) != 0;
-            const int list_count = fr.slices[m.slice_id].list_count, ylim = fr.field_picture ? 2 : 4;
             const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
             const int b = (y + 1) * 5 + x + 1, bn = b - (dir ? 5 : 1);
             int bs = 0;
@@ -665,66 +738,72 @@ k_wide_deblock(const mi355_h264_frame *frames, int d, int max_h)
             }
             s.bs[dir][edge][i] = (uint8_t)bs;
         }
-        MI355_WAVE_SYNC();
-        /* the edges: lanes 0..15 a luma line each, 16..31 Cb, 32..47 Cr */
+    }
+    MI355_WAVE_SYNC();
+    {
         const int qp_bd = 6 * (BD - 8), a_off = m.slice_alpha_c0_offset, b_off = m.slice_beta_offset;
-        const int comp = lane >> 4, line = lane & 15;
         const bool dct8 = (m.mb_type & MI355_MB_8x8DCT) != 0;
+        /* one chroma line across an edge: q = the sample at the edge's q side, st = step across the edge */
+        auto chroma_line = [&](int p, uint16_t *q, int st, int bs, int edge, const mi355_h264_mb &mm) {
+            const int qp = edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p];
+            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+            int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
+            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
+            else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
+            q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
+        };
         for (int dir = 0; dir < 2; dir++)
             for (int edge = 0; edge < 4; edge++) {
-                if (comp < 3) {
-                    const mi355_h264_mb &mm = s.m[1 + dir];
-                    if (comp == 0) {
-                        const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
-                        const int bs = s.bs[dir][edge][line >> 2];
-                        if (luma_on && bs) {
-                            const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
-                            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-                            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
-                            uint16_t *q = dir == 0 ? &DY(4 * edge, line) : &DY(line, 4 * edge);
-                            const int st = dir == 0 ? 1 : DYP;
-                            if (bs < 4) {
-                                int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
-                                lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)));
-                                q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
-                            } else {
-                                int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
-                                lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
-                                q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
-                            }
+                const mi355_h264_mb &mm = s.m[1 + dir];
+                /* luma: line (dir 0) or column (dir 1) l */
+                {
+                    const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
+                    const int bs = filter ? s.bs[dir][edge][l >> 2] : 0;
+                    if (luma_on && bs) {
+                        const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
+                        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+                        const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+                        uint16_t *q = dir == 0 ? &DY(4 * edge, l) : &DY(l, 4 * edge);
+                        const int st = dir == 0 ? 1 : DYP;
+                        if (bs < 4) {
+                            int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
+                            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)));
+                            q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
+                        } else {
+                            int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
+                            lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
+                            q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
                         }
+                    }
+                }
+                /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
+                 * at rows 0 and 4 in 4:2:0, all four at rows 0, 4, 8, 12 in 4:2:2 (:679-686) */
+                if (dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1))) {
+                    if (dir == 0 && CF == 2) {
+                        const int bs = filter ? s.bs[0][edge][l >> 2] : 0;
+                        for (int p = 0; p < 2; p++)
+                            if (bs) chroma_line(p, &DC(p, 2 * edge, l), 1, bs, edge, mm);
                     } else {
-                        /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
-                         * at rows 0 and 4 in 4:2:0, all four at rows 0, 4, 8, 12 in 4:2:2 (:679-686) */
-                        const int p = comp - 1;
-                        const bool on = dir == 0 ? !(edge & 1) && line < F::CH : (CF == 2 || !(edge & 1)) && line < 8;
-                        const int bs = dir == 0 ? s.bs[0][edge][CF == 2 ? line >> 2 : line >> 1] : s.bs[1][edge][line >> 1];
-                        if (on && bs) {
-                            const int qp = edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p];
-                            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-                            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
-                            uint16_t *q = dir == 0 ? &DC(p, 2 * edge, line) : &DC(p, line, CF == 2 ? 4 * edge : 2 * edge);
-                            const int st = dir == 0 ? 1 : DCPW;
-                            int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-                            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
-                            else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
-                            q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
-                        }
+                        const int p = l >> 3, k = l & 7;
+                        const int bs = filter ? s.bs[dir][edge][k >> 1] : 0;
+                        if (bs) chroma_line(p, dir == 0 ? &DC(p, 2 * edge, k) : &DC(p, k, CF == 2 ? 4 * edge : 2 * edge), dir == 0 ? 1 : DCPW, bs, edge, mm);
                     }
                 }
                 MI355_WAVE_SYNC();
             }
     }
     /* out: the macroblock, and what its left and top edges changed of the neighbours */
-    for (int i = lane; i < 256; i += 64)
-        reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + (i >> 4)) * yd)[16 * mb_x + (i & 15)] = (PX)DY(i & 15, i >> 4);
-    if (has_left && lane < 48) { const int r = lane / 3, c = lane % 3 - 3; reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c] = (PX)DY(c, r); }
-    if (has_top && lane < 48) { const int r = lane / 16 - 3, c = lane & 15; reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd)[16 * mb_x + c] = (PX)DY(c, r); }
-    for (int p = 0; p < 2; p++) {
-        for (int i = lane; i < 8 * F::CH; i += 64)
-            reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + (i >> 3)) * cd)[8 * mb_x + (i & 7)] = (PX)DC(p, i & 7, i >> 3);
-        if (has_left && lane < F::CH) reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + lane) * cd)[8 * mb_x - 1] = (PX)DC(p, -1, lane);
-        if (has_top && lane < 8) reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd)[8 * mb_x + lane] = (PX)DC(p, lane, -1);
+    if (ok) {
+        wide_st_row<PX, 16>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
+        if (has_left) { PX *q = reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd) + 16 * mb_x; q[-3] = (PX)DY(-3, l); q[-2] = (PX)DY(-2, l); q[-1] = (PX)DY(-1, l); }
+        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
+        for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
+            const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
+            wide_st_row<PX, 8>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
+            if (has_left) (reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd) + 8 * mb_x)[-1] = (PX)DC(p, -1, r);
+        }
+        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
     }
 }
 #undef DY
@@ -746,7 +825,7 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
         }
     if (passes & 4)
         for (int d = 0; d <= (mw - 1) + 2 * (mh - 1); d++)
-            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3((unsigned)(nframes * mh)), dim3(64), 0, st, d_frames, d, mh);
+            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3((unsigned)(((nframes + 3) / 4) * mh)), dim3(64), 0, st, d_frames, nframes, d, mh);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
