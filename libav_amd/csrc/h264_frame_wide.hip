@@ -250,19 +250,20 @@ struct WideInterLds {
     int32_t coef[512];
     uint16_t py[256], pc[2][128], qy[256], qc[2][128];
     uint16_t win[2 * CWIN + 8];     /* >= 21 * WP */
+    int16_t tmp[21 * 16];           /* the horizontal pass of the 2-D quarter positions: rows -2..h+2 of the block */
     int32_t t8[4][64];
 };
 
 /* one luma sample at quarter position (mx, my): h264qpel_template.c:77-300 as the standard writes it; the first pass of the 2-D
  * positions is kept in 16 bits around the reference's bias (:119-146), so that samples outside the bit depth's range wrap as they do there */
-__device__ inline int wide_qpel_px(const uint16_t *win, int x, int y, int mx, int my, int maxv)
+__device__ inline int wide_qpel_px(const uint16_t *win, const int16_t *tmp, int x, int y, int mx, int my, int maxv)
 {
 #define S(xx, yy) ((int)win[((yy) + 2) * WP + (xx) + 2])
     auto rawh = [&](int xx, int yy) { return tap6(S(xx - 2, yy), S(xx - 1, yy), S(xx, yy), S(xx + 1, yy), S(xx + 2, yy), S(xx + 3, yy)); };
     auto hh = [&](int xx, int yy) { return clip3((rawh(xx, yy) + 16) >> 5, 0, maxv); };
     auto vv = [&](int xx, int yy) { return clip3((tap6(S(xx, yy - 2), S(xx, yy - 1), S(xx, yy), S(xx, yy + 1), S(xx, yy + 2), S(xx, yy + 3)) + 16) >> 5, 0, maxv); };
     const int pad = maxv > 511 ? -10 * maxv : 0;
-    auto tmph = [&](int xx, int yy) { return (int)(int16_t)(rawh(xx, yy) + pad) - pad; };
+    auto tmph = [&](int xx, int yy) { return (int)tmp[(yy + 2) * 16 + xx] - pad; };      /* (int16_t)(rawh + pad), stored by the caller */
     auto hv = [&](int xx, int yy) {
         return clip3((tap6(tmph(xx, yy - 2), tmph(xx, yy - 1), tmph(xx, yy), tmph(xx, yy + 1), tmph(xx, yy + 2), tmph(xx, yy + 3)) + 512) >> 10, 0, maxv);
     };
@@ -311,9 +312,19 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
             s.win[r * WP + c] = reinterpret_cast<const PX *>(rp[0] + (size_t)yy * fr.dst_stride[0])[xx];
         }
         MI355_WAVE_SYNC();
+        if (((mx & 3) == 2 && (my & 3)) || ((my & 3) == 2 && (mx & 3))) {
+            /* the 2-D positions: the horizontal 6-tap sums of rows -2..h+2 once, in 16 bits around the reference's bias (h264qpel_template.c:119-146) */
+            const int pad = F::MAXV > 511 ? -10 * F::MAXV : 0;
+            for (int i = lane; i < w * (h + 5); i += 64) {
+                const int r = i >> lw, x = i & (w - 1);
+                const uint16_t *q = s.win + r * WP + x;
+                s.tmp[r * 16 + x] = (int16_t)(tap6(q[0], q[1], q[2], q[3], q[4], q[5]) + pad);
+            }
+            MI355_WAVE_SYNC();
+        }
         for (int i = lane; i < w * h; i += 64) {
             const int y = i >> lw, x = i & (w - 1);
-            const int v = wide_qpel_px(s.win, x, y, mx & 3, my & 3, F::MAXV);
+            const int v = wide_qpel_px(s.win, s.tmp, x, y, mx & 3, my & 3, F::MAXV);
             uint16_t *d = dy + (by + y) * 16 + bx + x;
             *d = (uint16_t)(avg ? f2(*d, v) : v);
         }
@@ -655,8 +666,12 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
     typedef typename F::PX PX;
     constexpr int PXB = (int)sizeof(PX);
     __shared__ WideDbLds sh[4];
+    /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane at every edge — from memory that is a dependent
+     * load of a microsecond in each of its sixteen steps */
+    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
     WideDbLds &s = sh[g];
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
     const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, mb_x = d - 2 * mb_y;
     const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
     const bool ok = f < nframes && mb_y < fr.mb_height && mb_x >= 0 && mb_x < fr.mb_width;
@@ -686,7 +701,10 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
     MI355_WAVE_SYNC();
     const mi355_h264_mb &m = s.m[0];
     const bool filter = ok && !(m.flags & MI355_MBF_NO_DEBLOCK);
+    int list_count = 1;
+    const int ylim = fr.field_picture ? 2 : 4;
     if (filter) {
+        list_count = fr.slices[m.slice_id].list_count;      /* in flight with the vectors below */
         /* the motion and coefficient flags the strengths are derived from (fill_filter_caches, h264_slice.c:2056-2196): lane l its own
          * 4x4 block, lanes 0..3 / 4..7 also a block of the left neighbour's last column / the top neighbour's last row */
         for (int k = 0; k < 2; k++) {
@@ -709,7 +727,6 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
         /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane l = 4 * edge + i, both directions */
         const uint32_t t = m.mb_type;
         const int edge = l >> 2, i = l & 3, tk = (t >> 3) & 7;
-        const int list_count = fr.slices[m.slice_id].list_count, ylim = fr.field_picture ? 2 : 4;
         for (int dir = 0; dir < 2; dir++) {
             const int mask_edge = dir == 0 ? (tk == 0 ? 0 : (tk < 4 ? 3 : 1)) : (tk == 0 ? 0 : (tk == 1 ? 3 : (tk < 4 ? 1 : 3)));
             const int edges = (mask_edge == 3 && !(m.cbp & 15)) ? 1 : 4;
@@ -747,9 +764,9 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
         auto chroma_line = [&](int p, uint16_t *q, int st, int bs, int edge, const mi355_h264_mb &mm) {
             const int qp = edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p];
             const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-            const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+            const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
             int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
+            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
             else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
             q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
         };
@@ -763,12 +780,12 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
                     if (luma_on && bs) {
                         const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
                         const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-                        const int alpha = kw_alpha[ia] << (BD - 8), beta = kw_beta[ib] << (BD - 8);
+                        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
                         uint16_t *q = dir == 0 ? &DY(4 * edge, l) : &DY(l, 4 * edge);
                         const int st = dir == 0 ? 1 : DYP;
                         if (bs < 4) {
                             int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
-                            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, kw_tc0[ia][bs - 1] * (1 << (BD - 8)));
+                            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
                             q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
                         } else {
                             int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
