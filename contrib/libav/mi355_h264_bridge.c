@@ -155,6 +155,7 @@ typedef struct Bridge {
     int open;                   /* a picture is being packed */
     DevPic pics[BR_MAX_PICS];
     int c444, npass;            /* 4:4:4: three passes (planes) per picture */
+    int bypass;                 /* sps->transform_bypass: macroblocks with qscale 0 are lossless (MI355_MBF_BYPASS) */
     int wide;                   /* the sequence's format goes through the second kernel set (mi355_h264_decode_frames_wide_dev): more than 8 bits or 4:2:2 */
     int bit_depth, idc;         /* sps->bit_depth_luma, sps->chroma_format_idc of the sequence the bridge is set up for */
     int kidc;                   /* the chroma format the kernels see: idc, or 1 for 4:4:4 (planes in the luma role, scratch chroma) */
@@ -488,7 +489,7 @@ void __wrap_ff_h264_flush_change(H264Context *h)
         const SPS *sps = h->ps.sps;
         const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == b->bit_depth &&
                          sps->chroma_format_idc == b->idc &&
-                         !sps->transform_bypass && !sps->residual_color_transform_flag &&
+                         !sps->transform_bypass == !b->bypass && !sps->residual_color_transform_flag &&
                          (!b->tiled || sps->frame_mbs_only_flag);        /* tiled device pictures hold frames only */
         if (!same) { bridge_release(b); b->state = 0; }
     } else if (b && b->state < 0 && b->soft) {
@@ -532,8 +533,8 @@ static Bridge *bridge_get(const H264Context *h)
     /* a sequence that may hold field MACROBLOCKS (mb_adaptive_frame_field_flag) is outside the path as a whole; field PICTURES
      * (PAFF: the choice between a frame and two fields is made per picture) are inside: begin_picture() looks at each one */
     if ((!h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff) || FRAME_MBAFF(h) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
-        (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || h->ps.sps->transform_bypass || getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2)) {
-        br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4 frame or field pictures without MBAFF and transform bypass)");
+        (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || (getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2 || h->ps.sps->transform_bypass))) {
+        br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4 frame or field pictures without MBAFF)");
         b->soft = 1;
         return b;
     }
@@ -565,7 +566,8 @@ static Bridge *bridge_get(const H264Context *h)
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
     b->bit_depth = h->ps.sps->bit_depth_luma; b->idc = idc; b->kidc = idc == 3 ? 1 : idc;
-    b->wide = b->bit_depth > 8 || idc == 2;
+    b->wide = b->bit_depth > 8 || idc == 2 || h->ps.sps->transform_bypass;      /* transform bypass: the second kernel set knows it, the first does not */
+    b->bypass = h->ps.sps->transform_bypass;
     b->px = b->bit_depth > 8 ? 2 : 1; b->csize = b->bit_depth > 8 ? 4 : 2;
     b->crows = idc == 2 ? 16 : 8; b->ncoef = idc == 2 ? 512 : 384;
     /* frame_num gaps: the decoder fills a lost frame with a host-side copy of the previous one (h264_slice.c:1425-1452) — every
@@ -774,6 +776,9 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
     return b->nslices++;
 }
 
+/* where level k of sl->mb_luma_dc goes in a transform-bypass Intra16x16 macroblock: dc_mapping[] of hl_decode_mb_predict_luma (h264_mb.c:712-718) */
+static const uint16_t br_dc_mapping[16] = { 0 * 16, 1 * 16, 4 * 16, 5 * 16, 2 * 16, 3 * 16, 6 * 16, 7 * 16, 8 * 16, 9 * 16, 12 * 16, 13 * 16, 10 * 16, 11 * 16, 14 * 16, 15 * 16 };
+
 /* I_PCM samples for the second kernel set, one per coefficient slot: samples `first` .. `first + n - 1` of the macroblock's PCM payload —
  * bytes at 8 bits, bit_depth-wide big-endian fields otherwise (h264_mb_template.c:99-153) */
 static void pcm_unpack(const Bridge *b, const uint8_t *src, int first, int n, uint8_t *cf)
@@ -820,7 +825,8 @@ static void pack_planes_444(const H264Context *h, H264SliceContext *sl, Staging 
             }
             if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX + p]]) {
                 m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
-                for (int k = 0; k < 16; k++) memcpy(cf + (size_t)mi355_luma_dc_slot(k) * cs, (const uint8_t *)sl->mb_luma_dc[p] + (size_t)k * cs, (size_t)cs);
+                for (int k = 0; k < 16; k++)
+                    memcpy(cf + (size_t)((m0->flags & MI355_MBF_BYPASS) ? br_dc_mapping[k] : mi355_luma_dc_slot(k)) * cs, (const uint8_t *)sl->mb_luma_dc[p] + (size_t)k * cs, (size_t)cs);
             }
         }
         /* the loop filter derives the boundary strengths of every plane from the luma coefficient flags */
@@ -863,6 +869,8 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         if (mb_row > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - (h->mb_stride << b->field)] == sl->slice_num)) m->flags |= MI355_MBF_TOP_EDGE;
     }
     if (sl->pwt.use_weight) m->flags |= MI355_MBF_WEIGHTED;
+    const int bypass = b->bypass && sl->qscale == 0;                  /* h264_mb_template.c:51 */
+    if (bypass) m->flags |= MI355_MBF_BYPASS | (h->ps.sps->profile_idc == 244 ? MI355_MBF_BYPASS_PRED : 0) | (h->x264_build < 151U ? MI355_MBF_BYPASS_X264OLD : 0);
     m->intra16x16_pred_mode = (uint8_t)sl->intra16x16_pred_mode;
     m->chroma_pred_mode = (uint8_t)sl->chroma_pred_mode;
     m->topleft_samples_available = (uint16_t)sl->topleft_samples_available;
@@ -898,7 +906,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         } else if (reads_coefs) memset(cf, 0, 256 * cs);
         if (IS_INTRA16x16(mb_type) && sl->non_zero_count_cache[scan8[LUMA_DC_BLOCK_INDEX]]) {
             m->nnz_mask |= 1u << MI355_NNZ_LUMA_DC;
-            for (int k = 0; k < 16; k++) memcpy(cf + (size_t)mi355_luma_dc_slot(k) * cs, (const uint8_t *)sl->mb_luma_dc[0] + k * cs, cs);
+            for (int k = 0; k < 16; k++) memcpy(cf + (size_t)(bypass ? br_dc_mapping[k] : mi355_luma_dc_slot(k)) * cs, (const uint8_t *)sl->mb_luma_dc[0] + k * cs, cs);
         }
         if (cbp & 0x30) {
             memcpy(cf + 256 * cs, mbp + 256 * cs, ncc * cs);

@@ -51,6 +51,14 @@ extern "C" {
 #define MI355_MBF_TOP_EDGE   0x02  /* same for the top edge (sl->top_type != 0) */
 #define MI355_MBF_NO_DEBLOCK 0x04  /* sl->deblocking_filter == 0 for this MB's slice: copy only */
 #define MI355_MBF_WEIGHTED   0x08  /* sl->pwt.use_weight != 0: the slice table must be consulted for MC */
+/* transform bypass (read by mi355_h264_decode_frames_wide_dev only — the 8-bit kernels never see such pictures) */
+#define MI355_MBF_BYPASS     0x10  /* sl->qscale == 0 && sps->transform_bypass: the coefficients are the residual itself, added without
+                                      a transform and without clipping (h264_mb_template.c:51, h264addpx_template.c:30-72); the Intra16x16
+                                      DC levels then sit at the reference's dc_mapping[] slots (h264_mb.c:706-722), not at mi355_luma_dc_slot() */
+#define MI355_MBF_BYPASS_PRED 0x20 /* ... in a High 4:4:4 Predictive stream (sps->profile_idc == 244): vertical / horizontal intra prediction
+                                      becomes the running sum of the pred*_add functions (h264pred_template.c:1127-1354; h264_mb.c:636, :668, :737) */
+#define MI355_MBF_BYPASS_X264OLD 0x40 /* ... decoded with h->x264_build < 151: Intra 8x8 sums start from the UNFILTERED edge (pred8x8l_add
+                                      instead of pred8x8l_filter_add, h264_mb.c:637-643) */
 
 /* mi355_h264_mb.sub_mb_type[i] (only for MI355_MB_8x8): shape of 8x8 quadrant i */
 #define MI355_SUB_8x8  0

@@ -196,6 +196,52 @@ __device__ inline void wide_chroma_dc(int32_t *c, int qmul)       /* c: the plan
     }
 }
 
+/* ---- transform bypass (sl->qscale == 0 in a sequence with qpprime_y_zero_transform_bypass_flag) ----------------------------------------------
+ * the coefficients are the residual: added sample by sample, no transform, no clipping — the sum wraps like the sample type (`pixel`),
+ * h264addpx_template.c:30-72.  Blocks without coefficients hold zeros, so every block is added. */
+template <int BD, int CF>
+__device__ __forceinline__ uint16_t wide_wrap(int v) { return (uint16_t)(typename Fmt<BD, CF>::PX)v; }
+/* nblocks 4x4 blocks (lane 4 * b + row) or 8x8 blocks (lane 8 * b + row) of one plane */
+template <int BD, int CF>
+__device__ inline void wide_add_raw(const int32_t *coef, int nblocks, int size, bool chroma, uint16_t *dst, int pitch)
+{
+    const int lane = lane_id();
+    if (size == 4) {
+        const int b = lane >> 2, q = lane & 3;
+        if (b < nblocks) {
+            const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
+            uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
+            for (int k = 0; k < 4; k++) d[k] = wide_wrap<BD, CF>(d[k] + coef[16 * b + 4 * q + k]);
+        }
+    } else {
+        const int b = lane >> 3, q = lane & 7;
+        if (b < nblocks) {
+            uint16_t *d = dst + (8 * (b >> 1) + q) * pitch + 8 * (b & 1);
+            for (int k = 0; k < 8; k++) d[k] = wide_wrap<BD, CF>(d[k] + coef[64 * b + 8 * q + k]);
+        }
+    }
+    MI355_WAVE_SYNC();
+}
+/* the running sums of the lossless vertical / horizontal predictors over an n_cols x n_rows region whose 4x4 blocks lie in `coef` as the
+ * plane's blocks (pred4x4_*_add chained by pred16x16_*_add / pred8x8_*_add / pred8x16_*_add, h264pred_template.c:1209-1354: a block starts
+ * from the sample above / left of it, which the block before it has just written — one sum down each column / along each row).
+ * start(k): the sample above column k / left of row k.  Lanes 0..n-1. */
+template <int BD, int CF, typename Start>
+__device__ inline void wide_lossless_run(const int32_t *coef, bool chroma, bool vertical, int n_cols, int n_rows, uint16_t *dst, int pitch, Start start)
+{
+    const int lane = lane_id();
+    if (lane < (vertical ? n_cols : n_rows)) {
+        int v = start(lane);
+        for (int k = 0; k < (vertical ? n_rows : n_cols); k++) {
+            const int x = vertical ? lane : k, y = vertical ? k : lane, x4 = x >> 2, y4 = y >> 2;
+            const int b = chroma ? x4 + 2 * (y4 & 1) + 4 * (y4 >> 1) : blk_index(x4, y4);
+            v = wide_wrap<BD, CF>(v + coef[16 * b + 4 * (y & 3) + (x & 3)]);
+            dst[y * pitch + x] = (uint16_t)v;
+        }
+    }
+    MI355_WAVE_SYNC();
+}
+
 /* The chroma residual of a macroblock (h264_mb_template.c:225-257): DC transforms where the record says DC levels were coded, then
  * every block through wide_block4 — idct_add8's choice between idct_add, idct_dc_add and nothing (h264idct_template.c:203-238) read off the
  * coefficients themselves (a chroma block's count is the count of its AC coefficients).  cb / cr: the planes' 8 x CH tiles. */
@@ -205,6 +251,18 @@ __device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &
     typedef Fmt<BD, CF> F;
     if (!(h.cbp & 0x30)) return;
     const int lane = lane_id();
+    if (h.flags & MI355_MBF_BYPASS) {            /* h264_mb_template.c:199-224 */
+        for (int p = 0; p < 2; p++) {
+            const int32_t *c = coef + 256 + 16 * F::NCB * p;
+            uint16_t *d = p ? cr : cb;
+            if ((h.mb_type & MI355_MB_INTRA) && (h.flags & MI355_MBF_BYPASS_PRED) && (h.chroma_pred_mode == 1 || h.chroma_pred_mode == 2)) {
+                const bool vertical = h.chroma_pred_mode == 2;           /* VERT_PRED8x8 = 2, HOR_PRED8x8 = 1 */
+                wide_lossless_run<BD, CF>(c, true, vertical, 8, F::CH, d, pitch, [&](int k) { return (int)(vertical ? d[-pitch + k] : d[k * pitch - 1]); });
+            } else
+                wide_add_raw<BD, CF>(c, F::NCB, 4, true, d, pitch);
+        }
+        return;
+    }
     if (lane < 2 && ((h.nnz_mask >> (MI355_NNZ_CB_DC + lane)) & 1))
         wide_chroma_dc<typename F::COEF, CF>(coef + 256 + 16 * F::NCB * lane, (int)h.dc_qmul[1 + lane]);
     MI355_WAVE_SYNC();
@@ -482,7 +540,8 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
     /* hl_decode_mb_idct_luma (h264_mb.c:726-795): idct_add16 / idct8_add4 choose between full, DC-only and nothing per block; so does
      * wide_block4 / wide_add_blocks8, from the coefficients (a block whose count is 1 with a DC level holds nothing else) */
     if (luma_coded) {
-        if (t & MI355_MB_8x8DCT) wide_add_blocks8<BD, CF>(s.coef, s.t8, 0, 4, s.py, 16);
+        if (s.hdr.flags & MI355_MBF_BYPASS) wide_add_raw<BD, CF>(s.coef, (t & MI355_MB_8x8DCT) ? 4 : 16, (t & MI355_MB_8x8DCT) ? 8 : 4, false, s.py, 16);
+        else if (t & MI355_MB_8x8DCT) wide_add_blocks8<BD, CF>(s.coef, s.t8, 0, 4, s.py, 16);
         else wide_add_blocks4<BD, CF>(s.coef, 16, false, s.py, 16);
     }
     wide_residual_chroma<BD, CF>(s.coef, s.hdr, s.pc[0], s.pc[1], 8);
@@ -523,6 +582,7 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
     wide_load_coefs<BD, CF>(s.coef, fr, mb_xy);
     const mi355_h264_mb &h = s.hdr;
     const uint32_t t = h.mb_type;
+    const bool bypass = (h.flags & MI355_MBF_BYPASS) != 0, bypass_pred = (h.flags & MI355_MBF_BYPASS_PRED) != 0, x264old = (h.flags & MI355_MBF_BYPASS_X264OLD) != 0;
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:101-153: the samples themselves, one per coefficient slot: Y, Cb, Cr */
         for (int i = lane; i < 256; i += 64) WTILE(i & 15, i >> 4) = (uint16_t)s.coef[i];
         for (int i = lane; i < 8 * F::CH; i += 64) { WCTILE(0, i & 7, i >> 3) = (uint16_t)s.coef[256 + i]; WCTILE(1, i & 7, i >> 3) = (uint16_t)s.coef[256 + 8 * F::CH + i]; }
@@ -556,17 +616,43 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
         if (lane >= 32 && lane < 49) s.ps.L[lane - 32] = WTILE(-1, lane - 33);
         MI355_WAVE_SYNC();
         intra_pred_wave<uint16_t, BD>(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &WTILE(0, 0), TPW);
+        if (bypass) {                     /* h264_mb.c:712-722 (the DC levels are in their blocks already), :733-750 */
+            if (bypass_pred && (h.intra16x16_pred_mode == 1 || h.intra16x16_pred_mode == 2)) {
+                const bool vertical = h.intra16x16_pred_mode == 2;
+                wide_lossless_run<BD, CF>(s.coef, false, vertical, 16, 16, &WTILE(0, 0), TPW, [&](int k) { return (int)(vertical ? WTILE(k, -1) : WTILE(-1, k)); });
+            } else
+                wide_add_raw<BD, CF>(s.coef, 16, 4, false, &WTILE(0, 0), TPW);
+        } else {
         if (lane == 0 && ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1)) wide_luma_dc<typename F::COEF>(s.coef, (int)h.dc_qmul[0]);
         MI355_WAVE_SYNC();
         wide_add_blocks4<BD, CF>(s.coef, 16, false, &WTILE(0, 0), TPW);      /* idct_add16intra: full, DC-only or nothing per block */
+        }
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
         for (int i8 = 0; i8 < 4; i8++) {
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
             if (lane < 17) s.ps.T[lane] = WTILE(x0 + lane - 1, y0 - 1);
             if (lane >= 32 && lane < 41) s.ps.L[lane - 32] = WTILE(x0 - 1, y0 + lane - 33);
             MI355_WAVE_SYNC();
-            intra_pred_wave<uint16_t, BD>(s.ps, 1, h.u.intra4x4_pred_mode[i], (h.topleft_samples_available << i) & 0x8000,
+            const int dir = h.u.intra4x4_pred_mode[i];
+            intra_pred_wave<uint16_t, BD>(s.ps, 1, dir, (h.topleft_samples_available << i) & 0x8000,
                                           (h.topright_samples_available << i) & 0x4000, &WTILE(x0, y0), TPW);
+            if (bypass) {                 /* h264_mb.c:628-643: the sums start from the filtered edge the predictor has just left in s.ps (pred8x8l_*_filter_add), or — x264 before build 151 — from the samples themselves */
+                if (bypass_pred && (dir == 0 || dir == 1)) {
+                    if (lane < 8) {
+                        const bool vertical = dir == 0;
+                        int v = x264old ? (int)(vertical ? WTILE(x0 + lane, y0 - 1) : WTILE(x0 - 1, y0 + lane)) : (int)(vertical ? s.ps.fT[1 + lane] : s.ps.fL[1 + lane]);
+                        for (int k = 0; k < 8; k++) {
+                            const int x = vertical ? lane : k, y = vertical ? k : lane;
+                            v = wide_wrap<BD, CF>(v + s.coef[64 * i8 + 8 * y + x]);
+                            WTILE(x0 + x, y0 + y) = (uint16_t)v;
+                        }
+                    }
+                    MI355_WAVE_SYNC();
+                } else {
+                    if (lane < 8) for (int k = 0; k < 8; k++) WTILE(x0 + k, y0 + lane) = wide_wrap<BD, CF>(WTILE(x0 + k, y0 + lane) + s.coef[64 * i8 + 8 * lane + k]);
+                    MI355_WAVE_SYNC();
+                }
+            } else
             wide_add_blocks8<BD, CF>(s.coef, s.t8, i8, 1, &WTILE(0, 0), TPW);
         }
     } else {                              /* Intra 4x4: h264_mb.c:657-700 */
@@ -577,7 +663,22 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
             else if (lane < 9) s.ps.T[lane] = tr_ok ? WTILE(x0 + lane - 1, y0 - 1) : WTILE(x0 + 3, y0 - 1);
             if (lane >= 32 && lane < 37) s.ps.L[lane - 32] = WTILE(x0 - 1, y0 + lane - 33);
             MI355_WAVE_SYNC();
-            intra_pred_wave<uint16_t, BD>(s.ps, 0, h.u.intra4x4_pred_mode[i], 0, 0, &WTILE(x0, y0), TPW);
+            const int dir = h.u.intra4x4_pred_mode[i];
+            intra_pred_wave<uint16_t, BD>(s.ps, 0, dir, 0, 0, &WTILE(x0, y0), TPW);
+            if (bypass) {                 /* h264_mb.c:665-669, :690-698 */
+                if (lane < 4) {
+                    if (bypass_pred && (dir == 0 || dir == 1)) {
+                        const bool vertical = dir == 0;
+                        int v = vertical ? WTILE(x0 + lane, y0 - 1) : WTILE(x0 - 1, y0 + lane);
+                        for (int k = 0; k < 4; k++) {
+                            const int x = vertical ? lane : k, y = vertical ? k : lane;
+                            v = wide_wrap<BD, CF>(v + s.coef[16 * i + 4 * y + x]);
+                            WTILE(x0 + x, y0 + y) = (uint16_t)v;
+                        }
+                    } else
+                        for (int k = 0; k < 4; k++) WTILE(x0 + k, y0 + lane) = wide_wrap<BD, CF>(WTILE(x0 + k, y0 + lane) + s.coef[16 * i + 4 * lane + k]);
+                }
+            } else
             if (lane < 4) {
                 int r[16];
                 if (wide_block4<typename F::COEF>(s.coef + 16 * i, r)) {

@@ -86,9 +86,9 @@ def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
 
 
 @needs_harness
-@pytest.mark.parametrize("name,no_wide", [(n, False) for n in SY.OUTSIDE] + [(n, True) for n in ("422_8_b", "420_10_t8x8", "444_10", "422_10_paff")])
+@pytest.mark.parametrize("name,no_wide", [(n, False) for n in SY.OUTSIDE] + [(n, True) for n in ("422_8_b", "420_10_t8x8", "444_10", "422_10_paff", "420_8_lossless", "444_8_lossless", "422_10_lossless")])
 def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name, no_wide):
-    """MBAFF, transform bypass (and High 4:2:2, 9 / 10 bit when the second kernel set is switched off): the bridge says so once and the
+    """MBAFF (and High 4:2:2, 9 / 10 bit, transform bypass when the second kernel set is switched off): the bridge says so once and the
     reference's C path decodes the stream — same pictures, nothing on the device"""
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
