@@ -300,9 +300,16 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=layout_tiled)
         try:
             conv = detile_jobs(lib, dev, fs, F) if detile else None
+            # a batch of I pictures: the host knows (slice types) that no picture holds an inter macroblock and does not launch that pass
+            # (what the bridge's dispatcher does for such a launch set); the descriptors say the same (MI355_FRAME_NO_INTER)
+            no_inter = all(int(fs.intra_start[g][-1]) == fs.mb_w * fs.mb_h for g in range(fs.F))
+
+            def inter():
+                if not no_inter:
+                    assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
 
             def once():
-                assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
+                inter()
                 assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
                 assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
                 if conv is not None:
@@ -317,7 +324,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             # one more step with an event after every pass: where the step's time goes
             ev = [lib.mi355_event_create() for _ in range(4)]
             lib.mi355_event_record(ev[0], None)
-            assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
+            inter()
             lib.mi355_event_record(ev[1], None)
             assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
             lib.mi355_event_record(ev[2], None)
@@ -346,7 +353,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
     run("config2_f512", base, 512, "512 pictures per step")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
-    run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra" % intra.max_intra_level)
+    run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra; the inter pass is not launched for a batch of I pictures" % intra.max_intra_level)
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
@@ -473,9 +480,12 @@ def h264_real_stream_points(lib):
     import tempfile
     out = []
     exe = os.path.join(ROOT, "oracle", "_ref", "h264_bridge_gpu")
-    src = os.path.join(ROOT, "tests", "golden", "h264_synth_1080p.samples")
-    if os.path.exists(exe) and os.path.exists(src):
-        pt = {"name": "h264_bridge_1080p_x64", "what": "reference H.264 decoder + Tier-2 bridge, 64 decoder threads, generated 1080p stream, 3 passes each"}
+    for name, fn, what in (("h264_bridge_1080p_x64", "h264_synth_1080p.samples", "generated 1080p stream"),
+                           ("h264_bridge_high10_1080p_x64", "h264_synth_1080p_high10.samples", "the same stream as High 10 (10-bit samples: the second kernel set)")):
+        src = os.path.join(ROOT, "tests", "golden", fn)
+        if not (os.path.exists(exe) and os.path.exists(src)):
+            continue
+        pt = {"name": name, "what": "reference H.264 decoder + Tier-2 bridge, 64 decoder threads, %s, 3 passes each" % what}
         for key, env in (("bridge", {}), ("reference_c_decoder", {"MI355_BRIDGE_PLAIN": "1"})):
             e = dict(os.environ)
             e.pop("MI355_BRIDGE_PLAIN", None)

@@ -323,11 +323,13 @@ static int disp_enqueue(Disp *D, int slot)
     mi355_h264_frame *dr = D->d_desc[slot], *dd = D->d_desc[slot] + nd;
     rc |= mi355_memcpy_h2d_async(dr, hr, 2 * (size_t)nd * sizeof(mi355_h264_frame), st);
     const Bridge *b0 = D->in[slot][0]->b;
-    if (b0->wide) {      /* High 10 / High 4:2:2: the second kernel set, reconstruction and loop filter from their descriptor arrays */
-        if (!rc && mi355_h264_decode_frames_wide_dev(dr, nd, mw, mh, maxl, D->widths, b0->bit_depth, b0->kidc, 3, st) != 0) rc = -1;
+    int any_inter = 0;          /* a launch set of I pictures: the inter pass would launch a wave per macroblock to find nothing */
+    for (int k = 0; k < nd; k++) any_inter |= !(hr[k].flags & MI355_FRAME_NO_INTER);
+    if (b0->wide) {      /* High 10 / High 4:2:2 / transform bypass: the second kernel set, reconstruction and loop filter from their descriptor arrays */
+        if (!rc && mi355_h264_decode_frames_wide_dev(dr, nd, mw, mh, maxl, D->widths, b0->bit_depth, b0->kidc, any_inter ? 3 : 2, st) != 0) rc = -1;
         if (!rc && mi355_h264_decode_frames_wide_dev(dd, nd, mw, mh, 0, NULL, b0->bit_depth, b0->kidc, 4, st) != 0) rc = -1;
     } else {
-    if (!rc && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
+    if (!rc && any_inter && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_layouts_dev(dd, nd, mw, mh, layouts, st) != 0) rc = -1;      /* the loop filter's kernel(s) for the layouts this batch holds */
     }

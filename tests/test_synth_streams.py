@@ -237,3 +237,25 @@ def test_bridge_through_the_session_facade_emulated(tmp_path, emu, name):
     st = SY.run_bridge("h264_bridge_emu", name, out, session=True)
     assert st.get("pictures_on_device") == SY.ON_DEVICE.get(name, SY.MD5[name]["pictures"]) and st.get("launch_sets") == 0, st
     SY.check_md5(out, name)
+
+
+@needs_harness
+def test_bridge_decodes_1080p_high10_stream_emulated(tmp_path, emu):
+    """tests/golden/h264_synth_1080p_high10.samples (tools/make_1080p_stream.py: 120 x 68 macroblocks, I / P / B with implicit weights, four slices,
+    8x8 transform, three references, 10-bit samples): every picture through the second kernel set on the emulator = the reference decoder's own output"""
+    import hashlib
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    src = os.path.join(SY.GOLD, "h264_synth_1080p_high10.samples")
+    md5 = {}
+    for mode, env in (("plain", {"MI355_BRIDGE_PLAIN": "1"}), ("bridge", {})):
+        e = dict(os.environ)
+        e.pop("MI355_BRIDGE_PLAIN", None)
+        e.update(env)
+        out = tmp_path / (mode + ".yuv")
+        r = subprocess.run([SY.exe("h264_bridge_emu"), src, str(out), "1", "1"], capture_output=True, text=True, env=e, timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        st = json.loads(r.stdout.strip().splitlines()[-1])
+        assert st["pictures_output"] == 10 and st["pictures_on_device"] == (10 if mode == "bridge" else 0), st
+        md5[mode] = hashlib.md5(open(out, "rb").read()).hexdigest()
+    assert md5["plain"] == md5["bridge"]

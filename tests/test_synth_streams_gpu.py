@@ -94,3 +94,26 @@ def test_bridge_sequence_changes_with_several_decoders_gpu(tmp_path, mi355, name
     st = SY.run_bridge("h264_bridge_gpu", name, out, threads=6, loops=3)
     assert st.get("pictures_on_device") == 18 * on_device and st.get("pictures_output") == 18 * SY.MD5[name]["pictures"], st
     SY.check_md5(out, name)
+
+
+@pytest.mark.parametrize("fn", ("h264_synth_1080p.samples", "h264_synth_1080p_high10.samples"))
+def test_bridge_decodes_1080p_streams_gpu(tmp_path, mi355, fn):
+    """the generated 1080p streams bench.py's real-stream points decode (8 bit: first kernel set, tiled surfaces; High 10: second kernel set), four
+    decoder threads: the bridge's pictures = the same binary's with everything left to the reference's C functions"""
+    import hashlib
+    import json
+    import subprocess
+    _need("h264_bridge_gpu")
+    src = os.path.join(SY.GOLD, fn)
+    md5 = {}
+    for mode, env in (("plain", {"MI355_BRIDGE_PLAIN": "1"}), ("bridge", {})):
+        e = dict(os.environ)
+        e.pop("MI355_BRIDGE_PLAIN", None)
+        e.update(env)
+        out = tmp_path / (mode + ".yuv")
+        r = subprocess.run([SY.exe("h264_bridge_gpu"), src, str(out), "4", "1"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        st = json.loads(r.stdout.strip().splitlines()[-1])
+        assert st["pictures_output"] == 40 and st["pictures_on_device"] == (40 if mode == "bridge" else 0), st
+        md5[mode] = hashlib.md5(open(out, "rb").read()).hexdigest()
+    assert md5["plain"] == md5["bridge"]
