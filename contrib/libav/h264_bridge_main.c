@@ -56,6 +56,7 @@ static void *decode_thread(void *vp)
         c->extradata_size = (int)el;
         memcpy(c->extradata, p, el); p += el;
         c->thread_count = 1;
+        if (getenv("MI355_HARNESS_SKIP_LOOP_FILTER")) c->skip_loop_filter = AVDISCARD_ALL;      /* developer switch: both sides without the in-loop filter */
         c->flags |= AV_CODEC_FLAG_BITEXACT;
         pthread_mutex_lock(&open_lock);
         const int opened = avcodec_open2(c, &ff_h264_decoder, NULL);
