@@ -131,10 +131,16 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
     uint8_t *out;               /* pinned: the decoded picture as it comes back (planes with line strides, back to back) */
     DevPic *pic;                /* the picture this set was submitted for */
     int field, parity;          /* it was a field picture: only the lines of its parity go to the frame */
+    int nmb_pic, nslices, uses_l1;  /* of the picture submitted from this set (side_upload) */
     mi355_surface_job *cvt;     /* pinned, direct mode with tiled device pictures: the conversion job of the copy-back */
     uint8_t *frame_data[3];     /* where it goes: the AVFrame the decoder will hand out */
     int frame_linesize[3];
     mi355_h264_frame *d_desc;   /* direct mode: the descriptors on the device */
+    /* the second kernel set's loop filter is one launch per anti-diagonal and reads a macroblock's record and vectors (and its neighbours') in
+     * every one of them: those go to HBM first (1.5 MB per 1080p picture; over PCIe each of the ~250 launches of a picture waited for three
+     * dependent round trips); everything that is read once (coefficients, the reconstruction's records) stays where the decoder wrote it */
+    uint8_t *d_side;            /* one allocation: mbd[npass], mv[2], slices[npass] */
+    size_t side_off_mbd[BR_MAX_PASSES], side_off_mv[2], side_off_sl[BR_MAX_PASSES];
     void *done;                 /* direct mode: event after the copy into `out` */
     Submission sub;             /* batched mode */
     int in_flight;
@@ -242,6 +248,13 @@ static int staging_alloc(Bridge *b, Staging *s)
     s->widths = malloc(nlev * 4);
     s->out = mi355_host_alloc(out_bytes(b));
     if (b->direct) { s->done = mi355_event_create(); s->d_desc = dalloc(2 * BR_MAX_PASSES * sizeof(mi355_h264_frame)); s->cvt = mi355_host_alloc(sizeof(mi355_surface_job)); }
+    if (b->wide) {
+        size_t d = 0;
+        for (int p = 0; p < np; p++) { s->side_off_mbd[p] = d; d = up64(d + n * sizeof(mi355_h264_mb)); s->side_off_sl[p] = d; d = up64(d + BR_MAX_SLICES * sizeof(mi355_h264_slice)); }
+        for (int l = 0; l < 2; l++) { s->side_off_mv[l] = d; d = up64(d + n * 64); }
+        s->d_side = dalloc(d);
+        if (!s->d_side) return 0;
+    }
     if (!s->host || !s->widths || !s->out || (b->direct && (!s->done || !s->d_desc || !s->cvt))) return 0;
     memset(s->host, 0, s->size);
     s->desc = (mi355_h264_frame *)(s->host + o_desc);
@@ -283,6 +296,21 @@ static Disp disps[DISP_MAX_DEVICES];
 static pthread_mutex_t disps_mu = PTHREAD_MUTEX_INITIALIZER;   /* creation of the dispatchers; each has its own lock afterwards */
 static int disps_ready, bridge_count;
 
+/* the loop filter's side information of one picture -> HBM, on the set's stream, before its kernels */
+static int side_upload(const Bridge *b, const Staging *s, void *st)
+{
+    if (!s->d_side) return 0;
+    const size_t n = (size_t)s->nmb_pic;
+    int rc = 0;
+    for (int p = 0; p < b->npass; p++) {
+        rc |= mi355_memcpy_h2d_async(s->d_side + s->side_off_mbd[p], s->mbd[p], n * sizeof(mi355_h264_mb), st);
+        rc |= mi355_memcpy_h2d_async(s->d_side + s->side_off_sl[p], s->slices[p], (size_t)s->nslices * sizeof(mi355_h264_slice), st);
+    }
+    rc |= mi355_memcpy_h2d_async(s->d_side + s->side_off_mv[0], s->mv[0], n * 64, st);
+    if (s->uses_l1) rc |= mi355_memcpy_h2d_async(s->d_side + s->side_off_mv[1], s->mv[1], n * 64, st);
+    return rc;
+}
+
 /* one launch set: a descriptor copy, the kernels for all its pictures (reconstruction from one descriptor array, loop
  * filter from a second one: they differ for the chroma planes of 4:4:4 pictures), one launch that brings the finished
  * pictures to the streams' pinned buffers; nothing waits here.  The sets of different slots run on different HIP streams:
@@ -303,6 +331,7 @@ static int disp_enqueue(Disp *D, int slot)
         const Bridge *b = sub->b;
         const size_t bytes = picture_bytes(b);
         if (sub->after) rc |= mi355_stream_wait_event(st, D->ev[(sub->after - 1) % DISP_DEPTH]);
+        rc |= side_upload(b, s, st);
         if (b->mb_w > mw) mw = b->mb_w;
         if (b->mb_h > mh) mh = b->mb_h;
         for (int l = 0; l < s->maxl; l++)
@@ -457,6 +486,7 @@ static void staging_free(Staging *s)
     if (s->out) mi355_host_free(s->out);
     if (s->done) mi355_event_destroy(s->done);
     if (s->d_desc) mi355_free(s->d_desc);
+    if (s->d_side) mi355_free(s->d_side);
     if (s->cvt) mi355_host_free(s->cvt);
     memset(s, 0, sizeof(*s));
 }
@@ -1058,15 +1088,24 @@ static int submit_picture(Bridge *b, H264Context *h)
         f->flags = maxl > 0 && s->istart[maxl] == b->nmb_pic ? MI355_FRAME_NO_INTER : 0;      /* an I picture: the inter pass has nothing to do */
         s->desc[np + p] = *f;                        /* the loop filter's view */
         s->desc[np + p].mb = s->mbd[p];
+        if (s->d_side) {                             /* the second kernel set: side information from HBM (side_upload) */
+            mi355_h264_frame *fd = &s->desc[np + p];
+            fd->mb = (const mi355_h264_mb *)(s->d_side + s->side_off_mbd[p]);
+            fd->slices = (const mi355_h264_slice *)(s->d_side + s->side_off_sl[p]);
+            fd->mv[0] = (const int16_t *)(s->d_side + s->side_off_mv[0]);
+            fd->mv[1] = b->uses_l1 ? (const int16_t *)(s->d_side + s->side_off_mv[1]) : NULL;
+        }
     }
     s->pic = cur;
     s->field = b->field; s->parity = b->parity;
+    s->nmb_pic = b->nmb_pic; s->nslices = b->nslices; s->uses_l1 = b->uses_l1;
     /* the finished picture goes to the frame the decoder hands out (coded size; the reference crops on output) */
     const AVFrame *fr = h->cur_pic_ptr->f;
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
     if (b->direct) {
         if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
         if (b->wide) {
+            if (side_upload(b, s, b->stream)) return -3;
             if (mi355_h264_decode_frames_wide_dev(s->d_desc, np, b->mb_w, b->mb_h, maxl, s->widths, b->bit_depth, b->kidc, 3, b->stream) != 0 ||
                 mi355_h264_decode_frames_wide_dev(s->d_desc + np, np, b->mb_w, b->mb_h, 0, NULL, b->bit_depth, b->kidc, 4, b->stream) != 0) return -4;
         } else
