@@ -653,42 +653,6 @@ k_deblock_bands(const mi355_h264_frame *__restrict__ frames, int band0, int skip
 
 
 
-/* agent-scope accesses of the band hand-over (plain in the emulator: workgroups run one after the other there) */
-#ifdef MI355_HIP_EMU_H
-static inline uint32_t agent_load_u32(const uint32_t *p) { return *p; }
-static inline void agent_store_u32(uint32_t *p, uint32_t v) { *p = v; }
-static inline uint2 agent_load8(const uint8_t *p, bool al8) { return ld8(p, al8); }
-static inline void agent_store8(uint8_t *p, uint2 v, bool al8) { st8(p, v, al8); }
-static inline void agent_drain_stores() {}
-static inline void agent_release() {}
-static inline void agent_acquire() {}
-static inline void wave_nap() { std::fprintf(stderr, "k_deblock_tiled: a band waits for a band that has not run (emulator: workgroups run in order)\n"); std::abort(); }
-#else
-__device__ __forceinline__ uint32_t agent_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void agent_store_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint2 agent_load8(const uint8_t *p, bool al8)
-{
-    if (al8) {
-        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-    }
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
-    return make_uint2(agent_load_u32(w), agent_load_u32(w + 1));
-}
-__device__ __forceinline__ void agent_store8(uint8_t *p, uint2 v, bool al8)
-{
-    if (al8) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    uint32_t *w = reinterpret_cast<uint32_t *>(p);
-    agent_store_u32(w, v.x); agent_store_u32(w + 1, v.y);
-}
-/* every store this wave has issued has left it (the write-through ones have reached memory) before the flag goes out; inline
- * asm: the compiler's own wait insertion may drop a wait it believes redundant (guide, G16 pitfall 12) */
-__device__ __forceinline__ void agent_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void agent_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-__device__ __forceinline__ void wave_nap() { __builtin_amdgcn_s_sleep(16); }
-#endif
-
 /* ===================================================================================================================== */
 /* The loop filter on macroblock-tiled surfaces (round 4): every band of every picture in ONE launch, tiles by LDS-DMA     */
 /* ===================================================================================================================== */
@@ -1190,7 +1154,8 @@ struct SyncBuf {
     uint32_t *dev;
     size_t words;
 };
-uint32_t *sync_words(hipStream_t st, size_t words)
+}  // namespace
+uint32_t *mi355::sync_words(hipStream_t st, size_t words)
 {
     static thread_local std::vector<SyncBuf> pool;
     const int device = mi355::current_device();
@@ -1211,7 +1176,6 @@ uint32_t *sync_words(hipStream_t st, size_t words)
     pool.push_back(b);
     return b.dev;
 }
-}  // namespace
 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)
 {
@@ -1233,7 +1197,7 @@ extern "C" int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, 
     if (tiled_launch) {
         if ((long long)nframes * nbands > 0x7FFFFFFFLL) return -3;
         const size_t words = 16 + (size_t)nframes * (size_t)nbands;
-        uint32_t *sync = sync_words(st, words);
+        uint32_t *sync = mi355::sync_words(st, words);
         if (!sync) return -4;
         MI355_TRY(hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st), -4);
         /* few bands in all (fewer than two per SIMD): two waves per band, the edge phases beside everything else (MI355_DEBLOCK_WAVES = 1 / 2 pins the form) */

@@ -64,7 +64,46 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
 
 /* h264_frame_tiled.hip: launches k_recon_inter_tiled (the tiled-only instance of the inter reconstruction kernel) */
 void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd, hipStream_t stream);
+/* h264_deblock.hip: the scratch words (ticket + progress counters) of a single-launch loop filter, one buffer per (thread, device, stream); the caller zeroes what it uses on `stream` */
+uint32_t *sync_words(hipStream_t stream, size_t words);
 }  // namespace mi355
+namespace {
+/* agent-scope accesses of the band hand-over (plain in the emulator: workgroups run one after the other there) */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t agent_load_u32(const uint32_t *p) { return *p; }
+static inline void agent_store_u32(uint32_t *p, uint32_t v) { *p = v; }
+static inline uint2 agent_load8(const uint8_t *p, bool al8) { return mi355::ld8(p, al8); }
+static inline void agent_store8(uint8_t *p, uint2 v, bool al8) { mi355::st8(p, v, al8); }
+static inline void agent_drain_stores() {}
+static inline void agent_release() {}
+static inline void agent_acquire() {}
+static inline void wave_nap() { std::fprintf(stderr, "k_deblock_tiled: a band waits for a band that has not run (emulator: workgroups run in order)\n"); std::abort(); }
+#else
+__device__ __forceinline__ uint32_t agent_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint2 agent_load8(const uint8_t *p, bool al8)
+{
+    if (al8) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    }
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return make_uint2(agent_load_u32(w), agent_load_u32(w + 1));
+}
+__device__ __forceinline__ void agent_store8(uint8_t *p, uint2 v, bool al8)
+{
+    if (al8) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    agent_store_u32(w, v.x); agent_store_u32(w + 1, v.y);
+}
+/* every store this wave has issued has left it (the write-through ones have reached memory) before the flag goes out; inline
+ * asm: the compiler's own wait insertion may drop a wait it believes redundant (guide, G16 pitfall 12) */
+__device__ __forceinline__ void agent_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void agent_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void wave_nap() { __builtin_amdgcn_s_sleep(16); }
+#endif
+}  // namespace
 /* sixteen bytes per lane from memory straight into LDS at lds_base + 16 * lane (lds_base wave-uniform) */
 #ifdef MI355_HIP_EMU_H
 template <bool AGENT> static inline void lds_dma16(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 16 * (threadIdx.x & 63), src, 16); }

@@ -18,6 +18,7 @@
  * needs left, top and top-right done).  Surfaces are planes with byte strides (MI355_SURFACE_LINEAR).  No byte packing, no
  * tiled surfaces, no single-launch loop filter yet: parity first (bench point config2_high10 in bench.py).
  */
+#include <cstdlib>
 #include <type_traits>
 #include "h264_frame_dev.h"
 
@@ -35,31 +36,35 @@ template <int BD, int CF> struct Fmt {
 };
 
 /* N samples between a picture row (4-byte aligned address, N * sizeof(PX) a multiple of 4) and 16-bit samples in LDS */
-template <typename PX, int N>
+/* AGENT: agent-scope accesses (another workgroup of the same launch wrote / will read these samples: the row hand-over of k_wide_deblock_rows) */
+template <typename PX, int N, bool AGENT = false>
 __device__ __forceinline__ void wide_ld_row(const uint8_t *p, uint16_t *d)
 {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
     if (sizeof(PX) == 2) {
 #pragma unroll
-        for (int k = 0; k < N / 2; k++) { const uint32_t v = w[k]; d[2 * k] = (uint16_t)(v & 0xFFFF); d[2 * k + 1] = (uint16_t)(v >> 16); }
+        for (int k = 0; k < N / 2; k++) { const uint32_t v = AGENT ? agent_load_u32(w + k) : w[k]; d[2 * k] = (uint16_t)(v & 0xFFFF); d[2 * k + 1] = (uint16_t)(v >> 16); }
     } else {
 #pragma unroll
         for (int k = 0; k < N / 4; k++) {
-            const uint32_t v = w[k];
+            const uint32_t v = AGENT ? agent_load_u32(w + k) : w[k];
             d[4 * k] = (uint16_t)(v & 0xFF); d[4 * k + 1] = (uint16_t)((v >> 8) & 0xFF); d[4 * k + 2] = (uint16_t)((v >> 16) & 0xFF); d[4 * k + 3] = (uint16_t)(v >> 24);
         }
     }
 }
-template <typename PX, int N>
+template <typename PX, int N, bool AGENT = false>
 __device__ __forceinline__ void wide_st_row(uint8_t *p, const uint16_t *d)
 {
     uint32_t *w = reinterpret_cast<uint32_t *>(p);
     if (sizeof(PX) == 2) {
 #pragma unroll
-        for (int k = 0; k < N / 2; k++) w[k] = (uint32_t)d[2 * k] | ((uint32_t)d[2 * k + 1] << 16);
+        for (int k = 0; k < N / 2; k++) { const uint32_t v = (uint32_t)d[2 * k] | ((uint32_t)d[2 * k + 1] << 16); if (AGENT) agent_store_u32(w + k, v); else w[k] = v; }
     } else {
 #pragma unroll
-        for (int k = 0; k < N / 4; k++) w[k] = (uint32_t)d[4 * k] | ((uint32_t)d[4 * k + 1] << 8) | ((uint32_t)d[4 * k + 2] << 16) | ((uint32_t)d[4 * k + 3] << 24);
+        for (int k = 0; k < N / 4; k++) {
+            const uint32_t v = (uint32_t)d[4 * k] | ((uint32_t)d[4 * k + 1] << 8) | ((uint32_t)d[4 * k + 2] << 16) | ((uint32_t)d[4 * k + 3] << 24);
+            if (AGENT) agent_store_u32(w + k, v); else w[k] = v;
+        }
     }
 }
 
@@ -715,7 +720,7 @@ __device__ const uint8_t kw_tc0[52][3] = {
     {3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},{9,12,18},{10,13,20},
     {11,15,23},{13,17,25} };
 
-constexpr int DYP = 20, DCPW = 10;       /* pitches of the filter's luma (-4..15) and chroma (-2..7) tiles */
+constexpr int DYP = 20, DCPW = 12;       /* pitches of the filter's luma (-4..15) and chroma (-4..7) tiles */
 struct WideDbLds {
     mi355_h264_mb m[3];                  /* this macroblock, its left and its top neighbour */
     int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
@@ -723,10 +728,10 @@ struct WideDbLds {
     uint8_t nnz[25];
     uint8_t bs[2][4][4];
     uint16_t y[20 * DYP];                /* rows / columns -4..15 */
-    uint16_t c[2][18 * DCPW];            /* rows -2..15, columns -2..7 */
+    uint16_t c[2][18 * DCPW];            /* rows -2..15, columns -4..7 (the filter reaches two to the left; four make the write-back whole dwords) */
 };
 #define DY(x, yy) s.y[((yy) + 4) * DYP + (x) + 4]
-#define DC(p, x, yy) s.c[p][((yy) + 2) * DCPW + (x) + 2]
+#define DC(p, x, yy) s.c[p][((yy) + 2) * DCPW + (x) + 4]
 
 __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
 {
@@ -753,29 +758,18 @@ __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int lis
     return r == 0xFF ? -1 : r;
 }
 
-/* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter macroblock (d - 2 * mb_y, mb_y) of picture 4 * k + g —
- * ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without MBAFF.  Sixteen lanes are what one macroblock has
- * to offer (the sixteen lines across a luma edge; 8 + 8 chroma lines); four macroblocks fill the wave, and a lane moves whole rows
- * (32 bytes of a 10-bit luma row) between memory and the group's LDS tiles.
- * A macroblock's own samples come from `recon`, four columns of the left and four rows of the top neighbour from `dst` (as those
- * macroblocks' own passes left them); the macroblock, three columns and three rows (one of each in chroma) go back to `dst`. */
-template <int BD, int CF>
-__global__ void __launch_bounds__(64)
-k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
+/* One macroblock (mb_x, mb_y) per sixteen-lane group — ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without
+ * MBAFF.  The macroblock's own samples come from `recon`, four rows of the top neighbour from `dst` (as that macroblock's own pass left
+ * them) and four columns of the left neighbour from `dst` or — carry_left: the caller filtered that macroblock with this tile a moment ago
+ * — from the tile's last columns; the macroblock, three columns and three rows (one of each in chroma) go back to `dst`.
+ * AGENT: `dst` is read and written with agent-scope accesses (k_wide_deblock_rows: the row above is another workgroup of the same launch). */
+template <int BD, int CF, bool AGENT>
+__device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4],
+                                                const mi355_h264_frame &fr, bool ok, int mb_x, int mb_y, int l, bool carry_left)
 {
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
     constexpr int PXB = (int)sizeof(PX);
-    __shared__ WideDbLds sh[4];
-    /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane at every edge — from memory that is a dependent
-     * load of a microsecond in each of its sixteen steps */
-    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
-    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-    WideDbLds &s = sh[g];
-    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
-    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, mb_x = d - 2 * mb_y;
-    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
-    const bool ok = f < nframes && mb_y < fr.mb_height && mb_x >= 0 && mb_x < fr.mb_width;
     const int mb_xy = mb_y * fr.mb_width + mb_x;
     const bool has_left = mb_x > 0, has_top = mb_y > 0;
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], yd = fr.dst_stride[0], cd = fr.dst_stride[1];
@@ -785,19 +779,19 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
         reinterpret_cast<uint32_t *>(&s.m[0])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[l];
         reinterpret_cast<uint32_t *>(&s.m[1])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xl])[l];
         reinterpret_cast<uint32_t *>(&s.m[2])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xt])[l];
-        /* samples: lane l brings row l of the macroblock, its four left neighbours, a quarter row of the four rows above */
+        /* samples: lane l brings row l of the macroblock, its four left neighbours (from memory, or from the tile's last columns), a quarter
+         * row of the four rows above */
+        if (has_left && carry_left) for (int k = 0; k < 4; k++) DY(k - 4, l) = DY(12 + k, l);
+        else if (has_left) wide_ld_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
         wide_ld_row<PX, 16>(fr.recon[0] + (size_t)(16 * mb_y + l) * ys + 16 * mb_x * PXB, &DY(0, l));
-        if (has_left) wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
-        if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
+        if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_ld_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
         for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
             const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
+            if (has_left && carry_left) for (int j = 0; j < 4; j++) DC(p, j - 4, r) = DC(p, 4 + j, r);
+            else if (has_left) wide_ld_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
             wide_ld_row<PX, 8>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + r) * cs + 8 * mb_x * PXB, &DC(p, 0, r));
-            if (has_left) {
-                const PX *q = reinterpret_cast<const PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd) + 8 * mb_x;
-                DC(p, -2, r) = q[-2]; DC(p, -1, r) = q[-1];
-            }
         }
-        if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_ld_row<PX, 4>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x + c) * PXB, &DC(p, c, r)); }
+        if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_ld_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x + c) * PXB, &DC(p, c, r)); }
     }
     MI355_WAVE_SYNC();
     const mi355_h264_mb &m = s.m[0];
@@ -913,15 +907,72 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
     }
     /* out: the macroblock, and what its left and top edges changed of the neighbours */
     if (ok) {
-        wide_st_row<PX, 16>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
-        if (has_left) { PX *q = reinterpret_cast<PX *>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd) + 16 * mb_x; q[-3] = (PX)DY(-3, l); q[-2] = (PX)DY(-2, l); q[-1] = (PX)DY(-1, l); }
-        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
+        /* (the left neighbour's four last columns go back as whole dwords: the first of them as it came) */
+        wide_st_row<PX, 16, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
+        if (has_left) wide_st_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
+        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
         for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
             const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-            wide_st_row<PX, 8>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
-            if (has_left) (reinterpret_cast<PX *>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd) + 8 * mb_x)[-1] = (PX)DC(p, -1, r);
+            wide_st_row<PX, 8, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
+            if (has_left) wide_st_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
         }
-        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
+        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
+    }
+}
+
+/* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter macroblock (d - 2 * mb_y, mb_y) of picture 4 * k + g.  Sixteen
+ * lanes are what one macroblock has to offer (the sixteen lines across a luma edge; 8 + 8 chroma lines); four macroblocks fill the
+ * wave, and a lane moves whole rows (32 bytes of a 10-bit luma row) between memory and the group's LDS tiles.  One launch per
+ * anti-diagonal (the reference's raster order needs left, top and top-right done): the form for batches that fill the device. */
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
+{
+    __shared__ WideDbLds sh[4];
+    /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane at every edge — from memory that is a dependent
+     * load of a microsecond in each of its sixteen steps */
+    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
+    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, mb_x = d - 2 * mb_y;
+    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
+    const bool ok = f < nframes && mb_y < fr.mb_height && mb_x >= 0 && mb_x < fr.mb_width;
+    wide_deblock_mb<BD, CF, false>(sh[g], t_alpha, t_beta, t_tc0, fr, ok, mb_x, mb_y, l, false);
+}
+
+/* The same filter as ONE launch: a wave = macroblock row `row` of four pictures, walking left to right; rows are taken in row-major order
+ * from a ticket counter (a wave only ever waits for a lower ticket, which is running or done), and row y follows row y - 1 two
+ * macroblocks behind: a wave publishes how many macroblocks it has written (after its write-through stores have left it) in a progress
+ * word, the wave below polls that word and fetches the four rows above its macroblock with agent-scope loads
+ * (/opt/skills/guides/cdna_hip_programming.md, guideline 16, form R1 — the protocol of k_deblock_tiled).  The left neighbour's columns
+ * stay in the tile from the step before.  254 launches of a 1080p set become one: what matters when a launch set is a dozen pictures
+ * of as many decoders (the bridge) and the launches, not the arithmetic, are its time. */
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_deblock_rows(const mi355_h264_frame *frames, int nframes, int max_w, int max_h, uint32_t *sync)
+{
+    __shared__ WideDbLds sh[4];
+    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(sync, 1u);
+    tk = (uint32_t)lane_value((int)tk, 0);
+    const int nquads = (nframes + 3) >> 2, row = (int)(tk / (uint32_t)nquads), quad = (int)(tk - (uint32_t)row * (uint32_t)nquads);
+    if (row >= max_h) return;
+    uint32_t *prog = sync + 16 + (size_t)quad * (size_t)max_h;
+    const int f = 4 * quad + g;
+    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
+    for (int x = 0; x < max_w; x++) {
+        if (row > 0) {
+            const uint32_t need = (uint32_t)(x + 2 < max_w ? x + 2 : max_w);
+            while (agent_load_u32(&prog[row - 1]) < need) wave_nap();
+        }
+        const bool ok = f < nframes && row < fr.mb_height && x < fr.mb_width;
+        wide_deblock_mb<BD, CF, true>(sh[g], t_alpha, t_beta, t_tc0, fr, ok, x, row, l, x > 0);
+        agent_drain_stores();                    /* every store of this macroblock has left the wave ... */
+        if (lane == 0) agent_store_u32(&prog[row], (uint32_t)(x + 1));      /* ... before the row below may fetch it */
+        MI355_WAVE_SYNC();                       /* the next macroblock's loads overwrite what the stores above read */
     }
 }
 #undef DY
@@ -941,9 +992,22 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
             if ((long long)nframes * width > 0x7FFFFFFFLL) return -3;
             hipLaunchKernelGGL((k_wide_intra<BD, CF>), dim3((unsigned)(nframes * width)), dim3(64), 0, st, d_frames, level, width);
         }
-    if (passes & 4)
+    if (passes & 4) {
+        /* few pictures (a launch set of the bridge): the single launch — a chain of ~250 tiny launches costs the host thread that issues it more
+         * than the device; many pictures: one launch per anti-diagonal (no waiting waves).  MI355_WIDE_DEBLOCK=rows / diag pins one */
+        const unsigned nquads = (unsigned)((nframes + 3) / 4);
+        const char *form = getenv("MI355_WIDE_DEBLOCK");
+        const bool rows = form ? form[0] == 'r' : nframes <= 64;
+        if (rows) {
+            const size_t words = 16 + (size_t)nquads * (size_t)mh;
+            uint32_t *sync = mi355::sync_words(st, words);
+            if (!sync) return -2;
+            if (hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st) != hipSuccess) return -2;
+            hipLaunchKernelGGL((k_wide_deblock_rows<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, mw, mh, sync);
+        } else
         for (int d = 0; d <= (mw - 1) + 2 * (mh - 1); d++)
-            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3((unsigned)(((nframes + 3) / 4) * mh)), dim3(64), 0, st, d_frames, nframes, d, mh);
+            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, d, mh);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

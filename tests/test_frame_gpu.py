@@ -218,3 +218,23 @@ def test_second_kernel_set_10bit_1080p_is_deterministic_and_in_range(mi355):
             d.free()
     for p in range(3):
         assert np.array_equal(outs[0][p], outs[1][p]) and outs[0][p].max() <= 1023 and outs[0][p].std() > 10
+
+
+@pytest.mark.parametrize("form,F", (("rows", 320), ("rows", 36), ("diag", 8)))
+def test_second_kernel_set_loop_filter_forms_under_load(mi355, oracle, monkeypatch, form, F):
+    """the second kernel set's two loop-filter forms (MI355_WIDE_DEBLOCK: `rows` = one launch, a wave per macroblock row of four pictures
+    following the row above through progress counters and agent-scope accesses — hundreds of rows in flight on every XCD; `diag` = one
+    launch per anti-diagonal) on replicated 1080p pictures (8-bit 4:2:0 instance): every picture equals the oracle's"""
+    monkeypatch.setenv("MI355_WIDE_DEBLOCK", form)
+    fs = HF.synth_frames_fast(4, 120, 68, seed=0x2264, lib=mi355.lib, refs="smooth", coef_b=4)
+    _, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(mi355, fs, replicate=F)
+    try:
+        for _ in range(2):
+            d.decode_wide()
+            got = d.fetch(d.dst)
+            for p in range(3):
+                for f in range(F):
+                    assert np.array_equal(got[p][f], dst_o[p][f % fs.F]), (form, f, p)
+    finally:
+        d.free()
