@@ -275,13 +275,15 @@ __device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &
     wide_add_blocks4<BD, CF>(coef + 256 + 16 * F::NCB, F::NCB, true, cr, pitch);
 }
 
-/* the macroblock's coefficients -> the 32-bit LDS copy */
+/* the macroblock's coefficients -> the 32-bit LDS copy.  parts: bits 0..3 the luma 8x8 quadrants (blocks 4q..4q+3 = coefficients 64q..64q+63: what
+ * coded_block_pattern bit q says), bit 4 both chroma planes; a part that is not coded is not fetched (it holds zeros) — with the bridge the array is
+ * pinned host memory, and the coefficients of a 10-bit macroblock are 1.5 KB across PCIe */
 template <int BD, int CF>
-__device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr, int mb_xy)
+__device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr, int mb_xy, int parts)
 {
     typedef Fmt<BD, CF> F;
     const typename F::COEF *cp = reinterpret_cast<const typename F::COEF *>(fr.coef) + (size_t)mb_xy * F::NCOEF;
-    for (int i = lane_id(); i < F::NCOEF; i += 64) dst[i] = cp[i];
+    for (int i = lane_id(); i < F::NCOEF; i += 64) dst[i] = ((parts >> (i < 256 ? i >> 6 : 4)) & 1) ? (int32_t)cp[i] : 0;
     MI355_WAVE_SYNC();
 }
 
@@ -513,7 +515,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
     const uint32_t t = s.hdr.mb_type;
     if (t & MI355_MB_INTRA) return;
     const bool luma_coded = (s.hdr.cbp & 15) != 0, chroma_coded = (s.hdr.cbp & 0x30) != 0;
-    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy);
+    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (s.hdr.cbp & 15) | (chroma_coded ? 16 : 0));
     const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
 
     /* hl_motion, h264_mc_template.c:64-163 */
@@ -584,9 +586,11 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
     if (k >= count) return;
     const int mb_xy = (int)fr.intra_list[first + k], mb_x = mb_xy % fr.mb_width, mb_y = mb_xy / fr.mb_width, lane = lane_id();
     if (lane < 16) reinterpret_cast<uint32_t *>(&s.hdr)[lane] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[lane];
-    wide_load_coefs<BD, CF>(s.coef, fr, mb_xy);
+    MI355_WAVE_SYNC();
     const mi355_h264_mb &h = s.hdr;
     const uint32_t t = h.mb_type;
+    /* Intra16x16 carries DC levels in every block whatever its pattern says; I_PCM is all samples */
+    wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (t & MI355_MB_INTRA_PCM) ? 31 : (((t & MI355_MB_INTRA16x16) ? 15 : (h.cbp & 15)) | ((h.cbp & 0x30) ? 16 : 0)));
     const bool bypass = (h.flags & MI355_MBF_BYPASS) != 0, bypass_pred = (h.flags & MI355_MBF_BYPASS_PRED) != 0, x264old = (h.flags & MI355_MBF_BYPASS_X264OLD) != 0;
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:101-153: the samples themselves, one per coefficient slot: Y, Cb, Cr */
         for (int i = lane; i < 256; i += 64) WTILE(i & 15, i >> 4) = (uint16_t)s.coef[i];
@@ -993,11 +997,12 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
             hipLaunchKernelGGL((k_wide_intra<BD, CF>), dim3((unsigned)(nframes * width)), dim3(64), 0, st, d_frames, level, width);
         }
     if (passes & 4) {
-        /* few pictures (a launch set of the bridge): the single launch — a chain of ~250 tiny launches costs the host thread that issues it more
-         * than the device; many pictures: one launch per anti-diagonal (no waiting waves).  MI355_WIDE_DEBLOCK=rows / diag pins one */
+        /* one launch per anti-diagonal; MI355_WIDE_DEBLOCK=rows: the single launch (k_wide_deblock_rows) — measured slower at every batch size in this
+         * first form (16 pictures 3.4 against 3.1 ms, 512: 30 against 14: a lone wave's macroblock step is ~13 us of dependent instructions, and
+         * waiting rows hold their slots), kept for the protocol and as the base of the band form */
         const unsigned nquads = (unsigned)((nframes + 3) / 4);
         const char *form = getenv("MI355_WIDE_DEBLOCK");
-        const bool rows = form ? form[0] == 'r' : nframes <= 64;
+        const bool rows = form && form[0] == 'r';
         if (rows) {
             const size_t words = 16 + (size_t)nquads * (size_t)mh;
             uint32_t *sync = mi355::sync_words(st, words);

@@ -839,9 +839,13 @@ __device__ __forceinline__ void recon_inter_mb(MbLds &s, const mi355_h264_frame 
     RPROF(1);
     if (uniform((int)s.hdr.mb_type) & MI355_MB_INTRA) return;
     if (SPARSE && (uniform((int)s.hdr.cbp) & 0x3F)) {
-        const int lane = lane_id();
+        /* ... and of those only the coded parts: an 8x8 luma quadrant (blocks 4q..4q+3 = 32 dwords) per coded_block_pattern bit, both chroma planes
+         * for its bits 4-5; a lane whose part is not coded reads a zero word from HBM instead (no predicated load) */
+        const int lane = lane_id(), cbp = uniform((int)s.hdr.cbp);
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-        const uint32_t c0 = cp[lane], c1 = cp[lane + 64], c2 = cp[lane + 128];
+        const uint32_t *z = k_zero16;
+        const uint32_t c0 = *(((cbp >> (lane >> 5)) & 1) ? cp + lane : z), c1 = *(((cbp >> (2 + (lane >> 5))) & 1) ? cp + lane + 64 : z),
+                       c2 = *((cbp & 0x30) ? cp + lane + 128 : z);
         uint32_t *dst = reinterpret_cast<uint32_t *>(s.coef);
         dst[lane] = c0; dst[lane + 64] = c1; dst[lane + 128] = c2;
         MI355_WAVE_SYNC();

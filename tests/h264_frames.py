@@ -666,6 +666,11 @@ class DeviceFrames:
             coef = fs.coef.copy()
             inter_empty = ((fs.mb["mb_type"] & 7) == 0) & ((fs.mb["cbp"] & 0x3F) == 0)     # not Intra4x4 / 16x16 / PCM
             coef[inter_empty] = 0x7F7F
+            # ... nor the parts of a coded macroblock its coded_block_pattern leaves out (an 8x8 luma quadrant per bit 0..3, both chroma planes for bits 4-5)
+            inter = (fs.mb["mb_type"] & 7) == 0
+            for q in range(4):
+                coef[inter & ((fs.mb["cbp"] >> q) & 1 == 0), 64 * q:64 * q + 64] = 0x7F7F
+            coef[inter & ((fs.mb["cbp"] & 0x30) == 0), 256:384] = 0x7F7F
             nmb = fs.mb_w * fs.mb_h
             for f in range(self.F):
                 self.h2d(self.coef + f * nmb * 768, coef[f % G])
