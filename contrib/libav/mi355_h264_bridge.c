@@ -132,6 +132,7 @@ typedef struct Staging {        /* one pinned, device-visible block (mi355_host_
     DevPic *pic;                /* the picture this set was submitted for */
     int field, parity;          /* it was a field picture: only the lines of its parity go to the frame */
     int nmb_pic, nslices, uses_l1;  /* of the picture submitted from this set (side_upload) */
+    int cls;                    /* fmt_class of that picture: pictures of one class share a launch set */
     mi355_surface_job *cvt;     /* pinned, direct mode with tiled device pictures: the conversion job of the copy-back */
     uint8_t *frame_data[3];     /* where it goes: the AVFrame the decoder will hand out */
     int frame_linesize[3];
@@ -161,6 +162,8 @@ typedef struct Bridge {
     int open;                   /* a picture is being packed */
     DevPic pics[BR_MAX_PICS];
     int c444, npass;            /* 4:4:4: three passes (planes) per picture */
+    int mbaff;                  /* sps->mb_aff: frame pictures of this sequence are MBAFF frames (macroblock pairs) */
+    int mbaff_frame;            /* the picture being packed is one */
     int bypass;                 /* sps->transform_bypass: macroblocks with qscale 0 are lossless (MI355_MBF_BYPASS) */
     int wide;                   /* the sequence's format goes through the second kernel set (mi355_h264_decode_frames_wide_dev): more than 8 bits or 4:2:2 */
     int bit_depth, idc;         /* sps->bit_depth_luma, sps->chroma_format_idc of the sequence the bridge is set up for */
@@ -206,7 +209,7 @@ static void br_fail(Bridge *b, const char *what)
     b->state = -1;
 }
 
-static int fmt_class(const Bridge *b) { return b->wide ? 10 * b->bit_depth + b->kidc : 0; }
+static int fmt_class(const Bridge *b) { return b->wide ? 10 * b->bit_depth + b->kidc + (b->mbaff_frame ? 1000 : 0) : 0; }
 static void *dalloc(size_t n) { return mi355_malloc(n); }
 static size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
@@ -389,7 +392,7 @@ static void *disp_main(void *arg)
         while (c) {
             Submission *nx = c->next;
             int later = nd + c->b->npass > DISP_MAX_BATCH;
-            if (n && !later) later = fmt_class(D->in[slot][0]->b) != fmt_class(c->b);      /* one kernel set per launch set */
+            if (n && !later) later = D->in[slot][0]->s->cls != c->s->cls;      /* one kernel set per launch set (MBAFF frames: their own loop filter) */
             for (int i = 0; i < n && !later; i++) later = D->in[slot][i]->b == c->b;
             if (later) {
                 c->next = NULL;
@@ -519,8 +522,8 @@ void __wrap_ff_h264_flush_change(H264Context *h)
         finish_all(b);
         b->open = 0;
         const SPS *sps = h->ps.sps;
-        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && !sps->mb_aff && sps->bit_depth_luma == b->bit_depth &&
-                         sps->chroma_format_idc == b->idc &&
+        const int same = sps && sps->mb_width == b->mb_w && sps->mb_height * (2 - sps->frame_mbs_only_flag) == b->mb_h && sps->bit_depth_luma == b->bit_depth &&
+                         sps->chroma_format_idc == b->idc && (!sps->frame_mbs_only_flag && sps->mb_aff) == b->mbaff &&
                          !sps->transform_bypass == !b->bypass && !sps->residual_color_transform_flag &&
                          (!b->tiled || sps->frame_mbs_only_flag);        /* tiled device pictures hold frames only */
         if (!same) { bridge_release(b); b->state = 0; }
@@ -564,7 +567,8 @@ static Bridge *bridge_get(const H264Context *h)
     const int idc = h->ps.sps->chroma_format_idc;
     /* a sequence that may hold field MACROBLOCKS (mb_adaptive_frame_field_flag) is outside the path as a whole; field PICTURES
      * (PAFF: the choice between a frame and two fields is made per picture) are inside: begin_picture() looks at each one */
-    if ((!h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff) || FRAME_MBAFF(h) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
+    const int seq_mbaff = !h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff;
+    if ((seq_mbaff && (getenv("MI355_BRIDGE_NO_WIDE") || !getenv("MI355_BRIDGE_MBAFF"))) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
         (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || (getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2 || h->ps.sps->transform_bypass))) {
         br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4 frame or field pictures without MBAFF)");
         b->soft = 1;
@@ -598,7 +602,8 @@ static Bridge *bridge_get(const H264Context *h)
     b->mb_w = h->mb_width; b->mb_h = h->mb_height; b->nmb = b->mb_w * b->mb_h;
     b->c444 = idc == 3; b->npass = b->c444 ? 3 : 1;
     b->bit_depth = h->ps.sps->bit_depth_luma; b->idc = idc; b->kidc = idc == 3 ? 1 : idc;
-    b->wide = b->bit_depth > 8 || idc == 2 || h->ps.sps->transform_bypass;      /* transform bypass: the second kernel set knows it, the first does not */
+    b->mbaff = seq_mbaff;
+    b->wide = b->bit_depth > 8 || idc == 2 || h->ps.sps->transform_bypass || b->mbaff;      /* transform bypass, macroblock pairs: the second kernel set knows them, the first does not */
     b->bypass = h->ps.sps->transform_bypass;
     b->px = b->bit_depth > 8 ? 2 : 1; b->csize = b->bit_depth > 8 ? 4 : 2;
     b->crows = idc == 2 ? 16 : 8; b->ncoef = idc == 2 ? 512 : 384;
@@ -757,6 +762,7 @@ static void begin_picture(Bridge *b, const H264Context *h)
     memset(s->mv[1], 0, (size_t)b->nmb * 64);
     b->nslices = b->nslots = b->uses_l1 = b->mbs_packed = 0;
     b->field = h->picture_structure != PICT_FRAME;
+    b->mbaff_frame = FRAME_MBAFF(h) != 0;
     b->parity = h->picture_structure == PICT_BOTTOM_FIELD;
     b->rows = b->field ? b->mb_h / 2 : b->mb_h;
     b->nmb_pic = b->mb_w * b->rows;
@@ -879,6 +885,9 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     const int mb_type = h->cur_pic.mb_type[mb_xy];
     mi355_h264_mb *m = &st->mb[0][idx];
     b->mbs_packed++;
+    if (b->mbaff_frame && sl->pwt.use_weight == 2) {      /* field macroblocks take implicit weights from tables of their own (implicit_weight[16 + ..][..][mb_y & 1]) */
+        br_fail(b, "MBAFF frame with implicit weights: outside the batched path"); __real_ff_h264_hl_decode_mb(h, sl); return;
+    }
     const int si = slice_index(b, h, sl);
     if (si < 0) { br_fail(b, "more slices or reference pictures than the batched path holds"); __real_ff_h264_hl_decode_mb(h, sl); return; }
     const int intra = IS_INTRA(mb_type);
@@ -961,6 +970,16 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
                 for (int q = 0; q < 4; q++) {
                     const int r = sl->ref_cache[list][scan8[4 * q]];
                     m->ref_idx[list][q] = (int8_t)(r < 0 ? -1 : r);
+                    if (r >= 0 && b->mbaff_frame && IS_INTERLACED(mb_type)) {
+                        /* a field macroblock of an MBAFF frame: reference index r counts FIELDS, same parity first — what hl_decode_mb turns into
+                         * ref_list[list][(16 + r) ^ (mb_y & 1)] (h264_mb_template.c:77-98; [16 + 2i] / [16 + 2i + 1] = the top / bottom field of frame i,
+                         * h264_refs.c) — a slot of its own per (frame, parity), and the chroma vector's parity correction of h264_mb.c:287-291 */
+                        const int par = (r & 1) ^ (sl->mb_y & 1);
+                        const int slot = slot_of(b, sl->ref_list[list][r >> 1].parent, par);
+                        if (slot < 0) { br_fail(b, "more reference pictures than the batched path holds"); __real_ff_h264_hl_decode_mb(h, sl); return; }
+                        m->u.inter.ref_pic[list][q] = (uint8_t)slot;
+                        m->u.inter.chroma_dy[list][q] = (int8_t)(2 * ((sl->mb_y & 1) - par));
+                    } else
                     if (r >= 0) m->u.inter.ref_pic[list][q] = st->slices[0][si].ref_slot[list][r];
                     if (r >= 0 && b->field) m->u.inter.chroma_dy[list][q] = (int8_t)(2 * (b->parity - ((sl->ref_list[list][r].reference & 3) - 1)));
                 }
@@ -1047,7 +1066,7 @@ static int submit_picture(Bridge *b, H264Context *h)
     cur->frame_num = h->cur_pic_ptr->frame_num; cur->poc = h->cur_pic_ptr->poc; cur->data0 = h->cur_pic_ptr->f->data[0];
     if (b->sess) { s->pic = cur; return submit_session(b, h, s, cur); }
     int lw = 0;
-    const int maxl = mi355_h264_intra_schedule(s->mb[0], b->mb_w, b->rows, s->ilist, s->istart, &lw);
+    const int maxl = (b->mbaff_frame ? mi355_h264_intra_schedule_mbaff : mi355_h264_intra_schedule)(s->mb[0], b->mb_w, b->rows, s->ilist, s->istart, &lw);
     if (maxl < 0) return -1;
     for (int l = 0; l < maxl; l++) s->widths[l] = s->istart[l + 1] - s->istart[l];
     s->maxl = maxl;
@@ -1085,7 +1104,8 @@ static int submit_picture(Bridge *b, H264Context *h)
         f->mb = s->mb[p]; f->mv[0] = s->mv[0]; f->mv[1] = b->uses_l1 ? s->mv[1] : NULL; f->coef = s->coef[p];
         f->slices = s->slices[p]; f->nslices = b->nslices;
         f->max_intra_level = maxl; f->intra_list = s->ilist; f->intra_level_start = s->istart; f->max_level_width = lw;
-        f->flags = maxl > 0 && s->istart[maxl] == b->nmb_pic ? MI355_FRAME_NO_INTER : 0;      /* an I picture: the inter pass has nothing to do */
+        f->flags = (maxl > 0 && s->istart[maxl] == b->nmb_pic ? MI355_FRAME_NO_INTER : 0) |      /* an I picture: the inter pass has nothing to do */
+                   (b->mbaff_frame ? MI355_FRAME_MBAFF : 0);
         s->desc[np + p] = *f;                        /* the loop filter's view */
         s->desc[np + p].mb = s->mbd[p];
         if (s->d_side) {                             /* the second kernel set: side information from HBM (side_upload) */
@@ -1099,9 +1119,14 @@ static int submit_picture(Bridge *b, H264Context *h)
     s->pic = cur;
     s->field = b->field; s->parity = b->parity;
     s->nmb_pic = b->nmb_pic; s->nslices = b->nslices; s->uses_l1 = b->uses_l1;
+    s->cls = fmt_class(b);
     /* the finished picture goes to the frame the decoder hands out (coded size; the reference crops on output) */
     const AVFrame *fr = h->cur_pic_ptr->f;
     for (int k = 0; k < 3; k++) { s->frame_data[k] = fr->data[k]; s->frame_linesize[k] = fr->linesize[k]; }
+    if (getenv("MI355_BRIDGE_DEBUG")) {
+        fprintf(stderr, "picture %lu mbaff %d maxl %d\n", b->pictures, b->mbaff_frame, maxl);
+        for (int y = 0; y < b->rows; y++) { for (int x = 0; x < b->mb_w; x++) { const mi355_h264_mb *m = &s->mb[0][y * b->mb_w + x]; fprintf(stderr, " %c%c%d", (m->mb_type & 0x80) ? 'F' : 'p', (m->mb_type & 7) ? ((m->mb_type & 1) ? ((m->mb_type & 0x01000000) ? '8' : '4') : ((m->mb_type & 2) ? 'I' : 'P')) : 'i', m->intra_level); } fprintf(stderr, "\n"); }
+    }
     if (b->direct) {
         if (mi355_memcpy_h2d_async(s->d_desc, s->desc, 2 * (size_t)np * sizeof(*s->desc), b->stream)) return -3;
         if (b->wide) {

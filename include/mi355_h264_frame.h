@@ -198,6 +198,11 @@ typedef struct mi355_h264_frame {
                                          pictures either way).  A hint: 0 is always right */
 } mi355_h264_frame;
 #define MI355_FRAME_NO_INTER 1
+#define MI355_FRAME_MBAFF    2        /* mi355_h264_decode_frames_wide_dev only: an MBAFF frame (mb_adaptive_frame_field_flag) — macroblock rows 2k, 2k + 1
+                                         are the top / bottom macroblocks of pair row k; a macroblock whose mb_type has MB_TYPE_INTERLACED (0x80) is a FIELD
+                                         macroblock: its sixteen rows are every other line of the pair (top macroblock: the even lines), it predicts from the
+                                         fields of its references (a slot per (frame, parity), the pointer at that field's first line; stride and height are
+                                         taken doubled / halved) and its vectors count field lines (h264_mb_template.c:61-98, h264_mb.c:59-101) */
 
 /* Macroblock-tiled surfaces (surface_layout == MI355_SURFACE_TILED).  What the reference keeps in an AVFrame with a line
  * stride (h264_mb.c:239-314 fetches a 21 x 21 window as 21 row pieces of 21 different cache lines, h264_mb_template.c:85-91
@@ -317,6 +322,11 @@ int mi355_h264_deblock_layouts_dev(const mi355_h264_frame *d_frames, int nframes
  * largest number of MBs on one level. */
 int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
                               uint32_t *list, int32_t *level_start, int *max_level_width);
+
+/* The same for an MBAFF frame (MI355_FRAME_MBAFF: macroblock rows 2k, 2k + 1 are the pairs of pair row k; mb_height even): a macroblock waits for
+ * both macroblocks of the left, above-left, above and above-right PAIRS, the bottom macroblock of a pair for the top one. */
+int mi355_h264_intra_schedule_mbaff(mi355_h264_mb *mb, int mb_width, int mb_height,
+                                    uint32_t *list, int32_t *level_start, int *max_level_width);
 
 /* Device-memory plumbing for callers that do not link a HIP runtime themselves. */
 void *mi355_malloc(size_t bytes);

@@ -367,8 +367,19 @@ extern "C" int mi355_h264_decode_frames(const mi355_h264_frame *frames, int nfra
     return mi355_h264_decode_frames_dev(st.dev, nframes, mw, mh, ml, lw, stream);
 }
 
+static int intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height, uint32_t *list, int32_t *level_start, int *max_level_width, bool pairs);
 extern "C" int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
                                          uint32_t *list, int32_t *level_start, int *max_level_width)
+{
+    return intra_schedule(mb, mb_width, mb_height, list, level_start, max_level_width, false);
+}
+extern "C" int mi355_h264_intra_schedule_mbaff(mi355_h264_mb *mb, int mb_width, int mb_height,
+                                               uint32_t *list, int32_t *level_start, int *max_level_width)
+{
+    if (mb_height & 1) return -1;
+    return intra_schedule(mb, mb_width, mb_height, list, level_start, max_level_width, true);
+}
+static int intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height, uint32_t *list, int32_t *level_start, int *max_level_width, bool pairs)
 {
     /* Levels are kept in a local int array: an all-intra picture reaches level mb_width + 2 * (mb_height - 1)
      * (254 at 1920x1088, 508 at 3840x2160), which the record's 8-bit field cannot hold.  The device reads only
@@ -377,13 +388,27 @@ extern "C" int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb
     if (!mb || !list || !level_start || nmb <= 0) return -1;
     std::vector<int32_t> level((size_t)nmb, 0), count;
     int maxl = 0;
-    for (int y = 0; y < mb_height; y++)
-        for (int x = 0; x < mb_width; x++) {
+    /* visiting order = decoding order: raster, or pair by pair (top, bottom) along a pair row */
+    for (int i = 0; i < nmb; i++) {
+            const int y = pairs ? 2 * (i / (2 * mb_width)) + (i & 1) : i / mb_width, x = pairs ? (i % (2 * mb_width)) >> 1 : i % mb_width;
             const int xy = x + y * mb_width;
             mi355_h264_mb &m = mb[xy];
             if (!(m.mb_type & MI355_MB_INTRA)) { m.intra_level = 0; continue; }
             int lv = 0;
             const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
+            if (pairs) {
+                /* macroblock PAIRS (MBAFF): which macroblock of a neighbouring pair holds a neighbouring sample depends on both pairs' frame / field
+                 * coding (6.4.12.2) — both macroblocks of the left, above-left, above and above-right pairs count, and the bottom macroblock of a
+                 * pair waits for the top one */
+                const int pr = y >> 1;
+                for (int k = 0; k < 4; k++)
+                    for (int pos = 0; pos < 2; pos++) {
+                        const int nx = x + dx[k], ny = 2 * (pr + dy[k]) + pos;
+                        if (nx >= 0 && nx < mb_width && ny >= 0 && ny < mb_height && level[(size_t)(nx + ny * mb_width)] > lv)
+                            lv = level[(size_t)(nx + ny * mb_width)];
+                    }
+                if ((y & 1) && level[(size_t)(xy - mb_width)] > lv) lv = level[(size_t)(xy - mb_width)];
+            } else
             for (int k = 0; k < 4; k++) {
                 const int nx = x + dx[k], ny = y + dy[k];
                 if (nx >= 0 && nx < mb_width && ny >= 0 && ny < mb_height && level[(size_t)(nx + ny * mb_width)] > lv)

@@ -275,6 +275,25 @@ __device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &
     wide_add_blocks4<BD, CF>(coef + 256 + 16 * F::NCB, F::NCB, true, cr, pitch);
 }
 
+/* Where a macroblock's rows are.  A frame or field PICTURE: rows 16 * mb_y + r of its planes.  An MBAFF frame (MI355_FRAME_MBAFF): macroblock rows
+ * 2k, 2k + 1 are pair k; a FRAME macroblock is as above, a FIELD macroblock (MB_TYPE_INTERLACED) owns every other line of its pair — the top
+ * macroblock the even ones — and lives in field coordinates for motion compensation: field row 16 * k, the reference's stride doubled, its height
+ * halved (h264_mb_template.c:61-76, h264_mb.c:59-101, :212-224). */
+struct WideGeom { int y0, cy0, ystep, mcy, hs; };
+template <int BD, int CF>
+__device__ __forceinline__ WideGeom wide_geom(const mi355_h264_frame &fr, uint32_t mb_type, int mb_y)
+{
+    typedef Fmt<BD, CF> F;
+    const bool field = (fr.flags & MI355_FRAME_MBAFF) && (mb_type & 0x80u);
+    WideGeom g;
+    g.ystep = field ? 2 : 1;
+    g.y0 = field ? 32 * (mb_y >> 1) + (mb_y & 1) : 16 * mb_y;
+    g.cy0 = field ? 2 * F::CH * (mb_y >> 1) + (mb_y & 1) : F::CH * mb_y;
+    g.mcy = field ? mb_y >> 1 : mb_y;
+    g.hs = field ? 1 : 0;
+    return g;
+}
+
 /* the macroblock's coefficients -> the 32-bit LDS copy.  parts: bits 0..3 the luma 8x8 quadrants (blocks 4q..4q+3 = coefficients 64q..64q+63: what
  * coded_block_pattern bit q says), bit 4 both chroma planes; a part that is not coded is not fetched (it holds zeros) — with the bridge the array is
  * pinned host memory, and the coefficients of a 10-bit macroblock are 1.5 KB across PCIe */
@@ -288,7 +307,7 @@ __device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr,
 }
 
 template <int BD, int CF>
-__device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, int mb_y, const uint16_t *y, int ypitch, const uint16_t *cb, const uint16_t *cr, int cpitch)
+__device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, const WideGeom &g, const uint16_t *y, int ypitch, const uint16_t *cb, const uint16_t *cr, int cpitch)
 {
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
@@ -296,11 +315,11 @@ __device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, int m
     const int lane = lane_id();
     {   /* luma: lane = 4 * row + quarter */
         const int r = lane >> 2, c = 4 * (lane & 3);
-        wide_st_row<PX, 4>(fr.recon[0] + (size_t)(16 * mb_y + r) * fr.recon_stride[0] + (16 * mb_x + c) * PXB, y + r * ypitch + c);
+        wide_st_row<PX, 4>(fr.recon[0] + (size_t)(g.y0 + g.ystep * r) * fr.recon_stride[0] + (16 * mb_x + c) * PXB, y + r * ypitch + c);
     }
     if (lane < 4 * F::CH) {   /* chroma: lane = (2 * row + half) of Cb, then of Cr */
         const int p = lane >= 2 * F::CH, k = lane - 2 * F::CH * p, r = k >> 1, c = 4 * (k & 1);
-        wide_st_row<PX, 4>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + r) * fr.recon_stride[1] + (8 * mb_x + c) * PXB, (p ? cr : cb) + r * cpitch + c);
+        wide_st_row<PX, 4>(fr.recon[1 + p] + (size_t)(g.cy0 + g.ystep * r) * fr.recon_stride[1] + (8 * mb_x + c) * PXB, (p ? cr : cb) + r * cpitch + c);
     }
 }
 
@@ -346,7 +365,7 @@ __device__ inline int wide_qpel_px(const uint16_t *win, const int16_t *tmp, int 
 /* one prediction direction of one partition: mc_dir_part, h264_mb.c:204-318.  Windows are fetched with clamped coordinates, which is
  * what emulated_edge_mc produces (videodsp_template.c:24-96).  dy / dcb / dcr: the macroblock's 16-pitch luma and 8-pitch chroma tiles */
 template <int BD, int CF>
-__device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, int mb_x, int mb_y, int list, int n_raster, int quadrant,
+__device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, int mb_x, const WideGeom &g, int list, int n_raster, int quadrant,
                                    int bx, int by, int w, int h, uint16_t *dy, uint16_t *dcb, uint16_t *dcr, int avg)
 {
     typedef Fmt<BD, CF> F;
@@ -355,9 +374,10 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const uint32_t mvw = s.mv[list][n_raster];
     const int slot = s.hdr.u.inter.ref_pic[list][quadrant];
     const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
-    const int my = (int16_t)(mvw >> 16) + (mb_y * 16 + by) * 4;
+    const int my = (int16_t)(mvw >> 16) + (g.mcy * 16 + by) * 4;
     const uint8_t *const *rp = fr.ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
-    const int W = 16 * fr.mb_width, H = 16 * fr.mb_height;
+    const int W = 16 * fr.mb_width, H = (16 * fr.mb_height) >> g.hs;
+    const size_t rys = (size_t)fr.dst_stride[0] << g.hs, rcs = (size_t)fr.dst_stride[1] << g.hs;      /* a field macroblock of an MBAFF frame predicts from fields */
     const int lw = w == 16 ? 4 : (w == 8 ? 3 : 2);            /* log2 of the block's width */
     {
         const int x0 = (mx >> 2) - 2, y0 = (my >> 2) - 2, ww = w + 5, hh = h + 5, nc = (ww + 7) >> 3;
@@ -366,7 +386,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
             const int r = nc == 3 ? lane / 3 : (nc == 2 ? lane >> 1 : lane), c = lane - r * nc;
             if (r < hh) {
                 PX v[8];
-                __builtin_memcpy(v, rp[0] + (size_t)(y0 + r) * fr.dst_stride[0] + (size_t)(x0 + 8 * c) * sizeof(PX), sizeof(v));
+                __builtin_memcpy(v, rp[0] + (size_t)(y0 + r) * rys + (size_t)(x0 + 8 * c) * sizeof(PX), sizeof(v));
 #pragma unroll
                 for (int k = 0; k < 8; k++) s.win[r * WP + 8 * c + k] = v[k];
             }
@@ -374,7 +394,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
         for (int i = lane; i < ww * hh; i += 64) {
             const int r = i / ww, c = i - r * ww;
             const int xx = clip3(x0 + c, 0, W - 1), yy = clip3(y0 + r, 0, H - 1);
-            s.win[r * WP + c] = reinterpret_cast<const PX *>(rp[0] + (size_t)yy * fr.dst_stride[0])[xx];
+            s.win[r * WP + c] = reinterpret_cast<const PX *>(rp[0] + (size_t)yy * rys)[xx];
         }
         MI355_WAVE_SYNC();
         if (((mx & 3) == 2 && (my & 3)) || ((my & 3) == 2 && (mx & 3))) {
@@ -399,13 +419,13 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, cby = CF == 2 ? by : by >> 1;
     const int myc = CF == 1 ? my + s.hdr.u.inter.chroma_dy[list][quadrant] : my;
     const int cx = mx >> 3, cy = CF == 2 ? myc >> 2 : myc >> 3, fx = mx & 7, fy = CF == 2 ? (myc << 1) & 7 : myc & 7;
-    const int CWd = 8 * fr.mb_width, CHt = F::CH * fr.mb_height, cww = cw + 1, chh = ch + 1, ncc = (cww + 7) >> 3;
+    const int CWd = 8 * fr.mb_width, CHt = (F::CH * fr.mb_height) >> g.hs, cww = cw + 1, chh = ch + 1, ncc = (cww + 7) >> 3;
     if (cx >= 0 && cy >= 0 && cx + 8 * ncc <= CWd && cy + chh <= CHt) {
         const int r = ncc == 2 ? lane >> 1 : lane, c = lane - r * ncc;
         for (int p = 0; p < 2; p++)
             if (r < chh) {
                 PX v[8];
-                __builtin_memcpy(v, rp[1 + p] + (size_t)(cy + r) * fr.dst_stride[1] + (size_t)(cx + 8 * c) * sizeof(PX), sizeof(v));
+                __builtin_memcpy(v, rp[1 + p] + (size_t)(cy + r) * rcs + (size_t)(cx + 8 * c) * sizeof(PX), sizeof(v));
 #pragma unroll
                 for (int k = 0; k < 8; k++) s.win[p * CWIN + r * CWP + 8 * c + k] = v[k];
             }
@@ -414,7 +434,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
         for (int i = lane; i < cww * chh; i += 64) {
             const int r = i / cww, c = i - r * cww;
             const int xx = clip3(cx + c, 0, CWd - 1), yy = clip3(cy + r, 0, CHt - 1);
-            s.win[p * CWIN + r * CWP + c] = reinterpret_cast<const PX *>(rp[1 + p] + (size_t)yy * fr.dst_stride[1])[xx];
+            s.win[p * CWIN + r * CWP + c] = reinterpret_cast<const PX *>(rp[1 + p] + (size_t)yy * rcs)[xx];
         }
     MI355_WAVE_SYNC();
     const int A = (8 - fx) * (8 - fy), B = fx * (8 - fy), C = (8 - fx) * fy, D = fx * fy;
@@ -456,16 +476,17 @@ __device__ inline void wide_biweight(uint16_t *d, const uint16_t *s, int pitch, 
 
 /* mc_part (h264_mc_template.c:44-62) -> mc_part_std / mc_part_weighted (h264_mb.c:320-471) */
 template <int BD, int CF>
-__device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, int mb_y,
+__device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr, const mi355_h264_slice &sl, int mb_x, const WideGeom &g,
                                     int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
-    const int r0 = s.hdr.ref_idx[0][quadrant], r1 = s.hdr.ref_idx[1][quadrant];
+    /* a field macroblock of an MBAFF frame counts fields: entry 16 + 2i (+ 1) of the reference's weight tables repeats frame i's (h264_slice.c pred_weight_table) */
+    const int r0 = s.hdr.ref_idx[0][quadrant] >> g.hs, r1 = s.hdr.ref_idx[1][quadrant] >> g.hs;
     const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
     const bool two = l0 && l1;
     for (int list = 0; list < 2; list++) {
         if (!(list ? l1 : l0)) continue;
         const bool second = list == 1 && two, to_q = second && weighted;
-        wide_mc_dir<BD, CF>(s, fr, mb_x, mb_y, list, n_raster, quadrant, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0], to_q ? s.qc[1] : s.pc[1],
+        wide_mc_dir<BD, CF>(s, fr, mb_x, g, list, n_raster, quadrant, bx, by, w, h, to_q ? s.qy : s.py, to_q ? s.qc[0] : s.pc[0], to_q ? s.qc[1] : s.pc[1],
                             second && !weighted);
     }
     if (!weighted) return;
@@ -517,6 +538,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
     const bool luma_coded = (s.hdr.cbp & 15) != 0, chroma_coded = (s.hdr.cbp & 0x30) != 0;
     if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (s.hdr.cbp & 15) | (chroma_coded ? 16 : 0));
     const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
+    const WideGeom g = wide_geom<BD, CF>(fr, t, mb_y);
 
     /* hl_motion, h264_mc_template.c:64-163 */
 #define DIRF(part, list) (int)((t >> (12 + (part) + 2 * (list))) & 1)
@@ -541,7 +563,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
             by = y + (shape == MI355_SUB_8x4 ? 4 * j : (shape == MI355_SUB_4x4 ? 4 * (j >> 1) : 0));
             n = (bx >> 2) + 4 * (by >> 2);
         }
-        wide_mc_part<BD, CF>(s, fr, sl, mb_x, mb_y, n, quad, bx, by, w, h, l0, l1);
+        wide_mc_part<BD, CF>(s, fr, sl, mb_x, g, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
     /* hl_decode_mb_idct_luma (h264_mb.c:726-795): idct_add16 / idct8_add4 choose between full, DC-only and nothing per block; so does
@@ -552,7 +574,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         else wide_add_blocks4<BD, CF>(s.coef, 16, false, s.py, 16);
     }
     wide_residual_chroma<BD, CF>(s.coef, s.hdr, s.pc[0], s.pc[1], 8);
-    wide_store_mb<BD, CF>(fr, mb_x, mb_y, s.py, 16, s.pc[0], s.pc[1], 8);
+    wide_store_mb<BD, CF>(fr, mb_x, g, s.py, 16, s.pc[0], s.pc[1], 8);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -591,25 +613,28 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
     const uint32_t t = h.mb_type;
     /* Intra16x16 carries DC levels in every block whatever its pattern says; I_PCM is all samples */
     wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (t & MI355_MB_INTRA_PCM) ? 31 : (((t & MI355_MB_INTRA16x16) ? 15 : (h.cbp & 15)) | ((h.cbp & 0x30) ? 16 : 0)));
+    const WideGeom g = wide_geom<BD, CF>(fr, t, mb_y);
     const bool bypass = (h.flags & MI355_MBF_BYPASS) != 0, bypass_pred = (h.flags & MI355_MBF_BYPASS_PRED) != 0, x264old = (h.flags & MI355_MBF_BYPASS_X264OLD) != 0;
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:101-153: the samples themselves, one per coefficient slot: Y, Cb, Cr */
         for (int i = lane; i < 256; i += 64) WTILE(i & 15, i >> 4) = (uint16_t)s.coef[i];
         for (int i = lane; i < 8 * F::CH; i += 64) { WCTILE(0, i & 7, i >> 3) = (uint16_t)s.coef[256 + i]; WCTILE(1, i & 7, i >> 3) = (uint16_t)s.coef[256 + 8 * F::CH + i]; }
         MI355_WAVE_SYNC();
-        wide_store_mb<BD, CF>(fr, mb_x, mb_y, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
+        wide_store_mb<BD, CF>(fr, mb_x, g, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
         return;
     }
     /* the unfiltered edge samples of the neighbours: the row above (columns -1..23), the column to the left */
     const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], pic_w = 16 * fr.mb_width;
-    if (mb_y > 0 && lane < 25 && mb_x * 16 + lane - 1 >= 0 && mb_x * 16 + lane - 1 < pic_w)
-        WTILE(lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y - 1) * ys)[16 * mb_x + lane - 1];
+    /* (a field macroblock of an MBAFF frame: the line above in ITS field, the column to its left on ITS lines — the samples the reference reads with
+     * the doubled line size, whatever the neighbouring pairs' coding) */
+    if (g.y0 - g.ystep >= 0 && lane < 25 && mb_x * 16 + lane - 1 >= 0 && mb_x * 16 + lane - 1 < pic_w)
+        WTILE(lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(g.y0 - g.ystep) * ys)[16 * mb_x + lane - 1];
     if (mb_x > 0 && lane >= 32 && lane < 48)
-        WTILE(-1, lane - 32) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(16 * mb_y + lane - 32) * ys)[16 * mb_x - 1];
+        WTILE(-1, lane - 32) = reinterpret_cast<const PX *>(fr.recon[0] + (size_t)(g.y0 + g.ystep * (lane - 32)) * ys)[16 * mb_x - 1];
     for (int p = 0; p < 2; p++) {
-        if (mb_y > 0 && lane < 9 && (mb_x > 0 || lane > 0))
-            WCTILE(p, lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y - 1) * cs)[8 * mb_x + lane - 1];
+        if (g.cy0 - g.ystep >= 0 && lane < 9 && (mb_x > 0 || lane > 0))
+            WCTILE(p, lane - 1, -1) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(g.cy0 - g.ystep) * cs)[8 * mb_x + lane - 1];
         if (mb_x > 0 && lane >= 16 && lane < 16 + F::CH)
-            WCTILE(p, -1, lane - 16) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + lane - 16) * cs)[8 * mb_x - 1];
+            WCTILE(p, -1, lane - 16) = reinterpret_cast<const PX *>(fr.recon[1 + p] + (size_t)(g.cy0 + g.ystep * (lane - 16)) * cs)[8 * mb_x - 1];
     }
     MI355_WAVE_SYNC();
 
@@ -703,7 +728,7 @@ k_wide_intra(const mi355_h264_frame *frames, int level, int width)
         }
     }
     wide_residual_chroma<BD, CF>(s.coef, h, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
-    wide_store_mb<BD, CF>(fr, mb_x, mb_y, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
+    wide_store_mb<BD, CF>(fr, mb_x, g, &WTILE(0, 0), TPW, &WCTILE(0, 0, 0), &WCTILE(1, 0, 0), CPW);
 }
 #undef WTILE
 #undef WCTILE
