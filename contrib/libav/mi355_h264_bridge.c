@@ -359,7 +359,7 @@ static int disp_enqueue(Disp *D, int slot)
     for (int k = 0; k < nd; k++) any_inter |= !(hr[k].flags & MI355_FRAME_NO_INTER);
     if (b0->wide) {      /* High 10 / High 4:2:2 / transform bypass: the second kernel set, reconstruction and loop filter from their descriptor arrays */
         if (!rc && mi355_h264_decode_frames_wide_dev(dr, nd, mw, mh, maxl, D->widths, b0->bit_depth, b0->kidc, any_inter ? 3 : 2, st) != 0) rc = -1;
-        if (!rc && mi355_h264_decode_frames_wide_dev(dd, nd, mw, mh, 0, NULL, b0->bit_depth, b0->kidc, 4, st) != 0) rc = -1;
+        if (!rc && mi355_h264_decode_frames_wide_dev(dd, nd, mw, mh, 0, NULL, b0->bit_depth, b0->kidc, D->in[slot][0]->s->cls >= 1000 ? 12 : 4, st) != 0) rc = -1;
     } else {
     if (!rc && any_inter && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
     if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
@@ -906,6 +906,7 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     /* which macroblock edges the loop filter sees a neighbour across: fill_filter_caches, h264_slice.c:2131-2145 */
     if (!sl->deblocking_filter) m->flags |= MI355_MBF_NO_DEBLOCK;
     else {
+        if (sl->deblocking_filter == 2) m->flags |= MI355_MBF_FILTER_OWN_SLICE;
         if (sl->mb_x > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - 1] == sl->slice_num)) m->flags |= MI355_MBF_LEFT_EDGE;
         if (mb_row > 0 && (sl->deblocking_filter != 2 || h->slice_table[mb_xy - (h->mb_stride << b->field)] == sl->slice_num)) m->flags |= MI355_MBF_TOP_EDGE;
     }
@@ -1132,7 +1133,7 @@ static int submit_picture(Bridge *b, H264Context *h)
         if (b->wide) {
             if (side_upload(b, s, b->stream)) return -3;
             if (mi355_h264_decode_frames_wide_dev(s->d_desc, np, b->mb_w, b->mb_h, maxl, s->widths, b->bit_depth, b->kidc, 3, b->stream) != 0 ||
-                mi355_h264_decode_frames_wide_dev(s->d_desc + np, np, b->mb_w, b->mb_h, 0, NULL, b->bit_depth, b->kidc, 4, b->stream) != 0) return -4;
+                mi355_h264_decode_frames_wide_dev(s->d_desc + np, np, b->mb_w, b->mb_h, 0, NULL, b->bit_depth, b->kidc, b->mbaff_frame ? 12 : 4, b->stream) != 0) return -4;
         } else
         if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
             mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||

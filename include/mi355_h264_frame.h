@@ -59,6 +59,9 @@ extern "C" {
                                       becomes the running sum of the pred*_add functions (h264pred_template.c:1127-1354; h264_mb.c:636, :668, :737) */
 #define MI355_MBF_BYPASS_X264OLD 0x40 /* ... decoded with h->x264_build < 151: Intra 8x8 sums start from the UNFILTERED edge (pred8x8l_add
                                       instead of pred8x8l_filter_add, h264_mb.c:637-643) */
+#define MI355_MBF_FILTER_OWN_SLICE 0x80 /* sl->deblocking_filter == 2: edges towards other slices are not filtered.  The kernels of plain frames and fields
+                                      read that from LEFT_EDGE / TOP_EDGE; the loop filter of MBAFF frames decides which macroblock is "left" and "above"
+                                      itself (fill_filter_caches, h264_slice.c:2066-2113) and compares slice_id */
 
 /* mi355_h264_mb.sub_mb_type[i] (only for MI355_MB_8x8): shape of 8x8 quadrant i */
 #define MI355_SUB_8x8  0
@@ -285,7 +288,8 @@ int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_frames, int n
  *   - mi355_h264_mb: qp / qpc are the table values (QpBdOffset included, as h->cur_pic.qscale_table holds them); dc_qmul[1..2] with
  *     chroma_format_idc 2 = dequant4_coeff[..][chroma_qp + 3][0] (h264_mb_template.c:232-236); the nnz_mask bits of chroma BLOCKS
  *     are not read (the kernels look at a block's coefficients: AC present, DC alone, nothing), the DC bits are.
- * passes: bit 0 inter, bit 1 intra, bit 2 loop filter (7 = everything; the separate bits are for measurement).
+ * passes: bit 0 inter, bit 1 intra, bit 2 loop filter (7 = everything; the separate bits are for measurement); bit 3 (8): the batch holds MBAFF
+ * frames (MI355_FRAME_MBAFF in every descriptor) — the loop filter then works on macroblock pairs.
  * bit_depth 8 with chroma_format_idc 1 is taken too: the pictures the kernels above decode, through this kernel set (linear surfaces
  * only; how the two sets are tested against each other and against the oracle).
  * Returns 0, -1 (arguments / a format outside 8..10 bits, 4:2:0 / 4:2:2), -2, -3 as the others. */

@@ -767,7 +767,8 @@ __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
     return iabs((int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF)) >= 4 || iabs((int16_t)(a >> 16) - (int16_t)(b >> 16)) >= ylim;
 }
 /* check_mv, h264_loopfilter.c:442-470 */
-__device__ inline int wide_check_mv(const WideDbLds &s, int b, int bn, int list_count, int ylim)
+template <typename LDS>
+__device__ inline int wide_check_mv(const LDS &s, int b, int bn, int list_count, int ylim)
 {
     bool v = s.ref[0][b] != s.ref[0][bn];
     if (!v && s.ref[0][b] != -1) v = wide_mv_far(s.mv[0][b], s.mv[0][bn], ylim);
@@ -1007,6 +1008,273 @@ k_wide_deblock_rows(const mi355_h264_frame *frames, int nframes, int max_w, int 
 #undef DY
 #undef DC
 
+/* ------------------------------------------------------------------------- */
+/* loop filter of MBAFF frames                                                  */
+/* ------------------------------------------------------------------------- */
+/* ff_h264_filter_mb for macroblock PAIRS (h264_loopfilter.c:716-847 with its FRAME_MBAFF branches, fill_filter_caches h264_slice.c:2056-2196):
+ * lanes 16g..16g+15 filter pair (x, pr) of picture 4k + g — its top macroblock, then its bottom one, in a tile that holds the pair's 32 lines,
+ * four columns of the left pair and six lines of the pair above.  A FRAME macroblock's lines are 16 * pos + r of the pair, a FIELD macroblock's
+ * pos + 2r.  What differs from a plain frame:
+ *   - the left edge between pairs of different coding: eight strengths from coefficient flags alone, two QPs (one per left macroblock), eight lines
+ *     per call of the *_mbaff edge filters (:733-806);
+ *   - the top edge of a frame macroblock under a field pair: filtered twice, once per field of the pair above, strengths 1 / 2 (3 intra), never the
+ *     strong filter (:497-540);
+ *   - which macroblock is "above": the same pair's top macroblock, the pair above's bottom macroblock, or for a top field macroblock the pair above's
+ *     top field macroblock (fill_filter_caches :2066-2080); frame / field neighbours in the vertical direction give strength 1 without looking at
+ *     vectors (:568-571); intra strength 4 only between frame macroblocks or on vertical edges (:551-556); the vertical vector limit is 2 for a field
+ *     macroblock (:723).
+ * One launch per anti-diagonal of PAIRS (d = x + 2 * pr). */
+struct WideMbaffLds {
+    mi355_h264_mb m[6];                  /* this pair (top, bottom), the left pair, the pair above */
+    int32_t ref[2][25];
+    uint32_t mv[2][25];
+    uint8_t nnz[25];
+    uint8_t bs[2][4][4];
+    uint8_t bs8[8];                      /* the left edge between pairs of different coding */
+    uint8_t bsd[2][4];                   /* the twice-filtered top edge: [field of the pair above][column / 4] */
+    uint16_t y[38 * DYP];                /* lines -6..31 of the pair, columns -4..15 */
+    uint16_t c[2][36 * DCPW];            /* lines -4..31 (4:2:0: ..15), columns -4..7 */
+};
+#define PY(x, R) s.y[((R) + 6) * DYP + (x) + 4]
+#define PC(p, x, R) s.c[p][((R) + 4) * DCPW + (x) + 4]
+
+template <int BD, int CF>
+__global__ void __launch_bounds__(64)
+k_wide_deblock_mbaff(const mi355_h264_frame *frames, int nframes, int d, int max_pr)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    constexpr int PXB = (int)sizeof(PX), CHP = 2 * F::CH;       /* chroma lines of a pair */
+    __shared__ WideMbaffLds sh[4];
+    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
+    WideMbaffLds &s = sh[g];
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
+    const int f = 4 * ((int)blockIdx.x / max_pr) + g, pr = (int)blockIdx.x % max_pr, x = d - 2 * pr;
+    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
+    const int W = fr.mb_width;
+    const bool ok = f < nframes && 2 * pr + 1 < fr.mb_height && x >= 0 && x < W;
+    const bool has_left = x > 0, has_top = pr > 0;
+    const int xy0 = 2 * pr * W + x;                              /* the pair's top macroblock */
+    const int yd = fr.dst_stride[0], cd = fr.dst_stride[1], ys = fr.recon_stride[0], cs = fr.recon_stride[1];
+    if (ok) {
+        const int idx[6] = { xy0, xy0 + W, has_left ? xy0 - 1 : xy0, has_left ? xy0 + W - 1 : xy0, has_top ? xy0 - 2 * W : xy0, has_top ? xy0 - W : xy0 };
+        for (int k = 0; k < 6; k++) reinterpret_cast<uint32_t *>(&s.m[k])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[idx[k]])[l];
+        for (int h2 = 0; h2 < 2; h2++) {
+            const int R = l + 16 * h2;
+            wide_ld_row<PX, 16>(fr.recon[0] + (size_t)(32 * pr + R) * ys + 16 * x * PXB, &PY(0, R));
+            if (has_left) wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(32 * pr + R) * yd + (16 * x - 4) * PXB, &PY(-4, R));
+            const int k = l + 16 * h2;                           /* 24 pieces of four samples: the six lines above */
+            if (has_top && k < 24) { const int R2 = (k >> 2) - 6, c = 4 * (k & 3); wide_ld_row<PX, 4>(fr.dst[0] + (size_t)(32 * pr + R2) * yd + (16 * x + c) * PXB, &PY(c, R2)); }
+        }
+        for (int p = 0; p < 2; p++) {
+            for (int R = l; R < CHP; R += 16) {
+                wide_ld_row<PX, 8>(fr.recon[1 + p] + (size_t)(CHP * pr + R) * cs + 8 * x * PXB, &PC(p, 0, R));
+                if (has_left) wide_ld_row<PX, 4>(fr.dst[1 + p] + (size_t)(CHP * pr + R) * cd + (8 * x - 4) * PXB, &PC(p, -4, R));
+            }
+            if (has_top && l < 8) { const int R2 = (l >> 1) - 4, c = 4 * (l & 1); wide_ld_row<PX, 4>(fr.dst[1 + p] + (size_t)(CHP * pr + R2) * cd + (8 * x + c) * PXB, &PC(p, c, R2)); }
+        }
+    }
+    MI355_WAVE_SYNC();
+    const int qp_bd = 6 * (BD - 8);
+    /* one luma line across an edge (q: the sample on the q side, st: step across the edge) */
+    auto luma_line = [&](uint16_t *q, int st, int bs, int qp, int a_off, int b_off) {
+        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
+        if (bs < 4) {
+            int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
+            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
+            q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
+        } else {
+            int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
+            lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
+            q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
+        }
+    };
+    auto chroma_line = [&](uint16_t *q, int st, int bs, int qp, int a_off, int b_off) {
+        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
+        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
+        int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
+        if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
+        else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
+        q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
+    };
+    for (int pos = 0; pos < 2; pos++) {
+        const mi355_h264_mb &m = s.m[pos];
+        const bool filter = ok && !(m.flags & MI355_MBF_NO_DEBLOCK);
+        const uint32_t t = m.mb_type;
+        const bool cur_field = (t & 0x80u) != 0;
+        const int R0 = cur_field ? pos : 16 * pos, step = cur_field ? 2 : 1;           /* luma (and 4:2:2 chroma) lines of this macroblock in the tile */
+        const int C0 = cur_field ? pos : F::CH * pos;
+        const int mb_xy = xy0 + pos * W;
+        const bool own_slice = (m.flags & MI355_MBF_FILTER_OWN_SLICE) != 0;
+        /* the neighbours: fill_filter_caches */
+        const bool left_ok = has_left && (!own_slice || s.m[2].slice_id == m.slice_id);
+        const bool left_field = (s.m[2].mb_type & 0x80u) != 0;
+        const bool left_mixed = left_ok && left_field != cur_field;
+        /* above: 0 = the same pair's top macroblock, 4 / 5 = the pair above's top / bottom macroblock */
+        int top_k = -1;
+        if (!cur_field && pos == 1) top_k = 0;
+        else if (has_top) top_k = (cur_field && pos == 0 && (s.m[4].mb_type & 0x80u)) ? 4 : 5;
+        if (top_k >= 4 && own_slice && s.m[top_k].slice_id != m.slice_id) top_k = -1;
+        const bool top_double = top_k == 5 && !cur_field && pos == 0 && (s.m[5].mb_type & 0x80u);       /* a frame macroblock under a field pair */
+        const int top_xy = top_k == 0 ? xy0 : (top_k == 4 ? xy0 - 2 * W : xy0 - W);
+        int list_count = 1;
+        const int ylim = cur_field ? 2 : 4;
+        if (filter) {
+            list_count = fr.slices[m.slice_id].list_count;
+            for (int k = 0; k < 2; k++) {
+                if (k && l >= 8) break;
+                int which, nxy, x4, y4, cx, cy;
+                if (!k) { which = pos; nxy = mb_xy; x4 = l & 3; y4 = l >> 2; cx = x4; cy = y4; }
+                else if (l < 4) { which = 2 + pos; nxy = mb_xy - 1; x4 = 3; y4 = l; cx = -1; cy = y4; }
+                else { which = top_k < 0 ? pos : top_k; nxy = top_k < 0 ? mb_xy : top_xy; x4 = l - 4; y4 = 3; cx = x4; cy = -1; }
+                if (k && l < 4 && !has_left) { which = pos; nxy = mb_xy; }
+                const int ci = (cy + 1) * 5 + cx + 1;
+                for (int list = 0; list < 2; list++) {
+                    s.ref[list][ci] = wide_ref_identity(s.m[which], list, x4, y4);
+                    s.mv[list][ci] = fr.mv[list] ? reinterpret_cast<const uint32_t *>(fr.mv[list])[(size_t)nxy * 16 + x4 + 4 * y4] : 0u;
+                }
+                s.nnz[ci] = (uint8_t)((s.m[which].nnz_mask >> blk_index(x4, y4)) & 1);
+            }
+        }
+        MI355_WAVE_SYNC();
+        if (filter) {
+            const int edge = l >> 2, i = l & 3, tk = (t >> 3) & 7;
+            for (int dir = 0; dir < 2; dir++) {
+                const int mask_edge = dir == 0 ? (tk == 0 ? 0 : (tk < 4 ? 3 : 1)) : (tk == 0 ? 0 : (tk == 1 ? 3 : (tk < 4 ? 1 : 3)));
+                const int edges = (mask_edge == 3 && !(m.cbp & 15)) ? 1 : 4;
+                const uint32_t par_types = MI355_MB_16x16 | (MI355_MB_8x16 >> dir);
+                const bool mask_par0 = (t & par_types) != 0;
+                const int bx = dir == 0 ? edge : i, by = dir == 0 ? i : edge;
+                const int b = (by + 1) * 5 + bx + 1, bn = b - (dir ? 5 : 1);
+                int bs = 0;
+                if (edge == 0) {
+                    const bool avail = dir == 0 ? (left_ok && !left_mixed) : (top_k >= 0 && !top_double);     /* the mixed left edge and the twice-filtered top edge: below */
+                    if (avail) {
+                        const mi355_h264_mb &mm = dir == 0 ? s.m[2 + pos] : s.m[top_k];
+                        const uint32_t tm = mm.mb_type;
+                        if ((t | tm) & MI355_MB_INTRA) bs = (!((t | tm) & 0x80u) || dir == 0) ? 4 : 3;
+                        else if (dir == 1 && ((t ^ tm) & 0x80u)) bs = (s.nnz[b] | s.nnz[bn]) ? 2 : 1;                /* frame above field or field above frame: no look at the vectors */
+                        else if (s.nnz[b] | s.nnz[bn]) bs = 2;
+                        else if (mask_par0 && (tm & par_types)) bs = wide_check_mv(s, 6, 6 - (dir ? 5 : 1), list_count, ylim);
+                        else bs = wide_check_mv(s, b, bn, list_count, ylim);
+                    }
+                } else if (edge < edges) {
+                    const bool deblock_edge = !((t & MI355_MB_8x8DCT) && (edge & 1));
+                    if (deblock_edge || (CF == 2 && dir == 1)) {
+                        if (t & MI355_MB_INTRA) bs = 3;
+                        else if (s.nnz[b] | s.nnz[bn]) bs = 2;
+                        else if (edge & mask_edge) bs = 0;
+                        else if (mask_par0) { const int b0 = dir == 0 ? 5 + edge + 1 : (edge + 1) * 5 + 1; bs = wide_check_mv(s, b0, b0 - (dir ? 5 : 1), list_count, ylim); }
+                        else bs = wide_check_mv(s, b, bn, list_count, ylim);
+                    }
+                }
+                s.bs[dir][edge][i] = (uint8_t)bs;
+            }
+            if (l < 8) {
+                /* the left edge between pairs of different coding, :748-770: strength i pairs this macroblock's block row i >> 1 with a block of one of the
+                 * left pair's macroblocks */
+                int bs = 0;
+                if (left_mixed) {
+                    const int j = cur_field ? l >> 2 : l & 1;                                     /* which macroblock of the left pair */
+                    const int lrow = cur_field ? (l & 3) : 2 * pos + (l >> 2);                    /* ... and which of its block rows (column 3) */
+                    const mi355_h264_mb &mn = s.m[2 + j];
+                    if ((t | mn.mb_type) & MI355_MB_INTRA) bs = 4;
+                    else bs = 1 + (int)((((m.nnz_mask >> blk_index(0, l >> 1)) | (mn.nnz_mask >> blk_index(3, lrow))) & 1) != 0);
+                }
+                s.bs8[l] = (uint8_t)bs;
+                /* the top edge of a frame macroblock under a field pair, :497-540: [field j of the pair above][column / 4] */
+                int bd2 = 0;
+                if (top_double) {
+                    const int j = l >> 2, col = l & 3;
+                    const mi355_h264_mb &mn = s.m[4 + j];
+                    if ((t | mn.mb_type) & MI355_MB_INTRA) bd2 = 3;
+                    else bd2 = 1 + (int)((((m.nnz_mask >> blk_index(col, 0)) | (mn.nnz_mask >> blk_index(col, 3))) & 1) != 0);
+                }
+                s.bsd[l >> 2][l & 3] = (uint8_t)bd2;
+            }
+        }
+        MI355_WAVE_SYNC();
+        {
+            const int a_off = m.slice_alpha_c0_offset, b_off = m.slice_beta_offset;
+            const bool dct8 = (t & MI355_MB_8x8DCT) != 0;
+            for (int dir = 0; dir < 2; dir++)
+                for (int edge = 0; edge < 4; edge++) {
+                    if (filter && dir == 0 && edge == 0 && left_mixed) {
+                        /* eight strengths, two QPs: luma lines l = 0..15 of this macroblock */
+                        {
+                            const int call = cur_field ? l >> 3 : l & 1, k = cur_field ? l & 7 : l >> 1;
+                            const int bs = s.bs8[cur_field ? 4 * call + (k >> 1) : call + 2 * (k >> 1)];
+                            if (bs) luma_line(&PY(0, R0 + step * l), 1, bs, (m.qp + s.m[2 + call].qp + 1) >> 1, a_off, b_off);
+                        }
+                        for (int p = 0; p < 2; p++) {
+                            if (l < F::CH) {
+                                const int call = cur_field ? l / (F::CH / 2) : l & 1, k = cur_field ? l % (F::CH / 2) : l >> 1;
+                                const int within = CF == 2 ? k >> 1 : k;                          /* 4:2:2: eight lines per call, two per strength */
+                                const int bs = s.bs8[cur_field ? 4 * call + within : call + 2 * within];
+                                if (bs) chroma_line(&PC(p, 0, C0 + step * l), 1, bs, (m.qpc[p] + s.m[2 + call].qpc[p] + 1) >> 1, a_off, b_off);
+                            }
+                        }
+                    } else if (filter && dir == 1 && edge == 0 && top_double) {
+                        /* below, with a rendezvous between the two fields */
+                    } else if (filter) {
+                        const mi355_h264_mb &mm = dir == 0 ? s.m[2 + pos] : s.m[top_k < 0 ? pos : top_k];
+                        {
+                            const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
+                            const int bs = s.bs[dir][edge][l >> 2];
+                            if (luma_on && bs) {
+                                const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
+                                if (dir == 0) luma_line(&PY(4 * edge, R0 + step * l), 1, bs, qp, a_off, b_off);
+                                else luma_line(&PY(l, R0 + step * 4 * edge), step * DYP, bs, qp, a_off, b_off);
+                            }
+                        }
+                        if (dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1))) {
+                            if (dir == 0) {
+                                for (int p = 0; p < 2; p++)
+                                    if (l < F::CH) {
+                                        const int bs = s.bs[0][edge][CF == 2 ? l >> 2 : l >> 1];
+                                        if (bs) chroma_line(&PC(p, 2 * edge, C0 + step * l), 1, bs, edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p], a_off, b_off);
+                                    }
+                            } else if (l < 8) {
+                                const int bs = s.bs[1][edge][l >> 1];
+                                for (int p = 0; p < 2; p++)
+                                    if (bs) chroma_line(&PC(p, l, C0 + step * (CF == 2 ? 4 * edge : 2 * edge)), step * DCPW, bs, edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p], a_off, b_off);
+                            }
+                        }
+                    }
+                    if (dir == 1 && edge == 0)
+                        for (int j = 0; j < 2; j++) {      /* the twice-filtered top edge: the top field's lines, then the bottom field's */
+                            if (filter && top_double) {
+                                const mi355_h264_mb &mn = s.m[4 + j];
+                                { const int bs = s.bsd[j][l >> 2]; if (bs) luma_line(&PY(l, j), 2 * DYP, bs, (m.qp + mn.qp + 1) >> 1, a_off, b_off); }
+                                if (l < 8) { const int bs = s.bsd[j][l >> 1]; for (int p = 0; p < 2; p++) if (bs) chroma_line(&PC(p, l, j), 2 * DCPW, bs, (m.qpc[p] + mn.qpc[p] + 1) >> 1, a_off, b_off); }
+                            }
+                            MI355_WAVE_SYNC();
+                        }
+                    MI355_WAVE_SYNC();
+                }
+        }
+    }
+    if (ok) {
+        for (int h2 = 0; h2 < 2; h2++) {
+            const int R = l + 16 * h2;
+            wide_st_row<PX, 16>(fr.dst[0] + (size_t)(32 * pr + R) * yd + 16 * x * PXB, &PY(0, R));
+            if (has_left) wide_st_row<PX, 4>(fr.dst[0] + (size_t)(32 * pr + R) * yd + (16 * x - 4) * PXB, &PY(-4, R));
+        }
+        if (has_top) { const int R2 = (l >> 2) - 4, c = 4 * (l & 3); wide_st_row<PX, 4>(fr.dst[0] + (size_t)(32 * pr + R2) * yd + (16 * x + c) * PXB, &PY(c, R2)); }
+        for (int p = 0; p < 2; p++) {
+            for (int R = l; R < CHP; R += 16) {
+                wide_st_row<PX, 8>(fr.dst[1 + p] + (size_t)(CHP * pr + R) * cd + 8 * x * PXB, &PC(p, 0, R));
+                if (has_left) wide_st_row<PX, 4>(fr.dst[1 + p] + (size_t)(CHP * pr + R) * cd + (8 * x - 4) * PXB, &PC(p, -4, R));
+            }
+            if (has_top && l < 4) { const int R2 = (l >> 1) - 2, c = 4 * (l & 1); wide_st_row<PX, 4>(fr.dst[1 + p] + (size_t)(CHP * pr + R2) * cd + (8 * x + c) * PXB, &PC(p, c, R2)); }
+        }
+    }
+}
+#undef PY
+#undef PC
+
 template <int BD, int CF>
 int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, int max_intra_level, const int32_t *level_widths, int passes, hipStream_t st)
 {
@@ -1021,6 +1289,12 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
             if ((long long)nframes * width > 0x7FFFFFFFLL) return -3;
             hipLaunchKernelGGL((k_wide_intra<BD, CF>), dim3((unsigned)(nframes * width)), dim3(64), 0, st, d_frames, level, width);
         }
+    if ((passes & 4) && (passes & 8)) {          /* a batch of MBAFF frames: pairs */
+        const unsigned nquads = (unsigned)((nframes + 3) / 4);
+        const int npr = mh / 2;
+        for (int d = 0; d <= (mw - 1) + 2 * (npr - 1); d++)
+            hipLaunchKernelGGL((k_wide_deblock_mbaff<BD, CF>), dim3(nquads * (unsigned)npr), dim3(64), 0, st, d_frames, nframes, d, npr);
+    } else
     if (passes & 4) {
         /* one launch per anti-diagonal; MI355_WIDE_DEBLOCK=rows: the single launch (k_wide_deblock_rows) — measured slower at every batch size in this
          * first form (16 pictures 3.4 against 3.1 ms, 512: 30 against 14: a lone wave's macroblock step is ~13 us of dependent instructions, and
