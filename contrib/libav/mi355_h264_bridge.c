@@ -64,7 +64,13 @@
  * through mi355_h264_decode_frames_wide_dev (the second kernel set, libav_amd/csrc/h264_frame_wide.hip) on planes with line strides;
  * a launch set of the dispatcher holds pictures of ONE format.
  *
- * Streams outside the Tier-2 scope (MBAFF, transform bypass, more than 10 bits), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
+ * MBAFF frames (macroblock pairs coded as frame or field macroblocks) go through the second kernel set too: the bridge names a field macroblock's
+ * references by (frame, parity) — what hl_decode_mb's ref_list[16 + ..] remap does — schedules intra macroblocks pair-wise
+ * (mi355_h264_intra_schedule_mbaff) and marks the picture MI355_FRAME_MBAFF; the kernels take a field macroblock's rows as every other line of its pair
+ * and filter pairs (k_wide_deblock_mbaff).  An MBAFF slice with IMPLICIT weights is the one thing left to the C path (field macroblocks take those from
+ * tables of their own).
+ *
+ * Streams outside the Tier-2 scope (more than 10 bits, separate colour planes), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
  * aside for that decoder: the reference's own C path continues.  Errors are reported once on stderr; nothing here
  * calls abort().
  */
@@ -231,7 +237,8 @@ static void convert_job(const Bridge *b, const DevPic *pic, uint8_t *out, mi355_
 
 static int staging_alloc(Bridge *b, Staging *s)
 {
-    const size_t n = (size_t)b->nmb, nlev = (size_t)(b->mb_w + 2 * b->mb_h + 2);
+    /* dependency levels of a picture: at most mb_w + 2 * mb_h along its anti-diagonals; in an MBAFF frame a pair adds two (top, then bottom) */
+    const size_t n = (size_t)b->nmb, nlev = (size_t)((b->mbaff ? 2 : 1) * (b->mb_w + 2 * b->mb_h) + 4);
     const int np = b->npass;
     size_t o = 0, o_mb[BR_MAX_PASSES], o_mbd[BR_MAX_PASSES], o_coef[BR_MAX_PASSES], o_sl[BR_MAX_PASSES];
     const size_t o_desc = o;   o = up64(o + 2 * BR_MAX_PASSES * sizeof(mi355_h264_frame));
@@ -568,9 +575,9 @@ static Bridge *bridge_get(const H264Context *h)
     /* a sequence that may hold field MACROBLOCKS (mb_adaptive_frame_field_flag) is outside the path as a whole; field PICTURES
      * (PAFF: the choice between a frame and two fields is made per picture) are inside: begin_picture() looks at each one */
     const int seq_mbaff = !h->ps.sps->frame_mbs_only_flag && h->ps.sps->mb_aff;
-    if ((seq_mbaff && (getenv("MI355_BRIDGE_NO_WIDE") || !getenv("MI355_BRIDGE_MBAFF"))) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
+    if ((seq_mbaff && getenv("MI355_BRIDGE_NO_WIDE")) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
         (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || (getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2 || h->ps.sps->transform_bypass))) {
-        br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4 frame or field pictures without MBAFF)");
+        br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4)");
         b->soft = 1;
         return b;
     }
@@ -620,7 +627,7 @@ static Bridge *bridge_get(const H264Context *h)
         b->stride[0] = b->lin_stride[0]; b->stride[1] = b->lin_stride[1];
         b->plane_bytes[0] = b->lin_bytes[0]; b->plane_bytes[1] = b->lin_bytes[1];
     }
-    int ok = b->mb_w + 2 * b->mb_h + 2 <= DISP_MAX_LEVELS;
+    int ok = (b->mbaff ? 2 : 1) * (b->mb_w + 2 * b->mb_h) + 4 <= DISP_MAX_LEVELS;
     if (getenv("MI355_BRIDGE_SESSION") && !b->c444 && !b->wide) {
         /* one surface per H264Picture the decoder may hold; a slice that is not one run of macroblocks goes in run by run */
         const mi355_h264_session_params sp = { b->mb_w, b->mb_h, BR_MAX_PICS, 255, b->tiled ? MI355_SURFACE_TILED : MI355_SURFACE_LINEAR, 0 };

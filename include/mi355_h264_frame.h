@@ -328,7 +328,8 @@ int mi355_h264_intra_schedule(mi355_h264_mb *mb, int mb_width, int mb_height,
                               uint32_t *list, int32_t *level_start, int *max_level_width);
 
 /* The same for an MBAFF frame (MI355_FRAME_MBAFF: macroblock rows 2k, 2k + 1 are the pairs of pair row k; mb_height even): a macroblock waits for
- * both macroblocks of the left, above-left, above and above-right PAIRS, the bottom macroblock of a pair for the top one. */
+ * both macroblocks of the left, above-left, above and above-right PAIRS, the bottom macroblock of a pair for the top one.
+ * level_start needs 2 * (mb_width + 2 * mb_height) + 1 entries here (a pair adds two levels). */
 int mi355_h264_intra_schedule_mbaff(mi355_h264_mb *mb, int mb_width, int mb_height,
                                     uint32_t *list, int32_t *level_start, int *max_level_width);
 

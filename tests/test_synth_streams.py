@@ -86,9 +86,9 @@ def test_bridge_decodes_generated_streams_emulated(tmp_path, emu, name, lazy):
 
 
 @needs_harness
-@pytest.mark.parametrize("name,no_wide", [(n, False) for n in SY.OUTSIDE] + [(n, True) for n in ("422_8_b", "420_10_t8x8", "444_10", "422_10_paff", "420_8_lossless", "444_8_lossless", "422_10_lossless")])
+@pytest.mark.parametrize("name,no_wide", [(n, False) for n in SY.OUTSIDE] + [(n, True) for n in ("422_8_b", "420_10_t8x8", "444_10", "422_10_paff", "420_8_lossless", "444_8_lossless", "422_10_lossless", "420_8_mbaff", "444_8_mbaff", "422_10_mbaff")])
 def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name, no_wide):
-    """MBAFF (and High 4:2:2, 9 / 10 bit, transform bypass when the second kernel set is switched off): the bridge says so once and the
+    """High 4:2:2, 9 / 10 bit, transform bypass and MBAFF with the second kernel set switched off (MI355_BRIDGE_NO_WIDE): the bridge says so once and the
     reference's C path decodes the stream — same pictures, nothing on the device"""
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)

@@ -68,7 +68,7 @@ def test_bridge_through_the_session_facade_gpu(tmp_path, mi355, name):
 
 
 @pytest.mark.parametrize("name,no_wide", (("422_8_b", True), ("420_10_t8x8", True), ("444_10", True), ("420_8_lossless", True), ("444_8_lossless", True), ("422_10_lossless", True),
-                                          ("422_10_paff", True), ("420_8_mbaff", False), ("444_8_mbaff", False), ("422_10_mbaff", False)))
+                                          ("422_10_paff", True), ("420_8_mbaff", True), ("444_8_mbaff", True), ("422_10_mbaff", True)))
 def test_bridge_steps_aside_for_streams_outside_tier2_gpu(tmp_path, mi355, name, no_wide):
     _need("h264_bridge_gpu")
     out = tmp_path / "o.yuv"
