@@ -32,7 +32,9 @@ typedef struct mi355_hevc_tu_job {
     uint8_t *dst;             /* picture samples of the block, or NULL */
     int32_t dst_stride;
     uint8_t log2_size;        /* 2..5 */
-    uint8_t col_limit;        /* as passed to c->idct[] */
+    uint8_t col_limit;        /* as passed to c->idct[]: hevcdec.c:1178-1196 derives it from the last significant coefficient of the block's scan
+                                 (last_x + last_y + 4, capped by size class), so rows col_limit + 4 .. size - 1 of `coeffs` hold zeros — the batched
+                                 kernel does not fetch them (the reference's pruned passes read nothing of them but every fourth row, which is zero) */
     uint8_t kind;             /* MI355_HEVC_TU_* */
     uint8_t reserved;
 } mi355_hevc_tu_job;
