@@ -359,7 +359,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
     # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set
     try:
-        F10 = 512
+        F10 = 2048
         dev = HF.DeviceFrames(prov, base, replicate=F10, bit_depth=10)
         try:
             lw = level_widths(base)
