@@ -788,29 +788,6 @@ __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int lis
     return r == 0xFF ? -1 : r;
 }
 
-/* The normal-strength line filters (h264dsp_template.c:104-150, :233-270) without branches: every condition a mask, every result a select —
- * in the four-pictures-per-wave kernels some lane always takes every path, and a divergent branch costs its exec-mask bookkeeping on top.
- * tc0 >= 0 (a strength above 0); tc (chroma) > 0. */
-template <int MAXV>
-__device__ __forceinline__ void wide_lf_luma_sel(int p2, int &p1, int &p0, int &q0, int &q1, int q2, int alpha, int beta, int tc0)
-{
-    const int f = (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta);
-    const int ap = (int)(iabs(p2 - p0) < beta), aq = (int)(iabs(q2 - q0) < beta);
-    const int tc = tc0 + ap + aq, avg = (p0 + q0 + 1) >> 1;
-    const int np1 = p1 + clip3(((p2 + avg) >> 1) - p1, -tc0, tc0), nq1 = q1 + clip3(((q2 + avg) >> 1) - q1, -tc0, tc0);
-    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-    const int np0 = clip3(p0 + delta, 0, MAXV), nq0 = clip3(q0 - delta, 0, MAXV);
-    p1 = (f & ap) ? np1 : p1; q1 = (f & aq) ? nq1 : q1; p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
-}
-template <int MAXV>
-__device__ __forceinline__ void wide_lf_chroma_sel(int p1, int &p0, int &q0, int q1, int alpha, int beta, int tc)
-{
-    const int f = (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta) & (int)(tc > 0);
-    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-    const int np0 = clip3(p0 + delta, 0, MAXV), nq0 = clip3(q0 - delta, 0, MAXV);
-    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
-}
-
 /* One macroblock (mb_x, mb_y) per sixteen-lane group — ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without
  * MBAFF.  The macroblock's own samples come from `recon`, four rows of the top neighbour from `dst` (as that macroblock's own pass left
  * them) and four columns of the left neighbour from `dst` or — carry_left: the caller filtered that macroblock with this tile a moment ago
@@ -914,7 +891,7 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
             const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
             const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
             int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-            if (bs < 4) wide_lf_chroma_sel<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
+            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
             else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
             q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
         };
@@ -933,7 +910,7 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
                         const int st = dir == 0 ? 1 : DYP;
                         if (bs < 4) {
                             int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
-                            wide_lf_luma_sel<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
+                            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
                             q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
                         } else {
                             int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
