@@ -357,7 +357,14 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
-    # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set
+    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
+        try:
+            r = fn(lib)
+            pts.extend(r if isinstance(r, list) else [r])
+        except Exception as e:                 # an extra point must not take the headline line down with it
+            pts.append({"name": fn.__name__, "error": repr(e)})
+    # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set — last: its 2048 pictures take
+    # 100 GB of HBM, and the decoder processes of the real-stream points above should not start beside an allocator that has just let go of them
     try:
         F10 = 2048
         dev = HF.DeviceFrames(prov, base, replicate=F10, bit_depth=10)
@@ -385,12 +392,6 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
                             "one loop-filter launch per anti-diagonal); parity: the generated High 10 / High 4:2:2 streams against the reference decoder"})
     except Exception as e:
         pts.append({"name": "config2_high10", "error": repr(e)})
-    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
-        try:
-            r = fn(lib)
-            pts.extend(r if isinstance(r, list) else [r])
-        except Exception as e:                 # an extra point must not take the headline line down with it
-            pts.append({"name": fn.__name__, "error": repr(e)})
     return pts
 
 
