@@ -805,6 +805,11 @@ static int slice_index(Bridge *b, const H264Context *h, const H264SliceContext *
             }
         for (int r1 = 0; r1 < MI355_H264_MAX_REFS; r1++) s->implicit_weight[r][r1] = (int16_t)sl->pwt.implicit_weight[r][r1][0];
     }
+    if (b->mbaff_frame && sl->pwt.use_weight == 2)        /* field macroblocks: the tables implicit_weight_table(h, sl, 0 / 1) filled (h264_slice.c:1786-1790) */
+        for (int p = 0; p < 2; p++)
+            for (unsigned r0 = 0; r0 < 2 * sl->ref_count[0]; r0++)
+                for (unsigned r1 = 0; r1 < 2 * sl->ref_count[1]; r1++)
+                    s->implicit_weight_field[p][r0][r1] = (int16_t)sl->pwt.implicit_weight[(16 + r0) ^ p][(16 + r1) ^ p][p];
     for (int t = 0; t < 2; t++)
         for (int q = 0; q < 52; q++) s->chroma_qp_table[t][q] = h->ps.pps->chroma_qp_table[t][q];
     /* 4:4:4: the plane's own weights in the luma role (mc_part_weighted, h264_mb.c:386-470: chroma_weight_op = luma_weight_op
@@ -892,9 +897,6 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     const int mb_type = h->cur_pic.mb_type[mb_xy];
     mi355_h264_mb *m = &st->mb[0][idx];
     b->mbs_packed++;
-    if (b->mbaff_frame && sl->pwt.use_weight == 2) {      /* field macroblocks take implicit weights from tables of their own (implicit_weight[16 + ..][..][mb_y & 1]) */
-        br_fail(b, "MBAFF frame with implicit weights: outside the batched path"); __real_ff_h264_hl_decode_mb(h, sl); return;
-    }
     const int si = slice_index(b, h, sl);
     if (si < 0) { br_fail(b, "more slices or reference pictures than the batched path holds"); __real_ff_h264_hl_decode_mb(h, sl); return; }
     const int intra = IS_INTRA(mb_type);

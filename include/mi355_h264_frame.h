@@ -161,6 +161,10 @@ typedef struct mi355_h264_slice {
     int16_t chroma_weight[MI355_H264_MAX_REFS][2][2][2]; /* [ref][list][cb/cr][{weight,offset}] */
     int16_t implicit_weight[MI355_H264_MAX_REFS][MI355_H264_MAX_REFS]; /* [ref0][ref1], frame MBs */
     uint8_t chroma_qp_table[2][52];   /* pps->chroma_qp_table[cb/cr][qp] (get_chroma_qp) */
+    int16_t implicit_weight_field[2][2 * MI355_H264_MAX_REFS][2 * MI355_H264_MAX_REFS];
+                                      /* MBAFF frames with use_weight 2, FIELD macroblocks: [mb_y & 1][ref0][ref1] with the field reference indices
+                                         the macroblock codes (0 .. 2 * ref_count - 1) = the reference's implicit_weight[(16 + ref0) ^ p][(16 + ref1) ^ p][p],
+                                         p = mb_y & 1 (h264_slice.c:623-682 with field 0 / 1; the index swap: h264_mb_template.c:78-91) */
 } mi355_h264_slice;
 
 /* Alignment contract of the picture surfaces (what the reference's own frame pool provides: av_frame_get_buffer

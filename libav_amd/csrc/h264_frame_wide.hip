@@ -481,7 +481,9 @@ __device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr,
 {
     /* a field macroblock of an MBAFF frame counts fields: entry 16 + 2i (+ 1) of the reference's weight tables repeats frame i's (h264_slice.c pred_weight_table) */
     const int r0 = s.hdr.ref_idx[0][quadrant] >> g.hs, r1 = s.hdr.ref_idx[1][quadrant] >> g.hs;
-    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && sl.implicit_weight[r0][r1] != 32) || sl.use_weight == 1);
+    /* implicit weights come from the distances between FIELDS for such a macroblock: a table per parity of the macroblock row (h264_slice.c:623-682) */
+    const int iw = g.hs ? sl.implicit_weight_field[g.y0 & 1][s.hdr.ref_idx[0][quadrant] & 31][s.hdr.ref_idx[1][quadrant] & 31] : sl.implicit_weight[r0 & 15][r1 & 15];
+    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && iw != 32) || sl.use_weight == 1);
     const bool two = l0 && l1;
     for (int list = 0; list < 2; list++) {
         if (!(list ? l1 : l0)) continue;
@@ -495,7 +497,7 @@ __device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr,
     if (two) {
         const uint16_t *ty = s.qy + by * 16 + bx, *tcb = s.qc[0] + co, *tcr = s.qc[1] + co;
         if (sl.use_weight == 2) {
-            const int w0 = sl.implicit_weight[r0][r1], w1 = 64 - w0;
+            const int w0 = iw, w1 = 64 - w0;
             wide_biweight<BD>(dy, ty, 16, w, h, 5, w0, w1, 0);
             wide_biweight<BD>(dcb, tcb, 8, cw, ch, 5, w0, w1, 0);
             wide_biweight<BD>(dcr, tcr, 8, cw, ch, 5, w0, w1, 0);

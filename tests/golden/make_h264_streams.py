@@ -341,6 +341,11 @@ class Stream:
         """left, top, top-left macroblock usable for intra prediction"""
         return self.iavail(mbx - 1, mby, sid), self.iavail(mbx, mby - 1, sid), self.iavail(mbx - 1, mby - 1, sid)
 
+    def left_rows(self, mbx, mby, sid, left):
+        """per row of 4x4 blocks: the samples to the left usable for intra prediction; the block to the left counts in the derivation of
+        the predicted Intra4x4PredMode (MbaffStream: the two differ, and differ by row)"""
+        return [left] * 4, [left] * 4
+
     def ref_range(self, nact):
         return nact
 
@@ -425,6 +430,7 @@ class Stream:
         """an intra macroblock; base: mb_type offset of intra types in this slice type (0 in I, 5 in P)"""
         r = self.r
         left, top, topleft = self.intra_avail(mbx, mby, sid)
+        ls, lm = self.left_rows(mbx, mby, sid, left)
         c = r.i(0, 9)
         if c == 0:                                           # I_PCM
             w.ue(base + 25)
@@ -443,12 +449,12 @@ class Stream:
             for b8 in range(4):
                 bx, by = 2 * (b8 & 1), 2 * (b8 >> 1)
                 x, y = 4 * mbx + bx, 4 * mby + by
-                l_ok, t_ok = bx > 0 or left, by > 0 or top
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else topleft))
+                l_ok, t_ok = bx > 0 or (ls[by] and ls[by + 1]), by > 0 or top
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else ((ls[by - 1] and ls[by]) if by > 0 else topleft))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
                 pa, pb = self.nbrs(x, y, 4, 4, mbx, mby, sid)
-                if pa is not None and not (bx > 0 or left):
+                if pa is not None and not (bx > 0 or lm[by]):
                     pa = None
                 if pb is not None and not (by > 0 or top):
                     pb = None
@@ -474,15 +480,15 @@ class Stream:
             for blk in range(16):
                 bx, by = (blk & 1) + 2 * ((blk >> 2) & 1), ((blk >> 1) & 1) + 2 * (blk >> 3)
                 x, y = 4 * mbx + bx, 4 * mby + by
-                l_ok, t_ok = bx > 0 or left, by > 0 or top
+                l_ok, t_ok = bx > 0 or ls[by], by > 0 or top
                 # the sample above-left of the block lies in this macroblock, the one above, the one to the left or the one above-left
-                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else (left if by > 0 else topleft))
+                tl_ok = True if (bx > 0 and by > 0) else (top if bx > 0 else ((ls[by - 1] and ls[by]) if by > 0 else topleft))
                 ok = [2] + ([0, 3, 7] if t_ok else []) + ([1, 8] if l_ok else []) + ([4, 5, 6] if l_ok and t_ok and tl_ok else [])
                 mode = ok[r.i(0, len(ok) - 1)]
                 # predicted mode: min of the neighbours' modes; a neighbour outside -> 2 for both; an available neighbour that is
                 # not Intra4x4 counts as 2 (8.3.1.1)
                 pa, pb = self.nbrs(x, y, 4, 4, mbx, mby, sid)
-                if pa is not None and not (bx > 0 or left):
+                if pa is not None and not (bx > 0 or lm[by]):
                     pa = None                                # constrained intra: an inter neighbour does not count
                 if pb is not None and not (by > 0 or top):
                     pb = None
@@ -562,11 +568,12 @@ class Stream:
                 w.ue(s_)
             spred = {0: 0, 1: L0, 2: L1, 3: BI, 4: L0, 5: L0, 6: L1, 7: L1, 8: BI, 9: BI, 10: L0, 11: L1, 12: BI}
             sparts = {0: 0, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 2, 8: 2, 9: 2, 10: 4, 11: 4, 12: 4}
+            rr = self.ref_range(nact)
             for lst in (L0, L1):
-                if nact > 1:
+                if rr > 1:
                     for s_ in subs:
                         if spred[s_] & lst:
-                            w.te(nact - 1, r.i(0, nact - 1))
+                            w.te(rr - 1, r.i(0, rr - 1))
             for lst in (L0, L1):
                 for s_ in subs:
                     if spred[s_] & lst:
@@ -578,11 +585,12 @@ class Stream:
             else:
                 pair = {4: (L0, L0), 6: (L1, L1), 8: (L0, L1), 10: (L1, L0), 12: (L0, BI), 14: (L1, BI), 16: (BI, L0), 18: (BI, L1), 20: (BI, BI)}
                 preds = list(pair[t & ~1])
+            rr = self.ref_range(nact)
             for lst in (L0, L1):
-                if nact > 1:
+                if rr > 1:
                     for pr in preds:
                         if pr & lst:
-                            w.te(nact - 1, r.i(0, nact - 1))
+                            w.te(rr - 1, r.i(0, rr - 1))
             for lst in (L0, L1):
                 for pr in preds:
                     if pr & lst:
@@ -783,6 +791,8 @@ class Stream:
             if len(order) < self.npics:
                 order.append(("B", 4 * k - 2))
             k += 1
+        if isinstance(self, MbaffStream):
+            nmb //= 2                                        # an MBAFF frame's slices are runs of pairs
         prev_ref_frame_num, nref_pics = -1, 0
         for i, (kind, poc) in enumerate(order):
             idr = i == 0
@@ -793,7 +803,7 @@ class Stream:
                 au += self.param_sets()
             self.begin_picture()
             nact = min(nref_pics, max(1, self.nrefs))
-            cuts = [0] + sorted(set(self.r.i(1, nmb - 1) for _ in range(self.nslices - 1))) + [nmb]
+            cuts = [0] + sorted(set(self.r.i(1, max(1, nmb - 1)) for _ in range(self.nslices - 1))) + [nmb]
             for s_ in range(len(cuts) - 1):
                 if cuts[s_] < cuts[s_ + 1]:
                     au += self.slice(i, frame_num, idr, kind == "P", cuts[s_], cuts[s_ + 1], s_, nact, is_b=kind == "B", poc=poc, ref_idc=2 if is_ref else 0)
@@ -819,11 +829,23 @@ class MbaffStream(Stream):
         if self.cidc == 3:
             w.u(1, 0)
         w.ue(self.depth - 8); w.ue(self.depth - 8); w.u(1, 0); w.u(1, 0)
-        w.ue(0); w.ue(2)
+        w.ue(0)
+        if self.bmode:
+            w.ue(0); w.ue(2)                                 # pic_order_cnt_type 0, 6 bits of pic_order_cnt_lsb
+        else:
+            w.ue(2)
         w.ue(max(1, self.nrefs)); w.u(1, 0)
         w.ue(self.mb_w - 1); w.ue(self.mb_h // 2 - 1)
         w.u(1, 0); w.u(1, 1); w.u(1, 1)                      # frame_mbs_only 0, mb_adaptive_frame_field 1, direct_8x8_inference
-        w.u(1, 0); w.u(1, 0)
+        w.u(1, 0)
+        if self.bmode:                                       # VUI: bitstream restrictions alone (one picture of reordering), as in Stream.sps
+            w.u(1, 1)
+            for _ in range(8):
+                w.u(1, 0)
+            w.u(1, 1)
+            w.u(1, 1); w.ue(0); w.ue(0); w.ue(16); w.ue(16); w.ue(1); w.ue(max(2, self.nrefs))
+        else:
+            w.u(1, 0)
         w.trailing()
         return nal(3, 7, w.bytes())
 
@@ -871,25 +893,61 @@ class MbaffStream(Stream):
             b = (bh * (2 * (py - 1) + nb_pos) + bh - 1, x)
         return a, b
 
+    def usable(self, mbx, mby):
+        """constrained_intra_pred: an inter macroblock's samples are not used"""
+        return not self.cip or self.kind[mby][mbx] in ("i4", "i8", "i16", "pcm")
+
+    def left_rows(self, mbx, mby, sid, left):
+        """what the reference's fill_decode_caches derives (h264_mvpred.h:  left_samples_available / intra4x4_pred_mode_cache): pairs of the
+        same kind -> the macroblock at the same position; a field macroblock next to a frame pair -> its upper eight rows look at the
+        pair's top macroblock, the lower eight at the bottom one; a frame macroblock next to a field pair -> samples need BOTH field
+        macroblocks, the predicted mode looks at the top one"""
+        px, py, pos = mbx, mby >> 1, mby & 1
+        if not self.pair_ok(px - 1, py, sid):
+            return [False] * 4, [False] * 4
+        cur, lf = int(self.fld[py, px]), int(self.fld[py, px - 1])
+        u = [self.usable(px - 1, 2 * py), self.usable(px - 1, 2 * py + 1)]
+        if cur == lf:
+            return [u[pos]] * 4, [u[pos]] * 4
+        if cur:
+            rows = [u[0], u[0], u[1], u[1]]
+            return rows, list(rows)
+        return [u[0] and u[1]] * 4, [u[0]] * 4
+
     def intra_avail(self, mbx, mby, sid):
         px, py, pos = mbx, mby >> 1, mby & 1
-        left = self.pair_ok(px - 1, py, sid)
-        top = True if (pos == 1 and not self.fld[py, px]) else self.pair_ok(px, py - 1, sid)
+        left = all(self.left_rows(mbx, mby, sid, None)[0])
+        if pos == 1 and not self.fld[py, px]:
+            top = self.usable(px, 2 * py)
+        elif not self.pair_ok(px, py - 1, sid):
+            top = False
+        else:
+            nb_pos = 0 if (self.fld[py, px] and pos == 0 and self.fld[py - 1, px]) else 1
+            top = self.usable(px, 2 * (py - 1) + nb_pos)
         return left, top, False
 
     def ref_range(self, nact):
         return 2 * nact if self.cur_field else nact
 
-    def slice(self, idx, frame_num, idr, is_p, first_pair, last_pair, sid, nact, **kw):
+    def slice(self, idx, frame_num, idr, is_p, first_pair, last_pair, sid, nact, is_b=False, poc=None, ref_idc=3, **kw):
         r = self.r
         w = Bits()
         w.ue(first_pair)                                     # first_mb_in_slice counts pairs in an MBAFF frame
-        w.ue(5 if is_p else 7)
+        w.ue(6 if is_b else (5 if is_p else 7))
         w.ue(0)
         w.u(4, frame_num & 15)
         w.u(1, 0)                                            # field_pic_flag
         if idr:
             w.ue(idx & 3)
+        if poc is not None:
+            w.u(6, poc & 63)
+        if is_b:
+            w.u(1, r.i(0, 1))                                # direct_spatial_mv_pred_flag
+            w.u(1, 1)
+            w.ue(nact - 1); w.ue(nact - 1)
+            w.u(1, 0); w.u(1, 0)                             # no reference list modification, either list
+            if self.bmode == 2:
+                self.weight_table(w, nact, 2)
         if is_p:
             w.u(1, 1)
             w.ue(nact - 1)
@@ -898,7 +956,7 @@ class MbaffStream(Stream):
                 self.weight_table(w, nact, 1)
         if idr:
             w.u(1, 0); w.u(1, 0)
-        else:
+        elif ref_idc:
             w.u(1, 0)
         self.qp = 26 + (0 if idx == 0 else r.i(-6, 6))
         w.se(self.qp - 26)
@@ -912,18 +970,22 @@ class MbaffStream(Stream):
             for pos in (0, 1):
                 mby = 2 * py + pos
                 self.slice_of[mby, px] = sid
-                if is_p:
+                if is_p or is_b:
                     w.ue(0)                                  # mb_skip_run
                 if pos == 0:
                     w.u(1, self.cur_field)                   # mb_field_decoding_flag
-                if not is_p or r.p(0.3):
-                    self.intra_mb(w, px, mby, sid, 5 if is_p else 0)
+                if not (is_p or is_b) or r.p(0.3 if is_p else 0.15):
+                    self.intra_mb(w, px, mby, sid, 5 if is_p else (23 if is_b else 0))
+                elif is_b:
+                    self.b_mb(w, px, mby, sid, nact)
                 else:
                     self.inter_mb(w, px, mby, sid, nact)
         w.trailing()
-        return nal(3, 5 if idr else 1, w.bytes())
+        return nal(ref_idc, 5 if idr else 1, w.bytes())
 
     def build(self):
+        if self.bmode:
+            return self.build_b()
         units = []
         npairs = self.mb_w * self.mb_h // 2
         for i in range(self.npics):
@@ -1012,6 +1074,14 @@ STREAMS = {
     "420_8_mbaff": dict(mb_w=7, mb_h=6, chroma_idc=1, depth=8, seed=161, nslices=2, deblock_idc=0, nrefs=2, npics=7, mbaff=True),
     "422_10_mbaff": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=162, nslices=1, deblock_idc=0, nrefs=2, npics=6, mbaff=True),
     "444_8_mbaff": dict(mb_w=4, mb_h=4, chroma_idc=3, depth=8, seed=163, nslices=2, deblock_idc=-1, nrefs=2, npics=6, mbaff=True),
+    # ... with B pictures: implicit weights (field macroblocks weigh by the distances between FIELDS), explicit tables, the plain average
+    "420_8_mbaff_b_implicit": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=8, seed=164, nslices=2, deblock_idc=0, nrefs=2, npics=7, mbaff=True, bmode=1),
+    "420_10_mbaff_b_explicit": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=10, seed=165, nslices=1, deblock_idc=-1, nrefs=2, npics=7, mbaff=True, bmode=2, weighted=True),
+    "422_8_mbaff_b": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=8, seed=166, nslices=2, deblock_idc=0, nrefs=3, npics=7, mbaff=True, bmode=3),
+    # ... with constrained intra prediction: a field macroblock beside a frame pair of which one macroblock is inter sees HALF a left edge
+    # (the reference's extra chroma DC predictors, h264pred_template.c:716-766), a frame macroblock beside a field pair needs both
+    "420_8_mbaff_cip": dict(mb_w=7, mb_h=6, chroma_idc=1, depth=8, seed=167, nslices=2, deblock_idc=0, nrefs=2, npics=7, mbaff=True, cip=True, t8x8=True),
+    "422_10_mbaff_cip_b": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=168, nslices=2, deblock_idc=-1, nrefs=2, npics=7, mbaff=True, cip=True, bmode=1),
     "420_8_cropped": dict(mb_w=6, mb_h=5, chroma_idc=1, depth=8, seed=71, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1, crop=(3, 4)),
     "444_8_cropped": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=72, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(5, 7)),
     "422_10_cropped": dict(mb_w=5, mb_h=4, chroma_idc=2, depth=10, seed=73, nslices=1, deblock_idc=0, nrefs=2, npics=5, crop=(2, 9)),

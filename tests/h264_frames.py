@@ -25,8 +25,24 @@ SLICE_DT = np.dtype([
     ("use_weight", "u1"), ("use_weight_chroma", "u1"), ("luma_denom", "u1"), ("chroma_denom", "u1"),
     ("list_count", "u1"), ("rsv", "u1", 3), ("ref_slot", "u1", (2, MAX_REFS)),
     ("luma_weight", "<i2", (MAX_REFS, 2, 2)), ("chroma_weight", "<i2", (MAX_REFS, 2, 2, 2)),
-    ("implicit_weight", "<i2", (MAX_REFS, MAX_REFS)), ("chroma_qp_table", "u1", (2, 52))])
-assert SLICE_DT.itemsize == 1040
+    ("implicit_weight", "<i2", (MAX_REFS, MAX_REFS)), ("chroma_qp_table", "u1", (2, 52)),
+    ("implicit_weight_field", "<i2", (2, 2 * MAX_REFS, 2 * MAX_REFS))])
+assert SLICE_DT.itemsize == 1040 + 4096
+
+
+def as_slices(a):
+    """slice records of any age -> SLICE_DT (the committed fixtures predate implicit_weight_field: their records are the first 1040 bytes)"""
+    a = np.asarray(a)
+    if a.dtype == SLICE_DT:
+        return a
+    out = np.zeros(a.shape if a.dtype.names else (a.size // 1040,), SLICE_DT)
+    if a.dtype.names:
+        for k in a.dtype.names:
+            out[k] = a[k]
+    else:
+        raw = a.view(np.uint8).reshape(-1, 1040)
+        out.view(np.uint8).reshape(-1, SLICE_DT.itemsize)[:, :1040] = raw
+    return out
 
 
 class Frame(C.Structure):

@@ -55,7 +55,7 @@ def load_npz(path):
             pc[k] = v if v.ndim else v.item()
         pc["slots"] = [int(s) for s in np.atleast_1d(pc["slots"])]
         pc["mb"] = pc["mb"].view(HF.MB_DT).reshape(-1) if pc["mb"].dtype != HF.MB_DT else pc["mb"]
-        pc["slices"] = pc["slices"].view(HF.SLICE_DT).reshape(-1) if pc["slices"].dtype != HF.SLICE_DT else pc["slices"]
+        pc["slices"] = HF.as_slices(pc["slices"]).reshape(-1)
         pics.append(pc)
     return pics
 

@@ -1,5 +1,5 @@
-"""Random MBAFF streams (tests/golden/make_h264_streams.py MbaffStream: macroblock pairs coded as frame or field macroblocks at random, I / P pictures,
-intra macroblocks in P pictures, explicit weights, slices with their own filter mode, 4:2:0 / 4:2:2 / 4:4:4 at 8 and 10 bit) through the reference's
+"""Random MBAFF streams (tests/golden/make_h264_streams.py MbaffStream: macroblock pairs coded as frame or field macroblocks at random, I / P / B pictures,
+intra macroblocks in P and B pictures, explicit and implicit weights, slices with their own filter mode, 4:2:0 / 4:2:2 / 4:4:4 at 8 and 10 bit) through the reference's
 decoder twice: plain (MI355_BRIDGE_PLAIN) and with the Tier-2 bridge on the SIMT emulator (oracle/_ref/h264_bridge_emu), outputs compared.
 A sweep to run after touching the MBAFF path.  usage: python tools/h264_mbaff_sweep.py [seed [count]]"""
 import sys, os, random, subprocess, hashlib, json, tempfile
@@ -18,7 +18,7 @@ for it in range(N):
     kw = dict(mb_w=rng.randrange(3, 11), mb_h=2 * rng.randrange(1, 5), chroma_idc=fmt[0], depth=fmt[1], seed=rng.randrange(1 << 30),
               nslices=rng.randrange(1, 5), deblock_idc=rng.choice((-1, 0, 0, 1, 2)), weighted=bool(rng.randrange(2)), nrefs=rng.randrange(1, 4),
               npics=rng.randrange(3, 9), far=rng.choice((9, 20, 40)), t8x8=bool(rng.randrange(2)), cip=bool(rng.randrange(2)),
-              sparse=rng.choice((1.0, 0.5)))
+              sparse=rng.choice((1.0, 0.5)), bmode=rng.choice((0, 0, 1, 1, 2, 3)))
     try:
         units = M.MbaffStream(T, 'sweep', **kw).build()
     except Exception as e:
@@ -44,7 +44,7 @@ for it in range(N):
         st = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
         outs.append((hashlib.md5(open(out, 'rb').read()).hexdigest() if os.path.exists(out) else None, st[-1] if st else {}, r.stderr.strip(), r.returncode))
     if outs[0][2] or outs[0][3]:
-        print(it, 'SKIP (the reference decoder rejects the stream: %s)' % outs[0][2].splitlines()[-1][-60:] if outs[0][2] else 'rc')
+        print(it, 'SKIP (the reference decoder rejects the stream: %s)' % outs[0][2].splitlines()[-1][-60:] if outs[0][2] else 'rc', kw)
         continue
     j = outs[1][1]
     same = outs[0][0] == outs[1][0]
