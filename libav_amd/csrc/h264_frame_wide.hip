@@ -37,9 +37,21 @@ template <int BD, int CF> struct Fmt {
 
 /* N samples between a picture row (4-byte aligned address, N * sizeof(PX) a multiple of 4) and 16-bit samples in LDS */
 /* AGENT: agent-scope accesses (another workgroup of the same launch wrote / will read these samples: the row hand-over of k_wide_deblock_rows) */
-template <typename PX, int N, bool AGENT = false>
+/* LA: what the caller knows about the alignment of the LDS side (bytes).  With LA >= 8 a row piece moves as ONE memory instruction of
+ * N * sizeof(PX) bytes (any alignment in memory: the hardware splits what straddles) and one or two LDS instructions — the loop filter's
+ * tiles: a lane's piece is its own cache line, so every further instruction for the same piece is another pass of that line through the L1 */
+template <typename PX, int N, bool AGENT = false, int LA = 2>
 __device__ __forceinline__ void wide_ld_row(const uint8_t *p, uint16_t *d)
 {
+    if (!AGENT && LA >= 8) {
+        PX v[N];
+        uint16_t t[N];
+        __builtin_memcpy(v, p, sizeof(v));
+#pragma unroll
+        for (int k = 0; k < N; k++) t[k] = v[k];
+        __builtin_memcpy(__builtin_assume_aligned(d, LA), t, sizeof(t));
+        return;
+    }
     const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
     if (sizeof(PX) == 2) {
 #pragma unroll
@@ -52,9 +64,18 @@ __device__ __forceinline__ void wide_ld_row(const uint8_t *p, uint16_t *d)
         }
     }
 }
-template <typename PX, int N, bool AGENT = false>
+template <typename PX, int N, bool AGENT = false, int LA = 2>
 __device__ __forceinline__ void wide_st_row(uint8_t *p, const uint16_t *d)
 {
+    if (!AGENT && LA >= 8) {
+        PX v[N];
+        uint16_t t[N];
+        __builtin_memcpy(t, __builtin_assume_aligned(d, LA), sizeof(t));
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = (PX)t[k];
+        __builtin_memcpy(p, v, sizeof(v));
+        return;
+    }
     uint32_t *w = reinterpret_cast<uint32_t *>(p);
     if (sizeof(PX) == 2) {
 #pragma unroll
@@ -102,25 +123,57 @@ __device__ inline bool wide_block4(const int32_t *c, int r[16])
     for (int k = 0; k < 16; k++) r[k] = dc;
     return true;
 }
-/* sixteen (or NB) 4x4 blocks at once: lane 4 * b + q adds row q of block b; every lane of the wave calls */
-template <int BD, int CF>
-__device__ inline void wide_add_blocks4(const int32_t *coef, int nblocks, bool chroma, uint16_t *dst, int pitch)
+/* The same transform on the four lanes of a quad (the arrangement of idct4_quad, h264_dev.h, with the width of dctcoef a parameter): lane j
+ * holds storage column j of the block, c[k] = block[j + 4 k]; the first loop of h264idct_template.c:33-66 is per lane, the second runs across
+ * the quad with two exchanges.  On return lane j holds the residuals (>> 6) of destination row {0, 3, 1, 2}[j], columns 0..3. */
+template <typename COEF>
+__device__ __forceinline__ void wide_idct4_quad(const int c[4], int j, int r[4], int &row)
+{
+    const int c0 = j == 0 ? (COEF)(c[0] + 32) : c[0];
+    const int e0 = c0 + c[2], e1 = c0 - c[2], e2 = (c[1] >> 1) - c[3], e3 = c[1] + (c[3] >> 1);
+    const int b[4] = { (COEF)(e0 + e3), (COEF)(e1 + e2), (COEF)(e1 - e2), (COEF)(e0 - e3) };
+    const int sh = j & 1;
+    const bool n1 = j >= 2, n2 = (j & 1) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int v = b[k];
+        const int s = (n1 ? -v : v) + (quad_xor2(v) >> sh);        /* z0, z3, z1, z2 on lanes 0..3 */
+        r[k] = ((n2 ? -s : s) + quad_xor1(s)) >> 6;
+    }
+    row = j == 0 ? 0 : (j == 1 ? 3 : (j == 2 ? 1 : 2));
+}
+/* up to sixteen 4x4 blocks at once, four lanes each (lane 4 * b + j: column j of block b's coefficients, then one row of its samples) with the
+ * dispatchers' choice per block (wide_block4 above): an AC coefficient anywhere in the block -> the transform; the DC alone -> (dc + 32) >> 6;
+ * nothing -> nothing.  dst_of(b): the block's first sample.  Every lane of the wave calls. */
+template <int BD, int CF, typename Dst>
+__device__ __forceinline__ void wide_add_blocks4(const int32_t *coef, int nblocks, Dst dst_of, int pitch)
 {
     typedef Fmt<BD, CF> F;
-    const int lane = lane_id(), b = lane >> 2, q = lane & 3;
-    if (b < nblocks) {
-        int r[16];
-        if (wide_block4<typename F::COEF>(coef + 16 * b, r)) {
-            const int x4 = chroma ? cblk_x4(b) : blk_x4(b), y4 = chroma ? cblk_y4(b) : blk_y4(b);
-            uint16_t *d = dst + (4 * y4 + q) * pitch + 4 * x4;
+    const int lane = lane_id(), b = lane >> 2, j = lane & 3;
+    const bool on = b < nblocks;
+    const int32_t *c = coef + 16 * (on ? b : 0);
+    int v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int rk = q == 0 ? r[k] : (q == 1 ? r[4 + k] : (q == 2 ? r[8 + k] : r[12 + k]));      /* row q, without indexing the array by a lane's value */
-                d[k] = (uint16_t)clip3(d[k] + rk, 0, F::MAXV);
-            }
-        }
+    for (int k = 0; k < 4; k++) v[k] = c[j + 4 * k];
+    int ac = v[1] | v[2] | v[3] | (j ? v[0] : 0);
+    ac |= quad_xor1(ac);
+    ac |= quad_xor2(ac);
+    const int dc = quad_bcast<0>(v[0]);
+    int r[4], row;
+    wide_idct4_quad<typename F::COEF>(v, j, r, row);
+    if (!ac) r[0] = r[1] = r[2] = r[3] = (dc + 32) >> 6;
+    if (on && (ac | dc)) {
+        uint16_t *d = dst_of(b) + row * pitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = (uint16_t)med3i(d[k] + r[k], 0, F::MAXV);
     }
     MI355_WAVE_SYNC();
+}
+/* ... of the luma plane (blocks in the reference's order) / of a chroma plane */
+template <int BD, int CF>
+__device__ __forceinline__ void wide_add_blocks4(const int32_t *coef, int nblocks, bool chroma, uint16_t *dst, int pitch)
+{
+    wide_add_blocks4<BD, CF>(coef, nblocks, [&](int b) { return dst + 4 * (chroma ? cblk_y4(b) : blk_y4(b)) * pitch + 4 * (chroma ? cblk_x4(b) : blk_x4(b)); }, pitch);
 }
 /* the four 8x8 blocks of the luma plane (h264idct_template.c:69-141, dispatch :189-201): lane 8 * b + i transforms column i of block b */
 template <int BD, int CF>
@@ -271,8 +324,11 @@ __device__ inline void wide_residual_chroma(int32_t *coef, const mi355_h264_mb &
     if (lane < 2 && ((h.nnz_mask >> (MI355_NNZ_CB_DC + lane)) & 1))
         wide_chroma_dc<typename F::COEF, CF>(coef + 256 + 16 * F::NCB * lane, (int)h.dc_qmul[1 + lane]);
     MI355_WAVE_SYNC();
-    wide_add_blocks4<BD, CF>(coef + 256, F::NCB, true, cb, pitch);
-    wide_add_blocks4<BD, CF>(coef + 256 + 16 * F::NCB, F::NCB, true, cr, pitch);
+    /* both planes in one pass: blocks 0..NCB-1 Cb, NCB..2 NCB-1 Cr (their coefficients follow each other) */
+    wide_add_blocks4<BD, CF>(coef + 256, 2 * F::NCB, [&](int b) {
+        const int bb = b >= F::NCB ? b - F::NCB : b;
+        return (b >= F::NCB ? cr : cb) + 4 * cblk_y4(bb) * pitch + 4 * cblk_x4(bb);
+    }, pitch);
 }
 
 /* Where a macroblock's rows are.  A frame or field PICTURE: rows 16 * mb_y + r of its planes.  An MBAFF frame (MI355_FRAME_MBAFF): macroblock rows
@@ -751,23 +807,93 @@ __device__ const uint8_t kw_tc0[52][3] = {
     {3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},{9,12,18},{10,13,20},
     {11,15,23},{13,17,25} };
 
-constexpr int DYP = 20, DCPW = 12;       /* pitches of the filter's luma (-4..15) and chroma (-4..7) tiles */
+constexpr int DYP = 20, DCPW = 12;       /* pitches of the MBAFF filter's luma (-4..15) and chroma (-4..7) tiles */
+constexpr int DBYP = 24, DBCP = 16;      /* ... of the frame / field filter's: columns -8..15 / -8..7 */
 struct WideDbLds {
     mi355_h264_mb m[3];                  /* this macroblock, its left and its top neighbour */
     int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
     uint32_t mv[2][25];
     uint8_t nnz[25];
     uint8_t bs[2][4][4];
-    uint16_t y[20 * DYP];                /* rows / columns -4..15 */
-    uint16_t c[2][18 * DCPW];            /* rows -2..15, columns -4..7 (the filter reaches two to the left; four make the write-back whole dwords) */
+    alignas(16) uint16_t y[20 * DBYP];   /* rows / columns -4..15; a row's sample 0 on a 16-byte boundary: a row piece is one LDS instruction */
+    alignas(16) uint16_t c[2][18 * DBCP];/* rows -2..15, columns -4..7 (the filter reaches two to the left; four make the write-back whole dwords) */
 };
-#define DY(x, yy) s.y[((yy) + 4) * DYP + (x) + 4]
-#define DC(p, x, yy) s.c[p][((yy) + 2) * DCPW + (x) + 4]
+#define DY(x, yy) s.y[((yy) + 4) * DBYP + (x) + 8]
+#define DC(p, x, yy) s.c[p][((yy) + 2) * DBCP + (x) + 8]
 
 __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
 {
-    return iabs((int16_t)(a & 0xFFFF) - (int16_t)(b & 0xFFFF)) >= 4 || iabs((int16_t)(a >> 16) - (int16_t)(b >> 16)) >= ylim;
+    return pk_absdiff_far(a, b, ylim == 2 ? 0xFFFEFFFCu : 0xFFFCFFFCu);
 }
+
+/* The line filters without branches — the form of h264_deblock.hip's luma_line / chroma_line for samples up to MAXV: a line's conditions are
+ * folded into the clipping bounds (tc = 0 leaves a sample as it is), |a - b| is one v_sad_u16 (samples and thresholds lie below 65536), a
+ * clip one v_med3_i32; the bS 4 forms run only where a lane of the wave has that strength (MAY_INTRA: macroblock edges).  Return: 0 — no line
+ * of the WAVE passes the conditions (nothing changed), 1, or 2 when the bS 4 filter ran (p2 / q2 may have changed).
+ * h264dsp_template.c:103-163 (normal), :165-210 (bS 4), :212-265 (chroma). */
+template <int MAXV, bool MAY_INTRA>
+__device__ __forceinline__ int wide_luma_line(int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3, int bs, int alpha, int beta, int tc0)
+{
+    const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
+    if (!__any(f)) return 0;
+    const bool ap = absdiff8(p2, p0) < beta, aq = absdiff8(q2, q0) < beta;
+    const bool fn = f && bs < 4;
+    const int avg = (p0 + q0 + 1) >> 1;
+    const int tp = fn && ap ? tc0 : 0, tq = fn && aq ? tc0 : 0, tc = fn ? tc0 + (int)ap + (int)aq : 0;
+    const int np1 = p1 + med3i(((p2 + avg) >> 1) - p1, -tp, tp), nq1 = q1 + med3i(((q2 + avg) >> 1) - q1, -tq, tq);
+    const int delta = med3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const int P0 = p0, P1 = p1, P2 = p2, Q0 = q0, Q1 = q1, Q2 = q2;
+    p1 = np1; q1 = nq1;
+    p0 = med3i(P0 + delta, 0, MAXV);
+    q0 = med3i(Q0 - delta, 0, MAXV);
+    if (MAY_INTRA) {
+        const bool fi = f && bs == 4;
+        if (__any(fi)) {
+            const bool strong = absdiff8(P0, Q0) < ((alpha >> 2) + 2), sp = strong && ap, sq = strong && aq;
+            const int wp0 = (2 * P1 + P0 + Q1 + 2) >> 2, wq0 = (2 * Q1 + Q0 + P1 + 2) >> 2;
+            const int s4 = P0 + Q0 + 4;
+            const int ip0 = sp ? (P2 + 2 * P1 + P0 + Q0 + Q1 + s4) >> 3 : wp0;
+            const int ip1 = sp ? (P2 + P1 + P0 + Q0 + 2) >> 2 : P1;
+            const int ip2 = sp ? (2 * p3 + 3 * P2 + P1 + s4) >> 3 : P2;
+            const int iq0 = sq ? (P1 + P0 + Q0 + 2 * Q1 + Q2 + s4) >> 3 : wq0;
+            const int iq1 = sq ? (P0 + Q0 + Q1 + Q2 + 2) >> 2 : Q1;
+            const int iq2 = sq ? (2 * q3 + 3 * Q2 + Q1 + s4) >> 3 : Q2;
+            p0 = fi ? ip0 : p0; p1 = fi ? ip1 : p1; p2 = fi ? ip2 : p2;
+            q0 = fi ? iq0 : q0; q1 = fi ? iq1 : q1; q2 = fi ? iq2 : q2;
+            return 2;
+        }
+    }
+    return 1;
+}
+/* tc1: the caller's tc0 + 1 (h264_loopfilter.c:126-129) */
+template <int MAXV>
+__device__ __forceinline__ bool wide_chroma_line(int p1, int &p0, int &q0, int q1, int bs, int alpha, int beta, int tc1)
+{
+    const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
+    if (!__any(f)) return false;
+    const int tc = f && bs < 4 ? tc1 : 0;
+    const int delta = med3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    const bool fi = f && bs == 4;
+    const int np0 = fi ? (2 * p1 + p0 + q1 + 2) >> 2 : med3i(p0 + delta, 0, MAXV);
+    const int nq0 = fi ? (2 * q1 + q0 + p1 + 2) >> 2 : med3i(q0 - delta, 0, MAXV);
+    p0 = np0; q0 = nq0;
+    return true;
+}
+/* alpha, beta and the tc0 row (table 8-16 / 8-17; tc0 of strength bs: byte bs - 1) of an edge with average QP qp: three of them per plane of a
+ * macroblock (left edge, top edge, inner edges), worked out once before the edge loop */
+struct WideThr { int alpha, beta; uint32_t tc0; };
+template <int BD>
+__device__ __forceinline__ WideThr wide_thr(const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4], int qp, int a_off, int b_off)
+{
+    const int ia = med3i(qp - 6 * (BD - 8) + a_off, 0, 51), ib = med3i(qp - 6 * (BD - 8) + b_off, 0, 51);
+    WideThr t;
+    t.alpha = t_alpha[ia] << (BD - 8);
+    t.beta = t_beta[ib] << (BD - 8);
+    t.tc0 = *reinterpret_cast<const uint32_t *>(t_tc0[ia]);
+    return t;
+}
+template <int BD>
+__device__ __forceinline__ int wide_tc0(const WideThr &t, int bs) { return (int)((t.tc0 >> (8 * ((bs - 1) & 3))) & 0xFF) << (BD - 8); }
 /* check_mv, h264_loopfilter.c:442-470 */
 template <typename LDS>
 __device__ inline int wide_check_mv(const LDS &s, int b, int bn, int list_count, int ylim)
@@ -783,6 +909,17 @@ __device__ inline int wide_check_mv(const LDS &s, int b, int bn, int list_count,
     }
     return v;
 }
+/* the same without branches (the frame / field filter's strengths: every lane evaluates one pair of blocks) */
+template <typename LDS>
+__device__ __forceinline__ int wide_check_mv_bf(const LDS &s, int b, int bn, bool two_lists, int ylim)
+{
+    const int r0b = s.ref[0][b], r0n = s.ref[0][bn], r1b = s.ref[1][b], r1n = s.ref[1][bn];
+    const uint32_t m0b = s.mv[0][b], m0n = s.mv[0][bn], m1b = s.mv[1][b], m1n = s.mv[1][bn];
+    const bool v1 = (r0b != r0n) | ((r0b != -1) & wide_mv_far(m0b, m0n, ylim));
+    const bool v2 = v1 | (r1b != r1n) | wide_mv_far(m1b, m1n, ylim);
+    const bool cross = (r0b != r1n) | (r0n != r1b) | wide_mv_far(m0b, m1n, ylim) | wide_mv_far(m1b, m0n, ylim);
+    return two_lists ? (int)(v2 & cross) : (int)v1;
+}
 __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int list, int x4, int y4)
 {
     if (m.mb_type & MI355_MB_INTRA) return -1;
@@ -790,135 +927,204 @@ __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int lis
     return r == 0xFF ? -1 : r;
 }
 
-/* One macroblock (mb_x, mb_y) per sixteen-lane group — ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without
- * MBAFF.  The macroblock's own samples come from `recon`, four rows of the top neighbour from `dst` (as that macroblock's own pass left
- * them) and four columns of the left neighbour from `dst` or — carry_left: the caller filtered that macroblock with this tile a moment ago
- * — from the tile's last columns; the macroblock, three columns and three rows (one of each in chroma) go back to `dst`.
- * AGENT: `dst` is read and written with agent-scope accesses (k_wide_deblock_rows: the row above is another workgroup of the same launch). */
-template <int BD, int CF, bool AGENT>
-__device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4],
-                                                const mi355_h264_frame &fr, bool ok, int mb_x, int mb_y, int l, bool carry_left)
+/* ---- the frame / field loop filter: what a group of sixteen lanes needs of its picture, of a macroblock, and the macroblock itself ---------- */
+/* the picture's descriptor in registers: read once per wave (a field of `frames[f]` read inside the macroblock loop is a load again after every
+ * store, for the compiler cannot know that the pictures do not overlap it) */
+struct WideDbPic {
+    const uint8_t *dst[3], *recon[3];
+    const mi355_h264_mb *mb;
+    const uint32_t *mv[2];
+    const mi355_h264_slice *slices;
+    int ys, cs, yd, cd, mbw, mbh, field, nslices;
+};
+__device__ __forceinline__ WideDbPic wide_db_pic(const mi355_h264_frame &fr)
+{
+    WideDbPic p;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { p.dst[k] = fr.dst[k]; p.recon[k] = fr.recon[k]; }
+    p.mb = fr.mb;
+    p.mv[0] = reinterpret_cast<const uint32_t *>(fr.mv[0]); p.mv[1] = reinterpret_cast<const uint32_t *>(fr.mv[1]);
+    p.slices = fr.slices;
+    p.ys = fr.recon_stride[0]; p.cs = fr.recon_stride[1]; p.yd = fr.dst_stride[0]; p.cd = fr.dst_stride[1];
+    p.mbw = fr.mb_width; p.mbh = fr.mb_height; p.field = fr.field_picture; p.nslices = fr.nslices;
+    return p;
+}
+/* N samples of a picture row in registers, as memory holds them */
+template <typename PX, int N> struct WidePiece { uint32_t w[N * sizeof(PX) / 4]; };
+template <typename PX, int N>
+__device__ __forceinline__ void wide_get(WidePiece<PX, N> &v, const uint8_t *p) { __builtin_memcpy(v.w, p, sizeof(v.w)); }      /* one load, any alignment */
+template <typename PX, int N, int LA>
+__device__ __forceinline__ void wide_put(const WidePiece<PX, N> &v, uint16_t *d)                                                /* -> 16-bit samples in LDS */
+{
+    PX t[N];
+    uint16_t u[N];
+    __builtin_memcpy(t, v.w, sizeof(t));
+#pragma unroll
+    for (int k = 0; k < N; k++) u[k] = t[k];
+    __builtin_memcpy(__builtin_assume_aligned(d, LA), u, sizeof(u));
+}
+/* one macroblock's inputs as the loads deliver them: a group fetches the NEXT macroblock of its unit while it filters this one (the loads of a
+ * macroblock — records, samples, vectors — are one round trip to memory, ~2 us under load, and a lone macroblock's arithmetic is about as long) */
+template <int BD, int CF> struct WideDbIn {
+    typedef typename Fmt<BD, CF>::PX PX;
+    static constexpr int NP = CF == 2 ? 2 : 1;     /* chroma planes a lane carries a row of */
+    uint32_t rec[3];                               /* dword l of this / the left / the top macroblock's record */
+    WidePiece<PX, 16> y;                           /* luma row l */
+    WidePiece<PX, 4> yl, yt;                       /* the four samples left of it (first macroblock of a unit); a quarter row of the four rows above */
+    WidePiece<PX, 8> c[NP];                        /* chroma row: 4:2:0 plane l >> 3 row l & 7; 4:2:2 row l of both planes */
+    WidePiece<PX, 4> cl[NP], ct;
+    uint32_t mv[2][2];                             /* [list][own block l | lanes 0..3 the left neighbour's last column, 4..7 the top neighbour's last row] */
+};
+template <int BD, int CF>
+__device__ __forceinline__ void wide_db_fetch(WideDbIn<BD, CF> &in, const WideDbPic &pic, bool ok, int mb_x, int mb_y, int l, bool FIRST)
 {
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
     constexpr int PXB = (int)sizeof(PX);
-    const int mb_xy = mb_y * fr.mb_width + mb_x;
+    if (!ok) return;
+    const int mb_xy = mb_y * pic.mbw + mb_x;
     const bool has_left = mb_x > 0, has_top = mb_y > 0;
-    const int ys = fr.recon_stride[0], cs = fr.recon_stride[1], yd = fr.dst_stride[0], cd = fr.dst_stride[1];
+    const int xl = has_left ? mb_xy - 1 : mb_xy, xt = has_top ? mb_xy - pic.mbw : mb_xy;
+    in.rec[0] = reinterpret_cast<const uint32_t *>(&pic.mb[mb_xy])[l];
+    in.rec[1] = reinterpret_cast<const uint32_t *>(&pic.mb[xl])[l];
+    in.rec[2] = reinterpret_cast<const uint32_t *>(&pic.mb[xt])[l];
+    wide_get(in.y, pic.recon[0] + (size_t)(16 * mb_y + l) * pic.ys + 16 * mb_x * PXB);
+    if (FIRST && has_left) wide_get(in.yl, pic.dst[0] + (size_t)(16 * mb_y + l) * pic.yd + (16 * mb_x - 4) * PXB);
+    if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_get(in.yt, pic.dst[0] + (size_t)(16 * mb_y + r) * pic.yd + (16 * mb_x + c) * PXB); }
+#pragma unroll
+    for (int k = 0; k < WideDbIn<BD, CF>::NP; k++) {
+        const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
+        wide_get(in.c[k], (p ? pic.recon[2] : pic.recon[1]) + (size_t)(F::CH * mb_y + r) * pic.cs + 8 * mb_x * PXB);
+        if (FIRST && has_left) wide_get(in.cl[k], (p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * pic.cd + (8 * mb_x - 4) * PXB);
+    }
+    if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_get(in.ct, (p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * pic.cd + (8 * mb_x + c) * PXB); }
+    /* vectors: lane l its own 4x4 block, lanes 0..3 / 4..7 also a block of the left neighbour's last column / the top neighbour's last row */
+    const int xy2 = l < 4 ? xl : xt, i2 = l < 4 ? 3 + 4 * l : 8 + l;
+#pragma unroll
+    for (int list = 0; list < 2; list++) {
+        in.mv[list][0] = pic.mv[list] ? pic.mv[list][(size_t)mb_xy * 16 + l] : 0u;
+        in.mv[list][1] = pic.mv[list] && l < 8 ? pic.mv[list][(size_t)xy2 * 16 + i2] : 0u;
+    }
+}
+
+/* One macroblock (mb_x, mb_y) per sixteen-lane group — ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without
+ * MBAFF.  The macroblock's own samples come from `recon`, four rows of the top neighbour from `dst` (as that macroblock's own pass left
+ * them) and four columns of the left neighbour from `dst` or — FIRST false: the group filtered that macroblock with this tile a moment ago
+ * — from the tile's last columns; the macroblock, three columns and three rows (one of each in chroma) go back to `dst`.
+ * `in`: what wide_db_fetch brought for this macroblock; once the tile is filled, `next` may fetch the following macroblock into it. */
+template <int BD, int CF, typename Next>
+__device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4], const uint8_t *t_lc,
+                                                const WideDbPic &pic, const WideDbIn<BD, CF> &in, bool ok, int mb_x, int mb_y, int l, bool FIRST, Next next)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    constexpr int PXB = (int)sizeof(PX);
+    const bool has_left = mb_x > 0, has_top = mb_y > 0;
+    const int yd = pic.yd, cd = pic.cd;
     if (ok) {
-        /* records: this macroblock, left, top; one dword of each per lane */
-        const int xl = has_left ? mb_xy - 1 : mb_xy, xt = has_top ? mb_xy - fr.mb_width : mb_xy;
-        reinterpret_cast<uint32_t *>(&s.m[0])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[mb_xy])[l];
-        reinterpret_cast<uint32_t *>(&s.m[1])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xl])[l];
-        reinterpret_cast<uint32_t *>(&s.m[2])[l] = reinterpret_cast<const uint32_t *>(&fr.mb[xt])[l];
-        /* samples: lane l brings row l of the macroblock, its four left neighbours (from memory, or from the tile's last columns), a quarter
-         * row of the four rows above */
-        if (has_left && carry_left) for (int k = 0; k < 4; k++) DY(k - 4, l) = DY(12 + k, l);
-        else if (has_left) wide_ld_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
-        wide_ld_row<PX, 16>(fr.recon[0] + (size_t)(16 * mb_y + l) * ys + 16 * mb_x * PXB, &DY(0, l));
-        if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_ld_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
-        for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) reinterpret_cast<uint32_t *>(&s.m[k])[l] = in.rec[k];
+        if (has_left && !FIRST) for (int k = 0; k < 4; k++) DY(k - 4, l) = DY(12 + k, l);
+        else if (has_left) wide_put<PX, 4, 8>(in.yl, &DY(-4, l));
+        wide_put<PX, 16, 16>(in.y, &DY(0, l));
+        if (has_top) wide_put<PX, 4, 8>(in.yt, &DY(4 * (l & 3), (l >> 2) - 4));
+#pragma unroll
+        for (int k = 0; k < WideDbIn<BD, CF>::NP; k++) {
             const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-            if (has_left && carry_left) for (int j = 0; j < 4; j++) DC(p, j - 4, r) = DC(p, 4 + j, r);
-            else if (has_left) wide_ld_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
-            wide_ld_row<PX, 8>(fr.recon[1 + p] + (size_t)(F::CH * mb_y + r) * cs + 8 * mb_x * PXB, &DC(p, 0, r));
+            if (has_left && !FIRST) for (int j = 0; j < 4; j++) DC(p, j - 4, r) = DC(p, 4 + j, r);
+            else if (has_left) wide_put<PX, 4, 8>(in.cl[k], &DC(p, -4, r));
+            wide_put<PX, 8, 16>(in.c[k], &DC(p, 0, r));
         }
-        if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_ld_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x + c) * PXB, &DC(p, c, r)); }
+        if (has_top && l < 8) wide_put<PX, 4, 8>(in.ct, &DC(l >> 2, 4 * (l & 1), ((l >> 1) & 1) - 2));
+        /* the vectors' places in the filter's view of the motion: (y + 1) * 5 + (x + 1) */
+        const int c0 = ((l >> 2) + 1) * 5 + (l & 3) + 1, c1 = l < 4 ? (l + 1) * 5 : l - 3;
+#pragma unroll
+        for (int list = 0; list < 2; list++) { s.mv[list][c0] = in.mv[list][0]; if (l < 8) s.mv[list][c1] = in.mv[list][1]; }
     }
     MI355_WAVE_SYNC();
+    next();                                      /* the next macroblock's loads leave now and arrive during the filter */
     const mi355_h264_mb &m = s.m[0];
     const bool filter = ok && !(m.flags & MI355_MBF_NO_DEBLOCK);
     int list_count = 1;
-    const int ylim = fr.field_picture ? 2 : 4;
+    const int ylim = pic.field ? 2 : 4;
     if (filter) {
-        list_count = fr.slices[m.slice_id].list_count;      /* in flight with the vectors below */
-        /* the motion and coefficient flags the strengths are derived from (fill_filter_caches, h264_slice.c:2056-2196): lane l its own
-         * 4x4 block, lanes 0..3 / 4..7 also a block of the left neighbour's last column / the top neighbour's last row */
+        /* the slice's list_count: of the picture's first sixteen slices in LDS since the wave began */
+        list_count = m.slice_id < 16 ? t_lc[m.slice_id] : pic.slices[m.slice_id].list_count;
+        /* picture identities and coefficient flags the strengths are derived from (fill_filter_caches, h264_slice.c:2056-2196), from the records */
         for (int k = 0; k < 2; k++) {
             if (k && l >= 8) break;
             int which, x4, y4, cx, cy;
             if (!k) { which = 0; x4 = l & 3; y4 = l >> 2; cx = x4; cy = y4; }
             else if (l < 4) { which = 1; x4 = 3; y4 = l; cx = -1; cy = y4; }
             else { which = 2; x4 = l - 4; y4 = 3; cx = x4; cy = -1; }
-            const int xy = which == 0 ? mb_xy : (which == 1 ? (has_left ? mb_xy - 1 : mb_xy) : (has_top ? mb_xy - fr.mb_width : mb_xy));
             const int ci = (cy + 1) * 5 + cx + 1;
-            for (int list = 0; list < 2; list++) {
-                s.ref[list][ci] = wide_ref_identity(s.m[which], list, x4, y4);
-                s.mv[list][ci] = fr.mv[list] ? reinterpret_cast<const uint32_t *>(fr.mv[list])[(size_t)xy * 16 + x4 + 4 * y4] : 0u;
-            }
+            for (int list = 0; list < 2; list++) s.ref[list][ci] = wide_ref_identity(s.m[which], list, x4, y4);
             s.nnz[ci] = (uint8_t)((s.m[which].nnz_mask >> blk_index(x4, y4)) & 1);
         }
     }
     MI355_WAVE_SYNC();
     if (filter) {
-        /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane l = 4 * edge + i, both directions */
+        /* boundary strengths: filter_mb_dir, h264_loopfilter.c:472-714; lane l = 4 * edge + i, both directions.  Without branches: the one
+         * pair of blocks whose motion decides (the lane's own pair, or the partition's first pair where the macroblock moves as a whole across
+         * the edge) is compared in any case, the cases of :553-607 / :638-690 pick among 0, 2, 3 / 4 and that comparison */
         const uint32_t t = m.mb_type;
         const int edge = l >> 2, i = l & 3, tk = (t >> 3) & 7;
+        const bool e0 = edge == 0, two = list_count == 2, intra_cur = (t & MI355_MB_INTRA) != 0;
+#pragma unroll
         for (int dir = 0; dir < 2; dir++) {
             const int mask_edge = dir == 0 ? (tk == 0 ? 0 : (tk < 4 ? 3 : 1)) : (tk == 0 ? 0 : (tk == 1 ? 3 : (tk < 4 ? 1 : 3)));
             const int edges = (mask_edge == 3 && !(m.cbp & 15)) ? 1 : 4;
             const uint32_t par_types = MI355_MB_16x16 | (MI355_MB_8x16 >> dir);
             const bool mask_par0 = (t & par_types) != 0;
-            const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
-            const int b = (y + 1) * 5 + x + 1, bn = b - (dir ? 5 : 1);
-            int bs = 0;
-            if (edge == 0) {
-                const mi355_h264_mb &mm = s.m[1 + dir];
-                if (m.flags & (dir ? MI355_MBF_TOP_EDGE : MI355_MBF_LEFT_EDGE)) {
-                    if ((t | mm.mb_type) & MI355_MB_INTRA) bs = (!fr.field_picture || dir == 0) ? 4 : 3;
-                    else if (s.nnz[b] | s.nnz[bn]) bs = 2;
-                    else if (mask_par0 && (mm.mb_type & par_types)) bs = wide_check_mv(s, 6, 6 - (dir ? 5 : 1), list_count, ylim);
-                    else bs = wide_check_mv(s, b, bn, list_count, ylim);
-                }
-            } else if (edge < edges) {
-                const bool deblock_edge = !((t & MI355_MB_8x8DCT) && (edge & 1));
-                if (deblock_edge || (CF == 2 && dir == 1)) {
-                    if (t & MI355_MB_INTRA) bs = 3;
-                    else if (s.nnz[b] | s.nnz[bn]) bs = 2;
-                    else if (edge & mask_edge) bs = 0;
-                    else if (mask_par0) { const int b0 = dir == 0 ? 5 + edge + 1 : (edge + 1) * 5 + 1; bs = wide_check_mv(s, b0, b0 - (dir ? 5 : 1), list_count, ylim); }
-                    else bs = wide_check_mv(s, b, bn, list_count, ylim);
-                }
-            }
+            const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge, step = dir ? 5 : 1;
+            const int b = (y + 1) * 5 + x + 1, bn = b - step;
+            const uint32_t mmt = s.m[1 + dir].mb_type;
+            const bool par = mask_par0 & (!e0 | ((mmt & par_types) != 0));
+            const int b0 = e0 ? 6 : (dir == 0 ? 6 + edge : (edge + 1) * 5 + 1), cb = par ? b0 : b;
+            const int mvd = wide_check_mv_bf(s, cb, cb - step, two, ylim);
+            const bool nz = (s.nnz[b] | s.nnz[bn]) != 0;
+            const bool deblock_edge = !((t & MI355_MB_8x8DCT) && (edge & 1));
+            const bool active = e0 ? (m.flags & (dir ? MI355_MBF_TOP_EDGE : MI355_MBF_LEFT_EDGE)) != 0 : (edge < edges) & (deblock_edge | (CF == 2 && dir == 1));
+            const bool intra = e0 ? ((t | mmt) & MI355_MB_INTRA) != 0 : intra_cur;
+            const int bs_intra = e0 ? ((!pic.field || dir == 0) ? 4 : 3) : 3;
+            const int bs_inter = nz ? 2 : ((!e0 & ((edge & mask_edge) != 0)) ? 0 : mvd);
+            const int bs = active ? (intra ? bs_intra : bs_inter) : 0;
             s.bs[dir][edge][i] = (uint8_t)bs;
         }
     }
     MI355_WAVE_SYNC();
     {
-        const int qp_bd = 6 * (BD - 8), a_off = m.slice_alpha_c0_offset, b_off = m.slice_beta_offset;
+        /* what the edge loop needs of the three records, read once (the tile's 16-bit stores below may alias a record's bytes for the compiler) */
+        const int a_off = m.slice_alpha_c0_offset, b_off = m.slice_beta_offset, qp0 = m.qp;
         const bool dct8 = (m.mb_type & MI355_MB_8x8DCT) != 0;
+        WideThr ty[3], tc[2][3];                 /* [inner, left, top]; chroma: [the plane(s) this lane filters] */
+        for (int e = 0; e < 3; e++) ty[e] = wide_thr<BD>(t_alpha, t_beta, t_tc0, e ? (qp0 + s.m[e].qp + 1) >> 1 : qp0, a_off, b_off);
+        for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
+            const int p = CF == 2 ? k : l >> 3;
+            for (int e = 0; e < 3; e++) tc[k][e] = wide_thr<BD>(t_alpha, t_beta, t_tc0, e ? (m.qpc[p] + s.m[e].qpc[p] + 1) >> 1 : m.qpc[p], a_off, b_off);
+        }
         /* one chroma line across an edge: q = the sample at the edge's q side, st = step across the edge */
-        auto chroma_line = [&](int p, uint16_t *q, int st, int bs, int edge, const mi355_h264_mb &mm) {
-            const int qp = edge == 0 ? (m.qpc[p] + mm.qpc[p] + 1) >> 1 : m.qpc[p];
-            const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-            const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
+        auto chroma_line = [&](uint16_t *q, int st, int bs, const WideThr &t) {
             int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-            if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
-            else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
-            q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
+            if (wide_chroma_line<F::MAXV>(p1, p0, q0, q1, bs, t.alpha, t.beta, wide_tc0<BD>(t, bs) + 1)) { q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; }
         };
+#pragma unroll
         for (int dir = 0; dir < 2; dir++)
+#pragma unroll
             for (int edge = 0; edge < 4; edge++) {
-                const mi355_h264_mb &mm = s.m[1 + dir];
+                const int te = edge ? 0 : 1 + dir;
                 /* luma: line (dir 0) or column (dir 1) l */
                 {
                     const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
-                    const int bs = filter ? s.bs[dir][edge][l >> 2] : 0;
-                    if (luma_on && bs) {
-                        const int qp = edge == 0 ? (m.qp + mm.qp + 1) >> 1 : m.qp;
-                        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-                        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
+                    const int bs = filter && luma_on ? s.bs[dir][edge][l >> 2] : 0;
+                    if (__any(bs != 0)) {
                         uint16_t *q = dir == 0 ? &DY(4 * edge, l) : &DY(l, 4 * edge);
-                        const int st = dir == 0 ? 1 : DYP;
-                        if (bs < 4) {
-                            int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
-                            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
-                            q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
-                        } else {
-                            int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
-                            lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
-                            q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
-                        }
+                        const int st = dir == 0 ? 1 : DBYP;
+                        int p3 = edge ? 0 : q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = edge ? 0 : q[3 * st];
+                        const int r = edge == 0 ? wide_luma_line<F::MAXV, true>(p3, p2, p1, p0, q0, q1, q2, q3, bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs))
+                                                : wide_luma_line<F::MAXV, false>(p3, p2, p1, p0, q0, q1, q2, q3, bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs));
+                        if (r) { q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; }
+                        if (r == 2) { q[-3 * st] = (uint16_t)p2; q[2 * st] = (uint16_t)q2; }
                     }
                 }
                 /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
@@ -926,12 +1132,15 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
                 if (dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1))) {
                     if (dir == 0 && CF == 2) {
                         const int bs = filter ? s.bs[0][edge][l >> 2] : 0;
-                        for (int p = 0; p < 2; p++)
-                            if (bs) chroma_line(p, &DC(p, 2 * edge, l), 1, bs, edge, mm);
+                        if (__any(bs != 0))
+                            for (int p = 0; p < 2; p++) chroma_line(&DC(p, 2 * edge, l), 1, bs, tc[p][te]);
                     } else {
                         const int p = l >> 3, k = l & 7;
                         const int bs = filter ? s.bs[dir][edge][k >> 1] : 0;
-                        if (bs) chroma_line(p, dir == 0 ? &DC(p, 2 * edge, k) : &DC(p, k, CF == 2 ? 4 * edge : 2 * edge), dir == 0 ? 1 : DCPW, bs, edge, mm);
+                        if (__any(bs != 0)) {
+                            const WideThr t = CF == 2 && p ? tc[CF == 2 ? 1 : 0][te] : tc[0][te];
+                            chroma_line(dir == 0 ? &DC(p, 2 * edge, k) : &DC(p, k, CF == 2 ? 4 * edge : 2 * edge), dir == 0 ? 1 : DBCP, bs, t);
+                        }
                     }
                 }
                 MI355_WAVE_SYNC();
@@ -940,71 +1149,52 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
     /* out: the macroblock, and what its left and top edges changed of the neighbours */
     if (ok) {
         /* (the left neighbour's four last columns go back as whole dwords: the first of them as it came) */
-        wide_st_row<PX, 16, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
-        if (has_left) wide_st_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
-        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4, AGENT>(fr.dst[0] + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
+        wide_st_row<PX, 16, false, 16>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
+        if (has_left) wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
+        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
         for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
             const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-            wide_st_row<PX, 8, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
-            if (has_left) wide_st_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
+            wide_st_row<PX, 8, false, 16>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
+            if (has_left) wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
         }
-        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4, AGENT>(fr.dst[1 + p] + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
+        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
     }
 }
 
-/* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter macroblock (d - 2 * mb_y, mb_y) of picture 4 * k + g.  Sixteen
- * lanes are what one macroblock has to offer (the sixteen lines across a luma edge; 8 + 8 chroma lines); four macroblocks fill the
- * wave, and a lane moves whole rows (32 bytes of a 10-bit luma row) between memory and the group's LDS tiles.  One launch per
- * anti-diagonal (the reference's raster order needs left, top and top-right done): the form for batches that fill the device. */
+/* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter a unit of picture 4 * k + g.  Sixteen lanes are what one macroblock has
+ * to offer (the sixteen lines across a luma edge; 8 + 8 chroma lines); four pictures fill the wave, and a lane moves whole rows (32 bytes of a
+ * 10-bit luma row) between memory and the group's LDS tiles.  One launch per anti-diagonal (the reference's raster order needs left, top and
+ * top-right done).
+ * A unit (X, y) = macroblocks unit * X .. unit * X + unit - 1 of row y, filtered one after the other by the same group; the anti-diagonals
+ * count units (d = X + 2 y: the unit to the left is launch d - 1, the units above and above-right are d - 2 and d - 1).  unit = 1: the shortest
+ * launches (few pictures: a launch is as long as its longest wave).  unit = 4: what a group fetches is a run of whole cache lines (four 10-bit
+ * macroblocks side by side are 128 bytes of a luma row) instead of a 32-byte piece of every line — measured: one macroblock per group moves
+ * 8.8 x the bytes it uses across the fabric (72 lines of 128 bytes for 1.1 KB) — the left neighbour's columns stay in the tile, and the loads
+ * of macroblock u + 1 are in flight while u is filtered. */
 template <int BD, int CF>
 __global__ void __launch_bounds__(64)
-k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h)
+k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h, int unit)
 {
     __shared__ WideDbLds sh[4];
-    /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane at every edge — from memory that is a dependent
-     * load of a microsecond in each of its sixteen steps */
-    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane — from memory that is a dependent load of a microsecond */
+    __shared__ uint8_t t_alpha[52], t_beta[52], t_lc[4][16];
+    __shared__ __attribute__((aligned(4))) uint8_t t_tc0[52][4];       /* a row is read as one dword (wide_thr) */
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
-    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, mb_x = d - 2 * mb_y;
-    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
-    const bool ok = f < nframes && mb_y < fr.mb_height && mb_x >= 0 && mb_x < fr.mb_width;
-    wide_deblock_mb<BD, CF, false>(sh[g], t_alpha, t_beta, t_tc0, fr, ok, mb_x, mb_y, l, false);
-}
-
-/* The same filter as ONE launch: a wave = macroblock row `row` of four pictures, walking left to right; rows are taken in row-major order
- * from a ticket counter (a wave only ever waits for a lower ticket, which is running or done), and row y follows row y - 1 two
- * macroblocks behind: a wave publishes how many macroblocks it has written (after its write-through stores have left it) in a progress
- * word, the wave below polls that word and fetches the four rows above its macroblock with agent-scope loads
- * (/opt/skills/guides/cdna_hip_programming.md, guideline 16, form R1 — the protocol of k_deblock_tiled).  The left neighbour's columns
- * stay in the tile from the step before.  254 launches of a 1080p set become one: what matters when a launch set is a dozen pictures
- * of as many decoders (the bridge) and the launches, not the arithmetic, are its time. */
-template <int BD, int CF>
-__global__ void __launch_bounds__(64)
-k_wide_deblock_rows(const mi355_h264_frame *frames, int nframes, int max_w, int max_h, uint32_t *sync)
-{
-    __shared__ WideDbLds sh[4];
-    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
-    const int lane = lane_id(), g = lane >> 4, l = lane & 15;
-    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
-    uint32_t tk = 0;
-    if (lane == 0) tk = atomicAdd(sync, 1u);
-    tk = (uint32_t)lane_value((int)tk, 0);
-    const int nquads = (nframes + 3) >> 2, row = (int)(tk / (uint32_t)nquads), quad = (int)(tk - (uint32_t)row * (uint32_t)nquads);
-    if (row >= max_h) return;
-    uint32_t *prog = sync + 16 + (size_t)quad * (size_t)max_h;
-    const int f = 4 * quad + g;
-    const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
-    for (int x = 0; x < max_w; x++) {
-        if (row > 0) {
-            const uint32_t need = (uint32_t)(x + 2 < max_w ? x + 2 : max_w);
-            while (agent_load_u32(&prog[row - 1]) < need) wave_nap();
-        }
-        const bool ok = f < nframes && row < fr.mb_height && x < fr.mb_width;
-        wide_deblock_mb<BD, CF, true>(sh[g], t_alpha, t_beta, t_tc0, fr, ok, x, row, l, x > 0);
-        agent_drain_stores();                    /* every store of this macroblock has left the wave ... */
-        if (lane == 0) agent_store_u32(&prog[row], (uint32_t)(x + 1));      /* ... before the row below may fetch it */
-        MI355_WAVE_SYNC();                       /* the next macroblock's loads overwrite what the stores above read */
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; t_tc0[lane][3] = 0; }
+    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, x0 = (d - 2 * mb_y) * unit;
+    const WideDbPic pic = wide_db_pic(frames[f < nframes ? f : nframes - 1]);
+    const bool row_ok = f < nframes && mb_y < pic.mbh && x0 >= 0;
+    WideDbIn<BD, CF> in;
+    wide_db_fetch<BD, CF>(in, pic, row_ok && x0 < pic.mbw, x0, mb_y, l, true);
+    t_lc[g][l] = row_ok && pic.nslices > 0 ? pic.slices[l < pic.nslices ? l : pic.nslices - 1].list_count : 1;
+    MI355_WAVE_SYNC();
+#pragma unroll 1
+    for (int u = 0; u < unit; u++) {
+        const int mb_x = x0 + u;
+        const bool ok = row_ok && mb_x < pic.mbw, more = u + 1 < unit;
+        wide_deblock_mb<BD, CF>(sh[g], t_alpha, t_beta, t_tc0, t_lc[g], pic, in, ok, mb_x, mb_y, l, u == 0,
+                                [&]() { if (more) wide_db_fetch<BD, CF>(in, pic, row_ok && mb_x + 1 < pic.mbw, mb_x + 1, mb_y, l, false); });
+        MI355_WAVE_SYNC();                       /* the next macroblock's tile overwrites what the stores above read */
     }
 }
 #undef DY
@@ -1048,10 +1238,11 @@ k_wide_deblock_mbaff(const mi355_h264_frame *frames, int nframes, int d, int max
     typedef typename F::PX PX;
     constexpr int PXB = (int)sizeof(PX), CHP = 2 * F::CH;       /* chroma lines of a pair */
     __shared__ WideMbaffLds sh[4];
-    __shared__ uint8_t t_alpha[52], t_beta[52], t_tc0[52][4];
+    __shared__ uint8_t t_alpha[52], t_beta[52];
+    __shared__ __attribute__((aligned(4))) uint8_t t_tc0[52][4];       /* a row is read as one dword (wide_thr) */
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
     WideMbaffLds &s = sh[g];
-    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; }
+    if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; t_tc0[lane][3] = 0; }
     const int f = 4 * ((int)blockIdx.x / max_pr) + g, pr = (int)blockIdx.x % max_pr, x = d - 2 * pr;
     const mi355_h264_frame &fr = frames[f < nframes ? f : nframes - 1];
     const int W = fr.mb_width;
@@ -1298,21 +1489,17 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
             hipLaunchKernelGGL((k_wide_deblock_mbaff<BD, CF>), dim3(nquads * (unsigned)npr), dim3(64), 0, st, d_frames, nframes, d, npr);
     } else
     if (passes & 4) {
-        /* one launch per anti-diagonal; MI355_WIDE_DEBLOCK=rows: the single launch (k_wide_deblock_rows) — measured slower at every batch size in this
-         * first form (16 pictures 3.4 against 3.1 ms, 512: 30 against 14: a lone wave's macroblock step is ~13 us of dependent instructions, and
-         * waiting rows hold their slots), kept for the protocol and as the base of the band form */
         const unsigned nquads = (unsigned)((nframes + 3) / 4);
-        const char *form = getenv("MI355_WIDE_DEBLOCK");
-        const bool rows = form && form[0] == 'r';
-        if (rows) {
-            const size_t words = 16 + (size_t)nquads * (size_t)mh;
-            uint32_t *sync = mi355::sync_words(st, words);
-            if (!sync) return -2;
-            if (hipMemsetAsync(sync, 0, words * sizeof(uint32_t), st) != hipSuccess) return -2;
-            hipLaunchKernelGGL((k_wide_deblock_rows<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, mw, mh, sync);
-        } else
-        for (int d = 0; d <= (mw - 1) + 2 * (mh - 1); d++)
-            hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, d, mh);
+        {
+            /* macroblocks per group and launch: 4 once the launches fill the device (the fabric traffic decides), 1 for small batches (a launch
+             * is then as long as its longest wave); MI355_WIDE_UNIT overrides */
+            const char *ue = getenv("MI355_WIDE_UNIT");
+            int unit = ue ? atoi(ue) : (nframes >= 96 ? 4 : 1);
+            if (unit < 1 || unit > 8) unit = 1;
+            const int uw = (mw + unit - 1) / unit;
+            for (int d = 0; d <= (uw - 1) + 2 * (mh - 1); d++)
+                hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, d, mh, unit);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

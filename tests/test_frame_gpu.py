@@ -220,12 +220,15 @@ def test_second_kernel_set_10bit_1080p_is_deterministic_and_in_range(mi355):
         assert np.array_equal(outs[0][p], outs[1][p]) and outs[0][p].max() <= 1023 and outs[0][p].std() > 10
 
 
-@pytest.mark.parametrize("form,F", (("rows", 320), ("rows", 36), ("diag", 8)))
-def test_second_kernel_set_loop_filter_forms_under_load(mi355, oracle, monkeypatch, form, F):
-    """the second kernel set's two loop-filter forms (MI355_WIDE_DEBLOCK: `rows` = one launch, a wave per macroblock row of four pictures
-    following the row above through progress counters and agent-scope accesses — hundreds of rows in flight on every XCD; `diag` = one
-    launch per anti-diagonal) on replicated 1080p pictures (8-bit 4:2:0 instance): every picture equals the oracle's"""
-    monkeypatch.setenv("MI355_WIDE_DEBLOCK", form)
+@pytest.mark.parametrize("unit,F", (("4", 320), ("3", 36), ("1", 8), ("", 128)))
+def test_second_kernel_set_loop_filter_units_under_load(mi355, oracle, monkeypatch, unit, F):
+    """the second kernel set's loop filter with 1, 3, 4 macroblocks per group and launch (MI355_WIDE_UNIT; "": the launcher's own choice — a group
+    filters a run of its row's macroblocks, the anti-diagonals count runs, the next macroblock's loads are in flight during the filter) on
+    replicated 1080p pictures (8-bit 4:2:0 instance; 120 macroblocks a row: not a multiple of 3): every picture equals the oracle's"""
+    if unit:
+        monkeypatch.setenv("MI355_WIDE_UNIT", unit)
+    else:
+        monkeypatch.delenv("MI355_WIDE_UNIT", raising=False)
     fs = HF.synth_frames_fast(4, 120, 68, seed=0x2264, lib=mi355.lib, refs="smooth", coef_b=4)
     _, dst_o = HF.run_oracle(oracle, fs)
     d = HF.DeviceFrames(mi355, fs, replicate=F)
@@ -235,6 +238,6 @@ def test_second_kernel_set_loop_filter_forms_under_load(mi355, oracle, monkeypat
             got = d.fetch(d.dst)
             for p in range(3):
                 for f in range(F):
-                    assert np.array_equal(got[p][f], dst_o[p][f % fs.F]), (form, f, p)
+                    assert np.array_equal(got[p][f], dst_o[p][f % fs.F]), (unit, f, p)
     finally:
         d.free()

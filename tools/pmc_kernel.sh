@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer experiment: per-wave instruction mix and wait counters of one kernel.
-# Usage (via gpurun): bash tools/pmc_kernel.sh <kernel substring> <command...>
+# Usage (via gpurun): bash tools/pmc_kernel.sh <kernel substring[,substring...]> <command...>
 set -u
 K=$1; shift
 export TMPDIR=/tmp
@@ -14,13 +14,14 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
 done
 python3 - "$K" <<'PY'
 import csv, glob, collections, sys
-agg = collections.defaultdict(float); n = 0
-for f in glob.glob("/tmp/pmck/p*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if sys.argv[1] in r["Kernel_Name"]:
-            agg[r["Counter_Name"]] += float(r["Counter_Value"])
-w = agg.get("SQ_WAVES", 1) / 3 or 1
-print("waves (per pass)", w)
-for k, v in sorted(agg.items()):
-    print("%-28s total %.4g  per wave %.1f" % (k, v, v / (w * (3 if k == "SQ_WAVES" else 1))))
+for K in sys.argv[1].split(","):                      # several kernels: comma-separated substrings
+    agg = collections.defaultdict(float)
+    for f in glob.glob("/tmp/pmck/p*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if K in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    w = agg.get("SQ_WAVES", 1) / 3 or 1
+    print("==", K, "waves (per pass)", w)
+    for k, v in sorted(agg.items()):
+        print("%-28s total %.4g  per wave %.1f" % (k, v, v / (w * (3 if k == "SQ_WAVES" else 1))))
 PY
