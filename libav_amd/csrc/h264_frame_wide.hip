@@ -400,12 +400,12 @@ __device__ inline int wide_qpel_px(const uint16_t *win, const int16_t *tmp, int 
 {
 #define S(xx, yy) ((int)win[((yy) + 2) * WP + (xx) + 2])
     auto rawh = [&](int xx, int yy) { return tap6(S(xx - 2, yy), S(xx - 1, yy), S(xx, yy), S(xx + 1, yy), S(xx + 2, yy), S(xx + 3, yy)); };
-    auto hh = [&](int xx, int yy) { return clip3((rawh(xx, yy) + 16) >> 5, 0, maxv); };
-    auto vv = [&](int xx, int yy) { return clip3((tap6(S(xx, yy - 2), S(xx, yy - 1), S(xx, yy), S(xx, yy + 1), S(xx, yy + 2), S(xx, yy + 3)) + 16) >> 5, 0, maxv); };
+    auto hh = [&](int xx, int yy) { return med3i((rawh(xx, yy) + 16) >> 5, 0, maxv); };
+    auto vv = [&](int xx, int yy) { return med3i((tap6(S(xx, yy - 2), S(xx, yy - 1), S(xx, yy), S(xx, yy + 1), S(xx, yy + 2), S(xx, yy + 3)) + 16) >> 5, 0, maxv); };
     const int pad = maxv > 511 ? -10 * maxv : 0;
     auto tmph = [&](int xx, int yy) { return (int)tmp[(yy + 2) * 16 + xx] - pad; };      /* (int16_t)(rawh + pad), stored by the caller */
     auto hv = [&](int xx, int yy) {
-        return clip3((tap6(tmph(xx, yy - 2), tmph(xx, yy - 1), tmph(xx, yy), tmph(xx, yy + 1), tmph(xx, yy + 2), tmph(xx, yy + 3)) + 512) >> 10, 0, maxv);
+        return med3i((tap6(tmph(xx, yy - 2), tmph(xx, yy - 1), tmph(xx, yy), tmph(xx, yy + 1), tmph(xx, yy + 2), tmph(xx, yy + 3)) + 512) >> 10, 0, maxv);
     };
     int v;
     if (my == 0) v = mx == 0 ? S(x, y) : (mx == 2 ? hh(x, y) : f2(S(x + (mx == 3), y), hh(x, y)));
@@ -427,8 +427,8 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     typedef Fmt<BD, CF> F;
     typedef typename F::PX PX;
     const int lane = lane_id();
-    const uint32_t mvw = s.mv[list][n_raster];
-    const int slot = s.hdr.u.inter.ref_pic[list][quadrant];
+    const uint32_t mvw = (uint32_t)uniform((int)s.mv[list][n_raster]);
+    const int slot = uniform((int)s.hdr.u.inter.ref_pic[list][quadrant]);
     const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x * 16 + bx) * 4;
     const int my = (int16_t)(mvw >> 16) + (g.mcy * 16 + by) * 4;
     const uint8_t *const *rp = fr.ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
@@ -473,7 +473,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     }
     /* chroma: eighth-sample bilinear (h264chroma_template.c:28-200); 4:2:2 keeps the luma's vertical resolution (h264_mb.c:284-315) */
     const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, cby = CF == 2 ? by : by >> 1;
-    const int myc = CF == 1 ? my + s.hdr.u.inter.chroma_dy[list][quadrant] : my;
+    const int myc = CF == 1 ? my + uniform((int)s.hdr.u.inter.chroma_dy[list][quadrant]) : my;
     const int cx = mx >> 3, cy = CF == 2 ? myc >> 2 : myc >> 3, fx = mx & 7, fy = CF == 2 ? (myc << 1) & 7 : myc & 7;
     const int CWd = 8 * fr.mb_width, CHt = (F::CH * fr.mb_height) >> g.hs, cww = cw + 1, chh = ch + 1, ncc = (cww + 7) >> 3;
     if (cx >= 0 && cy >= 0 && cx + 8 * ncc <= CWd && cy + chh <= CHt) {
@@ -514,7 +514,7 @@ __device__ inline void wide_weight(uint16_t *p, int pitch, int w, int h, int ld,
     const int lw = w == 16 ? 4 : (w == 8 ? 3 : (w == 4 ? 2 : 1));
     for (int i = lane_id(); i < w * h; i += 64) {
         const int y = i >> lw, x = i & (w - 1);
-        p[y * pitch + x] = (uint16_t)clip3((p[y * pitch + x] * wt + o) >> ld, 0, (1 << BD) - 1);
+        p[y * pitch + x] = (uint16_t)med3i((p[y * pitch + x] * wt + o) >> ld, 0, (1 << BD) - 1);
     }
     MI355_WAVE_SYNC();
 }
@@ -525,7 +525,7 @@ __device__ inline void wide_biweight(uint16_t *d, const uint16_t *s, int pitch, 
     const int lw = w == 16 ? 4 : (w == 8 ? 3 : (w == 4 ? 2 : 1));
     for (int i = lane_id(); i < w * h; i += 64) {
         const int y = i >> lw, x = i & (w - 1);
-        d[y * pitch + x] = (uint16_t)clip3((s[y * pitch + x] * ws + d[y * pitch + x] * wd + o) >> (ld + 1), 0, (1 << BD) - 1);
+        d[y * pitch + x] = (uint16_t)med3i((s[y * pitch + x] * ws + d[y * pitch + x] * wd + o) >> (ld + 1), 0, (1 << BD) - 1);
     }
     MI355_WAVE_SYNC();
 }
@@ -536,10 +536,11 @@ __device__ inline void wide_mc_part(WideInterLds &s, const mi355_h264_frame &fr,
                                     int n_raster, int quadrant, int bx, int by, int w, int h, int l0, int l1)
 {
     /* a field macroblock of an MBAFF frame counts fields: entry 16 + 2i (+ 1) of the reference's weight tables repeats frame i's (h264_slice.c pred_weight_table) */
-    const int r0 = s.hdr.ref_idx[0][quadrant] >> g.hs, r1 = s.hdr.ref_idx[1][quadrant] >> g.hs;
+    const int ri0 = uniform((int)s.hdr.ref_idx[0][quadrant]), ri1 = uniform((int)s.hdr.ref_idx[1][quadrant]), mbf = uniform((int)s.hdr.flags);
+    const int r0 = ri0 >> g.hs, r1 = ri1 >> g.hs;
     /* implicit weights come from the distances between FIELDS for such a macroblock: a table per parity of the macroblock row (h264_slice.c:623-682) */
-    const int iw = g.hs ? sl.implicit_weight_field[g.y0 & 1][s.hdr.ref_idx[0][quadrant] & 31][s.hdr.ref_idx[1][quadrant] & 31] : sl.implicit_weight[r0 & 15][r1 & 15];
-    const bool weighted = (s.hdr.flags & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && iw != 32) || sl.use_weight == 1);
+    const int iw = g.hs ? sl.implicit_weight_field[g.y0 & 1][ri0 & 31][ri1 & 31] : sl.implicit_weight[r0 & 15][r1 & 15];
+    const bool weighted = (mbf & MI355_MBF_WEIGHTED) && ((sl.use_weight == 2 && l0 && l1 && iw != 32) || sl.use_weight == 1);
     const bool two = l0 && l1;
     for (int list = 0; list < 2; list++) {
         if (!(list ? l1 : l0)) continue;
@@ -591,11 +592,14 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         s.mv[list][lane & 15] = fr.mv[list] ? reinterpret_cast<const uint32_t *>(fr.mv[list])[(size_t)mb_xy * 16 + (lane & 15)] : 0u;
     }
     MI355_WAVE_SYNC();
-    const uint32_t t = s.hdr.mb_type;
+    /* one macroblock per wave: what the record says is the same for every lane — as scalars the partition loop, the quarter-sample position
+     * and the window test below are branches of the wave, not masks of its lanes */
+    const uint32_t t = (uint32_t)uniform((int)s.hdr.mb_type);
     if (t & MI355_MB_INTRA) return;
-    const bool luma_coded = (s.hdr.cbp & 15) != 0, chroma_coded = (s.hdr.cbp & 0x30) != 0;
-    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (s.hdr.cbp & 15) | (chroma_coded ? 16 : 0));
-    const mi355_h264_slice &sl = fr.slices[s.hdr.slice_id];
+    const int cbp = uniform((int)s.hdr.cbp);
+    const bool luma_coded = (cbp & 15) != 0, chroma_coded = (cbp & 0x30) != 0;
+    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (cbp & 15) | (chroma_coded ? 16 : 0));
+    const mi355_h264_slice &sl = fr.slices[uniform((int)s.hdr.slice_id)];
     const WideGeom g = wide_geom<BD, CF>(fr, t, mb_y);
 
     /* hl_motion, h264_mc_template.c:64-163 */
@@ -609,7 +613,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         else if (kind == 2) { n = 2 * p; quad = p; bx = 8 * p; by = 0; w = 8; h = 16; l0 = DIRF(p, 0); l1 = DIRF(p, 1); }
         else {
             const int i = p >> 2, j = p & 3;
-            const int st = s.hdr.sub_mb_type[i], shape = st & 3;
+            const int st = uniform((int)s.hdr.sub_mb_type[i]), shape = st & 3;
             const int cnt = shape == MI355_SUB_8x8 ? 1 : (shape == MI355_SUB_4x4 ? 4 : 2);
             if (j >= cnt) continue;
             l0 = (st & MI355_SUB_L0) != 0; l1 = (st & MI355_SUB_L1) != 0;
@@ -814,7 +818,7 @@ struct WideDbLds {
     int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
     uint32_t mv[2][25];
     uint8_t nnz[25];
-    uint8_t bs[2][4][4];
+    alignas(8) uint8_t bs[4][8];         /* [i][4 * dir + edge]: the eight strengths a line meets are one 64-bit read */
     alignas(16) uint16_t y[20 * DBYP];   /* rows / columns -4..15; a row's sample 0 on a 16-byte boundary: a row piece is one LDS instruction */
     alignas(16) uint16_t c[2][18 * DBCP];/* rows -2..15, columns -4..7 (the filter reaches two to the left; four make the write-back whole dwords) */
 };
@@ -1089,7 +1093,7 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
             const int bs_intra = e0 ? ((!pic.field || dir == 0) ? 4 : 3) : 3;
             const int bs_inter = nz ? 2 : ((!e0 & ((edge & mask_edge) != 0)) ? 0 : mvd);
             const int bs = active ? (intra ? bs_intra : bs_inter) : 0;
-            s.bs[dir][edge][i] = (uint8_t)bs;
+            s.bs[i][4 * dir + edge] = (uint8_t)bs;
         }
     }
     MI355_WAVE_SYNC();
@@ -1103,48 +1107,82 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
             const int p = CF == 2 ? k : l >> 3;
             for (int e = 0; e < 3; e++) tc[k][e] = wide_thr<BD>(t_alpha, t_beta, t_tc0, e ? (m.qpc[p] + s.m[e].qpc[p] + 1) >> 1 : m.qpc[p], a_off, b_off);
         }
-        /* one chroma line across an edge: q = the sample at the edge's q side, st = step across the edge */
-        auto chroma_line = [&](uint16_t *q, int st, int bs, const WideThr &t) {
-            int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-            if (wide_chroma_line<F::MAXV>(p1, p0, q0, q1, bs, t.alpha, t.beta, wide_tc0<BD>(t, bs) + 1)) { q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; }
-        };
+        /* The edges, one direction at a time with the line in registers: lane l holds row l (then column l) of the luma tile, columns / rows
+         * -4..15, and a row (then a column) of chroma; the four edges of a direction pass over it without a trip to LDS in between — what a lone
+         * macroblock spends is latency (eight steps of read, filter, write, rendezvous were ~3 of its ~4 us), not arithmetic.  Writes go out
+         * as an edge changes samples; one rendezvous between the directions. */
+        const uint64_t bsy = filter ? *reinterpret_cast<const uint64_t *>(s.bs[l >> 2]) : 0;            /* strengths of luma line l: byte 4 * dir + edge */
+        const uint64_t bsc = filter ? *reinterpret_cast<const uint64_t *>(s.bs[(l & 7) >> 1]) : 0;       /* of chroma line l & 7 (two lines per strength) */
+        auto strength = [](uint64_t w, int dir, int edge) { return (int)((uint32_t)(w >> (8 * (4 * dir + edge))) & 0xFF); };
 #pragma unroll
-        for (int dir = 0; dir < 2; dir++)
+        for (int dir = 0; dir < 2; dir++) {
+            /* luma */
+            {
+                uint16_t *base = dir == 0 ? &DY(0, l) : &DY(l, 0);
+                const int st = dir == 0 ? 1 : DBYP;
+                int r[20];
+                bool any_bs = false;
 #pragma unroll
-            for (int edge = 0; edge < 4; edge++) {
-                const int te = edge ? 0 : 1 + dir;
-                /* luma: line (dir 0) or column (dir 1) l */
-                {
-                    const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
-                    const int bs = filter && luma_on ? s.bs[dir][edge][l >> 2] : 0;
-                    if (__any(bs != 0)) {
-                        uint16_t *q = dir == 0 ? &DY(4 * edge, l) : &DY(l, 4 * edge);
-                        const int st = dir == 0 ? 1 : DBYP;
-                        int p3 = edge ? 0 : q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = edge ? 0 : q[3 * st];
-                        const int r = edge == 0 ? wide_luma_line<F::MAXV, true>(p3, p2, p1, p0, q0, q1, q2, q3, bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs))
-                                                : wide_luma_line<F::MAXV, false>(p3, p2, p1, p0, q0, q1, q2, q3, bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs));
-                        if (r) { q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; }
-                        if (r == 2) { q[-3 * st] = (uint16_t)p2; q[2 * st] = (uint16_t)q2; }
-                    }
-                }
-                /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
-                 * at rows 0 and 4 in 4:2:0, all four at rows 0, 4, 8, 12 in 4:2:2 (:679-686) */
-                if (dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1))) {
-                    if (dir == 0 && CF == 2) {
-                        const int bs = filter ? s.bs[0][edge][l >> 2] : 0;
-                        if (__any(bs != 0))
-                            for (int p = 0; p < 2; p++) chroma_line(&DC(p, 2 * edge, l), 1, bs, tc[p][te]);
-                    } else {
-                        const int p = l >> 3, k = l & 7;
-                        const int bs = filter ? s.bs[dir][edge][k >> 1] : 0;
+                for (int edge = 0; edge < 4; edge++) any_bs |= strength(bsy, dir, edge) != 0 && (edge == 0 || !(dct8 && (edge & 1)));
+                if (__any(any_bs)) {
+#pragma unroll
+                    for (int j = 0; j < 20; j++) r[j] = base[(j - 4) * st];
+#pragma unroll
+                    for (int edge = 0; edge < 4; edge++) {
+                        const int te = edge ? 0 : 1 + dir;
+                        const bool luma_on = edge == 0 || !(dct8 && (edge & 1));
+                        const int bs = luma_on ? strength(bsy, dir, edge) : 0;
                         if (__any(bs != 0)) {
-                            const WideThr t = CF == 2 && p ? tc[CF == 2 ? 1 : 0][te] : tc[0][te];
-                            chroma_line(dir == 0 ? &DC(p, 2 * edge, k) : &DC(p, k, CF == 2 ? 4 * edge : 2 * edge), dir == 0 ? 1 : DBCP, bs, t);
+                            int *q = r + 4 + 4 * edge;
+                            const int rc = edge == 0 ? wide_luma_line<F::MAXV, true>(q[-4], q[-3], q[-2], q[-1], q[0], q[1], q[2], q[3], bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs))
+                                                     : wide_luma_line<F::MAXV, false>(q[-4], q[-3], q[-2], q[-1], q[0], q[1], q[2], q[3], bs, ty[te].alpha, ty[te].beta, wide_tc0<BD>(ty[te], bs));
+                            uint16_t *w = base + 4 * edge * st;
+                            if (rc) { w[-2 * st] = (uint16_t)q[-2]; w[-st] = (uint16_t)q[-1]; w[0] = (uint16_t)q[0]; w[st] = (uint16_t)q[1]; }
+                            if (rc == 2) { w[-3 * st] = (uint16_t)q[-3]; w[2 * st] = (uint16_t)q[2]; }
                         }
                     }
                 }
-                MI355_WAVE_SYNC();
             }
+            /* chroma: vertical edges 0 and 2 at columns 0 and 4 (sixteen lines in 4:2:2: four per strength); horizontal edges 0 and 2
+             * at rows 0 and 4 in 4:2:0, all four at rows 0, 4, 8, 12 in 4:2:2 (:679-686) */
+            {
+                constexpr int NE = 4;                                       /* edge slots; 4:2:0 and the vertical edges use 0 and 2 */
+                const bool both = dir == 0 && CF == 2;                      /* 4:2:2, vertical edges: lane l = row l of both planes */
+                const int pl = l >> 3, k = l & 7;
+                const uint64_t bw = both ? bsy : bsc;
+                const int est = dir == 0 ? 2 : (CF == 2 ? 4 : 2);           /* samples between edge slots */
+                bool any_bs = false;
+#pragma unroll
+                for (int edge = 0; edge < NE; edge++) if (dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1))) any_bs |= strength(bw, dir, edge) != 0;
+                if (__any(any_bs)) {
+#pragma unroll
+                    for (int pp = 0; pp < (both ? 2 : 1); pp++) {
+                        const int p = both ? pp : pl;
+                        uint16_t *base = dir == 0 ? &DC(p, 0, both ? l : k) : &DC(p, k, 0);
+                        const int st = dir == 0 ? 1 : DBCP;
+                        constexpr int NS = 2 + 3 * 4 + 2;                   /* samples -2 .. 13 along the line */
+                        int r[NS];
+#pragma unroll
+                        for (int j = 0; j < NS; j++) if (j - 2 < (dir == 0 ? 6 : (CF == 2 ? 14 : 6))) r[j] = base[(j - 2) * st];
+#pragma unroll
+                        for (int edge = 0; edge < NE; edge++) {
+                            if (!(dir == 0 ? !(edge & 1) : (CF == 2 || !(edge & 1)))) continue;
+                            const int te = edge ? 0 : 1 + dir;
+                            const int bs = strength(bw, dir, edge);
+                            if (__any(bs != 0)) {
+                                const WideThr t = both ? tc[CF == 2 ? pp : 0][te] : (CF == 2 && pl ? tc[CF == 2 ? 1 : 0][te] : tc[0][te]);
+                                int *q = r + 2 + est * edge;
+                                if (wide_chroma_line<F::MAXV>(q[-2], q[-1], q[0], q[1], bs, t.alpha, t.beta, wide_tc0<BD>(t, bs) + 1)) {
+                                    uint16_t *w = base + est * edge * st;
+                                    w[-st] = (uint16_t)q[-1]; w[0] = (uint16_t)q[0];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            MI355_WAVE_SYNC();
+        }
     }
     /* out: the macroblock, and what its left and top edges changed of the neighbours */
     if (ok) {
@@ -1173,7 +1211,7 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
  * of macroblock u + 1 are in flight while u is filtered. */
 template <int BD, int CF>
 __global__ void __launch_bounds__(64)
-k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h, int unit)
+k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int y_first, int rows, int unit)
 {
     __shared__ WideDbLds sh[4];
     /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane — from memory that is a dependent load of a microsecond */
@@ -1181,7 +1219,8 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int max_h, in
     __shared__ __attribute__((aligned(4))) uint8_t t_tc0[52][4];       /* a row is read as one dword (wide_thr) */
     const int lane = lane_id(), g = lane >> 4, l = lane & 15;
     if (lane < 52) { t_alpha[lane] = kw_alpha[lane]; t_beta[lane] = kw_beta[lane]; t_tc0[lane][0] = kw_tc0[lane][0]; t_tc0[lane][1] = kw_tc0[lane][1]; t_tc0[lane][2] = kw_tc0[lane][2]; t_tc0[lane][3] = 0; }
-    const int f = 4 * ((int)blockIdx.x / max_h) + g, mb_y = (int)blockIdx.x % max_h, x0 = (d - 2 * mb_y) * unit;
+    /* the launch holds the rows that have a unit on this anti-diagonal (of the largest picture): y_first .. y_first + rows - 1 */
+    const int f = 4 * ((int)blockIdx.x / rows) + g, mb_y = y_first + (int)blockIdx.x % rows, x0 = (d - 2 * mb_y) * unit;
     const WideDbPic pic = wide_db_pic(frames[f < nframes ? f : nframes - 1]);
     const bool row_ok = f < nframes && mb_y < pic.mbh && x0 >= 0;
     WideDbIn<BD, CF> in;
@@ -1491,14 +1530,19 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
     if (passes & 4) {
         const unsigned nquads = (unsigned)((nframes + 3) / 4);
         {
-            /* macroblocks per group and launch: 4 once the launches fill the device (the fabric traffic decides), 1 for small batches (a launch
-             * is then as long as its longest wave); MI355_WIDE_UNIT overrides */
+            /* macroblocks per group and launch: 1 for small batches (a launch is as long as its longest wave: ~3.8 us a macroblock, ~3.7 us a
+             * launch), 4 once the launches fill the device (the fabric traffic decides); measured on 1080p 10-bit batches of 32 .. 2048 pictures
+             * (profiles/r04_experiments.md, section 9).  MI355_WIDE_UNIT overrides */
             const char *ue = getenv("MI355_WIDE_UNIT");
-            int unit = ue ? atoi(ue) : (nframes >= 96 ? 4 : 1);
+            int unit = ue ? atoi(ue) : (nframes >= 384 ? 4 : (nframes >= 64 ? 2 : 1));
             if (unit < 1 || unit > 8) unit = 1;
             const int uw = (mw + unit - 1) / unit;
-            for (int d = 0; d <= (uw - 1) + 2 * (mh - 1); d++)
-                hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3(nquads * (unsigned)mh), dim3(64), 0, st, d_frames, nframes, d, mh, unit);
+            for (int d = 0; d <= (uw - 1) + 2 * (mh - 1); d++) {
+                const int y_first = d - (uw - 1) > 0 ? (d - (uw - 1) + 1) / 2 : 0, y_last = d / 2 < mh - 1 ? d / 2 : mh - 1;     /* 0 <= d - 2 y <= uw - 1 */
+                if (y_last < y_first) continue;              /* a picture one unit wide has nothing on the odd anti-diagonals */
+                hipLaunchKernelGGL((k_wide_deblock<BD, CF>), dim3(nquads * (unsigned)(y_last - y_first + 1)), dim3(64), 0, st, d_frames, nframes, d, y_first,
+                                   y_last - y_first + 1, unit);
+            }
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
