@@ -357,8 +357,20 @@ template <int BD, int CF>
 __device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr, int mb_xy, int parts)
 {
     typedef Fmt<BD, CF> F;
-    const typename F::COEF *cp = reinterpret_cast<const typename F::COEF *>(fr.coef) + (size_t)mb_xy * F::NCOEF;
-    for (int i = lane_id(); i < F::NCOEF; i += 64) dst[i] = ((parts >> (i < 256 ? i >> 6 : 4)) & 1) ? (int32_t)cp[i] : 0;
+    typedef typename F::COEF COEF;
+    const COEF *cp = reinterpret_cast<const COEF *>(fr.coef) + (size_t)mb_xy * F::NCOEF;
+    /* sixteen bytes of the array per lane and step (four 32-bit or eight 16-bit coefficients: one load, any alignment), 16-byte LDS stores */
+    constexpr int PER = 16 / (int)sizeof(COEF);
+    for (int i = lane_id(); i < F::NCOEF / PER; i += 64) {
+        const int first = PER * i;
+        COEF v[PER];
+        int32_t w[PER];
+        if ((parts >> (first < 256 ? first >> 6 : 4)) & 1) __builtin_memcpy(v, cp + first, sizeof(v));
+        else for (int k = 0; k < PER; k++) v[k] = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) w[k] = v[k];
+        __builtin_memcpy(__builtin_assume_aligned(dst + first, 16), w, sizeof(w));
+    }
     MI355_WAVE_SYNC();
 }
 
@@ -387,7 +399,7 @@ constexpr int CWP = 16, CWIN = 17 * CWP;   /* chroma windows: 9 x 17 per plane (
 struct WideInterLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];
-    int32_t coef[512];
+    alignas(16) int32_t coef[512];
     uint16_t py[256], pc[2][128], qy[256], qc[2][128];
     uint16_t win[2 * CWIN + 8];     /* >= 21 * WP */
     int16_t tmp[21 * 16];           /* the horizontal pass of the 2-D quarter positions: rows -2..h+2 of the block */
@@ -647,7 +659,7 @@ constexpr int CPW = 16;   /* chroma tile pitch: columns -1..7 */
 constexpr int TOW = 4;
 struct WideIntraLds {
     mi355_h264_mb hdr;
-    int32_t coef[512];
+    alignas(16) int32_t coef[512];
     uint16_t tile[17 * TPW];
     uint16_t ctile[2][17 * CPW];
     PredScratch ps;
