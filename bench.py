@@ -251,6 +251,9 @@ def main():
                 for key in ("bridge", "hooked", "reference_c_decoder"):            # decoder end to end: pictures/s, bridge (or hooked tables) vs C
                     if isinstance(p.get(key), dict) and "pictures_per_s" in p[key]:
                         points[p["name"] + ("_c" if key == "reference_c_decoder" else "")] = round(p[key]["pictures_per_s"], 1)
+                for key in p:                                                       # ... with several decoders in the process
+                    if isinstance(p[key], dict) and "pictures_per_s" in p[key] and (key.startswith("bridge_x") or key.startswith("reference_c_decoder_x")):
+                        points[p["name"] + "_" + key.replace("reference_c_decoder", "c")] = round(p[key]["pictures_per_s"], 1)
             if not args.notes:
                 for p in out["extra"]:
                     for key in ("note", "what", "sample"):
@@ -554,6 +557,19 @@ def hevc_bridge_points(lib):
             r = subprocess.run([exe, src, "-", "20"], capture_output=True, text=True, env=e, timeout=600)
             st = json.loads(r.stdout.strip().splitlines()[-1])
             pt[key] = {k: st[k] for k in ("pictures_output", "pictures_reconstructed_on_device", "reconstruction_launches", "dependency_levels", "pictures_per_s")}
+        if name == "pb_1080p_few_intra":
+            # many decoders in ONE process (a thread each, 4 passes each): their waiting pictures share launches (commit_launches); the C decoder with as many threads
+            for nthr in (4, 16):
+                for key, env in (("bridge_x%d" % nthr, {}), ("bridge_x%d_own_launches" % nthr, {"MI355_HEVC_BRIDGE_SOLO": "1"}),
+                                 ("reference_c_decoder_x%d" % nthr, {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
+                    e = dict(os.environ)
+                    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_MIN_PIXELS", "MI355_HEVC_BRIDGE_SOLO"):
+                        e.pop(k, None)
+                    e.update(env)
+                    r = subprocess.run([exe, src, "-", "4", str(nthr)], capture_output=True, text=True, env=e, timeout=900)
+                    st = json.loads(r.stdout.strip().splitlines()[-1])
+                    pt[key] = {k: st[k] for k in ("threads", "outputs_identical", "pictures_output", "pictures_reconstructed_on_device", "reconstruction_launches",
+                                                  "pictures_per_launch_set", "pictures_per_s")}
         pt["note"] = ("20 passes over the stream in one process; bit-exactness of this path: tests/test_hevc_bridge_gpu.py (all generated streams); "
                       "bridge_random_access_pictures_on_host: MI355_HEVC_BRIDGE_IRAP_ON_HOST=1, the all-intra first picture of each pass reconstructed by "
                       "the reference's functions on the host (filtered on the device, uploaded once)")

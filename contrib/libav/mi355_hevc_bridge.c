@@ -28,10 +28,19 @@
  * the plane a source pointer falls into); a reference this bridge did not decode (a frame the decoder made up for a missing
  * reference) is uploaded once.
  *
+ * Many decoders in one process (one per thread): their pictures share launches.  A picture's jobs are sorted by level on its own thread;
+ * the launches are issued by whichever thread finds no other doing so, for EVERY picture that is waiting at that moment — level l of all of
+ * them is one launch per job kind (the job arrays of the batch are merged level-major; jobs name their samples by device pointer and an
+ * intra block names its picture's descriptor by index, so the kernels need no change).  A lone decoder is a batch of one; the busier the
+ * device, the more pictures wait and the larger the batches (a picture of a 1080p stream is ~900 launches of a few microseconds each:
+ * sixteen decoder PROCESSES were 197 against the C decoder's 481 pictures/s).  MI355_HEVC_BRIDGE_SOLO=1: every
+ * picture issues its own launches (the form before).
+ *
  * Scope: what the filter bridge takes (4:2:0, no frame threads; tiles, wavefronts and dependent slice segments included), 8 / 9 / 10 bit, one decoder per thread.  A picture
  * outside it is reconstructed by the reference's own functions (the entries forward to the tables the reference filled) and
  * its surface is uploaded when a later picture needs it.  MI355_HEVC_RECON_PLAIN=1 forwards everything.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -97,6 +106,10 @@ static __thread struct Recon {
     uint8_t *d_emu; size_t d_emu_bytes;
     uint8_t *d_mvf, *d_zs; size_t d_mvf_bytes, d_zs_bytes;
 } R;
+
+/* counters of the whole process (decoders come and go with their threads) */
+static unsigned long g_pictures, g_on_device, g_uploads, g_launches, g_levels, g_batches, g_batched_pictures;
+#define COUNT(c, n) __atomic_fetch_add(&(c), (unsigned long)(n), __ATOMIC_RELAXED)
 
 static void recon_fail(const char *what)
 {
@@ -506,7 +519,7 @@ int __wrap_ff_hevc_frame_rps(HEVCContext *s)
         if (!held) { u->valid = 0; u->host[0] = u->host[1] = u->host[2] = NULL; }
     }
     R.on = 0;
-    R.pictures++;
+    R.pictures++; COUNT(g_pictures, 1);
     if (ret < 0 || R.plain || R.failed || !s->frame || !s->frame->data[0]) return ret;
     if (!mi355_hevc_lf_bridge_active || !mi355_hevc_lf_bridge_active(s)) return ret;
     if (R.irap_on_host && IS_IRAP(s)) return ret;
@@ -551,7 +564,7 @@ static int upload_surface(const HEVCContext *s, Surface *u)
         if (f->frame && f->frame->data[0] == u->host[0]) { u->poc = f->poc; u->seq = f->sequence; }
     }
     u->valid = 1;
-    R.uploads++;
+    R.uploads++; COUNT(g_uploads, 1);
     return 0;
 }
 /* is the device copy of surface `i` the picture the decoder's frame holds now? */
@@ -569,6 +582,141 @@ static int surface_current(const HEVCContext *s, const Surface *u)
  * recorded (the filter bridge then uploads the host frame as it always did), 1 when the unfiltered reconstruction now lies in
  * cur[] (device planes of s->frame) and the finished picture must go to fin[] (device planes of the frame later pictures
  * predict from: s->sao_frame with SAO, else the same), < 0 on failure. */
+/* ---- many decoders, one launch chain -------------------------------------------------------------------------------------------------- */
+/* what a thread hands over: its picture's jobs, sorted by level, in its own pinned staging (device pointers inside), and where each level starts */
+typedef struct Sub {
+    const mi355_edge_emu_job *je; const mi355_hevc_mcpred_job *jm; const mi355_hevc_tu_job *jt, *jf; const mi355_hevc_intra_block *ji;
+    const mi355_hevc_intra_picture *desc;
+    const int *smc, *stu, *sin;          /* [level] -> first job of that level, levels 1..L ([L + 1]: the end) */
+    int L, nemu, bd, split_intra;
+    int done, rc;
+    unsigned long launches;              /* launches this picture took part in */
+} Sub;
+#define MAX_WAITING 256
+#define MAX_BATCH 32
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
+static Sub *g_wait[MAX_WAITING];
+static int g_nwait, g_busy;
+/* merged job arrays: pinned host copy -> device copy on the stream (three of each in turn: the host copy of a batch is free again when the
+ * event behind that batch's launches has passed) */
+static struct Merged { uint8_t *h, *d; size_t bytes; void *ev; int used; } g_merged[3];
+static int g_merged_at;
+
+static int launch_batch(Sub **b, int K)
+{
+    int maxL = 0, nemu = 0, nmc = 0, ntu = 0, nin = 0;
+    for (int k = 0; k < K; k++) {
+        if (b[k]->L > maxL) maxL = b[k]->L;
+        nemu += b[k]->nemu; nmc += b[k]->smc[b[k]->L + 1]; ntu += b[k]->stu[b[k]->L + 1]; nin += b[k]->sin[b[k]->L + 1];
+    }
+    size_t o = 0;
+    const size_t o_desc = o; o += ((size_t)K * sizeof(mi355_hevc_intra_picture) + 63) & ~(size_t)63;
+    const size_t o_emu = o;  o += ((size_t)nemu * sizeof(mi355_edge_emu_job) + 63) & ~(size_t)63;
+    const size_t o_mc = o;   o += ((size_t)nmc * sizeof(mi355_hevc_mcpred_job) + 63) & ~(size_t)63;
+    const size_t o_tu = o;   o += ((size_t)ntu * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
+    const size_t o_in = o;   o += ((size_t)nin * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
+    const size_t o_fu = o;   o += ((size_t)nin * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
+    struct Merged *m = &g_merged[g_merged_at];
+    g_merged_at = (g_merged_at + 1) % 3;
+    if (m->used && mi355_event_sync(m->ev) != 0) return -1;
+    m->used = 0;
+    if (m->bytes < o) {
+        if (m->h) mi355_host_free(m->h);
+        if (m->d) { mi355_sync(NULL); mi355_free(m->d); }          /* launches of an earlier batch may still read it */
+        m->bytes = o + o / 2;
+        m->h = mi355_host_alloc(m->bytes);
+        m->d = mi355_malloc(m->bytes);
+        if (!m->h || !m->d) { m->bytes = 0; return -1; }
+    }
+    if (!m->ev && !(m->ev = mi355_event_create())) return -1;
+    int *first = malloc((size_t)(maxL + 2) * 3 * sizeof(int));     /* merged [level] -> first job, per kind */
+    if (!first) return -1;
+    int *fmc = first, *ftu = first + (maxL + 2), *fin = first + 2 * (maxL + 2);
+    mi355_hevc_intra_picture *md = (mi355_hevc_intra_picture *)(m->h + o_desc);
+    mi355_edge_emu_job *me = (mi355_edge_emu_job *)(m->h + o_emu);
+    mi355_hevc_mcpred_job *mm = (mi355_hevc_mcpred_job *)(m->h + o_mc);
+    mi355_hevc_tu_job *mt = (mi355_hevc_tu_job *)(m->h + o_tu), *mf = (mi355_hevc_tu_job *)(m->h + o_fu);
+    mi355_hevc_intra_block *mi = (mi355_hevc_intra_block *)(m->h + o_in);
+    int ae = 0, am = 0, at = 0, ai = 0;
+    for (int k = 0; k < K; k++) {
+        md[k] = *b[k]->desc;
+        if (b[k]->nemu) memcpy(me + ae, b[k]->je, (size_t)b[k]->nemu * sizeof(*me));
+        ae += b[k]->nemu;
+    }
+    for (int l = 1; l <= maxL; l++) {
+        fmc[l] = am; ftu[l] = at; fin[l] = ai;
+        for (int k = 0; k < K; k++) {
+            const Sub *u = b[k];
+            if (l > u->L) continue;
+            const int nm = u->smc[l + 1] - u->smc[l], nt = u->stu[l + 1] - u->stu[l], ni = u->sin[l + 1] - u->sin[l];
+            if (nm) memcpy(mm + am, u->jm + u->smc[l], (size_t)nm * sizeof(*mm));
+            if (nt) memcpy(mt + at, u->jt + u->stu[l], (size_t)nt * sizeof(*mt));
+            if (ni) {
+                memcpy(mi + ai, u->ji + u->sin[l], (size_t)ni * sizeof(*mi));
+                memcpy(mf + ai, u->jf + u->sin[l], (size_t)ni * sizeof(*mf));
+                for (int i = 0; i < ni; i++) mi[ai + i].pic = k;
+            }
+            am += nm; at += nt; ai += ni;
+        }
+    }
+    fmc[maxL + 1] = am; ftu[maxL + 1] = at; fin[maxL + 1] = ai;
+    const int bd = b[0]->bd;
+    int rc = mi355_memcpy_h2d_async(m->d, m->h, o, NULL);
+    unsigned long launches = 0;
+    if (!rc && nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(m->d + o_emu), nemu, bd, NULL) != 0) rc = -1;
+    for (int l = 1; l <= maxL && !rc; l++) {
+        const int nm = fmc[l + 1] - fmc[l], nt = ftu[l + 1] - ftu[l], ni = fin[l + 1] - fin[l];
+        if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(m->d + o_mc) + fmc[l], nm, bd, NULL) != 0) rc = -1;
+        if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(m->d + o_tu) + ftu[l], nt, bd, NULL) != 0) rc = -1;
+        if (ni && !b[0]->split_intra &&
+            mi355_hevc_intra_recon_blocks_dev((const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l],
+                                              (const mi355_hevc_tu_job *)(m->d + o_fu) + fin[l], ni, bd, NULL) != 0) rc = -1;
+        if (ni && b[0]->split_intra &&
+            mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l], ni, bd, NULL) != 0) rc = -1;
+        launches += (unsigned long)((nm != 0) + (nt != 0) + (ni != 0));
+    }
+    free(first);
+    if (mi355_event_record(m->ev, NULL) == 0) m->used = 1;
+    else if (mi355_sync(NULL) != 0) rc = -1;
+    COUNT(g_launches, launches); COUNT(g_batches, 1); COUNT(g_batched_pictures, K);
+    for (int k = 0; k < K; k++) b[k]->launches = launches;
+    return rc;
+}
+
+/* The calling thread's picture is launched — by this thread, together with every picture of the same sample format that is waiting, or by
+ * the thread that is at it already.  Returns when the launches are in the stream (the filter passes this thread queues next follow them). */
+static int commit_launches(Sub *me)
+{
+    static int solo = -1;
+    if (solo < 0) { const char *e = getenv("MI355_HEVC_BRIDGE_SOLO"); solo = e && *e && *e != '0'; }
+    if (solo) { Sub *one = me; pthread_mutex_lock(&g_mu); const int rc = launch_batch(&one, 1); pthread_mutex_unlock(&g_mu); return rc; }
+    pthread_mutex_lock(&g_mu);
+    while (g_nwait == MAX_WAITING) pthread_cond_wait(&g_cv, &g_mu);
+    g_wait[g_nwait++] = me;
+    while (!me->done) {
+        if (g_busy) { pthread_cond_wait(&g_cv, &g_mu); continue; }
+        /* the oldest waiting picture and all that can share its launches (same bit depth, same intra form) */
+        Sub *b[MAX_BATCH];
+        int K = 0, keep = 0;
+        for (int i = 0; i < g_nwait; i++) {
+            Sub *u = g_wait[i];
+            if (K < MAX_BATCH && (K == 0 || (u->bd == b[0]->bd && u->split_intra == b[0]->split_intra))) b[K++] = u;
+            else g_wait[keep++] = u;
+        }
+        g_nwait = keep;
+        g_busy = 1;
+        pthread_mutex_unlock(&g_mu);
+        const int rc = launch_batch(b, K);
+        pthread_mutex_lock(&g_mu);
+        for (int k = 0; k < K; k++) { b[k]->rc = rc; b[k]->done = 1; }
+        g_busy = 0;
+        pthread_cond_broadcast(&g_cv);
+    }
+    pthread_mutex_unlock(&g_mu);
+    return me->rc;
+}
+
 int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
 {
     if (!R.on || R.s != s) return 0;
@@ -689,25 +837,23 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     d->strong_intra_smoothing = sps->sps_strong_intra_smoothing_enable_flag;
     d->tab_mvf = (const mi355_hevc_mvfield *)R.d_mvf; d->min_tb_addr_zs = (const int32_t *)R.d_zs;
     memcpy(R.h_stage + o_coef, R.coef, R.ncoef * sizeof(int16_t));
-    int rc = mi355_memcpy_h2d(R.d_stage, R.h_stage, o);
+    /* the coefficients go to this decoder's device staging (the jobs name them there); the job arrays stay here, for the merge */
+    int rc = o > o_coef ? mi355_memcpy_h2d(R.d_stage + o_coef, R.h_stage + o_coef, o - o_coef) : 0;
     if (R.nintra) rc |= mi355_memcpy_h2d(R.d_mvf, s->ref->tab_mvf, mvf_bytes) | mi355_memcpy_h2d(R.d_zs, s->ps.pps->min_tb_addr_zs, zs_bytes);
     if (rc) { free(start); return -1; }
-    /* windows first (they read reference pictures only), then level by level: the three kinds of one level touch disjoint samples */
-    if (R.nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(R.d_stage + o_emu), R.nemu, R.bd, NULL) != 0) rc = -1;
-    for (int l = 1; l <= L && !rc; l++) {
-        const int nm = smc[l + 1] - smc[l], nt = stu[l + 1] - stu[l], ni = sin[l + 1] - sin[l];
-        if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(R.d_stage + o_mc) + smc[l], nm, R.bd, NULL) != 0) rc = -1;
-        if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(R.d_stage + o_tu) + stu[l], nt, R.bd, NULL) != 0) rc = -1;
-        if (ni && !R.split_intra &&
-            mi355_hevc_intra_recon_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l],
-                                              (const mi355_hevc_tu_job *)(R.d_stage + o_fu) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
-        if (ni && R.split_intra &&
-            mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(R.d_stage + o_desc), (const mi355_hevc_intra_block *)(R.d_stage + o_in) + sin[l], ni, R.bd, NULL) != 0) rc = -1;
-        R.launches += (nm != 0) + (nt != 0) + (ni != 0);
+    /* windows first (they read reference pictures only), then level by level: the three kinds of one level touch disjoint samples —
+     * together with whatever other decoders of this process have waiting (commit_launches) */
+    {
+        Sub me;
+        memset(&me, 0, sizeof(me));
+        me.je = je; me.jm = jm; me.jt = jt; me.ji = ji; me.jf = (const mi355_hevc_tu_job *)(R.h_stage + o_fu); me.desc = d;
+        me.smc = smc; me.stu = stu; me.sin = sin; me.L = L; me.nemu = R.nemu; me.bd = R.bd; me.split_intra = R.split_intra;
+        rc = commit_launches(&me);
+        R.launches += me.launches;
     }
     free(start);
     if (rc) return -1;
-    R.levels_total += (unsigned long)L;
+    R.levels_total += (unsigned long)L; COUNT(g_levels, L);
     /* where the finished picture goes */
     Surface *uf = uc;
     if (sps->sao_enabled) {
@@ -717,16 +863,22 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
     for (int k = 0; k < 3; k++) { cur[k] = uc->dev + uc->off[k]; fin[k] = uf->dev + uf->off[k]; }
     uf->valid = 1; uf->poc = s->poc; uf->seq = s->seq_decode;         /* true once the filter bridge's passes (queued behind these launches) have run */
     if (uf != uc) uc->valid = 0;
-    R.on_device++;
+    R.on_device++; COUNT(g_on_device, 1);
     return 1;
 }
 
 /* for hosts that want the numbers */
 void mi355_hevc_bridge_stats(unsigned long *pictures, unsigned long *on_device, unsigned long *uploads, unsigned long *launches, unsigned long *levels)
 {
-    if (pictures) *pictures = R.pictures;
-    if (on_device) *on_device = R.on_device;
-    if (uploads) *uploads = R.uploads;
-    if (launches) *launches = R.launches;
-    if (levels) *levels = R.levels_total;
+    if (pictures) *pictures = __atomic_load_n(&g_pictures, __ATOMIC_RELAXED);
+    if (on_device) *on_device = __atomic_load_n(&g_on_device, __ATOMIC_RELAXED);
+    if (uploads) *uploads = __atomic_load_n(&g_uploads, __ATOMIC_RELAXED);
+    if (launches) *launches = __atomic_load_n(&g_launches, __ATOMIC_RELAXED);
+    if (levels) *levels = __atomic_load_n(&g_levels, __ATOMIC_RELAXED);
+}
+/* launch sets issued and the pictures they held (one decoder: equal) */
+void mi355_hevc_bridge_batch_stats(unsigned long *sets, unsigned long *pictures)
+{
+    if (sets) *sets = __atomic_load_n(&g_batches, __ATOMIC_RELAXED);
+    if (pictures) *pictures = __atomic_load_n(&g_batched_pictures, __ATOMIC_RELAXED);
 }

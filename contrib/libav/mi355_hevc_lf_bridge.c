@@ -39,6 +39,7 @@ void __real_ff_hevc_hls_filter(HEVCContext *s, int x, int y);
 void __real_ff_hevc_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size);
 
 /* one decoder per thread (as the reconstruction bridge): the state is the thread's */
+static unsigned long g_lf_pictures;                    /* pictures filtered on the device, all decoders (threads) of the process */
 static __thread struct {
     size_t plane_bytes[3], bs_bytes, qp_bytes, pcm_bytes, db_bytes;
     uint8_t *plane[3], *vbs, *hbs, *qp, *pcm, *db;
@@ -389,7 +390,7 @@ static int filter_picture(HEVCContext *s)
         if (mi355_sync(lf.stream) != 0) return -2;
         for (int i = 0; i < 3; i++) rc |= picture_d2h(s->frame->data[i], plane[i], sz[i]);
         if (rc) return -2;
-        lf.pictures++;
+        lf.pictures++; __atomic_fetch_add(&g_lf_pictures, 1ul, __ATOMIC_RELAXED);
         return 0;
     }
     /* SAO: deblocked picture -> the picture the decoder keeps, one job per CTB component (the pieces that make up its own samples) */
@@ -451,7 +452,7 @@ static int filter_picture(HEVCContext *s)
     for (int i = 0; i < 3; i++) rc |= picture_d2h(s->sao_frame->data[i], out[i], sz[i]);
     if (restore) for (int i = 0; i < 3; i++) rc |= picture_d2h(s->frame->data[i], plane[i], sz[i]);
     if (rc) return -2;
-    lf.pictures++;
+    lf.pictures++; __atomic_fetch_add(&g_lf_pictures, 1ul, __ATOMIC_RELAXED);
     return 0;
 }
 
@@ -483,5 +484,5 @@ void __wrap_ff_hevc_hls_filter(HEVCContext *s, int x, int y)
     }
 }
 
-unsigned long mi355_hevc_lf_bridge_pictures(void) { return lf.pictures; }
+unsigned long mi355_hevc_lf_bridge_pictures(void) { return __atomic_load_n(&g_lf_pictures, __ATOMIC_RELAXED); }      /* of every decoder of the process */
 unsigned long mi355_hevc_lf_bridge_bs_pictures(void) { return lf.bs_pictures; }

@@ -77,3 +77,22 @@ def test_small_pictures_stay_on_the_host_by_default(emu, tmp_path):
     st = json.loads(r.stdout.strip().splitlines()[-1])
     assert st["pictures_output"] > 0 and st["pictures_reconstructed_on_device"] == 0
     HS.check_md5(out, name)
+
+
+@pytest.mark.parametrize("name,threads", [(n, t) for n in HS.EMU[::4] for t in (3,)] + [(HS.EMU[1], 7)])
+def test_hevc_bridge_many_decoders_share_launches_emulated(tmp_path, emu, name, threads):
+    """several decoders in one process (one per thread, the same stream twice over): a picture's launches are issued together with those of every
+    other decoder's picture that is waiting at that moment (contrib/libav/mi355_hevc_bridge.c commit_launches: level l of the whole batch is one
+    launch per job kind) — every decoder outputs what the unmodified decoder does, every picture is reconstructed and filtered on the device, and
+    the process needs fewer launches than the decoders would alone (MI355_HEVC_BRIDGE_SOLO=1: the same run, every picture its own launches)"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_emu", name, out, threads=threads, loops=2)
+    n = HS.MD5[name]["pictures"] * threads * 2
+    assert st["threads"] == threads and st["outputs_identical"] is True, st
+    assert st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n and st["pictures_filtered_on_device"] == n, st
+    HS.check_md5(out, name)
+    solo = HS.run_bridge("hevc_bridge_emu", name, tmp_path / "s.yuv", threads=threads, loops=2, solo=True)
+    assert solo["outputs_identical"] is True and solo["pictures_per_launch_set"] == 1.0, solo
+    HS.check_md5(tmp_path / "s.yuv", name)
+    assert st["reconstruction_launches"] <= solo["reconstruction_launches"], (st, solo)

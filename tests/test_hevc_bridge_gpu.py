@@ -52,3 +52,18 @@ def test_hevc_bridge_two_launch_form_of_intra_blocks_gpu(tmp_path, mi355, name):
     HS.check_md5(out, name)
     fused = HS.run_bridge("hevc_bridge_gpu", name, tmp_path / "f.yuv")
     assert fused["dependency_levels"] < split["dependency_levels"], (fused, split)
+
+
+@pytest.mark.parametrize("name,threads", (("pb_8bit", 4), ("i_10bit", 3), ("pb_480p_ctb64", 8)))
+def test_hevc_bridge_many_decoders_share_launches_gpu(tmp_path, mi355, name, threads):
+    """several decoders in one process (one per thread): the pictures that wait together are launched together (commit_launches) — every
+    decoder's output identical to the unmodified decoder's, everything on the device, fewer launches than with MI355_HEVC_BRIDGE_SOLO=1"""
+    out = tmp_path / "o.yuv"
+    st = HS.run_bridge("hevc_bridge_gpu", name, out, threads=threads, loops=3)
+    n = HS.MD5[name]["pictures"] * threads * 3
+    assert st["outputs_identical"] is True and st["pictures_output"] == n and st["pictures_reconstructed_on_device"] == n and st["pictures_filtered_on_device"] == n, st
+    HS.check_md5(out, name)
+    solo = HS.run_bridge("hevc_bridge_gpu", name, tmp_path / "s.yuv", threads=threads, loops=3, solo=True)
+    assert solo["outputs_identical"] is True and solo["pictures_per_launch_set"] == 1.0, solo
+    assert st["reconstruction_launches"] <= solo["reconstruction_launches"], (st, solo)
+

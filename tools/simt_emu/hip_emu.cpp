@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <cstdint>
 #include <ucontext.h>
+#include <mutex>
 #include <vector>
 
 namespace simt_emu {
@@ -230,8 +231,13 @@ int device_count()
 int &current_device() { static thread_local int d = 0; return d; }
 void note_alloc(size_t n) { g_alloc_bytes[current_device() & 15] += (long)n; }
 
+/* one kernel at a time: the fibers, the block index and the current lane are the emulator's own globals, and a host with several decoder
+ * threads (the bridges' tests) launches from all of them — on the device those launches queue in the stream, here behind this lock */
+static std::mutex g_launch_lock;
+
 void launch(dim3 grid, dim3 block, const std::function<void()> &body)
 {
+    std::lock_guard<std::mutex> hold(g_launch_lock);
     g_launches[current_device() & 15]++;
     g_gridDim = grid;
     g_blockDim = block;
