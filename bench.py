@@ -558,12 +558,13 @@ def hevc_bridge_points(lib):
             st = json.loads(r.stdout.strip().splitlines()[-1])
             pt[key] = {k: st[k] for k in ("pictures_output", "pictures_reconstructed_on_device", "reconstruction_launches", "dependency_levels", "pictures_per_s")}
         if name == "pb_1080p_few_intra":
-            # many decoders in ONE process (a thread each, 4 passes each): their waiting pictures share launches (commit_launches); the C decoder with as many threads
+            # many decoders in ONE process (a thread each, 4 passes each): their waiting pictures share launch sets, up to four sets side by side on their own
+            # streams (commit_launches); "_own_launches": every picture its own launches on the default stream (the bridge before); the C decoder with as many threads
             for nthr in (4, 16):
-                for key, env in (("bridge_x%d" % nthr, {}), ("bridge_x%d_own_launches" % nthr, {"MI355_HEVC_BRIDGE_SOLO": "1"}),
+                for key, env in (("bridge_x%d" % nthr, {}), ("bridge_x%d_own_launches" % nthr, {"MI355_HEVC_BRIDGE_SOLO": "1", "MI355_HEVC_BRIDGE_DEFAULT_STREAM": "1"}),
                                  ("reference_c_decoder_x%d" % nthr, {"MI355_HEVC_RECON_PLAIN": "1", "MI355_HEVC_LF_PLAIN": "1"})):
                     e = dict(os.environ)
-                    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_MIN_PIXELS", "MI355_HEVC_BRIDGE_SOLO"):
+                    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_MIN_PIXELS", "MI355_HEVC_BRIDGE_SOLO", "MI355_HEVC_BRIDGE_DEFAULT_STREAM", "MI355_HEVC_BRIDGE_SETS_IN_FLIGHT"):
                         e.pop(k, None)
                     e.update(env)
                     r = subprocess.run([exe, src, "-", "4", str(nthr)], capture_output=True, text=True, env=e, timeout=900)

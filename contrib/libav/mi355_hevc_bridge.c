@@ -29,12 +29,14 @@
  * reference) is uploaded once.
  *
  * Many decoders in one process (one per thread): their pictures share launches.  A picture's jobs are sorted by level on its own thread;
- * the launches are issued by whichever thread finds no other doing so, for EVERY picture that is waiting at that moment — level l of all of
- * them is one launch per job kind (the job arrays of the batch are merged level-major; jobs name their samples by device pointer and an
- * intra block names its picture's descriptor by index, so the kernels need no change).  A lone decoder is a batch of one; the busier the
- * device, the more pictures wait and the larger the batches (a picture of a 1080p stream is ~900 launches of a few microseconds each:
- * sixteen decoder PROCESSES were 197 against the C decoder's 481 pictures/s).  MI355_HEVC_BRIDGE_SOLO=1: every
- * picture issues its own launches (the form before).
+ * the launches are issued by a thread that finds a free SLOT (a stream with its own merged arrays; four by default,
+ * MI355_HEVC_BRIDGE_SETS_IN_FLIGHT), for EVERY picture that is waiting when the slot's last set has finished — level l of all of them is ONE
+ * launch (mi355_hevc_recon_level_dev: the level's prediction blocks, transform units and intra blocks side by side; the job arrays of the set
+ * are merged level-major, jobs name their samples by device pointer and an intra block names its picture's descriptor by index).  Sets of
+ * different slots run side by side on the device; a decoder's own copies and filter passes run on ITS stream behind the set's event.  A lone
+ * decoder is a set of one.  Measured (1080p P / B stream, 16 decoders, pictures/s): 132 with every picture's own launches on the default
+ * stream (the form before: MI355_HEVC_BRIDGE_SOLO=1 MI355_HEVC_BRIDGE_DEFAULT_STREAM=1) -> 204; the C decoder 464 — a picture's chain of ~480
+ * dependent levels (~18 ms on the device whatever rides along) stays the decoder's cycle, DESIGN.md section 9 item 5.
  *
  * Scope: what the filter bridge takes (4:2:0, no frame threads; tiles, wavefronts and dependent slice segments included), 8 / 9 / 10 bit, one decoder per thread.  A picture
  * outside it is reconstructed by the reference's own functions (the entries forward to the tables the reference filled) and
@@ -105,6 +107,7 @@ static __thread struct Recon {
     uint8_t *d_stage; size_t d_stage_bytes; uint8_t *h_stage; size_t h_stage_bytes;
     uint8_t *d_emu; size_t d_emu_bytes;
     uint8_t *d_mvf, *d_zs; size_t d_mvf_bytes, d_zs_bytes;
+    void *done_event;                  /* of the launch set that held the last picture */
 } R;
 
 /* counters of the whole process (decoders come and go with their threads) */
@@ -591,20 +594,32 @@ typedef struct Sub {
     int L, nemu, bd, split_intra;
     int done, rc;
     unsigned long launches;              /* launches this picture took part in */
+    void *done_event;                    /* recorded behind the set's last launch: what this picture's filter passes (on the decoder's own stream) wait for */
 } Sub;
 #define MAX_WAITING 256
 #define MAX_BATCH 32
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
 static Sub *g_wait[MAX_WAITING];
-static int g_nwait, g_busy;
+static int g_nwait, g_solo;
 /* merged job arrays: pinned host copy -> device copy on the stream (three of each in turn: the host copy of a batch is free again when the
  * event behind that batch's launches has passed) */
-static struct Merged { uint8_t *h, *d; size_t bytes; void *ev; int used; } g_merged[3];
-static int g_merged_at;
+/* A set runs on one of a few SLOTS: a stream of its own (non-blocking: a decoder's copies and filter passes — on ITS stream — neither wait for other
+ * decoders' sets nor hold them up; what orders a picture's filter passes behind its set is the set's event, mi355_hevc_recon_done_event) with its
+ * own copy of the merged arrays.  Sets of different slots run side by side on the device (they hold pictures of different decoders: nothing connects
+ * them) — a chain of hundreds of small dependent launches leaves most of the device idle; a slot takes its next set when its last one has finished,
+ * so the pictures that arrive meanwhile ride one chain together. */
+#define MAX_SLOTS 8
+static struct Merged { uint8_t *h, *d; size_t bytes; void *ev, *stream; int used, busy; } g_slot[MAX_SLOTS];
+static int g_nslots = -1, g_default_stream;
 
-static int launch_batch(Sub **b, int K)
+static int g_three_launches = -1;         /* MI355_HEVC_BRIDGE_THREE_LAUNCHES=1: a level's job kinds as separate launches (the form before mi355_hevc_recon_level_dev) */
+
+static int launch_batch(struct Merged *m, Sub **b, int K)
 {
+    if (g_three_launches < 0) { const char *e = getenv("MI355_HEVC_BRIDGE_THREE_LAUNCHES"); g_three_launches = e && *e && *e != '0'; }
+    if (!m->stream && !g_default_stream) m->stream = mi355_stream_create();
+    void *const st = m->stream;
     int maxL = 0, nemu = 0, nmc = 0, ntu = 0, nin = 0;
     for (int k = 0; k < K; k++) {
         if (b[k]->L > maxL) maxL = b[k]->L;
@@ -617,13 +632,11 @@ static int launch_batch(Sub **b, int K)
     const size_t o_tu = o;   o += ((size_t)ntu * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
     const size_t o_in = o;   o += ((size_t)nin * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
     const size_t o_fu = o;   o += ((size_t)nin * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
-    struct Merged *m = &g_merged[g_merged_at];
-    g_merged_at = (g_merged_at + 1) % 3;
-    if (m->used && mi355_event_sync(m->ev) != 0) return -1;
+    if (m->used && mi355_event_sync(m->ev) != 0) return -1;       /* (the caller has waited already: the arrays are free) */
     m->used = 0;
     if (m->bytes < o) {
         if (m->h) mi355_host_free(m->h);
-        if (m->d) { mi355_sync(NULL); mi355_free(m->d); }          /* launches of an earlier batch may still read it */
+        if (m->d) { mi355_sync(st); mi355_free(m->d); }          /* launches of an earlier batch may still read it */
         m->bytes = o + o / 2;
         m->h = mi355_host_alloc(m->bytes);
         m->d = mi355_malloc(m->bytes);
@@ -662,25 +675,33 @@ static int launch_batch(Sub **b, int K)
     }
     fmc[maxL + 1] = am; ftu[maxL + 1] = at; fin[maxL + 1] = ai;
     const int bd = b[0]->bd;
-    int rc = mi355_memcpy_h2d_async(m->d, m->h, o, NULL);
+    int rc = mi355_memcpy_h2d_async(m->d, m->h, o, st);
     unsigned long launches = 0;
-    if (!rc && nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(m->d + o_emu), nemu, bd, NULL) != 0) rc = -1;
+    if (!rc && nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(m->d + o_emu), nemu, bd, st) != 0) rc = -1;
     for (int l = 1; l <= maxL && !rc; l++) {
         const int nm = fmc[l + 1] - fmc[l], nt = ftu[l + 1] - ftu[l], ni = fin[l + 1] - fin[l];
-        if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(m->d + o_mc) + fmc[l], nm, bd, NULL) != 0) rc = -1;
-        if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(m->d + o_tu) + ftu[l], nt, bd, NULL) != 0) rc = -1;
+        if (!b[0]->split_intra && !g_three_launches) {
+            /* the level's three job kinds in one launch */
+            if (nm + nt + ni && mi355_hevc_recon_level_dev((const mi355_hevc_mcpred_job *)(m->d + o_mc) + fmc[l], nm, (const mi355_hevc_tu_job *)(m->d + o_tu) + ftu[l], nt,
+                                                          (const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l],
+                                                          (const mi355_hevc_tu_job *)(m->d + o_fu) + fin[l], ni, bd, st) != 0) rc = -1;
+            launches += (unsigned long)(nm + nt + ni != 0);
+            continue;
+        }
+        if (nm && mi355_hevc_mcpred_batch_dev((const mi355_hevc_mcpred_job *)(m->d + o_mc) + fmc[l], nm, bd, st) != 0) rc = -1;
+        if (nt && mi355_hevc_residual_batch_dev((const mi355_hevc_tu_job *)(m->d + o_tu) + ftu[l], nt, bd, st) != 0) rc = -1;
         if (ni && !b[0]->split_intra &&
             mi355_hevc_intra_recon_blocks_dev((const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l],
-                                              (const mi355_hevc_tu_job *)(m->d + o_fu) + fin[l], ni, bd, NULL) != 0) rc = -1;
+                                              (const mi355_hevc_tu_job *)(m->d + o_fu) + fin[l], ni, bd, st) != 0) rc = -1;
         if (ni && b[0]->split_intra &&
-            mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l], ni, bd, NULL) != 0) rc = -1;
+            mi355_hevc_intra_pred_blocks_dev((const mi355_hevc_intra_picture *)(m->d + o_desc), (const mi355_hevc_intra_block *)(m->d + o_in) + fin[l], ni, bd, st) != 0) rc = -1;
         launches += (unsigned long)((nm != 0) + (nt != 0) + (ni != 0));
     }
     free(first);
-    if (mi355_event_record(m->ev, NULL) == 0) m->used = 1;
-    else if (mi355_sync(NULL) != 0) rc = -1;
+    if (mi355_event_record(m->ev, st) == 0) m->used = 1;
+    else if (mi355_sync(st) != 0) rc = -1;
     COUNT(g_launches, launches); COUNT(g_batches, 1); COUNT(g_batched_pictures, K);
-    for (int k = 0; k < K; k++) b[k]->launches = launches;
+    for (int k = 0; k < K; k++) { b[k]->launches = launches; b[k]->done_event = m->used ? m->ev : NULL; }
     return rc;
 }
 
@@ -688,29 +709,42 @@ static int launch_batch(Sub **b, int K)
  * the thread that is at it already.  Returns when the launches are in the stream (the filter passes this thread queues next follow them). */
 static int commit_launches(Sub *me)
 {
-    static int solo = -1;
-    if (solo < 0) { const char *e = getenv("MI355_HEVC_BRIDGE_SOLO"); solo = e && *e && *e != '0'; }
-    if (solo) { Sub *one = me; pthread_mutex_lock(&g_mu); const int rc = launch_batch(&one, 1); pthread_mutex_unlock(&g_mu); return rc; }
     pthread_mutex_lock(&g_mu);
+    if (g_nslots < 0) {
+        const char *e = getenv("MI355_HEVC_BRIDGE_SETS_IN_FLIGHT"), *solo = getenv("MI355_HEVC_BRIDGE_SOLO");
+        g_default_stream = getenv("MI355_HEVC_BRIDGE_DEFAULT_STREAM") != NULL;
+        g_nslots = e && *e ? atoi(e) : 4;
+        if (g_nslots < 1 || g_default_stream) g_nslots = 1;
+        if (g_nslots > MAX_SLOTS) g_nslots = MAX_SLOTS;
+        g_solo = solo && *solo && *solo != '0';
+    }
     while (g_nwait == MAX_WAITING) pthread_cond_wait(&g_cv, &g_mu);
     g_wait[g_nwait++] = me;
     while (!me->done) {
-        if (g_busy) { pthread_cond_wait(&g_cv, &g_mu); continue; }
-        /* the oldest waiting picture and all that can share its launches (same bit depth, same intra form) */
+        struct Merged *m = NULL;
+        for (int i = 0; i < g_nslots && !m; i++) if (!g_slot[i].busy) m = &g_slot[i];
+        if (!m) { pthread_cond_wait(&g_cv, &g_mu); continue; }
+        m->busy = 1;
+        if (m->used) {                                /* the slot's last set: while it runs, pictures gather for the next one */
+            pthread_mutex_unlock(&g_mu);
+            mi355_event_sync(m->ev);
+            pthread_mutex_lock(&g_mu);
+        }
+        /* the oldest waiting picture and all that can share its launches (same bit depth, same intra form); MI355_HEVC_BRIDGE_SOLO=1: it alone */
         Sub *b[MAX_BATCH];
         int K = 0, keep = 0;
         for (int i = 0; i < g_nwait; i++) {
             Sub *u = g_wait[i];
-            if (K < MAX_BATCH && (K == 0 || (u->bd == b[0]->bd && u->split_intra == b[0]->split_intra))) b[K++] = u;
+            if (K < (g_solo ? 1 : MAX_BATCH) && (K == 0 || (u->bd == b[0]->bd && u->split_intra == b[0]->split_intra))) b[K++] = u;
             else g_wait[keep++] = u;
         }
         g_nwait = keep;
-        g_busy = 1;
+        if (!K) { m->busy = 0; pthread_cond_broadcast(&g_cv); continue; }       /* another thread took this one's picture along meanwhile */
         pthread_mutex_unlock(&g_mu);
-        const int rc = launch_batch(b, K);
+        const int rc = launch_batch(m, b, K);
         pthread_mutex_lock(&g_mu);
         for (int k = 0; k < K; k++) { b[k]->rc = rc; b[k]->done = 1; }
-        g_busy = 0;
+        m->busy = 0;
         pthread_cond_broadcast(&g_cv);
     }
     pthread_mutex_unlock(&g_mu);
@@ -850,6 +884,7 @@ int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3])
         me.smc = smc; me.stu = stu; me.sin = sin; me.L = L; me.nemu = R.nemu; me.bd = R.bd; me.split_intra = R.split_intra;
         rc = commit_launches(&me);
         R.launches += me.launches;
+        R.done_event = me.done_event;
     }
     free(start);
     if (rc) return -1;
@@ -882,3 +917,7 @@ void mi355_hevc_bridge_batch_stats(unsigned long *sets, unsigned long *pictures)
     if (sets) *sets = __atomic_load_n(&g_batches, __ATOMIC_RELAXED);
     if (pictures) *pictures = __atomic_load_n(&g_batched_pictures, __ATOMIC_RELAXED);
 }
+/* the event behind the launches of the calling decoder's last reconstructed picture (NULL: they ran on the default stream, which orders by itself):
+ * work on another stream that reads the picture waits for it (mi355_stream_wait_event) */
+void *mi355_hevc_recon_done_event(void) { return g_default_stream ? NULL : R.done_event; }
+

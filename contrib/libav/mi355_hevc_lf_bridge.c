@@ -89,6 +89,10 @@ static int active(const HEVCContext *s)
     if (!dev_init) {
         dev_init = 1;
         if (mi355_init(getenv("MI355_DEVICE") ? atoi(getenv("MI355_DEVICE")) : 0) != 0) fail("no MI355X");
+        /* this decoder's own stream for its passes: with several decoders in the process a synchronisation waits for this decoder's work, not for
+         * every other decoder's launch chain (the copies are host-synchronous hipMemcpy calls: done when they return).  MI355_HEVC_BRIDGE_DEFAULT_STREAM=1:
+         * everything on the default stream, as before round 4's last session */
+        else if (!getenv("MI355_HEVC_BRIDGE_DEFAULT_STREAM")) lf.stream = mi355_stream_create();
     }
     return !lf.failed;
 }
@@ -107,6 +111,7 @@ int mi355_hevc_lf_bridge_active(const HEVCContext *s) { return active(s); }
 /* ... and hands over the picture it reconstructed on the device: 1 = cur[] holds the unfiltered picture (device planes), the
  * finished one goes to fin[]; 0 = not its picture (the host frame is uploaded, as without it); < 0 = failed */
 int mi355_hevc_recon_finish(HEVCContext *s, uint8_t *cur[3], uint8_t *fin[3]) __attribute__((weak));
+void *mi355_hevc_recon_done_event(void) __attribute__((weak));
 
 static void fail(const char *what)
 {
@@ -338,11 +343,15 @@ static int filter_picture(HEVCContext *s)
     const HEVCSPS *sps = s->ps.sps;
     const int h[3] = { sps->height, sps->height >> 1, sps->height >> 1 };
     size_t sz[3];
-    /* lf.stream stays the default stream: the plain copies below run on it too, so copies and passes are ordered by the
-     * stream alone (a binding that overlaps pictures would take pinned staging + its own stream, as the H.264 bridge does) */
+    /* lf.stream is this decoder's own stream; the plain copies below are host-synchronous (hipMemcpy): what a pass reads is in device memory
+     * before the pass is launched, and a buffer is only written again after the synchronisation that ended the picture before */
     uint8_t *plane[3], *out[3], *rcur[3], *rfin[3];
     const int on_dev = mi355_hevc_recon_finish ? mi355_hevc_recon_finish(s, rcur, rfin) : 0;
     if (on_dev < 0) return -3;                                   /* the picture exists nowhere: see __wrap_ff_hevc_hls_filter */
+    if (on_dev > 0 && mi355_hevc_recon_done_event) {             /* the reconstruction's launches are in the bridge's stream: this stream follows them */
+        void *ev = mi355_hevc_recon_done_event();
+        if (ev && mi355_stream_wait_event(lf.stream, ev) != 0) return -2;
+    }
     for (int i = 0; i < 3; i++) {
         sz[i] = (size_t)s->frame->linesize[i] * h[i];
         if (s->frame->linesize[i] <= 0) return -1;

@@ -289,6 +289,14 @@ int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *d_pics, con
 int mi355_hevc_intra_recon_blocks_dev(const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
                                       const mi355_hevc_tu_job *d_tus, int n, int bit_depth, void *stream);
 
+/* One dependency level of a batch of pictures in ONE launch: n_mc prediction jobs (as mi355_hevc_mcpred_batch_dev takes them), n_tus transform
+ * units (mi355_hevc_residual_batch_dev), n_blocks intra blocks with their units (mi355_hevc_intra_recon_blocks_dev) — the three kinds of a level
+ * write disjoint samples and run side by side.  Any of the three may be empty (pointer NULL, count 0); all empty: -1.  What the reference does
+ * block by block in hls_coding_unit / hls_transform_unit (hevcdec.c:1002-1030, :1238-1260, :1695-1850) a caller replays level by level. */
+int mi355_hevc_recon_level_dev(const mi355_hevc_mcpred_job *d_mc, int n_mc, const mi355_hevc_tu_job *d_tus, int n_tus,
+                               const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
+                               const mi355_hevc_tu_job *d_block_tus, int n_blocks, int bit_depth, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -906,6 +906,49 @@ __global__ void __launch_bounds__(64) k_hevc_intra_recon_blocks(const mi355_hevc
     hevc_residual_run(t, j, lane < 32, lane >> 5, lane & 31, bd);
 }
 
+/* One dependency LEVEL of a batch of pictures in one launch: its prediction blocks, its transform units and its intra blocks (each with its
+ * residual) touch disjoint samples, so the three job kinds run side by side — workgroup b takes prediction job b, then pairs of transform
+ * units, then intra blocks.  A caller that walks levels (contrib/libav/mi355_hevc_bridge.c: hundreds per picture, most of them a handful of
+ * jobs) issues one launch per level instead of up to three. */
+union LevelLds {
+    HevcMcScratch mc;
+    IdctScratch tu;
+    struct { IntraWrapLds s; IdctScratch t; } in;
+};
+__global__ void __launch_bounds__(64) k_hevc_recon_level(const mi355_hevc_mcpred_job *mc, int nm, const mi355_hevc_tu_job *tu, int nt,
+                                                         const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks,
+                                                         const mi355_hevc_tu_job *btus, int ni, int bd)
+{
+    __shared__ LevelLds u;
+    int b = (int)blockIdx.x;
+    const int lane = lane_id();
+    if (b < nm) {
+        int16_t *const keep = u.mc.tmp + HEVC_MC_BI_ROWS * HEVC_MC_TPITCH;
+        const mi355_hevc_mcpred_job j = mc[b];
+        switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {
+        case 0: hevc_mcpred_taps<8, 0>(j, bd, u.mc, keep); break;   case 1: hevc_mcpred_taps<8, 1>(j, bd, u.mc, keep); break;
+        case 2: hevc_mcpred_taps<8, 2>(j, bd, u.mc, keep); break;   case 3: hevc_mcpred_taps<8, 3>(j, bd, u.mc, keep); break;
+        case 4: hevc_mcpred_taps<4, 0>(j, bd, u.mc, keep); break;   case 5: hevc_mcpred_taps<4, 1>(j, bd, u.mc, keep); break;
+        case 6: hevc_mcpred_taps<4, 2>(j, bd, u.mc, keep); break;   default: hevc_mcpred_taps<4, 3>(j, bd, u.mc, keep); break;
+        }
+        return;
+    }
+    b -= nm;
+    if (b < (nt + 1) / 2) {
+        const int half = lane >> 5, idx = 2 * b + half;
+        const bool on = idx < nt;
+        hevc_residual_run(u.tu, tu[on ? idx : 0], on, half, lane & 31, bd);
+        return;
+    }
+    b -= (nt + 1) / 2;
+    if (b >= ni) return;
+    hevc_intra_block_run(u.in.s, pics, mi355_global_v(blocks)[b], bd);
+    const mi355_hevc_tu_job j = mi355_global_v(btus)[b];
+    if (!j.coeffs) return;
+    __syncthreads();            /* as in k_hevc_intra_recon_blocks: the prediction's stores are what the residual's loads see */
+    hevc_residual_run(u.in.t, j, lane < 32, lane >> 5, lane & 31, bd);
+}
+
 bool check(int bit_depth, const void *jobs, int n)
 {
     /* bind(): the calling thread's device (mi355_set_device, else mi355_init's) — not whatever device the thread last used */
@@ -930,6 +973,18 @@ extern "C" int mi355_hevc_intra_recon_blocks_dev(const mi355_hevc_intra_picture 
     hipLaunchKernelGGL(k_hevc_intra_recon_blocks, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_pics, d_blocks, d_tus, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+extern "C" int mi355_hevc_recon_level_dev(const mi355_hevc_mcpred_job *d_mc, int n_mc, const mi355_hevc_tu_job *d_tus, int n_tus,
+                                          const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
+                                          const mi355_hevc_tu_job *d_block_tus, int n_blocks, int bit_depth, void *stream)
+{
+    if (n_mc < 0 || n_tus < 0 || n_blocks < 0 || (n_mc && !d_mc) || (n_tus && !d_tus) || (n_blocks && (!d_pics || !d_blocks || !d_block_tus))) return -1;
+    const int wgs = n_mc + (n_tus + 1) / 2 + n_blocks;
+    if (!check(bit_depth, &wgs, wgs)) return -1;
+    hipLaunchKernelGGL(k_hevc_recon_level, dim3((unsigned)wgs), dim3(64), 0, (hipStream_t)stream, d_mc, n_mc, d_tus, n_tus, d_pics, d_blocks, d_block_tus,
+                       n_blocks, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int mi355_hevc_mc_batch_dev(const mi355_hevc_mc_job *d_jobs, int n, int bit_depth, void *stream)
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
