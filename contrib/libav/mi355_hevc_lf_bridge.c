@@ -88,6 +88,9 @@ static int active(const HEVCContext *s)
     static __thread int dev_init;
     if (!dev_init) {
         dev_init = 1;
+        /* a decoder waits for its picture's chain every picture, and a host runs many decoders: waiting threads sleep (16 decoders on 16 cores: 183 -> 226
+         * pictures/s, 32: 214 -> 348 — the spinning had cost more processor time than the parsing; MI355_BLOCKING_SYNC=0 spins) */
+        mi355_prefer_blocking_sync(1);
         if (mi355_init(getenv("MI355_DEVICE") ? atoi(getenv("MI355_DEVICE")) : 0) != 0) fail("no MI355X");
         /* this decoder's own stream for its passes: with several decoders in the process a synchronisation waits for this decoder's work, not for
          * every other decoder's launch chain (the copies are host-synchronous hipMemcpy calls: done when they return).  MI355_HEVC_BRIDGE_DEFAULT_STREAM=1:

@@ -344,6 +344,9 @@ int   mi355_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int   mi355_memcpy_d2d(void *dst, const void *src, size_t bytes);
 int   mi355_sync(void *stream);
+/* before the first mi355_init(): 1 = a thread that waits for the device sleeps instead of spinning (a host with more waiting threads than cores);
+ * the environment variable MI355_BLOCKING_SYNC=0|1 overrides */
+void  mi355_prefer_blocking_sync(int on);
 /* pinned host memory and asynchronous copies on a stream: what a bridge needs to overlap the host's entropy decoding with
  * the device's reconstruction (contrib/libav/mi355_h264_bridge.c).  Host buffers of the async copies must come from
  * mi355_host_alloc(), or the copy is staged and effectively synchronous. */

@@ -539,7 +539,7 @@ extern "C" int mi355_stream_wait_event(void *st, void *e) { return hipStreamWait
 extern "C" void *mi355_event_create(void)
 {
     hipEvent_t e = nullptr;
-    if (!mi355::bind() || hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (!mi355::bind() || hipEventCreateWithFlags(&e, mi355::blocking_sync() ? hipEventBlockingSync : hipEventDefault) != hipSuccess) return nullptr;
     return e;
 }
 extern "C" void mi355_event_destroy(void *e) { (void)hipEventDestroy((hipEvent_t)e); }

@@ -146,6 +146,7 @@ Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int row
 void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows);
 
 bool ready();
+bool blocking_sync();      /* waits sleep instead of spinning (MI355_BLOCKING_SYNC / mi355_prefer_blocking_sync) */
 int current_device();
 /* bind the calling thread to its device — mi355_set_device() of this thread, else the one chosen in mi355_init() (the reference calls the tables and the batch entry points
  * from frame / slice threads; a thread that never set a device would use device 0); false without a successful init */

@@ -12,6 +12,15 @@ static std::atomic<unsigned> g_checked{0};   /* bit d: device d was found to be 
 int current_device() { return t_device >= 0 ? t_device : g_device.load(std::memory_order_acquire); }
 bool ready() { return current_device() >= 0; }
 
+/* waits that sleep instead of spinning: MI355_BLOCKING_SYNC=1 / 0 decides; without it, what the host asked for (mi355_prefer_blocking_sync) */
+static std::atomic<int> g_prefer_blocking{0};
+bool blocking_sync()
+{
+    const char *e = std::getenv("MI355_BLOCKING_SYNC");
+    if (e && *e) return *e != '0';
+    return g_prefer_blocking.load(std::memory_order_acquire) != 0;
+}
+
 /* 0, or mi355_init()'s error codes */
 static int check_device(int device)
 {
@@ -121,10 +130,18 @@ void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, 
 
 }  // namespace mi355
 
+/* A host with many threads that wait for the device (a decoder per thread) calls this with 1 BEFORE its first mi355_init(): waits then sleep
+ * (hipDeviceScheduleBlockingSync, hipEventBlockingSync) instead of spinning on a core the parsing threads need.  The environment variable
+ * MI355_BLOCKING_SYNC overrides either way. */
+extern "C" void mi355_prefer_blocking_sync(int on) { mi355::g_prefer_blocking.store(on ? 1 : 0, std::memory_order_release); }
+
 extern "C" int mi355_init(int device)
 {
     const int rc = mi355::check_device(device);
     if (rc) return rc;
+    /* MI355_BLOCKING_SYNC=1: a host thread that waits for the device sleeps instead of spinning (hipDeviceScheduleBlockingSync) — a host with
+     * more waiting decoder threads than it may use cores gives the cores back to the threads that parse.  Must precede the context. */
+    if (mi355::blocking_sync()) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     if (hipSetDevice(device) != hipSuccess) return -4;
     mi355::g_device.store(device, std::memory_order_release);
     return 0;

@@ -115,6 +115,10 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v,
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { static char tag; *s = reinterpret_cast<hipStream_t>(&tag); return hipSuccess; }   /* non-null: callers test the handle */
 #define hipStreamNonBlocking 1u
+#define hipEventDefault 0u
+#define hipEventBlockingSync 1u
+#define hipDeviceScheduleBlockingSync 4u
+static inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
