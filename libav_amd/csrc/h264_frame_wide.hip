@@ -847,11 +847,12 @@ __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
  * clip one v_med3_i32; the bS 4 forms run only where a lane of the wave has that strength (MAY_INTRA: macroblock edges).  Return: 0 — no line
  * of the WAVE passes the conditions (nothing changed), 1, or 2 when the bS 4 filter ran (p2 / q2 may have changed).
  * h264dsp_template.c:103-163 (normal), :165-210 (bS 4), :212-265 (chroma). */
-template <int MAXV, bool MAY_INTRA>
+/* VOTE false: for callers inside lane-dependent control flow (the MBAFF filter) — no wave vote, every lane computes; returns 1, or 2 for a bS 4 lane */
+template <int MAXV, bool MAY_INTRA, bool VOTE = true>
 __device__ __forceinline__ int wide_luma_line(int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3, int bs, int alpha, int beta, int tc0)
 {
     const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
-    if (!__any(f)) return 0;
+    if (VOTE && !__any(f)) return 0;
     const bool ap = absdiff8(p2, p0) < beta, aq = absdiff8(q2, q0) < beta;
     const bool fn = f && bs < 4;
     const int avg = (p0 + q0 + 1) >> 1;
@@ -864,7 +865,7 @@ __device__ __forceinline__ int wide_luma_line(int p3, int &p2, int &p1, int &p0,
     q0 = med3i(Q0 - delta, 0, MAXV);
     if (MAY_INTRA) {
         const bool fi = f && bs == 4;
-        if (__any(fi)) {
+        if (VOTE ? (bool)__any(fi) : fi) {
             const bool strong = absdiff8(P0, Q0) < ((alpha >> 2) + 2), sp = strong && ap, sq = strong && aq;
             const int wp0 = (2 * P1 + P0 + Q1 + 2) >> 2, wq0 = (2 * Q1 + Q0 + P1 + 2) >> 2;
             const int s4 = P0 + Q0 + 4;
@@ -882,11 +883,11 @@ __device__ __forceinline__ int wide_luma_line(int p3, int &p2, int &p1, int &p0,
     return 1;
 }
 /* tc1: the caller's tc0 + 1 (h264_loopfilter.c:126-129) */
-template <int MAXV>
+template <int MAXV, bool VOTE = true>
 __device__ __forceinline__ bool wide_chroma_line(int p1, int &p0, int &q0, int q1, int bs, int alpha, int beta, int tc1)
 {
     const bool f = bs != 0 && absdiff8(p0, q0) < alpha && absdiff8(p1, p0) < beta && absdiff8(q1, q0) < beta;
-    if (!__any(f)) return false;
+    if (VOTE && !__any(f)) return false;
     const int tc = f && bs < 4 ? tc1 : 0;
     const int delta = med3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
     const bool fi = f && bs == 4;
@@ -1320,27 +1321,19 @@ k_wide_deblock_mbaff(const mi355_h264_frame *frames, int nframes, int d, int max
         }
     }
     MI355_WAVE_SYNC();
-    const int qp_bd = 6 * (BD - 8);
-    /* one luma line across an edge (q: the sample on the q side, st: step across the edge) */
+    /* the line filters of the frame / field kernel in their voteless form: these run inside lane-dependent control flow */
     auto luma_line = [&](uint16_t *q, int st, int bs, int qp, int a_off, int b_off) {
-        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
-        if (bs < 4) {
-            int p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st];
-            lf_luma_line<F::MAXV>(p2, p1, p0, q0, q1, q2, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)));
-            q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
-        } else {
-            int p3 = q[-4 * st], p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = q[3 * st];
-            lf_luma_intra_line(p3, p2, p1, p0, q0, q1, q2, q3, alpha, beta);
-            q[-3 * st] = (uint16_t)p2; q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1; q[2 * st] = (uint16_t)q2;
-        }
+        const WideThr t = wide_thr<BD>(t_alpha, t_beta, t_tc0, qp, a_off, b_off);
+        /* (the fourth sample of a side only where bS 4 reads it: at the twice-filtered top edge it would lie outside the tile) */
+        int p3 = bs == 4 ? q[-4 * st] : 0, p2 = q[-3 * st], p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st], q2 = q[2 * st], q3 = bs == 4 ? q[3 * st] : 0;
+        const int r = wide_luma_line<F::MAXV, true, false>(p3, p2, p1, p0, q0, q1, q2, q3, bs, t.alpha, t.beta, wide_tc0<BD>(t, bs));
+        q[-2 * st] = (uint16_t)p1; q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0; q[st] = (uint16_t)q1;
+        if (r == 2) { q[-3 * st] = (uint16_t)p2; q[2 * st] = (uint16_t)q2; }
     };
     auto chroma_line = [&](uint16_t *q, int st, int bs, int qp, int a_off, int b_off) {
-        const int ia = clip3(qp - qp_bd + a_off, 0, 51), ib = clip3(qp - qp_bd + b_off, 0, 51);
-        const int alpha = t_alpha[ia] << (BD - 8), beta = t_beta[ib] << (BD - 8);
+        const WideThr t = wide_thr<BD>(t_alpha, t_beta, t_tc0, qp, a_off, b_off);
         int p1 = q[-2 * st], p0 = q[-st], q0 = q[0], q1 = q[st];
-        if (bs < 4) lf_chroma_line<F::MAXV>(p1, p0, q0, q1, alpha, beta, t_tc0[ia][bs - 1] * (1 << (BD - 8)) + 1);
-        else lf_chroma_intra_line(p1, p0, q0, q1, alpha, beta);
+        wide_chroma_line<F::MAXV, false>(p1, p0, q0, q1, bs, t.alpha, t.beta, wide_tc0<BD>(t, bs) + 1);
         q[-st] = (uint16_t)p0; q[0] = (uint16_t)q0;
     };
     for (int pos = 0; pos < 2; pos++) {

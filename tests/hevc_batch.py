@@ -632,5 +632,38 @@ def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
     return n
 
 
+class _LevelLib:
+    """the library with its prediction / transform-unit batches routed through mi355_hevc_recon_level_dev (one launch for a dependency level's
+    job kinds: here one kind at a time, the other two empty)"""
+
+    def __init__(self, lib):
+        self._lib = lib
+        lib.mi355_hevc_recon_level_dev.restype = C.c_int
+        lib.mi355_hevc_recon_level_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+    def mi355_hevc_mcpred_batch_dev(self, jobs, n, bd, stream):
+        return self._lib.mi355_hevc_recon_level_dev(jobs, n, None, 0, None, None, None, 0, bd, stream)
+
+    def mi355_hevc_residual_batch_dev(self, jobs, n, bd, stream):
+        return self._lib.mi355_hevc_recon_level_dev(None, 0, jobs, n, None, None, None, 0, bd, stream)
+
+
+class _LevelProv:
+    def __init__(self, prov):
+        self.lib = _LevelLib(prov.lib)
+
+
+def check_level_mcpred(prov, oracle, bd, seed):
+    return check_mcpred(_LevelProv(prov), oracle, bd, seed)
+
+
+def check_level_residual(prov, oracle, bd, seed):
+    return check_residual(_LevelProv(prov), oracle, bd, seed, cells=(5, 7))      # an odd number of units: the last workgroup holds one
+
+
 CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
-          "intra": check_intra, "mcpred": check_mcpred, "sao_ctbs": check_sao_ctbs, "edge_emu": check_edge_emu}
+          "intra": check_intra, "mcpred": check_mcpred, "sao_ctbs": check_sao_ctbs, "edge_emu": check_edge_emu,
+          "level_mcpred": check_level_mcpred, "level_residual": check_level_residual}
