@@ -592,7 +592,6 @@ template <int BD, int CF>
 __global__ void __launch_bounds__(64)
 k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
 {
-    typedef Fmt<BD, CF> F;
     __shared__ WideInterLds s;
     const int per = max_w * max_h, f = (int)blockIdx.x / per, rem = (int)blockIdx.x - f * per, mb_y = rem / max_w, mb_x = rem - mb_y * max_w;
     const mi355_h264_frame &fr = frames[f];
@@ -933,9 +932,10 @@ __device__ __forceinline__ int wide_check_mv_bf(const LDS &s, int b, int bn, boo
     const int r0b = s.ref[0][b], r0n = s.ref[0][bn], r1b = s.ref[1][b], r1n = s.ref[1][bn];
     const uint32_t m0b = s.mv[0][b], m0n = s.mv[0][bn], m1b = s.mv[1][b], m1n = s.mv[1][bn];
     const bool v1 = (r0b != r0n) | ((r0b != -1) & wide_mv_far(m0b, m0n, ylim));
-    const bool v2 = v1 | (r1b != r1n) | wide_mv_far(m1b, m1n, ylim);
-    const bool cross = (r0b != r1n) | (r0n != r1b) | wide_mv_far(m0b, m1n, ylim) | wide_mv_far(m1b, m0n, ylim);
-    return two_lists ? (int)(v2 & cross) : (int)v1;
+    /* (int operands: every term is evaluated, no short-circuit branches) */
+    const int v2 = (int)v1 | (int)(r1b != r1n) | (int)wide_mv_far(m1b, m1n, ylim);
+    const int cross = (int)(r0b != r1n) | (int)(r0n != r1b) | (int)wide_mv_far(m0b, m1n, ylim) | (int)wide_mv_far(m1b, m0n, ylim);
+    return two_lists ? (v2 & cross) : (int)v1;
 }
 __device__ __forceinline__ int wide_ref_identity(const mi355_h264_mb &m, int list, int x4, int y4)
 {
