@@ -529,7 +529,7 @@ def hevc_bridge_points(lib):
     """The reference's own HEVC decoder with the Tier-2 bridge (contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c: every
     prediction block, transform unit and intra block of a picture recorded and run on the device level by level, in-loop filters on the
     same device picture, references in HBM) on two generated streams, and the SAME binary with everything forwarded to the reference's
-    C functions beside it (oracle/_ref/hevc_bridge_gpu, built where /root/reference exists).  One decoder, one picture per launch set:
+    C functions beside it (oracle/_ref/hevc_bridge_gpu, built where /root/reference exists).  One decoder, one picture per launch set (the first 1080p stream also with 4 and 16 decoders in the process):
     generated 1920x1080 P / B streams (CTB 64) with 2 % and with 30 % intra coding units outside the first picture (a picture's launches
     follow its dependency levels, and those follow its intra blocks: 4x4 intra blocks everywhere are a wavefront of ~850 levels at 1080p),
     832x480, and two of the small ones (136x72: the launch-bound end of the path)."""
