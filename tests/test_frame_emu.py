@@ -146,6 +146,16 @@ def test_second_kernel_set_on_8bit_420_pictures_emulated(emu, oracle, name, pad)
     frame_cases.run_case(emu, oracle, name, pad=pad, wide=True)
 
 
+@pytest.mark.parametrize("unit", ("2", "3", "4"))
+@pytest.mark.parametrize("name", ("mixed_intra", "wide_b", "one_col"))
+def test_second_kernel_set_loop_filter_units_emulated(emu, oracle, monkeypatch, name, unit):
+    """the second kernel set's loop filter with 2, 3 and 4 macroblocks per group and launch (MI355_WIDE_UNIT; the launcher picks 1 for batches
+    this small): a group filters a run of its row — the left neighbour's columns stay in its tile, the next macroblock's loads are issued before
+    the filter — and the anti-diagonals count runs; pictures whose width is not a multiple of the run, one macroblock wide, with slices"""
+    monkeypatch.setenv("MI355_WIDE_UNIT", unit)
+    frame_cases.run_case(emu, oracle, name, pad=0, wide=True)
+
+
 @pytest.mark.parametrize("name", ("p16_noise", "p16_smooth", "b_weight_explicit"))
 def test_second_kernel_set_10bit_sanity_emulated(emu, oracle, name):
     """h264_frames.DeviceFrames(bit_depth=10): the 8-bit case scaled to 10 bits (samples and coefficients shifted by two, QPs raised by 12)
