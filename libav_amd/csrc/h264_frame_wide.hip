@@ -374,6 +374,40 @@ __device__ inline void wide_load_coefs(int32_t *dst, const mi355_h264_frame &fr,
     MI355_WAVE_SYNC();
 }
 
+/* The same in two halves, for a caller whose LDS copy shares its place with something it uses first (k_wide_inter: the motion compensation's windows):
+ * the loads leave at once, into registers (up to two 16-byte pieces per lane), and become the LDS copy later. */
+template <int BD, int CF> struct WideCoefRegs {
+    typedef typename Fmt<BD, CF>::COEF COEF;
+    static constexpr int PER = 16 / (int)sizeof(COEF), PIECES = Fmt<BD, CF>::NCOEF / PER;
+    COEF v[2][PER];
+};
+template <int BD, int CF>
+__device__ __forceinline__ void wide_fetch_coefs(WideCoefRegs<BD, CF> &r, const mi355_h264_frame &fr, int mb_xy, int parts)
+{
+    typedef WideCoefRegs<BD, CF> R;
+    const typename R::COEF *cp = reinterpret_cast<const typename R::COEF *>(fr.coef) + (size_t)mb_xy * Fmt<BD, CF>::NCOEF;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = lane_id() + 64 * k, first = R::PER * i;
+        if (i < R::PIECES && ((parts >> (first < 256 ? first >> 6 : 4)) & 1)) __builtin_memcpy(r.v[k], cp + first, sizeof(r.v[k]));
+        else for (int j = 0; j < R::PER; j++) r.v[k][j] = 0;
+    }
+}
+template <int BD, int CF>
+__device__ __forceinline__ void wide_commit_coefs(int32_t *dst, const WideCoefRegs<BD, CF> &r)
+{
+    typedef WideCoefRegs<BD, CF> R;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = lane_id() + 64 * k;
+        int32_t w[R::PER];
+#pragma unroll
+        for (int j = 0; j < R::PER; j++) w[j] = r.v[k][j];
+        if (i < R::PIECES) __builtin_memcpy(__builtin_assume_aligned(dst + R::PER * i, 16), w, sizeof(w));
+    }
+    MI355_WAVE_SYNC();
+}
+
 template <int BD, int CF>
 __device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, const WideGeom &g, const uint16_t *y, int ypitch, const uint16_t *cb, const uint16_t *cr, int cpitch)
 {
@@ -396,14 +430,23 @@ __device__ inline void wide_store_mb(const mi355_h264_frame &fr, int mb_x, const
 /* ------------------------------------------------------------------------- */
 constexpr int WP = 24;          /* pitch of the luma window: 16 + 5 columns, fetched as up to three pieces of eight */
 constexpr int CWP = 16, CWIN = 17 * CWP;   /* chroma windows: 9 x 17 per plane (two pieces of eight per row), the second plane at CWIN */
+/* 4.3 KB: the kernel holds 32 registers, so its waves per SIMD are what its LDS leaves — eight (the limit) instead of five with the coefficients and the
+ * windows side by side (7.1 KB).  The coefficients wait in registers while the prediction is made (wide_fetch_coefs / wide_commit_coefs). */
 struct WideInterLds {
     mi355_h264_mb hdr;
     uint32_t mv[2][16];
-    alignas(16) int32_t coef[512];
-    uint16_t py[256], pc[2][128], qy[256], qc[2][128];
-    uint16_t win[2 * CWIN + 8];     /* >= 21 * WP */
-    int16_t tmp[21 * 16];           /* the horizontal pass of the 2-D quarter positions: rows -2..h+2 of the block */
-    int32_t t8[4][64];
+    uint16_t py[256], pc[2][128];
+    union {
+        struct {                            /* motion compensation */
+            uint16_t qy[256], qc[2][128];   /* the second prediction of a weighted two-reference partition */
+            alignas(16) uint16_t win[2 * CWIN + 8];     /* >= 21 * WP */
+            int16_t tmp[21 * 16];           /* the horizontal pass of the 2-D quarter positions: rows -2..h+2 of the block */
+        };
+        struct {                            /* the residual, once the prediction stands in py / pc */
+            alignas(16) int32_t coef[512];
+            int32_t t8[4][64];
+        };
+    };
 };
 
 /* one luma sample at quarter position (mx, my): h264qpel_template.c:77-300 as the standard writes it; the first pass of the 2-D
@@ -609,7 +652,8 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
     if (t & MI355_MB_INTRA) return;
     const int cbp = uniform((int)s.hdr.cbp);
     const bool luma_coded = (cbp & 15) != 0, chroma_coded = (cbp & 0x30) != 0;
-    if (luma_coded || chroma_coded) wide_load_coefs<BD, CF>(s.coef, fr, mb_xy, (cbp & 15) | (chroma_coded ? 16 : 0));
+    WideCoefRegs<BD, CF> cregs;
+    if (luma_coded || chroma_coded) wide_fetch_coefs<BD, CF>(cregs, fr, mb_xy, (cbp & 15) | (chroma_coded ? 16 : 0));
     const mi355_h264_slice &sl = fr.slices[uniform((int)s.hdr.slice_id)];
     const WideGeom g = wide_geom<BD, CF>(fr, t, mb_y);
 
@@ -639,6 +683,7 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         wide_mc_part<BD, CF>(s, fr, sl, mb_x, g, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
+    if (luma_coded || chroma_coded) wide_commit_coefs<BD, CF>(s.coef, cregs);       /* the windows' place is free now */
     /* hl_decode_mb_idct_luma (h264_mb.c:726-795): idct_add16 / idct8_add4 choose between full, DC-only and nothing per block; so does
      * wide_block4 / wide_add_blocks8, from the coefficients (a block whose count is 1 with a DC level holds nothing else) */
     if (luma_coded) {
