@@ -1,0 +1,507 @@
+/*
+ * h264_recon_fast.h — the inter reconstruction pass on macroblock-tiled surfaces, third form (round 5): a wave walks a RUN of
+ * consecutive macroblocks, and the macroblock nearly every P picture is made of — one 16x16 partition predicted from list 0
+ * without weights, 4x4 transforms — takes a path of its own:
+ *
+ *   - what depends on nothing but the lane number (row / piece of the window fetch, operand addresses, filter matrices, the
+ *     residual lanes' table) is computed ONCE per wave and kept in registers over the run;
+ *   - the record's scalars (type, vector, reference slot, nnz, cbp) arrive through the scalar cache (s_load), the record itself
+ *     (coefficients) by LDS-DMA — and the NEXT macroblock's record is requested as soon as this one's coefficients have been
+ *     transformed into registers, so its memory round trip runs under this macroblock's prediction;
+ *   - the reference windows land in LDS RAW, as the 16-byte tile rows they are in HBM (LDS-DMA, no register in flight, no
+ *     re-alignment): gfx950 reads LDS at any byte address, so every tap is a plain ds_read at (row, o + column);
+ *     rows beyond the picture are clamped in the fetch, columns beyond it are replicated in LDS afterwards (emulated_edge_mc,
+ *     videodsp_template.c:24-96) — one path for every vector, however far outside;
+ *   - the 6-tap filters (h264qpel_template.c:77-378) are v_mfma_i32_16x16x32_i8 products with a constant Toeplitz matrix: the
+ *     horizontal half-sample plane straight from the window rows; vertical filters after a transposition that is itself a
+ *     product (with an identity / the horizontal filter) whose result a lane holds as four ROWS of one column.  The 2-D
+ *     position's intermediate (-2550 .. 10710) travels as a low and a high byte plane; everything is exact integer arithmetic;
+ *   - chroma (h264chroma_template.c:27-173) is one v_dot4_u32_u8 per sample: the four neighbours gathered by v_perm_b32
+ *     against the packed weights (A, B, C, D);
+ *   - averages of two components are v_lerp_u8 on packed bytes.
+ * Every other macroblock type in the run (two lists, weights, partitions, 8x8 transform) goes through h264_recon_dev.h's code
+ * unchanged.  Reference behaviour restated: hl_decode_mb (h264_mb_template.c:41-257), hl_motion (h264_mc_template.c:64-163),
+ * mc_dir_part (h264_mb.c:204-318), hl_decode_mb_idct_luma (h264_mb.c:726-795), h264idct_template.c:33-67,144-156.
+ */
+#ifndef MI355_H264_RECON_FAST_H
+#define MI355_H264_RECON_FAST_H
+
+#include "h264_recon_dev.h"
+
+namespace {
+
+/* ---- LDS of the fast path: behind py / pc (the q tiles and the motion scratch of the other paths are not live here) ---- */
+constexpr int FQ_WY = MB_PC_OFF + 128;          /* 1344: raw luma window, piece L (16 bytes) at 16 L: row L / 3 = 48 bytes = picture columns 16 t0 .. 16 t0 + 47 */
+constexpr int FQ_WC = FQ_WY + 1024;             /* raw chroma window [plane][row 0..8][12 bytes], dword q at 4 q: columns (cx & ~3) .. + 11 */
+constexpr int FQ_PL = FQ_WC + 224;              /* three transposed planes [column 0..15][24 rows]: low bytes, high bytes, raw samples */
+constexpr int FQ_PLANE = 16 * 24 + 8;           /* the last column's operand read runs eight bytes past its rows */
+constexpr int FQ_DUMP = FQ_PL + 3 * FQ_PLANE;   /* where the lanes that hold no row of a product's second half write */
+static_assert(FQ_WY == 1344 && (FQ_WY % 16) == 0 && (FQ_PL % 8) == 0 && FQ_DUMP + 2 * FQ_PLANE + 8 <= (int)sizeof(MbLds), "fast-path regions inside MbLds");
+static_assert(FQ_WY + 48 * 31 + 24 + 18 + 8 <= (int)sizeof(MbLds), "the second half of a transposing product reads window rows 16..31");
+
+/* ---- primitives: one instruction each on the device, their plain meaning in the emulator ---- */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t fq_lds32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+static inline uint64_t fq_lds64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+static inline uint32_t fq_lerp(uint32_t a, uint32_t b)                 /* v_lerp_u8 with 1 in every byte of the third operand: (a + b + 1) >> 1 per byte */
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= ((((a >> (8 * i)) & 0xFF) + ((b >> (8 * i)) & 0xFF) + 1) >> 1) << (8 * i);
+    return r;
+}
+static inline uint32_t fq_dot4(uint32_t a, uint32_t b, uint32_t c)     /* v_dot4_u32_u8 */
+{
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return c;
+}
+/* v_mfma_i32_16x16x32_i8: D[i][j] = c + sum_k A[i][k] B[k][j] with signed bytes; lane l supplies bytes 8 (l / 16) .. + 7 of row l % 16 of A (x) and of
+ * column l % 16 of B (y), and receives D[4 (l / 16) + t][l % 16], t = 0..3 */
+static inline void fq_mfma(uint64_t x, uint64_t y, int c, int d[4])
+{
+    const int lane = (int)(threadIdx.x & 63), g = lane >> 4, j = lane & 15;
+    d[0] = d[1] = d[2] = d[3] = c;
+    for (int kg = 0; kg < 4; kg++) {
+        const uint64_t yv = (uint64_t)(uint32_t)__shfl((int)(uint32_t)y, j + 16 * kg) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(y >> 32), j + 16 * kg) << 32);
+        for (int t = 0; t < 4; t++) {
+            const uint64_t xv = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 4 * g + t + 16 * kg) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 4 * g + t + 16 * kg) << 32);
+            for (int b = 0; b < 8; b++) d[t] += (int)(int8_t)(xv >> (8 * b)) * (int)(int8_t)(yv >> (8 * b));
+        }
+    }
+}
+static inline void fq_dma4(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 4 * (threadIdx.x & 63), src, 4); }
+static inline void fq_wait_vm0() {}
+static inline void fq_wait_vm1() {}
+static inline int fq_med3_0(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
+typedef const uint32_t *fq_kptr;
+static inline fq_kptr fq_konst(const void *p) { return reinterpret_cast<const uint32_t *>(p); }
+#else
+typedef uint32_t fq_u32u __attribute__((aligned(1)));
+typedef uint64_t fq_u64u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t fq_lds32(const uint8_t *p) { return *reinterpret_cast<const fq_u32u *>(p); }
+__device__ __forceinline__ uint64_t fq_lds64(const uint8_t *p) { return *reinterpret_cast<const fq_u64u *>(p); }
+__device__ __forceinline__ uint32_t fq_lerp(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+__device__ __forceinline__ uint32_t fq_dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+typedef int fq_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fq_mfma(uint64_t x, uint64_t y, int c, int d[4])
+{
+    fq_v4i acc = { c, c, c, c };
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)x, (long)y, acc, 0, 0, 0);
+    d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
+}
+/* four bytes per lane from memory straight into LDS at lds_base + 4 * lane */
+__device__ __forceinline__ void fq_dma4(const uint8_t *src, uint8_t *lds_base)
+{
+    typedef __attribute__((address_space(1))) const void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)lds_base, 4, 0, 0);
+}
+/* vector-memory operations complete in issue order: "at most N outstanding" means all but the N youngest have landed */
+__device__ __forceinline__ void fq_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void fq_wait_vm1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+__device__ __forceinline__ int fq_med3_0(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi)); return r; }      /* clamp to 0 .. hi (a wave constant) */
+/* a wave-uniform address read through the scalar cache: the record's words arrive in scalar registers, no LDS read, no v_readfirstlane */
+typedef const __attribute__((address_space(4))) uint32_t *fq_kptr;
+__device__ __forceinline__ fq_kptr fq_konst(const void *p) { return (fq_kptr)(unsigned long long)p; }
+#endif
+
+/* ---- what a lane is, for every macroblock of the run ---- */
+struct FqLane {
+    /* luma window fetch: piece L = min(lane, 62) is row L / 3, tile L % 3 */
+    int fr, fp;
+    /* chroma window fetch: dword q = min(lane, 53) is plane q / 27, row (q % 27) / 3, dword q % 3 */
+    int cplane64, crow, cd4;
+    /* luma: this lane's row = lane & 15 and group g = lane >> 4 (four samples 4 g .. 4 g + 3 of the row in a direct product, four rows 4 g .. of column lane & 15 in a transposing one) */
+    uint32_t a1;            /* FQ_WY + 48 row + 8 g: this lane's eight bytes of a window-row operand (+ o + 2 + ...) */
+    uint32_t a2;            /* FQ_WY + 48 row + 4 g: this lane's four integer samples (+ 48 (2 + dy) + o + 4 + dx) */
+    uint32_t a3;            /* MB_PY_OFF + 16 row + 4 g: where its four predicted samples go */
+    uint32_t a4, a5;        /* 24 (lane & 15) + 4 g: its four rows in a transposed plane, first / second half of the window rows (g >= 2: FQ_DUMP) */
+    uint32_t a6;            /* 24 (lane & 15) + 8 g: its eight rows of a transposed-plane operand */
+    uint64_t t6;            /* the 6-tap filter as a product operand: byte b = tap (8 g + b) - (lane & 15) of (1, -5, 20, 20, -5, 1) */
+    uint64_t i2;            /* the identity shifted by the two columns in front of the block: byte b = 1 where 8 g + b == (lane & 15) + 2 */
+    /* chroma: plane lane >> 5, row (lane >> 2) & 7, samples 2 c, 2 c + 1 (c = lane & 3) */
+    uint32_t c1;            /* FQ_WC + 108 plane + 12 row + 2 c */
+    uint32_t c2;            /* MB_PC_OFF + 64 plane + 8 row + 2 c */
+};
+__device__ __forceinline__ FqLane fq_lane()
+{
+    FqLane k;
+    const int lane = lane_id();
+    const int L = lane < 63 ? lane : 62;
+    k.fr = (int)(__umul24((unsigned)L, 43u) >> 7);
+    k.fp = L - 3 * k.fr;
+    const int q = lane < 54 ? lane : 53, plane = q >= 27, rem = q - 27 * plane;
+    k.cplane64 = plane * 64;
+    k.crow = (int)(__umul24((unsigned)rem, 43u) >> 7);
+    k.cd4 = 4 * (rem - 3 * k.crow);
+    const int row = lane & 15, g = lane >> 4;
+    k.a1 = (uint32_t)(FQ_WY + 48 * row + 8 * g);
+    k.a2 = (uint32_t)(FQ_WY + 48 * row + 4 * g);
+    k.a3 = (uint32_t)(MB_PY_OFF + 16 * row + 4 * g);
+    k.a4 = (uint32_t)(FQ_PL + 24 * row + 4 * g);
+    k.a5 = g < 2 ? k.a4 + 16u : (uint32_t)FQ_DUMP;
+    k.a6 = (uint32_t)(FQ_PL + 24 * row + 8 * g);
+    /* tap t = 8 g + b - row: the six taps as bytes 01 FB 14 14 FB 01 sit at bit 8 (row - 8 g) of the operand */
+    const int sh = 8 * (row - 8 * g);
+    const uint64_t taps = 0x01FB1414FB01ull;
+    k.t6 = sh >= 64 || sh <= -64 ? 0ull : (sh >= 0 ? taps << sh : taps >> -sh);
+    const int s1 = sh + 16;
+    k.i2 = s1 >= 64 || s1 < 0 ? 0ull : 1ull << s1;
+    const int cp = lane >> 5, cy = (lane >> 2) & 7, c = lane & 3;
+    k.c1 = (uint32_t)(FQ_WC + 108 * cp + 12 * cy + 2 * c);
+    k.c2 = (uint32_t)(MB_PC_OFF + 64 * cp + 8 * cy + 2 * c);
+    return k;
+}
+
+/* ---- the record's scalars ---- */
+struct FqRec {
+    uint32_t mb_type, nnz, w2;      /* w2: cbp | qp << 16 | flags << 24 */
+    uint32_t w12, w14;              /* inter.ref_pic[0][0..3], inter.chroma_dy[0][0..3] */
+    uint32_t mv0;                   /* the list-0 vector of block 0 */
+};
+static_assert(offsetof(mi355_h264_mb, cbp) == 8 && offsetof(mi355_h264_mb, flags) == 11 && offsetof(mi355_h264_mb, u) == 48, "the words fq_rec reads");
+__device__ __forceinline__ FqRec fq_rec(const FrameHot &fr, int mb_xy)
+{
+    FqRec r;
+    fq_kptr h = fq_konst(fr.mb + mb_xy);
+    r.mb_type = h[0]; r.nnz = h[1]; r.w2 = h[2];
+    r.w12 = h[12]; r.w14 = h[14];
+    r.mv0 = fr.mv[0] ? fq_konst(fr.mv[0] + (size_t)mb_xy * 32)[0] : 0u;
+    return r;
+}
+/* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms */
+__device__ __forceinline__ bool fq_is_fast(const FqRec &r)
+{
+    const uint32_t want = MI355_MB_16x16 | MI355_MB_P0L0;
+    const uint32_t look = MI355_MB_INTRA | MI355_MB_16x16 | MI355_MB_P0L0 | MI355_MB_P0L1 | MI355_MB_8x8DCT;
+    return (r.mb_type & look) == want && !((r.w2 >> 24) & MI355_MBF_WEIGHTED);
+}
+
+/* the 960 bytes of a record into LDS (MbLds begins with them): lanes 0-3 the record, 4-7 / 8-11 the vectors, 12-59 the coefficients.
+ * Lanes 60-63 stay out: behind the record lies the prediction tile, which this macroblock may be writing while the NEXT record arrives. */
+__device__ __forceinline__ void fq_record_dma(MbLds &s, const FrameHot &fr, int mb_xy)
+{
+    const int l = lane_id();
+    const uint8_t *hp = reinterpret_cast<const uint8_t *>(&fr.mb[mb_xy]);
+    const uint8_t *cp = reinterpret_cast<const uint8_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+    const uint8_t *zp = reinterpret_cast<const uint8_t *>(k_zero16);
+    const uint8_t *m0 = fr.mv[0] ? reinterpret_cast<const uint8_t *>(fr.mv[0]) + (size_t)mb_xy * 64 + 16 * (l - 4) : zp;
+    const uint8_t *m1 = fr.mv[1] ? reinterpret_cast<const uint8_t *>(fr.mv[1]) + (size_t)mb_xy * 64 + 16 * (l - 8) : zp;
+    const uint8_t *src = l < 4 ? hp + 16 * l : (l < 8 ? m0 : (l < 12 ? m1 : cp + 16 * (l - 12)));
+    if (l < 60) lds_dma16<false>(src, reinterpret_cast<uint8_t *>(&s));
+}
+
+/* ---- residual, first half: the 24 blocks' inverse transforms into registers (two lanes per block; residual_blocks's arithmetic, see there) ----
+ * o[i]: (residual of this lane's row a, of its row b) in column i, as two 16-bit halves */
+__device__ __forceinline__ void fq_idct(MbLds &s, const ResidLane &rl, uint32_t nnz, bool has_chroma, uint32_t o[4])
+{
+    const int lane = lane_id();
+    if (has_chroma) {
+        if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
+            int16_t *p = s.coef + 256 + 64 * lane;
+            int a = p[0], b = p[16], c = p[32], d = p[48];
+            chroma_dc_dequant(a, b, c, d, (int)s.hdr.dc_qmul[1 + lane]);
+            p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
+        }
+        MI355_WAVE_SYNC();
+    }
+    const uint32_t nnz24 = nnz & (has_chroma ? 0xFFFFFFu : 0xFFFFu), hc = has_chroma ? 0xFFFFFFFFu : 0u;
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const uint32_t keep = bit_mask(nnz24, lane >> 1);
+    const uint32_t keep0 = keep | (rl.dc16 & hc);
+    const int rnd = (int)(~keep & rl.rc & hc);
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(base + rl.cw);
+    const uint32_t c0 = pk_add(cw[0] & keep0, keep & rl.misc & 0xFFu), c1 = cw[2] & keep, c2 = cw[4] & keep, c3 = cw[6] & keep;
+    const uint32_t z0 = pk_add(c0, c2), z1 = pk_sub(c0, c2), z2 = pk_sub(pk_ashr(c1, 1), c3), z3 = pk_add(c1, pk_ashr(c3, 1));
+    const uint32_t w[4] = { pk_add(z0, z3), pk_add(z1, z2), pk_sub(z1, z2), pk_sub(z0, z3) };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t xh = pk_ashr_hi1((uint32_t)quad_xor1((int)w[i]));
+        const int ra = pk_dot2k(xh, 0x04000400u, pk_dot2(w[i], rl.ka, rnd)), rb = pk_dot2k(xh, 0xFC000400u, pk_dot2(w[i], rl.kb, rnd));
+        o[i] = byte_perm((uint32_t)rb, (uint32_t)ra, 0x07060302u);
+    }
+}
+/* ... second half: onto the prediction */
+__device__ __forceinline__ void fq_resid_add(MbLds &s, const ResidLane &rl, bool has_chroma, const uint32_t o[4])
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    if (rl.misc & (has_chroma ? 0x300u : 0x100u)) {
+        uint32_t *pa = reinterpret_cast<uint32_t *>(base + rl.off_a), *pb = reinterpret_cast<uint32_t *>(base + rl.off_b);
+        const uint32_t va = *pa, vb = *pb;
+        const uint32_t s0 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C040C00u), o[0])), s1 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C050C01u), o[1]));
+        const uint32_t s2 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C060C02u), o[2])), s3 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C070C03u), o[3]));
+        const uint32_t m01 = byte_perm(s1, s0, 0x05040100u), m23 = byte_perm(s3, s2, 0x05040100u);
+        *pa = byte_perm(m23, m01, 0x06040200u);
+        *pb = byte_perm(m23, m01, 0x07050301u);
+    }
+}
+
+/* ---- the windows ---- */
+struct FqWin {
+    int so2;        /* o + 2: where block column -2 sits in a 48-byte window row */
+    int oc;         /* cx & 3: where chroma column 0 of the block sits in a 12-byte window row */
+    bool patch_y, patch_c;
+    int t0, c0;     /* first luma tile column / first chroma sample column of the fetch (either may lie outside the picture) */
+};
+/* issue both fetches: rows clamped to the picture here, columns fetched from the clamped tile and replicated later (fq_windows_patch) */
+__device__ __forceinline__ FqWin fq_windows_issue(MbLds &s, const FqLane &k, const uint8_t *ry, const uint8_t *rc, const FrameHot &fr, int mx, int my, int myc)
+{
+    FqWin w;
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
+    const int mbw = fr.mb_width, hpix = 16 * fr.mb_height, hc = 8 * fr.mb_height;
+    w.t0 = (ix - 4) >> 4;
+    w.so2 = ((ix - 4) & 15) + 2;
+    w.c0 = cx & ~3;
+    w.oc = cx & 3;
+    w.patch_y = w.t0 < 0 || w.t0 + 2 >= mbw;
+    w.patch_c = w.c0 < 0 || w.c0 + 11 >= 8 * mbw;
+    {
+        const int y = fq_med3_0(iy - 2 + k.fr, hpix - 1);
+        const int tx = fq_med3_0(w.t0 + k.fp, mbw - 1);
+        lds_dma16<false>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), base + FQ_WY);
+    }
+    {
+        const int y = fq_med3_0(cy + k.crow, hc - 1);
+        const int col = w.c0 + k.cd4, t = col >> 3;
+        /* a dword of a tile beyond the picture: the dword of the edge tile that holds the edge column (replicated afterwards) */
+        const int tx = fq_med3_0(t, mbw - 1), within = t < 0 ? 0 : (t >= mbw ? 4 : (col & 4));
+        fq_dma4(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), base + FQ_WC);
+    }
+    return w;
+}
+/* columns left / right of the picture: the edge column's sample over the whole piece.  Each lane mends the piece it fetched. */
+__device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, const FqWin &w, int mbw)
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const int lane = lane_id();
+    if (w.patch_y && lane < 63) {
+        const int t = w.t0 + k.fp;
+        if (t < 0 || t >= mbw) {
+            uint8_t *p = base + FQ_WY + 16 * lane;
+            const uint32_t e = (uint32_t)p[t < 0 ? 0 : 15] * 0x01010101u;
+            *reinterpret_cast<mi355_u32x4 *>(p) = mi355_u32x4{ e, e, e, e };
+        }
+    }
+    if (w.patch_c && lane < 54) {
+        const int t = (w.c0 + k.cd4) >> 3;
+        if (t < 0 || t >= mbw) {
+            uint8_t *p = base + FQ_WC + 4 * lane;
+            *reinterpret_cast<uint32_t *>(p) = (uint32_t)p[t < 0 ? 0 : 3] * 0x01010101u;
+        }
+    }
+}
+
+/* ---- luma ---- */
+constexpr uint64_t FQ_SIGN = 0x8080808080808080ull;     /* unsigned sample -> signed operand byte: u - 128; the products' constant terms put 128 x (sum of the taps) back */
+/* four values -> four samples: clip_u8(d[t] >> SH) as bytes 0..3 (d fits 16 bits) */
+template <int SH>
+__device__ __forceinline__ uint32_t fq_pack16(const int d[4])
+{
+    uint32_t p01 = byte_perm((uint32_t)d[1], (uint32_t)d[0], 0x05040100u), p23 = byte_perm((uint32_t)d[3], (uint32_t)d[2], 0x05040100u);
+    if (SH) { p01 = pk_ashr(p01, SH); p23 = pk_ashr(p23, SH); }
+    return byte_perm(pk_sat_u8(p23), pk_sat_u8(p01), 0x05040100u);
+}
+/* byte B of four values as one dword */
+template <int B>
+__device__ __forceinline__ uint32_t fq_bytes(const int d[4])
+{
+    return byte_perm((uint32_t)d[1], (uint32_t)d[0], 0x0C0C0400u + 0x0101u * B) | byte_perm((uint32_t)d[3], (uint32_t)d[2], 0x04000C0Cu + 0x01010000u * B);
+}
+/* Quarter-sample prediction of the 16x16 block (h264qpel_template.c's mc00..mc33) from the raw window into the prediction tile.
+ * pos = (mx & 3) | (my & 3) << 2.  Components: G integer samples, b / h horizontal / vertical half samples, j the centre. */
+__device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int pos)
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    /* b of window row `row0` + this lane's row: a direct product, the filter on the column side */
+    auto hband = [&](int row0) -> uint32_t {
+        int d[4];
+        fq_mfma(k.t6, fq_lds64(base + k.a1 + (uint32_t)(48 * row0 + so2)) ^ FQ_SIGN, 4096 + 16, d);
+        return fq_pack16<5>(d);
+    };
+    auto gsamples = [&](int dy, int dx) -> uint32_t { return fq_lds32(base + k.a2 + (uint32_t)(48 * (2 + dy) + so2 + 2 + dx)); };
+    /* the window transposed through a product whose result a lane holds as four rows of column (lane & 15): with the identity the raw
+     * samples of columns dx .. dx + 15 (one byte plane), with the filter the unclipped horizontal sums (a low and a high byte plane) */
+    auto transpose = [&](bool filtered, int dx) {
+        const uint32_t off = (uint32_t)(so2 + dx);
+        const uint64_t x0 = fq_lds64(base + k.a1 + off) ^ FQ_SIGN, x1 = fq_lds64(base + k.a1 + 768u + off) ^ FQ_SIGN;
+        int d0[4], d1[4];
+        if (filtered) {
+            fq_mfma(x0, k.t6, 4096, d0);
+            fq_mfma(x1, k.t6, 4096, d1);
+            *reinterpret_cast<uint32_t *>(base + k.a4) = fq_bytes<0>(d0);
+            *reinterpret_cast<uint32_t *>(base + k.a5) = fq_bytes<0>(d1);
+            *reinterpret_cast<uint32_t *>(base + k.a4 + FQ_PLANE) = fq_bytes<1>(d0);
+            *reinterpret_cast<uint32_t *>(base + k.a5 + FQ_PLANE) = fq_bytes<1>(d1);
+        } else {
+            fq_mfma(x0, k.i2, 128, d0);
+            fq_mfma(x1, k.i2, 128, d1);
+            *reinterpret_cast<uint32_t *>(base + k.a4 + 2 * FQ_PLANE) = fq_bytes<0>(d0);
+            *reinterpret_cast<uint32_t *>(base + k.a5 + 2 * FQ_PLANE) = fq_bytes<0>(d1);
+        }
+        MI355_WAVE_SYNC();
+    };
+    /* h: the vertical filter over the raw transposed plane */
+    auto vraw = [&]() -> uint32_t {
+        int d[4];
+        fq_mfma(fq_lds64(base + k.a6 + 2 * FQ_PLANE) ^ FQ_SIGN, k.t6, 4096 + 16, d);
+        return fq_pack16<5>(d);
+    };
+    /* j: the vertical filter over the horizontal sums, 256 x (high bytes' sum) + (low bytes' sum) */
+    auto vsums = [&]() -> uint32_t {
+        int lo[4], hi[4], v[4];
+        fq_mfma(fq_lds64(base + k.a6) ^ FQ_SIGN, k.t6, 4096 + 512, lo);
+        fq_mfma(fq_lds64(base + k.a6 + FQ_PLANE), k.t6, 0, hi);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = (hi[t] * 256 + lo[t]) >> 10;
+        return fq_pack16<0>(v);
+    };
+    uint32_t v;
+    switch (pos) {
+    case 0: v = gsamples(0, 0); break;
+    case 1: v = fq_lerp(gsamples(0, 0), hband(2)); break;
+    case 2: v = hband(2); break;
+    case 3: v = fq_lerp(gsamples(0, 1), hband(2)); break;
+    case 4: transpose(false, 0); v = fq_lerp(gsamples(0, 0), vraw()); break;
+    case 8: transpose(false, 0); v = vraw(); break;
+    case 12: transpose(false, 0); v = fq_lerp(gsamples(1, 0), vraw()); break;
+    case 5: { const uint32_t b = hband(2); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
+    case 7: { const uint32_t b = hband(2); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
+    case 13: { const uint32_t b = hband(3); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
+    case 15: { const uint32_t b = hband(3); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
+    case 10: transpose(true, 0); v = vsums(); break;
+    case 6: { const uint32_t b = hband(2); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
+    case 14: { const uint32_t b = hband(3); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
+    case 9: { transpose(false, 0); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }
+    default: { transpose(false, 1); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }     /* 11 */
+    }
+    *reinterpret_cast<uint32_t *>(base + k.a3) = v;
+}
+
+/* ---- chroma: both 8x8 planes, two samples per lane ---- */
+__device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, int fx, int fy)
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const uint32_t wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
+    const uint32_t r0 = fq_lds32(base + k.c1 + (uint32_t)oc), r1 = fq_lds32(base + k.c1 + (uint32_t)(oc + 12));
+    const uint32_t d0 = fq_dot4(byte_perm(r1, r0, 0x05040100u), wts, 32u), d1 = fq_dot4(byte_perm(r1, r0, 0x06050201u), wts, 32u);
+    *reinterpret_cast<uint16_t *>(base + k.c2) = (uint16_t)((d0 >> 6) | ((d1 >> 6) << 8));
+}
+
+/* ---- one fast macroblock.  The record is in LDS; `next` >= 0: request that macroblock's record as soon as this one's coefficients are in registers ---- */
+__device__ __forceinline__ void fq_mb(MbLds &s, const FqLane &k, const ResidLane &rl, const FrameHot &fr, const FqRec &rec, int mb_x, int mb_y, int next)
+{
+    const int slot = (int)(rec.w12 & 0xFFu);
+    const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
+    const uint8_t *ry = mi355_global(rp[0]), *rc = mi355_global(rp[1]);
+    const int mx = (int16_t)(rec.mv0 & 0xFFFF) + mb_x * 64, my = (int16_t)(rec.mv0 >> 16) + mb_y * 64;
+    const int myc = my + (int8_t)(rec.w14 & 0xFFu);                       /* the other-parity field offset, h264_mb.c:287-291 */
+    const FqWin w = fq_windows_issue(s, k, ry, rc, fr, mx, my, myc);
+    /* under the windows' flight: the residual into registers */
+    const uint32_t nnz = rec.nnz;
+    const bool has_chroma = (rec.w2 & 0x30u) != 0, has_resid = (nnz & 0xFFFFu) != 0 || has_chroma;
+    uint32_t o[4] = { 0u, 0u, 0u, 0u };
+    if (has_resid) fq_idct(s, rl, nnz, has_chroma, o);
+    MI355_WAVE_SYNC();                                                     /* every lane has read its coefficients */
+    if (next >= 0) {
+        fq_record_dma(s, fr, next);
+        fq_wait_vm1();                                                     /* the windows are in; the next record may still be on its way */
+    } else {
+        fq_wait_vm0();
+    }
+    MI355_WAVE_SYNC();
+    if (w.patch_y || w.patch_c) {
+        fq_windows_patch(s, k, w, fr.mb_width);
+        MI355_WAVE_SYNC();
+    }
+    fq_luma(s, k, w.so2, (mx & 3) | ((my & 3) << 2));
+    fq_chroma(s, k, w.oc, mx & 7, myc & 7);
+    MI355_WAVE_SYNC();
+    if (has_resid) {
+        fq_resid_add(s, rl, has_chroma, o);
+        MI355_WAVE_SYNC();
+    }
+    store_mb_tiled(s, fr, mb_x, mb_y);
+}
+
+/* ---- any other inter macroblock of the run: h264_recon_dev.h's code, as a FUNCTION — its registers are its own, the run's loop does not pay for them ---- */
+#ifdef MI355_HIP_EMU_H
+static void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int mb_y)
+#else
+__device__ __attribute__((noinline)) void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int mb_y)
+#endif
+{
+    recon_inter_mb<false, true>(*s, *frd, mb_x, mb_y);
+}
+
+/* ---- the run: RUN consecutive macroblocks (of the launch's max_w x max_h grid per picture) per wave ---- */
+template <int RUN>
+__device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
+                                                unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+{
+    const int first = xcd_linear((int)blockIdx.x, per_xcd) * RUN;
+    if (first >= nblocks) return;
+    const int n = nblocks - first < RUN ? nblocks - first : RUN;
+    const int row = div_magic(first, inv_w);
+    int mb_x = first - row * max_w;
+    int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+    ResidLane rl;
+    resid_lane_issue(rl);
+    const FqLane k = fq_lane();
+    /* the table has arrived before the run begins: inside it the compiler must find no pending load of its own to wait for (it would wait for the
+     * window and record requests in flight with it) */
+    MI355_PIN(rl.off_a); MI355_PIN(rl.off_b); MI355_PIN(rl.cw); MI355_PIN(rl.dc16); MI355_PIN(rl.misc); MI355_PIN(rl.rc); MI355_PIN(rl.ka); MI355_PIN(rl.kb);
+    FrameHot fr = frame_hot(frames[f]);
+    bool pic_ok = uniform(frames[f].surface_layout) == MI355_SURFACE_TILED && !(uniform(frames[f].flags) & MI355_FRAME_NO_INTER);
+    bool have = false;                  /* this macroblock's record was requested by its predecessor */
+    uint32_t deferred = 0;              /* macroblocks of the run that are not of the fast kind: afterwards, by h264_recon_dev.h's code */
+    FqRec rec = {};
+    for (int i = 0; i < n; i++) {
+        bool requested = false;
+        if (pic_ok && mb_x < fr.mb_width && mb_y < fr.mb_height) {
+            const int mb_xy = mb_y * fr.mb_width + mb_x;
+            if (!have) {
+                rec = fq_rec(fr, mb_xy);
+                fq_record_dma(s, fr, mb_xy);
+                fq_wait_vm0();
+            } else {
+                fq_wait_vm1();          /* the record is in; the predecessor's store may still be on its way */
+            }
+            MI355_WAVE_SYNC();
+            if (!(rec.mb_type & MI355_MB_INTRA)) {
+                if (fq_is_fast(rec)) {
+                    requested = i + 1 < n && mb_x + 1 < max_w && mb_x + 1 < fr.mb_width;
+                    const FqRec cur = rec;
+                    if (requested) rec = fq_rec(fr, mb_xy + 1);
+                    fq_mb(s, k, rl, fr, cur, mb_x, mb_y, requested ? mb_xy + 1 : -1);
+                } else {
+                    deferred |= 1u << i;
+                }
+            }
+        }
+        have = requested;
+        if (++mb_x == max_w) {
+            mb_x = 0;
+            if (++mb_y == max_h) { mb_y = 0; f++; }
+            if (mb_y == 0 && i + 1 < n) {
+                fr = frame_hot(frames[f]);
+                pic_ok = uniform(frames[f].surface_layout) == MI355_SURFACE_TILED && !(uniform(frames[f].flags) & MI355_FRAME_NO_INTER);
+            }
+        }
+    }
+    /* two lists, weights, partitions, the 8x8 transform: one macroblock per pass of the general code, nothing of the run's state alive */
+#ifndef FQ_NO_DEFERRED
+    while (deferred) {
+        const int i = __builtin_ctz(deferred);
+        deferred &= deferred - 1;
+        const int lin = first + i, r = div_magic(lin, inv_w), x = lin - r * max_w;
+        const int pf = div_magic(r, inv_h), y = r - pf * max_h;
+        fq_wait_vm0();
+        MI355_WAVE_SYNC();
+        fq_general_mb(&s, &frames[pf], x, y);
+        MI355_WAVE_SYNC();
+    }
+#endif
+}
+
+}  // namespace
+#endif

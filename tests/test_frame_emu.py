@@ -178,3 +178,37 @@ def test_second_kernel_set_10bit_sanity_emulated(emu, oracle, name):
         assert np.array_equal(runs[0][p], runs[1][p])
         assert runs[0][p].max() <= 1023
         assert (np.abs(runs[0][p].astype(np.int32) / 4.0 - dst8[p]) <= 1.0).mean() > 0.9, (name, p)
+
+
+def _fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, **kw):
+    """the bench generator's pictures through the single-layout entry points on tiled surfaces (k_recon_inter_tiled: the run kernel of
+    h264_recon_fast.h), every sample of both surfaces against the oracle"""
+    fs = HF.synth_frames_fast(nframes, mb_w, mb_h, seed=seed, lib=backend.lib, **kw)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(backend, fs, tiled=True)
+    try:
+        d.decode_by_layout()
+        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
+    finally:
+        d.free()
+    for p in range(3):
+        assert np.array_equal(recon_o[p], recon_g[p])
+        assert np.array_equal(dst_o[p], dst_g[p])
+
+
+def test_full_size_1080p_picture_emulated_run_kernel(emu, oracle):
+    """one 1080p picture of the headline workload through the run kernel (raw LDS windows, filters as matrix products)"""
+    _fast_workload_by_layout(emu, oracle, 1, 120, 68, 0x264)
+
+
+@pytest.mark.parametrize("mv_range", (64, 200, 1200))
+@pytest.mark.parametrize("mb_w,mb_h", ((7, 5), (1, 1), (2, 3), (3, 1), (5, 9)))
+def test_run_kernel_windows_over_every_border_emulated(emu, oracle, mb_w, mb_h, mv_range):
+    """plain P macroblocks whose windows reach over the borders by a little, by more than a window, and by more than the picture:
+    the fast path replicates the edge column / row for any distance (emulated_edge_mc)"""
+    _fast_workload_by_layout(emu, oracle, 2, mb_w, mb_h, 0x2650 + mv_range + mb_w, mv_range=mv_range)
+
+
+def test_run_kernel_mixed_partitions_emulated(emu, oracle):
+    """runs that hold fast macroblocks and deferred ones (partitions) side by side"""
+    _fast_workload_by_layout(emu, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)
