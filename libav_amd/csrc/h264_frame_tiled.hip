@@ -10,7 +10,7 @@
 #include "h264_recon_fast.h"
 
 #ifndef MI355_RECON_RUN
-#define MI355_RECON_RUN 4
+#define MI355_RECON_RUN 8
 #endif
 
 namespace {

@@ -26,23 +26,29 @@
 #ifndef MI355_H264_RECON_FAST_H
 #define MI355_H264_RECON_FAST_H
 
+#include <type_traits>
 #include "h264_recon_dev.h"
 
 namespace {
 
 /* ---- LDS of the fast path: behind py / pc (the q tiles and the motion scratch of the other paths are not live here) ---- */
+/* Coefficients: where MbLds keeps them, but the 48 sixteen-byte pieces in another order — first halves of the 24 blocks (coefficients 0..7), then the
+ * second halves: a lane pair reads (dword h, h + 2) of one piece per access, and with the pieces of a block 32 bytes apart the 24 blocks met in four of the
+ * LDS's eight bank groups (six lanes per bank: 16 cycles a read, tools/ubench/lds_rate.hip); 16 bytes apart they spread over all eight */
+constexpr int FQ_COEF = (int)offsetof(MbCore, coef);
 constexpr int FQ_WY = MB_PC_OFF + 128;          /* 1344: raw luma window, piece L (16 bytes) at 16 L: row L / 3 = 48 bytes = picture columns 16 t0 .. 16 t0 + 47 */
-constexpr int FQ_WC = FQ_WY + 1024;             /* raw chroma window [plane][row 0..8][12 bytes], dword q at 4 q: columns (cx & ~3) .. + 11 */
-constexpr int FQ_PL = FQ_WC + 224;              /* three transposed planes [column 0..15][24 rows]: low bytes, high bytes, raw samples */
+constexpr int FQ_WC = FQ_WY + 1024;             /* raw chroma window [plane][row 0..8][12 bytes], dword q at 4 q: columns (cx & ~3) .. + 11; all 64 lanes of the request write (216 bytes used of 256) */
+constexpr int FQ_PL = FQ_WC + 256;              /* three transposed planes [column 0..15][24 rows]: low bytes, high bytes, raw samples */
 constexpr int FQ_PLANE = 16 * 24 + 8;           /* the last column's operand read runs eight bytes past its rows */
-constexpr int FQ_DUMP = FQ_PL + 3 * FQ_PLANE;   /* where the lanes that hold no row of a product's second half write */
-static_assert(FQ_WY == 1344 && (FQ_WY % 16) == 0 && (FQ_PL % 8) == 0 && FQ_DUMP + 2 * FQ_PLANE + 8 <= (int)sizeof(MbLds), "fast-path regions inside MbLds");
-static_assert(FQ_WY + 48 * 31 + 24 + 18 + 8 <= (int)sizeof(MbLds), "the second half of a transposing product reads window rows 16..31");
+constexpr int FQ_DUMP = FQ_PL + 16 * 24;        /* where the lanes that hold no row of a product's second half write: the plane's own tail */
+constexpr int FQ_WSTEP = 2464;                  /* the second set of windows (the NEXT macroblock's, in flight while this one is predicted) lies this far behind the first */
+static_assert(FQ_WY == 1344 && (FQ_WY % 16) == 0 && (FQ_PL % 8) == 0 && FQ_PL + 3 * FQ_PLANE <= FQ_WY + FQ_WSTEP && (FQ_WSTEP % 16) == 0 &&
+              FQ_WC + FQ_WSTEP + 256 <= (int)sizeof(MbLds), "fast-path regions inside MbLds");
+static_assert(FQ_WY + FQ_WSTEP + 48 * 20 + 24 + 16 + 12 <= (int)sizeof(MbLds), "the second half of a transposing product reads window rows 16..20");
 
 /* ---- primitives: one instruction each on the device, their plain meaning in the emulator ---- */
 #ifdef MI355_HIP_EMU_H
-static inline uint32_t fq_lds32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
-static inline uint64_t fq_lds64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+static inline uint64_t fq_lds64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }     /* p on 8 bytes */
 static inline uint32_t fq_lerp(uint32_t a, uint32_t b)                 /* v_lerp_u8 with 1 in every byte of the third operand: (a + b + 1) >> 1 per byte */
 {
     uint32_t r = 0;
@@ -68,17 +74,16 @@ static inline void fq_mfma(uint64_t x, uint64_t y, int c, int d[4])
         }
     }
 }
-static inline void fq_dma4(const uint8_t *src, uint8_t *lds_base) { std::memcpy(lds_base + 4 * (threadIdx.x & 63), src, 4); }
+/* LDS-DMA: 16 / 4 bytes per lane from memory to LDS offset OFF + 16 / 4 x lane of the wave's MbLds */
+template <int OFF> static inline void fq_dma16(const uint8_t *src, MbLds &s, int more = 0) { std::memcpy(reinterpret_cast<uint8_t *>(&s) + OFF + more + 16 * (threadIdx.x & 63), src, 16); }
+template <int OFF> static inline void fq_dma4(const uint8_t *src, MbLds &s, int more = 0) { std::memcpy(reinterpret_cast<uint8_t *>(&s) + OFF + more + 4 * (threadIdx.x & 63), src, 4); }
 static inline void fq_wait_vm0() {}
-static inline void fq_wait_vm1() {}
+static inline void fq_wait_vm2() {}
 static inline int fq_med3_0(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
 typedef const uint32_t *fq_kptr;
 static inline fq_kptr fq_konst(const void *p) { return reinterpret_cast<const uint32_t *>(p); }
 #else
-typedef uint32_t fq_u32u __attribute__((aligned(1)));
-typedef uint64_t fq_u64u __attribute__((aligned(1)));
-__device__ __forceinline__ uint32_t fq_lds32(const uint8_t *p) { return *reinterpret_cast<const fq_u32u *>(p); }
-__device__ __forceinline__ uint64_t fq_lds64(const uint8_t *p) { return *reinterpret_cast<const fq_u64u *>(p); }
+__device__ __forceinline__ uint64_t fq_lds64(const uint8_t *p) { return *reinterpret_cast<const uint64_t *>(p); }       /* p on 8 bytes */
 __device__ __forceinline__ uint32_t fq_lerp(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
 __device__ __forceinline__ uint32_t fq_dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 typedef int fq_v4i __attribute__((ext_vector_type(4)));
@@ -88,21 +93,43 @@ __device__ __forceinline__ void fq_mfma(uint64_t x, uint64_t y, int c, int d[4])
     acc = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)x, (long)y, acc, 0, 0, 0);
     d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
 }
-/* four bytes per lane from memory straight into LDS at lds_base + 4 * lane */
-__device__ __forceinline__ void fq_dma4(const uint8_t *src, uint8_t *lds_base)
+/* LDS-DMA: 16 / 4 bytes per lane from memory to LDS offset OFF + 16 / 4 x lane of the wave's MbLds.  OFF goes into M0 (an offset in the instruction would
+ * move the MEMORY address as well); the tile is cast to its address space first, so the sum is a literal and no generic-pointer null test is made */
+typedef __attribute__((address_space(3))) uint8_t *fq_lds_ptr;
+template <int OFF> __device__ __forceinline__ void fq_dma16(const uint8_t *src, MbLds &s, int more = 0)      /* more: a wave-uniform offset on top */
 {
     typedef __attribute__((address_space(1))) const void *gptr;
     typedef __attribute__((address_space(3))) void *lptr;
-    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)lds_base, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)((fq_lds_ptr)&s + OFF + more), 16, 0, 0);
 }
-/* vector-memory operations complete in issue order: "at most N outstanding" means all but the N youngest have landed */
+template <int OFF> __device__ __forceinline__ void fq_dma4(const uint8_t *src, MbLds &s, int more = 0)
+{
+    typedef __attribute__((address_space(1))) const void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)((fq_lds_ptr)&s + OFF + more), 4, 0, 0);
+}
+/* vector-memory LOADS complete in issue order: "at most N outstanding" with N loads youngest means every older load has landed */
 __device__ __forceinline__ void fq_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void fq_wait_vm1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+__device__ __forceinline__ void fq_wait_vm2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 __device__ __forceinline__ int fq_med3_0(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi)); return r; }      /* clamp to 0 .. hi (a wave constant) */
 /* a wave-uniform address read through the scalar cache: the record's words arrive in scalar registers, no LDS read, no v_readfirstlane */
 typedef const __attribute__((address_space(4))) uint32_t *fq_kptr;
 __device__ __forceinline__ fq_kptr fq_konst(const void *p) { return (fq_kptr)(unsigned long long)p; }
 #endif
+
+/* LDS answers a read that is not naturally aligned one lane per cycle (64 cycles a wave, tools/ubench/lds_rate.hip: a b64 four bytes off its alignment included):
+ * bytes at any offset come from aligned dwords and v_alignbyte.  p on 4 bytes, sh = 0..3 */
+__device__ __forceinline__ uint32_t fq_bytes4(const uint8_t *p, uint32_t sh)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    return mi355_alignbyte(w[1], w[0], sh);
+}
+__device__ __forceinline__ uint64_t fq_bytes8(const uint8_t *p, uint32_t sh)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    return (uint64_t)mi355_alignbyte(d1, d0, sh) | ((uint64_t)mi355_alignbyte(d2, d1, sh) << 32);
+}
 
 /* ---- what a lane is, for every macroblock of the run ---- */
 struct FqLane {
@@ -112,6 +139,7 @@ struct FqLane {
     int cplane64, crow, cd4;
     /* luma: this lane's row = lane & 15 and group g = lane >> 4 (four samples 4 g .. 4 g + 3 of the row in a direct product, four rows 4 g .. of column lane & 15 in a transposing one) */
     uint32_t a1;            /* FQ_WY + 48 row + 8 g: this lane's eight bytes of a window-row operand (+ o + 2 + ...) */
+    uint32_t a1b;           /* ... of window row 16 + row (the second half of a transposing product; rows past 20 do not exist: those lanes read a1 again) */
     uint32_t a2;            /* FQ_WY + 48 row + 4 g: this lane's four integer samples (+ 48 (2 + dy) + o + 4 + dx) */
     uint32_t a3;            /* MB_PY_OFF + 16 row + 4 g: where its four predicted samples go */
     uint32_t a4, a5;        /* 24 (lane & 15) + 4 g: its four rows in a transposed plane, first / second half of the window rows (g >= 2: FQ_DUMP) */
@@ -121,6 +149,9 @@ struct FqLane {
     /* chroma: plane lane >> 5, row (lane >> 2) & 7, samples 2 c, 2 c + 1 (c = lane & 3) */
     uint32_t c1;            /* FQ_WC + 108 plane + 12 row + 2 c */
     uint32_t c2;            /* MB_PC_OFF + 64 plane + 8 row + 2 c */
+    /* residual: lane 2 b + h holds columns 2 h, 2 h + 1 of block b (residual_blocks's arrangement) */
+    uint32_t cwf;           /* where its first coefficient pair lies in the fast path's coefficient layout (below) */
+    uint32_t csrc;          /* coefficient fetch: the byte offset in the macroblock's 768 bytes of the piece that goes to LDS slot `lane` */
 };
 __device__ __forceinline__ FqLane fq_lane()
 {
@@ -135,6 +166,7 @@ __device__ __forceinline__ FqLane fq_lane()
     k.cd4 = 4 * (rem - 3 * k.crow);
     const int row = lane & 15, g = lane >> 4;
     k.a1 = (uint32_t)(FQ_WY + 48 * row + 8 * g);
+    k.a1b = row < 5 ? k.a1 + 768u : k.a1;
     k.a2 = (uint32_t)(FQ_WY + 48 * row + 4 * g);
     k.a3 = (uint32_t)(MB_PY_OFF + 16 * row + 4 * g);
     k.a4 = (uint32_t)(FQ_PL + 24 * row + 4 * g);
@@ -149,23 +181,29 @@ __device__ __forceinline__ FqLane fq_lane()
     const int cp = lane >> 5, cy = (lane >> 2) & 7, c = lane & 3;
     k.c1 = (uint32_t)(FQ_WC + 108 * cp + 12 * cy + 2 * c);
     k.c2 = (uint32_t)(MB_PC_OFF + 64 * cp + 8 * cy + 2 * c);
+    const int blk = lane < 48 ? lane >> 1 : 23;
+    k.cwf = (uint32_t)(FQ_COEF + 16 * blk + 4 * (lane & 1));
+    const int slot = lane < 48 ? lane : 47;
+    k.csrc = (uint32_t)(slot < 24 ? 32 * slot : 32 * (slot - 24) + 16);
     return k;
 }
 
 /* ---- the record's scalars ---- */
 struct FqRec {
     uint32_t mb_type, nnz, w2;      /* w2: cbp | qp << 16 | flags << 24 */
+    uint32_t dcq1, dcq2;            /* dc_qmul[1], dc_qmul[2]: the chroma DC dequantisers */
     uint32_t w12, w14;              /* inter.ref_pic[0][0..3], inter.chroma_dy[0][0..3] */
     uint32_t mv0;                   /* the list-0 vector of block 0 */
 };
-static_assert(offsetof(mi355_h264_mb, cbp) == 8 && offsetof(mi355_h264_mb, flags) == 11 && offsetof(mi355_h264_mb, u) == 48, "the words fq_rec reads");
-__device__ __forceinline__ FqRec fq_rec(const FrameHot &fr, int mb_xy)
+static_assert(offsetof(mi355_h264_mb, cbp) == 8 && offsetof(mi355_h264_mb, flags) == 11 && offsetof(mi355_h264_mb, dc_qmul) == 32 && offsetof(mi355_h264_mb, u) == 48, "the words fq_rec reads");
+__device__ __forceinline__ FqRec fq_rec(const mi355_h264_mb *mb, const int16_t *mv0, int mb_xy)
 {
     FqRec r;
-    fq_kptr h = fq_konst(fr.mb + mb_xy);
+    fq_kptr h = fq_konst(mb + mb_xy);
     r.mb_type = h[0]; r.nnz = h[1]; r.w2 = h[2];
+    r.dcq1 = h[9]; r.dcq2 = h[10];
     r.w12 = h[12]; r.w14 = h[14];
-    r.mv0 = fr.mv[0] ? fq_konst(fr.mv[0] + (size_t)mb_xy * 32)[0] : 0u;
+    r.mv0 = mv0 ? fq_konst(mv0 + (size_t)mb_xy * 32)[0] : 0u;
     return r;
 }
 /* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms */
@@ -175,32 +213,29 @@ __device__ __forceinline__ bool fq_is_fast(const FqRec &r)
     const uint32_t look = MI355_MB_INTRA | MI355_MB_16x16 | MI355_MB_P0L0 | MI355_MB_P0L1 | MI355_MB_8x8DCT;
     return (r.mb_type & look) == want && !((r.w2 >> 24) & MI355_MBF_WEIGHTED);
 }
+__device__ __forceinline__ bool fq_has_chroma(const FqRec &r) { return (r.w2 & 0x30u) != 0; }
+__device__ __forceinline__ bool fq_has_resid(const FqRec &r) { return (r.nnz & 0xFFFFu) != 0 || fq_has_chroma(r); }
 
-/* the 960 bytes of a record into LDS (MbLds begins with them): lanes 0-3 the record, 4-7 / 8-11 the vectors, 12-59 the coefficients.
- * Lanes 60-63 stay out: behind the record lies the prediction tile, which this macroblock may be writing while the NEXT record arrives. */
-__device__ __forceinline__ void fq_record_dma(MbLds &s, const FrameHot &fr, int mb_xy)
+/* the 768 bytes of a macroblock's coefficients into the layout above: 48 lanes, 16 bytes each */
+__device__ __forceinline__ void fq_coef_dma(MbLds &s, const FqLane &k, const int16_t *coef, int mb_xy)
 {
-    const int l = lane_id();
-    const uint8_t *hp = reinterpret_cast<const uint8_t *>(&fr.mb[mb_xy]);
-    const uint8_t *cp = reinterpret_cast<const uint8_t *>(fr.coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-    const uint8_t *zp = reinterpret_cast<const uint8_t *>(k_zero16);
-    const uint8_t *m0 = fr.mv[0] ? reinterpret_cast<const uint8_t *>(fr.mv[0]) + (size_t)mb_xy * 64 + 16 * (l - 4) : zp;
-    const uint8_t *m1 = fr.mv[1] ? reinterpret_cast<const uint8_t *>(fr.mv[1]) + (size_t)mb_xy * 64 + 16 * (l - 8) : zp;
-    const uint8_t *src = l < 4 ? hp + 16 * l : (l < 8 ? m0 : (l < 12 ? m1 : cp + 16 * (l - 12)));
-    if (l < 60) lds_dma16<false>(src, reinterpret_cast<uint8_t *>(&s));
+    const uint8_t *cp = reinterpret_cast<const uint8_t *>(coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
+#ifndef FQ_EXP_NO_COEF
+    if (lane_id() < 48) fq_dma16<FQ_COEF>(cp + k.csrc, s);
+#endif
 }
 
 /* ---- residual, first half: the 24 blocks' inverse transforms into registers (two lanes per block; residual_blocks's arithmetic, see there) ----
  * o[i]: (residual of this lane's row a, of its row b) in column i, as two 16-bit halves */
-__device__ __forceinline__ void fq_idct(MbLds &s, const ResidLane &rl, uint32_t nnz, bool has_chroma, uint32_t o[4])
+__device__ __forceinline__ void fq_idct(MbLds &s, const FqLane &k, const ResidLane &rl, uint32_t nnz, bool has_chroma, uint32_t dcq1, uint32_t dcq2, uint32_t o[4])
 {
     const int lane = lane_id();
     if (has_chroma) {
         if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
-            int16_t *p = s.coef + 256 + 64 * lane;
-            int a = p[0], b = p[16], c = p[32], d = p[48];
-            chroma_dc_dequant(a, b, c, d, (int)s.hdr.dc_qmul[1 + lane]);
-            p[0] = (int16_t)a; p[16] = (int16_t)b; p[32] = (int16_t)c; p[48] = (int16_t)d;
+            int16_t *p = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(&s) + FQ_COEF + 16 * (16 + 4 * lane));      /* the DCs of blocks 16 + 4 lane .. + 3: 16 bytes apart */
+            int a = p[0], b = p[8], c = p[16], d = p[24];
+            chroma_dc_dequant(a, b, c, d, (int)(lane ? dcq2 : dcq1));
+            p[0] = (int16_t)a; p[8] = (int16_t)b; p[16] = (int16_t)c; p[24] = (int16_t)d;
         }
         MI355_WAVE_SYNC();
     }
@@ -209,8 +244,8 @@ __device__ __forceinline__ void fq_idct(MbLds &s, const ResidLane &rl, uint32_t 
     const uint32_t keep = bit_mask(nnz24, lane >> 1);
     const uint32_t keep0 = keep | (rl.dc16 & hc);
     const int rnd = (int)(~keep & rl.rc & hc);
-    const uint32_t *cw = reinterpret_cast<const uint32_t *>(base + rl.cw);
-    const uint32_t c0 = pk_add(cw[0] & keep0, keep & rl.misc & 0xFFu), c1 = cw[2] & keep, c2 = cw[4] & keep, c3 = cw[6] & keep;
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(base + k.cwf);
+    const uint32_t c0 = pk_add(cw[0] & keep0, keep & rl.misc & 0xFFu), c1 = cw[2] & keep, c2 = cw[96] & keep, c3 = cw[98] & keep;
     const uint32_t z0 = pk_add(c0, c2), z1 = pk_sub(c0, c2), z2 = pk_sub(pk_ashr(c1, 1), c3), z3 = pk_add(c1, pk_ashr(c3, 1));
     const uint32_t w[4] = { pk_add(z0, z3), pk_add(z1, z2), pk_sub(z1, z2), pk_sub(z0, z3) };
 #pragma unroll
@@ -237,42 +272,56 @@ __device__ __forceinline__ void fq_resid_add(MbLds &s, const ResidLane &rl, bool
 
 /* ---- the windows ---- */
 struct FqWin {
-    int so2;        /* o + 2: where block column -2 sits in a 48-byte window row */
-    int oc;         /* cx & 3: where chroma column 0 of the block sits in a 12-byte window row */
+    int so2w;       /* woff + o + 2: where block column -2 sits in a 48-byte window row of this macroblock's window set */
+    int ocw;        /* woff + (cx & 3): where chroma column 0 of the block sits in a 12-byte window row */
+    int woff;       /* 0 or FQ_WSTEP: the window set */
+    int pos, fxc, fyc;      /* (mx & 3) | (my & 3) << 2; mx & 7, myc & 7 */
     bool patch_y, patch_c;
     int t0, c0;     /* first luma tile column / first chroma sample column of the fetch (either may lie outside the picture) */
 };
-/* issue both fetches: rows clamped to the picture here, columns fetched from the clamped tile and replicated later (fq_windows_patch) */
-__device__ __forceinline__ FqWin fq_windows_issue(MbLds &s, const FqLane &k, const uint8_t *ry, const uint8_t *rc, const FrameHot &fr, int mx, int my, int myc)
+/* issue both fetches of a macroblock into window set `woff`: rows clamped to the picture here, columns fetched from the clamped tile and replicated
+ * later (fq_windows_patch).  mc_dir_part's addressing (h264_mb.c:204-318) */
+__device__ __forceinline__ FqWin fq_windows_issue(MbLds &s, const FqLane &k, const mi355_h264_frame *desc, const FrameHot &fr, const FqRec &rec, int mb_x, int mb_y, int woff)
 {
     FqWin w;
-    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    const int slot = (int)(rec.w12 & 0xFFu);
+    fq_kptr rp = fq_konst(desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0]);
+    const uint8_t *ry = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)));
+    const uint8_t *rc = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[2] | ((unsigned long long)rp[3] << 32)));
+    const int mx = (int16_t)(rec.mv0 & 0xFFFF) + mb_x * 64, my = (int16_t)(rec.mv0 >> 16) + mb_y * 64;
+    const int myc = my + (int8_t)(rec.w14 & 0xFFu);                       /* the other-parity field offset, h264_mb.c:287-291 */
     const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
     const int mbw = fr.mb_width, hpix = 16 * fr.mb_height, hc = 8 * fr.mb_height;
+    w.woff = woff;
+    w.pos = (mx & 3) | ((my & 3) << 2); w.fxc = mx & 7; w.fyc = myc & 7;
     w.t0 = (ix - 4) >> 4;
-    w.so2 = ((ix - 4) & 15) + 2;
+    w.so2w = ((ix - 4) & 15) + 2 + woff;
     w.c0 = cx & ~3;
-    w.oc = cx & 3;
+    w.ocw = (cx & 3) + woff;
     w.patch_y = w.t0 < 0 || w.t0 + 2 >= mbw;
     w.patch_c = w.c0 < 0 || w.c0 + 11 >= 8 * mbw;
     {
         const int y = fq_med3_0(iy - 2 + k.fr, hpix - 1);
         const int tx = fq_med3_0(w.t0 + k.fp, mbw - 1);
-        lds_dma16<false>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), base + FQ_WY);
+#ifndef FQ_EXP_NO_LUMA_FETCH
+        fq_dma16<FQ_WY>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), s, woff);
+#endif
     }
     {
         const int y = fq_med3_0(cy + k.crow, hc - 1);
         const int col = w.c0 + k.cd4, t = col >> 3;
         /* a dword of a tile beyond the picture: the dword of the edge tile that holds the edge column (replicated afterwards) */
         const int tx = fq_med3_0(t, mbw - 1), within = t < 0 ? 0 : (t >= mbw ? 4 : (col & 4));
-        fq_dma4(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), base + FQ_WC);
+#ifndef FQ_EXP_NO_CHROMA_FETCH
+        fq_dma4<FQ_WC>(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), s, woff);
+#endif
     }
     return w;
 }
 /* columns left / right of the picture: the edge column's sample over the whole piece.  Each lane mends the piece it fetched. */
 __device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, const FqWin &w, int mbw)
 {
-    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s) + w.woff;
     const int lane = lane_id();
     if (w.patch_y && lane < 63) {
         const int t = w.t0 + k.fp;
@@ -292,13 +341,14 @@ __device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, cons
 }
 
 /* ---- luma ---- */
-constexpr uint64_t FQ_SIGN = 0x8080808080808080ull;     /* unsigned sample -> signed operand byte: u - 128; the products' constant terms put 128 x (sum of the taps) back */
-/* four values -> four samples: clip_u8(d[t] >> SH) as bytes 0..3 (d fits 16 bits) */
-template <int SH>
-__device__ __forceinline__ uint32_t fq_pack16(const int d[4])
+/* A sample enters a product as the signed byte u - 128 (u ^ 0x80).  Every product starts from zero (the matrix unit takes its addend from registers
+ * or from a small literal only), so a filtered sum comes out as  sum - 128 x 32 = sum - 4096  and what each user adds back is written at its place. */
+constexpr uint64_t FQ_SIGN = 0x8080808080808080ull;
+/* four sums of six taps (d = sum - 4096) -> four half samples clip_u8((sum + 16) >> 5) as bytes 0..3 */
+__device__ __forceinline__ uint32_t fq_half_samples(const int d[4])
 {
-    uint32_t p01 = byte_perm((uint32_t)d[1], (uint32_t)d[0], 0x05040100u), p23 = byte_perm((uint32_t)d[3], (uint32_t)d[2], 0x05040100u);
-    if (SH) { p01 = pk_ashr(p01, SH); p23 = pk_ashr(p23, SH); }
+    const uint32_t p01 = pk_ashr(pk_add(byte_perm((uint32_t)d[1], (uint32_t)d[0], 0x05040100u), 0x10101010u), 5);       /* + 4096 + 16 on both halves */
+    const uint32_t p23 = pk_ashr(pk_add(byte_perm((uint32_t)d[3], (uint32_t)d[2], 0x05040100u), 0x10101010u), 5);
     return byte_perm(pk_sat_u8(p23), pk_sat_u8(p01), 0x05040100u);
 }
 /* byte B of four values as one dword */
@@ -315,45 +365,55 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
     /* b of window row `row0` + this lane's row: a direct product, the filter on the column side */
     auto hband = [&](int row0) -> uint32_t {
         int d[4];
-        fq_mfma(k.t6, fq_lds64(base + k.a1 + (uint32_t)(48 * row0 + so2)) ^ FQ_SIGN, 4096 + 16, d);
-        return fq_pack16<5>(d);
+        const uint32_t off = (uint32_t)(48 * row0 + so2);
+        fq_mfma(k.t6, fq_bytes8(base + k.a1 + (off & ~3u), off & 3u) ^ FQ_SIGN, 0, d);
+        return fq_half_samples(d);
     };
-    auto gsamples = [&](int dy, int dx) -> uint32_t { return fq_lds32(base + k.a2 + (uint32_t)(48 * (2 + dy) + so2 + 2 + dx)); };
-    /* the window transposed through a product whose result a lane holds as four rows of column (lane & 15): with the identity the raw
-     * samples of columns dx .. dx + 15 (one byte plane), with the filter the unclipped horizontal sums (a low and a high byte plane) */
+    auto gsamples = [&](int dy, int dx) -> uint32_t {
+        const uint32_t off = (uint32_t)(48 * (2 + dy) + so2 + 2 + dx);
+        return fq_bytes4(base + k.a2 + (off & ~3u), off & 3u);
+    };
+    /* the window transposed through a product whose result a lane holds as four rows of column (lane & 15).  With the identity: the samples of
+     * columns dx .. dx + 15 as they are needed next, u ^ 0x80 (the low byte of u - 128), one byte plane.  With the filter: the unclipped horizontal sums
+     * H - 4096 (-6646 .. 6614) as a low byte plane (H & 255, kept as (H & 255) ^ 0x80 for the product to come) and a high one ((H >> 8) - 16, signed) */
     auto transpose = [&](bool filtered, int dx) {
         const uint32_t off = (uint32_t)(so2 + dx);
-        const uint64_t x0 = fq_lds64(base + k.a1 + off) ^ FQ_SIGN, x1 = fq_lds64(base + k.a1 + 768u + off) ^ FQ_SIGN;
+        const uint64_t x0 = fq_bytes8(base + k.a1 + (off & ~3u), off & 3u) ^ FQ_SIGN, x1 = fq_bytes8(base + k.a1b + (off & ~3u), off & 3u) ^ FQ_SIGN;
         int d0[4], d1[4];
         if (filtered) {
-            fq_mfma(x0, k.t6, 4096, d0);
-            fq_mfma(x1, k.t6, 4096, d1);
-            *reinterpret_cast<uint32_t *>(base + k.a4) = fq_bytes<0>(d0);
-            *reinterpret_cast<uint32_t *>(base + k.a5) = fq_bytes<0>(d1);
+            fq_mfma(x0, k.t6, 0, d0);
+            fq_mfma(x1, k.t6, 0, d1);
+            *reinterpret_cast<uint32_t *>(base + k.a4) = fq_bytes<0>(d0) ^ 0x80808080u;
+            *reinterpret_cast<uint32_t *>(base + k.a5) = fq_bytes<0>(d1) ^ 0x80808080u;
             *reinterpret_cast<uint32_t *>(base + k.a4 + FQ_PLANE) = fq_bytes<1>(d0);
             *reinterpret_cast<uint32_t *>(base + k.a5 + FQ_PLANE) = fq_bytes<1>(d1);
         } else {
-            fq_mfma(x0, k.i2, 128, d0);
-            fq_mfma(x1, k.i2, 128, d1);
+            fq_mfma(x0, k.i2, 0, d0);
+            fq_mfma(x1, k.i2, 0, d1);
             *reinterpret_cast<uint32_t *>(base + k.a4 + 2 * FQ_PLANE) = fq_bytes<0>(d0);
             *reinterpret_cast<uint32_t *>(base + k.a5 + 2 * FQ_PLANE) = fq_bytes<0>(d1);
         }
         MI355_WAVE_SYNC();
     };
-    /* h: the vertical filter over the raw transposed plane */
+    /* h: the vertical filter over the transposed samples */
     auto vraw = [&]() -> uint32_t {
         int d[4];
-        fq_mfma(fq_lds64(base + k.a6 + 2 * FQ_PLANE) ^ FQ_SIGN, k.t6, 4096 + 16, d);
-        return fq_pack16<5>(d);
+        fq_mfma(fq_lds64(base + k.a6 + 2 * FQ_PLANE), k.t6, 0, d);
+        return fq_half_samples(d);
     };
-    /* j: the vertical filter over the horizontal sums, 256 x (high bytes' sum) + (low bytes' sum) */
+    /* j: the vertical filter over both planes of the horizontal sums.  With lo = sum over ((H & 255) - 128) and hi = sum over ((H >> 8) - 16):
+     * J = 256 hi + lo + 256 x 16 x 32 + 128 x 32 = t + 135168, and clip((J + 512) >> 10) = clip((t / 16 + 8480) >> 6) exactly (t / 16 = 16 hi + (lo >> 4)
+     * floors once more, 135168 + 512 = 16 x 8480; |t / 16 + 8480| < 2^15) */
     auto vsums = [&]() -> uint32_t {
-        int lo[4], hi[4], v[4];
-        fq_mfma(fq_lds64(base + k.a6) ^ FQ_SIGN, k.t6, 4096 + 512, lo);
+        int lo[4], hi[4];
+        uint32_t v[4];
+        fq_mfma(fq_lds64(base + k.a6), k.t6, 0, lo);
         fq_mfma(fq_lds64(base + k.a6 + FQ_PLANE), k.t6, 0, hi);
 #pragma unroll
-        for (int t = 0; t < 4; t++) v[t] = (hi[t] * 256 + lo[t]) >> 10;
-        return fq_pack16<0>(v);
+        for (int t = 0; t < 4; t++) v[t] = (uint32_t)(hi[t] * 16 + (lo[t] >> 4));
+        const uint32_t p01 = pk_ashr(pk_add(byte_perm(v[1], v[0], 0x05040100u), 0x21202120u), 6);
+        const uint32_t p23 = pk_ashr(pk_add(byte_perm(v[3], v[2], 0x05040100u), 0x21202120u), 6);
+        return byte_perm(pk_sat_u8(p23), pk_sat_u8(p01), 0x05040100u);
     };
     uint32_t v;
     switch (pos) {
@@ -382,46 +442,18 @@ __device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, int
 {
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     const uint32_t wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
-    const uint32_t r0 = fq_lds32(base + k.c1 + (uint32_t)oc), r1 = fq_lds32(base + k.c1 + (uint32_t)(oc + 12));
+    const uint32_t at = k.c1 + (uint32_t)oc, sh = at & 3u;                  /* FQ_WC and the 12-byte row pitch are multiples of four */
+    const uint32_t r0 = fq_bytes4(base + (at & ~3u), sh), r1 = fq_bytes4(base + (at & ~3u) + 12, sh);
     const uint32_t d0 = fq_dot4(byte_perm(r1, r0, 0x05040100u), wts, 32u), d1 = fq_dot4(byte_perm(r1, r0, 0x06050201u), wts, 32u);
     *reinterpret_cast<uint16_t *>(base + k.c2) = (uint16_t)((d0 >> 6) | ((d1 >> 6) << 8));
 }
 
-/* ---- one fast macroblock.  The record is in LDS; `next` >= 0: request that macroblock's record as soon as this one's coefficients are in registers ---- */
-__device__ __forceinline__ void fq_mb(MbLds &s, const FqLane &k, const ResidLane &rl, const FrameHot &fr, const FqRec &rec, int mb_x, int mb_y, int next)
-{
-    const int slot = (int)(rec.w12 & 0xFFu);
-    const uint8_t *const *rp = fr.desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0];
-    const uint8_t *ry = mi355_global(rp[0]), *rc = mi355_global(rp[1]);
-    const int mx = (int16_t)(rec.mv0 & 0xFFFF) + mb_x * 64, my = (int16_t)(rec.mv0 >> 16) + mb_y * 64;
-    const int myc = my + (int8_t)(rec.w14 & 0xFFu);                       /* the other-parity field offset, h264_mb.c:287-291 */
-    const FqWin w = fq_windows_issue(s, k, ry, rc, fr, mx, my, myc);
-    /* under the windows' flight: the residual into registers */
-    const uint32_t nnz = rec.nnz;
-    const bool has_chroma = (rec.w2 & 0x30u) != 0, has_resid = (nnz & 0xFFFFu) != 0 || has_chroma;
-    uint32_t o[4] = { 0u, 0u, 0u, 0u };
-    if (has_resid) fq_idct(s, rl, nnz, has_chroma, o);
-    MI355_WAVE_SYNC();                                                     /* every lane has read its coefficients */
-    if (next >= 0) {
-        fq_record_dma(s, fr, next);
-        fq_wait_vm1();                                                     /* the windows are in; the next record may still be on its way */
-    } else {
-        fq_wait_vm0();
-    }
-    MI355_WAVE_SYNC();
-    if (w.patch_y || w.patch_c) {
-        fq_windows_patch(s, k, w, fr.mb_width);
-        MI355_WAVE_SYNC();
-    }
-    fq_luma(s, k, w.so2, (mx & 3) | ((my & 3) << 2));
-    fq_chroma(s, k, w.oc, mx & 7, myc & 7);
-    MI355_WAVE_SYNC();
-    if (has_resid) {
-        fq_resid_add(s, rl, has_chroma, o);
-        MI355_WAVE_SYNC();
-    }
-    store_mb_tiled(s, fr, mb_x, mb_y);
-}
+struct FqPic {          /* what the run keeps of the picture descriptor */
+    const mi355_h264_mb *mb;
+    const int16_t *mv0, *coef;
+    const mi355_h264_frame *desc;
+    FrameHot hot;       /* recon planes and strides for the stores (store_mb_tiled) */
+};
 
 /* ---- any other inter macroblock of the run: h264_recon_dev.h's code, as a FUNCTION — its registers are its own, the run's loop does not pay for them ---- */
 #ifdef MI355_HIP_EMU_H
@@ -430,7 +462,7 @@ static void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int m
 __device__ __attribute__((noinline)) void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int mb_y)
 #endif
 {
-    recon_inter_mb<false, true>(*s, *frd, mb_x, mb_y);
+    if (uniform(frd->surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<false, true>(*s, *frd, mb_x, mb_y);
 }
 
 /* ---- the run: RUN consecutive macroblocks (of the launch's max_w x max_h grid per picture) per wave ---- */
@@ -438,54 +470,91 @@ template <int RUN>
 __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
                                                 unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
 {
+    static_assert(RUN >= 1 && RUN <= 32, "the deferred macroblocks are a 32-bit mask");
     const int first = xcd_linear((int)blockIdx.x, per_xcd) * RUN;
     if (first >= nblocks) return;
     const int n = nblocks - first < RUN ? nblocks - first : RUN;
     const int row = div_magic(first, inv_w);
-    int mb_x = first - row * max_w;
-    int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+    const int mb_x = first - row * max_w;
+    const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
     ResidLane rl;
     resid_lane_issue(rl);
     const FqLane k = fq_lane();
     /* the table has arrived before the run begins: inside it the compiler must find no pending load of its own to wait for (it would wait for the
-     * window and record requests in flight with it) */
+     * window and coefficient requests in flight with it) */
     MI355_PIN(rl.off_a); MI355_PIN(rl.off_b); MI355_PIN(rl.cw); MI355_PIN(rl.dc16); MI355_PIN(rl.misc); MI355_PIN(rl.rc); MI355_PIN(rl.ka); MI355_PIN(rl.kb);
-    FrameHot fr = frame_hot(frames[f]);
-    bool pic_ok = uniform(frames[f].surface_layout) == MI355_SURFACE_TILED && !(uniform(frames[f].flags) & MI355_FRAME_NO_INTER);
-    bool have = false;                  /* this macroblock's record was requested by its predecessor */
-    uint32_t deferred = 0;              /* macroblocks of the run that are not of the fast kind: afterwards, by h264_recon_dev.h's code */
-    FqRec rec = {};
-    for (int i = 0; i < n; i++) {
-        bool requested = false;
-        if (pic_ok && mb_x < fr.mb_width && mb_y < fr.mb_height) {
-            const int mb_xy = mb_y * fr.mb_width + mb_x;
-            if (!have) {
-                rec = fq_rec(fr, mb_xy);
-                fq_record_dma(s, fr, mb_xy);
-                fq_wait_vm0();
-            } else {
-                fq_wait_vm1();          /* the record is in; the predecessor's store may still be on its way */
-            }
-            MI355_WAVE_SYNC();
+    auto picture = [&](int pf, FqPic &pic) -> bool {
+        const mi355_h264_frame &frd = frames[pf];
+        pic.hot = frame_hot(frd);
+        pic.mb = pic.hot.mb; pic.mv0 = pic.hot.mv[0]; pic.coef = pic.hot.coef; pic.desc = &frd;
+        return uniform(frd.surface_layout) == MI355_SURFACE_TILED && !(uniform(frd.flags) & MI355_FRAME_NO_INTER);
+    };
+    FqPic pic;
+    const bool pic_ok = picture(f, pic);
+    /* The run's macroblocks that lie in ONE row of one picture are walked here; what follows a row's end (a launch whose grid is wider than this picture,
+     * a row length that is no multiple of RUN) and every macroblock that is not of the fast kind is left to the general code below */
+    const int n_row = pic_ok && mb_x < pic.hot.mb_width && mb_y < pic.hot.mb_height ? (n < pic.hot.mb_width - mb_x ? n : pic.hot.mb_width - mb_x) : 0;
+    uint32_t deferred = (n < 32 ? (1u << n) - 1u : 0xFFFFFFFFu) & ~(n_row < 32 ? (1u << n_row) - 1u : 0xFFFFFFFFu);
+    if (n_row > 0) {
+        /* The pipeline of a run of fast macroblocks.  In macroblock i's turn:
+         *   the windows of macroblock i + 1 are requested (into the other window set) — they have this whole turn to arrive;
+         *   ONE wait: everything requested for macroblock i in the turn before (windows, coefficients) has landed — only the two requests just made
+         *   may still be out (loads complete in issue order);
+         *   coefficients -> residual in registers; the coefficients of macroblock i + 1 are requested into the place just read;
+         *   prediction from window set i & 1, residual on top, store.
+         * What was not requested ahead (the run's first macroblock, the one after a macroblock of another kind) is requested at the head of its own turn. */
+        const int mb_xy0 = mb_y * pic.hot.mb_width + mb_x;
+        bool pre_w = false, pre_c = false;      /* this macroblock's windows / coefficients were requested in the turn before */
+        /* one turn; two copies of it alternate (window set 0 / 1, the two records' and windows' scalars changing roles) so that nothing is moved between turns */
+        auto turn = [&](int i, const FqRec &rec, FqRec &nrec, FqWin &w, FqWin &wn, auto set) {
+            constexpr int woff = decltype(set)::value;
+            const bool has_next = i + 1 < n_row;
+            if (has_next) nrec = fq_rec(pic.mb, pic.mv0, mb_xy0 + i + 1);
+            bool next_w = false, next_c = false;
             if (!(rec.mb_type & MI355_MB_INTRA)) {
                 if (fq_is_fast(rec)) {
-                    requested = i + 1 < n && mb_x + 1 < max_w && mb_x + 1 < fr.mb_width;
-                    const FqRec cur = rec;
-                    if (requested) rec = fq_rec(fr, mb_xy + 1);
-                    fq_mb(s, k, rl, fr, cur, mb_x, mb_y, requested ? mb_xy + 1 : -1);
+                    const bool has_chroma = fq_has_chroma(rec), has_resid = fq_has_resid(rec);
+                    if (!pre_w) w = fq_windows_issue(s, k, pic.desc, pic.hot, rec, mb_x + i, mb_y, woff);
+                    if (has_resid && !pre_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i);
+                    next_w = has_next && !(nrec.mb_type & MI355_MB_INTRA) && fq_is_fast(nrec);
+                    if (next_w) wn = fq_windows_issue(s, k, pic.desc, pic.hot, nrec, mb_x + i + 1, mb_y, woff ^ FQ_WSTEP);
+                    /* LOADS complete in issue order, a store's acknowledgement may overtake them: "at most 2 outstanding" with the two window requests of
+                     * macroblock i + 1 youngest means every older load has landed whatever the predecessor's store is doing (a count that allowed for the
+                     * store as well returned with coefficients still in flight: found on the device, never in the emulator).  Without younger loads: all. */
+                    if (next_w) fq_wait_vm2(); else fq_wait_vm0();
+                    MI355_WAVE_SYNC();
+                    uint32_t o[4] = { 0u, 0u, 0u, 0u };
+                    if (has_resid) fq_idct(s, k, rl, rec.nnz, has_chroma, rec.dcq1, rec.dcq2, o);
+                    MI355_WAVE_SYNC();                                     /* every lane has read its coefficients */
+                    next_c = next_w && fq_has_resid(nrec);
+                    if (next_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i + 1);
+                    if (w.patch_y || w.patch_c) {
+                        fq_windows_patch(s, k, w, pic.hot.mb_width);
+                        MI355_WAVE_SYNC();
+                    }
+#ifndef FQ_EXP_NO_MC
+                    fq_luma(s, k, w.so2w, w.pos);
+                    fq_chroma(s, k, w.ocw, w.fxc, w.fyc);
+#endif
+                    MI355_WAVE_SYNC();
+                    if (has_resid) {
+                        fq_resid_add(s, rl, has_chroma, o);
+                        MI355_WAVE_SYNC();
+                    }
+#ifndef FQ_EXP_NO_STORE
+                    store_mb_tiled(s, pic.hot, mb_x + i, mb_y);
+#endif
                 } else {
                     deferred |= 1u << i;
                 }
             }
-        }
-        have = requested;
-        if (++mb_x == max_w) {
-            mb_x = 0;
-            if (++mb_y == max_h) { mb_y = 0; f++; }
-            if (mb_y == 0 && i + 1 < n) {
-                fr = frame_hot(frames[f]);
-                pic_ok = uniform(frames[f].surface_layout) == MI355_SURFACE_TILED && !(uniform(frames[f].flags) & MI355_FRAME_NO_INTER);
-            }
+            pre_w = next_w; pre_c = next_c;
+        };
+        FqRec rec0 = fq_rec(pic.mb, pic.mv0, mb_xy0), rec1 = rec0;
+        FqWin w0 = {}, w1 = {};
+        for (int i = 0; i < n_row; i += 2) {
+            turn(i, rec0, rec1, w0, w1, std::integral_constant<int, 0>());
+            if (i + 1 < n_row) turn(i + 1, rec1, rec0, w1, w0, std::integral_constant<int, FQ_WSTEP>());
         }
     }
     /* two lists, weights, partitions, the 8x8 transform: one macroblock per pass of the general code, nothing of the run's state alive */

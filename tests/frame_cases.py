@@ -199,3 +199,24 @@ def run_surface_convert(backend, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24,
         for p in bufs:
             lib.mi355_free(p)
     return len(cases)
+
+
+def run_fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, replicate=None, **kw):
+    """the bench generator's pictures through the single-layout entry points on tiled surfaces (k_recon_inter_tiled: the run kernel of
+    h264_recon_fast.h), every sample of both surfaces of every picture against the oracle"""
+    fs = HF.synth_frames_fast(nframes, mb_w, mb_h, seed=seed, lib=backend.lib, **kw)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    F = replicate or nframes
+    d = HF.DeviceFrames(backend, fs, tiled=True, replicate=replicate) if replicate else HF.DeviceFrames(backend, fs, tiled=True)
+    try:
+        d.decode_by_layout()
+        for first in range(0, F, 32):
+            n = min(32, F - first)
+            recon_g, dst_g = (d.fetch(d.recon, first, n), d.fetch(d.dst, first, n)) if replicate else (d.fetch(d.recon), d.fetch(d.dst))
+            for i in range(n):
+                g = (first + i) % fs.F
+                for p in range(3):
+                    assert np.array_equal(recon_o[p][g], recon_g[p][i]), "picture %d: reconstruction differs in plane %d" % (first + i, p)
+                    assert np.array_equal(dst_o[p][g], dst_g[p][i]), "picture %d: deblocked picture differs in plane %d" % (first + i, p)
+    finally:
+        d.free()

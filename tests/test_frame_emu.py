@@ -180,20 +180,7 @@ def test_second_kernel_set_10bit_sanity_emulated(emu, oracle, name):
         assert (np.abs(runs[0][p].astype(np.int32) / 4.0 - dst8[p]) <= 1.0).mean() > 0.9, (name, p)
 
 
-def _fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, **kw):
-    """the bench generator's pictures through the single-layout entry points on tiled surfaces (k_recon_inter_tiled: the run kernel of
-    h264_recon_fast.h), every sample of both surfaces against the oracle"""
-    fs = HF.synth_frames_fast(nframes, mb_w, mb_h, seed=seed, lib=backend.lib, **kw)
-    recon_o, dst_o = HF.run_oracle(oracle, fs)
-    d = HF.DeviceFrames(backend, fs, tiled=True)
-    try:
-        d.decode_by_layout()
-        recon_g, dst_g = d.fetch(d.recon), d.fetch(d.dst)
-    finally:
-        d.free()
-    for p in range(3):
-        assert np.array_equal(recon_o[p], recon_g[p])
-        assert np.array_equal(dst_o[p], dst_g[p])
+_fast_workload_by_layout = frame_cases.run_fast_workload_by_layout
 
 
 def test_full_size_1080p_picture_emulated_run_kernel(emu, oracle):

@@ -241,3 +241,24 @@ def test_second_kernel_set_loop_filter_units_under_load(mi355, oracle, monkeypat
                     assert np.array_equal(got[p][f], dst_o[p][f % fs.F]), (unit, f, p)
     finally:
         d.free()
+
+
+def test_full_size_1080p_batch_run_kernel(mi355, oracle):
+    """three 1080p pictures of the headline workload through k_recon_inter_tiled (the run kernel: raw LDS-DMA windows, the 6-tap filters as
+    v_mfma_i32_16x16x32_i8 products, coefficients of the next macroblock in flight), every sample of both surfaces"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x264)
+
+
+@pytest.mark.parametrize("mv_range", (64, 200, 1200))
+@pytest.mark.parametrize("mb_w,mb_h", ((7, 5), (1, 1), (2, 3), (3, 1), (5, 9)))
+def test_run_kernel_windows_over_every_border(mi355, oracle, mb_w, mb_h, mv_range):
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, mb_w, mb_h, 0x2650 + mv_range + mb_w, mv_range=mv_range)
+
+
+def test_run_kernel_mixed_partitions(mi355, oracle):
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)
+
+
+def test_run_kernel_many_pictures(mi355, oracle):
+    """the same under load: 256 pictures in one launch (every SIMD at eight waves, requests of several macroblocks in flight per wave), all compared"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x2265, replicate=256)
