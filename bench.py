@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
+    ap.add_argument("--pipelines", type=int, default=4, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
+                    "HIP stream through the three passes: one pipeline's loop filter (bound by instruction issue) runs beside another's reconstruction (bound by the "
+                    "memory pipeline); 1 = the three passes over the whole batch one after the other (how rounds 1-4 measured)")
     ap.add_argument("--mb-width", type=int, default=120)
     ap.add_argument("--mb-height", type=int, default=68)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,25 +150,37 @@ def main():
                           ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = at
-    stream = None   # the null stream: every launch and every event below is on it
+    # the batch as P pipelines of F / P pictures, each on its own stream (P = 1: the null stream); every event below is recorded on the stream of the launches it brackets
+    P = args.pipelines if args.pipelines > 0 and F % args.pipelines == 0 and F // args.pipelines >= 1 else 1
+    lib.mi355_stream_create.restype = C.c_void_p
+    streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(P)] if P > 1 else [None]
+    per = F // P
+    frame_bytes = C.sizeof(dev.host_desc) // F
 
     def step(events=None):
-        if events is not None:
-            lib.mi355_event_record(events[0], stream)
-        assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[tiled], stream) == 0
-        if events is not None:
-            lib.mi355_event_record(events[1], stream)
-        assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, big.max_intra_level, level_widths(big), stream) == 0
-        if events is not None:
-            lib.mi355_event_record(events[2], stream)
-        assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[tiled], stream) == 0
-        if events is not None:
-            lib.mi355_event_record(events[3], stream)
+        for p_, st in enumerate(streams):
+            d = C.c_void_p(dev.d_desc + p_ * per * frame_bytes)
+            ev = events[p_] if events is not None else None
+            if ev is not None:
+                lib.mi355_event_record(ev[0], st)
+            assert lib.mi355_h264_recon_inter_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
+            if ev is not None:
+                lib.mi355_event_record(ev[1], st)
+            assert lib.mi355_h264_recon_intra_levels_dev(d, per, big.max_intra_level, level_widths(big), st) == 0
+            if ev is not None:
+                lib.mi355_event_record(ev[2], st)
+            assert lib.mi355_h264_deblock_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
+            if ev is not None:
+                lib.mi355_event_record(ev[3], st)
+
+    def sync_all():
+        for st in streams:
+            assert lib.mi355_sync(st) == 0
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        assert lib.mi355_sync(stream) == 0
+        sync_all()
 
     for _ in range(args.warmup):
         step()
@@ -173,27 +188,32 @@ def main():
     evs = []
     barrier()
     t0 = time.perf_counter()
+    def new_events():
+        return [[lib.mi355_event_create() for _ in range(4)] for _ in range(P)]
     if queue is None:
         for k in range(args.steps):
-            evs.append([lib.mi355_event_create() for _ in range(4)])
+            evs.append(new_events())
             step(evs[-1])
     else:
         # one batch in flight plus one queued: a rank only pulls when its previous-but-one batch has finished
         while True:
             if len(evs) >= 2:
-                lib.mi355_event_elapsed_ms(evs[-2][0], evs[-2][3])      # waits for that batch's last event
+                for e in evs[-2]:
+                    lib.mi355_event_elapsed_ms(e[0], e[3])      # waits for that batch's last events
             if queue.next() is None:
                 break
-            evs.append([lib.mi355_event_create() for _ in range(4)])
+            evs.append(new_events())
             step(evs[-1])
-    assert lib.mi355_sync(stream) == 0
+    sync_all()
     barrier()
     elapsed = time.perf_counter() - t0
     my_steps = len(evs)
 
-    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for e in evs) / max(1, my_steps)
-    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for e in evs) / max(1, my_steps)
-    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for e in evs) / max(1, my_steps)
+    # per LAUNCH (one pipeline's share of the batch): with P > 1 the launches of different pipelines run side by side, so the passes' times do not add up to the step
+    nl = max(1, my_steps * P)
+    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for st_ in evs for e in st_) / nl
+    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for st_ in evs for e in st_) / nl
+    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for st_ in evs for e in st_) / nl
 
     elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * my_steps, ctl)
     steps_per_rank = shard.gather_counts(my_steps, ctl)
@@ -204,11 +224,11 @@ def main():
         n_intra = int(sum(len(big.intra_list[f % G]) for f in range(F)))
         n_inter = F * nmb - n_intra
         # dominant kernel = the pass with the largest share of the step (the loop filter is ONE launch for all bands of all pictures since round 4)
-        passes = {"k_recon_inter_tiled" if tiled else "k_recon_inter": (t_inter, 1, n_inter * B_RECON),
-                  "k_deblock_tiled" if tiled else "k_deblock_linear": (t_deblock, 1, F * nmb * B_DEBLOCK)}
+        passes = {"k_recon_inter_tiled" if tiled else "k_recon_inter": (t_inter, P, n_inter * B_RECON),
+                  "k_deblock_tiled" if tiled else "k_deblock_linear": (t_deblock, P, F * nmb * B_DEBLOCK)}
         dom = max(passes, key=lambda k: passes[k][0])
-        t_pass, launches, bytes_pass = passes[dom]
-        achieved = bytes_pass / launches / (t_pass / launches * 1e-3)   # algorithmic bytes per launch / avg launch time
+        t_pass, launches, bytes_pass = passes[dom]               # t_pass: the average duration of ONE launch (HIP events on its stream)
+        achieved = bytes_pass / launches / (t_pass * 1e-3)       # algorithmic bytes per launch / avg launch time
         out = {
             "metric": "macroblocks_per_s", "value": value, "unit": "macroblocks/s",
             "frames_per_s": value / nmb, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,24 +237,25 @@ def main():
             "steps_per_rank": steps_per_rank,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "H.264 8-bit 4:2:0 1080p (1920x1088 coded), P pictures: qpel MC + idct_add + deblock, "
-                                   "two-surface pipeline, %d independent pictures per GPU per step "
-                                   "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, G),
+                                   "two-surface pipeline, %d independent pictures per GPU per step as %d pipeline(s) of %d on their own HIP streams "
+                                   "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, P, per, G),
                        "surface_layout": "macroblock-tiled decoded-picture-buffer surfaces (256-byte luma + 128-byte chroma tiles; "
                                          "a picture is de-tiled only when it leaves HBM: extra point config2_f2048_detile)" if tiled
                                          else "planes with line strides",
-                       "frames_per_gpu": F, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
+                       "frames_per_gpu": F, "pipelines": P, "frames_per_launch": per, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
                        "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
                        "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world,
                        "verified_by": "tests/test_frame_gpu.py::test_full_size_1080p_batch_matches_oracle (same generator, bit-exact)"},
             "pass_ms": {"recon_inter": t_inter, "recon_intra": t_intra, "deblock": t_deblock},
+            "pass_ms_is": "average duration of one launch (%d pictures) by HIP events on its stream%s" % (per, "; the %d pipelines' launches overlap: the passes do not add up to ms_per_step" % P if P > 1 else ""),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "launches_per_step": launches, "avg_launch_us": t_pass / launches * 1e3,
+                         "launches_per_step": launches, "avg_launch_us": t_pass * 1e3,
                          "algorithmic_bytes_per_launch": bytes_pass / launches},
         }
         # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
         # (tools/gpu_traffic.sh -> profiles/*hbm_traffic*.json; cannot be collected from inside this process)
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, F)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, per)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fs, args.cpu_seconds)
         dev.free()
@@ -261,6 +282,8 @@ def main():
                     if isinstance(p.get("cpu_baseline"), dict):
                         p["cpu_baseline"].pop("sample", None)
         out["config"]["points"] = points
+        for k_, v_ in points.items():               # ... and flat (the driver's record keeps the scalars of `config`, not nested objects)
+            out["config"]["p_" + k_] = v_
         print(json.dumps(out))
     if dev is not None:
         dev.free()
@@ -342,6 +365,13 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
                     "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "pass_ms": passes, "note": note})
 
     base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
+    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
+        try:
+            r = fn(lib)
+            pts.extend(r if isinstance(r, list) else [r])
+        except Exception as e:                 # an extra point must not take the headline line down with it
+            pts.append({"name": fn.__name__, "error": repr(e)})
+    # the config-2 family LAST on the line (the driver's record keeps the line's last 16 KB)
     if tiled:
         run("config2_f2048_detile", base, 2048, "the headline workload with every finished picture also converted to planes with line strides "
             "(mi355_h264_surface_convert_dev: what a picture costs when it LEAVES HBM — display, host copy, a consumer that wants lines; "
@@ -353,6 +383,8 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         "quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each), one vector per partition, one reference per partition / quadrant: 5.6 prediction blocks "
         "and reference windows per macroblock on average instead of 1 (the algorithmic bytes stay 2432 per macroblock: the fraction is against the "
         "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
+    run("config2_f2048_one_pipeline", base, 2048, "the headline batch as ONE pipeline on one stream: the three passes over all 2048 pictures one after the other "
+        "(how rounds 1-4 measured the headline; pass_ms here are the passes' own times)")
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
     run("config2_f512", base, 512, "512 pictures per step")
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
@@ -360,12 +392,6 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
         "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
-    for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
-        try:
-            r = fn(lib)
-            pts.extend(r if isinstance(r, list) else [r])
-        except Exception as e:                 # an extra point must not take the headline line down with it
-            pts.append({"name": fn.__name__, "error": repr(e)})
     # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set — last: its 2048 pictures take
     # 100 GB of HBM, and the decoder processes of the real-stream points above should not start beside an allocator that has just let go of them
     try:

@@ -137,7 +137,7 @@ typedef struct Bound {
     mi355_sws_ctx *dev;
     int failed;                   /* the device side does not take this context: the reference's function from now on */
     int busy;                     /* calls of mi355_sws_scale in flight on `dev` (under bound_mu): the device context is destroyed only at 0 */
-    unsigned long stamp;          /* last use: the slot with the oldest stamp is recycled when the table is full */
+    unsigned long stamp;          /* last use (diagnostics) */
     uint8_t y_table[1024];        /* the tables the device context was built from */
     int32_t gv0;
 } Bound;
@@ -164,14 +164,16 @@ static void slot_release(Bound *b)
 }
 static Bound *bound_find(SwsContext *c, int create)
 {
-    Bound *free_slot = NULL, *oldest = NULL;
+    Bound *free_slot = NULL;
     for (int i = 0; i < MI355_SWS_SLOTS; i++) {
         if (bound[i].c == c) return &bound[i];
         if (!free_slot && !bound[i].c) free_slot = &bound[i];
-        if (bound[i].c && !bound[i].busy && (!oldest || bound[i].stamp < oldest->stamp)) oldest = &bound[i];
     }
     if (!create) return NULL;
-    if (!free_slot && oldest) { slot_release(oldest); free_slot = oldest; }     /* table full: the least recently used context loses its device side */
+    /* Table full: the new context stays UNBOUND (bind() hands back the reference's function).  A slot is never taken from another context: it may be
+     * alive — its SwsContext.swscale points here, and without its slot a call could neither reach the device nor the reference's function
+     * (an eviction turned such a call into "0 lines, no error").  Slots come back through sws_freeContext (--wrap) or when a new context
+     * is built at a freed one's address; a host linked without the wrap that leaks 256 addresses runs further contexts on the CPU, correctly. */
     if (free_slot) { memset(free_slot, 0, sizeof(*free_slot)); free_slot->c = c; }
     return free_slot;
 }
@@ -220,6 +222,7 @@ static int mi355_swsfunc(SwsContext *c, const uint8_t *src[], int srcStride[], i
         if (n > 0) { __sync_fetch_and_add(&n_pictures, 1); return n; }
         /* a failed copy / launch / allocation: this picture by the reference's function (mi355_sws_scale leaves the context usable) */
     }
+    /* real == NULL: no slot for a context whose swscale points here — only a context used after sws_freeContext gets this far (slots are never taken away) */
     return real ? real(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride) : 0;
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
 }
 
 /* h264_frame_tiled.hip: launches k_recon_inter_tiled (the tiled-only instance of the inter reconstruction kernel) */
-void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd, hipStream_t stream);
+void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int nframes, int max_w, int max_h, hipStream_t stream);
 /* h264_deblock.hip: the scratch words (ticket + progress counters) of a single-launch loop filter, one buffer per (thread, device, stream); the caller zeroes what it uses on `stream` */
 uint32_t *sync_words(hipStream_t stream, size_t words);
 }  // namespace mi355

@@ -9,24 +9,35 @@
 #define MI355_PLAIN_LANE 1
 #include "h264_recon_fast.h"
 
-#ifndef MI355_RECON_RUN
-#define MI355_RECON_RUN 8
-#endif
+#include <cstdlib>
 
 namespace {
 __attribute__((amdgpu_waves_per_eu(MI355_RECON_WAVES, MI355_RECON_WAVES)))
 __global__ void __launch_bounds__(64)
-k_recon_inter_tiled(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+k_recon_inter_tiled(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, int run, int runs_row, unsigned long long inv_runs, unsigned long long inv_h, int nwaves, int per_xcd)
 {
     __shared__ MbLds s;
-    recon_inter_run<MI355_RECON_RUN>(s, frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
+    recon_inter_run(s, frames, max_w, max_h, run, runs_row, inv_runs, inv_h, nwaves, per_xcd);
 }
 }  // namespace
 
 namespace mi355 {
-void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, unsigned long long inv_w, unsigned long long inv_h, int nblocks, int /*per_xcd*/, hipStream_t stream)
+/* nframes pictures of a max_w x max_h grid.  The run length: long runs spread the per-wave set-up (lane constants, the run's description) over more
+ * macroblocks, short ones keep a small batch's waves many enough to fill the device (256 CUs x 32 waves) */
+void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int nframes, int max_w, int max_h, hipStream_t stream)
 {
-    const int waves = (nblocks + MI355_RECON_RUN - 1) / MI355_RECON_RUN, per_xcd = (waves + 7) / 8;
-    hipLaunchKernelGGL(k_recon_inter_tiled, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, stream, d_frames, max_w, max_h, inv_w, inv_h, nblocks, per_xcd);
+    static const int forced = std::getenv("MI355_RECON_RUN") ? std::atoi(std::getenv("MI355_RECON_RUN")) : 0;
+    /* some forty rounds of the device's 8192 wave slots keep the last round's idle slots a few per cent of the launch; beyond that, longer runs */
+    const long long mbs = (long long)nframes * max_w * max_h;
+    int run = forced > 0 ? forced : (int)(mbs / (40ll * 8192));
+    run = run < 4 ? 4 : (run > 15 ? 15 : run);
+    if (run > max_w) run = max_w;
+    const int runs_row = (max_w + run - 1) / run;
+    run = (max_w + runs_row - 1) / runs_row;                      /* a row's runs of equal length */
+    const unsigned long long one = 1ull << 40;
+    const long long total = (long long)nframes * max_h * runs_row;
+    const int nwaves = (int)total, per_xcd = (nwaves + 7) / 8;
+    hipLaunchKernelGGL(k_recon_inter_tiled, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, stream, d_frames, max_w, max_h, run, runs_row,
+                       (one + runs_row - 1) / runs_row, (one + max_h - 1) / max_h, nwaves, per_xcd);
 }
 }  // namespace mi355

@@ -26,7 +26,6 @@
 #ifndef MI355_H264_RECON_FAST_H
 #define MI355_H264_RECON_FAST_H
 
-#include <type_traits>
 #include "h264_recon_dev.h"
 
 namespace {
@@ -36,14 +35,16 @@ namespace {
  * second halves: a lane pair reads (dword h, h + 2) of one piece per access, and with the pieces of a block 32 bytes apart the 24 blocks met in four of the
  * LDS's eight bank groups (six lanes per bank: 16 cycles a read, tools/ubench/lds_rate.hip); 16 bytes apart they spread over all eight */
 constexpr int FQ_COEF = (int)offsetof(MbCore, coef);
-constexpr int FQ_WY = MB_PC_OFF + 128;          /* 1344: raw luma window, piece L (16 bytes) at 16 L: row L / 3 = 48 bytes = picture columns 16 t0 .. 16 t0 + 47 */
+constexpr int FQ_RS = FQ_COEF + 768;            /* 960: the residual, int16: luma [16 rows][16], then chroma [plane][8 rows][8] — where the other paths keep their prediction tiles */
+constexpr int FQ_RSC = FQ_RS + 512;
+constexpr int FQ_ST = FQ_RS;                    /* ... and, once a lane holds its residual, the finished macroblock in tile order (luma 256 bytes, chroma 128 from FQ_ST + 256 — below FQ_RSC) on its way out */
+constexpr int FQ_WY = FQ_RS + 768;              /* 1728: raw luma window, piece L (16 bytes) at 16 L: row L / 3 = 48 bytes = picture columns 16 t0 .. 16 t0 + 47 */
 constexpr int FQ_WC = FQ_WY + 1024;             /* raw chroma window [plane][row 0..8][12 bytes], dword q at 4 q: columns (cx & ~3) .. + 11; all 64 lanes of the request write (216 bytes used of 256) */
-constexpr int FQ_PL = FQ_WC + 256;              /* three transposed planes [column 0..15][24 rows]: low bytes, high bytes, raw samples */
+constexpr int FQ_PL = FQ_WC + 256;              /* two transposed planes [column 0..15][24 rows]: low bytes (or the samples themselves), high bytes */
 constexpr int FQ_PLANE = 16 * 24 + 8;           /* the last column's operand read runs eight bytes past its rows */
 constexpr int FQ_DUMP = FQ_PL + 16 * 24;        /* where the lanes that hold no row of a product's second half write: the plane's own tail */
-constexpr int FQ_WSTEP = 2464;                  /* the second set of windows (the NEXT macroblock's, in flight while this one is predicted) lies this far behind the first */
-static_assert(FQ_WY == 1344 && (FQ_WY % 16) == 0 && (FQ_PL % 8) == 0 && FQ_PL + 3 * FQ_PLANE <= FQ_WY + FQ_WSTEP && (FQ_WSTEP % 16) == 0 &&
-              FQ_WC + FQ_WSTEP + 256 <= (int)sizeof(MbLds), "fast-path regions inside MbLds");
+constexpr int FQ_WSTEP = FQ_PL + 2 * FQ_PLANE - FQ_WY;      /* the second set of windows (the NEXT macroblock's, in flight while this one is predicted) lies this far behind the first */
+static_assert(FQ_RS == MB_PY_OFF && (FQ_WY % 16) == 0 && (FQ_PL % 8) == 0 && (FQ_WSTEP % 16) == 0 && FQ_WC + FQ_WSTEP + 256 <= (int)sizeof(MbLds), "fast-path regions inside MbLds");
 static_assert(FQ_WY + FQ_WSTEP + 48 * 20 + 24 + 16 + 12 <= (int)sizeof(MbLds), "the second half of a transposing product reads window rows 16..20");
 
 /* ---- primitives: one instruction each on the device, their plain meaning in the emulator ---- */
@@ -141,16 +142,19 @@ struct FqLane {
     uint32_t a1;            /* FQ_WY + 48 row + 8 g: this lane's eight bytes of a window-row operand (+ o + 2 + ...) */
     uint32_t a1b;           /* ... of window row 16 + row (the second half of a transposing product; rows past 20 do not exist: those lanes read a1 again) */
     uint32_t a2;            /* FQ_WY + 48 row + 4 g: this lane's four integer samples (+ 48 (2 + dy) + o + 4 + dx) */
-    uint32_t a3;            /* MB_PY_OFF + 16 row + 4 g: where its four predicted samples go */
+    uint32_t sy;            /* 16 row + 4 g: where its four samples lie in the luma tile (the store's offset) */
+    uint32_t rsy;           /* FQ_RS + 32 row + 8 g: their residual */
     uint32_t a4, a5;        /* 24 (lane & 15) + 4 g: its four rows in a transposed plane, first / second half of the window rows (g >= 2: FQ_DUMP) */
     uint32_t a6;            /* 24 (lane & 15) + 8 g: its eight rows of a transposed-plane operand */
     uint64_t t6;            /* the 6-tap filter as a product operand: byte b = tap (8 g + b) - (lane & 15) of (1, -5, 20, 20, -5, 1) */
     uint64_t i2;            /* the identity shifted by the two columns in front of the block: byte b = 1 where 8 g + b == (lane & 15) + 2 */
     /* chroma: plane lane >> 5, row (lane >> 2) & 7, samples 2 c, 2 c + 1 (c = lane & 3) */
     uint32_t c1;            /* FQ_WC + 108 plane + 12 row + 2 c */
-    uint32_t c2;            /* MB_PC_OFF + 64 plane + 8 row + 2 c */
+    uint32_t sc;            /* 64 plane + 8 row + 2 c: where its two samples lie in the chroma tile */
+    uint32_t rsc;           /* FQ_RSC + 128 plane + 16 row + 4 c: their residual */
     /* residual: lane 2 b + h holds columns 2 h, 2 h + 1 of block b (residual_blocks's arrangement) */
     uint32_t cwf;           /* where its first coefficient pair lies in the fast path's coefficient layout (below) */
+    uint32_t wa, wb;        /* where the four residuals of its two rows go (eight bytes each) */
     uint32_t csrc;          /* coefficient fetch: the byte offset in the macroblock's 768 bytes of the piece that goes to LDS slot `lane` */
 };
 __device__ __forceinline__ FqLane fq_lane()
@@ -168,7 +172,8 @@ __device__ __forceinline__ FqLane fq_lane()
     k.a1 = (uint32_t)(FQ_WY + 48 * row + 8 * g);
     k.a1b = row < 5 ? k.a1 + 768u : k.a1;
     k.a2 = (uint32_t)(FQ_WY + 48 * row + 4 * g);
-    k.a3 = (uint32_t)(MB_PY_OFF + 16 * row + 4 * g);
+    k.sy = (uint32_t)(16 * row + 4 * g);
+    k.rsy = (uint32_t)(FQ_RS + 32 * row + 8 * g);
     k.a4 = (uint32_t)(FQ_PL + 24 * row + 4 * g);
     k.a5 = g < 2 ? k.a4 + 16u : (uint32_t)FQ_DUMP;
     k.a6 = (uint32_t)(FQ_PL + 24 * row + 8 * g);
@@ -180,41 +185,80 @@ __device__ __forceinline__ FqLane fq_lane()
     k.i2 = s1 >= 64 || s1 < 0 ? 0ull : 1ull << s1;
     const int cp = lane >> 5, cy = (lane >> 2) & 7, c = lane & 3;
     k.c1 = (uint32_t)(FQ_WC + 108 * cp + 12 * cy + 2 * c);
-    k.c2 = (uint32_t)(MB_PC_OFF + 64 * cp + 8 * cy + 2 * c);
+    k.sc = (uint32_t)(64 * cp + 8 * cy + 2 * c);
+    k.rsc = (uint32_t)(FQ_RSC + 128 * cp + 16 * cy + 4 * c);
     const int blk = lane < 48 ? lane >> 1 : 23;
     k.cwf = (uint32_t)(FQ_COEF + 16 * blk + 4 * (lane & 1));
+    {   /* block blk: luma 4x4 block (x4, y4) in the reference's order, or chroma block blk - 16 = 4 plane + 2 y4 + x4; lane h = 0 holds rows 0 and 3, h = 1 rows 1 and 2 */
+        const int h = lane & 1, ra = h ? 1 : 0, rb = h ? 2 : 3;
+        if (blk < 16) {
+            const int x4 = (blk & 1) + 2 * ((blk >> 2) & 1), y4 = ((blk >> 1) & 1) + 2 * (blk >> 3);
+            k.wa = (uint32_t)(FQ_RS + 32 * (4 * y4 + ra) + 8 * x4);
+            k.wb = (uint32_t)(FQ_RS + 32 * (4 * y4 + rb) + 8 * x4);
+        } else {
+            const int jj = blk & 3, pl = (blk >> 2) & 1;
+            k.wa = (uint32_t)(FQ_RSC + 128 * pl + 16 * (4 * (jj >> 1) + ra) + 8 * (jj & 1));
+            k.wb = (uint32_t)(FQ_RSC + 128 * pl + 16 * (4 * (jj >> 1) + rb) + 8 * (jj & 1));
+        }
+    }
     const int slot = lane < 48 ? lane : 47;
     k.csrc = (uint32_t)(slot < 24 ? 32 * slot : 32 * (slot - 24) + 16);
     return k;
 }
 
-/* ---- the record's scalars ---- */
-struct FqRec {
-    uint32_t mb_type, nnz, w2;      /* w2: cbp | qp << 16 | flags << 24 */
-    uint32_t dcq1, dcq2;            /* dc_qmul[1], dc_qmul[2]: the chroma DC dequantisers */
-    uint32_t w12, w14;              /* inter.ref_pic[0][0..3], inter.chroma_dy[0][0..3] */
-    uint32_t mv0;                   /* the list-0 vector of block 0 */
+/* ---- the run's macroblocks, described ONCE: lane m works out everything about macroblock m of the run that does not depend on a lane — vector, motion position,
+ * window origins, flags, chroma weights — for all of them at a time (one vector instruction per step instead of a scalar one per macroblock and step: the scalar
+ * unit was the kernel's narrowest place), and a macroblock's turn fetches its five words with v_readlane. ---- */
+constexpr uint32_t FQA_PATCH_Y = 1u << 11, FQA_PATCH_C = 1u << 12, FQA_FAST = 1u << 13, FQA_INTRA = 1u << 14, FQA_CHROMA = 1u << 15, FQA_RESID = 1u << 16;
+struct FqRun {
+    uint32_t a;         /* bits 0-4 o + 2 | 5-6 cx & 3 | 7-10 (mx & 3) | (my & 3) << 2 | 11 / 12 luma / chroma window over a side border | 13 fast kind | 14 intra |
+                           15 chroma coefficients | 16 any coefficients | 17-21 reference slot */
+    uint32_t wts;       /* the chroma weights A | B << 8 | C << 16 | D << 24 (h264chroma_template.c:27-40) */
+    uint32_t nnz;
+    uint32_t d;         /* first luma window row iy - 2 (low half, signed) | first chroma window row cy (high half, signed) */
+    uint32_t e;         /* first luma tile column t0 (low half, signed) | first chroma window column c0 (high half, signed) */
 };
-static_assert(offsetof(mi355_h264_mb, cbp) == 8 && offsetof(mi355_h264_mb, flags) == 11 && offsetof(mi355_h264_mb, dc_qmul) == 32 && offsetof(mi355_h264_mb, u) == 48, "the words fq_rec reads");
-__device__ __forceinline__ FqRec fq_rec(const mi355_h264_mb *mb, const int16_t *mv0, int mb_xy)
+static_assert(offsetof(mi355_h264_mb, cbp) == 8 && offsetof(mi355_h264_mb, flags) == 11 && offsetof(mi355_h264_mb, dc_qmul) == 32 && offsetof(mi355_h264_mb, u) == 48, "the words read here");
+struct FqPic {          /* what the run keeps of the picture descriptor */
+    const mi355_h264_mb *mb;
+    const int16_t *mv0, *coef;
+    const mi355_h264_frame *desc;
+    FrameHot hot;       /* recon planes and strides for the stores (store_mb_tiled) */
+};
+__device__ __forceinline__ FqRun fq_describe(const FqPic &pic, int mb_xy0, int mb_x, int mb_y, int n_row)
 {
-    FqRec r;
-    fq_kptr h = fq_konst(mb + mb_xy);
-    r.mb_type = h[0]; r.nnz = h[1]; r.w2 = h[2];
-    r.dcq1 = h[9]; r.dcq2 = h[10];
-    r.w12 = h[12]; r.w14 = h[14];
-    r.mv0 = mv0 ? fq_konst(mv0 + (size_t)mb_xy * 32)[0] : 0u;
+    FqRun r;
+    const int lane = lane_id(), m = lane < n_row ? lane : n_row - 1;
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(mi355_global_v(pic.mb + (mb_xy0 + m)));
+    const uint32_t type = h[0], nnz = h[1], w2 = h[2], w12 = h[12], w14 = h[14];
+    const uint32_t mvw = pic.mv0 ? reinterpret_cast<const uint32_t *>(mi355_global_v(pic.mv0 + (size_t)(mb_xy0 + m) * 32))[0] : 0u;
+    const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x + m) * 64, my = (int16_t)(mvw >> 16) + mb_y * 64;
+    const int myc = my + (int8_t)(w14 & 0xFFu);                           /* the other-parity field offset, h264_mb.c:287-291 */
+    const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
+    const int mbw = pic.hot.mb_width;
+    const int t0 = (ix - 4) >> 4, c0 = cx & ~3;
+    /* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms */
+    const uint32_t want = MI355_MB_16x16 | MI355_MB_P0L0, look = MI355_MB_INTRA | MI355_MB_16x16 | MI355_MB_P0L0 | MI355_MB_P0L1 | MI355_MB_8x8DCT;
+    const bool fast = (type & look) == want && !((w2 >> 24) & MI355_MBF_WEIGHTED);
+    const bool chroma = (w2 & 0x30u) != 0, resid = (nnz & 0xFFFFu) != 0 || chroma;
+    const uint32_t slot = (w12 & 0xFFu) < (uint32_t)MI355_H264_MAX_SLOTS ? (w12 & 0xFFu) : 0u;
+    static_assert(MI355_H264_MAX_SLOTS <= 32, "five bits of slot");
+    r.a = (uint32_t)(((ix - 4) & 15) + 2) | ((uint32_t)(cx & 3) << 5) | ((uint32_t)((mx & 3) | ((my & 3) << 2)) << 7) |
+          (t0 < 0 || t0 + 2 >= mbw ? FQA_PATCH_Y : 0u) | (c0 < 0 || c0 + 11 >= 8 * mbw ? FQA_PATCH_C : 0u) |
+          (fast ? FQA_FAST : 0u) | ((type & MI355_MB_INTRA) ? FQA_INTRA : 0u) | (chroma ? FQA_CHROMA : 0u) | (resid ? FQA_RESID : 0u) | (slot << 17);
+    const int fx = mx & 7, fy = myc & 7;
+    r.wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
+    r.nnz = nnz;
+    r.d = ((uint32_t)(iy - 2) & 0xFFFFu) | ((uint32_t)cy << 16);
+    r.e = ((uint32_t)t0 & 0xFFFFu) | ((uint32_t)c0 << 16);
     return r;
 }
-/* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms */
-__device__ __forceinline__ bool fq_is_fast(const FqRec &r)
-{
-    const uint32_t want = MI355_MB_16x16 | MI355_MB_P0L0;
-    const uint32_t look = MI355_MB_INTRA | MI355_MB_16x16 | MI355_MB_P0L0 | MI355_MB_P0L1 | MI355_MB_8x8DCT;
-    return (r.mb_type & look) == want && !((r.w2 >> 24) & MI355_MBF_WEIGHTED);
-}
-__device__ __forceinline__ bool fq_has_chroma(const FqRec &r) { return (r.w2 & 0x30u) != 0; }
-__device__ __forceinline__ bool fq_has_resid(const FqRec &r) { return (r.nnz & 0xFFFFu) != 0 || fq_has_chroma(r); }
+/* the value lane `l` (wave-uniform) holds */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t fq_lane_word(uint32_t v, int l) { return (uint32_t)__shfl((int)v, l); }
+#else
+__device__ __forceinline__ uint32_t fq_lane_word(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+#endif
 
 /* the 768 bytes of a macroblock's coefficients into the layout above: 48 lanes, 16 bytes each */
 __device__ __forceinline__ void fq_coef_dma(MbLds &s, const FqLane &k, const int16_t *coef, int mb_xy)
@@ -226,11 +270,13 @@ __device__ __forceinline__ void fq_coef_dma(MbLds &s, const FqLane &k, const int
 }
 
 /* ---- residual, first half: the 24 blocks' inverse transforms into registers (two lanes per block; residual_blocks's arithmetic, see there) ----
- * o[i]: (residual of this lane's row a, of its row b) in column i, as two 16-bit halves */
-__device__ __forceinline__ void fq_idct(MbLds &s, const FqLane &k, const ResidLane &rl, uint32_t nnz, bool has_chroma, uint32_t dcq1, uint32_t dcq2, uint32_t o[4])
+ * The four residuals of each of the lane's two rows go to the residual tile (FQ_RS); a block without coefficients writes zeros */
+__device__ __forceinline__ void fq_idct(MbLds &s, const FqLane &k, const ResidLane &rl, uint32_t nnz, bool has_chroma, const mi355_h264_mb *rec)
 {
     const int lane = lane_id();
-    if (has_chroma) {
+    if (has_chroma && (nnz & (3u << MI355_NNZ_CB_DC))) {
+        fq_kptr h = fq_konst(rec);                                          /* the two chroma DC dequantisers: through the scalar cache */
+        const uint32_t dcq1 = h[9], dcq2 = h[10];
         if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
             int16_t *p = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(&s) + FQ_COEF + 16 * (16 + 4 * lane));      /* the DCs of blocks 16 + 4 lane .. + 3: 16 bytes apart */
             int a = p[0], b = p[8], c = p[16], d = p[24];
@@ -248,91 +294,61 @@ __device__ __forceinline__ void fq_idct(MbLds &s, const FqLane &k, const ResidLa
     const uint32_t c0 = pk_add(cw[0] & keep0, keep & rl.misc & 0xFFu), c1 = cw[2] & keep, c2 = cw[96] & keep, c3 = cw[98] & keep;
     const uint32_t z0 = pk_add(c0, c2), z1 = pk_sub(c0, c2), z2 = pk_sub(pk_ashr(c1, 1), c3), z3 = pk_add(c1, pk_ashr(c3, 1));
     const uint32_t w[4] = { pk_add(z0, z3), pk_add(z1, z2), pk_sub(z1, z2), pk_sub(z0, z3) };
+    uint32_t ra[4], rb[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t xh = pk_ashr_hi1((uint32_t)quad_xor1((int)w[i]));
-        const int ra = pk_dot2k(xh, 0x04000400u, pk_dot2(w[i], rl.ka, rnd)), rb = pk_dot2k(xh, 0xFC000400u, pk_dot2(w[i], rl.kb, rnd));
-        o[i] = byte_perm((uint32_t)rb, (uint32_t)ra, 0x07060302u);
+        ra[i] = (uint32_t)pk_dot2k(xh, 0x04000400u, pk_dot2(w[i], rl.ka, rnd));          /* the residual is the upper half */
+        rb[i] = (uint32_t)pk_dot2k(xh, 0xFC000400u, pk_dot2(w[i], rl.kb, rnd));
     }
-}
-/* ... second half: onto the prediction */
-__device__ __forceinline__ void fq_resid_add(MbLds &s, const ResidLane &rl, bool has_chroma, const uint32_t o[4])
-{
-    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
-    if (rl.misc & (has_chroma ? 0x300u : 0x100u)) {
-        uint32_t *pa = reinterpret_cast<uint32_t *>(base + rl.off_a), *pb = reinterpret_cast<uint32_t *>(base + rl.off_b);
-        const uint32_t va = *pa, vb = *pb;
-        const uint32_t s0 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C040C00u), o[0])), s1 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C050C01u), o[1]));
-        const uint32_t s2 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C060C02u), o[2])), s3 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C070C03u), o[3]));
-        const uint32_t m01 = byte_perm(s1, s0, 0x05040100u), m23 = byte_perm(s3, s2, 0x05040100u);
-        *pa = byte_perm(m23, m01, 0x06040200u);
-        *pb = byte_perm(m23, m01, 0x07050301u);
+    if (lane < 48) {
+        *reinterpret_cast<mi355_u32x2 *>(base + k.wa) = mi355_u32x2{ byte_perm(ra[1], ra[0], 0x07060302u), byte_perm(ra[3], ra[2], 0x07060302u) };
+        *reinterpret_cast<mi355_u32x2 *>(base + k.wb) = mi355_u32x2{ byte_perm(rb[1], rb[0], 0x07060302u), byte_perm(rb[3], rb[2], 0x07060302u) };
     }
 }
 
 /* ---- the windows ---- */
-struct FqWin {
-    int so2w;       /* woff + o + 2: where block column -2 sits in a 48-byte window row of this macroblock's window set */
-    int ocw;        /* woff + (cx & 3): where chroma column 0 of the block sits in a 12-byte window row */
-    int woff;       /* 0 or FQ_WSTEP: the window set */
-    int pos, fxc, fyc;      /* (mx & 3) | (my & 3) << 2; mx & 7, myc & 7 */
-    bool patch_y, patch_c;
-    int t0, c0;     /* first luma tile column / first chroma sample column of the fetch (either may lie outside the picture) */
-};
-/* issue both fetches of a macroblock into window set `woff`: rows clamped to the picture here, columns fetched from the clamped tile and replicated
- * later (fq_windows_patch).  mc_dir_part's addressing (h264_mb.c:204-318) */
-__device__ __forceinline__ FqWin fq_windows_issue(MbLds &s, const FqLane &k, const mi355_h264_frame *desc, const FrameHot &fr, const FqRec &rec, int mb_x, int mb_y, int woff)
+/* issue both fetches of a macroblock (first luma row y0 = iy - 2, first luma tile column t0, first chroma row cy, first chroma column c0 = cx & ~3) into window
+ * set `woff`: rows clamped to the picture here, columns fetched from the clamped tile and replicated later (fq_windows_patch).  mc_dir_part's addressing
+ * (h264_mb.c:204-318) */
+__device__ __forceinline__ void fq_windows_issue(MbLds &s, const FqLane &k, const mi355_h264_frame *desc, const FrameHot &fr, int slot, int y0, int t0, int cy, int c0, int woff)
 {
-    FqWin w;
-    const int slot = (int)(rec.w12 & 0xFFu);
-    fq_kptr rp = fq_konst(desc->ref[slot < MI355_H264_MAX_SLOTS ? slot : 0]);
+    fq_kptr rp = fq_konst(desc->ref[slot]);
     const uint8_t *ry = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)));
     const uint8_t *rc = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[2] | ((unsigned long long)rp[3] << 32)));
-    const int mx = (int16_t)(rec.mv0 & 0xFFFF) + mb_x * 64, my = (int16_t)(rec.mv0 >> 16) + mb_y * 64;
-    const int myc = my + (int8_t)(rec.w14 & 0xFFu);                       /* the other-parity field offset, h264_mb.c:287-291 */
-    const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
     const int mbw = fr.mb_width, hpix = 16 * fr.mb_height, hc = 8 * fr.mb_height;
-    w.woff = woff;
-    w.pos = (mx & 3) | ((my & 3) << 2); w.fxc = mx & 7; w.fyc = myc & 7;
-    w.t0 = (ix - 4) >> 4;
-    w.so2w = ((ix - 4) & 15) + 2 + woff;
-    w.c0 = cx & ~3;
-    w.ocw = (cx & 3) + woff;
-    w.patch_y = w.t0 < 0 || w.t0 + 2 >= mbw;
-    w.patch_c = w.c0 < 0 || w.c0 + 11 >= 8 * mbw;
     {
-        const int y = fq_med3_0(iy - 2 + k.fr, hpix - 1);
-        const int tx = fq_med3_0(w.t0 + k.fp, mbw - 1);
+        const int y = fq_med3_0(y0 + k.fr, hpix - 1);
+        const int tx = fq_med3_0(t0 + k.fp, mbw - 1);
 #ifndef FQ_EXP_NO_LUMA_FETCH
         fq_dma16<FQ_WY>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), s, woff);
 #endif
     }
     {
         const int y = fq_med3_0(cy + k.crow, hc - 1);
-        const int col = w.c0 + k.cd4, t = col >> 3;
+        const int col = c0 + k.cd4, t = col >> 3;
         /* a dword of a tile beyond the picture: the dword of the edge tile that holds the edge column (replicated afterwards) */
         const int tx = fq_med3_0(t, mbw - 1), within = t < 0 ? 0 : (t >= mbw ? 4 : (col & 4));
 #ifndef FQ_EXP_NO_CHROMA_FETCH
         fq_dma4<FQ_WC>(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), s, woff);
 #endif
     }
-    return w;
 }
 /* columns left / right of the picture: the edge column's sample over the whole piece.  Each lane mends the piece it fetched. */
-__device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, const FqWin &w, int mbw)
+__device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, bool patch_y, bool patch_c, int t0, int c0, int woff, int mbw)
 {
-    uint8_t *const base = reinterpret_cast<uint8_t *>(&s) + w.woff;
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s) + woff;
     const int lane = lane_id();
-    if (w.patch_y && lane < 63) {
-        const int t = w.t0 + k.fp;
+    if (patch_y && lane < 63) {
+        const int t = t0 + k.fp;
         if (t < 0 || t >= mbw) {
             uint8_t *p = base + FQ_WY + 16 * lane;
             const uint32_t e = (uint32_t)p[t < 0 ? 0 : 15] * 0x01010101u;
             *reinterpret_cast<mi355_u32x4 *>(p) = mi355_u32x4{ e, e, e, e };
         }
     }
-    if (w.patch_c && lane < 54) {
-        const int t = (w.c0 + k.cd4) >> 3;
+    if (patch_c && lane < 54) {
+        const int t = (c0 + k.cd4) >> 3;
         if (t < 0 || t >= mbw) {
             uint8_t *p = base + FQ_WC + 4 * lane;
             *reinterpret_cast<uint32_t *>(p) = (uint32_t)p[t < 0 ? 0 : 3] * 0x01010101u;
@@ -359,7 +375,7 @@ __device__ __forceinline__ uint32_t fq_bytes(const int d[4])
 }
 /* Quarter-sample prediction of the 16x16 block (h264qpel_template.c's mc00..mc33) from the raw window into the prediction tile.
  * pos = (mx & 3) | (my & 3) << 2.  Components: G integer samples, b / h horizontal / vertical half samples, j the centre. */
-__device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int pos)
+__device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int pos, bool has_resid)
 {
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     /* b of window row `row0` + this lane's row: a direct product, the filter on the column side */
@@ -390,15 +406,15 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
         } else {
             fq_mfma(x0, k.i2, 0, d0);
             fq_mfma(x1, k.i2, 0, d1);
-            *reinterpret_cast<uint32_t *>(base + k.a4 + 2 * FQ_PLANE) = fq_bytes<0>(d0);
-            *reinterpret_cast<uint32_t *>(base + k.a5 + 2 * FQ_PLANE) = fq_bytes<0>(d1);
+            *reinterpret_cast<uint32_t *>(base + k.a4) = fq_bytes<0>(d0);
+            *reinterpret_cast<uint32_t *>(base + k.a5) = fq_bytes<0>(d1);
         }
         MI355_WAVE_SYNC();
     };
     /* h: the vertical filter over the transposed samples */
     auto vraw = [&]() -> uint32_t {
         int d[4];
-        fq_mfma(fq_lds64(base + k.a6 + 2 * FQ_PLANE), k.t6, 0, d);
+        fq_mfma(fq_lds64(base + k.a6), k.t6, 0, d);
         return fq_half_samples(d);
     };
     /* j: the vertical filter over both planes of the horizontal sums.  With lo = sum over ((H & 255) - 128) and hi = sum over ((H >> 8) - 16):
@@ -434,26 +450,40 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
     case 9: { transpose(false, 0); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }
     default: { transpose(false, 1); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }     /* 11 */
     }
-    *reinterpret_cast<uint32_t *>(base + k.a3) = v;
+    if (has_resid) {
+        /* the four residuals of these samples on top (h264idct_template.c:54-66's "+ dst", clipped) */
+        const mi355_u32x2 r = *reinterpret_cast<const mi355_u32x2 *>(base + k.rsy);
+        const uint32_t s01 = pk_sat_u8(pk_add(byte_perm(0u, v, 0x0C010C00u), r[0])), s23 = pk_sat_u8(pk_add(byte_perm(0u, v, 0x0C030C02u), r[1]));
+        v = byte_perm(s23, s01, 0x05040100u);
+    }
+    MI355_WAVE_SYNC();                                                     /* every lane has its residual: the tile may take their place */
+    *reinterpret_cast<uint32_t *>(base + FQ_ST + k.sy) = v;
 }
 
 /* ---- chroma: both 8x8 planes, two samples per lane ---- */
-__device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, int fx, int fy)
+__device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, uint32_t wts, bool has_resid)
 {
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
-    const uint32_t wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
     const uint32_t at = k.c1 + (uint32_t)oc, sh = at & 3u;                  /* FQ_WC and the 12-byte row pitch are multiples of four */
     const uint32_t r0 = fq_bytes4(base + (at & ~3u), sh), r1 = fq_bytes4(base + (at & ~3u) + 12, sh);
     const uint32_t d0 = fq_dot4(byte_perm(r1, r0, 0x05040100u), wts, 32u), d1 = fq_dot4(byte_perm(r1, r0, 0x06050201u), wts, 32u);
-    *reinterpret_cast<uint16_t *>(base + k.c2) = (uint16_t)((d0 >> 6) | ((d1 >> 6) << 8));
+    uint32_t two = (d0 >> 6) | ((d1 >> 6) << 8);
+    if (has_resid) two = pk_sat_u8(pk_add(byte_perm(0u, two, 0x0C010C00u), *reinterpret_cast<const uint32_t *>(base + k.rsc)));
+    *reinterpret_cast<uint16_t *>(base + FQ_ST + 256 + k.sc) = (uint16_t)two;
 }
-
-struct FqPic {          /* what the run keeps of the picture descriptor */
-    const mi355_h264_mb *mb;
-    const int16_t *mv0, *coef;
-    const mi355_h264_frame *desc;
-    FrameHot hot;       /* recon planes and strides for the stores (store_mb_tiled) */
-};
+/* the finished macroblock, 384 bytes in tile order, to the picture: whole 16-byte pieces, sixteen lanes the luma tile (two cache lines), eight the chroma tile.
+ * (Four samples per lane straight to memory — sixty-four 4-byte pieces sixteen bytes apart — cost the memory pipeline sixteen address groups a store instead of
+ * four and the pass 1.6 ms of 6.8: tools/gpu_r05c.sh, knock-out "nostore".) */
+__device__ __forceinline__ void fq_store(MbLds &s, uint8_t *ytile, uint8_t *ctile)
+{
+    const uint8_t *const base = reinterpret_cast<const uint8_t *>(&s);
+    const int lane = lane_id();
+    if (lane < 24) {
+        const mi355_u32x4 v = *reinterpret_cast<const mi355_u32x4 *>(base + FQ_ST + 16 * lane);
+        if (lane < 16) *reinterpret_cast<mi355_u32x4 *>(ytile + (uint32_t)(16 * lane)) = v;
+        else *reinterpret_cast<mi355_u32x4 *>(ctile + (uint32_t)(16 * lane - 256)) = v;
+    }
+}
 
 /* ---- any other inter macroblock of the run: h264_recon_dev.h's code, as a FUNCTION — its registers are its own, the run's loop does not pay for them ---- */
 #ifdef MI355_HIP_EMU_H
@@ -466,23 +496,20 @@ __device__ __attribute__((noinline)) void fq_general_mb(MbLds *s, const mi355_h2
 }
 
 /* ---- the run: RUN consecutive macroblocks (of the launch's max_w x max_h grid per picture) per wave ---- */
-template <int RUN>
-__device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h,
-                                                unsigned long long inv_w, unsigned long long inv_h, int nblocks, int per_xcd)
+/* ---- the run: `run` (<= 32) consecutive macroblocks of ONE row of the launch's max_w x max_h grid per wave; runs_row = ceil(max_w / run) runs to a row.
+ * Wave w works on run w % runs_row of row w / runs_row of the launch (row = picture * max_h + mb_y). ---- */
+__device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, int run, int runs_row,
+                                                unsigned long long inv_runs, unsigned long long inv_h, int nwaves, int per_xcd)
 {
-    static_assert(RUN >= 1 && RUN <= 32, "the deferred macroblocks are a 32-bit mask");
-    const int first = xcd_linear((int)blockIdx.x, per_xcd) * RUN;
-    if (first >= nblocks) return;
-    const int n = nblocks - first < RUN ? nblocks - first : RUN;
-    const int row = div_magic(first, inv_w);
-    const int mb_x = first - row * max_w;
+    const int wave = xcd_linear((int)blockIdx.x, per_xcd);
+    if (wave >= nwaves) return;
+    const int row = div_magic(wave, inv_runs);
+    const int mb_x = (wave - row * runs_row) * run;
     const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+    const int n = max_w - mb_x < run ? max_w - mb_x : run;
     ResidLane rl;
-    resid_lane_issue(rl);
+    resid_lane_compute(rl);             /* the transform's lane constants (signs, DC masks), from the lane number: no load whose wait would fall into the run */
     const FqLane k = fq_lane();
-    /* the table has arrived before the run begins: inside it the compiler must find no pending load of its own to wait for (it would wait for the
-     * window and coefficient requests in flight with it) */
-    MI355_PIN(rl.off_a); MI355_PIN(rl.off_b); MI355_PIN(rl.cw); MI355_PIN(rl.dc16); MI355_PIN(rl.misc); MI355_PIN(rl.rc); MI355_PIN(rl.ka); MI355_PIN(rl.kb);
     auto picture = [&](int pf, FqPic &pic) -> bool {
         const mi355_h264_frame &frd = frames[pf];
         pic.hot = frame_hot(frd);
@@ -491,70 +518,68 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
     };
     FqPic pic;
     const bool pic_ok = picture(f, pic);
-    /* The run's macroblocks that lie in ONE row of one picture are walked here; what follows a row's end (a launch whose grid is wider than this picture,
-     * a row length that is no multiple of RUN) and every macroblock that is not of the fast kind is left to the general code below */
+    /* the run's macroblocks that lie inside this picture (a launch's grid may be wider / higher than a picture of its batch); every macroblock that is not of
+     * the fast kind is left to the general code below */
     const int n_row = pic_ok && mb_x < pic.hot.mb_width && mb_y < pic.hot.mb_height ? (n < pic.hot.mb_width - mb_x ? n : pic.hot.mb_width - mb_x) : 0;
-    uint32_t deferred = (n < 32 ? (1u << n) - 1u : 0xFFFFFFFFu) & ~(n_row < 32 ? (1u << n_row) - 1u : 0xFFFFFFFFu);
+    uint32_t deferred = 0;
     if (n_row > 0) {
         /* The pipeline of a run of fast macroblocks.  In macroblock i's turn:
          *   the windows of macroblock i + 1 are requested (into the other window set) — they have this whole turn to arrive;
          *   ONE wait: everything requested for macroblock i in the turn before (windows, coefficients) has landed — only the two requests just made
          *   may still be out (loads complete in issue order);
          *   coefficients -> residual in registers; the coefficients of macroblock i + 1 are requested into the place just read;
-         *   prediction from window set i & 1, residual on top, store.
+         *   prediction from window set i & 1, residual on top, straight into the picture.
          * What was not requested ahead (the run's first macroblock, the one after a macroblock of another kind) is requested at the head of its own turn. */
         const int mb_xy0 = mb_y * pic.hot.mb_width + mb_x;
+        const FqRun run = fq_describe(pic, mb_xy0, mb_x, mb_y, n_row);
+        uint32_t ra = run.a, rw = run.wts, rn = run.nnz, rd = run.d, re = run.e;
+        MI355_PIN(ra); MI355_PIN(rw); MI355_PIN(rn); MI355_PIN(rd); MI355_PIN(re);            /* its loads have landed before the first request of the run goes out */
         bool pre_w = false, pre_c = false;      /* this macroblock's windows / coefficients were requested in the turn before */
-        /* one turn; two copies of it alternate (window set 0 / 1, the two records' and windows' scalars changing roles) so that nothing is moved between turns */
-        auto turn = [&](int i, const FqRec &rec, FqRec &nrec, FqWin &w, FqWin &wn, auto set) {
-            constexpr int woff = decltype(set)::value;
+        uint32_t a = fq_lane_word(ra, 0);
+        for (int i = 0; i < n_row; i++) {
             const bool has_next = i + 1 < n_row;
-            if (has_next) nrec = fq_rec(pic.mb, pic.mv0, mb_xy0 + i + 1);
+            const uint32_t an = has_next ? fq_lane_word(ra, i + 1) : 0u;
+            const int woff = (i & 1) * FQ_WSTEP;
             bool next_w = false, next_c = false;
-            if (!(rec.mb_type & MI355_MB_INTRA)) {
-                if (fq_is_fast(rec)) {
-                    const bool has_chroma = fq_has_chroma(rec), has_resid = fq_has_resid(rec);
-                    if (!pre_w) w = fq_windows_issue(s, k, pic.desc, pic.hot, rec, mb_x + i, mb_y, woff);
-                    if (has_resid && !pre_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i);
-                    next_w = has_next && !(nrec.mb_type & MI355_MB_INTRA) && fq_is_fast(nrec);
-                    if (next_w) wn = fq_windows_issue(s, k, pic.desc, pic.hot, nrec, mb_x + i + 1, mb_y, woff ^ FQ_WSTEP);
-                    /* LOADS complete in issue order, a store's acknowledgement may overtake them: "at most 2 outstanding" with the two window requests of
-                     * macroblock i + 1 youngest means every older load has landed whatever the predecessor's store is doing (a count that allowed for the
-                     * store as well returned with coefficients still in flight: found on the device, never in the emulator).  Without younger loads: all. */
-                    if (next_w) fq_wait_vm2(); else fq_wait_vm0();
-                    MI355_WAVE_SYNC();
-                    uint32_t o[4] = { 0u, 0u, 0u, 0u };
-                    if (has_resid) fq_idct(s, k, rl, rec.nnz, has_chroma, rec.dcq1, rec.dcq2, o);
-                    MI355_WAVE_SYNC();                                     /* every lane has read its coefficients */
-                    next_c = next_w && fq_has_resid(nrec);
-                    if (next_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i + 1);
-                    if (w.patch_y || w.patch_c) {
-                        fq_windows_patch(s, k, w, pic.hot.mb_width);
-                        MI355_WAVE_SYNC();
-                    }
-#ifndef FQ_EXP_NO_MC
-                    fq_luma(s, k, w.so2w, w.pos);
-                    fq_chroma(s, k, w.ocw, w.fxc, w.fyc);
+            if (a & FQA_FAST) {
+                auto issue = [&](int m, uint32_t am, int set) {
+                    const uint32_t d = fq_lane_word(rd, m), e = fq_lane_word(re, m);
+                    fq_windows_issue(s, k, pic.desc, pic.hot, (int)((am >> 17) & 31u), (int16_t)(d & 0xFFFFu), (int16_t)(e & 0xFFFFu), (int)d >> 16, (int)e >> 16, set);
+                };
+                if (!pre_w) issue(i, a, woff);
+                if ((a & FQA_RESID) && !pre_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i);
+                next_w = (an & FQA_FAST) != 0;
+                if (next_w) issue(i + 1, an, woff ^ FQ_WSTEP);
+                /* LOADS complete in issue order, a store's acknowledgement may overtake them: "at most 2 outstanding" with the two window requests of
+                 * macroblock i + 1 youngest means every older load has landed whatever the predecessor's store is doing (a count that allowed for the
+                 * store as well returned with coefficients still in flight: found on the device, never in the emulator).  Without younger loads: all. */
+                if (next_w) fq_wait_vm2(); else fq_wait_vm0();
+                MI355_WAVE_SYNC();
+#ifndef FQ_EXP_NO_IDCT
+                if (a & FQA_RESID) fq_idct(s, k, rl, fq_lane_word(rn, i), (a & FQA_CHROMA) != 0, pic.mb + (mb_xy0 + i));
 #endif
+                MI355_WAVE_SYNC();                                         /* every lane has read its coefficients */
+                next_c = next_w && (an & FQA_RESID);
+                if (next_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i + 1);
+                if (a & (FQA_PATCH_Y | FQA_PATCH_C)) {
+                    const uint32_t e = fq_lane_word(re, i);
+                    fq_windows_patch(s, k, (a & FQA_PATCH_Y) != 0, (a & FQA_PATCH_C) != 0, (int16_t)(e & 0xFFFFu), (int)e >> 16, woff, pic.hot.mb_width);
                     MI355_WAVE_SYNC();
-                    if (has_resid) {
-                        fq_resid_add(s, rl, has_chroma, o);
-                        MI355_WAVE_SYNC();
-                    }
-#ifndef FQ_EXP_NO_STORE
-                    store_mb_tiled(s, pic.hot, mb_x + i, mb_y);
-#endif
-                } else {
-                    deferred |= 1u << i;
                 }
+#ifndef FQ_EXP_NO_MC
+                fq_luma(s, k, (int)(a & 31u) + woff, (int)((a >> 7) & 15u), (a & FQA_RESID) != 0);
+                fq_chroma(s, k, (int)((a >> 5) & 3u) + woff, fq_lane_word(rw, i), (a & FQA_RESID) != 0);
+#endif
+                MI355_WAVE_SYNC();
+#ifndef FQ_EXP_NO_STORE
+                fq_store(s, pic.hot.recon[0] + tile_y_off(mb_x + i, mb_y, pic.hot.recon_stride[0]), pic.hot.recon[1] + tile_c_off(mb_x + i, mb_y, pic.hot.recon_stride[1]));
+#endif
+                MI355_WAVE_SYNC();
+            } else if (!(a & FQA_INTRA)) {
+                deferred |= 1u << i;
             }
             pre_w = next_w; pre_c = next_c;
-        };
-        FqRec rec0 = fq_rec(pic.mb, pic.mv0, mb_xy0), rec1 = rec0;
-        FqWin w0 = {}, w1 = {};
-        for (int i = 0; i < n_row; i += 2) {
-            turn(i, rec0, rec1, w0, w1, std::integral_constant<int, 0>());
-            if (i + 1 < n_row) turn(i + 1, rec1, rec0, w1, w0, std::integral_constant<int, FQ_WSTEP>());
+            a = an;
         }
     }
     /* two lists, weights, partitions, the 8x8 transform: one macroblock per pass of the general code, nothing of the run's state alive */
@@ -562,11 +587,9 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
     while (deferred) {
         const int i = __builtin_ctz(deferred);
         deferred &= deferred - 1;
-        const int lin = first + i, r = div_magic(lin, inv_w), x = lin - r * max_w;
-        const int pf = div_magic(r, inv_h), y = r - pf * max_h;
         fq_wait_vm0();
         MI355_WAVE_SYNC();
-        fq_general_mb(&s, &frames[pf], x, y);
+        fq_general_mb(&s, &frames[f], mb_x + i, mb_y);
         MI355_WAVE_SYNC();
     }
 #endif

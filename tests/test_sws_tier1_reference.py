@@ -133,11 +133,45 @@ def test_freed_contexts_give_their_device_side_back(hooked, monkeypatch):
         before = lib.ref_sws_pictures()
         assert lib.sws_scale(c, src, strides, 0, sh, dst, dstrides) == dh
         live = lib.mi355_sws_glue_live_contexts()
-        # (base + 1, or base when the table was full of contexts earlier tests of this process never freed — ctypes callers do not pass
-        # through the wrapper — and binding this one evicted the least recently used of them)
+        # (the table is never full here: the contexts earlier tests of this process left behind — ctypes callers do not pass through the
+        # wrapper — are far fewer than its 256 entries; a full table would leave this context unbound, never take an entry from another)
         assert lib.ref_sws_pictures() == before + 1 and base <= live <= base + 1
         getattr(lib, "__wrap_sws_freeContext")(C.c_void_p(c))
         assert lib.mi355_sws_glue_live_contexts() == live - 1
         base = live - 1
     out = hooked.scale(name, S.picture(name), dst_pad=8)                          # and the binding still takes pictures afterwards
     assert hashlib.sha1(out.tobytes()).hexdigest()[:20] == GOLD["pictures"][name]
+
+
+def test_full_table_leaves_new_contexts_to_the_reference(hooked, monkeypatch):
+    """with every entry of the binding's table taken by a context that may be alive, a new context is NOT given another's entry (the other
+    one's next call would have converted nothing and returned 0 lines): it stays with the reference's function.  270 live contexts, every one of
+    them converts its picture — the ones past the table's size on the CPU — and the first ones still do afterwards."""
+    monkeypatch.delenv("MI355_SWS_LINES", raising=False)
+    lib = hooked.lib
+    lib.mi355_sws_glue_live_contexts.restype = C.c_int
+    getattr(lib, "__wrap_sws_freeContext").argtypes = [C.c_void_p]
+    name = "generic_64x48"
+    import numpy as np
+    sw, sh, dw, dh = S.CONFIGS[name][:4]
+    planes = S.picture(name)
+    src = (C.c_void_p * 4)(*[p.ctypes.data for p in planes], None)
+    strides = (C.c_int * 4)(*[p.strides[0] for p in planes], 0)
+
+    def convert(c):
+        out = np.zeros((dh, dw * 3), np.uint8)
+        dst = (C.c_void_p * 4)(out.ctypes.data, None, None, None)
+        dstrides = (C.c_int * 4)(out.strides[0], 0, 0, 0)
+        assert lib.sws_scale(c, src, strides, 0, sh, dst, dstrides) == dh
+        return hashlib.sha1(out.tobytes()).hexdigest()[:20]
+    ctxs = [hooked.open(name) for _ in range(270)]
+    try:
+        on_device = lib.ref_sws_pictures()
+        sums = [convert(c) for c in ctxs]
+        assert len(set(sums)) == 1                                                   # device and reference pictures alike (bit-exact path)
+        taken = lib.ref_sws_pictures() - on_device
+        assert 0 < taken <= 256 and lib.mi355_sws_glue_live_contexts() <= 256      # the rest ran the reference's function
+        assert [convert(c) for c in ctxs[:8]] == sums[:8]                          # nobody lost its entry to a later context
+    finally:
+        for c in ctxs:
+            getattr(lib, "__wrap_sws_freeContext")(C.c_void_p(c))
