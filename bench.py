@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
-    ap.add_argument("--pipelines", type=int, default=4, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
+    ap.add_argument("--pipelines", type=int, default=1, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
                     "HIP stream through the three passes: one pipeline's loop filter (bound by instruction issue) runs beside another's reconstruction (bound by the "
                     "memory pipeline); 1 = the three passes over the whole batch one after the other (how rounds 1-4 measured)")
     ap.add_argument("--mb-width", type=int, default=120)

@@ -67,8 +67,8 @@
  * MBAFF frames (macroblock pairs coded as frame or field macroblocks) go through the second kernel set too: the bridge names a field macroblock's
  * references by (frame, parity) — what hl_decode_mb's ref_list[16 + ..] remap does — schedules intra macroblocks pair-wise
  * (mi355_h264_intra_schedule_mbaff) and marks the picture MI355_FRAME_MBAFF; the kernels take a field macroblock's rows as every other line of its pair
- * and filter pairs (k_wide_deblock_mbaff).  An MBAFF slice with IMPLICIT weights is the one thing left to the C path (field macroblocks take those from
- * tables of their own).
+ * and filter pairs (k_wide_deblock_mbaff).  An MBAFF slice with IMPLICIT weights is packed with the field macroblocks' own table as well
+ * (implicit_weight_field, what the reference's implicit_weight[..][..][1 + parity] holds: h264_frame_wide.hip reads it for field macroblocks).
  *
  * Streams outside the Tier-2 scope (more than 10 bits, separate colour planes), MI355_BRIDGE_PLAIN=1 and any runtime failure make the bridge step
  * aside for that decoder: the reference's own C path continues.  Errors are reported once on stderr; nothing here

@@ -264,7 +264,6 @@ __device__ __forceinline__ uint32_t fq_lane_word(uint32_t v, int l) { return (ui
 __device__ __forceinline__ void fq_coef_dma(MbLds &s, const FqLane &k, const int16_t *coef, int mb_xy)
 {
     const uint8_t *cp = reinterpret_cast<const uint8_t *>(coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
-#ifndef FQ_EXP_NO_COEF
     if (lane_id() < 48) fq_dma16<FQ_COEF>(cp + k.csrc, s);
 #endif
 }
@@ -320,18 +319,14 @@ __device__ __forceinline__ void fq_windows_issue(MbLds &s, const FqLane &k, cons
     {
         const int y = fq_med3_0(y0 + k.fr, hpix - 1);
         const int tx = fq_med3_0(t0 + k.fp, mbw - 1);
-#ifndef FQ_EXP_NO_LUMA_FETCH
         fq_dma16<FQ_WY>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), s, woff);
-#endif
     }
     {
         const int y = fq_med3_0(cy + k.crow, hc - 1);
         const int col = c0 + k.cd4, t = col >> 3;
         /* a dword of a tile beyond the picture: the dword of the edge tile that holds the edge column (replicated afterwards) */
         const int tx = fq_med3_0(t, mbw - 1), within = t < 0 ? 0 : (t >= mbw ? 4 : (col & 4));
-#ifndef FQ_EXP_NO_CHROMA_FETCH
         fq_dma4<FQ_WC>(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), s, woff);
-#endif
     }
 }
 /* columns left / right of the picture: the edge column's sample over the whole piece.  Each lane mends the piece it fetched. */
@@ -555,9 +550,7 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
                  * store as well returned with coefficients still in flight: found on the device, never in the emulator).  Without younger loads: all. */
                 if (next_w) fq_wait_vm2(); else fq_wait_vm0();
                 MI355_WAVE_SYNC();
-#ifndef FQ_EXP_NO_IDCT
                 if (a & FQA_RESID) fq_idct(s, k, rl, fq_lane_word(rn, i), (a & FQA_CHROMA) != 0, pic.mb + (mb_xy0 + i));
-#endif
                 MI355_WAVE_SYNC();                                         /* every lane has read its coefficients */
                 next_c = next_w && (an & FQA_RESID);
                 if (next_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i + 1);
@@ -566,14 +559,10 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
                     fq_windows_patch(s, k, (a & FQA_PATCH_Y) != 0, (a & FQA_PATCH_C) != 0, (int16_t)(e & 0xFFFFu), (int)e >> 16, woff, pic.hot.mb_width);
                     MI355_WAVE_SYNC();
                 }
-#ifndef FQ_EXP_NO_MC
                 fq_luma(s, k, (int)(a & 31u) + woff, (int)((a >> 7) & 15u), (a & FQA_RESID) != 0);
                 fq_chroma(s, k, (int)((a >> 5) & 3u) + woff, fq_lane_word(rw, i), (a & FQA_RESID) != 0);
-#endif
                 MI355_WAVE_SYNC();
-#ifndef FQ_EXP_NO_STORE
                 fq_store(s, pic.hot.recon[0] + tile_y_off(mb_x + i, mb_y, pic.hot.recon_stride[0]), pic.hot.recon[1] + tile_c_off(mb_x + i, mb_y, pic.hot.recon_stride[1]));
-#endif
                 MI355_WAVE_SYNC();
             } else if (!(a & FQA_INTRA)) {
                 deferred |= 1u << i;
@@ -583,7 +572,6 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
         }
     }
     /* two lists, weights, partitions, the 8x8 transform: one macroblock per pass of the general code, nothing of the run's state alive */
-#ifndef FQ_NO_DEFERRED
     while (deferred) {
         const int i = __builtin_ctz(deferred);
         deferred &= deferred - 1;
@@ -592,8 +580,6 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
         fq_general_mb(&s, &frames[f], mb_x + i, mb_y);
         MI355_WAVE_SYNC();
     }
-#endif
 }
 
 }  // namespace
-#endif

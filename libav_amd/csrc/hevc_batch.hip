@@ -24,8 +24,10 @@ __device__ __forceinline__ void hevc_residual_run(IdctScratch &s, mi355_hevc_tu_
     /* coefficients -> LDS: eight per lane and access where the block allows it (16-byte aligned, 8x8 and larger), two otherwise */
     if (on) {
         /* an inverse DCT's coefficients lie in rows 0 .. col_limit + 3 of its block (what the first pass's pruning relies on, hevc_idct_half;
-         * hevcdsp_template.c:208-236 — the rows below are read only where the even part takes every fourth row, and hold zeros): those rows are
-         * not fetched but zeroed in LDS — half of a 32x32 block's 2 KB at col_limit 12 */
+         * hevcdsp_template.c:208-236 — the reference's even part still READS rows below that (every second row of a 16x16 block, every fourth of a 32x32
+         * one), which hold zeros in every block the decoder hands over: with the diagonal scan no coefficient lies that low (hevcdec.c:1178-1196)): those
+         * rows are not fetched but zeroed in LDS — half of a 32x32 block's 2 KB at col_limit 12.  A precondition of this entry point (include/mi355_hevc_batch.h),
+         * not of c->idct[] in general: tests/hevc_batch.py draws col_limit from the block's last coefficient, as the decoder does */
         const int rows = j.kind == MI355_HEVC_TU_IDCT && j.col_limit + 4 < size ? j.col_limit + 4 : size, ncopy = rows << j.log2_size;
         if (cnt >= 64 && (reinterpret_cast<uintptr_t>(j.coeffs) & 15) == 0) {
             for (int i = hl; i < cnt / 8; i += 32) reinterpret_cast<uint4 *>(c)[i] = i < ncopy / 8 ? reinterpret_cast<const uint4 *>(j.coeffs)[i] : make_uint4(0u, 0u, 0u, 0u);

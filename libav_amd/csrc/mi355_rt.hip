@@ -44,6 +44,9 @@ bool bind()
     if (d < 0) return false;
     if (bound != d) {
         if (hipSetDevice(d) != hipSuccess) return false;
+        /* the blocking-wait schedule is per device and per thread: every device a thread switches to gets it (once: a second call on a device with a
+         * live context is refused and changes nothing) */
+        if (blocking_sync()) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }      /* a refusal must not pass for a later launch's error */
         bound = d;
     }
     return true;
@@ -140,9 +143,10 @@ extern "C" int mi355_init(int device)
     const int rc = mi355::check_device(device);
     if (rc) return rc;
     /* MI355_BLOCKING_SYNC=1: a host thread that waits for the device sleeps instead of spinning (hipDeviceScheduleBlockingSync) — a host with
-     * more waiting decoder threads than it may use cores gives the cores back to the threads that parse.  Must precede the context. */
-    if (mi355::blocking_sync()) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+     * more waiting decoder threads than it may use cores gives the cores back to the threads that parse.  The flags belong to the calling thread's
+     * CURRENT device: the device is chosen first (set before, they went to device 0 whatever `device` was). */
     if (hipSetDevice(device) != hipSuccess) return -4;
+    if (mi355::blocking_sync()) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
     mi355::g_device.store(device, std::memory_order_release);
     return 0;
 }

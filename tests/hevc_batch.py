@@ -152,6 +152,23 @@ def check_residual(prov, oracle, bd, seed, cells=(6, 8)):
             m = c.reshape(size, size)
             m[lim:, :] = 0
             m[:, lim:] = 0
+        if kind == 0 and size > 4 and r.randint(0, 2) == 0:
+            # a block as the DECODER makes it: a last significant position (lx, ly) of the diagonal scan, coefficients only in the 4x4 groups the scan
+            # reaches before that one's (and inside it up to the position's own diagonal), and col_limit from (lx, ly) with hevcdec.c:1245-1256's caps
+            lx, ly = r.randint(0, size - 1), r.randint(0, size - 1)
+            if lx == 0 and ly == 0:
+                lx = 1
+            c = r.laplace_int(300, size * size, 32767).astype(np.int16)
+            m = c.reshape(size, size)                       # m[y][x]
+            ys, xs = np.mgrid[0:size, 0:size]
+            gl = (lx >> 2) + (ly >> 2)
+            keep = ((xs >> 2) + (ys >> 2) < gl) | (((xs >> 2) == (lx >> 2)) & ((ys >> 2) == (ly >> 2)) & ((xs & 3) + (ys & 3) <= (lx & 3) + (ly & 3)))
+            m[~keep] = 0
+            m[ly, lx] = m[ly, lx] or 1
+            mx = max(lx, ly)
+            lim = lx + ly + 4
+            lim = min(4, lim) if mx < 4 else (min(8, lim) if mx < 8 else (min(24, lim) if mx < 12 else lim))
+            lim = min(lim, size) if lim > size else lim
         if kind == 1:
             c[1:] = 0x1111
         coefs[k, :size * size] = c

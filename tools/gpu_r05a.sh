@@ -12,7 +12,7 @@ cd $GRAFT_REPO_ROOT
 timeout 600 python -m pytest tests/test_frame_gpu.py -m gpu -q -x -k "$KEXPR" > $OUT/pytest_gpu.txt 2>&1; rc=$?; echo "pytest rc=$rc"; tail -6 $OUT/pytest_gpu.txt | cut -c1-400
 [ $rc -eq 0 ] || exit 1
 run_bench() {   # name, extra args
-  timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 2 $2 > /tmp/b.json 2> /tmp/b.err || { echo "$1: bench failed"; tail -3 /tmp/b.err; return 1; }
+  timeout 200 python bench.py --no-cpu-baseline --no-extra --pipelines 1 --steps 10 --warmup 2 $2 > /tmp/b.json 2> /tmp/b.err || { echo "$1: bench failed"; tail -3 /tmp/b.err; return 1; }
   python3 - "$1" <<'PY' | tee -a $OUT/pass_ms.txt
 import json, sys
 b = json.load(open("/tmp/b.json"))

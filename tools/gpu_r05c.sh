@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 ulimit -c 0
 cd $GRAFT_REPO_ROOT
 run_bench() {   # name, extra args
-  timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2 $2 > /tmp/b.json 2> /tmp/b.err || { echo "$1: bench failed"; tail -3 /tmp/b.err; return 1; }
+  timeout 200 python bench.py --no-cpu-baseline --no-extra --pipelines 1 --steps 6 --warmup 2 $2 > /tmp/b.json 2> /tmp/b.err || { echo "$1: bench failed"; tail -3 /tmp/b.err; return 1; }
   python3 - "$1" <<'PY' | tee -a $OUT/pass_ms.txt
 import json, sys
 b = json.load(open("/tmp/b.json"))
