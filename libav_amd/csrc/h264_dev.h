@@ -1129,5 +1129,86 @@ __device__ inline void intra_pred_wave(PredScratch &s, int kind, int mode, int h
     }
 }
 
+/* ---- the two predictors every intra macroblock of a P / I picture uses most, without per-lane loops (intra_pred_wave above sums the edge samples
+ * in EVERY lane: thirty-two LDS reads a lane for a DC mode, the plane parameters' sixteen-term sums likewise) ----
+ * sums run across lanes: within groups of four (quad_xor1 / quad_xor2) and within rows of sixteen lanes (row_ror) */
+#ifdef MI355_HIP_EMU_H
+template <int N> static inline int row_ror(int v) { const int l = (int)(threadIdx.x & 63); return __shfl(v, (l & ~15) | ((l + N) & 15)); }
+#else
+template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, true); }   /* row_ror:N */
+#endif
+__device__ __forceinline__ int row_sum16(int v)         /* every lane: the sum over its row of sixteen lanes */
+{
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+    return v;
+}
+/* Intra16x16 (h264pred_template.c:329-486, slots DC 0, HOR 1, VERT 2, PLANE 3, LEFT_DC 4, TOP_DC 5, DC128 6), 8-bit: lane = row lane >> 2, samples 4 (lane & 3) .. + 3;
+ * `out` and `pitch` on dwords.  s.T / s.L as for intra_pred_wave. */
+__device__ inline void intra16_pred_fast(PredScratch &s, int mode, uint8_t *out, int pitch)
+{
+    const int lane = lane_id(), row = lane >> 2, seg = lane & 3;
+    const uint16_t *T = s.T + 1, *L = s.L + 1;
+    uint32_t v;
+    if (mode == 2) {
+        v = (uint32_t)T[4 * seg] | ((uint32_t)T[4 * seg + 1] << 8) | ((uint32_t)T[4 * seg + 2] << 16) | ((uint32_t)T[4 * seg + 3] << 24);
+    } else if (mode == 1) {
+        v = (uint32_t)L[row] * 0x01010101u;
+    } else if (mode == 3) {
+        /* pred16x16_plane (:434-481): H, V from eight differences each — lane k - 1 takes term k */
+        const int k = (lane & 7) + 1;
+        const int h = lane < 8 ? k * ((int)T[7 + k] - (int)T[7 - k]) : 0, w = lane < 8 ? k * ((int)L[7 + k] - (int)L[7 - k]) : 0;
+        const int H = (5 * lane_value(row_sum16(h), 0) + 32) >> 6, V = (5 * lane_value(row_sum16(w), 0) + 32) >> 6;
+        const int a = 16 * (lane_value((int)L[15], 0) + lane_value((int)T[15], 0) + 1) - 7 * (V + H);
+        const int b = a + row * V + 4 * seg * H;
+        /* med3i by name: written as comparisons the four clips become v_ashr_pk_u8_i32 + shifts, and the pictures came out wrong on the device
+         * (tests/test_frame_gpu.py, wide_mixed / mid_* cases; the emulator has no such instruction) */
+        const int p0 = med3i(b >> 5, 0, 255), p1 = med3i((b + H) >> 5, 0, 255), p2 = med3i((b + 2 * H) >> 5, 0, 255), p3 = med3i((b + 3 * H) >> 5, 0, 255);
+        v = (uint32_t)p0 | ((uint32_t)p1 << 8) | ((uint32_t)p2 << 16) | ((uint32_t)p3 << 24);
+    } else {
+        const int st = lane_value(row_sum16(lane < 16 ? (int)T[lane & 15] : 0), 0), sl = lane_value(row_sum16(lane < 16 ? (int)L[lane & 15] : 0), 0);
+        const int dc = mode == 0 ? (st + sl + 16) >> 5 : (mode == 4 ? (sl + 8) >> 4 : (mode == 5 ? (st + 8) >> 4 : 128));
+        v = (uint32_t)dc * 0x01010101u;
+    }
+    *reinterpret_cast<uint32_t *>(out + row * pitch + 4 * seg) = v;
+    MI355_WAVE_SYNC();
+}
+/* 8x8 chroma (h264pred_template.c:563-802, the eleven slots of intra_pred_wave's kind 2), 8-bit, one plane: a row of sixteen lanes is one 4x4 quadrant
+ * (lane = 32 qy + 16 qx + 4 (y & 3) + (x & 3)), so the quadrant's top sum is a sum over the group of four and its left sum one over the row's groups */
+__device__ inline void chroma8_pred_fast(PredScratch &s, int mode, uint8_t *out, int pitch)
+{
+    const int lane = lane_id(), qx = (lane >> 4) & 1, qy = lane >> 5, x = (lane & 3) + 4 * qx, y = ((lane >> 2) & 3) + 4 * qy;
+    const uint16_t *T = s.T + 1, *L = s.L + 1;
+    int v;
+    if (mode == 1) v = L[y];
+    else if (mode == 2) v = T[x];
+    else if (mode == 3) {
+        /* pred8x8_plane (:768-802): four differences each */
+        const int k = (lane & 3) + 1;
+        int h = lane < 4 ? k * ((int)T[3 + k] - (int)T[3 - k]) : 0, w = lane < 4 ? k * ((int)L[3 + k] - (int)L[3 - k]) : 0;
+        h += quad_xor1(h); h += quad_xor2(h); w += quad_xor1(w); w += quad_xor2(w);
+        const int H = (17 * lane_value(h, 0) + 16) >> 5, V = (17 * lane_value(w, 0) + 16) >> 5;
+        const int a = 16 * (lane_value((int)L[7], 0) + lane_value((int)T[7], 0) + 1) - 3 * (V + H);
+        v = clip_u8((a + x * H + y * V) >> 5);
+    } else if (mode == 6) v = 128;
+    else {
+        int t = T[x], l = L[y];
+        t += quad_xor1(t); t += quad_xor2(t);
+        l += row_ror<4>(l) + row_ror<8>(l) + row_ror<12>(l);
+        const int dc_left = (l + 2) >> 2, dc_top = (t + 2) >> 2, both = (t + l + 4) >> 3;
+        const int dc_full = (qx == qy) ? both : (qx ? dc_top : dc_left);
+        switch (mode) {
+        case 0: v = dc_full; break;
+        case 4: v = dc_left; break;
+        case 5: v = dc_top; break;
+        case 7: v = (qx == 0 && qy == 0) ? both : dc_top; break;      /* L0T */
+        case 8: v = (qx == 0 && qy == 0) ? dc_top : dc_full; break;   /* 0LT */
+        case 9: v = qy ? 128 : dc_left; break;                        /* L00 */
+        default: v = qy ? dc_left : 128; break;                       /* 0L0 */
+        }
+    }
+    out[y * pitch + x] = (uint8_t)v;
+    MI355_WAVE_SYNC();
+}
+
 }  // namespace mi355
 #endif

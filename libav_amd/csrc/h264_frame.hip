@@ -120,14 +120,14 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
         if (lane < 9) s.ps.T[lane] = CTILE(p, lane - 1, -1);
         if (lane >= 16 && lane < 25) s.ps.L[lane - 16] = CTILE(p, -1, lane - 17);
         MI355_WAVE_SYNC();
-        intra_pred_wave(s.ps, 2, h.chroma_pred_mode, 0, 0, &CTILE(p, 0, 0), CP);
+        chroma8_pred_fast(s.ps, h.chroma_pred_mode, &CTILE(p, 0, 0), CP);
     }
 
     if (t & MI355_MB_INTRA16x16) {       /* h264_mb.c:701-722 */
         if (lane < 17) s.ps.T[lane] = TILE(lane - 1, -1);
         if (lane >= 32 && lane < 49) s.ps.L[lane - 32] = TILE(-1, lane - 33);
         MI355_WAVE_SYNC();
-        intra_pred_wave(s.ps, 3, h.intra16x16_pred_mode, 0, 0, &TILE(0, 0), TP);
+        intra16_pred_fast(s.ps, h.intra16x16_pred_mode, &TILE(0, 0), TP);
         if ((h.nnz_mask >> MI355_NNZ_LUMA_DC) & 1) {
             /* ff_h264_luma_dc_dequant_idct (h264idct_template.c:242-271) on sixteen lanes: lane 4a + b holds level b of
              * row a; the row butterflies run inside the quads (DPP), the column butterflies after a turn through LDS, and
@@ -150,7 +150,8 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
             }
             MI355_WAVE_SYNC();
         }
-        residual_luma<true>(s.mb, &TILE(0, 0), TP, true);
+        /* luma (with the DC-only rule) and chroma residual in one pass, two lanes per block */
+        residual_tile(s.mb, &TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, true);
     } else if (t & MI355_MB_8x8DCT) {    /* Intra 8x8: h264_mb.c:626-656 */
         for (int i8 = 0; i8 < 4; i8++) {
             const int x0 = 8 * (i8 & 1), y0 = 8 * (i8 >> 1), i = 4 * i8;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
             MI355_WAVE_SYNC();
         }
     }
-    residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
+    if (!(t & MI355_MB_INTRA16x16)) residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
     if (TILED) store_mb_pitched_tiled<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
     else store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
 }

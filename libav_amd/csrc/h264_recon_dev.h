@@ -741,6 +741,58 @@ __device__ inline void residual_blocks(MbLds &s, const ResidLane &rl_in)
     MI355_WAVE_SYNC();
 }
 
+/* The same transform arrangement (two lanes per block, residual_blocks above) onto tiles with any row pitch — the intra kernel's — and with the DC-only
+ * rule for LUMA as well when `intra16` (an Intra16x16 block without the nnz bit whose DC level ff_h264_luma_dc_dequant_idct left non-zero takes
+ * h264_idct_dc_add, (dc + 32) >> 6 in int: h264_mb.c:726-760 with h264idct_template.c:144-156).  Every tile row segment starts on a dword. */
+__device__ inline void residual_tile(MbCore &s, uint8_t *y, int ypitch, uint8_t *cb, uint8_t *cr, int cpitch, bool intra16)
+{
+    const int lane = lane_id(), b = lane >> 1, h = lane & 1;
+    const uint32_t nnz = (uint32_t)uniform((int)s.hdr.nnz_mask);
+    const bool has_chroma = (uniform(s.hdr.cbp) & 0x30) != 0;
+    if (has_chroma) {
+        if (lane < 2 && ((nnz >> (MI355_NNZ_CB_DC + lane)) & 1)) {
+            int16_t *p = s.coef + 256 + 64 * lane;
+            int a = p[0], bb = p[16], c = p[32], d = p[48];
+            chroma_dc_dequant(a, bb, c, d, (int)s.hdr.dc_qmul[1 + lane]);
+            p[0] = (int16_t)a; p[16] = (int16_t)bb; p[32] = (int16_t)c; p[48] = (int16_t)d;
+        }
+        MI355_WAVE_SYNC();
+    }
+    const bool chroma = b >= 16;
+    const bool live = b < 16 || (b < 24 && has_chroma);
+    const bool dc_rule = chroma ? has_chroma : intra16;                         /* a block of this lane may be DC only */
+    const uint32_t nnz24 = nnz & (has_chroma ? 0xFFFFFFu : 0xFFFFu);
+    const uint32_t keep = bit_mask(nnz24, b < 24 ? b : 31);
+    const uint32_t keep0 = keep | (h == 0 && dc_rule && b < 24 ? 0xFFFFu : 0u);
+    const int rnd = (int)(~keep & (dc_rule && b < 24 ? 32u * 1024u : 0u));
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(s.coef) + (b < 24 ? b : 23) * 8 + h;
+    const uint32_t c0 = pk_add(cw[0] & keep0, keep & (h ? 0u : 32u)), c1 = cw[2] & keep, c2 = cw[4] & keep, c3 = cw[6] & keep;
+    const uint32_t z0 = pk_add(c0, c2), z1 = pk_sub(c0, c2), z2 = pk_sub(pk_ashr(c1, 1), c3), z3 = pk_add(c1, pk_ashr(c3, 1));
+    const uint32_t w[4] = { pk_add(z0, z3), pk_add(z1, z2), pk_sub(z1, z2), pk_sub(z0, z3) };
+    const uint32_t ka = h ? 0xFC00FC00u : 0x04000400u, kb = h ? 0x0400FC00u : 0xFC000400u;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t xh = pk_ashr_hi1((uint32_t)quad_xor1((int)w[i]));
+        const int ra = pk_dot2k(xh, 0x04000400u, pk_dot2(w[i], ka, rnd)), rb = pk_dot2k(xh, 0xFC000400u, pk_dot2(w[i], kb, rnd));
+        o[i] = byte_perm((uint32_t)rb, (uint32_t)ra, 0x07060302u);
+    }
+    if (live) {
+        const int jj = b & 3;
+        uint8_t *base = chroma ? ((b & 4) ? cr : cb) + (4 * (jj >> 1)) * cpitch + 4 * (jj & 1)
+                               : y + (4 * blk_y4(b)) * ypitch + 4 * blk_x4(b);
+        const int pitch = chroma ? cpitch : ypitch;
+        uint32_t *pa = reinterpret_cast<uint32_t *>(base + (h ? 1 : 0) * pitch), *pb = reinterpret_cast<uint32_t *>(base + (h ? 2 : 3) * pitch);
+        const uint32_t va = *pa, vb = *pb;
+        const uint32_t s0 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C040C00u), o[0])), s1 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C050C01u), o[1]));
+        const uint32_t s2 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C060C02u), o[2])), s3 = pk_sat_u8(pk_add(byte_perm(vb, va, 0x0C070C03u), o[3]));
+        const uint32_t m01 = byte_perm(s1, s0, 0x05040100u), m23 = byte_perm(s3, s2, 0x05040100u);
+        *pa = byte_perm(m23, m01, 0x06040200u);
+        *pb = byte_perm(m23, m01, 0x07050301u);
+    }
+    MI355_WAVE_SYNC();
+}
+
 /* tile (LDS) -> picture, 4 bytes per lane */
 template <bool ALIGNED>
 __device__ __forceinline__ uint32_t tile_dword(const uint8_t *p)
