@@ -416,6 +416,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         v = F10 * mbw * mbh / (ms * 1e-3)
         pts.append({"name": "config2_high10_f%d" % F10, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F10,
                     "bytes_per_mb_fused": B_FUSED_HIGH10, "fused_fraction_of_hbm_roofline": v * B_FUSED_HIGH10 / HBM_PEAK, "pass_ms": passes,
+                    "verified_by": "tests/test_frame_gpu.py::test_config2_high10_full_size_matches_the_frame_checker (same generator, every sample, against the reference's own 10-bit tables)",
                     "note": "config 2 as a High 10 batch: 16-bit samples, 32-bit coefficients (DeviceFrames(bit_depth=10)), planes with line strides, through "
                             "mi355_h264_decode_frames_wide_dev — the second kernel set in its first, plain form (one wave per macroblock, per-sample arithmetic, "
                             "one loop-filter launch per anti-diagonal); parity: the generated High 10 / High 4:2:2 streams against the reference decoder"})

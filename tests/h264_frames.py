@@ -7,6 +7,7 @@ slice decoder would hold when it calls ff_h264_hl_decode_mb() (mb_type bits, mv/
 availability masks and remapped intra modes).  Inputs come from splitmix64 only.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -428,25 +429,29 @@ def intra_levels(mb, mb_w, mb_h):
     return lv
 
 
-def host_frames(fs, recon, dst):
-    """ctypes Frame array whose pointers are HOST addresses into fs / recon / dst (for the oracle)."""
+def host_frames(fs, recon, dst, px=1, mb=None, coef=None, refs=None):
+    """ctypes Frame array whose pointers are HOST addresses into fs / recon / dst (for the oracle).
+    px = 2: 16-bit samples (strides in bytes); mb / coef / refs: replacements for fs's own arrays (the High 10 variant of a picture set)"""
     arr = (Frame * fs.F)()
     keep = []
+    mb = fs.mb if mb is None else mb
+    coef = fs.coef if coef is None else coef
+    refs = fs.refs if refs is None else refs
     for f in range(fs.F):
         fr = arr[f]
         fr.mb_width, fr.mb_height = fs.mb_w, fs.mb_h
         for p in range(3):
             fr.dst[p] = dst[p][f].ctypes.data
             fr.recon[p] = recon[p][f].ctypes.data
-        fr.dst_stride[0], fr.dst_stride[1] = fs.W, fs.W // 2
-        fr.recon_stride[0], fr.recon_stride[1] = fs.W, fs.W // 2
+        fr.dst_stride[0], fr.dst_stride[1] = px * fs.W, px * fs.W // 2
+        fr.recon_stride[0], fr.recon_stride[1] = px * fs.W, px * fs.W // 2
         for s in range(fs.nrefs):
             for p in range(3):
-                fr.ref[s][p] = fs.refs[f][s][p].ctypes.data
-        fr.mb = fs.mb[f].ctypes.data
+                fr.ref[s][p] = refs[f][s][p].ctypes.data
+        fr.mb = mb[f].ctypes.data
         fr.mv[0] = fs.mv[0, f].ctypes.data
         fr.mv[1] = fs.mv[1, f].ctypes.data if fs.use_l1 else None
-        fr.coef = fs.coef[f].ctypes.data
+        fr.coef = coef[f].ctypes.data
         fr.slices = fs.slices[f].ctypes.data
         fr.nslices = fs.slices.shape[1]
         fr.max_intra_level = int(fs.intra_start[f].shape[0]) - 1
@@ -455,6 +460,57 @@ def host_frames(fs, recon, dst):
         fr.max_level_width = fs.max_level_width
         fr.flags = 1 if int(fs.intra_start[f][-1]) == fs.mb_w * fs.mb_h else 0       # MI355_FRAME_NO_INTER: every macroblock is on some intra level
     return arr, keep
+
+
+def widen_samples(a, sh):
+    """an 8-bit plane as DeviceFrames(bit_depth=8 + sh) uploads it: shifted up, the low bits filled from the sample's position"""
+    lo = (np.arange(a.shape[1], dtype=np.uint16)[None, :] * 3 + np.arange(a.shape[0], dtype=np.uint16)[:, None] * 5) & ((1 << sh) - 1)
+    return np.ascontiguousarray((a.astype(np.uint16) << sh) | lo)
+
+
+def widen_records(fs, sh):
+    """records and coefficients as DeviceFrames(bit_depth=8 + sh) uploads them: QPs raised by QpBdOffset, 32-bit coefficients scaled by the shift,
+    an I_PCM macroblock's samples one per coefficient slot"""
+    mb = fs.mb.copy()
+    mb["qp"] += 6 * sh
+    mb["qpc"] += 6 * sh
+    coef = fs.coef.astype(np.int32) << sh
+    pcm = (fs.mb["mb_type"] & 4) != 0
+    coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32) << sh
+    return mb, np.ascontiguousarray(coef)
+
+
+def ref_library():
+    """oracle/_ref/libref.so — the reference's own DSP objects, built where /root/reference exists (__graft_entry__.build()) and shipped with the tree; None without it"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref.so")
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+def run_oracle_hbd(oracle, fs, bit_depth, deblock=True):
+    """The frame-level checker above 8 bits (oracle/oracle_h264frame_hbd.c: the restated per-macroblock drivers calling THE REFERENCE'S OWN tables at
+    that bit depth, oracle/_ref/libref.so) on the High 10 variant of a picture set — the pictures DeviceFrames(bit_depth=...) uploads.
+    Returns (recon, dst) as uint16 plane lists, or None when libref.so is not there."""
+    ref = ref_library()
+    if ref is None:
+        return None
+    sh = bit_depth - 8
+    lib = oracle.lib
+    fns = [C.cast(getattr(ref, n), C.c_void_p) for n in ("ff_h264dsp_init", "ff_h264qpel_init", "ff_h264chroma_init", "ff_h264_pred_init")]
+    lib.oracle_h264frame_hbd_bind.restype = C.c_int
+    lib.oracle_h264frame_hbd_bind.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    assert lib.oracle_h264frame_hbd_bind(*fns, bit_depth) == 0
+    mb, coef = widen_records(fs, sh)
+    refs = [[tuple(widen_samples(pl, sh) for pl in fs.refs[f][s_]) for s_ in range(fs.nrefs)] for f in range(fs.F)]
+    recon = [np.zeros((fs.F, fs.H, fs.W), np.uint16), np.zeros((fs.F, fs.H // 2, fs.W // 2), np.uint16), np.zeros((fs.F, fs.H // 2, fs.W // 2), np.uint16)]
+    dst = [np.zeros_like(a) for a in recon]
+    arr, _ = host_frames(fs, recon, dst, px=2, mb=mb, coef=coef, refs=refs)
+    lib.oracle_h264_recon_frame_hbd.restype = C.c_int
+    lib.oracle_h264_deblock_frame_hbd.restype = C.c_int
+    for f in range(fs.F):
+        assert lib.oracle_h264_recon_frame_hbd(C.byref(arr[f])) == 0
+        if deblock:
+            assert lib.oracle_h264_deblock_frame_hbd(C.byref(arr[f])) == 0
+    return recon, dst
 
 
 def run_oracle(oracle, fs, deblock=True):
@@ -479,8 +535,7 @@ class DeviceFrames:
     def __init__(self, prov, fs, replicate=None, pad=0, tiled=False, bit_depth=8):
         """bit_depth 9 / 10: the same pictures as a High 10 batch for mi355_h264_decode_frames_wide_dev — 16-bit samples (the 8-bit reference
         samples shifted up, the low bits filled from the sample's position), 32-bit coefficients (scaled by the same shift), QPs raised by
-        QpBdOffset; there is no frame-level oracle for these (parity of the wide kernels: the generated High 10 / High 4:2:2 streams
-        against the reference decoder, and decode_wide(8, 1) against the oracle): measurement and determinism only.
+        QpBdOffset; the frame-level checker for these is run_oracle_hbd() (oracle/oracle_h264frame_hbd.c on the reference's own 9 / 10-bit tables).
         pad: extra bytes per luma row (chroma rows get pad // 2): strides that are multiples of 4 but not of
         16 / 8 take the kernels' narrow-access paths.
         tiled: dst / recon / reference surfaces in the macroblock-tiled layout (pad then = extra bytes per macroblock ROW of
@@ -524,12 +579,7 @@ class DeviceFrames:
         mb = fs.mb
         coef, cbytes = fs.coef, 768
         if px == 2:
-            mb = fs.mb.copy()
-            mb["qp"] += 6 * sh
-            mb["qpc"] += 6 * sh
-            coef, cbytes = fs.coef.astype(np.int32) << sh, 1536
-            pcm = (fs.mb["mb_type"] & 4) != 0
-            coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32) << sh
+            (mb, coef), cbytes = widen_records(fs, sh), 1536
         self.cbytes = cbytes
         self.mb = up_rep(mb, nmb * 64)
         self.mv0 = up_rep(fs.mv[0], nmb * 64)
@@ -550,8 +600,7 @@ class DeviceFrames:
                     continue
                 if px == 2:
                     def wide(a):
-                        lo = (np.arange(a.shape[1], dtype=np.uint16)[None, :] * 3 + np.arange(a.shape[0], dtype=np.uint16)[:, None] * 5) & ((1 << sh) - 1)
-                        return ((a.astype(np.uint16) << sh) | lo).view(np.uint8).reshape(a.shape[0], -1)
+                        return widen_samples(a, sh).view(np.uint8).reshape(a.shape[0], -1)
                     y, cb, cr = wide(y), wide(cb), wide(cr)
                 refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :px * fs.W] = y
                 refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :px * fs.W // 2] = cb

@@ -262,3 +262,25 @@ def test_run_kernel_mixed_partitions(mi355, oracle):
 def test_run_kernel_many_pictures(mi355, oracle):
     """the same under load: 256 pictures in one launch (every SIMD at eight waves, requests of several macroblocks in flight per wave), all compared"""
     frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x2265, replicate=256)
+
+
+HBD_CASES = [n for n in frame_cases.CASES if n not in ("tall_all_intra", "mid_hugecoef", "mid_wrapcoef", "p16_wrapcoef")]
+
+
+@pytest.mark.parametrize("name", HBD_CASES)
+def test_second_kernel_set_against_the_frame_checker_at_10_bits(mi355, oracle, name):
+    """the High 10 instantiation of the second kernel set, frame level: 16-bit samples, 32-bit coefficients against oracle/oracle_h264frame_hbd.c on the reference's
+    own 10-bit tables (oracle/_ref/libref.so, built by __graft_entry__.build() where /root/reference exists and shipped with the tree)"""
+    assert frame_cases.run_case_hbd(mi355, oracle, name, 10), "oracle/_ref/libref.so missing: __graft_entry__.build() makes it where /root/reference exists"
+
+
+@pytest.mark.parametrize("name", ("mixed_intra", "b_weight_explicit", "wide_b"))
+def test_second_kernel_set_against_the_frame_checker_at_9_bits(mi355, oracle, name):
+    assert frame_cases.run_case_hbd(mi355, oracle, name, 9), "oracle/_ref/libref.so missing"
+
+
+def test_config2_high10_full_size_matches_the_frame_checker(mi355, oracle):
+    """bench.py's config2_high10 workload at its real size: three 1080p pictures of the headline generator as a High 10 batch (replicated to 24 in the launch),
+    every sample of both surfaces of every picture"""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x264, lib=mi355.lib)
+    assert frame_cases.run_case_hbd(mi355, oracle, "config2_high10", 10, fs=fs, replicate=24), "oracle/_ref/libref.so missing"
