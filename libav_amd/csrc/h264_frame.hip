@@ -223,8 +223,9 @@ static int recon_inter_launch(const mi355_h264_frame *d_frames, int nframes, int
         if (sparse)
             hipLaunchKernelGGL(k_recon_inter_sparse, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
                                d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);
-        else if (layouts == MI355_LAYOUTS_TILED)
-            mi355::recon_inter_tiled_launch(d_frames + f0, nf, max_mb_width, max_mb_height, (hipStream_t)stream);
+        else if (layouts == MI355_LAYOUTS_TILED) {
+            if (!mi355::recon_inter_tiled_launch(d_frames + f0, nf, max_mb_width, max_mb_height, (hipStream_t)stream)) return -4;
+        }
         else
             hipLaunchKernelGGL(k_recon_inter, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, (hipStream_t)stream,
                                d_frames + f0, max_mb_width, max_mb_height, iw, ih, nblocks, per_xcd);

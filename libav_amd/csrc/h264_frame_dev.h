@@ -62,8 +62,11 @@ __device__ __forceinline__ void st8(uint8_t *p, uint2 v, bool al)
     w[0] = v.x; w[1] = v.y;
 }
 
-/* h264_frame_tiled.hip: launches k_recon_inter_tiled (the tiled-only instance of the inter reconstruction kernel) */
-void recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int nframes, int max_w, int max_h, hipStream_t stream);
+/* h264_frame_tiled.hip: launches k_recon_inter_tiled and k_recon_inter_rest (the tiled-only form of the inter reconstruction); false: no scratch words */
+bool recon_inter_tiled_launch(const mi355_h264_frame *d_frames, int nframes, int max_w, int max_h, hipStream_t stream);
+/* h264_frame_rest.hip: k_recon_inter_rest over the words (one per run) k_recon_inter_tiled wrote */
+void recon_inter_rest_launch(const mi355_h264_frame *d_frames, int max_w, int max_h, int run, int runs_row, unsigned long long inv_runs, unsigned long long inv_h, int nruns,
+                             const uint32_t *rest, hipStream_t stream);
 /* h264_deblock.hip: the scratch words (ticket + progress counters) of a single-launch loop filter, one buffer per (thread, device, stream); the caller zeroes what it uses on `stream` */
 uint32_t *sync_words(hipStream_t stream, size_t words);
 }  // namespace mi355

@@ -480,21 +480,10 @@ __device__ __forceinline__ void fq_store(MbLds &s, uint8_t *ytile, uint8_t *ctil
     }
 }
 
-/* ---- any other inter macroblock of the run: h264_recon_dev.h's code, as a FUNCTION — its registers are its own, the run's loop does not pay for them ---- */
-#ifdef MI355_HIP_EMU_H
-static void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int mb_y)
-#else
-__device__ __attribute__((noinline)) void fq_general_mb(MbLds *s, const mi355_h264_frame *frd, int mb_x, int mb_y)
-#endif
-{
-    if (uniform(frd->surface_layout) == MI355_SURFACE_TILED) recon_inter_mb<false, true>(*s, *frd, mb_x, mb_y);
-}
-
-/* ---- the run: RUN consecutive macroblocks (of the launch's max_w x max_h grid per picture) per wave ---- */
 /* ---- the run: `run` (<= 32) consecutive macroblocks of ONE row of the launch's max_w x max_h grid per wave; runs_row = ceil(max_w / run) runs to a row.
  * Wave w works on run w % runs_row of row w / runs_row of the launch (row = picture * max_h + mb_y). ---- */
 __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, int run, int runs_row,
-                                                unsigned long long inv_runs, unsigned long long inv_h, int nwaves, int per_xcd)
+                                                unsigned long long inv_runs, unsigned long long inv_h, int nwaves, int per_xcd, uint32_t *__restrict__ rest)
 {
     const int wave = xcd_linear((int)blockIdx.x, per_xcd);
     if (wave >= nwaves) return;
@@ -571,14 +560,38 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
             a = an;
         }
     }
-    /* two lists, weights, partitions, the 8x8 transform: one macroblock per pass of the general code, nothing of the run's state alive */
-    while (deferred) {
-        const int i = __builtin_ctz(deferred);
-        deferred &= deferred - 1;
-        fq_wait_vm0();
-        MI355_WAVE_SYNC();
-        fq_general_mb(&s, &frames[f], mb_x + i, mb_y);
-        MI355_WAVE_SYNC();
+    /* two lists, weights, partitions, the 8x8 transform: left to recon_inter_rest, a launch of its own behind this one (the general code inside this
+     * kernel — a function called once per such macroblock at the end of the run — took 17 us a macroblock where a wave of its own takes 9: its
+     * registers saved and restored through scratch memory on every call, nothing of one macroblock overlapping the next) */
+    if (lane_id() == 0) rest[wave] = deferred;
+}
+
+/* ---- the macroblocks the runs left: wave g looks at the words of runs 16 g .. 16 g + 15 (one word a run: bit i = the run's macroblock i is an inter macroblock
+ * of another kind than the plain one) and takes them one at a time through h264_recon_dev.h's code.  A batch of plain P macroblocks costs this launch
+ * nruns / 16 waves that read sixty-four bytes and end. ---- */
+__device__ __forceinline__ void recon_inter_rest(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, int run, int runs_row,
+                                                 unsigned long long inv_runs, unsigned long long inv_h, int nruns, int ngroups, int per_xcd, const uint32_t *__restrict__ rest)
+{
+    const int g = xcd_linear((int)blockIdx.x, per_xcd);
+    if (g >= ngroups) return;
+    const int r = 16 * g + (lane_id() & 15);
+    const uint32_t mine = r < nruns ? rest[r] : 0u;
+    if (!__any(mine != 0)) return;
+    for (int j = 0; j < 16; j++) {
+        uint32_t m = fq_lane_word(mine, j);
+        if (!m) continue;
+        const int w = 16 * g + j;
+        const int row = div_magic(w, inv_runs);
+        const int mb_x = (w - row * runs_row) * run;
+        const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+        if (uniform(frames[f].surface_layout) != MI355_SURFACE_TILED) continue;
+        while (m) {
+            const int i = __builtin_ctz(m);
+            m &= m - 1;
+            recon_inter_mb<false, true>(s, frames[f], mb_x + i, mb_y);
+            fq_wait_vm0();                                      /* the macroblock's stores have left its LDS tile */
+            MI355_WAVE_SYNC();
+        }
     }
 }
 
