@@ -4,7 +4,7 @@
  * Two launches.  k_recon_inter_tiled: a wave walks a run of consecutive macroblocks of one row; the plain P macroblock (16x16, list 0, no
  * weights, 4x4 transforms) goes through h264_recon_fast.h (raw LDS-DMA windows, the 6-tap filters as v_mfma_i32_16x16x32_i8 products, the
  * next macroblock's windows and coefficients in flight under the prediction), every other inter macroblock is noted in the run's word of
- * a scratch buffer.  k_recon_inter_rest (h264_frame_rest.hip): a wave per sixteen runs takes the noted macroblocks through
+ * a scratch buffer.  k_recon_inter_rest (h264_frame_rest.hip): a wave per eight runs takes the noted macroblocks through
  * h264_recon_dev.h's code.  This file is compiled with the lane id PLAIN: the compiler may keep what it derives from the lane number in
  * registers over the run.
  */

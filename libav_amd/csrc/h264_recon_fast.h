@@ -34,6 +34,13 @@ namespace {
 /* Coefficients: where MbLds keeps them, but the 48 sixteen-byte pieces in another order — first halves of the 24 blocks (coefficients 0..7), then the
  * second halves: a lane pair reads (dword h, h + 2) of one piece per access, and with the pieces of a block 32 bytes apart the 24 blocks met in four of the
  * LDS's eight bank groups (six lanes per bank: 16 cycles a read, tools/ubench/lds_rate.hip); 16 bytes apart they spread over all eight */
+/* section marks in the listing (tools/isa_sections.py): analysis builds only */
+#if defined(FQ_MARKS) && !defined(MI355_HIP_EMU_H)
+#define FQ_MARK(name) asm volatile("; MARK " name)
+#else
+#define FQ_MARK(name)
+#endif
+
 constexpr int FQ_COEF = (int)offsetof(MbCore, coef);
 constexpr int FQ_RS = FQ_COEF + 768;            /* 960: the residual, int16: luma [16 rows][16], then chroma [plane][8 rows][8] — where the other paths keep their prediction tiles */
 constexpr int FQ_RSC = FQ_RS + 512;
@@ -134,10 +141,11 @@ __device__ __forceinline__ uint64_t fq_bytes8(const uint8_t *p, uint32_t sh)
 
 /* ---- what a lane is, for every macroblock of the run ---- */
 struct FqLane {
-    /* luma window fetch: piece L = min(lane, 62) is row L / 3, tile L % 3 */
-    int fr, fp;
-    /* chroma window fetch: dword q = min(lane, 53) is plane q / 27, row (q % 27) / 3, dword q % 3 */
-    int cplane64, crow, cd4;
+    /* luma window fetch: piece L = min(lane, 62) is row fr = L / 3, tile L % 3 (fp256 = 256 (L % 3): the tile's bytes) */
+    int fr, fp256;
+    /* chroma window fetch: dword q = min(lane, 53) is plane q / 27, row crow = (q % 27) / 3, dword d = q % 3 (kq68 = 68 d: with 68 b added, b = the window's first
+     * dword of its tile row, bit 7 is the tile step and bit 2 the dword of the tile row) */
+    int cplane64, crow, kq68;
     /* luma: this lane's row = lane & 15 and group g = lane >> 4 (four samples 4 g .. 4 g + 3 of the row in a direct product, four rows 4 g .. of column lane & 15 in a transposing one) */
     uint32_t a1;            /* FQ_WY + 48 row + 8 g: this lane's eight bytes of a window-row operand (+ o + 2 + ...) */
     uint32_t a1b;           /* ... of window row 16 + row (the second half of a transposing product; rows past 20 do not exist: those lanes read a1 again) */
@@ -163,11 +171,11 @@ __device__ __forceinline__ FqLane fq_lane()
     const int lane = lane_id();
     const int L = lane < 63 ? lane : 62;
     k.fr = (int)(__umul24((unsigned)L, 43u) >> 7);
-    k.fp = L - 3 * k.fr;
+    k.fp256 = 256 * (L - 3 * k.fr);
     const int q = lane < 54 ? lane : 53, plane = q >= 27, rem = q - 27 * plane;
     k.cplane64 = plane * 64;
     k.crow = (int)(__umul24((unsigned)rem, 43u) >> 7);
-    k.cd4 = 4 * (rem - 3 * k.crow);
+    k.kq68 = 68 * (rem - 3 * k.crow);
     const int row = lane & 15, g = lane >> 4;
     k.a1 = (uint32_t)(FQ_WY + 48 * row + 8 * g);
     k.a1b = row < 5 ? k.a1 + 768u : k.a1;
@@ -209,6 +217,7 @@ __device__ __forceinline__ FqLane fq_lane()
 /* ---- the run's macroblocks, described ONCE: lane m works out everything about macroblock m of the run that does not depend on a lane — vector, motion position,
  * window origins, flags, chroma weights — for all of them at a time (one vector instruction per step instead of a scalar one per macroblock and step: the scalar
  * unit was the kernel's narrowest place), and a macroblock's turn fetches its five words with v_readlane. ---- */
+constexpr uint32_t FQA_INSIDE = 1u << 22;        /* both windows inside the picture: fq_windows_issue_inside */
 constexpr uint32_t FQA_PATCH_Y = 1u << 11, FQA_PATCH_C = 1u << 12, FQA_FAST = 1u << 13, FQA_INTRA = 1u << 14, FQA_CHROMA = 1u << 15, FQA_RESID = 1u << 16;
 struct FqRun {
     uint32_t a;         /* bits 0-4 o + 2 | 5-6 cx & 3 | 7-10 (mx & 3) | (my & 3) << 2 | 11 / 12 luma / chroma window over a side border | 13 fast kind | 14 intra |
@@ -243,9 +252,12 @@ __device__ __forceinline__ FqRun fq_describe(const FqPic &pic, int mb_xy0, int m
     const bool chroma = (w2 & 0x30u) != 0, resid = (nnz & 0xFFFFu) != 0 || chroma;
     const uint32_t slot = (w12 & 0xFFu) < (uint32_t)MI355_H264_MAX_SLOTS ? (w12 & 0xFFu) : 0u;
     static_assert(MI355_H264_MAX_SLOTS <= 32, "five bits of slot");
+    /* t0 < 0 || t0 + 2 >= mbw; c0 < 0 || c0 + 11 >= 8 mbw: one unsigned comparison each (the bounds are wave constants, not below zero) */
+    const bool patch_y = (uint32_t)t0 >= (uint32_t)imax(mbw - 2, 0), patch_c = (uint32_t)c0 >= (uint32_t)imax(8 * mbw - 11, 0);
+    const bool inside = !patch_y && !patch_c && (uint32_t)(iy - 2) < (uint32_t)imax(16 * pic.hot.mb_height - 20, 0) && (uint32_t)cy < (uint32_t)imax(8 * pic.hot.mb_height - 8, 0);
     r.a = (uint32_t)(((ix - 4) & 15) + 2) | ((uint32_t)(cx & 3) << 5) | ((uint32_t)((mx & 3) | ((my & 3) << 2)) << 7) |
-          (t0 < 0 || t0 + 2 >= mbw ? FQA_PATCH_Y : 0u) | (c0 < 0 || c0 + 11 >= 8 * mbw ? FQA_PATCH_C : 0u) |
-          (fast ? FQA_FAST : 0u) | ((type & MI355_MB_INTRA) ? FQA_INTRA : 0u) | (chroma ? FQA_CHROMA : 0u) | (resid ? FQA_RESID : 0u) | (slot << 17);
+          (patch_y ? FQA_PATCH_Y : 0u) | (patch_c ? FQA_PATCH_C : 0u) |
+          (inside ? FQA_INSIDE : 0u) | (fast ? FQA_FAST : 0u) | ((type & MI355_MB_INTRA) ? FQA_INTRA : 0u) | (chroma ? FQA_CHROMA : 0u) | (resid ? FQA_RESID : 0u) | (slot << 17);
     const int fx = mx & 7, fy = myc & 7;
     r.wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
     r.nnz = nnz;
@@ -318,15 +330,32 @@ __device__ __forceinline__ void fq_windows_issue(MbLds &s, const FqLane &k, cons
     const int mbw = fr.mb_width, hpix = 16 * fr.mb_height, hc = 8 * fr.mb_height;
     {
         const int y = fq_med3_0(y0 + k.fr, hpix - 1);
-        const int tx = fq_med3_0(t0 + k.fp, mbw - 1);
+        const int tx = fq_med3_0(t0 + (k.fp256 >> 8), mbw - 1);
         fq_dma16<FQ_WY>(ry + (uint32_t)(__mul24(y >> 4, fr.ref_stride[0]) + tx * 256 + (y & 15) * 16), s, woff);
     }
     {
         const int y = fq_med3_0(cy + k.crow, hc - 1);
-        const int col = c0 + k.cd4, t = col >> 3;
+        const int col = c0 + (k.kq68 >> 4), t = col >> 3;                        /* 68 d >> 4 = 4 d */
         /* a dword of a tile beyond the picture: the dword of the edge tile that holds the edge column (replicated afterwards) */
         const int tx = fq_med3_0(t, mbw - 1), within = t < 0 ? 0 : (t >= mbw ? 4 : (col & 4));
         fq_dma4<FQ_WC>(rc + (uint32_t)(__mul24(y >> 3, fr.ref_stride[1]) + tx * 128 + k.cplane64 + (y & 7) * 8 + within), s, woff);
+    }
+}
+/* the same for windows that lie inside the picture (FQA_INSIDE: nine macroblocks of ten in a 1080p picture with vectors of +-16 samples): no clamps, the
+ * window's first tile in the scalar base, twelve vector instructions for the two addresses instead of twenty-five */
+__device__ __forceinline__ void fq_windows_issue_inside(MbLds &s, const FqLane &k, const mi355_h264_frame *desc, const FrameHot &fr, int slot, int y0, int t0, int cy, int c0, int woff)
+{
+    fq_kptr rp = fq_konst(desc->ref[slot]);
+    const uint8_t *ry = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)));
+    const uint8_t *rc = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[2] | ((unsigned long long)rp[3] << 32)));
+    {
+        const uint32_t y = (uint32_t)(y0 + k.fr);
+        fq_dma16<FQ_WY>(ry + (uint32_t)(t0 * 256) + (uint32_t)(__umul24(y >> 4, (uint32_t)fr.ref_stride[0]) + (((y & 15u) << 4) + (uint32_t)k.fp256)), s, woff);
+    }
+    {
+        const uint32_t y = (uint32_t)(cy + k.crow);
+        const uint32_t x = (((uint32_t)k.kq68 + (uint32_t)((c0 >> 2) & 1) * 68u) & 0x84u) | (uint32_t)k.cplane64;
+        fq_dma4<FQ_WC>(rc + (uint32_t)((c0 >> 3) * 128) + (uint32_t)(__umul24(y >> 3, (uint32_t)fr.ref_stride[1]) + (((y & 7u) << 3) + x)), s, woff);
     }
 }
 /* columns left / right of the picture: the edge column's sample over the whole piece.  Each lane mends the piece it fetched. */
@@ -335,7 +364,7 @@ __device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, bool
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s) + woff;
     const int lane = lane_id();
     if (patch_y && lane < 63) {
-        const int t = t0 + k.fp;
+        const int t = t0 + (k.fp256 >> 8);
         if (t < 0 || t >= mbw) {
             uint8_t *p = base + FQ_WY + 16 * lane;
             const uint32_t e = (uint32_t)p[t < 0 ? 0 : 15] * 0x01010101u;
@@ -343,7 +372,7 @@ __device__ __forceinline__ void fq_windows_patch(MbLds &s, const FqLane &k, bool
         }
     }
     if (patch_c && lane < 54) {
-        const int t = (c0 + k.cd4) >> 3;
+        const int t = (c0 + (k.kq68 >> 4)) >> 3;
         if (t < 0 || t >= mbw) {
             uint8_t *p = base + FQ_WC + 4 * lane;
             *reinterpret_cast<uint32_t *>(p) = (uint32_t)p[t < 0 ? 0 : 3] * 0x01010101u;
@@ -427,24 +456,26 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
         return byte_perm(pk_sat_u8(p23), pk_sat_u8(p01), 0x05040100u);
     };
     uint32_t v;
+    FQ_MARK("luma_switch");
     switch (pos) {
-    case 0: v = gsamples(0, 0); break;
-    case 1: v = fq_lerp(gsamples(0, 0), hband(2)); break;
-    case 2: v = hband(2); break;
-    case 3: v = fq_lerp(gsamples(0, 1), hband(2)); break;
-    case 4: transpose(false, 0); v = fq_lerp(gsamples(0, 0), vraw()); break;
-    case 8: transpose(false, 0); v = vraw(); break;
-    case 12: transpose(false, 0); v = fq_lerp(gsamples(1, 0), vraw()); break;
-    case 5: { const uint32_t b = hband(2); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
-    case 7: { const uint32_t b = hband(2); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
-    case 13: { const uint32_t b = hband(3); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
-    case 15: { const uint32_t b = hband(3); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
-    case 10: transpose(true, 0); v = vsums(); break;
-    case 6: { const uint32_t b = hband(2); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
-    case 14: { const uint32_t b = hband(3); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
-    case 9: { transpose(false, 0); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }
-    default: { transpose(false, 1); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }     /* 11 */
+    case 0: FQ_MARK("case0"); v = gsamples(0, 0); break;
+    case 1: FQ_MARK("case1"); v = fq_lerp(gsamples(0, 0), hband(2)); break;
+    case 2: FQ_MARK("case2"); v = hband(2); break;
+    case 3: FQ_MARK("case3"); v = fq_lerp(gsamples(0, 1), hband(2)); break;
+    case 4: FQ_MARK("case4"); transpose(false, 0); v = fq_lerp(gsamples(0, 0), vraw()); break;
+    case 8: FQ_MARK("case8"); transpose(false, 0); v = vraw(); break;
+    case 12: FQ_MARK("case12"); transpose(false, 0); v = fq_lerp(gsamples(1, 0), vraw()); break;
+    case 5: FQ_MARK("case5"); { const uint32_t b = hband(2); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
+    case 7: FQ_MARK("case7"); { const uint32_t b = hband(2); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
+    case 13: FQ_MARK("case13"); { const uint32_t b = hband(3); transpose(false, 0); v = fq_lerp(b, vraw()); break; }
+    case 15: FQ_MARK("case15"); { const uint32_t b = hband(3); transpose(false, 1); v = fq_lerp(b, vraw()); break; }
+    case 10: FQ_MARK("case10"); transpose(true, 0); v = vsums(); break;
+    case 6: FQ_MARK("case6"); { const uint32_t b = hband(2); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
+    case 14: FQ_MARK("case14"); { const uint32_t b = hband(3); transpose(true, 0); v = fq_lerp(b, vsums()); break; }
+    case 9: FQ_MARK("case9"); { transpose(false, 0); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }
+    default: { FQ_MARK("case11"); transpose(false, 1); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }     /* 11 */
     }
+    FQ_MARK("luma_resid");
     if (has_resid) {
         /* the four residuals of these samples on top (h264idct_template.c:54-66's "+ dst", clipped) */
         const mi355_u32x2 r = *reinterpret_cast<const mi355_u32x2 *>(base + k.rsy);
@@ -528,8 +559,10 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
             if (a & FQA_FAST) {
                 auto issue = [&](int m, uint32_t am, int set) {
                     const uint32_t d = fq_lane_word(rd, m), e = fq_lane_word(re, m);
-                    fq_windows_issue(s, k, pic.desc, pic.hot, (int)((am >> 17) & 31u), (int16_t)(d & 0xFFFFu), (int16_t)(e & 0xFFFFu), (int)d >> 16, (int)e >> 16, set);
+                    if (am & FQA_INSIDE) fq_windows_issue_inside(s, k, pic.desc, pic.hot, (int)((am >> 17) & 31u), (int16_t)(d & 0xFFFFu), (int16_t)(e & 0xFFFFu), (int)d >> 16, (int)e >> 16, set);
+                    else fq_windows_issue(s, k, pic.desc, pic.hot, (int)((am >> 17) & 31u), (int16_t)(d & 0xFFFFu), (int16_t)(e & 0xFFFFu), (int)d >> 16, (int)e >> 16, set);
                 };
+                FQ_MARK("issue");
                 if (!pre_w) issue(i, a, woff);
                 if ((a & FQA_RESID) && !pre_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i);
                 next_w = (an & FQA_FAST) != 0;
@@ -539,8 +572,10 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
                  * store as well returned with coefficients still in flight: found on the device, never in the emulator).  Without younger loads: all. */
                 if (next_w) fq_wait_vm2(); else fq_wait_vm0();
                 MI355_WAVE_SYNC();
+                FQ_MARK("idct");
                 if (a & FQA_RESID) fq_idct(s, k, rl, fq_lane_word(rn, i), (a & FQA_CHROMA) != 0, pic.mb + (mb_xy0 + i));
                 MI355_WAVE_SYNC();                                         /* every lane has read its coefficients */
+                FQ_MARK("coefnext");
                 next_c = next_w && (an & FQA_RESID);
                 if (next_c) fq_coef_dma(s, k, pic.coef, mb_xy0 + i + 1);
                 if (a & (FQA_PATCH_Y | FQA_PATCH_C)) {
@@ -548,14 +583,18 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
                     fq_windows_patch(s, k, (a & FQA_PATCH_Y) != 0, (a & FQA_PATCH_C) != 0, (int16_t)(e & 0xFFFFu), (int)e >> 16, woff, pic.hot.mb_width);
                     MI355_WAVE_SYNC();
                 }
+                FQ_MARK("luma");
                 fq_luma(s, k, (int)(a & 31u) + woff, (int)((a >> 7) & 15u), (a & FQA_RESID) != 0);
+                FQ_MARK("chroma");
                 fq_chroma(s, k, (int)((a >> 5) & 3u) + woff, fq_lane_word(rw, i), (a & FQA_RESID) != 0);
                 MI355_WAVE_SYNC();
+                FQ_MARK("store");
                 fq_store(s, pic.hot.recon[0] + tile_y_off(mb_x + i, mb_y, pic.hot.recon_stride[0]), pic.hot.recon[1] + tile_c_off(mb_x + i, mb_y, pic.hot.recon_stride[1]));
                 MI355_WAVE_SYNC();
             } else if (!(a & FQA_INTRA)) {
                 deferred |= 1u << i;
             }
+            FQ_MARK("tail");
             pre_w = next_w; pre_c = next_c;
             a = an;
         }
@@ -566,21 +605,23 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
     if (lane_id() == 0) rest[wave] = deferred;
 }
 
-/* ---- the macroblocks the runs left: wave g looks at the words of runs 16 g .. 16 g + 15 (one word a run: bit i = the run's macroblock i is an inter macroblock
- * of another kind than the plain one) and takes them one at a time through h264_recon_dev.h's code.  A batch of plain P macroblocks costs this launch
- * nruns / 16 waves that read sixty-four bytes and end. ---- */
+/* ---- the macroblocks the runs left: wave g looks at the words of runs FQ_REST g .. FQ_REST g + FQ_REST - 1 (one word a run: bit i = the run's macroblock i is an
+ * inter macroblock of another kind than the plain one) and takes them one at a time through h264_recon_dev.h's code.  A batch of plain P macroblocks costs this
+ * launch nruns / FQ_REST waves that read a few words and end (some 10 us per 2048 pictures of 1080p); a batch of partitioned macroblocks gives every wave some
+ * hundred of them, a millisecond's work: the fewer runs per wave, the less the last round of waves leaves idle. ---- */
+constexpr int FQ_REST = 8;
 __device__ __forceinline__ void recon_inter_rest(MbLds &s, const mi355_h264_frame *__restrict__ frames, int max_w, int max_h, int run, int runs_row,
                                                  unsigned long long inv_runs, unsigned long long inv_h, int nruns, int ngroups, int per_xcd, const uint32_t *__restrict__ rest)
 {
     const int g = xcd_linear((int)blockIdx.x, per_xcd);
     if (g >= ngroups) return;
-    const int r = 16 * g + (lane_id() & 15);
+    const int r = FQ_REST * g + (lane_id() & (FQ_REST - 1));
     const uint32_t mine = r < nruns ? rest[r] : 0u;
     if (!__any(mine != 0)) return;
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < FQ_REST; j++) {
         uint32_t m = fq_lane_word(mine, j);
         if (!m) continue;
-        const int w = 16 * g + j;
+        const int w = FQ_REST * g + j;
         const int row = div_magic(w, inv_runs);
         const int mb_x = (w - row * runs_row) * run;
         const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
