@@ -90,6 +90,8 @@ static inline void fq_wait_vm2() {}
 static inline int fq_med3_0(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
 typedef const uint32_t *fq_kptr;
 static inline fq_kptr fq_konst(const void *p) { return reinterpret_cast<const uint32_t *>(p); }
+struct fq_ptr2 { uint32_t w[4]; uint32_t operator[](int i) const { return w[i]; } };
+static inline const fq_ptr2 *fq_konst2(const void *p) { return reinterpret_cast<const fq_ptr2 *>(p); }
 #else
 __device__ __forceinline__ uint64_t fq_lds64(const uint8_t *p) { return *reinterpret_cast<const uint64_t *>(p); }       /* p on 8 bytes */
 __device__ __forceinline__ uint32_t fq_lerp(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
@@ -123,6 +125,8 @@ __device__ __forceinline__ int fq_med3_0(int x, int hi) { int r; asm("v_med3_i32
 /* a wave-uniform address read through the scalar cache: the record's words arrive in scalar registers, no LDS read, no v_readfirstlane */
 typedef const __attribute__((address_space(4))) uint32_t *fq_kptr;
 __device__ __forceinline__ fq_kptr fq_konst(const void *p) { return (fq_kptr)(unsigned long long)p; }
+typedef uint32_t fq_ptr2 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ const __attribute__((address_space(4))) fq_ptr2 *fq_konst2(const void *p) { return (const __attribute__((address_space(4))) fq_ptr2 *)(unsigned long long)p; }
 #endif
 
 /* LDS answers a read that is not naturally aligned one lane per cycle (64 cycles a wave, tools/ubench/lds_rate.hip: a b64 four bytes off its alignment included):
@@ -277,7 +281,6 @@ __device__ __forceinline__ void fq_coef_dma(MbLds &s, const FqLane &k, const int
 {
     const uint8_t *cp = reinterpret_cast<const uint8_t *>(coef + (size_t)mb_xy * MI355_H264_COEFS_PER_MB);
     if (lane_id() < 48) fq_dma16<FQ_COEF>(cp + k.csrc, s);
-#endif
 }
 
 /* ---- residual, first half: the 24 blocks' inverse transforms into registers (two lanes per block; residual_blocks's arithmetic, see there) ----
@@ -345,7 +348,8 @@ __device__ __forceinline__ void fq_windows_issue(MbLds &s, const FqLane &k, cons
  * window's first tile in the scalar base, twelve vector instructions for the two addresses instead of twenty-five */
 __device__ __forceinline__ void fq_windows_issue_inside(MbLds &s, const FqLane &k, const mi355_h264_frame *desc, const FrameHot &fr, int slot, int y0, int t0, int cy, int c0, int woff)
 {
-    fq_kptr rp = fq_konst(desc->ref[slot]);
+    /* both plane pointers in ONE scalar load (as two loads the second took the first's registers and waited behind the luma request) */
+    const fq_ptr2 rp = *fq_konst2(desc->ref[slot]);
     const uint8_t *ry = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)));
     const uint8_t *rc = mi355_global(reinterpret_cast<const uint8_t *>((unsigned long long)rp[2] | ((unsigned long long)rp[3] << 32)));
     {
@@ -637,3 +641,4 @@ __device__ __forceinline__ void recon_inter_rest(MbLds &s, const mi355_h264_fram
 }
 
 }  // namespace
+#endif
