@@ -377,6 +377,7 @@ int   mi355_stream_wait_event(void *stream, void *event);
 void *mi355_event_create(void);
 void  mi355_event_destroy(void *event);
 int   mi355_event_record(void *event, void *stream);
+int   mi355_event_query(void *event);                  /* 1 finished, 0 not yet, -1 error; never waits */
 float mi355_event_elapsed_ms(void *start, void *end);   /* waits for `end` */
 
 #ifdef __cplusplus

@@ -1105,10 +1105,6 @@ k_deblock_tiled(const mi355_h264_frame *__restrict__ frames, int nframes, int nb
     const mi355_h264_frame &fr = frames[pic];
     if (4 * band >= uniform(fr.mb_height) || uniform(fr.surface_layout) != MI355_SURFACE_TILED) return;
     uint32_t *prog = mi355_global(sync) + 16 + (size_t)pic * (size_t)nbands;
-#ifdef MI355_EXP_DB2_ONLY        /* developer experiment: the instruction listing / register count of one instance alone (P pictures) */
-    deblock3_band<false, 1>(s, nullptr, fr, band, prog, 0);
-    return;
-#endif
     if (mi355_global(fr.mv[1]) != nullptr) deblock3_band<true, 1>(s, nullptr, fr, band, prog, 0);
     else deblock3_band<false, 1>(s, nullptr, fr, band, prog, 0);
 }

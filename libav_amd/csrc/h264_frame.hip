@@ -546,6 +546,13 @@ extern "C" void *mi355_event_create(void)
 }
 extern "C" void mi355_event_destroy(void *e) { (void)hipEventDestroy((hipEvent_t)e); }
 extern "C" int mi355_event_record(void *e, void *stream) { return hipEventRecord((hipEvent_t)e, (hipStream_t)stream) == hipSuccess ? 0 : -1; }
+/* 1: everything recorded before the event has finished; 0: not yet; -1: error.  Never waits (a caller that polls with a deadline of its own) */
+extern "C" int mi355_event_query(void *e)
+{
+    const hipError_t r = hipEventQuery((hipEvent_t)e);
+    if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return r == hipSuccess ? 1 : -1;
+}
 /* milliseconds between two recorded events; waits for `b` */
 extern "C" float mi355_event_elapsed_ms(void *a, void *b)
 {

@@ -172,6 +172,70 @@ def test_loop_filter_bands_hand_down_under_load(mi355, oracle, F, tiled):
         d.free()
 
 
+def test_single_launch_loop_filter_with_every_cu_taken(mi355, oracle):
+    """k_deblock_tiled hands rows from band to band inside ONE launch: a band spins on the progress counter of the band above.  That is safe only
+    because bands are taken in ticket order — the band waited for has always started.  Here the launch gets the device the hard way: 2048 1080p
+    pictures (34816 bands) on one stream while a second stream keeps every CU's LDS and wave slots full with reconstruction launches of another
+    batch (k_recon_inter_tiled: eight waves per SIMD, all 160 KB of a CU's LDS), so the filter's workgroups start a few at a time, in whatever
+    slots fall free.  Must finish (polled with a deadline: no blocking wait that a hang would turn into a dead test process) and every picture
+    must equal the oracle's."""
+    import ctypes as C
+    import time
+    lib = mi355.lib
+    F, FB = 2048, 256
+    fs = HF.synth_frames_fast(4, 120, 68, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
+    other = HF.synth_frames_fast(2, 120, 68, seed=0x264, lib=lib)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_stream_create", C.c_void_p, []), ("mi355_stream_destroy", None, [C.c_void_p]),
+                          ("mi355_event_create", C.c_void_p, []), ("mi355_event_destroy", None, [C.c_void_p]),
+                          ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]), ("mi355_event_query", C.c_int, [C.c_void_p]),
+                          ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p])):
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = at
+    d = HF.DeviceFrames(mi355, fs, replicate=F, tiled=True)
+    busy = HF.DeviceFrames(mi355, other, replicate=FB, tiled=True)
+    sa, sb = C.c_void_p(lib.mi355_stream_create()), C.c_void_p(lib.mi355_stream_create())
+    ev = [C.c_void_p(lib.mi355_event_create()) for _ in range(4)]
+    try:
+        d.decode_by_layout()                                                   # reconstruction (and a first, undisturbed run of the filter)
+        assert lib.mi355_memcpy_d2d(d.dst, d.recon, F * d.fsz) == 0             # scribble: the unfiltered pictures
+        assert lib.mi355_sync(None) == 0
+        # ~60 ms of reconstruction launches queued on stream b, then the loop filter of the 2048 pictures on stream a
+        lib.mi355_event_record(ev[0], sb)
+        for _ in range(80):
+            assert lib.mi355_h264_recon_inter_layouts_dev(busy.d_desc, FB, fs.mb_w, fs.mb_h, 2, sb) == 0
+        lib.mi355_event_record(ev[1], sb)
+        lib.mi355_event_record(ev[2], sa)
+        assert lib.mi355_h264_deblock_layouts_dev(d.d_desc, F, fs.mb_w, fs.mb_h, 2, sa) == 0
+        lib.mi355_event_record(ev[3], sa)
+        deadline = time.time() + 120
+        while not (lib.mi355_event_query(ev[3]) == 1 and lib.mi355_event_query(ev[1]) == 1):
+            assert lib.mi355_event_query(ev[3]) >= 0 and lib.mi355_event_query(ev[1]) >= 0
+            assert time.time() < deadline, "the loop filter did not finish within 120 s beside a device full of other work"
+            time.sleep(0.002)
+        t_busy, t_filter = lib.mi355_event_elapsed_ms(ev[0], ev[1]), lib.mi355_event_elapsed_ms(ev[2], ev[3])
+        print("busy stream %.1f ms, loop filter of %d pictures beside it %.1f ms" % (t_busy, F, t_filter))
+        assert t_filter > 8.0, "the filter ran as if alone (%.1f ms): the other stream did not take the device" % t_filter
+        bad = []
+        for first in range(0, F, 32):
+            got = d.fetch(d.dst, first, 32)
+            for i in range(32):
+                g = (first + i) % fs.F
+                if not all(np.array_equal(dst_o[p][g], got[p][i]) for p in range(3)):
+                    bad.append(first + i)
+        assert not bad, "%d of %d pictures differ from the oracle, first: %s" % (len(bad), F, bad[:8])
+    finally:
+        lib.mi355_sync(None)
+        for e in ev:
+            lib.mi355_event_destroy(e)
+        lib.mi355_stream_destroy(sa)
+        lib.mi355_stream_destroy(sb)
+        busy.free()
+        d.free()
+
+
 @pytest.mark.parametrize("tiled", (True, False))
 @pytest.mark.parametrize("name", list(frame_cases.CASES))
 def test_frame_pipeline_gpu_layout_entry_points(mi355, oracle, name, tiled):

@@ -80,7 +80,7 @@ static inline void __threadfence_block() {}
 typedef int hipError_t;
 typedef struct emu_stream *hipStream_t;
 typedef struct emu_event *hipEvent_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 struct hipDeviceProp_t {
     char name[256];
@@ -135,6 +135,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }                /* the emulator's launches are synchronous: always finished */
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
