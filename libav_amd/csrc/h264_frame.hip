@@ -62,8 +62,45 @@ struct IntraLds {
 #define TILE(x, y) s.tile[((y) + 1) * TP + (x) + TO]
 #define CTILE(p, x, y) s.ctile[p][((y) + 1) * CP + (x) + TO]
 
-template <bool TILED>
-__device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_frame &frd, int mb_xy)
+/* AGENT (k_recon_intra_all, a macroblock with intra neighbours of the SAME launch): the neighbours' samples were written by other waves — perhaps of another
+ * XCD — a moment ago: they are read, and this macroblock's samples written, at agent scope (past the L2 of the wave's own XCD; the writer's stores
+ * write-through), the recipe of k_deblock_tiled's hand-down */
+__device__ __forceinline__ uint8_t intra_edge_byte(const uint8_t *p, bool agent)
+{
+    if (!agent) return *p;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return (uint8_t)(agent_load_u32(reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3)) >> (8 * (a & 3)));
+}
+template <bool AGENT>
+__device__ __forceinline__ void intra_store_dword(uint8_t *p, uint32_t v)
+{
+    if (AGENT) agent_store_u32(reinterpret_cast<uint32_t *>(p), v);
+    else *reinterpret_cast<uint32_t *>(p) = v;
+}
+/* store_mb / store_mb_pitched_tiled (h264_recon_dev.h) with the scope as a parameter */
+template <bool TILED, bool AGENT>
+__device__ __forceinline__ void intra_store_mb(const uint8_t *y, int ypitch, const uint8_t *cb, const uint8_t *cr, int cpitch, const FrameHot &fr, int mb_x, int mb_y)
+{
+    if (!AGENT) {
+        if (TILED) store_mb_pitched_tiled<true>(y, ypitch, cb, cr, cpitch, fr, mb_x, mb_y);
+        else store_mb<true>(y, ypitch, cb, cr, cpitch, fr, mb_x, mb_y);
+        return;
+    }
+    const int lane = lane_id();
+    const int row = lane >> 2, seg = lane & 3;
+    const int plane = (lane >> 4) & 1, crow = (lane >> 1) & 7, cseg = lane & 1;
+    const uint32_t vy = tile_dword<true>(y + row * ypitch + 4 * seg), vc = tile_dword<true>((plane ? cr : cb) + crow * cpitch + 4 * cseg);
+    if (TILED) {
+        intra_store_dword<true>(fr.recon[0] + tile_y_off(mb_x, mb_y, fr.recon_stride[0]) + 4 * lane, vy);
+        if (lane < 32) intra_store_dword<true>(fr.recon[1] + tile_c_off(mb_x, mb_y, fr.recon_stride[1]) + 4 * lane, vc);
+    } else {
+        intra_store_dword<true>(fr.recon[0] + (uint32_t)(__mul24(mb_y * 16 + row, fr.recon_stride[0]) + mb_x * 16 + 4 * seg), vy);
+        if (lane < 32) intra_store_dword<true>((plane ? fr.recon[2] : fr.recon[1]) + (uint32_t)(__mul24(mb_y * 8 + crow, fr.recon_stride[1]) + mb_x * 8 + 4 * cseg), vc);
+    }
+}
+
+template <bool TILED, bool AGENT = false>
+__device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_frame &frd, int mb_xy, bool agent_edges = false)
 {
     const int lane = lane_id();
     const FrameHot fr = frame_hot(frd);
@@ -93,9 +130,10 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
                                   : (left_y ? tile_y_off(mb_x - 1, mb_y, ys) + (lane - 32) * 16 + 15 : tile_y_off(mb_x, mb_y, ys));
         const uint32_t tc = top_c ? tile_c_off(xtc >> 3, mb_y - 1, cs) + 7 * 8 + (xtc & 7)
                                   : (left_c ? tile_c_off(mb_x - 1, mb_y, cs) + (lane - 16) * 8 + 7 : tile_c_off(mb_x, mb_y, cs));
-        e_y = fr.recon[0][ty]; e_cb = fr.recon[1][tc]; e_cr = fr.recon[1][tc + 64];
+        e_y = intra_edge_byte(fr.recon[0] + ty, AGENT && agent_edges); e_cb = intra_edge_byte(fr.recon[1] + tc, AGENT && agent_edges);
+        e_cr = intra_edge_byte(fr.recon[1] + tc + 64, AGENT && agent_edges);
     } else {
-        e_y = ry[oy]; e_cb = rcb[oc]; e_cr = rcr[oc];
+        e_y = intra_edge_byte(ry + oy, AGENT && agent_edges); e_cb = intra_edge_byte(rcb + oc, AGENT && agent_edges); e_cr = intra_edge_byte(rcr + oc, AGENT && agent_edges);
     }
     MI355_ISSUE_FENCE();
     load_mb_commit(s.mb, ld, true, fr.mv[0] != nullptr, fr.mv[1] != nullptr);
@@ -104,8 +142,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
 
     if (t & MI355_MB_INTRA_PCM) {        /* h264_mb_template.c:139-153 */
         const uint8_t *src = reinterpret_cast<const uint8_t *>(s.mb.coef);
-        if (TILED) store_mb_pitched_tiled<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
-        else store_mb<true>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
+        intra_store_mb<TILED, AGENT>(src, 16, src + 256, src + 320, 8, fr, mb_x, mb_y);
         return;
     }
     /* edge samples -> tiles */
@@ -184,8 +221,7 @@ __device__ __forceinline__ void recon_intra_mb(IntraLds &s, const mi355_h264_fra
         }
     }
     if (!(t & MI355_MB_INTRA16x16)) residual_chroma<true>(s.mb, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP);
-    if (TILED) store_mb_pitched_tiled<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
-    else store_mb<true>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
+    intra_store_mb<TILED, AGENT>(&TILE(0, 0), TP, &CTILE(0, 0, 0), &CTILE(1, 0, 0), CP, fr, mb_x, mb_y);
 }
 #undef TILE
 
@@ -201,6 +237,49 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     const int mb_xy = (int)mi355_global(frd.intra_list)[first + k];
     if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true>(s, frd, mb_xy);
     else recon_intra_mb<false>(s, frd, mb_xy);
+}
+
+/* Every level of every picture in ONE launch.  Workgroup b belongs to picture b % nframes and takes the next entry of that picture's intra list (a ticket from
+ * the picture's counter: the list is in level order, so whoever holds a ticket waits only for holders of lower ones, and those have started).  A macroblock of
+ * level L may go when every macroblock of the levels below has left its samples in memory: the picture's second counter, raised by each macroblock behind its
+ * write-through stores, has reached the number of list entries below level L.  A launch per level made all pictures wait for the slowest wave of a level, 254
+ * times for an I picture; here a picture's levels follow each other as fast as its own macroblocks finish, side by side with the other pictures'. */
+constexpr int INTRA_SINGLE_LEVELS = 1;                 /* batches with at least this many levels take the single launch (MI355_INTRA_SINGLE=0 / 1 pins a form) */
+constexpr uint32_t INTRA_NAPS_MAX = 1u << 22;          /* ~2 s of naps: a wave that has waited this long goes on (a wrong picture rather than a hung device) */
+__global__ void __launch_bounds__(64)
+k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, uint32_t *__restrict__ sync)
+{
+    __shared__ IntraLds s;
+    const int k = (int)(blockIdx.x / (unsigned)nframes), f = (int)(blockIdx.x - (unsigned)k * (unsigned)nframes);
+    const mi355_h264_frame &frd = frames[f];
+    const int nlev = uniform(frd.max_intra_level);
+    if (nlev <= 0) return;
+    const int32_t *const ls = mi355_global(frd.intra_level_start);
+    const int count = uniform(ls[nlev]);
+    if (k >= count) return;                               /* the picture's first `count` workgroups take its `count` tickets */
+    uint32_t *const ticket = mi355_global(sync) + 2 * (size_t)f, *const done = ticket + 1;
+    const int lane = lane_id();
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1u);
+    t = (uint32_t)lane_value((int)t, 0);
+    if (t >= (uint32_t)count) return;
+    /* list entries below the ticket's level: the largest level start that is <= t (the starts ascend, ls[0] = 0) */
+    int below = 0;
+    for (int j = 0; j <= nlev; j += 64) {
+        const int i = j + lane;
+        below += __popcll(__ballot(i <= nlev && (uint32_t)mi355_global_v(ls)[i < nlev ? i : nlev] <= t));
+    }
+    const uint32_t need = (uint32_t)uniform(ls[below - 1]);
+    if (need) {
+        uint32_t naps = 0;
+        while ((uint32_t)uniform((int)agent_load_u32(mi355_global_v(done))) < need && naps < INTRA_NAPS_MAX) { wave_nap(); naps++; }
+        MI355_ISSUE_FENCE();
+    }
+    const int mb_xy = (int)uniform((int)mi355_global(frd.intra_list)[t]);
+    if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true, true>(s, frd, mb_xy, need != 0);
+    else recon_intra_mb<false, true>(s, frd, mb_xy, need != 0);
+    agent_drain_stores();                                 /* the macroblock's samples have reached memory */
+    if (lane == 0) atomicAdd(done, 1u);
 }
 
 }  // namespace
@@ -264,6 +343,19 @@ extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frame
      * 64 pictures 5.0 against 1.9, P pictures 1.1 against 0.9: a level of an I picture is up to 60 macroblocks wide, a workgroup
      * works through it in rounds, and the picture's 254 levels become a serial chain of ~20 us each whatever the batch, while a
      * launch runs a level of ALL pictures side by side for ~7.5 us */
+    static const int single = std::getenv("MI355_INTRA_SINGLE") ? std::atoi(std::getenv("MI355_INTRA_SINGLE")) : -1;     /* 0 / 1 pins the form */
+    long long per_picture = 0;
+    for (int level = 1; level <= max_intra_level; level++) per_picture += level_widths[level - 1] > 0 ? level_widths[level - 1] : 0;
+    if (per_picture <= 0) return 0;
+    if (single == 1 || (single != 0 && max_intra_level >= INTRA_SINGLE_LEVELS)) {
+        /* ONE launch: a picture needs at most the sum of the level widths workgroups (the widths are maxima over the batch) */
+        if ((long long)nframes * per_picture > 0x7FFFFFFFLL) return -3;
+        uint32_t *sync = mi355::sync_words((hipStream_t)stream, 2 * (size_t)nframes);
+        if (!sync) return -4;
+        MI355_TRY(hipMemsetAsync(sync, 0, 2 * (size_t)nframes * sizeof(uint32_t), (hipStream_t)stream), -4);
+        hipLaunchKernelGGL(k_recon_intra_all, dim3((unsigned)(nframes * per_picture)), dim3(64), 0, (hipStream_t)stream, d_frames, nframes, sync);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     for (int level = 1; level <= max_intra_level; level++) {
         const int width = level_widths[level - 1];
         if (width <= 0) continue;

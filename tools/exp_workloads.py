@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer experiment (GPU box, round 5): pass times of the three passes on a few workloads of the config-2 family with the library that is in
-libav_amd/ right now (the session script swaps build/variants/*.so in).  usage: exp_workloads.py <label> [workload ...]   workloads: base mixed f512 f64"""
+libav_amd/ right now (the session script swaps build/variants/*.so in).  usage: exp_workloads.py <label> [workload ...]   workloads: base mixed f512 f64 intra512 intra64"""
 import ctypes as C
 import os
 import sys
@@ -71,3 +71,7 @@ for w in which:
         measure("f512", base, 512)
     elif w == "f64":
         measure("f64", base, 64)
+    elif w == "intra512":
+        measure("intra512", HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0), 512)
+    elif w == "intra64":
+        measure("intra64", HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0), 64)
