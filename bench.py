@@ -40,7 +40,7 @@ LAYOUT_MASK = {False: 1, True: 2}        # MI355_LAYOUTS_LINEAR / MI355_LAYOUTS_
 
 
 def level_widths(fs):
-    """host array for mi355_h264_recon_intra_levels_dev: widest level l over the pictures of the batch"""
+    """host array for mi355_h264_recon_intra_all_dev / _levels_dev: widest level l over the pictures of the batch"""
     import ctypes as C
     return (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
 
@@ -143,7 +143,7 @@ def main():
     big = fs
 
     for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-                          ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                          ("mi355_h264_recon_intra_all_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                           ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_h264_decode_frames_wide_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                           ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -166,7 +166,7 @@ def main():
             assert lib.mi355_h264_recon_inter_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[1], st)
-            assert lib.mi355_h264_recon_intra_levels_dev(d, per, big.max_intra_level, level_widths(big), st) == 0
+            assert lib.mi355_h264_recon_intra_all_dev(d, per, mbw, mbh, big.max_intra_level, level_widths(big), st) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[2], st)
             assert lib.mi355_h264_deblock_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
@@ -336,7 +336,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
 
             def once():
                 inter()
-                assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
+                assert lib.mi355_h264_recon_intra_all_dev(dev.d_desc, F, mbw, mbh, fs.max_intra_level, level_widths(fs), None) == 0
                 assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
                 if conv is not None:
                     assert lib.mi355_h264_surface_convert_dev(conv, F, mbw, mbh, None) == 0
@@ -352,7 +352,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             lib.mi355_event_record(ev[0], None)
             inter()
             lib.mi355_event_record(ev[1], None)
-            assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, level_widths(fs), None) == 0
+            assert lib.mi355_h264_recon_intra_all_dev(dev.d_desc, F, mbw, mbh, fs.max_intra_level, level_widths(fs), None) == 0
             lib.mi355_event_record(ev[2], None)
             assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, LAYOUT_MASK[layout_tiled], None) == 0
             lib.mi355_event_record(ev[3], None)

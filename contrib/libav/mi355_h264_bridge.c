@@ -369,7 +369,7 @@ static int disp_enqueue(Disp *D, int slot)
         if (!rc && mi355_h264_decode_frames_wide_dev(dd, nd, mw, mh, 0, NULL, b0->bit_depth, b0->kidc, D->in[slot][0]->s->cls >= 1000 ? 12 : 4, st) != 0) rc = -1;
     } else {
     if (!rc && any_inter && mi355_h264_recon_inter_sparse_dev(dr, nd, mw, mh, st) != 0) rc = -1;      /* staging in host memory: skip what is not coded */
-    if (!rc && mi355_h264_recon_intra_levels_dev(dr, nd, maxl, D->widths, st) != 0) rc = -1;
+    if (!rc && mi355_h264_recon_intra_all_dev(dr, nd, mw, mh, maxl, D->widths, st) != 0) rc = -1;
     if (!rc && mi355_h264_deblock_layouts_dev(dd, nd, mw, mh, layouts, st) != 0) rc = -1;      /* the loop filter's kernel(s) for the layouts this batch holds */
     }
     if (!rc && ncopy && mi355_copy_batch_dev(D->jobs[slot], ncopy, max_bytes, st) != 0) rc = -1;
@@ -1145,7 +1145,7 @@ static int submit_picture(Bridge *b, H264Context *h)
                 mi355_h264_decode_frames_wide_dev(s->d_desc + np, np, b->mb_w, b->mb_h, 0, NULL, b->bit_depth, b->kidc, b->mbaff_frame ? 12 : 4, b->stream) != 0) return -4;
         } else
         if (mi355_h264_recon_inter_sparse_dev(s->d_desc, np, b->mb_w, b->mb_h, b->stream) != 0 ||
-            mi355_h264_recon_intra_levels_dev(s->d_desc, np, maxl, s->widths, b->stream) != 0 ||
+            mi355_h264_recon_intra_all_dev(s->d_desc, np, b->mb_w, b->mb_h, maxl, s->widths, b->stream) != 0 ||
             mi355_h264_deblock_layouts_dev(s->d_desc + np, np, b->mb_w, b->mb_h, b->tiled ? MI355_LAYOUTS_TILED : MI355_LAYOUTS_LINEAR, b->stream) != 0) return -4;
         if (b->tiled) {
             convert_job(b, cur, s->out, s->cvt);

@@ -303,6 +303,11 @@ int mi355_h264_decode_frames_wide_dev(const mi355_h264_frame *d_frames, int nfra
 
 /* Individual passes (same argument meaning), exposed for measurement and tests. */
 int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream);
+/* The intra pass for a caller that names the batch's grid (as the decode_frames entry points do): every level of every picture in ONE launch — a macroblock
+ * waits for its own intra neighbours (left, above-left, above, above-right: the type words of their records, one flag byte per macroblock in scratch memory of
+ * the stream) instead of all pictures waiting for a level's slowest wave at a launch boundary.  The records must hold what mi355_h264_intra_schedule() saw
+ * (mb_type) and the list its order.  MI355_INTRA_SINGLE=0 in the environment: the launch per level of mi355_h264_recon_intra_levels_dev. */
+int mi355_h264_recon_intra_all_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int max_intra_level, const int32_t *level_widths, void *stream);
 int mi355_h264_recon_inter_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream);
 /* The same for a caller that knows which surface layouts occur in the batch (MI355_LAYOUTS_*, below): a batch that is tiled throughout runs the
  * kernel instance that carries the tiled form of the macroblock code alone (fewer registers spilled, half the code); a picture of another layout

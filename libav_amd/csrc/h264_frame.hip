@@ -239,47 +239,55 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
     else recon_intra_mb<false>(s, frd, mb_xy);
 }
 
-/* Every level of every picture in ONE launch.  Workgroup b belongs to picture b % nframes and takes the next entry of that picture's intra list (a ticket from
- * the picture's counter: the list is in level order, so whoever holds a ticket waits only for holders of lower ones, and those have started).  A macroblock of
- * level L may go when every macroblock of the levels below has left its samples in memory: the picture's second counter, raised by each macroblock behind its
- * write-through stores, has reached the number of list entries below level L.  A launch per level made all pictures wait for the slowest wave of a level, 254
- * times for an I picture; here a picture's levels follow each other as fast as its own macroblocks finish, side by side with the other pictures'. */
+/* Every level of every picture in ONE launch.  Workgroup b takes entry k = b / nframes of the intra list of picture b % nframes.  The list is in level order
+ * and a macroblock's level is one more than the highest level among its left, above-left, above and above-right neighbours (mi355_h264_intra_schedule), so the
+ * intra macroblocks among those four are earlier entries: the wave reads their type words, waits until each of them has set its byte in `flags` (one byte per
+ * macroblock of the launch's grid, zeroed by the host) — set behind write-through stores of the samples, which this wave then reads at agent scope — and sets
+ * its own when its stores have reached memory.  No counter anybody shares: two atomics per macroblock on a picture's pair of counters (the first form) took
+ * 0.3 - 0.6 us EACH, one after the other.  A launch per level made all pictures wait for the slowest wave of a level, 254 times for an I picture; here a
+ * macroblock goes as soon as its own neighbours are done.
+ * Progress: workgroups start in the order of their numbers on every XCD, so the lowest-numbered unfinished workgroup is always running, and it waits for
+ * nobody (its neighbours have lower numbers).  Should a device ever start them otherwise, INTRA_NAPS_MAX ends the wait: a wrong picture, not a hung device. */
 constexpr int INTRA_SINGLE_LEVELS = 1;                 /* batches with at least this many levels take the single launch (MI355_INTRA_SINGLE=0 / 1 pins a form) */
-constexpr uint32_t INTRA_NAPS_MAX = 1u << 22;          /* ~2 s of naps: a wave that has waited this long goes on (a wrong picture rather than a hung device) */
+constexpr uint32_t INTRA_NAPS_MAX = 1u << 21;          /* ~1 s of naps */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t intra_flag_word(const uint8_t *p) { uint32_t v; std::memcpy(&v, reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3), 4); return v; }
+static inline void intra_flag_set(uint8_t *p) { *p = 1; }
+#else
+__device__ __forceinline__ uint32_t intra_flag_word(const uint8_t *p) { return agent_load_u32(reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3)); }
+__device__ __forceinline__ void intra_flag_set(uint8_t *p) { __hip_atomic_store(p, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 __global__ void __launch_bounds__(64)
-k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, uint32_t *__restrict__ sync)
+k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, int nmb_max, uint8_t *__restrict__ flags)
 {
     __shared__ IntraLds s;
     const int k = (int)(blockIdx.x / (unsigned)nframes), f = (int)(blockIdx.x - (unsigned)k * (unsigned)nframes);
     const mi355_h264_frame &frd = frames[f];
     const int nlev = uniform(frd.max_intra_level);
     if (nlev <= 0) return;
-    const int32_t *const ls = mi355_global(frd.intra_level_start);
-    const int count = uniform(ls[nlev]);
-    if (k >= count) return;                               /* the picture's first `count` workgroups take its `count` tickets */
-    uint32_t *const ticket = mi355_global(sync) + 2 * (size_t)f, *const done = ticket + 1;
+    if (k >= uniform(mi355_global(frd.intra_level_start)[nlev])) return;
+    const int mb_xy = (int)uniform((int)mi355_global(frd.intra_list)[k]);
+    const int W = uniform(frd.mb_width), mb_y = mb_xy / W, mb_x = mb_xy - mb_y * W;
+    uint8_t *const pic_flags = mi355_global(flags) + (size_t)f * (size_t)nmb_max;
     const int lane = lane_id();
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(ticket, 1u);
-    t = (uint32_t)lane_value((int)t, 0);
-    if (t >= (uint32_t)count) return;
-    /* list entries below the ticket's level: the largest level start that is <= t (the starts ascend, ls[0] = 0) */
-    int below = 0;
-    for (int j = 0; j <= nlev; j += 64) {
-        const int i = j + lane;
-        below += __popcll(__ballot(i <= nlev && (uint32_t)mi355_global_v(ls)[i < nlev ? i : nlev] <= t));
-    }
-    const uint32_t need = (uint32_t)uniform(ls[below - 1]);
-    if (need) {
+    /* lane i < 4: neighbour i (left, above-left, above, above-right) */
+    const int nx = mb_x + (lane == 3 ? 1 : (lane == 2 ? 0 : -1)), ny = mb_y - (lane == 0 ? 0 : 1);
+    const bool inside = lane < 4 && nx >= 0 && nx < W && ny >= 0;
+    const int nxy = inside ? ny * W + nx : mb_xy;
+    const bool dep = inside && (mi355_global_v(reinterpret_cast<const uint32_t *>(mi355_global(frd.mb) + nxy))[0] & MI355_MB_INTRA) != 0;
+    static_assert(offsetof(mi355_h264_mb, mb_type) == 0, "the type word of a record");
+    const bool waits = __any(dep);
+    if (waits) {
+        const uint8_t *fp = pic_flags + nxy;
+        const int sh = 8 * (int)(reinterpret_cast<uintptr_t>(fp) & 3);
         uint32_t naps = 0;
-        while ((uint32_t)uniform((int)agent_load_u32(mi355_global_v(done))) < need && naps < INTRA_NAPS_MAX) { wave_nap(); naps++; }
+        while (__any(dep && ((intra_flag_word(fp) >> sh) & 0xFFu) == 0) && naps < INTRA_NAPS_MAX) { wave_nap(); naps++; }
         MI355_ISSUE_FENCE();
     }
-    const int mb_xy = (int)uniform((int)mi355_global(frd.intra_list)[t]);
-    if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true, true>(s, frd, mb_xy, need != 0);
-    else recon_intra_mb<false, true>(s, frd, mb_xy, need != 0);
+    if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true, true>(s, frd, mb_xy, waits);
+    else recon_intra_mb<false, true>(s, frd, mb_xy, waits);
     agent_drain_stores();                                 /* the macroblock's samples have reached memory */
-    if (lane == 0) atomicAdd(done, 1u);
+    if (lane == 0) intra_flag_set(pic_flags + mb_xy);
 }
 
 }  // namespace
@@ -335,6 +343,26 @@ extern "C" int mi355_h264_recon_intra_dev(const mi355_h264_frame *d_frames, int 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+/* the intra pass of a batch whose grid the caller knows (max_mb_width x max_mb_height macroblocks per picture at most): ONE launch, k_recon_intra_all */
+extern "C" int mi355_h264_recon_intra_all_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, int max_intra_level, const int32_t *level_widths, void *stream)
+{
+    if (!mi355::bind() || !d_frames || nframes <= 0 || max_mb_width <= 0 || max_mb_height <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
+    static const int single = std::getenv("MI355_INTRA_SINGLE") ? std::atoi(std::getenv("MI355_INTRA_SINGLE")) : -1;     /* 0 / 1 pins the form */
+    if (single == 0 || (single != 1 && max_intra_level < INTRA_SINGLE_LEVELS)) return mi355_h264_recon_intra_levels_dev(d_frames, nframes, max_intra_level, level_widths, stream);
+    long long per_picture = 0;                           /* a picture has at most the sum of the level widths intra macroblocks (the widths are maxima over the batch) */
+    for (int level = 1; level <= max_intra_level; level++) per_picture += level_widths[level - 1] > 0 ? level_widths[level - 1] : 0;
+    if (per_picture <= 0) return 0;
+    const long long nmb = (long long)max_mb_width * max_mb_height;
+    if (per_picture > nmb) per_picture = nmb;
+    if ((long long)nframes * per_picture > 0x7FFFFFFFLL || (long long)nframes * nmb > 0x7FFFFFFFLL) return -3;
+    const size_t bytes = ((size_t)nframes * (size_t)nmb + 3) & ~(size_t)3;
+    uint32_t *flags = mi355::sync_words((hipStream_t)stream, bytes / 4);
+    if (!flags) return -4;
+    MI355_TRY(hipMemsetAsync(flags, 0, bytes, (hipStream_t)stream), -4);
+    hipLaunchKernelGGL(k_recon_intra_all, dim3((unsigned)(nframes * per_picture)), dim3(64), 0, (hipStream_t)stream, d_frames, nframes, (int)nmb, reinterpret_cast<uint8_t *>(flags));
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frames, int nframes, int max_intra_level, const int32_t *level_widths, void *stream)
 {
     if (!mi355::bind() || !d_frames || nframes <= 0 || (max_intra_level > 0 && !level_widths)) return -1;
@@ -343,19 +371,6 @@ extern "C" int mi355_h264_recon_intra_levels_dev(const mi355_h264_frame *d_frame
      * 64 pictures 5.0 against 1.9, P pictures 1.1 against 0.9: a level of an I picture is up to 60 macroblocks wide, a workgroup
      * works through it in rounds, and the picture's 254 levels become a serial chain of ~20 us each whatever the batch, while a
      * launch runs a level of ALL pictures side by side for ~7.5 us */
-    static const int single = std::getenv("MI355_INTRA_SINGLE") ? std::atoi(std::getenv("MI355_INTRA_SINGLE")) : -1;     /* 0 / 1 pins the form */
-    long long per_picture = 0;
-    for (int level = 1; level <= max_intra_level; level++) per_picture += level_widths[level - 1] > 0 ? level_widths[level - 1] : 0;
-    if (per_picture <= 0) return 0;
-    if (single == 1 || (single != 0 && max_intra_level >= INTRA_SINGLE_LEVELS)) {
-        /* ONE launch: a picture needs at most the sum of the level widths workgroups (the widths are maxima over the batch) */
-        if ((long long)nframes * per_picture > 0x7FFFFFFFLL) return -3;
-        uint32_t *sync = mi355::sync_words((hipStream_t)stream, 2 * (size_t)nframes);
-        if (!sync) return -4;
-        MI355_TRY(hipMemsetAsync(sync, 0, 2 * (size_t)nframes * sizeof(uint32_t), (hipStream_t)stream), -4);
-        hipLaunchKernelGGL(k_recon_intra_all, dim3((unsigned)(nframes * per_picture)), dim3(64), 0, (hipStream_t)stream, d_frames, nframes, sync);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
     for (int level = 1; level <= max_intra_level; level++) {
         const int width = level_widths[level - 1];
         if (width <= 0) continue;
@@ -390,7 +405,7 @@ extern "C" int mi355_h264_decode_frames_layouts_dev(const mi355_h264_frame *d_fr
 {
     int rc = mi355_h264_recon_inter_layouts_dev(d_frames, nframes, max_mb_width, max_mb_height, layouts, stream);
     if (rc) return rc;
-    rc = mi355_h264_recon_intra_levels_dev(d_frames, nframes, max_intra_level, level_widths, stream);
+    rc = mi355_h264_recon_intra_all_dev(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, stream);
     if (rc) return rc;
     return mi355_h264_deblock_layouts_dev(d_frames, nframes, max_mb_width, max_mb_height, layouts, stream);
 }
@@ -400,7 +415,7 @@ extern "C" int mi355_h264_decode_frames_levels_dev(const mi355_h264_frame *d_fra
 {
     int rc = mi355_h264_recon_inter_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
     if (rc) return rc;
-    rc = mi355_h264_recon_intra_levels_dev(d_frames, nframes, max_intra_level, level_widths, stream);
+    rc = mi355_h264_recon_intra_all_dev(d_frames, nframes, max_mb_width, max_mb_height, max_intra_level, level_widths, stream);
     if (rc) return rc;
     return mi355_h264_deblock_dev(d_frames, nframes, max_mb_width, max_mb_height, stream);
 }

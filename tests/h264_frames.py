@@ -700,7 +700,7 @@ class DeviceFrames:
         fs, lib = self.fs, self.lib
         mask = 2 if self.tiled else 1
         lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
-        for name, args in (("mi355_h264_recon_inter_layouts_dev", (fs.mb_w, fs.mb_h, mask)), ("mi355_h264_recon_intra_levels_dev", (fs.max_intra_level, lw)),
+        for name, args in (("mi355_h264_recon_inter_layouts_dev", (fs.mb_w, fs.mb_h, mask)), ("mi355_h264_recon_intra_all_dev", (fs.mb_w, fs.mb_h, fs.max_intra_level, lw)),
                            ("mi355_h264_deblock_layouts_dev", (fs.mb_w, fs.mb_h, mask))):
             fn = getattr(lib, name)
             fn.restype = C.c_int

@@ -25,7 +25,7 @@ prov = P()
 prov.lib = lib
 mbw, mbh = 120, 68
 for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-                      ("mi355_h264_recon_intra_levels_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                      ("mi355_h264_recon_intra_all_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                       ("mi355_h264_deblock_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
                       ("mi355_event_create", C.c_void_p, []), ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]),
                       ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
@@ -41,7 +41,7 @@ def measure(name, fs, F):
             if ev: lib.mi355_event_record(ev[0], None)
             assert lib.mi355_h264_recon_inter_layouts_dev(dev.d_desc, F, mbw, mbh, 2, None) == 0
             if ev: lib.mi355_event_record(ev[1], None)
-            assert lib.mi355_h264_recon_intra_levels_dev(dev.d_desc, F, fs.max_intra_level, lw, None) == 0
+            assert lib.mi355_h264_recon_intra_all_dev(dev.d_desc, F, mbw, mbh, fs.max_intra_level, lw, None) == 0
             if ev: lib.mi355_event_record(ev[2], None)
             assert lib.mi355_h264_deblock_layouts_dev(dev.d_desc, F, mbw, mbh, 2, None) == 0
             if ev: lib.mi355_event_record(ev[3], None)
