@@ -248,7 +248,10 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
  * macroblock goes as soon as its own neighbours are done.
  * Progress: workgroups start in the order of their numbers on every XCD, so the lowest-numbered unfinished workgroup is always running, and it waits for
  * nobody (its neighbours have lower numbers).  Should a device ever start them otherwise, INTRA_NAPS_MAX ends the wait: a wrong picture, not a hung device. */
-constexpr int INTRA_SINGLE_LEVELS = 1;                 /* batches with at least this many levels take the single launch (MI355_INTRA_SINGLE=0 / 1 pins a form) */
+/* Batches with at least this many levels take the single launch (MI355_INTRA_SINGLE=0 / 1 pins a form).  Measured (profiles/r05s_pass_ms.txt): I pictures 4.17 -> 3.76 ms
+ * per 512, 1.58 -> 1.36 per 64 (254 levels); P pictures with 5 % intra macroblocks in four levels 0.68 -> 0.81 ms per 2048 — their level launches are short as they are, and
+ * the single launch adds the neighbours' type words (a memory round trip before the macroblock's own loads), the wait for the stores and the zeroing of the flags */
+constexpr int INTRA_SINGLE_LEVELS = 16;
 constexpr uint32_t INTRA_NAPS_MAX = 1u << 21;          /* ~1 s of naps */
 #ifdef MI355_HIP_EMU_H
 static inline uint32_t intra_flag_word(const uint8_t *p) { uint32_t v; std::memcpy(&v, reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3), 4); return v; }
