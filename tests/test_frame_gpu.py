@@ -237,6 +237,66 @@ def test_single_launch_loop_filter_with_every_cu_taken(mi355, oracle):
         d.free()
 
 
+def test_single_launch_intra_pass_with_every_cu_taken(mi355, oracle):
+    """k_recon_intra_all (the intra levels of a batch of I pictures in ONE launch): a macroblock waits for the flag bytes of its intra neighbours, which is safe
+    because workgroups start in the order of their numbers and a neighbour's number is lower.  192 all-intra 1080p pictures (254 levels each) on one stream
+    while a second stream fills every CU with reconstruction launches of another batch: must finish well inside the waits' own bound and every picture must
+    equal the oracle's."""
+    import ctypes as C
+    import time
+    lib = mi355.lib
+    F, FB = 192, 256
+    fs = HF.synth_frames_fast(2, 120, 68, seed=0x1264, lib=lib, intra_frac=1.0)
+    other = HF.synth_frames_fast(2, 120, 68, seed=0x264, lib=lib)
+    assert fs.max_intra_level >= 200
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    for name, res, at in (("mi355_h264_recon_inter_layouts_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                          ("mi355_h264_recon_intra_all_dev", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                          ("mi355_stream_create", C.c_void_p, []), ("mi355_stream_destroy", None, [C.c_void_p]),
+                          ("mi355_event_create", C.c_void_p, []), ("mi355_event_destroy", None, [C.c_void_p]),
+                          ("mi355_event_record", C.c_int, [C.c_void_p, C.c_void_p]), ("mi355_event_query", C.c_int, [C.c_void_p]),
+                          ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p])):
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = at
+    d = HF.DeviceFrames(mi355, fs, replicate=F, tiled=True)
+    busy = HF.DeviceFrames(mi355, other, replicate=FB, tiled=True)
+    sa, sb = C.c_void_p(lib.mi355_stream_create()), C.c_void_p(lib.mi355_stream_create())
+    ev = [C.c_void_p(lib.mi355_event_create()) for _ in range(4)]
+    lw = (C.c_int32 * fs.max_intra_level)(*fs.level_widths[:fs.max_intra_level])
+    try:
+        lib.mi355_event_record(ev[0], sb)
+        for _ in range(60):
+            assert lib.mi355_h264_recon_inter_layouts_dev(busy.d_desc, FB, fs.mb_w, fs.mb_h, 2, sb) == 0
+        lib.mi355_event_record(ev[1], sb)
+        lib.mi355_event_record(ev[2], sa)
+        assert lib.mi355_h264_recon_intra_all_dev(d.d_desc, F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, sa) == 0
+        lib.mi355_event_record(ev[3], sa)
+        deadline = time.time() + 120
+        while not (lib.mi355_event_query(ev[3]) == 1 and lib.mi355_event_query(ev[1]) == 1):
+            assert lib.mi355_event_query(ev[3]) >= 0 and lib.mi355_event_query(ev[1]) >= 0
+            assert time.time() < deadline, "the intra pass did not finish within 120 s beside a device full of other work"
+            time.sleep(0.002)
+        t_intra = lib.mi355_event_elapsed_ms(ev[2], ev[3])
+        print("busy stream %.1f ms, intra pass of %d I pictures beside it %.1f ms" % (lib.mi355_event_elapsed_ms(ev[0], ev[1]), F, t_intra))
+        assert t_intra < 500, "a wave gave up waiting (%.0f ms): workgroups did not start in order" % t_intra
+        bad = []
+        for first in range(0, F, 32):
+            got = d.fetch(d.recon, first, 32)
+            for i in range(32):
+                g = (first + i) % fs.F
+                if not all(np.array_equal(recon_o[p][g], got[p][i]) for p in range(3)):
+                    bad.append(first + i)
+        assert not bad, "%d of %d pictures differ from the oracle, first: %s" % (len(bad), F, bad[:8])
+    finally:
+        lib.mi355_sync(None)
+        for e in ev:
+            lib.mi355_event_destroy(e)
+        lib.mi355_stream_destroy(sa)
+        lib.mi355_stream_destroy(sb)
+        busy.free()
+        d.free()
+
+
 @pytest.mark.parametrize("tiled", (True, False))
 @pytest.mark.parametrize("name", list(frame_cases.CASES))
 def test_frame_pipeline_gpu_layout_entry_points(mi355, oracle, name, tiled):
