@@ -222,6 +222,7 @@ __device__ __forceinline__ FqLane fq_lane()
  * window origins, flags, chroma weights — for all of them at a time (one vector instruction per step instead of a scalar one per macroblock and step: the scalar
  * unit was the kernel's narrowest place), and a macroblock's turn fetches its five words with v_readlane. ---- */
 constexpr uint32_t FQA_INSIDE = 1u << 22;        /* both windows inside the picture: fq_windows_issue_inside */
+constexpr uint32_t FQA_TWO = 1u << 23, FQA_VSPLIT = 1u << 24;       /* two partitions from list 0 (fq_two); ... side by side (8x16) instead of one above the other */
 constexpr uint32_t FQA_PATCH_Y = 1u << 11, FQA_PATCH_C = 1u << 12, FQA_FAST = 1u << 13, FQA_INTRA = 1u << 14, FQA_CHROMA = 1u << 15, FQA_RESID = 1u << 16;
 struct FqRun {
     uint32_t a;         /* bits 0-4 o + 2 | 5-6 cx & 3 | 7-10 (mx & 3) | (my & 3) << 2 | 11 / 12 luma / chroma window over a side border | 13 fast kind | 14 intra |
@@ -238,6 +239,31 @@ struct FqPic {          /* what the run keeps of the picture descriptor */
     const mi355_h264_frame *desc;
     FrameHot hot;       /* recon planes and strides for the stores (store_mb_tiled) */
 };
+/* what one prediction's vector decides: window offsets, quarter-sample position, border flags, reference slot (word a, without the macroblock's own flags), the chroma
+ * weights, the windows' first rows (d) and columns (e).  Vector code in fq_describe (lane m = macroblock m), scalar code in fq_two (a partition at a time) */
+struct FqGeo {
+    uint32_t a, wts, d, e;
+};
+__device__ __forceinline__ FqGeo fq_geometry(uint32_t mvw, int mb_x, int mb_y, int chroma_dy, uint32_t slot_byte, int mbw, int mbh)
+{
+    FqGeo g;
+    const int mx = (int16_t)(mvw & 0xFFFF) + mb_x * 64, my = (int16_t)(mvw >> 16) + mb_y * 64;
+    const int myc = my + chroma_dy;                                       /* the other-parity field offset, h264_mb.c:287-291 */
+    const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
+    const int t0 = (ix - 4) >> 4, c0 = cx & ~3;
+    const uint32_t slot = slot_byte < (uint32_t)MI355_H264_MAX_SLOTS ? slot_byte : 0u;
+    static_assert(MI355_H264_MAX_SLOTS <= 32, "five bits of slot");
+    /* t0 < 0 || t0 + 2 >= mbw; c0 < 0 || c0 + 11 >= 8 mbw: one unsigned comparison each (the bounds are wave constants, not below zero) */
+    const bool patch_y = (uint32_t)t0 >= (uint32_t)imax(mbw - 2, 0), patch_c = (uint32_t)c0 >= (uint32_t)imax(8 * mbw - 11, 0);
+    const bool inside = !patch_y && !patch_c && (uint32_t)(iy - 2) < (uint32_t)imax(16 * mbh - 20, 0) && (uint32_t)cy < (uint32_t)imax(8 * mbh - 8, 0);
+    g.a = (uint32_t)(((ix - 4) & 15) + 2) | ((uint32_t)(cx & 3) << 5) | ((uint32_t)((mx & 3) | ((my & 3) << 2)) << 7) |
+          (patch_y ? FQA_PATCH_Y : 0u) | (patch_c ? FQA_PATCH_C : 0u) | (inside ? FQA_INSIDE : 0u) | (slot << 17);
+    const int fx = mx & 7, fy = myc & 7;
+    g.wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
+    g.d = ((uint32_t)(iy - 2) & 0xFFFFu) | ((uint32_t)cy << 16);
+    g.e = ((uint32_t)t0 & 0xFFFFu) | ((uint32_t)c0 << 16);
+    return g;
+}
 __device__ __forceinline__ FqRun fq_describe(const FqPic &pic, int mb_xy0, int mb_x, int mb_y, int n_row)
 {
     FqRun r;
@@ -245,28 +271,21 @@ __device__ __forceinline__ FqRun fq_describe(const FqPic &pic, int mb_xy0, int m
     const uint32_t *h = reinterpret_cast<const uint32_t *>(mi355_global_v(pic.mb + (mb_xy0 + m)));
     const uint32_t type = h[0], nnz = h[1], w2 = h[2], w12 = h[12], w14 = h[14];
     const uint32_t mvw = pic.mv0 ? reinterpret_cast<const uint32_t *>(mi355_global_v(pic.mv0 + (size_t)(mb_xy0 + m) * 32))[0] : 0u;
-    const int mx = (int16_t)(mvw & 0xFFFF) + (mb_x + m) * 64, my = (int16_t)(mvw >> 16) + mb_y * 64;
-    const int myc = my + (int8_t)(w14 & 0xFFu);                           /* the other-parity field offset, h264_mb.c:287-291 */
-    const int ix = mx >> 2, iy = my >> 2, cx = mx >> 3, cy = myc >> 3;
-    const int mbw = pic.hot.mb_width;
-    const int t0 = (ix - 4) >> 4, c0 = cx & ~3;
-    /* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms */
+    /* the macroblock the fast path is for: one 16x16 partition, list 0 only, no weights, 4x4 transforms ... */
     const uint32_t want = MI355_MB_16x16 | MI355_MB_P0L0, look = MI355_MB_INTRA | MI355_MB_16x16 | MI355_MB_P0L0 | MI355_MB_P0L1 | MI355_MB_8x8DCT;
-    const bool fast = (type & look) == want && !((w2 >> 24) & MI355_MBF_WEIGHTED);
+    const bool plain = !((w2 >> 24) & MI355_MBF_WEIGHTED);
+    const bool fast = (type & look) == want && plain;
+    /* ... and its sibling of two partitions, 16x8 or 8x16, both from list 0: the same code twice, a lane keeps the partition it lies in (fq_two) */
+    const uint32_t look2 = MI355_MB_INTRA | MI355_MB_P0L0 | MI355_MB_P1L0 | MI355_MB_P0L1 | MI355_MB_P1L1 | MI355_MB_8x8DCT;
+    const bool two = (type & look2) == (MI355_MB_P0L0 | MI355_MB_P1L0) && (type & (MI355_MB_16x8 | MI355_MB_8x16)) != 0 && plain && pic.mv0 != nullptr;
     const bool chroma = (w2 & 0x30u) != 0, resid = (nnz & 0xFFFFu) != 0 || chroma;
-    const uint32_t slot = (w12 & 0xFFu) < (uint32_t)MI355_H264_MAX_SLOTS ? (w12 & 0xFFu) : 0u;
-    static_assert(MI355_H264_MAX_SLOTS <= 32, "five bits of slot");
-    /* t0 < 0 || t0 + 2 >= mbw; c0 < 0 || c0 + 11 >= 8 mbw: one unsigned comparison each (the bounds are wave constants, not below zero) */
-    const bool patch_y = (uint32_t)t0 >= (uint32_t)imax(mbw - 2, 0), patch_c = (uint32_t)c0 >= (uint32_t)imax(8 * mbw - 11, 0);
-    const bool inside = !patch_y && !patch_c && (uint32_t)(iy - 2) < (uint32_t)imax(16 * pic.hot.mb_height - 20, 0) && (uint32_t)cy < (uint32_t)imax(8 * pic.hot.mb_height - 8, 0);
-    r.a = (uint32_t)(((ix - 4) & 15) + 2) | ((uint32_t)(cx & 3) << 5) | ((uint32_t)((mx & 3) | ((my & 3) << 2)) << 7) |
-          (patch_y ? FQA_PATCH_Y : 0u) | (patch_c ? FQA_PATCH_C : 0u) |
-          (inside ? FQA_INSIDE : 0u) | (fast ? FQA_FAST : 0u) | ((type & MI355_MB_INTRA) ? FQA_INTRA : 0u) | (chroma ? FQA_CHROMA : 0u) | (resid ? FQA_RESID : 0u) | (slot << 17);
-    const int fx = mx & 7, fy = myc & 7;
-    r.wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) | ((uint32_t)(fx * fy) << 24);
+    const FqGeo g = fq_geometry(mvw, mb_x + m, mb_y, (int8_t)(w14 & 0xFFu), w12 & 0xFFu, pic.hot.mb_width, pic.hot.mb_height);
+    r.a = g.a | (fast ? FQA_FAST : 0u) | (two ? FQA_TWO : 0u) | ((type & MI355_MB_8x16) ? FQA_VSPLIT : 0u) | ((type & MI355_MB_INTRA) ? FQA_INTRA : 0u) |
+          (chroma ? FQA_CHROMA : 0u) | (resid ? FQA_RESID : 0u);
+    r.wts = g.wts;
     r.nnz = nnz;
-    r.d = ((uint32_t)(iy - 2) & 0xFFFFu) | ((uint32_t)cy << 16);
-    r.e = ((uint32_t)t0 & 0xFFFFu) | ((uint32_t)c0 << 16);
+    r.d = g.d;
+    r.e = g.e;
     return r;
 }
 /* the value lane `l` (wave-uniform) holds */
@@ -403,7 +422,8 @@ __device__ __forceinline__ uint32_t fq_bytes(const int d[4])
 }
 /* Quarter-sample prediction of the 16x16 block (h264qpel_template.c's mc00..mc33) from the raw window into the prediction tile.
  * pos = (mx & 3) | (my & 3) << 2.  Components: G integer samples, b / h horizontal / vertical half samples, j the centre. */
-__device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int pos, bool has_resid)
+/* the prediction of this lane's four samples (row lane & 15, columns 4 (lane >> 4) ..) from the window set so2 lies in */
+__device__ __forceinline__ uint32_t fq_luma_pred(MbLds &s, const FqLane &k, int so2, int pos)
 {
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     /* b of window row `row0` + this lane's row: a direct product, the filter on the column side */
@@ -479,6 +499,12 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
     case 9: FQ_MARK("case9"); { transpose(false, 0); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }
     default: { FQ_MARK("case11"); transpose(false, 1); const uint32_t h = vraw(); transpose(true, 0); v = fq_lerp(h, vsums()); break; }     /* 11 */
     }
+    return v;
+}
+/* ... the residual on top, and into the outgoing tile */
+__device__ __forceinline__ void fq_luma_out(MbLds &s, const FqLane &k, uint32_t v, bool has_resid)
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     FQ_MARK("luma_resid");
     if (has_resid) {
         /* the four residuals of these samples on top (h264idct_template.c:54-66's "+ dst", clipped) */
@@ -489,18 +515,24 @@ __device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int 
     MI355_WAVE_SYNC();                                                     /* every lane has its residual: the tile may take their place */
     *reinterpret_cast<uint32_t *>(base + FQ_ST + k.sy) = v;
 }
+__device__ __forceinline__ void fq_luma(MbLds &s, const FqLane &k, int so2, int pos, bool has_resid) { fq_luma_out(s, k, fq_luma_pred(s, k, so2, pos), has_resid); }
 
 /* ---- chroma: both 8x8 planes, two samples per lane ---- */
-__device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, uint32_t wts, bool has_resid)
+__device__ __forceinline__ uint32_t fq_chroma_pred(MbLds &s, const FqLane &k, int oc, uint32_t wts)
 {
     uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     const uint32_t at = k.c1 + (uint32_t)oc, sh = at & 3u;                  /* FQ_WC and the 12-byte row pitch are multiples of four */
     const uint32_t r0 = fq_bytes4(base + (at & ~3u), sh), r1 = fq_bytes4(base + (at & ~3u) + 12, sh);
     const uint32_t d0 = fq_dot4(byte_perm(r1, r0, 0x05040100u), wts, 32u), d1 = fq_dot4(byte_perm(r1, r0, 0x06050201u), wts, 32u);
-    uint32_t two = (d0 >> 6) | ((d1 >> 6) << 8);
+    return (d0 >> 6) | ((d1 >> 6) << 8);
+}
+__device__ __forceinline__ void fq_chroma_out(MbLds &s, const FqLane &k, uint32_t two, bool has_resid)
+{
+    uint8_t *const base = reinterpret_cast<uint8_t *>(&s);
     if (has_resid) two = pk_sat_u8(pk_add(byte_perm(0u, two, 0x0C010C00u), *reinterpret_cast<const uint32_t *>(base + k.rsc)));
     *reinterpret_cast<uint16_t *>(base + FQ_ST + 256 + k.sc) = (uint16_t)two;
 }
+__device__ __forceinline__ void fq_chroma(MbLds &s, const FqLane &k, int oc, uint32_t wts, bool has_resid) { fq_chroma_out(s, k, fq_chroma_pred(s, k, oc, wts), has_resid); }
 /* the finished macroblock, 384 bytes in tile order, to the picture: whole 16-byte pieces, sixteen lanes the luma tile (two cache lines), eight the chroma tile.
  * (Four samples per lane straight to memory — sixty-four 4-byte pieces sixteen bytes apart — cost the memory pipeline sixteen address groups a store instead of
  * four and the pass 1.6 ms of 6.8: tools/gpu_r05c.sh, knock-out "nostore".) */
@@ -513,6 +545,55 @@ __device__ __forceinline__ void fq_store(MbLds &s, uint8_t *ytile, uint8_t *ctil
         if (lane < 16) *reinterpret_cast<mi355_u32x4 *>(ytile + (uint32_t)(16 * lane)) = v;
         else *reinterpret_cast<mi355_u32x4 *>(ctile + (uint32_t)(16 * lane - 256)) = v;
     }
+}
+
+/* ---- a macroblock of two partitions, 16x8 or 8x16, both predicted from list 0 (hl_motion's mc_part calls for those types, h264_mc_template.c:83-108): the plain macroblock's
+ * code once per partition — each partition's vector applied to the WHOLE macroblock, its windows in a window set of its own — and a lane keeps the result of the partition it lies in.
+ * Runs in the second launch (recon_inter_rest): nothing is requested ahead (both window sets are in use); the macroblock's flags and geometry are scalar code on its record's words. ---- */
+__device__ __forceinline__ void fq_two(MbLds &s, const FqLane &k, const ResidLane &rl, const FqPic &pic, int mb_xy, int mb_x, int mb_y)
+{
+    fq_kptr h = fq_konst(pic.mb + mb_xy), mv = fq_konst(pic.mv0 + (size_t)mb_xy * 32);
+    const uint32_t type = h[0], nnz = h[1], w2 = h[2], w12 = h[12], w14 = h[14];
+    const bool vsplit = (type & MI355_MB_8x16) != 0, has_chroma = (w2 & 0x30u) != 0, resid = (nnz & 0xFFFFu) != 0 || has_chroma;
+    const int woff = 0;
+    /* the second partition: 4x4 block 8 / quadrant 2 (16x8: the lower half), block 2 / quadrant 1 (8x16: the right half) */
+    const int n1 = vsplit ? 2 : 8, q1 = vsplit ? 8 : 16;
+    const FqGeo g0 = fq_geometry(mv[0], mb_x, mb_y, (int8_t)(w14 & 0xFFu), w12 & 0xFFu, pic.hot.mb_width, pic.hot.mb_height);
+    const FqGeo g1 = fq_geometry(mv[n1], mb_x, mb_y, (int8_t)((w14 >> q1) & 0xFFu), (w12 >> q1) & 0xFFu, pic.hot.mb_width, pic.hot.mb_height);
+    const int set0 = woff, set1 = woff ^ FQ_WSTEP;
+    auto issue = [&](const FqGeo &g, int set) {
+        if (g.a & FQA_INSIDE) fq_windows_issue_inside(s, k, pic.desc, pic.hot, (int)((g.a >> 17) & 31u), (int16_t)(g.d & 0xFFFFu), (int16_t)(g.e & 0xFFFFu), (int)g.d >> 16, (int)g.e >> 16, set);
+        else fq_windows_issue(s, k, pic.desc, pic.hot, (int)((g.a >> 17) & 31u), (int16_t)(g.d & 0xFFFFu), (int16_t)(g.e & 0xFFFFu), (int)g.d >> 16, (int)g.e >> 16, set);
+    };
+    issue(g0, set0);
+    issue(g1, set1);
+    if (resid) fq_coef_dma(s, k, pic.coef, mb_xy);
+    fq_wait_vm0();
+    MI355_WAVE_SYNC();
+    if (resid) fq_idct(s, k, rl, nnz, has_chroma, pic.mb + mb_xy);
+    if ((g0.a | g1.a) & (FQA_PATCH_Y | FQA_PATCH_C)) {
+        fq_windows_patch(s, k, (g0.a & FQA_PATCH_Y) != 0, (g0.a & FQA_PATCH_C) != 0, (int16_t)(g0.e & 0xFFFFu), (int)g0.e >> 16, set0, pic.hot.mb_width);
+        fq_windows_patch(s, k, (g1.a & FQA_PATCH_Y) != 0, (g1.a & FQA_PATCH_C) != 0, (int16_t)(g1.e & 0xFFFFu), (int)g1.e >> 16, set1, pic.hot.mb_width);
+    }
+    MI355_WAVE_SYNC();
+    const int lane = lane_id();
+    /* luma: lane = row (lane & 15), columns 4 (lane >> 4) ..; chroma: row (lane >> 2) & 7, columns 2 (lane & 3) .. */
+    const bool second_y = vsplit ? lane >= 32 : (lane & 8) != 0, second_c = vsplit ? (lane & 2) != 0 : (lane & 16) != 0;
+    uint32_t vy = 0, vc = 0;
+#pragma nounroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t ga = p ? g1.a : g0.a, gw = p ? g1.wts : g0.wts;
+        const int set = p ? set1 : set0;
+        const uint32_t y = fq_luma_pred(s, k, (int)(ga & 31u) + set, (int)((ga >> 7) & 15u));
+        const uint32_t c = fq_chroma_pred(s, k, (int)((ga >> 5) & 3u) + set, gw);
+        if (second_y == (p != 0)) vy = y;
+        if (second_c == (p != 0)) vc = c;
+    }
+    fq_luma_out(s, k, vy, resid);
+    fq_chroma_out(s, k, vc, resid);
+    MI355_WAVE_SYNC();
+    fq_store(s, pic.hot.recon[0] + tile_y_off(mb_x, mb_y, pic.hot.recon_stride[0]), pic.hot.recon[1] + tile_c_off(mb_x, mb_y, pic.hot.recon_stride[1]));
+    MI355_WAVE_SYNC();
 }
 
 /* ---- the run: `run` (<= 32) consecutive macroblocks of ONE row of the launch's max_w x max_h grid per wave; runs_row = ceil(max_w / run) runs to a row.
@@ -596,14 +677,14 @@ __device__ __forceinline__ void recon_inter_run(MbLds &s, const mi355_h264_frame
                 fq_store(s, pic.hot.recon[0] + tile_y_off(mb_x + i, mb_y, pic.hot.recon_stride[0]), pic.hot.recon[1] + tile_c_off(mb_x + i, mb_y, pic.hot.recon_stride[1]));
                 MI355_WAVE_SYNC();
             } else if (!(a & FQA_INTRA)) {
-                deferred |= 1u << i;
+                deferred |= (a & FQA_TWO) ? 0x10000u << i : 1u << i;          /* upper half: two partitions from list 0 (fq_two), lower: the general code */
             }
             FQ_MARK("tail");
             pre_w = next_w; pre_c = next_c;
             a = an;
         }
     }
-    /* two lists, weights, partitions, the 8x8 transform: left to recon_inter_rest, a launch of its own behind this one (the general code inside this
+    /* partitions, two lists, weights, the 8x8 transform: left to recon_inter_rest, a launch of its own behind this one (the general code inside this
      * kernel — a function called once per such macroblock at the end of the run — took 17 us a macroblock where a wave of its own takes 9: its
      * registers saved and restored through scratch memory on every call, nothing of one macroblock overlapping the next) */
     if (lane_id() == 0) rest[wave] = deferred;
@@ -622,13 +703,41 @@ __device__ __forceinline__ void recon_inter_rest(MbLds &s, const mi355_h264_fram
     const int r = FQ_REST * g + (lane_id() & (FQ_REST - 1));
     const uint32_t mine = r < nruns ? rest[r] : 0u;
     if (!__any(mine != 0)) return;
-    for (int j = 0; j < FQ_REST; j++) {
-        uint32_t m = fq_lane_word(mine, j);
-        if (!m) continue;
+    auto place = [&](int j, int &f, int &mb_x, int &mb_y) {
         const int w = FQ_REST * g + j;
         const int row = div_magic(w, inv_runs);
-        const int mb_x = (w - row * runs_row) * run;
-        const int f = div_magic(row, inv_h), mb_y = row - f * max_h;
+        mb_x = (w - row * runs_row) * run;
+        f = div_magic(row, inv_h); mb_y = row - f * max_h;
+    };
+    /* first the macroblocks of two list-0 partitions: the fast path's code, its lane constants made once */
+    if (__any((mine >> 16) != 0)) {
+        ResidLane rl;
+        resid_lane_compute(rl);
+        const FqLane k = fq_lane();
+        for (int j = 0; j < FQ_REST; j++) {
+            uint32_t m = fq_lane_word(mine, j) >> 16;
+            if (!m) continue;
+            int f, mb_x, mb_y;
+            place(j, f, mb_x, mb_y);
+            const mi355_h264_frame &frd = frames[f];
+            if (uniform(frd.surface_layout) != MI355_SURFACE_TILED) continue;
+            FqPic pic;
+            pic.hot = frame_hot(frd);
+            pic.mb = pic.hot.mb; pic.mv0 = pic.hot.mv[0]; pic.coef = pic.hot.coef; pic.desc = &frd;
+            while (m) {
+                const int i = __builtin_ctz(m);
+                m &= m - 1;
+                fq_two(s, k, rl, pic, mb_y * pic.hot.mb_width + mb_x + i, mb_x + i, mb_y);
+                fq_wait_vm0();                                  /* the macroblock's stores have left its LDS tile */
+                MI355_WAVE_SYNC();
+            }
+        }
+    }
+    for (int j = 0; j < FQ_REST; j++) {
+        uint32_t m = fq_lane_word(mine, j) & 0xFFFFu;
+        if (!m) continue;
+        int f, mb_x, mb_y;
+        place(j, f, mb_x, mb_y);
         if (uniform(frames[f].surface_layout) != MI355_SURFACE_TILED) continue;
         while (m) {
             const int i = __builtin_ctz(m);

@@ -201,6 +201,14 @@ def test_run_kernel_mixed_partitions_emulated(emu, oracle):
     _fast_workload_by_layout(emu, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)
 
 
+@pytest.mark.parametrize("mv_range", (64, 200, 1200))
+@pytest.mark.parametrize("mb_w,mb_h", ((7, 5), (1, 1), (2, 3), (5, 9)))
+def test_two_partition_path_over_every_border_emulated(emu, oracle, mb_w, mb_h, mv_range):
+    """16x8 / 8x16 macroblocks through fq_two (the fast path's code once per partition, in the second launch) beside plain ones and 8x8 ones (general code),
+    windows of either partition reaching over the borders by any distance"""
+    _fast_workload_by_layout(emu, oracle, 2, mb_w, mb_h, 0x2660 + mv_range + mb_w, partitions="mixed", mv_range=mv_range)
+
+
 HBD_CASES = [n for n in frame_cases.CASES if n not in ("tall_all_intra", "mid_hugecoef", "mid_wrapcoef", "p16_wrapcoef")]     # (levels up to +-32767 << 2: beyond what a High 10 stream can carry)
 
 

@@ -384,6 +384,18 @@ def test_run_kernel_mixed_partitions(mi355, oracle):
     frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)
 
 
+@pytest.mark.parametrize("mv_range", (64, 200, 1200))
+@pytest.mark.parametrize("mb_w,mb_h", ((7, 5), (1, 1), (2, 3), (5, 9)))
+def test_two_partition_path_over_every_border(mi355, oracle, mb_w, mb_h, mv_range):
+    """16x8 / 8x16 macroblocks through fq_two (k_recon_inter_rest) beside plain and 8x8 ones, windows over the borders by any distance"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, mb_w, mb_h, 0x2660 + mv_range + mb_w, partitions="mixed", mv_range=mv_range)
+
+
+def test_two_partition_path_many_pictures(mi355, oracle):
+    """mixed partitions under load: 192 1080p pictures in one launch pair, all compared"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x2266, replicate=192, partitions="mixed")
+
+
 def test_run_kernel_many_pictures(mi355, oracle):
     """the same under load: 256 pictures in one launch (every SIMD at eight waves, requests of several macroblocks in flight per wave), all compared"""
     frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x2265, replicate=256)
