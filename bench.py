@@ -65,9 +65,11 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
-    ap.add_argument("--pipelines", type=int, default=1, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
-                    "HIP stream through the three passes: one pipeline's loop filter (bound by instruction issue) runs beside another's reconstruction (bound by the "
-                    "memory pipeline); 1 = the three passes over the whole batch one after the other (how rounds 1-4 measured)")
+    ap.add_argument("--pipelines", type=int, default=2, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
+                    "HIP stream through the three passes: one pipeline's loop filter (bound by instruction issue) runs beside the other's reconstruction (bound by the "
+                    "memory pipeline).  2 (the default since round 5's last session: 12.6 - 12.8 ms per step against 13.0 - 13.4 for 1 on the same box, three alternations, "
+                    "profiles/r05w_pipelines.txt; 4 is slower again); 1 = the three passes over the whole batch one after the other (how rounds 1-4 measured; the "
+                    "extra point config2_f2048_one_pipeline keeps measuring that)")
     ap.add_argument("--mb-width", type=int, default=120)
     ap.add_argument("--mb-height", type=int, default=68)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,6 +255,11 @@ def main():
                          "launches_per_step": launches, "avg_launch_us": t_pass * 1e3,
                          "algorithmic_bytes_per_launch": bytes_pass / launches},
         }
+        if P > 1:
+            # a launch shares the device with the other pipeline's launches: its duration is the time it was resident, not the time it would take alone
+            out["roofline"]["shared_device"] = ("%d pipelines: this kernel's launch (%d pictures) runs beside the other pipeline's passes, so achieved / frac are per launch WHILE SHARING; "
+                                               "alone (one pipeline, the whole batch per launch) the same kernel is measured in extra point config2_f2048_one_pipeline "
+                                               "(pass_ms.recon_inter), and the whole job's rate is config.fused_fraction_of_hbm_roofline" % (P, per))
         # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
         # (tools/gpu_traffic.sh -> profiles/*hbm_traffic*.json; cannot be collected from inside this process)
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, per)
