@@ -50,7 +50,7 @@ def measured_traffic(kernel, frames):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
         try:
             t = json.load(open(path))
-            if t.get("frames_per_gpu") == frames and kernel in t.get("kernels", {}):
+            if abs(t.get("frames_per_gpu", -9) - frames) <= 1 and kernel in t.get("kernels", {}):      # 2048 pictures as three launches: 683 / 683 / 682
                 return t["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError):
             pass
@@ -65,11 +65,14 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="independent 1080p pictures (streams) per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pictures generated on the host; "
                     "they are replicated (own copies in HBM) to fill --frames")
-    ap.add_argument("--pipelines", type=int, default=2, help="the step's batch as this many independent pipelines (equal shares of the pictures), each with its own "
-                    "HIP stream through the three passes: one pipeline's loop filter (bound by instruction issue) runs beside the other's reconstruction (bound by the "
-                    "memory pipeline).  2 (the default since round 5's last session: 12.6 - 12.8 ms per step against 13.0 - 13.4 for 1 on the same box, three alternations, "
-                    "profiles/r05w_pipelines.txt; 4 is slower again); 1 = the three passes over the whole batch one after the other (how rounds 1-4 measured; the "
-                    "extra point config2_f2048_one_pipeline keeps measuring that)")
+    ap.add_argument("--pipelines", type=int, default=3, help="the step's batch as this many independent pipelines (shares of the pictures as equal as they come), each with its own "
+                    "HIP stream through the three passes: one pipeline's loop filter (bound by the vector pipe) runs beside another's reconstruction (bound by the memory "
+                    "pipeline), and the reconstruction launches take turns (--no-phased: they do not).  3 is the default since round 5's last sessions (profiles/r05y_pipelines.txt, one box, "
+                    "alternating: 12.0 - 12.2 ms per step against 12.7 for 2 and 12.9 - 13.7 for 1; 4 and more are slower again); 1 = the three passes over the whole batch one after the "
+                    "other (how rounds 1-4 measured; the extra point config2_f2048_one_pipeline keeps measuring that)")
+    ap.add_argument("--no-phased", dest="phased", action="store_false", help="with --pipelines > 1: let the pipelines' reconstruction launches start whenever their streams get to them "
+                    "(default: they take turns — pipeline p's waits for pipeline p - 1's, the first one's for the last one's of the step before — so a reconstruction never runs beside "
+                    "another reconstruction, only beside the other pipelines' loop filters)")
     ap.add_argument("--mb-width", type=int, default=120)
     ap.add_argument("--mb-height", type=int, default=68)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,25 +156,40 @@ def main():
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = at
     # the batch as P pipelines of F / P pictures, each on its own stream (P = 1: the null stream); every event below is recorded on the stream of the launches it brackets
-    P = args.pipelines if args.pipelines > 0 and F % args.pipelines == 0 and F // args.pipelines >= 1 else 1
+    P = args.pipelines if args.pipelines > 0 and F // args.pipelines >= 1 else 1
     lib.mi355_stream_create.restype = C.c_void_p
     streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(P)] if P > 1 else [None]
-    per = F // P
+    counts = [F // P + (1 if i < F % P else 0) for i in range(P)]         # 2048 as 683 + 683 + 682
+    firsts = [sum(counts[:i]) for i in range(P)]
+    per = counts[0]                                                       # the (largest) launch the line's per-launch figures are quoted on
     frame_bytes = C.sizeof(dev.host_desc) // F
+
+    # --phased: the pipelines' reconstruction launches take turns (pipeline p's waits for pipeline p - 1's, the first one's for the last one's of the step before), so a
+    # reconstruction never runs beside another reconstruction but beside the other pipelines' loop filters
+    lib.mi355_stream_wait_event.restype = C.c_int
+    lib.mi355_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+    turn = [C.c_void_p(lib.mi355_event_create()) for _ in range(P)] if (args.phased and P > 1) else None
+    turn_set = [False]
 
     def step(events=None):
         for p_, st in enumerate(streams):
-            d = C.c_void_p(dev.d_desc + p_ * per * frame_bytes)
+            d = C.c_void_p(dev.d_desc + firsts[p_] * frame_bytes)
+            n_ = counts[p_]
             ev = events[p_] if events is not None else None
+            if turn is not None and (p_ > 0 or turn_set[0]):
+                assert lib.mi355_stream_wait_event(st, turn[(p_ - 1) % P]) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[0], st)
-            assert lib.mi355_h264_recon_inter_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
+            assert lib.mi355_h264_recon_inter_layouts_dev(d, n_, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
+            if turn is not None:
+                lib.mi355_event_record(turn[p_], st)
+                turn_set[0] = True
             if ev is not None:
                 lib.mi355_event_record(ev[1], st)
-            assert lib.mi355_h264_recon_intra_all_dev(d, per, mbw, mbh, big.max_intra_level, level_widths(big), st) == 0
+            assert lib.mi355_h264_recon_intra_all_dev(d, n_, mbw, mbh, big.max_intra_level, level_widths(big), st) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[2], st)
-            assert lib.mi355_h264_deblock_layouts_dev(d, per, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
+            assert lib.mi355_h264_deblock_layouts_dev(d, n_, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[3], st)
 
@@ -239,12 +257,12 @@ def main():
             "steps_per_rank": steps_per_rank,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "H.264 8-bit 4:2:0 1080p (1920x1088 coded), P pictures: qpel MC + idct_add + deblock, "
-                                   "two-surface pipeline, %d independent pictures per GPU per step as %d pipeline(s) of %d on their own HIP streams "
-                                   "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, P, per, G),
+                                   "two-surface pipeline, %d independent pictures per GPU per step as %d pipeline(s) of %s pictures on their own HIP streams%s "
+                                   "(%d distinct synthetic pictures replicated), 5%% Intra16x16 MBs" % (F, P, " / ".join(str(c) for c in counts), ", reconstruction launches taking turns" if (args.phased and P > 1) else "", G),
                        "surface_layout": "macroblock-tiled decoded-picture-buffer surfaces (256-byte luma + 128-byte chroma tiles; "
                                          "a picture is de-tiled only when it leaves HBM: extra point config2_f2048_detile)" if tiled
                                          else "planes with line strides",
-                       "frames_per_gpu": F, "pipelines": P, "frames_per_launch": per, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
+                       "frames_per_gpu": F, "pipelines": P, "phased": bool(args.phased and P > 1), "frames_per_launch": per, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
                        "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
                        "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world,
                        "verified_by": "tests/test_frame_gpu.py::test_full_size_1080p_batch_matches_oracle (same generator, bit-exact)"},
@@ -257,7 +275,7 @@ def main():
         }
         if P > 1:
             # a launch shares the device with the other pipeline's launches: its duration is the time it was resident, not the time it would take alone
-            out["roofline"]["shared_device"] = ("%d pipelines: this kernel's launch (%d pictures) runs beside the other pipeline's passes, so achieved / frac are per launch WHILE SHARING; "
+            out["roofline"]["shared_device"] = ("%d pipelines: this kernel's launch (%d pictures) runs beside the other pipelines' loop filters and intra passes, so achieved / frac are per launch WHILE SHARING the device; "
                                                "alone (one pipeline, the whole batch per launch) the same kernel is measured in extra point config2_f2048_one_pipeline "
                                                "(pass_ms.recon_inter), and the whole job's rate is config.fused_fraction_of_hbm_roofline" % (P, per))
         # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
