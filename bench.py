@@ -246,7 +246,9 @@ def main():
         # dominant kernel = the pass with the largest share of the step (the loop filter is ONE launch for all bands of all pictures since round 4)
         passes = {"k_recon_inter_tiled" if tiled else "k_recon_inter": (t_inter, P, n_inter * B_RECON),
                   "k_deblock_tiled" if tiled else "k_deblock_linear": (t_deblock, P, F * nmb * B_DEBLOCK)}
-        dom = max(passes, key=lambda k: passes[k][0])
+        # dominant kernel = the one that moves the most algorithmic bytes per step (with one pipeline also the longest pass; with several, launches share the device and
+        # a launch's duration says how long it was resident, not how much of the device it had)
+        dom = max(passes, key=lambda k: passes[k][2])
         t_pass, launches, bytes_pass = passes[dom]               # t_pass: the average duration of ONE launch (HIP events on its stream)
         achieved = bytes_pass / launches / (t_pass * 1e-3)       # algorithmic bytes per launch / avg launch time
         out = {
@@ -274,10 +276,24 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_pass / launches},
         }
         if P > 1:
+            # the same kernel ALONE, outside the timed region: one launch over the whole batch, nothing beside it (what rounds 1-4's lines and the extra point
+            # config2_f2048_one_pipeline measure)
+            e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
+            sync_all()
+            alone = []
+            for _ in range(3):
+                lib.mi355_event_record(e0, None)
+                assert lib.mi355_h264_recon_inter_layouts_dev(C.c_void_p(dev.d_desc), F, mbw, mbh, LAYOUT_MASK[tiled], None) == 0
+                lib.mi355_event_record(e1, None)
+                alone.append(lib.mi355_event_elapsed_ms(e0, e1))
+            t_alone = sum(alone[1:]) / 2
+            out["roofline"]["alone"] = {"kernel": "k_recon_inter_tiled" if tiled else "k_recon_inter", "frames_per_launch": F, "avg_launch_us": t_alone * 1e3,
+                                        "algorithmic_bytes_per_launch": n_inter * B_RECON, "achieved": n_inter * B_RECON / (t_alone * 1e-3) / 1e9, "frac": n_inter * B_RECON / (t_alone * 1e-3) / HBM_PEAK,
+                                        "note": "measured after the timed region: one launch over all %d pictures with nothing beside it" % F}
             # a launch shares the device with the other pipeline's launches: its duration is the time it was resident, not the time it would take alone
             out["roofline"]["shared_device"] = ("%d pipelines: this kernel's launch (%d pictures) runs beside the other pipelines' loop filters and intra passes, so achieved / frac are per launch WHILE SHARING the device; "
-                                               "alone (one pipeline, the whole batch per launch) the same kernel is measured in extra point config2_f2048_one_pipeline "
-                                               "(pass_ms.recon_inter), and the whole job's rate is config.fused_fraction_of_hbm_roofline" % (P, per))
+                                               "the same kernel with the device to itself: roofline.alone (and extra point config2_f2048_one_pipeline); the whole job's rate is "
+                                               "config.fused_fraction_of_hbm_roofline" % (P, per))
         # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
         # (tools/gpu_traffic.sh -> profiles/*hbm_traffic*.json; cannot be collected from inside this process)
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(dom, per)
