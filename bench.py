@@ -318,13 +318,14 @@ def main():
                         points[p["name"] + "_" + key.replace("reference_c_decoder", "c")] = round(p[key]["pictures_per_s"], 1)
             if not args.notes:
                 for p in out["extra"]:
-                    for key in ("note", "what", "sample"):
+                    for key in ("note", "what", "sample", "pass_ms_is"):
                         p.pop(key, None)
                     if isinstance(p.get("cpu_baseline"), dict):
                         p["cpu_baseline"].pop("sample", None)
-        out["config"]["points"] = points
-        for k_, v_ in points.items():               # ... and flat (the driver's record keeps the scalars of `config`, not nested objects)
+        for k_, v_ in points.items():               # flat (the driver's record keeps the scalars of `config`, not nested objects)
             out["config"]["p_" + k_] = v_
+        if args.notes:
+            out["config"]["points"] = points
         print(json.dumps(out))
     if dev is not None:
         dev.free()
@@ -363,7 +364,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     import h264_frames as HF
     pts = []
 
-    def run(name, fs, F, note, layout_tiled=tiled, detile=False):
+    def run(name, fs, F, note, layout_tiled=tiled, detile=False, pipelines=1):
         dev = HF.DeviceFrames(prov, fs, replicate=F, tiled=layout_tiled)
         try:
             conv = detile_jobs(lib, dev, fs, F) if detile else None
@@ -382,12 +383,47 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
                 if conv is not None:
                     assert lib.mi355_h264_surface_convert_dev(conv, F, mbw, mbh, None) == 0
             once()
-            e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
-            lib.mi355_event_record(e0, None)
-            for _ in range(3):
-                once()
-            lib.mi355_event_record(e1, None)
-            ms = lib.mi355_event_elapsed_ms(e0, e1) / 3
+            if pipelines > 1:
+                # the headline's execution: the batch as `pipelines` shares on their own streams, reconstruction launches taking turns (main()'s step)
+                lib.mi355_stream_wait_event.restype = C.c_int
+                lib.mi355_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+                lib.mi355_stream_create.restype = C.c_void_p
+                streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(pipelines)]
+                turn = [C.c_void_p(lib.mi355_event_create()) for _ in range(pipelines)]
+                counts = [F // pipelines + (1 if i < F % pipelines else 0) for i in range(pipelines)]
+                fb = C.sizeof(dev.host_desc) // F
+                lw = level_widths(fs)
+                started = [False]
+
+                def piped():
+                    for p_, st in enumerate(streams):
+                        d = C.c_void_p(dev.d_desc + sum(counts[:p_]) * fb)
+                        if p_ > 0 or started[0]:
+                            assert lib.mi355_stream_wait_event(st, turn[(p_ - 1) % pipelines]) == 0
+                        assert lib.mi355_h264_recon_inter_layouts_dev(d, counts[p_], mbw, mbh, LAYOUT_MASK[layout_tiled], st) == 0
+                        lib.mi355_event_record(turn[p_], st)
+                        started[0] = True
+                        assert lib.mi355_h264_recon_intra_all_dev(d, counts[p_], mbw, mbh, fs.max_intra_level, lw, st) == 0
+                        assert lib.mi355_h264_deblock_layouts_dev(d, counts[p_], mbw, mbh, LAYOUT_MASK[layout_tiled], st) == 0
+
+                def sync_streams():
+                    for st in streams:
+                        assert lib.mi355_sync(st) == 0
+                lib.mi355_sync(None)
+                piped(); piped()
+                sync_streams()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    piped()
+                sync_streams()
+                ms = (time.perf_counter() - t0) * 1e3 / 4
+            else:
+                e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
+                lib.mi355_event_record(e0, None)
+                for _ in range(3):
+                    once()
+                lib.mi355_event_record(e1, None)
+                ms = lib.mi355_event_elapsed_ms(e0, e1) / 3
             # one more step with an event after every pass: where the step's time goes
             ev = [lib.mi355_event_create() for _ in range(4)]
             lib.mi355_event_record(ev[0], None)
@@ -402,8 +438,10 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         finally:
             dev.free()
         v = F * mbw * mbh / (ms * 1e-3)
-        pts.append({"name": name, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F,
-                    "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "pass_ms": passes, "note": note})
+        pts.append({"name": name, "macroblocks_per_s": v, "frames_per_s": v / (mbw * mbh), "ms_per_step": ms, "frames_per_step": F, "pipelines": pipelines,
+                    "fused_fraction_of_hbm_roofline": v * B_FUSED / HBM_PEAK, "pass_ms": passes,
+                    "pass_ms_is": "one further step, the three passes one after the other on one stream" + (" (ms_per_step: %d pipelines as in the headline)" % pipelines if pipelines > 1 else ""),
+                    "note": note})
 
     base = HF.synth_frames_fast(4, mbw, mbh, seed=0x264, lib=lib)
     for fn in (hevc_point, hevc_bridge_points, sws_points, session_points, h264_real_stream_points):
@@ -418,12 +456,12 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             "(mi355_h264_surface_convert_dev: what a picture costs when it LEAVES HBM — display, host copy, a consumer that wants lines; "
             "+384 B read and written per macroblock; references stay tiled)", detile=True)
     run("config2_f2048_linear" if tiled else "config2_f2048_tiled", base, 2048, "the headline workload on the OTHER surface layout (%s)"
-        % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled)
+        % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled, pipelines=3)
     mixed = HF.synth_frames_fast(4, mbw, mbh, seed=0x2640, lib=lib, partitions="mixed")
     run("config2_mixed_partitions_f2048", mixed, 2048, "SURVEY 8d's second run of config 2: inter macroblocks are 16x16 / 16x8 / 8x16 / 8x8 (a quarter each), 8x8 "
         "quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each), one vector per partition, one reference per partition / quadrant: 5.6 prediction blocks "
         "and reference windows per macroblock on average instead of 1 (the algorithmic bytes stay 2432 per macroblock: the fraction is against the "
-        "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
+        "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle", pipelines=3)
     run("config2_f2048_one_pipeline", base, 2048, "the headline batch as ONE pipeline on one stream: the three passes over all 2048 pictures one after the other "
         "(how rounds 1-4 measured the headline; pass_ms here are the passes' own times)")
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
@@ -432,7 +470,7 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
     run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra; the inter pass is not launched for a batch of I pictures" % intra.max_intra_level)
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
     run("config2_smooth_f2048", smooth, 2048, "same shapes, smooth reference pictures and small residuals: the loop filter's conditions "
-        "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)")
+        "hold on most lines (on config 2's random references they almost never do and the wave-level early-outs skip the arithmetic)", pipelines=3)
     # High 10: the same workload with 10-bit samples and 32-bit coefficients through the second kernel set — last: its 2048 pictures take
     # 100 GB of HBM, and the decoder processes of the real-stream points above should not start beside an allocator that has just let go of them
     try:
