@@ -456,12 +456,12 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
             "(mi355_h264_surface_convert_dev: what a picture costs when it LEAVES HBM — display, host copy, a consumer that wants lines; "
             "+384 B read and written per macroblock; references stay tiled)", detile=True)
     run("config2_f2048_linear" if tiled else "config2_f2048_tiled", base, 2048, "the headline workload on the OTHER surface layout (%s)"
-        % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled, pipelines=3)
+        % ("planes with line strides, as rounds 1-2 measured" if tiled else "macroblock-tiled"), layout_tiled=not tiled)
     mixed = HF.synth_frames_fast(4, mbw, mbh, seed=0x2640, lib=lib, partitions="mixed")
     run("config2_mixed_partitions_f2048", mixed, 2048, "SURVEY 8d's second run of config 2: inter macroblocks are 16x16 / 16x8 / 8x16 / 8x8 (a quarter each), 8x8 "
         "quadrants 8x8 / 8x4 / 4x8 / 4x4 (a quarter each), one vector per partition, one reference per partition / quadrant: 5.6 prediction blocks "
         "and reference windows per macroblock on average instead of 1 (the algorithmic bytes stay 2432 per macroblock: the fraction is against the "
-        "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle", pipelines=3)
+        "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
     run("config2_f2048_one_pipeline", base, 2048, "the headline batch as ONE pipeline on one stream: the three passes over all 2048 pictures one after the other "
         "(how rounds 1-4 measured the headline; pass_ms here are the passes' own times)")
     run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
