@@ -250,19 +250,62 @@ class Chain:
             done += k
         return base
 
-    def run(self):
+    def run(self, stream=None, turn_stage=-1, wait_ev=None, record_ev=None):
+        """turn_stage (with several chains on their own streams): stage 1 (MC + prediction), 2 (transform + residual) or 4 (SAO) waits for `wait_ev` and is followed by `record_ev`"""
         L = self.lib
+
+        def around(stage, launch):
+            if stage == turn_stage and wait_ev is not None:
+                assert L.mi355_stream_wait_event(stream, wait_ev) == 0
+            launch()
+            if stage == turn_stage and record_ev is not None:
+                L.mi355_event_record(record_ev, stream)
         if self.n_ee:
-            assert L.mi355_edge_emu_batch_dev(C.c_void_p(self.d_ee), self.n_ee, self.BD, None) == 0
-        assert L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, None) == 0
-        assert L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, None) == 0
-        assert L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, None) == 0
-        assert L.mi355_hevc_sao_ctbs_dev(C.c_void_p(self.d_sao), self.n_sao, self.BD, None) == 0
+            assert L.mi355_edge_emu_batch_dev(C.c_void_p(self.d_ee), self.n_ee, self.BD, stream) == 0
+        around(1, lambda: L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, stream))
+        around(2, lambda: L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, stream))
+        around(3, lambda: L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, stream))
+        around(4, lambda: L.mi355_hevc_sao_ctbs_dev(C.c_void_p(self.d_sao), self.n_sao, self.BD, stream))
 
     def free(self):
         for p in self.bufs:
             self.lib.mi355_free(p)
         self.bufs = []
+
+
+def measure_pipelines(lib, pictures=64, pipelines=2, steps=6, turn_stage=-1):
+    """the same 64 pictures as `pipelines` chains of pictures / pipelines each on their own streams (developer experiment: profiles/r05_experiments.md 13)"""
+    import time
+    lib.mi355_stream_create.restype = C.c_void_p
+    chains = [Chain(lib, pictures // pipelines, seed=0x265 + i) for i in range(pipelines)]
+    streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(pipelines)]
+    try:
+        lib.mi355_stream_wait_event.restype = C.c_int
+        lib.mi355_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+        lib.mi355_event_record.argtypes = [C.c_void_p, C.c_void_p]
+        lib.mi355_event_create.restype = C.c_void_p
+        turn = [C.c_void_p(lib.mi355_event_create()) for _ in range(pipelines)]
+        started = [False]
+
+        def step():
+            for i, (ch, st) in enumerate(zip(chains, streams)):
+                ch.run(st, turn_stage, turn[(i - 1) % pipelines] if (turn_stage > 0 and (i > 0 or started[0])) else None, turn[i] if turn_stage > 0 else None)
+                started[0] = True
+
+        def sync():
+            for st in streams:
+                lib.mi355_sync(st)
+        step(); step(); sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        ctbs = sum(ch.ctbs for ch in chains)
+        return {"pipelines": pipelines, "turn_stage": turn_stage, "pictures_per_step": pictures, "ms_per_step": ms, "fraction_of_hbm_roofline": ctbs * BYTES_PER_CTB / (ms * 1e-3) / 8e12}
+    finally:
+        for ch in chains:
+            ch.free()
 
 
 def measure(lib, pictures=64, steps=3, cpu_seconds=6.0):
@@ -295,7 +338,10 @@ def measure(lib, pictures=64, steps=3, cpu_seconds=6.0):
 if __name__ == "__main__":
     import json
     import libav_amd
-    print(json.dumps(measure(libav_amd.load(0), int(sys.argv[1]) if len(sys.argv) > 1 else 64, cpu_seconds=0)))
+    if len(sys.argv) > 2:
+        print(json.dumps(measure_pipelines(libav_amd.load(0), int(sys.argv[1]), int(sys.argv[2]), turn_stage=int(sys.argv[3]) if len(sys.argv) > 3 else -1)))
+    else:
+        print(json.dumps(measure(libav_amd.load(0), int(sys.argv[1]) if len(sys.argv) > 1 else 64, cpu_seconds=0)))
 
 
 # ---- the same pictures through the reference's own functions (oracle/ref_hevc_chain.c in oracle/_ref/libhevcfilterref.so) --------
