@@ -155,35 +155,44 @@ def main():
                           ("mi355_event_elapsed_ms", C.c_float, [C.c_void_p, C.c_void_p]), ("mi355_sync", C.c_int, [C.c_void_p])):
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = at
-    # the batch as P pipelines of F / P pictures, each on its own stream (P = 1: the null stream); every event below is recorded on the stream of the launches it brackets
+    # the batch as P pipelines of about F / P pictures, each on its own stream (P = 1: the null stream)
     P = args.pipelines if args.pipelines > 0 and F // args.pipelines >= 1 else 1
     lib.mi355_stream_create.restype = C.c_void_p
-    streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(P)] if P > 1 else [None]
+    streams = [None]
     counts = [F // P + (1 if i < F % P else 0) for i in range(P)]         # 2048 as 683 + 683 + 682
     firsts = [sum(counts[:i]) for i in range(P)]
     per = counts[0]                                                       # the (largest) launch the line's per-launch figures are quoted on
     frame_bytes = C.sizeof(dev.host_desc) // F
 
-    # --phased: the pipelines' reconstruction launches take turns (pipeline p's waits for pipeline p - 1's, the first one's for the last one's of the step before), so a
-    # reconstruction never runs beside another reconstruction but beside the other pipelines' loop filters
-    lib.mi355_stream_wait_event.restype = C.c_int
-    lib.mi355_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
-    turn = [C.c_void_p(lib.mi355_event_create()) for _ in range(P)] if (args.phased and P > 1) else None
-    turn_set = [False]
+    # Several pipelines: the library's own object (libav_amd/csrc/h264_pipelines.hip: a stream per share, the shares' reconstruction launches taking turns, events around
+    # every pass) — the schedule is product code, this file only calls it.  One pipeline (and the work-queue mode): the three entry points on the null stream.
+    pipe = None
+    if P > 1 and not (args.queue and world > 1):
+        lib.mi355_h264_pipelines_create.restype = C.c_void_p
+        lib.mi355_h264_pipelines_create.argtypes = [C.c_int, C.c_int]
+        lib.mi355_h264_pipelines_decode_dev.restype = C.c_int
+        lib.mi355_h264_pipelines_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.mi355_h264_pipelines_sync.argtypes = [C.c_void_p]
+        lib.mi355_h264_pipelines_timing.argtypes = [C.c_void_p, C.c_int]
+        lib.mi355_h264_pipelines_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mi355_h264_pipelines_destroy.argtypes = [C.c_void_p]
+        pipe = C.c_void_p(lib.mi355_h264_pipelines_create(P, 1 if args.phased else 0))
+        assert pipe
+        lib.mi355_h264_pipelines_timing(pipe, 1)
+    elif P > 1:
+        P, counts, firsts, per = 1, [F], [0], F
 
     def step(events=None):
+        if pipe is not None:
+            assert lib.mi355_h264_pipelines_decode_dev(pipe, C.c_void_p(dev.d_desc), F, mbw, mbh, big.max_intra_level, level_widths(big), LAYOUT_MASK[tiled]) == 0
+            return
         for p_, st in enumerate(streams):
             d = C.c_void_p(dev.d_desc + firsts[p_] * frame_bytes)
             n_ = counts[p_]
             ev = events[p_] if events is not None else None
-            if turn is not None and (p_ > 0 or turn_set[0]):
-                assert lib.mi355_stream_wait_event(st, turn[(p_ - 1) % P]) == 0
             if ev is not None:
                 lib.mi355_event_record(ev[0], st)
             assert lib.mi355_h264_recon_inter_layouts_dev(d, n_, mbw, mbh, LAYOUT_MASK[tiled], st) == 0
-            if turn is not None:
-                lib.mi355_event_record(turn[p_], st)
-                turn_set[0] = True
             if ev is not None:
                 lib.mi355_event_record(ev[1], st)
             assert lib.mi355_h264_recon_intra_all_dev(d, n_, mbw, mbh, big.max_intra_level, level_widths(big), st) == 0
@@ -194,6 +203,8 @@ def main():
                 lib.mi355_event_record(ev[3], st)
 
     def sync_all():
+        if pipe is not None:
+            assert lib.mi355_h264_pipelines_sync(pipe) == 0
         for st in streams:
             assert lib.mi355_sync(st) == 0
 
@@ -204,6 +215,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        assert lib.mi355_h264_pipelines_collect(pipe, None, None) == 0         # the warm-up's events
     queue = shard.WorkQueue(world * args.steps, 1) if (args.queue and world > 1) else None
     evs = []
     barrier()
@@ -212,7 +225,7 @@ def main():
         return [[lib.mi355_event_create() for _ in range(4)] for _ in range(P)]
     if queue is None:
         for k in range(args.steps):
-            evs.append(new_events())
+            evs.append(new_events() if pipe is None else None)
             step(evs[-1])
     else:
         # one batch in flight plus one queued: a rank only pulls when its previous-but-one batch has finished
@@ -230,10 +243,16 @@ def main():
     my_steps = len(evs)
 
     # per LAUNCH (one pipeline's share of the batch): with P > 1 the launches of different pipelines run side by side, so the passes' times do not add up to the step
-    nl = max(1, my_steps * P)
-    t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for st_ in evs for e in st_) / nl
-    t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for st_ in evs for e in st_) / nl
-    t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for st_ in evs for e in st_) / nl
+    if pipe is not None:
+        sums, nl_ = (C.c_double * 3)(), C.c_int(0)
+        assert lib.mi355_h264_pipelines_collect(pipe, sums, C.byref(nl_)) == 0
+        assert nl_.value == my_steps * P, (nl_.value, my_steps, P)
+        t_inter, t_intra, t_deblock = (sums[k] / max(1, nl_.value) for k in range(3))
+    else:
+        nl = max(1, my_steps * P)
+        t_inter = sum(lib.mi355_event_elapsed_ms(e[0], e[1]) for st_ in evs for e in st_) / nl
+        t_intra = sum(lib.mi355_event_elapsed_ms(e[1], e[2]) for st_ in evs for e in st_) / nl
+        t_deblock = sum(lib.mi355_event_elapsed_ms(e[2], e[3]) for st_ in evs for e in st_) / nl
 
     elapsed, total_mbs = shard.reduce_counters(elapsed, F * nmb * my_steps, ctl)
     steps_per_rank = shard.gather_counts(my_steps, ctl)
@@ -384,39 +403,28 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
                     assert lib.mi355_h264_surface_convert_dev(conv, F, mbw, mbh, None) == 0
             once()
             if pipelines > 1:
-                # the headline's execution: the batch as `pipelines` shares on their own streams, reconstruction launches taking turns (main()'s step)
-                lib.mi355_stream_wait_event.restype = C.c_int
-                lib.mi355_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
-                lib.mi355_stream_create.restype = C.c_void_p
-                streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(pipelines)]
-                turn = [C.c_void_p(lib.mi355_event_create()) for _ in range(pipelines)]
-                counts = [F // pipelines + (1 if i < F % pipelines else 0) for i in range(pipelines)]
-                fb = C.sizeof(dev.host_desc) // F
+                # the headline's execution: the library's pipelines object (shares on their own streams, reconstruction launches taking turns)
+                lib.mi355_h264_pipelines_create.restype = C.c_void_p
+                lib.mi355_h264_pipelines_create.argtypes = [C.c_int, C.c_int]
+                lib.mi355_h264_pipelines_decode_dev.restype = C.c_int
+                lib.mi355_h264_pipelines_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+                lib.mi355_h264_pipelines_sync.argtypes = [C.c_void_p]
+                lib.mi355_h264_pipelines_destroy.argtypes = [C.c_void_p]
+                pipe = C.c_void_p(lib.mi355_h264_pipelines_create(pipelines, 1))
+                assert pipe
                 lw = level_widths(fs)
-                started = [False]
 
                 def piped():
-                    for p_, st in enumerate(streams):
-                        d = C.c_void_p(dev.d_desc + sum(counts[:p_]) * fb)
-                        if p_ > 0 or started[0]:
-                            assert lib.mi355_stream_wait_event(st, turn[(p_ - 1) % pipelines]) == 0
-                        assert lib.mi355_h264_recon_inter_layouts_dev(d, counts[p_], mbw, mbh, LAYOUT_MASK[layout_tiled], st) == 0
-                        lib.mi355_event_record(turn[p_], st)
-                        started[0] = True
-                        assert lib.mi355_h264_recon_intra_all_dev(d, counts[p_], mbw, mbh, fs.max_intra_level, lw, st) == 0
-                        assert lib.mi355_h264_deblock_layouts_dev(d, counts[p_], mbw, mbh, LAYOUT_MASK[layout_tiled], st) == 0
-
-                def sync_streams():
-                    for st in streams:
-                        assert lib.mi355_sync(st) == 0
+                    assert lib.mi355_h264_pipelines_decode_dev(pipe, C.c_void_p(dev.d_desc), F, mbw, mbh, fs.max_intra_level, lw, LAYOUT_MASK[layout_tiled]) == 0
                 lib.mi355_sync(None)
                 piped(); piped()
-                sync_streams()
+                assert lib.mi355_h264_pipelines_sync(pipe) == 0
                 t0 = time.perf_counter()
                 for _ in range(4):
                     piped()
-                sync_streams()
+                assert lib.mi355_h264_pipelines_sync(pipe) == 0
                 ms = (time.perf_counter() - t0) * 1e3 / 4
+                lib.mi355_h264_pipelines_destroy(pipe)
             else:
                 e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
                 lib.mi355_event_record(e0, None)

@@ -373,6 +373,24 @@ typedef struct mi355_copy_job {
     uint64_t bytes;
 } mi355_copy_job;
 int   mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t max_bytes, void *stream);
+/* LARGE batches (hundreds of pictures and more; round 5, libav_amd/csrc/h264_pipelines.hip): the batch as `shares` shares, each through the three passes on a HIP stream
+ * of its own, the shares' reconstruction launches taking turns (`turns` != 0) so that a reconstruction — bound by the memory pipeline — runs beside the other shares' loop
+ * filters and intra passes — bound by the vector pipe — and never beside another reconstruction.  Three shares: 12.0 - 12.2 ms per 2048 1080p pictures against 13.4 - 13.7
+ * for mi355_h264_decode_frames_layouts_dev on one stream.  The object keeps its streams and the turn across calls: consecutive batches run into each other; nothing is
+ * finished before mi355_h264_pipelines_sync() (or _collect) returns.  One object per host thread and device.
+ * _share(): which pictures of a batch of nframes share i takes (first, count): 2048 as 683 + 683 + 682.
+ * _timing(1) + _collect(): sums[0..2] += milliseconds of the reconstruction / intra / loop-filter pass of every (share, call) since the last collect, measured by events on
+ * the share's stream (the passes of different shares overlap: the sums exceed the wall time), *launches += their number. */
+typedef struct mi355_h264_pipelines mi355_h264_pipelines;
+mi355_h264_pipelines *mi355_h264_pipelines_create(int shares, int turns);      /* shares 1..16 */
+void mi355_h264_pipelines_destroy(mi355_h264_pipelines *p);                      /* waits first */
+int  mi355_h264_pipelines_decode_dev(mi355_h264_pipelines *p, const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height,
+                                     int max_intra_level, const int32_t *level_widths, int layouts);
+int  mi355_h264_pipelines_sync(mi355_h264_pipelines *p);
+int  mi355_h264_pipelines_share(const mi355_h264_pipelines *p, int nframes, int share, int *first, int *count);
+void mi355_h264_pipelines_timing(mi355_h264_pipelines *p, int on);
+int  mi355_h264_pipelines_collect(mi355_h264_pipelines *p, double sums[3], int *launches);
+
 /* Streams for callers that pipeline half-batches (reconstruction of one against deblocking of the other);
  * `stream` arguments of every entry point accept these or NULL (the default stream). */
 void *mi355_stream_create(void);

@@ -201,7 +201,7 @@ def run_surface_convert(backend, cases=((5, 3, 0, 0), (1, 1, 0, 256), (9, 4, 24,
     return len(cases)
 
 
-def run_fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, replicate=None, **kw):
+def run_fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, replicate=None, pipelined=None, **kw):
     """the bench generator's pictures through the single-layout entry points on tiled surfaces (k_recon_inter_tiled: the run kernel of
     h264_recon_fast.h), every sample of both surfaces of every picture against the oracle"""
     fs = HF.synth_frames_fast(nframes, mb_w, mb_h, seed=seed, lib=backend.lib, **kw)
@@ -209,7 +209,10 @@ def run_fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, repl
     F = replicate or nframes
     d = HF.DeviceFrames(backend, fs, tiled=True, replicate=replicate) if replicate else HF.DeviceFrames(backend, fs, tiled=True)
     try:
-        d.decode_by_layout()
+        if pipelined:
+            d.decode_pipelined(*pipelined)                 # (shares, turns, calls): mi355_h264_pipelines_*
+        else:
+            d.decode_by_layout()
         for first in range(0, F, 32):
             n = min(32, F - first)
             recon_g, dst_g = (d.fetch(d.recon, first, n), d.fetch(d.dst, first, n)) if replicate else (d.fetch(d.recon), d.fetch(d.dst))

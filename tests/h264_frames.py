@@ -708,6 +708,26 @@ class DeviceFrames:
             assert fn(self.d_desc, self.F, *args, None) == 0, name
         assert lib.mi355_sync(None) == 0
 
+    def decode_pipelined(self, shares=3, turns=1, calls=1):
+        """mi355_h264_pipelines_*: the batch as `shares` shares on their own streams, reconstruction launches taking turns; `calls` batches one behind the other"""
+        fs, lib = self.fs, self.lib
+        lib.mi355_h264_pipelines_create.restype = C.c_void_p
+        lib.mi355_h264_pipelines_create.argtypes = [C.c_int, C.c_int]
+        lib.mi355_h264_pipelines_decode_dev.restype = C.c_int
+        lib.mi355_h264_pipelines_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.mi355_h264_pipelines_sync.argtypes = [C.c_void_p]
+        lib.mi355_h264_pipelines_destroy.argtypes = [C.c_void_p]
+        lib.mi355_h264_pipelines_destroy.restype = None
+        lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+        p = lib.mi355_h264_pipelines_create(shares, turns)
+        assert p
+        try:
+            for _ in range(calls):
+                assert lib.mi355_h264_pipelines_decode_dev(p, self.d_desc, self.F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, 2 if self.tiled else 1) == 0
+            assert lib.mi355_h264_pipelines_sync(p) == 0
+        finally:
+            lib.mi355_h264_pipelines_destroy(p)
+
     def decode_wide(self, bit_depth=8, idc=1, passes=7, sync=True):
         """the three passes of the SECOND kernel set (mi355_h264_decode_frames_wide_dev: High 10 / High 4:2:2, and 8-bit 4:2:0 for this
         comparison) on linear surfaces"""

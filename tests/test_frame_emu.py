@@ -196,6 +196,13 @@ def test_run_kernel_windows_over_every_border_emulated(emu, oracle, mb_w, mb_h, 
     _fast_workload_by_layout(emu, oracle, 2, mb_w, mb_h, 0x2650 + mv_range + mb_w, mv_range=mv_range)
 
 
+@pytest.mark.parametrize("shares,turns,replicate", ((3, 1, 8), (2, 0, 5), (5, 1, 3), (1, 1, 4)))
+def test_pipelines_object_emulated(emu, oracle, shares, turns, replicate):
+    """mi355_h264_pipelines_*: uneven shares, more shares than pictures, two calls one behind the other — the same pictures as the one-stream entry points
+    (streams and events do nothing in the emulator: this checks the shares' arithmetic and the entry point's plumbing; the ordering is the device test's)"""
+    _fast_workload_by_layout(emu, oracle, 2, 9, 5, 0x2670 + shares, replicate=replicate, pipelined=(shares, turns, 2), partitions="mixed", intra_frac=0.2)
+
+
 def test_run_kernel_mixed_partitions_emulated(emu, oracle):
     """runs that hold fast macroblocks and deferred ones (partitions) side by side"""
     _fast_workload_by_layout(emu, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)

@@ -380,6 +380,17 @@ def test_run_kernel_windows_over_every_border(mi355, oracle, mb_w, mb_h, mv_rang
     frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, mb_w, mb_h, 0x2650 + mv_range + mb_w, mv_range=mv_range)
 
 
+@pytest.mark.parametrize("shares,turns,replicate", ((3, 1, 8), (2, 0, 5), (5, 1, 3), (1, 1, 4)))
+def test_pipelines_object_small(mi355, oracle, shares, turns, replicate):
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, 9, 5, 0x2670 + shares, replicate=replicate, pipelined=(shares, turns, 2), partitions="mixed", intra_frac=0.2)
+
+
+def test_pipelines_object_under_load(mi355, oracle):
+    """mi355_h264_pipelines_*: 256 1080p pictures as three shares whose reconstruction launches take turns, three batches one behind the other on the object's streams
+    (the passes of different shares and of consecutive calls overlap on the device): every picture equals the oracle's"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 3, 120, 68, 0x2267, replicate=256, pipelined=(3, 1, 3))
+
+
 def test_run_kernel_mixed_partitions(mi355, oracle):
     frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, 9, 5, 0x2641, partitions="mixed", intra_frac=0.2)
 
