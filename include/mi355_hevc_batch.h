@@ -297,6 +297,40 @@ int mi355_hevc_recon_level_dev(const mi355_hevc_mcpred_job *d_mc, int n_mc, cons
                                const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
                                const mi355_hevc_tu_job *d_block_tus, int n_blocks, int bit_depth, void *stream);
 
+/* ---- a12-a15 fused per coding tree block: what hls_coding_quadtree (hevcdec.c:2202-2290) does for the INTER coding units of one CTB —
+ * every prediction block (hls_prediction_unit :1695-1885: luma_mc / chroma_mc + put_unweighted_pred / weighted_pred), then every transform
+ * unit (hls_transform_unit :1238-1260: idct / transform_skip / ..., add_residual) — as ONE workgroup: the CTB's samples are predicted into an
+ * LDS tile, the residuals are added there, and the tile leaves for the picture once, in whole lines.  The prediction is never written to
+ * the picture and read back (what mi355_hevc_mcpred_batch_dev followed by mi355_hevc_residual_batch_dev does: 2 x 12 KB per 64x64 CTB at
+ * 10 bit), and there is one launch instead of two.  Results are identical to those two launches.
+ *
+ * A CTB job names its prediction jobs d_mc[first_mc .. first_mc + n_mc) and its transform units d_tus[first_tu .. first_tu + n_tu): the
+ * SAME records the two batch entry points take, `dst` pointing into the picture — every `dst` of a CTB's jobs must lie inside that CTB
+ * (the kernel turns it into tile coordinates through dst[] / stride[] of the CTB job).  Prediction jobs run before transform units, each
+ * list in any order among the workgroup's waves: blocks of one list must not overlap.
+ * MI355_HEVC_CTB_PARTIAL: the jobs do not cover every sample of the CTB (intra coding units reconstructed by other launches, a picture whose
+ * last rows no block covers): the tile is first loaded from the picture, so uncovered samples come back unchanged.  Without the flag the
+ * CTB is not read.
+ * Fast paths (the matrix unit on byte planes, libav_amd/csrc/hevc_ctb_fast.h): one-reference unweighted prediction blocks whose width and
+ * height are multiples of 16 samples of their plane, and 16x16 / 32x32 inverse DCTs (MI355_HEVC_TU_IDCT) with 16-byte aligned
+ * coefficients; everything else runs the bodies of the two batch kernels on the tile.  Precondition for the transform units, as for
+ * mi355_hevc_residual_batch_dev and for the same reason (hevcdec.c:1249-1256): a unit's coefficients lie in rows AND columns
+ * 0 .. col_limit + 3 of its block (the diagonal scan leaves none beyond either). */
+enum { MI355_HEVC_CTB_PARTIAL = 1 };
+typedef struct mi355_hevc_ctb_job {
+    uint8_t *dst[3];              /* first sample of the CTB in the picture's three planes */
+    int32_t stride[3];            /* bytes */
+    uint16_t width, height;       /* luma samples of the CTB inside the picture: 1 << log2_ctb_size except in the last column / row */
+    uint8_t log2_ctb_size;        /* 4..6 */
+    uint8_t flags;                /* MI355_HEVC_CTB_* */
+    uint8_t reserved[2];
+    uint32_t first_mc, n_mc;
+    uint32_t first_tu, n_tu;
+    uint32_t reserved1;
+} mi355_hevc_ctb_job;
+int mi355_hevc_recon_ctbs_dev(const mi355_hevc_ctb_job *d_ctbs, int n_ctbs, const mi355_hevc_mcpred_job *d_mc, const mi355_hevc_tu_job *d_tus,
+                              int bit_depth, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,19 @@
 #include <cstdint>
 #include "h264_dev.h"   /* clip3, iabs, lane_id */
 
-namespace mi355 {
+/* Which rendezvous the wave-level building blocks below use between their LDS phases.  Default: __syncthreads() — the kernels of
+ * hevc_batch.hip / hevc_tier1.hip are one wavefront per workgroup.  hevc_ctb.hip (several wavefronts per workgroup, each on its own
+ * job and its own scratch) includes this file with MI355_HEVC_SYNC() = MI355_WAVE_SYNC() and MI355_HEVC_NS = a namespace of its own,
+ * so that the two instantiations of these inline functions are different entities (the emulator build links them into one object). */
+#ifndef MI355_HEVC_NS
+#define MI355_HEVC_NS mi355
+#endif
+#ifndef MI355_HEVC_SYNC
+#define MI355_HEVC_SYNC() __syncthreads()
+#endif
+
+namespace MI355_HEVC_NS {
+using namespace mi355;
 
 __device__ __forceinline__ int clip_i16(int v) { return clip3(v, -32768, 32767); }
 __device__ __forceinline__ int clip_px(int v, int bd) { return clip3(v, 0, (1 << bd) - 1); }
@@ -151,7 +163,7 @@ __device__ inline void hevc_idct_half(int16_t *c, int hl, bool active, int col_l
 #pragma unroll
         for (int n = 0; n < H; n++) c[i + H * n] = (int16_t)clip_i16((out[n] + 64) >> 7);
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
     if (active && hl < H) {
         const int i = hl, shift = 20 - bd, add = 1 << (shift - 1);
         if (H >= 16 && limit <= H / 2) {
@@ -166,7 +178,7 @@ __device__ inline void hevc_idct_half(int16_t *c, int hl, bool active, int col_l
 #pragma unroll
         for (int n = 0; n < H; n++) c[H * i + n] = (int16_t)clip_i16((out[n] + add) >> shift);
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
 }
 
 /* 4x4 DST-VII for intra luma (:103-136), lanes 0..3 */
@@ -186,14 +198,14 @@ __device__ inline void hevc_dst4_wave(int16_t *c, int bd, int lane, bool active 
         dst4_1d(in, out);
         for (int k = 0; k < 4; k++) c[lane + 4 * k] = (int16_t)clip_i16((out[k] + 64) >> 7);
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
     if (active && lane < 4) {
         const int shift = 20 - bd, add = 1 << (shift - 1);
         for (int k = 0; k < 4; k++) in[k] = c[4 * lane + k];
         dst4_1d(in, out);
         for (int k = 0; k < 4; k++) c[4 * lane + k] = (int16_t)clip_i16((out[k] + add) >> shift);
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
 }
 
 /* ---- a14: luma 8-tap / chroma 4-tap MC to the 14-bit intermediate ----------------------------- */
@@ -416,7 +428,7 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
     }
     const int rows = th_ + (my ? extra : 0);
     hevc_mc_stage(s, w0, sb, rows, tw + (mx ? extra : 0), bd);
-    __syncthreads();
+    MI355_HEVC_SYNC();
     const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
     if (!mx && !my) {
         /* put_hevc_*_pixels: sample << (14 - bd); two values per dword shift together (no carry across) */
@@ -440,7 +452,7 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
             if (my) *reinterpret_cast<uint2 *>(&s.tmp[r * HEVC_MC_TPITCH + x0]) = make_uint2(lo, hi);
             else sink.put4(r, x0, lo, hi, tw - x0);
         }
-        if (my) __syncthreads();
+        if (my) MI355_HEVC_SYNC();
     }
     if (my) {
         /* vertical pass: lane = (column pair, R output rows).  R = 8 when that fills the wave (a 32x32 tile: 16 pairs x 4 groups);
@@ -454,7 +466,7 @@ __device__ inline void hevc_mc_tile(const Sink &sink, const uint8_t *w0, ptrdiff
         else if (cp * ((th_ + 3) >> 2) > 32) hevc_mc_vpass<TAPS, 4>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
         else hevc_mc_vpass<TAPS, 2>(sink, lines, pitch2, tv, cp, th_, vshift, lane);
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
 }
 /* the same tile of BOTH chroma planes (4-tap filters, one vector): windows staged together, every pass over the rows of both.
  * sink0 / sink1: where plane 0 / plane 1 results go; w0a / w0b: first sample the taps touch in each plane */
@@ -473,7 +485,7 @@ __device__ inline void hevc_mc_tile_pair(const Sink &sink0, const Sink &sink1, c
     }
     const int rows = th_ + (my ? extra : 0);
     hevc_mc_stage_pair(s, w0a, w0b, sb, rows, tw + (mx ? extra : 0), bd);
-    __syncthreads();
+    MI355_HEVC_SYNC();
     const int wseg = (tw + 3) >> 2, winv = mi355_inv20(wseg);
     /* item i of a row-wise pass: row r of plane pl, LDS row lr */
 #define MI355_PAIR_ROW(i) const int r2 = mi355_div20(i, winv), x0 = 4 * (i - r2 * wseg), pl = r2 >= rows, r = r2 - (pl ? rows : 0), lr = r + (pl ? HEVC_MC_PAIR_ROW : 0)
@@ -499,7 +511,7 @@ __device__ inline void hevc_mc_tile_pair(const Sink &sink0, const Sink &sink1, c
             else if (pl) sink1.put4(r, x0, lo, hi, tw - x0);
             else sink0.put4(r, x0, lo, hi, tw - x0);
         }
-        if (my) __syncthreads();
+        if (my) MI355_HEVC_SYNC();
     }
 #undef MI355_PAIR_ROW
     if (my) {
@@ -511,7 +523,7 @@ __device__ inline void hevc_mc_tile_pair(const Sink &sink0, const Sink &sink1, c
         if (cp * ((th_ + 3) >> 2) > 32) { hevc_mc_vpass<TAPS, 4>(sink0, lines, pitch2, tv, cp, th_, vshift, lane); hevc_mc_vpass<TAPS, 4>(sink1, lines1, pitch2, tv, cp, th_, vshift, lane); }
         else { hevc_mc_vpass<TAPS, 2>(sink0, lines, pitch2, tv, cp, th_, vshift, lane); hevc_mc_vpass<TAPS, 2>(sink1, lines1, pitch2, tv, cp, th_, vshift, lane); }
     }
-    __syncthreads();
+    MI355_HEVC_SYNC();
 }
 template <int TAPS>
 __device__ inline void hevc_mc_taps(int16_t *dst, int ds, const uint8_t *src, int ss, int width, int height,
@@ -534,7 +546,7 @@ __device__ inline void hevc_mc_wave(int16_t *dst, int ds, const uint8_t *src, in
 {
     if (taps == 8) hevc_mc_taps<8>(dst, ds, src, ss, width, height, mx, my, bd, s);
     else hevc_mc_taps<4>(dst, ds, src, ss, width, height, mx, my, bd, s);
-    __syncthreads();
+    MI355_HEVC_SYNC();
 }
 
 /* ---- a15: 14-bit intermediate -> samples (:1091-1242); mode 0 plain, 1 average, 2 weighted,
@@ -693,7 +705,7 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
     if (w0 > 0 && (w0 & 1) == 0 && (!j.edge || plain_edge)) {
         if (!j.edge) { if (lane < 32) { const int k = (lane - j.band_position) & 31; tbl[lane] = k < 4 ? j.offset_val[k + 1] : 0; } }
         else if (lane < 5) tbl[lane] = j.offset_val[lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4)))];   /* edge_idx[] = {1,2,0,3,4} */
-        __syncthreads();
+        MI355_HEVC_SYNC();
         const int eo = j.eo_class, hw = w0 >> 1, winv = mi355_inv20(hw), shift = bd - 5;
         const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
         const ptrdiff_t da = dx0 + (ptrdiff_t)dy0 * st;
@@ -714,7 +726,7 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
             }
             sao_st2(dst, (ptrdiff_t)(y0 + y) * dt + x0 + x, clip_px(v0, bd), clip_px(v1, bd), bd);
         }
-        __syncthreads();
+        MI355_HEVC_SYNC();
         return;
     }
     if (!j.edge) {
@@ -810,7 +822,7 @@ __device__ inline void hevc_pred_wave(HevcPredScratch &s, uint8_t *dst, int st, 
     for (int k = lane; k <= (angle < 0 ? size : 2 * size); k += 64) ref[k] = main_e[k - 1];
     if (angle < 0 && last < -1)
         for (int k = last + lane; k <= -1; k += 64) ref[k] = side_e[-1 + ((k * k_inv_angle[mode - 11] + 128) >> 8)];
-    __syncthreads();
+    MI355_HEVC_SYNC();
     const bool edge_fix = c_idx == 0 && size < 32 && (mode == 26 || mode == 10);
     for (int i = lane; i < size * size; i += 64) {
         const int a = i >> log2, b = i & (size - 1);         /* a: along the minor axis */
@@ -825,5 +837,5 @@ __device__ inline void hevc_pred_wave(HevcPredScratch &s, uint8_t *dst, int st, 
     }
 }
 
-}  // namespace mi355
+}  // namespace MI355_HEVC_NS
 #endif

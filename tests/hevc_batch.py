@@ -649,6 +649,235 @@ def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
     return n
 
 
+
+class CtbJob(C.Structure):
+    _fields_ = [("dst", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("width", C.c_uint16), ("height", C.c_uint16), ("log2_ctb_size", C.c_uint8),
+                ("flags", C.c_uint8), ("reserved", C.c_uint8 * 2), ("first_mc", C.c_uint32), ("n_mc", C.c_uint32), ("first_tu", C.c_uint32),
+                ("n_tu", C.c_uint32), ("reserved1", C.c_uint32)]
+
+
+assert C.sizeof(CtbJob) == 64
+
+
+def decoder_block(r, size):
+    """coefficients of a size x size block as the DECODER leaves them (hevcdec.c:1062-1256): a last significant position of the diagonal scan,
+    coefficients only in the 4x4 groups the scan reaches before that one's (and inside it up to the position's own diagonal); col_limit from it"""
+    lx, ly = r.randint(0, size - 1), r.randint(0, size - 1)
+    if r.randint(0, 2) == 0:                               # low-frequency blocks are the common case
+        lx, ly = lx % 8, ly % 8
+    if lx == 0 and ly == 0:
+        lx = 1
+    c = r.laplace_int(300, size * size, 32767).astype(np.int16)
+    m = c.reshape(size, size)
+    ys, xs = np.mgrid[0:size, 0:size]
+    gl = (lx >> 2) + (ly >> 2)
+    keep = ((xs >> 2) + (ys >> 2) < gl) | (((xs >> 2) == (lx >> 2)) & ((ys >> 2) == (ly >> 2)) & ((xs & 3) + (ys & 3) <= (lx & 3) + (ly & 3)))
+    m[~keep] = 0
+    m[ly, lx] = m[ly, lx] or 1
+    mx = max(lx, ly)
+    lim = lx + ly + 4
+    lim = min(4, lim) if mx < 4 else (min(8, lim) if mx < 8 else (min(24, lim) if mx < 12 else lim))
+    return c, lim
+
+
+def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3)):
+    """mi355_hevc_recon_ctbs_dev — a coding tree block's prediction blocks and transform units in one workgroup — against the oracle's tables
+    called block by block in the reference's order (hls_prediction_unit, then hls_transform_unit: hevcdec.c:1695-1885, :1238-1260): random
+    partitions (squares 64..8, halves, quarter splits), every prediction kind with one or two references, chroma blocks alone and as pairs,
+    transform trees 32..4 with every unit kind; some blocks leave samples uncovered (MI355_HEVC_CTB_PARTIAL)."""
+    r = SplitMix64(seed)
+    px = 2 if bd > 8 else 1
+    cy, cx = cells
+    H, W = cy * 64, cx * 64
+    pic = [pixels(r, (H, W), bd), pixels(r, (H // 2, W // 2), bd), pixels(r, (H // 2, W // 2), bd)]
+    # reference 0: rows a multiple of the matrix path's piece size; reference 1: not (those blocks take the general path)
+    ry = [pixels(r, (H + 80, W + 80), bd), pixels(r, (H + 80, W + 84), bd)]
+    rc = [[pixels(r, (H // 2 + 48, W // 2 + 48), bd) for _ in range(2)], [pixels(r, (H // 2 + 48, W // 2 + 44), bd) for _ in range(2)]]
+
+    def split_pu(x, y, sz, out):
+        if sz > 8 and r.randint(0, 99) < (100 if sz == 64 and r.randint(0, 3) else 45):
+            for k in range(4):
+                split_pu(x + (k & 1) * sz // 2, y + (k >> 1) * sz // 2, sz // 2, out)
+            return
+        m = r.randint(0, 7)
+        if m == 0:
+            out += [(x, y, sz, sz // 2), (x, y + sz // 2, sz, sz // 2)]
+        elif m == 1:
+            out += [(x, y, sz // 2, sz), (x + sz // 2, y, sz // 2, sz)]
+        elif m == 2 and sz >= 16:
+            out += [(x, y, sz, sz // 4), (x, y + sz // 4, sz, 3 * sz // 4)]
+        elif m == 3 and sz >= 16:
+            out += [(x, y, 3 * sz // 4, sz), (x + 3 * sz // 4, y, sz // 4, sz)]
+        else:
+            out.append((x, y, sz, sz))
+
+    def split_tu(x, y, sz, out, mn):
+        if sz > 32 or (sz > mn and r.randint(0, 99) < 40):
+            for k in range(4):
+                split_tu(x + (k & 1) * sz // 2, y + (k >> 1) * sz // 2, sz // 2, out, mn)
+        elif r.randint(0, 3):
+            out.append((x, y, sz))
+
+    c_o = oracle.hevcdsp(bd)
+    pic_o = [a.copy() for a in pic]
+    mcbuf = np.zeros((64 + 24) * 64, np.int16)
+    t0, t1 = np.zeros(64 * 64, np.int16), np.zeros(64 * 64, np.int16)
+    mc_meta, tu_meta, ctbs, coefs = [], [], [], []
+    for cyi in range(cy):
+        for cxi in range(cx):
+            X, Y = cxi * 64, cyi * 64
+            pus, first_mc, first_tu = [], len(mc_meta), len(tu_meta)
+            uniform = r.randint(0, 2) == 0                   # a block of the measured shape: four 32x32 blocks of one reference, 32x32 units
+            if uniform:
+                pus = [(X + 32 * (k & 1), Y + 32 * (k >> 1), 32, 32) for k in range(4)]
+            else:
+                split_pu(X, Y, 64, pus)
+            partial = (not uniform) and r.randint(0, 2) == 0
+            if partial:
+                pus = [q for q in pus if r.randint(0, 3)]
+            for (x, y, w, h) in pus:
+                kind = 0 if (uniform or r.randint(0, 1)) else r.randint(1, 3)
+                refs = (0, 1) if (uniform or r.randint(0, 2)) else (1, 0)
+                mv = [(r.randint(-96, 96), r.randint(-96, 96)) for _ in range(2)]          # quarter samples
+                if r.randint(0, 3) == 0:
+                    mv[0] = (mv[0][0] & ~3, mv[0][1])
+                if r.randint(0, 3) == 0:
+                    mv[0] = (mv[0][0], mv[0][1] & ~3)
+                wts = (r.randint(0, 7), r.randint(-128, 127), r.randint(-128, 127), r.randint(-128, 127), r.randint(-128, 127))
+                pair = kind < 2 and r.randint(0, 2) != 0
+                for comp in ((0,), (1, 2)):
+                    for c_idx in comp:
+                        ch = c_idx != 0
+                        bw, bh, bx, by = (w >> ch, h >> ch, x >> ch, y >> ch)
+                        wi = (EW if ch else QW).index(bw)
+                        tab = c_o.put_hevc_epel if ch else c_o.put_hevc_qpel
+                        srcs = []
+                        for t, ref, (mvx, mvy) in ((t0, refs[0], mv[0]), (t1, refs[1], mv[1])):
+                            plane = rc[ref][c_idx - 1] if ch else ry[ref]
+                            sx, sy = bx + (24 if ch else 40) + (mvx >> (3 if ch else 2)), by + (24 if ch else 40) + (mvy >> (3 if ch else 2))
+                            fx, fy = (mvx & 7, mvy & 7) if ch else (mvx & 3, mvy & 3)
+                            tab[int(fy != 0)][int(fx != 0)][wi](_i16p(t), 128, _u8p(plane, sy * plane.strides[0] + sx * px), plane.strides[0], bh, fx, fy, _i16p(mcbuf))
+                            srcs.append((ref, sx, sy, fx, fy))
+                        dp = _u8p(pic_o[c_idx], by * pic_o[c_idx].strides[0] + bx * px)
+                        st = pic_o[c_idx].strides[0]
+                        tabs = ((c_o.put_unweighted_pred_chroma, c_o.put_unweighted_pred_avg_chroma, c_o.weighted_pred_chroma, c_o.weighted_pred_avg_chroma)
+                                if ch else (c_o.put_unweighted_pred, c_o.put_unweighted_pred_avg, c_o.weighted_pred, c_o.weighted_pred_avg))
+                        fn = tabs[kind][wi]
+                        denom, w0, w1, o0, o1 = wts
+                        if kind == 0:
+                            fn(dp, st, _i16p(t0), 128, bh)
+                        elif kind == 1:
+                            fn(dp, st, _i16p(t0), _i16p(t1), 128, bh)
+                        elif kind == 2:
+                            fn(denom, w0, o0, dp, st, _i16p(t0), 128, bh)
+                        else:
+                            fn(denom, w0, w1, o0, o1, dp, st, _i16p(t0), _i16p(t1), 128, bh)
+                        mc_meta.append((c_idx, bx, by, bw, bh, kind, wts, srcs, pair))
+            tus = []
+            if uniform:
+                tus = [(0, X + 32 * (k & 1), Y + 32 * (k >> 1), 32) for k in range(4)] + [(1, X // 2, Y // 2, 32), (2, X // 2, Y // 2, 32)]
+            else:
+                for c_idx in range(3):
+                    leaves = []
+                    split_tu(X >> (c_idx > 0), Y >> (c_idx > 0), 64 >> (c_idx > 0), leaves, 4)
+                    tus += [(c_idx, x, y, sz) for (x, y, sz) in leaves]
+            for (c_idx, x, y, sz) in tus:
+                log2 = sz.bit_length() - 1
+                kind = 0 if uniform else [0, 0, 0, 0, 1, 2, 3][r.randint(0, 6)]
+                if kind >= 2 and sz != 4:
+                    kind = 0
+                lim = sz
+                if kind == 0:
+                    if sz >= 16 or r.randint(0, 1):
+                        c, lim = decoder_block(r, sz)
+                        if uniform and r.randint(0, 3) == 0:
+                            c, lim = r.laplace_int(300, sz * sz, 32767).astype(np.int16), 32          # a dense block: no pruning
+                    else:
+                        lim = min(sz, [1, 2, 3, 4, 5, 7, 8][r.randint(0, 6)])
+                        c = r.laplace_int(300, sz * sz, 32767).astype(np.int16)
+                        c.reshape(sz, sz)[lim + 4:, :] = 0
+                else:
+                    c = r.laplace_int(300, sz * sz, 32767).astype(np.int16)
+                    if kind == 1:
+                        c[1:] = 0x1111
+                blk = np.zeros(1024, np.int16)
+                blk[:sz * sz] = c
+                coefs.append(blk.copy())
+                i = log2 - 2
+                if kind == 0:
+                    c_o.idct[i](_i16p(blk), lim)
+                elif kind == 1:
+                    c_o.idct_dc[i](_i16p(blk))
+                elif kind == 2:
+                    c_o.transform_4x4_luma(_i16p(blk))
+                else:
+                    c_o.dequant(_i16p(blk))
+                st = pic_o[c_idx].strides[0]
+                c_o.add_residual[i](_u8p(pic_o[c_idx], y * st + x * px), _i16p(blk), st)
+                tu_meta.append((c_idx, x, y, log2, kind, lim))
+            ctbs.append((X, Y, partial, first_mc, first_tu))
+    d = Dev(prov.lib)
+    try:
+        p_pic = [d.up(a) for a in pic]
+        p_ry = [d.up(a) for a in ry]
+        p_rc = [[d.up(a) for a in pl] for pl in rc]
+        p_coef = d.up(np.stack(coefs))
+        mc_jobs, ctb_first_mc = [], {}
+        k = 0
+        while k < len(mc_meta):
+            c_idx, bx, by, bw, bh, kind, wts, srcs, pair = mc_meta[k]
+            ctb_first_mc[k] = len(mc_jobs)
+            plane_p = p_pic[c_idx]
+            st = pic[c_idx].strides[0]
+
+            def src_ptr(c, s):
+                ref, sx, sy = s[0], s[1], s[2]
+                plane = rc[ref][c - 1] if c else ry[ref]
+                return (p_rc[ref][c - 1] if c else p_ry[ref]) + sy * plane.strides[0] + sx * px, plane.strides[0]
+            (s0p, s0s), (s1p, s1s) = src_ptr(c_idx, srcs[0]), src_ptr(c_idx, srcs[1])
+            j = McPredJob(s0p, s1p, plane_p + by * st + bx * px, s0s, s1s, st, bw, bh, 1 if c_idx else 0, kind, srcs[0][3], srcs[0][4], srcs[1][3], srcs[1][4], wts[0])
+            j.w0, j.w1, j.o0, j.o1 = wts[1], wts[2], wts[3], wts[4]
+            if c_idx == 1 and pair:
+                # Cb and Cr of a block as one job: the same vector, strides and (unweighted) parameters
+                srcs2 = mc_meta[k + 1][7]
+                j.chroma = 2
+                j.src0_b, j.src1_b = src_ptr(2, srcs2[0])[0], src_ptr(2, srcs2[1])[0]
+                j.dst_b = p_pic[2] + by * st + bx * px
+                ctb_first_mc[k + 1] = len(mc_jobs) + 1
+                k += 1
+            mc_jobs.append(j)
+            k += 1
+        ctb_first_mc[len(mc_meta)] = len(mc_jobs)
+        tu_jobs = [TuJob(p_coef + i * 2048, p_pic[c_idx] + y * pic[c_idx].strides[0] + x * px, pic[c_idx].strides[0], log2, lim, kind, 0)
+                   for i, (c_idx, x, y, log2, kind, lim) in enumerate(tu_meta)]
+        jobs = []
+        for i, (X, Y, partial, first_mc, first_tu) in enumerate(ctbs):
+            nxt_mc = ctbs[i + 1][3] if i + 1 < len(ctbs) else len(mc_meta)
+            nxt_tu = ctbs[i + 1][4] if i + 1 < len(ctbs) else len(tu_meta)
+            j = CtbJob()
+            for pl in range(3):
+                sh = 1 if pl else 0
+                j.dst[pl] = p_pic[pl] + (Y >> sh) * pic[pl].strides[0] + (X >> sh) * px
+                j.stride[pl] = pic[pl].strides[0]
+            j.width, j.height, j.log2_ctb_size = 64, 64, 6
+            # without the flag the block is not read: every sample must then be covered (a dropped prediction block leaves a hole)
+            j.flags = 1 if partial else 0
+            j.first_mc, j.n_mc = ctb_first_mc[first_mc], ctb_first_mc[nxt_mc] - ctb_first_mc[first_mc]
+            j.first_tu, j.n_tu = first_tu, nxt_tu - first_tu
+            jobs.append(j)
+        lib = prov.lib
+        lib.mi355_hevc_recon_ctbs_dev.restype = C.c_int
+        lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        assert lib.mi355_hevc_recon_ctbs_dev(d.up_jobs(jobs), len(jobs), d.up_jobs(mc_jobs), d.up_jobs(tu_jobs), bd, None) == 0
+        got = [d.down(p_pic[pl], pic[pl]) for pl in range(3)]
+    finally:
+        d.free()
+    for pl in range(3):
+        bad = np.argwhere(got[pl] != pic_o[pl])
+        assert bad.size == 0, "recon_ctbs: plane %d differs at %d samples, first (y, x) = %s (bd %d)" % (pl, len(bad), bad[0], bd)
+    return len(mc_jobs) + len(tu_jobs)
+
+
 class _LevelLib:
     """the library with its prediction / transform-unit batches routed through mi355_hevc_recon_level_dev (one launch for a dependency level's
     job kinds: here one kind at a time, the other two empty)"""
@@ -683,4 +912,4 @@ def check_level_residual(prov, oracle, bd, seed):
 
 CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
           "intra": check_intra, "mcpred": check_mcpred, "sao_ctbs": check_sao_ctbs, "edge_emu": check_edge_emu,
-          "level_mcpred": check_level_mcpred, "level_residual": check_level_residual}
+          "level_mcpred": check_level_mcpred, "level_residual": check_level_residual, "recon_ctbs": check_recon_ctbs}

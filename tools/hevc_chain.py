@@ -32,16 +32,20 @@ PIECE_DT = np.dtype([("offset_val", "<i4", 5), ("cls", "u1"), ("type", "u1"), ("
 SAOC_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("c_idx", "u1"), ("npieces", "u1"), ("rsv", "u1", 2), ("piece", PIECE_DT, 4)])
 EE_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("dst_stride", "<i4"), ("src_stride", "<i4"), ("block_w", "<i4"), ("block_h", "<i4"),
                   ("src_x", "<i4"), ("src_y", "<i4"), ("w", "<i4"), ("h", "<i4")])
+CTB_DT = np.dtype([("dst", "<u8", 3), ("stride", "<i4", 3), ("width", "<u2"), ("height", "<u2"), ("log2_ctb_size", "u1"), ("flags", "u1"), ("rsv", "u1", 2),
+                   ("first_mc", "<u4"), ("n_mc", "<u4"), ("first_tu", "<u4"), ("n_tu", "<u4"), ("rsv1", "<u4")])
+assert CTB_DT.itemsize == 64
 assert TU_DT.itemsize == 24 and MP_DT.itemsize == 80 and SAO_DT.itemsize == 72 and PIECE_DT.itemsize == 36 and SAOC_DT.itemsize == 168 and EE_DT.itemsize == 48
 BYTES_PER_CTB = 73984
 
 
 class Chain:
-    def __init__(self, lib, pictures, distinct=2, seed=0x265, width=W, height=H, bd=BD):
+    def __init__(self, lib, pictures, distinct=2, seed=0x265, width=W, height=H, bd=BD, fused=True):
         """width, height: multiples of 64 x 16 at least (the bench: 3840 x 2160); the parity tests run smaller pictures.  self.host keeps
         what the CPU side (oracle/ref_hevc_chain.c: the reference's own functions) needs to decode the same pictures."""
         W, H, BD, PX = width, height, bd, (2 if bd > 8 else 1)
         self.W, self.H, self.BD, self.PX = W, H, BD, PX
+        self.fused = fused
         self.lib, self.P = lib, pictures
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -127,6 +131,7 @@ class Chain:
         pairs = mp[:, :, 1].copy()
         pairs["chroma"] = 2
         pairs["src0_b"], pairs["dst_b"] = mp["src0"][:, :, 2], mp["dst"][:, :, 2]
+        mp_luma = mp[:, :, 0].copy()
         mp = np.concatenate([mp[:, :, 0].reshape(-1), pairs.reshape(-1)])
         self.n_mp, self.d_mp = mp.size, self.up(mp)
         # ---- transform units: 32x32, all coded; 75 % carry non-zeros in the top-left 8x8 only (col_limit 12)
@@ -153,6 +158,8 @@ class Chain:
             tu["dst_stride"][:, sl] = cs
         tu["log2_size"] = 5
         tu["col_limit"] = np.where(sparse, 12, 32)
+        if fused:
+            self.fused_lists(mp_luma, pairs, tu, bx, by, n32, n64)
         tu = tu.reshape(-1)
         tu = tu[np.argsort(tu["col_limit"], kind="stable")]                # the bridge bins its list by pruning class
         self.n_tu, self.d_tu = tu.size, self.up(tu)
@@ -225,6 +232,50 @@ class Chain:
         self.ctbs = P * (W // 64) * (H // 64)
         lib.mi355_hevc_deblock_pictures_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 
+    def fused_lists(self, mp_luma, pairs, tu, bx, by, n32, n64):
+        """the same prediction jobs and transform units listed per coding tree block for mi355_hevc_recon_ctbs_dev: a block's luma prediction
+        blocks, its chroma pairs; its luma transform units, its Cb and Cr units"""
+        W, H, PX, P = self.W, self.H, self.PX, self.P
+        ncx, ncy = W // 64, (H + 63) // 64
+        ctb32 = ((by // 2) * ncx + (bx // 2)).reshape(-1)
+        order = np.argsort(ctb32, kind="stable")
+        cnt = np.bincount(ctb32, minlength=ncx * ncy)
+        start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        c_sorted = ctb32[order]
+        rank = np.arange(n32) - start[c_sorted]
+        comb = np.zeros((P, 2 * n32), MP_DT)
+        comb[:, 2 * start[c_sorted] + rank] = mp_luma[:, order]
+        comb[:, 2 * start[c_sorted] + cnt[c_sorted] + rank] = pairs[:, order]
+        has_c = (np.arange(ncx * ncy) // ncx) < (H // 64)              # the block has its two chroma units
+        ntu = cnt + 2 * has_c
+        tstart = np.concatenate([[0], np.cumsum(ntu)[:-1]])
+        per_pic = n32 + 2 * n64
+        tus = np.zeros((P, per_pic), TU_DT)
+        tus[:, tstart[c_sorted] + rank] = tu[:, :n32][:, order]
+        cc = np.flatnonzero(has_c)                                       # = the raster index of the 64x64 chroma units
+        assert len(cc) == n64
+        tus[:, tstart[cc] + cnt[cc]] = tu[:, n32:n32 + n64]
+        tus[:, tstart[cc] + cnt[cc] + 1] = tu[:, n32 + n64:]
+        live = np.flatnonzero(cnt > 0)
+        ctb = np.zeros((P, len(live)), CTB_DT)
+        cy, cx = live // ncx, live % ncx
+        pic = np.arange(P, dtype=np.uint64)[:, None]
+        ctb["dst"][:, :, 0] = self.rec_y + pic * self.ysz + (cy * 64 * self.ls + cx * 64 * PX).astype(np.uint64)[None]
+        for pl in range(2):
+            ctb["dst"][:, :, 1 + pl] = self.rec_c + (pic * 2 + pl) * self.csz + (cy * 32 * self.cs + cx * 32 * PX).astype(np.uint64)[None]
+        ctb["stride"][:, :, 0], ctb["stride"][:, :, 1], ctb["stride"][:, :, 2] = self.ls, self.cs, self.cs
+        ctb["width"], ctb["height"] = 64, np.minimum(64, H - 64 * cy)[None]
+        ctb["log2_ctb_size"] = 6
+        ctb["flags"] = np.where(cnt[live] < 4, 1, 0)[None]             # MI355_HEVC_CTB_PARTIAL: rows of the block that no prediction block covers
+        ctb["first_mc"] = (np.arange(P) * 2 * n32)[:, None] + 2 * start[live][None]
+        ctb["n_mc"] = 2 * cnt[live][None]
+        ctb["first_tu"] = (np.arange(P) * per_pic)[:, None] + tstart[live][None]
+        ctb["n_tu"] = ntu[live][None]
+        self.n_ctb, self.d_ctb = ctb.size, self.up(ctb)
+        self.d_mp_ctb, self.d_tu_ctb = self.up(comb), self.up(tus)
+        self.lib.mi355_hevc_recon_ctbs_dev.restype = C.c_int
+        self.lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+
     def alloc(self, n):
         p = self.lib.mi355_malloc(int(n) + 64)
         assert p, "device allocation of %d bytes failed" % n
@@ -257,13 +308,17 @@ class Chain:
         def around(stage, launch):
             if stage == turn_stage and wait_ev is not None:
                 assert L.mi355_stream_wait_event(stream, wait_ev) == 0
-            launch()
+            assert launch() == 0
             if stage == turn_stage and record_ev is not None:
                 L.mi355_event_record(record_ev, stream)
         if self.n_ee:
             assert L.mi355_edge_emu_batch_dev(C.c_void_p(self.d_ee), self.n_ee, self.BD, stream) == 0
-        around(1, lambda: L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, stream))
-        around(2, lambda: L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, stream))
+        if self.fused:
+            # prediction + residual of a coding tree block in one workgroup: the block's samples leave for the picture once
+            around(1, lambda: L.mi355_hevc_recon_ctbs_dev(C.c_void_p(self.d_ctb), self.n_ctb, C.c_void_p(self.d_mp_ctb), C.c_void_p(self.d_tu_ctb), self.BD, stream))
+        else:
+            around(1, lambda: L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, stream))
+            around(2, lambda: L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, stream))
         around(3, lambda: L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, stream))
         around(4, lambda: L.mi355_hevc_sao_ctbs_dev(C.c_void_p(self.d_sao), self.n_sao, self.BD, stream))
 
@@ -391,14 +446,14 @@ def surfaces(ch, fill=0):
     return [np.full((ch.H, ch.W), fill, dt), np.full((2, ch.H // 2, ch.W // 2), fill, dt)]
 
 
-def check_against_reference(lib, pictures=2, width=256, height=192, bd=10, seed=0x265):
+def check_against_reference(lib, pictures=2, width=256, height=192, bd=10, seed=0x265, fused=True):
     """the measured chain at any size: device pictures (reconstruction after deblocking, SAO output) of every picture against the
     reference's own functions on the same parameters.  Surfaces start zeroed on both sides (the chain leaves the rows below the
     last whole 32 / 64 block unpredicted, as the workload is defined)."""
     ref = ref_library()
     assert ref is not None, "oracle/_ref/libhevcfilterref.so (with ref_hevc_chain.c) is missing"
     lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-    ch = Chain(lib, pictures, distinct=min(2, pictures), seed=seed, width=width, height=height, bd=bd)
+    ch = Chain(lib, pictures, distinct=min(2, pictures), seed=seed, width=width, height=height, bd=bd, fused=fused)
     try:
         zero = np.zeros(pictures * ch.ysz, np.uint8)
         for base, n in ((ch.rec_y, ch.ysz), (ch.out_y, ch.ysz), (ch.rec_c, 2 * ch.csz), (ch.out_c, 2 * ch.csz)):
