@@ -17,6 +17,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include "mi355dsp.h"      /* the device error word */
 
 #ifdef __cplusplus
 extern "C" {
@@ -328,8 +329,14 @@ typedef struct mi355_hevc_ctb_job {
     uint32_t first_tu, n_tu;
     uint32_t reserved1;
 } mi355_hevc_ctb_job;
+/* Two launches: the matrix-path kernel takes the blocks ALL of whose jobs are of its shapes (eight waves per block, 4.6 KB of scratch per wave), the general
+ * kernel follows on the same list and takes exactly the others (every body of the batch kernels compiled in: four waves, larger scratch, more registers).  A
+ * caller that KNOWS its list holds only matrix-path shapes (it made the jobs) passes MI355_HEVC_RECON_UNIFORM and saves the second launch (a launch of
+ * workgroups that look at their block's records and leave: ~40 us per 130 k blocks); the promise is checked on the device — a block that breaks it is left
+ * untouched and MI355_ERR_CTB_NOT_UNIFORM is set in the device's error word (include/mi355dsp.h: mi355_sync returns MI355_E_DEVICE_FAULT). */
+enum { MI355_HEVC_RECON_UNIFORM = 1 };
 int mi355_hevc_recon_ctbs_dev(const mi355_hevc_ctb_job *d_ctbs, int n_ctbs, const mi355_hevc_mcpred_job *d_mc, const mi355_hevc_tu_job *d_tus,
-                              int bit_depth, void *stream);
+                              int bit_depth, unsigned flags, void *stream);
 
 #ifdef __cplusplus
 }

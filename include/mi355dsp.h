@@ -42,6 +42,18 @@ int mi355_get_thread_device(void);     /* the thread's OWN setting: -1 while it 
                                           devices temporarily must put back with mi355_set_device) */
 int mi355_device_count(void);
 
+/* The device's ERROR WORD.  A kernel that cannot do what it was launched for — a bounded wait on another workgroup that ran out
+ * (MI355_ERR_WAIT_EXPIRED: the picture it was working on is NOT valid), a coding tree block outside the shapes its caller promised
+ * (MI355_ERR_CTB_NOT_UNIFORM: the block was left untouched) — ORs its bit into one word per device, in pinned host memory.  mi355_sync(),
+ * mi355_event_sync() and mi355_h264_pipelines_sync() read it after their wait and return MI355_E_DEVICE_FAULT (-5) when it is set;
+ * mi355_error_word_take() returns the bits and clears them (what a caller does before it repeats the batch another way). */
+enum { MI355_ERR_WAIT_EXPIRED = 1, MI355_ERR_CTB_NOT_UNIFORM = 2, MI355_ERR_TEST = 0x40000000 };
+enum { MI355_E_DEVICE_FAULT = -5 };
+unsigned mi355_error_word_take(void);      /* bits set since the last take (this thread's device); 0: none */
+unsigned mi355_error_word_peek(void);
+/* test hook: a one-thread kernel on `stream` that ORs `bits` into the word the way a failing kernel does */
+int mi355_error_word_inject(unsigned bits, void *stream);
+
 /* replaces ff_h264dsp_init_{x86,arm,...}   libavcodec/h264dsp.h:119-128, call site h264dsp.c:139-142 */
 void ff_h264dsp_init_mi355x(H264DSPContext *c, const int bit_depth, const int chroma_format_idc);
 /* replaces ff_h264qpel_init_{x86,...}      libavcodec/h264qpel.h:34-37, call site h264qpel.c:102-109 */

@@ -636,8 +636,9 @@ extern "C" int mi355_h264_surface_convert_dev(const mi355_surface_job *jobs, int
     hipLaunchKernelGGL(k_surface_convert, dim3((unsigned)((nmb + 7) / 8), (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
-extern "C" int mi355_event_sync(void *event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? 0 : -1; }
-extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : -1; }
+/* the waits also report the device's error word (include/mi355dsp.h): a kernel that gave up says so there, and the wait that follows returns it */
+extern "C" int mi355_event_sync(void *event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? mi355::fault_after_wait() : -1; }
+extern "C" int mi355_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? mi355::fault_after_wait() : -1; }
 
 extern "C" void *mi355_stream_create(void)
 {

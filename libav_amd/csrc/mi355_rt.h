@@ -146,6 +146,11 @@ Win win_pack(Arena &a, const uint8_t *src, ptrdiff_t stride, int wbytes, int row
 void win_unpack(Arena &a, const Win &w, uint8_t *dst, ptrdiff_t stride, int x0, int y0, int wbytes, int rows);
 
 bool ready();
+/* the calling thread's device's error word (include/mi355dsp.h): a device-visible pointer into pinned host memory, nullptr without a device.
+ * fault_after_wait(): what a sync entry point returns once its wait is over: 0, or MI355_E_DEVICE_FAULT while bits are set (they stay set until
+ * mi355_error_word_take()) */
+uint32_t *error_word();
+int fault_after_wait();
 bool blocking_sync();      /* waits sleep instead of spinning (MI355_BLOCKING_SYNC / mi355_prefer_blocking_sync) */
 int current_device();
 /* bind the calling thread to its device — mi355_set_device() of this thread, else the one chosen in mi355_init() (the reference calls the tables and the batch entry points

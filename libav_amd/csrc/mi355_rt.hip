@@ -37,6 +37,30 @@ static int check_device(int device)
     return 0;
 }
 
+/* one word per device in pinned, device-visible host memory: a kernel's atomicOr reaches it over the fabric (rare by construction), the host
+ * reads it with a plain load after a wait */
+static std::atomic<uint32_t *> g_error_words[32];
+uint32_t *error_word()
+{
+    const int d = current_device();
+    if (d < 0 || d >= 32 || !bind()) return nullptr;
+    uint32_t *w = g_error_words[d].load(std::memory_order_acquire);
+    if (w) return w;
+    uint32_t *fresh = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&fresh), 64) != hipSuccess) return nullptr;
+    *fresh = 0u;
+    uint32_t *expected = nullptr;
+    if (!g_error_words[d].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) { (void)hipHostFree(fresh); return expected; }
+    return fresh;
+}
+int fault_after_wait()
+{
+    const int d = current_device();
+    if (d < 0 || d >= 32) return 0;
+    const uint32_t *w = g_error_words[d].load(std::memory_order_acquire);
+    return w && __atomic_load_n(w, __ATOMIC_ACQUIRE) ? MI355_E_DEVICE_FAULT : 0;
+}
+
 bool bind()
 {
     static thread_local int bound = -1;
@@ -169,6 +193,31 @@ extern "C" int mi355_device_count(void)
 {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+extern "C" unsigned mi355_error_word_peek(void)
+{
+    const int d = mi355::current_device();
+    if (d < 0 || d >= 32) return 0u;
+    const uint32_t *w = mi355::g_error_words[d].load(std::memory_order_acquire);
+    return w ? __atomic_load_n(w, __ATOMIC_ACQUIRE) : 0u;
+}
+extern "C" unsigned mi355_error_word_take(void)
+{
+    const int d = mi355::current_device();
+    if (d < 0 || d >= 32) return 0u;
+    uint32_t *w = mi355::g_error_words[d].load(std::memory_order_acquire);
+    return w ? __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL) : 0u;
+}
+namespace {
+__global__ void k_error_word_inject(uint32_t *word, uint32_t bits) { atomicOr(word, bits); }
+}
+extern "C" int mi355_error_word_inject(unsigned bits, void *stream)
+{
+    uint32_t *w = mi355::error_word();
+    if (!w) return -1;
+    hipLaunchKernelGGL(k_error_word_inject, dim3(1), dim3(1), 0, (hipStream_t)stream, w, (uint32_t)bits);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int mi355_device_cus(void)

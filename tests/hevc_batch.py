@@ -680,7 +680,7 @@ def decoder_block(r, size):
     return c, lim
 
 
-def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3)):
+def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3), promise_check=True):
     """mi355_hevc_recon_ctbs_dev — a coding tree block's prediction blocks and transform units in one workgroup — against the oracle's tables
     called block by block in the reference's order (hls_prediction_unit, then hls_transform_unit: hevcdec.c:1695-1885, :1238-1260): random
     partitions (squares 64..8, halves, quarter splits), every prediction kind with one or two references, chroma blocks alone and as pairs,
@@ -722,7 +722,7 @@ def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3)):
     pic_o = [a.copy() for a in pic]
     mcbuf = np.zeros((64 + 24) * 64, np.int16)
     t0, t1 = np.zeros(64 * 64, np.int16), np.zeros(64 * 64, np.int16)
-    mc_meta, tu_meta, ctbs, coefs = [], [], [], []
+    mc_meta, tu_meta, ctbs, coefs, uniform_ctbs = [], [], [], [], []
     for cyi in range(cy):
         for cxi in range(cx):
             X, Y = cxi * 64, cyi * 64
@@ -816,6 +816,10 @@ def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3)):
                 c_o.add_residual[i](_u8p(pic_o[c_idx], y * st + x * px), _i16p(blk), st)
                 tu_meta.append((c_idx, x, y, log2, kind, lim))
             ctbs.append((X, Y, partial, first_mc, first_tu))
+            # does the matrix path take every job of this block (include/mi355_hevc_batch.h)?  one reference whose rows are a multiple of the piece size,
+            # sides multiples of 16 in the plane's samples, 16x16 / 32x32 inverse DCTs
+            uniform_ctbs.append(all(m[5] == 0 and m[3] % 16 == 0 and m[4] % 16 == 0 and m[7][0][0] == 0 for m in mc_meta[first_mc:]) and
+                                all(t[4] == 0 and t[3] >= 4 for t in tu_meta[first_tu:]))
     d = Dev(prov.lib)
     try:
         p_pic = [d.up(a) for a in pic]
@@ -867,8 +871,27 @@ def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3)):
             jobs.append(j)
         lib = prov.lib
         lib.mi355_hevc_recon_ctbs_dev.restype = C.c_int
-        lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        assert lib.mi355_hevc_recon_ctbs_dev(d.up_jobs(jobs), len(jobs), d.up_jobs(mc_jobs), d.up_jobs(tu_jobs), bd, None) == 0
+        lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
+        lib.mi355_error_word_take.restype = C.c_uint
+        p_jobs, p_mc, p_tu = d.up_jobs(jobs), d.up_jobs(mc_jobs), d.up_jobs(tu_jobs)
+        if promise_check:
+            # the caller's promise (MI355_HEVC_RECON_UNIFORM) on a list that breaks it: the blocks of other shapes are left as they were and the device says so
+            lib.mi355_error_word_take()
+            assert lib.mi355_hevc_recon_ctbs_dev(p_jobs, len(jobs), p_mc, p_tu, bd, 1, None) == 0
+            assert lib.mi355_sync(None) == -5, "a block outside the promised shapes must be reported (MI355_E_DEVICE_FAULT)"
+            assert lib.mi355_error_word_take() == 2 and lib.mi355_sync(None) == 0
+            got = [d.down(p_pic[pl], pic[pl]) for pl in range(3)]
+            n_uniform = 0
+            for (X, Y, partial, first_mc, first_tu), is_u in zip(ctbs, uniform_ctbs):
+                for pl in range(3):
+                    sh = 1 if pl else 0
+                    sl = (slice(Y >> sh, (Y + 64) >> sh), slice(X >> sh, (X + 64) >> sh))
+                    want = pic_o[pl][sl] if is_u else pic[pl][sl]
+                    assert np.array_equal(got[pl][sl], want), "promise check: block (%d, %d) plane %d" % (X, Y, pl)
+                n_uniform += is_u
+            assert 0 < n_uniform < len(ctbs)
+        assert lib.mi355_hevc_recon_ctbs_dev(p_jobs, len(jobs), p_mc, p_tu, bd, 0, None) == 0
+        assert lib.mi355_sync(None) == 0
         got = [d.down(p_pic[pl], pic[pl]) for pl in range(3)]
     finally:
         d.free()

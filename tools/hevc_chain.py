@@ -46,6 +46,7 @@ class Chain:
         W, H, BD, PX = width, height, bd, (2 if bd > 8 else 1)
         self.W, self.H, self.BD, self.PX = W, H, BD, PX
         self.fused = fused
+        self.recon_flags = 0 if os.environ.get("MI355_CHAIN_NO_PROMISE") else 1      # MI355_HEVC_RECON_UNIFORM: this generator makes 32x32 one-reference blocks and 32x32 units only
         self.lib, self.P = lib, pictures
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -274,7 +275,7 @@ class Chain:
         self.n_ctb, self.d_ctb = ctb.size, self.up(ctb)
         self.d_mp_ctb, self.d_tu_ctb = self.up(comb), self.up(tus)
         self.lib.mi355_hevc_recon_ctbs_dev.restype = C.c_int
-        self.lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
 
     def alloc(self, n):
         p = self.lib.mi355_malloc(int(n) + 64)
@@ -315,7 +316,7 @@ class Chain:
             assert L.mi355_edge_emu_batch_dev(C.c_void_p(self.d_ee), self.n_ee, self.BD, stream) == 0
         if self.fused:
             # prediction + residual of a coding tree block in one workgroup: the block's samples leave for the picture once
-            around(1, lambda: L.mi355_hevc_recon_ctbs_dev(C.c_void_p(self.d_ctb), self.n_ctb, C.c_void_p(self.d_mp_ctb), C.c_void_p(self.d_tu_ctb), self.BD, stream))
+            around(1, lambda: L.mi355_hevc_recon_ctbs_dev(C.c_void_p(self.d_ctb), self.n_ctb, C.c_void_p(self.d_mp_ctb), C.c_void_p(self.d_tu_ctb), self.BD, self.recon_flags, stream))
         else:
             around(1, lambda: L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, stream))
             around(2, lambda: L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, stream))
@@ -332,7 +333,7 @@ def measure_pipelines(lib, pictures=64, pipelines=2, steps=6, turn_stage=-1):
     """the same 64 pictures as `pipelines` chains of pictures / pipelines each on their own streams (developer experiment: profiles/r05_experiments.md 13)"""
     import time
     lib.mi355_stream_create.restype = C.c_void_p
-    chains = [Chain(lib, pictures // pipelines, seed=0x265 + i) for i in range(pipelines)]
+    chains = [Chain(lib, pictures // pipelines, seed=0x265 + i, fused=not os.environ.get("MI355_CHAIN_SPLIT")) for i in range(pipelines)]
     streams = [C.c_void_p(lib.mi355_stream_create()) for _ in range(pipelines)]
     try:
         lib.mi355_stream_wait_event.restype = C.c_int
@@ -366,7 +367,7 @@ def measure_pipelines(lib, pictures=64, pipelines=2, steps=6, turn_stage=-1):
 def measure(lib, pictures=64, steps=3, cpu_seconds=6.0):
     lib.mi355_event_create.restype = C.c_void_p
     lib.mi355_event_elapsed_ms.restype = C.c_float
-    ch = Chain(lib, pictures)
+    ch = Chain(lib, pictures, fused=not os.environ.get("MI355_CHAIN_SPLIT"))      # MI355_CHAIN_SPLIT=1: prediction and residual as two launches (rounds 3-5)
     try:
         ch.run()
         lib.mi355_sync(None)

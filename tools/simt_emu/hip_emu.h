@@ -72,6 +72,7 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  /* wave-uniform by contract */
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
