@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64) k_hevc_sao_batch(const mi355_hevc_sao_job 
  * write every sample of their region) or, where the owning CTB has SAO off, copied — every sample of the output picture is
  * written exactly once, by the job whose pieces partition its neighbourhood */
 typedef uint32_t mi355_sao_u32x4a4 __attribute__((vector_size(16), aligned(4)));
-__device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src, int stride, int x0, int y0, int w, int h, int px)
+__device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src, int stride, int x0, int y0, int w, int h, int px, int tid, int nthreads)
 {
     if (w <= 0 || h <= 0) return;
     const int nbytes = w * px;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src
     if ((((uintptr_t)dst | (uintptr_t)src | (uintptr_t)stride | (uintptr_t)(x0 * px) | (uintptr_t)nbytes) & 3) == 0) {
         /* rows in 16-byte pieces (dword-aligned vector accesses) and a tail of dwords */
         const int nv = nbytes >> 4, nt = (nbytes & 15) >> 2, per = nv + nt, inv = mi355_inv20(per);
-        for (int i = lane_id(); i < per * h; i += 64) {
+        for (int i = tid; i < per * h; i += nthreads) {
             const int y = mi355_div20(i, inv), k = i - y * per;
             const ptrdiff_t o = o0 + (ptrdiff_t)y * stride;
             if (k < nv) *reinterpret_cast<mi355_sao_u32x4a4 *>(dst + o + 16 * k) = *reinterpret_cast<const mi355_sao_u32x4a4 *>(src + o + 16 * k);
@@ -383,7 +383,7 @@ __device__ __forceinline__ void sao_copy_region(uint8_t *dst, const uint8_t *src
         }
         return;
     }
-    for (int i = lane_id(); i < nbytes * h; i += 64) {          /* (the reciprocal division is exact below 2^19 only) */
+    for (int i = tid; i < nbytes * h; i += nthreads) {          /* (the reciprocal division is exact below 2^19 only) */
         const int y = i / nbytes, k = i - y * nbytes;
         dst[o0 + (ptrdiff_t)y * stride + k] = src[o0 + (ptrdiff_t)y * stride + k];
     }
@@ -421,95 +421,211 @@ __device__ __forceinline__ void sao_ld8(const uint8_t *p, bool wide, int v[8])
         for (int k = 0; k < 8; k++) v[k] = (int)((q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
     }
 }
-/* The whole region of an owner CTB in one pass when its pieces differ in nothing that matters: the band filter always (it
- * knows no borders), the edge filter when no piece touches a picture border or an unfilterable slice / tile edge (every
- * sample then has both neighbours and none is restored) — same arithmetic as hevc_sao_wave's fast forms (sao_band_filter,
- * sao_edge_filter: hevcdsp_template.c:270-718), eight samples per lane, rows written in whole aligned pieces. */
-__device__ inline void sao_region_fast(uint8_t *dst, const uint8_t *src, int stride, int W, int H, bool edge, int eo, int band_position,
-                                       const int32_t *offset_val, int bd, int *tbl)
+/* ---- two 16-bit samples per register for SAO (v_pk_*_u16 / _i16; plain meaning in the emulator) ---- */
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t sao_pk_sign(uint32_t c, uint32_t a)       /* per half: sign(c - a) as an int16 */
 {
-    const int lane = lane_id();
-    if (!edge) { if (lane < 32) { const int k = (lane - band_position) & 31; tbl[lane] = k < 4 ? offset_val[k + 1] : 0; } }
-    else if (lane < 5) tbl[lane] = offset_val[lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4)))];   /* edge_idx[] = {1,2,0,3,4} */
-    __syncthreads();
-    const bool wide = bd > 8;
+    const int l = (int)(c & 0xFFFF) - (int)(a & 0xFFFF), h = (int)(c >> 16) - (int)(a >> 16);
+    return pk_make(l < 0 ? -1 : (l > 0 ? 1 : 0), h < 0 ? -1 : (h > 0 ? 1 : 0));
+}
+static inline uint32_t sao_pk_subs_u(uint32_t a, uint32_t b)     /* unsigned, saturating at 0 */
+{
+    const int l = (int)(a & 0xFFFF) - (int)(b & 0xFFFF), h = (int)(a >> 16) - (int)(b >> 16);
+    return (uint32_t)(l < 0 ? 0 : l) | ((uint32_t)(h < 0 ? 0 : h) << 16);
+}
+static inline uint32_t sao_pk_min_u(uint32_t a, uint32_t b)
+{
+    const uint32_t al = a & 0xFFFF, bl = b & 0xFFFF, ah = a >> 16, bh = b >> 16;
+    return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+}
+static inline uint32_t sao_pk_shr_u(uint32_t a, int n) { return ((a & 0xFFFF) >> n) | (((a >> 16) >> n) << 16); }
+#else
+typedef unsigned short mi355_v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sao_pk_sign(uint32_t c, uint32_t a)
+{
+    return pk_u(__builtin_elementwise_min(__builtin_elementwise_max(pk_v(c) - pk_v(a), (mi355_v2s)((short)-1)), (mi355_v2s)((short)1)));
+}
+__device__ __forceinline__ uint32_t sao_pk_subs_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(mi355_v2us, a), __builtin_bit_cast(mi355_v2us, b)));
+}
+__device__ __forceinline__ uint32_t sao_pk_min_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mi355_v2us, a), __builtin_bit_cast(mi355_v2us, b)));
+}
+__device__ __forceinline__ uint32_t sao_pk_shr_u(uint32_t a, int n)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(mi355_v2us, a) >> (mi355_v2us)((unsigned short)n));
+}
+#endif
+
+/* eight samples as four registers of 16-bit pairs (8-bit samples widened) and back */
+__device__ __forceinline__ void sao_pairs(const SaoRaw &r, bool wide, uint32_t v[4])
+{
+    if (wide) { v[0] = r.q[0]; v[1] = r.q[1]; v[2] = r.q[2]; v[3] = r.q[3]; }
+    else { v[0] = mi355_widen_lo(r.q[0]); v[1] = mi355_widen_hi(r.q[0]); v[2] = mi355_widen_lo(r.q[1]); v[3] = mi355_widen_hi(r.q[1]); }
+}
+/* the eight samples one position to the left / right of `v`'s (the outermost one: unspecified) */
+__device__ __forceinline__ void sao_shift_left(uint32_t v[4])
+{
+    v[3] = mi355_alignbyte(v[3], v[2], 2); v[2] = mi355_alignbyte(v[2], v[1], 2); v[1] = mi355_alignbyte(v[1], v[0], 2); v[0] = v[0] << 16;
+}
+__device__ __forceinline__ void sao_shift_right(uint32_t v[4])
+{
+    v[0] = mi355_alignbyte(v[1], v[0], 2); v[1] = mi355_alignbyte(v[2], v[1], 2); v[2] = mi355_alignbyte(v[3], v[2], 2); v[3] = v[3] >> 16;
+}
+
+/* The whole region of an owner CTB in one pass when its pieces differ in nothing that matters: the band filter always (it knows no borders), the
+ * edge filter when no piece touches an unfilterable slice / tile edge (nothing is restored) — sao_band_filter / sao_edge_filter
+ * (hevcdsp_template.c:270-718) on packed pairs: eight samples per thread and step (a whole 16-byte / 8-byte piece of a row), the loads of a thread's steps
+ * issued together, the offsets looked up with v_perm_b32 in a table of bytes held in two registers (offset + 128: |offset| < 128), rows written in whole
+ * aligned pieces.  BORDERS: the region touches a picture border (`bo`: bit 0 left, 1 top, 2 right, 3 bottom).  A sample whose neighbour lies outside the
+ * picture gets offset_val[0] (the reference's init_x / init_y / width-- / height-- columns and rows, :388-430), and no load leaves the
+ * rows and columns the picture has: a neighbour piece that would start left of column 0 / end right of the last column is fetched in place and shifted
+ * in registers, a neighbour row above row 0 / below the last row is the row itself (its samples are kept anyway). */
+template <bool WIDE, bool EDGE, bool BORDERS>
+__device__ __forceinline__ void sao_region_fast(uint8_t *dst, const uint8_t *src, int stride, int W, int H, int eo, int band_position,
+                                                const int32_t *offset_val, int bd, int bo, int tid, int nthreads)
+{
+    constexpr int BIAS = 128;
+    constexpr bool wide = WIDE, edge = EDGE;     /* compile-time: a load under a run-time choice of its width is a branch, the load and a wait for it */
     const int px = wide ? 2 : 1, per = W >> 3, inv = mi355_inv20(per), shift = bd - 5;
     const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
-    const ptrdiff_t da = (ptrdiff_t)dx0 * px + (ptrdiff_t)dy0 * stride;
-    /* two steps of a lane at a time: the loads of both (centre and, for the edge filter, its two neighbours) are issued before
-     * the first result is stored — source and destination may be one picture as far as the compiler knows, so a store
-     * ends the loads it will move ahead of it, and a 64x64 region was eight memory round trips one after the other */
-#ifndef MI355_SAO_U
-#define MI355_SAO_U 2
-#endif
-    constexpr int U = MI355_SAO_U;
-    const int n = per * H;
-    for (int i0 = lane; i0 < n; i0 += 64 * U) {
-        SaoRaw rc[U], ra[U], rb[U];
-        ptrdiff_t o[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + 64 * u < n ? i0 + 64 * u : n - 1;       /* a step past the end repeats the last one and stores nothing */
-            const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
-            o[u] = (ptrdiff_t)y * stride + (ptrdiff_t)x * px;
-            rc[u] = sao_raw(src + o[u], wide);
-            if (edge) { ra[u] = sao_raw(src + o[u] + da, wide); rb[u] = sao_raw(src + o[u] - da, wide); }
-        }
-        MI355_ISSUE_FENCE();
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (i0 + 64 * u >= n) continue;
-            int c[8], v[8];
-            sao_unpack(rc[u], wide, c);
-            if (!edge) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[c[k] >> shift], bd);
-            } else {
-                int a[8], b[8];
-                sao_unpack(ra[u], wide, a);
-                sao_unpack(rb[u], wide, b);
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = clip_px(c[k] + tbl[clip3(c[k] - a[k], -1, 1) + clip3(c[k] - b[k], -1, 1) + 2], bd);
-            }
-            if (wide) {
-                *reinterpret_cast<mi355_sao_u32x4a2 *>(dst + o[u]) = mi355_sao_u32x4a2{ (uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
-                                                                                      (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16) };
-            } else {
-                *reinterpret_cast<mi355_sao_u32x2a1 *>(dst + o[u]) = mi355_sao_u32x2a1{ (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24),
-                                                                                      (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24) };
-            }
-        }
+    /* the offsets as bytes at the places the selectors name.  edge: selector = (sign(c - a) + sign(c - b)) & 7 -> 0: 0, 1: 1, 2: 2, 7: -1, 6: -2;
+     * edge_idx[] = { 1, 2, 0, 3, 4 } (:310).  band: selector = min((c >> shift) - band_position & 31, 4) -> offsets 1..4, 4: none */
+    uint32_t t_lo, t_hi;
+    if (edge) {
+        t_lo = (uint32_t)(offset_val[0] + BIAS) | ((uint32_t)(offset_val[3] + BIAS) << 8) | ((uint32_t)(offset_val[4] + BIAS) << 16) | ((uint32_t)BIAS << 24);
+        t_hi = (uint32_t)BIAS | ((uint32_t)BIAS << 8) | ((uint32_t)(offset_val[1] + BIAS) << 16) | ((uint32_t)(offset_val[2] + BIAS) << 24);
+    } else {
+        t_lo = (uint32_t)(offset_val[1] + BIAS) | ((uint32_t)(offset_val[2] + BIAS) << 8) | ((uint32_t)(offset_val[3] + BIAS) << 16) | ((uint32_t)(offset_val[4] + BIAS) << 24);
+        t_hi = (uint32_t)BIAS * 0x01010101u;
     }
-    __syncthreads();
+    const uint32_t bias2 = (uint32_t)BIAS * 0x00010001u, max2 = (uint32_t)((1 << bd) - 1) * 0x00010001u, bp2 = (uint32_t)band_position * 0x00010001u;
+    /* A step = the eight samples of one piece.  The loads of the next two steps are in flight while a step is worked on and stored (source and
+     * destination may be one picture as far as the compiler knows: written in this order, no load waits behind a store): a wave keeps 2-3 KB of
+     * requests open all the time instead of waiting out a memory round trip per step — what a wave moves per microsecond it occupies its slot is what
+     * bounds this kernel (32 waves per CU x bytes in flight per wave / latency). */
+    struct Step { SaoRaw c, a, b; ptrdiff_t o; int fix; };    /* BORDERS: fix bit 0 sample 0 has no neighbour, 1 sample 7, 2 the row; 3 / 4: neighbour a / b fetched in place, to be shifted */
+    const int n = per * H;
+    auto fetch = [&](int i_) {
+        Step s;
+        const int i = i_ < n ? i_ : n - 1;       /* a step past the end repeats the last one and is never worked on */
+        const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
+        s.o = (ptrdiff_t)y * stride + (ptrdiff_t)x * px;
+        s.c = sao_raw(src + s.o, wide);
+        s.fix = 0;
+        s.a = s.c; s.b = s.c;
+        if (edge) {
+            if (BORDERS) {
+                const bool xl = (bo & 1) && x == 0, xr = (bo & 4) && x + 8 == W, yt = (bo & 2) && y == 0, yb = (bo & 8) && y == H - 1;
+                const bool keep_row = dy0 && (yt || yb);
+                const bool fa = dx0 < 0 ? xl : (dx0 > 0 ? xr : false), fb = dx0 < 0 ? xr : (dx0 > 0 ? xl : false);      /* a lies at dx0, b at -dx0 */
+                s.fix = (dx0 && xl ? 1 : 0) | (dx0 && xr ? 2 : 0) | (keep_row ? 4 : 0) | (fa ? 8 : 0) | (fb ? 16 : 0);
+                const ptrdiff_t rowa = dy0 && !yt ? -(ptrdiff_t)stride : 0, rowb = dy0 && !yb ? (ptrdiff_t)stride : 0;
+                s.a = sao_raw(src + s.o + rowa + (fa ? 0 : dx0 * px), wide);
+                s.b = sao_raw(src + s.o + rowb - (fb ? 0 : dx0 * px), wide);
+            } else {
+                const ptrdiff_t da = (ptrdiff_t)dx0 * px + (ptrdiff_t)dy0 * stride;
+                s.a = sao_raw(src + s.o + da, wide); s.b = sao_raw(src + s.o - da, wide);
+            }
+        }
+        return s;
+    };
+    auto work = [&](const Step &s) {
+        uint32_t c[4], sel[4], v[4];
+        sao_pairs(s.c, wide, c);
+        if (!edge) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel[k] = sao_pk_min_u(pk_sub(sao_pk_shr_u(c[k], shift), bp2) & 0x001F001Fu, 0x00040004u);
+        } else {
+            uint32_t a[4], b[4];
+            sao_pairs(s.a, wide, a);
+            sao_pairs(s.b, wide, b);
+            if (BORDERS) {
+                if (s.fix & 8) { if (dx0 < 0) sao_shift_left(a); else sao_shift_right(a); }
+                if (s.fix & 16) { if (dx0 < 0) sao_shift_right(b); else sao_shift_left(b); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel[k] = pk_add(sao_pk_sign(c[k], a[k]), sao_pk_sign(c[k], b[k]));
+            if (BORDERS) {
+                /* a sample without one of its neighbours: selector 0 = offset_val[0], as the reference's border columns and rows (:388-430) */
+                const uint32_t row = (s.fix & 4) ? 0xFFFFFFFFu : 0u;
+                sel[0] &= ~(row | ((s.fix & 1) ? 0x0000FFFFu : 0u));
+                sel[1] &= ~row;
+                sel[2] &= ~row;
+                sel[3] &= ~(row | ((s.fix & 2) ? 0xFFFF0000u : 0u));
+            }
+        }
+        /* the low bytes of four selectors -> four offset bytes -> two pairs */
+        const uint32_t s01 = byte_perm(sel[1], sel[0], 0x06040200u) & 0x07070707u, s23 = byte_perm(sel[3], sel[2], 0x06040200u) & 0x07070707u;
+        const uint32_t f01 = byte_perm(t_hi, t_lo, s01), f23 = byte_perm(t_hi, t_lo, s23);
+        const uint32_t off[4] = { mi355_widen_lo(f01), mi355_widen_hi(f01), mi355_widen_lo(f23), mi355_widen_hi(f23) };
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = sao_pk_min_u(sao_pk_subs_u(pk_add(c[k], off[k]), bias2), max2);       /* clip(c + offset) */
+        if (wide) *reinterpret_cast<mi355_sao_u32x4a2 *>(dst + s.o) = mi355_sao_u32x4a2{ v[0], v[1], v[2], v[3] };
+        else *reinterpret_cast<mi355_sao_u32x2a1 *>(dst + s.o) = mi355_sao_u32x2a1{ byte_perm(v[1], v[0], 0x06040200u), byte_perm(v[3], v[2], 0x06040200u) };
+    };
+    if (tid >= n) return;
+    /* three sets of registers taking turns (a set handed on by copying would have to wait for its loads first) */
+    Step s0 = fetch(tid), s1 = fetch(tid + nthreads), s2;
+    for (int i = tid;;) {
+        s2 = fetch(i + 2 * nthreads); MI355_ISSUE_FENCE(); work(s0); if ((i += nthreads) >= n) break;
+        s0 = fetch(i + 2 * nthreads); MI355_ISSUE_FENCE(); work(s1); if ((i += nthreads) >= n) break;
+        s1 = fetch(i + 2 * nthreads); MI355_ISSUE_FENCE(); work(s2); if ((i += nthreads) >= n) break;
+    }
 }
-__global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
+constexpr int SAO_CTB_THREADS = 64;
+/* The job record (168 bytes = 42 dwords) is fetched ONCE, a dword per lane, and its fields are read out of that register as scalars (v_readlane): the
+ * record is not known to be read-only to the compiler (the kernel stores through other pointers), so field-by-field reads are vector loads, each waited
+ * for before the branch that depends on it — 20-40 dependent memory round trips per wave before the first sample was requested, which is what this kernel's
+ * time consisted of (profiles/r06_experiments.md). */
+static_assert(sizeof(mi355_hevc_sao_ctb_job) == 168 && sizeof(mi355_hevc_sao_piece) == 36 && offsetof(mi355_hevc_sao_ctb_job, piece) == 24, "k_hevc_sao_ctbs reads the record by dword index");
+template <bool WIDE>
+__global__ void __launch_bounds__(SAO_CTB_THREADS) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
     const mi355_hevc_sao_ctb_job &j = jobs[blockIdx.x];
-    const int chroma = uniform(j.c_idx) != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, px = bd > 8 ? 2 : 1;
-    const int stride = uniform(j.stride);
-    uint8_t *dst0 = mi355_global(j.dst);
-    const uint8_t *src0 = mi355_global(j.src);
+    const int tid = (int)threadIdx.x;
+    const int rec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(&j))[tid < 42 ? tid : 41];
+#define SAO_REC(dw) ((uint32_t)lane_value(rec, (dw)))
+    uint8_t *dst0 = mi355_global(reinterpret_cast<uint8_t *>((uintptr_t)SAO_REC(0) | ((uintptr_t)SAO_REC(1) << 32)));
+    const uint8_t *src0 = mi355_global(reinterpret_cast<const uint8_t *>((uintptr_t)SAO_REC(2) | ((uintptr_t)SAO_REC(3) << 32)));
+    const int stride = (int)SAO_REC(4), chroma = (SAO_REC(5) & 0xFF) != 0, np = (int)((SAO_REC(5) >> 8) & 0xFF);
+    const int cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, px = bd > 8 ? 2 : 1;
     __shared__ int tbl[32];
-    const int st = stride / px, np = uniform(j.npieces);
+    const int st = stride / px;
+    /* piece k: dwords 6 + 9 k ..: offset_val[5]; cls | type << 8 | eo_class << 16 | band_position << 24; vert | horiz << 8 | diag << 16 | borders << 24;
+     * dx | dy << 16; width | height << 16 */
+    const uint32_t p0a = SAO_REC(6 + 5), p0b = SAO_REC(6 + 6), p0c = SAO_REC(6 + 7), p0d = SAO_REC(6 + 8);
     /* piece 0 is the owner's own call (class 0): its size is the region's, its parameters are every piece's */
-    if (np >= 1 && uniform(j.piece[0].cls) == 0 && uniform(j.piece[0].dx) == 0 && uniform(j.piece[0].dy) == 0) {
-        const mi355_hevc_sao_piece &q0 = j.piece[0];
-        const int type = uniform(q0.type), W = uniform(q0.width), H = uniform(q0.height);
-        bool plain = true, same = true;
-        for (int k = 0; k < np && k < 4; k++) {
-            const mi355_hevc_sao_piece &q = j.piece[k];
-            plain = plain && !(uniform(q.borders) | uniform(q.vert_edge) | uniform(q.horiz_edge) | uniform(q.diag_edge));
-            same = same && uniform(q.type) == type;
-        }
-        if (same && type == 0) { sao_copy_region(dst0, src0, stride, 0, 0, W, H, px); return; }
-        if (same && (W & 7) == 0 && (type == 1 || (type == 2 && plain))) {
-            int32_t ov[5];
-            for (int e = 0; e < 5; e++) ov[e] = uniform(q0.offset_val[e]);
-            sao_region_fast(dst0, src0, stride, W, H, type == 2, uniform(q0.eo_class), uniform(q0.band_position), ov, bd, tbl);
+    if (np >= 1 && (p0a & 0xFF) == 0 && p0c == 0) {
+        const int type = (int)((p0a >> 8) & 0xFF), W = (int)(int16_t)(p0d & 0xFFFF), H = (int)(int16_t)(p0d >> 16);
+        /* every piece of the owner's type, none with a restored edge */
+        uint32_t flags = p0b & 0x00FFFFFFu, types = 0;
+        if (np > 1) { flags |= SAO_REC(15 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(15 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        if (np > 2) { flags |= SAO_REC(24 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(24 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        if (np > 3) { flags |= SAO_REC(33 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(33 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        const bool unrestored = flags == 0, same = types == 0;
+        if (same && type == 0) { sao_copy_region(dst0, src0, stride, 0, 0, W, H, px, tid, SAO_CTB_THREADS); return; }
+        const int32_t ov[5] = { (int32_t)SAO_REC(6), (int32_t)SAO_REC(7), (int32_t)SAO_REC(8), (int32_t)SAO_REC(9), (int32_t)SAO_REC(10) };
+        bool small = true;
+        for (int e = 0; e < 5; e++) small = small && ov[e] > -128 && ov[e] < 128;
+        if (same && small && (W & 7) == 0 && (type == 1 || (type == 2 && unrestored))) {
+            /* which picture borders the REGION touches: the owner's own left / top; right / bottom when no other CTB's call covers a strip of it */
+            const int bo = type == 2 ? (int)(p0b >> 24) : 0, eo = (int)((p0a >> 16) & 0xFF), bp = (int)(p0a >> 24);
+            if (type == 1) sao_region_fast<WIDE, false, false>(dst0, src0, stride, W, H, eo, bp, ov, bd, 0, tid, SAO_CTB_THREADS);
+            else if (bo) sao_region_fast<WIDE, true, true>(dst0, src0, stride, W, H, eo, bp, ov, bd, bo, tid, SAO_CTB_THREADS);
+            else sao_region_fast<WIDE, true, false>(dst0, src0, stride, W, H, eo, bp, ov, bd, 0, tid, SAO_CTB_THREADS);
             return;
         }
     }
+#undef SAO_REC
+#ifdef MI355_EXP_SAO_NOSLOW
+    return;
+#endif
+    /* piece by piece, as the reference makes its calls: the first wave alone (hevc_sao_wave is a wave's function) */
+    if (tid >= 64) return;
     for (int k = 0; k < np && k < 4; k++) {
         const mi355_hevc_sao_piece &q = j.piece[k];
         const int cls = uniform(q.cls), type = uniform(q.type), W = uniform(q.width), H = uniform(q.height), bo = uniform(q.borders);
@@ -520,7 +636,7 @@ __global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_j
             /* the region hevc_sao_wave would take for this class */
             const int x0 = (cls & 2) ? -cw : 0, y0 = (cls & 1) ? -ch : 0;
             const int w = (cls & 2) ? cw : ((bo & 4) ? W : W - cw), h = (cls & 1) ? ch : ((bo & 8) ? H : H - ch);
-            sao_copy_region(dst, src, stride, x0, y0, w, h, px);
+            sao_copy_region(dst, src, stride, x0, y0, w, h, px, tid, 64);
             continue;
         }
         SaoJob p;
@@ -530,7 +646,7 @@ __global__ void __launch_bounds__(64) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_j
         p.eo_class = uniform(q.eo_class); p.band_position = uniform(q.band_position);
         for (int e = 0; e < 5; e++) p.offset_val[e] = uniform(q.offset_val[e]);
         hevc_sao_wave(dst, st, src, st, p, tbl);
-        __syncthreads();
+        MI355_WAVE_SYNC();
     }
 }
 
@@ -886,7 +1002,8 @@ extern "C" int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *
 extern "C" int mi355_hevc_sao_ctbs_dev(const mi355_hevc_sao_ctb_job *d_jobs, int n, int bit_depth, void *stream)
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
-    hipLaunchKernelGGL(k_hevc_sao_ctbs, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    if (bit_depth > 8) hipLaunchKernelGGL(k_hevc_sao_ctbs<true>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    else hipLaunchKernelGGL(k_hevc_sao_ctbs<false>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_edge_emu_batch_dev(const mi355_edge_emu_job *d_jobs, int n, int bit_depth, void *stream)

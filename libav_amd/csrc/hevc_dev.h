@@ -690,6 +690,11 @@ __device__ __forceinline__ void sao_st2(uint8_t *p, ptrdiff_t o, int v0, int v1,
     else { const uint16_t v = (uint16_t)(v0 | (v1 << 8)); __builtin_memcpy(p + o, &v, 2); }
 }
 /* src/dst point at the caller's (0,0) sample; `dt`/`st` = samples per row of dst/src; `tbl`: 32 ints of LDS */
+/* offset_val[i] without an indexed read (an array indexed at run time would live in scratch memory) */
+__device__ __forceinline__ int sao_offset(const SaoJob &j, int i)
+{
+    return i == 0 ? j.offset_val[0] : (i == 1 ? j.offset_val[1] : (i == 2 ? j.offset_val[2] : (i == 3 ? j.offset_val[3] : j.offset_val[4])));
+}
 __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, int st, const SaoJob &j, int *tbl)
 {
     const int chroma = j.c_idx != 0, cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, bd = j.bd, cls = j.cls;
@@ -703,9 +708,9 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
      * restored) — the bulk of a picture. */
     const bool plain_edge = !(j.borders[0] | j.borders[1] | j.borders[2] | j.borders[3] | j.vert_edge | j.horiz_edge | j.diag_edge);
     if (w0 > 0 && (w0 & 1) == 0 && (!j.edge || plain_edge)) {
-        if (!j.edge) { if (lane < 32) { const int k = (lane - j.band_position) & 31; tbl[lane] = k < 4 ? j.offset_val[k + 1] : 0; } }
-        else if (lane < 5) tbl[lane] = j.offset_val[lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4)))];   /* edge_idx[] = {1,2,0,3,4} */
-        MI355_HEVC_SYNC();
+        if (!j.edge) { if (lane < 32) { const int k = (lane - j.band_position) & 31; tbl[lane] = k < 4 ? sao_offset(j, k + 1) : 0; } }
+        else if (lane < 5) tbl[lane] = sao_offset(j, lane == 2 ? 0 : (lane == 0 ? 1 : (lane == 1 ? 2 : (lane == 3 ? 3 : 4))));   /* edge_idx[] = {1,2,0,3,4} */
+        MI355_WAVE_SYNC();      /* a wave's function: the table is this wave's */
         const int eo = j.eo_class, hw = w0 >> 1, winv = mi355_inv20(hw), shift = bd - 5;
         const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
         const ptrdiff_t da = dx0 + (ptrdiff_t)dy0 * st;
@@ -726,7 +731,7 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
             }
             sao_st2(dst, (ptrdiff_t)(y0 + y) * dt + x0 + x, clip_px(v0, bd), clip_px(v1, bd), bd);
         }
-        MI355_HEVC_SYNC();
+        MI355_WAVE_SYNC();      /* a wave's function: the table is this wave's */
         return;
     }
     if (!j.edge) {
@@ -734,7 +739,7 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
         for (int i = lane_id(); i < w * h; i += 64) {
             const int y = mi355_div20(i, winv), x = i - y * w, o = (y0 + y) * st + x0 + x;
             const int v = ldpx(src, o, bd), k = ((v >> shift) - j.band_position) & 31;
-            stpx(dst, (y0 + y) * dt + x0 + x, clip_px(v + (k < 4 ? j.offset_val[k + 1] : 0), bd), bd);
+            stpx(dst, (y0 + y) * dt + x0 + x, clip_px(v + (k < 4 ? sao_offset(j, k + 1) : 0), bd), bd);
         }
         return;
     }
@@ -765,7 +770,7 @@ __device__ inline void hevc_sao_wave(uint8_t *dst, int dt, const uint8_t *src, i
             const int a = ldpx(src, o + dx0 + dy0 * st, bd), b = ldpx(src, o + dx1 + dy1 * st, bd);
             const int d = (c > a) - (c < a) + (c > b) - (c < b);          /* -2..2 */
             const int idx = d == 0 ? 0 : (d == -2 ? 1 : (d == -1 ? 2 : (d == 1 ? 3 : 4)));
-            v = clip_px(c + j.offset_val[idx], bd);
+            v = clip_px(c + sao_offset(j, idx), bd);
         } else {
             v = clip_px(c + j.offset_val[0], bd);   /* picture-border column / row */
         }
