@@ -31,6 +31,21 @@ namespace {
 #define MI355_CTB_WAVES 8
 #endif
 constexpr int CTB_WAVES_FAST = MI355_CTB_WAVES, CTB_WAVES_GENERAL = 4;
+/* Workgroups that stay and take turns (blocks blockIdx.x, + gridDim.x, ...) with the next block's records on their way while one is worked on: built and
+ * measured in round 6 (profiles/r06_experiments.md) — 2.35 ms against 2.08 ms for a workgroup per block: with the records fetched a dword per lane the waves no
+ * longer wait for records but for each other and for the vector unit, and the turn loop costs registers (88 against 71: two workgroups per CU instead of three
+ * unless values go to scratch memory).  Kept behind this switch. */
+#ifndef MI355_CTB_PERSIST
+#define MI355_CTB_PERSIST 0
+#endif
+constexpr bool CTB_PERSIST = MI355_CTB_PERSIST != 0;
+#ifndef MI355_CTB_WAVES_ATTR
+#if MI355_CTB_PERSIST
+#define MI355_CTB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define MI355_CTB_WAVES_ATTR
+#endif
+#endif
 /* the block's samples in LDS: rows 16 bytes longer than a full row, so that the rows a matrix product's sixteen lanes write (8 bytes each, one row per
  * lane) spread over the banks two by two instead of all sixteen meeting in two banks; still 16-byte aligned for the way out */
 constexpr int CTB_PITCH_Y = 64 * 2 + 16, CTB_PITCH_C = 32 * 2 + 16;
@@ -44,16 +59,16 @@ union __attribute__((aligned(16))) CtbScratch {
     CfWin win;
 };
 
-/* a / b for a < 2^22, b > 0 (an offset inside a block over its picture's stride), both wave-uniform */
+/* a / b for wave-uniform a, b with a quotient below 64 (a row inside a block): six compare steps on the scalar unit (a reciprocal would run on the vector unit) */
 __device__ __forceinline__ int ctb_div(unsigned a, unsigned b)
 {
 #ifdef MI355_HIP_EMU_H
     return (int)(a / b);
 #else
-    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
-    if ((unsigned)q * b > a) q--;
-    if ((unsigned)(q + 1) * b <= a) q++;
-    return q;
+    unsigned q = 0;
+#pragma unroll
+    for (unsigned bit = 32; bit; bit >>= 1) if ((q + bit) * b <= a) q += bit;
+    return (int)q;
 #endif
 }
 
@@ -135,6 +150,9 @@ __device__ __forceinline__ bool ctb_predict(CtbTile &tile, Scratch &s, const Ctb
     const int pitch = pl ? CTB_PITCH_C : CTB_PITCH_Y, px = G.px;
     uint8_t *t0 = tile_at(tile, pl, x, y, px), *t1 = j.chroma == 2 ? tile_at(tile, plb, xb, yb, px) : nullptr;
     if (mc_is_fast<WIDE>(j)) {
+#ifdef MI355_EXP_CTB_NOMC
+        return true;
+#endif
         const int before = j.chroma ? 1 : 3, bx = j.mx0 ? before : 0, by = j.my0 ? before : 0;
         CfPass ph, pv;
         if (j.chroma) {
@@ -182,6 +200,9 @@ __device__ __forceinline__ bool ctb_residual(CtbTile &tile, Scratch &s, const Ct
     const int pitch = pl ? CTB_PITCH_C : CTB_PITCH_Y;
     uint8_t *tp = tile_at(tile, pl, x, y, G.px);
     if (tu_is_fast(j)) {
+#ifdef MI355_EXP_CTB_NOTU
+        return true;
+#endif
         const uint8_t *c = reinterpret_cast<const uint8_t *>(mi355_global(j.coeffs));
         if (j.log2_size == 5) { if (!pre) cf_idct_load<5>(raw, c, j.col_limit, lane); cf_idct_run<5, WIDE>(raw, j.col_limit, bd, tp, pitch, lane); }
         else { if (!pre) cf_idct_load<4>(raw, c, j.col_limit, lane); cf_idct_run<4, WIDE>(raw, j.col_limit, bd, tp, pitch, lane); }
@@ -199,70 +220,198 @@ __device__ __forceinline__ bool ctb_residual(CtbTile &tile, Scratch &s, const Ct
 
 struct FastScratch { CfWin win; };
 
+/* Job records are fetched a dword per lane and read out of that register as scalars (v_readlane).  The compiler cannot know the records are read-only (the kernel
+ * stores through other pointers), so reading a record field by field is a vector load per field, each waited for before the branch that depends on it: 20-odd
+ * dependent memory round trips per wave before its first sample was requested — two thirds of this kernel's time (profiles/r06_experiments.md).  Now three: the
+ * block's record, the wave's first prediction job and first transform unit together, then samples and coefficients. */
+static_assert(sizeof(mi355_hevc_ctb_job) == 64 && sizeof(mi355_hevc_mcpred_job) == 80 && sizeof(mi355_hevc_tu_job) == 24, "k_hevc_recon_ctbs reads its records by dword index");
+template <int BASE> __device__ __forceinline__ mi355_hevc_mcpred_job ctb_mc_record(int rec)
+{
+    uint32_t w[20];
+#pragma unroll
+    for (int k = 0; k < 20; k++) w[k] = (uint32_t)lane_value(rec, BASE + k);
+    mi355_hevc_mcpred_job j;
+    __builtin_memcpy(&j, w, sizeof(j));
+    return j;
+}
+template <int BASE> __device__ __forceinline__ mi355_hevc_tu_job ctb_tu_record(int rec)
+{
+    uint32_t w[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) w[k] = (uint32_t)lane_value(rec, BASE + k);
+    mi355_hevc_tu_job j;
+    __builtin_memcpy(&j, w, sizeof(j));
+    return j;
+}
+/* lanes 0..19: the prediction job at `mc` (when have_mc), lanes 32..37: the transform unit at `tu` (when have_tu); `safe`: any readable address */
+__device__ __forceinline__ int ctb_fetch_records(const mi355_hevc_mcpred_job *mc, bool have_mc, const mi355_hevc_tu_job *tu, bool have_tu, const void *safe, int lane)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(safe);
+    if (lane < 32) { if (have_mc) p = reinterpret_cast<const uint32_t *>(mc) + (lane < 20 ? lane : 19); }
+    else if (have_tu) p = reinterpret_cast<const uint32_t *>(tu) + (lane < 38 ? lane - 32 : 5);
+    return (int)*mi355_global_v(p);
+}
+
+/* a block's record as scalars */
+struct CtbHead {
+    CtbGeom G;
+    int flags, n_mc, n_tu;
+    const mi355_hevc_mcpred_job *mc;
+    const mi355_hevc_tu_job *tu;
+};
+template <bool WIDE>
+__device__ __forceinline__ CtbHead ctb_head(int crec, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tus)
+{
+    CtbHead H;
+    H.G.d0 = reinterpret_cast<uint8_t *>((uintptr_t)(uint32_t)lane_value(crec, 0) | ((uintptr_t)(uint32_t)lane_value(crec, 1) << 32));
+    H.G.d1 = reinterpret_cast<uint8_t *>((uintptr_t)(uint32_t)lane_value(crec, 2) | ((uintptr_t)(uint32_t)lane_value(crec, 3) << 32));
+    H.G.d2 = reinterpret_cast<uint8_t *>((uintptr_t)(uint32_t)lane_value(crec, 4) | ((uintptr_t)(uint32_t)lane_value(crec, 5) << 32));
+    H.G.s0 = lane_value(crec, 6); H.G.s1 = lane_value(crec, 7); H.G.s2 = lane_value(crec, 8);
+    H.G.w = lane_value(crec, 9) & 0xFFFF; H.G.h = (int)((uint32_t)lane_value(crec, 9) >> 16); H.G.px = WIDE ? 2 : 1;
+    H.flags = (lane_value(crec, 10) >> 8) & 0xFF;
+    H.mc = mc + lane_value(crec, 11); H.n_mc = lane_value(crec, 12);
+    H.tu = tus + lane_value(crec, 13); H.n_tu = lane_value(crec, 14);
+    return H;
+}
+/* is job `i` of the block (prediction jobs first, then transform units) outside the matrix path?  What the test needs of a record, as fetched: a prediction
+ * job's dwords 6 (src0_stride) and 9 (width, height, chroma, kind), a unit's dwords 0 (coeffs, low half), 2 and 3 (dst) and 5 (log2_size, col_limit, kind) */
+struct CtbProbe { uint32_t a, b, c, d; int what; };      /* what: 0 nothing, 1 prediction job, 2 transform unit */
+__device__ __forceinline__ CtbProbe ctb_probe(const CtbHead &H, int i)
+{
+    CtbProbe q;
+    q.a = q.b = q.c = q.d = 0u; q.what = 0;
+    if (i < H.n_mc) {
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(mi355_global_v(H.mc) + i);
+        q.a = r[6]; q.b = r[9]; q.what = 1;
+    } else if (i < H.n_mc + H.n_tu) {
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(mi355_global_v(H.tu) + (i - H.n_mc));
+        q.a = r[0]; q.b = r[2]; q.c = r[3]; q.d = r[5]; q.what = 2;
+    }
+    return q;
+}
+template <bool WIDE> __device__ __forceinline__ bool ctb_probe_odd(const CtbProbe &q)
+{
+    if (q.what == 1) {
+        mi355_hevc_mcpred_job j;
+        j.src0_stride = (int32_t)q.a; j.width = (uint8_t)q.b; j.height = (uint8_t)(q.b >> 8); j.kind = (uint8_t)(q.b >> 24);
+        return !mc_is_fast<WIDE>(j);
+    }
+    if (q.what == 2) {
+        mi355_hevc_tu_job j;
+        j.coeffs = reinterpret_cast<int16_t *>((uintptr_t)q.a); j.dst = reinterpret_cast<uint8_t *>((uintptr_t)q.b | ((uintptr_t)q.c << 32));
+        j.log2_size = (uint8_t)q.d; j.kind = (uint8_t)(q.d >> 16);
+        return !tu_is_fast(j);
+    }
+    return false;
+}
+
 /* GENERAL = false: the matrix-path kernel — it takes the blocks ALL of whose jobs are of the matrix path's shapes and leaves every other block untouched
- * (a wave that meets such a job says so in LDS; nothing is stored);
+ * (the workgroup's threads look at a job record each before anything else; nothing is stored);
  * GENERAL = true: the kernel with every body compiled in.  `only_rest`: it follows the matrix-path kernel on the same list and takes exactly the blocks that one
- * left (the same test, made by the lanes on the job records before anything else). */
+ * left (the same test).
+ * A workgroup stays and takes blocks blockIdx.x, + gridDim.x, ...: while it works on one block the NEXT block's records are on their way (the block's record is
+ * requested at the top of the turn, the wave's first prediction job and transform unit of it — and a job per thread for the shape test — once that has arrived, after
+ * the predictions), so that a turn begins with the requests for its samples and coefficients instead of with three dependent round trips. */
 template <bool WIDE, bool GENERAL, int NW>
-__global__ void __launch_bounds__(64 * NW) k_hevc_recon_ctbs(const mi355_hevc_ctb_job *ctbs, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tus, int bd,
-                                                             int only_rest, uint32_t *error_word)
+__device__ __forceinline__ void ctb_turns(const mi355_hevc_ctb_job *ctbs, int n_ctbs, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tus, int bd, int only_rest, uint32_t *error_word)
 {
     typedef typename std::conditional<GENERAL, CtbScratch, FastScratch>::type Scratch;
+    constexpr int NT = 64 * NW;
     __shared__ CtbTile tile;
     __shared__ Scratch scratch[NW];
-    __shared__ int s_flag;
+    __shared__ int s_flag[2];
     const int tid = (int)threadIdx.x, wave = uniform(tid >> 6), lane = lane_id();
-    const mi355_hevc_ctb_job &cj = ctbs[blockIdx.x];
-    CtbGeom G;
-    G.d0 = cj.dst[0]; G.d1 = cj.dst[1]; G.d2 = cj.dst[2];
-    G.s0 = uniform(cj.stride[0]); G.s1 = uniform(cj.stride[1]); G.s2 = uniform(cj.stride[2]);
-    G.w = uniform(cj.width); G.h = uniform(cj.height); G.px = WIDE ? 2 : 1;
-    const int n_mc = uniform((int)cj.n_mc), n_tu = uniform((int)cj.n_tu);
-    const mi355_hevc_mcpred_job *my_mc = mc + uniform((int)cj.first_mc);
-    const mi355_hevc_tu_job *my_tu = tus + uniform((int)cj.first_tu);
-    if (tid == 0) s_flag = 0;
-    if (GENERAL && only_rest) {
-        /* is any job of the block outside the matrix path?  (a job record per lane) */
-        __syncthreads();
-        bool odd = false;
-        for (int i = tid; i < n_mc + n_tu; i += 64 * NW)
-            odd = odd || (i < n_mc ? !mc_is_fast<WIDE>(mi355_global_v(my_mc)[i]) : !tu_is_fast(mi355_global_v(my_tu)[i - n_mc]));
-        if (odd) s_flag = 1;
-        __syncthreads();
-        if (!s_flag) return;
-        __syncthreads();
-        if (tid == 0) s_flag = 0;
-    }
-    /* the first transform unit of this wave: its coefficients are requested now and arrive while the wave predicts */
-    CfRaw raw;
-    bool pre = false;
-    if (wave < n_tu) {
-        const mi355_hevc_tu_job &j = my_tu[wave];
-        if (tu_is_fast(j)) {
-            const uint8_t *c = reinterpret_cast<const uint8_t *>(mi355_global(j.coeffs));
-            if (j.log2_size == 5) cf_idct_load<5>(raw, c, j.col_limit, lane); else cf_idct_load<4>(raw, c, j.col_limit, lane);
+    /* which blocks are whose: the general kernel behind the matrix-path one looks at every job of a block first (a job per thread); the matrix-path kernel's
+     * waves look at their own jobs as they come and drop the block before anything is stored */
+    const bool probed = GENERAL && only_rest;
+    if (tid < 2) s_flag[tid] = 0;
+    int c = (int)blockIdx.x;
+    if (c >= n_ctbs) return;
+    CtbHead H = ctb_head<WIDE>((int)mi355_global_v(reinterpret_cast<const uint32_t *>(ctbs + c))[lane & 15], mc, tus);
+    int rec = ctb_fetch_records(H.mc + wave, wave < H.n_mc, H.tu + wave, wave < H.n_tu, ctbs + c, lane);
+    __syncthreads();
+    for (int k = 0;; k++) {
+        const int cn = c + (int)gridDim.x;
+        const bool more = CTB_PERSIST && cn < n_ctbs;
+        /* the lane's number, opaque to the compiler from here on: everything derived from it (tile addresses, operand tables, tap words) is worked out inside
+         * the turn that uses it — taken out of the loop as invariants those values hold 30 registers through every phase (104 in all: four waves per SIMD
+         * instead of the six the LDS allows) */
+        int lane_t = lane, tid_t = tid;
+        if (CTB_PERSIST) { MI355_PIN(lane_t); MI355_PIN(tid_t); }
+        /* the next block's record: needed after the predictions */
+        const int crec_n = CTB_PERSIST ? (int)mi355_global_v(reinterpret_cast<const uint32_t *>(ctbs + (more ? cn : c)))[lane & 15] : 0;
+        bool mine = true;
+        if (GENERAL && probed) {
+            bool odd = false;
+            for (int i = tid; i < H.n_mc + H.n_tu; i += NT) odd = odd || ctb_probe_odd<WIDE>(ctb_probe(H, i));
+            if (odd) s_flag[0] = 1;
+            __syncthreads();
+            mine = s_flag[0] != 0;
+            __syncthreads();
+            if (tid == 0) s_flag[0] = 0;
+        }
+        mi355_hevc_mcpred_job j_mc = ctb_mc_record<0>(rec);
+        mi355_hevc_tu_job j_tu = ctb_tu_record<32>(rec);
+        /* the first transform unit's coefficients are requested now and arrive while the wave predicts */
+        CfRaw raw;
+        bool pre = false;
+        if (mine && wave < H.n_tu && tu_is_fast(j_tu)) {
+            const uint8_t *cf = reinterpret_cast<const uint8_t *>(mi355_global(j_tu.coeffs));
+            if (j_tu.log2_size == 5) cf_idct_load<5>(raw, cf, j_tu.col_limit, lane_t); else cf_idct_load<4>(raw, cf, j_tu.col_limit, lane_t);
             pre = true;
         }
+        if (mine && (H.flags & MI355_HEVC_CTB_PARTIAL)) { tile_all<true>(tile, H.G, tid_t, NT); __syncthreads(); }
+        Scratch &s = scratch[wave];
+        bool ok = true;
+        if (mine) {
+            for (int i = wave; i < H.n_mc; i += NW) {
+                if (i != wave) j_mc = ctb_mc_record<0>(ctb_fetch_records(H.mc + i, true, H.tu, false, ctbs + c, lane));
+                ok = ctb_predict<WIDE, GENERAL>(tile, s, H.G, j_mc, bd, lane_t) && ok;
+            }
+            if (!GENERAL) {
+                /* a unit the matrix path does not take: known before any residual is added */
+                ok = ok && (wave >= H.n_tu || tu_is_fast(j_tu));
+                for (int i = wave + NW; i < H.n_tu; i += NW) ok = ok && tu_is_fast(ctb_tu_record<32>(ctb_fetch_records(H.mc, false, H.tu + i, true, ctbs + c, lane)));
+                if (!ok) s_flag[k & 1] = 1;
+            }
+        }
+        /* the next block: its record has arrived; request the wave's first jobs of it */
+        CtbHead Hn = H;
+        if (CTB_PERSIST) Hn = ctb_head<WIDE>(crec_n, mc, tus);
+        const int rec_n = more ? ctb_fetch_records(Hn.mc + wave, wave < Hn.n_mc, Hn.tu + wave, wave < Hn.n_tu, ctbs + cn, lane) : rec;
+        __syncthreads();
+        if (!GENERAL && s_flag[k & 1]) {
+            /* left to the general kernel; a caller that promised there are no such blocks (MI355_HEVC_RECON_UNIFORM) finds out */
+            mine = false;
+            if (error_word && tid == 0) atomicOr(error_word, (uint32_t)MI355_ERR_CTB_NOT_UNIFORM);
+        }
+        if (mine)
+            for (int i = wave; i < H.n_tu; i += NW) {
+                if (i != wave) j_tu = ctb_tu_record<32>(ctb_fetch_records(H.mc, false, H.tu + i, true, ctbs + c, lane));
+                ctb_residual<WIDE, GENERAL>(tile, s, H.G, j_tu, bd, lane_t, pre && i == wave, raw);
+            }
+        __syncthreads();
+        if (!GENERAL && tid == 0) s_flag[k & 1] = 0;         /* everyone has read it; it is set again two turns from now at the earliest */
+#ifndef MI355_EXP_CTB_NOSTORE
+        if (mine) tile_all<false>(tile, H.G, tid_t, NT);
+#endif
+        if (!more) break;
+        c = cn; H = Hn; rec = rec_n;
     }
-    if (uniform(cj.flags) & MI355_HEVC_CTB_PARTIAL) tile_all<true>(tile, G, tid, 64 * NW);
-    __syncthreads();
-    Scratch &s = scratch[wave];
-    bool ok = true;
-    for (int i = wave; i < n_mc; i += NW) ok = ctb_predict<WIDE, GENERAL>(tile, s, G, my_mc[i], bd, lane) && ok;
-    if (!GENERAL) {
-        /* a unit the matrix path does not take: known before any residual is added */
-        for (int i = wave; i < n_tu; i += NW) ok = ok && tu_is_fast(my_tu[i]);
-        if (!ok) s_flag = 1;
-    }
-    __syncthreads();
-    if (!GENERAL && s_flag) {
-        /* left to the general kernel; a caller that promised there are no such blocks (MI355_HEVC_RECON_UNIFORM) finds out */
-        if (error_word && tid == 0) atomicOr(error_word, (uint32_t)MI355_ERR_CTB_NOT_UNIFORM);
-        return;
-    }
-    for (int i = wave; i < n_tu; i += NW) { ctb_residual<WIDE, GENERAL>(tile, s, G, my_tu[i], bd, lane, pre && i == wave, raw); }
-    __syncthreads();
-    tile_all<false>(tile, G, tid, 64 * NW);
+}
+/* the matrix-path kernel with registers for six waves per SIMD (three workgroups of eight waves per CU, what its LDS allows; a handful of values move to scratch
+ * memory for it); the general kernel as the compiler sizes it */
+template <bool WIDE, int NW>
+__global__ void __launch_bounds__(64 * NW) MI355_CTB_WAVES_ATTR k_hevc_recon_ctbs(const mi355_hevc_ctb_job *ctbs, int n_ctbs, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tus,
+                                                                                  int bd, uint32_t *error_word)
+{
+    ctb_turns<WIDE, false, NW>(ctbs, n_ctbs, mc, tus, bd, 0, error_word);
+}
+template <bool WIDE, int NW>
+__global__ void __launch_bounds__(64 * NW) k_hevc_recon_ctbs_general(const mi355_hevc_ctb_job *ctbs, int n_ctbs, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tus,
+                                                                     int bd, int only_rest)
+{
+    ctb_turns<WIDE, true, NW>(ctbs, n_ctbs, mc, tus, bd, only_rest, nullptr);
 }
 
 }  // namespace
@@ -273,7 +422,14 @@ extern "C" int mi355_hevc_recon_ctbs_dev(const mi355_hevc_ctb_job *d_ctbs, int n
     if (!bind()) { std::fprintf(stderr, "mi355dsp: HEVC batch entry point without mi355_init(); no CPU fallback\n"); std::abort(); }
     if (!d_ctbs || n_ctbs <= 0 || !(bit_depth == 8 || bit_depth == 9 || bit_depth == 10)) return -1;
     const hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)n_ctbs);
+    /* workgroups stay and take turns: as many as the device holds at once */
+    static const int cus = [] { const int n = mi355_device_cus(); return n > 0 ? n : 256; }();
+    auto resident = [](auto kernel, int threads) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        return per_cu;
+    };
+    auto grid_for = [&](int per_cu) { const long want = CTB_PERSIST ? (long)per_cu * cus : (long)n_ctbs; return dim3((unsigned)(n_ctbs < want ? n_ctbs : want)); };
     static const bool general_only = std::getenv("MI355_CTB_GENERAL_ONLY") != nullptr;      /* developer switch: every block through the general kernel */
     const bool uniform_promised = (flags & MI355_HEVC_RECON_UNIFORM) != 0;
     uint32_t *err = uniform_promised ? mi355::error_word() : nullptr;
@@ -281,17 +437,20 @@ extern "C" int mi355_hevc_recon_ctbs_dev(const mi355_hevc_ctb_job *d_ctbs, int n
     static const int waves = std::getenv("MI355_CTB_WAVES") ? std::atoi(std::getenv("MI355_CTB_WAVES")) : CTB_WAVES_FAST;      /* developer switch: 4 */
     if (!general_only) {
         if (waves == 4) {
-            if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs<true, false, 4>), grid, dim3(256), 0, st, d_ctbs, d_mc, d_tus, bit_depth, 0, err);
-            else hipLaunchKernelGGL((k_hevc_recon_ctbs<false, false, 4>), grid, dim3(256), 0, st, d_ctbs, d_mc, d_tus, bit_depth, 0, err);
+            static const int r1 = resident(k_hevc_recon_ctbs<true, 4>, 256), r0 = resident(k_hevc_recon_ctbs<false, 4>, 256);
+            if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs<true, 4>), grid_for(r1), dim3(256), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, err);
+            else hipLaunchKernelGGL((k_hevc_recon_ctbs<false, 4>), grid_for(r0), dim3(256), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, err);
         } else {
-            if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs<true, false, CTB_WAVES_FAST>), grid, dim3(64 * CTB_WAVES_FAST), 0, st, d_ctbs, d_mc, d_tus, bit_depth, 0, err);
-            else hipLaunchKernelGGL((k_hevc_recon_ctbs<false, false, CTB_WAVES_FAST>), grid, dim3(64 * CTB_WAVES_FAST), 0, st, d_ctbs, d_mc, d_tus, bit_depth, 0, err);
+            static const int r1 = resident(k_hevc_recon_ctbs<true, CTB_WAVES_FAST>, 64 * CTB_WAVES_FAST), r0 = resident(k_hevc_recon_ctbs<false, CTB_WAVES_FAST>, 64 * CTB_WAVES_FAST);
+            if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs<true, CTB_WAVES_FAST>), grid_for(r1), dim3(64 * CTB_WAVES_FAST), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, err);
+            else hipLaunchKernelGGL((k_hevc_recon_ctbs<false, CTB_WAVES_FAST>), grid_for(r0), dim3(64 * CTB_WAVES_FAST), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, err);
         }
     }
     if (general_only || !uniform_promised) {
         const int only_rest = general_only ? 0 : 1;
-        if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs<true, true, CTB_WAVES_GENERAL>), grid, dim3(64 * CTB_WAVES_GENERAL), 0, st, d_ctbs, d_mc, d_tus, bit_depth, only_rest, (uint32_t *)nullptr);
-        else hipLaunchKernelGGL((k_hevc_recon_ctbs<false, true, CTB_WAVES_GENERAL>), grid, dim3(64 * CTB_WAVES_GENERAL), 0, st, d_ctbs, d_mc, d_tus, bit_depth, only_rest, (uint32_t *)nullptr);
+        static const int r1 = resident(k_hevc_recon_ctbs_general<true, CTB_WAVES_GENERAL>, 64 * CTB_WAVES_GENERAL), r0 = resident(k_hevc_recon_ctbs_general<false, CTB_WAVES_GENERAL>, 64 * CTB_WAVES_GENERAL);
+        if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_recon_ctbs_general<true, CTB_WAVES_GENERAL>), grid_for(r1), dim3(64 * CTB_WAVES_GENERAL), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, only_rest);
+        else hipLaunchKernelGGL((k_hevc_recon_ctbs_general<false, CTB_WAVES_GENERAL>), grid_for(r0), dim3(64 * CTB_WAVES_GENERAL), 0, st, d_ctbs, n_ctbs, d_mc, d_tus, bit_depth, only_rest);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -246,9 +246,11 @@ __device__ __forceinline__ uint64_t cf_taps_at(uint64_t taps, int d)
 struct CfPass { uint64_t taps; int ext, shift, sum; };      /* taps from the window's first row / column on; ext = taps - 1 */
 __device__ __forceinline__ CfPass cf_pass(const int8_t *f, int ntaps, int shift)
 {
+    /* the table row IS the word (taps as consecutive signed bytes); every interpolation filter of the standard sums to 64 (hevcdsp.c:92-115) */
     CfPass p;
-    p.taps = 0; p.sum = 0;
-    for (int k = 0; k < ntaps; k++) { p.taps |= (uint64_t)(uint8_t)f[k] << (8 * k); p.sum += f[k]; }
+    if (ntaps == 8) { uint64_t w; __builtin_memcpy(&w, f, 8); p.taps = w; }
+    else { uint32_t w; __builtin_memcpy(&w, f, 4); p.taps = w; }
+    p.sum = 64;
     p.ext = ntaps - 1; p.shift = shift;
     return p;
 }
@@ -270,34 +272,37 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
     const int j = lane & 15, g = lane >> 4;
     const int off = (int)((uintptr_t)src & (PB - 1)) >> (WIDE ? 1 : 0);
     const uint8_t *base = src - ((uintptr_t)src & (PB - 1));
-    const int rows = th + pv.ext, npr = (off + tw + ph.ext + 7) >> 3, n = rows * npr, inv = mi355_inv20(npr);
-    /* the window -> byte planes in LDS, eight samples per lane and piece, all loads of the tile in flight together */
+    const int rows = th + pv.ext, npr = (off + tw + ph.ext + 7) >> 3;
+    /* the window -> byte planes in LDS, eight samples per lane and piece, all loads of the tile in flight together.  A lane keeps its piece of a row and
+     * walks down the rows (8 pieces a row and 8 rows a round for a 32-wide tile, 4 and 16 for a 16-wide one: addresses are the lane's first one plus a
+     * round's constant; pieces past the row's last and rows past the window's last are not fetched) */
     {
-        uint32_t v[4][4];
-        int at[4];
+        const int ppr_log = tw > 16 ? 3 : 2, rstep = 64 >> ppr_log;
+        const int r0 = lane >> ppr_log, p = lane & ((1 << ppr_log) - 1);
+        const uint32_t voff = (uint32_t)r0 * (uint32_t)sb + (uint32_t)(PB * p);
+        const int lds0 = r0 * CF_WIN_PITCH + 8 * p;
+        uint32_t v[5][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = lane + 64 * u, ic = i < n ? i : n - 1;
-            const int r = mi355_div20(ic, inv), p = ic - r * npr;
-            at[u] = i < n ? r * CF_WIN_PITCH + 8 * p : -1;
-            if (64 * u < n) {
-                if (WIDE) __builtin_memcpy(v[u], base + (ptrdiff_t)r * sb + 16 * p, 16);
-                else { __builtin_memcpy(v[u], base + (ptrdiff_t)r * sb + 8 * p, 8); v[u][2] = v[u][3] = 0u; }
+        for (int u = 0; u < 5; u++)
+            if (u * rstep < rows && p < npr && r0 + u * rstep < rows) {
+                const uint8_t *q = base + (ptrdiff_t)(u * rstep) * sb + voff;
+                if (WIDE) __builtin_memcpy(v[u], q, 16);
+                else { __builtin_memcpy(v[u], q, 8); v[u][2] = v[u][3] = 0u; }
             }
-        }
         MI355_ISSUE_FENCE();
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (64 * u >= n || at[u] < 0) continue;
-            if (WIDE) {
-                uint64_t lo, hi;
-                cf_planes8(v[u][0], v[u][1], v[u][2], v[u][3], lo, hi);
-                cf_st64(w.lo + at[u], lo ^ CF_SIGN8);
-                cf_st64(w.hi + at[u], hi);
-            } else {
-                cf_st64(w.lo + at[u], cf_u64(v[u][0], v[u][1]) ^ CF_SIGN8);
+        for (int u = 0; u < 5; u++)
+            if (u * rstep < rows && p < npr && r0 + u * rstep < rows) {
+                const int at = lds0 + u * rstep * CF_WIN_PITCH;
+                if (WIDE) {
+                    uint64_t lo, hi;
+                    cf_planes8(v[u][0], v[u][1], v[u][2], v[u][3], lo, hi);
+                    cf_st64(w.lo + at, lo ^ CF_SIGN8);
+                    cf_st64(w.hi + at, hi);
+                } else {
+                    cf_st64(w.lo + at, cf_u64(v[u][0], v[u][1]) ^ CF_SIGN8);
+                }
             }
-        }
     }
     MI355_WAVE_SYNC();
     const int RT = (rows + 15) >> 4, XT = tw >> 4, YT = th >> 4;
@@ -331,8 +336,9 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
     /* vertical pass: v[x][y] = (sum_r t[r][x] tapV[r - y]) >> shift over the rows of two row tiles (slot (g, s) = row 16 (s / 4) + 4 g + s % 4 of the
      * pair); the lane receives row y = 16 yt + j, columns 16 xt + 4 g .. + 3 of the 14-bit intermediate; put_unweighted_pred (:1092-1113) on top */
     const uint64_t toep_v = cf_u64((uint32_t)cf_taps_at(pv.taps, 4 * g - j), (uint32_t)cf_taps_at(pv.taps, 16 + 4 * g - j));
-    const int cv = 128 * pv.sum, cv4[4] = { cv, cv, cv, cv };
-    const int sh14 = 14 - bd, rnd = 1 << (sh14 - 1), maxv = (1 << bd) - 1;
+    /* ((sum >> shift) + rnd) >> sh14 with rnd = 1 << (sh14 - 1) is (sum + (rnd << shift)) >> (shift + sh14): one shift, the addend in the accumulator's start value */
+    const int sh14 = 14 - bd, maxv = (1 << bd) - 1, shv = pv.shift + sh14;
+    const int cv = 128 * pv.sum + ((1 << (sh14 - 1)) << pv.shift), cv4[4] = { cv, cv, cv, cv };
 #pragma unroll
     for (int yt = 0; yt < 2; yt++)
 #pragma unroll
@@ -342,7 +348,7 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
                 cf_mfma(cf_u64(thi[yt][xt], thi[yt + 1][xt]), toep_v, zero4, h);
                 cf_mfma(cf_u64(tlo[yt][xt], tlo[yt + 1][xt]), toep_v, cv4, l);
 #pragma unroll
-                for (int t = 0; t < 4; t++) s[t] = clip3(((((h[t] << 8) + l[t]) >> pv.shift) + rnd) >> sh14, 0, maxv);
+                for (int t = 0; t < 4; t++) s[t] = med3i(((h[t] << 8) + l[t]) >> shv, 0, maxv);
                 uint8_t *p = tile + (16 * yt + j) * pitch + ((16 * xt + 4 * g) << (WIDE ? 1 : 0));
                 if (WIDE) *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
                 else *reinterpret_cast<uint32_t *>(p) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);

@@ -102,6 +102,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->multiProcessorCount = 4;
     return hipSuccess;
 }
+/* the emulator "holds" one workgroup per CU: persistent kernels (grid = resident workgroups) take many turns each, which is what the tests want to see */
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); simt_emu::note_alloc(n); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
