@@ -186,7 +186,17 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
     __shared__ uint8_t s_act[64];
     const int lane = lane_id(), slot = lane >> 3;
     const int pic = (int)blockIdx.x / waves_per_pic, w = (int)blockIdx.x - pic * waves_per_pic;
-    const mi355_hevc_lf_picture &p = pics[pic];
+    /* the picture's record once, a dword per lane, its fields as scalars from there (v_readlane): read field by field through `pics` every use of a field is a
+     * vector load and a wait in front of the load that needed it (the strengths' pointer, then the strength) */
+    static_assert(sizeof(mi355_hevc_lf_picture) == 136, "the record is read by dword index");
+    mi355_hevc_lf_picture p;
+    {
+        const int rec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(pics + pic))[lane < 34 ? lane : 33];
+        uint32_t wds[34];
+#pragma unroll
+        for (int k = 0; k < 34; k++) wds[k] = (uint32_t)lane_value(rec, k);
+        __builtin_memcpy(&p, wds, sizeof(p));
+    }
     const LfPic P{ p };
     const int ps = bd > 8, W = p.width, H = p.height;
     const bool luma = w < luma_waves;
