@@ -46,15 +46,29 @@ def level_widths(fs):
 
 
 def measured_traffic(kernel, frames):
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
-        try:
-            t = json.load(open(path))
-            if abs(t.get("frames_per_gpu", -9) - frames) <= 1 and kernel in t.get("kernels", {}):      # 2048 pictures as three launches: 683 / 683 / 682
-                return t["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, ROOT)
-        except (OSError, ValueError, KeyError):
-            pass
+    """HBM bytes per launch of `kernel` from the PMC passes of the session named in profiles/CURRENT_TRAFFIC.json (a tracked file: {"file": ..., "session": ...});
+    the passes cannot be collected from inside this process (tools/gpu_traffic.sh, tools/mk_traffic_profile.py)"""
+    try:
+        cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT_TRAFFIC.json")))
+        path = os.path.join(ROOT, "profiles", cur["file"])
+        t = json.load(open(path))
+        if abs(t.get("frames_per_gpu", -9) - frames) <= 1 and kernel in t.get("kernels", {}):      # 2048 pictures as three launches: 683 / 683 / 682
+            return t["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, ROOT)
+    except (OSError, ValueError, KeyError):
+        pass
     return None, None
+
+
+# The driver's record keeps the scalars of `config` under keys cut at 40 characters, about twenty of them: the points it should carry, in this order,
+# under these (<= 32 characters, unique) names.  Everything else stays in the line's `extra` (and in profiles/ as the session's full line).
+POINT_KEYS = [
+    ("config2_f%(F)d", "p_c2_f%(F)d"), ("config2_f2048_one_pipeline", "p_c2_one_pipeline"), ("config3_hevc_2160p10_chain", "p_c3_hevc_chain"),
+    ("config3_hevc_2160p10_chain:one_chain", "p_c3_hevc_one_chain"), ("config5_sws_hd_special", "p_c5_sws_special"), ("config5_sws_hd_generic", "p_c5_sws_generic"),
+    ("config5_sws_uhd_to_hd", "p_c5_sws_uhd_to_hd"), ("config2_f64", "p_c2_f64"), ("config2_f512", "p_c2_f512"), ("config2_smooth_f2048", "p_c2_smooth"),
+    ("config2_mixed_partitions_f2048", "p_c2_mixed_parts"), ("config2_high10_f2048", "p_c2_high10"), ("all_intra_f512", "p_all_intra_f512"),
+    ("config2_f2048_detile", "p_c2_detile"), ("hevc_bridge_pb_1080p_few_intra_bridge_x16", "p_hevc_br_x16"), ("hevc_bridge_pb_1080p_few_intra_c_x16", "p_hevc_c_x16"),
+    ("h264_bridge_1080p_x64", "p_h264_br_x64"), ("h264_bridge_1080p_x64_c", "p_h264_c_x64"), ("hevc_bridge_i_ctb64:forced", "p_hevc_i_on_device"),
+]
 
 
 def main():
@@ -78,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-extra", action="store_true", help="skip the additional measured points (rank 0, N=1 only)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the three whole-batch launches of the dominant kernel after the timed region (roofline.alone_*): what the "
+                    "counter passes use (tools/gpu_traffic.sh), so that every launch of the profiled command is a share-sized one")
     ap.add_argument("--notes", action="store_true", help="keep the long `note` / `sample` texts of the extra points in the JSON line (without them "
                     "the whole line stays under the 16 KB the driver's record keeps; what each point is: README.md, DESIGN.md 6)")
     ap.add_argument("--layout", choices=("tiled", "linear"), default="tiled", help="surface layout of dst / recon / reference "
@@ -286,7 +302,7 @@ def main():
                        "frames_per_gpu": F, "pipelines": P, "phased": bool(args.phased and P > 1), "frames_per_launch": per, "mb_per_frame": nmb, "bytes_per_mb_fused": B_FUSED,
                        "fused_fraction_of_hbm_roofline": value / world * B_FUSED / HBM_PEAK,
                        "parallelism": "independent streams sharded over %d GPU(s), no data-path collective" % world,
-                       "verified_by": "tests/test_frame_gpu.py::test_full_size_1080p_batch_matches_oracle (same generator, bit-exact)"},
+                       "verified_by": "tests/test_frame_gpu.py::test_full_size_1080p_batch_run_kernel + ::test_pipelines_object_at_the_bench_share (same generator, tiled surfaces, the run kernel, the pipelines object at a 683-picture share; every sample)"},
             "pass_ms": {"recon_inter": t_inter, "recon_intra": t_intra, "deblock": t_deblock},
             "pass_ms_is": "average duration of one launch (%d pictures) by HIP events on its stream%s" % (per, "; the %d pipelines' launches overlap: the passes do not add up to ms_per_step" % P if P > 1 else ""),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -294,7 +310,7 @@ def main():
                          "launches_per_step": launches, "avg_launch_us": t_pass * 1e3,
                          "algorithmic_bytes_per_launch": bytes_pass / launches},
         }
-        if P > 1:
+        if P > 1 and not args.no_alone:
             # the same kernel ALONE, outside the timed region: one launch over the whole batch, nothing beside it (what rounds 1-4's lines and the extra point
             # config2_f2048_one_pipeline measure)
             e0, e1 = lib.mi355_event_create(), lib.mi355_event_create()
@@ -306,12 +322,12 @@ def main():
                 lib.mi355_event_record(e1, None)
                 alone.append(lib.mi355_event_elapsed_ms(e0, e1))
             t_alone = sum(alone[1:]) / 2
-            out["roofline"]["alone"] = {"kernel": "k_recon_inter_tiled" if tiled else "k_recon_inter", "frames_per_launch": F, "avg_launch_us": t_alone * 1e3,
-                                        "algorithmic_bytes_per_launch": n_inter * B_RECON, "achieved": n_inter * B_RECON / (t_alone * 1e-3) / 1e9, "frac": n_inter * B_RECON / (t_alone * 1e-3) / HBM_PEAK,
-                                        "note": "measured after the timed region: one launch over all %d pictures with nothing beside it" % F}
+            out["roofline"]["alone_us"] = t_alone * 1e3            # the same kernel, one launch over all F pictures with nothing beside it (after the timed region)
+            out["roofline"]["alone_frac"] = n_inter * B_RECON / (t_alone * 1e-3) / HBM_PEAK
+            out["roofline"]["alone_frames"] = F
             # a launch shares the device with the other pipeline's launches: its duration is the time it was resident, not the time it would take alone
             out["roofline"]["shared_device"] = ("%d pipelines: this kernel's launch (%d pictures) runs beside the other pipelines' loop filters and intra passes, so achieved / frac are per launch WHILE SHARING the device; "
-                                               "the same kernel with the device to itself: roofline.alone (and extra point config2_f2048_one_pipeline); the whole job's rate is "
+                                               "the same kernel with the device to itself: roofline.alone_frac / alone_us (and extra point config2_f2048_one_pipeline); the whole job's rate is "
                                                "config.fused_fraction_of_hbm_roofline" % (P, per))
         # HBM bytes per launch of the dominant kernel from the PMC passes of the same command
         # (tools/gpu_traffic.sh -> profiles/*hbm_traffic*.json; cannot be collected from inside this process)
@@ -332,6 +348,10 @@ def main():
                 for key in ("bridge", "hooked", "reference_c_decoder"):            # decoder end to end: pictures/s, bridge (or hooked tables) vs C
                     if isinstance(p.get(key), dict) and "pictures_per_s" in p[key]:
                         points[p["name"] + ("_c" if key == "reference_c_decoder" else "")] = round(p[key]["pictures_per_s"], 1)
+                if isinstance(p.get("one_pipeline"), dict) and "fraction_of_hbm_roofline" in p["one_pipeline"]:      # config 3 as ONE chain (the point itself: two chains on streams)
+                    points[p["name"] + ":one_chain"] = round(p["one_pipeline"]["fraction_of_hbm_roofline"], 4)
+                if isinstance(p.get("bridge_forced"), dict) and "pictures_per_s" in p["bridge_forced"]:
+                    points[p["name"] + ":forced"] = round(p["bridge_forced"]["pictures_per_s"], 1)
                 for key in p:                                                       # ... with several decoders in the process
                     if isinstance(p[key], dict) and "pictures_per_s" in p[key] and (key.startswith("bridge_x") or key.startswith("reference_c_decoder_x")):
                         points[p["name"] + "_" + key.replace("reference_c_decoder", "c")] = round(p[key]["pictures_per_s"], 1)
@@ -341,8 +361,11 @@ def main():
                         p.pop(key, None)
                     if isinstance(p.get("cpu_baseline"), dict):
                         p["cpu_baseline"].pop("sample", None)
-        for k_, v_ in points.items():               # flat (the driver's record keeps the scalars of `config`, not nested objects)
-            out["config"]["p_" + k_] = v_
+        for long_, short_ in POINT_KEYS:            # flat (the driver's record keeps the scalars of `config`, not nested objects), the named ones only, in this order
+            long_, short_ = long_ % {"F": F}, short_ % {"F": F}
+            if long_ in points:
+                assert len(short_) <= 32
+                out["config"][short_] = points[long_]
         if args.notes:
             out["config"]["points"] = points
         print(json.dumps(out))

@@ -389,6 +389,12 @@ int  mi355_h264_pipelines_decode_dev(mi355_h264_pipelines *p, const mi355_h264_f
 int  mi355_h264_pipelines_sync(mi355_h264_pipelines *p);
 int  mi355_h264_pipelines_share(const mi355_h264_pipelines *p, int nframes, int share, int *first, int *count);
 void mi355_h264_pipelines_timing(mi355_h264_pipelines *p, int on);
+/* How consecutive calls are ordered.  Inside a call a share's three passes follow each other on its stream, and share i's pictures of the NEXT call follow them there.
+ * A picture that references one decoded by ANOTHER share of the call before needs more: mode 1 (default) — a call whose batch differs from the one before (another
+ * d_frames or nframes: pictures move between shares) first waits in every share for every share's loop filter of the call before; calls on the same batch are not
+ * joined (a stream's pictures keep their share; they run into each other, which is where the schedule's gain at the call boundary comes from).  mode 2: every call is
+ * joined.  mode 0: never (the caller orders what needs ordering).  A caller that moves streams between slots of an unchanged batch uses 2. */
+void mi355_h264_pipelines_join(mi355_h264_pipelines *p, int mode);
 int  mi355_h264_pipelines_collect(mi355_h264_pipelines *p, double sums[3], int *launches);
 
 /* Streams for callers that pipeline half-batches (reconstruction of one against deblocking of the other);

@@ -1151,9 +1151,10 @@ struct SyncBuf {
     size_t words;
 };
 }  // namespace
+static std::vector<SyncBuf> &sync_pool() { static thread_local std::vector<SyncBuf> pool; return pool; }
 uint32_t *mi355::sync_words(hipStream_t st, size_t words)
 {
-    static thread_local std::vector<SyncBuf> pool;
+    std::vector<SyncBuf> &pool = sync_pool();
     const int device = mi355::current_device();
     for (SyncBuf &b : pool) {
         if (b.device != device || b.stream != st) continue;
@@ -1171,6 +1172,17 @@ uint32_t *mi355::sync_words(hipStream_t st, size_t words)
     if (hipMalloc(reinterpret_cast<void **>(&b.dev), b.words * sizeof(uint32_t)) != hipSuccess) return nullptr;
     pool.push_back(b);
     return b.dev;
+}
+void mi355::sync_words_release(hipStream_t st)
+{
+    std::vector<SyncBuf> &pool = sync_pool();
+    const int device = mi355::current_device();
+    for (size_t i = 0; i < pool.size(); i++)
+        if (pool[i].device == device && pool[i].stream == st) {
+            if (pool[i].dev) (void)hipFree(pool[i].dev);
+            pool.erase(pool.begin() + (long)i);
+            return;
+        }
 }
 
 extern "C" int mi355_h264_deblock_dev(const mi355_h264_frame *d_frames, int nframes, int max_mb_width, int max_mb_height, void *stream)

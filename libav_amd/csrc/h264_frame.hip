@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <vector>
 #include "h264_recon_dev.h"
+#include "../../include/mi355dsp.h"      /* the device error word */
 
 
 namespace {
@@ -247,7 +248,9 @@ k_recon_intra(const mi355_h264_frame *frames, int level, int width)
  * 0.3 - 0.6 us EACH, one after the other.  A launch per level made all pictures wait for the slowest wave of a level, 254 times for an I picture; here a
  * macroblock goes as soon as its own neighbours are done.
  * Progress: workgroups start in the order of their numbers on every XCD, so the lowest-numbered unfinished workgroup is always running, and it waits for
- * nobody (its neighbours have lower numbers).  Should a device ever start them otherwise, INTRA_NAPS_MAX ends the wait: a wrong picture, not a hung device. */
+ * nobody (its neighbours have lower numbers).  That order is what devices do, not something the API promises: should one ever start them otherwise, INTRA_NAPS_MAX ends
+ * the wait — not a hung device, and not a silently wrong picture either: MI355_ERR_WAIT_EXPIRED is set in the device's error word and the next mi355_sync /
+ * mi355_event_sync / mi355_h264_pipelines_sync returns MI355_E_DEVICE_FAULT. */
 /* Batches with at least this many levels take the single launch (MI355_INTRA_SINGLE=0 / 1 pins a form).  Measured (profiles/r05s_pass_ms.txt): I pictures 4.17 -> 3.76 ms
  * per 512, 1.58 -> 1.36 per 64 (254 levels); P pictures with 5 % intra macroblocks in four levels 0.68 -> 0.81 ms per 2048 — their level launches are short as they are, and
  * the single launch adds the neighbours' type words (a memory round trip before the macroblock's own loads), the wait for the stores and the zeroing of the flags */
@@ -261,7 +264,7 @@ __device__ __forceinline__ uint32_t intra_flag_word(const uint8_t *p) { return a
 __device__ __forceinline__ void intra_flag_set(uint8_t *p) { __hip_atomic_store(p, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 __global__ void __launch_bounds__(64)
-k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, int nmb_max, uint8_t *__restrict__ flags)
+k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, int nmb_max, uint8_t *__restrict__ flags, uint32_t *error_word, uint32_t naps_max)
 {
     __shared__ IntraLds s;
     const int k = (int)(blockIdx.x / (unsigned)nframes), f = (int)(blockIdx.x - (unsigned)k * (unsigned)nframes);
@@ -284,13 +287,17 @@ k_recon_intra_all(const mi355_h264_frame *__restrict__ frames, int nframes, int 
         const uint8_t *fp = pic_flags + nxy;
         const int sh = 8 * (int)(reinterpret_cast<uintptr_t>(fp) & 3);
         uint32_t naps = 0;
-        while (__any(dep && ((intra_flag_word(fp) >> sh) & 0xFFu) == 0) && naps < INTRA_NAPS_MAX) { wave_nap(); naps++; }
+        while (__any(dep && ((intra_flag_word(fp) >> sh) & 0xFFu) == 0) && naps < naps_max) { wave_nap(); naps++; }
+        /* the wait ran out (the device started workgroups in another order than the progress argument above assumes): the macroblock is reconstructed from whatever
+         * is there — and the device says so: the wait that follows this launch returns MI355_E_DEVICE_FAULT (include/mi355dsp.h), the caller repeats the batch with
+         * mi355_h264_recon_intra_levels_dev (MI355_INTRA_SINGLE=0 pins that form) */
+        if (naps >= naps_max && __any(dep && ((intra_flag_word(fp) >> sh) & 0xFFu) == 0) && lane_id() == 0) atomicOr(error_word, (uint32_t)MI355_ERR_WAIT_EXPIRED);
         MI355_ISSUE_FENCE();
     }
     if (uniform(frd.surface_layout) == MI355_SURFACE_TILED) recon_intra_mb<true, true>(s, frd, mb_xy, waits);
     else recon_intra_mb<false, true>(s, frd, mb_xy, waits);
     agent_drain_stores();                                 /* the macroblock's samples have reached memory */
-    if (lane == 0) intra_flag_set(pic_flags + mb_xy);
+    if (lane == 0 && naps_max) intra_flag_set(pic_flags + mb_xy);       /* (bound 0, the test hook: nobody reports, every wait on a neighbour runs out) */
 }
 
 }  // namespace
@@ -362,7 +369,11 @@ extern "C" int mi355_h264_recon_intra_all_dev(const mi355_h264_frame *d_frames, 
     uint32_t *flags = mi355::sync_words((hipStream_t)stream, bytes / 4);
     if (!flags) return -4;
     MI355_TRY(hipMemsetAsync(flags, 0, bytes, (hipStream_t)stream), -4);
-    hipLaunchKernelGGL(k_recon_intra_all, dim3((unsigned)(nframes * per_picture)), dim3(64), 0, (hipStream_t)stream, d_frames, nframes, (int)nmb, reinterpret_cast<uint8_t *>(flags));
+    uint32_t *err = mi355::error_word();
+    if (!err) return -4;
+    /* test hook: MI355_INTRA_NAPS_MAX=0 — no macroblock reports completion and no wait lasts: every macroblock with an intra neighbour gives up (tests/test_frame_emu.py: the error channel) */
+    static const uint32_t naps_max = std::getenv("MI355_INTRA_NAPS_MAX") ? (uint32_t)std::strtoul(std::getenv("MI355_INTRA_NAPS_MAX"), nullptr, 0) : INTRA_NAPS_MAX;
+    hipLaunchKernelGGL(k_recon_intra_all, dim3((unsigned)(nframes * per_picture)), dim3(64), 0, (hipStream_t)stream, d_frames, nframes, (int)nmb, reinterpret_cast<uint8_t *>(flags), err, naps_max);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -646,7 +657,7 @@ extern "C" void *mi355_stream_create(void)
     if (!mi355::bind() || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return st;
 }
-extern "C" void mi355_stream_destroy(void *st) { (void)hipStreamDestroy((hipStream_t)st); }
+extern "C" void mi355_stream_destroy(void *st) { mi355::sync_words_release((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
 extern "C" int mi355_stream_wait_event(void *st, void *e) { return hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)e, 0) == hipSuccess ? 0 : -1; }
 
 extern "C" void *mi355_event_create(void)

@@ -537,7 +537,14 @@ __device__ __forceinline__ void sao_region_fast(uint8_t *dst, const uint8_t *src
                 s.b = sao_raw(src + s.o + rowb - (fb ? 0 : dx0 * px), wide);
             } else {
                 const ptrdiff_t da = (ptrdiff_t)dx0 * px + (ptrdiff_t)dy0 * stride;
+#ifdef MI355_EXP_SAO_NONEIGH
+                (void)da;
+#elif defined(MI355_EXP_SAO_ALIGNED)
+                const ptrdiff_t dal = (ptrdiff_t)dy0 * stride;
+                s.a = sao_raw(src + s.o + dal, wide); s.b = sao_raw(src + s.o - dal, wide);
+#else
                 s.a = sao_raw(src + s.o + da, wide); s.b = sao_raw(src + s.o - da, wide);
+#endif
             }
         }
         return s;

@@ -571,6 +571,50 @@ __device__ __forceinline__ int hevc_pred_px(const HevcPredParams &p, int a, int 
 /* ---- a16: deblocking of one 8-sample edge, lanes 0..7 = the 8 lines (:1264-1392) ----------------
  * `xs`: sample step across the edge, `ys`: along it.  Decisions use lines 0 and 3 of each 4-line
  * half, fetched from the neighbouring lanes with shuffles. */
+/* the decisions and the arithmetic of one line of an edge (hevc_loop_filter_luma, hevcdsp_template.c:1520-1620): p[0..3] / q[0..3] = the line's samples from the
+ * edge outwards, the lane's seven neighbours of its group of eight hold the other lines (lines 0 and 3 of each half decide for the half).  Every lane of the
+ * group calls it (the shuffles); np / nq = p0..p2 / q0..q2 afterwards; false: the line is left as it is */
+__device__ __forceinline__ bool hevc_lf_luma_core(const int p[4], const int q[4], int beta, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd, bool act,
+                                                  int np[3], int nq[3])
+{
+    const int lane = lane_id(), l = lane & 7, j = l >> 2, g0 = lane & ~7;
+    const int dp = iabs(p[2] - 2 * p[1] + p[0]), dq = iabs(q[2] - 2 * q[1] + q[0]);
+    const int sflat = iabs(p[3] - p[0]) + iabs(q[3] - q[0]), sgap = iabs(p[0] - q[0]);
+    /* values of line 0 and line 3 of this lane's half */
+    const int dp0 = __shfl(dp, g0 + 4 * j), dp3 = __shfl(dp, g0 + 4 * j + 3), dq0 = __shfl(dq, g0 + 4 * j), dq3 = __shfl(dq, g0 + 4 * j + 3);
+    const int f0 = __shfl(sflat, g0 + 4 * j), f3 = __shfl(sflat, g0 + 4 * j + 3), gp0 = __shfl(sgap, g0 + 4 * j), gp3 = __shfl(sgap, g0 + 4 * j + 3);
+    if (!act) return false;
+    beta <<= bd - 8;
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    const int tc = tc_[j] << (bd - 8), no_p = no_p_[j], no_q = no_q_[j];
+    if (d0 + d3 >= beta) return false;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    np[0] = p[0]; np[1] = p[1]; np[2] = p[2]; nq[0] = q[0]; nq[1] = q[1]; nq[2] = q[2];          /* the samples after filtering */
+    if (f0 < beta_3 && gp0 < tc25 && f3 < beta_3 && gp3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        const int tc2 = tc << 1;
+        if (!no_p) {
+            np[0] = p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2);
+            np[1] = p[1] + clip3(((p[2] + p[1] + p[0] + q[0] + 2) >> 2) - p[1], -tc2, tc2);
+            np[2] = p[2] + clip3(((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3) - p[2], -tc2, tc2);
+        }
+        if (!no_q) {
+            nq[0] = q[0] + clip3(((p[1] + 2 * p[0] + 2 * q[0] + 2 * q[1] + q[2] + 4) >> 3) - q[0], -tc2, tc2);
+            nq[1] = q[1] + clip3(((p[0] + q[0] + q[1] + q[2] + 2) >> 2) - q[1], -tc2, tc2);
+            nq[2] = q[2] + clip3(((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3) - q[2], -tc2, tc2);
+        }
+    } else {
+        const int tc_2 = tc >> 1, thr = (beta + (beta >> 1)) >> 3;
+        const int nd_p = dp0 + dp3 < thr ? 2 : 1, nd_q = dq0 + dq3 < thr ? 2 : 1;
+        int delta0 = (9 * (q[0] - p[0]) - 3 * (q[1] - p[1]) + 8) >> 4;
+        if (iabs(delta0) >= 10 * tc) return false;
+        delta0 = clip3(delta0, -tc, tc);
+        if (!no_p) np[0] = clip_px(p[0] + delta0, bd);
+        if (!no_q) nq[0] = clip_px(q[0] - delta0, bd);
+        if (!no_p && nd_p > 1) np[1] = clip_px(p[1] + clip3((((p[2] + p[0] + 1) >> 1) - p[1] + delta0) >> 1, -tc_2, tc_2), bd);
+        if (!no_q && nd_q > 1) nq[1] = clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd);
+    }
+    return true;
+}
 /* `groups`: false = lanes 0..7 filter one edge (the other lanes idle); true = every group of eight lanes
  * filters its own edge (per-lane arguments) */
 __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta, const int *tc_, const uint8_t *no_p_,
@@ -600,41 +644,8 @@ __device__ inline void hevc_lf_luma_wave(uint8_t *pix, int xs, int ys, int beta,
             q[k] = act ? ldpx(pix, k * xs + l * ys, bd) : 0;
         }
     }
-    const int dp = iabs(p[2] - 2 * p[1] + p[0]), dq = iabs(q[2] - 2 * q[1] + q[0]);
-    const int sflat = iabs(p[3] - p[0]) + iabs(q[3] - q[0]), sgap = iabs(p[0] - q[0]);
-    /* values of line 0 and line 3 of this lane's half */
-    const int dp0 = __shfl(dp, g0 + 4 * j), dp3 = __shfl(dp, g0 + 4 * j + 3), dq0 = __shfl(dq, g0 + 4 * j), dq3 = __shfl(dq, g0 + 4 * j + 3);
-    const int f0 = __shfl(sflat, g0 + 4 * j), f3 = __shfl(sflat, g0 + 4 * j + 3), gp0 = __shfl(sgap, g0 + 4 * j), gp3 = __shfl(sgap, g0 + 4 * j + 3);
-    if (!act) return;
-    beta <<= bd - 8;
-    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
-    const int tc = tc_[j] << (bd - 8), no_p = no_p_[j], no_q = no_q_[j];
-    if (d0 + d3 >= beta) return;
-    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
-    int np[3] = { p[0], p[1], p[2] }, nq[3] = { q[0], q[1], q[2] };          /* the samples after filtering */
-    if (f0 < beta_3 && gp0 < tc25 && f3 < beta_3 && gp3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
-        const int tc2 = tc << 1;
-        if (!no_p) {
-            np[0] = p[0] + clip3(((p[2] + 2 * p[1] + 2 * p[0] + 2 * q[0] + q[1] + 4) >> 3) - p[0], -tc2, tc2);
-            np[1] = p[1] + clip3(((p[2] + p[1] + p[0] + q[0] + 2) >> 2) - p[1], -tc2, tc2);
-            np[2] = p[2] + clip3(((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3) - p[2], -tc2, tc2);
-        }
-        if (!no_q) {
-            nq[0] = q[0] + clip3(((p[1] + 2 * p[0] + 2 * q[0] + 2 * q[1] + q[2] + 4) >> 3) - q[0], -tc2, tc2);
-            nq[1] = q[1] + clip3(((p[0] + q[0] + q[1] + q[2] + 2) >> 2) - q[1], -tc2, tc2);
-            nq[2] = q[2] + clip3(((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3) - q[2], -tc2, tc2);
-        }
-    } else {
-        const int tc_2 = tc >> 1, thr = (beta + (beta >> 1)) >> 3;
-        const int nd_p = dp0 + dp3 < thr ? 2 : 1, nd_q = dq0 + dq3 < thr ? 2 : 1;
-        int delta0 = (9 * (q[0] - p[0]) - 3 * (q[1] - p[1]) + 8) >> 4;
-        if (iabs(delta0) >= 10 * tc) return;
-        delta0 = clip3(delta0, -tc, tc);
-        if (!no_p) np[0] = clip_px(p[0] + delta0, bd);
-        if (!no_q) nq[0] = clip_px(q[0] - delta0, bd);
-        if (!no_p && nd_p > 1) np[1] = clip_px(p[1] + clip3((((p[2] + p[0] + 1) >> 1) - p[1] + delta0) >> 1, -tc_2, tc_2), bd);
-        if (!no_q && nd_q > 1) nq[1] = clip_px(q[1] + clip3((((q[2] + q[0] + 1) >> 1) - q[1] - delta0) >> 1, -tc_2, tc_2), bd);
-    }
+    int np[3], nq[3];
+    if (!hevc_lf_luma_core(p, q, beta, tc_, no_p_, no_q_, bd, act, np, nq)) return;
     if (row_wise) {
         /* p3 and q3 go back unchanged; no other job of a launch touches this line's eight samples */
         if (bd > 8) {

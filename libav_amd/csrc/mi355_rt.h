@@ -149,6 +149,8 @@ bool ready();
 /* the calling thread's device's error word (include/mi355dsp.h): a device-visible pointer into pinned host memory, nullptr without a device.
  * fault_after_wait(): what a sync entry point returns once its wait is over: 0, or MI355_E_DEVICE_FAULT while bits are set (they stay set until
  * mi355_error_word_take()) */
+/* the calling thread's counter buffer of `stream` (h264_deblock.hip: sync_words) is freed: a stream about to be destroyed */
+void sync_words_release(hipStream_t stream);
 uint32_t *error_word();
 int fault_after_wait();
 bool blocking_sync();      /* waits sleep instead of spinning (MI355_BLOCKING_SYNC / mi355_prefer_blocking_sync) */

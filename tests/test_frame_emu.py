@@ -236,3 +236,85 @@ def test_config2_high10_workload_against_the_frame_checker_emulated(emu, oracle)
     fs = HF.synth_frames_fast(2, 12, 7, seed=0x264, lib=emu.lib)
     if not frame_cases.run_case_hbd(emu, oracle, "config2_high10", 10, fs=fs):
         pytest.skip("oracle/_ref/libref.so not built (no /root/reference)")
+
+
+def test_error_word_round_trip_emulated(emu):
+    """the device's error word (include/mi355dsp.h): a kernel's bits reach the host, the waits return MI355_E_DEVICE_FAULT until the caller takes them"""
+    import ctypes as C
+    lib = emu.lib
+    lib.mi355_error_word_take.restype = C.c_uint
+    lib.mi355_error_word_peek.restype = C.c_uint
+    lib.mi355_error_word_inject.argtypes = [C.c_uint, C.c_void_p]
+    lib.mi355_sync.restype = C.c_int
+    lib.mi355_error_word_take()
+    assert lib.mi355_sync(None) == 0
+    assert lib.mi355_error_word_inject(0x40000000, None) == 0
+    assert lib.mi355_sync(None) == -5 and lib.mi355_error_word_peek() == 0x40000000
+    assert lib.mi355_error_word_take() == 0x40000000 and lib.mi355_sync(None) == 0
+
+
+def test_intra_single_launch_wait_that_runs_out_is_reported_emulated(tmp_path):
+    """k_recon_intra_all's bounded wait (h264_frame.hip): with the bound at zero every macroblock that has an intra neighbour gives up at once — the entry point still
+    returns 0 (the launch was made), the wait behind it returns MI355_E_DEVICE_FAULT and the word says MI355_ERR_WAIT_EXPIRED; a process of its own: the bound is read once"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import providers, frame_cases, h264_frames as HF\n"
+        "emu = providers.emu()\n"
+        "fs = HF.synth_frames(**frame_cases.CASES['tall_all_intra'])\n"
+        "d = HF.DeviceFrames(emu, fs, tiled=True)\n"
+        "lib = emu.lib\n"
+        "lib.mi355_error_word_take.restype = C.c_uint\n"
+        "lib.mi355_error_word_take()\n"
+        "lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])\n"
+        "lib.mi355_h264_recon_intra_all_dev.restype = C.c_int\n"
+        "lib.mi355_h264_recon_intra_all_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]\n"
+        "assert lib.mi355_h264_recon_intra_all_dev(d.d_desc, d.F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, None) == 0\n"
+        "lib.mi355_sync.restype = C.c_int\n"
+        "rc = lib.mi355_sync(None)\n"
+        "word = lib.mi355_error_word_take()\n"
+        "print('RESULT', rc, word, lib.mi355_sync(None))\n"
+    ) % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MI355_INTRA_NAPS_MAX="0", MI355_INTRA_SINGLE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[1:] == ["-5", "1", "0"], line
+
+
+def test_pipelines_object_joins_calls_on_different_batches_emulated(emu, oracle):
+    """mi355_h264_pipelines_join: calls on another batch (count / array) and joined-always mode go through the waits on every share's loop filter of the call before;
+    the pictures are the same (what the waits order is the device test's business)"""
+    import ctypes as C
+    fs = HF.synth_frames_fast(2, 9, 5, seed=0x2671, lib=emu.lib, partitions="mixed", intra_frac=0.2)
+    recon_o, dst_o = HF.run_oracle(oracle, fs)
+    d = HF.DeviceFrames(emu, fs, tiled=True, replicate=7)
+    lib = emu.lib
+    try:
+        lib.mi355_h264_pipelines_create.restype = C.c_void_p
+        lib.mi355_h264_pipelines_create.argtypes = [C.c_int, C.c_int]
+        lib.mi355_h264_pipelines_decode_dev.restype = C.c_int
+        lib.mi355_h264_pipelines_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.mi355_h264_pipelines_sync.argtypes = [C.c_void_p]
+        lib.mi355_h264_pipelines_join.argtypes = [C.c_void_p, C.c_int]
+        lib.mi355_h264_pipelines_join.restype = None
+        lib.mi355_h264_pipelines_destroy.argtypes = [C.c_void_p]
+        lib.mi355_h264_pipelines_destroy.restype = None
+        lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])
+        p = lib.mi355_h264_pipelines_create(3, 1)
+        assert p
+        for mode, counts in ((1, (7, 5, 7)), (2, (7, 7)), (0, (7, 4))):
+            lib.mi355_h264_pipelines_join(p, mode)
+            for n in counts:
+                assert lib.mi355_h264_pipelines_decode_dev(p, d.d_desc, n, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, 2) == 0
+        assert lib.mi355_h264_pipelines_sync(p) == 0
+        lib.mi355_h264_pipelines_destroy(p)
+        recon_g, dst_g = d.fetch(d.recon, 0, 7), d.fetch(d.dst, 0, 7)
+        for i in range(7):
+            for pl in range(3):
+                assert np.array_equal(recon_o[pl][i % fs.F], recon_g[pl][i]) and np.array_equal(dst_o[pl][i % fs.F], dst_g[pl][i]), (i, pl)
+    finally:
+        d.free()

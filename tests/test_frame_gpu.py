@@ -432,3 +432,41 @@ def test_config2_high10_full_size_matches_the_frame_checker(mi355, oracle):
     every sample of both surfaces of every picture"""
     fs = HF.synth_frames_fast(3, 120, 68, seed=0x264, lib=mi355.lib)
     assert frame_cases.run_case_hbd(mi355, oracle, "config2_high10", 10, fs=fs, replicate=24), "oracle/_ref/libref.so missing"
+
+
+def test_pipelines_object_at_the_bench_share(mi355, oracle):
+    """what bench.py's headline times, at its size: 2049 1080p pictures (two distinct ones) through mi355_h264_pipelines_* as three shares of 683 whose reconstruction
+    launches take turns, two calls one behind the other: every sample of both surfaces of every picture against the oracle"""
+    frame_cases.run_fast_workload_by_layout(mi355, oracle, 2, 120, 68, 0x2268, replicate=2049, pipelined=(3, 1, 2))
+
+
+def test_intra_single_launch_wait_that_runs_out_is_reported(mi355):
+    """k_recon_intra_all's bounded wait (h264_frame.hip): with the bound at zero every macroblock that has an intra neighbour gives up at once — the entry point still
+    returns 0 (the launch was made), the wait behind it returns MI355_E_DEVICE_FAULT and the word says MI355_ERR_WAIT_EXPIRED; a process of its own: the bound is read once"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import providers, frame_cases, h264_frames as HF\n"
+        "emu = providers.mi355()\n"
+        "fs = HF.synth_frames(**frame_cases.CASES['tall_all_intra'])\n"
+        "d = HF.DeviceFrames(emu, fs, tiled=True)\n"
+        "lib = emu.lib\n"
+        "lib.mi355_error_word_take.restype = C.c_uint\n"
+        "lib.mi355_error_word_take()\n"
+        "lw = (C.c_int32 * max(1, fs.max_intra_level))(*fs.level_widths[:fs.max_intra_level])\n"
+        "lib.mi355_h264_recon_intra_all_dev.restype = C.c_int\n"
+        "lib.mi355_h264_recon_intra_all_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]\n"
+        "assert lib.mi355_h264_recon_intra_all_dev(d.d_desc, d.F, fs.mb_w, fs.mb_h, fs.max_intra_level, lw, None) == 0\n"
+        "lib.mi355_sync.restype = C.c_int\n"
+        "rc = lib.mi355_sync(None)\n"
+        "word = lib.mi355_error_word_take()\n"
+        "print('RESULT', rc, word, lib.mi355_sync(None))\n"
+    ) % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MI355_INTRA_NAPS_MAX="0", MI355_INTRA_SINGLE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[1:] == ["-5", "1", "0"], line
