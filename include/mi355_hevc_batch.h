@@ -214,6 +214,25 @@ typedef struct mi355_hevc_lf_picture {
  * then horizontal) and returns.  max_width / max_height: the largest picture of the batch. */
 int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pics, int npics, int max_width, int max_height, int bit_depth, void *stream);
 
+/* a16 + a17 fused per coding tree block: deblocking_filter_CTB (hevc_filter.c:337-505) and sao_filter_CTB (:188-314) of a block's OWN samples as ONE workgroup,
+ * from the unfiltered reconstruction to the output picture: the block and eight samples around it are fetched into LDS, the vertical edges are filtered there,
+ * then the horizontal ones (ff_hevc_deblocking_filter's order), then SAO reads the tile — the deblocked picture is never written and read back (what
+ * mi355_hevc_deblock_pictures_dev followed by mi355_hevc_sao_ctbs_dev does: 2 x 12 KB written and read per 64x64 block at 10 bit), and there is one launch
+ * instead of three.  The output picture is identical to those two entry points' (tests/test_hevc_chain_*.py against the reference's functions).
+ *   d_pics[pic]  the picture as for mi355_hevc_deblock_pictures_dev, `data` = the RECONSTRUCTION, which is only read here;
+ *   d_sao[sao[c]]  the block's job of component c as for mi355_hevc_sao_ctbs_dev: `dst` = the block's first sample in the OUTPUT picture, `src` is not used.
+ * The jobs must be of the whole-region forms (every piece of the owner's type, no restored slice / tile / pcm edge in an edge-offset job, offsets within a signed
+ * byte) — pictures whose slices forbid filtering across their edges take the two separate entry points.  A job of another form is refused on the device: that
+ * component of the block is left unwritten and MI355_ERR_FILTER_CTB_FORM is set in the device's error word (mi355_sync returns MI355_E_DEVICE_FAULT). */
+typedef struct mi355_hevc_filter_ctb_job {
+    int32_t pic;              /* index into d_pics */
+    uint16_t x0, y0;          /* luma position of the block's first sample */
+    uint32_t sao[3];          /* index into d_sao: the block's luma / Cb / Cr job */
+} mi355_hevc_filter_ctb_job;
+int mi355_hevc_filter_ctbs_dev(const mi355_hevc_lf_picture *d_pics, const mi355_hevc_filter_ctb_job *d_ctbs, int n_ctbs, const mi355_hevc_sao_ctb_job *d_sao,
+                               int log2_ctb_size, int bit_depth, void *stream);
+
+
 /* ---- a16, boundary strengths: ff_hevc_deblocking_boundary_strengths (hevc_filter.c:585-725) + boundary_strength
  * (:507-583) for every 4-sample edge segment of a picture at once, from the motion field and the geometry of the blocks
  * the reference calls that function for (transform-tree leaves, hevcdec.c:1451, and coding units without residual,

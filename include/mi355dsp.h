@@ -44,10 +44,11 @@ int mi355_device_count(void);
 
 /* The device's ERROR WORD.  A kernel that cannot do what it was launched for — a bounded wait on another workgroup that ran out
  * (MI355_ERR_WAIT_EXPIRED: the picture it was working on is NOT valid), a coding tree block outside the shapes its caller promised
- * (MI355_ERR_CTB_NOT_UNIFORM: the block was left untouched) — ORs its bit into one word per device, in pinned host memory.  mi355_sync(),
+ * (MI355_ERR_CTB_NOT_UNIFORM: the block was left untouched), a SAO job outside the forms mi355_hevc_filter_ctbs_dev takes (MI355_ERR_FILTER_CTB_FORM: that component of
+ * the block was left unwritten) — ORs its bit into one word per device, in pinned host memory.  mi355_sync(),
  * mi355_event_sync() and mi355_h264_pipelines_sync() read it after their wait and return MI355_E_DEVICE_FAULT (-5) when it is set;
  * mi355_error_word_take() returns the bits and clears them (what a caller does before it repeats the batch another way). */
-enum { MI355_ERR_WAIT_EXPIRED = 1, MI355_ERR_CTB_NOT_UNIFORM = 2, MI355_ERR_TEST = 0x40000000 };
+enum { MI355_ERR_WAIT_EXPIRED = 1, MI355_ERR_CTB_NOT_UNIFORM = 2, MI355_ERR_FILTER_CTB_FORM = 4, MI355_ERR_TEST = 0x40000000 };
 enum { MI355_E_DEVICE_FAULT = -5 };
 unsigned mi355_error_word_take(void);      /* bits set since the last take (this thread's device); 0: none */
 unsigned mi355_error_word_peek(void);

@@ -922,6 +922,350 @@ __global__ void __launch_bounds__(64) k_hevc_recon_level(const mi355_hevc_mcpred
     hevc_residual_run(u.in.t, j, lane < 32, lane >> 5, lane & 31, bd);
 }
 
+/* ---- a16 + a17 fused: deblocking and SAO of a coding tree block in ONE workgroup (mi355_hevc_filter_ctbs_dev) --------------------------------------------
+ * What deblocking_filter_CTB (hevc_filter.c:337-505) and sao_filter_CTB (:188-314) do to a block's own samples, from the UNFILTERED reconstruction to the output
+ * picture, without the deblocked picture ever leaving the chip.  The block and 8 samples around it are fetched into LDS (rows and columns -4 .. size + 3 are
+ * used: a sample of the block's one-sample ring — SAO's neighbours — is changed by edges up to 3 samples away, whose decisions read 4 samples on either side);
+ * vertical edges are filtered there, then horizontal ones on the result (the order of the reference's two passes over a picture: every vertical edge reads
+ * unfiltered samples only, every horizontal one reads what the vertical pass left), then SAO reads the tile and writes the output picture in whole pieces.
+ * Edges on the block's border and in its ring are filtered by this workgroup AND by the neighbour's for its own ring: both start from the same unfiltered
+ * samples and get the same values.  Traffic: the reconstruction read 1.27 times (the ring), the output written once — against read + write for each of the two
+ * deblocking launches' edges and read + write for SAO. */
+constexpr int FT_THREADS = 256, FT_Y = 80, FT_C = 48;      /* tile sides in samples for a 64x64 block: the block + 8 samples each way */
+template <bool WIDE> struct __attribute__((aligned(16))) FtTile {
+    uint8_t y[FT_Y * FT_Y * (WIDE ? 2 : 1)];
+    uint8_t c[2][FT_C * FT_C * (WIDE ? 2 : 1)];
+};
+/* one line of an edge in the tile: the eight samples across it one by one (LDS), the decisions and the arithmetic of hevc_lf_luma_wave */
+__device__ __forceinline__ void ft_lf_luma(uint8_t *pix, int xs, int ys, int beta, const int *tc_, const uint8_t *no_p_, const uint8_t *no_q_, int bd, bool on)
+{
+    const int l = lane_id() & 7;
+    int p[4], q[4], np[3], nq[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p[k] = on ? ldpx(pix, -(k + 1) * xs + l * ys, bd) : 0;
+        q[k] = on ? ldpx(pix, k * xs + l * ys, bd) : 0;
+    }
+    if (!hevc_lf_luma_core(p, q, beta, tc_, no_p_, no_q_, bd, on, np, nq)) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (np[k] != p[k]) stpx(pix, -(k + 1) * xs + l * ys, np[k], bd);
+        if (nq[k] != q[k]) stpx(pix, k * xs + l * ys, nq[k], bd);
+    }
+}
+/* candidates of a pass: the luma edge segments (8 samples along the edge: two halves of 4 with a strength each) that touch rows / columns -4 .. size + 3 of the
+ * block, then those of the two chroma planes (8 chroma samples: two halves of 4 = 8 luma samples each; ring -2 .. size / 2 + 1).  Candidate `cand` of pass DIR ->
+ * everything the filter needs, as two dwords: [0] = tile x | tile y << 8 | plane << 16 | no_p / no_q bits << 24 (the segment's first q-side sample; tile sample
+ * (0, 0) = picture sample (x0 - 8, y0 - 8), chroma likewise in its plane), [1] = beta | tc[0] << 8 | tc[1] << 16 | live << 24 (live: a strength that filters —
+ * luma != 0, chroma 2).  Worked out ONCE per candidate, by one thread, while the tile's samples are on their way (k_hevc_deblock_pictures' groups of eight lanes each
+ * derive their segment's parameters themselves, in front of the samples' loads: three dependent round trips per group of segments). */
+template <int DIR>
+__device__ __forceinline__ uint2 ft_params(const mi355_hevc_lf_picture &p, int x0, int y0, int S, int cand)
+{
+    const LfPic P{ p };
+    const int W = p.width, H = p.height;
+    const int nUl = (S >> 3) + 2, nl = ((S >> 3) + 1) * nUl;
+    const int nUc = DIR ? (S >> 4) + 1 : (S >> 4) + 2, nc = ((S >> 4) + 1) * nUc;
+    const uint8_t *vbs = mi355_global_v(p.vertical_bs), *hbs = mi355_global_v(p.horizontal_bs);
+    int plane = 0, x = 0, y = 0, bs0 = 0, bs1 = 0;
+    bool live = false;
+    if (cand < nl) {
+        const int e = mi355_div20(cand, mi355_inv20(nUl)), u = cand - e * nUl;
+        if (DIR == 0) { x = x0 + 8 * e; y = y0 - 8 + 8 * u; } else { y = y0 + 8 * e; x = x0 - 8 + 8 * u; }
+        if (x >= 0 && y >= 0 && x < W && y < H && (DIR ? y >= 8 : x >= 8)) {
+            if (DIR) { bs0 = hbs[(x + y * p.bs_width) >> 2]; bs1 = hbs[(x + 4 + y * p.bs_width) >> 2]; }
+            else { bs0 = vbs[(x >> 3) + (y >> 2) * p.bs_width]; bs1 = vbs[(x >> 3) + ((y + 4) >> 2) * p.bs_width]; }
+            if (u == 0) bs0 = 0;                       /* the halves beyond the four rows / columns around the block: not this block's business, not in the tile */
+            if (u == nUl - 1) bs1 = 0;
+            live = (bs0 | bs1) != 0;
+        }
+    } else if (cand - nl < 2 * nc) {
+        const int c1 = cand - nl, pl = mi355_div20(c1, mi355_inv20(nc)), c2 = c1 - pl * nc, e = mi355_div20(c2, mi355_inv20(nUc)), u = c2 - e * nUc;
+        plane = 1 + pl;
+        if (DIR == 0) {
+            x = x0 + 16 * e; y = y0 - 16 + 16 * u;
+            if (x >= 16 && x < W && y >= 0 && y < H) {
+                bs0 = vbs[(x >> 3) + (y >> 2) * p.bs_width]; bs1 = vbs[(x >> 3) + ((y + 8) >> 2) * p.bs_width];
+                if (u == 0) bs0 = 0;
+                if (u == nUc - 1) bs1 = 0;
+            }
+        } else {
+            /* the reference's pairs of horizontal chroma segments start at x = 8 (mod 16), i.e. at -8 (hevc_filter.c:469-484); a half outside the picture has bS 0 */
+            y = y0 + 16 * e; x = x0 - 8 + 16 * u;
+            if (y >= 16 && y < H && x < W) {
+                bs0 = x < 0 ? 0 : hbs[(x + y * p.bs_width) >> 2];
+                bs1 = x + 8 >= W ? 0 : hbs[(x + 8 + y * p.bs_width) >> 2];
+            }
+        }
+        live = bs0 == 2 || bs1 == 2;
+    }
+    if (!live) return make_uint2(0u, 0u);
+    int beta = 0, tc[2] = { 0, 0 }, no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+    if (plane == 0) {
+        const mi355_hevc_db_params d = P.db(x, y);
+        const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
+        beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
+        tc[0] = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
+        tc[1] = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
+        if (p.pcmf) {
+            if (DIR) { no_p[0] = P.pcm(x, y - 1); no_p[1] = P.pcm(x + 4, y - 1); no_q[0] = P.pcm(x, y); no_q[1] = P.pcm(x + 4, y); }
+            else { no_p[0] = P.pcm(x - 1, y); no_p[1] = P.pcm(x - 1, y + 4); no_q[0] = P.pcm(x, y); no_q[1] = P.pcm(x, y + 4); }
+        }
+    } else if (DIR) {
+        if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, plane, P.db(x, y).tc_offset);
+        if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, plane, P.db(x + 8, y).tc_offset);
+        if (p.pcmf) { no_p[0] = P.pcm(x, y - 1); no_p[1] = P.pcm(x + 8, y - 1); no_q[0] = P.pcm(x, y); no_q[1] = P.pcm(x + 8, y); }
+    } else {
+        const int tco = P.db(x, y).tc_offset;
+        if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, plane, tco);
+        if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, plane, tco);
+        if (p.pcmf) { no_p[0] = P.pcm(x - 1, y); no_p[1] = P.pcm(x - 1, y + 8); no_q[0] = P.pcm(x, y); no_q[1] = P.pcm(x, y + 8); }
+    }
+    const int tx = plane == 0 ? x - x0 + 8 : (x >> 1) - (x0 >> 1) + 8, ty = plane == 0 ? y - y0 + 8 : (y >> 1) - (y0 >> 1) + 8;
+    /* the pcm / bypass marks as the filters test them: != 0 */
+    const uint32_t nob = (no_p[0] ? 1u : 0u) | (no_p[1] ? 2u : 0u) | (no_q[0] ? 4u : 0u) | (no_q[1] ? 8u : 0u);
+    return make_uint2((uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)plane << 16) | (nob << 24), (uint32_t)beta | ((uint32_t)tc[0] << 8) | ((uint32_t)tc[1] << 16) | (1u << 24));
+}
+/* a pass over the tile: a wave lists the live ones among its candidates (every fourth: a share of the luma and of the chroma segments each) and works through them
+ * eight at a time, eight lanes per segment; nothing but LDS is touched */
+template <int DIR, bool WIDE>
+__device__ __forceinline__ void ft_deblock_pass(FtTile<WIDE> &t, const uint2 *par, int bd, int tid, uint8_t (*s_act)[64])
+{
+    const int wave = tid >> 6, lane = tid & 63, slot = lane >> 3, ps = WIDE ? 1 : 0;
+    const bool cand = (par[lane * 4 + wave].y >> 24) != 0;
+    const unsigned long long live = __ballot(cand);
+    const int count = __popcll(live);
+    if (cand) s_act[wave][__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    MI355_WAVE_SYNC();
+    for (int it = 0; it * 8 < count; it++) {
+        const int k = it * 8 + slot;
+        const bool on = k < count;
+        const uint2 q = par[(int)s_act[wave][on ? k : 0] * 4 + wave];
+        const int tx = (int)(q.x & 0xFF), ty = (int)((q.x >> 8) & 0xFF), plane = (int)((q.x >> 16) & 0xFF);
+        const int beta = (int)(q.y & 0xFF);
+        int tc[2] = { (int)((q.y >> 8) & 0xFF), (int)((q.y >> 16) & 0xFF) };
+        uint8_t no_p[2] = { (uint8_t)((q.x >> 24) & 1), (uint8_t)((q.x >> 25) & 1) }, no_q[2] = { (uint8_t)((q.x >> 26) & 1), (uint8_t)((q.x >> 27) & 1) };
+        const bool luma = plane == 0;
+        const int pitch = luma ? FT_Y : FT_C;
+        uint8_t *pix = (luma ? t.y : (plane == 1 ? t.c[0] : t.c[1])) + ((ty * pitch + tx) << ps);
+        ft_lf_luma(pix, DIR ? pitch : 1, DIR ? 1 : pitch, beta, tc, no_p, no_q, bd, on && luma);
+        hevc_lf_chroma_wave(pix, DIR ? pitch : 1, DIR ? 1 : pitch, tc, no_p, no_q, bd, true, on && !luma);
+    }
+}
+
+/* SAO of a region whose deblocked samples (and their one-sample ring) lie in LDS: sao_region_fast's arithmetic, neighbours from the tile (the pieces before / behind
+ * a piece by whole dwords and a funnel shift), the output picture written in whole 16-byte / 8-byte pieces.  `tile`: the region's sample (0, 0), tp bytes per row. */
+template <bool WIDE, bool EDGE, bool BORDERS>
+__device__ __forceinline__ void ft_sao_region(const uint8_t *tile, int tp, uint8_t *dst, int stride, int W, int H, int eo, int band_position, const int32_t *offset_val,
+                                              int bd, int bo, int first, int nthreads)
+{
+    constexpr int BIAS = 128, PX = WIDE ? 2 : 1;
+    const int per = W >> 3, inv = mi355_inv20(per), shift = bd - 5;
+    const int dx0 = eo == 0 ? -1 : (eo == 1 ? 0 : (eo == 2 ? -1 : 1)), dy0 = eo == 0 ? 0 : -1;
+    uint32_t t_lo, t_hi;
+    if (EDGE) {
+        t_lo = (uint32_t)(offset_val[0] + BIAS) | ((uint32_t)(offset_val[3] + BIAS) << 8) | ((uint32_t)(offset_val[4] + BIAS) << 16) | ((uint32_t)BIAS << 24);
+        t_hi = (uint32_t)BIAS | ((uint32_t)BIAS << 8) | ((uint32_t)(offset_val[1] + BIAS) << 16) | ((uint32_t)(offset_val[2] + BIAS) << 24);
+    } else {
+        t_lo = (uint32_t)(offset_val[1] + BIAS) | ((uint32_t)(offset_val[2] + BIAS) << 8) | ((uint32_t)(offset_val[3] + BIAS) << 16) | ((uint32_t)(offset_val[4] + BIAS) << 24);
+        t_hi = (uint32_t)BIAS * 0x01010101u;
+    }
+    const uint32_t bias2 = (uint32_t)BIAS * 0x00010001u, max2 = (uint32_t)((1 << bd) - 1) * 0x00010001u, bp2 = (uint32_t)band_position * 0x00010001u;
+    /* eight samples at (x + dx, y + dy), dx in -1 .. 1, as pairs: the aligned piece, and for dx != 0 the dword before / behind it shifted in */
+    auto fetch = [&](int x, int y, int dx, uint32_t v[4]) {
+        const uint8_t *q = tile + y * tp + x * PX;
+        SaoRaw r;
+        uint32_t side = 0u;
+        if (WIDE) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(q);
+            r.q[0] = w.x; r.q[1] = w.y; r.q[2] = w.z; r.q[3] = w.w;
+            if (dx) side = *reinterpret_cast<const uint32_t *>(q + (dx < 0 ? -4 : 16));
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2 *>(q);
+            r.q[0] = w.x; r.q[1] = w.y; r.q[2] = r.q[3] = 0u;
+            if (dx) side = *reinterpret_cast<const uint32_t *>(q + (dx < 0 ? -4 : 8));
+        }
+        sao_pairs(r, WIDE, v);
+        if (dx < 0) {
+            const uint32_t prev = WIDE ? side >> 16 : side >> 24;                   /* the sample before the piece */
+            sao_shift_left(v); v[0] |= prev;
+        } else if (dx > 0) {
+            const uint32_t next = WIDE ? side & 0xFFFFu : side & 0xFFu;          /* the sample behind it */
+            sao_shift_right(v); v[3] |= next << 16;
+        }
+    };
+    const int n = per * H;
+    for (int i = first; i < n; i += nthreads) {
+        const int y = mi355_div20(i, inv), x = 8 * (i - y * per);
+        uint32_t c[4], sel[4], v[4];
+        fetch(x, y, 0, c);
+        if (!EDGE) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel[k] = sao_pk_min_u(pk_sub(sao_pk_shr_u(c[k], shift), bp2) & 0x001F001Fu, 0x00040004u);
+        } else {
+            uint32_t a[4], b[4];
+            fetch(x, y + dy0, dx0, a);
+            fetch(x, y - dy0, -dx0, b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel[k] = pk_add(sao_pk_sign(c[k], a[k]), sao_pk_sign(c[k], b[k]));
+            if (BORDERS) {
+                /* a sample without one of its neighbours (the picture ends there): selector 0 = offset_val[0] (hevcdsp_template.c:388-430) */
+                const bool xl = (bo & 1) && x == 0, xr = (bo & 4) && x + 8 == W, yt = (bo & 2) && y == 0, yb = (bo & 8) && y == H - 1;
+                const uint32_t row = dy0 && (yt || yb) ? 0xFFFFFFFFu : 0u;
+                sel[0] &= ~(row | (dx0 && xl ? 0x0000FFFFu : 0u));
+                sel[1] &= ~row;
+                sel[2] &= ~row;
+                sel[3] &= ~(row | (dx0 && xr ? 0xFFFF0000u : 0u));
+            }
+        }
+        const uint32_t s01 = byte_perm(sel[1], sel[0], 0x06040200u) & 0x07070707u, s23 = byte_perm(sel[3], sel[2], 0x06040200u) & 0x07070707u;
+        const uint32_t f01 = byte_perm(t_hi, t_lo, s01), f23 = byte_perm(t_hi, t_lo, s23);
+        const uint32_t off[4] = { mi355_widen_lo(f01), mi355_widen_hi(f01), mi355_widen_lo(f23), mi355_widen_hi(f23) };
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = sao_pk_min_u(sao_pk_subs_u(pk_add(c[k], off[k]), bias2), max2);
+        uint8_t *d = dst + (ptrdiff_t)y * stride + x * PX;
+        if (WIDE) *reinterpret_cast<mi355_sao_u32x4a2 *>(d) = mi355_sao_u32x4a2{ v[0], v[1], v[2], v[3] };
+        else *reinterpret_cast<mi355_sao_u32x2a1 *>(d) = mi355_sao_u32x2a1{ byte_perm(v[1], v[0], 0x06040200u), byte_perm(v[3], v[2], 0x06040200u) };
+    }
+}
+/* the region leaves as it is (SAO off for the block's component) */
+template <bool WIDE>
+__device__ __forceinline__ void ft_copy_region(const uint8_t *tile, int tp, uint8_t *dst, int stride, int W, int H, int first, int nthreads)
+{
+    constexpr int PX = WIDE ? 2 : 1;
+    const int per = W >> 2, inv = mi355_inv20(per);          /* pieces of four samples: a region's width is a multiple of four (chroma of an 8-multiple) */
+    for (int i = first; i < per * H; i += nthreads) {
+        const int y = mi355_div20(i, inv), x = 4 * (i - y * per);
+        const uint8_t *q = tile + y * tp + x * PX;
+        uint8_t *d = dst + (ptrdiff_t)y * stride + x * PX;
+        if (WIDE) { const uint2 w = *reinterpret_cast<const uint2 *>(q); *reinterpret_cast<mi355_sao_u32x2a1 *>(d) = mi355_sao_u32x2a1{ w.x, w.y }; }
+        else { const uint32_t w = *reinterpret_cast<const uint32_t *>(q); __builtin_memcpy(d, &w, 4); }
+    }
+}
+
+static_assert(sizeof(mi355_hevc_filter_ctb_job) == 20, "the record is read by dword index");
+template <bool WIDE, bool VPASS>
+__global__ void __launch_bounds__(FT_THREADS) k_hevc_filter_ctbs(const mi355_hevc_lf_picture *pics, const mi355_hevc_filter_ctb_job *ctbs, int n, const mi355_hevc_sao_ctb_job *sao,
+                                                                 int log2_ctb, int bd, uint32_t *error_word)
+{
+    constexpr int PX = WIDE ? 2 : 1;
+    __shared__ FtTile<WIDE> tile;
+    __shared__ uint8_t s_act[FT_THREADS / 64][64];
+    __shared__ uint2 s_par[2][FT_THREADS];
+    if ((int)blockIdx.x >= n) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int S = 1 << log2_ctb;
+    /* the block's record (5 dwords), then — a dword per lane each — the picture's and the three SAO jobs' */
+    const int brec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(ctbs + blockIdx.x))[lane < 5 ? lane : 4];
+    const int pic = lane_value(brec, 0), x0 = lane_value(brec, 1) & 0xFFFF, y0 = (int)((uint32_t)lane_value(brec, 1) >> 16);
+    const int prec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(pics + pic))[lane < 34 ? lane : 33];
+    /* the SAO job of the component this wave takes in the last phase: luma for every wave's first two rounds; the chroma planes: waves 0, 1 Cb, waves 2, 3 Cr */
+    const mi355_hevc_sao_ctb_job *job_y = sao + (uint32_t)lane_value(brec, 2), *job_c = sao + (uint32_t)lane_value(brec, wave < 2 ? 3 : 4);
+    const int srec_y = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(job_y))[lane < 42 ? lane : 41];
+    const int srec_c = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(job_c))[lane < 42 ? lane : 41];
+    mi355_hevc_lf_picture p;
+    {
+        uint32_t wds[34];
+#pragma unroll
+        for (int k = 0; k < 34; k++) wds[k] = (uint32_t)lane_value(prec, k);
+        __builtin_memcpy(&p, wds, sizeof(p));
+    }
+    const int W = p.width, H = p.height;
+    /* ---- the tile: luma rows / columns -8 .. S + 7 in pieces of eight samples (rows -4 .. S + 3 are used), chroma -8 .. S / 2 + 7 (rows -2 .. S / 2 + 1) */
+    {
+        const int npr = (S >> 3) + 2, nrow = S + 8, inv = mi355_inv20(npr);
+        const uint8_t *src = mi355_global(p.data[0]);
+        uint32_t v[3][4];
+        int at[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = tid + FT_THREADS * u, r = mi355_div20(i, inv), pc = i - r * npr;
+            const int ty = 4 + r, y = y0 - 8 + ty, x = x0 - 8 + 8 * pc;
+            const bool ok = i < npr * nrow && y >= 0 && y < H && x >= 0 && x < W;
+            at[u] = ok ? (ty * FT_Y + 8 * pc) * PX : -1;
+            if (ok) {
+                const uint8_t *q = src + (ptrdiff_t)y * p.linesize[0] + (ptrdiff_t)x * PX;
+                if (WIDE) __builtin_memcpy(v[u], q, 16); else { __builtin_memcpy(v[u], q, 8); v[u][2] = v[u][3] = 0u; }
+            }
+        }
+        const int nprc = (S >> 4) + 2, nrowc = (S >> 1) + 4, invc = mi355_inv20(nprc), Wc = W >> 1, Hc = H >> 1;
+        uint32_t vc[2][4];
+        int atc[2], fullc[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int i = tid, r = mi355_div20(i, invc), pc = i - r * nprc;
+            const int ty = 6 + r, y = (y0 >> 1) - 8 + ty, x = (x0 >> 1) - 8 + 8 * pc;
+            const bool ok = i < nprc * nrowc && y >= 0 && y < Hc && x >= 0 && x + 4 <= Wc;
+            atc[pl] = ok ? (ty * FT_C + 8 * pc) * PX : -1;
+            fullc[pl] = x + 8 <= Wc;                    /* a plane's width is a multiple of four: the last piece of a row may be half a piece */
+            vc[pl][0] = vc[pl][1] = vc[pl][2] = vc[pl][3] = 0u;
+            if (ok) {
+                const uint8_t *q = mi355_global(p.data[1 + pl]) + (ptrdiff_t)y * p.linesize[1 + pl] + (ptrdiff_t)x * PX;
+                if (fullc[pl]) { if (WIDE) __builtin_memcpy(vc[pl], q, 16); else __builtin_memcpy(vc[pl], q, 8); }
+                else { if (WIDE) __builtin_memcpy(vc[pl], q, 8); else __builtin_memcpy(vc[pl], q, 4); }
+            }
+        }
+        MI355_ISSUE_FENCE();
+        /* the segments' parameters while the samples are on their way: this thread's candidate of the vertical and of the horizontal pass */
+        if (VPASS) s_par[0][tid] = ft_params<0>(p, x0, y0, S, tid);
+        s_par[1][tid] = ft_params<1>(p, x0, y0, S, tid);
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (at[u] >= 0) {
+                if (WIDE) *reinterpret_cast<uint4 *>(tile.y + at[u]) = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+                else *reinterpret_cast<uint2 *>(tile.y + at[u]) = make_uint2(v[u][0], v[u][1]);
+            }
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+            if (atc[pl] >= 0) {
+                if (WIDE) *reinterpret_cast<uint4 *>(tile.c[pl] + atc[pl]) = make_uint4(vc[pl][0], vc[pl][1], vc[pl][2], vc[pl][3]);
+                else *reinterpret_cast<uint2 *>(tile.c[pl] + atc[pl]) = make_uint2(vc[pl][0], vc[pl][1]);
+            }
+    }
+    __syncthreads();
+    if (VPASS) {
+        ft_deblock_pass<0, WIDE>(tile, s_par[0], bd, tid, s_act);
+        __syncthreads();
+    }
+    ft_deblock_pass<1, WIDE>(tile, s_par[1], bd, tid, s_act);
+    __syncthreads();
+    /* ---- SAO: rounds 0 and 1 the luma region (every thread), round 2 the chroma regions (threads 0..127 Cb, 128..255 Cr) */
+#pragma unroll 1
+    for (int round = 0; round < 2; round++) {
+        const bool chroma = round == 1;
+        const int rec = chroma ? srec_c : srec_y;
+#define SAO_REC(dw) ((uint32_t)lane_value(rec, (dw)))
+        uint8_t *dst0 = mi355_global(reinterpret_cast<uint8_t *>((uintptr_t)SAO_REC(0) | ((uintptr_t)SAO_REC(1) << 32)));
+        const int stride = (int)SAO_REC(4), np = (int)((SAO_REC(5) >> 8) & 0xFF);
+        const uint32_t p0a = SAO_REC(6 + 5), p0b = SAO_REC(6 + 6), p0c = SAO_REC(6 + 7), p0d = SAO_REC(6 + 8);
+        const int type = (int)((p0a >> 8) & 0xFF), RW = (int)(int16_t)(p0d & 0xFFFF), RH = (int)(int16_t)(p0d >> 16);
+        uint32_t flags = p0b & 0x00FFFFFFu, types = 0;
+        if (np > 1) { flags |= SAO_REC(15 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(15 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        if (np > 2) { flags |= SAO_REC(24 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(24 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        if (np > 3) { flags |= SAO_REC(33 + 6) & 0x00FFFFFFu; types |= ((SAO_REC(33 + 5) >> 8) & 0xFF) ^ (uint32_t)type; }
+        const int32_t ov[5] = { (int32_t)SAO_REC(6), (int32_t)SAO_REC(7), (int32_t)SAO_REC(8), (int32_t)SAO_REC(9), (int32_t)SAO_REC(10) };
+        bool fits = np >= 1 && (p0a & 0xFF) == 0 && p0c == 0 && types == 0 && (RW & 3) == 0;
+        for (int e = 0; e < 5; e++) fits = fits && ov[e] > -128 && ov[e] < 128;
+        if (type == 2) fits = fits && flags == 0 && (RW & 7) == 0;
+        if (type == 1) fits = fits && (RW & 7) == 0;
+        /* the region in the tile, this thread's first step and the step count's stride */
+        const uint8_t *region = chroma ? tile.c[wave < 2 ? 0 : 1] + (8 * FT_C + 8) * PX : tile.y + (8 * FT_Y + 8) * PX;
+        const int tp = (chroma ? FT_C : FT_Y) * PX, first = chroma ? (tid & 127) : tid, nth = chroma ? 128 : FT_THREADS;
+        if (!fits) {
+            /* a job outside the whole-region forms (pieces of different kinds, an edge that is restored, offsets beyond a byte): this entry point does not take it —
+             * the block's component is left unwritten and the device says so (include/mi355_hevc_batch.h) */
+            if (error_word && lane == 0) atomicOr(error_word, (uint32_t)MI355_ERR_FILTER_CTB_FORM);
+            continue;
+        }
+        const int eo = (int)((p0a >> 16) & 0xFF), bp = (int)(p0a >> 24), bo = type == 2 ? (int)(p0b >> 24) : 0;
+        if (type == 0) ft_copy_region<WIDE>(region, tp, dst0, stride, RW, RH, first, nth);
+        else if (type == 1) ft_sao_region<WIDE, false, false>(region, tp, dst0, stride, RW, RH, eo, bp, ov, bd, 0, first, nth);
+        else if (bo) ft_sao_region<WIDE, true, true>(region, tp, dst0, stride, RW, RH, eo, bp, ov, bd, bo, first, nth);
+        else ft_sao_region<WIDE, true, false>(region, tp, dst0, stride, RW, RH, eo, bp, ov, bd, 0, first, nth);
+#undef SAO_REC
+    }
+}
+
 bool check(int bit_depth, const void *jobs, int n)
 {
     /* bind(): the calling thread's device (mi355_set_device, else mi355_init's) — not whatever device the thread last used */
@@ -987,7 +1331,9 @@ extern "C" int mi355_hevc_deblock_pictures_dev(const mi355_hevc_lf_picture *d_pi
 {
     if (!check(bit_depth, d_pics, npics) || max_width <= 0 || max_height <= 0) return -1;
     const int lc = (max_width + 7) / 8, lr = (max_height + 7) / 8;
+    static const int dirs = std::getenv("MI355_DEBLOCK_DIRS") ? std::atoi(std::getenv("MI355_DEBLOCK_DIRS")) : 3;      /* developer experiment: bit 0 vertical edges, bit 1 horizontal */
     for (int dir = 0; dir < 2; dir++) {
+        if (!(dirs & (1 << dir))) continue;
         /* horizontal chroma segments start at x = -8: one more column may be needed */
         const int cc = dir ? (max_width + 8 + 15) / 16 : (max_width + 15) / 16, cr = (max_height + 15) / 16;
         const int lw = (lc * lr + 63) / 64, cw = (2 * cc * cr + 63) / 64;      /* a wave takes 64 candidate segments */
@@ -1021,6 +1367,20 @@ extern "C" int mi355_hevc_sao_ctbs_dev(const mi355_hevc_sao_ctb_job *d_jobs, int
     if (!check(bit_depth, d_jobs, n)) return -1;
     if (bit_depth > 8) hipLaunchKernelGGL(k_hevc_sao_ctbs<true>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     else hipLaunchKernelGGL(k_hevc_sao_ctbs<false>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int mi355_hevc_filter_ctbs_dev(const mi355_hevc_lf_picture *d_pics, const mi355_hevc_filter_ctb_job *d_ctbs, int n_ctbs, const mi355_hevc_sao_ctb_job *d_sao,
+                                          int log2_ctb_size, int bit_depth, void *stream)
+{
+    if (!check(bit_depth, d_ctbs, n_ctbs) || !d_pics || !d_sao || log2_ctb_size < 4 || log2_ctb_size > 6) return -1;
+    uint32_t *err = mi355::error_word();
+    if (!err) return -4;
+    static const bool skip_v = std::getenv("MI355_FT_SKIP_V") != nullptr;      /* developer experiment: the vertical edges were filtered in the picture before (profiles/r06_experiments.md) */
+    if (skip_v) {
+        if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_filter_ctbs<true, false>), dim3((unsigned)n_ctbs), dim3(FT_THREADS), 0, (hipStream_t)stream, d_pics, d_ctbs, n_ctbs, d_sao, log2_ctb_size, bit_depth, err);
+        else hipLaunchKernelGGL((k_hevc_filter_ctbs<false, false>), dim3((unsigned)n_ctbs), dim3(FT_THREADS), 0, (hipStream_t)stream, d_pics, d_ctbs, n_ctbs, d_sao, log2_ctb_size, bit_depth, err);
+    } else if (bit_depth > 8) hipLaunchKernelGGL((k_hevc_filter_ctbs<true, true>), dim3((unsigned)n_ctbs), dim3(FT_THREADS), 0, (hipStream_t)stream, d_pics, d_ctbs, n_ctbs, d_sao, log2_ctb_size, bit_depth, err);
+    else hipLaunchKernelGGL((k_hevc_filter_ctbs<false, true>), dim3((unsigned)n_ctbs), dim3(FT_THREADS), 0, (hipStream_t)stream, d_pics, d_ctbs, n_ctbs, d_sao, log2_ctb_size, bit_depth, err);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_edge_emu_batch_dev(const mi355_edge_emu_job *d_jobs, int n, int bit_depth, void *stream)

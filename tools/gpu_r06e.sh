@@ -13,4 +13,9 @@ for round in 1 2; do
 done
 rm -rf /tmp/prof_f; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -- python $GRAFT_REPO_ROOT/tools/hevc_chain.py 64 > /tmp/prof_f.log 2>&1 )
 cp $(find /tmp/prof_f -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_hevc_chain.csv
-grep "k_hevc\|k_edge" $OUT/kernel_stats_hevc_chain.csv | sed 's/(anonymous namespace):://; s/(.*)"//' | awk -F, '{printf "%s %.3f ms\n", $1, $4/1e6}'
+python3 - $OUT/kernel_stats_hevc_chain.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "k_hevc" in r["Name"] or "k_edge" in r["Name"]:
+        print(r["Name"].replace("(anonymous namespace)::", "").split("(")[0][:60], round(float(r["AverageNs"]) / 1e6, 3), "ms")
+PY

@@ -29,6 +29,7 @@ SAO_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("width", 
                    ("vert_edge", "u1"), ("horiz_edge", "u1"), ("diag_edge", "u1")])
 PIECE_DT = np.dtype([("offset_val", "<i4", 5), ("cls", "u1"), ("type", "u1"), ("eo_class", "u1"), ("band_position", "u1"), ("vert_edge", "u1"),
                      ("horiz_edge", "u1"), ("diag_edge", "u1"), ("borders", "u1"), ("dx", "<i2"), ("dy", "<i2"), ("width", "<i2"), ("height", "<i2")])
+FCTB_DT = np.dtype([("pic", "<i4"), ("x0", "<u2"), ("y0", "<u2"), ("sao", "<u4", 3)])
 SAOC_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("stride", "<i4"), ("c_idx", "u1"), ("npieces", "u1"), ("rsv", "u1", 2), ("piece", PIECE_DT, 4)])
 EE_DT = np.dtype([("dst", "<u8"), ("src", "<u8"), ("dst_stride", "<i4"), ("src_stride", "<i4"), ("block_w", "<i4"), ("block_h", "<i4"),
                   ("src_x", "<i4"), ("src_y", "<i4"), ("w", "<i4"), ("h", "<i4")])
@@ -40,12 +41,15 @@ BYTES_PER_CTB = 73984
 
 
 class Chain:
-    def __init__(self, lib, pictures, distinct=2, seed=0x265, width=W, height=H, bd=BD, fused=True):
+    def __init__(self, lib, pictures, distinct=2, seed=0x265, width=W, height=H, bd=BD, fused=True, filter_fused=None):
         """width, height: multiples of 64 x 16 at least (the bench: 3840 x 2160); the parity tests run smaller pictures.  self.host keeps
         what the CPU side (oracle/ref_hevc_chain.c: the reference's own functions) needs to decode the same pictures."""
         W, H, BD, PX = width, height, bd, (2 if bd > 8 else 1)
         self.W, self.H, self.BD, self.PX = W, H, BD, PX
         self.fused = fused
+        # MI355_CHAIN_FILTER_FUSED=1: deblocking + SAO of a coding tree block in one workgroup (mi355_hevc_filter_ctbs_dev: the deblocked picture never leaves the chip) instead
+        # of the picture-level deblocking launches and the SAO launch.  Measured in round 6 (profiles/r06_experiments.md): 1.7 - 1.8 ms against 0.53 + 0.78 ms — not the default
+        self.filter_fused = bool(os.environ.get("MI355_CHAIN_FILTER_FUSED")) if filter_fused is None else filter_fused
         self.recon_flags = 0 if os.environ.get("MI355_CHAIN_NO_PROMISE") else 1      # MI355_HEVC_RECON_UNIFORM: this generator makes 32x32 one-reference blocks and 32x32 units only
         self.lib, self.P = lib, pictures
         lib.mi355_malloc.restype = C.c_void_p
@@ -228,6 +232,15 @@ class Chain:
                 npieces = npieces + have
             sao["npieces"][:, c] = npieces[None].astype(np.uint8)
         self.n_sao, self.d_sao = sao.size, self.up(sao)
+        # the fused form's block list: picture, position, the three components' SAO jobs
+        fctb = np.zeros((P, ncy, ncx), FCTB_DT)
+        fctb["pic"] = np.arange(P, dtype=np.int32)[:, None, None]
+        fctb["x0"], fctb["y0"] = (cx * 64)[None], (cy * 64)[None]
+        for c in range(3):
+            fctb["sao"][..., c] = ((np.arange(P)[:, None, None] * 3 + c) * ncy + cy[None]) * ncx + cx[None]
+        self.n_fctb, self.d_fctb = fctb.size, self.up(fctb)
+        self.lib.mi355_hevc_filter_ctbs_dev.restype = C.c_int
+        self.lib.mi355_hevc_filter_ctbs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         # credited units: the CTBs the chain codes COMPLETELY (prediction + residual of luma and chroma: H // 64 rows; VERDICT r3: the 34th,
         # partial CTB row of 2160 lines gets luma blocks for its first 32 lines only and no chroma units — filtered and SAO'd, not credited)
         self.ctbs = P * (W // 64) * (H // 64)
@@ -320,8 +333,13 @@ class Chain:
         else:
             around(1, lambda: L.mi355_hevc_mcpred_batch_dev(C.c_void_p(self.d_mp), self.n_mp, self.BD, stream))
             around(2, lambda: L.mi355_hevc_residual_batch_dev(C.c_void_p(self.d_tu), self.n_tu, self.BD, stream))
-        around(3, lambda: L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, stream))
-        around(4, lambda: L.mi355_hevc_sao_ctbs_dev(C.c_void_p(self.d_sao), self.n_sao, self.BD, stream))
+        if self.filter_fused:
+            if os.environ.get("MI355_FT_SKIP_V"):          # developer experiment: vertical edges in the picture (MI355_DEBLOCK_DIRS=1), horizontal edges + SAO fused
+                around(3, lambda: L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, stream))
+            around(4, lambda: L.mi355_hevc_filter_ctbs_dev(C.c_void_p(self.d_lf), C.c_void_p(self.d_fctb), self.n_fctb, C.c_void_p(self.d_sao), 6, self.BD, stream))
+        else:
+            around(3, lambda: L.mi355_hevc_deblock_pictures_dev(C.c_void_p(self.d_lf), self.P, self.W, self.H, self.BD, stream))
+            around(4, lambda: L.mi355_hevc_sao_ctbs_dev(C.c_void_p(self.d_sao), self.n_sao, self.BD, stream))
 
     def free(self):
         for p in self.bufs:
@@ -447,14 +465,14 @@ def surfaces(ch, fill=0):
     return [np.full((ch.H, ch.W), fill, dt), np.full((2, ch.H // 2, ch.W // 2), fill, dt)]
 
 
-def check_against_reference(lib, pictures=2, width=256, height=192, bd=10, seed=0x265, fused=True):
+def check_against_reference(lib, pictures=2, width=256, height=192, bd=10, seed=0x265, fused=True, filter_fused=None):
     """the measured chain at any size: device pictures (reconstruction after deblocking, SAO output) of every picture against the
     reference's own functions on the same parameters.  Surfaces start zeroed on both sides (the chain leaves the rows below the
     last whole 32 / 64 block unpredicted, as the workload is defined)."""
     ref = ref_library()
     assert ref is not None, "oracle/_ref/libhevcfilterref.so (with ref_hevc_chain.c) is missing"
     lib.mi355_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-    ch = Chain(lib, pictures, distinct=min(2, pictures), seed=seed, width=width, height=height, bd=bd, fused=fused)
+    ch = Chain(lib, pictures, distinct=min(2, pictures), seed=seed, width=width, height=height, bd=bd, fused=fused, filter_fused=filter_fused)
     try:
         zero = np.zeros(pictures * ch.ysz, np.uint8)
         for base, n in ((ch.rec_y, ch.ysz), (ch.out_y, ch.ysz), (ch.rec_c, 2 * ch.csz), (ch.out_c, 2 * ch.csz)):
@@ -469,8 +487,9 @@ def check_against_reference(lib, pictures=2, width=256, height=192, bd=10, seed=
             for arr, base, n in ((got_cur[0], ch.rec_y + p * ch.ysz, ch.ysz), (got_cur[1], ch.rec_c + 2 * p * ch.csz, 2 * ch.csz),
                                  (got_out[0], ch.out_y + p * ch.ysz, ch.ysz), (got_out[1], ch.out_c + 2 * p * ch.csz, 2 * ch.csz)):
                 assert lib.mi355_memcpy_d2h(arr.ctypes.data, base, n) == 0
-            for name, a, b in (("deblocked luma", got_cur[0], cur[0]), ("deblocked chroma", got_cur[1], cur[1]), ("SAO luma", got_out[0], out[0]),
-                               ("SAO chroma", got_out[1], out[1])):
+            # the fused filters never write the deblocked picture: its surfaces keep the unfiltered reconstruction, and the output is what is compared
+            for name, a, b in ((("deblocked luma", got_cur[0], cur[0]), ("deblocked chroma", got_cur[1], cur[1])) if not ch.filter_fused else ()) + (
+                               ("SAO luma", got_out[0], out[0]), ("SAO chroma", got_out[1], out[1])):
                 assert np.array_equal(a, b), "picture %d: %s differs from the reference's functions (%d samples)" % (p, name, int((a != b).sum()))
         return ch.n_ee
     finally:
