@@ -141,12 +141,13 @@ __device__ __forceinline__ void cf_idct_load(CfRaw &raw, const uint8_t *coeffs, 
 }
 
 /* tile: the block's sample (0, 0) in LDS, `pitch` bytes per row; WIDE: 16-bit samples */
-template <int LOG2, bool WIDE>
-__device__ __forceinline__ void cf_idct_run(const CfRaw &raw, int col_limit, int bd, uint8_t *tile, int pitch, int lane)
+/* DENSE (compile-time: which tiles take part is then known, and the products of a pass are one stretch of straight-line code) */
+template <int LOG2, bool WIDE, bool DENSE>
+__device__ __forceinline__ void cf_idct_run_n(const CfRaw &raw, int bd, uint8_t *tile, int pitch, int lane)
 {
     constexpr int NT = (1 << LOG2) / 16;
     const int j = lane & 15, g = lane >> 4;
-    const bool dense = cf_idct_dense<LOG2>(col_limit);
+    constexpr bool dense = DENSE;
     const int zero4[4] = { 0, 0, 0, 0 };
     /* byte planes of the fetched rows: first operands of the transposing products */
     uint64_t alo[2], ahi[2];
@@ -229,6 +230,13 @@ __device__ __forceinline__ void cf_idct_run(const CfRaw &raw, int col_limit, int
             }
         }
     }
+}
+
+template <int LOG2, bool WIDE>
+__device__ __forceinline__ void cf_idct_run(const CfRaw &raw, int col_limit, int bd, uint8_t *tile, int pitch, int lane)
+{
+    if (cf_idct_dense<LOG2>(col_limit)) cf_idct_run_n<LOG2, WIDE, true>(raw, bd, tile, pitch, lane);
+    else cf_idct_run_n<LOG2, WIDE, false>(raw, bd, tile, pitch, lane);
 }
 
 /* ---- motion compensation of one tile (16 or 32 samples each way) + put_unweighted_pred into LDS -------------------------------------- */

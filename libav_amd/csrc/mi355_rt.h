@@ -69,6 +69,12 @@ __device__ __forceinline__ int mi355_div20(int i, int inv) { return (int)(__umul
 #else
 #define MI355_ISSUE_FENCE() asm volatile("" ::: "memory")
 #endif
+/* the instruction scheduler does not move anything across this point (a straight-line stretch in groups: registers of one group are free before the next one's loads go out) */
+#if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
+#define MI355_SCHED_BARRIER() ((void)0)
+#else
+#define MI355_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 /* make a just-loaded value "used" at this point, so that the wait for it is placed here and not at a later join */
 #if defined(MI355_HIP_EMU_H) || !defined(__HIP_DEVICE_COMPILE__)
 #define MI355_PIN(v) ((void)(v))
