@@ -161,6 +161,7 @@ typedef struct Bridge {
     struct Disp *disp;          /* ... and its dispatcher (batched mode) */
     mi355_h264_session *sess;   /* MI355_BRIDGE_SESSION: pictures go through a whole-frame session; pics[i] is surface i */
     int null_submit;            /* MI355_BRIDGE_NULL (developer): pictures are packed and dropped — times the host side alone */
+    int keep_field_idc2;        /* MI355_BRIDGE_KEEP_FIELD_IDC2 (tests): field pictures with disable_deblocking_filter_idc 2 are not handed back to the C path */
     int mb_w, mb_h, nmb;
     void *stream;               /* direct mode */
     Staging st[2];
@@ -565,6 +566,8 @@ static Bridge *bridge_get(const H264Context *h)
         b->lazy = getenv("MI355_BRIDGE_LAZY") != NULL;
         b->direct = getenv("MI355_BRIDGE_DIRECT") != NULL;
         b->null_submit = getenv("MI355_BRIDGE_NULL") != NULL;
+        /* tests: field pictures with disable_deblocking_filter_idc 2 stay on the device (streams on which the reference's inconsistency does not show: see hl_decode_mb below) */
+        b->keep_field_idc2 = getenv("MI355_BRIDGE_KEEP_FIELD_IDC2") != NULL;
         /* MI355_BRIDGE_MAX_SLICES: a smaller slice table (tests: a picture with more slices than the path holds) */
         const int ms = getenv("MI355_BRIDGE_MAX_SLICES") ? atoi(getenv("MI355_BRIDGE_MAX_SLICES")) : BR_MAX_SLICES;
         b->max_slices = ms < 1 ? 1 : (ms > BR_MAX_SLICES ? BR_MAX_SLICES : ms);
@@ -578,6 +581,14 @@ static Bridge *bridge_get(const H264Context *h)
     if ((seq_mbaff && getenv("MI355_BRIDGE_NO_WIDE")) || (h->mb_height & 1 && !h->ps.sps->frame_mbs_only_flag) || h->ps.sps->bit_depth_luma > 10 || h->ps.sps->bit_depth_luma != h->ps.sps->bit_depth_chroma ||
         (idc != 1 && idc != 2 && idc != 3) || h->ps.sps->residual_color_transform_flag || (getenv("MI355_BRIDGE_NO_WIDE") && (h->pixel_shift || idc == 2 || h->ps.sps->transform_bypass))) {
         br_fail(b, "stream outside the batched path (needs 8- to 10-bit 4:2:0, 4:2:2 or 4:4:4)");
+        b->soft = 1;
+        return b;
+    }
+    /* pictures one macroblock wide, and two wide with chroma planes of their own: the reference's decoder is not consistent with ITSELF there (one wide: a P macroblock
+     * with 4-wide partitions and zero vectors is not a copy of its reference; two wide: the Cr intermediate of two-reference weighted prediction overwrites the Cb one,
+     * h264_mb.c:407-409 — bipred_scratchpad rows are mb_uvlinesize apart, 16 bytes there).  What it outputs for such streams is its business: they stay on its path */
+    if (h->mb_width == 1 || (h->mb_width == 2 && idc != 3)) {
+        br_fail(b, "pictures one or two macroblocks wide are left to the reference's decoder (its bi-prediction scratch rows overlap there: h264_mb.c:407-409)");
         b->soft = 1;
         return b;
     }
@@ -889,6 +900,17 @@ void __wrap_ff_h264_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
 {
     Bridge *b = bridge_get(h);
     if (!b || b->state < 0) { __real_ff_h264_hl_decode_mb(h, sl); return; }
+    if (!b->open && h->picture_structure != PICT_FRAME && sl->deblocking_filter == 2 && !b->keep_field_idc2) {
+        /* a FIELD picture whose slices filter only their own edges: whether the reference predicts an intra macroblock from the unfiltered or from the filtered above-left
+         * sample it decides from slice_table[mb_xy - 1 - mb_stride] (h264_mb.c:525-527) — in a field picture the OTHER field's row, whose entries an earlier picture
+         * left.  The device predicts from unfiltered samples throughout (the standard's rule) and has no filtered ones at that point: such pictures are the reference's.
+         * Seen at the picture's first macroblock: nothing of it has been packed, the pictures in flight come back, the decoder continues on its own path.  (A picture
+         * that reaches this combination only in a later slice stays here.) */
+        br_fail(b, "field picture with disable_deblocking_filter_idc 2 (the reference decides its intra border from the other field's slice table: h264_mb.c:525-527)");
+        b->soft = 1;
+        __real_ff_h264_hl_decode_mb(h, sl);
+        return;
+    }
     if (!b->open) begin_picture(b, h);
     if (b->state < 0) { __real_ff_h264_hl_decode_mb(h, sl); return; }
     Staging *st = &b->st[b->cur];

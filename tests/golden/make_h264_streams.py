@@ -1088,6 +1088,11 @@ STREAMS = {
     "420_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=1, depth=8, seed=61, nslices=2, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True),
     "444_8_lossless": dict(mb_w=5, mb_h=4, chroma_idc=3, depth=8, seed=62, nslices=1, deblock_idc=0, nrefs=2, npics=6, weighted=False, lossless=True, t8x8=True),
     "422_10_lossless": dict(mb_w=4, mb_h=4, chroma_idc=2, depth=10, seed=63, nslices=1, deblock_idc=0, nrefs=2, npics=5, weighted=False, lossless=True),
+    # the two places where the reference's decoder is not consistent with itself: pictures two macroblocks wide with two-reference weighted
+    # prediction (h264_mb.c:407-409: the Cr intermediate overwrites the Cb one), field pictures with disable_deblocking_filter_idc 2 and intra macroblocks
+    # (h264_mb.c:525-527: the other field's row of slice_table decides the above-left border).  The bridge leaves such pictures to the C path.
+    "420_8_2wide_b": dict(mb_w=2, mb_h=5, chroma_idc=1, depth=8, seed=171, nslices=1, deblock_idc=0, nrefs=2, npics=7, bmode=2),
+    "420_8_paff_idc2_intra": dict(mb_w=6, mb_h=6, chroma_idc=1, depth=8, seed=172, nslices=2, deblock_idc=2, nrefs=2, npics=8, paff=True, cip=True, mixed=True),
     "422_8_bframes": dict(mb_w=6, mb_h=4, chroma_idc=2, depth=8, seed=34, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=1),
     "420_10_bframes": dict(mb_w=6, mb_h=4, chroma_idc=1, depth=10, seed=35, nslices=2, deblock_idc=0, nrefs=2, npics=7, bmode=2),
 }

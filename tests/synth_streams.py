@@ -14,12 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 MD5 = json.load(open(os.path.join(GOLD, "h264_synth_ref_md5.json")))
 ALL = sorted(MD5)
-CLASSIC = [n for n in ALL if n.startswith(("420_8_", "444_8")) and "lossless" not in n and "mbaff" not in n]            # 8-bit 4:2:0 and 4:4:4: the first kernel set
+# the two places where the reference's decoder is not consistent with itself: the bridge hands such pictures to the C path
+QUIRKS = ["420_8_2wide_b", "420_8_paff_idc2_intra"]
+CLASSIC = [n for n in ALL if n.startswith(("420_8_", "444_8")) and "lossless" not in n and "mbaff" not in n and n not in QUIRKS]            # 8-bit 4:2:0 and 4:4:4: the first kernel set
 # High 10 (9 / 10 bit), High 4:2:2 (8 / 10 bit), 4:4:4 at 10 bit, and transform bypass at any of these and at 8-bit 4:2:0 / 4:4:4: the second kernel set
 # (mi355_h264_decode_frames_wide_dev); MBAFF frames (macroblock pairs) at every format too
 WIDE = [n for n in ALL if n.startswith(("420_10", "420_9", "422_", "444_10")) or "lossless" in n or "mbaff" in n]
 BRIDGE = CLASSIC + WIDE                                                                                                   # what Tier 2 decodes
-OUTSIDE = [n for n in ALL if n not in BRIDGE and n not in ("mixed_formats", "paff_and_frames")]                           # nothing any more
+OUTSIDE = [n for n in ALL if n not in BRIDGE and n not in ("mixed_formats", "paff_and_frames") and n not in QUIRKS]                           # nothing any more
 # field pictures: the bridge counts pictures (a frame coded as two fields is two), the md5 file counts output frames
 ON_DEVICE = {"420_8_paff": 13, "420_8_paff_b": 19, "420_8_paff_t8x8": 14, "444_8_paff": 8, "422_10_paff": 10}
 EXPORTED = ["420_8_slices", "420_8_qcif", "420_8_nofilter", "420_8_b_implicit", "420_8_b_explicit", "420_8_b_average", "420_8_t8x8", "420_8_cip_mixed", "420_8_reorder_b"]
@@ -49,8 +51,13 @@ def run_tier1(which, name, out, plain=False):
     return lines[0]
 
 
-def run_bridge(which, name, out, threads=1, lazy=False, direct=False, loops=1, session=False, no_wide=False):
+def run_bridge(which, name, out, threads=1, lazy=False, direct=False, loops=1, session=False, no_wide=False, keep_field_idc2=True):
     env = dict(os.environ)
+    # field pictures with disable_deblocking_filter_idc 2 stay on the device in every test but the one of the hand-over (the fixtures' streams are ones on which the
+    # reference's inconsistency does not show: identical output either way)
+    env.pop("MI355_BRIDGE_KEEP_FIELD_IDC2", None)
+    if keep_field_idc2:
+        env["MI355_BRIDGE_KEEP_FIELD_IDC2"] = "1"
     for k in ("MI355_BRIDGE_LAZY", "MI355_BRIDGE_DIRECT", "MI355_BRIDGE_PLAIN", "MI355_BRIDGE_SESSION", "MI355_BRIDGE_LINEAR", "MI355_BRIDGE_NO_WIDE"):
         env.pop(k, None)
     if no_wide:

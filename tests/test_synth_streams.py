@@ -99,6 +99,24 @@ def test_bridge_steps_aside_for_streams_outside_tier2(tmp_path, emu, name, no_wi
 
 
 @needs_harness
+@pytest.mark.parametrize("name,on_device", (("420_8_2wide_b", 0), ("420_8_paff_idc2_intra", None)))
+def test_bridge_leaves_the_reference_s_inconsistent_cases_to_it(tmp_path, emu, name, on_device):
+    """pictures two macroblocks wide with two-reference weighted prediction (h264_mb.c:407-409), field pictures with disable_deblocking_filter_idc 2
+    (h264_mb.c:525-527): the reference's output there follows from its own buffers, not from the standard — the bridge says so once and hands the decoder back
+    (the whole stream / from the first such field picture on); the output is the reference's"""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(SY.ROOT, "oracle"), "_ref/h264_bridge_emu"], check=True)
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_emu", name, out, keep_field_idc2=False)
+    assert st.get("pictures_output") == SY.MD5[name]["pictures"], st
+    if on_device is None:
+        assert 0 < st.get("pictures_on_device") < SY.MD5[name]["pictures"], st        # the frame pictures before the first field picture were the device's
+    else:
+        assert st.get("pictures_on_device") == on_device, st
+    SY.check_md5(out, name)
+
+
+@needs_harness
 @pytest.mark.parametrize("name,on_device,frames", (("mixed_formats", 12, 12), ("paff_and_frames", 23, 17)))
 @pytest.mark.parametrize("lazy,direct", ((False, False), (True, False), (False, True)))
 def test_bridge_follows_sequence_changes_emulated(tmp_path, emu, lazy, direct, name, on_device, frames):

@@ -117,3 +117,18 @@ def test_bridge_decodes_1080p_streams_gpu(tmp_path, mi355, fn):
         assert st["pictures_output"] == 40 and st["pictures_on_device"] == (40 if mode == "bridge" else 0), st
         md5[mode] = hashlib.md5(open(out, "rb").read()).hexdigest()
     assert md5["plain"] == md5["bridge"]
+
+
+@pytest.mark.parametrize("name,on_device", (("420_8_2wide_b", 0), ("420_8_paff_idc2_intra", None)))
+def test_bridge_leaves_the_reference_s_inconsistent_cases_to_it_gpu(tmp_path, mi355, name, on_device):
+    """as tests/test_synth_streams.py: pictures two macroblocks wide (h264_mb.c:407-409) and field pictures with disable_deblocking_filter_idc 2 (:525-527) are
+    handed back to the reference's decoder; the output is the reference's"""
+    _need("h264_bridge_gpu")
+    out = tmp_path / "o.yuv"
+    st = SY.run_bridge("h264_bridge_gpu", name, out, keep_field_idc2=False)
+    assert st.get("pictures_output") == SY.MD5[name]["pictures"], st
+    if on_device is None:
+        assert 0 < st.get("pictures_on_device") < SY.MD5[name]["pictures"], st
+    else:
+        assert st.get("pictures_on_device") == on_device, st
+    SY.check_md5(out, name)
