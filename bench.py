@@ -495,8 +495,10 @@ def extra_points(lib, prov, mbw, mbh, tiled=True):
         "same figure); verified by tests/test_frame_gpu.py::test_full_size_1080p_mixed_partitions_matches_oracle")
     run("config2_f2048_one_pipeline", base, 2048, "the headline batch as ONE pipeline on one stream: the three passes over all 2048 pictures one after the other "
         "(how rounds 1-4 measured the headline; pass_ms here are the passes' own times)")
-    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step ")
-    run("config2_f512", base, 512, "512 pictures per step")
+    # small batches run as the headline does — three shares through the library's pipelines object (profiles/r06_experiments.md 6: 512 pictures 35.9 -> 40.3 %,
+    # 64 pictures 15.7 -> 17.7 %: there the loop filter's chain of dependent steps per picture is the step)
+    run("config2_f64", base, 64, "SURVEY 8d's stated batch: 64 pictures per step, three shares on streams ", pipelines=3)
+    run("config2_f512", base, 512, "512 pictures per step, three shares on streams", pipelines=3)
     intra = HF.synth_frames_fast(2, mbw, mbh, seed=0x1264, lib=lib, intra_frac=1.0)
     run("all_intra_f512", intra, 512, "I pictures: every macroblock Intra16x16, %d dependency levels = launches of k_recon_intra; the inter pass is not launched for a batch of I pictures" % intra.max_intra_level)
     smooth = HF.synth_frames_fast(4, mbw, mbh, seed=0x2264, lib=lib, refs="smooth", coef_b=4)
