@@ -162,12 +162,19 @@ __device__ __forceinline__ bool ctb_predict(CtbTile &tile, Scratch &s, const Ctb
             ph = j.mx0 ? cf_pass(k_qpel[j.mx0], 8, bd - 8) : cf_pass_one(1, 0);
             pv = j.my0 ? cf_pass(k_qpel[j.my0], 8, j.mx0 ? 6 : bd - 8) : cf_pass_one(j.mx0 ? 1 : 1 << (14 - bd), 0);
         }
+        /* (one tile at a time: unrolled, the tiles of a job — two planes, up to four tiles a plane — would be scheduled into each other and hold twice the registers) */
+#pragma unroll 1
         for (int plane = 0; plane < (j.chroma == 2 ? 2 : 1); plane++) {
             const uint8_t *src = mi355_global(plane ? j.src0_b : j.src0);
             uint8_t *tp = plane ? t1 : t0;
+#pragma unroll 1
             for (int ty = 0; ty < j.height; ty += 32)
+#pragma unroll 1
             for (int tx = 0; tx < j.width; tx += 32) {
                 const int tw = j.width - tx < 32 ? j.width - tx : 32, th = j.height - ty < 32 ? j.height - ty : 32;
+                /* the lane's number anew for every tile: the constants a tile derives from it (piece and row of the fetch, operand addresses, tap words) are loop
+                 * invariants to the compiler, and taken out of the loops they hold ~50 registers for the life of the kernel */
+                MI355_PIN(lane);
                 cf_mc_tile<WIDE>(s.win, src + (ptrdiff_t)(ty - by) * j.src0_stride + (ptrdiff_t)(tx - bx) * px, j.src0_stride, tw, th, ph, pv, bd,
                                  tp + ty * pitch + tx * px, pitch, lane);
             }
@@ -336,8 +343,12 @@ __device__ __forceinline__ void ctb_turns(const mi355_hevc_ctb_job *ctbs, int n_
         /* the lane's number, opaque to the compiler from here on: everything derived from it (tile addresses, operand tables, tap words) is worked out inside
          * the turn that uses it — taken out of the loop as invariants those values hold 30 registers through every phase (104 in all: four waves per SIMD
          * instead of the six the LDS allows) */
-        int lane_t = lane, tid_t = tid;
-        if (CTB_PERSIST) { MI355_PIN(lane_t); MI355_PIN(tid_t); }
+        /* the lane's number anew for each phase: what a phase derives from it (operand tables, tap words, tile addresses) is worked out inside that phase and not
+         * held in registers through the others (the transform's operand words are loads from constant tables: hoisted to the top they occupy 14 registers through the
+         * prediction) */
+        int lane_t = lane, tid_t = tid, lane_u = lane;
+        MI355_PIN(lane_t);
+        if (CTB_PERSIST) MI355_PIN(tid_t);
         /* the next block's record: needed after the predictions */
         const int crec_n = CTB_PERSIST ? (int)mi355_global_v(reinterpret_cast<const uint32_t *>(ctbs + (more ? cn : c)))[lane & 15] : 0;
         bool mine = true;
@@ -385,10 +396,11 @@ __device__ __forceinline__ void ctb_turns(const mi355_hevc_ctb_job *ctbs, int n_
             mine = false;
             if (error_word && tid == 0) atomicOr(error_word, (uint32_t)MI355_ERR_CTB_NOT_UNIFORM);
         }
+        MI355_PIN(lane_u);
         if (mine)
             for (int i = wave; i < H.n_tu; i += NW) {
                 if (i != wave) j_tu = ctb_tu_record<32>(ctb_fetch_records(H.mc, false, H.tu + i, true, ctbs + c, lane));
-                ctb_residual<WIDE, GENERAL>(tile, s, H.G, j_tu, bd, lane_t, pre && i == wave, raw);
+                ctb_residual<WIDE, GENERAL>(tile, s, H.G, j_tu, bd, lane_u, pre && i == wave, raw);
             }
         __syncthreads();
         if (!GENERAL && tid == 0) s_flag[k & 1] = 0;         /* everyone has read it; it is set again two turns from now at the earliest */

@@ -272,10 +272,14 @@ __device__ __forceinline__ CfPass cf_pass_one(int tap, int shift)      /* no fil
 /* src: the first sample the taps touch (block sample (0, 0) minus the taps before it in each FILTERED direction); sb: bytes per source row, a multiple of
  * the piece size (16 bytes of 16-bit samples, 8 of 8-bit ones: eight samples).  tw, th: 16 or 32.  The tile's samples go to `tile` (LDS, `pitch` bytes
  * per row) as put_unweighted_pred makes them. */
-template <bool WIDE>
-__device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff_t sb, int tw, int th, const CfPass ph, const CfPass pv, int bd,
-                                           uint8_t *tile, int pitch, int lane)
+/* XT, YT: the tile's 16-sample columns / rows (1 or 2), RT: the 16-row tiles of the window (the tile's rows + the vertical taps' reach: YT or YT + 1) — compile-time,
+ * so that the products of a pass are one stretch of straight-line code: their LDS reads go out together and the matrix unit's latency of one product is covered by
+ * the next (with run-time bounds every product sat in a branch of its own: read, wait, product, wait, eight idle cycles, arithmetic — six times over) */
+template <bool WIDE, int XT, int YT, int RT>
+__device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, ptrdiff_t sb, const CfPass ph, const CfPass pv, int bd,
+                                             uint8_t *tile, int pitch, int lane)
 {
+    constexpr int tw = 16 * XT, th = 16 * YT;
     constexpr int PB = WIDE ? 16 : 8;
     const int j = lane & 15, g = lane >> 4;
     const int off = (int)((uintptr_t)src & (PB - 1)) >> (WIDE ? 1 : 0);
@@ -285,46 +289,67 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
      * walks down the rows (8 pieces a row and 8 rows a round for a 32-wide tile, 4 and 16 for a 16-wide one: addresses are the lane's first one plus a
      * round's constant; pieces past the row's last and rows past the window's last are not fetched) */
     {
-        const int ppr_log = tw > 16 ? 3 : 2, rstep = 64 >> ppr_log;
+        constexpr int ppr_log = tw > 16 ? 3 : 2, rstep = 64 >> ppr_log;
         const int r0 = lane >> ppr_log, p = lane & ((1 << ppr_log) - 1);
         const uint32_t voff = (uint32_t)r0 * (uint32_t)sb + (uint32_t)(PB * p);
         const int lds0 = r0 * CF_WIN_PITCH + 8 * p;
-        uint32_t v[5][4];
+        constexpr int NR = 16 * RT / rstep;           /* rounds: the window has at most 16 RT rows */
+        /* at most MI355_CF_FETCH rounds' loads in flight at a time (registers: four a round) */
+#ifndef MI355_CF_FETCH
+#define MI355_CF_FETCH 6
+#endif
+        constexpr int NB = NR < MI355_CF_FETCH ? NR : MI355_CF_FETCH;
 #pragma unroll
-        for (int u = 0; u < 5; u++)
-            if (u * rstep < rows && p < npr && r0 + u * rstep < rows) {
-                const uint8_t *q = base + (ptrdiff_t)(u * rstep) * sb + voff;
-                if (WIDE) __builtin_memcpy(v[u], q, 16);
-                else { __builtin_memcpy(v[u], q, 8); v[u][2] = v[u][3] = 0u; }
-            }
-        MI355_ISSUE_FENCE();
+        for (int u0 = 0; u0 < NR; u0 += NB) {
+            uint32_t v[NB][4];
 #pragma unroll
-        for (int u = 0; u < 5; u++)
-            if (u * rstep < rows && p < npr && r0 + u * rstep < rows) {
-                const int at = lds0 + u * rstep * CF_WIN_PITCH;
-                if (WIDE) {
-                    uint64_t lo, hi;
-                    cf_planes8(v[u][0], v[u][1], v[u][2], v[u][3], lo, hi);
-                    cf_st64(w.lo + at, lo ^ CF_SIGN8);
-                    cf_st64(w.hi + at, hi);
-                } else {
-                    cf_st64(w.lo + at, cf_u64(v[u][0], v[u][1]) ^ CF_SIGN8);
+            for (int k = 0; k < NB; k++) {
+                const int u = u0 + k;
+                if (u < NR && p < npr && r0 + u * rstep < rows) {
+                    const uint8_t *q = base + (ptrdiff_t)(u * rstep) * sb + voff;
+                    if (WIDE) __builtin_memcpy(v[k], q, 16);
+                    else { __builtin_memcpy(v[k], q, 8); v[k][2] = v[k][3] = 0u; }
                 }
             }
+            MI355_ISSUE_FENCE();
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int u = u0 + k;
+                if (u < NR && p < npr && r0 + u * rstep < rows) {
+                    const int at = lds0 + u * rstep * CF_WIN_PITCH;
+                    if (WIDE) {
+                        uint64_t lo, hi;
+                        cf_planes8(v[k][0], v[k][1], v[k][2], v[k][3], lo, hi);
+                        cf_st64(w.lo + at, lo ^ CF_SIGN8);
+                        cf_st64(w.hi + at, hi);
+                    } else {
+                        cf_st64(w.lo + at, cf_u64(v[k][0], v[k][1]) ^ CF_SIGN8);
+                    }
+                }
+            }
+        }
     }
     MI355_WAVE_SYNC();
-    const int RT = (rows + 15) >> 4, XT = tw >> 4, YT = th >> 4;
     const int zero4[4] = { 0, 0, 0, 0 };
-    /* horizontal pass: t[r][x] = (sum_c W[r][c] tapH[c - off - x]) >> shift; the lane receives column x = 16 xt + j, rows 16 rt + 4 g .. + 3 */
+    /* A 16-sample COLUMN of the tile at a time, both passes (the first pass's results of one column — RT x 2 registers — are all the second pass of that column
+     * needs: held for both columns at once they are twice the registers).
+     * horizontal pass: t[r][x] = (sum_c W[r][c] tapH[c - off - x]) >> shift; the lane receives column x = 16 xt + j, rows 16 rt + 4 g .. + 3.
+     * vertical pass: v[x][y] = (sum_r t[r][x] tapV[r - y]) >> shift over the rows of two row tiles (slot (g, s) = row 16 (s / 4) + 4 g + s % 4 of the
+     * pair); the lane receives row y = 16 yt + j, columns 16 xt + 4 g .. + 3 of the 14-bit intermediate; put_unweighted_pred (:1092-1113) on top */
     const uint64_t toep_h = cf_taps_at(ph.taps, 8 * g - off - j);
     const int ch = 128 * ph.sum, ch4[4] = { ch, ch, ch, ch };
-    uint32_t tlo[4][2], thi[4][2];                  /* [row tile][column tile]; row tile 3: what an unfiltered tile pairs its last rows with */
+    const uint64_t toep_v = cf_u64((uint32_t)cf_taps_at(pv.taps, 4 * g - j), (uint32_t)cf_taps_at(pv.taps, 16 + 4 * g - j));
+    /* ((sum >> shift) + rnd) >> sh14 with rnd = 1 << (sh14 - 1) is (sum + (rnd << shift)) >> (shift + sh14): one shift, the addend in the accumulator's start value */
+    const int sh14 = 14 - bd, maxv = (1 << bd) - 1, shv = pv.shift + sh14;
+    const int cv = 128 * pv.sum + ((1 << (sh14 - 1)) << pv.shift), cv4[4] = { cv, cv, cv, cv };
 #pragma unroll
-    for (int rt = 0; rt < 4; rt++)
+    for (int xt = 0; xt < XT; xt++) {
+        MI355_SCHED_BARRIER();
+        uint32_t tlo[YT + 1], thi[YT + 1];          /* [row tile]; row tile YT where the window has none: what an unfiltered tile pairs its last rows with */
 #pragma unroll
-        for (int xt = 0; xt < 2; xt++) {
-            tlo[rt][xt] = CF_SIGN4; thi[rt][xt] = 0u;
-            if (rt < RT && xt < XT) {
+        for (int rt = 0; rt < YT + 1; rt++) {
+            tlo[rt] = CF_SIGN4; thi[rt] = 0u;
+            if (rt < RT) {
                 const int a = (16 * rt + j) * CF_WIN_PITCH + 16 * xt + 8 * g;
                 int l[4], v[4];
                 cf_mfma(cf_lds64(w.lo + a), toep_h, ch4, l);
@@ -337,31 +362,34 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
 #pragma unroll
                     for (int t = 0; t < 4; t++) v[t] = l[t] >> ph.shift;
                 }
-                cf_split4(v, tlo[rt][xt], thi[rt][xt]);
-                tlo[rt][xt] ^= CF_SIGN4;
+                cf_split4(v, tlo[rt], thi[rt]);
+                tlo[rt] ^= CF_SIGN4;
             }
         }
-    /* vertical pass: v[x][y] = (sum_r t[r][x] tapV[r - y]) >> shift over the rows of two row tiles (slot (g, s) = row 16 (s / 4) + 4 g + s % 4 of the
-     * pair); the lane receives row y = 16 yt + j, columns 16 xt + 4 g .. + 3 of the 14-bit intermediate; put_unweighted_pred (:1092-1113) on top */
-    const uint64_t toep_v = cf_u64((uint32_t)cf_taps_at(pv.taps, 4 * g - j), (uint32_t)cf_taps_at(pv.taps, 16 + 4 * g - j));
-    /* ((sum >> shift) + rnd) >> sh14 with rnd = 1 << (sh14 - 1) is (sum + (rnd << shift)) >> (shift + sh14): one shift, the addend in the accumulator's start value */
-    const int sh14 = 14 - bd, maxv = (1 << bd) - 1, shv = pv.shift + sh14;
-    const int cv = 128 * pv.sum + ((1 << (sh14 - 1)) << pv.shift), cv4[4] = { cv, cv, cv, cv };
 #pragma unroll
-    for (int yt = 0; yt < 2; yt++)
+        for (int yt = 0; yt < YT; yt++) {
+            int h[4], l[4], s[4];
+            cf_mfma(cf_u64(thi[yt], thi[yt + 1]), toep_v, zero4, h);
+            cf_mfma(cf_u64(tlo[yt], tlo[yt + 1]), toep_v, cv4, l);
 #pragma unroll
-        for (int xt = 0; xt < 2; xt++)
-            if (yt < YT && xt < XT) {
-                int h[4], l[4], s[4];
-                cf_mfma(cf_u64(thi[yt][xt], thi[yt + 1][xt]), toep_v, zero4, h);
-                cf_mfma(cf_u64(tlo[yt][xt], tlo[yt + 1][xt]), toep_v, cv4, l);
-#pragma unroll
-                for (int t = 0; t < 4; t++) s[t] = med3i(((h[t] << 8) + l[t]) >> shv, 0, maxv);
-                uint8_t *p = tile + (16 * yt + j) * pitch + ((16 * xt + 4 * g) << (WIDE ? 1 : 0));
-                if (WIDE) *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
-                else *reinterpret_cast<uint32_t *>(p) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-            }
+            for (int t = 0; t < 4; t++) s[t] = med3i(((h[t] << 8) + l[t]) >> shv, 0, maxv);
+            uint8_t *p = tile + (16 * yt + j) * pitch + ((16 * xt + 4 * g) << (WIDE ? 1 : 0));
+            if (WIDE) *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
+            else *reinterpret_cast<uint32_t *>(p) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+        }
+    }
     MI355_WAVE_SYNC();      /* the window may be overwritten by the wave's next tile */
+}
+/* tw, th: 16 or 32 */
+template <bool WIDE>
+__device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff_t sb, int tw, int th, const CfPass ph, const CfPass pv, int bd,
+                                           uint8_t *tile, int pitch, int lane)
+{
+    const bool more = ((th + pv.ext + 15) >> 4) > (th >> 4);         /* the vertical taps reach into one more 16-row tile of the window */
+    if (tw == 32 && th == 32) { if (more) cf_mc_tile_n<WIDE, 2, 2, 3>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 2, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
+    else if (tw == 16 && th == 16) { if (more) cf_mc_tile_n<WIDE, 1, 1, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 1, 1>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
+    else if (tw == 32) { if (more) cf_mc_tile_n<WIDE, 2, 1, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 1, 1>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
+    else { if (more) cf_mc_tile_n<WIDE, 1, 2, 3>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 2, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
 }
 
 #endif
