@@ -183,7 +183,6 @@ template <int DIR>      /* 0: vertical edges, 1: horizontal edges */
 __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_lf_picture *pics, int luma_cols, int luma_rows, int chroma_cols,
                                                               int chroma_rows, int luma_waves, int waves_per_pic, int bd)
 {
-    __shared__ uint8_t s_act[64];
     const int lane = lane_id(), slot = lane >> 3;
     const int pic = (int)blockIdx.x / waves_per_pic, w = (int)blockIdx.x - pic * waves_per_pic;
     /* the picture's record once, a dword per lane, its fields as scalars from there (v_readlane): read field by field through `pics` every use of a field is a
@@ -204,7 +203,7 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
     /* strengths of segment `seg` (luma: the 8x8 grid; chroma: plane c on the 16-luma-sample grid; horizontal chroma edges: the reference's
      * pairs start at x = 8 (mod 16), i.e. at -8 (:469-484), a half outside the picture has bS 0) -> does it filter anything */
     auto luma_seg = [&](int seg, int &x, int &y, int &bs0, int &bs1) {
-        const int gy = seg / luma_cols, gx = seg - gy * luma_cols;
+        const int gy = seg / luma_cols, gx = seg - gy * luma_cols;            /* (not mi355_div20: that is exact for seg * luma_cols < 2^20 only) */
         x = 8 * gx; y = 8 * gy;
         bs0 = bs1 = 0;
         if (!(gy < luma_rows && x < W && y < H && (DIR ? y >= 8 : x >= 8))) return false;
@@ -227,59 +226,64 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
         }
         return bs0 == 2 || bs1 == 2;
     };
-    /* ---- the wave's 64 candidates, the live ones listed in LDS in lane order */
+    /* ---- the wave's 64 candidates: each lane works out ITS segment's parameters (QP average, beta / tc through the tables, pcm marks) — every live lane at once, one
+     * chain of round trips per wave — and lists them in LDS in lane order; the groups of eight lanes then only fetch samples (before: each group derived its
+     * segment's parameters itself in front of its samples' loads, a chain per round of eight segments) */
+    __shared__ uint2 s_par[64];
     const int seg_base = (luma ? w : w - luma_waves) * 64;
+    uint2 par = make_uint2(0u, 0u);
     bool cand;
     {
-        int c, x, y, b0, b1;
-        cand = luma ? luma_seg(seg_base + lane, x, y, b0, b1) : chroma_seg(seg_base + lane, c, x, y, b0, b1);
+        int c = 0, x, y, bs0, bs1;
+        cand = luma ? luma_seg(seg_base + lane, x, y, bs0, bs1) : chroma_seg(seg_base + lane, c, x, y, bs0, bs1);
+        if (cand) {
+            int beta = 0, tc0 = 0, tc1 = 0;
+            uint32_t nob = 0;
+            if (luma) {
+                const mi355_hevc_db_params d = P.db(x, y);
+                const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
+                beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
+                tc0 = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
+                tc1 = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
+                if (p.pcmf) {
+                    if (DIR) nob = (P.pcm(x, y - 1) ? 1u : 0u) | (P.pcm(x + 4, y - 1) ? 2u : 0u) | (P.pcm(x, y) ? 4u : 0u) | (P.pcm(x + 4, y) ? 8u : 0u);
+                    else nob = (P.pcm(x - 1, y) ? 1u : 0u) | (P.pcm(x - 1, y + 4) ? 2u : 0u) | (P.pcm(x, y) ? 4u : 0u) | (P.pcm(x, y + 4) ? 8u : 0u);
+                }
+            } else if (DIR) {
+                if (bs0 == 2) tc0 = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, c, P.db(x, y).tc_offset);
+                if (bs1 == 2) tc1 = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, c, P.db(x + 8, y).tc_offset);
+                if (p.pcmf) nob = (P.pcm(x, y - 1) ? 1u : 0u) | (P.pcm(x + 8, y - 1) ? 2u : 0u) | (P.pcm(x, y) ? 4u : 0u) | (P.pcm(x + 8, y) ? 8u : 0u);
+            } else {
+                const int tco = P.db(x, y).tc_offset;
+                if (bs0 == 2) tc0 = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, c, tco);
+                if (bs1 == 2) tc1 = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, c, tco);
+                if (p.pcmf) nob = (P.pcm(x - 1, y) ? 1u : 0u) | (P.pcm(x - 1, y + 8) ? 2u : 0u) | (P.pcm(x, y) ? 4u : 0u) | (P.pcm(x, y + 8) ? 8u : 0u);
+            }
+            /* [0] = (x + 8) | y << 14 | plane << 28, [1] = beta | tc[0] << 8 | tc[1] << 16 | pcm marks << 24 */
+            par = make_uint2((uint32_t)(x + 8) | ((uint32_t)y << 14) | ((uint32_t)c << 28), (uint32_t)beta | ((uint32_t)tc0 << 8) | ((uint32_t)tc1 << 16) | (nob << 24));
+        }
     }
     const unsigned long long live = __ballot(cand);
     const int count = __popcll(live);
     if (!count) return;
-    if (cand) s_act[__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    if (cand) s_par[__popcll(live & ((1ull << lane) - 1ull))] = par;
     __syncthreads();
     for (int it = 0; it * 8 < count; it++) {
         const int k = it * 8 + slot;
-        const int seg = seg_base + (k < count ? s_act[k] : s_act[0]);
+        const bool on = k < count;
+        const uint2 q = s_par[on ? k : 0];
+        const int x = (int)(q.x & 0x3FFF) - 8, y = (int)((q.x >> 14) & 0x3FFF), c = (int)(q.x >> 28);
+        const int beta = (int)(q.y & 0xFF);
+        int tc[2] = { (int)((q.y >> 8) & 0xFF), (int)((q.y >> 16) & 0xFF) };
+        uint8_t no_p[2] = { (uint8_t)((q.y >> 24) & 1), (uint8_t)((q.y >> 25) & 1) }, no_q[2] = { (uint8_t)((q.y >> 26) & 1), (uint8_t)((q.y >> 27) & 1) };
         if (luma) {
-            int x, y, bs0, bs1;
-            const bool on = luma_seg(seg, x, y, bs0, bs1) && k < count;
-            int beta = 0, tc[2] = { 0, 0 };
-            uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
-            if (on) {
-                const mi355_hevc_db_params d = P.db(x, y);
-                const int qp = (P.qpy(DIR ? x : x - 1, DIR ? y - 1 : y) + P.qpy(x, y) + 1) >> 1;
-                beta = k_hevc_betatable[clip3(qp + d.beta_offset, 0, 51)];
-                tc[0] = bs0 ? hevc_tc_calc(qp, bs0, d.tc_offset) : 0;
-                tc[1] = bs1 ? hevc_tc_calc(qp, bs1, d.tc_offset) : 0;
-                if (p.pcmf) {
-                    if (DIR) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 4, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 4, y); }
-                    else { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 4); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 4); }
-                }
-            }
             const int st = p.linesize[0] >> ps;
             uint8_t *pix = mi355_global_v(p.data[0]) + (on ? (ptrdiff_t)y * p.linesize[0] + ((ptrdiff_t)x << ps) : 0);
             hevc_lf_luma_wave(pix, DIR ? st : 1, DIR ? 1 : st, beta, tc, no_p, no_q, bd, true, on);
         } else {
-            int c, x, y, bs0, bs1;
-            const bool on = chroma_seg(seg, c, x, y, bs0, bs1) && k < count;
-            int tc[2] = { 0, 0 };
-            uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
-            if (on) {
-                if (DIR) {
-                    if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x, y - 1) + P.qpy(x, y) + 1) >> 1, c, P.db(x, y).tc_offset);
-                    if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x + 8, y - 1) + P.qpy(x + 8, y) + 1) >> 1, c, P.db(x + 8, y).tc_offset);
-                    if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x, y - 1); no_p[1] = (uint8_t)P.pcm(x + 8, y - 1); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x + 8, y); }
-                } else {
-                    const int tco = P.db(x, y).tc_offset;
-                    if (bs0 == 2) tc[0] = P.chroma_tc((P.qpy(x - 1, y) + P.qpy(x, y) + 1) >> 1, c, tco);
-                    if (bs1 == 2) tc[1] = P.chroma_tc((P.qpy(x - 1, y + 8) + P.qpy(x, y + 8) + 1) >> 1, c, tco);
-                    if (p.pcmf) { no_p[0] = (uint8_t)P.pcm(x - 1, y); no_p[1] = (uint8_t)P.pcm(x - 1, y + 8); no_q[0] = (uint8_t)P.pcm(x, y); no_q[1] = (uint8_t)P.pcm(x, y + 8); }
-                }
-            }
-            const int st = p.linesize[c] >> ps;
-            uint8_t *pix = mi355_global_v(p.data[c]) + (on ? (ptrdiff_t)(y / 2) * p.linesize[c] + (ptrdiff_t)(x / 2) * (1 << ps) : 0);
+            const int cc = c == 2 ? 2 : 1;
+            const int st = p.linesize[cc] >> ps;
+            uint8_t *pix = mi355_global_v(p.data[cc]) + (on ? (ptrdiff_t)(y / 2) * p.linesize[cc] + (ptrdiff_t)(x / 2) * (1 << ps) : 0);
             hevc_lf_chroma_wave(pix, DIR ? st : 1, DIR ? 1 : st, tc, no_p, no_q, bd, true, on);
         }
     }
