@@ -602,19 +602,28 @@ constexpr int SAO_CTB_THREADS = 64;
  * for before the branch that depends on it — 20-40 dependent memory round trips per wave before the first sample was requested, which is what this kernel's
  * time consisted of (profiles/r06_experiments.md). */
 static_assert(sizeof(mi355_hevc_sao_ctb_job) == 168 && sizeof(mi355_hevc_sao_piece) == 36 && offsetof(mi355_hevc_sao_ctb_job, piece) == 24, "k_hevc_sao_ctbs reads the record by dword index");
+/* A wave per job; SAO_CTB_JOBS consecutive jobs share a workgroup, i.e. a CU and its XCD's L2, at the same time: a caller's jobs of one component run along a row of
+ * blocks, so a chroma block's 64-byte half of a line is asked for next to its neighbour's other half (fetched once, written back once), and the luma rows of four
+ * neighbours are 512 contiguous bytes. */
+#ifndef MI355_SAO_CTB_JOBS
+#define MI355_SAO_CTB_JOBS 4
+#endif
+constexpr int SAO_CTB_JOBS = MI355_SAO_CTB_JOBS;
 template <bool WIDE>
-__global__ void __launch_bounds__(SAO_CTB_THREADS) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
+__global__ void __launch_bounds__(SAO_CTB_THREADS * SAO_CTB_JOBS) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
 {
-    if ((int)blockIdx.x >= n) return;
-    const mi355_hevc_sao_ctb_job &j = jobs[blockIdx.x];
-    const int tid = (int)threadIdx.x;
+    const int job = (int)blockIdx.x * SAO_CTB_JOBS + uniform((int)(threadIdx.x >> 6));
+    if (job >= n) return;
+    const mi355_hevc_sao_ctb_job &j = jobs[job];
+    const int tid = (int)threadIdx.x & 63;
     const int rec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(&j))[tid < 42 ? tid : 41];
 #define SAO_REC(dw) ((uint32_t)lane_value(rec, (dw)))
     uint8_t *dst0 = mi355_global(reinterpret_cast<uint8_t *>((uintptr_t)SAO_REC(0) | ((uintptr_t)SAO_REC(1) << 32)));
     const uint8_t *src0 = mi355_global(reinterpret_cast<const uint8_t *>((uintptr_t)SAO_REC(2) | ((uintptr_t)SAO_REC(3) << 32)));
     const int stride = (int)SAO_REC(4), chroma = (SAO_REC(5) & 0xFF) != 0, np = (int)((SAO_REC(5) >> 8) & 0xFF);
     const int cw = (8 >> chroma) + 2, ch = (4 >> chroma) + 2, px = bd > 8 ? 2 : 1;
-    __shared__ int tbl[32];
+    __shared__ int tbl_all[SAO_CTB_JOBS][32];          /* the piece-by-piece path's table: a wave's own */
+    int *const tbl = tbl_all[uniform((int)(threadIdx.x >> 6))];
     const int st = stride / px;
     /* piece k: dwords 6 + 9 k ..: offset_val[5]; cls | type << 8 | eo_class << 16 | band_position << 24; vert | horiz << 8 | diag << 16 | borders << 24;
      * dx | dy << 16; width | height << 16 */
@@ -645,8 +654,7 @@ __global__ void __launch_bounds__(SAO_CTB_THREADS) k_hevc_sao_ctbs(const mi355_h
 #ifdef MI355_EXP_SAO_NOSLOW
     return;
 #endif
-    /* piece by piece, as the reference makes its calls: the first wave alone (hevc_sao_wave is a wave's function) */
-    if (tid >= 64) return;
+    /* piece by piece, as the reference makes its calls (hevc_sao_wave is a wave's function) */
     for (int k = 0; k < np && k < 4; k++) {
         const mi355_hevc_sao_piece &q = j.piece[k];
         const int cls = uniform(q.cls), type = uniform(q.type), W = uniform(q.width), H = uniform(q.height), bo = uniform(q.borders);
@@ -1369,8 +1377,9 @@ extern "C" int mi355_hevc_intra_pred_blocks_dev(const mi355_hevc_intra_picture *
 extern "C" int mi355_hevc_sao_ctbs_dev(const mi355_hevc_sao_ctb_job *d_jobs, int n, int bit_depth, void *stream)
 {
     if (!check(bit_depth, d_jobs, n)) return -1;
-    if (bit_depth > 8) hipLaunchKernelGGL(k_hevc_sao_ctbs<true>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
-    else hipLaunchKernelGGL(k_hevc_sao_ctbs<false>, dim3((unsigned)n), dim3(SAO_CTB_THREADS), 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    const dim3 grid((unsigned)((n + SAO_CTB_JOBS - 1) / SAO_CTB_JOBS)), block(SAO_CTB_THREADS * SAO_CTB_JOBS);
+    if (bit_depth > 8) hipLaunchKernelGGL(k_hevc_sao_ctbs<true>, grid, block, 0, (hipStream_t)stream, d_jobs, n, bit_depth);
+    else hipLaunchKernelGGL(k_hevc_sao_ctbs<false>, grid, block, 0, (hipStream_t)stream, d_jobs, n, bit_depth);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int mi355_hevc_filter_ctbs_dev(const mi355_hevc_lf_picture *d_pics, const mi355_hevc_filter_ctb_job *d_ctbs, int n_ctbs, const mi355_hevc_sao_ctb_job *d_sao,
