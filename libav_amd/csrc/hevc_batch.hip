@@ -612,7 +612,9 @@ constexpr int SAO_CTB_JOBS = MI355_SAO_CTB_JOBS;
 template <bool WIDE>
 __global__ void __launch_bounds__(SAO_CTB_THREADS * SAO_CTB_JOBS) k_hevc_sao_ctbs(const mi355_hevc_sao_ctb_job *jobs, int n, int bd)
 {
-    const int job = (int)blockIdx.x * SAO_CTB_JOBS + uniform((int)(threadIdx.x >> 6));
+    /* ... and the workgroups of an XCD (they go to the eight in turn) take consecutive groups: XCD k the k-th eighth of the list */
+    const int ngroups = (int)gridDim.x, grp = (ngroups & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (ngroups >> 3) + ((int)blockIdx.x >> 3);
+    const int job = grp * SAO_CTB_JOBS + uniform((int)(threadIdx.x >> 6));
     if (job >= n) return;
     const mi355_hevc_sao_ctb_job &j = jobs[job];
     const int tid = (int)threadIdx.x & 63;

@@ -334,6 +334,9 @@ __device__ __forceinline__ void ctb_turns(const mi355_hevc_ctb_job *ctbs, int n_
     if (tid < 2) s_flag[tid] = 0;
     int c = (int)blockIdx.x;
     if (c >= n_ctbs) return;
+    /* workgroups go to the eight XCDs in turn: XCD k takes the k-th eighth of the list, in order — a caller's blocks run along rows, so neighbours (whose chroma rows are the
+     * two halves of one line, whose windows overlap) meet in ONE L2 at about the same time instead of in eight (1.98 -> 1.96 ms; a list that does not divide: as it comes) */
+    if (!CTB_PERSIST && !(n_ctbs & 7)) c = (c & 7) * (n_ctbs >> 3) + (c >> 3);
     CtbHead H = ctb_head<WIDE>((int)mi355_global_v(reinterpret_cast<const uint32_t *>(ctbs + c))[lane & 15], mc, tus);
     int rec = ctb_fetch_records(H.mc + wave, wave < H.n_mc, H.tu + wave, wave < H.n_tu, ctbs + c, lane);
     __syncthreads();
