@@ -162,6 +162,13 @@ __device__ __forceinline__ bool ctb_predict(CtbTile &tile, Scratch &s, const Ctb
             ph = j.mx0 ? cf_pass(k_qpel[j.mx0], 8, bd - 8) : cf_pass_one(1, 0);
             pv = j.my0 ? cf_pass(k_qpel[j.my0], 8, j.mx0 ? 6 : bd - 8) : cf_pass_one(j.mx0 ? 1 : 1 << (14 - bd), 0);
         }
+        if (j.chroma == 2 && j.width == 16 && j.height == 16 && (((uintptr_t)j.src0 ^ (uintptr_t)j.src0_b) & (WIDE ? 15 : 7)) == 0) {
+            /* both planes' 16x16 tiles: their windows in ONE round trip */
+            MI355_PIN(lane);
+            cf_mc_tile_pair<WIDE>(s.win, mi355_global(j.src0) - (ptrdiff_t)by * j.src0_stride - (ptrdiff_t)bx * px, mi355_global(j.src0_b) - (ptrdiff_t)by * j.src0_stride - (ptrdiff_t)bx * px,
+                                  j.src0_stride, ph, pv, bd, t0, t1, pitch, lane);
+            return true;
+        }
         /* (one tile at a time: unrolled, the tiles of a job — two planes, up to four tiles a plane — would be scheduled into each other and hold twice the registers) */
 #pragma unroll 1
         for (int plane = 0; plane < (j.chroma == 2 ? 2 : 1); plane++) {

@@ -275,17 +275,21 @@ __device__ __forceinline__ CfPass cf_pass_one(int tap, int shift)      /* no fil
 /* XT, YT: the tile's 16-sample columns / rows (1 or 2), RT: the 16-row tiles of the window (the tile's rows + the vertical taps' reach: YT or YT + 1) — compile-time,
  * so that the products of a pass are one stretch of straight-line code: their LDS reads go out together and the matrix unit's latency of one product is covered by
  * the next (with run-time bounds every product sat in a branch of its own: read, wait, product, wait, eight idle cycles, arithmetic — six times over) */
-template <bool WIDE, int XT, int YT, int RT>
-__device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, ptrdiff_t sb, const CfPass ph, const CfPass pv, int bd,
-                                             uint8_t *tile, int pitch, int lane)
+/* NPL = 2: the tile of BOTH chroma planes of a block (a 16x16 tile each: XT = YT = 1) — the two windows are fetched in ONE round trip into rows 0 .. and CF_WIN_SECOND .. of the
+ * wave's window and worked on one after the other (one after the other from fetch to store, a chroma job's wave waited out two memory round trips while the luma job's wave
+ * beside it waited out one: the chroma waves were the last at the block's barrier).  Both windows start at the same offset inside their first piece (the caller checks). */
+constexpr int CF_WIN_SECOND = 24;
+template <bool WIDE, int XT, int YT, int RT, int NPL = 1>
+__device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, const uint8_t *src_b, ptrdiff_t sb, const CfPass ph, const CfPass pv, int bd,
+                                             uint8_t *tile, uint8_t *tile_b, int pitch, int lane)
 {
+    static_assert(NPL == 1 || (XT == 1 && YT == 1), "two planes: 16x16 tiles (19 rows of window each)");
     constexpr int tw = 16 * XT, th = 16 * YT;
     constexpr int PB = WIDE ? 16 : 8;
     const int j = lane & 15, g = lane >> 4;
     const int off = (int)((uintptr_t)src & (PB - 1)) >> (WIDE ? 1 : 0);
-    const uint8_t *base = src - ((uintptr_t)src & (PB - 1));
     const int rows = th + pv.ext, npr = (off + tw + ph.ext + 7) >> 3;
-    /* the window -> byte planes in LDS, eight samples per lane and piece, all loads of the tile in flight together.  A lane keeps its piece of a row and
+    /* the window(s) -> byte planes in LDS, eight samples per lane and piece, all loads in flight together.  A lane keeps its piece of a row and
      * walks down the rows (8 pieces a row and 8 rows a round for a 32-wide tile, 4 and 16 for a 16-wide one: addresses are the lane's first one plus a
      * round's constant; pieces past the row's last and rows past the window's last are not fetched) */
     {
@@ -294,40 +298,34 @@ __device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, ptrdi
         const uint32_t voff = (uint32_t)r0 * (uint32_t)sb + (uint32_t)(PB * p);
         const int lds0 = r0 * CF_WIN_PITCH + 8 * p;
         constexpr int NR = 16 * RT / rstep;           /* rounds: the window has at most 16 RT rows */
-        /* at most MI355_CF_FETCH rounds' loads in flight at a time (registers: four a round) */
-#ifndef MI355_CF_FETCH
-#define MI355_CF_FETCH 6
-#endif
-        constexpr int NB = NR < MI355_CF_FETCH ? NR : MI355_CF_FETCH;
+        uint32_t v[NPL][NR][4];
 #pragma unroll
-        for (int u0 = 0; u0 < NR; u0 += NB) {
-            uint32_t v[NB][4];
+        for (int pl = 0; pl < NPL; pl++) {
+            const uint8_t *s0 = pl ? src_b : src, *base = s0 - ((uintptr_t)s0 & (PB - 1));
 #pragma unroll
-            for (int k = 0; k < NB; k++) {
-                const int u = u0 + k;
-                if (u < NR && p < npr && r0 + u * rstep < rows) {
+            for (int u = 0; u < NR; u++)
+                if (p < npr && r0 + u * rstep < rows) {
                     const uint8_t *q = base + (ptrdiff_t)(u * rstep) * sb + voff;
-                    if (WIDE) __builtin_memcpy(v[k], q, 16);
-                    else { __builtin_memcpy(v[k], q, 8); v[k][2] = v[k][3] = 0u; }
+                    if (WIDE) __builtin_memcpy(v[pl][u], q, 16);
+                    else { __builtin_memcpy(v[pl][u], q, 8); v[pl][u][2] = v[pl][u][3] = 0u; }
                 }
-            }
-            MI355_ISSUE_FENCE();
+        }
+        MI355_ISSUE_FENCE();
 #pragma unroll
-            for (int k = 0; k < NB; k++) {
-                const int u = u0 + k;
-                if (u < NR && p < npr && r0 + u * rstep < rows) {
-                    const int at = lds0 + u * rstep * CF_WIN_PITCH;
+        for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+            for (int u = 0; u < NR; u++)
+                if (p < npr && r0 + u * rstep < rows) {
+                    const int at = lds0 + (u * rstep + pl * CF_WIN_SECOND) * CF_WIN_PITCH;
                     if (WIDE) {
                         uint64_t lo, hi;
-                        cf_planes8(v[k][0], v[k][1], v[k][2], v[k][3], lo, hi);
+                        cf_planes8(v[pl][u][0], v[pl][u][1], v[pl][u][2], v[pl][u][3], lo, hi);
                         cf_st64(w.lo + at, lo ^ CF_SIGN8);
                         cf_st64(w.hi + at, hi);
                     } else {
-                        cf_st64(w.lo + at, cf_u64(v[k][0], v[k][1]) ^ CF_SIGN8);
+                        cf_st64(w.lo + at, cf_u64(v[pl][u][0], v[pl][u][1]) ^ CF_SIGN8);
                     }
                 }
-            }
-        }
     }
     MI355_WAVE_SYNC();
     const int zero4[4] = { 0, 0, 0, 0 };
@@ -343,14 +341,24 @@ __device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, ptrdi
     const int sh14 = 14 - bd, maxv = (1 << bd) - 1, shv = pv.shift + sh14;
     const int cv = 128 * pv.sum + ((1 << (sh14 - 1)) << pv.shift), cv4[4] = { cv, cv, cv, cv };
 #pragma unroll
+    for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
     for (int xt = 0; xt < XT; xt++) {
         MI355_SCHED_BARRIER();
+        uint8_t *const out = pl ? tile_b : tile;
         uint32_t tlo[YT + 1], thi[YT + 1];          /* [row tile]; row tile YT where the window has none: what an unfiltered tile pairs its last rows with */
 #pragma unroll
         for (int rt = 0; rt < YT + 1; rt++) {
             tlo[rt] = CF_SIGN4; thi[rt] = 0u;
             if (rt < RT) {
-                const int a = (16 * rt + j) * CF_WIN_PITCH + 16 * xt + 8 * g;
+                /* (the second window's last rows lie past the wave's window: what is read there — the other byte plane, the next wave's window, past the workgroup's
+                 * LDS: zeros — only meets taps that are zero; the emulator's arrays have no such neighbourhood: it reads the window's last row instead) */
+#ifdef MI355_HIP_EMU_H
+                const int wrow = 16 * rt + j + pl * CF_WIN_SECOND < CF_WIN_ROWS ? 16 * rt + j + pl * CF_WIN_SECOND : CF_WIN_ROWS - 1;
+#else
+                const int wrow = 16 * rt + j + pl * CF_WIN_SECOND;
+#endif
+                const int a = wrow * CF_WIN_PITCH + 16 * xt + 8 * g;
                 int l[4], v[4];
                 cf_mfma(cf_lds64(w.lo + a), toep_h, ch4, l);
                 if (WIDE) {
@@ -373,7 +381,7 @@ __device__ __forceinline__ void cf_mc_tile_n(CfWin &w, const uint8_t *src, ptrdi
             cf_mfma(cf_u64(tlo[yt], tlo[yt + 1]), toep_v, cv4, l);
 #pragma unroll
             for (int t = 0; t < 4; t++) s[t] = med3i(((h[t] << 8) + l[t]) >> shv, 0, maxv);
-            uint8_t *p = tile + (16 * yt + j) * pitch + ((16 * xt + 4 * g) << (WIDE ? 1 : 0));
+            uint8_t *p = out + (16 * yt + j) * pitch + ((16 * xt + 4 * g) << (WIDE ? 1 : 0));
             if (WIDE) *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
             else *reinterpret_cast<uint32_t *>(p) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
         }
@@ -386,10 +394,18 @@ __device__ __forceinline__ void cf_mc_tile(CfWin &w, const uint8_t *src, ptrdiff
                                            uint8_t *tile, int pitch, int lane)
 {
     const bool more = ((th + pv.ext + 15) >> 4) > (th >> 4);         /* the vertical taps reach into one more 16-row tile of the window */
-    if (tw == 32 && th == 32) { if (more) cf_mc_tile_n<WIDE, 2, 2, 3>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 2, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
-    else if (tw == 16 && th == 16) { if (more) cf_mc_tile_n<WIDE, 1, 1, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 1, 1>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
-    else if (tw == 32) { if (more) cf_mc_tile_n<WIDE, 2, 1, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 1, 1>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
-    else { if (more) cf_mc_tile_n<WIDE, 1, 2, 3>(w, src, sb, ph, pv, bd, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 2, 2>(w, src, sb, ph, pv, bd, tile, pitch, lane); }
+    if (tw == 32 && th == 32) { if (more) cf_mc_tile_n<WIDE, 2, 2, 3>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 2, 2>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); }
+    else if (tw == 16 && th == 16) { if (more) cf_mc_tile_n<WIDE, 1, 1, 2>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 1, 1>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); }
+    else if (tw == 32) { if (more) cf_mc_tile_n<WIDE, 2, 1, 2>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); else cf_mc_tile_n<WIDE, 2, 1, 1>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); }
+    else { if (more) cf_mc_tile_n<WIDE, 1, 2, 3>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); else cf_mc_tile_n<WIDE, 1, 2, 2>(w, src, src, sb, ph, pv, bd, tile, tile, pitch, lane); }
+}
+/* the 16x16 tiles of both chroma planes of a block at once (windows at the same offset inside their first pieces) */
+template <bool WIDE>
+__device__ __forceinline__ void cf_mc_tile_pair(CfWin &w, const uint8_t *src, const uint8_t *src_b, ptrdiff_t sb, const CfPass ph, const CfPass pv, int bd,
+                                                uint8_t *tile, uint8_t *tile_b, int pitch, int lane)
+{
+    if (pv.ext) cf_mc_tile_n<WIDE, 1, 1, 2, 2>(w, src, src_b, sb, ph, pv, bd, tile, tile_b, pitch, lane);
+    else cf_mc_tile_n<WIDE, 1, 1, 1, 2>(w, src, src_b, sb, ph, pv, bd, tile, tile_b, pitch, lane);
 }
 
 #endif
