@@ -184,7 +184,13 @@ __global__ void __launch_bounds__(64) k_hevc_deblock_pictures(const mi355_hevc_l
                                                               int chroma_rows, int luma_waves, int waves_per_pic, int bd)
 {
     const int lane = lane_id(), slot = lane >> 3;
-    const int pic = (int)blockIdx.x / waves_per_pic, w = (int)blockIdx.x - pic * waves_per_pic;
+#ifndef MI355_LF_NO_XCD_ORDER
+    /* the workgroups of an XCD (they go to the eight in turn) take consecutive waves' worth of segments: XCD k the k-th eighth of the launch */
+    const int nb = (int)gridDim.x, bidx = (nb & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+#else
+    const int bidx = (int)blockIdx.x;
+#endif
+    const int pic = bidx / waves_per_pic, w = bidx - pic * waves_per_pic;
     /* the picture's record once, a dword per lane, its fields as scalars from there (v_readlane): read field by field through `pics` every use of a field is a
      * vector load and a wait in front of the load that needed it (the strengths' pointer, then the strength) */
     static_assert(sizeof(mi355_hevc_lf_picture) == 136, "the record is read by dword index");
