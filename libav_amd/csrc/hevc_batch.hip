@@ -688,15 +688,18 @@ __global__ void __launch_bounds__(SAO_CTB_THREADS * SAO_CTB_JOBS) k_hevc_sao_ctb
 }
 
 /* emulated_edge_mc as a batch: one wave per window */
+static_assert(sizeof(mi355_edge_emu_job) == 48 && offsetof(mi355_edge_emu_job, block_w) == 24 && offsetof(mi355_edge_emu_job, w) == 40, "the record is read by dword index");
 __global__ void __launch_bounds__(64) k_edge_emu_batch(const mi355_edge_emu_job *jobs, int n, int bd)
 {
     if ((int)blockIdx.x >= n) return;
-    const mi355_edge_emu_job &j = jobs[blockIdx.x];
-    const int bw = uniform(j.block_w), bh = uniform(j.block_h), sx = uniform(j.src_x), sy = uniform(j.src_y), w = uniform(j.w), h = uniform(j.h);
-    const int ss = uniform(j.src_stride), ds = uniform(j.dst_stride), px = bd > 8 ? 2 : 1;
-    uint8_t *dst = mi355_global(j.dst);
+    /* the record once, a dword per lane (field by field it is a chain of vector loads: see k_hevc_sao_ctbs) */
+    const int rec = (int)mi355_global_v(reinterpret_cast<const uint32_t *>(jobs + blockIdx.x))[lane_id() < 12 ? lane_id() : 11];
+    uint8_t *dst = mi355_global(reinterpret_cast<uint8_t *>((uintptr_t)(uint32_t)lane_value(rec, 0) | ((uintptr_t)(uint32_t)lane_value(rec, 1) << 32)));
+    const uint8_t *src = reinterpret_cast<const uint8_t *>((uintptr_t)(uint32_t)lane_value(rec, 2) | ((uintptr_t)(uint32_t)lane_value(rec, 3) << 32));
+    const int ds = lane_value(rec, 4), ss = lane_value(rec, 5), bw = lane_value(rec, 6), bh = lane_value(rec, 7);
+    const int sx = lane_value(rec, 8), sy = lane_value(rec, 9), w = lane_value(rec, 10), h = lane_value(rec, 11), px = bd > 8 ? 2 : 1;
     /* `src` is the window's first sample (possibly outside the plane): the plane's sample (0, 0) lies sy rows and sx samples before it */
-    const uint8_t *plane = mi355_global(j.src) - (ptrdiff_t)sy * ss - (ptrdiff_t)sx * px;
+    const uint8_t *plane = mi355_global(src) - (ptrdiff_t)sy * ss - (ptrdiff_t)sx * px;
     if (bw <= 0 || bh <= 0 || w <= 0 || h <= 0) return;
     const int inv = mi355_inv20(bw);
     for (int i = lane_id(); i < bw * bh; i += 64) {
