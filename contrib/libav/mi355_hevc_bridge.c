@@ -613,11 +613,14 @@ static int g_nwait, g_solo;
 static struct Merged { uint8_t *h, *d; size_t bytes; void *ev, *stream; int used, busy; } g_slot[MAX_SLOTS];
 static int g_nslots = -1, g_default_stream;
 
+static int g_one_launch = -1;             /* MI355_HEVC_BRIDGE_ONE_LAUNCH=1: all levels of a set in ONE launch (mi355_hevc_recon_levels_dev) instead of a launch per level — measured slower for
+                                           * sets with wide levels (P / B pictures: a thousand workgroups counting themselves into one word) and level with it for chains of small ones */
 static int g_three_launches = -1;         /* MI355_HEVC_BRIDGE_THREE_LAUNCHES=1: a level's job kinds as separate launches (the form before mi355_hevc_recon_level_dev) */
 
 static int launch_batch(struct Merged *m, Sub **b, int K)
 {
     if (g_three_launches < 0) { const char *e = getenv("MI355_HEVC_BRIDGE_THREE_LAUNCHES"); g_three_launches = e && *e && *e != '0'; }
+    if (g_one_launch < 0) { const char *e = getenv("MI355_HEVC_BRIDGE_ONE_LAUNCH"); g_one_launch = e && *e && *e != '0'; }
     if (!m->stream && !g_default_stream) m->stream = mi355_stream_create();
     void *const st = m->stream;
     int maxL = 0, nemu = 0, nmc = 0, ntu = 0, nin = 0;
@@ -632,6 +635,7 @@ static int launch_batch(struct Merged *m, Sub **b, int K)
     const size_t o_tu = o;   o += ((size_t)ntu * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
     const size_t o_in = o;   o += ((size_t)nin * sizeof(mi355_hevc_intra_block) + 63) & ~(size_t)63;
     const size_t o_fu = o;   o += ((size_t)nin * sizeof(mi355_hevc_tu_job) + 63) & ~(size_t)63;
+    const size_t o_lv = o;   o += ((size_t)(maxL + 1) * sizeof(mi355_hevc_level) + 63) & ~(size_t)63;
     if (m->used && mi355_event_sync(m->ev) != 0) return -1;       /* (the caller has waited already: the arrays are free) */
     m->used = 0;
     if (m->bytes < o) {
@@ -675,10 +679,29 @@ static int launch_batch(struct Merged *m, Sub **b, int K)
     }
     fmc[maxL + 1] = am; ftu[maxL + 1] = at; fin[maxL + 1] = ai;
     const int bd = b[0]->bd;
+    /* every level of the set in ONE launch: the level table beside the job arrays */
+    const int one_launch = g_one_launch && !b[0]->split_intra && !g_three_launches && maxL > 1;
+    int nlv = 0;
+    unsigned total_wg = 0;
+    if (one_launch) {
+        mi355_hevc_level *lv = (mi355_hevc_level *)(m->h + o_lv);
+        for (int l = 1; l <= maxL; l++) {
+            const int nm = fmc[l + 1] - fmc[l], nt = ftu[l + 1] - ftu[l], ni = fin[l + 1] - fin[l];
+            if (!(nm + nt + ni)) continue;
+            lv[nlv++] = (mi355_hevc_level){ total_wg, (uint32_t)fmc[l], (uint32_t)nm, (uint32_t)ftu[l], (uint32_t)nt, (uint32_t)fin[l], (uint32_t)ni, 0 };
+            total_wg += (unsigned)(nm + (nt + 1) / 2 + ni);
+        }
+    }
     int rc = mi355_memcpy_h2d_async(m->d, m->h, o, st);
     unsigned long launches = 0;
     if (!rc && nemu && mi355_edge_emu_batch_dev((const mi355_edge_emu_job *)(m->d + o_emu), nemu, bd, st) != 0) rc = -1;
-    for (int l = 1; l <= maxL && !rc; l++) {
+    if (one_launch && nlv && !rc) {
+        if (mi355_hevc_recon_levels_dev((const mi355_hevc_level *)(m->d + o_lv), nlv, (int)total_wg, (const mi355_hevc_mcpred_job *)(m->d + o_mc),
+                                        (const mi355_hevc_tu_job *)(m->d + o_tu), (const mi355_hevc_intra_picture *)(m->d + o_desc),
+                                        (const mi355_hevc_intra_block *)(m->d + o_in), (const mi355_hevc_tu_job *)(m->d + o_fu), bd, st) != 0) rc = -1;
+        launches = 1;
+    }
+    for (int l = 1; l <= maxL && !rc && !one_launch; l++) {
         const int nm = fmc[l + 1] - fmc[l], nt = ftu[l + 1] - ftu[l], ni = fin[l + 1] - fin[l];
         if (!b[0]->split_intra && !g_three_launches) {
             /* the level's three job kinds in one launch */

@@ -317,6 +317,28 @@ int mi355_hevc_recon_level_dev(const mi355_hevc_mcpred_job *d_mc, int n_mc, cons
                                const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
                                const mi355_hevc_tu_job *d_block_tus, int n_blocks, int bit_depth, void *stream);
 
+/* EVERY dependency level of a batch of pictures in ONE launch.  d_levels[l] names level l's jobs inside the three job arrays (the arrays in level order,
+ * as a caller that walks levels has them anyway) and `first_wg`, the number of workgroups of the levels before it: a level takes
+ * n_mc + (n_tu + 1) / 2 + n_in workgroups (what mi355_hevc_recon_level_dev launches for it), first_wg of level 0 is 0, n_workgroups is the total.
+ * Results are those of mi355_hevc_recon_level_dev called for each level in turn: a workgroup of level l starts its job when every workgroup of the
+ * levels before has finished and its samples are visible.  An all-intra picture is hundreds to thousands of levels of a handful of blocks each
+ * (contrib/libav/mi355_hevc_bridge.c).  Measured on MI355X: 3.0 us per level for levels of two workgroups, growing with the level's size (7 us at 32 workgroups,
+ * 147 us at 1000: every workgroup counts itself into one word); back-to-back calls of mi355_hevc_recon_level_dev are 3.5 - 4 us per level whatever its size when
+ * the caller keeps the queue ahead of the device.  For chains of small levels whose caller cannot do that.
+ * Should the device ever start workgroups in an order that leaves a level waiting for good, the wait ends after about a second and
+ * MI355_ERR_WAIT_EXPIRED is set in the error word (mi355dsp.h): the next mi355_sync / mi355_event_sync returns MI355_E_DEVICE_FAULT and the caller
+ * repeats the batch level by level. */
+typedef struct mi355_hevc_level {
+    uint32_t first_wg;                  /* workgroups of levels 0 .. l - 1 */
+    uint32_t mc0, n_mc;                 /* d_mc[mc0 .. mc0 + n_mc) */
+    uint32_t tu0, n_tu;                 /* d_tus[tu0 .. tu0 + n_tu) */
+    uint32_t in0, n_in;                 /* d_blocks / d_block_tus[in0 .. in0 + n_in) */
+    uint32_t reserved;
+} mi355_hevc_level;
+int mi355_hevc_recon_levels_dev(const mi355_hevc_level *d_levels, int n_levels, int n_workgroups, const mi355_hevc_mcpred_job *d_mc,
+                                const mi355_hevc_tu_job *d_tus, const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks,
+                                const mi355_hevc_tu_job *d_block_tus, int bit_depth, void *stream);
+
 /* ---- a12-a15 fused per coding tree block: what hls_coding_quadtree (hevcdec.c:2202-2290) does for the INTER coding units of one CTB —
  * every prediction block (hls_prediction_unit :1695-1885: luma_mc / chroma_mc + put_unweighted_pred / weighted_pred), then every transform
  * unit (hls_transform_unit :1238-1260: idct / transform_skip / ..., add_residual) — as ONE workgroup: the CTB's samples are predicted into an

@@ -9,6 +9,7 @@
 #include "mi355_rt.h"
 #include "hevc_dev.h"
 #include "../../include/mi355_hevc_batch.h"
+#include "../../include/mi355dsp.h"
 
 using namespace mi355;
 
@@ -945,6 +946,98 @@ __global__ void __launch_bounds__(64) k_hevc_recon_level(const mi355_hevc_mcpred
     hevc_residual_run(u.in.t, j, lane < 32, lane >> 5, lane & 31, bd);
 }
 
+/* EVERY level of a batch of pictures in ONE launch (mi355_hevc_recon_levels_dev): the workgroups of all levels in level order, each doing what its
+ * workgroup of k_hevc_recon_level does.  A workgroup takes a ticket (sync[0]: tickets go out in the order workgroups START, whatever numbers the device gave
+ * them), finds the level its ticket lies in, and waits until every workgroup of the levels before has counted itself into sync[1] — behind an agent-scope
+ * release of its stores; the waiter's loads follow an agent-scope acquire.  The same order between levels as a launch per level gives, for one launch: an
+ * all-intra 1080p picture is a chain of ~2800 levels of a handful of blocks each.
+ * MEASURED (profiles/r06_experiments.md 12, tools/exp_levels.py): the hop inside the launch is 3.0 us per level for levels of two workgroups — against 3.5 us for back-to-back
+ * launches of mi355_hevc_recon_level_dev, whose host side keeps the queue ahead of the device — and grows with the level's size (every workgroup counts itself into ONE word:
+ * 7 us at 32 workgroups per level, 147 us at 1000), where a launch boundary stays at 3.5 - 4 us.  The entry point is for chains of SMALL levels whose caller cannot keep a
+ * queue full; the reference-side bridge keeps its launch per level (MI355_HEVC_BRIDGE_ONE_LAUNCH=1 switches it over).
+ * Progress: the unfinished workgroup with the lowest ticket waits for workgroups with lower tickets only — all finished.  A wait that runs out all the same
+ * (LV_NAPS_MAX) sets MI355_ERR_WAIT_EXPIRED in the device's error word: the next mi355_sync / mi355_event_sync returns MI355_E_DEVICE_FAULT.
+ * A waiter far from its turn sleeps longer between looks (every resident wave looking at one word every half microsecond would be that word's whole traffic). */
+constexpr uint32_t LV_NAPS_MAX = 1u << 21;
+#ifdef MI355_HIP_EMU_H
+static inline uint32_t lv_load(const uint32_t *p) { return *p; }
+static inline void lv_release() {}
+static inline void lv_acquire() {}
+static inline void lv_nap(uint32_t) { std::fprintf(stderr, "k_hevc_recon_levels: a level waits for one that has not run (emulator: workgroups run in order)\n"); std::abort(); }
+#else
+__device__ __forceinline__ uint32_t lv_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lv_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lv_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void lv_nap(uint32_t far)
+{
+    __builtin_amdgcn_s_sleep(8);
+    for (uint32_t k = 0; k < far; k++) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+static_assert(sizeof(mi355_hevc_level) == 32, "eight dwords per level record (fetched a dword per lane)");
+__global__ void __launch_bounds__(64) k_hevc_recon_levels(const mi355_hevc_level *levels, int n_levels, const mi355_hevc_mcpred_job *mc, const mi355_hevc_tu_job *tu,
+                                                          const mi355_hevc_intra_picture *pics, const mi355_hevc_intra_block *blocks, const mi355_hevc_tu_job *btus,
+                                                          int bd, uint32_t *sync, uint32_t *error_word, uint32_t naps_max)
+{
+    __shared__ LevelLds u;
+    const int lane = lane_id();
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(mi355_global(sync), 1u);
+    tk = (uint32_t)lane_value((int)tk, 0);
+    /* the level of ticket tk: the last one whose first workgroup is <= tk — 64 probes per round trip */
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(mi355_global(levels));
+    int lo = 0, cnt = n_levels;                        /* the answer lies in [lo, lo + cnt) */
+    while (cnt > 1) {
+        const int stride = (cnt + 63) >> 6, idx = lo + lane * stride;
+        const bool in = lane * stride < cnt;
+        const uint32_t first = in ? mi355_global_v(lw)[8 * (size_t)idx] : 0xFFFFFFFFu;
+        const int below = __popcll(__ballot(in && first <= tk));          /* >= 1: level lo starts at or before tk */
+        const int base = lo + (below - 1) * stride;
+        cnt = imin(stride, lo + cnt - base);
+        lo = base;
+    }
+    const uint32_t rec = mi355_global_v(lw)[8 * (size_t)lo + (lane < 8 ? lane : 7)];
+    const uint32_t first_wg = (uint32_t)lane_value((int)rec, 0);
+    const int mc0 = lane_value((int)rec, 1), nm = lane_value((int)rec, 2), tu0 = lane_value((int)rec, 3), nt = lane_value((int)rec, 4);
+    const int in0 = lane_value((int)rec, 5), ni = lane_value((int)rec, 6);
+    uint32_t *const done = mi355_global(sync) + 1;
+    if (first_wg) {
+        uint32_t naps = 0, seen;
+        for (;;) {
+            seen = (uint32_t)lane_value((int)lv_load(mi355_global_v(done)), 0);
+            if (seen >= first_wg || naps >= naps_max) break;
+            lv_nap(imin((int)((first_wg - seen) >> 3), 24));
+            naps++;
+        }
+        if (seen < first_wg && lane == 0) atomicOr(error_word, (uint32_t)MI355_ERR_WAIT_EXPIRED);
+        lv_acquire();
+    }
+    int b = (int)(tk - first_wg);
+    if (b < nm) {
+        int16_t *const keep = u.mc.tmp + HEVC_MC_BI_ROWS * HEVC_MC_TPITCH;
+        const mi355_hevc_mcpred_job j = mc[mc0 + b];
+        switch ((j.chroma ? 4 : 0) + (j.kind & 3)) {
+        case 0: hevc_mcpred_taps<8, 0>(j, bd, u.mc, keep); break;   case 1: hevc_mcpred_taps<8, 1>(j, bd, u.mc, keep); break;
+        case 2: hevc_mcpred_taps<8, 2>(j, bd, u.mc, keep); break;   case 3: hevc_mcpred_taps<8, 3>(j, bd, u.mc, keep); break;
+        case 4: hevc_mcpred_taps<4, 0>(j, bd, u.mc, keep); break;   case 5: hevc_mcpred_taps<4, 1>(j, bd, u.mc, keep); break;
+        case 6: hevc_mcpred_taps<4, 2>(j, bd, u.mc, keep); break;   default: hevc_mcpred_taps<4, 3>(j, bd, u.mc, keep); break;
+        }
+    } else if ((b -= nm) < (nt + 1) / 2) {
+        const int half = lane >> 5, idx = 2 * b + half;
+        const bool on = idx < nt;
+        hevc_residual_run(u.tu, tu[tu0 + (on ? idx : 0)], on, half, lane & 31, bd);
+    } else if ((b -= (nt + 1) / 2) < ni) {
+        hevc_intra_block_run(u.in.s, pics, mi355_global_v(blocks)[in0 + b], bd);
+        const mi355_hevc_tu_job j = mi355_global_v(btus)[in0 + b];
+        if (j.coeffs) {
+            __syncthreads();        /* as in k_hevc_intra_recon_blocks: the prediction's stores are what the residual's loads see */
+            hevc_residual_run(u.in.t, j, lane < 32, lane >> 5, lane & 31, bd);
+        }
+    }
+    lv_release();                   /* this workgroup's samples are where every other workgroup's loads (behind their acquire) find them */
+    if (lane == 0 && naps_max) atomicAdd(done, 1u);       /* (bound 0, the test hook: nobody counts, every wait runs out) */
+}
+
 /* ---- a16 + a17 fused: deblocking and SAO of a coding tree block in ONE workgroup (mi355_hevc_filter_ctbs_dev) --------------------------------------------
  * What deblocking_filter_CTB (hevc_filter.c:337-505) and sao_filter_CTB (:188-314) do to a block's own samples, from the UNFILTERED reconstruction to the output
  * picture, without the deblocked picture ever leaving the chip.  The block and 8 samples around it are fetched into LDS (rows and columns -4 .. size + 3 are
@@ -1322,6 +1415,25 @@ extern "C" int mi355_hevc_recon_level_dev(const mi355_hevc_mcpred_job *d_mc, int
     if (!check(bit_depth, &wgs, wgs)) return -1;
     hipLaunchKernelGGL(k_hevc_recon_level, dim3((unsigned)wgs), dim3(64), 0, (hipStream_t)stream, d_mc, n_mc, d_tus, n_tus, d_pics, d_blocks, d_block_tus,
                        n_blocks, bit_depth);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int mi355_hevc_recon_levels_dev(const mi355_hevc_level *d_levels, int n_levels, int n_workgroups, const mi355_hevc_mcpred_job *d_mc, const mi355_hevc_tu_job *d_tus,
+                                           const mi355_hevc_intra_picture *d_pics, const mi355_hevc_intra_block *d_blocks, const mi355_hevc_tu_job *d_block_tus,
+                                           int bit_depth, void *stream)
+{
+    if (n_levels <= 0 || !d_levels) return -1;
+    if (!check(bit_depth, d_levels, n_workgroups)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *sync = mi355::sync_words(st, 16);
+    uint32_t *err = mi355::error_word();
+    if (!sync || !err) return -4;
+    if (hipMemsetAsync(sync, 0, 16 * sizeof(uint32_t), st) != hipSuccess) return -4;
+    /* MI355_LEVELS_NAPS_MAX (developer / test hook): the bound of a wait; 0: nobody counts itself done, every wait runs out at once (tests/test_hevc_batch_*: the error word) */
+    static const char *e = std::getenv("MI355_LEVELS_NAPS_MAX");
+    const uint32_t naps_max = e && *e ? (uint32_t)std::strtoul(e, nullptr, 0) : LV_NAPS_MAX;
+    hipLaunchKernelGGL(k_hevc_recon_levels, dim3((unsigned)n_workgroups), dim3(64), 0, st, d_levels, n_levels, d_mc, d_tus, d_pics, d_blocks, d_block_tus, bit_depth,
+                       sync, err, naps_max);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -157,6 +157,8 @@ bool ready();
  * mi355_error_word_take()) */
 /* the calling thread's counter buffer of `stream` (h264_deblock.hip: sync_words) is freed: a stream about to be destroyed */
 void sync_words_release(hipStream_t stream);
+/* h264_deblock.hip: the scratch words (ticket + progress counters) of a single-launch form, one buffer per (thread, device, stream); the caller zeroes what it uses on `stream` */
+uint32_t *sync_words(hipStream_t stream, size_t words);
 uint32_t *error_word();
 int fault_after_wait();
 bool blocking_sync();      /* waits sleep instead of spinning (MI355_BLOCKING_SYNC / mi355_prefer_blocking_sync) */

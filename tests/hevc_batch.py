@@ -650,6 +650,12 @@ def check_intra(prov, oracle, bd, seed, cells=(5, 7)):
 
 
 
+class Level(C.Structure):
+    """mi355_hevc_level"""
+    _fields_ = [("first_wg", C.c_uint32), ("mc0", C.c_uint32), ("n_mc", C.c_uint32), ("tu0", C.c_uint32), ("n_tu", C.c_uint32), ("in0", C.c_uint32),
+                ("n_in", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class CtbJob(C.Structure):
     _fields_ = [("dst", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("width", C.c_uint16), ("height", C.c_uint16), ("log2_ctb_size", C.c_uint8),
                 ("flags", C.c_uint8), ("reserved", C.c_uint8 * 2), ("first_mc", C.c_uint32), ("n_mc", C.c_uint32), ("first_tu", C.c_uint32),
@@ -680,7 +686,7 @@ def decoder_block(r, size):
     return c, lim
 
 
-def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3), promise_check=True):
+def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3), promise_check=True, form="ctbs"):
     """mi355_hevc_recon_ctbs_dev — a coding tree block's prediction blocks and transform units in one workgroup — against the oracle's tables
     called block by block in the reference's order (hls_prediction_unit, then hls_transform_unit: hevcdec.c:1695-1885, :1238-1260): random
     partitions (squares 64..8, halves, quarter splits), every prediction kind with one or two references, chroma blocks alone and as pairs,
@@ -874,6 +880,24 @@ def check_recon_ctbs(prov, oracle, bd, seed, cells=(2, 3), promise_check=True):
         lib.mi355_hevc_recon_ctbs_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
         lib.mi355_error_word_take.restype = C.c_uint
         p_jobs, p_mc, p_tu = d.up_jobs(jobs), d.up_jobs(mc_jobs), d.up_jobs(tu_jobs)
+        if form == "levels":
+            # the same jobs through mi355_hevc_recon_levels_dev: the prediction jobs as level 0, then the transform units (they add to what level 0 wrote) as
+            # levels of 1 .. 5 units — a few hundred levels in one launch, each waiting for all before it
+            lib.mi355_hevc_recon_levels_dev.restype = C.c_int
+            lib.mi355_hevc_recon_levels_dev.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+            levels, wg, t = [Level(0, 0, len(mc_jobs), 0, 0, 0, 0, 0)], len(mc_jobs), 0
+            while t < len(tu_jobs):
+                n = min(r.randint(1, 5), len(tu_jobs) - t)
+                levels.append(Level(wg, 0, 0, t, n, 0, 0, 0))
+                wg += (n + 1) // 2
+                t += n
+            assert lib.mi355_hevc_recon_levels_dev(d.up_jobs(levels), len(levels), wg, p_mc, p_tu, None, None, None, bd, None) == 0
+            assert lib.mi355_sync(None) == 0
+            got = [d.down(p_pic[pl], pic[pl]) for pl in range(3)]
+            for pl in range(3):
+                bad = np.argwhere(got[pl] != pic_o[pl])
+                assert bad.size == 0, "recon_levels: plane %d differs at %d samples, first (y, x) = %s (bd %d)" % (pl, len(bad), bad[0], bd)
+            return len(levels)
         if promise_check:
             # the caller's promise (MI355_HEVC_RECON_UNIFORM) on a list that breaks it: the blocks of other shapes are left as they were and the device says so
             lib.mi355_error_word_take()
@@ -933,6 +957,39 @@ def check_level_residual(prov, oracle, bd, seed):
     return check_residual(_LevelProv(prov), oracle, bd, seed, cells=(5, 7))      # an odd number of units: the last workgroup holds one
 
 
+def check_recon_levels(prov, oracle, bd, seed):
+    return check_recon_ctbs(prov, oracle, bd, seed, promise_check=False, form="levels")
+
+
 CHECKS = {"residual": check_residual, "mc": check_mc, "pred": check_pred, "deblock": check_deblock, "sao": check_sao,
           "intra": check_intra, "mcpred": check_mcpred, "sao_ctbs": check_sao_ctbs, "edge_emu": check_edge_emu,
-          "level_mcpred": check_level_mcpred, "level_residual": check_level_residual, "recon_ctbs": check_recon_ctbs}
+          "level_mcpred": check_level_mcpred, "level_residual": check_level_residual, "recon_ctbs": check_recon_ctbs, "recon_levels": check_recon_levels}
+
+
+def levels_wait_expiry_in_subprocess(provider_name):
+    """mi355_hevc_recon_levels_dev's bounded wait (hevc_batch.hip: k_hevc_recon_levels): with the bound at zero (MI355_LEVELS_NAPS_MAX=0, read once per process: a process of its
+    own) nobody counts itself done and every workgroup behind level 0 gives up at once — the entry point returns 0 (the launch was made), the wait behind it
+    MI355_E_DEVICE_FAULT, the error word says MI355_ERR_WAIT_EXPIRED, and the word once taken the device is usable again."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import providers, hevc_batch\n"
+        "prov = providers.%s()\n"
+        "lib = prov.lib\n"
+        "lib.mi355_error_word_take.restype = C.c_uint\n"
+        "lib.mi355_error_word_take()\n"
+        "try:\n"
+        "    hevc_batch.check_recon_levels(prov, providers.oracle(), 8, 5)\n"
+        "    print('RESULT no assertion')\n"
+        "except AssertionError:\n"
+        "    word = lib.mi355_error_word_take()\n"
+        "    print('RESULT', word, lib.mi355_sync(None))\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), provider_name)
+    env = dict(os.environ, MI355_LEVELS_NAPS_MAX="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert line[1:] == ["1", "0"], line

@@ -63,11 +63,11 @@ def check_md5(path, name):
     assert hashlib.md5(raw).hexdigest() == MD5[name]["md5"], "%s: pictures differ from the reference decoder's" % name
 
 
-def run_bridge(which, name, out, plain=False, irap_on_host=False, split_intra=False, threads=1, loops=1, solo=False):
+def run_bridge(which, name, out, plain=False, irap_on_host=False, split_intra=False, threads=1, loops=1, solo=False, one_launch=False):
     """the reference's HEVC decoder with contrib/libav/mi355_hevc_bridge.c + mi355_hevc_lf_bridge.c (oracle/_ref/hevc_bridge_{emu,gpu}): -> its
     JSON counters; plain = the comparison run (everything forwarded to the reference's own functions)"""
     env = dict(os.environ)
-    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BS_HOST", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_SPLIT_INTRA", "MI355_HEVC_BRIDGE_SOLO"):
+    for k in ("MI355_HEVC_RECON_PLAIN", "MI355_HEVC_LF_PLAIN", "MI355_HEVC_BS_HOST", "MI355_HEVC_BRIDGE_IRAP_ON_HOST", "MI355_HEVC_BRIDGE_SPLIT_INTRA", "MI355_HEVC_BRIDGE_SOLO", "MI355_HEVC_BRIDGE_ONE_LAUNCH"):
         env.pop(k, None)
     env["MI355_HEVC_BRIDGE_MIN_PIXELS"] = "0"           # small streams on the device all the same (default: pictures below 1.5 M samples stay on the host)
     if plain:
@@ -76,6 +76,8 @@ def run_bridge(which, name, out, plain=False, irap_on_host=False, split_intra=Fa
         env["MI355_HEVC_BRIDGE_IRAP_ON_HOST"] = "1"
     if split_intra:
         env["MI355_HEVC_BRIDGE_SPLIT_INTRA"] = "1"      # an intra block's prediction and its residual as two launches
+    if one_launch:
+        env["MI355_HEVC_BRIDGE_ONE_LAUNCH"] = "1"       # every dependency level of a launch set in one launch (mi355_hevc_recon_levels_dev)
     if solo:
         env["MI355_HEVC_BRIDGE_SOLO"] = "1"             # every picture issues its own launches (no sharing between the decoders of the process)
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", which), samples(name), str(out), str(loops), str(threads)], capture_output=True, text=True, env=env, timeout=1800)

@@ -15,3 +15,7 @@ def test_emulated_config3_chain_small_picture(emu, oracle, bd):
     """MC -> pred -> residual -> edges (V, H) -> SAO of one small picture, stage outputs feeding the next stage"""
     import hevc_config3
     assert hevc_config3.check(emu, oracle, 256, 192, bd, seed=3) > 0
+
+
+def test_emulated_levels_launch_wait_that_runs_out_is_reported():
+    hevc_batch.levels_wait_expiry_in_subprocess("emu")

@@ -23,3 +23,7 @@ def test_gpu_config3_chain_full_size_picture(mi355, oracle):
     the oracle's table functions called in the same order (about 0.4 M jobs)"""
     import hevc_config3
     assert hevc_config3.check(mi355, oracle, 3840, 2160, 10, seed=0x265) > 0
+
+
+def test_gpu_levels_launch_wait_that_runs_out_is_reported(mi355):
+    hevc_batch.levels_wait_expiry_in_subprocess("mi355")

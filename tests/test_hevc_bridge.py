@@ -60,6 +60,16 @@ def test_hevc_bridge_intra_blocks_with_their_residual_in_one_launch_emulated(tmp
     assert fused["dependency_levels"] < split["dependency_levels"] and fused["reconstruction_launches"] < split["reconstruction_launches"], (fused, split)
 
 
+@pytest.mark.parametrize("name", ["i_ctb64", "pb_tiles_dep", "pb_10bit_weighted", "pb_480p_ctb64"])
+def test_hevc_bridge_all_levels_in_one_launch_emulated(tmp_path, emu, name):
+    """MI355_HEVC_BRIDGE_ONE_LAUNCH=1: every dependency level of a picture's launch set through mi355_hevc_recon_levels_dev — one reconstruction launch per set, the
+    same pictures (on the emulator workgroups run in ticket order: what the waits order is the device test's business)"""
+    subprocess.run(["make", "-s", "-C", os.path.join(HS.ROOT, "oracle"), "_ref/hevc_bridge_emu"], check=True)
+    st = HS.run_bridge("hevc_bridge_emu", name, tmp_path / "o.yuv", one_launch=True)
+    HS.check_md5(tmp_path / "o.yuv", name)
+    assert st["pictures_reconstructed_on_device"] == HS.MD5[name]["pictures"] and st["reconstruction_launches"] <= st["launch_sets"] < st["dependency_levels"], st
+
+
 def test_small_pictures_stay_on_the_host_by_default(emu, tmp_path):
     """the bridges' size policy (MI355_HEVC_BRIDGE_MIN_PIXELS, default 1.5 M luma samples): a 96x64 stream decoded WITHOUT the tests' override is left to
     the reference's C path — same pictures, nothing reconstructed on the device — because one decoder's launch set per dependency level costs more than the C

@@ -54,6 +54,16 @@ def test_hevc_bridge_two_launch_form_of_intra_blocks_gpu(tmp_path, mi355, name):
     assert fused["dependency_levels"] < split["dependency_levels"], (fused, split)
 
 
+@pytest.mark.parametrize("name,threads", (("i_ctb64", 1), ("pb_tiles_dep", 1), ("pb_10bit_weighted", 1), ("pb_480p_ctb64", 4), ("pb_1080p_few_intra", 2)))
+def test_hevc_bridge_all_levels_in_one_launch_gpu(tmp_path, mi355, name, threads):
+    """MI355_HEVC_BRIDGE_ONE_LAUNCH=1: every dependency level of a launch set through mi355_hevc_recon_levels_dev (hundreds to thousands of levels waiting for each
+    other inside ONE launch, several sets side by side on their streams when there are several decoders) — the reference decoder's pictures"""
+    st = HS.run_bridge("hevc_bridge_gpu", name, tmp_path / "o.yuv", one_launch=True, threads=threads, loops=2)
+    HS.check_md5(tmp_path / "o.yuv", name)
+    n = HS.MD5[name]["pictures"] * threads * 2
+    assert st["outputs_identical"] is True and st["pictures_reconstructed_on_device"] == n and st["reconstruction_launches"] <= st["launch_sets"] < st["dependency_levels"], st
+
+
 @pytest.mark.parametrize("name,threads", (("pb_8bit", 4), ("i_10bit", 3), ("pb_480p_ctb64", 8)))
 def test_hevc_bridge_many_decoders_share_launches_gpu(tmp_path, mi355, name, threads):
     """several decoders in one process (one per thread): the pictures that wait together are launched together (commit_launches) — every
