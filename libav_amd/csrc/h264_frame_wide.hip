@@ -490,6 +490,7 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
     const int W = 16 * fr.mb_width, H = (16 * fr.mb_height) >> g.hs;
     const size_t rys = (size_t)fr.dst_stride[0] << g.hs, rcs = (size_t)fr.dst_stride[1] << g.hs;      /* a field macroblock of an MBAFF frame predicts from fields */
     const int lw = w == 16 ? 4 : (w == 8 ? 3 : 2);            /* log2 of the block's width */
+#ifndef MI355_WIDE_EXP_NOLUMA
     {
         const int x0 = (mx >> 2) - 2, y0 = (my >> 2) - 2, ww = w + 5, hh = h + 5, nc = (ww + 7) >> 3;
         if (x0 >= 0 && y0 >= 0 && x0 + 8 * nc <= W && y0 + hh <= H) {
@@ -526,6 +527,10 @@ __device__ inline void wide_mc_dir(WideInterLds &s, const mi355_h264_frame &fr, 
         }
         MI355_WAVE_SYNC();
     }
+#endif
+#ifdef MI355_WIDE_EXP_NOCHROMA
+    return;
+#endif
     /* chroma: eighth-sample bilinear (h264chroma_template.c:28-200); 4:2:2 keeps the luma's vertical resolution (h264_mb.c:284-315) */
     const int cw = w >> 1, ch = CF == 2 ? h : h >> 1, cby = CF == 2 ? by : by >> 1;
     const int myc = CF == 1 ? my + uniform((int)s.hdr.u.inter.chroma_dy[list][quadrant]) : my;
@@ -683,6 +688,10 @@ k_wide_inter(const mi355_h264_frame *__restrict__ frames, int max_w, int max_h)
         wide_mc_part<BD, CF>(s, fr, sl, mb_x, g, n, quad, bx, by, w, h, l0, l1);
     }
 #undef DIRF
+#ifdef MI355_WIDE_EXP_NORES
+    wide_store_mb<BD, CF>(fr, mb_x, g, s.py, 16, s.pc[0], s.pc[1], 8);
+    return;
+#endif
     if (luma_coded || chroma_coded) wide_commit_coefs<BD, CF>(s.coef, cregs);       /* the windows' place is free now */
     /* hl_decode_mb_idct_luma (h264_mb.c:726-795): idct_add16 / idct8_add4 choose between full, DC-only and nothing per block; so does
      * wide_block4 / wide_add_blocks8, from the coefficients (a block whose count is 1 with a DC level holds nothing else) */

@@ -1,5 +1,5 @@
 /*
- * oracle_h264frame_hbd.c — the frame-level checker of oracle_h264frame.c for 9 / 10-bit pictures (4:2:0): the same per-macroblock
+ * oracle_h264frame_hbd.c — the frame-level checker of oracle_h264frame.c for 9 / 10-bit pictures, 4:2:0 and (round 6) 4:2:2: the same per-macroblock
  * reconstruction and loop-filter drivers on 16-bit samples and 32-bit coefficients (`dctcoef` is int32 above 8 bits, h264dec.h), calling
  * THE REFERENCE'S OWN tables at that bit depth — ff_h264dsp_init(c, bd, 1), ff_h264qpel_init, ff_h264chroma_init, ff_h264_pred_init from
  * oracle/_ref/libref.so (the reference's C files compiled where they lie; libavcodec/h264dsp.c:37-47,57-137, h264qpel.c:37-89), bound
@@ -13,6 +13,12 @@
  *   - the loop filter's table indices take the 8-bit QP: index_a = qp + a with a = 52 + slice_alpha_c0_offset - qp_bd_offset
  *     (h264_loopfilter.c:104-236 with h264_slice.c's qp_bd_offset); alpha, beta and tc0 are scaled to the depth inside the tables' functions;
  *   - a macroblock's chroma QPs come from its record (mi355_h264_mb.qpc, what the second kernel set reads).
+ * With chroma_format_idc 2 (oracle_h264frame_hbd_bind_cf): the tables are initialised for it, which makes h264_chroma_dc_dequant_idct the 2x4 form
+ * (h264idct_template.c:275-310), h264_idct_add8 the eight-blocks-a-plane form (:216-238), h264_h_loop_filter_chroma* the sixteen-line forms
+ * (h264dsp.c:57-137) and pred8x8[] the 8x16 predictors (h264pred.c:448-507); the drivers follow the CHROMA422 branches: chroma blocks keep the luma's
+ * height and vertical vector resolution (mc_dir_part h264_mb.c:284-315: ysh = 2, (my << 1) & 7), weights run over h lines, horizontal chroma edges lie
+ * at chroma rows 0, 4, 8, 12 with the strengths of luma edges 0..3 — also where an 8x8 transform leaves the luma edge out (h264_loopfilter.c:633, :693-700).
+ * A chroma block's non_zero_count_cache entry is read off its coefficients (any AC level), as the second kernel set does (include/mi355_h264_frame.h).
  * Restated drivers: hl_decode_mb (h264_mb_template.c:41-257), hl_motion (h264_mc_template.c:64-163), mc_part_* (h264_mb.c:320-471),
  * hl_decode_mb_predict_luma / _idct_luma (h264_mb.c:612-795), ff_h264_filter_mb (h264_loopfilter.c:716-847).
  */
@@ -33,19 +39,28 @@ static H264QpelContext qpel;
 static H264ChromaContext chroma;
 static H264PredContext pred;
 static int bit_depth;                /* 0: not bound */
+static int cfi = 1;                  /* chroma_format_idc the tables were bound for: 1 or 2 */
+#define CH (cfi == 2 ? 16 : 8)       /* chroma rows of a macroblock */
+#define NCB (cfi == 2 ? 8 : 4)       /* 4x4 blocks of a chroma plane */
 
 /* fills the four tables with the reference's functions at `bd` bits (9 or 10), 4:2:0 */
+int oracle_h264frame_hbd_bind_cf(void (*dsp_init)(H264DSPContext *, int, int), void (*qpel_init)(H264QpelContext *, int),
+                                 void (*chroma_init)(H264ChromaContext *, int), void (*pred_init)(H264PredContext *, int, int, int), int bd, int chroma_format_idc)
+{
+    if (!dsp_init || !qpel_init || !chroma_init || !pred_init || bd < 9 || bd > 10 || chroma_format_idc < 1 || chroma_format_idc > 2) return -1;
+    memset(&dsp, 0, sizeof(dsp)); memset(&qpel, 0, sizeof(qpel)); memset(&chroma, 0, sizeof(chroma)); memset(&pred, 0, sizeof(pred));
+    dsp_init(&dsp, bd, chroma_format_idc);
+    qpel_init(&qpel, bd);
+    chroma_init(&chroma, bd);
+    pred_init(&pred, MI355_AV_CODEC_ID_H264, bd, chroma_format_idc);
+    bit_depth = bd;
+    cfi = chroma_format_idc;
+    return 0;
+}
 int oracle_h264frame_hbd_bind(void (*dsp_init)(H264DSPContext *, int, int), void (*qpel_init)(H264QpelContext *, int),
                               void (*chroma_init)(H264ChromaContext *, int), void (*pred_init)(H264PredContext *, int, int, int), int bd)
 {
-    if (!dsp_init || !qpel_init || !chroma_init || !pred_init || bd < 9 || bd > 10) return -1;
-    memset(&dsp, 0, sizeof(dsp)); memset(&qpel, 0, sizeof(qpel)); memset(&chroma, 0, sizeof(chroma)); memset(&pred, 0, sizeof(pred));
-    dsp_init(&dsp, bd, 1);
-    qpel_init(&qpel, bd);
-    chroma_init(&chroma, bd);
-    pred_init(&pred, MI355_AV_CODEC_ID_H264, bd, 1);
-    bit_depth = bd;
-    return 0;
+    return oracle_h264frame_hbd_bind_cf(dsp_init, qpel_init, chroma_init, pred_init, bd, 1);
 }
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
@@ -103,10 +118,12 @@ static void mc_dir_part(Ctx *c, int list, int n_raster, int refn, int bx, int by
     for (int j = 0; j < h; j++) memcpy(dy + (size_t)j * dys, td + j * MCS, (size_t)w * PX);
     for (int p = 1; p < 3; p++) {
         uint8_t *d = p == 1 ? dcb : dcr;
-        const int cw = w >> 1, ch = h >> 1, tab = cw == 8 ? 0 : (cw == 4 ? 1 : 2);
-        fetch(win, MCS, f->ref[slot][p], f->dst_stride[1], pw >> 1, ph >> 1, mx >> 3, myc >> 3, cw + 1, ch + 1);
+        /* h264_mb.c:284-315: 4:2:2 keeps the luma's lines (ysh = 2, the fraction (my << 1) & 7) and has no field offset */
+        const int v422 = cfi == 2, ysh = v422 ? 2 : 3, myv = v422 ? my : myc;
+        const int cw = w >> 1, ch = v422 ? h : h >> 1, tab = cw == 8 ? 0 : (cw == 4 ? 1 : 2);
+        fetch(win, MCS, f->ref[slot][p], f->dst_stride[1], pw >> 1, v422 ? ph : ph >> 1, mx >> 3, myv >> ysh, cw + 1, ch + 1);
         for (int j = 0; j < ch; j++) memcpy(td + j * MCS, d + (size_t)j * dcs, (size_t)cw * PX);
-        (avg ? chroma.avg_h264_chroma_pixels_tab : chroma.put_h264_chroma_pixels_tab)[tab](td, win, MCS, ch, mx & 7, myc & 7);
+        (avg ? chroma.avg_h264_chroma_pixels_tab : chroma.put_h264_chroma_pixels_tab)[tab](td, win, MCS, ch, mx & 7, (v422 ? myv << 1 : myv) & 7);
         for (int j = 0; j < ch; j++) memcpy(d + (size_t)j * dcs, td + j * MCS, (size_t)cw * PX);
     }
 }
@@ -118,7 +135,8 @@ static void mc_part(Ctx *c, int n_raster, int quadrant, int bx, int by, int w, i
     const mi355_h264_frame *f = c->f;
     const mi355_h264_slice *sl = c->sl;
     const int ys = f->recon_stride[0], cs = f->recon_stride[1];
-    uint8_t *py = dy + bx * PX + by * ys, *pcb = dcb + (bx >> 1) * PX + (by >> 1) * cs, *pcr = dcr + (bx >> 1) * PX + (by >> 1) * cs;
+    const int hc = cfi == 2 ? h : h >> 1, cby = cfi == 2 ? by : by >> 1;      /* chroma lines of the partition, its first chroma line */
+    uint8_t *py = dy + bx * PX + by * ys, *pcb = dcb + (bx >> 1) * PX + cby * cs, *pcr = dcr + (bx >> 1) * PX + cby * cs;
     const int r0 = c->m->ref_idx[0][quadrant], r1 = c->m->ref_idx[1][quadrant];
     const int weighted = (sl->use_weight == 2 && list0 && list1 && sl->implicit_weight[r0][r1] != 32) || sl->use_weight == 1;
     const int widx = w == 16 ? 0 : (w == 8 ? 1 : (w == 4 ? 2 : 3)), cwidx = widx + 1;
@@ -136,14 +154,14 @@ static void mc_part(Ctx *c, int n_raster, int quadrant, int bx, int by, int w, i
         if (sl->use_weight == 2) {
             int w0 = sl->implicit_weight[r0][r1], w1 = 64 - w0;
             dsp.biweight_h264_pixels_tab[widx](py, ty, ys, h, 5, w0, w1, 0);
-            dsp.biweight_h264_pixels_tab[cwidx](pcb, tcb, cs, h >> 1, 5, w0, w1, 0);
-            dsp.biweight_h264_pixels_tab[cwidx](pcr, tcr, cs, h >> 1, 5, w0, w1, 0);
+            dsp.biweight_h264_pixels_tab[cwidx](pcb, tcb, cs, hc, 5, w0, w1, 0);
+            dsp.biweight_h264_pixels_tab[cwidx](pcr, tcr, cs, hc, 5, w0, w1, 0);
         } else {
             dsp.biweight_h264_pixels_tab[widx](py, ty, ys, h, sl->luma_log2_weight_denom,
                                                sl->luma_weight[r0][0][0], sl->luma_weight[r1][1][0],
                                                sl->luma_weight[r0][0][1] + sl->luma_weight[r1][1][1]);
             for (int p = 0; p < 2; p++)
-                dsp.biweight_h264_pixels_tab[cwidx](p ? pcr : pcb, p ? tcr : tcb, cs, h >> 1, sl->chroma_log2_weight_denom,
+                dsp.biweight_h264_pixels_tab[cwidx](p ? pcr : pcb, p ? tcr : tcb, cs, hc, sl->chroma_log2_weight_denom,
                                                     sl->chroma_weight[r0][0][p][0], sl->chroma_weight[r1][1][p][0],
                                                     sl->chroma_weight[r0][0][p][1] + sl->chroma_weight[r1][1][p][1]);
         }
@@ -153,9 +171,9 @@ static void mc_part(Ctx *c, int n_raster, int quadrant, int bx, int by, int w, i
         dsp.weight_h264_pixels_tab[widx](py, ys, h, sl->luma_log2_weight_denom,
                                          sl->luma_weight[refn][list][0], sl->luma_weight[refn][list][1]);
         if (sl->use_weight_chroma) {
-            dsp.weight_h264_pixels_tab[cwidx](pcb, cs, h >> 1, sl->chroma_log2_weight_denom,
+            dsp.weight_h264_pixels_tab[cwidx](pcb, cs, hc, sl->chroma_log2_weight_denom,
                                               sl->chroma_weight[refn][list][0][0], sl->chroma_weight[refn][list][0][1]);
-            dsp.weight_h264_pixels_tab[cwidx](pcr, cs, h >> 1, sl->chroma_log2_weight_denom,
+            dsp.weight_h264_pixels_tab[cwidx](pcr, cs, hc, sl->chroma_log2_weight_denom,
                                               sl->chroma_weight[refn][list][1][0], sl->chroma_weight[refn][list][1][1]);
         }
     }
@@ -209,33 +227,45 @@ static void recon_mb(Ctx *c)
     const mi355_h264_mb *m = c->m;
     const int ys = f->recon_stride[0], cs = f->recon_stride[1];
     uint8_t *dy = f->recon[0] + (size_t)c->mb_y * 16 * ys + c->mb_x * 16 * PX;
-    uint8_t *dcb = f->recon[1] + (size_t)c->mb_y * 8 * cs + c->mb_x * 8 * PX;
-    uint8_t *dcr = f->recon[2] + (size_t)c->mb_y * 8 * cs + c->mb_x * 8 * PX;
-    const dctcoef *src = (const dctcoef *)f->coef + (size_t)c->mb_xy * MI355_H264_COEFS_PER_MB;
+    uint8_t *dcb = f->recon[1] + (size_t)c->mb_y * CH * cs + c->mb_x * 8 * PX;
+    uint8_t *dcr = f->recon[2] + (size_t)c->mb_y * CH * cs + c->mb_x * 8 * PX;
+    const int ncc = 16 * NCB;                                 /* coefficients of a chroma plane: 64 / 128 */
+    const dctcoef *src = (const dctcoef *)f->coef + (size_t)c->mb_xy * (256 + 2 * ncc);
     const uint32_t t = m->mb_type;
     int off[48];
     block_offsets(off, ys, cs);
 
     if (t & MI355_MB_INTRA_PCM) {   /* h264_mb_template.c:139-153: one sample per coefficient slot (the second kernel set's convention) */
         for (int i = 0; i < 16; i++) for (int x = 0; x < 16; x++) ((pixel *)(dy + i * ys))[x] = (pixel)src[16 * i + x];
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < CH; i++)
             for (int x = 0; x < 8; x++) {
                 ((pixel *)(dcb + i * cs))[x] = (pixel)src[256 + 8 * i + x];
-                ((pixel *)(dcr + i * cs))[x] = (pixel)src[320 + 8 * i + x];
+                ((pixel *)(dcr + i * cs))[x] = (pixel)src[256 + 8 * CH + 8 * i + x];
             }
         return;
     }
     /* sl->mb image + nnz cache */
     memset(c->coef, 0, sizeof(c->coef));
     memcpy(c->coef, src, 256 * sizeof(dctcoef));
-    memcpy(c->coef + 256, src + 256, 64 * sizeof(dctcoef));
-    memcpy(c->coef + 512, src + 320, 64 * sizeof(dctcoef));
+    memcpy(c->coef + 256, src + 256, (size_t)ncc * sizeof(dctcoef));
+    memcpy(c->coef + 512, src + 256 + ncc, (size_t)ncc * sizeof(dctcoef));
     memset(c->nnzc, 0, sizeof(c->nnzc));
     for (int i = 0; i < 16; i++) c->nnzc[oracle_scan8(i)] = (m->nnz_mask >> i) & 1 ? 2 : 0;
-    for (int j = 0; j < 4; j++) {
-        c->nnzc[oracle_scan8(16 + j)] = (m->nnz_mask >> (16 + j)) & 1 ? 2 : 0;
-        c->nnzc[oracle_scan8(32 + j)] = (m->nnz_mask >> (20 + j)) & 1 ? 2 : 0;
-    }
+    if (cfi == 1)
+        for (int j = 0; j < 4; j++) {
+            c->nnzc[oracle_scan8(16 + j)] = (m->nnz_mask >> (16 + j)) & 1 ? 2 : 0;
+            c->nnzc[oracle_scan8(32 + j)] = (m->nnz_mask >> (20 + j)) & 1 ? 2 : 0;
+        }
+    else
+        /* eight blocks a plane: block j < 4 at scan8[16 + j], block 4 + j at scan8[16 + j + 8] — where idct_add8_422 looks (h264idct_template.c:222-236:
+         * nnzc[scan8[i]] for i = 16..19, nnzc[scan8[i + 4]] for i = 20..23); the entry is the count of the block's AC levels (decode_residual on the 15
+         * coefficients behind the DC), read off the coefficients here */
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j < 8; j++) {
+                int ac = 0;
+                for (int k = 1; k < 16; k++) ac |= c->coef[256 * (1 + p) + 16 * j + k] != 0;
+                c->nnzc[oracle_scan8(16 * (1 + p) + (j < 4 ? j : j + 4))] = ac ? 2 : 0;
+            }
 #define COEF(i) ((int16_t *)(c->coef + (i)))          /* the tables' prototypes say int16_t; above 8 bits their functions read dctcoef = int32 */
     if (t & MI355_MB_INTRA) {
         pred.pred8x8[m->chroma_pred_mode](dcb, cs);
@@ -301,8 +331,8 @@ int oracle_h264_recon_frame_hbd(const mi355_h264_frame *f)
     const int ys = f->recon_stride[0], cs = f->recon_stride[1];
     c->emu = (uint8_t *)calloc(1, (size_t)(22 + 16) * MCS);
     c->tmp[0] = (uint8_t *)calloc(1, (size_t)16 * ys);
-    c->tmp[1] = (uint8_t *)calloc(1, (size_t)8 * cs);
-    c->tmp[2] = (uint8_t *)calloc(1, (size_t)8 * cs);
+    c->tmp[1] = (uint8_t *)calloc(1, (size_t)16 * cs);
+    c->tmp[2] = (uint8_t *)calloc(1, (size_t)16 * cs);
     c->f = f;
     for (int y = 0; y < f->mb_height; y++)
         for (int x = 0; x < f->mb_width; x++) {
@@ -384,19 +414,21 @@ static int check_mv(const MbView *p, int px, int py, const MbView *q, int qx, in
 
 /* filter one 16-sample luma edge + the matching chroma edges: filter_mb_edge{v,h,cv,ch}, h264_loopfilter.c:104-236.  qp, qpc0, qpc1 carry
  * qp_bd_offset (the record's QPs do, above 8 bits); the tables are indexed without it (a = 52 + offset - qp_bd_offset there) */
-static void filter_edge(const mi355_h264_mb *m, const int16_t bS[4], int dir, int edge, int intra_ok,
+static void filter_edge(const mi355_h264_mb *m, const int16_t bS[4], int dir, int edge, int intra_ok, int luma_on,
                         int qp, int qpc0, int qpc1, uint8_t *y, int ys, uint8_t *cb, uint8_t *cr, int cs)
 {
     const int bdo = 6 * (bit_depth - 8);
     const int a = m->slice_alpha_c0_offset - bdo, b = m->slice_beta_offset - bdo;
+    const int c422h = cfi == 2 && dir == 1;           /* :693-700: horizontal chroma edges of 4:2:2 at chroma rows 4 * edge, every edge */
     for (int plane = 0; plane < 3; plane++) {
-        if (plane && (edge & 1)) break;
+        if (plane == 0 && !luma_on) continue;
+        if (plane && (edge & 1) && !c422h) break;
         const int q = plane == 0 ? qp : (plane == 1 ? qpc0 : qpc1);
         const int ia = clampi(q + a, 0, 51), ib = clampi(q + b, 0, 51);
         const int alpha = alpha_tab[ia], beta = beta_tab[ib];
         if (!alpha || !beta) continue;
         uint8_t *pix = plane == 0 ? y + (dir ? 4 * edge * ys : 4 * edge * PX)
-                                  : (plane == 1 ? cb : cr) + (dir ? 2 * edge * cs : 2 * edge * PX);
+                                  : (plane == 1 ? cb : cr) + (dir ? (c422h ? 4 : 2) * edge * cs : 2 * edge * PX);
         const int st = plane ? cs : ys;
         if (bS[0] < 4 || !intra_ok) {
             int8_t tc[4];
@@ -419,8 +451,8 @@ static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
     if (m->flags & MI355_MBF_NO_DEBLOCK) return;
     const int ys = f->dst_stride[0], cs = f->dst_stride[1];
     uint8_t *y = f->dst[0] + (size_t)mb_y * 16 * ys + mb_x * 16 * PX;
-    uint8_t *cb = f->dst[1] + (size_t)mb_y * 8 * cs + mb_x * 8 * PX;
-    uint8_t *cr = f->dst[2] + (size_t)mb_y * 8 * cs + mb_x * 8 * PX;
+    uint8_t *cb = f->dst[1] + (size_t)mb_y * CH * cs + mb_x * 8 * PX;
+    uint8_t *cr = f->dst[2] + (size_t)mb_y * CH * cs + mb_x * 8 * PX;
     const int intra = (m->mb_type & MI355_MB_INTRA) != 0;
     const int dct8 = (m->mb_type & MI355_MB_8x8DCT) != 0;
     for (int dir = 0; dir < 2; dir++) {
@@ -448,7 +480,7 @@ static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
                 qc0 = (m->qpc[0] + nb.m->qpc[0] + 1) >> 1;     /* both by the CURRENT slice's table in the reference (:628-629): the records' own values when one table serves the picture */
                 qc1 = (m->qpc[1] + nb.m->qpc[1] + 1) >> 1;
             } else {
-                if (dct8 && (edge & 1)) continue;
+                if (dct8 && (edge & 1) && !(cfi == 2 && dir == 1)) continue;      /* :633: 4:2:2 still has a horizontal CHROMA edge there */
                 if (intra) bS[0] = bS[1] = bS[2] = bS[3] = 3;
                 else {
                     for (int i = 0; i < 4; i++) {
@@ -463,7 +495,7 @@ static void filter_mb(const mi355_h264_frame *f, int mb_x, int mb_y)
                 }
                 qp = m->qp; qc0 = m->qpc[0]; qc1 = m->qpc[1];
             }
-            filter_edge(m, bS, dir, edge, edge == 0, qp, qc0, qc1, y, ys, cb, cr, cs);
+            filter_edge(m, bS, dir, edge, edge == 0, !(edge && dct8 && (edge & 1)), qp, qc0, qc1, y, ys, cb, cr, cs);
         }
     }
 }
@@ -473,7 +505,7 @@ int oracle_h264_deblock_frame_hbd(const mi355_h264_frame *f)
     if (!bit_depth) return -1;
     mvy_limit = f->field_picture ? 2 : 4;
     for (int p = 0; p < 3; p++) {
-        int rows = (p ? 8 : 16) * f->mb_height, w = (p ? 8 : 16) * f->mb_width * PX;
+        int rows = (p ? CH : 16) * f->mb_height, w = (p ? 8 : 16) * f->mb_width * PX;
         for (int r = 0; r < rows; r++)
             memcpy(f->dst[p] + (size_t)r * f->dst_stride[p ? 1 : 0], f->recon[p] + (size_t)r * f->recon_stride[p ? 1 : 0], (size_t)w);
     }

@@ -225,18 +225,18 @@ def run_fast_workload_by_layout(backend, oracle, nframes, mb_w, mb_h, seed, repl
         d.free()
 
 
-def run_case_hbd(backend, oracle, name, bit_depth=10, fs=None, replicate=None):
+def run_case_hbd(backend, oracle, name, bit_depth=10, fs=None, replicate=None, idc=1):
     """A case (or a given picture set) as a High 10 / 9-bit batch through the SECOND kernel set (mi355_h264_decode_frames_wide_dev) against the
     frame-level checker above 8 bits — oracle/oracle_h264frame_hbd.c: the restated macroblock drivers on the reference's own tables of that bit
     depth (oracle/_ref/libref.so) — every sample of both surfaces.  Returns False when libref.so is not there."""
     fs = HF.synth_frames(**CASES[name]) if fs is None else fs
-    ref = HF.run_oracle_hbd(oracle, fs, bit_depth)
+    ref = HF.run_oracle_hbd(oracle, fs, bit_depth, idc=idc)      # idc 2: the 4:2:2 variant of the set (chroma planes of the luma's height, eight chroma blocks a plane)
     if ref is None:
         return False
     recon_o, dst_o = ref
-    d = HF.DeviceFrames(backend, fs, bit_depth=bit_depth, replicate=replicate)
+    d = HF.DeviceFrames(backend, fs, bit_depth=bit_depth, replicate=replicate, idc=idc)
     try:
-        d.decode_wide(bit_depth=bit_depth)
+        d.decode_wide(bit_depth=bit_depth, idc=idc)
         n = d.F
         for first in range(0, n, 16):
             cnt = min(16, n - first)
@@ -244,7 +244,7 @@ def run_case_hbd(backend, oracle, name, bit_depth=10, fs=None, replicate=None):
             for i in range(cnt):
                 g = (first + i) % fs.F
                 for p in range(3):
-                    assert np.array_equal(recon_o[p][g], recon_g[p][i]), "%s at %d bits, picture %d: reconstruction differs in plane %d" % (name, bit_depth, first + i, p)
+                    assert np.array_equal(recon_o[p][g], recon_g[p][i]), "%s at %d bits (chroma_format_idc %d), picture %d: reconstruction differs in plane %d" % (name, bit_depth, idc, first + i, p)
                     assert np.array_equal(dst_o[p][g], dst_g[p][i]), "%s at %d bits, picture %d: deblocked picture differs in plane %d" % (name, bit_depth, first + i, p)
     finally:
         d.free()

@@ -468,15 +468,47 @@ def widen_samples(a, sh):
     return np.ascontiguousarray((a.astype(np.uint16) << sh) | lo)
 
 
-def widen_records(fs, sh):
+def chroma_422(pl):
+    """a 4:2:0 chroma plane (H / 2 rows) as the 4:2:2 variant of the picture set holds it (H rows): every row twice, the second copy moved a little by its position"""
+    out = np.repeat(pl.astype(np.int16), 2, axis=0)
+    rr, cc = np.arange(out.shape[0])[:, None], np.arange(out.shape[1])[None, :]
+    out[1::2] += ((rr[1::2] * 5 + cc * 3) % 7) - 3
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def coefs_422(c):
+    """[..., 384] coefficients of 4:2:0 macroblocks (256 luma, Cb blocks 0..3, Cr blocks 0..3) -> [..., 512] of 4:2:2 ones (eight blocks a plane, Cb at 256, Cr at 384:
+    include/mi355_h264_frame.h): the plane's own four blocks, then the other plane's four in reverse order with the sign turned"""
+    out = np.zeros(c.shape[:-1] + (512,), c.dtype)
+    out[..., :256] = c[..., :256]
+    cb, cr = c[..., 256:320], c[..., 320:384]
+    rev = lambda a: a.reshape(a.shape[:-1] + (4, 16))[..., ::-1, :].reshape(a.shape)
+    out[..., 256:320], out[..., 320:384] = cb, -rev(cr)
+    out[..., 384:448], out[..., 448:512] = cr, -rev(cb)
+    return out
+
+
+def widen_records(fs, sh, idc=1):
     """records and coefficients as DeviceFrames(bit_depth=8 + sh) uploads them: QPs raised by QpBdOffset, 32-bit coefficients scaled by the shift,
-    an I_PCM macroblock's samples one per coefficient slot"""
+    an I_PCM macroblock's samples one per coefficient slot.  idc 2: the 4:2:2 variant of the set — coefs_422(), an I_PCM macroblock's 8x16 chroma samples
+    (its 8x8 ones, then the other plane's), the chroma DC bits of nnz_mask read off the eight DC levels of each plane"""
     mb = fs.mb.copy()
     mb["qp"] += 6 * sh
     mb["qpc"] += 6 * sh
-    coef = fs.coef.astype(np.int32) << sh
     pcm = (fs.mb["mb_type"] & 4) != 0
-    coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32) << sh
+    if idc == 1:
+        coef = fs.coef.astype(np.int32) << sh
+        coef[pcm] = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32) << sh
+        return mb, np.ascontiguousarray(coef)
+    coef = coefs_422(fs.coef.astype(np.int32)) << sh
+    if pcm.any():
+        b = fs.coef[pcm].view(np.uint8)[:, :384].astype(np.int32)
+        coef[pcm] = np.concatenate([b[:, :256], b[:, 256:320], b[:, 320:384], b[:, 320:384], b[:, 256:320][:, ::-1]], axis=1) << sh
+    dc_cb, dc_cr = (coef[..., 256:384:16] != 0).any(axis=-1), (coef[..., 384:512:16] != 0).any(axis=-1)
+    keep = pcm | ((fs.mb["cbp"] & 0x30) == 0)
+    nz = mb["nnz_mask"] & ~np.uint32(3 << 25)
+    nz = nz | (dc_cb.astype(np.uint32) << 25) | (dc_cr.astype(np.uint32) << 26)
+    mb["nnz_mask"] = np.where(keep, mb["nnz_mask"], nz)
     return mb, np.ascontiguousarray(coef)
 
 
@@ -486,9 +518,11 @@ def ref_library():
     return C.CDLL(path) if os.path.exists(path) else None
 
 
-def run_oracle_hbd(oracle, fs, bit_depth, deblock=True):
+def run_oracle_hbd(oracle, fs, bit_depth, deblock=True, idc=1):
     """The frame-level checker above 8 bits (oracle/oracle_h264frame_hbd.c: the restated per-macroblock drivers calling THE REFERENCE'S OWN tables at
     that bit depth, oracle/_ref/libref.so) on the High 10 variant of a picture set — the pictures DeviceFrames(bit_depth=...) uploads.
+    idc 2: the 4:2:2 variant of the set (chroma_422 / coefs_422: chroma planes of the luma's height, eight chroma blocks a plane) against the same drivers
+    with the reference's tables initialised for chroma_format_idc 2 (oracle_h264frame_hbd_bind_cf).
     Returns (recon, dst) as uint16 plane lists, or None when libref.so is not there."""
     ref = ref_library()
     if ref is None:
@@ -496,12 +530,14 @@ def run_oracle_hbd(oracle, fs, bit_depth, deblock=True):
     sh = bit_depth - 8
     lib = oracle.lib
     fns = [C.cast(getattr(ref, n), C.c_void_p) for n in ("ff_h264dsp_init", "ff_h264qpel_init", "ff_h264chroma_init", "ff_h264_pred_init")]
-    lib.oracle_h264frame_hbd_bind.restype = C.c_int
-    lib.oracle_h264frame_hbd_bind.argtypes = [C.c_void_p] * 4 + [C.c_int]
-    assert lib.oracle_h264frame_hbd_bind(*fns, bit_depth) == 0
-    mb, coef = widen_records(fs, sh)
-    refs = [[tuple(widen_samples(pl, sh) for pl in fs.refs[f][s_]) for s_ in range(fs.nrefs)] for f in range(fs.F)]
-    recon = [np.zeros((fs.F, fs.H, fs.W), np.uint16), np.zeros((fs.F, fs.H // 2, fs.W // 2), np.uint16), np.zeros((fs.F, fs.H // 2, fs.W // 2), np.uint16)]
+    lib.oracle_h264frame_hbd_bind_cf.restype = C.c_int
+    lib.oracle_h264frame_hbd_bind_cf.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int]
+    assert lib.oracle_h264frame_hbd_bind_cf(*fns, bit_depth, idc) == 0
+    mb, coef = widen_records(fs, sh, idc)
+    c422 = chroma_422 if idc == 2 else (lambda a: a)
+    refs = [[tuple(widen_samples(pl if i == 0 else c422(pl), sh) for i, pl in enumerate(fs.refs[f][s_])) for s_ in range(fs.nrefs)] for f in range(fs.F)]
+    hc = fs.H if idc == 2 else fs.H // 2
+    recon = [np.zeros((fs.F, fs.H, fs.W), np.uint16), np.zeros((fs.F, hc, fs.W // 2), np.uint16), np.zeros((fs.F, hc, fs.W // 2), np.uint16)]
     dst = [np.zeros_like(a) for a in recon]
     arr, _ = host_frames(fs, recon, dst, px=2, mb=mb, coef=coef, refs=refs)
     lib.oracle_h264_recon_frame_hbd.restype = C.c_int
@@ -532,7 +568,7 @@ class DeviceFrames:
     `replicate` = total number of pictures F >= fs.F: picture f is a device-side copy of picture
     f % fs.F with its own buffers (bench.py: many independent streams from a few distinct ones)."""
 
-    def __init__(self, prov, fs, replicate=None, pad=0, tiled=False, bit_depth=8):
+    def __init__(self, prov, fs, replicate=None, pad=0, tiled=False, bit_depth=8, idc=1):
         """bit_depth 9 / 10: the same pictures as a High 10 batch for mi355_h264_decode_frames_wide_dev — 16-bit samples (the 8-bit reference
         samples shifted up, the low bits filled from the sample's position), 32-bit coefficients (scaled by the same shift), QPs raised by
         QpBdOffset; the frame-level checker for these is run_oracle_hbd() (oracle/oracle_h264frame_hbd.c on the reference's own 9 / 10-bit tables).
@@ -542,8 +578,9 @@ class DeviceFrames:
         luma tiles, a multiple of 256; chroma rows get half)"""
         self.lib, self.fs, self.pad, self.tiled = prov.lib, fs, pad, tiled
         self.bit_depth, px, sh = bit_depth, (2 if bit_depth > 8 else 1), bit_depth - 8
-        self.px = px
-        assert not (tiled and px == 2)
+        self.px, self.idc = px, idc
+        assert not (tiled and px == 2) and (idc == 1 or px == 2)      # idc 2: the 4:2:2 variant of the set (run_oracle_hbd(idc=2)), 9 / 10 bit
+        hc = self.hc = fs.H if idc == 2 else fs.H // 2               # chroma rows
         lib = self.lib
         lib.mi355_malloc.restype = C.c_void_p
         lib.mi355_malloc.argtypes = [C.c_size_t]
@@ -556,7 +593,7 @@ class DeviceFrames:
         F = self.F = replicate or G
         nmb = fs.mb_w * fs.mb_h
         ys, cs = px * fs.W + pad, px * fs.W // 2 + pad // 2            # strides
-        ysz, csz = fs.H * ys, (fs.H // 2) * cs
+        ysz, csz = fs.H * ys, hc * cs
         if tiled:
             assert pad % 256 == 0
             ys, cs = fs.mb_w * 256 + pad, fs.mb_w * 128 + pad // 2   # bytes per macroblock row of tiles
@@ -579,7 +616,7 @@ class DeviceFrames:
         mb = fs.mb
         coef, cbytes = fs.coef, 768
         if px == 2:
-            (mb, coef), cbytes = widen_records(fs, sh), 1536
+            (mb, coef), cbytes = widen_records(fs, sh, idc), (2048 if idc == 2 else 1536)
         self.cbytes = cbytes
         self.mb = up_rep(mb, nmb * 64)
         self.mv0 = up_rep(fs.mv[0], nmb * 64)
@@ -601,10 +638,12 @@ class DeviceFrames:
                 if px == 2:
                     def wide(a):
                         return widen_samples(a, sh).view(np.uint8).reshape(a.shape[0], -1)
+                    if idc == 2:
+                        cb, cr = chroma_422(cb), chroma_422(cr)
                     y, cb, cr = wide(y), wide(cb), wide(cr)
                 refs_host[f, s_, :ysz].reshape(fs.H, ys)[:, :px * fs.W] = y
-                refs_host[f, s_, ysz:ysz + csz].reshape(fs.H // 2, cs)[:, :px * fs.W // 2] = cb
-                refs_host[f, s_, ysz + csz:].reshape(fs.H // 2, cs)[:, :px * fs.W // 2] = cr
+                refs_host[f, s_, ysz:ysz + csz].reshape(hc, cs)[:, :px * fs.W // 2] = cb
+                refs_host[f, s_, ysz + csz:].reshape(hc, cs)[:, :px * fs.W // 2] = cr
         self.refs = up_rep(refs_host, fs.nrefs * self.fsz)
         ilist = [self.up(fs.intra_list[g]) if len(fs.intra_list[g]) else None for g in range(G)]
         istart = [self.up(fs.intra_start[g]) for g in range(G)]
@@ -667,11 +706,11 @@ class DeviceFrames:
             return untile_planes(ty, tc, fs.mb_w, fs.mb_h)
         px = self.px
         ys, cs = px * fs.W + self.pad, px * fs.W // 2 + self.pad // 2
-        ysz, csz = fs.H * ys, (fs.H // 2) * cs
+        ysz, csz = fs.H * ys, self.hc * cs
         if px == 2:
             return [np.ascontiguousarray(raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :2 * fs.W]).view(np.uint16),
-                    np.ascontiguousarray(raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W]).view(np.uint16),
-                    np.ascontiguousarray(raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W]).view(np.uint16)]
+                    np.ascontiguousarray(raw[:, ysz:ysz + csz].reshape(n, self.hc, cs)[:, :, :fs.W]).view(np.uint16),
+                    np.ascontiguousarray(raw[:, ysz + csz:].reshape(n, self.hc, cs)[:, :, :fs.W]).view(np.uint16)]
         return [raw[:, :ysz].reshape(n, fs.H, ys)[:, :, :fs.W], raw[:, ysz:ysz + csz].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2],
                 raw[:, ysz + csz:].reshape(n, fs.H // 2, cs)[:, :, :fs.W // 2]]
 

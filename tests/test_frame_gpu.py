@@ -427,6 +427,24 @@ def test_second_kernel_set_against_the_frame_checker_at_9_bits(mi355, oracle, na
     assert frame_cases.run_case_hbd(mi355, oracle, name, 9), "oracle/_ref/libref.so missing"
 
 
+@pytest.mark.parametrize("name", HBD_CASES)
+def test_second_kernel_set_against_the_frame_checker_at_422_10_bits(mi355, oracle, name):
+    """the High 4:2:2 instantiation (10 bit) of the second kernel set, frame level: the 4:2:2 variant of every case against oracle/oracle_h264frame_hbd.c on the
+    reference's tables initialised with chroma_format_idc 2 (the 2x4 chroma DC transform, idct_add8_422, the 8x16 predictors, the sixteen-line chroma edge)"""
+    assert frame_cases.run_case_hbd(mi355, oracle, name, 10, idc=2), "oracle/_ref/libref.so missing: __graft_entry__.build() makes it where /root/reference exists"
+
+
+@pytest.mark.parametrize("name", ("mixed_intra", "b_weight_explicit", "wide_b"))
+def test_second_kernel_set_against_the_frame_checker_at_422_9_bits(mi355, oracle, name):
+    assert frame_cases.run_case_hbd(mi355, oracle, name, 9, idc=2), "oracle/_ref/libref.so missing"
+
+
+def test_config2_422_full_size_matches_the_frame_checker(mi355, oracle):
+    """the headline generator's 1080p pictures as a High 4:2:2 (10-bit) batch, replicated to 24 in the launch: every sample of both surfaces of every picture"""
+    fs = HF.synth_frames_fast(3, 120, 68, seed=0x2642, lib=mi355.lib)
+    assert frame_cases.run_case_hbd(mi355, oracle, "config2_high422", 10, fs=fs, replicate=24, idc=2), "oracle/_ref/libref.so missing"
+
+
 def test_config2_high10_full_size_matches_the_frame_checker(mi355, oracle):
     """bench.py's config2_high10 workload at its real size: three 1080p pictures of the headline generator as a High 10 batch (replicated to 24 in the launch),
     every sample of both surfaces of every picture"""
