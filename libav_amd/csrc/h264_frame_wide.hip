@@ -877,18 +877,28 @@ __device__ const uint8_t kw_tc0[52][3] = {
     {11,15,23},{13,17,25} };
 
 constexpr int DYP = 20, DCPW = 12;       /* pitches of the MBAFF filter's luma (-4..15) and chroma (-4..7) tiles */
-constexpr int DBYP = 24, DBCP = 16;      /* ... of the frame / field filter's: columns -8..15 / -8..7 */
-struct WideDbLds {
+/* The frame / field filter's tiles hold a UNIT: up to WIDE_UNIT macroblocks side by side (round 6).  A lane's piece of a 10-bit luma row is 32 bytes of a 128-byte line; fetched
+ * macroblock by macroblock the rest of the line came again for the next macroblock unless the L2 had kept it — it had not (3072 groups of sixteen lines each in flight per XCD's
+ * 4 MB): 20 GB crossed the fabric per 512 pictures for 4.6 GB of samples (profiles/r04zzz_wide_first_form_counters.txt).  Now a unit's rows come in ONCE, as runs of whole lines
+ * (four macroblocks = 128 bytes of a luma row, 64 of a chroma row), the macroblocks are filtered where they lie — macroblock u at columns 16 u .., its left neighbour's columns
+ * beside it — and the rows leave once. */
+#ifndef MI355_WIDE_UNIT_MAX
+#define MI355_WIDE_UNIT_MAX 4            /* developer switch: 2 = tiles of two macroblocks (half the LDS, half lines per piece) */
+#endif
+constexpr int WIDE_UNIT = MI355_WIDE_UNIT_MAX;
+constexpr int DBYP = 8 + 16 * WIDE_UNIT, DBCP = 8 + 8 * WIDE_UNIT;      /* pitches: columns -8 .. 16 * WIDE_UNIT - 1 / -8 .. 8 * WIDE_UNIT - 1 */
+template <int CF> struct WideDbLds {
     mi355_h264_mb m[3];                  /* this macroblock, its left and its top neighbour */
     int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
     uint32_t mv[2][25];
     uint8_t nnz[25];
     alignas(8) uint8_t bs[4][8];         /* [i][4 * dir + edge]: the eight strengths a line meets are one 64-bit read */
-    alignas(16) uint16_t y[20 * DBYP];   /* rows / columns -4..15; a row's sample 0 on a 16-byte boundary: a row piece is one LDS instruction */
-    alignas(16) uint16_t c[2][18 * DBCP];/* rows -2..15, columns -4..7 (the filter reaches two to the left; four make the write-back whole dwords) */
+    alignas(16) uint16_t y[20 * DBYP];   /* rows -4..15; a macroblock's sample 0 on a 16-byte boundary: a row piece is one LDS instruction */
+    alignas(16) uint16_t c[2][(CF == 2 ? 18 : 10) * DBCP];       /* rows -2..7 (4:2:2: ..15), columns -4.. (the filter reaches two to the left; four make the write-back whole dwords) */
 };
-#define DY(x, yy) s.y[((yy) + 4) * DBYP + (x) + 8]
-#define DC(p, x, yy) s.c[p][((yy) + 2) * DBCP + (x) + 8]
+/* (xo, xc: the macroblock's first column inside the unit's tile, luma and chroma — locals of the code that uses the macros) */
+#define DY(x, yy) s.y[((yy) + 4) * DBYP + (x) + 8 + xo]
+#define DC(p, x, yy) s.c[p][((yy) + 2) * DBCP + (x) + 8 + xc]
 
 __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
 {
@@ -1034,24 +1044,14 @@ __device__ __forceinline__ void wide_put(const WidePiece<PX, N> &v, uint16_t *d)
     for (int k = 0; k < N; k++) u[k] = t[k];
     __builtin_memcpy(__builtin_assume_aligned(d, LA), u, sizeof(u));
 }
-/* one macroblock's inputs as the loads deliver them: a group fetches the NEXT macroblock of its unit while it filters this one (the loads of a
- * macroblock — records, samples, vectors — are one round trip to memory, ~2 us under load, and a lone macroblock's arithmetic is about as long) */
+/* one macroblock's records and vectors as the loads deliver them: a group fetches those of the NEXT macroblock of its unit while it filters this one */
 template <int BD, int CF> struct WideDbIn {
-    typedef typename Fmt<BD, CF>::PX PX;
-    static constexpr int NP = CF == 2 ? 2 : 1;     /* chroma planes a lane carries a row of */
     uint32_t rec[3];                               /* dword l of this / the left / the top macroblock's record */
-    WidePiece<PX, 16> y;                           /* luma row l */
-    WidePiece<PX, 4> yl, yt;                       /* the four samples left of it (first macroblock of a unit); a quarter row of the four rows above */
-    WidePiece<PX, 8> c[NP];                        /* chroma row: 4:2:0 plane l >> 3 row l & 7; 4:2:2 row l of both planes */
-    WidePiece<PX, 4> cl[NP], ct;
     uint32_t mv[2][2];                             /* [list][own block l | lanes 0..3 the left neighbour's last column, 4..7 the top neighbour's last row] */
 };
 template <int BD, int CF>
-__device__ __forceinline__ void wide_db_fetch(WideDbIn<BD, CF> &in, const WideDbPic &pic, bool ok, int mb_x, int mb_y, int l, bool FIRST)
+__device__ __forceinline__ void wide_db_fetch(WideDbIn<BD, CF> &in, const WideDbPic &pic, bool ok, int mb_x, int mb_y, int l)
 {
-    typedef Fmt<BD, CF> F;
-    typedef typename F::PX PX;
-    constexpr int PXB = (int)sizeof(PX);
     if (!ok) return;
     const int mb_xy = mb_y * pic.mbw + mb_x;
     const bool has_left = mb_x > 0, has_top = mb_y > 0;
@@ -1059,16 +1059,6 @@ __device__ __forceinline__ void wide_db_fetch(WideDbIn<BD, CF> &in, const WideDb
     in.rec[0] = reinterpret_cast<const uint32_t *>(&pic.mb[mb_xy])[l];
     in.rec[1] = reinterpret_cast<const uint32_t *>(&pic.mb[xl])[l];
     in.rec[2] = reinterpret_cast<const uint32_t *>(&pic.mb[xt])[l];
-    wide_get(in.y, pic.recon[0] + (size_t)(16 * mb_y + l) * pic.ys + 16 * mb_x * PXB);
-    if (FIRST && has_left) wide_get(in.yl, pic.dst[0] + (size_t)(16 * mb_y + l) * pic.yd + (16 * mb_x - 4) * PXB);
-    if (has_top) { const int r = (l >> 2) - 4, c = 4 * (l & 3); wide_get(in.yt, pic.dst[0] + (size_t)(16 * mb_y + r) * pic.yd + (16 * mb_x + c) * PXB); }
-#pragma unroll
-    for (int k = 0; k < WideDbIn<BD, CF>::NP; k++) {
-        const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-        wide_get(in.c[k], (p ? pic.recon[2] : pic.recon[1]) + (size_t)(F::CH * mb_y + r) * pic.cs + 8 * mb_x * PXB);
-        if (FIRST && has_left) wide_get(in.cl[k], (p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * pic.cd + (8 * mb_x - 4) * PXB);
-    }
-    if (has_top && l < 8) { const int p = l >> 2, r = ((l >> 1) & 1) - 2, c = 4 * (l & 1); wide_get(in.ct, (p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * pic.cd + (8 * mb_x + c) * PXB); }
     /* vectors: lane l its own 4x4 block, lanes 0..3 / 4..7 also a block of the left neighbour's last column / the top neighbour's last row */
     const int xy2 = l < 4 ? xl : xt, i2 = l < 4 ? 3 + 4 * l : 8 + l;
 #pragma unroll
@@ -1078,35 +1068,99 @@ __device__ __forceinline__ void wide_db_fetch(WideDbIn<BD, CF> &in, const WideDb
     }
 }
 
+/* The samples of a unit — macroblocks x0 .. x0 + nu - 1 of row mb_y (nu <= WIDE_UNIT) — into the group's tile: their own from `recon`; four rows of the top neighbours and
+ * four columns of the left neighbour from `dst`, as those macroblocks' own passes left them (earlier launches).  Lane l: luma row l (nu pieces of sixteen samples), a quarter
+ * of one of the four rows above, a chroma row (4:2:0: plane l >> 3, row l & 7; 4:2:2: row l of both planes), lanes 0..7 half of one of the two chroma rows above. */
+template <int BD, int CF>
+__device__ __forceinline__ void wide_db_fetch_unit(WideDbLds<CF> &s, const WideDbPic &pic, int x0, int nu, int mb_y, int l)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    constexpr int PXB = (int)sizeof(PX), xo = 0, xc = 0;
+    const bool has_left = x0 > 0, has_top = mb_y > 0;
+    WidePiece<PX, 16> y[WIDE_UNIT], yt;
+    WidePiece<PX, 4> yl;
+    const uint8_t *row = pic.recon[0] + (size_t)(16 * mb_y + l) * pic.ys + 16 * x0 * PXB;
+#pragma unroll
+    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_get(y[k], row + 16 * PXB * k);
+    if (has_left) wide_get(yl, pic.dst[0] + (size_t)(16 * mb_y + l) * pic.yd + (16 * x0 - 4) * PXB);
+    const int tr = (l >> 2) - 4, tk = l & 3;
+    if (has_top && tk < nu) wide_get(yt, pic.dst[0] + (size_t)(16 * mb_y + tr) * pic.yd + (16 * x0 + 16 * tk) * PXB);
+    constexpr int NP = CF == 2 ? 2 : 1;
+    WidePiece<PX, 8> c[NP][WIDE_UNIT];
+    WidePiece<PX, 4> cl[NP];
+    WidePiece<PX, 8> ct;
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const int p = CF == 2 ? q : l >> 3, r = CF == 2 ? l : l & 7;
+        const uint8_t *crow = (p ? pic.recon[2] : pic.recon[1]) + (size_t)(F::CH * mb_y + r) * pic.cs + 8 * x0 * PXB;
+#pragma unroll
+        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_get(c[q][k], crow + 8 * PXB * k);
+        if (has_left) wide_get(cl[q], (p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * pic.cd + (8 * x0 - 4) * PXB);
+    }
+    /* the two chroma rows above: lane = plane (l >> 3), row ((l >> 2) & 1) - 2, macroblock l & 3 of the unit */
+    const int cp = l >> 3, cr = ((l >> 2) & 1) - 2, ck = l & 3;
+    const bool ct_on = has_top && ck < nu;
+    if (ct_on) wide_get(ct, (cp ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + cr) * pic.cd + (8 * x0 + 8 * ck) * PXB);
+    /* ---- into the tile ---- */
+#pragma unroll
+    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 16, 16>(y[k], &DY(16 * k, l));
+    if (has_left) wide_put<PX, 4, 8>(yl, &DY(-4, l));
+    if (has_top && tk < nu) wide_put<PX, 16, 16>(yt, &DY(16 * tk, tr));
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const int p = CF == 2 ? q : l >> 3, r = CF == 2 ? l : l & 7;
+#pragma unroll
+        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 8, 16>(c[q][k], &DC(p, 8 * k, r));
+        if (has_left) wide_put<PX, 4, 8>(cl[q], &DC(p, -4, r));
+    }
+    if (ct_on) wide_put<PX, 8, 16>(ct, &DC(cp, 8 * ck, cr));
+}
+/* ... and back: the unit's macroblocks, the three columns its first left edge changed (four: whole dwords) and the three rows (one in chroma) its top edges changed */
+template <int BD, int CF>
+__device__ __forceinline__ void wide_db_store_unit(const WideDbLds<CF> &s, const WideDbPic &pic, int x0, int nu, int mb_y, int l)
+{
+    typedef Fmt<BD, CF> F;
+    typedef typename F::PX PX;
+    constexpr int PXB = (int)sizeof(PX), xo = 0, xc = 0;
+    const bool has_left = x0 > 0, has_top = mb_y > 0;
+    const int yd = pic.yd, cd = pic.cd;
+    uint8_t *row = const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + 16 * x0 * PXB;
+#pragma unroll
+    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 16, false, 16>(row + 16 * PXB * k, &DY(16 * k, l));
+    if (has_left) wide_st_row<PX, 4, false, 8>(row - 4 * PXB, &DY(-4, l));
+    if (has_top && l < 12) {
+        const int r = (l >> 2) - 3, k = l & 3;
+        if (k < nu) wide_st_row<PX, 16, false, 16>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + r) * yd + (16 * x0 + 16 * k) * PXB, &DY(16 * k, r));
+    }
+#pragma unroll
+    for (int q = 0; q < (CF == 2 ? 2 : 1); q++) {
+        const int p = CF == 2 ? q : l >> 3, r = CF == 2 ? l : l & 7;
+        uint8_t *crow = const_cast<uint8_t *>(p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * cd + 8 * x0 * PXB;
+#pragma unroll
+        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 8, false, 16>(crow + 8 * PXB * k, &DC(p, 8 * k, r));
+        if (has_left) wide_st_row<PX, 4, false, 8>(crow - 4 * PXB, &DC(p, -4, r));
+    }
+    if (has_top && l < 2 * WIDE_UNIT) {           /* chroma row -1: lane = plane * WIDE_UNIT + macroblock */
+        const int p = l / WIDE_UNIT, k = l % WIDE_UNIT;
+        if (k < nu) wide_st_row<PX, 8, false, 16>(const_cast<uint8_t *>(p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y - 1) * cd + (8 * x0 + 8 * k) * PXB, &DC(p, 8 * k, -1));
+    }
+}
+
 /* One macroblock (mb_x, mb_y) per sixteen-lane group — ff_h264_filter_mb (h264_loopfilter.c:716-847) for frame and field pictures without
  * MBAFF.  The macroblock's own samples come from `recon`, four rows of the top neighbour from `dst` (as that macroblock's own pass left
  * them) and four columns of the left neighbour from `dst` or — FIRST false: the group filtered that macroblock with this tile a moment ago
  * — from the tile's last columns; the macroblock, three columns and three rows (one of each in chroma) go back to `dst`.
  * `in`: what wide_db_fetch brought for this macroblock; once the tile is filled, `next` may fetch the following macroblock into it. */
 template <int BD, int CF, typename Next>
-__device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4], const uint8_t *t_lc,
-                                                const WideDbPic &pic, const WideDbIn<BD, CF> &in, bool ok, int mb_x, int mb_y, int l, bool FIRST, Next next)
+__device__ __forceinline__ void wide_deblock_mb(WideDbLds<CF> &s, const uint8_t *t_alpha, const uint8_t *t_beta, const uint8_t (*t_tc0)[4], const uint8_t *t_lc,
+                                                const WideDbPic &pic, const WideDbIn<BD, CF> &in, bool ok, int u, int l, Next next)
 {
     typedef Fmt<BD, CF> F;
-    typedef typename F::PX PX;
-    constexpr int PXB = (int)sizeof(PX);
-    const bool has_left = mb_x > 0, has_top = mb_y > 0;
-    const int yd = pic.yd, cd = pic.cd;
+    const int xo = 16 * u, xc = 8 * u;           /* the macroblock's place in the unit's tile (DY / DC) */
     if (ok) {
 #pragma unroll
         for (int k = 0; k < 3; k++) reinterpret_cast<uint32_t *>(&s.m[k])[l] = in.rec[k];
-        if (has_left && !FIRST) for (int k = 0; k < 4; k++) DY(k - 4, l) = DY(12 + k, l);
-        else if (has_left) wide_put<PX, 4, 8>(in.yl, &DY(-4, l));
-        wide_put<PX, 16, 16>(in.y, &DY(0, l));
-        if (has_top) wide_put<PX, 4, 8>(in.yt, &DY(4 * (l & 3), (l >> 2) - 4));
-#pragma unroll
-        for (int k = 0; k < WideDbIn<BD, CF>::NP; k++) {
-            const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-            if (has_left && !FIRST) for (int j = 0; j < 4; j++) DC(p, j - 4, r) = DC(p, 4 + j, r);
-            else if (has_left) wide_put<PX, 4, 8>(in.cl[k], &DC(p, -4, r));
-            wide_put<PX, 8, 16>(in.c[k], &DC(p, 0, r));
-        }
-        if (has_top && l < 8) wide_put<PX, 4, 8>(in.ct, &DC(l >> 2, 4 * (l & 1), ((l >> 1) & 1) - 2));
         /* the vectors' places in the filter's view of the motion: (y + 1) * 5 + (x + 1) */
         const int c0 = ((l >> 2) + 1) * 5 + (l & 3) + 1, c1 = l < 4 ? (l + 1) * 5 : l - 3;
 #pragma unroll
@@ -1251,19 +1305,6 @@ __device__ __forceinline__ void wide_deblock_mb(WideDbLds &s, const uint8_t *t_a
             MI355_WAVE_SYNC();
         }
     }
-    /* out: the macroblock, and what its left and top edges changed of the neighbours */
-    if (ok) {
-        /* (the left neighbour's four last columns go back as whole dwords: the first of them as it came) */
-        wide_st_row<PX, 16, false, 16>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + 16 * mb_x * PXB, &DY(0, l));
-        if (has_left) wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + (16 * mb_x - 4) * PXB, &DY(-4, l));
-        if (has_top && l < 12) { const int r = (l >> 2) - 3, c = 4 * (l & 3); wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + r) * yd + (16 * mb_x + c) * PXB, &DY(c, r)); }
-        for (int k = 0; k < (CF == 2 ? 2 : 1); k++) {
-            const int p = CF == 2 ? k : l >> 3, r = CF == 2 ? l : l & 7;
-            wide_st_row<PX, 8, false, 16>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y + r) * cd + 8 * mb_x * PXB, &DC(p, 0, r));
-            if (has_left) wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y + r) * cd + (8 * mb_x - 4) * PXB, &DC(p, -4, r));
-        }
-        if (has_top && l < 4) { const int p = l >> 1, c = 4 * (l & 1); wide_st_row<PX, 4, false, 8>(const_cast<uint8_t *>((p ? pic.dst[2] : pic.dst[1])) + (size_t)(F::CH * mb_y - 1) * cd + (8 * mb_x + c) * PXB, &DC(p, c, -1)); }
-    }
 }
 
 /* Anti-diagonal d of FOUR pictures per wave: lanes 16g..16g+15 filter a unit of picture 4 * k + g.  Sixteen lanes are what one macroblock has
@@ -1280,7 +1321,7 @@ template <int BD, int CF>
 __global__ void __launch_bounds__(64)
 k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int y_first, int rows, int unit)
 {
-    __shared__ WideDbLds sh[4];
+    __shared__ WideDbLds<CF> sh[4];
     /* tables 8-16 / 8-17 in LDS: the edge loop looks alpha, beta and tc0 up per lane — from memory that is a dependent load of a microsecond */
     __shared__ uint8_t t_alpha[52], t_beta[52], t_lc[4][16];
     __shared__ __attribute__((aligned(4))) uint8_t t_tc0[52][4];       /* a row is read as one dword (wide_thr) */
@@ -1290,18 +1331,22 @@ k_wide_deblock(const mi355_h264_frame *frames, int nframes, int d, int y_first, 
     const int f = 4 * ((int)blockIdx.x / rows) + g, mb_y = y_first + (int)blockIdx.x % rows, x0 = (d - 2 * mb_y) * unit;
     const WideDbPic pic = wide_db_pic(frames[f < nframes ? f : nframes - 1]);
     const bool row_ok = f < nframes && mb_y < pic.mbh && x0 >= 0;
+    /* the unit's macroblocks inside the picture: nu (0: this group has nothing on this anti-diagonal) */
+    const int nu = row_ok && x0 < pic.mbw ? imin(unit, pic.mbw - x0) : 0;
     WideDbIn<BD, CF> in;
-    wide_db_fetch<BD, CF>(in, pic, row_ok && x0 < pic.mbw, x0, mb_y, l, true);
+    wide_db_fetch<BD, CF>(in, pic, nu > 0, x0, mb_y, l);
+    if (nu > 0) wide_db_fetch_unit<BD, CF>(sh[g], pic, x0, nu, mb_y, l);
     t_lc[g][l] = row_ok && pic.nslices > 0 ? pic.slices[l < pic.nslices ? l : pic.nslices - 1].list_count : 1;
     MI355_WAVE_SYNC();
 #pragma unroll 1
     for (int u = 0; u < unit; u++) {
         const int mb_x = x0 + u;
-        const bool ok = row_ok && mb_x < pic.mbw, more = u + 1 < unit;
-        wide_deblock_mb<BD, CF>(sh[g], t_alpha, t_beta, t_tc0, t_lc[g], pic, in, ok, mb_x, mb_y, l, u == 0,
-                                [&]() { if (more) wide_db_fetch<BD, CF>(in, pic, row_ok && mb_x + 1 < pic.mbw, mb_x + 1, mb_y, l, false); });
-        MI355_WAVE_SYNC();                       /* the next macroblock's tile overwrites what the stores above read */
+        const bool ok = u < nu, more = u + 1 < nu;
+        wide_deblock_mb<BD, CF>(sh[g], t_alpha, t_beta, t_tc0, t_lc[g], pic, in, ok, u, l,
+                                [&]() { if (more) wide_db_fetch<BD, CF>(in, pic, true, mb_x + 1, mb_y, l); });
+        MI355_WAVE_SYNC();                       /* the next macroblock's records overwrite what this one's strengths read */
     }
+    if (nu > 0) wide_db_store_unit<BD, CF>(sh[g], pic, x0, nu, mb_y, l);
 }
 #undef DY
 #undef DC
@@ -1594,7 +1639,7 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
              * (profiles/r04_experiments.md, section 9).  MI355_WIDE_UNIT overrides */
             const char *ue = getenv("MI355_WIDE_UNIT");
             int unit = ue ? atoi(ue) : (nframes >= 384 ? 4 : (nframes >= 64 ? 2 : 1));
-            if (unit < 1 || unit > 8) unit = 1;
+            if (unit < 1 || unit > WIDE_UNIT) unit = unit > WIDE_UNIT ? WIDE_UNIT : 1;
             const int uw = (mw + unit - 1) / unit;
             for (int d = 0; d <= (uw - 1) + 2 * (mh - 1); d++) {
                 const int y_first = d - (uw - 1) > 0 ? (d - (uw - 1) + 1) / 2 : 0, y_last = d / 2 < mh - 1 ? d / 2 : mh - 1;     /* 0 <= d - 2 y <= uw - 1 */
