@@ -1638,7 +1638,7 @@ int wide_launch(const mi355_h264_frame *d_frames, int nframes, int mw, int mh, i
              * launch), 4 once the launches fill the device (the fabric traffic decides); measured on 1080p 10-bit batches of 32 .. 2048 pictures
              * (profiles/r04_experiments.md, section 9).  MI355_WIDE_UNIT overrides */
             const char *ue = getenv("MI355_WIDE_UNIT");
-            int unit = ue ? atoi(ue) : (nframes >= 384 ? 4 : (nframes >= 64 ? 2 : 1));
+            int unit = ue ? atoi(ue) : (nframes >= 192 ? 4 : (nframes >= 64 ? 2 : 1));      /* profiles/r06o_wide_unit_sweep.txt: 256 pictures 4.42 (4) against 5.18 ms (2), 128 pictures 3.67 against 3.28 */
             if (unit < 1 || unit > WIDE_UNIT) unit = unit > WIDE_UNIT ? WIDE_UNIT : 1;
             const int uw = (mw + unit - 1) / unit;
             for (int d = 0; d <= (uw - 1) + 2 * (mh - 1); d++) {
