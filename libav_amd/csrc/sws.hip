@@ -753,6 +753,117 @@ __global__ void __launch_bounds__(NT) k_sws_c24(const mi355_sws_luts *luts, int 
     }
 }
 
+/* The generic scaler on a context that does not scale (round 6): identity horizontal filters (hident_l / hident_c) and ONE vertical luma tap — what swscale() runs for an
+ * unscaled yuv420p -> rgb24 conversion that may not take the special converter (SWS_ACCURATE_RND): hScale8To15 is src << 7, and the vertical pass reads those 15-bit values of
+ * one luma line and of the row's one to four chroma lines (bicubic: four taps on the chroma planes' half height).  The same integers k_sws_generic computes through its LDS tile
+ * (vertical_rows), straight from the source bytes to the LUT:
+ *   X false, yuv2rgb24_1_c (output.c:1043-1110; vChrFilterSize <= 2): Y = (src << 7) >> 7, U / V = the first chroma line's sample, or ((c0 << 7) + (c1 << 7)) >> 8 = the mean of
+ *     the two lines when the row's second coefficient is >= 2048;
+ *   X true, yuv2rgb24_X_c (:937-996; three or four chroma taps): Y = ((1 << 18) + (src << 7) * lumFilter[0]) >> 19, U / V = ((1 << 18) + sum (c_j << 7) * chrFilter[j]) >> 19,
+ *     a pair's four values clipped only if one of them has bit 8 set.
+ * 512 x 16 sample tiles, a thread eight samples of a line per step; the rows' table entries, then all the samples of a thread are requested before the LUT copy (two round
+ * trips per workgroup instead of the tile's staging rounds and barriers).  Only for even dstW (the phantom partner of an odd width's last sample stays with k_sws_generic). */
+template <bool X>
+__global__ void __launch_bounds__(NT) k_sws_ident1(const SwsDev *cp, const mi355_sws_frame *frames)
+{
+    __shared__ LutLds s_lut;
+    constexpr int NC = X ? 4 : 2;
+    const int tid = threadIdx.x;
+    const int dstW = cp->dstW, dstH = cp->dstH, cs = cp->vcs, srcH = cp->srcH, chrSrcH = cp->chrSrcH;
+    const int32_t *vLumP = mi355_global(cp->vLumP), *vChrP = mi355_global(cp->vChrP);
+    const int16_t *vLumC = mi355_global(cp->vLumC), *vChrC = mi355_global(cp->vChrC);
+    mi355_sws_frame fr = frames[blockIdx.z];
+    for (int k = 0; k < 3; k++) fr.src[k] = mi355_global(fr.src[k]);
+    fr.dst = mi355_global(fr.dst);
+    const int x = blockIdx.x * C24_COLS + (tid & 63) * 8;   /* first of the thread's eight samples */
+    const int npairs = dstW >> 1;
+    const bool mine = (x >> 1) < npairs;
+    const bool wide = mine && (x >> 1) + 4 <= npairs &&
+                      ((reinterpret_cast<uintptr_t>(fr.src[0]) | (uintptr_t)fr.src_stride[0] | reinterpret_cast<uintptr_t>(fr.dst) | (uintptr_t)fr.dst_stride) & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fr.src[1]) | (uintptr_t)fr.src_stride[1] | reinterpret_cast<uintptr_t>(fr.src[2]) | (uintptr_t)fr.src_stride[2]) & 3) == 0;
+    constexpr int NR = C24_ROWS / (NT / 64);
+    /* the rows' lines and taps: every load unconditional (rows past the picture repeat its last row and are not written; a tap past the filter reads tap 0 and becomes zero) */
+    int li[NR], lf[NR], c0[NR], cf[NR][NC];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int gy = imin(blockIdx.y * C24_ROWS + (tid >> 6) + q * (NT / 64), dstH - 1);
+        li[q] = vLumP[gy]; lf[q] = vLumC[gy]; c0[q] = vChrP[gy];
+#pragma unroll
+        for (int j = 0; j < NC; j++) cf[q][j] = vChrC[(size_t)gy * cs + (j < cs ? j : 0)];
+    }
+    sws_u32x2 ya[NR];
+    uint32_t u[NR][NC], v[NR][NC];
+    int ci[NR][NC];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        li[q] = clampi(imax(0, li[q]), 0, srcH - 1);
+        const int cfirst = imax(1 - cs, c0[q]);
+        ya[q] = sws_u32x2{ 0u, 0u };
+        if (wide) ya[q] = *reinterpret_cast<const sws_u32x2 *>(fr.src[0] + (size_t)li[q] * fr.src_stride[0] + x);
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            cf[q][j] = j < cs ? cf[q][j] : 0;
+            ci[q][j] = clampi(cfirst + (j < cs ? j : 0), 0, chrSrcH - 1);
+            u[q][j] = v[q][j] = 0;
+            if (wide) {
+                u[q][j] = *reinterpret_cast<const uint32_t *>(fr.src[1] + (size_t)ci[q][j] * fr.src_stride[1] + (x >> 1));
+                v[q][j] = *reinterpret_cast<const uint32_t *>(fr.src[2] + (size_t)ci[q][j] * fr.src_stride[2] + (x >> 1));
+            }
+        }
+    }
+    MI355_ISSUE_FENCE();
+    lut_load(s_lut, &cp->luts, tid, NT);
+    __syncthreads();
+    if (!mine) return;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int gy = blockIdx.y * C24_ROWS + (tid >> 6) + q * (NT / 64);
+        if (gy >= dstH) break;
+        uint8_t *d = fr.dst + (size_t)gy * fr.dst_stride + (size_t)x * 3;
+        const bool mean = !X && cs > 1 && cf[q][1] >= 2048;
+        /* one pair of the row from its bytes: two luma samples, the pair's chroma sample of each tap line */
+        auto pair = [&](int y1, int y2, const int *us, const int *vs, int &Y1, int &Y2, int &U, int &V) {
+            if (!X) {
+                Y1 = y1; Y2 = y2;
+                U = mean ? (us[0] + us[1]) >> 1 : us[0];
+                V = mean ? (vs[0] + vs[1]) >> 1 : vs[0];
+                return;
+            }
+            Y1 = ((1 << 18) + (y1 << 7) * lf[q]) >> 19; Y2 = ((1 << 18) + (y2 << 7) * lf[q]) >> 19;
+            U = V = 1 << 18;
+#pragma unroll
+            for (int j = 0; j < NC; j++) { U += (us[j] << 7) * cf[q][j]; V += (vs[j] << 7) * cf[q][j]; }
+            U >>= 19; V >>= 19;
+            if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
+        };
+        if (wide) {
+            int Y[8], r[4], g[4], b[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int us[NC], vs[NC], U, V;
+#pragma unroll
+                for (int j = 0; j < NC; j++) { us[j] = (u[q][j] >> (8 * p)) & 0xFF; vs[j] = (v[q][j] >> (8 * p)) & 0xFF; }
+                const uint32_t w = ya[q][p >> 1] >> (16 * (p & 1));
+                pair((int)(w & 0xFF), (int)((w >> 8) & 0xFF), us, vs, Y[2 * p], Y[2 * p + 1], U, V);
+                r[p] = s_lut.rV[V]; g[p] = s_lut.gU[U] + s_lut.gV[V]; b[p] = s_lut.bU[U];
+            }
+            rgb24_store8(s_lut, d, Y, r, g, b);
+        } else {
+            const uint8_t *py = fr.src[0] + (size_t)li[q] * fr.src_stride[0] + x;
+            for (int p = 0; p < 4 && (x >> 1) + p < npairs; p++) {
+                int us[NC], vs[NC], Y1, Y2, U, V;
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    us[j] = fr.src[1][(size_t)ci[q][j] * fr.src_stride[1] + (x >> 1) + p];
+                    vs[j] = fr.src[2][(size_t)ci[q][j] * fr.src_stride[2] + (x >> 1) + p];
+                }
+                pair(py[2 * p], py[2 * p + 1], us, vs, Y1, Y2, U, V);
+                write_pair(s_lut, d + 6 * p, Y1, Y2, U, V);
+            }
+        }
+    }
+}
+
 /* ---- Tier-1 line kernels ---------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(NT) k_sws_line_hscale(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs)
 {
@@ -909,6 +1020,14 @@ extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fram
                            &c->d->luts, h.dstW, h.srcH, 0, d_frames);
     } else {
         /* a CU's 160 KB of LDS hold `wgs` workgroups, one wave of each per SIMD: the instance whose register budget matches */
+        /* a context that does not scale: straight from the source bytes (k_sws_ident1; MI355_SWS_NO_IDENT1=1, developer switch: through the tile all the same) */
+        static const bool no_ident1 = std::getenv("MI355_SWS_NO_IDENT1") != nullptr;
+        if (!no_ident1 && h.hident_l && h.hident_c && h.vls == 1 && h.vcs <= 4 && !(h.dstW & 1) && h.srcW >= h.dstW && 2 * h.chrSrcW >= h.dstW) {
+            const dim3 grid((h.dstW + C24_COLS - 1) / C24_COLS, (h.dstH + C24_ROWS - 1) / C24_ROWS, nframes);
+            if (h.vcs <= 2) hipLaunchKernelGGL(k_sws_ident1<false>, grid, dim3(NT), 0, s, c->d, d_frames);       /* packed_mode() 1 */
+            else hipLaunchKernelGGL(k_sws_ident1<true>, grid, dim3(NT), 0, s, c->d, d_frames);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
         const dim3 grid((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes);
         static_assert(160 * 1024 / sws_lds_bytes(28, 16) >= 8 && 160 * 1024 / sws_lds_bytes(40, 20) == 7 && 160 * 1024 / sws_lds_bytes(MAXL, MAXC) == 6, "workgroups per CU of the instances");
         if (h.lum_lines <= 28 && h.chr_lines <= 16) hipLaunchKernelGGL((k_sws_generic<28, 16, 8>), grid, dim3(NT), 0, s, c->d, d_frames);

@@ -44,6 +44,7 @@ CONFIGS = {
     "special_64x48": (64, 48, 64, 48, 1, 0, 0),             # unscaled -> yuv2rgb_c_24_rgb
     "special_70x50": (70, 50, 70, 50, 1, 0, 0),             # width with 4 and 2 sample tails
     "generic_64x48": (64, 48, 64, 48, 1, 1, 1),             # accurate_rnd: generic path, chroma x2 vertically
+    "generic_bilinear_72x40": (72, 40, 72, 40, 0, 1, 1),    # the same with two vertical chroma taps: yuv2rgb24_1_c (uvalpha below / above 2048 by row)
     "down2_128x96": (128, 96, 64, 48, 1, 1, 1),             # 2:1 bicubic, 8 taps
     "down_100x76": (100, 76, 64, 48, 1, 1, 1),              # odd ratio
     "down4_256x192": (256, 192, 64, 48, 1, 1, 1),           # 4:1: more than 8 taps per filter (the generic loops)
