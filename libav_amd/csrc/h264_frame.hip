@@ -612,30 +612,54 @@ extern "C" int mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t ma
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 namespace {
-/* linear planes <-> macroblock tiles: 32 lanes per macroblock (16 luma rows of 16 bytes, 16 chroma rows of 8), eight macroblocks
- * per workgroup; the tiled side of a macroblock is one run of 256 + 128 bytes */
+/* linear planes <-> macroblock tiles: 32 lanes per macroblock (16 luma rows of 16 bytes, 16 chroma rows of 8), eight macroblocks side by side
+ * per step (128 bytes of every luma row), CONV_STEPS steps per workgroup; the tiled side of a macroblock is one run of 256 + 128 bytes.
+ * The job's record is fetched ONCE per wave, a dword per lane (read field by field it was a vector load and a wait per field: the compiler cannot
+ * know that the stores do not touch it), and a thread's pieces of all its steps are requested before the first is stored. */
+constexpr int CONV_STEPS = 4;
+static_assert(sizeof(mi355_surface_job) == 72, "eighteen dwords per conversion job");
 __global__ void __launch_bounds__(256) k_surface_convert(const mi355_surface_job *jobs, int n)
 {
     if ((int)blockIdx.y >= n) return;
-    const mi355_surface_job &j = mi355_global(jobs)[blockIdx.y];
-    const int W = uniform(j.mb_width), H = uniform(j.mb_height);
-    const int mb = (int)blockIdx.x * 8 + (int)(threadIdx.x >> 5), r = (int)threadIdx.x & 31;
-    if (mb >= W * H) return;
-    const int mb_y = mb / W, mb_x = mb - mb_y * W;
-    const bool to_tiled = uniform(j.to_tiled) != 0;
-    if (r < 16) {
-        uint8_t *lin = mi355_global(j.lin[0]) + (size_t)(mb_y * 16 + r) * j.lin_stride[0] + mb_x * 16;
-        uint8_t *til = mi355_global(j.tiled[0]) + (size_t)mb_y * j.tiled_stride[0] + mb_x * MI355_TILE_LUMA_BYTES + 16 * r;
-        const bool al = ((reinterpret_cast<uintptr_t>(j.lin[0]) | (uintptr_t)j.lin_stride[0]) & 15) == 0;
-        if (to_tiled) st16(til, ld16(lin, al), true);
-        else st16(lin, ld16(til, true), al);
-    } else {
-        const int plane = (r - 16) >> 3, row = (r - 16) & 7;
-        uint8_t *lin = mi355_global_v(plane ? j.lin[2] : j.lin[1]) + (size_t)(mb_y * 8 + row) * j.lin_stride[1] + mb_x * 8;      /* per lane: not mi355_global */
-        uint8_t *til = mi355_global(j.tiled[1]) + (size_t)mb_y * j.tiled_stride[1] + mb_x * MI355_TILE_CHROMA_BYTES + 8 * (r - 16);
-        const bool al = ((reinterpret_cast<uintptr_t>(j.lin[1]) | reinterpret_cast<uintptr_t>(j.lin[2]) | (uintptr_t)j.lin_stride[1]) & 7) == 0;
-        if (to_tiled) st8(til, ld8(lin, al), true);
-        else st8(lin, ld8(til, true), al);
+    mi355_surface_job j;
+    {
+        const int lane = (int)threadIdx.x & 63;
+        const uint32_t rec = mi355_global_v(reinterpret_cast<const uint32_t *>(mi355_global(jobs) + blockIdx.y))[lane < 18 ? lane : 17];
+        uint32_t w[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) w[k] = (uint32_t)lane_value((int)rec, k);
+        __builtin_memcpy(&j, w, sizeof(j));
+    }
+    const int W = j.mb_width, H = j.mb_height, nmb = W * H;
+    const int r = (int)threadIdx.x & 31;
+    const bool to_tiled = j.to_tiled != 0, luma = r < 16;
+    const int plane = (r - 16) >> 3, row = (r - 16) & 7;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(j.lin[0]) | (uintptr_t)j.lin_stride[0]) & 15) == 0;
+    const bool al8 = ((reinterpret_cast<uintptr_t>(j.lin[1]) | reinterpret_cast<uintptr_t>(j.lin[2]) | (uintptr_t)j.lin_stride[1]) & 7) == 0;
+    uint8_t *lin[CONV_STEPS], *til[CONV_STEPS];
+    uint4 v[CONV_STEPS];
+#pragma unroll
+    for (int q = 0; q < CONV_STEPS; q++) {
+        const int mb = ((int)blockIdx.x * CONV_STEPS + q) * 8 + (int)(threadIdx.x >> 5);
+        const int mbc = mb < nmb ? mb : nmb - 1;             /* a step past the picture repeats its last macroblock's loads and stores nothing */
+        const int mb_y = mbc / W, mb_x = mbc - mb_y * W;
+        if (luma) {
+            lin[q] = mi355_global_v(j.lin[0]) + (size_t)(mb_y * 16 + r) * j.lin_stride[0] + mb_x * 16;
+            til[q] = mi355_global_v(j.tiled[0]) + (size_t)mb_y * j.tiled_stride[0] + mb_x * MI355_TILE_LUMA_BYTES + 16 * r;
+            v[q] = to_tiled ? ld16(lin[q], al16) : ld16(til[q], true);
+        } else {
+            lin[q] = mi355_global_v(plane ? j.lin[2] : j.lin[1]) + (size_t)(mb_y * 8 + row) * j.lin_stride[1] + mb_x * 8;
+            til[q] = mi355_global_v(j.tiled[1]) + (size_t)mb_y * j.tiled_stride[1] + mb_x * MI355_TILE_CHROMA_BYTES + 8 * (r - 16);
+            const uint2 c = to_tiled ? ld8(lin[q], al8) : ld8(til[q], true);
+            v[q] = make_uint4(c.x, c.y, 0u, 0u);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CONV_STEPS; q++) {
+        const int mb = ((int)blockIdx.x * CONV_STEPS + q) * 8 + (int)(threadIdx.x >> 5);
+        if (mb >= nmb) break;
+        if (luma) { if (to_tiled) st16(til[q], v[q], true); else st16(lin[q], v[q], al16); }
+        else { const uint2 c = make_uint2(v[q].x, v[q].y); if (to_tiled) st8(til[q], c, true); else st8(lin[q], c, al8); }
     }
 }
 }
@@ -644,7 +668,7 @@ extern "C" int mi355_h264_surface_convert_dev(const mi355_surface_job *jobs, int
     if (!mi355::bind() || !jobs || n <= 0 || max_mb_width <= 0 || max_mb_height <= 0) return -1;
     const long long nmb = (long long)max_mb_width * max_mb_height;
     if (nmb > 0x3FFFFFFF || n > 65535) return -3;
-    hipLaunchKernelGGL(k_surface_convert, dim3((unsigned)((nmb + 7) / 8), (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    hipLaunchKernelGGL(k_surface_convert, dim3((unsigned)((nmb + 8 * CONV_STEPS - 1) / (8 * CONV_STEPS)), (unsigned)n), dim3(256), 0, (hipStream_t)stream, jobs, n);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 /* the waits also report the device's error word (include/mi355dsp.h): a kernel that gave up says so there, and the wait that follows returns it */
