@@ -613,10 +613,13 @@ extern "C" int mi355_copy_batch_dev(const mi355_copy_job *jobs, int n, size_t ma
 }
 namespace {
 /* linear planes <-> macroblock tiles: 32 lanes per macroblock (16 luma rows of 16 bytes, 16 chroma rows of 8), eight macroblocks side by side
- * per step (128 bytes of every luma row), CONV_STEPS steps per workgroup; the tiled side of a macroblock is one run of 256 + 128 bytes.
+ * per step (128 bytes of every luma row), CONV_STEPS steps per workgroup (2 / 4 / 8 / 16 steps: 1.94 / 2.0 / 1.7 / 1.35 ms per 1024 1080p pictures = 4.8 TB/s, 2.37 ms before: profiles/r06q_detile.txt); the tiled side of a macroblock is one run of 256 + 128 bytes.
  * The job's record is fetched ONCE per wave, a dword per lane (read field by field it was a vector load and a wait per field: the compiler cannot
  * know that the stores do not touch it), and a thread's pieces of all its steps are requested before the first is stored. */
-constexpr int CONV_STEPS = 4;
+#ifndef MI355_CONV_STEPS
+#define MI355_CONV_STEPS 16
+#endif
+constexpr int CONV_STEPS = MI355_CONV_STEPS;
 static_assert(sizeof(mi355_surface_job) == 72, "eighteen dwords per conversion job");
 __global__ void __launch_bounds__(256) k_surface_convert(const mi355_surface_job *jobs, int n)
 {
