@@ -1009,6 +1009,16 @@ extern "C" void mi355_sws_destroy(mi355_sws_ctx *c)
     delete c;
 }
 
+/* waves per SIMD the three instances' register allocation aims at (developer switches; the defaults are what their LDS tiles allow) */
+#ifndef MI355_SWS_WAVES_A
+#define MI355_SWS_WAVES_A 8
+#endif
+#ifndef MI355_SWS_WAVES_B
+#define MI355_SWS_WAVES_B 7
+#endif
+#ifndef MI355_SWS_WAVES_C
+#define MI355_SWS_WAVES_C 6
+#endif
 extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_frame *d_frames, int nframes, void *stream)
 {
     if (!c || !d_frames || nframes <= 0) return -1;
@@ -1030,9 +1040,9 @@ extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fram
         }
         const dim3 grid((h.dstW + TW - 1) / TW, (h.dstH + h.th - 1) / h.th, nframes);
         static_assert(160 * 1024 / sws_lds_bytes(28, 16) >= 8 && 160 * 1024 / sws_lds_bytes(40, 20) == 7 && 160 * 1024 / sws_lds_bytes(MAXL, MAXC) == 6, "workgroups per CU of the instances");
-        if (h.lum_lines <= 28 && h.chr_lines <= 16) hipLaunchKernelGGL((k_sws_generic<28, 16, 8>), grid, dim3(NT), 0, s, c->d, d_frames);
-        else if (h.lum_lines <= 40 && h.chr_lines <= 20) hipLaunchKernelGGL((k_sws_generic<40, 20, 7>), grid, dim3(NT), 0, s, c->d, d_frames);
-        else hipLaunchKernelGGL((k_sws_generic<MAXL, MAXC, 6>), grid, dim3(NT), 0, s, c->d, d_frames);
+        if (h.lum_lines <= 28 && h.chr_lines <= 16) hipLaunchKernelGGL((k_sws_generic<28, 16, MI355_SWS_WAVES_A>), grid, dim3(NT), 0, s, c->d, d_frames);
+        else if (h.lum_lines <= 40 && h.chr_lines <= 20) hipLaunchKernelGGL((k_sws_generic<40, 20, MI355_SWS_WAVES_B>), grid, dim3(NT), 0, s, c->d, d_frames);
+        else hipLaunchKernelGGL((k_sws_generic<MAXL, MAXC, MI355_SWS_WAVES_C>), grid, dim3(NT), 0, s, c->d, d_frames);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
