@@ -681,7 +681,13 @@ __global__ void __launch_bounds__(NT) k_sws_generic(const SwsDev *cp, const mi35
 #undef MI355_VR
 }
 
-constexpr int C24_ROWS = 16, C24_COLS = 512;
+#ifndef MI355_C24_ROWS
+#define MI355_C24_ROWS 16
+#endif
+#ifndef MI355_IDENT_ROWS
+#define MI355_IDENT_ROWS 16
+#endif
+constexpr int C24_ROWS = MI355_C24_ROWS, C24_COLS = 512, IDENT_ROWS = MI355_IDENT_ROWS;      /* rows of a tile of k_sws_c24 / of k_sws_ident1 */
 /* eight samples of one line: Y bytes in (y0, y1), the four pairs' LUT row offsets in r/g/b -> 24 RGB bytes */
 __device__ __forceinline__ void c24_line(const LutLds &t, uint8_t *d, uint32_t y0, uint32_t y1, const int *r, const int *g, const int *b)
 {
@@ -781,12 +787,12 @@ __global__ void __launch_bounds__(NT) k_sws_ident1(const SwsDev *cp, const mi355
     const bool wide = mine && (x >> 1) + 4 <= npairs &&
                       ((reinterpret_cast<uintptr_t>(fr.src[0]) | (uintptr_t)fr.src_stride[0] | reinterpret_cast<uintptr_t>(fr.dst) | (uintptr_t)fr.dst_stride) & 7) == 0 &&
                       ((reinterpret_cast<uintptr_t>(fr.src[1]) | (uintptr_t)fr.src_stride[1] | reinterpret_cast<uintptr_t>(fr.src[2]) | (uintptr_t)fr.src_stride[2]) & 3) == 0;
-    constexpr int NR = C24_ROWS / (NT / 64);
+    constexpr int NR = IDENT_ROWS / (NT / 64);
     /* the rows' lines and taps: every load unconditional (rows past the picture repeat its last row and are not written; a tap past the filter reads tap 0 and becomes zero) */
     int li[NR], lf[NR], c0[NR], cf[NR][NC];
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        const int gy = imin(blockIdx.y * C24_ROWS + (tid >> 6) + q * (NT / 64), dstH - 1);
+        const int gy = imin(blockIdx.y * IDENT_ROWS + (tid >> 6) + q * (NT / 64), dstH - 1);
         li[q] = vLumP[gy]; lf[q] = vLumC[gy]; c0[q] = vChrP[gy];
 #pragma unroll
         for (int j = 0; j < NC; j++) cf[q][j] = vChrC[(size_t)gy * cs + (j < cs ? j : 0)];
@@ -817,7 +823,7 @@ __global__ void __launch_bounds__(NT) k_sws_ident1(const SwsDev *cp, const mi355
     if (!mine) return;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        const int gy = blockIdx.y * C24_ROWS + (tid >> 6) + q * (NT / 64);
+        const int gy = blockIdx.y * IDENT_ROWS + (tid >> 6) + q * (NT / 64);
         if (gy >= dstH) break;
         uint8_t *d = fr.dst + (size_t)gy * fr.dst_stride + (size_t)x * 3;
         const bool mean = !X && cs > 1 && cf[q][1] >= 2048;
@@ -1033,7 +1039,7 @@ extern "C" int mi355_sws_scale_frames_dev(mi355_sws_ctx *c, const mi355_sws_fram
         /* a context that does not scale: straight from the source bytes (k_sws_ident1; MI355_SWS_NO_IDENT1=1, developer switch: through the tile all the same) */
         static const bool no_ident1 = std::getenv("MI355_SWS_NO_IDENT1") != nullptr;
         if (!no_ident1 && h.hident_l && h.hident_c && h.vls == 1 && h.vcs <= 4 && !(h.dstW & 1) && h.srcW >= h.dstW && 2 * h.chrSrcW >= h.dstW) {
-            const dim3 grid((h.dstW + C24_COLS - 1) / C24_COLS, (h.dstH + C24_ROWS - 1) / C24_ROWS, nframes);
+            const dim3 grid((h.dstW + C24_COLS - 1) / C24_COLS, (h.dstH + IDENT_ROWS - 1) / IDENT_ROWS, nframes);
             if (h.vcs <= 2) hipLaunchKernelGGL(k_sws_ident1<false>, grid, dim3(NT), 0, s, c->d, d_frames);       /* packed_mode() 1 */
             else hipLaunchKernelGGL(k_sws_ident1<true>, grid, dim3(NT), 0, s, c->d, d_frames);
             return hipGetLastError() == hipSuccess ? 0 : -2;
