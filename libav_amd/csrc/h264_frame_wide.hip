@@ -886,7 +886,11 @@ constexpr int DYP = 20, DCPW = 12;       /* pitches of the MBAFF filter's luma (
 #define MI355_WIDE_UNIT_MAX 4            /* developer switch: 2 = tiles of two macroblocks (half the LDS, half lines per piece) */
 #endif
 constexpr int WIDE_UNIT = MI355_WIDE_UNIT_MAX;
-constexpr int DBYP = 8 + 16 * WIDE_UNIT, DBCP = 8 + 8 * WIDE_UNIT;      /* pitches: columns -8 .. 16 * WIDE_UNIT - 1 / -8 .. 8 * WIDE_UNIT - 1 */
+#ifndef MI355_WIDE_TILE_MARGIN
+#define MI355_WIDE_TILE_MARGIN 4        /* columns left of the unit in a tile row: the four the filter reaches (8: a macroblock's sample 0 on a 16-byte boundary, 320 bytes more per group) */
+#endif
+constexpr int DBM = MI355_WIDE_TILE_MARGIN, DBLA = DBM % 8 == 0 ? 16 : 8;      /* ... and what that says about the alignment of a macroblock's row piece in LDS */
+constexpr int DBYP = DBM + 16 * WIDE_UNIT, DBCP = DBM + 8 * WIDE_UNIT;      /* pitches: columns -DBM .. 16 * WIDE_UNIT - 1 / -DBM .. 8 * WIDE_UNIT - 1 */
 template <int CF> struct WideDbLds {
     mi355_h264_mb m[3];                  /* this macroblock, its left and its top neighbour */
     int32_t ref[2][25];                  /* the filter's view of the motion, (y + 1) * 5 + (x + 1), x, y = -1..3: picture identity (-1: none) */
@@ -897,8 +901,8 @@ template <int CF> struct WideDbLds {
     alignas(16) uint16_t c[2][(CF == 2 ? 18 : 10) * DBCP];       /* rows -2..7 (4:2:2: ..15), columns -4.. (the filter reaches two to the left; four make the write-back whole dwords) */
 };
 /* (xo, xc: the macroblock's first column inside the unit's tile, luma and chroma — locals of the code that uses the macros) */
-#define DY(x, yy) s.y[((yy) + 4) * DBYP + (x) + 8 + xo]
-#define DC(p, x, yy) s.c[p][((yy) + 2) * DBCP + (x) + 8 + xc]
+#define DY(x, yy) s.y[((yy) + 4) * DBYP + (x) + DBM + xo]
+#define DC(p, x, yy) s.c[p][((yy) + 2) * DBCP + (x) + DBM + xc]
 
 __device__ __forceinline__ bool wide_mv_far(uint32_t a, uint32_t b, int ylim)
 {
@@ -1104,17 +1108,17 @@ __device__ __forceinline__ void wide_db_fetch_unit(WideDbLds<CF> &s, const WideD
     if (ct_on) wide_get(ct, (cp ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + cr) * pic.cd + (8 * x0 + 8 * ck) * PXB);
     /* ---- into the tile ---- */
 #pragma unroll
-    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 16, 16>(y[k], &DY(16 * k, l));
+    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 16, DBLA>(y[k], &DY(16 * k, l));
     if (has_left) wide_put<PX, 4, 8>(yl, &DY(-4, l));
-    if (has_top && tk < nu) wide_put<PX, 16, 16>(yt, &DY(16 * tk, tr));
+    if (has_top && tk < nu) wide_put<PX, 16, DBLA>(yt, &DY(16 * tk, tr));
 #pragma unroll
     for (int q = 0; q < NP; q++) {
         const int p = CF == 2 ? q : l >> 3, r = CF == 2 ? l : l & 7;
 #pragma unroll
-        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 8, 16>(c[q][k], &DC(p, 8 * k, r));
+        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_put<PX, 8, DBLA>(c[q][k], &DC(p, 8 * k, r));
         if (has_left) wide_put<PX, 4, 8>(cl[q], &DC(p, -4, r));
     }
-    if (ct_on) wide_put<PX, 8, 16>(ct, &DC(cp, 8 * ck, cr));
+    if (ct_on) wide_put<PX, 8, DBLA>(ct, &DC(cp, 8 * ck, cr));
 }
 /* ... and back: the unit's macroblocks, the three columns its first left edge changed (four: whole dwords) and the three rows (one in chroma) its top edges changed */
 template <int BD, int CF>
@@ -1127,23 +1131,23 @@ __device__ __forceinline__ void wide_db_store_unit(const WideDbLds<CF> &s, const
     const int yd = pic.yd, cd = pic.cd;
     uint8_t *row = const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + l) * yd + 16 * x0 * PXB;
 #pragma unroll
-    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 16, false, 16>(row + 16 * PXB * k, &DY(16 * k, l));
+    for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 16, false, DBLA>(row + 16 * PXB * k, &DY(16 * k, l));
     if (has_left) wide_st_row<PX, 4, false, 8>(row - 4 * PXB, &DY(-4, l));
     if (has_top && l < 12) {
         const int r = (l >> 2) - 3, k = l & 3;
-        if (k < nu) wide_st_row<PX, 16, false, 16>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + r) * yd + (16 * x0 + 16 * k) * PXB, &DY(16 * k, r));
+        if (k < nu) wide_st_row<PX, 16, false, DBLA>(const_cast<uint8_t *>(pic.dst[0]) + (size_t)(16 * mb_y + r) * yd + (16 * x0 + 16 * k) * PXB, &DY(16 * k, r));
     }
 #pragma unroll
     for (int q = 0; q < (CF == 2 ? 2 : 1); q++) {
         const int p = CF == 2 ? q : l >> 3, r = CF == 2 ? l : l & 7;
         uint8_t *crow = const_cast<uint8_t *>(p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y + r) * cd + 8 * x0 * PXB;
 #pragma unroll
-        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 8, false, 16>(crow + 8 * PXB * k, &DC(p, 8 * k, r));
+        for (int k = 0; k < WIDE_UNIT; k++) if (k < nu) wide_st_row<PX, 8, false, DBLA>(crow + 8 * PXB * k, &DC(p, 8 * k, r));
         if (has_left) wide_st_row<PX, 4, false, 8>(crow - 4 * PXB, &DC(p, -4, r));
     }
     if (has_top && l < 2 * WIDE_UNIT) {           /* chroma row -1: lane = plane * WIDE_UNIT + macroblock */
         const int p = l / WIDE_UNIT, k = l % WIDE_UNIT;
-        if (k < nu) wide_st_row<PX, 8, false, 16>(const_cast<uint8_t *>(p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y - 1) * cd + (8 * x0 + 8 * k) * PXB, &DC(p, 8 * k, -1));
+        if (k < nu) wide_st_row<PX, 8, false, DBLA>(const_cast<uint8_t *>(p ? pic.dst[2] : pic.dst[1]) + (size_t)(F::CH * mb_y - 1) * cd + (8 * x0 + 8 * k) * PXB, &DC(p, 8 * k, -1));
     }
 }
 

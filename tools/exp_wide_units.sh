@@ -1,5 +1,5 @@
 cp libav_amd/libmi355dsp.so /tmp/built.so
-for rep in 1 2 3; do
+for rep in 1 2; do
   for F in 512 2048; do
     echo "== built F=$F"; timeout 600 python tools/wide_times.py $F 10 2>&1 | grep noise
     for v in build/variants/wide_base.so; do
